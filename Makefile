@@ -1,0 +1,32 @@
+# Build the gfx950 block-codec engine (C-ABI shared library) and the test oracle.
+HIPCC   ?= hipcc
+ARCH    ?= gfx950
+CSRC    := htslib_amd/csrc
+HIPSRC  := $(wildcard $(CSRC)/*.hip)
+HDRS    := $(wildcard $(CSRC)/*.h) $(wildcard include/*.h)
+LIB     := htslib_amd/libhtsgpu.so
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+
+all: $(LIB) oracle
+
+$(LIB): $(HIPSRC) $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -shared $(HIPSRC) -o $@
+
+oracle:
+	$(MAKE) -C oracle all
+
+resource-usage:
+	$(HIPCC) $(HIPFLAGS) -shared $(HIPSRC) -o /dev/null -Rpass-analysis=kernel-resource-usage
+
+clean:
+	rm -f $(LIB)
+	$(MAKE) -C oracle clean
+.PHONY: all oracle clean resource-usage
+
+# bring-up probe: separate library variant with in-kernel tracing
+diag: tests/native/diag
+tests/native/diag: tests/native/diag.cpp $(HIPSRC) $(HDRS) $(LIB)
+	$(HIPCC) $(HIPFLAGS) -DHG_DEBUG_TRACE -shared $(HIPSRC) -o tests/native/libhtsgpu_trace.so
+	$(HIPCC) -O2 --offload-arch=$(ARCH) -Iinclude tests/native/diag.cpp -o $@ -Ltests/native -lhtsgpu_trace -Wl,-rpath,'$$ORIGIN'
+	$(HIPCC) -O2 --offload-arch=$(ARCH) -Iinclude tests/native/diag.cpp -o $@_plain -Lhtslib_amd -lhtsgpu -Wl,-rpath,'$$ORIGIN/../../htslib_amd'
+.PHONY: diag

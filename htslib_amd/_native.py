@@ -1,0 +1,123 @@
+"""ctypes binding of the C ABI in include/htsgpu.h (libhtsgpu.so, built in-tree).
+
+There is no Python or CPU implementation behind these calls: if the shared
+library has not been built (``make`` / ``__graft_entry__.build()``) importing
+this module raises, and if no gfx950 device is usable ``Engine()`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhtsgpu.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the gfx950 engine first (run `make` at the repo root or "
+        "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+
+class BgzfDesc(C.Structure):
+    """struct hg_bgzf_desc (include/htsgpu.h)."""
+    _fields_ = [("coff", C.c_uint64), ("uoff", C.c_uint64), ("clen", C.c_uint32), ("ulen", C.c_uint32)]
+
+
+DESC_DTYPE = [("coff", "<u8"), ("uoff", "<u8"), ("clen", "<u4"), ("ulen", "<u4")]
+
+_vp = C.c_void_p
+lib.hg_version.restype = C.c_char_p
+lib.hg_strerror.restype = C.c_char_p
+lib.hg_strerror.argtypes = [C.c_int]
+lib.hg_init.argtypes = [C.c_int, C.POINTER(_vp)]
+lib.hg_destroy.argtypes = [_vp]
+lib.hg_destroy.restype = None
+lib.hg_device_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.hg_bgzf_scan.restype = C.c_long
+lib.hg_bgzf_scan.argtypes = [_vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_uint64)]
+lib.hg_bgzf_inflate_dev.argtypes = [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]
+lib.hg_bgzf_inflate_host.argtypes = [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t),
+                                     _vp, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_int)]
+lib.hg_crc32_dev.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]
+
+EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info", "hg_bgzf_scan",
+           "hg_bgzf_inflate_dev", "hg_bgzf_inflate_host", "hg_crc32_dev"]
+
+
+class HgError(RuntimeError):
+    def __init__(self, code: int, what: str = ""):
+        self.code = code
+        super().__init__(f"{what}: {lib.hg_strerror(code).decode()} ({code})")
+
+
+def check(rc: int, what: str = "htsgpu"):
+    if rc != 0:
+        raise HgError(rc, what)
+
+
+def bgzf_scan(buf) -> "tuple":
+    """Host framing scan -> (numpy structured array of descriptors, total_ulen)."""
+    import numpy as np
+    mv = memoryview(buf)
+    arr = (C.c_char * len(mv)).from_buffer_copy(mv) if mv.readonly else (C.c_char * len(mv)).from_buffer(mv)
+    total = C.c_uint64(0)
+    n = lib.hg_bgzf_scan(C.addressof(arr), len(mv), None, 0, C.byref(total))
+    if n < 0:
+        raise HgError(int(n), "hg_bgzf_scan")
+    desc = np.zeros(int(n), dtype=DESC_DTYPE)
+    if n:
+        lib.hg_bgzf_scan(C.addressof(arr), len(mv), desc.ctypes.data, int(n), C.byref(total))
+    return desc, int(total.value)
+
+
+class Engine:
+    """One engine context bound to one MI355X (hg_ctx)."""
+
+    def __init__(self, device: int = 0):
+        h = _vp()
+        check(lib.hg_init(device, C.byref(h)), "hg_init")
+        self._h = h
+        self.device = device
+        cus, waves = C.c_int(), C.c_int()
+        lib.hg_device_info(h, C.byref(cus), C.byref(waves))
+        self.cus, self.waves = cus.value, waves.value
+
+    def close(self):
+        if self._h:
+            lib.hg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host-buffer convenience (synchronous) --------------------------------
+    def bgzf_inflate_host(self, comp: bytes):
+        """Returns (plain bytes, per-block status ndarray). Raises HgError on failure."""
+        import numpy as np
+        desc, total = bgzf_scan(comp)
+        out = C.create_string_buffer(max(total, 1))
+        status = np.full(len(desc), 99, dtype=np.int32)
+        out_len = C.c_size_t(0)
+        bad_i, bad_c = C.c_long(-1), C.c_int(0)
+        src = (C.c_char * len(comp)).from_buffer_copy(comp)
+        rc = lib.hg_bgzf_inflate_host(self._h, C.addressof(src), len(comp), C.addressof(out), total,
+                                      C.byref(out_len), status.ctypes.data, len(status),
+                                      C.byref(bad_i), C.byref(bad_c))
+        self.last_status = status
+        self.last_bad = (bad_i.value, bad_c.value)
+        check(rc, f"hg_bgzf_inflate_host (block {bad_i.value} code {bad_c.value})")
+        return out.raw[:out_len.value], status
+
+    # -- device-resident entry points (torch tensors or raw pointers) ----------
+    def bgzf_inflate_dev(self, d_comp: int, comp_len: int, d_desc: int, nblocks: int, d_out: int,
+                         out_cap: int, d_status: int, stream: int = 0):
+        check(lib.hg_bgzf_inflate_dev(self._h, d_comp, comp_len, d_desc, nblocks, d_out, out_cap,
+                                      d_status, stream), "hg_bgzf_inflate_dev")
+
+    def crc32_dev(self, d_data: int, d_off: int, d_len: int, n: int, d_crc: int, stream: int = 0):
+        check(lib.hg_crc32_dev(self._h, d_data, d_off, d_len, n, d_crc, stream), "hg_crc32_dev")

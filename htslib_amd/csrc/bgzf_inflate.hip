@@ -1,0 +1,569 @@
+// bgzf_inflate.hip -- BGZF block inflate for MI355X (gfx950 / CDNA4).
+//
+// Replaces the worker hot loop of htslib's reader, bgzf_decode_func ->
+// bgzf_uncompress (reference bgzf.c:1373-1384, 730-804): raw DEFLATE decode
+// (RFC 1951) of one <=64 KiB block + CRC-32 check against the trailer.
+//
+// Mapping (designed for CDNA4, not translated from a CPU inflate):
+//   * one BGZF block per 64-lane wavefront; wavefronts are persistent and pull
+//     block indices from a global ticket counter, so 164 k blocks of a 10 GiB
+//     BAM load-balance over 256 CUs without a tail;
+//   * the compressed stream is read with coalesced 256-byte wave loads: the
+//     wave keeps a 64-dword window of the input in ONE VGPR (+ the next window
+//     prefetched in a second VGPR) and the bit reader pulls dwords out of it
+//     with v_readlane into a 64-bit SGPR bit buffer -- no per-byte loads, no
+//     LDS staging traffic on the critical path;
+//   * all decode state is wave-uniform, so the Huffman loop runs largely on
+//     the scalar ALU; decode tables (10-bit litlen root, 8-bit distance root,
+//     zlib-style second-level tables) live in LDS, 7.3 KiB per wave, and are
+//     built by all 64 lanes in parallel (ballot-ranked canonical codes);
+//   * literals are gathered into a VGPR with v_writelane and flushed with one
+//     coalesced byte store per run; LZ77 matches are copied by the 64 lanes
+//     straight in global memory (the wave's own earlier stores are visible to
+//     its later loads in program order, so HBM/L2 is the 32 KiB window);
+//   * the CRC-32 is fused: after the last deflate block the wave re-reads its
+//     output (L2-resident), 64 lanes x slice-by-4, and folds the partials.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "htsgpu.h"
+#include "hg_device.h"
+#include "hg_internal.h"
+
+namespace hg {
+
+// Bring-up tracing (tests/native/diag.cpp): compiled in only with -DHG_DEBUG_TRACE.
+#ifdef HG_DEBUG_TRACE
+__device__ volatile uint32_t *g_trace = nullptr;    // host-pinned, 64 words per block
+__device__ uint32_t g_trace_blk = 0;
+#define HG_TRACE(slot, val) do { if (g_trace && lane_id() == 0) { g_trace[16 * (blockIdx.x * 4 + (threadIdx.x >> 6)) + (slot)] = (uint32_t)(val); __threadfence_system(); } } while (0)
+#else
+#define HG_TRACE(slot, val) do { } while (0)
+#endif
+
+constexpr int LIT_RB = 10;
+constexpr int DIST_RB = 8;
+constexpr int LIT_TAB = 1344;   // >= ENOUGH(286 symbols, root 10, max 15) = 1332
+constexpr int DIST_TAB = 416;   // >= ENOUGH(30 symbols, root 8, max 15)  = 402
+constexpr int PRE_RB = 7;
+constexpr int WAVES_PER_WG = 4;
+
+// table entry: [3:0] code bits to drop, [4] literal, [5] length/distance,
+// [6] end of block, [7] second-level pointer, [11:8] extra bits (or sub-table
+// bits), [31:16] value (literal / base / sub-table offset)
+constexpr uint32_t F_LIT = 0x10u, F_BASE = 0x20u, F_EOB = 0x40u, F_SUB = 0x80u;
+
+struct WaveLds {
+    uint32_t lit[LIT_TAB];
+    uint32_t dist[DIST_TAB];
+    uint32_t cnt[16];
+    uint32_t nc[16];
+    uint32_t alloc;
+    uint32_t pad[3];
+    uint8_t lens[352];
+};
+
+enum { KIND_LITLEN = 0, KIND_DIST = 1, KIND_PRE = 2 };
+
+__device__ __forceinline__ uint32_t make_entry(int kind, uint32_t sym, uint32_t nb) {
+    if (kind == KIND_PRE) return (sym << 16) | F_LIT | nb;
+    if (kind == KIND_LITLEN) {
+        if (sym < 256) return (sym << 16) | F_LIT | nb;
+        if (sym == 256) return F_EOB | nb;
+        uint32_t s = sym - 257;
+        if (s > 28) return 0;                                  // 286, 287: invalid
+        uint32_t extra, base;
+        if (s < 8) { extra = 0; base = 3 + s; }
+        else if (s == 28) { extra = 0; base = 258; }
+        else { extra = (s - 4) >> 2; base = 3 + ((4 + (s & 3)) << extra); }
+        return (base << 16) | (extra << 8) | F_BASE | nb;
+    }
+    if (sym > 29) return 0;                                    // 30, 31: invalid
+    uint32_t extra, base;
+    if (sym < 4) { extra = 0; base = 1 + sym; }
+    else { extra = (sym - 2) >> 1; base = 1 + ((2 + (sym & 1)) << extra); }
+    return (base << 16) | (extra << 8) | F_BASE | nb;
+}
+
+// Build a root+subtable decode table from code lengths S.lens[lens_off ..+n).
+// Returns 0 ok, 1 invalid code set (over-subscribed / illegal incomplete).
+// All 64 lanes participate; result uniform.
+template <int KIND, int RB, int CAP, int NCHUNK>
+__device__ __forceinline__ int build_table(WaveLds &S, uint32_t *tab, int lens_off, int n, int lane) {
+    // ---- zero root + count code lengths --------------------------------
+    HG_TRACE(4, 100 + KIND);
+    if (lane < 16) { S.cnt[lane] = 0; }
+    for (int i = lane; i < (1 << RB); i += 64) tab[i] = 0;
+    if (lane == 0) S.alloc = 1u << RB;
+    wave_sync();
+    uint32_t L[NCHUNK];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++) {
+        int sym = c * 64 + lane;
+        L[c] = sym < n ? S.lens[lens_off + sym] : 0;
+        if (L[c]) atomicAdd(&S.cnt[L[c]], 1u);
+    }
+    wave_sync();
+    // ---- canonical first codes (RFC 1951 3.2.2), uniform -----------------
+    uint32_t code = 0;
+    int left = 1, total = 0, maxlen = 0;
+    uint32_t mycnt = lane < 16 ? S.cnt[lane] : 0;
+    uint32_t first_code = 0;
+#pragma unroll
+    for (int l = 1; l <= 15; l++) {
+        uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)mycnt, l);
+        if (lane == l) first_code = code;
+        code = (code + c) << 1;
+        left = (left << 1) - (int)c;
+        if (left < 0) return 1;                                  // over-subscribed
+        total += (int)c;
+        if (c) maxlen = l;
+    }
+    if (left > 0) {
+        // incomplete: legal only for "no codes" or "a single 1-bit code"
+        // (same rule as the oracle / zlib inftrees: max != 1 -> error)
+        if (!(total == 0 || (total == 1 && maxlen == 1))) return 1;
+    }
+    if (lane >= 1 && lane < 16) S.nc[lane] = first_code;
+    wave_sync();
+    HG_TRACE(4, 200 + KIND);
+    // ---- assign codes in symbol order, fill root entries -----------------
+    bool any_long = maxlen > RB;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++) {
+        uint32_t len = L[c];
+        uint32_t mycode = 0;
+        unsigned long long todo = __ballot(len != 0);
+        int guard = 0;
+        while (todo) {                                           // one pass per distinct length
+            if (++guard > 16) return 1;                          // cannot happen (<= 15 lengths)
+            HG_TRACE(8, guard); HG_TRACE(9, (uint32_t)todo); HG_TRACE(10, (uint32_t)(todo >> 32));
+            int leader = __builtin_ctzll(todo);
+            uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, leader);
+            unsigned long long m = __ballot(len == l);
+            uint32_t base = S.nc[l];                             // uniform LDS read
+            uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (len == l) mycode = base + rank;
+            wave_sync();
+            if (lane == leader) S.nc[l] = base + (uint32_t)__popcll(m);
+            wave_sync();
+            todo &= ~m;
+        }
+        L[c] = len | (mycode << 8);
+        if (len) {
+            uint32_t sym = (uint32_t)(c * 64 + lane);
+            uint32_t rev = __brev(mycode) >> (32 - len);
+            if (len <= (uint32_t)RB) {
+                uint32_t e = make_entry(KIND, sym, len);
+                for (uint32_t idx = rev; idx < (1u << RB); idx += 1u << len) tab[idx] = e;
+            } else {
+                atomicMax(&tab[rev & ((1u << RB) - 1)], len);     // longest code under this root slot
+            }
+        }
+    }
+    HG_TRACE(4, 300 + KIND);
+    if (!any_long) { wave_sync(); return 0; }
+    wave_sync();
+    // ---- size and place second-level tables ------------------------------
+    int bad = 0;
+    for (int i = lane; i < (1 << RB); i += 64) {
+        uint32_t v = tab[i];
+        if (v != 0 && v < 16) {
+            uint32_t sb = v - RB;
+            uint32_t off = atomicAdd(&S.alloc, 1u << sb);
+            if (off + (1u << sb) > (uint32_t)CAP) { bad = 1; tab[i] = 0; }
+            else tab[i] = (off << 16) | (sb << 8) | F_SUB | RB;
+        }
+    }
+    if (__ballot(bad)) return 1;
+    wave_sync();
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++) {
+        uint32_t len = L[c] & 0xff, mycode = L[c] >> 8;
+        if (len > (uint32_t)RB) {
+            uint32_t sym = (uint32_t)(c * 64 + lane);
+            uint32_t rev = __brev(mycode) >> (32 - len);
+            uint32_t root = tab[rev & ((1u << RB) - 1)];
+            uint32_t off = root >> 16, sb = (root >> 8) & 0xf;
+            uint32_t e = make_entry(KIND, sym, len - RB);
+            for (uint32_t idx = rev >> RB; idx < (1u << sb); idx += 1u << (len - RB)) tab[off + idx] = e;
+        }
+    }
+    wave_sync();
+    return 0;
+}
+
+// ------------------------------------------------------------------ bit reader
+struct BitReader {
+    const uint32_t *g;     // dword view of the stream, aligned down from the block start
+    uint32_t max_dw;       // last readable dword index (clamp)
+    uint32_t wbase;        // dword index held by lane 0 of `win`
+    uint32_t win, win_next;
+    uint32_t next_dw;      // next dword to append to the bit buffer
+    uint64_t bb;
+    uint32_t bc;
+};
+
+__device__ __forceinline__ uint32_t br_gload(const BitReader &br, uint32_t idx) {
+    idx = idx < br.max_dw ? idx : br.max_dw;
+    return br.g[idx];
+}
+
+__device__ __forceinline__ uint32_t br_fetch(BitReader &br, uint32_t idx, int lane) {
+    uint32_t rel = idx - br.wbase;
+    if (rel >= 64u) {
+        if (rel < 128u) { br.win = br.win_next; br.wbase += 64u; }
+        else { br.wbase = idx; br.win = br_gload(br, idx + lane); }
+        br.win_next = br_gload(br, br.wbase + 64u + lane);
+        rel = idx - br.wbase;
+    }
+    return (uint32_t)__builtin_amdgcn_readlane((int)br.win, (int)rel);
+}
+
+// position the reader at byte offset `byte_pos` (relative to br.g)
+__device__ __forceinline__ void br_seek(BitReader &br, uint32_t byte_pos, int lane) {
+    uint32_t dw = byte_pos >> 2, sh = (byte_pos & 3u) * 8u;
+    uint32_t w = br_fetch(br, dw, lane);
+    br.bb = (uint64_t)(w >> sh);
+    br.bc = 32u - sh;
+    br.next_dw = dw + 1;
+}
+
+__device__ __forceinline__ void br_refill(BitReader &br, int lane) {
+    if (br.bc <= 32u) {
+        uint32_t w = br_fetch(br, br.next_dw, lane);
+        br.next_dw++;
+        br.bb |= (uint64_t)w << br.bc;
+        br.bc += 32u;
+    }
+}
+__device__ __forceinline__ uint32_t br_peek(const BitReader &br, uint32_t n) {
+    return (uint32_t)br.bb & ((1u << n) - 1u);
+}
+__device__ __forceinline__ void br_drop(BitReader &br, uint32_t n) { br.bb >>= n; br.bc -= n; }
+__device__ __forceinline__ uint32_t br_bits(BitReader &br, uint32_t n) {
+    uint32_t v = br_peek(br, n);
+    br_drop(br, n);
+    return v;
+}
+// bytes consumed so far, relative to br.g
+__device__ __forceinline__ uint32_t br_byte_pos(const BitReader &br) {
+    return br.next_dw * 4u - (br.bc >> 3);
+}
+
+__device__ __forceinline__ uint32_t lds_uniform(const uint32_t *p) {
+    return uni(*p);
+}
+
+// status codes internal to the kernel
+enum { ST_OK = 0, ST_HEADER = 1, ST_INFLATE = 2, ST_SIZE = 3, ST_CRC = 4 };
+
+// Decode one raw deflate stream.  `in_end` = first byte (relative to br.g)
+// that is NOT part of the payload.  Returns ST_*; *out_len receives bytes made.
+__device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_t in_start, uint32_t in_end,
+                              uint8_t *out, uint32_t cap, uint32_t *out_len, int lane) {
+    uint32_t pos = 0;
+    HG_TRACE(2, 1);
+    br_seek(br, in_start, lane);
+    HG_TRACE(2, 2);
+    for (;;) {
+        br_refill(br, lane);
+        HG_TRACE(2, 3);
+        if (br_byte_pos(br) > in_end) return ST_INFLATE;
+        uint32_t bfinal = br_bits(br, 1);
+        uint32_t btype = br_bits(br, 2);
+        if (btype == 0) {
+            // ---- stored (RFC 1951 3.2.4) ----
+            br_drop(br, br.bc & 7u);
+            br_refill(br, lane);
+            uint32_t len = br_bits(br, 16);
+            br_refill(br, lane);
+            uint32_t nlen = br_bits(br, 16);
+            if ((len ^ 0xffffu) != nlen) return ST_INFLATE;
+            uint32_t src = br_byte_pos(br);
+            if (src + len > in_end || pos + len > cap) return ST_INFLATE;
+            const uint8_t *sp = (const uint8_t *)br.g + src;
+            for (uint32_t i = lane; i < len; i += 64) out[pos + i] = sp[i];
+            pos += len;
+            br_seek(br, src + len, lane);
+        } else if (btype == 3) {
+            return ST_INFLATE;
+        } else {
+            if (btype == 1) {
+                // ---- fixed codes (RFC 1951 3.2.6) ----
+                for (int i = lane; i < 288; i += 64)
+                    S.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+                if (lane < 32) S.lens[288 + lane] = 5;
+                wave_sync();
+                if (build_table<KIND_LITLEN, LIT_RB, LIT_TAB, 5>(S, S.lit, 0, 288, lane)) return ST_INFLATE;
+                if (build_table<KIND_DIST, DIST_RB, DIST_TAB, 1>(S, S.dist, 288, 32, lane)) return ST_INFLATE;
+            } else {
+                // ---- dynamic codes (RFC 1951 3.2.7) ----
+                br_refill(br, lane);
+                uint32_t nlen = br_bits(br, 5) + 257;
+                uint32_t ndist = br_bits(br, 5) + 1;
+                uint32_t ncode = br_bits(br, 4) + 4;
+                if (nlen > 286 || ndist > 30) return ST_INFLATE;
+                // code-length code lengths: 3 bits each, permuted order
+                if (lane < 19) S.lens[lane] = 0;
+                wave_sync();
+                for (uint32_t i = 0; i < ncode; i++) {
+                    br_refill(br, lane);
+                    uint32_t v = br_bits(br, 3);
+                    // order 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15 packed 5 bits each
+                    const uint64_t ord_lo = 16ull | (17ull << 5) | (18ull << 10) | (0ull << 15) | (8ull << 20) |
+                                            (7ull << 25) | (9ull << 30) | (6ull << 35) | (10ull << 40) |
+                                            (5ull << 45) | (11ull << 50) | (4ull << 55);
+                    const uint64_t ord_hi = 12ull | (3ull << 5) | (13ull << 10) | (2ull << 15) | (14ull << 20) |
+                                            (1ull << 25) | (15ull << 30);
+                    uint32_t sym = i < 12 ? (uint32_t)(ord_lo >> (5 * i)) & 31u
+                                          : (uint32_t)(ord_hi >> (5 * (i - 12))) & 31u;
+                    if (lane == 0) S.lens[sym] = (uint8_t)v;
+                }
+                wave_sync();
+                if (build_table<KIND_PRE, PRE_RB, DIST_TAB, 1>(S, S.dist, 0, 19, lane)) return ST_INFLATE;
+                // the precode must be complete unless trivially small: zlib rejects incomplete
+                // code-length codes outright; build_table allows the 1-code case, which a
+                // conforming encoder never emits -- keep oracle behaviour (complete only).
+                {
+                    uint32_t c = lane < 16 ? S.cnt[lane] : 0;
+                    int left = 1;
+#pragma unroll
+                    for (int l = 1; l <= 7; l++)
+                        left = (left << 1) - (int)__builtin_amdgcn_readlane((int)c, l);
+                    if (left != 0) return ST_INFLATE;
+                }
+                // literal/length + distance code lengths, run-length coded
+                uint32_t idx = 0, total = nlen + ndist, prev = 0;
+                while (idx < total) {
+                    br_refill(br, lane);
+                    uint32_t e = lds_uniform(&S.dist[br_peek(br, PRE_RB)]);
+                    if (!(e & F_LIT)) return ST_INFLATE;
+                    br_drop(br, e & 15u);
+                    uint32_t sym = e >> 16;
+                    if (sym < 16) {
+                        if (lane == 0) S.lens[32 + idx] = (uint8_t)sym;
+                        prev = sym; idx++;
+                    } else {
+                        uint32_t rep, val = 0;
+                        if (sym == 16) {
+                            if (idx == 0) return ST_INFLATE;
+                            val = prev; rep = 3 + br_bits(br, 2);
+                        } else if (sym == 17) rep = 3 + br_bits(br, 3);
+                        else rep = 11 + br_bits(br, 7);
+                        if (idx + rep > total) return ST_INFLATE;
+                        for (uint32_t j = lane; j < rep; j += 64) S.lens[32 + idx + j] = (uint8_t)val;
+                        idx += rep; prev = val;
+                    }
+                }
+                wave_sync();
+                if (S.lens[32 + 256] == 0) return ST_INFLATE;          // no end-of-block code
+                // lengths sit at lens[32 .. 32+nlen+ndist): the precode table in S.dist is dead now
+                if (build_table<KIND_LITLEN, LIT_RB, LIT_TAB, 5>(S, S.lit, 32, (int)nlen, lane)) return ST_INFLATE;
+                if (build_table<KIND_DIST, DIST_RB, DIST_TAB, 1>(S, S.dist, 32 + (int)nlen, (int)ndist, lane)) return ST_INFLATE;
+            }
+            // ---- symbol loop -------------------------------------------------
+            uint32_t litv = 0, nlit = 0;
+            HG_TRACE(2, 5);
+            for (;;) {
+                HG_TRACE(3, pos);
+                br_refill(br, lane);
+                HG_TRACE(5, br.bc); HG_TRACE(6, (uint32_t)br.bb);
+                uint32_t e = lds_uniform(&S.lit[br_peek(br, LIT_RB)]);
+                HG_TRACE(7, e);
+                if (e & F_SUB) {
+                    br_drop(br, LIT_RB);
+                    e = lds_uniform(&S.lit[(e >> 16) + br_peek(br, (e >> 8) & 15u)]);
+                }
+                br_drop(br, e & 15u);
+                if (e & F_LIT) {
+                    litv = writelane(e >> 16, nlit, litv);
+                    nlit++;
+                    if (nlit == 64) {
+                        if (pos + 64 > cap) return ST_INFLATE;
+                        out[pos + lane] = (uint8_t)litv;
+                        pos += 64; nlit = 0;
+                    }
+                    continue;
+                }
+                // flush pending literals before anything that ends the run
+                if (nlit) {
+                    if (pos + nlit > cap) return ST_INFLATE;
+                    if ((uint32_t)lane < nlit) out[pos + lane] = (uint8_t)litv;
+                    pos += nlit; nlit = 0;
+                }
+                if (!(e & F_BASE)) {
+                    if (e & F_EOB) break;
+                    return ST_INFLATE;                                  // invalid code
+                }
+                uint32_t len = (e >> 16) + br_bits(br, (e >> 8) & 15u);
+                br_refill(br, lane);
+                uint32_t d = lds_uniform(&S.dist[br_peek(br, DIST_RB)]);
+                if (d & F_SUB) {
+                    br_drop(br, DIST_RB);
+                    d = lds_uniform(&S.dist[(d >> 16) + br_peek(br, (d >> 8) & 15u)]);
+                }
+                if (!(d & F_BASE)) return ST_INFLATE;
+                br_drop(br, d & 15u);
+                uint32_t dist = (d >> 16) + br_bits(br, (d >> 8) & 15u);
+                if (dist > pos || pos + len > cap) return ST_INFLATE;
+                // LZ77 copy: span = largest multiple-of-dist look-back usable so far
+                uint32_t done = 0, span = dist;
+                do {
+                    uint32_t n = len - done;
+                    n = n < 64u ? n : 64u;
+                    n = n < span ? n : span;
+                    uint8_t *dst = out + pos + done;
+                    if ((uint32_t)lane < n) dst[lane] = dst[(int)lane - (int)span];
+                    done += n;
+                    if (n == span) span <<= 1;
+                } while (done < len);
+                pos += len;
+            }
+            if (br_byte_pos(br) > in_end) return ST_INFLATE;
+        }
+        if (bfinal) break;
+    }
+    *out_len = pos;
+    return ST_OK;
+}
+
+__global__ __launch_bounds__(WAVES_PER_WG * 64)
+void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
+                         const hg_bgzf_desc *__restrict__ desc, uint32_t nblocks,
+                         uint8_t *out, uint64_t out_cap, int32_t *status,
+                         unsigned int *ticket) {
+    __shared__ WaveLds lds[WAVES_PER_WG];
+    const int lane = lane_id();
+    const int wave = (int)uni(threadIdx.x >> 6);
+    WaveLds &S = lds[wave];
+    const uint64_t max_dw_abs = (comp_len + 3) / 4 - 1;   // buffer is padded to a dword multiple
+
+    uint32_t iter = 0;
+    for (;;) {
+        uint32_t b = 0;
+        iter++;
+        HG_TRACE(12, iter);
+        // every lane takes part (lane 0 adds 1, the others add 0): no lane-0-only control
+        // flow at the loop back-edge, which hipcc (ROCm 7.2) was seen to merge with the
+        // lane-0-only status store of the previous iteration and hang the wave.
+        b = atomicAdd(ticket, lane == 0 ? 1u : 0u);
+        b = (uint32_t)__builtin_amdgcn_readlane((int)b, 0);
+        HG_TRACE(13, b + 1000);
+        if (b >= nblocks) break;
+        HG_TRACE(0, b + 1);
+        const hg_bgzf_desc dsc = desc[b];
+        const uint64_t coff = ((uint64_t)uni((uint32_t)(dsc.coff >> 32)) << 32) | uni((uint32_t)dsc.coff);
+        const uint64_t uoff = ((uint64_t)uni((uint32_t)(dsc.uoff >> 32)) << 32) | uni((uint32_t)dsc.uoff);
+        const uint32_t clen = uni(dsc.clen), ulen = uni(dsc.ulen);
+        int st = ST_OK;
+        if (clen < 26 || coff + clen > comp_len || uoff + ulen > out_cap) {
+            st = ST_HEADER;
+        } else {
+            BitReader br;
+            const uint64_t base_dw = coff >> 2;
+            const uint32_t skew = (uint32_t)(coff & 3u);
+            br.g = (const uint32_t *)comp + base_dw;
+            br.max_dw = (uint32_t)(max_dw_abs - base_dw);
+            br.wbase = 0;
+            br.win = br_gload(br, (uint32_t)lane);
+            br.win_next = br_gload(br, 64u + (uint32_t)lane);
+            br.next_dw = 0; br.bb = 0; br.bc = 0;
+            // header (bgzf.c:896-903 check_header + BSIZE) and trailer
+            const uint8_t *hb = comp + coff;
+            uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0;
+            {
+                // 18 header bytes via the window (dword granular, skewed by coff&3)
+                uint32_t w[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)br.win, i);
+                auto byte_at = [&](int k) -> uint32_t {
+                    uint32_t p = skew + (uint32_t)k;
+                    return (w[p >> 2] >> ((p & 3u) * 8u)) & 0xffu;
+                };
+                h0 = byte_at(0) | (byte_at(1) << 8) | (byte_at(2) << 16) | (byte_at(3) << 24);
+                h1 = byte_at(10) | (byte_at(11) << 8);
+                h2 = byte_at(12) | (byte_at(13) << 8);
+                h3 = byte_at(14) | (byte_at(15) << 8);
+                h4 = byte_at(16) | (byte_at(17) << 8);
+            }
+            bool hdr_ok = (h0 & 0x04ffffffu) == 0x04088b1fu && h1 == 6 && h2 == 0x4342u && h3 == 2 &&
+                          h4 + 1u == clen;
+            if (!hdr_ok) {
+                st = ST_HEADER;
+            } else {
+                uint32_t tr[2];
+                {
+                    const uint8_t *t = hb + clen - 8;
+                    uint32_t c = 0, z = 0;
+                    for (int k = 0; k < 4; k++) { c |= (uint32_t)t[k] << (8 * k); z |= (uint32_t)t[4 + k] << (8 * k); }
+                    tr[0] = uni(c); tr[1] = uni(z);
+                }
+                uint32_t made = 0;
+                uint8_t *o = out + uoff;
+                // payload handed to inflate = block[18 .. clen) like the reference (slen = block_length-18)
+                st = inflate_stream(S, br, skew + 18u, skew + clen, o, ulen, &made, lane);
+                HG_TRACE(1, 50 + st);
+                if (st == ST_OK && made != ulen) st = ST_SIZE;
+                if (st == ST_OK && tr[1] != ulen) st = ST_SIZE;
+                if (st == ST_OK) {
+                    HG_TRACE(11, 1);
+                    uint32_t crc = wave_crc32(o, ulen, lane);
+                    HG_TRACE(11, 2);
+                    if (uni(crc) != tr[0]) st = ST_CRC;
+                }
+            }
+        }
+        HG_TRACE(1, 90 + st);
+        // all lanes store the same word (one coalesced write)
+        status[b] = st == ST_OK ? HG_BLOCK_OK : st == ST_CRC ? HG_BLOCK_ECRC : HG_BLOCK_EINFLATE;
+        HG_TRACE(14, 555);
+    }
+    HG_TRACE(15, 777);
+}
+
+__global__ __launch_bounds__(256)
+void crc32_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ off,
+                  const uint32_t *__restrict__ len, uint32_t n, uint32_t *crc) {
+    const int lane = lane_id();
+    uint32_t w = uni((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    uint32_t nw = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = w; i < n; i += nw) {
+        uint32_t c = wave_crc32(data + off[i], len[i], lane);
+        if (lane == 0) crc[i] = c;
+    }
+}
+
+#ifdef HG_DEBUG_TRACE
+extern "C" int hg_debug_set_trace(void *pinned_host_words) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &pinned_host_words, sizeof(void *)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// ---------------------------------------------------------------- host launchers
+int launch_bgzf_inflate(hg_ctx *ctx, const void *d_comp, size_t comp_len, const hg_bgzf_desc *d_desc,
+                        size_t nblocks, void *d_out, size_t out_cap, int32_t *d_status, hipStream_t s) {
+    if (nblocks == 0) return HG_OK;
+    if (nblocks > 0xffffffffull) return HG_EINVAL;
+    if (hipMemsetAsync(ctx->d_ticket, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
+    size_t waves = (size_t)ctx->waves_per_launch;
+    size_t wgs = (waves + WAVES_PER_WG - 1) / WAVES_PER_WG;
+    size_t need = (nblocks + WAVES_PER_WG - 1) / WAVES_PER_WG;
+    if (wgs > need) wgs = need;
+    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)wgs), dim3(WAVES_PER_WG * 64), 0, s,
+                       (const uint8_t *)d_comp, (uint64_t)comp_len, d_desc, (uint32_t)nblocks,
+                       (uint8_t *)d_out, (uint64_t)out_cap, d_status, ctx->d_ticket);
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+
+int launch_crc32(hg_ctx *ctx, const void *d_data, const uint64_t *d_off, const uint32_t *d_len, size_t n,
+                 uint32_t *d_crc, hipStream_t s) {
+    if (n == 0) return HG_OK;
+    size_t wgs = (n + 3) / 4;
+    size_t maxw = (size_t)ctx->cus * 8;
+    if (wgs > maxw) wgs = maxw;
+    hipLaunchKernelGGL(crc32_kernel, dim3((unsigned)wgs), dim3(256), 0, s, (const uint8_t *)d_data, d_off, d_len,
+                       (uint32_t)n, d_crc);
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+
+}  // namespace hg

@@ -1,0 +1,162 @@
+// htsgpu_api.hip -- the C-ABI shim declared in include/htsgpu.h.
+//
+// Thin host layer: context lifetime, the BGZF framing scan that replaces the
+// header walk of bgzf_mt_read_block (reference bgzf.c:1485-1539), and the
+// batch entry points that launch the gfx950 kernels.  There is deliberately NO
+// CPU implementation of any codec here: if HIP or the device is unavailable
+// every entry point fails with HG_ENODEV.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "htsgpu.h"
+#include "hg_internal.h"
+
+#define HG_VERSION_STRING "htsgpu 0.1 (gfx950)"
+
+static int ensure_scratch(hg_ctx *ctx, int slot, size_t bytes) {
+    if (ctx->d_scratch_cap[slot] >= bytes) return HG_OK;
+    if (ctx->d_scratch[slot]) (void)hipFree(ctx->d_scratch[slot]);
+    ctx->d_scratch[slot] = nullptr; ctx->d_scratch_cap[slot] = 0;
+    size_t cap = bytes + bytes / 4 + 4096;
+    if (hipMalloc(&ctx->d_scratch[slot], cap) != hipSuccess) return HG_ENOMEM;
+    ctx->d_scratch_cap[slot] = cap;
+    return HG_OK;
+}
+
+extern "C" {
+
+const char *hg_version(void) { return HG_VERSION_STRING; }
+
+const char *hg_strerror(int code) {
+    switch (code) {
+    case HG_OK: return "ok";
+    case HG_EINVAL: return "invalid argument";
+    case HG_ENODEV: return "no usable gfx950 device / HIP runtime failure";
+    case HG_ENOMEM: return "out of (device) memory";
+    case HG_EFORMAT: return "BGZF framing error";
+    case HG_ELAUNCH: return "kernel launch or execution failed";
+    case HG_EBLOCK: return "one or more blocks failed to decode";
+    default: return "unknown error";
+    }
+}
+
+int hg_init(int device, hg_ctx **out) {
+    if (!out) return HG_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return HG_ENODEV;
+    if (hipSetDevice(device) != hipSuccess) return HG_ENODEV;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return HG_ENODEV;
+    hg_ctx *ctx = (hg_ctx *)calloc(1, sizeof(hg_ctx));
+    if (!ctx) return HG_ENOMEM;
+    ctx->device = device;
+    ctx->cus = prop.multiProcessorCount;
+    // inflate: 30 KiB LDS per 4-wave workgroup -> 5 workgroups (20 waves) per CU
+    ctx->waves_per_launch = ctx->cus * 20;
+    if (hipMalloc((void **)&ctx->d_ticket, 64) != hipSuccess) { free(ctx); return HG_ENOMEM; }
+    *out = ctx;
+    return HG_OK;
+}
+
+void hg_destroy(hg_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (int i = 0; i < 4; i++) if (ctx->d_scratch[i]) (void)hipFree(ctx->d_scratch[i]);
+    if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
+    free(ctx);
+}
+
+int hg_device_info(hg_ctx *ctx, int *cus, int *waves) {
+    if (!ctx) return HG_EINVAL;
+    if (cus) *cus = ctx->cus;
+    if (waves) *waves = ctx->waves_per_launch;
+    return HG_OK;
+}
+
+long hg_bgzf_scan(const uint8_t *buf, size_t len, hg_bgzf_desc *desc, size_t max_desc, uint64_t *total_ulen) {
+    size_t pos = 0; long n = 0; uint64_t u = 0;
+    while (pos < len) {
+        if (len - pos < 18) return HG_EFORMAT;
+        const uint8_t *h = buf + pos;
+        if (!(h[0] == 31 && h[1] == 139 && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 &&
+              h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0))
+            return HG_EFORMAT;
+        size_t bs = (size_t)(h[16] | (h[17] << 8)) + 1;
+        if (bs < 26 || bs > len - pos) return HG_EFORMAT;
+        const uint8_t *t = h + bs - 4;
+        uint32_t isize = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (isize > HG_BGZF_MAX_BLOCK_SIZE) return HG_EFORMAT;
+        if (desc && (size_t)n < max_desc) {
+            desc[n].coff = pos; desc[n].uoff = u; desc[n].clen = (uint32_t)bs; desc[n].ulen = isize;
+        }
+        u += isize; pos += bs; n++;
+    }
+    if (total_ulen) *total_ulen = u;
+    return n;
+}
+
+int hg_bgzf_inflate_dev(hg_ctx *ctx, const void *d_comp, size_t comp_len, const hg_bgzf_desc *d_desc,
+                        size_t nblocks, void *d_out, size_t out_cap, int32_t *d_status, void *stream) {
+    if (!ctx || (nblocks && (!d_comp || !d_desc || !d_status))) return HG_EINVAL;
+    if (((uintptr_t)d_comp & 3u) != 0) return HG_EINVAL;
+    return hg::launch_bgzf_inflate(ctx, d_comp, comp_len, d_desc, nblocks, d_out, out_cap, d_status,
+                                   (hipStream_t)stream);
+}
+
+int hg_bgzf_inflate_host(hg_ctx *ctx, const uint8_t *comp, size_t comp_len, uint8_t *out, size_t out_cap,
+                         size_t *out_len, int32_t *status, size_t max_status, long *first_bad_idx,
+                         int *first_bad_code) {
+    if (!ctx || (!comp && comp_len)) return HG_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    uint64_t total = 0;
+    long n = hg_bgzf_scan(comp, comp_len, nullptr, 0, &total);
+    if (n < 0) return (int)n;
+    if (out_len) *out_len = (size_t)total;
+    if (total > out_cap) return HG_EINVAL;
+    if (n == 0) return HG_OK;
+    hg_bgzf_desc *desc = (hg_bgzf_desc *)malloc((size_t)n * sizeof(hg_bgzf_desc));
+    int32_t *st = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    if (!desc || !st) { free(desc); free(st); return HG_ENOMEM; }
+    hg_bgzf_scan(comp, comp_len, desc, (size_t)n, nullptr);
+    int rc;
+    size_t comp_pad = (comp_len + 3) & ~(size_t)3;
+    if ((rc = ensure_scratch(ctx, 0, comp_pad)) || (rc = ensure_scratch(ctx, 1, (size_t)total + 4)) ||
+        (rc = ensure_scratch(ctx, 2, (size_t)n * sizeof(hg_bgzf_desc))) ||
+        (rc = ensure_scratch(ctx, 3, (size_t)n * sizeof(int32_t)))) {
+        free(desc); free(st); return rc;
+    }
+    hipStream_t s = nullptr;
+    bool ok = hipMemcpyAsync(ctx->d_scratch[0], comp, comp_len, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(ctx->d_scratch[2], desc, (size_t)n * sizeof(hg_bgzf_desc), hipMemcpyHostToDevice, s) == hipSuccess;
+    rc = ok ? hg::launch_bgzf_inflate(ctx, ctx->d_scratch[0], comp_len, (const hg_bgzf_desc *)ctx->d_scratch[2],
+                                      (size_t)n, ctx->d_scratch[1], (size_t)total, (int32_t *)ctx->d_scratch[3], s)
+            : HG_ELAUNCH;
+    if (rc == HG_OK) {
+        ok = hipMemcpyAsync(st, ctx->d_scratch[3], (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s) == hipSuccess &&
+             (total == 0 || hipMemcpyAsync(out, ctx->d_scratch[1], (size_t)total, hipMemcpyDeviceToHost, s) == hipSuccess) &&
+             hipStreamSynchronize(s) == hipSuccess;
+        if (!ok) rc = HG_ELAUNCH;
+    }
+    if (rc == HG_OK) {
+        for (long i = 0; i < n; i++) {
+            if (status && (size_t)i < max_status) status[i] = st[i];
+            if (st[i] != HG_BLOCK_OK && rc == HG_OK) {
+                rc = HG_EBLOCK;
+                if (first_bad_idx) *first_bad_idx = i;
+                if (first_bad_code) *first_bad_code = st[i];
+            }
+        }
+    }
+    free(desc); free(st);
+    return rc;
+}
+
+int hg_crc32_dev(hg_ctx *ctx, const void *d_data, const uint64_t *d_off, const uint32_t *d_len, size_t n,
+                 uint32_t *d_crc, void *stream) {
+    if (!ctx || (n && (!d_data || !d_off || !d_len || !d_crc))) return HG_EINVAL;
+    return hg::launch_crc32(ctx, d_data, d_off, d_len, n, d_crc, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+/*
+ * htsgpu.h -- C ABI of the MI355X (gfx950) block-codec engine.
+ *
+ * This is the drop-in boundary for htslib's block-codec hot path.  There is no
+ * codec plugin API in htslib (the only plugin interface is hFILE transports,
+ * hfile_internal.h:65-154), so the boundary is a plain C library that a libhts
+ * build links and calls from the places listed next to each entry point.  All
+ * signatures are extern "C", plain pointers and sizes; no torch / C++ types.
+ *
+ * Unit of work = a BATCH of independent blocks (BGZF blocks or CRAM
+ * data-series buffers).  One block is decoded/encoded by one 64-lane wavefront.
+ *
+ * Conventions
+ *   - "dev" entry points take DEVICE pointers, are asynchronous on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream) and never
+ *     synchronise.  "host" entry points take host pointers and are synchronous.
+ *   - per-block status codes mirror bgzf_uncompress (bgzf.c:730-804):
+ *        0 ok, -1 inflate/format failure, -2 CRC mismatch.
+ *   - functions return 0 on success or a negative HG_E* code.
+ */
+#ifndef HTSGPU_H
+#define HTSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HG_OK            0
+#define HG_EINVAL       -1   /* bad argument                                  */
+#define HG_ENODEV       -2   /* no usable gfx950 device / HIP runtime failure */
+#define HG_ENOMEM       -3
+#define HG_EFORMAT      -4   /* framing error found by a host-side scan       */
+#define HG_ELAUNCH      -5   /* kernel launch / execution failure             */
+#define HG_EBLOCK       -6   /* at least one block of the batch failed        */
+
+/* per-block status, identical meaning to bgzf_uncompress()'s return value */
+#define HG_BLOCK_OK      0
+#define HG_BLOCK_EINFLATE (-1)
+#define HG_BLOCK_ECRC    (-2)
+
+#define HG_BGZF_BLOCK_SIZE     0xff00   /* htslib/bgzf.h:50 */
+#define HG_BGZF_MAX_BLOCK_SIZE 0x10000  /* htslib/bgzf.h:51 */
+
+typedef struct hg_ctx hg_ctx;
+
+/* One descriptor per BGZF block.  Built by the host framing scan
+ * (replaces the header walk of bgzf_mt_read_block, bgzf.c:1485-1539). */
+typedef struct hg_bgzf_desc {
+    uint64_t coff;   /* byte offset of the block's first header byte          */
+    uint64_t uoff;   /* byte offset of the block's payload in the plain image */
+    uint32_t clen;   /* BSIZE+1: whole block incl. 18 B header + 8 B trailer  */
+    uint32_t ulen;   /* ISIZE                                                  */
+} hg_bgzf_desc;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int  hg_init(int device, hg_ctx **ctx);      /* binds ctx to HIP device `device` */
+void hg_destroy(hg_ctx *ctx);
+const char *hg_strerror(int code);
+const char *hg_version(void);
+/* number of compute units / resident wavefronts the engine will launch */
+int  hg_device_info(hg_ctx *ctx, int *cus, int *waves_per_launch);
+
+/* ---- BGZF framing (host) ----------------------------------------------- */
+/* Walk `len` bytes of a BGZF stream (check_header, bgzf.c:896-903) and fill
+ * up to `max_desc` descriptors.  Returns the number of blocks found
+ * (may exceed max_desc: call again with a larger array) or HG_EFORMAT.
+ * *total_ulen receives the sum of ISIZE over all blocks. */
+long hg_bgzf_scan(const uint8_t *buf, size_t len,
+                  hg_bgzf_desc *desc, size_t max_desc, uint64_t *total_ulen);
+
+/* ---- BGZF inflate (replaces bgzf_uncompress / bgzf_decode_func,
+ *      bgzf.c:730-804, 1373-1384) ----------------------------------------- */
+/* d_comp: the compressed stream image in HBM (comp_len bytes, any alignment
+ *         >= 4); d_desc: nblocks descriptors in HBM; d_out: plain image
+ *         (out_cap bytes); d_status: nblocks int32 (HG_BLOCK_*).
+ * Each block's raw deflate payload is decoded, its length checked against
+ * ISIZE and its CRC-32 against the trailer, all inside one kernel. */
+int hg_bgzf_inflate_dev(hg_ctx *ctx,
+                        const void *d_comp, size_t comp_len,
+                        const hg_bgzf_desc *d_desc, size_t nblocks,
+                        void *d_out, size_t out_cap,
+                        int32_t *d_status, void *stream);
+
+/* Host-buffer convenience: scan + H2D + inflate + D2H, synchronous.
+ * status may be NULL.  Returns 0, or HG_EBLOCK if any block failed (the first
+ * failing block's code is stored in *first_bad_code, its index in
+ * *first_bad_idx when non-NULL). */
+int hg_bgzf_inflate_host(hg_ctx *ctx,
+                         const uint8_t *comp, size_t comp_len,
+                         uint8_t *out, size_t out_cap, size_t *out_len,
+                         int32_t *status, size_t max_status,
+                         long *first_bad_idx, int *first_bad_code);
+
+/* ---- CRC-32 (replaces hts_crc32, bgzf.c:557-559 / 620-622) -------------- */
+/* crc[i] = crc32(0, d_data + off[i], len[i]) for n independent buffers. */
+int hg_crc32_dev(hg_ctx *ctx, const void *d_data,
+                 const uint64_t *d_off, const uint32_t *d_len, size_t n,
+                 uint32_t *d_crc, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HTSGPU_H */
