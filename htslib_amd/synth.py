@@ -193,7 +193,7 @@ def bam_stream(nbytes: int, seed: int = SEED, chunk: int = 0, with_header: bool 
     record_starts are byte offsets at which a BGZF block may be cut (the
     header counts as one unit, like bam_hdr_write + bgzf_flush)."""
     hdr = bam_header() if with_header else b""
-    n = max(16, int(nbytes / 288) + 64)
+    n = max(16, int(nbytes / 308.6) + 8)          # mean record = 308.6 B
     body = bam_records(n, seed, chunk)
     a = np.frombuffer(body, dtype=np.uint8)
     # record boundaries by walking block_size (vectorised: sizes differ little, walk in python once)

@@ -278,7 +278,8 @@ ORC_EXPORT int orc_bgzf_uncompress_block(uint8_t *dst, size_t *dlen,
     uint32_t crc = blk[blen - 8] | (blk[blen - 7] << 8) | (blk[blen - 6] << 16) | ((uint32_t)blk[blen - 5] << 24);
     uint32_t isize = blk[blen - 4] | (blk[blen - 3] << 8) | (blk[blen - 2] << 16) | ((uint32_t)blk[blen - 1] << 24);
     size_t got = 0, used = 0;
-    if (orc_inflate_raw(blk + 18, blen - 26, dst, *dlen, &got, &used)) return -1;
+    /* slen = block_length - 18: the 8 trailer bytes are visible to inflate, bgzf.c:813-816 */
+    if (orc_inflate_raw(blk + 18, blen - 18, dst, *dlen, &got, &used)) return -1;
     if (got != isize) return -1;
     *dlen = got;
     if (orc_crc32(0, dst, got) != crc) return -2;

@@ -1,0 +1,103 @@
+"""Checker-side helpers: ctypes views of oracle/liboracle.so (our C restatement) and of the REAL
+reference built in oracle/_ref (htslib bgzf.c against zlib / libdeflate).  Test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import json
+import os
+import struct
+import subprocess
+import tempfile
+import zlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "bgzf")
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        L = self.lib
+        L.orc_crc32.restype = C.c_uint32
+        L.orc_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]
+        L.orc_inflate_raw.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.orc_bgzf_uncompress_block.argtypes = [C.c_char_p, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+        L.orc_bgzf_decompress_stream.restype = C.c_long
+        L.orc_bgzf_decompress_stream.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.orc_bgzf_scan.restype = C.c_long
+        L.orc_bgzf_scan.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def crc32(self, data: bytes, crc: int = 0) -> int:
+        return self.lib.orc_crc32(crc, data, len(data))
+
+    def inflate_raw(self, data: bytes, cap: int = 1 << 20):
+        out = C.create_string_buffer(cap)
+        n, used = C.c_size_t(0), C.c_size_t(0)
+        rc = self.lib.orc_inflate_raw(data, len(data), out, cap, C.byref(n), C.byref(used))
+        return rc, out.raw[:n.value], used.value
+
+    def uncompress_block(self, block: bytes):
+        """-> (rc, bytes) with rc as bgzf_uncompress: 0 / -1 / -2."""
+        out = C.create_string_buffer(65536)
+        n = C.c_size_t(65536)
+        rc = self.lib.orc_bgzf_uncompress_block(out, C.byref(n), block, len(block))
+        return rc, (out.raw[:n.value] if rc == 0 else b"")
+
+    def decompress(self, stream: bytes, cap: int | None = None):
+        if cap is None:
+            cap = sum(b[2] for b in split_blocks(stream)) + 16
+        out = C.create_string_buffer(cap)
+        n = self.lib.orc_bgzf_decompress_stream(stream, len(stream), out, cap)
+        return n, (out.raw[:n] if n >= 0 else b"")
+
+
+def split_blocks(stream: bytes):
+    """[(offset, clen, isize)] by BSIZE hopping (no validation beyond bounds)."""
+    pos, out = 0, []
+    while pos + 18 <= len(stream):
+        bs = (stream[pos + 16] | (stream[pos + 17] << 8)) + 1
+        isize = struct.unpack_from("<I", stream, pos + bs - 4)[0] if pos + bs <= len(stream) else 0
+        out.append((pos, bs, isize))
+        pos += bs
+    return out
+
+
+def golden_cases():
+    man = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
+    for name in sorted(man):
+        yield name, open(os.path.join(GOLDEN, name), "rb").read(), open(os.path.join(GOLDEN, name + ".plain"), "rb").read()
+
+
+def have_ref() -> bool:
+    return os.path.exists(os.path.join(REF_DIR, "ref_bgzip")) and os.path.exists(os.path.join(REF_DIR, "ref_bgzip_ld"))
+
+
+def ref_bgzip(args, data: bytes, flavour: str = "zlib") -> bytes:
+    """Run the real reference bgzip (oracle/_ref) on `data` through a temp file."""
+    exe = os.path.join(REF_DIR, "ref_bgzip" if flavour == "zlib" else "ref_bgzip_ld")
+    with tempfile.NamedTemporaryFile(dir="/dev/shm" if os.path.isdir("/dev/shm") else None, delete=False) as f:
+        f.write(data)
+        path = f.name
+    try:
+        r = subprocess.run([exe] + list(args) + ["-c", path], capture_output=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{exe} {args}: rc={r.returncode} {r.stderr[-300:]!r}")
+        return r.stdout
+    finally:
+        os.unlink(path)
+
+
+def raw_block(data: bytes, level: int = 6, strategy: int = 0, mem: int = 8) -> bytes:
+    """One BGZF block around a raw-deflate payload made with given zlib parameters."""
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, mem, strategy)
+    p = co.compress(data) + co.flush()
+    return wrap_payload(p, data)
+
+
+def wrap_payload(payload: bytes, data: bytes, crc: int | None = None, isize: int | None = None) -> bytes:
+    hdr = bytes.fromhex("1f8b08040000000000ff060042430200")
+    return b"".join([hdr, struct.pack("<H", len(payload) + 25), payload,
+                     struct.pack("<II", zlib.crc32(data) if crc is None else crc, len(data) if isize is None else isize)])
