@@ -3,7 +3,7 @@ HIPCC   ?= hipcc
 ARCH    ?= gfx950
 CSRC    := htslib_amd/csrc
 HIPSRC  := $(wildcard $(CSRC)/*.hip)
-HDRS    := $(wildcard $(CSRC)/*.h) $(wildcard include/*.h)
+HDRS    := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc) $(wildcard include/*.h)
 LIB     := htslib_amd/libhtsgpu.so
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
@@ -30,3 +30,9 @@ tests/native/diag: tests/native/diag.cpp $(HIPSRC) $(HDRS) $(LIB)
 	$(HIPCC) -O2 --offload-arch=$(ARCH) -Iinclude tests/native/diag.cpp -o $@ -Ltests/native -lhtsgpu_trace -Wl,-rpath,'$$ORIGIN'
 	$(HIPCC) -O2 --offload-arch=$(ARCH) -Iinclude tests/native/diag.cpp -o $@_plain -Lhtslib_amd -lhtsgpu -Wl,-rpath,'$$ORIGIN/../../htslib_amd'
 .PHONY: diag
+
+# kernel A/B timing tool (dlopens any number of library builds)
+tests/native/kbench: tests/native/kbench.cpp include/htsgpu.h
+	$(HIPCC) -O2 --offload-arch=$(ARCH) -Iinclude tests/native/kbench.cpp -o $@ -ldl
+kbench: tests/native/kbench
+.PHONY: kbench

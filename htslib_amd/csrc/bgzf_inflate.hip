@@ -40,17 +40,44 @@ __device__ uint32_t g_trace_blk = 0;
 #define HG_TRACE(slot, val) do { } while (0)
 #endif
 
-constexpr int LIT_RB = 10;
+// In-kernel phase timing (s_memtime), compiled in only with -DHG_PROFILE (kbench).
+#ifdef HG_PROFILE
+__device__ unsigned long long g_prof[16];   // 0 total, 1 header+tables, 2 symbols, 3 resolve, 4 crc, 5 blocks, 6 stored
+#define HG_T0(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#define HG_TACC(slot, var) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (lane_id() == 0) atomicAdd(&g_prof[slot], n_ - var); var = n_; } while (0)
+#define HG_CNT(slot, v) do { if (lane_id() == 0) atomicAdd(&g_prof[slot], (unsigned long long)(v)); } while (0)
+#else
+#define HG_T0(var) do { } while (0)
+#define HG_TACC(slot, var) do { } while (0)
+#define HG_CNT(slot, v) do { } while (0)
+#endif
+
+#ifndef HG_LIT_RB
+#define HG_LIT_RB 10
+#endif
+constexpr int LIT_RB = HG_LIT_RB;
 constexpr int DIST_RB = 8;
-constexpr int LIT_TAB = 1344;   // >= ENOUGH(286 symbols, root 10, max 15) = 1332
+// zlib's ENOUGH bound for 286 symbols / 15-bit codes: root 10 -> 1332 entries, root 9 -> 852
+constexpr int LIT_TAB = HG_LIT_RB == 10 ? 1344 : 864;
 constexpr int DIST_TAB = 416;   // >= ENOUGH(30 symbols, root 8, max 15)  = 402
 constexpr int PRE_RB = 7;
 constexpr int WAVES_PER_WG = 4;
+#ifndef HG_RING
+#define HG_RING 2048
+#endif
+#ifndef HG_WALK
+#define HG_WALK 0        // 0: vector-uniform serial loop (inflate_loop_vec.inc)  1: gather + scalar walk
+#endif
+constexpr uint32_t RING = HG_RING;          // bytes of most recent output mirrored in LDS per wave
+constexpr uint32_t RING_NEAR = RING - 64u;  // look-back spans up to this are served from LDS
 
 // table entry: [3:0] code bits to drop, [4] literal, [5] length/distance,
 // [6] end of block, [7] second-level pointer, [11:8] extra bits (or sub-table
 // bits), [31:16] value (literal / base / sub-table offset)
 constexpr uint32_t F_LIT = 0x10u, F_BASE = 0x20u, F_EOB = 0x40u, F_SUB = 0x80u;
+// bit 31: "fast literal" -- a literal whose whole code sits in the root table, so the hot loop
+// needs ONE sign test to know it can emit a byte and drop e&15 bits.
+constexpr uint32_t F_FAST = 0x80000000u;
 
 struct WaveLds {
     uint32_t lit[LIT_TAB];
@@ -60,14 +87,15 @@ struct WaveLds {
     uint32_t alloc;
     uint32_t pad[3];
     uint8_t lens[352];
+    uint8_t ring[RING];
 };
 
 enum { KIND_LITLEN = 0, KIND_DIST = 1, KIND_PRE = 2 };
 
-__device__ __forceinline__ uint32_t make_entry(int kind, uint32_t sym, uint32_t nb) {
+__device__ __forceinline__ uint32_t make_entry(int kind, uint32_t sym, uint32_t nb, bool root) {
     if (kind == KIND_PRE) return (sym << 16) | F_LIT | nb;
     if (kind == KIND_LITLEN) {
-        if (sym < 256) return (sym << 16) | F_LIT | nb;
+        if (sym < 256) return (sym << 16) | F_LIT | nb | (root ? F_FAST : 0u);
         if (sym == 256) return F_EOB | nb;
         uint32_t s = sym - 257;
         if (s > 28) return 0;                                  // 286, 287: invalid
@@ -153,7 +181,7 @@ __device__ __forceinline__ int build_table(WaveLds &S, uint32_t *tab, int lens_o
             uint32_t sym = (uint32_t)(c * 64 + lane);
             uint32_t rev = __brev(mycode) >> (32 - len);
             if (len <= (uint32_t)RB) {
-                uint32_t e = make_entry(KIND, sym, len);
+                uint32_t e = make_entry(KIND, sym, len, true);
                 for (uint32_t idx = rev; idx < (1u << RB); idx += 1u << len) tab[idx] = e;
             } else {
                 atomicMax(&tab[rev & ((1u << RB) - 1)], len);     // longest code under this root slot
@@ -184,7 +212,7 @@ __device__ __forceinline__ int build_table(WaveLds &S, uint32_t *tab, int lens_o
             uint32_t rev = __brev(mycode) >> (32 - len);
             uint32_t root = tab[rev & ((1u << RB) - 1)];
             uint32_t off = root >> 16, sb = (root >> 8) & 0xf;
-            uint32_t e = make_entry(KIND, sym, len - RB);
+            uint32_t e = make_entry(KIND, sym, len - RB, false);
             for (uint32_t idx = rev >> RB; idx < (1u << sb); idx += 1u << (len - RB)) tab[off + idx] = e;
         }
     }
@@ -228,6 +256,15 @@ __device__ __forceinline__ void br_seek(BitReader &br, uint32_t byte_pos, int la
     br.next_dw = dw + 1;
 }
 
+// position the reader at BIT offset `bit_pos` (relative to br.g)
+__device__ __forceinline__ void br_seek_bits(BitReader &br, uint32_t bit_pos, int lane) {
+    uint32_t dw = bit_pos >> 5, sh = bit_pos & 31u;
+    uint32_t w = br_fetch(br, dw, lane);
+    br.bb = (uint64_t)(w >> sh);
+    br.bc = 32u - sh;
+    br.next_dw = dw + 1;
+}
+
 __device__ __forceinline__ void br_refill(BitReader &br, int lane) {
     if (br.bc <= 32u) {
         uint32_t w = br_fetch(br, br.next_dw, lane);
@@ -262,6 +299,7 @@ enum { ST_OK = 0, ST_HEADER = 1, ST_INFLATE = 2, ST_SIZE = 3, ST_CRC = 4 };
 __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_t in_start, uint32_t in_end,
                               uint8_t *out, uint32_t cap, uint32_t *out_len, int lane) {
     uint32_t pos = 0;
+    HG_T0(tph);
     HG_TRACE(2, 1);
     br_seek(br, in_start, lane);
     HG_TRACE(2, 2);
@@ -284,6 +322,12 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
             const uint8_t *sp = (const uint8_t *)br.g + src;
             for (uint32_t i = lane; i < len; i += 64) out[pos + i] = sp[i];
             pos += len;
+            if (!bfinal) {
+                // later blocks may reach back into these bytes: mirror the tail into the LDS ring
+                uint32_t lo = pos > RING ? pos - RING : 0u;
+                for (uint32_t p = lo + lane; p < pos; p += 64) S.ring[p & (RING - 1u)] = out[p];
+                wave_sync();
+            }
             br_seek(br, src + len, lane);
         } else if (btype == 3) {
             return ST_INFLATE;
@@ -361,64 +405,12 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                 if (build_table<KIND_LITLEN, LIT_RB, LIT_TAB, 5>(S, S.lit, 32, (int)nlen, lane)) return ST_INFLATE;
                 if (build_table<KIND_DIST, DIST_RB, DIST_TAB, 1>(S, S.dist, 32 + (int)nlen, (int)ndist, lane)) return ST_INFLATE;
             }
-            // ---- symbol loop -------------------------------------------------
-            uint32_t litv = 0, nlit = 0;
-            HG_TRACE(2, 5);
-            for (;;) {
-                HG_TRACE(3, pos);
-                br_refill(br, lane);
-                HG_TRACE(5, br.bc); HG_TRACE(6, (uint32_t)br.bb);
-                uint32_t e = lds_uniform(&S.lit[br_peek(br, LIT_RB)]);
-                HG_TRACE(7, e);
-                if (e & F_SUB) {
-                    br_drop(br, LIT_RB);
-                    e = lds_uniform(&S.lit[(e >> 16) + br_peek(br, (e >> 8) & 15u)]);
-                }
-                br_drop(br, e & 15u);
-                if (e & F_LIT) {
-                    litv = writelane(e >> 16, nlit, litv);
-                    nlit++;
-                    if (nlit == 64) {
-                        if (pos + 64 > cap) return ST_INFLATE;
-                        out[pos + lane] = (uint8_t)litv;
-                        pos += 64; nlit = 0;
-                    }
-                    continue;
-                }
-                // flush pending literals before anything that ends the run
-                if (nlit) {
-                    if (pos + nlit > cap) return ST_INFLATE;
-                    if ((uint32_t)lane < nlit) out[pos + lane] = (uint8_t)litv;
-                    pos += nlit; nlit = 0;
-                }
-                if (!(e & F_BASE)) {
-                    if (e & F_EOB) break;
-                    return ST_INFLATE;                                  // invalid code
-                }
-                uint32_t len = (e >> 16) + br_bits(br, (e >> 8) & 15u);
-                br_refill(br, lane);
-                uint32_t d = lds_uniform(&S.dist[br_peek(br, DIST_RB)]);
-                if (d & F_SUB) {
-                    br_drop(br, DIST_RB);
-                    d = lds_uniform(&S.dist[(d >> 16) + br_peek(br, (d >> 8) & 15u)]);
-                }
-                if (!(d & F_BASE)) return ST_INFLATE;
-                br_drop(br, d & 15u);
-                uint32_t dist = (d >> 16) + br_bits(br, (d >> 8) & 15u);
-                if (dist > pos || pos + len > cap) return ST_INFLATE;
-                // LZ77 copy: span = largest multiple-of-dist look-back usable so far
-                uint32_t done = 0, span = dist;
-                do {
-                    uint32_t n = len - done;
-                    n = n < 64u ? n : 64u;
-                    n = n < span ? n : span;
-                    uint8_t *dst = out + pos + done;
-                    if ((uint32_t)lane < n) dst[lane] = dst[(int)lane - (int)span];
-                    done += n;
-                    if (n == span) span <<= 1;
-                } while (done < len);
-                pos += len;
-            }
+            HG_TACC(1, tph);
+#if HG_WALK
+#include "inflate_loop_walk.inc"
+#else
+#include "inflate_loop_vec.inc"
+#endif
             if (br_byte_pos(br) > in_end) return ST_INFLATE;
         }
         if (bfinal) break;
@@ -438,7 +430,7 @@ void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
     WaveLds &S = lds[wave];
     const uint64_t max_dw_abs = (comp_len + 3) / 4 - 1;   // buffer is padded to a dword multiple
 
-    uint32_t iter = 0;
+    uint32_t iter = 0; (void)iter;
     for (;;) {
         uint32_t b = 0;
         iter++;
@@ -451,6 +443,7 @@ void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
         HG_TRACE(13, b + 1000);
         if (b >= nblocks) break;
         HG_TRACE(0, b + 1);
+        HG_T0(tblk);
         const hg_bgzf_desc dsc = desc[b];
         const uint64_t coff = ((uint64_t)uni((uint32_t)(dsc.coff >> 32)) << 32) | uni((uint32_t)dsc.coff);
         const uint64_t uoff = ((uint64_t)uni((uint32_t)(dsc.uoff >> 32)) << 32) | uni((uint32_t)dsc.uoff);
@@ -507,13 +500,16 @@ void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
                 if (st == ST_OK && tr[1] != ulen) st = ST_SIZE;
                 if (st == ST_OK) {
                     HG_TRACE(11, 1);
+                    HG_T0(tcrc);
                     uint32_t crc = wave_crc32(o, ulen, lane);
+                    HG_TACC(4, tcrc);
                     HG_TRACE(11, 2);
                     if (uni(crc) != tr[0]) st = ST_CRC;
                 }
             }
         }
         HG_TRACE(1, 90 + st);
+        HG_TACC(0, tblk); HG_CNT(5, 1);
         // all lanes store the same word (one coalesced write)
         status[b] = st == ST_OK ? HG_BLOCK_OK : st == ST_CRC ? HG_BLOCK_ECRC : HG_BLOCK_EINFLATE;
         HG_TRACE(14, 555);
@@ -533,6 +529,13 @@ void crc32_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__
     }
 }
 
+#ifdef HG_PROFILE
+extern "C" int hg_debug_get_profile(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 #ifdef HG_DEBUG_TRACE
 extern "C" int hg_debug_set_trace(void *pinned_host_words) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &pinned_host_words, sizeof(void *)) == hipSuccess ? 0 : -1;

@@ -22,6 +22,15 @@ __device__ __forceinline__ uint32_t writelane(uint32_t val, uint32_t lane, uint3
 __device__ __forceinline__ uint32_t uni(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
+// A zero the compiler cannot see through, living in a VGPR: OR-ing it into a wave-uniform
+// value moves the arithmetic that follows from the scalar ALU to the vector ALUs.
+__device__ __forceinline__ uint32_t vzero() {
+    uint32_t z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+// true in every lane iff the predicate holds in some lane (predicates here are wave-uniform)
+__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ int lane_id() {
     return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }

@@ -30,6 +30,10 @@
 #include <string.h>
 
 #define ORC_EXPORT __attribute__((visibility("default")))
+#ifndef TOKSTAT_MATCH            /* instrumentation hooks for scripts/tokstats.c; no-ops normally */
+#define TOKSTAT_MATCH(len, dist) do { } while (0)
+#define TOKSTAT_LIT() do { } while (0)
+#endif
 
 /* ------------------------------------------------------------------ CRC-32 */
 /* RFC 1952 section 8: reflected polynomial 0xEDB88320, init/xorout ~0. */
@@ -143,6 +147,7 @@ static int codes(orc_state *s, const orc_huff *lc, const orc_huff *dc)
         if (sym < 256) {
             if (s->out_pos == s->out_cap) return -1;
             s->out[s->out_pos++] = (uint8_t)sym;
+            TOKSTAT_LIT();
         } else if (sym == 256) {
             return 0;
         } else {
@@ -156,6 +161,7 @@ static int codes(orc_state *s, const orc_huff *lc, const orc_huff *dc)
             if (s->err) return -1;
             if (dist > s->out_pos) return -1;           /* before start of block */
             if (s->out_pos + (size_t)len > s->out_cap) return -1;
+            TOKSTAT_MATCH(len, dist);
             while (len--) { s->out[s->out_pos] = s->out[s->out_pos - dist]; s->out_pos++; }
         }
     }
