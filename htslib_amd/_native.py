@@ -41,9 +41,14 @@ lib.hg_bgzf_inflate_dev.argtypes = [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, 
 lib.hg_bgzf_inflate_host.argtypes = [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t),
                                      _vp, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_int)]
 lib.hg_crc32_dev.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]
+lib.hg_bgzf_deflate_dev.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp, _vp, _vp]
+lib.hg_bgzf_pack_dev.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, C.c_int, _vp]
+lib.hg_bgzf_deflate_host.argtypes = [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_int, _vp, C.c_size_t,
+                                     C.POINTER(C.c_size_t)]
 
 EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info", "hg_bgzf_scan",
-           "hg_bgzf_inflate_dev", "hg_bgzf_inflate_host", "hg_crc32_dev"]
+           "hg_bgzf_inflate_dev", "hg_bgzf_inflate_host", "hg_crc32_dev", "hg_bgzf_deflate_dev", "hg_bgzf_pack_dev",
+           "hg_bgzf_deflate_host"]
 
 
 class HgError(RuntimeError):
@@ -112,6 +117,24 @@ class Engine:
         self.last_bad = (bad_i.value, bad_c.value)
         check(rc, f"hg_bgzf_inflate_host (block {bad_i.value} code {bad_c.value})")
         return out.raw[:out_len.value], status
+
+    def bgzf_deflate_host(self, plain: bytes, level: int = 6, cuts=None, add_eof: bool = True) -> bytes:
+        """BGZF-compress `plain` on the GPU; blocks end at `cuts` (default every 0xff00 bytes)."""
+        import numpy as np
+        n = len(plain)
+        nb = (len(cuts) - 1) if cuts is not None else (n + 0xFF00 - 1) // 0xFF00
+        cap = nb * 65536 + 64
+        out = C.create_string_buffer(cap)
+        out_len = C.c_size_t(0)
+        src = (C.c_char * max(n, 1)).from_buffer_copy(plain if n else b"\0")
+        carr = None
+        if cuts is not None:
+            carr = np.ascontiguousarray(np.asarray(cuts, dtype=np.uint64))
+        rc = lib.hg_bgzf_deflate_host(self._h, C.addressof(src), n, carr.ctypes.data if carr is not None else None,
+                                      nb if carr is not None else 0, level, 1 if add_eof else 0, C.addressof(out), cap,
+                                      C.byref(out_len))
+        check(rc, "hg_bgzf_deflate_host")
+        return out.raw[:out_len.value]
 
     # -- device-resident entry points (torch tensors or raw pointers) ----------
     def bgzf_inflate_dev(self, d_comp: int, comp_len: int, d_desc: int, nblocks: int, d_out: int,

@@ -1,0 +1,497 @@
+// bgzf_deflate.hip -- BGZF block deflate for MI355X (gfx950 / CDNA4).
+//
+// Replaces the writer-side worker of htslib, bgzf_encode_func -> bgzf_compress (reference
+// bgzf.c:1330-1341, 561-683): raw DEFLATE of one <= 0xff00-byte block, BGZF header, CRC-32 and
+// ISIZE trailer, stored-block fallback when deflate does not shrink the block (bgzf.c:652-667),
+// the canonical 28-byte EOF block for empty input (bgzf.c:563-569).  Compressed bytes are not
+// expected to equal zlib's or libdeflate's (the reference's own tests accept any valid stream,
+// test/test.pl:1238-1260); they must decode bit-exactly with stock htslib and stay within a few
+// per cent of zlib level 6 in size.
+//
+// Mapping (CDNA4 first, not a port of a CPU deflate):
+//   * one BGZF block per 256-thread workgroup, the whole 64 KiB input staged ONCE in LDS with
+//     coalesced 16-byte loads; every later access (hashing, match extension, literals, CRC) is an
+//     LDS access.  77 KiB of LDS per workgroup -> 2 workgroups (8 waves) per CU, persistent
+//     workgroups pull block tickets from a global counter;
+//   * match finding is position-parallel: the block is walked in chunks of 256 positions, one
+//     position per lane; a lane hashes its 4 bytes, reads the WAYS most recent earlier
+//     positions with that hash from a set-associative table in LDS (one ds_read_b128), extends
+//     each candidate 4 bytes at a time, then the chunk's positions are inserted (LDS atomics
+//     pick the way).  Candidates are always from earlier chunks; distance 1 is probed directly;
+//   * the lazy parse (take a match unless the next position has a longer one) is a chain over
+//     positions; it is resolved per chunk with 8 rounds of pointer jumping in LDS, then the
+//     chosen tokens are compacted in order with ballots and appended to a per-workgroup token
+//     list in HBM while LDS atomics build the litlen/distance histograms;
+//   * Huffman construction (<= 316 symbols) is the serial tail, run by one lane on LDS arrays
+//     (deflate_huff.h, unit-tested on the host);
+//   * bit packing is a prefix scan of code lengths over 256 tokens per step; lanes OR their
+//     <= 48 bits into an LDS staging window with ds_or and the finished dwords leave with
+//     coalesced stores.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "htsgpu.h"
+#include "hg_device.h"
+#include "hg_internal.h"
+#include "deflate_huff.h"
+
+namespace hgd {
+
+#ifndef HG_DEF_HB
+#define HG_DEF_HB 9
+#endif
+constexpr int WG = 256;
+constexpr int HB = HG_DEF_HB;                 // hash buckets = 2^HB
+constexpr int WAYS = 8;                        // most recent positions kept per bucket
+constexpr uint32_t MAX_IN = 0xff00u;           // BGZF_BLOCK_SIZE (htslib/bgzf.h:50)
+constexpr uint32_t TOO_FAR = 4096u;            // a 3-byte match this far away costs more than 3 literals
+
+struct Huff {                                  // overlays the hash table once matching is done
+    uint32_t obuf[520];                        // bit-packing staging window (dwords)
+    uint32_t work[320];
+    uint16_t order[320];
+    uint16_t ll_code[288];
+    uint16_t d_code[32];
+    uint8_t ll_len[288];
+    uint8_t d_len[32];
+    uint8_t cl_sym[320];
+    uint8_t cl_ext[320];
+    uint8_t hdr[328];
+};
+
+struct Lds {
+    uint32_t in32[(MAX_IN + 16) / 4];
+    union {
+        uint16_t tab[(1 << HB) * WAYS];
+        Huff h;
+    } u;
+    uint32_t cnt32[(1 << HB) / 4];             // 8-bit insertion counters, 4 per dword
+    uint32_t lfreq[288];
+    uint32_t dfreq[32];
+    uint16_t mlen[WG + 2];
+    uint16_t mdist[WG];
+    uint16_t jump[WG];
+    uint8_t mark[WG];
+    uint32_t wsum[8];
+    uint32_t carry_next;
+    uint32_t misc[7];
+};
+static_assert(sizeof(Huff) <= sizeof(uint16_t) * (1 << HB) * WAYS, "Huff scratch must fit in the hash table");
+static_assert(sizeof(Lds) <= 80 * 1024, "two workgroups per CU");
+
+__device__ __forceinline__ uint32_t load4(const uint32_t *in32, uint32_t off) {
+    uint32_t lo = in32[off >> 2], hi = in32[(off >> 2) + 1];
+    return __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
+}
+__device__ __forceinline__ uint32_t hash4(uint32_t v) { return (v * 2654435761u) >> (32 - HB); }
+
+// longest common prefix of the strings at a and b (a < b), at most maxl bytes
+__device__ __forceinline__ uint32_t match_len(const uint32_t *in32, uint32_t a, uint32_t b, uint32_t maxl) {
+    uint32_t l = 0;
+    while (l < maxl) {
+        uint32_t x = load4(in32, a + l) ^ load4(in32, b + l);
+        if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
+        l += 4;
+    }
+    return l < maxl ? l : maxl;
+}
+
+// CRC-32 of the LDS-resident block, all 256 threads; result valid in thread 0.
+__device__ uint32_t wg_crc32(Lds &S, uint32_t n, int tid) {
+    using namespace hg;
+    if (n == 0) return 0;
+    uint32_t per = (n + 255u) >> 8;
+    int k = 2;
+    while ((1u << k) < per) k++;
+    const uint32_t K = 1u << k;
+    long long beg = (long long)n - (long long)(256 - tid) * (long long)K;
+    long long end = beg + (long long)K;
+    if (beg < 0) beg = 0;
+    if (end < 0) end = 0;
+    uint32_t len = (uint32_t)(end - beg), q = (uint32_t)beg;
+    uint32_t c = (beg == 0 && end > 0) ? 0xffffffffu : 0u;
+    const uint8_t *in8 = (const uint8_t *)S.in32;
+    uint32_t head = len & 3u;
+    for (uint32_t i = 0; i < head; i++) c = crc_byte(c, in8[q + i]);
+    q += head; len -= head;
+    for (uint32_t i = 0; i < len; i += 4) c = crc_word(c, load4(S.in32, q + i));
+    const int lane = tid & 63;
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+        uint32_t other = (uint32_t)__shfl_xor((int)c, 1 << s, 64);
+        uint32_t m = g_crc.xpow[k + s];
+        bool left = ((lane >> s) & 1) == 0;
+        uint32_t a = left ? c : other, b = left ? other : c;
+        c = crc_mulmod(a, m) ^ b;
+    }
+    if (lane == 0) S.wsum[4 + (tid >> 6)] = c;
+    __syncthreads();
+    uint32_t r = 0;
+    if (tid == 0) {
+        uint32_t X = g_crc.xpow[k + 6];
+        r = S.wsum[4];
+        r = crc_mulmod(r, X) ^ S.wsum[5];
+        r = crc_mulmod(r, X) ^ S.wsum[6];
+        r = crc_mulmod(r, X) ^ S.wsum[7];
+        r ^= 0xffffffffu;
+    }
+    __syncthreads();
+    return r;
+}
+
+// Bit packer: every thread contributes `nb` (<= 56) bits `v` (LSB first) in thread order.
+// *bitpos is the absolute bit offset in the output slot; complete dwords are flushed.
+__device__ __forceinline__ void pack_bits(Lds &S, uint32_t *out32, uint32_t &bitpos, uint64_t v, uint32_t nb, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    // inclusive scan of nb inside the wave
+    uint32_t x = nb;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        uint32_t y = (uint32_t)__shfl_up((int)x, s, 64);
+        if (lane >= s) x += y;
+    }
+    if (lane == 63) S.wsum[wave] = x;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { uint32_t t = S.wsum[w]; if (w < wave) base += t; total += t; }
+    const uint32_t my = bitpos + base + x - nb;            // my first bit
+    const uint32_t w0 = bitpos >> 5;                        // first dword of the staging window
+    uint32_t *ob = S.u.h.obuf;
+    if (nb) {
+        uint32_t wi = (my >> 5) - w0, sh = my & 31u;
+        uint64_t lo = v << sh;
+        atomicOr(&ob[wi], (uint32_t)lo);
+        if (sh + nb > 32) atomicOr(&ob[wi + 1], (uint32_t)(lo >> 32));
+        if (sh + nb > 64) atomicOr(&ob[wi + 2], (uint32_t)(v >> (64 - sh)));
+    }
+    __syncthreads();
+    const uint32_t endbit = bitpos + total;
+    const uint32_t ndone = (endbit >> 5) - w0;              // complete dwords
+    for (uint32_t i = tid; i < ndone; i += WG) out32[w0 + i] = ob[i];
+    uint32_t carry = ob[ndone];
+    __syncthreads();
+    for (uint32_t i = tid; i <= ndone + 1 && i < 520; i += WG) ob[i] = 0;
+    __syncthreads();
+    if (tid == 0) ob[0] = carry;
+    bitpos = endbit;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(WG)
+void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *__restrict__ desc, uint32_t nblocks,
+                         uint8_t *slots, uint32_t *clen_out, uint32_t *tokbuf, unsigned int *ticket, int level) {
+    __shared__ Lds S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *tok = tokbuf + (size_t)blockIdx.x * 65536u;
+    const uint8_t *in8 = (const uint8_t *)S.in32;
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) S.misc[0] = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const uint32_t b = S.misc[0];
+        if (b >= nblocks) break;
+        const hg_bgzf_desc dsc = desc[b];
+        const uint32_t n = dsc.ulen > MAX_IN ? MAX_IN : dsc.ulen;     // API guarantees ulen <= 0xff00
+        const uint8_t *src = plain + dsc.uoff;
+        uint8_t *o8 = slots + dsc.coff;
+        uint32_t *o32 = (uint32_t *)o8;
+
+        if (n == 0) {                                      // canonical EOF block (bgzf.c:566)
+            const uint8_t eofb[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0,
+                                      0, 0, 0, 0, 0, 0, 0, 0};
+            if (tid < 28) o8[tid] = eofb[tid];
+            if (tid == 0) clen_out[b] = 28;
+            continue;
+        }
+        // ---- stage the block in LDS (coalesced 16-byte loads) ----------------------------
+        for (uint32_t i = (uint32_t)tid * 16u; i < n + 16u; i += WG * 16u) {
+            uint4 w = {0, 0, 0, 0};
+            if (i + 16u <= n) __builtin_memcpy(&w, src + i, 16);
+            else if (i < n) {
+                uint8_t t[16];
+                for (int k = 0; k < 16; k++) t[k] = i + k < n ? src[i + k] : 0;
+                __builtin_memcpy(&w, t, 16);
+            }
+            if (i / 4 + 3 < sizeof(S.in32) / 4) {
+                S.in32[i / 4] = w.x; S.in32[i / 4 + 1] = w.y; S.in32[i / 4 + 2] = w.z; S.in32[i / 4 + 3] = w.w;
+            }
+        }
+        for (int i = tid; i < (1 << HB) * WAYS / 2; i += WG) ((uint32_t *)S.u.tab)[i] = 0xffffffffu;
+        for (int i = tid; i < (1 << HB) / 4; i += WG) S.cnt32[i] = 0;
+        for (int i = tid; i < 288; i += WG) S.lfreq[i] = 0;
+        if (tid < 32) S.dfreq[tid] = 0;
+        if (tid == 0) S.mlen[WG] = 0;
+        __syncthreads();
+        const uint32_t crc = wg_crc32(S, n, tid);          // valid in thread 0
+
+        uint32_t ntok = 0;
+        if (level != 0) {
+            // ---- match finding + lazy parse, 256 positions per step -----------------------
+            uint32_t carry = 0;                            // chunk-relative position of the next token
+            for (uint32_t c0 = 0; c0 < n; c0 += WG) {
+                const uint32_t p = c0 + (uint32_t)tid;
+                uint32_t best = 0, bd = 0, h = 0;
+                const bool hashable = p + 4u <= n;
+                if (hashable) {
+                    const uint32_t maxl = n - p < 258u ? n - p : 258u;
+                    const uint32_t cur = load4(S.in32, p);
+                    h = hash4(cur);
+                    const uint4 row = *(const uint4 *)&S.u.tab[h * WAYS];
+                    const uint32_t cw[4] = {row.x, row.y, row.z, row.w};
+#pragma unroll
+                    for (int w = 0; w < WAYS; w++) {
+                        const uint32_t cand = (cw[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+                        if (cand != 0xffffu && p - cand <= 32768u && load4(S.in32, cand) == cur) {   // 32 KiB window
+                            const uint32_t l = 4u + match_len(S.in32, cand + 4u, p + 4u, maxl - 4u);
+                            const uint32_t d = p - cand;
+                            if (l > best || (l == best && d < bd)) { best = l; bd = d; }
+                        }
+                    }
+                    if (p >= 1u) {                          // distance 1 (runs) is never in the table of this chunk
+                        const uint32_t l = match_len(S.in32, p - 1u, p, maxl);
+                        if (l > best) { best = l; bd = 1; }
+                    }
+                    if (best < 3u || (best == 3u && bd > TOO_FAR)) best = 0;
+                }
+                S.mlen[tid] = (uint16_t)best;
+                S.mdist[tid] = (uint16_t)bd;
+                __syncthreads();
+                if (hashable) {                            // publish this chunk's positions
+                    const uint32_t sh = (h & 3u) * 8u;
+                    const uint32_t old = atomicAdd(&S.cnt32[h >> 2], 1u << sh);
+                    S.u.tab[h * WAYS + ((old >> sh) & (WAYS - 1))] = (uint16_t)p;
+                }
+                // ---- lazy parse by pointer jumping -----------------------------------------
+                const bool live = p < n;
+                const bool take = best >= 3u && !(tid < WG - 1 && (uint32_t)S.mlen[tid + 1] > best);
+                const uint32_t step = take ? best : 1u;
+                uint32_t nx = (uint32_t)tid + step;
+                if (nx > WG) nx = WG;
+                bool marked = false;
+                if (carry < WG) {
+                    S.jump[tid] = (uint16_t)nx;
+                    S.mark[tid] = (uint8_t)(((uint32_t)tid == carry) && live);
+                    __syncthreads();
+#pragma unroll 1
+                    for (int r = 0; r < 8; r++) {
+                        const uint32_t j = S.jump[tid];
+                        if (S.mark[tid] && j < WG) S.mark[j] = 1;
+                        const uint32_t nj = j < WG ? (uint32_t)S.jump[j] : (uint32_t)WG;
+                        __syncthreads();
+                        S.jump[tid] = (uint16_t)nj;
+                        __syncthreads();
+                    }
+                    marked = S.mark[tid] != 0 && live;
+                    if (marked && (uint32_t)tid + step >= WG) S.carry_next = (uint32_t)tid + step - WG;
+                    if (tid == 0 && c0 + WG >= n) S.carry_next = 0;   // last chunk: value unused
+                } else if (tid == 0) {
+                    S.carry_next = carry - WG;
+                }
+                // ---- compact the chosen tokens, in order -----------------------------------
+                const unsigned long long bal = __ballot(marked);
+                if (lane == 0) S.wsum[wave] = (uint32_t)__popcll(bal);
+                __syncthreads();
+                uint32_t base = ntok, total = 0;
+#pragma unroll
+                for (int w = 0; w < 4; w++) { uint32_t t = S.wsum[w]; if (w < wave) base += t; total += t; }
+                if (marked) {
+                    const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    if (take) {
+                        tok[idx] = 0x80000000u | ((best - 3u) << 16) | (bd - 1u);
+                        uint32_t s, xb, xv;
+                        hgdef::len_symbol(best, s, xb, xv); atomicAdd(&S.lfreq[257 + s], 1u);
+                        hgdef::dist_symbol(bd, s, xb, xv); atomicAdd(&S.dfreq[s], 1u);
+                    } else {
+                        const uint32_t byte = in8[p];
+                        tok[idx] = byte;
+                        atomicAdd(&S.lfreq[byte], 1u);
+                    }
+                }
+                ntok += total;
+                carry = S.carry_next;
+                __syncthreads();
+            }
+        }
+        // ---- choose the block type and build the codes -------------------------------------
+        __syncthreads();
+        uint32_t hdr_bits = 0, dyn_bits = 0;
+        if (level != 0) {
+            if (tid == 0) {
+                Huff &H = S.u.h;
+                S.lfreq[256] = 1;
+                hgdef::build_lengths(S.lfreq, 286, 15, H.ll_len, H.order, H.work);
+                hgdef::build_lengths(S.dfreq, 30, 15, H.d_len, H.order, H.work);
+                hgdef::assign_codes(H.ll_len, 286, H.ll_code);
+                hgdef::assign_codes(H.d_len, 30, H.d_code);
+                uint32_t hb = hgdef::write_dynamic_header(H.ll_len, H.d_len, H.hdr, H.cl_sym, H.cl_ext, H.work, H.order);
+                uint32_t bits = hb;
+                for (int s = 0; s < 286; s++) {
+                    uint32_t xb = 0;
+                    if (s > 264 && s < 285) xb = (uint32_t)(s - 261) >> 2;
+                    bits += S.lfreq[s] * (H.ll_len[s] + xb);
+                }
+                for (int s = 0; s < 30; s++) bits += S.dfreq[s] * (H.d_len[s] + (s < 4 ? 0u : (uint32_t)(s - 2) >> 1));
+                S.misc[1] = hb; S.misc[2] = bits;
+            }
+            __syncthreads();
+            hdr_bits = S.misc[1]; dyn_bits = S.misc[2];
+        }
+        const uint32_t dyn_bytes = (dyn_bits + 7u) >> 3;
+        const bool stored = level == 0 || dyn_bytes >= n + 5u;
+        // ---- BGZF header (BSIZE patched at the end) ------------------------------------------
+        if (tid < 18) {
+            const uint8_t h18[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0, 0};
+            o8[tid] = h18[tid];
+        }
+        uint32_t total_len;
+        if (stored) {
+            // 01 LEN NLEN data (bgzf.c:573-580, 652-667)
+            if (tid == 0) {
+                o8[18] = 1; o8[19] = (uint8_t)n; o8[20] = (uint8_t)(n >> 8);
+                o8[21] = (uint8_t)~n; o8[22] = (uint8_t)(~n >> 8);
+            }
+            for (uint32_t i = tid; i < n; i += WG) o8[23 + i] = in8[i];
+            total_len = 18u + 5u + n + 8u;
+        } else {
+            Huff &H = S.u.h;
+            for (int i = tid; i < 520; i += WG) H.obuf[i] = 0;
+            __syncthreads();
+            uint32_t bitpos = 18u * 8u;
+            // the dynamic-block header, one byte per thread
+            const uint32_t hbytes = (hdr_bits + 7u) >> 3;
+            for (uint32_t i0 = 0; i0 < hbytes; i0 += WG) {
+                const uint32_t i = i0 + (uint32_t)tid;
+                uint32_t nb = 0; uint64_t v = 0;
+                if (i < hbytes) { v = H.hdr[i]; nb = (i == hbytes - 1 && (hdr_bits & 7u)) ? (hdr_bits & 7u) : 8u; }
+                pack_bits(S, o32, bitpos, v, nb, tid);
+            }
+            // the tokens (+ end-of-block after the last one)
+            for (uint32_t i0 = 0; i0 <= ntok; i0 += WG) {
+                const uint32_t i = i0 + (uint32_t)tid;
+                uint32_t nb = 0; uint64_t v = 0;
+                if (i < ntok) {
+                    const uint32_t t = tok[i];
+                    if (t & 0x80000000u) {
+                        uint32_t s, xb, xv;
+                        hgdef::len_symbol(((t >> 16) & 0xffu) + 3u, s, xb, xv);
+                        v = H.ll_code[257 + s]; nb = H.ll_len[257 + s];
+                        v |= (uint64_t)xv << nb; nb += xb;
+                        hgdef::dist_symbol((t & 0x7fffu) + 1u, s, xb, xv);
+                        v |= (uint64_t)H.d_code[s] << nb; nb += H.d_len[s];
+                        v |= (uint64_t)xv << nb; nb += xb;
+                    } else {
+                        v = H.ll_code[t & 0xffu]; nb = H.ll_len[t & 0xffu];
+                    }
+                } else if (i == ntok) {
+                    v = H.ll_code[256]; nb = H.ll_len[256];
+                }
+                pack_bits(S, o32, bitpos, v, nb, tid);
+            }
+            // pad to a byte boundary, then CRC32 + ISIZE as 8 single bytes
+            {
+                uint32_t nb = 0; uint64_t v = 0;
+                if (tid == 0) nb = (8u - (bitpos & 7u)) & 7u;
+                pack_bits(S, o32, bitpos, v, nb, tid);
+            }
+            total_len = (bitpos >> 3) + 8u;
+            // flush the partial dword that is still in the staging window
+            if (tid == 0 && (bitpos & 31u)) o32[bitpos >> 5] = H.obuf[0];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            uint8_t *t = o8 + total_len - 8;
+            for (int k = 0; k < 4; k++) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)(n >> (8 * k)); }
+            o8[16] = (uint8_t)(total_len - 1u); o8[17] = (uint8_t)((total_len - 1u) >> 8);
+            clen_out[b] = total_len;
+        }
+    }
+}
+
+// exclusive prefix sum of clen -> packed offsets; one workgroup, sequential over 1024-element tiles
+__global__ __launch_bounds__(1024)
+void scan_clen_kernel(const uint32_t *__restrict__ clen, uint32_t n, uint64_t *poff, uint64_t *total, int add_eof) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long run;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) run = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+        uint32_t i = i0 + tid;
+        unsigned long long v = i < n ? clen[i] : 0, x = v;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            unsigned long long y = __shfl_up(x, s, 64);
+            if (lane >= s) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        unsigned long long base = run;
+        for (int w = 0; w < wave; w++) base += wsum[w];
+        if (i < n) poff[i] = base + x - v;
+        __syncthreads();
+        if (tid == 1023) run = base + x;
+        __syncthreads();
+    }
+    if (tid == 0) *total = run + (add_eof ? 28 : 0);
+}
+
+// gather the slots into one contiguous BGZF stream (+ optional EOF block)
+__global__ __launch_bounds__(256)
+void pack_slots_kernel(const uint8_t *__restrict__ slots, const hg_bgzf_desc *__restrict__ desc,
+                       const uint32_t *__restrict__ clen, const uint64_t *__restrict__ poff, uint32_t n,
+                       uint8_t *packed, uint64_t cap, const uint64_t *total, int add_eof) {
+    for (uint32_t b = blockIdx.x; b < n + (add_eof ? 1u : 0u); b += gridDim.x) {
+        if (b == n) {
+            const uint8_t eofb[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0,
+                                      0, 0, 0, 0, 0, 0, 0, 0};
+            uint64_t at = *total - 28;
+            if (threadIdx.x < 28 && at + 28 <= cap) packed[at + threadIdx.x] = eofb[threadIdx.x];
+            continue;
+        }
+        const uint8_t *s = slots + desc[b].coff;
+        uint8_t *d = packed + poff[b];
+        const uint32_t len = clen[b];
+        if (poff[b] + len > cap) continue;
+        for (uint32_t i = threadIdx.x; i < len; i += 256) d[i] = s[i];
+    }
+}
+
+}  // namespace hgd
+
+namespace hg {
+
+int launch_bgzf_deflate(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_desc, size_t nblocks, int level,
+                        void *d_slots, uint32_t *d_clen, hipStream_t s) {
+    if (nblocks == 0) return HG_OK;
+    if (nblocks > 0xffffffffull) return HG_EINVAL;
+    size_t wgs = (size_t)ctx->cus * 2;
+    if (wgs > nblocks) wgs = nblocks;
+    size_t need = (size_t)ctx->cus * 2 * 65536 * sizeof(uint32_t);
+    if (ctx->d_tok_cap < need) {
+        if (ctx->d_tok) (void)hipFree(ctx->d_tok);
+        ctx->d_tok = nullptr; ctx->d_tok_cap = 0;
+        if (hipMalloc(&ctx->d_tok, need) != hipSuccess) return HG_ENOMEM;
+        ctx->d_tok_cap = need;
+    }
+    if (hipMemsetAsync(ctx->d_ticket + 4, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
+    hipLaunchKernelGGL(hgd::bgzf_deflate_kernel, dim3((unsigned)wgs), dim3(hgd::WG), 0, s, (const uint8_t *)d_plain,
+                       d_desc, (uint32_t)nblocks, (uint8_t *)d_slots, d_clen, (uint32_t *)ctx->d_tok,
+                       ctx->d_ticket + 4, level);
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+
+int launch_bgzf_pack(hg_ctx *ctx, const void *d_slots, const hg_bgzf_desc *d_desc, const uint32_t *d_clen,
+                     size_t nblocks, void *d_packed, size_t cap, uint64_t *d_poff, uint64_t *d_total, int add_eof,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(hgd::scan_clen_kernel, dim3(1), dim3(1024), 0, s, d_clen, (uint32_t)nblocks, d_poff, d_total,
+                       add_eof);
+    size_t wgs = nblocks + 1;
+    size_t maxw = (size_t)ctx->cus * 16;
+    if (wgs > maxw) wgs = maxw;
+    hipLaunchKernelGGL(hgd::pack_slots_kernel, dim3((unsigned)wgs), dim3(256), 0, s, (const uint8_t *)d_slots, d_desc,
+                       d_clen, d_poff, (uint32_t)nblocks, (uint8_t *)d_packed, (uint64_t)cap, d_total, add_eof);
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+
+}  // namespace hg

@@ -63,7 +63,8 @@ int hg_init(int device, hg_ctx **out) {
 void hg_destroy(hg_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (int i = 0; i < 4; i++) if (ctx->d_scratch[i]) (void)hipFree(ctx->d_scratch[i]);
+    for (int i = 0; i < 8; i++) if (ctx->d_scratch[i]) (void)hipFree(ctx->d_scratch[i]);
+    if (ctx->d_tok) (void)hipFree(ctx->d_tok);
     if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
     free(ctx);
 }
@@ -150,6 +151,67 @@ int hg_bgzf_inflate_host(hg_ctx *ctx, const uint8_t *comp, size_t comp_len, uint
         }
     }
     free(desc); free(st);
+    return rc;
+}
+
+int hg_bgzf_deflate_dev(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_desc, size_t nblocks, int level,
+                        void *d_slots, uint32_t *d_clen, void *stream) {
+    if (!ctx || (nblocks && (!d_plain || !d_desc || !d_slots || !d_clen)) || level < 0 || level > 9) return HG_EINVAL;
+    if (((uintptr_t)d_slots & 3u) != 0) return HG_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    return hg::launch_bgzf_deflate(ctx, d_plain, d_desc, nblocks, level, d_slots, d_clen, (hipStream_t)stream);
+}
+
+int hg_bgzf_pack_dev(hg_ctx *ctx, const void *d_slots, const hg_bgzf_desc *d_desc, const uint32_t *d_clen,
+                     size_t nblocks, void *d_packed, size_t packed_cap, uint64_t *d_packed_off, uint64_t *d_total,
+                     int add_eof, void *stream) {
+    if (!ctx || !d_packed || !d_packed_off || !d_total || (nblocks && (!d_slots || !d_desc || !d_clen))) return HG_EINVAL;
+    return hg::launch_bgzf_pack(ctx, d_slots, d_desc, d_clen, nblocks, d_packed, packed_cap, d_packed_off, d_total,
+                                add_eof, (hipStream_t)stream);
+}
+
+int hg_bgzf_deflate_host(hg_ctx *ctx, const uint8_t *plain, size_t len, const uint64_t *cuts, size_t ncuts, int level,
+                         int add_eof, uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!ctx || (!plain && len) || !out || level < 0 || level > 9) return HG_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    size_t nb = cuts ? ncuts : (len + HG_BGZF_BLOCK_SIZE - 1) / HG_BGZF_BLOCK_SIZE;
+    hg_bgzf_desc *desc = (hg_bgzf_desc *)malloc((nb ? nb : 1) * sizeof(hg_bgzf_desc));
+    if (!desc) return HG_ENOMEM;
+    for (size_t i = 0; i < nb; i++) {
+        uint64_t a = cuts ? cuts[i] : (uint64_t)i * HG_BGZF_BLOCK_SIZE;
+        uint64_t b = cuts ? cuts[i + 1] : (a + HG_BGZF_BLOCK_SIZE < len ? a + HG_BGZF_BLOCK_SIZE : len);
+        if (b < a || b > len || b - a > HG_BGZF_BLOCK_SIZE) { free(desc); return HG_EINVAL; }
+        desc[i].uoff = a; desc[i].ulen = (uint32_t)(b - a); desc[i].coff = (uint64_t)i * HG_BGZF_MAX_BLOCK_SIZE; desc[i].clen = 0;
+    }
+    int rc;
+    size_t slots = nb * (size_t)HG_BGZF_MAX_BLOCK_SIZE;
+    if ((rc = ensure_scratch(ctx, 0, len + 64)) || (rc = ensure_scratch(ctx, 1, slots + 64)) ||
+        (rc = ensure_scratch(ctx, 2, (nb + 1) * sizeof(hg_bgzf_desc))) || (rc = ensure_scratch(ctx, 3, (nb + 1) * 4)) ||
+        (rc = ensure_scratch(ctx, 4, (nb + 2) * 8)) || (rc = ensure_scratch(ctx, 5, slots + 64))) {
+        free(desc); return rc;
+    }
+    hipStream_t s = nullptr;
+    uint64_t *d_poff = (uint64_t *)ctx->d_scratch[4];
+    uint64_t *d_total = d_poff + nb;
+    bool ok = (len == 0 || hipMemcpyAsync(ctx->d_scratch[0], plain, len, hipMemcpyHostToDevice, s) == hipSuccess) &&
+              (nb == 0 || hipMemcpyAsync(ctx->d_scratch[2], desc, nb * sizeof(hg_bgzf_desc), hipMemcpyHostToDevice, s) == hipSuccess);
+    rc = ok ? hg::launch_bgzf_deflate(ctx, ctx->d_scratch[0], (const hg_bgzf_desc *)ctx->d_scratch[2], nb, level,
+                                      ctx->d_scratch[1], (uint32_t *)ctx->d_scratch[3], s) : HG_ELAUNCH;
+    if (rc == HG_OK)
+        rc = hg::launch_bgzf_pack(ctx, ctx->d_scratch[1], (const hg_bgzf_desc *)ctx->d_scratch[2],
+                                  (const uint32_t *)ctx->d_scratch[3], nb, ctx->d_scratch[5], slots + 64, d_poff, d_total,
+                                  add_eof, s);
+    uint64_t total = 0;
+    if (rc == HG_OK) {
+        ok = hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        if (!ok) rc = HG_ELAUNCH;
+    }
+    if (rc == HG_OK) {
+        if (out_len) *out_len = (size_t)total;
+        if (total > out_cap) rc = HG_EINVAL;
+        else if (total && (hipMemcpy(out, ctx->d_scratch[5], (size_t)total, hipMemcpyDeviceToHost) != hipSuccess)) rc = HG_ELAUNCH;
+    }
+    free(desc);
     return rc;
 }
 

@@ -94,6 +94,31 @@ int hg_bgzf_inflate_host(hg_ctx *ctx,
                          int32_t *status, size_t max_status,
                          long *first_bad_idx, int *first_bad_code);
 
+/* ---- BGZF deflate (replaces bgzf_compress / bgzf_encode_func / bgzf_encode_level0_func,
+ *      bgzf.c:561-683, 1330-1368) ------------------------------------------ */
+/* d_plain: the uncompressed image in HBM; d_desc[i].uoff/.ulen = the bytes of block i
+ * (ulen <= 0xff00, as cut by bgzf_write / bgzf_flush_try, bgzf.c:1996-2024) and d_desc[i].coff =
+ * byte offset of that block's 64 KiB output slot inside d_slots (normally i * 65536).  Every block
+ * becomes one complete BGZF block (18 B header, raw deflate or stored payload, CRC32, ISIZE) at
+ * the start of its slot; its length (BSIZE+1) is written to d_clen[i].  ulen == 0 yields the
+ * 28-byte EOF marker block.  level 0 = stored blocks (bgzf_encode_level0_func), 1..9 = deflate. */
+int hg_bgzf_deflate_dev(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_desc, size_t nblocks,
+                        int level, void *d_slots, uint32_t *d_clen, void *stream);
+
+/* Gather the slots into one contiguous BGZF stream (what bgzf_mt_writer hwrite()s in order,
+ * bgzf.c:1398-1473).  d_packed_off (nblocks u64) receives each block's offset in the stream (the
+ * block_address needed by the .gzi / BAI index code, bgzf.c:228-290), *d_total the stream length.
+ * add_eof != 0 appends the EOF marker block (bgzf_close, bgzf.c:2084-2101). */
+int hg_bgzf_pack_dev(hg_ctx *ctx, const void *d_slots, const hg_bgzf_desc *d_desc, const uint32_t *d_clen,
+                     size_t nblocks, void *d_packed, size_t packed_cap, uint64_t *d_packed_off,
+                     uint64_t *d_total, int add_eof, void *stream);
+
+/* Host-buffer convenience: cut `plain` into blocks (at cuts[0..ncuts] if given -- cuts[0] = 0,
+ * cuts[ncuts] = len, every piece <= 0xff00 -- otherwise every 0xff00 bytes), H2D, deflate, pack,
+ * D2H; appends the EOF block when add_eof != 0.  Synchronous. */
+int hg_bgzf_deflate_host(hg_ctx *ctx, const uint8_t *plain, size_t len, const uint64_t *cuts, size_t ncuts,
+                         int level, int add_eof, uint8_t *out, size_t out_cap, size_t *out_len);
+
 /* ---- CRC-32 (replaces hts_crc32, bgzf.c:557-559 / 620-622) -------------- */
 /* crc[i] = crc32(0, d_data + off[i], len[i]) for n independent buffers. */
 int hg_crc32_dev(hg_ctx *ctx, const void *d_data,

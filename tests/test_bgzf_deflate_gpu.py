@@ -1,0 +1,97 @@
+"""GPU tests (pytest -m gpu) of the gfx950 BGZF deflate kernel through the C ABI.
+Compressed bytes need not equal zlib's (the reference's own tests accept any valid stream,
+test/test.pl:1238-1260); what must hold: stock decoders reproduce the input bit-exactly, framing
+is spec-valid (bgzf.c:64-78), size stays close to the reference's zlib level 6."""
+import gzip
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import refutil
+from htslib_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def check_stream(comp, plain, oracle, expect_eof=True):
+    blocks = refutil.split_blocks(comp)
+    pos = 0
+    for off, clen, isize in blocks:
+        assert comp[off:off + 4] == b"\x1f\x8b\x08\x04" and comp[off + 12:off + 16] == b"BC\x02\x00"
+        assert 26 <= clen <= 65536 and isize <= 0xFF00
+        assert struct.unpack_from("<I", comp, off + clen - 8)[0] == zlib.crc32(plain[pos:pos + isize])
+        pos += isize
+    assert pos == len(plain) and sum(b[1] for b in blocks) == len(comp)
+    if expect_eof:
+        assert comp[-28:] == synth.BGZF_EOF
+    n, got = oracle.decompress(comp)
+    assert n == len(plain) and got == plain                      # oracle (RFC 1951 restatement)
+    assert gzip.decompress(comp) == plain                         # zlib, independent decoder
+    if refutil.have_ref():                                        # the real reference, both flavours
+        assert refutil.ref_bgzip(["-d"], comp, "zlib") == plain
+        assert refutil.ref_bgzip(["-d"], comp, "libdeflate") == plain
+    return blocks
+
+
+def test_synthetic_bam_roundtrip_and_ratio(engine, oracle):
+    plain, ref_stream = synth.bam_bgzf(4 << 20, level=6)
+    comp = engine.bgzf_deflate_host(plain, level=6)
+    blocks = check_stream(comp, plain, oracle)
+    assert len(blocks) == (len(plain) + 0xFF00 - 1) // 0xFF00 + 1
+    ref_len = len(synth.bgzf_compress(plain, level=6))
+    assert len(comp) <= 1.08 * ref_len, (len(comp), ref_len)     # within 8 % of zlib level 6
+    # and back through the GPU inflate kernel
+    got, st = engine.bgzf_inflate_host(comp)
+    assert got == plain and (st == 0).all()
+
+
+def test_block_cuts_like_bam_write1(engine, oracle):
+    data, starts, hdr_len = synth.bam_stream(1 << 20)
+    cuts = synth.cut_blocks(len(data), starts, hdr_len)
+    comp = engine.bgzf_deflate_host(data, level=6, cuts=cuts)
+    blocks = check_stream(comp, data, oracle)
+    assert [b[2] for b in blocks[:-1]] == np.diff(cuts).tolist()
+
+
+@pytest.mark.parametrize("name", ["fastq", "zeros", "random", "text", "short", "one", "period3", "max_block"])
+def test_data_shapes(engine, oracle, name):
+    rng = np.random.default_rng(11)
+    data = {"fastq": synth.fastq(300_000), "zeros": bytes(200_000),
+            "random": rng.integers(0, 256, 150_000, dtype=np.uint8).tobytes(),
+            "text": b"the quick brown fox jumps over the lazy dog\n" * 5000, "short": b"abc", "one": b"x",
+            "period3": b"xyz" * 40000, "max_block": rng.integers(0, 3, 0xFF00, dtype=np.uint8).tobytes()}[name]
+    comp = engine.bgzf_deflate_host(data, level=6)
+    blocks = check_stream(comp, data, oracle)
+    if name == "random":                                          # incompressible -> stored blocks (bgzf.c:652-667)
+        off, clen, isize = blocks[0]
+        assert comp[off + 18] == 1 and clen == isize + 31
+    if name in ("zeros", "text", "period3"):
+        assert len(comp) < len(data) / 50
+
+
+def test_empty_input_and_level0(engine, oracle):
+    assert engine.bgzf_deflate_host(b"", level=6) == synth.BGZF_EOF
+    assert engine.bgzf_deflate_host(b"", level=6, add_eof=False) == b""
+    data = synth.fastq(100_000)
+    comp = engine.bgzf_deflate_host(data, level=0)
+    check_stream(comp, data, oracle)
+    assert comp == synth.bgzf_compress(data, level=0)             # stored blocks are fully determined
+
+
+def test_many_ragged_blocks(engine, oracle):
+    rng = np.random.default_rng(3)
+    data = synth.fastq(400_000)
+    sizes = []
+    left = len(data)
+    while left:
+        s = int(min(left, rng.integers(0, 3000)))
+        sizes.append(s); left -= s
+    cuts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    comp = engine.bgzf_deflate_host(data, level=6, cuts=cuts)
+    blocks = refutil.split_blocks(comp)
+    assert [b[2] for b in blocks[:-1]] == sizes                   # zero-length pieces become EOF-marker blocks
+    assert gzip.decompress(comp) == data
+    n, got = oracle.decompress(comp)
+    assert got == data

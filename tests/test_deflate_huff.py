@@ -1,0 +1,119 @@
+"""CPU tests of the serial part of the GPU deflate encoder (htslib_amd/csrc/deflate_huff.h, compiled
+for the host): length-limited Huffman code lengths, canonical codes, RFC 1951 dynamic header."""
+import ctypes as C
+import heapq
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import refutil
+
+ROOT = refutil.ROOT
+
+
+@pytest.fixture(scope="module")
+def hh():
+    so = os.path.join(ROOT, "tests", "native", "libhuffhost.so")
+    src = os.path.join(ROOT, "tests", "native", "huff_host.cpp")
+    hdr = os.path.join(ROOT, "htslib_amd", "csrc", "deflate_huff.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "htslib_amd", "csrc"), src, "-o", so], check=True)
+    L = C.CDLL(so)
+    L.hh_encode_tokens.restype = C.c_long
+    L.hh_encode_tokens.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long]
+    L.hh_build_lengths.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.hh_len_symbol.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hh_dist_symbol.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    return L
+
+
+def optimal_cost(freq):
+    h = [(f, i) for i, f in enumerate(freq) if f]
+    if len(h) < 2:
+        return sum(freq)
+    heapq.heapify(h)
+    cost = 0
+    while len(h) > 1:
+        a = heapq.heappop(h); b = heapq.heappop(h)
+        cost += a[0] + b[0]
+        heapq.heappush(h, (a[0] + b[0], -1))
+    return cost
+
+
+def lengths(hh, freq, maxbits):
+    f = np.asarray(freq, dtype=np.uint32)
+    out = np.zeros(len(f), dtype=np.uint8)
+    hh.hh_build_lengths(f.ctypes.data, len(f), maxbits, out.ctypes.data)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_lengths_are_complete_limited_and_optimal_when_unconstrained(hh, seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([19, 30, 286]))
+    kind = seed % 4
+    if kind == 0: freq = rng.integers(0, 1000, n)
+    elif kind == 1: freq = (rng.pareto(0.7, n) * 10).astype(np.int64)           # heavy tail -> deep trees
+    elif kind == 2: freq = np.where(rng.random(n) < 0.1, rng.integers(1, 50, n), 0)
+    else: freq = np.array([int(1.6 ** i) for i in range(n)]) % (1 << 31)         # fibonacci-like: needs limiting
+    freq = np.asarray(freq, dtype=np.int64)
+    maxbits = 7 if n == 19 else 15
+    ln = lengths(hh, freq, maxbits)
+    used = freq > 0
+    assert ln.max() <= maxbits
+    if used.sum() >= 2:
+        assert (ln[used] > 0).all() and (ln[~used] == 0).all()
+        assert sum(2.0 ** -int(l) for l in ln if l) == 1.0                       # complete code
+        cost = int((freq * ln).sum())
+        opt = optimal_cost(freq.tolist())
+        assert cost >= opt
+        unl = lengths(hh, freq, 30)
+        if unl.max() <= maxbits:
+            assert cost == opt
+        else:
+            assert cost <= opt * 1.05 + 64
+    else:
+        assert sum(2.0 ** -int(l) for l in ln if l) == 1.0                       # two 1-bit codes
+
+
+def test_symbol_mapping_matches_rfc1951_tables(hh):
+    lbase = [3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258]
+    lext = [0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0]
+    dbase = [1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577]
+    dext = [0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13]
+    s, xb, xv = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    for ln in range(3, 259):
+        hh.hh_len_symbol(ln, C.byref(s), C.byref(xb), C.byref(xv))
+        k = max(i for i in range(29) if lbase[i] <= ln) if ln != 258 else 28
+        assert (s.value, xb.value, xv.value) == (k, lext[k], ln - lbase[k])
+    for d in list(range(1, 2000)) + [4096, 4097, 8192, 16384, 24576, 24577, 32767, 32768]:
+        hh.hh_dist_symbol(d, C.byref(s), C.byref(xb), C.byref(xv))
+        k = max(i for i in range(30) if dbase[i] <= d)
+        assert (s.value, xb.value, xv.value) == (k, dext[k], d - dbase[k])
+
+
+@pytest.mark.parametrize("case", ["text", "binary", "one_symbol", "empty", "runs"])
+def test_dynamic_header_and_codes_decode_with_zlib(hh, oracle, case):
+    rng = np.random.default_rng(5)
+    data = {"text": b"GATTACA quality IIIIFFFF:::: " * 400, "binary": rng.integers(0, 256, 20000, dtype=np.uint8).tobytes(),
+            "one_symbol": b"A" * 5000, "empty": b"", "runs": bytes([7] * 3000 + [9] * 10 + list(range(256)) * 3)}[case]
+    tok = np.frombuffer(data, dtype=np.uint8).astype(np.uint32)
+    if case in ("text", "runs") and len(data) > 600:            # sprinkle real matches over repeated text
+        toks, i = [], 0
+        while i < len(data):
+            per = 29 if case == "text" else 1
+            if i >= 300 and i + 40 < len(data) and data[i:i + 40] == data[i - per:i - per + 40] and rng.random() < 0.5:
+                ln = int(rng.integers(3, 41)); toks.append(0x80000000 | ((ln - 3) << 16) | (per - 1)); i += ln
+            else:
+                toks.append(data[i]); i += 1
+        tok = np.array(toks, dtype=np.uint32)
+    out = np.zeros(len(data) * 2 + 1024, dtype=np.uint8)
+    n = hh.hh_encode_tokens(tok.ctypes.data, len(tok), out.ctypes.data, len(out))
+    assert n > 0
+    raw = out[:n].tobytes()
+    assert zlib.decompress(raw, -15) == data
+    rc, got, used = oracle.inflate_raw(raw, len(data) + 16)
+    assert rc == 0 and got == data
