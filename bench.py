@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--gib", type=float, default=10.0, help="plain GiB of synthetic BAM per GPU")
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--workers", type=int, default=0, help="host processes for workload preparation")
+    ap.add_argument("--op", choices=["inflate", "deflate"], default="inflate",
+                    help="inflate = BASELINE configs[1] (default, the headline); deflate = configs[2]")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -156,6 +158,10 @@ def main():
     d_status = torch.full((nblocks,), 77, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
+
+    if args.op == "deflate":
+        return bench_deflate(args, eng, comp, desc, total_u, d_comp, d_desc, d_out, d_status, dev, rank, world,
+                             ncores, t_prep, seed)
 
     def step():
         eng.bgzf_inflate_dev(d_comp.data_ptr(), comp_len, d_desc.data_ptr(), nblocks, d_out.data_ptr(), total_u,
@@ -236,6 +242,125 @@ def main():
             cb = cpu_baseline(sample, plen, ncores)
             if cb:
                 out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(2)
+
+
+def bench_deflate(args, eng, comp, desc, total_u, d_comp, d_desc, d_plain, d_status, dev, rank, world, ncores,
+                  t_prep, seed):
+    """BASELINE configs[2]: BGZF deflate level 6 of the same BAM; the plain image is produced on the
+    device by the inflate kernel, re-cut into the same blocks, compressed, then verified by inflating
+    the GPU-written stream again and comparing CRCs/bytes."""
+    import torch
+    import torch.distributed as dist
+    from htslib_amd import _native as nat
+    stream = torch.cuda.current_stream().cuda_stream
+    nblocks = len(desc)
+    eng.bgzf_inflate_dev(d_comp.data_ptr(), len(comp), d_desc.data_ptr(), nblocks, d_plain.data_ptr(), total_u,
+                         d_status.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert int((d_status != 0).sum()) == 0
+    ddesc = desc.copy()
+    ddesc["coff"] = np.arange(nblocks, dtype=np.uint64) * 65536
+    d_ddesc = torch.from_numpy(ddesc.view(np.uint8).reshape(-1).copy()).to(dev)
+    d_slots = torch.empty(nblocks * 65536 + 256, dtype=torch.uint8, device=dev)
+    d_clen = torch.zeros(nblocks, dtype=torch.int32, device=dev)
+
+    def step():
+        nat.check(nat.lib.hg_bgzf_deflate_dev(eng._h, d_plain.data_ptr(), d_ddesc.data_ptr(), nblocks, args.level,
+                                              d_slots.data_ptr(), d_clen.data_ptr(), stream), "deflate")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(); step(); b.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    # verify: pack, inflate the GPU-written stream on the GPU, compare with the plain image
+    d_packed = torch.empty(nblocks * 65536 + 256, dtype=torch.uint8, device=dev)
+    d_poff = torch.zeros(nblocks + 1, dtype=torch.int64, device=dev)
+    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+    nat.check(nat.lib.hg_bgzf_pack_dev(eng._h, d_slots.data_ptr(), d_ddesc.data_ptr(), d_clen.data_ptr(), nblocks,
+                                       d_packed.data_ptr(), d_packed.numel(), d_poff.data_ptr(), d_total.data_ptr(), 0,
+                                       stream), "pack")
+    torch.cuda.synchronize()
+    comp_len = int(d_total.item())
+    rdesc = desc.copy()
+    rdesc["coff"] = d_poff[:nblocks].cpu().numpy().astype(np.uint64)
+    rdesc["clen"] = d_clen.cpu().numpy().astype(np.uint32)
+    d_rdesc = torch.from_numpy(rdesc.view(np.uint8).reshape(-1).copy()).to(dev)
+    d_back = torch.empty(total_u + 256, dtype=torch.uint8, device=dev)
+    st2 = torch.full((nblocks,), 77, dtype=torch.int32, device=dev)
+    eng.bgzf_inflate_dev(d_packed.data_ptr(), comp_len, d_rdesc.data_ptr(), nblocks, d_back.data_ptr(), total_u,
+                         st2.data_ptr(), stream)
+    torch.cuda.synchronize()
+    ok = int((st2 != 0).sum()) == 0 and bool(torch.equal(d_back[:total_u], d_plain[:total_u]))
+    # a slice of the GPU-written stream must also decode with the REAL reference when it is present
+    ref_ok = None
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_bgzip_ld")
+    if rank == 0 and os.path.exists(exe):
+        cut = min(nblocks, 2000)
+        end = int(rdesc["coff"][cut - 1] + rdesc["clen"][cut - 1])
+        blob = d_packed[:end].cpu().numpy().tobytes()
+        want = d_plain[:int(desc["uoff"][cut - 1] + desc["ulen"][cut - 1])].cpu().numpy().tobytes()
+        p = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"htsgpu_defl_{os.getpid()}.gz")
+        open(p, "wb").write(blob)
+        r = subprocess.run([exe, "-d", "-c", p], capture_output=True)
+        os.unlink(p)
+        ref_ok = r.returncode == 0 and r.stdout == want
+        ok = ok and ref_ok
+    sum_u, sum_c = float(total_u), float(comp_len)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([sum_u, sum_c, float(0 if ok else 1)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot)
+        sum_u, sum_c, ok = float(tot[0]), float(tot[1]), int(tot[2]) == 0
+    if rank == 0:
+        value = sum_u * args.steps / elapsed / 1e9
+        alg = float(total_u + comp_len)
+        out = {"metric": "BGZF deflate throughput, uncompressed GB/s (encode, HBM-resident)", "value": round(value, 3),
+               "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": f"BGZF deflate (level {args.level}) of a {args.gib:g} GiB synthetic BAM per GPU, "
+                                      "blocks cut as bam_write1/bgzf_flush_try would", "blocks_per_gpu": nblocks,
+                          "plain_bytes_per_gpu": int(total_u), "compressed_bytes_per_gpu": int(comp_len),
+                          "ratio": round(total_u / comp_len, 3), "zlib6_ratio": round(total_u / len(comp), 3),
+                          "size_vs_zlib6": round(comp_len / len(comp), 4), "verified": bool(ok),
+                          "decodes_with_reference_htslib": ref_ok},
+               "roofline": {"bound": "hbm", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                            "kernel": "hgd::bgzf_deflate_kernel", "kernel_ms": round(k_ms, 3),
+                            "algorithmic_bytes_per_launch": int(alg)}}
+        if world == 1 and not args.no_cpu_baseline and os.path.exists(exe):
+            lim = min(int(total_u), 1 << 30)
+            sample = d_plain[:lim].cpu().numpy().tobytes()
+            p = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"htsgpu_defl_in_{os.getpid()}")
+            open(p, "wb").write(sample)
+            best = None
+            for _ in range(2):
+                t = time.perf_counter()
+                with open(os.devnull, "wb") as dn:
+                    r = subprocess.run([exe, "-c", "-l", str(args.level), "-@", str(ncores), p], stdout=dn)
+                best = min(best or 1e9, time.perf_counter() - t)
+            os.unlink(p)
+            out["cpu_baseline"] = {"value": round(lim / best / 1e9, 3), "unit": "GB/s", "cores": ncores, "kind": "reference",
+                                   "sample": f"oracle/_ref/ref_bgzip_ld -l{args.level} -@{ncores} (htslib bgzf.c + libdeflate 1.8) "
+                                             f"on {lim / 2**30:.2f} GiB of the same BAM from /dev/shm, best of 2"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

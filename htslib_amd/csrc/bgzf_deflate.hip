@@ -36,6 +36,15 @@
 
 namespace hgd {
 
+#ifdef HG_PROFILE
+__device__ unsigned long long g_dprof[16];   // 0 total, 1 stage+crc, 2 match+parse, 3 huffman, 4 emit, 5 blocks
+#define HD_T0(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#define HD_TACC(slot, var) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); dacc[slot] += n_ - var; var = n_; } while (0)
+#else
+#define HD_T0(var) do { } while (0)
+#define HD_TACC(slot, var) do { } while (0)
+#endif
+
 #ifndef HG_DEF_HB
 #define HG_DEF_HB 9
 #endif
@@ -43,6 +52,7 @@ constexpr int WG = 256;
 constexpr int HB = HG_DEF_HB;                 // hash buckets = 2^HB
 constexpr int WAYS = 8;                        // most recent positions kept per bucket
 constexpr uint32_t MAX_IN = 0xff00u;           // BGZF_BLOCK_SIZE (htslib/bgzf.h:50)
+constexpr uint32_t LOCKSTEP = 32u;            // bytes over which all candidates are extended together
 constexpr uint32_t TOO_FAR = 4096u;            // a 3-byte match this far away costs more than 3 literals
 
 struct Huff {                                  // overlays the hash table once matching is done
@@ -56,6 +66,10 @@ struct Huff {                                  // overlays the hash table once m
     uint8_t cl_sym[320];
     uint8_t cl_ext[320];
     uint8_t hdr[328];
+    uint32_t work2[32];
+    uint16_t order2[32];
+    uint32_t cntA[34], cntB[34];
+    uint32_t nxtA[16], nxtB[16];
 };
 
 struct Lds {
@@ -204,6 +218,10 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
             if (tid == 0) clen_out[b] = 28;
             continue;
         }
+#ifdef HG_PROFILE
+        unsigned long long dacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+        HD_T0(tp); HD_T0(tb);
         // ---- stage the block in LDS (coalesced 16-byte loads) ----------------------------
         for (uint32_t i = (uint32_t)tid * 16u; i < n + 16u; i += WG * 16u) {
             uint4 w = {0, 0, 0, 0};
@@ -225,11 +243,13 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
         __syncthreads();
         const uint32_t crc = wg_crc32(S, n, tid);          // valid in thread 0
 
+        HD_TACC(1, tp);
         uint32_t ntok = 0;
         if (level != 0) {
             // ---- match finding + lazy parse, 256 positions per step -----------------------
             uint32_t carry = 0;                            // chunk-relative position of the next token
             for (uint32_t c0 = 0; c0 < n; c0 += WG) {
+                HD_T0(tq);
                 const uint32_t p = c0 + (uint32_t)tid;
                 uint32_t best = 0, bd = 0, h = 0;
                 const bool hashable = p + 4u <= n;
@@ -239,24 +259,82 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                     h = hash4(cur);
                     const uint4 row = *(const uint4 *)&S.u.tab[h * WAYS];
                     const uint32_t cw[4] = {row.x, row.y, row.z, row.w};
+                    // candidates 0..7 from the table, candidate 8 = distance 1 (runs are never in this
+                    // chunk's table).  All are advanced in LOCKSTEP, 4 bytes per step, so that a step
+                    // costs one LDS round trip for every candidate together instead of one each.
+                    uint32_t cand[WAYS + 1], len[WAYS + 1], alive = 0;
 #pragma unroll
                     for (int w = 0; w < WAYS; w++) {
-                        const uint32_t cand = (cw[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
-                        if (cand != 0xffffu && p - cand <= 32768u && load4(S.in32, cand) == cur) {   // 32 KiB window
-                            const uint32_t l = 4u + match_len(S.in32, cand + 4u, p + 4u, maxl - 4u);
-                            const uint32_t d = p - cand;
-                            if (l > best || (l == best && d < bd)) { best = l; bd = d; }
+                        const uint32_t c = (cw[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+                        const bool ok = c != 0xffffu && p - c <= 32768u;              // 32 KiB window
+                        cand[w] = ok ? c : 0u;
+                        if (ok) alive |= 1u << w;
+                    }
+                    cand[WAYS] = p >= 1u ? p - 1u : 0u;
+                    if (p >= 1u) alive |= 1u << WAYS;
+                    uint32_t first[WAYS + 1];
+#pragma unroll
+                    for (int w = 0; w <= WAYS; w++) first[w] = load4(S.in32, cand[w]);
+#pragma unroll
+                    for (int w = 0; w <= WAYS; w++) {
+                        const uint32_t x = first[w] ^ cur;
+                        len[w] = 0;
+                        if ((alive >> w) & 1u) {
+                            if (x) { len[w] = (uint32_t)__builtin_ctz(x) >> 3; alive &= ~(1u << w); }
+                            else len[w] = 4;
                         }
                     }
-                    if (p >= 1u) {                          // distance 1 (runs) is never in the table of this chunk
-                        const uint32_t l = match_len(S.in32, p - 1u, p, maxl);
-                        if (l > best) { best = l; bd = 1; }
+                    // lockstep phase: all candidates together, up to LOCKSTEP bytes
+                    uint32_t off = 4;
+                    while (alive != 0u && off < maxl && off < LOCKSTEP) {
+                        const uint32_t own = load4(S.in32, p + off);
+                        uint32_t nxt[WAYS + 1];
+#pragma unroll
+                        for (int w = 0; w <= WAYS; w++) nxt[w] = load4(S.in32, ((alive >> w) & 1u) ? cand[w] + off : 0u);
+#pragma unroll
+                        for (int w = 0; w <= WAYS; w++) {
+                            if ((alive >> w) & 1u) {
+                                const uint32_t x = nxt[w] ^ own;
+                                if (x) { len[w] = off + ((uint32_t)__builtin_ctz(x) >> 3); alive &= ~(1u << w); }
+                                else len[w] = off + 4;
+                            }
+                        }
+                        off += 4;
+                    }
+                    // long-match phase: only the nearest candidate that is still going is extended
+                    // (8 bytes per step); the others keep the LOCKSTEP bytes they have proven.
+                    if (alive != 0u && off < maxl) {
+                        uint32_t bw = 0, bdist = 0xffffffffu;
+#pragma unroll
+                        for (int w = 0; w <= WAYS; w++)
+                            if (((alive >> w) & 1u) && p - cand[w] < bdist) { bdist = p - cand[w]; bw = (uint32_t)w; }
+                        uint32_t c = 0;
+#pragma unroll
+                        for (int w = 0; w <= WAYS; w++) c = bw == (uint32_t)w ? cand[w] : c;
+                        uint32_t l = off;
+                        while (l < maxl) {
+                            const uint32_t x0 = load4(S.in32, c + l) ^ load4(S.in32, p + l);
+                            const uint32_t x1 = load4(S.in32, c + l + 4) ^ load4(S.in32, p + l + 4);
+                            if (x0) { l += (uint32_t)__builtin_ctz(x0) >> 3; break; }
+                            if (x1) { l += 4u + ((uint32_t)__builtin_ctz(x1) >> 3); break; }
+                            l += 8;
+                        }
+#pragma unroll
+                        for (int w = 0; w <= WAYS; w++) len[w] = bw == (uint32_t)w ? l : len[w];
+                    }
+#pragma unroll
+                    for (int w = 0; w <= WAYS; w++) {
+                        const uint32_t l = len[w] < maxl ? len[w] : maxl;
+                        const uint32_t d = p - cand[w];
+                        if (l >= 3u && (l > best || (l == best && d < bd))) { best = l; bd = d; }
                     }
                     if (best < 3u || (best == 3u && bd > TOO_FAR)) best = 0;
                 }
                 S.mlen[tid] = (uint16_t)best;
                 S.mdist[tid] = (uint16_t)bd;
+                HD_TACC(6, tq);
                 __syncthreads();
+                HD_TACC(7, tq);
                 if (hashable) {                            // publish this chunk's positions
                     const uint32_t sh = (h & 3u) * 8u;
                     const uint32_t old = atomicAdd(&S.cnt32[h >> 2], 1u << sh);
@@ -288,6 +366,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 } else if (tid == 0) {
                     S.carry_next = carry - WG;
                 }
+                HD_TACC(8, tq);
                 // ---- compact the chosen tokens, in order -----------------------------------
                 const unsigned long long bal = __ballot(marked);
                 if (lane == 0) S.wsum[wave] = (uint32_t)__popcll(bal);
@@ -311,19 +390,38 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 ntok += total;
                 carry = S.carry_next;
                 __syncthreads();
+                HD_TACC(9, tq);
             }
         }
         // ---- choose the block type and build the codes -------------------------------------
         __syncthreads();
+        HD_TACC(2, tp);
         uint32_t hdr_bits = 0, dyn_bits = 0;
         if (level != 0) {
+            Huff &H = S.u.h;
+            // (the hash table is dead now: its LDS is reused for the Huffman scratch)
+            for (int i = tid; i < 288; i += WG) H.ll_len[i] = 0;
+            if (tid < 32) H.d_len[tid] = 0;
+            if (tid == 0) { S.lfreq[256] = 1; S.misc[3] = 0; S.misc[4] = 0; }
+            __syncthreads();
+            // rank-sort the used symbols by frequency: one thread per symbol
+            for (int i = tid; i < 286; i += WG) {
+                const uint32_t f = S.lfreq[i];
+                if (f) { const int r = hgdef::rank_symbol(S.lfreq, 286, i); H.order[r] = (uint16_t)i; H.work[r] = f; atomicAdd(&S.misc[3], 1u); }
+            }
+            if (tid >= 64 && tid < 94) {
+                const int i = tid - 64;
+                const uint32_t f = S.dfreq[i];
+                if (f) { const int r = hgdef::rank_symbol(S.dfreq, 30, i); H.order2[r] = (uint16_t)i; H.work2[r] = f; atomicAdd(&S.misc[4], 1u); }
+            }
+            __syncthreads();
+            // serial tails of the two trees on two different waves
+            if (tid == 0) { hgdef::finish_lengths((int)S.misc[3], 15, H.ll_len, H.order, H.work, H.cntA); hgdef::first_codes(H.ll_len, 286, H.cntA, H.nxtA); }
+            if (tid == 64) { hgdef::finish_lengths((int)S.misc[4], 15, H.d_len, H.order2, H.work2, H.cntB); hgdef::first_codes(H.d_len, 30, H.cntB, H.nxtB); }
+            __syncthreads();
+            for (int i = tid; i < 286; i += WG) H.ll_code[i] = hgdef::code_of(H.ll_len, i, H.nxtA);
+            if (tid >= 64 && tid < 94) H.d_code[tid - 64] = hgdef::code_of(H.d_len, tid - 64, H.nxtB);
             if (tid == 0) {
-                Huff &H = S.u.h;
-                S.lfreq[256] = 1;
-                hgdef::build_lengths(S.lfreq, 286, 15, H.ll_len, H.order, H.work);
-                hgdef::build_lengths(S.dfreq, 30, 15, H.d_len, H.order, H.work);
-                hgdef::assign_codes(H.ll_len, 286, H.ll_code);
-                hgdef::assign_codes(H.d_len, 30, H.d_code);
                 uint32_t hb = hgdef::write_dynamic_header(H.ll_len, H.d_len, H.hdr, H.cl_sym, H.cl_ext, H.work, H.order);
                 uint32_t bits = hb;
                 for (int s = 0; s < 286; s++) {
@@ -337,6 +435,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
             __syncthreads();
             hdr_bits = S.misc[1]; dyn_bits = S.misc[2];
         }
+        HD_TACC(3, tp);
         const uint32_t dyn_bytes = (dyn_bits + 7u) >> 3;
         const bool stored = level == 0 || dyn_bytes >= n + 5u;
         // ---- BGZF header (BSIZE patched at the end) ------------------------------------------
@@ -405,6 +504,10 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
             o8[16] = (uint8_t)(total_len - 1u); o8[17] = (uint8_t)((total_len - 1u) >> 8);
             clen_out[b] = total_len;
         }
+        HD_TACC(4, tp); HD_TACC(0, tb);
+#ifdef HG_PROFILE
+        if (tid == 0) { atomicAdd(&g_dprof[5], 1ull); for (int k = 0; k < 10; k++) if (k != 5) atomicAdd(&g_dprof[k], dacc[k]); }
+#endif
     }
 }
 
@@ -458,6 +561,14 @@ void pack_slots_kernel(const uint8_t *__restrict__ slots, const hg_bgzf_desc *__
 }
 
 }  // namespace hgd
+
+#ifdef HG_PROFILE
+extern "C" int hg_debug_get_deflate_profile(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hgd::g_dprof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hgd::g_dprof), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 namespace hg {
 

@@ -13,8 +13,11 @@
 
 #if defined(__HIPCC__)
 #define HG_HD __host__ __device__ __forceinline__
+// serial tails: real calls on the device, so that they do not bloat the kernel's register budget
+#define HG_HD_SERIAL __host__ __device__ __attribute__((noinline))
 #else
 #define HG_HD inline
+#define HG_HD_SERIAL inline
 #endif
 
 namespace hgdef {
@@ -49,32 +52,30 @@ HG_HD void min_redundancy_lengths(uint32_t *A, int n) {
     }
 }
 
-// Build length-limited canonical Huffman code lengths.
-//   freq[0..n)   symbol frequencies (may contain zeros)
-//   len[0..n)    out: code length per symbol (0 = unused), all <= maxbits
-//   order/work   scratch arrays of n entries each
-// Guarantees a complete code with at least two codes when only 0 or 1 symbols are used (so that
-// every decoder accepts the tree), like zlib does by forcing two symbols.
-HG_HD void build_lengths(const uint32_t *freq, int n, int maxbits, uint8_t *len, uint16_t *order, uint32_t *work) {
-    // rank-sort the used symbols by (freq, symbol) ascending: order[rank] = symbol
-    int used = 0;
-    for (int i = 0; i < n; i++) { len[i] = 0; if (freq[i]) used++; }
-    if (used == 0) { len[0] = 1; len[1] = 1; return; }
-    if (used == 1) {
-        int s = 0; while (!freq[s]) s++;
-        len[s] = 1; len[s == 0 ? 1 : 0] = 1;            // second, unused code keeps the set complete
-        return;
+// Rank of symbol i among the used symbols ordered by (freq, symbol) ascending.  O(n) per
+// symbol, independent per symbol: the kernel runs it with one thread per symbol.
+HG_HD int rank_symbol(const uint32_t *freq, int n, int i) {
+    int r = 0;
+    const uint32_t fi = freq[i];
+    for (int j = 0; j < n; j++) {
+        const uint32_t fj = freq[j];
+        if (fj && (fj < fi || (fj == fi && j < i))) r++;
     }
-    for (int i = 0; i < n; i++) {
-        if (!freq[i]) continue;
-        int r = 0;
-        for (int j = 0; j < n; j++)
-            if (freq[j] && (freq[j] < freq[i] || (freq[j] == freq[i] && j < i))) r++;
-        order[r] = (uint16_t)i; work[r] = freq[i];
+    return r;
+}
+
+// Serial tail of the length computation.  On entry order[r] = symbol of rank r and
+// work[r] = its frequency for r in [0, used); `cnt` is a 33-entry scratch array.
+// Writes len[sym] for the used symbols (the caller zeroed len[]).
+HG_HD_SERIAL void finish_lengths(int used, int maxbits, uint8_t *len, const uint16_t *order, uint32_t *work, uint32_t *cnt) {
+    if (used == 0) { len[0] = 1; len[1] = 1; return; }          // keep every decoder happy: a complete
+    if (used == 1) {                                             // two-code set even if <2 symbols occur
+        int s = order[0];
+        len[s] = 1; len[s == 0 ? 1 : 0] = 1;
+        return;
     }
     min_redundancy_lengths(work, used);
     // enforce the limit: count codes per length, clamp, then repair the Kraft sum
-    uint32_t cnt[33];
     for (int i = 0; i <= 32; i++) cnt[i] = 0;
     for (int i = 0; i < used; i++) cnt[work[i] > 32 ? 32 : work[i]]++;
     for (int i = maxbits + 1; i <= 32; i++) { cnt[maxbits] += cnt[i]; cnt[i] = 0; }
@@ -92,21 +93,52 @@ HG_HD void build_lengths(const uint32_t *freq, int n, int maxbits, uint8_t *len,
         for (uint32_t c = cnt[l]; c > 0; c--) len[order[idx--]] = (uint8_t)l;
 }
 
-// Canonical codes (RFC 1951 3.2.2), bit-reversed so they can be OR-ed LSB-first into the stream.
+// Build length-limited canonical Huffman code lengths (whole thing, one thread).
+//   freq[0..n)   symbol frequencies (may contain zeros)
+//   len[0..n)    out: code length per symbol (0 = unused), all <= maxbits
+//   order/work   scratch arrays of n entries each
+HG_HD void build_lengths(const uint32_t *freq, int n, int maxbits, uint8_t *len, uint16_t *order, uint32_t *work) {
+    int used = 0;
+    for (int i = 0; i < n; i++) { len[i] = 0; if (freq[i]) used++; }
+    for (int i = 0; i < n; i++) {
+        if (!freq[i]) continue;
+        int r = rank_symbol(freq, n, i);
+        order[r] = (uint16_t)i; work[r] = freq[i];
+    }
+    uint32_t cnt[33];
+    finish_lengths(used, maxbits, len, order, work, cnt);
+}
+
+HG_HD uint32_t rev16(uint32_t v) {                      // reverse the low 16 bits
+    v = ((v & 0x5555u) << 1) | ((v >> 1) & 0x5555u);
+    v = ((v & 0x3333u) << 2) | ((v >> 2) & 0x3333u);
+    v = ((v & 0x0f0fu) << 4) | ((v >> 4) & 0x0f0fu);
+    return ((v & 0x00ffu) << 8) | ((v >> 8) & 0x00ffu);
+}
+
+// First canonical code of every length (RFC 1951 3.2.2) into nxt[1..15]; cnt16 is scratch.
+HG_HD_SERIAL void first_codes(const uint8_t *len, int n, uint32_t *cnt16, uint32_t *nxt16) {
+    for (int i = 0; i < 16; i++) cnt16[i] = 0;
+    for (int i = 0; i < n; i++) cnt16[len[i]]++;
+    cnt16[0] = 0;
+    uint32_t c = 0;
+    nxt16[0] = 0;
+    for (int l = 1; l < 16; l++) { c = (c + cnt16[l - 1]) << 1; nxt16[l] = c; }
+}
+// Code of symbol i given the first codes: first + number of earlier symbols of the same length.
+// Bit-reversed so it can be OR-ed LSB-first into the stream.  Independent per symbol.
+HG_HD uint16_t code_of(const uint8_t *len, int i, const uint32_t *nxt16) {
+    const uint32_t l = len[i];
+    if (!l) return 0;
+    uint32_t k = 0;
+    for (int j = 0; j < i; j++) k += len[j] == l;
+    return (uint16_t)(rev16(nxt16[l] + k) >> (16 - l));
+}
+// Canonical codes for all symbols (one thread).
 HG_HD void assign_codes(const uint8_t *len, int n, uint16_t *code) {
     uint32_t cnt[16], nxt[16];
-    for (int i = 0; i < 16; i++) cnt[i] = 0;
-    for (int i = 0; i < n; i++) cnt[len[i]]++;
-    cnt[0] = 0;
-    uint32_t c = 0;
-    for (int l = 1; l < 16; l++) { c = (c + cnt[l - 1]) << 1; nxt[l] = c; }
-    for (int i = 0; i < n; i++) {
-        uint32_t l = len[i];
-        if (!l) { code[i] = 0; continue; }
-        uint32_t v = nxt[l]++, r = 0;
-        for (uint32_t b = 0; b < l; b++) { r = (r << 1) | (v & 1); v >>= 1; }
-        code[i] = (uint16_t)r;
-    }
+    first_codes(len, n, cnt, nxt);
+    for (int i = 0; i < n; i++) code[i] = code_of(len, i, nxt);
 }
 
 // LSB-first bit writer into a byte buffer (used for the <= ~200 byte block header only)
@@ -125,7 +157,7 @@ struct BitSink {
 // Emit BFINAL=1, BTYPE=10 and the two trees (RFC 1951 3.2.7) into `dst` (>= 320 bytes).
 // ll_len[0..286), d_len[0..30).  Returns the number of bits written.
 // scratch: cl_sym/cl_ext hold the run-length coded length sequence (<= 316 entries each).
-HG_HD uint32_t write_dynamic_header(const uint8_t *ll_len, const uint8_t *d_len, uint8_t *dst,
+HG_HD_SERIAL uint32_t write_dynamic_header(const uint8_t *ll_len, const uint8_t *d_len, uint8_t *dst,
                                     uint8_t *cl_sym, uint8_t *cl_ext, uint32_t *work, uint16_t *order) {
     int hlit = 286; while (hlit > 257 && ll_len[hlit - 1] == 0) hlit--;
     int hdist = 30; while (hdist > 1 && d_len[hdist - 1] == 0) hdist--;

@@ -46,6 +46,28 @@ int main(int argc, char **argv) {
                    pr[5], tot / pr[5], 100 * pr[1] / tot, 100 * pr[2] / tot, 100 * pr[3] / tot, 100 * pr[4] / tot);
         }
         fflush(stdout);
+        // ---- deflate the plain image that the inflate above produced --------------------------
+        auto p_def = (int (*)(hg_ctx *, const void *, const hg_bgzf_desc *, size_t, int, void *, uint32_t *, void *))dlsym(h, "hg_bgzf_deflate_dev");
+        auto p_dprof = (int (*)(unsigned long long *, int))dlsym(h, "hg_debug_get_deflate_profile");
+        if (p_def && getenv("KBENCH_DEFLATE")) {
+            std::vector<hg_bgzf_desc> dd2(desc); for (long i = 0; i < n; i++) dd2[i].coff = (uint64_t)i * 65536;
+            void *dslots, *ddd; uint32_t *dclen;
+            CK(hipMalloc(&dslots, (size_t)n * 65536 + 256)); CK(hipMalloc(&ddd, n * sizeof(hg_bgzf_desc))); CK(hipMalloc((void **)&dclen, n * 4));
+            CK(hipMemcpy(ddd, dd2.data(), n * sizeof(hg_bgzf_desc), hipMemcpyHostToDevice));
+            p_def(ctx, dout, (hg_bgzf_desc *)ddd, n, 6, dslots, dclen, s); CK(hipStreamSynchronize(s));
+            if (p_dprof) { unsigned long long pr[16]; p_dprof(pr, 1); }
+            CK(hipEventRecord(e0, s)); p_def(ctx, dout, (hg_bgzf_desc *)ddd, n, 6, dslots, dclen, s); CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            std::vector<uint32_t> cl(n); CK(hipMemcpy(cl.data(), dclen, n * 4, hipMemcpyDeviceToHost));
+            double csum = 0; for (long i = 0; i < n; i++) csum += cl[i];
+            printf("   DEFLATE: %.3f ms => %.2f GB/s, ratio %.3f (input stream ratio %.3f)\n", ms, total / 1e6 / ms, total / csum, (double)total / len);
+            if (p_dprof) { unsigned long long pr[16]; p_dprof(pr, 1); double tot = (double)pr[0];
+                printf("   deflate in-kernel time per block %.0f ticks: stage+crc %.1f%%  match+parse %.1f%%  huffman %.1f%%  emit %.1f%%\n",
+                       tot / pr[5], 100 * pr[1] / tot, 100 * pr[2] / tot, 100 * pr[3] / tot, 100 * pr[4] / tot);
+                printf("      match detail: candidates %.1f%%  barrier-wait %.1f%%  insert+parse %.1f%%  compact+hist %.1f%%\n", 100 * pr[6] / tot, 100 * pr[7] / tot, 100 * pr[8] / tot, 100 * pr[9] / tot); }
+            CK(hipFree(dslots)); CK(hipFree(ddd)); CK(hipFree(dclen));
+        }
+        fflush(stdout);
         CK(hipFree(dc)); CK(hipFree(dd)); CK(hipFree(dout)); CK(hipFree(dst)); p_fini(ctx); 
     }
     return 0;
