@@ -46,9 +46,12 @@ lib.hg_bgzf_pack_dev.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t
 lib.hg_bgzf_deflate_host.argtypes = [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_int, _vp, C.c_size_t,
                                      C.POINTER(C.c_size_t)]
 
+lib.hg_rans4x8_decode_dev.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp]
+lib.hg_rans4x8_decode_host.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp]
+
 EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info", "hg_bgzf_scan",
            "hg_bgzf_inflate_dev", "hg_bgzf_inflate_host", "hg_crc32_dev", "hg_bgzf_deflate_dev", "hg_bgzf_pack_dev",
-           "hg_bgzf_deflate_host"]
+           "hg_bgzf_deflate_host", "hg_rans4x8_decode_dev", "hg_rans4x8_decode_host"]
 
 
 class HgError(RuntimeError):
@@ -135,6 +138,28 @@ class Engine:
                                       C.byref(out_len))
         check(rc, "hg_bgzf_deflate_host")
         return out.raw[:out_len.value]
+
+    def rans4x8_decode_host(self, streams):
+        """Decode a list of CRAM 3.0 rANS 4x8 streams (bytes) -> (list of bytes, status ndarray)."""
+        import numpy as np
+        n = len(streams)
+        if n == 0:
+            return [], np.zeros(0, dtype=np.int32)
+        ins = [(C.c_char * max(len(s), 1)).from_buffer_copy(s if len(s) else b"\0") for s in streams]
+        in_ptr = (_vp * n)(*[C.addressof(b) for b in ins])
+        in_len = np.array([len(s) for s in streams], dtype=np.uint32)
+        usz = [int.from_bytes(s[5:9], "little") if len(s) >= 9 else 0 for s in streams]
+        outs = [C.create_string_buffer(max(u, 1)) for u in usz]
+        out_ptr = (_vp * n)(*[C.addressof(b) for b in outs])
+        out_cap = np.array([max(u, 1) for u in usz], dtype=np.uint32)
+        out_len = np.zeros(n, dtype=np.uint32)
+        status = np.full(n, 99, dtype=np.int32)
+        rc = lib.hg_rans4x8_decode_host(self._h, in_ptr, in_len.ctypes.data, n, out_ptr, out_cap.ctypes.data,
+                                        out_len.ctypes.data, status.ctypes.data)
+        self.last_status = status
+        if rc not in (0, -6):
+            check(rc, "hg_rans4x8_decode_host")
+        return [outs[i].raw[:int(out_len[i])] for i in range(n)], status
 
     # -- device-resident entry points (torch tensors or raw pointers) ----------
     def bgzf_inflate_dev(self, d_comp: int, comp_len: int, d_desc: int, nblocks: int, d_out: int,

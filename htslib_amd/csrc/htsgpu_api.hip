@@ -215,6 +215,56 @@ int hg_bgzf_deflate_host(hg_ctx *ctx, const uint8_t *plain, size_t len, const ui
     return rc;
 }
 
+int hg_rans4x8_decode_dev(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, size_t n, void *d_out,
+                          int32_t *d_status, uint32_t *d_scratch, void *stream) {
+    if (!ctx || (n && (!d_in || !d_desc || !d_out || !d_status || !d_scratch))) return HG_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    return hg::launch_rans4x8_decode(ctx, d_in, d_desc, n, d_out, d_status, d_scratch, (hipStream_t)stream);
+}
+
+int hg_rans4x8_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
+                           uint8_t *const *out, const uint32_t *out_cap, uint32_t *out_len, int32_t *status) {
+    if (!ctx || (n && (!in || !in_len || !out || !out_cap || !out_len))) return HG_EINVAL;
+    if (n == 0) return HG_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg_stream_desc *desc = (hg_stream_desc *)calloc(n, sizeof(hg_stream_desc));
+    int32_t *st = (int32_t *)malloc(n * sizeof(int32_t));
+    if (!desc || !st) { free(desc); free(st); return HG_ENOMEM; }
+    uint64_t ioff = 0, ooff = 0, soff = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t usz = 0;
+        if (in_len[i] >= 9) usz = (uint32_t)in[i][5] | ((uint32_t)in[i][6] << 8) | ((uint32_t)in[i][7] << 16) | ((uint32_t)in[i][8] << 24);
+        desc[i].in_off = ioff; desc[i].in_len = in_len[i]; desc[i].out_off = ooff; desc[i].out_len = usz;
+        desc[i].scratch_off = (uint32_t)soff;
+        out_len[i] = usz;
+        ioff += ((uint64_t)in_len[i] + 15u) & ~15ull;
+        ooff += ((uint64_t)usz + 15u) & ~15ull;
+        soff += HG_RANS4X8_SCRATCH_WORDS(in_len[i]);
+        if (usz > out_cap[i] || soff > 0xffffffffull) { free(desc); free(st); return HG_EINVAL; }
+    }
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, ioff + 64)) || (rc = ensure_scratch(ctx, 1, ooff + 64)) ||
+        (rc = ensure_scratch(ctx, 2, n * sizeof(hg_stream_desc))) || (rc = ensure_scratch(ctx, 3, n * 4)) ||
+        (rc = ensure_scratch(ctx, 6, soff * 4 + 64))) { free(desc); free(st); return rc; }
+    hipStream_t s = nullptr;
+    bool ok = true;
+    for (size_t i = 0; i < n && ok; i++)
+        if (in_len[i]) ok = hipMemcpyAsync((uint8_t *)ctx->d_scratch[0] + desc[i].in_off, in[i], in_len[i], hipMemcpyHostToDevice, s) == hipSuccess;
+    ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc, n * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess;
+    rc = ok ? hg::launch_rans4x8_decode(ctx, ctx->d_scratch[0], (const hg_stream_desc *)ctx->d_scratch[2], n, ctx->d_scratch[1],
+                                        (int32_t *)ctx->d_scratch[3], (uint32_t *)ctx->d_scratch[6], s) : HG_ELAUNCH;
+    if (rc == HG_OK) {
+        ok = hipMemcpyAsync(st, ctx->d_scratch[3], n * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        for (size_t i = 0; i < n && ok; i++)
+            if (out_len[i]) ok = hipMemcpy(out[i], (uint8_t *)ctx->d_scratch[1] + desc[i].out_off, out_len[i], hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok) rc = HG_ELAUNCH;
+    }
+    if (rc == HG_OK)
+        for (size_t i = 0; i < n; i++) { if (status) status[i] = st[i]; if (st[i] != 0) rc = HG_EBLOCK; }
+    free(desc); free(st);
+    return rc;
+}
+
 int hg_crc32_dev(hg_ctx *ctx, const void *d_data, const uint64_t *d_off, const uint32_t *d_len, size_t n,
                  uint32_t *d_crc, void *stream) {
     if (!ctx || (n && (!d_data || !d_off || !d_len || !d_crc))) return HG_EINVAL;

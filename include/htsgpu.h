@@ -119,6 +119,30 @@ int hg_bgzf_pack_dev(hg_ctx *ctx, const void *d_slots, const hg_bgzf_desc *d_des
 int hg_bgzf_deflate_host(hg_ctx *ctx, const uint8_t *plain, size_t len, const uint64_t *cuts, size_t ncuts,
                          int level, int add_eof, uint8_t *out, size_t out_cap, size_t *out_len);
 
+/* ---- CRAM 3.0 rANS 4x8 (replaces rans_uncompress as called by cram_uncompress_block,
+ *      cram/cram_io.c:1666-1683; CRAM block method 4) ------------------------------ */
+/* One descriptor per entropy-coded stream (= the payload of one CRAM block). */
+typedef struct hg_stream_desc {
+    uint64_t in_off;        /* byte offset of the stream in the input image              */
+    uint64_t out_off;       /* byte offset of its plaintext in the output image          */
+    uint32_t in_len;        /* compressed bytes (cram_block.comp_size)                   */
+    uint32_t out_len;       /* expected plaintext bytes (cram_block.uncomp_size)         */
+    uint32_t scratch_off;   /* offset (32-bit words) of this stream's table scratch      */
+    uint32_t reserved;
+} hg_stream_desc;
+
+/* words of table scratch a stream of in_len bytes may need (order-1 context tables) */
+#define HG_RANS4X8_SCRATCH_WORDS(in_len) (1024u + 2u * (uint32_t)(in_len))
+
+/* status[i] = 0 ok, -1 malformed stream / size mismatch (cram_uncompress_block returns -1). */
+int hg_rans4x8_decode_dev(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, size_t nstreams,
+                          void *d_out, int32_t *d_status, uint32_t *d_scratch, void *stream);
+
+/* Host convenience for n streams: in[i]/in_len[i] -> out[i] (capacity out_cap[i], actual size in
+ * out_len[i] = the size stored in the stream header).  Synchronous.  Returns 0 or HG_EBLOCK. */
+int hg_rans4x8_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
+                           uint8_t *const *out, const uint32_t *out_cap, uint32_t *out_len, int32_t *status);
+
 /* ---- CRC-32 (replaces hts_crc32, bgzf.c:557-559 / 620-622) -------------- */
 /* crc[i] = crc32(0, d_data + off[i], len[i]) for n independent buffers. */
 int hg_crc32_dev(hg_ctx *ctx, const void *d_data,

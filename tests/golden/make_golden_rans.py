@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Freeze rANS 4x8 known-answer vectors from the reference's CRAM v3.0 fixtures.
+
+htscodecs (the reference implementation of the CRAM entropy codecs) is an absent submodule, so the
+expected plaintext cannot come from running the reference.  It is derived INDEPENDENTLY of any
+rANS decoder from the fixture's .sam twin: the QS data series of a CRAM slice is the concatenation
+of the records' quality values (QUAL - 33), the RN series the read names each followed by the
+BYTE_ARRAY_STOP byte.  Blocks whose content cannot be derived that way are stored with their
+declared raw size only ("size-only" vectors).
+
+Output: tests/golden/rans4x8/<file>.<n>.bin (compressed block payload), MANIFEST.json
+(content id, order, raw size, series name, expected plaintext hex or null).
+Needs /root/reference; run in the build container.
+"""
+import json, os, struct, sys
+
+REF = "/root/reference/test"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "rans4x8")
+PAIRS = [("ce#5b_java.cram", "ce#5b.sam"), ("auxf#values_java.cram", "auxf#values.sam"),
+         ("xx#large_aux_java.cram", "xx#large_aux.sam"), ("range.cram", None)]
+
+
+def itf8(b, p):
+    v = b[p]
+    if v < 0x80: return v, p + 1
+    if v < 0xC0: return ((v & 0x3F) << 8) | b[p + 1], p + 2
+    if v < 0xE0: return ((v & 0x1F) << 16) | (b[p + 1] << 8) | b[p + 2], p + 3
+    if v < 0xF0: return ((v & 0x0F) << 24) | (b[p + 1] << 16) | (b[p + 2] << 8) | b[p + 3], p + 4
+    return ((v & 0x0F) << 28) | (b[p + 1] << 20) | (b[p + 2] << 12) | (b[p + 3] << 4) | (b[p + 4] & 0x0F), p + 5
+
+
+def ltf8(b, p):
+    v = b[p]; n = 0
+    while n < 8 and (v & (0x80 >> n)): n += 1
+    if n == 0: return v, p + 1
+    val = v & (0xFF >> (n + 1)) if n < 8 else 0
+    for i in range(n): val = (val << 8) | b[p + 1 + i]
+    return val, p + 1 + n
+
+
+def parse_comp_header(d):
+    """-> {series: (codec, params bytes)}"""
+    p = 0
+    sz, p = itf8(d, p); p += sz                                   # preservation map
+    sz, p = itf8(d, p); end = p + sz
+    n, p = itf8(d, p)
+    enc = {}
+    for _ in range(n):
+        key = bytes(d[p:p + 2]).decode(); p += 2
+        codec, p = itf8(d, p); ln, p = itf8(d, p)
+        enc[key] = (codec, bytes(d[p:p + ln])); p += ln
+    return enc
+
+
+def containers(b):
+    p = 26
+    while p < len(b):
+        clen = struct.unpack_from("<i", b, p)[0]; p += 4
+        refid, p = itf8(b, p); start, p = itf8(b, p); span, p = itf8(b, p); nrec, p = itf8(b, p)
+        cnt, p = ltf8(b, p); bases, p = ltf8(b, p)
+        nblk, p = itf8(b, p); nland, p = itf8(b, p)
+        for _ in range(nland): _, p = itf8(b, p)
+        p += 4
+        end = p + clen; q = p; blks = []
+        while q < end and len(blks) < nblk:
+            method, ctype = b[q], b[q + 1]; q += 2
+            cid, q = itf8(b, q); csz, q = itf8(b, q); usz, q = itf8(b, q)
+            blks.append((method, ctype, cid, csz, usz, bytes(b[q:q + csz]))); q += csz + 4
+        yield nrec, blks
+        p = end
+
+
+def sam_records(path):
+    recs = []
+    for ln in open(path):
+        if ln.startswith("@"): continue
+        f = ln.rstrip("\n").split("\t")
+        recs.append((f[0], f[10]))
+    return recs
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    man, nfile = {}, 0
+    for cram, sam in PAIRS:
+        b = open(os.path.join(REF, cram), "rb").read()
+        assert b[:4] == b"CRAM" and b[4] == 3
+        recs = sam_records(os.path.join(REF, sam)) if sam else None
+        rpos = 0
+        for nrec, blks in containers(b):
+            if nrec == 0 or not blks: continue
+            assert blks[0][1] == 1 and blks[0][0] == 0, "compression header expected raw"
+            enc = parse_comp_header(blks[0][5])
+            series_of = {}
+            for key, (codec, par) in enc.items():
+                if codec == 1: series_of[itf8(par, 0)[0]] = (key, None)             # EXTERNAL
+                elif codec == 5: series_of[itf8(par, 1)[0]] = (key, par[0])         # BYTE_ARRAY_STOP
+            mine = recs[rpos:rpos + nrec] if recs else None
+            rpos += nrec
+            for (method, ctype, cid, csz, usz, data) in blks:
+                if method != 4 or ctype != 4 or csz == 0: continue
+                key, stop = series_of.get(cid, ("??", None))
+                exp = None
+                if mine is not None:
+                    if key == "QS": exp = b"".join(bytes(c - 33 for c in q.encode()) for _, q in mine if q != "*")
+                    elif key == "RN" and stop is not None: exp = b"".join(nm.encode() + bytes([stop]) for nm, _ in mine)
+                    if exp is not None and len(exp) != usz: exp = None
+                name = f"{cram.replace('#', '_')}.{nfile}.bin"; nfile += 1
+                open(os.path.join(OUT, name), "wb").write(data)
+                man[name] = {"source": "test/" + cram, "content_id": cid, "series": key, "order": data[0], "csize": csz,
+                             "usize": usz, "expected_hex": exp.hex() if exp is not None else None}
+    json.dump(man, open(os.path.join(OUT, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
+    pinned = sum(1 for v in man.values() if v["expected_hex"] is not None)
+    print(len(man), "rANS 4x8 blocks,", pinned, "with SAM-derived plaintext;", "orders", sorted({v['order'] for v in man.values()}))
+
+
+if __name__ == "__main__":
+    main()

@@ -101,3 +101,38 @@ def wrap_payload(payload: bytes, data: bytes, crc: int | None = None, isize: int
     hdr = bytes.fromhex("1f8b08040000000000ff060042430200")
     return b"".join([hdr, struct.pack("<H", len(payload) + 25), payload,
                      struct.pack("<II", zlib.crc32(data) if crc is None else crc, len(data) if isize is None else isize)])
+
+
+# ------------------------------------------------------------------ rANS 4x8 (CRAM 3.0)
+RANS_GOLDEN = os.path.join(ROOT, "tests", "golden", "rans4x8")
+
+
+class Rans4x8Oracle:
+    def __init__(self):
+        L = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        L.orc_rans4x8_uncompress.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.orc_rans4x8_compress.restype = C.c_size_t
+        L.orc_rans4x8_compress.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int]
+        L.orc_rans4x8_compress_bound.restype = C.c_size_t
+        L.orc_rans4x8_compress_bound.argtypes = [C.c_size_t]
+        self.L = L
+
+    def decode(self, b: bytes):
+        usz = int.from_bytes(b[5:9], "little") if len(b) >= 9 else 0
+        out = C.create_string_buffer(max(usz, 1))
+        n = C.c_size_t(0)
+        rc = self.L.orc_rans4x8_uncompress(b, len(b), out, usz, C.byref(n))
+        return rc, (out.raw[:n.value] if rc == 0 else b"")
+
+    def encode(self, d: bytes, order: int) -> bytes:
+        out = C.create_string_buffer(self.L.orc_rans4x8_compress_bound(len(d)))
+        n = self.L.orc_rans4x8_compress(d, len(d), out, order)
+        return out.raw[:n]
+
+
+def rans_golden_cases():
+    man = json.load(open(os.path.join(RANS_GOLDEN, "MANIFEST.json")))
+    for name in sorted(man):
+        v = man[name]
+        yield name, open(os.path.join(RANS_GOLDEN, name), "rb").read(), v["usize"], \
+            (bytes.fromhex(v["expected_hex"]) if v["expected_hex"] is not None else None), v["order"]
