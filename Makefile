@@ -7,7 +7,13 @@ HDRS    := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc) $(wildcard include/
 LIB     := htslib_amd/libhtsgpu.so
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
-all: $(LIB) oracle
+FRONT   := htslib_amd/libhts_bgzf.so
+
+all: $(LIB) $(FRONT) oracle
+
+# htslib's BGZF front-end API (bgzf_open/read/write/...) over the engine: host C++ only
+$(FRONT): $(CSRC)/bgzf_front.cpp include/hts_bgzf_gpu.h include/htsgpu.h $(LIB)
+	g++ -O2 -std=c++17 -fPIC -shared -Wall -Iinclude $(CSRC)/bgzf_front.cpp -o $@ -Lhtslib_amd -lhtsgpu -Wl,-rpath,'$$ORIGIN'
 
 $(LIB): $(HIPSRC) $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared $(HIPSRC) -o $@
