@@ -197,16 +197,8 @@ def main():
     bytes_ok = got0 == plain0
     ok = nbad == 0 and bytes_ok
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(total_u), float(comp_len), float(0 if ok else 1)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        sum_u, sum_c, bad_ranks = float(tot[0]), float(tot[1]), int(tot[2])
-        ok = bad_ranks == 0
-    else:
-        sum_u, sum_c = float(total_u), float(comp_len)
+    from htslib_amd.bgzf import reduce_timing
+    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(total_u), float(comp_len), ok, world, dev)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -321,14 +313,8 @@ def bench_deflate(args, eng, comp, desc, total_u, d_comp, d_desc, d_plain, d_sta
         os.unlink(p)
         ref_ok = r.returncode == 0 and r.stdout == want
         ok = ok and ref_ok
-    sum_u, sum_c = float(total_u), float(comp_len)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([sum_u, sum_c, float(0 if ok else 1)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot)
-        sum_u, sum_c, ok = float(tot[0]), float(tot[1]), int(tot[2]) == 0
+    from htslib_amd.bgzf import reduce_timing
+    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(total_u), float(comp_len), ok, world, dev)
     if rank == 0:
         value = sum_u * args.steps / elapsed / 1e9
         alg = float(total_u + comp_len)

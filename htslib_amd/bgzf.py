@@ -12,6 +12,37 @@ import numpy as np
 from . import _native as nat
 
 
+def shard_blocks(desc, world: int):
+    """Static split of a block list over `world` GPUs: contiguous ranges of blocks,
+    balanced by uncompressed bytes, no exchange.  Returns [(first, last_exclusive)] per rank."""
+    n = len(desc)
+    if world <= 1 or n == 0:
+        return [(0, n)] + [(n, n)] * (max(world, 1) - 1)
+    csum = np.cumsum(desc["ulen"].astype(np.int64))
+    total = int(csum[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r // world
+        cuts.append(int(np.searchsorted(csum, target, side="left")) + (0 if target == 0 else 1))
+    cuts.append(n)
+    cuts = np.maximum.accumulate(np.minimum(cuts, n)).tolist()
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def reduce_timing(elapsed: float, plain_bytes: float, comp_bytes: float, ok: bool, world: int, device=None):
+    """What bench.py reports for N ranks: MAX of the per-rank elapsed time, SUM of bytes, AND of
+    the verification flags.  Uses torch.distributed when world > 1 (RCCL on GPUs, gloo in tests)."""
+    if world <= 1:
+        return elapsed, plain_bytes, comp_bytes, ok
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tot = torch.tensor([plain_bytes, comp_bytes, 0.0 if ok else 1.0], dtype=torch.float64, device=device)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    return float(t[0]), float(tot[0]), float(tot[1]), int(tot[2]) == 0
+
+
 class DeviceStream:
     """A BGZF stream resident in HBM together with its block descriptors."""
 

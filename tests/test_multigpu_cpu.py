@@ -1,0 +1,62 @@
+"""N>1 path on CPU (gloo, world_size 2): the static block split and the cross-rank reduction that
+bench.py uses.  The data path itself has no collective (blocks are independent)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from htslib_amd import synth
+
+
+def test_static_split_is_contiguous_complete_and_balanced(built):
+    from htslib_amd import _native as nat
+    from htslib_amd.bgzf import shard_blocks
+    _, bg = synth.bam_bgzf(6 << 20)
+    desc, total = nat.bgzf_scan(bg)
+    for world in (1, 2, 3, 4, 8):
+        parts = shard_blocks(desc, world)
+        assert len(parts) == world and parts[0][0] == 0 and parts[-1][1] == len(desc)
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+        sizes = [int(desc["ulen"][a:b].sum()) for a, b in parts]
+        assert sum(sizes) == total
+        assert max(sizes) - min(sizes) <= 2 * 0xFF00 + total // 1000          # within a couple of blocks
+    assert shard_blocks(desc[:0], 4) == [(0, 0)] * 4
+    assert shard_blocks(desc[:1], 2)[0][1] + shard_blocks(desc[:1], 2)[1][1] >= 1
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from htslib_amd.bgzf import reduce_timing
+    import bench
+    # every rank prepares its OWN shard deterministically (weak scaling: different seeds)
+    seed = 0x5EED0001 + 1000003 * rank
+    comp = bench.prepare(seed, 1 << 20, 6, 1, None)
+    again = bench.prepare(seed, 1 << 20, 6, 1, None)
+    elapsed = 0.010 * (rank + 1)
+    out = reduce_timing(elapsed, float(1 << 20), float(len(comp)), comp == again, world)
+    dist.barrier()
+    q.put((rank, out, len(comp)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_reduction_over_gloo(built):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, o0, c0), (r1, o1, c1) = res
+    assert o0 == o1                                            # every rank sees the same reduced values
+    elapsed, sum_u, sum_c, ok = o0
+    assert elapsed == pytest.approx(0.020) and sum_u == 2 * (1 << 20) and sum_c == c0 + c1 and ok
+    assert c0 != c1                                            # different shards, not replicas of one
