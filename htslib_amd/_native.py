@@ -49,9 +49,13 @@ lib.hg_bgzf_deflate_host.argtypes = [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_
 lib.hg_rans4x8_decode_dev.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp]
 lib.hg_rans4x8_decode_host.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _vp]
 
+lib.hg_gzip_inflate_dev.argtypes = [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]
+lib.hg_cram_uncompress_blocks_host.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp]
+
 EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info", "hg_bgzf_scan",
            "hg_bgzf_inflate_dev", "hg_bgzf_inflate_host", "hg_crc32_dev", "hg_bgzf_deflate_dev", "hg_bgzf_pack_dev",
-           "hg_bgzf_deflate_host", "hg_rans4x8_decode_dev", "hg_rans4x8_decode_host"]
+           "hg_bgzf_deflate_host", "hg_rans4x8_decode_dev", "hg_rans4x8_decode_host",
+           "hg_gzip_inflate_dev", "hg_cram_uncompress_blocks_host"]
 
 
 class HgError(RuntimeError):
@@ -160,6 +164,28 @@ class Engine:
         if rc not in (0, -6):
             check(rc, "hg_rans4x8_decode_host")
         return [outs[i].raw[:int(out_len[i])] for i in range(n)], status
+
+    def cram_uncompress_blocks(self, blocks):
+        """blocks: list of (method, comp_bytes, uncomp_size) as found in CRAM block headers.
+        Returns (list of plaintext bytes or None, status ndarray) -- the batch form of
+        cram_uncompress_block (cram/cram_io.c:1576-1754)."""
+        import numpy as np
+        n = len(blocks)
+        if n == 0:
+            return [], np.zeros(0, dtype=np.int32)
+        ins = [(C.c_char * max(len(b[1]), 1)).from_buffer_copy(b[1] if len(b[1]) else b"\0") for b in blocks]
+        outs = [C.create_string_buffer(max(b[2], 1)) for b in blocks]
+        in_ptr = (_vp * n)(*[C.addressof(x) for x in ins])
+        out_ptr = (_vp * n)(*[C.addressof(x) for x in outs])
+        method = np.array([b[0] for b in blocks], dtype=np.int32)
+        in_len = np.array([len(b[1]) for b in blocks], dtype=np.uint32)
+        out_len = np.array([b[2] for b in blocks], dtype=np.uint32)
+        status = np.full(n, 99, dtype=np.int32)
+        rc = lib.hg_cram_uncompress_blocks_host(self._h, n, method.ctypes.data, in_ptr, in_len.ctypes.data, out_ptr,
+                                                out_len.ctypes.data, status.ctypes.data)
+        if rc not in (0, -6):
+            check(rc, "hg_cram_uncompress_blocks_host")
+        return [outs[i].raw[:blocks[i][2]] if status[i] == 0 else None for i in range(n)], status
 
     # -- device-resident entry points (torch tensors or raw pointers) ----------
     def bgzf_inflate_dev(self, d_comp: int, comp_len: int, d_desc: int, nblocks: int, d_out: int,

@@ -423,7 +423,9 @@ __global__ __launch_bounds__(WAVES_PER_WG * 64)
 void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
                          const hg_bgzf_desc *__restrict__ desc, uint32_t nblocks,
                          uint8_t *out, uint64_t out_cap, int32_t *status,
-                         unsigned int *ticket) {
+                         unsigned int *ticket, int mode) {
+    // mode 0: BGZF blocks (strict check_header + BSIZE);  mode 1: generic gzip members of any
+    // length (CRAM block method GZIP, zlib_mem_inflate, cram/cram_io.c:1068-1110)
     __shared__ WaveLds lds[WAVES_PER_WG];
     const int lane = lane_id();
     const int wave = (int)uni(threadIdx.x >> 6);
@@ -449,7 +451,7 @@ void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
         const uint64_t uoff = ((uint64_t)uni((uint32_t)(dsc.uoff >> 32)) << 32) | uni((uint32_t)dsc.uoff);
         const uint32_t clen = uni(dsc.clen), ulen = uni(dsc.ulen);
         int st = ST_OK;
-        if (clen < 26 || coff + clen > comp_len || uoff + ulen > out_cap) {
+        if (clen < (mode == 1 ? 18u : 26u) || coff + clen > comp_len || uoff + ulen > out_cap) {
             st = ST_HEADER;
         } else {
             BitReader br;
@@ -481,6 +483,19 @@ void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
             }
             bool hdr_ok = (h0 & 0x04ffffffu) == 0x04088b1fu && h1 == 6 && h2 == 0x4342u && h3 == 2 &&
                           h4 + 1u == clen;
+            uint32_t pay = 18u;                                  // payload offset inside the member
+            if (mode == 1) {
+                // RFC 1952 member header: ID1 ID2 CM FLG MTIME(4) XFL OS [XLEN+extra] [name] [comment] [hcrc]
+                hdr_ok = (h0 & 0x00ffffffu) == 0x00088b1fu && (h0 >> 29) == 0;
+                const uint32_t flg = h0 >> 24;
+                uint32_t q = 10;
+                if (hdr_ok && (flg & 4u)) { q += 2u + h1; }
+                if (hdr_ok && (flg & 8u)) { while (q < clen && uni(hb[q]) != 0) q++; q++; }
+                if (hdr_ok && (flg & 16u)) { while (q < clen && uni(hb[q]) != 0) q++; q++; }
+                if (hdr_ok && (flg & 2u)) q += 2;
+                if (q + 8u > clen) hdr_ok = false;
+                pay = q;
+            }
             if (!hdr_ok) {
                 st = ST_HEADER;
             } else {
@@ -494,7 +509,7 @@ void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
                 uint32_t made = 0;
                 uint8_t *o = out + uoff;
                 // payload handed to inflate = block[18 .. clen) like the reference (slen = block_length-18)
-                st = inflate_stream(S, br, skew + 18u, skew + clen, o, ulen, &made, lane);
+                st = inflate_stream(S, br, skew + pay, skew + clen, o, ulen, &made, lane);
                 HG_TRACE(1, 50 + st);
                 if (st == ST_OK && made != ulen) st = ST_SIZE;
                 if (st == ST_OK && tr[1] != ulen) st = ST_SIZE;
@@ -544,7 +559,7 @@ extern "C" int hg_debug_set_trace(void *pinned_host_words) {
 
 // ---------------------------------------------------------------- host launchers
 int launch_bgzf_inflate(hg_ctx *ctx, const void *d_comp, size_t comp_len, const hg_bgzf_desc *d_desc,
-                        size_t nblocks, void *d_out, size_t out_cap, int32_t *d_status, hipStream_t s) {
+                        size_t nblocks, void *d_out, size_t out_cap, int32_t *d_status, hipStream_t s, int mode) {
     if (nblocks == 0) return HG_OK;
     if (nblocks > 0xffffffffull) return HG_EINVAL;
     if (hipMemsetAsync(ctx->d_ticket, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
@@ -554,7 +569,7 @@ int launch_bgzf_inflate(hg_ctx *ctx, const void *d_comp, size_t comp_len, const 
     if (wgs > need) wgs = need;
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)wgs), dim3(WAVES_PER_WG * 64), 0, s,
                        (const uint8_t *)d_comp, (uint64_t)comp_len, d_desc, (uint32_t)nblocks,
-                       (uint8_t *)d_out, (uint64_t)out_cap, d_status, ctx->d_ticket);
+                       (uint8_t *)d_out, (uint64_t)out_cap, d_status, ctx->d_ticket, mode);
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
 

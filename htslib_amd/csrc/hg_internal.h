@@ -19,7 +19,7 @@ struct hg_ctx {
 
 namespace hg {
 int launch_bgzf_inflate(hg_ctx *ctx, const void *d_comp, size_t comp_len, const hg_bgzf_desc *d_desc,
-                        size_t nblocks, void *d_out, size_t out_cap, int32_t *d_status, hipStream_t s);
+                        size_t nblocks, void *d_out, size_t out_cap, int32_t *d_status, hipStream_t s, int mode = 0);
 int launch_bgzf_deflate(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_desc, size_t nblocks, int level,
                         void *d_slots, uint32_t *d_clen, hipStream_t s);
 int launch_bgzf_pack(hg_ctx *ctx, const void *d_slots, const hg_bgzf_desc *d_desc, const uint32_t *d_clen,

@@ -106,6 +106,77 @@ int hg_bgzf_inflate_dev(hg_ctx *ctx, const void *d_comp, size_t comp_len, const 
                                    (hipStream_t)stream);
 }
 
+int hg_gzip_inflate_dev(hg_ctx *ctx, const void *d_comp, size_t comp_len, const hg_bgzf_desc *d_desc, size_t n,
+                        void *d_out, size_t out_cap, int32_t *d_status, void *stream) {
+    if (!ctx || (n && (!d_comp || !d_desc || !d_status))) return HG_EINVAL;
+    if (((uintptr_t)d_comp & 3u) != 0) return HG_EINVAL;
+    return hg::launch_bgzf_inflate(ctx, d_comp, comp_len, d_desc, n, d_out, out_cap, d_status, (hipStream_t)stream, 1);
+}
+
+int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method, const uint8_t *const *in,
+                                   const uint32_t *in_len, uint8_t *const *out, const uint32_t *out_len,
+                                   int32_t *status) {
+    if (!ctx || (n && (!method || !in || !in_len || !out || !out_len || !status))) return HG_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    // partition by method
+    size_t ng = 0, nr = 0;
+    for (size_t i = 0; i < n; i++) {
+        status[i] = 0;
+        if (out_len[i] == 0 || method[i] == HG_CRAM_RAW) {            // cram_io.c:1594-1603: nothing to do
+            if (method[i] == HG_CRAM_RAW) { if (in_len[i] != out_len[i]) status[i] = -1; else if (out_len[i]) memcpy(out[i], in[i], out_len[i]); }
+        } else if (method[i] == HG_CRAM_GZIP) ng++;
+        else if (method[i] == HG_CRAM_RANS4x8) nr++;
+        else status[i] = HG_BLOCK_EUNSUPPORTED;
+    }
+    int rc = HG_OK;
+    if (nr) {
+        const uint8_t **rin = (const uint8_t **)malloc(nr * sizeof(void *));
+        uint8_t **rout = (uint8_t **)malloc(nr * sizeof(void *));
+        uint32_t *rl = (uint32_t *)malloc(nr * 4), *rc_ = (uint32_t *)malloc(nr * 4), *ro = (uint32_t *)malloc(nr * 4);
+        int32_t *rs = (int32_t *)malloc(nr * 4);
+        size_t *map = (size_t *)malloc(nr * sizeof(size_t));
+        size_t k = 0;
+        for (size_t i = 0; i < n; i++)
+            if (out_len[i] && method[i] == HG_CRAM_RANS4x8) { rin[k] = in[i]; rout[k] = out[i]; rl[k] = in_len[i]; rc_[k] = out_len[i]; map[k] = i; k++; }
+        int r = hg_rans4x8_decode_host(ctx, rin, rl, nr, rout, rc_, ro, rs);
+        if (r != HG_OK && r != HG_EBLOCK) rc = r;
+        for (k = 0; k < nr; k++) status[map[k]] = (r == HG_OK || r == HG_EBLOCK) ? ((rs[k] == 0 && ro[k] == out_len[map[k]]) ? 0 : -1) : -1;
+        free(rin); free(rout); free(rl); free(rc_); free(ro); free(rs); free(map);
+    }
+    if (ng && rc == HG_OK) {
+        hg_bgzf_desc *desc = (hg_bgzf_desc *)calloc(ng, sizeof(hg_bgzf_desc));
+        size_t *map = (size_t *)malloc(ng * sizeof(size_t));
+        int32_t *st = (int32_t *)malloc(ng * 4);
+        uint64_t ioff = 0, ooff = 0; size_t k = 0;
+        for (size_t i = 0; i < n; i++)
+            if (out_len[i] && method[i] == HG_CRAM_GZIP) {
+                desc[k].coff = ioff; desc[k].clen = in_len[i]; desc[k].uoff = ooff; desc[k].ulen = out_len[i]; map[k] = i; k++;
+                ioff += ((uint64_t)in_len[i] + 15u) & ~15ull; ooff += ((uint64_t)out_len[i] + 15u) & ~15ull;
+            }
+        if ((rc = ensure_scratch(ctx, 0, ioff + 64)) == HG_OK && (rc = ensure_scratch(ctx, 1, ooff + 64)) == HG_OK &&
+            (rc = ensure_scratch(ctx, 2, ng * sizeof(hg_bgzf_desc))) == HG_OK && (rc = ensure_scratch(ctx, 3, ng * 4)) == HG_OK) {
+            hipStream_t s = nullptr;
+            bool ok = true;
+            for (k = 0; k < ng && ok; k++) ok = hipMemcpyAsync((uint8_t *)ctx->d_scratch[0] + desc[k].coff, in[map[k]], desc[k].clen, hipMemcpyHostToDevice, s) == hipSuccess;
+            ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc, ng * sizeof(hg_bgzf_desc), hipMemcpyHostToDevice, s) == hipSuccess;
+            rc = ok ? hg::launch_bgzf_inflate(ctx, ctx->d_scratch[0], (size_t)ioff, (const hg_bgzf_desc *)ctx->d_scratch[2], ng,
+                                              ctx->d_scratch[1], (size_t)ooff, (int32_t *)ctx->d_scratch[3], s, 1) : HG_ELAUNCH;
+            if (rc == HG_OK) {
+                ok = hipMemcpyAsync(st, ctx->d_scratch[3], ng * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+                for (k = 0; k < ng && ok; k++) {
+                    status[map[k]] = st[k];
+                    if (st[k] == 0) ok = hipMemcpy(out[map[k]], (uint8_t *)ctx->d_scratch[1] + desc[k].uoff, desc[k].ulen, hipMemcpyDeviceToHost) == hipSuccess;
+                }
+                if (!ok) rc = HG_ELAUNCH;
+            }
+        }
+        free(desc); free(map); free(st);
+    }
+    if (rc != HG_OK) return rc;
+    for (size_t i = 0; i < n; i++) if (status[i] != 0) return HG_EBLOCK;
+    return HG_OK;
+}
+
 int hg_bgzf_inflate_host(hg_ctx *ctx, const uint8_t *comp, size_t comp_len, uint8_t *out, size_t out_cap,
                          size_t *out_len, int32_t *status, size_t max_status, long *first_bad_idx,
                          int *first_bad_code) {

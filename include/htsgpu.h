@@ -94,6 +94,13 @@ int hg_bgzf_inflate_host(hg_ctx *ctx,
                          int32_t *status, size_t max_status,
                          long *first_bad_idx, int *first_bad_code);
 
+/* Same kernel for generic gzip members of any length (RFC 1952; 32 KiB window, several deflate
+ * blocks): the CRAM block method GZIP path, zlib_mem_inflate (cram/cram_io.c:1068-1110, called from
+ * cram_uncompress_block :1605-1624).  desc[i]: coff/clen = the member, uoff/ulen = where its
+ * plaintext goes and the size the CRAM block header promises (checked, with ISIZE and CRC-32). */
+int hg_gzip_inflate_dev(hg_ctx *ctx, const void *d_comp, size_t comp_len, const hg_bgzf_desc *d_desc,
+                        size_t nmembers, void *d_out, size_t out_cap, int32_t *d_status, void *stream);
+
 /* ---- BGZF deflate (replaces bgzf_compress / bgzf_encode_func / bgzf_encode_level0_func,
  *      bgzf.c:561-683, 1330-1368) ------------------------------------------ */
 /* d_plain: the uncompressed image in HBM; d_desc[i].uoff/.ulen = the bytes of block i
@@ -142,6 +149,28 @@ int hg_rans4x8_decode_dev(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d
  * out_len[i] = the size stored in the stream header).  Synchronous.  Returns 0 or HG_EBLOCK. */
 int hg_rans4x8_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
                            uint8_t *const *out, const uint32_t *out_cap, uint32_t *out_len, int32_t *status);
+
+/* ---- CRAM block layer (replaces cram_uncompress_block, cram/cram_io.c:1576-1754) ------------ */
+/* on-disk method ids, htslib/cram.h:84-101 */
+#define HG_CRAM_RAW      0
+#define HG_CRAM_GZIP     1
+#define HG_CRAM_BZIP2    2
+#define HG_CRAM_LZMA     3
+#define HG_CRAM_RANS4x8  4
+#define HG_CRAM_RANSNx16 5
+#define HG_CRAM_ARITH    6
+#define HG_CRAM_FQZ      7
+#define HG_CRAM_TOK3     8
+#define HG_BLOCK_EUNSUPPORTED (-3)   /* method not implemented by the engine (yet): caller keeps its CPU codec */
+
+/* Uncompress n CRAM blocks in one batch: block i has on-disk method method[i], compressed payload
+ * in[i] (in_len[i] = comp_size) and must produce exactly out_len[i] = uncomp_size bytes into out[i]
+ * (cram_uncompress_block's size check, cram_io.c:1611-1614).  RAW blocks are copied, GZIP and
+ * RANS4x8 blocks go to the gfx950 kernels; status[i] = 0 / -1 / -2 (CRC) / -3 (unsupported method).
+ * Synchronous; returns 0, or HG_EBLOCK if any status is non-zero. */
+int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method, const uint8_t *const *in,
+                                   const uint32_t *in_len, uint8_t *const *out, const uint32_t *out_len,
+                                   int32_t *status);
 
 /* ---- CRC-32 (replaces hts_crc32, bgzf.c:557-559 / 620-622) -------------- */
 /* crc[i] = crc32(0, d_data + off[i], len[i]) for n independent buffers. */
