@@ -52,10 +52,13 @@ lib.hg_rans4x8_decode_host.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp,
 lib.hg_gzip_inflate_dev.argtypes = [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]
 lib.hg_cram_uncompress_blocks_host.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp]
 
+lib.hg_ransnx16_decode_host.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]
+lib.hg_ransnx16_decode_dev.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, _vp]
+
 EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info", "hg_bgzf_scan",
            "hg_bgzf_inflate_dev", "hg_bgzf_inflate_host", "hg_crc32_dev", "hg_bgzf_deflate_dev", "hg_bgzf_pack_dev",
            "hg_bgzf_deflate_host", "hg_rans4x8_decode_dev", "hg_rans4x8_decode_host",
-           "hg_gzip_inflate_dev", "hg_cram_uncompress_blocks_host"]
+           "hg_gzip_inflate_dev", "hg_cram_uncompress_blocks_host", "hg_ransnx16_decode_host", "hg_ransnx16_decode_dev"]
 
 
 class HgError(RuntimeError):

@@ -1,0 +1,314 @@
+// ransnx16.hip -- CRAM 3.1 "rANS Nx16" block decoder for MI355X (gfx950 / CDNA4).
+//
+// Replaces rans_uncompress_4x16() as called by cram_uncompress_block (reference
+// cram/cram_io.c:1697-1714; implementation = htscodecs rANS_static4x16pr.c / 32x16pr, an ABSENT
+// submodule).  Format per the hts-specs CRAM-codecs document as restated in
+// oracle/ransnx16_oracle.c -- PARITY UNPINNED (no stock-htslib stream exists in the reference to
+// check against); the GPU decoder is bit-exact with that oracle.
+//
+// Mapping: the N (4 or 32) interleaved rANS states of a stream live in N adjacent lanes (16 or 2
+// streams per wavefront); every step each lane decodes one symbol and the lanes whose state drops
+// below 2^15 pull the next 16-bit words of the SHARED stream in lane order -- a ballot and a
+// prefix popcount per step, which is exactly what the 32-way SIMD CPU decoders emulate with
+// shuffles.  Order-0 tables: 257-entry cumulative array per stream in LDS, slot -> symbol by binary
+// search.  Order-1 tables: sparse per-context (cumulative, symbol) lists in a global scratch area
+// (L1/L2 resident for quality-value alphabets).  Tables are parsed by the first lane of the group.
+// Handled here: flags ORDER, X32, NOSZ (size from the descriptor), CAT.  PACK / RLE / STRIPE
+// streams are reported as unsupported (-3) for now.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "htsgpu.h"
+#include "hg_device.h"
+#include "hg_internal.h"
+
+namespace hgn {
+
+constexpr uint32_t RANS_L = 1u << 15;
+constexpr int WAVES = 4;
+enum { F_ORDER = 1, F_X32 = 4, F_STRIPE = 8, F_NOSZ = 16, F_CAT = 32, F_RLE = 64, F_PACK = 128 };
+
+struct GroupLds { uint16_t C[258]; };
+
+__device__ __forceinline__ uint32_t rd32(const uint8_t *p) {
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+__device__ __forceinline__ int get_u7(const uint8_t *&cp, const uint8_t *end, uint32_t &v) {
+    uint32_t x = 0;
+    for (int n = 0; n < 5; n++) {
+        if (cp >= end) return -1;
+        const uint8_t c = *cp++;
+        x = (x << 7) | (c & 0x7fu);
+        if (!(c & 0x80u)) { v = x; return 0; }
+    }
+    return -1;
+}
+// alphabet (symbol run-length list) -> 256-bit presence mask in 8 words
+__device__ __forceinline__ int get_alphabet(const uint8_t *&cp, const uint8_t *end, uint32_t *present) {
+    for (int i = 0; i < 8; i++) present[i] = 0;
+    if (cp >= end) return -1;
+    uint32_t rle = 0, j = *cp++;
+    for (int guard = 0; guard < 257; guard++) {
+        present[j >> 5] |= 1u << (j & 31);
+        if (cp >= end) return -1;
+        if (!rle && j + 1 == *cp) {
+            j = *cp++;
+            if (cp >= end) return -1;
+            rle = *cp++;
+        } else if (rle) {
+            rle--; j++;
+            if (j > 255) return -1;
+        } else {
+            j = *cp++;
+        }
+        if (j == 0) return 0;
+    }
+    return -1;
+}
+
+// Single-lane order-0 Nx16 decoder (N = 4) for small side streams (compressed order-1 tables).
+__device__ int serial_dec_o0_n4(const uint8_t *cp, const uint8_t *end, uint8_t *out, uint32_t out_sz, uint16_t *C /*258 LDS*/) {
+    uint32_t present[8];
+    if (get_alphabet(cp, end, present)) return -1;
+    uint32_t tot = 0;
+    // first pass: raw frequencies into C (as F), then convert to cumulative
+    for (int j = 0; j < 256; j++) {
+        uint32_t f = 0;
+        if ((present[j >> 5] >> (j & 31)) & 1u) { if (get_u7(cp, end, f)) return -1; }
+        C[j] = (uint16_t)f; tot += f;
+        if (tot > 4096u) return -1;
+    }
+    if (!tot || (tot & (tot - 1))) return -1;
+    int sh = 0;
+    while ((tot << sh) < 4096u) sh++;
+    uint32_t x = 0;
+    for (int j = 0; j < 256; j++) { uint32_t f = (uint32_t)C[j] << sh; C[j] = (uint16_t)x; x += f; }
+    C[256] = (uint16_t)x;
+    if (cp + 16 > end) return -1;
+    uint32_t R[4];
+    for (int z = 0; z < 4; z++, cp += 4) R[z] = rd32(cp);
+    const uint32_t out_end = out_sz & ~3u;
+    for (uint32_t i = 0; i < out_sz; i++) {
+        const int z = (int)(i & 3u);
+        const uint32_t m = R[z] & 4095u;
+        uint32_t lo = 0, hi = 256;
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (C[mid] <= m) lo = mid; else hi = mid; }
+        out[i] = (uint8_t)lo;
+        if (i < out_end) {
+            const uint32_t cum = C[lo], f = (uint32_t)C[lo + 1] - cum;
+            R[z] = f * (R[z] >> 12) + m - cum;
+            if (R[z] < RANS_L) { if (cp + 2 > end) return -1; R[z] = (R[z] << 16) | cp[0] | ((uint32_t)cp[1] << 8); cp += 2; }
+        }
+    }
+    return 0;
+}
+
+template <int N>
+__global__ __launch_bounds__(WAVES * 64)
+void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc,
+                            const uint32_t *__restrict__ sel, uint32_t nsel, uint8_t *out, int32_t *status,
+                            uint32_t *scratch) {
+    constexpr int GROUPS = 64 / N;
+    __shared__ GroupLds lds[WAVES * GROUPS];
+    const int tid = threadIdx.x, lane = tid & 63, sub = lane & (N - 1), grp = lane / N;
+    const uint32_t g_global = (blockIdx.x * WAVES + (tid >> 6)) * GROUPS + grp;
+    const uint32_t g_total = gridDim.x * WAVES * GROUPS;
+    GroupLds &G = lds[(tid >> 6) * GROUPS + grp];
+    const unsigned long long gmask = (N == 64 ? ~0ull : ((1ull << N) - 1ull)) << (grp * N);
+    const int lane0 = grp * N;
+
+    for (uint32_t k = g_global; __any(k < nsel); k += g_total) {
+        const bool have = k < nsel;
+        const uint32_t sidx = have ? sel[k] : 0;
+        int err = have ? 0 : 2;
+        uint32_t flags = 0, usz = 0, shift = 12;
+        const uint8_t *cp = nullptr, *end = nullptr;
+        uint8_t *o = nullptr;
+        uint32_t *tabs = nullptr;
+        if (have) {
+            const hg_stream_desc d = desc[sidx];
+            cp = in + d.in_off; end = cp + d.in_len;
+            o = out + d.out_off; tabs = scratch + d.scratch_off;
+            if (d.in_len < 1) err = 1;
+            else {
+                flags = *cp++;
+                if (flags & F_NOSZ) usz = d.out_len;
+                else if (get_u7(cp, end, usz)) err = 1;
+                if (!err && usz != d.out_len) err = 1;
+                if (!err && (flags & (F_STRIPE | F_RLE | F_PACK))) err = 3;      // not handled yet
+                if (!err && ((flags & F_X32) ? 32 : 4) != N) err = 1;
+            }
+        }
+        const bool cat = !err && (flags & F_CAT);
+        if (cat) {
+            if (cp + usz > end) err = 1;
+            else for (uint32_t i = (uint32_t)sub; i < usz; i += N) o[i] = cp[i];
+        }
+        const uint32_t order = flags & F_ORDER;
+        const bool core = !err && !cat && usz != 0;
+        // ---- tables (first lane of the group) ---------------------------------------------------
+        if (core && sub == 0) {
+            if (order == 0) {
+                uint32_t present[8];
+                if (get_alphabet(cp, end, present)) err = 1;
+                uint32_t tot = 0;
+                for (int j = 0; j < 256 && !err; j++) {
+                    uint32_t f = 0;
+                    if ((present[j >> 5] >> (j & 31)) & 1u) { if (get_u7(cp, end, f)) err = 1; }
+                    G.C[j] = (uint16_t)f; tot += f;
+                    if (tot > 4096u) err = 1;
+                }
+                if (!err && (!tot || (tot & (tot - 1)))) err = 1;
+                if (!err) {
+                    int sh = 0;
+                    while ((tot << sh) < 4096u) sh++;
+                    uint32_t x = 0;
+                    for (int j = 0; j < 256; j++) { uint32_t f = (uint32_t)G.C[j] << sh; G.C[j] = (uint16_t)x; x += f; }
+                    G.C[256] = (uint16_t)x;
+                }
+            } else {
+                if (cp >= end) err = 1;
+                uint32_t comp = 0;
+                if (!err) { shift = *cp >> 4; comp = *cp & 1u; cp++; if (shift != 10 && shift != 12) err = 1; }
+                const uint8_t *tp = cp, *tend = end;
+                uint32_t np = 512;                                   // words used so far in tabs
+                if (!err && comp) {
+                    uint32_t ulen = 0, clen = 0;
+                    if (get_u7(cp, end, ulen) || get_u7(cp, end, clen) || cp + clen > end || ulen > 262144u) err = 1;
+                    else {
+                        uint8_t *tb = (uint8_t *)(tabs + 512);
+                        if (serial_dec_o0_n4(cp, cp + clen, tb, ulen, G.C)) err = 1;
+                        tp = tb; tend = tb + ulen; cp += clen;
+                        np = 512 + (ulen + 3) / 4;
+                    }
+                }
+                uint32_t A[8];
+                if (!err && get_alphabet(tp, tend, A)) err = 1;
+                if (!err) {
+                    for (int i = 0; i < 512; i++) tabs[i] = 0;
+                    for (int i = 0; i < 256 && !err; i++) {
+                        if (!((A[i >> 5] >> (i & 31)) & 1u)) continue;
+                        const uint32_t first = np;
+                        uint32_t tot = 0, cnt = 0, run = 0;
+                        for (int j = 0; j < 256 && !err; j++) {
+                            if (!((A[j >> 5] >> (j & 31)) & 1u)) continue;
+                            if (run) { run--; continue; }
+                            uint32_t f = 0;
+                            if (get_u7(tp, tend, f)) { err = 1; break; }
+                            if (f == 0) { if (tp >= tend) { err = 1; break; } run = *tp++; }
+                            else { tabs[np++] = (f << 8) | (uint32_t)j; tot += f; cnt++; }
+                        }
+                        if (err) break;
+                        if (tot > (1u << shift) || (tot & (tot - 1))) { err = 1; break; }
+                        int sh = 0;
+                        while (tot && (tot << sh) < (1u << shift)) sh++;
+                        uint32_t x = 0;
+                        for (uint32_t e = first; e < np; e++) {              // raw freq -> cumulative
+                            const uint32_t f = (tabs[e] >> 8) << sh, s = tabs[e] & 0xffu;
+                            tabs[e] = (x << 8) | s; x += f;
+                        }
+                        tabs[np++] = x << 8;                                 // sentinel = total
+                        tabs[i] = first; tabs[256 + i] = cnt;
+                    }
+                    if (!comp) cp = tp;
+                }
+            }
+        }
+        // broadcast parse results from the first lane of the group
+        {
+            err = __shfl(err, lane0, 64);
+            shift = (uint32_t)__shfl((int)shift, lane0, 64);
+            const unsigned long long cpv = (unsigned long long)(uintptr_t)cp;
+            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)cpv, lane0, 64);
+            const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(cpv >> 32), lane0, 64);
+            cp = (const uint8_t *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool live = core && !err;
+        uint32_t R = 0;
+        if (live) {
+            if (cp + 4 * N > end) err = 1;
+            else { R = rd32(cp + 4 * sub); cp += 4 * N; }
+        }
+        const uint32_t mask = (1u << shift) - 1u;
+        const uint32_t per = usz / N;
+        uint32_t pos = order == 0 ? (uint32_t)sub : (uint32_t)sub * per, ctx = 0;
+        const uint32_t steps = per, rem = usz - per * N;
+        const uint32_t max_steps = (live && !err) ? steps + (order ? rem : 0u) : 0u;
+        for (uint32_t it = 0; __any(it < max_steps); it++) {
+            const bool act = live && !err && it < max_steps;
+            const bool mine = act && (it < steps || (order && sub == N - 1));
+            uint32_t need = 0;
+            if (mine) {
+                const uint32_t m = R & mask;
+                uint32_t sym = 0, cum = 0, f = 1;
+                if (order == 0) {
+                    uint32_t lo = 0, hi = 256;
+                    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (G.C[mid] <= m) lo = mid; else hi = mid; }
+                    sym = lo; cum = G.C[lo]; f = (uint32_t)G.C[lo + 1] - cum;
+                } else {
+                    const uint32_t n = tabs[256 + ctx], base = tabs[ctx];
+                    if (n == 0 || (tabs[base + n] >> 8) <= m) err = 1;
+                    else {
+                        uint32_t lo = 0, hi = n;
+                        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if ((tabs[base + mid] >> 8) <= m) lo = mid; else hi = mid; }
+                        const uint32_t e = tabs[base + lo];
+                        sym = e & 0xffu; cum = e >> 8; f = (tabs[base + lo + 1] >> 8) - cum;
+                    }
+                }
+                if (!err) {
+                    o[pos] = (uint8_t)sym;
+                    pos += order == 0 ? (uint32_t)N : 1u;
+                    ctx = sym;
+                    R = f * (R >> shift) + m - cum;
+                    need = R < RANS_L ? 1u : 0u;
+                }
+            }
+            // the lanes that renormalise take consecutive 16-bit words in lane order
+            const unsigned long long b = __ballot(need != 0) & gmask;
+            const uint32_t before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+            const uint32_t tot = (uint32_t)__popcll(b);
+            if (need) {
+                const uint8_t *w = cp + 2u * before;
+                if (w + 2 > end) err = 1;
+                else R = (R << 16) | (uint32_t)w[0] | ((uint32_t)w[1] << 8);
+            }
+            cp += 2u * tot;
+            err = (__ballot(err == 1) & gmask) ? 1 : err;
+        }
+        // order-0 tail: states 0..rem-1 give one more symbol each, without update
+        if (live && !err && order == 0 && (uint32_t)sub < rem) {
+            const uint32_t m = R & mask;
+            uint32_t lo = 0, hi = 256;
+            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (G.C[mid] <= m) lo = mid; else hi = mid; }
+            o[per * N + sub] = (uint8_t)lo;
+        }
+        err = (__ballot(err == 1) & gmask) ? 1 : err;
+        if (have && sub == 0) status[sidx] = err == 0 ? 0 : (err == 3 ? HG_BLOCK_EUNSUPPORTED : -1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace hgn
+
+namespace hg {
+int launch_ransnx16_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_sel4,
+                           size_t n4, const uint32_t *d_sel32, size_t n32, void *d_out, int32_t *d_status,
+                           uint32_t *d_scratch, hipStream_t s) {
+    const size_t maxw = (size_t)ctx->cus * 8;
+    if (n4) {
+        size_t wgs = (n4 + hgn::WAVES * 16 - 1) / (hgn::WAVES * 16);
+        if (wgs > maxw) wgs = maxw;
+        hipLaunchKernelGGL(hgn::ransnx16_decode_kernel<4>, dim3((unsigned)wgs), dim3(hgn::WAVES * 64), 0, s,
+                           (const uint8_t *)d_in, d_desc, d_sel4, (uint32_t)n4, (uint8_t *)d_out, d_status, d_scratch);
+    }
+    if (n32) {
+        size_t wgs = (n32 + hgn::WAVES * 2 - 1) / (hgn::WAVES * 2);
+        if (wgs > maxw) wgs = maxw;
+        hipLaunchKernelGGL(hgn::ransnx16_decode_kernel<32>, dim3((unsigned)wgs), dim3(hgn::WAVES * 64), 0, s,
+                           (const uint8_t *)d_in, d_desc, d_sel32, (uint32_t)n32, (uint8_t *)d_out, d_status, d_scratch);
+    }
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+}  // namespace hg

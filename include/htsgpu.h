@@ -150,6 +150,19 @@ int hg_rans4x8_decode_dev(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d
 int hg_rans4x8_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
                            uint8_t *const *out, const uint32_t *out_cap, uint32_t *out_len, int32_t *status);
 
+/* ---- CRAM 3.1 rANS Nx16 (replaces rans_uncompress_4x16 as called by cram_uncompress_block,
+ *      cram/cram_io.c:1697-1714; CRAM block method 5).  PARITY UNPINNED: htscodecs is absent from
+ *      the reference and no stock stream exists to check against (oracle/ransnx16_oracle.c). ---- */
+/* Decode n streams; out_len[i] = expected plaintext size (cram_block.uncomp_size, also the size
+ * for NOSZ streams).  Handles order 0/1, 4-way and 32-way (X32), NOSZ, CAT; streams using PACK, RLE
+ * or STRIPE get status -3 (HG_BLOCK_EUNSUPPORTED).  Synchronous.  Returns 0 or HG_EBLOCK. */
+int hg_ransnx16_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
+                            uint8_t *const *out, const uint32_t *out_len, int32_t *status);
+/* device form: d_sel4 / d_sel32 list the descriptor indices of the 4-way / 32-way streams */
+int hg_ransnx16_decode_dev(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_sel4,
+                           size_t n4, const uint32_t *d_sel32, size_t n32, void *d_out, int32_t *d_status,
+                           uint32_t *d_scratch, void *stream);
+
 /* ---- CRAM block layer (replaces cram_uncompress_block, cram/cram_io.c:1576-1754) ------------ */
 /* on-disk method ids, htslib/cram.h:84-101 */
 #define HG_CRAM_RAW      0

@@ -136,3 +136,28 @@ def rans_golden_cases():
         v = man[name]
         yield name, open(os.path.join(RANS_GOLDEN, name), "rb").read(), v["usize"], \
             (bytes.fromhex(v["expected_hex"]) if v["expected_hex"] is not None else None), v["order"]
+
+
+# ------------------------------------------------------------------ rANS Nx16 (CRAM 3.1) -- parity unpinned
+class RansNx16Oracle:
+    FLAGS = {"ORDER": 1, "X32": 4, "STRIPE": 8, "NOSZ": 16, "CAT": 32, "RLE": 64, "PACK": 128}
+
+    def __init__(self):
+        L = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        L.orc_ransnx16_uncompress.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.orc_ransnx16_compress.restype = C.c_size_t
+        L.orc_ransnx16_compress.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int]
+        L.orc_ransnx16_compress_bound.restype = C.c_size_t
+        L.orc_ransnx16_compress_bound.argtypes = [C.c_size_t]
+        self.L = L
+
+    def encode(self, d: bytes, flags: int) -> bytes:
+        out = C.create_string_buffer(self.L.orc_ransnx16_compress_bound(len(d)))
+        n = self.L.orc_ransnx16_compress(d, len(d), out, flags)
+        return out.raw[:n]
+
+    def decode(self, b: bytes, cap: int):
+        out = C.create_string_buffer(max(cap, 1))
+        n = C.c_size_t(0)
+        rc = self.L.orc_ransnx16_uncompress(b, len(b), out, cap, C.byref(n))
+        return rc, (out.raw[:n.value] if rc == 0 else b"")
