@@ -163,6 +163,14 @@ int hg_ransnx16_decode_dev(hg_ctx *ctx, const void *d_in, const hg_stream_desc *
                            size_t n4, const uint32_t *d_sel32, size_t n32, void *d_out, int32_t *d_status,
                            uint32_t *d_scratch, void *stream);
 
+/* Encoder (replaces rans_compress_4x16 as called by cram_compress_by_method,
+ * cram/cram_io.c:1853-1866).  flags[i]: bit 0x01 order-1, 0x04 32-way, 0x10 NOSZ, 0x20 CAT (the
+ * RANS_ORDER_* bits of cram/cram_external.c:616-624); PACK / RLE / STRIPE are not applied yet.
+ * out[i] must hold hg_ransnx16_compress_bound(in_len[i]) bytes.  Synchronous. */
+size_t hg_ransnx16_compress_bound(size_t in_len);
+int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags,
+                            size_t n, uint8_t *const *out, uint32_t *out_len);
+
 /* ---- CRAM block layer (replaces cram_uncompress_block, cram/cram_io.c:1576-1754) ------------ */
 /* on-disk method ids, htslib/cram.h:84-101 */
 #define HG_CRAM_RAW      0
