@@ -113,8 +113,10 @@ def main():
     ap.add_argument("--gib", type=float, default=10.0, help="plain GiB of synthetic BAM per GPU")
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--workers", type=int, default=0, help="host processes for workload preparation")
-    ap.add_argument("--op", choices=["inflate", "deflate"], default="inflate",
-                    help="inflate = BASELINE configs[1] (default, the headline); deflate = configs[2]")
+    ap.add_argument("--op", choices=["inflate", "deflate", "rans"], default="inflate",
+                    help="inflate = BASELINE configs[1] (default, the headline); deflate = configs[2]; "
+                         "rans = configs[3] (CRAM 3.1 rANS Nx16 decode of QS+BA series)")
+    ap.add_argument("--slices", type=int, default=1000, help="--op rans: CRAM slices of 10 000 reads (1000 = 10 M reads)")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -127,6 +129,8 @@ def main():
     ncores = os.cpu_count() or 1
     workers = args.workers or max(1, (ncores - 4) // max(1, world))
 
+    if args.op == "rans":
+        return bench_rans(args, rank, world, local, ncores)
     # ---------------- workload preparation (host, not timed, before HIP init) --------------
     total_bytes = int(args.gib * (1 << 30))
     seed = 0x5EED0001 + 1000003 * rank
@@ -234,6 +238,126 @@ def main():
             cb = cpu_baseline(sample, plen, ncores)
             if cb:
                 out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(2)
+
+
+def _rans_series(seed, nslices):
+    """QS (4-bin Markov qualities) and BA (bases) data series of `nslices` CRAM slices, 10 000 x 150 bp each."""
+    out = []
+    for sl in range(nslices):
+        rng = np.random.Generator(np.random.PCG64(seed + sl))
+        n = 10_000 * 150
+        change = rng.random(n) < 0.1
+        idx = np.maximum.accumulate(np.where(change, np.arange(n), 0))
+        qs = np.array([2, 12, 23, 37], dtype=np.uint8)[rng.integers(0, 4, n)][idx]
+        ba = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.choice(5, n, p=[.2495, .2495, .2495, .2495, .002])]
+        out.append((qs.tobytes(), ba.tobytes()))
+    return out
+
+
+def bench_rans(args, rank, world, local, ncores):
+    """BASELINE configs[3]: CRAM 3.1 rANS Nx16 decode (order-1 32-way QS + order-0 32-way BA) of
+    --slices x 10 000 reads per GPU.  The streams are produced by the gfx950 ENCODER (the oracle is
+    used only as cpu_baseline); the timed region is the decode launch, device resident."""
+    import ctypes as C
+    import torch
+    from htslib_amd import _native as nat
+    from htslib_amd.bgzf import reduce_timing
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(min(64, max(1, (ncores - 4) // max(1, world)))) as pool:
+        chunks = pool.starmap(_rans_series, [(0x5EED0001 + 7_000_003 * rank + 1000 * i, 1) for i in range(args.slices)])
+    series = [c[0] for c in chunks]
+    t_prep = time.perf_counter() - t0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    eng = nat.Engine(local)
+    plains, flags = [], []
+    for qs, ba in series:
+        plains += [qs, ba]; flags += [5, 4]                      # QS: order-1 X32, BA: order-0 X32
+    streams = []
+    for i in range(0, len(plains), 64):                           # encode on the GPU, in batches
+        streams += eng.ransnx16_encode_host(plains[i:i + 64], flags[i:i + 64])
+    n = len(streams)
+    in_len = np.array([len(s) for s in streams], dtype=np.uint32)
+    out_len = np.array([len(p) for p in plains], dtype=np.uint32)
+    desc = np.zeros(n, dtype=[("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"),
+                              ("scratch_off", "<u4"), ("reserved", "<u4")])
+    pad = lambda v: (v + 15) & ~np.uint64(15)
+    desc["in_len"], desc["out_len"] = in_len, out_len
+    desc["in_off"] = np.concatenate([[0], np.cumsum(pad(in_len.astype(np.uint64)))[:-1]])
+    desc["out_off"] = np.concatenate([[0], np.cumsum(pad(out_len.astype(np.uint64)))[:-1]])
+    words = np.array([512 + min(65792, int(l)) + 272 if f & 1 else 16 for l, f in zip(in_len, flags)], dtype=np.uint64)
+    desc["scratch_off"] = np.concatenate([[0], np.cumsum(words)[:-1]]).astype(np.uint32)
+    blob = bytearray(int(desc["in_off"][-1] + pad(np.uint64(in_len[-1]))))
+    for d, s_ in zip(desc, streams):
+        blob[int(d["in_off"]):int(d["in_off"]) + len(s_)] = s_
+    d_in = torch.frombuffer(blob, dtype=torch.uint8).to(dev)
+    d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(dev)
+    total_u = int(out_len.astype(np.uint64).sum()); total_c = int(in_len.astype(np.uint64).sum())
+    d_out = torch.zeros(int(desc["out_off"][-1]) + int(out_len[-1]) + 64, dtype=torch.uint8, device=dev)
+    d_status = torch.full((n,), 77, dtype=torch.int32, device=dev)
+    d_scratch = torch.zeros(int(words.sum()) + 64, dtype=torch.int32, device=dev)
+    d_sel = torch.arange(n, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+
+    def step():
+        nat.check(nat.lib.hg_ransnx16_decode_dev(eng._h, d_in.data_ptr(), d_desc.data_ptr(), None, 0, d_sel.data_ptr(), n,
+                                                 d_out.data_ptr(), d_status.data_ptr(), d_scratch.data_ptr(), stream), "rans decode")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(); step(); b.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    ok = int((d_status != 0).sum()) == 0
+    host_out = d_out.cpu().numpy()
+    for i in (0, 1, n - 2, n - 1):
+        ok = ok and host_out[int(desc["out_off"][i]):int(desc["out_off"][i]) + int(out_len[i])].tobytes() == plains[i]
+    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(total_u), float(total_c), ok, world, dev)
+    if rank == 0:
+        alg = float(total_u + total_c)
+        out = {"metric": "CRAM 3.1 rANS Nx16 decode throughput, uncompressed GB/s (HBM-resident)",
+               "value": round(sum_u * args.steps / elapsed / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": f"rANS Nx16 decode of {args.slices} CRAM slices x 10 000 x 150 bp per GPU: QS (order-1, 32-way) "
+                                      "+ BA (order-0, 32-way) data series; streams written by the gfx950 encoder; format parity "
+                                      "with htscodecs UNPINNED", "streams_per_gpu": n, "plain_bytes_per_gpu": total_u,
+                          "compressed_bytes_per_gpu": total_c, "verified": bool(ok), "prep_seconds": round(t_prep, 1)},
+               "roofline": {"bound": "hbm", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                            "kernel": "hgn::ransnx16_decode_kernel<32>", "kernel_ms": round(k_ms, 3),
+                            "algorithmic_bytes_per_launch": int(alg)}}
+        if world == 1 and not args.no_cpu_baseline:
+            orc = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+            orc.orc_ransnx16_uncompress.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+            buf = C.create_string_buffer(1_500_000 + 64); got = C.c_size_t(0)
+            k = min(n, 24); t = time.perf_counter(); done = 0
+            for i in range(k):
+                orc.orc_ransnx16_uncompress(streams[i], len(streams[i]), buf, 1_500_064, C.byref(got)); done += got.value
+            dt = time.perf_counter() - t
+            out["cpu_baseline"] = {"value": round(done / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+                                   "sample": f"oracle/ransnx16_oracle.c (scalar C restatement, NOT reference code: htscodecs absent) "
+                                             f"decoding {k} of the same streams on one core"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
