@@ -53,7 +53,7 @@ __device__ unsigned long long g_prof[16];   // 0 total, 1 header+tables, 2 symbo
 #endif
 
 #ifndef HG_LIT_RB
-#define HG_LIT_RB 10
+#define HG_LIT_RB 9
 #endif
 constexpr int LIT_RB = HG_LIT_RB;
 constexpr int DIST_RB = 8;
@@ -63,7 +63,7 @@ constexpr int DIST_TAB = 416;   // >= ENOUGH(30 symbols, root 8, max 15)  = 402
 constexpr int PRE_RB = 7;
 constexpr int WAVES_PER_WG = 4;
 #ifndef HG_RING
-#define HG_RING 2048
+#define HG_RING 1024
 #endif
 #ifndef HG_WALK
 #define HG_WALK 0        // 0: vector-uniform serial loop (inflate_loop_vec.inc)  1: gather + scalar walk
@@ -79,15 +79,20 @@ constexpr uint32_t F_LIT = 0x10u, F_BASE = 0x20u, F_EOB = 0x40u, F_SUB = 0x80u;
 // needs ONE sign test to know it can emit a byte and drop e&15 bits.
 constexpr uint32_t F_FAST = 0x80000000u;
 
-struct WaveLds {
-    uint32_t lit[LIT_TAB];
-    uint32_t dist[DIST_TAB];
+struct BuildScratch {               // only live while the Huffman tables of a deflate block are built
     uint32_t cnt[16];
     uint32_t nc[16];
     uint32_t alloc;
     uint32_t pad[3];
     uint8_t lens[352];
-    uint8_t ring[RING];
+};
+struct WaveLds {
+    uint32_t lit[LIT_TAB];
+    uint32_t dist[DIST_TAB];
+    union {                         // the output ring shares its LDS with the table-build scratch;
+        BuildScratch b;             // it is re-filled from the wave's own output after each build
+        uint8_t ring[RING > sizeof(BuildScratch) ? RING : sizeof(BuildScratch)];
+    } u;
 };
 
 enum { KIND_LITLEN = 0, KIND_DIST = 1, KIND_PRE = 2 };
@@ -112,29 +117,29 @@ __device__ __forceinline__ uint32_t make_entry(int kind, uint32_t sym, uint32_t 
     return (base << 16) | (extra << 8) | F_BASE | nb;
 }
 
-// Build a root+subtable decode table from code lengths S.lens[lens_off ..+n).
+// Build a root+subtable decode table from code lengths S.u.b.lens[lens_off ..+n).
 // Returns 0 ok, 1 invalid code set (over-subscribed / illegal incomplete).
 // All 64 lanes participate; result uniform.
 template <int KIND, int RB, int CAP, int NCHUNK>
 __device__ __forceinline__ int build_table(WaveLds &S, uint32_t *tab, int lens_off, int n, int lane) {
     // ---- zero root + count code lengths --------------------------------
     HG_TRACE(4, 100 + KIND);
-    if (lane < 16) { S.cnt[lane] = 0; }
+    if (lane < 16) { S.u.b.cnt[lane] = 0; }
     for (int i = lane; i < (1 << RB); i += 64) tab[i] = 0;
-    if (lane == 0) S.alloc = 1u << RB;
+    if (lane == 0) S.u.b.alloc = 1u << RB;
     wave_sync();
     uint32_t L[NCHUNK];
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++) {
         int sym = c * 64 + lane;
-        L[c] = sym < n ? S.lens[lens_off + sym] : 0;
-        if (L[c]) atomicAdd(&S.cnt[L[c]], 1u);
+        L[c] = sym < n ? S.u.b.lens[lens_off + sym] : 0;
+        if (L[c]) atomicAdd(&S.u.b.cnt[L[c]], 1u);
     }
     wave_sync();
     // ---- canonical first codes (RFC 1951 3.2.2), uniform -----------------
     uint32_t code = 0;
     int left = 1, total = 0, maxlen = 0;
-    uint32_t mycnt = lane < 16 ? S.cnt[lane] : 0;
+    uint32_t mycnt = lane < 16 ? S.u.b.cnt[lane] : 0;
     uint32_t first_code = 0;
 #pragma unroll
     for (int l = 1; l <= 15; l++) {
@@ -151,7 +156,7 @@ __device__ __forceinline__ int build_table(WaveLds &S, uint32_t *tab, int lens_o
         // (same rule as the oracle / zlib inftrees: max != 1 -> error)
         if (!(total == 0 || (total == 1 && maxlen == 1))) return 1;
     }
-    if (lane >= 1 && lane < 16) S.nc[lane] = first_code;
+    if (lane >= 1 && lane < 16) S.u.b.nc[lane] = first_code;
     wave_sync();
     HG_TRACE(4, 200 + KIND);
     // ---- assign codes in symbol order, fill root entries -----------------
@@ -168,11 +173,11 @@ __device__ __forceinline__ int build_table(WaveLds &S, uint32_t *tab, int lens_o
             int leader = __builtin_ctzll(todo);
             uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, leader);
             unsigned long long m = __ballot(len == l);
-            uint32_t base = S.nc[l];                             // uniform LDS read
+            uint32_t base = S.u.b.nc[l];                             // uniform LDS read
             uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (len == l) mycode = base + rank;
             wave_sync();
-            if (lane == leader) S.nc[l] = base + (uint32_t)__popcll(m);
+            if (lane == leader) S.u.b.nc[l] = base + (uint32_t)__popcll(m);
             wave_sync();
             todo &= ~m;
         }
@@ -197,7 +202,7 @@ __device__ __forceinline__ int build_table(WaveLds &S, uint32_t *tab, int lens_o
         uint32_t v = tab[i];
         if (v != 0 && v < 16) {
             uint32_t sb = v - RB;
-            uint32_t off = atomicAdd(&S.alloc, 1u << sb);
+            uint32_t off = atomicAdd(&S.u.b.alloc, 1u << sb);
             if (off + (1u << sb) > (uint32_t)CAP) { bad = 1; tab[i] = 0; }
             else tab[i] = (off << 16) | (sb << 8) | F_SUB | RB;
         }
@@ -325,7 +330,7 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
             if (!bfinal) {
                 // later blocks may reach back into these bytes: mirror the tail into the LDS ring
                 uint32_t lo = pos > RING ? pos - RING : 0u;
-                for (uint32_t p = lo + lane; p < pos; p += 64) S.ring[p & (RING - 1u)] = out[p];
+                for (uint32_t p = lo + lane; p < pos; p += 64) S.u.ring[p & (RING - 1u)] = out[p];
                 wave_sync();
             }
             br_seek(br, src + len, lane);
@@ -335,8 +340,8 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
             if (btype == 1) {
                 // ---- fixed codes (RFC 1951 3.2.6) ----
                 for (int i = lane; i < 288; i += 64)
-                    S.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
-                if (lane < 32) S.lens[288 + lane] = 5;
+                    S.u.b.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+                if (lane < 32) S.u.b.lens[288 + lane] = 5;
                 wave_sync();
                 if (build_table<KIND_LITLEN, LIT_RB, LIT_TAB, 5>(S, S.lit, 0, 288, lane)) return ST_INFLATE;
                 if (build_table<KIND_DIST, DIST_RB, DIST_TAB, 1>(S, S.dist, 288, 32, lane)) return ST_INFLATE;
@@ -348,7 +353,7 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                 uint32_t ncode = br_bits(br, 4) + 4;
                 if (nlen > 286 || ndist > 30) return ST_INFLATE;
                 // code-length code lengths: 3 bits each, permuted order
-                if (lane < 19) S.lens[lane] = 0;
+                if (lane < 19) S.u.b.lens[lane] = 0;
                 wave_sync();
                 for (uint32_t i = 0; i < ncode; i++) {
                     br_refill(br, lane);
@@ -361,7 +366,7 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                                             (1ull << 25) | (15ull << 30);
                     uint32_t sym = i < 12 ? (uint32_t)(ord_lo >> (5 * i)) & 31u
                                           : (uint32_t)(ord_hi >> (5 * (i - 12))) & 31u;
-                    if (lane == 0) S.lens[sym] = (uint8_t)v;
+                    if (lane == 0) S.u.b.lens[sym] = (uint8_t)v;
                 }
                 wave_sync();
                 if (build_table<KIND_PRE, PRE_RB, DIST_TAB, 1>(S, S.dist, 0, 19, lane)) return ST_INFLATE;
@@ -369,7 +374,7 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                 // code-length codes outright; build_table allows the 1-code case, which a
                 // conforming encoder never emits -- keep oracle behaviour (complete only).
                 {
-                    uint32_t c = lane < 16 ? S.cnt[lane] : 0;
+                    uint32_t c = lane < 16 ? S.u.b.cnt[lane] : 0;
                     int left = 1;
 #pragma unroll
                     for (int l = 1; l <= 7; l++)
@@ -385,7 +390,7 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                     br_drop(br, e & 15u);
                     uint32_t sym = e >> 16;
                     if (sym < 16) {
-                        if (lane == 0) S.lens[32 + idx] = (uint8_t)sym;
+                        if (lane == 0) S.u.b.lens[32 + idx] = (uint8_t)sym;
                         prev = sym; idx++;
                     } else {
                         uint32_t rep, val = 0;
@@ -395,17 +400,24 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                         } else if (sym == 17) rep = 3 + br_bits(br, 3);
                         else rep = 11 + br_bits(br, 7);
                         if (idx + rep > total) return ST_INFLATE;
-                        for (uint32_t j = lane; j < rep; j += 64) S.lens[32 + idx + j] = (uint8_t)val;
+                        for (uint32_t j = lane; j < rep; j += 64) S.u.b.lens[32 + idx + j] = (uint8_t)val;
                         idx += rep; prev = val;
                     }
                 }
                 wave_sync();
-                if (S.lens[32 + 256] == 0) return ST_INFLATE;          // no end-of-block code
+                if (S.u.b.lens[32 + 256] == 0) return ST_INFLATE;          // no end-of-block code
                 // lengths sit at lens[32 .. 32+nlen+ndist): the precode table in S.dist is dead now
                 if (build_table<KIND_LITLEN, LIT_RB, LIT_TAB, 5>(S, S.lit, 32, (int)nlen, lane)) return ST_INFLATE;
                 if (build_table<KIND_DIST, DIST_RB, DIST_TAB, 1>(S, S.dist, 32 + (int)nlen, (int)ndist, lane)) return ST_INFLATE;
             }
             HG_TACC(1, tph);
+            // the table-build scratch overlays the output ring: restore the ring from the wave's own
+            // output (visible to it in program order) when this is not the first deflate block
+            if (pos) {
+                const uint32_t lo = pos > RING ? pos - RING : 0u;
+                for (uint32_t p = lo + (uint32_t)lane; p < pos; p += 64) S.u.ring[p & (RING - 1u)] = out[p];
+            }
+            wave_sync();
 #if HG_WALK
 #include "inflate_loop_walk.inc"
 #else
@@ -419,7 +431,10 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
     return ST_OK;
 }
 
-__global__ __launch_bounds__(WAVES_PER_WG * 64)
+#ifndef HG_INFLATE_MIN_WAVES
+#define HG_INFLATE_MIN_WAVES 6      // 80 VGPRs, 5.6 KiB LDS per wave -> 24 waves per CU
+#endif
+__global__ __launch_bounds__(WAVES_PER_WG * 64, HG_INFLATE_MIN_WAVES)
 void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
                          const hg_bgzf_desc *__restrict__ desc, uint32_t nblocks,
                          uint8_t *out, uint64_t out_cap, int32_t *status,

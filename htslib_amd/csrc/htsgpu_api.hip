@@ -54,7 +54,7 @@ int hg_init(int device, hg_ctx **out) {
     ctx->device = device;
     ctx->cus = prop.multiProcessorCount;
     // inflate: 30 KiB LDS per 4-wave workgroup -> 5 workgroups (20 waves) per CU
-    ctx->waves_per_launch = ctx->cus * 20;
+    ctx->waves_per_launch = ctx->cus * 24;
     if (hipMalloc((void **)&ctx->d_ticket, 64) != hipSuccess) { free(ctx); return HG_ENOMEM; }
     *out = ctx;
     return HG_OK;
