@@ -105,6 +105,16 @@ def cpu_baseline(bgzf_sample: bytes, plain_len: int, threads: int):
                       f"{plain_len / 2**30:.2f} GiB of the same BAM from /dev/shm, best of 3"}
 
 
+def hbm_traffic(plain_bytes):
+    """HBM bytes per launch from the committed PMC passes (profiles/hbm_traffic_inflate.json:
+    FETCH_SIZE + WRITE_SIZE per plain byte at the 10 GiB config), scaled to this workload; None if absent."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_inflate.json")))
+        return int((t["fetch_bytes_per_plain_byte"] + t["write_bytes_per_plain_byte"]) * plain_bytes)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,7 +232,7 @@ def main():
                        "sharding": "independent blocks, static split, no collective", "verified": bool(ok),
                        "prep_seconds": round(t_prep, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": hbm_traffic(total_u),
                          "kernel": "hg::bgzf_inflate_kernel", "kernel_ms": round(k_ms, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
