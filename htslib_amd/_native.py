@@ -59,11 +59,16 @@ lib.hg_ransnx16_compress_bound.restype = C.c_size_t
 lib.hg_ransnx16_compress_bound.argtypes = [C.c_size_t]
 lib.hg_ransnx16_encode_host.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]
 
+lib.hg_rans4x8_compress_bound.restype = C.c_size_t
+lib.hg_rans4x8_compress_bound.argtypes = [C.c_size_t]
+lib.hg_rans4x8_encode_host.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]
+
 EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info", "hg_bgzf_scan",
            "hg_bgzf_inflate_dev", "hg_bgzf_inflate_host", "hg_crc32_dev", "hg_bgzf_deflate_dev", "hg_bgzf_pack_dev",
            "hg_bgzf_deflate_host", "hg_rans4x8_decode_dev", "hg_rans4x8_decode_host",
            "hg_gzip_inflate_dev", "hg_cram_uncompress_blocks_host", "hg_ransnx16_decode_host", "hg_ransnx16_decode_dev",
-           "hg_ransnx16_compress_bound", "hg_ransnx16_encode_host"]
+           "hg_ransnx16_compress_bound", "hg_ransnx16_encode_host", "hg_rans4x8_compress_bound",
+           "hg_rans4x8_encode_host"]
 
 
 class HgError(RuntimeError):
@@ -194,6 +199,23 @@ class Engine:
         if rc not in (0, -6):
             check(rc, "hg_cram_uncompress_blocks_host")
         return [outs[i].raw[:blocks[i][2]] if status[i] == 0 else None for i in range(n)], status
+
+    def rans4x8_encode_host(self, datas, orders):
+        """rANS 4x8-encode each bytes object with the matching order (0/1) -> list of streams."""
+        import numpy as np
+        n = len(datas)
+        if n == 0:
+            return []
+        ins = [(C.c_char * max(len(d), 1)).from_buffer_copy(d if len(d) else b"\0") for d in datas]
+        outs = [C.create_string_buffer(lib.hg_rans4x8_compress_bound(len(d))) for d in datas]
+        in_ptr = (_vp * n)(*[C.addressof(x) for x in ins])
+        out_ptr = (_vp * n)(*[C.addressof(x) for x in outs])
+        in_len = np.array([len(d) for d in datas], dtype=np.uint32)
+        od = np.array(orders, dtype=np.uint8)
+        out_len = np.zeros(n, dtype=np.uint32)
+        check(lib.hg_rans4x8_encode_host(self._h, in_ptr, in_len.ctypes.data, od.ctypes.data, n, out_ptr,
+                                         out_len.ctypes.data), "hg_rans4x8_encode_host")
+        return [outs[i].raw[:int(out_len[i])] for i in range(n)]
 
     def ransnx16_encode_host(self, datas, flags):
         """rANS Nx16-encode each bytes object in `datas` with the matching flag byte -> list of streams."""

@@ -34,6 +34,9 @@ uint32_t ransnx16_enc_scratch_words(uint32_t flags);
 int launch_ransnx16_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags,
                            const uint32_t *d_sel4, size_t n4, const uint32_t *d_sel32, size_t n32, void *d_out,
                            uint32_t *d_out_len, void *d_wbuf, uint32_t *d_scratch, hipStream_t s);
+uint32_t rans4x8_enc_scratch_words(uint32_t order);
+int launch_rans4x8_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_order, size_t n,
+                          void *d_out, uint32_t *d_out_len, void *d_wbuf, uint32_t *d_scratch, hipStream_t s);
 int launch_crc32(hg_ctx *ctx, const void *d_data, const uint64_t *d_off, const uint32_t *d_len, size_t n,
                  uint32_t *d_crc, hipStream_t s);
 }

@@ -180,6 +180,53 @@ int hg_ransnx16_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_
     return rc;
 }
 
+size_t hg_rans4x8_compress_bound(size_t n) { return n + n / 16 + 257 * 257 * 3 + 9 + 64; }
+
+int hg_rans4x8_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *order, size_t n,
+                           uint8_t *const *out, uint32_t *out_len) {
+    if (!ctx || (n && (!in || !in_len || !order || !out || !out_len))) return HG_EINVAL;
+    if (n == 0) return HG_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg_stream_desc *desc = (hg_stream_desc *)calloc(n, sizeof(hg_stream_desc));
+    uint32_t *ol = (uint32_t *)malloc(n * 4);
+    if (!desc || !ol) { free(desc); free(ol); return HG_ENOMEM; }
+    uint64_t ioff = 0, ooff = 0, soff = 0, woff = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t cap = hg_rans4x8_compress_bound(in_len[i]);
+        desc[i].in_off = ioff; desc[i].in_len = in_len[i]; desc[i].out_off = ooff; desc[i].out_len = (uint32_t)cap;
+        desc[i].scratch_off = (uint32_t)soff; desc[i].reserved = (uint32_t)(woff / 16);
+        ioff += ((uint64_t)in_len[i] + 15u) & ~15ull;
+        ooff += (cap + 15u) & ~15ull;
+        soff += hg::rans4x8_enc_scratch_words(order[i] & 1u);
+        woff += (2ull * in_len[i] + 64u + 15u) & ~15ull;
+        if (soff > 0xffffffffull || woff / 16 > 0xffffffffull) { free(desc); free(ol); return HG_EINVAL; }
+    }
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, ioff + 64)) || (rc = ensure_scratch(ctx, 1, ooff + 64)) ||
+        (rc = ensure_scratch(ctx, 2, n * sizeof(hg_stream_desc))) || (rc = ensure_scratch(ctx, 3, n * 4 + n + 64)) ||
+        (rc = ensure_scratch(ctx, 4, woff + 64)) || (rc = ensure_scratch(ctx, 6, soff * 4 + 64))) { free(desc); free(ol); return rc; }
+    hipStream_t s = nullptr;
+    uint32_t *d_ol = (uint32_t *)ctx->d_scratch[3];
+    uint8_t *d_ord = (uint8_t *)ctx->d_scratch[3] + n * 4;
+    bool ok = hipMemsetAsync(d_ol, 0, n * 4, s) == hipSuccess;
+    for (size_t i = 0; i < n && ok; i++)
+        if (in_len[i]) ok = hipMemcpyAsync((uint8_t *)ctx->d_scratch[0] + desc[i].in_off, in[i], in_len[i], hipMemcpyHostToDevice, s) == hipSuccess;
+    ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc, n * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(d_ord, order, n, hipMemcpyHostToDevice, s) == hipSuccess;
+    rc = ok ? hg::launch_rans4x8_encode(ctx, ctx->d_scratch[0], (const hg_stream_desc *)ctx->d_scratch[2], d_ord, n,
+                                        ctx->d_scratch[1], d_ol, ctx->d_scratch[4], (uint32_t *)ctx->d_scratch[6], s) : HG_ELAUNCH;
+    if (rc == HG_OK) {
+        ok = hipMemcpyAsync(ol, d_ol, n * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        for (size_t i = 0; i < n && ok; i++) {
+            out_len[i] = ol[i];
+            if (ol[i]) ok = hipMemcpy(out[i], (uint8_t *)ctx->d_scratch[1] + desc[i].out_off, ol[i], hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        if (!ok) rc = HG_ELAUNCH;
+    }
+    free(desc); free(ol);
+    return rc;
+}
+
 size_t hg_ransnx16_compress_bound(size_t n) { return n + n / 16 + 4 * 257 * 257 * 3 + 8192; }
 
 int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags, size_t n,

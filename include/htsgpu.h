@@ -150,6 +150,12 @@ int hg_rans4x8_decode_dev(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d
 int hg_rans4x8_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
                            uint8_t *const *out, const uint32_t *out_cap, uint32_t *out_len, int32_t *status);
 
+/* Encoder (replaces rans_compress as called by cram_compress_by_method, cram/cram_io.c:1834-1848).
+ * order[i] = 0 | 1.  out[i] must hold hg_rans4x8_compress_bound(in_len[i]) bytes.  Synchronous. */
+size_t hg_rans4x8_compress_bound(size_t in_len);
+int hg_rans4x8_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *order,
+                           size_t n, uint8_t *const *out, uint32_t *out_len);
+
 /* ---- CRAM 3.1 rANS Nx16 (replaces rans_uncompress_4x16 as called by cram_uncompress_block,
  *      cram/cram_io.c:1697-1714; CRAM block method 5).  PARITY UNPINNED: htscodecs is absent from
  *      the reference and no stock stream exists to check against (oracle/ransnx16_oracle.c). ---- */
