@@ -63,12 +63,20 @@ lib.hg_rans4x8_compress_bound.restype = C.c_size_t
 lib.hg_rans4x8_compress_bound.argtypes = [C.c_size_t]
 lib.hg_rans4x8_encode_host.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]
 
+lib.hg_gzip_compress_bound.restype = C.c_size_t
+lib.hg_gzip_compress_bound.argtypes = [C.c_size_t]
+lib.hg_cram_compress_bound.restype = C.c_size_t
+lib.hg_cram_compress_bound.argtypes = [C.c_size_t]
+lib.hg_gzip_deflate_host.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp, _vp]
+lib.hg_cram_compress_blocks_host.argtypes = [_vp, C.c_size_t, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
+
 EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info", "hg_bgzf_scan",
            "hg_bgzf_inflate_dev", "hg_bgzf_inflate_host", "hg_crc32_dev", "hg_bgzf_deflate_dev", "hg_bgzf_pack_dev",
            "hg_bgzf_deflate_host", "hg_rans4x8_decode_dev", "hg_rans4x8_decode_host",
            "hg_gzip_inflate_dev", "hg_cram_uncompress_blocks_host", "hg_ransnx16_decode_host", "hg_ransnx16_decode_dev",
            "hg_ransnx16_compress_bound", "hg_ransnx16_encode_host", "hg_rans4x8_compress_bound",
-           "hg_rans4x8_encode_host"]
+           "hg_rans4x8_encode_host", "hg_gzip_compress_bound", "hg_gzip_deflate_host", "hg_cram_compress_bound",
+           "hg_cram_compress_blocks_host"]
 
 
 class HgError(RuntimeError):
@@ -199,6 +207,34 @@ class Engine:
         if rc not in (0, -6):
             check(rc, "hg_cram_uncompress_blocks_host")
         return [outs[i].raw[:blocks[i][2]] if status[i] == 0 else None for i in range(n)], status
+
+    def _ptr_batch(self, datas, bound):
+        import numpy as np
+        n = len(datas)
+        ins = [(C.c_char * max(len(d), 1)).from_buffer_copy(d if len(d) else b"\0") for d in datas]
+        outs = [C.create_string_buffer(bound(len(d))) for d in datas]
+        return (ins, outs, (_vp * n)(*[C.addressof(x) for x in ins]), (_vp * n)(*[C.addressof(x) for x in outs]),
+                np.array([len(d) for d in datas], dtype=np.uint32), np.zeros(n, dtype=np.uint32))
+
+    def gzip_deflate_host(self, datas, level=6):
+        """Each bytes object -> one gzip member (CRAM GZIP block payload)."""
+        if not datas:
+            return []
+        ins, outs, ip, op, il, ol = self._ptr_batch(datas, lib.hg_gzip_compress_bound)
+        check(lib.hg_gzip_deflate_host(self._h, ip, il.ctypes.data, len(datas), level, op, ol.ctypes.data), "hg_gzip_deflate_host")
+        return [outs[i].raw[:int(ol[i])] for i in range(len(datas))]
+
+    def cram_compress_blocks(self, datas, masks, level=5):
+        """Trial-compress each block with every method in its mask; -> (list of payloads, method ids)."""
+        import numpy as np
+        if not datas:
+            return [], np.zeros(0, dtype=np.int32)
+        ins, outs, ip, op, il, ol = self._ptr_batch(datas, lib.hg_cram_compress_bound)
+        mk = np.array(masks, dtype=np.uint32)
+        used = np.full(len(datas), -9, dtype=np.int32)
+        check(lib.hg_cram_compress_blocks_host(self._h, len(datas), mk.ctypes.data, level, ip, il.ctypes.data, op,
+                                               ol.ctypes.data, used.ctypes.data), "hg_cram_compress_blocks_host")
+        return [outs[i].raw[:int(ol[i])] for i in range(len(datas))], used
 
     def rans4x8_encode_host(self, datas, orders):
         """rANS 4x8-encode each bytes object with the matching order (0/1) -> list of streams."""

@@ -193,7 +193,12 @@ __device__ __forceinline__ void pack_bits(Lds &S, uint32_t *out32, uint32_t &bit
 
 __global__ __launch_bounds__(WG)
 void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *__restrict__ desc, uint32_t nblocks,
-                         uint8_t *slots, uint32_t *clen_out, uint32_t *tokbuf, unsigned int *ticket, int level) {
+                         uint8_t *slots, uint32_t *clen_out, uint32_t *tokbuf, unsigned int *ticket, int level,
+                         int mode, uint32_t *crc_out) {
+    // mode 0: complete BGZF blocks.  mode 1: bare deflate blocks that concatenate into ONE stream
+    // (CRAM GZIP blocks, zlib_mem_deflate cram/cram_io.c:1222-1277): desc[b].clen bit 0 = this chunk is
+    // the last of its stream (BFINAL); every other chunk ends with an empty stored block (the zlib
+    // "sync flush" marker 00 00 FF FF) so that chunks are byte aligned; crc_out[b] = CRC-32 of the chunk.
     __shared__ Lds S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *tok = tokbuf + (size_t)blockIdx.x * 65536u;
@@ -211,6 +216,13 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
         uint8_t *o8 = slots + dsc.coff;
         uint32_t *o32 = (uint32_t *)o8;
 
+        const bool last_chunk = (dsc.clen & 1u) != 0;
+        if (n == 0 && mode == 1) {
+            const uint8_t fin[5] = {1, 0, 0, 0xff, 0xff};
+            if (last_chunk && tid < 5) o8[tid] = fin[tid];
+            if (tid == 0) { clen_out[b] = last_chunk ? 5u : 0u; if (crc_out) crc_out[b] = 0; }
+            continue;
+        }
         if (n == 0) {                                      // canonical EOF block (bgzf.c:566)
             const uint8_t eofb[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0,
                                       0, 0, 0, 0, 0, 0, 0, 0};
@@ -423,6 +435,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
             if (tid >= 64 && tid < 94) H.d_code[tid - 64] = hgdef::code_of(H.d_len, tid - 64, H.nxtB);
             if (tid == 0) {
                 uint32_t hb = hgdef::write_dynamic_header(H.ll_len, H.d_len, H.hdr, H.cl_sym, H.cl_ext, H.work, H.order);
+                if (mode == 1 && !last_chunk) H.hdr[0] &= 0xfe;                 // BFINAL = 0
                 uint32_t bits = hb;
                 for (int s = 0; s < 286; s++) {
                     uint32_t xb = 0;
@@ -439,7 +452,8 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
         const uint32_t dyn_bytes = (dyn_bits + 7u) >> 3;
         const bool stored = level == 0 || dyn_bytes >= n + 5u;
         // ---- BGZF header (BSIZE patched at the end) ------------------------------------------
-        if (tid < 18) {
+        const uint32_t hoff = mode == 1 ? 0u : 18u;
+        if (mode == 0 && tid < 18) {
             const uint8_t h18[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0, 0};
             o8[tid] = h18[tid];
         }
@@ -447,16 +461,16 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
         if (stored) {
             // 01 LEN NLEN data (bgzf.c:573-580, 652-667)
             if (tid == 0) {
-                o8[18] = 1; o8[19] = (uint8_t)n; o8[20] = (uint8_t)(n >> 8);
-                o8[21] = (uint8_t)~n; o8[22] = (uint8_t)(~n >> 8);
+                o8[hoff] = (mode == 1 && !last_chunk) ? 0 : 1; o8[hoff + 1] = (uint8_t)n; o8[hoff + 2] = (uint8_t)(n >> 8);
+                o8[hoff + 3] = (uint8_t)~n; o8[hoff + 4] = (uint8_t)(~n >> 8);
             }
-            for (uint32_t i = tid; i < n; i += WG) o8[23 + i] = in8[i];
-            total_len = 18u + 5u + n + 8u;
+            for (uint32_t i = tid; i < n; i += WG) o8[hoff + 5 + i] = in8[i];
+            total_len = hoff + 5u + n + (mode == 1 ? 0u : 8u);
         } else {
             Huff &H = S.u.h;
             for (int i = tid; i < 520; i += WG) H.obuf[i] = 0;
             __syncthreads();
-            uint32_t bitpos = 18u * 8u;
+            uint32_t bitpos = hoff * 8u;
             // the dynamic-block header, one byte per thread
             const uint32_t hbytes = (hdr_bits + 7u) >> 3;
             for (uint32_t i0 = 0; i0 < hbytes; i0 += WG) {
@@ -487,22 +501,31 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 }
                 pack_bits(S, o32, bitpos, v, nb, tid);
             }
+            // a chunk that is not the last of its stream continues with an empty stored block:
+            // 000 (BFINAL=0, BTYPE=00), pad to a byte, LEN=0000 NLEN=FFFF
+            if (mode == 1 && !last_chunk) { uint32_t nb = tid == 0 ? 3u : 0u; pack_bits(S, o32, bitpos, 0, nb, tid); }
             // pad to a byte boundary, then CRC32 + ISIZE as 8 single bytes
             {
                 uint32_t nb = 0; uint64_t v = 0;
                 if (tid == 0) nb = (8u - (bitpos & 7u)) & 7u;
                 pack_bits(S, o32, bitpos, v, nb, tid);
             }
-            total_len = (bitpos >> 3) + 8u;
+            if (mode == 1 && !last_chunk) {
+                { uint32_t nb = tid < 4 ? 8u : 0u; uint64_t v = tid >= 2 ? 0xffu : 0u; pack_bits(S, o32, bitpos, v, nb, tid); }
+            }
+            total_len = (bitpos >> 3) + (mode == 1 ? 0u : 8u);
             // flush the partial dword that is still in the staging window
             if (tid == 0 && (bitpos & 31u)) o32[bitpos >> 5] = H.obuf[0];
             __syncthreads();
         }
         if (tid == 0) {
-            uint8_t *t = o8 + total_len - 8;
-            for (int k = 0; k < 4; k++) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)(n >> (8 * k)); }
-            o8[16] = (uint8_t)(total_len - 1u); o8[17] = (uint8_t)((total_len - 1u) >> 8);
+            if (mode == 0) {
+                uint8_t *t = o8 + total_len - 8;
+                for (int k = 0; k < 4; k++) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)(n >> (8 * k)); }
+                o8[16] = (uint8_t)(total_len - 1u); o8[17] = (uint8_t)((total_len - 1u) >> 8);
+            }
             clen_out[b] = total_len;
+            if (crc_out) crc_out[b] = crc;
         }
         HD_TACC(4, tp); HD_TACC(0, tb);
 #ifdef HG_PROFILE
@@ -573,7 +596,7 @@ extern "C" int hg_debug_get_deflate_profile(unsigned long long *out16, int reset
 namespace hg {
 
 int launch_bgzf_deflate(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_desc, size_t nblocks, int level,
-                        void *d_slots, uint32_t *d_clen, hipStream_t s) {
+                        void *d_slots, uint32_t *d_clen, hipStream_t s, int mode, uint32_t *d_crc) {
     if (nblocks == 0) return HG_OK;
     if (nblocks > 0xffffffffull) return HG_EINVAL;
     size_t wgs = (size_t)ctx->cus * 2;
@@ -588,7 +611,7 @@ int launch_bgzf_deflate(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_
     if (hipMemsetAsync(ctx->d_ticket + 4, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
     hipLaunchKernelGGL(hgd::bgzf_deflate_kernel, dim3((unsigned)wgs), dim3(hgd::WG), 0, s, (const uint8_t *)d_plain,
                        d_desc, (uint32_t)nblocks, (uint8_t *)d_slots, d_clen, (uint32_t *)ctx->d_tok,
-                       ctx->d_ticket + 4, level);
+                       ctx->d_ticket + 4, level, mode, d_crc);
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
 

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 #include "htsgpu.h"
 #include "hg_internal.h"
 
@@ -522,6 +523,130 @@ int hg_rans4x8_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t
     if (rc == HG_OK)
         for (size_t i = 0; i < n; i++) { if (status) status[i] = st[i]; if (st[i] != 0) rc = HG_EBLOCK; }
     free(desc); free(st);
+    return rc;
+}
+
+// ---- host-side CRC-32 concatenation: crc(A||B) from crc(A), crc(B), |B| (GF(2) polynomial arithmetic) ----
+static uint32_t crc_mulmod_h(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) { if (a & (0x80000000u >> i)) p ^= b; b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1; }
+    return p;
+}
+static uint32_t crc_combine_h(uint32_t crc1, uint32_t crc2, uint64_t len2) {
+    uint32_t xp = 0x00800000u, acc = 0x80000000u;                    // x^8, x^0
+    for (; len2; len2 >>= 1) { if (len2 & 1) acc = crc_mulmod_h(acc, xp); xp = crc_mulmod_h(xp, xp); }
+    return crc_mulmod_h(acc, crc1) ^ crc2;
+}
+
+size_t hg_gzip_compress_bound(size_t n) { return n + (n / HG_BGZF_BLOCK_SIZE + 2) * 16 + 64; }
+
+int hg_gzip_deflate_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n, int level,
+                         uint8_t *const *out, uint32_t *out_len) {
+    if (!ctx || (n && (!in || !in_len || !out || !out_len)) || level < 0 || level > 9) return HG_EINVAL;
+    if (n == 0) return HG_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    size_t nchunks = 0; uint64_t total_in = 0;
+    for (size_t i = 0; i < n; i++) { nchunks += in_len[i] ? (in_len[i] + HG_BGZF_BLOCK_SIZE - 1) / HG_BGZF_BLOCK_SIZE : 1; total_in += ((uint64_t)in_len[i] + 15u) & ~15ull; }
+    hg_bgzf_desc *desc = (hg_bgzf_desc *)calloc(nchunks, sizeof(hg_bgzf_desc));
+    uint32_t *clen = (uint32_t *)malloc(nchunks * 4), *crc = (uint32_t *)malloc(nchunks * 4);
+    if (!desc || !clen || !crc) { free(desc); free(clen); free(crc); return HG_ENOMEM; }
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, total_in + 64)) || (rc = ensure_scratch(ctx, 1, nchunks * (size_t)HG_BGZF_MAX_BLOCK_SIZE + 64)) ||
+        (rc = ensure_scratch(ctx, 2, nchunks * sizeof(hg_bgzf_desc))) || (rc = ensure_scratch(ctx, 3, nchunks * 8 + 64))) {
+        free(desc); free(clen); free(crc); return rc;
+    }
+    hipStream_t s = nullptr;
+    bool ok = true;
+    uint64_t ioff = 0; size_t k = 0;
+    for (size_t i = 0; i < n && ok; i++) {
+        if (in_len[i]) ok = hipMemcpyAsync((uint8_t *)ctx->d_scratch[0] + ioff, in[i], in_len[i], hipMemcpyHostToDevice, s) == hipSuccess;
+        const size_t nc = in_len[i] ? (in_len[i] + HG_BGZF_BLOCK_SIZE - 1) / HG_BGZF_BLOCK_SIZE : 1;
+        for (size_t c = 0; c < nc; c++, k++) {
+            const uint64_t a = (uint64_t)c * HG_BGZF_BLOCK_SIZE;
+            desc[k].uoff = ioff + a;
+            desc[k].ulen = (uint32_t)(in_len[i] - a < HG_BGZF_BLOCK_SIZE ? in_len[i] - a : HG_BGZF_BLOCK_SIZE);
+            desc[k].coff = (uint64_t)k * HG_BGZF_MAX_BLOCK_SIZE;
+            desc[k].clen = c + 1 == nc ? 1u : 0u;                     // last chunk of its member
+        }
+        ioff += ((uint64_t)in_len[i] + 15u) & ~15ull;
+    }
+    uint32_t *d_clen = (uint32_t *)ctx->d_scratch[3], *d_crc = d_clen + nchunks;
+    ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc, nchunks * sizeof(hg_bgzf_desc), hipMemcpyHostToDevice, s) == hipSuccess;
+    rc = ok ? hg::launch_bgzf_deflate(ctx, ctx->d_scratch[0], (const hg_bgzf_desc *)ctx->d_scratch[2], nchunks, level,
+                                      ctx->d_scratch[1], d_clen, s, 1, d_crc) : HG_ELAUNCH;
+    if (rc == HG_OK) {
+        ok = hipMemcpyAsync(clen, d_clen, nchunks * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipMemcpyAsync(crc, d_crc, nchunks * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        k = 0;
+        for (size_t i = 0; i < n && ok; i++) {
+            const size_t nc = in_len[i] ? (in_len[i] + HG_BGZF_BLOCK_SIZE - 1) / HG_BGZF_BLOCK_SIZE : 1;
+            uint8_t *o = out[i];
+            const uint8_t hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
+            memcpy(o, hdr, 10);
+            size_t pos = 10; uint32_t c32 = 0;
+            for (size_t c = 0; c < nc && ok; c++, k++) {
+                if (clen[k]) ok = hipMemcpy(o + pos, (uint8_t *)ctx->d_scratch[1] + desc[k].coff, clen[k], hipMemcpyDeviceToHost) == hipSuccess;
+                pos += clen[k];
+                c32 = c == 0 ? crc[k] : crc_combine_h(c32, crc[k], desc[k].ulen);
+            }
+            for (int b = 0; b < 4; b++) { o[pos + b] = (uint8_t)(c32 >> (8 * b)); o[pos + 4 + b] = (uint8_t)(in_len[i] >> (8 * b)); }
+            out_len[i] = (uint32_t)(pos + 8);
+        }
+        if (!ok) rc = HG_ELAUNCH;
+    }
+    free(desc); free(clen); free(crc);
+    return rc;
+}
+
+size_t hg_cram_compress_bound(size_t n) {
+    size_t a = hg_gzip_compress_bound(n), b = hg_rans4x8_compress_bound(n), c = hg_ransnx16_compress_bound(n);
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
+}
+
+int hg_cram_compress_blocks_host(hg_ctx *ctx, size_t n, const uint32_t *method_mask, int level, const uint8_t *const *in,
+                                 const uint32_t *in_len, uint8_t *const *out, uint32_t *out_len, int32_t *method_used) {
+    if (!ctx || (n && (!method_mask || !in || !in_len || !out || !out_len || !method_used))) return HG_EINVAL;
+    // start from RAW (sz_best = uncomp_size, cram_io.c:2001)
+    for (size_t i = 0; i < n; i++) { out_len[i] = in_len[i]; method_used[i] = HG_CRAM_RAW; if (in_len[i]) memcpy(out[i], in[i], in_len[i]); }
+    if (level == 0) return HG_OK;                                      // cram_io.c:1967-1972
+    std::vector<uint8_t *> tmp(n, nullptr);
+    std::vector<const uint8_t *> sin; std::vector<uint8_t *> sout; std::vector<uint32_t> slen, solen; std::vector<size_t> map;
+    std::vector<uint8_t> par;
+    auto keep = [&](size_t k) {                                        // candidate k beat the incumbent?
+        const size_t i = map[k];
+        if (solen[k] && solen[k] < out_len[i]) { memcpy(out[i], sout[k], solen[k]); out_len[i] = solen[k]; return true; }
+        return false;
+    };
+    auto gather = [&](uint32_t bit) {
+        sin.clear(); sout.clear(); slen.clear(); map.clear();
+        for (size_t i = 0; i < n; i++) if (in_len[i] && (method_mask[i] >> bit) & 1u) {
+            if (!tmp[i]) tmp[i] = (uint8_t *)malloc(hg_cram_compress_bound(in_len[i]));
+            sin.push_back(in[i]); sout.push_back(tmp[i]); slen.push_back(in_len[i]); map.push_back(i);
+        }
+        solen.assign(sin.size(), 0);
+    };
+    int rc = HG_OK;
+    gather(HG_CRAM_GZIP);
+    if (!sin.empty()) {
+        rc = hg_gzip_deflate_host(ctx, sin.data(), slen.data(), sin.size(), level, sout.data(), solen.data());
+        for (size_t k = 0; rc == HG_OK && k < sin.size(); k++) if (keep(k)) method_used[map[k]] = HG_CRAM_GZIP;
+    }
+    for (int order = 0; order < 2 && rc == HG_OK; order++) {
+        gather(HG_CRAM_RANS4x8);
+        if (sin.empty()) break;
+        par.assign(sin.size(), (uint8_t)order);
+        rc = hg_rans4x8_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
+        for (size_t k = 0; rc == HG_OK && k < sin.size(); k++) if (keep(k)) method_used[map[k]] = HG_CRAM_RANS4x8;
+    }
+    for (int order = 0; order < 2 && rc == HG_OK; order++) {
+        gather(HG_CRAM_RANSNx16);
+        if (sin.empty()) break;
+        par.resize(sin.size());
+        for (size_t k = 0; k < sin.size(); k++) par[k] = (uint8_t)(order | (slen[k] >= 65536u ? 4 : 0));   // 32-way for big inputs
+        rc = hg_ransnx16_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
+        for (size_t k = 0; rc == HG_OK && k < sin.size(); k++) if (keep(k)) method_used[map[k]] = HG_CRAM_RANSNx16;
+    }
+    for (auto p : tmp) free(p);
     return rc;
 }
 

@@ -199,6 +199,25 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
                                    const uint32_t *in_len, uint8_t *const *out, const uint32_t *out_len,
                                    int32_t *status);
 
+/* gzip-wrapped deflate of whole buffers (CRAM block method GZIP on the write side: zlib_mem_deflate /
+ * libdeflate_deflate, cram/cram_io.c:1113-1148,1222-1277).  Each buffer becomes ONE gzip member: it is
+ * deflated in 0xff00-byte chunks by the BGZF deflate kernel (matches do not cross chunks, chunks are
+ * joined with empty stored blocks).  out[i] must hold hg_gzip_compress_bound(in_len[i]).  Synchronous. */
+size_t hg_gzip_compress_bound(size_t in_len);
+int hg_gzip_deflate_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n, int level,
+                         uint8_t *const *out, uint32_t *out_len);
+
+/* Batch form of cram_compress_block's trial phase (cram/cram_io.c:1912-2325): block i is compressed
+ * with EVERY method whose bit is set in method_mask[i] and the smallest result is kept; RAW is kept
+ * when nothing beats it (cram_io.c:2001,2271-2278).  Bits: 1<<HG_CRAM_GZIP, 1<<HG_CRAM_RANS4x8 (orders 0
+ * and 1 are both tried), 1<<HG_CRAM_RANSNx16 (order 0/1, 32-way for inputs >= 64 KiB like
+ * RANS_ORDER_SIMD_AUTO).  method_used[i] = on-disk method id of the winner; out[i] must hold
+ * hg_cram_compress_bound(in_len[i]).  No cross-slice metrics are kept (every call is a trial). */
+size_t hg_cram_compress_bound(size_t in_len);
+int hg_cram_compress_blocks_host(hg_ctx *ctx, size_t n, const uint32_t *method_mask, int level,
+                                 const uint8_t *const *in, const uint32_t *in_len, uint8_t *const *out,
+                                 uint32_t *out_len, int32_t *method_used);
+
 /* ---- CRC-32 (replaces hts_crc32, bgzf.c:557-559 / 620-622) -------------- */
 /* crc[i] = crc32(0, d_data + off[i], len[i]) for n independent buffers. */
 int hg_crc32_dev(hg_ctx *ctx, const void *d_data,

@@ -66,3 +66,47 @@ def test_status_codes(engine):
     outs, st = engine.cram_uncompress_blocks(blocks)
     assert list(st) == [0, -2, -1, -1, -3, -3, 0, -1, 0]
     assert outs[0] == d and outs[6] == d and outs[1] is None
+
+
+def test_gzip_members_written_by_the_gpu_decode_everywhere(engine, oracle):
+    """CRAM GZIP blocks on the write side: one gzip member per data series, deflated in 64 KiB chunks
+    joined by empty stored blocks.  Must decode with zlib (what stock htslib uses), with our inflate
+    kernel, and stay close to zlib level 6 in size."""
+    rng = np.random.default_rng(4)
+    plain_bam, _ = synth.bam_bgzf(2 << 20)
+    series = [plain_bam, synth.fastq(700_000), bytes(300_000), rng.integers(0, 256, 200_000, dtype=np.uint8).tobytes(),
+              b"", b"x", b"ab" * 40000, synth.fastq(0xFF00 * 2)[:0xFF00 * 2], synth.fastq(70_000)[:0xFF00 + 1]]
+    outs = engine.gzip_deflate_host(series, level=6)
+    for d, g in zip(series, outs):
+        assert g[:3] == b"\x1f\x8b\x08"
+        assert zlib.decompress(g, 15 + 16) == d
+        assert gzip.decompress(g) == d
+    back, st = engine.cram_uncompress_blocks([(1, g, len(d)) for d, g in zip(series, outs)])
+    assert (st == 0).all() and back == series
+    # zlib sees one 32 KiB sliding window over the whole series; our chunks restart the window every 0xff00 bytes
+    assert len(outs[0]) <= 1.12 * len(zlib.compress(series[0], 6))
+
+
+def test_cram_compress_blocks_trial_selection_and_roundtrip(engine):
+    """cram_compress_block's trial phase in batch form: smallest of the enabled methods wins, RAW when
+    nothing shrinks the block; whatever is chosen decodes through the block layer."""
+    from tests.test_rans4x8 import synth_series
+    rng = np.random.default_rng(10)
+    G, R4, RN = 1 << 1, 1 << 4, 1 << 5
+    datas = [synth_series(rng, "qual4", 300_000), synth_series(rng, "qual41", 150_000), synth_series(rng, "bases", 150_000),
+             rng.integers(0, 256, 50_000, dtype=np.uint8).tobytes(), rng.integers(0, 256, 4000, dtype=np.uint8).tobytes() * 50, b"", b"A", bytes(100_000),
+             synth_series(rng, "qual41", 150_000), synth_series(rng, "qual41", 150_000)]
+    masks = [G | R4 | RN] * 8 + [G, R4]
+    outs, used = engine.cram_compress_blocks(datas, masks, level=5)
+    assert used[3] == 0 and outs[3] == datas[3]                      # random bytes stay RAW
+    assert used[5] == 0 and outs[5] == b"" and used[6] == 0
+    assert used[0] in (4, 5) and len(outs[0]) < 0.2 * len(datas[0])  # Markov qualities: an order-1 rANS wins
+    assert used[4] == 1                                              # long repeats of flat-histogram bytes: only deflate wins
+    assert used[8] == 1 and used[9] == 4                             # only the enabled method is tried
+    for d, o, u in zip(datas, outs, used):
+        assert len(o) <= len(d)
+    back, st = engine.cram_uncompress_blocks([(int(u), o, len(d)) for d, o, u in zip(datas, outs, used)])
+    assert (st == 0).all() and back == datas
+    # level 0 = store (cram_io.c:1967-1972)
+    outs0, used0 = engine.cram_compress_blocks(datas[:3], masks[:3], level=0)
+    assert list(used0) == [0, 0, 0] and outs0 == datas[:3]
