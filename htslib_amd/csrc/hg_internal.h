@@ -30,6 +30,23 @@ int launch_rans4x8_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d
 int launch_ransnx16_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_sel4,
                            size_t n4, const uint32_t *d_sel32, size_t n32, void *d_out, int32_t *d_status,
                            uint32_t *d_scratch, hipStream_t s);
+// One post-entropy-decode job of an Nx16 stream (ransnx16_xform.hip): [RLE expand] -> [bit unpack] -> strided write.
+struct nx16_xform {
+    uint64_t s1_off;       // work buffer: entropy-decoded bytes (lit_len of them)
+    uint64_t meta_off;     // RLE meta stream: in the work buffer (ops & 4) or in the input buffer
+    uint64_t s2_off;       // work buffer: RLE output when a PACK step follows
+    uint64_t out_off;      // output buffer: first byte written
+    uint32_t lit_len, meta_len, plen, ulen;
+    uint32_t stride;       // output byte i goes to out_off + i * stride (STRIPE de-interleave)
+    uint32_t ops;          // 1 RLE, 2 PACK, 4 meta lives in the work buffer
+    uint32_t nsym;         // PACK symbol count (<= 16)
+    uint32_t dep0, dep1;   // status slots of the entropy-decode jobs this one consumes (0xffffffff = none)
+    uint8_t map[16];
+    uint32_t pad[3];
+};
+int launch_ransnx16_xform(hg_ctx *ctx, const void *d_in, void *d_work, void *d_out, const nx16_xform *d_jobs, size_t njobs,
+                          int32_t *d_status, uint32_t status_base, hipStream_t s);
+int ensure_scratch(hg_ctx *ctx, int slot, size_t bytes);
 uint32_t ransnx16_enc_scratch_words(uint32_t flags);
 int launch_ransnx16_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags,
                            const uint32_t *d_sel4, size_t n4, const uint32_t *d_sel32, size_t n32, void *d_out,

@@ -15,7 +15,8 @@
 
 #define HG_VERSION_STRING "htsgpu 0.1 (gfx950)"
 
-static int ensure_scratch(hg_ctx *ctx, int slot, size_t bytes) {
+namespace hg {
+int ensure_scratch(hg_ctx *ctx, int slot, size_t bytes) {
     if (ctx->d_scratch_cap[slot] >= bytes) return HG_OK;
     if (ctx->d_scratch[slot]) (void)hipFree(ctx->d_scratch[slot]);
     ctx->d_scratch[slot] = nullptr; ctx->d_scratch_cap[slot] = 0;
@@ -24,6 +25,8 @@ static int ensure_scratch(hg_ctx *ctx, int slot, size_t bytes) {
     ctx->d_scratch_cap[slot] = cap;
     return HG_OK;
 }
+}  // namespace hg
+using hg::ensure_scratch;
 
 extern "C" {
 
@@ -113,72 +116,6 @@ int hg_ransnx16_decode_dev(hg_ctx *ctx, const void *d_in, const hg_stream_desc *
     if (!ctx || ((n4 || n32) && (!d_in || !d_desc || !d_out || !d_status || !d_scratch))) return HG_EINVAL;
     if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
     return hg::launch_ransnx16_decode(ctx, d_in, d_desc, d_sel4, n4, d_sel32, n32, d_out, d_status, d_scratch, (hipStream_t)stream);
-}
-
-// words of order-1 table scratch a stream may need (host peeks at the stream header)
-static uint64_t nx16_scratch_words(const uint8_t *p, uint32_t len) {
-    if (len < 2) return 16;
-    const uint8_t *cp = p, *end = p + len;
-    const uint32_t flags = *cp++;
-    if (!(flags & 0x10)) { int n = 0; while (cp < end && n < 5 && (*cp++ & 0x80)) n++; }
-    if (!(flags & 1) || (flags & (0x20 | 0x08))) return 16;
-    if (cp >= end) return 16;
-    const uint32_t comp = *cp++ & 1u;
-    uint64_t tab_bytes = len, extra = 0;
-    if (comp) {
-        uint32_t ulen = 0; int n = 0; uint8_t c;
-        do { if (cp >= end) return 16; c = *cp++; ulen = (ulen << 7) | (c & 0x7f); } while ((c & 0x80) && ++n < 5);
-        if (ulen > 262144u) ulen = 262144u;
-        tab_bytes = ulen; extra = (ulen + 3) / 4;
-    }
-    uint64_t entries = tab_bytes < 65536u + 256u ? tab_bytes : 65536u + 256u;
-    return 512 + extra + entries + 256 + 16;
-}
-
-int hg_ransnx16_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
-                            uint8_t *const *out, const uint32_t *out_len, int32_t *status) {
-    if (!ctx || (n && (!in || !in_len || !out || !out_len))) return HG_EINVAL;
-    if (n == 0) return HG_OK;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
-    hg_stream_desc *desc = (hg_stream_desc *)calloc(n, sizeof(hg_stream_desc));
-    int32_t *st = (int32_t *)malloc(n * sizeof(int32_t));
-    uint32_t *sel = (uint32_t *)malloc(n * sizeof(uint32_t));
-    if (!desc || !st || !sel) { free(desc); free(st); free(sel); return HG_ENOMEM; }
-    uint64_t ioff = 0, ooff = 0, soff = 0;
-    size_t n4 = 0, n32 = 0;
-    for (size_t i = 0; i < n; i++) {
-        desc[i].in_off = ioff; desc[i].in_len = in_len[i]; desc[i].out_off = ooff; desc[i].out_len = out_len[i];
-        desc[i].scratch_off = (uint32_t)soff;
-        ioff += ((uint64_t)in_len[i] + 15u) & ~15ull;
-        ooff += ((uint64_t)out_len[i] + 15u) & ~15ull;
-        soff += nx16_scratch_words(in[i], in_len[i]);
-        if (soff > 0xffffffffull) { free(desc); free(st); free(sel); return HG_EINVAL; }
-        if (in_len[i] && (in[i][0] & 4)) n32++; else n4++;
-    }
-    { size_t a = 0, b = n4; for (size_t i = 0; i < n; i++) { if (in_len[i] && (in[i][0] & 4)) sel[b++] = (uint32_t)i; else sel[a++] = (uint32_t)i; } }
-    int rc;
-    if ((rc = ensure_scratch(ctx, 0, ioff + 64)) || (rc = ensure_scratch(ctx, 1, ooff + 64)) ||
-        (rc = ensure_scratch(ctx, 2, n * sizeof(hg_stream_desc))) || (rc = ensure_scratch(ctx, 3, n * 4)) ||
-        (rc = ensure_scratch(ctx, 6, soff * 4 + 64)) || (rc = ensure_scratch(ctx, 7, n * 4 + 64))) { free(desc); free(st); free(sel); return rc; }
-    hipStream_t s = nullptr;
-    bool ok = hipMemsetAsync(ctx->d_scratch[3], 0xff, n * 4, s) == hipSuccess;
-    for (size_t i = 0; i < n && ok; i++)
-        if (in_len[i]) ok = hipMemcpyAsync((uint8_t *)ctx->d_scratch[0] + desc[i].in_off, in[i], in_len[i], hipMemcpyHostToDevice, s) == hipSuccess;
-    ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc, n * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess &&
-         hipMemcpyAsync(ctx->d_scratch[7], sel, n * 4, hipMemcpyHostToDevice, s) == hipSuccess;
-    rc = ok ? hg::launch_ransnx16_decode(ctx, ctx->d_scratch[0], (const hg_stream_desc *)ctx->d_scratch[2],
-                                         (const uint32_t *)ctx->d_scratch[7], n4, (const uint32_t *)ctx->d_scratch[7] + n4, n32,
-                                         ctx->d_scratch[1], (int32_t *)ctx->d_scratch[3], (uint32_t *)ctx->d_scratch[6], s) : HG_ELAUNCH;
-    if (rc == HG_OK) {
-        ok = hipMemcpyAsync(st, ctx->d_scratch[3], n * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-        for (size_t i = 0; i < n && ok; i++)
-            if (out_len[i] && st[i] == 0) ok = hipMemcpy(out[i], (uint8_t *)ctx->d_scratch[1] + desc[i].out_off, out_len[i], hipMemcpyDeviceToHost) == hipSuccess;
-        if (!ok) rc = HG_ELAUNCH;
-    }
-    if (rc == HG_OK)
-        for (size_t i = 0; i < n; i++) { if (status) status[i] = st[i]; if (st[i] != 0) rc = HG_EBLOCK; }
-    free(desc); free(st); free(sel);
-    return rc;
 }
 
 size_t hg_rans4x8_compress_bound(size_t n) { return n + n / 16 + 257 * 257 * 3 + 9 + 64; }

@@ -13,8 +13,11 @@
 // shuffles.  Order-0 tables: 257-entry cumulative array per stream in LDS, slot -> symbol by binary
 // search.  Order-1 tables: sparse per-context (cumulative, symbol) lists in a global scratch area
 // (L1/L2 resident for quality-value alphabets).  Tables are parsed by the first lane of the group.
-// Handled here: flags ORDER, X32, NOSZ (size from the descriptor), CAT.  PACK / RLE / STRIPE
-// streams are reported as unsupported (-3) for now.
+// Handled here: flags ORDER, X32, NOSZ (size from the descriptor), CAT.  The PACK / RLE / STRIPE
+// transforms are undone by ransnx16_xform.hip after this kernel: the host planner
+// (ransnx16_host.hip) parses their headers and hands this kernel pre-parsed core descriptors
+// (desc.reserved bit 31).  Raw streams carrying those flags are reported -3 by THIS kernel, which is
+// what the device-resident entry point (hg_ransnx16_decode_dev) returns for them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "htsgpu.h"
@@ -128,7 +131,11 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
             const hg_stream_desc d = desc[sidx];
             cp = in + d.in_off; end = cp + d.in_len;
             o = out + d.out_off; tabs = scratch + d.scratch_off;
-            if (d.in_len < 1) err = 1;
+            if (d.reserved & 0x80000000u) {                       // header already parsed by the host planner
+                flags = d.reserved & (F_ORDER | F_X32 | F_CAT);
+                usz = d.out_len;
+                if (((flags & F_X32) ? 32 : 4) != N) err = 1;
+            } else if (d.in_len < 1) err = 1;
             else {
                 flags = *cp++;
                 if (flags & F_NOSZ) usz = d.out_len;

@@ -160,11 +160,14 @@ int hg_rans4x8_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t
  *      cram/cram_io.c:1697-1714; CRAM block method 5).  PARITY UNPINNED: htscodecs is absent from
  *      the reference and no stock stream exists to check against (oracle/ransnx16_oracle.c). ---- */
 /* Decode n streams; out_len[i] = expected plaintext size (cram_block.uncomp_size, also the size
- * for NOSZ streams).  Handles order 0/1, 4-way and 32-way (X32), NOSZ, CAT; streams using PACK, RLE
- * or STRIPE get status -3 (HG_BLOCK_EUNSUPPORTED).  Synchronous.  Returns 0 or HG_EBLOCK. */
+ * for NOSZ streams).  Handles every flag: order 0/1, 4-way and 32-way (X32), NOSZ, CAT, and the PACK /
+ * RLE / STRIPE transforms (headers planned on the host, all payload work in the gfx950 kernels
+ * ransnx16.hip + ransnx16_xform.hip).  Synchronous.  Returns 0 or HG_EBLOCK. */
 int hg_ransnx16_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
                             uint8_t *const *out, const uint32_t *out_len, int32_t *status);
-/* device form: d_sel4 / d_sel32 list the descriptor indices of the 4-way / 32-way streams */
+/* device form (entropy core only): d_sel4 / d_sel32 list the descriptor indices of the 4-way / 32-way
+ * streams; a stream whose flag byte carries PACK, RLE or STRIPE gets status -3 here -- use the host form,
+ * which plans those transforms. */
 int hg_ransnx16_decode_dev(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_sel4,
                            size_t n4, const uint32_t *d_sel32, size_t n32, void *d_out, int32_t *d_status,
                            uint32_t *d_scratch, void *stream);

@@ -461,7 +461,6 @@ static size_t compress_inner(const uint8_t *in, size_t n, uint8_t *out, int flag
         free(tmp);
         return (size_t)(cp - out);
     }
-    if (flags & F_CAT) { out[0] = (uint8_t)flags; memcpy(cp, in, n); return (size_t)(cp - out) + n; }
     uint8_t *packed = NULL, *lit = NULL, *rmeta = NULL;
     const uint8_t *cur = in; size_t cur_n = n;
     if (flags & F_PACK) {
@@ -476,15 +475,28 @@ static size_t compress_inner(const uint8_t *in, size_t n, uint8_t *out, int flag
         size_t ml = 0, ll = cur_n ? rle_encode(cur, cur_n, rmeta, &ml, lit) : (size_t)-1;
         if (ll == (size_t)-1) flags &= ~F_RLE;
         else {
-            cp += put_u7(cp, (uint32_t)(ml * 2 + 1));        /* meta stored raw */
-            cp += put_u7(cp, (uint32_t)ll);
-            memcpy(cp, rmeta, ml); cp += ml;
+            /* the meta stream is itself order-0 4-way coded when that is smaller than storing it raw */
+            uint8_t *cm = malloc(orc_ransnx16_compress_bound(ml));
+            size_t cl = enc_o0(rmeta, ml, cm, 4);
+            if (cl + 5 < ml) {
+                cp += put_u7(cp, (uint32_t)(ml * 2));
+                cp += put_u7(cp, (uint32_t)ll);
+                cp += put_u7(cp, (uint32_t)cl);
+                memcpy(cp, cm, cl); cp += cl;
+            } else {
+                cp += put_u7(cp, (uint32_t)(ml * 2 + 1));    /* meta stored raw */
+                cp += put_u7(cp, (uint32_t)ll);
+                memcpy(cp, rmeta, ml); cp += ml;
+            }
+            free(cm);
             cur = lit; cur_n = ll;
         }
     }
     if ((flags & F_ORDER) && cur_n < (size_t)N * 2) flags &= ~F_ORDER;   /* tiny inputs: order 0 */
     out[0] = (uint8_t)flags;
-    if (cur_n) cp += (flags & F_ORDER) ? enc_o1(cur, cur_n, cp, N) : enc_o0(cur, cur_n, cp, N);
+    /* CAT replaces only the entropy coder: the PACK / RLE transforms above still apply */
+    if (flags & F_CAT) { memcpy(cp, cur, cur_n); cp += cur_n; }
+    else if (cur_n) cp += (flags & F_ORDER) ? enc_o1(cur, cur_n, cp, N) : enc_o0(cur, cur_n, cp, N);
     free(packed); free(lit); free(rmeta);
     return (size_t)(cp - out);
 }
@@ -522,7 +534,6 @@ static int uncompress_inner(const uint8_t *in, size_t in_size, uint8_t *out, siz
         free(tmp);
         return 0;
     }
-    if (flags & F_CAT) { if (cp + ulen > end) return -1; memcpy(out, cp, ulen); return 0; }
     int nsym = 0; uint8_t map[16] = {0}; uint32_t plen = ulen;
     if (flags & F_PACK) {
         if (cp >= end) return -1;
@@ -530,12 +541,16 @@ static int uncompress_inner(const uint8_t *in, size_t in_size, uint8_t *out, siz
         if (nsym > 16 || cp + nsym > end) return -1;
         memcpy(map, cp, nsym); cp += nsym;
         int k = get_u7(cp, end, &plen); if (k < 0) return -1; cp += k;
+        if (plen > ulen) return -1;                           /* resource guard: packing never grows the data */
     }
     uint32_t rmeta_len = 0, lit_len = plen; const uint8_t *rmeta = NULL; uint8_t *rmeta_free = NULL;
     if (flags & F_RLE) {
         uint32_t v; int k = get_u7(cp, end, &v); if (k < 0) return -1; cp += k;
         k = get_u7(cp, end, &lit_len); if (k < 0) return -1; cp += k;
         rmeta_len = v >> 1;
+        /* resource guards: every literal yields >= 1 byte; the meta stream holds at most a 257-byte symbol
+         * list and one 5-byte run length per literal */
+        if (lit_len > plen || rmeta_len > 5ull * lit_len + 257) return -1;
         if (v & 1) { if (cp + rmeta_len > end) return -1; rmeta = cp; cp += rmeta_len; }
         else {
             uint32_t cl; k = get_u7(cp, end, &cl); if (k < 0 || cp + k + cl > end) return -1; cp += k;
@@ -546,7 +561,8 @@ static int uncompress_inner(const uint8_t *in, size_t in_size, uint8_t *out, siz
     }
     int rc = 0;
     uint8_t *stage1 = (flags & (F_RLE | F_PACK)) ? malloc((size_t)lit_len + 8) : out;
-    if (lit_len) rc = (flags & F_ORDER) ? dec_o1(cp, (size_t)(end - cp), stage1, lit_len, N) : dec_o0(cp, (size_t)(end - cp), stage1, lit_len, N);
+    if (flags & F_CAT) { if ((size_t)(end - cp) < lit_len) rc = -1; else memcpy(stage1, cp, lit_len); }
+    else if (lit_len) rc = (flags & F_ORDER) ? dec_o1(cp, (size_t)(end - cp), stage1, lit_len, N) : dec_o0(cp, (size_t)(end - cp), stage1, lit_len, N);
     uint8_t *stage2 = stage1;
     if (!rc && (flags & F_RLE)) {
         stage2 = (flags & F_PACK) ? malloc((size_t)plen + 8) : out;

@@ -8,8 +8,9 @@ import pytest
 from tests import refutil
 from tests.test_rans4x8 import synth_series
 
-ALL_FLAGS = [0, 1, 4, 5, 0x20, 0x80, 0x81, 0x84, 0x40, 0x41, 0x44, 0xC0, 0xC1, 0xC5, 0x08, 0x09, 0x0C, 0x0D]
-GPU_FLAGS = [0, 1, 4, 5, 0x20, 0x24]
+ALL_FLAGS = [0, 1, 4, 5, 0x20, 0x80, 0x81, 0x84, 0x40, 0x41, 0x44, 0xC0, 0xC1, 0xC5, 0x08, 0x09, 0x0C, 0x0D,
+             0x24, 0xA0, 0x60, 0xE0, 0xE4]
+GPU_FLAGS = ALL_FLAGS
 SIZES = (0, 1, 2, 3, 4, 7, 8, 9, 31, 32, 33, 63, 64, 65, 100, 1000, 4097, 150_000)
 
 
@@ -52,10 +53,39 @@ def test_gpu_matches_oracle(engine, norc):
     outs, st = engine.cram_uncompress_blocks(blocks)
     assert (st == 0).all()
     assert outs == want
-    # flags the kernel does not handle yet are reported, not mis-decoded
-    d = synth_series(rng, "qual4", 5000)
-    outs, st = engine.cram_uncompress_blocks([(5, norc.encode(d, fl), len(d)) for fl in (0x80, 0x40, 0x08)])
-    assert list(st) == [-3, -3, -3]
+
+
+def runs_series(rng, n, nsym=6, mean=40):
+    """Long runs of a few symbols: what the RLE transform is for (and big enough run counts that the
+    oracle rANS-codes the RLE meta stream)."""
+    out = bytearray()
+    while len(out) < n:
+        out += bytes([int(rng.integers(0, nsym)) + 33]) * int(rng.geometric(1.0 / mean))
+    return bytes(out[:n])
+
+
+@pytest.mark.gpu
+def test_gpu_transforms_rle_pack_stripe(engine, norc):
+    """PACK / RLE / STRIPE are undone on the device (ransnx16_xform.hip) after the entropy decode."""
+    rng = np.random.default_rng(77)
+    cases = []
+    for n in (1, 5, 63, 64, 65, 4096, 70_000, 1_200_000):
+        cases += [runs_series(rng, n), runs_series(rng, n, nsym=2, mean=3), runs_series(rng, n, nsym=16, mean=900),
+                  bytes([65]) * n, synth_series(rng, "bases", n)]
+    u32 = rng.integers(0, 50_000, 100_000, dtype=np.uint32).tobytes()          # what STRIPE is for
+    cases += [u32, u32[:-3], rng.integers(0, 256, 3000, dtype=np.uint8).tobytes()]
+    blocks, want = [], []
+    for d in cases:
+        for fl in (0x40, 0x41, 0x80, 0xC0, 0xC1, 0xC5, 0x08, 0x09, 0x0D, 0xE0, 0x50, 0x90):
+            e = norc.encode(d, fl)
+            if not fl & 0x10:                    # NOSZ streams need the size from outside (the CRAM block header)
+                rc, back = norc.decode(e, len(d))
+                assert rc == 0 and back == d
+            blocks.append((5, e, len(d))); want.append(d)
+    assert any(not (e[1][0] & 0x10) and (e[1][0] & 0x40) for e in blocks)
+    outs, st = engine.cram_uncompress_blocks(blocks)
+    bad = [(i, hex(blocks[i][1][0]), blocks[i][2]) for i in range(len(blocks)) if st[i] != 0 or outs[i] != want[i]]
+    assert not bad, bad[:10]
 
 
 @pytest.mark.gpu
@@ -66,10 +96,12 @@ def test_gpu_big_quality_streams_and_fuzz(engine, norc):
     outs, st = engine.cram_uncompress_blocks([(5, s, len(d)) for s in streams])
     assert (st == 0).all() and all(o == d for o in outs)
     small = synth_series(rng, "qual41", 20_000)
-    base = [norc.encode(small, fl) for fl in (0, 1, 4, 5)]
+    runs = (small[:200] + bytes([70]) * 300) * 40
+    base = [norc.encode(small, fl) for fl in (0, 1, 4, 5)] + [norc.encode(runs, fl) for fl in (0xC1, 0x40, 0x09, 0x80)]
+    assert len(runs) == len(small)
     bad = []
-    for rep in range(200):
-        b = bytearray(base[rep & 3])
+    for rep in range(400):
+        b = bytearray(base[rep & 7])
         pos = int(rng.integers(1, len(b)))
         b[pos] ^= 1 << int(rng.integers(0, 8))
         bad.append(bytes(b))
