@@ -46,6 +46,18 @@ struct nx16_xform {
 };
 int launch_ransnx16_xform(hg_ctx *ctx, const void *d_in, void *d_work, void *d_out, const nx16_xform *d_jobs, size_t njobs,
                           int32_t *d_status, uint32_t status_base, hipStream_t s);
+// Encoder-side transform job (ransnx16_xenc.hip): [gather stripe] -> [PACK] -> [RLE]; offsets into ONE buffer.
+struct nx16_xenc {
+    uint64_t src_off, g_off, p_off, l_off, m_off;
+    uint32_t n, stride, flags, pad;
+};
+struct nx16_xenc_res {
+    uint64_t cur_off;      // where the bytes to entropy-code ended up
+    uint32_t cur_len, flags, nsym, plen, lit_len, meta_len;
+    uint8_t map[16];
+    uint64_t pad;
+};
+int launch_ransnx16_xenc(hg_ctx *ctx, void *d_buf, const nx16_xenc *d_jobs, size_t njobs, nx16_xenc_res *d_res, hipStream_t s);
 int ensure_scratch(hg_ctx *ctx, int slot, size_t bytes);
 uint32_t ransnx16_enc_scratch_words(uint32_t flags);
 int launch_ransnx16_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags,

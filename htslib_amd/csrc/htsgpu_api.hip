@@ -167,57 +167,6 @@ int hg_rans4x8_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t
 
 size_t hg_ransnx16_compress_bound(size_t n) { return n + n / 16 + 4 * 257 * 257 * 3 + 8192; }
 
-int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags, size_t n,
-                            uint8_t *const *out, uint32_t *out_len) {
-    if (!ctx || (n && (!in || !in_len || !flags || !out || !out_len))) return HG_EINVAL;
-    if (n == 0) return HG_OK;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
-    hg_stream_desc *desc = (hg_stream_desc *)calloc(n, sizeof(hg_stream_desc));
-    uint32_t *sel = (uint32_t *)malloc(n * 4), *ol = (uint32_t *)malloc(n * 4);
-    if (!desc || !sel || !ol) { free(desc); free(sel); free(ol); return HG_ENOMEM; }
-    uint64_t ioff = 0, ooff = 0, soff = 0, woff = 0;
-    size_t n4 = 0, n32 = 0;
-    for (size_t i = 0; i < n; i++) {
-        const uint64_t cap = hg_ransnx16_compress_bound(in_len[i]);
-        desc[i].in_off = ioff; desc[i].in_len = in_len[i]; desc[i].out_off = ooff; desc[i].out_len = (uint32_t)(cap > 0xffffffffull ? 0xffffffffu : cap);
-        desc[i].scratch_off = (uint32_t)soff; desc[i].reserved = (uint32_t)(woff / 16);
-        ioff += ((uint64_t)in_len[i] + 15u) & ~15ull;
-        ooff += (cap + 15u) & ~15ull;
-        soff += hg::ransnx16_enc_scratch_words(flags[i]);
-        woff += (2ull * in_len[i] + 256u + 15u) & ~15ull;
-        if (soff > 0xffffffffull || woff / 16 > 0xffffffffull) { free(desc); free(sel); free(ol); return HG_EINVAL; }
-        if (flags[i] & 4) n32++; else n4++;
-    }
-    { size_t a = 0, b = n4; for (size_t i = 0; i < n; i++) { if (flags[i] & 4) sel[b++] = (uint32_t)i; else sel[a++] = (uint32_t)i; } }
-    int rc;
-    if ((rc = ensure_scratch(ctx, 0, ioff + 64)) || (rc = ensure_scratch(ctx, 1, ooff + 64)) ||
-        (rc = ensure_scratch(ctx, 2, n * sizeof(hg_stream_desc))) || (rc = ensure_scratch(ctx, 3, n * 4 + n + 64)) ||
-        (rc = ensure_scratch(ctx, 4, woff + 64)) || (rc = ensure_scratch(ctx, 6, soff * 4 + 64)) ||
-        (rc = ensure_scratch(ctx, 7, n * 4 + 64))) { free(desc); free(sel); free(ol); return rc; }
-    hipStream_t s = nullptr;
-    uint32_t *d_ol = (uint32_t *)ctx->d_scratch[3];
-    uint8_t *d_fl = (uint8_t *)ctx->d_scratch[3] + n * 4;
-    bool ok = hipMemsetAsync(d_ol, 0, n * 4, s) == hipSuccess;
-    for (size_t i = 0; i < n && ok; i++)
-        if (in_len[i]) ok = hipMemcpyAsync((uint8_t *)ctx->d_scratch[0] + desc[i].in_off, in[i], in_len[i], hipMemcpyHostToDevice, s) == hipSuccess;
-    ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc, n * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess &&
-         hipMemcpyAsync(ctx->d_scratch[7], sel, n * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
-         hipMemcpyAsync(d_fl, flags, n, hipMemcpyHostToDevice, s) == hipSuccess;
-    rc = ok ? hg::launch_ransnx16_encode(ctx, ctx->d_scratch[0], (const hg_stream_desc *)ctx->d_scratch[2], d_fl,
-                                         (const uint32_t *)ctx->d_scratch[7], n4, (const uint32_t *)ctx->d_scratch[7] + n4, n32,
-                                         ctx->d_scratch[1], d_ol, ctx->d_scratch[4], (uint32_t *)ctx->d_scratch[6], s) : HG_ELAUNCH;
-    if (rc == HG_OK) {
-        ok = hipMemcpyAsync(ol, d_ol, n * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-        for (size_t i = 0; i < n && ok; i++) {
-            out_len[i] = ol[i];
-            if (ol[i]) ok = hipMemcpy(out[i], (uint8_t *)ctx->d_scratch[1] + desc[i].out_off, ol[i], hipMemcpyDeviceToHost) == hipSuccess;
-        }
-        if (!ok) rc = HG_ELAUNCH;
-    }
-    free(desc); free(sel); free(ol);
-    return rc;
-}
-
 int hg_gzip_inflate_dev(hg_ctx *ctx, const void *d_comp, size_t comp_len, const hg_bgzf_desc *d_desc, size_t n,
                         void *d_out, size_t out_cap, int32_t *d_status, void *stream) {
     if (!ctx || (n && (!d_comp || !d_desc || !d_status))) return HG_EINVAL;
@@ -575,11 +524,14 @@ int hg_cram_compress_blocks_host(hg_ctx *ctx, size_t n, const uint32_t *method_m
         rc = hg_rans4x8_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
         for (size_t k = 0; rc == HG_OK && k < sin.size(); k++) if (keep(k)) method_used[map[k]] = HG_CRAM_RANS4x8;
     }
-    for (int order = 0; order < 2 && rc == HG_OK; order++) {
+    // RANS_PR0, PR1 always; PR64, PR9, PR128, PR193 above level 1; PR129, PR192 above level 5 (cram_encode.c:818-826)
+    static const uint8_t nx16_sets[] = {0, 1, 64, 9, 128, 193, 129, 192};
+    const int nsets = level > 5 ? 8 : level > 1 ? 6 : 2;
+    for (int v = 0; v < nsets && rc == HG_OK; v++) {
         gather(HG_CRAM_RANSNx16);
         if (sin.empty()) break;
         par.resize(sin.size());
-        for (size_t k = 0; k < sin.size(); k++) par[k] = (uint8_t)(order | (slen[k] >= 65536u ? 4 : 0));   // 32-way for big inputs
+        for (size_t k = 0; k < sin.size(); k++) par[k] = (uint8_t)(nx16_sets[v] | (slen[k] >= 65536u ? 4 : 0));   // 32-way for big inputs
         rc = hg_ransnx16_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
         for (size_t k = 0; rc == HG_OK && k < sin.size(); k++) if (keep(k)) method_used[map[k]] = HG_CRAM_RANSNx16;
     }

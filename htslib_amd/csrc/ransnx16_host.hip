@@ -214,3 +214,185 @@ extern "C" int hg_ransnx16_decode_host(hg_ctx *ctx, const uint8_t *const *in, co
         for (size_t i = 0; i < n; i++) { if (status) status[i] = st[i]; if (st[i] != 0) rc = HG_EBLOCK; }
     return rc;
 }
+
+// ================================================================================================
+// Encoder: hg_ransnx16_encode_host (replaces rans_compress_4x16, call site cram/cram_io.c:1853-1866).
+// Mirror image of the decoder plan: STRIPE / PACK / RLE run first (ransnx16_xenc.hip), their results
+// (how many literals, which symbols...) come back in one small D2H, then every piece that needs entropy
+// coding -- the data of each leaf and each RLE meta stream -- goes through the core encoder
+// (ransnx16_enc.hip) in one launch, and the host stitches headers and pieces together in the layout
+// of oracle/ransnx16_oracle.c compress_inner() (byte-identical output).
+// ================================================================================================
+namespace {
+
+struct Leaf {
+    uint32_t top, n, stride, flags;     // flags as requested for this leaf
+    uint64_t src_off;                   // in the device buffer
+    const uint8_t *host_src;            // non-null when the leaf is the untouched host input
+    int xjob, core, mcore;
+    hg::nx16_xenc_res r;
+};
+
+int put_u7(uint8_t *cp, uint32_t v) {
+    uint8_t tmp[5]; int n = 0;
+    do { tmp[n++] = v & 0x7f; v >>= 7; } while (v);
+    for (int i = n - 1; i >= 0; i--) *cp++ = tmp[i] | (i ? 0x80 : 0);
+    return n;
+}
+
+}  // namespace
+
+extern "C" int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags, size_t n,
+                                       uint8_t *const *out, uint32_t *out_len) {
+    if (!ctx || (n && (!in || !in_len || !flags || !out || !out_len))) return HG_EINVAL;
+    if (n == 0) return HG_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    std::vector<Leaf> leaves;
+    std::vector<hg::nx16_xenc> xj;
+    std::vector<uint64_t> ioffs(n);
+    std::vector<uint32_t> first_leaf(n + 1);
+    uint64_t ioff = 0;
+    for (size_t i = 0; i < n; i++) { ioffs[i] = ioff; ioff += ((uint64_t)in_len[i] + 15u) & ~15ull; }
+    uint64_t work = (ioff + 63u) & ~63ull;                                    // work area follows the inputs
+    auto walloc = [&](uint64_t bytes) { const uint64_t o = work; work += (bytes + 31u) & ~15ull; return o; };
+    for (size_t i = 0; i < n; i++) {
+        first_leaf[i] = (uint32_t)leaves.size();
+        uint32_t f = flags[i];
+        const uint32_t S = (f & F_STRIPE) ? 4u : 1u;
+        if (f & F_STRIPE) f &= ~(uint32_t)(F_PACK | F_RLE | F_CAT);
+        for (uint32_t k = 0; k < S; k++) {
+            Leaf L;
+            memset(&L, 0, sizeof L);
+            L.top = (uint32_t)i; L.stride = S; L.src_off = ioffs[i] + k;
+            L.n = S == 1 ? in_len[i] : in_len[i] / S + ((in_len[i] % S) > k ? 1u : 0u);
+            L.flags = S == 1 ? f : ((f & (F_ORDER | F_X32)) | F_NOSZ);
+            L.host_src = S == 1 ? in[i] : nullptr;
+            L.xjob = L.core = L.mcore = -1;
+            if (S != 1 || (L.flags & (F_PACK | F_RLE))) {
+                hg::nx16_xenc J;
+                memset(&J, 0, sizeof J);
+                J.src_off = L.src_off; J.n = L.n; J.stride = S; J.flags = L.flags;
+                if (S != 1) J.g_off = walloc(L.n);
+                if (L.flags & F_PACK) J.p_off = walloc(L.n / 2 + 8);
+                if (L.flags & F_RLE) { J.l_off = walloc(L.n); J.m_off = walloc((uint64_t)L.n + 300); }
+                L.xjob = (int)xj.size(); xj.push_back(J);
+            }
+            leaves.push_back(L);
+        }
+    }
+    first_leaf[n] = (uint32_t)leaves.size();
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, work + 64)) || (rc = ensure_scratch(ctx, 4, xj.size() * (sizeof(hg::nx16_xenc) + sizeof(hg::nx16_xenc_res)) + 64))) return rc;
+    hipStream_t s = nullptr;
+    uint8_t *d_buf = (uint8_t *)ctx->d_scratch[0];
+    bool ok = true;
+    for (size_t i = 0; i < n && ok; i++)
+        if (in_len[i]) ok = hipMemcpyAsync(d_buf + ioffs[i], in[i], in_len[i], hipMemcpyHostToDevice, s) == hipSuccess;
+    std::vector<hg::nx16_xenc_res> xr(xj.size());
+    if (ok && !xj.empty()) {
+        hg::nx16_xenc *d_j = (hg::nx16_xenc *)ctx->d_scratch[4];
+        hg::nx16_xenc_res *d_r = (hg::nx16_xenc_res *)(d_j + xj.size());
+        ok = hipMemcpyAsync(d_j, xj.data(), xj.size() * sizeof(hg::nx16_xenc), hipMemcpyHostToDevice, s) == hipSuccess;
+        if (ok && (rc = hg::launch_ransnx16_xenc(ctx, d_buf, d_j, xj.size(), d_r, s))) return rc;
+        ok = ok && hipMemcpyAsync(xr.data(), d_r, xj.size() * sizeof(hg::nx16_xenc_res), hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipStreamSynchronize(s) == hipSuccess;
+    }
+    if (!ok) return HG_ELAUNCH;
+    // ---- entropy-coding jobs ------------------------------------------------------------------
+    std::vector<hg_stream_desc> cd;
+    std::vector<uint8_t> cfl;
+    uint64_t ooff = 0, soff = 0, woff = 0;
+    bool too_big = false;
+    auto add_core = [&](uint64_t src_off, uint32_t len, uint32_t fl) {
+        hg_stream_desc d;
+        memset(&d, 0, sizeof d);
+        const uint64_t cap = (fl & F_ORDER) ? hg_ransnx16_compress_bound(len) : (uint64_t)len + len / 16 + 4096;
+        d.in_off = src_off; d.in_len = len; d.out_off = ooff; d.out_len = (uint32_t)(cap > 0xffffffffull ? 0xffffffffu : cap);
+        d.scratch_off = (uint32_t)soff; d.reserved = (uint32_t)(woff / 16);
+        ooff += (cap + 15u) & ~15ull;
+        soff += hg::ransnx16_enc_scratch_words(fl);
+        woff += (2ull * len + 256u + 15u) & ~15ull;
+        if (soff > 0xffffffffull || woff / 16 > 0xffffffffull) too_big = true;
+        cd.push_back(d); cfl.push_back((uint8_t)fl);
+        return (int)cd.size() - 1;
+    };
+    for (Leaf &L : leaves) {
+        if (L.xjob >= 0) L.r = xr[L.xjob];
+        else { L.r.flags = L.flags; L.r.cur_off = L.src_off; L.r.cur_len = L.n; }
+        const uint32_t N = (L.r.flags & F_X32) ? 32u : 4u;
+        if ((L.r.flags & F_ORDER) && L.r.cur_len < 2u * N) L.r.flags &= ~(uint32_t)F_ORDER;
+        if (L.r.flags & F_RLE) L.mcore = add_core(xj[L.xjob].m_off, L.r.meta_len, F_NOSZ);
+        if (!(L.r.flags & F_CAT) && L.r.cur_len) L.core = add_core(L.r.cur_off, L.r.cur_len, (L.r.flags & (F_ORDER | F_X32)) | F_NOSZ);
+    }
+    if (too_big) return HG_EINVAL;
+    const size_t nc = cd.size();
+    std::vector<uint32_t> sel(nc), ol(nc, 0);
+    size_t n4 = 0, n32 = 0;
+    for (size_t k = 0; k < nc; k++) { if (cfl[k] & F_X32) n32++; else n4++; }
+    { size_t a = 0, b = n4; for (size_t k = 0; k < nc; k++) { if (cfl[k] & F_X32) sel[b++] = (uint32_t)k; else sel[a++] = (uint32_t)k; } }
+    uint8_t *d_out = nullptr;
+    if (nc) {
+        if ((rc = ensure_scratch(ctx, 1, ooff + 64)) || (rc = ensure_scratch(ctx, 2, nc * sizeof(hg_stream_desc) + 64)) ||
+            (rc = ensure_scratch(ctx, 3, nc * 5 + 64)) || (rc = ensure_scratch(ctx, 5, woff + 64)) ||
+            (rc = ensure_scratch(ctx, 6, soff * 4 + 64)) || (rc = ensure_scratch(ctx, 7, nc * 4 + 64))) return rc;
+        d_out = (uint8_t *)ctx->d_scratch[1];
+        uint32_t *d_ol = (uint32_t *)ctx->d_scratch[3];
+        uint8_t *d_fl = (uint8_t *)ctx->d_scratch[3] + nc * 4;
+        ok = hipMemsetAsync(d_ol, 0, nc * 4, s) == hipSuccess &&
+             hipMemcpyAsync(ctx->d_scratch[2], cd.data(), nc * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess &&
+             hipMemcpyAsync(ctx->d_scratch[7], sel.data(), nc * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+             hipMemcpyAsync(d_fl, cfl.data(), nc, hipMemcpyHostToDevice, s) == hipSuccess;
+        if (!ok) return HG_ELAUNCH;
+        rc = hg::launch_ransnx16_encode(ctx, d_buf, (const hg_stream_desc *)ctx->d_scratch[2], d_fl, (const uint32_t *)ctx->d_scratch[7], n4,
+                                        (const uint32_t *)ctx->d_scratch[7] + n4, n32, d_out, d_ol, ctx->d_scratch[5],
+                                        (uint32_t *)ctx->d_scratch[6], s);
+        if (rc) return rc;
+        if (hipMemcpyAsync(ol.data(), d_ol, nc * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+    }
+    // ---- stitch --------------------------------------------------------------------------------
+    auto fetch = [&](uint8_t *dst, const uint8_t *d_src, size_t len) { if (len && ok) ok = hipMemcpy(dst, d_src, len, hipMemcpyDeviceToHost) == hipSuccess; };
+    auto emit_leaf = [&](uint8_t *cp, const Leaf &L) -> uint8_t * {
+        const uint32_t f = L.r.flags;
+        *cp++ = (uint8_t)f;
+        if (!(f & F_NOSZ)) cp += put_u7(cp, L.n);
+        if (f & F_PACK) { *cp++ = (uint8_t)L.r.nsym; memcpy(cp, L.r.map, L.r.nsym); cp += L.r.nsym; cp += put_u7(cp, L.r.plen); }
+        if (f & F_RLE) {
+            const uint32_t ml = L.r.meta_len, cl = ol[L.mcore] ? ol[L.mcore] - 1u : 0u;   // core output minus its flag byte
+            if (cl + 5u < ml) {
+                cp += put_u7(cp, ml * 2u); cp += put_u7(cp, L.r.lit_len); cp += put_u7(cp, cl);
+                fetch(cp, d_out + cd[L.mcore].out_off + 1, cl); cp += cl;
+            } else {
+                cp += put_u7(cp, ml * 2u + 1u); cp += put_u7(cp, L.r.lit_len);
+                fetch(cp, d_buf + xj[L.xjob].m_off, ml); cp += ml;
+            }
+        }
+        if (f & F_CAT) {
+            if (L.xjob < 0 && L.host_src) { memcpy(cp, L.host_src, L.r.cur_len); }
+            else fetch(cp, d_buf + L.r.cur_off, L.r.cur_len);
+            cp += L.r.cur_len;
+        } else if (L.core >= 0) {
+            const uint32_t bl = ol[L.core] ? ol[L.core] - 1u : 0u;
+            fetch(cp, d_out + cd[L.core].out_off + 1, bl); cp += bl;
+        }
+        return cp;
+    };
+    std::vector<uint8_t> tmp;
+    for (size_t i = 0; i < n && ok; i++) {
+        uint8_t *cp = out[i];
+        const uint32_t l0 = first_leaf[i], nl = first_leaf[i + 1] - l0;
+        if (nl == 1) cp = emit_leaf(cp, leaves[l0]);
+        else {
+            const uint32_t f = flags[i] & ~(uint32_t)(F_PACK | F_RLE | F_CAT);
+            *cp++ = (uint8_t)f;
+            if (!(f & F_NOSZ)) cp += put_u7(cp, in_len[i]);
+            *cp++ = (uint8_t)nl;
+            // sub-streams are laid out after their length list: build them in a side buffer first
+            tmp.resize(hg_ransnx16_compress_bound(in_len[i]));
+            uint8_t *tp = tmp.data();
+            for (uint32_t k = 0; k < nl; k++) { uint8_t *e = emit_leaf(tp, leaves[l0 + k]); cp += put_u7(cp, (uint32_t)(e - tp)); tp = e; }
+            memcpy(cp, tmp.data(), (size_t)(tp - tmp.data())); cp += tp - tmp.data();
+        }
+        out_len[i] = (uint32_t)(cp - out[i]);
+    }
+    return ok ? HG_OK : HG_ELAUNCH;
+}

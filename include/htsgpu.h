@@ -173,8 +173,10 @@ int hg_ransnx16_decode_dev(hg_ctx *ctx, const void *d_in, const hg_stream_desc *
                            uint32_t *d_scratch, void *stream);
 
 /* Encoder (replaces rans_compress_4x16 as called by cram_compress_by_method,
- * cram/cram_io.c:1853-1866).  flags[i]: bit 0x01 order-1, 0x04 32-way, 0x10 NOSZ, 0x20 CAT (the
- * RANS_ORDER_* bits of cram/cram_external.c:616-624); PACK / RLE / STRIPE are not applied yet.
+ * cram/cram_io.c:1853-1866).  flags[i]: bit 0x01 order-1, 0x04 32-way, 0x08 STRIPE (4 stripes), 0x10 NOSZ,
+ * 0x20 CAT, 0x40 RLE, 0x80 PACK (the RANS_ORDER_* bits of cram/cram_external.c:616-624), i.e. every
+ * RANS_PR* set of cram_io.c:1856.  PACK / RLE are dropped from the stream's flag byte when they do not
+ * apply (more than 16 distinct symbols / no symbol worth run-length coding).
  * out[i] must hold hg_ransnx16_compress_bound(in_len[i]) bytes.  Synchronous. */
 size_t hg_ransnx16_compress_bound(size_t in_len);
 int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags,
@@ -213,8 +215,9 @@ int hg_gzip_deflate_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *
 /* Batch form of cram_compress_block's trial phase (cram/cram_io.c:1912-2325): block i is compressed
  * with EVERY method whose bit is set in method_mask[i] and the smallest result is kept; RAW is kept
  * when nothing beats it (cram_io.c:2001,2271-2278).  Bits: 1<<HG_CRAM_GZIP, 1<<HG_CRAM_RANS4x8 (orders 0
- * and 1 are both tried), 1<<HG_CRAM_RANSNx16 (order 0/1, 32-way for inputs >= 64 KiB like
- * RANS_ORDER_SIMD_AUTO).  method_used[i] = on-disk method id of the winner; out[i] must hold
+ * and 1 are both tried), 1<<HG_CRAM_RANSNx16 (flag sets {0,1} / +{64,9,128,193} above level 1 /
+ * +{129,192} above level 5 as cram_compress_slice builds them, cram/cram_encode.c:818-826; 32-way for
+ * inputs >= 64 KiB like RANS_ORDER_SIMD_AUTO).  method_used[i] = on-disk method id of the winner; out[i] must hold
  * hg_cram_compress_bound(in_len[i]).  No cross-slice metrics are kept (every call is a trial). */
 size_t hg_cram_compress_bound(size_t in_len);
 int hg_cram_compress_blocks_host(hg_ctx *ctx, size_t n, const uint32_t *method_mask, int level,
