@@ -1,0 +1,349 @@
+// arith.hip -- CRAM 3.1 adaptive arithmetic ("range") coder, block method 6, for MI355X (gfx950).
+//
+// Replaces arith_uncompress_to / arith_compress_to as called by cram_uncompress_block /
+// cram_compress_by_method (reference cram/cram_io.c:1716-1733, 1869-1883; implementation = htscodecs
+// arith_dynamic.c, an ABSENT submodule).  Format and arithmetic per oracle/arith_oracle.c -- PARITY
+// UNPINNED; the kernels are bit-exact with that oracle.
+//
+// The coder is adaptive: symbol i+1 cannot be decoded before the model update of symbol i, so a stream
+// is one serial dependency chain and the parallelism is ACROSS streams (a CRAM slice holds ~25 blocks, a
+// batch of slices thousands; STRIPE adds 4 per block).  Mapping: one wavefront per stream.
+//   * range-coder registers (low/code, range, input cursor) are wave-uniform scalars;
+//   * a model is an array of (freq << 8 | symbol) words kept sorted by frequency in LDS (global scratch when
+//     an order-1 alphabet is too big for the per-wave pool); the symbol search is done by all 64 lanes at
+//     once: one coalesced LDS read, a DPP prefix sum, one ballot -- constant time instead of the CPU's walk
+//     down the list; the halving of a model is lane-parallel as well;
+//   * the compressed bytes are read 64 at a time into one VGPR and picked out with v_readlane.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "htsgpu.h"
+#include "hg_device.h"
+#include "hg_internal.h"
+
+namespace hga {
+using hg::wave_sync;
+using hg::wave_incl_scan_dpp;
+
+constexpr uint32_t STEP = 16, MAX_FREQ = (1u << 16) - 17u, TOP = 1u << 24;
+enum { F_ORDER = 1, F_RLE = 64 };
+
+__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+
+// 64-byte window over the compressed stream: lane l holds byte pos0 + l
+struct ByteWindow {
+    const uint8_t *base; uint32_t len, pos0, idx, win; bool overrun;
+    __device__ void init(const uint8_t *b, uint32_t n, int lane) { base = b; len = n; pos0 = 0; idx = 0; overrun = false; load(lane); }
+    __device__ void load(int lane) { const uint32_t p = pos0 + (uint32_t)lane; win = p < len ? base[p] : 0u; }
+    __device__ uint32_t next(int lane) {
+        if (idx == 64) { pos0 += 64; idx = 0; load(lane); }
+        if (pos0 + idx >= len) overrun = true;
+        return rl(win, idx++);
+    }
+};
+
+// Layout of a stream's model memory (32-bit words): nl literal models of m entries, their nl totals, then
+// (RLE) 258 run models of 4 entries and their 258 totals.
+struct Models {
+    uint32_t *M; uint32_t m, nl;
+    __device__ uint32_t lit(uint32_t k) const { return k * m; }
+    __device__ uint32_t lit_tot(uint32_t k) const { return nl * m + k; }
+    __device__ uint32_t run(uint32_t k) const { return nl * (m + 1) + k * 4; }
+    __device__ uint32_t run_tot(uint32_t k) const { return nl * (m + 1) + 258 * 4 + k; }
+};
+__host__ __device__ inline uint32_t model_words(uint32_t m, uint32_t order, uint32_t rle) { return (order ? m : 1u) * (m + 1u) + (rle ? 258u * 5u : 0u); }
+
+__device__ void models_init(const Models &Q, bool rle, int lane) {
+    for (uint32_t i = (uint32_t)lane; i < Q.nl * Q.m; i += 64) Q.M[i] = (1u << 8) | (i % Q.m);
+    for (uint32_t i = (uint32_t)lane; i < Q.nl; i += 64) Q.M[Q.nl * Q.m + i] = Q.m;
+    if (rle) {
+        for (uint32_t i = (uint32_t)lane; i < 258 * 4; i += 64) Q.M[Q.run(0) + i] = (1u << 8) | (i & 3u);
+        for (uint32_t i = (uint32_t)lane; i < 258; i += 64) Q.M[Q.run_tot(0) + i] = 4u;
+    }
+    wave_sync();
+}
+
+// After the coder step: bump entry x of the model at B (n entries, total at T), halve when due, keep sorted.
+// f_x / f_prev are the frequencies of entries x and x-1 as read before the bump.
+__device__ __forceinline__ void model_update(uint32_t *M, uint32_t B, uint32_t n, uint32_t T, uint32_t tot, uint32_t x,
+                                             uint32_t e_x, int lane) {
+    uint32_t ex = e_x + (STEP << 8);
+    tot += STEP;
+    if (tot > MAX_FREQ) {                                            // halve every frequency (rare)
+        if (lane == 0) M[B + x] = ex;
+        wave_sync();
+        uint32_t sum = 0;
+        for (uint32_t b = 0; b < n; b += 64) {
+            const uint32_t i = b + (uint32_t)lane;
+            uint32_t f = 0;
+            if (i < n) { const uint32_t e = M[B + i]; f = e >> 8; f -= f >> 1; M[B + i] = (f << 8) | (e & 0xffu); }
+            sum += rl(wave_incl_scan_dpp(f), 63);
+        }
+        tot = sum;
+        wave_sync();
+        ex = M[B + x];
+    }
+    if (x > 0) {
+        const uint32_t ep = M[B + x - 1];
+        if ((ex >> 8) > (ep >> 8)) { if (lane == 0) { M[B + x] = ep; M[B + x - 1] = ex; } }
+        else if (lane == 0) M[B + x] = ex;
+    } else if (lane == 0) M[B + x] = ex;
+    if (lane == 0) M[T] = tot;
+    wave_sync();
+}
+
+struct Decoder {
+    uint32_t code, range; ByteWindow in; int err;
+    __device__ void start(const uint8_t *b, uint32_t n, int lane) {
+        in.init(b, n, lane); err = 0; code = 0; range = 0xffffffffu;
+        for (int i = 0; i < 5; i++) code = (code << 8) | in.next(lane);
+    }
+    // decodes one symbol with the model at B (n entries, total at T)
+    __device__ uint32_t symbol(uint32_t *M, uint32_t B, uint32_t n, uint32_t T, int lane) {
+        const uint32_t tot = M[T];
+        const uint32_t r = range / tot, freq = code / r;
+        if (freq >= tot) { err = 1; return 0; }
+        uint32_t acc0 = 0, x = 0, ex = 0, acc = 0;
+        for (uint32_t b = 0; b < n; b += 64) {
+            const uint32_t i = b + (uint32_t)lane;
+            const uint32_t e = i < n ? M[B + i] : 0u;
+            const uint32_t incl = acc0 + wave_incl_scan_dpp(e >> 8);
+            const unsigned long long hit = __ballot(i < n && incl > freq);
+            if (hit) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(hit);
+                x = b + l; ex = rl(e, l); acc = rl(incl, l) - (ex >> 8);
+                break;
+            }
+            acc0 = rl(incl, 63);
+        }
+        const uint32_t f = ex >> 8;
+        code -= acc * r; range = r * f;
+        while (range < TOP) { code = (code << 8) | in.next(lane); range <<= 8; }
+        model_update(M, B, n, T, tot, x, ex, lane);
+        return ex & 0xffu;
+    }
+};
+
+template <int POOLW, int WAVES>
+__global__ __launch_bounds__(WAVES * 64)
+void arith_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc, const uint32_t *__restrict__ sel,
+                         uint32_t nsel, uint8_t *out, int32_t *status, uint32_t *gscratch) {
+    __shared__ uint32_t pool[WAVES][POOLW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t k = blockIdx.x * WAVES + wv; k < nsel; k += gridDim.x * WAVES) {
+        const uint32_t sidx = sel[k];
+        const hg_stream_desc d = desc[sidx];
+        const uint32_t flags = d.reserved & 0xffu, order = flags & F_ORDER, rle = (flags & F_RLE) ? 1u : 0u;
+        const uint8_t *cp = in + d.in_off;
+        uint8_t *o = out + d.out_off;
+        const uint32_t n = d.out_len;
+        int err = 0;
+        if (d.in_len < 1) err = 1;
+        if (!err && n) {
+            Models Q;
+            Q.m = cp[0] ? cp[0] : 256u; Q.nl = order ? Q.m : 1u;
+            Q.M = model_words(Q.m, order, rle) <= (uint32_t)POOLW ? pool[wv] : gscratch + d.scratch_off;
+            models_init(Q, rle != 0, lane);
+            Decoder D;
+            D.start(cp + 1, d.in_len - 1, lane);
+            uint32_t last = 0, keep = 0;
+            if (!rle) {
+                for (uint32_t i = 0; i < n; i++) {
+                    const uint32_t ctx = order ? last : 0u;
+                    const uint32_t c = D.symbol(Q.M, Q.lit(ctx), Q.m, Q.lit_tot(ctx), lane);
+                    if (D.err) break;
+                    last = c;
+                    if ((uint32_t)lane == (i & 63u)) keep = c;
+                    if ((i & 63u) == 63u) o[i - 63u + (uint32_t)lane] = (uint8_t)keep;   // 64 symbols per store
+                }
+                if (!D.err && (n & 63u) && (uint32_t)lane < (n & 63u)) o[(n & ~63u) + (uint32_t)lane] = (uint8_t)keep;
+            } else {
+                for (uint32_t i = 0; i < n;) {
+                    const uint32_t ctx = order ? last : 0u;
+                    const uint32_t c = D.symbol(Q.M, Q.lit(ctx), Q.m, Q.lit_tot(ctx), lane);
+                    if (D.err) break;
+                    last = c;
+                    unsigned long long r = 0; uint32_t rctx = c, part;
+                    do {
+                        part = D.symbol(Q.M, Q.run(rctx), 4, Q.run_tot(rctx), lane);
+                        if (D.err) break;
+                        rctx = rctx == c ? 256u : 257u;
+                        r += part;
+                        if (r >= n) D.err = 1;
+                    } while (part == 3 && !D.err);
+                    if (D.err) break;
+                    if ((unsigned long long)i + 1ull + r > n) { D.err = 1; break; }
+                    for (uint32_t p = (uint32_t)lane; p <= (uint32_t)r; p += 64) o[i + p] = (uint8_t)c;
+                    i += (uint32_t)r + 1u;
+                }
+            }
+            if (D.err || D.in.overrun) err = 1;
+        }
+        status[sidx] = err ? -1 : 0;                                 // every lane stores the same word
+        wave_sync();
+    }
+}
+
+}  // namespace hga
+
+namespace hg {
+uint32_t arith_model_words(uint32_t max_sym, uint32_t flags) { return hga::model_words(max_sym ? max_sym : 256u, flags & 1u, (flags & 64u) ? 1u : 0u); }
+
+int launch_arith_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_sel_small, size_t nsmall,
+                        const uint32_t *d_sel_big, size_t nbig, void *d_out, int32_t *d_status, uint32_t *d_scratch, hipStream_t s) {
+    const size_t maxw = (size_t)ctx->cus * 8;
+    if (nsmall) {
+        size_t wgs = (nsmall + 3) / 4;
+        if (wgs > maxw) wgs = maxw;
+        hipLaunchKernelGGL((hga::arith_decode_kernel<HG_ARITH_POOL_SMALL, 4>), dim3((unsigned)wgs), dim3(256), 0, s, (const uint8_t *)d_in,
+                           d_desc, d_sel_small, (uint32_t)nsmall, (uint8_t *)d_out, d_status, d_scratch);
+    }
+    if (nbig) {
+        size_t wgs = nbig;
+        if (wgs > maxw) wgs = maxw;
+        hipLaunchKernelGGL((hga::arith_decode_kernel<HG_ARITH_POOL_BIG, 1>), dim3((unsigned)wgs), dim3(64), 0, s, (const uint8_t *)d_in,
+                           d_desc, d_sel_big, (uint32_t)nbig, (uint8_t *)d_out, d_status, d_scratch);
+    }
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+}  // namespace hg
+
+// ================================================================================================
+// Encoder
+// ================================================================================================
+namespace hga {
+
+struct Encoder {
+    uint32_t low, range, carry, cache, ffnum;
+    uint8_t *out; uint32_t opos, oidx, obuf;                         // 64 output bytes are gathered in one VGPR
+    __device__ void start(uint8_t *o) { low = 0; range = 0xffffffffu; carry = 0; cache = 0; ffnum = 0; out = o; opos = 0; oidx = 0; obuf = 0; }
+    __device__ void put(uint32_t b, int lane) {
+        obuf = hg::writelane(b & 0xffu, oidx, obuf);
+        if (++oidx == 64) { out[opos + (uint32_t)lane] = (uint8_t)obuf; opos += 64; oidx = 0; }
+    }
+    __device__ void shift_low(int lane) {
+        if (low < 0xff000000u || carry) {
+            put(cache + carry, lane);
+            while (ffnum) { put(carry - 1u, lane); ffnum--; }
+            cache = low >> 24; carry = 0;
+        } else ffnum++;
+        low <<= 8;
+    }
+    __device__ void encode(uint32_t cum, uint32_t freq, uint32_t tot, int lane) {
+        const uint32_t old = low;
+        range /= tot;
+        low += cum * range;
+        range *= freq;
+        if (low < old) carry = 1;
+        while (range < TOP) { range <<= 8; shift_low(lane); }
+    }
+    __device__ uint32_t finish(int lane) {
+        for (int i = 0; i < 5; i++) shift_low(lane);
+        if ((uint32_t)lane < oidx) out[opos + (uint32_t)lane] = (uint8_t)obuf;
+        return opos + oidx;
+    }
+    // codes `sym` with the model at B (n entries, total at T)
+    __device__ void symbol(uint32_t *M, uint32_t B, uint32_t n, uint32_t T, uint32_t sym, int lane) {
+        const uint32_t tot = M[T];
+        uint32_t acc0 = 0, x = 0, ex = 0, acc = 0;
+        for (uint32_t b = 0; b < n; b += 64) {
+            const uint32_t i = b + (uint32_t)lane;
+            const uint32_t e = i < n ? M[B + i] : 0u;
+            const uint32_t incl = acc0 + wave_incl_scan_dpp(e >> 8);
+            const unsigned long long hit = __ballot(i < n && (e & 0xffu) == sym);
+            if (hit) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(hit);
+                x = b + l; ex = rl(e, l); acc = rl(incl, l) - (ex >> 8);
+                break;
+            }
+            acc0 = rl(incl, 63);
+        }
+        encode(acc, ex >> 8, tot, lane);
+        model_update(M, B, n, T, tot, x, ex, lane);
+    }
+};
+
+template <int POOLW, int WAVES>
+__global__ __launch_bounds__(WAVES * 64)
+void arith_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc, const uint8_t *__restrict__ flags_in,
+                         const uint32_t *__restrict__ sel, uint32_t nsel, uint8_t *out, uint32_t *out_len, uint32_t *gscratch) {
+    __shared__ uint32_t pool[WAVES][POOLW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t k = blockIdx.x * WAVES + wv; k < nsel; k += gridDim.x * WAVES) {
+        const uint32_t sidx = sel[k];
+        const hg_stream_desc d = desc[sidx];
+        const uint32_t flags = flags_in[sidx], order = flags & F_ORDER, rle = (flags & F_RLE) ? 1u : 0u;
+        const uint8_t *src = in + d.in_off;
+        uint8_t *o = out + d.out_off;
+        const uint32_t n = d.in_len;
+        uint32_t total = 0;
+        if (n) {
+            uint32_t mx = 0;
+            for (uint32_t i = (uint32_t)lane; i < n; i += 64) { const uint32_t c = src[i]; mx = c > mx ? c : mx; }
+            for (int s = 32; s; s >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)mx, s, 64); mx = t > mx ? t : mx; }
+            Models Q;
+            Q.m = mx + 1u; Q.nl = order ? Q.m : 1u;
+            Q.M = model_words(Q.m, order, rle) <= (uint32_t)POOLW ? pool[wv] : gscratch + d.scratch_off;
+            models_init(Q, rle != 0, lane);
+            o[0] = (uint8_t)Q.m;                                     // every lane, same byte (256 -> 0)
+            Encoder E;
+            E.start(o + 1);
+            uint32_t last = 0;
+            if (!rle) {
+                uint32_t win = 0;
+                for (uint32_t i = 0; i < n; i++) {
+                    if ((i & 63u) == 0) { const uint32_t p = i + (uint32_t)lane; win = p < n ? src[p] : 0u; }
+                    const uint32_t c = rl(win, i & 63u), ctx = order ? last : 0u;
+                    E.symbol(Q.M, Q.lit(ctx), Q.m, Q.lit_tot(ctx), c, lane);
+                    last = c;
+                }
+            } else {
+                for (uint32_t i = 0; i < n;) {
+                    const uint32_t c = src[i], ctx = order ? last : 0u;
+                    E.symbol(Q.M, Q.lit(ctx), Q.m, Q.lit_tot(ctx), c, lane);
+                    last = c;
+                    uint32_t r = 0;                                  // how many more copies of c follow
+                    for (;;) {
+                        const uint32_t p = i + 1u + r + (uint32_t)lane;
+                        const unsigned long long ne = __ballot(!(p < n && src[p] == c));
+                        if (ne) { r += (uint32_t)__builtin_ctzll(ne); break; }
+                        r += 64;
+                    }
+                    i += r + 1u;
+                    uint32_t rctx = c, part;
+                    do {
+                        part = r < 3u ? r : 3u;
+                        E.symbol(Q.M, Q.run(rctx), 4, Q.run_tot(rctx), part, lane);
+                        rctx = rctx == c ? 256u : 257u;
+                        r -= part;
+                    } while (part == 3u);
+                }
+            }
+            total = 1u + E.finish(lane);
+        }
+        out_len[sidx] = total;                                       // every lane stores the same word
+        wave_sync();
+    }
+}
+
+}  // namespace hga
+
+namespace hg {
+int launch_arith_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags, const uint32_t *d_sel_small,
+                        size_t nsmall, const uint32_t *d_sel_big, size_t nbig, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch,
+                        hipStream_t s) {
+    const size_t maxw = (size_t)ctx->cus * 8;
+    if (nsmall) {
+        size_t wgs = (nsmall + 3) / 4;
+        if (wgs > maxw) wgs = maxw;
+        hipLaunchKernelGGL((hga::arith_encode_kernel<HG_ARITH_POOL_SMALL, 4>), dim3((unsigned)wgs), dim3(256), 0, s, (const uint8_t *)d_in,
+                           d_desc, d_flags, d_sel_small, (uint32_t)nsmall, (uint8_t *)d_out, d_out_len, d_scratch);
+    }
+    if (nbig) {
+        size_t wgs = nbig;
+        if (wgs > maxw) wgs = maxw;
+        hipLaunchKernelGGL((hga::arith_encode_kernel<HG_ARITH_POOL_BIG, 1>), dim3((unsigned)wgs), dim3(64), 0, s, (const uint8_t *)d_in,
+                           d_desc, d_flags, d_sel_big, (uint32_t)nbig, (uint8_t *)d_out, d_out_len, d_scratch);
+    }
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+}  // namespace hg

@@ -1,11 +1,13 @@
-// ransnx16_host.hip -- host planner for CRAM 3.1 rANS Nx16 block decoding (hg_ransnx16_decode_host).
+// cram_entropy_host.hip -- host planners for the CRAM 3.1 rANS Nx16 and adaptive-arithmetic block codecs
+// (hg_ransnx16_decode_host / hg_ransnx16_encode_host / hg_arith_decode_host / hg_arith_encode_host).
 //
-// Replaces rans_uncompress_4x16 at its call site in cram_uncompress_block (reference
-// cram/cram_io.c:1697-1714).  An Nx16 stream is a small tree: STRIPE splits it into S complete
+// Replaces rans_uncompress_4x16 / arith_uncompress_to at their call sites in cram_uncompress_block (reference
+// cram/cram_io.c:1697-1733).  Both formats share one container: a stream is a small tree, STRIPE splits it into S complete
 // sub-streams, and every leaf is  [PACK header] [RLE header + meta stream] entropy-coded core.
 // The planner walks the few header bytes of every stream on the host (no payload byte is touched
 // here), and emits
 //   * "core" jobs  -- entropy decode (rANS order 0/1, 4- or 32-way, or CAT) : ransnx16.hip
+//                     (adaptive range coder order 0/1, with or without its run-length models) : arith.hip
 //   * "xform" jobs -- RLE expand / bit unpack / strided (de-striping) write : ransnx16_xform.hip
 // then runs the two kernels back to back on one HIP stream.  All payload work is on the GPU; there
 // is no CPU decode path.  Header rules follow oracle/ransnx16_oracle.c (PARITY UNPINNED).
@@ -20,12 +22,15 @@
 using hg::ensure_scratch;
 namespace {
 
-enum { F_ORDER = 1, F_X32 = 4, F_STRIPE = 8, F_NOSZ = 16, F_CAT = 32, F_RLE = 64, F_PACK = 128 };
+enum { F_ORDER = 1, F_X32 = 4, F_EXT = 4, F_STRIPE = 8, F_NOSZ = 16, F_CAT = 32, F_RLE = 64, F_PACK = 128 };
 constexpr uint32_t NONE = 0xffffffffu;
+enum Codec { NX16 = 0, ARITH = 1 };
+enum CoreClass { C_NX4 = 0, C_NX32 = 1, C_ARITH_SMALL = 2, C_ARITH_BIG = 3, C_CLASSES = 4 };
 
 struct Plan {
     std::vector<hg_stream_desc> core;      // out_off is into the work buffer, or (bit 63 set) the output buffer
     std::vector<uint32_t> core_top;
+    std::vector<uint8_t> core_cls;
     std::vector<hg::nx16_xform> xf;
     std::vector<uint32_t> xf_top;
     uint64_t work = 0, scratch = 0;
@@ -62,24 +67,34 @@ uint64_t o1_scratch_words(const uint8_t *cp, const uint8_t *end) {
 }
 
 // Adds the entropy-decode job for one payload; returns its status slot.
-uint32_t add_core(Plan &P, uint32_t top, uint64_t in_base, const uint8_t *base, const uint8_t *cp, const uint8_t *end,
+uint32_t add_core(Plan &P, Codec codec, uint32_t top, uint64_t in_base, const uint8_t *base, const uint8_t *cp, const uint8_t *end,
                   uint32_t flags, uint32_t out_len, uint64_t out_off) {
     hg_stream_desc d;
     memset(&d, 0, sizeof d);
     d.in_off = in_base + (uint64_t)(cp - base);
     d.in_len = (uint32_t)(end - cp);
     d.out_off = out_off; d.out_len = out_len;
-    d.reserved = 0x80000000u | (flags & (F_ORDER | F_X32 | F_CAT));
     d.scratch_off = (uint32_t)P.scratch;
-    P.scratch += ((flags & F_ORDER) && !(flags & F_CAT)) ? o1_scratch_words(cp, end) : 16;
+    uint8_t cls;
+    if (codec == NX16 || (flags & F_CAT)) {                 // raw copies of either codec go through the Nx16 core kernel
+        if (codec == ARITH) flags &= F_CAT;
+        d.reserved = 0x80000000u | (flags & (F_ORDER | F_X32 | F_CAT));
+        P.scratch += ((flags & F_ORDER) && !(flags & F_CAT)) ? o1_scratch_words(cp, end) : 16;
+        cls = (flags & F_X32) ? C_NX32 : C_NX4;
+    } else {
+        d.reserved = 0x80000000u | (flags & (F_ORDER | F_RLE));
+        const uint32_t words = hg::arith_model_words(cp < end ? *cp : 1u, flags);
+        cls = words <= HG_ARITH_POOL_SMALL ? C_ARITH_SMALL : C_ARITH_BIG;
+        P.scratch += words > HG_ARITH_POOL_BIG ? words + 16 : 16;
+    }
     if (P.scratch > 0xffffffffull) P.too_big = true;
-    P.core.push_back(d); P.core_top.push_back(top);
+    P.core.push_back(d); P.core_top.push_back(top); P.core_cls.push_back(cls);
     return (uint32_t)P.core.size() - 1;
 }
 
 // Plans one (sub-)stream.  known = size when the caller knows it (NOSZ).  out_off/stride place byte i of this
 // stream at output offset out_off + i*stride.  Returns 0, -1 (malformed).
-int plan_stream(Plan &P, uint32_t top, uint64_t in_base, const uint8_t *base, const uint8_t *cp, const uint8_t *end,
+int plan_stream(Plan &P, Codec codec, uint32_t top, uint64_t in_base, const uint8_t *base, const uint8_t *cp, const uint8_t *end,
                 long long known, uint64_t out_off, uint32_t stride, int depth) {
     if (cp >= end || depth > 8) return -1;
     const uint32_t flags = *cp++;
@@ -96,7 +111,7 @@ int plan_stream(Plan &P, uint32_t top, uint64_t in_base, const uint8_t *base, co
         for (uint32_t k = 0; k < S; k++) {
             const uint32_t m = ulen / S + ((ulen % S) > k ? 1u : 0u);
             if ((uint64_t)(end - cp) < cl[k]) return -1;
-            if (plan_stream(P, top, in_base, base, cp, cp + cl[k], m, out_off + (uint64_t)k * stride, stride * S, depth + 1)) return -1;
+            if (int r = plan_stream(P, codec, top, in_base, base, cp, cp + cl[k], m, out_off + (uint64_t)k * stride, stride * S, depth + 1)) return r;
             cp += cl[k];
         }
         return 0;
@@ -110,7 +125,9 @@ int plan_stream(Plan &P, uint32_t top, uint64_t in_base, const uint8_t *base, co
         if (get_u7(cp, end, plen) || plen > ulen) return -1;
     }
     uint32_t lit_len = plen, meta_len = 0, dep1 = NONE; uint64_t meta_off = 0; bool meta_in_work = false;
-    if (flags & F_RLE) {
+    if (codec == ARITH && (flags & F_EXT) && !(flags & F_CAT)) return HG_BLOCK_EUNSUPPORTED;      // bzip2 payload
+    const bool rle_xform = codec == NX16 && (flags & F_RLE);         // the range coder's RLE lives inside its models
+    if (rle_xform) {
         uint32_t v;
         if (get_u7(cp, end, v) || get_u7(cp, end, lit_len)) return -1;
         meta_len = v >> 1;
@@ -122,24 +139,24 @@ int plan_stream(Plan &P, uint32_t top, uint64_t in_base, const uint8_t *base, co
             uint32_t cl;
             if (get_u7(cp, end, cl) || (uint64_t)(end - cp) < cl) return -1;
             meta_off = work_alloc(P, meta_len); meta_in_work = true;
-            dep1 = add_core(P, top, in_base, base, cp, cp + cl, 0, meta_len, meta_off);
+            dep1 = add_core(P, codec, top, in_base, base, cp, cp + cl, 0, meta_len, meta_off);
             cp += cl;
         }
     }
-    const bool xform = (flags & (F_RLE | F_PACK)) || stride != 1;
+    const bool xform = rle_xform || (flags & F_PACK) || stride != 1;
     if (!xform) {                                         // plain core straight into the output buffer
-        if (ulen) add_core(P, top, in_base, base, cp, end, flags, ulen, out_off | (1ull << 63));
+        if (ulen) add_core(P, codec, top, in_base, base, cp, end, flags, ulen, out_off | (1ull << 63));
         return 0;
     }
     hg::nx16_xform J;
     memset(&J, 0, sizeof J);
     J.s1_off = work_alloc(P, lit_len);
-    J.dep0 = lit_len ? add_core(P, top, in_base, base, cp, end, flags, lit_len, J.s1_off) : NONE;
+    J.dep0 = lit_len ? add_core(P, codec, top, in_base, base, cp, end, flags, lit_len, J.s1_off) : NONE;
     J.dep1 = dep1;
     J.meta_off = meta_off; J.meta_len = meta_len;
     J.lit_len = lit_len; J.plen = plen; J.ulen = ulen;
-    J.ops = ((flags & F_RLE) ? 1u : 0u) | ((flags & F_PACK) ? 2u : 0u) | (meta_in_work ? 4u : 0u);
-    if ((flags & F_RLE) && (flags & F_PACK)) J.s2_off = work_alloc(P, plen);
+    J.ops = (rle_xform ? 1u : 0u) | ((flags & F_PACK) ? 2u : 0u) | (meta_in_work ? 4u : 0u);
+    if (rle_xform && (flags & F_PACK)) J.s2_off = work_alloc(P, plen);
     J.out_off = out_off; J.stride = stride; J.nsym = nsym;
     memcpy(J.map, map, 16);
     P.xf.push_back(J); P.xf_top.push_back(top);
@@ -148,8 +165,8 @@ int plan_stream(Plan &P, uint32_t top, uint64_t in_base, const uint8_t *base, co
 
 }  // namespace
 
-extern "C" int hg_ransnx16_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
-                                       uint8_t *const *out, const uint32_t *out_len, int32_t *status) {
+static int entropy_decode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
+                               uint8_t *const *out, const uint32_t *out_len, int32_t *status) {
     if (!ctx || (n && (!in || !in_len || !out || !out_len))) return HG_EINVAL;
     if (n == 0) return HG_OK;
     if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
@@ -161,9 +178,9 @@ extern "C" int hg_ransnx16_decode_host(hg_ctx *ctx, const uint8_t *const *in, co
         ioffs[i] = ioff; ooffs[i] = ooff;
         const size_t c0 = P.core.size(), x0 = P.xf.size();
         const uint64_t w0 = P.work, s0 = P.scratch;
-        if (plan_stream(P, (uint32_t)i, ioff, in[i], in[i], in[i] + in_len[i], out_len[i], ooff, 1, 0)) {
-            st[i] = -1;                                   // malformed header: drop whatever was planned for it
-            P.core.resize(c0); P.core_top.resize(c0); P.xf.resize(x0); P.xf_top.resize(x0); P.work = w0; P.scratch = s0;
+        if (int r = plan_stream(P, codec, (uint32_t)i, ioff, in[i], in[i], in[i] + in_len[i], out_len[i], ooff, 1, 0)) {
+            st[i] = r;                                    // malformed header (-1) / bzip2 payload (-3): drop its jobs
+            P.core.resize(c0); P.core_top.resize(c0); P.core_cls.resize(c0); P.xf.resize(x0); P.xf_top.resize(x0); P.work = w0; P.scratch = s0;
         }
         ioff += ((uint64_t)in_len[i] + 15u) & ~15ull;
         ooff += ((uint64_t)out_len[i] + 15u) & ~15ull;
@@ -173,13 +190,15 @@ extern "C" int hg_ransnx16_decode_host(hg_ctx *ctx, const uint8_t *const *in, co
     // the core kernel addresses ONE output allocation: [ output buffer | work buffer ]
     const uint64_t obytes = (ooff + 63u) & ~63ull;
     std::vector<uint32_t> sel(nc);
-    size_t n4 = 0, n32 = 0;
+    size_t cnt[C_CLASSES] = {0}, first[C_CLASSES + 1] = {0};
     for (size_t k = 0; k < nc; k++) {
         hg_stream_desc &d = P.core[k];
         if (d.out_off >> 63) d.out_off &= ~(1ull << 63); else d.out_off += obytes;
-        if (d.reserved & F_X32) n32++; else n4++;
+        cnt[P.core_cls[k]]++;
     }
-    { size_t a = 0, b = n4; for (size_t k = 0; k < nc; k++) { if (P.core[k].reserved & F_X32) sel[b++] = (uint32_t)k; else sel[a++] = (uint32_t)k; } }
+    for (int c = 0; c < C_CLASSES; c++) first[c + 1] = first[c] + cnt[c];
+    { size_t fill[C_CLASSES]; for (int c = 0; c < C_CLASSES; c++) fill[c] = first[c];
+      for (size_t k = 0; k < nc; k++) sel[fill[P.core_cls[k]]++] = (uint32_t)k; }
     int rc;
     const size_t nst = nc + nx;
     if ((rc = ensure_scratch(ctx, 0, ioff + 64)) || (rc = ensure_scratch(ctx, 1, obytes + P.work + 64)) ||
@@ -196,9 +215,13 @@ extern "C" int hg_ransnx16_decode_host(hg_ctx *ctx, const uint8_t *const *in, co
                  hipMemcpyAsync(ctx->d_scratch[7], sel.data(), nc * 4, hipMemcpyHostToDevice, s) == hipSuccess;
     if (nx) ok = ok && hipMemcpyAsync(ctx->d_scratch[4], P.xf.data(), nx * sizeof(hg::nx16_xform), hipMemcpyHostToDevice, s) == hipSuccess;
     rc = ok ? HG_OK : HG_ELAUNCH;
-    if (rc == HG_OK && nc)
-        rc = hg::launch_ransnx16_decode(ctx, d_in, (const hg_stream_desc *)ctx->d_scratch[2], (const uint32_t *)ctx->d_scratch[7], n4,
-                                        (const uint32_t *)ctx->d_scratch[7] + n4, n32, d_out, d_st, (uint32_t *)ctx->d_scratch[6], s);
+    const uint32_t *d_sel = (const uint32_t *)ctx->d_scratch[7];
+    if (rc == HG_OK && cnt[C_NX4] + cnt[C_NX32])
+        rc = hg::launch_ransnx16_decode(ctx, d_in, (const hg_stream_desc *)ctx->d_scratch[2], d_sel + first[C_NX4], cnt[C_NX4],
+                                        d_sel + first[C_NX32], cnt[C_NX32], d_out, d_st, (uint32_t *)ctx->d_scratch[6], s);
+    if (rc == HG_OK && cnt[C_ARITH_SMALL] + cnt[C_ARITH_BIG])
+        rc = hg::launch_arith_decode(ctx, d_in, (const hg_stream_desc *)ctx->d_scratch[2], d_sel + first[C_ARITH_SMALL], cnt[C_ARITH_SMALL],
+                                     d_sel + first[C_ARITH_BIG], cnt[C_ARITH_BIG], d_out, d_st, (uint32_t *)ctx->d_scratch[6], s);
     if (rc == HG_OK && nx)
         rc = hg::launch_ransnx16_xform(ctx, d_in, d_out + obytes, d_out, (const hg::nx16_xform *)ctx->d_scratch[4], nx, d_st, (uint32_t)nc, s);
     if (rc == HG_OK) {
@@ -215,6 +238,15 @@ extern "C" int hg_ransnx16_decode_host(hg_ctx *ctx, const uint8_t *const *in, co
     return rc;
 }
 
+extern "C" int hg_ransnx16_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
+                                       uint8_t *const *out, const uint32_t *out_len, int32_t *status) {
+    return entropy_decode_host(NX16, ctx, in, in_len, n, out, out_len, status);
+}
+extern "C" int hg_arith_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
+                                    uint8_t *const *out, const uint32_t *out_len, int32_t *status) {
+    return entropy_decode_host(ARITH, ctx, in, in_len, n, out, out_len, status);
+}
+
 // ================================================================================================
 // Encoder: hg_ransnx16_encode_host (replaces rans_compress_4x16, call site cram/cram_io.c:1853-1866).
 // Mirror image of the decoder plan: STRIPE / PACK / RLE run first (ransnx16_xenc.hip), their results
@@ -227,6 +259,7 @@ namespace {
 
 struct Leaf {
     uint32_t top, n, stride, flags;     // flags as requested for this leaf
+    uint32_t max_sym;                   // upper bound of the byte values (sizes the range coder's models)
     uint64_t src_off;                   // in the device buffer
     const uint8_t *host_src;            // non-null when the leaf is the untouched host input
     int xjob, core, mcore;
@@ -242,8 +275,8 @@ int put_u7(uint8_t *cp, uint32_t v) {
 
 }  // namespace
 
-extern "C" int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags, size_t n,
-                                       uint8_t *const *out, uint32_t *out_len) {
+static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags, size_t n,
+                               uint8_t *const *out, uint32_t *out_len) {
     if (!ctx || (n && (!in || !in_len || !flags || !out || !out_len))) return HG_EINVAL;
     if (n == 0) return HG_OK;
     if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
@@ -251,6 +284,7 @@ extern "C" int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, co
     std::vector<hg::nx16_xenc> xj;
     std::vector<uint64_t> ioffs(n);
     std::vector<uint32_t> first_leaf(n + 1);
+    std::vector<uint8_t> top_flags(n);
     uint64_t ioff = 0;
     for (size_t i = 0; i < n; i++) { ioffs[i] = ioff; ioff += ((uint64_t)in_len[i] + 15u) & ~15ull; }
     uint64_t work = (ioff + 63u) & ~63ull;                                    // work area follows the inputs
@@ -258,23 +292,29 @@ extern "C" int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, co
     for (size_t i = 0; i < n; i++) {
         first_leaf[i] = (uint32_t)leaves.size();
         uint32_t f = flags[i];
+        if (codec == ARITH) f &= ~(uint32_t)F_EXT;
         const uint32_t S = (f & F_STRIPE) ? 4u : 1u;
-        if (f & F_STRIPE) f &= ~(uint32_t)(F_PACK | F_RLE | F_CAT);
+        if (f & F_STRIPE) f &= codec == NX16 ? ~(uint32_t)(F_PACK | F_RLE | F_CAT) : ~(uint32_t)(F_PACK | F_CAT);
+        top_flags[i] = (uint8_t)f;
+        uint32_t host_max = 255;
+        if (codec == ARITH && (f & F_ORDER)) { host_max = 0; for (uint32_t q = 0; q < in_len[i]; q++) if (in[i][q] > host_max) host_max = in[i][q]; }
         for (uint32_t k = 0; k < S; k++) {
             Leaf L;
             memset(&L, 0, sizeof L);
             L.top = (uint32_t)i; L.stride = S; L.src_off = ioffs[i] + k;
             L.n = S == 1 ? in_len[i] : in_len[i] / S + ((in_len[i] % S) > k ? 1u : 0u);
-            L.flags = S == 1 ? f : ((f & (F_ORDER | F_X32)) | F_NOSZ);
+            L.flags = S == 1 ? f : ((f & (codec == NX16 ? (F_ORDER | F_X32) : (F_ORDER | F_RLE))) | F_NOSZ);
+            L.max_sym = (L.flags & F_PACK) ? 255u : host_max;
             L.host_src = S == 1 ? in[i] : nullptr;
             L.xjob = L.core = L.mcore = -1;
-            if (S != 1 || (L.flags & (F_PACK | F_RLE))) {
+            const uint32_t xops = L.flags & (codec == NX16 ? (F_PACK | F_RLE) : F_PACK);     // the range coder's RLE is not a transform
+            if (S != 1 || xops) {
                 hg::nx16_xenc J;
                 memset(&J, 0, sizeof J);
-                J.src_off = L.src_off; J.n = L.n; J.stride = S; J.flags = L.flags;
+                J.src_off = L.src_off; J.n = L.n; J.stride = S; J.flags = xops;
                 if (S != 1) J.g_off = walloc(L.n);
-                if (L.flags & F_PACK) J.p_off = walloc(L.n / 2 + 8);
-                if (L.flags & F_RLE) { J.l_off = walloc(L.n); J.m_off = walloc((uint64_t)L.n + 300); }
+                if (xops & F_PACK) J.p_off = walloc(L.n / 2 + 8);
+                if (xops & F_RLE) { J.l_off = walloc(L.n); J.m_off = walloc((uint64_t)L.n + 300); }
                 L.xjob = (int)xj.size(); xj.push_back(J);
             }
             leaves.push_back(L);
@@ -303,33 +343,47 @@ extern "C" int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, co
     std::vector<uint8_t> cfl;
     uint64_t ooff = 0, soff = 0, woff = 0;
     bool too_big = false;
-    auto add_core = [&](uint64_t src_off, uint32_t len, uint32_t fl) {
+    std::vector<uint8_t> ccls;
+    auto add_core = [&](uint64_t src_off, uint32_t len, uint32_t fl, Codec cc, uint32_t max_sym) {
         hg_stream_desc d;
         memset(&d, 0, sizeof d);
-        const uint64_t cap = (fl & F_ORDER) ? hg_ransnx16_compress_bound(len) : (uint64_t)len + len / 16 + 4096;
+        const uint64_t cap = cc == ARITH ? (uint64_t)len + len / 4 + 4096
+                           : (fl & F_ORDER) ? hg_ransnx16_compress_bound(len) : (uint64_t)len + len / 16 + 4096;
         d.in_off = src_off; d.in_len = len; d.out_off = ooff; d.out_len = (uint32_t)(cap > 0xffffffffull ? 0xffffffffu : cap);
         d.scratch_off = (uint32_t)soff; d.reserved = (uint32_t)(woff / 16);
         ooff += (cap + 15u) & ~15ull;
-        soff += hg::ransnx16_enc_scratch_words(fl);
-        woff += (2ull * len + 256u + 15u) & ~15ull;
+        if (cc == ARITH) {
+            const uint32_t words = hg::arith_model_words(max_sym + 1u, fl);
+            ccls.push_back(words <= HG_ARITH_POOL_SMALL ? C_ARITH_SMALL : C_ARITH_BIG);
+            soff += words > HG_ARITH_POOL_BIG ? words + 16 : 16;
+        } else {
+            ccls.push_back((fl & F_X32) ? C_NX32 : C_NX4);
+            soff += hg::ransnx16_enc_scratch_words(fl);
+            woff += (2ull * len + 256u + 15u) & ~15ull;
+        }
         if (soff > 0xffffffffull || woff / 16 > 0xffffffffull) too_big = true;
         cd.push_back(d); cfl.push_back((uint8_t)fl);
         return (int)cd.size() - 1;
     };
     for (Leaf &L : leaves) {
-        if (L.xjob >= 0) L.r = xr[L.xjob];
+        if (L.xjob >= 0) { const uint32_t keep = L.flags & ~(uint32_t)(codec == NX16 ? (F_PACK | F_RLE) : F_PACK); L.r = xr[L.xjob]; L.r.flags |= keep; }
         else { L.r.flags = L.flags; L.r.cur_off = L.src_off; L.r.cur_len = L.n; }
-        const uint32_t N = (L.r.flags & F_X32) ? 32u : 4u;
-        if ((L.r.flags & F_ORDER) && L.r.cur_len < 2u * N) L.r.flags &= ~(uint32_t)F_ORDER;
-        if (L.r.flags & F_RLE) L.mcore = add_core(xj[L.xjob].m_off, L.r.meta_len, F_NOSZ);
-        if (!(L.r.flags & F_CAT) && L.r.cur_len) L.core = add_core(L.r.cur_off, L.r.cur_len, (L.r.flags & (F_ORDER | F_X32)) | F_NOSZ);
+        if (codec == NX16) {
+            const uint32_t N = (L.r.flags & F_X32) ? 32u : 4u;
+            if ((L.r.flags & F_ORDER) && L.r.cur_len < 2u * N) L.r.flags &= ~(uint32_t)F_ORDER;
+            if (L.r.flags & F_RLE) L.mcore = add_core(xj[L.xjob].m_off, L.r.meta_len, F_NOSZ, NX16, 255);
+            if (!(L.r.flags & F_CAT) && L.r.cur_len) L.core = add_core(L.r.cur_off, L.r.cur_len, (L.r.flags & (F_ORDER | F_X32)) | F_NOSZ, NX16, 255);
+        } else if (!(L.r.flags & F_CAT) && L.r.cur_len)
+            L.core = add_core(L.r.cur_off, L.r.cur_len, L.r.flags & (F_ORDER | F_RLE), ARITH, (L.r.flags & F_PACK) ? 255u : L.max_sym);
     }
     if (too_big) return HG_EINVAL;
     const size_t nc = cd.size();
     std::vector<uint32_t> sel(nc), ol(nc, 0);
-    size_t n4 = 0, n32 = 0;
-    for (size_t k = 0; k < nc; k++) { if (cfl[k] & F_X32) n32++; else n4++; }
-    { size_t a = 0, b = n4; for (size_t k = 0; k < nc; k++) { if (cfl[k] & F_X32) sel[b++] = (uint32_t)k; else sel[a++] = (uint32_t)k; } }
+    size_t cnt[C_CLASSES] = {0}, first[C_CLASSES + 1] = {0};
+    for (size_t k = 0; k < nc; k++) cnt[ccls[k]]++;
+    for (int c = 0; c < C_CLASSES; c++) first[c + 1] = first[c] + cnt[c];
+    { size_t fill[C_CLASSES]; for (int c = 0; c < C_CLASSES; c++) fill[c] = first[c];
+      for (size_t k = 0; k < nc; k++) sel[fill[ccls[k]]++] = (uint32_t)k; }
     uint8_t *d_out = nullptr;
     if (nc) {
         if ((rc = ensure_scratch(ctx, 1, ooff + 64)) || (rc = ensure_scratch(ctx, 2, nc * sizeof(hg_stream_desc) + 64)) ||
@@ -343,9 +397,14 @@ extern "C" int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, co
              hipMemcpyAsync(ctx->d_scratch[7], sel.data(), nc * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
              hipMemcpyAsync(d_fl, cfl.data(), nc, hipMemcpyHostToDevice, s) == hipSuccess;
         if (!ok) return HG_ELAUNCH;
-        rc = hg::launch_ransnx16_encode(ctx, d_buf, (const hg_stream_desc *)ctx->d_scratch[2], d_fl, (const uint32_t *)ctx->d_scratch[7], n4,
-                                        (const uint32_t *)ctx->d_scratch[7] + n4, n32, d_out, d_ol, ctx->d_scratch[5],
-                                        (uint32_t *)ctx->d_scratch[6], s);
+        const uint32_t *d_sel = (const uint32_t *)ctx->d_scratch[7];
+        rc = HG_OK;
+        if (cnt[C_NX4] + cnt[C_NX32])
+            rc = hg::launch_ransnx16_encode(ctx, d_buf, (const hg_stream_desc *)ctx->d_scratch[2], d_fl, d_sel + first[C_NX4], cnt[C_NX4],
+                                            d_sel + first[C_NX32], cnt[C_NX32], d_out, d_ol, ctx->d_scratch[5], (uint32_t *)ctx->d_scratch[6], s);
+        if (rc == HG_OK && cnt[C_ARITH_SMALL] + cnt[C_ARITH_BIG])
+            rc = hg::launch_arith_encode(ctx, d_buf, (const hg_stream_desc *)ctx->d_scratch[2], d_fl, d_sel + first[C_ARITH_SMALL], cnt[C_ARITH_SMALL],
+                                         d_sel + first[C_ARITH_BIG], cnt[C_ARITH_BIG], d_out, d_ol, (uint32_t *)ctx->d_scratch[6], s);
         if (rc) return rc;
         if (hipMemcpyAsync(ol.data(), d_ol, nc * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
     }
@@ -356,7 +415,7 @@ extern "C" int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, co
         *cp++ = (uint8_t)f;
         if (!(f & F_NOSZ)) cp += put_u7(cp, L.n);
         if (f & F_PACK) { *cp++ = (uint8_t)L.r.nsym; memcpy(cp, L.r.map, L.r.nsym); cp += L.r.nsym; cp += put_u7(cp, L.r.plen); }
-        if (f & F_RLE) {
+        if (codec == NX16 && (f & F_RLE)) {
             const uint32_t ml = L.r.meta_len, cl = ol[L.mcore] ? ol[L.mcore] - 1u : 0u;   // core output minus its flag byte
             if (cl + 5u < ml) {
                 cp += put_u7(cp, ml * 2u); cp += put_u7(cp, L.r.lit_len); cp += put_u7(cp, cl);
@@ -371,8 +430,9 @@ extern "C" int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, co
             else fetch(cp, d_buf + L.r.cur_off, L.r.cur_len);
             cp += L.r.cur_len;
         } else if (L.core >= 0) {
-            const uint32_t bl = ol[L.core] ? ol[L.core] - 1u : 0u;
-            fetch(cp, d_out + cd[L.core].out_off + 1, bl); cp += bl;
+            const uint32_t skip = codec == NX16 ? 1u : 0u;                    // the Nx16 core kernel writes its own flag byte first
+            const uint32_t bl = ol[L.core] > skip ? ol[L.core] - skip : 0u;
+            fetch(cp, d_out + cd[L.core].out_off + skip, bl); cp += bl;
         }
         return cp;
     };
@@ -382,12 +442,12 @@ extern "C" int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, co
         const uint32_t l0 = first_leaf[i], nl = first_leaf[i + 1] - l0;
         if (nl == 1) cp = emit_leaf(cp, leaves[l0]);
         else {
-            const uint32_t f = flags[i] & ~(uint32_t)(F_PACK | F_RLE | F_CAT);
+            const uint32_t f = top_flags[i];
             *cp++ = (uint8_t)f;
             if (!(f & F_NOSZ)) cp += put_u7(cp, in_len[i]);
             *cp++ = (uint8_t)nl;
             // sub-streams are laid out after their length list: build them in a side buffer first
-            tmp.resize(hg_ransnx16_compress_bound(in_len[i]));
+            tmp.resize(codec == NX16 ? hg_ransnx16_compress_bound(in_len[i]) : hg_arith_compress_bound(in_len[i]));
             uint8_t *tp = tmp.data();
             for (uint32_t k = 0; k < nl; k++) { uint8_t *e = emit_leaf(tp, leaves[l0 + k]); cp += put_u7(cp, (uint32_t)(e - tp)); tp = e; }
             memcpy(cp, tmp.data(), (size_t)(tp - tmp.data())); cp += tp - tmp.data();
@@ -395,4 +455,14 @@ extern "C" int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, co
         out_len[i] = (uint32_t)(cp - out[i]);
     }
     return ok ? HG_OK : HG_ELAUNCH;
+}
+
+extern "C" int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags, size_t n,
+                                       uint8_t *const *out, uint32_t *out_len) {
+    return entropy_encode_host(NX16, ctx, in, in_len, flags, n, out, out_len);
+}
+extern "C" size_t hg_arith_compress_bound(size_t n) { return n + n / 4 + 4 * 4096 + 64; }
+extern "C" int hg_arith_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags, size_t n,
+                                    uint8_t *const *out, uint32_t *out_len) {
+    return entropy_encode_host(ARITH, ctx, in, in_len, flags, n, out, out_len);
 }

@@ -43,6 +43,19 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Inclusive prefix sum over the 64 lanes on the DPP data path (no LDS round trips): shifts by
+// 1/2/4/8 inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals.
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1, out-of-row lanes read 0
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
+    return (uint32_t)v;
+}
+
 // ---------------------------------------------------------------------------
 // CRC-32 (RFC 1952 section 8; zlib's crc32(), called at bgzf.c:612,747,793).
 // Slice-by-4 tables and the x^(8*2^j) mod P table used to concatenate per-lane

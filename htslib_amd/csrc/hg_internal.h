@@ -58,6 +58,16 @@ struct nx16_xenc_res {
     uint64_t pad;
 };
 int launch_ransnx16_xenc(hg_ctx *ctx, void *d_buf, const nx16_xenc *d_jobs, size_t njobs, nx16_xenc_res *d_res, hipStream_t s);
+// arith.hip: model memory is an LDS pool per wavefront; streams are sorted into a small-pool launch (many
+// waves per CU) and a big-pool launch, larger models fall back to global scratch words.
+#define HG_ARITH_POOL_SMALL 2560     /* words: order-0 (+RLE), order-1 up to 49 symbols */
+#define HG_ARITH_POOL_BIG   16384    /* words: order-1 up to 127 symbols, or 120 with RLE */
+uint32_t arith_model_words(uint32_t max_sym, uint32_t flags);
+int launch_arith_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_sel_small, size_t nsmall,
+                        const uint32_t *d_sel_big, size_t nbig, void *d_out, int32_t *d_status, uint32_t *d_scratch, hipStream_t s);
+int launch_arith_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags, const uint32_t *d_sel_small,
+                        size_t nsmall, const uint32_t *d_sel_big, size_t nbig, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch,
+                        hipStream_t s);
 int ensure_scratch(hg_ctx *ctx, int slot, size_t bytes);
 uint32_t ransnx16_enc_scratch_words(uint32_t flags);
 int launch_ransnx16_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags,

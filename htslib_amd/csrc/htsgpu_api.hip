@@ -180,18 +180,22 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
     if (!ctx || (n && (!method || !in || !in_len || !out || !out_len || !status))) return HG_EINVAL;
     if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
     // partition by method
-    size_t ng = 0, nr = 0, nx = 0;
+    size_t ng = 0, nr = 0, nx_ = 0, na = 0;
     for (size_t i = 0; i < n; i++) {
         status[i] = 0;
         if (out_len[i] == 0 || method[i] == HG_CRAM_RAW) {            // cram_io.c:1594-1603: nothing to do
             if (method[i] == HG_CRAM_RAW) { if (in_len[i] != out_len[i]) status[i] = -1; else if (out_len[i]) memcpy(out[i], in[i], out_len[i]); }
         } else if (method[i] == HG_CRAM_GZIP) ng++;
         else if (method[i] == HG_CRAM_RANS4x8) nr++;
-        else if (method[i] == HG_CRAM_RANSNx16) nx++;
+        else if (method[i] == HG_CRAM_RANSNx16) nx_++;
+        else if (method[i] == HG_CRAM_ARITH) na++;
         else status[i] = HG_BLOCK_EUNSUPPORTED;
     }
     int rc = HG_OK;
-    if (nx) {
+    for (int pass = 0; pass < 2; pass++) {                            // Nx16, then the range coder
+        const int32_t meth = pass ? HG_CRAM_ARITH : HG_CRAM_RANSNx16;
+        const size_t nx = pass ? na : nx_;
+        if (!nx) continue;
         const uint8_t **xin = (const uint8_t **)malloc(nx * sizeof(void *));
         uint8_t **xout = (uint8_t **)malloc(nx * sizeof(void *));
         uint32_t *xl = (uint32_t *)malloc(nx * 4), *xo = (uint32_t *)malloc(nx * 4);
@@ -199,8 +203,8 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
         size_t *map = (size_t *)malloc(nx * sizeof(size_t));
         size_t k = 0;
         for (size_t i = 0; i < n; i++)
-            if (out_len[i] && method[i] == HG_CRAM_RANSNx16) { xin[k] = in[i]; xout[k] = out[i]; xl[k] = in_len[i]; xo[k] = out_len[i]; map[k] = i; k++; }
-        int r = hg_ransnx16_decode_host(ctx, xin, xl, nx, xout, xo, xs);
+            if (out_len[i] && method[i] == meth) { xin[k] = in[i]; xout[k] = out[i]; xl[k] = in_len[i]; xo[k] = out_len[i]; map[k] = i; k++; }
+        int r = pass ? hg_arith_decode_host(ctx, xin, xl, nx, xout, xo, xs) : hg_ransnx16_decode_host(ctx, xin, xl, nx, xout, xo, xs);
         if (r != HG_OK && r != HG_EBLOCK) rc = r;
         for (k = 0; k < nx; k++) status[map[k]] = (r == HG_OK || r == HG_EBLOCK) ? xs[k] : -1;
         free(xin); free(xout); free(xl); free(xo); free(xs); free(map);
@@ -485,8 +489,10 @@ int hg_gzip_deflate_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *
 }
 
 size_t hg_cram_compress_bound(size_t n) {
-    size_t a = hg_gzip_compress_bound(n), b = hg_rans4x8_compress_bound(n), c = hg_ransnx16_compress_bound(n);
-    return a > b ? (a > c ? a : c) : (b > c ? b : c);
+    size_t a = hg_gzip_compress_bound(n), b = hg_rans4x8_compress_bound(n), c = hg_ransnx16_compress_bound(n), d = hg_arith_compress_bound(n);
+    if (b > a) a = b;
+    if (c > a) a = c;
+    return d > a ? d : a;
 }
 
 int hg_cram_compress_blocks_host(hg_ctx *ctx, size_t n, const uint32_t *method_mask, int level, const uint8_t *const *in,
@@ -534,6 +540,14 @@ int hg_cram_compress_blocks_host(hg_ctx *ctx, size_t n, const uint32_t *method_m
         for (size_t k = 0; k < sin.size(); k++) par[k] = (uint8_t)(nx16_sets[v] | (slen[k] >= 65536u ? 4 : 0));   // 32-way for big inputs
         rc = hg_ransnx16_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
         for (size_t k = 0; rc == HG_OK && k < sin.size(); k++) if (keep(k)) method_used[map[k]] = HG_CRAM_RANSNx16;
+    }
+    // arith: same flag sets as Nx16 (cram_io.c:1877), no 32-way
+    for (int v = 0; v < nsets && rc == HG_OK; v++) {
+        gather(HG_CRAM_ARITH);
+        if (sin.empty()) break;
+        par.assign(sin.size(), nx16_sets[v]);
+        rc = hg_arith_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
+        for (size_t k = 0; rc == HG_OK && k < sin.size(); k++) if (keep(k)) method_used[map[k]] = HG_CRAM_ARITH;
     }
     for (auto p : tmp) free(p);
     return rc;

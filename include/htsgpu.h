@@ -182,6 +182,17 @@ size_t hg_ransnx16_compress_bound(size_t in_len);
 int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags,
                             size_t n, uint8_t *const *out, uint32_t *out_len);
 
+/* ---- CRAM 3.1 adaptive arithmetic ("range") coder (replaces arith_uncompress_to / arith_compress_to as
+ *      called at cram/cram_io.c:1716-1733 and 1869-1883; CRAM block method 6).  PARITY UNPINNED like Nx16
+ *      (oracle/arith_oracle.c).  flags[i] = the stream's first byte: 0x01 order-1, 0x08 STRIPE, 0x10 NOSZ,
+ *      0x20 CAT, 0x40 RLE (run-length models), 0x80 PACK (cram/cram_external.c:628-638).  Streams whose
+ *      payload is bzip2 (EXT 0x04) get status -3.  One wavefront per stream; see arith.hip. ---- */
+int hg_arith_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
+                         uint8_t *const *out, const uint32_t *out_len, int32_t *status);
+size_t hg_arith_compress_bound(size_t in_len);
+int hg_arith_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags,
+                         size_t n, uint8_t *const *out, uint32_t *out_len);
+
 /* ---- CRAM block layer (replaces cram_uncompress_block, cram/cram_io.c:1576-1754) ------------ */
 /* on-disk method ids, htslib/cram.h:84-101 */
 #define HG_CRAM_RAW      0
@@ -197,8 +208,8 @@ int hg_ransnx16_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_
 
 /* Uncompress n CRAM blocks in one batch: block i has on-disk method method[i], compressed payload
  * in[i] (in_len[i] = comp_size) and must produce exactly out_len[i] = uncomp_size bytes into out[i]
- * (cram_uncompress_block's size check, cram_io.c:1611-1614).  RAW blocks are copied, GZIP and
- * RANS4x8 blocks go to the gfx950 kernels; status[i] = 0 / -1 / -2 (CRC) / -3 (unsupported method).
+ * (cram_uncompress_block's size check, cram_io.c:1611-1614).  RAW blocks are copied, GZIP, RANS4x8,
+ * RANSNx16 and ARITH blocks go to the gfx950 kernels; status[i] = 0 / -1 / -2 (CRC) / -3 (unsupported method).
  * Synchronous; returns 0, or HG_EBLOCK if any status is non-zero. */
 int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method, const uint8_t *const *in,
                                    const uint32_t *in_len, uint8_t *const *out, const uint32_t *out_len,
@@ -217,7 +228,7 @@ int hg_gzip_deflate_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *
  * when nothing beats it (cram_io.c:2001,2271-2278).  Bits: 1<<HG_CRAM_GZIP, 1<<HG_CRAM_RANS4x8 (orders 0
  * and 1 are both tried), 1<<HG_CRAM_RANSNx16 (flag sets {0,1} / +{64,9,128,193} above level 1 /
  * +{129,192} above level 5 as cram_compress_slice builds them, cram/cram_encode.c:818-826; 32-way for
- * inputs >= 64 KiB like RANS_ORDER_SIMD_AUTO).  method_used[i] = on-disk method id of the winner; out[i] must hold
+ * inputs >= 64 KiB like RANS_ORDER_SIMD_AUTO), 1<<HG_CRAM_ARITH (the same flag sets, cram_io.c:1877).  method_used[i] = on-disk method id of the winner; out[i] must hold
  * hg_cram_compress_bound(in_len[i]).  No cross-slice metrics are kept (every call is a trial). */
 size_t hg_cram_compress_bound(size_t in_len);
 int hg_cram_compress_blocks_host(hg_ctx *ctx, size_t n, const uint32_t *method_mask, int level,

@@ -161,3 +161,27 @@ class RansNx16Oracle:
         n = C.c_size_t(0)
         rc = self.L.orc_ransnx16_uncompress(b, len(b), out, cap, C.byref(n))
         return rc, (out.raw[:n.value] if rc == 0 else b"")
+
+
+class ArithOracle:
+    """oracle/arith_oracle.c -- CRAM 3.1 adaptive range coder, PARITY UNPINNED."""
+
+    def __init__(self):
+        L = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        L.orc_arith_uncompress.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_long]
+        L.orc_arith_compress.restype = C.c_size_t
+        L.orc_arith_compress.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int]
+        L.orc_arith_compress_bound.restype = C.c_size_t
+        L.orc_arith_compress_bound.argtypes = [C.c_size_t]
+        self.L = L
+
+    def encode(self, d: bytes, flags: int) -> bytes:
+        out = C.create_string_buffer(self.L.orc_arith_compress_bound(len(d)))
+        n = self.L.orc_arith_compress(d, len(d), out, flags)
+        return out.raw[:n]
+
+    def decode(self, b: bytes, cap: int, known: int = -1):
+        out = C.create_string_buffer(max(cap, 1))
+        n = C.c_size_t(0)
+        rc = self.L.orc_arith_uncompress(b, len(b), out, cap, C.byref(n), known)
+        return rc, (out.raw[:n.value] if rc == 0 else b"")
