@@ -185,3 +185,27 @@ class ArithOracle:
         n = C.c_size_t(0)
         rc = self.L.orc_arith_uncompress(b, len(b), out, cap, C.byref(n), known)
         return rc, (out.raw[:n.value] if rc == 0 else b"")
+
+
+class Tok3Oracle:
+    """oracle/tok3_oracle.c -- CRAM 3.1 read-name tokeniser, PARITY UNPINNED."""
+
+    def __init__(self):
+        L = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        L.orc_tok3_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.orc_tok3_encode.restype = C.c_size_t
+        L.orc_tok3_encode.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int]
+        L.orc_tok3_compress_bound.restype = C.c_size_t
+        L.orc_tok3_compress_bound.argtypes = [C.c_size_t]
+        self.L = L
+
+    def encode(self, d: bytes, use_arith: int = 0) -> bytes:
+        out = C.create_string_buffer(self.L.orc_tok3_compress_bound(len(d)))
+        n = self.L.orc_tok3_encode(d, len(d), out, use_arith)
+        return out.raw[:n]
+
+    def decode(self, b: bytes, cap: int):
+        out = C.create_string_buffer(max(cap, 1))
+        n = C.c_size_t(0)
+        rc = self.L.orc_tok3_decode(b, len(b), out, cap, C.byref(n))
+        return rc, (out.raw[:n.value] if rc == 0 else b"")
