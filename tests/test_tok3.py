@@ -67,4 +67,4 @@ def test_oracle_compresses_names(torc):
     dup = illumina_names(rng, 5000, paired=True)
     assert len(torc.encode(dup)) < 0.15 * len(dup)              # the mate costs a DUP token
     # constant leading tokens cost one implied TYPE stream each, not a byte per name
-    assert len(torc.encode(b"same\0" * 1000)) < 120
+    assert len(torc.encode(b"same\0" * 1000)) < 150
