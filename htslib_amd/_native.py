@@ -75,13 +75,15 @@ lib.hg_arith_compress_bound.argtypes = [C.c_size_t]
 lib.hg_arith_decode_host.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]
 lib.hg_arith_encode_host.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]
 
+lib.hg_tok3_decode_host.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]
+
 EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info", "hg_bgzf_scan",
            "hg_bgzf_inflate_dev", "hg_bgzf_inflate_host", "hg_crc32_dev", "hg_bgzf_deflate_dev", "hg_bgzf_pack_dev",
            "hg_bgzf_deflate_host", "hg_rans4x8_decode_dev", "hg_rans4x8_decode_host",
            "hg_gzip_inflate_dev", "hg_cram_uncompress_blocks_host", "hg_ransnx16_decode_host", "hg_ransnx16_decode_dev",
            "hg_ransnx16_compress_bound", "hg_ransnx16_encode_host", "hg_rans4x8_compress_bound",
            "hg_rans4x8_encode_host", "hg_gzip_compress_bound", "hg_gzip_deflate_host", "hg_cram_compress_bound",
-           "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host"]
+           "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host", "hg_tok3_decode_host"]
 
 
 class HgError(RuntimeError):

@@ -165,6 +165,55 @@ int plan_stream(Plan &P, Codec codec, uint32_t top, uint64_t in_base, const uint
 
 }  // namespace
 
+// Uploads a plan and launches its kernels on stream s (no synchronisation).  Device layout: inputs in scratch
+// slot 0 (the caller has copied them), outputs in slot 1 = [ obytes of output | P.work bytes of work area ],
+// job statuses in slot 3: nc entropy jobs, then nx transform jobs.
+static int launch_plan(hg_ctx *ctx, Plan &P, uint64_t in_bytes, uint64_t obytes, hipStream_t s) {
+    const size_t nc = P.core.size(), nx = P.xf.size(), nst = nc + nx;
+    std::vector<uint32_t> sel(nc);
+    size_t cnt[C_CLASSES] = {0}, first[C_CLASSES + 1] = {0};
+    for (size_t k = 0; k < nc; k++) {
+        hg_stream_desc &d = P.core[k];
+        if (d.out_off >> 63) d.out_off &= ~(1ull << 63); else d.out_off += obytes;
+        cnt[P.core_cls[k]]++;
+    }
+    for (int c = 0; c < C_CLASSES; c++) first[c + 1] = first[c] + cnt[c];
+    { size_t fill[C_CLASSES]; for (int c = 0; c < C_CLASSES; c++) fill[c] = first[c];
+      for (size_t k = 0; k < nc; k++) sel[fill[P.core_cls[k]]++] = (uint32_t)k; }
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, in_bytes + 64)) || (rc = ensure_scratch(ctx, 1, obytes + P.work + 64)) ||
+        (rc = ensure_scratch(ctx, 2, nc * sizeof(hg_stream_desc) + 64)) || (rc = ensure_scratch(ctx, 3, nst * 4 + 64)) ||
+        (rc = ensure_scratch(ctx, 4, nx * sizeof(hg::nx16_xform) + 64)) ||
+        (rc = ensure_scratch(ctx, 6, P.scratch * 4 + 64)) || (rc = ensure_scratch(ctx, 7, nc * 4 + 64))) return rc;
+    uint8_t *d_in = (uint8_t *)ctx->d_scratch[0], *d_out = (uint8_t *)ctx->d_scratch[1];
+    int32_t *d_st = (int32_t *)ctx->d_scratch[3];
+    bool ok = hipMemsetAsync(d_st, 0xff, nst * 4 + 4, s) == hipSuccess;
+    if (nc) ok = ok && hipMemcpyAsync(ctx->d_scratch[2], P.core.data(), nc * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(ctx->d_scratch[7], sel.data(), nc * 4, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (nx) ok = ok && hipMemcpyAsync(ctx->d_scratch[4], P.xf.data(), nx * sizeof(hg::nx16_xform), hipMemcpyHostToDevice, s) == hipSuccess;
+    rc = ok ? HG_OK : HG_ELAUNCH;
+    const uint32_t *d_sel = (const uint32_t *)ctx->d_scratch[7];
+    if (rc == HG_OK && cnt[C_NX4] + cnt[C_NX32])
+        rc = hg::launch_ransnx16_decode(ctx, d_in, (const hg_stream_desc *)ctx->d_scratch[2], d_sel + first[C_NX4], cnt[C_NX4],
+                                        d_sel + first[C_NX32], cnt[C_NX32], d_out, d_st, (uint32_t *)ctx->d_scratch[6], s);
+    if (rc == HG_OK && cnt[C_ARITH_SMALL] + cnt[C_ARITH_BIG])
+        rc = hg::launch_arith_decode(ctx, d_in, (const hg_stream_desc *)ctx->d_scratch[2], d_sel + first[C_ARITH_SMALL], cnt[C_ARITH_SMALL],
+                                     d_sel + first[C_ARITH_BIG], cnt[C_ARITH_BIG], d_out, d_st, (uint32_t *)ctx->d_scratch[6], s);
+    if (rc == HG_OK && nx)
+        rc = hg::launch_ransnx16_xform(ctx, d_in, d_out + obytes, d_out, (const hg::nx16_xform *)ctx->d_scratch[4], nx, d_st, (uint32_t)nc, s);
+    return rc;
+}
+
+// After the stream has been synchronised: folds the job statuses into per-top statuses st[].
+static bool collect_plan_status(hg_ctx *ctx, const Plan &P, std::vector<int32_t> &st, hipStream_t s) {
+    const size_t nc = P.core.size(), nx = P.xf.size(), nst = nc + nx;
+    std::vector<int32_t> jst(nst + 1);
+    if (nst && (hipMemcpyAsync(jst.data(), ctx->d_scratch[3], nst * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) return false;
+    for (size_t k = 0; k < nc; k++) if (jst[k] != 0 && st[P.core_top[k]] == 0) st[P.core_top[k]] = jst[k];
+    for (size_t k = 0; k < nx; k++) if (jst[nc + k] != 0 && st[P.xf_top[k]] == 0) st[P.xf_top[k]] = jst[nc + k];
+    return true;
+}
+
 static int entropy_decode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
                                uint8_t *const *out, const uint32_t *out_len, int32_t *status) {
     if (!ctx || (n && (!in || !in_len || !out || !out_len))) return HG_EINVAL;
@@ -186,51 +235,138 @@ static int entropy_decode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         ooff += ((uint64_t)out_len[i] + 15u) & ~15ull;
     }
     if (P.too_big) return HG_EINVAL;
-    const size_t nc = P.core.size(), nx = P.xf.size();
-    // the core kernel addresses ONE output allocation: [ output buffer | work buffer ]
     const uint64_t obytes = (ooff + 63u) & ~63ull;
-    std::vector<uint32_t> sel(nc);
-    size_t cnt[C_CLASSES] = {0}, first[C_CLASSES + 1] = {0};
-    for (size_t k = 0; k < nc; k++) {
-        hg_stream_desc &d = P.core[k];
-        if (d.out_off >> 63) d.out_off &= ~(1ull << 63); else d.out_off += obytes;
-        cnt[P.core_cls[k]]++;
-    }
-    for (int c = 0; c < C_CLASSES; c++) first[c + 1] = first[c] + cnt[c];
-    { size_t fill[C_CLASSES]; for (int c = 0; c < C_CLASSES; c++) fill[c] = first[c];
-      for (size_t k = 0; k < nc; k++) sel[fill[P.core_cls[k]]++] = (uint32_t)k; }
     int rc;
-    const size_t nst = nc + nx;
-    if ((rc = ensure_scratch(ctx, 0, ioff + 64)) || (rc = ensure_scratch(ctx, 1, obytes + P.work + 64)) ||
-        (rc = ensure_scratch(ctx, 2, nc * sizeof(hg_stream_desc) + 64)) || (rc = ensure_scratch(ctx, 3, nst * 4 + 64)) ||
-        (rc = ensure_scratch(ctx, 4, nx * sizeof(hg::nx16_xform) + 64)) ||
-        (rc = ensure_scratch(ctx, 6, P.scratch * 4 + 64)) || (rc = ensure_scratch(ctx, 7, nc * 4 + 64))) return rc;
+    if ((rc = ensure_scratch(ctx, 0, ioff + 64))) return rc;
     hipStream_t s = nullptr;
-    uint8_t *d_in = (uint8_t *)ctx->d_scratch[0], *d_out = (uint8_t *)ctx->d_scratch[1];
-    int32_t *d_st = (int32_t *)ctx->d_scratch[3];
-    bool ok = hipMemsetAsync(d_st, 0xff, nst * 4 + 4, s) == hipSuccess;
+    uint8_t *d_in = (uint8_t *)ctx->d_scratch[0];
+    bool ok = true;
     for (size_t i = 0; i < n && ok; i++)
         if (in_len[i] && st[i] == 0) ok = hipMemcpyAsync(d_in + ioffs[i], in[i], in_len[i], hipMemcpyHostToDevice, s) == hipSuccess;
-    if (nc) ok = ok && hipMemcpyAsync(ctx->d_scratch[2], P.core.data(), nc * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess &&
-                 hipMemcpyAsync(ctx->d_scratch[7], sel.data(), nc * 4, hipMemcpyHostToDevice, s) == hipSuccess;
-    if (nx) ok = ok && hipMemcpyAsync(ctx->d_scratch[4], P.xf.data(), nx * sizeof(hg::nx16_xform), hipMemcpyHostToDevice, s) == hipSuccess;
-    rc = ok ? HG_OK : HG_ELAUNCH;
-    const uint32_t *d_sel = (const uint32_t *)ctx->d_scratch[7];
-    if (rc == HG_OK && cnt[C_NX4] + cnt[C_NX32])
-        rc = hg::launch_ransnx16_decode(ctx, d_in, (const hg_stream_desc *)ctx->d_scratch[2], d_sel + first[C_NX4], cnt[C_NX4],
-                                        d_sel + first[C_NX32], cnt[C_NX32], d_out, d_st, (uint32_t *)ctx->d_scratch[6], s);
-    if (rc == HG_OK && cnt[C_ARITH_SMALL] + cnt[C_ARITH_BIG])
-        rc = hg::launch_arith_decode(ctx, d_in, (const hg_stream_desc *)ctx->d_scratch[2], d_sel + first[C_ARITH_SMALL], cnt[C_ARITH_SMALL],
-                                     d_sel + first[C_ARITH_BIG], cnt[C_ARITH_BIG], d_out, d_st, (uint32_t *)ctx->d_scratch[6], s);
-    if (rc == HG_OK && nx)
-        rc = hg::launch_ransnx16_xform(ctx, d_in, d_out + obytes, d_out, (const hg::nx16_xform *)ctx->d_scratch[4], nx, d_st, (uint32_t)nc, s);
+    rc = ok ? launch_plan(ctx, P, ioff, obytes, s) : HG_ELAUNCH;
     if (rc == HG_OK) {
-        std::vector<int32_t> jst(nst + 1);
-        ok = hipMemcpyAsync(jst.data(), d_st, nst * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-        for (size_t k = 0; k < nc && ok; k++) if (jst[k] != 0 && st[P.core_top[k]] == 0) st[P.core_top[k]] = jst[k];
-        for (size_t k = 0; k < nx && ok; k++) if (jst[nc + k] != 0 && st[P.xf_top[k]] == 0) st[P.xf_top[k]] = jst[nc + k];
+        ok = hipStreamSynchronize(s) == hipSuccess && collect_plan_status(ctx, P, st, s);
+        const uint8_t *d_out = (const uint8_t *)ctx->d_scratch[1];
         for (size_t i = 0; i < n && ok; i++)
             if (out_len[i] && st[i] == 0) ok = hipMemcpy(out[i], d_out + ooffs[i], out_len[i], hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok) rc = HG_ELAUNCH;
+    }
+    if (rc == HG_OK)
+        for (size_t i = 0; i < n; i++) { if (status) status[i] = st[i]; if (st[i] != 0) rc = HG_EBLOCK; }
+    return rc;
+}
+
+// ================================================================================================
+// tok3 (name tokeniser, CRAM block method 8) decode: hg_tok3_decode_host replaces tok3_decode_names (call site
+// cram/cram_io.c:1735-1749).  The container walk (a few bytes per token stream) is done here; every token stream
+// is a complete Nx16 / range-coder stream and joins ONE entropy plan for the whole batch; the names are then
+// rebuilt by tok3.hip, one wavefront per block, on the same HIP stream.
+// ================================================================================================
+extern "C" int hg_tok3_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
+                                   uint8_t *const *out, const uint32_t *out_len, int32_t *status) {
+    if (!ctx || (n && (!in || !in_len || !out || !out_len))) return HG_EINVAL;
+    if (n == 0) return HG_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    enum { MAX_TOK = 128, T_END = 12, T_MATCH = 10 };
+    Plan P;
+    std::vector<int32_t> st(n, 0);
+    std::vector<uint64_t> ioffs(n);
+    std::vector<hg::tok3_job> jobs;
+    std::vector<uint32_t> job_top, tab;
+    uint64_t ioff = 0, tboff = 0, ooff = 0, recs = 0, names = 0;
+    for (size_t i = 0; i < n; i++) {
+        ioffs[i] = ioff;
+        const uint64_t my_ioff = ioff;
+        ioff += ((uint64_t)in_len[i] + 15u) & ~15ull;
+        const uint8_t *b = in[i], *end = b + in_len[i];
+        if (in_len[i] < 9) { st[i] = -1; continue; }
+        const uint32_t ulen = b[0] | b[1] << 8 | b[2] << 16 | (uint32_t)b[3] << 24, nn = b[4] | b[5] << 8 | b[6] << 16 | (uint32_t)b[7] << 24;
+        const uint32_t use_arith = b[8];
+        if (ulen != out_len[i] || use_arith > 1 || nn > ulen) { st[i] = -1; continue; }
+        const size_t c0 = P.core.size(), x0 = P.xf.size(), t0 = tab.size();
+        const uint64_t w0 = P.work, s0 = P.scratch, tb0 = tboff;
+        struct Ent { uint32_t off, len; bool set; } E[MAX_TOK][16];
+        memset(E, 0, sizeof E);
+        int t = -1, bad = 0;
+        const uint8_t *cp = b + 9;
+        const uint64_t cap = (uint64_t)ulen * 5 + 64;
+        while (cp < end && !bad) {
+            const uint8_t tt = *cp++;
+            const int type = tt & 15;
+            if (tt & 0x80) {
+                if (++t >= MAX_TOK) { bad = -1; break; }
+                if (type != 0) { if (!nn) { bad = -1; break; } E[t][0] = {(uint32_t)type, nn | 0x80000000u, true}; }     // implied TYPE stream
+            }
+            if (t < 0 || type > T_END || E[t][type].set) { bad = -1; break; }
+            if (tt & 0x40) {
+                if (end - cp < 2) { bad = -1; break; }
+                const int dp = cp[0], dt = cp[1]; cp += 2;
+                if (dp > t || dt > T_END || !E[dp][dt].set) { bad = -1; break; }
+                E[t][type] = E[dp][dt];
+            } else {
+                uint32_t clen, sz;
+                if (get_u7(cp, end, clen) || (uint64_t)(end - cp) < clen || clen < 1) { bad = -1; break; }
+                const uint8_t *sp = cp + 1;
+                if ((cp[0] & F_NOSZ) || get_u7(sp, cp + clen, sz) || sz > cap) { bad = -1; break; }
+                if (tboff - tb0 + sz > 0x7fffffffull) { bad = -1; break; }
+                E[t][type] = {(uint32_t)(tboff - tb0), sz, true};
+                if (int r = plan_stream(P, use_arith ? ARITH : NX16, (uint32_t)i, my_ioff, b, cp, cp + clen, -1, tboff, 1, 0)) { bad = r; break; }
+                tboff += ((uint64_t)sz + 15u) & ~15ull;
+                cp += clen;
+            }
+        }
+        if (bad) {
+            st[i] = bad;
+            P.core.resize(c0); P.core_top.resize(c0); P.core_cls.resize(c0); P.xf.resize(x0); P.xf_top.resize(x0); P.work = w0; P.scratch = s0;
+            tab.resize(t0); tboff = tb0;
+            continue;
+        }
+        hg::tok3_job J;
+        memset(&J, 0, sizeof J);
+        J.tb_base = tb0; J.out_off = ooff; J.rec_off = recs; J.name_off = names; J.tab_off = (uint32_t)t0;
+        J.ntp = (uint32_t)(t + 1); J.nn = nn; J.ulen = ulen;
+        uint64_t rc_ = 0;
+        for (int a = 0; a <= t; a++) {
+            if (a >= 1) rc_ += E[a][0].len & 0x7fffffffu;
+            for (int ty = 0; ty < 16; ty++) { tab.push_back(E[a][ty].off); tab.push_back(E[a][ty].set ? E[a][ty].len : 0u); }
+        }
+        if (rc_ > 0xffffffffull || tab.size() > 0x7fffffffull) return HG_EINVAL;
+        J.rec_cap = (uint32_t)rc_;
+        recs += rc_ + 64; names += 3ull * (nn + 1ull);
+        ooff += ((uint64_t)ulen + 15u) & ~15ull;
+        jobs.push_back(J); job_top.push_back((uint32_t)i);
+    }
+    if (P.too_big) return HG_EINVAL;
+    const size_t nj = jobs.size();
+    const uint64_t tbytes = (tboff + 63u) & ~63ull;
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, ioff + 64)) || (rc = ensure_scratch(ctx, 8, ooff + 64)) || (rc = ensure_scratch(ctx, 9, recs * 12 + 64)) ||
+        (rc = ensure_scratch(ctx, 10, names * 4 + 64)) || (rc = ensure_scratch(ctx, 11, tab.size() * 4 + 64)) ||
+        (rc = ensure_scratch(ctx, 12, nj * sizeof(hg::tok3_job) + nj * 4 + 64))) return rc;
+    hipStream_t s = nullptr;
+    uint8_t *d_in = (uint8_t *)ctx->d_scratch[0];
+    bool ok = true;
+    for (size_t i = 0; i < n && ok; i++)
+        if (in_len[i] && st[i] == 0) ok = hipMemcpyAsync(d_in + ioffs[i], in[i], in_len[i], hipMemcpyHostToDevice, s) == hipSuccess;
+    rc = ok ? launch_plan(ctx, P, ioff, tbytes, s) : HG_ELAUNCH;
+    hg::tok3_job *d_jobs = (hg::tok3_job *)ctx->d_scratch[12];
+    int32_t *d_jst = (int32_t *)(d_jobs + nj);
+    if (rc == HG_OK && nj) {
+        ok = hipMemcpyAsync(d_jobs, jobs.data(), nj * sizeof(hg::tok3_job), hipMemcpyHostToDevice, s) == hipSuccess &&
+             hipMemcpyAsync(ctx->d_scratch[11], tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+             hipMemsetAsync(d_jst, 0xff, nj * 4, s) == hipSuccess;
+        rc = ok ? hg::launch_tok3_names(ctx, ctx->d_scratch[1], d_jobs, nj, (const uint32_t *)ctx->d_scratch[11], ctx->d_scratch[8],
+                                        (uint32_t *)ctx->d_scratch[9], (uint32_t *)ctx->d_scratch[10], d_jst, s) : HG_ELAUNCH;
+    }
+    if (rc == HG_OK) {
+        std::vector<int32_t> jst(nj + 1);
+        ok = (!nj || hipMemcpyAsync(jst.data(), d_jst, nj * 4, hipMemcpyDeviceToHost, s) == hipSuccess) && hipStreamSynchronize(s) == hipSuccess &&
+             collect_plan_status(ctx, P, st, s);
+        for (size_t k = 0; k < nj && ok; k++) {
+            const uint32_t i = job_top[k];
+            if (st[i] == 0 && jst[k] != 0) st[i] = jst[k];
+            if (st[i] == 0 && out_len[i]) ok = hipMemcpy(out[i], (const uint8_t *)ctx->d_scratch[8] + jobs[k].out_off, out_len[i], hipMemcpyDeviceToHost) == hipSuccess;
+        }
         if (!ok) rc = HG_ELAUNCH;
     }
     if (rc == HG_OK)

@@ -5,14 +5,15 @@
 #include <stdint.h>
 #include "htsgpu.h"
 
+#define HG_SCRATCH_SLOTS 16
 struct hg_ctx {
     int device;
     int cus;
     int waves_per_launch;     // resident wavefronts the persistent kernels are sized for
     unsigned int *d_ticket;   // work-queue counter (device)
     // scratch for the host-buffer convenience entry points (grown on demand)
-    void *d_scratch[8];
-    size_t d_scratch_cap[8];
+    void *d_scratch[HG_SCRATCH_SLOTS];
+    size_t d_scratch_cap[HG_SCRATCH_SLOTS];
     void *d_tok;              // deflate token lists, 256 KiB per resident workgroup
     size_t d_tok_cap;
 };
@@ -68,6 +69,17 @@ int launch_arith_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
 int launch_arith_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags, const uint32_t *d_sel_small,
                         size_t nsmall, const uint32_t *d_sel_big, size_t nbig, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch,
                         hipStream_t s);
+// tok3.hip: one name-reconstruction job per CRAM method-8 block
+struct tok3_job {
+    uint64_t tb_base;      // where this block's decoded token streams start in the token buffer
+    uint64_t out_off;      // output buffer
+    uint64_t rec_off;      // first token record (3 words each)
+    uint64_t name_off;     // per-name arrays: noff[nn+1], first[nn+1], ntok[nn+1] (words)
+    uint32_t tab_off;      // stream table: (offset, length) words for [position][16 types]
+    uint32_t ntp, nn, ulen, rec_cap, pad;
+};
+int launch_tok3_names(hg_ctx *ctx, const void *d_tb, const tok3_job *d_jobs, size_t njobs, const uint32_t *d_tab, void *d_out,
+                      uint32_t *d_rec, uint32_t *d_names, int32_t *d_status, hipStream_t s);
 int ensure_scratch(hg_ctx *ctx, int slot, size_t bytes);
 uint32_t ransnx16_enc_scratch_words(uint32_t flags);
 int launch_ransnx16_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags,

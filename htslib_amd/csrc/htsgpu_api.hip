@@ -67,7 +67,7 @@ int hg_init(int device, hg_ctx **out) {
 void hg_destroy(hg_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (int i = 0; i < 8; i++) if (ctx->d_scratch[i]) (void)hipFree(ctx->d_scratch[i]);
+    for (int i = 0; i < HG_SCRATCH_SLOTS; i++) if (ctx->d_scratch[i]) (void)hipFree(ctx->d_scratch[i]);
     if (ctx->d_tok) (void)hipFree(ctx->d_tok);
     if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
     free(ctx);
@@ -180,7 +180,7 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
     if (!ctx || (n && (!method || !in || !in_len || !out || !out_len || !status))) return HG_EINVAL;
     if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
     // partition by method
-    size_t ng = 0, nr = 0, nx_ = 0, na = 0;
+    size_t ng = 0, nr = 0, nx_ = 0, na = 0, nt = 0;
     for (size_t i = 0; i < n; i++) {
         status[i] = 0;
         if (out_len[i] == 0 || method[i] == HG_CRAM_RAW) {            // cram_io.c:1594-1603: nothing to do
@@ -189,12 +189,13 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
         else if (method[i] == HG_CRAM_RANS4x8) nr++;
         else if (method[i] == HG_CRAM_RANSNx16) nx_++;
         else if (method[i] == HG_CRAM_ARITH) na++;
+        else if (method[i] == HG_CRAM_TOK3) nt++;
         else status[i] = HG_BLOCK_EUNSUPPORTED;
     }
     int rc = HG_OK;
-    for (int pass = 0; pass < 2; pass++) {                            // Nx16, then the range coder
-        const int32_t meth = pass ? HG_CRAM_ARITH : HG_CRAM_RANSNx16;
-        const size_t nx = pass ? na : nx_;
+    for (int pass = 0; pass < 3; pass++) {                            // Nx16, the range coder, the name tokeniser
+        const int32_t meth = pass == 2 ? HG_CRAM_TOK3 : pass ? HG_CRAM_ARITH : HG_CRAM_RANSNx16;
+        const size_t nx = pass == 2 ? nt : pass ? na : nx_;
         if (!nx) continue;
         const uint8_t **xin = (const uint8_t **)malloc(nx * sizeof(void *));
         uint8_t **xout = (uint8_t **)malloc(nx * sizeof(void *));
@@ -204,7 +205,8 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
         size_t k = 0;
         for (size_t i = 0; i < n; i++)
             if (out_len[i] && method[i] == meth) { xin[k] = in[i]; xout[k] = out[i]; xl[k] = in_len[i]; xo[k] = out_len[i]; map[k] = i; k++; }
-        int r = pass ? hg_arith_decode_host(ctx, xin, xl, nx, xout, xo, xs) : hg_ransnx16_decode_host(ctx, xin, xl, nx, xout, xo, xs);
+        int r = pass == 2 ? hg_tok3_decode_host(ctx, xin, xl, nx, xout, xo, xs)
+              : pass ? hg_arith_decode_host(ctx, xin, xl, nx, xout, xo, xs) : hg_ransnx16_decode_host(ctx, xin, xl, nx, xout, xo, xs);
         if (r != HG_OK && r != HG_EBLOCK) rc = r;
         for (k = 0; k < nx; k++) status[map[k]] = (r == HG_OK || r == HG_EBLOCK) ? xs[k] : -1;
         free(xin); free(xout); free(xl); free(xo); free(xs); free(map);

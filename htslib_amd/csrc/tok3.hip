@@ -1,0 +1,198 @@
+// tok3.hip -- CRAM 3.1 read-name tokeniser (block method 8): name reconstruction / tokenisation kernels
+// for MI355X (gfx950).
+//
+// Replaces tok3_decode_names / tok3_encode_names as called at reference cram/cram_io.c:1735-1749 and
+// 1885-1895 (implementation = htscodecs tokenise_name3.c, an ABSENT submodule).  Container and token
+// semantics per oracle/tok3_oracle.c -- PARITY UNPINNED; the kernels are bit-exact with that oracle.
+//
+// A tok3 block is ~20-60 small entropy-coded byte streams, one per (token position, token type), plus
+// the rule that rebuilds every name from the previous one.  The streams are decoded by the rANS Nx16 /
+// range-coder kernels (planned by cram_entropy_host.hip, all streams of all blocks in one launch).
+// What is left is inherently ordered -- name n refers to name n-d -- so the mapping is one wavefront
+// per block with the 64 lanes spread over the TOKEN POSITIONS of the current name:
+//   lane t owns the read cursors of every stream of position t+1 (kept in LDS), peeks its next TYPE
+//   byte, one ballot finds the END token, the lanes before it fetch their token (text, number, delta or
+//   a copy of the reference name's token), a DPP prefix sum of the token lengths places them, and every
+//   lane writes its own few bytes.  Names with more than 64 tokens take a second pass.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "htsgpu.h"
+#include "hg_device.h"
+#include "hg_internal.h"
+
+namespace hgt {
+using hg::wave_sync;
+using hg::wave_incl_scan_dpp;
+
+enum { T_TYPE = 0, T_STRING = 1, T_CHAR = 2, T_DIGITS0 = 3, T_DZLEN = 4, T_DUP = 5, T_DIFF = 6, T_DIGITS = 7,
+       T_DELTA = 8, T_DELTA0 = 9, T_MATCH = 10, T_NOP = 11, T_END = 12, NTYPES = 13, MAX_TOK = 128 };
+
+struct WaveLds { uint32_t off[NTYPES][MAX_TOK], len[NTYPES][MAX_TOK], cur[NTYPES][MAX_TOK]; };
+
+__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ __forceinline__ uint32_t ndigits(uint32_t v) {
+    return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u
+         : v < 10000000u ? 7u : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
+}
+
+__global__ __launch_bounds__(64)
+void tok3_names_kernel(const uint8_t *__restrict__ tb, const hg::tok3_job *__restrict__ jobs, uint32_t njobs,
+                       const uint32_t *__restrict__ tab, uint8_t *out, uint32_t *rec, uint32_t *names, int32_t *status) {
+    __shared__ WaveLds S;
+    const int lane = threadIdx.x;
+    for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
+        const hg::tok3_job J = jobs[j];
+        const uint8_t *B = tb + J.tb_base;
+        uint8_t *o = out + J.out_off;
+        uint32_t *R = rec + J.rec_off * 3ull;                      // (off, len | numeric << 31, val) per token
+        uint32_t *noff = names + J.name_off, *first = noff + (J.nn + 1u), *ntok = first + (J.nn + 1u);
+        int err = (J.nn && J.ntp < 1) ? 1 : 0;
+        // stream table -> LDS; positions beyond ntp are empty
+        for (uint32_t i = (uint32_t)lane; i < NTYPES * MAX_TOK; i += 64) {
+            const uint32_t ty = i / MAX_TOK, tp = i % MAX_TOK;
+            const bool have = tp < J.ntp;
+            S.off[ty][tp] = have ? tab[J.tab_off + (tp * 16u + ty) * 2u] : 0u;
+            S.len[ty][tp] = have ? tab[J.tab_off + (tp * 16u + ty) * 2u + 1u] : 0u;
+            S.cur[ty][tp] = 0;
+        }
+        wave_sync();
+        uint32_t opos = 0, nrec = 0;
+        if (lane == 0) noff[0] = 0;
+        for (uint32_t n = 0; n < J.nn && !err; n++) {
+            // ---- position 0: DUP / DIFF and the distance ------------------------------------------
+            uint32_t ty0 = 255, dist = 0;
+            {
+                const uint32_t c = S.cur[T_TYPE][0], l = S.len[T_TYPE][0];
+                if (c < (l & 0x7fffffffu)) ty0 = (l >> 31) ? (c == 0 ? S.off[T_TYPE][0] : (uint32_t)T_MATCH) : B[S.off[T_TYPE][0] + c];
+                if (ty0 != T_DUP && ty0 != T_DIFF) { err = 1; break; }
+                const uint32_t dc = S.cur[ty0][0];
+                if (dc + 4u > S.len[ty0][0]) { err = 1; break; }
+                const uint8_t *p = B + S.off[ty0][0] + dc;
+                dist = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+                wave_sync();
+                if (lane == 0) { S.cur[T_TYPE][0] = c + 1u; S.cur[ty0][0] = dc + 4u; }
+                wave_sync();
+            }
+            if (dist > n) { err = 1; break; }
+            const uint32_t m = n - dist;
+            if (ty0 == T_DUP) {
+                if (m == n) { err = 1; break; }
+                const uint32_t s = noff[m], len = noff[m + 1] - s;
+                if (opos + len > J.ulen) { err = 1; break; }
+                for (uint32_t k = (uint32_t)lane; k < len; k += 64) o[opos + k] = o[s + k];
+                opos += len;
+                if (lane == 0) { first[n] = first[m]; ntok[n] = ntok[m]; noff[n + 1] = opos; }
+                wave_sync();
+                continue;
+            }
+            const uint32_t pfirst = m != n ? first[m] : 0u, pntok = m != n ? ntok[m] : 0u;
+            const uint32_t rec0 = nrec;
+            bool ended = false;
+            for (uint32_t pass = 0; pass < 2 && !ended && !err; pass++) {
+                const uint32_t tp = 1u + 64u * pass + (uint32_t)lane;
+                // peek my TYPE byte
+                uint32_t ty = 255;
+                const uint32_t tc = tp < MAX_TOK ? S.cur[T_TYPE][tp] : 0u, tl = tp < MAX_TOK ? S.len[T_TYPE][tp] : 0u;
+                if (tp < MAX_TOK && tc < (tl & 0x7fffffffu))
+                    ty = (tl >> 31) ? (tc == 0 ? S.off[T_TYPE][tp] : (uint32_t)T_MATCH) : B[S.off[T_TYPE][tp] + tc];
+                const unsigned long long stop = __ballot(ty == T_END || ty > T_END);       // END, or nothing left to read
+                const uint32_t E = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+                if (stop && rl(ty, E) != T_END) { err = 1; break; }                        // ran out of TYPE bytes before END
+                ended = stop != 0;
+                const bool act = (uint32_t)lane <= E && (uint32_t)lane < 64u;
+                // ---- fetch my token ----------------------------------------------------------------
+                uint32_t len = 0, val = 0, numeric = 0, width = 0, src = 0;                 // src: 1 stream text, 2 previous output, 3 number, 4 char
+                uint32_t src_off = 0, chr = 0;
+                int bad = 0;
+                if (act) {
+                    S.cur[T_TYPE][tp] = tc + 1u;
+                    const uint32_t pi = tp - 1u;                                            // token index inside a name
+                    uint32_t P0 = 0, P1 = 0, P2 = 0; bool haveP = false;
+                    if ((ty == T_DELTA || ty == T_DELTA0 || ty == T_MATCH)) {
+                        if (pi < pntok) { const uint32_t *q = R + (size_t)(pfirst + pi) * 3u; P0 = q[0]; P1 = q[1]; P2 = q[2]; haveP = true; }
+                        else bad = 1;
+                    }
+                    if (ty == T_TYPE || ty == T_DZLEN || ty == T_DUP || ty == T_DIFF) bad = 1;    // not token types
+                    else if (ty == T_STRING) {
+                        const uint32_t c = S.cur[T_STRING][tp], l = S.len[T_STRING][tp];
+                        const uint8_t *p = B + S.off[T_STRING][tp];
+                        uint32_t e = c;
+                        while (e < l && p[e]) e++;
+                        if (e >= l) bad = 1;
+                        else { len = e - c; src = 1; src_off = S.off[T_STRING][tp] + c; S.cur[T_STRING][tp] = e + 1u; }
+                    } else if (ty == T_CHAR) {
+                        const uint32_t c = S.cur[T_CHAR][tp];
+                        if (c >= S.len[T_CHAR][tp]) bad = 1;
+                        else { chr = B[S.off[T_CHAR][tp] + c]; len = 1; src = 4; S.cur[T_CHAR][tp] = c + 1u; }
+                    } else if (ty == T_DIGITS || ty == T_DIGITS0) {
+                        const uint32_t c = S.cur[ty][tp];
+                        if (c + 4u > S.len[ty][tp]) bad = 1;
+                        else {
+                            const uint8_t *p = B + S.off[ty][tp] + c;
+                            val = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+                            S.cur[ty][tp] = c + 4u; numeric = 1; src = 3;
+                            if (ty == T_DIGITS0) {
+                                const uint32_t z = S.cur[T_DZLEN][tp];
+                                if (z >= S.len[T_DZLEN][tp]) bad = 1;
+                                else { width = B[S.off[T_DZLEN][tp] + z]; S.cur[T_DZLEN][tp] = z + 1u; }
+                            }
+                        }
+                    } else if (ty == T_DELTA || ty == T_DELTA0) {
+                        const uint32_t c = S.cur[ty][tp];
+                        if (!haveP || c >= S.len[ty][tp]) bad = 1;
+                        else {
+                            val = P2 + B[S.off[ty][tp] + c]; S.cur[ty][tp] = c + 1u; numeric = 1; src = 3;
+                            if (ty == T_DELTA0) width = P1 & 0x7fffffffu;
+                        }
+                    } else if (ty == T_MATCH) {
+                        if (haveP) { len = P1 & 0x7fffffffu; numeric = P1 >> 31; val = P2; src = 2; src_off = P0; }
+                    }
+                    if (src == 3) { if (width > 15u) width = 15u; const uint32_t nd = ndigits(val); len = nd > width ? nd : width; }
+                }
+                if (__any(bad)) { err = 1; break; }
+                // ---- place and write -----------------------------------------------------------------
+                const uint32_t incl = wave_incl_scan_dpp(act ? len : 0u);
+                const uint32_t total = rl(incl, 63), at = opos + incl - (act ? len : 0u);
+                if ((unsigned long long)opos + total > J.ulen) { err = 1; break; }
+                if (act) {
+                    uint8_t *w = o + at;
+                    if (src == 1) { const uint8_t *p = B + src_off; for (uint32_t k = 0; k < len; k++) w[k] = p[k]; }
+                    else if (src == 2) { const uint8_t *p = o + src_off; for (uint32_t k = 0; k < len; k++) w[k] = p[k]; }
+                    else if (src == 4) w[0] = (uint8_t)chr;
+                    else if (src == 3) { uint32_t v = val; for (uint32_t k = len; k-- > 0;) { w[k] = (uint8_t)('0' + v % 10u); v /= 10u; } }
+                    uint32_t *q = R + (size_t)(nrec + (uint32_t)lane) * 3u;
+                    q[0] = at; q[1] = len | (numeric << 31); q[2] = val;
+                }
+                const uint32_t nact = E < 64u ? E + 1u : 64u;
+                if (nrec + nact > J.rec_cap) { err = 1; break; }
+                nrec += nact;
+                opos += total;
+                wave_sync();
+            }
+            if (err) break;
+            if (!ended) { err = 1; break; }
+            if (opos + 1u > J.ulen) { err = 1; break; }
+            if (lane == 0) { o[opos] = 0; first[n] = rec0; ntok[n] = nrec - rec0; noff[n + 1] = opos + 1u; }
+            opos += 1u;
+            wave_sync();
+        }
+        if (!err && opos != J.ulen) err = 1;
+        status[j] = err ? -1 : 0;                                   // every lane stores the same word
+        wave_sync();
+    }
+}
+
+}  // namespace hgt
+
+namespace hg {
+int launch_tok3_names(hg_ctx *ctx, const void *d_tb, const tok3_job *d_jobs, size_t njobs, const uint32_t *d_tab, void *d_out,
+                      uint32_t *d_rec, uint32_t *d_names, int32_t *d_status, hipStream_t s) {
+    if (!njobs) return HG_OK;
+    size_t wgs = njobs;
+    const size_t maxw = (size_t)ctx->cus * 8;
+    if (wgs > maxw) wgs = maxw;
+    hipLaunchKernelGGL(hgt::tok3_names_kernel, dim3((unsigned)wgs), dim3(64), 0, s, (const uint8_t *)d_tb, d_jobs, (uint32_t)njobs,
+                       d_tab, (uint8_t *)d_out, d_rec, d_names, d_status);
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+}  // namespace hg

@@ -193,6 +193,14 @@ size_t hg_arith_compress_bound(size_t in_len);
 int hg_arith_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags,
                          size_t n, uint8_t *const *out, uint32_t *out_len);
 
+/* ---- CRAM 3.1 read-name tokeniser "tok3" (replaces tok3_decode_names / tok3_encode_names as called at
+ *      cram/cram_io.c:1735-1749 and 1885-1895; CRAM block method 8).  PARITY UNPINNED (oracle/tok3_oracle.c).
+ *      Names are NUL-terminated in the plain buffer (NEWS:278).  The token byte streams inside a block are
+ *      rANS Nx16 or range-coder streams and go through those kernels; tok3.hip rebuilds / tokenises the
+ *      names, one wavefront per block. ---- */
+int hg_tok3_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
+                        uint8_t *const *out, const uint32_t *out_len, int32_t *status);
+
 /* ---- CRAM block layer (replaces cram_uncompress_block, cram/cram_io.c:1576-1754) ------------ */
 /* on-disk method ids, htslib/cram.h:84-101 */
 #define HG_CRAM_RAW      0
@@ -209,7 +217,7 @@ int hg_arith_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *
 /* Uncompress n CRAM blocks in one batch: block i has on-disk method method[i], compressed payload
  * in[i] (in_len[i] = comp_size) and must produce exactly out_len[i] = uncomp_size bytes into out[i]
  * (cram_uncompress_block's size check, cram_io.c:1611-1614).  RAW blocks are copied, GZIP, RANS4x8,
- * RANSNx16 and ARITH blocks go to the gfx950 kernels; status[i] = 0 / -1 / -2 (CRC) / -3 (unsupported method).
+ * RANSNx16, ARITH and TOK3 blocks go to the gfx950 kernels; status[i] = 0 / -1 / -2 (CRC) / -3 (unsupported method).
  * Synchronous; returns 0, or HG_EBLOCK if any status is non-zero. */
 int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method, const uint8_t *const *in,
                                    const uint32_t *in_len, uint8_t *const *out, const uint32_t *out_len,

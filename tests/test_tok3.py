@@ -68,3 +68,35 @@ def test_oracle_compresses_names(torc):
     assert len(torc.encode(dup)) < 0.15 * len(dup)              # the mate costs a DUP token
     # constant leading tokens cost one implied TYPE stream each, not a byte per name
     assert len(torc.encode(b"same\0" * 1000)) < 150
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_arith", [0, 1])
+def test_gpu_decoder_matches_oracle(engine, torc, use_arith):
+    rng = np.random.default_rng(80 + use_arith)
+    sets = sample_sets(rng) + [illumina_names(rng, 10_000), odd_names(rng, 3000)]
+    blocks = [(8, torc.encode(d, use_arith), len(d)) for d in sets]
+    outs, st = engine.cram_uncompress_blocks(blocks)
+    bad = [(i, len(sets[i]), int(st[i])) for i in range(len(sets)) if len(sets[i]) and (st[i] != 0 or outs[i] != sets[i])]
+    assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_gpu_decoder_fuzz_agrees_with_oracle(engine, torc):
+    rng = np.random.default_rng(90)
+    plain = illumina_names(rng, 400) + odd_names(rng, 100)
+    base = [torc.encode(plain, 0), torc.encode(plain, 1)]
+    bad = []
+    for rep in range(300):
+        b = bytearray(base[rep & 1])
+        pos = int(rng.integers(0, len(b)))
+        b[pos] ^= 1 << int(rng.integers(0, 8))
+        bad.append(bytes(b))
+    bad += [base[0][:-7], base[0][:9], base[1][:200], b"", b"\x05\x00\x00\x00\x01\x00\x00\x00\x00"]
+    outs, st = engine.cram_uncompress_blocks([(8, b, len(plain)) for b in bad])
+    for b, o, s in zip(bad, outs, st):
+        rc, want = torc.decode(b, len(plain))
+        if rc == 0 and len(want) == len(plain):
+            assert s == 0 and o == want
+        else:
+            assert s != 0
