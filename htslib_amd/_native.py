@@ -77,13 +77,17 @@ lib.hg_arith_encode_host.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]
 
 lib.hg_tok3_decode_host.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]
 
+lib.hg_tok3_compress_bound.restype = C.c_size_t
+lib.hg_tok3_compress_bound.argtypes = [C.c_size_t]
+lib.hg_tok3_encode_host.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]
+
 EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info", "hg_bgzf_scan",
            "hg_bgzf_inflate_dev", "hg_bgzf_inflate_host", "hg_crc32_dev", "hg_bgzf_deflate_dev", "hg_bgzf_pack_dev",
            "hg_bgzf_deflate_host", "hg_rans4x8_decode_dev", "hg_rans4x8_decode_host",
            "hg_gzip_inflate_dev", "hg_cram_uncompress_blocks_host", "hg_ransnx16_decode_host", "hg_ransnx16_decode_dev",
            "hg_ransnx16_compress_bound", "hg_ransnx16_encode_host", "hg_rans4x8_compress_bound",
            "hg_rans4x8_encode_host", "hg_gzip_compress_bound", "hg_gzip_deflate_host", "hg_cram_compress_bound",
-           "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host", "hg_tok3_decode_host"]
+           "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host", "hg_tok3_decode_host", "hg_tok3_compress_bound", "hg_tok3_encode_host"]
 
 
 class HgError(RuntimeError):
@@ -268,6 +272,16 @@ class Engine:
         ins, outs, ip, op, il, ol = self._ptr_batch(datas, lib.hg_arith_compress_bound)
         fl = np.array(flags, dtype=np.uint8)
         check(lib.hg_arith_encode_host(self._h, ip, il.ctypes.data, fl.ctypes.data, len(datas), op, ol.ctypes.data), "hg_arith_encode_host")
+        return [outs[i].raw[:int(ol[i])] for i in range(len(datas))]
+
+    def tok3_encode_host(self, datas, use_arith):
+        """Tokenise + entropy-code each buffer of NUL-terminated names -> list of CRAM method-8 payloads (b"" = not names)."""
+        import numpy as np
+        if not datas:
+            return []
+        ins, outs, ip, op, il, ol = self._ptr_batch(datas, lib.hg_tok3_compress_bound)
+        ua = np.array(use_arith, dtype=np.uint8)
+        check(lib.hg_tok3_encode_host(self._h, ip, il.ctypes.data, ua.ctypes.data, len(datas), op, ol.ctypes.data), "hg_tok3_encode_host")
         return [outs[i].raw[:int(ol[i])] for i in range(len(datas))]
 
     def ransnx16_encode_host(self, datas, flags):

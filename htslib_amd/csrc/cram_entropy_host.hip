@@ -402,6 +402,10 @@ struct Leaf {
     hg::nx16_xenc_res r;
 };
 
+// An order-1 table costs at most ~4 bytes per distinct (context, symbol) pair plus the alphabet; four stripes each pay
+// their own fixed part.  (hg_ransnx16_compress_bound keeps the reference-style worst case for callers.)
+uint64_t nx16_tight_bound(uint64_t len) { return 7 * len + 40000; }
+
 int put_u7(uint8_t *cp, uint32_t v) {
     uint8_t tmp[5]; int n = 0;
     do { tmp[n++] = v & 0x7f; v >>= 7; } while (v);
@@ -411,9 +415,11 @@ int put_u7(uint8_t *cp, uint32_t v) {
 
 }  // namespace
 
+// When d_src is given the inputs are device-resident (input i = d_src + d_src_off[i], copied device-to-device into
+// the encoder's own staging buffer) and `in` is not read.
 static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags, size_t n,
-                               uint8_t *const *out, uint32_t *out_len) {
-    if (!ctx || (n && (!in || !in_len || !flags || !out || !out_len))) return HG_EINVAL;
+                               uint8_t *const *out, uint32_t *out_len, const uint8_t *d_src = nullptr, const uint64_t *d_src_off = nullptr) {
+    if (!ctx || (n && ((!in && !d_src) || !in_len || !flags || !out || !out_len))) return HG_EINVAL;
     if (n == 0) return HG_OK;
     if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
     std::vector<Leaf> leaves;
@@ -433,7 +439,7 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         if (f & F_STRIPE) f &= codec == NX16 ? ~(uint32_t)(F_PACK | F_RLE | F_CAT) : ~(uint32_t)(F_PACK | F_CAT);
         top_flags[i] = (uint8_t)f;
         uint32_t host_max = 255;
-        if (codec == ARITH && (f & F_ORDER)) { host_max = 0; for (uint32_t q = 0; q < in_len[i]; q++) if (in[i][q] > host_max) host_max = in[i][q]; }
+        if (codec == ARITH && (f & F_ORDER) && !d_src) { host_max = 0; for (uint32_t q = 0; q < in_len[i]; q++) if (in[i][q] > host_max) host_max = in[i][q]; }
         for (uint32_t k = 0; k < S; k++) {
             Leaf L;
             memset(&L, 0, sizeof L);
@@ -441,7 +447,7 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
             L.n = S == 1 ? in_len[i] : in_len[i] / S + ((in_len[i] % S) > k ? 1u : 0u);
             L.flags = S == 1 ? f : ((f & (codec == NX16 ? (F_ORDER | F_X32) : (F_ORDER | F_RLE))) | F_NOSZ);
             L.max_sym = (L.flags & F_PACK) ? 255u : host_max;
-            L.host_src = S == 1 ? in[i] : nullptr;
+            L.host_src = (S == 1 && !d_src) ? in[i] : nullptr;
             L.xjob = L.core = L.mcore = -1;
             const uint32_t xops = L.flags & (codec == NX16 ? (F_PACK | F_RLE) : F_PACK);     // the range coder's RLE is not a transform
             if (S != 1 || xops) {
@@ -463,7 +469,8 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
     uint8_t *d_buf = (uint8_t *)ctx->d_scratch[0];
     bool ok = true;
     for (size_t i = 0; i < n && ok; i++)
-        if (in_len[i]) ok = hipMemcpyAsync(d_buf + ioffs[i], in[i], in_len[i], hipMemcpyHostToDevice, s) == hipSuccess;
+        if (in_len[i]) ok = (d_src ? hipMemcpyAsync(d_buf + ioffs[i], d_src + d_src_off[i], in_len[i], hipMemcpyDeviceToDevice, s)
+                                   : hipMemcpyAsync(d_buf + ioffs[i], in[i], in_len[i], hipMemcpyHostToDevice, s)) == hipSuccess;
     std::vector<hg::nx16_xenc_res> xr(xj.size());
     if (ok && !xj.empty()) {
         hg::nx16_xenc *d_j = (hg::nx16_xenc *)ctx->d_scratch[4];
@@ -484,7 +491,7 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         hg_stream_desc d;
         memset(&d, 0, sizeof d);
         const uint64_t cap = cc == ARITH ? (uint64_t)len + len / 4 + 4096
-                           : (fl & F_ORDER) ? hg_ransnx16_compress_bound(len) : (uint64_t)len + len / 16 + 4096;
+                           : (fl & F_ORDER) ? nx16_tight_bound(len) : (uint64_t)len + len / 16 + 4096;
         d.in_off = src_off; d.in_len = len; d.out_off = ooff; d.out_len = (uint32_t)(cap > 0xffffffffull ? 0xffffffffu : cap);
         d.scratch_off = (uint32_t)soff; d.reserved = (uint32_t)(woff / 16);
         ooff += (cap + 15u) & ~15ull;
@@ -583,7 +590,7 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
             if (!(f & F_NOSZ)) cp += put_u7(cp, in_len[i]);
             *cp++ = (uint8_t)nl;
             // sub-streams are laid out after their length list: build them in a side buffer first
-            tmp.resize(codec == NX16 ? hg_ransnx16_compress_bound(in_len[i]) : hg_arith_compress_bound(in_len[i]));
+            tmp.resize(codec == NX16 ? nx16_tight_bound(in_len[i]) : hg_arith_compress_bound(in_len[i]));
             uint8_t *tp = tmp.data();
             for (uint32_t k = 0; k < nl; k++) { uint8_t *e = emit_leaf(tp, leaves[l0 + k]); cp += put_u7(cp, (uint32_t)(e - tp)); tp = e; }
             memcpy(cp, tmp.data(), (size_t)(tp - tmp.data())); cp += tp - tmp.data();
@@ -601,4 +608,120 @@ extern "C" size_t hg_arith_compress_bound(size_t n) { return n + n / 4 + 4 * 409
 extern "C" int hg_arith_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags, size_t n,
                                     uint8_t *const *out, uint32_t *out_len) {
     return entropy_encode_host(ARITH, ctx, in, in_len, flags, n, out, out_len);
+}
+
+// ================================================================================================
+// tok3 encode: hg_tok3_encode_host replaces tok3_encode_names (call site cram/cram_io.c:1885-1895).
+// tok3.hip tokenises the names into (position, type) byte streams on the device; each stream is then entropy-coded
+// with every setting of a short list (the same list as oracle/tok3_oracle.c best_entropy) through the Nx16 / range-coder
+// encoders above -- inputs stay in HBM -- and the smallest result is kept.  The host only stitches the container.
+// ================================================================================================
+extern "C" size_t hg_tok3_compress_bound(size_t n) { return n * 2 + 65536 + 13 * 128 * 64; }
+
+extern "C" int hg_tok3_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *use_arith, size_t n,
+                                   uint8_t *const *out, uint32_t *out_len) {
+    if (!ctx || (n && (!in || !in_len || !use_arith || !out || !out_len))) return HG_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hipStream_t s = nullptr;
+    size_t i0 = 0;
+    while (i0 < n) {
+        // one group of blocks per round keeps the host-side trial buffers bounded
+        size_t i1 = i0; uint64_t sum = 0;
+        while (i1 < n && (i1 == i0 || sum + in_len[i1] <= (64u << 20))) { sum += in_len[i1]; i1++; }
+        std::vector<hg::tok3_enc_job> jobs;
+        std::vector<size_t> job_blk;
+        uint64_t ioff = 0, sboff = 0;
+        for (size_t i = i0; i < i1; i++) {
+            out_len[i] = 0;
+            if (in_len[i] == 0) {                                       // no names: header only
+                memset(out[i], 0, 9); out[i][8] = use_arith[i] ? 1 : 0; out_len[i] = 9; continue;
+            }
+            if (in[i][in_len[i] - 1] != 0) continue;                    // not a list of NUL-terminated names: out_len 0
+            hg::tok3_enc_job J;
+            J.in_off = ioff; J.sb_off = sboff; J.n = in_len[i]; J.sb_cap = 8u * in_len[i] + 1024u;
+            if ((uint64_t)in_len[i] * 8 + 1024 > 0x7fffffffull) return HG_EINVAL;
+            ioff += ((uint64_t)in_len[i] + 15u) & ~15ull; sboff += ((uint64_t)J.sb_cap + 15u) & ~15ull;
+            jobs.push_back(J); job_blk.push_back(i);
+        }
+        const size_t nj = jobs.size();
+        if (nj) {
+            int rc;
+            if ((rc = ensure_scratch(ctx, 8, ioff + 64)) || (rc = ensure_scratch(ctx, 9, sboff + 64)) ||
+                (rc = ensure_scratch(ctx, 10, nj * (size_t)HG_TOK3_MAX_STREAMS * sizeof(hg::tok3_enc_stream) + 64)) ||
+                (rc = ensure_scratch(ctx, 11, nj * (sizeof(hg::tok3_enc_job) + sizeof(hg::tok3_enc_res)) + 64))) return rc;
+            uint8_t *d_names = (uint8_t *)ctx->d_scratch[8], *d_sb = (uint8_t *)ctx->d_scratch[9];
+            hg::tok3_enc_stream *d_list = (hg::tok3_enc_stream *)ctx->d_scratch[10];
+            hg::tok3_enc_job *d_jobs = (hg::tok3_enc_job *)ctx->d_scratch[11];
+            hg::tok3_enc_res *d_res = (hg::tok3_enc_res *)(d_jobs + nj);
+            bool ok = hipMemcpyAsync(d_jobs, jobs.data(), nj * sizeof(hg::tok3_enc_job), hipMemcpyHostToDevice, s) == hipSuccess;
+            for (size_t k = 0; k < nj && ok; k++)
+                ok = hipMemcpyAsync(d_names + jobs[k].in_off, in[job_blk[k]], jobs[k].n, hipMemcpyHostToDevice, s) == hipSuccess;
+            if (!ok) return HG_ELAUNCH;
+            if ((rc = hg::launch_tok3_tokenise(ctx, d_names, d_jobs, nj, d_sb, d_list, d_res, s))) return rc;
+            std::vector<hg::tok3_enc_res> res(nj);
+            if (hipMemcpyAsync(res.data(), d_res, nj * sizeof(hg::tok3_enc_res), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+            std::vector<std::vector<hg::tok3_enc_stream>> lists(nj);
+            for (size_t k = 0; k < nj; k++) {
+                if (res[k].total == 0xffffffffu || res[k].nstreams > HG_TOK3_MAX_STREAMS) return HG_ELAUNCH;   // cannot happen: 8 bytes/char is the worst case
+                lists[k].resize(res[k].nstreams);
+                if (res[k].nstreams && hipMemcpy(lists[k].data(), d_list + k * (size_t)HG_TOK3_MAX_STREAMS, res[k].nstreams * sizeof(hg::tok3_enc_stream),
+                                                 hipMemcpyDeviceToHost) != hipSuccess) return HG_ELAUNCH;
+            }
+            // ---- entropy trials: one item per (stream, setting) ----------------------------------------------
+            static const uint8_t sets[8] = {0, 1, 64, 65, 128, 129, 8, 9};
+            for (int codec = 0; codec < 2; codec++) {
+                std::vector<uint64_t> soff; std::vector<uint32_t> slen; std::vector<uint8_t> sfl;
+                std::vector<std::pair<uint32_t, uint32_t>> owner;          // (job, stream index)
+                for (size_t k = 0; k < nj; k++) {
+                    if ((use_arith[job_blk[k]] ? 1 : 0) != codec) continue;
+                    for (uint32_t q = 0; q < lists[k].size(); q++) {
+                        const hg::tok3_enc_stream &E = lists[k][q];
+                        if (E.ttype & 0x40) continue;
+                        const int nsets = (E.type == 7 || E.type == 3 || E.type == 5 || E.type == 6) ? 8 : 6;
+                        for (int v = 0; v < nsets; v++) { soff.push_back(jobs[k].sb_off + E.off); slen.push_back(E.len); sfl.push_back(sets[v]); owner.push_back({(uint32_t)k, q}); }
+                    }
+                }
+                const size_t ni = soff.size();
+                if (!ni) continue;
+                std::vector<uint64_t> boff(ni + 1, 0);
+                for (size_t t = 0; t < ni; t++) boff[t + 1] = boff[t] + (codec ? hg_arith_compress_bound(slen[t]) : nx16_tight_bound(slen[t]));
+                uint8_t *arena = (uint8_t *)malloc(boff[ni] + 64);
+                if (!arena) return HG_ENOMEM;
+                std::vector<uint8_t *> optr(ni); std::vector<uint32_t> olen(ni, 0);
+                for (size_t t = 0; t < ni; t++) optr[t] = arena + boff[t];
+                rc = entropy_encode_host(codec ? ARITH : NX16, ctx, nullptr, slen.data(), sfl.data(), ni, optr.data(), olen.data(), d_sb, soff.data());
+                if (rc) { free(arena); return rc; }
+                // keep the smallest setting of every stream (the first one on ties), in list order
+                size_t t = 0;
+                std::vector<std::vector<std::pair<const uint8_t *, uint32_t>>> best(nj);
+                for (size_t k = 0; k < nj; k++) best[k].assign(lists[k].size(), {nullptr, 0});
+                while (t < ni) {
+                    size_t e = t, b = t;
+                    while (e < ni && owner[e] == owner[t]) { if (olen[e] < olen[b]) b = e; e++; }
+                    best[owner[t].first][owner[t].second] = {optr[b], olen[b]};
+                    t = e;
+                }
+                for (size_t k = 0; k < nj; k++) {
+                    if ((use_arith[job_blk[k]] ? 1 : 0) != codec) continue;
+                    const size_t i = job_blk[k];
+                    uint8_t *cp = out[i];
+                    for (int b = 0; b < 4; b++) *cp++ = (uint8_t)(in_len[i] >> (8 * b));
+                    for (int b = 0; b < 4; b++) *cp++ = (uint8_t)(res[k].nn >> (8 * b));
+                    *cp++ = (uint8_t)codec;
+                    for (uint32_t q = 0; q < lists[k].size(); q++) {
+                        const hg::tok3_enc_stream &E = lists[k][q];
+                        *cp++ = E.ttype;
+                        if (E.ttype & 0x40) { *cp++ = E.dup_pos; *cp++ = E.dup_type; continue; }
+                        cp += put_u7(cp, best[k][q].second);
+                        memcpy(cp, best[k][q].first, best[k][q].second); cp += best[k][q].second;
+                    }
+                    out_len[i] = (uint32_t)(cp - out[i]);
+                }
+                free(arena);
+            }
+        }
+        i0 = i1;
+    }
+    return HG_OK;
 }

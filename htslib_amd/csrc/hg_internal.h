@@ -80,6 +80,13 @@ struct tok3_job {
 };
 int launch_tok3_names(hg_ctx *ctx, const void *d_tb, const tok3_job *d_jobs, size_t njobs, const uint32_t *d_tab, void *d_out,
                       uint32_t *d_rec, uint32_t *d_names, int32_t *d_status, hipStream_t s);
+// tok3.hip encoder side: tokenise one block of NUL-terminated names into its token byte streams
+#define HG_TOK3_MAX_STREAMS (13 * 128)
+struct tok3_enc_job { uint64_t in_off, sb_off; uint32_t n, sb_cap; };
+struct tok3_enc_stream { uint32_t off, len; uint8_t pos, type, ttype, dup_pos, dup_type, pad[3]; };   // in emission order
+struct tok3_enc_res { uint32_t nn, nstreams, total, pad; };                                       // total = 0xffffffff: did not fit
+int launch_tok3_tokenise(hg_ctx *ctx, const void *d_in, const tok3_enc_job *d_jobs, size_t njobs, void *d_sb, tok3_enc_stream *d_list,
+                         tok3_enc_res *d_res, hipStream_t s);
 int ensure_scratch(hg_ctx *ctx, int slot, size_t bytes);
 uint32_t ransnx16_enc_scratch_words(uint32_t flags);
 int launch_ransnx16_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags,

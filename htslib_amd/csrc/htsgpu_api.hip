@@ -492,6 +492,8 @@ int hg_gzip_deflate_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *
 
 size_t hg_cram_compress_bound(size_t n) {
     size_t a = hg_gzip_compress_bound(n), b = hg_rans4x8_compress_bound(n), c = hg_ransnx16_compress_bound(n), d = hg_arith_compress_bound(n);
+    const size_t e = hg_tok3_compress_bound(n);
+    if (e > a) a = e;
     if (b > a) a = b;
     if (c > a) a = c;
     return d > a ? d : a;
@@ -550,6 +552,14 @@ int hg_cram_compress_blocks_host(hg_ctx *ctx, size_t n, const uint32_t *method_m
         par.assign(sin.size(), nx16_sets[v]);
         rc = hg_arith_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
         for (size_t k = 0; rc == HG_OK && k < sin.size(); k++) if (keep(k)) method_used[map[k]] = HG_CRAM_ARITH;
+    }
+    // name tokeniser: rANS back-end (TOK3) and range-coder back-end (TOKA); an out_len of 0 means "not a list of names"
+    for (int v = 0; v < 2 && rc == HG_OK; v++) {
+        gather(v ? 9u : (uint32_t)HG_CRAM_TOK3);
+        if (sin.empty()) continue;
+        par.assign(sin.size(), (uint8_t)v);
+        rc = hg_tok3_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
+        for (size_t k = 0; rc == HG_OK && k < sin.size(); k++) if (keep(k)) method_used[map[k]] = HG_CRAM_TOK3;
     }
     for (auto p : tmp) free(p);
     return rc;

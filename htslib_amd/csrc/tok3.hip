@@ -196,3 +196,218 @@ int launch_tok3_names(hg_ctx *ctx, const void *d_tb, const tok3_job *d_jobs, siz
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
 }  // namespace hg
+
+// ================================================================================================
+// Encoder side: tokenise every name against its predecessor and append to the (position, type) byte
+// streams -- the choices of oracle/tok3_oracle.c orc_tok3_encode(), so that the assembled block is
+// byte-identical to the oracle's.  One wavefront per block, two sweeps over the names: the first only counts
+// stream sizes, a prefix sum lays the streams out back to back, the second writes.  Lanes = the characters
+// of the current name (64 per step): token boundaries come from one ballot of the "class changes here"
+// flags; the lane sitting on a token's first character owns that token (length, value, comparison with the
+// previous name's token, append to the streams of its position -- no two tokens of a name share a position).
+// ================================================================================================
+namespace hgt {
+
+struct EncLds {
+    uint32_t base[NTYPES][MAX_TOK], cur[NTYPES][MAX_TOK];
+    uint32_t toff[2][MAX_TOK], tlen[2][MAX_TOK], tval[2][MAX_TOK];
+    uint8_t tcls[2][MAX_TOK];
+};
+
+__device__ __forceinline__ int char_class(uint32_t c) {          // 0 digit, 1 letter, 2 anything else
+    return (c - '0') < 10u ? 0 : (((c | 0x20u) - 'a') < 26u ? 1 : 2);
+}
+__device__ __forceinline__ void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+
+__global__ __launch_bounds__(64)
+void tok3_tokenise_kernel(const uint8_t *__restrict__ in, const hg::tok3_enc_job *__restrict__ jobs, uint32_t njobs,
+                          uint8_t *sb, hg::tok3_enc_stream *list, hg::tok3_enc_res *res) {
+    __shared__ EncLds S;
+    const int lane = threadIdx.x;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
+        const hg::tok3_enc_job J = jobs[j];
+        const uint8_t *src = in + J.in_off;
+        uint8_t *B = sb + J.sb_off;
+        const uint32_t n = J.n;
+        uint32_t nn = 0, maxpos = 0, total = 0;
+        for (uint32_t i = (uint32_t)lane; i < NTYPES * MAX_TOK; i += 64) { (&S.base[0][0])[i] = 0; (&S.cur[0][0])[i] = 0; }
+        wave_sync();
+        for (int sweep = 0; sweep < 2; sweep++) {
+            const bool wr = sweep == 1;
+            uint32_t pos = 0, ppos = 0, plen = 0, pn = 0, rb = 0;
+            nn = 0; maxpos = 0;
+            // append helpers: sizes only in the first sweep
+            auto put8 = [&](uint32_t ty, uint32_t tp, uint32_t v) {
+                const uint32_t c = S.cur[ty][tp];
+                if (wr) B[S.base[ty][tp] + c] = (uint8_t)v;
+                S.cur[ty][tp] = c + 1u;
+            };
+            auto put32s = [&](uint32_t ty, uint32_t tp, uint32_t v) {
+                const uint32_t c = S.cur[ty][tp];
+                if (wr) put32(B + S.base[ty][tp] + c, v);
+                S.cur[ty][tp] = c + 4u;
+            };
+            while (pos < n) {
+                uint32_t len = 0;                                   // distance to the terminating NUL
+                for (;;) {
+                    const uint32_t p = pos + len + (uint32_t)lane;
+                    const unsigned long long z = __ballot(p >= n || src[p] == 0);
+                    if (z) { len += (uint32_t)__builtin_ctzll(z); break; }
+                    len += 64;
+                }
+                bool dup = false;
+                if (nn && len == plen) {
+                    dup = true;
+                    for (uint32_t k = 0; k < len && dup; k += 64) {
+                        const uint32_t q = k + (uint32_t)lane;
+                        if (__any(q < len && src[pos + q] != src[ppos + q])) dup = false;
+                    }
+                }
+                if (dup) {
+                    if (lane == 0) { put8(T_TYPE, 0, T_DUP); put32s(T_DUP, 0, 1); }
+                    if (maxpos < 1) maxpos = 1;
+                } else {
+                    if (lane == 0) { put8(T_TYPE, 0, T_DIFF); put32s(T_DIFF, 0, nn ? 1u : 0u); }
+                    uint32_t nb = 0, pc = 3, prun = 0;              // boundaries so far, class / run position of the previous char
+                    for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+                        const uint32_t i = c0 + (uint32_t)lane;
+                        const bool has = i < len;
+                        const uint32_t ch = has ? src[pos + i] : 0u;
+                        const int cls = has ? char_class(ch) : 3;
+                        const uint32_t pcl = (uint32_t)__shfl_up(cls, 1, 64);
+                        const bool chg = has && (cls == 2 || (uint32_t)cls != (lane == 0 ? pc : pcl));
+                        const unsigned long long CH = __ballot(chg);
+                        const unsigned long long upto = CH & (below | (1ull << lane));
+                        const uint32_t runpos = upto ? (uint32_t)lane - (63u - (uint32_t)__clzll(upto)) : prun + 1u + (uint32_t)lane;
+                        const bool bnd0 = has && (chg || (cls == 0 && runpos % 9u == 0u));
+                        const unsigned long long BD0 = __ballot(bnd0);
+                        const uint32_t idx0 = nb + (uint32_t)__popcll(BD0 & (below | (1ull << lane))) - 1u;   // token index of my char
+                        const bool bnd = bnd0 && idx0 <= (uint32_t)(MAX_TOK - 3);       // later boundaries fold into the last token
+                        if (bnd) {
+                            const uint32_t t = idx0, tp = t + 1u;
+                            // ---- my token: length, class, value -------------------------------------------
+                            uint32_t tl = 1, val = 0; uint32_t tc;
+                            if (t == (uint32_t)(MAX_TOK - 3)) { tc = T_STRING; tl = len - i; }
+                            else if (cls == 0) {
+                                uint32_t e = i;
+                                while (e < len && e - i < 9u && (src[pos + e] - '0') < 10u) { val = val * 10u + (src[pos + e] - '0'); e++; }
+                                tl = e - i;
+                                tc = (ch == '0' && tl > 1u) ? T_DIGITS0 : T_DIGITS;
+                            } else if (cls == 1) {
+                                uint32_t e = i;
+                                while (e < len && char_class(src[pos + e]) == 1) e++;
+                                tl = e - i; tc = tl == 1u ? T_CHAR : T_STRING;
+                            } else tc = T_CHAR;
+                            const uint32_t off = pos + i;
+                            S.toff[rb][t] = off; S.tlen[rb][t] = tl; S.tval[rb][t] = val; S.tcls[rb][t] = (uint8_t)tc;
+                            // ---- against the previous name's token ----------------------------------------
+                            const bool haveP = nn && t < pn;
+                            const uint32_t po = S.toff[rb ^ 1][t], pl = S.tlen[rb ^ 1][t], pv = S.tval[rb ^ 1][t], pcs = S.tcls[rb ^ 1][t];
+                            bool same = haveP && pcs == tc && pl == tl;
+                            for (uint32_t k = 0; same && k < tl; k++) same = src[po + k] == src[off + k];
+                            if (same) put8(T_TYPE, tp, T_MATCH);
+                            else if (haveP && tc == T_DIGITS && pcs == T_DIGITS && val >= pv && val - pv < 256u) { put8(T_TYPE, tp, T_DELTA); put8(T_DELTA, tp, val - pv); }
+                            else if (haveP && tc == T_DIGITS0 && pcs == T_DIGITS0 && tl == pl && val >= pv && val - pv < 256u) { put8(T_TYPE, tp, T_DELTA0); put8(T_DELTA0, tp, val - pv); }
+                            else {
+                                put8(T_TYPE, tp, tc);
+                                if (tc == T_STRING) {
+                                    const uint32_t c = S.cur[T_STRING][tp];
+                                    if (wr) { uint8_t *w = B + S.base[T_STRING][tp] + c; for (uint32_t k = 0; k < tl; k++) w[k] = src[off + k]; w[tl] = 0; }
+                                    S.cur[T_STRING][tp] = c + tl + 1u;
+                                } else if (tc == T_CHAR) put8(T_CHAR, tp, ch);
+                                else { put32s(tc, tp, val); if (tc == T_DIGITS0) put8(T_DZLEN, tp, tl); }
+                            }
+                        }
+                        const uint32_t nbd = (uint32_t)__popcll(BD0);
+                        nb = nb + nbd > (uint32_t)(MAX_TOK - 2) ? (uint32_t)(MAX_TOK - 2) : nb + nbd;
+                        pc = (uint32_t)__shfl(cls, 63, 64); prun = (uint32_t)__shfl((int)runpos, 63, 64);
+                        wave_sync();
+                    }
+                    const uint32_t nt = nb;
+                    if (lane == 0) put8(T_TYPE, nt + 1u, T_END);
+                    if (maxpos < nt + 2u) maxpos = nt + 2u;
+                    rb ^= 1u; pn = nt;
+                }
+                wave_sync();
+                ppos = pos; plen = len; nn++;
+                pos += len + 1u;
+            }
+            if (!wr) {                                              // lay the streams out: exclusive prefix sum of the sizes
+                uint32_t carry = 0;
+                for (uint32_t b0 = 0; b0 < NTYPES * MAX_TOK; b0 += 64) {
+                    const uint32_t i = b0 + (uint32_t)lane;
+                    const uint32_t sz = (&S.cur[0][0])[i];
+                    const uint32_t incl = wave_incl_scan_dpp(sz);
+                    (&S.base[0][0])[i] = carry + incl - sz;
+                    (&S.cur[0][0])[i] = 0;
+                    carry += rl(incl, 63);
+                }
+                total = carry;
+                wave_sync();
+                if (total > J.sb_cap) { total = 0xffffffffu; break; }
+            }
+        }
+        // ---- emission list: order, implied TYPE streams, duplicates -------------------------------
+        uint32_t nem = 0;
+        hg::tok3_enc_stream *L = list + (size_t)j * (NTYPES * MAX_TOK);
+        if (total != 0xffffffffu) {
+            for (uint32_t t = 0; t < maxpos; t++) {
+                int implied = -1;
+                const uint32_t tyn = S.cur[T_TYPE][t];
+                if (t > 0 && tyn == nn && tyn) {
+                    const uint8_t *ty = B + S.base[T_TYPE][t];
+                    const uint32_t f = ty[0];
+                    if (f != T_TYPE && f != T_MATCH && f <= T_DELTA0 && S.cur[f][t]) {
+                        bool all = true;
+                        for (uint32_t k = 1; k < nn && all; k += 64) { const uint32_t q = k + (uint32_t)lane; if (__any(q < nn && ty[q] != T_MATCH)) all = false; }
+                        if (all) implied = (int)f;
+                    }
+                }
+                bool firsts = true;
+                for (int pass = 0; pass < 2; pass++)
+                for (uint32_t ty = 0; ty <= T_END; ty++) {
+                    if (implied >= 0) { if (ty == T_TYPE) continue; if ((pass == 0) != ((int)ty == implied)) continue; }
+                    else if (pass) continue;
+                    const uint32_t sl = S.cur[ty][t], so = S.base[ty][t];
+                    if (!sl) continue;
+                    uint32_t dupk = 0xffffffffu;
+                    for (uint32_t k = 0; k < nem && dupk == 0xffffffffu; k++) {
+                        if (L[k].len != sl) continue;
+                        bool eq = true;
+                        for (uint32_t q0 = 0; q0 < sl && eq; q0 += 64) { const uint32_t q = q0 + (uint32_t)lane; if (__any(q < sl && B[L[k].off + q] != B[so + q])) eq = false; }
+                        if (eq) dupk = k;
+                    }
+                    hg::tok3_enc_stream E;
+                    E.off = so; E.len = sl; E.pos = (uint8_t)t; E.type = (uint8_t)ty;
+                    E.ttype = (uint8_t)(ty | (firsts ? 0x80u : 0u) | (dupk != 0xffffffffu ? 0x40u : 0u));
+                    E.dup_pos = dupk != 0xffffffffu ? L[dupk].pos : 0; E.dup_type = dupk != 0xffffffffu ? L[dupk].type : 0;
+                    E.pad[0] = E.pad[1] = E.pad[2] = 0;
+                    firsts = false;
+                    L[nem] = E;                                     // every lane stores the same record
+                    wave_sync();
+                    nem++;
+                }
+            }
+        }
+        hg::tok3_enc_res R;
+        R.nn = nn; R.nstreams = nem; R.total = total; R.pad = 0;
+        res[j] = R;
+        wave_sync();
+    }
+}
+
+}  // namespace hgt
+
+namespace hg {
+int launch_tok3_tokenise(hg_ctx *ctx, const void *d_in, const tok3_enc_job *d_jobs, size_t njobs, void *d_sb, tok3_enc_stream *d_list,
+                         tok3_enc_res *d_res, hipStream_t s) {
+    if (!njobs) return HG_OK;
+    size_t wgs = njobs;
+    const size_t maxw = (size_t)ctx->cus * 8;
+    if (wgs > maxw) wgs = maxw;
+    hipLaunchKernelGGL(hgt::tok3_tokenise_kernel, dim3((unsigned)wgs), dim3(64), 0, s, (const uint8_t *)d_in, d_jobs, (uint32_t)njobs,
+                       (uint8_t *)d_sb, d_list, d_res);
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+}  // namespace hg

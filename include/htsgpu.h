@@ -200,6 +200,12 @@ int hg_arith_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *
  *      names, one wavefront per block. ---- */
 int hg_tok3_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
                         uint8_t *const *out, const uint32_t *out_len, int32_t *status);
+/* use_arith[i]: 0 = rANS Nx16 back-end, 1 = range coder (the use_arith argument of tok3_encode_names).  A buffer that
+ * is not a list of NUL-terminated names gets out_len[i] = 0 (the caller keeps another method).  out[i] must hold
+ * hg_tok3_compress_bound(in_len[i]).  Synchronous. */
+size_t hg_tok3_compress_bound(size_t in_len);
+int hg_tok3_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *use_arith,
+                        size_t n, uint8_t *const *out, uint32_t *out_len);
 
 /* ---- CRAM block layer (replaces cram_uncompress_block, cram/cram_io.c:1576-1754) ------------ */
 /* on-disk method ids, htslib/cram.h:84-101 */
@@ -212,6 +218,7 @@ int hg_tok3_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *i
 #define HG_CRAM_ARITH    6
 #define HG_CRAM_FQZ      7
 #define HG_CRAM_TOK3     8
+#define HG_CRAM_MASK_TOKA (1u << 9) /* method_mask bit for hg_cram_compress_blocks_host only */
 #define HG_BLOCK_EUNSUPPORTED (-3)   /* method not implemented by the engine (yet): caller keeps its CPU codec */
 
 /* Uncompress n CRAM blocks in one batch: block i has on-disk method method[i], compressed payload
@@ -236,7 +243,9 @@ int hg_gzip_deflate_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *
  * when nothing beats it (cram_io.c:2001,2271-2278).  Bits: 1<<HG_CRAM_GZIP, 1<<HG_CRAM_RANS4x8 (orders 0
  * and 1 are both tried), 1<<HG_CRAM_RANSNx16 (flag sets {0,1} / +{64,9,128,193} above level 1 /
  * +{129,192} above level 5 as cram_compress_slice builds them, cram/cram_encode.c:818-826; 32-way for
- * inputs >= 64 KiB like RANS_ORDER_SIMD_AUTO), 1<<HG_CRAM_ARITH (the same flag sets, cram_io.c:1877).  method_used[i] = on-disk method id of the winner; out[i] must hold
+ * inputs >= 64 KiB like RANS_ORDER_SIMD_AUTO), 1<<HG_CRAM_ARITH (the same flag sets, cram_io.c:1877),
+ * 1<<HG_CRAM_TOK3 (name tokeniser over rANS; the reference's TOK3) and HG_CRAM_MASK_TOKA (name tokeniser over the
+ * range coder; the reference's TOKA, cram/cram_structs.h:215-266 -- both are written as on-disk method 8).  method_used[i] = on-disk method id of the winner; out[i] must hold
  * hg_cram_compress_bound(in_len[i]).  No cross-slice metrics are kept (every call is a trial). */
 size_t hg_cram_compress_bound(size_t in_len);
 int hg_cram_compress_blocks_host(hg_ctx *ctx, size_t n, const uint32_t *method_mask, int level,

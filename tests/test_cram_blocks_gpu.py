@@ -110,3 +110,23 @@ def test_cram_compress_blocks_trial_selection_and_roundtrip(engine):
     # level 0 = store (cram_io.c:1967-1972)
     outs0, used0 = engine.cram_compress_blocks(datas[:3], masks[:3], level=0)
     assert list(used0) == [0, 0, 0] and outs0 == datas[:3]
+
+
+def test_cram_compress_blocks_all_31_methods(engine):
+    """CRAM 3.1 method set (cram_compress_slice, cram_encode.c:818-942): names pick the tokeniser, qualities an
+    order-1 coder; everything decodes through the block layer."""
+    from tests.test_rans4x8 import synth_series
+    from tests.test_tok3 import illumina_names
+    rng = np.random.default_rng(31)
+    G, R4, RN, AR, TK, TKA = 1 << 1, 1 << 4, 1 << 5, 1 << 6, 1 << 8, 1 << 9
+    names = illumina_names(rng, 4000)
+    qual = synth_series(rng, "qual4", 200_000)
+    ints = rng.integers(0, 50_000, 20_000, dtype=np.uint32).tobytes()
+    datas = [names, names, qual, qual, ints, names]
+    masks = [G | RN | TK, G | AR | TKA, G | RN, G | AR, G | RN | AR, G | RN]
+    outs, used = engine.cram_compress_blocks(datas, masks, level=5)
+    assert list(used[:4]) == [8, 8, 5, 6] and used[5] in (1, 5)
+    assert len(outs[0]) < 0.6 * len(outs[5])                           # what the tokeniser buys over gzip / rANS
+    assert outs[0][8] == 0 and outs[1][8] == 1                        # back-end byte of the tok3 header
+    back, st = engine.cram_uncompress_blocks([(int(u), o, len(d)) for d, o, u in zip(datas, outs, used)])
+    assert (st == 0).all() and back == datas

@@ -100,3 +100,17 @@ def test_gpu_decoder_fuzz_agrees_with_oracle(engine, torc):
             assert s == 0 and o == want
         else:
             assert s != 0
+
+
+@pytest.mark.gpu
+def test_gpu_encoder_is_byte_identical_to_oracle(engine, torc):
+    rng = np.random.default_rng(95)
+    sets = sample_sets(rng) + [illumina_names(rng, 10_000), odd_names(rng, 3000), b"not names"]
+    datas = sets + sets
+    ua = [0] * len(sets) + [1] * len(sets)
+    enc = engine.tok3_encode_host(datas, ua)
+    bad = [(i, len(d), u) for i, (d, u, e) in enumerate(zip(datas, ua, enc)) if e != torc.encode(d, u)]
+    assert not bad, bad
+    ok = [(8, e, len(d)) for d, e in zip(datas, enc) if e]
+    outs, st = engine.cram_uncompress_blocks(ok)
+    assert (st == 0).all() and [o for o in outs] == [d for d, e in zip(datas, enc) if e]
