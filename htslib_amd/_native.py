@@ -81,13 +81,27 @@ lib.hg_tok3_compress_bound.restype = C.c_size_t
 lib.hg_tok3_compress_bound.argtypes = [C.c_size_t]
 lib.hg_tok3_encode_host.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]
 
+lib.hg_cram_metrics_new.restype = _vp
+lib.hg_cram_metrics_new.argtypes = []
+lib.hg_cram_metrics_free.argtypes = [_vp]
+lib.hg_cram_compress_blocks_metrics_host.argtypes = [_vp, C.c_size_t, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
+
+
+class CramMetrics(C.Structure):
+    """struct hg_cram_metrics (= the reference's struct cram_metrics)."""
+    _fields_ = [("trial", C.c_int), ("next_trial", C.c_int), ("consistency", C.c_int), ("sz", C.c_int * 32),
+                ("input_avg_sz", C.c_int), ("input_avg_delta", C.c_int), ("method", C.c_int), ("revised_method", C.c_int),
+                ("strat", C.c_int), ("cnt", C.c_int * 32), ("extra", C.c_double * 32), ("unpackable", C.c_int)]
+
+
 EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info", "hg_bgzf_scan",
            "hg_bgzf_inflate_dev", "hg_bgzf_inflate_host", "hg_crc32_dev", "hg_bgzf_deflate_dev", "hg_bgzf_pack_dev",
            "hg_bgzf_deflate_host", "hg_rans4x8_decode_dev", "hg_rans4x8_decode_host",
            "hg_gzip_inflate_dev", "hg_cram_uncompress_blocks_host", "hg_ransnx16_decode_host", "hg_ransnx16_decode_dev",
            "hg_ransnx16_compress_bound", "hg_ransnx16_encode_host", "hg_rans4x8_compress_bound",
            "hg_rans4x8_encode_host", "hg_gzip_compress_bound", "hg_gzip_deflate_host", "hg_cram_compress_bound",
-           "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host", "hg_tok3_decode_host", "hg_tok3_compress_bound", "hg_tok3_encode_host"]
+           "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host", "hg_tok3_decode_host", "hg_tok3_compress_bound", "hg_tok3_encode_host", "hg_cram_metrics_new", "hg_cram_metrics_free",
+           "hg_cram_compress_blocks_metrics_host"]
 
 
 class HgError(RuntimeError):
@@ -245,6 +259,20 @@ class Engine:
         used = np.full(len(datas), -9, dtype=np.int32)
         check(lib.hg_cram_compress_blocks_host(self._h, len(datas), mk.ctypes.data, level, ip, il.ctypes.data, op,
                                                ol.ctypes.data, used.ctypes.data), "hg_cram_compress_blocks_host")
+        return [outs[i].raw[:int(ol[i])] for i in range(len(datas))], used
+
+    def cram_compress_blocks_metrics(self, datas, metrics, method_sets, level=5, version_major=3):
+        """cram_compress_block with the auto-tuner: metrics[i] = pointer from hg_cram_metrics_new (or None)."""
+        import numpy as np
+        if not datas:
+            return [], np.zeros(0, dtype=np.int32)
+        ins, outs, ip, op, il, ol = self._ptr_batch(datas, lib.hg_cram_compress_bound)
+        mk = np.array(method_sets, dtype=np.uint32)
+        mp = (_vp * len(datas))(*[m if m else None for m in metrics])
+        used = np.full(len(datas), -9, dtype=np.int32)
+        check(lib.hg_cram_compress_blocks_metrics_host(self._h, len(datas), mp, mk.ctypes.data, level, version_major, ip,
+                                                       il.ctypes.data, op, ol.ctypes.data, used.ctypes.data),
+              "hg_cram_compress_blocks_metrics_host")
         return [outs[i].raw[:int(ol[i])] for i in range(len(datas))], used
 
     def rans4x8_encode_host(self, datas, orders):

@@ -1,0 +1,206 @@
+// cram_metrics_host.hip -- batch form of cram_compress_block / cram_compress_block2 WITH the per-data-series
+// method auto-tuner (reference cram/cram_io.c:1912-2325: cram_compress_block3, cram_new_metrics :2327-2339,
+// TRIAL_SPAN 70 / NTRIALS 3 :118-119, meth_cost :2116-2154, methmap :1928-1943; struct cram_metrics
+// cram/cram_structs.h:284-305).  Host logic only: every byte of compression work goes to the gfx950 encoders
+// through the hg_*_encode_host entry points, one batched call per method id.
+//
+// Batching rule (the one deliberate difference from the reference's block-at-a-time loop): all blocks of one call
+// that share a metrics object take the SAME branch -- trial or cached method -- decided from the state at entry;
+// the statistics are then folded in block order exactly as the reference does.  A trial phase that ends in the
+// middle of a batch therefore costs a few extra trial compressions, never a different on-disk result class.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "htsgpu.h"
+#include "hg_internal.h"
+
+namespace {
+
+constexpr int TRIAL_SPAN = 70, NTRIALS = 3, MAXM = HG_CRAM_MAX_METHOD;
+
+// internal method id -> on-disk method id (methmap, cram_io.c:1928-1943)
+const int8_t methmap[MAXM] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 0, 0, 1, 1, 7, 7, 7, 4, 5, 5, 5, 5, 5, 5, 5, 8, 6, 6, 6, 6, 6, 6, 6};
+// relative cost of the methods (meth_cost, cram_io.c:2116-2154)
+const double meth_cost[MAXM] = {1, 1.04, 1.07, 1.08, 1.00, 1.00, 1.04, 1.05, 1.05, 1.00, 1.00, 1.01, 1.01, 1.05, 1.05, 1.05,
+                                1.01, 1.01, 1.00, 1.03, 1.00, 1.01, 1.00, 1.01, 1.07, 1.04, 1.04, 1.04, 1.03, 1.04, 1.04, 1.04};
+// the flag byte of the parameterised rANS Nx16 / arith methods ({1,64,9,128,129,192,193}, cram_io.c:1856,1877)
+int pr_flags(int m) {
+    static const int f[8] = {0, 1, 64, 9, 128, 129, 192, 193};
+    if (m == HG_M_RANS_PR0 || m == HG_M_ARITH_PR0) return 0;
+    if (m >= HG_M_RANS_PR1 && m <= HG_M_RANS_PR193) return f[m - HG_M_RANS_PR1 + 1];
+    if (m >= HG_M_ARITH_PR1 && m <= HG_M_ARITH_PR193) return f[m - HG_M_ARITH_PR1 + 1];
+    return -1;
+}
+
+struct Job { size_t blk; int m; };
+
+// Runs every (block, method) job, grouped by method so that each group is ONE batched GPU call.
+// res[j] = malloc'd payload (or null when the method is not available / failed), rlen[j] = its size.
+int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t *const *in, const uint32_t *in_len,
+             std::vector<uint8_t *> &res, std::vector<uint32_t> &rlen) {
+    res.assign(jobs.size(), nullptr); rlen.assign(jobs.size(), 0);
+    for (int m = 0; m < MAXM; m++) {
+        std::vector<size_t> idx;
+        for (size_t j = 0; j < jobs.size(); j++) if (jobs[j].m == m) idx.push_back(j);
+        if (idx.empty()) continue;
+        const int pf = pr_flags(m);
+        const bool rans4 = m == HG_M_RANS0 || m == HG_M_RANS1, gz = m == HG_M_GZIP || m == HG_M_GZIP_RLE || m == HG_M_GZIP_1;
+        const bool nx = m == HG_M_RANS_PR0 || (m >= HG_M_RANS_PR1 && m <= HG_M_RANS_PR193);
+        const bool ar = m == HG_M_ARITH_PR0 || (m >= HG_M_ARITH_PR1 && m <= HG_M_ARITH_PR193);
+        const bool tk = m == HG_M_TOK3 || m == HG_M_TOKA;
+        if (!(rans4 || gz || nx || ar || tk)) continue;                // bzip2 / lzma / fqzcomp: not in the engine -> "failed"
+        std::vector<const uint8_t *> sin; std::vector<uint8_t *> sout; std::vector<uint32_t> slen, solen(idx.size(), 0);
+        std::vector<uint8_t> par(idx.size());
+        for (size_t k = 0; k < idx.size(); k++) {
+            const size_t b = jobs[idx[k]].blk;
+            sin.push_back(in[b]); slen.push_back(in_len[b]);
+            const size_t cap = gz ? hg_gzip_compress_bound(in_len[b]) : rans4 ? hg_rans4x8_compress_bound(in_len[b])
+                             : nx ? hg_ransnx16_compress_bound(in_len[b]) : ar ? hg_arith_compress_bound(in_len[b]) : hg_tok3_compress_bound(in_len[b]);
+            uint8_t *p = (uint8_t *)malloc(cap);
+            if (!p) { for (auto q : sout) free(q); return HG_ENOMEM; }
+            sout.push_back(p);
+            // RANS_ORDER_SIMD_AUTO (cram_io.c:1860): the 32-way layout for inputs big enough to fill it
+            par[k] = rans4 ? (uint8_t)(m == HG_M_RANS1) : nx ? (uint8_t)(pf | (in_len[b] >= 65536u ? 4 : 0)) : ar ? (uint8_t)pf : (uint8_t)(m == HG_M_TOKA);
+        }
+        int rc;
+        // libdeflate has no Z_RLE strategy: GZIP_RLE is run as level 1, like GZIP_1 (cram_io.c:2057-2062)
+        if (gz) rc = hg_gzip_deflate_host(ctx, sin.data(), slen.data(), sin.size(), m == HG_M_GZIP ? level : 1, sout.data(), solen.data());
+        else if (rans4) rc = hg_rans4x8_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
+        else if (nx) rc = hg_ransnx16_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
+        else if (ar) rc = hg_arith_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
+        else rc = hg_tok3_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
+        if (rc != HG_OK) { for (auto q : sout) free(q); return rc; }
+        for (size_t k = 0; k < idx.size(); k++) {
+            if (solen[k]) { res[idx[k]] = sout[k]; rlen[idx[k]] = solen[k]; } else free(sout[k]);
+        }
+    }
+    return HG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+hg_cram_metrics *hg_cram_metrics_new(void) {                            // cram_new_metrics, cram_io.c:2327-2339
+    hg_cram_metrics *m = (hg_cram_metrics *)calloc(1, sizeof *m);
+    if (!m) return nullptr;
+    m->trial = NTRIALS - 1;
+    m->next_trial = TRIAL_SPAN / 2;                                     // learn quicker at start
+    m->method = HG_M_RAW;
+    return m;
+}
+void hg_cram_metrics_free(hg_cram_metrics *m) { free(m); }
+
+int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics *const *metrics, const uint32_t *method_set, int level,
+                                         int version_major, const uint8_t *const *in, const uint32_t *in_len, uint8_t *const *out,
+                                         uint32_t *out_len, int32_t *method_used) {
+    if (!ctx || (n && (!method_set || !in || !in_len || !out || !out_len || !method_used))) return HG_EINVAL;
+    struct Blk { bool trial; uint32_t method; int single; size_t j0, j1; };
+    std::vector<Blk> B(n);
+    std::vector<Job> jobs;
+    // ---- decide per block (state at entry; the size-independent bookkeeping of cram_io.c:1978-2021) -------------
+    std::vector<hg_cram_metrics *> seen;
+    std::vector<char> seen_trial;
+    for (size_t i = 0; i < n; i++) {
+        Blk &b = B[i];
+        b.trial = false; b.method = method_set[i]; b.single = -1; b.j0 = b.j1 = jobs.size();
+        out_len[i] = in_len[i]; method_used[i] = HG_CRAM_RAW;
+        if (in_len[i]) memcpy(out[i], in[i], in_len[i]);
+        if (method_set[i] == HG_M_RAW || level == 0 || in_len[i] == 0) continue;          // cram_io.c:1967-1972
+        hg_cram_metrics *M = metrics ? metrics[i] : nullptr;
+        if (!M) { b.single = HG_M_GZIP; jobs.push_back({i, HG_M_GZIP}); b.j1 = jobs.size(); continue; }   // cram_io.c:2282-2299
+        const int sz = (int)in_len[i];
+        // sudden changes in size trigger a retrial (cram_io.c:1988-1997)
+        if (M->input_avg_sz && (sz / 4 - 750 > M->input_avg_sz || sz < M->input_avg_sz / 4 - 750) &&
+            abs(sz - M->input_avg_sz) / 10 > M->input_avg_delta)
+            M->next_trial = 0;
+        size_t k = 0;
+        while (k < seen.size() && seen[k] != M) k++;
+        bool trial;
+        if (k < seen.size()) { trial = seen_trial[k] != 0; if (!trial) --M->next_trial; }
+        else { trial = M->trial > 0 || --M->next_trial <= 0; seen.push_back(M); seen_trial.push_back(trial); }
+        M->input_avg_delta = (int)(0.9 * (M->input_avg_delta + abs(sz - M->input_avg_sz)));
+        M->input_avg_sz += (int)(sz * .2);
+        M->input_avg_sz = (int)(M->input_avg_sz * 0.8);
+        if (!trial) { b.single = M->method; if (b.single != HG_M_RAW) jobs.push_back({i, b.single}); b.j1 = jobs.size(); continue; }
+        b.trial = true;
+        // like an htslib built without bz2 / lzma (fd->use_bz2 = 0): methods the engine does not have leave the set
+        const uint32_t have = ~((1u << HG_M_BZIP2) | (1u << HG_M_LZMA) | (1u << HG_M_FQZ) | (1u << HG_M_FQZ_b) | (1u << HG_M_FQZ_c) |
+                                (1u << HG_M_FQZ_d) | (1u << 9) | (1u << 10));
+        uint32_t method = b.method & have;
+        if (M->revised_method) method = M->revised_method & have; else M->revised_method = method;
+        if (M->next_trial <= 0) {
+            M->next_trial = TRIAL_SPAN; M->trial = NTRIALS;
+            for (int m = 0; m < MAXM; m++) M->sz[m] /= 2;
+            M->unpackable = 0;
+        }
+        if (M->unpackable && version_major > 3) {                        // no point bit-packing 17+ symbols (cram_io.c:2026-2047)
+            auto sw = [&](int from, uint32_t to) { if (method & (1u << from)) method = (method | to) & ~(1u << from); };
+            sw(HG_M_RANS_PR128, 1u << HG_M_RANS_PR0); sw(HG_M_RANS_PR129, 1u << HG_M_RANS_PR1); sw(HG_M_RANS_PR192, 1u << HG_M_RANS_PR64);
+            sw(HG_M_RANS_PR193, (1u << HG_M_RANS_PR64) | (1u << HG_M_RANS_PR1));
+            sw(HG_M_ARITH_PR128, 1u << HG_M_ARITH_PR0); sw(HG_M_ARITH_PR129, 1u << HG_M_ARITH_PR1); sw(HG_M_ARITH_PR192, 1u << HG_M_ARITH_PR64);
+            sw(HG_M_ARITH_PR193, (1u << HG_M_ARITH_PR64) | (1u << HG_M_ARITH_PR1));
+        }
+        if ((method & (1u << HG_M_GZIP_RLE)) && (method & (1u << HG_M_GZIP_1))) method &= ~(1u << HG_M_GZIP_RLE);   // cram_io.c:2057-2062
+        b.method = method;
+        for (int m = 0; m < MAXM; m++) if (method & (1u << m)) jobs.push_back({i, m});
+        b.j1 = jobs.size();
+    }
+    // ---- compress -------------------------------------------------------------------------------------------------
+    std::vector<uint8_t *> res; std::vector<uint32_t> rlen;
+    int rc = run_jobs(ctx, jobs, level, in, in_len, res, rlen);
+    if (rc != HG_OK) { for (auto p : res) free(p); return rc; }
+    // ---- select, then fold the statistics in block order (cram_io.c:2064-2244) ----------------------------------
+    for (size_t i = 0; i < n; i++) {
+        Blk &b = B[i];
+        hg_cram_metrics *M = metrics ? metrics[i] : nullptr;
+        if (b.j0 == b.j1 && !b.trial) continue;
+        if (!b.trial) {                                                  // cached / default method: keep it only if it shrinks the block
+            const size_t j = b.j0;
+            if (res[j] && rlen[j] < in_len[i]) { memcpy(out[i], res[j], rlen[j]); out_len[i] = rlen[j]; method_used[i] = methmap[jobs[j].m]; }
+            continue;
+        }
+        uint32_t sz[MAXM];
+        for (int m = 0; m < MAXM; m++) sz[m] = UINT_MAX;                // arbitrarily worse than raw
+        uint32_t sz_best = in_len[i]; int method_best = 0; size_t jbest = (size_t)-1;
+        for (size_t j = b.j0; j < b.j1; j++) {
+            if (!res[j]) continue;
+            sz[jobs[j].m] = rlen[j];
+            if (sz_best > rlen[j]) { sz_best = rlen[j]; method_best = jobs[j].m; jbest = j; }
+        }
+        if (jbest != (size_t)-1) { memcpy(out[i], res[jbest], sz_best); out_len[i] = sz_best; method_used[i] = methmap[method_best]; }
+        for (int m = 0; m < MAXM; m++) M->sz[m] = (int)((unsigned)M->sz[m] + sz[m] + 2000u);   // int arithmetic wraps as in the reference
+        if (M->trial > 0 && --M->trial == 0) {
+            uint32_t method = b.method;
+            int best_method = HG_M_RAW, best_sz = INT_MAX;
+            const double div = level <= 1 ? 0.25 : level <= 3 ? 1 : level <= 6 ? 2 : level <= 7 ? 3 : 0;
+            if (div > 0) for (int m = 0; m < MAXM; m++) M->sz[m] = (int)(M->sz[m] * (1 + (meth_cost[m] - 1) / div));
+            M->sz[9] = M->sz[10] = INT_MAX;
+            for (int m = 0; m < MAXM; m++) {
+                if (!M->sz[m] || !(method & (1u << m))) continue;
+                if (best_sz > M->sz[m]) { best_sz = M->sz[m]; best_method = m; }
+            }
+            if (best_method != M->method) M->consistency = 0;
+            else { const double f = 1 + M->consistency / 4.0; M->next_trial = (int)(M->next_trial * (f < 2 ? f : 2)); M->consistency++; }
+            M->method = best_method;
+            M->strat = best_method == HG_M_TOKA ? 1 : 0;
+            const double MAXDELTA = 0.20; const int MAXFAILS = 4, mul = 1 + (level >= 7);
+            for (int m = 0; m < MAXM; m++) {
+                if (best_method == m) { M->cnt[m] = 0; M->extra[m] = 0; }
+                else if (best_sz < M->sz[m]) {
+                    const double r = (double)M->sz[m] / best_sz - 1;
+                    if (++M->cnt[m] >= MAXFAILS * mul && (M->extra[m] += r) >= MAXDELTA * mul) method &= ~(1u << m);
+                    if ((m == HG_M_FQZ || (m >= 13 && m <= 15)) && M->sz[m] > best_sz) method &= ~(1u << m);
+                }
+            }
+            M->revised_method = method;
+        }
+    }
+    for (auto p : res) free(p);
+    return HG_OK;
+}
+
+}  // extern "C"

@@ -252,6 +252,39 @@ int hg_cram_compress_blocks_host(hg_ctx *ctx, size_t n, const uint32_t *method_m
                                  const uint8_t *const *in, const uint32_t *in_len, uint8_t *const *out,
                                  uint32_t *out_len, int32_t *method_used);
 
+/* ---- cram_compress_block / cram_compress_block2 with the per-data-series method auto-tuner
+ *      (cram/cram_io.c:1912-2325).  Method sets use the reference's INTERNAL method ids
+ *      (enum cram_block_method_int, cram/cram_structs.h:215-266): bit m of a set = method m. ---- */
+#define HG_CRAM_MAX_METHOD 32
+enum hg_cram_method_int {
+    HG_M_RAW = 0, HG_M_GZIP = 1, HG_M_BZIP2 = 2, HG_M_LZMA = 3, HG_M_RANS0 = 4, HG_M_RANS_PR0 = 5, HG_M_ARITH_PR0 = 6,
+    HG_M_FQZ = 7, HG_M_TOK3 = 8, HG_M_GZIP_RLE = 11, HG_M_GZIP_1 = 12, HG_M_FQZ_b = 13, HG_M_FQZ_c = 14, HG_M_FQZ_d = 15,
+    HG_M_RANS1 = 16, HG_M_RANS_PR1 = 17, HG_M_RANS_PR64 = 18, HG_M_RANS_PR9 = 19, HG_M_RANS_PR128 = 20, HG_M_RANS_PR129 = 21,
+    HG_M_RANS_PR192 = 22, HG_M_RANS_PR193 = 23, HG_M_TOKA = 24, HG_M_ARITH_PR1 = 25, HG_M_ARITH_PR64 = 26, HG_M_ARITH_PR9 = 27,
+    HG_M_ARITH_PR128 = 28, HG_M_ARITH_PR129 = 29, HG_M_ARITH_PR192 = 30, HG_M_ARITH_PR193 = 31
+};
+/* same fields as struct cram_metrics (cram/cram_structs.h:284-305) */
+typedef struct hg_cram_metrics {
+    int trial, next_trial, consistency;
+    int sz[HG_CRAM_MAX_METHOD];
+    int input_avg_sz, input_avg_delta;
+    int method, revised_method, strat;
+    int cnt[HG_CRAM_MAX_METHOD];
+    double extra[HG_CRAM_MAX_METHOD];
+    int unpackable;
+} hg_cram_metrics;
+hg_cram_metrics *hg_cram_metrics_new(void);             /* cram_new_metrics, cram_io.c:2327-2339 */
+void hg_cram_metrics_free(hg_cram_metrics *m);
+/* Block i is compressed under metrics[i] (one object per data series; NULL metrics / NULL entry = plain GZIP as
+ * cram_io.c:2282-2299) starting from method_set[i]: while the series is in a trial phase every method of the set is
+ * run and the smallest output kept, afterwards only the learnt method; statistics, method costs, retrial spans and
+ * the culling of persistently bad methods follow the reference.  Blocks of one call that share a metrics object all
+ * take the branch chosen from its state at entry.  bzip2 / lzma / fqzcomp bits are dropped from the set, as in an
+ * htslib built without those libraries.  method_used[i] = on-disk method id; out[i] must hold hg_cram_compress_bound(in_len[i]). */
+int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics *const *metrics, const uint32_t *method_set,
+                                         int level, int version_major, const uint8_t *const *in, const uint32_t *in_len,
+                                         uint8_t *const *out, uint32_t *out_len, int32_t *method_used);
+
 /* ---- CRC-32 (replaces hts_crc32, bgzf.c:557-559 / 620-622) -------------- */
 /* crc[i] = crc32(0, d_data + off[i], len[i]) for n independent buffers. */
 int hg_crc32_dev(hg_ctx *ctx, const void *d_data,
