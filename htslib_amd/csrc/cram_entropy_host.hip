@@ -240,16 +240,15 @@ static int entropy_decode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
     if ((rc = ensure_scratch(ctx, 0, ioff + 64))) return rc;
     hipStream_t s = nullptr;
     uint8_t *d_in = (uint8_t *)ctx->d_scratch[0];
-    bool ok = true;
-    for (size_t i = 0; i < n && ok; i++)
-        if (in_len[i] && st[i] == 0) ok = hipMemcpyAsync(d_in + ioffs[i], in[i], in_len[i], hipMemcpyHostToDevice, s) == hipSuccess;
-    rc = ok ? launch_plan(ctx, P, ioff, obytes, s) : HG_ELAUNCH;
+    rc = hg::stage_upload(ctx, in, in_len, ioffs.data(), st.data(), n, ioff, d_in, s);
+    if (rc == HG_OK) rc = launch_plan(ctx, P, ioff, obytes, s);
     if (rc == HG_OK) {
-        ok = hipStreamSynchronize(s) == hipSuccess && collect_plan_status(ctx, P, st, s);
-        const uint8_t *d_out = (const uint8_t *)ctx->d_scratch[1];
-        for (size_t i = 0; i < n && ok; i++)
-            if (out_len[i] && st[i] == 0) ok = hipMemcpy(out[i], d_out + ooffs[i], out_len[i], hipMemcpyDeviceToHost) == hipSuccess;
-        if (!ok) rc = HG_ELAUNCH;
+        bool ok = hipStreamSynchronize(s) == hipSuccess && collect_plan_status(ctx, P, st, s);
+        if (ok) {
+            std::vector<uint32_t> dl(n);
+            for (size_t i = 0; i < n; i++) dl[i] = st[i] == 0 ? out_len[i] : 0u;
+            rc = hg::stage_download(ctx, (const uint8_t *)ctx->d_scratch[1], ooffs.data(), dl.data(), out, n, s);
+        } else rc = HG_ELAUNCH;
     }
     if (rc == HG_OK)
         for (size_t i = 0; i < n; i++) { if (status) status[i] = st[i]; if (st[i] != 0) rc = HG_EBLOCK; }
@@ -346,9 +345,8 @@ extern "C" int hg_tok3_decode_host(hg_ctx *ctx, const uint8_t *const *in, const 
     hipStream_t s = nullptr;
     uint8_t *d_in = (uint8_t *)ctx->d_scratch[0];
     bool ok = true;
-    for (size_t i = 0; i < n && ok; i++)
-        if (in_len[i] && st[i] == 0) ok = hipMemcpyAsync(d_in + ioffs[i], in[i], in_len[i], hipMemcpyHostToDevice, s) == hipSuccess;
-    rc = ok ? launch_plan(ctx, P, ioff, tbytes, s) : HG_ELAUNCH;
+    rc = hg::stage_upload(ctx, in, in_len, ioffs.data(), st.data(), n, ioff, d_in, s);
+    if (rc == HG_OK) rc = launch_plan(ctx, P, ioff, tbytes, s);
     hg::tok3_job *d_jobs = (hg::tok3_job *)ctx->d_scratch[12];
     int32_t *d_jst = (int32_t *)(d_jobs + nj);
     if (rc == HG_OK && nj) {
@@ -362,12 +360,14 @@ extern "C" int hg_tok3_decode_host(hg_ctx *ctx, const uint8_t *const *in, const 
         std::vector<int32_t> jst(nj + 1);
         ok = (!nj || hipMemcpyAsync(jst.data(), d_jst, nj * 4, hipMemcpyDeviceToHost, s) == hipSuccess) && hipStreamSynchronize(s) == hipSuccess &&
              collect_plan_status(ctx, P, st, s);
+        std::vector<uint64_t> so(nj); std::vector<uint32_t> sl(nj); std::vector<uint8_t *> sd(nj);
         for (size_t k = 0; k < nj && ok; k++) {
             const uint32_t i = job_top[k];
             if (st[i] == 0 && jst[k] != 0) st[i] = jst[k];
-            if (st[i] == 0 && out_len[i]) ok = hipMemcpy(out[i], (const uint8_t *)ctx->d_scratch[8] + jobs[k].out_off, out_len[i], hipMemcpyDeviceToHost) == hipSuccess;
+            so[k] = jobs[k].out_off; sl[k] = st[i] == 0 ? out_len[i] : 0u; sd[k] = out[i];
         }
         if (!ok) rc = HG_ELAUNCH;
+        else rc = hg::stage_download(ctx, (const uint8_t *)ctx->d_scratch[8], so.data(), sl.data(), sd.data(), nj, s);
     }
     if (rc == HG_OK)
         for (size_t i = 0; i < n; i++) { if (status) status[i] = st[i]; if (st[i] != 0) rc = HG_EBLOCK; }
@@ -468,9 +468,9 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
     hipStream_t s = nullptr;
     uint8_t *d_buf = (uint8_t *)ctx->d_scratch[0];
     bool ok = true;
-    for (size_t i = 0; i < n && ok; i++)
-        if (in_len[i]) ok = (d_src ? hipMemcpyAsync(d_buf + ioffs[i], d_src + d_src_off[i], in_len[i], hipMemcpyDeviceToDevice, s)
-                                   : hipMemcpyAsync(d_buf + ioffs[i], in[i], in_len[i], hipMemcpyHostToDevice, s)) == hipSuccess;
+    rc = d_src ? hg::stage_gather_dev(ctx, d_src, d_src_off, in_len, d_buf, ioffs.data(), n, s)
+               : hg::stage_upload(ctx, in, in_len, ioffs.data(), nullptr, n, ioff, d_buf, s);
+    if (rc) return rc;
     std::vector<hg::nx16_xenc_res> xr(xj.size());
     if (ok && !xj.empty()) {
         hg::nx16_xenc *d_j = (hg::nx16_xenc *)ctx->d_scratch[4];
@@ -552,35 +552,47 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         if (hipMemcpyAsync(ol.data(), d_ol, nc * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
     }
     // ---- stitch --------------------------------------------------------------------------------
-    auto fetch = [&](uint8_t *dst, const uint8_t *d_src, size_t len) { if (len && ok) ok = hipMemcpy(dst, d_src, len, hipMemcpyDeviceToHost) == hipSuccess; };
+    // Payload pieces live in two device buffers (0: d_buf -- raw RLE meta and CAT data, 1: d_out -- entropy-coder output).
+    // The headers are written now; the pieces are only RECORDED (every length is already known on the host) and
+    // then fetched with one gather + one PCIe transfer per buffer.
+    struct Fetch { std::vector<uint64_t> off; std::vector<uint32_t> len; std::vector<uint8_t *> dst; } F[2];
+    auto fetch = [&](uint8_t *dst, int which, uint64_t off, size_t len) {
+        if (len && dst) { F[which].off.push_back(off); F[which].len.push_back((uint32_t)len); F[which].dst.push_back(dst); }
+    };
+    // dst == nullptr: measure only (returns the length as a pointer difference from nullptr)
     auto emit_leaf = [&](uint8_t *cp, const Leaf &L) -> uint8_t * {
+        const bool wr = cp != nullptr;
+        uint8_t hdr[64], *hp = hdr;
         const uint32_t f = L.r.flags;
-        *cp++ = (uint8_t)f;
-        if (!(f & F_NOSZ)) cp += put_u7(cp, L.n);
-        if (f & F_PACK) { *cp++ = (uint8_t)L.r.nsym; memcpy(cp, L.r.map, L.r.nsym); cp += L.r.nsym; cp += put_u7(cp, L.r.plen); }
+        *hp++ = (uint8_t)f;
+        if (!(f & F_NOSZ)) hp += put_u7(hp, L.n);
+        if (f & F_PACK) { *hp++ = (uint8_t)L.r.nsym; memcpy(hp, L.r.map, L.r.nsym); hp += L.r.nsym; hp += put_u7(hp, L.r.plen); }
+        size_t pos = 0;
+        auto flush_hdr = [&]() { const size_t hl = (size_t)(hp - hdr); if (wr) memcpy(cp + pos, hdr, hl); pos += hl; hp = hdr; };
         if (codec == NX16 && (f & F_RLE)) {
             const uint32_t ml = L.r.meta_len, cl = ol[L.mcore] ? ol[L.mcore] - 1u : 0u;   // core output minus its flag byte
             if (cl + 5u < ml) {
-                cp += put_u7(cp, ml * 2u); cp += put_u7(cp, L.r.lit_len); cp += put_u7(cp, cl);
-                fetch(cp, d_out + cd[L.mcore].out_off + 1, cl); cp += cl;
+                hp += put_u7(hp, ml * 2u); hp += put_u7(hp, L.r.lit_len); hp += put_u7(hp, cl);
+                flush_hdr();
+                fetch(wr ? cp + pos : nullptr, 1, cd[L.mcore].out_off + 1, cl); pos += cl;
             } else {
-                cp += put_u7(cp, ml * 2u + 1u); cp += put_u7(cp, L.r.lit_len);
-                fetch(cp, d_buf + xj[L.xjob].m_off, ml); cp += ml;
+                hp += put_u7(hp, ml * 2u + 1u); hp += put_u7(hp, L.r.lit_len);
+                flush_hdr();
+                fetch(wr ? cp + pos : nullptr, 0, xj[L.xjob].m_off, ml); pos += ml;
             }
-        }
+        } else flush_hdr();
         if (f & F_CAT) {
-            if (L.xjob < 0 && L.host_src) { memcpy(cp, L.host_src, L.r.cur_len); }
-            else fetch(cp, d_buf + L.r.cur_off, L.r.cur_len);
-            cp += L.r.cur_len;
+            if (L.xjob < 0 && L.host_src) { if (wr) memcpy(cp + pos, L.host_src, L.r.cur_len); }
+            else fetch(wr ? cp + pos : nullptr, 0, L.r.cur_off, L.r.cur_len);
+            pos += L.r.cur_len;
         } else if (L.core >= 0) {
             const uint32_t skip = codec == NX16 ? 1u : 0u;                    // the Nx16 core kernel writes its own flag byte first
             const uint32_t bl = ol[L.core] > skip ? ol[L.core] - skip : 0u;
-            fetch(cp, d_out + cd[L.core].out_off + skip, bl); cp += bl;
+            fetch(wr ? cp + pos : nullptr, 1, cd[L.core].out_off + skip, bl); pos += bl;
         }
-        return cp;
+        return cp + pos;
     };
-    std::vector<uint8_t> tmp;
-    for (size_t i = 0; i < n && ok; i++) {
+    for (size_t i = 0; i < n; i++) {
         uint8_t *cp = out[i];
         const uint32_t l0 = first_leaf[i], nl = first_leaf[i + 1] - l0;
         if (nl == 1) cp = emit_leaf(cp, leaves[l0]);
@@ -589,14 +601,13 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
             *cp++ = (uint8_t)f;
             if (!(f & F_NOSZ)) cp += put_u7(cp, in_len[i]);
             *cp++ = (uint8_t)nl;
-            // sub-streams are laid out after their length list: build them in a side buffer first
-            tmp.resize(codec == NX16 ? nx16_tight_bound(in_len[i]) : hg_arith_compress_bound(in_len[i]));
-            uint8_t *tp = tmp.data();
-            for (uint32_t k = 0; k < nl; k++) { uint8_t *e = emit_leaf(tp, leaves[l0 + k]); cp += put_u7(cp, (uint32_t)(e - tp)); tp = e; }
-            memcpy(cp, tmp.data(), (size_t)(tp - tmp.data())); cp += tp - tmp.data();
+            for (uint32_t k = 0; k < nl; k++) cp += put_u7(cp, (uint32_t)(emit_leaf(nullptr, leaves[l0 + k]) - (uint8_t *)nullptr));
+            for (uint32_t k = 0; k < nl; k++) cp = emit_leaf(cp, leaves[l0 + k]);
         }
         out_len[i] = (uint32_t)(cp - out[i]);
     }
+    if (!F[0].off.empty() && (rc = hg::stage_download(ctx, d_buf, F[0].off.data(), F[0].len.data(), F[0].dst.data(), F[0].off.size(), s))) return rc;
+    if (!F[1].off.empty() && (rc = hg::stage_download(ctx, d_out, F[1].off.data(), F[1].len.data(), F[1].dst.data(), F[1].off.size(), s))) return rc;
     return ok ? HG_OK : HG_ELAUNCH;
 }
 

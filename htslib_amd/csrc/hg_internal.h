@@ -16,6 +16,8 @@ struct hg_ctx {
     size_t d_scratch_cap[HG_SCRATCH_SLOTS];
     void *d_tok;              // deflate token lists, 256 KiB per resident workgroup
     size_t d_tok_cap;
+    void *h_stage[2];         // pinned staging buffers of the host entry points (0: upload, 1: download)
+    size_t h_stage_cap[2];
 };
 
 namespace hg {
@@ -61,7 +63,7 @@ struct nx16_xenc_res {
 int launch_ransnx16_xenc(hg_ctx *ctx, void *d_buf, const nx16_xenc *d_jobs, size_t njobs, nx16_xenc_res *d_res, hipStream_t s);
 // arith.hip: model memory is an LDS pool per wavefront; streams are sorted into a small-pool launch (many
 // waves per CU) and a big-pool launch, larger models fall back to global scratch words.
-#define HG_ARITH_POOL_SMALL 2560     /* words: order-0 (+RLE), order-1 up to 49 symbols */
+#define HG_ARITH_POOL_SMALL 3072     /* words: order-0 (+RLE), order-1 up to 54 symbols (41 with RLE) */
 #define HG_ARITH_POOL_BIG   16384    /* words: order-1 up to 127 symbols, or 120 with RLE */
 uint32_t arith_model_words(uint32_t max_sym, uint32_t flags);
 int launch_arith_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_sel_small, size_t nsmall,
@@ -88,6 +90,14 @@ struct tok3_enc_res { uint32_t nn, nstreams, total, pad; };                     
 int launch_tok3_tokenise(hg_ctx *ctx, const void *d_in, const tok3_enc_job *d_jobs, size_t njobs, void *d_sb, tok3_enc_stream *d_list,
                          tok3_enc_res *d_res, hipStream_t s);
 int ensure_scratch(hg_ctx *ctx, int slot, size_t bytes);
+// hg_stage.hip: many scattered host buffers <-> one device buffer, one PCIe transfer each way
+int stage_upload(hg_ctx *ctx, const uint8_t *const *src, const uint32_t *len, const uint64_t *dst_off, const int32_t *skip, size_t n,
+                 uint64_t total, uint8_t *d_base, hipStream_t s);
+int stage_download(hg_ctx *ctx, const uint8_t *d_base, const uint64_t *src_off, const uint32_t *len, uint8_t *const *dst, size_t n,
+                   hipStream_t s);
+int stage_gather_dev(hg_ctx *ctx, const uint8_t *d_src, const uint64_t *src_off, const uint32_t *len, uint8_t *d_dst, const uint64_t *dst_off,
+                     size_t n, hipStream_t s);
+void stage_free(hg_ctx *ctx);
 uint32_t ransnx16_enc_scratch_words(uint32_t flags);
 int launch_ransnx16_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags,
                            const uint32_t *d_sel4, size_t n4, const uint32_t *d_sel32, size_t n32, void *d_out,

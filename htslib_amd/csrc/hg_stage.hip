@@ -1,0 +1,122 @@
+// hg_stage.hip -- batched host<->device staging for the host-buffer entry points.
+//
+// The reference hands the codecs one malloc'd buffer per block (cram_block.data, cram/cram_structs.h:312-332).  A
+// batch of CRAM blocks is therefore hundreds to thousands of small scattered host buffers; one hipMemcpy per buffer
+// costs ~3 us each and used to dominate the host entry points (893 k copies in profiles/r01 codec probe).  Here the
+// pieces are packed into ONE pinned staging buffer and moved with ONE transfer each way; on the way back a gather
+// kernel first compacts the pieces (they sit in worst-case-sized slots) so that only payload crosses PCIe.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+#include "htsgpu.h"
+#include "hg_internal.h"
+
+namespace hgs {
+
+struct Piece { uint64_t src, dst; uint32_t len, pad; };
+constexpr uint32_t CHUNK = 1u << 16;                                   // pieces are cut into <= 64 KiB work items
+
+__global__ __launch_bounds__(256)
+void gather_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const Piece *__restrict__ pc, uint32_t n) {
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        const Piece p = pc[k];
+        const uint8_t *s = src + p.src; uint8_t *d = dst + p.dst;
+        // dword path when both ends are aligned the same way
+        const uint32_t head = (uint32_t)((4u - ((uintptr_t)s & 3u)) & 3u);
+        if ((((uintptr_t)s ^ (uintptr_t)d) & 3u) == 0 && p.len >= 64u) {
+            if (threadIdx.x < head) d[threadIdx.x] = s[threadIdx.x];
+            const uint32_t nw = (p.len - head) >> 2;
+            const uint32_t *s4 = (const uint32_t *)(s + head); uint32_t *d4 = (uint32_t *)(d + head);
+            for (uint32_t i = threadIdx.x; i < nw; i += 256) d4[i] = s4[i];
+            for (uint32_t i = head + (nw << 2) + threadIdx.x; i < p.len; i += 256) d[i] = s[i];
+        } else for (uint32_t i = threadIdx.x; i < p.len; i += 256) d[i] = s[i];
+    }
+}
+
+static int ensure_pinned(hg_ctx *ctx, int which, size_t bytes) {
+    if (ctx->h_stage_cap[which] >= bytes) return HG_OK;
+    if (ctx->h_stage[which]) (void)hipHostFree(ctx->h_stage[which]);
+    ctx->h_stage[which] = nullptr; ctx->h_stage_cap[which] = 0;
+    const size_t cap = bytes + bytes / 4 + (1u << 20);
+    if (hipHostMalloc(&ctx->h_stage[which], cap, hipHostMallocDefault) != hipSuccess) return HG_ENOMEM;
+    ctx->h_stage_cap[which] = cap;
+    return HG_OK;
+}
+
+}  // namespace hgs
+
+namespace hg {
+
+// Host buffers src[i] (len[i] bytes) -> d_base + dst_off[i].  The device layout [0, total) is mirrored in a pinned
+// buffer and sent in one transfer; src[i] may be null when len[i] is 0.  skip[i] != 0 leaves a piece out.
+int stage_upload(hg_ctx *ctx, const uint8_t *const *src, const uint32_t *len, const uint64_t *dst_off, const int32_t *skip, size_t n,
+                 uint64_t total, uint8_t *d_base, hipStream_t s) {
+    if (!n || !total) return HG_OK;
+    // the previous user of this pinned buffer may still be in flight on the stream
+    if (hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+    if (int rc = hgs::ensure_pinned(ctx, 0, total)) return rc;
+    uint8_t *h = (uint8_t *)ctx->h_stage[0];
+    uint64_t hi = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!len[i] || (skip && skip[i])) continue;
+        memcpy(h + dst_off[i], src[i], len[i]);
+        if (dst_off[i] + len[i] > hi) hi = dst_off[i] + len[i];
+    }
+    if (!hi) return HG_OK;
+    return hipMemcpyAsync(d_base, h, hi, hipMemcpyHostToDevice, s) == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+
+// Device pieces d_base + src_off[i] (len[i] bytes) -> host buffers dst[i].  Synchronises the stream.
+int stage_download(hg_ctx *ctx, const uint8_t *d_base, const uint64_t *src_off, const uint32_t *len, uint8_t *const *dst, size_t n,
+                   hipStream_t s) {
+    std::vector<hgs::Piece> pc;
+    std::vector<uint64_t> hoff(n);
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+        hoff[i] = total;
+        for (uint32_t o = 0; o < len[i]; o += hgs::CHUNK) {
+            const uint32_t l = len[i] - o < hgs::CHUNK ? len[i] - o : hgs::CHUNK;
+            pc.push_back({src_off[i] + o, total + o, l, 0});
+        }
+        total += ((uint64_t)len[i] + 3u) & ~3ull;
+    }
+    if (!total) return hipStreamSynchronize(s) == hipSuccess ? HG_OK : HG_ELAUNCH;
+    int rc;
+    if ((rc = ensure_scratch(ctx, 13, total + 64)) || (rc = ensure_scratch(ctx, 14, pc.size() * sizeof(hgs::Piece) + 64)) ||
+        (rc = hgs::ensure_pinned(ctx, 1, total))) return rc;
+    if (hipMemcpyAsync(ctx->d_scratch[14], pc.data(), pc.size() * sizeof(hgs::Piece), hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
+    size_t wgs = pc.size();
+    const size_t maxw = (size_t)ctx->cus * 16;
+    if (wgs > maxw) wgs = maxw;
+    hipLaunchKernelGGL(hgs::gather_kernel, dim3((unsigned)wgs), dim3(256), 0, s, d_base, (uint8_t *)ctx->d_scratch[13],
+                       (const hgs::Piece *)ctx->d_scratch[14], (uint32_t)pc.size());
+    if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
+    if (hipMemcpyAsync(ctx->h_stage[1], ctx->d_scratch[13], total, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+    const uint8_t *h = (const uint8_t *)ctx->h_stage[1];
+    for (size_t i = 0; i < n; i++) if (len[i]) memcpy(dst[i], h + hoff[i], len[i]);
+    return HG_OK;
+}
+
+// Device-to-device form of the same gather: d_src + src_off[i] -> d_dst + dst_off[i], one launch.
+int stage_gather_dev(hg_ctx *ctx, const uint8_t *d_src, const uint64_t *src_off, const uint32_t *len, uint8_t *d_dst, const uint64_t *dst_off,
+                     size_t n, hipStream_t s) {
+    std::vector<hgs::Piece> pc;
+    for (size_t i = 0; i < n; i++)
+        for (uint32_t o = 0; o < len[i]; o += hgs::CHUNK) pc.push_back({src_off[i] + o, dst_off[i] + o, len[i] - o < hgs::CHUNK ? len[i] - o : hgs::CHUNK, 0});
+    if (pc.empty()) return HG_OK;
+    if (int rc = ensure_scratch(ctx, 15, pc.size() * sizeof(hgs::Piece) + 64)) return rc;
+    if (hipMemcpyAsync(ctx->d_scratch[15], pc.data(), pc.size() * sizeof(hgs::Piece), hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
+    size_t wgs = pc.size();
+    const size_t maxw = (size_t)ctx->cus * 16;
+    if (wgs > maxw) wgs = maxw;
+    hipLaunchKernelGGL(hgs::gather_kernel, dim3((unsigned)wgs), dim3(256), 0, s, d_src, d_dst, (const hgs::Piece *)ctx->d_scratch[15], (uint32_t)pc.size());
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+
+void stage_free(hg_ctx *ctx) {
+    for (int k = 0; k < 2; k++) if (ctx->h_stage[k]) { (void)hipHostFree(ctx->h_stage[k]); ctx->h_stage[k] = nullptr; ctx->h_stage_cap[k] = 0; }
+}
+
+}  // namespace hg

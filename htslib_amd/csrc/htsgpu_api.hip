@@ -69,6 +69,7 @@ void hg_destroy(hg_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     for (int i = 0; i < HG_SCRATCH_SLOTS; i++) if (ctx->d_scratch[i]) (void)hipFree(ctx->d_scratch[i]);
     if (ctx->d_tok) (void)hipFree(ctx->d_tok);
+    hg::stage_free(ctx);
     if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
     free(ctx);
 }
@@ -146,19 +147,18 @@ int hg_rans4x8_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t
     hipStream_t s = nullptr;
     uint32_t *d_ol = (uint32_t *)ctx->d_scratch[3];
     uint8_t *d_ord = (uint8_t *)ctx->d_scratch[3] + n * 4;
-    bool ok = hipMemsetAsync(d_ol, 0, n * 4, s) == hipSuccess;
-    for (size_t i = 0; i < n && ok; i++)
-        if (in_len[i]) ok = hipMemcpyAsync((uint8_t *)ctx->d_scratch[0] + desc[i].in_off, in[i], in_len[i], hipMemcpyHostToDevice, s) == hipSuccess;
+    std::vector<uint64_t> ioffs(n), ooffs(n);
+    for (size_t i = 0; i < n; i++) { ioffs[i] = desc[i].in_off; ooffs[i] = desc[i].out_off; }
+    bool ok = hg::stage_upload(ctx, in, in_len, ioffs.data(), nullptr, n, ioff, (uint8_t *)ctx->d_scratch[0], s) == HG_OK &&
+              hipMemsetAsync(d_ol, 0, n * 4, s) == hipSuccess;
     ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc, n * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess &&
          hipMemcpyAsync(d_ord, order, n, hipMemcpyHostToDevice, s) == hipSuccess;
     rc = ok ? hg::launch_rans4x8_encode(ctx, ctx->d_scratch[0], (const hg_stream_desc *)ctx->d_scratch[2], d_ord, n,
                                         ctx->d_scratch[1], d_ol, ctx->d_scratch[4], (uint32_t *)ctx->d_scratch[6], s) : HG_ELAUNCH;
     if (rc == HG_OK) {
         ok = hipMemcpyAsync(ol, d_ol, n * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-        for (size_t i = 0; i < n && ok; i++) {
-            out_len[i] = ol[i];
-            if (ol[i]) ok = hipMemcpy(out[i], (uint8_t *)ctx->d_scratch[1] + desc[i].out_off, ol[i], hipMemcpyDeviceToHost) == hipSuccess;
-        }
+        for (size_t i = 0; i < n && ok; i++) out_len[i] = ol[i];
+        ok = ok && hg::stage_download(ctx, (const uint8_t *)ctx->d_scratch[1], ooffs.data(), ol, out, n, s) == HG_OK;
         if (!ok) rc = HG_ELAUNCH;
     }
     free(desc); free(ol);
@@ -239,16 +239,22 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
             (rc = ensure_scratch(ctx, 2, ng * sizeof(hg_bgzf_desc))) == HG_OK && (rc = ensure_scratch(ctx, 3, ng * 4)) == HG_OK) {
             hipStream_t s = nullptr;
             bool ok = true;
-            for (k = 0; k < ng && ok; k++) ok = hipMemcpyAsync((uint8_t *)ctx->d_scratch[0] + desc[k].coff, in[map[k]], desc[k].clen, hipMemcpyHostToDevice, s) == hipSuccess;
+            {
+                std::vector<const uint8_t *> gp(ng); std::vector<uint32_t> gl(ng); std::vector<uint64_t> go(ng);
+                for (k = 0; k < ng; k++) { gp[k] = in[map[k]]; gl[k] = desc[k].clen; go[k] = desc[k].coff; }
+                ok = hg::stage_upload(ctx, gp.data(), gl.data(), go.data(), nullptr, ng, ioff, (uint8_t *)ctx->d_scratch[0], s) == HG_OK;
+            }
             ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc, ng * sizeof(hg_bgzf_desc), hipMemcpyHostToDevice, s) == hipSuccess;
             rc = ok ? hg::launch_bgzf_inflate(ctx, ctx->d_scratch[0], (size_t)ioff, (const hg_bgzf_desc *)ctx->d_scratch[2], ng,
                                               ctx->d_scratch[1], (size_t)ooff, (int32_t *)ctx->d_scratch[3], s, 1) : HG_ELAUNCH;
             if (rc == HG_OK) {
                 ok = hipMemcpyAsync(st, ctx->d_scratch[3], ng * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+                std::vector<uint64_t> go(ng); std::vector<uint32_t> gl(ng); std::vector<uint8_t *> gd(ng);
                 for (k = 0; k < ng && ok; k++) {
                     status[map[k]] = st[k];
-                    if (st[k] == 0) ok = hipMemcpy(out[map[k]], (uint8_t *)ctx->d_scratch[1] + desc[k].uoff, desc[k].ulen, hipMemcpyDeviceToHost) == hipSuccess;
+                    go[k] = desc[k].uoff; gl[k] = st[k] == 0 ? desc[k].ulen : 0u; gd[k] = out[map[k]];
                 }
+                ok = ok && hg::stage_download(ctx, (const uint8_t *)ctx->d_scratch[1], go.data(), gl.data(), gd.data(), ng, s) == HG_OK;
                 if (!ok) rc = HG_ELAUNCH;
             }
         }
@@ -400,16 +406,15 @@ int hg_rans4x8_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t
         (rc = ensure_scratch(ctx, 2, n * sizeof(hg_stream_desc))) || (rc = ensure_scratch(ctx, 3, n * 4)) ||
         (rc = ensure_scratch(ctx, 6, soff * 4 + 64))) { free(desc); free(st); return rc; }
     hipStream_t s = nullptr;
-    bool ok = true;
-    for (size_t i = 0; i < n && ok; i++)
-        if (in_len[i]) ok = hipMemcpyAsync((uint8_t *)ctx->d_scratch[0] + desc[i].in_off, in[i], in_len[i], hipMemcpyHostToDevice, s) == hipSuccess;
+    std::vector<uint64_t> ioffs(n), ooffs(n);
+    for (size_t i = 0; i < n; i++) { ioffs[i] = desc[i].in_off; ooffs[i] = desc[i].out_off; }
+    bool ok = hg::stage_upload(ctx, in, in_len, ioffs.data(), nullptr, n, ioff, (uint8_t *)ctx->d_scratch[0], s) == HG_OK;
     ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc, n * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess;
     rc = ok ? hg::launch_rans4x8_decode(ctx, ctx->d_scratch[0], (const hg_stream_desc *)ctx->d_scratch[2], n, ctx->d_scratch[1],
                                         (int32_t *)ctx->d_scratch[3], (uint32_t *)ctx->d_scratch[6], s) : HG_ELAUNCH;
     if (rc == HG_OK) {
         ok = hipMemcpyAsync(st, ctx->d_scratch[3], n * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-        for (size_t i = 0; i < n && ok; i++)
-            if (out_len[i]) ok = hipMemcpy(out[i], (uint8_t *)ctx->d_scratch[1] + desc[i].out_off, out_len[i], hipMemcpyDeviceToHost) == hipSuccess;
+        ok = ok && hg::stage_download(ctx, (const uint8_t *)ctx->d_scratch[1], ooffs.data(), out_len, out, n, s) == HG_OK;
         if (!ok) rc = HG_ELAUNCH;
     }
     if (rc == HG_OK)
@@ -450,8 +455,9 @@ int hg_gzip_deflate_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *
     hipStream_t s = nullptr;
     bool ok = true;
     uint64_t ioff = 0; size_t k = 0;
+    std::vector<uint64_t> ioffs(n);
     for (size_t i = 0; i < n && ok; i++) {
-        if (in_len[i]) ok = hipMemcpyAsync((uint8_t *)ctx->d_scratch[0] + ioff, in[i], in_len[i], hipMemcpyHostToDevice, s) == hipSuccess;
+        ioffs[i] = ioff;
         const size_t nc = in_len[i] ? (in_len[i] + HG_BGZF_BLOCK_SIZE - 1) / HG_BGZF_BLOCK_SIZE : 1;
         for (size_t c = 0; c < nc; c++, k++) {
             const uint64_t a = (uint64_t)c * HG_BGZF_BLOCK_SIZE;
@@ -463,6 +469,7 @@ int hg_gzip_deflate_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *
         ioff += ((uint64_t)in_len[i] + 15u) & ~15ull;
     }
     uint32_t *d_clen = (uint32_t *)ctx->d_scratch[3], *d_crc = d_clen + nchunks;
+    ok = ok && hg::stage_upload(ctx, in, in_len, ioffs.data(), nullptr, n, ioff, (uint8_t *)ctx->d_scratch[0], s) == HG_OK;
     ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc, nchunks * sizeof(hg_bgzf_desc), hipMemcpyHostToDevice, s) == hipSuccess;
     rc = ok ? hg::launch_bgzf_deflate(ctx, ctx->d_scratch[0], (const hg_bgzf_desc *)ctx->d_scratch[2], nchunks, level,
                                       ctx->d_scratch[1], d_clen, s, 1, d_crc) : HG_ELAUNCH;
@@ -470,6 +477,7 @@ int hg_gzip_deflate_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *
         ok = hipMemcpyAsync(clen, d_clen, nchunks * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
              hipMemcpyAsync(crc, d_crc, nchunks * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
         k = 0;
+        std::vector<uint64_t> po(nchunks); std::vector<uint8_t *> pd(nchunks);
         for (size_t i = 0; i < n && ok; i++) {
             const size_t nc = in_len[i] ? (in_len[i] + HG_BGZF_BLOCK_SIZE - 1) / HG_BGZF_BLOCK_SIZE : 1;
             uint8_t *o = out[i];
@@ -477,13 +485,14 @@ int hg_gzip_deflate_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *
             memcpy(o, hdr, 10);
             size_t pos = 10; uint32_t c32 = 0;
             for (size_t c = 0; c < nc && ok; c++, k++) {
-                if (clen[k]) ok = hipMemcpy(o + pos, (uint8_t *)ctx->d_scratch[1] + desc[k].coff, clen[k], hipMemcpyDeviceToHost) == hipSuccess;
+                po[k] = desc[k].coff; pd[k] = o + pos;                // chunk payloads are fetched in one batch below
                 pos += clen[k];
                 c32 = c == 0 ? crc[k] : crc_combine_h(c32, crc[k], desc[k].ulen);
             }
             for (int b = 0; b < 4; b++) { o[pos + b] = (uint8_t)(c32 >> (8 * b)); o[pos + 4 + b] = (uint8_t)(in_len[i] >> (8 * b)); }
             out_len[i] = (uint32_t)(pos + 8);
         }
+        ok = ok && hg::stage_download(ctx, (const uint8_t *)ctx->d_scratch[1], po.data(), clen, pd.data(), nchunks, s) == HG_OK;
         if (!ok) rc = HG_ELAUNCH;
     }
     free(desc); free(clen); free(crc);
