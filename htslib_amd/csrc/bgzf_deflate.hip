@@ -347,11 +347,19 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 HD_TACC(6, tq);
                 __syncthreads();
                 HD_TACC(7, tq);
-                if (hashable) {                            // publish this chunk's positions
-                    const uint32_t sh = (h & 3u) * 8u;
-                    const uint32_t old = atomicAdd(&S.cnt32[h >> 2], 1u << sh);
-                    S.u.tab[h * WAYS + ((old >> sh) & (WAYS - 1))] = (uint16_t)p;
-                }
+                // Publish this chunk's positions.  The slot a position gets inside its bucket comes from an atomic
+                // counter, so the four waves insert one after the other (a wave's own LDS atomics resolve in lane
+                // order): the table -- and with it the compressed bytes -- is the same on every run.
+                auto publish = [&]() {
+                    if (hashable) {
+                        const uint32_t sh = (h & 3u) * 8u;
+                        const uint32_t old = atomicAdd(&S.cnt32[h >> 2], 1u << sh);
+                        S.u.tab[h * WAYS + ((old >> sh) & (WAYS - 1))] = (uint16_t)p;
+                    }
+                };
+                if (wave == 0) publish();
+                __syncthreads();
+                if (wave == 1) publish();
                 // ---- lazy parse by pointer jumping -----------------------------------------
                 const bool live = p < n;
                 const bool take = best >= 3u && !(tid < WG - 1 && (uint32_t)S.mlen[tid + 1] > best);
@@ -383,6 +391,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 const unsigned long long bal = __ballot(marked);
                 if (lane == 0) S.wsum[wave] = (uint32_t)__popcll(bal);
                 __syncthreads();
+                if (wave == 2) publish();
                 uint32_t base = ntok, total = 0;
 #pragma unroll
                 for (int w = 0; w < 4; w++) { uint32_t t = S.wsum[w]; if (w < wave) base += t; total += t; }
@@ -401,6 +410,8 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 }
                 ntok += total;
                 carry = S.carry_next;
+                __syncthreads();
+                if (wave == 3) publish();
                 __syncthreads();
                 HD_TACC(9, tq);
             }

@@ -4,10 +4,9 @@
 // cram/cram_structs.h:284-305).  Host logic only: every byte of compression work goes to the gfx950 encoders
 // through the hg_*_encode_host entry points, one batched call per method id.
 //
-// Batching rule (the one deliberate difference from the reference's block-at-a-time loop): all blocks of one call
-// that share a metrics object take the SAME branch -- trial or cached method -- decided from the state at entry;
-// the statistics are then folded in block order exactly as the reference does.  A trial phase that ends in the
-// middle of a batch therefore costs a few extra trial compressions, never a different on-disk result class.
+// Batching: blocks that share a metrics object see exactly the state sequence of the reference's block-at-a-time
+// loop.  A call is split into rounds at the points where a trial phase finishes (the blocks after it need the method
+// it learns); everything decidable goes to the GPU together, across all data series -- usually two rounds per call.
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
@@ -98,108 +97,121 @@ int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics 
                                          int version_major, const uint8_t *const *in, const uint32_t *in_len, uint8_t *const *out,
                                          uint32_t *out_len, int32_t *method_used) {
     if (!ctx || (n && (!method_set || !in || !in_len || !out || !out_len || !method_used))) return HG_EINVAL;
-    struct Blk { bool trial; uint32_t method; int single; size_t j0, j1; };
+    struct Blk { bool trial, done; uint32_t method; size_t j0, j1; };
     std::vector<Blk> B(n);
-    std::vector<Job> jobs;
-    // ---- decide per block (state at entry; the size-independent bookkeeping of cram_io.c:1978-2021) -------------
-    std::vector<hg_cram_metrics *> seen;
-    std::vector<char> seen_trial;
     for (size_t i = 0; i < n; i++) {
-        Blk &b = B[i];
-        b.trial = false; b.method = method_set[i]; b.single = -1; b.j0 = b.j1 = jobs.size();
+        B[i] = {false, false, method_set[i], 0, 0};
         out_len[i] = in_len[i]; method_used[i] = HG_CRAM_RAW;
         if (in_len[i]) memcpy(out[i], in[i], in_len[i]);
-        if (method_set[i] == HG_M_RAW || level == 0 || in_len[i] == 0) continue;          // cram_io.c:1967-1972
-        hg_cram_metrics *M = metrics ? metrics[i] : nullptr;
-        if (!M) { b.single = HG_M_GZIP; jobs.push_back({i, HG_M_GZIP}); b.j1 = jobs.size(); continue; }   // cram_io.c:2282-2299
-        const int sz = (int)in_len[i];
-        // sudden changes in size trigger a retrial (cram_io.c:1988-1997)
-        if (M->input_avg_sz && (sz / 4 - 750 > M->input_avg_sz || sz < M->input_avg_sz / 4 - 750) &&
-            abs(sz - M->input_avg_sz) / 10 > M->input_avg_delta)
-            M->next_trial = 0;
-        size_t k = 0;
-        while (k < seen.size() && seen[k] != M) k++;
-        bool trial;
-        if (k < seen.size()) { trial = seen_trial[k] != 0; if (!trial) --M->next_trial; }
-        else { trial = M->trial > 0 || --M->next_trial <= 0; seen.push_back(M); seen_trial.push_back(trial); }
-        M->input_avg_delta = (int)(0.9 * (M->input_avg_delta + abs(sz - M->input_avg_sz)));
-        M->input_avg_sz += (int)(sz * .2);
-        M->input_avg_sz = (int)(M->input_avg_sz * 0.8);
-        if (!trial) { b.single = M->method; if (b.single != HG_M_RAW) jobs.push_back({i, b.single}); b.j1 = jobs.size(); continue; }
-        b.trial = true;
-        // like an htslib built without bz2 / lzma (fd->use_bz2 = 0): methods the engine does not have leave the set
-        const uint32_t have = ~((1u << HG_M_BZIP2) | (1u << HG_M_LZMA) | (1u << HG_M_FQZ) | (1u << HG_M_FQZ_b) | (1u << HG_M_FQZ_c) |
-                                (1u << HG_M_FQZ_d) | (1u << 9) | (1u << 10));
-        uint32_t method = b.method & have;
-        if (M->revised_method) method = M->revised_method & have; else M->revised_method = method;
-        if (M->next_trial <= 0) {
-            M->next_trial = TRIAL_SPAN; M->trial = NTRIALS;
-            for (int m = 0; m < MAXM; m++) M->sz[m] /= 2;
-            M->unpackable = 0;
-        }
-        if (M->unpackable && version_major > 3) {                        // no point bit-packing 17+ symbols (cram_io.c:2026-2047)
-            auto sw = [&](int from, uint32_t to) { if (method & (1u << from)) method = (method | to) & ~(1u << from); };
-            sw(HG_M_RANS_PR128, 1u << HG_M_RANS_PR0); sw(HG_M_RANS_PR129, 1u << HG_M_RANS_PR1); sw(HG_M_RANS_PR192, 1u << HG_M_RANS_PR64);
-            sw(HG_M_RANS_PR193, (1u << HG_M_RANS_PR64) | (1u << HG_M_RANS_PR1));
-            sw(HG_M_ARITH_PR128, 1u << HG_M_ARITH_PR0); sw(HG_M_ARITH_PR129, 1u << HG_M_ARITH_PR1); sw(HG_M_ARITH_PR192, 1u << HG_M_ARITH_PR64);
-            sw(HG_M_ARITH_PR193, (1u << HG_M_ARITH_PR64) | (1u << HG_M_ARITH_PR1));
-        }
-        if ((method & (1u << HG_M_GZIP_RLE)) && (method & (1u << HG_M_GZIP_1))) method &= ~(1u << HG_M_GZIP_RLE);   // cram_io.c:2057-2062
-        b.method = method;
-        for (int m = 0; m < MAXM; m++) if (method & (1u << m)) jobs.push_back({i, m});
-        b.j1 = jobs.size();
+        if (method_set[i] == HG_M_RAW || level == 0 || in_len[i] == 0) B[i].done = true;   // cram_io.c:1967-1972
     }
-    // ---- compress -------------------------------------------------------------------------------------------------
-    std::vector<uint8_t *> res; std::vector<uint32_t> rlen;
-    int rc = run_jobs(ctx, jobs, level, in, in_len, res, rlen);
-    if (rc != HG_OK) { for (auto p : res) free(p); return rc; }
-    // ---- select, then fold the statistics in block order (cram_io.c:2064-2244) ----------------------------------
-    for (size_t i = 0; i < n; i++) {
-        Blk &b = B[i];
-        hg_cram_metrics *M = metrics ? metrics[i] : nullptr;
-        if (b.j0 == b.j1 && !b.trial) continue;
-        if (!b.trial) {                                                  // cached / default method: keep it only if it shrinks the block
-            const size_t j = b.j0;
-            if (res[j] && rlen[j] < in_len[i]) { memcpy(out[i], res[j], rlen[j]); out_len[i] = rlen[j]; method_used[i] = methmap[jobs[j].m]; }
-            continue;
-        }
-        uint32_t sz[MAXM];
-        for (int m = 0; m < MAXM; m++) sz[m] = UINT_MAX;                // arbitrarily worse than raw
-        uint32_t sz_best = in_len[i]; int method_best = 0; size_t jbest = (size_t)-1;
-        for (size_t j = b.j0; j < b.j1; j++) {
-            if (!res[j]) continue;
-            sz[jobs[j].m] = rlen[j];
-            if (sz_best > rlen[j]) { sz_best = rlen[j]; method_best = jobs[j].m; jbest = j; }
-        }
-        if (jbest != (size_t)-1) { memcpy(out[i], res[jbest], sz_best); out_len[i] = sz_best; method_used[i] = methmap[method_best]; }
-        for (int m = 0; m < MAXM; m++) M->sz[m] = (int)((unsigned)M->sz[m] + sz[m] + 2000u);   // int arithmetic wraps as in the reference
-        if (M->trial > 0 && --M->trial == 0) {
-            uint32_t method = b.method;
-            int best_method = HG_M_RAW, best_sz = INT_MAX;
-            const double div = level <= 1 ? 0.25 : level <= 3 ? 1 : level <= 6 ? 2 : level <= 7 ? 3 : 0;
-            if (div > 0) for (int m = 0; m < MAXM; m++) M->sz[m] = (int)(M->sz[m] * (1 + (meth_cost[m] - 1) / div));
-            M->sz[9] = M->sz[10] = INT_MAX;
-            for (int m = 0; m < MAXM; m++) {
-                if (!M->sz[m] || !(method & (1u << m))) continue;
-                if (best_sz > M->sz[m]) { best_sz = M->sz[m]; best_method = m; }
+    // Blocks that share a metrics object are handled in their order, exactly as the reference's one-at-a-time loop
+    // would: a ROUND takes, per metrics object, every block whose branch is already decided by the current state --
+    // cached-method blocks, then the blocks of the next trial phase -- and stops there, because the blocks after a
+    // trial phase need the method that phase is about to learn.  Usually two rounds per call.
+    for (;;) {
+        std::vector<Job> jobs;
+        std::vector<size_t> taken;
+        std::vector<hg_cram_metrics *> seen; std::vector<int> pend; std::vector<char> blocked;
+        for (size_t i = 0; i < n; i++) {
+            Blk &b = B[i];
+            if (b.done) continue;
+            hg_cram_metrics *M = metrics ? metrics[i] : nullptr;
+            b.j0 = b.j1 = jobs.size(); b.trial = false;
+            if (!M) { jobs.push_back({i, HG_M_GZIP}); b.j1 = jobs.size(); taken.push_back(i); continue; }   // cram_io.c:2282-2299
+            size_t k = 0;
+            while (k < seen.size() && seen[k] != M) k++;
+            if (k == seen.size()) { seen.push_back(M); pend.push_back(0); blocked.push_back(0); }
+            if (blocked[k]) continue;
+            const int sz = (int)in_len[i];
+            // sudden changes in size trigger a retrial (cram_io.c:1988-1997)
+            if (M->input_avg_sz && (sz / 4 - 750 > M->input_avg_sz || sz < M->input_avg_sz / 4 - 750) &&
+                abs(sz - M->input_avg_sz) / 10 > M->input_avg_delta)
+                M->next_trial = 0;
+            const bool trial = M->trial - pend[k] > 0 || --M->next_trial <= 0;
+            M->input_avg_delta = (int)(0.9 * (M->input_avg_delta + abs(sz - M->input_avg_sz)));
+            M->input_avg_sz += (int)(sz * .2);
+            M->input_avg_sz = (int)(M->input_avg_sz * 0.8);
+            taken.push_back(i);
+            if (!trial) { if (M->method != HG_M_RAW) jobs.push_back({i, M->method}); b.j1 = jobs.size(); continue; }
+            b.trial = true;
+            // like an htslib built without bz2 / lzma (fd->use_bz2 = 0): methods the engine does not have leave the set
+            const uint32_t have = ~((1u << HG_M_BZIP2) | (1u << HG_M_LZMA) | (1u << HG_M_FQZ) | (1u << HG_M_FQZ_b) | (1u << HG_M_FQZ_c) |
+                                    (1u << HG_M_FQZ_d) | (1u << 9) | (1u << 10));
+            uint32_t method = b.method & have;
+            if (M->revised_method) method = M->revised_method & have; else M->revised_method = method;
+            if (M->next_trial <= 0) {
+                M->next_trial = TRIAL_SPAN; M->trial = NTRIALS;
+                for (int m = 0; m < MAXM; m++) M->sz[m] /= 2;
+                M->unpackable = 0;
             }
-            if (best_method != M->method) M->consistency = 0;
-            else { const double f = 1 + M->consistency / 4.0; M->next_trial = (int)(M->next_trial * (f < 2 ? f : 2)); M->consistency++; }
-            M->method = best_method;
-            M->strat = best_method == HG_M_TOKA ? 1 : 0;
-            const double MAXDELTA = 0.20; const int MAXFAILS = 4, mul = 1 + (level >= 7);
-            for (int m = 0; m < MAXM; m++) {
-                if (best_method == m) { M->cnt[m] = 0; M->extra[m] = 0; }
-                else if (best_sz < M->sz[m]) {
-                    const double r = (double)M->sz[m] / best_sz - 1;
-                    if (++M->cnt[m] >= MAXFAILS * mul && (M->extra[m] += r) >= MAXDELTA * mul) method &= ~(1u << m);
-                    if ((m == HG_M_FQZ || (m >= 13 && m <= 15)) && M->sz[m] > best_sz) method &= ~(1u << m);
+            if (M->unpackable && version_major > 3) {                    // no point bit-packing 17+ symbols (cram_io.c:2026-2047)
+                auto sw = [&](int from, uint32_t to) { if (method & (1u << from)) method = (method | to) & ~(1u << from); };
+                sw(HG_M_RANS_PR128, 1u << HG_M_RANS_PR0); sw(HG_M_RANS_PR129, 1u << HG_M_RANS_PR1); sw(HG_M_RANS_PR192, 1u << HG_M_RANS_PR64);
+                sw(HG_M_RANS_PR193, (1u << HG_M_RANS_PR64) | (1u << HG_M_RANS_PR1));
+                sw(HG_M_ARITH_PR128, 1u << HG_M_ARITH_PR0); sw(HG_M_ARITH_PR129, 1u << HG_M_ARITH_PR1); sw(HG_M_ARITH_PR192, 1u << HG_M_ARITH_PR64);
+                sw(HG_M_ARITH_PR193, (1u << HG_M_ARITH_PR64) | (1u << HG_M_ARITH_PR1));
+            }
+            if ((method & (1u << HG_M_GZIP_RLE)) && (method & (1u << HG_M_GZIP_1))) method &= ~(1u << HG_M_GZIP_RLE);   // cram_io.c:2057-2062
+            b.method = method;
+            for (int m = 0; m < MAXM; m++) if (method & (1u << m)) jobs.push_back({i, m});
+            b.j1 = jobs.size();
+            if (M->trial - ++pend[k] <= 0) blocked[k] = 1;              // this block ends the trial phase: later blocks wait a round
+        }
+        if (taken.empty()) break;
+        // ---- compress -------------------------------------------------------------------------------------------
+        std::vector<uint8_t *> res; std::vector<uint32_t> rlen;
+        int rc = run_jobs(ctx, jobs, level, in, in_len, res, rlen);
+        if (rc != HG_OK) { for (auto p : res) free(p); return rc; }
+        // ---- select, then fold the statistics in block order (cram_io.c:2064-2244) ------------------------------
+        for (size_t i : taken) {
+            Blk &b = B[i];
+            b.done = true;
+            hg_cram_metrics *M = metrics ? metrics[i] : nullptr;
+            if (!b.trial) {                                              // cached / default method: kept only if it shrinks the block
+                if (b.j0 == b.j1) continue;
+                const size_t j = b.j0;
+                if (res[j] && rlen[j] < in_len[i]) { memcpy(out[i], res[j], rlen[j]); out_len[i] = rlen[j]; method_used[i] = methmap[jobs[j].m]; }
+                continue;
+            }
+            uint32_t sz[MAXM];
+            for (int m = 0; m < MAXM; m++) sz[m] = UINT_MAX;            // arbitrarily worse than raw
+            uint32_t sz_best = in_len[i]; int method_best = 0; size_t jbest = (size_t)-1;
+            for (size_t j = b.j0; j < b.j1; j++) {
+                if (!res[j]) continue;
+                sz[jobs[j].m] = rlen[j];
+                if (sz_best > rlen[j]) { sz_best = rlen[j]; method_best = jobs[j].m; jbest = j; }
+            }
+            if (jbest != (size_t)-1) { memcpy(out[i], res[jbest], sz_best); out_len[i] = sz_best; method_used[i] = methmap[method_best]; }
+            for (int m = 0; m < MAXM; m++) M->sz[m] = (int)((unsigned)M->sz[m] + sz[m] + 2000u);   // int arithmetic wraps as in the reference
+            if (--M->trial == 0) {
+                uint32_t method = b.method;
+                int best_method = HG_M_RAW, best_sz = INT_MAX;
+                const double div = level <= 1 ? 0.25 : level <= 3 ? 1 : level <= 6 ? 2 : level <= 7 ? 3 : 0;
+                if (div > 0) for (int m = 0; m < MAXM; m++) M->sz[m] = (int)(M->sz[m] * (1 + (meth_cost[m] - 1) / div));
+                M->sz[9] = M->sz[10] = INT_MAX;
+                for (int m = 0; m < MAXM; m++) {
+                    if (!M->sz[m] || !(method & (1u << m))) continue;
+                    if (best_sz > M->sz[m]) { best_sz = M->sz[m]; best_method = m; }
                 }
+                if (best_method != M->method) M->consistency = 0;
+                else { const double f = 1 + M->consistency / 4.0; M->next_trial = (int)(M->next_trial * (f < 2 ? f : 2)); M->consistency++; }
+                M->method = best_method;
+                M->strat = best_method == HG_M_TOKA ? 1 : 0;
+                const double MAXDELTA = 0.20; const int MAXFAILS = 4, mul = 1 + (level >= 7);
+                for (int m = 0; m < MAXM; m++) {
+                    if (best_method == m) { M->cnt[m] = 0; M->extra[m] = 0; }
+                    else if (best_sz < M->sz[m]) {
+                        const double r = (double)M->sz[m] / best_sz - 1;
+                        if (++M->cnt[m] >= MAXFAILS * mul && (M->extra[m] += r) >= MAXDELTA * mul) method &= ~(1u << m);
+                        if ((m == HG_M_FQZ || (m >= 13 && m <= 15)) && M->sz[m] > best_sz) method &= ~(1u << m);
+                    }
+                }
+                M->revised_method = method;
             }
-            M->revised_method = method;
         }
+        for (auto p : res) free(p);
     }
-    for (auto p : res) free(p);
     return HG_OK;
 }
 

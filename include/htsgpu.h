@@ -278,8 +278,9 @@ void hg_cram_metrics_free(hg_cram_metrics *m);
 /* Block i is compressed under metrics[i] (one object per data series; NULL metrics / NULL entry = plain GZIP as
  * cram_io.c:2282-2299) starting from method_set[i]: while the series is in a trial phase every method of the set is
  * run and the smallest output kept, afterwards only the learnt method; statistics, method costs, retrial spans and
- * the culling of persistently bad methods follow the reference.  Blocks of one call that share a metrics object all
- * take the branch chosen from its state at entry.  bzip2 / lzma / fqzcomp bits are dropped from the set, as in an
+ * the culling of persistently bad methods follow the reference.  Blocks of one call that share a metrics object are
+ * handled in their order with the reference's state sequence (the call runs in rounds, split where a trial phase
+ * ends).  bzip2 / lzma / fqzcomp bits are dropped from the set, as in an
  * htslib built without those libraries.  method_used[i] = on-disk method id; out[i] must hold hg_cram_compress_bound(in_len[i]). */
 int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics *const *metrics, const uint32_t *method_set,
                                          int level, int version_major, const uint8_t *const *in, const uint32_t *in_len,

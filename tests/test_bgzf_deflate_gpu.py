@@ -95,3 +95,15 @@ def test_many_ragged_blocks(engine, oracle):
     assert gzip.decompress(comp) == data
     n, got = oracle.decompress(comp)
     assert got == data
+
+
+def test_deflate_output_is_reproducible(engine):
+    """Same input -> same bytes, run after run and whatever else is in the batch (the hash-table insert order is
+    fixed by design; zlib and libdeflate are deterministic too)."""
+    import hashlib
+    plain, _ = synth.bam_bgzf(6 << 20)
+    runs = [hashlib.sha1(engine.bgzf_deflate_host(plain, level=6)).hexdigest() for _ in range(4)]
+    assert len(set(runs)) == 1
+    a = engine.gzip_deflate_host([plain[:300_000], plain[300_000:900_000]], level=6)
+    b = engine.gzip_deflate_host([plain[300_000:900_000], plain[:2_000_000], plain[:300_000]], level=6)
+    assert a[0] == b[2] and a[1] == b[0]

@@ -169,3 +169,23 @@ def test_cram_metrics_auto_tuner_follows_the_reference_state_machine(engine):
     # bzip2 and fqz are not in the engine: dropped from the set like an htslib built without them
     assert Q.method not in (2, 7) and not (Q.revised_method & ((1 << 2) | (1 << 7)))
     nat.lib.hg_cram_metrics_free(mq); nat.lib.hg_cram_metrics_free(mn)
+
+
+def test_cram_metrics_many_slices_in_one_call_match_one_at_a_time(engine):
+    """A batch of slices goes through the same per-series state sequence as feeding the blocks one call at a time
+    (the reference's loop): same methods, same bytes, same final metrics."""
+    import ctypes as C
+    from htslib_amd import _native as nat
+    from tests.test_rans4x8 import synth_series
+    rng = np.random.default_rng(56)
+    qset = sum(1 << i for i in (1, 5, 17, 18, 20, 6, 25))
+    blocks = [synth_series(rng, "qual4" if i % 7 else "bytes", 20_000 + 500 * (i % 5)) for i in range(120)]
+    ma, mb = nat.lib.hg_cram_metrics_new(), nat.lib.hg_cram_metrics_new()
+    one = [engine.cram_compress_blocks_metrics([b], [ma], [qset], level=5) for b in blocks]
+    outs_b, used_b = engine.cram_compress_blocks_metrics(blocks, [mb] * len(blocks), [qset] * len(blocks), level=5)
+    assert [int(u[0]) for _, u in one] == [int(u) for u in used_b]
+    assert [o[0] for o, _ in one] == outs_b
+    A = C.cast(ma, C.POINTER(nat.CramMetrics)).contents
+    Bm = C.cast(mb, C.POINTER(nat.CramMetrics)).contents
+    assert bytes(A) == bytes(Bm)
+    nat.lib.hg_cram_metrics_free(ma); nat.lib.hg_cram_metrics_free(mb)
