@@ -31,6 +31,10 @@ constexpr int WAVES = 4;
 enum { F_ORDER = 1, F_X32 = 4, F_STRIPE = 8, F_NOSZ = 16, F_CAT = 32, F_RLE = 64, F_PACK = 128 };
 
 struct GroupLds { uint16_t C[258]; };
+// 32-way streams (the big data series) keep their order-1 tables in LDS when they fit: a symbol lookup is a chain
+// of 6-7 DEPENDENT table reads, which from global memory (~600 cycles each) capped a stream at ~23 MB/s.
+constexpr uint32_t O1_LDS_WORDS = 4352;          // per stream; 8 streams per workgroup -> 136 KiB
+// Order 0 uses the same pool as a direct slot -> symbol table (4096 one-byte entries) instead of a binary search.
 
 __device__ __forceinline__ uint32_t rd32(const uint8_t *p) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
@@ -112,6 +116,8 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                             uint32_t *scratch) {
     constexpr int GROUPS = 64 / N;
     __shared__ GroupLds lds[WAVES * GROUPS];
+    // one pool per stream slot, used either as the order-1 table copy or as the order-0 lookup table
+    __shared__ uint32_t pool[N == 32 ? WAVES * GROUPS : 1][N == 32 ? O1_LDS_WORDS : 1];
     const int tid = threadIdx.x, lane = tid & 63, sub = lane & (N - 1), grp = lane / N;
     const uint32_t g_global = (blockIdx.x * WAVES + (tid >> 6)) * GROUPS + grp;
     const uint32_t g_total = gridDim.x * WAVES * GROUPS;
@@ -123,7 +129,7 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
         const bool have = k < nsel;
         const uint32_t sidx = have ? sel[k] : 0;
         int err = have ? 0 : 2;
-        uint32_t flags = 0, usz = 0, shift = 12;
+        uint32_t flags = 0, usz = 0, shift = 12, np_words = 0xffffffffu;
         const uint8_t *cp = nullptr, *end = nullptr;
         uint8_t *o = nullptr;
         uint32_t *tabs = nullptr;
@@ -217,6 +223,7 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                         tabs[i] = first; tabs[256 + i] = cnt;
                     }
                     if (!comp) cp = tp;
+                    np_words = np;
                 }
             }
         }
@@ -231,6 +238,23 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const uint32_t *T = tabs;                                    // where the decode loop reads the order-1 tables
+        const uint8_t *lut = nullptr;                                // order-0 slot -> symbol
+        if constexpr (N == 32) {
+            uint32_t *P = pool[(tid >> 6) * GROUPS + grp];
+            const uint32_t npw = (uint32_t)__shfl((int)np_words, lane0, 64);
+            if (core && !err && order && npw <= O1_LDS_WORDS) {
+                for (uint32_t i = (uint32_t)sub; i < npw; i += N) P[i] = tabs[i];
+                T = P;
+            } else if (core && !err && !order) {
+                uint8_t *L8 = (uint8_t *)P;
+                // lane l fills the slots of symbols l, l+32, ...
+                for (uint32_t sy = (uint32_t)sub; sy < 256; sy += N) { const uint32_t a = G.C[sy], b = G.C[sy + 1]; for (uint32_t q = a; q < b; q++) L8[q] = (uint8_t)sy; }
+                lut = L8;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         const bool live = core && !err;
         uint32_t R = 0;
         if (live) {
@@ -251,16 +275,17 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                 uint32_t sym = 0, cum = 0, f = 1;
                 if (order == 0) {
                     uint32_t lo = 0, hi = 256;
-                    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (G.C[mid] <= m) lo = mid; else hi = mid; }
+                    if (lut) lo = lut[m];
+                    else while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (G.C[mid] <= m) lo = mid; else hi = mid; }
                     sym = lo; cum = G.C[lo]; f = (uint32_t)G.C[lo + 1] - cum;
                 } else {
-                    const uint32_t n = tabs[256 + ctx], base = tabs[ctx];
-                    if (n == 0 || (tabs[base + n] >> 8) <= m) err = 1;
+                    const uint32_t n = T[256 + ctx], base = T[ctx];
+                    if (n == 0 || (T[base + n] >> 8) <= m) err = 1;
                     else {
                         uint32_t lo = 0, hi = n;
-                        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if ((tabs[base + mid] >> 8) <= m) lo = mid; else hi = mid; }
-                        const uint32_t e = tabs[base + lo];
-                        sym = e & 0xffu; cum = e >> 8; f = (tabs[base + lo + 1] >> 8) - cum;
+                        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if ((T[base + mid] >> 8) <= m) lo = mid; else hi = mid; }
+                        const uint32_t e = T[base + lo];
+                        sym = e & 0xffu; cum = e >> 8; f = (T[base + lo + 1] >> 8) - cum;
                     }
                 }
                 if (!err) {
@@ -287,7 +312,8 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
         if (live && !err && order == 0 && (uint32_t)sub < rem) {
             const uint32_t m = R & mask;
             uint32_t lo = 0, hi = 256;
-            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (G.C[mid] <= m) lo = mid; else hi = mid; }
+            if (lut) lo = lut[m];
+            else while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (G.C[mid] <= m) lo = mid; else hi = mid; }
             o[per * N + sub] = (uint8_t)lo;
         }
         err = (__ballot(err == 1) & gmask) ? 1 : err;
