@@ -82,6 +82,7 @@ __device__ uint8_t *put_alphabet(uint8_t *cp, const Arr &F) {
 //   [66048, 66048+65792/2...)  C[ctx][sym] cumulative (u16 pairs packed as u32: 256*257 entries)
 constexpr uint32_t O1_F = 0, O1_T = 65536, O1_A = 65792, O1_C = 66048;
 constexpr uint32_t O1_WORDS = 66048 + (256 * 258) / 2 + 16;
+constexpr uint32_t DENSE_MAX = 64;
 
 template <int N>
 __global__ __launch_bounds__(WAVES * 64)
@@ -90,6 +91,9 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                             uint8_t *out, uint32_t *out_len, uint8_t *wbuf, uint32_t *scratch) {
     constexpr int GROUPS = 64 / N;
     __shared__ GroupLds lds[WAVES * GROUPS];
+    // 32-way streams (the big data series): order-1 counts, then (start << 16 | freq), for alphabets of <= 64 symbols
+    __shared__ uint32_t dpool[N == 32 ? WAVES * GROUPS : 1][N == 32 ? DENSE_MAX * DENSE_MAX : 1];
+    __shared__ uint8_t ipool[N == 32 ? WAVES * GROUPS : 1][64];
     const int tid = threadIdx.x, lane = tid & 63, sub = lane & (N - 1), grp = lane / N;
     const uint32_t g_global = (blockIdx.x * WAVES + (tid >> 6)) * GROUPS + grp;
     const uint32_t g_total = gridDim.x * WAVES * GROUPS;
@@ -131,6 +135,10 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
         const bool core = have && !(flags & F_CAT) && n != 0;
         if (have && !core && !(flags & F_CAT) && sub == 0) out_len[sidx] = hdr;   // empty input
         uint32_t tab = 0;                                        // bytes of table written after hdr
+        bool dense = false;                                      // order-1 tables held in LDS, indexed by alphabet rank
+        uint32_t nsym_d = 0;
+        uint32_t *D = dpool[N == 32 ? (tid >> 6) * GROUPS + grp : 0];
+        uint8_t *isym = ipool[N == 32 ? (tid >> 6) * GROUPS + grp : 0];
         if (core && order == 0) {
             // ---- order-0 histogram in LDS --------------------------------------------------------
             for (int j = sub; j < 256; j += N) G.H[j] = 0;
@@ -151,17 +159,48 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                 G.C[256] = (uint16_t)x;
             }
         } else if (core) {
-            // ---- order-1 histogram in global scratch (atomics) -----------------------------------
+            // ---- order 1.  Pass 0: which byte values occur (value 0 always: it is the start context) ---------------
             const uint32_t per = n / N;
-            for (uint32_t i = (uint32_t)sub; i < O1_C; i += N) sc[i] = 0;
+            for (int j = sub; j < 256; j += N) G.H[j] = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = (uint32_t)sub; i < n; i += N) {
-                const uint32_t c = src[i], l = i ? src[i - 1] : 0u;
-                atomicAdd(&sc[O1_F + l * 256u + c], 1u);
-                atomicAdd(&sc[O1_T + l], 1u);
-                sc[O1_A + l] = 1; sc[O1_A + c] = 1;
+            for (uint32_t i = (uint32_t)sub; i < n; i += N) G.H[src[i]] = 1;
+            if (sub == 0) G.H[0] = 1;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            // dense numbering of the alphabet (G.C[value] = index), only the rows / columns that exist are touched below
+            uint32_t nsym = 0;
+            if (sub == 0) { for (int j = 0; j < 256; j++) { G.C[j] = (uint16_t)nsym; if (G.H[j]) { if (N == 32) isym[nsym & 63u] = (uint8_t)j; nsym++; } } }
+            nsym = (uint32_t)__shfl((int)nsym, lane0, 64);
+            dense = N == 32 && nsym <= DENSE_MAX;
+            nsym_d = nsym;
+            for (uint32_t i = 0; i < 256; i++) {
+                if (!G.H[i]) continue;
+                for (uint32_t j = (uint32_t)sub; j < 256; j += N) sc[O1_F + i * 256u + j] = 0;
             }
-            if (sub >= 1) { atomicAdd(&sc[O1_F + src[(uint32_t)sub * per]], 1u); atomicAdd(&sc[O1_T], 1u); }   // states start in ctx 0
+            for (uint32_t i = (uint32_t)sub; i < 256; i += N) { sc[O1_T + i] = 0; sc[O1_A + i] = G.H[i]; }
+            if (dense) for (uint32_t i = (uint32_t)sub; i < nsym * nsym; i += N) D[i] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (dense) {
+                // histogram with LDS atomics on the nsym x nsym matrix, then written out in the 256 x 256 layout
+                for (uint32_t i = (uint32_t)sub; i < n; i += N) {
+                    const uint32_t c = src[i], l = i ? src[i - 1] : 0u;
+                    atomicAdd(&D[(uint32_t)G.C[l] * nsym + G.C[c]], 1u);
+                }
+                if (sub >= 1) atomicAdd(&D[(uint32_t)G.C[0] * nsym + G.C[src[(uint32_t)sub * per]]], 1u);   // states start in ctx 0
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                for (uint32_t a = (uint32_t)sub; a < nsym; a += N) {
+                    uint32_t tsum = 0;
+                    const uint32_t ia = isym[a];
+                    for (uint32_t b = 0; b < nsym; b++) { const uint32_t v = D[a * nsym + b]; sc[O1_F + ia * 256u + isym[b]] = v; tsum += v; }
+                    sc[O1_T + ia] = tsum;
+                }
+            } else {
+                for (uint32_t i = (uint32_t)sub; i < n; i += N) {
+                    const uint32_t c = src[i], l = i ? src[i - 1] : 0u;
+                    atomicAdd(&sc[O1_F + l * 256u + c], 1u);
+                    atomicAdd(&sc[O1_T + l], 1u);
+                }
+                if (sub >= 1) { atomicAdd(&sc[O1_F + src[(uint32_t)sub * per]], 1u); atomicAdd(&sc[O1_T], 1u); }   // states start in ctx 0
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
             // normalise one context row per lane (rows are independent)
             for (uint32_t i = (uint32_t)sub; i < 256; i += N) {
@@ -200,15 +239,20 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                 }
                 tab = (uint32_t)(cp - (o + hdr));
             }
-            // cumulative tables, shifted up to 2^12, one row per lane
+            // cumulative tables, shifted up to 2^12, one row per lane (only rows that are contexts)
             uint16_t *C16 = (uint16_t *)(sc + O1_C);
             for (uint32_t i = (uint32_t)sub; i < 256; i += N) {
+                if (!G.H[i]) continue;
                 const uint32_t tot = sc[O1_T + i];
                 uint32_t *row = sc + O1_F + i * 256u;
                 int sh = 0;
                 while (tot && (tot << sh) < 4096u) sh++;
                 uint32_t x = 0;
-                for (int j = 0; j < 256; j++) { const uint32_t f = sc[O1_A + i] ? row[j] << sh : 0u; row[j] = f; C16[i * 258u + j] = (uint16_t)x; x += f; }
+                for (int j = 0; j < 256; j++) {
+                    const uint32_t f = G.H[j] ? row[j] << sh : 0u;
+                    if (G.H[j]) { row[j] = f; if (dense) D[(uint32_t)G.C[i] * nsym + G.C[j]] = (x << 16) | f; }
+                    C16[i * 258u + j] = (uint16_t)x; x += f;
+                }
                 C16[i * 258u + 256] = (uint16_t)x;
             }
         }
@@ -224,6 +268,7 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
             uint32_t f = 1, start = 0;
             if (mine) {
                 if (order == 0) { start = G.C[sym]; f = (uint32_t)G.C[sym + 1] - start; }
+                else if (dense) { const uint32_t e = D[(uint32_t)G.C[ctx] * nsym_d + G.C[sym]]; start = e >> 16; f = e & 0xffffu; }
                 else { start = C16[ctx * 258u + sym]; f = sc[O1_F + ctx * 256u + sym]; }
                 const uint32_t x_max = ((RANS_L >> shift) << 16) * f;
                 emit = R >= x_max ? 1u : 0u;
