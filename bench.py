@@ -123,9 +123,10 @@ def main():
     ap.add_argument("--gib", type=float, default=10.0, help="plain GiB of synthetic BAM per GPU")
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--workers", type=int, default=0, help="host processes for workload preparation")
-    ap.add_argument("--op", choices=["inflate", "deflate", "rans"], default="inflate",
+    ap.add_argument("--op", choices=["inflate", "deflate", "rans", "bam"], default="inflate",
                     help="inflate = BASELINE configs[1] (default, the headline); deflate = configs[2]; "
-                         "rans = configs[3] (CRAM 3.1 rANS Nx16 decode of QS+BA series)")
+                         "rans = configs[3] (CRAM 3.1 rANS Nx16 decode of QS+BA series); bam = SURVEY 8f N1: record framing "
+                         "(bam_read1) + nibble2base over the inflated stream, on the device")
     ap.add_argument("--slices", type=int, default=1000, help="--op rans: CRAM slices of 10 000 reads (1000 = 10 M reads)")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -173,6 +174,8 @@ def main():
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
 
+    if args.op == "bam":
+        return bench_bam(args, eng, comp, desc, total_u, d_comp, d_desc, d_out, d_status, dev, rank, world, seed)
     if args.op == "deflate":
         return bench_deflate(args, eng, comp, desc, total_u, d_comp, d_desc, d_out, d_status, dev, rank, world,
                              ncores, t_prep, seed)
@@ -373,6 +376,100 @@ def bench_rans(args, rank, world, local, ncores):
         dist.destroy_process_group()
     if not ok:
         sys.exit(2)
+
+
+def bench_bam(args, eng, comp, desc, total_u, d_comp, d_desc, d_plain, d_status, dev, rank, world, seed):
+    """frame every record of the inflated BAM (bam_read1's framing + checks) and decode all bases
+    (nibble2base), stream resident in HBM.  A step = one framing pass + one base-decoding pass over the whole stream."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from htslib_amd import _native as nat, synth
+    stream = torch.cuda.current_stream().cuda_stream
+    nblocks = len(desc)
+    eng.bgzf_inflate_dev(d_comp.data_ptr(), len(comp), d_desc.data_ptr(), nblocks, d_plain.data_ptr(), total_u, d_status.data_ptr(), stream)
+    torch.cuda.synchronize()
+    head = d_plain[:1 << 20].cpu().numpy().tobytes()
+    n_ref, first = C.c_int32(), C.c_uint64()
+    nat.check(nat.lib.hg_bam_header_host(head, len(head), C.byref(n_ref), C.byref(first)), "bam header")
+    bad = C.c_uint64()
+    n = nat.lib.hg_bam_frame_dev(eng._h, d_plain.data_ptr(), total_u, first.value, n_ref.value, None, 0, C.byref(bad), stream)
+    assert n > 0, n
+    d_off = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_boff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    tot = C.c_uint64()
+    nat.check(nat.lib.hg_bam_bases_dev(eng._h, d_plain.data_ptr(), d_off.data_ptr(), 0, d_boff.data_ptr(), None, 0, C.byref(tot), stream), "bases")
+    d_bases = torch.empty(int(n) * 160 + 4096, dtype=torch.uint8, device=dev)
+
+    def step():
+        m = nat.lib.hg_bam_frame_dev(eng._h, d_plain.data_ptr(), total_u, first.value, n_ref.value, d_off.data_ptr(), n, C.byref(bad), stream)
+        assert m == n
+        nat.check(nat.lib.hg_bam_bases_dev(eng._h, d_plain.data_ptr(), d_off.data_ptr(), n, d_boff.data_ptr(), d_bases.data_ptr(),
+                                           d_bases.numel(), C.byref(tot), stream), "bases")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # verification against the oracle on the first chunk (outside the timed region)
+    ok = True
+    try:
+        from tests.test_bam_frame import BamOracle
+        orc = BamOracle()
+        chk = d_plain[:8 << 20].cpu().numpy().tobytes()
+        off = d_off[:20000].cpu().numpy().astype(np.uint64)
+        lim = min(int((off < (8 << 20) - 70000).sum()), len(off) - 1)
+        wn, _, woff = orc.frame(chk[:int(off[lim])], first.value)
+        ok = wn == lim and bool((woff == off[:lim]).all())
+        boff = d_boff[:lim + 1].cpu().numpy(); bases = d_bases[:int(boff[lim])].cpu().numpy().tobytes()
+        ok = ok and all(bases[boff[i]:boff[i + 1]] == orc.bases(chk, int(off[i])) for i in range(0, lim, 97))
+        # CPU baseline: the oracle's scalar port of the same two loops, one core, on the sample
+        cpu = None
+        if rank == 0 and not args.no_cpu_baseline:
+            samp = chk[:int(off[lim])]
+            t = time.perf_counter()
+            for _ in range(3):
+                wn2, _, woff2 = orc.frame(samp, first.value)
+                buf = C.create_string_buffer(1 << 16)
+                for o in woff2:
+                    x = int(o) + 4
+                    lq, nc, ls = samp[x + 8], int.from_bytes(samp[x + 12:x + 14], "little"), int.from_bytes(samp[x + 16:x + 20], "little")
+                    orc.L.orc_nibble2base(samp[x + 32 + lq + 4 * nc:x + 32 + lq + 4 * nc + (ls + 1) // 2], buf, ls)
+            dt = (time.perf_counter() - t) / 3
+            cpu = {"value": round(len(samp) / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+                   "sample": "oracle/bam_oracle.c framing + nibble2base driven record by record from Python over the first %.1f MB "
+                             "(call overhead included; the reference's bam_read1 cannot be built without all of libhts)" % (len(samp) / 1e6)}
+    except Exception as e:  # oracle not built on this box
+        ok = ok and False
+        cpu = None
+        print("verification unavailable:", e, file=sys.stderr)
+    from htslib_amd.bgzf import reduce_timing
+    elapsed, sum_u, sum_n, ok = reduce_timing(elapsed, float(total_u), float(n), ok, world, dev)
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        alg = total_u / 290.0 * 36 + tot.value / 2 + tot.value        # core fields read + packed bases read + ASCII written, per rank
+        print(json.dumps({"metric": "BAM record framing + base decoding throughput, uncompressed BAM GB/s (HBM-resident)",
+                          "value": round(sum_u * args.steps / elapsed / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                          "config": {"workload": "bam_read1 framing + nibble2base over a %.1f GiB inflated synthetic BAM per GPU" % (total_u / 2**30),
+                                     "records_per_gpu": int(n), "records_per_s": round(sum_n * args.steps / elapsed, 1), "verified": bool(ok)},
+                          "roofline": {"bound": "hbm", "achieved": round(alg / (ms / 1e3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                                       "frac": round(alg / (ms / 1e3) / 1e9 / 8000.0, 4), "traffic": None,
+                                       "algorithmic_bytes_per_launch": int(alg)},
+                          **({"cpu_baseline": cpu} if cpu else {})}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def bench_deflate(args, eng, comp, desc, total_u, d_comp, d_desc, d_plain, d_status, dev, rank, world, ncores,

@@ -286,6 +286,24 @@ int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics 
                                          int level, int version_major, const uint8_t *const *in, const uint32_t *in_len,
                                          uint8_t *const *out, uint32_t *out_len, int32_t *method_used);
 
+/* ---- BAM record framing on the device: the framing half of bam_read1 (sam.c:784-866) and
+ *      nibble2base (simd.c:119-161) for consumers that keep the inflated stream in HBM. ---- */
+#define HG_BAM_ETRUNC   (-2)   /* the stream ends inside a record (bam_read1 returns -2 / -3) */
+#define HG_BAM_EINVALID (-4)   /* a record fails bam_read1's sanity checks (it returns -4) */
+/* bam_hdr_read's walk (sam.c:229-335) over a host copy of the start of the stream: number of reference sequences and
+ * the offset of the first alignment record. */
+int hg_bam_header_host(const uint8_t *bam, size_t len, int32_t *n_ref, uint64_t *first_record_off);
+/* Offsets of every record's block_len field in a device-resident uncompressed BAM stream, in order.  Returns the
+ * record count (even when d_rec_off is NULL or smaller than the count -- only max_rec offsets are written), or
+ * HG_BAM_ETRUNC / HG_BAM_EINVALID with *bad_off = offset of the offending record, or a negative HG_E* code.
+ * Exact: per-chunk guesses are verified link by link on the host.  Synchronises the stream. */
+long hg_bam_frame_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, uint64_t first_record_off, int32_t n_ref,
+                      uint64_t *d_rec_off, uint64_t max_rec, uint64_t *bad_off, void *stream);
+/* d_base_off[i] (n+1 entries) = start of record i's bases in d_bases; d_bases = "=ACMGRSVTWYHKDBN" text of every
+ * record back to back (pass d_bases NULL to get only the offsets and *total_bases).  Synchronises the stream. */
+int hg_bam_bases_dev(hg_ctx *ctx, const void *d_bam, const uint64_t *d_rec_off, uint64_t n, uint64_t *d_base_off,
+                     void *d_bases, uint64_t bases_cap, uint64_t *total_bases, void *stream);
+
 /* ---- CRC-32 (replaces hts_crc32, bgzf.c:557-559 / 620-622) -------------- */
 /* crc[i] = crc32(0, d_data + off[i], len[i]) for n independent buffers. */
 int hg_crc32_dev(hg_ctx *ctx, const void *d_data,
