@@ -120,29 +120,58 @@ void bam_bases_kernel(const uint8_t *__restrict__ b, const uint64_t *__restrict_
         }
     }
 }
-// exclusive prefix sum of n 32-bit values into 64-bit offsets (n+1 outputs), single workgroup, chunked
-__global__ __launch_bounds__(1024)
-void scan32_kernel(const uint32_t *__restrict__ v, uint64_t n, uint64_t *out) {
-    __shared__ unsigned long long wsum[16];
-    __shared__ unsigned long long carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
+// Exclusive prefix sum of n 32-bit values into 64-bit offsets (n+1 outputs), three launches: per-tile sums, a scan of
+// the tile sums by one workgroup, then the tiles again with their base added.
+constexpr uint32_t TILE = 4096;
+__device__ __forceinline__ unsigned long long wg_incl_scan(unsigned long long x, unsigned long long *wsum, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned long long s = x;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(s, d, 64); if (lane >= d) s += y; }
+    if (lane == 63) wsum[wave] = s;
     __syncthreads();
-    for (uint64_t b0 = 0; b0 < n; b0 += 1024) {
-        const uint64_t i = b0 + (uint64_t)tid;
+    unsigned long long pre = 0;
+    for (int w = 0; w < wave; w++) pre += wsum[w];
+    __syncthreads();
+    return pre + s;
+}
+__global__ __launch_bounds__(256)
+void scan_tiles_kernel(const uint32_t *__restrict__ v, uint64_t n, const uint64_t *__restrict__ tile_base, uint64_t *tile_sum, uint64_t *out) {
+    __shared__ unsigned long long wsum[4];
+    const int tid = threadIdx.x;
+    const uint64_t t0 = (uint64_t)blockIdx.x * TILE;
+    unsigned long long carry = tile_base ? tile_base[blockIdx.x] : 0ull;
+    for (uint32_t k = 0; k < TILE; k += 256) {
+        const uint64_t i = t0 + k + (uint64_t)tid;
         const unsigned long long x = i < n ? v[i] : 0ull;
-        unsigned long long s = x;
-        for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(s, d, 64); if (lane >= d) s += y; }
-        if (lane == 63) wsum[wave] = s;
+        const unsigned long long incl = wg_incl_scan(x, wsum, tid);
+        if (out && i < n) out[i] = carry + incl - x;
+        __shared__ unsigned long long tot;
+        if (tid == 255) tot = incl;
         __syncthreads();
-        unsigned long long pre = carry_s;
-        for (int w = 0; w < wave; w++) pre += wsum[w];
-        if (i < n) out[i] = pre + s - x;
-        __syncthreads();
-        if (tid == 1023) carry_s = pre + s;
+        carry += tot;
         __syncthreads();
     }
-    if (tid == 0) out[n] = carry_s;
+    if (tile_sum && tid == 0) tile_sum[blockIdx.x] = carry;
+    if (out && tid == 0 && t0 + TILE >= n) out[n] = carry;
+}
+__global__ __launch_bounds__(1024)
+void scan_sums_kernel(uint64_t *sums, uint64_t nt) {                   // in place: exclusive scan of the tile sums
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry_s, tot;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint64_t b0 = 0; b0 < nt; b0 += 1024) {
+        const uint64_t i = b0 + (uint64_t)tid;
+        const unsigned long long x = i < nt ? sums[i] : 0ull;
+        const unsigned long long incl = wg_incl_scan(x, wsum, tid);
+        const unsigned long long c = carry_s;
+        if (i < nt) sums[i] = c + incl - x;
+        if (tid == 1023) tot = incl;
+        __syncthreads();
+        if (tid == 0) carry_s = c + tot;
+        __syncthreads();
+    }
 }
 
 }  // namespace hgb
@@ -235,7 +264,12 @@ int hg_bam_bases_dev(hg_ctx *ctx, const void *d_bam, const uint64_t *d_rec_off, 
         if ((rc = hg::ensure_scratch(ctx, 8, (size_t)n * 4 + 64))) return rc;
         uint32_t *d_lseq = (uint32_t *)ctx->d_scratch[8];
         hipLaunchKernelGGL(hgb::bam_lseq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_bam, d_rec_off, n, d_lseq);
-        hipLaunchKernelGGL(hgb::scan32_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)d_lseq, n, d_base_off);
+        const uint64_t nt = (n + hgb::TILE - 1) / hgb::TILE;
+        if ((rc = hg::ensure_scratch(ctx, 9, (size_t)nt * 8 + 64))) return rc;
+        uint64_t *d_ts = (uint64_t *)ctx->d_scratch[9];
+        hipLaunchKernelGGL(hgb::scan_tiles_kernel, dim3((unsigned)nt), dim3(256), 0, s, (const uint32_t *)d_lseq, n, (const uint64_t *)nullptr, d_ts, (uint64_t *)nullptr);
+        hipLaunchKernelGGL(hgb::scan_sums_kernel, dim3(1), dim3(1024), 0, s, d_ts, nt);
+        hipLaunchKernelGGL(hgb::scan_tiles_kernel, dim3((unsigned)nt), dim3(256), 0, s, (const uint32_t *)d_lseq, n, (const uint64_t *)d_ts, (uint64_t *)nullptr, d_base_off);
         if (hipMemcpyAsync(&total, d_base_off + n, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
         if (d_bases && total) {
             if (total > bases_cap) { if (total_bases) *total_bases = total; return HG_EINVAL; }
