@@ -216,25 +216,31 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
             if (sub == 0) {                                       // serialise the table (oracle layout)
                 uint8_t *cp = o + hdr;
                 *cp++ = (uint8_t)(12u << 4);
-                cp = put_alphabet(cp, *(const uint32_t(*)[256])(sc + O1_A));
+                cp = put_alphabet(cp, G.H);
+                int cnt_alpha = 0;
+                for (int j = 0; j < 256; j++) cnt_alpha += G.H[j] != 0;
                 for (int i = 0; i < 256; i++) {
-                    if (!sc[O1_A + i]) continue;
-                    const uint32_t *row = sc + O1_F + (uint32_t)i * 256u;
+                    if (!G.H[i]) continue;
                     if (sc[O1_T + i]) {
-                        int run = 0;
-                        for (int j = 0; j < 256; j++) {
-                            if (!sc[O1_A + j]) continue;
-                            if (run) { run--; continue; }
-                            cp += put_u7(cp, row[j]);
-                            if (!row[j]) {
-                                for (int q = j + 1; q < 256; q++) { if (!sc[O1_A + q]) continue; if (row[q] == 0) run++; else break; }
-                                *cp++ = (uint8_t)run;
+                        // a zero frequency is written as (0, how many MORE zero entries follow): streamed with a pending
+                        // run byte instead of looking ahead, the row fetched four words at a time
+                        const uint4 *row4 = (const uint4 *)(sc + O1_F + (uint32_t)i * 256u);
+                        uint8_t *runbyte = nullptr; uint32_t runcnt = 0;
+                        for (int j4 = 0; j4 < 64; j4++) {
+                            const uint4 q = row4[j4];
+                            const uint32_t v4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                if (!G.H[j4 * 4 + k]) continue;
+                                const uint32_t v = v4[k];
+                                if (runbyte) { if (!v) { runcnt++; continue; } *runbyte = (uint8_t)runcnt; runbyte = nullptr; }
+                                cp += put_u7(cp, v);
+                                if (!v) { runbyte = cp++; runcnt = 0; }
                             }
                         }
+                        if (runbyte) *runbyte = (uint8_t)runcnt;
                     } else {
-                        int cnt = 0;
-                        for (int j = 0; j < 256; j++) cnt += sc[O1_A + j] != 0;
-                        cp += put_u7(cp, 0); *cp++ = (uint8_t)(cnt - 1);
+                        cp += put_u7(cp, 0); *cp++ = (uint8_t)(cnt_alpha - 1);
                     }
                 }
                 tab = (uint32_t)(cp - (o + hdr));
