@@ -118,6 +118,10 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
     __shared__ GroupLds lds[WAVES * GROUPS];
     // one pool per stream slot, used either as the order-1 table copy or as the order-0 lookup table
     __shared__ uint32_t pool[N == 32 ? WAVES * GROUPS : 1][N == 32 ? O1_LDS_WORDS : 1];
+    // 32-way only: the next 128 renormalisation words of the stream (filled 64 at a time from a register prefetch, so a
+    // step never waits on global memory) and the dense numbering of the order-1 contexts (for the bucket table below)
+    __shared__ uint32_t ring_s[N == 32 ? WAVES * GROUPS : 1][N == 32 ? 64 : 1];
+    __shared__ uint8_t rank_s[N == 32 ? WAVES * GROUPS : 1][N == 32 ? 256 : 1];
     const int tid = threadIdx.x, lane = tid & 63, sub = lane & (N - 1), grp = lane / N;
     const uint32_t g_global = (blockIdx.x * WAVES + (tid >> 6)) * GROUPS + grp;
     const uint32_t g_total = gridDim.x * WAVES * GROUPS;
@@ -240,12 +244,40 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
         __builtin_amdgcn_wave_barrier();
         const uint32_t *T = tabs;                                    // where the decode loop reads the order-1 tables
         const uint8_t *lut = nullptr;                                // order-0 slot -> symbol
+        const uint8_t *o1lut = nullptr;                              // order-1 bucket tables (64 bytes per context)
         if constexpr (N == 32) {
             uint32_t *P = pool[(tid >> 6) * GROUPS + grp];
             const uint32_t npw = (uint32_t)__shfl((int)np_words, lane0, 64);
             if (core && !err && order && npw <= O1_LDS_WORDS) {
                 for (uint32_t i = (uint32_t)sub; i < npw; i += N) P[i] = tabs[i];
                 T = P;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // bucket table: for every context, which list entry holds slot b * (range / 64) -- replaces the binary
+                // search (6-7 dependent LDS reads) by one read plus a short forward scan
+                uint8_t *rk = rank_s[(tid >> 6) * GROUPS + grp];
+                uint32_t nctx = 0;
+                if (sub == 0) for (int i = 0; i < 256; i++) { rk[i] = (uint8_t)nctx; if (P[256 + i]) nctx++; }
+                nctx = (uint32_t)__shfl((int)nctx, lane0, 64);
+                if (npw + nctx * 16u <= O1_LDS_WORDS) {
+                    const uint32_t sh6 = shift - 6u;
+                    for (uint32_t i = (uint32_t)sub; i < 256; i += N) {
+                        const uint32_t cnt = P[256 + i], base = P[i];
+                        if (!cnt) continue;
+                        uint8_t *l8 = (uint8_t *)(P + npw + 16u * rk[i]);
+                        uint32_t k = 0;
+                        for (uint32_t bkt = 0; bkt < 64; bkt++) {
+                            const uint32_t sl = bkt << sh6;
+                            while (k + 1 < cnt && (P[base + k + 1] >> 8) <= sl) k++;
+                            l8[bkt] = (uint8_t)k;
+                        }
+                    }
+                    o1lut = (const uint8_t *)(P + npw);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    // one word per context for the decode loop: list start | bucket-table number << 13 | entries << 21
+                    for (uint32_t i = (uint32_t)sub; i < 256; i += N) P[i] = P[i] | ((uint32_t)rk[i] << 13) | (P[256 + i] << 21);
+                }
             } else if (core && !err && !order) {
                 uint8_t *L8 = (uint8_t *)P;
                 // lane l fills the slots of symbols l, l+32, ...
@@ -260,6 +292,27 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
         if (live) {
             if (cp + 4 * N > end) err = 1;
             else { R = rd32(cp + 4 * sub); cp += 4 * N; }
+        }
+        // 32-way: renormalisation words come from the LDS ring, topped up from a register prefetch
+        uint32_t *ring = ring_s[N == 32 ? (tid >> 6) * GROUPS + grp : 0];
+        uint32_t wpos = 0, wfill = 0, wavail = 0, pre = 0;
+        const uint8_t *wbase = cp;
+        auto load_chunk = [&](uint32_t c) -> uint32_t {               // words 64c + 2*sub, +1 of the stream (0 past the end)
+            const uint8_t *p = wbase + 2u * (64u * c + 2u * (uint32_t)sub);
+            uint32_t v = 0;
+            if (p + 4 <= end) v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+            else for (int q = 0; q < 4; q++) if (p + q < end) v |= (uint32_t)p[q] << (8 * q);
+            return v;
+        };
+        if constexpr (N == 32) {
+            if (live && !err) {
+                wavail = (uint32_t)((end - wbase) >> 1);
+                ring[sub] = load_chunk(0);
+                pre = load_chunk(1);
+                wfill = 64;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         const uint32_t mask = (1u << shift) - 1u;
         const uint32_t per = usz / N;
@@ -279,8 +332,16 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                     else while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (G.C[mid] <= m) lo = mid; else hi = mid; }
                     sym = lo; cum = G.C[lo]; f = (uint32_t)G.C[lo + 1] - cum;
                 } else {
-                    const uint32_t n = T[256 + ctx], base = T[ctx];
-                    if (n == 0 || (T[base + n] >> 8) <= m) err = 1;
+                    if (N == 32 && o1lut) {
+                        const uint32_t info = T[ctx], base = info & 0x1fffu;
+                        if ((info >> 21) == 0) err = 1;               // context never seen by the encoder
+                        else {
+                            uint32_t lo = o1lut[64u * ((info >> 13) & 0xffu) + (m >> (shift - 6u))];
+                            uint32_t e = T[base + lo], e1 = T[base + lo + 1];
+                            while ((e1 >> 8) <= m) { lo++; e = e1; e1 = T[base + lo + 1]; }   // the list ends with (range << 8) > m
+                            sym = e & 0xffu; cum = e >> 8; f = (e1 >> 8) - cum;
+                        }
+                    } else if (const uint32_t n = T[256 + ctx], base = T[ctx]; n == 0 || (T[base + n] >> 8) <= m) err = 1;
                     else {
                         uint32_t lo = 0, hi = n;
                         while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if ((T[base + mid] >> 8) <= m) lo = mid; else hi = mid; }
@@ -300,12 +361,26 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
             const unsigned long long b = __ballot(need != 0) & gmask;
             const uint32_t before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
             const uint32_t tot = (uint32_t)__popcll(b);
-            if (need) {
-                const uint8_t *w = cp + 2u * before;
-                if (w + 2 > end) err = 1;
-                else R = (R << 16) | (uint32_t)w[0] | ((uint32_t)w[1] << 8);
+            if constexpr (N == 32) {
+                if (need) {
+                    const uint32_t k = wpos + before;
+                    if (k >= wavail) err = 1;
+                    else R = (R << 16) | (uint32_t)((const uint16_t *)ring)[k & 127u];
+                }
+                wpos += tot;
+                if (act && wfill - wpos < 32u) {                      // whole group takes this branch together
+                    ring[((wfill >> 1) + (uint32_t)sub) & 63u] = pre;
+                    wfill += 64;
+                    pre = load_chunk(wfill >> 6);
+                }
+            } else {
+                if (need) {
+                    const uint8_t *w = cp + 2u * before;
+                    if (w + 2 > end) err = 1;
+                    else R = (R << 16) | (uint32_t)w[0] | ((uint32_t)w[1] << 8);
+                }
+                cp += 2u * tot;
             }
-            cp += 2u * tot;
             err = (__ballot(err == 1) & gmask) ? 1 : err;
         }
         // order-0 tail: states 0..rem-1 give one more symbol each, without update
