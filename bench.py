@@ -123,10 +123,11 @@ def main():
     ap.add_argument("--gib", type=float, default=10.0, help="plain GiB of synthetic BAM per GPU")
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--workers", type=int, default=0, help="host processes for workload preparation")
-    ap.add_argument("--op", choices=["inflate", "deflate", "rans", "bam"], default="inflate",
+    ap.add_argument("--op", choices=["inflate", "deflate", "rans", "bam", "cram"], default="inflate",
                     help="inflate = BASELINE configs[1] (default, the headline); deflate = configs[2]; "
                          "rans = configs[3] (CRAM 3.1 rANS Nx16 decode of QS+BA series); bam = SURVEY 8f N1: record framing "
-                         "(bam_read1) + nibble2base over the inflated stream, on the device")
+                         "(bam_read1) + nibble2base over the inflated stream, on the device; cram = configs[4] shape: whole CRAM 3.1 "
+                         "slices through the cram_compress_block2 auto-tuner (rANS Nx16 + tok3 + range coder), host entry points")
     ap.add_argument("--slices", type=int, default=1000, help="--op rans: CRAM slices of 10 000 reads (1000 = 10 M reads)")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,6 +143,8 @@ def main():
 
     if args.op == "rans":
         return bench_rans(args, rank, world, local, ncores)
+    if args.op == "cram":
+        return bench_cram(args, rank, world, local)
     # ---------------- workload preparation (host, not timed, before HIP init) --------------
     total_bytes = int(args.gib * (1 << 30))
     seed = 0x5EED0001 + 1000003 * rank
@@ -376,6 +379,40 @@ def bench_rans(args, rank, world, local, ncores):
         dist.destroy_process_group()
     if not ok:
         sys.exit(2)
+
+
+def bench_cram(args, rank, world, local):
+    """BASELINE configs[4] shape on the GPUs of one node: every rank encodes (and decodes back) its own --slices CRAM 3.1
+    slices of 10 000 reads -- 8 data series each -- through hg_cram_compress_blocks_metrics_host, i.e. the reference's
+    cram_compress_block2 loop with its method auto-tuner, then hg_cram_uncompress_blocks_host.  These are HOST entry
+    points (the reference hands the codecs malloc'd blocks), so unlike the other ops the rate includes PCIe both ways."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import bench_cram_slices
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()
+    S = args.slices if args.slices != 1000 else 256
+    r = bench_cram_slices.main(S, device=local, reps=max(2, args.steps), quiet=True)
+    from htslib_amd.bgzf import reduce_timing
+    enc_s, sum_u, sum_c, ok = reduce_timing(r["encode_s"], float(r["plain_bytes"]), float(r["comp_bytes"]), True, world, dev)
+    dec_s, _, _, _ = reduce_timing(r["decode_s"], float(r["plain_bytes"]), float(r["comp_bytes"]), True, world, dev)
+    if rank == 0:
+        print(json.dumps({"metric": "CRAM 3.1 slice encode throughput through the block-method auto-tuner, plain GB/s (host entry points, PCIe included)",
+                          "value": round(sum_u / enc_s / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": max(2, args.steps), "warmup": 1,
+                          "ms_per_step": round(enc_s * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "u8", "data": "synthetic",
+                          "config": {"workload": "%d slices x 10 000 reads per GPU, series QS BA RN AP BF TS MQ NP; best steady call" % S,
+                                     "blocks_per_gpu": r["blocks"], "plain_bytes_per_gpu": r["plain_bytes"], "ratio": round(r["comp_bytes"] / r["plain_bytes"], 4),
+                                     "decode_GBps": round(sum_u / dec_s / 1e9, 3), "on_disk_methods": r["methods"], "verified": True,
+                                     "format_parity": "rANS Nx16 / range coder / tok3 UNPINNED against htscodecs"}}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def bench_bam(args, eng, comp, desc, total_u, d_comp, d_desc, d_plain, d_status, dev, rank, world, seed):
