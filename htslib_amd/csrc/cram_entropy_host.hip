@@ -238,7 +238,7 @@ static int entropy_decode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
     const uint64_t obytes = (ooff + 63u) & ~63ull;
     int rc;
     if ((rc = ensure_scratch(ctx, 0, ioff + 64))) return rc;
-    hipStream_t s = nullptr;
+    hipStream_t s = ctx->stream;
     uint8_t *d_in = (uint8_t *)ctx->d_scratch[0];
     rc = hg::stage_upload(ctx, in, in_len, ioffs.data(), st.data(), n, ioff, d_in, s);
     if (rc == HG_OK) rc = launch_plan(ctx, P, ioff, obytes, s);
@@ -342,7 +342,7 @@ extern "C" int hg_tok3_decode_host(hg_ctx *ctx, const uint8_t *const *in, const 
     if ((rc = ensure_scratch(ctx, 0, ioff + 64)) || (rc = ensure_scratch(ctx, 8, ooff + 64)) || (rc = ensure_scratch(ctx, 9, recs * 12 + 64)) ||
         (rc = ensure_scratch(ctx, 10, names * 4 + 64)) || (rc = ensure_scratch(ctx, 11, tab.size() * 4 + 64)) ||
         (rc = ensure_scratch(ctx, 12, nj * sizeof(hg::tok3_job) + nj * 4 + 64))) return rc;
-    hipStream_t s = nullptr;
+    hipStream_t s = ctx->stream;
     uint8_t *d_in = (uint8_t *)ctx->d_scratch[0];
     bool ok = true;
     rc = hg::stage_upload(ctx, in, in_len, ioffs.data(), st.data(), n, ioff, d_in, s);
@@ -465,7 +465,7 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
     first_leaf[n] = (uint32_t)leaves.size();
     int rc;
     if ((rc = ensure_scratch(ctx, 0, work + 64)) || (rc = ensure_scratch(ctx, 4, xj.size() * (sizeof(hg::nx16_xenc) + sizeof(hg::nx16_xenc_res)) + 64))) return rc;
-    hipStream_t s = nullptr;
+    hipStream_t s = ctx->stream;
     uint8_t *d_buf = (uint8_t *)ctx->d_scratch[0];
     bool ok = true;
     rc = d_src ? hg::stage_gather_dev(ctx, d_src, d_src_off, in_len, d_buf, ioffs.data(), n, s)
@@ -633,7 +633,7 @@ extern "C" int hg_tok3_encode_host(hg_ctx *ctx, const uint8_t *const *in, const 
                                    uint8_t *const *out, uint32_t *out_len) {
     if (!ctx || (n && (!in || !in_len || !use_arith || !out || !out_len))) return HG_EINVAL;
     if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
-    hipStream_t s = nullptr;
+    hipStream_t s = ctx->stream;
     size_t i0 = 0;
     while (i0 < n) {
         // one group of blocks per round keeps the host-side trial buffers bounded

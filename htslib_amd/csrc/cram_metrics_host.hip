@@ -2,7 +2,7 @@
 // method auto-tuner (reference cram/cram_io.c:1912-2325: cram_compress_block3, cram_new_metrics :2327-2339,
 // TRIAL_SPAN 70 / NTRIALS 3 :118-119, meth_cost :2116-2154, methmap :1928-1943; struct cram_metrics
 // cram/cram_structs.h:284-305).  Host logic only: every byte of compression work goes to the gfx950 encoders
-// through the hg_*_encode_host entry points, one batched call per method id.
+// through the hg_*_encode_host entry points, one batched call per codec family and round.
 //
 // Batching: blocks that share a metrics object see exactly the state sequence of the reference's block-at-a-time
 // loop.  A call is split into rounds at the points where a trial phase finishes (the blocks after it need the method
@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 #include <vector>
 #include "htsgpu.h"
 #include "hg_internal.h"
@@ -36,46 +37,65 @@ int pr_flags(int m) {
 
 struct Job { size_t blk; int m; };
 
-// Runs every (block, method) job, grouped by method so that each group is ONE batched GPU call.
-// res[j] = malloc'd payload (or null when the method is not available / failed), rlen[j] = its size.
+// Runs every (block, method) job.  Jobs are grouped by CODEC FAMILY, not by method id: the entry points take a
+// parameter per stream (order / flag byte / back-end), so e.g. all seven RANS_PR* trials of all blocks are ONE batched
+// GPU call.  res[j] = malloc'd payload (or null when the method is not available / failed), rlen[j] = its size.
 int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t *const *in, const uint32_t *in_len,
              std::vector<uint8_t *> &res, std::vector<uint32_t> &rlen) {
     res.assign(jobs.size(), nullptr); rlen.assign(jobs.size(), 0);
-    for (int m = 0; m < MAXM; m++) {
+    enum Fam { F_GZ = 0, F_GZ1, F_R4, F_NX, F_AR, F_TK, F_N };
+    auto family = [](int m) -> int {
+        if (m == HG_M_GZIP) return F_GZ;
+        if (m == HG_M_GZIP_RLE || m == HG_M_GZIP_1) return F_GZ1;
+        if (m == HG_M_RANS0 || m == HG_M_RANS1) return F_R4;
+        if (m == HG_M_RANS_PR0 || (m >= HG_M_RANS_PR1 && m <= HG_M_RANS_PR193)) return F_NX;
+        if (m == HG_M_ARITH_PR0 || (m >= HG_M_ARITH_PR1 && m <= HG_M_ARITH_PR193)) return F_AR;
+        if (m == HG_M_TOK3 || m == HG_M_TOKA) return F_TK;
+        return -1;                                                     // bzip2 / lzma / fqzcomp: not in the engine -> "failed"
+    };
+    // The families are independent: each runs on its own thread, sibling context (own scratch, own HIP stream), so
+    // their -- individually latency-bound -- kernels overlap on the GPU.
+    int frc[F_N];
+    std::vector<std::thread> th;
+    for (int fam = 0; fam < F_N; fam++) {
+        frc[fam] = HG_OK;
         std::vector<size_t> idx;
-        for (size_t j = 0; j < jobs.size(); j++) if (jobs[j].m == m) idx.push_back(j);
+        for (size_t j = 0; j < jobs.size(); j++) if (family(jobs[j].m) == fam) idx.push_back(j);
         if (idx.empty()) continue;
-        const int pf = pr_flags(m);
-        const bool rans4 = m == HG_M_RANS0 || m == HG_M_RANS1, gz = m == HG_M_GZIP || m == HG_M_GZIP_RLE || m == HG_M_GZIP_1;
-        const bool nx = m == HG_M_RANS_PR0 || (m >= HG_M_RANS_PR1 && m <= HG_M_RANS_PR193);
-        const bool ar = m == HG_M_ARITH_PR0 || (m >= HG_M_ARITH_PR1 && m <= HG_M_ARITH_PR193);
-        const bool tk = m == HG_M_TOK3 || m == HG_M_TOKA;
-        if (!(rans4 || gz || nx || ar || tk)) continue;                // bzip2 / lzma / fqzcomp: not in the engine -> "failed"
-        std::vector<const uint8_t *> sin; std::vector<uint8_t *> sout; std::vector<uint32_t> slen, solen(idx.size(), 0);
-        std::vector<uint8_t> par(idx.size());
-        for (size_t k = 0; k < idx.size(); k++) {
-            const size_t b = jobs[idx[k]].blk;
-            sin.push_back(in[b]); slen.push_back(in_len[b]);
-            const size_t cap = gz ? hg_gzip_compress_bound(in_len[b]) : rans4 ? hg_rans4x8_compress_bound(in_len[b])
-                             : nx ? hg_ransnx16_compress_bound(in_len[b]) : ar ? hg_arith_compress_bound(in_len[b]) : hg_tok3_compress_bound(in_len[b]);
-            uint8_t *p = (uint8_t *)malloc(cap);
-            if (!p) { for (auto q : sout) free(q); return HG_ENOMEM; }
-            sout.push_back(p);
-            // RANS_ORDER_SIMD_AUTO (cram_io.c:1860): the 32-way layout for inputs big enough to fill it
-            par[k] = rans4 ? (uint8_t)(m == HG_M_RANS1) : nx ? (uint8_t)(pf | (in_len[b] >= 65536u ? 4 : 0)) : ar ? (uint8_t)pf : (uint8_t)(m == HG_M_TOKA);
-        }
-        int rc;
-        // libdeflate has no Z_RLE strategy: GZIP_RLE is run as level 1, like GZIP_1 (cram_io.c:2057-2062)
-        if (gz) rc = hg_gzip_deflate_host(ctx, sin.data(), slen.data(), sin.size(), m == HG_M_GZIP ? level : 1, sout.data(), solen.data());
-        else if (rans4) rc = hg_rans4x8_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
-        else if (nx) rc = hg_ransnx16_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
-        else if (ar) rc = hg_arith_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
-        else rc = hg_tok3_encode_host(ctx, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
-        if (rc != HG_OK) { for (auto q : sout) free(q); return rc; }
-        for (size_t k = 0; k < idx.size(); k++) {
-            if (solen[k]) { res[idx[k]] = sout[k]; rlen[idx[k]] = solen[k]; } else free(sout[k]);
-        }
+        if (!ctx->sub[fam] && hg_init(ctx->device, &ctx->sub[fam]) != HG_OK) { frc[fam] = HG_ENOMEM; continue; }
+        hg_ctx *sub = ctx->sub[fam];
+        th.emplace_back([&, fam, sub, idx]() {
+            if (hipSetDevice(ctx->device) != hipSuccess) { frc[fam] = HG_ENODEV; return; }
+            std::vector<const uint8_t *> sin; std::vector<uint8_t *> sout; std::vector<uint32_t> slen, solen(idx.size(), 0);
+            std::vector<uint8_t> par(idx.size());
+            for (size_t k = 0; k < idx.size(); k++) {
+                const size_t b = jobs[idx[k]].blk; const int m = jobs[idx[k]].m;
+                sin.push_back(in[b]); slen.push_back(in_len[b]);
+                const size_t cap = fam <= F_GZ1 ? hg_gzip_compress_bound(in_len[b]) : fam == F_R4 ? hg_rans4x8_compress_bound(in_len[b])
+                                 : fam == F_NX ? hg_ransnx16_compress_bound(in_len[b]) : fam == F_AR ? hg_arith_compress_bound(in_len[b])
+                                 : hg_tok3_compress_bound(in_len[b]);
+                uint8_t *p = (uint8_t *)malloc(cap);
+                if (!p) { for (auto q : sout) free(q); frc[fam] = HG_ENOMEM; return; }
+                sout.push_back(p);
+                // RANS_ORDER_SIMD_AUTO (cram_io.c:1860): the 32-way layout for inputs big enough to fill it
+                par[k] = fam == F_R4 ? (uint8_t)(m == HG_M_RANS1) : fam == F_NX ? (uint8_t)(pr_flags(m) | (in_len[b] >= 65536u ? 4 : 0))
+                       : fam == F_AR ? (uint8_t)pr_flags(m) : (uint8_t)(m == HG_M_TOKA);
+            }
+            int rc;
+            // libdeflate has no Z_RLE strategy: GZIP_RLE is run as level 1, like GZIP_1 (cram_io.c:2057-2062)
+            if (fam <= F_GZ1) rc = hg_gzip_deflate_host(sub, sin.data(), slen.data(), sin.size(), fam == F_GZ ? level : 1, sout.data(), solen.data());
+            else if (fam == F_R4) rc = hg_rans4x8_encode_host(sub, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
+            else if (fam == F_NX) rc = hg_ransnx16_encode_host(sub, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
+            else if (fam == F_AR) rc = hg_arith_encode_host(sub, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
+            else rc = hg_tok3_encode_host(sub, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
+            if (rc != HG_OK) { for (auto q : sout) free(q); frc[fam] = rc; return; }
+            for (size_t k = 0; k < idx.size(); k++) {                  // distinct jobs: no two threads touch the same slot
+                if (solen[k]) { res[idx[k]] = sout[k]; rlen[idx[k]] = solen[k]; } else free(sout[k]);
+            }
+        });
     }
+    for (auto &t : th) t.join();
+    for (int fam = 0; fam < F_N; fam++) if (frc[fam] != HG_OK) return frc[fam];
     return HG_OK;
 }
 

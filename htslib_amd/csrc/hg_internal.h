@@ -18,6 +18,8 @@ struct hg_ctx {
     size_t d_tok_cap;
     void *h_stage[2];         // pinned staging buffers of the host entry points (0: upload, 1: download)
     size_t h_stage_cap[2];
+    hipStream_t stream;       // the host entry points run on this non-blocking stream (one per context)
+    hg_ctx *sub[8];           // lazily created sibling contexts: independent codec families of one CRAM batch run concurrently
 };
 
 namespace hg {

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 #include <vector>
 #include "htsgpu.h"
 #include "hg_internal.h"
@@ -60,6 +61,7 @@ int hg_init(int device, hg_ctx **out) {
     // inflate: 30 KiB LDS per 4-wave workgroup -> 5 workgroups (20 waves) per CU
     ctx->waves_per_launch = ctx->cus * 24;
     if (hipMalloc((void **)&ctx->d_ticket, 64) != hipSuccess) { free(ctx); return HG_ENOMEM; }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipFree(ctx->d_ticket); free(ctx); return HG_ENODEV; }
     *out = ctx;
     return HG_OK;
 }
@@ -70,6 +72,8 @@ void hg_destroy(hg_ctx *ctx) {
     for (int i = 0; i < HG_SCRATCH_SLOTS; i++) if (ctx->d_scratch[i]) (void)hipFree(ctx->d_scratch[i]);
     if (ctx->d_tok) (void)hipFree(ctx->d_tok);
     hg::stage_free(ctx);
+    for (hg_ctx *c : ctx->sub) if (c) hg_destroy(c);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
     free(ctx);
 }
@@ -144,7 +148,7 @@ int hg_rans4x8_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t
     if ((rc = ensure_scratch(ctx, 0, ioff + 64)) || (rc = ensure_scratch(ctx, 1, ooff + 64)) ||
         (rc = ensure_scratch(ctx, 2, n * sizeof(hg_stream_desc))) || (rc = ensure_scratch(ctx, 3, n * 4 + n + 64)) ||
         (rc = ensure_scratch(ctx, 4, woff + 64)) || (rc = ensure_scratch(ctx, 6, soff * 4 + 64))) { free(desc); free(ol); return rc; }
-    hipStream_t s = nullptr;
+    hipStream_t s = ctx->stream;
     uint32_t *d_ol = (uint32_t *)ctx->d_scratch[3];
     uint8_t *d_ord = (uint8_t *)ctx->d_scratch[3] + n * 4;
     std::vector<uint64_t> ioffs(n), ooffs(n);
@@ -192,11 +196,12 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
         else if (method[i] == HG_CRAM_TOK3) nt++;
         else status[i] = HG_BLOCK_EUNSUPPORTED;
     }
-    int rc = HG_OK;
-    for (int pass = 0; pass < 3; pass++) {                            // Nx16, the range coder, the name tokeniser
+    // Five independent codec families; each runs on its own thread / sibling context / HIP stream when more than one
+    // is present, so their kernels (each latency-bound on its slowest block) overlap on the GPU.
+    auto run_entropy = [&](hg_ctx *ctx, int pass) -> int {            // 0 Nx16, 1 the range coder, 2 the name tokeniser
+        int rc = HG_OK;
         const int32_t meth = pass == 2 ? HG_CRAM_TOK3 : pass ? HG_CRAM_ARITH : HG_CRAM_RANSNx16;
         const size_t nx = pass == 2 ? nt : pass ? na : nx_;
-        if (!nx) continue;
         const uint8_t **xin = (const uint8_t **)malloc(nx * sizeof(void *));
         uint8_t **xout = (uint8_t **)malloc(nx * sizeof(void *));
         uint32_t *xl = (uint32_t *)malloc(nx * 4), *xo = (uint32_t *)malloc(nx * 4);
@@ -210,8 +215,10 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
         if (r != HG_OK && r != HG_EBLOCK) rc = r;
         for (k = 0; k < nx; k++) status[map[k]] = (r == HG_OK || r == HG_EBLOCK) ? xs[k] : -1;
         free(xin); free(xout); free(xl); free(xo); free(xs); free(map);
-    }
-    if (nr) {
+        return rc;
+    };
+    auto run_rans4x8 = [&](hg_ctx *ctx) -> int {
+        int rc = HG_OK;
         const uint8_t **rin = (const uint8_t **)malloc(nr * sizeof(void *));
         uint8_t **rout = (uint8_t **)malloc(nr * sizeof(void *));
         uint32_t *rl = (uint32_t *)malloc(nr * 4), *rc_ = (uint32_t *)malloc(nr * 4), *ro = (uint32_t *)malloc(nr * 4);
@@ -224,8 +231,10 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
         if (r != HG_OK && r != HG_EBLOCK) rc = r;
         for (k = 0; k < nr; k++) status[map[k]] = (r == HG_OK || r == HG_EBLOCK) ? ((rs[k] == 0 && ro[k] == out_len[map[k]]) ? 0 : -1) : -1;
         free(rin); free(rout); free(rl); free(rc_); free(ro); free(rs); free(map);
-    }
-    if (ng && rc == HG_OK) {
+        return rc;
+    };
+    auto run_gzip = [&](hg_ctx *ctx) -> int {
+        int rc = HG_OK;
         hg_bgzf_desc *desc = (hg_bgzf_desc *)calloc(ng, sizeof(hg_bgzf_desc));
         size_t *map = (size_t *)malloc(ng * sizeof(size_t));
         int32_t *st = (int32_t *)malloc(ng * 4);
@@ -237,7 +246,7 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
             }
         if ((rc = ensure_scratch(ctx, 0, ioff + 64)) == HG_OK && (rc = ensure_scratch(ctx, 1, ooff + 64)) == HG_OK &&
             (rc = ensure_scratch(ctx, 2, ng * sizeof(hg_bgzf_desc))) == HG_OK && (rc = ensure_scratch(ctx, 3, ng * 4)) == HG_OK) {
-            hipStream_t s = nullptr;
+            hipStream_t s = ctx->stream;
             bool ok = true;
             {
                 std::vector<const uint8_t *> gp(ng); std::vector<uint32_t> gl(ng); std::vector<uint64_t> go(ng);
@@ -259,7 +268,26 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
             }
         }
         free(desc); free(map); free(st);
+        return rc;
+    };
+    struct Task { int kind; size_t cnt; } tasks[5] = {{0, nx_}, {1, na}, {2, nt}, {3, nr}, {4, ng}};
+    int nact = 0;
+    for (auto &t : tasks) nact += t.cnt != 0;
+    int trc[5] = {HG_OK, HG_OK, HG_OK, HG_OK, HG_OK};
+    auto run_one = [&](int kind, hg_ctx *c) { trc[kind] = kind <= 2 ? run_entropy(c, kind) : kind == 3 ? run_rans4x8(c) : run_gzip(c); };
+    if (nact <= 1) { for (auto &t : tasks) if (t.cnt) run_one(t.kind, ctx); }
+    else {
+        std::vector<std::thread> th;
+        for (auto &t : tasks) {
+            if (!t.cnt) continue;
+            if (!ctx->sub[t.kind] && hg_init(ctx->device, &ctx->sub[t.kind]) != HG_OK) { trc[t.kind] = HG_ENOMEM; continue; }
+            hg_ctx *c = ctx->sub[t.kind]; const int kind = t.kind;
+            th.emplace_back([&, kind, c]() { if (hipSetDevice(ctx->device) != hipSuccess) { trc[kind] = HG_ENODEV; return; } run_one(kind, c); });
+        }
+        for (auto &t : th) t.join();
     }
+    int rc = HG_OK;
+    for (int k = 0; k < 5; k++) if (trc[k] != HG_OK && rc == HG_OK) rc = trc[k];
     if (rc != HG_OK) return rc;
     for (size_t i = 0; i < n; i++) if (status[i] != 0) return HG_EBLOCK;
     return HG_OK;
@@ -287,7 +315,7 @@ int hg_bgzf_inflate_host(hg_ctx *ctx, const uint8_t *comp, size_t comp_len, uint
         (rc = ensure_scratch(ctx, 3, (size_t)n * sizeof(int32_t)))) {
         free(desc); free(st); return rc;
     }
-    hipStream_t s = nullptr;
+    hipStream_t s = ctx->stream;
     bool ok = hipMemcpyAsync(ctx->d_scratch[0], comp, comp_len, hipMemcpyHostToDevice, s) == hipSuccess &&
               hipMemcpyAsync(ctx->d_scratch[2], desc, (size_t)n * sizeof(hg_bgzf_desc), hipMemcpyHostToDevice, s) == hipSuccess;
     rc = ok ? hg::launch_bgzf_inflate(ctx, ctx->d_scratch[0], comp_len, (const hg_bgzf_desc *)ctx->d_scratch[2],
@@ -349,7 +377,7 @@ int hg_bgzf_deflate_host(hg_ctx *ctx, const uint8_t *plain, size_t len, const ui
         (rc = ensure_scratch(ctx, 4, (nb + 2) * 8)) || (rc = ensure_scratch(ctx, 5, slots + 64))) {
         free(desc); return rc;
     }
-    hipStream_t s = nullptr;
+    hipStream_t s = ctx->stream;
     uint64_t *d_poff = (uint64_t *)ctx->d_scratch[4];
     uint64_t *d_total = d_poff + nb;
     bool ok = (len == 0 || hipMemcpyAsync(ctx->d_scratch[0], plain, len, hipMemcpyHostToDevice, s) == hipSuccess) &&
@@ -405,7 +433,7 @@ int hg_rans4x8_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t
     if ((rc = ensure_scratch(ctx, 0, ioff + 64)) || (rc = ensure_scratch(ctx, 1, ooff + 64)) ||
         (rc = ensure_scratch(ctx, 2, n * sizeof(hg_stream_desc))) || (rc = ensure_scratch(ctx, 3, n * 4)) ||
         (rc = ensure_scratch(ctx, 6, soff * 4 + 64))) { free(desc); free(st); return rc; }
-    hipStream_t s = nullptr;
+    hipStream_t s = ctx->stream;
     std::vector<uint64_t> ioffs(n), ooffs(n);
     for (size_t i = 0; i < n; i++) { ioffs[i] = desc[i].in_off; ooffs[i] = desc[i].out_off; }
     bool ok = hg::stage_upload(ctx, in, in_len, ioffs.data(), nullptr, n, ioff, (uint8_t *)ctx->d_scratch[0], s) == HG_OK;
@@ -452,7 +480,7 @@ int hg_gzip_deflate_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *
         (rc = ensure_scratch(ctx, 2, nchunks * sizeof(hg_bgzf_desc))) || (rc = ensure_scratch(ctx, 3, nchunks * 8 + 64))) {
         free(desc); free(clen); free(crc); return rc;
     }
-    hipStream_t s = nullptr;
+    hipStream_t s = ctx->stream;
     bool ok = true;
     uint64_t ioff = 0; size_t k = 0;
     std::vector<uint64_t> ioffs(n);
