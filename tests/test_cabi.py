@@ -66,3 +66,20 @@ def test_scan_rejects_bad_framing(built):
         assert e.value.code == -4       # HG_EFORMAT
     d, t = nat.bgzf_scan(b"")
     assert len(d) == 0 and t == 0
+
+
+def test_headers_are_plain_c99_and_link_from_c(built, tmp_path):
+    """The boundary is a C ABI: both public headers compile as strict C99 and a plain-C caller links against the
+    libraries (this is what an htslib maintainer's binding in INTEGRATION.md does)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "caller.c"
+    src.write_text('#include <stdio.h>\n#include "htsgpu.h"\n#include "hts_bgzf_gpu.h"\n'
+                   'int main(void) { hg_ctx *c = 0; int rc = hg_init(0, &c);\n'
+                   '  printf("%s rc=%d bound=%zu\\n", hg_version(), rc, hg_cram_compress_bound(1000));\n'
+                   '  if (c) hg_destroy(c);\n  return 0; }\n')
+    exe = tmp_path / "caller"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                    "-L", os.path.join(root, "htslib_amd"), "-lhtsgpu", "-lhts_bgzf", "-Wl,-rpath," + os.path.join(root, "htslib_amd")], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "htsgpu" in out.stdout, out.stderr
