@@ -191,6 +191,8 @@ uint32_t arith_model_words(uint32_t max_sym, uint32_t flags) { return hga::model
 int launch_arith_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_sel_small, size_t nsmall,
                         const uint32_t *d_sel_big, size_t nbig, void *d_out, int32_t *d_status, uint32_t *d_scratch, hipStream_t s) {
     const size_t maxw = (size_t)ctx->cus * 8;
+    const bool side = nsmall != 0 && nbig != 0;                  // both variants present: overlap them
+    hipStream_t s2 = side ? fork_side(ctx, s) : s;
     if (nsmall) {
         size_t wgs = (nsmall + 3) / 4;
         if (wgs > maxw) wgs = maxw;
@@ -200,8 +202,9 @@ int launch_arith_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
     if (nbig) {
         size_t wgs = nbig;
         if (wgs > maxw) wgs = maxw;
-        hipLaunchKernelGGL((hga::arith_decode_kernel<HG_ARITH_POOL_BIG, 1>), dim3((unsigned)wgs), dim3(64), 0, s, (const uint8_t *)d_in,
+        hipLaunchKernelGGL((hga::arith_decode_kernel<HG_ARITH_POOL_BIG, 1>), dim3((unsigned)wgs), dim3(64), 0, s2, (const uint8_t *)d_in,
                            d_desc, d_sel_big, (uint32_t)nbig, (uint8_t *)d_out, d_status, d_scratch);
+        if (side) join_side(ctx, s);
     }
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
@@ -332,6 +335,8 @@ int launch_arith_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
                         size_t nsmall, const uint32_t *d_sel_big, size_t nbig, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch,
                         hipStream_t s) {
     const size_t maxw = (size_t)ctx->cus * 8;
+    const bool side = nsmall != 0 && nbig != 0;                  // both variants present: overlap them
+    hipStream_t s2 = side ? fork_side(ctx, s) : s;
     if (nsmall) {
         size_t wgs = (nsmall + 3) / 4;
         if (wgs > maxw) wgs = maxw;
@@ -341,8 +346,9 @@ int launch_arith_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
     if (nbig) {
         size_t wgs = nbig;
         if (wgs > maxw) wgs = maxw;
-        hipLaunchKernelGGL((hga::arith_encode_kernel<HG_ARITH_POOL_BIG, 1>), dim3((unsigned)wgs), dim3(64), 0, s, (const uint8_t *)d_in,
+        hipLaunchKernelGGL((hga::arith_encode_kernel<HG_ARITH_POOL_BIG, 1>), dim3((unsigned)wgs), dim3(64), 0, s2, (const uint8_t *)d_in,
                            d_desc, d_flags, d_sel_big, (uint32_t)nbig, (uint8_t *)d_out, d_out_len, d_scratch);
+        if (side) join_side(ctx, s);
     }
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }

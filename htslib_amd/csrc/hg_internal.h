@@ -19,6 +19,8 @@ struct hg_ctx {
     void *h_stage[2];         // pinned staging buffers of the host entry points (0: upload, 1: download)
     size_t h_stage_cap[2];
     hipStream_t stream;       // the host entry points run on this non-blocking stream (one per context)
+    hipStream_t stream2;      // side stream: the second of two independent kernel variants of one call (fork_side / join_side)
+    hipEvent_t ev_fork, ev_join;
     hg_ctx *sub[8];           // lazily created sibling contexts: independent codec families of one CRAM batch run concurrently
 };
 
@@ -92,6 +94,18 @@ struct tok3_enc_res { uint32_t nn, nstreams, total, pad; };                     
 int launch_tok3_tokenise(hg_ctx *ctx, const void *d_in, const tok3_enc_job *d_jobs, size_t njobs, void *d_sb, tok3_enc_stream *d_list,
                          tok3_enc_res *d_res, hipStream_t s);
 int ensure_scratch(hg_ctx *ctx, int slot, size_t bytes);
+// Two kernel variants of one call (4-way / 32-way rANS, small / big range-coder pool) work on disjoint streams of the
+// batch and are each latency-bound: the second one goes to the context's side stream, ordered after everything already
+// queued on s, and s then waits for it.
+inline hipStream_t fork_side(hg_ctx *ctx, hipStream_t s) {
+    (void)hipEventRecord(ctx->ev_fork, s);
+    (void)hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
+    return ctx->stream2;
+}
+inline void join_side(hg_ctx *ctx, hipStream_t s) {
+    (void)hipEventRecord(ctx->ev_join, ctx->stream2);
+    (void)hipStreamWaitEvent(s, ctx->ev_join, 0);
+}
 // hg_stage.hip: many scattered host buffers <-> one device buffer, one PCIe transfer each way
 int stage_upload(hg_ctx *ctx, const uint8_t *const *src, const uint32_t *len, const uint64_t *dst_off, const int32_t *skip, size_t n,
                  uint64_t total, uint8_t *d_base, hipStream_t s);

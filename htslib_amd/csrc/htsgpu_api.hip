@@ -61,7 +61,10 @@ int hg_init(int device, hg_ctx **out) {
     // inflate: 30 KiB LDS per 4-wave workgroup -> 5 workgroups (20 waves) per CU
     ctx->waves_per_launch = ctx->cus * 24;
     if (hipMalloc((void **)&ctx->d_ticket, 64) != hipSuccess) { free(ctx); return HG_ENOMEM; }
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipFree(ctx->d_ticket); free(ctx); return HG_ENODEV; }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipFree(ctx->d_ticket); free(ctx); return HG_ENODEV; }
     *out = ctx;
     return HG_OK;
 }
@@ -74,6 +77,9 @@ void hg_destroy(hg_ctx *ctx) {
     hg::stage_free(ctx);
     for (hg_ctx *c : ctx->sub) if (c) hg_destroy(c);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
     free(ctx);
 }

@@ -405,6 +405,8 @@ int launch_ransnx16_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *
                            size_t n4, const uint32_t *d_sel32, size_t n32, void *d_out, int32_t *d_status,
                            uint32_t *d_scratch, hipStream_t s) {
     const size_t maxw = (size_t)ctx->cus * 8;
+    const bool side = n4 != 0 && n32 != 0;                  // both variants present: overlap them
+    hipStream_t s2 = side ? fork_side(ctx, s) : s;
     if (n4) {
         size_t wgs = (n4 + hgn::WAVES * 16 - 1) / (hgn::WAVES * 16);
         if (wgs > maxw) wgs = maxw;
@@ -414,8 +416,9 @@ int launch_ransnx16_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *
     if (n32) {
         size_t wgs = (n32 + hgn::WAVES * 2 - 1) / (hgn::WAVES * 2);
         if (wgs > maxw) wgs = maxw;
-        hipLaunchKernelGGL(hgn::ransnx16_decode_kernel<32>, dim3((unsigned)wgs), dim3(hgn::WAVES * 64), 0, s,
+        hipLaunchKernelGGL(hgn::ransnx16_decode_kernel<32>, dim3((unsigned)wgs), dim3(hgn::WAVES * 64), 0, s2,
                            (const uint8_t *)d_in, d_desc, d_sel32, (uint32_t)n32, (uint8_t *)d_out, d_status, d_scratch);
+        if (side) join_side(ctx, s);
     }
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }

@@ -343,6 +343,8 @@ int launch_ransnx16_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *
                            const uint32_t *d_sel4, size_t n4, const uint32_t *d_sel32, size_t n32, void *d_out,
                            uint32_t *d_out_len, void *d_wbuf, uint32_t *d_scratch, hipStream_t s) {
     const size_t maxw = (size_t)ctx->cus * 8;
+    const bool side = n4 != 0 && n32 != 0;                  // both variants present: overlap them
+    hipStream_t s2 = side ? fork_side(ctx, s) : s;
     if (n4) {
         size_t wgs = (n4 + hge::WAVES * 16 - 1) / (hge::WAVES * 16);
         if (wgs > maxw) wgs = maxw;
@@ -353,9 +355,10 @@ int launch_ransnx16_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *
     if (n32) {
         size_t wgs = (n32 + hge::WAVES * 2 - 1) / (hge::WAVES * 2);
         if (wgs > maxw) wgs = maxw;
-        hipLaunchKernelGGL(hge::ransnx16_encode_kernel<32>, dim3((unsigned)wgs), dim3(hge::WAVES * 64), 0, s,
+        hipLaunchKernelGGL(hge::ransnx16_encode_kernel<32>, dim3((unsigned)wgs), dim3(hge::WAVES * 64), 0, s2,
                            (const uint8_t *)d_in, d_desc, d_flags, d_sel32, (uint32_t)n32, (uint8_t *)d_out, d_out_len,
                            (uint8_t *)d_wbuf, d_scratch);
+        if (side) join_side(ctx, s);
     }
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
