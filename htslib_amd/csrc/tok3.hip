@@ -200,8 +200,9 @@ int launch_tok3_names(hg_ctx *ctx, const void *d_tb, const tok3_job *d_jobs, siz
 // ================================================================================================
 // Encoder side: tokenise every name against its predecessor and append to the (position, type) byte
 // streams -- the choices of oracle/tok3_oracle.c orc_tok3_encode(), so that the assembled block is
-// byte-identical to the oracle's.  One wavefront per block, two sweeps over the names: the first only counts
-// stream sizes, a prefix sum lays the streams out back to back, the second writes.  Lanes = the characters
+// byte-identical to the oracle's.  Sixteen wavefronts per block, each taking a contiguous share of the names (a name
+// only needs its predecessor, which the wave re-tokenises for itself); two sweeps: the first only counts stream
+// sizes per wave, a layout kernel turns them into per-wave write offsets, the second writes.  Lanes = the characters
 // of the current name (64 per step): token boundaries come from one ballot of the "class changes here"
 // flags; the lane sitting on a token's first character owns that token (length, value, comparison with the
 // previous name's token, append to the streams of its position -- no two tokens of a name share a position).
@@ -219,138 +220,216 @@ __device__ __forceinline__ int char_class(uint32_t c) {          // 0 digit, 1 l
 }
 __device__ __forceinline__ void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
 
-__global__ __launch_bounds__(64)
-void tok3_tokenise_kernel(const uint8_t *__restrict__ in, const hg::tok3_enc_job *__restrict__ jobs, uint32_t njobs,
-                          uint8_t *sb, hg::tok3_enc_stream *list, hg::tok3_enc_res *res) {
-    __shared__ EncLds S;
-    const int lane = threadIdx.x;
+// Tokenises the names that START in [begin, end) of one block and appends them to the streams (sizes only unless wr).
+// The name before `begin` (if any) is tokenised first, without emitting, so that the first name of the range sees its
+// predecessor exactly as a single sweep over the whole block would.  Returns the number of names; maxpos by reference.
+__device__ uint32_t tok_sweep(const uint8_t *__restrict__ src, uint32_t n, uint32_t begin, uint32_t end, bool wr, uint8_t *B, EncLds &S,
+                              int lane, uint32_t &maxpos_out) {
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
-        const hg::tok3_enc_job J = jobs[j];
-        const uint8_t *src = in + J.in_off;
-        uint8_t *B = sb + J.sb_off;
-        const uint32_t n = J.n;
-        uint32_t nn = 0, maxpos = 0, total = 0;
-        for (uint32_t i = (uint32_t)lane; i < NTYPES * MAX_TOK; i += 64) { (&S.base[0][0])[i] = 0; (&S.cur[0][0])[i] = 0; }
-        wave_sync();
-        for (int sweep = 0; sweep < 2; sweep++) {
-            const bool wr = sweep == 1;
-            uint32_t pos = 0, ppos = 0, plen = 0, pn = 0, rb = 0;
-            nn = 0; maxpos = 0;
-            // append helpers: sizes only in the first sweep
-            auto put8 = [&](uint32_t ty, uint32_t tp, uint32_t v) {
-                const uint32_t c = S.cur[ty][tp];
-                if (wr) B[S.base[ty][tp] + c] = (uint8_t)v;
-                S.cur[ty][tp] = c + 1u;
-            };
-            auto put32s = [&](uint32_t ty, uint32_t tp, uint32_t v) {
-                const uint32_t c = S.cur[ty][tp];
-                if (wr) put32(B + S.base[ty][tp] + c, v);
-                S.cur[ty][tp] = c + 4u;
-            };
-            while (pos < n) {
-                uint32_t len = 0;                                   // distance to the terminating NUL
-                for (;;) {
-                    const uint32_t p = pos + len + (uint32_t)lane;
-                    const unsigned long long z = __ballot(p >= n || src[p] == 0);
-                    if (z) { len += (uint32_t)__builtin_ctzll(z); break; }
-                    len += 64;
-                }
-                bool dup = false;
-                if (nn && len == plen) {
-                    dup = true;
-                    for (uint32_t k = 0; k < len && dup; k += 64) {
-                        const uint32_t q = k + (uint32_t)lane;
-                        if (__any(q < len && src[pos + q] != src[ppos + q])) dup = false;
+    uint32_t pos = begin, ppos = 0, plen = 0, pn = 0, rb = 0, nn = 0, maxpos = 0;
+    bool have_prev = false;
+    auto put8 = [&](uint32_t ty, uint32_t tp, uint32_t v) {
+        const uint32_t c = S.cur[ty][tp];
+        if (wr) B[S.base[ty][tp] + c] = (uint8_t)v;
+        S.cur[ty][tp] = c + 1u;
+    };
+    auto put32s = [&](uint32_t ty, uint32_t tp, uint32_t v) {
+        const uint32_t c = S.cur[ty][tp];
+        if (wr) put32(B + S.base[ty][tp] + c, v);
+        S.cur[ty][tp] = c + 4u;
+    };
+    // tokenises name [p0, p0+len): emit == false only records the tokens (for the predecessor of the range)
+    auto do_name = [&](uint32_t p0, uint32_t len, bool emit) {
+        uint32_t nb = 0, pc = 3, prun = 0;                          // boundaries so far, class / run position of the previous char
+        for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+            const uint32_t i = c0 + (uint32_t)lane;
+            const bool has = i < len;
+            const uint32_t ch = has ? src[p0 + i] : 0u;
+            const int cls = has ? char_class(ch) : 3;
+            const uint32_t pcl = (uint32_t)__shfl_up(cls, 1, 64);
+            const bool chg = has && (cls == 2 || (uint32_t)cls != (lane == 0 ? pc : pcl));
+            const unsigned long long CH = __ballot(chg);
+            const unsigned long long upto = CH & (below | (1ull << lane));
+            const uint32_t runpos = upto ? (uint32_t)lane - (63u - (uint32_t)__clzll(upto)) : prun + 1u + (uint32_t)lane;
+            const bool bnd0 = has && (chg || (cls == 0 && runpos % 9u == 0u));
+            const unsigned long long BD0 = __ballot(bnd0);
+            const uint32_t idx0 = nb + (uint32_t)__popcll(BD0 & (below | (1ull << lane))) - 1u;   // token index of my char
+            const bool bnd = bnd0 && idx0 <= (uint32_t)(MAX_TOK - 3);       // later boundaries fold into the last token
+            if (bnd) {
+                const uint32_t t = idx0, tp = t + 1u;
+                uint32_t tl = 1, val = 0; uint32_t tc;
+                if (t == (uint32_t)(MAX_TOK - 3)) { tc = T_STRING; tl = len - i; }
+                else if (cls == 0) {
+                    uint32_t e = i;
+                    while (e < len && e - i < 9u && (src[p0 + e] - '0') < 10u) { val = val * 10u + (src[p0 + e] - '0'); e++; }
+                    tl = e - i;
+                    tc = (ch == '0' && tl > 1u) ? T_DIGITS0 : T_DIGITS;
+                } else if (cls == 1) {
+                    uint32_t e = i;
+                    while (e < len && char_class(src[p0 + e]) == 1) e++;
+                    tl = e - i; tc = tl == 1u ? T_CHAR : T_STRING;
+                } else tc = T_CHAR;
+                const uint32_t off = p0 + i;
+                S.toff[rb][t] = off; S.tlen[rb][t] = tl; S.tval[rb][t] = val; S.tcls[rb][t] = (uint8_t)tc;
+                if (emit) {
+                    const bool haveP = have_prev && t < pn;
+                    const uint32_t po = S.toff[rb ^ 1][t], pl = S.tlen[rb ^ 1][t], pv = S.tval[rb ^ 1][t], pcs = S.tcls[rb ^ 1][t];
+                    bool same = haveP && pcs == tc && pl == tl;
+                    for (uint32_t k = 0; same && k < tl; k++) same = src[po + k] == src[off + k];
+                    if (same) put8(T_TYPE, tp, T_MATCH);
+                    else if (haveP && tc == T_DIGITS && pcs == T_DIGITS && val >= pv && val - pv < 256u) { put8(T_TYPE, tp, T_DELTA); put8(T_DELTA, tp, val - pv); }
+                    else if (haveP && tc == T_DIGITS0 && pcs == T_DIGITS0 && tl == pl && val >= pv && val - pv < 256u) { put8(T_TYPE, tp, T_DELTA0); put8(T_DELTA0, tp, val - pv); }
+                    else {
+                        put8(T_TYPE, tp, tc);
+                        if (tc == T_STRING) {
+                            const uint32_t c = S.cur[T_STRING][tp];
+                            if (wr) { uint8_t *w = B + S.base[T_STRING][tp] + c; for (uint32_t k = 0; k < tl; k++) w[k] = src[off + k]; w[tl] = 0; }
+                            S.cur[T_STRING][tp] = c + tl + 1u;
+                        } else if (tc == T_CHAR) put8(T_CHAR, tp, ch);
+                        else { put32s(tc, tp, val); if (tc == T_DIGITS0) put8(T_DZLEN, tp, tl); }
                     }
                 }
-                if (dup) {
-                    if (lane == 0) { put8(T_TYPE, 0, T_DUP); put32s(T_DUP, 0, 1); }
-                    if (maxpos < 1) maxpos = 1;
-                } else {
-                    if (lane == 0) { put8(T_TYPE, 0, T_DIFF); put32s(T_DIFF, 0, nn ? 1u : 0u); }
-                    uint32_t nb = 0, pc = 3, prun = 0;              // boundaries so far, class / run position of the previous char
-                    for (uint32_t c0 = 0; c0 < len; c0 += 64) {
-                        const uint32_t i = c0 + (uint32_t)lane;
-                        const bool has = i < len;
-                        const uint32_t ch = has ? src[pos + i] : 0u;
-                        const int cls = has ? char_class(ch) : 3;
-                        const uint32_t pcl = (uint32_t)__shfl_up(cls, 1, 64);
-                        const bool chg = has && (cls == 2 || (uint32_t)cls != (lane == 0 ? pc : pcl));
-                        const unsigned long long CH = __ballot(chg);
-                        const unsigned long long upto = CH & (below | (1ull << lane));
-                        const uint32_t runpos = upto ? (uint32_t)lane - (63u - (uint32_t)__clzll(upto)) : prun + 1u + (uint32_t)lane;
-                        const bool bnd0 = has && (chg || (cls == 0 && runpos % 9u == 0u));
-                        const unsigned long long BD0 = __ballot(bnd0);
-                        const uint32_t idx0 = nb + (uint32_t)__popcll(BD0 & (below | (1ull << lane))) - 1u;   // token index of my char
-                        const bool bnd = bnd0 && idx0 <= (uint32_t)(MAX_TOK - 3);       // later boundaries fold into the last token
-                        if (bnd) {
-                            const uint32_t t = idx0, tp = t + 1u;
-                            // ---- my token: length, class, value -------------------------------------------
-                            uint32_t tl = 1, val = 0; uint32_t tc;
-                            if (t == (uint32_t)(MAX_TOK - 3)) { tc = T_STRING; tl = len - i; }
-                            else if (cls == 0) {
-                                uint32_t e = i;
-                                while (e < len && e - i < 9u && (src[pos + e] - '0') < 10u) { val = val * 10u + (src[pos + e] - '0'); e++; }
-                                tl = e - i;
-                                tc = (ch == '0' && tl > 1u) ? T_DIGITS0 : T_DIGITS;
-                            } else if (cls == 1) {
-                                uint32_t e = i;
-                                while (e < len && char_class(src[pos + e]) == 1) e++;
-                                tl = e - i; tc = tl == 1u ? T_CHAR : T_STRING;
-                            } else tc = T_CHAR;
-                            const uint32_t off = pos + i;
-                            S.toff[rb][t] = off; S.tlen[rb][t] = tl; S.tval[rb][t] = val; S.tcls[rb][t] = (uint8_t)tc;
-                            // ---- against the previous name's token ----------------------------------------
-                            const bool haveP = nn && t < pn;
-                            const uint32_t po = S.toff[rb ^ 1][t], pl = S.tlen[rb ^ 1][t], pv = S.tval[rb ^ 1][t], pcs = S.tcls[rb ^ 1][t];
-                            bool same = haveP && pcs == tc && pl == tl;
-                            for (uint32_t k = 0; same && k < tl; k++) same = src[po + k] == src[off + k];
-                            if (same) put8(T_TYPE, tp, T_MATCH);
-                            else if (haveP && tc == T_DIGITS && pcs == T_DIGITS && val >= pv && val - pv < 256u) { put8(T_TYPE, tp, T_DELTA); put8(T_DELTA, tp, val - pv); }
-                            else if (haveP && tc == T_DIGITS0 && pcs == T_DIGITS0 && tl == pl && val >= pv && val - pv < 256u) { put8(T_TYPE, tp, T_DELTA0); put8(T_DELTA0, tp, val - pv); }
-                            else {
-                                put8(T_TYPE, tp, tc);
-                                if (tc == T_STRING) {
-                                    const uint32_t c = S.cur[T_STRING][tp];
-                                    if (wr) { uint8_t *w = B + S.base[T_STRING][tp] + c; for (uint32_t k = 0; k < tl; k++) w[k] = src[off + k]; w[tl] = 0; }
-                                    S.cur[T_STRING][tp] = c + tl + 1u;
-                                } else if (tc == T_CHAR) put8(T_CHAR, tp, ch);
-                                else { put32s(tc, tp, val); if (tc == T_DIGITS0) put8(T_DZLEN, tp, tl); }
-                            }
-                        }
-                        const uint32_t nbd = (uint32_t)__popcll(BD0);
-                        nb = nb + nbd > (uint32_t)(MAX_TOK - 2) ? (uint32_t)(MAX_TOK - 2) : nb + nbd;
-                        pc = (uint32_t)__shfl(cls, 63, 64); prun = (uint32_t)__shfl((int)runpos, 63, 64);
-                        wave_sync();
-                    }
-                    const uint32_t nt = nb;
-                    if (lane == 0) put8(T_TYPE, nt + 1u, T_END);
-                    if (maxpos < nt + 2u) maxpos = nt + 2u;
-                    rb ^= 1u; pn = nt;
-                }
-                wave_sync();
-                ppos = pos; plen = len; nn++;
-                pos += len + 1u;
             }
-            if (!wr) {                                              // lay the streams out: exclusive prefix sum of the sizes
-                uint32_t carry = 0;
-                for (uint32_t b0 = 0; b0 < NTYPES * MAX_TOK; b0 += 64) {
-                    const uint32_t i = b0 + (uint32_t)lane;
-                    const uint32_t sz = (&S.cur[0][0])[i];
-                    const uint32_t incl = wave_incl_scan_dpp(sz);
-                    (&S.base[0][0])[i] = carry + incl - sz;
-                    (&S.cur[0][0])[i] = 0;
-                    carry += rl(incl, 63);
-                }
-                total = carry;
-                wave_sync();
-                if (total > J.sb_cap) { total = 0xffffffffu; break; }
+            const uint32_t nbd = (uint32_t)__popcll(BD0);
+            nb = nb + nbd > (uint32_t)(MAX_TOK - 2) ? (uint32_t)(MAX_TOK - 2) : nb + nbd;
+            pc = (uint32_t)__shfl(cls, 63, 64); prun = (uint32_t)__shfl((int)runpos, 63, 64);
+            wave_sync();
+        }
+        const uint32_t nt = nb;
+        if (emit) {
+            if (lane == 0) put8(T_TYPE, nt + 1u, T_END);
+            if (maxpos < nt + 2u) maxpos = nt + 2u;
+        }
+        rb ^= 1u; pn = nt;
+        wave_sync();
+    };
+    if (begin > 0 && begin < end) {                                   // predecessor: the name that ends at begin - 1
+        uint32_t q = begin - 1u;                                      // its NUL
+        for (;;) {                                                    // walk back to the byte after the previous NUL (or 0)
+            if (q == 0) break;
+            const uint32_t back = q < 64u ? q : 64u;
+            const uint32_t p = q - 1u - (uint32_t)lane;               // lanes look at q-1, q-2, ...
+            const unsigned long long z = __ballot((uint32_t)lane < back && src[p] == 0);
+            if (z) { q -= (uint32_t)__builtin_ctzll(z); break; }
+            q -= back;
+        }
+        ppos = q; plen = begin - 1u - q; have_prev = true;
+        do_name(ppos, plen, false);
+    }
+    while (pos < end) {
+        uint32_t len = 0;                                             // distance to the terminating NUL
+        for (;;) {
+            const uint32_t p = pos + len + (uint32_t)lane;
+            const unsigned long long z = __ballot(p >= n || src[p] == 0);
+            if (z) { len += (uint32_t)__builtin_ctzll(z); break; }
+            len += 64;
+        }
+        bool dup = false;
+        if (have_prev && len == plen) {
+            dup = true;
+            for (uint32_t k = 0; k < len && dup; k += 64) {
+                const uint32_t q = k + (uint32_t)lane;
+                if (__any(q < len && src[pos + q] != src[ppos + q])) dup = false;
             }
         }
-        // ---- emission list: order, implied TYPE streams, duplicates -------------------------------
+        if (dup) {
+            if (lane == 0) { put8(T_TYPE, 0, T_DUP); put32s(T_DUP, 0, 1); }
+            if (maxpos < 1) maxpos = 1;
+            wave_sync();
+        } else {
+            if (lane == 0) { put8(T_TYPE, 0, T_DIFF); put32s(T_DIFF, 0, have_prev ? 1u : 0u); }
+            do_name(pos, len, true);
+        }
+        ppos = pos; plen = len; have_prev = true; nn++;
+        pos += len + 1u;
+    }
+    maxpos_out = maxpos;
+    return nn;
+}
+
+constexpr uint32_t TOKW = 16;                                          // wavefronts that share one block
+constexpr uint32_t NSTR = NTYPES * MAX_TOK;
+
+// first name start at or after byte offset lo (a name starts at 0 or right after a NUL)
+__device__ uint32_t name_start_at(const uint8_t *__restrict__ src, uint32_t n, uint32_t lo, int lane) {
+    if (lo == 0) return 0;
+    uint32_t p = lo;
+    for (;;) {
+        if (p >= n) return n;
+        const uint32_t q = p + (uint32_t)lane;
+        const unsigned long long z = __ballot(q <= n && src[q - 1u] == 0);
+        if (z) return p + (uint32_t)__builtin_ctzll(z);
+        p += 64;
+    }
+}
+
+// pass 0 (wr = 0): sizes of every (position, type) stream for this wave's share of the names; pass 1 (wr = 1): write them
+__global__ __launch_bounds__(64)
+void tok3_sweep_kernel(const uint8_t *__restrict__ in, const hg::tok3_enc_job *__restrict__ jobs, uint32_t njobs, uint8_t *sb,
+                       uint32_t *counts, uint32_t *meta, const hg::tok3_enc_res *res, int wr) {
+    __shared__ EncLds S;
+    const int lane = threadIdx.x;
+    for (uint32_t u = blockIdx.x; u < njobs * TOKW; u += gridDim.x) {
+        const uint32_t j = u / TOKW, w = u % TOKW;
+        if (wr && res[j].total == 0xffffffffu) continue;               // the streams would not fit their buffer (cannot happen: <= 6 bytes per input byte)
+        const hg::tok3_enc_job J = jobs[j];
+        const uint8_t *src = in + J.in_off;
+        const uint32_t n = J.n;
+        const uint32_t begin = name_start_at(src, n, (uint32_t)((uint64_t)n * w / TOKW), lane);
+        const uint32_t end = w + 1 == TOKW ? n : name_start_at(src, n, (uint32_t)((uint64_t)n * (w + 1) / TOKW), lane);
+        uint32_t *C = counts + ((size_t)j * TOKW + w) * NSTR;
+        for (uint32_t i = (uint32_t)lane; i < NSTR; i += 64) { (&S.base[0][0])[i] = wr ? C[i] : 0u; (&S.cur[0][0])[i] = 0; }
+        wave_sync();
+        uint32_t maxpos = 0;
+        const uint32_t nn = tok_sweep(src, n, begin, end, wr != 0, sb + J.sb_off, S, lane, maxpos);
+        if (!wr) {
+            for (uint32_t i = (uint32_t)lane; i < NSTR; i += 64) C[i] = (&S.cur[0][0])[i];
+            if (lane == 0) { meta[((size_t)j * TOKW + w) * 2] = nn; meta[((size_t)j * TOKW + w) * 2 + 1] = maxpos; }
+        }
+        wave_sync();
+    }
+}
+
+// between the passes: turn the per-wave sizes into per-wave write offsets (in place) and the per-stream totals
+__global__ __launch_bounds__(64)
+void tok3_layout_kernel(const hg::tok3_enc_job *__restrict__ jobs, uint32_t njobs, uint32_t *counts, const uint32_t *__restrict__ meta,
+                        uint32_t *fin, hg::tok3_enc_res *res) {
+    const int lane = threadIdx.x;
+    for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
+        uint32_t carry = 0;
+        for (uint32_t b0 = 0; b0 < NSTR; b0 += 64) {
+            const uint32_t i = b0 + (uint32_t)lane;
+            uint32_t tot = 0;
+            for (uint32_t w = 0; w < TOKW; w++) tot += counts[((size_t)j * TOKW + w) * NSTR + i];
+            const uint32_t incl = wave_incl_scan_dpp(tot);
+            uint32_t off = carry + incl - tot;
+            fin[(size_t)j * NSTR * 2 + i] = off; fin[(size_t)j * NSTR * 2 + NSTR + i] = tot;
+            for (uint32_t w = 0; w < TOKW; w++) { uint32_t *c = &counts[((size_t)j * TOKW + w) * NSTR + i]; const uint32_t v = *c; *c = off; off += v; }
+            carry += rl(incl, 63);
+        }
+        uint32_t nn = 0, maxpos = 0;
+        for (uint32_t w = 0; w < TOKW; w++) { nn += meta[((size_t)j * TOKW + w) * 2]; const uint32_t m = meta[((size_t)j * TOKW + w) * 2 + 1]; maxpos = m > maxpos ? m : maxpos; }
+        hg::tok3_enc_res R;
+        R.nn = nn; R.nstreams = 0; R.total = carry > jobs[j].sb_cap ? 0xffffffffu : carry; R.pad = maxpos;
+        res[j] = R;
+        wave_sync();
+    }
+}
+
+// after the write pass: emission order, implied TYPE streams, duplicate streams
+__global__ __launch_bounds__(64)
+void tok3_emit_kernel(const hg::tok3_enc_job *__restrict__ jobs, uint32_t njobs, const uint8_t *__restrict__ sb, const uint32_t *__restrict__ fin,
+                      hg::tok3_enc_stream *list, hg::tok3_enc_res *res) {
+    __shared__ EncLds S;
+    const int lane = threadIdx.x;
+    for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
+        const uint8_t *B = sb + jobs[j].sb_off;
+        for (uint32_t i = (uint32_t)lane; i < NSTR; i += 64) { (&S.base[0][0])[i] = fin[(size_t)j * NSTR * 2 + i]; (&S.cur[0][0])[i] = fin[(size_t)j * NSTR * 2 + NSTR + i]; }
+        wave_sync();
+        hg::tok3_enc_res R = res[j];
+        const uint32_t nn = R.nn, maxpos = R.pad, total = R.total;
         uint32_t nem = 0;
-        hg::tok3_enc_stream *L = list + (size_t)j * (NTYPES * MAX_TOK);
+        hg::tok3_enc_stream *L = list + (size_t)j * NSTR;
         if (total != 0xffffffffu) {
             for (uint32_t t = 0; t < maxpos; t++) {
                 int implied = -1;
@@ -390,8 +469,7 @@ void tok3_tokenise_kernel(const uint8_t *__restrict__ in, const hg::tok3_enc_job
                 }
             }
         }
-        hg::tok3_enc_res R;
-        R.nn = nn; R.nstreams = nem; R.total = total; R.pad = 0;
+        R.nstreams = nem; R.pad = 0;
         res[j] = R;
         wave_sync();
     }
@@ -403,11 +481,19 @@ namespace hg {
 int launch_tok3_tokenise(hg_ctx *ctx, const void *d_in, const tok3_enc_job *d_jobs, size_t njobs, void *d_sb, tok3_enc_stream *d_list,
                          tok3_enc_res *d_res, hipStream_t s) {
     if (!njobs) return HG_OK;
-    size_t wgs = njobs;
+    // per job: TOKW x 1664 stream sizes / offsets, (names, positions) per wave, 2 x 1664 final (offset, size) rows
+    const size_t words = njobs * ((size_t)hgt::TOKW * hgt::NSTR + hgt::TOKW * 2 + 2 * (size_t)hgt::NSTR);
+    if (int rc = ensure_scratch(ctx, 12, words * 4 + 64)) return rc;
+    uint32_t *d_counts = (uint32_t *)ctx->d_scratch[12], *d_meta = d_counts + njobs * (size_t)hgt::TOKW * hgt::NSTR;
+    uint32_t *d_fin = d_meta + njobs * (size_t)hgt::TOKW * 2;
     const size_t maxw = (size_t)ctx->cus * 8;
-    if (wgs > maxw) wgs = maxw;
-    hipLaunchKernelGGL(hgt::tok3_tokenise_kernel, dim3((unsigned)wgs), dim3(64), 0, s, (const uint8_t *)d_in, d_jobs, (uint32_t)njobs,
-                       (uint8_t *)d_sb, d_list, d_res);
+    size_t wg1 = njobs * hgt::TOKW, wg0 = njobs;
+    if (wg1 > maxw) wg1 = maxw;
+    if (wg0 > maxw) wg0 = maxw;
+    hipLaunchKernelGGL(hgt::tok3_sweep_kernel, dim3((unsigned)wg1), dim3(64), 0, s, (const uint8_t *)d_in, d_jobs, (uint32_t)njobs, (uint8_t *)d_sb, d_counts, d_meta, (const tok3_enc_res *)d_res, 0);
+    hipLaunchKernelGGL(hgt::tok3_layout_kernel, dim3((unsigned)wg0), dim3(64), 0, s, d_jobs, (uint32_t)njobs, d_counts, (const uint32_t *)d_meta, d_fin, d_res);
+    hipLaunchKernelGGL(hgt::tok3_sweep_kernel, dim3((unsigned)wg1), dim3(64), 0, s, (const uint8_t *)d_in, d_jobs, (uint32_t)njobs, (uint8_t *)d_sb, d_counts, d_meta, (const tok3_enc_res *)d_res, 1);
+    hipLaunchKernelGGL(hgt::tok3_emit_kernel, dim3((unsigned)wg0), dim3(64), 0, s, d_jobs, (uint32_t)njobs, (const uint8_t *)d_sb, (const uint32_t *)d_fin, d_list, d_res);
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
 }  // namespace hg
