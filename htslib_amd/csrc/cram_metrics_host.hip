@@ -121,8 +121,7 @@ int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics 
     std::vector<Blk> B(n);
     for (size_t i = 0; i < n; i++) {
         B[i] = {false, false, method_set[i], 0, 0};
-        out_len[i] = in_len[i]; method_used[i] = HG_CRAM_RAW;
-        if (in_len[i]) memcpy(out[i], in[i], in_len[i]);
+        out_len[i] = in_len[i]; method_used[i] = HG_CRAM_RAW;               // RAW until something smaller turns up (copied at the end)
         if (method_set[i] == HG_M_RAW || level == 0 || in_len[i] == 0) B[i].done = true;   // cram_io.c:1967-1972
     }
     // Blocks that share a metrics object are handled in their order, exactly as the reference's one-at-a-time loop
@@ -232,6 +231,7 @@ int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics 
         }
         for (auto p : res) free(p);
     }
+    for (size_t i = 0; i < n; i++) if (method_used[i] == HG_CRAM_RAW && in_len[i]) memcpy(out[i], in[i], in_len[i]);
     return HG_OK;
 }
 
