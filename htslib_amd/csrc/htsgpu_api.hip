@@ -208,11 +208,10 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
         int rc = HG_OK;
         const int32_t meth = pass == 2 ? HG_CRAM_TOK3 : pass ? HG_CRAM_ARITH : HG_CRAM_RANSNx16;
         const size_t nx = pass == 2 ? nt : pass ? na : nx_;
-        const uint8_t **xin = (const uint8_t **)malloc(nx * sizeof(void *));
-        uint8_t **xout = (uint8_t **)malloc(nx * sizeof(void *));
-        uint32_t *xl = (uint32_t *)malloc(nx * 4), *xo = (uint32_t *)malloc(nx * 4);
-        int32_t *xs = (int32_t *)malloc(nx * 4);
-        size_t *map = (size_t *)malloc(nx * sizeof(size_t));
+        std::vector<const uint8_t *> xin_(nx); std::vector<uint8_t *> xout_(nx); std::vector<uint32_t> xl_(nx), xo_(nx);
+        std::vector<int32_t> xs_(nx); std::vector<size_t> map_(nx);
+        const uint8_t **xin = xin_.data(); uint8_t **xout = xout_.data(); uint32_t *xl = xl_.data(), *xo = xo_.data();
+        int32_t *xs = xs_.data(); size_t *map = map_.data();
         size_t k = 0;
         for (size_t i = 0; i < n; i++)
             if (out_len[i] && method[i] == meth) { xin[k] = in[i]; xout[k] = out[i]; xl[k] = in_len[i]; xo[k] = out_len[i]; map[k] = i; k++; }
@@ -220,30 +219,27 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
               : pass ? hg_arith_decode_host(ctx, xin, xl, nx, xout, xo, xs) : hg_ransnx16_decode_host(ctx, xin, xl, nx, xout, xo, xs);
         if (r != HG_OK && r != HG_EBLOCK) rc = r;
         for (k = 0; k < nx; k++) status[map[k]] = (r == HG_OK || r == HG_EBLOCK) ? xs[k] : -1;
-        free(xin); free(xout); free(xl); free(xo); free(xs); free(map);
         return rc;
     };
     auto run_rans4x8 = [&](hg_ctx *ctx) -> int {
         int rc = HG_OK;
-        const uint8_t **rin = (const uint8_t **)malloc(nr * sizeof(void *));
-        uint8_t **rout = (uint8_t **)malloc(nr * sizeof(void *));
-        uint32_t *rl = (uint32_t *)malloc(nr * 4), *rc_ = (uint32_t *)malloc(nr * 4), *ro = (uint32_t *)malloc(nr * 4);
-        int32_t *rs = (int32_t *)malloc(nr * 4);
-        size_t *map = (size_t *)malloc(nr * sizeof(size_t));
+        std::vector<const uint8_t *> rin_(nr); std::vector<uint8_t *> rout_(nr); std::vector<uint32_t> rl_(nr), rcap_(nr), ro_(nr);
+        std::vector<int32_t> rs_(nr); std::vector<size_t> map_(nr);
+        const uint8_t **rin = rin_.data(); uint8_t **rout = rout_.data(); uint32_t *rl = rl_.data(), *rc_ = rcap_.data(), *ro = ro_.data();
+        int32_t *rs = rs_.data(); size_t *map = map_.data();
         size_t k = 0;
         for (size_t i = 0; i < n; i++)
             if (out_len[i] && method[i] == HG_CRAM_RANS4x8) { rin[k] = in[i]; rout[k] = out[i]; rl[k] = in_len[i]; rc_[k] = out_len[i]; map[k] = i; k++; }
         int r = hg_rans4x8_decode_host(ctx, rin, rl, nr, rout, rc_, ro, rs);
         if (r != HG_OK && r != HG_EBLOCK) rc = r;
         for (k = 0; k < nr; k++) status[map[k]] = (r == HG_OK || r == HG_EBLOCK) ? ((rs[k] == 0 && ro[k] == out_len[map[k]]) ? 0 : -1) : -1;
-        free(rin); free(rout); free(rl); free(rc_); free(ro); free(rs); free(map);
         return rc;
     };
     auto run_gzip = [&](hg_ctx *ctx) -> int {
         int rc = HG_OK;
-        hg_bgzf_desc *desc = (hg_bgzf_desc *)calloc(ng, sizeof(hg_bgzf_desc));
-        size_t *map = (size_t *)malloc(ng * sizeof(size_t));
-        int32_t *st = (int32_t *)malloc(ng * 4);
+        std::vector<hg_bgzf_desc> desc_(ng); std::vector<size_t> map_(ng); std::vector<int32_t> st_(ng);
+        memset(desc_.data(), 0, ng * sizeof(hg_bgzf_desc));
+        hg_bgzf_desc *desc = desc_.data(); size_t *map = map_.data(); int32_t *st = st_.data();
         uint64_t ioff = 0, ooff = 0; size_t k = 0;
         for (size_t i = 0; i < n; i++)
             if (out_len[i] && method[i] == HG_CRAM_GZIP) {
@@ -273,7 +269,6 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
                 if (!ok) rc = HG_ELAUNCH;
             }
         }
-        free(desc); free(map); free(st);
         return rc;
     };
     struct Task { int kind; size_t cnt; } tasks[5] = {{0, nx_}, {1, na}, {2, nt}, {3, nr}, {4, ng}};
