@@ -77,6 +77,40 @@ def prepare(seed: int, total_bytes: int, level: int, workers: int, cache_dir: st
     return b"".join(parts)
 
 
+def prepare_shared(rank: int, world: int, seed: int, total_bytes: int, level: int, workers: int, cache_dir: str, rotate: bool = True,
+                   timeout_s: float = 3600.0):
+    """Multi-GPU runs: ONE synthetic data set is generated cooperatively (rank r builds chunks r, r+world, ... into the
+    shared cache, every rank uses all of its worker processes) and each rank takes the whole set starting at its own
+    chunk -- its own shard order of independent BGZF blocks -- instead of every rank synthesising and deflating a private
+    10 GiB.  Returns (stream, index of the first chunk)."""
+    nchunks = max(1, (total_bytes + CHUNK - 1) // CHUNK)
+    per = min(CHUNK, total_bytes) if nchunks == 1 else CHUNK
+    os.makedirs(cache_dir, exist_ok=True)
+    mine = [(seed, i, per, level, cache_dir) for i in range(nchunks) if i % world == rank]
+    if mine:
+        if workers > 1 and len(mine) > 1:
+            ctx = mp.get_context("fork")
+            with ctx.Pool(min(workers, len(mine))) as pool:
+                for _ in pool.imap_unordered(_prep_chunk, mine):
+                    pass
+        else:
+            for t in mine:
+                _prep_chunk(t)
+    paths = [os.path.join(cache_dir, f"{GEN_VERSION}_{seed:x}_{i}_{per}_{level}.bgzf") for i in range(nchunks)]
+    t0 = time.time()
+    for pth in paths:                                       # the other ranks' chunks appear atomically (tmp + rename)
+        while not os.path.exists(pth):
+            if time.time() - t0 > timeout_s:
+                raise RuntimeError("timed out waiting for " + pth)
+            time.sleep(0.05)
+    start = (rank * nchunks) // world if rotate else 0
+    parts = []
+    for k in range(nchunks):
+        with open(paths[(start + k) % nchunks], "rb") as f:
+            parts.append(f.read())
+    return b"".join(parts), start
+
+
 def cpu_baseline(bgzf_sample: bytes, plain_len: int, threads: int):
     """Reference htslib (bgzf.c + libdeflate 1.8, hts_tpool) decoding the sample: ref_bgzip -d -@T."""
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bgzip_ld")
@@ -147,10 +181,15 @@ def main():
         return bench_cram(args, rank, world, local)
     # ---------------- workload preparation (host, not timed, before HIP init) --------------
     total_bytes = int(args.gib * (1 << 30))
-    seed = 0x5EED0001 + 1000003 * rank
     cache = None if args.no_cache else os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "htsgpu_bench_cache")
     t0 = time.perf_counter()
-    comp = prepare(seed, total_bytes, args.level, workers, cache)
+    first_chunk = 0
+    if world > 1 and cache:
+        seed = 0x5EED0001
+        comp, first_chunk = prepare_shared(rank, world, seed, total_bytes, args.level, workers, cache, rotate=args.op != "bam")
+    else:
+        seed = 0x5EED0001 + 1000003 * rank
+        comp = prepare(seed, total_bytes, args.level, workers, cache)
     t_prep = time.perf_counter() - t0
 
     import torch
@@ -212,7 +251,7 @@ def main():
     # additionally compare the first chunk byte-for-byte with a regenerated plain image
     from htslib_amd import synth
     chk = min(CHUNK, total_bytes)
-    plain0, _, _ = synth.bam_stream(chk, seed, 0, True)
+    plain0, _, _ = synth.bam_stream(chk, seed, first_chunk, first_chunk == 0)
     got0 = d_out[:len(plain0)].cpu().numpy().tobytes()
     bytes_ok = got0 == plain0
     ok = nbad == 0 and bytes_ok

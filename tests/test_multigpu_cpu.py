@@ -60,3 +60,44 @@ def test_two_rank_reduction_over_gloo(built):
     elapsed, sum_u, sum_c, ok = o0
     assert elapsed == pytest.approx(0.020) and sum_u == 2 * (1 << 20) and sum_c == c0 + c1 and ok
     assert c0 != c1                                            # different shards, not replicas of one
+
+
+def _shared_prep_worker(rank, world, cache, q):
+    import bench
+    bench.CHUNK = 1 << 20
+    comp, start = bench.prepare_shared(rank, world, 0x5EED0001, 5 << 20, 6, 2, cache, rotate=True, timeout_s=300)
+    q.put((rank, start, comp))
+
+
+def test_bench_ranks_share_one_cooperatively_built_data_set(tmp_path):
+    """bench.py at N > 1: the ranks build ONE synthetic BGZF data set together (rank r deflates chunks r, r+N, ...) and
+    each takes all of it starting at its own chunk, instead of every rank preparing a private 10 GiB."""
+    import multiprocessing as mp
+    import zlib
+    import bench
+    from htslib_amd import synth
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    cache = str(tmp_path / "cache")
+    ps = [ctx.Process(target=_shared_prep_worker, args=(r, 2, cache, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = {}
+    for _ in ps:
+        r, start, comp = q.get(timeout=600)
+        got[r] = (start, comp)
+    for p in ps:
+        p.join(timeout=60)
+    assert got[0][0] == 0 and got[1][0] == 2                          # 5 chunks: rank 1 starts at chunk 2
+    files = sorted(os.listdir(cache))
+    assert len(files) == 5 and not any(f.endswith(".tmp") for f in files)
+    chunks = [open(os.path.join(cache, "v1_5eed0001_%d_%d_6.bgzf" % (i, 1 << 20)), "rb").read() for i in range(5)]
+    assert got[0][1] == b"".join(chunks) and got[1][1] == b"".join(chunks[2:] + chunks[:2])
+    # what rank 1 verifies against in bench.py: its first chunk regenerated from (seed, chunk index)
+    plain2, _, _ = synth.bam_stream(1 << 20, 0x5EED0001, 2, False)
+    out, p, c = b"", 0, chunks[2]
+    while p < len(c):
+        bs = int.from_bytes(c[p + 16:p + 18], "little") + 1
+        out += zlib.decompress(c[p + 18:p + bs - 8], -15)
+        p += bs
+    assert out == plain2
