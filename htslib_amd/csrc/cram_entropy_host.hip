@@ -307,7 +307,8 @@ extern "C" int hg_tok3_decode_host(hg_ctx *ctx, const uint8_t *const *in, const 
                 if (get_u7(cp, end, clen) || (uint64_t)(end - cp) < clen || clen < 1) { bad = -1; break; }
                 const uint8_t *sp = cp + 1;
                 if ((cp[0] & F_NOSZ) || get_u7(sp, cp + clen, sz) || sz > cap) { bad = -1; break; }
-                if (tboff - tb0 + sz > 0x7fffffffull) { bad = -1; break; }
+                // resource guard: a name costs at most ~6 stream bytes per character (see the encoder's buffer bound)
+                if (tboff - tb0 + sz > 16ull * ulen + 65536u) { bad = -1; break; }
                 E[t][type] = {(uint32_t)(tboff - tb0), sz, true};
                 if (int r = plan_stream(P, use_arith ? ARITH : NX16, (uint32_t)i, my_ioff, b, cp, cp + clen, -1, tboff, 1, 0)) { bad = r; break; }
                 tboff += ((uint64_t)sz + 15u) & ~15ull;

@@ -84,6 +84,7 @@ ORC_EXPORT int orc_tok3_decode(const uint8_t *in, size_t in_size, uint8_t *out, 
     uint8_t owned[MAX_TOK][16];
     memset(S, 0, sizeof S); memset(owned, 0, sizeof owned);
     int rc = 0, t = -1;
+    unsigned long long total_stream = 0;
     const uint8_t *cp = in + 9, *end = in + in_size;
     while (cp < end && !rc) {
         const uint8_t tt = *cp++;
@@ -111,6 +112,8 @@ ORC_EXPORT int orc_tok3_decode(const uint8_t *in, size_t in_size, uint8_t *out, 
             uint8_t *b = malloc(cap + 1); size_t got = 0;
             int r = use_arith ? orc_arith_uncompress(cp, clen, b, cap, &got, -1) : orc_ransnx16_uncompress(cp, clen, b, cap, &got);
             if (r) { free(b); rc = -1; break; }
+            total_stream += got;
+            if (total_stream > 16ull * ulen + 65536u) { free(b); rc = -1; break; }   /* resource guard, as in the GPU planner */
             S[t][type].b = b; S[t][type].n = got; owned[t][type] = 1;
             cp += clen;
         }
