@@ -120,6 +120,40 @@ void bam_bases_kernel(const uint8_t *__restrict__ b, const uint64_t *__restrict_
         }
     }
 }
+// the fixed fields of every record as columns (bam1_core_t, sam.c:808-821): one thread per record
+__global__ __launch_bounds__(256)
+void bam_core_kernel(const uint8_t *__restrict__ b, const uint64_t *__restrict__ rec_off, uint64_t n, hg_bam_core_cols c) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *x = b + rec_off[i] + 4;
+    const uint32_t x2 = ld32(x + 8), x3 = ld32(x + 12);
+    if (c.tid) c.tid[i] = (int32_t)ld32(x);
+    if (c.pos) c.pos[i] = (int32_t)ld32(x + 4);
+    if (c.bin) c.bin[i] = (uint16_t)(x2 >> 16);
+    if (c.mapq) c.mapq[i] = (uint8_t)(x2 >> 8);
+    if (c.l_qname) c.l_qname[i] = (uint8_t)x2;
+    if (c.flag) c.flag[i] = (uint16_t)(x3 >> 16);
+    if (c.n_cigar) c.n_cigar[i] = (uint16_t)x3;
+    if (c.l_qseq) c.l_qseq[i] = (int32_t)ld32(x + 16);
+    if (c.mtid) c.mtid[i] = (int32_t)ld32(x + 20);
+    if (c.mpos) c.mpos[i] = (int32_t)ld32(x + 24);
+    if (c.isize) c.isize[i] = (int32_t)ld32(x + 28);
+}
+// qualities as Phred+33 text at the same offsets as the bases (0xff = absent stays 0xff, as sam_format1 prints '*')
+__global__ __launch_bounds__(256)
+void bam_quals_kernel(const uint8_t *__restrict__ b, const uint64_t *__restrict__ rec_off, uint64_t n,
+                      const uint64_t *__restrict__ base_off, uint8_t *quals) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t w0 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6, nw = ((uint64_t)gridDim.x * 256u) >> 6;
+    for (uint64_t i = w0; i < n; i += nw) {
+        const uint8_t *x = b + rec_off[i] + 4;
+        const uint32_t l_qname = ld32(x + 8) & 0xffu, n_cigar = ld32(x + 12) & 0xffffu, l_qseq = ld32(x + 16);
+        const uint8_t *q = x + 32 + l_qname + 4u * n_cigar + ((l_qseq + 1u) >> 1);
+        uint8_t *o = quals + base_off[i];
+        for (uint32_t j = (uint32_t)lane; j < l_qseq; j += 64) { const uint32_t v = q[j]; o[j] = (uint8_t)(v == 0xffu ? 0xffu : v + 33u); }
+    }
+}
+
 // Exclusive prefix sum of n 32-bit values into 64-bit offsets (n+1 outputs), three launches: per-tile sums, a scan of
 // the tile sums by one workgroup, then the tiles again with their base added.
 constexpr uint32_t TILE = 4096;
@@ -251,6 +285,25 @@ long hg_bam_frame_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, uint64_t fir
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
     }
     return (long)total;
+}
+
+int hg_bam_core_dev(hg_ctx *ctx, const void *d_bam, const uint64_t *d_rec_off, uint64_t n, const hg_bam_core_cols *cols, void *stream) {
+    if (!ctx || !cols || (n && (!d_bam || !d_rec_off))) return HG_EINVAL;
+    if (!n) return HG_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hipLaunchKernelGGL(hgb::bam_core_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)d_bam, d_rec_off, n, *cols);
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+
+int hg_bam_quals_dev(hg_ctx *ctx, const void *d_bam, const uint64_t *d_rec_off, uint64_t n, const uint64_t *d_base_off, void *d_quals, void *stream) {
+    if (!ctx || (n && (!d_bam || !d_rec_off || !d_base_off || !d_quals))) return HG_EINVAL;
+    if (!n) return HG_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    size_t wgs = (size_t)((n + 3) / 4);
+    const size_t maxw = (size_t)ctx->cus * 32;
+    if (wgs > maxw) wgs = maxw;
+    hipLaunchKernelGGL(hgb::bam_quals_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)d_bam, d_rec_off, n, d_base_off, (uint8_t *)d_quals);
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
 
 int hg_bam_bases_dev(hg_ctx *ctx, const void *d_bam, const uint64_t *d_rec_off, uint64_t n, uint64_t *d_base_off, void *d_bases,

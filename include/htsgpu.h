@@ -299,6 +299,16 @@ int hg_bam_header_host(const uint8_t *bam, size_t len, int32_t *n_ref, uint64_t 
  * Exact: per-chunk guesses are verified link by link on the host.  Synchronises the stream. */
 long hg_bam_frame_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, uint64_t first_record_off, int32_t n_ref,
                       uint64_t *d_rec_off, uint64_t max_rec, uint64_t *bad_off, void *stream);
+/* The fixed fields of every record as device columns (bam1_core_t as bam_read1 fills it, sam.c:808-821); NULL
+ * columns are skipped.  Asynchronous on `stream`. */
+typedef struct hg_bam_core_cols {
+    int32_t *tid, *pos; uint16_t *bin; uint8_t *mapq, *l_qname; uint16_t *flag, *n_cigar; int32_t *l_qseq, *mtid, *mpos, *isize;
+} hg_bam_core_cols;
+int hg_bam_core_dev(hg_ctx *ctx, const void *d_bam, const uint64_t *d_rec_off, uint64_t n, const hg_bam_core_cols *cols, void *stream);
+/* Qualities as Phred+33 text (what sam_format1 prints, sam.c:4368-4376; 0xff = absent is kept) at the SAME offsets as the
+ * bases of hg_bam_bases_dev.  Asynchronous on `stream`. */
+int hg_bam_quals_dev(hg_ctx *ctx, const void *d_bam, const uint64_t *d_rec_off, uint64_t n, const uint64_t *d_base_off,
+                     void *d_quals, void *stream);
 /* d_base_off[i] (n+1 entries) = start of record i's bases in d_bases; d_bases = "=ACMGRSVTWYHKDBN" text of every
  * record back to back (pass d_bases NULL to get only the offsets and *total_bases).  Synchronises the stream. */
 int hg_bam_bases_dev(hg_ctx *ctx, const void *d_bam, const uint64_t *d_rec_off, uint64_t n, uint64_t *d_base_off,

@@ -182,5 +182,22 @@ def test_gpu_framing_and_bases_match_oracle(engine, borc):
         assert nat.lib.hg_bam_bases_dev(engine._h, d.data_ptr(), d_off.data_ptr(), n, d_boff.data_ptr(), d_bases.data_ptr(), tot.value, C.byref(tot), None) == 0
         boff = d_boff.cpu().numpy()
         bases = d_bases.cpu().numpy().tobytes()
+        d_quals = torch.zeros(tot.value + 64, dtype=torch.uint8, device="cuda")
+        assert nat.lib.hg_bam_quals_dev(engine._h, d.data_ptr(), d_off.data_ptr(), n, d_boff.data_ptr(), d_quals.data_ptr(), None) == 0
+        quals = d_quals.cpu().numpy().tobytes()
+        cols = {k: torch.zeros(max(n, 1), dtype=t, device="cuda") for k, t in (("tid", torch.int32), ("pos", torch.int32), ("bin", torch.int16),
+                ("mapq", torch.uint8), ("l_qname", torch.uint8), ("flag", torch.int16), ("n_cigar", torch.int16), ("l_qseq", torch.int32),
+                ("mtid", torch.int32), ("mpos", torch.int32), ("isize", torch.int32))}
+        cc = nat.BamCoreCols(**{k: v.data_ptr() for k, v in cols.items()})
+        assert nat.lib.hg_bam_core_dev(engine._h, d.data_ptr(), d_off.data_ptr(), n, C.byref(cc), None) == 0
+        torch.cuda.synchronize()
+        host = {k: v.cpu().numpy() for k, v in cols.items()}
         for i in list(range(min(n, 40))) + list(range(max(0, n - 40), n)) + list(range(0, n, max(1, n // 200))):
-            assert bases[boff[i]:boff[i + 1]] == borc.bases(b, int(want_off[i]))
+            r = int(want_off[i])
+            assert bases[boff[i]:boff[i + 1]] == borc.bases(b, r)
+            tid, pos, x2, x3, l_qseq, mtid, mpos, isize = struct.unpack_from("<iiIIiiii", b, r + 4)
+            assert (host["tid"][i], host["pos"][i], host["l_qseq"][i], host["mtid"][i], host["mpos"][i], host["isize"][i]) == (tid, pos, l_qseq, mtid, mpos, isize)
+            assert (int(host["bin"][i]) & 0xffff, host["mapq"][i], host["l_qname"][i], int(host["flag"][i]) & 0xffff, int(host["n_cigar"][i]) & 0xffff) == \
+                   (x2 >> 16, (x2 >> 8) & 0xff, x2 & 0xff, x3 >> 16, x3 & 0xffff)
+            qs = r + 36 + (x2 & 0xff) + 4 * (x3 & 0xffff) + (l_qseq + 1) // 2
+            assert quals[boff[i]:boff[i + 1]] == bytes(0xff if v == 0xff else v + 33 for v in b[qs:qs + l_qseq])
