@@ -210,6 +210,20 @@ void scan_sums_kernel(uint64_t *sums, uint64_t nt) {                   // in pla
 
 }  // namespace hgb
 
+namespace hg {
+// exclusive prefix sum of n 32-bit values into 64-bit offsets (n + 1 outputs); uses scratch slot 14
+int scan32_to64(hg_ctx *ctx, const uint32_t *d_v, uint64_t n, uint64_t *d_out, hipStream_t s) {
+    if (!n) return hipMemsetAsync(d_out, 0, 8, s) == hipSuccess ? HG_OK : HG_ELAUNCH;
+    const uint64_t nt = (n + hgb::TILE - 1) / hgb::TILE;
+    if (int rc = ensure_scratch(ctx, 14, (size_t)nt * 8 + 64)) return rc;
+    uint64_t *d_ts = (uint64_t *)ctx->d_scratch[14];
+    hipLaunchKernelGGL(hgb::scan_tiles_kernel, dim3((unsigned)nt), dim3(256), 0, s, d_v, n, (const uint64_t *)nullptr, d_ts, (uint64_t *)nullptr);
+    hipLaunchKernelGGL(hgb::scan_sums_kernel, dim3(1), dim3(1024), 0, s, d_ts, nt);
+    hipLaunchKernelGGL(hgb::scan_tiles_kernel, dim3((unsigned)nt), dim3(256), 0, s, d_v, n, (const uint64_t *)d_ts, (uint64_t *)nullptr, d_out);
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+}  // namespace hg
+
 extern "C" {
 
 int hg_bam_header_host(const uint8_t *bam, size_t len, int32_t *n_ref, uint64_t *first_record_off) {
@@ -317,12 +331,7 @@ int hg_bam_bases_dev(hg_ctx *ctx, const void *d_bam, const uint64_t *d_rec_off, 
         if ((rc = hg::ensure_scratch(ctx, 8, (size_t)n * 4 + 64))) return rc;
         uint32_t *d_lseq = (uint32_t *)ctx->d_scratch[8];
         hipLaunchKernelGGL(hgb::bam_lseq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_bam, d_rec_off, n, d_lseq);
-        const uint64_t nt = (n + hgb::TILE - 1) / hgb::TILE;
-        if ((rc = hg::ensure_scratch(ctx, 9, (size_t)nt * 8 + 64))) return rc;
-        uint64_t *d_ts = (uint64_t *)ctx->d_scratch[9];
-        hipLaunchKernelGGL(hgb::scan_tiles_kernel, dim3((unsigned)nt), dim3(256), 0, s, (const uint32_t *)d_lseq, n, (const uint64_t *)nullptr, d_ts, (uint64_t *)nullptr);
-        hipLaunchKernelGGL(hgb::scan_sums_kernel, dim3(1), dim3(1024), 0, s, d_ts, nt);
-        hipLaunchKernelGGL(hgb::scan_tiles_kernel, dim3((unsigned)nt), dim3(256), 0, s, (const uint32_t *)d_lseq, n, (const uint64_t *)d_ts, (uint64_t *)nullptr, d_base_off);
+        if ((rc = hg::scan32_to64(ctx, d_lseq, n, d_base_off, s))) return rc;
         if (hipMemcpyAsync(&total, d_base_off + n, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
         if (d_bases && total) {
             if (total > bases_cap) { if (total_bases) *total_bases = total; return HG_EINVAL; }

@@ -314,6 +314,19 @@ int hg_bam_quals_dev(hg_ctx *ctx, const void *d_bam, const uint64_t *d_rec_off, 
 int hg_bam_bases_dev(hg_ctx *ctx, const void *d_bam, const uint64_t *d_rec_off, uint64_t n, uint64_t *d_base_off,
                      void *d_bases, uint64_t bases_cap, uint64_t *total_bases, void *stream);
 
+/* ---- BAI index from a device-resident BAM stream: what `samtools index` computes -- the
+ *      bam_read1 + hts_idx_push loop of sam_index (sam.c:994-1031), hts_idx_finish / compress_binning and idx_save_core
+ *      (hts.c:2431-2640, 2759-2822).  d_rec_off / nrec come from hg_bam_frame_dev; blocks[] = EVERY BGZF block of the file
+ *      in order as hg_bgzf_scan reports them (empty blocks and the EOF block included), file_size = compressed size;
+ *      ref_len[] = the header's reference lengths.  Writes the .bai bytes to out and returns their count; the bins of a
+ *      reference are written in ascending order (htslib writes its hash-table order; the content is identical).
+ *      HG_BAM_EUNSORTED = the conditions `samtools index` refuses (unsorted positions, a reference in several blocks,
+ *      unplaced reads before placed ones).  Synchronises the stream. ---- */
+#define HG_BAM_EUNSORTED (-5)
+long hg_bai_build_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, uint64_t first_record_off, int32_t n_ref,
+                      const uint32_t *ref_len, const uint64_t *d_rec_off, uint64_t nrec, const hg_bgzf_desc *blocks,
+                      uint64_t nblocks, uint64_t file_size, uint8_t *out, size_t out_cap, void *stream);
+
 /* ---- CRC-32 (replaces hts_crc32, bgzf.c:557-559 / 620-622) -------------- */
 /* crc[i] = crc32(0, d_data + off[i], len[i]) for n independent buffers. */
 int hg_crc32_dev(hg_ctx *ctx, const void *d_data,

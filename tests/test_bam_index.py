@@ -82,3 +82,60 @@ def test_oracle_rejects_unsorted_input(iorc):
     pa = struct.unpack_from("<i", plain, a + 8)[0]; pb = struct.unpack_from("<i", plain, b + 8)[0]
     if pa != pb:
         assert iorc.bai(swapped, bgzf) is None
+
+
+def gpu_bai(engine, plain, bgzf, iorc):
+    import torch
+    from htslib_amd import _native as nat
+    rc, n_ref, first = iorc.header(plain)
+    # reference lengths from the header (l_ref follows each name)
+    p = 8 + struct.unpack_from("<I", plain, 4)[0] + 4
+    ref_len = []
+    for _ in range(n_ref):
+        l = struct.unpack_from("<i", plain, p)[0]
+        ref_len.append(struct.unpack_from("<I", plain, p + 4 + l)[0]); p += 8 + l
+    rl = np.array(ref_len + [0], dtype=np.uint32)
+    d = torch.frombuffer(bytearray(plain + bytes(64)), dtype=torch.uint8).cuda()
+    bad = C.c_uint64(0)
+    n = nat.lib.hg_bam_frame_dev(engine._h, d.data_ptr(), len(plain), first, n_ref, None, 0, C.byref(bad), None)
+    assert n >= 0
+    d_off = torch.zeros(max(n, 1), dtype=torch.int64, device="cuda")
+    assert nat.lib.hg_bam_frame_dev(engine._h, d.data_ptr(), len(plain), first, n_ref, d_off.data_ptr(), n, C.byref(bad), None) == n
+    blk, fsize = block_table(bgzf)
+    desc = np.zeros(len(blk), dtype=nat.DESC_DTYPE) if hasattr(nat, "DESC_DTYPE") else None
+    if desc is None:
+        desc = np.zeros(len(blk), dtype=[("coff", "<u8"), ("uoff", "<u8"), ("clen", "<u4"), ("ulen", "<u4")])
+    desc["coff"], desc["uoff"], desc["ulen"] = blk["coff"], blk["uoff"], blk["ulen"]
+    out = C.create_string_buffer(1 << 24)
+    r = nat.lib.hg_bai_build_dev(engine._h, d.data_ptr(), len(plain), first, n_ref, rl.ctypes.data, d_off.data_ptr(), n, desc.ctypes.data,
+                                 len(desc), fsize, out, len(out), None)
+    return r, out.raw[:max(r, 0)]
+
+
+@pytest.mark.gpu
+def test_gpu_index_equals_oracle_and_reference(engine, iorc):
+    for name in ("colons.bam", "range.bam", "mpileup__small.bam", "bgzf_boundaries__bgzf_boundaries1.bam", "bgzf_boundaries__bgzf_boundaries3.bam"):
+        bgzf = open(os.path.join(GOLD, "bgzf", name), "rb").read()
+        plain = plain_of(name)
+        want = iorc.bai(plain, bgzf)
+        r, got = gpu_bai(engine, plain, bgzf, iorc)
+        if want is None:
+            assert r == -5, name
+        else:
+            assert r == len(want) and got == want, name
+    for name in ("colons.bam", "range.bam"):                               # and through the oracle to reference htslib's own files
+        ref = open(os.path.join(GOLD, "bam", name + ".bai"), "rb").read()
+        assert gpu_bai(engine, plain_of(name), open(os.path.join(GOLD, "bgzf", name), "rb").read(), iorc)[1] == canonical_bai(ref)
+    plain, bgzf = synth.bam_bgzf(24 << 20)                                # ~80 k records, many bins, several references
+    want = iorc.bai(plain, bgzf)
+    assert want is not None and len(want) > 1000
+    r, got = gpu_bai(engine, plain, bgzf, iorc)
+    assert r == len(want) and got == want
+    # unsorted input is refused like `samtools index` does
+    rc, n_ref, first = iorc.header(plain)
+    n, _, off = iorc.frame(plain, first)
+    k = next(i for i in range(10, n - 2) if struct.unpack_from("<i", plain, int(off[i]) + 8)[0] < struct.unpack_from("<i", plain, int(off[i + 1]) + 8)[0]
+             and struct.unpack_from("<i", plain, int(off[i]) + 4)[0] == struct.unpack_from("<i", plain, int(off[i + 1]) + 4)[0])
+    a, b, c = int(off[k]), int(off[k + 1]), int(off[k + 2])
+    swapped = plain[:a] + plain[b:c] + plain[a:b] + plain[c:]
+    assert iorc.bai(swapped, bgzf) is None and gpu_bai(engine, swapped, bgzf, iorc)[0] == -5
