@@ -110,6 +110,11 @@ class BamCoreCols(C.Structure):
 lib.hg_bai_build_dev.restype = C.c_long
 lib.hg_bai_build_dev.argtypes = [_vp, _vp, C.c_uint64, C.c_uint64, C.c_int32, _vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, C.c_size_t, _vp]
 
+lib.hg_idx_build_dev.restype = C.c_long
+lib.hg_idx_build_dev.argtypes = [_vp, _vp, C.c_uint64, C.c_uint64, C.c_int32, _vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int,
+                                 C.c_int, _vp, C.c_size_t, _vp]
+lib.hg_csi_levels.argtypes = [C.c_uint64, C.c_int]
+
 EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info", "hg_bgzf_scan",
            "hg_bgzf_inflate_dev", "hg_bgzf_inflate_host", "hg_crc32_dev", "hg_bgzf_deflate_dev", "hg_bgzf_pack_dev",
            "hg_bgzf_deflate_host", "hg_rans4x8_decode_dev", "hg_rans4x8_decode_host",
@@ -117,7 +122,7 @@ EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info
            "hg_ransnx16_compress_bound", "hg_ransnx16_encode_host", "hg_rans4x8_compress_bound",
            "hg_rans4x8_encode_host", "hg_gzip_compress_bound", "hg_gzip_deflate_host", "hg_cram_compress_bound",
            "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host", "hg_tok3_decode_host", "hg_tok3_compress_bound", "hg_tok3_encode_host", "hg_cram_metrics_new", "hg_cram_metrics_free",
-           "hg_cram_compress_blocks_metrics_host", "hg_bam_header_host", "hg_bam_frame_dev", "hg_bam_bases_dev", "hg_bam_core_dev", "hg_bam_quals_dev", "hg_bai_build_dev"]
+           "hg_cram_compress_blocks_metrics_host", "hg_bam_header_host", "hg_bam_frame_dev", "hg_bam_bases_dev", "hg_bam_core_dev", "hg_bam_quals_dev", "hg_bai_build_dev", "hg_idx_build_dev", "hg_csi_levels"]
 
 
 class HgError(RuntimeError):

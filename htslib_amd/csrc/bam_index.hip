@@ -44,9 +44,9 @@ __host__ __device__ inline uint64_t voff_of(const Blk *blk, uint64_t nb, uint64_
     if (lo == nb && u >= blk[nb - 1].uoff + blk[nb - 1].ulen) return file_size << 16;
     return (blk[lo - 1].coff << 16) | (u - blk[lo - 1].uoff);
 }
-__host__ __device__ inline int reg2bin(long long beg, long long end) {       // hts_reg2bin(beg, end, 14, 5)
-    int l, s = 14, t = ((1 << 15) - 1) / 7;
-    for (--end, l = 5; l > 0; --l, s += 3, t -= 1 << (3 * l))
+__host__ __device__ inline int reg2bin(long long beg, long long end, int min_shift, int n_lvls) {       // hts_reg2bin
+    int l, s = min_shift, t = ((1 << (3 * n_lvls)) - 1) / 7;
+    for (--end, l = n_lvls; l > 0; --l, s += 3, t -= 1 << (3 * l))
         if (beg >> s == end >> s) return t + (int)(beg >> s);
     return 0;
 }
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256)
 void idx_record_kernel(const uint8_t *__restrict__ b, const uint64_t *__restrict__ rec_off, uint64_t n, int32_t n_ref, const Blk *__restrict__ blk,
                        uint64_t nb, uint64_t file_size, int32_t *tid_o, uint32_t *bin_o, uint64_t *voff_o, uint32_t *flag_o,
                        const uint64_t *__restrict__ lin_base, const uint32_t *__restrict__ lin_cap, unsigned long long *lin, uint32_t *lin_n,
-                       uint32_t *cnt, uint32_t *err) {
+                       uint32_t *cnt, uint32_t *err, int min_shift, int n_lvls) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     long long raw_beg = 0;                                            // the position as stored, before hts_idx_push clamps it
@@ -83,7 +83,7 @@ void idx_record_kernel(const uint8_t *__restrict__ b, const uint64_t *__restrict
     const long long my_raw = raw_beg;
     uint32_t e = 0;
     if (tid >= n_ref) { e |= E_TID; tid = -1; beg = -1; end = 0; }
-    const int bin = reg2bin(beg, end);
+    const int bin = reg2bin(beg, end, min_shift, n_lvls);
     const uint64_t vo = voff_of(blk, nb, file_size, rec_off[i]);
     bool start = true;
     if (i) {
@@ -92,12 +92,12 @@ void idx_record_kernel(const uint8_t *__restrict__ b, const uint64_t *__restrict
         if (ptid >= n_ref) ptid = -1;
         if (ptid == tid) {
             if (tid >= 0 && pbeg > my_raw) e |= E_UNSORTED;        // last_coor (clamped) against the raw position, as the reference does
-            start = reg2bin(pbeg, pend) != bin;
+            start = reg2bin(pbeg, pend, min_shift, n_lvls) != bin;
         } else if (ptid < 0 && tid >= 0) e |= E_NOCOOR;
     }
     tid_o[i] = tid; bin_o[i] = (uint32_t)bin; voff_o[i] = vo; flag_o[i] = start ? 1u : 0u;
     if (tid >= 0) {
-        const long long wb = beg >> 14, we = (end - 1) >> 14;
+        const long long wb = beg >> min_shift, we = (end - 1) >> min_shift;
         if ((unsigned long long)we >= lin_cap[tid]) e |= E_LIN;
         else {
             for (long long w = wb; w <= we; w++) atomicMin(&lin[lin_base[tid] + (uint64_t)w], (unsigned long long)vo);
@@ -123,9 +123,23 @@ void idx_runs_kernel(const int32_t *__restrict__ tid, const uint32_t *__restrict
 
 namespace hg { int scan32_to64(hg_ctx *ctx, const uint32_t *d_v, uint64_t n, uint64_t *d_out, hipStream_t s); }
 
+extern "C" int hg_csi_levels(uint64_t max_ref_len, int min_shift) {      // hts_adjust_csi_settings with n_lvls = 0 (sam_index, sam.c:1003-1012)
+    int n_lvls = 0;
+    unsigned long long maxpos = 1ull << min_shift;
+    while (max_ref_len + 256 > maxpos && n_lvls < 9) { n_lvls++; maxpos *= 8; }
+    return n_lvls;
+}
+
 extern "C" long hg_bai_build_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, uint64_t first_record_off, int32_t n_ref, const uint32_t *ref_len,
                                  const uint64_t *d_rec_off, uint64_t nrec, const hg_bgzf_desc *blocks, uint64_t nblocks, uint64_t file_size,
                                  uint8_t *out, size_t out_cap, void *stream) {
+    return hg_idx_build_dev(ctx, d_bam, len, first_record_off, n_ref, ref_len, d_rec_off, nrec, blocks, nblocks, file_size, 0, 14, 5, out, out_cap, stream);
+}
+
+extern "C" long hg_idx_build_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, uint64_t first_record_off, int32_t n_ref, const uint32_t *ref_len,
+                                 const uint64_t *d_rec_off, uint64_t nrec, const hg_bgzf_desc *blocks, uint64_t nblocks, uint64_t file_size,
+                                 int csi, int min_shift, int n_lvls, uint8_t *out, size_t out_cap, void *stream) {
+    if (min_shift < 1 || min_shift > 30 || n_lvls < 1 || n_lvls > 9) return HG_EINVAL;
     if (!ctx || n_ref < 0 || (n_ref && !ref_len) || (nrec && (!d_bam || !d_rec_off)) || (nblocks && !blocks) || !out) return HG_EINVAL;
     if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
     hipStream_t s = (hipStream_t)stream;
@@ -134,7 +148,7 @@ extern "C" long hg_bai_build_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, u
     for (uint64_t k = 0; k < nblocks; k++) { blk[k].coff = blocks[k].coff; blk[k].uoff = blocks[k].uoff; blk[k].ulen = blocks[k].ulen; blk[k].pad = 0; }
     // linear-index windows per reference: what the header's length needs, plus slack for reads hanging over the end
     std::vector<uint64_t> lin_base(n_ref + 1, 0); std::vector<uint32_t> lin_cap(n_ref);
-    for (int32_t t = 0; t < n_ref; t++) { lin_cap[t] = (ref_len[t] >> 14) + 64u; lin_base[t + 1] = lin_base[t] + lin_cap[t]; }
+    for (int32_t t = 0; t < n_ref; t++) { lin_cap[t] = (ref_len[t] >> min_shift) + 64u; lin_base[t + 1] = lin_base[t] + lin_cap[t]; }
     const uint64_t nlin = lin_base[n_ref];
     const size_t ncnt = 3 * (size_t)n_ref + 1;
     int rc;
@@ -160,7 +174,7 @@ extern "C" long hg_bai_build_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, u
     if (nrec) {
         hipLaunchKernelGGL(hgi::idx_record_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_bam, d_rec_off, nrec, n_ref,
                            (const Blk *)d_blk, nblocks, file_size, d_tid, d_bin, d_voff, d_flag, (const uint64_t *)d_lbase, (const uint32_t *)d_lcap,
-                           d_lin, d_linn, d_cnt, d_err);
+                           d_lin, d_linn, d_cnt, d_err, min_shift, n_lvls);
         if ((rc = hg::scan32_to64(ctx, d_flag, nrec, d_rank, s))) return rc;
         if (hipMemcpyAsync(&nruns, d_rank + nrec, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
         if ((rc = hg::ensure_scratch(ctx, 13, nruns * sizeof(Run) + 64))) return rc;
@@ -178,7 +192,7 @@ extern "C" long hg_bai_build_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, u
     if (err) return HG_BAM_EUNSORTED;
     for (int32_t t = 0; t < n_ref; t++) if (cnt[2 * n_ref + t] > 1) return HG_BAM_EUNSORTED;   // "Chromosome blocks not continuous"
     // ---- fold the runs into bins (insert_to_b in hts_idx_push order) and the meta bins -------------------------------
-    const uint32_t N_BINS = 37449, META = 37450;
+    const uint32_t N_BINS = (uint32_t)(((1ull << (3 * n_lvls + 3)) - 1) / 7), META = N_BINS + 1;
     const uint64_t final_off = hgi::voff_of(blk.data(), nblocks, file_size, len);
     typedef std::pair<uint64_t, uint64_t> Chunk;
     std::vector<std::map<uint32_t, std::vector<Chunk>>> bins(n_ref);
@@ -201,12 +215,12 @@ extern "C" long hg_bai_build_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, u
         for (long long l = (long long)linn[t] - 2; l >= 0; l--) if (L[l] == ~0ull) L[l] = L[l + 1];
         // compress_binning: small bins move into their parent, deepest level first
         auto &B = bins[t];
-        for (int l = 5; l > 0; l--) {
+        for (int l = n_lvls; l > 0; l--) {
             std::vector<uint32_t> keys;
             for (auto &kv : B) if (kv.first < N_BINS && level(kv.first) == l) keys.push_back(kv.first);
             for (uint32_t k : keys) {
                 auto &p = B[k];
-                if (l < 5 && p.size() > 1) std::sort(p.begin(), p.end(), by_u);
+                if (l < n_lvls && p.size() > 1) std::sort(p.begin(), p.end(), by_u);
                 if ((p.back().second >> 16) - (p.front().first >> 16) < 0x10000u) {
                     auto q = B.find((k - 1) >> 3);
                     if (q == B.end()) continue;
@@ -231,13 +245,29 @@ extern "C" long hg_bai_build_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, u
     std::vector<uint8_t> o;
     auto put32 = [&](uint32_t v) { for (int k = 0; k < 4; k++) o.push_back((uint8_t)(v >> (8 * k))); };
     auto put64 = [&](uint64_t v) { put32((uint32_t)v); put32((uint32_t)(v >> 32)); };
-    o.insert(o.end(), {'B', 'A', 'I', 1});
+    o.insert(o.end(), {(uint8_t)(csi ? 'C' : 'B'), (uint8_t)(csi ? 'S' : 'A'), 'I', 1});
+    if (csi) { put32((uint32_t)min_shift); put32((uint32_t)n_lvls); put32(0); }         // hts_idx_write_out: no meta block
     put32((uint32_t)n_ref);
     for (int32_t t = 0; t < n_ref; t++) {
         put32((uint32_t)bins[t].size());
-        for (auto &kv : bins[t]) { put32(kv.first); put32((uint32_t)kv.second.size()); for (auto &c : kv.second) { put64(c.first); put64(c.second); } }
-        put32(linn[t]);
-        for (uint32_t w = 0; w < linn[t]; w++) put64(lin[lin_base[t] + w]);
+        for (auto &kv : bins[t]) {
+            put32(kv.first);
+            if (csi) {                                                    // update_loff (hts.c:2443-2453): the linear index, folded into the bins
+                uint64_t loff = 0;
+                if (kv.first < N_BINS) {
+                    const int l = level(kv.first);
+                    const uint64_t bot = (uint64_t)(kv.first - (uint32_t)(((1ull << (3 * l)) - 1) / 7)) << ((n_lvls - l) * 3);
+                    loff = bot < linn[t] ? lin[lin_base[t] + bot] : 0;
+                }
+                put64(loff);
+            }
+            put32((uint32_t)kv.second.size());
+            for (auto &c : kv.second) { put64(c.first); put64(c.second); }
+        }
+        if (!csi) {
+            put32(linn[t]);
+            for (uint32_t w = 0; w < linn[t]; w++) put64(lin[lin_base[t] + w]);
+        }
     }
     put64(cnt[3 * n_ref]);                                                // n_no_coor
     if (o.size() > out_cap) return HG_EINVAL;

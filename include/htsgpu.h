@@ -326,6 +326,14 @@ int hg_bam_bases_dev(hg_ctx *ctx, const void *d_bam, const uint64_t *d_rec_off, 
 long hg_bai_build_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, uint64_t first_record_off, int32_t n_ref,
                       const uint32_t *ref_len, const uint64_t *d_rec_off, uint64_t nrec, const hg_bgzf_desc *blocks,
                       uint64_t nblocks, uint64_t file_size, uint8_t *out, size_t out_cap, void *stream);
+/* General form: csi = 0 -> BAI (min_shift 14, n_lvls 5); csi = 1 -> the CSI layout of `samtools index -c` (min_shift 14
+ * by default, n_lvls = hg_csi_levels(longest reference, min_shift), i.e. hts_adjust_csi_settings as sam_index calls it,
+ * sam.c:1003-1012), uncompressed: the caller BGZF-compresses it as hts_idx_save_as does. */
+int hg_csi_levels(uint64_t max_ref_len, int min_shift);
+long hg_idx_build_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, uint64_t first_record_off, int32_t n_ref,
+                      const uint32_t *ref_len, const uint64_t *d_rec_off, uint64_t nrec, const hg_bgzf_desc *blocks,
+                      uint64_t nblocks, uint64_t file_size, int csi, int min_shift, int n_lvls, uint8_t *out, size_t out_cap,
+                      void *stream);
 
 /* ---- CRC-32 (replaces hts_crc32, bgzf.c:557-559 / 620-622) -------------- */
 /* crc[i] = crc32(0, d_data + off[i], len[i]) for n independent buffers. */

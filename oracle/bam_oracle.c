@@ -96,10 +96,10 @@ static uint64_t voff_of(const oblk_t *blk, long nb, uint64_t file_size, uint64_t
     if (lo == nb && u >= blk[nb - 1].uoff + blk[nb - 1].ulen) return file_size << 16;
     return (blk[lo - 1].coff << 16) | (u - blk[lo - 1].uoff);
 }
-static int reg2bin(int64_t beg, int64_t end)
+static int reg2bin(int64_t beg, int64_t end, int min_shift, int n_lvls)
 {
-    int l, s = 14, t = ((1 << 15) - 1) / 7;
-    for (--end, l = 5; l > 0; --l, s += 3, t -= 1 << (3 * l))
+    int l, s = min_shift, t = ((1 << (3 * n_lvls)) - 1) / 7;
+    for (--end, l = n_lvls; l > 0; --l, s += 3, t -= 1 << (3 * l))
         if (beg >> s == end >> s) return t + (int)(beg >> s);
     return 0;
 }
@@ -124,10 +124,20 @@ static int bin_level(uint32_t bin) { int l = 0; while (bin) { bin = (bin - 1) >>
 
 /* returns the number of bytes written to out (<= cap), or -1 (unsorted input / chromosome blocks not continuous / bad
  * record) like `samtools index` failing */
+ORC_EXPORT long orc_idx_build(const uint8_t *b, uint64_t len, uint64_t first, int32_t n_ref, const oblk_t *blk, long nb,
+                              uint64_t file_size, int csi, int min_shift, int n_lvls, uint8_t *out, long cap);
 ORC_EXPORT long orc_bai_build(const uint8_t *b, uint64_t len, uint64_t first, int32_t n_ref, const oblk_t *blk, long nb,
                               uint64_t file_size, uint8_t *out, long cap)
 {
-    const uint32_t N_BINS = 37449, META = 37450;
+    return orc_idx_build(b, len, first, n_ref, blk, nb, file_size, 0, 14, 5, out, cap);
+}
+/* csi != 0: the CSI layout (hts_idx_write_out / idx_save_core with HTS_FMT_CSI: min_shift, depth, l_meta = 0, a
+ * linear-index-derived `loff` per bin instead of the linear index itself), uncompressed -- samtools BGZF-compresses it.
+ * n_lvls as sam_index derives it with hts_adjust_csi_settings (hts.c:2367-2403). */
+ORC_EXPORT long orc_idx_build(const uint8_t *b, uint64_t len, uint64_t first, int32_t n_ref, const oblk_t *blk, long nb,
+                              uint64_t file_size, int csi, int min_shift, int n_lvls, uint8_t *out, long cap)
+{
+    const uint32_t N_BINS = (uint32_t)(((1ull << (3 * n_lvls + 3)) - 1) / 7), META = N_BINS + 1;
     oref_t *R = calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(oref_t));
     int32_t save_tid = -1, last_tid = -1; uint32_t save_bin = 0xffffffffu, last_bin = 0xffffffffu;
     uint64_t offset0 = voff_of(blk, nb, file_size, first);
@@ -164,7 +174,7 @@ ORC_EXPORT long orc_bai_build(const uint8_t *b, uint64_t len, uint64_t first, in
             if (beg < 0) beg = 0;
             if (end <= 0) end = 1;
             oref_t *r = &R[tid];
-            int64_t wb = beg >> 14, we = (end - 1) >> 14;
+            int64_t wb = beg >> min_shift, we = (end - 1) >> min_shift;
             if (r->lin_m < we + 1) {
                 int64_t nm = r->lin_m * 2 > we + 1 ? r->lin_m * 2 : we + 1;
                 r->lin = realloc(r->lin, (size_t)nm * 8);
@@ -174,7 +184,7 @@ ORC_EXPORT long orc_bai_build(const uint8_t *b, uint64_t len, uint64_t first, in
             for (int64_t i = wb; i <= we; i++) if (r->lin[i] == ~0ull) r->lin[i] = last_off;
             if (r->lin_n < we + 1) r->lin_n = we + 1;
         } else n_no_coor++;
-        int bin = reg2bin(beg, end);
+        int bin = reg2bin(beg, end, min_shift, n_lvls);
         if ((int)last_bin != bin) {
             if (save_bin != 0xffffffffu) bin_add(&R[save_tid], save_bin, save_off, last_off);
             if (last_bin == 0xffffffffu && save_bin != 0xffffffffu) {              /* change of reference: its meta bin */
@@ -202,11 +212,11 @@ ORC_EXPORT long orc_bai_build(const uint8_t *b, uint64_t len, uint64_t first, in
             oref_t *r = &R[t];
             for (int64_t l = r->lin_n - 2; l >= 0; l--) if (r->lin[l] == ~0ull) r->lin[l] = r->lin[l + 1];
             /* compress_binning: a bin spanning < 0x10000 compressed bytes moves into its parent, bottom level first */
-            for (int l = 5; l > 0; l--)
+            for (int l = n_lvls; l > 0; l--)
                 for (uint32_t i = 0; i < r->n; i++) {
                     obin_t *pb = &r->bins[i];
                     if (pb->bin >= N_BINS || !pb->n || bin_level(pb->bin) != l) continue;
-                    if (l < 5 && pb->n > 1) qsort(pb->list, pb->n, sizeof(opair_t), cmp_pair);
+                    if (l < n_lvls && pb->n > 1) qsort(pb->list, pb->n, sizeof(opair_t), cmp_pair);
                     if ((pb->list[pb->n - 1].v >> 16) - (pb->list[0].u >> 16) < 0x10000) {
                         obin_t *q = bin_get(r, (pb->bin - 1) >> 3, 0);
                         if (!q || !q->n) continue;
@@ -233,7 +243,8 @@ ORC_EXPORT long orc_bai_build(const uint8_t *b, uint64_t len, uint64_t first, in
 #define PUT32(v) do { if (o + 4 > oe) goto full; uint32_t _v = (uint32_t)(v); o[0] = _v; o[1] = _v >> 8; o[2] = _v >> 16; o[3] = _v >> 24; o += 4; } while (0)
 #define PUT64(v) do { uint64_t _w = (v); PUT32(_w); PUT32(_w >> 32); } while (0)
         if (o + 4 > oe) goto full;
-        memcpy(o, "BAI\1", 4); o += 4;
+        memcpy(o, csi ? "CSI\1" : "BAI\1", 4); o += 4;
+        if (csi) { PUT32(min_shift); PUT32(n_lvls); PUT32(0); }
         PUT32(n_ref);
         for (int32_t t = 0; t < n_ref; t++) {
             oref_t *r = &R[t];
@@ -244,11 +255,23 @@ ORC_EXPORT long orc_bai_build(const uint8_t *b, uint64_t len, uint64_t first, in
             for (uint32_t i = 0; i < r->n; i++) {
                 obin_t *pb = &r->bins[i];
                 if (!pb->n) continue;
-                PUT32(pb->bin); PUT32(pb->n);
+                PUT32(pb->bin);
+                if (csi) {                                                          /* update_loff, hts.c:2443-2453 */
+                    uint64_t loff = 0;
+                    if (pb->bin < N_BINS) {
+                        int l = bin_level(pb->bin);
+                        int64_t bot = (int64_t)(pb->bin - (uint32_t)(((1ull << (3 * l)) - 1) / 7)) << ((n_lvls - l) * 3);
+                        loff = bot < r->lin_n ? r->lin[bot] : 0;
+                    }
+                    PUT64(loff);
+                }
+                PUT32(pb->n);
                 for (uint32_t k = 0; k < pb->n; k++) { PUT64(pb->list[k].u); PUT64(pb->list[k].v); }
             }
-            PUT32((uint32_t)r->lin_n);
-            for (int64_t i = 0; i < r->lin_n; i++) PUT64(r->lin[i]);
+            if (!csi) {
+                PUT32((uint32_t)r->lin_n);
+                for (int64_t i = 0; i < r->lin_n; i++) PUT64(r->lin[i]);
+            }
         }
         PUT64(n_no_coor);
         written = (long)(o - out);

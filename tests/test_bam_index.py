@@ -49,6 +49,17 @@ class BaiOracle(BamOracle):
         self.L.orc_bai_build.restype = C.c_long
         self.L.orc_bai_build.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_long, C.c_uint64, C.c_char_p, C.c_long]
 
+    def idx(self, plain, bgzf, csi, min_shift, n_lvls):
+        self.L.orc_idx_build.restype = C.c_long
+        self.L.orc_idx_build.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, C.c_long, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                                         C.c_char_p, C.c_long]
+        rc, n_ref, first = self.header(plain)
+        assert rc == 0
+        blk, fsize = block_table(bgzf)
+        out = C.create_string_buffer(1 << 22)
+        n = self.L.orc_idx_build(plain, len(plain), first, n_ref, blk.ctypes.data, len(blk), fsize, csi, min_shift, n_lvls, out, len(out))
+        return out.raw[:n] if n >= 0 else None
+
     def bai(self, plain, bgzf):
         rc, n_ref, first = self.header(plain)
         assert rc == 0
@@ -72,6 +83,28 @@ def test_oracle_reproduces_the_index_reference_htslib_wrote(iorc, name):
     assert got == canonical_bai(want)
 
 
+def ref_lengths(plain):
+    n_ref = struct.unpack_from("<i", plain, 8 + struct.unpack_from("<I", plain, 4)[0])[0]
+    p = 8 + struct.unpack_from("<I", plain, 4)[0] + 4
+    out = []
+    for _ in range(n_ref):
+        l = struct.unpack_from("<i", plain, p)[0]
+        out.append(struct.unpack_from("<I", plain, p + 4 + l)[0]); p += 8 + l
+    return out
+
+
+def test_oracle_reproduces_the_csi_reference_htslib_wrote(iorc):
+    """`samtools index -c`: the CSI layout; depth from hts_adjust_csi_settings (14 / 2 for a 1 Mbp reference)."""
+    from htslib_amd import _native as nat
+    name = "no_hdr_sq_1.bam"
+    plain = plain_of(name)
+    want = open(os.path.join(GOLD, "bgzf", name + ".csi.plain"), "rb").read()
+    depth = nat.lib.hg_csi_levels(max(ref_lengths(plain)), 14)
+    assert depth == struct.unpack_from("<i", want, 8)[0] == 2
+    assert nat.lib.hg_csi_levels(249_250_621, 14) == 5 and nat.lib.hg_csi_levels(600_000_000, 14) == 6
+    assert iorc.idx(plain, open(os.path.join(GOLD, "bgzf", name), "rb").read(), 1, 14, depth) == want
+
+
 def test_oracle_rejects_unsorted_input(iorc):
     plain, bgzf = synth.bam_bgzf(1 << 20)
     assert iorc.bai(plain, bgzf) is not None
@@ -84,7 +117,7 @@ def test_oracle_rejects_unsorted_input(iorc):
         assert iorc.bai(swapped, bgzf) is None
 
 
-def gpu_bai(engine, plain, bgzf, iorc):
+def gpu_bai(engine, plain, bgzf, iorc, csi=0, min_shift=14, n_lvls=5):
     import torch
     from htslib_amd import _native as nat
     rc, n_ref, first = iorc.header(plain)
@@ -107,8 +140,8 @@ def gpu_bai(engine, plain, bgzf, iorc):
         desc = np.zeros(len(blk), dtype=[("coff", "<u8"), ("uoff", "<u8"), ("clen", "<u4"), ("ulen", "<u4")])
     desc["coff"], desc["uoff"], desc["ulen"] = blk["coff"], blk["uoff"], blk["ulen"]
     out = C.create_string_buffer(1 << 24)
-    r = nat.lib.hg_bai_build_dev(engine._h, d.data_ptr(), len(plain), first, n_ref, rl.ctypes.data, d_off.data_ptr(), n, desc.ctypes.data,
-                                 len(desc), fsize, out, len(out), None)
+    r = nat.lib.hg_idx_build_dev(engine._h, d.data_ptr(), len(plain), first, n_ref, rl.ctypes.data, d_off.data_ptr(), n, desc.ctypes.data,
+                                 len(desc), fsize, csi, min_shift, n_lvls, out, len(out), None)
     return r, out.raw[:max(r, 0)]
 
 
@@ -131,6 +164,13 @@ def test_gpu_index_equals_oracle_and_reference(engine, iorc):
     assert want is not None and len(want) > 1000
     r, got = gpu_bai(engine, plain, bgzf, iorc)
     assert r == len(want) and got == want
+    # CSI: the reference's own fixture, and other depths / shifts against the oracle
+    name = "no_hdr_sq_1.bam"
+    bg = open(os.path.join(GOLD, "bgzf", name), "rb").read()
+    assert gpu_bai(engine, plain_of(name), bg, iorc, 1, 14, 2)[1] == open(os.path.join(GOLD, "bgzf", name + ".csi.plain"), "rb").read()
+    for ms, nl in ((14, 5), (12, 6), (16, 4)):
+        want = iorc.idx(plain, bgzf, 1, ms, nl)
+        assert want is not None and gpu_bai(engine, plain, bgzf, iorc, 1, ms, nl)[1] == want
     # unsorted input is refused like `samtools index` does
     rc, n_ref, first = iorc.header(plain)
     n, _, off = iorc.frame(plain, first)
