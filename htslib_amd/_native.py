@@ -115,6 +115,8 @@ lib.hg_idx_build_dev.argtypes = [_vp, _vp, C.c_uint64, C.c_uint64, C.c_int32, _v
                                  C.c_int, _vp, C.c_size_t, _vp]
 lib.hg_csi_levels.argtypes = [C.c_uint64, C.c_int]
 
+lib.hg_cram_uncompress_blocks_crc_host.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+
 EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info", "hg_bgzf_scan",
            "hg_bgzf_inflate_dev", "hg_bgzf_inflate_host", "hg_crc32_dev", "hg_bgzf_deflate_dev", "hg_bgzf_pack_dev",
            "hg_bgzf_deflate_host", "hg_rans4x8_decode_dev", "hg_rans4x8_decode_host",
@@ -122,7 +124,7 @@ EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info
            "hg_ransnx16_compress_bound", "hg_ransnx16_encode_host", "hg_rans4x8_compress_bound",
            "hg_rans4x8_encode_host", "hg_gzip_compress_bound", "hg_gzip_deflate_host", "hg_cram_compress_bound",
            "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host", "hg_tok3_decode_host", "hg_tok3_compress_bound", "hg_tok3_encode_host", "hg_cram_metrics_new", "hg_cram_metrics_free",
-           "hg_cram_compress_blocks_metrics_host", "hg_bam_header_host", "hg_bam_frame_dev", "hg_bam_bases_dev", "hg_bam_core_dev", "hg_bam_quals_dev", "hg_bai_build_dev", "hg_idx_build_dev", "hg_csi_levels"]
+           "hg_cram_compress_blocks_metrics_host", "hg_bam_header_host", "hg_bam_frame_dev", "hg_bam_bases_dev", "hg_bam_core_dev", "hg_bam_quals_dev", "hg_bai_build_dev", "hg_idx_build_dev", "hg_csi_levels", "hg_cram_uncompress_blocks_crc_host"]
 
 
 class HgError(RuntimeError):
@@ -252,6 +254,23 @@ class Engine:
                                                 out_len.ctypes.data, status.ctypes.data)
         if rc not in (0, -6):
             check(rc, "hg_cram_uncompress_blocks_host")
+        return [outs[i].raw[:blocks[i][2]] if status[i] == 0 else None for i in range(n)], status
+
+    def cram_uncompress_blocks_crc(self, blocks):
+        """blocks: (method, comp_bytes, uncomp_size, crc_part, crc32) -- with cram_uncompress_block's CRC check."""
+        import numpy as np
+        n = len(blocks)
+        ins = [(C.c_char * max(len(b[1]), 1)).from_buffer_copy(b[1] if len(b[1]) else b"\0") for b in blocks]
+        outs = [C.create_string_buffer(max(b[2], 1)) for b in blocks]
+        in_ptr = (_vp * n)(*[C.addressof(x) for x in ins]); out_ptr = (_vp * n)(*[C.addressof(x) for x in outs])
+        method = np.array([b[0] for b in blocks], dtype=np.int32)
+        in_len = np.array([len(b[1]) for b in blocks], dtype=np.uint32); out_len = np.array([b[2] for b in blocks], dtype=np.uint32)
+        part = np.array([b[3] for b in blocks], dtype=np.uint32); crc = np.array([b[4] for b in blocks], dtype=np.uint32)
+        status = np.full(n, 99, dtype=np.int32)
+        rc = lib.hg_cram_uncompress_blocks_crc_host(self._h, n, method.ctypes.data, in_ptr, in_len.ctypes.data, part.ctypes.data, crc.ctypes.data,
+                                                    out_ptr, out_len.ctypes.data, status.ctypes.data)
+        if rc not in (0, -6):
+            check(rc, "hg_cram_uncompress_blocks_crc_host")
         return [outs[i].raw[:blocks[i][2]] if status[i] == 0 else None for i in range(n)], status
 
     def _ptr_batch(self, datas, bound):

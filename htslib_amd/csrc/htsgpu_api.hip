@@ -294,6 +294,43 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
     return HG_OK;
 }
 
+static uint32_t crc_combine_h(uint32_t crc1, uint32_t crc2, uint64_t len2);
+// cram_uncompress_block's first step (cram_io.c:1585-1592): crc32(b->crc_part, payload) must equal the stored CRC.
+int hg_cram_uncompress_blocks_crc_host(hg_ctx *ctx, size_t n, const int32_t *method, const uint8_t *const *in, const uint32_t *in_len,
+                                       const uint32_t *crc_part, const uint32_t *crc32, uint8_t *const *out, const uint32_t *out_len,
+                                       int32_t *status) {
+    if (!ctx || (n && (!method || !in || !in_len || !crc_part || !crc32 || !out || !out_len || !status))) return HG_EINVAL;
+    if (n == 0) return HG_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    // payload CRCs on the device, one wavefront per block
+    std::vector<uint64_t> off(n); uint64_t tot = 0;
+    for (size_t i = 0; i < n; i++) { off[i] = tot; tot += ((uint64_t)in_len[i] + 15u) & ~15ull; }
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, tot + 64)) || (rc = ensure_scratch(ctx, 2, n * 8 + 64)) || (rc = ensure_scratch(ctx, 3, n * 8 + 64))) return rc;
+    hipStream_t s = ctx->stream;
+    if ((rc = hg::stage_upload(ctx, in, in_len, off.data(), nullptr, n, tot, (uint8_t *)ctx->d_scratch[0], s))) return rc;
+    uint32_t *d_len = (uint32_t *)ctx->d_scratch[3], *d_crc = d_len + n;
+    std::vector<uint32_t> crc(n);
+    if (hipMemcpyAsync(ctx->d_scratch[2], off.data(), n * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_len, in_len, n * 4, hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
+    if ((rc = hg::launch_crc32(ctx, ctx->d_scratch[0], (const uint64_t *)ctx->d_scratch[2], d_len, n, d_crc, s))) return rc;
+    if (hipMemcpyAsync(crc.data(), d_crc, n * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+    // blocks that fail the check are not decoded (the reference returns -1 before looking at the method)
+    std::vector<int32_t> m2(method, method + n);
+    std::vector<uint32_t> ol2(out_len, out_len + n);
+    std::vector<char> bad(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t c = in_len[i] ? crc_combine_h(crc_part[i], crc[i], in_len[i]) : crc_part[i];
+        if (c != crc32[i]) { bad[i] = 1; m2[i] = HG_CRAM_RAW; ol2[i] = 0; }     // parked as an empty RAW block for the dispatcher
+    }
+    std::vector<uint32_t> il2(in_len, in_len + n);
+    for (size_t i = 0; i < n; i++) if (bad[i]) il2[i] = 0;
+    rc = hg_cram_uncompress_blocks_host(ctx, n, m2.data(), in, il2.data(), out, ol2.data(), status);
+    if (rc != HG_OK && rc != HG_EBLOCK) return rc;
+    for (size_t i = 0; i < n; i++) if (bad[i]) { status[i] = -1; rc = HG_EBLOCK; }
+    return rc;
+}
+
 int hg_bgzf_inflate_host(hg_ctx *ctx, const uint8_t *comp, size_t comp_len, uint8_t *out, size_t out_cap,
                          size_t *out_len, int32_t *status, size_t max_status, long *first_bad_idx,
                          int *first_bad_code) {

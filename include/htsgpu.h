@@ -230,6 +230,14 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
                                    const uint32_t *in_len, uint8_t *const *out, const uint32_t *out_len,
                                    int32_t *status);
 
+/* Same, preceded by cram_uncompress_block's CRC check (cram_io.c:1585-1592): crc_part[i] = CRC-32 of block i's header
+ * bytes as cram_read_block leaves it in b->crc_part, crc32[i] = the CRC stored after the payload.  The payload CRCs
+ * are computed on the device; a block whose CRC does not match gets status -1 ("Block CRC32 failure") and is not
+ * decoded. */
+int hg_cram_uncompress_blocks_crc_host(hg_ctx *ctx, size_t n, const int32_t *method, const uint8_t *const *in,
+                                       const uint32_t *in_len, const uint32_t *crc_part, const uint32_t *crc32,
+                                       uint8_t *const *out, const uint32_t *out_len, int32_t *status);
+
 /* gzip-wrapped deflate of whole buffers (CRAM block method GZIP on the write side: zlib_mem_deflate /
  * libdeflate_deflate, cram/cram_io.c:1113-1148,1222-1277).  Each buffer becomes ONE gzip member: it is
  * deflated in 0xff00-byte chunks by the BGZF deflate kernel (matches do not cross chunks, chunks are

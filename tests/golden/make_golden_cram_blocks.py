@@ -20,7 +20,8 @@ def main():
     for cram, _ in R.PAIRS:
         b = open(os.path.join(R.REF, cram), "rb").read()
         for nrec, blks in R.containers(b):
-            for (method, ctype, cid, csz, usz, data) in blks:
+            for blk in blks:
+                (method, ctype, cid, csz, usz, data) = blk
                 exp = None
                 if method == 0: exp = data
                 elif method == 1: exp = zlib.decompress(data, 15 + 32)
@@ -29,7 +30,8 @@ def main():
                     exp = bytes.fromhex(h) if h else None
                 if exp is not None: assert len(exp) == usz, (cram, method, cid)
                 out.append({"source": "test/" + cram, "method": method, "content_type": ctype, "content_id": cid,
-                            "usize": usz, "data_hex": data.hex(), "expected_hex": exp.hex() if exp is not None else None})
+                            "usize": usz, "data_hex": data.hex(), "expected_hex": exp.hex() if exp is not None else None,
+                            "hdr_hex": blk.hdr.hex(), "crc32": blk.crc})
     json.dump(out, open(OUT, "w"))
     from collections import Counter
     print(len(out), "blocks", Counter(o["method"] for o in out), "with plaintext:", sum(o["expected_hex"] is not None for o in out))

@@ -53,6 +53,14 @@ def parse_comp_header(d):
     return enc
 
 
+class Blk(tuple):
+    """(method, content_type, content_id, csize, usize, payload) + .hdr (the block header bytes) + .crc (the stored CRC-32)"""
+    def __new__(cls, t, hdr, crc):
+        o = super().__new__(cls, t)
+        o.hdr, o.crc = hdr, crc
+        return o
+
+
 def containers(b):
     p = 26
     while p < len(b):
@@ -64,9 +72,10 @@ def containers(b):
         p += 4
         end = p + clen; q = p; blks = []
         while q < end and len(blks) < nblk:
+            q0 = q
             method, ctype = b[q], b[q + 1]; q += 2
             cid, q = itf8(b, q); csz, q = itf8(b, q); usz, q = itf8(b, q)
-            blks.append((method, ctype, cid, csz, usz, bytes(b[q:q + csz]))); q += csz + 4
+            blks.append(Blk((method, ctype, cid, csz, usz, bytes(b[q:q + csz])), bytes(b[q0:q]), struct.unpack_from("<I", b, q + csz)[0])); q += csz + 4
         yield nrec, blks
         p = end
 

@@ -189,3 +189,29 @@ def test_cram_metrics_many_slices_in_one_call_match_one_at_a_time(engine):
     Bm = C.cast(mb, C.POINTER(nat.CramMetrics)).contents
     assert bytes(A) == bytes(Bm)
     nat.lib.hg_cram_metrics_free(ma); nat.lib.hg_cram_metrics_free(mb)
+
+
+def test_block_crc_check_on_the_reference_fixtures(engine):
+    """cram_uncompress_block verifies crc32(header || payload) first (cram_io.c:1585-1592).  All 195 blocks of the
+    reference's CRAM fixtures carry their writer's CRC: they must pass, a flipped payload bit or a wrong CRC must not."""
+    import json, os
+    blocks = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cram_blocks.json")))
+    rows, want = [], []
+    for b in blocks:
+        data, hdr = bytes.fromhex(b["data_hex"]), bytes.fromhex(b["hdr_hex"])
+        rows.append((b["method"], data, b["usize"], zlib.crc32(hdr), b["crc32"]))
+        want.append(bytes.fromhex(b["expected_hex"]) if b["expected_hex"] is not None else None)
+    outs, st = engine.cram_uncompress_blocks_crc(rows)
+    assert (st == 0).all()
+    assert all(w is None or o == w for o, w in zip(outs, want))
+    # corrupt: a payload bit (blocks 3, 50), the stored CRC (block 7), the header CRC (block 90)
+    bad = list(rows)
+    for k in (3, 50):
+        d = bytearray(bad[k][1]); d[len(d) // 2] ^= 0x10
+        bad[k] = (bad[k][0], bytes(d), bad[k][2], bad[k][3], bad[k][4])
+    bad[7] = bad[7][:4] + (bad[7][4] ^ 1,)
+    bad[90] = bad[90][:3] + (bad[90][3] ^ 0x80000000, bad[90][4])
+    outs2, st2 = engine.cram_uncompress_blocks_crc(bad)
+    flagged = {int(i) for i in np.nonzero(st2)[0]}
+    assert flagged == {3, 7, 50, 90} and all(st2[i] == -1 for i in flagged)
+    assert all(outs2[i] == outs[i] for i in range(len(rows)) if i not in flagged)
