@@ -279,7 +279,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": hbm_traffic(total_u),
                          "kernel": "hg::bgzf_inflate_kernel", "kernel_ms": round(k_ms, 3),
-                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "traffic_note": "FETCH_SIZE + WRITE_SIZE PMC passes at face value; FETCH_SIZE is not a byte count for this access mix "
+                                         "(profiles/hbm_traffic_inflate.json: calibration)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample: at most 4 GiB plain of the same stream
