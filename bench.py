@@ -139,6 +139,15 @@ def cpu_baseline(bgzf_sample: bytes, plain_len: int, threads: int):
                       f"{plain_len / 2**30:.2f} GiB of the same BAM from /dev/shm, best of 3"}
 
 
+def hbm_traffic_rans(plain_bytes):
+    """Same for the rANS Nx16 decode kernel (profiles/hbm_traffic_rans.json: FETCH_SIZE doubled as calibrated, + WRITE_SIZE)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_rans.json")))
+        return int(t["traffic_bytes_per_plain_byte"] * plain_bytes)
+    except Exception:
+        return None
+
+
 def hbm_traffic(plain_bytes):
     """HBM bytes per launch from the committed PMC passes (profiles/hbm_traffic_inflate.json:
     FETCH_SIZE + WRITE_SIZE per plain byte at the 10 GiB config), scaled to this workload; None if absent."""
@@ -401,7 +410,7 @@ def bench_rans(args, rank, world, local, ncores):
                                       "with htscodecs UNPINNED", "streams_per_gpu": n, "plain_bytes_per_gpu": total_u,
                           "compressed_bytes_per_gpu": total_c, "verified": bool(ok), "prep_seconds": round(t_prep, 1)},
                "roofline": {"bound": "hbm", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                            "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": hbm_traffic_rans(total_u),
                             "kernel": "hgn::ransnx16_decode_kernel<32>", "kernel_ms": round(k_ms, 3),
                             "algorithmic_bytes_per_launch": int(alg)}}
         if world == 1 and not args.no_cpu_baseline:
