@@ -65,6 +65,12 @@ constexpr int WAVES_PER_WG = 4;
 #ifndef HG_RING
 #define HG_RING 1024
 #endif
+#ifndef HG_LOOP
+#define HG_LOOP 0        // 2: inflate_loop_mix.inc (vector bit buffer, scalar everything else)
+#endif
+#ifndef HG_MIX_VPOS
+#define HG_MIX_VPOS 1
+#endif
 #ifndef HG_WALK
 #define HG_WALK 0        // 0: vector-uniform serial loop (inflate_loop_vec.inc)  1: gather + scalar walk
 #endif
@@ -418,7 +424,9 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                 for (uint32_t p = lo + (uint32_t)lane; p < pos; p += 64) S.u.ring[p & (RING - 1u)] = out[p];
             }
             wave_sync();
-#if HG_WALK
+#if HG_LOOP == 2
+#include "inflate_loop_mix.inc"
+#elif HG_WALK
 #include "inflate_loop_walk.inc"
 #else
 #include "inflate_loop_vec.inc"
