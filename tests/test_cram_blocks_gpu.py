@@ -28,7 +28,7 @@ def test_reference_cram_fixture_blocks(engine):
             assert o.hex() == v["expected_hex"]; checked += 1
         elif v["method"] == 4 and v["usize"]:
             assert o == rorc.decode(bytes.fromhex(v["data_hex"]))[1]
-    assert checked >= 149
+    assert checked >= 500
 
 
 def test_large_gzip_members_and_mixed_batch(engine):
@@ -192,7 +192,7 @@ def test_cram_metrics_many_slices_in_one_call_match_one_at_a_time(engine):
 
 
 def test_block_crc_check_on_the_reference_fixtures(engine):
-    """cram_uncompress_block verifies crc32(header || payload) first (cram_io.c:1585-1592).  All 195 blocks of the
+    """cram_uncompress_block verifies crc32(header || payload) first (cram_io.c:1585-1592).  All 565 blocks of the
     reference's CRAM fixtures carry their writer's CRC: they must pass, a flipped payload bit or a wrong CRC must not."""
     import json, os
     blocks = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cram_blocks.json")))
