@@ -66,10 +66,7 @@ constexpr int WAVES_PER_WG = 4;
 #define HG_RING 1024
 #endif
 #ifndef HG_LOOP
-#define HG_LOOP 0        // 2: inflate_loop_mix.inc (vector bit buffer, scalar everything else)
-#endif
-#ifndef HG_MIX_VPOS
-#define HG_MIX_VPOS 1
+#define HG_LOOP 0        // 0: inflate_loop_vec.inc (all vector-uniform, default)  2: inflate_loop_mix.inc (per-knob vector / scalar split)
 #endif
 #ifndef HG_WALK
 #define HG_WALK 0        // 0: vector-uniform serial loop (inflate_loop_vec.inc)  1: gather + scalar walk
