@@ -12,11 +12,18 @@ FRONT   := htslib_amd/libhts_bgzf.so
 all: $(LIB) $(FRONT) oracle
 
 # htslib's BGZF front-end API (bgzf_open/read/write/...) over the engine: host C++ only
-$(FRONT): $(CSRC)/bgzf_front.cpp include/hts_bgzf_gpu.h include/htsgpu.h $(LIB)
-	g++ -O2 -std=c++17 -fPIC -shared -Wall -Iinclude $(CSRC)/bgzf_front.cpp -o $@ -Lhtslib_amd -lhtsgpu -Wl,-rpath,'$$ORIGIN'
+# (hfile_min.cpp = bundled local-file hFILE provider; a libhts build links hfile.c instead, see oracle/Makefile)
+$(FRONT): $(CSRC)/bgzf_front.cpp $(CSRC)/hfile_min.cpp include/hts_bgzf_gpu.h include/hts_hfile_abi.h include/htsgpu.h $(LIB)
+	g++ -O2 -std=c++17 -fPIC -shared -Wall -Iinclude $(CSRC)/bgzf_front.cpp $(CSRC)/hfile_min.cpp -o $@ -Lhtslib_amd -lhtsgpu -lpthread -Wl,-rpath,'$$ORIGIN'
 
-$(LIB): $(HIPSRC) $(HDRS)
-	$(HIPCC) $(HIPFLAGS) -shared $(HIPSRC) -o $@
+# one object per source (make -j builds them in parallel; a kernel edit recompiles one file)
+OBJDIR  := build/obj
+HIPOBJ  := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(HIPSRC))
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(LIB): $(HIPOBJ)
+	$(HIPCC) $(HIPFLAGS) -shared $(HIPOBJ) -o $@
 
 oracle:
 	$(MAKE) -C oracle all

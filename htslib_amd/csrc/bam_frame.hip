@@ -247,7 +247,7 @@ int hg_bam_header_host(const uint8_t *bam, size_t len, int32_t *n_ref, uint64_t 
 long hg_bam_frame_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, uint64_t first_record_off, int32_t n_ref, uint64_t *d_rec_off,
                       uint64_t max_rec, uint64_t *bad_off, void *stream) {
     if (!ctx || !d_bam || first_record_off > len) return HG_EINVAL;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t CH = 1u << 16;
     const uint64_t nch64 = (len + CH - 1) / CH;
@@ -323,7 +323,7 @@ int hg_bam_quals_dev(hg_ctx *ctx, const void *d_bam, const uint64_t *d_rec_off, 
 int hg_bam_bases_dev(hg_ctx *ctx, const void *d_bam, const uint64_t *d_rec_off, uint64_t n, uint64_t *d_base_off, void *d_bases,
                      uint64_t bases_cap, uint64_t *total_bases, void *stream) {
     if (!ctx || (n && (!d_bam || !d_rec_off || !d_base_off))) return HG_EINVAL;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     hipStream_t s = (hipStream_t)stream;
     uint64_t total = 0;
     if (n) {

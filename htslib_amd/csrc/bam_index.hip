@@ -141,7 +141,7 @@ extern "C" long hg_idx_build_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, u
                                  int csi, int min_shift, int n_lvls, uint8_t *out, size_t out_cap, void *stream) {
     if (min_shift < 1 || min_shift > 30 || n_lvls < 1 || n_lvls > 9) return HG_EINVAL;
     if (!ctx || n_ref < 0 || (n_ref && !ref_len) || (nrec && (!d_bam || !d_rec_off)) || (nblocks && !blocks) || !out) return HG_EINVAL;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     hipStream_t s = (hipStream_t)stream;
     using hgi::Blk; using hgi::Run;
     std::vector<Blk> blk(nblocks);

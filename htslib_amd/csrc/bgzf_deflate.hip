@@ -613,17 +613,28 @@ int launch_bgzf_deflate(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_
     size_t wgs = (size_t)ctx->cus * 2;
     if (wgs > nblocks) wgs = nblocks;
     size_t need = (size_t)ctx->cus * 2 * 65536 * sizeof(uint32_t);
-    if (ctx->d_tok_cap < need) {
-        if (ctx->d_tok) (void)hipFree(ctx->d_tok);
-        ctx->d_tok = nullptr; ctx->d_tok_cap = 0;
-        if (hipMalloc(&ctx->d_tok, need) != hipSuccess) return HG_ENOMEM;
-        ctx->d_tok_cap = need;
+    {
+        std::lock_guard<std::mutex> order(*ctx->tok_mu);
+        if (ctx->d_tok_cap < need) {                                   // allocated once (the size depends on the device only)
+            if (hipMalloc(&ctx->d_tok, need) != hipSuccess) return HG_ENOMEM;
+            ctx->d_tok_cap = need;
+        }
     }
-    if (hipMemsetAsync(ctx->d_ticket + 4, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
-    hipLaunchKernelGGL(hgd::bgzf_deflate_kernel, dim3((unsigned)wgs), dim3(hgd::WG), 0, s, (const uint8_t *)d_plain,
-                       d_desc, (uint32_t)nblocks, (uint8_t *)d_slots, d_clen, (uint32_t *)ctx->d_tok,
-                       ctx->d_ticket + 4, level, mode, d_crc);
-    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+    // The token lists (ctx->d_tok) are indexed by workgroup, so two deflate launches of one context must not overlap:
+    // each launch waits for the previous one's completion event, whatever streams the callers use.
+    {
+        std::lock_guard<std::mutex> order(*ctx->tok_mu);
+        if (ctx->ev_deflate_used && hipStreamWaitEvent(s, ctx->ev_deflate, 0) != hipSuccess) return HG_ELAUNCH;
+        unsigned int *ticket = next_ticket(ctx);
+        if (hipMemsetAsync(ticket, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
+        hipLaunchKernelGGL(hgd::bgzf_deflate_kernel, dim3((unsigned)wgs), dim3(hgd::WG), 0, s, (const uint8_t *)d_plain,
+                           d_desc, (uint32_t)nblocks, (uint8_t *)d_slots, d_clen, (uint32_t *)ctx->d_tok,
+                           ticket, level, mode, d_crc);
+        if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
+        if (hipEventRecord(ctx->ev_deflate, s) != hipSuccess) return HG_ELAUNCH;
+        ctx->ev_deflate_used = 1;
+    }
+    return HG_OK;
 }
 
 int launch_bgzf_pack(hg_ctx *ctx, const void *d_slots, const hg_bgzf_desc *d_desc, const uint32_t *d_clen,

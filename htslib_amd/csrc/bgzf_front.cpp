@@ -8,592 +8,1131 @@
 //   write state machine      bgzf.c:1927-2124   (blocks cut at 0xff00, bgzf_flush_try keeps records
 //                                                whole, close appends the 28-byte EOF block)
 //   seek / virtual offsets   bgzf.c:2175-2258   htslib/bgzf.h:261
-//   .gzi index               bgzf.c:2336-2542
+//   .gzi index               bgzf.c:2336-2542   deferred index offsets bgzf.c:189-290
 //   error bits               htslib/bgzf.h:53-58
-// What differs is the engine: instead of one pool job per block (bgzf.c:1598-1738, 1852-1925) the
-// reader inflates a read-ahead WINDOW of blocks per kernel launch and the writer deflates a queue
-// of blocks per launch (include/htsgpu.h).
+//
+// Engine.  Every compressed handle is the reference's *threaded* mode re-thought for a device that wants
+// thousands of blocks per launch:
+//   reader : an I/O thread hread()s a window of the file into a pipe's pinned buffer, frames the blocks and
+//            submits ONE inflate job (H2D, kernel, D2H on the pipe's stream); three pipes rotate, so reading
+//            window n+2, moving / inflating window n+1 and consuming window n overlap.  The consumer never
+//            copies a block: fp->uncompressed_block points into the pipe's pinned plain image (the
+//            reference steals the job's buffer the same way, bgzf.c:1077-1089), and because that image is
+//            contiguous bgzf_read / bgzf_getline work on SPANS of blocks, not block by block.
+//            The window starts small after open / seek (random access stays cheap) and grows 4x per batch.
+//   writer : bgzf_write cuts blocks straight into a pipe's pinned input buffer; a full buffer is one
+//            deflate job; an output thread collects jobs in order, resolves deferred index entries with
+//            the now-known block addresses and hwrite()s each batch with one call.
+//   gzip   : plain gzip streams (read) and mode "g" (write) use the engine's single-wavefront stream codec.
 #include <errno.h>
 #include <fcntl.h>
+#include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "hts_bgzf_gpu.h"
+#include "hts_hfile_abi.h"
 #include "htsgpu.h"
+
+// libhts symbols used when present (inside a libhts build they always are)
+extern "C" {
+void hts_log(int severity, const char *context, const char *format, ...) __attribute__((weak));
+int hts_idx_push(void *idx, int tid, int64_t beg, int64_t end, uint64_t offset, int is_mapped) __attribute__((weak));
+int hg_crc32_host(hg_ctx *ctx, const void *buf, size_t len, uint32_t *crc);
+}
+
+struct GziEntry { uint64_t caddr, uaddr; };
+struct bgzidx_t {                      // behind fp->idx; opaque to callers (bgzf.c:169-174)
+    std::vector<GziEntry> offs;        // offs[0] = {0, 0}
+    uint64_t ublock_addr = 0;          // uncompressed offset of the block being read
+    size_t recut = 0;                  // bgzf_block_write: which indexed block is being filled
+    bool loaded = false;
+};
 
 namespace {
 
-constexpr size_t READ_WINDOW = 32u << 20;     // compressed bytes inflated per launch
-constexpr size_t WRITE_QUEUE = 512;           // blocks deflated per launch (32 MiB of input)
+constexpr int NPIPES = 3;
+constexpr size_t WINDOW_MIN = 256u << 10;      // compressed bytes of the first batch after open / seek
+constexpr size_t WINDOW_MAX = 32u << 20;
+constexpr uint64_t PLAIN_MAX = 768ull << 20;   // plain bytes per batch (highly compressible input)
+constexpr size_t WBLOCKS_MIN = 16, WBLOCKS_MAX = 512;
 const uint8_t kEof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0,
                           0, 0, 0, 0, 0, 0, 0, 0};
+enum { LOG_ERROR = 1, LOG_WARNING = 3 };
 
-struct IdxEntry { uint64_t caddr, uaddr; };
-
-struct Front {
-    int fd = -1;
-    bool own_fd = true;
-    hg_ctx *gpu = nullptr;
-    // ---- reader ----
-    std::vector<uint8_t> win;          // compressed window; win[0] is file offset win_off
-    int64_t win_off = 0;
-    size_t win_len = 0;
-    bool fd_eof = false;
-    std::vector<hg_bgzf_desc> desc;    // blocks of the current batch (offsets relative to batch_off)
-    std::vector<int32_t> status;
-    std::vector<uint8_t> plain;
-    int64_t batch_off = 0;             // file offset of the batch's first block
-    size_t cur = 0, nblk = 0;          // current block index inside the batch
-    bool cur_loaded = false;
-    int64_t next_addr = 0;             // file offset of the block after the current one
-    bool warned_eof = false;
-    // ---- writer ----
-    std::vector<uint8_t> q_plain;
-    std::vector<uint64_t> q_cuts;      // q_cuts[0] = 0
-    int64_t file_off = 0;              // compressed bytes written so far
-    std::vector<uint8_t> out;
-    // ---- index ----
-    std::vector<IdxEntry> idx;
-    uint64_t ublock_addr = 0;
-    bool idx_loaded = false;
-};
-
-hg_ctx *shared_ctx() {                   // one engine context per process, created on demand
-    static hg_ctx *ctx = nullptr;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
-        const char *dev = getenv("HTS_GPU_DEVICE");
-        if (hg_init(dev ? atoi(dev) : 0, &ctx) != HG_OK) ctx = nullptr;
-    }
-    return ctx;
+void logmsg(int level, const char *ctx, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (hts_log) hts_log(level, ctx, "%s", buf);
+    else fprintf(stderr, "[%c::%s] %s\n", level == LOG_ERROR ? 'E' : 'W', ctx, buf);
 }
 
-inline Front *F(BGZF *fp) { return reinterpret_cast<Front *>(fp->fp); }
-
-ssize_t read_full(int fd, uint8_t *p, size_t n) {
-    size_t got = 0;
-    while (got < n) {
-        ssize_t r = read(fd, p + got, n - got);
-        if (r < 0) { if (errno == EINTR) continue; return -1; }
-        if (r == 0) break;
-        got += (size_t)r;
-    }
-    return (ssize_t)got;
+uint32_t crc_mulmod(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) { if (a & (0x80000000u >> i)) p ^= b; b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1; }
+    return p;
 }
-int write_full(int fd, const uint8_t *p, size_t n) {
-    while (n) {
-        ssize_t r = write(fd, p, n);
-        if (r < 0) { if (errno == EINTR) continue; return -1; }
-        p += r; n -= (size_t)r;
-    }
-    return 0;
+uint32_t crc_concat(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {           // crc(A||B)
+    uint32_t xp = 0x00800000u, acc = 0x80000000u;
+    for (; len_b; len_b >>= 1) { if (len_b & 1) acc = crc_mulmod(acc, xp); xp = crc_mulmod(xp, xp); }
+    return crc_mulmod(acc, crc_a) ^ crc_b;
 }
 
-bool header_ok(const uint8_t *h) {        // check_header, bgzf.c:896-903
+bool bgzf_header_ok(const uint8_t *h) {   // check_header, bgzf.c:896-903
     return h[0] == 31 && h[1] == 139 && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 && h[12] == 'B' &&
            h[13] == 'C' && h[14] == 2 && h[15] == 0;
 }
 
-int mode2level(const char *mode) {        // bgzf.c:426-434
-    int level = -1;
-    for (const char *m = mode; *m; m++)
-        if (*m >= '0' && *m <= '9') level = *m - '0';
-    if (strchr(mode, 'u')) level = -2;
-    return level;
+int device_choice() { const char *d = getenv("HTS_GPU_DEVICE"); return d ? atoi(d) : 0; }
+
+// process-wide context for the stateless entry points (bgzf_compress, hts_crc32); its host calls lock it
+hg_ctx *shared_ctx() {
+    static hg_ctx *ctx = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] { if (hg_init(device_choice(), &ctx) != HG_OK) ctx = nullptr; });
+    return ctx;
 }
 
-BGZF *new_handle(int fd, bool own, const char *mode) {
-    const bool wr = strchr(mode, 'w') || strchr(mode, 'a');
-    if (strchr(mode, 'g')) { errno = ENOTSUP; return nullptr; }             // plain gzip output unsupported
-    BGZF *fp = (BGZF *)calloc(1, sizeof(BGZF));
-    Front *f = new Front();
-    if (!fp) { delete f; return nullptr; }
-    f->fd = fd; f->own_fd = own;
-    fp->fp = reinterpret_cast<struct hFILE *>(f);
-    { const uint16_t one = 1; fp->is_be = *(const uint8_t *)&one == 0; }
-    fp->uncompressed_block = malloc(2 * BGZF_MAX_BLOCK_SIZE);
-    if (!fp->uncompressed_block) { delete f; free(fp); return nullptr; }
-    fp->compressed_block = (uint8_t *)fp->uncompressed_block + BGZF_MAX_BLOCK_SIZE;
-    if (wr) {
-        fp->is_write = 1;
-        const int level = mode2level(mode);
-        if (level == -2) fp->is_compressed = 0;
-        else { fp->is_compressed = 1; fp->compress_level = level < 0 || level > 9 ? -1 : level; }
-        f->q_cuts.push_back(0);
-        if (strchr(mode, 'a')) f->file_off = (int64_t)lseek(fd, 0, SEEK_END);
-        fp->block_address = f->file_off;
-    } else {
-        // sniff the magic (bgzf_read_init, bgzf.c:383-424)
-        f->win.resize(READ_WINDOW + BGZF_MAX_BLOCK_SIZE);
-        ssize_t n = read_full(fd, f->win.data(), 18);
-        if (n < 0) { free(fp->uncompressed_block); delete f; free(fp); return nullptr; }
-        f->win_len = (size_t)n;
-        if (n >= 2 && f->win[0] == 31 && f->win[1] == 139) {
-            if (n == 18 && header_ok(f->win.data())) fp->is_compressed = 1;
-            else { errno = ENOTSUP; free(fp->uncompressed_block); delete f; free(fp); return nullptr; }  // plain gzip
-        } else fp->is_compressed = 0;
-    }
-    if (fp->is_compressed) {
-        f->gpu = shared_ctx();
-        if (!f->gpu) { errno = ENODEV; free(fp->uncompressed_block); delete f; free(fp); return nullptr; }
-    }
-    return fp;
-}
+struct ReadBatch {
+    hg_pipe *pipe = nullptr;
+    std::vector<hg_bgzf_desc> desc;
+    int64_t file_off = 0;          // file offset of desc[0]
+    size_t comp_len = 0;           // bytes covered by desc
+    int fail = 0;                  // BGZF_ERR_* met while reading / framing BEHIND the last good block
+    bool submitted = false;
+    // after hg_pipe_wait:
+    const uint8_t *plain = nullptr;
+    const int32_t *status = nullptr;
+    size_t good = 0;               // leading blocks with status 0
+};
 
-// ---------------------------------------------------------------------------- reader engine
-// Load the next batch of whole blocks starting at file offset `at` (== win_off + consumed).
-int load_batch(BGZF *fp) {
-    Front *f = F(fp);
-    // top the window up
-    if (!f->fd_eof && f->win_len < READ_WINDOW) {
-        ssize_t n = read_full(f->fd, f->win.data() + f->win_len, READ_WINDOW - f->win_len);
-        if (n < 0) { fp->errcode |= BGZF_ERR_IO; return -1; }
-        if ((size_t)n < READ_WINDOW - f->win_len) f->fd_eof = true;
-        f->win_len += (size_t)n;
+struct IdxPush { void *hidx; int tid; int64_t beg, end; uint32_t offset; int mapped; uint64_t block_number; };
+
+struct WriteBatch {
+    hg_pipe *pipe = nullptr;
+    uint8_t *in = nullptr;         // the pipe's pinned input buffer
+    size_t cap = 0, len = 0, target = 0;
+    std::vector<uint64_t> cuts;
+};
+
+enum Kind { K_READ, K_WRITE, K_GZREAD, K_GZWRITE };
+
+struct Engine {
+    BGZF *fp = nullptr;
+    Kind kind = K_READ;
+    hg_ctx *gpu = nullptr;
+    void *own_block = nullptr;     // the malloc'd 128 KiB block (fp->uncompressed_block is re-pointed by readers)
+    std::thread th;
+    bool started = false;
+    std::mutex m;
+    std::condition_variable cv;
+    bool stop = false;
+    // ---------------- reader
+    ReadBatch rb[NPIPES];
+    uint64_t fill_seq = 0, done_seq = 0;   // batches filled by the I/O thread / released by the consumer
+    bool cur_loaded = false;               // rb[done_seq % NPIPES] has been waited for and is being consumed
+    bool input_done = false;               // the I/O thread met EOF or a fatal input error
+    bool pause_req = false, paused = false;
+    size_t window = WINDOW_MIN;
+    std::vector<uint8_t> carry;            // bytes of a block cut by the window end
+    int64_t read_off = 0;                  // file offset of carry[0] / of the next byte to hread
+    size_t blk = 0;                        // current block inside the current batch
+    bool blk_pending = false;              // a seek positioned us BEFORE rb.desc[blk]
+    int64_t next_addr = 0;                 // file offset of the block after the current one
+    bool eof_seen = false;
+    // ---------------- writer
+    WriteBatch wb[NPIPES];
+    uint64_t w_fill = 0, w_done = 0;       // batches submitted / written out
+    bool w_open = false;                   // wb[w_fill % NPIPES] is being filled
+    size_t w_target = WBLOCKS_MIN;
+    int64_t block_address = 0;             // compressed bytes written so far (owned by the output thread)
+    int w_err = 0;                         // BGZF_ERR_* raised by the output thread
+    uint64_t block_number = 0;             // blocks queued so far (bgzf.c:1856)
+    uint64_t block_written = 0;
+    std::mutex idx_m;
+    std::vector<IdxPush> pushes;
+    // gzip member being written (mode "g")
+    bool gz_header_done = false;
+    uint32_t gz_crc = 0; uint64_t gz_isize = 0;
+    // ---------------- plain gzip reader
+    std::vector<uint8_t> gz_comp; int64_t gz_base = 0; bool gz_eof = false, gz_finished = false;
+    hg_gz_state gz_st{};
+    std::vector<uint8_t> gz_out; size_t gz_out_pos = 0;
+    std::vector<uint8_t> gz_hist;
+};
+
+// The engine hangs on fp->cache (an opaque pointer the reference uses for its block cache, which has no role
+// here).  fp->mt is the reference's "threaded semantics" marker that callers test (sam.c:942, vcf.c:4596): set for
+// every compressed reader, and for a writer once bgzf_mt() / bgzf_thread_pool() has been called -- see queue_block().
+inline Engine *E(BGZF *fp) { return reinterpret_cast<Engine *>(fp->cache); }
+
+// ================================================================================ reader: I/O thread
+// Fill one batch: read a window, frame whole blocks, submit the inflate job.  Returns true when no further batch
+// can follow (end of input or a fatal input error); the caller publishes that together with the batch.
+bool fill_batch(Engine *e, ReadBatch &b) {
+    bool finished = false;
+    BGZF *fp = e->fp;
+    b.desc.clear(); b.fail = 0; b.submitted = false; b.comp_len = 0; b.good = 0;
+    b.file_off = e->read_off;
+    const size_t want = e->window;
+    uint8_t *buf = (uint8_t *)hg_pipe_input(b.pipe, e->carry.size() + want + BGZF_MAX_BLOCK_SIZE);
+    if (!buf) { b.fail = BGZF_ERR_IO; return true; }
+    size_t have = e->carry.size();
+    if (have) memcpy(buf, e->carry.data(), have);
+    e->carry.clear();
+    bool at_eof = false;
+    {
+        ssize_t n = hg_hread(fp->fp, buf + have, want);
+        if (n < 0) { b.fail = BGZF_ERR_IO; return true; }
+        if ((size_t)n < want) at_eof = true;
+        have += (size_t)n;
     }
-    f->desc.clear(); f->nblk = 0; f->cur = 0; f->cur_loaded = false;
-    if (f->win_len == 0) return 0;                                   // clean EOF
-    // frame whole blocks
-    size_t pos = 0; uint64_t u = 0;
-    while (pos + 18 <= f->win_len) {
-        const uint8_t *h = f->win.data() + pos;
-        if (!header_ok(h)) { if (pos == 0) { fp->errcode |= BGZF_ERR_HEADER; return -1; } break; }
-        size_t bs = (size_t)(h[16] | (h[17] << 8)) + 1;
-        if (bs < 26) { if (pos == 0) { fp->errcode |= BGZF_ERR_HEADER; return -1; } break; }
-        if (pos + bs > f->win_len) break;
+    size_t pos = 0; uint64_t plain = 0;
+    bool capped = false;
+    while (have - pos >= 18) {
+        const uint8_t *h = buf + pos;
+        if (!bgzf_header_ok(h)) { b.fail = BGZF_ERR_HEADER; break; }
+        const size_t bs = (size_t)(h[16] | (h[17] << 8)) + 1;
+        if (bs < 26) { b.fail = BGZF_ERR_HEADER; break; }
+        if (bs > have - pos) break;                                       // cut by the window end
         const uint8_t *t = h + bs - 4;
-        uint32_t isize = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-        if (isize > BGZF_MAX_BLOCK_SIZE) { if (pos == 0) { fp->errcode |= BGZF_ERR_HEADER; return -1; } break; }
-        hg_bgzf_desc d; d.coff = pos; d.uoff = u; d.clen = (uint32_t)bs; d.ulen = isize;
-        f->desc.push_back(d);
-        u += isize; pos += bs;
+        const uint32_t isize = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (isize > BGZF_MAX_BLOCK_SIZE) { b.fail = BGZF_ERR_ZLIB; break; }
+        if (plain + isize > PLAIN_MAX && !b.desc.empty()) { capped = true; break; }
+        hg_bgzf_desc d; d.coff = pos; d.uoff = plain; d.clen = (uint32_t)bs; d.ulen = isize;
+        b.desc.push_back(d);
+        plain += isize; pos += bs;
     }
-    if (f->desc.empty()) {                                            // truncated block at EOF
-        fp->errcode |= f->fd_eof ? BGZF_ERR_IO : BGZF_ERR_HEADER;
-        return -1;
+    // the file ends inside a block header or payload (bgzf.c:1140-1163, 1206-1212)
+    if (!b.fail && at_eof && !capped && pos < have) b.fail = have - pos >= 18 ? BGZF_ERR_IO : BGZF_ERR_HEADER;
+    if (b.fail || (at_eof && !capped)) finished = true;
+    else if (pos < have) e->carry.assign(buf + pos, buf + have);
+    b.comp_len = pos;
+    e->read_off += (int64_t)pos;
+    if (!b.desc.empty()) {
+        if (hg_pipe_inflate(b.pipe, pos, b.desc.data(), b.desc.size()) != HG_OK) {
+            b.desc.clear(); b.fail = BGZF_ERR_ZLIB; finished = true;
+        } else b.submitted = true;
     }
-    f->nblk = f->desc.size();
-    f->plain.resize((size_t)u + 64);
-    f->status.assign(f->nblk, 0);
-    size_t out_len = 0; long bad_i = -1; int bad_c = 0;
-    int rc = hg_bgzf_inflate_host(f->gpu, f->win.data(), pos, f->plain.data(), f->plain.size(), &out_len,
-                                  f->status.data(), f->nblk, &bad_i, &bad_c);
-    if (rc != HG_OK && rc != HG_EBLOCK) { fp->errcode |= BGZF_ERR_ZLIB; return -1; }
-    f->batch_off = f->win_off;
-    // keep the unconsumed tail for the next batch
-    memmove(f->win.data(), f->win.data() + pos, f->win_len - pos);
-    f->win_len -= pos; f->win_off += (int64_t)pos;
+    if (e->window < WINDOW_MAX) e->window = e->window * 4 > WINDOW_MAX ? WINDOW_MAX : e->window * 4;
+    return finished;
+}
+
+void reader_main(Engine *e) {
+    std::unique_lock<std::mutex> lk(e->m);
+    for (;;) {
+        e->cv.wait(lk, [&] { return e->stop || e->pause_req || (!e->input_done && e->fill_seq - e->done_seq < NPIPES); });
+        if (e->stop) break;
+        if (e->pause_req) {
+            e->paused = true; e->cv.notify_all();
+            e->cv.wait(lk, [&] { return !e->pause_req || e->stop; });
+            e->paused = false;
+            continue;
+        }
+        ReadBatch &b = e->rb[e->fill_seq % NPIPES];
+        lk.unlock();
+        const bool finished = fill_batch(e, b);
+        lk.lock();
+        if (finished) e->input_done = true;                               // published with the batch, never before it
+        e->fill_seq++;
+        e->cv.notify_all();
+    }
+}
+
+bool start_reader(Engine *e) {
+    if (e->started) return true;
+    for (auto &b : e->rb) if (!b.pipe && hg_pipe_create(e->gpu, &b.pipe) != HG_OK) return false;
+    e->read_off = hg_htell(e->fp->fp);
+    e->started = true;
+    e->th = std::thread(reader_main, e);
+    return true;
+}
+
+// Park the I/O thread (seek, EOF check); returns with e->m held by `lk`.
+void pause_reader(Engine *e, std::unique_lock<std::mutex> &lk) {
+    if (!e->started) return;
+    e->pause_req = true; e->cv.notify_all();
+    e->cv.wait(lk, [&] { return e->paused; });
+}
+void resume_reader(Engine *e) { e->pause_req = false; e->cv.notify_all(); }
+
+// Drop every batch (filled or in flight) and restart reading at file offset `addr`.
+int restart_reader_at(Engine *e, int64_t addr) {
+    std::unique_lock<std::mutex> lk(e->m);
+    pause_reader(e, lk);
+    for (uint64_t s = e->done_seq + (e->cur_loaded ? 1 : 0); s < e->fill_seq; s++) {
+        ReadBatch &b = e->rb[s % NPIPES];
+        if (b.submitted) { (void)hg_pipe_wait(b.pipe, nullptr, nullptr, nullptr, nullptr, nullptr); b.submitted = false; }
+    }
+    e->fill_seq = e->done_seq = 0; e->cur_loaded = false;
+    e->carry.clear(); e->input_done = false; e->window = WINDOW_MIN; e->eof_seen = false;
+    e->blk = 0; e->blk_pending = false;
+    int rc = 0;
+    if (hseek(e->fp->fp, (off_t)addr, SEEK_SET) < 0) rc = -1;
+    e->read_off = addr;
+    if (rc != 0) e->input_done = true;
+    resume_reader(e);
+    return rc;
+}
+
+// Make the next batch current.  Returns 1 = batch loaded, 0 = end of input, -1 = error (errcode set).
+int next_batch(Engine *e) {
+    BGZF *fp = e->fp;
+    if (!start_reader(e)) { fp->errcode |= BGZF_ERR_IO; return -1; }
+    std::unique_lock<std::mutex> lk(e->m);
+    if (e->cur_loaded) { e->cur_loaded = false; e->done_seq++; e->cv.notify_all(); }
+    e->cv.wait(lk, [&] { return e->done_seq < e->fill_seq || e->input_done; });
+    if (e->done_seq == e->fill_seq) return 0;
+    ReadBatch &b = e->rb[e->done_seq % NPIPES];
+    lk.unlock();
+    b.plain = nullptr; b.status = nullptr; b.good = 0;
+    if (b.submitted) {
+        size_t plen = 0;
+        const int rc = hg_pipe_wait(b.pipe, &b.plain, &plen, &b.status, nullptr, nullptr);
+        b.submitted = false;
+        if (rc != HG_OK && rc != HG_EBLOCK) { b.desc.clear(); b.fail = BGZF_ERR_ZLIB; }
+        while (b.good < b.desc.size() && b.status[b.good] == 0) b.good++;
+    }
+    lk.lock();
+    e->cur_loaded = true;
+    e->blk = 0; e->blk_pending = true;
+    return 1;
+}
+
+inline ReadBatch &cur_batch(Engine *e) { return e->rb[e->done_seq % NPIPES]; }
+
+// Bookkeeping for a block the consumer steps onto or over (bgzf.c:1066-1076).
+inline void note_block(BGZF *fp, const ReadBatch &b, size_t i) {
+    const hg_bgzf_desc &d = b.desc[i];
+    fp->last_block_eof = d.ulen == 0;
+    if (d.ulen && fp->idx_build_otf && fp->idx && !fp->idx->loaded) {
+        fp->idx->offs.push_back(GziEntry{(uint64_t)(b.file_off + (int64_t)d.coff), fp->idx->ublock_addr});
+        fp->idx->ublock_addr += d.ulen;
+    }
+}
+
+// Engine reader: position on the next non-empty block.  0 ok (block_length == 0 at EOF), -1 error.
+int engine_read_block(BGZF *fp) {
+    Engine *e = E(fp);
+    for (;;) {
+        if (e->eof_seen) { fp->block_length = 0; return 0; }
+        if (!e->cur_loaded) {
+            const int r = next_batch(e);
+            if (r < 0) return -1;
+            if (r == 0) {                                                // end of input (bgzf.c:1044-1051)
+                if (!fp->last_block_eof && !fp->no_eof_block) {
+                    fp->no_eof_block = 1;
+                    logmsg(LOG_WARNING, "bgzf_read_block", "EOF marker is absent. The input may be truncated");
+                }
+                e->eof_seen = true;
+                fp->block_length = 0;
+                return 0;
+            }
+        }
+        ReadBatch &b = cur_batch(e);
+        if (e->blk_pending) e->blk_pending = false; else e->blk++;
+        if (e->blk >= b.desc.size()) {
+            if (b.fail) {
+                fp->errcode |= b.fail;
+                logmsg(LOG_ERROR, "bgzf_read_block", "%s at offset %lld", b.fail == BGZF_ERR_HEADER ? "Invalid BGZF header" :
+                       b.fail == BGZF_ERR_IO ? "Failed to read BGZF block data" : "Inflate block operation failed",
+                       (long long)(b.file_off + (int64_t)b.comp_len));
+                e->blk = b.desc.size(); e->blk_pending = true;          // stay here: later calls fail the same way
+                return -1;
+            }
+            std::unique_lock<std::mutex> lk(e->m);
+            e->cur_loaded = false; e->done_seq++; e->cv.notify_all();
+            continue;
+        }
+        const hg_bgzf_desc &d = b.desc[e->blk];
+        const int64_t addr = b.file_off + (int64_t)d.coff;
+        if (b.status[e->blk] != 0) {
+            fp->errcode |= b.status[e->blk] == HG_BLOCK_ECRC ? BGZF_ERR_CRC : BGZF_ERR_ZLIB;
+            logmsg(LOG_ERROR, "bgzf_read_block", "BGZF decode returned error %d for block offset %lld", (int)b.status[e->blk], (long long)addr);
+            e->blk_pending = true;
+            return -1;
+        }
+        e->next_addr = addr + d.clen;
+        note_block(fp, b, e->blk);
+        if (d.ulen == 0) { fp->block_address = e->next_addr; continue; }  // empty blocks are skipped (bgzf.c:1054-1061)
+        if (fp->block_length != 0) fp->block_offset = 0;                 // a seek's offset survives (bgzf.c:1064)
+        fp->block_address = addr;
+        fp->block_clength = (int)d.clen;
+        fp->block_length = (int)d.ulen;
+        fp->uncompressed_block = const_cast<uint8_t *>(b.plain) + d.uoff;   // no copy: the batch's pinned plain image
+        return 0;
+    }
+}
+
+// The current block is used up: "tell never points at the end of a block" (bgzf.c:1282-1285).
+inline void block_consumed(BGZF *fp) {
+    Engine *e = E(fp);
+    fp->block_address = e && e->kind == K_READ ? e->next_addr : hg_htell(fp->fp);
+    fp->block_offset = 0; fp->block_length = 0;
+}
+
+// Bytes readable without another bgzf_read_block: the rest of the current block and, for engine readers, every
+// following block of the batch up to the first bad one -- they are adjacent in the plain image.
+inline size_t span_avail(BGZF *fp, Engine *e) {
+    const size_t in_block = (size_t)(fp->block_length - fp->block_offset);
+    if (!e || e->kind != K_READ || !e->cur_loaded) return in_block;
+    const ReadBatch &b = cur_batch(e);
+    if (e->blk >= b.good) return in_block;
+    const uint64_t here = b.desc[e->blk].uoff + (uint64_t)fp->block_offset;
+    const uint64_t end = b.good < b.desc.size() ? b.desc[b.good].uoff : b.desc.back().uoff + b.desc.back().ulen;
+    return (size_t)(end - here);
+}
+
+// Move the read position `n` bytes forward inside the span (n <= span_avail), stepping over whole blocks.
+void span_advance(BGZF *fp, Engine *e, size_t n) {
+    const size_t in_block = (size_t)(fp->block_length - fp->block_offset);
+    if (n < in_block) { fp->block_offset += (int)n; return; }
+    if (n == in_block) { block_consumed(fp); return; }
+    ReadBatch &b = cur_batch(e);
+    uint64_t target = b.desc[e->blk].uoff + (uint64_t)fp->block_offset + n;
+    size_t j = e->blk + 1;
+    for (;; j++) {                                                        // j < b.good by construction
+        const hg_bgzf_desc &d = b.desc[j];
+        note_block(fp, b, j);
+        e->next_addr = b.file_off + (int64_t)d.coff + d.clen;
+        if (target <= d.uoff + d.ulen && d.ulen) break;
+    }
+    const hg_bgzf_desc &d = b.desc[j];
+    e->blk = j;
+    fp->block_address = b.file_off + (int64_t)d.coff;
+    fp->block_clength = (int)d.clen;
+    fp->block_length = (int)d.ulen;
+    fp->block_offset = (int)(target - d.uoff);
+    fp->uncompressed_block = const_cast<uint8_t *>(b.plain) + d.uoff;
+    if (fp->block_offset == fp->block_length) block_consumed(fp);
+}
+
+// ================================================================================ plain gzip reader
+int gz_read_block(BGZF *fp) {
+    Engine *e = E(fp);
+    const int64_t addr = e->gz_base + (int64_t)(e->gz_st.in_bit >> 3);
+    while (e->gz_out_pos >= e->gz_out.size() && !e->gz_finished) {
+        e->gz_out.clear(); e->gz_out_pos = 0;
+        // top the compressed window up
+        if (!e->gz_eof && e->gz_comp.size() - (size_t)(e->gz_st.in_bit >> 3) < (1u << 20)) {
+            const size_t old = e->gz_comp.size(), add = 4u << 20;
+            e->gz_comp.resize(old + add);
+            ssize_t n = hg_hread(fp->fp, e->gz_comp.data() + old, add);
+            if (n < 0) { fp->errcode |= BGZF_ERR_IO; return -1; }
+            e->gz_comp.resize(old + (size_t)n);
+            if ((size_t)n < add) e->gz_eof = true;
+        }
+        if (!e->gz_st.in_member && (size_t)(e->gz_st.in_bit >> 3) >= e->gz_comp.size() && e->gz_eof) { e->gz_finished = true; break; }
+        const size_t soft = 8u << 20, cap = 40u << 20;
+        e->gz_out.resize(cap);
+        size_t made = 0;
+        const bool fresh = e->gz_st.in_member == 0;
+        const int rc = hg_gzip_stream_inflate_host(e->gpu, e->gz_comp.data(), e->gz_comp.size(), e->gz_eof ? 1 : 0, &e->gz_st,
+                                                   fresh ? nullptr : e->gz_hist.data(), fresh ? 0 : e->gz_hist.size(),
+                                                   e->gz_out.data(), cap, soft, &made);
+        if (rc < 0) {
+            logmsg(LOG_ERROR, "bgzf_read_block", "Reading GZIP stream failed at offset %lld", (long long)addr);
+            fp->errcode |= (rc == HG_EBLOCK && e->gz_eof && e->gz_st.in_member) ? BGZF_ERR_ZLIB : BGZF_ERR_ZLIB;
+            e->gz_out.clear();
+            return -1;
+        }
+        e->gz_out.resize(made);
+        if (rc == HG_GZ_NEEDIN) {
+            if (e->gz_eof || e->gz_comp.size() > (1ull << 30)) {
+                logmsg(LOG_ERROR, "bgzf_read_block", "Gzip file truncated");
+                fp->errcode |= BGZF_ERR_IO;
+                return -1;
+            }
+            const size_t old = e->gz_comp.size(), add = old < (4u << 20) ? (4u << 20) : old;
+            e->gz_comp.resize(old + add);
+            ssize_t n = hg_hread(fp->fp, e->gz_comp.data() + old, add);
+            if (n < 0) { fp->errcode |= BGZF_ERR_IO; return -1; }
+            e->gz_comp.resize(old + (size_t)n);
+            if ((size_t)n < add) e->gz_eof = true;
+            continue;
+        }
+        // history for the next call = the last 32 KiB of this member's output
+        if (rc == HG_GZ_MEMBER) e->gz_hist.clear();
+        else if (made >= 32768) e->gz_hist.assign(e->gz_out.end() - 32768, e->gz_out.end());
+        else {
+            e->gz_hist.insert(e->gz_hist.end(), e->gz_out.begin(), e->gz_out.end());
+            if (e->gz_hist.size() > 32768) e->gz_hist.erase(e->gz_hist.begin(), e->gz_hist.end() - 32768);
+        }
+        // forget consumed input (dword granular so that bit offsets stay valid)
+        const size_t drop = (size_t)(e->gz_st.in_bit >> 3) & ~(size_t)3;
+        if (drop > (1u << 20) || drop == e->gz_comp.size()) {
+            e->gz_comp.erase(e->gz_comp.begin(), e->gz_comp.begin() + drop);
+            e->gz_base += (int64_t)drop; e->gz_st.in_bit -= (uint64_t)drop * 8u;
+        }
+    }
+    const size_t left = e->gz_out.size() - e->gz_out_pos;
+    const size_t take = left < BGZF_MAX_BLOCK_SIZE ? left : BGZF_MAX_BLOCK_SIZE;
+    fp->uncompressed_block = e->own_block;
+    if (take) memcpy(fp->uncompressed_block, e->gz_out.data() + e->gz_out_pos, take);
+    e->gz_out_pos += take;
+    if (fp->block_length != 0) fp->block_offset = 0;
+    fp->block_address = addr;
+    fp->block_length = (int)take;
     return 0;
 }
 
+// ================================================================================ writer: output thread
+int flush_index_pushes(Engine *e, uint64_t block_addr, size_t ulen, size_t clen) {     // bgzf_idx_flush, bgzf.c:228-290
+    std::lock_guard<std::mutex> g(e->idx_m);
+    size_t i = 0;
+    for (; i < e->pushes.size() && e->pushes[i].block_number == e->block_written; i++) {
+        const IdxPush &p = e->pushes[i];
+        if (!hts_idx_push) return -1;
+        if (ulen > 0 && p.offset == ulen) {
+            // an offset at the very end of a block means the start of the next one; it is this block's last entry
+            if (hts_idx_push(p.hidx, p.tid, p.beg, p.end, (block_addr + clen) << 16, p.mapped) < 0) return -1;
+            i++;
+            break;
+        }
+        if (hts_idx_push(p.hidx, p.tid, p.beg, p.end, (block_addr << 16) + p.offset, p.mapped) < 0) return -1;
+    }
+    e->pushes.erase(e->pushes.begin(), e->pushes.begin() + (long)i);
+    e->block_written++;
+    return 0;
+}
+
+void writer_main(Engine *e) {
+    BGZF *fp = e->fp;
+    std::unique_lock<std::mutex> lk(e->m);
+    for (;;) {
+        e->cv.wait(lk, [&] { return e->stop || e->w_done < e->w_fill; });
+        if (e->w_done >= e->w_fill) { if (e->stop) break; continue; }
+        WriteBatch &b = e->wb[e->w_done % NPIPES];
+        lk.unlock();
+        const uint8_t *out = nullptr; size_t out_len = 0; const uint64_t *off = nullptr; const uint32_t *crc = nullptr;
+        int err = 0;
+        const size_t n = b.cuts.size() - 1;
+        if (hg_pipe_wait(b.pipe, &out, &out_len, nullptr, &off, &crc) != HG_OK) err = BGZF_ERR_ZLIB;
+        int64_t addr = e->block_address;
+        if (!err) {
+            if (e->kind == K_GZWRITE && !e->gz_header_done) {
+                const uint8_t hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
+                if (hg_hwrite(fp->fp, hdr, 10) != 10) err = BGZF_ERR_IO;
+                e->gz_header_done = true; addr += 10;
+            }
+            for (size_t i = 0; i < n && !err; i++) {
+                const size_t clen = (size_t)(off[i + 1] - off[i]), ulen = (size_t)(b.cuts[i + 1] - b.cuts[i]);
+                if (e->kind == K_GZWRITE) { e->gz_crc = crc_concat(e->gz_crc, crc[i], ulen); e->gz_isize += ulen; }
+                if (fp->idx_build_otf && fp->idx) {
+                    const GziEntry last = fp->idx->offs.back();
+                    fp->idx->offs.push_back(GziEntry{last.caddr + clen, last.uaddr + ulen});
+                }
+                if (flush_index_pushes(e, (uint64_t)(addr + (int64_t)off[i]), ulen, clen) != 0) err = BGZF_ERR_IO;
+            }
+            if (!err && out_len && hg_hwrite(fp->fp, out, out_len) != (ssize_t)out_len) err = BGZF_ERR_IO;
+        }
+        lk.lock();
+        if (err) e->w_err |= err; else e->block_address = addr + (int64_t)out_len;
+        e->w_done++;
+        e->cv.notify_all();
+    }
+}
+
+bool start_writer(Engine *e) {
+    if (e->started) return true;
+    for (auto &b : e->wb) if (!b.pipe && hg_pipe_create(e->gpu, &b.pipe) != HG_OK) return false;
+    e->started = true;
+    e->th = std::thread(writer_main, e);
+    return true;
+}
+
+// Hand the batch being filled to the device.
+int submit_write_batch(Engine *e) {
+    BGZF *fp = e->fp;
+    if (!e->w_open) return 0;
+    WriteBatch &b = e->wb[e->w_fill % NPIPES];
+    e->w_open = false;
+    if (b.cuts.size() <= 1) return 0;
+    int level = fp->compress_level < 0 ? 6 : fp->compress_level;
+    if (hg_pipe_deflate(b.pipe, b.len, b.cuts.data(), b.cuts.size() - 1, level, e->kind == K_GZWRITE) != HG_OK) {
+        fp->errcode |= BGZF_ERR_ZLIB;
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(e->m);
+    e->w_fill++;
+    e->cv.notify_all();
+    return 0;
+}
+
+// Queue fp->uncompressed_block[0 .. block_offset) as one block (mt_queue, bgzf.c:1852-1895).
+int queue_block(BGZF *fp) {
+    Engine *e = E(fp);
+    if (fp->block_offset == 0) return 0;
+    if (!start_writer(e)) { fp->errcode |= BGZF_ERR_IO; return -1; }
+    if (!e->w_open) {
+        std::unique_lock<std::mutex> lk(e->m);
+        e->cv.wait(lk, [&] { return e->w_fill - e->w_done < NPIPES; });
+        if (e->w_err) { fp->errcode |= e->w_err; return -1; }
+        lk.unlock();
+        WriteBatch &b = e->wb[e->w_fill % NPIPES];
+        b.target = fp->mt ? e->w_target : 1;                               // exact mode: one block per job
+        if (fp->mt && e->w_target < WBLOCKS_MAX) e->w_target *= 2;
+        b.cap = b.target * (size_t)BGZF_BLOCK_SIZE;
+        b.in = (uint8_t *)hg_pipe_input(b.pipe, b.cap);
+        if (!b.in) { fp->errcode |= BGZF_ERR_IO; return -1; }
+        b.len = 0; b.cuts.assign(1, 0);
+        e->w_open = true;
+    }
+    WriteBatch &b = e->wb[e->w_fill % NPIPES];
+    memcpy(b.in + b.len, fp->uncompressed_block, (size_t)fp->block_offset);
+    b.len += (size_t)fp->block_offset;
+    b.cuts.push_back(b.len);
+    e->block_number++;
+    fp->block_offset = 0;
+    if (b.cuts.size() - 1 >= b.target || b.len + BGZF_BLOCK_SIZE > b.cap) return submit_write_batch(e);
+    return 0;
+}
+
+int drain_writer(BGZF *fp);
+
+// A block has been cut (lazy_flush, bgzf.c:1927-1933).  Without bgzf_mt() the reference compresses it on the spot and
+// callers may rely on an exact bgzf_tell() between writes (test/test_bgzf.c test_tell_seek_getc; sam.c:942-943 amends
+// the index with it), so the block goes through the engine alone and is waited for: correct, but one device round
+// trip per block.  After bgzf_mt() blocks are batched and fp->block_address is only valid after bgzf_flush(), exactly
+// as with the reference's threads (bgzf.c:1953-1967).
+int cut_block(BGZF *fp) {
+    if (queue_block(fp) != 0) return -1;
+    return fp->mt ? 0 : drain_writer(fp);
+}
+
+int drain_writer(BGZF *fp) {
+    Engine *e = E(fp);
+    if (submit_write_batch(e) != 0) return -1;
+    std::unique_lock<std::mutex> lk(e->m);
+    e->cv.wait(lk, [&] { return e->w_done == e->w_fill; });
+    if (e->w_err) { fp->errcode |= e->w_err; return -1; }
+    fp->block_address = e->block_address;                                  // bgzf.c:1953-1967
+    return 0;
+}
+
+// ================================================================================ handle lifetime
+void stop_engine(Engine *e) {
+    if (e->started) {
+        { std::lock_guard<std::mutex> g(e->m); e->stop = true; e->pause_req = false; e->cv.notify_all(); }
+        e->th.join();
+        e->started = false;
+    }
+    for (auto &b : e->rb) if (b.pipe) { if (b.submitted) (void)hg_pipe_wait(b.pipe, nullptr, nullptr, nullptr, nullptr, nullptr); hg_pipe_destroy(b.pipe); b.pipe = nullptr; }
+    for (auto &b : e->wb) if (b.pipe) { hg_pipe_destroy(b.pipe); b.pipe = nullptr; }
+    if (e->gpu) { hg_destroy(e->gpu); e->gpu = nullptr; }
+}
+
+void free_handle(BGZF *fp) {
+    Engine *e = E(fp);
+    if (e) { stop_engine(e); free(e->own_block); delete e; }
+    else free(fp->uncompressed_block);
+    delete fp->idx;
+    free(fp);
+}
+
+int mode_level(const char *mode) {            // first digit = level, 'u' = no compression
+    int level = -1;
+    for (const char *m = mode; *m; m++) if (*m >= '0' && *m <= '9') { level = *m - '0'; break; }
+    return strchr(mode, 'u') ? -2 : level;
+}
+
+Engine *new_engine(BGZF *fp, Kind kind) {
+    Engine *e = new Engine();
+    e->fp = fp; e->kind = kind;
+    if (hg_init(device_choice(), &e->gpu) != HG_OK) { delete e; errno = ENODEV; return nullptr; }
+    e->own_block = fp->uncompressed_block;
+    fp->cache = reinterpret_cast<bgzf_cache_t *>(e);
+    if (kind == K_READ || kind == K_GZREAD) fp->mt = reinterpret_cast<struct bgzf_mtaux_t *>(e);
+    return e;
+}
+
+BGZF *make_reader(hFILE *h) {
+    uint8_t magic[18];
+    const ssize_t n = hpeek(h, magic, 18);
+    if (n < 0) return nullptr;
+    BGZF *fp = (BGZF *)calloc(1, sizeof(BGZF));
+    if (!fp) return nullptr;
+    fp->uncompressed_block = malloc(2 * BGZF_MAX_BLOCK_SIZE);
+    if (!fp->uncompressed_block) { free(fp); return nullptr; }
+    fp->compressed_block = (uint8_t *)fp->uncompressed_block + BGZF_MAX_BLOCK_SIZE;
+    fp->fp = h;
+    fp->is_compressed = n == 18 && magic[0] == 0x1f && magic[1] == 0x8b;
+    const bool extra = fp->is_compressed && (magic[3] & 4);
+    fp->is_gzip = fp->is_compressed && !(extra && memcmp(magic + 12, "BC\2\0", 4) == 0);
+    if (extra && memcmp(magic + 12, "RAZF", 4) == 0) {
+        logmsg(LOG_ERROR, "bgzf_read_init", "Cannot decompress legacy RAZF format");
+        free(fp->uncompressed_block); free(fp);
+        errno = ENOEXEC;
+        return nullptr;
+    }
+    if (fp->is_compressed && !new_engine(fp, fp->is_gzip ? K_GZREAD : K_READ)) { free(fp->uncompressed_block); free(fp); return nullptr; }
+    return fp;
+}
+
+BGZF *make_writer(hFILE *h, const char *mode) {
+    BGZF *fp = (BGZF *)calloc(1, sizeof(BGZF));
+    if (!fp) return nullptr;
+    fp->is_write = 1;
+    fp->fp = h;
+    const int level = mode_level(mode);
+    if (level == -2) return fp;                                             // "u": pass-through, no buffers (bgzf.c:446-450)
+    fp->is_compressed = 1;
+    fp->uncompressed_block = malloc(2 * BGZF_MAX_BLOCK_SIZE);
+    if (!fp->uncompressed_block) { free(fp); return nullptr; }
+    fp->compressed_block = (uint8_t *)fp->uncompressed_block + BGZF_MAX_BLOCK_SIZE;
+    fp->compress_level = level < 0 || level > 9 ? -1 : level;
+    if (strchr(mode, 'g')) fp->is_gzip = 1;
+    Engine *e = new_engine(fp, fp->is_gzip ? K_GZWRITE : K_WRITE);
+    if (!e) { free(fp->uncompressed_block); free(fp); return nullptr; }
+    return fp;
+}
+
+BGZF *finish_open(BGZF *fp) {
+    if (fp) { const uint16_t one = 1; fp->is_be = *(const uint8_t *)&one == 0; }
+    return fp;
+}
 
 }  // namespace
 
 extern "C" {
 
-BGZF *bgzf_dopen(int fd, const char *mode) { return new_handle(fd, true, mode); }
+// -------------------------------------------------------------------------------- open / close
+BGZF *bgzf_hopen(hFILE *h, const char *mode) {
+    if (strchr(mode, 'r')) return finish_open(make_reader(h));
+    if (strchr(mode, 'w') || strchr(mode, 'a')) return finish_open(make_writer(h, mode));
+    errno = EINVAL;
+    return nullptr;
+}
 
 BGZF *bgzf_open(const char *path, const char *mode) {
-    int fd;
-    if (strchr(mode, 'r')) fd = open(path, O_RDONLY);
-    else if (strchr(mode, 'a')) fd = open(path, O_WRONLY | O_CREAT | O_APPEND, 0666);
-    else if (strchr(mode, 'w')) fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
-    else { errno = EINVAL; return nullptr; }
-    if (fd < 0) return nullptr;
-    BGZF *fp = new_handle(fd, true, mode);
-    if (!fp) { int e = errno; close(fd); errno = e; }
+    if (!strchr(mode, 'r') && !strchr(mode, 'w') && !strchr(mode, 'a')) { errno = EINVAL; return nullptr; }
+    hFILE *h = hopen(path, mode);
+    if (!h) return nullptr;
+    BGZF *fp = bgzf_hopen(h, mode);
+    if (!fp) hclose_abruptly(h);
     return fp;
 }
 
+BGZF *bgzf_dopen(int fd, const char *mode) {
+    if (!strchr(mode, 'r') && !strchr(mode, 'w') && !strchr(mode, 'a')) { errno = EINVAL; return nullptr; }
+    hFILE *h = hdopen(fd, mode);
+    if (!h) return nullptr;
+    BGZF *fp = bgzf_hopen(h, mode);
+    if (!fp) hclose_abruptly(h);
+    return fp;
+}
+
+hFILE *bgzf_hfile(BGZF *fp) { return fp->fp; }
+
+int bgzf_close(BGZF *fp) {
+    if (!fp) return -1;
+    Engine *e = E(fp);
+    bool ok = true;
+    if (fp->is_write && fp->is_compressed) {
+        if (bgzf_flush(fp) != 0) ok = false;
+        else if (e->kind == K_GZWRITE) {                                     // end the member: final empty stored block + trailer
+            uint8_t tail[23]; size_t k = 0;
+            if (!e->gz_header_done) { const uint8_t hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3}; memcpy(tail, hdr, 10); k = 10; }
+            const uint8_t fin[5] = {1, 0, 0, 0xff, 0xff};
+            memcpy(tail + k, fin, 5); k += 5;
+            for (int i = 0; i < 4; i++) { tail[k + i] = (uint8_t)(e->gz_crc >> (8 * i)); tail[k + 4 + i] = (uint8_t)(e->gz_isize >> (8 * i)); }
+            k += 8;
+            if (hg_hwrite(fp->fp, tail, k) != (ssize_t)k || hflush(fp->fp) != 0) { fp->errcode |= BGZF_ERR_IO; ok = false; }
+        } else if (hg_hwrite(fp->fp, kEof, 28) != 28 || hflush(fp->fp) != 0) {   // bgzf.c:2084-2101
+            logmsg(LOG_ERROR, "bgzf_close", "File write failed");
+            fp->errcode |= BGZF_ERR_IO; ok = false;
+        }
+    }
+    if (e) stop_engine(e);
+    if (hclose(fp->fp) != 0) ok = false;
+    if (fp->errcode) ok = false;
+    free_handle(fp);
+    return ok ? 0 : -1;
+}
+
+// -------------------------------------------------------------------------------- reading
 int bgzf_read_block(BGZF *fp) {
-    Front *f = F(fp);
+    if (fp->errcode) return -1;
+    Engine *e = E(fp);
+    if (e && e->kind == K_READ) return engine_read_block(fp);
+    if (e && e->kind == K_GZREAD) return gz_read_block(fp);
     if (fp->is_write) { fp->errcode |= BGZF_ERR_MISUSE; return -1; }
-    if (!fp->is_compressed) {                                         // pass-through, bgzf.c:1110-1124
-        int64_t at = f->win_off;
-        size_t have = f->win_len;
-        if (have < BGZF_MAX_BLOCK_SIZE && !f->fd_eof) {
-            ssize_t n = read_full(f->fd, f->win.data() + have, BGZF_MAX_BLOCK_SIZE - have);
-            if (n < 0) { fp->errcode |= BGZF_ERR_IO; return -1; }
-            if ((size_t)n < BGZF_MAX_BLOCK_SIZE - have) f->fd_eof = true;
-            have += (size_t)n;
-        }
-        size_t take = have < BGZF_MAX_BLOCK_SIZE ? have : BGZF_MAX_BLOCK_SIZE;
-        memcpy(fp->uncompressed_block, f->win.data(), take);
-        memmove(f->win.data(), f->win.data() + take, have - take);
-        f->win_len = have - take; f->win_off += (int64_t)take;
-        if (fp->block_length != 0) fp->block_offset = 0;
-        fp->block_address = at;
-        fp->block_length = (int)take;
-        f->next_addr = at + (int64_t)take;
-        return 0;
+    // uncompressed pass-through (bgzf.c:1110-1131)
+    const int64_t at = hg_htell(fp->fp);
+    const ssize_t n = hg_hread(fp->fp, fp->uncompressed_block, BGZF_MAX_BLOCK_SIZE);
+    if (n < 0) {
+        logmsg(LOG_ERROR, "bgzf_read_block", "Failed to read uncompressed data at offset %lld", (long long)at);
+        fp->errcode |= BGZF_ERR_IO;
+        return -1;
     }
-    for (;;) {
-        if (f->cur_loaded) f->cur++;
-        if (f->cur >= f->nblk) {
-            if (load_batch(fp) != 0) return -1;
-            if (f->nblk == 0) {                                       // end of file
-                if (!fp->last_block_eof && !fp->no_eof_block && !f->warned_eof) {
-                    fp->no_eof_block = 1; f->warned_eof = true;       // bgzf.c:1047-1050: a warning, not an error
-                    fprintf(stderr, "[W::bgzf_read_block] EOF marker is absent. The input may be truncated\n");
-                }
-                fp->block_length = 0;
-                return 0;
-            }
-            f->cur = 0;
-        }
-        f->cur_loaded = true;
-        const hg_bgzf_desc &d = f->desc[f->cur];
-        if (f->status[f->cur] != 0) {
-            fp->errcode |= (f->status[f->cur] == HG_BLOCK_ECRC) ? BGZF_ERR_CRC : BGZF_ERR_ZLIB;
-            return -1;
-        }
-        const int64_t addr = f->batch_off + (int64_t)d.coff;
-        f->next_addr = addr + d.clen;
-        fp->last_block_eof = d.ulen == 0;
-        if (fp->idx_build_otf && !f->idx_loaded) { f->idx.push_back(IdxEntry{(uint64_t)addr, f->ublock_addr}); f->ublock_addr += d.ulen; }
-        if (d.ulen == 0) { fp->block_address = f->next_addr; continue; }   // skip empty blocks (bgzf.c:1054-1061)
-        if (fp->block_length != 0) fp->block_offset = 0;              // keep a seek's offset (bgzf.c:1064)
-        fp->block_address = addr;
-        fp->block_clength = (int)d.clen;
-        fp->block_length = (int)d.ulen;
-        memcpy(fp->uncompressed_block, f->plain.data() + d.uoff, d.ulen);
-        return 0;
-    }
+    if (n == 0) { fp->block_length = 0; return 0; }
+    if (fp->block_length != 0) fp->block_offset = 0;
+    fp->block_address = at;
+    fp->block_length = (int)n;
+    return 0;
 }
 
 ssize_t bgzf_read(BGZF *fp, void *data, size_t length) {
-    Front *f = F(fp);
-    if (fp->is_write) { fp->errcode |= BGZF_ERR_MISUSE; return -1; }
     if (length == 0) return 0;
-    uint8_t *out = (uint8_t *)data;
-    size_t done = 0;
-    while (done < length) {
-        int avail = fp->block_length - fp->block_offset;
-        if (avail <= 0) {
+    if (fp->is_write) { fp->errcode |= BGZF_ERR_MISUSE; return -1; }
+    Engine *e = E(fp);
+    uint8_t *dst = (uint8_t *)data;
+    size_t want = length;
+    while (want) {
+        if (fp->block_offset >= fp->block_length) {
             if (bgzf_read_block(fp) != 0) return -1;
-            avail = fp->block_length - fp->block_offset;
-            if (avail == 0) {
-                if (fp->block_length == 0) break;                     // EOF
-                continue;                                              // seek landed at a block's end
-            } else if (avail < 0) { fp->errcode |= BGZF_ERR_MISUSE; return -1; }
+            if (fp->block_length == 0) break;                                // end of file
+            if (fp->block_offset > fp->block_length) { fp->errcode |= BGZF_ERR_MISUSE; return -1; }   // seek beyond the block
+            if (fp->block_offset == fp->block_length) { block_consumed(fp); continue; }
         }
-        size_t n = length - done < (size_t)avail ? length - done : (size_t)avail;
-        memcpy(out + done, (uint8_t *)fp->uncompressed_block + fp->block_offset, n);
-        fp->block_offset += (int)n;
-        done += n;
-        if (fp->block_offset == fp->block_length) {                   // bgzf.c:1282-1285
-            fp->block_address = f->next_addr;
-            fp->block_offset = fp->block_length = 0;
-        }
+        size_t n = span_avail(fp, e);
+        if (n > want) n = want;
+        memcpy(dst, (const uint8_t *)fp->uncompressed_block + fp->block_offset, n);
+        span_advance(fp, e, n);
+        dst += n; want -= n;
     }
-    fp->uncompressed_address += (int64_t)done;
-    return (ssize_t)done;
+    fp->uncompressed_address += (int64_t)(length - want);
+    return (ssize_t)(length - want);
 }
 
 int bgzf_peek(BGZF *fp) {
-    if (fp->is_write) { fp->errcode |= BGZF_ERR_MISUSE; return -2; }
     if (fp->block_offset >= fp->block_length) {
-        if (bgzf_read_block(fp) != 0) return -2;
-        if (fp->block_length == 0) return -1;
+        if (bgzf_read_block(fp) != 0) { fp->errcode = BGZF_ERR_ZLIB; return -2; }
+        if (fp->block_offset >= fp->block_length) return -1;
     }
-    return ((uint8_t *)fp->uncompressed_block)[fp->block_offset];
+    return ((const uint8_t *)fp->uncompressed_block)[fp->block_offset];
 }
 
 int bgzf_getc(BGZF *fp) {
-    Front *f = F(fp);
-    if (fp->block_offset + 1 < fp->block_length) {
-        fp->uncompressed_address++;
-        return ((uint8_t *)fp->uncompressed_block)[fp->block_offset++];
-    }
-    int c;
     if (fp->block_offset >= fp->block_length) {
         if (bgzf_read_block(fp) != 0) return -2;
         if (fp->block_length == 0) return -1;
     }
-    c = ((uint8_t *)fp->uncompressed_block)[fp->block_offset++];
-    if (fp->block_offset == fp->block_length) {
-        fp->block_address = f->next_addr;
-        fp->block_offset = 0; fp->block_length = 0;
-    }
+    const int c = ((const uint8_t *)fp->uncompressed_block)[fp->block_offset++];
+    if (fp->block_offset == fp->block_length) block_consumed(fp);
     fp->uncompressed_address++;
     return c;
 }
 
+// Lines are cut out of the batch's contiguous plain image: one memchr over the whole readable span, one copy.
 int bgzf_getline(BGZF *fp, int delim, kstring_t *str) {
-    Front *f = F(fp);
-    int state = 0;
+    Engine *e = E(fp);
     str->l = 0;
-    do {
+    bool found = false;
+    int fail = 0;
+    while (!found) {
         if (fp->block_offset >= fp->block_length) {
-            if (bgzf_read_block(fp) != 0) { state = -2; break; }
-            if (fp->block_length == 0) { state = -1; break; }
+            if (bgzf_read_block(fp) != 0) { fail = -2; break; }
+            if (fp->block_length == 0) { fail = -1; break; }
         }
-        const uint8_t *buf = (const uint8_t *)fp->uncompressed_block;
-        int l;
-        for (l = fp->block_offset; l < fp->block_length && buf[l] != delim; ++l) {}
-        if (l < fp->block_length) state = 1;
-        l -= fp->block_offset;
-        if (str->l + (size_t)l + 2 > str->m) {
-            size_t m = str->l + (size_t)l + 2;
-            m = m < 64 ? 64 : m + (m >> 1);
-            char *ns = (char *)realloc(str->s, m);
-            if (!ns) { state = -3; break; }
-            str->s = ns; str->m = m;
+        const uint8_t *p = (const uint8_t *)fp->uncompressed_block + fp->block_offset;
+        const size_t span = span_avail(fp, e);
+        const uint8_t *hit = (const uint8_t *)memchr(p, delim, span);
+        const size_t take = hit ? (size_t)(hit - p) : span;
+        if (str->l + take + 2 > str->m) {
+            size_t m = str->l + take + 2;
+            m += m >> 1;
+            char *ns = (char *)realloc(str->s, m < 64 ? 64 : m);
+            if (!ns) { fail = -3; break; }
+            str->s = ns; str->m = m < 64 ? 64 : m;
         }
-        memcpy(str->s + str->l, buf + fp->block_offset, (size_t)l);
-        str->l += (size_t)l;
-        fp->block_offset += l + 1;
-        if (fp->block_offset >= fp->block_length) {
-            fp->block_address = f->next_addr;
-            fp->block_offset = 0; fp->block_length = 0;
-        }
-    } while (state == 0);
-    if (state < -1) return state;
-    if (str->l == 0 && state < 0) return state;
+        memcpy(str->s + str->l, p, take);
+        str->l += take;
+        span_advance(fp, e, take + (hit ? 1 : 0));
+        found = hit != nullptr;
+    }
+    if (fail < -1) return fail;
+    if (fail == -1 && str->l == 0) return -1;
     fp->uncompressed_address += (int64_t)str->l + 1;
     if (delim == '\n' && str->l > 0 && str->s[str->l - 1] == '\r') str->l--;
-    if (str->s) str->s[str->l] = 0;
-    return (int)str->l <= 0x7fffffff ? (int)str->l : 0x7fffffff;
-}
-
-int64_t bgzf_seek(BGZF *fp, int64_t pos, int whence) {
-    Front *f = F(fp);
-    if (fp->is_write || whence != SEEK_SET) { fp->errcode |= BGZF_ERR_MISUSE; return -1; }
-    const int block_offset = (int)(pos & 0xFFFF);
-    const int64_t block_address = pos >> 16;
-    if (lseek(f->fd, (off_t)block_address, SEEK_SET) < 0) { fp->errcode |= BGZF_ERR_IO; return -1; }
-    f->win_len = 0; f->win_off = block_address; f->fd_eof = false;
-    f->nblk = 0; f->cur = 0; f->cur_loaded = false;
-    fp->block_length = 0;                                             // "not loaded"
-    fp->block_address = block_address;
-    fp->block_offset = block_offset;
-    fp->seeked = pos;
-    fp->last_block_eof = 0;
-    f->next_addr = block_address;
-    return 0;
-}
-
-int bgzf_check_EOF(BGZF *fp) {
-    Front *f = F(fp);
-    off_t cur = lseek(f->fd, 0, SEEK_CUR);
-    if (cur < 0) return errno == ESPIPE ? 2 : -1;
-    off_t end = lseek(f->fd, -28, SEEK_END);
-    if (end < 0) { int e = errno; lseek(f->fd, cur, SEEK_SET); return e == EINVAL ? 0 : (e == ESPIPE ? 2 : -1); }
-    uint8_t buf[28];
-    ssize_t n = read_full(f->fd, buf, 28);
-    lseek(f->fd, cur, SEEK_SET);
-    if (n != 28) return n < 0 ? -1 : 0;
-    return memcmp(buf, kEof, 28) == 0 ? 1 : 0;
-}
-
-int bgzf_compression(BGZF *fp) { return !fp->is_compressed ? 0 /*no_compression*/ : 2 /*bgzf*/; }
-
-int bgzf_is_bgzf(const char *fn) {
-    int fd = open(fn, O_RDONLY);
-    if (fd < 0) return 0;
-    uint8_t h[18];
-    ssize_t n = read_full(fd, h, 18);
-    close(fd);
-    return n == 18 && header_ok(h);
-}
-
-void bgzf_set_cache_size(BGZF *fp, int size) { (void)fp; (void)size; }       // ignored like with threads (bgzf.c:2126-2130)
-int bgzf_thread_pool(BGZF *fp, struct hts_tpool *pool, int qsize) { (void)fp; (void)pool; (void)qsize; return 0; }
-int bgzf_mt(BGZF *fp, int n_threads, int n_sub_blks) { (void)fp; (void)n_threads; (void)n_sub_blks; return 0; }
-
-// ---------------------------------------------------------------------------- writer engine
-static int drain_queue(BGZF *fp) {
-    Front *f = F(fp);
-    const size_t nb = f->q_cuts.size() - 1;
-    if (nb == 0) return 0;
-    f->out.resize(nb * (size_t)BGZF_MAX_BLOCK_SIZE + 64);
-    size_t out_len = 0;
-    const int level = fp->compress_level < 0 ? 6 : fp->compress_level;
-    int rc = hg_bgzf_deflate_host(f->gpu, f->q_plain.data(), f->q_plain.size(), f->q_cuts.data(), nb, level, 0,
-                                  f->out.data(), f->out.size(), &out_len);
-    if (rc != HG_OK) { fp->errcode |= BGZF_ERR_ZLIB; return -1; }
-    if (fp->idx_build_otf) {                                          // one entry per block start (bgzf.c:2354-2366)
-        size_t pos = 0;
-        for (size_t i = 0; i < nb; i++) {
-            const size_t bs = (size_t)(f->out[pos + 16] | (f->out[pos + 17] << 8)) + 1;
-            f->ublock_addr += f->q_cuts[i + 1] - f->q_cuts[i];
-            pos += bs;
-            f->idx.push_back(IdxEntry{(uint64_t)f->file_off + pos, f->ublock_addr});
-        }
-    }
-    if (write_full(f->fd, f->out.data(), out_len) != 0) { fp->errcode |= BGZF_ERR_IO; return -1; }
-    f->file_off += (int64_t)out_len;
-    f->q_plain.clear(); f->q_cuts.assign(1, 0);
-    return 0;
-}
-
-static int queue_block(BGZF *fp) {                                    // lazy_flush / mt_queue, bgzf.c:1852-1933
-    Front *f = F(fp);
-    if (fp->block_offset == 0) return 0;
-    const uint8_t *p = (const uint8_t *)fp->uncompressed_block;
-    f->q_plain.insert(f->q_plain.end(), p, p + fp->block_offset);
-    f->q_cuts.push_back(f->q_plain.size());
-    fp->block_offset = 0;
-    if (f->q_cuts.size() - 1 >= WRITE_QUEUE) return drain_queue(fp);
-    return 0;
-}
-
-ssize_t bgzf_write(BGZF *fp, const void *data, size_t length) {
-    Front *f = F(fp);
-    if (!fp->is_write) { fp->errcode |= BGZF_ERR_MISUSE; return -1; }
-    if (!fp->is_compressed) {                                         // bgzf.c:2004-2009
-        size_t push = length + (size_t)fp->block_offset;
-        fp->block_offset = (int)(push % BGZF_MAX_BLOCK_SIZE);
-        fp->block_address += (int64_t)(push - (size_t)fp->block_offset);
-        if (write_full(f->fd, (const uint8_t *)data, length) != 0) { fp->errcode |= BGZF_ERR_IO; return -1; }
-        return (ssize_t)length;
-    }
-    const uint8_t *in = (const uint8_t *)data;
-    size_t remaining = length;
-    while (remaining > 0) {
-        size_t n = (size_t)(BGZF_BLOCK_SIZE - fp->block_offset);
-        if (n > remaining) n = remaining;
-        memcpy((uint8_t *)fp->uncompressed_block + fp->block_offset, in, n);
-        fp->block_offset += (int)n; in += n; remaining -= n;
-        if (fp->block_offset == BGZF_BLOCK_SIZE && queue_block(fp) != 0) return -1;
-    }
-    return (ssize_t)(length - remaining);
-}
-
-ssize_t bgzf_block_write(BGZF *fp, const void *data, size_t length) { return bgzf_write(fp, data, length); }
-
-int bgzf_flush_try(BGZF *fp, ssize_t size) {
-    if (fp->block_offset + size > BGZF_BLOCK_SIZE) return queue_block(fp);
-    return 0;
-}
-
-int bgzf_flush(BGZF *fp) {
-    Front *f = F(fp);
-    if (!fp->is_write) return 0;
-    if (!fp->is_compressed) return 0;
-    if (queue_block(fp) != 0) return -1;
-    if (drain_queue(fp) != 0) return -1;
-    fp->block_address = f->file_off;                                   // bgzf.c:1953-1967
-    return 0;
+    if (str->s) str->s[str->l] = '\0';
+    return str->l <= 0x7fffffff ? (int)str->l : 0x7fffffff;
 }
 
 ssize_t bgzf_raw_read(BGZF *fp, void *data, size_t length) {
-    ssize_t n = read_full(F(fp)->fd, (uint8_t *)data, length);
+    const ssize_t n = hg_hread(fp->fp, data, length);
     if (n < 0) fp->errcode |= BGZF_ERR_IO;
     return n;
 }
-ssize_t bgzf_raw_write(BGZF *fp, const void *data, size_t length) {
-    if (write_full(F(fp)->fd, (const uint8_t *)data, length) != 0) { fp->errcode |= BGZF_ERR_IO; return -1; }
-    return (ssize_t)length;
-}
 
-int bgzf_close(BGZF *fp) {
-    if (!fp) return -1;
-    Front *f = F(fp);
-    int ret = 0;
-    if (fp->is_write && fp->is_compressed) {
-        if (bgzf_flush(fp) != 0) ret = -1;
-        else if (write_full(f->fd, kEof, 28) != 0) { fp->errcode |= BGZF_ERR_IO; ret = -1; }   // bgzf.c:2084-2101
-    }
-    if (f->own_fd && close(f->fd) != 0) ret = -1;
-    free(fp->uncompressed_block);
-    delete f;
-    free(fp);
-    return ret;
-}
-
-int bgzf_compress(void *dst, size_t *dlen, const void *src, size_t slen, int level) {
-    hg_ctx *ctx = shared_ctx();
-    if (!ctx || slen > BGZF_BLOCK_SIZE) return -1;
-    std::vector<uint8_t> tmp(BGZF_MAX_BLOCK_SIZE + 64);
-    size_t out_len = 0;
-    if (slen == 0) {                                                   // bgzf.c:563-569
-        if (*dlen < 28) return -1;
-        memcpy(dst, kEof, 28); *dlen = 28; return 0;
-    }
-    const uint64_t cuts[2] = {0, slen};
-    int rc = hg_bgzf_deflate_host(ctx, (const uint8_t *)src, slen, cuts, 1, level < 0 || level > 9 ? 6 : level, 0,
-                                  tmp.data(), tmp.size(), &out_len);
-    if (rc != HG_OK || out_len > *dlen) return -1;
-    memcpy(dst, tmp.data(), out_len);
-    *dlen = out_len;
+// -------------------------------------------------------------------------------- seeking
+int64_t bgzf_seek(BGZF *fp, int64_t pos, int whence) {
+    if (fp->is_write || whence != SEEK_SET || fp->is_gzip) { fp->errcode |= BGZF_ERR_MISUSE; return -1; }
+    fp->seeked = pos;
+    const int64_t addr = pos >> 16;
+    Engine *e = E(fp);
+    if (e) {
+        bool inside = false;
+        if (e->cur_loaded) {
+            // a target inside the batch being consumed needs no I/O and no new launch
+            const ReadBatch &b = cur_batch(e);
+            if (addr >= b.file_off && addr < b.file_off + (int64_t)b.comp_len) {
+                size_t lo = 0, hi = b.desc.size();
+                while (lo < hi) { const size_t mid = (lo + hi) / 2; if (b.file_off + (int64_t)b.desc[mid].coff < addr) lo = mid + 1; else hi = mid; }
+                if (lo < b.desc.size() && b.file_off + (int64_t)b.desc[lo].coff == addr) { e->blk = lo; e->blk_pending = true; inside = true; }
+            }
+        }
+        e->eof_seen = false;
+        if (!inside && (e->started ? restart_reader_at(e, addr) : (hseek(fp->fp, (off_t)addr, SEEK_SET) < 0 ? -1 : 0)) != 0) {
+            fp->errcode |= BGZF_ERR_IO;
+            return -1;
+        }
+    } else if (hseek(fp->fp, (off_t)addr, SEEK_SET) < 0) { fp->errcode |= BGZF_ERR_IO; return -1; }
+    fp->block_length = 0;                                                    // "not loaded"
+    fp->block_address = addr;
+    fp->block_offset = (int)(pos & 0xFFFF);
     return 0;
 }
 
-// ---------------------------------------------------------------------------- .gzi index
-int bgzf_index_build_init(BGZF *fp) {
-    Front *f = F(fp);
-    f->idx.clear(); f->ublock_addr = 0; f->idx_loaded = false;
-    if (fp->is_write) f->idx.push_back(IdxEntry{0, 0});
-    fp->idx_build_otf = 1;
-    return 0;
-}
-
-int bgzf_index_dump(BGZF *fp, const char *bname, const char *suffix) {
-    Front *f = F(fp);
-    if (fp->is_write && bgzf_flush(fp) != 0) return -1;
-    std::string name = std::string(bname) + (suffix ? suffix : "");
-    FILE *o = fopen(name.c_str(), "wb");
-    if (!o) return -1;
-    // entry 0 (the first block at 0,0) is implicit (bgzf.c:2405-2411)
-    std::vector<IdxEntry> e(f->idx);
-    if (!e.empty() && e[0].caddr == 0 && e[0].uaddr == 0) e.erase(e.begin());
-    uint64_t n = e.size();
-    bool ok = fwrite(&n, 8, 1, o) == 1;
-    for (auto &x : e) ok = ok && fwrite(&x.caddr, 8, 1, o) == 1 && fwrite(&x.uaddr, 8, 1, o) == 1;
-    return fclose(o) == 0 && ok ? 0 : -1;
-}
-
-int bgzf_index_load(BGZF *fp, const char *bname, const char *suffix) {
-    Front *f = F(fp);
-    std::string name = std::string(bname) + (suffix ? suffix : "");
-    FILE *in = fopen(name.c_str(), "rb");
-    if (!in) return -1;
-    uint64_t n = 0;
-    bool ok = fread(&n, 8, 1, in) == 1 && n < (1ull << 32);
-    f->idx.assign(1, IdxEntry{0, 0});
-    for (uint64_t i = 0; ok && i < n; i++) {
-        IdxEntry x;
-        ok = fread(&x.caddr, 8, 1, in) == 1 && fread(&x.uaddr, 8, 1, in) == 1;
-        if (ok) f->idx.push_back(x);
-    }
-    fclose(in);
-    if (!ok) { f->idx.clear(); return -1; }
-    f->idx_loaded = true;
-    return 0;
-}
-
-int64_t bgzf_useek(BGZF *fp, off_t uoffset, int where) {
-    Front *f = F(fp);
-    if (fp->is_write || where != SEEK_SET) { fp->errcode |= BGZF_ERR_MISUSE; return -1; }
-    if (!fp->is_compressed) {
-        if (lseek(f->fd, uoffset, SEEK_SET) < 0) { fp->errcode |= BGZF_ERR_IO; return -1; }
-        f->win_len = 0; f->win_off = uoffset; f->fd_eof = false;
-        fp->block_length = 0; fp->block_address = uoffset; fp->block_offset = 0;
+int bgzf_useek(BGZF *fp, off_t uoffset, int where) {
+    if (fp->is_write || where != SEEK_SET || fp->is_gzip) { fp->errcode |= BGZF_ERR_MISUSE; return -1; }
+    const int64_t block_start = fp->uncompressed_address - fp->block_offset;
+    if (uoffset >= block_start && uoffset < block_start + fp->block_length) {            // inside the loaded block
+        fp->block_offset += (int)(uoffset - fp->uncompressed_address);
         fp->uncompressed_address = uoffset;
         return 0;
     }
-    if (!f->idx_loaded || f->idx.empty()) { fp->errcode |= BGZF_ERR_MISUSE; return -1; }
-    // last entry with uaddr <= uoffset (bgzf.c:2544-2611)
-    size_t lo = 0, hi = f->idx.size();
-    while (hi - lo > 1) { size_t mid = (lo + hi) / 2; if (f->idx[mid].uaddr <= (uint64_t)uoffset) lo = mid; else hi = mid; }
-    if (bgzf_seek(fp, (int64_t)(f->idx[lo].caddr << 16), SEEK_SET) != 0) return -1;
-    if (bgzf_read_block(fp) != 0) return -1;
-    const int64_t off = (int64_t)uoffset - (int64_t)f->idx[lo].uaddr;
-    if (off > 0) {
-        if (off > fp->block_length) { fp->errcode |= BGZF_ERR_MISUSE; return -1; }
-        fp->block_offset = (int)off;
-        if (fp->block_offset == fp->block_length) { fp->block_address = f->next_addr; fp->block_offset = fp->block_length = 0; }
+    if (!fp->is_compressed) {
+        if (hseek(fp->fp, uoffset, SEEK_SET) < 0) { fp->errcode |= BGZF_ERR_IO; return -1; }
+        fp->block_length = 0; fp->block_address = uoffset; fp->block_offset = 0;
+        if (bgzf_read_block(fp) < 0) { fp->errcode |= BGZF_ERR_IO; return -1; }
+        fp->uncompressed_address = uoffset;
+        return 0;
+    }
+    if (!fp->idx || fp->idx->offs.empty()) { fp->errcode |= BGZF_ERR_IO; return -1; }
+    const std::vector<GziEntry> &o = fp->idx->offs;
+    size_t lo = 0, hi = o.size();                                            // last entry with uaddr <= uoffset
+    while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (o[mid].uaddr <= (uint64_t)uoffset) lo = mid; else hi = mid; }
+    if (bgzf_seek(fp, (int64_t)(o[lo].caddr << 16), SEEK_SET) != 0) return -1;
+    if (bgzf_read_block(fp) < 0) { fp->errcode |= BGZF_ERR_IO; return -1; }
+    const int64_t inside = (int64_t)uoffset - (int64_t)o[lo].uaddr;
+    if (inside > 0) {
+        if (inside > fp->block_length) { fp->errcode |= BGZF_ERR_IO; return -1; }
+        fp->block_offset = (int)inside;
     }
     fp->uncompressed_address = uoffset;
     return 0;
 }
 
 off_t bgzf_utell(BGZF *fp) { return (off_t)fp->uncompressed_address; }
+
+int bgzf_check_EOF(BGZF *fp) {
+    Engine *e = E(fp);
+    std::unique_lock<std::mutex> lk;
+    if (e && e->kind == K_READ && e->started) { lk = std::unique_lock<std::mutex>(e->m); pause_reader(e, lk); }
+    int has = -1;
+    const off_t here = hg_htell(fp->fp);
+    if (hseek(fp->fp, -28, SEEK_END) < 0) {
+        if (errno == ESPIPE) { fp->fp->has_errno = 0; has = 2; }
+        else if (errno == EINVAL) { fp->fp->has_errno = 0; has = 0; }       // shorter than an EOF block
+    } else {
+        uint8_t buf[28];
+        if (hg_hread(fp->fp, buf, 28) == 28 && hseek(fp->fp, here, SEEK_SET) >= 0) has = memcmp(buf, kEof, 28) == 0 ? 1 : 0;
+    }
+    if (lk.owns_lock()) resume_reader(e);
+    fp->no_eof_block = has == 0;
+    return has;
+}
+
+int bgzf_compression(BGZF *fp) { return !fp->is_compressed ? 0 /* no_compression */ : fp->is_gzip ? 1 /* gzip */ : 2 /* bgzf */; }
+
+int bgzf_is_bgzf(const char *fn) {
+    hFILE *h = hopen(fn, "r");
+    if (!h) return 0;
+    uint8_t buf[16];
+    const ssize_t n = hg_hread(h, buf, 16);
+    if (hclose(h) < 0) return 0;
+    return n == 16 && bgzf_header_ok(buf);
+}
+
+void bgzf_set_cache_size(BGZF *fp, int size) { if (fp && !fp->mt) fp->cache_size = size; }   // no block cache: reads come from the prefetched batch
+// bgzf_mt / bgzf_thread_pool: the engine is the pool, so no threads are created; for a writer the call switches on the
+// reference's threaded contract (batched blocks, block addresses resolved later).  No-ops for uncompressed handles
+// (bgzf.c:1742-1743, 1786-1787).
+int bgzf_thread_pool(BGZF *fp, struct hts_tpool *, int) {
+    Engine *e = E(fp);
+    if (e && fp->is_write) fp->mt = reinterpret_cast<struct bgzf_mtaux_t *>(e);
+    return 0;
+}
+int bgzf_mt(BGZF *fp, int, int) { return bgzf_thread_pool(fp, nullptr, 0); }
+
+// -------------------------------------------------------------------------------- writing
+ssize_t bgzf_write(BGZF *fp, const void *data, size_t length) {
+    if (!fp->is_write) { fp->errcode |= BGZF_ERR_MISUSE; return -1; }
+    if (!fp->is_compressed) {                                                // bgzf.c:2004-2009
+        const size_t push = length + (size_t)fp->block_offset;
+        fp->block_offset = (int)(push % BGZF_MAX_BLOCK_SIZE);
+        fp->block_address += (int64_t)(push - (size_t)fp->block_offset);
+        return hg_hwrite(fp->fp, data, length);
+    }
+    const uint8_t *in = (const uint8_t *)data;
+    size_t left = length;
+    while (left) {
+        size_t n = (size_t)(BGZF_BLOCK_SIZE - fp->block_offset);
+        if (n > left) n = left;
+        memcpy((uint8_t *)fp->uncompressed_block + fp->block_offset, in, n);
+        fp->block_offset += (int)n; in += n; left -= n;
+        if (fp->block_offset == BGZF_BLOCK_SIZE && cut_block(fp) != 0) return -1;
+    }
+    return (ssize_t)length;
+}
+
+// bgzip -g / --reindex: cut the blocks where a loaded .gzi says the original file cut them (bgzf.c:2029-2060)
+ssize_t bgzf_block_write(BGZF *fp, const void *data, size_t length) {
+    if (!fp->is_compressed || !fp->idx || !fp->idx->loaded) return bgzf_write(fp, data, length);
+    const uint8_t *in = (const uint8_t *)data;
+    size_t left = length;
+    bgzidx_t *ix = fp->idx;
+    while (left) {
+        size_t limit = BGZF_BLOCK_SIZE;
+        if (ix->recut + 1 < ix->offs.size()) {
+            const uint64_t sz = ix->offs[ix->recut + 1].uaddr - ix->offs[ix->recut].uaddr;
+            if (sz >= 1 && sz <= BGZF_BLOCK_SIZE) limit = (size_t)sz;
+        }
+        size_t n = limit > (size_t)fp->block_offset ? limit - (size_t)fp->block_offset : 0;
+        if (n > left) n = left;
+        memcpy((uint8_t *)fp->uncompressed_block + fp->block_offset, in, n);
+        fp->block_offset += (int)n; in += n; left -= n;
+        if ((size_t)fp->block_offset >= limit) {
+            if (cut_block(fp) != 0) return -1;
+            ix->recut++;
+        }
+    }
+    return (ssize_t)length;
+}
+
+int bgzf_flush_try(BGZF *fp, ssize_t size) {
+    if (fp->block_offset + size > BGZF_BLOCK_SIZE) return fp->is_compressed ? cut_block(fp) : bgzf_flush(fp);
+    return 0;
+}
+
+int bgzf_flush(BGZF *fp) {
+    if (!fp->is_write) return 0;
+    if (!fp->is_compressed) return hflush(fp->fp);
+    if (queue_block(fp) != 0) return -1;
+    return drain_writer(fp);
+}
+
+ssize_t bgzf_raw_write(BGZF *fp, const void *data, size_t length) {
+    const ssize_t n = hg_hwrite(fp->fp, data, length);
+    if (n < 0) fp->errcode |= BGZF_ERR_IO;
+    return n;
+}
+
+int bgzf_idx_push(BGZF *fp, void *hidx, int tid, int64_t beg, int64_t end, uint64_t offset, int is_mapped) {
+    Engine *e = E(fp);
+    if (!e || !fp->is_write || !fp->mt) return hts_idx_push ? hts_idx_push(hidx, tid, beg, end, offset, is_mapped) : -1;
+    std::lock_guard<std::mutex> g(e->idx_m);
+    e->pushes.push_back(IdxPush{hidx, tid, beg, end, (uint32_t)(offset & 0xffff), is_mapped, e->block_number});
+    return 0;
+}
+
+int bgzf_compress(void *dst, size_t *dlen, const void *src, size_t slen, int level) {
+    if (slen == 0) {                                                         // the canonical EOF block (bgzf.c:563-569)
+        if (*dlen < 28) return -1;
+        memcpy(dst, kEof, 28); *dlen = 28;
+        return 0;
+    }
+    hg_ctx *ctx = shared_ctx();
+    if (!ctx || slen > BGZF_BLOCK_SIZE) return -1;
+    std::vector<uint8_t> tmp(BGZF_MAX_BLOCK_SIZE + 64);
+    size_t out_len = 0;
+    const uint64_t cuts[2] = {0, slen};
+    const int rc = hg_bgzf_deflate_host(ctx, (const uint8_t *)src, slen, cuts, 1, level < 0 || level > 9 ? 6 : level, 0,
+                                        tmp.data(), tmp.size(), &out_len);
+    if (rc != HG_OK || out_len > *dlen) return -1;
+    memcpy(dst, tmp.data(), out_len);
+    *dlen = out_len;
+    return 0;
+}
+
+uint32_t hts_crc32(uint32_t crc, const void *buf, size_t len) {
+    if (len == 0) return crc;
+    hg_ctx *ctx = shared_ctx();
+    uint32_t c = 0;
+    if (!ctx || hg_crc32_host(ctx, buf, len, &c) != HG_OK) {
+        logmsg(LOG_ERROR, "hts_crc32", "no usable GPU engine");
+        abort();                                                             // no silent wrong checksum, no CPU fallback
+    }
+    return crc_concat(crc, c, len);
+}
+
+// -------------------------------------------------------------------------------- .gzi index
+int bgzf_index_build_init(BGZF *fp) {
+    delete fp->idx;
+    fp->idx = new bgzidx_t();
+    if (fp->is_write) fp->idx->offs.push_back(GziEntry{0, 0});
+    fp->idx_build_otf = 1;
+    return 0;
+}
+
+int bgzf_index_dump_hfile(BGZF *fp, hFILE *out, const char *name) {
+    if (!fp->idx) { logmsg(LOG_ERROR, "bgzf_index_dump_hfile", "Called for BGZF handle with no index"); errno = EINVAL; return -1; }
+    if (bgzf_flush(fp) != 0) return -1;
+    // writers hold one entry per block END, readers one per block START: the file lists every block start but the
+    // first (bgzf.c:2385-2411), so a writer's last entry (the end of the file) is left out
+    const std::vector<GziEntry> &o = fp->idx->offs;
+    size_t n = o.size();
+    if (fp->is_write && n > 0) n--;
+    size_t first = !o.empty() && o[0].caddr == 0 && o[0].uaddr == 0 ? 1 : 0;
+    if (first > n) first = n;
+    const uint64_t cnt = n - first;
+    bool ok = hg_hwrite(out, &cnt, 8) == 8;
+    for (size_t i = first; ok && i < n; i++) ok = hg_hwrite(out, &o[i].caddr, 8) == 8 && hg_hwrite(out, &o[i].uaddr, 8) == 8;
+    if (!ok) logmsg(LOG_ERROR, "bgzf_index_dump_hfile", "Error writing to %s : %s", name ? name : "index", strerror(errno));
+    return ok ? 0 : -1;
+}
+
+int bgzf_index_dump(BGZF *fp, const char *bname, const char *suffix) {
+    if (!fp->idx) { logmsg(LOG_ERROR, "bgzf_index_dump", "Called for BGZF handle with no index"); errno = EINVAL; return -1; }
+    const std::string name = std::string(bname) + (suffix ? suffix : "");
+    hFILE *out = hopen(name.c_str(), "wb");
+    if (!out) { logmsg(LOG_ERROR, "bgzf_index_dump", "Error opening %s : %s", name.c_str(), strerror(errno)); return -1; }
+    if (bgzf_index_dump_hfile(fp, out, name.c_str()) != 0) { hclose_abruptly(out); return -1; }
+    if (hclose(out) < 0) { logmsg(LOG_ERROR, "bgzf_index_dump", "Error on closing %s : %s", name.c_str(), strerror(errno)); return -1; }
+    return 0;
+}
+
+int bgzf_index_load_hfile(BGZF *fp, hFILE *in, const char *name) {
+    bgzidx_t *ix = new bgzidx_t();
+    uint64_t n = 0;
+    bool ok = hg_hread(in, &n, 8) == 8 && n < (1ull << 40);
+    if (ok) {
+        ix->offs.assign(1, GziEntry{0, 0});
+        for (uint64_t i = 0; ok && i < n; i++) {
+            GziEntry x;
+            ok = hg_hread(in, &x.caddr, 8) == 8 && hg_hread(in, &x.uaddr, 8) == 8;
+            if (ok) ix->offs.push_back(x);
+        }
+    }
+    if (!ok) {
+        logmsg(LOG_ERROR, "bgzf_index_load_hfile", "Error reading %s : %s", name ? name : "index", strerror(errno));
+        delete ix;
+        return -1;
+    }
+    ix->loaded = true;
+    delete fp->idx;
+    fp->idx = ix;
+    return 0;
+}
+
+int bgzf_index_load(BGZF *fp, const char *bname, const char *suffix) {
+    const std::string name = std::string(bname) + (suffix ? suffix : "");
+    hFILE *in = hopen(name.c_str(), "rb");
+    if (!in) { logmsg(LOG_ERROR, "bgzf_index_load", "Error opening %s : %s", name.c_str(), strerror(errno)); return -1; }
+    if (bgzf_index_load_hfile(fp, in, name.c_str()) != 0) { hclose_abruptly(in); return -1; }
+    if (hclose(in) != 0) { logmsg(LOG_ERROR, "bgzf_index_load", "Error closing %s : %s", name.c_str(), strerror(errno)); return -1; }
+    return 0;
+}
 
 }  // extern "C"

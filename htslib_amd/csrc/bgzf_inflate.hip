@@ -25,6 +25,7 @@
 //     output (L2-resident), 64 lanes x slice-by-4, and folds the partials.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "htsgpu.h"
 #include "hg_device.h"
 #include "hg_internal.h"
@@ -300,18 +301,34 @@ __device__ __forceinline__ uint32_t lds_uniform(const uint32_t *p) {
 }
 
 // status codes internal to the kernel
-enum { ST_OK = 0, ST_HEADER = 1, ST_INFLATE = 2, ST_SIZE = 3, ST_CRC = 4 };
+enum { ST_OK = 0, ST_HEADER = 1, ST_INFLATE = 2, ST_SIZE = 3, ST_CRC = 4, ST_PAUSE = 5 };
+
+// Resumable decoding (plain gzip streams, hg_gzip_stream_inflate_host): where to start, when to pause, and the
+// last deflate-block boundary reached -- the only places a decode can be suspended without saving Huffman tables.
+struct StreamCtl {
+    uint32_t start_bit;      // in: first bit of a deflate block, relative to br.g
+    uint32_t pos0;           // in: bytes of history already present at out[0..pos0)
+    uint32_t soft_cap;       // in: pause at the first block boundary with pos - pos0 >= soft_cap
+    uint32_t good_bit;       // out: bit position of the last block boundary reached
+    uint32_t good_pos;       // out: output position at that boundary
+};
 
 // Decode one raw deflate stream.  `in_end` = first byte (relative to br.g)
 // that is NOT part of the payload.  Returns ST_*; *out_len receives bytes made.
+template <bool RESUMABLE>
 __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_t in_start, uint32_t in_end,
-                              uint8_t *out, uint32_t cap, uint32_t *out_len, int lane) {
+                              uint8_t *out, uint32_t cap, uint32_t *out_len, int lane, StreamCtl *ctl = nullptr) {
     uint32_t pos = 0;
     HG_T0(tph);
     HG_TRACE(2, 1);
-    br_seek(br, in_start, lane);
+    if (RESUMABLE) { br_seek_bits(br, ctl->start_bit, lane); pos = ctl->pos0; }
+    else br_seek(br, in_start, lane);
     HG_TRACE(2, 2);
     for (;;) {
+        if (RESUMABLE) {
+            ctl->good_bit = br.next_dw * 32u - br.bc; ctl->good_pos = pos;
+            if (pos - ctl->pos0 >= ctl->soft_cap) { *out_len = pos; return ST_PAUSE; }
+        }
         br_refill(br, lane);
         HG_TRACE(2, 3);
         if (br_byte_pos(br) > in_end) return ST_INFLATE;
@@ -432,6 +449,7 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
         }
         if (bfinal) break;
     }
+    if (RESUMABLE) { ctl->good_bit = br.next_dw * 32u - br.bc; ctl->good_pos = pos; }
     *out_len = pos;
     return ST_OK;
 }
@@ -529,7 +547,7 @@ void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
                 uint32_t made = 0;
                 uint8_t *o = out + uoff;
                 // payload handed to inflate = block[18 .. clen) like the reference (slen = block_length-18)
-                st = inflate_stream(S, br, skew + pay, skew + clen, o, ulen, &made, lane);
+                st = inflate_stream<false>(S, br, skew + pay, skew + clen, o, ulen, &made, lane);
                 HG_TRACE(1, 50 + st);
                 if (st == ST_OK && made != ulen) st = ST_SIZE;
                 if (st == ST_OK && tr[1] != ulen) st = ST_SIZE;
@@ -550,6 +568,89 @@ void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
         HG_TRACE(14, 555);
     }
     HG_TRACE(15, 777);
+}
+
+// ---- plain gzip stream, one wavefront, resumable at deflate-block boundaries (hg_gzip_stream_inflate_host) ----
+struct GzJob {               // device copy of the request / result
+    uint64_t in_bit;         // in: where to start; out: where the next call starts
+    uint32_t in_member;      // in/out
+    uint32_t hist_len;       // in: history bytes at out[0..hist_len)
+    uint32_t soft_cap, out_cap;   // in: out_cap counts NEW bytes after the history
+    uint32_t comp_eof;       // in
+    int32_t status;          // out: HG_GZ_* or -1 (corrupt) / -2 (trailer CRC is checked on the host; unused here)
+    uint32_t made;           // out: new bytes at out[hist_len ..)
+    uint32_t crc_new;        // out: CRC-32 of the new bytes
+    uint32_t trailer_crc, trailer_isize;   // out: when status == HG_GZ_MEMBER
+};
+
+__global__ __launch_bounds__(64)
+void gzip_stream_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len, uint8_t *out, GzJob *job) {
+    __shared__ WaveLds S;
+    const int lane = lane_id();
+    const uint64_t in_bit = ((uint64_t)uni((uint32_t)(job->in_bit >> 32)) << 32) | uni((uint32_t)job->in_bit);
+    const uint32_t hist = uni(job->hist_len), soft = uni(job->soft_cap), ocap = uni(job->out_cap), eof = uni(job->comp_eof);
+    uint32_t in_member = uni(job->in_member);
+    int32_t status = -1;
+    uint32_t made = 0, crc_new = 0, tcrc = 0, tisz = 0;
+    uint64_t next_bit = in_bit;
+    const uint32_t clen = comp_len > 0x1ffffff0ull ? 0x1ffffff0u : (uint32_t)comp_len;     // bit offsets are 32-bit
+    uint32_t q = (uint32_t)(in_bit >> 3);
+    bool go = true;
+    if (!in_member) {
+        // RFC 1952 member header at byte q: ID1 ID2 CM FLG MTIME(4) XFL OS [XLEN + extra] [name] [comment] [hcrc]
+        if ((in_bit & 7u) != 0 || q > clen) { go = false; }
+        else if (q + 10u > clen) { status = eof ? -1 : HG_GZ_NEEDIN; go = false; }
+        else {
+            const uint8_t *h = comp + q;
+            const uint32_t id = uni((uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16)), flg = uni(h[3]);
+            bool short_in = false;
+            if (id != 0x088b1fu || (flg >> 5) != 0) go = false;
+            uint32_t r = q + 10u;
+            if (go && (flg & 4u)) {
+                if (r + 2u > clen) short_in = true;
+                else r += 2u + uni((uint32_t)comp[r] | ((uint32_t)comp[r + 1] << 8));
+            }
+            for (int pass = 0; pass < 2 && go && !short_in; pass++)
+                if (flg & (pass ? 16u : 8u)) {
+                    while (r < clen && uni(comp[r]) != 0) r++;
+                    if (r >= clen) short_in = true; else r++;
+                }
+            if (go && !short_in && (flg & 2u)) r += 2u;
+            if (go && (short_in || r > clen)) { status = eof ? -1 : HG_GZ_NEEDIN; go = false; }
+            if (go) { next_bit = (uint64_t)r * 8u; in_member = 1; }
+        }
+    }
+    if (go) {
+        BitReader br;
+        br.g = (const uint32_t *)comp;
+        br.max_dw = (uint32_t)((comp_len + 3) / 4 - 1);
+        br.wbase = 0;
+        br.win = br_gload(br, (uint32_t)lane);
+        br.win_next = br_gload(br, 64u + (uint32_t)lane);
+        br.next_dw = 0; br.bb = 0; br.bc = 0;
+        StreamCtl ctl;
+        ctl.start_bit = (uint32_t)next_bit; ctl.pos0 = hist; ctl.soft_cap = soft; ctl.good_bit = ctl.start_bit; ctl.good_pos = hist;
+        uint32_t pos_end = hist;
+        const int st = inflate_stream<true>(S, br, 0, clen, out, hist + ocap, &pos_end, lane, &ctl);
+        uint32_t keep_pos = hist;                                       // output that stands
+        if (st == ST_PAUSE) { status = HG_GZ_MORE; keep_pos = pos_end; next_bit = ctl.good_bit; }
+        else if (st == ST_OK) {
+            const uint32_t t = (ctl.good_bit + 7u) >> 3;                // trailer: CRC32, ISIZE after the final block, byte aligned
+            if (t + 8u <= clen) {
+                for (int k = 0; k < 4; k++) { tcrc |= (uint32_t)uni(comp[t + k]) << (8 * k); tisz |= (uint32_t)uni(comp[t + 4 + k]) << (8 * k); }
+                status = HG_GZ_MEMBER; keep_pos = pos_end; next_bit = (uint64_t)(t + 8u) * 8u; in_member = 0;
+            } else status = eof ? -1 : HG_GZ_NEEDIN;                     // trailer not here yet: this call is redone with more input
+        } else if (ctl.good_pos > hist) {
+            // a block failed or ran past the input: everything up to the last block boundary stands
+            status = HG_GZ_MORE; keep_pos = ctl.good_pos; next_bit = ctl.good_bit;
+        } else status = eof ? -1 : HG_GZ_NEEDIN;
+        made = keep_pos - hist;
+        if (made) crc_new = uni(wave_crc32(out + hist, made, lane));
+    }
+    if (lane == 0) {
+        job->in_bit = next_bit; job->in_member = in_member; job->status = status; job->made = made; job->crc_new = crc_new;
+        job->trailer_crc = tcrc; job->trailer_isize = tisz;
+    }
 }
 
 __global__ __launch_bounds__(256)
@@ -582,14 +683,15 @@ int launch_bgzf_inflate(hg_ctx *ctx, const void *d_comp, size_t comp_len, const 
                         size_t nblocks, void *d_out, size_t out_cap, int32_t *d_status, hipStream_t s, int mode) {
     if (nblocks == 0) return HG_OK;
     if (nblocks > 0xffffffffull) return HG_EINVAL;
-    if (hipMemsetAsync(ctx->d_ticket, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
+    unsigned int *ticket = next_ticket(ctx);
+    if (hipMemsetAsync(ticket, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
     size_t waves = (size_t)ctx->waves_per_launch;
     size_t wgs = (waves + WAVES_PER_WG - 1) / WAVES_PER_WG;
     size_t need = (nblocks + WAVES_PER_WG - 1) / WAVES_PER_WG;
     if (wgs > need) wgs = need;
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)wgs), dim3(WAVES_PER_WG * 64), 0, s,
                        (const uint8_t *)d_comp, (uint64_t)comp_len, d_desc, (uint32_t)nblocks,
-                       (uint8_t *)d_out, (uint64_t)out_cap, d_status, ctx->d_ticket, mode);
+                       (uint8_t *)d_out, (uint64_t)out_cap, d_status, ticket, mode);
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
 
@@ -605,3 +707,61 @@ int launch_crc32(hg_ctx *ctx, const void *d_data, const uint64_t *d_off, const u
 }
 
 }  // namespace hg
+
+// ---- host-side CRC-32 concatenation (GF(2) polynomial arithmetic): crc(A||B) from crc(A), crc(B), |B| ----
+static uint32_t gz_mulmod(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) { if (a & (0x80000000u >> i)) p ^= b; b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1; }
+    return p;
+}
+static uint32_t gz_crc_concat(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+    uint32_t xp = 0x00800000u, acc = 0x80000000u;                    // x^8, x^0
+    for (; len_b; len_b >>= 1) { if (len_b & 1) acc = gz_mulmod(acc, xp); xp = gz_mulmod(xp, xp); }
+    return gz_mulmod(acc, crc_a) ^ crc_b;
+}
+
+extern "C" int hg_gzip_stream_inflate_host(hg_ctx *ctx, const uint8_t *comp, size_t comp_len, int comp_eof, hg_gz_state *state,
+                                           const uint8_t *hist, size_t hist_len, uint8_t *out, size_t out_cap, size_t soft_cap,
+                                           size_t *out_len) {
+    if (!ctx || !state || !out || !out_len || (!comp && comp_len) || (hist_len && !hist) || hist_len > 32768 ||
+        out_cap == 0 || out_cap > 0x7fffffffu || comp_len > 0x1ffffff0ull || (state->in_bit >> 3) > comp_len) return HG_EINVAL;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
+    *out_len = 0;
+    int rc;
+    if ((rc = hg::ensure_scratch(ctx, 0, comp_len + 512)) || (rc = hg::ensure_scratch(ctx, 1, hist_len + out_cap + 256)) ||
+        (rc = hg::ensure_scratch(ctx, 2, sizeof(hg::GzJob)))) return rc;
+    hg::GzJob job;
+    memset(&job, 0, sizeof job);
+    job.in_bit = state->in_bit; job.in_member = state->in_member; job.hist_len = (uint32_t)hist_len;
+    job.soft_cap = (uint32_t)(soft_cap < out_cap ? soft_cap : out_cap); job.out_cap = (uint32_t)out_cap; job.comp_eof = comp_eof ? 1u : 0u;
+    job.status = -1;
+    hipStream_t s = ctx->stream;
+    uint8_t *d_comp = (uint8_t *)ctx->d_scratch[0], *d_out = (uint8_t *)ctx->d_scratch[1];
+    bool ok = hipMemsetAsync(d_comp + (comp_len & ~(size_t)3), 0, 256, s) == hipSuccess &&
+              (comp_len == 0 || hipMemcpyAsync(d_comp, comp, comp_len, hipMemcpyHostToDevice, s) == hipSuccess) &&
+              (hist_len == 0 || hipMemcpyAsync(d_out, hist, hist_len, hipMemcpyHostToDevice, s) == hipSuccess) &&
+              hipMemcpyAsync(ctx->d_scratch[2], &job, sizeof job, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (!ok) return HG_ELAUNCH;
+    hipLaunchKernelGGL(hg::gzip_stream_kernel, dim3(1), dim3(64), 0, s, (const uint8_t *)d_comp, (uint64_t)comp_len, d_out,
+                       (hg::GzJob *)ctx->d_scratch[2]);
+    if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
+    if (hipMemcpyAsync(&job, ctx->d_scratch[2], sizeof job, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+    if (job.status < 0) return HG_EBLOCK;
+    if (job.made) {
+        if (job.made > out_cap) return HG_ELAUNCH;
+        if (hipMemcpy(out, d_out + hist_len, job.made, hipMemcpyDeviceToHost) != hipSuccess) return HG_ELAUNCH;
+        state->crc = gz_crc_concat(state->crc, job.crc_new, job.made);      // crc(empty) = 0 is the identity
+        state->isize += job.made;
+    }
+    *out_len = job.made;
+    state->in_bit = job.in_bit; state->in_member = job.in_member;
+    if (job.status == HG_GZ_MEMBER) {
+        // trailer check (RFC 1952 2.3.1): CRC-32 and ISIZE of the member that just ended
+        const bool good = state->crc == job.trailer_crc && state->isize == job.trailer_isize;
+        state->crc = 0; state->isize = 0;
+        if (!good) return HG_EBLOCK;
+    }
+    return job.status;
+}
+

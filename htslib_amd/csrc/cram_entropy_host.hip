@@ -265,7 +265,7 @@ extern "C" int hg_tok3_decode_host(hg_ctx *ctx, const uint8_t *const *in, const 
                                    uint8_t *const *out, const uint32_t *out_len, int32_t *status) {
     if (!ctx || (n && (!in || !in_len || !out || !out_len))) return HG_EINVAL;
     if (n == 0) return HG_OK;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     enum { MAX_TOK = 128, T_END = 12, T_MATCH = 10 };
     Plan P;
     std::vector<int32_t> st(n, 0);
@@ -422,7 +422,7 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
                                uint8_t *const *out, uint32_t *out_len, const uint8_t *d_src = nullptr, const uint64_t *d_src_off = nullptr) {
     if (!ctx || (n && ((!in && !d_src) || !in_len || !flags || !out || !out_len))) return HG_EINVAL;
     if (n == 0) return HG_OK;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     std::vector<Leaf> leaves;
     std::vector<hg::nx16_xenc> xj;
     std::vector<uint64_t> ioffs(n);
@@ -633,7 +633,7 @@ extern "C" size_t hg_tok3_compress_bound(size_t n) { return n * 2 + 65536 + 13 *
 extern "C" int hg_tok3_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *use_arith, size_t n,
                                    uint8_t *const *out, uint32_t *out_len) {
     if (!ctx || (n && (!in || !in_len || !use_arith || !out || !out_len))) return HG_EINVAL;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     hipStream_t s = ctx->stream;
     size_t i0 = 0;
     while (i0 < n) {

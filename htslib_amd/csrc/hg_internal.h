@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <atomic>
+#include <mutex>
 #include "htsgpu.h"
 
 #define HG_SCRATCH_SLOTS 16
@@ -10,7 +12,11 @@ struct hg_ctx {
     int device;
     int cus;
     int waves_per_launch;     // resident wavefronts the persistent kernels are sized for
-    unsigned int *d_ticket;   // work-queue counter (device)
+    unsigned int *d_ticket;   // ring of HG_TICKETS work-queue counters (device): one per launch, see next_ticket()
+    std::atomic<unsigned int> *launch_seq;   // launches issued so far (any thread, any stream)
+    std::mutex *tok_mu;       // orders deflate launches (shared token lists, see launch_bgzf_deflate)
+    hipEvent_t ev_deflate; int ev_deflate_used;
+    std::recursive_mutex *mu;           // serialises the host-buffer entry points of this context (they share scratch + staging)
     // scratch for the host-buffer convenience entry points (grown on demand)
     void *d_scratch[HG_SCRATCH_SLOTS];
     size_t d_scratch_cap[HG_SCRATCH_SLOTS];
@@ -24,7 +30,20 @@ struct hg_ctx {
     hg_ctx *sub[8];           // lazily created sibling contexts: independent codec families of one CRAM batch run concurrently
 };
 
+// Persistent kernels pull block indices from a counter that must start at 0.  Launches of one context may overlap
+// (caller streams, double-buffered pipelines, the side stream), so every launch takes the next counter of a ring and
+// zeroes it on its own stream; HG_TICKETS bounds the number of launches of one context that may be in flight at once.
+#define HG_TICKETS 256
 namespace hg {
+inline unsigned int *next_ticket(hg_ctx *ctx) {
+    return ctx->d_ticket + (ctx->launch_seq->fetch_add(1u, std::memory_order_relaxed) % HG_TICKETS);
+}
+// RAII guard of a host entry point: binds the device and holds the context lock
+struct CtxGuard {
+    std::unique_lock<std::recursive_mutex> lk;
+    int rc;
+    explicit CtxGuard(hg_ctx *ctx) : lk(*ctx->mu), rc(hipSetDevice(ctx->device) == hipSuccess ? HG_OK : HG_ENODEV) {}
+};
 int launch_bgzf_inflate(hg_ctx *ctx, const void *d_comp, size_t comp_len, const hg_bgzf_desc *d_desc,
                         size_t nblocks, void *d_out, size_t out_cap, int32_t *d_status, hipStream_t s, int mode = 0);
 int launch_bgzf_deflate(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_desc, size_t nblocks, int level,

@@ -60,11 +60,15 @@ int hg_init(int device, hg_ctx **out) {
     ctx->cus = prop.multiProcessorCount;
     // inflate: 30 KiB LDS per 4-wave workgroup -> 5 workgroups (20 waves) per CU
     ctx->waves_per_launch = ctx->cus * 24;
-    if (hipMalloc((void **)&ctx->d_ticket, 64) != hipSuccess) { free(ctx); return HG_ENOMEM; }
+    if (hipMalloc((void **)&ctx->d_ticket, HG_TICKETS * sizeof(unsigned int)) != hipSuccess) { free(ctx); return HG_ENOMEM; }
+    ctx->launch_seq = new std::atomic<unsigned int>(0);
+    ctx->mu = new std::recursive_mutex();
+    ctx->tok_mu = new std::mutex();
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipFree(ctx->d_ticket); free(ctx); return HG_ENODEV; }
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_deflate, hipEventDisableTiming) != hipSuccess) { (void)hipFree(ctx->d_ticket); delete ctx->launch_seq; delete ctx->mu; delete ctx->tok_mu; free(ctx); return HG_ENODEV; }
     *out = ctx;
     return HG_OK;
 }
@@ -81,6 +85,10 @@ void hg_destroy(hg_ctx *ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
+    delete ctx->launch_seq;
+    delete ctx->mu;
+    delete ctx->tok_mu;
+    if (ctx->ev_deflate) (void)hipEventDestroy(ctx->ev_deflate);
     free(ctx);
 }
 
@@ -117,6 +125,7 @@ int hg_bgzf_inflate_dev(hg_ctx *ctx, const void *d_comp, size_t comp_len, const 
                         size_t nblocks, void *d_out, size_t out_cap, int32_t *d_status, void *stream) {
     if (!ctx || (nblocks && (!d_comp || !d_desc || !d_status))) return HG_EINVAL;
     if (((uintptr_t)d_comp & 3u) != 0) return HG_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
     return hg::launch_bgzf_inflate(ctx, d_comp, comp_len, d_desc, nblocks, d_out, out_cap, d_status,
                                    (hipStream_t)stream);
 }
@@ -135,7 +144,7 @@ int hg_rans4x8_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t
                            uint8_t *const *out, uint32_t *out_len) {
     if (!ctx || (n && (!in || !in_len || !order || !out || !out_len))) return HG_EINVAL;
     if (n == 0) return HG_OK;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     hg_stream_desc *desc = (hg_stream_desc *)calloc(n, sizeof(hg_stream_desc));
     uint32_t *ol = (uint32_t *)malloc(n * 4);
     if (!desc || !ol) { free(desc); free(ol); return HG_ENOMEM; }
@@ -181,6 +190,7 @@ int hg_gzip_inflate_dev(hg_ctx *ctx, const void *d_comp, size_t comp_len, const 
                         void *d_out, size_t out_cap, int32_t *d_status, void *stream) {
     if (!ctx || (n && (!d_comp || !d_desc || !d_status))) return HG_EINVAL;
     if (((uintptr_t)d_comp & 3u) != 0) return HG_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
     return hg::launch_bgzf_inflate(ctx, d_comp, comp_len, d_desc, n, d_out, out_cap, d_status, (hipStream_t)stream, 1);
 }
 
@@ -188,7 +198,7 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
                                    const uint32_t *in_len, uint8_t *const *out, const uint32_t *out_len,
                                    int32_t *status) {
     if (!ctx || (n && (!method || !in || !in_len || !out || !out_len || !status))) return HG_EINVAL;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     // partition by method
     size_t ng = 0, nr = 0, nx_ = 0, na = 0, nt = 0;
     for (size_t i = 0; i < n; i++) {
@@ -301,7 +311,7 @@ int hg_cram_uncompress_blocks_crc_host(hg_ctx *ctx, size_t n, const int32_t *met
                                        int32_t *status) {
     if (!ctx || (n && (!method || !in || !in_len || !crc_part || !crc32 || !out || !out_len || !status))) return HG_EINVAL;
     if (n == 0) return HG_OK;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     // payload CRCs on the device, one wavefront per block
     std::vector<uint64_t> off(n); uint64_t tot = 0;
     for (size_t i = 0; i < n; i++) { off[i] = tot; tot += ((uint64_t)in_len[i] + 15u) & ~15ull; }
@@ -335,7 +345,7 @@ int hg_bgzf_inflate_host(hg_ctx *ctx, const uint8_t *comp, size_t comp_len, uint
                          size_t *out_len, int32_t *status, size_t max_status, long *first_bad_idx,
                          int *first_bad_code) {
     if (!ctx || (!comp && comp_len)) return HG_EINVAL;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     uint64_t total = 0;
     long n = hg_bgzf_scan(comp, comp_len, nullptr, 0, &total);
     if (n < 0) return (int)n;
@@ -391,6 +401,7 @@ int hg_bgzf_pack_dev(hg_ctx *ctx, const void *d_slots, const hg_bgzf_desc *d_des
                      size_t nblocks, void *d_packed, size_t packed_cap, uint64_t *d_packed_off, uint64_t *d_total,
                      int add_eof, void *stream) {
     if (!ctx || !d_packed || !d_packed_off || !d_total || (nblocks && (!d_slots || !d_desc || !d_clen))) return HG_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
     return hg::launch_bgzf_pack(ctx, d_slots, d_desc, d_clen, nblocks, d_packed, packed_cap, d_packed_off, d_total,
                                 add_eof, (hipStream_t)stream);
 }
@@ -398,7 +409,7 @@ int hg_bgzf_pack_dev(hg_ctx *ctx, const void *d_slots, const hg_bgzf_desc *d_des
 int hg_bgzf_deflate_host(hg_ctx *ctx, const uint8_t *plain, size_t len, const uint64_t *cuts, size_t ncuts, int level,
                          int add_eof, uint8_t *out, size_t out_cap, size_t *out_len) {
     if (!ctx || (!plain && len) || !out || level < 0 || level > 9) return HG_EINVAL;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     size_t nb = cuts ? ncuts : (len + HG_BGZF_BLOCK_SIZE - 1) / HG_BGZF_BLOCK_SIZE;
     hg_bgzf_desc *desc = (hg_bgzf_desc *)malloc((nb ? nb : 1) * sizeof(hg_bgzf_desc));
     if (!desc) return HG_ENOMEM;
@@ -451,21 +462,27 @@ int hg_rans4x8_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t
                            uint8_t *const *out, const uint32_t *out_cap, uint32_t *out_len, int32_t *status) {
     if (!ctx || (n && (!in || !in_len || !out || !out_cap || !out_len))) return HG_EINVAL;
     if (n == 0) return HG_OK;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     hg_stream_desc *desc = (hg_stream_desc *)calloc(n, sizeof(hg_stream_desc));
     int32_t *st = (int32_t *)malloc(n * sizeof(int32_t));
     if (!desc || !st) { free(desc); free(st); return HG_ENOMEM; }
     uint64_t ioff = 0, ooff = 0, soff = 0;
+    // A stream whose header promises more bytes than the caller's buffer holds is that STREAM's failure (the size is
+    // data, not an argument): it is parked as an empty descriptor, not uploaded, and reported -1; the rest of the batch
+    // is decoded (cram_uncompress_block fails only the offending block, cram_io.c:1671-1674).
+    std::vector<int32_t> skip(n, 0);
+    std::vector<uint32_t> ilen(in_len, in_len + n);
     for (size_t i = 0; i < n; i++) {
         uint32_t usz = 0;
         if (in_len[i] >= 9) usz = (uint32_t)in[i][5] | ((uint32_t)in[i][6] << 8) | ((uint32_t)in[i][7] << 16) | ((uint32_t)in[i][8] << 24);
-        desc[i].in_off = ioff; desc[i].in_len = in_len[i]; desc[i].out_off = ooff; desc[i].out_len = usz;
+        if (usz > out_cap[i]) { skip[i] = 1; ilen[i] = 0; usz = 0; }
+        desc[i].in_off = ioff; desc[i].in_len = ilen[i]; desc[i].out_off = ooff; desc[i].out_len = usz;
         desc[i].scratch_off = (uint32_t)soff;
         out_len[i] = usz;
-        ioff += ((uint64_t)in_len[i] + 15u) & ~15ull;
+        ioff += ((uint64_t)ilen[i] + 15u) & ~15ull;
         ooff += ((uint64_t)usz + 15u) & ~15ull;
-        soff += HG_RANS4X8_SCRATCH_WORDS(in_len[i]);
-        if (usz > out_cap[i] || soff > 0xffffffffull) { free(desc); free(st); return HG_EINVAL; }
+        soff += HG_RANS4X8_SCRATCH_WORDS(ilen[i]);
+        if (soff > 0xffffffffull) { free(desc); free(st); return HG_EINVAL; }
     }
     int rc;
     if ((rc = ensure_scratch(ctx, 0, ioff + 64)) || (rc = ensure_scratch(ctx, 1, ooff + 64)) ||
@@ -474,7 +491,7 @@ int hg_rans4x8_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t
     hipStream_t s = ctx->stream;
     std::vector<uint64_t> ioffs(n), ooffs(n);
     for (size_t i = 0; i < n; i++) { ioffs[i] = desc[i].in_off; ooffs[i] = desc[i].out_off; }
-    bool ok = hg::stage_upload(ctx, in, in_len, ioffs.data(), nullptr, n, ioff, (uint8_t *)ctx->d_scratch[0], s) == HG_OK;
+    bool ok = hg::stage_upload(ctx, in, ilen.data(), ioffs.data(), skip.data(), n, ioff, (uint8_t *)ctx->d_scratch[0], s) == HG_OK;
     ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc, n * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess;
     rc = ok ? hg::launch_rans4x8_decode(ctx, ctx->d_scratch[0], (const hg_stream_desc *)ctx->d_scratch[2], n, ctx->d_scratch[1],
                                         (int32_t *)ctx->d_scratch[3], (uint32_t *)ctx->d_scratch[6], s) : HG_ELAUNCH;
@@ -483,6 +500,7 @@ int hg_rans4x8_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t
         ok = ok && hg::stage_download(ctx, (const uint8_t *)ctx->d_scratch[1], ooffs.data(), out_len, out, n, s) == HG_OK;
         if (!ok) rc = HG_ELAUNCH;
     }
+    if (rc == HG_OK) for (size_t i = 0; i < n; i++) if (skip[i]) st[i] = -1;
     if (rc == HG_OK)
         for (size_t i = 0; i < n; i++) { if (status) status[i] = st[i]; if (st[i] != 0) rc = HG_EBLOCK; }
     free(desc); free(st);
@@ -507,7 +525,7 @@ int hg_gzip_deflate_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *
                          uint8_t *const *out, uint32_t *out_len) {
     if (!ctx || (n && (!in || !in_len || !out || !out_len)) || level < 0 || level > 9) return HG_EINVAL;
     if (n == 0) return HG_OK;
-    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     size_t nchunks = 0; uint64_t total_in = 0;
     for (size_t i = 0; i < n; i++) { nchunks += in_len[i] ? (in_len[i] + HG_BGZF_BLOCK_SIZE - 1) / HG_BGZF_BLOCK_SIZE : 1; total_in += ((uint64_t)in_len[i] + 15u) & ~15ull; }
     hg_bgzf_desc *desc = (hg_bgzf_desc *)calloc(nchunks, sizeof(hg_bgzf_desc));
@@ -640,9 +658,34 @@ int hg_cram_compress_blocks_host(hg_ctx *ctx, size_t n, const uint32_t *method_m
     return rc;
 }
 
+// CRC-32 of one host buffer (hts_crc32, bgzf.c:557-559): upload, one wavefront per 1 MiB piece, combine on the host
+int hg_crc32_host(hg_ctx *ctx, const void *buf, size_t len, uint32_t *crc) {
+    if (!ctx || !crc || (!buf && len)) return HG_EINVAL;
+    *crc = 0;
+    if (len == 0) return HG_OK;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
+    const size_t piece = 1u << 20, n = (len + piece - 1) / piece;
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, len + 64)) || (rc = ensure_scratch(ctx, 2, n * 8 + 64)) || (rc = ensure_scratch(ctx, 3, n * 8 + 64))) return rc;
+    std::vector<uint64_t> off(n); std::vector<uint32_t> ln(n), c(n);
+    for (size_t i = 0; i < n; i++) { off[i] = i * piece; ln[i] = (uint32_t)(len - off[i] < piece ? len - off[i] : piece); }
+    hipStream_t s = ctx->stream;
+    uint32_t *d_len = (uint32_t *)ctx->d_scratch[3], *d_crc = d_len + n;
+    if (hipMemcpyAsync(ctx->d_scratch[0], buf, len, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(ctx->d_scratch[2], off.data(), n * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_len, ln.data(), n * 4, hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
+    if ((rc = hg::launch_crc32(ctx, ctx->d_scratch[0], (const uint64_t *)ctx->d_scratch[2], d_len, n, d_crc, s))) return rc;
+    if (hipMemcpyAsync(c.data(), d_crc, n * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+    uint32_t acc = c[0];
+    for (size_t i = 1; i < n; i++) acc = crc_combine_h(acc, c[i], ln[i]);
+    *crc = acc;
+    return HG_OK;
+}
+
 int hg_crc32_dev(hg_ctx *ctx, const void *d_data, const uint64_t *d_off, const uint32_t *d_len, size_t n,
                  uint32_t *d_crc, void *stream) {
     if (!ctx || (n && (!d_data || !d_off || !d_len || !d_crc))) return HG_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
     return hg::launch_crc32(ctx, d_data, d_off, d_len, n, d_crc, (hipStream_t)stream);
 }
 

@@ -5,17 +5,22 @@
  * htslib/bgzf.h:50-58,68-84,110-495) so that code written against libhts' BGZF API compiles and
  * behaves the same; `struct BGZF` has the reference's public layout because callers read
  * block_offset / block_length / block_address / uncompressed_block directly (bgzf_tell macro,
- * bgzf_read_small/bgzf_write_small inlines, sam.c:800-803).
+ * bgzf_read_small/bgzf_write_small inlines, sam.c:800-803).  The reference's own test/test_bgzf.c
+ * and bgzip.c are built against this library, unmodified, by tests/test_reference_programs.py.
  *
- * Differences (by design):
- *   - blocks are (de)compressed in BATCHES on the GPU (libhtsgpu.so): the reader reads ahead and
- *     inflates a window of blocks per kernel launch, the writer collects blocks and deflates them
- *     per launch.  bgzf_mt()/bgzf_thread_pool() are accepted and are no-ops (the batch engine
- *     replaces the per-block pool jobs of bgzf.c:1598-1738 and 1852-1925).
- *   - transport is a plain POSIX fd (no hFILE plugins); `fp->fp` is private.
- *   - plain gzip input (not BGZF) and mode "g" are not supported (bgzf_open returns NULL);
- *     uncompressed pass-through ("u", or non-gzip input) is.
- *   - there is no CPU codec: without a usable MI355X bgzf_open() fails for compressed streams.
+ * How it differs from bgzf.c, by design:
+ *   - blocks are (de)compressed in BATCHES on the GPU (libhtsgpu.so, hg_pipe_*): every compressed handle
+ *     behaves like the reference's multi-threaded mode -- a reader prefetches and inflates windows of blocks
+ *     on an I/O thread, a writer queues blocks and an output thread writes them in order.  `fp->mt` is
+ *     therefore non-NULL for compressed handles and callers take their "threaded" paths (deferred index
+ *     offsets via bgzf_idx_push, bgzf_tell on a writer valid in its low 16 bits until bgzf_flush;
+ *     bgzf.c:1953-1967, sam.c:942).  bgzf_mt() / bgzf_thread_pool() are accepted and change nothing;
+ *     bgzf_set_cache_size() is ignored as it is with threads (bgzf.c:2126-2130).
+ *   - `fp->fp` is a real hFILE; all I/O goes through the exported hFILE functions, so the library works with
+ *     libhts' hfile.c (every transport) or with the bundled local-file provider (hfile_min.cpp).
+ *   - plain gzip input and mode "g" output are supported through the engine as well (one wavefront per stream:
+ *     it works, slowly; BGZF is the fast path).
+ *   - there is no CPU codec: without a usable MI355X bgzf_open() fails (ENODEV) for compressed streams.
  */
 #ifndef HTS_BGZF_GPU_H
 #define HTS_BGZF_GPU_H
@@ -61,17 +66,19 @@ struct BGZF {
     int64_t block_address, uncompressed_address;
     void *uncompressed_block, *compressed_block;
     bgzf_cache_t *cache;
-    struct hFILE *fp;               /* private: the fd-based engine state */
-    struct bgzf_mtaux_t *mt;
+    struct hFILE *fp;               /* the transport, as in the reference (bgzf_hfile) */
+    struct bgzf_mtaux_t *mt;        /* the batch engine of this handle (NULL for uncompressed handles) */
     bgzidx_t *idx;
     int idx_build_otf;
-    struct z_stream_s *gz_stream;
+    struct z_stream_s *gz_stream;   /* unused: gzip streams go through the engine too */
     int64_t seeked;
 };
 typedef struct BGZF BGZF;
 
 BGZF *bgzf_dopen(int fd, const char *mode);
 BGZF *bgzf_open(const char *path, const char *mode);
+BGZF *bgzf_hopen(struct hFILE *fp, const char *mode);          /* bgzf.c:539 */
+struct hFILE *bgzf_hfile(BGZF *fp);                            /* bgzf.c:2619 */
 int bgzf_close(BGZF *fp);
 ssize_t bgzf_read(BGZF *fp, void *data, size_t length);
 ssize_t bgzf_write(BGZF *fp, const void *data, size_t length);
@@ -93,11 +100,19 @@ int bgzf_read_block(BGZF *fp);
 int bgzf_thread_pool(BGZF *fp, struct hts_tpool *pool, int qsize);
 int bgzf_mt(BGZF *fp, int n_threads, int n_sub_blks);
 int bgzf_compress(void *dst, size_t *dlen, const void *src, size_t slen, int level);
-int64_t bgzf_useek(BGZF *fp, off_t uoffset, int where);
+int bgzf_useek(BGZF *fp, off_t uoffset, int where);
 off_t bgzf_utell(BGZF *fp);
 int bgzf_index_build_init(BGZF *fp);
 int bgzf_index_load(BGZF *fp, const char *bname, const char *suffix);
+int bgzf_index_load_hfile(BGZF *fp, struct hFILE *idx, const char *name);   /* bgzf.c:2472 */
 int bgzf_index_dump(BGZF *fp, const char *bname, const char *suffix);
+int bgzf_index_dump_hfile(BGZF *fp, struct hFILE *idx, const char *name);   /* bgzf.c:2385 */
+/* hts_idx_push with the block address resolved once the block has been compressed (bgzf.c:189-290);
+ * hidx is the caller's hts_idx_t, handed on to libhts' hts_idx_push. */
+int bgzf_idx_push(BGZF *fp, void *hidx, int tid, int64_t beg, int64_t end, uint64_t offset, int is_mapped);
+/* CRC-32 of a host buffer, computed on the device (bgzf.c:557-559).  One PCIe round trip per call: hot paths
+ * use the batch entry points of htsgpu.h instead. */
+uint32_t hts_crc32(uint32_t crc, const void *buf, size_t len);
 
 static inline ssize_t bgzf_read_small(BGZF *fp, void *data, size_t length) {
     if ((ssize_t)length < fp->block_length - fp->block_offset) {

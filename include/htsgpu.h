@@ -126,6 +126,54 @@ int hg_bgzf_pack_dev(hg_ctx *ctx, const void *d_slots, const hg_bgzf_desc *d_des
 int hg_bgzf_deflate_host(hg_ctx *ctx, const uint8_t *plain, size_t len, const uint64_t *cuts, size_t ncuts,
                          int level, int add_eof, uint8_t *out, size_t out_cap, size_t *out_len);
 
+/* ---- asynchronous host-buffer jobs ("pipes"): the batching engine behind bgzf_read / bgzf_write.
+ *      Replaces the I/O-thread + pool + ordered-result-queue pipeline of bgzf_mt_reader / bgzf_mt_writer
+ *      (bgzf.c:1598-1738, 1398-1473; hts_tpool ordered results thread_pool.c:149-252): a pipe owns pinned host
+ *      buffers, device buffers and a HIP stream; a submitted job (H2D -> kernels -> D2H) runs asynchronously and
+ *      the caller collects results in submission order.  Two or three pipes per stream overlap file I/O, PCIe and
+ *      the kernels.  A pipe carries ONE job at a time; different pipes may be driven from different threads. ---- */
+typedef struct hg_pipe hg_pipe;
+int  hg_pipe_create(hg_ctx *ctx, hg_pipe **pipe);
+void hg_pipe_destroy(hg_pipe *pipe);
+/* Pinned staging buffer for the NEXT job's input, at least `bytes` long (contents are lost when it grows).
+ * NULL while a job is in flight or on allocation failure. */
+void *hg_pipe_input(hg_pipe *pipe, size_t bytes);
+/* Inflate job: the first comp_len bytes of the input buffer are n whole BGZF blocks; desc[i].coff is relative to
+ * the buffer, desc[i].uoff cumulative from 0.  Returns after queueing the work. */
+int hg_pipe_inflate(hg_pipe *pipe, size_t comp_len, const hg_bgzf_desc *desc, size_t n);
+/* Deflate job: the input buffer holds len plain bytes cut into n blocks at cuts[0..n] (cuts[0] = 0, cuts[n] = len,
+ * pieces <= 0xff00).  raw = 0: complete BGZF blocks back to back.  raw != 0: bare byte-aligned deflate chunks
+ * without BFINAL that concatenate into one deflate stream (bgzf mode "g", bgzf.c:686-706); crc[i] = CRC-32 of chunk i. */
+int hg_pipe_deflate(hg_pipe *pipe, size_t len, const uint64_t *cuts, size_t n, int level, int raw);
+/* Wait for the job.  Inflate: *out / *out_len = the plain image (pinned host memory owned by the pipe, valid until
+ * the next job), status[i] = HG_BLOCK_*; returns HG_OK or HG_EBLOCK.  Deflate: *out = the compressed stream,
+ * blk_off[0..n] = offset of every block in it (blk_off[n] = *out_len), crc[i] as above.  Unused outputs may be NULL. */
+int hg_pipe_wait(hg_pipe *pipe, const uint8_t **out, size_t *out_len, const int32_t **status, const uint64_t **blk_off,
+                 const uint32_t **crc);
+
+/* ---- plain gzip streams (not BGZF): the fallback of bgzf_read_block for ordinary .gz input
+ *      (inflate_gzip_block, bgzf.c:826-893, 1165-1196).  One deflate stream is one dependency chain, so this runs
+ *      on a single wavefront; it exists so that the drop-in reads what stock htslib reads.  Resumable at deflate-block
+ *      boundaries: each call decodes whole deflate blocks from state->in_bit until `soft_cap` bytes have been made,
+ *      the member ends, or the input runs out. ---- */
+typedef struct hg_gz_state {
+    uint64_t in_bit;       /* next bit to decode, relative to comp[0]                                   */
+    uint32_t in_member;    /* 0: comp + in_bit/8 is a member header; 1: inside a member's deflate data   */
+    uint32_t crc;          /* CRC-32 of the current member's output so far                              */
+    uint32_t isize;        /* bytes of the current member so far (mod 2^32)                             */
+    uint32_t reserved;
+} hg_gz_state;
+#define HG_GZ_MORE     1   /* soft_cap reached at a deflate-block boundary: call again                  */
+#define HG_GZ_MEMBER   2   /* a member ended and its CRC-32 / ISIZE trailer matched; in_bit is past it  */
+#define HG_GZ_NEEDIN   3   /* the next deflate block is not complete in comp[0..comp_len): supply more   */
+/* hist/hist_len: the last <= 32768 bytes produced before this call (the LZ77 window), NULL at a member start.
+ * out receives the new bytes (*out_len of them, <= out_cap; out_cap should exceed soft_cap by the size of one
+ * deflate block's output).  comp_eof != 0: no more input exists (an incomplete block is then an error).
+ * Returns HG_GZ_* (> 0), or a negative HG_E* / HG_EBLOCK on a corrupt stream. */
+int hg_gzip_stream_inflate_host(hg_ctx *ctx, const uint8_t *comp, size_t comp_len, int comp_eof, hg_gz_state *state,
+                                const uint8_t *hist, size_t hist_len, uint8_t *out, size_t out_cap, size_t soft_cap,
+                                size_t *out_len);
+
 /* ---- CRAM 3.0 rANS 4x8 (replaces rans_uncompress as called by cram_uncompress_block,
  *      cram/cram_io.c:1666-1683; CRAM block method 4) ------------------------------ */
 /* One descriptor per entropy-coded stream (= the payload of one CRAM block). */
@@ -348,6 +396,9 @@ long hg_idx_build_dev(hg_ctx *ctx, const void *d_bam, uint64_t len, uint64_t fir
 int hg_crc32_dev(hg_ctx *ctx, const void *d_data,
                  const uint64_t *d_off, const uint32_t *d_len, size_t n,
                  uint32_t *d_crc, void *stream);
+
+/* CRC-32 of one host buffer (upload + device CRC + host combine).  Synchronous. */
+int hg_crc32_host(hg_ctx *ctx, const void *buf, size_t len, uint32_t *crc);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,37 @@
+"""CPU check of the BGZF front-end's HOST logic (state machine, I/O / output threads, seek, index, EOF handling):
+the reference's own test/test_bgzf.c and bgzip.c, compiled unmodified, run against  bgzf_front.cpp + hfile_min.cpp  on
+the zlib TEST DOUBLE of the engine (tests/native/fake_engine.c).  The product library is not involved: it links the
+gfx950 engine and refuses to open compressed streams without a GPU (tests/test_cabi.py::test_no_gpu_fails_loudly).
+The same scenarios run against the real library on the MI355X in tests/test_reference_programs.py."""
+import os
+import subprocess
+
+import pytest
+
+from tests import dropin_cases, refutil
+
+ROOT = refutil.ROOT
+OUT = os.path.join(ROOT, "build", "hostlogic")
+REF = "/root/reference"
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference sources to compile test_bgzf.c / bgzip.c")
+
+
+@pytest.fixture(scope="module", params=["", "thread"])
+def progs(request):
+    san = request.param
+    r = subprocess.run(["bash", os.path.join(ROOT, "tests", "native", "build_hostlogic.sh"), *([san] if san else [])],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    suf = f"_{san}" if san else ""
+    return os.path.join(OUT, "test_bgzf_fake" + suf), os.path.join(OUT, "bgzip_fake" + suf)
+
+
+def test_reference_test_bgzf_passes_on_the_front_end(progs, tmp_path):
+    dropin_cases.reference_test_bgzf(progs[0], str(tmp_path))
+
+
+@pytest.mark.parametrize("threads", [0, 4])
+def test_reference_bgzip_scenarios(progs, tmp_path, threads):
+    checker = os.path.join(refutil.REF_DIR, "ref_bgzip") if refutil.have_ref() else None
+    dropin_cases.reference_bgzip(progs[1], str(tmp_path), threads, checker)
