@@ -37,9 +37,11 @@ def load():
     L.bgzf_compress.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.c_int]
     L.bgzf_index_build_init.argtypes = [P]
     L.bgzf_index_dump.argtypes = [P, C.c_char_p, C.c_char_p]; L.bgzf_index_load.argtypes = [P, C.c_char_p, C.c_char_p]
-    L.bgzf_useek.restype = C.c_int64; L.bgzf_useek.argtypes = [P, C.c_long, C.c_int]
+    L.bgzf_useek.restype = C.c_int; L.bgzf_useek.argtypes = [P, C.c_long, C.c_int]
     L.bgzf_utell.restype = C.c_long; L.bgzf_utell.argtypes = [P]
     L.bgzf_is_bgzf.argtypes = [C.c_char_p]; L.bgzf_compression.argtypes = [P]
+    L.hts_crc32.restype = C.c_uint32; L.hts_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]
+    L.bgzf_hfile.restype = C.c_void_p; L.bgzf_hfile.argtypes = [P]
     return L
 
 
