@@ -1,0 +1,419 @@
+// cram_block_front.cpp -- htslib's CRAM block layer (cram_uncompress_block / cram_compress_block, cram_block framing)
+// on the gfx950 batch engine.  Host C++ only; every codec runs in libhtsgpu.so.  Interfaces and their reference
+// anchors are in include/hts_cram_gpu.h.
+//
+// The reference calls these functions one block at a time from many pool workers (one slice each); a
+// single block cannot fill a GPU.  The single-block entry points therefore COALESCE concurrent callers: the first
+// caller to arrive becomes the leader, lingers for a moment so that the other workers can join, runs ONE engine batch
+// for everybody and hands the results back.  A lone caller pays the linger (tens of microseconds) and gets its block
+// alone -- correct, just not fast; the array forms (a whole slice per call) are the intended hook
+// (cram_decode.c:624-627 loops over a slice's blocks; cram_encode.c:803-988 compresses them in one function).
+#include <errno.h>
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include "hts_cram_gpu.h"
+#include "hts_hfile_abi.h"
+#include "htsgpu.h"
+
+extern "C" void hts_log(int severity, const char *context, const char *format, ...) __attribute__((weak));
+
+static_assert(sizeof(cram_metrics) == sizeof(hg_cram_metrics), "cram_metrics and the engine's view of it must agree");
+
+namespace {
+
+void logerr(const char *ctx, const char *fmt, ...) {
+    char buf[400];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (hts_log) hts_log(1, ctx, "%s", buf); else fprintf(stderr, "[E::%s] %s\n", ctx, buf);
+}
+
+hg_ctx *engine() {                                   // one context for the block layer; its host calls lock it
+    static hg_ctx *ctx = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *d = getenv("HTS_GPU_DEVICE");
+        if (hg_init(d ? atoi(d) : 0, &ctx) != HG_OK) ctx = nullptr;
+    });
+    return ctx;
+}
+
+// CRC-32 of the few framing bytes of a block header (<= 17 bytes; the payload's CRC is computed on the device)
+uint32_t crc_small(uint32_t crc, const uint8_t *p, size_t n) {
+    crc = ~crc;
+    for (size_t i = 0; i < n; i++) { crc ^= p[i]; for (int k = 0; k < 8; k++) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u))); }
+    return ~crc;
+}
+uint32_t crc_mulmod(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) { if (a & (0x80000000u >> i)) p ^= b; b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1; }
+    return p;
+}
+uint32_t crc_concat(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+    uint32_t xp = 0x00800000u, acc = 0x80000000u;
+    for (; len_b; len_b >>= 1) { if (len_b & 1) acc = crc_mulmod(acc, xp); xp = crc_mulmod(xp, xp); }
+    return crc_mulmod(acc, crc_a) ^ crc_b;
+}
+
+// ---- variable-length integers of the block header ------------------------------------------------------------
+int itf8_put(uint8_t *p, int32_t sv) {
+    const uint32_t v = (uint32_t)sv;
+    if (v < 0x80u) { p[0] = (uint8_t)v; return 1; }
+    if (v < 0x4000u) { p[0] = (uint8_t)(0x80 | (v >> 8)); p[1] = (uint8_t)v; return 2; }
+    if (v < 0x200000u) { p[0] = (uint8_t)(0xc0 | (v >> 16)); p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)v; return 3; }
+    if (v < 0x10000000u) { p[0] = (uint8_t)(0xe0 | (v >> 24)); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; return 4; }
+    p[0] = (uint8_t)(0xf0 | (v >> 28)); p[1] = (uint8_t)(v >> 20); p[2] = (uint8_t)(v >> 12); p[3] = (uint8_t)(v >> 4); p[4] = (uint8_t)(v & 0x0f);
+    return 5;
+}
+int uint7_put(uint8_t *p, uint32_t v) {                       // big-endian base 128, MSB = "more" (cram_io.c:892-990)
+    int n = 1;
+    for (uint32_t t = v >> 7; t; t >>= 7) n++;
+    for (int i = 0; i < n; i++) p[i] = (uint8_t)(((v >> (7 * (n - 1 - i))) & 0x7f) | (i + 1 < n ? 0x80 : 0));
+    return n;
+}
+int varint_put(uint8_t *p, int major, int32_t v) { return major >= 4 ? uint7_put(p, (uint32_t)v) : itf8_put(p, v); }
+
+// reads one header integer, appending its raw bytes to hdr[] (for the CRC); -1 at EOF
+int varint_get(hFILE *fp, int major, int32_t *out, uint8_t *hdr, size_t *hl) {
+    auto next = [&]() -> int {
+        const int c = fp->end > fp->begin ? (unsigned char)*fp->begin++ : hgetc2(fp);
+        if (c >= 0) hdr[(*hl)++] = (uint8_t)c;
+        return c;
+    };
+    int c = next();
+    if (c < 0) return -1;
+    if (major >= 4) {
+        uint32_t v = (uint32_t)c & 0x7f;
+        for (int k = 0; (c & 0x80) && k < 5; k++) { if ((c = next()) < 0) return -1; v = (v << 7) | ((uint32_t)c & 0x7f); }
+        *out = (int32_t)v;
+        return 0;
+    }
+    const int extra = c < 0x80 ? 0 : c < 0xc0 ? 1 : c < 0xe0 ? 2 : c < 0xf0 ? 3 : 4;
+    uint32_t v = (uint32_t)c & (0xffu >> (extra + (extra < 4 ? 1 : 0)));
+    if (extra == 4) v = (uint32_t)c & 0x0f;
+    for (int k = 0; k < extra; k++) {
+        if ((c = next()) < 0) return -1;
+        v = (extra == 4 && k == 3) ? (v << 4) | ((uint32_t)c & 0x0f) : (v << 8) | (uint32_t)c;
+    }
+    *out = (int32_t)v;
+    return 0;
+}
+
+// ================================================================================ batch workers
+// Decode a set of blocks in one engine round.  rc[i] = 0 / -1.
+void uncompress_batch(cram_block **b, int n, int *rc) {
+    hg_ctx *ctx = engine();
+    std::vector<int> todo;                                     // blocks that need the device
+    for (int i = 0; i < n; i++) rc[i] = 0;
+    // ---- 1. block CRCs (cram_io.c:1585-1592), all unchecked blocks in one device batch
+    std::vector<int> chk;
+    for (int i = 0; i < n; i++) if (b[i]->crc32_checked == 0) chk.push_back(i);
+    if (!chk.empty()) {
+        std::vector<const uint8_t *> p(chk.size()); std::vector<uint32_t> len(chk.size()), crc(chk.size(), 0);
+        static const uint8_t none[1] = {0};
+        for (size_t k = 0; k < chk.size(); k++) { cram_block *x = b[chk[k]]; p[k] = x->data ? x->data : none; len[k] = x->data ? (uint32_t)x->alloc : 0u; }
+        const int r = ctx ? hg_crc32_batch_host(ctx, p.data(), len.data(), chk.size(), crc.data()) : HG_ENODEV;
+        for (size_t k = 0; k < chk.size(); k++) {
+            cram_block *x = b[chk[k]];
+            x->crc32_checked = 1;
+            const uint32_t full = len[k] ? crc_concat(x->crc_part, crc[k], len[k]) : x->crc_part;
+            if (r != HG_OK || full != x->crc32) { logerr("cram_uncompress_block", r != HG_OK ? "no usable GPU engine" : "Block CRC32 failure"); rc[chk[k]] = -1; }
+        }
+    }
+    // ---- 2. method dispatch
+    for (int i = 0; i < n; i++) {
+        if (rc[i]) continue;
+        cram_block *x = b[i];
+        if (x->uncomp_size == 0) { x->method = RAW; continue; }            // blank block (cram_io.c:1594-1598)
+        if (x->method == RAW) continue;
+        if (x->uncomp_size < 0 || x->comp_size < 0 || (int)x->method < 0 || (int)x->method > TOK3) { rc[i] = -1; continue; }
+        todo.push_back(i);
+    }
+    if (todo.empty()) return;
+    const size_t m = todo.size();
+    std::vector<int32_t> meth(m), st(m, -1); std::vector<const uint8_t *> in(m); std::vector<uint8_t *> out(m, nullptr);
+    std::vector<uint32_t> il(m), ol(m);
+    bool oom = false;
+    for (size_t k = 0; k < m; k++) {
+        cram_block *x = b[todo[k]];
+        meth[k] = (int32_t)x->method; in[k] = x->data; il[k] = (uint32_t)x->comp_size; ol[k] = (uint32_t)x->uncomp_size;
+        out[k] = (uint8_t *)malloc(ol[k] ? ol[k] : 1);
+        if (!out[k]) oom = true;
+    }
+    int r = oom ? HG_ENOMEM : ctx ? hg_cram_uncompress_blocks_host(ctx, m, meth.data(), in.data(), il.data(), out.data(), ol.data(), st.data()) : HG_ENODEV;
+    if (r != HG_OK && r != HG_EBLOCK) { logerr("cram_uncompress_block", "engine failure: %s", hg_strerror(r)); for (auto &s : st) s = -1; }
+    for (size_t k = 0; k < m; k++) {
+        cram_block *x = b[todo[k]];
+        if (st[k] != 0) {
+            if (st[k] == HG_BLOCK_EUNSUPPORTED)
+                logerr("cram_uncompress_block", "%s compression is not compiled into this version. Please rebuild and try again",
+                       x->method == BZIP2 ? "Bzip2" : x->method == LZMA ? "Lzma" : "Fqzcomp");
+            free(out[k]);
+            rc[todo[k]] = -1;
+            continue;
+        }
+        if (x->method == RANSPR || x->method == ARITH || x->method == TOK3) x->orig_method = x->method;   // cram_io.c:1706,1725,1740
+        free(x->data);
+        x->data = out[k];
+        x->alloc = ol[k];
+        x->method = RAW;
+    }
+}
+
+struct CompJob { const hg_cram_opts *opts; cram_block *b; cram_metrics *m; int method, level; int rc; };
+
+void compress_batch(CompJob *jobs, int n) {
+    hg_ctx *ctx = engine();
+    std::vector<int> todo;
+    for (int i = 0; i < n; i++) {
+        CompJob &j = jobs[i];
+        j.rc = 0;
+        cram_block *x = j.b;
+        if (!x || x->method != RAW) continue;                                  // already compressed (cram_io.c:1945-1952)
+        if (j.method == -1) j.method = 1 << GZIP;                             // bz2 / lzma are never offered
+        if (j.level == -1) j.level = j.opts ? j.opts->level : 5;
+        if (j.method == RAW || j.level == 0 || x->uncomp_size == 0) { x->method = RAW; x->comp_size = x->uncomp_size; continue; }
+        todo.push_back(i);
+    }
+    if (todo.empty()) return;
+    // Jobs are grouped by (level, version): the engine call takes one of each.  Metrics objects are updated inside the
+    // engine call in block order (the reference's state sequence), under the callers' metrics locks.
+    std::sort(todo.begin(), todo.end(), [&](int a, int c) {
+        const int va = jobs[a].opts ? jobs[a].opts->version : 0x301, vc = jobs[c].opts ? jobs[c].opts->version : 0x301;
+        if (jobs[a].level != jobs[c].level) return jobs[a].level < jobs[c].level;
+        if (va != vc) return va < vc;
+        return a < c;
+    });
+    size_t g0 = 0;
+    while (g0 < todo.size()) {
+        size_t g1 = g0;
+        const int level = jobs[todo[g0]].level, version = jobs[todo[g0]].opts ? jobs[todo[g0]].opts->version : 0x301;
+        while (g1 < todo.size() && jobs[todo[g1]].level == level && (jobs[todo[g1]].opts ? jobs[todo[g1]].opts->version : 0x301) == version) g1++;
+        const size_t m = g1 - g0;
+        std::vector<hg_cram_metrics *> met(m); std::vector<uint32_t> set(m), il(m), ol(m, 0); std::vector<const uint8_t *> in(m);
+        std::vector<uint8_t *> out(m, nullptr); std::vector<int32_t> used(m, 0);
+        std::vector<pthread_mutex_t *> locks;
+        bool oom = false;
+        for (size_t k = 0; k < m; k++) {
+            CompJob &j = jobs[todo[g0 + k]];
+            met[k] = reinterpret_cast<hg_cram_metrics *>(j.m); set[k] = (uint32_t)j.method;
+            in[k] = j.b->data; il[k] = (uint32_t)j.b->uncomp_size;
+            out[k] = (uint8_t *)malloc(hg_cram_compress_bound(il[k]));
+            if (!out[k]) oom = true;
+            if (j.m && j.opts && j.opts->metrics_lock) locks.push_back((pthread_mutex_t *)j.opts->metrics_lock);
+        }
+        std::sort(locks.begin(), locks.end());
+        locks.erase(std::unique(locks.begin(), locks.end()), locks.end());
+        for (auto l : locks) pthread_mutex_lock(l);
+        int r = oom ? HG_ENOMEM : ctx ? hg_cram_compress_blocks_metrics_host(ctx, m, met.data(), set.data(), level, version >> 8, in.data(), il.data(),
+                                                                             out.data(), ol.data(), used.data()) : HG_ENODEV;
+        for (auto it = locks.rbegin(); it != locks.rend(); ++it) pthread_mutex_unlock(*it);
+        for (size_t k = 0; k < m; k++) {
+            CompJob &j = jobs[todo[g0 + k]];
+            cram_block *x = j.b;
+            if (r != HG_OK) { free(out[k]); j.rc = -1; continue; }
+            if (used[k] == HG_CRAM_RAW || ol[k] >= il[k]) {                     // nothing beat the raw bytes (cram_io.c:2271-2278)
+                free(out[k]);
+                x->method = RAW; x->comp_size = x->uncomp_size;
+                continue;
+            }
+            uint8_t *fit = (uint8_t *)realloc(out[k], ol[k] ? ol[k] : 1);
+            free(x->data);
+            x->data = fit ? fit : out[k];
+            x->alloc = ol[k];
+            x->comp_size = (int32_t)ol[k];
+            x->method = (enum cram_block_method_int)used[k];                   // already the on-disk id
+        }
+        if (r != HG_OK) logerr("cram_compress_block", "engine failure: %s", hg_strerror(r));
+        g0 = g1;
+    }
+}
+
+// ================================================================================ coalescing of single-block callers
+// Leader / follower: requests queue up; whoever finds no leader becomes one, lingers, takes everything queued so far,
+// runs the batch and publishes the results.
+template <class Req>
+struct Coalescer {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<Req *> queue;
+    bool leader = false;
+    void (*run)(Req **, int);
+
+    void submit(Req *r) {
+        std::unique_lock<std::mutex> lk(m);
+        queue.push_back(r);
+        while (!r->done) {
+            if (!leader) {
+                leader = true;
+                lk.unlock();
+                std::this_thread::sleep_for(std::chrono::microseconds(linger_us()));
+                lk.lock();
+                std::vector<Req *> batch;
+                batch.swap(queue);
+                lk.unlock();
+                run(batch.data(), (int)batch.size());
+                lk.lock();
+                for (Req *q : batch) q->done = true;
+                leader = false;
+                cv.notify_all();
+            } else cv.wait(lk);
+        }
+    }
+    static int linger_us() {
+        static const int us = [] { const char *e = getenv("HTS_GPU_LINGER_US"); return e ? atoi(e) : 50; }();
+        return us;
+    }
+};
+
+struct UncReq { cram_block *b; int rc; bool done; };
+struct CompReq { CompJob job; bool done; };
+
+void run_unc(UncReq **r, int n) {
+    std::vector<cram_block *> b(n); std::vector<int> rc(n);
+    for (int i = 0; i < n; i++) b[i] = r[i]->b;
+    uncompress_batch(b.data(), n, rc.data());
+    for (int i = 0; i < n; i++) r[i]->rc = rc[i];
+}
+void run_comp(CompReq **r, int n) {
+    std::vector<CompJob> jobs(n);
+    for (int i = 0; i < n; i++) jobs[i] = r[i]->job;
+    compress_batch(jobs.data(), n);
+    for (int i = 0; i < n; i++) r[i]->job.rc = jobs[i].rc;
+}
+Coalescer<UncReq> g_unc{{}, {}, {}, false, run_unc};
+Coalescer<CompReq> g_comp{{}, {}, {}, false, run_comp};
+
+}  // namespace
+
+extern "C" {
+
+cram_block *cram_new_block(enum cram_content_type content_type, int content_id) {
+    cram_block *b = (cram_block *)calloc(1, sizeof(cram_block));
+    if (!b) return nullptr;
+    b->method = b->orig_method = RAW;
+    b->content_type = content_type;
+    b->content_id = content_id;
+    b->bit = 7;
+    return b;
+}
+
+void cram_free_block(cram_block *b) {
+    if (!b) return;
+    free(b->data);
+    free(b);
+}
+
+cram_metrics *cram_new_metrics(void) { return reinterpret_cast<cram_metrics *>(hg_cram_metrics_new()); }
+
+int cram_uncompress_block(cram_block *b) {
+    if (!b) return -1;
+    // nothing for the device to do: answer at once (cram_io.c:1594-1603) -- no linger for RAW blocks
+    if (b->crc32_checked && (b->uncomp_size == 0 || b->method == RAW)) { if (b->uncomp_size == 0) b->method = RAW; return 0; }
+    UncReq r{b, -1, false};
+    g_unc.submit(&r);
+    return r.rc;
+}
+
+int cram_uncompress_blocks(cram_block **b, int n, int *blk_rc) {
+    if (n <= 0) return 0;
+    std::vector<int> rc(n);
+    uncompress_batch(b, n, rc.data());
+    int any = 0;
+    for (int i = 0; i < n; i++) { if (blk_rc) blk_rc[i] = rc[i]; if (rc[i]) any = -1; }
+    return any;
+}
+
+int hg_cram_compress_block(const hg_cram_opts *opts, cram_block *b, cram_metrics *metrics, int method, int level) {
+    if (!b) return 0;
+    if (b->method != RAW) return 0;
+    CompReq r{{opts, b, metrics, method, level, -1}, false};
+    const int lv = level == -1 ? (opts ? opts->level : 5) : level;
+    if (method == RAW || lv == 0 || b->uncomp_size == 0) { compress_batch(&r.job, 1); return r.job.rc; }   // no device work
+    g_comp.submit(&r);
+    return r.job.rc;
+}
+
+int hg_cram_compress_blocks(const hg_cram_opts *opts, cram_block **b, cram_metrics **metrics, const int *method, int level, int n) {
+    if (n <= 0) return 0;
+    std::vector<CompJob> jobs(n);
+    for (int i = 0; i < n; i++) jobs[i] = CompJob{opts, b[i], metrics ? metrics[i] : nullptr, method ? method[i] : -1, level, -1};
+    compress_batch(jobs.data(), n);
+    for (int i = 0; i < n; i++) if (jobs[i].rc) return -1;
+    return 0;
+}
+
+uint32_t cram_block_size(cram_block *b) {
+    uint8_t tmp[32];
+    size_t n = 2;
+    n += (size_t)itf8_put(tmp, b->content_id) + (size_t)itf8_put(tmp, b->comp_size) + (size_t)itf8_put(tmp, b->uncomp_size);
+    return (uint32_t)(n + 4 + (size_t)(b->method == RAW ? b->uncomp_size : b->comp_size));
+}
+
+cram_block *hg_cram_read_block(hFILE *fp, int major, int ignore_crc) {
+    cram_block *b = (cram_block *)calloc(1, sizeof(cram_block));
+    if (!b) return nullptr;
+    uint8_t hdr[40]; size_t hl = 0;
+    auto byte = [&]() -> int { const int c = fp->end > fp->begin ? (unsigned char)*fp->begin++ : hgetc2(fp); if (c >= 0) hdr[hl++] = (uint8_t)c; return c; };
+    int c = byte();
+    if (c < 0) { free(b); return nullptr; }
+    if (c > TOK3) { logerr("cram_read_block", "Unknown block compression method %d", c); free(b); return nullptr; }
+    b->method = (enum cram_block_method_int)c;
+    if ((c = byte()) < 0) { free(b); return nullptr; }
+    b->content_type = (enum cram_content_type)c;
+    if (varint_get(fp, major, &b->content_id, hdr, &hl) || varint_get(fp, major, &b->comp_size, hdr, &hl) ||
+        varint_get(fp, major, &b->uncomp_size, hdr, &hl)) { free(b); return nullptr; }
+    if (b->comp_size < 0 || b->uncomp_size < 0 || (b->method == RAW && b->comp_size != b->uncomp_size)) { free(b); return nullptr; }
+    const size_t payload = (size_t)(b->method == RAW ? b->uncomp_size : b->comp_size);
+    b->alloc = payload;
+    if (!(b->data = (unsigned char *)malloc(payload ? payload : 1)) || hg_hread(fp, b->data, payload) != (ssize_t)payload) { cram_free_block(b); return nullptr; }
+    if (major >= 3) {
+        uint8_t t[4];
+        if (hg_hread(fp, t, 4) != 4) { cram_free_block(b); return nullptr; }
+        b->crc32 = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        b->crc32_checked = ignore_crc ? 1 : 0;
+        b->crc_part = crc_small(0, hdr, hl);
+    } else b->crc32_checked = 1;                                              // no CRC before v3
+    b->orig_method = b->method;
+    b->bit = 7;
+    return b;
+}
+
+int hg_cram_write_block(hFILE *fp, int major, cram_block *b) {
+    uint8_t hdr[40]; size_t hl = 0;
+    if (b->method == RAW && b->comp_size != b->uncomp_size) return -1;
+    hdr[hl++] = (uint8_t)b->method; hdr[hl++] = (uint8_t)b->content_type;
+    hl += (size_t)varint_put(hdr + hl, major, b->content_id);
+    hl += (size_t)varint_put(hdr + hl, major, b->comp_size);
+    hl += (size_t)varint_put(hdr + hl, major, b->uncomp_size);
+    if (hg_hwrite(fp, hdr, hl) != (ssize_t)hl) return -1;
+    const size_t payload = b->data ? (size_t)(b->method == RAW ? b->uncomp_size : b->comp_size) : 0;
+    if (payload && hg_hwrite(fp, b->data, payload) != (ssize_t)payload) return -1;
+    if (major >= 3) {
+        uint32_t crc = crc_small(0, hdr, hl);
+        if (payload) {
+            hg_ctx *ctx = engine();
+            uint32_t pc = 0;
+            if (!ctx || hg_crc32_host(ctx, b->data, payload, &pc) != HG_OK) { logerr("cram_write_block", "no usable GPU engine"); return -1; }
+            crc = crc_concat(crc, pc, payload);
+        }
+        b->crc32 = crc;
+        const uint8_t t[4] = {(uint8_t)crc, (uint8_t)(crc >> 8), (uint8_t)(crc >> 16), (uint8_t)(crc >> 24)};
+        if (hg_hwrite(fp, t, 4) != 4) return -1;
+    }
+    return 0;
+}
+
+}  // extern "C"

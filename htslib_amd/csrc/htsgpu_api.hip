@@ -658,6 +658,25 @@ int hg_cram_compress_blocks_host(hg_ctx *ctx, size_t n, const uint32_t *method_m
     return rc;
 }
 
+// crc[i] = CRC-32 of host buffer i: one staged upload, one wavefront per buffer, one download
+int hg_crc32_batch_host(hg_ctx *ctx, const uint8_t *const *buf, const uint32_t *len, size_t n, uint32_t *crc) {
+    if (!ctx || (n && (!buf || !len || !crc))) return HG_EINVAL;
+    if (n == 0) return HG_OK;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
+    std::vector<uint64_t> off(n); uint64_t tot = 0;
+    for (size_t i = 0; i < n; i++) { off[i] = tot; tot += ((uint64_t)len[i] + 15u) & ~15ull; }
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, tot + 64)) || (rc = ensure_scratch(ctx, 2, n * 8 + 64)) || (rc = ensure_scratch(ctx, 3, n * 8 + 64))) return rc;
+    hipStream_t s = ctx->stream;
+    if ((rc = hg::stage_upload(ctx, buf, len, off.data(), nullptr, n, tot, (uint8_t *)ctx->d_scratch[0], s))) return rc;
+    uint32_t *d_len = (uint32_t *)ctx->d_scratch[3], *d_crc = d_len + n;
+    if (hipMemcpyAsync(ctx->d_scratch[2], off.data(), n * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_len, len, n * 4, hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
+    if ((rc = hg::launch_crc32(ctx, ctx->d_scratch[0], (const uint64_t *)ctx->d_scratch[2], d_len, n, d_crc, s))) return rc;
+    if (hipMemcpyAsync(crc, d_crc, n * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+    return HG_OK;
+}
+
 // CRC-32 of one host buffer (hts_crc32, bgzf.c:557-559): upload, one wavefront per 1 MiB piece, combine on the host
 int hg_crc32_host(hg_ctx *ctx, const void *buf, size_t len, uint32_t *crc) {
     if (!ctx || !crc || (!buf && len)) return HG_EINVAL;

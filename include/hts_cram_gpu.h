@@ -1,0 +1,122 @@
+/*
+ * hts_cram_gpu.h -- the CRAM block layer of htslib on the gfx950 engine: cram_uncompress_block / cram_compress_block
+ * with the reference's own `struct cram_block` calling convention (one malloc'd buffer per block, replaced in place).
+ *
+ * Reference interfaces replaced (file:line in /root/reference):
+ *   struct cram_block, enum cram_block_method_int, struct cram_metrics   cram/cram_structs.h:215-266,284-305,312-332
+ *   int  cram_uncompress_block(cram_block *b)                            cram/cram_io.c:1576-1754   (htslib.map:164)
+ *   int  cram_compress_block / cram_compress_block2 / 3                  cram/cram_io.c:1912-2325   (htslib.map:149)
+ *   cram_block *cram_new_block / void cram_free_block                    cram/cram_io.c:1388, 1565
+ *   cram_block *cram_read_block(cram_fd*) / int cram_write_block         cram/cram_io.c:1414-1483, 1511-1560
+ *   cram_metrics *cram_new_metrics(void)                                 cram/cram_io.c:2327-2339
+ *
+ * The two structs below have the reference's layout (tests/native/cram_layout_check.c asserts every offset against
+ * the real cram/cram_structs.h), so objects compiled against htslib's headers can call these functions directly.
+ * `cram_fd` / `cram_slice` are large private structs; the block layer needs five scalars of the former and nothing
+ * of the latter (fqzcomp's per-record lengths aside), so those travel in `hg_cram_opts`.  INTEGRATION.md shows the
+ * three-line bodies that make cram_io.c's own cram_compress_block2 / cram_read_block forward here.
+ *
+ * Batching.  One block is far too little work for a GPU, and htslib calls these functions one block at a time from
+ * many pool workers (one slice per worker).  Two answers:
+ *   - the ARRAY forms (cram_uncompress_blocks, hg_cram_compress_blocks) take all blocks of a slice in one call;
+ *   - the single-block forms COALESCE: concurrent callers are gathered for a short window by a leader thread and
+ *     sent to the device as one batch (each caller still gets its own result and its own malloc'd buffer).
+ * Results follow the reference's ownership rule: b->data is free()d and replaced by a malloc()ed buffer
+ * (cram_io.c:1615-1617, 2093-2097).
+ */
+#ifndef HTS_CRAM_GPU_H
+#define HTS_CRAM_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <sys/types.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct hFILE;
+
+/* cram/cram_structs.h:215-266 (values are the on-disk ids up to TOK3, internal parameterised ones above) */
+enum cram_block_method_int {
+    BM_ERROR = -1,
+    RAW = 0, GZIP = 1, BZIP2 = 2, LZMA = 3, RANS = 4, RANS0 = RANS,
+    RANSPR = 5, RANS_PR0 = RANSPR, ARITH = 6, ARITH_PR0 = ARITH, FQZ = 7, TOK3 = 8,
+    GZIP_RLE = 11, GZIP_1, FQZ_b, FQZ_c, FQZ_d,
+    RANS1,
+    RANS_PR1, RANS_PR64, RANS_PR9, RANS_PR128, RANS_PR129, RANS_PR192, RANS_PR193,
+    TOKA,
+    ARITH_PR1, ARITH_PR64, ARITH_PR9, ARITH_PR128, ARITH_PR129, ARITH_PR192, ARITH_PR193
+};
+
+/* htslib/cram.h:103-111 */
+enum cram_content_type {
+    CT_ERROR = -1, FILE_HEADER = 0, COMPRESSION_HEADER = 1, MAPPED_SLICE = 2, UNMAPPED_SLICE = 3, EXTERNAL = 4, CORE = 5
+};
+
+#define CRAM_MAX_METHOD 32
+typedef struct cram_metrics {
+    int trial, next_trial, consistency;
+    int sz[CRAM_MAX_METHOD];
+    int input_avg_sz, input_avg_delta;
+    int method, revised_method;
+    int strat;
+    int cnt[CRAM_MAX_METHOD];
+    double extra[CRAM_MAX_METHOD];
+    int unpackable;
+} cram_metrics;
+
+typedef struct cram_block {
+    enum cram_block_method_int method, orig_method;
+    enum cram_content_type content_type;
+    int32_t content_id;
+    int32_t comp_size;
+    int32_t uncomp_size;
+    uint32_t crc32;
+    int32_t idx;
+    unsigned char *data;
+    size_t alloc;
+    size_t byte;
+    int bit;
+    cram_metrics *m;
+    int crc32_checked;
+    uint32_t crc_part;
+} cram_block;
+
+cram_block *cram_new_block(enum cram_content_type content_type, int content_id);
+void cram_free_block(cram_block *b);
+cram_metrics *cram_new_metrics(void);
+
+/* Exactly the reference's function: CRC check (once), method dispatch, b->data replaced, method = RAW; 0 / -1.
+ * bzip2, lzma and fqzcomp blocks fail with -1 and an error message, like a libhts built without those codecs. */
+int cram_uncompress_block(cram_block *b);
+/* All blocks of a slice / container at once; returns 0 or -1 if any block failed (each block is left either fully
+ * decoded or untouched; blk_rc, if given, receives the per-block 0 / -1). */
+int cram_uncompress_blocks(cram_block **b, int n, int *blk_rc);
+
+/* What cram_compress_block3 reads from its cram_fd (cram_io.c:1951-1965, 1979, 2282). */
+typedef struct hg_cram_opts {
+    int level;            /* fd->level                                                              */
+    int version;          /* fd->version (major << 8 | minor)                                       */
+    int use_bz2, use_lzma;/* accepted; those codecs are not offered (as in a build without the libs) */
+    void *metrics_lock;   /* &fd->metrics_lock (pthread_mutex_t *) or NULL                          */
+} hg_cram_opts;
+
+/* cram_compress_block2(fd, s, b, metrics, method, level) with fd reduced to opts: `method` is a bit set of
+ * cram_block_method_int values (-1 = default GZIP), level -1 = opts->level.  The block is compressed with every
+ * method of the set while `metrics` is in a trial phase, else with the method it learnt; statistics, costs and
+ * retrial spans follow cram_io.c:1978-2278.  b->data / comp_size / method are replaced as the reference does. */
+int hg_cram_compress_block(const hg_cram_opts *opts, cram_block *b, cram_metrics *metrics, int method, int level);
+int hg_cram_compress_blocks(const hg_cram_opts *opts, cram_block **b, cram_metrics **metrics, const int *method, int level, int n);
+
+/* Block framing (cram_read_block / cram_write_block with fd reduced to the transport and the file's major version):
+ * method u8, content_type u8, content_id / comp_size / uncomp_size as ITF8 (v2, v3) or uint7 varints (v4), payload,
+ * CRC-32 (v3+).  read: b->crc_part = CRC of the header bytes, crc32_checked = ignore_crc. */
+cram_block *hg_cram_read_block(struct hFILE *fp, int major_version, int ignore_crc);
+int hg_cram_write_block(struct hFILE *fp, int major_version, cram_block *b);
+uint32_t cram_block_size(cram_block *b);                                   /* cram_io.c:1490-1505 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

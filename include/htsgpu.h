@@ -397,6 +397,9 @@ int hg_crc32_dev(hg_ctx *ctx, const void *d_data,
                  const uint64_t *d_off, const uint32_t *d_len, size_t n,
                  uint32_t *d_crc, void *stream);
 
+/* crc[i] = crc32(0, buf[i], len[i]) for n host buffers in one device round trip (the block CRCs of
+ * cram_uncompress_block / cram_write_block, cram_io.c:1585-1592, 1538-1554).  Synchronous. */
+int hg_crc32_batch_host(hg_ctx *ctx, const uint8_t *const *buf, const uint32_t *len, size_t n, uint32_t *crc);
 /* CRC-32 of one host buffer (upload + device CRC + host combine).  Synchronous. */
 int hg_crc32_host(hg_ctx *ctx, const void *buf, size_t len, uint32_t *crc);
 

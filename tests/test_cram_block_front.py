@@ -1,0 +1,87 @@
+"""include/hts_cram_gpu.h: cram_uncompress_block / cram_compress_block with the reference's own struct cram_block.
+CPU: the struct / enum layout equals the reference's cram/cram_structs.h (checked by compiling against both headers).
+GPU: a plain-C driver (tests/native/cram_blocks_c.c) pushes all 565 blocks of the reference's 34 CRAM v3.0 fixtures
+through hg_cram_read_block -> hg_cram_write_block (byte-identical, CRC recomputed on the device) ->
+cram_uncompress_block (array form, one by one, and from 8 threads at once = the coalescing path) and then through
+the auto-tuning compressor and back."""
+import json
+import os
+import struct
+import subprocess
+
+import pytest
+
+from tests import refutil
+
+ROOT = refutil.ROOT
+NAT = os.path.join(ROOT, "tests", "native")
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference headers")
+def test_struct_layout_equals_reference_headers(tmp_path, built):
+    t = str(tmp_path)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "_ref/config.h"], check=False, capture_output=True)
+    subprocess.run(["gcc", "-c", "-I", os.path.join(ROOT, "oracle", "_ref"), "-I", REF, os.path.join(NAT, "cram_layout_ref.c"), "-o", t + "/r.o"], check=True)
+    subprocess.run(["gcc", "-c", "-I", os.path.join(ROOT, "include"), os.path.join(NAT, "cram_layout_ours.c"), "-o", t + "/o.o"], check=True)
+    subprocess.run(["gcc", os.path.join(NAT, "cram_layout_main.c"), t + "/r.o", t + "/o.o", "-o", t + "/layout"], check=True)
+    out = subprocess.run([t + "/layout"], capture_output=True, text=True)
+    assert out.returncode == 0 and "layout identical" in out.stdout, out.stdout
+
+
+def blocks():
+    return json.load(open(os.path.join(refutil.ROOT, "tests", "golden", "cram_blocks.json")))
+
+
+@pytest.fixture(scope="module")
+def driver(built, tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("cramc") / "cram_blocks_c")
+    lib = os.path.join(ROOT, "htslib_amd")
+    subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(NAT, "cram_blocks_c.c"),
+                    "-o", exe, "-L", lib, "-lhts_bgzf", "-lhtsgpu", "-lpthread", "-Wl,-rpath," + lib], check=True)
+    return exe
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["array", "single", "threads"])
+def test_c_driver_decodes_every_reference_fixture_block(driver, engine, tmp_path, mode):
+    bl = blocks()
+    disk = b"".join(bytes.fromhex(b["hdr_hex"]) + bytes.fromhex(b["data_hex"]) + struct.pack("<I", b["crc32"]) for b in bl)
+    src, out = str(tmp_path / "blocks.bin"), str(tmp_path / "out.bin")
+    open(src, "wb").write(disk)
+    r = subprocess.run([driver, src, out, mode], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-500:]
+    assert f"blocks {len(bl)} decoded_ok {len(bl)}" in r.stdout, r.stdout
+    assert open(out + ".rewrite", "rb").read() == disk                      # hg_cram_write_block reproduces the file bytes
+    raw = open(out, "rb").read()
+    pos = 0
+    pinned = 0
+    for b in bl:
+        rc, n = struct.unpack_from("<ii", raw, pos); pos += 8
+        assert rc == 0 and n == b["usize"], (b["source"], b["method"], b["content_id"])
+        got = raw[pos:pos + n]; pos += n
+        if b["expected_hex"] is not None:                                   # plaintext known without any code of ours
+            assert got == bytes.fromhex(b["expected_hex"]), (b["source"], b["method"], b["content_id"])
+            pinned += 1
+    assert pos == len(raw) and pinned >= 500
+
+
+@pytest.mark.gpu
+def test_c_driver_reports_corrupt_blocks_like_the_reference(driver, engine, tmp_path):
+    """A flipped payload byte = "Block CRC32 failure" -> -1 for that block only (cram_io.c:1585-1592)."""
+    bl = [b for b in blocks() if b["method"] in (1, 4)][:40]
+    parts = []
+    for i, b in enumerate(bl):
+        data = bytearray(bytes.fromhex(b["data_hex"]))
+        if i % 5 == 0: data[len(data) // 2] ^= 0x40
+        parts.append(bytes.fromhex(b["hdr_hex"]) + bytes(data) + struct.pack("<I", b["crc32"]))
+    src, out = str(tmp_path / "blocks.bin"), str(tmp_path / "out.bin")
+    open(src, "wb").write(b"".join(parts))
+    r = subprocess.run([driver, src, out, "threads"], capture_output=True, text=True, timeout=600, env=dict(os.environ, CRAMC_ALLOW_BAD_CRC="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count("Block CRC32 failure") == 8
+    raw = open(out, "rb").read()
+    pos = 0
+    for i, b in enumerate(bl):
+        rc, n = struct.unpack_from("<ii", raw, pos); pos += 8 + n
+        assert rc == (-1 if i % 5 == 0 else 0) and n == (0 if i % 5 == 0 else b["usize"])
