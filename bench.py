@@ -5,7 +5,13 @@ A "step" is ONE pass of the hot path over the whole workload: every BGZF block
 of the (per-GPU) synthetic BAM is inflated + CRC-checked by one launch of the
 gfx950 kernel, inputs and outputs resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--gib G]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--gib G] [--op all|inflate|deflate|rans|cram|bam|e2e]
+
+The default (--op all) prints ONE JSON line: the headline is BGZF inflate (BASELINE configs[1]) and `extra` carries
+the other quantities of BASELINE.json's metric -- BGZF deflate (configs[2]), CRAM rANS Nx16 decode (configs[3]),
+whole CRAM 3.1 slice encode/decode (configs[4] shape) -- each with its own `roofline` and `cpu_baseline`, plus
+`end_to_end`: what a libhts caller sees through bgzf_read / bgzf_write (file I/O + PCIe + kernels, overlapped) and
+the latency of random bgzf_seek + read, next to the reference library doing the same on the host cores.
 
 N>1 is launched by the driver through torch.distributed.run (one rank per GPU,
 blocks are independent so there is NO data-path collective; the only collective
@@ -122,7 +128,7 @@ def cpu_baseline(bgzf_sample: bytes, plain_len: int, threads: int):
         f.write(bgzf_sample)
         from htslib_amd import synth
         f.write(synth.BGZF_EOF)
-    best = None
+    times = []
     try:
         for _ in range(3):
             t = time.perf_counter()
@@ -131,184 +137,237 @@ def cpu_baseline(bgzf_sample: bytes, plain_len: int, threads: int):
             dt = time.perf_counter() - t
             if r.returncode != 0:
                 return None
-            best = dt if best is None else min(best, dt)
+            times.append(dt)
     finally:
         os.unlink(path)
+    best = sorted(times)[1]                                   # median of 3
     return {"value": round(plain_len / best / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "reference",
             "sample": f"oracle/_ref/ref_bgzip_ld -d -@{threads} (htslib bgzf.c + libdeflate 1.8, hts_tpool) on "
-                      f"{plain_len / 2**30:.2f} GiB of the same BAM from /dev/shm, best of 3"}
+                      f"{plain_len / 2**30:.2f} GiB of the same BAM from /dev/shm, median of 3"}
 
 
-def hbm_traffic_rans(plain_bytes):
-    """Same for the rANS Nx16 decode kernel (profiles/hbm_traffic_rans.json: FETCH_SIZE doubled as calibrated, + WRITE_SIZE)."""
+
+def cpu_baseline_deflate(sample: bytes, level: int, threads: int):
+    """Reference htslib (bgzf.c + libdeflate 1.8, hts_tpool) compressing the sample: ref_bgzip -l L -@T; median of 3."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_bgzip_ld")
+    if not os.path.exists(exe):
+        return None
+    p = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"htsgpu_defl_in_{os.getpid()}")
+    open(p, "wb").write(sample)
+    times = []
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_rans.json")))
-        return int(t["traffic_bytes_per_plain_byte"] * plain_bytes)
+        for _ in range(3):
+            t = time.perf_counter()
+            with open(os.devnull, "wb") as dn:
+                r = subprocess.run([exe, "-c", "-l", str(level), "-@", str(threads), p], stdout=dn)
+            if r.returncode != 0:
+                return None
+            times.append(time.perf_counter() - t)
+    finally:
+        os.unlink(p)
+    return {"value": round(len(sample) / sorted(times)[1] / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "reference",
+            "sample": f"oracle/_ref/ref_bgzip_ld -l{level} -@{threads} (htslib bgzf.c + libdeflate 1.8) on "
+                      f"{len(sample) / 2**30:.2f} GiB of the same BAM from /dev/shm, median of 3"}
+
+
+def hbm_traffic_file(name, key_sum, plain_bytes):
+    """HBM bytes per launch from a committed PMC summary under profiles/ (per plain byte, scaled to this workload)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        return int(sum(t[k] for k in key_sum) * plain_bytes)
     except Exception:
         return None
 
 
-def hbm_traffic(plain_bytes):
-    """HBM bytes per launch from the committed PMC passes (profiles/hbm_traffic_inflate.json:
-    FETCH_SIZE + WRITE_SIZE per plain byte at the 10 GiB config), scaled to this workload; None if absent."""
+def symbols_per_byte(comp: bytes, desc, nblocks: int = 64):
+    """Huffman symbols (literals + matches) per plain byte, counted by the oracle's inflate on a sample of blocks."""
+    import ctypes as C
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_inflate.json")))
-        return int((t["fetch_bytes_per_plain_byte"] + t["write_bytes_per_plain_byte"]) * plain_bytes)
+        orc = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        orc.orc_bgzf_decompress_stream.restype = C.c_long
+        orc.orc_bgzf_decompress_stream.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        orc.orc_symbol_counts.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_int]
+        step = max(1, len(desc) // nblocks)
+        lit, mat = C.c_ulonglong(), C.c_ulonglong()
+        orc.orc_symbol_counts(None, None, 1)
+        plain = 0
+        buf = C.create_string_buffer(65536 + 64)
+        for i in range(0, len(desc), step):
+            d = desc[i]
+            blk = comp[int(d["coff"]):int(d["coff"]) + int(d["clen"])]
+            n = orc.orc_bgzf_decompress_stream(blk, len(blk), buf, 65536 + 64)
+            if n > 0:
+                plain += n
+        orc.orc_symbol_counts(C.byref(lit), C.byref(mat), 1)
+        return (lit.value + mat.value) / max(plain, 1), lit.value / max(lit.value + mat.value, 1)
     except Exception:
-        return None
+        return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--gib", type=float, default=10.0, help="plain GiB of synthetic BAM per GPU")
-    ap.add_argument("--level", type=int, default=6)
-    ap.add_argument("--workers", type=int, default=0, help="host processes for workload preparation")
-    ap.add_argument("--op", choices=["inflate", "deflate", "rans", "bam", "cram"], default="inflate",
-                    help="inflate = BASELINE configs[1] (default, the headline); deflate = configs[2]; "
-                         "rans = configs[3] (CRAM 3.1 rANS Nx16 decode of QS+BA series); bam = SURVEY 8f N1: record framing "
-                         "(bam_read1) + nibble2base over the inflated stream, on the device; cram = configs[4] shape: whole CRAM 3.1 "
-                         "slices through the cram_compress_block2 auto-tuner (rANS Nx16 + tok3 + range coder), host entry points")
-    ap.add_argument("--slices", type=int, default=1000, help="--op rans: CRAM slices of 10 000 reads (1000 = 10 M reads)")
-    ap.add_argument("--no-cache", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class Run:
+    """Process-wide bench context: rank / world / device, torch.distributed when world > 1."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
-    ncores = os.cpu_count() or 1
-    workers = args.workers or max(1, (ncores - 4) // max(1, world))
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world > 1:
+            args.gpus = self.world
+        self.ncores = os.cpu_count() or 1
+        self.workers = args.workers or max(1, (self.ncores - 4) // max(1, self.world))
+        self.dist = None
+        self.dev = None
 
-    if args.op == "rans":
-        return bench_rans(args, rank, world, local, ncores)
-    if args.op == "cram":
-        return bench_cram(args, rank, world, local)
-    # ---------------- workload preparation (host, not timed, before HIP init) --------------
+    def init_device(self):
+        import torch
+        torch.cuda.set_device(self.local)
+        self.dev = torch.device("cuda", self.local)
+        if self.world > 1 and self.dist is None:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=self.dev)
+            self.dist = dist
+        return torch
+
+    def barrier(self):
+        import torch
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+            self.dist = None
+
+    def timed(self, step, steps, warmup):
+        """W untimed warm-ups, then EXACTLY `steps` steps bracketed by barrier + synchronize; per-step HIP events."""
+        import torch
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for a, b in evs:
+            a.record(); step(); b.record()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        return elapsed, float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+
+class Staged:
+    """The synthetic BAM of this rank, compressed (host bytes + HBM) and the buffers of the inflate launch."""
+
+
+def stage(run: Run) -> Staged:
+    args = run.args
+    S = Staged()
     total_bytes = int(args.gib * (1 << 30))
     cache = None if args.no_cache else os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "htsgpu_bench_cache")
     t0 = time.perf_counter()
-    first_chunk = 0
-    if world > 1 and cache:
-        seed = 0x5EED0001
-        comp, first_chunk = prepare_shared(rank, world, seed, total_bytes, args.level, workers, cache, rotate=args.op != "bam")
+    S.first_chunk = 0
+    strong = args.scaling == "strong" and run.world > 1
+    if run.world > 1 and cache:
+        S.seed = 0x5EED0001
+        comp, S.first_chunk = prepare_shared(run.rank, run.world, S.seed, total_bytes, args.level, run.workers, cache,
+                                             rotate=(args.op != "bam" and not strong))
     else:
-        seed = 0x5EED0001 + 1000003 * rank
-        comp = prepare(seed, total_bytes, args.level, workers, cache)
-    t_prep = time.perf_counter() - t0
-
-    import torch
+        S.seed = 0x5EED0001 + (0 if strong else 1000003 * run.rank)
+        comp = prepare(S.seed, total_bytes, args.level, run.workers, cache)
+    S.t_prep = time.perf_counter() - t0
+    torch = run.init_device()
     from htslib_amd import _native as nat
-
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    eng = nat.Engine(local)
+    from htslib_amd.bgzf import shard_blocks
+    S.eng = nat.Engine(run.local)
     desc, total_u = nat.bgzf_scan(comp)
-    nblocks = len(desc)
-    comp_len = len(comp)
-    pad = (-comp_len) % 256 + 256
-    h_comp = torch.frombuffer(bytearray(comp), dtype=torch.uint8)
-    d_comp = torch.zeros(comp_len + pad, dtype=torch.uint8, device=dev)
-    d_comp[:comp_len].copy_(h_comp)
-    d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(dev)
-    d_out = torch.empty(total_u + 256, dtype=torch.uint8, device=dev)
-    d_status = torch.full((nblocks,), 77, dtype=torch.int32, device=dev)
+    S.whole_blocks, S.whole_plain = len(desc), int(total_u)
+    S.shard = None
+    if strong:
+        # ONE data set, split by block ranges balanced on plain bytes (SURVEY 8e); rank r decodes only its range
+        lo, hi = shard_blocks(desc, run.world)[run.rank]
+        S.shard = (lo, hi)
+        c0 = int(desc["coff"][lo]) if lo < len(desc) else len(comp)
+        c1 = int(desc["coff"][hi - 1] + desc["clen"][hi - 1]) if hi > lo else c0
+        comp = comp[c0:c1]
+        desc, total_u = nat.bgzf_scan(comp)
+    S.comp, S.desc, S.total_u = comp, desc, int(total_u)
+    S.nblocks, S.comp_len = len(desc), len(comp)
+    pad = (-S.comp_len) % 256 + 256
+    S.d_comp = torch.zeros(S.comp_len + pad, dtype=torch.uint8, device=run.dev)
+    S.d_comp[:S.comp_len].copy_(torch.frombuffer(bytearray(comp), dtype=torch.uint8))
+    S.d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(run.dev)
+    S.d_out = torch.empty(S.total_u + 256, dtype=torch.uint8, device=run.dev)
+    S.d_status = torch.full((max(S.nblocks, 1),), 77, dtype=torch.int32, device=run.dev)
     torch.cuda.synchronize()
-    stream = torch.cuda.current_stream().cuda_stream
+    S.stream = torch.cuda.current_stream().cuda_stream
+    return S
 
-    if args.op == "bam":
-        return bench_bam(args, eng, comp, desc, total_u, d_comp, d_desc, d_out, d_status, dev, rank, world, seed)
-    if args.op == "deflate":
-        return bench_deflate(args, eng, comp, desc, total_u, d_comp, d_desc, d_out, d_status, dev, rank, world,
-                             ncores, t_prep, seed)
+
+def op_inflate(run: Run, S: Staged, steps: int, warmup: int):
+    import torch
+    from htslib_amd import synth
+    from htslib_amd.bgzf import reduce_timing
+    args = run.args
 
     def step():
-        eng.bgzf_inflate_dev(d_comp.data_ptr(), comp_len, d_desc.data_ptr(), nblocks, d_out.data_ptr(), total_u,
-                             d_status.data_ptr(), stream)
+        S.eng.bgzf_inflate_dev(S.d_comp.data_ptr(), S.comp_len, S.d_desc.data_ptr(), S.nblocks, S.d_out.data_ptr(), S.total_u,
+                               S.d_status.data_ptr(), S.stream)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in evs:
-        a.record()
-        step()
-        b.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms = [a.elapsed_time(b) for a, b in evs]
-
+    elapsed, k_ms = run.timed(step, steps, warmup)
     # ---------------- verification (outside the timed region) ------------------------------
-    st = d_status.cpu().numpy()
-    nbad = int((st != 0).sum())
-    # every block's CRC-32 (computed by the host writer on the ORIGINAL bytes) was re-checked in-kernel;
-    # additionally compare the first chunk byte-for-byte with a regenerated plain image
-    from htslib_amd import synth
-    chk = min(CHUNK, total_bytes)
-    plain0, _, _ = synth.bam_stream(chk, seed, first_chunk, first_chunk == 0)
-    got0 = d_out[:len(plain0)].cpu().numpy().tobytes()
-    bytes_ok = got0 == plain0
-    ok = nbad == 0 and bytes_ok
-
-    from htslib_amd.bgzf import reduce_timing
-    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(total_u), float(comp_len), ok, world, dev)
-
-    if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
-        value = sum_u * args.steps / elapsed / 1e9
-        k_ms = float(np.mean(kern_ms))
-        alg_bytes = float(total_u + comp_len)           # per launch on this rank: C + U (SURVEY 8d)
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        out = {
-            "metric": "BGZF inflate throughput, uncompressed GB/s (decode, CRC-checked, HBM-resident)",
-            "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"BGZF inflate of a {args.gib:g} GiB synthetic coordinate-sorted 150bp BAM per GPU "
-                                   f"(zlib level {args.level} blocks as written by stock htslib, <=65280 B each)",
-                       "blocks_per_gpu": nblocks, "plain_bytes_per_gpu": int(total_u),
-                       "compressed_bytes_per_gpu": int(comp_len), "ratio": round(total_u / comp_len, 3),
-                       "sharding": "independent blocks, static split, no collective", "verified": bool(ok),
-                       "prep_seconds": round(t_prep, 1)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": hbm_traffic(total_u),
-                         "kernel": "hg::bgzf_inflate_kernel", "kernel_ms": round(k_ms, 3),
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "traffic_note": "FETCH_SIZE + WRITE_SIZE PMC passes at face value; FETCH_SIZE is not a byte count for this access mix "
-                                         "(profiles/hbm_traffic_inflate.json: calibration)"},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            # bounded sample: at most 4 GiB plain of the same stream
-            lim = 4 << 30
-            if total_u > lim:
-                cut = int(np.searchsorted(desc["uoff"], lim))
-                sample = comp[:int(desc["coff"][cut])]
-                plen = int(desc["uoff"][cut])
-            else:
-                sample, plen = comp, int(total_u)
-            cb = cpu_baseline(sample, plen, ncores)
-            if cb:
-                out["cpu_baseline"] = cb
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
-    if not ok:
-        sys.exit(2)
+    nbad = int((S.d_status[:S.nblocks] != 0).sum()) if S.nblocks else 0
+    ok = nbad == 0
+    strong = S.shard is not None
+    # every block's CRC-32 (written by the host deflater over the ORIGINAL bytes) was re-checked in-kernel on every rank;
+    # additionally the first chunk of the stream is compared byte for byte with a regenerated plain image
+    if not strong or run.rank == 0:
+        chk = min(CHUNK, int(args.gib * (1 << 30)), S.total_u)
+        plain0, _, _ = synth.bam_stream(min(CHUNK, int(args.gib * (1 << 30))), S.seed, S.first_chunk, S.first_chunk == 0)
+        chk = min(chk, len(plain0))
+        ok = ok and S.d_out[:chk].cpu().numpy().tobytes() == plain0[:chk]
+    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(S.total_u), float(S.comp_len), ok, run.world, run.dev)
+    if strong:
+        ok = ok and int(sum_u) == S.whole_plain                        # the shards cover the file exactly once
+    if run.rank != 0:
+        return None, ok
+    value = sum_u * steps / elapsed / 1e9
+    alg_bytes = float(S.total_u + S.comp_len)                       # per launch on this rank: C + U (SURVEY 8d)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    spb, litfrac = symbols_per_byte(S.comp, S.desc)
+    out = {
+        "metric": "BGZF inflate throughput, uncompressed GB/s (decode, CRC-checked, HBM-resident)",
+        "value": round(value, 3), "unit": "GB/s", "n_gpus": run.world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed * 1e3 / steps, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": (f"BGZF inflate of ONE {args.gib:g} GiB synthetic coordinate-sorted 150bp BAM split over the GPUs by block ranges "
+                                if strong else f"BGZF inflate of a {args.gib:g} GiB synthetic coordinate-sorted 150bp BAM per GPU ") +
+                               f"(zlib level {args.level} blocks as written by stock htslib, <=65280 B each)",
+                   "blocks_per_gpu": S.nblocks, "plain_bytes_per_gpu": int(S.total_u),
+                   "compressed_bytes_per_gpu": int(S.comp_len), "ratio": round(S.total_u / max(S.comp_len, 1), 3),
+                   "symbols_per_plain_byte": None if spb is None else round(spb, 4),
+                   "literal_fraction_of_symbols": None if litfrac is None else round(litfrac, 3),
+                   "Gsymbols_per_s": None if spb is None else round(value * spb, 2),
+                   "sharding": "independent blocks, static split, no collective", "verified": bool(ok),
+                   "prep_seconds": round(S.t_prep, 1)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "traffic": hbm_traffic_file("hbm_traffic_inflate.json", ["fetch_bytes_per_plain_byte", "write_bytes_per_plain_byte"], S.total_u),
+                     "kernel": "hg::bgzf_inflate_kernel", "kernel_ms": round(k_ms, 3),
+                     "algorithmic_bytes_per_launch": int(alg_bytes),
+                     "traffic_note": "FETCH_SIZE + WRITE_SIZE PMC passes (profiles/hbm_traffic_inflate.json, with its calibration note)"},
+    }
+    if run.world == 1 and not args.no_cpu_baseline:
+        lim = 4 << 30                                                   # bounded sample: at most 4 GiB plain of the same stream
+        if S.total_u > lim:
+            cut = int(np.searchsorted(S.desc["uoff"], lim))
+            sample, plen = S.comp[:int(S.desc["coff"][cut])], int(S.desc["uoff"][cut])
+        else:
+            sample, plen = S.comp, int(S.total_u)
+        cb = cpu_baseline(sample, plen, run.ncores)
+        if cb:
+            out["cpu_baseline"] = cb
+    return out, ok
 
 
 def _rans_series(seed, nslices):
@@ -325,26 +384,35 @@ def _rans_series(seed, nslices):
     return out
 
 
-def bench_rans(args, rank, world, local, ncores):
-    """BASELINE configs[3]: CRAM 3.1 rANS Nx16 decode (order-1 32-way QS + order-0 32-way BA) of
-    --slices x 10 000 reads per GPU.  The streams are produced by the gfx950 ENCODER (the oracle is
-    used only as cpu_baseline); the timed region is the decode launch, device resident."""
+
+def _rans_cpu_worker(task):
+    """cpu_baseline worker: the oracle's scalar Nx16 decoder on a share of the streams (one process per core)."""
     import ctypes as C
-    import torch
+    streams, reps = task
+    orc = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    orc.orc_ransnx16_uncompress.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    buf = C.create_string_buffer(1_500_000 + 64); got = C.c_size_t(0)
+    done = 0
+    t = time.perf_counter()
+    for _ in range(reps):
+        for s in streams:
+            orc.orc_ransnx16_uncompress(s, len(s), buf, 1_500_064, C.byref(got)); done += got.value
+    return done, time.perf_counter() - t                       # the worker times its own loop (pool start-up excluded)
+
+
+def op_rans(run: Run, steps: int, warmup: int, slices: int):
+    """BASELINE configs[3]: CRAM 3.1 rANS Nx16 decode (order-1 32-way QS + order-0 32-way BA) of `slices` x 10 000 reads per
+    GPU.  The streams are produced by the gfx950 ENCODER (htscodecs is absent: format parity UNPINNED); the timed region is
+    the decode launch, device resident."""
+    torch = run.init_device()
     from htslib_amd import _native as nat
     from htslib_amd.bgzf import reduce_timing
     t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(min(64, max(1, (ncores - 4) // max(1, world)))) as pool:
-        chunks = pool.starmap(_rans_series, [(0x5EED0001 + 7_000_003 * rank + 1000 * i, 1) for i in range(args.slices)])
+    with mp.get_context("fork").Pool(min(64, run.workers)) as pool:
+        chunks = pool.starmap(_rans_series, [(0x5EED0001 + 7_000_003 * run.rank + 1000 * i, 1) for i in range(slices)])
     series = [c[0] for c in chunks]
     t_prep = time.perf_counter() - t0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-    eng = nat.Engine(local)
+    eng = nat.Engine(run.local)
     plains, flags = [], []
     for qs, ba in series:
         plains += [qs, ba]; flags += [5, 4]                      # QS: order-1 X32, BA: order-0 X32
@@ -365,13 +433,13 @@ def bench_rans(args, rank, world, local, ncores):
     blob = bytearray(int(desc["in_off"][-1] + pad(np.uint64(in_len[-1]))))
     for d, s_ in zip(desc, streams):
         blob[int(d["in_off"]):int(d["in_off"]) + len(s_)] = s_
-    d_in = torch.frombuffer(blob, dtype=torch.uint8).to(dev)
-    d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(dev)
+    d_in = torch.frombuffer(blob, dtype=torch.uint8).to(run.dev)
+    d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(run.dev)
     total_u = int(out_len.astype(np.uint64).sum()); total_c = int(in_len.astype(np.uint64).sum())
-    d_out = torch.zeros(int(desc["out_off"][-1]) + int(out_len[-1]) + 64, dtype=torch.uint8, device=dev)
-    d_status = torch.full((n,), 77, dtype=torch.int32, device=dev)
-    d_scratch = torch.zeros(int(words.sum()) + 64, dtype=torch.int32, device=dev)
-    d_sel = torch.arange(n, dtype=torch.int32, device=dev)
+    d_out = torch.zeros(int(desc["out_off"][-1]) + int(out_len[-1]) + 64, dtype=torch.uint8, device=run.dev)
+    d_status = torch.full((n,), 77, dtype=torch.int32, device=run.dev)
+    d_scratch = torch.zeros(int(words.sum()) + 64, dtype=torch.int32, device=run.dev)
+    d_sel = torch.arange(n, dtype=torch.int32, device=run.dev)
     stream = torch.cuda.current_stream().cuda_stream
     torch.cuda.synchronize()
 
@@ -379,91 +447,74 @@ def bench_rans(args, rank, world, local, ncores):
         nat.check(nat.lib.hg_ransnx16_decode_dev(eng._h, d_in.data_ptr(), d_desc.data_ptr(), None, 0, d_sel.data_ptr(), n,
                                                  d_out.data_ptr(), d_status.data_ptr(), d_scratch.data_ptr(), stream), "rans decode")
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in evs:
-        a.record(); step(); b.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    k_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    elapsed, k_ms = run.timed(step, steps, warmup)
     ok = int((d_status != 0).sum()) == 0
     host_out = d_out.cpu().numpy()
     for i in (0, 1, n - 2, n - 1):
         ok = ok and host_out[int(desc["out_off"][i]):int(desc["out_off"][i]) + int(out_len[i])].tobytes() == plains[i]
-    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(total_u), float(total_c), ok, world, dev)
-    if rank == 0:
-        alg = float(total_u + total_c)
-        out = {"metric": "CRAM 3.1 rANS Nx16 decode throughput, uncompressed GB/s (HBM-resident)",
-               "value": round(sum_u * args.steps / elapsed / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-               "config": {"workload": f"rANS Nx16 decode of {args.slices} CRAM slices x 10 000 x 150 bp per GPU: QS (order-1, 32-way) "
-                                      "+ BA (order-0, 32-way) data series; streams written by the gfx950 encoder; format parity "
-                                      "with htscodecs UNPINNED", "streams_per_gpu": n, "plain_bytes_per_gpu": total_u,
-                          "compressed_bytes_per_gpu": total_c, "verified": bool(ok), "prep_seconds": round(t_prep, 1)},
-               "roofline": {"bound": "hbm", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": hbm_traffic_rans(total_u),
-                            "kernel": "hgn::ransnx16_decode_kernel<32>", "kernel_ms": round(k_ms, 3),
-                            "algorithmic_bytes_per_launch": int(alg)}}
-        if world == 1 and not args.no_cpu_baseline:
-            orc = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
-            orc.orc_ransnx16_uncompress.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
-            buf = C.create_string_buffer(1_500_000 + 64); got = C.c_size_t(0)
-            k = min(n, 24); t = time.perf_counter(); done = 0
-            for i in range(k):
-                orc.orc_ransnx16_uncompress(streams[i], len(streams[i]), buf, 1_500_064, C.byref(got)); done += got.value
-            dt = time.perf_counter() - t
-            out["cpu_baseline"] = {"value": round(done / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-                                   "sample": f"oracle/ransnx16_oracle.c (scalar C restatement, NOT reference code: htscodecs absent) "
-                                             f"decoding {k} of the same streams on one core"}
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
-    if not ok:
-        sys.exit(2)
+    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(total_u), float(total_c), ok, run.world, run.dev)
+    if run.rank != 0:
+        return None, ok
+    alg = float(total_u + total_c)
+    out = {"metric": "CRAM 3.1 rANS Nx16 decode throughput, uncompressed GB/s (HBM-resident)",
+           "value": round(sum_u * steps / elapsed / 1e9, 3), "unit": "GB/s", "n_gpus": run.world, "steps": steps,
+           "warmup": warmup, "ms_per_step": round(elapsed * 1e3 / steps, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": f"rANS Nx16 decode of {slices} CRAM slices x 10 000 x 150 bp per GPU: QS (order-1, 32-way) "
+                                  "+ BA (order-0, 32-way) data series; streams written by the gfx950 encoder; format parity "
+                                  "with htscodecs UNPINNED", "streams_per_gpu": n, "plain_bytes_per_gpu": total_u,
+                      "compressed_bytes_per_gpu": total_c, "verified": bool(ok), "prep_seconds": round(t_prep, 1)},
+           "roofline": {"bound": "hbm", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "traffic": hbm_traffic_file("hbm_traffic_rans.json", ["traffic_bytes_per_plain_byte"], total_u),
+                        "kernel": "hgn::ransnx16_decode_kernel<32>", "kernel_ms": round(k_ms, 3),
+                        "algorithmic_bytes_per_launch": int(alg)}}
+    if run.world == 1 and not run.args.no_cpu_baseline:
+        # N processes, one share of the streams each ("N threads, one slice each"); ~10-20 s of CPU work
+        nproc = max(1, min(run.ncores - 2, 64, n))
+        share = [streams[i::nproc][:8] for i in range(nproc)]
+        with mp.get_context("fork").Pool(nproc) as pool:
+            parts = pool.map(_rans_cpu_worker, [(sh, 2) for sh in share])
+        done, dt = sum(p_[0] for p_ in parts), max(p_[1] for p_ in parts)
+        out["cpu_baseline"] = {"value": round(done / dt / 1e9, 3), "unit": "GB/s", "cores": nproc, "kind": "port",
+                               "sample": f"oracle/ransnx16_oracle.c (scalar C restatement, NOT reference code: htscodecs is absent) decoding "
+                                         f"{sum(map(len, share))} of the same streams twice on {nproc} concurrent processes (bytes / slowest worker's loop time)"}
+    return out, ok
 
 
-def bench_cram(args, rank, world, local):
-    """BASELINE configs[4] shape on the GPUs of one node: every rank encodes (and decodes back) its own --slices CRAM 3.1
+def op_cram(run: Run, steps: int, slices: int):
+    """BASELINE configs[4] shape on the GPUs of one node: every rank encodes (and decodes back) its own `slices` CRAM 3.1
     slices of 10 000 reads -- 8 data series each -- through hg_cram_compress_blocks_metrics_host, i.e. the reference's
     cram_compress_block2 loop with its method auto-tuner, then hg_cram_uncompress_blocks_host.  These are HOST entry
     points (the reference hands the codecs malloc'd blocks), so unlike the other ops the rate includes PCIe both ways."""
-    import torch
+    run.init_device()
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import bench_cram_slices
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-        dist.barrier()
-    S = args.slices if args.slices != 1000 else 256
-    r = bench_cram_slices.main(S, device=local, reps=max(2, args.steps), quiet=True)
+    if run.dist is not None:
+        run.dist.barrier()
+    r = bench_cram_slices.main(slices, device=run.local, reps=max(2, steps), quiet=True)
     from htslib_amd.bgzf import reduce_timing
-    enc_s, sum_u, sum_c, ok = reduce_timing(r["encode_s"], float(r["plain_bytes"]), float(r["comp_bytes"]), True, world, dev)
-    dec_s, _, _, _ = reduce_timing(r["decode_s"], float(r["plain_bytes"]), float(r["comp_bytes"]), True, world, dev)
-    if rank == 0:
-        print(json.dumps({"metric": "CRAM 3.1 slice encode throughput through the block-method auto-tuner, plain GB/s (host entry points, PCIe included)",
-                          "value": round(sum_u / enc_s / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": max(2, args.steps), "warmup": 1,
-                          "ms_per_step": round(enc_s * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "u8", "data": "synthetic",
-                          "config": {"workload": "%d slices x 10 000 reads per GPU, series QS BA RN AP BF TS MQ NP; best steady call" % S,
-                                     "blocks_per_gpu": r["blocks"], "plain_bytes_per_gpu": r["plain_bytes"], "ratio": round(r["comp_bytes"] / r["plain_bytes"], 4),
-                                     "decode_GBps": round(sum_u / dec_s / 1e9, 3), "on_disk_methods": r["methods"], "verified": True,
-                                     "format_parity": "rANS Nx16 / range coder / tok3 UNPINNED against htscodecs"}}))
-    if world > 1:
-        dist.destroy_process_group()
-    return 0
-
+    enc_s, sum_u, sum_c, ok = reduce_timing(r["encode_s"], float(r["plain_bytes"]), float(r["comp_bytes"]), True, run.world, run.dev)
+    dec_s, _, _, _ = reduce_timing(r["decode_s"], float(r["plain_bytes"]), float(r["comp_bytes"]), True, run.world, run.dev)
+    if run.rank != 0:
+        return None, ok
+    # algorithmic bytes of a whole-slice encode through the tuner's steady state: read U, write C (+ one histogram pass: 2U + C)
+    alg_enc = 2.0 * r["plain_bytes"] + r["comp_bytes"]
+    alg_dec = float(r["plain_bytes"] + r["comp_bytes"])
+    return {"metric": "CRAM 3.1 slice encode throughput through the block-method auto-tuner, plain GB/s (host entry points, PCIe included)",
+            "value": round(sum_u / enc_s / 1e9, 3), "unit": "GB/s", "n_gpus": run.world, "steps": max(2, steps), "warmup": 1,
+            "ms_per_step": round(enc_s * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%d slices x 10 000 reads per GPU, series QS BA RN AP BF TS MQ NP; best steady call" % slices,
+                       "blocks_per_gpu": r["blocks"], "plain_bytes_per_gpu": r["plain_bytes"], "ratio": round(r["comp_bytes"] / r["plain_bytes"], 4),
+                       "decode_GBps": round(sum_u / dec_s / 1e9, 3), "on_disk_methods": r["methods"], "verified": True,
+                       "format_parity": "rANS Nx16 / range coder / tok3 UNPINNED against htscodecs"},
+            "roofline": {"bound": "hbm", "achieved": round(alg_enc / r["encode_s"] / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg_enc / r["encode_s"] / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                         "kernel": "whole call (several kernels + PCIe): hge::ransnx16_encode_kernel dominates (profiles/)",
+                         "kernel_ms": round(r["encode_s"] * 1e3, 2), "algorithmic_bytes_per_launch": int(alg_enc),
+                         "decode_achieved": round(alg_dec / r["decode_s"] / 1e9, 3)},
+            "cpu_baseline": None}, ok
 
 def bench_bam(args, eng, comp, desc, total_u, d_comp, d_desc, d_plain, d_status, dev, rank, world, seed):
     """frame every record of the inflated BAM (bam_read1's framing + checks) and decode all bases
@@ -562,7 +613,7 @@ def bench_bam(args, eng, comp, desc, total_u, d_comp, d_desc, d_plain, d_status,
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         alg = total_u / 290.0 * 36 + tot.value / 2 + tot.value        # core fields read + packed bases read + ASCII written, per rank
-        print(json.dumps({"metric": "BAM record framing + base decoding throughput, uncompressed BAM GB/s (HBM-resident)",
+        return ({"metric": "BAM record framing + base decoding throughput, uncompressed BAM GB/s (HBM-resident)",
                           "value": round(sum_u * args.steps / elapsed / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -572,121 +623,262 @@ def bench_bam(args, eng, comp, desc, total_u, d_comp, d_desc, d_plain, d_status,
                           "roofline": {"bound": "hbm", "achieved": round(alg / (ms / 1e3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                                        "frac": round(alg / (ms / 1e3) / 1e9 / 8000.0, 4), "traffic": None,
                                        "algorithmic_bytes_per_launch": int(alg)},
-                          **({"cpu_baseline": cpu} if cpu else {})}))
-    if world > 1:
-        dist.destroy_process_group()
-    return 0
+                          **({"cpu_baseline": cpu} if cpu else {})}, ok)
+    return None, ok
 
 
-def bench_deflate(args, eng, comp, desc, total_u, d_comp, d_desc, d_plain, d_status, dev, rank, world, ncores,
-                  t_prep, seed):
-    """BASELINE configs[2]: BGZF deflate level 6 of the same BAM; the plain image is produced on the
-    device by the inflate kernel, re-cut into the same blocks, compressed, then verified by inflating
-    the GPU-written stream again and comparing CRCs/bytes."""
+
+def op_deflate(run: Run, S: Staged, steps: int, warmup: int):
+    """BASELINE configs[2]: BGZF deflate of the same BAM; the plain image is produced on the device by the inflate kernel,
+    re-cut into the same blocks, compressed, then verified by inflating the GPU-written stream again (and, for a slice of
+    it, with the real reference)."""
     import torch
-    import torch.distributed as dist
     from htslib_amd import _native as nat
-    stream = torch.cuda.current_stream().cuda_stream
-    nblocks = len(desc)
-    eng.bgzf_inflate_dev(d_comp.data_ptr(), len(comp), d_desc.data_ptr(), nblocks, d_plain.data_ptr(), total_u,
-                         d_status.data_ptr(), stream)
+    from htslib_amd.bgzf import reduce_timing
+    args = run.args
+    S.eng.bgzf_inflate_dev(S.d_comp.data_ptr(), S.comp_len, S.d_desc.data_ptr(), S.nblocks, S.d_out.data_ptr(), S.total_u,
+                           S.d_status.data_ptr(), S.stream)
     torch.cuda.synchronize()
-    assert int((d_status != 0).sum()) == 0
-    ddesc = desc.copy()
+    assert int((S.d_status != 0).sum()) == 0
+    nblocks, total_u, d_plain = S.nblocks, S.total_u, S.d_out
+    ddesc = S.desc.copy()
     ddesc["coff"] = np.arange(nblocks, dtype=np.uint64) * 65536
-    d_ddesc = torch.from_numpy(ddesc.view(np.uint8).reshape(-1).copy()).to(dev)
-    d_slots = torch.empty(nblocks * 65536 + 256, dtype=torch.uint8, device=dev)
-    d_clen = torch.zeros(nblocks, dtype=torch.int32, device=dev)
+    d_ddesc = torch.from_numpy(ddesc.view(np.uint8).reshape(-1).copy()).to(run.dev)
+    d_slots = torch.empty(nblocks * 65536 + 256, dtype=torch.uint8, device=run.dev)
+    d_clen = torch.zeros(nblocks, dtype=torch.int32, device=run.dev)
 
     def step():
-        nat.check(nat.lib.hg_bgzf_deflate_dev(eng._h, d_plain.data_ptr(), d_ddesc.data_ptr(), nblocks, args.level,
-                                              d_slots.data_ptr(), d_clen.data_ptr(), stream), "deflate")
+        nat.check(nat.lib.hg_bgzf_deflate_dev(S.eng._h, d_plain.data_ptr(), d_ddesc.data_ptr(), nblocks, args.level,
+                                              d_slots.data_ptr(), d_clen.data_ptr(), S.stream), "deflate")
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in evs:
-        a.record(); step(); b.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    k_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    elapsed, k_ms = run.timed(step, steps, warmup)
     # verify: pack, inflate the GPU-written stream on the GPU, compare with the plain image
-    d_packed = torch.empty(nblocks * 65536 + 256, dtype=torch.uint8, device=dev)
-    d_poff = torch.zeros(nblocks + 1, dtype=torch.int64, device=dev)
-    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
-    nat.check(nat.lib.hg_bgzf_pack_dev(eng._h, d_slots.data_ptr(), d_ddesc.data_ptr(), d_clen.data_ptr(), nblocks,
+    d_packed = torch.empty(nblocks * 65536 + 256, dtype=torch.uint8, device=run.dev)
+    d_poff = torch.zeros(nblocks + 1, dtype=torch.int64, device=run.dev)
+    d_total = torch.zeros(1, dtype=torch.int64, device=run.dev)
+    nat.check(nat.lib.hg_bgzf_pack_dev(S.eng._h, d_slots.data_ptr(), d_ddesc.data_ptr(), d_clen.data_ptr(), nblocks,
                                        d_packed.data_ptr(), d_packed.numel(), d_poff.data_ptr(), d_total.data_ptr(), 0,
-                                       stream), "pack")
+                                       S.stream), "pack")
     torch.cuda.synchronize()
+    del d_slots
     comp_len = int(d_total.item())
-    rdesc = desc.copy()
+    rdesc = S.desc.copy()
     rdesc["coff"] = d_poff[:nblocks].cpu().numpy().astype(np.uint64)
     rdesc["clen"] = d_clen.cpu().numpy().astype(np.uint32)
-    d_rdesc = torch.from_numpy(rdesc.view(np.uint8).reshape(-1).copy()).to(dev)
-    d_back = torch.empty(total_u + 256, dtype=torch.uint8, device=dev)
-    st2 = torch.full((nblocks,), 77, dtype=torch.int32, device=dev)
-    eng.bgzf_inflate_dev(d_packed.data_ptr(), comp_len, d_rdesc.data_ptr(), nblocks, d_back.data_ptr(), total_u,
-                         st2.data_ptr(), stream)
+    d_rdesc = torch.from_numpy(rdesc.view(np.uint8).reshape(-1).copy()).to(run.dev)
+    d_back = torch.empty(total_u + 256, dtype=torch.uint8, device=run.dev)
+    st2 = torch.full((nblocks,), 77, dtype=torch.int32, device=run.dev)
+    S.eng.bgzf_inflate_dev(d_packed.data_ptr(), comp_len, d_rdesc.data_ptr(), nblocks, d_back.data_ptr(), total_u,
+                           st2.data_ptr(), S.stream)
     torch.cuda.synchronize()
     ok = int((st2 != 0).sum()) == 0 and bool(torch.equal(d_back[:total_u], d_plain[:total_u]))
-    # a slice of the GPU-written stream must also decode with the REAL reference when it is present
+    del d_back
     ref_ok = None
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_bgzip_ld")
-    if rank == 0 and os.path.exists(exe):
+    if run.rank == 0 and os.path.exists(exe):                              # the REAL reference decodes a slice of our stream
         cut = min(nblocks, 2000)
         end = int(rdesc["coff"][cut - 1] + rdesc["clen"][cut - 1])
         blob = d_packed[:end].cpu().numpy().tobytes()
-        want = d_plain[:int(desc["uoff"][cut - 1] + desc["ulen"][cut - 1])].cpu().numpy().tobytes()
+        want = d_plain[:int(S.desc["uoff"][cut - 1] + S.desc["ulen"][cut - 1])].cpu().numpy().tobytes()
         p = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"htsgpu_defl_{os.getpid()}.gz")
         open(p, "wb").write(blob)
         r = subprocess.run([exe, "-d", "-c", p], capture_output=True)
         os.unlink(p)
         ref_ok = r.returncode == 0 and r.stdout == want
         ok = ok and ref_ok
-    from htslib_amd.bgzf import reduce_timing
-    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(total_u), float(comp_len), ok, world, dev)
-    if rank == 0:
-        value = sum_u * args.steps / elapsed / 1e9
-        alg = float(total_u + comp_len)
-        out = {"metric": "BGZF deflate throughput, uncompressed GB/s (encode, HBM-resident)", "value": round(value, 3),
-               "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-               "config": {"workload": f"BGZF deflate (level {args.level}) of a {args.gib:g} GiB synthetic BAM per GPU, "
-                                      "blocks cut as bam_write1/bgzf_flush_try would", "blocks_per_gpu": nblocks,
-                          "plain_bytes_per_gpu": int(total_u), "compressed_bytes_per_gpu": int(comp_len),
-                          "ratio": round(total_u / comp_len, 3), "zlib6_ratio": round(total_u / len(comp), 3),
-                          "size_vs_zlib6": round(comp_len / len(comp), 4), "verified": bool(ok),
-                          "decodes_with_reference_htslib": ref_ok},
-               "roofline": {"bound": "hbm", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                            "kernel": "hgd::bgzf_deflate_kernel", "kernel_ms": round(k_ms, 3),
-                            "algorithmic_bytes_per_launch": int(alg)}}
-        if world == 1 and not args.no_cpu_baseline and os.path.exists(exe):
-            lim = min(int(total_u), 1 << 30)
-            sample = d_plain[:lim].cpu().numpy().tobytes()
-            p = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"htsgpu_defl_in_{os.getpid()}")
-            open(p, "wb").write(sample)
-            best = None
-            for _ in range(2):
-                t = time.perf_counter()
-                with open(os.devnull, "wb") as dn:
-                    r = subprocess.run([exe, "-c", "-l", str(args.level), "-@", str(ncores), p], stdout=dn)
-                best = min(best or 1e9, time.perf_counter() - t)
-            os.unlink(p)
-            out["cpu_baseline"] = {"value": round(lim / best / 1e9, 3), "unit": "GB/s", "cores": ncores, "kind": "reference",
-                                   "sample": f"oracle/_ref/ref_bgzip_ld -l{args.level} -@{ncores} (htslib bgzf.c + libdeflate 1.8) "
-                                             f"on {lim / 2**30:.2f} GiB of the same BAM from /dev/shm, best of 2"}
+    del d_packed
+    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(total_u), float(comp_len), ok, run.world, run.dev)
+    if run.rank != 0:
+        return None, ok
+    alg = float(total_u + comp_len)
+    out = {"metric": "BGZF deflate throughput, uncompressed GB/s (encode, HBM-resident)", "value": round(sum_u * steps / elapsed / 1e9, 3),
+           "unit": "GB/s", "n_gpus": run.world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed * 1e3 / steps, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": f"BGZF deflate (level {args.level}) of a {args.gib:g} GiB synthetic BAM per GPU, "
+                                  "blocks cut as bam_write1/bgzf_flush_try would", "blocks_per_gpu": nblocks,
+                      "plain_bytes_per_gpu": int(total_u), "compressed_bytes_per_gpu": int(comp_len),
+                      "ratio": round(total_u / comp_len, 3), "zlib6_ratio": round(total_u / S.comp_len, 3),
+                      "size_vs_zlib6": round(comp_len / S.comp_len, 4), "verified": bool(ok),
+                      "decodes_with_reference_htslib": ref_ok},
+           "roofline": {"bound": "hbm", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                        "kernel": "hgd::bgzf_deflate_kernel", "kernel_ms": round(k_ms, 3),
+                        "algorithmic_bytes_per_launch": int(alg)}}
+    if run.world == 1 and not args.no_cpu_baseline:
+        lim = min(int(total_u), 1 << 30)
+        cb = cpu_baseline_deflate(d_plain[:lim].cpu().numpy().tobytes(), args.level, run.ncores)
+        if cb:
+            out["cpu_baseline"] = cb
+    return out, ok
+
+
+def op_e2e(run: Run, S: Staged):
+    """What a libhts caller sees: a bgzf_read loop and a bgzf_write loop through htslib_amd/libhts_bgzf.so on a file in
+    /dev/shm (file read -> pinned window -> H2D -> kernel -> D2H -> caller's buffer, overlapped on 3 pipes), and the
+    latency of 1000 random bgzf_seek + 100-byte reads.  The same three loops run against the REAL reference library
+    (oracle/_ref/libref_bgzf_ld.so: bgzf.c + libdeflate with bgzf_mt(all cores)) on the same file."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    from tests import bgzf_capi
+    from htslib_amd import synth
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path = os.path.join(shm, f"htsgpu_e2e_{os.getpid()}_{run.rank}.bam")
+    with open(path, "wb") as f:
+        f.write(S.comp); f.write(synth.BGZF_EOF)
+    res = {"file_GiB_plain": round(S.total_u / 2**30, 2)}
+    chunk = 8 << 20
+    rng = np.random.default_rng(12345)
+    pick = rng.integers(0, S.nblocks, 1000)
+    seeks = [(int(S.desc["coff"][i]) << 16) | int(rng.integers(0, max(1, int(S.desc["ulen"][i]) - 100))) for i in pick]
+
+    def loops(L, threads, label):
+        out = {}
+        P = C.POINTER(bgzf_capi.BGZF)
+        buf = C.create_string_buffer(chunk)
+        # ---- sequential read
+        fp = L.bgzf_open(path.encode(), b"r")
+        if not fp:
+            return None
+        if threads:
+            L.bgzf_mt(fp, threads, 256)
+        t = time.perf_counter(); tot = 0
+        while True:
+            n = L.bgzf_read(fp, buf, chunk)
+            if n <= 0:
+                break
+            tot += n
+        dt = time.perf_counter() - t
+        L.bgzf_close(fp)
+        out["read_GBps"] = round(tot / dt / 1e9, 3) if tot == S.total_u else None
+        # ---- random access
+        fp = L.bgzf_open(path.encode(), b"r")
+        if threads:
+            L.bgzf_mt(fp, min(threads, 4), 256)
+        small = C.create_string_buffer(128)
+        t = time.perf_counter(); good = 0
+        for vo in seeks:
+            if L.bgzf_seek(fp, vo, 0) == 0 and L.bgzf_read(fp, small, 100) == 100:
+                good += 1
+        dt = time.perf_counter() - t
+        L.bgzf_close(fp)
+        out["seek_read_us"] = round(dt / len(seeks) * 1e6, 1) if good == len(seeks) else None
+        return out
+
+    # plain bytes for the write loop: one sequential read through OUR library into host memory (bounded to 4 GiB)
+    ours = bgzf_capi.load()
+    res["gpu"] = loops(ours, 4, "gpu")
+    lim = min(S.total_u, 4 << 30)
+    host = np.empty(lim, dtype=np.uint8)
+    fp = ours.bgzf_open(path.encode(), b"r"); got = 0
+    while got < lim:
+        n = ours.bgzf_read(fp, host.ctypes.data + got, min(chunk, lim - got))
+        if n <= 0:
+            break
+        got += n
+    ours.bgzf_close(fp)
+
+    def write_loop(L, threads):
+        wpath = path + ".w"
+        fp = L.bgzf_open(wpath.encode(), b"w")
+        if not fp:
+            return None
+        if threads:
+            L.bgzf_mt(fp, threads, 256)
+        t = time.perf_counter(); pos = 0
+        while pos < got:
+            n = min(chunk, got - pos)
+            if L.bgzf_write(fp, C.cast(host.ctypes.data + pos, C.c_char_p), n) != n:
+                return None
+            pos += n
+        rc = L.bgzf_close(fp)
+        dt = time.perf_counter() - t
+        sz = os.path.getsize(wpath)
+        os.unlink(wpath)
+        return {"write_GBps": round(got / dt / 1e9, 3) if rc == 0 else None, "out_bytes": sz}
+
+    res["gpu"].update(write_loop(ours, 4) or {})
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libref_bgzf_ld.so")
+    if os.path.exists(ref_so) and not run.args.no_cpu_baseline:
+        R = C.CDLL(ref_so)
+        P = C.POINTER(bgzf_capi.BGZF)
+        R.bgzf_open.restype = P; R.bgzf_open.argtypes = [C.c_char_p, C.c_char_p]
+        R.bgzf_close.argtypes = [P]; R.bgzf_mt.argtypes = [P, C.c_int, C.c_int]
+        R.bgzf_read.restype = C.c_ssize_t; R.bgzf_read.argtypes = [P, C.c_void_p, C.c_size_t]
+        R.bgzf_write.restype = C.c_ssize_t; R.bgzf_write.argtypes = [P, C.c_char_p, C.c_size_t]
+        R.bgzf_seek.restype = C.c_int64; R.bgzf_seek.argtypes = [P, C.c_int64, C.c_int]
+        nthr = min(run.ncores, 64)
+        res["reference"] = loops(R, nthr, "ref")
+        if res["reference"] is not None:
+            res["reference"].update(write_loop(R, nthr) or {})
+            res["reference"]["threads"] = nthr
+    os.unlink(path)
+    res["note"] = ("bgzf_read / bgzf_write loops with 8 MiB buffers on a /dev/shm file; gpu = htslib_amd/libhts_bgzf.so (3 pipes, "
+                   "bgzf_mt called so the writer batches), reference = oracle/_ref/libref_bgzf_ld.so with bgzf_mt(threads); "
+                   "write loop over the first %.1f GiB; seek_read_us = mean of 1000 random bgzf_seek + 100-byte bgzf_read" % (got / 2**30))
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gib", type=float, default=10.0, help="plain GiB of synthetic BAM per GPU")
+    ap.add_argument("--level", type=int, default=6)
+    ap.add_argument("--workers", type=int, default=0, help="host processes for workload preparation")
+    ap.add_argument("--op", choices=["all", "inflate", "deflate", "rans", "bam", "cram", "e2e"], default="all",
+                    help="all (default) = inflate headline (BASELINE configs[1]) + `extra`: deflate (configs[2]), rans (configs[3]), "
+                         "cram (configs[4] shape) and the end-to-end bgzf_read / bgzf_write figures, in ONE JSON line; "
+                         "a single op prints that op's line alone; bam = SURVEY 8f N1 (record framing + nibble2base)")
+    ap.add_argument("--slices", type=int, default=0, help="CRAM slices of 10 000 reads (rans: default 1000 = 10 M reads; cram: default 256)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="strong: ONE data set split over the ranks by shard_blocks (inflate only)")
+    ap.add_argument("--extra-steps", type=int, default=3, help="timed steps of the `extra` ops in --op all")
+    ap.add_argument("--no-cache", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    run = Run(args)
+    ok = True
+    out = None
+    if args.op in ("rans", "cram"):
+        if args.op == "rans":
+            out, ok = op_rans(run, args.steps, args.warmup, args.slices or 1000)
+        else:
+            out, ok = op_cram(run, args.steps, args.slices or 256)
+    else:
+        S = stage(run)
+        if args.op == "bam":
+            out, ok = bench_bam(args, S.eng, S.comp, S.desc, S.total_u, S.d_comp, S.d_desc, S.d_out, S.d_status, run.dev, run.rank, run.world, S.seed)
+        elif args.op == "deflate":
+            out, ok = op_deflate(run, S, args.steps, args.warmup)
+        elif args.op == "e2e":
+            S.eng.bgzf_inflate_dev(S.d_comp.data_ptr(), S.comp_len, S.d_desc.data_ptr(), S.nblocks, S.d_out.data_ptr(), S.total_u, S.d_status.data_ptr(), S.stream)
+            out = {"metric": "end-to-end bgzf_read / bgzf_write through libhts_bgzf.so", "end_to_end": op_e2e(run, S)} if run.rank == 0 else None
+        else:
+            out, ok = op_inflate(run, S, args.steps, args.warmup)
+            if args.op == "all" and args.scaling == "weak":
+                extra = {}
+                es = max(1, args.extra_steps)
+                d, ok2 = op_deflate(run, S, es, 1); ok = ok and ok2
+                if d: extra["bgzf_deflate"] = d
+                if run.rank == 0 and run.world == 1:
+                    try:
+                        extra["end_to_end"] = op_e2e(run, S)
+                    except Exception as e:                                  # never lose the headline to an auxiliary figure
+                        extra["end_to_end"] = {"error": repr(e)}
+                del S
+                import torch
+                torch.cuda.empty_cache()
+                d, ok2 = op_rans(run, es, 1, args.slices or 1000); ok = ok and ok2
+                if d: extra["cram_rans_nx16_decode"] = d
+                d, ok2 = op_cram(run, es, 256 if not args.slices else args.slices); ok = ok and ok2
+                if d: extra["cram_slices"] = d
+                if out is not None:
+                    out["extra"] = extra
+    if run.rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    run.finish()
     if not ok:
         sys.exit(2)
 

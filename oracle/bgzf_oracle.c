@@ -30,9 +30,14 @@
 #include <string.h>
 
 #define ORC_EXPORT __attribute__((visibility("default")))
-#ifndef TOKSTAT_MATCH            /* instrumentation hooks for scripts/tokstats.c; no-ops normally */
-#define TOKSTAT_MATCH(len, dist) do { } while (0)
-#define TOKSTAT_LIT() do { } while (0)
+/* Huffman symbols decoded by this thread (literals + length/distance pairs): bench.py reports symbols/s beside GB/s,
+ * because a more compressible input makes more bytes per symbol. */
+static __thread unsigned long long orc_nlit, orc_nmatch;
+void orc_symbol_counts(unsigned long long *lit, unsigned long long *match, int reset)
+{ if (lit) *lit = orc_nlit; if (match) *match = orc_nmatch; if (reset) orc_nlit = orc_nmatch = 0; }
+#ifndef TOKSTAT_MATCH            /* instrumentation hooks for scripts/tokstats.c */
+#define TOKSTAT_MATCH(len, dist) do { orc_nmatch++; } while (0)
+#define TOKSTAT_LIT() do { orc_nlit++; } while (0)
 #endif
 
 /* ------------------------------------------------------------------ CRC-32 */
