@@ -50,7 +50,7 @@ __device__ unsigned long long g_dprof[16];   // 0 total, 1 stage+crc, 2 match+pa
 #endif
 constexpr int WG = 256;
 constexpr int HB = HG_DEF_HB;                 // hash buckets = 2^HB
-constexpr int WAYS = 8;                        // most recent positions kept per bucket
+constexpr int MAX_WAYS = 12;                   // most recent positions kept per bucket (the level picks 4, 8 or 12 of them)
 constexpr uint32_t MAX_IN = 0xff00u;           // BGZF_BLOCK_SIZE (htslib/bgzf.h:50)
 constexpr uint32_t LOCKSTEP = 32u;            // bytes over which all candidates are extended together
 constexpr uint32_t TOO_FAR = 4096u;            // a 3-byte match this far away costs more than 3 literals
@@ -75,7 +75,7 @@ struct Huff {                                  // overlays the hash table once m
 struct Lds {
     uint32_t in32[(MAX_IN + 16) / 4];
     union {
-        uint16_t tab[(1 << HB) * WAYS];
+        uint16_t tab[(1 << HB) * MAX_WAYS];
         Huff h;
     } u;
     uint32_t cnt32[(1 << HB) / 4];             // 8-bit insertion counters, 4 per dword
@@ -89,7 +89,7 @@ struct Lds {
     uint32_t carry_next;
     uint32_t misc[7];
 };
-static_assert(sizeof(Huff) <= sizeof(uint16_t) * (1 << HB) * WAYS, "Huff scratch must fit in the hash table");
+static_assert(sizeof(Huff) <= sizeof(uint16_t) * (1 << HB) * MAX_WAYS, "Huff scratch must fit in the hash table");
 static_assert(sizeof(Lds) <= 80 * 1024, "two workgroups per CU");
 
 __device__ __forceinline__ uint32_t load4(const uint32_t *in32, uint32_t off) {
@@ -191,6 +191,12 @@ __device__ __forceinline__ void pack_bits(Lds &S, uint32_t *out32, uint32_t &bit
     __syncthreads();
 }
 
+// Compression levels (bgzf.c:583-585 maps 1..9 onto libdeflate levels; zlib uses them directly): the level picks the
+// search effort -- WAYS candidates per hash bucket and the parse --
+//   1-3: 4 candidates, greedy parse            (fastest, largest)
+//   4-5: 8 candidates, one-step lazy parse
+//   6-9: 12 candidates, two-step lazy parse, 4-byte matches farther than 2 KiB dropped (they cost more than literals)
+template <int WAYS, int LAZY>
 __global__ __launch_bounds__(WG)
 void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *__restrict__ desc, uint32_t nblocks,
                          uint8_t *slots, uint32_t *clen_out, uint32_t *tokbuf, unsigned int *ticket, int level,
@@ -247,11 +253,11 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 S.in32[i / 4] = w.x; S.in32[i / 4 + 1] = w.y; S.in32[i / 4 + 2] = w.z; S.in32[i / 4 + 3] = w.w;
             }
         }
-        for (int i = tid; i < (1 << HB) * WAYS / 2; i += WG) ((uint32_t *)S.u.tab)[i] = 0xffffffffu;
+        for (int i = tid; i < (1 << HB) * MAX_WAYS / 2; i += WG) ((uint32_t *)S.u.tab)[i] = 0xffffffffu;
         for (int i = tid; i < (1 << HB) / 4; i += WG) S.cnt32[i] = 0;
         for (int i = tid; i < 288; i += WG) S.lfreq[i] = 0;
         if (tid < 32) S.dfreq[tid] = 0;
-        if (tid == 0) S.mlen[WG] = 0;
+        if (tid == 0) { S.mlen[WG] = 0; S.mlen[WG + 1] = 0; }
         __syncthreads();
         const uint32_t crc = wg_crc32(S, n, tid);          // valid in thread 0
 
@@ -269,78 +275,85 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                     const uint32_t maxl = n - p < 258u ? n - p : 258u;
                     const uint32_t cur = load4(S.in32, p);
                     h = hash4(cur);
-                    const uint4 row = *(const uint4 *)&S.u.tab[h * WAYS];
-                    const uint32_t cw[4] = {row.x, row.y, row.z, row.w};
-                    // candidates 0..7 from the table, candidate 8 = distance 1 (runs are never in this
-                    // chunk's table).  All are advanced in LOCKSTEP, 4 bytes per step, so that a step
-                    // costs one LDS round trip for every candidate together instead of one each.
-                    uint32_t cand[WAYS + 1], len[WAYS + 1], alive = 0;
+                    // Candidates are evaluated in groups of up to GW table entries (+ distance 1 with the first group: runs are
+                    // never in this chunk's table) to bound the registers held per lane: one group for 4 or 8 ways, 8 + 4 for 12.  Inside a group all candidates
+                    // advance in LOCKSTEP, 4 bytes per step, so that a step costs one LDS round trip for every candidate together.
+                    constexpr int GW = WAYS < 8 ? WAYS : 8, G = GW + 1, NGROUPS = (WAYS + GW - 1) / GW;
+                    const uint32_t *row32 = (const uint32_t *)&S.u.tab[h * MAX_WAYS];           // 24-byte rows, 8-byte aligned
+#pragma unroll 1
+                    for (int g = 0; g < NGROUPS; g++) {
+                        uint32_t cw[GW / 2];
 #pragma unroll
-                    for (int w = 0; w < WAYS; w++) {
-                        const uint32_t c = (cw[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
-                        const bool ok = c != 0xffffu && p - c <= 32768u;              // 32 KiB window
-                        cand[w] = ok ? c : 0u;
-                        if (ok) alive |= 1u << w;
-                    }
-                    cand[WAYS] = p >= 1u ? p - 1u : 0u;
-                    if (p >= 1u) alive |= 1u << WAYS;
-                    uint32_t first[WAYS + 1];
-#pragma unroll
-                    for (int w = 0; w <= WAYS; w++) first[w] = load4(S.in32, cand[w]);
-#pragma unroll
-                    for (int w = 0; w <= WAYS; w++) {
-                        const uint32_t x = first[w] ^ cur;
-                        len[w] = 0;
-                        if ((alive >> w) & 1u) {
-                            if (x) { len[w] = (uint32_t)__builtin_ctz(x) >> 3; alive &= ~(1u << w); }
-                            else len[w] = 4;
+                        for (int k = 0; k < GW / 2; k += 2) {
+                            const bool in_row = g * GW + 2 * k < WAYS;
+                            const uint2 rw = in_row ? *(const uint2 *)(row32 + g * (GW / 2) + k) : uint2{0xffffffffu, 0xffffffffu};
+                            cw[k] = rw.x; cw[k + 1] = rw.y;
                         }
-                    }
-                    // lockstep phase: all candidates together, up to LOCKSTEP bytes
-                    uint32_t off = 4;
-                    while (alive != 0u && off < maxl && off < LOCKSTEP) {
-                        const uint32_t own = load4(S.in32, p + off);
-                        uint32_t nxt[WAYS + 1];
+                        uint32_t cand[G], len[G], alive = 0;
 #pragma unroll
-                        for (int w = 0; w <= WAYS; w++) nxt[w] = load4(S.in32, ((alive >> w) & 1u) ? cand[w] + off : 0u);
+                        for (int w = 0; w < GW; w++) {
+                            const uint32_t c = (cw[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+                            const bool ok = c != 0xffffu && p - c <= 32768u && g * GW + w < WAYS;     // 32 KiB window
+                            cand[w] = ok ? c : 0u;
+                            if (ok) alive |= 1u << w;
+                        }
+                        cand[GW] = p >= 1u ? p - 1u : 0u;
+                        if (g == 0 && p >= 1u) alive |= 1u << GW;
 #pragma unroll
-                        for (int w = 0; w <= WAYS; w++) {
+                        for (int w = 0; w < G; w++) {
+                            const uint32_t x = load4(S.in32, cand[w]) ^ cur;
+                            len[w] = 0;
                             if ((alive >> w) & 1u) {
-                                const uint32_t x = nxt[w] ^ own;
-                                if (x) { len[w] = off + ((uint32_t)__builtin_ctz(x) >> 3); alive &= ~(1u << w); }
-                                else len[w] = off + 4;
+                                if (x) { len[w] = (uint32_t)__builtin_ctz(x) >> 3; alive &= ~(1u << w); }
+                                else len[w] = 4;
                             }
                         }
-                        off += 4;
-                    }
-                    // long-match phase: only the nearest candidate that is still going is extended
-                    // (8 bytes per step); the others keep the LOCKSTEP bytes they have proven.
-                    if (alive != 0u && off < maxl) {
-                        uint32_t bw = 0, bdist = 0xffffffffu;
+                        // lockstep phase: all candidates of the group together, up to LOCKSTEP bytes
+                        uint32_t off = 4;
+                        while (alive != 0u && off < maxl && off < LOCKSTEP) {
+                            const uint32_t own = load4(S.in32, p + off);
+                            uint32_t nxt[G];
 #pragma unroll
-                        for (int w = 0; w <= WAYS; w++)
-                            if (((alive >> w) & 1u) && p - cand[w] < bdist) { bdist = p - cand[w]; bw = (uint32_t)w; }
-                        uint32_t c = 0;
+                            for (int w = 0; w < G; w++) nxt[w] = load4(S.in32, ((alive >> w) & 1u) ? cand[w] + off : 0u);
 #pragma unroll
-                        for (int w = 0; w <= WAYS; w++) c = bw == (uint32_t)w ? cand[w] : c;
-                        uint32_t l = off;
-                        while (l < maxl) {
-                            const uint32_t x0 = load4(S.in32, c + l) ^ load4(S.in32, p + l);
-                            const uint32_t x1 = load4(S.in32, c + l + 4) ^ load4(S.in32, p + l + 4);
-                            if (x0) { l += (uint32_t)__builtin_ctz(x0) >> 3; break; }
-                            if (x1) { l += 4u + ((uint32_t)__builtin_ctz(x1) >> 3); break; }
-                            l += 8;
+                            for (int w = 0; w < G; w++) {
+                                if ((alive >> w) & 1u) {
+                                    const uint32_t x = nxt[w] ^ own;
+                                    if (x) { len[w] = off + ((uint32_t)__builtin_ctz(x) >> 3); alive &= ~(1u << w); }
+                                    else len[w] = off + 4;
+                                }
+                            }
+                            off += 4;
+                        }
+                        // long-match phase: only the nearest candidate that is still going is extended
+                        // (8 bytes per step); the others keep the LOCKSTEP bytes they have proven.
+                        if (alive != 0u && off < maxl) {
+                            uint32_t bw = 0, bdist = 0xffffffffu;
+#pragma unroll
+                            for (int w = 0; w < G; w++)
+                                if (((alive >> w) & 1u) && p - cand[w] < bdist) { bdist = p - cand[w]; bw = (uint32_t)w; }
+                            uint32_t c = 0;
+#pragma unroll
+                            for (int w = 0; w < G; w++) c = bw == (uint32_t)w ? cand[w] : c;
+                            uint32_t l = off;
+                            while (l < maxl) {
+                                const uint32_t x0 = load4(S.in32, c + l) ^ load4(S.in32, p + l);
+                                const uint32_t x1 = load4(S.in32, c + l + 4) ^ load4(S.in32, p + l + 4);
+                                if (x0) { l += (uint32_t)__builtin_ctz(x0) >> 3; break; }
+                                if (x1) { l += 4u + ((uint32_t)__builtin_ctz(x1) >> 3); break; }
+                                l += 8;
+                            }
+#pragma unroll
+                            for (int w = 0; w < G; w++) len[w] = bw == (uint32_t)w ? l : len[w];
                         }
 #pragma unroll
-                        for (int w = 0; w <= WAYS; w++) len[w] = bw == (uint32_t)w ? l : len[w];
+                        for (int w = 0; w < G; w++) {
+                            const uint32_t l = len[w] < maxl ? len[w] : maxl;
+                            const uint32_t d = p - cand[w];
+                            if (l >= 3u && (l > best || (l == best && d < bd))) { best = l; bd = d; }
+                        }
                     }
-#pragma unroll
-                    for (int w = 0; w <= WAYS; w++) {
-                        const uint32_t l = len[w] < maxl ? len[w] : maxl;
-                        const uint32_t d = p - cand[w];
-                        if (l >= 3u && (l > best || (l == best && d < bd))) { best = l; bd = d; }
-                    }
-                    if (best < 3u || (best == 3u && bd > TOO_FAR)) best = 0;
+                    if (best < 3u || (best == 3u && bd > TOO_FAR) || (LAZY >= 2 && best == 4u && bd > 2048u)) best = 0;
                 }
                 S.mlen[tid] = (uint16_t)best;
                 S.mdist[tid] = (uint16_t)bd;
@@ -354,7 +367,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                     if (hashable) {
                         const uint32_t sh = (h & 3u) * 8u;
                         const uint32_t old = atomicAdd(&S.cnt32[h >> 2], 1u << sh);
-                        S.u.tab[h * WAYS + ((old >> sh) & (WAYS - 1))] = (uint16_t)p;
+                        S.u.tab[h * MAX_WAYS + ((old >> sh) & 0xffu) % (uint32_t)WAYS] = (uint16_t)p;
                     }
                 };
                 if (wave == 0) publish();
@@ -362,7 +375,10 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 if (wave == 1) publish();
                 // ---- lazy parse by pointer jumping -----------------------------------------
                 const bool live = p < n;
-                const bool take = best >= 3u && !(tid < WG - 1 && (uint32_t)S.mlen[tid + 1] > best);
+                // lazy parse: a match yields to a longer one starting at the next position (and, two-step, to one longer by
+                // two or more at the position after that); mlen[WG], mlen[WG + 1] = 0: the chunk's last positions cannot look ahead
+                const bool take = best >= 3u && !(LAZY >= 1 && (uint32_t)S.mlen[tid + 1] > best) &&
+                                  !(LAZY >= 2 && (uint32_t)S.mlen[tid + 2] > best + 1u);
                 const uint32_t step = take ? best : 1u;
                 uint32_t nx = (uint32_t)tid + step;
                 if (nx > WG) nx = WG;
@@ -627,7 +643,8 @@ int launch_bgzf_deflate(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_
         if (ctx->ev_deflate_used && hipStreamWaitEvent(s, ctx->ev_deflate, 0) != hipSuccess) return HG_ELAUNCH;
         unsigned int *ticket = next_ticket(ctx);
         if (hipMemsetAsync(ticket, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
-        hipLaunchKernelGGL(hgd::bgzf_deflate_kernel, dim3((unsigned)wgs), dim3(hgd::WG), 0, s, (const uint8_t *)d_plain,
+        auto kern = level <= 3 ? hgd::bgzf_deflate_kernel<4, 0> : level <= 5 ? hgd::bgzf_deflate_kernel<8, 1> : hgd::bgzf_deflate_kernel<12, 2>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(hgd::WG), 0, s, (const uint8_t *)d_plain,
                            d_desc, (uint32_t)nblocks, (uint8_t *)d_slots, d_clen, (uint32_t *)ctx->d_tok,
                            ticket, level, mode, d_crc);
         if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;

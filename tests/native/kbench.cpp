@@ -54,13 +54,18 @@ int main(int argc, char **argv) {
             void *dslots, *ddd; uint32_t *dclen;
             CK(hipMalloc(&dslots, (size_t)n * 65536 + 256)); CK(hipMalloc(&ddd, n * sizeof(hg_bgzf_desc))); CK(hipMalloc((void **)&dclen, n * 4));
             CK(hipMemcpy(ddd, dd2.data(), n * sizeof(hg_bgzf_desc), hipMemcpyHostToDevice));
-            p_def(ctx, dout, (hg_bgzf_desc *)ddd, n, 6, dslots, dclen, s); CK(hipStreamSynchronize(s));
+            const char *lv = getenv("KBENCH_LEVELS"); std::vector<int> levels;
+            for (const char *q = lv ? lv : "6"; *q; q++) if (*q >= '0' && *q <= '9') levels.push_back(*q - '0');
+            float ms = 0;
+            for (int level : levels) {
+            p_def(ctx, dout, (hg_bgzf_desc *)ddd, n, level, dslots, dclen, s); CK(hipStreamSynchronize(s));
             if (p_dprof) { unsigned long long pr[16]; p_dprof(pr, 1); }
-            CK(hipEventRecord(e0, s)); p_def(ctx, dout, (hg_bgzf_desc *)ddd, n, 6, dslots, dclen, s); CK(hipEventRecord(e1, s));
-            CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            CK(hipEventRecord(e0, s)); p_def(ctx, dout, (hg_bgzf_desc *)ddd, n, level, dslots, dclen, s); CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             std::vector<uint32_t> cl(n); CK(hipMemcpy(cl.data(), dclen, n * 4, hipMemcpyDeviceToHost));
             double csum = 0; for (long i = 0; i < n; i++) csum += cl[i];
-            printf("   DEFLATE: %.3f ms => %.2f GB/s, ratio %.3f (input stream ratio %.3f)\n", ms, total / 1e6 / ms, total / csum, (double)total / len);
+            printf("   DEFLATE level %d: %.3f ms => %.2f GB/s, ratio %.3f (input stream ratio %.3f, size vs input stream %.4f)\n", level, ms, total / 1e6 / ms, total / csum, (double)total / len, csum / len);
+            }
             if (p_dprof) { unsigned long long pr[16]; p_dprof(pr, 1); double tot = (double)pr[0];
                 printf("   deflate in-kernel time per block %.0f ticks: stage+crc %.1f%%  match+parse %.1f%%  huffman %.1f%%  emit %.1f%%\n",
                        tot / pr[5], 100 * pr[1] / tot, 100 * pr[2] / tot, 100 * pr[3] / tot, 100 * pr[4] / tot);
