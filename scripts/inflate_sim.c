@@ -9,6 +9,13 @@
  *      source may belong to an earlier lane that is still working: lanes publish their write cursors).
  * The model runs the lanes in lock step and reports how many passes / iterations the data needs, and checks the result
  * byte for byte against the serial decode.     gcc -O2 -o inflate_sim scripts/inflate_sim.c && ./inflate_sim file.bgzf
+ *
+ * Finding (10 GiB-config BAM, 256 lanes x 512 bits, profiles/r02_inflate_design_model.txt): the parse needs ~20 passes per
+ * block (re-synchronisation is slower than hoped: a chain of ~20 consecutive lanes has to be corrected one after the
+ * other) and -- decisive -- the write phase degenerates into a systolic pipeline: a sorted BAM copies every record from
+ * the previous one (~1 lane back at the same relative offset), so each lane waits for its predecessor (34 stalls per
+ * token, 2575 lock-step iterations instead of 73).  The design was therefore NOT built; see DESIGN.md section 9.
+ * Limitation: the write-phase model is only complete for blocks that fit one round (lanes x segment bits >= block bits).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -57,11 +64,13 @@ static int sim_codes(orc_state *s, const orc_huff *lc, const orc_huff *dc) {
     uint32_t *e = malloc((NL + 1) * 4), *x = malloc(NL * 4), *nb = malloc(NL * 4), *nt = malloc(NL * 4), *pe = malloc((NL + 1) * 4);
     int *flag = malloc(NL * 4);
     st_dblocks++;
-    for (;;) {                                                     /* rounds of NL * S bits */
+    for (int round = 0;; round++) {                                /* rounds of NL * S bits */
+        if (round > 4096) { fprintf(stderr, "model: too many rounds\n"); return -1; }
         st_rounds++;
         for (int i = 0; i <= NL; i++) { e[i] = B + (uint32_t)i * SBITS; pe[i] = ~e[i]; }
         int passes = 0;
         for (;;) {
+            if (passes > 4 * NL) { fprintf(stderr, "model: parse passes do not converge\n"); return -1; }
             int changed = 0, worst = 0;
             for (int i = 0; i < NL; i++) {
                 if (e[i] == pe[i]) continue;                       /* clean: keeps its results */
@@ -100,7 +109,8 @@ static int sim_codes(orc_state *s, const orc_huff *lc, const orc_huff *dc) {
         st_w_iters_ideal += (unsigned long long)maxtok;
         int remaining = k + 1;
         for (int i = 0; i <= k; i++) if (!left[i]) remaining--;
-        while (remaining > 0) {
+        for (unsigned long long guard = 0; remaining > 0; guard++) {
+            if (guard > 10000000ull) { fprintf(stderr, "model: W phase does not finish\n"); return -1; }
             memcpy(snap, cur, (k + 1) * 4);
             int maxcopy = 0;
             st_w_iters++;
@@ -134,7 +144,8 @@ static int sim_codes(orc_state *s, const orc_huff *lc, const orc_huff *dc) {
         s->out_pos = start[k + 1];
         free(start); free(cur); free(snap); free(bit); free(left);
         if (eob) { seek_bits(s, s, x[k]); break; }
-        B = x[k];
+        fprintf(stderr, "model: block needs more than one round of %d x %d bits -- not modelled\n", NL, SBITS);
+        return -1;
     }
     free(e); free(x); free(nb); free(nt); free(pe); free(flag);
     return 0;
