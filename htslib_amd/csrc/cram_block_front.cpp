@@ -355,6 +355,109 @@ int hg_cram_compress_blocks(const hg_cram_opts *opts, cram_block **b, cram_metri
     return 0;
 }
 
+int hg_cram_compress_blocks_lv(const hg_cram_opts *opts, cram_block **b, cram_metrics **metrics, const int *method, const int *level, int n) {
+    if (n <= 0) return 0;
+    std::vector<CompJob> jobs(n);
+    for (int i = 0; i < n; i++) jobs[i] = CompJob{opts, b[i], metrics ? metrics[i] : nullptr, method ? method[i] : -1, level ? level[i] : -1, -1};
+    compress_batch(jobs.data(), n);
+    for (int i = 0; i < n; i++) if (jobs[i].rc) return -1;
+    return 0;
+}
+
+// ---- cram_compress_slice's policy (cram/cram_encode.c:803-988) ------------------------------------------------------
+void hg_cram_slice_method_sets(const hg_cram_slice_opts *o, hg_cram_slice_sets *out) {
+    auto bit = [](int m) { return (int)(1u << m); };
+    const bool v31 = o->version >= (3 << 8) + 1;
+    int method = bit(GZIP) | bit(GZIP_RLE);
+    if (o->use_bz2) method |= bit(BZIP2);
+    const int rans30 = bit(RANS0) | bit(RANS1);
+    int ranspr = rans30;
+    if (o->use_rans) {
+        ranspr = bit(RANS_PR0) | bit(RANS_PR1);
+        if (o->level > 1) ranspr |= bit(RANS_PR64) | bit(RANS_PR9) | bit(RANS_PR128) | bit(RANS_PR193);
+        if (o->level > 5) ranspr |= bit(RANS_PR129) | bit(RANS_PR192);
+        method |= v31 ? ranspr : rans30;
+    }
+    if (o->use_arith && v31) {
+        method |= bit(ARITH_PR0) | bit(ARITH_PR1);
+        if (o->level > 1) method |= bit(ARITH_PR64) | bit(ARITH_PR9) | bit(ARITH_PR128) | bit(ARITH_PR129) | bit(ARITH_PR192) | bit(ARITH_PR193);
+    }
+    if (o->use_lzma) method |= bit(LZMA);
+    int methodF = method & ~(bit(GZIP) | bit(BZIP2) | bit(LZMA));      // entropy coders only, for the series nobody named
+    if (o->level >= 5) { method |= bit(GZIP_1); methodF = method; }
+    if (o->level == 1) { method = (method & ~bit(GZIP)) | bit(GZIP_1); methodF = method; }
+    int q = method;
+    if (v31 && o->use_fqz) {
+        q |= bit(FQZ);
+        if (o->level > 4) q |= bit(FQZ_b);
+        if (o->level > 6) q |= bit(FQZ_c) | bit(FQZ_d);
+    }
+    int rn = method & ~(rans30 | ranspr | bit(GZIP_RLE));
+    if (v31 && o->use_tok) rn |= o->use_arith ? bit(TOKA) : bit(TOK3);
+    out->method = method; out->methodF = methodF; out->qmethod = q; out->qmethodF = q; out->method_rn = rn;
+}
+
+// The calls cram_compress_slice makes before its final sweep, in its order: (data series, method set, level).  Series
+// ids >= HG_DS_END are the per-tag aux blocks.  present[ds] != 0: the slice has that block.
+int hg_cram_slice_plan(const hg_cram_slice_opts *o, const uint8_t *present, int naux, int core_size, int *ds, int *set, int *lv, int max) {
+    hg_cram_slice_sets S;
+    hg_cram_slice_method_sets(o, &S);
+    int n = 0;
+    auto add = [&](int d, int s_, int l) { if ((d >= HG_DS_END || present[d]) && n < max) { ds[n] = d; set[n] = s_; lv[n] = l; n++; } };
+    const int level = o->level;
+    if (level > 5 && core_size > 500) add(HG_DS_CORE, 1 << GZIP, 1);
+    add(HG_DS_IN, S.method, level);
+    if (level == 1) {
+        add(HG_DS_QS, S.qmethodF, 1);
+        for (int i = HG_DS_aux; i <= HG_DS_aux_oz; i++) add(i, S.method, 1);
+    } else if (level > 1) {
+        const int l = level < 3 ? 1 : level;
+        add(HG_DS_QS, S.qmethod, l);
+        add(HG_DS_BA, S.method, l);
+        add(HG_DS_BB, S.method, l);
+        for (int i = HG_DS_aux; i <= HG_DS_aux_oz; i++) add(i, S.method, level);
+    }
+    add(HG_DS_RN, S.method_rn, level);
+    add(HG_DS_NS, S.method, level);
+    for (int i = 0; i < naux; i++) add(HG_DS_END + i, S.method, level);
+    return n;
+}
+
+int hg_cram_compress_slice(const hg_cram_slice_opts *o, const hg_cram_opts *opts, cram_block **block, cram_metrics **metrics,
+                           const int *nvals, cram_block **aux, int naux) {
+    hg_cram_slice_sets S;
+    hg_cram_slice_method_sets(o, &S);
+    std::vector<cram_block *> jb; std::vector<cram_metrics *> jm; std::vector<int> jset, jlv;
+    cram_block *core = block[HG_DS_CORE];
+    auto add = [&](cram_block *b, cram_metrics *m, int set, int lv) {
+        if (!b || b->method != RAW) return;                                    // cram_io.c:1945-1952
+        for (cram_block *x : jb) if (x == b) return;                           // aliased series: the first call wins
+        jb.push_back(b); jm.push_back(m); jset.push_back(set); jlv.push_back(lv);
+    };
+    if (nvals && metrics) {                                                    // cram_encode.c:877-881
+        pthread_mutex_t *lk = opts ? (pthread_mutex_t *)opts->metrics_lock : nullptr;
+        if (lk) pthread_mutex_lock(lk);
+        for (int i = 0; i < HG_DS_END; i++) if (nvals[i] > 16 && metrics[i]) metrics[i]->unpackable = 1;
+        if (lk) pthread_mutex_unlock(lk);
+    }
+    uint8_t present[HG_DS_END];
+    for (int i = 0; i < HG_DS_END; i++) present[i] = block[i] != nullptr;
+    std::vector<int> ds(HG_DS_END + naux + 8), set(ds.size()), lv(ds.size());
+    const int n = hg_cram_slice_plan(o, present, naux, core ? core->uncomp_size : 0, ds.data(), set.data(), lv.data(), (int)ds.size());
+    for (int k = 0; k < n; k++) {
+        const int d = ds[k];
+        if (d >= HG_DS_END) { cram_block *b = aux[d - HG_DS_END]; if (b && b != core) add(b, b->m, set[k], lv[k]); }
+        else if (d == HG_DS_CORE) add(core, nullptr, set[k], lv[k]);
+        else if (!(d == HG_DS_NS && block[d] == core)) add(block[d], metrics ? metrics[d] : nullptr, set[k], lv[k]);
+    }
+    if (!jb.empty() && hg_cram_compress_blocks_lv(opts, jb.data(), jm.data(), jset.data(), jlv.data(), (int)jb.size()) != 0) return -1;
+    // final sweep: whatever is still RAW (never named above, or nothing beat the raw bytes) is tried with methodF
+    jb.clear(); jm.clear(); jset.clear(); jlv.clear();
+    for (int i = 1; i < HG_DS_END; i++) if (block[i] && block[i] != core) add(block[i], metrics ? metrics[i] : nullptr, S.methodF, o->level);
+    if (!jb.empty() && hg_cram_compress_blocks_lv(opts, jb.data(), jm.data(), jset.data(), jlv.data(), (int)jb.size()) != 0) return -1;
+    return 0;
+}
+
 uint32_t cram_block_size(cram_block *b) {
     uint8_t tmp[32];
     size_t n = 2;

@@ -37,12 +37,24 @@ int pr_flags(int m) {
 
 struct Job { size_t blk; int m; };
 
+// Test hook (tests/test_cram_metrics_reference.py): when set, no codec runs -- every (block, method) job "compresses" to the
+// size the script names (0 = the method fails), so that the auto-tuner's decisions can be compared, on the CPU, with the
+// reference's cram_compress_block3 driven by the same script.
+uint32_t (*g_size_script)(int method, size_t blk, uint32_t in_len) = nullptr;
+
 // Runs every (block, method) job.  Jobs are grouped by CODEC FAMILY, not by method id: the entry points take a
 // parameter per stream (order / flag byte / back-end), so e.g. all seven RANS_PR* trials of all blocks are ONE batched
 // GPU call.  res[j] = malloc'd payload (or null when the method is not available / failed), rlen[j] = its size.
 int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t *const *in, const uint32_t *in_len,
              std::vector<uint8_t *> &res, std::vector<uint32_t> &rlen) {
     res.assign(jobs.size(), nullptr); rlen.assign(jobs.size(), 0);
+    if (g_size_script) {
+        for (size_t j = 0; j < jobs.size(); j++) {
+            const uint32_t sz = g_size_script(jobs[j].m, jobs[j].blk, in_len[jobs[j].blk]);
+            if (sz) { res[j] = (uint8_t *)calloc(sz, 1); rlen[j] = sz; }
+        }
+        return HG_OK;
+    }
     enum Fam { F_GZ = 0, F_GZ1, F_R4, F_NX, F_AR, F_TK, F_N };
     auto family = [](int m) -> int {
         if (m == HG_M_GZIP) return F_GZ;
@@ -103,6 +115,8 @@ int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t
 
 extern "C" {
 
+void hg_debug_set_cram_size_script(uint32_t (*fn)(int, size_t, uint32_t)) { g_size_script = fn; }
+
 hg_cram_metrics *hg_cram_metrics_new(void) {                            // cram_new_metrics, cram_io.c:2327-2339
     hg_cram_metrics *m = (hg_cram_metrics *)calloc(1, sizeof *m);
     if (!m) return nullptr;
@@ -117,10 +131,10 @@ int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics 
                                          int version_major, const uint8_t *const *in, const uint32_t *in_len, uint8_t *const *out,
                                          uint32_t *out_len, int32_t *method_used) {
     if (!ctx || (n && (!method_set || !in || !in_len || !out || !out_len || !method_used))) return HG_EINVAL;
-    struct Blk { bool trial, done; uint32_t method; size_t j0, j1; };
+    struct Blk { bool trial, done, retry; uint32_t method, orig; size_t j0, j1; };
     std::vector<Blk> B(n);
     for (size_t i = 0; i < n; i++) {
-        B[i] = {false, false, method_set[i], 0, 0};
+        B[i] = {false, false, false, method_set[i], method_set[i], 0, 0};
         out_len[i] = in_len[i]; method_used[i] = HG_CRAM_RAW;               // RAW until something smaller turns up (copied at the end)
         if (method_set[i] == HG_M_RAW || level == 0 || in_len[i] == 0) B[i].done = true;   // cram_io.c:1967-1972
     }
@@ -143,16 +157,42 @@ int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics 
             if (k == seen.size()) { seen.push_back(M); pend.push_back(0); blocked.push_back(0); }
             if (blocked[k]) continue;
             const int sz = (int)in_len[i];
-            // sudden changes in size trigger a retrial (cram_io.c:1988-1997)
-            if (M->input_avg_sz && (sz / 4 - 750 > M->input_avg_sz || sz < M->input_avg_sz / 4 - 750) &&
-                abs(sz - M->input_avg_sz) / 10 > M->input_avg_delta)
-                M->next_trial = 0;
-            const bool trial = M->trial - pend[k] > 0 || --M->next_trial <= 0;
-            M->input_avg_delta = (int)(0.9 * (M->input_avg_delta + abs(sz - M->input_avg_sz)));
-            M->input_avg_sz += (int)(sz * .2);
-            M->input_avg_sz = (int)(M->input_avg_sz * 0.8);
+            auto size_check_and_avg = [&]() {
+                // sudden changes in size trigger a retrial (cram_io.c:1988-1997)
+                if (M->input_avg_sz && (sz / 4 - 750 > M->input_avg_sz || sz < M->input_avg_sz / 4 - 750) &&
+                    abs(sz - M->input_avg_sz) / 10 > M->input_avg_delta)
+                    M->next_trial = 0;
+            };
+            auto avg_update = [&]() {
+                M->input_avg_delta = (int)(0.9 * (M->input_avg_delta + abs(sz - M->input_avg_sz)));
+                M->input_avg_sz += (int)(sz * .2);
+                M->input_avg_sz = (int)(M->input_avg_sz * 0.8);
+            };
+            bool trial;
+            if (b.retry) {
+                // second entry of a block whose cached method failed in the previous round (cram_io.c:2252-2268): the
+                // metrics were re-armed there; cram_compress_block3 runs again from the top
+                b.retry = false;
+                size_check_and_avg();
+                trial = M->trial - pend[k] > 0 || --M->next_trial <= 0;
+                avg_update();
+            } else {
+                size_check_and_avg();
+                trial = M->trial - pend[k] > 0 || --M->next_trial <= 0;
+                avg_update();
+                if (!trial && M->method == HG_M_RAW) {
+                    // The learnt method is RAW: cram_compress_by_method(RAW) returns NULL (cram_io.c:1896-1903), which the
+                    // reference takes as "cached method failed" -- it re-arms the trial counters and restores the caller's
+                    // method set (cram_io.c:2252-2262) -- and then calls itself with method = RAW, which stores the block raw
+                    // (cram_io.c:1967-1972).  So: this block stays RAW, the NEXT block of the series starts a trial phase.
+                    M->trial = NTRIALS; M->next_trial = TRIAL_SPAN; M->revised_method = (int)b.orig;
+                    pend[k] = 0;
+                    taken.push_back(i);
+                    continue;
+                }
+            }
             taken.push_back(i);
-            if (!trial) { if (M->method != HG_M_RAW) jobs.push_back({i, M->method}); b.j1 = jobs.size(); continue; }
+            if (!trial) { jobs.push_back({i, M->method}); b.j1 = jobs.size(); continue; }
             b.trial = true;
             // like an htslib built without bz2 / lzma (fd->use_bz2 = 0): methods the engine does not have leave the set
             const uint32_t have = ~((1u << HG_M_BZIP2) | (1u << HG_M_LZMA) | (1u << HG_M_FQZ) | (1u << HG_M_FQZ_b) | (1u << HG_M_FQZ_c) |
@@ -191,6 +231,13 @@ int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics 
                 if (b.j0 == b.j1) continue;
                 const size_t j = b.j0;
                 if (res[j] && rlen[j] < in_len[i]) { memcpy(out[i], res[j], rlen[j]); out_len[i] = rlen[j]; method_used[i] = methmap[jobs[j].m]; }
+                else if (!res[j] && M) {
+                    // the cached method failed on this block: re-arm the trial and run the block again next round
+                    // (cram_io.c:2252-2268).  Later blocks of the same series that this round already handled with the
+                    // cached method keep their result -- the reference, working block by block, would have trialled them.
+                    M->trial = NTRIALS; M->next_trial = TRIAL_SPAN; M->revised_method = (int)b.orig;
+                    b.done = false; b.retry = true;
+                }
                 continue;
             }
             uint32_t sz[MAXM];
@@ -216,7 +263,8 @@ int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics 
                 if (best_method != M->method) M->consistency = 0;
                 else { const double f = 1 + M->consistency / 4.0; M->next_trial = (int)(M->next_trial * (f < 2 ? f : 2)); M->consistency++; }
                 M->method = best_method;
-                M->strat = best_method == HG_M_TOKA ? 1 : 0;
+                // zlib strategy / fqzcomp preset / tokeniser back-end of the learnt method (cram_io.c:2193-2205): Z_FILTERED = 1, Z_RLE = 3
+                M->strat = best_method == HG_M_GZIP ? 1 : best_method == HG_M_GZIP_RLE ? 3 : best_method == HG_M_TOKA ? 1 : 0;
                 const double MAXDELTA = 0.20; const int MAXFAILS = 4, mul = 1 + (level >= 7);
                 for (int m = 0; m < MAXM; m++) {
                     if (best_method == m) { M->cnt[m] = 0; M->extra[m] = 0; }

@@ -109,6 +109,42 @@ typedef struct hg_cram_opts {
 int hg_cram_compress_block(const hg_cram_opts *opts, cram_block *b, cram_metrics *metrics, int method, int level);
 int hg_cram_compress_blocks(const hg_cram_opts *opts, cram_block **b, cram_metrics **metrics, const int *method, int level, int n);
 
+/* Same with one level per block (cram_compress_slice mixes level 1 and fd->level, cram_encode.c:886-935). */
+int hg_cram_compress_blocks_lv(const hg_cram_opts *opts, cram_block **b, cram_metrics **metrics, const int *method, const int *level, int n);
+
+/* ---- cram_compress_slice's method-set policy (cram/cram_encode.c:803-988) as data.  Which codecs a block may be tried
+ *      with depends on the file version, the compression level, the use_* options and the data series; the reference
+ *      computes five bit sets of cram_block_method_int values and hands one of them, with a level, to cram_compress_block2
+ *      per data series.  Pinned by running the reference's own function with a recording cram_compress_block2
+ *      (tests/test_cram_slice_policy.py). ---- */
+typedef struct hg_cram_slice_opts {
+    int level, version;                                   /* fd->level, fd->version (major << 8 | minor)            */
+    int use_bz2, use_lzma, use_rans, use_arith, use_fqz, use_tok;
+} hg_cram_slice_opts;
+typedef struct hg_cram_slice_sets {
+    int method;        /* general set                                                    */
+    int methodF;       /* the final sweep over blocks that are still RAW                 */
+    int qmethod;       /* quality values: + fqzcomp variants                             */
+    int qmethodF;
+    int method_rn;     /* read names: no rANS / GZIP_RLE, + TOK3 or TOKA                 */
+} hg_cram_slice_sets;
+void hg_cram_slice_method_sets(const hg_cram_slice_opts *o, hg_cram_slice_sets *sets);
+/* Data-series ids (enum cram_DS_ID, cram/cram_structs.h:143-197) of the series the policy names. */
+enum { HG_DS_CORE = 0, HG_DS_aux = 1, HG_DS_aux_oz = 9, HG_DS_RN = 11, HG_DS_QS = 12, HG_DS_IN = 13, HG_DS_NS = 20, HG_DS_BA = 30,
+       HG_DS_BB = 37, HG_DS_END = 47 };
+/* The calls cram_compress_slice makes before its final sweep, in its order: ds[k] = data series (ids >= HG_DS_END = the
+ * per-tag aux blocks), set[k] = method set, lv[k] = level.  present[ds] != 0: the slice has that block; core_size = bytes of
+ * the CORE block.  Returns the number of calls.  (The final sweep then offers methodF at the slice level to every block
+ * that is still RAW.) */
+int hg_cram_slice_plan(const hg_cram_slice_opts *o, const uint8_t *present, int naux, int core_size, int *ds, int *set, int *lv, int max);
+/* cram_compress_slice for one slice in ONE engine batch (two when a block is still RAW after its first attempt, as the
+ * reference's final sweep re-tries it with methodF).  block[ds] / metrics[ds] for ds < HG_DS_END (NULL = absent), nvals[ds] =
+ * c->stats[ds]->nvals or 0 (series with > 16 distinct values are marked unpackable, cram_encode.c:877-881); aux[] = the
+ * per-tag blocks beyond DS_END with their own b->m metrics.  opts carries the level / version / metrics lock as for
+ * hg_cram_compress_block.  Returns 0 / -1. */
+int hg_cram_compress_slice(const hg_cram_slice_opts *o, const hg_cram_opts *opts, cram_block **block, cram_metrics **metrics,
+                           const int *nvals, cram_block **aux, int naux);
+
 /* Block framing (cram_read_block / cram_write_block with fd reduced to the transport and the file's major version):
  * method u8, content_type u8, content_id / comp_size / uncomp_size as ITF8 (v2, v3) or uint7 varints (v4), payload,
  * CRC-32 (v3+).  read: b->crc_part = CRC of the header bytes, crc32_checked = ignore_crc. */
