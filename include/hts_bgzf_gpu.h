@@ -8,16 +8,18 @@
  * bgzf_read_small/bgzf_write_small inlines, sam.c:800-803).  The reference's own test/test_bgzf.c
  * and bgzip.c are built against this library, unmodified, by tests/test_reference_programs.py.
  *
- * How it differs from bgzf.c, by design (DESIGN.md):
- *   - blocks are (de)compressed in BATCHES on the GPU (libhtsgpu.so, hg_pipe_*): every compressed handle
- *     behaves like the reference's multi-threaded mode -- a reader prefetches and inflates windows of blocks
- *     on an I/O thread, a writer queues blocks and an output thread writes them in order.  `fp->mt` is
- *     therefore non-NULL for compressed handles and callers take their "threaded" paths (deferred index
- *     offsets via bgzf_idx_push, bgzf_tell on a writer valid in its low 16 bits until bgzf_flush;
- *     bgzf.c:1953-1967, sam.c:942).  bgzf_mt() / bgzf_thread_pool() are accepted and change nothing;
+ * How it differs from bgzf.c, by design (DESIGN.md, INTEGRATION.md A1):
+ *   - blocks are (de)compressed in BATCHES on the GPU (libhtsgpu.so, hg_pipe_*).  A reader always behaves like the
+ *     reference's threaded mode: an I/O thread prefetches and inflates windows of blocks, `fp->mt` is non-NULL,
  *     bgzf_set_cache_size() is ignored as it is with threads (bgzf.c:2126-2130).
- *   - `fp->fp` is a real hFILE; all I/O goes through the exported hFILE functions, so the library works with
- *     libhts' hfile.c (every transport) or with the bundled local-file provider (hfile_min.cpp).
+ *   - a writer WITHOUT bgzf_mt() keeps bgzf_tell() exact between writes like the reference's single-threaded writer
+ *     (each block goes to the device alone and is waited for: correct, slow).  bgzf_mt() / bgzf_thread_pool() create no
+ *     threads but switch the writer to the reference's threaded contract: blocks are batched, `fp->mt` becomes non-NULL,
+ *     fp->block_address is valid after bgzf_flush() only and index offsets go through bgzf_idx_push
+ *     (bgzf.c:189-290, 1953-1967; sam.c:942).
+ *   - `fp->fp` is a real hFILE; all I/O goes through the exported hFILE functions, so the library works with libhts'
+ *     hfile.c (every transport) or with the bundled local-file provider (hfile_min.cpp).  The engine state hangs on
+ *     `fp->cache` (the reference's block cache has no role here).
  *   - plain gzip input and mode "g" output are supported through the engine as well (one wavefront per stream:
  *     it works, slowly; BGZF is the fast path).
  *   - there is no CPU codec: without a usable MI355X bgzf_open() fails (ENODEV) for compressed streams.
@@ -65,9 +67,9 @@ struct BGZF {
     int block_length, block_clength, block_offset;
     int64_t block_address, uncompressed_address;
     void *uncompressed_block, *compressed_block;
-    bgzf_cache_t *cache;
+    bgzf_cache_t *cache;            /* the batch engine of this handle (NULL for uncompressed handles); opaque */
     struct hFILE *fp;               /* the transport, as in the reference (bgzf_hfile) */
-    struct bgzf_mtaux_t *mt;        /* the batch engine of this handle (NULL for uncompressed handles) */
+    struct bgzf_mtaux_t *mt;        /* non-NULL = "threaded" contract in force (see above); opaque */
     bgzidx_t *idx;
     int idx_build_otf;
     struct z_stream_s *gz_stream;   /* unused: gzip streams go through the engine too */

@@ -101,3 +101,53 @@ def test_bench_ranks_share_one_cooperatively_built_data_set(tmp_path):
         out += zlib.decompress(c[p + 18:p + bs - 8], -15)
         p += bs
     assert out == plain2
+
+
+def _strong_worker(rank, world, port, path, q):
+    """What bench.py --scaling strong does per rank, with zlib standing in for the kernel (this test is about the SPLIT:
+    one file, block ranges from shard_blocks, no exchange of data between ranks)."""
+    import hashlib
+    import zlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from htslib_amd import _native as nat
+    from htslib_amd.bgzf import shard_blocks, reduce_timing
+    comp = open(path, "rb").read()
+    desc, total = nat.bgzf_scan(comp)
+    lo, hi = shard_blocks(desc, world)[rank]
+    out = bytearray()
+    for d in desc[lo:hi]:
+        a = int(d["coff"]); blk = comp[a:a + int(d["clen"])]
+        piece = zlib.decompress(blk[18:-8], -15)
+        assert zlib.crc32(piece) == int.from_bytes(blk[-8:-4], "little") and len(piece) == int(d["ulen"])
+        out += piece
+    elapsed, sum_u, sum_c, ok = reduce_timing(0.01, float(len(out)), 0.0, True, world)
+    # the sink is host memory: rank outputs are simply concatenated in rank order (gather only for the check)
+    parts = [None] * world
+    dist.all_gather_object(parts, bytes(out))
+    dist.barrier()
+    q.put((rank, hashlib.md5(b"".join(parts)).hexdigest(), int(sum_u), int(total), (lo, hi)))
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_split_reassembles_the_file(built, tmp_path):
+    """bench.py --scaling strong: ONE BGZF file, rank r decodes the contiguous block range shard_blocks gives it; the
+    concatenation of the rank outputs is the file's plain stream (md5 equal to the single-rank decode)."""
+    import hashlib
+    plain, bg = synth.bam_bgzf(3 << 20)
+    path = str(tmp_path / "one.bam")
+    open(path, "wb").write(bg)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_strong_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = hashlib.md5(plain).hexdigest()
+    for rank, md5, sum_u, total, rng in res:
+        assert md5 == want and sum_u == total == len(plain)
+    assert res[0][4][1] == res[1][4][0] and res[0][4][0] == 0          # contiguous, no overlap
