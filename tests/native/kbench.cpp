@@ -45,6 +45,15 @@ int main(int argc, char **argv) {
             printf("   in-kernel wave time (s_memtime ticks, 100 MHz): blocks %llu  per-block total %.0f  header+tables %.1f%%  symbols %.1f%%  resolve %.1f%%  crc %.1f%%\n",
                    pr[5], tot / pr[5], 100 * pr[1] / tot, 100 * pr[2] / tot, 100 * pr[3] / tot, 100 * pr[4] / tot);
         }
+        auto p_prof2 = (int (*)(unsigned long long *, int))dlsym(h, "hg_debug_get_profile2");
+        if (p_prof2 && getenv("HG_INFLATE_V2")) {
+            unsigned long long pr[16]; p_prof2(pr, 1);
+            p_inf(ctx, dc, len, (hg_bgzf_desc *)dd, n, dout, total, dst, s); CK(hipStreamSynchronize(s)); p_prof2(pr, 1);
+            printf("   v2 parse  (ticks of 10 ns per block, workgroup time): total %.0f  header+tables %.0f  passes %.0f  prefix+emit %.0f   passes/round %.1f  rounds/block %.2f\n",
+                   (double)pr[0] / pr[4], (double)pr[1] / pr[4], (double)pr[2] / pr[4], (double)pr[3] / pr[4], (double)pr[5] / (pr[6] ? pr[6] : 1), (double)pr[6] / pr[4]);
+            printf("   v2 resolve (ticks per block, wave time): total %.0f  tokens %.0f  tail flush %.0f  crc %.0f\n",
+                   (double)pr[8] / pr[12], (double)pr[9] / pr[12], (double)pr[10] / pr[12], (double)pr[11] / pr[12]);
+        }
         fflush(stdout);
         // ---- deflate the plain image that the inflate above produced --------------------------
         auto p_def = (int (*)(hg_ctx *, const void *, const hg_bgzf_desc *, size_t, int, void *, uint32_t *, void *))dlsym(h, "hg_bgzf_deflate_dev");
