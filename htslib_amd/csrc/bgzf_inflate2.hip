@@ -1,20 +1,24 @@
 // bgzf_inflate2.hip -- BGZF inflate as a two-kernel pipeline ("v2"): a lane-parallel PARSE kernel and a
-// one-wavefront-per-block RESOLVE kernel that exchange LZ77 tokens through HBM.
+// one-wavefront-per-block RESOLVE kernel that exchange LZ77 tokens through HBM.  OPT-IN (HG_INFLATE_V2=1): it is
+// bit-exact on every fixture and test (tests/test_bgzf_inflate_gpu.py runs them through it), but it measured 65 GB/s against
+// 106 GB/s for the one-kernel path on the same file -- profiles/r02_inflate_v2_steps.txt has the step-by-step numbers.
 //
-// Why.  The one-block-per-wavefront kernel (bgzf_inflate.hip) spends ~40 vector instructions per Huffman symbol with all
-// 64 lanes computing the same value: it is VALU-issue bound at 1.7 % of the HBM roofline.  Decoding is the part that can
-// use the lanes: the bits of a deflate block are cut into 256 segments, every lane parses the tokens that START in its
-// segment from a guessed entry bit, and entries are corrected until they chain (Huffman streams re-synchronise; lane 0 is
-// always right, so the fixpoint is the true parse).  What cannot be parallelised inside a block is the LZ77 copy chain
-// (a sorted BAM copies each record from the previous one: scripts/inflate_sim.c) -- so that part stays sequential, one
-// wavefront per block, but it no longer decodes: it reads ready-made 32-bit tokens, scatters 64 literals per step and spends
-// ~16 vector + ~20 scalar instructions per match.
+// Idea.  The one-block-per-wavefront kernel (bgzf_inflate.hip) spends ~40 vector instructions per Huffman symbol with all
+// 64 lanes computing the same value.  Decoding can use the lanes: the bits of a deflate block are cut into segments, every
+// lane parses the tokens that START in its segment from a guessed entry bit, and entries are corrected until they chain
+// (lane 0 is always right, so the fixpoint is the true parse).  What cannot be parallelised inside a block is the LZ77 copy
+// chain (a sorted BAM copies each record from the previous one: scripts/inflate_sim.c) -- so that part stays sequential,
+// one wavefront per block, but it no longer decodes: it reads ready-made 32-bit tokens.
 //
-//   parse_kernel    256 threads per block.  wave 0: deflate block header + decode tables (shared code, inflate_common.h);
-//                   all waves: speculative parse passes over LDS tables, prefix sum of token counts, token emission.
+//   parse_kernel    one wavefront per block (256 lanes per block were tried: 20 correction passes instead of 3).
+//                   Deflate block header + decode tables (shared code, inflate_common.h), speculative parse passes over the
+//                   LDS tables, prefix sum of token counts, token emission.
 //                   token = literal byte | 0x80000000 | (len-3) << 16 | (dist-1).
-//   resolve_kernel  one wavefront per block, 1 KiB LDS ring of recent output as in v1, CRC-32 as in v1.
-// Tokens: <= 4 B per symbol, ~0.5 B per plain byte on the bench BAM, written once and read once.
+//   resolve_kernel  one wavefront per block: 64 tokens per step, prefix sum of lengths, literals and matches go to a 4 KiB
+//                   LDS ring that is flushed to HBM 1 KiB at a time with 16-byte stores; CRC-32 as in v1.
+// Tokens: 4 B per symbol, ~0.5 B per plain byte on the bench BAM, written once and read once.
+// What it taught: 2.0x fewer vector instructions per block than v1, but the resolve loop is bound by the CU's single
+// scalar ALU and the parse loop by per-lane dependent-instruction latency (see the profile file).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -44,12 +48,20 @@ __device__ unsigned long long g_prof2[16];
 #define P_CNTW(slot, v) do { } while (0)
 #endif
 
-constexpr int NL = 256;                       // lanes (threads) per block in the parse kernel
-constexpr uint32_t SEG = 512;                 // bits per lane segment
+#ifndef HG2_NL
+#define HG2_NL 64
+#endif
+constexpr int NL = HG2_NL;                    // lanes (threads) per block in the parse kernel: 64 (measured) or 256
+constexpr int NW = NL / 64;                   // wavefronts per block
+constexpr uint32_t SEG = 131072u / NL;        // bits per lane segment: one round covers 128 Kibit, the usual block in one round
 constexpr uint32_t TOK_CAP = 65536u + 256u;   // tokens per block: at most one per output byte
 constexpr uint32_t IDLE = 0xffffffffu;
 enum { P_OK = 0, P_EOB = 1, P_ERR = 2, P_IDLE = 3 };
 enum { ST_OK = 0, ST_HEADER = 1, ST_INFLATE = 2, ST_SIZE = 3, ST_CRC = 4 };
+
+constexpr uint32_t ROUND_DW = (uint32_t)NL * SEG / 32u;           // dwords per round (4096)
+constexpr uint32_t STAGE_DW = ROUND_DW + 64u;                      // + what the last lane may read past its segment
+constexpr uint32_t STAGE_WORDS __attribute__((unused)) = STAGE_DW + (STAGE_DW >> 6) + 2u;
 
 struct ParseLds {
     WaveLds T;                                // tables + build scratch (the ring is not used here)
@@ -58,40 +70,67 @@ struct ParseLds {
     uint32_t ntok[NL];
     uint32_t nbyte[NL];
     uint32_t flag[NL];
+#if HG2_STAGE
+    uint32_t inb[STAGE_WORDS];                // the round's dwords (see LaneBits)
+#endif
     uint32_t wsum[8];
     // wave 0 -> everybody: [0] first symbol bit of the deflate block / round  [1] status  [2] bfinal  [3] btype
     // [4] stored length  [5] stored source byte  [6] tokens so far  [7] bytes so far  [8] ticket
     uint32_t bc[12];
 };
 
-// ---- per-lane bit reader over the compressed stream in global memory ------------------------------------------------
-struct LaneBits { uint64_t bb; uint32_t bc, dw; };
-__device__ __forceinline__ uint32_t lb_load(const uint32_t *g, uint32_t max_dw, uint32_t dw) { return g[dw < max_dw ? dw : max_dw]; }
-__device__ __forceinline__ void lb_seek(LaneBits &r, const uint32_t *g, uint32_t max_dw, uint32_t bit) {
+// ---- per-lane bit reader over the round's bits, staged in LDS ----------------------------------------------------------
+// A round covers NL segments of SEG bits = 16 KiB of the stream.  Lanes walk their own segments, i.e. 64 different cache
+// lines per load instruction if they read global memory (measured: the L2 -> L1 traffic of that pattern, ~9 MB per 12 KiB
+// block, bounded the kernel).  So the round's dwords are copied to LDS once, coalesced, and read from there.  Dword d of
+// the round sits at index d + (d >> 6): one padding word per 64 keeps lanes that are at the same offset of their segments
+// on different banks.
+// Measured (profiles/r02_inflate_v2_steps.txt): staging cuts a block's parse latency by 40 % but its 17 KiB of LDS leave 6
+// wavefronts per CU instead of 20, and the kernel as a whole gets slower (4.7 ms vs 3.9 ms per 8192 blocks): HG2_STAGE=0,
+// the default, lets the lanes read global memory (clamped to the stream's last dword).
+#ifndef HG2_STAGE
+#define HG2_STAGE 0
+#endif
+struct LaneBits { uint64_t bb; uint32_t bc, dw, max_rel; };
+__device__ __forceinline__ uint32_t lb_load_(const uint32_t *inb, uint32_t dw, uint32_t max_rel) {
+#if HG2_STAGE
+    (void)max_rel;
+    const uint32_t d = dw < STAGE_DW - 1u ? dw : STAGE_DW - 1u;    // (a lane never needs more; the clamp keeps garbage lanes in bounds)
+    return inb[d + (d >> 6)];
+#else
+    return inb[dw < max_rel ? dw : max_rel];                      // inb = global base of the round, clamped to the image's last dword
+#endif
+}
+#define lb_load(inb, dw) lb_load_(inb, dw, r.max_rel)
+__device__ __forceinline__ void lb_seek(LaneBits &r, const uint32_t *inb, uint32_t bit, uint32_t max_rel) {   // bit: relative to the round's base
+    r.max_rel = max_rel;
     r.dw = bit >> 5;
     const uint32_t sh = bit & 31u;
-    r.bb = (uint64_t)(lb_load(g, max_dw, r.dw) >> sh);
+    r.bb = (uint64_t)(lb_load(inb, r.dw) >> sh);
     r.bc = 32u - sh;
     r.dw++;
 }
-__device__ __forceinline__ void lb_refill(LaneBits &r, const uint32_t *g, uint32_t max_dw) {
-    if (r.bc <= 32u) { r.bb |= (uint64_t)lb_load(g, max_dw, r.dw) << r.bc; r.bc += 32u; r.dw++; }
+__device__ __forceinline__ void lb_refill(LaneBits &r, const uint32_t *inb) {
+    if (r.bc <= 32u) { r.bb |= (uint64_t)lb_load(inb, r.dw) << r.bc; r.bc += 32u; r.dw++; }
 }
 __device__ __forceinline__ uint32_t lb_pos(const LaneBits &r) { return r.dw * 32u - r.bc; }
 
 // Parse the tokens that start in [entry, lim).  EMIT: also write them to tok_out.
+// (A variant that stopped correction parses at positions an earlier parse of the lane had visited was tried: the lanes on
+// the correction chain are by definition the ones that do NOT re-synchronise, so it saved nothing.)
 template <bool EMIT>
-__device__ __forceinline__ void lane_parse(const uint32_t *g, uint32_t max_dw, const uint32_t *lit, const uint32_t *dist, uint32_t entry,
+__device__ __forceinline__ void lane_parse(const uint32_t *inb, uint32_t base_bit, uint32_t max_rel, const uint32_t *lit, const uint32_t *dist, uint32_t entry,
                                            uint32_t lim, uint32_t end_bit, uint32_t &x, uint32_t &flag, uint32_t &nt, uint32_t &nb,
                                            uint32_t *tok_out) {
+    // positions are bit offsets relative to br.g as everywhere else; the reader works relative to the staged base
     LaneBits r;
-    lb_seek(r, g, max_dw, entry);
+    lb_seek(r, inb, entry - base_bit, max_rel);
     nt = 0; nb = 0; flag = P_OK;
-    for (uint32_t guard = 0; guard < 640u; guard++) {
-        const uint32_t start = lb_pos(r);
+    for (uint32_t guard = 0; guard < SEG + 128u; guard++) {
+        const uint32_t start = lb_pos(r) + base_bit;
         if (start >= lim) break;
         if (start >= end_bit) { flag = P_ERR; break; }
-        lb_refill(r, g, max_dw);
+        lb_refill(r, inb);
         uint32_t e = lit[(uint32_t)r.bb & ((1u << LIT_RB) - 1u)];
         if (e & F_SUB) {
             r.bb >>= LIT_RB; r.bc -= LIT_RB;
@@ -112,7 +151,7 @@ __device__ __forceinline__ void lane_parse(const uint32_t *g, uint32_t max_dw, c
         const uint32_t xb = (e >> 8) & 15u;
         const uint32_t len = (e >> 16) + (((uint32_t)r.bb >> nbits) & ((1u << xb) - 1u));
         r.bb >>= (nbits + xb); r.bc -= nbits + xb;
-        lb_refill(r, g, max_dw);
+        lb_refill(r, inb);
         uint32_t d = dist[(uint32_t)r.bb & ((1u << DIST_RB) - 1u)];
         if (d & F_SUB) {
             r.bb >>= DIST_RB; r.bc -= DIST_RB;
@@ -126,7 +165,7 @@ __device__ __forceinline__ void lane_parse(const uint32_t *g, uint32_t max_dw, c
         if (EMIT) tok_out[nt] = 0x80000000u | ((len - 3u) << 16) | (dv - 1u);
         nt++; nb += len;
     }
-    x = lb_pos(r);
+    x = lb_pos(r) + base_bit;
 }
 
 // Deflate block header + tables, wave 0 only (the code of inflate_stream in bgzf_inflate.hip up to its symbol loop).
@@ -279,16 +318,30 @@ void parse_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len, const hg_
                 // ---- rounds of NL segments until the end-of-block code -----------------------------------------------------
                 for (;;) {
                     const uint32_t B = L.bc[0];
+                    const uint32_t base_dw = B >> 5, base_bit = base_dw << 5;
+#if HG2_STAGE
+                    for (uint32_t d = (uint32_t)tid; d < STAGE_DW; d += NL) {          // coalesced copy of the round's dwords
+                        const uint32_t a_dw = base_dw + d;
+                        L.inb[d + (d >> 6)] = g[a_dw < max_dw ? a_dw : max_dw];
+                    }
+                    const uint32_t *inb = L.inb;
+#else
+                    const uint32_t *inb = g + base_dw;              // reads stay below end_bit + 64 bits <= the padded end of the image
+#endif
                     const uint32_t Ni = B + (uint32_t)tid * SEG, lim = Ni + SEG;
                     L.entry[tid] = tid == 0 ? B : (Ni < end_bit ? Ni : IDLE);
                     uint32_t last = ~L.entry[tid];                 // "never parsed"
                     for (;;) {
                         __syncthreads();
                         const uint32_t e = L.entry[tid];
+#ifdef HG_PROFILE
+                        { const unsigned long long dm = __ballot(e != last && e != IDLE && e < end_bit);
+                          if (lane == 0 && dm) { atomicAdd(&g_prof2[7], 1ull); atomicAdd(&g_prof2[13], (unsigned long long)__popcll(dm)); } }
+#endif
                         if (e != last) {
                             last = e;
                             uint32_t x = IDLE, f = P_IDLE, nt = 0, nb = 0;
-                            if (e != IDLE && e < end_bit) lane_parse<false>(g, max_dw, L.T.lit, L.T.dist, e, lim, end_bit, x, f, nt, nb, nullptr);
+                            if (e != IDLE && e < end_bit) lane_parse<false>(inb, base_bit, max_dw - base_dw, L.T.lit, L.T.dist, e, lim, end_bit, x, f, nt, nb, nullptr);
                             L.exitb[tid] = x; L.flag[tid] = f; L.ntok[tid] = nt; L.nbyte[tid] = nb;
                         }
                         __syncthreads();
@@ -305,7 +358,8 @@ void parse_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len, const hg_
                     if (lane == 0) L.wsum[wave] = bal ? (uint32_t)(wave * 64 + __builtin_ctzll(bal)) : (uint32_t)NL;
                     __syncthreads();
                     uint32_t k = L.wsum[0];
-                    k = k < L.wsum[1] ? k : L.wsum[1]; k = k < L.wsum[2] ? k : L.wsum[2]; k = k < L.wsum[3] ? k : L.wsum[3];
+#pragma unroll
+                    for (int w = 1; w < NW; w++) k = k < L.wsum[w] ? k : L.wsum[w];
                     const bool flagged = k < (uint32_t)NL;
                     const uint32_t fk = flagged ? L.flag[k] : (uint32_t)P_OK;
                     const uint32_t last_lane = flagged ? k : (uint32_t)NL - 1u;
@@ -317,12 +371,12 @@ void parse_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len, const hg_
                     __syncthreads();
                     uint32_t off = incl - mine, tot = 0, totb = 0;
 #pragma unroll
-                    for (int w = 0; w < 4; w++) { const uint32_t t = L.wsum[w]; if (w < wave) off += t; tot += t; totb += L.wsum[4 + w]; }
+                    for (int w = 0; w < NW; w++) { const uint32_t t = L.wsum[w]; if (w < wave) off += t; tot += t; totb += L.wsum[4 + w]; }
                     const uint32_t t0 = L.bc[6];
                     const bool bad = (flagged && fk != P_EOB) || t0 + tot > TOK_CAP;
                     if (!bad && (uint32_t)tid <= last_lane && mine) {
                         uint32_t x, ff, nt, nb;
-                        lane_parse<true>(g, max_dw, L.T.lit, L.T.dist, L.entry[tid], lim, end_bit, x, ff, nt, nb, tok + t0 + off);
+                        lane_parse<true>(inb, base_bit, max_dw - base_dw, L.T.lit, L.T.dist, L.entry[tid], lim, end_bit, x, ff, nt, nb, tok + t0 + off);
                     }
                     const uint32_t next_bit = L.exitb[last_lane];
                     __syncthreads();
@@ -427,6 +481,14 @@ void resolve_kernel(const uint8_t *__restrict__ comp, const hg_bgzf_desc *__rest
                         flush_span(ring, o_al, flushed, upto, qmin, qmax, lane);
                         flushed = upto;
                     }
+#ifndef HG2_NO_FAST
+                    if (mlen <= 64u && mdist >= mlen && mdist <= RING2_NEAR) {
+                        // the common match: one LDS read, one LDS write, no loop
+                        const uint8_t v = ring[(mpos - mdist + (uint32_t)lane + a) & (RING2 - 1u)];
+                        if ((uint32_t)lane < mlen) ring[(mpos + (uint32_t)lane + a) & (RING2 - 1u)] = v;
+                        continue;
+                    }
+#endif
                     uint32_t done = 0, span = mdist;
                     do {                                              // spans double for overlapping matches
                         uint32_t c = mlen - done;
@@ -504,7 +566,7 @@ int launch_bgzf_inflate_v2(hg_ctx *ctx, const void *d_comp, size_t comp_len, con
         const size_t n = nblocks - c0 < chunk ? nblocks - c0 : chunk;
         unsigned int *t1 = next_ticket(ctx), *t2 = next_ticket(ctx);
         if (hipMemsetAsync(t1, 0, sizeof(unsigned int), s) != hipSuccess || hipMemsetAsync(t2, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
-        size_t wg1 = (size_t)ctx->cus * 8; if (wg1 > n) wg1 = n;
+        size_t wg1 = (size_t)ctx->cus * (HG2_STAGE ? (hg2::NL == 64 ? 6 : 3) : (hg2::NL == 64 ? 20 : 8)); if (wg1 > n) wg1 = n;
         hipLaunchKernelGGL(hg2::parse_kernel, dim3((unsigned)wg1), dim3(hg2::NL), 0, s, (const uint8_t *)d_comp, (uint64_t)comp_len, d_desc,
                            (uint32_t)c0, (uint32_t)n, tokbuf, ntok, pst, t1);
         size_t wg2 = (size_t)ctx->cus * 8; const size_t need2 = (n + 3) / 4; if (wg2 > need2) wg2 = need2;

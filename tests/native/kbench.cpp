@@ -51,6 +51,7 @@ int main(int argc, char **argv) {
             p_inf(ctx, dc, len, (hg_bgzf_desc *)dd, n, dout, total, dst, s); CK(hipStreamSynchronize(s)); p_prof2(pr, 1);
             printf("   v2 parse  (ticks of 10 ns per block, workgroup time): total %.0f  header+tables %.0f  passes %.0f  prefix+emit %.0f   passes/round %.1f  rounds/block %.2f\n",
                    (double)pr[0] / pr[4], (double)pr[1] / pr[4], (double)pr[2] / pr[4], (double)pr[3] / pr[4], (double)pr[5] / (pr[6] ? pr[6] : 1), (double)pr[6] / pr[4]);
+            printf("   v2 parse: wave-passes with a dirty lane per block %.1f, lane parses per block %.1f\n", (double)pr[7] / pr[4], (double)pr[13] / pr[4]);
             printf("   v2 resolve (ticks per block, wave time): total %.0f  tokens %.0f  tail flush %.0f  crc %.0f\n",
                    (double)pr[8] / pr[12], (double)pr[9] / pr[12], (double)pr[10] / pr[12], (double)pr[11] / pr[12]);
         }
