@@ -1,0 +1,7 @@
+#!/bin/bash
+# GPU box: deflate parity tests + kbench by level for libhtsgpu.so and the variants given
+R=$GRAFT_REPO_ROOT; cd $R
+timeout 600 python -m pytest tests/test_bgzf_deflate_gpu.py -m gpu -q -x --timeout 300 2>&1 | tail -5
+python scripts/prep_bgzf.py ${1:-2} /dev/shm/k.bgzf >/dev/null
+shift
+KBENCH_DEFLATE=1 KBENCH_LEVELS=${LEVELS:-156} timeout 300 tests/native/kbench /dev/shm/k.bgzf 2 htslib_amd/libhtsgpu.so "$@" 2>&1 | grep -v "in-kernel wave time\|v2 \|inflate"
