@@ -48,5 +48,7 @@ tests/native/diag: tests/native/diag.cpp $(HIPSRC) $(HDRS) $(LIB)
 # kernel A/B timing tool (dlopens any number of library builds)
 tests/native/kbench: tests/native/kbench.cpp include/htsgpu.h
 	$(HIPCC) -O2 --offload-arch=$(ARCH) -Iinclude tests/native/kbench.cpp -o $@ -ldl
-kbench: tests/native/kbench
+tests/native/latprobe: tests/native/latprobe.cpp include/htsgpu.h
+	$(HIPCC) -O2 --offload-arch=$(ARCH) -Iinclude tests/native/latprobe.cpp -o $@ -ldl
+kbench: tests/native/kbench tests/native/latprobe
 .PHONY: kbench

@@ -144,6 +144,8 @@ struct Engine {
     bool input_done = false;               // the I/O thread met EOF or a fatal input error
     bool pause_req = false, paused = false;
     size_t window = WINDOW_MIN;
+    size_t ahead = NPIPES;                 // batches the I/O thread may run ahead: 1 after a seek until the consumer shows
+                                           // that it is scanning (a random-access caller reads a few bytes and seeks again)
     std::vector<uint8_t> carry;            // bytes of a block cut by the window end
     int64_t read_off = 0;                  // file offset of carry[0] / of the next byte to hread
     size_t blk = 0;                        // current block inside the current batch
@@ -231,7 +233,7 @@ bool fill_batch(Engine *e, ReadBatch &b) {
 void reader_main(Engine *e) {
     std::unique_lock<std::mutex> lk(e->m);
     for (;;) {
-        e->cv.wait(lk, [&] { return e->stop || e->pause_req || (!e->input_done && e->fill_seq - e->done_seq < NPIPES); });
+        e->cv.wait(lk, [&] { return e->stop || e->pause_req || (!e->input_done && e->fill_seq - e->done_seq < e->ahead); });
         if (e->stop) break;
         if (e->pause_req) {
             e->paused = true; e->cv.notify_all();
@@ -281,8 +283,22 @@ int restart_reader_at(Engine *e, int64_t addr) {
     if (hseek(e->fp->fp, (off_t)addr, SEEK_SET) < 0) rc = -1;
     e->read_off = addr;
     if (rc != 0) e->input_done = true;
+    else {
+        // The first (small) window is read and submitted right here, on the caller's thread: no hand-over to the I/O
+        // thread on the latency path of a random access.  Nothing is prefetched behind it until widen_readahead().
+        e->ahead = 1;
+        if (fill_batch(e, e->rb[0])) e->input_done = true;
+        e->fill_seq = 1;
+    }
     resume_reader(e);
     return rc;
+}
+
+// The consumer has moved past the first blocks after a seek: it is scanning, let the I/O thread run ahead again.
+inline void widen_readahead(Engine *e) {
+    if (e->ahead >= NPIPES) return;
+    std::lock_guard<std::mutex> lk(e->m);
+    e->ahead = NPIPES; e->cv.notify_all();
 }
 
 // Make the next batch current.  Returns 1 = batch loaded, 0 = end of input, -1 = error (errcode set).
@@ -290,7 +306,7 @@ int next_batch(Engine *e) {
     BGZF *fp = e->fp;
     if (!start_reader(e)) { fp->errcode |= BGZF_ERR_IO; return -1; }
     std::unique_lock<std::mutex> lk(e->m);
-    if (e->cur_loaded) { e->cur_loaded = false; e->done_seq++; e->cv.notify_all(); }
+    if (e->cur_loaded) { e->cur_loaded = false; e->done_seq++; e->ahead = NPIPES; e->cv.notify_all(); }
     e->cv.wait(lk, [&] { return e->done_seq < e->fill_seq || e->input_done; });
     if (e->done_seq == e->fill_seq) return 0;
     ReadBatch &b = e->rb[e->done_seq % NPIPES];
@@ -341,6 +357,7 @@ int engine_read_block(BGZF *fp) {
         }
         ReadBatch &b = cur_batch(e);
         if (e->blk_pending) e->blk_pending = false; else e->blk++;
+        if (e->blk >= 2) widen_readahead(e);
         if (e->blk >= b.desc.size()) {
             if (b.fail) {
                 fp->errcode |= b.fail;
@@ -351,7 +368,7 @@ int engine_read_block(BGZF *fp) {
                 return -1;
             }
             std::unique_lock<std::mutex> lk(e->m);
-            e->cur_loaded = false; e->done_seq++; e->cv.notify_all();
+            e->cur_loaded = false; e->done_seq++; e->ahead = NPIPES; e->cv.notify_all();
             continue;
         }
         const hg_bgzf_desc &d = b.desc[e->blk];
@@ -409,6 +426,7 @@ void span_advance(BGZF *fp, Engine *e, size_t n) {
     }
     const hg_bgzf_desc &d = b.desc[j];
     e->blk = j;
+    if (j >= 2) widen_readahead(e);
     fp->block_address = b.file_off + (int64_t)d.coff;
     fp->block_clength = (int)d.clen;
     fp->block_length = (int)d.ulen;
