@@ -519,4 +519,32 @@ int hg_cram_write_block(hFILE *fp, int major, cram_block *b) {
     return 0;
 }
 
+// ---- htscodecs' pack.h / rle.h functions that cram_codecs.c calls for CRAM 4.0 E_XPACK / E_XRLE, under the
+// reference's own names and signatures so that cram_codecs.c links against them unchanged
+// (cram/cram_codecs.c:1399, 1520, 2106, 2278).  var_put_u64 / var_get_u64 (:2276, :2103) are static inlines of
+// htscodecs/varint.h, restated in hts_cram_gpu.h.
+uint8_t *hts_pack(uint8_t *data, int64_t len, uint8_t *out_meta, int *out_meta_len, uint64_t *out_len) {
+    hg_ctx *ctx = engine();
+    if (!ctx) { logerr("hts_pack", "no usable GPU engine"); return nullptr; }
+    return hg_hts_pack(ctx, data, len, out_meta, out_meta_len, out_len);
+}
+uint8_t *hts_unpack(uint8_t *data, int64_t len, uint8_t *out, uint64_t out_len, int nsym, uint8_t *p) {
+    hg_ctx *ctx = engine();
+    if (!ctx) { logerr("hts_unpack", "no usable GPU engine"); return nullptr; }
+    return hg_hts_unpack(ctx, data, len, out, out_len, nsym, p);
+}
+uint8_t *hts_rle_encode(uint8_t *data, uint64_t data_len, uint8_t *run, uint64_t *run_len, uint8_t *rle_syms, int *rle_nsyms,
+                        uint8_t *out, uint64_t *out_len) {
+    hg_ctx *ctx = engine();
+    if (!ctx) { logerr("hts_rle_encode", "no usable GPU engine"); return nullptr; }
+    return hg_hts_rle_encode(ctx, data, data_len, run, run_len, rle_syms, rle_nsyms, out, out_len);
+}
+uint8_t *hts_rle_decode(uint8_t *lit, uint64_t lit_len, uint8_t *run, uint64_t run_len, uint8_t *rle_syms, int rle_nsyms,
+                        uint8_t *out, uint64_t *out_len) {
+    hg_ctx *ctx = engine();
+    if (!ctx) { logerr("hts_rle_decode", "no usable GPU engine"); return nullptr; }
+    if (rle_nsyms < 0) return nullptr;
+    return hg_hts_rle_decode(ctx, lit, lit_len, run, run_len, rle_syms, (uint32_t)rle_nsyms, out, out_len);
+}
+
 }  // extern "C"

@@ -69,18 +69,21 @@ struct nx16_xform {
     uint64_t out_off;      // output buffer: first byte written
     uint32_t lit_len, meta_len, plen, ulen;
     uint32_t stride;       // output byte i goes to out_off + i * stride (STRIPE de-interleave)
-    uint32_t ops;          // 1 RLE, 2 PACK, 4 meta lives in the work buffer
+    uint32_t ops;          // 1 RLE, 2 PACK, 4 meta lives in the work buffer, 8 plen is a CAPACITY (hts_rle_decode): the
+                           //   number of bytes produced is stored as a uint64 at work + len_off
     uint32_t nsym;         // PACK symbol count (<= 16)
     uint32_t dep0, dep1;   // status slots of the entropy-decode jobs this one consumes (0xffffffff = none)
     uint8_t map[16];
-    uint32_t pad[3];
+    uint32_t pad;
+    uint64_t len_off;
 };
+static_assert(sizeof(nx16_xform) == 96, "nx16_xform layout");
 int launch_ransnx16_xform(hg_ctx *ctx, const void *d_in, void *d_work, void *d_out, const nx16_xform *d_jobs, size_t njobs,
                           int32_t *d_status, uint32_t status_base, hipStream_t s);
 // Encoder-side transform job (ransnx16_xenc.hip): [gather stripe] -> [PACK] -> [RLE]; offsets into ONE buffer.
 struct nx16_xenc {
     uint64_t src_off, g_off, p_off, l_off, m_off;
-    uint32_t n, stride, flags, pad;
+    uint32_t n, stride, flags, pad;     // flags: 0x80 PACK, 0x40 RLE, 0x100 the run symbols are PRESET at m_off ([count][symbols])
 };
 struct nx16_xenc_res {
     uint64_t cur_off;      // where the bytes to entropy-code ended up

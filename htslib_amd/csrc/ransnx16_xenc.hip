@@ -95,12 +95,19 @@ void nx16_xenc_kernel(uint8_t *buf, const hg::nx16_xenc *__restrict__ jobs, uint
         } else flags &= ~0x80u;
         // ------------------------------------------------------------------ RLE
         if ((flags & 0x40u) && n) {
+            uint8_t *meta = buf + J.m_off, *lit = buf + J.l_off;
+            uint32_t nr = 0;
+            if (flags & 0x100u) {                                          // the caller chose the run symbols (hts_rle_encode)
+                nr = meta[0]; if (!nr) nr = 256;
+                for (int k = lane; k < 256; k += 64) S.used[k] = 0;
+                wave_sync();
+                for (uint32_t k = (uint32_t)lane; k < nr; k += 64) S.used[meta[1u + k]] = 1;
+                wave_sync();
+            } else {
             for (int k = lane; k < 256; k += 64) S.score[k] = 0;
             wave_sync();
             for (uint32_t i = (uint32_t)lane; i < n; i += 64) atomicAdd(&S.score[cur[i]], (i && cur[i] == cur[i - 1]) ? 1 : -1);
             wave_sync();
-            uint8_t *meta = buf + J.m_off, *lit = buf + J.l_off;
-            uint32_t nr = 0;
             for (int q = 0; q < 4; q++) {
                 const int sym = q * 64 + lane;
                 const bool r = S.score[sym] > 0;
@@ -110,6 +117,7 @@ void nx16_xenc_kernel(uint8_t *buf, const hg::nx16_xenc *__restrict__ jobs, uint
                 nr += (uint32_t)__popcll(B);
             }
             wave_sync();
+            }
             if (!nr) flags &= ~0x40u;
             else {
                 if (lane == 0) meta[0] = (uint8_t)nr;

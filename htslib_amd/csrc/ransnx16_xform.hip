@@ -130,7 +130,8 @@ void nx16_xform_kernel(const uint8_t *__restrict__ in, uint8_t *work, uint8_t *o
                 o += total;
                 wave_sync();
             }
-            if (!err && o != (unsigned long long)J.plen) err = 1;
+            if (!err && !(J.ops & 8u) && o != (unsigned long long)J.plen) err = 1;
+            if (J.ops & 8u) *(unsigned long long *)(work + J.len_off) = err ? 0ull : o;          // every lane stores the same word
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             wave_sync();
             src = work + J.s2_off; src_len = J.plen;

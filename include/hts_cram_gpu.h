@@ -152,6 +152,42 @@ cram_block *hg_cram_read_block(struct hFILE *fp, int major_version, int ignore_c
 int hg_cram_write_block(struct hFILE *fp, int major_version, cram_block *b);
 uint32_t cram_block_size(cram_block *b);                                   /* cram_io.c:1490-1505 */
 
+/* ---- CRAM 4.0 E_XPACK / E_XRLE transforms: the htscodecs functions cram_codecs.c calls (cram/cram_codecs.c:1399, 1520,
+ *      2106, 2278), same names and signatures as htscodecs/pack.h and rle.h, computed by the engine (htsgpu.h:
+ *      hg_hts_pack ... document the argument conventions).  htscodecs is an un-vendored submodule of the reference:
+ *      semantics follow its published headers, parity unpinned. ---- */
+uint8_t *hts_pack(uint8_t *data, int64_t len, uint8_t *out_meta, int *out_meta_len, uint64_t *out_len);
+uint8_t *hts_unpack(uint8_t *data, int64_t len, uint8_t *out, uint64_t out_len, int nsym, uint8_t *p);
+uint8_t *hts_rle_encode(uint8_t *data, uint64_t data_len, uint8_t *run, uint64_t *run_len, uint8_t *rle_syms, int *rle_nsyms,
+                        uint8_t *out, uint64_t *out_len);
+uint8_t *hts_rle_decode(uint8_t *lit, uint64_t lit_len, uint8_t *run, uint64_t run_len, uint8_t *rle_syms, int rle_nsyms,
+                        uint8_t *out, uint64_t *out_len);
+
+/* htscodecs/varint.h (static inlines there too; cram_codecs.c:2103, 2276): big-endian 7 bits per byte, continuation in
+ * bit 7.  endp may be NULL for put (no bound).  Return the number of bytes used, 0 when out of room / input. */
+#ifndef VARINT_H
+static inline int var_put_u64(uint8_t *cp, const uint8_t *endp, uint64_t v) {
+    int n = 1, k;
+    uint64_t t = v;
+    while (t >>= 7) n++;
+    if (endp && endp - cp < n) return 0;
+    for (k = 0; k < n; k++) cp[k] = (uint8_t)(((v >> (7 * (n - 1 - k))) & 0x7f) | (k + 1 < n ? 0x80 : 0));
+    return n;
+}
+static inline int var_get_u64(uint8_t *cp, const uint8_t *endp, uint64_t *v) {
+    uint64_t x = 0;
+    int n = 0;
+    if (endp && cp >= endp) { *v = 0; return 0; }
+    for (;;) {
+        const uint8_t c = cp[n++];
+        x = (x << 7) | (c & 0x7f);
+        if (!(c & 0x80) || n == 10 || (endp && cp + n >= endp)) break;
+    }
+    *v = x;
+    return n;
+}
+#endif
+
 #ifdef __cplusplus
 }
 #endif

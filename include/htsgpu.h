@@ -403,6 +403,27 @@ int hg_crc32_batch_host(hg_ctx *ctx, const uint8_t *const *buf, const uint32_t *
 /* CRC-32 of one host buffer (upload + device CRC + host combine).  Synchronous. */
 int hg_crc32_host(hg_ctx *ctx, const void *buf, size_t len, uint32_t *crc);
 
+/* ---- CRAM 4.0 E_XPACK / E_XRLE byte transforms: the htscodecs functions cram_codecs.c calls --
+ * hts_unpack (cram/cram_codecs.c:1399), hts_pack (:1520), hts_rle_decode (:2106), hts_rle_encode (:2278) -- with the
+ * context as an extra first argument; arguments and results otherwise as htscodecs/pack.h and rle.h define them.
+ * The same kernels serve the PACK / RLE flags of rANS Nx16 streams.  Synchronous, one wavefront per call; lengths
+ * up to 2^31-1.  hts_cram_gpu.h has the wrappers under the reference's own names. ---- */
+/* <= 16 distinct byte values -> 1-, 2- or 4-bit codes, first value in the low bits.  out_meta (room for 17 bytes) =
+ * [number of symbols][symbols ascending]; returns a malloc'd buffer of *out_len bytes.  More than 16 values: a copy,
+ * out_meta_len 1.  One value: *out_len 0.  NULL on error. */
+uint8_t *hg_hts_pack(hg_ctx *ctx, const uint8_t *data, int64_t len, uint8_t *out_meta, int *out_meta_len, uint64_t *out_len);
+/* nsym = symbols PER BYTE as hts_unpack_meta reports them: 8, 4, 2; 1 = not packed (copy), 0 = constant p[0].
+ * p = the symbol map (>= 16 entries).  Returns out, NULL when data is too short for out_len symbols. */
+uint8_t *hg_hts_unpack(hg_ctx *ctx, const uint8_t *data, int64_t len, uint8_t *out, uint64_t out_len, int nsym, const uint8_t *p);
+/* Symbols in rle_syms are written once per run to the literal stream, run length - 1 as a 7-bit varint to `run`
+ * (room for data_len + 8 bytes).  *rle_nsyms == 0 on entry: the symbols whose repeats outnumber their run starts are
+ * chosen and returned.  out == NULL: malloc'd (2 * data_len).  Returns the literals (*out_len bytes). */
+uint8_t *hg_hts_rle_encode(hg_ctx *ctx, const uint8_t *data, uint64_t data_len, uint8_t *run, uint64_t *run_len, uint8_t *rle_syms,
+                           int *rle_nsyms, uint8_t *out, uint64_t *out_len);
+/* The inverse; *out_len = room in `out` on entry, bytes produced on return.  NULL on overrun / malformed run lengths. */
+uint8_t *hg_hts_rle_decode(hg_ctx *ctx, const uint8_t *lit, uint64_t lit_len, const uint8_t *run, uint64_t run_len, const uint8_t *rle_syms,
+                           uint32_t rle_nsyms, uint8_t *out, uint64_t *out_len);
+
 #ifdef __cplusplus
 }
 #endif
