@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #include "htsgpu.h"
 #include "hg_internal.h"
@@ -528,6 +529,14 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
     for (int c = 0; c < C_CLASSES; c++) first[c + 1] = first[c] + cnt[c];
     { size_t fill[C_CLASSES]; for (int c = 0; c < C_CLASSES; c++) fill[c] = first[c];
       for (size_t k = 0; k < nc; k++) sel[fill[ccls[k]]++] = (uint32_t)k; }
+    // Streams that share a wavefront (2 or 16 lane groups) run in lock step: groups that take different code paths (order 0 /
+    // order 1) are executed one after the other and a short stream waits for a long neighbour.  Neighbours are therefore
+    // made alike: same flags first, then by length.
+    for (int c = 0; c < C_CLASSES; c++)
+        std::stable_sort(sel.begin() + first[c], sel.begin() + first[c + 1], [&](uint32_t a, uint32_t b) {
+            if (cfl[a] != cfl[b]) return cfl[a] < cfl[b];
+            return cd[a].in_len > cd[b].in_len;
+        });
     uint8_t *d_out = nullptr;
     if (nc) {
         if ((rc = ensure_scratch(ctx, 1, ooff + 64)) || (rc = ensure_scratch(ctx, 2, nc * sizeof(hg_stream_desc) + 64)) ||

@@ -15,22 +15,34 @@
 // first lane / are spread one context row per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "htsgpu.h"
 #include "hg_device.h"
 #include "hg_internal.h"
 
 namespace hge {
 
+// LDS traffic of one wavefront is processed in issue order: ordering LDS accesses between its lanes needs no wait, only the
+// compiler kept from moving them (a full fence would also wait for every global store in flight, ~thousands of cycles)
+#define LDS_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// -DHG_ENC_PROFILE: the first group of the first workgroup prints its phase times (s_memtime ticks, 100 MHz) per stream
+#ifdef HG_ENC_PROFILE
+#define HE_T(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tacc[slot] += n_ - tlast; tlast = n_; } while (0)
+#else
+#define HE_T(slot) do { } while (0)
+#endif
+
 constexpr uint32_t RANS_L = 1u << 15;
-constexpr int WAVES = 4;
+constexpr int waves_of(int) { return 2; }     // wavefronts per workgroup (LDS budget of the 32-way variant)
 enum { F_ORDER = 1, F_X32 = 4, F_NOSZ = 16, F_CAT = 32 };
 
 struct GroupLds { uint32_t H[256]; uint16_t C[258]; uint16_t pad[2]; };
 
+// big-endian 7-bit groups, continuation bit on all but the last (no local array: that would live in scratch memory)
 __device__ __forceinline__ int put_u7(uint8_t *cp, uint32_t v) {
-    uint8_t tmp[5]; int n = 0;
-    do { tmp[n++] = v & 0x7f; v >>= 7; } while (v);
-    for (int i = n - 1; i >= 0; i--) *cp++ = tmp[i] | (i ? 0x80 : 0);
+    const int n = v < (1u << 7) ? 1 : v < (1u << 14) ? 2 : v < (1u << 21) ? 3 : v < (1u << 28) ? 4 : 5;
+    for (int k = 0; k < n; k++) cp[k] = (uint8_t)(((v >> (7 * (n - 1 - k))) & 0x7fu) | (k + 1 < n ? 0x80u : 0u));
     return n;
 }
 __device__ __forceinline__ uint32_t round2(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
@@ -80,20 +92,54 @@ __device__ uint8_t *put_alphabet(uint8_t *cp, const Arr &F) {
 //   [65536, 65792)    T[ctx] row totals
 //   [65792, 66048)    A[sym] alphabet flags
 //   [66048, 66048+65792/2...)  C[ctx][sym] cumulative (u16 pairs packed as u32: 256*257 entries)
-constexpr uint32_t O1_F = 0, O1_T = 65536, O1_A = 65792, O1_C = 66048;
+constexpr uint32_t O1_F = 0, O1_C = 66048;
 constexpr uint32_t O1_WORDS = 66048 + (256 * 258) / 2 + 16;
 constexpr uint32_t DENSE_MAX = 64;
 
+__device__ __forceinline__ uint4 ld16(const uint8_t *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }   // any alignment
+
+// fn(c, prev) for every byte c = src[i] with prev = src[i - 1] (0 for i = 0), in no particular order: each lane takes 16
+// contiguous bytes per step (one 16-byte load), the tail goes byte by byte.
+template <int N, typename F>
+__device__ __forceinline__ void for_each_pair(const uint8_t *src, uint32_t n, int sub, F fn) {
+    const uint32_t blk = 16u * N;
+    uint32_t i0 = 0;
+    for (; i0 + blk <= n; i0 += blk) {
+        const uint32_t p = i0 + 16u * (uint32_t)sub;
+        const uint4 v = ld16(src + p);
+        uint32_t prev = p ? src[p - 1] : 0u;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const uint32_t c = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu; fn(c, prev); prev = c; }
+    }
+    for (uint32_t i = i0 + (uint32_t)sub; i < n; i += N) fn((uint32_t)src[i], i ? (uint32_t)src[i - 1] : 0u);
+}
+
 template <int N>
-__global__ __launch_bounds__(WAVES * 64)
+__global__ __launch_bounds__(waves_of(N) * 64)
 void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc,
                             const uint8_t *__restrict__ flags_in, const uint32_t *__restrict__ sel, uint32_t nsel,
                             uint8_t *out, uint32_t *out_len, uint8_t *wbuf, uint32_t *scratch) {
-    constexpr int GROUPS = 64 / N;
+    constexpr int GROUPS = 64 / N, WAVES = waves_of(N);
+    // renormalisation words are collected in an LDS ring and written out a ring at a time: a scattered global store per
+    // step would sit in front of every later source load (one counter orders loads and stores on gfx9)
+    constexpr uint32_t STAGE = N == 32 ? 2048u : 128u;           // 16-bit words per group
+    __shared__ uint16_t wstage[WAVES * GROUPS][STAGE + 2];       // + a spare word for the lanes that emit nothing
+    __shared__ __attribute__((aligned(4))) uint8_t alist[WAVES * GROUPS][260];
+    __shared__ uint32_t rowbuf[WAVES * GROUPS][256];             // the context row being normalised / serialised (order 1)
     __shared__ GroupLds lds[WAVES * GROUPS];
     // 32-way streams (the big data series): order-1 counts, then (start << 16 | freq), for alphabets of <= 64 symbols
     __shared__ uint32_t dpool[N == 32 ? WAVES * GROUPS : 1][N == 32 ? DENSE_MAX * DENSE_MAX : 1];
     __shared__ uint8_t ipool[N == 32 ? WAVES * GROUPS : 1][64];
+    // x / f for the state update without an integer division (no such instruction: ~40 VALU ops on the loop-carried chain):
+    // rcp[f] = ceil(2^(31 + ceil(log2 f)) / f), q = mulhi(x, rcp[f]) >> (ceil(log2 f) - 1), exact for x < 2^31, 2 <= f <= 4096
+    __shared__ uint32_t rcp_tab[4097];
+    for (uint32_t f = threadIdx.x; f <= 4096u; f += WAVES * 64) {
+        uint32_t sh = 0;
+        while (f > (1u << sh)) sh++;
+        rcp_tab[f] = f < 2u ? 0u : (uint32_t)((((unsigned long long)1 << (sh + 31u)) + f - 1u) / f);
+    }
+    __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63, sub = lane & (N - 1), grp = lane / N;
     const uint32_t g_global = (blockIdx.x * WAVES + (tid >> 6)) * GROUPS + grp;
     const uint32_t g_total = gridDim.x * WAVES * GROUPS;
@@ -104,6 +150,9 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
     for (uint32_t k = g_global; __any(k < nsel); k += g_total) {
         const bool have = k < nsel;
         const uint32_t sidx = have ? sel[k] : 0;
+#ifdef HG_ENC_PROFILE
+        unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
         uint32_t n = 0, flags = 0, shift = 12;
         const uint8_t *src = nullptr;
         uint8_t *o = nullptr, *wb = nullptr;
@@ -141,9 +190,24 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
         uint8_t *isym = ipool[N == 32 ? (tid >> 6) * GROUPS + grp : 0];
         if (core && order == 0) {
             // ---- order-0 histogram in LDS --------------------------------------------------------
-            for (int j = sub; j < 256; j += N) G.H[j] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = (uint32_t)sub; i < n; i += N) atomicAdd(&G.H[src[i]], 1u);
+            if (N == 32) {
+                // 16 copies of the 256 counters (the order-1 pool is free here): a few symbols shared by 32 lanes serialise on one
+                for (uint32_t j = (uint32_t)sub; j < 4096u; j += N) D[j] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                uint32_t *Hc = D + ((uint32_t)sub & 15u) * 256u;
+                for_each_pair<N>(src, n, sub, [&](uint32_t c, uint32_t) { atomicAdd(&Hc[c], 1u); });
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                for (uint32_t j = (uint32_t)sub; j < 256u; j += N) {
+                    uint32_t t = 0;
+#pragma unroll
+                    for (uint32_t c = 0; c < 16u; c++) t += D[c * 256u + j];
+                    G.H[j] = t;
+                }
+            } else {
+                for (int j = sub; j < 256; j += N) G.H[j] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                for_each_pair<N>(src, n, sub, [&](uint32_t c, uint32_t) { atomicAdd(&G.H[c], 1u); });
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
             if (sub == 0) {
                 uint32_t tot = round2(n);
@@ -163,12 +227,13 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
             const uint32_t per = n / N;
             for (int j = sub; j < 256; j += N) G.H[j] = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = (uint32_t)sub; i < n; i += N) G.H[src[i]] = 1;
+            for_each_pair<N>(src, n, sub, [&](uint32_t c, uint32_t) { G.H[c] = 1; });
             if (sub == 0) G.H[0] = 1;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
             // dense numbering of the alphabet (G.C[value] = index), only the rows / columns that exist are touched below
             uint32_t nsym = 0;
-            if (sub == 0) { for (int j = 0; j < 256; j++) { G.C[j] = (uint16_t)nsym; if (G.H[j]) { if (N == 32) isym[nsym & 63u] = (uint8_t)j; nsym++; } } }
+            uint8_t *AL = alist[(tid >> 6) * GROUPS + grp];       // the alphabet, ascending
+            if (sub == 0) { for (int j = 0; j < 256; j++) { G.C[j] = (uint16_t)nsym; if (G.H[j]) { if (N == 32) isym[nsym & 63u] = (uint8_t)j; AL[nsym] = (uint8_t)j; nsym++; } } }
             nsym = (uint32_t)__shfl((int)nsym, lane0, 64);
             dense = N == 32 && nsym <= DENSE_MAX;
             nsym_d = nsym;
@@ -176,127 +241,270 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                 if (!G.H[i]) continue;
                 for (uint32_t j = (uint32_t)sub; j < 256; j += N) sc[O1_F + i * 256u + j] = 0;
             }
-            for (uint32_t i = (uint32_t)sub; i < 256; i += N) { sc[O1_T + i] = 0; sc[O1_A + i] = G.H[i]; }
-            if (dense) for (uint32_t i = (uint32_t)sub; i < nsym * nsym; i += N) D[i] = 0;
+            // as many copies of the nsym x nsym counter matrix as the pool holds (a power of two <= 32): lanes that count the
+            // same (context, symbol) pair -- the usual case for quality values -- would serialise on one LDS word
+            uint32_t copies = 1;
+            if (dense) { while (copies < 32u && 2u * copies * nsym * nsym <= DENSE_MAX * DENSE_MAX) copies <<= 1; }
+            if (dense) for (uint32_t i = (uint32_t)sub; i < copies * nsym * nsym; i += N) D[i] = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            HE_T(0);
             if (dense) {
                 // histogram with LDS atomics on the nsym x nsym matrix, then written out in the 256 x 256 layout
-                for (uint32_t i = (uint32_t)sub; i < n; i += N) {
-                    const uint32_t c = src[i], l = i ? src[i - 1] : 0u;
-                    atomicAdd(&D[(uint32_t)G.C[l] * nsym + G.C[c]], 1u);
-                }
-                if (sub >= 1) atomicAdd(&D[(uint32_t)G.C[0] * nsym + G.C[src[(uint32_t)sub * per]]], 1u);   // states start in ctx 0
+                uint32_t *Dc = D + ((uint32_t)sub & (copies - 1u)) * nsym * nsym;
+                for_each_pair<N>(src, n, sub, [&](uint32_t c, uint32_t l) { atomicAdd(&Dc[(uint32_t)G.C[l] * nsym + G.C[c]], 1u); });
+                if (sub >= 1) atomicAdd(&Dc[(uint32_t)G.C[0] * nsym + G.C[src[(uint32_t)sub * per]]], 1u);   // states start in ctx 0
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                if (copies > 1u) {
+                    for (uint32_t i = (uint32_t)sub; i < nsym * nsym; i += N) {
+                        uint32_t t = 0;
+                        for (uint32_t c = 0; c < copies; c++) t += D[c * nsym * nsym + i];
+                        D[i] = t;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                }
                 for (uint32_t a = (uint32_t)sub; a < nsym; a += N) {
                     uint32_t tsum = 0;
                     const uint32_t ia = isym[a];
                     for (uint32_t b = 0; b < nsym; b++) { const uint32_t v = D[a * nsym + b]; sc[O1_F + ia * 256u + isym[b]] = v; tsum += v; }
-                    sc[O1_T + ia] = tsum;
+                    (void)tsum;
                 }
             } else {
-                for (uint32_t i = (uint32_t)sub; i < n; i += N) {
-                    const uint32_t c = src[i], l = i ? src[i - 1] : 0u;
+                for_each_pair<N>(src, n, sub, [&](uint32_t c, uint32_t l) {
                     atomicAdd(&sc[O1_F + l * 256u + c], 1u);
-                    atomicAdd(&sc[O1_T + l], 1u);
+                });
+                if (sub >= 1) atomicAdd(&sc[O1_F + src[(uint32_t)sub * per]], 1u);   // states start in ctx 0
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            HE_T(1);
+            // ---- one context row at a time, all lanes of the group on it: load (coalesced) -> normalise -> serialise -> cumulative.
+            // (One row per LANE, as before round 2, meant 256-step loops of dependent global loads and 64-bit divisions per lane,
+            // and the table was serialised by one lane reading global memory word by word: ~60 of the ~85 M cycles of a 40 kB
+            // stream with a full alphabet.)  The row lives in an LDS buffer; only lane 0's byte emission is serial.
+            constexpr uint32_t SEG = 256u / N;                     // entries of a row per lane
+            uint32_t *RB = rowbuf[(tid >> 6) * GROUPS + grp];
+            uint16_t *C16w = (uint16_t *)(sc + O1_C);
+            uint8_t *cp = o + hdr;                                 // output cursor, the same in every lane of the group
+            const int cnt_alpha = (int)nsym;
+            {
+                uint32_t used = 0;
+                if (sub == 0) { uint8_t *e = cp; *e++ = (uint8_t)(12u << 4); e = put_alphabet(e, G.H); used = (uint32_t)(e - cp); }
+                cp += (uint32_t)__shfl((int)used, lane0, 64);
+            }
+            auto gsum = [&](uint32_t v) { for (int m = 1; m < N; m <<= 1) v += (uint32_t)__shfl_xor((int)v, m, 64); return v; };
+            // (value, index) -> the largest value, the lowest index among equals; every lane of the group gets the result
+            auto gargmax = [&](uint32_t &v, uint32_t &ix) {
+                for (int m = 1; m < N; m <<= 1) {
+                    const uint32_t ov = (uint32_t)__shfl_xor((int)v, m, 64), oi = (uint32_t)__shfl_xor((int)ix, m, 64);
+                    if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
                 }
-                if (sub >= 1) { atomicAdd(&sc[O1_F + src[(uint32_t)sub * per]], 1u); atomicAdd(&sc[O1_T], 1u); }   // states start in ctx 0
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-            // normalise one context row per lane (rows are independent)
-            for (uint32_t i = (uint32_t)sub; i < 256; i += N) {
-                const uint32_t T = sc[O1_T + i];
-                if (!sc[O1_A + i] || !T) continue;
-                uint32_t tot = round2(T);
-                if (tot > 4096u) tot = 4096u;
+            };
+            for (uint32_t i = 0; i < 256u; i++) {
+                if (!G.H[i]) continue;
                 uint32_t *row = sc + O1_F + i * 256u;
-                normalise(row, T, tot);
-                sc[O1_T + i] = tot;                               // remember the stored total
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-            if (sub == 0) {                                       // serialise the table (oracle layout)
-                uint8_t *cp = o + hdr;
-                *cp++ = (uint8_t)(12u << 4);
-                cp = put_alphabet(cp, G.H);
-                int cnt_alpha = 0;
-                for (int j = 0; j < 256; j++) cnt_alpha += G.H[j] != 0;
-                for (int i = 0; i < 256; i++) {
-                    if (!G.H[i]) continue;
-                    if (sc[O1_T + i]) {
-                        // a zero frequency is written as (0, how many MORE zero entries follow): streamed with a pending
-                        // run byte instead of looking ahead, the row fetched four words at a time
-                        const uint4 *row4 = (const uint4 *)(sc + O1_F + (uint32_t)i * 256u);
-                        uint8_t *runbyte = nullptr; uint32_t runcnt = 0;
-                        for (int j4 = 0; j4 < 64; j4++) {
-                            const uint4 q = row4[j4];
-                            const uint32_t v4[4] = {q.x, q.y, q.z, q.w};
+                const uint32_t j0 = (uint32_t)sub * SEG;
+                // load my segment, row total and the first largest count
+                uint32_t lsum = 0, lmax = 0, lidx = 0xffffffffu;
+                {
+                    uint4 v[SEG / 4];
 #pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                if (!G.H[j4 * 4 + k]) continue;
-                                const uint32_t v = v4[k];
-                                if (runbyte) { if (!v) { runcnt++; continue; } *runbyte = (uint8_t)runcnt; runbyte = nullptr; }
-                                cp += put_u7(cp, v);
-                                if (!v) { runbyte = cp++; runcnt = 0; }
-                            }
-                        }
-                        if (runbyte) *runbyte = (uint8_t)runcnt;
-                    } else {
-                        cp += put_u7(cp, 0); *cp++ = (uint8_t)(cnt_alpha - 1);
+                    for (uint32_t q = 0; q < SEG / 4; q++) v[q] = *(const uint4 *)(row + j0 + 4u * q);        // all loads in flight together
+#pragma unroll
+                    for (uint32_t q = 0; q < SEG / 4; q++) {
+                        const uint32_t c4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { RB[j0 + 4u * q + k] = c4[k]; lsum += c4[k]; if (c4[k] > lmax) { lmax = c4[k]; lidx = j0 + 4u * q + k; } }
                     }
                 }
-                tab = (uint32_t)(cp - (o + hdr));
-            }
-            // cumulative tables, shifted up to 2^12, one row per lane (only rows that are contexts)
-            uint16_t *C16 = (uint16_t *)(sc + O1_C);
-            for (uint32_t i = (uint32_t)sub; i < 256; i += N) {
-                if (!G.H[i]) continue;
-                const uint32_t tot = sc[O1_T + i];
-                uint32_t *row = sc + O1_F + i * 256u;
-                int sh = 0;
-                while (tot && (tot << sh) < 4096u) sh++;
-                uint32_t x = 0;
-                for (int j = 0; j < 256; j++) {
-                    const uint32_t f = G.H[j] ? row[j] << sh : 0u;
-                    if (G.H[j]) { row[j] = f; if (dense) D[(uint32_t)G.C[i] * nsym + G.C[j]] = (x << 16) | f; }
-                    C16[i * 258u + j] = (uint16_t)x; x += f;
+                const uint32_t T = gsum(lsum);
+                if (!T) {                                          // a symbol that is never a context
+                    if (sub == 0) { cp[0] = 0; cp[1] = (uint8_t)(cnt_alpha - 1); }
+                    cp += 2;
+                    continue;
                 }
-                C16[i * 258u + 256] = (uint16_t)x;
+                gargmax(lmax, lidx);
+                uint32_t tot = round2(T);
+                if (tot > 4096u) tot = 4096u;
+                // f = max(1, c * tot / T); the quotient via double (exact here: c * tot < 2^44, the fraction is >= 1/T away from
+                // the next integer) and checked against the integer remainder all the same
+                uint32_t fsum = 0;
+                const double scale = (double)tot / (double)T;
+                for (uint32_t q = 0; q < SEG; q++) {
+                    const uint32_t c = RB[j0 + q];
+                    if (!c) continue;
+                    const unsigned long long x = (unsigned long long)c * tot;
+                    uint32_t f = (uint32_t)((double)c * scale);       // <= 4096; off by at most one, corrected below
+                    long long r = (long long)x - (long long)((unsigned long long)f * T);
+                    if (r < 0) { f--; r += T; }
+                    if (r >= (long long)T) f++;
+                    if (!f) f = 1;
+                    RB[j0 + q] = f; fsum += f;
+                }
+                unsigned long long sum = gsum(fsum);
+                LDS_ORDER();
+                if (sum < tot) { if (sub == 0) RB[lidx] += (uint32_t)(tot - sum); }
+                while (sum > tot) {                                // take the excess from the largest entries (> 1), first one wins
+                    uint32_t bv = 0, bi = 0xffffffffu;
+                    for (uint32_t q = 0; q < SEG; q++) { const uint32_t fj = RB[j0 + q]; if (fj > 1u && fj > bv) { bv = fj; bi = j0 + q; } }
+                    gargmax(bv, bi);
+                    if (bi == 0xffffffffu) break;                   // nothing left to take from (cannot happen: sum <= tot then)
+                    uint32_t take = (uint32_t)(sum - tot);
+                    if (take > bv - 1u) take = bv - 1u;
+                    if (sub == 0) RB[bi] = bv - take;
+                    sum -= take;
+                    LDS_ORDER();
+                }
+                LDS_ORDER();
+                {
+                    // Serialise the row over the alphabet: a non-zero frequency as a 7-bit varint (1 or 2 bytes), a zero as
+                    // (0, how many MORE zeros follow) once per run of zeros.  Every lane takes SEG consecutive alphabet entries;
+                    // what an entry emits and where follows from three bit masks (zero / non-zero / two-byte) of the lane's
+                    // entries, the zero flag of the entry before them and the position of the next non-zero entry after them.
+                    const uint32_t ka = (uint32_t)sub * SEG < nsym ? (uint32_t)sub * SEG : nsym;
+                    const uint32_t kb = ka + SEG < nsym ? ka + SEG : nsym;
+                    unsigned long long zm = 0, nzm = 0, big = 0;
+                    for (uint32_t q = 0; ka + q < kb; q++) {
+                        const uint32_t v = RB[AL[ka + q]];
+                        if (v) { nzm |= 1ull << q; if (v >= 128u) big |= 1ull << q; } else zm |= 1ull << q;
+                    }
+                    const uint32_t cnt = kb - ka;
+                    const uint32_t lastz = cnt ? (uint32_t)((zm >> (cnt - 1u)) & 1ull) : 0u;
+                    uint32_t prevz = (uint32_t)__shfl_up((int)lastz, 1, N);
+                    if (sub == 0) prevz = 0;
+                    // first non-zero entry at or after the start of each lane's range -> suffix minimum over the lanes
+                    uint32_t fnz = nzm ? ka + (uint32_t)__builtin_ctzll(nzm) : nsym;
+                    for (int m = 1; m < N; m <<= 1) { const uint32_t t = (uint32_t)__shfl_down((int)fnz, m, N); if (sub + m < N && t < fnz) fnz = t; }
+                    uint32_t after = (uint32_t)__shfl_down((int)fnz, 1, N);        // next non-zero entry beyond my range
+                    if (sub == N - 1) after = nsym;
+                    const unsigned long long first = zm & ~((zm << 1) | (unsigned long long)prevz);   // zeros that open a run
+                    const uint32_t mybytes = 2u * (uint32_t)__popcll(first) + (uint32_t)__popcll(nzm) + (uint32_t)__popcll(big);
+                    uint32_t base = mybytes;
+                    for (int m = 1; m < N; m <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)base, m, N); if (sub >= m) base += t; }
+                    const uint32_t rowbytes = (uint32_t)__shfl((int)base, lane0 + N - 1, 64);
+                    base -= mybytes;
+                    for (unsigned long long w = nzm | first; w; w &= w - 1ull) {
+                        const uint32_t q = (uint32_t)__builtin_ctzll(w);
+                        const unsigned long long below = (1ull << q) - 1ull;
+                        uint8_t *e = cp + base + 2u * (uint32_t)__popcll(first & below) + (uint32_t)__popcll(nzm & below) + (uint32_t)__popcll(big & below);
+                        if ((nzm >> q) & 1ull) {
+                            const uint32_t v = RB[AL[ka + q]];
+                            if (v >= 128u) { e[0] = (uint8_t)(0x80u | (v >> 7)); e[1] = (uint8_t)(v & 0x7fu); } else e[0] = (uint8_t)v;
+                        } else {
+                            const unsigned long long later = q == 63u ? 0ull : nzm >> (q + 1u);
+                            const uint32_t nxt = later ? ka + q + 1u + (uint32_t)__builtin_ctzll(later) : after;
+                            e[0] = 0; e[1] = (uint8_t)(nxt - (ka + q) - 1u);
+                        }
+                    }
+                    cp += rowbytes;
+                }
+                // cumulative frequencies scaled up to 2^12
+                int sh = 0;
+                while ((tot << sh) < 4096u) sh++;
+                uint32_t fl[SEG], mine = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < SEG; q++) { fl[q] = G.H[j0 + q] ? RB[j0 + q] << sh : 0u; mine += fl[q]; }
+                uint32_t x = mine;                                  // inclusive scan over the lanes of the group
+                for (int m = 1; m < N; m <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)x, m, N); if (sub >= m) x += t; }
+                const uint32_t total = (uint32_t)__shfl((int)x, lane0 + N - 1, 64);
+                x -= mine;
+#pragma unroll
+                for (uint32_t q = 0; q < SEG; q++) {
+                    const uint32_t j = j0 + q;
+                    if (G.H[j]) { row[j] = fl[q]; if (dense) D[(uint32_t)G.C[i] * nsym + G.C[j]] = (x << 16) | fl[q]; }
+                    C16w[i * 258u + j] = (uint16_t)x; x += fl[q];
+                }
+                if (sub == N - 1) C16w[i * 258u + 256] = (uint16_t)total;
+                LDS_ORDER();
             }
+            tab = (uint32_t)(cp - (o + hdr));
+            HE_T(3);
         }
         tab = (uint32_t)__shfl((int)tab, lane0, 64);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        HE_T(4);
         // ---- encode backwards ------------------------------------------------------------------
         uint32_t R = RANS_L;
         uint32_t wpos = wcap;                                     // next free byte (from the end) in wb
+        uint32_t whi = wcap;                                      // words in [wpos, whi) are still in the LDS ring
+        uint16_t *WS = wstage[(tid >> 6) * GROUPS + grp];
         const uint16_t *C16 = (const uint16_t *)(sc + O1_C);
-        auto push = [&](bool mine, uint32_t sym, uint32_t ctx) {
-            uint32_t emit = 0;
-            uint32_t f = 1, start = 0;
-            if (mine) {
-                if (order == 0) { start = G.C[sym]; f = (uint32_t)G.C[sym + 1] - start; }
-                else if (dense) { const uint32_t e = D[(uint32_t)G.C[ctx] * nsym_d + G.C[sym]]; start = e >> 16; f = e & 0xffffu; }
+        // prep: everything that depends on the symbols only (table entry, reciprocal) -- issued for a whole chunk of steps
+        // ahead of the state updates; step: the loop-carried part (renormalisation decision, word placement, x -> x').
+        // The table flavour (MODE 0: order 0, 1: order 1 in LDS, 2: order 1 in global memory) and "every lane takes part" (ALL)
+        // are compile-time so that the chunk loops are straight-line code whose loads the compiler can batch.
+        auto prep = [&](auto mode, auto all, bool mine, uint32_t sym, uint32_t ctx, uint32_t &f, uint32_t &start, uint32_t &rc) {
+            constexpr int MODE = decltype(mode)::value;
+            constexpr bool ALL = decltype(all)::value;
+            f = 1; start = 0; rc = 0;
+            if (ALL || mine) {
+                if (MODE == 0) { start = G.C[sym]; f = (uint32_t)G.C[sym + 1] - start; }
+                else if (MODE == 1) { const uint32_t e = D[(uint32_t)G.C[ctx] * nsym_d + G.C[sym]]; start = e >> 16; f = e & 0xffffu; }
                 else { start = C16[ctx * 258u + sym]; f = sc[O1_F + ctx * 256u + sym]; }
-                const uint32_t x_max = ((RANS_L >> shift) << 16) * f;
-                emit = R >= x_max ? 1u : 0u;
+                rc = rcp_tab[f & 0x1fffu];
             }
-            const unsigned long long b = __ballot(emit != 0) & gmask;
+        };
+        auto step = [&](auto all, bool mine, uint32_t f, uint32_t start, uint32_t rc) {
+            constexpr bool ALL = decltype(all)::value;
+            const uint32_t x_max = ((RANS_L >> shift) << 16) * f;
+            const bool emit = (ALL || mine) && R >= x_max;
+            const unsigned long long b = __ballot(emit) & gmask;
             const uint32_t above = (uint32_t)__popcll(b & ~((2ull << lane) - 1ull));   // emitting lanes above me
             const uint32_t tot = (uint32_t)__popcll(b);
-            if (emit) {
-                uint8_t *w = wb + wpos - 2u * (above + 1u);
-                w[0] = (uint8_t)R; w[1] = (uint8_t)(R >> 8);
-                R >>= 16;
-            }
+            // branch-free: lanes that do not emit write to a spare word behind the ring
+            WS[emit ? (((wpos >> 1) - (above + 1u)) & (STAGE - 1u)) : STAGE] = (uint16_t)R;   // wb and wpos are even
+            R = emit ? R >> 16 : R;
             wpos -= 2u * tot;
-            if (mine) R = ((R / f) << shift) + (R % f) + start;
+            const uint32_t q = f < 2u ? R : __umulhi(R, rc) >> (31u - (uint32_t)__builtin_clz(f - 1u));
+            const uint32_t Rn = (q << shift) + (R - q * f) + start;
+            R = (ALL || mine) ? Rn : R;
         };
+        using M0 = std::integral_constant<int, 0>; using M1 = std::integral_constant<int, 1>; using M2 = std::integral_constant<int, 2>;
+        using YES = std::true_type; using NO = std::false_type;
+        // staged words [wpos, whi) -> the word buffer; called when the next `room` steps might not fit in the ring
+        auto flush_words = [&](uint32_t room) {
+            if (((whi - wpos) >> 1) + room * (uint32_t)N <= STAGE) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            uint16_t *w16 = (uint16_t *)wb;
+            for (uint32_t w = (wpos >> 1) + (uint32_t)sub; w < (whi >> 1); w += N) w16[w] = WS[w & (STAGE - 1u)];
+            whi = wpos;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        };
+        auto push = [&](bool mine, uint32_t sym, uint32_t ctx) {
+            uint32_t f, start, rc;
+            flush_words(1);
+            if (order == 0) prep(M0{}, NO{}, mine, sym, ctx, f, start, rc);
+            else if (dense) prep(M1{}, NO{}, mine, sym, ctx, f, start, rc);
+            else prep(M2{}, NO{}, mine, sym, ctx, f, start, rc);
+            step(NO{}, mine, f, start, rc);
+        };
+        constexpr int CH = 8;                                     // order 0: steps whose loads are issued together
+        constexpr int CH1 = 16;                                   // order 1: one 16-byte load per lane and chunk
         if (core && order == 0) {
             const uint32_t rem = n & (uint32_t)(N - 1);
             {   // tail symbols belong to states 0..rem-1
                 const bool mine = (uint32_t)sub < rem;
                 push(mine, mine ? src[n - rem + sub] : 0u, 0u);
             }
-            for (uint32_t i = n & ~(uint32_t)(N - 1); i > 0; i -= N) push(true, src[i - N + sub], 0u);
+            uint32_t i = n & ~(uint32_t)(N - 1);
+            if (i >= (uint32_t)(CH * N)) {
+                uint32_t sy[CH], nx[CH];
+#pragma unroll
+                for (int k = 0; k < CH; k++) sy[k] = src[i - (uint32_t)((k + 1) * N) + sub];
+                for (; i >= (uint32_t)(CH * N); i -= CH * N) {
+                    const bool more = i >= (uint32_t)(2 * CH * N);
+#pragma unroll
+                    for (int k = 0; k < CH; k++) nx[k] = more ? src[i - (uint32_t)((CH + k + 1) * N) + sub] : 0u;   // next chunk, ahead of the stores
+                    flush_words(CH);
+                    uint32_t f[CH], st[CH], rc[CH];
+#pragma unroll
+                    for (int k = 0; k < CH; k++) prep(M0{}, YES{}, true, sy[k], 0u, f[k], st[k], rc[k]);
+#pragma unroll
+                    for (int k = 0; k < CH; k++) step(YES{}, true, f[k], st[k], rc[k]);
+#pragma unroll
+                    for (int k = 0; k < CH; k++) sy[k] = nx[k];
+                }
+            }
+            for (; i > 0; i -= N) push(true, src[i - N + sub], 0u);
         } else if (core) {
             const uint32_t per = n / N;
             // last state first eats the remainder [N*per, n)
@@ -309,7 +517,27 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                 push(mine, l, c);
                 if (mine) { l = c; idx--; }
             }
-            for (uint32_t s = 0; s + 1 < per; s++) {
+            uint32_t s = 0;
+            if (s + 1 + CH1 <= per) {
+                uint4 cur = ld16(src + idx - (CH1 - 1));
+                auto chunks = [&](auto mode) {
+                    for (; s + 1 + CH1 <= per; s += CH1) {
+                        const uint4 nxt = s + 1 + 2 * CH1 <= per ? ld16(src + idx - (2 * CH1 - 1)) : cur;       // next chunk, ahead of the stores
+                        flush_words(CH1);
+                        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+                        uint32_t f[CH1], st[CH1], rc[CH1], cs[CH1];
+#pragma unroll
+                        for (int k = 0; k < CH1; k++) cs[k] = (w[(15 - k) >> 2] >> (((15 - k) & 3) * 8)) & 0xffu;   // cs[k] = src[idx - k]
+#pragma unroll
+                        for (int k = 0; k < CH1; k++) prep(mode, YES{}, true, k ? cs[k - 1] : l, cs[k], f[k], st[k], rc[k]);
+#pragma unroll
+                        for (int k = 0; k < CH1; k++) step(YES{}, true, f[k], st[k], rc[k]);
+                        l = cs[CH1 - 1]; idx -= CH1; cur = nxt;
+                    }
+                };
+                if (dense) chunks(M1{}); else chunks(M2{});
+            }
+            for (; s + 1 < per; s++) {
                 const uint32_t c = src[idx];
                 push(true, l, c);
                 l = c; idx--;
@@ -319,6 +547,8 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
         // non-core groups must still take part in the ballots above?  No: push() is only called by
         // core groups, and __ballot is masked with gmask, so groups proceed independently.
         if (core) {
+            HE_T(5);
+            flush_words(STAGE);                                   // everything still in the ring
             // flush the states: state z ends up at (final ptr) + 4 z
             wpos -= 4u * N;
             uint8_t *w = wb + wpos + 4u * sub;
@@ -326,11 +556,28 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
             const uint32_t body = wcap - wpos;
             uint8_t *dst = o + hdr + tab;
-            for (uint32_t i = (uint32_t)sub; i < body; i += N) dst[i] = wb[wpos + i];
+            {   // word buffer -> output slot, four bytes per lane and step once dst is dword aligned
+                const uint8_t *from = wb + wpos;
+                uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u);
+                if (head > body) head = body;
+                if ((uint32_t)sub < head) dst[sub] = from[sub];
+                const uint32_t nw = (body - head) >> 2;
+                for (uint32_t i = (uint32_t)sub; i < nw; i += N) {
+                    const uint8_t *q = from + head + 4u * i;
+                    *(uint32_t *)(dst + head + 4u * i) = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+                }
+                for (uint32_t i = head + 4u * nw + (uint32_t)sub; i < body; i += N) dst[i] = from[i];
+            }
             if (sub == 0) { o[0] = (uint8_t)flags; out_len[sidx] = hdr + tab + body; }
+            HE_T(6);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+#ifdef HG_ENC_PROFILE
+        if (have && sub == 0 && ((blockIdx.x == 0 && tid == 0) || k + 2 >= nsel))
+            printf("enc<%d> n=%u order=%u dense=%d nsym=%u ticks: setup %llu hist %llu norm %llu serialise %llu cum %llu encode %llu flush+copy %llu\n", N, n,
+                   order, (int)dense, nsym_d, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], tacc[6]);
+#endif
     }
 }
 
@@ -346,16 +593,18 @@ int launch_ransnx16_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *
     const bool side = n4 != 0 && n32 != 0;                  // both variants present: overlap them
     hipStream_t s2 = side ? fork_side(ctx, s) : s;
     if (n4) {
-        size_t wgs = (n4 + hge::WAVES * 16 - 1) / (hge::WAVES * 16);
+        constexpr int W4 = hge::waves_of(4);
+        size_t wgs = (n4 + W4 * 16 - 1) / (W4 * 16);
         if (wgs > maxw) wgs = maxw;
-        hipLaunchKernelGGL(hge::ransnx16_encode_kernel<4>, dim3((unsigned)wgs), dim3(hge::WAVES * 64), 0, s,
+        hipLaunchKernelGGL(hge::ransnx16_encode_kernel<4>, dim3((unsigned)wgs), dim3(W4 * 64), 0, s,
                            (const uint8_t *)d_in, d_desc, d_flags, d_sel4, (uint32_t)n4, (uint8_t *)d_out, d_out_len,
                            (uint8_t *)d_wbuf, d_scratch);
     }
     if (n32) {
-        size_t wgs = (n32 + hge::WAVES * 2 - 1) / (hge::WAVES * 2);
+        constexpr int W32 = hge::waves_of(32);
+        size_t wgs = (n32 + W32 * 2 - 1) / (W32 * 2);
         if (wgs > maxw) wgs = maxw;
-        hipLaunchKernelGGL(hge::ransnx16_encode_kernel<32>, dim3((unsigned)wgs), dim3(hge::WAVES * 64), 0, s2,
+        hipLaunchKernelGGL(hge::ransnx16_encode_kernel<32>, dim3((unsigned)wgs), dim3(W32 * 64), 0, s2,
                            (const uint8_t *)d_in, d_desc, d_flags, d_sel32, (uint32_t)n32, (uint8_t *)d_out, d_out_len,
                            (uint8_t *)d_wbuf, d_scratch);
         if (side) join_side(ctx, s);
