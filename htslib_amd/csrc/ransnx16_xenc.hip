@@ -123,12 +123,19 @@ void nx16_xenc_kernel(uint8_t *buf, const hg::nx16_xenc *__restrict__ jobs, uint
                 if (lane == 0) meta[0] = (uint8_t)nr;
                 uint32_t mp = 1u + nr, lo = 0;
                 bool pend = false; uint32_t pend_pos = 0;
+                // the bytes of the NEXT step are requested before this step's scattered stores: loads issued behind stores
+                // would wait for them (one counter orders both on gfx9)
+                uint8_t cn = (uint32_t)lane < n ? cur[lane] : 0, carry = 0;          // carry = the last byte of the previous step
                 for (uint32_t i0 = 0; i0 < n; i0 += 64) {
                     const uint32_t i = i0 + (uint32_t)lane;
                     const bool has = i < n;
-                    const uint8_t c = has ? cur[i] : 0;
+                    const uint8_t c = cn;
+                    if (i + 64u < n) cn = cur[i + 64u];
+                    const uint8_t up = (uint8_t)__shfl_up((int)c, 1, 64);
+                    const uint8_t pc = lane == 0 ? carry : up;                           // byte i - 1
+                    carry = (uint8_t)__shfl((int)c, 63, 64);
                     const bool isr = has && S.used[c];
-                    const bool st = has && (i == 0 || !isr || cur[i - 1] != c);
+                    const bool st = has && (i == 0 || !isr || pc != c);
                     const unsigned long long St = __ballot(st);
                     if (st) lit[lo + (uint32_t)__popcll(St & below)] = c;
                     lo += (uint32_t)__popcll(St);
