@@ -3,10 +3,12 @@
 
 htscodecs (the reference implementation of the CRAM entropy codecs) is an absent submodule, so the
 expected plaintext cannot come from running the reference.  It is derived INDEPENDENTLY of any
-rANS decoder from the fixture's .sam twin: the QS data series of a CRAM slice is the concatenation
+rANS decoder from the fixture's .sam / .bam twin: the QS data series of a CRAM slice is the concatenation
 of the records' quality values (QUAL - 33), the RN series the read names each followed by the
-BYTE_ARRAY_STOP byte.  Blocks whose content cannot be derived that way are stored with their
-declared raw size only ("size-only" vectors).
+BYTE_ARRAY_STOP byte, BF / RL / AP the ITF8-coded flags, read lengths and positions (absolute, or deltas
+from the slice start when the preservation map says AP is delta-coded), and a one-byte aux tag (type c / C)
+the tag values of the records in order.  Blocks whose content cannot be derived that way are stored with
+their declared raw size only ("size-only" vectors).
 
 Output: tests/golden/rans4x8/<file>.<n>.bin (compressed block payload), MANIFEST.json
 (content id, order, raw size, series name, expected plaintext hex or null).
@@ -18,7 +20,7 @@ REF = "/root/reference/test"
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "rans4x8")
 PAIRS = [("ce#5b_java.cram", "ce#5b.sam"), ("auxf#values_java.cram", "auxf#values.sam"),
-         ("xx#large_aux_java.cram", "xx#large_aux.sam"), ("range.cram", None)]
+         ("xx#large_aux_java.cram", "xx#large_aux.sam"), ("range.cram", "range.bam")]
 
 
 def itf8(b, p):
@@ -37,6 +39,30 @@ def ltf8(b, p):
     val = v & (0xFF >> (n + 1)) if n < 8 else 0
     for i in range(n): val = (val << 8) | b[p + 1 + i]
     return val, p + 1 + n
+
+
+def put_itf8(v):
+    v &= 0xFFFFFFFF
+    if v < 0x80: return bytes([v])
+    if v < 0x4000: return bytes([0x80 | (v >> 8), v & 0xFF])
+    if v < 0x200000: return bytes([0xC0 | (v >> 16), (v >> 8) & 0xFF, v & 0xFF])
+    if v < 0x10000000: return bytes([0xE0 | (v >> 24), (v >> 16) & 0xFF, (v >> 8) & 0xFF, v & 0xFF])
+    return bytes([0xF0 | (v >> 28), (v >> 20) & 0xFF, (v >> 12) & 0xFF, (v >> 4) & 0xFF, v & 0x0F])
+
+
+def parse_preservation(d):
+    """-> {key: first value byte} of the preservation map (RN, AP, RR are one-byte booleans)"""
+    p = 0
+    sz, p = itf8(d, p); end = p + sz
+    n, p = itf8(d, p)
+    out = {}
+    for _ in range(n):
+        key = bytes(d[p:p + 2]).decode(); p += 2
+        if key in ("RN", "AP", "RR"): out[key] = d[p]; p += 1
+        elif key == "SM": p += 5
+        elif key == "TD": ln, p = itf8(d, p); p += ln
+        else: break
+    return out
 
 
 def parse_comp_header(d):
@@ -80,12 +106,53 @@ def containers(b):
         p = end
 
 
+class Rec(tuple):
+    """(name, qual text) + .flag .pos .seqlen .aux ({tag: (type, value)} for one-byte integer tags)"""
+    def __new__(cls, name, qual, flag, pos, seqlen, aux):
+        o = super().__new__(cls, (name, qual))
+        o.flag, o.pos, o.seqlen, o.aux = flag, pos, seqlen, aux
+        return o
+
+
 def sam_records(path):
+    if path.endswith(".bam"):
+        return bam_records(path)
     recs = []
     for ln in open(path):
         if ln.startswith("@"): continue
         f = ln.rstrip("\n").split("\t")
-        recs.append((f[0], f[10]))
+        recs.append(Rec(f[0], f[10], int(f[1]), int(f[3]), 0 if f[9] == "*" else len(f[9]), {}))
+    return recs
+
+
+def bam_records(path):
+    import gzip
+    d = gzip.open(path, "rb").read()                              # BGZF is a multi-member gzip file
+    assert d[:4] == b"BAM\1"
+    p = 8 + struct.unpack_from("<i", d, 4)[0]
+    nref = struct.unpack_from("<i", d, p)[0]; p += 4
+    for _ in range(nref):
+        ln = struct.unpack_from("<i", d, p)[0]; p += 4 + ln + 4
+    recs = []
+    while p < len(d):
+        bs = struct.unpack_from("<i", d, p)[0]; q = p + 4; p = q + bs
+        _, pos, lname, _, _, ncig, flag, lseq = struct.unpack_from("<iiBBHHHi", d, q)
+        name = d[q + 32:q + 32 + lname - 1].decode()
+        a = q + 32 + lname + 4 * ncig + (lseq + 1) // 2
+        qual = d[a:a + lseq]
+        qtxt = "*" if lseq == 0 or qual[0] == 0xFF else bytes(c + 33 for c in qual).decode("latin1")
+        a += lseq
+        aux = {}
+        size = {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}
+        while a < p:
+            tag, ty = d[a:a + 2].decode(), chr(d[a + 2]); a += 3
+            if ty in ("c", "C"): aux[tag] = (ty, d[a])
+            if ty in size: a += size[ty]
+            elif ty in ("Z", "H"): a = d.index(b"\0", a) + 1
+            elif ty == "B":
+                sub = chr(d[a]); cnt = struct.unpack_from("<i", d, a + 1)[0]; a += 5 + cnt * size[sub]
+            else: raise ValueError(ty)
+        recs.append(Rec(name, qtxt, flag, pos + 1, lseq, aux))
     return recs
 
 
@@ -101,6 +168,12 @@ def main():
             if nrec == 0 or not blks: continue
             assert blks[0][1] == 1 and blks[0][0] == 0, "compression header expected raw"
             enc = parse_comp_header(blks[0][5])
+            pres = parse_preservation(blks[0][5])
+            slice_start = None                                     # alignment start of the (single) slice of this container
+            nslices = sum(1 for k in blks if k[1] in (2, 3))
+            for k in blks:
+                if k[1] in (2, 3) and k[0] == 0 and nslices == 1:
+                    _, q = itf8(k[5], 0); slice_start, _ = itf8(k[5], q)
             series_of = {}
             for key, (codec, par) in enc.items():
                 if codec == 1: series_of[itf8(par, 0)[0]] = (key, None)             # EXTERNAL
@@ -114,6 +187,17 @@ def main():
                 if mine is not None:
                     if key == "QS": exp = b"".join(bytes(c - 33 for c in q.encode()) for _, q in mine if q != "*")
                     elif key == "RN" and stop is not None: exp = b"".join(nm.encode() + bytes([stop]) for nm, _ in mine)
+                    elif key == "BF": exp = b"".join(put_itf8(r.flag) for r in mine)
+                    elif key == "RL": exp = b"".join(put_itf8(r.seqlen) for r in mine)
+                    elif key == "AP" and nslices == 1:
+                        if pres.get("AP", 1) == 0: exp = b"".join(put_itf8(r.pos) for r in mine)
+                        elif slice_start is not None:
+                            prev, parts = slice_start, []
+                            for r in mine: parts.append(put_itf8(r.pos - prev)); prev = r.pos
+                            exp = b"".join(parts)
+                    elif key == "??" and cid >= 0x410000:           # aux tag block: content id = tag << 8 | type
+                        tag, ty = bytes([(cid >> 16) & 0xFF, (cid >> 8) & 0xFF]).decode("latin1"), chr(cid & 0xFF)
+                        if ty in ("c", "C") and all(tag in r.aux for r in mine): exp = bytes(r.aux[tag][1] for r in mine)
                     if exp is not None and len(exp) != usz: exp = None
                 name = f"{cram.replace('#', '_')}.{nfile}.bin"; nfile += 1
                 open(os.path.join(OUT, name), "wb").write(data)
