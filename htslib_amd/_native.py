@@ -127,7 +127,8 @@ EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info
            "hg_cram_compress_blocks_metrics_host", "hg_bam_header_host", "hg_bam_frame_dev", "hg_bam_bases_dev", "hg_bam_core_dev", "hg_bam_quals_dev", "hg_bai_build_dev", "hg_idx_build_dev", "hg_csi_levels", "hg_cram_uncompress_blocks_crc_host",
            "hg_pipe_create", "hg_pipe_destroy", "hg_pipe_input", "hg_pipe_inflate", "hg_pipe_deflate", "hg_pipe_wait",
            "hg_gzip_stream_inflate_host", "hg_crc32_host", "hg_crc32_batch_host",
-           "hg_hts_pack", "hg_hts_unpack", "hg_hts_rle_encode", "hg_hts_rle_decode"]
+           "hg_hts_pack", "hg_hts_unpack", "hg_hts_rle_encode", "hg_hts_rle_decode",
+           "hg_cram_itf8_decode_dev", "hg_cram_itf8_encode_dev", "hg_cram_itf8_decode_host", "hg_cram_itf8_encode_host"]
 
 
 class HgError(RuntimeError):

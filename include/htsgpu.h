@@ -424,6 +424,25 @@ uint8_t *hg_hts_rle_encode(hg_ctx *ctx, const uint8_t *data, uint64_t data_len, 
 uint8_t *hg_hts_rle_decode(hg_ctx *ctx, const uint8_t *lit, uint64_t lit_len, const uint8_t *run, uint64_t run_len, const uint8_t *rle_syms,
                            uint32_t rle_nsyms, uint8_t *out, uint64_t *out_len);
 
+/* ---- CRAM integer data series <-> EXTERNAL blocks (first step): a whole block of ITF8 values becomes an
+ * int32 column in one pass and back, instead of cram_decode_slice pulling one value per record out of the block
+ * (cram_external_decode_int, cram/cram_codecs.c:350-368 -> safe_itf8_get, cram/cram_io.c:644-673; encode side
+ * cram_external_encode_int, cram_codecs.c:523-527 -> itf8_put, cram_io.c:277-305). ---- */
+/* d_desc[i]: in_off / in_len = the block's bytes in d_in; out_off = first int32 of its column in d_out, counted in VALUES;
+ * out_len = room there, in values.  d_count[i] = values decoded.  d_status[i] = 0, or -1 when the block ends inside a
+ * value (the reference's *err) or the column has no room.  No sync inside. */
+int hg_cram_itf8_decode_dev(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, size_t n, int32_t *d_out, uint32_t *d_count,
+                            int32_t *d_status, void *stream);
+/* d_desc[i]: in_off / in_len = first value / number of values in d_in; out_off / out_len = where the bytes go in d_out and
+ * the room there (5 bytes per value always suffice).  d_out_len[i] = bytes written; d_status[i] = 0 / -1 (no room). */
+int hg_cram_itf8_encode_dev(hg_ctx *ctx, const int32_t *d_in, const hg_stream_desc *d_desc, size_t n, void *d_out, uint32_t *d_out_len,
+                            int32_t *d_status, void *stream);
+/* Host-buffer forms (one PCIe round trip for the batch); HG_EBLOCK when some status[i] != 0. */
+int hg_cram_itf8_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n, int32_t *const *out, const uint32_t *cap,
+                             uint32_t *count, int32_t *status);
+int hg_cram_itf8_encode_host(hg_ctx *ctx, const int32_t *const *in, const uint32_t *nvals, size_t n, uint8_t *const *out, const uint32_t *cap,
+                             uint32_t *out_len, int32_t *status);
+
 #ifdef __cplusplus
 }
 #endif
