@@ -391,6 +391,64 @@ int engine_read_block(BGZF *fp) {
     }
 }
 
+// ---- large copies out of the pinned plain image.  A caller that reads megabytes per bgzf_read (bgzip -d, bulk loaders) is
+// bounded by ONE thread's memcpy (~20 GB/s) while the pipeline behind it delivers several times that, so copies of
+// COPY_SPLIT_MIN bytes and more are cut into slices for a few helper threads (process-wide, created on first use;
+// HTS_GPU_COPY_THREADS = number of helpers, default 3, 0 = never).  Record-sized reads never get here.
+constexpr size_t COPY_SPLIT_MIN = 2u << 20;
+class CopyPool {
+    struct Job { uint8_t *d; const uint8_t *s; size_t n; };
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, done_cv;
+    std::vector<Job> q;
+    size_t pending = 0;
+    bool stop = false;
+    void worker() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || !q.empty(); });
+            if (stop && q.empty()) return;
+            const Job j = q.back(); q.pop_back();
+            lk.unlock();
+            memcpy(j.d, j.s, j.n);
+            lk.lock();
+            if (--pending == 0) done_cv.notify_all();
+        }
+    }
+public:
+    explicit CopyPool(int n) { for (int i = 0; i < n; i++) th.emplace_back([this] { worker(); }); }
+    ~CopyPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); for (auto &t : th) t.join(); }
+    size_t helpers() const { return th.size(); }
+    // one caller at a time per pool use is enough here: concurrent callers serialise on `big`
+    std::mutex big;
+    void copy(uint8_t *d, const uint8_t *s, size_t n) {
+        std::lock_guard<std::mutex> one(big);
+        const size_t parts = th.size() + 1, each = ((n / parts) + 4095) & ~(size_t)4095;
+        size_t off = each < n ? each : n;                                   // the caller takes the first slice itself
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for (size_t o = off; o < n; o += each) { q.push_back(Job{d + o, s + o, n - o < each ? n - o : each}); pending++; }
+        }
+        cv.notify_all();
+        memcpy(d, s, off);
+        std::unique_lock<std::mutex> lk(m);
+        done_cv.wait(lk, [&] { return pending == 0; });
+    }
+};
+CopyPool *copy_pool() {
+    static CopyPool *pool = [] {
+        const char *v = getenv("HTS_GPU_COPY_THREADS");
+        const int n = v ? atoi(v) : 3;
+        return n > 0 ? new CopyPool(n > 16 ? 16 : n) : nullptr;             // lives until exit (threads are parked on a condition variable)
+    }();
+    return pool;
+}
+inline void copy_out(uint8_t *d, const uint8_t *s, size_t n) {
+    CopyPool *p = n >= COPY_SPLIT_MIN ? copy_pool() : nullptr;
+    if (p) p->copy(d, s, n); else memcpy(d, s, n);
+}
+
 // The current block is used up: "tell never points at the end of a block" (bgzf.c:1282-1285).
 inline void block_consumed(BGZF *fp) {
     Engine *e = E(fp);
@@ -815,7 +873,7 @@ ssize_t bgzf_read(BGZF *fp, void *data, size_t length) {
         }
         size_t n = span_avail(fp, e);
         if (n > want) n = want;
-        memcpy(dst, (const uint8_t *)fp->uncompressed_block + fp->block_offset, n);
+        copy_out(dst, (const uint8_t *)fp->uncompressed_block + fp->block_offset, n);
         span_advance(fp, e, n);
         dst += n; want -= n;
     }
