@@ -43,29 +43,35 @@ struct ByteWindow {
 
 // Layout of a stream's model memory (32-bit words): nl literal models of m entries, their nl totals, then
 // (RLE) 258 run models of 4 entries and their 258 totals.
+// The totals are addressed through their own pointer TT: when the models live in global scratch (order-1 alphabets too big for the
+// pool) the totals move into the otherwise idle LDS pool -- one global round trip less on every symbol's dependency chain.
 struct Models {
-    uint32_t *M; uint32_t m, nl;
+    uint32_t *M; uint32_t *TT; uint32_t m, nl; bool split;
     __device__ uint32_t lit(uint32_t k) const { return k * m; }
-    __device__ uint32_t lit_tot(uint32_t k) const { return nl * m + k; }
+    __device__ uint32_t lit_tot(uint32_t k) const { return split ? k : nl * m + k; }
     __device__ uint32_t run(uint32_t k) const { return nl * (m + 1) + k * 4; }
-    __device__ uint32_t run_tot(uint32_t k) const { return nl * (m + 1) + 258 * 4 + k; }
+    __device__ uint32_t run_tot(uint32_t k) const { return split ? nl + k : nl * (m + 1) + 258 * 4 + k; }
+    __device__ void place(uint32_t *pool, uint32_t poolw, uint32_t *global, uint32_t words) {
+        if (words <= poolw) { M = pool; TT = pool; split = false; } else { M = global; TT = pool; split = true; }
+    }
 };
 __host__ __device__ inline uint32_t model_words(uint32_t m, uint32_t order, uint32_t rle) { return (order ? m : 1u) * (m + 1u) + (rle ? 258u * 5u : 0u); }
 
 __device__ void models_init(const Models &Q, bool rle, int lane) {
     for (uint32_t i = (uint32_t)lane; i < Q.nl * Q.m; i += 64) Q.M[i] = (1u << 8) | (i % Q.m);
-    for (uint32_t i = (uint32_t)lane; i < Q.nl; i += 64) Q.M[Q.nl * Q.m + i] = Q.m;
+    for (uint32_t i = (uint32_t)lane; i < Q.nl; i += 64) Q.TT[Q.lit_tot(i)] = Q.m;
     if (rle) {
         for (uint32_t i = (uint32_t)lane; i < 258 * 4; i += 64) Q.M[Q.run(0) + i] = (1u << 8) | (i & 3u);
-        for (uint32_t i = (uint32_t)lane; i < 258; i += 64) Q.M[Q.run_tot(0) + i] = 4u;
+        for (uint32_t i = (uint32_t)lane; i < 258; i += 64) Q.TT[Q.run_tot(i)] = 4u;
     }
     wave_sync();
 }
 
 // After the coder step: bump entry x of the model at B (n entries, total at T), halve when due, keep sorted.
 // f_x / f_prev are the frequencies of entries x and x-1 as read before the bump.
-__device__ __forceinline__ void model_update(uint32_t *M, uint32_t B, uint32_t n, uint32_t T, uint32_t tot, uint32_t x,
-                                             uint32_t e_x, int lane) {
+// e_prev = entry x - 1 as the symbol search saw it (HAVE_PREV) -- it came in the same 64-entry read, so the update needs no load.
+__device__ __forceinline__ void model_update(uint32_t *M, uint32_t *TT, uint32_t B, uint32_t n, uint32_t T, uint32_t tot, uint32_t x,
+                                             uint32_t e_x, bool have_prev, uint32_t e_prev, int lane) {
     uint32_t ex = e_x + (STEP << 8);
     tot += STEP;
     if (tot > MAX_FREQ) {                                            // halve every frequency (rare)
@@ -81,13 +87,14 @@ __device__ __forceinline__ void model_update(uint32_t *M, uint32_t B, uint32_t n
         tot = sum;
         wave_sync();
         ex = M[B + x];
+        have_prev = false;
     }
     if (x > 0) {
-        const uint32_t ep = M[B + x - 1];
+        const uint32_t ep = have_prev ? e_prev : M[B + x - 1];
         if ((ex >> 8) > (ep >> 8)) { if (lane == 0) { M[B + x] = ep; M[B + x - 1] = ex; } }
         else if (lane == 0) M[B + x] = ex;
     } else if (lane == 0) M[B + x] = ex;
-    if (lane == 0) M[T] = tot;
+    if (lane == 0) TT[T] = tot;
     wave_sync();
 }
 
@@ -98,19 +105,22 @@ struct Decoder {
         for (int i = 0; i < 5; i++) code = (code << 8) | in.next(lane);
     }
     // decodes one symbol with the model at B (n entries, total at T)
-    __device__ uint32_t symbol(uint32_t *M, uint32_t B, uint32_t n, uint32_t T, int lane) {
-        const uint32_t tot = M[T];
+    __device__ uint32_t symbol(uint32_t *M, uint32_t *TT, uint32_t B, uint32_t n, uint32_t T, int lane) {
+        uint32_t e = (uint32_t)lane < n ? M[B + (uint32_t)lane] : 0u;     // the first 64 entries travel together with the total
+        const uint32_t tot = TT[T];
         const uint32_t r = range / tot, freq = code / r;
         if (freq >= tot) { err = 1; return 0; }
-        uint32_t acc0 = 0, x = 0, ex = 0, acc = 0;
+        uint32_t acc0 = 0, x = 0, ex = 0, acc = 0, eprev = 0;
+        bool have_prev = false;
         for (uint32_t b = 0; b < n; b += 64) {
             const uint32_t i = b + (uint32_t)lane;
-            const uint32_t e = i < n ? M[B + i] : 0u;
+            if (b) e = i < n ? M[B + i] : 0u;
             const uint32_t incl = acc0 + wave_incl_scan_dpp(e >> 8);
             const unsigned long long hit = __ballot(i < n && incl > freq);
             if (hit) {
                 const uint32_t l = (uint32_t)__builtin_ctzll(hit);
                 x = b + l; ex = rl(e, l); acc = rl(incl, l) - (ex >> 8);
+                if (l) { have_prev = true; eprev = rl(e, l - 1u); }
                 break;
             }
             acc0 = rl(incl, 63);
@@ -118,7 +128,7 @@ struct Decoder {
         const uint32_t f = ex >> 8;
         code -= acc * r; range = r * f;
         while (range < TOP) { code = (code << 8) | in.next(lane); range <<= 8; }
-        model_update(M, B, n, T, tot, x, ex, lane);
+        model_update(M, TT, B, n, T, tot, x, ex, have_prev, eprev, lane);
         return ex & 0xffu;
     }
 };
@@ -141,7 +151,7 @@ void arith_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
         if (!err && n) {
             Models Q;
             Q.m = cp[0] ? cp[0] : 256u; Q.nl = order ? Q.m : 1u;
-            Q.M = model_words(Q.m, order, rle) <= (uint32_t)POOLW ? pool[wv] : gscratch + d.scratch_off;
+            Q.place(pool[wv], (uint32_t)POOLW, gscratch + d.scratch_off, model_words(Q.m, order, rle));
             models_init(Q, rle != 0, lane);
             Decoder D;
             D.start(cp + 1, d.in_len - 1, lane);
@@ -149,7 +159,7 @@ void arith_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
             if (!rle) {
                 for (uint32_t i = 0; i < n; i++) {
                     const uint32_t ctx = order ? last : 0u;
-                    const uint32_t c = D.symbol(Q.M, Q.lit(ctx), Q.m, Q.lit_tot(ctx), lane);
+                    const uint32_t c = D.symbol(Q.M, Q.TT, Q.lit(ctx), Q.m, Q.lit_tot(ctx), lane);
                     if (D.err) break;
                     last = c;
                     if ((uint32_t)lane == (i & 63u)) keep = c;
@@ -159,12 +169,12 @@ void arith_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
             } else {
                 for (uint32_t i = 0; i < n;) {
                     const uint32_t ctx = order ? last : 0u;
-                    const uint32_t c = D.symbol(Q.M, Q.lit(ctx), Q.m, Q.lit_tot(ctx), lane);
+                    const uint32_t c = D.symbol(Q.M, Q.TT, Q.lit(ctx), Q.m, Q.lit_tot(ctx), lane);
                     if (D.err) break;
                     last = c;
                     unsigned long long r = 0; uint32_t rctx = c, part;
                     do {
-                        part = D.symbol(Q.M, Q.run(rctx), 4, Q.run_tot(rctx), lane);
+                        part = D.symbol(Q.M, Q.TT, Q.run(rctx), 4, Q.run_tot(rctx), lane);
                         if (D.err) break;
                         rctx = rctx == c ? 256u : 257u;
                         r += part;
@@ -245,23 +255,26 @@ struct Encoder {
         return opos + oidx;
     }
     // codes `sym` with the model at B (n entries, total at T)
-    __device__ void symbol(uint32_t *M, uint32_t B, uint32_t n, uint32_t T, uint32_t sym, int lane) {
-        const uint32_t tot = M[T];
-        uint32_t acc0 = 0, x = 0, ex = 0, acc = 0;
+    __device__ void symbol(uint32_t *M, uint32_t *TT, uint32_t B, uint32_t n, uint32_t T, uint32_t sym, int lane) {
+        uint32_t e = (uint32_t)lane < n ? M[B + (uint32_t)lane] : 0u;     // the first 64 entries travel together with the total
+        const uint32_t tot = TT[T];
+        uint32_t acc0 = 0, x = 0, ex = 0, acc = 0, eprev = 0;
+        bool have_prev = false;
         for (uint32_t b = 0; b < n; b += 64) {
             const uint32_t i = b + (uint32_t)lane;
-            const uint32_t e = i < n ? M[B + i] : 0u;
+            if (b) e = i < n ? M[B + i] : 0u;
             const uint32_t incl = acc0 + wave_incl_scan_dpp(e >> 8);
             const unsigned long long hit = __ballot(i < n && (e & 0xffu) == sym);
             if (hit) {
                 const uint32_t l = (uint32_t)__builtin_ctzll(hit);
                 x = b + l; ex = rl(e, l); acc = rl(incl, l) - (ex >> 8);
+                if (l) { have_prev = true; eprev = rl(e, l - 1u); }
                 break;
             }
             acc0 = rl(incl, 63);
         }
         encode(acc, ex >> 8, tot, lane);
-        model_update(M, B, n, T, tot, x, ex, lane);
+        model_update(M, TT, B, n, T, tot, x, ex, have_prev, eprev, lane);
     }
 };
 
@@ -285,7 +298,7 @@ void arith_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
             for (int s = 32; s; s >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)mx, s, 64); mx = t > mx ? t : mx; }
             Models Q;
             Q.m = mx + 1u; Q.nl = order ? Q.m : 1u;
-            Q.M = model_words(Q.m, order, rle) <= (uint32_t)POOLW ? pool[wv] : gscratch + d.scratch_off;
+            Q.place(pool[wv], (uint32_t)POOLW, gscratch + d.scratch_off, model_words(Q.m, order, rle));
             models_init(Q, rle != 0, lane);
             o[0] = (uint8_t)Q.m;                                     // every lane, same byte (256 -> 0)
             Encoder E;
@@ -296,13 +309,13 @@ void arith_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
                 for (uint32_t i = 0; i < n; i++) {
                     if ((i & 63u) == 0) { const uint32_t p = i + (uint32_t)lane; win = p < n ? src[p] : 0u; }
                     const uint32_t c = rl(win, i & 63u), ctx = order ? last : 0u;
-                    E.symbol(Q.M, Q.lit(ctx), Q.m, Q.lit_tot(ctx), c, lane);
+                    E.symbol(Q.M, Q.TT, Q.lit(ctx), Q.m, Q.lit_tot(ctx), c, lane);
                     last = c;
                 }
             } else {
                 for (uint32_t i = 0; i < n;) {
                     const uint32_t c = src[i], ctx = order ? last : 0u;
-                    E.symbol(Q.M, Q.lit(ctx), Q.m, Q.lit_tot(ctx), c, lane);
+                    E.symbol(Q.M, Q.TT, Q.lit(ctx), Q.m, Q.lit_tot(ctx), c, lane);
                     last = c;
                     uint32_t r = 0;                                  // how many more copies of c follow
                     for (;;) {
@@ -315,7 +328,7 @@ void arith_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
                     uint32_t rctx = c, part;
                     do {
                         part = r < 3u ? r : 3u;
-                        E.symbol(Q.M, Q.run(rctx), 4, Q.run_tot(rctx), part, lane);
+                        E.symbol(Q.M, Q.TT, Q.run(rctx), 4, Q.run_tot(rctx), part, lane);
                         rctx = rctx == c ? 256u : 257u;
                         r -= part;
                     } while (part == 3u);
