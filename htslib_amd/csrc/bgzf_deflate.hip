@@ -52,7 +52,10 @@ constexpr int WG = 256;
 constexpr int HB = HG_DEF_HB;                 // hash buckets = 2^HB
 constexpr int MAX_WAYS = 12;                   // most recent positions kept per bucket (the level picks 4, 8 or 12 of them)
 constexpr uint32_t MAX_IN = 0xff00u;           // BGZF_BLOCK_SIZE (htslib/bgzf.h:50)
-constexpr uint32_t LOCKSTEP = 32u;            // bytes over which all candidates are extended together
+#ifndef HG_LS8
+#define HG_LS8 1
+#endif
+constexpr uint32_t LOCKSTEP = HG_LS8 ? 36u : 32u;   // bytes proven in lock step (4 + 4 steps of 8, or 8 steps of 4)            // bytes over which all candidates are extended together
 constexpr uint32_t TOO_FAR = 4096u;            // a 3-byte match this far away costs more than 3 literals
 
 struct Huff {                                  // overlays the hash table once matching is done
@@ -95,6 +98,11 @@ static_assert(sizeof(Lds) <= 80 * 1024, "two workgroups per CU");
 __device__ __forceinline__ uint32_t load4(const uint32_t *in32, uint32_t off) {
     uint32_t lo = in32[off >> 2], hi = in32[(off >> 2) + 1];
     return __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
+}
+__device__ __forceinline__ unsigned long long load8(const uint32_t *in32, uint32_t off) {
+    const uint32_t w0 = in32[off >> 2], w1 = in32[(off >> 2) + 1], w2 = in32[(off >> 2) + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, off & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, off & 3u);
+    return ((unsigned long long)hi << 32) | lo;
 }
 __device__ __forceinline__ uint32_t hash4(uint32_t v) { return (v * 2654435761u) >> (32 - HB); }
 
@@ -310,6 +318,47 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                         }
                         // lockstep phase: all candidates of the group together, up to LOCKSTEP bytes
                         uint32_t off = 4;
+#if HG_LS8
+                        // sixteen bytes per step where the registers allow it (<= 8 ways), else eight: the steps are dependent LDS round
+                        // trips, so fewer and wider ones win (4 -> 8 bytes: +21 % at level 6; 16 bytes: +4 % more at levels 1-5, spills at 12 ways)
+                        if constexpr (WAYS <= 8) {
+                        while (alive != 0u && off < maxl && off < LOCKSTEP) {
+                            const unsigned long long own0 = load8(S.in32, p + off), own1 = load8(S.in32, p + off + 8u);
+                            unsigned long long nx0[G], nx1[G];
+#pragma unroll
+                            for (int w = 0; w < G; w++) {
+                                const uint32_t a = ((alive >> w) & 1u) ? cand[w] + off : 0u;
+                                nx0[w] = load8(S.in32, a); nx1[w] = load8(S.in32, a + 8u);
+                            }
+#pragma unroll
+                            for (int w = 0; w < G; w++) {
+                                if ((alive >> w) & 1u) {
+                                    const unsigned long long x0 = nx0[w] ^ own0, x1 = nx1[w] ^ own1;
+                                    if (x0) { len[w] = off + ((uint32_t)__builtin_ctzll(x0) >> 3); alive &= ~(1u << w); }
+                                    else if (x1) { len[w] = off + 8u + ((uint32_t)__builtin_ctzll(x1) >> 3); alive &= ~(1u << w); }
+                                    else len[w] = off + 16;
+                                }
+                            }
+                            off += 16;
+                        }
+                        } else {
+                        while (alive != 0u && off < maxl && off < LOCKSTEP) {
+                            const unsigned long long own = load8(S.in32, p + off);
+                            unsigned long long nxt[G];
+#pragma unroll
+                            for (int w = 0; w < G; w++) nxt[w] = load8(S.in32, ((alive >> w) & 1u) ? cand[w] + off : 0u);
+#pragma unroll
+                            for (int w = 0; w < G; w++) {
+                                if ((alive >> w) & 1u) {
+                                    const unsigned long long x = nxt[w] ^ own;
+                                    if (x) { len[w] = off + ((uint32_t)__builtin_ctzll(x) >> 3); alive &= ~(1u << w); }
+                                    else len[w] = off + 8;
+                                }
+                            }
+                            off += 8;
+                        }
+                        }
+#else
                         while (alive != 0u && off < maxl && off < LOCKSTEP) {
                             const uint32_t own = load4(S.in32, p + off);
                             uint32_t nxt[G];
@@ -325,6 +374,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                             }
                             off += 4;
                         }
+#endif
                         // long-match phase: only the nearest candidate that is still going is extended
                         // (8 bytes per step); the others keep the LOCKSTEP bytes they have proven.
                         if (alive != 0u && off < maxl) {
