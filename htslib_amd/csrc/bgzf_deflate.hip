@@ -55,7 +55,10 @@ constexpr uint32_t MAX_IN = 0xff00u;           // BGZF_BLOCK_SIZE (htslib/bgzf.h
 #ifndef HG_LS8
 #define HG_LS8 1
 #endif
-constexpr uint32_t LOCKSTEP = HG_LS8 ? 36u : 32u;   // bytes proven in lock step (4 + 4 steps of 8, or 8 steps of 4)            // bytes over which all candidates are extended together
+#ifndef HG_MERGE1
+#define HG_MERGE1 1
+#endif
+constexpr uint32_t LOCKSTEP = HG_LS8 ? (HG_MERGE1 ? 32u : 36u) : 32u;   // bytes proven in lock step (4 + 4 steps of 8, or 8 steps of 4)            // bytes over which all candidates are extended together
 constexpr uint32_t TOO_FAR = 4096u;            // a 3-byte match this far away costs more than 3 literals
 
 struct Huff {                                  // overlays the hash table once matching is done
@@ -76,7 +79,7 @@ struct Huff {                                  // overlays the hash table once m
 };
 
 struct Lds {
-    uint32_t in32[(MAX_IN + 16) / 4];
+    uint32_t in32[(MAX_IN + 48) / 4];          // + zero padding: the wide compares read up to 19 bytes past the last position
     union {
         uint16_t tab[(1 << HB) * MAX_WAYS];
         Huff h;
@@ -249,7 +252,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
 #endif
         HD_T0(tp); HD_T0(tb);
         // ---- stage the block in LDS (coalesced 16-byte loads) ----------------------------
-        for (uint32_t i = (uint32_t)tid * 16u; i < n + 16u; i += WG * 16u) {
+        for (uint32_t i = (uint32_t)tid * 16u; i < n + 32u; i += WG * 16u) {
             uint4 w = {0, 0, 0, 0};
             if (i + 16u <= n) __builtin_memcpy(&w, src + i, 16);
             else if (i < n) {
@@ -307,6 +310,13 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                         }
                         cand[GW] = p >= 1u ? p - 1u : 0u;
                         if (g == 0 && p >= 1u) alive |= 1u << GW;
+#if HG_LS8 && HG_MERGE1
+                        // no separate look at the first four bytes: on BAM data most bucket entries are real repeats and survive
+                        // it, so it was one more dependent round for nothing
+#pragma unroll
+                        for (int w = 0; w < G; w++) len[w] = 0;
+                        uint32_t off = 0;
+#else
 #pragma unroll
                         for (int w = 0; w < G; w++) {
                             const uint32_t x = load4(S.in32, cand[w]) ^ cur;
@@ -318,6 +328,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                         }
                         // lockstep phase: all candidates of the group together, up to LOCKSTEP bytes
                         uint32_t off = 4;
+#endif
 #if HG_LS8
                         // sixteen bytes per step where the registers allow it (<= 8 ways), else eight: the steps are dependent LDS round
                         // trips, so fewer and wider ones win (4 -> 8 bytes: +21 % at level 6; 16 bytes: +4 % more at levels 1-5, spills at 12 ways)
@@ -386,12 +397,12 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
 #pragma unroll
                             for (int w = 0; w < G; w++) c = bw == (uint32_t)w ? cand[w] : c;
                             uint32_t l = off;
-                            while (l < maxl) {
-                                const uint32_t x0 = load4(S.in32, c + l) ^ load4(S.in32, p + l);
-                                const uint32_t x1 = load4(S.in32, c + l + 4) ^ load4(S.in32, p + l + 4);
-                                if (x0) { l += (uint32_t)__builtin_ctz(x0) >> 3; break; }
-                                if (x1) { l += 4u + ((uint32_t)__builtin_ctz(x1) >> 3); break; }
-                                l += 8;
+                            while (l < maxl) {                             // 16 bytes per (dependent) round
+                                const unsigned long long x0 = load8(S.in32, c + l) ^ load8(S.in32, p + l);
+                                const unsigned long long x1 = load8(S.in32, c + l + 8) ^ load8(S.in32, p + l + 8);
+                                if (x0) { l += (uint32_t)__builtin_ctzll(x0) >> 3; break; }
+                                if (x1) { l += 8u + ((uint32_t)__builtin_ctzll(x1) >> 3); break; }
+                                l += 16;
                             }
 #pragma unroll
                             for (int w = 0; w < G; w++) len[w] = bw == (uint32_t)w ? l : len[w];
