@@ -58,7 +58,13 @@ constexpr uint32_t MAX_IN = 0xff00u;           // BGZF_BLOCK_SIZE (htslib/bgzf.h
 #ifndef HG_MERGE1
 #define HG_MERGE1 1
 #endif
-constexpr uint32_t LOCKSTEP = HG_LS8 ? (HG_MERGE1 ? 32u : 36u) : 32u;   // bytes proven in lock step (4 + 4 steps of 8, or 8 steps of 4)            // bytes over which all candidates are extended together
+#ifndef HG_LS_G0
+#define HG_LS_G0 32
+#endif
+#ifndef HG_LS_G1
+#define HG_LS_G1 24      // lock-step bytes of the second group (12 ways): 24 costs 0.02 % of size and gives 3.5 % of speed (r02 sweep)
+#endif
+constexpr uint32_t LOCKSTEP = HG_LS8 ? (HG_MERGE1 ? (uint32_t)HG_LS_G0 : 36u) : 32u;   // bytes proven in lock step (4 + 4 steps of 8, or 8 steps of 4)            // bytes over which all candidates are extended together
 constexpr uint32_t TOO_FAR = 4096u;            // a 3-byte match this far away costs more than 3 literals
 
 struct Huff {                                  // overlays the hash table once matching is done
@@ -353,7 +359,8 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                             off += 16;
                         }
                         } else {
-                        while (alive != 0u && off < maxl && off < LOCKSTEP) {
+                        const uint32_t lsg = g == 0 ? LOCKSTEP : (uint32_t)HG_LS_G1;     // the second group holds the older positions
+                        while (alive != 0u && off < maxl && off < lsg) {
                             const unsigned long long own = load8(S.in32, p + off);
                             unsigned long long nxt[G];
 #pragma unroll
