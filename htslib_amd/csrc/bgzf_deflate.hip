@@ -40,9 +40,18 @@ namespace hgd {
 __device__ unsigned long long g_dprof[16];   // 0 total, 1 stage+crc, 2 match+parse, 3 huffman, 4 emit, 5 blocks
 #define HD_T0(var) unsigned long long var = __builtin_amdgcn_s_memtime()
 #define HD_TACC(slot, var) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); dacc[slot] += n_ - var; var = n_; } while (0)
+#ifdef HG_PROFILE_HUFF   /* slots 6..9 = sub-phases of the Huffman construction instead of the match detail */
+#define HD_TACCM(slot, var) do { } while (0)
+#define HD_TACCH(slot, var) HD_TACC(slot, var)
+#else
+#define HD_TACCM(slot, var) HD_TACC(slot, var)
+#define HD_TACCH(slot, var) do { } while (0)
+#endif
 #else
 #define HD_T0(var) do { } while (0)
 #define HD_TACC(slot, var) do { } while (0)
+#define HD_TACCM(slot, var) do { } while (0)
+#define HD_TACCH(slot, var) do { } while (0)
 #endif
 
 #ifndef HG_DEF_HB
@@ -425,9 +434,9 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 }
                 S.mlen[tid] = (uint16_t)best;
                 S.mdist[tid] = (uint16_t)bd;
-                HD_TACC(6, tq);
+                HD_TACCM(6, tq);
                 __syncthreads();
-                HD_TACC(7, tq);
+                HD_TACCM(7, tq);
                 // Publish this chunk's positions.  The slot a position gets inside its bucket comes from an atomic
                 // counter, so the four waves insert one after the other (a wave's own LDS atomics resolve in lane
                 // order): the table -- and with it the compressed bytes -- is the same on every run.
@@ -470,7 +479,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 } else if (tid == 0) {
                     S.carry_next = carry - WG;
                 }
-                HD_TACC(8, tq);
+                HD_TACCM(8, tq);
                 // ---- compact the chosen tokens, in order -----------------------------------
                 const unsigned long long bal = __ballot(marked);
                 if (lane == 0) S.wsum[wave] = (uint32_t)__popcll(bal);
@@ -497,7 +506,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 __syncthreads();
                 if (wave == 3) publish();
                 __syncthreads();
-                HD_TACC(9, tq);
+                HD_TACCM(9, tq);
             }
         }
         // ---- choose the block type and build the codes -------------------------------------
@@ -522,23 +531,31 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 if (f) { const int r = hgdef::rank_symbol(S.dfreq, 30, i); H.order2[r] = (uint16_t)i; H.work2[r] = f; atomicAdd(&S.misc[4], 1u); }
             }
             __syncthreads();
+            HD_T0(th);
+            HD_TACCH(6, th);
             // serial tails of the two trees on two different waves
             if (tid == 0) { hgdef::finish_lengths((int)S.misc[3], 15, H.ll_len, H.order, H.work, H.cntA); hgdef::first_codes(H.ll_len, 286, H.cntA, H.nxtA); }
             if (tid == 64) { hgdef::finish_lengths((int)S.misc[4], 15, H.d_len, H.order2, H.work2, H.cntB); hgdef::first_codes(H.d_len, 30, H.cntB, H.nxtB); }
             __syncthreads();
+            HD_TACCH(7, th);
             for (int i = tid; i < 286; i += WG) H.ll_code[i] = hgdef::code_of(H.ll_len, i, H.nxtA);
             if (tid >= 64 && tid < 94) H.d_code[tid - 64] = hgdef::code_of(H.d_len, tid - 64, H.nxtB);
             if (tid == 0) {
                 uint32_t hb = hgdef::write_dynamic_header(H.ll_len, H.d_len, H.hdr, H.cl_sym, H.cl_ext, H.work, H.order);
                 if (mode == 1 && !last_chunk) H.hdr[0] &= 0xfe;                 // BFINAL = 0
-                uint32_t bits = hb;
-                for (int s = 0; s < 286; s++) {
+                S.misc[1] = hb; S.misc[2] = hb;
+            }
+            __syncthreads();
+            HD_TACCH(8, th);
+            {   // size of the dynamic block: one symbol per thread, summed with an LDS atomic
+                uint32_t part = 0;
+                for (int s = tid; s < 286; s += WG) {
                     uint32_t xb = 0;
                     if (s > 264 && s < 285) xb = (uint32_t)(s - 261) >> 2;
-                    bits += S.lfreq[s] * (H.ll_len[s] + xb);
+                    part += S.lfreq[s] * (H.ll_len[s] + xb);
                 }
-                for (int s = 0; s < 30; s++) bits += S.dfreq[s] * (H.d_len[s] + (s < 4 ? 0u : (uint32_t)(s - 2) >> 1));
-                S.misc[1] = hb; S.misc[2] = bits;
+                if (tid < 30) part += S.dfreq[tid] * (H.d_len[tid] + (tid < 4 ? 0u : (uint32_t)(tid - 2) >> 1));
+                if (part) atomicAdd(&S.misc[2], part);
             }
             __syncthreads();
             hdr_bits = S.misc[1]; dyn_bits = S.misc[2];

@@ -13,8 +13,15 @@
 
 #if defined(__HIPCC__)
 #define HG_HD __host__ __device__ __forceinline__
-// serial tails: real calls on the device, so that they do not bloat the kernel's register budget
+// serial tails: real calls on the device, so that they do not bloat the kernel's register budget (-DHG_SERIAL_INLINE=1 inlines them)
+#ifndef HG_SERIAL_INLINE
+#define HG_SERIAL_INLINE 0
+#endif
+#if HG_SERIAL_INLINE
+#define HG_HD_SERIAL __host__ __device__ __forceinline__
+#else
 #define HG_HD_SERIAL __host__ __device__ __attribute__((noinline))
+#endif
 #else
 #define HG_HD inline
 #define HG_HD_SERIAL inline
@@ -142,16 +149,18 @@ HG_HD void assign_codes(const uint8_t *len, int n, uint16_t *code) {
 }
 
 // LSB-first bit writer into a byte buffer (used for the <= ~200 byte block header only)
+// (bits are collected in a register and leave a byte at a time: a read-modify-write of the buffer per BIT was ~40 % of the
+// single-lane Huffman tail on the device)
 struct BitSink {
     uint8_t *p; uint32_t nbits;
-    HG_HD void put(uint32_t v, uint32_t n) {
-        for (uint32_t i = 0; i < n; i++) {
-            uint32_t bit = nbits + i;
-            if ((bit & 7u) == 0) p[bit >> 3] = 0;
-            p[bit >> 3] = (uint8_t)(p[bit >> 3] | (((v >> i) & 1u) << (bit & 7u)));
-        }
-        nbits += n;
+    unsigned long long acc = 0; uint32_t have = 0;
+    HG_HD void put(uint32_t v, uint32_t n) {                     // n <= 16
+        acc |= (unsigned long long)(v & ((1u << n) - 1u)) << have;
+        have += n; nbits += n;
+        while (have >= 8) { p[(nbits - have) >> 3] = (uint8_t)acc; acc >>= 8; have -= 8; }
     }
+    HG_HD void finish() { if (have) p[(nbits - have) >> 3] = (uint8_t)acc; }   // the last, partial byte (upper bits zero)
+    HG_HD void resume() { have = nbits & 7u; acc = have ? (p[nbits >> 3] & ((1u << have) - 1u)) : 0u; }   // continue behind nbits bits already in p
 };
 
 // Emit BFINAL=1, BTYPE=10 and the two trees (RFC 1951 3.2.7) into `dst` (>= 320 bytes).
@@ -200,6 +209,7 @@ HG_HD_SERIAL uint32_t write_dynamic_header(const uint8_t *ll_len, const uint8_t 
         bs.put(cl_code[s], cl_len[s]);
         if (s == 16) bs.put(cl_ext[k], 2); else if (s == 17) bs.put(cl_ext[k], 3); else if (s == 18) bs.put(cl_ext[k], 7);
     }
+    bs.finish();
     return bs.nbits;
 }
 

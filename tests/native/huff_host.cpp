@@ -30,6 +30,7 @@ long hh_encode_tokens(const uint32_t *tok, long ntok, uint8_t *out, long cap) {
     memset(out, 0, cap);
     uint32_t nb = write_dynamic_header(ll, dl, out, cs, ce, work, order);
     BitSink bs{out, nb};
+    bs.resume();
     for (long i = 0; i < ntok; i++) {
         uint32_t t = tok[i];
         if ((long)(bs.nbits >> 3) + 16 > cap) return -1;
@@ -40,6 +41,7 @@ long hh_encode_tokens(const uint32_t *tok, long ntok, uint8_t *out, long cap) {
         } else bs.put(lc[t & 0xff], ll[t & 0xff]);
     }
     bs.put(lc[256], ll[256]);
+    bs.finish();
     return (bs.nbits + 7) >> 3;
 }
 }
