@@ -8,6 +8,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <stdlib.h>
+#include <thread>
 #include <vector>
 #include "htsgpu.h"
 #include "hg_internal.h"
@@ -34,6 +40,72 @@ void gather_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, c
     }
 }
 
+// ---- the host side of staging: hundreds of MB are memcpy'd between the callers' malloc'd blocks and the pinned buffer per batch;
+// one thread does that at ~10 GB/s, which made the copies -- not the kernels, not PCIe -- the longest part of a CRAM batch.  A few
+// process-wide helper threads share them (HTS_GPU_COPY_THREADS helpers, default 3, 0 = none); callers on different contexts may
+// submit concurrently.
+struct CopyJob { uint8_t *d; const uint8_t *s; size_t n; };
+class CopyPool {
+    struct Batch { std::atomic<size_t> left{0}; std::mutex m; std::condition_variable cv; };
+    struct Task { const CopyJob *j; size_t n; Batch *b; };
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Task> q;
+    bool stop = false;
+    static void run(const Task &t) {
+        for (size_t i = 0; i < t.n; i++) memcpy(t.j[i].d, t.j[i].s, t.j[i].n);
+        if (t.b->left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(t.b->m); t.b->cv.notify_all(); }
+    }
+    void worker() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || !q.empty(); });
+            if (q.empty()) return;
+            const Task t = q.front(); q.pop_front();
+            lk.unlock(); run(t); lk.lock();
+        }
+    }
+public:
+    explicit CopyPool(int n) { for (int i = 0; i < n; i++) th.emplace_back([this] { worker(); }); }
+    ~CopyPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); for (auto &t : th) t.join(); }
+    // jobs are cut into helpers + 1 runs of about equal bytes; the caller takes the first run itself
+    void copy(const std::vector<CopyJob> &jobs) {
+        size_t total = 0;
+        for (const CopyJob &j : jobs) total += j.n;
+        const size_t parts = th.size() + 1, target = total / parts + 1;
+        std::vector<std::pair<size_t, size_t>> runs;                       // [first, count)
+        size_t first = 0, acc = 0;
+        for (size_t i = 0; i < jobs.size(); i++) {
+            acc += jobs[i].n;
+            if (acc >= target && runs.size() + 1 < parts) { runs.push_back({first, i + 1 - first}); first = i + 1; acc = 0; }
+        }
+        if (first < jobs.size()) runs.push_back({first, jobs.size() - first});
+        if (runs.empty()) return;
+        Batch b;
+        b.left = runs.size();
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for (size_t r = 1; r < runs.size(); r++) q.push_back(Task{jobs.data() + runs[r].first, runs[r].second, &b});
+        }
+        cv.notify_all();
+        run(Task{jobs.data() + runs[0].first, runs[0].second, &b});
+        std::unique_lock<std::mutex> lk(b.m);
+        b.cv.wait(lk, [&] { return b.left.load() == 0; });
+    }
+};
+static void host_copies(const std::vector<CopyJob> &jobs) {
+    static CopyPool *pool = [] {
+        const char *v = getenv("HTS_GPU_COPY_THREADS");
+        const int n = v ? atoi(v) : 3;
+        return n > 0 ? new CopyPool(n > 16 ? 16 : n) : nullptr;
+    }();
+    size_t total = 0;
+    for (const CopyJob &j : jobs) total += j.n;
+    if (pool && total >= (4u << 20)) pool->copy(jobs);
+    else for (const CopyJob &j : jobs) memcpy(j.d, j.s, j.n);
+}
+
 static int ensure_pinned(hg_ctx *ctx, int which, size_t bytes) {
     if (ctx->h_stage_cap[which] >= bytes) return HG_OK;
     if (ctx->h_stage[which]) (void)hipHostFree(ctx->h_stage[which]);
@@ -58,11 +130,14 @@ int stage_upload(hg_ctx *ctx, const uint8_t *const *src, const uint32_t *len, co
     if (int rc = hgs::ensure_pinned(ctx, 0, total)) return rc;
     uint8_t *h = (uint8_t *)ctx->h_stage[0];
     uint64_t hi = 0;
+    std::vector<hgs::CopyJob> jobs;
+    jobs.reserve(n);
     for (size_t i = 0; i < n; i++) {
         if (!len[i] || (skip && skip[i])) continue;
-        memcpy(h + dst_off[i], src[i], len[i]);
+        jobs.push_back({h + dst_off[i], src[i], len[i]});
         if (dst_off[i] + len[i] > hi) hi = dst_off[i] + len[i];
     }
+    hgs::host_copies(jobs);
     if (!hi) return HG_OK;
     return hipMemcpyAsync(d_base, h, hi, hipMemcpyHostToDevice, s) == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
@@ -95,7 +170,10 @@ int stage_download(hg_ctx *ctx, const uint8_t *d_base, const uint64_t *src_off, 
     if (hipMemcpyAsync(ctx->h_stage[1], ctx->d_scratch[13], total, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
     const uint8_t *h = (const uint8_t *)ctx->h_stage[1];
-    for (size_t i = 0; i < n; i++) if (len[i]) memcpy(dst[i], h + hoff[i], len[i]);
+    std::vector<hgs::CopyJob> jobs;
+    jobs.reserve(n);
+    for (size_t i = 0; i < n; i++) if (len[i]) jobs.push_back({dst[i], h + hoff[i], len[i]});
+    hgs::host_copies(jobs);
     return HG_OK;
 }
 
