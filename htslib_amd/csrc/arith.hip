@@ -16,11 +16,21 @@
 //   * the compressed bytes are read 64 at a time into one VGPR and picked out with v_readlane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "htsgpu.h"
 #include "hg_device.h"
 #include "hg_internal.h"
 
 namespace hga {
+
+// -DHG_ARITH_PROFILE: per-symbol phase times of the decoder (core-clock ticks), printed by the first wavefront per stream
+#ifdef HG_ARITH_PROFILE
+#define HA_T(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); g_tacc[slot] += n_ - g_tlast; g_tlast = n_; } while (0)
+__device__ unsigned long long g_dummy;
+#define HA_DECL unsigned long long g_tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g_tlast = __builtin_amdgcn_s_memtime()
+#else
+#define HA_T(slot) do { } while (0)
+#endif
 using hg::wave_sync;
 using hg::wave_incl_scan_dpp;
 
@@ -100,16 +110,25 @@ __device__ __forceinline__ void model_update(uint32_t *M, uint32_t *TT, uint32_t
 
 struct Decoder {
     uint32_t code, range; ByteWindow in; int err;
+#ifdef HG_ARITH_PROFILE
+    unsigned long long g_tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g_tlast = 0;
+#endif
     __device__ void start(const uint8_t *b, uint32_t n, int lane) {
+#ifdef HG_ARITH_PROFILE
+        g_tlast = __builtin_amdgcn_s_memtime();
+#endif
         in.init(b, n, lane); err = 0; code = 0; range = 0xffffffffu;
         for (int i = 0; i < 5; i++) code = (code << 8) | in.next(lane);
     }
     // decodes one symbol with the model at B (n entries, total at T)
     __device__ uint32_t symbol(uint32_t *M, uint32_t *TT, uint32_t B, uint32_t n, uint32_t T, int lane) {
+        HA_T(5);
         uint32_t e = (uint32_t)lane < n ? M[B + (uint32_t)lane] : 0u;     // the first 64 entries travel together with the total
         const uint32_t tot = TT[T];
+        HA_T(0);
         const uint32_t r = range / tot, freq = code / r;
         if (freq >= tot) { err = 1; return 0; }
+        HA_T(1);
         uint32_t acc0 = 0, x = 0, ex = 0, acc = 0, eprev = 0;
         bool have_prev = false;
         for (uint32_t b = 0; b < n; b += 64) {
@@ -125,10 +144,13 @@ struct Decoder {
             }
             acc0 = rl(incl, 63);
         }
+        HA_T(2);
         const uint32_t f = ex >> 8;
         code -= acc * r; range = r * f;
         while (range < TOP) { code = (code << 8) | in.next(lane); range <<= 8; }
+        HA_T(3);
         model_update(M, TT, B, n, T, tot, x, ex, have_prev, eprev, lane);
+        HA_T(4);
         return ex & 0xffu;
     }
 };
@@ -148,10 +170,14 @@ void arith_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
         const uint32_t n = d.out_len;
         int err = 0;
         if (d.in_len < 1) err = 1;
-        if (!err && n) {
+        // The model pointer is LDS in one instantiation of the body and global memory in the other: with a pointer chosen at run
+        // time every model access was a FLAT load (slow for LDS, and its wait also covers every global store in flight).
+        auto body = [&](auto lds_models) {
+            constexpr bool LM = decltype(lds_models)::value;
             Models Q;
             Q.m = cp[0] ? cp[0] : 256u; Q.nl = order ? Q.m : 1u;
-            Q.place(pool[wv], (uint32_t)POOLW, gscratch + d.scratch_off, model_words(Q.m, order, rle));
+            Q.TT = pool[wv]; Q.split = !LM;
+            if (LM) Q.M = pool[wv]; else Q.M = gscratch + d.scratch_off;
             models_init(Q, rle != 0, lane);
             Decoder D;
             D.start(cp + 1, d.in_len - 1, lane);
@@ -187,6 +213,15 @@ void arith_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
                 }
             }
             if (D.err || D.in.overrun) err = 1;
+#ifdef HG_ARITH_PROFILE
+            if (blockIdx.x == 0 && threadIdx.x == 0)
+                printf("arith dec n=%u m=%u order=%u rle=%u lds=%d ticks/symbol: load %.0f div %.0f search %.0f renorm %.0f update %.0f outside %.0f\n", n, Q.m, order, rle, (int)LM,
+                       (double)D.g_tacc[0] / n, (double)D.g_tacc[1] / n, (double)D.g_tacc[2] / n, (double)D.g_tacc[3] / n, (double)D.g_tacc[4] / n, (double)D.g_tacc[5] / n);
+#endif
+        };
+        if (!err && n) {
+            const uint32_t m0 = cp[0] ? cp[0] : 256u;
+            if (model_words(m0, order, rle) <= (uint32_t)POOLW) body(std::true_type{}); else body(std::false_type{});
         }
         status[sidx] = err ? -1 : 0;                                 // every lane stores the same word
         wave_sync();
@@ -296,9 +331,12 @@ void arith_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
             uint32_t mx = 0;
             for (uint32_t i = (uint32_t)lane; i < n; i += 64) { const uint32_t c = src[i]; mx = c > mx ? c : mx; }
             for (int s = 32; s; s >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)mx, s, 64); mx = t > mx ? t : mx; }
+            auto body = [&](auto lds_models) {
+            constexpr bool LM = decltype(lds_models)::value;
             Models Q;
             Q.m = mx + 1u; Q.nl = order ? Q.m : 1u;
-            Q.place(pool[wv], (uint32_t)POOLW, gscratch + d.scratch_off, model_words(Q.m, order, rle));
+            Q.TT = pool[wv]; Q.split = !LM;
+            if (LM) Q.M = pool[wv]; else Q.M = gscratch + d.scratch_off;
             models_init(Q, rle != 0, lane);
             o[0] = (uint8_t)Q.m;                                     // every lane, same byte (256 -> 0)
             Encoder E;
@@ -335,6 +373,8 @@ void arith_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
                 }
             }
             total = 1u + E.finish(lane);
+            };
+            if (model_words(mx + 1u, order, rle) <= (uint32_t)POOLW) body(std::true_type{}); else body(std::false_type{});
         }
         out_len[sidx] = total;                                       // every lane stores the same word
         wave_sync();
