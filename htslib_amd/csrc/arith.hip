@@ -123,7 +123,11 @@ struct Decoder {
     // decodes one symbol with the model at B (n entries, total at T)
     __device__ uint32_t symbol(uint32_t *M, uint32_t *TT, uint32_t B, uint32_t n, uint32_t T, int lane) {
         HA_T(5);
-        uint32_t e = (uint32_t)lane < n ? M[B + (uint32_t)lane] : 0u;     // the first 64 entries travel together with the total
+        // all (<= 4) 64-entry pieces of the model are requested at once, together with the total: the search below then runs
+        // on registers -- with the pieces fetched one per probe a 256-symbol model in global memory cost up to 4 round trips
+        uint32_t ev[4];
+#pragma unroll
+        for (uint32_t c = 0; c < 4; c++) { const uint32_t i = c * 64u + (uint32_t)lane; ev[c] = (c * 64u < n && i < n) ? M[B + i] : 0u; }
         const uint32_t tot = TT[T];
         HA_T(0);
         const uint32_t r = range / tot, freq = code / r;
@@ -131,9 +135,11 @@ struct Decoder {
         HA_T(1);
         uint32_t acc0 = 0, x = 0, ex = 0, acc = 0, eprev = 0;
         bool have_prev = false;
-        for (uint32_t b = 0; b < n; b += 64) {
+#pragma unroll
+        for (uint32_t b = 0; b < 256u; b += 64) {
+            if (b >= n) break;
             const uint32_t i = b + (uint32_t)lane;
-            if (b) e = i < n ? M[B + i] : 0u;
+            const uint32_t e = ev[b >> 6];
             const uint32_t incl = acc0 + wave_incl_scan_dpp(e >> 8);
             const unsigned long long hit = __ballot(i < n && incl > freq);
             if (hit) {
@@ -291,13 +297,17 @@ struct Encoder {
     }
     // codes `sym` with the model at B (n entries, total at T)
     __device__ void symbol(uint32_t *M, uint32_t *TT, uint32_t B, uint32_t n, uint32_t T, uint32_t sym, int lane) {
-        uint32_t e = (uint32_t)lane < n ? M[B + (uint32_t)lane] : 0u;     // the first 64 entries travel together with the total
+        uint32_t ev[4];                                                    // the whole model at once (see the decoder)
+#pragma unroll
+        for (uint32_t c = 0; c < 4; c++) { const uint32_t i = c * 64u + (uint32_t)lane; ev[c] = (c * 64u < n && i < n) ? M[B + i] : 0u; }
         const uint32_t tot = TT[T];
         uint32_t acc0 = 0, x = 0, ex = 0, acc = 0, eprev = 0;
         bool have_prev = false;
-        for (uint32_t b = 0; b < n; b += 64) {
+#pragma unroll
+        for (uint32_t b = 0; b < 256u; b += 64) {
+            if (b >= n) break;
             const uint32_t i = b + (uint32_t)lane;
-            if (b) e = i < n ? M[B + i] : 0u;
+            const uint32_t e = ev[b >> 6];
             const uint32_t incl = acc0 + wave_incl_scan_dpp(e >> 8);
             const unsigned long long hit = __ballot(i < n && (e & 0xffu) == sym);
             if (hit) {
