@@ -33,7 +33,7 @@ enum { F_ORDER = 1, F_X32 = 4, F_STRIPE = 8, F_NOSZ = 16, F_CAT = 32, F_RLE = 64
 struct GroupLds { uint16_t C[258]; };
 // 32-way streams (the big data series) keep their order-1 tables in LDS when they fit: a symbol lookup is a chain
 // of 6-7 DEPENDENT table reads, which from global memory (~600 cycles each) capped a stream at ~23 MB/s.
-constexpr uint32_t O1_LDS_WORDS = 4352;          // per stream; 8 streams per workgroup -> 136 KiB
+constexpr uint32_t O1_LDS_WORDS = 4352;          // per stream; 4 streams (wavefronts) per workgroup -> 68 KiB, two workgroups per CU
 // Order 0 uses the same pool as a direct slot -> symbol table (4096 one-byte entries) instead of a binary search.
 
 __device__ __forceinline__ uint32_t rd32(const uint8_t *p) {
@@ -114,7 +114,10 @@ __global__ __launch_bounds__(WAVES * 64)
 void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc,
                             const uint32_t *__restrict__ sel, uint32_t nsel, uint8_t *out, int32_t *status,
                             uint32_t *scratch) {
-    constexpr int GROUPS = 64 / N;
+    // 32-way: ONE stream per wavefront (lanes 32..63 idle).  Two streams side by side ran in lock step: an order-0 and an order-1
+    // neighbour cost the sum of both decode chains per step and a short stream waited for a long one; with the chain being LDS
+    // latency, the idle lanes cost nothing and twice as many wavefronts hide more of it.
+    constexpr int GROUPS = N == 32 ? 1 : 64 / N;
     __shared__ GroupLds lds[WAVES * GROUPS];
     // one pool per stream slot, used either as the order-1 table copy or as the order-0 lookup table
     __shared__ uint32_t pool[N == 32 ? WAVES * GROUPS : 1][N == 32 ? O1_LDS_WORDS : 1];
@@ -122,7 +125,9 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
     // step never waits on global memory) and the dense numbering of the order-1 contexts (for the bucket table below)
     __shared__ uint32_t ring_s[N == 32 ? WAVES * GROUPS : 1][N == 32 ? 64 : 1];
     __shared__ uint8_t rank_s[N == 32 ? WAVES * GROUPS : 1][N == 32 ? 256 : 1];
-    const int tid = threadIdx.x, lane = tid & 63, sub = lane & (N - 1), grp = lane / N;
+    const int tid = threadIdx.x, lane = tid & 63, sub = lane & (N - 1);
+    const bool idle = lane / N >= GROUPS;                          // lanes beyond the groups in use
+    const int grp = idle ? 0 : lane / N;
     const uint32_t g_global = (blockIdx.x * WAVES + (tid >> 6)) * GROUPS + grp;
     const uint32_t g_total = gridDim.x * WAVES * GROUPS;
     GroupLds &G = lds[(tid >> 6) * GROUPS + grp];
@@ -130,7 +135,7 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
     const int lane0 = grp * N;
 
     for (uint32_t k = g_global; __any(k < nsel); k += g_total) {
-        const bool have = k < nsel;
+        const bool have = k < nsel && !idle;
         const uint32_t sidx = have ? sel[k] : 0;
         int err = have ? 0 : 2;
         uint32_t flags = 0, usz = 0, shift = 12, np_words = 0xffffffffu;
@@ -245,6 +250,8 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
         const uint32_t *T = tabs;                                    // where the decode loop reads the order-1 tables
         const uint8_t *lut = nullptr;                                // order-0 slot -> symbol
         const uint8_t *o1lut = nullptr;                              // order-1 bucket tables (64 bytes per context)
+        const uint8_t *dL = nullptr; const uint32_t *dD = nullptr;   // order-1 dense form (small alphabets)
+        uint32_t drank0 = 0;
         if constexpr (N == 32) {
             uint32_t *P = pool[(tid >> 6) * GROUPS + grp];
             const uint32_t npw = (uint32_t)__shfl((int)np_words, lane0, 64);
@@ -259,6 +266,39 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                 uint32_t nctx = 0;
                 if (sub == 0) for (int i = 0; i < 256; i++) { rk[i] = (uint8_t)nctx; if (P[256 + i]) nctx++; }
                 nctx = (uint32_t)__shfl((int)nctx, lane0, 64);
+                // Small alphabets (<= 16 contexts of <= 16 symbols: binned qualities, bases, flags): a DENSE form that costs two
+                // dependent LDS reads per symbol instead of four -- L256[context rank][slot >> (shift - 8)] = list index of the slot's
+                // bucket, DD[context rank][index] = cumulative << 12 | symbol << 4 | rank of the symbol as the next context (bit 25:
+                // that symbol never is a context).  The decode loop is a chain of such reads; with a few wavefronts per CU nothing
+                // hides them.
+                uint32_t big = 0;
+                for (uint32_t i = (uint32_t)sub; i < 256; i += N) if (P[256 + i] > 16u) big = 1;
+                big = (__ballot(big != 0) & gmask) ? 1u : 0u;
+                if (!big && nctx <= 16u && npw + 1024u + 16u * 17u <= O1_LDS_WORDS && shift >= 8u) {
+                    uint8_t *L = (uint8_t *)(P + npw);
+                    uint32_t *DDw = P + npw + 1024u;
+                    const uint32_t sh8 = shift - 8u;
+                    for (uint32_t i = (uint32_t)sub; i < 256; i += N) {
+                        const uint32_t cnt = P[256 + i], base = P[i];
+                        if (!cnt) continue;
+                        const uint32_t r = rk[i];
+                        for (uint32_t k = 0; k <= cnt; k++) {
+                            const uint32_t e = P[base + k], sy = e & 0xffu;
+                            const uint32_t nx = k < cnt ? (P[256 + sy] ? (uint32_t)rk[sy] : (1u << 25)) : 0u;
+                            DDw[r * 17u + k] = ((e >> 8) << 12) | (sy << 4) | nx;
+                        }
+                        uint32_t k = 0;
+                        for (uint32_t bkt = 0; bkt < 256; bkt++) {
+                            const uint32_t sl = bkt << sh8;
+                            while (k + 1 < cnt && (P[base + k + 1] >> 8) <= sl) k++;
+                            L[r * 256u + bkt] = (uint8_t)k;
+                        }
+                    }
+                    dL = L; dD = DDw;
+                    drank0 = P[256] ? (uint32_t)rk[0] : 0xffffffffu;            // the states start in context 0
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                } else
                 if (npw + nctx * 16u <= O1_LDS_WORDS) {
                     const uint32_t sh6 = shift - 6u;
                     for (uint32_t i = (uint32_t)sub; i < 256; i += N) {
@@ -317,6 +357,7 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
         const uint32_t mask = (1u << shift) - 1u;
         const uint32_t per = usz / N;
         uint32_t pos = order == 0 ? (uint32_t)sub : (uint32_t)sub * per, ctx = 0;
+        uint32_t rctx = drank0;                                      // dense form: rank of the current context
         const uint32_t steps = per, rem = usz - per * N;
         const uint32_t max_steps = (live && !err) ? steps + (order ? rem : 0u) : 0u;
         for (uint32_t it = 0; __any(it < max_steps); it++) {
@@ -332,7 +373,17 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                     else while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (G.C[mid] <= m) lo = mid; else hi = mid; }
                     sym = lo; cum = G.C[lo]; f = (uint32_t)G.C[lo + 1] - cum;
                 } else {
-                    if (N == 32 && o1lut) {
+                    if (N == 32 && dD) {
+                        if (rctx > 15u) err = 1;                      // context never seen by the encoder
+                        else {
+                            uint32_t kb = dL[rctx * 256u + (m >> (shift - 8u))];
+                            const uint32_t *row = dD + rctx * 17u;
+                            uint32_t e = row[kb], e1 = row[kb + 1];
+                            while (((e1 >> 12) & 0x1fffu) <= m) { kb++; e = e1; e1 = row[kb + 1]; }   // the list ends with the total > m
+                            sym = (e >> 4) & 0xffu; cum = (e >> 12) & 0x1fffu; f = ((e1 >> 12) & 0x1fffu) - cum;
+                            rctx = (e >> 25) ? 0xffffu : (e & 15u);
+                        }
+                    } else if (N == 32 && o1lut) {
                         const uint32_t info = T[ctx], base = info & 0x1fffu;
                         if ((info >> 21) == 0) err = 1;               // context never seen by the encoder
                         else {
@@ -414,8 +465,8 @@ int launch_ransnx16_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *
                            (const uint8_t *)d_in, d_desc, d_sel4, (uint32_t)n4, (uint8_t *)d_out, d_status, d_scratch);
     }
     if (n32) {
-        size_t wgs = (n32 + hgn::WAVES * 2 - 1) / (hgn::WAVES * 2);
-        if (wgs > maxw) wgs = maxw;
+        size_t wgs = (n32 + hgn::WAVES - 1) / hgn::WAVES;                  // one 32-way stream per wavefront
+        if (wgs > maxw * 2) wgs = maxw * 2;
         hipLaunchKernelGGL(hgn::ransnx16_decode_kernel<32>, dim3((unsigned)wgs), dim3(hgn::WAVES * 64), 0, s2,
                            (const uint8_t *)d_in, d_desc, d_sel32, (uint32_t)n32, (uint8_t *)d_out, d_status, d_scratch);
         if (side) join_side(ctx, s);
