@@ -33,7 +33,10 @@ enum { F_ORDER = 1, F_X32 = 4, F_STRIPE = 8, F_NOSZ = 16, F_CAT = 32, F_RLE = 64
 struct GroupLds { uint16_t C[258]; };
 // 32-way streams (the big data series) keep their order-1 tables in LDS when they fit: a symbol lookup is a chain
 // of 6-7 DEPENDENT table reads, which from global memory (~600 cycles each) capped a stream at ~23 MB/s.
-constexpr uint32_t O1_LDS_WORDS = 4352;          // per stream; 4 streams (wavefronts) per workgroup -> 68 KiB, two workgroups per CU
+#ifndef HG_O1_POOL
+#define HG_O1_POOL 4352
+#endif
+constexpr uint32_t O1_LDS_WORDS = HG_O1_POOL;          // per stream; 4 streams (wavefronts) per workgroup -> 68 KiB, two workgroups per CU
 // Order 0 uses the same pool as a direct slot -> symbol table (4096 one-byte entries) instead of a binary search.
 
 __device__ __forceinline__ uint32_t rd32(const uint8_t *p) {
