@@ -120,7 +120,8 @@ __global__ __launch_bounds__(waves_of(N) * 64)
 void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc,
                             const uint8_t *__restrict__ flags_in, const uint32_t *__restrict__ sel, uint32_t nsel,
                             uint8_t *out, uint32_t *out_len, uint8_t *wbuf, uint32_t *scratch) {
-    constexpr int GROUPS = 64 / N, WAVES = waves_of(N);
+    // 32-way: one stream per wavefront, lanes 32..63 idle (as in the decoder: streams that share a wavefront run in lock step)
+    constexpr int GROUPS = N == 32 ? 1 : 64 / N, WAVES = waves_of(N);
     // renormalisation words are collected in an LDS ring and written out a ring at a time: a scattered global store per
     // step would sit in front of every later source load (one counter orders loads and stores on gfx9)
     constexpr uint32_t STAGE = N == 32 ? 2048u : 128u;           // 16-bit words per group
@@ -140,7 +141,9 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
         rcp_tab[f] = f < 2u ? 0u : (uint32_t)((((unsigned long long)1 << (sh + 31u)) + f - 1u) / f);
     }
     __syncthreads();
-    const int tid = threadIdx.x, lane = tid & 63, sub = lane & (N - 1), grp = lane / N;
+    const int tid = threadIdx.x, lane = tid & 63, sub = lane & (N - 1);
+    const bool idle = lane / N >= GROUPS;
+    const int grp = idle ? 0 : lane / N;
     const uint32_t g_global = (blockIdx.x * WAVES + (tid >> 6)) * GROUPS + grp;
     const uint32_t g_total = gridDim.x * WAVES * GROUPS;
     GroupLds &G = lds[(tid >> 6) * GROUPS + grp];
@@ -148,7 +151,7 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
     const int lane0 = grp * N;
 
     for (uint32_t k = g_global; __any(k < nsel); k += g_total) {
-        const bool have = k < nsel;
+        const bool have = k < nsel && !idle;
         const uint32_t sidx = have ? sel[k] : 0;
 #ifdef HG_ENC_PROFILE
         unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
@@ -602,7 +605,7 @@ int launch_ransnx16_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *
     }
     if (n32) {
         constexpr int W32 = hge::waves_of(32);
-        size_t wgs = (n32 + W32 * 2 - 1) / (W32 * 2);
+        size_t wgs = (n32 + W32 - 1) / W32;                                   // one 32-way stream per wavefront
         if (wgs > maxw) wgs = maxw;
         hipLaunchKernelGGL(hge::ransnx16_encode_kernel<32>, dim3((unsigned)wgs), dim3(W32 * 64), 0, s2,
                            (const uint8_t *)d_in, d_desc, d_flags, d_sel32, (uint32_t)n32, (uint8_t *)d_out, d_out_len,
