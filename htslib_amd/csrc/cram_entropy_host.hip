@@ -181,6 +181,13 @@ static int launch_plan(hg_ctx *ctx, Plan &P, uint64_t in_bytes, uint64_t obytes,
     for (int c = 0; c < C_CLASSES; c++) first[c + 1] = first[c] + cnt[c];
     { size_t fill[C_CLASSES]; for (int c = 0; c < C_CLASSES; c++) fill[c] = first[c];
       for (size_t k = 0; k < nc; k++) sel[fill[P.core_cls[k]]++] = (uint32_t)k; }
+    // streams that share a wavefront (16 four-way streams) run in lock step: neighbours alike -- same flags, then by length
+    for (int c = 0; c < C_CLASSES; c++)
+        std::stable_sort(sel.begin() + first[c], sel.begin() + first[c + 1], [&](uint32_t a, uint32_t b) {
+            const uint32_t fa = P.core[a].reserved & 0xffu, fb = P.core[b].reserved & 0xffu;
+            if (fa != fb) return fa < fb;
+            return P.core[a].out_len > P.core[b].out_len;
+        });
     int rc;
     if ((rc = ensure_scratch(ctx, 0, in_bytes + 64)) || (rc = ensure_scratch(ctx, 1, obytes + P.work + 64)) ||
         (rc = ensure_scratch(ctx, 2, nc * sizeof(hg_stream_desc) + 64)) || (rc = ensure_scratch(ctx, 3, nst * 4 + 64)) ||
