@@ -128,7 +128,8 @@ EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info
            "hg_pipe_create", "hg_pipe_destroy", "hg_pipe_input", "hg_pipe_inflate", "hg_pipe_deflate", "hg_pipe_wait",
            "hg_gzip_stream_inflate_host", "hg_crc32_host", "hg_crc32_batch_host",
            "hg_hts_pack", "hg_hts_unpack", "hg_hts_rle_encode", "hg_hts_rle_decode",
-           "hg_cram_itf8_decode_dev", "hg_cram_itf8_encode_dev", "hg_cram_itf8_decode_host", "hg_cram_itf8_encode_host"]
+           "hg_cram_itf8_decode_dev", "hg_cram_itf8_encode_dev", "hg_cram_itf8_decode_host", "hg_cram_itf8_encode_host",
+           "hg_cram_byte_array_stop_dev", "hg_cram_byte_array_stop_host"]
 
 
 class HgError(RuntimeError):

@@ -205,6 +205,50 @@ void itf8_encode_kernel(const int32_t *__restrict__ in, const hg_stream_desc *__
     }
 }
 
+// BYTE_ARRAY_STOP series (read names, string tags; cram_byte_array_stop_decode_char, cram/cram_codecs.c:3586-3624): the items of a
+// block are separated by a stop byte.  One wavefront per block, 1 KiB per step: every lane compares its 16 bytes with the stop byte
+// (a 16-bit mask), a wave prefix sum numbers the stops, and the lane writes for every stop the offset of the item that FOLLOWS it --
+// off[0] = 0, off[k + 1] = position of the k-th stop + 1; off[count] is the end of the last complete item.  Bytes behind the last
+// stop are an unterminated item: the reference's -1.
+__global__ __launch_bounds__(WAVES * 64)
+void byte_array_stop_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc, uint32_t n, uint32_t *out,
+                            uint32_t *count, int32_t *status) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t k = blockIdx.x * WAVES + wv; k < n; k += gridDim.x * WAVES) {
+        const hg_stream_desc d = desc[k];
+        const uint8_t *src = in + d.in_off;
+        uint32_t *dst = out + d.out_off;
+        const uint32_t len = d.in_len, cap = d.out_len, stop = d.reserved & 0xffu;
+        uint32_t nitems = 0, last_end = 0;
+        int err = cap < 1 ? 1 : 0;
+        if (!err && lane == 0) dst[0] = 0;
+        for (uint32_t t0 = 0; t0 < len && !err; t0 += 1024u) {
+            const uint32_t p = t0 + 16u * (uint32_t)lane;
+            uint32_t w[4] = {0, 0, 0, 0}, valid = 0;
+            if (p + 16u <= len) { uint4 v; __builtin_memcpy(&v, src + p, 16); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; valid = 16; }
+            else if (p < len) { valid = len - p; for (uint32_t b = 0; b < valid; b++) w[b >> 2] |= (uint32_t)src[p + b] << (8u * (b & 3u)); }
+            uint32_t m = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 16; b++) if (b < valid && ((w[b >> 2] >> (8u * (b & 3u))) & 0xffu) == stop) m |= 1u << b;
+            const uint32_t c = (uint32_t)__popc(m);
+            uint32_t pre = hg::wave_incl_scan_dpp(c);
+            const uint32_t total = (uint32_t)__shfl((int)pre, 63, 64);
+            pre -= c;
+            if (nitems + total + 1u > cap) { err = 1; break; }
+            uint32_t j = nitems + pre;
+            for (uint32_t mm = m; mm; mm &= mm - 1u) { j++; dst[j] = p + (uint32_t)__builtin_ctz(mm) + 1u; }
+            const uint32_t my_last = m ? p + 32u - (uint32_t)__builtin_clz(m) : 0u;           // end of my last complete item
+            uint32_t le = my_last;
+            for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)le, sft, 64); le = o > le ? o : le; }
+            if (le > last_end) last_end = le;
+            nitems += total;
+        }
+        if (!err && last_end != len) err = 1;                                                // unterminated bytes at the end
+        count[k] = err ? 0u : nitems;                                                        // every lane stores the same word
+        status[k] = err ? -1 : 0;
+    }
+}
+
 }  // namespace hgc
 
 using hg::ensure_scratch;
@@ -239,6 +283,56 @@ int hg_cram_itf8_encode_dev(hg_ctx *ctx, const int32_t *d_in, const hg_stream_de
     hipLaunchKernelGGL(hgc::itf8_encode_kernel, dim3((unsigned)wgs), dim3(hgc::WAVES * 64), 0, (hipStream_t)stream, d_in, d_desc, (uint32_t)n,
                        (uint8_t *)d_out, d_out_len, d_status);
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+
+// d_desc[i]: in_off / in_len = the block; reserved = the stop byte; out_off = first uint32 of its offset table in d_off (in WORDS),
+// out_len = room there (words; items + 1 are written).  d_off[out_off + k] = offset of item k inside the block, [count] = end of
+// the last item + 1 (= in_len).  d_status[i] = 0, or -1 for bytes behind the last stop byte / no room.
+int hg_cram_byte_array_stop_dev(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, size_t n, uint32_t *d_off, uint32_t *d_count,
+                                int32_t *d_status, void *stream) {
+    if (!ctx || (n && (!d_in || !d_desc || !d_off || !d_count || !d_status))) return HG_EINVAL;
+    if (!n) return HG_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HG_ENODEV;
+    size_t wgs = (n + hgc::WAVES - 1) / hgc::WAVES;
+    const size_t maxw = (size_t)ctx->cus * 8;
+    if (wgs > maxw) wgs = maxw;
+    hipLaunchKernelGGL(hgc::byte_array_stop_kernel, dim3((unsigned)wgs), dim3(hgc::WAVES * 64), 0, (hipStream_t)stream, (const uint8_t *)d_in, d_desc,
+                       (uint32_t)n, d_off, d_count, d_status);
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+
+int hg_cram_byte_array_stop_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *stop, size_t n, uint32_t *const *off,
+                                 const uint32_t *cap, uint32_t *count, int32_t *status) {
+    if (!ctx || (n && (!in || !in_len || !stop || !off || !cap || !count || !status))) return HG_EINVAL;
+    if (!n) return HG_OK;
+    hg::CtxGuard guard_(ctx);
+    if (guard_.rc) return guard_.rc;
+    std::vector<hg_stream_desc> d(n);
+    std::vector<uint64_t> ioff(n), ooff(n);
+    std::vector<uint32_t> olen(n);
+    uint64_t ib = 0, ov = 0;
+    for (size_t i = 0; i < n; i++) {
+        memset(&d[i], 0, sizeof d[i]);
+        d[i].in_off = ib; d[i].in_len = in_len[i]; d[i].out_off = ov; d[i].out_len = cap[i]; d[i].reserved = stop[i];
+        ioff[i] = ib; ooff[i] = ov * 4;
+        ib += ((uint64_t)in_len[i] + 15u) & ~15ull; ov += ((uint64_t)cap[i] + 3u) & ~3ull;
+    }
+    int rc;
+    if ((rc = ensure_scratch(ctx, 0, ib + 64)) || (rc = ensure_scratch(ctx, 1, ov * 4 + 64)) || (rc = ensure_scratch(ctx, 2, n * sizeof(hg_stream_desc) + 64)) ||
+        (rc = ensure_scratch(ctx, 3, n * 8 + 64))) return rc;
+    hipStream_t s = ctx->stream;
+    if ((rc = hg::stage_upload(ctx, in, in_len, ioff.data(), nullptr, n, ib, (uint8_t *)ctx->d_scratch[0], s)) != HG_OK) return rc;
+    uint32_t *d_cnt = (uint32_t *)ctx->d_scratch[3]; int32_t *d_st = (int32_t *)ctx->d_scratch[3] + n;
+    if (hipMemcpyAsync(ctx->d_scratch[2], d.data(), n * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
+    if ((rc = hg_cram_byte_array_stop_dev(ctx, ctx->d_scratch[0], (const hg_stream_desc *)ctx->d_scratch[2], n, (uint32_t *)ctx->d_scratch[1], d_cnt, d_st, s)) != HG_OK) return rc;
+    if (hipMemcpyAsync(count, d_cnt, n * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipMemcpyAsync(status, d_st, n * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+    bool bad = false;
+    for (size_t i = 0; i < n; i++) { olen[i] = status[i] == 0 ? (count[i] + 1u) * 4u : 0u; bad |= status[i] != 0; }
+    std::vector<uint8_t *> dst(n);
+    for (size_t i = 0; i < n; i++) dst[i] = (uint8_t *)off[i];
+    if ((rc = hg::stage_download(ctx, (const uint8_t *)ctx->d_scratch[1], ooff.data(), olen.data(), dst.data(), n, s)) != HG_OK) return rc;
+    return bad ? HG_EBLOCK : HG_OK;
 }
 
 // Host-buffer forms: n blocks in, n int32 columns out (cap[i] values of room each), one device round trip.

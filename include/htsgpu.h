@@ -437,6 +437,14 @@ int hg_cram_itf8_decode_dev(hg_ctx *ctx, const void *d_in, const hg_stream_desc 
  * the room there (5 bytes per value always suffice).  d_out_len[i] = bytes written; d_status[i] = 0 / -1 (no room). */
 int hg_cram_itf8_encode_dev(hg_ctx *ctx, const int32_t *d_in, const hg_stream_desc *d_desc, size_t n, void *d_out, uint32_t *d_out_len,
                             int32_t *d_status, void *stream);
+/* BYTE_ARRAY_STOP series (read names, string tags; cram_byte_array_stop_decode_char, cram/cram_codecs.c:3586-3624): the offset of every
+ * item of a block.  d_desc[i]: in_off / in_len = the block, reserved = the stop byte, out_off = first word of its offset table in
+ * d_off, out_len = room there in words.  d_off[out_off + k] = start of item k (k < count), [count] = in_len; item k is the bytes
+ * [off[k], off[k + 1] - 1).  d_status[i] = 0, or -1 when bytes follow the last stop byte (the reference's -1) or the table has no room. */
+int hg_cram_byte_array_stop_dev(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, size_t n, uint32_t *d_off, uint32_t *d_count,
+                                int32_t *d_status, void *stream);
+int hg_cram_byte_array_stop_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *stop, size_t n,
+                                 uint32_t *const *off, const uint32_t *cap, uint32_t *count, int32_t *status);
 /* Host-buffer forms (one PCIe round trip for the batch); HG_EBLOCK when some status[i] != 0. */
 int hg_cram_itf8_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n, int32_t *const *out, const uint32_t *cap,
                              uint32_t *count, int32_t *status);

@@ -50,3 +50,23 @@ ORC_EXPORT size_t orc_itf8_encode_block(const int32_t *in, size_t n, uint8_t *ou
     }
     return o;
 }
+
+/* BYTE_ARRAY_STOP: the item loop of cram_byte_array_stop_decode_char (/root/reference/cram/cram_codecs.c:3586-3624) run over a whole
+ * block.  off[k] = start of item k, off[count] = end of the last item + 1.  Returns the item count, or -1 when bytes follow the last
+ * stop byte (the reference function's -1 on that item) or off[] is full.  PINNED the same way as the ITF8 pair
+ * (tests/native/gen_bas_ref.sh runs the reference's own function). */
+ORC_EXPORT long orc_byte_array_stop_split(const uint8_t *in, size_t len, uint8_t stop, uint32_t *off, size_t cap)
+{
+    size_t n = 0, p = 0;
+    if (cap < 1) return -1;
+    off[0] = 0;
+    while (p < len) {
+        size_t q = p;
+        while (q < len && in[q] != stop) q++;
+        if (q >= len) return -1;                      /* unterminated */
+        if (n + 2 > cap) return -1;
+        off[++n] = (uint32_t)(q + 1);
+        p = q + 1;
+    }
+    return (long)n;
+}

@@ -28,6 +28,8 @@ def orc():
     L.orc_itf8_decode_block.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.orc_itf8_encode_block.restype = C.c_size_t
     L.orc_itf8_encode_block.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p]
+    L.orc_byte_array_stop_split.restype = C.c_long
+    L.orc_byte_array_stop_split.argtypes = [C.c_char_p, C.c_size_t, C.c_uint8, C.c_void_p, C.c_size_t]
     return L
 
 
@@ -198,3 +200,80 @@ def test_gpu_decodes_fixture_columns_to_the_sam_values(engine):
     assert rc == 0 and st == [0] * len(cols)
     for (name, _, vals), g in zip(cols, got):
         assert np.array_equal(g, vals), name
+
+
+# ---------------------------------------------------------------------------------------------- BYTE_ARRAY_STOP (read names, string tags)
+def orc_split(L, b: bytes, stop: int, cap=None):
+    cap = len(b) + 2 if cap is None else cap
+    off = np.zeros(max(cap, 1), dtype=np.uint32)
+    n = L.orc_byte_array_stop_split(b, len(b), stop, off.ctypes.data, cap)
+    return n, (off[:n + 1].copy() if n >= 0 else None)
+
+
+def bas_blocks():
+    rng = np.random.default_rng(77)
+    names = [b"", b"\t", b"read1\t", b"a\tb\t\tc\t"]
+    names.append(b"".join(b"IL%d_%d:%d:%d#0\t" % (rng.integers(1, 9), rng.integers(1, 99), rng.integers(1, 9999), rng.integers(1, 99999)) for _ in range(20000)))
+    names.append(b"".join(bytes(rng.integers(65, 91, rng.integers(0, 40), dtype=np.uint8)) + b"\0" for _ in range(5000)))
+    names.append(b"\0" * 3000)                                                       # empty items only
+    names.append(bytes(rng.integers(1, 256, 70000, dtype=np.uint8)) + b"\0")          # one long item
+    r = bytes(rng.integers(0, 4, 100000, dtype=np.uint8))
+    names.append(r[:r.rfind(b"\0") + 1])
+    stops = [9, 9, 9, 9, 9, 0, 0, 0, 0]
+    return names, stops
+
+
+def test_byte_array_stop_oracle_equals_reference_function(built, tmp_path):
+    if not os.path.isdir(REF):
+        pytest.skip("no reference checkout here")
+    subprocess.run(["bash", os.path.join(ROOT, "tests", "native", "gen_bas_ref.sh"), str(tmp_path)], check=True)
+    exe = str(tmp_path / "bas_ref")
+    L = orc()
+    blocks, stops = bas_blocks()
+    for b, st in zip(blocks, stops):
+        for cut in (0, 1):
+            bb = b[:len(b) - cut] if cut and len(b) > 1 and b[-2] != st else b
+            r = subprocess.run([exe, str(st)], input=bb, capture_output=True, check=True).stdout.decode().split("\n")
+            end = [x for x in r if x.startswith("END")][0].split()
+            sizes = [int(x) for x in r if x and not x.startswith("END")]
+            n, off = orc_split(L, bb, st)
+            if int(end[2]) != 0:
+                assert n == -1, (len(bb), st)
+            else:
+                assert n == len(sizes) and [int(off[k + 1] - off[k] - 1) for k in range(n)] == sizes, (len(bb), st)
+
+
+@pytest.mark.gpu
+def test_gpu_byte_array_stop_equals_oracle(engine):
+    from htslib_amd import _native as nat
+    L = orc()
+    blocks, stops = bas_blocks()
+    blocks = blocks + [blocks[4][:-1], blocks[5][:-3]]                                 # unterminated tails
+    stops = stops + [9, 0]
+    n = len(blocks)
+    caps = [len(b) + 2 for b in blocks]
+    bufs = [C.create_string_buffer(b, max(len(b), 1)) for b in blocks]
+    outs = [np.zeros(c, dtype=np.uint32) for c in caps]
+    inp = (C.c_void_p * n)(*[C.addressof(x) for x in bufs])
+    ilen = (C.c_uint32 * n)(*[len(b) for b in blocks])
+    stp = (C.c_uint8 * n)(*stops)
+    outp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    cap = (C.c_uint32 * n)(*caps)
+    cnt = (C.c_uint32 * n)(); st = (C.c_int32 * n)()
+    f = nat.lib.hg_cram_byte_array_stop_host
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = f(engine._h, inp, ilen, stp, n, outp, cap, cnt, st)
+    assert rc in (0, -6)
+    for i, (b, s_) in enumerate(zip(blocks, stops)):
+        en, eoff = orc_split(L, b, s_)
+        if en < 0:
+            assert st[i] == -1, i
+        else:
+            assert st[i] == 0 and cnt[i] == en and np.array_equal(outs[i][:en + 1], eoff), i
+    # the read names of a reference fixture: items == the .sam twin's QNAMEs
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "rans4x8", "MANIFEST.json")))
+    rn = [e for e in man.values() if e["series"] == "RN" and e["expected_hex"]]
+    for e in rn:
+        b = bytes.fromhex(e["expected_hex"])
+        en, eoff = orc_split(L, b, b[-1])
+        assert en > 0
