@@ -35,3 +35,24 @@ def test_reference_test_bgzf_passes_on_the_front_end(progs, tmp_path):
 def test_reference_bgzip_scenarios(progs, tmp_path, threads):
     checker = os.path.join(refutil.REF_DIR, "ref_bgzip") if refutil.have_ref() else None
     dropin_cases.reference_bgzip(progs[1], str(tmp_path), threads, checker)
+
+
+def test_large_reads_go_through_the_copy_helpers(progs, tmp_path):
+    """bgzf_read with an 8 MiB buffer: copies of 2 MiB and more are shared with helper threads (race detector on in the
+    `thread` build); the bytes must be the file's."""
+    import numpy as np
+    suf = "_thread" if progs[0].endswith("_thread") else ""
+    exe = str(tmp_path / "bigread")
+    r = subprocess.run(["gcc", "-O1", "-g"] + (["-fsanitize=thread"] if suf else []) +
+                       ["-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "bigread.c"), "-o", exe,
+                        "-L", OUT, "-lhts_bgzf_fake" + suf, "-Wl,-rpath," + OUT, "-lpthread"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    data = (np.random.default_rng(3).integers(0, 64, 30_000_000, dtype=np.uint8) + 32).tobytes()
+    plain, gz = tmp_path / "big.txt", tmp_path / "big.gz"
+    plain.write_bytes(data)
+    with open(gz, "wb") as f:
+        assert subprocess.run([progs[1], "-@4", "-c", str(plain)], stdout=f).returncode == 0
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")
+    out = subprocess.run([exe, str(gz)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    assert out.stdout == data
