@@ -14,10 +14,12 @@
 //     LDS access.  77 KiB of LDS per workgroup -> 2 workgroups (8 waves) per CU, persistent
 //     workgroups pull block tickets from a global counter;
 //   * match finding is position-parallel: the block is walked in chunks of 256 positions, one
-//     position per lane; a lane hashes its 4 bytes, reads the WAYS most recent earlier
-//     positions with that hash from a set-associative table in LDS (one ds_read_b128), extends
-//     each candidate 4 bytes at a time, then the chunk's positions are inserted (LDS atomics
-//     pick the way).  Candidates are always from earlier chunks; distance 1 is probed directly;
+//     position per lane; a lane hashes its 4 bytes, reads the WAYS (4 / 8 / 12 by level) most recent
+//     earlier positions with that hash from a set-associative table in LDS and compares all of
+//     them with its own bytes in LOCK STEP, 16 or 8 bytes per round (the rounds are dependent LDS
+//     round trips: few and wide), then the nearest survivor alone; then the chunk's positions are
+//     inserted (LDS atomics pick the way).  Candidates are always from earlier chunks; distance 1
+//     is probed directly;
 //   * the lazy parse (take a match unless the next position has a longer one) is a chain over
 //     positions; it is resolved per chunk with 8 rounds of pointer jumping in LDS, then the
 //     chosen tokens are compacted in order with ballots and appended to a per-workgroup token
@@ -61,19 +63,13 @@ constexpr int WG = 256;
 constexpr int HB = HG_DEF_HB;                 // hash buckets = 2^HB
 constexpr int MAX_WAYS = 12;                   // most recent positions kept per bucket (the level picks 4, 8 or 12 of them)
 constexpr uint32_t MAX_IN = 0xff00u;           // BGZF_BLOCK_SIZE (htslib/bgzf.h:50)
-#ifndef HG_LS8
-#define HG_LS8 1
-#endif
-#ifndef HG_MERGE1
-#define HG_MERGE1 1
-#endif
 #ifndef HG_LS_G0
-#define HG_LS_G0 32
+#define HG_LS_G0 32      // bytes over which the candidates of the first group are compared in lock step
 #endif
 #ifndef HG_LS_G1
-#define HG_LS_G1 24      // lock-step bytes of the second group (12 ways): 24 costs 0.02 % of size and gives 3.5 % of speed (r02 sweep)
+#define HG_LS_G1 24      // ... of the second group (12 ways): 24 costs 0.02 % of size and gives 3.5 % of speed (r02 sweep)
 #endif
-constexpr uint32_t LOCKSTEP = HG_LS8 ? (HG_MERGE1 ? (uint32_t)HG_LS_G0 : 36u) : 32u;   // bytes proven in lock step (4 + 4 steps of 8, or 8 steps of 4)            // bytes over which all candidates are extended together
+constexpr uint32_t LOCKSTEP = (uint32_t)HG_LS_G0;
 constexpr uint32_t TOO_FAR = 4096u;            // a 3-byte match this far away costs more than 3 literals
 
 struct Huff {                                  // overlays the hash table once matching is done
@@ -303,7 +299,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                     h = hash4(cur);
                     // Candidates are evaluated in groups of up to GW table entries (+ distance 1 with the first group: runs are
                     // never in this chunk's table) to bound the registers held per lane: one group for 4 or 8 ways, 8 + 4 for 12.  Inside a group all candidates
-                    // advance in LOCKSTEP, 4 bytes per step, so that a step costs one LDS round trip for every candidate together.
+                    // advance in LOCKSTEP, 16 or 8 bytes per round, so that a round costs one LDS round trip for every candidate together.
                     constexpr int GW = WAYS < 8 ? WAYS : 8, G = GW + 1, NGROUPS = (WAYS + GW - 1) / GW;
                     const uint32_t *row32 = (const uint32_t *)&S.u.tab[h * MAX_WAYS];           // 24-byte rows, 8-byte aligned
 #pragma unroll 1
@@ -325,26 +321,11 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                         }
                         cand[GW] = p >= 1u ? p - 1u : 0u;
                         if (g == 0 && p >= 1u) alive |= 1u << GW;
-#if HG_LS8 && HG_MERGE1
                         // no separate look at the first four bytes: on BAM data most bucket entries are real repeats and survive
                         // it, so it was one more dependent round for nothing
 #pragma unroll
                         for (int w = 0; w < G; w++) len[w] = 0;
                         uint32_t off = 0;
-#else
-#pragma unroll
-                        for (int w = 0; w < G; w++) {
-                            const uint32_t x = load4(S.in32, cand[w]) ^ cur;
-                            len[w] = 0;
-                            if ((alive >> w) & 1u) {
-                                if (x) { len[w] = (uint32_t)__builtin_ctz(x) >> 3; alive &= ~(1u << w); }
-                                else len[w] = 4;
-                            }
-                        }
-                        // lockstep phase: all candidates of the group together, up to LOCKSTEP bytes
-                        uint32_t off = 4;
-#endif
-#if HG_LS8
                         // sixteen bytes per step where the registers allow it (<= 8 ways), else eight: the steps are dependent LDS round
                         // trips, so fewer and wider ones win (4 -> 8 bytes: +21 % at level 6; 16 bytes: +4 % more at levels 1-5, spills at 12 ways)
                         if constexpr (WAYS <= 8) {
@@ -385,23 +366,6 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                             off += 8;
                         }
                         }
-#else
-                        while (alive != 0u && off < maxl && off < LOCKSTEP) {
-                            const uint32_t own = load4(S.in32, p + off);
-                            uint32_t nxt[G];
-#pragma unroll
-                            for (int w = 0; w < G; w++) nxt[w] = load4(S.in32, ((alive >> w) & 1u) ? cand[w] + off : 0u);
-#pragma unroll
-                            for (int w = 0; w < G; w++) {
-                                if ((alive >> w) & 1u) {
-                                    const uint32_t x = nxt[w] ^ own;
-                                    if (x) { len[w] = off + ((uint32_t)__builtin_ctz(x) >> 3); alive &= ~(1u << w); }
-                                    else len[w] = off + 4;
-                                }
-                            }
-                            off += 4;
-                        }
-#endif
                         // long-match phase: only the nearest candidate that is still going is extended
                         // (8 bytes per step); the others keep the LOCKSTEP bytes they have proven.
                         if (alive != 0u && off < maxl) {

@@ -27,9 +27,6 @@ constexpr int WAVES_PER_WG = 4;
 #ifndef HG_LOOP
 #define HG_LOOP 0        // 0: inflate_loop_vec.inc (all vector-uniform, default)  2: inflate_loop_mix.inc (per-knob vector / scalar split)
 #endif
-#ifndef HG_TRIM
-#define HG_TRIM 1        // merged bit-buffer shifts + straight-line short-match copy (see inflate_loop_vec.inc)
-#endif
 #ifndef HG_WALK
 #define HG_WALK 0        // 0: vector-uniform serial loop (inflate_loop_vec.inc)  1: gather + scalar walk
 #endif
