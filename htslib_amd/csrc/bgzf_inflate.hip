@@ -5,24 +5,24 @@
 // (RFC 1951) of one <=64 KiB block + CRC-32 check against the trailer.
 //
 // Mapping (designed for CDNA4, not translated from a CPU inflate):
-//   * one BGZF block per 64-lane wavefront; wavefronts are persistent and pull
-//     block indices from a global ticket counter, so 164 k blocks of a 10 GiB
-//     BAM load-balance over 256 CUs without a tail;
-//   * the compressed stream is read with coalesced 256-byte wave loads: the
-//     wave keeps a 64-dword window of the input in ONE VGPR (+ the next window
-//     prefetched in a second VGPR) and the bit reader pulls dwords out of it
-//     with v_readlane into a 64-bit SGPR bit buffer -- no per-byte loads, no
-//     LDS staging traffic on the critical path;
-//   * all decode state is wave-uniform, so the Huffman loop runs largely on
-//     the scalar ALU; decode tables (10-bit litlen root, 8-bit distance root,
-//     zlib-style second-level tables) live in LDS, 7.3 KiB per wave, and are
-//     built by all 64 lanes in parallel (ballot-ranked canonical codes);
-//   * literals are gathered into a VGPR with v_writelane and flushed with one
-//     coalesced byte store per run; LZ77 matches are copied by the 64 lanes
-//     straight in global memory (the wave's own earlier stores are visible to
-//     its later loads in program order, so HBM/L2 is the 32 KiB window);
-//   * the CRC-32 is fused: after the last deflate block the wave re-reads its
-//     output (L2-resident), 64 lanes x slice-by-4, and folds the partials.
+//   * one BGZF block per 64-lane wavefront, 4 wavefronts per workgroup; wavefronts are persistent and pull block indices from
+//     a per-launch ticket counter, so the 168 k blocks of a 10 GiB BAM load-balance over 256 CUs without a tail;
+//   * the compressed stream is read with coalesced 256-byte wave loads: the wave keeps a 64-dword window of the input in ONE
+//     VGPR (+ the next window prefetched in a second one) and the bit reader pulls dwords out of it with v_readlane;
+//   * the symbol loop keeps bit buffer, bit count and output position VECTOR-UNIFORM (the same value in every lane of a VGPR):
+//     a CU has one scalar ALU for its four SIMDs, and the first version of this kernel, with the decode state in SGPRs, was
+//     bound by it (inflate_loop_vec.inc);
+//   * decode tables live in LDS (9-bit litlen root + zlib-style second level, 8-bit distance root: 5.1 KiB per wave) and are
+//     built by all 64 lanes (LDS-atomic histogram, ballot-ranked canonical codes); root-table literals carry a sign bit so
+//     that the hot path is one compare;
+//   * literals are parked one per lane and written with one scattered byte store per 64; the last 1 KiB of output is mirrored
+//     in an LDS ring, so near matches are LDS -> LDS plus a fire-and-forget global store, far matches read global memory (a
+//     wave sees its own earlier stores in program order);
+//   * the CRC-32 is fused: after the last deflate block the wave re-reads its output (L2-resident), 64 lanes x slice-by-4, and
+//     folds the partials with a 6-step butterfly;
+//   * 80 VGPRs, 6 KiB of LDS per wave -> 24 wavefronts per CU; at that occupancy the kernel is VALU-issue bound (~40 vector
+//     instructions per symbol).  gzip members of any length (CRAM GZIP blocks, plain .gz files) use the same decoder in a
+//     resumable form (mode 1, gzip_stream_kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -195,13 +195,7 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                 for (uint32_t p = lo + (uint32_t)lane; p < pos; p += 64) S.u.ring[p & (RING - 1u)] = out[p];
             }
             wave_sync();
-#if HG_LOOP == 2
-#include "inflate_loop_mix.inc"
-#elif HG_WALK
-#include "inflate_loop_walk.inc"
-#else
 #include "inflate_loop_vec.inc"
-#endif
             if (br_byte_pos(br) > in_end) return ST_INFLATE;
         }
         if (bfinal) break;

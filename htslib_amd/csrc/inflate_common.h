@@ -24,12 +24,6 @@ constexpr int WAVES_PER_WG = 4;
 #ifndef HG_RING
 #define HG_RING 1024
 #endif
-#ifndef HG_LOOP
-#define HG_LOOP 0        // 0: inflate_loop_vec.inc (all vector-uniform, default)  2: inflate_loop_mix.inc (per-knob vector / scalar split)
-#endif
-#ifndef HG_WALK
-#define HG_WALK 0        // 0: vector-uniform serial loop (inflate_loop_vec.inc)  1: gather + scalar walk
-#endif
 constexpr uint32_t RING = HG_RING;          // bytes of most recent output mirrored in LDS per wave
 constexpr uint32_t RING_NEAR = RING - 64u;  // look-back spans up to this are served from LDS
 
