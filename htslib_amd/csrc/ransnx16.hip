@@ -6,16 +6,18 @@
 // oracle/ransnx16_oracle.c -- PARITY UNPINNED (no stock-htslib stream exists in the reference to
 // check against); the GPU decoder is bit-exact with that oracle.
 //
-// Mapping: the N (4 or 32) interleaved rANS states of a stream live in N adjacent lanes (16 or 2
-// streams per wavefront); every step each lane decodes one symbol and the lanes whose state drops
-// below 2^15 pull the next 16-bit words of the SHARED stream in lane order -- a ballot and a
-// prefix popcount per step, which is exactly what the 32-way SIMD CPU decoders emulate with
-// shuffles.  Order-0 tables: 257-entry cumulative array per stream in LDS, slot -> symbol by binary
-// search.  Order-1 tables: sparse per-context (cumulative, symbol) lists in a global scratch area
-// (L1/L2 resident for quality-value alphabets).  Tables are parsed by the first lane of the group.
+// Mapping: the N (4 or 32) interleaved rANS states of a stream live in N adjacent lanes -- sixteen 4-way streams per wavefront, ONE
+// 32-way stream per wavefront (lanes 32..63 idle: two streams side by side ran in lock step, so an order-0 and an order-1 neighbour
+// cost the sum of both decode chains); every step each lane decodes one symbol and the lanes whose state drops below 2^15 pull the next
+// 16-bit words of the SHARED stream in lane order -- a ballot and a prefix popcount per step, which is exactly what the 32-way SIMD CPU
+// decoders emulate with shuffles.  A stream is one chain of n / N steps of dependent LDS reads, and a launch lasts as long as its longest
+// chain, so the tables are shaped for few reads per step: order 0 -- a slot -> symbol byte table + the 257-entry cumulative array; order 1
+// with a small alphabet (<= 16 contexts of <= 16 symbols) -- a dense form, two reads per symbol (a 256-bucket index per context, then the
+// (cumulative, symbol, next-context rank) entry and its neighbour); order 1 otherwise -- sparse per-context lists with a 64-bucket index,
+// in LDS when they fit, else in global scratch.  Tables are parsed by the first lane of the group.
 // Handled here: flags ORDER, X32, NOSZ (size from the descriptor), CAT.  The PACK / RLE / STRIPE
 // transforms are undone by ransnx16_xform.hip after this kernel: the host planner
-// (ransnx16_host.hip) parses their headers and hands this kernel pre-parsed core descriptors
+// (cram_entropy_host.hip) parses their headers and hands this kernel pre-parsed core descriptors
 // (desc.reserved bit 31).  Raw streams carrying those flags are reported -3 by THIS kernel, which is
 // what the device-resident entry point (hg_ransnx16_decode_dev) returns for them.
 #include <hip/hip_runtime.h>
