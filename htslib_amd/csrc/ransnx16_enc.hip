@@ -5,14 +5,20 @@
 // oracle/ransnx16_oracle.c, PARITY UNPINNED).  The kernel reproduces the oracle's encoder byte for
 // byte (same normalisation, same table layout), which is what the tests check.
 //
-// Mapping: like the decoder, the N (4 / 32) interleaved states of a stream live in N adjacent
-// lanes.  rANS encodes backwards: each step every lane pushes one symbol into its state and the
-// lanes whose state would overflow first spill their low 16 bits; the spilled words are laid out
-// from the END of a per-stream buffer towards the front, the highest lane first, so the split of
-// the shared word stream is again one ballot + popcount per step (of the lanes ABOVE me).
-// Histograms are built with LDS atomics (order 0) or global atomics into a 256x256 scratch matrix
-// (order 1); the small serial parts (normalisation, table serialisation) run on the group's
-// first lane / are spread one context row per lane.
+// Mapping: like the decoder, the N (4 / 32) interleaved states of a stream live in N adjacent lanes (sixteen 4-way streams or ONE
+// 32-way stream per wavefront).  rANS encodes backwards: each step every lane pushes one symbol into its state and the lanes whose
+// state would overflow first spill their low 16 bits; the spilled words are laid out from the END of a per-stream buffer towards the
+// front, the highest lane first, so the split of the shared word stream is again one ballot + popcount per step (of the lanes ABOVE me).
+// A stream is one serial chain and a launch lasts as long as its longest stream, so the work is organised around the latency of a step
+// and of the table build:
+//   * x / f through a 4096-entry LDS table of reciprocals (exact for x < 2^31; no integer divide on gfx950);
+//   * source bytes in 16-byte loads, one chunk AHEAD of the steps that use them; renormalisation words staged in an LDS ring and written
+//     out 2 048 at a time (a load issued behind a scattered store waits for it: one counter orders both on gfx9);
+//   * histograms from 16-byte reads into replicated LDS counter matrices (order 0, and order 1 for alphabets of <= 64 symbols), global
+//     atomics into a 256 x 256 scratch matrix otherwise;
+//   * order-1 tables one context row at a time by the whole lane group: coalesced load, oracle-identical normalisation, serialisation
+//     from bit masks (what every alphabet entry emits and where), cumulative scan.
+// The host sorts the streams of a launch by flags and length (lane groups of a wavefront run in lock step).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
