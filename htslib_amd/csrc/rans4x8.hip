@@ -5,19 +5,20 @@
 // Format and arithmetic: CRAM v3.0 specification, rANS codec (restated and pinned against the
 // reference's CRAM fixtures in oracle/rans4x8_oracle.c).
 //
-// Mapping: a stream has only 4 interleaved rANS states that share ONE renormalisation byte
-// pointer, so the parallelism inside a stream is 4 lanes; the chip is filled with streams:
-//   * one stream per 4-lane group, 16 streams per wavefront; the four lanes of a group hold the
-//     four states and decode one symbol each per step;
-//   * the data-dependent split of the shared byte stream between the four states is a prefix sum
-//     of the per-lane renormalisation byte counts inside the group (two DPP-style shuffles);
-//   * order-0 frequency tables live in LDS as a 257-entry cumulative array per group (514 B) and
-//     the slot -> symbol map is a binary search over it (8 LDS reads) instead of a 4 KiB lookup
-//     table per stream, which would limit a CU to a few streams;
-//   * order-1 tables (256 contexts) are kept as sparse per-context (cumulative, symbol) lists in
-//     a global scratch area sized from the stream itself (every table entry costs >= 1 stream byte),
-//     L1/L2 resident for the few KiB typical of quality-value alphabets;
-//   * tables are parsed by lane 0 of each group (serial, small), all 16 groups of a wave in parallel.
+// Mapping: a stream has only 4 interleaved rANS states that share ONE renormalisation byte pointer, so the parallelism inside a
+// stream is 4 lanes and a stream is one chain of n / 4 steps; a launch lasts as long as its longest chain, so everything a step
+// touches is in LDS (round 2; before, the order-1 lists and the stream bytes were read from global memory inside the chain --
+// ~10 dependent loads, 1.5 us per step):
+//   * four streams per wavefront (lanes 0..15; the lanes of a quad hold the four states), 16 per workgroup, 9 KiB of LDS each;
+//   * the stream bytes come from a 128-byte LDS ring per stream, topped up 64 bytes at a time from a register prefetch (the same
+//     scheme as the 32-way Nx16 decoder); the data-dependent split of the bytes between the four states is a prefix sum inside
+//     the quad on the DPP path (quad_perm, no LDS round trip);
+//   * order 0: slot -> symbol byte table (4 KiB) + the 257-entry cumulative array;
+//   * order 1, small alphabet (<= 16 contexts of <= 16 symbols): the dense two-read form of the Nx16 decoder (a 256-bucket index per
+//     context, then the (cumulative, symbol, next-context rank) entry and its neighbour);
+//   * order 1 otherwise: the sparse per-context (cumulative, symbol) lists copied into LDS when they fit (binary search there), else
+//     left in the global scratch area they were parsed into;
+//   * tables are parsed by lane 0 of each quad (serial, small).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "htsgpu.h"
@@ -27,8 +28,9 @@
 namespace hgr {
 
 constexpr uint32_t TF_SHIFT = 12, TOTFREQ = 1u << TF_SHIFT, RANS_L = 1u << 23;
-constexpr int GROUPS = 16;                     // streams per wave
-constexpr int WAVES = 4;                       // waves per workgroup
+constexpr int GROUPS = 4;                      // streams per wave (lanes 16..63 idle)
+constexpr int WAVES = 2;                       // waves per workgroup
+constexpr uint32_t POOLW = 4096;               // LDS words per stream for the tables (8 streams per workgroup: 138 KiB)
 
 struct GroupLds { uint16_t C[258]; };          // exclusive cumulative frequencies, C[256] = total
 
@@ -65,31 +67,45 @@ __device__ __forceinline__ const uint8_t *parse_table0(const uint8_t *cp, const 
     return nullptr;
 }
 
-// inclusive prefix sum inside a 4-lane group
+// inclusive prefix sum inside a quad, and the quad's total, on the DPP path (quad_perm)
 __device__ __forceinline__ uint32_t group_scan4(uint32_t v, int sub) {
-    uint32_t t = (uint32_t)__shfl_up((int)v, 1, 4);
+    uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x90, 0xf, 0xf, false);      // lane i <- lane max(i - 1, 0)
     if (sub >= 1) v += t;
-    t = (uint32_t)__shfl_up((int)v, 2, 4);
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x44, 0xf, 0xf, false);               // lanes 2, 3 <- lanes 0, 1
     if (sub >= 2) v += t;
     return v;
 }
+__device__ __forceinline__ uint32_t quad_perm0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xf, 0xf, false); }   // lane 0 of the quad
+__device__ __forceinline__ uint32_t quad_perm1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false); }   // xor 1: [1,0,3,2]
+__device__ __forceinline__ uint32_t quad_perm2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false); }   // xor 2: [2,3,0,1]
+__device__ __forceinline__ uint32_t quad_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xff, 0xf, 0xf, false); }
 
 __global__ __launch_bounds__(WAVES * 64)
 void rans4x8_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc, uint32_t nstreams,
                            uint8_t *out, int32_t *status, uint32_t *scratch) {
     __shared__ GroupLds lds[WAVES * GROUPS];
-    const int tid = threadIdx.x, lane = tid & 63, sub = lane & 3, grp = lane >> 2;
+    __shared__ uint32_t pool[WAVES * GROUPS][POOLW];
+    __shared__ uint32_t ring_s[WAVES * GROUPS][32];             // 128 stream bytes
+    __shared__ uint8_t rank_s[WAVES * GROUPS][256];
+    const int tid = threadIdx.x, lane = tid & 63, sub = lane & 3;
+    const bool idle = (lane >> 2) >= GROUPS;
+    const int grp = idle ? 0 : lane >> 2;
+    const int slot = (tid >> 6) * GROUPS + grp;
     const uint32_t g_global = (blockIdx.x * WAVES + (tid >> 6)) * GROUPS + grp;
     const uint32_t g_total = gridDim.x * WAVES * GROUPS;
-    GroupLds &G = lds[(tid >> 6) * GROUPS + grp];
+    GroupLds &G = lds[slot];
+    uint32_t *P = pool[slot];
+    uint32_t *ring = ring_s[slot];
+    uint8_t *rk = rank_s[slot];
 
     for (uint32_t sidx = g_global; __any(sidx < nstreams); sidx += g_total) {
-        const bool have = sidx < nstreams;
+        const bool have = sidx < nstreams && !idle;
         int err = 0;
         uint32_t order = 0, usz = 0;
         const uint8_t *cp = nullptr, *end = nullptr;
         uint8_t *o = nullptr;
         uint32_t *tabs = nullptr;                               // order-1: cbase[256], cn[256], pairs...
+        uint32_t np_words = 0xffffffffu;
         if (have) {
             const hg_stream_desc d = desc[sidx];
             const uint8_t *s = in + d.in_off;
@@ -104,8 +120,8 @@ void rans4x8_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc 
                 if ((uint64_t)csz + 9u != d.in_len || usz != d.out_len || order > 1) err = 1;
                 cp = s + 9;
             }
-        } else err = 2;                                          // idle group
-        // ---- frequency tables: parsed by lane 0 of the group ----------------------------------
+        } else err = 2;                                          // idle quad
+        // ---- frequency tables: parsed by lane 0 of the quad -----------------------------------
         if (!err && usz && sub == 0) {
             if (order == 0) {
                 for (int i = 0; i < 258; i++) G.C[i] = 0;
@@ -149,12 +165,14 @@ void rans4x8_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc 
                     if (i == 0) break;
                 }
                 if (!ok) err = 1;
+                np_words = np;
             }
         }
-        // broadcast the parse result (cursor, error) from lane 0 of the group
+        // broadcast the parse result (cursor, error, table size) from lane 0 of the quad
         {
             const int src = lane & ~3;
             err = __shfl(err, src, 64);
+            np_words = (uint32_t)__shfl((int)np_words, src, 64);
             const unsigned long long cpv = (unsigned long long)(uintptr_t)cp;
             const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)cpv, src, 64);
             const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(cpv >> 32), src, 64);
@@ -162,20 +180,106 @@ void rans4x8_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc 
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // ---- tables into LDS ---------------------------------------------------------------------
+        const bool core = !err && usz != 0;
+        const uint8_t *lut = nullptr;                            // order 0: slot -> symbol
+        const uint8_t *dL = nullptr; const uint32_t *dD = nullptr, *dT = nullptr; uint32_t rctx = 0;   // order 1, dense form
+        const uint32_t *bI = nullptr, *bL = nullptr; const uint8_t *bB = nullptr;           // order 1, bucket form in LDS
+        const uint32_t *T = tabs;                                // order 1, lists in global scratch (tables too big for LDS)
+        if (core && order == 0) {
+            uint8_t *L8 = (uint8_t *)P;
+            for (uint32_t sy = (uint32_t)sub; sy < 256; sy += 4) { const uint32_t a = G.C[sy], b2 = G.C[sy + 1]; for (uint32_t q = a; q < b2; q++) L8[q] = (uint8_t)sy; }
+            lut = L8;
+        } else if (core) {
+            uint32_t nctx = 0, big = 0;
+            if (sub == 0) for (int i = 0; i < 256; i++) { rk[i] = (uint8_t)nctx; const uint32_t c = tabs[256 + i]; if (c) nctx++; if (c > 16u) big = 1; }
+            nctx = quad_perm0(nctx); big = quad_perm0(big);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (!big && nctx <= 16u) {
+                // dense: L[rank][slot >> 4] = list index of the bucket, DD[rank][index] = cum << 12 | sym << 4 | rank of sym as a context
+                uint8_t *L = (uint8_t *)P;
+                uint32_t *DDw = P + 1024u, *TOT = P + 1024u + 16u * 17u;
+                for (uint32_t i = (uint32_t)sub; i < 256; i += 4) {
+                    const uint32_t cnt = tabs[256 + i], base = tabs[i];
+                    if (!cnt) continue;
+                    const uint32_t r = rk[i];
+                    TOT[r] = tabs[base + cnt] >> 8;                  // the context's total: slots at or beyond it are not decodable
+                    for (uint32_t k = 0; k <= cnt; k++) {
+                        const uint32_t e = tabs[base + k], sy = e & 0xffu;
+                        const uint32_t nx = k < cnt ? (tabs[256 + sy] ? (uint32_t)rk[sy] : (1u << 25)) : 0u;
+                        DDw[r * 17u + k] = ((e >> 8) << 12) | (sy << 4) | nx;
+                    }
+                    uint32_t k = 0;
+                    for (uint32_t bkt = 0; bkt < 256; bkt++) {
+                        const uint32_t sl = bkt << 4;
+                        while (k + 1 < cnt && (tabs[base + k + 1] >> 8) <= sl) k++;
+                        L[r * 256u + bkt] = (uint8_t)k;
+                    }
+                }
+                dL = L; dD = DDw; dT = TOT;
+                rctx = tabs[256] ? (uint32_t)rk[0] : 0xffffu;     // the states start in context 0
+            } else if ((np_words - 512u) + nctx * 17u <= POOLW) {
+                // bucket form: INFO[rank] = list start | entries << 16; BK[rank][slot >> 6] = list index of the bucket (64 buckets);
+                // list entries cum << 16 | rank of the symbol as a context << 8 | symbol (rank 255 + flag bit 29: never a context)
+                uint32_t *INFO = P, *LST = P + nctx * 17u;
+                uint8_t *BK = (uint8_t *)(P + nctx);
+                uint32_t off = 0;
+                // list offsets in rank order: lane 0 of the quad walks the 256 contexts once
+                if (sub == 0) for (int i = 0; i < 256; i++) { const uint32_t c = tabs[256 + i]; if (c) { INFO[rk[i]] = off | (c << 16); off += c + 1u; } }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t i = (uint32_t)sub; i < 256; i += 4) {
+                    const uint32_t cnt = tabs[256 + i], base = tabs[i];
+                    if (!cnt) continue;
+                    const uint32_t r = rk[i], lo = INFO[r] & 0xffffu;
+                    for (uint32_t k = 0; k <= cnt; k++) {
+                        const uint32_t e = tabs[base + k], sy = e & 0xffu;
+                        const uint32_t nx = k < cnt ? (tabs[256 + sy] ? ((uint32_t)rk[sy] << 8) : (1u << 29)) : 0u;
+                        LST[lo + k] = ((e >> 8) << 16) | nx | sy;
+                    }
+                    uint32_t k = 0;
+                    for (uint32_t bkt = 0; bkt < 64; bkt++) {
+                        const uint32_t sl = bkt << 6;
+                        while (k + 1 < cnt && (tabs[base + k + 1] >> 8) <= sl) k++;
+                        BK[r * 64u + bkt] = (uint8_t)k;
+                    }
+                }
+                bI = INFO; bB = BK; bL = LST;
+                rctx = tabs[256] ? (uint32_t)rk[0] : 0xffffu;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         uint32_t R = 0;
-        if (!err && usz) {
+        if (core) {
             if (cp + 16 > end) err = 1;
             else { R = rd32(cp + 4 * sub); cp += 16; }
         }
+        // ---- the stream bytes: a 128-byte LDS ring, 64 bytes per refill (16 per lane), one refill prefetched in registers
+        const uint8_t *wbase = cp;
+        const uint32_t wavail = core && !err ? (uint32_t)(end - wbase) : 0u;
+        auto load_chunk = [&](uint32_t c) -> uint4 {             // bytes 64 c + 16 sub .. + 16 (zeros past the end)
+            const uint8_t *p = wbase + 64u * c + 16u * (uint32_t)sub;
+            uint4 v = {0, 0, 0, 0};
+            if (p + 16 <= end) __builtin_memcpy(&v, p, 16);
+            else if (p < end) { uint32_t w[4] = {0, 0, 0, 0}; for (uint32_t q = 0; p + q < end; q++) w[q >> 2] |= (uint32_t)p[q] << (8u * (q & 3u)); v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3]; }
+            return v;
+        };
+        auto put_chunk = [&](uint32_t c, const uint4 &v) { uint32_t *d = ring + ((c & 1u) * 16u + 4u * (uint32_t)sub); d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; };
+        uint32_t wpos = 0, wfill = 0;                            // bytes consumed / bytes present in the ring (multiples of 64)
+        uint4 pre = {0, 0, 0, 0};
+        if (core && !err) { put_chunk(0, load_chunk(0)); put_chunk(1, load_chunk(1)); wfill = 128; pre = load_chunk(2); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t *ring8 = (const uint8_t *)ring;
         // ---- decode ----------------------------------------------------------------------------
         const uint32_t q4 = usz >> 2;
-        uint32_t steps = 0, ctx = 0;
-        uint32_t pos;                                            // my next output index
-        if (order == 0) { steps = q4; pos = (uint32_t)sub; }
-        else { steps = q4; pos = (uint32_t)sub * q4; }
-        const bool live = !err && usz != 0;
+        uint32_t steps = q4, ctx = 0;
+        uint32_t pos = order == 0 ? (uint32_t)sub : (uint32_t)sub * q4;      // my next output index
+        const bool live = core && !err;
         uint32_t max_steps = live ? steps + (order == 1 ? (usz & 3u) : 0u) : 0u;
-        // the loop runs while any group of the wave has steps left
+        // the loop runs while any quad of the wave has steps left
         for (uint32_t it = 0; __any(it < max_steps); it++) {
             const bool act = live && !err && it < max_steps;
             // order-1 tail: only state 3 continues past q4 steps
@@ -183,20 +287,41 @@ void rans4x8_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc 
             uint32_t nbytes = 0;
             if (mine) {
                 const uint32_t m = R & (TOTFREQ - 1);
-                uint32_t sym, cum, f;
+                uint32_t sym = 0, cum = 0, f = 1;
                 if (order == 0) {
-                    uint32_t lo = 0, hi = 256;                   // last j with C[j] <= m
-                    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (G.C[mid] <= m) lo = mid; else hi = mid; }
-                    if (G.C[256] <= m) { err = 1; sym = 0; cum = 0; f = 1; }
-                    else { sym = lo; cum = G.C[lo]; f = G.C[lo + 1] - cum; }
+                    if (G.C[256] <= m) err = 1;
+                    else { sym = lut[m]; cum = G.C[sym]; f = (uint32_t)G.C[sym + 1] - cum; }
+                } else if (dD) {
+                    if (rctx > 15u || dT[rctx] <= m) err = 1;     // context never seen by the encoder / slot beyond its total
+                    else {
+                        uint32_t kb = dL[rctx * 256u + (m >> 4)];
+                        const uint32_t *row = dD + rctx * 17u;
+                        uint32_t e = row[kb], e1 = row[kb + 1];
+                        while (((e1 >> 12) & 0x1fffu) <= m) { kb++; e = e1; e1 = row[kb + 1]; }      // ends at the total (> m)
+                        sym = (e >> 4) & 0xffu; cum = (e >> 12) & 0x1fffu; f = ((e1 >> 12) & 0x1fffu) - cum;
+                        rctx = (e >> 25) ? 0xffffu : (e & 15u);
+                    }
+                } else if (bL) {
+                    if (rctx > 255u) err = 1;                    // context never seen by the encoder
+                    else {
+                        const uint32_t info = bI[rctx], base = info & 0xffffu, n = info >> 16;
+                        uint32_t kb = bB[rctx * 64u + (m >> 6)];
+                        uint32_t e = bL[base + kb], e1 = bL[base + kb + 1];
+                        if (((bL[base + n] >> 16) & 0x1fffu) <= m) err = 1;          // slot beyond the context's total
+                        else {
+                            while (((e1 >> 16) & 0x1fffu) <= m) { kb++; e = e1; e1 = bL[base + kb + 1]; }
+                            sym = e & 0xffu; cum = (e >> 16) & 0x1fffu; f = ((e1 >> 16) & 0x1fffu) - cum;
+                            rctx = (e >> 29) ? 0xffffu : ((e >> 8) & 0xffu);
+                        }
+                    }
                 } else {
-                    const uint32_t n = tabs[256 + ctx], base = tabs[ctx];
-                    if (n == 0 || (tabs[base + n] >> 8) <= m) { err = 1; sym = 0; cum = 0; f = 1; }
+                    const uint32_t n = T[256 + ctx], base = T[ctx];
+                    if (n == 0 || (T[base + n] >> 8) <= m) err = 1;
                     else {
                         uint32_t lo = 0, hi = n;
-                        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if ((tabs[base + mid] >> 8) <= m) lo = mid; else hi = mid; }
-                        const uint32_t e = tabs[base + lo];
-                        sym = e & 0xffu; cum = e >> 8; f = (tabs[base + lo + 1] >> 8) - cum;
+                        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if ((T[base + mid] >> 8) <= m) lo = mid; else hi = mid; }
+                        const uint32_t e = T[base + lo];
+                        sym = e & 0xffu; cum = e >> 8; f = (T[base + lo + 1] >> 8) - cum;
                     }
                 }
                 if (!err) {
@@ -207,28 +332,31 @@ void rans4x8_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc 
                     nbytes = R < RANS_L ? (R < (1u << 15) ? 2u : 1u) : 0u;
                 }
             }
-            // split the shared byte stream: prefix sum of byte counts inside the group
+            // split the shared byte stream: prefix sum of byte counts inside the quad
             const uint32_t incl = group_scan4(nbytes, sub);
-            const uint32_t tot = (uint32_t)__shfl((int)incl, (lane & ~3) | 3, 64);
+            const uint32_t tot = quad_last(incl);
             if (mine && !err && nbytes) {
-                const uint8_t *b = cp + (incl - nbytes);
-                if (b + nbytes > end) err = 1;
-                else { R = (R << 8) | b[0]; if (nbytes == 2) R = (R << 8) | b[1]; }
+                const uint32_t k = wpos + incl - nbytes;
+                if (k + nbytes > wavail) err = 1;
+                else { R = (R << 8) | ring8[k & 127u]; if (nbytes == 2) R = (R << 8) | ring8[(k + 1u) & 127u]; }
             }
-            cp += tot;
-            // any lane of the group failing fails the stream
-            err |= __shfl_xor(err, 1, 64);
-            err |= __shfl_xor(err, 2, 64);
+            wpos += tot;
+            if (act && wfill - wpos < 64u) {                     // the whole quad takes this branch together: at least 64 bytes are free
+                put_chunk(wfill >> 6, pre);
+                wfill += 64;
+                pre = load_chunk(wfill >> 6);
+            }
+            // any lane of the quad failing fails the stream
+            err |= (int)quad_perm1((uint32_t)err);
+            err |= (int)quad_perm2((uint32_t)err);
         }
         // order-0 tail: states 0..(usz&3)-1 give one more symbol each, without update
         if (live && !err && order == 0 && (uint32_t)sub < (usz & 3u)) {
             const uint32_t m = R & (TOTFREQ - 1);
-            uint32_t lo = 0, hi = 256;
-            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (G.C[mid] <= m) lo = mid; else hi = mid; }
-            if (G.C[256] <= m) err = 1; else o[(usz & ~3u) + sub] = (uint8_t)lo;
+            if (G.C[256] <= m) err = 1; else o[(usz & ~3u) + sub] = lut[m];
         }
-        err |= __shfl_xor(err, 1, 64);
-        err |= __shfl_xor(err, 2, 64);
+        err |= (int)quad_perm1((uint32_t)err);
+        err |= (int)quad_perm2((uint32_t)err);
         if (have && sub == 0) status[sidx] = (err == 0) ? 0 : -1;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
