@@ -129,7 +129,7 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
     // 32-way only: the next 128 renormalisation words of the stream (filled 64 at a time from a register prefetch, so a
     // step never waits on global memory) and the dense numbering of the order-1 contexts (for the bucket table below)
     __shared__ uint32_t ring_s[N == 32 ? WAVES * GROUPS : 1][N == 32 ? 64 : 1];
-    __shared__ uint8_t rank_s[N == 32 ? WAVES * GROUPS : 1][N == 32 ? 256 : 1];
+    __shared__ uint8_t rank_s[WAVES * GROUPS][256];            // alphabet list while the tables are parsed, then (32-way) the context ranks
     const int tid = threadIdx.x, lane = tid & 63, sub = lane & (N - 1);
     const bool idle = lane / N >= GROUPS;                          // lanes beyond the groups in use
     const int grp = idle ? 0 : lane / N;
@@ -212,17 +212,21 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                 if (!err && get_alphabet(tp, tend, A)) err = 1;
                 if (!err) {
                     for (int i = 0; i < 512; i++) tabs[i] = 0;
-                    for (int i = 0; i < 256 && !err; i++) {
-                        if (!((A[i >> 5] >> (i & 31)) & 1u)) continue;
+                    // the alphabet as a list (in the LDS bytes that hold the context ranks later): a row is walked over its TOKENS -- a
+                    // frequency, or a zero with the number of further zeros to skip -- not over 256 symbols with a bit test each
+                    // (a sparse 256-context table cost 65 k iterations of this single lane: 13 ms)
+                    uint8_t *al = rank_s[(tid >> 6) * GROUPS + grp];
+                    uint32_t nal = 0;
+                    for (int i = 0; i < 256; i++) if ((A[i >> 5] >> (i & 31)) & 1u) al[nal++] = (uint8_t)i;
+                    for (uint32_t ci = 0; ci < nal && !err; ci++) {
+                        const int i = al[ci];
                         const uint32_t first = np;
-                        uint32_t tot = 0, cnt = 0, run = 0;
-                        for (int j = 0; j < 256 && !err; j++) {
-                            if (!((A[j >> 5] >> (j & 31)) & 1u)) continue;
-                            if (run) { run--; continue; }
+                        uint32_t tot = 0, cnt = 0;
+                        for (uint32_t k = 0; k < nal; k++) {
                             uint32_t f = 0;
                             if (get_u7(tp, tend, f)) { err = 1; break; }
-                            if (f == 0) { if (tp >= tend) { err = 1; break; } run = *tp++; }
-                            else { tabs[np++] = (f << 8) | (uint32_t)j; tot += f; cnt++; }
+                            if (f == 0) { if (tp >= tend) { err = 1; break; } k += *tp++; }       // the next *tp symbols are zero as well
+                            else { tabs[np++] = (f << 8) | (uint32_t)al[k]; tot += f; cnt++; }
                         }
                         if (err) break;
                         if (tot > (1u << shift) || (tot & (tot - 1))) { err = 1; break; }
@@ -254,7 +258,8 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
         __builtin_amdgcn_wave_barrier();
         const uint32_t *T = tabs;                                    // where the decode loop reads the order-1 tables
         const uint8_t *lut = nullptr;                                // order-0 slot -> symbol
-        const uint8_t *o1lut = nullptr;                              // order-1 bucket tables (64 bytes per context)
+        const uint8_t *o1lut = nullptr;                              // order-1 bucket tables (64, 16 or 4 bytes per context)
+        uint32_t o1bb = 0;                                           // log2 of the buckets per context
         const uint8_t *dL = nullptr; const uint32_t *dD = nullptr;   // order-1 dense form (small alphabets)
         uint32_t drank0 = 0;
         if constexpr (N == 32) {
@@ -304,14 +309,16 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 } else
-                if (npw + nctx * 16u <= O1_LDS_WORDS) {
-                    const uint32_t sh6 = shift - 6u;
+                // 64 buckets per context when they fit beside the lists, else 16, else 4 (sparse tables with many contexts)
+                if (npw + nctx * 16u <= O1_LDS_WORDS) o1bb = 6; else if (npw + nctx * 4u <= O1_LDS_WORDS) o1bb = 4; else if (npw + nctx <= O1_LDS_WORDS) o1bb = 2;
+                if (o1bb) {
+                    const uint32_t sh6 = shift - o1bb, nb = 1u << o1bb;
                     for (uint32_t i = (uint32_t)sub; i < 256; i += N) {
                         const uint32_t cnt = P[256 + i], base = P[i];
                         if (!cnt) continue;
-                        uint8_t *l8 = (uint8_t *)(P + npw + 16u * rk[i]);
+                        uint8_t *l8 = (uint8_t *)(P + npw) + nb * rk[i];
                         uint32_t k = 0;
-                        for (uint32_t bkt = 0; bkt < 64; bkt++) {
+                        for (uint32_t bkt = 0; bkt < nb; bkt++) {
                             const uint32_t sl = bkt << sh6;
                             while (k + 1 < cnt && (P[base + k + 1] >> 8) <= sl) k++;
                             l8[bkt] = (uint8_t)k;
@@ -392,7 +399,12 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                         const uint32_t info = T[ctx], base = info & 0x1fffu;
                         if ((info >> 21) == 0) err = 1;               // context never seen by the encoder
                         else {
-                            uint32_t lo = o1lut[64u * ((info >> 13) & 0xffu) + (m >> (shift - 6u))];
+                            const uint32_t bk = m >> (shift - o1bb), bofs = ((info >> 13) & 0xffu) << o1bb;
+                            uint32_t lo = o1lut[bofs + bk];
+                            if (o1bb < 6u) {                          // few, wide buckets: binary search between this bucket's start and the next one's
+                                uint32_t hi = bk + 1u < (1u << o1bb) ? (uint32_t)o1lut[bofs + bk + 1u] + 1u : (info >> 21);
+                                while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if ((T[base + mid] >> 8) <= m) lo = mid; else hi = mid; }
+                            }
                             uint32_t e = T[base + lo], e1 = T[base + lo + 1];
                             while ((e1 >> 8) <= m) { lo++; e = e1; e1 = T[base + lo + 1]; }   // the list ends with (range << 8) > m
                             sym = e & 0xffu; cum = e >> 8; f = (e1 >> 8) - cum;
