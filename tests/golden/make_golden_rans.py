@@ -6,15 +6,18 @@ expected plaintext cannot come from running the reference.  It is derived INDEPE
 rANS decoder from the fixture's .sam / .bam twin: the QS data series of a CRAM slice is the concatenation
 of the records' quality values (QUAL - 33), the RN series the read names each followed by the
 BYTE_ARRAY_STOP byte, BF / RL / AP the ITF8-coded flags, read lengths and positions (absolute, or deltas
-from the slice start when the preservation map says AP is delta-coded), and a one-byte aux tag (type c / C)
-the tag values of the records in order.  Blocks whose content cannot be derived that way are stored with
+from the slice start when the preservation map says AP is delta-coded), TS the ITF8-coded template lengths,
+SC the soft-clipped bases of each S CIGAR op followed by the stop byte, a one-byte aux tag (type c / C) the
+tag values of the records in order, and a string tag (type Z) ITF8(length + 1), the value and its NUL per
+record (the 900 KB ZZ:Z tag of xx#large_aux is the largest real order-1 stream the fixtures hold).  Blocks whose content cannot be derived that way are stored with
 their declared raw size only ("size-only" vectors).
 
 Output: tests/golden/rans4x8/<file>.<n>.bin (compressed block payload), MANIFEST.json
-(content id, order, raw size, series name, expected plaintext hex or null).
+(content id, order, raw size, series name, expected plaintext hex or null; plaintexts over 4 KiB go to
+<file>.<n>.bin.plain.z, zlib-packed, named by "expected_z").
 Needs /root/reference; run in the build container.
 """
-import json, os, struct, sys
+import json, os, re, struct, sys, zlib
 
 REF = "/root/reference/test"
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -108,10 +111,20 @@ def containers(b):
 
 class Rec(tuple):
     """(name, qual text) + .flag .pos .seqlen .aux ({tag: (type, value)} for one-byte integer tags)"""
-    def __new__(cls, name, qual, flag, pos, seqlen, aux):
+    def __new__(cls, name, qual, flag, pos, seqlen, aux, clips=b"", tlen=0):
         o = super().__new__(cls, (name, qual))
         o.flag, o.pos, o.seqlen, o.aux = flag, pos, seqlen, aux
+        o.clips, o.tlen = clips, tlen                               # clips: list of soft-clipped base runs, in read order
         return o
+
+
+def soft_clips(cigar_ops, seq):
+    """[(op char, length)] + the read's bases -> the soft-clipped runs (what the SC series stores, one per S op)"""
+    out, at = [], 0
+    for op, ln in cigar_ops:
+        if op == "S": out.append(seq[at:at + ln].encode())
+        if op in "MIS=X": at += ln
+    return out
 
 
 def sam_records(path):
@@ -121,7 +134,13 @@ def sam_records(path):
     for ln in open(path):
         if ln.startswith("@"): continue
         f = ln.rstrip("\n").split("\t")
-        recs.append(Rec(f[0], f[10], int(f[1]), int(f[3]), 0 if f[9] == "*" else len(f[9]), {}))
+        aux = {}
+        for t in f[11:]:
+            tag, ty, val = t.split(":", 2)
+            if ty == "Z": aux[tag] = ("Z", val.encode("latin1"))
+        ops = [] if f[5] == "*" else [(m[1], int(m[0])) for m in re.findall(r"(\d+)([MIDNSHP=X])", f[5])]
+        recs.append(Rec(f[0], f[10], int(f[1]), int(f[3]), 0 if f[9] == "*" else len(f[9]), aux,
+                        soft_clips(ops, f[9]), int(f[8])))
     return recs
 
 
@@ -137,6 +156,10 @@ def bam_records(path):
     while p < len(d):
         bs = struct.unpack_from("<i", d, p)[0]; q = p + 4; p = q + bs
         _, pos, lname, _, _, ncig, flag, lseq = struct.unpack_from("<iiBBHHHi", d, q)
+        tlen = struct.unpack_from("<i", d, q + 28)[0]
+        cig = struct.unpack_from("<%dI" % ncig, d, q + 32 + lname)
+        packed = d[q + 32 + lname + 4 * ncig:q + 32 + lname + 4 * ncig + (lseq + 1) // 2]
+        seq = "".join("=ACMGRSVTWYHKDBN"[(packed[i >> 1] >> (4 if i % 2 == 0 else 0)) & 15] for i in range(lseq))
         name = d[q + 32:q + 32 + lname - 1].decode()
         a = q + 32 + lname + 4 * ncig + (lseq + 1) // 2
         qual = d[a:a + lseq]
@@ -147,12 +170,14 @@ def bam_records(path):
         while a < p:
             tag, ty = d[a:a + 2].decode(), chr(d[a + 2]); a += 3
             if ty in ("c", "C"): aux[tag] = (ty, d[a])
+            if ty == "Z": aux[tag] = ("Z", d[a:d.index(b"\0", a)])
             if ty in size: a += size[ty]
             elif ty in ("Z", "H"): a = d.index(b"\0", a) + 1
             elif ty == "B":
                 sub = chr(d[a]); cnt = struct.unpack_from("<i", d, a + 1)[0]; a += 5 + cnt * size[sub]
             else: raise ValueError(ty)
-        recs.append(Rec(name, qtxt, flag, pos + 1, lseq, aux))
+        recs.append(Rec(name, qtxt, flag, pos + 1, lseq, aux,
+                        soft_clips([("MIDNSHP=X"[c & 15], c >> 4) for c in cig], seq), tlen))
     return recs
 
 
@@ -198,13 +223,23 @@ def main():
                     elif key == "??" and cid >= 0x410000:           # aux tag block: content id = tag << 8 | type
                         tag, ty = bytes([(cid >> 16) & 0xFF, (cid >> 8) & 0xFF]).decode("latin1"), chr(cid & 0xFF)
                         if ty in ("c", "C") and all(tag in r.aux for r in mine): exp = bytes(r.aux[tag][1] for r in mine)
+                        # a string tag is a BYTE_ARRAY_LEN whose length and bytes share the block: ITF8(len + 1), value, NUL
+                        if ty == "Z": exp = b"".join(put_itf8(len(r.aux[tag][1]) + 1) + r.aux[tag][1] + b"\0"
+                                                     for r in mine if r.aux.get(tag, ("", 0))[0] == "Z")
+                    elif key == "SC" and stop is not None:
+                        exp = b"".join(c + bytes([stop]) for r in mine for c in r.clips)
+                    elif key == "TS":
+                        exp = b"".join(put_itf8(r.tlen & 0xFFFFFFFF) for r in mine)
                     if exp is not None and len(exp) != usz: exp = None
                 name = f"{cram.replace('#', '_')}.{nfile}.bin"; nfile += 1
                 open(os.path.join(OUT, name), "wb").write(data)
                 man[name] = {"source": "test/" + cram, "content_id": cid, "series": key, "order": data[0], "csize": csz,
-                             "usize": usz, "expected_hex": exp.hex() if exp is not None else None}
+                             "usize": usz, "expected_hex": exp.hex() if exp is not None and len(exp) <= 4096 else None}
+                if exp is not None and len(exp) > 4096:             # a long plaintext travels zlib-packed beside the stream
+                    open(os.path.join(OUT, name + ".plain.z"), "wb").write(zlib.compress(exp, 9))
+                    man[name]["expected_z"] = name + ".plain.z"
     json.dump(man, open(os.path.join(OUT, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
-    pinned = sum(1 for v in man.values() if v["expected_hex"] is not None)
+    pinned = sum(1 for v in man.values() if v["expected_hex"] is not None or "expected_z" in v)
     print(len(man), "rANS 4x8 blocks,", pinned, "with SAM-derived plaintext;", "orders", sorted({v['order'] for v in man.values()}))
 
 

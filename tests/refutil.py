@@ -134,8 +134,10 @@ def rans_golden_cases():
     man = json.load(open(os.path.join(RANS_GOLDEN, "MANIFEST.json")))
     for name in sorted(man):
         v = man[name]
-        yield name, open(os.path.join(RANS_GOLDEN, name), "rb").read(), v["usize"], \
-            (bytes.fromhex(v["expected_hex"]) if v["expected_hex"] is not None else None), v["order"]
+        exp = bytes.fromhex(v["expected_hex"]) if v["expected_hex"] is not None else None
+        if "expected_z" in v:                                      # long plaintexts travel zlib-packed beside the stream
+            exp = zlib.decompress(open(os.path.join(RANS_GOLDEN, v["expected_z"]), "rb").read())
+        yield name, open(os.path.join(RANS_GOLDEN, name), "rb").read(), v["usize"], exp, v["order"]
 
 
 # ------------------------------------------------------------------ rANS Nx16 (CRAM 3.1) -- parity unpinned

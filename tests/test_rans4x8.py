@@ -42,7 +42,7 @@ def test_oracle_decodes_reference_cram_fixture_blocks(rorc):
         for o in (0, 1):                          # our encoder's streams are decodable and lossless
             rc2, back = rorc.decode(rorc.encode(out, o))
             assert rc2 == 0 and back == out
-    assert pinned >= 20                  # QS, RN, BF, RL, AP and one-byte aux tags derived from the .sam / .bam twins: 7 order-1, 13 order-0
+    assert pinned >= 28                  # QS, RN, SC, BF, RL, AP, TS, one-byte and string aux tags derived from the .sam / .bam twins
 
 
 @pytest.mark.parametrize("kind", ["qual4", "qual41", "bases", "bytes", "const"])
