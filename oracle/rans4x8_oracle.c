@@ -13,10 +13,11 @@
  *
  * Pinning: tests/golden/rans4x8/ holds every rANS 4x8 block of the reference's CRAM v3.0 test
  * files (test/ce#5b_java.cram, auxf#values_java.cram, xx#large_aux_java.cram, range.cram --
- * written by an independent Java implementation).  For the QS blocks the expected plaintext is
- * derived from the .sam twins WITHOUT any rANS code (tests/golden/make_golden_rans.py); all other
- * blocks are checked for their declared size and for encode->decode identity.
- * Order-0 plaintext is therefore pinned only through sizes + round trips: "parity partially pinned".
+ * the first three written by an independent Java implementation, range.cram by htslib).  For 28
+ * of the 44 blocks, of both orders, the expected plaintext is derived from the .sam / .bam twins
+ * WITHOUT any rANS code (QS, RN, SC, BF, RL, TS, AP, one-byte and string aux tags:
+ * tests/golden/make_golden_rans.py); the other blocks are checked for their declared size and for
+ * encode->decode identity.  The DECODER is pinned by those; the encoder through decode(encode(x)).
  *
  * Stream layout (all little endian):
  *   u8  order (0|1)   u32 compressed size (bytes after this 9-byte prefix)   u32 uncompressed size
