@@ -1,0 +1,184 @@
+// arith_dev.h -- device-side range coder and adaptive model shared by the CRAM 3.1 adaptive arithmetic coder (arith.hip, block
+// method 6) and the fqzcomp quality codec (fqzcomp.hip, block method 7): the wave-cooperative restatement of htscodecs'
+// c_range_coder.h / c_simple_model.h (absent submodule; arithmetic per oracle/range_model.h -- PARITY UNPINNED).
+//
+// One wavefront works on one stream.  The range-coder registers are wave-uniform; a model is an array of (freq << 8 | symbol)
+// words kept sorted by frequency, searched by all 64 lanes at once (one read of up to 4 x 64 entries, a DPP prefix sum, one
+// ballot); the compressed bytes are read 64 at a time into one VGPR and picked out with v_readlane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hg_device.h"
+
+namespace hga {
+
+// -DHG_ARITH_PROFILE: per-symbol phase times of the decoder (core-clock ticks), printed by the first wavefront per stream
+#ifdef HG_ARITH_PROFILE
+#define HA_T(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); g_tacc[slot] += n_ - g_tlast; g_tlast = n_; } while (0)
+__device__ unsigned long long g_dummy;
+#define HA_DECL unsigned long long g_tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g_tlast = __builtin_amdgcn_s_memtime()
+#else
+#define HA_T(slot) do { } while (0)
+#endif
+using hg::wave_sync;
+using hg::wave_incl_scan_dpp;
+
+constexpr uint32_t STEP = 16, MAX_FREQ = (1u << 16) - 17u, TOP = 1u << 24;
+enum { F_ORDER = 1, F_RLE = 64 };
+
+__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+
+// 64-byte window over the compressed stream: lane l holds byte pos0 + l
+struct ByteWindow {
+    const uint8_t *base; uint32_t len, pos0, idx, win; bool overrun;
+    __device__ void init(const uint8_t *b, uint32_t n, int lane) { base = b; len = n; pos0 = 0; idx = 0; overrun = false; load(lane); }
+    __device__ void load(int lane) { const uint32_t p = pos0 + (uint32_t)lane; win = p < len ? base[p] : 0u; }
+    __device__ uint32_t next(int lane) {
+        if (idx == 64) { pos0 += 64; idx = 0; load(lane); }
+        if (pos0 + idx >= len) overrun = true;
+        return rl(win, idx++);
+    }
+};
+
+// After the coder step: bump entry x of the model at B (n entries, total at T), halve when due, keep sorted.
+// f_x / f_prev are the frequencies of entries x and x-1 as read before the bump.
+// e_prev = entry x - 1 as the symbol search saw it (HAVE_PREV) -- it came in the same 64-entry read, so the update needs no load.
+__device__ __forceinline__ void model_update(uint32_t *M, uint32_t *TT, uint32_t B, uint32_t n, uint32_t T, uint32_t tot, uint32_t x,
+                                             uint32_t e_x, bool have_prev, uint32_t e_prev, int lane) {
+    uint32_t ex = e_x + (STEP << 8);
+    tot += STEP;
+    if (tot > MAX_FREQ) {                                            // halve every frequency (rare)
+        if (lane == 0) M[B + x] = ex;
+        wave_sync();
+        uint32_t sum = 0;
+        for (uint32_t b = 0; b < n; b += 64) {
+            const uint32_t i = b + (uint32_t)lane;
+            uint32_t f = 0;
+            if (i < n) { const uint32_t e = M[B + i]; f = e >> 8; f -= f >> 1; M[B + i] = (f << 8) | (e & 0xffu); }
+            sum += rl(wave_incl_scan_dpp(f), 63);
+        }
+        tot = sum;
+        wave_sync();
+        ex = M[B + x];
+        have_prev = false;
+    }
+    if (x > 0) {
+        const uint32_t ep = have_prev ? e_prev : M[B + x - 1];
+        if ((ex >> 8) > (ep >> 8)) { if (lane == 0) { M[B + x] = ep; M[B + x - 1] = ex; } }
+        else if (lane == 0) M[B + x] = ex;
+    } else if (lane == 0) M[B + x] = ex;
+    if (lane == 0) TT[T] = tot;
+    wave_sync();
+}
+
+struct Decoder {
+    uint32_t code, range; ByteWindow in; int err;
+#ifdef HG_ARITH_PROFILE
+    unsigned long long g_tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g_tlast = 0;
+#endif
+    __device__ void start(const uint8_t *b, uint32_t n, int lane) {
+#ifdef HG_ARITH_PROFILE
+        g_tlast = __builtin_amdgcn_s_memtime();
+#endif
+        in.init(b, n, lane); err = 0; code = 0; range = 0xffffffffu;
+        for (int i = 0; i < 5; i++) code = (code << 8) | in.next(lane);
+    }
+    // decodes one symbol with the model at B (n entries, total at T)
+    __device__ uint32_t symbol(uint32_t *M, uint32_t *TT, uint32_t B, uint32_t n, uint32_t T, int lane) {
+        HA_T(5);
+        // all (<= 4) 64-entry pieces of the model are requested at once, together with the total: the search below then runs
+        // on registers -- with the pieces fetched one per probe a 256-symbol model in global memory cost up to 4 round trips
+        uint32_t ev[4];
+#pragma unroll
+        for (uint32_t c = 0; c < 4; c++) { const uint32_t i = c * 64u + (uint32_t)lane; ev[c] = (c * 64u < n && i < n) ? M[B + i] : 0u; }
+        const uint32_t tot = TT[T];
+        HA_T(0);
+        const uint32_t r = range / tot, freq = code / r;
+        if (freq >= tot) { err = 1; return 0; }
+        HA_T(1);
+        uint32_t acc0 = 0, x = 0, ex = 0, acc = 0, eprev = 0;
+        bool have_prev = false;
+#pragma unroll
+        for (uint32_t b = 0; b < 256u; b += 64) {
+            if (b >= n) break;
+            const uint32_t i = b + (uint32_t)lane;
+            const uint32_t e = ev[b >> 6];
+            const uint32_t incl = acc0 + wave_incl_scan_dpp(e >> 8);
+            const unsigned long long hit = __ballot(i < n && incl > freq);
+            if (hit) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(hit);
+                x = b + l; ex = rl(e, l); acc = rl(incl, l) - (ex >> 8);
+                if (l) { have_prev = true; eprev = rl(e, l - 1u); }
+                break;
+            }
+            acc0 = rl(incl, 63);
+        }
+        HA_T(2);
+        const uint32_t f = ex >> 8;
+        code -= acc * r; range = r * f;
+        while (range < TOP) { code = (code << 8) | in.next(lane); range <<= 8; }
+        HA_T(3);
+        model_update(M, TT, B, n, T, tot, x, ex, have_prev, eprev, lane);
+        HA_T(4);
+        return ex & 0xffu;
+    }
+};
+
+struct Encoder {
+    uint32_t low, range, carry, cache, ffnum;
+    uint8_t *out; uint32_t opos, oidx, obuf;                         // 64 output bytes are gathered in one VGPR
+    __device__ void start(uint8_t *o) { low = 0; range = 0xffffffffu; carry = 0; cache = 0; ffnum = 0; out = o; opos = 0; oidx = 0; obuf = 0; }
+    __device__ void put(uint32_t b, int lane) {
+        obuf = hg::writelane(b & 0xffu, oidx, obuf);
+        if (++oidx == 64) { out[opos + (uint32_t)lane] = (uint8_t)obuf; opos += 64; oidx = 0; }
+    }
+    __device__ void shift_low(int lane) {
+        if (low < 0xff000000u || carry) {
+            put(cache + carry, lane);
+            while (ffnum) { put(carry - 1u, lane); ffnum--; }
+            cache = low >> 24; carry = 0;
+        } else ffnum++;
+        low <<= 8;
+    }
+    __device__ void encode(uint32_t cum, uint32_t freq, uint32_t tot, int lane) {
+        const uint32_t old = low;
+        range /= tot;
+        low += cum * range;
+        range *= freq;
+        if (low < old) carry = 1;
+        while (range < TOP) { range <<= 8; shift_low(lane); }
+    }
+    __device__ uint32_t finish(int lane) {
+        for (int i = 0; i < 5; i++) shift_low(lane);
+        if ((uint32_t)lane < oidx) out[opos + (uint32_t)lane] = (uint8_t)obuf;
+        return opos + oidx;
+    }
+    // codes `sym` with the model at B (n entries, total at T)
+    __device__ void symbol(uint32_t *M, uint32_t *TT, uint32_t B, uint32_t n, uint32_t T, uint32_t sym, int lane) {
+        uint32_t ev[4];                                                    // the whole model at once (see the decoder)
+#pragma unroll
+        for (uint32_t c = 0; c < 4; c++) { const uint32_t i = c * 64u + (uint32_t)lane; ev[c] = (c * 64u < n && i < n) ? M[B + i] : 0u; }
+        const uint32_t tot = TT[T];
+        uint32_t acc0 = 0, x = 0, ex = 0, acc = 0, eprev = 0;
+        bool have_prev = false;
+#pragma unroll
+        for (uint32_t b = 0; b < 256u; b += 64) {
+            if (b >= n) break;
+            const uint32_t i = b + (uint32_t)lane;
+            const uint32_t e = ev[b >> 6];
+            const uint32_t incl = acc0 + wave_incl_scan_dpp(e >> 8);
+            const unsigned long long hit = __ballot(i < n && (e & 0xffu) == sym);
+            if (hit) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(hit);
+                x = b + l; ex = rl(e, l); acc = rl(incl, l) - (ex >> 8);
+                if (l) { have_prev = true; eprev = rl(e, l - 1u); }
+                break;
+            }
+            acc0 = rl(incl, 63);
+        }
+        encode(acc, ex >> 8, tot, lane);
+        model_update(M, TT, B, n, T, tot, x, ex, have_prev, eprev, lane);
+    }
+};
+
+}  // namespace hga

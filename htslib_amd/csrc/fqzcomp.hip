@@ -1,0 +1,338 @@
+// fqzcomp.hip -- CRAM 3.1 fqzcomp quality codec, block method 7, for MI355X (gfx950).
+//
+// Replaces fqz_decompress as called by cram_uncompress_block (reference cram/cram_io.c:1684-1695; implementation = htscodecs
+// fqzcomp_qual.c, an ABSENT submodule).  Format and arithmetic per oracle/fqzcomp_oracle.c -- PARITY UNPINNED; the kernel is
+// bit-exact with that oracle.
+//
+// A quality stream is ONE adaptive chain: every symbol is coded with the model its 16-bit context selects, and the context is
+// a hash of the previous qualities, the position in the read and the number of changes so far, so symbol i+1 cannot start
+// before symbol i is known.  The parallelism is ACROSS streams (one QS block per CRAM slice; a batch of slices gives hundreds
+// to thousands).  Mapping: one wavefront per stream, as in arith.hip:
+//   * the 65536 quality models (max_sym + 1 entries and their total each) live in a per-wavefront slot of global scratch --
+//     5.5 to 67 MB, far beyond LDS; the model of a symbol is fetched with one 64-lane read (total + up to 4 x 64 entries at
+//     once) and searched with a DPP prefix sum + ballot, so the dependent chain per quality is: model read -> divide -> search
+//     -> context tables (LDS) -> next model read;
+//   * the parameter block (qmap / qtab / ptab / dtab per parameter set, the selector table) is parsed ON THE HOST -- a few
+//     hundred bytes per stream -- and shipped as a fixed-layout image that the wavefront copies to LDS; the record-level models
+//     (4 length bytes, reverse, duplicate, selector) are LDS too;
+//   * output bytes are gathered 64 per store; a record that is reversed or a duplicate of its predecessor is fixed up in
+//     place when it ends (reversal is an involution, so "copy the predecessor as decoded, reverse at the very end" of the
+//     oracle becomes "copy straight or mirrored, depending on whether the two reverse flags agree").
+// Streams with more than HGQ_MAX_PARAM parameter sets report HG_BLOCK_EUNSUPPORTED (the caller keeps its CPU codec).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "htsgpu.h"
+#include "hg_device.h"
+#include "hg_internal.h"
+#include "arith_dev.h"
+
+namespace hgq {
+using hg::wave_sync;
+using hga::rl;
+
+enum { GF_MULTI = 1, GF_STAB = 2, GF_REV = 4, PF_DEDUP = 2, PF_LEN = 4, PF_SEL = 8, PF_QMAP = 16, PF_PTAB = 32, PF_DTAB = 64, PF_QTAB = 128 };
+constexpr uint32_t FQZ_VERS = 5, CTX_SIZE = 65536;
+constexpr int HGQ_MAX_PARAM = 2;
+
+// ---- the per-stream image the host builds (32-bit words) ------------------------------------------------------------
+// head: [0] gflags [1] nparam [2] max_sel [3] ns = max_sym + 1 [4] offset of the range-coder bytes in the stream [5] ulen
+//       [6] (encoder) number of records [7] reserved; then stab (256 bytes = 64 words); then per parameter set:
+//       8 words {context, pflags, qmask, qshift, qloc, sloc, ploc, dloc}, qmap (256 bytes), qtab / dtab (256 x u16 each), ptab (1024 x u16)
+constexpr uint32_t IMG_HEAD = 8, IMG_STAB = 64, IMG_PSCAL = 8, IMG_QMAP = 64, IMG_QTAB = 128, IMG_DTAB = 128, IMG_PTAB = 512;
+constexpr uint32_t IMG_PARAM = IMG_PSCAL + IMG_QMAP + IMG_QTAB + IMG_DTAB + IMG_PTAB;          // 840 words
+constexpr uint32_t IMG_WORDS = IMG_HEAD + IMG_STAB + HGQ_MAX_PARAM * IMG_PARAM;               // 1752 words
+// record-level models in LDS: [total, entries...] each
+constexpr uint32_t M_LEN = 0, M_REV = 4 * 257, M_DUP = M_REV + 3, M_SEL = M_DUP + 3, M_WORDS = M_SEL + 257;   // 1291 words
+constexpr uint32_t POOLW = ((M_WORDS + 3) & ~3u) + IMG_WORDS;
+
+// ---- host: parameter block -> image ----------------------------------------------------------------------------------
+static int read_array_h(const uint8_t *in, size_t in_size, uint16_t *array, int size) {
+    uint8_t R[1024];
+    int i, j, z, last = -1;
+    for (i = j = z = 0; z < size && (size_t)i < in_size; i++) {
+        const int run = in[i];
+        R[j++] = (uint8_t)run;
+        z += run;
+        if (run == last) {
+            if ((size_t)i + 1 >= in_size) return -1;
+            int copy = in[++i];
+            z += run * copy;
+            while (copy-- && z <= size && j < 1024) R[j++] = (uint8_t)run;
+        }
+        if (j >= 1024) return -1;
+        last = run;
+    }
+    const int nb = i, rmax = j;
+    for (i = j = z = 0; j < size; i++) {
+        int len = 0, part;
+        if (z >= rmax) return -1;
+        do { part = R[z++]; len += part; } while (part == 255 && z < rmax);
+        while (len && j < size) { len--; array[j++] = (uint16_t)i; }
+    }
+    return nb;
+}
+
+// 0 ok, -1 malformed, -3 more parameter sets than the kernel keeps in LDS
+static int build_image(const uint8_t *in, uint32_t n, uint32_t want_ulen, uint32_t *img) {
+    memset(img, 0, IMG_WORDS * 4);
+    uint32_t ulen = 0, k = 0; uint8_t c;
+    do { if (k >= n || k >= 5) return -1; c = in[k++]; ulen = (ulen << 7) | (c & 0x7fu); } while (c & 0x80u);
+    if (ulen != want_ulen) return -1;
+    size_t p = k;
+    if ((size_t)n < p + 10 || in[p++] != FQZ_VERS) return -1;
+    const uint32_t gflags = in[p++];
+    const uint32_t nparam = (gflags & GF_MULTI) ? in[p++] : 1u;
+    if (nparam == 0) return -1;
+    uint32_t max_sel = nparam > 1 ? nparam - 1 : 0;
+    uint8_t *stab = (uint8_t *)(img + IMG_HEAD);
+    if (gflags & GF_STAB) {
+        max_sel = in[p++];
+        uint16_t t[256];
+        const int r = read_array_h(in + p, n - p, t, 256);
+        if (r < 0) return -1;
+        p += (size_t)r;
+        for (int i = 0; i < 256; i++) { if (t[i] >= nparam) return -1; stab[i] = (uint8_t)t[i]; }
+    } else {
+        for (uint32_t i = 0; i < 256; i++) stab[i] = (uint8_t)(i < nparam ? i : nparam - 1);
+    }
+    if (nparam > (uint32_t)HGQ_MAX_PARAM) return -3;
+    uint32_t max_sym = 0;
+    for (uint32_t s = 0; s < nparam; s++) {
+        uint32_t *P = img + IMG_HEAD + IMG_STAB + s * IMG_PARAM;
+        if (p + 7 > n) return -1;
+        const uint32_t pflags = in[p + 2], msym = in[p + 3];
+        P[0] = in[p] | (uint32_t)in[p + 1] << 8; P[1] = pflags;
+        P[2] = (1u << (in[p + 4] >> 4)) - 1u; P[3] = in[p + 4] & 15u;
+        P[4] = in[p + 5] >> 4; P[5] = in[p + 5] & 15u; P[6] = in[p + 6] >> 4; P[7] = in[p + 6] & 15u;
+        p += 7;
+        uint8_t *qmap = (uint8_t *)(P + IMG_PSCAL);
+        uint16_t *qtab = (uint16_t *)(P + IMG_PSCAL + IMG_QMAP), *dtab = qtab + 256, *ptab = dtab + 256;
+        for (uint32_t i = 0; i < 256; i++) { qmap[i] = (uint8_t)i; qtab[i] = (uint16_t)i; }
+        if (pflags & PF_QMAP) { if (p + msym > n) return -1; for (uint32_t i = 0; i < msym; i++) qmap[i] = in[p++]; }
+        if (pflags & PF_QTAB) { const int r = read_array_h(in + p, n - p, qtab, 256); if (r < 0) return -1; p += (size_t)r; }
+        if (pflags & PF_PTAB) { const int r = read_array_h(in + p, n - p, ptab, 1024); if (r < 0) return -1; p += (size_t)r; }
+        if (pflags & PF_DTAB) { const int r = read_array_h(in + p, n - p, dtab, 256); if (r < 0) return -1; p += (size_t)r; }
+        if (msym > max_sym) max_sym = msym;
+    }
+    if (p > n) return -1;
+    img[0] = gflags; img[1] = nparam; img[2] = max_sel; img[3] = max_sym + 1u; img[4] = (uint32_t)p; img[5] = ulen;
+    return 0;
+}
+
+// ---- device ----------------------------------------------------------------------------------------------------------
+struct ParamRegs { uint32_t context, pflags, qmask, qshift, qloc, sloc, ploc, dloc; const uint32_t *base; };
+__device__ __forceinline__ void load_param(ParamRegs &R, const uint32_t *img, uint32_t x) {
+    const uint32_t *P = img + IMG_HEAD + IMG_STAB + x * IMG_PARAM;
+    R.context = P[0]; R.pflags = P[1]; R.qmask = P[2]; R.qshift = P[3]; R.qloc = P[4]; R.sloc = P[5]; R.ploc = P[6]; R.dloc = P[7];
+    R.base = P;
+}
+struct State { uint32_t qctx, p, delta, prevq, s; };
+__device__ __forceinline__ uint32_t update_ctx(const ParamRegs &R, State &st, uint32_t q) {
+    const uint16_t *qtab = (const uint16_t *)(R.base + IMG_PSCAL + IMG_QMAP), *dtab = qtab + 256, *ptab = dtab + 256;
+    const uint32_t tq = qtab[q], tp = ptab[st.p < 1023u ? st.p : 1023u], td = dtab[st.delta < 255u ? st.delta : 255u];   // three independent LDS reads
+    uint32_t c = R.context;
+    st.qctx = (st.qctx << R.qshift) + tq;
+    c += (st.qctx & R.qmask) << R.qloc;
+    if (R.pflags & PF_PTAB) c += tp << R.ploc;
+    if (R.pflags & PF_DTAB) { c += td << R.dloc; st.delta += st.prevq != q; st.prevq = q; }
+    if (R.pflags & PF_SEL) c += st.s << R.sloc;
+    st.p--;
+    return c & (CTX_SIZE - 1u);
+}
+__device__ __forceinline__ void lds_model_init(uint32_t *m, uint32_t n, int lane) {
+    for (uint32_t i = (uint32_t)lane; i <= n; i += 64) m[i] = i ? ((1u << 8) | (i - 1u)) : n;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64)
+void fqz_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc, const uint32_t *__restrict__ images,
+                       uint32_t nstreams, uint8_t *out, int32_t *status, uint32_t *gscratch, unsigned long long slot_words) {
+    __shared__ uint32_t pool[WAVES][POOLW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t slot = blockIdx.x * WAVES + wv;
+    uint32_t *gq = gscratch + (size_t)slot * slot_words;
+    uint32_t *mdl = pool[wv], *img = pool[wv] + ((M_WORDS + 3) & ~3u);
+    for (uint32_t k = slot; k < nstreams; k += gridDim.x * WAVES) {
+        const hg_stream_desc d = desc[k];
+        for (uint32_t i = (uint32_t)lane; i < IMG_WORDS; i += 64) img[i] = images[(size_t)d.scratch_off * IMG_WORDS + i];
+        wave_sync();
+        const uint32_t gflags = img[0], max_sel = img[2], ns = img[3], data_off = img[4], ulen = img[5];
+        const uint8_t *stab = (const uint8_t *)(img + IMG_HEAD);
+        uint8_t *o = out + d.out_off;
+        // models
+        {
+            const uint32_t w = ns + 1u;
+            uint32_t r = (uint32_t)lane % w;                           // word i of the slot is word (i mod w) of its model
+            const uint32_t step = 64u % w;
+            for (size_t i = (size_t)lane; i < (size_t)CTX_SIZE * w; i += 64) {
+                gq[i] = r ? ((1u << 8) | (r - 1u)) : ns;
+                r += step; if (r >= w) r -= w;
+            }
+            for (int j = 0; j < 4; j++) lds_model_init(mdl + M_LEN + j * 257, 256, lane);
+            lds_model_init(mdl + M_REV, 2, lane); lds_model_init(mdl + M_DUP, 2, lane);
+            lds_model_init(mdl + M_SEL, max_sel + 1u, lane);
+            wave_sync();
+        }
+        hga::Decoder D;
+        D.start(in + d.in_off + data_off, d.in_len - data_off, lane);
+        ParamRegs R; load_param(R, img, 0);
+        State st = {0, 0, 0, 0, 0};
+        uint32_t i = 0, last = 0, last_len = 0, keep = 0, prev_rev = 0;
+        bool first_len = true;
+        int err = 0;
+        auto lsym = [&](uint32_t base, uint32_t n) { return D.symbol(mdl, mdl, base + 1u, n, base, lane); };
+        auto flush_tail = [&]() { if ((uint32_t)lane < (i & 63u)) o[(i & ~63u) + (uint32_t)lane] = (uint8_t)keep; wave_sync(); };
+        auto reload_tail = [&]() { wave_sync(); if ((uint32_t)lane < (i & 63u)) keep = o[(i & ~63u) + (uint32_t)lane]; };
+        uint32_t rec_start = 0, rec_len = 0, rec_rev = 0;
+        while (i < ulen) {
+            if (st.p == 0) {
+                uint32_t s = 0;
+                if (max_sel > 0) { s = lsym(M_SEL, max_sel + 1u); if (D.err) break; }
+                st.s = s;
+                load_param(R, img, stab[s]);
+                uint32_t len;
+                if (!(R.pflags & PF_LEN) || first_len) {
+                    len = lsym(M_LEN, 256);
+                    len |= lsym(M_LEN + 257, 256) << 8;
+                    len |= lsym(M_LEN + 2 * 257, 256) << 16;
+                    len |= lsym(M_LEN + 3 * 257, 256) << 24;
+                    if (D.err) break;
+                    first_len = false; last_len = len;
+                } else len = last_len;
+                if (len == 0 || len > ulen - i) { err = 1; break; }
+                uint32_t rv = 0;
+                if (gflags & GF_REV) { rv = lsym(M_REV, 2); if (D.err) break; }
+                rec_start = i; rec_len = len; rec_rev = rv;
+                if (R.pflags & PF_DEDUP) {
+                    const uint32_t dup = lsym(M_DUP, 2);
+                    if (D.err) break;
+                    if (dup) {
+                        if (i < len) { err = 1; break; }
+                        flush_tail();
+                        // the predecessor sits in o[i - len, i) in its FINAL orientation: mirrored iff the two reverse flags differ
+                        const bool mirror = rv != prev_rev;
+                        for (uint32_t b = (uint32_t)lane; b < len; b += 64) o[i + b] = mirror ? o[i - 1u - b] : o[i - len + b];
+                        i += len;
+                        prev_rev = rv;
+                        reload_tail();
+                        continue;
+                    }
+                }
+                st.p = len; st.delta = 0; st.qctx = 0; st.prevq = 0;
+                last = R.context;
+            }
+            const size_t mb = (size_t)last * (ns + 1u);
+            const uint32_t Q = D.symbol(gq + mb, gq + mb, 1u, ns, 0u, lane);
+            if (D.err) break;
+            const uint32_t q = ((const uint8_t *)(R.base + IMG_PSCAL))[Q];
+            last = update_ctx(R, st, Q);
+            if ((uint32_t)lane == (i & 63u)) keep = q;
+            if ((i & 63u) == 63u) o[i - 63u + (uint32_t)lane] = (uint8_t)keep;       // 64 qualities per store
+            i++;
+            if (st.p == 0 && (gflags & GF_REV)) {                                // the record is complete
+                if (rec_rev) {
+                    flush_tail();
+                    for (uint32_t b = (uint32_t)lane; b < rec_len / 2u; b += 64) {
+                        const uint8_t x = o[rec_start + b], y = o[rec_start + rec_len - 1u - b];
+                        o[rec_start + b] = y; o[rec_start + rec_len - 1u - b] = x;
+                    }
+                    reload_tail();
+                }
+                prev_rev = rec_rev;
+            }
+        }
+        if (!err && !D.err && (ulen & 63u) && (uint32_t)lane < (ulen & 63u) && i == ulen) o[(ulen & ~63u) + (uint32_t)lane] = (uint8_t)keep;
+        if (D.err || D.in.overrun || st.p != 0 || i != ulen) err = 1;
+        status[k] = err ? -1 : 0;                                     // every lane stores the same word
+        wave_sync();
+    }
+}
+
+}  // namespace hgq
+
+namespace hg {
+// images: one IMG_WORDS image per stream (desc[k].scratch_off = its index); d_scratch: gridDim * WAVES slots of slot_words words
+int launch_fqz_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_images, size_t n, void *d_out,
+                      int32_t *d_status, uint32_t *d_scratch, size_t slots, size_t slot_words, hipStream_t s) {
+    (void)ctx;
+    if (!n) return HG_OK;
+    constexpr int WAVES = 2;
+    const size_t wgs = (slots + WAVES - 1) / WAVES;
+    hipLaunchKernelGGL((hgq::fqz_decode_kernel<WAVES>), dim3((unsigned)wgs), dim3(WAVES * 64), 0, s, (const uint8_t *)d_in, d_desc, d_images,
+                       (uint32_t)n, (uint8_t *)d_out, d_status, d_scratch, (unsigned long long)slot_words);
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+}  // namespace hg
+
+// Host convenience for n method-7 blocks: in[i]/in_len[i] -> out[i] (out_len[i] = the block's uncompressed size, which must
+// equal the size stored in the stream).  status[i] = 0, -1 (malformed) or HG_BLOCK_EUNSUPPORTED.  Synchronous.
+extern "C" int hg_fqz_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n, uint8_t *const *out,
+                                  const uint32_t *out_len, int32_t *status) {
+    if (!ctx || (n && (!in || !in_len || !out || !out_len || !status))) return HG_EINVAL;
+    if (n == 0) return HG_OK;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
+    std::vector<uint32_t> images; images.reserve(n * hgq::IMG_WORDS);
+    std::vector<size_t> live;                                         // streams that reach the device, longest first
+    uint32_t max_ns = 0;
+    for (size_t i = 0; i < n; i++) {
+        status[i] = 0;
+        if (out_len[i] == 0) { continue; }
+        uint32_t img[hgq::IMG_WORDS];
+        const int r = hgq::build_image(in[i], in_len[i], out_len[i], img);
+        if (r) { status[i] = r == -3 ? HG_BLOCK_EUNSUPPORTED : -1; continue; }
+        images.insert(images.end(), img, img + hgq::IMG_WORDS);
+        live.push_back(i);
+        max_ns = std::max(max_ns, img[3]);
+    }
+    int rc = HG_OK;
+    const size_t m = live.size();
+    if (m) {
+        std::vector<size_t> ord(m);
+        for (size_t k = 0; k < m; k++) ord[k] = k;
+        std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return out_len[live[a]] > out_len[live[b]]; });
+        std::vector<hg_stream_desc> desc(m);
+        std::vector<const uint8_t *> sp(m); std::vector<uint32_t> sl(m), ol(m); std::vector<uint64_t> so(m), oo(m); std::vector<uint8_t *> dp(m);
+        uint64_t ioff = 0, ooff = 0;
+        for (size_t k = 0; k < m; k++) {
+            const size_t i = live[ord[k]];
+            desc[k].in_off = ioff; desc[k].in_len = in_len[i]; desc[k].out_off = ooff; desc[k].out_len = out_len[i];
+            desc[k].scratch_off = (uint32_t)ord[k]; desc[k].reserved = 0;
+            sp[k] = in[i]; sl[k] = in_len[i]; so[k] = ioff; oo[k] = ooff; ol[k] = out_len[i]; dp[k] = out[i];
+            ioff += ((uint64_t)in_len[i] + 15u) & ~15ull; ooff += ((uint64_t)out_len[i] + 63u) & ~63ull;
+        }
+        // resident wavefronts: every one owns 65536 models in scratch, so the count is bounded by memory as well as by the chip
+        const size_t slot_words = (size_t)hgq::CTX_SIZE * (max_ns + 1u);
+        size_t slots = std::min<size_t>(m, (size_t)ctx->cus * 8);
+        size_t freeb = 0, totalb = 0;
+        if (hipMemGetInfo(&freeb, &totalb) == hipSuccess) {
+            const size_t have = freeb + ctx->d_scratch_cap[6];
+            const size_t fit = (have / 2) / (slot_words * 4);
+            if (fit < 1) return HG_ENOMEM;
+            slots = std::min(slots, fit);
+        }
+        slots = (slots + 1) & ~(size_t)1;
+        if ((rc = hg::ensure_scratch(ctx, 0, ioff + 64)) || (rc = hg::ensure_scratch(ctx, 1, ooff + 64)) ||
+            (rc = hg::ensure_scratch(ctx, 2, m * sizeof(hg_stream_desc))) || (rc = hg::ensure_scratch(ctx, 3, m * 4 + 64)) ||
+            (rc = hg::ensure_scratch(ctx, 4, images.size() * 4 + 64)) || (rc = hg::ensure_scratch(ctx, 6, slots * slot_words * 4 + 64))) return rc;
+        hipStream_t s = ctx->stream;
+        bool ok = hg::stage_upload(ctx, sp.data(), sl.data(), so.data(), nullptr, m, ioff, (uint8_t *)ctx->d_scratch[0], s) == HG_OK;
+        ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc.data(), m * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess &&
+             hipMemcpyAsync(ctx->d_scratch[4], images.data(), images.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess;
+        rc = ok ? hg::launch_fqz_decode(ctx, ctx->d_scratch[0], (const hg_stream_desc *)ctx->d_scratch[2], (const uint32_t *)ctx->d_scratch[4], m,
+                                        ctx->d_scratch[1], (int32_t *)ctx->d_scratch[3], (uint32_t *)ctx->d_scratch[6], slots, slot_words, s)
+                : HG_ELAUNCH;
+        if (rc == HG_OK) {
+            std::vector<int32_t> st(m);
+            ok = hipMemcpyAsync(st.data(), ctx->d_scratch[3], m * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+            for (size_t k = 0; k < m && ok; k++) { status[live[ord[k]]] = st[k]; if (st[k] != 0) ol[k] = 0; }
+            ok = ok && hg::stage_download(ctx, (const uint8_t *)ctx->d_scratch[1], oo.data(), ol.data(), dp.data(), m, s) == HG_OK;
+            if (!ok) rc = HG_ELAUNCH;
+        }
+    }
+    if (rc != HG_OK) return rc;
+    for (size_t i = 0; i < n; i++) if (status[i] != 0) return HG_EBLOCK;
+    return HG_OK;
+}

@@ -204,7 +204,7 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
     if (!ctx || (n && (!method || !in || !in_len || !out || !out_len || !status))) return HG_EINVAL;
     hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     // partition by method
-    size_t ng = 0, nr = 0, nx_ = 0, na = 0, nt = 0;
+    size_t ng = 0, nr = 0, nx_ = 0, na = 0, nt = 0, nq = 0;
     for (size_t i = 0; i < n; i++) {
         status[i] = 0;
         if (out_len[i] == 0 || method[i] == HG_CRAM_RAW) {            // cram_io.c:1594-1603: nothing to do
@@ -214,14 +214,15 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
         else if (method[i] == HG_CRAM_RANSNx16) nx_++;
         else if (method[i] == HG_CRAM_ARITH) na++;
         else if (method[i] == HG_CRAM_TOK3) nt++;
+        else if (method[i] == HG_CRAM_FQZ) nq++;
         else status[i] = HG_BLOCK_EUNSUPPORTED;
     }
-    // Five independent codec families; each runs on its own thread / sibling context / HIP stream when more than one
+    // Six independent codec families; each runs on its own thread / sibling context / HIP stream when more than one
     // is present, so their kernels (each latency-bound on its slowest block) overlap on the GPU.
-    auto run_entropy = [&](hg_ctx *ctx, int pass) -> int {            // 0 Nx16, 1 the range coder, 2 the name tokeniser
+    auto run_entropy = [&](hg_ctx *ctx, int pass) -> int {            // 0 Nx16, 1 the range coder, 2 the name tokeniser, 5 fqzcomp
         int rc = HG_OK;
-        const int32_t meth = pass == 2 ? HG_CRAM_TOK3 : pass ? HG_CRAM_ARITH : HG_CRAM_RANSNx16;
-        const size_t nx = pass == 2 ? nt : pass ? na : nx_;
+        const int32_t meth = pass == 5 ? HG_CRAM_FQZ : pass == 2 ? HG_CRAM_TOK3 : pass ? HG_CRAM_ARITH : HG_CRAM_RANSNx16;
+        const size_t nx = pass == 5 ? nq : pass == 2 ? nt : pass ? na : nx_;
         std::vector<const uint8_t *> xin_(nx); std::vector<uint8_t *> xout_(nx); std::vector<uint32_t> xl_(nx), xo_(nx);
         std::vector<int32_t> xs_(nx); std::vector<size_t> map_(nx);
         const uint8_t **xin = xin_.data(); uint8_t **xout = xout_.data(); uint32_t *xl = xl_.data(), *xo = xo_.data();
@@ -229,7 +230,7 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
         size_t k = 0;
         for (size_t i = 0; i < n; i++)
             if (out_len[i] && method[i] == meth) { xin[k] = in[i]; xout[k] = out[i]; xl[k] = in_len[i]; xo[k] = out_len[i]; map[k] = i; k++; }
-        int r = pass == 2 ? hg_tok3_decode_host(ctx, xin, xl, nx, xout, xo, xs)
+        int r = pass == 5 ? hg_fqz_decode_host(ctx, xin, xl, nx, xout, xo, xs) : pass == 2 ? hg_tok3_decode_host(ctx, xin, xl, nx, xout, xo, xs)
               : pass ? hg_arith_decode_host(ctx, xin, xl, nx, xout, xo, xs) : hg_ransnx16_decode_host(ctx, xin, xl, nx, xout, xo, xs);
         if (r != HG_OK && r != HG_EBLOCK) rc = r;
         for (k = 0; k < nx; k++) status[map[k]] = (r == HG_OK || r == HG_EBLOCK) ? xs[k] : -1;
@@ -285,11 +286,11 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
         }
         return rc;
     };
-    struct Task { int kind; size_t cnt; } tasks[5] = {{0, nx_}, {1, na}, {2, nt}, {3, nr}, {4, ng}};
+    struct Task { int kind; size_t cnt; } tasks[6] = {{5, nq}, {0, nx_}, {1, na}, {2, nt}, {3, nr}, {4, ng}};
     int nact = 0;
     for (auto &t : tasks) nact += t.cnt != 0;
-    int trc[5] = {HG_OK, HG_OK, HG_OK, HG_OK, HG_OK};
-    auto run_one = [&](int kind, hg_ctx *c) { trc[kind] = kind <= 2 ? run_entropy(c, kind) : kind == 3 ? run_rans4x8(c) : run_gzip(c); };
+    int trc[6] = {HG_OK, HG_OK, HG_OK, HG_OK, HG_OK, HG_OK};
+    auto run_one = [&](int kind, hg_ctx *c) { trc[kind] = (kind <= 2 || kind == 5) ? run_entropy(c, kind) : kind == 3 ? run_rans4x8(c) : run_gzip(c); };
     if (nact <= 1) { for (auto &t : tasks) if (t.cnt) run_one(t.kind, ctx); }
     else {
         std::vector<std::thread> th;
@@ -302,7 +303,7 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
         for (auto &t : th) t.join();
     }
     int rc = HG_OK;
-    for (int k = 0; k < 5; k++) if (trc[k] != HG_OK && rc == HG_OK) rc = trc[k];
+    for (int k = 0; k < 6; k++) if (trc[k] != HG_OK && rc == HG_OK) rc = trc[k];
     if (rc != HG_OK) return rc;
     for (size_t i = 0; i < n; i++) if (status[i] != 0) return HG_EBLOCK;
     return HG_OK;

@@ -255,6 +255,15 @@ size_t hg_tok3_compress_bound(size_t in_len);
 int hg_tok3_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *use_arith,
                         size_t n, uint8_t *const *out, uint32_t *out_len);
 
+/* ---- CRAM 3.1 fqzcomp quality codec (replaces fqz_decompress as called at cram/cram_io.c:1684-1695; CRAM block
+ *      method 7).  PARITY UNPINNED (oracle/fqzcomp_oracle.c).  The stream carries its own record lengths, so the
+ *      call needs nothing but the block (the reference passes lengths = NULL as well).  out_len[i] = the block's
+ *      uncompressed size; a stream that stores a different size gets status -1, one with more than two parameter
+ *      sets HG_BLOCK_EUNSUPPORTED.  One wavefront per stream, 65536 adaptive models per wavefront in device
+ *      scratch (up to 67 MB each: the number of resident streams is sized to the free memory); see fqzcomp.hip. ---- */
+int hg_fqz_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
+                       uint8_t *const *out, const uint32_t *out_len, int32_t *status);
+
 /* ---- CRAM block layer (replaces cram_uncompress_block, cram/cram_io.c:1576-1754) ------------ */
 /* on-disk method ids, htslib/cram.h:84-101 */
 #define HG_CRAM_RAW      0

@@ -189,6 +189,52 @@ class ArithOracle:
         return rc, (out.raw[:n.value] if rc == 0 else b"")
 
 
+class FqzOracle:
+    """oracle/fqzcomp_oracle.c -- CRAM 3.1 fqzcomp quality codec, PARITY UNPINNED."""
+    SEL, REV, DEDUP, STAB, NOQMAP = 1, 2, 4, 8, 16               # encoder options
+
+    def __init__(self):
+        L = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        L.orc_fqz_encode.restype = C.c_size_t
+        L.orc_fqz_encode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p]
+        L.orc_fqz_compress_bound.restype = C.c_size_t
+        L.orc_fqz_compress_bound.argtypes = [C.c_size_t, C.c_size_t]
+        L.orc_fqz_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t,
+                                     C.POINTER(C.c_size_t)]
+        L.orc_fqz_store_array.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+        L.orc_fqz_read_array.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int]
+        self.L = L
+
+    def encode(self, quals: bytes, lens, rflags=None, strat: int = 0, opts: int = 0) -> bytes:
+        import numpy as np
+        ln = np.ascontiguousarray(lens, dtype=np.uint32)
+        fl = None if rflags is None else np.ascontiguousarray(rflags, dtype=np.uint8)
+        out = C.create_string_buffer(self.L.orc_fqz_compress_bound(len(quals), len(ln)))
+        n = self.L.orc_fqz_encode(quals, len(quals), ln.ctypes.data, None if fl is None else fl.ctypes.data, len(ln), strat, opts, out)
+        assert n > 0, "fqz oracle encoder refused the input"
+        return out.raw[:n]
+
+    def decode(self, b: bytes, cap: int, max_rec: int = 0):
+        import numpy as np
+        out = C.create_string_buffer(max(cap, 1))
+        n, nr = C.c_size_t(0), C.c_size_t(0)
+        lens = np.zeros(max(max_rec, 1), dtype=np.uint32)
+        rc = self.L.orc_fqz_decode(b, len(b), out, cap, C.byref(n), lens.ctypes.data if max_rec else None, max_rec, C.byref(nr))
+        return rc, (out.raw[:n.value] if rc == 0 else b""), lens[:min(nr.value, max_rec)]
+
+    def store_array(self, a) -> bytes:
+        import numpy as np
+        v = np.ascontiguousarray(a, dtype=np.uint32)
+        out = C.create_string_buffer(4096)
+        n = self.L.orc_fqz_store_array(v.ctypes.data, len(v), out)
+        return out.raw[:n]
+
+    def read_array(self, b: bytes, size: int):
+        import numpy as np
+        v = np.zeros(size, dtype=np.uint32)
+        return self.L.orc_fqz_read_array(b, len(b), v.ctypes.data, size), v
+
+
 class Tok3Oracle:
     """oracle/tok3_oracle.c -- CRAM 3.1 read-name tokeniser, PARITY UNPINNED."""
 

@@ -1,0 +1,122 @@
+"""fqzcomp quality codec, CRAM 3.1 block method 7 -- PARITY UNPINNED (see oracle/fqzcomp_oracle.c): htscodecs is absent
+from the reference and no method-7 stream exists in its tests (all CRAM fixtures are v3.0).  CPU part: the oracle's
+encoder/decoder agree over every parameter-block feature (quality maps, position / delta / quality tables, fixed and
+variable lengths, duplicates, reversed records, two parameter sets with and without a selector table) and its array
+coder over the edge cases; GPU part: the gfx950 decoder is bit-exact with the oracle, alone and through the CRAM block
+dispatcher (the boundary cram_uncompress_block uses, cram/cram_io.c:1684-1695)."""
+import numpy as np
+import pytest
+
+from tests import refutil
+
+F = refutil.FqzOracle
+
+
+@pytest.fixture(scope="module")
+def qorc(built):
+    return refutil.FqzOracle()
+
+
+def reads(rng, nrec, maxlen, fixed=True, nq=41, dup=0.0):
+    """Quality strings the way a sequencer writes them: a slow random walk that decays along the read."""
+    lens = np.full(nrec, maxlen, np.uint32) if fixed else rng.integers(1, maxlen + 1, nrec).astype(np.uint32)
+    off = np.concatenate([[0], np.cumsum(lens.astype(np.int64))]).astype(np.int64)
+    q = np.empty(int(off[-1]), np.uint8)
+    for r in range(nrec):
+        n = int(lens[r])
+        walk = np.cumsum(rng.integers(-2, 3, n)) - np.arange(n) * (nq / (3.0 * max(n, 1)))
+        q[off[r]:off[r + 1]] = np.clip(nq - 1 + walk, 0, nq - 1).astype(np.uint8)
+        if r and dup and lens[r] == lens[r - 1] and rng.random() < dup:
+            q[off[r]:off[r + 1]] = q[off[r - 1]:off[r]]
+    return q.tobytes(), lens, rng.integers(0, 4, nrec).astype(np.uint8)
+
+
+VARIANTS = [(s, o) for s in range(4) for o in (0, F.SEL, F.REV, F.DEDUP, F.SEL | F.REV | F.DEDUP, F.SEL | F.STAB | F.REV | F.DEDUP,
+                                               F.NOQMAP, F.SEL | F.STAB | F.REV | F.DEDUP | F.NOQMAP)]
+
+
+def corpus(rng, nrec=120, maxlen=100):
+    for strat, opts in VARIANTS:
+        for fixed in (True, False):
+            for nq in (2, 4, 8, 41, 94):
+                yield strat, opts, reads(rng, nrec, maxlen, fixed, nq, dup=0.3 if opts & F.DEDUP else 0.0)
+
+
+def test_oracle_roundtrip_every_feature(qorc):
+    rng = np.random.default_rng(5)
+    seen_flags = set()
+    for strat, opts, (q, lens, fl) in corpus(rng):
+        e = qorc.encode(q, lens, fl, strat, opts)
+        rc, out, ln = qorc.decode(e, len(q), len(lens))
+        assert rc == 0 and out == q and (ln == lens).all(), (strat, opts)
+        k = 1 + (e[0] >= 0x80) + (e[1] >= 0x80 if e[0] >= 0x80 else 0)      # uint7 size, then version and the global flags
+        assert e[k] == 5
+        seen_flags.add(e[k + 1])
+        assert qorc.decode(e[:len(e) * 2 // 3], len(q))[0] == -1           # truncation is detected
+        assert qorc.decode(e, len(q) - 1)[0] == -1                         # does not fit
+    assert seen_flags == {0, 1, 4, 5, 7}                                  # MULTI_PARAM, HAVE_STAB, DO_REV in every combination the encoder makes
+
+
+def test_oracle_models_actually_compress(qorc):
+    rng = np.random.default_rng(6)
+    q, lens, fl = reads(rng, 2000, 150, True, 41)
+    sizes = [len(qorc.encode(q, lens, None, s, 0)) for s in range(4)]
+    assert max(sizes) < 0.45 * len(q)                                      # an order-0 coder needs ~0.6 here
+    q8, lens8, _ = reads(rng, 2000, 150, True, 8)
+    assert qorc.encode(q8, lens8, None, 0, 0) != qorc.encode(q8, lens8, None, 0, F.NOQMAP)                # the quality map is used
+    assert len(qorc.encode(q8, lens8, None, 0, 0)) < 0.3 * len(q8)
+    d, dl, _ = reads(rng, 2000, 150, True, 41, dup=0.5)
+    assert len(qorc.encode(d, dl, None, 0, F.DEDUP)) < 0.7 * len(qorc.encode(d, dl, None, 0, 0))
+
+
+def test_array_coder_edges(qorc):
+    rng = np.random.default_rng(7)
+    cases = [np.zeros(256, np.uint32), np.arange(256, dtype=np.uint32), np.minimum(np.arange(1024) >> 3, 127).astype(np.uint32),
+             np.repeat(np.arange(4, dtype=np.uint32), 256),                # four runs of 256: 255 + 1 each
+             np.concatenate([np.zeros(1, np.uint32), np.ones(255, np.uint32)]),      # last run is exactly 255 (header note in the oracle)
+             np.concatenate([np.zeros(514, np.uint32), np.full(510, 3, np.uint32)]),  # skipped values, last run 2 x 255
+             np.sort(rng.integers(0, 40, 1024)).astype(np.uint32), np.sort(rng.integers(0, 255, 256)).astype(np.uint32)]
+    for a in cases:
+        b = qorc.store_array(a)
+        used, back = qorc.read_array(b + b"\x07\x07\x07", len(a))          # trailing bytes belong to the next field
+        assert used == len(b) and (back == a).all(), a[:8]
+        assert len(b) < 300
+
+
+@pytest.mark.gpu
+def test_gpu_decoder_matches_oracle(engine, qorc):
+    rng = np.random.default_rng(8)
+    blocks, want = [], []
+    for strat, opts, (q, lens, fl) in corpus(rng, nrec=60, maxlen=90):
+        blocks.append((7, qorc.encode(q, lens, fl, strat, opts), len(q))); want.append(q)
+    for n, ln in ((1, 1), (1, 63), (1, 64), (1, 65), (2, 64), (3, 128), (1, 5000), (40, 1000)):   # sizes around the 64-byte store
+        for opts in (0, F.REV | F.DEDUP, F.SEL | F.REV | F.DEDUP):
+            q, lens, fl = reads(rng, n, ln, False, 41, dup=0.3)
+            blocks.append((7, qorc.encode(q, lens, fl, 0, opts), len(q))); want.append(q)
+    big, blens, bfl = reads(rng, 3000, 150, True, 41, dup=0.05)           # crosses many model halvings
+    for opts in (0, F.SEL | F.REV | F.DEDUP):
+        blocks.append((7, qorc.encode(big, blens, bfl, 1, opts), len(big))); want.append(big)
+    wide = bytes(rng.integers(0, 256, 20_000, dtype=np.uint8))            # 256 symbols: 4 x 64 model entries per read
+    blocks.append((7, qorc.encode(wide, [20_000], None, 3, 0), len(wide))); want.append(wide)
+    outs, st = engine.cram_uncompress_blocks(blocks)
+    assert (st == 0).all(), np.nonzero(st)[0][:10]
+    for k, (o, w) in enumerate(zip(outs, want)):
+        assert o == w, k
+
+
+@pytest.mark.gpu
+def test_gpu_decoder_rejects_what_the_oracle_rejects(engine, qorc):
+    rng = np.random.default_rng(9)
+    q, lens, fl = reads(rng, 50, 100, False, 41)
+    good = qorc.encode(q, lens, fl, 0, F.SEL | F.REV)
+    bad = [good[:len(good) // 2], good[:20], b"", bytes([good[0], good[1], 4]) + good[3:], good[:2] + bytes([good[2] ^ 0xFF]) + good[3:]]
+    blocks = [(7, good, len(q))] + [(7, b, len(q)) for b in bad] + [(7, good, len(q) + 1), (7, good, len(q) - 1)]
+    outs, st = engine.cram_uncompress_blocks(blocks)
+    assert st[0] == 0 and outs[0] == q
+    for k in range(1, len(blocks)):
+        assert st[k] == -1 and outs[k] is None, k
+        assert blocks[k][2] != len(q) or qorc.decode(blocks[k][1], blocks[k][2])[0] != 0, k      # the oracle rejects the same streams
+    # mixed with the other methods of a CRAM 3.1 slice: the dispatcher runs the families side by side
+    mixed = [(7, good, len(q)), (0, b"abc", 3), (7, good, len(q))]
+    outs, st = engine.cram_uncompress_blocks(mixed)
+    assert (st == 0).all() and outs[0] == q and outs[1] == b"abc" and outs[2] == q
