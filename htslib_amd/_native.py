@@ -75,6 +75,14 @@ lib.hg_arith_compress_bound.argtypes = [C.c_size_t]
 lib.hg_arith_decode_host.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]
 lib.hg_arith_encode_host.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]
 lib.hg_fqz_decode_host.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]
+lib.hg_fqz_compress_bound.restype = C.c_size_t
+lib.hg_fqz_compress_bound.argtypes = [C.c_size_t, C.c_size_t]
+lib.hg_fqz_encode_host.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]
+
+
+class FqzSlice(C.Structure):
+    """hg_fqz_slice: the reference's fqz_slice (record lengths + BAM flags of one QS block, cram_io.c:1808-1820)."""
+    _fields_ = [("num_records", C.c_uint32), ("len", _vp), ("flags", _vp)]
 
 lib.hg_tok3_decode_host.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]
 
@@ -124,7 +132,7 @@ EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info
            "hg_gzip_inflate_dev", "hg_cram_uncompress_blocks_host", "hg_ransnx16_decode_host", "hg_ransnx16_decode_dev",
            "hg_ransnx16_compress_bound", "hg_ransnx16_encode_host", "hg_rans4x8_compress_bound",
            "hg_rans4x8_encode_host", "hg_gzip_compress_bound", "hg_gzip_deflate_host", "hg_cram_compress_bound",
-           "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host", "hg_fqz_decode_host", "hg_tok3_decode_host", "hg_tok3_compress_bound", "hg_tok3_encode_host", "hg_cram_metrics_new", "hg_cram_metrics_free",
+           "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host", "hg_fqz_decode_host", "hg_fqz_compress_bound", "hg_fqz_encode_host", "hg_tok3_decode_host", "hg_tok3_compress_bound", "hg_tok3_encode_host", "hg_cram_metrics_new", "hg_cram_metrics_free",
            "hg_cram_compress_blocks_metrics_host", "hg_bam_header_host", "hg_bam_frame_dev", "hg_bam_bases_dev", "hg_bam_core_dev", "hg_bam_quals_dev", "hg_bai_build_dev", "hg_idx_build_dev", "hg_csi_levels", "hg_cram_uncompress_blocks_crc_host",
            "hg_pipe_create", "hg_pipe_destroy", "hg_pipe_input", "hg_pipe_inflate", "hg_pipe_deflate", "hg_pipe_wait",
            "hg_gzip_stream_inflate_host", "hg_crc32_host", "hg_crc32_batch_host",
@@ -347,6 +355,25 @@ class Engine:
         fl = np.array(flags, dtype=np.uint8)
         check(lib.hg_arith_encode_host(self._h, ip, il.ctypes.data, fl.ctypes.data, len(datas), op, ol.ctypes.data), "hg_arith_encode_host")
         return [outs[i].raw[:int(ol[i])] for i in range(len(datas))]
+
+    def fqz_encode_host(self, datas, lens, flags, strats):
+        """fqzcomp-encode each quality buffer; lens[i] / flags[i] = its records' lengths / BAM flags (flags[i] may be None),
+        strats[i] = 0..3 -> list of CRAM method-7 payloads (b"" = refused)."""
+        import numpy as np
+        n = len(datas)
+        if n == 0:
+            return []
+        ins = [(C.c_char * max(len(d), 1)).from_buffer_copy(d if len(d) else b"\0") for d in datas]
+        ln = [np.ascontiguousarray(x, dtype=np.uint32) for x in lens]
+        fl = [None if x is None else np.ascontiguousarray(x, dtype=np.uint32) for x in flags]
+        outs = [C.create_string_buffer(lib.hg_fqz_compress_bound(len(d), len(l))) for d, l in zip(datas, ln)]
+        sl = [FqzSlice(len(l), l.ctypes.data, None if f is None else f.ctypes.data) for l, f in zip(ln, fl)]
+        slp = (_vp * n)(*[C.addressof(x) for x in sl])
+        ip = (_vp * n)(*[C.addressof(x) for x in ins]); op = (_vp * n)(*[C.addressof(x) for x in outs])
+        il = np.array([len(d) for d in datas], dtype=np.uint32); ol = np.zeros(n, dtype=np.uint32)
+        st = np.array(strats, dtype=np.int32)
+        check(lib.hg_fqz_encode_host(self._h, ip, il.ctypes.data, slp, st.ctypes.data, n, op, ol.ctypes.data), "hg_fqz_encode_host")
+        return [outs[i].raw[:int(ol[i])] for i in range(n)]
 
     def tok3_encode_host(self, datas, use_arith):
         """Tokenise + entropy-code each buffer of NUL-terminated names -> list of CRAM method-8 payloads (b"" = not names)."""

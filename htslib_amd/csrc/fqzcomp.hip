@@ -122,6 +122,121 @@ static int build_image(const uint8_t *in, uint32_t n, uint32_t want_ulen, uint32
     return 0;
 }
 
+// ---- host: choice of parameters for the encoder -> header bytes + image ------------------------------------------------
+// The format leaves the choice free (any parameter block a decoder accepts is valid).  Ours is modelled on the four presets
+// of htscodecs (strat 0..3 = CRAM methods FQZ, FQZ_b, FQZ_c, FQZ_d, cram_io.c:2065-2068): {qbits, qshift, pbits, pshift, dbits,
+// dshift, qloc, sloc, ploc, dloc}; the READ2 flag selects one of two parameter sets in preset 1; reverse-strand records are
+// turned round when flags are supplied; duplicates are flagged when at least one record in ten repeats its predecessor;
+// eight or fewer distinct values are coded through a quality map.
+static const int PRESET[4][10] = {
+    {10, 5, 4, -1, 2, 1, 0, 14, 10, 14},
+    {8, 5, 7, 0, 0, 0, 0, 14, 8, 14},
+    {12, 6, 2, 0, 2, 3, 0, 9, 12, 14},
+    {12, 6, 0, 0, 0, 0, 0, 12, 0, 0},
+};
+constexpr uint32_t FQZ_FREVERSE = 16, FQZ_FREAD2 = 128;
+
+static size_t store_array_h(uint8_t *out, const uint16_t *array, int size) {
+    uint8_t tmp[2048];
+    int i = 0, k = 0;
+    for (uint32_t v = 0; i < size; v++) {
+        int len = 0;
+        while (i < size && array[i] == v) { i++; len++; }
+        int r;
+        do { r = std::min(len, 255); tmp[k++] = (uint8_t)r; len -= r; } while (r == 255);
+    }
+    if (k >= 2 && tmp[k - 1] == 0 && tmp[k - 2] == 255) k--;          // the reader stops once the table is full
+    size_t o = 0; int last = -1;
+    for (int j = 0; j < k;) {
+        out[o] = tmp[j++];
+        if (out[o] == last) {
+            int n = 0;
+            while (j < k && tmp[j] == last && n < 255) { j++; n++; }
+            out[++o] = (uint8_t)n;
+        } else last = out[o];
+        o++;
+    }
+    return o;
+}
+
+// records a and b (same length) equal once each is put in coding orientation (ra / rb = reversed)?
+static bool same_record(const uint8_t *a, bool ra, const uint8_t *b, bool rb, uint32_t len) {
+    if (ra == rb) return memcmp(a, b, len) == 0;
+    for (uint32_t j = 0; j < len; j++) if (a[j] != b[len - 1 - j]) return false;
+    return true;
+}
+
+// Fills the image (tables for the context, qual -> code map in the qmap slot) and the stream's header bytes.  0 or -1.
+static int build_encode_image(const uint8_t *in, uint32_t n, const hg_fqz_slice *sl, int strat, uint32_t *img, std::vector<uint8_t> &hdr) {
+    memset(img, 0, IMG_WORDS * 4);
+    if (strat < 0 || strat > 3 || !sl || !sl->len || sl->num_records == 0) return -1;
+    const uint32_t nrec = sl->num_records;
+    const bool have_flags = sl->flags != nullptr;
+    uint64_t tot = 0;
+    for (uint32_t r = 0; r < nrec; r++) { if (sl->len[r] == 0) return -1; tot += sl->len[r]; }
+    if (tot != n) return -1;
+    bool seen[256] = {false};
+    for (uint32_t i = 0; i < n; i++) seen[in[i]] = true;
+    uint32_t nsym = 0, max_q = 0;
+    for (uint32_t i = 0; i < 256; i++) if (seen[i]) { nsym++; max_q = i; }
+    bool fixed = true; size_t dups = 0;
+    {
+        size_t at = 0;
+        for (uint32_t r = 0; r < nrec; r++) {
+            const uint32_t len = sl->len[r];
+            if (len != sl->len[0]) fixed = false;
+            if (r && len == sl->len[r - 1] &&
+                same_record(in + at, have_flags && (sl->flags[r] & FQZ_FREVERSE), in + at - len, have_flags && (sl->flags[r - 1] & FQZ_FREVERSE), len)) dups++;
+            at += len;
+        }
+    }
+    const bool do_sel = strat == 1 && have_flags, do_rev = have_flags, do_dedup = dups * 10 >= nrec && nrec > 1;
+    const uint32_t gflags = (do_sel ? GF_MULTI : 0u) | (do_rev ? GF_REV : 0u), nparam = do_sel ? 2u : 1u;
+    const int *PR = PRESET[strat];
+    hdr.clear();
+    { uint8_t t[5]; int k = 0; uint32_t v = n; do { t[k++] = v & 0x7f; v >>= 7; } while (v); while (k--) hdr.push_back((uint8_t)(t[k] | (k ? 0x80 : 0))); }
+    hdr.push_back((uint8_t)FQZ_VERS); hdr.push_back((uint8_t)gflags);
+    if (gflags & GF_MULTI) hdr.push_back((uint8_t)nparam);
+    uint8_t *stab = (uint8_t *)(img + IMG_HEAD);
+    for (uint32_t i = 0; i < 256; i++) stab[i] = (uint8_t)(i < nparam ? i : nparam - 1);
+    uint32_t max_sym = 0;
+    for (uint32_t s = 0; s < nparam; s++) {
+        uint32_t *P = img + IMG_HEAD + IMG_STAB + s * IMG_PARAM;
+        uint8_t *inv = (uint8_t *)(P + IMG_PSCAL);
+        uint16_t *qtab = (uint16_t *)(P + IMG_PSCAL + IMG_QMAP), *dtab = qtab + 256, *ptab = dtab + 256;
+        uint32_t pflags = (do_dedup ? PF_DEDUP : 0u) | (fixed ? PF_LEN : 0u) | (do_sel ? PF_SEL : 0u);
+        uint32_t qbits = (uint32_t)PR[0], qshift = (uint32_t)PR[1], msym = max_q;
+        uint8_t qmap[256];
+        for (uint32_t i = 0; i < 256; i++) { inv[i] = (uint8_t)i; qtab[i] = (uint16_t)i; }
+        if (nsym <= 8) {
+            pflags |= PF_QMAP;
+            uint32_t j = 0;
+            for (uint32_t i = 0; i < 256; i++) if (seen[i]) { qmap[j] = (uint8_t)i; inv[i] = (uint8_t)j; j++; }
+            msym = nsym;
+            qshift = nsym <= 2 ? 1 : nsym <= 4 ? 2 : 3;
+        }
+        if (qbits > 12) qbits = 12;
+        const int pbits = PR[2], pshift = PR[3] < 0 ? (sl->len[0] > 511 ? 3 : sl->len[0] > 255 ? 2 : sl->len[0] > 127 ? 1 : 0) : PR[3];
+        if (pbits > 0) { pflags |= PF_PTAB; for (uint32_t i = 0; i < 1024; i++) ptab[i] = (uint16_t)std::min<uint32_t>(i >> pshift, (1u << pbits) - 1u); }
+        const int dbits = PR[4], dshift = PR[5];
+        if (dbits > 0) { pflags |= PF_DTAB; for (uint32_t i = 0; i < 256; i++) dtab[i] = (uint16_t)std::min<uint32_t>(i >> dshift, (1u << dbits) - 1u); }
+        if (strat == 2) { pflags |= PF_QTAB; for (uint32_t i = 0; i < 256; i++) qtab[i] = (uint16_t)(i < 32 ? i : std::min<uint32_t>(32 + (i - 32) / 4, 63)); }
+        P[0] = 0; P[1] = pflags; P[2] = (1u << qbits) - 1u; P[3] = qshift;
+        P[4] = (uint32_t)PR[6]; P[5] = (uint32_t)PR[7]; P[6] = (uint32_t)PR[8]; P[7] = (uint32_t)PR[9];
+        hdr.push_back(0); hdr.push_back(0); hdr.push_back((uint8_t)pflags); hdr.push_back((uint8_t)msym);
+        hdr.push_back((uint8_t)(qbits << 4 | qshift)); hdr.push_back((uint8_t)(P[4] << 4 | P[5])); hdr.push_back((uint8_t)(P[6] << 4 | P[7]));
+        if (pflags & PF_QMAP) hdr.insert(hdr.end(), qmap, qmap + msym);
+        uint8_t tmp[4096];
+        if (pflags & PF_QTAB) { const size_t k = store_array_h(tmp, qtab, 256); hdr.insert(hdr.end(), tmp, tmp + k); }
+        if (pflags & PF_PTAB) { const size_t k = store_array_h(tmp, ptab, 1024); hdr.insert(hdr.end(), tmp, tmp + k); }
+        if (pflags & PF_DTAB) { const size_t k = store_array_h(tmp, dtab, 256); hdr.insert(hdr.end(), tmp, tmp + k); }
+        max_sym = std::max(max_sym, msym);
+    }
+    img[0] = gflags; img[1] = nparam; img[2] = nparam - 1u; img[3] = max_sym + 1u; img[4] = (uint32_t)hdr.size(); img[5] = n; img[6] = nrec;
+    img[7] = have_flags ? 1u : 0u;
+    return 0;
+}
+
 // ---- device ----------------------------------------------------------------------------------------------------------
 struct ParamRegs { uint32_t context, pflags, qmask, qshift, qloc, sloc, ploc, dloc; const uint32_t *base; };
 __device__ __forceinline__ void load_param(ParamRegs &R, const uint32_t *img, uint32_t x) {
@@ -251,6 +366,88 @@ void fqz_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__r
     }
 }
 
+// Encoder: the same chain run forwards.  rec_len / rec_flags: the records of all streams back to back (desc.reserved = index of
+// the stream's first record).  The qmap slot of the image holds the INVERSE map (quality -> code).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64)
+void fqz_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc, const uint32_t *__restrict__ images,
+                       const uint32_t *__restrict__ rec_len, const uint32_t *__restrict__ rec_flags, uint32_t nstreams, uint8_t *out,
+                       uint32_t *out_len, uint32_t *gscratch, unsigned long long slot_words) {
+    __shared__ uint32_t pool[WAVES][POOLW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t slot = blockIdx.x * WAVES + wv;
+    uint32_t *gq = gscratch + (size_t)slot * slot_words;
+    uint32_t *mdl = pool[wv], *img = pool[wv] + ((M_WORDS + 3) & ~3u);
+    for (uint32_t k = slot; k < nstreams; k += gridDim.x * WAVES) {
+        const hg_stream_desc d = desc[k];
+        for (uint32_t i = (uint32_t)lane; i < IMG_WORDS; i += 64) img[i] = images[(size_t)d.scratch_off * IMG_WORDS + i];
+        wave_sync();
+        const uint32_t gflags = img[0], max_sel = img[2], ns = img[3], nrec = img[6], have_flags = img[7];
+        const uint8_t *stab = (const uint8_t *)(img + IMG_HEAD);
+        const uint8_t *src = in + d.in_off;
+        const uint32_t *lens = rec_len + d.reserved, *flg = rec_flags + d.reserved;
+        {
+            const uint32_t w = ns + 1u;
+            uint32_t r = (uint32_t)lane % w;
+            const uint32_t step = 64u % w;
+            for (size_t i = (size_t)lane; i < (size_t)CTX_SIZE * w; i += 64) {
+                gq[i] = r ? ((1u << 8) | (r - 1u)) : ns;
+                r += step; if (r >= w) r -= w;
+            }
+            for (int j = 0; j < 4; j++) lds_model_init(mdl + M_LEN + j * 257, 256, lane);
+            lds_model_init(mdl + M_REV, 2, lane); lds_model_init(mdl + M_DUP, 2, lane);
+            lds_model_init(mdl + M_SEL, max_sel + 1u, lane);
+            wave_sync();
+        }
+        hga::Encoder E;
+        E.start(out + d.out_off);
+        auto lsym = [&](uint32_t base, uint32_t n, uint32_t sym) { E.symbol(mdl, mdl, base + 1u, n, base, sym, lane); };
+        ParamRegs R; load_param(R, img, 0);
+        State st = {0, 0, 0, 0, 0};
+        bool first_len = true;
+        uint32_t at = 0, prev_len = 0, prev_rev = 0;
+        for (uint32_t r = 0; r < nrec; r++) {
+            const uint32_t len = lens[r], fl = have_flags ? flg[r] : 0u;
+            const uint32_t rv = (gflags & GF_REV) && (fl & FQZ_FREVERSE) ? 1u : 0u, s = max_sel && (fl & FQZ_FREAD2) ? 1u : 0u;
+            if (max_sel > 0) lsym(M_SEL, max_sel + 1u, s);
+            st.s = s;
+            load_param(R, img, stab[s]);
+            if (!(R.pflags & PF_LEN) || first_len) {
+                lsym(M_LEN, 256, len & 0xffu); lsym(M_LEN + 257, 256, (len >> 8) & 0xffu);
+                lsym(M_LEN + 2 * 257, 256, (len >> 16) & 0xffu); lsym(M_LEN + 3 * 257, 256, len >> 24);
+                first_len = false;
+            }
+            if (gflags & GF_REV) lsym(M_REV, 2, rv);
+            if (R.pflags & PF_DEDUP) {
+                uint32_t dup = 0;
+                if (r && prev_len == len) {                            // equal to the predecessor, both in coding orientation?
+                    dup = 1;
+                    for (uint32_t b = 0; b < len && dup; b += 64) {
+                        const uint32_t j = b + (uint32_t)lane;
+                        const bool ne = j < len && src[at + j] != (rv == prev_rev ? src[at - len + j] : src[at - 1u - j]);
+                        if (__ballot(ne)) dup = 0;
+                    }
+                }
+                lsym(M_DUP, 2, dup);
+                if (dup) { at += len; prev_len = len; prev_rev = rv; continue; }
+            }
+            st.p = len; st.delta = 0; st.qctx = 0; st.prevq = 0;
+            uint32_t last = R.context, win = 0;
+            const uint8_t *inv = (const uint8_t *)(R.base + IMG_PSCAL);
+            for (uint32_t j = 0; j < len; j++) {
+                if ((j & 63u) == 0) { const uint32_t jj = j + (uint32_t)lane; win = jj < len ? src[rv ? at + len - 1u - jj : at + jj] : 0u; }
+                const uint32_t q = inv[rl(win, j & 63u)];
+                const size_t mb = (size_t)last * (ns + 1u);
+                E.symbol(gq + mb, gq + mb, 1u, ns, 0u, q, lane);
+                last = update_ctx(R, st, q);
+            }
+            at += len; prev_len = len; prev_rev = rv;
+        }
+        out_len[k] = E.finish(lane);                                   // every lane stores the same word
+        wave_sync();
+    }
+}
+
 }  // namespace hgq
 
 namespace hg {
@@ -264,6 +461,29 @@ int launch_fqz_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_des
     hipLaunchKernelGGL((hgq::fqz_decode_kernel<WAVES>), dim3((unsigned)wgs), dim3(WAVES * 64), 0, s, (const uint8_t *)d_in, d_desc, d_images,
                        (uint32_t)n, (uint8_t *)d_out, d_status, d_scratch, (unsigned long long)slot_words);
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+int launch_fqz_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_images, const uint32_t *d_rec_len,
+                      const uint32_t *d_rec_flags, size_t n, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch, size_t slots,
+                      size_t slot_words, hipStream_t s) {
+    (void)ctx;
+    if (!n) return HG_OK;
+    constexpr int WAVES = 2;
+    const size_t wgs = (slots + WAVES - 1) / WAVES;
+    hipLaunchKernelGGL((hgq::fqz_encode_kernel<WAVES>), dim3((unsigned)wgs), dim3(WAVES * 64), 0, s, (const uint8_t *)d_in, d_desc, d_images,
+                       d_rec_len, d_rec_flags, (uint32_t)n, (uint8_t *)d_out, d_out_len, d_scratch, (unsigned long long)slot_words);
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+// resident wavefronts: every one owns 65536 models in scratch, so the count is bounded by memory as well as by the chip
+static int fqz_slots(hg_ctx *ctx, size_t m, size_t slot_words, size_t *slots) {
+    size_t n = std::min<size_t>(m, (size_t)ctx->cus * 8);
+    size_t freeb = 0, totalb = 0;
+    if (hipMemGetInfo(&freeb, &totalb) == hipSuccess) {
+        const size_t fit = ((freeb + ctx->d_scratch_cap[6]) / 2) / (slot_words * 4);
+        if (fit < 2) return HG_ENOMEM;
+        n = std::min(n, fit & ~(size_t)1);
+    }
+    *slots = (n + 1) & ~(size_t)1;
+    return HG_OK;
 }
 }  // namespace hg
 
@@ -303,17 +523,9 @@ extern "C" int hg_fqz_decode_host(hg_ctx *ctx, const uint8_t *const *in, const u
             sp[k] = in[i]; sl[k] = in_len[i]; so[k] = ioff; oo[k] = ooff; ol[k] = out_len[i]; dp[k] = out[i];
             ioff += ((uint64_t)in_len[i] + 15u) & ~15ull; ooff += ((uint64_t)out_len[i] + 63u) & ~63ull;
         }
-        // resident wavefronts: every one owns 65536 models in scratch, so the count is bounded by memory as well as by the chip
         const size_t slot_words = (size_t)hgq::CTX_SIZE * (max_ns + 1u);
-        size_t slots = std::min<size_t>(m, (size_t)ctx->cus * 8);
-        size_t freeb = 0, totalb = 0;
-        if (hipMemGetInfo(&freeb, &totalb) == hipSuccess) {
-            const size_t have = freeb + ctx->d_scratch_cap[6];
-            const size_t fit = (have / 2) / (slot_words * 4);
-            if (fit < 1) return HG_ENOMEM;
-            slots = std::min(slots, fit);
-        }
-        slots = (slots + 1) & ~(size_t)1;
+        size_t slots = 0;
+        if ((rc = hg::fqz_slots(ctx, m, slot_words, &slots))) return rc;
         if ((rc = hg::ensure_scratch(ctx, 0, ioff + 64)) || (rc = hg::ensure_scratch(ctx, 1, ooff + 64)) ||
             (rc = hg::ensure_scratch(ctx, 2, m * sizeof(hg_stream_desc))) || (rc = hg::ensure_scratch(ctx, 3, m * 4 + 64)) ||
             (rc = hg::ensure_scratch(ctx, 4, images.size() * 4 + 64)) || (rc = hg::ensure_scratch(ctx, 6, slots * slot_words * 4 + 64))) return rc;
@@ -334,5 +546,84 @@ extern "C" int hg_fqz_decode_host(hg_ctx *ctx, const uint8_t *const *in, const u
     }
     if (rc != HG_OK) return rc;
     for (size_t i = 0; i < n; i++) if (status[i] != 0) return HG_EBLOCK;
+    return HG_OK;
+}
+
+// Encoder (replaces fqz_compress as called by cram_compress_by_method, cram/cram_io.c:1801-1825).  slice[i] = the record
+// lengths and BAM flags of block i (the reference's fqz_slice, built at cram_io.c:1808-1820), strat[i] = 0..3 (methods FQZ,
+// FQZ_b, FQZ_c, FQZ_d, cram_io.c:2065-2068).  out[i] must hold hg_fqz_compress_bound(in_len[i], num_records).  A block whose
+// record lengths do not add up to in_len[i] gets out_len[i] = 0 (the caller keeps another method).  Synchronous.
+extern "C" size_t hg_fqz_compress_bound(size_t n, size_t nrec) { return n + n / 4 + 8 * nrec + 16384; }
+extern "C" int hg_fqz_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const hg_fqz_slice *const *slice,
+                                  const int32_t *strat, size_t n, uint8_t *const *out, uint32_t *out_len) {
+    if (!ctx || (n && (!in || !in_len || !slice || !strat || !out || !out_len))) return HG_EINVAL;
+    if (n == 0) return HG_OK;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
+    std::vector<uint32_t> images; images.reserve(n * hgq::IMG_WORDS);
+    std::vector<std::vector<uint8_t>> hdrs;
+    std::vector<size_t> live;
+    uint32_t max_ns = 0;
+    for (size_t i = 0; i < n; i++) {
+        out_len[i] = 0;
+        if (in_len[i] == 0) continue;
+        uint32_t img[hgq::IMG_WORDS];
+        std::vector<uint8_t> hdr;
+        if (hgq::build_encode_image(in[i], in_len[i], slice[i], strat[i], img, hdr)) continue;
+        images.insert(images.end(), img, img + hgq::IMG_WORDS);
+        hdrs.push_back(std::move(hdr));
+        live.push_back(i);
+        max_ns = std::max(max_ns, img[3]);
+    }
+    const size_t m = live.size();
+    if (!m) return HG_OK;
+    std::vector<size_t> ord(m);
+    for (size_t k = 0; k < m; k++) ord[k] = k;
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return in_len[live[a]] > in_len[live[b]]; });
+    std::vector<hg_stream_desc> desc(m);
+    std::vector<const uint8_t *> sp(m); std::vector<uint32_t> sl(m); std::vector<uint64_t> so(m), oo(m); std::vector<uint8_t *> dp(m);
+    std::vector<uint32_t> rlen, rflg;
+    uint64_t ioff = 0, ooff = 0;
+    for (size_t k = 0; k < m; k++) {
+        const size_t i = live[ord[k]];
+        const hg_fqz_slice *f = slice[i];
+        desc[k].in_off = ioff; desc[k].in_len = in_len[i]; desc[k].out_off = ooff; desc[k].out_len = 0;
+        desc[k].scratch_off = (uint32_t)ord[k]; desc[k].reserved = (uint32_t)rlen.size();
+        rlen.insert(rlen.end(), f->len, f->len + f->num_records);
+        if (f->flags) rflg.insert(rflg.end(), f->flags, f->flags + f->num_records); else rflg.resize(rflg.size() + f->num_records, 0u);
+        sp[k] = in[i]; sl[k] = in_len[i]; so[k] = ioff; oo[k] = ooff; dp[k] = out[i] + hdrs[ord[k]].size();
+        ioff += ((uint64_t)in_len[i] + 15u) & ~15ull;
+        ooff += (hg_fqz_compress_bound(in_len[i], f->num_records) + 63u) & ~63ull;
+        if (rlen.size() > 0xffffffffull) return HG_EINVAL;
+    }
+    const size_t slot_words = (size_t)hgq::CTX_SIZE * (max_ns + 1u);
+    size_t slots = 0;
+    int rc;
+    if ((rc = hg::fqz_slots(ctx, m, slot_words, &slots))) return rc;
+    const size_t recb = rlen.size() * 4;
+    if ((rc = hg::ensure_scratch(ctx, 0, ioff + 64)) || (rc = hg::ensure_scratch(ctx, 1, ooff + 64)) ||
+        (rc = hg::ensure_scratch(ctx, 2, m * sizeof(hg_stream_desc))) || (rc = hg::ensure_scratch(ctx, 3, m * 4 + 64)) ||
+        (rc = hg::ensure_scratch(ctx, 4, images.size() * 4 + 64)) || (rc = hg::ensure_scratch(ctx, 5, 2 * recb + 64)) ||
+        (rc = hg::ensure_scratch(ctx, 6, slots * slot_words * 4 + 64))) return rc;
+    hipStream_t s = ctx->stream;
+    uint32_t *d_rlen = (uint32_t *)ctx->d_scratch[5], *d_rflg = d_rlen + rlen.size();
+    bool ok = hg::stage_upload(ctx, sp.data(), sl.data(), so.data(), nullptr, m, ioff, (uint8_t *)ctx->d_scratch[0], s) == HG_OK;
+    ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc.data(), m * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(ctx->d_scratch[4], images.data(), images.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(d_rlen, rlen.data(), recb, hipMemcpyHostToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(d_rflg, rflg.data(), recb, hipMemcpyHostToDevice, s) == hipSuccess;
+    rc = ok ? hg::launch_fqz_encode(ctx, ctx->d_scratch[0], (const hg_stream_desc *)ctx->d_scratch[2], (const uint32_t *)ctx->d_scratch[4], d_rlen,
+                                    d_rflg, m, ctx->d_scratch[1], (uint32_t *)ctx->d_scratch[3], (uint32_t *)ctx->d_scratch[6], slots, slot_words, s)
+            : HG_ELAUNCH;
+    if (rc != HG_OK) return rc;
+    std::vector<uint32_t> ol(m);
+    ok = hipMemcpyAsync(ol.data(), ctx->d_scratch[3], m * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    ok = ok && hg::stage_download(ctx, (const uint8_t *)ctx->d_scratch[1], oo.data(), ol.data(), dp.data(), m, s) == HG_OK;
+    if (!ok) return HG_ELAUNCH;
+    for (size_t k = 0; k < m; k++) {
+        const size_t i = live[ord[k]];
+        const std::vector<uint8_t> &h = hdrs[ord[k]];
+        memcpy(out[i], h.data(), h.size());
+        out_len[i] = (uint32_t)h.size() + ol[k];
+    }
     return HG_OK;
 }

@@ -263,6 +263,16 @@ int hg_tok3_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *i
  *      scratch (up to 67 MB each: the number of resident streams is sized to the free memory); see fqzcomp.hip. ---- */
 int hg_fqz_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, size_t n,
                        uint8_t *const *out, const uint32_t *out_len, int32_t *status);
+/* Encoder (replaces fqz_compress as called by cram_compress_by_method, cram/cram_io.c:1801-1825).  hg_fqz_slice is the
+ * reference's fqz_slice as cram_io.c:1808-1820 fills it: the records' quality lengths and BAM flags (16 = reverse strand,
+ * 128 = second read; flags may be NULL).  strat[i] = 0..3 for the methods FQZ, FQZ_b, FQZ_c, FQZ_d (cram_io.c:2065-2068).
+ * The parameter block is chosen on the host (modelled on the four htscodecs presets; any choice is valid by the format),
+ * the adaptive coding runs one wavefront per block.  A block whose record lengths do not add up to in_len[i] gets
+ * out_len[i] = 0.  out[i] must hold hg_fqz_compress_bound(in_len[i], num_records).  Synchronous. */
+typedef struct hg_fqz_slice { uint32_t num_records; const uint32_t *len; const uint32_t *flags; } hg_fqz_slice;
+size_t hg_fqz_compress_bound(size_t in_len, size_t num_records);
+int hg_fqz_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const hg_fqz_slice *const *slice,
+                       const int32_t *strat, size_t n, uint8_t *const *out, uint32_t *out_len);
 
 /* ---- CRAM block layer (replaces cram_uncompress_block, cram/cram_io.c:1576-1754) ------------ */
 /* on-disk method ids, htslib/cram.h:84-101 */

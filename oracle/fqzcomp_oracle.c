@@ -288,9 +288,12 @@ static const int PRESET[4][10] = {
 };
 /* opts: bit 0 = use the READ2 flag of each record as the selector (two parameter sets), bit 1 = honour the reverse flags,
  * bit 2 = allow duplicate detection, bit 3 = force a selector table, bit 4 = never use a quality map.
- * rflags[i]: bit 0 reverse, bit 1 second read (NULL = none).  Returns the stream length or 0 on error. */
+ * rflags[i]: the record's BAM flags as in fqz_slice.flags (cram_io.c:1815): 16 = reverse strand, 128 = second read; NULL = none.
+ * Returns the stream length or 0 on error. */
+#define FQZ_FREVERSE 16u
+#define FQZ_FREAD2 128u
 ORC_EXPORT size_t orc_fqz_compress_bound(size_t n, size_t nrec) { return n + n / 4 + 8 * nrec + 16384; }
-ORC_EXPORT size_t orc_fqz_encode(const uint8_t *in_, size_t n, const uint32_t *lens, const uint8_t *rflags, size_t nrec, int strat,
+ORC_EXPORT size_t orc_fqz_encode(const uint8_t *in_, size_t n, const uint32_t *lens, const uint32_t *rflags, size_t nrec, int strat,
                                  int opts, uint8_t *out)
 {
     if (strat < 0 || strat > 3) return 0;
@@ -304,7 +307,7 @@ ORC_EXPORT size_t orc_fqz_encode(const uint8_t *in_, size_t n, const uint32_t *l
     if (!in || !g) { free(in); free(g); return 0; }
     memcpy(in, in_, n);
     const int do_rev = (opts & 2) && rflags;
-    if (do_rev) { size_t at = 0; for (size_t r = 0; r < nrec; r++) { if (rflags[r] & 1) reverse_bytes(in + at, lens[r]); at += lens[r]; } }
+    if (do_rev) { size_t at = 0; for (size_t r = 0; r < nrec; r++) { if (rflags[r] & FQZ_FREVERSE) reverse_bytes(in + at, lens[r]); at += lens[r]; } }
     /* survey of the data */
     int seen[256] = {0}, nsym = 0, max_q = 0, fixed = 1;
     for (size_t i = 0; i < n; i++) seen[in[i]] = 1;
@@ -369,7 +372,7 @@ ORC_EXPORT size_t orc_fqz_encode(const uint8_t *in_, size_t n, const uint32_t *l
     size_t at = 0;
     for (size_t r = 0; r < nrec; r++) {
         const uint32_t len = lens[r];
-        const uint32_t s = do_sel ? (uint32_t)((rflags[r] >> 1) & 1) : 0;
+        const uint32_t s = do_sel ? (uint32_t)((rflags[r] & FQZ_FREAD2) != 0) : 0;
         if (g->max_sel > 0) model_encode(&M.sel, &rc, s);
         st.s = s;
         const fqz_param *pm = &g->p[g->stab[s]];
@@ -378,7 +381,7 @@ ORC_EXPORT size_t orc_fqz_encode(const uint8_t *in_, size_t n, const uint32_t *l
             model_encode(&M.len[2], &rc, (len >> 16) & 0xff); model_encode(&M.len[3], &rc, len >> 24);
             first_len = 0;
         }
-        if (g->gflags & GF_REV) model_encode(&M.rev, &rc, rflags[r] & 1u);
+        if (g->gflags & GF_REV) model_encode(&M.rev, &rc, (rflags[r] & FQZ_FREVERSE) != 0);
         if (pm->pflags & PF_DEDUP) {
             const int d = r && lens[r - 1] == len && !memcmp(in + at, in + at - len, len);
             model_encode(&M.dup, &rc, (uint32_t)d);

@@ -208,7 +208,7 @@ class FqzOracle:
     def encode(self, quals: bytes, lens, rflags=None, strat: int = 0, opts: int = 0) -> bytes:
         import numpy as np
         ln = np.ascontiguousarray(lens, dtype=np.uint32)
-        fl = None if rflags is None else np.ascontiguousarray(rflags, dtype=np.uint8)
+        fl = None if rflags is None else np.ascontiguousarray(rflags, dtype=np.uint32)      # BAM flags: 16 reverse, 128 second read
         out = C.create_string_buffer(self.L.orc_fqz_compress_bound(len(quals), len(ln)))
         n = self.L.orc_fqz_encode(quals, len(quals), ln.ctypes.data, None if fl is None else fl.ctypes.data, len(ln), strat, opts, out)
         assert n > 0, "fqz oracle encoder refused the input"

@@ -28,7 +28,7 @@ def reads(rng, nrec, maxlen, fixed=True, nq=41, dup=0.0):
         q[off[r]:off[r + 1]] = np.clip(nq - 1 + walk, 0, nq - 1).astype(np.uint8)
         if r and dup and lens[r] == lens[r - 1] and rng.random() < dup:
             q[off[r]:off[r + 1]] = q[off[r - 1]:off[r]]
-    return q.tobytes(), lens, rng.integers(0, 4, nrec).astype(np.uint8)
+    return q.tobytes(), lens, (rng.integers(0, 2, nrec) * 16 + rng.integers(0, 2, nrec) * 128 + 1).astype(np.uint32)   # BAM flags
 
 
 VARIANTS = [(s, o) for s in range(4) for o in (0, F.SEL, F.REV, F.DEDUP, F.SEL | F.REV | F.DEDUP, F.SEL | F.STAB | F.REV | F.DEDUP,
@@ -120,3 +120,32 @@ def test_gpu_decoder_rejects_what_the_oracle_rejects(engine, qorc):
     mixed = [(7, good, len(q)), (0, b"abc", 3), (7, good, len(q))]
     outs, st = engine.cram_uncompress_blocks(mixed)
     assert (st == 0).all() and outs[0] == q and outs[1] == b"abc" and outs[2] == q
+
+
+@pytest.mark.gpu
+def test_gpu_encoder_matches_oracle_and_decodes(engine, qorc):
+    """The gfx950 encoder emits exactly the oracle's bytes for the parameter choice both make (selector for preset 1, reversal when
+    flags are given, duplicates when one record in ten repeats), and the gfx950 decoder takes them back."""
+    rng = np.random.default_rng(10)
+    datas, lens, flags, strats, want = [], [], [], [], []
+    for strat in range(4):
+        for fixed in (True, False):
+            for nq in (2, 5, 8, 41, 94):
+                for with_flags in (True, False):
+                    for dup in (0.0, 0.3):
+                        q, ln, fl = reads(rng, 50, 80, fixed, nq, dup)
+                        datas.append(q); lens.append(ln); flags.append(fl if with_flags else None); strats.append(strat)
+                        opts = F.DEDUP | (F.REV if with_flags else 0) | (F.SEL if with_flags and strat == 1 else 0)
+                        want.append(qorc.encode(q, ln, fl if with_flags else None, strat, opts))
+    for n, ln_ in ((1, 1), (1, 64), (2, 65), (1, 3000), (700, 151)):
+        q, ln, fl = reads(rng, n, ln_, False, 41, 0.2)
+        datas.append(q); lens.append(ln); flags.append(fl); strats.append(n % 4)
+        want.append(qorc.encode(q, ln, fl, n % 4, F.DEDUP | F.REV | (F.SEL if n % 4 == 1 else 0)))
+    got = engine.fqz_encode_host(datas, lens, flags, strats)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g == w, (k, len(g), len(w))
+    outs, st = engine.cram_uncompress_blocks([(7, g, len(d)) for g, d in zip(got, datas)])
+    assert (st == 0).all() and all(o == d for o, d in zip(outs, datas))
+    # refused inputs: record lengths that do not add up, an empty record, no slice information
+    bad = engine.fqz_encode_host([datas[0], datas[0]], [lens[0][:-1], np.concatenate([lens[0][:-1], [0], lens[0][-1:]])], [None, None], [0, 0])
+    assert bad == [b"", b""]
