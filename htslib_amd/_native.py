@@ -94,6 +94,7 @@ lib.hg_cram_metrics_new.restype = _vp
 lib.hg_cram_metrics_new.argtypes = []
 lib.hg_cram_metrics_free.argtypes = [_vp]
 lib.hg_cram_compress_blocks_metrics_host.argtypes = [_vp, C.c_size_t, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
+lib.hg_cram_compress_blocks_metrics_fqz_host.argtypes = [_vp, C.c_size_t, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
 
 
 class CramMetrics(C.Structure):
@@ -133,7 +134,7 @@ EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info
            "hg_ransnx16_compress_bound", "hg_ransnx16_encode_host", "hg_rans4x8_compress_bound",
            "hg_rans4x8_encode_host", "hg_gzip_compress_bound", "hg_gzip_deflate_host", "hg_cram_compress_bound",
            "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host", "hg_fqz_decode_host", "hg_fqz_compress_bound", "hg_fqz_encode_host", "hg_tok3_decode_host", "hg_tok3_compress_bound", "hg_tok3_encode_host", "hg_cram_metrics_new", "hg_cram_metrics_free",
-           "hg_cram_compress_blocks_metrics_host", "hg_bam_header_host", "hg_bam_frame_dev", "hg_bam_bases_dev", "hg_bam_core_dev", "hg_bam_quals_dev", "hg_bai_build_dev", "hg_idx_build_dev", "hg_csi_levels", "hg_cram_uncompress_blocks_crc_host",
+           "hg_cram_compress_blocks_metrics_host", "hg_cram_compress_blocks_metrics_fqz_host", "hg_bam_header_host", "hg_bam_frame_dev", "hg_bam_bases_dev", "hg_bam_core_dev", "hg_bam_quals_dev", "hg_bai_build_dev", "hg_idx_build_dev", "hg_csi_levels", "hg_cram_uncompress_blocks_crc_host",
            "hg_pipe_create", "hg_pipe_destroy", "hg_pipe_input", "hg_pipe_inflate", "hg_pipe_deflate", "hg_pipe_wait",
            "hg_gzip_stream_inflate_host", "hg_crc32_host", "hg_crc32_batch_host",
            "hg_hts_pack", "hg_hts_unpack", "hg_hts_rle_encode", "hg_hts_rle_decode",
@@ -315,8 +316,9 @@ class Engine:
                                                ol.ctypes.data, used.ctypes.data), "hg_cram_compress_blocks_host")
         return [outs[i].raw[:int(ol[i])] for i in range(len(datas))], used
 
-    def cram_compress_blocks_metrics(self, datas, metrics, method_sets, level=5, version_major=3):
-        """cram_compress_block with the auto-tuner: metrics[i] = pointer from hg_cram_metrics_new (or None)."""
+    def cram_compress_blocks_metrics(self, datas, metrics, method_sets, level=5, version_major=3, fqz=None):
+        """cram_compress_block with the auto-tuner: metrics[i] = pointer from hg_cram_metrics_new (or None);
+        fqz[i] = None or (record lengths, BAM flags or None) of a quality block -- the cram_slice argument of cram_compress_block2."""
         import numpy as np
         if not datas:
             return [], np.zeros(0, dtype=np.int32)
@@ -324,9 +326,20 @@ class Engine:
         mk = np.array(method_sets, dtype=np.uint32)
         mp = (_vp * len(datas))(*[m if m else None for m in metrics])
         used = np.full(len(datas), -9, dtype=np.int32)
-        check(lib.hg_cram_compress_blocks_metrics_host(self._h, len(datas), mp, mk.ctypes.data, level, version_major, ip,
-                                                       il.ctypes.data, op, ol.ctypes.data, used.ctypes.data),
-              "hg_cram_compress_blocks_metrics_host")
+        keep, slp = [], None
+        if fqz is not None:
+            ptrs = []
+            for f in fqz:
+                if f is None:
+                    ptrs.append(None); continue
+                ln = np.ascontiguousarray(f[0], dtype=np.uint32)
+                fl = None if f[1] is None else np.ascontiguousarray(f[1], dtype=np.uint32)
+                sl = FqzSlice(len(ln), ln.ctypes.data, None if fl is None else fl.ctypes.data)
+                keep.append((ln, fl, sl)); ptrs.append(C.addressof(sl))
+            slp = (_vp * len(datas))(*ptrs)
+        check(lib.hg_cram_compress_blocks_metrics_fqz_host(self._h, len(datas), mp, mk.ctypes.data, level, version_major, ip,
+                                                           il.ctypes.data, slp, op, ol.ctypes.data, used.ctypes.data),
+              "hg_cram_compress_blocks_metrics_fqz_host")
         return [outs[i].raw[:int(ol[i])] for i in range(len(datas))], used
 
     def rans4x8_encode_host(self, datas, orders):

@@ -172,7 +172,7 @@ void uncompress_batch(cram_block **b, int n, int *rc) {
     }
 }
 
-struct CompJob { const hg_cram_opts *opts; cram_block *b; cram_metrics *m; int method, level; int rc; };
+struct CompJob { const hg_cram_opts *opts; cram_block *b; cram_metrics *m; int method, level; int rc; const hg_fqz_slice *fqz = nullptr; };
 
 void compress_batch(CompJob *jobs, int n) {
     hg_ctx *ctx = engine();
@@ -204,21 +204,22 @@ void compress_batch(CompJob *jobs, int n) {
         const size_t m = g1 - g0;
         std::vector<hg_cram_metrics *> met(m); std::vector<uint32_t> set(m), il(m), ol(m, 0); std::vector<const uint8_t *> in(m);
         std::vector<uint8_t *> out(m, nullptr); std::vector<int32_t> used(m, 0);
+        std::vector<const hg_fqz_slice *> fq(m, nullptr);
         std::vector<pthread_mutex_t *> locks;
         bool oom = false;
         for (size_t k = 0; k < m; k++) {
             CompJob &j = jobs[todo[g0 + k]];
             met[k] = reinterpret_cast<hg_cram_metrics *>(j.m); set[k] = (uint32_t)j.method;
-            in[k] = j.b->data; il[k] = (uint32_t)j.b->uncomp_size;
-            out[k] = (uint8_t *)malloc(hg_cram_compress_bound(il[k]));
+            in[k] = j.b->data; il[k] = (uint32_t)j.b->uncomp_size; fq[k] = j.fqz;
+            out[k] = (uint8_t *)malloc(std::max(hg_cram_compress_bound(il[k]), j.fqz ? hg_fqz_compress_bound(il[k], j.fqz->num_records) : (size_t)0));
             if (!out[k]) oom = true;
             if (j.m && j.opts && j.opts->metrics_lock) locks.push_back((pthread_mutex_t *)j.opts->metrics_lock);
         }
         std::sort(locks.begin(), locks.end());
         locks.erase(std::unique(locks.begin(), locks.end()), locks.end());
         for (auto l : locks) pthread_mutex_lock(l);
-        int r = oom ? HG_ENOMEM : ctx ? hg_cram_compress_blocks_metrics_host(ctx, m, met.data(), set.data(), level, version >> 8, in.data(), il.data(),
-                                                                             out.data(), ol.data(), used.data()) : HG_ENODEV;
+        int r = oom ? HG_ENOMEM : ctx ? hg_cram_compress_blocks_metrics_fqz_host(ctx, m, met.data(), set.data(), level, version >> 8, in.data(), il.data(),
+                                                                                 fq.data(), out.data(), ol.data(), used.data()) : HG_ENODEV;
         for (auto it = locks.rbegin(); it != locks.rend(); ++it) pthread_mutex_unlock(*it);
         for (size_t k = 0; k < m; k++) {
             CompJob &j = jobs[todo[g0 + k]];
@@ -356,9 +357,25 @@ int hg_cram_compress_blocks(const hg_cram_opts *opts, cram_block **b, cram_metri
 }
 
 int hg_cram_compress_blocks_lv(const hg_cram_opts *opts, cram_block **b, cram_metrics **metrics, const int *method, const int *level, int n) {
+    return hg_cram_compress_blocks_fqz(opts, b, metrics, method, level, nullptr, n);
+}
+
+int hg_cram_compress_block_fqz(const hg_cram_opts *opts, const hg_fqz_slice *fqz, cram_block *b, cram_metrics *metrics, int method, int level) {
+    if (!b) return 0;
+    if (b->method != RAW) return 0;
+    CompReq r{{opts, b, metrics, method, level, -1, fqz}, false};
+    const int lv = level == -1 ? (opts ? opts->level : 5) : level;
+    if (method == RAW || lv == 0 || b->uncomp_size == 0) { compress_batch(&r.job, 1); return r.job.rc; }
+    g_comp.submit(&r);
+    return r.job.rc;
+}
+
+int hg_cram_compress_blocks_fqz(const hg_cram_opts *opts, cram_block **b, cram_metrics **metrics, const int *method, const int *level,
+                                const hg_fqz_slice *const *fqz, int n) {
     if (n <= 0) return 0;
     std::vector<CompJob> jobs(n);
-    for (int i = 0; i < n; i++) jobs[i] = CompJob{opts, b[i], metrics ? metrics[i] : nullptr, method ? method[i] : -1, level ? level[i] : -1, -1};
+    for (int i = 0; i < n; i++)
+        jobs[i] = CompJob{opts, b[i], metrics ? metrics[i] : nullptr, method ? method[i] : -1, level ? level[i] : -1, -1, fqz ? fqz[i] : nullptr};
     compress_batch(jobs.data(), n);
     for (int i = 0; i < n; i++) if (jobs[i].rc) return -1;
     return 0;
@@ -425,14 +442,21 @@ int hg_cram_slice_plan(const hg_cram_slice_opts *o, const uint8_t *present, int 
 
 int hg_cram_compress_slice(const hg_cram_slice_opts *o, const hg_cram_opts *opts, cram_block **block, cram_metrics **metrics,
                            const int *nvals, cram_block **aux, int naux) {
+    return hg_cram_compress_slice_fqz(o, opts, block, metrics, nvals, aux, naux, nullptr);
+}
+
+int hg_cram_compress_slice_fqz(const hg_cram_slice_opts *o, const hg_cram_opts *opts, cram_block **block, cram_metrics **metrics,
+                               const int *nvals, cram_block **aux, int naux, const hg_fqz_slice *qs) {
     hg_cram_slice_sets S;
     hg_cram_slice_method_sets(o, &S);
     std::vector<cram_block *> jb; std::vector<cram_metrics *> jm; std::vector<int> jset, jlv;
+    std::vector<const hg_fqz_slice *> jfq;
     cram_block *core = block[HG_DS_CORE];
     auto add = [&](cram_block *b, cram_metrics *m, int set, int lv) {
         if (!b || b->method != RAW) return;                                    // cram_io.c:1945-1952
         for (cram_block *x : jb) if (x == b) return;                           // aliased series: the first call wins
         jb.push_back(b); jm.push_back(m); jset.push_back(set); jlv.push_back(lv);
+        jfq.push_back(b == block[HG_DS_QS] ? qs : nullptr);                    // only the quality block is fqzcomp material
     };
     if (nvals && metrics) {                                                    // cram_encode.c:877-881
         pthread_mutex_t *lk = opts ? (pthread_mutex_t *)opts->metrics_lock : nullptr;
@@ -450,11 +474,11 @@ int hg_cram_compress_slice(const hg_cram_slice_opts *o, const hg_cram_opts *opts
         else if (d == HG_DS_CORE) add(core, nullptr, set[k], lv[k]);
         else if (!(d == HG_DS_NS && block[d] == core)) add(block[d], metrics ? metrics[d] : nullptr, set[k], lv[k]);
     }
-    if (!jb.empty() && hg_cram_compress_blocks_lv(opts, jb.data(), jm.data(), jset.data(), jlv.data(), (int)jb.size()) != 0) return -1;
+    if (!jb.empty() && hg_cram_compress_blocks_fqz(opts, jb.data(), jm.data(), jset.data(), jlv.data(), jfq.data(), (int)jb.size()) != 0) return -1;
     // final sweep: whatever is still RAW (never named above, or nothing beat the raw bytes) is tried with methodF
-    jb.clear(); jm.clear(); jset.clear(); jlv.clear();
+    jb.clear(); jm.clear(); jset.clear(); jlv.clear(); jfq.clear();
     for (int i = 1; i < HG_DS_END; i++) if (block[i] && block[i] != core) add(block[i], metrics ? metrics[i] : nullptr, S.methodF, o->level);
-    if (!jb.empty() && hg_cram_compress_blocks_lv(opts, jb.data(), jm.data(), jset.data(), jlv.data(), (int)jb.size()) != 0) return -1;
+    if (!jb.empty() && hg_cram_compress_blocks_fqz(opts, jb.data(), jm.data(), jset.data(), jlv.data(), jfq.data(), (int)jb.size()) != 0) return -1;
     return 0;
 }
 

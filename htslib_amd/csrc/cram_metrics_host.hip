@@ -46,7 +46,7 @@ uint32_t (*g_size_script)(int method, size_t blk, uint32_t in_len) = nullptr;
 // parameter per stream (order / flag byte / back-end), so e.g. all seven RANS_PR* trials of all blocks are ONE batched
 // GPU call.  res[j] = malloc'd payload (or null when the method is not available / failed), rlen[j] = its size.
 int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t *const *in, const uint32_t *in_len,
-             std::vector<uint8_t *> &res, std::vector<uint32_t> &rlen) {
+             const hg_fqz_slice *const *fqz, std::vector<uint8_t *> &res, std::vector<uint32_t> &rlen) {
     res.assign(jobs.size(), nullptr); rlen.assign(jobs.size(), 0);
     if (g_size_script) {
         for (size_t j = 0; j < jobs.size(); j++) {
@@ -55,7 +55,7 @@ int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t
         }
         return HG_OK;
     }
-    enum Fam { F_GZ = 0, F_GZ1, F_R4, F_NX, F_AR, F_TK, F_N };
+    enum Fam { F_GZ = 0, F_GZ1, F_R4, F_NX, F_AR, F_TK, F_FQ, F_N };
     auto family = [](int m) -> int {
         if (m == HG_M_GZIP) return F_GZ;
         if (m == HG_M_GZIP_RLE || m == HG_M_GZIP_1) return F_GZ1;
@@ -63,7 +63,8 @@ int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t
         if (m == HG_M_RANS_PR0 || (m >= HG_M_RANS_PR1 && m <= HG_M_RANS_PR193)) return F_NX;
         if (m == HG_M_ARITH_PR0 || (m >= HG_M_ARITH_PR1 && m <= HG_M_ARITH_PR193)) return F_AR;
         if (m == HG_M_TOK3 || m == HG_M_TOKA) return F_TK;
-        return -1;                                                     // bzip2 / lzma / fqzcomp: not in the engine -> "failed"
+        if (m == HG_M_FQZ || (m >= HG_M_FQZ_b && m <= HG_M_FQZ_d)) return F_FQ;
+        return -1;                                                     // bzip2 / lzma: not in the engine -> "failed"
     };
     // The families are independent: each runs on its own thread, sibling context (own scratch, own HIP stream), so
     // their -- individually latency-bound -- kernels overlap on the GPU.
@@ -80,12 +81,17 @@ int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t
             if (hipSetDevice(ctx->device) != hipSuccess) { frc[fam] = HG_ENODEV; return; }
             std::vector<const uint8_t *> sin; std::vector<uint8_t *> sout; std::vector<uint32_t> slen, solen(idx.size(), 0);
             std::vector<uint8_t> par(idx.size());
+            std::vector<const hg_fqz_slice *> fsl; std::vector<int32_t> fstrat;
             for (size_t k = 0; k < idx.size(); k++) {
                 const size_t b = jobs[idx[k]].blk; const int m = jobs[idx[k]].m;
                 sin.push_back(in[b]); slen.push_back(in_len[b]);
                 const size_t cap = fam <= F_GZ1 ? hg_gzip_compress_bound(in_len[b]) : fam == F_R4 ? hg_rans4x8_compress_bound(in_len[b])
                                  : fam == F_NX ? hg_ransnx16_compress_bound(in_len[b]) : fam == F_AR ? hg_arith_compress_bound(in_len[b])
+                                 : fam == F_FQ ? hg_fqz_compress_bound(in_len[b], fqz && fqz[b] ? fqz[b]->num_records : 0)
                                  : hg_tok3_compress_bound(in_len[b]);
+                if (fam == F_FQ) {                                     // strat = 0..3 for FQZ, FQZ_b, FQZ_c, FQZ_d (cram_io.c:2065-2068)
+                    fsl.push_back(fqz ? fqz[b] : nullptr); fstrat.push_back(m == HG_M_FQZ ? 0 : m - HG_M_FQZ_b + 1);
+                }
                 uint8_t *p = (uint8_t *)malloc(cap);
                 if (!p) { for (auto q : sout) free(q); frc[fam] = HG_ENOMEM; return; }
                 sout.push_back(p);
@@ -99,6 +105,7 @@ int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t
             else if (fam == F_R4) rc = hg_rans4x8_encode_host(sub, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
             else if (fam == F_NX) rc = hg_ransnx16_encode_host(sub, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
             else if (fam == F_AR) rc = hg_arith_encode_host(sub, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
+            else if (fam == F_FQ) rc = hg_fqz_encode_host(sub, sin.data(), slen.data(), fsl.data(), fstrat.data(), sin.size(), sout.data(), solen.data());
             else rc = hg_tok3_encode_host(sub, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
             if (rc != HG_OK) { for (auto q : sout) free(q); frc[fam] = rc; return; }
             for (size_t k = 0; k < idx.size(); k++) {                  // distinct jobs: no two threads touch the same slot
@@ -130,6 +137,12 @@ void hg_cram_metrics_free(hg_cram_metrics *m) { free(m); }
 int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics *const *metrics, const uint32_t *method_set, int level,
                                          int version_major, const uint8_t *const *in, const uint32_t *in_len, uint8_t *const *out,
                                          uint32_t *out_len, int32_t *method_used) {
+    return hg_cram_compress_blocks_metrics_fqz_host(ctx, n, metrics, method_set, level, version_major, in, in_len, nullptr, out, out_len, method_used);
+}
+
+int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metrics *const *metrics, const uint32_t *method_set, int level,
+                                             int version_major, const uint8_t *const *in, const uint32_t *in_len, const hg_fqz_slice *const *fqz,
+                                             uint8_t *const *out, uint32_t *out_len, int32_t *method_used) {
     if (!ctx || (n && (!method_set || !in || !in_len || !out || !out_len || !method_used))) return HG_EINVAL;
     struct Blk { bool trial, done, retry; uint32_t method, orig; size_t j0, j1; };
     std::vector<Blk> B(n);
@@ -194,9 +207,10 @@ int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics 
             taken.push_back(i);
             if (!trial) { jobs.push_back({i, M->method}); b.j1 = jobs.size(); continue; }
             b.trial = true;
-            // like an htslib built without bz2 / lzma (fd->use_bz2 = 0): methods the engine does not have leave the set
-            const uint32_t have = ~((1u << HG_M_BZIP2) | (1u << HG_M_LZMA) | (1u << HG_M_FQZ) | (1u << HG_M_FQZ_b) | (1u << HG_M_FQZ_c) |
-                                    (1u << HG_M_FQZ_d) | (1u << 9) | (1u << 10));
+            // like an htslib built without bz2 / lzma (fd->use_bz2 = 0): methods the engine does not have leave the set; fqzcomp
+            // needs the slice's record lengths (cram_compress_by_method gets them from its cram_slice, cram_io.c:1808-1820)
+            const uint32_t fqz_bits = (1u << HG_M_FQZ) | (1u << HG_M_FQZ_b) | (1u << HG_M_FQZ_c) | (1u << HG_M_FQZ_d);
+            const uint32_t have = ~((1u << HG_M_BZIP2) | (1u << HG_M_LZMA) | (fqz && fqz[i] ? 0u : fqz_bits) | (1u << 9) | (1u << 10));
             uint32_t method = b.method & have;
             if (M->revised_method) method = M->revised_method & have; else M->revised_method = method;
             if (M->next_trial <= 0) {
@@ -220,7 +234,7 @@ int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics 
         if (taken.empty()) break;
         // ---- compress -------------------------------------------------------------------------------------------
         std::vector<uint8_t *> res; std::vector<uint32_t> rlen;
-        int rc = run_jobs(ctx, jobs, level, in, in_len, res, rlen);
+        int rc = run_jobs(ctx, jobs, level, in, in_len, fqz, res, rlen);
         if (rc != HG_OK) { for (auto p : res) free(p); return rc; }
         // ---- select, then fold the statistics in block order (cram_io.c:2064-2244) ------------------------------
         for (size_t i : taken) {

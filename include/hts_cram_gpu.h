@@ -88,7 +88,7 @@ void cram_free_block(cram_block *b);
 cram_metrics *cram_new_metrics(void);
 
 /* Exactly the reference's function: CRC check (once), method dispatch, b->data replaced, method = RAW; 0 / -1.
- * bzip2, lzma and fqzcomp blocks fail with -1 and an error message, like a libhts built without those codecs. */
+ * bzip2 and lzma blocks fail with -1 and an error message, like a libhts built without those libraries. */
 int cram_uncompress_block(cram_block *b);
 /* All blocks of a slice / container at once; returns 0 or -1 if any block failed (each block is left either fully
  * decoded or untouched; blk_rc, if given, receives the per-block 0 / -1). */
@@ -111,6 +111,18 @@ int hg_cram_compress_blocks(const hg_cram_opts *opts, cram_block **b, cram_metri
 
 /* Same with one level per block (cram_compress_slice mixes level 1 and fd->level, cram_encode.c:886-935). */
 int hg_cram_compress_blocks_lv(const hg_cram_opts *opts, cram_block **b, cram_metrics **metrics, const int *method, const int *level, int n);
+
+/* The `cram_slice *s` argument of cram_compress_block2/3 reduced to what a codec reads from it: the per-record quality lengths
+ * and BAM flags that cram_compress_by_method copies into an fqz_slice for the FQZ* methods (cram_io.c:1808-1820; same layout as
+ * htscodecs' fqz_slice, so that one can be passed with a cast).  With it a quality block keeps the FQZ / FQZ_b / FQZ_c / FQZ_d
+ * bits of its method set (fqzcomp.hip); without it those bits are dropped, as for a NULL slice. */
+#ifndef HG_FQZ_SLICE_DEFINED
+#define HG_FQZ_SLICE_DEFINED
+typedef struct hg_fqz_slice { uint32_t num_records; const uint32_t *len; const uint32_t *flags; } hg_fqz_slice;
+#endif
+int hg_cram_compress_block_fqz(const hg_cram_opts *opts, const hg_fqz_slice *fqz, cram_block *b, cram_metrics *metrics, int method, int level);
+int hg_cram_compress_blocks_fqz(const hg_cram_opts *opts, cram_block **b, cram_metrics **metrics, const int *method, const int *level,
+                                const hg_fqz_slice *const *fqz, int n);
 
 /* ---- cram_compress_slice's method-set policy (cram/cram_encode.c:803-988) as data.  Which codecs a block may be tried
  *      with depends on the file version, the compression level, the use_* options and the data series; the reference
@@ -144,6 +156,9 @@ int hg_cram_slice_plan(const hg_cram_slice_opts *o, const uint8_t *present, int 
  * hg_cram_compress_block.  Returns 0 / -1. */
 int hg_cram_compress_slice(const hg_cram_slice_opts *o, const hg_cram_opts *opts, cram_block **block, cram_metrics **metrics,
                            const int *nvals, cram_block **aux, int naux);
+/* ... with the slice's fqz_slice for the DS_QS block (use_fqz puts the FQZ* methods into its set, cram_encode.c:864-869) */
+int hg_cram_compress_slice_fqz(const hg_cram_slice_opts *o, const hg_cram_opts *opts, cram_block **block, cram_metrics **metrics,
+                               const int *nvals, cram_block **aux, int naux, const hg_fqz_slice *qs);
 
 /* Block framing (cram_read_block / cram_write_block with fd reduced to the transport and the file's major version):
  * method u8, content_type u8, content_id / comp_size / uncomp_size as ITF8 (v2, v3) or uint7 varints (v4), payload,

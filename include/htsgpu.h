@@ -269,7 +269,10 @@ int hg_fqz_decode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in
  * The parameter block is chosen on the host (modelled on the four htscodecs presets; any choice is valid by the format),
  * the adaptive coding runs one wavefront per block.  A block whose record lengths do not add up to in_len[i] gets
  * out_len[i] = 0.  out[i] must hold hg_fqz_compress_bound(in_len[i], num_records).  Synchronous. */
+#ifndef HG_FQZ_SLICE_DEFINED
+#define HG_FQZ_SLICE_DEFINED
 typedef struct hg_fqz_slice { uint32_t num_records; const uint32_t *len; const uint32_t *flags; } hg_fqz_slice;
+#endif
 size_t hg_fqz_compress_bound(size_t in_len, size_t num_records);
 int hg_fqz_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const hg_fqz_slice *const *slice,
                        const int32_t *strat, size_t n, uint8_t *const *out, uint32_t *out_len);
@@ -355,11 +358,17 @@ void hg_cram_metrics_free(hg_cram_metrics *m);
  * run and the smallest output kept, afterwards only the learnt method; statistics, method costs, retrial spans and
  * the culling of persistently bad methods follow the reference.  Blocks of one call that share a metrics object are
  * handled in their order with the reference's state sequence (the call runs in rounds, split where a trial phase
- * ends).  bzip2 / lzma / fqzcomp bits are dropped from the set, as in an
+ * ends).  bzip2 / lzma bits (and the fqzcomp bits of a block without slice information) are dropped from the set, as in an
  * htslib built without those libraries.  method_used[i] = on-disk method id; out[i] must hold hg_cram_compress_bound(in_len[i]). */
 int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics *const *metrics, const uint32_t *method_set,
                                          int level, int version_major, const uint8_t *const *in, const uint32_t *in_len,
                                          uint8_t *const *out, uint32_t *out_len, int32_t *method_used);
+/* The same with the cram_slice argument of cram_compress_block2/3 reduced to what the codecs read from it: fqz[i] = the record
+ * lengths and flags of block i when it is a quality block (cram_io.c:1808-1820), NULL otherwise; fqz itself may be NULL.
+ * Blocks with a slice keep the FQZ / FQZ_b / FQZ_c / FQZ_d bits of their method set (fqzcomp.hip). */
+int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metrics *const *metrics, const uint32_t *method_set,
+                                             int level, int version_major, const uint8_t *const *in, const uint32_t *in_len,
+                                             const hg_fqz_slice *const *fqz, uint8_t *const *out, uint32_t *out_len, int32_t *method_used);
 
 /* ---- BAM record framing on the device: the framing half of bam_read1 (sam.c:784-866) and
  *      nibble2base (simd.c:119-161) for consumers that keep the inflated stream in HBM. ---- */

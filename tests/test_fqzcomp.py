@@ -149,3 +149,29 @@ def test_gpu_encoder_matches_oracle_and_decodes(engine, qorc):
     # refused inputs: record lengths that do not add up, an empty record, no slice information
     bad = engine.fqz_encode_host([datas[0], datas[0]], [lens[0][:-1], np.concatenate([lens[0][:-1], [0], lens[0][-1:]])], [None, None], [0, 0])
     assert bad == [b"", b""]
+
+
+@pytest.mark.gpu
+def test_auto_tuner_offers_fqzcomp_when_the_slice_is_known(engine, qorc):
+    """cram_compress_block2(fd, s, b, ...) with use_fqz: the FQZ* bits of a quality block's method set are tried next to rANS / gzip when
+    the slice's record lengths travel with the block (cram_io.c:1801-1825), learnt by the metrics object, and written as method 7."""
+    import ctypes as C
+    from htslib_amd import _native as nat
+    rng = np.random.default_rng(12)
+    M = lambda *ids: sum(1 << i for i in ids)
+    qset = M(1, 5, 17, 7, 13, 14, 15)                   # GZIP, RANS_PR0, RANS_PR1, FQZ, FQZ_b, FQZ_c, FQZ_d  (cram_encode.c:864-869 at level > 6)
+    m1, m2 = nat.lib.hg_cram_metrics_new(), nat.lib.hg_cram_metrics_new()
+    A = C.cast(m1, C.POINTER(nat.CramMetrics)).contents
+    Bm = C.cast(m2, C.POINTER(nat.CramMetrics)).contents
+    for call in range(6):
+        q, ln, fl = reads(rng, 400, 100, True, 41)
+        outs, used = engine.cram_compress_blocks_metrics([q, q], [m1, m2], [qset, qset], level=7, fqz=[(ln, fl), None])
+        assert used[0] == 7 and used[1] == 5, (call, used)                # with the slice fqzcomp wins; without it the bits are dropped
+        assert len(outs[0]) < 0.9 * len(outs[1])
+        rc, back, lens = qorc.decode(outs[0], len(q), len(ln))            # the oracle reads what the tuner kept
+        assert rc == 0 and back == q and (lens == ln).all()
+        back, st = engine.cram_uncompress_blocks([(int(u), o, len(q)) for o, u in zip(outs, used)])
+        assert (st == 0).all() and back == [q, q]
+    assert A.method in (7, 13, 14, 15) and Bm.method in (5, 17)           # learnt: an fqzcomp preset / an Nx16 order
+    assert not (Bm.revised_method & M(7, 13, 14, 15)) and (A.revised_method & M(7, 13, 14, 15))
+    nat.lib.hg_cram_metrics_free(m1); nat.lib.hg_cram_metrics_free(m2)
