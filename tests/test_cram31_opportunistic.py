@@ -1,6 +1,6 @@
-"""Pinning of the CRAM 3.1 codecs (rANS Nx16, range coder, tok3) needs ONE stream written by stock htslib >= 1.12; the
+"""Pinning of the CRAM 3.1 codecs (rANS Nx16, range coder, fqzcomp, tok3) needs ONE stream written by stock htslib >= 1.12; the
 reference checkout has none (htscodecs submodule empty, all CRAM fixtures are v3.0).  If a `samtools` binary exists on the
-box running the tests, write the synthetic reads as CRAM 3.1 in every profile, pull out each method 5 / 6 / 8 block, decode
+box running the tests, write the synthetic reads as CRAM 3.1 in every profile, pull out each method 5 / 6 / 7 / 8 block, decode
 it on the GPU and compare with samtools' own decode -- and freeze the blocks as golden vectors.  Otherwise: skip, loudly."""
 import os
 import shutil
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def test_decode_blocks_written_by_stock_samtools(engine, tmp_path):
     sam = shutil.which("samtools")
     if not sam:
-        pytest.skip("UNPINNED: no samtools on this box -- rANS Nx16 / arith / tok3 parity with htscodecs remains unverified "
+        pytest.skip("UNPINNED: no samtools on this box -- rANS Nx16 / arith / fqzcomp / tok3 parity with htscodecs remains unverified "
                     "(tests compare the kernels with oracle/*_oracle.c, a restatement of the published format)")
     ver = subprocess.run([sam, "--version"], capture_output=True, text=True).stdout.split("\n")[0]
     from htslib_amd import synth
@@ -33,7 +33,7 @@ def test_decode_blocks_written_by_stock_samtools(engine, tmp_path):
             continue
         back = subprocess.run([sam, "fastq", str(cram)], capture_output=True).stdout
         raw = cram.read_bytes()
-        blocks = [b for _, blks in R.containers(raw) for b in blks if b[0] in (5, 6, 8)]
+        blocks = [b for _, blks in R.containers(raw) for b in blks if b[0] in (5, 6, 7, 8)]
         if not blocks:
             continue
         n = len(blocks)

@@ -64,7 +64,7 @@ def test_status_codes(engine):
     blocks = [(1, good, len(d)), (1, bad_crc, len(d)), (1, good, len(d) - 1), (1, good[:len(good) // 2], len(d)),
               (7, b"\x00" * 20, 10), (2, b"BZh", 10), (0, d, len(d)), (0, d, len(d) + 1), (1, b"", 0)]
     outs, st = engine.cram_uncompress_blocks(blocks)
-    assert list(st) == [0, -2, -1, -1, -3, -3, 0, -1, 0]
+    assert list(st) == [0, -2, -1, -1, -1, -3, 0, -1, 0]        # a malformed fqzcomp block is -1 (the codec is in the engine), bzip2 is not offered
     assert outs[0] == d and outs[6] == d and outs[1] is None
 
 

@@ -163,15 +163,17 @@ def test_auto_tuner_offers_fqzcomp_when_the_slice_is_known(engine, qorc):
     m1, m2 = nat.lib.hg_cram_metrics_new(), nat.lib.hg_cram_metrics_new()
     A = C.cast(m1, C.POINTER(nat.CramMetrics)).contents
     Bm = C.cast(m2, C.POINTER(nat.CramMetrics)).contents
+    profile = rng.integers(5, 38, 100)                   # qualities that depend on the cycle: a position context pays, an order-1 model does not
     for call in range(6):
-        q, ln, fl = reads(rng, 400, 100, True, 41)
+        ln = np.full(400, 100, np.uint32); fl = (rng.integers(0, 2, 400) * 128 + 1).astype(np.uint32)
+        q = (np.tile(profile, 400) + rng.integers(-1, 2, 40_000)).astype(np.uint8).tobytes()
         outs, used = engine.cram_compress_blocks_metrics([q, q], [m1, m2], [qset, qset], level=7, fqz=[(ln, fl), None])
-        assert used[0] == 7 and used[1] == 5, (call, used)                # with the slice fqzcomp wins; without it the bits are dropped
+        assert used[0] == 7 and used[1] in (1, 5), (call, used, [len(o) for o in outs])   # with the slice fqzcomp wins; without it the bits are dropped
         assert len(outs[0]) < 0.9 * len(outs[1])
         rc, back, lens = qorc.decode(outs[0], len(q), len(ln))            # the oracle reads what the tuner kept
         assert rc == 0 and back == q and (lens == ln).all()
         back, st = engine.cram_uncompress_blocks([(int(u), o, len(q)) for o, u in zip(outs, used)])
         assert (st == 0).all() and back == [q, q]
-    assert A.method in (7, 13, 14, 15) and Bm.method in (5, 17)           # learnt: an fqzcomp preset / an Nx16 order
+    assert A.method in (7, 13, 14, 15) and Bm.method in (1, 5, 17)        # learnt: an fqzcomp preset / gzip or an Nx16 order
     assert not (Bm.revised_method & M(7, 13, 14, 15)) and (A.revised_method & M(7, 13, 14, 15))
     nat.lib.hg_cram_metrics_free(m1); nat.lib.hg_cram_metrics_free(m2)
