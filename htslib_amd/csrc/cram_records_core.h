@@ -1,0 +1,418 @@
+// cram_records_core.h -- the record loop of cram_decode_slice (reference cram/cram_decode.c:2346-3026) for CRAM 2.x / 3.x slices,
+// reduced to what does not need the reference sequence: every data series is CONSUMED exactly as the reference consumes it (so
+// that series sharing an EXTERNAL block or the CORE bit stream stay in step), and the per-record results that are functions of the
+// series alone are produced -- flags, reference id, position, read length, read group, mapping quality, read name, mate fields,
+// CIGAR (cram_decode_seq's feature walk, cram_decode.c:1096-1900, without the base reconstruction), alignment end, and, after the
+// mate cross-referencing pass (cram_decode_slice_xref, cram_decode.c:2140-2307), mate position / reference, template length and
+// the mate bits of the flags.  Bases, qualities and aux values are skipped over, not produced (next step of SURVEY 8f N2).
+//
+// Codecs (cram/cram_codecs.c): EXTERNAL (:350-410; ITF8 for integer series, bytes for byte series), HUFFMAN (canonical codes,
+// :2641-2930), BETA (:1072-1130), GAMMA (:2546-2568), SUBEXP (:2452-2494), BYTE_ARRAY_LEN (:2937-3010), BYTE_ARRAY_STOP (:3180-3260).
+// GOLOMB / GOLOMB_RICE (never written by htslib or htsjdk) and the CRAM 4 transforms are not handled: the slice reports -3.
+//
+// One slice is one serial chain -- a record's bits start where the previous record's end -- so the unit of parallelism is the
+// slice.  The code is written once for host and device: the gfx950 kernel (cram_records.hip) runs it with one wavefront per slice,
+// the test harness (tests/native/cram_records_host.cpp) compiles the same source for the CPU to check it against the reference's
+// SAM twins without a GPU.  It is NOT a CPU fallback of the product: libhtsgpu exports only the device path.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define HGR_FN __host__ __device__ inline
+#else
+#define HGR_FN inline
+#endif
+
+namespace hgr {
+
+enum { E_NULL = 0, E_EXTERNAL = 1, E_GOLOMB = 2, E_HUFFMAN = 3, E_BYTE_ARRAY_LEN = 4, E_BYTE_ARRAY_STOP = 5, E_BETA = 6, E_SUBEXP = 7,
+       E_GOLOMB_RICE = 8, E_GAMMA = 9 };
+// kind / a / b / c:  EXTERNAL: a = block slot.  HUFFMAN: a = first code in the code table, b = number of codes.  BETA: a = offset,
+// b = bits.  GAMMA: a = offset.  SUBEXP: a = offset, b = k.  BYTE_ARRAY_LEN: a = codec of the length, b = codec of the bytes.
+// BYTE_ARRAY_STOP: a = block slot, b = stop byte.
+struct Codec { int32_t kind, a, b, c; };
+struct HuffCode { int32_t symbol, len; uint32_t code; int32_t pad; };            // sorted by (len, symbol), canonical codes assigned
+enum Series { S_BF, S_CF, S_RI, S_RL, S_AP, S_RG, S_RN, S_MF, S_NS, S_NP, S_TS, S_NF, S_TL, S_FN, S_FC, S_FP, S_DL, S_BA, S_BS, S_IN, S_SC,
+              S_HC, S_PD, S_RS, S_MQ, S_QS, S_BB, S_QQ, S_N };
+
+// What the compression header says (cram_decode_compression_header, cram_decode.c:144-950), flattened by the host
+struct Plan {
+    int32_t codec_of[S_N];                // index into codecs[] or -1 (series absent from the encoding map)
+    int32_t rn_included, ap_delta, qs_seq_orient, nslots;
+    int32_t nTL;                          // tag dictionary lines; line t holds tags tl_off[t] .. tl_off[t+1]-1 of tl_codec[]
+    const int32_t *tl_off;
+    const int32_t *tl_codec;              // codec index of the tag's encoding (tag encoding map), -1 = not in the map
+    const Codec *codecs;
+    const HuffCode *huff;
+};
+// One slice: its blocks by slot (offset / length into `data`; length 0xffffffff = block absent), the CORE block, scratch cursors
+struct Slice {
+    const uint8_t *data;
+    const uint32_t *blk_off, *blk_len;    // nslots each
+    uint32_t *cursor;                     // nslots words of scratch, zeroed by the decoder
+    uint32_t core_off, core_len;
+    int32_t nrec, ref_seq_id;             // slice header: -2 = multi-reference slice (RI is read), -1 = unmapped
+    int64_t ref_seq_start;
+    int32_t nref;                         // number of @SQ lines (bounds of RI / NS)
+    uint32_t cigar_cap, name_cap;
+};
+// Per-record results (arrays of nrec), the CIGAR ops and the read names of the slice
+struct Cols {
+    int32_t *flags, *cram_flags, *ref_id, *len, *rg, *mqual, *mate_flags, *mate_ref_id, *mate_line, *ncigar, *name_len;
+    uint32_t *cigar_off, *name_off;
+    int64_t *apos, *aend, *mate_pos, *tlen, *explicit_tlen;
+    uint32_t *cigar;                      // (len << 4 | op), BAM encoding
+    uint8_t *names;
+    uint32_t *totals;                     // [0] = cigar ops written, [1] = name bytes written
+};
+enum { ERR_MALFORMED = -1, ERR_UNSUPPORTED = -3 };
+enum { BAM_FPAIRED = 1, BAM_FUNMAP = 4, BAM_FMUNMAP = 8, BAM_FREVERSE = 16, BAM_FMREVERSE = 32, BAM_FREAD1 = 64 };
+enum { CF_PRESERVE_QUAL = 1, CF_DETACHED = 2, CF_MATE_DOWNSTREAM = 4, CF_NO_SEQ = 8, CF_EXPLICIT_TLEN = 16 };
+enum { CRAM_M_REVERSE = 1, CRAM_M_UNMAP = 2 };
+enum { C_MATCH = 0, C_INS = 1, C_DEL = 2, C_REF_SKIP = 3, C_SOFT_CLIP = 4, C_HARD_CLIP = 5, C_PAD = 6 };
+constexpr int64_t TLEN_UNSET = INT64_MIN;
+
+struct Reader {
+    const Plan *P; const Slice *S;
+    uint64_t bit;                         // position in the CORE block, MSB first
+    int err;
+
+    // ---- CORE bit stream (get_bit_MSB / get_bits_MSB, cram_codecs.c:73-200) ----
+    HGR_FN bool need_bits(uint64_t n) { if (bit + n > (uint64_t)S->core_len * 8u) { if (!err) err = ERR_MALFORMED; return false; } return true; }
+    HGR_FN uint32_t bit1() { const uint32_t b = (S->data[S->core_off + (bit >> 3)] >> (7u - (bit & 7u))) & 1u; bit++; return b; }
+    HGR_FN uint32_t bits(int n) { uint32_t v = 0; for (int i = 0; i < n; i++) v = (v << 1) | bit1(); return v; }
+
+    // ---- EXTERNAL blocks ----
+    HGR_FN bool slot_ok(int32_t s) { if (s < 0 || s >= P->nslots || S->blk_len[s] == 0xffffffffu) { if (!err) err = ERR_MALFORMED; return false; } return true; }
+    HGR_FN int32_t ext_itf8(int32_t s) {                          // itf8_get at the cursor (cram_external_decode_int)
+        if (!slot_ok(s)) return 0;
+        const uint8_t *p = S->data + S->blk_off[s]; const uint32_t n = S->blk_len[s]; uint32_t c = S->cursor[s];
+        if (c >= n) { if (!err) err = ERR_MALFORMED; return 0; }
+        const uint32_t b0 = p[c];
+        const int extra = b0 < 0x80 ? 0 : b0 < 0xc0 ? 1 : b0 < 0xe0 ? 2 : b0 < 0xf0 ? 3 : 4;
+        if (c + (uint32_t)extra >= n) { if (!err) err = ERR_MALFORMED; return 0; }
+        uint32_t v;
+        if (extra == 0) v = b0;
+        else if (extra == 1) v = ((b0 & 0x3f) << 8) | p[c + 1];
+        else if (extra == 2) v = ((b0 & 0x1f) << 16) | (p[c + 1] << 8) | p[c + 2];
+        else if (extra == 3) v = ((b0 & 0x0f) << 24) | (p[c + 1] << 16) | (p[c + 2] << 8) | p[c + 3];
+        else v = ((b0 & 0x0f) << 28) | (p[c + 1] << 20) | (p[c + 2] << 12) | (p[c + 3] << 4) | (p[c + 4] & 0x0f);
+        S->cursor[s] = c + 1u + (uint32_t)extra;
+        return (int32_t)v;
+    }
+    HGR_FN void ext_bytes(int32_t s, uint8_t *out, uint32_t n) {      // cram_external_decode_char
+        if (!slot_ok(s)) return;
+        const uint32_t c = S->cursor[s];
+        if (n > S->blk_len[s] || c > S->blk_len[s] - n) { if (!err) err = ERR_MALFORMED; return; }
+        if (out) for (uint32_t i = 0; i < n; i++) out[i] = S->data[S->blk_off[s] + c + i];
+        S->cursor[s] = c + n;
+    }
+
+    // ---- one value of an integer / byte series ----
+    HGR_FN int32_t huffman(const Codec &C) {
+        if (C.b <= 0) { if (!err) err = ERR_MALFORMED; return 0; }
+        const HuffCode *h = P->huff + C.a;
+        if (h[0].len == 0 && C.b == 1) return h[0].symbol;                // one symbol, no bits (cram_huffman_decode_int0)
+        uint32_t val = 0; int len = 0;
+        for (int i = 0; i < C.b; i++) {                                   // codes are sorted by length: extend, then compare
+            const int d = h[i].len - len;
+            if (d > 0) { if (!need_bits((uint64_t)d)) return 0; val = (val << d) | bits(d); len = h[i].len; }
+            if (h[i].code == val) return h[i].symbol;
+        }
+        if (!err) err = ERR_MALFORMED;
+        return 0;
+    }
+    HGR_FN int32_t value(int32_t ci, bool as_byte) {
+        if (ci < 0) { if (!err) err = ERR_MALFORMED; return 0; }
+        const Codec C = P->codecs[ci];
+        switch (C.kind) {
+        case E_EXTERNAL:
+            if (as_byte) { uint8_t b = 0; ext_bytes(C.a, &b, 1); return b; }
+            return ext_itf8(C.a);
+        case E_HUFFMAN: return huffman(C);
+        case E_BETA: if (C.b < 0 || C.b > 32 || !need_bits((uint64_t)C.b)) { if (!err) err = ERR_MALFORMED; return 0; } return (int32_t)(bits(C.b) - (uint32_t)C.a);
+        case E_GAMMA: {
+            int nz = 0;
+            for (;;) { if (!need_bits(1)) return 0; if (bit1()) break; if (++nz > 31) { if (!err) err = ERR_MALFORMED; return 0; } }
+            if (!need_bits((uint64_t)nz)) return 0;
+            uint32_t v = 1; for (int i = 0; i < nz; i++) v = (v << 1) | bit1();
+            return (int32_t)(v - (uint32_t)C.a);
+        }
+        case E_SUBEXP: {
+            int i = 0;
+            for (;;) { if (!need_bits(1)) return 0; if (!bit1()) break; if (++i > 31) { if (!err) err = ERR_MALFORMED; return 0; } }
+            const int tail = i ? i + C.b - 1 : C.b;
+            if (tail < 0 || tail > 31 || !need_bits((uint64_t)tail)) { if (!err) err = ERR_MALFORMED; return 0; }
+            uint32_t v = bits(tail);
+            if (i) v += 1u << (i + C.b - 1);
+            return (int32_t)(v - (uint32_t)C.a);
+        }
+        default: if (!err) err = ERR_UNSUPPORTED; return 0;
+        }
+    }
+    HGR_FN int32_t ival(int s) { return value(P->codec_of[s], false); }
+    HGR_FN int32_t bval(int s) { return value(P->codec_of[s], true); }
+
+    // ---- one item of a byte-array series: the bytes go to out (may be null), the length is returned ----
+    HGR_FN int32_t array(int32_t ci, uint8_t *out, uint32_t cap) {
+        if (ci < 0) { if (!err) err = ERR_MALFORMED; return 0; }
+        const Codec C = P->codecs[ci];
+        if (C.kind == E_BYTE_ARRAY_STOP) {                                // cram_byte_array_stop_decode_char
+            if (!slot_ok(C.a)) return 0;
+            const uint8_t *p = S->data + S->blk_off[C.a]; const uint32_t n = S->blk_len[C.a]; uint32_t c = S->cursor[C.a], k = 0;
+            while (c < n && p[c] != (uint8_t)C.b) { if (out) { if (k >= cap) { if (!err) err = ERR_UNSUPPORTED; return 0; } out[k] = p[c]; } k++; c++; }
+            if (c >= n) { if (!err) err = ERR_MALFORMED; return 0; }      // no stop byte
+            S->cursor[C.a] = c + 1u;
+            return (int32_t)k;
+        }
+        if (C.kind == E_BYTE_ARRAY_LEN) {                                 // length from one codec, bytes from the other
+            const int32_t len = value(C.a, false);
+            if (err) return 0;
+            if (len < 0) { err = ERR_MALFORMED; return 0; }
+            if (out && (uint32_t)len > cap) { err = ERR_UNSUPPORTED; return 0; }
+            if (C.b < 0) { err = ERR_MALFORMED; return 0; }
+            const Codec V = P->codecs[C.b];
+            if (V.kind == E_EXTERNAL) ext_bytes(V.a, out, (uint32_t)len);
+            else for (int32_t i = 0; i < len && !err; i++) { const int32_t b = value(C.b, true); if (out) out[i] = (uint8_t)b; }
+            return len;
+        }
+        if (!err) err = ERR_UNSUPPORTED;                                  // array series through a scalar codec: not written by any encoder we know
+        return 0;
+    }
+};
+
+// cram_decode_seq without the bases (cram_decode.c:1096-1900): features -> CIGAR, alignment end; MQ; the QS bytes are skipped
+HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint32_t &ncig_total) {
+    const Plan *P = R.P;
+    const int32_t len = O.len[rec];
+    int64_t ref_pos = O.apos[rec] - 1;
+    int32_t prev_pos = 0, seq_pos = 1, cig_len = 0, cig_op = C_MATCH;
+    const uint32_t cig0 = ncig_total;
+    auto emit = [&](uint32_t l, int op) { if (ncig_total >= R.S->cigar_cap) { if (!R.err) R.err = ERR_UNSUPPORTED; return; } O.cigar[ncig_total++] = (l << 4) | (uint32_t)op; };
+    auto flush_unless = [&](int op) { if (cig_len && cig_op != op) { emit((uint32_t)cig_len, cig_op); cig_len = 0; } };
+    const int32_t fn = R.ival(S_FN);                                      // a series the walk needs and the map lacks is an error, as in the reference
+    {
+        for (int32_t f = 0; f < fn && !R.err; f++) {
+            const int32_t op = R.bval(S_FC);
+            int32_t pos = R.ival(S_FP) + prev_pos;
+            if (R.err) break;
+            if (pos <= 0) { R.err = ERR_MALFORMED; break; }
+            if (len != 0 && pos > len) {
+                const int32_t valid_end = (op == 'N' || op == 'P' || op == 'H' || op == 'D') ? len + 1 : len;
+                if (pos > valid_end) { R.err = ERR_MALFORMED; break; }
+            }
+            if (pos > seq_pos) { flush_unless(C_MATCH); cig_op = C_MATCH; cig_len += pos - seq_pos; ref_pos += pos - seq_pos; seq_pos = pos; }
+            prev_pos = pos;
+            switch (op) {
+            case 'S': {
+                if (cig_len) { emit((uint32_t)cig_len, cig_op); cig_len = 0; }
+                {                                                         // no SC codec: one unknown base (cram_decode.c:1317-1329)
+                    const int32_t n = P->codec_of[S_SC] >= 0 ? R.array(P->codec_of[S_SC], nullptr, 0) : 1;
+                    emit((uint32_t)n, C_SOFT_CLIP); cig_op = C_SOFT_CLIP; seq_pos += n;
+                }
+                break;
+            }
+            case 'X': flush_unless(C_MATCH); (void)R.bval(S_BS); cig_op = C_MATCH; cig_len++; seq_pos++; ref_pos++; break;
+            case 'D': {
+                flush_unless(C_DEL);
+                { const int32_t v = R.ival(S_DL); if (v < 0) { if (!R.err) R.err = ERR_MALFORMED; break; } cig_op = C_DEL; cig_len += v; ref_pos += v; }
+                break;
+            }
+            case 'I': {
+                flush_unless(C_INS);
+                { const int32_t n = R.array(P->codec_of[S_IN], nullptr, 0); cig_op = C_INS; cig_len += n; seq_pos += n; }
+                break;
+            }
+            case 'i': flush_unless(C_INS); (void)R.bval(S_BA); cig_op = C_INS; cig_len++; seq_pos++; break;
+            case 'b': {
+                flush_unless(C_MATCH);
+                const int32_t n = R.array(P->codec_of[S_BB], nullptr, 0);
+                cig_op = C_MATCH; cig_len += n; seq_pos += n; ref_pos += n;
+                break;
+            }
+            case 'q': flush_unless(C_MATCH); (void)R.array(P->codec_of[S_QQ], nullptr, 0); cig_op = C_MATCH; break;
+            case 'B':
+                flush_unless(C_MATCH);
+                (void)R.bval(S_BA);
+                (void)R.bval(S_QS);
+                cig_op = C_MATCH; cig_len++; seq_pos++; ref_pos++;
+                break;
+            case 'Q': (void)R.bval(S_QS); break;
+            case 'H': {
+                flush_unless(C_HARD_CLIP);
+                { const int32_t v = R.ival(S_HC); if (v < 0) { if (!R.err) R.err = ERR_MALFORMED; break; } cig_op = C_HARD_CLIP; cig_len += v; }
+                break;
+            }
+            case 'P': {
+                flush_unless(C_PAD);
+                { const int32_t v = R.ival(S_PD); if (v < 0) { if (!R.err) R.err = ERR_MALFORMED; break; } cig_op = C_PAD; cig_len += v; }
+                break;
+            }
+            case 'N': {
+                flush_unless(C_REF_SKIP);
+                { const int32_t v = R.ival(S_RS); if (v < 0) { if (!R.err) R.err = ERR_MALFORMED; break; } cig_op = C_REF_SKIP; cig_len += v; ref_pos += v; }
+                break;
+            }
+            default: if (!R.err) R.err = ERR_MALFORMED; break;
+            }
+        }
+        // an implicit match for the bases no feature accounted for (cram_decode.c:1701-1797)
+        if (!R.err && len >= seq_pos) {
+            ref_pos += len - seq_pos + 1;
+            flush_unless(C_MATCH); cig_op = C_MATCH; cig_len += len - seq_pos + 1;
+        }
+    }
+    if (cig_len) emit((uint32_t)cig_len, cig_op);
+    O.cigar_off[rec] = cig0; O.ncigar[rec] = (int32_t)(ncig_total - cig0);
+    O.aend[rec] = ref_pos > O.apos[rec] ? ref_pos : O.apos[rec];
+    O.mqual[rec] = R.ival(S_MQ);
+    if ((cf & CF_PRESERVE_QUAL) && !R.err) {                             // len quality bytes
+        if (P->codec_of[S_QS] < 0) { R.err = ERR_MALFORMED; return; }
+        const Codec C = P->codecs[P->codec_of[S_QS]];
+        if (C.kind == E_EXTERNAL) R.ext_bytes(C.a, nullptr, (uint32_t)len);
+        else for (int32_t i = 0; i < len && !R.err; i++) (void)R.bval(S_QS);
+    }
+    if (cf & CF_NO_SEQ) O.len[rec] = 0;
+}
+
+// cram_decode_aux (cram_decode.c:2008-2137): the tag values are consumed, not kept
+HGR_FN void skip_aux(Reader &R) {
+    const Plan *P = R.P;
+    const int32_t tl = R.ival(S_TL);
+    if (R.err) return;
+    if (tl < 0 || tl >= P->nTL) { R.err = ERR_MALFORMED; return; }
+    for (int32_t t = P->tl_off[tl]; t < P->tl_off[tl + 1] && !R.err; t++) {
+        const int32_t ci = P->tl_codec[t];
+        if (ci < 0) { R.err = ERR_MALFORMED; return; }
+        const int32_t k = P->codecs[ci].kind;
+        if (k == E_BYTE_ARRAY_LEN || k == E_BYTE_ARRAY_STOP) (void)R.array(ci, nullptr, 0);
+        else (void)R.value(ci, true);                                     // out_sz = 1: one byte through a scalar codec
+    }
+}
+
+// cram_decode_slice_xref (cram_decode.c:2140-2307)
+HGR_FN int xref(const Cols &O, int32_t nrec) {
+    for (int32_t rec = 0; rec < nrec; rec++) {
+        if (O.mate_line[rec] >= 0) {
+            if (O.mate_line[rec] < nrec) {
+                if (O.tlen[rec] == TLEN_UNSET) {
+                    int32_t id1 = rec, id2 = rec, ref = O.ref_id[rec], left_cnt = 0, right_cnt = 0;
+                    int64_t aleft = O.apos[rec], aright = O.aend[rec];
+                    do {
+                        if (aleft > O.apos[id2]) { aleft = O.apos[id2]; left_cnt = 1; } else if (aleft == O.apos[id2]) left_cnt++;
+                        if (aright < O.aend[id2]) { aright = O.aend[id2]; right_cnt = 1; } else if (aright == O.aend[id2]) right_cnt++;
+                        if (O.mate_line[id2] == -1) { O.mate_line[id2] = rec; break; }
+                        if (O.mate_line[id2] <= id2 || O.mate_line[id2] >= nrec) return -1;
+                        id2 = O.mate_line[id2];
+                        if (O.ref_id[id2] != ref) ref = -1;
+                    } while (id2 != id1);
+                    if (ref != -1) {
+                        int64_t tlen = aright - aleft + 1;
+                        id1 = id2 = rec;
+                        if (O.apos[id2] == aleft && (O.aend[id2] < aright || left_cnt <= 1)) { O.tlen[id2] = tlen; tlen = -tlen; }
+                        else if (O.apos[id2] == aleft && O.aend[id2] == aright && left_cnt > 1 && right_cnt > 1) {
+                            if (O.flags[id2] & BAM_FREAD1) { O.tlen[id2] = tlen; tlen = -tlen; } else O.tlen[id2] = -tlen;
+                        } else O.tlen[id2] = -tlen;
+                        id2 = O.mate_line[id2];
+                        while (id2 != id1) { O.tlen[id2] = tlen; id2 = O.mate_line[id2]; }
+                    } else {
+                        id1 = id2 = rec;
+                        O.tlen[id2] = 0;
+                        id2 = O.mate_line[id2];
+                        while (id2 != id1) { O.tlen[id2] = 0; id2 = O.mate_line[id2]; }
+                    }
+                }
+                const int32_t m = O.mate_line[rec];
+                O.mate_pos[rec] = O.apos[m];
+                O.mate_ref_id[rec] = O.ref_id[m];
+                O.flags[rec] |= BAM_FPAIRED;
+                if (O.flags[m] & BAM_FUNMAP) { O.flags[rec] |= BAM_FMUNMAP; O.tlen[rec] = 0; }
+                if (O.flags[rec] & BAM_FUNMAP) O.tlen[rec] = 0;
+                if (O.flags[m] & BAM_FREVERSE) O.flags[rec] |= BAM_FMREVERSE;
+            }
+        } else {
+            if (O.mate_flags[rec] & CRAM_M_REVERSE) O.flags[rec] |= BAM_FPAIRED | BAM_FMREVERSE;
+            if (O.mate_flags[rec] & CRAM_M_UNMAP) O.flags[rec] |= BAM_FMUNMAP;
+            if (!(O.flags[rec] & BAM_FPAIRED)) O.mate_ref_id[rec] = -1;
+        }
+        if (O.tlen[rec] == TLEN_UNSET) O.tlen[rec] = 0;
+    }
+    for (int32_t rec = 0; rec < nrec; rec++) if (O.explicit_tlen[rec] != TLEN_UNSET) O.tlen[rec] = O.explicit_tlen[rec];
+    return 0;
+}
+
+// The record loop of cram_decode_slice (cram_decode.c:2553-2967).  Returns 0, ERR_MALFORMED or ERR_UNSUPPORTED.
+HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
+    Reader R; R.P = P; R.S = S; R.bit = 0; R.err = 0;
+    for (int32_t i = 0; i < P->nslots; i++) S->cursor[i] = 0;
+    uint32_t ncig = 0, nname = 0;
+    int64_t last_apos = S->ref_seq_start;
+    for (int32_t rec = 0; rec < S->nrec && !R.err; rec++) {
+        const int32_t bf = R.ival(S_BF);
+        if (!R.err && (bf < 0 || bf >= 0x1000)) R.err = ERR_MALFORMED;
+        O.flags[rec] = bf;
+        const int32_t cf = R.ival(S_CF);
+        O.cram_flags[rec] = cf;
+        int32_t ref_id = S->ref_seq_id;
+        if (S->ref_seq_id == -2) ref_id = R.ival(S_RI);
+        if (!R.err && (ref_id < -1 || ref_id >= S->nref)) R.err = ERR_MALFORMED;
+        O.ref_id[rec] = ref_id;
+        const int32_t len = R.ival(S_RL);
+        if (!R.err && len < 0) R.err = ERR_MALFORMED;
+        O.len[rec] = len;
+        int64_t apos;
+        {
+            apos = R.ival(S_AP);
+            if (P->ap_delta) apos += last_apos;
+            last_apos = apos;
+            if (!R.err && S->ref_seq_id >= 0 && apos < S->ref_seq_start) R.err = ERR_MALFORMED;
+        }
+        O.apos[rec] = apos;
+        O.rg[rec] = R.ival(S_RG);
+        O.name_off[rec] = nname; O.name_len[rec] = 0;
+        auto read_name = [&]() {
+            const int32_t n = R.array(P->codec_of[S_RN], O.names + nname, S->name_cap - nname);
+            if (!R.err) { O.name_len[rec] = n; nname += (uint32_t)n; }
+        };
+        if (P->rn_included) read_name();
+        O.mate_pos[rec] = 0; O.mate_line[rec] = -1; O.mate_ref_id[rec] = -1; O.explicit_tlen[rec] = TLEN_UNSET;
+        O.mate_flags[rec] = 0; O.tlen[rec] = TLEN_UNSET;
+        if (cf & CF_DETACHED) {
+            O.mate_flags[rec] = R.ival(S_MF);
+            if (!P->rn_included) { O.name_off[rec] = nname; read_name(); }
+            { const int32_t v = R.ival(S_NS); if (!R.err && (v < -1 || v >= S->nref)) R.err = ERR_MALFORMED; O.mate_ref_id[rec] = v; }
+            O.mate_pos[rec] = R.ival(S_NP);
+            O.tlen[rec] = R.ival(S_TS);
+        } else if (cf & CF_MATE_DOWNSTREAM) {
+            O.mate_line[rec] = R.ival(S_NF) + rec + 1;
+            if (cf & CF_EXPLICIT_TLEN) O.explicit_tlen[rec] = R.ival(S_TS);
+        } else if (cf & CF_EXPLICIT_TLEN) {
+            O.explicit_tlen[rec] = R.ival(S_TS);
+        }
+        skip_aux(R);
+        if (R.err) break;
+        if (!(bf & BAM_FUNMAP)) {
+            if (apos <= 0) { R.err = ERR_MALFORMED; break; }
+            decode_features(R, O, rec, cf, ncig);
+        } else {
+            O.cigar_off[rec] = ncig; O.ncigar[rec] = 0; O.aend[rec] = apos; O.mqual[rec] = 0;
+            if (len) {
+                if (P->codec_of[S_BA] < 0) { R.err = ERR_MALFORMED; break; }
+                const Codec C = P->codecs[P->codec_of[S_BA]];
+                if (C.kind == E_EXTERNAL) R.ext_bytes(C.a, nullptr, (uint32_t)len);
+                else for (int32_t i = 0; i < len && !R.err; i++) (void)R.bval(S_BA);
+            }
+            if (cf & CF_PRESERVE_QUAL) {
+                if (P->codec_of[S_QS] < 0) { R.err = ERR_MALFORMED; break; }
+                const Codec C = P->codecs[P->codec_of[S_QS]];
+                if (C.kind == E_EXTERNAL) R.ext_bytes(C.a, nullptr, (uint32_t)len);
+                else for (int32_t i = 0; i < len && !R.err; i++) (void)R.bval(S_QS);
+            }
+        }
+    }
+    O.totals[0] = ncig; O.totals[1] = nname;
+    if (R.err) return R.err;
+    return xref(O, S->nrec) ? ERR_MALFORMED : 0;
+}
+
+}  // namespace hgr

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Freeze the reference's CRAM v3.0 fixtures as record-decoding vectors (cram_decode_slice).
+
+For every CRAM file of the reference's test directory that has a SAM / BAM twin (test/*.cram, test/tlen/*.cram), each slice
+is stored with its DECODED blocks (compression header, slice header, CORE, EXTERNAL blocks by content id -- RAW / gzip / rANS 4x8
+payloads are expanded here with zlib and the pinned rANS oracle) and the expected per-record fields taken from the twin WITHOUT
+any CRAM code: QNAME, FLAG, reference id, POS, MAPQ, CIGAR, mate reference id, PNEXT, TLEN.  The tlen/ pairs were written by the
+reference's authors to pin the template-length and mate logic of cram_decode_slice_xref (test/tlen/README).
+
+Output: tests/golden/cram_records.json (blocks as base64 of zlib).  Needs /root/reference; run in the build container."""
+import base64, glob, gzip, json, os, struct, sys, zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+import make_golden_rans as R                                       # container / block walk, ITF8
+from tests import refutil
+
+REF = "/root/reference/test"
+TWINS = {"ce#5b_java.cram": "ce#5b.sam", "auxf#values_java.cram": "auxf#values.sam", "xx#large_aux_java.cram": "xx#large_aux.sam", "range.cram": "range.bam"}
+
+
+def expand(blk, rans):
+    method, _, _, csz, usz, data = blk
+    if usz == 0: return b""
+    if method == 0: return data
+    if method == 1: return zlib.decompress(data, 31)
+    if method == 4:
+        rc, out = rans.decode(data)
+        assert rc == 0 and len(out) == usz
+        return out
+    raise ValueError("block method %d" % method)
+
+
+def sam_text(path):
+    """-> (reference names, [(qname, flag, rname, pos, mapq, cigar, rnext, pnext, tlen)])"""
+    if path.endswith(".bam"):
+        d = gzip.open(path, "rb").read()
+        assert d[:4] == b"BAM\1"
+        p = 8 + struct.unpack_from("<i", d, 4)[0]
+        nref = struct.unpack_from("<i", d, p)[0]; p += 4
+        refs = []
+        for _ in range(nref):
+            ln = struct.unpack_from("<i", d, p)[0]; refs.append(d[p + 4:p + 4 + ln - 1].decode()); p += 4 + ln + 4
+        recs = []
+        while p < len(d):
+            bs = struct.unpack_from("<i", d, p)[0]; q = p + 4; p = q + bs
+            tid, pos, lname, mapq, _, ncig, flag, lseq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", d, q)
+            name = d[q + 32:q + 32 + lname - 1].decode()
+            cig = struct.unpack_from("<%dI" % ncig, d, q + 32 + lname)
+            recs.append((name, flag, tid, pos + 1, mapq, [(c >> 4, c & 15) for c in cig], mtid, mpos + 1, tlen))
+        return refs, recs
+    refs, recs = [], []
+    for ln in open(path):
+        f = ln.rstrip("\n").split("\t")
+        if ln.startswith("@"):
+            if f[0] == "@SQ": refs.append([x[3:] for x in f if x.startswith("SN:")][0])
+            continue
+        import re
+        cig = [] if f[5] == "*" else [(int(n), "MIDNSHP=X".index(o)) for n, o in re.findall(r"(\d+)([MIDNSHP=X])", f[5])]
+        tid = -1 if f[2] == "*" else refs.index(f[2])
+        mtid = -1 if f[6] == "*" else tid if f[6] == "=" else refs.index(f[6])
+        recs.append((f[0], int(f[1]), tid, int(f[3]), int(f[4]), cig, mtid, int(f[7]), int(f[8])))
+    return refs, recs
+
+
+def main():
+    rans = refutil.Rans4x8Oracle()
+    pack = lambda b: base64.b64encode(zlib.compress(bytes(b), 9)).decode()
+    out = []
+    files = sorted(glob.glob(REF + "/tlen/*.cram")) + [os.path.join(REF, k) for k in sorted(TWINS)]
+    for path in files:
+        base = os.path.basename(path)
+        twin = os.path.join(REF, TWINS[base]) if base in TWINS else path[:-5] + ".sam"
+        refs, recs = sam_text(twin)
+        b = open(path, "rb").read()
+        assert b[:4] == b"CRAM" and b[4] == 3
+        slices, at = [], 0
+        for nrec, blks in R.containers(b):
+            if not blks or blks[0][1] != 1: continue                 # the file-header container, EOF container
+            comp = expand(blks[0], rans)
+            k = 1
+            while k < len(blks):
+                assert blks[k][1] == 2, "slice header expected"
+                sh = expand(blks[k], rans)
+                p = 0
+                _, p = R.itf8(sh, p); _, p = R.itf8(sh, p); _, p = R.itf8(sh, p)
+                n, p = R.itf8(sh, p); _, p = R.ltf8(sh, p); nb, p = R.itf8(sh, p)
+                body = blks[k + 1:k + 1 + nb]
+                core = [x for x in body if x[1] == 5]
+                ext = [x for x in body if x[1] == 4]
+                assert len(core) == 1 and len(core) + len(ext) == nb
+                slices.append({"comp_hdr": pack(comp), "slice_hdr": pack(sh), "core": pack(expand(core[0], rans)),
+                               "blocks": [[x[2], pack(expand(x, rans))] for x in ext], "nrec": n,
+                               "expect": [[r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]] for r in recs[at:at + n]]})
+                at += n
+                k += 1 + nb
+        assert at == len(recs), (base, at, len(recs))
+        out.append({"file": "test/" + os.path.relpath(path, REF), "twin": "test/" + os.path.relpath(twin, REF), "major": 3, "nref": len(refs), "slices": slices})
+    json.dump(out, open(os.path.join(HERE, "cram_records.json"), "w"), separators=(",", ":"))
+    print(len(out), "files,", sum(len(f["slices"]) for f in out), "slices,", sum(s["nrec"] for f in out for s in f["slices"]), "records,",
+          os.path.getsize(os.path.join(HERE, "cram_records.json")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

