@@ -1,0 +1,148 @@
+// cram_records.hip -- CRAM record decoding on MI355X (gfx950): the record loop of cram_decode_slice (reference
+// cram/cram_decode.c:2346-3026) for batches of slices.  SURVEY.md 8f N2, second step (the first, cram_series.hip, decodes whole
+// ITF8 / byte-array columns).
+//
+// What a slice is: nrec records whose fields are spread over ~28 data series; each series is coded by the codec the container's
+// compression header names -- bits of the shared CORE block (HUFFMAN / BETA / GAMMA / SUBEXP) or items of an EXTERNAL block (ITF8
+// integers, bytes, byte arrays), several series may share one block -- and WHICH series a record reads depends on values it has
+// just read (flags, feature count, feature codes).  So a slice is one serial chain of variable-length reads; the parallelism is
+// across slices (a 30x genome has ~10^5).  Mapping: one wavefront per slice; lane 0 walks the chain with cram_records_core.h (the
+// same source the CPU harness checks against the reference's SAM twins), then all 64 lanes turn the slice-relative CIGAR / name
+// offsets into offsets of the caller's arrays.  The compression / slice headers are parsed on the host (cram_records_plan.h): a
+// few hundred bytes per container.
+// Honest limits: bases, qualities and aux values are consumed but not produced yet; lane 0 working alone uses 1/64 of the wave --
+// the EXTERNAL-only fast path (prefix sums over per-record item counts, then the column kernels of cram_series.hip) is the
+// next step and will be checked against this kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+#include "htsgpu.h"
+#include "hg_device.h"
+#include "hg_internal.h"
+#include "cram_records_plan.h"
+
+namespace hgr {
+
+struct DevTables {
+    const PlanDev *plans; const Codec *codecs; const HuffCode *huff; const int32_t *tl_off, *tl_codec;
+    const SliceDev *slices; uint32_t *tab; const uint8_t *data;
+};
+struct DevCols {
+    int32_t *flags, *cram_flags, *ref_id, *len, *rg, *mqual, *mate_ref_id, *ncigar, *name_len;
+    int64_t *apos, *aend, *mate_pos, *tlen;
+    uint64_t *cigar_off, *name_off;
+    uint32_t *cigar; uint8_t *names;
+    int32_t *mate_flags, *mate_line; int64_t *explicit_tlen; uint32_t *coff, *noff;      // scratch columns
+};
+
+__global__ __launch_bounds__(64)
+void cram_records_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref, const int32_t *pre_status, int32_t *status) {
+    const int lane = threadIdx.x & 63;
+    for (uint32_t k = blockIdx.x; k < nslices; k += gridDim.x) {
+        if (pre_status[k] != 0) { if (lane == 0) status[k] = pre_status[k]; continue; }
+        const SliceDev d = T.slices[k];
+        int rc = 0;
+        if (lane == 0) {
+            const PlanDev &pd = T.plans[d.plan];
+            Plan P;
+            for (int i = 0; i < S_N; i++) P.codec_of[i] = pd.codec_of[i];
+            P.rn_included = pd.rn_included; P.ap_delta = pd.ap_delta; P.qs_seq_orient = pd.qs_seq_orient; P.nslots = pd.nslots; P.nTL = pd.nTL;
+            P.tl_off = T.tl_off + pd.tl_off_base; P.tl_codec = T.tl_codec + pd.tl_codec_base; P.codecs = T.codecs + pd.codec_base; P.huff = T.huff + pd.huff_base;
+            Slice S;
+            S.data = T.data; S.blk_off = T.tab + d.tab_off; S.blk_len = S.blk_off + pd.nslots; S.cursor = T.tab + d.tab_off + 2 * pd.nslots;
+            S.core_off = d.core_off; S.core_len = d.core_len; S.nrec = d.nrec; S.ref_seq_id = d.ref_seq_id; S.ref_seq_start = d.ref_seq_start; S.nref = nref;
+            S.cigar_cap = d.cig_cap; S.name_cap = d.name_cap;
+            uint32_t totals[2];
+            const uint64_t r0 = d.rec_off;
+            Cols O{D.flags + r0, D.cram_flags + r0, D.ref_id + r0, D.len + r0, D.rg + r0, D.mqual + r0, D.mate_flags + r0, D.mate_ref_id + r0, D.mate_line + r0,
+                   D.ncigar + r0, D.name_len + r0, D.coff + r0, D.noff + r0, D.apos + r0, D.aend + r0, D.mate_pos + r0, D.tlen + r0, D.explicit_tlen + r0,
+                   D.cigar + d.cig_off, D.names + d.name_off, totals};
+            rc = decode_slice(&P, &S, O);
+            status[k] = rc;
+        }
+        hg::wave_sync();
+        for (int32_t r = lane; r < d.nrec; r += 64) {
+            D.cigar_off[d.rec_off + (uint64_t)r] = d.cig_off + D.coff[d.rec_off + (uint64_t)r];
+            D.name_off[d.rec_off + (uint64_t)r] = d.name_off + D.noff[d.rec_off + (uint64_t)r];
+        }
+    }
+}
+
+}  // namespace hgr
+
+extern "C" int hg_cram_records_bound(size_t nslices, const hg_cram_slice_blocks *slices, int major_version, uint64_t *nrec, uint64_t *cigar_cap,
+                                     uint64_t *name_cap) {
+    if ((nslices && !slices) || !nrec || !cigar_cap || !name_cap) return HG_EINVAL;
+    static_assert(sizeof(hg_cram_slice_blocks) == sizeof(hgr::SliceIn), "hg_cram_slice_blocks layout");
+    hgr::Batch B;
+    const int rc = hgr::batch_build(B, (const hgr::SliceIn *)slices, nslices, major_version);
+    if (rc) return rc == -3 ? HG_BLOCK_EUNSUPPORTED : HG_EINVAL;
+    *nrec = B.nrec; *cigar_cap = B.cig_total; *name_cap = B.name_total;
+    return HG_OK;
+}
+
+extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, size_t rec_cap,
+                                           size_t cigar_cap, size_t name_cap, const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status) {
+    if (!ctx || (nslices && (!slices || !out || !rec_off || !status))) return HG_EINVAL;
+    if (nslices == 0) { if (rec_off) rec_off[0] = 0; return HG_OK; }
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
+    hgr::Batch B;
+    int rc = hgr::batch_build(B, (const hgr::SliceIn *)slices, nslices, major_version);
+    if (rc) return rc == -3 ? HG_BLOCK_EUNSUPPORTED : HG_EINVAL;
+    if (B.nrec > rec_cap || B.cig_total > cigar_cap || B.name_total > name_cap) return HG_EINVAL;
+    for (size_t i = 0; i < nslices; i++) rec_off[i] = B.slices[i].rec_off;
+    rec_off[nslices] = B.nrec;
+    // device image of the tables: one buffer, carved
+    struct Part { const void *src; size_t bytes; size_t off; };
+    std::vector<Part> parts = {{B.plans.data(), B.plans.size() * sizeof(hgr::PlanDev), 0}, {B.codecs.data(), B.codecs.size() * sizeof(hgr::Codec), 0},
+                               {B.huff.data(), B.huff.size() * sizeof(hgr::HuffCode), 0}, {B.tl_off.data(), B.tl_off.size() * 4, 0},
+                               {B.tl_codec.data(), B.tl_codec.size() * 4, 0}, {B.slices.data(), B.slices.size() * sizeof(hgr::SliceDev), 0},
+                               {B.tab.data(), B.tab.size() * 4, 0}, {B.status.data(), B.status.size() * 4, 0}};
+    size_t tbytes = 0;
+    for (auto &p : parts) { p.off = tbytes; tbytes += (p.bytes + 63) & ~(size_t)63; }
+    const size_t R = B.nrec ? B.nrec : 1;
+    // output image: 9 + 2 int32, 4 + 1 int64, 2 uint64, 2 uint32 scratch columns, cigar, names, status
+    size_t obytes = 0;
+    auto carve = [&](size_t bytes) { const size_t o = obytes; obytes += (bytes + 63) & ~(size_t)63; return o; };
+    size_t o32[11], o64[5], ou64[2], ou32[2];
+    for (auto &o : o32) o = carve(R * 4);
+    for (auto &o : o64) o = carve(R * 8);
+    for (auto &o : ou64) o = carve(R * 8);
+    for (auto &o : ou32) o = carve(R * 4);
+    const size_t ocig = carve((B.cig_total ? B.cig_total : 1) * 4), onam = carve(B.name_total ? B.name_total : 1), ost = carve(nslices * 4);
+    if ((rc = hg::ensure_scratch(ctx, 0, B.data_bytes + 64)) || (rc = hg::ensure_scratch(ctx, 1, obytes + 64)) || (rc = hg::ensure_scratch(ctx, 2, tbytes + 64))) return rc;
+    hipStream_t s = ctx->stream;
+    uint8_t *d_data = (uint8_t *)ctx->d_scratch[0], *d_out = (uint8_t *)ctx->d_scratch[1], *d_tab = (uint8_t *)ctx->d_scratch[2];
+    bool ok = hg::stage_upload(ctx, B.src_ptr.data(), B.src_len.data(), B.src_off.data(), nullptr, B.src_ptr.size(), B.data_bytes, d_data, s) == HG_OK;
+    for (auto &p : parts) if (ok && p.bytes) ok = hipMemcpyAsync(d_tab + p.off, p.src, p.bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (!ok) return HG_ELAUNCH;
+    hgr::DevTables T{(const hgr::PlanDev *)(d_tab + parts[0].off), (const hgr::Codec *)(d_tab + parts[1].off), (const hgr::HuffCode *)(d_tab + parts[2].off),
+                     (const int32_t *)(d_tab + parts[3].off), (const int32_t *)(d_tab + parts[4].off), (const hgr::SliceDev *)(d_tab + parts[5].off),
+                     (uint32_t *)(d_tab + parts[6].off), d_data};
+    hgr::DevCols D;
+    int32_t **p32[11] = {&D.flags, &D.cram_flags, &D.ref_id, &D.len, &D.rg, &D.mqual, &D.mate_ref_id, &D.ncigar, &D.name_len, &D.mate_flags, &D.mate_line};
+    for (int i = 0; i < 11; i++) *p32[i] = (int32_t *)(d_out + o32[i]);
+    int64_t **p64[5] = {&D.apos, &D.aend, &D.mate_pos, &D.tlen, &D.explicit_tlen};
+    for (int i = 0; i < 5; i++) *p64[i] = (int64_t *)(d_out + o64[i]);
+    D.cigar_off = (uint64_t *)(d_out + ou64[0]); D.name_off = (uint64_t *)(d_out + ou64[1]);
+    D.coff = (uint32_t *)(d_out + ou32[0]); D.noff = (uint32_t *)(d_out + ou32[1]);
+    D.cigar = (uint32_t *)(d_out + ocig); D.names = d_out + onam;
+    int32_t *d_status = (int32_t *)(d_out + ost);
+    const unsigned grid = (unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 16);
+    hipLaunchKernelGGL(hgr::cram_records_kernel, dim3(grid), dim3(64), 0, s, T, D, (uint32_t)nslices, (int32_t)nref, (const int32_t *)(d_tab + parts[7].off), d_status);
+    if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
+    // results back: the dense record columns in one copy each, CIGAR / names as laid out (capacity-spaced per slice)
+    void *dst32[9] = {out->flags, out->cram_flags, out->ref_id, out->len, out->rg, out->mqual, out->mate_ref_id, out->ncigar, out->name_len};
+    for (int i = 0; i < 9 && ok; i++) if (dst32[i] && B.nrec) ok = hipMemcpyAsync(dst32[i], d_out + o32[i], B.nrec * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
+    void *dst64[4] = {out->apos, out->aend, out->mate_pos, out->tlen};
+    for (int i = 0; i < 4 && ok; i++) if (dst64[i] && B.nrec) ok = hipMemcpyAsync(dst64[i], d_out + o64[i], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (ok && out->cigar_off && B.nrec) ok = hipMemcpyAsync(out->cigar_off, d_out + ou64[0], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (ok && out->name_off && B.nrec) ok = hipMemcpyAsync(out->name_off, d_out + ou64[1], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (ok && out->cigar && B.cig_total) ok = hipMemcpyAsync(out->cigar, d_out + ocig, B.cig_total * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (ok && out->names && B.name_total) ok = hipMemcpyAsync(out->names, d_out + onam, B.name_total, hipMemcpyDeviceToHost, s) == hipSuccess;
+    ok = ok && hipMemcpyAsync(status, d_status, nslices * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    if (!ok) return HG_ELAUNCH;
+    for (size_t i = 0; i < nslices; i++) if (status[i] != 0) return HG_EBLOCK;
+    return HG_OK;
+}

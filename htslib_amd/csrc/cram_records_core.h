@@ -75,6 +75,7 @@ constexpr int64_t TLEN_UNSET = INT64_MIN;
 struct Reader {
     const Plan *P; const Slice *S;
     uint64_t bit;                         // position in the CORE block, MSB first
+    uint64_t work;                        // features walked so far: a damaged count with zero-bit codecs must not spin for minutes
     int err;
 
     // ---- CORE bit stream (get_bit_MSB / get_bits_MSB, cram_codecs.c:73-200) ----
@@ -193,6 +194,7 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
     const int32_t fn = R.ival(S_FN);                                      // a series the walk needs and the map lacks is an error, as in the reference
     {
         for (int32_t f = 0; f < fn && !R.err; f++) {
+            if (++R.work > 16ull * R.S->cigar_cap) { R.err = ERR_UNSUPPORTED; break; }
             const int32_t op = R.bval(S_FC);
             int32_t pos = R.ival(S_FP) + prev_pos;
             if (R.err) break;
@@ -343,7 +345,7 @@ HGR_FN int xref(const Cols &O, int32_t nrec) {
 
 // The record loop of cram_decode_slice (cram_decode.c:2553-2967).  Returns 0, ERR_MALFORMED or ERR_UNSUPPORTED.
 HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
-    Reader R; R.P = P; R.S = S; R.bit = 0; R.err = 0;
+    Reader R; R.P = P; R.S = S; R.bit = 0; R.work = 0; R.err = 0;
     for (int32_t i = 0; i < P->nslots; i++) S->cursor[i] = 0;
     uint32_t ncig = 0, nname = 0;
     int64_t last_apos = S->ref_seq_start;

@@ -370,6 +370,39 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
                                              int level, int version_major, const uint8_t *const *in, const uint32_t *in_len,
                                              const hg_fqz_slice *const *fqz, uint8_t *const *out, uint32_t *out_len, int32_t *method_used);
 
+/* ---- CRAM record decoding: the record loop of cram_decode_slice (cram/cram_decode.c:2346-3026) for batches of
+ *      slices, CRAM 2.x / 3.x.  Input per slice: the DECODED blocks (after cram_uncompress_block) -- the container's compression
+ *      header block, the slice header block, the CORE block and the EXTERNAL blocks with their content ids.  All codecs htslib and
+ *      htsjdk write are handled (EXTERNAL, HUFFMAN, BETA, GAMMA, SUBEXP, BYTE_ARRAY_LEN, BYTE_ARRAY_STOP); a slice that needs
+ *      GOLOMB / GOLOMB_RICE reports HG_BLOCK_EUNSUPPORTED.  Output per record: the cram_record fields that do not need the reference
+ *      sequence, after cram_decode_slice_xref -- flags (with the mate bits), cram_flags, ref_id, len, apos, aend, rg, mqual, the
+ *      CIGAR (BAM encoding, cram_decode_seq's feature walk), the read name, mate_ref_id, mate_pos, tlen.  Bases, qualities and aux
+ *      values are consumed but not produced yet.  Pinned on the reference's 34 CRAM fixtures against their SAM / BAM twins
+ *      (tests/test_cram_records.py).  One wavefront per slice (cram_records.hip). ---- */
+typedef struct hg_cram_slice_blocks {
+    const uint8_t *comp_hdr; uint32_t comp_hdr_len;     /* compression header block of the slice's container (slices of one container may share the pointer) */
+    const uint8_t *slice_hdr; uint32_t slice_hdr_len;   /* slice header block */
+    const uint8_t *core; uint32_t core_len;             /* CORE block (content type 5) */
+    uint32_t nblocks;                                   /* EXTERNAL blocks (content type 4): */
+    const int32_t *content_id; const uint8_t *const *data; const uint32_t *len;
+} hg_cram_slice_blocks;
+typedef struct hg_cram_record_cols {                    /* arrays of rec_cap entries; a NULL column is not copied back */
+    int32_t *flags, *cram_flags, *ref_id, *len, *rg, *mqual, *mate_ref_id, *ncigar, *name_len;
+    int64_t *apos, *aend, *mate_pos, *tlen;
+    uint64_t *cigar_off, *name_off;                     /* first CIGAR op / name byte of the record in cigar[] / names[] */
+    uint32_t *cigar;                                    /* cigar_cap words: len << 4 | op */
+    uint8_t *names;                                     /* name_cap bytes, names are not terminated */
+} hg_cram_record_cols;
+/* Sizes the caller must provide for these slices: records (exact), CIGAR words and name bytes (upper bounds; slices get disjoint
+ * regions).  Host only. */
+int hg_cram_records_bound(size_t nslices, const hg_cram_slice_blocks *slices, int major_version, uint64_t *nrec, uint64_t *cigar_cap,
+                          uint64_t *name_cap);
+/* nref = number of @SQ lines (bounds of RI / NS).  rec_off[i] .. rec_off[i+1] = the records of slice i (nslices + 1 entries).
+ * status[i] = 0, -1 (malformed slice, as cram_decode_slice returning -1) or HG_BLOCK_EUNSUPPORTED.  Returns HG_OK / HG_EBLOCK. */
+int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref,
+                                size_t rec_cap, size_t cigar_cap, size_t name_cap, const hg_cram_record_cols *out, uint64_t *rec_off,
+                                int32_t *status);
+
 /* ---- BAM record framing on the device: the framing half of bam_read1 (sam.c:784-866) and
  *      nibble2base (simd.c:119-161) for consumers that keep the inflated stream in HBM. ---- */
 #define HG_BAM_ETRUNC   (-2)   /* the stream ends inside a record (bam_read1 returns -2 / -3) */

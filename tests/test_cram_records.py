@@ -110,3 +110,58 @@ def test_decoder_source_on_the_cpu_matches_the_sam_twins(hostlib):
         for s, g in zip(slices, got):
             check_against_twin(fname, g, s["expect"]); nrec += len(g)
     assert nrec == 230
+
+
+def _gpu_calls(engine):
+    from htslib_amd import _native as nat
+    bound = lambda n, arr, major, a, b, c: nat.lib.hg_cram_records_bound(n, C.cast(arr, _vp), major, C.cast(a, _vp), C.cast(b, _vp), C.cast(c, _vp))
+    dec = lambda n, arr, major, nref, R, cc, nc, cols, ro, st: nat.lib.hg_cram_decode_records_host(engine._h, n, C.cast(arr, _vp), major, nref, R, cc, nc,
+                                                                                                  C.cast(cols, _vp), ro, st)
+    return bound, dec
+
+
+@pytest.mark.gpu
+def test_gpu_decoder_matches_the_sam_twins(engine):
+    bound, dec = _gpu_calls(engine)
+    files = {}
+    for fname, major, nref, s in load_slices():
+        files.setdefault((fname, major, nref), []).append(s)
+    nrec = 0
+    for (fname, major, nref), slices in files.items():
+        st, got = decode(bound, dec, slices, major, nref)
+        assert (st == 0).all(), (fname, st)
+        for s, g in zip(slices, got):
+            check_against_twin(fname, g, s["expect"]); nrec += len(g)
+    assert nrec == 230
+
+
+@pytest.mark.gpu
+def test_gpu_decoder_batch_of_slices_and_error_statuses(engine, hostlib):
+    """Many slices in one call (all fixtures with one reference, replicated), and damaged slices: the device reports exactly what the
+    same source reports on the CPU."""
+    bound, dec = _gpu_calls(engine)
+    base = [s for fname, major, nref, s in load_slices() if nref == 1]
+    slices = [base[i % len(base)] for i in range(600)]
+    st, got = decode(bound, dec, slices, 3, 1)
+    assert (st == 0).all()
+    for s, g in zip(slices, got):
+        check_against_twin("batch", g, s["expect"])
+    rng = np.random.default_rng(3)
+    bad = []
+    for i in range(60):
+        s = dict(base[i % len(base)])
+        kind = i % 4
+        if kind == 0: s["core"] = s["core"][:len(s["core"]) // 2]
+        elif kind == 1 and s["blocks"]: s["blocks"] = [(cid, d[:len(d) // 2]) for cid, d in s["blocks"]]
+        elif kind == 2 and s["blocks"]: s["blocks"] = s["blocks"][1:]
+        else:
+            c = bytearray(s["core"])
+            for _ in range(3):
+                if c: c[int(rng.integers(0, len(c)))] ^= 1 << int(rng.integers(0, 8))
+            s["core"] = bytes(c)
+        bad.append(s)
+    st_g, got_g = decode(bound, dec, bad, 3, 1)
+    st_c, got_c = decode(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, bad, 3, 1)
+    assert (st_g == st_c).all() and (st_g != 0).any()
+    for k in range(len(bad)):
+        if st_g[k] == 0: assert got_g[k] == got_c[k], k
