@@ -63,7 +63,7 @@ def decode(call_bound, call_decode, slices, major, nref):
     cols = Cols(*[a.ctypes.data for a in list(i32.values()) + list(i64.values()) + list(u64.values()) + [cigar, names]])
     rec_off = np.zeros(n + 1, np.uint64); status = np.full(n, 77, np.int32)
     rc = call_decode(n, arr, major, nref, R, len(cigar), len(names), C.byref(cols), rec_off.ctypes.data, status.ctypes.data)
-    assert rc == 0, rc
+    assert rc in (0, -6), rc                      # HG_EBLOCK: some slice has a non-zero status
     out = []
     for i in range(n):
         recs = []
