@@ -10,9 +10,12 @@
 // same source the CPU harness checks against the reference's SAM twins), then all 64 lanes turn the slice-relative CIGAR / name
 // offsets into offsets of the caller's arrays.  The compression / slice headers are parsed on the host (cram_records_plan.h): a
 // few hundred bytes per container.
-// Honest limits: bases, qualities and aux values are consumed but not produced yet; lane 0 working alone uses 1/64 of the wave --
-// the EXTERNAL-only fast path (prefix sums over per-record item counts, then the column kernels of cram_series.hip) is the
-// next step and will be checked against this kernel.
+// Bases and qualities are rebuilt when the caller passes the reference spans (cram_decode_seq's copy-and-edit, without MD / NM
+// generation); each record takes its len bytes from one pool with an atomic add, so the order of records in seq[] / qual[] is not
+// the record order -- seq_off[] says where each one is.
+// Honest limits: aux values are consumed but not produced yet; lane 0 working alone uses 1/64 of the wave -- the EXTERNAL-only
+// fast path (prefix sums over per-record item counts, then the column kernels of cram_series.hip) is the next step and will be
+// checked against this kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -26,13 +29,14 @@ namespace hgr {
 
 struct DevTables {
     const PlanDev *plans; const Codec *codecs; const HuffCode *huff; const int32_t *tl_off, *tl_codec;
-    const SliceDev *slices; uint32_t *tab; const uint8_t *data;
+    const SliceDev *slices; uint32_t *tab; const uint8_t *data; const RefSpan *refs;
 };
 struct DevCols {
     int32_t *flags, *cram_flags, *ref_id, *len, *rg, *mqual, *mate_ref_id, *ncigar, *name_len;
     int64_t *apos, *aend, *mate_pos, *tlen;
     uint64_t *cigar_off, *name_off;
     uint32_t *cigar; uint8_t *names;
+    uint64_t *seq_off; uint8_t *seq, *qual; unsigned long long *seq_pool; uint64_t seq_cap;   // seq == nullptr: bases / qualities not wanted
     int32_t *mate_flags, *mate_line; int64_t *explicit_tlen; uint32_t *coff, *noff;      // scratch columns
 };
 
@@ -47,17 +51,18 @@ void cram_records_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref,
             const PlanDev &pd = T.plans[d.plan];
             Plan P;
             for (int i = 0; i < S_N; i++) P.codec_of[i] = pd.codec_of[i];
+            for (int i = 0; i < 20; i++) (&P.sm[0][0])[i] = (&pd.sm[0][0])[i];
             P.rn_included = pd.rn_included; P.ap_delta = pd.ap_delta; P.qs_seq_orient = pd.qs_seq_orient; P.nslots = pd.nslots; P.nTL = pd.nTL;
             P.tl_off = T.tl_off + pd.tl_off_base; P.tl_codec = T.tl_codec + pd.tl_codec_base; P.codecs = T.codecs + pd.codec_base; P.huff = T.huff + pd.huff_base;
             Slice S;
             S.data = T.data; S.blk_off = T.tab + d.tab_off; S.blk_len = S.blk_off + pd.nslots; S.cursor = T.tab + d.tab_off + 2 * pd.nslots;
             S.core_off = d.core_off; S.core_len = d.core_len; S.nrec = d.nrec; S.ref_seq_id = d.ref_seq_id; S.ref_seq_start = d.ref_seq_start; S.nref = nref;
-            S.cigar_cap = d.cig_cap; S.name_cap = d.name_cap;
+            S.cigar_cap = d.cig_cap; S.name_cap = d.name_cap; S.refs = T.refs + d.ref_first; S.nrefs = (int32_t)d.nrefs;
             uint32_t totals[2];
             const uint64_t r0 = d.rec_off;
             Cols O{D.flags + r0, D.cram_flags + r0, D.ref_id + r0, D.len + r0, D.rg + r0, D.mqual + r0, D.mate_flags + r0, D.mate_ref_id + r0, D.mate_line + r0,
                    D.ncigar + r0, D.name_len + r0, D.coff + r0, D.noff + r0, D.apos + r0, D.aend + r0, D.mate_pos + r0, D.tlen + r0, D.explicit_tlen + r0,
-                   D.cigar + d.cig_off, D.names + d.name_off, totals};
+                   D.cigar + d.cig_off, D.names + d.name_off, totals, D.seq, D.qual, D.seq ? D.seq_off + r0 : nullptr, D.seq_pool, D.seq_cap};
             rc = decode_slice(&P, &S, O);
             status[k] = rc;
         }
@@ -83,7 +88,7 @@ extern "C" int hg_cram_records_bound(size_t nslices, const hg_cram_slice_blocks 
 }
 
 extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, size_t rec_cap,
-                                           size_t cigar_cap, size_t name_cap, const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status) {
+                                           size_t cigar_cap, size_t name_cap, size_t seq_cap, const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status) {
     if (!ctx || (nslices && (!slices || !out || !rec_off || !status))) return HG_EINVAL;
     if (nslices == 0) { if (rec_off) rec_off[0] = 0; return HG_OK; }
     hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
@@ -98,7 +103,8 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     std::vector<Part> parts = {{B.plans.data(), B.plans.size() * sizeof(hgr::PlanDev), 0}, {B.codecs.data(), B.codecs.size() * sizeof(hgr::Codec), 0},
                                {B.huff.data(), B.huff.size() * sizeof(hgr::HuffCode), 0}, {B.tl_off.data(), B.tl_off.size() * 4, 0},
                                {B.tl_codec.data(), B.tl_codec.size() * 4, 0}, {B.slices.data(), B.slices.size() * sizeof(hgr::SliceDev), 0},
-                               {B.tab.data(), B.tab.size() * 4, 0}, {B.status.data(), B.status.size() * 4, 0}};
+                               {B.tab.data(), B.tab.size() * 4, 0}, {B.status.data(), B.status.size() * 4, 0},
+                               {B.refs.data(), B.refs.size() * sizeof(hgr::RefSpan), 0}};
     size_t tbytes = 0;
     for (auto &p : parts) { p.off = tbytes; tbytes += (p.bytes + 63) & ~(size_t)63; }
     const size_t R = B.nrec ? B.nrec : 1;
@@ -111,6 +117,8 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     for (auto &o : ou64) o = carve(R * 8);
     for (auto &o : ou32) o = carve(R * 4);
     const size_t ocig = carve((B.cig_total ? B.cig_total : 1) * 4), onam = carve(B.name_total ? B.name_total : 1), ost = carve(nslices * 4);
+    const bool want_seq = out->seq && out->qual && out->seq_off;
+    const size_t oso = carve(R * 8), oseq = carve(want_seq ? seq_cap + 1 : 1), oqual = carve(want_seq ? seq_cap + 1 : 1), opool = carve(8);
     if ((rc = hg::ensure_scratch(ctx, 0, B.data_bytes + 64)) || (rc = hg::ensure_scratch(ctx, 1, obytes + 64)) || (rc = hg::ensure_scratch(ctx, 2, tbytes + 64))) return rc;
     hipStream_t s = ctx->stream;
     uint8_t *d_data = (uint8_t *)ctx->d_scratch[0], *d_out = (uint8_t *)ctx->d_scratch[1], *d_tab = (uint8_t *)ctx->d_scratch[2];
@@ -119,7 +127,7 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     if (!ok) return HG_ELAUNCH;
     hgr::DevTables T{(const hgr::PlanDev *)(d_tab + parts[0].off), (const hgr::Codec *)(d_tab + parts[1].off), (const hgr::HuffCode *)(d_tab + parts[2].off),
                      (const int32_t *)(d_tab + parts[3].off), (const int32_t *)(d_tab + parts[4].off), (const hgr::SliceDev *)(d_tab + parts[5].off),
-                     (uint32_t *)(d_tab + parts[6].off), d_data};
+                     (uint32_t *)(d_tab + parts[6].off), d_data, (const hgr::RefSpan *)(d_tab + parts[8].off)};
     hgr::DevCols D;
     int32_t **p32[11] = {&D.flags, &D.cram_flags, &D.ref_id, &D.len, &D.rg, &D.mqual, &D.mate_ref_id, &D.ncigar, &D.name_len, &D.mate_flags, &D.mate_line};
     for (int i = 0; i < 11; i++) *p32[i] = (int32_t *)(d_out + o32[i]);
@@ -128,6 +136,9 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     D.cigar_off = (uint64_t *)(d_out + ou64[0]); D.name_off = (uint64_t *)(d_out + ou64[1]);
     D.coff = (uint32_t *)(d_out + ou32[0]); D.noff = (uint32_t *)(d_out + ou32[1]);
     D.cigar = (uint32_t *)(d_out + ocig); D.names = d_out + onam;
+    D.seq_off = (uint64_t *)(d_out + oso); D.seq = want_seq ? d_out + oseq : nullptr; D.qual = want_seq ? d_out + oqual : nullptr;
+    D.seq_pool = (unsigned long long *)(d_out + opool); D.seq_cap = seq_cap;
+    if (hipMemsetAsync(d_out + opool, 0, 8, s) != hipSuccess) return HG_ELAUNCH;
     int32_t *d_status = (int32_t *)(d_out + ost);
     const unsigned grid = (unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 16);
     hipLaunchKernelGGL(hgr::cram_records_kernel, dim3(grid), dim3(64), 0, s, T, D, (uint32_t)nslices, (int32_t)nref, (const int32_t *)(d_tab + parts[7].off), d_status);
@@ -141,6 +152,14 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     if (ok && out->name_off && B.nrec) ok = hipMemcpyAsync(out->name_off, d_out + ou64[1], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
     if (ok && out->cigar && B.cig_total) ok = hipMemcpyAsync(out->cigar, d_out + ocig, B.cig_total * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
     if (ok && out->names && B.name_total) ok = hipMemcpyAsync(out->names, d_out + onam, B.name_total, hipMemcpyDeviceToHost, s) == hipSuccess;
+    unsigned long long used = 0;
+    if (ok && want_seq) ok = hipMemcpyAsync(&used, d_out + opool, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    if (ok && want_seq && B.nrec) {
+        if (used > seq_cap) used = seq_cap;
+        ok = hipMemcpyAsync(out->seq_off, d_out + oso, B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             (!used || (hipMemcpyAsync(out->seq, d_out + oseq, used, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                        hipMemcpyAsync(out->qual, d_out + oqual, used, hipMemcpyDeviceToHost, s) == hipSuccess));
+    }
     ok = ok && hipMemcpyAsync(status, d_status, nslices * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
     for (size_t i = 0; i < nslices; i++) if (status[i] != 0) return HG_EBLOCK;

@@ -39,12 +39,15 @@ enum Series { S_BF, S_CF, S_RI, S_RL, S_AP, S_RG, S_RN, S_MF, S_NS, S_NP, S_TS, 
 struct Plan {
     int32_t codec_of[S_N];                // index into codecs[] or -1 (series absent from the encoding map)
     int32_t rn_included, ap_delta, qs_seq_orient, nslots;
+    uint8_t sm[5][4];                     // substitution matrix (preservation map SM): sm[reference base A C G T N][BS code]
     int32_t nTL;                          // tag dictionary lines; line t holds tags tl_off[t] .. tl_off[t+1]-1 of tl_codec[]
     const int32_t *tl_off;
     const int32_t *tl_codec;              // codec index of the tag's encoding (tag encoding map), -1 = not in the map
     const Codec *codecs;
     const HuffCode *huff;
 };
+// A stretch of reference bases the caller supplies for a slice (upper case ASCII; an embedded-reference block is one of these)
+struct RefSpan { int32_t ref_id; uint32_t off, len, pad; int64_t start, sq_len; };   // off into Slice::data; start = 1-based position of the first base; sq_len = @SQ LN
 // One slice: its blocks by slot (offset / length into `data`; length 0xffffffff = block absent), the CORE block, scratch cursors
 struct Slice {
     const uint8_t *data;
@@ -55,6 +58,7 @@ struct Slice {
     int64_t ref_seq_start;
     int32_t nref;                         // number of @SQ lines (bounds of RI / NS)
     uint32_t cigar_cap, name_cap;
+    const RefSpan *refs; int32_t nrefs;   // reference spans of this slice (none: bases come out as '=' plus the stored edits)
 };
 // Per-record results (arrays of nrec), the CIGAR ops and the read names of the slice
 struct Cols {
@@ -64,6 +68,8 @@ struct Cols {
     uint32_t *cigar;                      // (len << 4 | op), BAM encoding
     uint8_t *names;
     uint32_t *totals;                     // [0] = cigar ops written, [1] = name bytes written
+    // bases and qualities (seq == nullptr: not wanted): len bytes each per record at seq_off[rec], handed out from one pool
+    uint8_t *seq, *qual; uint64_t *seq_off; unsigned long long *seq_pool; uint64_t seq_cap;
 };
 enum { ERR_MALFORMED = -1, ERR_UNSUPPORTED = -3 };
 enum { BAM_FPAIRED = 1, BAM_FUNMAP = 4, BAM_FMUNMAP = 8, BAM_FREVERSE = 16, BAM_FMREVERSE = 32, BAM_FREAD1 = 64 };
@@ -182,15 +188,23 @@ struct Reader {
     }
 };
 
-// cram_decode_seq without the bases (cram_decode.c:1096-1900): features -> CIGAR, alignment end; MQ; the QS bytes are skipped
-HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint32_t &ncig_total) {
+// cram_decode_seq (cram_decode.c:1096-1900) without MD / NM generation: features -> CIGAR, alignment end, and -- when the caller asked
+// for them -- the bases (reference span + edits) and the qualities; MQ.
+HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint32_t &ncig_total, uint8_t *seq, uint8_t *qual, const RefSpan *ref) {
     const Plan *P = R.P;
-    const int32_t len = O.len[rec];
-    int64_t ref_pos = O.apos[rec] - 1;
+    const int32_t len = O.len[rec], ref_id = O.ref_id[rec];
+    int64_t ref_pos = O.apos[rec] - 1;                                    // 0-based position of the next reference base
     int32_t prev_pos = 0, seq_pos = 1, cig_len = 0, cig_op = C_MATCH;
     const uint32_t cig0 = ncig_total;
+    const uint8_t *refb = ref ? R.S->data + ref->off : nullptr;           // refb[p - ref->start] = base at 1-based position p
+    const int64_t ref_start = ref ? ref->start : 0, ref_end = ref ? ref->start + (int64_t)ref->len - 1 : 0, sq_len = ref ? ref->sq_len : 0;
+    const bool have_ref = ref && ref_id >= 0;
     auto emit = [&](uint32_t l, int op) { if (ncig_total >= R.S->cigar_cap) { if (!R.err) R.err = ERR_UNSUPPORTED; return; } O.cigar[ncig_total++] = (l << 4) | (uint32_t)op; };
     auto flush_unless = [&](int op) { if (cig_len && cig_op != op) { emit((uint32_t)cig_len, cig_op); cig_len = 0; } };
+    auto fill = [&](int32_t at, uint8_t c, int64_t n) { if (seq) for (int64_t i = 0; i < n; i++) seq[at + i] = c; };
+    auto copy_ref = [&](int32_t at, int64_t n) { if (seq) for (int64_t i = 0; i < n; i++) seq[at + i] = refb[ref_pos + 1 - ref_start + i]; };
+    auto qual_touch = [&]() { if (qual && !(cf & CF_PRESERVE_QUAL) && len > 0 && qual[0] == 255) for (int32_t i = 0; i < len; i++) qual[i] = 30; };   // "same as htsjdk"
+    if (qual && !(cf & CF_PRESERVE_QUAL)) for (int32_t i = 0; i < len; i++) qual[i] = 255;
     const int32_t fn = R.ival(S_FN);                                      // a series the walk needs and the map lacks is an error, as in the reference
     {
         for (int32_t f = 0; f < fn && !R.err; f++) {
@@ -203,18 +217,47 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
                 const int32_t valid_end = (op == 'N' || op == 'P' || op == 'H' || op == 'D') ? len + 1 : len;
                 if (pos > valid_end) { R.err = ERR_MALFORMED; break; }
             }
-            if (pos > seq_pos) { flush_unless(C_MATCH); cig_op = C_MATCH; cig_len += pos - seq_pos; ref_pos += pos - seq_pos; seq_pos = pos; }
+            if (pos > seq_pos) {
+                if (have_ref) {                                           // the stretch up to the feature is a copy of the reference
+                    if (ref_pos + pos - seq_pos > sq_len) {               // ... running off the end of the reference: pad with N
+                        const int64_t rlen = sq_len - ref_pos;
+                        if (rlen > 0) {
+                            if (ref_pos + rlen > ref_end) { R.err = ERR_MALFORMED; break; }
+                            if (len) { copy_ref(seq_pos - 1, rlen); if ((pos - seq_pos) - rlen > 0) fill(seq_pos - 1 + (int32_t)rlen, 'N', (pos - seq_pos) - rlen); }
+                        } else if (len) fill(seq_pos - 1, 'N', len - seq_pos + 1);
+                    } else {
+                        if (ref_pos + pos - seq_pos > ref_end) { R.err = ERR_MALFORMED; break; }
+                        if (len) copy_ref(seq_pos - 1, pos - seq_pos);
+                    }
+                }
+                flush_unless(C_MATCH); cig_op = C_MATCH; cig_len += pos - seq_pos; ref_pos += pos - seq_pos; seq_pos = pos;
+            }
             prev_pos = pos;
+            uint8_t *sp = seq && len ? seq + (pos - 1) : nullptr;          // "cr->len ? &seq[pos-1] : NULL"
+            uint8_t *qp = qual && len ? qual + (pos - 1) : nullptr;
+            const uint32_t room = len ? (uint32_t)(len - (pos - 1)) : 0u;    // bytes a byte-array item may write
             switch (op) {
             case 'S': {
                 if (cig_len) { emit((uint32_t)cig_len, cig_op); cig_len = 0; }
-                {                                                         // no SC codec: one unknown base (cram_decode.c:1317-1329)
-                    const int32_t n = P->codec_of[S_SC] >= 0 ? R.array(P->codec_of[S_SC], nullptr, 0) : 1;
-                    emit((uint32_t)n, C_SOFT_CLIP); cig_op = C_SOFT_CLIP; seq_pos += n;
-                }
+                int32_t n = 1;                                            // no SC codec: one unknown base (cram_decode.c:1317-1329)
+                if (P->codec_of[S_SC] >= 0) n = R.array(P->codec_of[S_SC], sp, room); else if (sp) sp[0] = 'N';
+                emit((uint32_t)n, C_SOFT_CLIP); cig_op = C_SOFT_CLIP; seq_pos += n;
                 break;
             }
-            case 'X': flush_unless(C_MATCH); (void)R.bval(S_BS); cig_op = C_MATCH; cig_len++; seq_pos++; ref_pos++; break;
+            case 'X': {
+                flush_unless(C_MATCH);
+                const int32_t base = R.bval(S_BS) & 3;
+                if (seq && pos - 1 < len) {
+                    if (ref_id < 0 || ref_pos >= sq_len || !ref) seq[pos - 1] = P->sm[4][base];
+                    else {
+                        const uint8_t rc = ref_pos < ref_end ? refb[ref_pos + 1 - ref_start] : (uint8_t)'N';
+                        const int l1 = (rc == 'A' || rc == 'a') ? 0 : (rc == 'C' || rc == 'c') ? 1 : (rc == 'G' || rc == 'g') ? 2 : (rc == 'T' || rc == 't') ? 3 : 4;
+                        seq[pos - 1] = P->sm[l1][base];
+                    }
+                }
+                cig_op = C_MATCH; cig_len++; seq_pos++; ref_pos++;
+                break;
+            }
             case 'D': {
                 flush_unless(C_DEL);
                 { const int32_t v = R.ival(S_DL); if (v < 0) { if (!R.err) R.err = ERR_MALFORMED; break; } cig_op = C_DEL; cig_len += v; ref_pos += v; }
@@ -222,24 +265,26 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
             }
             case 'I': {
                 flush_unless(C_INS);
-                { const int32_t n = R.array(P->codec_of[S_IN], nullptr, 0); cig_op = C_INS; cig_len += n; seq_pos += n; }
+                { const int32_t n = R.array(P->codec_of[S_IN], sp, room); cig_op = C_INS; cig_len += n; seq_pos += n; }
                 break;
             }
-            case 'i': flush_unless(C_INS); (void)R.bval(S_BA); cig_op = C_INS; cig_len++; seq_pos++; break;
+            case 'i': { flush_unless(C_INS); const int32_t b = R.bval(S_BA); if (sp) sp[0] = (uint8_t)b; cig_op = C_INS; cig_len++; seq_pos++; break; }
             case 'b': {
                 flush_unless(C_MATCH);
-                const int32_t n = R.array(P->codec_of[S_BB], nullptr, 0);
+                const int32_t n = R.array(P->codec_of[S_BB], sp, room);
                 cig_op = C_MATCH; cig_len += n; seq_pos += n; ref_pos += n;
                 break;
             }
-            case 'q': flush_unless(C_MATCH); (void)R.array(P->codec_of[S_QQ], nullptr, 0); cig_op = C_MATCH; break;
-            case 'B':
+            case 'q': flush_unless(C_MATCH); qual_touch(); (void)R.array(P->codec_of[S_QQ], qp, room); cig_op = C_MATCH; break;
+            case 'B': {
                 flush_unless(C_MATCH);
-                (void)R.bval(S_BA);
-                (void)R.bval(S_QS);
+                const int32_t b = R.bval(S_BA); if (sp) sp[0] = (uint8_t)b;
+                qual_touch();
+                const int32_t q = R.bval(S_QS); if (qp) qp[0] = (uint8_t)q;
                 cig_op = C_MATCH; cig_len++; seq_pos++; ref_pos++;
                 break;
-            case 'Q': (void)R.bval(S_QS); break;
+            }
+            case 'Q': { qual_touch(); const int32_t q = R.bval(S_QS); if (qp) qp[0] = (uint8_t)q; break; }
             case 'H': {
                 flush_unless(C_HARD_CLIP);
                 { const int32_t v = R.ival(S_HC); if (v < 0) { if (!R.err) R.err = ERR_MALFORMED; break; } cig_op = C_HARD_CLIP; cig_len += v; }
@@ -258,9 +303,20 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
             default: if (!R.err) R.err = ERR_MALFORMED; break;
             }
         }
-        // an implicit match for the bases no feature accounted for (cram_decode.c:1701-1797)
+        // an implicit match for the bases no feature accounted for (cram_decode.c:1710-1795)
         if (!R.err && len >= seq_pos) {
-            ref_pos += len - seq_pos + 1;
+            if (have_ref) {
+                if (ref_pos + len - seq_pos + 1 > sq_len) {
+                    const int64_t rlen = sq_len - ref_pos;
+                    if (rlen > 0) {
+                        if (ref_pos + rlen > ref_end) R.err = ERR_MALFORMED;
+                        else { if (seq_pos - 1 + rlen < len) copy_ref(seq_pos - 1, rlen); if ((len - seq_pos + 1) - rlen > 0) fill(seq_pos - 1 + (int32_t)rlen, 'N', (len - seq_pos + 1) - rlen); }
+                    } else if (len - seq_pos + 1 > 0) fill(seq_pos - 1, 'N', len - seq_pos + 1);
+                } else {
+                    if (len - seq_pos + 1 > 0) { if (ref_pos + len - seq_pos + 1 > ref_end) R.err = ERR_MALFORMED; else copy_ref(seq_pos - 1, len - (seq_pos - 1)); }
+                    ref_pos += len - seq_pos + 1;
+                }
+            } else if (ref_id >= 0) ref_pos += len - seq_pos + 1;
             flush_unless(C_MATCH); cig_op = C_MATCH; cig_len += len - seq_pos + 1;
         }
     }
@@ -271,8 +327,8 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
     if ((cf & CF_PRESERVE_QUAL) && !R.err) {                             // len quality bytes
         if (P->codec_of[S_QS] < 0) { R.err = ERR_MALFORMED; return; }
         const Codec C = P->codecs[P->codec_of[S_QS]];
-        if (C.kind == E_EXTERNAL) R.ext_bytes(C.a, nullptr, (uint32_t)len);
-        else for (int32_t i = 0; i < len && !R.err; i++) (void)R.bval(S_QS);
+        if (C.kind == E_EXTERNAL) R.ext_bytes(C.a, qual, (uint32_t)len);
+        else for (int32_t i = 0; i < len && !R.err; i++) { const int32_t q = R.bval(S_QS); if (qual) qual[i] = (uint8_t)q; }
     }
     if (cf & CF_NO_SEQ) O.len[rec] = 0;
 }
@@ -393,24 +449,41 @@ HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
         }
         skip_aux(R);
         if (R.err) break;
+        // room for the bases / qualities of this record (cram_decode.c:2890-2906), and the reference span it aligns to
+        uint8_t *seq = nullptr, *qual = nullptr;
+        const RefSpan *ref = nullptr;
+        if (O.seq) {
+            uint64_t at;
+#if defined(__HIP_DEVICE_COMPILE__)
+            at = atomicAdd(O.seq_pool, (unsigned long long)len);
+#else
+            at = *O.seq_pool; *O.seq_pool += (unsigned long long)len;
+#endif
+            if (at + (uint64_t)len > O.seq_cap) { R.err = ERR_UNSUPPORTED; break; }
+            O.seq_off[rec] = at; seq = O.seq + at; qual = O.qual + at;
+            for (int32_t i = 0; i < S->nrefs; i++) if (S->refs[i].ref_id == ref_id) { ref = &S->refs[i]; break; }
+            if (!ref) for (int32_t i = 0; i < len; i++) seq[i] = '=';
+        }
         if (!(bf & BAM_FUNMAP)) {
             if (apos <= 0) { R.err = ERR_MALFORMED; break; }
-            decode_features(R, O, rec, cf, ncig);
+            decode_features(R, O, rec, cf, ncig, seq, qual, ref);
         } else {
             O.cigar_off[rec] = ncig; O.ncigar[rec] = 0; O.aend[rec] = apos; O.mqual[rec] = 0;
             if (len) {
                 if (P->codec_of[S_BA] < 0) { R.err = ERR_MALFORMED; break; }
                 const Codec C = P->codecs[P->codec_of[S_BA]];
-                if (C.kind == E_EXTERNAL) R.ext_bytes(C.a, nullptr, (uint32_t)len);
-                else for (int32_t i = 0; i < len && !R.err; i++) (void)R.bval(S_BA);
+                if (C.kind == E_EXTERNAL) R.ext_bytes(C.a, seq, (uint32_t)len);
+                else for (int32_t i = 0; i < len && !R.err; i++) { const int32_t b = R.bval(S_BA); if (seq) seq[i] = (uint8_t)b; }
             }
             if (cf & CF_PRESERVE_QUAL) {
                 if (P->codec_of[S_QS] < 0) { R.err = ERR_MALFORMED; break; }
                 const Codec C = P->codecs[P->codec_of[S_QS]];
-                if (C.kind == E_EXTERNAL) R.ext_bytes(C.a, nullptr, (uint32_t)len);
-                else for (int32_t i = 0; i < len && !R.err; i++) (void)R.bval(S_QS);
-            }
+                if (C.kind == E_EXTERNAL) R.ext_bytes(C.a, qual, (uint32_t)len);
+                else for (int32_t i = 0; i < len && !R.err; i++) { const int32_t q = R.bval(S_QS); if (qual) qual[i] = (uint8_t)q; }
+            } else if (qual) for (int32_t i = 0; i < len; i++) qual[i] = 255;
         }
+        if (qual && !R.err && !P->qs_seq_orient && (O.flags[rec] & BAM_FREVERSE))           // qualities stored in read orientation (cram_decode.c:2957-2965)
+            for (int32_t i = 0, j = len - 1; i < j; i++, j--) { const uint8_t t = qual[i]; qual[i] = qual[j]; qual[j] = t; }
     }
     O.totals[0] = ncig; O.totals[1] = nname;
     if (R.err) return R.err;

@@ -116,6 +116,7 @@ inline int plan_from_compression_header(PlanHost &H, const uint8_t *b, size_t n)
     H = PlanHost();
     for (int i = 0; i < S_N; i++) H.plan.codec_of[i] = -1;
     H.plan.rn_included = 0; H.plan.ap_delta = 1; H.plan.qs_seq_orient = 1;   // defaults (cram_decode.c:203-207)
+    memcpy(H.plan.sm, "CGTNAGTNACTNACGNACGT", 20);
     Cursor c{b, b + n};
     std::vector<std::vector<uint8_t>> td;                               // tag dictionary lines: 3-byte (tag, type) triples
     {   // preservation map
@@ -127,7 +128,12 @@ inline int plan_from_compression_header(PlanHost &H, const uint8_t *b, size_t n)
             if (k0 == 'R' && k1 == 'N') H.plan.rn_included = c.byte();
             else if (k0 == 'A' && k1 == 'P') H.plan.ap_delta = c.byte();
             else if (k0 == 'Q' && k1 == 'O') H.plan.qs_seq_orient = c.byte();
-            else if (k0 == 'S' && k1 == 'M') { if (c.end - c.p < 5) return -1; c.p += 5; }
+            else if (k0 == 'S' && k1 == 'M') {                          // cram_decode.c:290-318: code -> base, per reference base
+                if (c.end - c.p < 5) return -1;
+                static const char *others[5] = {"CGTN", "AGTN", "ACTN", "ACGN", "ACGT"};
+                for (int r = 0; r < 5; r++) for (int k = 0; k < 4; k++) H.plan.sm[r][(c.p[r] >> (6 - 2 * k)) & 3] = (uint8_t)others[r][k];
+                c.p += 5;
+            }
             else if (k0 == 'T' && k1 == 'D') {
                 const int32_t sz = c.itf8();
                 if (c.bad || sz < 0 || c.end - c.p < sz) return -1;
@@ -194,7 +200,7 @@ inline int parse_slice_header(const uint8_t *b, size_t n, int major, SliceHeader
 
 
 // ---- a batch of slices laid out for the decoder (shared by the device launcher and the CPU test harness) -------------------
-struct PlanDev { int32_t codec_of[S_N]; int32_t rn_included, ap_delta, qs_seq_orient, nslots, nTL; uint32_t tl_off_base, tl_codec_base, codec_base, huff_base; };
+struct PlanDev { int32_t codec_of[S_N]; int32_t rn_included, ap_delta, qs_seq_orient, nslots, nTL; uint32_t tl_off_base, tl_codec_base, codec_base, huff_base; uint8_t sm[5][4]; };
 struct SliceDev {
     uint32_t plan, tab_off;               // tab: nslots offsets, nslots lengths, nslots cursors (words) in the block table
     uint32_t core_off, core_len;
@@ -202,11 +208,13 @@ struct SliceDev {
     int64_t ref_seq_start;
     uint64_t rec_off, cig_off, name_off;
     uint32_t cig_cap, name_cap;
+    uint32_t ref_first, nrefs;            // reference spans of the slice in Batch::refs
 };
 struct Batch {
     std::vector<PlanDev> plans;
     std::vector<Codec> codecs; std::vector<HuffCode> huff; std::vector<int32_t> tl_off, tl_codec;
     std::vector<SliceDev> slices;
+    std::vector<RefSpan> refs;
     std::vector<uint32_t> tab;
     std::vector<uint64_t> src_off;        // where each staged buffer goes in the data image, in the order of src_ptr / src_len
     std::vector<const uint8_t *> src_ptr; std::vector<uint32_t> src_len;
@@ -214,9 +222,10 @@ struct Batch {
     std::vector<int32_t> status;          // per slice: 0 = goes to the decoder, else the status already known
 };
 
-// One input slice as the caller hands it over (mirrors hg_cram_slice_blocks)
+// One input slice as the caller hands it over (mirrors hg_cram_slice_blocks / hg_cram_ref_span)
+struct RefIn { int32_t ref_id; int64_t start; const uint8_t *bases; uint32_t len; int64_t sq_len; };
 struct SliceIn { const uint8_t *comp_hdr; uint32_t comp_hdr_len; const uint8_t *slice_hdr; uint32_t slice_hdr_len; const uint8_t *core; uint32_t core_len;
-                 uint32_t nblocks; const int32_t *content_id; const uint8_t *const *data; const uint32_t *len; };
+                 uint32_t nblocks; const int32_t *content_id; const uint8_t *const *data; const uint32_t *len; uint32_t nrefs; const RefIn *refs; };
 
 inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
     B = Batch();
@@ -240,6 +249,7 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
                 pi = (int32_t)B.plans.size();
                 PlanDev pd; memcpy(pd.codec_of, H.plan.codec_of, sizeof pd.codec_of);
                 pd.rn_included = H.plan.rn_included; pd.ap_delta = H.plan.ap_delta; pd.qs_seq_orient = H.plan.qs_seq_orient; pd.nslots = H.plan.nslots; pd.nTL = H.plan.nTL;
+                memcpy(pd.sm, H.plan.sm, 20);
                 pd.tl_off_base = (uint32_t)B.tl_off.size(); pd.tl_codec_base = (uint32_t)B.tl_codec.size(); pd.codec_base = (uint32_t)B.codecs.size(); pd.huff_base = (uint32_t)B.huff.size();
                 B.tl_off.insert(B.tl_off.end(), H.tl_off.begin(), H.tl_off.end()); B.tl_codec.insert(B.tl_codec.end(), H.tl_codec.begin(), H.tl_codec.end());
                 B.codecs.insert(B.codecs.end(), H.codecs.begin(), H.codecs.end()); B.huff.insert(B.huff.end(), H.huff.begin(), H.huff.end());
@@ -263,6 +273,11 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
             ext_bytes += s.len[k];
         }
         d.core_off = (uint32_t)stage(s.core, s.core ? s.core_len : 0); d.core_len = s.core ? s.core_len : 0;
+        d.ref_first = (uint32_t)B.refs.size(); d.nrefs = s.refs ? s.nrefs : 0;
+        for (uint32_t k = 0; k < d.nrefs; k++) {
+            const RefIn &r = s.refs[k];
+            B.refs.push_back(RefSpan{r.ref_id, (uint32_t)stage(r.bases, r.len), r.len, 0u, r.start, r.sq_len});
+        }
         d.rec_off = B.nrec; B.nrec += (uint64_t)sh.nrec;
         // capacities: a read name is copied out of a block, a CIGAR op needs a feature; features that cost no bits at all (constant
         // codecs) are bounded by 4 ops per record on top of one op per byte of the slice

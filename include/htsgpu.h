@@ -376,8 +376,9 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
  *      htsjdk write are handled (EXTERNAL, HUFFMAN, BETA, GAMMA, SUBEXP, BYTE_ARRAY_LEN, BYTE_ARRAY_STOP); a slice that needs
  *      GOLOMB / GOLOMB_RICE reports HG_BLOCK_EUNSUPPORTED.  Output per record: the cram_record fields that do not need the reference
  *      sequence, after cram_decode_slice_xref -- flags (with the mate bits), cram_flags, ref_id, len, apos, aend, rg, mqual, the
- *      CIGAR (BAM encoding, cram_decode_seq's feature walk), the read name, mate_ref_id, mate_pos, tlen.  Bases, qualities and aux
- *      values are consumed but not produced yet.  Pinned on the reference's 34 CRAM fixtures against their SAM / BAM twins
+ *      CIGAR (BAM encoding, cram_decode_seq's feature walk), the read name, mate_ref_id, mate_pos, tlen, and -- given the reference
+ *      spans -- the bases and qualities (cram_decode_seq's reconstruction, without MD / NM generation).  Aux values are consumed but
+ *      not produced yet.  Pinned on the reference's 34 CRAM fixtures against their SAM / BAM twins
  *      (tests/test_cram_records.py).  One wavefront per slice (cram_records.hip). ---- */
 typedef struct hg_cram_slice_blocks {
     const uint8_t *comp_hdr; uint32_t comp_hdr_len;     /* compression header block of the slice's container (slices of one container may share the pointer) */
@@ -385,13 +386,20 @@ typedef struct hg_cram_slice_blocks {
     const uint8_t *core; uint32_t core_len;             /* CORE block (content type 5) */
     uint32_t nblocks;                                   /* EXTERNAL blocks (content type 4): */
     const int32_t *content_id; const uint8_t *const *data; const uint32_t *len;
+    uint32_t nrefs; const struct hg_cram_ref_span *refs; /* reference bases the slice aligns to (only needed for SEQ; may be 0 / NULL) */
 } hg_cram_slice_blocks;
+/* A stretch of one reference sequence, upper case ASCII: what cram_get_ref hands cram_decode_slice (s->ref, ref_start, ref_end), or the
+ * slice's embedded-reference block.  start = 1-based position of bases[0]; sq_len = the @SQ LN of that reference. */
+typedef struct hg_cram_ref_span { int32_t ref_id; int64_t start; const uint8_t *bases; uint32_t len; int64_t sq_len; } hg_cram_ref_span;
 typedef struct hg_cram_record_cols {                    /* arrays of rec_cap entries; a NULL column is not copied back */
     int32_t *flags, *cram_flags, *ref_id, *len, *rg, *mqual, *mate_ref_id, *ncigar, *name_len;
     int64_t *apos, *aend, *mate_pos, *tlen;
     uint64_t *cigar_off, *name_off;                     /* first CIGAR op / name byte of the record in cigar[] / names[] */
     uint32_t *cigar;                                    /* cigar_cap words: len << 4 | op */
     uint8_t *names;                                     /* name_cap bytes, names are not terminated */
+    uint64_t *seq_off; uint8_t *seq, *qual;             /* bases (ASCII, '=' where no reference span was given) and qualities (255 = absent):
+                                                           len[r] bytes each at seq_off[r]; all three NULL = not wanted.  seq_cap >= the number
+                                                           of bases of the slices (the containers' `bases` header field). */
 } hg_cram_record_cols;
 /* Sizes the caller must provide for these slices: records (exact), CIGAR words and name bytes (upper bounds; slices get disjoint
  * regions).  Host only. */
@@ -400,8 +408,8 @@ int hg_cram_records_bound(size_t nslices, const hg_cram_slice_blocks *slices, in
 /* nref = number of @SQ lines (bounds of RI / NS).  rec_off[i] .. rec_off[i+1] = the records of slice i (nslices + 1 entries).
  * status[i] = 0, -1 (malformed slice, as cram_decode_slice returning -1) or HG_BLOCK_EUNSUPPORTED.  Returns HG_OK / HG_EBLOCK. */
 int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref,
-                                size_t rec_cap, size_t cigar_cap, size_t name_cap, const hg_cram_record_cols *out, uint64_t *rec_off,
-                                int32_t *status);
+                                size_t rec_cap, size_t cigar_cap, size_t name_cap, size_t seq_cap, const hg_cram_record_cols *out,
+                                uint64_t *rec_off, int32_t *status);
 
 /* ---- BAM record framing on the device: the framing half of bam_read1 (sam.c:784-866) and
  *      nibble2base (simd.c:119-161) for consumers that keep the inflated stream in HBM. ---- */

@@ -4,7 +4,8 @@
 For every CRAM file of the reference's test directory that has a SAM / BAM twin (test/*.cram, test/tlen/*.cram), each slice
 is stored with its DECODED blocks (compression header, slice header, CORE, EXTERNAL blocks by content id -- RAW / gzip / rANS 4x8
 payloads are expanded here with zlib and the pinned rANS oracle) and the expected per-record fields taken from the twin WITHOUT
-any CRAM code: QNAME, FLAG, reference id, POS, MAPQ, CIGAR, mate reference id, PNEXT, TLEN.  The tlen/ pairs were written by the
+any CRAM code: QNAME, FLAG, reference id, POS, MAPQ, CIGAR, mate reference id, PNEXT, TLEN, SEQ, QUAL -- plus the stretch of each
+reference the slice's records align to (from the reference's .fa files), which the decoder needs to rebuild the bases.  The tlen/ pairs were written by the
 reference's authors to pin the template-length and mate logic of cram_decode_slice_xref (test/tlen/README).
 
 Output: tests/golden/cram_records.json (blocks as base64 of zlib).  Needs /root/reference; run in the build container."""
@@ -17,6 +18,8 @@ import make_golden_rans as R                                       # container /
 from tests import refutil
 
 REF = "/root/reference/test"
+FASTA = {"ce#5b_java.cram": "ce.fa", "range.cram": "ce.fa", "auxf#values_java.cram": "auxf.fa", "xx#large_aux_java.cram": "xx.fa"}
+TLEN_REF = {"ref": "AAAAACCCCCGGGGGTTTTT"}                          # test/tlen/README
 TWINS = {"ce#5b_java.cram": "ce#5b.sam", "auxf#values_java.cram": "auxf#values.sam", "xx#large_aux_java.cram": "xx#large_aux.sam", "range.cram": "range.bam"}
 
 
@@ -48,7 +51,12 @@ def sam_text(path):
             tid, pos, lname, mapq, _, ncig, flag, lseq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", d, q)
             name = d[q + 32:q + 32 + lname - 1].decode()
             cig = struct.unpack_from("<%dI" % ncig, d, q + 32 + lname)
-            recs.append((name, flag, tid, pos + 1, mapq, [(c >> 4, c & 15) for c in cig], mtid, mpos + 1, tlen))
+            a = q + 32 + lname + 4 * ncig
+            packed = d[a:a + (lseq + 1) // 2]
+            seq = "".join("=ACMGRSVTWYHKDBN"[(packed[i >> 1] >> (4 if i % 2 == 0 else 0)) & 15] for i in range(lseq)) or "*"
+            ql = d[a + (lseq + 1) // 2:a + (lseq + 1) // 2 + lseq]
+            qual = "*" if lseq == 0 or ql[0] == 0xFF else bytes(c + 33 for c in ql).decode("latin1")
+            recs.append((name, flag, tid, pos + 1, mapq, [(c >> 4, c & 15) for c in cig], mtid, mpos + 1, tlen, seq, qual))
         return refs, recs
     refs, recs = [], []
     for ln in open(path):
@@ -60,8 +68,31 @@ def sam_text(path):
         cig = [] if f[5] == "*" else [(int(n), "MIDNSHP=X".index(o)) for n, o in re.findall(r"(\d+)([MIDNSHP=X])", f[5])]
         tid = -1 if f[2] == "*" else refs.index(f[2])
         mtid = -1 if f[6] == "*" else tid if f[6] == "=" else refs.index(f[6])
-        recs.append((f[0], int(f[1]), tid, int(f[3]), int(f[4]), cig, mtid, int(f[7]), int(f[8])))
+        recs.append((f[0], int(f[1]), tid, int(f[3]), int(f[4]), cig, mtid, int(f[7]), int(f[8]), f[9], f[10]))
     return refs, recs
+
+
+def fasta(path):
+    out, name = {}, None
+    for ln in open(path):
+        if ln.startswith(">"): name = ln[1:].split()[0]; out[name] = []
+        else: out[name].append(ln.strip().upper())
+    return {k: "".join(v) for k, v in out.items()}
+
+
+def ref_spans(recs, refs, bases):
+    """the stretch of every reference the mapped records of one slice touch: [[ref id, start (1-based), bases, @SQ length]]"""
+    lo, hi = {}, {}
+    for r in recs:
+        if r[1] & 4 or r[2] < 0: continue
+        end = r[3] + sum(n for n, op in r[5] if op in (0, 2, 3, 7, 8)) - 1
+        lo[r[2]] = min(lo.get(r[2], r[3]), r[3]); hi[r[2]] = max(hi.get(r[2], end), end)
+    out = []
+    for tid in sorted(lo):
+        full = bases[refs[tid]]
+        a, b = max(1, lo[tid]), min(len(full), hi[tid] + 5)
+        out.append([tid, a, full[a - 1:b], len(full)])
+    return out
 
 
 def main():
@@ -73,6 +104,7 @@ def main():
         base = os.path.basename(path)
         twin = os.path.join(REF, TWINS[base]) if base in TWINS else path[:-5] + ".sam"
         refs, recs = sam_text(twin)
+        bases = fasta(os.path.join(REF, FASTA[base])) if base in FASTA else TLEN_REF
         b = open(path, "rb").read()
         assert b[:4] == b"CRAM" and b[4] == 3
         slices, at = [], 0
@@ -92,7 +124,8 @@ def main():
                 assert len(core) == 1 and len(core) + len(ext) == nb
                 slices.append({"comp_hdr": pack(comp), "slice_hdr": pack(sh), "core": pack(expand(core[0], rans)),
                                "blocks": [[x[2], pack(expand(x, rans))] for x in ext], "nrec": n,
-                               "expect": [[r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]] for r in recs[at:at + n]]})
+                               "refs": [[t, a, pack(sq.encode()), ln] for t, a, sq, ln in ref_spans(recs[at:at + n], refs, bases)],
+                               "expect": [list(r) for r in recs[at:at + n]]})
                 at += n
                 k += 1 + nb
         assert at == len(recs), (base, at, len(recs))

@@ -1,7 +1,8 @@
 """CRAM record decoding (the record loop of cram_decode_slice, cram/cram_decode.c:2346-3026, with cram_decode_seq's
 feature walk and cram_decode_slice_xref) -- PINNED on the reference's own fixtures: every slice of the 34 CRAM v3.0 files that have a
 SAM / BAM twin (tests/golden/cram_records.json, frozen by make_golden_cram_records.py with NO CRAM decoding code involved on the
-expectation side) must decode to the twin's QNAME, FLAG, RNAME, POS, MAPQ, CIGAR, RNEXT, PNEXT and TLEN.  The 31 test/tlen pairs were
+expectation side) must decode to the twin's QNAME, FLAG, RNAME, POS, MAPQ, CIGAR, RNEXT, PNEXT, TLEN, SEQ and QUAL (the bases are rebuilt
+from the reference's .fa files plus the stored edits, cram_decode_seq).  The 31 test/tlen pairs were
 written by the reference's authors to pin the mate / template-length logic.
 CPU part: the decoder source (htslib_amd/csrc/cram_records_core.h) compiled for the host by tests/native/cram_records_host.cpp.
 GPU part: the same fixtures through hg_cram_decode_records_host (one wavefront per slice), plus a replicated batch."""
@@ -17,12 +18,16 @@ _vp = C.c_void_p
 
 class SliceIn(C.Structure):                 # = hg_cram_slice_blocks
     _fields_ = [("comp_hdr", _vp), ("comp_hdr_len", C.c_uint32), ("slice_hdr", _vp), ("slice_hdr_len", C.c_uint32), ("core", _vp), ("core_len", C.c_uint32),
-                ("nblocks", C.c_uint32), ("content_id", _vp), ("data", _vp), ("len", _vp)]
+                ("nblocks", C.c_uint32), ("content_id", _vp), ("data", _vp), ("len", _vp), ("nrefs", C.c_uint32), ("refs", _vp)]
+
+
+class RefIn(C.Structure):                   # = hg_cram_ref_span
+    _fields_ = [("ref_id", C.c_int32), ("start", C.c_int64), ("bases", _vp), ("len", C.c_uint32), ("sq_len", C.c_int64)]
 
 
 class Cols(C.Structure):                    # = hg_cram_record_cols
     _fields_ = [(k, _vp) for k in ("flags", "cram_flags", "ref_id", "len", "rg", "mqual", "mate_ref_id", "ncigar", "name_len", "apos", "aend", "mate_pos", "tlen",
-                                   "cigar_off", "name_off", "cigar", "names")]
+                                   "cigar_off", "name_off", "cigar", "names", "seq_off", "seq", "qual")]
 
 
 def unpack(s):
@@ -35,11 +40,12 @@ def load_slices():
     for f in json.load(open(GOLD)):
         for s in f["slices"]:
             out.append((f["file"], f["major"], f["nref"], {"comp_hdr": unpack(s["comp_hdr"]), "slice_hdr": unpack(s["slice_hdr"]), "core": unpack(s["core"]),
-                                                          "blocks": [(cid, unpack(d)) for cid, d in s["blocks"]], "nrec": s["nrec"], "expect": s["expect"]}))
+                                                          "blocks": [(cid, unpack(d)) for cid, d in s["blocks"]], "nrec": s["nrec"], "expect": s["expect"],
+                                                          "refs": [(t, a, unpack(b), ln) for t, a, b, ln in s["refs"]]}))
     return out
 
 
-def decode(call_bound, call_decode, slices, major, nref):
+def decode(call_bound, call_decode, slices, major, nref, with_seq=True):
     """slices: dicts as above -> (status, per-slice list of record tuples in the twin's layout)"""
     n = len(slices)
     keep, arr = [], (SliceIn * n)()
@@ -50,9 +56,11 @@ def decode(call_bound, call_decode, slices, major, nref):
         bl = [C.create_string_buffer(d, max(len(d), 1)) for _, d in s["blocks"]]
         ids = np.array([cid for cid, _ in s["blocks"]], dtype=np.int32); lens = np.array([len(d) for _, d in s["blocks"]], dtype=np.uint32)
         ptrs = (_vp * max(len(bl), 1))(*[C.addressof(x) for x in bl])
-        keep.append((ch, sh, co, bl, ids, lens, ptrs))
+        rb = [C.create_string_buffer(b, max(len(b), 1)) for _, _, b, _ in s.get("refs", [])]
+        ra = (RefIn * max(len(rb), 1))(*[RefIn(t, a, C.addressof(buf), len(b), ln) for (t, a, b, ln), buf in zip(s.get("refs", []), rb)])
+        keep.append((ch, sh, co, bl, ids, lens, ptrs, rb, ra))
         arr[i] = SliceIn(C.addressof(ch), len(s["comp_hdr"]), C.addressof(sh), len(s["slice_hdr"]), C.addressof(co), len(s["core"]), len(bl), ids.ctypes.data,
-                         C.addressof(ptrs), lens.ctypes.data)
+                         C.addressof(ptrs), lens.ctypes.data, len(rb) if with_seq else 0, C.addressof(ra))
     nrec, ccap, ncap = C.c_uint64(), C.c_uint64(), C.c_uint64()
     assert call_bound(n, arr, major, C.byref(nrec), C.byref(ccap), C.byref(ncap)) == 0
     R = max(nrec.value, 1)
@@ -60,9 +68,12 @@ def decode(call_bound, call_decode, slices, major, nref):
     i64 = {k: np.full(R, -99, np.int64) for k in ("apos", "aend", "mate_pos", "tlen")}
     u64 = {k: np.zeros(R, np.uint64) for k in ("cigar_off", "name_off")}
     cigar = np.zeros(max(ccap.value, 1), np.uint32); names = np.zeros(max(ncap.value, 1), np.uint8)
-    cols = Cols(*[a.ctypes.data for a in list(i32.values()) + list(i64.values()) + list(u64.values()) + [cigar, names]])
+    seq_cap = sum(len(e[9]) if len(e) > 9 and e[9] != "*" else 0 for s in slices for e in s["expect"]) + 4096     # the containers' base count would do
+    seq_off = np.zeros(R, np.uint64); seq = np.zeros(seq_cap, np.uint8); qual = np.zeros(seq_cap, np.uint8)
+    cols = Cols(*[a.ctypes.data for a in list(i32.values()) + list(i64.values()) + list(u64.values()) + [cigar, names]],
+                *([seq_off.ctypes.data, seq.ctypes.data, qual.ctypes.data] if with_seq else [None, None, None]))
     rec_off = np.zeros(n + 1, np.uint64); status = np.full(n, 77, np.int32)
-    rc = call_decode(n, arr, major, nref, R, len(cigar), len(names), C.byref(cols), rec_off.ctypes.data, status.ctypes.data)
+    rc = call_decode(n, arr, major, nref, R, len(cigar), len(names), seq_cap, C.byref(cols), rec_off.ctypes.data, status.ctypes.data)
     assert rc in (0, -6), rc                      # HG_EBLOCK: some slice has a non-zero status
     out = []
     for i in range(n):
@@ -73,6 +84,11 @@ def decode(call_bound, call_decode, slices, major, nref):
             no, nl = int(u64["name_off"][r]), int(i32["name_len"][r])
             recs.append([bytes(names[no:no + nl]).decode("latin1"), int(i32["flags"][r]), int(i32["ref_id"][r]), int(i64["apos"][r]), int(i32["mqual"][r]), cg,
                          int(i32["mate_ref_id"][r]), int(i64["mate_pos"][r]), int(i64["tlen"][r])])
+            if with_seq:
+                so, ln = int(seq_off[r]), int(i32["len"][r])
+                q = qual[so:so + ln]
+                recs[-1] += [bytes(seq[so:so + ln]).decode("latin1") if ln else "*",
+                             "*" if ln == 0 or (q == 255).all() else bytes((q + 33).astype(np.uint8)).decode("latin1")]
         out.append(recs)
     return status, out
 
@@ -83,8 +99,7 @@ def check_against_twin(fname, got, expect):
         g, e = list(g), list(e)
         if e[1] & 4:                         # unmapped: CRAM does not store a mapping quality or a CIGAR for these
             e[4] = 0; e[5] = []
-        if not (e[1] & 1):                   # unpaired: SAM prints RNEXT / PNEXT / TLEN as * 0 0
-            pass
+        if len(g) == 9: e = e[:9]            # decoded without bases / qualities
         assert g == e, (fname, g, e)
 
 
@@ -94,7 +109,7 @@ def hostlib(tmp_path_factory):
     subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", so, os.path.join(ROOT, "tests", "native", "cram_records_host.cpp")], check=True)
     L = C.CDLL(so)
     L.hgr_host_records_bound.argtypes = [C.c_size_t, _vp, C.c_int, _vp, _vp, _vp]
-    L.hgr_host_decode_records.argtypes = [C.c_size_t, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp]
+    L.hgr_host_decode_records.argtypes = [C.c_size_t, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp]
     return L
 
 
@@ -115,8 +130,8 @@ def test_decoder_source_on_the_cpu_matches_the_sam_twins(hostlib):
 def _gpu_calls(engine):
     from htslib_amd import _native as nat
     bound = lambda n, arr, major, a, b, c: nat.lib.hg_cram_records_bound(n, C.cast(arr, _vp), major, C.cast(a, _vp), C.cast(b, _vp), C.cast(c, _vp))
-    dec = lambda n, arr, major, nref, R, cc, nc, cols, ro, st: nat.lib.hg_cram_decode_records_host(engine._h, n, C.cast(arr, _vp), major, nref, R, cc, nc,
-                                                                                                  C.cast(cols, _vp), ro, st)
+    dec = lambda n, arr, major, nref, R, cc, nc, sc, cols, ro, st: nat.lib.hg_cram_decode_records_host(engine._h, n, C.cast(arr, _vp), major, nref, R, cc, nc, sc,
+                                                                                                      C.cast(cols, _vp), ro, st)
     return bound, dec
 
 
