@@ -75,8 +75,8 @@ lib.hg_arith_compress_bound.argtypes = [C.c_size_t]
 lib.hg_arith_decode_host.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]
 lib.hg_arith_encode_host.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]
 lib.hg_fqz_decode_host.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]
-lib.hg_cram_records_bound.argtypes = [C.c_size_t, _vp, C.c_int, _vp, _vp, _vp]
-lib.hg_cram_decode_records_host.argtypes = [_vp, C.c_size_t, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp]
+lib.hg_cram_records_bound.argtypes = [C.c_size_t, _vp, C.c_int, _vp, _vp, _vp, _vp]
+lib.hg_cram_decode_records_host.argtypes = [_vp, C.c_size_t, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp]
 lib.hg_fqz_compress_bound.restype = C.c_size_t
 lib.hg_fqz_compress_bound.argtypes = [C.c_size_t, C.c_size_t]
 lib.hg_fqz_encode_host.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]

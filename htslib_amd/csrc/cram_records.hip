@@ -28,7 +28,7 @@
 namespace hgr {
 
 struct DevTables {
-    const PlanDev *plans; const Codec *codecs; const HuffCode *huff; const int32_t *tl_off, *tl_codec;
+    const PlanDev *plans; const Codec *codecs; const HuffCode *huff; const int32_t *tl_off, *tl_codec, *tl_tag;
     const SliceDev *slices; uint32_t *tab; const uint8_t *data; const RefSpan *refs;
 };
 struct DevCols {
@@ -37,7 +37,8 @@ struct DevCols {
     uint64_t *cigar_off, *name_off;
     uint32_t *cigar; uint8_t *names;
     uint64_t *seq_off; uint8_t *seq, *qual; unsigned long long *seq_pool; uint64_t seq_cap;   // seq == nullptr: bases / qualities not wanted
-    int32_t *mate_flags, *mate_line; int64_t *explicit_tlen; uint32_t *coff, *noff;      // scratch columns
+    uint64_t *aux_off; int32_t *aux_len; uint8_t *aux;                                      // aux == nullptr: not wanted
+    int32_t *mate_flags, *mate_line; int64_t *explicit_tlen; uint32_t *coff, *noff, *aoff;   // scratch columns
 };
 
 __global__ __launch_bounds__(64)
@@ -53,16 +54,16 @@ void cram_records_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref,
             for (int i = 0; i < S_N; i++) P.codec_of[i] = pd.codec_of[i];
             for (int i = 0; i < 20; i++) (&P.sm[0][0])[i] = (&pd.sm[0][0])[i];
             P.rn_included = pd.rn_included; P.ap_delta = pd.ap_delta; P.qs_seq_orient = pd.qs_seq_orient; P.nslots = pd.nslots; P.nTL = pd.nTL;
-            P.tl_off = T.tl_off + pd.tl_off_base; P.tl_codec = T.tl_codec + pd.tl_codec_base; P.codecs = T.codecs + pd.codec_base; P.huff = T.huff + pd.huff_base;
+            P.tl_off = T.tl_off + pd.tl_off_base; P.tl_codec = T.tl_codec + pd.tl_codec_base; P.tl_tag = T.tl_tag + pd.tl_codec_base; P.codecs = T.codecs + pd.codec_base; P.huff = T.huff + pd.huff_base;
             Slice S;
             S.data = T.data; S.blk_off = T.tab + d.tab_off; S.blk_len = S.blk_off + pd.nslots; S.cursor = T.tab + d.tab_off + 2 * pd.nslots;
             S.core_off = d.core_off; S.core_len = d.core_len; S.nrec = d.nrec; S.ref_seq_id = d.ref_seq_id; S.ref_seq_start = d.ref_seq_start; S.nref = nref;
-            S.cigar_cap = d.cig_cap; S.name_cap = d.name_cap; S.refs = T.refs + d.ref_first; S.nrefs = (int32_t)d.nrefs;
-            uint32_t totals[2];
+            S.cigar_cap = d.cig_cap; S.name_cap = d.name_cap; S.aux_cap = d.aux_cap; S.refs = T.refs + d.ref_first; S.nrefs = (int32_t)d.nrefs;
+            uint32_t totals[3];
             const uint64_t r0 = d.rec_off;
             Cols O{D.flags + r0, D.cram_flags + r0, D.ref_id + r0, D.len + r0, D.rg + r0, D.mqual + r0, D.mate_flags + r0, D.mate_ref_id + r0, D.mate_line + r0,
                    D.ncigar + r0, D.name_len + r0, D.coff + r0, D.noff + r0, D.apos + r0, D.aend + r0, D.mate_pos + r0, D.tlen + r0, D.explicit_tlen + r0,
-                   D.cigar + d.cig_off, D.names + d.name_off, totals, D.seq, D.qual, D.seq ? D.seq_off + r0 : nullptr, D.seq_pool, D.seq_cap};
+                   D.cigar + d.cig_off, D.names + d.name_off, totals, D.aux ? D.aux + d.aux_off : nullptr, D.aoff + r0, D.aux ? D.aux_len + r0 : nullptr, D.seq, D.qual, D.seq ? D.seq_off + r0 : nullptr, D.seq_pool, D.seq_cap};
             rc = decode_slice(&P, &S, O);
             status[k] = rc;
         }
@@ -70,6 +71,7 @@ void cram_records_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref,
         for (int32_t r = lane; r < d.nrec; r += 64) {
             D.cigar_off[d.rec_off + (uint64_t)r] = d.cig_off + D.coff[d.rec_off + (uint64_t)r];
             D.name_off[d.rec_off + (uint64_t)r] = d.name_off + D.noff[d.rec_off + (uint64_t)r];
+            if (D.aux) D.aux_off[d.rec_off + (uint64_t)r] = d.aux_off + D.aoff[d.rec_off + (uint64_t)r];
         }
     }
 }
@@ -77,25 +79,26 @@ void cram_records_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref,
 }  // namespace hgr
 
 extern "C" int hg_cram_records_bound(size_t nslices, const hg_cram_slice_blocks *slices, int major_version, uint64_t *nrec, uint64_t *cigar_cap,
-                                     uint64_t *name_cap) {
-    if ((nslices && !slices) || !nrec || !cigar_cap || !name_cap) return HG_EINVAL;
+                                     uint64_t *name_cap, uint64_t *aux_cap) {
+    if ((nslices && !slices) || !nrec || !cigar_cap || !name_cap || !aux_cap) return HG_EINVAL;
     static_assert(sizeof(hg_cram_slice_blocks) == sizeof(hgr::SliceIn), "hg_cram_slice_blocks layout");
     hgr::Batch B;
     const int rc = hgr::batch_build(B, (const hgr::SliceIn *)slices, nslices, major_version);
     if (rc) return rc == -3 ? HG_BLOCK_EUNSUPPORTED : HG_EINVAL;
-    *nrec = B.nrec; *cigar_cap = B.cig_total; *name_cap = B.name_total;
+    *nrec = B.nrec; *cigar_cap = B.cig_total; *name_cap = B.name_total; *aux_cap = B.aux_total;
     return HG_OK;
 }
 
 extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, size_t rec_cap,
-                                           size_t cigar_cap, size_t name_cap, size_t seq_cap, const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status) {
+                                           size_t cigar_cap, size_t name_cap, size_t seq_cap, size_t aux_cap, const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status) {
     if (!ctx || (nslices && (!slices || !out || !rec_off || !status))) return HG_EINVAL;
     if (nslices == 0) { if (rec_off) rec_off[0] = 0; return HG_OK; }
     hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     hgr::Batch B;
     int rc = hgr::batch_build(B, (const hgr::SliceIn *)slices, nslices, major_version);
     if (rc) return rc == -3 ? HG_BLOCK_EUNSUPPORTED : HG_EINVAL;
-    if (B.nrec > rec_cap || B.cig_total > cigar_cap || B.name_total > name_cap) return HG_EINVAL;
+    const bool want_aux = out->aux && out->aux_off && out->aux_len;
+    if (B.nrec > rec_cap || B.cig_total > cigar_cap || B.name_total > name_cap || (want_aux && B.aux_total > aux_cap)) return HG_EINVAL;
     for (size_t i = 0; i < nslices; i++) rec_off[i] = B.slices[i].rec_off;
     rec_off[nslices] = B.nrec;
     // device image of the tables: one buffer, carved
@@ -104,20 +107,21 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
                                {B.huff.data(), B.huff.size() * sizeof(hgr::HuffCode), 0}, {B.tl_off.data(), B.tl_off.size() * 4, 0},
                                {B.tl_codec.data(), B.tl_codec.size() * 4, 0}, {B.slices.data(), B.slices.size() * sizeof(hgr::SliceDev), 0},
                                {B.tab.data(), B.tab.size() * 4, 0}, {B.status.data(), B.status.size() * 4, 0},
-                               {B.refs.data(), B.refs.size() * sizeof(hgr::RefSpan), 0}};
+                               {B.refs.data(), B.refs.size() * sizeof(hgr::RefSpan), 0}, {B.tl_tag.data(), B.tl_tag.size() * 4, 0}};
     size_t tbytes = 0;
     for (auto &p : parts) { p.off = tbytes; tbytes += (p.bytes + 63) & ~(size_t)63; }
     const size_t R = B.nrec ? B.nrec : 1;
     // output image: 9 + 2 int32, 4 + 1 int64, 2 uint64, 2 uint32 scratch columns, cigar, names, status
     size_t obytes = 0;
     auto carve = [&](size_t bytes) { const size_t o = obytes; obytes += (bytes + 63) & ~(size_t)63; return o; };
-    size_t o32[11], o64[5], ou64[2], ou32[2];
+    size_t o32[12], o64[5], ou64[3], ou32[3];
     for (auto &o : o32) o = carve(R * 4);
     for (auto &o : o64) o = carve(R * 8);
     for (auto &o : ou64) o = carve(R * 8);
     for (auto &o : ou32) o = carve(R * 4);
     const size_t ocig = carve((B.cig_total ? B.cig_total : 1) * 4), onam = carve(B.name_total ? B.name_total : 1), ost = carve(nslices * 4);
     const bool want_seq = out->seq && out->qual && out->seq_off;
+    const size_t oaux = carve(want_aux ? B.aux_total + 1 : 1);
     const size_t oso = carve(R * 8), oseq = carve(want_seq ? seq_cap + 1 : 1), oqual = carve(want_seq ? seq_cap + 1 : 1), opool = carve(8);
     if ((rc = hg::ensure_scratch(ctx, 0, B.data_bytes + 64)) || (rc = hg::ensure_scratch(ctx, 1, obytes + 64)) || (rc = hg::ensure_scratch(ctx, 2, tbytes + 64))) return rc;
     hipStream_t s = ctx->stream;
@@ -126,7 +130,8 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     for (auto &p : parts) if (ok && p.bytes) ok = hipMemcpyAsync(d_tab + p.off, p.src, p.bytes, hipMemcpyHostToDevice, s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
     hgr::DevTables T{(const hgr::PlanDev *)(d_tab + parts[0].off), (const hgr::Codec *)(d_tab + parts[1].off), (const hgr::HuffCode *)(d_tab + parts[2].off),
-                     (const int32_t *)(d_tab + parts[3].off), (const int32_t *)(d_tab + parts[4].off), (const hgr::SliceDev *)(d_tab + parts[5].off),
+                     (const int32_t *)(d_tab + parts[3].off), (const int32_t *)(d_tab + parts[4].off), (const int32_t *)(d_tab + parts[9].off),
+                     (const hgr::SliceDev *)(d_tab + parts[5].off),
                      (uint32_t *)(d_tab + parts[6].off), d_data, (const hgr::RefSpan *)(d_tab + parts[8].off)};
     hgr::DevCols D;
     int32_t **p32[11] = {&D.flags, &D.cram_flags, &D.ref_id, &D.len, &D.rg, &D.mqual, &D.mate_ref_id, &D.ncigar, &D.name_len, &D.mate_flags, &D.mate_line};
@@ -134,7 +139,8 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     int64_t **p64[5] = {&D.apos, &D.aend, &D.mate_pos, &D.tlen, &D.explicit_tlen};
     for (int i = 0; i < 5; i++) *p64[i] = (int64_t *)(d_out + o64[i]);
     D.cigar_off = (uint64_t *)(d_out + ou64[0]); D.name_off = (uint64_t *)(d_out + ou64[1]);
-    D.coff = (uint32_t *)(d_out + ou32[0]); D.noff = (uint32_t *)(d_out + ou32[1]);
+    D.coff = (uint32_t *)(d_out + ou32[0]); D.noff = (uint32_t *)(d_out + ou32[1]); D.aoff = (uint32_t *)(d_out + ou32[2]);
+    D.aux_off = (uint64_t *)(d_out + ou64[2]); D.aux_len = (int32_t *)(d_out + o32[11]); D.aux = want_aux ? d_out + oaux : nullptr;
     D.cigar = (uint32_t *)(d_out + ocig); D.names = d_out + onam;
     D.seq_off = (uint64_t *)(d_out + oso); D.seq = want_seq ? d_out + oseq : nullptr; D.qual = want_seq ? d_out + oqual : nullptr;
     D.seq_pool = (unsigned long long *)(d_out + opool); D.seq_cap = seq_cap;
@@ -152,6 +158,9 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     if (ok && out->name_off && B.nrec) ok = hipMemcpyAsync(out->name_off, d_out + ou64[1], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
     if (ok && out->cigar && B.cig_total) ok = hipMemcpyAsync(out->cigar, d_out + ocig, B.cig_total * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
     if (ok && out->names && B.name_total) ok = hipMemcpyAsync(out->names, d_out + onam, B.name_total, hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (ok && want_aux && B.nrec) ok = hipMemcpyAsync(out->aux_off, d_out + ou64[2], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                                       hipMemcpyAsync(out->aux_len, d_out + o32[11], B.nrec * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                                       (!B.aux_total || hipMemcpyAsync(out->aux, d_out + oaux, B.aux_total, hipMemcpyDeviceToHost, s) == hipSuccess);
     unsigned long long used = 0;
     if (ok && want_seq) ok = hipMemcpyAsync(&used, d_out + opool, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     if (ok && want_seq && B.nrec) {

@@ -43,6 +43,7 @@ struct Plan {
     int32_t nTL;                          // tag dictionary lines; line t holds tags tl_off[t] .. tl_off[t+1]-1 of tl_codec[]
     const int32_t *tl_off;
     const int32_t *tl_codec;              // codec index of the tag's encoding (tag encoding map), -1 = not in the map
+    const int32_t *tl_tag;                // tag[0] << 16 | tag[1] << 8 | type, parallel to tl_codec
     const Codec *codecs;
     const HuffCode *huff;
 };
@@ -57,7 +58,7 @@ struct Slice {
     int32_t nrec, ref_seq_id;             // slice header: -2 = multi-reference slice (RI is read), -1 = unmapped
     int64_t ref_seq_start;
     int32_t nref;                         // number of @SQ lines (bounds of RI / NS)
-    uint32_t cigar_cap, name_cap;
+    uint32_t cigar_cap, name_cap, aux_cap;
     const RefSpan *refs; int32_t nrefs;   // reference spans of this slice (none: bases come out as '=' plus the stored edits)
 };
 // Per-record results (arrays of nrec), the CIGAR ops and the read names of the slice
@@ -67,7 +68,8 @@ struct Cols {
     int64_t *apos, *aend, *mate_pos, *tlen, *explicit_tlen;
     uint32_t *cigar;                      // (len << 4 | op), BAM encoding
     uint8_t *names;
-    uint32_t *totals;                     // [0] = cigar ops written, [1] = name bytes written
+    uint32_t *totals;                     // [0] = cigar ops written, [1] = name bytes written, [2] = aux bytes written
+    uint8_t *aux; uint32_t *aux_off; int32_t *aux_len;    // aux == nullptr: not wanted.  BAM encoding: tag[2] type value, back to back
     // bases and qualities (seq == nullptr: not wanted): len bytes each per record at seq_off[rec], handed out from one pool
     uint8_t *seq, *qual; uint64_t *seq_off; unsigned long long *seq_pool; uint64_t seq_cap;
 };
@@ -333,19 +335,36 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
     if (cf & CF_NO_SEQ) O.len[rec] = 0;
 }
 
-// cram_decode_aux (cram_decode.c:2008-2137): the tag values are consumed, not kept
-HGR_FN void skip_aux(Reader &R) {
+// cram_decode_aux (cram_decode.c:2008-2137): tag list of the record (TL -> dictionary line), then one value per tag.  The values are
+// stored in BAM encoding already; with O.aux the record's tags are written as tag[2] type value ..., else only consumed.
+HGR_FN void decode_aux(Reader &R, const Cols &O, int rec, uint32_t &naux) {
     const Plan *P = R.P;
     const int32_t tl = R.ival(S_TL);
+    if (O.aux) { O.aux_off[rec] = naux; O.aux_len[rec] = 0; }
     if (R.err) return;
     if (tl < 0 || tl >= P->nTL) { R.err = ERR_MALFORMED; return; }
+    const uint32_t start = naux;
     for (int32_t t = P->tl_off[tl]; t < P->tl_off[tl + 1] && !R.err; t++) {
-        const int32_t ci = P->tl_codec[t];
+        if (++R.work > 16ull * R.S->cigar_cap) { R.err = ERR_UNSUPPORTED; return; }
+        const int32_t ci = P->tl_codec[t], tag = P->tl_tag[t];
         if (ci < 0) { R.err = ERR_MALFORMED; return; }
+        uint8_t *out = nullptr; uint32_t cap = 0;
+        if (O.aux) {
+            if (naux + 3u > R.S->aux_cap) { R.err = ERR_UNSUPPORTED; return; }
+            O.aux[naux] = (uint8_t)(tag >> 16); O.aux[naux + 1] = (uint8_t)(tag >> 8); O.aux[naux + 2] = (uint8_t)tag;
+            naux += 3; out = O.aux + naux; cap = R.S->aux_cap - naux;
+        }
         const int32_t k = P->codecs[ci].kind;
-        if (k == E_BYTE_ARRAY_LEN || k == E_BYTE_ARRAY_STOP) (void)R.array(ci, nullptr, 0);
-        else (void)R.value(ci, true);                                     // out_sz = 1: one byte through a scalar codec
+        int32_t n;
+        if (k == E_BYTE_ARRAY_LEN || k == E_BYTE_ARRAY_STOP) n = R.array(ci, out, cap);
+        else { const int32_t b = R.value(ci, true); n = 1; if (out) { if (cap < 1) { R.err = ERR_UNSUPPORTED; return; } out[0] = (uint8_t)b; } }   // out_sz = 1
+        if (R.err) return;
+        if (O.aux) {
+            naux += (uint32_t)n;
+            if (tag == (('c' << 16) | ('F' << 8) | 'C') && n == 1) naux -= 4;     // cF:C only tells the decoder to regenerate MD / NM (cram_decode.c:2107-2118)
+        }
     }
+    if (O.aux) O.aux_len[rec] = (int32_t)(naux - start);
 }
 
 // cram_decode_slice_xref (cram_decode.c:2140-2307)
@@ -403,7 +422,7 @@ HGR_FN int xref(const Cols &O, int32_t nrec) {
 HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
     Reader R; R.P = P; R.S = S; R.bit = 0; R.work = 0; R.err = 0;
     for (int32_t i = 0; i < P->nslots; i++) S->cursor[i] = 0;
-    uint32_t ncig = 0, nname = 0;
+    uint32_t ncig = 0, nname = 0, naux = 0;
     int64_t last_apos = S->ref_seq_start;
     for (int32_t rec = 0; rec < S->nrec && !R.err; rec++) {
         const int32_t bf = R.ival(S_BF);
@@ -447,7 +466,7 @@ HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
         } else if (cf & CF_EXPLICIT_TLEN) {
             O.explicit_tlen[rec] = R.ival(S_TS);
         }
-        skip_aux(R);
+        decode_aux(R, O, rec, naux);
         if (R.err) break;
         // room for the bases / qualities of this record (cram_decode.c:2890-2906), and the reference span it aligns to
         uint8_t *seq = nullptr, *qual = nullptr;
@@ -485,7 +504,7 @@ HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
         if (qual && !R.err && !P->qs_seq_orient && (O.flags[rec] & BAM_FREVERSE))           // qualities stored in read orientation (cram_decode.c:2957-2965)
             for (int32_t i = 0, j = len - 1; i < j; i++, j--) { const uint8_t t = qual[i]; qual[i] = qual[j]; qual[j] = t; }
     }
-    O.totals[0] = ncig; O.totals[1] = nname;
+    O.totals[0] = ncig; O.totals[1] = nname; O.totals[2] = naux;
     if (R.err) return R.err;
     return xref(O, S->nrec) ? ERR_MALFORMED : 0;
 }

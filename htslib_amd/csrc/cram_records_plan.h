@@ -16,11 +16,11 @@ struct PlanHost {
     Plan plan;                                   // pointers are filled in by finish() (host) or by the uploader (device)
     std::vector<Codec> codecs;
     std::vector<HuffCode> huff;
-    std::vector<int32_t> tl_off, tl_codec;
+    std::vector<int32_t> tl_off, tl_codec, tl_tag;
     std::map<int32_t, int32_t> slot_of;          // content id -> slot
     std::vector<int32_t> slot_id;                // slot -> content id
     int unsupported = 0;                         // a codec this build does not decode is present (reported when a slice uses the plan)
-    void finish() { plan.tl_off = tl_off.data(); plan.tl_codec = tl_codec.data(); plan.codecs = codecs.data(); plan.huff = huff.data(); plan.nslots = (int32_t)slot_id.size(); }
+    void finish() { plan.tl_off = tl_off.data(); plan.tl_codec = tl_codec.data(); plan.tl_tag = tl_tag.data(); plan.codecs = codecs.data(); plan.huff = huff.data(); plan.nslots = (int32_t)slot_id.size(); }
 };
 
 struct Cursor {
@@ -178,6 +178,7 @@ inline int plan_from_compression_header(PlanHost &H, const uint8_t *b, size_t n)
             const int32_t key = (line[t] << 16) | (line[t + 1] << 8) | line[t + 2];
             auto it = tag_codec.find(key);
             H.tl_codec.push_back(it == tag_codec.end() ? -1 : it->second);
+            H.tl_tag.push_back(key);
         }
         H.tl_off.push_back((int32_t)H.tl_codec.size());
     }
@@ -206,19 +207,19 @@ struct SliceDev {
     uint32_t core_off, core_len;
     int32_t nrec, ref_seq_id;
     int64_t ref_seq_start;
-    uint64_t rec_off, cig_off, name_off;
-    uint32_t cig_cap, name_cap;
+    uint64_t rec_off, cig_off, name_off, aux_off;
+    uint32_t cig_cap, name_cap, aux_cap, pad;
     uint32_t ref_first, nrefs;            // reference spans of the slice in Batch::refs
 };
 struct Batch {
     std::vector<PlanDev> plans;
-    std::vector<Codec> codecs; std::vector<HuffCode> huff; std::vector<int32_t> tl_off, tl_codec;
+    std::vector<Codec> codecs; std::vector<HuffCode> huff; std::vector<int32_t> tl_off, tl_codec, tl_tag;
     std::vector<SliceDev> slices;
     std::vector<RefSpan> refs;
     std::vector<uint32_t> tab;
     std::vector<uint64_t> src_off;        // where each staged buffer goes in the data image, in the order of src_ptr / src_len
     std::vector<const uint8_t *> src_ptr; std::vector<uint32_t> src_len;
-    uint64_t data_bytes = 0, nrec = 0, cig_total = 0, name_total = 0;
+    uint64_t data_bytes = 0, nrec = 0, cig_total = 0, name_total = 0, aux_total = 0;
     std::vector<int32_t> status;          // per slice: 0 = goes to the decoder, else the status already known
 };
 
@@ -251,7 +252,7 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
                 pd.rn_included = H.plan.rn_included; pd.ap_delta = H.plan.ap_delta; pd.qs_seq_orient = H.plan.qs_seq_orient; pd.nslots = H.plan.nslots; pd.nTL = H.plan.nTL;
                 memcpy(pd.sm, H.plan.sm, 20);
                 pd.tl_off_base = (uint32_t)B.tl_off.size(); pd.tl_codec_base = (uint32_t)B.tl_codec.size(); pd.codec_base = (uint32_t)B.codecs.size(); pd.huff_base = (uint32_t)B.huff.size();
-                B.tl_off.insert(B.tl_off.end(), H.tl_off.begin(), H.tl_off.end()); B.tl_codec.insert(B.tl_codec.end(), H.tl_codec.begin(), H.tl_codec.end());
+                B.tl_off.insert(B.tl_off.end(), H.tl_off.begin(), H.tl_off.end()); B.tl_codec.insert(B.tl_codec.end(), H.tl_codec.begin(), H.tl_codec.end()); B.tl_tag.insert(B.tl_tag.end(), H.tl_tag.begin(), H.tl_tag.end());
                 B.codecs.insert(B.codecs.end(), H.codecs.begin(), H.codecs.end()); B.huff.insert(B.huff.end(), H.huff.begin(), H.huff.end());
                 B.plans.push_back(pd); hosts.push_back(std::move(H));
             }
@@ -285,6 +286,9 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
         d.cig_cap = (uint32_t)std::min<uint64_t>(4ull * (uint64_t)sh.nrec + ext_bytes + 8ull * d.core_len + 16u, 0xffffffffull);
         d.cig_off = B.cig_total; B.cig_total += d.cig_cap;
         d.name_off = B.name_total; B.name_total += d.name_cap;
+        // aux: the values are copied out of blocks, 3 bytes of tag + type are added per value; values that cost no bits bounded as above
+        d.aux_cap = (uint32_t)std::min<uint64_t>(4ull * (ext_bytes + d.core_len) + 64ull * (uint64_t)sh.nrec + 64u, 0xffffffffull);
+        d.aux_off = B.aux_total; B.aux_total += d.aux_cap;
         B.slices.push_back(d);
     }
     if (B.data_bytes > 0xfffffff0ull) return -4;                       // 32-bit offsets into the data image

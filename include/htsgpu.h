@@ -377,8 +377,8 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
  *      GOLOMB / GOLOMB_RICE reports HG_BLOCK_EUNSUPPORTED.  Output per record: the cram_record fields that do not need the reference
  *      sequence, after cram_decode_slice_xref -- flags (with the mate bits), cram_flags, ref_id, len, apos, aend, rg, mqual, the
  *      CIGAR (BAM encoding, cram_decode_seq's feature walk), the read name, mate_ref_id, mate_pos, tlen, and -- given the reference
- *      spans -- the bases and qualities (cram_decode_seq's reconstruction, without MD / NM generation).  Aux values are consumed but
- *      not produced yet.  Pinned on the reference's 34 CRAM fixtures against their SAM / BAM twins
+ *      spans -- the bases and qualities (cram_decode_seq's reconstruction, without MD / NM generation), and the aux tags as stored
+ *      (cram_decode_aux).  Pinned on the reference's 34 CRAM fixtures against their SAM / BAM twins
  *      (tests/test_cram_records.py).  One wavefront per slice (cram_records.hip). ---- */
 typedef struct hg_cram_slice_blocks {
     const uint8_t *comp_hdr; uint32_t comp_hdr_len;     /* compression header block of the slice's container (slices of one container may share the pointer) */
@@ -400,16 +400,18 @@ typedef struct hg_cram_record_cols {                    /* arrays of rec_cap ent
     uint64_t *seq_off; uint8_t *seq, *qual;             /* bases (ASCII, '=' where no reference span was given) and qualities (255 = absent):
                                                            len[r] bytes each at seq_off[r]; all three NULL = not wanted.  seq_cap >= the number
                                                            of bases of the slices (the containers' `bases` header field). */
+    uint64_t *aux_off; int32_t *aux_len; uint8_t *aux;  /* the record's tags in BAM encoding (tag[2] type value ...), aux_len[r] bytes at
+                                                           aux_off[r]; all three NULL = not wanted.  As stored: RG / MD / NM are not added. */
 } hg_cram_record_cols;
-/* Sizes the caller must provide for these slices: records (exact), CIGAR words and name bytes (upper bounds; slices get disjoint
- * regions).  Host only. */
+/* Sizes the caller must provide for these slices: records (exact), CIGAR words, name bytes and aux bytes (upper bounds; slices get
+ * disjoint regions).  Host only. */
 int hg_cram_records_bound(size_t nslices, const hg_cram_slice_blocks *slices, int major_version, uint64_t *nrec, uint64_t *cigar_cap,
-                          uint64_t *name_cap);
+                          uint64_t *name_cap, uint64_t *aux_cap);
 /* nref = number of @SQ lines (bounds of RI / NS).  rec_off[i] .. rec_off[i+1] = the records of slice i (nslices + 1 entries).
  * status[i] = 0, -1 (malformed slice, as cram_decode_slice returning -1) or HG_BLOCK_EUNSUPPORTED.  Returns HG_OK / HG_EBLOCK. */
 int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref,
-                                size_t rec_cap, size_t cigar_cap, size_t name_cap, size_t seq_cap, const hg_cram_record_cols *out,
-                                uint64_t *rec_off, int32_t *status);
+                                size_t rec_cap, size_t cigar_cap, size_t name_cap, size_t seq_cap, size_t aux_cap,
+                                const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status);
 
 /* ---- BAM record framing on the device: the framing half of bam_read1 (sam.c:784-866) and
  *      nibble2base (simd.c:119-161) for consumers that keep the inflated stream in HBM. ---- */

@@ -4,7 +4,7 @@
 For every CRAM file of the reference's test directory that has a SAM / BAM twin (test/*.cram, test/tlen/*.cram), each slice
 is stored with its DECODED blocks (compression header, slice header, CORE, EXTERNAL blocks by content id -- RAW / gzip / rANS 4x8
 payloads are expanded here with zlib and the pinned rANS oracle) and the expected per-record fields taken from the twin WITHOUT
-any CRAM code: QNAME, FLAG, reference id, POS, MAPQ, CIGAR, mate reference id, PNEXT, TLEN, SEQ, QUAL -- plus the stretch of each
+any CRAM code: QNAME, FLAG, reference id, POS, MAPQ, CIGAR, mate reference id, PNEXT, TLEN, SEQ, QUAL, the optional tags as SAM text -- plus the stretch of each
 reference the slice's records align to (from the reference's .fa files), which the decoder needs to rebuild the bases.  The tlen/ pairs were written by the
 reference's authors to pin the template-length and mate logic of cram_decode_slice_xref (test/tlen/README).
 
@@ -35,6 +35,31 @@ def expand(blk, rans):
     raise ValueError("block method %d" % method)
 
 
+def aux_to_text(b):
+    """BAM aux bytes -> SAM text tags (integers of every width print as type i, as samtools view does)"""
+    out, p = [], 0
+    size = {"c": ("<b", 1), "C": ("<B", 1), "s": ("<h", 2), "S": ("<H", 2), "i": ("<i", 4), "I": ("<I", 4), "f": ("<f", 4)}
+    while p < len(b):
+        tag, ty = b[p:p + 2].decode("latin1"), chr(b[p + 2]); p += 3
+        if ty == "A": out.append("%s:A:%s" % (tag, chr(b[p]))); p += 1
+        elif ty in "cCsSiI": fmt, n = size[ty]; out.append("%s:i:%d" % (tag, struct.unpack_from(fmt, b, p)[0])); p += n
+        elif ty == "f": out.append("%s:f:%g" % (tag, struct.unpack_from("<f", b, p)[0])); p += 4
+        elif ty in "ZH": e = b.index(b"\0", p); out.append("%s:%s:%s" % (tag, ty, b[p:e].decode("latin1"))); p = e + 1
+        elif ty == "B":
+            sub = chr(b[p]); cnt = struct.unpack_from("<i", b, p + 1)[0]; p += 5
+            fmt, n = size[sub]
+            vals = [struct.unpack_from(fmt, b, p + k * n)[0] for k in range(cnt)]; p += cnt * n
+            out.append("%s:B:%s%s" % (tag, sub, "".join(",%g" % v if sub == "f" else ",%d" % v for v in vals)))
+        else: raise ValueError(ty)
+    return out
+
+
+def short_tag(t):
+    """long values (the 900 kB ZZ:Z of xx#large_aux) are compared through a digest"""
+    import hashlib
+    return t if len(t) <= 512 else "%s<sha1=%s,len=%d>" % (t[:5], hashlib.sha1(t.encode("latin1")).hexdigest(), len(t))
+
+
 def sam_text(path):
     """-> (reference names, [(qname, flag, rname, pos, mapq, cigar, rnext, pnext, tlen)])"""
     if path.endswith(".bam"):
@@ -56,7 +81,7 @@ def sam_text(path):
             seq = "".join("=ACMGRSVTWYHKDBN"[(packed[i >> 1] >> (4 if i % 2 == 0 else 0)) & 15] for i in range(lseq)) or "*"
             ql = d[a + (lseq + 1) // 2:a + (lseq + 1) // 2 + lseq]
             qual = "*" if lseq == 0 or ql[0] == 0xFF else bytes(c + 33 for c in ql).decode("latin1")
-            recs.append((name, flag, tid, pos + 1, mapq, [(c >> 4, c & 15) for c in cig], mtid, mpos + 1, tlen, seq, qual))
+            recs.append((name, flag, tid, pos + 1, mapq, [(c >> 4, c & 15) for c in cig], mtid, mpos + 1, tlen, seq, qual, [short_tag(t) for t in aux_to_text(d[a + (lseq + 1) // 2 + lseq:p])]))
         return refs, recs
     refs, recs = [], []
     for ln in open(path):
@@ -68,7 +93,7 @@ def sam_text(path):
         cig = [] if f[5] == "*" else [(int(n), "MIDNSHP=X".index(o)) for n, o in re.findall(r"(\d+)([MIDNSHP=X])", f[5])]
         tid = -1 if f[2] == "*" else refs.index(f[2])
         mtid = -1 if f[6] == "*" else tid if f[6] == "=" else refs.index(f[6])
-        recs.append((f[0], int(f[1]), tid, int(f[3]), int(f[4]), cig, mtid, int(f[7]), int(f[8]), f[9], f[10]))
+        recs.append((f[0], int(f[1]), tid, int(f[3]), int(f[4]), cig, mtid, int(f[7]), int(f[8]), f[9], f[10], [short_tag(t) for t in f[11:]]))
     return refs, recs
 
 

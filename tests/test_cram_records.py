@@ -1,8 +1,8 @@
 """CRAM record decoding (the record loop of cram_decode_slice, cram/cram_decode.c:2346-3026, with cram_decode_seq's
 feature walk and cram_decode_slice_xref) -- PINNED on the reference's own fixtures: every slice of the 34 CRAM v3.0 files that have a
 SAM / BAM twin (tests/golden/cram_records.json, frozen by make_golden_cram_records.py with NO CRAM decoding code involved on the
-expectation side) must decode to the twin's QNAME, FLAG, RNAME, POS, MAPQ, CIGAR, RNEXT, PNEXT, TLEN, SEQ and QUAL (the bases are rebuilt
-from the reference's .fa files plus the stored edits, cram_decode_seq).  The 31 test/tlen pairs were
+expectation side) must decode to the twin's QNAME, FLAG, RNAME, POS, MAPQ, CIGAR, RNEXT, PNEXT, TLEN, SEQ, QUAL (the bases are rebuilt
+from the reference's .fa files plus the stored edits, cram_decode_seq) and optional tags (cram_decode_aux).  The 31 test/tlen pairs were
 written by the reference's authors to pin the mate / template-length logic.
 CPU part: the decoder source (htslib_amd/csrc/cram_records_core.h) compiled for the host by tests/native/cram_records_host.cpp.
 GPU part: the same fixtures through hg_cram_decode_records_host (one wavefront per slice), plus a replicated batch."""
@@ -10,6 +10,8 @@ import base64, ctypes as C, json, os, subprocess, zlib
 
 import numpy as np
 import pytest
+
+from tests.golden import make_golden_cram_records as G
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden", "cram_records.json")
@@ -27,7 +29,7 @@ class RefIn(C.Structure):                   # = hg_cram_ref_span
 
 class Cols(C.Structure):                    # = hg_cram_record_cols
     _fields_ = [(k, _vp) for k in ("flags", "cram_flags", "ref_id", "len", "rg", "mqual", "mate_ref_id", "ncigar", "name_len", "apos", "aend", "mate_pos", "tlen",
-                                   "cigar_off", "name_off", "cigar", "names", "seq_off", "seq", "qual")]
+                                   "cigar_off", "name_off", "cigar", "names", "seq_off", "seq", "qual", "aux_off", "aux_len", "aux")]
 
 
 def unpack(s):
@@ -61,8 +63,8 @@ def decode(call_bound, call_decode, slices, major, nref, with_seq=True):
         keep.append((ch, sh, co, bl, ids, lens, ptrs, rb, ra))
         arr[i] = SliceIn(C.addressof(ch), len(s["comp_hdr"]), C.addressof(sh), len(s["slice_hdr"]), C.addressof(co), len(s["core"]), len(bl), ids.ctypes.data,
                          C.addressof(ptrs), lens.ctypes.data, len(rb) if with_seq else 0, C.addressof(ra))
-    nrec, ccap, ncap = C.c_uint64(), C.c_uint64(), C.c_uint64()
-    assert call_bound(n, arr, major, C.byref(nrec), C.byref(ccap), C.byref(ncap)) == 0
+    nrec, ccap, ncap, acap = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    assert call_bound(n, arr, major, C.byref(nrec), C.byref(ccap), C.byref(ncap), C.byref(acap)) == 0
     R = max(nrec.value, 1)
     i32 = {k: np.full(R, -99, np.int32) for k in ("flags", "cram_flags", "ref_id", "len", "rg", "mqual", "mate_ref_id", "ncigar", "name_len")}
     i64 = {k: np.full(R, -99, np.int64) for k in ("apos", "aend", "mate_pos", "tlen")}
@@ -70,10 +72,12 @@ def decode(call_bound, call_decode, slices, major, nref, with_seq=True):
     cigar = np.zeros(max(ccap.value, 1), np.uint32); names = np.zeros(max(ncap.value, 1), np.uint8)
     seq_cap = sum(len(e[9]) if len(e) > 9 and e[9] != "*" else 0 for s in slices for e in s["expect"]) + 4096     # the containers' base count would do
     seq_off = np.zeros(R, np.uint64); seq = np.zeros(seq_cap, np.uint8); qual = np.zeros(seq_cap, np.uint8)
+    aux_off = np.zeros(R, np.uint64); aux_len = np.zeros(R, np.int32); aux = np.zeros(max(acap.value, 1), np.uint8)
     cols = Cols(*[a.ctypes.data for a in list(i32.values()) + list(i64.values()) + list(u64.values()) + [cigar, names]],
-                *([seq_off.ctypes.data, seq.ctypes.data, qual.ctypes.data] if with_seq else [None, None, None]))
+                *([seq_off.ctypes.data, seq.ctypes.data, qual.ctypes.data] if with_seq else [None, None, None]),
+                *([aux_off.ctypes.data, aux_len.ctypes.data, aux.ctypes.data] if with_seq else [None, None, None]))
     rec_off = np.zeros(n + 1, np.uint64); status = np.full(n, 77, np.int32)
-    rc = call_decode(n, arr, major, nref, R, len(cigar), len(names), seq_cap, C.byref(cols), rec_off.ctypes.data, status.ctypes.data)
+    rc = call_decode(n, arr, major, nref, R, len(cigar), len(names), seq_cap, len(aux), C.byref(cols), rec_off.ctypes.data, status.ctypes.data)
     assert rc in (0, -6), rc                      # HG_EBLOCK: some slice has a non-zero status
     out = []
     for i in range(n):
@@ -88,7 +92,8 @@ def decode(call_bound, call_decode, slices, major, nref, with_seq=True):
                 so, ln = int(seq_off[r]), int(i32["len"][r])
                 q = qual[so:so + ln]
                 recs[-1] += [bytes(seq[so:so + ln]).decode("latin1") if ln else "*",
-                             "*" if ln == 0 or (q == 255).all() else bytes((q + 33).astype(np.uint8)).decode("latin1")]
+                             "*" if ln == 0 or (q == 255).all() else bytes((q + 33).astype(np.uint8)).decode("latin1"),
+                             [G.short_tag(t) for t in G.aux_to_text(bytes(aux[int(aux_off[r]):int(aux_off[r]) + int(aux_len[r])]))]]
         out.append(recs)
     return status, out
 
@@ -99,7 +104,25 @@ def check_against_twin(fname, got, expect):
         g, e = list(g), list(e)
         if e[1] & 4:                         # unmapped: CRAM does not store a mapping quality or a CIGAR for these
             e[4] = 0; e[5] = []
-        if len(g) == 9: e = e[:9]            # decoded without bases / qualities
+        if len(g) == 9: e = e[:9]            # decoded without bases / qualities / tags
+        else:
+            # tags: what the CRAM stores must be in the twin with the same value; the writer may drop RG (kept as the RG series), MD and NM
+            # (regenerated from the reference on request), so those three may be missing on our side
+            stored, twin = list(g[11]), e[11]
+            twin = [t[:5] + t[5:].upper() if t[2:5] == ":H:" else t for t in twin]
+            hexed = {t[:2]: t for t in twin if t[2:5] == ":H:"}          # htsjdk stores an H (hex string) tag as a B:c array of its bytes
+            for k, t in enumerate(stored):
+                if t[2:6] == ":B:c" and t[:2] in hexed:
+                    vals = [int(v) & 0xFF for v in t[7:].split(",")] if len(t) > 6 else []
+                    stored[k] = "%s:H:%s" % (t[:2], "".join("%02X" % v for v in vals))
+            def canon(t):                                                 # htsjdk has no unsigned types: B:C / B:S / B:I arrays come back as c / s / i with the same bytes
+                if t[2:5] != ":B:" or t[5] == "f": return t
+                w = {"c": 8, "s": 16, "i": 32}[t[5].lower()]
+                return "%s:B:%d%s" % (t[:2], w, "".join(",%d" % (int(v) & ((1 << w) - 1)) for v in t[7:].split(",") if v))
+            stored, twin = [canon(t) for t in stored], [canon(t) for t in twin]
+            assert all(t in twin for t in stored), (fname, g[0], [t for t in stored if t not in twin])
+            assert all(t in stored or t[:2] in ("RG", "MD", "NM") for t in twin), (fname, g[0], [t for t in twin if t not in stored])
+            g, e = g[:11], e[:11]
         assert g == e, (fname, g, e)
 
 
@@ -108,8 +131,8 @@ def hostlib(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("cramrec") / "libcram_records_host.so")
     subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", so, os.path.join(ROOT, "tests", "native", "cram_records_host.cpp")], check=True)
     L = C.CDLL(so)
-    L.hgr_host_records_bound.argtypes = [C.c_size_t, _vp, C.c_int, _vp, _vp, _vp]
-    L.hgr_host_decode_records.argtypes = [C.c_size_t, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp]
+    L.hgr_host_records_bound.argtypes = [C.c_size_t, _vp, C.c_int, _vp, _vp, _vp, _vp]
+    L.hgr_host_decode_records.argtypes = [C.c_size_t, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp]
     return L
 
 
@@ -129,9 +152,9 @@ def test_decoder_source_on_the_cpu_matches_the_sam_twins(hostlib):
 
 def _gpu_calls(engine):
     from htslib_amd import _native as nat
-    bound = lambda n, arr, major, a, b, c: nat.lib.hg_cram_records_bound(n, C.cast(arr, _vp), major, C.cast(a, _vp), C.cast(b, _vp), C.cast(c, _vp))
-    dec = lambda n, arr, major, nref, R, cc, nc, sc, cols, ro, st: nat.lib.hg_cram_decode_records_host(engine._h, n, C.cast(arr, _vp), major, nref, R, cc, nc, sc,
-                                                                                                      C.cast(cols, _vp), ro, st)
+    bound = lambda n, arr, major, a, b, c, d: nat.lib.hg_cram_records_bound(n, C.cast(arr, _vp), major, C.cast(a, _vp), C.cast(b, _vp), C.cast(c, _vp), C.cast(d, _vp))
+    dec = lambda n, arr, major, nref, R, cc, nc, sc, ac, cols, ro, st: nat.lib.hg_cram_decode_records_host(engine._h, n, C.cast(arr, _vp), major, nref, R, cc, nc, sc, ac,
+                                                                                                          C.cast(cols, _vp), ro, st)
     return bound, dec
 
 
