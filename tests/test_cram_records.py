@@ -82,6 +82,8 @@ def decode(call_bound, call_decode, slices, major, nref, with_seq=True):
     out = []
     for i in range(n):
         recs = []
+        if status[i] != 0:                   # a failed slice leaves its columns undefined
+            out.append(recs); continue
         for r in range(int(rec_off[i]), int(rec_off[i + 1])):
             co, nc = int(u64["cigar_off"][r]), int(i32["ncigar"][r])
             cg = [[int(c >> 4), int(c & 15)] for c in cigar[co:co + nc]]
