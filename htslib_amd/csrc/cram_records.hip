@@ -174,3 +174,33 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     for (size_t i = 0; i < nslices; i++) if (status[i] != 0) return HG_EBLOCK;
     return HG_OK;
 }
+
+// The .crai lines of one slice (cram_index_slice / cram_index_build_multiref, reference cram/cram_index.c:632-728): a single-reference
+// slice is indexed from its header; a multi-reference slice (ref_seq_id == -2) gets one line per run of records on the same reference,
+// with the run's first position and the span up to its furthest alignment end -- the ref_id / apos / aend columns of
+// hg_cram_decode_records_host.  Host code: a few comparisons per record on columns that are already in host memory.
+extern "C" long hg_cram_crai_slice(const uint8_t *slice_hdr, uint32_t slice_hdr_len, int major_version, const int32_t *ref_id, const int64_t *apos,
+                                   const int64_t *aend, int64_t container_pos, int32_t landmark, int32_t slice_bytes, char *out, size_t cap) {
+    if (!slice_hdr || !out) return HG_EINVAL;
+    hgr::SliceHeader sh;
+    if (hgr::parse_slice_header(slice_hdr, slice_hdr_len, major_version, sh)) return HG_EINVAL;
+    size_t n = 0;
+    auto line = [&](int32_t ref, int64_t start, int64_t span) {
+        const int k = snprintf(out + n, cap - n, "%d\t%lld\t%lld\t%lld\t%d\t%d\n", ref, (long long)start, (long long)span, (long long)container_pos, landmark, slice_bytes);
+        if (k < 0 || (size_t)k >= cap - n) return false;
+        n += (size_t)k;
+        return true;
+    };
+    if (sh.ref_seq_id != -2) return line(sh.ref_seq_id, sh.ref_seq_start, sh.ref_seq_span) ? (long)n : (long)HG_ENOMEM;
+    if (sh.nrec && (!ref_id || !apos || !aend)) return HG_EINVAL;
+    int32_t ref = -2, last_ref = -9; int64_t ref_start = 0, ref_end = INT32_MIN, last_pos = -9;
+    for (int32_t i = 0; i < sh.nrec; i++) {
+        if (ref_id[i] == last_ref && apos[i] < last_pos) return -2;      // "CRAM file is not sorted by chromosome / position"
+        last_ref = ref_id[i]; last_pos = apos[i];
+        if (ref_id[i] == ref) { if (ref_end < aend[i]) ref_end = aend[i]; continue; }
+        if (ref != -2 && !line(ref, ref_start, ref_end - ref_start + 1)) return HG_ENOMEM;
+        ref = ref_id[i]; ref_start = apos[i]; ref_end = aend[i];
+    }
+    if (ref != -2 && !line(ref, ref_start, ref_end - ref_start + 1)) return HG_ENOMEM;
+    return (long)n;
+}

@@ -413,6 +413,13 @@ int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice
                                 size_t rec_cap, size_t cigar_cap, size_t name_cap, size_t seq_cap, size_t aux_cap,
                                 const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status);
 
+/* The .crai text of one slice (cram_index_slice / cram_index_build_multiref, cram/cram_index.c:632-728): "ref start span container_pos
+ * landmark slice_bytes" -- one line from the slice header, or, for a multi-reference slice, one line per run of records on the same
+ * reference from the ref_id / apos / aend columns of hg_cram_decode_records_host (the arrays of THIS slice).  Returns the number of
+ * bytes written (no terminator), -2 if the records are not sorted (as the reference), or a negative HG_E* code.  Host only. */
+long hg_cram_crai_slice(const uint8_t *slice_hdr, uint32_t slice_hdr_len, int major_version, const int32_t *ref_id, const int64_t *apos,
+                        const int64_t *aend, int64_t container_pos, int32_t landmark, int32_t slice_bytes, char *out, size_t cap);
+
 /* ---- BAM record framing on the device: the framing half of bam_read1 (sam.c:784-866) and
  *      nibble2base (simd.c:119-161) for consumers that keep the inflated stream in HBM. ---- */
 #define HG_BAM_ETRUNC   (-2)   /* the stream ends inside a record (bam_read1 returns -2 / -3) */

@@ -133,10 +133,22 @@ def main():
         b = open(path, "rb").read()
         assert b[:4] == b"CRAM" and b[4] == 3
         slices, at = [], 0
+        cpos_list, q = [], 26                                          # container offsets and landmarks, for the .crai columns
+        while q < len(b):
+            q0 = q; clen = struct.unpack_from("<i", b, q)[0]; q += 4
+            for _ in range(4): _, q = R.itf8(b, q)
+            _, q = R.ltf8(b, q); _, q = R.ltf8(b, q)
+            _, q = R.itf8(b, q); nland, q = R.itf8(b, q)
+            lm = []
+            for _ in range(nland): v, q = R.itf8(b, q); lm.append(v)
+            q += 4
+            cpos_list.append((q0, lm, clen)); q += clen
+        ci = -1
         for nrec, blks in R.containers(b):
+            ci += 1
             if not blks or blks[0][1] != 1: continue                 # the file-header container, EOF container
             comp = expand(blks[0], rans)
-            k = 1
+            k = 1; sidx = 0
             while k < len(blks):
                 assert blks[k][1] == 2, "slice header expected"
                 sh = expand(blks[k], rans)
@@ -149,12 +161,15 @@ def main():
                 assert len(core) == 1 and len(core) + len(ext) == nb
                 slices.append({"comp_hdr": pack(comp), "slice_hdr": pack(sh), "core": pack(expand(core[0], rans)),
                                "blocks": [[x[2], pack(expand(x, rans))] for x in ext], "nrec": n,
+                               "cpos": cpos_list[ci][0], "landmark": cpos_list[ci][1][sidx],
+                               "slice_bytes": sum(len(x.hdr) + x[3] + 4 for x in blks[k:k + 1 + nb]),
                                "refs": [[t, a, pack(sq.encode()), ln] for t, a, sq, ln in ref_spans(recs[at:at + n], refs, bases)],
                                "expect": [list(r) for r in recs[at:at + n]]})
                 at += n
-                k += 1 + nb
+                k += 1 + nb; sidx += 1
         assert at == len(recs), (base, at, len(recs))
-        out.append({"file": "test/" + os.path.relpath(path, REF), "twin": "test/" + os.path.relpath(twin, REF), "major": 3, "nref": len(refs), "slices": slices})
+        crai = gzip.open(path + ".crai", "rt").read() if os.path.exists(path + ".crai") else None
+        out.append({"crai": crai, "file": "test/" + os.path.relpath(path, REF), "twin": "test/" + os.path.relpath(twin, REF), "major": 3, "nref": len(refs), "slices": slices})
     json.dump(out, open(os.path.join(HERE, "cram_records.json"), "w"), separators=(",", ":"))
     print(len(out), "files,", sum(len(f["slices"]) for f in out), "slices,", sum(s["nrec"] for f in out for s in f["slices"]), "records,",
           os.path.getsize(os.path.join(HERE, "cram_records.json")), "bytes")

@@ -97,6 +97,7 @@ def decode(call_bound, call_decode, slices, major, nref, with_seq=True):
                              "*" if ln == 0 or (q == 255).all() else bytes((q + 33).astype(np.uint8)).decode("latin1"),
                              [G.short_tag(t) for t in G.aux_to_text(bytes(aux[int(aux_off[r]):int(aux_off[r]) + int(aux_len[r])]))]]
         out.append(recs)
+    decode.last_aend = [[int(i64["aend"][r]) for r in range(int(rec_off[i]), int(rec_off[i + 1]))] for i in range(n)]    # for the index test
     return status, out
 
 
@@ -205,3 +206,32 @@ def test_gpu_decoder_batch_of_slices_and_error_statuses(engine, hostlib):
     assert (st_g == st_c).all() and (st_g != 0).any()
     for k in range(len(bad)):
         if st_g[k] == 0: assert got_g[k] == got_c[k], k
+
+
+def crai_of(slices_meta, decoded, major):
+    """.crai text of a file from its slices' headers and the decoded ref_id / apos / aend (hg_cram_crai_slice = cram_index_slice)"""
+    from htslib_amd import _native as nat
+    text = b""
+    for meta, recs, ends in zip(slices_meta, decoded, decode.last_aend):
+        rid = np.array([r[2] for r in recs], np.int32); ap = np.array([r[3] for r in recs], np.int64)
+        ae = np.array(ends, np.int64)                                  # the decoder's alignment ends (cram_record.aend)
+        buf = C.create_string_buffer(4096)
+        sh = meta["slice_hdr"]
+        n = nat.lib.hg_cram_crai_slice(C.cast(C.c_char_p(sh), _vp), len(sh), major, rid.ctypes.data, ap.ctypes.data, ae.ctypes.data, meta["cpos"], meta["landmark"],
+                                       meta["slice_bytes"], buf, 4096)
+        assert n > 0, n
+        text += buf.raw[:n]
+    return text.decode()
+
+
+def test_crai_of_a_multi_reference_file_matches_the_reference_index(hostlib, built):
+    """test/range.cram.crai was written by the reference: three multi-reference slices, six index lines whose starts and spans come from
+    the decoded alignment positions and ends (cram_index_build_multiref, cram_index.c:632-690)."""
+    gold = [f for f in json.load(open(GOLD)) if f["crai"]]
+    assert len(gold) == 1 and gold[0]["file"] == "test/range.cram"
+    f = gold[0]
+    slices = [s for fname, major, nref, s in load_slices() if fname == f["file"]]
+    st, got = decode(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, f["major"], f["nref"])
+    assert (st == 0).all()
+    meta = [{"slice_hdr": unpack(s["slice_hdr"]), "cpos": s["cpos"], "landmark": s["landmark"], "slice_bytes": s["slice_bytes"]} for s in f["slices"]]
+    assert crai_of(meta, got, f["major"]) == f["crai"]
