@@ -1,10 +1,11 @@
 // cram_records_core.h -- the record loop of cram_decode_slice (reference cram/cram_decode.c:2346-3026) for CRAM 2.x / 3.x slices,
-// reduced to what does not need the reference sequence: every data series is CONSUMED exactly as the reference consumes it (so
-// that series sharing an EXTERNAL block or the CORE bit stream stay in step), and the per-record results that are functions of the
-// series alone are produced -- flags, reference id, position, read length, read group, mapping quality, read name, mate fields,
-// CIGAR (cram_decode_seq's feature walk, cram_decode.c:1096-1900, without the base reconstruction), alignment end, and, after the
-// mate cross-referencing pass (cram_decode_slice_xref, cram_decode.c:2140-2307), mate position / reference, template length and
-// the mate bits of the flags.  Bases, qualities and aux values are skipped over, not produced (next step of SURVEY 8f N2).
+// every data series is CONSUMED exactly as the reference consumes it (so that series sharing an EXTERNAL block or the CORE bit stream
+// stay in step), and the cram_record fields are produced -- flags, reference id, position, read length, read group, mapping quality,
+// read name, mate fields, CIGAR and alignment end (cram_decode_seq's feature walk, cram_decode.c:1096-1900), the bases (reference span
+// + edits through the substitution matrix) and qualities when the caller supplies the reference spans, the aux tags as stored
+// (cram_decode_aux, :2008-2137), and, after the mate cross-referencing pass (cram_decode_slice_xref, :2140-2307), mate position /
+// reference, template length and the mate bits of the flags.  Not done: MD / NM regeneration (decode_md), RG:Z insertion and the
+// BAM packing of cram_to_bam.
 //
 // Codecs (cram/cram_codecs.c): EXTERNAL (:350-410; ITF8 for integer series, bytes for byte series), HUFFMAN (canonical codes,
 // :2641-2930), BETA (:1072-1130), GAMMA (:2546-2568), SUBEXP (:2452-2494), BYTE_ARRAY_LEN (:2937-3010), BYTE_ARRAY_STOP (:3180-3260).
