@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 #include <vector>
 #include "htsgpu.h"
 #include "hg_device.h"
@@ -41,38 +42,56 @@ struct DevCols {
     int32_t *mate_flags, *mate_line; int64_t *explicit_tlen; uint32_t *coff, *noff, *aoff;   // scratch columns
 };
 
+// Runs the record loop of slice k (one thread).
+__device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, const SliceDev &d, int32_t nref) {
+    const PlanDev &pd = T.plans[d.plan];
+    Plan P;
+    for (int i = 0; i < S_N; i++) P.codec_of[i] = pd.codec_of[i];
+    for (int i = 0; i < 20; i++) (&P.sm[0][0])[i] = (&pd.sm[0][0])[i];
+    P.rn_included = pd.rn_included; P.ap_delta = pd.ap_delta; P.qs_seq_orient = pd.qs_seq_orient; P.nslots = pd.nslots; P.nTL = pd.nTL;
+    P.tl_off = T.tl_off + pd.tl_off_base; P.tl_codec = T.tl_codec + pd.tl_codec_base; P.tl_tag = T.tl_tag + pd.tl_codec_base; P.codecs = T.codecs + pd.codec_base; P.huff = T.huff + pd.huff_base;
+    Slice S;
+    S.data = T.data; S.blk_off = T.tab + d.tab_off; S.blk_len = S.blk_off + pd.nslots; S.cursor = T.tab + d.tab_off + 2 * pd.nslots;
+    S.core_off = d.core_off; S.core_len = d.core_len; S.nrec = d.nrec; S.ref_seq_id = d.ref_seq_id; S.ref_seq_start = d.ref_seq_start; S.nref = nref;
+    S.cigar_cap = d.cig_cap; S.name_cap = d.name_cap; S.aux_cap = d.aux_cap; S.refs = T.refs + d.ref_first; S.nrefs = (int32_t)d.nrefs;
+    uint32_t totals[3];
+    const uint64_t r0 = d.rec_off;
+    Cols O{D.flags + r0, D.cram_flags + r0, D.ref_id + r0, D.len + r0, D.rg + r0, D.mqual + r0, D.mate_flags + r0, D.mate_ref_id + r0, D.mate_line + r0,
+           D.ncigar + r0, D.name_len + r0, D.coff + r0, D.noff + r0, D.apos + r0, D.aend + r0, D.mate_pos + r0, D.tlen + r0, D.explicit_tlen + r0,
+           D.cigar + d.cig_off, D.names + d.name_off, totals, D.aux ? D.aux + d.aux_off : nullptr, D.aoff + r0, D.aux ? D.aux_len + r0 : nullptr, D.seq, D.qual,
+           D.seq ? D.seq_off + r0 : nullptr, D.seq_pool, D.seq_cap};
+    return decode_slice(&P, &S, O);
+}
+__device__ __forceinline__ void rebase(const DevCols &D, const SliceDev &d, int32_t first, int32_t step) {
+    for (int32_t r = first; r < d.nrec; r += step) {
+        D.cigar_off[d.rec_off + (uint64_t)r] = d.cig_off + D.coff[d.rec_off + (uint64_t)r];
+        D.name_off[d.rec_off + (uint64_t)r] = d.name_off + D.noff[d.rec_off + (uint64_t)r];
+        if (D.aux) D.aux_off[d.rec_off + (uint64_t)r] = d.aux_off + D.aoff[d.rec_off + (uint64_t)r];
+    }
+}
+
+// Two mappings of slices to the machine.  WAVE: one wavefront per slice, lane 0 walks the chain and the 64 lanes rebase the offsets --
+// the right shape for a handful of large slices.  LANE: one slice per lane, 64 unlike chains per wavefront; the lanes diverge at every
+// codec switch, yet all SIMD slots do useful work part of the time -- the right shape for batches of thousands of slices
+// (the launcher picks by the slice count; HG_CRAM_RECORDS_MODE = wave | lane overrides, profiles/r02_cram_records_probe.txt).
 __global__ __launch_bounds__(64)
 void cram_records_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref, const int32_t *pre_status, int32_t *status) {
     const int lane = threadIdx.x & 63;
     for (uint32_t k = blockIdx.x; k < nslices; k += gridDim.x) {
         if (pre_status[k] != 0) { if (lane == 0) status[k] = pre_status[k]; continue; }
         const SliceDev d = T.slices[k];
-        int rc = 0;
-        if (lane == 0) {
-            const PlanDev &pd = T.plans[d.plan];
-            Plan P;
-            for (int i = 0; i < S_N; i++) P.codec_of[i] = pd.codec_of[i];
-            for (int i = 0; i < 20; i++) (&P.sm[0][0])[i] = (&pd.sm[0][0])[i];
-            P.rn_included = pd.rn_included; P.ap_delta = pd.ap_delta; P.qs_seq_orient = pd.qs_seq_orient; P.nslots = pd.nslots; P.nTL = pd.nTL;
-            P.tl_off = T.tl_off + pd.tl_off_base; P.tl_codec = T.tl_codec + pd.tl_codec_base; P.tl_tag = T.tl_tag + pd.tl_codec_base; P.codecs = T.codecs + pd.codec_base; P.huff = T.huff + pd.huff_base;
-            Slice S;
-            S.data = T.data; S.blk_off = T.tab + d.tab_off; S.blk_len = S.blk_off + pd.nslots; S.cursor = T.tab + d.tab_off + 2 * pd.nslots;
-            S.core_off = d.core_off; S.core_len = d.core_len; S.nrec = d.nrec; S.ref_seq_id = d.ref_seq_id; S.ref_seq_start = d.ref_seq_start; S.nref = nref;
-            S.cigar_cap = d.cig_cap; S.name_cap = d.name_cap; S.aux_cap = d.aux_cap; S.refs = T.refs + d.ref_first; S.nrefs = (int32_t)d.nrefs;
-            uint32_t totals[3];
-            const uint64_t r0 = d.rec_off;
-            Cols O{D.flags + r0, D.cram_flags + r0, D.ref_id + r0, D.len + r0, D.rg + r0, D.mqual + r0, D.mate_flags + r0, D.mate_ref_id + r0, D.mate_line + r0,
-                   D.ncigar + r0, D.name_len + r0, D.coff + r0, D.noff + r0, D.apos + r0, D.aend + r0, D.mate_pos + r0, D.tlen + r0, D.explicit_tlen + r0,
-                   D.cigar + d.cig_off, D.names + d.name_off, totals, D.aux ? D.aux + d.aux_off : nullptr, D.aoff + r0, D.aux ? D.aux_len + r0 : nullptr, D.seq, D.qual, D.seq ? D.seq_off + r0 : nullptr, D.seq_pool, D.seq_cap};
-            rc = decode_slice(&P, &S, O);
-            status[k] = rc;
-        }
+        if (lane == 0) status[k] = decode_one(T, D, d, nref);
         hg::wave_sync();
-        for (int32_t r = lane; r < d.nrec; r += 64) {
-            D.cigar_off[d.rec_off + (uint64_t)r] = d.cig_off + D.coff[d.rec_off + (uint64_t)r];
-            D.name_off[d.rec_off + (uint64_t)r] = d.name_off + D.noff[d.rec_off + (uint64_t)r];
-            if (D.aux) D.aux_off[d.rec_off + (uint64_t)r] = d.aux_off + D.aoff[d.rec_off + (uint64_t)r];
-        }
+        rebase(D, d, lane, 64);
+    }
+}
+__global__ __launch_bounds__(64)
+void cram_records_lane_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref, const int32_t *pre_status, int32_t *status) {
+    for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < nslices; k += gridDim.x * 64u) {
+        if (pre_status[k] != 0) { status[k] = pre_status[k]; continue; }
+        const SliceDev d = T.slices[k];
+        status[k] = decode_one(T, D, d, nref);
+        rebase(D, d, 0, 1);
     }
 }
 
@@ -146,8 +165,16 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     D.seq_pool = (unsigned long long *)(d_out + opool); D.seq_cap = seq_cap;
     if (hipMemsetAsync(d_out + opool, 0, 8, s) != hipSuccess) return HG_ELAUNCH;
     int32_t *d_status = (int32_t *)(d_out + ost);
-    const unsigned grid = (unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 16);
-    hipLaunchKernelGGL(hgr::cram_records_kernel, dim3(grid), dim3(64), 0, s, T, D, (uint32_t)nslices, (int32_t)nref, (const int32_t *)(d_tab + parts[7].off), d_status);
+    // one wavefront per slice until the chip is full of them several times over, then one slice per lane
+    bool lane_mode = nslices >= (size_t)ctx->cus * 64;
+    if (const char *m = getenv("HG_CRAM_RECORDS_MODE")) lane_mode = m[0] == 'l';
+    if (lane_mode) {
+        const unsigned grid = (unsigned)std::min<size_t>((nslices + 63) / 64, (size_t)ctx->cus * 16);
+        hipLaunchKernelGGL(hgr::cram_records_lane_kernel, dim3(grid), dim3(64), 0, s, T, D, (uint32_t)nslices, (int32_t)nref, (const int32_t *)(d_tab + parts[7].off), d_status);
+    } else {
+        const unsigned grid = (unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 16);
+        hipLaunchKernelGGL(hgr::cram_records_kernel, dim3(grid), dim3(64), 0, s, T, D, (uint32_t)nslices, (int32_t)nref, (const int32_t *)(d_tab + parts[7].off), d_status);
+    }
     if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
     // results back: the dense record columns in one copy each, CIGAR / names as laid out (capacity-spaced per slice)
     void *dst32[9] = {out->flags, out->cram_flags, out->ref_id, out->len, out->rg, out->mqual, out->mate_ref_id, out->ncigar, out->name_len};
