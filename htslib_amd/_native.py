@@ -78,7 +78,7 @@ lib.hg_fqz_decode_host.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]
 lib.hg_cram_crai_slice.restype = C.c_long
 lib.hg_cram_crai_slice.argtypes = [_vp, C.c_uint32, C.c_int, _vp, _vp, _vp, C.c_int64, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]
 lib.hg_cram_records_bound.argtypes = [C.c_size_t, _vp, C.c_int, _vp, _vp, _vp, _vp]
-lib.hg_cram_decode_records_host.argtypes = [_vp, C.c_size_t, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp]
+lib.hg_cram_decode_records_host.argtypes = [_vp, C.c_size_t, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp, _vp]
 lib.hg_fqz_compress_bound.restype = C.c_size_t
 lib.hg_fqz_compress_bound.argtypes = [C.c_size_t, C.c_size_t]
 lib.hg_fqz_encode_host.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]

@@ -40,10 +40,11 @@ struct DevCols {
     uint64_t *seq_off; uint8_t *seq, *qual; unsigned long long *seq_pool; uint64_t seq_cap;   // seq == nullptr: bases / qualities not wanted
     uint64_t *aux_off; int32_t *aux_len; uint8_t *aux;                                      // aux == nullptr: not wanted
     int32_t *mate_flags, *mate_line; int64_t *explicit_tlen; uint32_t *coff, *noff, *aoff;   // scratch columns
+    uint32_t *totals;                                                                        // per slice: CIGAR words, name bytes, aux bytes written
 };
 
 // Runs the record loop of slice k (one thread).
-__device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, const SliceDev &d, int32_t nref) {
+__device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, const SliceDev &d, int32_t nref, uint32_t k) {
     const PlanDev &pd = T.plans[d.plan];
     Plan P;
     for (int i = 0; i < S_N; i++) P.codec_of[i] = pd.codec_of[i];
@@ -54,7 +55,8 @@ __device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, 
     S.data = T.data; S.blk_off = T.tab + d.tab_off; S.blk_len = S.blk_off + pd.nslots; S.cursor = T.tab + d.tab_off + 2 * pd.nslots;
     S.core_off = d.core_off; S.core_len = d.core_len; S.nrec = d.nrec; S.ref_seq_id = d.ref_seq_id; S.ref_seq_start = d.ref_seq_start; S.nref = nref;
     S.cigar_cap = d.cig_cap; S.name_cap = d.name_cap; S.aux_cap = d.aux_cap; S.refs = T.refs + d.ref_first; S.nrefs = (int32_t)d.nrefs;
-    uint32_t totals[3];
+    uint32_t *totals = D.totals + 3 * (size_t)k;
+    totals[0] = totals[1] = totals[2] = 0;
     const uint64_t r0 = d.rec_off;
     Cols O{D.flags + r0, D.cram_flags + r0, D.ref_id + r0, D.len + r0, D.rg + r0, D.mqual + r0, D.mate_flags + r0, D.mate_ref_id + r0, D.mate_line + r0,
            D.ncigar + r0, D.name_len + r0, D.coff + r0, D.noff + r0, D.apos + r0, D.aend + r0, D.mate_pos + r0, D.tlen + r0, D.explicit_tlen + r0,
@@ -62,11 +64,26 @@ __device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, 
            D.seq ? D.seq_off + r0 : nullptr, D.seq_pool, D.seq_cap};
     return decode_slice(&P, &S, O);
 }
-__device__ __forceinline__ void rebase(const DevCols &D, const SliceDev &d, int32_t first, int32_t step) {
-    for (int32_t r = first; r < d.nrec; r += step) {
-        D.cigar_off[d.rec_off + (uint64_t)r] = d.cig_off + D.coff[d.rec_off + (uint64_t)r];
-        D.name_off[d.rec_off + (uint64_t)r] = d.name_off + D.noff[d.rec_off + (uint64_t)r];
-        if (D.aux) D.aux_off[d.rec_off + (uint64_t)r] = d.aux_off + D.aoff[d.rec_off + (uint64_t)r];
+// Second pass: the slices wrote their CIGAR / name / aux bytes into capacity-sized regions; pack them back to back (dense[] = where
+// each slice's part starts, from a host prefix sum over the totals) and turn the slice-relative offsets of the records into offsets
+// of the packed arrays.  One wavefront per slice.
+struct Dense { uint32_t *cigar; uint8_t *names, *aux; const uint64_t *base; };      // base: 3 per slice
+__global__ __launch_bounds__(64)
+void cram_records_pack_kernel(DevTables T, DevCols D, Dense P, uint32_t nslices, const int32_t *status) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t k = blockIdx.x; k < nslices; k += gridDim.x) {
+        if (status[k] != 0) continue;
+        const SliceDev d = T.slices[k];
+        const uint64_t bc = P.base[3 * (size_t)k], bn = P.base[3 * (size_t)k + 1], ba = P.base[3 * (size_t)k + 2];
+        const uint32_t nc = D.totals[3 * (size_t)k], nn = D.totals[3 * (size_t)k + 1], na = D.totals[3 * (size_t)k + 2];
+        for (uint32_t i = lane; i < nc; i += 64) P.cigar[bc + i] = D.cigar[d.cig_off + i];
+        for (uint32_t i = lane; i < nn; i += 64) P.names[bn + i] = D.names[d.name_off + i];
+        if (D.aux) for (uint32_t i = lane; i < na; i += 64) P.aux[ba + i] = D.aux[d.aux_off + i];
+        for (uint32_t r = lane; r < (uint32_t)d.nrec; r += 64) {
+            D.cigar_off[d.rec_off + r] = bc + D.coff[d.rec_off + r];
+            D.name_off[d.rec_off + r] = bn + D.noff[d.rec_off + r];
+            if (D.aux) D.aux_off[d.rec_off + r] = ba + D.aoff[d.rec_off + r];
+        }
     }
 }
 
@@ -80,9 +97,7 @@ void cram_records_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref,
     for (uint32_t k = blockIdx.x; k < nslices; k += gridDim.x) {
         if (pre_status[k] != 0) { if (lane == 0) status[k] = pre_status[k]; continue; }
         const SliceDev d = T.slices[k];
-        if (lane == 0) status[k] = decode_one(T, D, d, nref);
-        hg::wave_sync();
-        rebase(D, d, lane, 64);
+        if (lane == 0) status[k] = decode_one(T, D, d, nref, k);
     }
 }
 __global__ __launch_bounds__(64)
@@ -90,8 +105,7 @@ void cram_records_lane_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t 
     for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < nslices; k += gridDim.x * 64u) {
         if (pre_status[k] != 0) { status[k] = pre_status[k]; continue; }
         const SliceDev d = T.slices[k];
-        status[k] = decode_one(T, D, d, nref);
-        rebase(D, d, 0, 1);
+        status[k] = decode_one(T, D, d, nref, k);
     }
 }
 
@@ -109,7 +123,8 @@ extern "C" int hg_cram_records_bound(size_t nslices, const hg_cram_slice_blocks 
 }
 
 extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, size_t rec_cap,
-                                           size_t cigar_cap, size_t name_cap, size_t seq_cap, size_t aux_cap, const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status) {
+                                           size_t cigar_cap, size_t name_cap, size_t seq_cap, size_t aux_cap, const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status,
+                                           uint64_t *used) {
     if (!ctx || (nslices && (!slices || !out || !rec_off || !status))) return HG_EINVAL;
     if (nslices == 0) { if (rec_off) rec_off[0] = 0; return HG_OK; }
     hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
@@ -117,7 +132,7 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     int rc = hgr::batch_build(B, (const hgr::SliceIn *)slices, nslices, major_version);
     if (rc) return rc == -3 ? HG_BLOCK_EUNSUPPORTED : HG_EINVAL;
     const bool want_aux = out->aux && out->aux_off && out->aux_len;
-    if (B.nrec > rec_cap || B.cig_total > cigar_cap || B.name_total > name_cap || (want_aux && B.aux_total > aux_cap)) return HG_EINVAL;
+    if (B.nrec > rec_cap) return HG_EINVAL;
     for (size_t i = 0; i < nslices; i++) rec_off[i] = B.slices[i].rec_off;
     rec_off[nslices] = B.nrec;
     // device image of the tables: one buffer, carved
@@ -141,6 +156,7 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     const size_t ocig = carve((B.cig_total ? B.cig_total : 1) * 4), onam = carve(B.name_total ? B.name_total : 1), ost = carve(nslices * 4);
     const bool want_seq = out->seq && out->qual && out->seq_off;
     const size_t oaux = carve(want_aux ? B.aux_total + 1 : 1);
+    const size_t otot = carve(nslices * 12), obase = carve(nslices * 24);
     const size_t oso = carve(R * 8), oseq = carve(want_seq ? seq_cap + 1 : 1), oqual = carve(want_seq ? seq_cap + 1 : 1), opool = carve(8);
     if ((rc = hg::ensure_scratch(ctx, 0, B.data_bytes + 64)) || (rc = hg::ensure_scratch(ctx, 1, obytes + 64)) || (rc = hg::ensure_scratch(ctx, 2, tbytes + 64))) return rc;
     hipStream_t s = ctx->stream;
@@ -164,6 +180,7 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     D.seq_off = (uint64_t *)(d_out + oso); D.seq = want_seq ? d_out + oseq : nullptr; D.qual = want_seq ? d_out + oqual : nullptr;
     D.seq_pool = (unsigned long long *)(d_out + opool); D.seq_cap = seq_cap;
     if (hipMemsetAsync(d_out + opool, 0, 8, s) != hipSuccess) return HG_ELAUNCH;
+    D.totals = (uint32_t *)(d_out + otot);
     int32_t *d_status = (int32_t *)(d_out + ost);
     // one wavefront per slice until the chip is full of them several times over, then one slice per lane
     bool lane_mode = nslices >= (size_t)ctx->cus * 64;
@@ -176,27 +193,48 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
         hipLaunchKernelGGL(hgr::cram_records_kernel, dim3(grid), dim3(64), 0, s, T, D, (uint32_t)nslices, (int32_t)nref, (const int32_t *)(d_tab + parts[7].off), d_status);
     }
     if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
-    // results back: the dense record columns in one copy each, CIGAR / names as laid out (capacity-spaced per slice)
+    // pack: totals back, prefix sums on the host, second kernel
+    std::vector<uint32_t> tot(nslices * 3);
+    ok = hipMemcpyAsync(status, d_status, nslices * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+         hipMemcpyAsync(tot.data(), d_out + otot, nslices * 12, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    if (!ok) return HG_ELAUNCH;
+    std::vector<uint64_t> base(nslices * 3);
+    uint64_t used_c = 0, used_n = 0, used_a = 0;
+    for (size_t i = 0; i < nslices; i++) {
+        base[3 * i] = used_c; base[3 * i + 1] = used_n; base[3 * i + 2] = used_a;
+        if (status[i] == 0) { used_c += tot[3 * i]; used_n += tot[3 * i + 1]; used_a += want_aux ? tot[3 * i + 2] : 0u; }
+    }
+    if (used) { used[0] = used_c; used[1] = used_n; used[2] = used_a; used[3] = 0; }
+    if (used_c > cigar_cap || used_n > name_cap || used_a > aux_cap) return HG_ENOMEM;      // the caller's arrays are too small: `used` says what is needed
+    const size_t pc = (used_c * 4 + 63) & ~(size_t)63, pn = (used_n + 63) & ~(size_t)63, pa = (used_a + 63) & ~(size_t)63;
+    if ((rc = hg::ensure_scratch(ctx, 3, pc + pn + pa + 64))) return rc;
+    uint8_t *d_pack = (uint8_t *)ctx->d_scratch[3];
+    hgr::Dense PK{(uint32_t *)d_pack, d_pack + pc, d_pack + pc + pn, (const uint64_t *)(d_out + obase)};
+    if (hipMemcpyAsync(d_out + obase, base.data(), nslices * 24, hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
+    hipLaunchKernelGGL(hgr::cram_records_pack_kernel, dim3((unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 32)), dim3(64), 0, s, T, D, PK, (uint32_t)nslices, d_status);
+    if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
+    // results back: every column in one copy
     void *dst32[9] = {out->flags, out->cram_flags, out->ref_id, out->len, out->rg, out->mqual, out->mate_ref_id, out->ncigar, out->name_len};
     for (int i = 0; i < 9 && ok; i++) if (dst32[i] && B.nrec) ok = hipMemcpyAsync(dst32[i], d_out + o32[i], B.nrec * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
     void *dst64[4] = {out->apos, out->aend, out->mate_pos, out->tlen};
     for (int i = 0; i < 4 && ok; i++) if (dst64[i] && B.nrec) ok = hipMemcpyAsync(dst64[i], d_out + o64[i], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
     if (ok && out->cigar_off && B.nrec) ok = hipMemcpyAsync(out->cigar_off, d_out + ou64[0], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
     if (ok && out->name_off && B.nrec) ok = hipMemcpyAsync(out->name_off, d_out + ou64[1], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
-    if (ok && out->cigar && B.cig_total) ok = hipMemcpyAsync(out->cigar, d_out + ocig, B.cig_total * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
-    if (ok && out->names && B.name_total) ok = hipMemcpyAsync(out->names, d_out + onam, B.name_total, hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (ok && out->cigar && used_c) ok = hipMemcpyAsync(out->cigar, PK.cigar, used_c * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (ok && out->names && used_n) ok = hipMemcpyAsync(out->names, PK.names, used_n, hipMemcpyDeviceToHost, s) == hipSuccess;
     if (ok && want_aux && B.nrec) ok = hipMemcpyAsync(out->aux_off, d_out + ou64[2], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
                                        hipMemcpyAsync(out->aux_len, d_out + o32[11], B.nrec * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                                       (!B.aux_total || hipMemcpyAsync(out->aux, d_out + oaux, B.aux_total, hipMemcpyDeviceToHost, s) == hipSuccess);
-    unsigned long long used = 0;
-    if (ok && want_seq) ok = hipMemcpyAsync(&used, d_out + opool, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+                                       (!used_a || hipMemcpyAsync(out->aux, PK.aux, used_a, hipMemcpyDeviceToHost, s) == hipSuccess);
+    unsigned long long pool_used = 0;
+    if (ok && want_seq) ok = hipMemcpyAsync(&pool_used, d_out + opool, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     if (ok && want_seq && B.nrec) {
-        if (used > seq_cap) used = seq_cap;
+        if (used) used[3] = pool_used;
+        if (pool_used > seq_cap) pool_used = seq_cap;
         ok = hipMemcpyAsync(out->seq_off, d_out + oso, B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
-             (!used || (hipMemcpyAsync(out->seq, d_out + oseq, used, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                        hipMemcpyAsync(out->qual, d_out + oqual, used, hipMemcpyDeviceToHost, s) == hipSuccess));
+             (!pool_used || (hipMemcpyAsync(out->seq, d_out + oseq, pool_used, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                             hipMemcpyAsync(out->qual, d_out + oqual, pool_used, hipMemcpyDeviceToHost, s) == hipSuccess));
     }
-    ok = ok && hipMemcpyAsync(status, d_status, nslices * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    ok = ok && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
     for (size_t i = 0; i < nslices; i++) if (status[i] != 0) return HG_EBLOCK;
     return HG_OK;

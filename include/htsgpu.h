@@ -403,15 +403,18 @@ typedef struct hg_cram_record_cols {                    /* arrays of rec_cap ent
     uint64_t *aux_off; int32_t *aux_len; uint8_t *aux;  /* the record's tags in BAM encoding (tag[2] type value ...), aux_len[r] bytes at
                                                            aux_off[r]; all three NULL = not wanted.  As stored: RG / MD / NM are not added. */
 } hg_cram_record_cols;
-/* Sizes the caller must provide for these slices: records (exact), CIGAR words, name bytes and aux bytes (upper bounds; slices get
- * disjoint regions).  Host only. */
+/* For these slices: the number of records (exact) and WORST-CASE sizes of the CIGAR / name / aux arrays (what a slice could produce
+ * given the size of its blocks; typical slices need a few per cent of that).  Host only. */
 int hg_cram_records_bound(size_t nslices, const hg_cram_slice_blocks *slices, int major_version, uint64_t *nrec, uint64_t *cigar_cap,
                           uint64_t *name_cap, uint64_t *aux_cap);
 /* nref = number of @SQ lines (bounds of RI / NS).  rec_off[i] .. rec_off[i+1] = the records of slice i (nslices + 1 entries).
- * status[i] = 0, -1 (malformed slice, as cram_decode_slice returning -1) or HG_BLOCK_EUNSUPPORTED.  Returns HG_OK / HG_EBLOCK. */
+ * status[i] = 0, -1 (malformed slice, as cram_decode_slice returning -1) or HG_BLOCK_EUNSUPPORTED.  cigar[] / names[] / aux[] come back
+ * PACKED (slice after slice, no gaps); the capacities may be any estimate: if one is too small the call returns HG_ENOMEM and used[]
+ * (optional, 4 entries: CIGAR words, name bytes, aux bytes, sequence bytes) says what the batch needs -- hg_cram_records_bound's
+ * figures always suffice.  Returns HG_OK / HG_EBLOCK / HG_ENOMEM. */
 int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref,
                                 size_t rec_cap, size_t cigar_cap, size_t name_cap, size_t seq_cap, size_t aux_cap,
-                                const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status);
+                                const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status, uint64_t *used);
 
 /* The .crai text of one slice (cram_index_slice / cram_index_build_multiref, cram/cram_index.c:632-728): "ref start span container_pos
  * landmark slice_bytes" -- one line from the slice header, or, for a multi-reference slice, one line per run of records on the same

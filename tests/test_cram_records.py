@@ -156,8 +156,11 @@ def test_decoder_source_on_the_cpu_matches_the_sam_twins(hostlib):
 def _gpu_calls(engine):
     from htslib_amd import _native as nat
     bound = lambda n, arr, major, a, b, c, d: nat.lib.hg_cram_records_bound(n, C.cast(arr, _vp), major, C.cast(a, _vp), C.cast(b, _vp), C.cast(c, _vp), C.cast(d, _vp))
-    dec = lambda n, arr, major, nref, R, cc, nc, sc, ac, cols, ro, st: nat.lib.hg_cram_decode_records_host(engine._h, n, C.cast(arr, _vp), major, nref, R, cc, nc, sc, ac,
-                                                                                                          C.cast(cols, _vp), ro, st)
+    def dec(n, arr, major, nref, R, cc, nc, sc, ac, cols, ro, st):
+        used = np.zeros(4, np.uint64)
+        rc = nat.lib.hg_cram_decode_records_host(engine._h, n, C.cast(arr, _vp), major, nref, R, cc, nc, sc, ac, C.cast(cols, _vp), ro, st, used.ctypes.data)
+        _gpu_calls.last_used = used
+        return rc
     return bound, dec
 
 
@@ -235,3 +238,21 @@ def test_crai_of_a_multi_reference_file_matches_the_reference_index(hostlib, bui
     assert (st == 0).all()
     meta = [{"slice_hdr": unpack(s["slice_hdr"]), "cpos": s["cpos"], "landmark": s["landmark"], "slice_bytes": s["slice_bytes"]} for s in f["slices"]]
     assert crai_of(meta, got, f["major"]) == f["crai"]
+
+
+@pytest.mark.gpu
+def test_gpu_outputs_come_back_packed_and_small_arrays_are_reported(engine):
+    from htslib_amd import _native as nat
+    bound, dec = _gpu_calls(engine)
+    base = [s for fname, major, nref, s in load_slices() if fname == "test/range.cram"]
+    slices = [base[i % 3] for i in range(30)]
+    st, got = decode(bound, dec, slices, 3, 7)
+    assert (st == 0).all()
+    used = _gpu_calls.last_used
+    ncig = sum(len(r[5]) for g in got for r in g); nname = sum(len(r[0]) for g in got for r in g)
+    assert used[0] == ncig and used[1] == nname and used[3] == sum(len(r[9]) for g in got for r in g)       # exactly what the records hold: no gaps
+    # the same call with arrays of half the needed size: HG_ENOMEM (-2) and the needed sizes
+    tight = lambda n, arr, major, nref, R, cc, nc, sc, ac, cols, ro, stt: dec(n, arr, major, nref, R, int(used[0]) // 2, nc, sc, ac, cols, ro, stt)
+    with pytest.raises(AssertionError):
+        decode(bound, tight, slices, 3, 7)
+    assert _gpu_calls.last_used[0] == ncig
