@@ -1,0 +1,113 @@
+"""Synthetic CRAM 3.0 slices of production size for the record decoder (tests / probes): what current htslib writes -- every
+variable series in its own EXTERNAL block, constants as zero-bit HUFFMAN codes, names and inserted / clipped bases as
+BYTE_ARRAY_STOP -- built from reads whose alignment, bases and qualities are known by construction.  This is a WRITER OF TEST
+INPUT, not a restatement of cram_encode_slice; the fixtures of the reference pin the decoder, these slices scale it."""
+import numpy as np
+
+from tests.golden.make_golden_rans import put_itf8
+
+SERIES = ["BF", "CF", "RI", "RL", "AP", "RG", "RN", "MF", "NS", "NP", "TS", "NF", "TL", "FN", "FC", "FP", "DL", "BA", "BS", "IN", "SC", "HC", "PD", "RS", "MQ", "QS"]
+BASES = b"ACGT"
+SM = ["CGTN", "AGTN", "ACTN", "ACGN", "ACGT"]                          # the default substitution matrix (cram_decode.c:207)
+
+
+def _ltf8(v):
+    assert 0 <= v < 0x80
+    return bytes([v])
+
+
+def _map(entries):
+    body = put_itf8(len(entries)) + b"".join(entries)
+    return put_itf8(len(body)) + body
+
+
+def compression_header():
+    """-> (block bytes, {series: content id})"""
+    ids = {s: 10 + k for k, s in enumerate(SERIES)}
+    pres = _map([b"RN\x01", b"AP\x01", b"RR\x01", b"SM" + bytes([0x1B] * 5), b"TD" + put_itf8(1) + b"\0"])
+    ext = lambda cid: put_itf8(1) + put_itf8(len(put_itf8(cid))) + put_itf8(cid)
+    const = lambda v: put_itf8(3) + (lambda p: put_itf8(len(p)) + p)(put_itf8(1) + put_itf8(v) + put_itf8(1) + put_itf8(0))
+    stop = lambda c, cid: put_itf8(5) + (lambda p: put_itf8(len(p)) + p)(bytes([c]) + put_itf8(cid))
+    enc = []
+    for s in SERIES:
+        if s == "RG": e = const(-1)
+        elif s == "TL": e = const(0)
+        elif s == "RN": e = stop(0, ids[s])
+        elif s in ("IN", "SC"): e = stop(ord("\t"), ids[s])
+        else: e = ext(ids[s])
+        enc.append(s.encode() + e)
+    return pres + _map(enc) + _map([]), ids
+
+
+def make_slice(rng, nrec, readlen=100, ref_len=None, unmapped_every=37, detached_every=11):
+    """-> a slice dict in the layout of tests/test_cram_records.load_slices() plus "truth": per record (flag base bits, pos, len, cigar, seq, qual)"""
+    ref_len = ref_len or (nrec * 8 + 10 * readlen)
+    ref = bytes(BASES[i] for i in rng.integers(0, 4, ref_len))
+    comp, ids = compression_header()
+    col = {s: bytearray() for s in SERIES}
+    truth, pos_prev, start = [], 1, 1
+    positions = np.sort(rng.integers(1, ref_len - 3 * readlen, nrec))
+    start = int(positions[0]); pos_prev = start
+    for r in range(nrec):
+        unmapped = unmapped_every and r % unmapped_every == unmapped_every - 1
+        pos = int(positions[r])
+        flag = (4 if unmapped else 0) | (16 if rng.random() < 0.5 else 0)
+        paired_down = (not unmapped) and r % 2 == 0 and r + 1 < nrec and not (unmapped_every and (r + 1) % unmapped_every == unmapped_every - 1) \
+            and not (detached_every and r % detached_every == 0)
+        detached = detached_every and r % detached_every == 0
+        if paired_down: flag |= 1 | 64
+        elif r % 2 == 1 and truth and truth[-1]["down"]: flag |= 1 | 128
+        cf = 1 | (2 if detached else 0) | (4 if paired_down else 0)
+        col["BF"] += put_itf8(flag); col["CF"] += put_itf8(cf); col["RL"] += put_itf8(readlen)
+        col["AP"] += put_itf8(pos - pos_prev); pos_prev = pos
+        name = ("r%07d" % r).encode(); col["RN"] += name + b"\0"
+        if detached:
+            col["MF"] += put_itf8(0); col["NS"] += put_itf8(-1); col["NP"] += put_itf8(0); col["TS"] += put_itf8(0)
+        elif paired_down: col["NF"] += put_itf8(0)
+        qual = rng.integers(2, 41, readlen).astype(np.uint8).tobytes()
+        if unmapped:
+            seq = bytes(BASES[i] for i in rng.integers(0, 4, readlen))
+            col["BA"] += seq; col["QS"] += qual
+            truth.append({"flag": flag, "pos": pos, "cigar": [], "seq": seq, "qual": qual, "down": False, "name": name})
+            continue
+        # features: a leading soft clip, then substitutions / one insertion / one deletion at increasing read positions
+        feats, cigar, seq, rp, sp = [], [], bytearray(), pos, 1                # rp: reference position, sp: read position (1-based)
+        def match(n):
+            nonlocal rp, sp
+            if n <= 0: return
+            seq.extend(ref[rp - 1:rp - 1 + n]); rp += n; sp += n
+            if cigar and cigar[-1][1] == 0: cigar[-1][0] += n
+            else: cigar.append([n, 0])
+        if rng.random() < 0.2:
+            n = int(rng.integers(1, 8)); clip = bytes(BASES[i] for i in rng.integers(0, 4, n))
+            feats.append((ord("S"), sp, clip)); seq.extend(clip); sp += n; cigar.append([n, 4])
+        for kind in rng.permutation(["X", "X", "I", "D", "X"])[:int(rng.integers(0, 5))]:
+            gap = int(rng.integers(1, 12))
+            if sp + gap + 8 > readlen: break
+            match(gap)
+            if kind == "X":
+                rb = "ACGT".index(chr(ref[rp - 1])); code = int(rng.integers(0, 3))        # never N
+                feats.append((ord("X"), sp, code)); seq.append(ord(SM[rb][code])); rp += 1; sp += 1
+                if cigar and cigar[-1][1] == 0: cigar[-1][0] += 1
+                else: cigar.append([1, 0])
+            elif kind == "I":
+                n = int(rng.integers(1, 5)); ins = bytes(BASES[i] for i in rng.integers(0, 4, n))
+                feats.append((ord("I"), sp, ins)); seq.extend(ins); sp += n; cigar.append([n, 1])
+            else:
+                n = int(rng.integers(1, 6)); feats.append((ord("D"), sp, n)); rp += n; cigar.append([n, 2])
+        match(readlen - (sp - 1))
+        col["FN"] += put_itf8(len(feats))
+        prev = 0
+        for code, at, val in feats:
+            col["FC"].append(code); col["FP"] += put_itf8(at - prev); prev = at
+            if code == ord("S"): col["SC"] += val + b"\t"
+            elif code == ord("I"): col["IN"] += val + b"\t"
+            elif code == ord("X"): col["BS"].append(val)
+            else: col["DL"] += put_itf8(val)
+        col["MQ"] += put_itf8(int(rng.integers(0, 61))); col["QS"] += qual
+        truth.append({"flag": flag, "pos": pos, "cigar": [c[:] for c in cigar], "seq": bytes(seq), "qual": qual, "down": bool(paired_down), "name": name})
+    sh = put_itf8(0) + put_itf8(start) + put_itf8(ref_len - start) + put_itf8(nrec) + _ltf8(0) + put_itf8(len(SERIES) + 1)
+    blocks = [(ids[s], bytes(col[s])) for s in SERIES if len(col[s])]
+    sh += put_itf8(len(blocks)) + b"".join(put_itf8(cid) for cid, _ in blocks) + put_itf8(-1) + bytes(16)
+    return {"comp_hdr": comp, "slice_hdr": sh, "core": b"", "blocks": blocks, "nrec": nrec, "refs": [(0, 1, ref, ref_len)], "truth": truth,
+            "expect": [[t["name"].decode(), 0, 0, 0, 0, [], 0, 0, 0, t["seq"].decode()] for t in truth]}

@@ -256,3 +256,39 @@ def test_gpu_outputs_come_back_packed_and_small_arrays_are_reported(engine):
     with pytest.raises(AssertionError):
         decode(bound, tight, slices, 3, 7)
     assert _gpu_calls.last_used[0] == ncig
+
+
+def _check_truth(slices, got):
+    for s, g in zip(slices, got):
+        assert len(g) == s["nrec"]
+        for r, t in zip(g, s["truth"]):
+            qual = "*" if not len(t["qual"]) else bytes(q + 33 for q in t["qual"]).decode("latin1")
+            assert (r[0], r[1] & ~0x28, r[3], r[5], r[9], r[10]) == (t["name"].decode(), t["flag"], t["pos"], t["cigar"], t["seq"].decode(), qual), (r, t)
+
+
+def test_synthetic_slices_of_production_size_on_the_cpu_compile(hostlib):
+    """EXTERNAL-only slices as current htslib writes them (tests/cram_synth.py), 2 000 records each with clips, substitutions, insertions,
+    deletions, unmapped reads, in-slice and detached mates: names, flags, positions, CIGARs, bases and qualities equal what the generator
+    put in."""
+    from tests import cram_synth
+    rng = np.random.default_rng(21)
+    slices = [cram_synth.make_slice(rng, 2000, 100), cram_synth.make_slice(rng, 700, 151, unmapped_every=5), cram_synth.make_slice(rng, 1, 50, ref_len=2000)]
+    st, got = decode(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, 3, 1)
+    assert (st == 0).all(), st
+    _check_truth(slices, got)
+
+
+@pytest.mark.gpu
+def test_gpu_synthetic_slices_match_the_cpu_compile(engine, hostlib):
+    from tests import cram_synth
+    bound, dec = _gpu_calls(engine)
+    rng = np.random.default_rng(22)
+    slices = [cram_synth.make_slice(rng, int(n), 100) for n in (3000, 1, 2, 63, 64, 65, 1500, 10)] + [cram_synth.make_slice(rng, 800, 151, unmapped_every=4)]
+    for mode in ("wave", "lane"):
+        os.environ["HG_CRAM_RECORDS_MODE"] = mode
+        st, got = decode(bound, dec, slices, 3, 1)
+        assert (st == 0).all(), (mode, st)
+        _check_truth(slices, got)
+        st_c, got_c = decode(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, 3, 1)
+        assert got == got_c, mode
+    del os.environ["HG_CRAM_RECORDS_MODE"]
