@@ -48,7 +48,7 @@ __device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, 
     const PlanDev &pd = T.plans[d.plan];
     Plan P;
     for (int i = 0; i < S_N; i++) P.codec_of[i] = pd.codec_of[i];
-    for (int i = 0; i < 20; i++) (&P.sm[0][0])[i] = (&pd.sm[0][0])[i];
+    P.sm = &pd.sm[0][0];
     P.rn_included = pd.rn_included; P.ap_delta = pd.ap_delta; P.qs_seq_orient = pd.qs_seq_orient; P.nslots = pd.nslots; P.nTL = pd.nTL;
     P.tl_off = T.tl_off + pd.tl_off_base; P.tl_codec = T.tl_codec + pd.tl_codec_base; P.tl_tag = T.tl_tag + pd.tl_codec_base; P.codecs = T.codecs + pd.codec_base; P.huff = T.huff + pd.huff_base;
     Slice S;

@@ -17,10 +17,11 @@ struct PlanHost {
     std::vector<Codec> codecs;
     std::vector<HuffCode> huff;
     std::vector<int32_t> tl_off, tl_codec, tl_tag;
+    std::vector<uint8_t> sm = std::vector<uint8_t>(20);
     std::map<int32_t, int32_t> slot_of;          // content id -> slot
     std::vector<int32_t> slot_id;                // slot -> content id
     int unsupported = 0;                         // a codec this build does not decode is present (reported when a slice uses the plan)
-    void finish() { plan.tl_off = tl_off.data(); plan.tl_codec = tl_codec.data(); plan.tl_tag = tl_tag.data(); plan.codecs = codecs.data(); plan.huff = huff.data(); plan.nslots = (int32_t)slot_id.size(); }
+    void finish() { plan.sm = sm.data(); plan.tl_off = tl_off.data(); plan.tl_codec = tl_codec.data(); plan.tl_tag = tl_tag.data(); plan.codecs = codecs.data(); plan.huff = huff.data(); plan.nslots = (int32_t)slot_id.size(); }
 };
 
 struct Cursor {
@@ -116,7 +117,7 @@ inline int plan_from_compression_header(PlanHost &H, const uint8_t *b, size_t n)
     H = PlanHost();
     for (int i = 0; i < S_N; i++) H.plan.codec_of[i] = -1;
     H.plan.rn_included = 0; H.plan.ap_delta = 1; H.plan.qs_seq_orient = 1;   // defaults (cram_decode.c:203-207)
-    memcpy(H.plan.sm, "CGTNAGTNACTNACGNACGT", 20);
+    memcpy(H.sm.data(), "CGTNAGTNACTNACGNACGT", 20);
     Cursor c{b, b + n};
     std::vector<std::vector<uint8_t>> td;                               // tag dictionary lines: 3-byte (tag, type) triples
     {   // preservation map
@@ -131,7 +132,7 @@ inline int plan_from_compression_header(PlanHost &H, const uint8_t *b, size_t n)
             else if (k0 == 'S' && k1 == 'M') {                          // cram_decode.c:290-318: code -> base, per reference base
                 if (c.end - c.p < 5) return -1;
                 static const char *others[5] = {"CGTN", "AGTN", "ACTN", "ACGN", "ACGT"};
-                for (int r = 0; r < 5; r++) for (int k = 0; k < 4; k++) H.plan.sm[r][(c.p[r] >> (6 - 2 * k)) & 3] = (uint8_t)others[r][k];
+                for (int r = 0; r < 5; r++) for (int k = 0; k < 4; k++) H.sm[(size_t)(4 * r + ((c.p[r] >> (6 - 2 * k)) & 3))] = (uint8_t)others[r][k];
                 c.p += 5;
             }
             else if (k0 == 'T' && k1 == 'D') {
@@ -250,7 +251,7 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
                 pi = (int32_t)B.plans.size();
                 PlanDev pd; memcpy(pd.codec_of, H.plan.codec_of, sizeof pd.codec_of);
                 pd.rn_included = H.plan.rn_included; pd.ap_delta = H.plan.ap_delta; pd.qs_seq_orient = H.plan.qs_seq_orient; pd.nslots = H.plan.nslots; pd.nTL = H.plan.nTL;
-                memcpy(pd.sm, H.plan.sm, 20);
+                memcpy(pd.sm, H.sm.data(), 20);
                 pd.tl_off_base = (uint32_t)B.tl_off.size(); pd.tl_codec_base = (uint32_t)B.tl_codec.size(); pd.codec_base = (uint32_t)B.codecs.size(); pd.huff_base = (uint32_t)B.huff.size();
                 B.tl_off.insert(B.tl_off.end(), H.tl_off.begin(), H.tl_off.end()); B.tl_codec.insert(B.tl_codec.end(), H.tl_codec.begin(), H.tl_codec.end()); B.tl_tag.insert(B.tl_tag.end(), H.tl_tag.begin(), H.tl_tag.end());
                 B.codecs.insert(B.codecs.end(), H.codecs.begin(), H.codecs.end()); B.huff.insert(B.huff.end(), H.huff.begin(), H.huff.end());

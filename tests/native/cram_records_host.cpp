@@ -32,7 +32,7 @@ extern "C" int hgr_host_decode_records(size_t nslices, const hgr::SliceIn *in, i
         if (status[i]) continue;
         const hgr::PlanDev &pd = B.plans[d.plan];
         hgr::Plan P; memcpy(P.codec_of, pd.codec_of, sizeof P.codec_of);
-        memcpy(P.sm, pd.sm, 20);
+        P.sm = &pd.sm[0][0];
         P.rn_included = pd.rn_included; P.ap_delta = pd.ap_delta; P.qs_seq_orient = pd.qs_seq_orient; P.nslots = pd.nslots; P.nTL = pd.nTL;
         P.tl_off = B.tl_off.data() + pd.tl_off_base; P.tl_codec = B.tl_codec.data() + pd.tl_codec_base; P.tl_tag = B.tl_tag.data() + pd.tl_codec_base; P.codecs = B.codecs.data() + pd.codec_base; P.huff = B.huff.data() + pd.huff_base;
         hgr::Slice S; S.data = data.data(); S.blk_off = B.tab.data() + d.tab_off; S.blk_len = S.blk_off + pd.nslots; S.cursor = B.tab.data() + d.tab_off + 2 * pd.nslots;
