@@ -109,6 +109,103 @@ void cram_records_lane_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t 
     }
 }
 
+// ---- cram_to_bam (cram_decode.c:3100-3192) + bam_set1 (sam.c) + the on-disk layout of bam_write1: decoded columns -> BAM records ----
+// One wavefront per slice, one record per lane.  sizes first (so that a prefix sum can place the records), then the bytes.
+struct BamIn {
+    const DevCols *D; const unsigned char *rg_names; const uint32_t *rg_off;   // read-group names back to back, rg_off[nrg + 1]
+    int32_t nrg;
+};
+__device__ __forceinline__ uint32_t bam_record_bytes(const DevCols &D, uint64_t r, const uint32_t *rg_off, int32_t nrg) {
+    const uint32_t nl = D.name_len[r] > 0 ? (uint32_t)D.name_len[r] : 1u, len = (uint32_t)D.len[r];
+    const int32_t rg = D.rg[r];
+    const uint32_t rgb = rg >= 0 && rg < nrg ? rg_off[rg + 1] - rg_off[rg] + 4u : 0u;
+    return 4u + 32u + nl + 1u + 4u * (uint32_t)D.ncigar[r] + (len + 1u) / 2u + len + (uint32_t)D.aux_len[r] + rgb;
+}
+__global__ __launch_bounds__(64)
+void cram_bam_size_kernel(DevTables T, DevCols D, const uint32_t *rg_off, int32_t nrg, uint32_t nslices, const int32_t *status, uint64_t *sizes) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t k = blockIdx.x; k < nslices; k += gridDim.x) {
+        const SliceDev d = T.slices[k];
+        for (uint32_t r = lane; r < (uint32_t)d.nrec; r += 64) sizes[d.rec_off + r] = status[k] == 0 ? bam_record_bytes(D, d.rec_off + r, rg_off, nrg) : 0u;
+    }
+}
+// exclusive prefix sum of n values in place, n + 1 outputs (one workgroup: each thread owns a contiguous piece)
+__global__ __launch_bounds__(1024)
+void scan_u64_kernel(uint64_t *v, uint64_t n) {
+    __shared__ uint64_t part[1024];
+    const uint64_t t = threadIdx.x, per = (n + 1023) / 1024, a = t * per < n ? t * per : n, b = a + per < n ? a + per : n;
+    uint64_t sum = 0;
+    for (uint64_t i = a; i < b; i++) sum += v[i];
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) { uint64_t run = 0; for (int i = 0; i < 1024; i++) { const uint64_t x = part[i]; part[i] = run; run += x; } v[n] = run; }
+    __syncthreads();
+    uint64_t run = part[t];
+    for (uint64_t i = a; i < b; i++) { const uint64_t x = v[i]; v[i] = run; run += x; }
+}
+__device__ __forceinline__ uint32_t nt16(uint32_t c) {                    // seq_nt16_table (hts.c)
+    switch (c & ~0x20u) {
+    case 'A': return 1; case 'C': return 2; case 'M': return 3; case 'G': return 4; case 'R': return 5; case 'S': return 6; case 'V': return 7; case 'T': return 8;
+    case 'W': return 9; case 'Y': return 10; case 'H': return 11; case 'K': return 12; case 'D': return 13; case 'B': return 14;
+    default: return c == '=' ? 0u : 15u;
+    }
+}
+__device__ __forceinline__ uint32_t reg2bin(int64_t beg, int64_t end) {  // bam_reg2bin (sam.h)
+    --end;
+    if (beg >> 14 == end >> 14) return (uint32_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (uint32_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (uint32_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (uint32_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (uint32_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+__global__ __launch_bounds__(64)
+void cram_bam_write_kernel(DevTables T, DevCols D, Dense P, const unsigned char *rg_names, const uint32_t *rg_off, int32_t nrg, uint32_t nslices,
+                           const int32_t *status, const uint64_t *off, uint8_t *out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t k = blockIdx.x; k < nslices; k += gridDim.x) {
+        if (status[k] != 0) continue;
+        const SliceDev d = T.slices[k];
+        for (uint32_t q = lane; q < (uint32_t)d.nrec; q += 64) {
+            const uint64_t r = d.rec_off + q;
+            uint8_t *o = out + off[r];
+            const uint32_t bytes = (uint32_t)(off[r + 1] - off[r]);
+            const uint32_t nl = D.name_len[r] > 0 ? (uint32_t)D.name_len[r] : 0u, len = (uint32_t)D.len[r], nc = (uint32_t)D.ncigar[r], flag = (uint32_t)D.flags[r];
+            const uint32_t *cig = P.cigar + D.cigar_off[r];
+            int64_t rlen = 0;
+            if (!(flag & BAM_FUNMAP)) for (uint32_t i = 0; i < nc; i++) { const uint32_t op = cig[i] & 15u; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += cig[i] >> 4; }
+            if (rlen == 0) rlen = 1;
+            const int64_t pos = D.apos[r] - 1, mpos = D.mate_pos[r] - 1;
+            auto put32 = [&](uint32_t at, uint32_t v) { o[at] = (uint8_t)v; o[at + 1] = (uint8_t)(v >> 8); o[at + 2] = (uint8_t)(v >> 16); o[at + 3] = (uint8_t)(v >> 24); };
+            put32(0, bytes - 4u);
+            put32(4, (uint32_t)D.ref_id[r]); put32(8, (uint32_t)pos);
+            put32(12, reg2bin(pos, pos + rlen) << 16 | ((uint32_t)D.mqual[r] & 0xffu) << 8 | ((nl ? nl : 1u) + 1u));
+            put32(16, flag << 16 | (nc & 0xffffu)); put32(20, len);
+            put32(24, (uint32_t)D.mate_ref_id[r]); put32(28, (uint32_t)mpos); put32(32, (uint32_t)D.tlen[r]);
+            uint32_t at = 36;
+            if (nl) { const uint8_t *nm = P.names + D.name_off[r]; for (uint32_t i = 0; i < nl; i++) o[at + i] = nm[i]; at += nl; } else o[at++] = '*';
+            o[at++] = 0;
+            for (uint32_t i = 0; i < nc; i++) { put32(at, cig[i]); at += 4; }
+            const uint8_t *sq = D.seq + D.seq_off[r], *ql = D.qual + D.seq_off[r];
+            for (uint32_t i = 0; i + 1 < len; i += 2) o[at + (i >> 1)] = (uint8_t)(nt16(sq[i]) << 4 | nt16(sq[i + 1]));
+            if (len & 1u) o[at + (len >> 1)] = (uint8_t)(nt16(sq[len - 1]) << 4);
+            at += (len + 1u) / 2u;
+            for (uint32_t i = 0; i < len; i++) o[at + i] = ql[i];
+            at += len;
+            const uint32_t na = (uint32_t)D.aux_len[r];
+            const uint8_t *ax = P.aux + D.aux_off[r];
+            for (uint32_t i = 0; i < na; i++) o[at + i] = ax[i];
+            at += na;
+            const int32_t rg = D.rg[r];
+            if (rg >= 0 && rg < nrg) {                                       // RG:Z: from the read-group series (cram_decode.c:3180-3189)
+                o[at++] = 'R'; o[at++] = 'G'; o[at++] = 'Z';
+                for (uint32_t i = rg_off[rg]; i < rg_off[rg + 1]; i++) o[at++] = rg_names[i];
+                o[at++] = 0;
+            }
+        }
+    }
+}
+
 }  // namespace hgr
 
 extern "C" int hg_cram_records_bound(size_t nslices, const hg_cram_slice_blocks *slices, int major_version, uint64_t *nrec, uint64_t *cigar_cap,
@@ -122,16 +219,19 @@ extern "C" int hg_cram_records_bound(size_t nslices, const hg_cram_slice_blocks 
     return HG_OK;
 }
 
-extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, size_t rec_cap,
-                                           size_t cigar_cap, size_t name_cap, size_t seq_cap, size_t aux_cap, const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status,
-                                           uint64_t *used) {
+namespace {
+struct BamSink { const char *const *rg_names; int nrg; uint8_t *out; size_t cap; uint64_t *rec_bam_off; uint64_t *total; };
+}
+static int records_impl(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, size_t rec_cap, size_t cigar_cap,
+                        size_t name_cap, size_t seq_cap, size_t aux_cap, const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status, uint64_t *used,
+                        const BamSink *bam) {
     if (!ctx || (nslices && (!slices || !out || !rec_off || !status))) return HG_EINVAL;
     if (nslices == 0) { if (rec_off) rec_off[0] = 0; return HG_OK; }
     hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     hgr::Batch B;
     int rc = hgr::batch_build(B, (const hgr::SliceIn *)slices, nslices, major_version);
     if (rc) return rc == -3 ? HG_BLOCK_EUNSUPPORTED : HG_EINVAL;
-    const bool want_aux = out->aux && out->aux_off && out->aux_len;
+    const bool want_aux = bam || (out->aux && out->aux_off && out->aux_len);
     if (B.nrec > rec_cap) return HG_EINVAL;
     for (size_t i = 0; i < nslices; i++) rec_off[i] = B.slices[i].rec_off;
     rec_off[nslices] = B.nrec;
@@ -154,7 +254,7 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     for (auto &o : ou64) o = carve(R * 8);
     for (auto &o : ou32) o = carve(R * 4);
     const size_t ocig = carve((B.cig_total ? B.cig_total : 1) * 4), onam = carve(B.name_total ? B.name_total : 1), ost = carve(nslices * 4);
-    const bool want_seq = out->seq && out->qual && out->seq_off;
+    const bool want_seq = bam || (out->seq && out->qual && out->seq_off);
     const size_t oaux = carve(want_aux ? B.aux_total + 1 : 1);
     const size_t otot = carve(nslices * 12), obase = carve(nslices * 24);
     const size_t oso = carve(R * 8), oseq = carve(want_seq ? seq_cap + 1 : 1), oqual = carve(want_seq ? seq_cap + 1 : 1), opool = carve(8);
@@ -222,22 +322,68 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
     if (ok && out->name_off && B.nrec) ok = hipMemcpyAsync(out->name_off, d_out + ou64[1], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
     if (ok && out->cigar && used_c) ok = hipMemcpyAsync(out->cigar, PK.cigar, used_c * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
     if (ok && out->names && used_n) ok = hipMemcpyAsync(out->names, PK.names, used_n, hipMemcpyDeviceToHost, s) == hipSuccess;
-    if (ok && want_aux && B.nrec) ok = hipMemcpyAsync(out->aux_off, d_out + ou64[2], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+    if (ok && want_aux && out->aux && B.nrec) ok = hipMemcpyAsync(out->aux_off, d_out + ou64[2], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
                                        hipMemcpyAsync(out->aux_len, d_out + o32[11], B.nrec * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
                                        (!used_a || hipMemcpyAsync(out->aux, PK.aux, used_a, hipMemcpyDeviceToHost, s) == hipSuccess);
     unsigned long long pool_used = 0;
     if (ok && want_seq) ok = hipMemcpyAsync(&pool_used, d_out + opool, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-    if (ok && want_seq && B.nrec) {
-        if (used) used[3] = pool_used;
+    if (ok && want_seq && B.nrec && used) used[3] = pool_used;
+    if (ok && want_seq && pool_used > seq_cap) return HG_ENOMEM;
+    if (ok && want_seq && out->seq && B.nrec) {
         if (pool_used > seq_cap) pool_used = seq_cap;
         ok = hipMemcpyAsync(out->seq_off, d_out + oso, B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
              (!pool_used || (hipMemcpyAsync(out->seq, d_out + oseq, pool_used, hipMemcpyDeviceToHost, s) == hipSuccess &&
                              hipMemcpyAsync(out->qual, d_out + oqual, pool_used, hipMemcpyDeviceToHost, s) == hipSuccess));
     }
+    if (ok && bam) {                                                     // cram_to_bam on the device: sizes, prefix sum, bytes
+        std::vector<uint32_t> rgo((size_t)bam->nrg + 1, 0u); std::vector<unsigned char> rgn;
+        for (int i = 0; i < bam->nrg; i++) { const size_t l = strlen(bam->rg_names[i]); rgn.insert(rgn.end(), bam->rg_names[i], bam->rg_names[i] + l); rgo[(size_t)i + 1] = (uint32_t)rgn.size(); }
+        const size_t szb = (R + 1) * 8, rgb = (rgo.size() * 4 + 63) & ~(size_t)63;
+        if ((rc = hg::ensure_scratch(ctx, 4, szb + rgb + rgn.size() + 128))) return rc;
+        uint8_t *d_b = (uint8_t *)ctx->d_scratch[4];
+        uint64_t *d_sz = (uint64_t *)d_b; uint32_t *d_rgo = (uint32_t *)(d_b + ((szb + 63) & ~(size_t)63)); unsigned char *d_rgn = (unsigned char *)d_rgo + rgb;
+        ok = hipMemcpyAsync(d_rgo, rgo.data(), rgo.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+             (rgn.empty() || hipMemcpyAsync(d_rgn, rgn.data(), rgn.size(), hipMemcpyHostToDevice, s) == hipSuccess);
+        const unsigned grid = (unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 32);
+        if (ok) {
+            hipLaunchKernelGGL(hgr::cram_bam_size_kernel, dim3(grid), dim3(64), 0, s, T, D, d_rgo, (int32_t)bam->nrg, (uint32_t)nslices, d_status, d_sz);
+            hipLaunchKernelGGL(hgr::scan_u64_kernel, dim3(1), dim3(1024), 0, s, d_sz, (uint64_t)B.nrec);
+        }
+        uint64_t total = 0;
+        ok = ok && hipMemcpyAsync(&total, d_sz + B.nrec, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        if (!ok) return HG_ELAUNCH;
+        if (bam->total) *bam->total = total;
+        if (total > bam->cap) return HG_ENOMEM;
+        if ((rc = hg::ensure_scratch(ctx, 5, total + 64))) return rc;
+        uint8_t *d_bam = (uint8_t *)ctx->d_scratch[5];
+        hipLaunchKernelGGL(hgr::cram_bam_write_kernel, dim3(grid), dim3(64), 0, s, T, D, PK, d_rgn, d_rgo, (int32_t)bam->nrg, (uint32_t)nslices, d_status, d_sz, d_bam);
+        ok = hipGetLastError() == hipSuccess && (!total || hipMemcpyAsync(bam->out, d_bam, total, hipMemcpyDeviceToHost, s) == hipSuccess) &&
+             (!bam->rec_bam_off || hipMemcpyAsync(bam->rec_bam_off, d_sz, (B.nrec + 1) * 8, hipMemcpyDeviceToHost, s) == hipSuccess);
+    }
     ok = ok && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
     for (size_t i = 0; i < nslices; i++) if (status[i] != 0) return HG_EBLOCK;
     return HG_OK;
+}
+
+extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, size_t rec_cap,
+                                           size_t cigar_cap, size_t name_cap, size_t seq_cap, size_t aux_cap, const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status,
+                                           uint64_t *used) {
+    return records_impl(ctx, nslices, slices, major_version, nref, rec_cap, cigar_cap, name_cap, seq_cap, aux_cap, out, rec_off, status, used, nullptr);
+}
+
+// CRAM slices -> uncompressed BAM records (cram_decode_slice + cram_to_bam, cram_decode.c:2346-3192), everything on the device; only the
+// BAM bytes come back.  rg_names: the @RG IDs in header order (the RG series indexes them).  Records of failed slices are left out.
+extern "C" int hg_cram_decode_bam_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, const char *const *rg_names,
+                                       int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap, uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes,
+                                       int32_t *status) {
+    if (!ctx || (nslices && (!slices || !bam_out || !rec_off || !status)) || (nrg && !rg_names)) return HG_EINVAL;
+    hg_cram_record_cols none; memset(&none, 0, sizeof none);
+    uint64_t nrec = 0, c0 = 0, c1 = 0, c2 = 0;
+    int rc = hg_cram_records_bound(nslices, slices, major_version, &nrec, &c0, &c1, &c2);
+    if (rc) return rc;
+    const BamSink sink{rg_names, nrg, bam_out, bam_cap, rec_bam_off, bam_bytes};
+    return records_impl(ctx, nslices, slices, major_version, nref, (size_t)nrec, (size_t)-1, (size_t)-1, (size_t)total_bases, (size_t)-1, &none, rec_off, status, nullptr, &sink);
 }
 
 // The .crai lines of one slice (cram_index_slice / cram_index_build_multiref, reference cram/cram_index.c:632-728): a single-reference

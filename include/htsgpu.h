@@ -416,6 +416,18 @@ int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice
                                 size_t rec_cap, size_t cigar_cap, size_t name_cap, size_t seq_cap, size_t aux_cap,
                                 const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status, uint64_t *used);
 
+/* CRAM slices -> uncompressed BAM records: cram_decode_slice + cram_to_bam (cram/cram_decode.c:2346-3192; bam_set1 and the on-disk
+ * layout of bam_write1, sam.c) entirely on the device -- the record loop above, then one lane per record sizes and writes
+ * block_size, the 32-byte core (bin from the CIGAR's reference length), QNAME, CIGAR, 4-bit bases, qualities, the stored tags and RG:Z
+ * from the read-group series.  Only the BAM bytes cross PCIe; they are what bgzf_write / hg_bgzf_deflate take.  rg_names = the @RG IDs
+ * in header order; total_bases >= the bases of the slices (sum of the containers' `bases` fields).  rec_off as above; rec_bam_off
+ * (optional, records + 1 entries) = where each record starts in bam_out; *bam_bytes = bytes written, or needed when the call returns
+ * HG_ENOMEM.  Records of failed slices are left out.  Not done: MD / NM regeneration, names for files written without read names
+ * (such records get "*"), CIGARs of more than 65535 operations. */
+int hg_cram_decode_bam_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref,
+                            const char *const *rg_names, int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap,
+                            uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes, int32_t *status);
+
 /* The .crai text of one slice (cram_index_slice / cram_index_build_multiref, cram/cram_index.c:632-728): "ref start span container_pos
  * landmark slice_bytes" -- one line from the slice header, or, for a multi-reference slice, one line per run of records on the same
  * reference from the ref_id / apos / aend columns of hg_cram_decode_records_host (the arrays of THIS slice).  Returns the number of

@@ -81,7 +81,8 @@ def sam_text(path):
             seq = "".join("=ACMGRSVTWYHKDBN"[(packed[i >> 1] >> (4 if i % 2 == 0 else 0)) & 15] for i in range(lseq)) or "*"
             ql = d[a + (lseq + 1) // 2:a + (lseq + 1) // 2 + lseq]
             qual = "*" if lseq == 0 or ql[0] == 0xFF else bytes(c + 33 for c in ql).decode("latin1")
-            recs.append((name, flag, tid, pos + 1, mapq, [(c >> 4, c & 15) for c in cig], mtid, mpos + 1, tlen, seq, qual, [short_tag(t) for t in aux_to_text(d[a + (lseq + 1) // 2 + lseq:p])]))
+            recs.append((name, flag, tid, pos + 1, mapq, [(c >> 4, c & 15) for c in cig], mtid, mpos + 1, tlen, seq, qual, [short_tag(t) for t in aux_to_text(d[a + (lseq + 1) // 2 + lseq:p])],
+                         base64.b64encode(d[q:a + (lseq + 1) // 2 + lseq]).decode()))     # the record from refID up to the tags, as the reference wrote it
         return refs, recs
     refs, recs = [], []
     for ln in open(path):
@@ -169,7 +170,12 @@ def main():
                 k += 1 + nb; sidx += 1
         assert at == len(recs), (base, at, len(recs))
         crai = gzip.open(path + ".crai", "rt").read() if os.path.exists(path + ".crai") else None
-        out.append({"crai": crai, "file": "test/" + os.path.relpath(path, REF), "twin": "test/" + os.path.relpath(twin, REF), "major": 3, "nref": len(refs), "slices": slices})
+        rgs = []
+        if twin.endswith(".sam"): rgs = [[x[3:] for x in ln.rstrip("\n").split("\t") if x.startswith("ID:")][0] for ln in open(twin) if ln.startswith("@RG")]
+        else:
+            hd = gzip.open(twin, "rb").read(); hl = struct.unpack_from("<i", hd, 4)[0]
+            rgs = [[x[3:] for x in ln.split("\t") if x.startswith("ID:")][0] for ln in hd[8:8 + hl].decode().split("\n") if ln.startswith("@RG")]
+        out.append({"rg": rgs, "crai": crai, "file": "test/" + os.path.relpath(path, REF), "twin": "test/" + os.path.relpath(twin, REF), "major": 3, "nref": len(refs), "slices": slices})
     json.dump(out, open(os.path.join(HERE, "cram_records.json"), "w"), separators=(",", ":"))
     print(len(out), "files,", sum(len(f["slices"]) for f in out), "slices,", sum(s["nrec"] for f in out for s in f["slices"]), "records,",
           os.path.getsize(os.path.join(HERE, "cram_records.json")), "bytes")

@@ -292,3 +292,84 @@ def test_gpu_synthetic_slices_match_the_cpu_compile(engine, hostlib):
         st_c, got_c = decode(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, 3, 1)
         assert got == got_c, mode
     del os.environ["HG_CRAM_RECORDS_MODE"]
+
+
+def _slice_array(slices, keep):
+    """ctypes view of slice dicts (as decode() builds it)"""
+    n = len(slices)
+    arr = (SliceIn * n)()
+    same = {}
+    for i, s in enumerate(slices):
+        ch = same.setdefault(s["comp_hdr"], C.create_string_buffer(s["comp_hdr"], len(s["comp_hdr"])))
+        sh = C.create_string_buffer(s["slice_hdr"], len(s["slice_hdr"])); co = C.create_string_buffer(s["core"], max(len(s["core"]), 1))
+        bl = [C.create_string_buffer(d, max(len(d), 1)) for _, d in s["blocks"]]
+        ids = np.array([cid for cid, _ in s["blocks"]], dtype=np.int32); lens = np.array([len(d) for _, d in s["blocks"]], dtype=np.uint32)
+        ptrs = (_vp * max(len(bl), 1))(*[C.addressof(x) for x in bl])
+        rb = [C.create_string_buffer(b, max(len(b), 1)) for _, _, b, _ in s.get("refs", [])]
+        ra = (RefIn * max(len(rb), 1))(*[RefIn(t, a, C.addressof(buf), len(b), ln) for (t, a, b, ln), buf in zip(s.get("refs", []), rb)])
+        keep.append((ch, sh, co, bl, ids, lens, ptrs, rb, ra))
+        arr[i] = SliceIn(C.addressof(ch), len(s["comp_hdr"]), C.addressof(sh), len(s["slice_hdr"]), C.addressof(co), len(s["core"]), len(bl), ids.ctypes.data,
+                         C.addressof(ptrs), lens.ctypes.data, len(rb), C.addressof(ra))
+    return arr
+
+
+def _parse_bam_records(b):
+    """uncompressed BAM records -> [(fields as in the twin layout ..., bin, raw bytes from refID up to the tags)]"""
+    import struct
+    out, p = [], 0
+    while p < len(b):
+        bs = struct.unpack_from("<i", b, p)[0]; q = p + 4; p = q + bs
+        tid, pos, lname, mapq, bn, ncig, flag, lseq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", b, q)
+        name = b[q + 32:q + 32 + lname - 1].decode("latin1")
+        assert b[q + 32 + lname - 1] == 0
+        cig = struct.unpack_from("<%dI" % ncig, b, q + 32 + lname)
+        a = q + 32 + lname + 4 * ncig
+        packed = b[a:a + (lseq + 1) // 2]
+        seq = "".join("=ACMGRSVTWYHKDBN"[(packed[i >> 1] >> (4 if i % 2 == 0 else 0)) & 15] for i in range(lseq)) or "*"
+        ql = b[a + (lseq + 1) // 2:a + (lseq + 1) // 2 + lseq]
+        qual = "*" if lseq == 0 or all(c == 0xFF for c in ql) else bytes(c + 33 for c in ql).decode("latin1")
+        tags = [G.short_tag(t) for t in G.aux_to_text(b[a + (lseq + 1) // 2 + lseq:p])]
+        out.append(([name, flag, tid, pos + 1, mapq, [[c >> 4, c & 15] for c in cig], mtid, mpos + 1, tlen, seq, qual, tags], bn, bytes(b[q:a + (lseq + 1) // 2 + lseq])))
+    return out
+
+
+@pytest.mark.gpu
+def test_gpu_cram_to_bam_records(engine):
+    """hg_cram_decode_bam_host: the fixtures' slices come back as uncompressed BAM records whose fields are the twin's; for range.cram the
+    bytes from refID up to the tags are the bytes of the reference's own range.bam (bin, l_read_name, packed bases, ... included), and
+    the read group comes back as an RG:Z tag."""
+    import base64
+    from htslib_amd import _native as nat
+    gold = json.load(open(GOLD))
+    by_file = {}
+    for fname, major, nref, s in load_slices():
+        by_file.setdefault(fname, []).append(s)
+    nrec = 0
+    for f in gold:
+        slices = by_file[f["file"]]
+        keep = []
+        arr = _slice_array(slices, keep)
+        rg = [r.encode() for r in f["rg"]]
+        rgp = (C.c_char_p * max(len(rg), 1))(*rg) if rg else None
+        bases = sum(len(e[9]) for s in slices for e in s["expect"] if e[9] != "*") + 64
+        n = len(slices)
+        out = np.zeros(1 << 22, np.uint8); rec_off = np.zeros(n + 1, np.uint64); total = C.c_uint64(); st = np.full(n, 9, np.int32)
+        nr = sum(s["nrec"] for s in slices)
+        boff = np.zeros(nr + 1, np.uint64)
+        rc = nat.lib.hg_cram_decode_bam_host(engine._h, n, C.cast(arr, _vp), f["major"], f["nref"], C.cast(rgp, _vp) if rg else None, len(rg), bases, out.ctypes.data, len(out),
+                                             rec_off.ctypes.data, boff.ctypes.data, C.byref(total), st.ctypes.data)
+        assert rc == 0 and (st == 0).all(), (f["file"], rc, st)
+        recs = _parse_bam_records(bytes(out[:total.value]))
+        expect = [e for s in slices for e in s["expect"]]
+        assert len(recs) == len(expect) == nr and int(boff[nr]) == total.value
+        for (g, bn, raw), e in zip(recs, expect):
+            check_against_twin(f["file"], g, e)
+            if g[11] or f["rg"]:                                          # a record of a file with read groups ends with RG:Z:<id> unless the stored tags hold it
+                assert not f["rg"] or any(t.startswith("RG:Z:") for t in g[11]), g
+            if len(e) > 12: assert raw == base64.b64decode(e[12]), (f["file"], g[0])       # byte-identical to the reference's BAM record up to the tags
+            nrec += 1
+    assert nrec == 230
+    # a buffer that is too small: HG_ENOMEM and the size needed
+    small = np.zeros(64, np.uint8)
+    rc = nat.lib.hg_cram_decode_bam_host(engine._h, n, C.cast(arr, _vp), 3, f["nref"], None, 0, bases, small.ctypes.data, len(small), rec_off.ctypes.data, None, C.byref(total), st.ctypes.data)
+    assert rc == -3 and total.value > 64
