@@ -364,8 +364,7 @@ def test_gpu_cram_to_bam_records(engine):
         assert len(recs) == len(expect) == nr and int(boff[nr]) == total.value
         for (g, bn, raw), e in zip(recs, expect):
             check_against_twin(f["file"], [g], [e])
-            if g[11] or f["rg"]:                                          # a record of a file with read groups ends with RG:Z:<id> unless the stored tags hold it
-                assert not f["rg"] or any(t.startswith("RG:Z:") for t in g[11]), g
+            assert [t for t in g[11] if t.startswith("RG:Z:")] == [t for t in e[11] if t.startswith("RG:Z:")], g      # RG:Z comes back from the read-group series
             if len(e) > 12: assert raw == base64.b64decode(e[12]), (f["file"], g[0])       # byte-identical to the reference's BAM record up to the tags
             nrec += 1
     assert nrec == 230
