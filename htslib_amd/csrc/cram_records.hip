@@ -13,7 +13,8 @@
 // Bases and qualities are rebuilt when the caller passes the reference spans (cram_decode_seq's copy-and-edit, without MD / NM
 // generation); each record takes its len bytes from one pool with an atomic add, so the order of records in seq[] / qual[] is not
 // the record order -- seq_off[] says where each one is.
-// Honest limits: aux values are consumed but not produced yet; lane 0 working alone uses 1/64 of the wave -- the EXTERNAL-only
+// cram_to_bam follows on the device (sizes, prefix sum, one lane per record writes the BAM bytes).
+// Honest limits: the record loop is chain-bound (one serial chain per slice); MD / NM are not regenerated -- the EXTERNAL-only
 // fast path (prefix sums over per-record item counts, then the column kernels of cram_series.hip) is the next step and will be
 // checked against this kernel.
 #include <hip/hip_runtime.h>
