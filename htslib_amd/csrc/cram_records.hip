@@ -10,11 +10,11 @@
 // same source the CPU harness checks against the reference's SAM twins), then all 64 lanes turn the slice-relative CIGAR / name
 // offsets into offsets of the caller's arrays.  The compression / slice headers are parsed on the host (cram_records_plan.h): a
 // few hundred bytes per container.
-// Bases and qualities are rebuilt when the caller passes the reference spans (cram_decode_seq's copy-and-edit, without MD / NM
-// generation); each record takes its len bytes from one pool with an atomic add, so the order of records in seq[] / qual[] is not
+// Bases and qualities are rebuilt when the caller passes the reference spans (cram_decode_seq's copy-and-edit, MD:Z / NM regenerated
+// when decode_md asks); each record takes its len bytes from one pool with an atomic add, so the order of records in seq[] / qual[] is not
 // the record order -- seq_off[] says where each one is.
 // cram_to_bam follows on the device (sizes, prefix sum, one lane per record writes the BAM bytes).
-// Honest limits: the record loop is chain-bound (one serial chain per slice); MD / NM are not regenerated -- the EXTERNAL-only
+// Honest limits: the record loop is chain-bound (one serial chain per slice) -- the EXTERNAL-only
 // fast path (prefix sums over per-record item counts, then the column kernels of cram_series.hip) is the next step and will be
 // checked against this kernel.
 #include <hip/hip_runtime.h>
@@ -55,7 +55,7 @@ __device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, 
     Slice S;
     S.data = T.data; S.blk_off = T.tab + d.tab_off; S.blk_len = S.blk_off + pd.nslots; S.cursor = T.tab + d.tab_off + 2 * pd.nslots;
     S.core_off = d.core_off; S.core_len = d.core_len; S.nrec = d.nrec; S.ref_seq_id = d.ref_seq_id; S.ref_seq_start = d.ref_seq_start; S.nref = nref;
-    S.cigar_cap = d.cig_cap; S.name_cap = d.name_cap; S.aux_cap = d.aux_cap; S.refs = T.refs + d.ref_first; S.nrefs = (int32_t)d.nrefs;
+    S.cigar_cap = d.cig_cap; S.name_cap = d.name_cap; S.aux_cap = d.aux_cap; S.refs = T.refs + d.ref_first; S.nrefs = (int32_t)d.nrefs; S.decode_md = d.decode_md;
     uint32_t *totals = D.totals + 3 * (size_t)k;
     totals[0] = totals[1] = totals[2] = 0;
     const uint64_t r0 = d.rec_off;

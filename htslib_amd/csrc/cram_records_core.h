@@ -4,8 +4,7 @@
 // read name, mate fields, CIGAR and alignment end (cram_decode_seq's feature walk, cram_decode.c:1096-1900), the bases (reference span
 // + edits through the substitution matrix) and qualities when the caller supplies the reference spans, the aux tags as stored
 // (cram_decode_aux, :2008-2137), and, after the mate cross-referencing pass (cram_decode_slice_xref, :2140-2307), mate position /
-// reference, template length and the mate bits of the flags.  Not done: MD / NM regeneration (decode_md), RG:Z insertion and the
-// BAM packing of cram_to_bam.
+// reference, template length and the mate bits of the flags; MD:Z / NM are regenerated like the reference's decode_md option does.
 //
 // Codecs (cram/cram_codecs.c): EXTERNAL (:350-410; ITF8 for integer series, bytes for byte series), HUFFMAN (canonical codes,
 // :2641-2930), BETA (:1072-1130), GAMMA (:2546-2568), SUBEXP (:2452-2494), BYTE_ARRAY_LEN (:2937-3010), BYTE_ARRAY_STOP (:3180-3260).
@@ -61,6 +60,7 @@ struct Slice {
     int32_t nref;                         // number of @SQ lines (bounds of RI / NS)
     uint32_t cigar_cap, name_cap, aux_cap;
     const RefSpan *refs; int32_t nrefs;   // reference spans of this slice (none: bases come out as '=' plus the stored edits)
+    int32_t decode_md;                    // fd->decode_md: non-zero = MD:Z / NM are generated for mapped records that do not store them (hts_open's default is -1)
 };
 // Per-record results (arrays of nrec), the CIGAR ops and the read names of the slice
 struct Cols {
@@ -224,7 +224,8 @@ struct Reader {
 
 // cram_decode_seq (cram_decode.c:1096-1900) without MD / NM generation: features -> CIGAR, alignment end, and -- when the caller asked
 // for them -- the bases (reference span + edits) and the qualities; MQ.
-HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint32_t &ncig_total, uint8_t *seq, uint8_t *qual, const RefSpan *ref) {
+HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint32_t &ncig_total, uint8_t *seq, uint8_t *qual, const RefSpan *ref,
+                            uint32_t &naux, int has_md, int has_nm) {
     const Plan *P = R.P;
     const int32_t len = O.len[rec], ref_id = O.ref_id[rec];
     int64_t ref_pos = O.apos[rec] - 1;                                    // 0-based position of the next reference base
@@ -239,6 +240,21 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
     auto copy_ref = [&](int32_t at, int64_t n) { if (seq && n > 0) copy_bytes(seq + at, refb + (ref_pos + 1 - ref_start), (uint32_t)n); };
     auto qual_touch = [&]() { if (qual && !(cf & CF_PRESERVE_QUAL) && len > 0 && qual[0] == 255) for (int32_t i = 0; i < len; i++) qual[i] = 30; };   // "same as htsjdk"
     if (qual && !(cf & CF_PRESERVE_QUAL)) for (int32_t i = 0; i < len; i++) qual[i] = 255;
+    // MD:Z / NM regeneration (decode_md, cram_decode.c:1111-1137): needs the reference and somewhere to put the tags
+    const bool do_md = R.S->decode_md != 0 && O.aux != nullptr;
+    bool decode_md = do_md && ref && ref_id >= 0 && !has_md, decode_nm = do_md && ref && ref_id >= 0 && !has_nm;
+    if (cf & CF_NO_SEQ) decode_md = decode_nm = false;
+    uint32_t nm = 0; int32_t md_dist = 0;
+    const uint32_t aux0 = naux;
+    auto aux_char = [&](uint8_t c) { if (naux >= R.S->aux_cap) { if (!R.err) R.err = ERR_UNSUPPORTED; return; } O.aux[naux++] = c; };
+    auto aux_uint = [&](uint32_t v) { uint8_t t[10]; int k = 0; do { t[k++] = (uint8_t)('0' + v % 10u); v /= 10u; } while (v); while (k) aux_char(t[--k]); };
+    auto md_char = [&](uint8_t c) { if (decode_md) { aux_uint((uint32_t)md_dist); aux_char(c); md_dist = 0; } };      // add_md_char
+    auto ref_at = [&](int64_t p0) -> uint8_t { return refb[p0 + 1 - ref_start]; };                                      // base at 0-based position p0
+    auto md_run = [&](int64_t n) {                                        // n reference bases copied as they are: only an N counts as a mismatch
+        if (!(decode_md || decode_nm)) return;
+        for (int64_t i = 0; i < n; i++) { if (ref_at(ref_pos + i) == 'N') { md_char('N'); nm++; } else md_dist++; }
+    };
+    if (decode_md) { aux_char('M'); aux_char('D'); aux_char('Z'); }
     const int32_t fn = R.ival(S_FN);                                      // a series the walk needs and the map lacks is an error, as in the reference
     {
         for (int32_t f = 0; f < fn && !R.err; f++) {
@@ -259,8 +275,10 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
                             if (ref_pos + rlen > ref_end) { R.err = ERR_MALFORMED; break; }
                             if (len) { copy_ref(seq_pos - 1, rlen); if ((pos - seq_pos) - rlen > 0) fill(seq_pos - 1 + (int32_t)rlen, 'N', (pos - seq_pos) - rlen); }
                         } else if (len) fill(seq_pos - 1, 'N', len - seq_pos + 1);
+                        if (md_dist >= 0) md_dist += pos - seq_pos;
                     } else {
                         if (ref_pos + pos - seq_pos > ref_end) { R.err = ERR_MALFORMED; break; }
+                        md_run(pos - seq_pos);
                         if (len) copy_ref(seq_pos - 1, pos - seq_pos);
                     }
                 }
@@ -281,31 +299,62 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
             case 'X': {
                 flush_unless(C_MATCH);
                 const int32_t base = R.bval(S_BS) & 3;
-                if (seq && pos - 1 < len) {
-                    if (ref_id < 0 || ref_pos >= sq_len || !ref) seq[pos - 1] = P->sm[16 + base];
-                    else {
-                        const uint8_t rc = ref_pos < ref_end ? refb[ref_pos + 1 - ref_start] : (uint8_t)'N';
-                        const int l1 = (rc == 'A' || rc == 'a') ? 0 : (rc == 'C' || rc == 'c') ? 1 : (rc == 'G' || rc == 'g') ? 2 : (rc == 'T' || rc == 't') ? 3 : 4;
-                        seq[pos - 1] = P->sm[4 * l1 + base];
-                    }
+                if (ref_id < 0 || ref_pos >= sq_len || !ref) {
+                    if (seq && pos - 1 < len) seq[pos - 1] = P->sm[16 + base];
+                    if (decode_md || decode_nm) { if (md_dist >= 0 && decode_md) aux_uint((uint32_t)md_dist); md_dist = -1; nm--; }
+                } else {
+                    const uint8_t rc = ref_pos < ref_end ? refb[ref_pos + 1 - ref_start] : (uint8_t)'N';
+                    const int l1 = (rc == 'A' || rc == 'a') ? 0 : (rc == 'C' || rc == 'c') ? 1 : (rc == 'G' || rc == 'g') ? 2 : (rc == 'T' || rc == 't') ? 3 : 4;
+                    if (seq && pos - 1 < len) seq[pos - 1] = P->sm[4 * l1 + base];
+                    md_char(rc);
                 }
+                nm++;
                 cig_op = C_MATCH; cig_len++; seq_pos++; ref_pos++;
                 break;
             }
             case 'D': {
                 flush_unless(C_DEL);
-                { const int32_t v = R.ival(S_DL); if (v < 0) { if (!R.err) R.err = ERR_MALFORMED; break; } cig_op = C_DEL; cig_len += v; ref_pos += v; }
+                {
+                    const int32_t v = R.ival(S_DL);
+                    if (v < 0) { if (!R.err) R.err = ERR_MALFORMED; break; }
+                    if (decode_md || decode_nm) {                         // ^ + the deleted reference bases (cram_decode.c:1417-1448)
+                        if (ref_pos + v > ref_end) { R.err = ERR_MALFORMED; break; }
+                        if (md_dist >= 0 && decode_md) aux_uint((uint32_t)md_dist);
+                        if (ref_pos + v <= sq_len) {
+                            if (decode_md) { aux_char('^'); for (int32_t i = 0; i < v; i++) aux_char(ref_at(ref_pos + i)); md_dist = 0; }
+                            nm += (uint32_t)v;
+                        } else {
+                            if (sq_len >= ref_pos) {
+                                if (decode_md) { aux_char('^'); for (int64_t i = 0; i < sq_len - ref_pos; i++) aux_char(ref_at(ref_pos + i)); aux_uint(0); }
+                                nm += (uint32_t)(sq_len - ref_pos);
+                            }
+                            md_dist = -1;
+                        }
+                    }
+                    cig_op = C_DEL; cig_len += v; ref_pos += v;
+                }
                 break;
             }
             case 'I': {
                 flush_unless(C_INS);
-                { const int32_t n = R.array(P->codec_of[S_IN], sp, room); cig_op = C_INS; cig_len += n; seq_pos += n; }
+                { const int32_t n = R.array(P->codec_of[S_IN], sp, room); cig_op = C_INS; cig_len += n; seq_pos += n; nm += (uint32_t)n; }
                 break;
             }
-            case 'i': { flush_unless(C_INS); const int32_t b = R.bval(S_BA); if (sp) sp[0] = (uint8_t)b; cig_op = C_INS; cig_len++; seq_pos++; break; }
+            case 'i': { flush_unless(C_INS); const int32_t b = R.bval(S_BA); if (sp) sp[0] = (uint8_t)b; cig_op = C_INS; cig_len++; seq_pos++; nm++; break; }
             case 'b': {
                 flush_unless(C_MATCH);
                 const int32_t n = R.array(P->codec_of[S_BB], sp, room);
+                if (decode_md || decode_nm) {                             // every stored base counts as a mismatch (cram_decode.c:1515-1541)
+                    if (md_dist >= 0 && decode_md) aux_uint((uint32_t)md_dist);
+                    int32_t x = 0;
+                    for (; x < n; x++) {
+                        if (x && decode_md) aux_uint(0);
+                        if (ref_pos + x >= sq_len || !ref) { md_dist = -1; break; }
+                        if (decode_md) { if (ref_pos + x >= ref_end) { R.err = ERR_MALFORMED; break; } aux_char(ref_at(ref_pos + x)); }
+                    }
+                    nm += (uint32_t)x;
+                    md_dist = 0;
+                }
                 cig_op = C_MATCH; cig_len += n; seq_pos += n; ref_pos += n;
                 break;
             }
@@ -313,6 +362,11 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
             case 'B': {
                 flush_unless(C_MATCH);
                 const int32_t b = R.bval(S_BA); if (sp) sp[0] = (uint8_t)b;
+                if (decode_md || decode_nm) {                             // cram_decode.c:1593-1610
+                    if (md_dist >= 0 && decode_md) aux_uint((uint32_t)md_dist);
+                    if (ref_pos >= sq_len || !ref) md_dist = -1;
+                    else { if (decode_md) { if (ref_pos >= ref_end) { R.err = ERR_MALFORMED; break; } aux_char(ref_at(ref_pos)); } nm++; md_dist = 0; }
+                }
                 qual_touch();
                 const int32_t q = R.bval(S_QS); if (qp) qp[0] = (uint8_t)q;
                 cig_op = C_MATCH; cig_len++; seq_pos++; ref_pos++;
@@ -346,14 +400,16 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
                         if (ref_pos + rlen > ref_end) R.err = ERR_MALFORMED;
                         else { if (seq_pos - 1 + rlen < len) copy_ref(seq_pos - 1, rlen); if ((len - seq_pos + 1) - rlen > 0) fill(seq_pos - 1 + (int32_t)rlen, 'N', (len - seq_pos + 1) - rlen); }
                     } else if (len - seq_pos + 1 > 0) fill(seq_pos - 1, 'N', len - seq_pos + 1);
+                    if (md_dist >= 0) md_dist += len - seq_pos + 1;
                 } else {
-                    if (len - seq_pos + 1 > 0) { if (ref_pos + len - seq_pos + 1 > ref_end) R.err = ERR_MALFORMED; else copy_ref(seq_pos - 1, len - (seq_pos - 1)); }
+                    if (len - seq_pos + 1 > 0) { if (ref_pos + len - seq_pos + 1 > ref_end) R.err = ERR_MALFORMED; else { md_run(len - (seq_pos - 1)); copy_ref(seq_pos - 1, len - (seq_pos - 1)); } }
                     ref_pos += len - seq_pos + 1;
                 }
             } else if (ref_id >= 0) ref_pos += len - seq_pos + 1;
             flush_unless(C_MATCH); cig_op = C_MATCH; cig_len += len - seq_pos + 1;
         }
     }
+    if (decode_md && md_dist >= 0) aux_uint((uint32_t)md_dist);
     if (cig_len) emit((uint32_t)cig_len, cig_op);
     O.cigar_off[rec] = cig0; O.ncigar[rec] = (int32_t)(ncig_total - cig0);
     O.aend[rec] = ref_pos > O.apos[rec] ? ref_pos : O.apos[rec];
@@ -365,11 +421,19 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
         else for (int32_t i = 0; i < len && !R.err; i++) { const int32_t q = R.bval(S_QS); if (qual) qual[i] = (uint8_t)q; }
     }
     if (cf & CF_NO_SEQ) O.len[rec] = 0;
+    if (decode_md) aux_char(0);                                           // MD:Z: is a NUL-terminated string
+    if (decode_nm) {                                                      // NM in the narrowest unsigned type (cram_decode.c:1884-1908)
+        aux_char('N'); aux_char('M');
+        if (nm <= 0xffu) { aux_char('C'); aux_char((uint8_t)nm); }
+        else if (nm <= 0xffffu) { aux_char('S'); aux_char((uint8_t)nm); aux_char((uint8_t)(nm >> 8)); }
+        else { aux_char('I'); aux_char((uint8_t)nm); aux_char((uint8_t)(nm >> 8)); aux_char((uint8_t)(nm >> 16)); aux_char((uint8_t)(nm >> 24)); }
+    }
+    if (O.aux && !R.err) O.aux_len[rec] += (int32_t)(naux - aux0);
 }
 
 // cram_decode_aux (cram_decode.c:2008-2137): tag list of the record (TL -> dictionary line), then one value per tag.  The values are
 // stored in BAM encoding already; with O.aux the record's tags are written as tag[2] type value ..., else only consumed.
-HGR_FN void decode_aux(Reader &R, const Cols &O, int rec, uint32_t &naux) {
+HGR_FN void decode_aux(Reader &R, const Cols &O, int rec, uint32_t &naux, int &has_md, int &has_nm) {
     const Plan *P = R.P;
     const int32_t tl = R.ival(S_TL);
     if (O.aux) { O.aux_off[rec] = naux; O.aux_len[rec] = 0; }
@@ -379,6 +443,8 @@ HGR_FN void decode_aux(Reader &R, const Cols &O, int rec, uint32_t &naux) {
     for (int32_t t = P->tl_off[tl]; t < P->tl_off[tl + 1] && !R.err; t++) {
         if (++R.work > 16ull * R.S->cigar_cap) { R.err = ERR_UNSUPPORTED; return; }
         const int32_t ci = P->tl_codec[t], tag = P->tl_tag[t];
+        if ((tag >> 8) == (('M' << 8) | 'D')) has_md = 1;                 // stored: not regenerated (cram_decode.c:2044-2047)
+        if ((tag >> 8) == (('N' << 8) | 'M')) has_nm = 1;
         if (ci < 0) { R.err = ERR_MALFORMED; return; }
         uint8_t *out = nullptr; uint32_t cap = 0;
         if (O.aux) {
@@ -393,7 +459,12 @@ HGR_FN void decode_aux(Reader &R, const Cols &O, int rec, uint32_t &naux) {
         if (R.err) return;
         if (O.aux) {
             naux += (uint32_t)n;
-            if (tag == (('c' << 16) | ('F' << 8) | 'C') && n == 1) naux -= 4;     // cF:C only tells the decoder to regenerate MD / NM (cram_decode.c:2107-2118)
+            if (tag == (('c' << 16) | ('F' << 8) | 'C') && n == 1) {          // cF:C is a note to the decoder, not a tag (cram_decode.c:2107-2118)
+                const uint8_t cF = O.aux[naux - 1];
+                naux -= 4;
+                if ((cF & 1) && has_md == 0) has_md = 1;
+                if ((cF & 2) && has_nm == 0) has_nm = 1;
+            }
         }
     }
     if (O.aux) O.aux_len[rec] = (int32_t)(naux - start);
@@ -498,7 +569,8 @@ HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
         } else if (cf & CF_EXPLICIT_TLEN) {
             O.explicit_tlen[rec] = R.ival(S_TS);
         }
-        decode_aux(R, O, rec, naux);
+        int has_md = 0, has_nm = 0;
+        decode_aux(R, O, rec, naux, has_md, has_nm);
         if (R.err) break;
         // room for the bases / qualities of this record (cram_decode.c:2890-2906), and the reference span it aligns to
         uint8_t *seq = nullptr, *qual = nullptr;
@@ -512,12 +584,12 @@ HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
 #endif
             if (at + (uint64_t)len > O.seq_cap) { R.err = ERR_UNSUPPORTED; break; }
             O.seq_off[rec] = at; seq = O.seq + at; qual = O.qual + at;
-            for (int32_t i = 0; i < S->nrefs; i++) if (S->refs[i].ref_id == ref_id) { ref = &S->refs[i]; break; }
-            if (!ref) for (int32_t i = 0; i < len; i++) seq[i] = '=';
         }
+        for (int32_t i = 0; i < S->nrefs; i++) if (S->refs[i].ref_id == ref_id) { ref = &S->refs[i]; break; }
+        if (seq && !ref) for (int32_t i = 0; i < len; i++) seq[i] = '=';
         if (!(bf & BAM_FUNMAP)) {
             if (apos <= 0) { R.err = ERR_MALFORMED; break; }
-            decode_features(R, O, rec, cf, ncig, seq, qual, ref);
+            decode_features(R, O, rec, cf, ncig, seq, qual, ref, naux, has_md, has_nm);
         } else {
             O.cigar_off[rec] = ncig; O.ncigar[rec] = 0; O.aend[rec] = apos; O.mqual[rec] = 0;
             if (len) {

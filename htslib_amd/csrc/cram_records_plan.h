@@ -211,6 +211,7 @@ struct SliceDev {
     uint64_t rec_off, cig_off, name_off, aux_off;
     uint32_t cig_cap, name_cap, aux_cap, pad;
     uint32_t ref_first, nrefs;            // reference spans of the slice in Batch::refs
+    int32_t decode_md, pad2;
 };
 struct Batch {
     std::vector<PlanDev> plans;
@@ -227,7 +228,7 @@ struct Batch {
 // One input slice as the caller hands it over (mirrors hg_cram_slice_blocks / hg_cram_ref_span)
 struct RefIn { int32_t ref_id; int64_t start; const uint8_t *bases; uint32_t len; int64_t sq_len; };
 struct SliceIn { const uint8_t *comp_hdr; uint32_t comp_hdr_len; const uint8_t *slice_hdr; uint32_t slice_hdr_len; const uint8_t *core; uint32_t core_len;
-                 uint32_t nblocks; const int32_t *content_id; const uint8_t *const *data; const uint32_t *len; uint32_t nrefs; const RefIn *refs; };
+                 uint32_t nblocks; const int32_t *content_id; const uint8_t *const *data; const uint32_t *len; uint32_t nrefs; const RefIn *refs; int32_t decode_md; };
 
 inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
     B = Batch();
@@ -275,7 +276,7 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
             ext_bytes += s.len[k];
         }
         d.core_off = (uint32_t)stage(s.core, s.core ? s.core_len : 0); d.core_len = s.core ? s.core_len : 0;
-        d.ref_first = (uint32_t)B.refs.size(); d.nrefs = s.refs ? s.nrefs : 0;
+        d.ref_first = (uint32_t)B.refs.size(); d.nrefs = s.refs ? s.nrefs : 0; d.decode_md = s.decode_md;
         for (uint32_t k = 0; k < d.nrefs; k++) {
             const RefIn &r = s.refs[k];
             B.refs.push_back(RefSpan{r.ref_id, (uint32_t)stage(r.bases, r.len), r.len, 0u, r.start, r.sq_len});

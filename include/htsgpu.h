@@ -377,8 +377,8 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
  *      GOLOMB / GOLOMB_RICE reports HG_BLOCK_EUNSUPPORTED.  Output per record: the cram_record fields that do not need the reference
  *      sequence, after cram_decode_slice_xref -- flags (with the mate bits), cram_flags, ref_id, len, apos, aend, rg, mqual, the
  *      CIGAR (BAM encoding, cram_decode_seq's feature walk), the read name, mate_ref_id, mate_pos, tlen, and -- given the reference
- *      spans -- the bases and qualities (cram_decode_seq's reconstruction, without MD / NM generation), and the aux tags as stored
- *      (cram_decode_aux).  Pinned on the reference's 34 CRAM fixtures against their SAM / BAM twins
+ *      spans -- the bases and qualities (cram_decode_seq's reconstruction), the aux tags as stored (cram_decode_aux) and, with
+ *      decode_md, regenerated MD:Z / NM.  Pinned on the reference's 34 CRAM fixtures against their SAM / BAM twins
  *      (tests/test_cram_records.py).  One wavefront per slice (cram_records.hip). ---- */
 typedef struct hg_cram_slice_blocks {
     const uint8_t *comp_hdr; uint32_t comp_hdr_len;     /* compression header block of the slice's container (slices of one container may share the pointer) */
@@ -387,6 +387,8 @@ typedef struct hg_cram_slice_blocks {
     uint32_t nblocks;                                   /* EXTERNAL blocks (content type 4): */
     const int32_t *content_id; const uint8_t *const *data; const uint32_t *len;
     uint32_t nrefs; const struct hg_cram_ref_span *refs; /* reference bases the slice aligns to (only needed for SEQ; may be 0 / NULL) */
+    int32_t decode_md;                                  /* fd->decode_md: non-zero = regenerate MD:Z / NM for mapped records that do not store them
+                                                           (hts_open sets -1, "auto" = on below CRAM 4); needs refs and the aux output */
 } hg_cram_slice_blocks;
 /* A stretch of one reference sequence, upper case ASCII: what cram_get_ref hands cram_decode_slice (s->ref, ref_start, ref_end), or the
  * slice's embedded-reference block.  start = 1-based position of bases[0]; sq_len = the @SQ LN of that reference. */
@@ -401,7 +403,7 @@ typedef struct hg_cram_record_cols {                    /* arrays of rec_cap ent
                                                            len[r] bytes each at seq_off[r]; all three NULL = not wanted.  seq_cap >= the number
                                                            of bases of the slices (the containers' `bases` header field). */
     uint64_t *aux_off; int32_t *aux_len; uint8_t *aux;  /* the record's tags in BAM encoding (tag[2] type value ...), aux_len[r] bytes at
-                                                           aux_off[r]; all three NULL = not wanted.  As stored: RG / MD / NM are not added. */
+                                                           aux_off[r]; all three NULL = not wanted.  As stored, plus MD:Z / NM when decode_md asks; RG:Z is not added here. */
 } hg_cram_record_cols;
 /* For these slices: the number of records (exact) and WORST-CASE sizes of the CIGAR / name / aux arrays (what a slice could produce
  * given the size of its blocks; typical slices need a few per cent of that).  Host only. */
@@ -422,7 +424,7 @@ int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice
  * from the read-group series.  Only the BAM bytes cross PCIe; they are what bgzf_write / hg_bgzf_deflate take.  rg_names = the @RG IDs
  * in header order; total_bases >= the bases of the slices (sum of the containers' `bases` fields).  rec_off as above; rec_bam_off
  * (optional, records + 1 entries) = where each record starts in bam_out; *bam_bytes = bytes written, or needed when the call returns
- * HG_ENOMEM.  Records of failed slices are left out.  Not done: MD / NM regeneration, names for files written without read names
+ * HG_ENOMEM.  Records of failed slices are left out.  Not done: names for files written without read names
  * (such records get "*"), CIGARs of more than 65535 operations. */
 int hg_cram_decode_bam_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref,
                             const char *const *rg_names, int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap,

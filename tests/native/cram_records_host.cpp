@@ -37,7 +37,7 @@ extern "C" int hgr_host_decode_records(size_t nslices, const hgr::SliceIn *in, i
         P.tl_off = B.tl_off.data() + pd.tl_off_base; P.tl_codec = B.tl_codec.data() + pd.tl_codec_base; P.tl_tag = B.tl_tag.data() + pd.tl_codec_base; P.codecs = B.codecs.data() + pd.codec_base; P.huff = B.huff.data() + pd.huff_base;
         hgr::Slice S; S.data = data.data(); S.blk_off = B.tab.data() + d.tab_off; S.blk_len = S.blk_off + pd.nslots; S.cursor = B.tab.data() + d.tab_off + 2 * pd.nslots;
         S.core_off = d.core_off; S.core_len = d.core_len; S.nrec = d.nrec; S.ref_seq_id = d.ref_seq_id; S.ref_seq_start = d.ref_seq_start; S.nref = nref;
-        S.cigar_cap = d.cig_cap; S.name_cap = d.name_cap; S.aux_cap = d.aux_cap; S.refs = B.refs.data() + d.ref_first; S.nrefs = (int32_t)d.nrefs;
+        S.cigar_cap = d.cig_cap; S.name_cap = d.name_cap; S.aux_cap = d.aux_cap; S.refs = B.refs.data() + d.ref_first; S.nrefs = (int32_t)d.nrefs; S.decode_md = d.decode_md;
         uint32_t totals[3] = {0, 0, 0};
         const uint64_t r0 = d.rec_off;
         hgr::Cols O{out->flags + r0, out->cram_flags + r0, out->ref_id + r0, out->len + r0, out->rg + r0, out->mqual + r0, mate_flags.data() + r0, out->mate_ref_id + r0,
