@@ -123,11 +123,18 @@ __device__ __forceinline__ uint32_t bam_record_bytes(const DevCols &D, uint64_t 
     return 4u + 32u + nl + 1u + 4u * (uint32_t)D.ncigar[r] + (len + 1u) / 2u + len + (uint32_t)D.aux_len[r] + rgb;
 }
 __global__ __launch_bounds__(64)
-void cram_bam_size_kernel(DevTables T, DevCols D, const uint32_t *rg_off, int32_t nrg, uint32_t nslices, const int32_t *status, uint64_t *sizes) {
+void cram_bam_size_kernel(DevTables T, DevCols D, const uint32_t *rg_off, int32_t nrg, uint32_t nslices, int32_t *status, uint64_t *sizes) {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t k = blockIdx.x; k < nslices; k += gridDim.x) {
         const SliceDev d = T.slices[k];
-        for (uint32_t r = lane; r < (uint32_t)d.nrec; r += 64) sizes[d.rec_off + r] = status[k] == 0 ? bam_record_bytes(D, d.rec_off + r, rg_off, nrg) : 0u;
+        bool ok = status[k] == 0;
+        if (ok) {                                                          // what a BAM record cannot hold (bam_set1 / bam_write1 refuse or re-route these)
+            bool bad = false;
+            for (uint32_t r = lane; r < (uint32_t)d.nrec; r += 64) bad |= D.name_len[d.rec_off + r] > 254 || D.ncigar[d.rec_off + r] > 65535 || D.len[d.rec_off + r] < 0;
+            if (__ballot(bad)) { ok = false; if (lane == 0) status[k] = ERR_UNSUPPORTED; }
+        }
+        for (uint32_t r = lane; r < (uint32_t)d.nrec; r += 64) sizes[d.rec_off + r] = ok ? bam_record_bytes(D, d.rec_off + r, rg_off, nrg) : 0u;
+        hg::wave_sync();
     }
 }
 // exclusive prefix sum of n values in place, n + 1 outputs (one workgroup: each thread owns a contiguous piece)
@@ -359,7 +366,8 @@ static int records_impl(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks 
         uint8_t *d_bam = (uint8_t *)ctx->d_scratch[5];
         hipLaunchKernelGGL(hgr::cram_bam_write_kernel, dim3(grid), dim3(64), 0, s, T, D, PK, d_rgn, d_rgo, (int32_t)bam->nrg, (uint32_t)nslices, d_status, d_sz, d_bam);
         ok = hipGetLastError() == hipSuccess && (!total || hipMemcpyAsync(bam->out, d_bam, total, hipMemcpyDeviceToHost, s) == hipSuccess) &&
-             (!bam->rec_bam_off || hipMemcpyAsync(bam->rec_bam_off, d_sz, (B.nrec + 1) * 8, hipMemcpyDeviceToHost, s) == hipSuccess);
+             (!bam->rec_bam_off || hipMemcpyAsync(bam->rec_bam_off, d_sz, (B.nrec + 1) * 8, hipMemcpyDeviceToHost, s) == hipSuccess) &&
+             hipMemcpyAsync(status, d_status, nslices * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
     }
     ok = ok && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
