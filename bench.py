@@ -819,6 +819,62 @@ def op_e2e(run: Run, S: Staged):
     return res
 
 
+def op_records(run: Run, steps: int, slices: int = 256, nrec: int = 4000):
+    """CRAM slices -> uncompressed BAM records on the device (hg_cram_decode_bam_host = cram_decode_slice + cram_to_bam),
+    host entry point, PCIe included.  Synthetic EXTERNAL-only slices as current htslib writes them (htslib_amd/synth_cram.py)."""
+    run.init_device()
+    import numpy as np
+    from htslib_amd import _native as nat, synth_cram
+    eng = nat.Engine(run.local)
+    rng = np.random.default_rng(7)
+    base = [synth_cram.make_slice(rng, nrec, 150) for _ in range(4)]
+    sl = [base[i % 4] for i in range(slices)]
+    keep = []
+    arr = nat.cram_slice_array(sl, keep)
+    bases = slices * nrec * 150 + 4096
+    cap = slices * nrec * 420
+    ts, bam = [], None
+    for _ in range(max(2, steps) + 1):
+        t = time.perf_counter(); bam, rec_off, st = eng.cram_decode_bam(arr, slices, 3, 1, [], bases, cap); ts.append(time.perf_counter() - t)
+    assert (st == 0).all() and int(rec_off[-1]) == slices * nrec
+    t = min(ts[1:])
+    # first record of the stream carries the first read's name
+    assert bytes(bam[36:36 + 8]) == base[0]["truth"][0]["name"]
+    return {"metric": "CRAM record decoding: slices -> uncompressed BAM records (cram_decode_slice + cram_to_bam on the device), M records/s, host entry point incl. PCIe",
+            "value": round(slices * nrec / t / 1e6, 3), "unit": "M records/s", "n_gpus": 1, "steps": max(2, steps), "warmup": 1, "ms_per_step": round(t * 1e3, 2),
+            "higher_is_better": True, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%d slices x %d records x 150 bp, EXTERNAL-only encodings; one serial chain per slice" % (slices, nrec), "bam_GBps": round(len(bam) / t / 1e9, 3),
+                       "parity": "decoder pinned on the reference's 34 CRAM fixtures vs their SAM/BAM twins (tests/test_cram_records.py)"}}
+
+
+def op_fqz(run: Run, steps: int, streams: int = 512):
+    """fqzcomp (CRAM method 7) decode + encode through the host entry points: quality blocks of 2 000 x 150 bp reads."""
+    run.init_device()
+    import numpy as np
+    from htslib_amd import _native as nat
+    eng = nat.Engine(run.local)
+    rng = np.random.default_rng(8)
+    nrec, rl = 2000, 150
+    quals, lens = [], []
+    for _ in range(4):
+        q = np.clip(38 + np.cumsum(rng.integers(-2, 3, nrec * rl)) % 12 - np.tile(np.arange(rl) // 12, nrec), 2, 41).astype(np.uint8)
+        quals.append(q.tobytes()); lens.append(np.full(nrec, rl, np.uint32))
+    datas = [quals[i % 4] for i in range(streams)]
+    args = (datas, [lens[i % 4] for i in range(streams)], [None] * streams, [i % 4 for i in range(streams)])
+    te, td, enc = [], [], None
+    for _ in range(max(2, steps)):
+        t = time.perf_counter(); enc = eng.fqz_encode_host(*args); te.append(time.perf_counter() - t)
+        blocks = [(7, e, len(d)) for e, d in zip(enc, datas)]
+        t = time.perf_counter(); outs, st = eng.cram_uncompress_blocks(blocks); td.append(time.perf_counter() - t)
+    assert (st == 0).all() and outs[0] == datas[0] and outs[-1] == datas[-1]
+    nb = sum(map(len, datas))
+    return {"metric": "fqzcomp (CRAM method 7) decode, plain GB/s through the host entry points (PCIe included)", "value": round(nb / min(td) / 1e9, 3), "unit": "GB/s",
+            "n_gpus": 1, "steps": max(2, steps), "warmup": 0, "ms_per_step": round(min(td) * 1e3, 2), "higher_is_better": True, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%d quality blocks of %d x %d bp; one adaptive chain per block" % (streams, nrec, rl), "encode_GBps": round(nb / min(te) / 1e9, 3),
+                       "ratio": round(sum(map(len, enc)) / nb, 4), "format_parity": "UNPINNED against htscodecs (oracle/fqzcomp_oracle.c)"}}
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -827,7 +883,7 @@ def main():
     ap.add_argument("--gib", type=float, default=10.0, help="plain GiB of synthetic BAM per GPU")
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--workers", type=int, default=0, help="host processes for workload preparation")
-    ap.add_argument("--op", choices=["all", "inflate", "deflate", "rans", "bam", "cram", "e2e"], default="all",
+    ap.add_argument("--op", choices=["all", "inflate", "deflate", "rans", "bam", "cram", "e2e", "records", "fqz"], default="all",
                     help="all (default) = inflate headline (BASELINE configs[1]) + `extra`: deflate (configs[2]), rans (configs[3]), "
                          "cram (configs[4] shape) and the end-to-end bgzf_read / bgzf_write figures, in ONE JSON line; "
                          "a single op prints that op's line alone; bam = SURVEY 8f N1 (record framing + nibble2base)")
@@ -841,7 +897,9 @@ def main():
     run = Run(args)
     ok = True
     out = None
-    if args.op in ("rans", "cram"):
+    if args.op in ("records", "fqz"):
+        out = op_records(run, args.steps, args.slices or 256) if args.op == "records" else op_fqz(run, args.steps, args.slices or 512)
+    elif args.op in ("rans", "cram"):
         if args.op == "rans":
             out, ok = op_rans(run, args.steps, args.warmup, args.slices or 1000)
         else:
@@ -874,6 +932,12 @@ def main():
                 if d: extra["cram_rans_nx16_decode"] = d
                 d, ok2 = op_cram(run, es, 256 if not args.slices else args.slices); ok = ok and ok2
                 if d: extra["cram_slices"] = d
+                if run.rank == 0 and run.world == 1:                         # the "next" rows of SURVEY 8f built this round: small, guarded probes
+                    for key, fn in (("cram_records_to_bam", lambda: op_records(run, 2, 128, 2000)), ("cram_fqzcomp", lambda: op_fqz(run, 2, 256))):
+                        try:
+                            extra[key] = fn()
+                        except Exception as e:
+                            extra[key] = {"error": repr(e)}
                 if out is not None:
                     out["extra"] = extra
     if run.rank == 0 and out is not None:

@@ -102,6 +102,38 @@ lib.hg_cram_compress_blocks_metrics_host.argtypes = [_vp, C.c_size_t, _vp, _vp, 
 lib.hg_cram_compress_blocks_metrics_fqz_host.argtypes = [_vp, C.c_size_t, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
 
 
+class CramSliceBlocks(C.Structure):
+    """hg_cram_slice_blocks"""
+    _fields_ = [("comp_hdr", _vp), ("comp_hdr_len", C.c_uint32), ("slice_hdr", _vp), ("slice_hdr_len", C.c_uint32), ("core", _vp), ("core_len", C.c_uint32),
+                ("nblocks", C.c_uint32), ("content_id", _vp), ("data", _vp), ("len", _vp), ("nrefs", C.c_uint32), ("refs", _vp), ("decode_md", C.c_int32)]
+
+
+class CramRefSpan(C.Structure):
+    """hg_cram_ref_span"""
+    _fields_ = [("ref_id", C.c_int32), ("start", C.c_int64), ("bases", _vp), ("len", C.c_uint32), ("sq_len", C.c_int64)]
+
+
+def cram_slice_array(slices, keep, decode_md=-1, with_refs=True):
+    """slice dicts {"comp_hdr", "slice_hdr", "core", "blocks": [(content id, bytes)], "refs": [(ref id, start, bases, @SQ length)]} -> ctypes array of
+    hg_cram_slice_blocks; `keep` receives the buffers that must stay alive.  Slices of one container may share their compression header bytes object."""
+    import numpy as np
+    arr = (CramSliceBlocks * len(slices))()
+    same = {}
+    for i, s in enumerate(slices):
+        ch = same.setdefault(s["comp_hdr"], C.create_string_buffer(s["comp_hdr"], len(s["comp_hdr"])))
+        sh = C.create_string_buffer(s["slice_hdr"], len(s["slice_hdr"])); co = C.create_string_buffer(s["core"], max(len(s["core"]), 1))
+        bl = [C.create_string_buffer(d, max(len(d), 1)) for _, d in s["blocks"]]
+        ids = np.array([cid for cid, _ in s["blocks"]], dtype=np.int32); lens = np.array([len(d) for _, d in s["blocks"]], dtype=np.uint32)
+        ptrs = (_vp * max(len(bl), 1))(*[C.addressof(x) for x in bl])
+        refs = s.get("refs", []) if with_refs else []
+        rb = [C.create_string_buffer(b, max(len(b), 1)) for _, _, b, _ in refs]
+        ra = (CramRefSpan * max(len(rb), 1))(*[CramRefSpan(t, a, C.addressof(buf), len(b), ln) for (t, a, b, ln), buf in zip(refs, rb)])
+        keep.append((ch, sh, co, bl, ids, lens, ptrs, rb, ra))
+        arr[i] = CramSliceBlocks(C.addressof(ch), len(s["comp_hdr"]), C.addressof(sh), len(s["slice_hdr"]), C.addressof(co), len(s["core"]), len(bl), ids.ctypes.data,
+                                 C.addressof(ptrs), lens.ctypes.data, len(rb), C.addressof(ra), decode_md)
+    return arr
+
+
 class CramMetrics(C.Structure):
     """struct hg_cram_metrics (= the reference's struct cram_metrics)."""
     _fields_ = [("trial", C.c_int), ("next_trial", C.c_int), ("consistency", C.c_int), ("sz", C.c_int * 32),
@@ -392,6 +424,18 @@ class Engine:
         st = np.array(strats, dtype=np.int32)
         check(lib.hg_fqz_encode_host(self._h, ip, il.ctypes.data, slp, st.ctypes.data, n, op, ol.ctypes.data), "hg_fqz_encode_host")
         return [outs[i].raw[:int(ol[i])] for i in range(n)]
+
+    def cram_decode_bam(self, slice_array, nslices, major, nref, rg_names, total_bases, cap):
+        """hg_cram_decode_bam_host on a cram_slice_array: -> (uncompressed BAM bytes as ndarray view, record offsets per slice, status)"""
+        import numpy as np
+        out = np.empty(cap, np.uint8); rec_off = np.zeros(nslices + 1, np.uint64); st = np.full(nslices, 9, np.int32); total = C.c_uint64()
+        rg = [r.encode() if isinstance(r, str) else r for r in rg_names]
+        rgp = (C.c_char_p * max(len(rg), 1))(*rg) if rg else None
+        rc = lib.hg_cram_decode_bam_host(self._h, nslices, C.cast(slice_array, _vp), major, nref, C.cast(rgp, _vp) if rg else None, len(rg), total_bases,
+                                         out.ctypes.data, cap, rec_off.ctypes.data, None, C.byref(total), st.ctypes.data)
+        if rc not in (0, -6):
+            check(rc, "hg_cram_decode_bam_host")
+        return out[:total.value], rec_off, st
 
     def tok3_encode_host(self, datas, use_arith):
         """Tokenise + entropy-code each buffer of NUL-terminated names -> list of CRAM method-8 payloads (b"" = not names)."""

@@ -1,10 +1,17 @@
-"""Synthetic CRAM 3.0 slices of production size for the record decoder (tests / probes): what current htslib writes -- every
+"""Synthetic CRAM 3.0 slices of production size for the record decoder (tests / probes / bench.py): what current htslib writes -- every
 variable series in its own EXTERNAL block, constants as zero-bit HUFFMAN codes, names and inserted / clipped bases as
 BYTE_ARRAY_STOP -- built from reads whose alignment, bases and qualities are known by construction.  This is a WRITER OF TEST
 INPUT, not a restatement of cram_encode_slice; the fixtures of the reference pin the decoder, these slices scale it."""
 import numpy as np
 
-from tests.golden.make_golden_rans import put_itf8
+
+def put_itf8(v):
+    v &= 0xFFFFFFFF
+    if v < 0x80: return bytes([v])
+    if v < 0x4000: return bytes([0x80 | (v >> 8), v & 0xFF])
+    if v < 0x200000: return bytes([0xC0 | (v >> 16), (v >> 8) & 0xFF, v & 0xFF])
+    if v < 0x10000000: return bytes([0xE0 | (v >> 24), (v >> 16) & 0xFF, (v >> 8) & 0xFF, v & 0xFF])
+    return bytes([0xF0 | (v >> 28), (v >> 20) & 0xFF, (v >> 12) & 0xFF, (v >> 4) & 0xFF, v & 0x0F])
 
 SERIES = ["BF", "CF", "RI", "RL", "AP", "RG", "RN", "MF", "NS", "NP", "TS", "NF", "TL", "FN", "FC", "FP", "DL", "BA", "BS", "IN", "SC", "HC", "PD", "RS", "MQ", "QS"]
 BASES = b"ACGT"
@@ -40,7 +47,7 @@ def compression_header():
 
 
 def make_slice(rng, nrec, readlen=100, ref_len=None, unmapped_every=37, detached_every=11):
-    """-> a slice dict in the layout of tests/test_cram_records.load_slices() plus "truth": per record (flag base bits, pos, len, cigar, seq, qual)"""
+    """-> a slice dict in the layout Engine.cram_decode_bam takes (and tests/test_cram_records.load_slices() yields) plus "truth": per record (flag base bits, pos, len, cigar, seq, qual)"""
     ref_len = ref_len or (nrec * 8 + 10 * readlen)
     ref = bytes(BASES[i] for i in rng.integers(0, 4, ref_len))
     comp, ids = compression_header()

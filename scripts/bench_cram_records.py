@@ -9,10 +9,10 @@ from htslib_amd import _native as nat
 from tests import test_cram_records as T
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-SYNTH = int(sys.argv[2]) if len(sys.argv) > 2 else 0            # records per synthetic slice (tests/cram_synth.py); 0 = the range.cram fixtures
+SYNTH = int(sys.argv[2]) if len(sys.argv) > 2 else 0            # records per synthetic slice (htslib_amd/synth_cram.py); 0 = the range.cram fixtures
 eng = nat.Engine(0)
 if SYNTH:
-    from tests import cram_synth
+    from htslib_amd import synth_cram as cram_synth
     rng = np.random.default_rng(5)
     base = [cram_synth.make_slice(rng, SYNTH, 150) for _ in range(4)]
     NREF = 1

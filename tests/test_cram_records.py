@@ -269,10 +269,10 @@ def _check_truth(slices, got):
 
 
 def test_synthetic_slices_of_production_size_on_the_cpu_compile(hostlib):
-    """EXTERNAL-only slices as current htslib writes them (tests/cram_synth.py), 2 000 records each with clips, substitutions, insertions,
+    """EXTERNAL-only slices as current htslib writes them (htslib_amd/synth_cram.py), 2 000 records each with clips, substitutions, insertions,
     deletions, unmapped reads, in-slice and detached mates: names, flags, positions, CIGARs, bases and qualities equal what the generator
     put in."""
-    from tests import cram_synth
+    from htslib_amd import synth_cram as cram_synth
     rng = np.random.default_rng(21)
     slices = [cram_synth.make_slice(rng, 2000, 100), cram_synth.make_slice(rng, 700, 151, unmapped_every=5), cram_synth.make_slice(rng, 1, 50, ref_len=2000)]
     st, got = decode(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, 3, 1)
@@ -282,7 +282,7 @@ def test_synthetic_slices_of_production_size_on_the_cpu_compile(hostlib):
 
 @pytest.mark.gpu
 def test_gpu_synthetic_slices_match_the_cpu_compile(engine, hostlib):
-    from tests import cram_synth
+    from htslib_amd import synth_cram as cram_synth
     bound, dec = _gpu_calls(engine)
     rng = np.random.default_rng(22)
     slices = [cram_synth.make_slice(rng, int(n), 100) for n in (3000, 1, 2, 63, 64, 65, 1500, 10)] + [cram_synth.make_slice(rng, 800, 151, unmapped_every=4)]
