@@ -41,11 +41,12 @@ struct DevCols {
     uint64_t *seq_off; uint8_t *seq, *qual; unsigned long long *seq_pool; uint64_t seq_cap;   // seq == nullptr: bases / qualities not wanted
     uint64_t *aux_off; int32_t *aux_len; uint8_t *aux;                                      // aux == nullptr: not wanted
     int32_t *mate_flags, *mate_line; int64_t *explicit_tlen; uint32_t *coff, *noff, *aoff;   // scratch columns
-    uint32_t *totals;                                                                        // per slice: CIGAR words, name bytes, aux bytes written
+    uint32_t *totals;                                                                        // per slice: CIGAR words, name bytes, aux bytes written, copy jobs noted
+    CopyJob *jobs;                                                                           // deferred bulk copies of all slices (SliceDev::job_off); nullptr = none
 };
 
 // Runs the record loop of slice k (one thread).
-__device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, const SliceDev &d, int32_t nref, uint32_t k) {
+__device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, const SliceDev &d, int32_t nref, uint32_t k, bool defer) {
     const PlanDev &pd = T.plans[d.plan];
     Plan P;
     for (int i = 0; i < S_N; i++) P.codec_of[i] = pd.codec_of[i];
@@ -56,8 +57,9 @@ __device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, 
     S.data = T.data; S.blk_off = T.tab + d.tab_off; S.blk_len = S.blk_off + pd.nslots; S.cursor = T.tab + d.tab_off + 2 * pd.nslots;
     S.core_off = d.core_off; S.core_len = d.core_len; S.nrec = d.nrec; S.ref_seq_id = d.ref_seq_id; S.ref_seq_start = d.ref_seq_start; S.nref = nref;
     S.cigar_cap = d.cig_cap; S.name_cap = d.name_cap; S.aux_cap = d.aux_cap; S.refs = T.refs + d.ref_first; S.nrefs = (int32_t)d.nrefs; S.decode_md = d.decode_md;
-    uint32_t *totals = D.totals + 3 * (size_t)k;
-    totals[0] = totals[1] = totals[2] = 0;
+    uint32_t *totals = D.totals + 4 * (size_t)k;
+    totals[0] = totals[1] = totals[2] = totals[3] = 0;
+    S.jobs = defer && D.jobs ? D.jobs + d.job_off : nullptr; S.job_cap = d.job_cap;
     const uint64_t r0 = d.rec_off;
     Cols O{D.flags + r0, D.cram_flags + r0, D.ref_id + r0, D.len + r0, D.rg + r0, D.mqual + r0, D.mate_flags + r0, D.mate_ref_id + r0, D.mate_line + r0,
            D.ncigar + r0, D.name_len + r0, D.coff + r0, D.noff + r0, D.apos + r0, D.aend + r0, D.mate_pos + r0, D.tlen + r0, D.explicit_tlen + r0,
@@ -76,7 +78,7 @@ void cram_records_pack_kernel(DevTables T, DevCols D, Dense P, uint32_t nslices,
         if (status[k] != 0) continue;
         const SliceDev d = T.slices[k];
         const uint64_t bc = P.base[3 * (size_t)k], bn = P.base[3 * (size_t)k + 1], ba = P.base[3 * (size_t)k + 2];
-        const uint32_t nc = D.totals[3 * (size_t)k], nn = D.totals[3 * (size_t)k + 1], na = D.totals[3 * (size_t)k + 2];
+        const uint32_t nc = D.totals[4 * (size_t)k], nn = D.totals[4 * (size_t)k + 1], na = D.totals[4 * (size_t)k + 2];
         for (uint32_t i = lane; i < nc; i += 64) P.cigar[bc + i] = D.cigar[d.cig_off + i];
         for (uint32_t i = lane; i < nn; i += 64) P.names[bn + i] = D.names[d.name_off + i];
         if (D.aux) for (uint32_t i = lane; i < na; i += 64) P.aux[ba + i] = D.aux[d.aux_off + i];
@@ -98,7 +100,13 @@ void cram_records_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref,
     for (uint32_t k = blockIdx.x; k < nslices; k += gridDim.x) {
         if (pre_status[k] != 0) { if (lane == 0) status[k] = pre_status[k]; continue; }
         const SliceDev d = T.slices[k];
-        if (lane == 0) status[k] = decode_one(T, D, d, nref, k);
+        if (lane == 0) status[k] = decode_one(T, D, d, nref, k, true);
+        hg::wave_sync();
+        if (D.jobs) {                                                      // the bulk copies lane 0 noted, one per lane
+            const uint32_t nj = D.totals[4 * (size_t)k + 3];
+            const CopyJob *J = D.jobs + d.job_off;
+            for (uint32_t j = (uint32_t)lane; j < nj; j += 64) copy_bytes(J[j].dst, J[j].src, J[j].n);
+        }
     }
 }
 __global__ __launch_bounds__(64)
@@ -106,7 +114,7 @@ void cram_records_lane_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t 
     for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < nslices; k += gridDim.x * 64u) {
         if (pre_status[k] != 0) { status[k] = pre_status[k]; continue; }
         const SliceDev d = T.slices[k];
-        status[k] = decode_one(T, D, d, nref, k);
+        status[k] = decode_one(T, D, d, nref, k, false);                   // every lane is a chain of its own here: nothing to hand the copies to
     }
 }
 
@@ -264,7 +272,7 @@ static int records_impl(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks 
     const size_t ocig = carve((B.cig_total ? B.cig_total : 1) * 4), onam = carve(B.name_total ? B.name_total : 1), ost = carve(nslices * 4);
     const bool want_seq = bam || (out->seq && out->qual && out->seq_off);
     const size_t oaux = carve(want_aux ? B.aux_total + 1 : 1);
-    const size_t otot = carve(nslices * 12), obase = carve(nslices * 24);
+    const size_t otot = carve(nslices * 16), obase = carve(nslices * 24);
     const size_t oso = carve(R * 8), oseq = carve(want_seq ? seq_cap + 1 : 1), oqual = carve(want_seq ? seq_cap + 1 : 1), opool = carve(8);
     if ((rc = hg::ensure_scratch(ctx, 0, B.data_bytes + 64)) || (rc = hg::ensure_scratch(ctx, 1, obytes + 64)) || (rc = hg::ensure_scratch(ctx, 2, tbytes + 64))) return rc;
     hipStream_t s = ctx->stream;
@@ -289,10 +297,15 @@ static int records_impl(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks 
     D.seq_pool = (unsigned long long *)(d_out + opool); D.seq_cap = seq_cap;
     if (hipMemsetAsync(d_out + opool, 0, 8, s) != hipSuccess) return HG_ELAUNCH;
     D.totals = (uint32_t *)(d_out + otot);
+    D.jobs = nullptr;
     int32_t *d_status = (int32_t *)(d_out + ost);
     // one wavefront per slice until the chip is full of them several times over, then one slice per lane
     bool lane_mode = nslices >= 1024;                                  // measured at 8192 slices: 19.9 ms per call against 32.6 ms (profiles/r02_cram_records_probe.txt)
     if (const char *m = getenv("HG_CRAM_RECORDS_MODE")) lane_mode = m[0] == 'l';
+    if (!lane_mode && (want_seq || want_aux)) {                           // room for the copies the chain hands over
+        if ((rc = hg::ensure_scratch(ctx, 7, (B.job_total + 1) * sizeof(hgr::CopyJob)))) return rc;
+        D.jobs = (hgr::CopyJob *)ctx->d_scratch[7];
+    }
     if (lane_mode) {
         const unsigned grid = (unsigned)std::min<size_t>((nslices + 63) / 64, (size_t)ctx->cus * 16);
         hipLaunchKernelGGL(hgr::cram_records_lane_kernel, dim3(grid), dim3(64), 0, s, T, D, (uint32_t)nslices, (int32_t)nref, (const int32_t *)(d_tab + parts[7].off), d_status);
@@ -302,15 +315,15 @@ static int records_impl(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks 
     }
     if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
     // pack: totals back, prefix sums on the host, second kernel
-    std::vector<uint32_t> tot(nslices * 3);
+    std::vector<uint32_t> tot(nslices * 4);
     ok = hipMemcpyAsync(status, d_status, nslices * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
-         hipMemcpyAsync(tot.data(), d_out + otot, nslices * 12, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+         hipMemcpyAsync(tot.data(), d_out + otot, nslices * 16, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
     std::vector<uint64_t> base(nslices * 3);
     uint64_t used_c = 0, used_n = 0, used_a = 0;
     for (size_t i = 0; i < nslices; i++) {
         base[3 * i] = used_c; base[3 * i + 1] = used_n; base[3 * i + 2] = used_a;
-        if (status[i] == 0) { used_c += tot[3 * i]; used_n += tot[3 * i + 1]; used_a += want_aux ? tot[3 * i + 2] : 0u; }
+        if (status[i] == 0) { used_c += tot[4 * i]; used_n += tot[4 * i + 1]; used_a += want_aux ? tot[4 * i + 2] : 0u; }
     }
     if (used) { used[0] = used_c; used[1] = used_n; used[2] = used_a; used[3] = 0; }
     if (used_c > cigar_cap || used_n > name_cap || used_a > aux_cap) return HG_ENOMEM;      // the caller's arrays are too small: `used` says what is needed

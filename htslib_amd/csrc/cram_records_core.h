@@ -47,6 +47,11 @@ struct Plan {
     const Codec *codecs;
     const HuffCode *huff;
 };
+// A bulk copy taken off the chain: bases copied from the reference, the qualities of a record, the bases of an unmapped read, long
+// tag values.  None of them is read again while the slice is decoded, so the walk only notes them; they are carried out afterwards --
+// one job per lane on the device.
+struct CopyJob { uint8_t *dst; const uint8_t *src; uint32_t n, pad; };
+
 // A stretch of reference bases the caller supplies for a slice (upper case ASCII; an embedded-reference block is one of these)
 struct RefSpan { int32_t ref_id; uint32_t off, len, pad; int64_t start, sq_len; };   // off into Slice::data; start = 1-based position of the first base; sq_len = @SQ LN
 // One slice: its blocks by slot (offset / length into `data`; length 0xffffffff = block absent), the CORE block, scratch cursors
@@ -59,6 +64,7 @@ struct Slice {
     int64_t ref_seq_start;
     int32_t nref;                         // number of @SQ lines (bounds of RI / NS)
     uint32_t cigar_cap, name_cap, aux_cap;
+    CopyJob *jobs; uint32_t job_cap;      // room for deferred bulk copies (nullptr: copy while walking); the count comes back in totals[3]
     const RefSpan *refs; int32_t nrefs;   // reference spans of this slice (none: bases come out as '=' plus the stored edits)
     int32_t decode_md;                    // fd->decode_md: non-zero = MD:Z / NM are generated for mapped records that do not store them (hts_open's default is -1)
 };
@@ -69,7 +75,7 @@ struct Cols {
     int64_t *apos, *aend, *mate_pos, *tlen, *explicit_tlen;
     uint32_t *cigar;                      // (len << 4 | op), BAM encoding
     uint8_t *names;
-    uint32_t *totals;                     // [0] = cigar ops written, [1] = name bytes written, [2] = aux bytes written
+    uint32_t *totals;                     // [0] = cigar ops written, [1] = name bytes written, [2] = aux bytes written, [3] = copy jobs noted
     uint8_t *aux; uint32_t *aux_off; int32_t *aux_len;    // aux == nullptr: not wanted.  BAM encoding: tag[2] type value, back to back
     // bases and qualities (seq == nullptr: not wanted): len bytes each per record at seq_off[rec], handed out from one pool
     uint8_t *seq, *qual; uint64_t *seq_off; unsigned long long *seq_pool; uint64_t seq_cap;
@@ -100,6 +106,12 @@ struct Reader {
     uint64_t bit;                         // position in the CORE block, MSB first
     uint64_t work;                        // features walked so far: a damaged count with zero-bit codecs must not spin for minutes
     int err;
+    CopyJob *jobs; uint32_t njobs, job_cap;   // jobs == nullptr: copy at once
+
+    HGR_FN void bulk(uint8_t *dst, const uint8_t *src, uint32_t n) {
+        if (jobs && n >= 32u && njobs < job_cap) { jobs[njobs].dst = dst; jobs[njobs].src = src; jobs[njobs].n = n; jobs[njobs].pad = 0; njobs++; }
+        else copy_bytes(dst, src, n);
+    }
 
     // ---- CORE bit stream (get_bit_MSB / get_bits_MSB, cram_codecs.c:73-200) ----
     HGR_FN bool need_bits(uint64_t n) { if (bit + n > (uint64_t)S->core_len * 8u) { if (!err) err = ERR_MALFORMED; return false; } return true; }
@@ -129,7 +141,7 @@ struct Reader {
         if (!slot_ok(s)) return;
         const uint32_t c = S->cursor[s];
         if (n > S->blk_len[s] || c > S->blk_len[s] - n) { if (!err) err = ERR_MALFORMED; return; }
-        if (out) copy_bytes(out, S->data + S->blk_off[s] + c, n);
+        if (out) bulk(out, S->data + S->blk_off[s] + c, n);
         S->cursor[s] = c + n;
     }
 
@@ -237,7 +249,7 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
     auto emit = [&](uint32_t l, int op) { if (ncig_total >= R.S->cigar_cap) { if (!R.err) R.err = ERR_UNSUPPORTED; return; } O.cigar[ncig_total++] = (l << 4) | (uint32_t)op; };
     auto flush_unless = [&](int op) { if (cig_len && cig_op != op) { emit((uint32_t)cig_len, cig_op); cig_len = 0; } };
     auto fill = [&](int32_t at, uint8_t c, int64_t n) { if (seq) for (int64_t i = 0; i < n; i++) seq[at + i] = c; };
-    auto copy_ref = [&](int32_t at, int64_t n) { if (seq && n > 0) copy_bytes(seq + at, refb + (ref_pos + 1 - ref_start), (uint32_t)n); };
+    auto copy_ref = [&](int32_t at, int64_t n) { if (seq && n > 0) R.bulk(seq + at, refb + (ref_pos + 1 - ref_start), (uint32_t)n); };
     auto qual_touch = [&]() { if (qual && !(cf & CF_PRESERVE_QUAL) && len > 0 && qual[0] == 255) for (int32_t i = 0; i < len; i++) qual[i] = 30; };   // "same as htsjdk"
     if (qual && !(cf & CF_PRESERVE_QUAL)) for (int32_t i = 0; i < len; i++) qual[i] = 255;
     // MD:Z / NM regeneration (decode_md, cram_decode.c:1111-1137): needs the reference and somewhere to put the tags
@@ -524,6 +536,7 @@ HGR_FN int xref(const Cols &O, int32_t nrec) {
 // The record loop of cram_decode_slice (cram_decode.c:2553-2967).  Returns 0, ERR_MALFORMED or ERR_UNSUPPORTED.
 HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
     Reader R; R.P = P; R.S = S; R.bit = 0; R.work = 0; R.err = 0;
+    R.jobs = P->qs_seq_orient ? S->jobs : nullptr; R.njobs = 0; R.job_cap = S->job_cap;      // the quality reversal of QO = 0 files reads the record back: no deferral there
     for (int32_t i = 0; i < P->nslots; i++) S->cursor[i] = 0;
     uint32_t ncig = 0, nname = 0, naux = 0;
     int64_t last_apos = S->ref_seq_start;
@@ -608,7 +621,7 @@ HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
         if (qual && !R.err && !P->qs_seq_orient && (O.flags[rec] & BAM_FREVERSE))           // qualities stored in read orientation (cram_decode.c:2957-2965)
             for (int32_t i = 0, j = len - 1; i < j; i++, j--) { const uint8_t t = qual[i]; qual[i] = qual[j]; qual[j] = t; }
     }
-    O.totals[0] = ncig; O.totals[1] = nname; O.totals[2] = naux;
+    O.totals[0] = ncig; O.totals[1] = nname; O.totals[2] = naux; O.totals[3] = R.njobs;
     if (R.err) return R.err;
     return xref(O, S->nrec) ? ERR_MALFORMED : 0;
 }

@@ -212,6 +212,7 @@ struct SliceDev {
     uint32_t cig_cap, name_cap, aux_cap, pad;
     uint32_t ref_first, nrefs;            // reference spans of the slice in Batch::refs
     int32_t decode_md, pad2;
+    uint64_t job_off; uint32_t job_cap, pad3;   // deferred bulk copies (Batch::job_total entries in all)
 };
 struct Batch {
     std::vector<PlanDev> plans;
@@ -221,7 +222,7 @@ struct Batch {
     std::vector<uint32_t> tab;
     std::vector<uint64_t> src_off;        // where each staged buffer goes in the data image, in the order of src_ptr / src_len
     std::vector<const uint8_t *> src_ptr; std::vector<uint32_t> src_len;
-    uint64_t data_bytes = 0, nrec = 0, cig_total = 0, name_total = 0, aux_total = 0;
+    uint64_t data_bytes = 0, nrec = 0, cig_total = 0, name_total = 0, aux_total = 0, job_total = 0;
     std::vector<int32_t> status;          // per slice: 0 = goes to the decoder, else the status already known
 };
 
@@ -291,6 +292,8 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
         // aux: the values are copied out of blocks, 3 bytes of tag + type are added per value; values that cost no bits bounded as above
         d.aux_cap = (uint32_t)std::min<uint64_t>(4ull * (ext_bytes + d.core_len) + 64ull * (uint64_t)sh.nrec + 64u, 0xffffffffull);
         d.aux_off = B.aux_total; B.aux_total += d.aux_cap;
+        d.job_cap = (uint32_t)std::min<uint64_t>(4ull * (uint64_t)sh.nrec + 64u, 0x7fffffffull);     // a few per record; when the room runs out the copy is made at once
+        d.job_off = B.job_total; B.job_total += d.job_cap;
         B.slices.push_back(d);
     }
     if (B.data_bytes > 0xfffffff0ull) return -4;                       // 32-bit offsets into the data image
