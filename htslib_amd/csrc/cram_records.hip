@@ -21,6 +21,9 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdlib.h>
+#include <stdio.h>
+#include <chrono>
+#include <string>
 #include <vector>
 #include "htsgpu.h"
 #include "hg_device.h"
@@ -236,6 +239,18 @@ extern "C" int hg_cram_records_bound(size_t nslices, const hg_cram_slice_blocks 
 }
 
 namespace {
+// HG_CRAM_RECORDS_TIMING=1: phase times of a call on stderr (stream-synchronising, for probes only)
+struct PhaseTimer {
+    bool on; hipStream_t s; std::chrono::steady_clock::time_point t0; std::string log;
+    PhaseTimer(hipStream_t st) : on(getenv("HG_CRAM_RECORDS_TIMING") != nullptr), s(st), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto t = std::chrono::steady_clock::now();
+        char b[96]; snprintf(b, sizeof b, " %s %.1f ms", what, std::chrono::duration<double, std::milli>(t - t0).count()); log += b; t0 = t;
+    }
+    ~PhaseTimer() { if (on) fprintf(stderr, "cram records phases:%s\n", log.c_str()); }
+};
 struct BamSink { const char *const *rg_names; int nrg; uint8_t *out; size_t cap; uint64_t *rec_bam_off; uint64_t *total; };
 }
 static int records_impl(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, size_t rec_cap, size_t cigar_cap,
@@ -276,6 +291,8 @@ static int records_impl(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks 
     const size_t oso = carve(R * 8), oseq = carve(want_seq ? seq_cap + 1 : 1), oqual = carve(want_seq ? seq_cap + 1 : 1), opool = carve(8);
     if ((rc = hg::ensure_scratch(ctx, 0, B.data_bytes + 64)) || (rc = hg::ensure_scratch(ctx, 1, obytes + 64)) || (rc = hg::ensure_scratch(ctx, 2, tbytes + 64))) return rc;
     hipStream_t s = ctx->stream;
+    PhaseTimer PT(s);
+    PT.mark("plan");
     uint8_t *d_data = (uint8_t *)ctx->d_scratch[0], *d_out = (uint8_t *)ctx->d_scratch[1], *d_tab = (uint8_t *)ctx->d_scratch[2];
     bool ok = hg::stage_upload(ctx, B.src_ptr.data(), B.src_len.data(), B.src_off.data(), nullptr, B.src_ptr.size(), B.data_bytes, d_data, s) == HG_OK;
     for (auto &p : parts) if (ok && p.bytes) ok = hipMemcpyAsync(d_tab + p.off, p.src, p.bytes, hipMemcpyHostToDevice, s) == hipSuccess;
@@ -299,6 +316,7 @@ static int records_impl(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks 
     D.totals = (uint32_t *)(d_out + otot);
     D.jobs = nullptr;
     int32_t *d_status = (int32_t *)(d_out + ost);
+    PT.mark("upload");
     // one wavefront per slice until the chip is full of them several times over, then one slice per lane
     bool lane_mode = nslices >= 1024;                                  // measured at 8192 slices: 19.9 ms per call against 32.6 ms (profiles/r02_cram_records_probe.txt)
     if (const char *m = getenv("HG_CRAM_RECORDS_MODE")) lane_mode = m[0] == 'l';
@@ -314,6 +332,7 @@ static int records_impl(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks 
         hipLaunchKernelGGL(hgr::cram_records_kernel, dim3(grid), dim3(64), 0, s, T, D, (uint32_t)nslices, (int32_t)nref, (const int32_t *)(d_tab + parts[7].off), d_status);
     }
     if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
+    PT.mark("record loop");
     // pack: totals back, prefix sums on the host, second kernel
     std::vector<uint32_t> tot(nslices * 4);
     ok = hipMemcpyAsync(status, d_status, nslices * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
@@ -334,6 +353,7 @@ static int records_impl(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks 
     if (hipMemcpyAsync(d_out + obase, base.data(), nslices * 24, hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
     hipLaunchKernelGGL(hgr::cram_records_pack_kernel, dim3((unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 32)), dim3(64), 0, s, T, D, PK, (uint32_t)nslices, d_status);
     if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
+    PT.mark("pack");
     // results back: every column in one copy
     void *dst32[9] = {out->flags, out->cram_flags, out->ref_id, out->len, out->rg, out->mqual, out->mate_ref_id, out->ncigar, out->name_len};
     for (int i = 0; i < 9 && ok; i++) if (dst32[i] && B.nrec) ok = hipMemcpyAsync(dst32[i], d_out + o32[i], B.nrec * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
@@ -356,6 +376,7 @@ static int records_impl(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks 
              (!pool_used || (hipMemcpyAsync(out->seq, d_out + oseq, pool_used, hipMemcpyDeviceToHost, s) == hipSuccess &&
                              hipMemcpyAsync(out->qual, d_out + oqual, pool_used, hipMemcpyDeviceToHost, s) == hipSuccess));
     }
+    PT.mark("columns back");
     if (ok && bam) {                                                     // cram_to_bam on the device: sizes, prefix sum, bytes
         std::vector<uint32_t> rgo((size_t)bam->nrg + 1, 0u); std::vector<unsigned char> rgn;
         for (int i = 0; i < bam->nrg; i++) { const size_t l = strlen(bam->rg_names[i]); rgn.insert(rgn.end(), bam->rg_names[i], bam->rg_names[i] + l); rgo[(size_t)i + 1] = (uint32_t)rgn.size(); }
@@ -373,6 +394,7 @@ static int records_impl(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks 
         uint64_t total = 0;
         ok = ok && hipMemcpyAsync(&total, d_sz + B.nrec, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
         if (!ok) return HG_ELAUNCH;
+        PT.mark("bam sizes + scan");
         if (bam->total) *bam->total = total;
         if (total > bam->cap) return HG_ENOMEM;
         if ((rc = hg::ensure_scratch(ctx, 5, total + 64))) return rc;
@@ -383,6 +405,7 @@ static int records_impl(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks 
              hipMemcpyAsync(status, d_status, nslices * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
     }
     ok = ok && hipStreamSynchronize(s) == hipSuccess;
+    PT.mark("bam write + back");
     if (!ok) return HG_ELAUNCH;
     for (size_t i = 0; i < nslices; i++) if (status[i] != 0) return HG_EBLOCK;
     return HG_OK;

@@ -259,12 +259,21 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
     uint32_t nm = 0; int32_t md_dist = 0;
     const uint32_t aux0 = naux;
     auto aux_char = [&](uint8_t c) { if (naux >= R.S->aux_cap) { if (!R.err) R.err = ERR_UNSUPPORTED; return; } O.aux[naux++] = c; };
-    auto aux_uint = [&](uint32_t v) { uint8_t t[10]; int k = 0; do { t[k++] = (uint8_t)('0' + v % 10u); v /= 10u; } while (v); while (k) aux_char(t[--k]); };
+    auto aux_uint = [&](uint32_t v) { uint32_t div = 1; while (v / div >= 10u) div *= 10u; for (; div; div /= 10u) aux_char((uint8_t)('0' + (v / div) % 10u)); };   // BLOCK_APPEND_UINT
     auto md_char = [&](uint8_t c) { if (decode_md) { aux_uint((uint32_t)md_dist); aux_char(c); md_dist = 0; } };      // add_md_char
     auto ref_at = [&](int64_t p0) -> uint8_t { return refb[p0 + 1 - ref_start]; };                                      // base at 0-based position p0
     auto md_run = [&](int64_t n) {                                        // n reference bases copied as they are: only an N counts as a mismatch
         if (!(decode_md || decode_nm)) return;
-        for (int64_t i = 0; i < n; i++) { if (ref_at(ref_pos + i) == 'N') { md_char('N'); nm++; } else md_dist++; }
+        int64_t i = 0;
+        for (; i + 16 <= n; i += 16) {                                    // 16 bases per round trip; a stretch without N just adds to the distance
+            uint8_t t[16]; bool any = false;
+#pragma unroll
+            for (int k = 0; k < 16; k++) { t[k] = ref_at(ref_pos + i + k); any |= t[k] == 'N'; }
+            if (!any) { md_dist += 16; continue; }
+#pragma unroll
+            for (int k = 0; k < 16; k++) { if (t[k] == 'N') { md_char('N'); nm++; } else md_dist++; }
+        }
+        for (; i < n; i++) { if (ref_at(ref_pos + i) == 'N') { md_char('N'); nm++; } else md_dist++; }
     };
     if (decode_md) { aux_char('M'); aux_char('D'); aux_char('Z'); }
     const int32_t fn = R.ival(S_FN);                                      // a series the walk needs and the map lacks is an error, as in the reference
