@@ -18,7 +18,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define HGR_FN __host__ __device__ inline
+#define HGR_FN __host__ __device__ __forceinline__      /* by-reference counters must stay in registers: an out-of-line call puts them in scratch */
 #else
 #define HGR_FN inline
 #endif
