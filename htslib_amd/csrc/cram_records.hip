@@ -49,13 +49,13 @@ struct DevCols {
 };
 
 // Runs the record loop of slice k (one thread).
-__device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, const SliceDev &d, int32_t nref, uint32_t k, bool defer, uint32_t *tab) {
+__device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, const SliceDev &d, int32_t nref, uint32_t k, bool defer, uint32_t *tab, const Codec *codecs) {
     const PlanDev &pd = T.plans[d.plan];
     Plan P;
     for (int i = 0; i < S_N; i++) P.codec_of[i] = pd.codec_of[i];
     P.sm = &pd.sm[0][0];
     P.rn_included = pd.rn_included; P.ap_delta = pd.ap_delta; P.qs_seq_orient = pd.qs_seq_orient; P.nslots = pd.nslots; P.nTL = pd.nTL;
-    P.tl_off = T.tl_off + pd.tl_off_base; P.tl_codec = T.tl_codec + pd.tl_codec_base; P.tl_tag = T.tl_tag + pd.tl_codec_base; P.codecs = T.codecs + pd.codec_base; P.huff = T.huff + pd.huff_base;
+    P.tl_off = T.tl_off + pd.tl_off_base; P.tl_codec = T.tl_codec + pd.tl_codec_base; P.tl_tag = T.tl_tag + pd.tl_codec_base; P.codecs = codecs; P.huff = T.huff + pd.huff_base;
     Slice S;
     S.data = T.data; S.blk_off = tab; S.blk_len = tab + pd.nslots; S.cursor = tab + 2 * pd.nslots;     // tab: the slice's slot table, in LDS when it fits
     S.core_off = d.core_off; S.core_len = d.core_len; S.nrec = d.nrec; S.ref_seq_id = d.ref_seq_id; S.ref_seq_start = d.ref_seq_start; S.nref = nref;
@@ -105,14 +105,17 @@ void cram_records_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref,
         const SliceDev d = T.slices[k];
         // block offsets / lengths / cursors of the slice: every value read starts with a look at them, so they live in LDS (a global
         // table cost one extra dependent round trip per value)
+        // ... and so do the codec descriptions the container's compression header gave
         __shared__ uint32_t lds_tab[3 * 96];
-        const uint32_t ns = (uint32_t)T.plans[d.plan].nslots;
-        uint32_t *tab = T.tab + d.tab_off;
-        if (ns <= 96u) {
+        __shared__ Codec lds_codecs[192];
+        const PlanDev &pdk = T.plans[d.plan];
+        const uint32_t ns = (uint32_t)pdk.nslots, ncd = pdk.ncodecs;
+        if (ns <= 96u && ncd <= 192u) {
             for (uint32_t i = (uint32_t)lane; i < 3u * ns; i += 64) lds_tab[i] = i < 2u * ns ? T.tab[d.tab_off + i] : 0u;
+            for (uint32_t i = (uint32_t)lane; i < ncd; i += 64) lds_codecs[i] = T.codecs[pdk.codec_base + i];
             hg::wave_sync();
-            if (lane == 0) status[k] = decode_one(T, D, d, nref, k, true, lds_tab);
-        } else if (lane == 0) status[k] = decode_one(T, D, d, nref, k, true, tab);
+            if (lane == 0) status[k] = decode_one(T, D, d, nref, k, true, lds_tab, lds_codecs);
+        } else if (lane == 0) status[k] = decode_one(T, D, d, nref, k, true, T.tab + d.tab_off, T.codecs + pdk.codec_base);
         hg::wave_sync();
         if (D.jobs) {                                                      // the bulk copies lane 0 noted, one per lane
             const uint32_t nj = D.totals[4 * (size_t)k + 3];
@@ -126,7 +129,7 @@ void cram_records_lane_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t 
     for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < nslices; k += gridDim.x * 64u) {
         if (pre_status[k] != 0) { status[k] = pre_status[k]; continue; }
         const SliceDev d = T.slices[k];
-        status[k] = decode_one(T, D, d, nref, k, false, T.tab + d.tab_off);                   // every lane is a chain of its own here: nothing to hand the copies to
+        status[k] = decode_one(T, D, d, nref, k, false, T.tab + d.tab_off, T.codecs + T.plans[d.plan].codec_base);                   // every lane is a chain of its own here: nothing to hand the copies to
     }
 }
 

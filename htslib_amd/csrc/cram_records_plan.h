@@ -202,7 +202,7 @@ inline int parse_slice_header(const uint8_t *b, size_t n, int major, SliceHeader
 
 
 // ---- a batch of slices laid out for the decoder (shared by the device launcher and the CPU test harness) -------------------
-struct PlanDev { int32_t codec_of[S_N]; int32_t rn_included, ap_delta, qs_seq_orient, nslots, nTL; uint32_t tl_off_base, tl_codec_base, codec_base, huff_base; uint8_t sm[5][4]; };
+struct PlanDev { int32_t codec_of[S_N]; int32_t rn_included, ap_delta, qs_seq_orient, nslots, nTL; uint32_t tl_off_base, tl_codec_base, codec_base, huff_base; uint8_t sm[5][4]; uint32_t ncodecs, nhuff; };
 struct SliceDev {
     uint32_t plan, tab_off;               // tab: nslots offsets, nslots lengths, nslots cursors (words) in the block table
     uint32_t core_off, core_len;
@@ -253,7 +253,7 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
                 pi = (int32_t)B.plans.size();
                 PlanDev pd; memcpy(pd.codec_of, H.plan.codec_of, sizeof pd.codec_of);
                 pd.rn_included = H.plan.rn_included; pd.ap_delta = H.plan.ap_delta; pd.qs_seq_orient = H.plan.qs_seq_orient; pd.nslots = H.plan.nslots; pd.nTL = H.plan.nTL;
-                memcpy(pd.sm, H.sm.data(), 20);
+                memcpy(pd.sm, H.sm.data(), 20); pd.ncodecs = (uint32_t)H.codecs.size(); pd.nhuff = (uint32_t)H.huff.size();
                 pd.tl_off_base = (uint32_t)B.tl_off.size(); pd.tl_codec_base = (uint32_t)B.tl_codec.size(); pd.codec_base = (uint32_t)B.codecs.size(); pd.huff_base = (uint32_t)B.huff.size();
                 B.tl_off.insert(B.tl_off.end(), H.tl_off.begin(), H.tl_off.end()); B.tl_codec.insert(B.tl_codec.end(), H.tl_codec.begin(), H.tl_codec.end()); B.tl_tag.insert(B.tl_tag.end(), H.tl_tag.begin(), H.tl_tag.end());
                 B.codecs.insert(B.codecs.end(), H.codecs.begin(), H.codecs.end()); B.huff.insert(B.huff.end(), H.huff.begin(), H.huff.end());
