@@ -49,7 +49,7 @@ struct DevCols {
 };
 
 // Runs the record loop of slice k (one thread).
-__device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, const SliceDev &d, int32_t nref, uint32_t k, bool defer, uint32_t *tab, const Codec *codecs) {
+__device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, const SliceDev &d, int32_t nref, uint32_t k, bool defer, uint32_t *tab, const Codec *codecs, HGR_LDS uint8_t *wbuf, HGR_LDS uint32_t *wpos) {
     const PlanDev &pd = T.plans[d.plan];
     Plan P;
     for (int i = 0; i < S_N; i++) P.codec_of[i] = pd.codec_of[i];
@@ -63,6 +63,7 @@ __device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, 
     uint32_t *totals = D.totals + 4 * (size_t)k;
     totals[0] = totals[1] = totals[2] = totals[3] = 0;
     S.jobs = defer && D.jobs ? D.jobs + d.job_off : nullptr; S.job_cap = d.job_cap;
+    S.wbuf = wbuf; S.wpos = wpos;
     const uint64_t r0 = d.rec_off;
     Cols O{D.flags + r0, D.cram_flags + r0, D.ref_id + r0, D.len + r0, D.rg + r0, D.mqual + r0, D.mate_flags + r0, D.mate_ref_id + r0, D.mate_line + r0,
            D.ncigar + r0, D.name_len + r0, D.coff + r0, D.noff + r0, D.apos + r0, D.aend + r0, D.mate_pos + r0, D.tlen + r0, D.explicit_tlen + r0,
@@ -108,14 +109,16 @@ void cram_records_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref,
         // ... and so do the codec descriptions the container's compression header gave
         __shared__ uint32_t lds_tab[3 * 96];
         __shared__ Codec lds_codecs[192];
+        __shared__ uint32_t lds_win[32 * 97];                               // 128-byte read-ahead window per block (cram_records_core.h, Reader::peek)
+        __shared__ uint32_t lds_wpos[97];
         const PlanDev &pdk = T.plans[d.plan];
         const uint32_t ns = (uint32_t)pdk.nslots, ncd = pdk.ncodecs;
         if (ns <= 96u && ncd <= 192u) {
             for (uint32_t i = (uint32_t)lane; i < 3u * ns; i += 64) lds_tab[i] = i < 2u * ns ? T.tab[d.tab_off + i] : 0u;
             for (uint32_t i = (uint32_t)lane; i < ncd; i += 64) lds_codecs[i] = T.codecs[pdk.codec_base + i];
             hg::wave_sync();
-            if (lane == 0) status[k] = decode_one(T, D, d, nref, k, true, lds_tab, lds_codecs);
-        } else if (lane == 0) status[k] = decode_one(T, D, d, nref, k, true, T.tab + d.tab_off, T.codecs + pdk.codec_base);
+            if (lane == 0) status[k] = decode_one(T, D, d, nref, k, true, lds_tab, lds_codecs, (HGR_LDS uint8_t *)lds_win, (HGR_LDS uint32_t *)lds_wpos);
+        } else if (lane == 0) status[k] = decode_one(T, D, d, nref, k, true, T.tab + d.tab_off, T.codecs + pdk.codec_base, nullptr, nullptr);
         hg::wave_sync();
         if (D.jobs) {                                                      // the bulk copies lane 0 noted, one per lane
             const uint32_t nj = D.totals[4 * (size_t)k + 3];
@@ -129,7 +132,7 @@ void cram_records_lane_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t 
     for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < nslices; k += gridDim.x * 64u) {
         if (pre_status[k] != 0) { status[k] = pre_status[k]; continue; }
         const SliceDev d = T.slices[k];
-        status[k] = decode_one(T, D, d, nref, k, false, T.tab + d.tab_off, T.codecs + T.plans[d.plan].codec_base);                   // every lane is a chain of its own here: nothing to hand the copies to
+        status[k] = decode_one(T, D, d, nref, k, false, T.tab + d.tab_off, T.codecs + T.plans[d.plan].codec_base, nullptr, nullptr);                   // every lane is a chain of its own here: nothing to hand the copies to
     }
 }
 

@@ -17,6 +17,11 @@
 #pragma once
 #include <stdint.h>
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HGR_LDS __attribute__((address_space(3)))      /* the read-ahead windows live in LDS on the device: say so in the type, a generic pointer would make every access a FLAT one */
+#else
+#define HGR_LDS
+#endif
 #if defined(__HIPCC__)
 #define HGR_FN __host__ __device__ __forceinline__      /* by-reference counters must stay in registers: an out-of-line call puts them in scratch */
 #else
@@ -65,6 +70,7 @@ struct Slice {
     int32_t nref;                         // number of @SQ lines (bounds of RI / NS)
     uint32_t cigar_cap, name_cap, aux_cap;
     CopyJob *jobs; uint32_t job_cap;      // room for deferred bulk copies (nullptr: copy while walking); the count comes back in totals[3]
+    HGR_LDS uint8_t *wbuf; HGR_LDS uint32_t *wpos;   // read-ahead windows: 128 * (nslots + 1) bytes and nslots + 1 words (nullptr: read the blocks directly)
     const RefSpan *refs; int32_t nrefs;   // reference spans of this slice (none: bases come out as '=' plus the stored edits)
     int32_t decode_md;                    // fd->decode_md: non-zero = MD:Z / NM are generated for mapped records that do not store them (hts_open's default is -1)
 };
@@ -107,6 +113,30 @@ struct Reader {
     uint64_t work;                        // features walked so far: a damaged count with zero-bit codecs must not spin for minutes
     int err;
     CopyJob *jobs; uint32_t njobs, job_cap;   // jobs == nullptr: copy at once
+    // Read-ahead windows (device, wave mapping: in LDS): WIN bytes of every block -- slot s at wbuf + WIN * s, the CORE block after the
+    // last slot -- so that the values of a series cost one global round trip per WIN bytes, not one per value.  wbuf == nullptr: none.
+    HGR_LDS uint8_t *wbuf; HGR_LDS uint32_t *wpos;
+    enum { WIN = 128 };
+
+    // bytes [c, c + need) of the block that starts at data + off (len bytes, staged on a 16-byte boundary with >= 16 readable bytes of
+    // slack): a pointer INTO THE WINDOW to them, at least `need` (<= 16) valid.  Only called when wbuf != nullptr -- callers keep the
+    // window pointer and the global pointer apart so that neither becomes a generic (FLAT) access on the device.
+    HGR_FN const HGR_LDS uint8_t *win(uint32_t w, uint32_t off, uint32_t len, uint32_t c, uint32_t need) {
+        uint32_t st = wpos[w];
+        if (c < st || c + need > st + (uint32_t)WIN) {
+            st = c & ~3u;
+            const uint32_t lim = (len + 15u) & ~15u;                       // the staged image is readable up to here
+            const uint32_t *src = (const uint32_t *)(S->data + off + st);
+            HGR_LDS uint32_t *dst = (HGR_LDS uint32_t *)(wbuf + (size_t)WIN * w);
+            uint32_t t[WIN / 4];
+#pragma unroll
+            for (int k = 0; k < WIN / 4; k++) t[k] = st + 4u * (uint32_t)k < lim ? src[k] : 0u;   // all loads first: one round trip
+#pragma unroll
+            for (int k = 0; k < WIN / 4; k++) dst[k] = t[k];
+            wpos[w] = st;
+        }
+        return wbuf + (size_t)WIN * w + (c - st);
+    }
 
     HGR_FN void bulk(uint8_t *dst, const uint8_t *src, uint32_t n) {
         if (jobs && n >= 32u && njobs < job_cap) { jobs[njobs].dst = dst; jobs[njobs].src = src; jobs[njobs].n = n; jobs[njobs].pad = 0; njobs++; }
@@ -115,17 +145,23 @@ struct Reader {
 
     // ---- CORE bit stream (get_bit_MSB / get_bits_MSB, cram_codecs.c:73-200) ----
     HGR_FN bool need_bits(uint64_t n) { if (bit + n > (uint64_t)S->core_len * 8u) { if (!err) err = ERR_MALFORMED; return false; } return true; }
-    HGR_FN uint32_t bit1() { const uint32_t b = (S->data[S->core_off + (bit >> 3)] >> (7u - (bit & 7u))) & 1u; bit++; return b; }
+    HGR_FN uint32_t bit1() {
+        const uint32_t at = (uint32_t)(bit >> 3);
+        const uint32_t byte = wbuf ? *win((uint32_t)P->nslots, S->core_off, S->core_len, at, 1) : S->data[S->core_off + at];
+        const uint32_t b = (byte >> (7u - (bit & 7u))) & 1u; bit++; return b;
+    }
     HGR_FN uint32_t bits(int n) { uint32_t v = 0; for (int i = 0; i < n; i++) v = (v << 1) | bit1(); return v; }
 
     // ---- EXTERNAL blocks ----
     HGR_FN bool slot_ok(int32_t s) { if (s < 0 || s >= P->nslots || S->blk_len[s] == 0xffffffffu) { if (!err) err = ERR_MALFORMED; return false; } return true; }
     HGR_FN int32_t ext_itf8(int32_t s) {                          // itf8_get at the cursor (cram_external_decode_int)
         if (!slot_ok(s)) return 0;
-        const uint8_t *p = S->data + S->blk_off[s]; const uint32_t n = S->blk_len[s]; uint32_t c = S->cursor[s];
+        const uint32_t n = S->blk_len[s]; uint32_t c = S->cursor[s];
         if (c >= n) { if (!err) err = ERR_MALFORMED; return 0; }
-        // all five possible bytes are requested at once (one round trip), then the length is read off the first
-        const uint32_t b0 = p[c], b1 = c + 1 < n ? p[c + 1] : 0u, b2 = c + 2 < n ? p[c + 2] : 0u, b3 = c + 3 < n ? p[c + 3] : 0u, b4 = c + 4 < n ? p[c + 4] : 0u;
+        // all five possible bytes at once (from the window, or one round trip), then the length is read off the first
+        uint32_t b0, b1, b2, b3, b4;
+        if (wbuf) { const HGR_LDS uint8_t *p = win((uint32_t)s, S->blk_off[s], n, c, 5); b0 = p[0]; b1 = p[1]; b2 = p[2]; b3 = p[3]; b4 = p[4]; }
+        else { const uint8_t *p = S->data + S->blk_off[s] + c; b0 = p[0]; b1 = c + 1 < n ? p[1] : 0u; b2 = c + 2 < n ? p[2] : 0u; b3 = c + 3 < n ? p[3] : 0u; b4 = c + 4 < n ? p[4] : 0u; }
         const int extra = b0 < 0x80 ? 0 : b0 < 0xc0 ? 1 : b0 < 0xe0 ? 2 : b0 < 0xf0 ? 3 : 4;
         if (c + (uint32_t)extra >= n) { if (!err) err = ERR_MALFORMED; return 0; }
         uint32_t v;
@@ -141,7 +177,8 @@ struct Reader {
         if (!slot_ok(s)) return;
         const uint32_t c = S->cursor[s];
         if (n > S->blk_len[s] || c > S->blk_len[s] - n) { if (!err) err = ERR_MALFORMED; return; }
-        if (out) bulk(out, S->data + S->blk_off[s] + c, n);
+        if (out && n == 1u) out[0] = wbuf ? *win((uint32_t)s, S->blk_off[s], S->blk_len[s], c, 1) : S->data[S->blk_off[s] + c];     // a byte series (FC, BS, BA, QS of a feature)
+        else if (out) bulk(out, S->data + S->blk_off[s] + c, n);
         S->cursor[s] = c + n;
     }
 
@@ -196,13 +233,20 @@ struct Reader {
         const Codec C = P->codecs[ci];
         if (C.kind == E_BYTE_ARRAY_STOP) {                                // cram_byte_array_stop_decode_char
             if (!slot_ok(C.a)) return 0;
-            const uint8_t *p = S->data + S->blk_off[C.a]; const uint32_t n = S->blk_len[C.a]; uint32_t c = S->cursor[C.a], k = 0;
+            const uint32_t n = S->blk_len[C.a]; uint32_t c = S->cursor[C.a], k = 0;
             bool found = false;
             while (c < n && !found) {                                     // 16 bytes per round trip, then the scan runs on registers
                 uint8_t t[16];
                 const uint32_t m = n - c < 16u ? n - c : 16u;
+                if (wbuf) {
+                    const HGR_LDS uint8_t *w = win((uint32_t)C.a, S->blk_off[C.a], n, c, 16);
 #pragma unroll
-                for (int j = 0; j < 16; j++) t[j] = (uint32_t)j < m ? p[c + j] : 0;
+                    for (int j = 0; j < 16; j++) t[j] = (uint32_t)j < m ? w[j] : 0;
+                } else {
+                    const uint8_t *g = S->data + S->blk_off[C.a] + c;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) t[j] = (uint32_t)j < m ? g[j] : 0;
+                }
                 uint32_t j = m;                                           // first stop byte among the m (constant indices: t stays in registers)
 #pragma unroll
                 for (int q = 15; q >= 0; q--) if ((uint32_t)q < m && t[q] == (uint8_t)C.b) j = (uint32_t)q;
@@ -545,6 +589,8 @@ HGR_FN int xref(const Cols &O, int32_t nrec) {
 // The record loop of cram_decode_slice (cram_decode.c:2553-2967).  Returns 0, ERR_MALFORMED or ERR_UNSUPPORTED.
 HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
     Reader R; R.P = P; R.S = S; R.bit = 0; R.work = 0; R.err = 0;
+    R.wbuf = S->wbuf; R.wpos = S->wpos;
+    if (R.wbuf) for (int32_t i = 0; i <= P->nslots; i++) R.wpos[i] = 0xffffff00u;          // windows empty
     R.jobs = P->qs_seq_orient ? S->jobs : nullptr; R.njobs = 0; R.job_cap = S->job_cap;      // the quality reversal of QO = 0 files reads the record back: no deferral there
     for (int32_t i = 0; i < P->nslots; i++) S->cursor[i] = 0;
     uint32_t ncig = 0, nname = 0, naux = 0;
