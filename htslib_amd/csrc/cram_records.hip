@@ -109,8 +109,8 @@ void cram_records_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref,
         // ... and so do the codec descriptions the container's compression header gave
         __shared__ uint32_t lds_tab[3 * 96];
         __shared__ Codec lds_codecs[192];
-        __shared__ uint32_t lds_win[32 * 97];                               // 128-byte read-ahead window per block (cram_records_core.h, Reader::peek)
-        __shared__ uint32_t lds_wpos[97];
+        __shared__ uint32_t lds_win[32 * 98];                               // 128-byte read-ahead window per block (cram_records_core.h, Reader::peek)
+        __shared__ uint32_t lds_wpos[98];
         const PlanDev &pdk = T.plans[d.plan];
         const uint32_t ns = (uint32_t)pdk.nslots, ncd = pdk.ncodecs;
         if (ns <= 96u && ncd <= 192u) {

@@ -70,7 +70,7 @@ struct Slice {
     int32_t nref;                         // number of @SQ lines (bounds of RI / NS)
     uint32_t cigar_cap, name_cap, aux_cap;
     CopyJob *jobs; uint32_t job_cap;      // room for deferred bulk copies (nullptr: copy while walking); the count comes back in totals[3]
-    HGR_LDS uint8_t *wbuf; HGR_LDS uint32_t *wpos;   // read-ahead windows: 128 * (nslots + 1) bytes and nslots + 1 words (nullptr: read the blocks directly)
+    HGR_LDS uint8_t *wbuf; HGR_LDS uint32_t *wpos;   // read-ahead windows: 128 * (nslots + 2) bytes and nslots + 2 words (nullptr: read the blocks directly)
     const RefSpan *refs; int32_t nrefs;   // reference spans of this slice (none: bases come out as '=' plus the stored edits)
     int32_t decode_md;                    // fd->decode_md: non-zero = MD:Z / NM are generated for mapped records that do not store them (hts_open's default is -1)
 };
@@ -116,6 +116,7 @@ struct Reader {
     // Read-ahead windows (device, wave mapping: in LDS): WIN bytes of every block -- slot s at wbuf + WIN * s, the CORE block after the
     // last slot -- so that the values of a series cost one global round trip per WIN bytes, not one per value.  wbuf == nullptr: none.
     HGR_LDS uint8_t *wbuf; HGR_LDS uint32_t *wpos;
+    const RefSpan *win_ref;               // the reference span the last window (index nslots + 1) holds
     enum { WIN = 128 };
 
     // bytes [c, c + need) of the block that starts at data + off (len bytes, staged on a 16-byte boundary with >= 16 readable bytes of
@@ -281,10 +282,10 @@ struct Reader {
 // cram_decode_seq (cram_decode.c:1096-1900) without MD / NM generation: features -> CIGAR, alignment end, and -- when the caller asked
 // for them -- the bases (reference span + edits) and the qualities; MQ.
 HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint32_t &ncig_total, uint8_t *seq, uint8_t *qual, const RefSpan *ref,
-                            uint32_t &naux, int has_md, int has_nm) {
+                            uint32_t &naux, int has_md, int has_nm, int32_t len, int32_t ref_id, int64_t apos, uint32_t aux_stored) {
     const Plan *P = R.P;
-    const int32_t len = O.len[rec], ref_id = O.ref_id[rec];
-    int64_t ref_pos = O.apos[rec] - 1;                                    // 0-based position of the next reference base
+    int64_t ref_pos = apos - 1;                                           // 0-based position of the next reference base (the record's fields come in as
+                                                                          // arguments: reading a column back waits for every store in flight)
     int32_t prev_pos = 0, seq_pos = 1, cig_len = 0, cig_op = C_MATCH;
     const uint32_t cig0 = ncig_total;
     const uint8_t *refb = ref ? R.S->data + ref->off : nullptr;           // refb[p - ref->start] = base at 1-based position p
@@ -305,7 +306,11 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
     auto aux_char = [&](uint8_t c) { if (naux >= R.S->aux_cap) { if (!R.err) R.err = ERR_UNSUPPORTED; return; } O.aux[naux++] = c; };
     auto aux_uint = [&](uint32_t v) { uint32_t div = 1; while (v / div >= 10u) div *= 10u; for (; div; div /= 10u) aux_char((uint8_t)('0' + (v / div) % 10u)); };   // BLOCK_APPEND_UINT
     auto md_char = [&](uint8_t c) { if (decode_md) { aux_uint((uint32_t)md_dist); aux_char(c); md_dist = 0; } };      // add_md_char
-    auto ref_at = [&](int64_t p0) -> uint8_t { return refb[p0 + 1 - ref_start]; };                                      // base at 0-based position p0
+    if (R.wbuf && ref && R.win_ref != ref) { R.wpos[R.P->nslots + 1] = 0xffffff00u; R.win_ref = ref; }   // another reference: its window starts empty
+    auto ref_at = [&](int64_t p0) -> uint8_t {                            // base at 0-based position p0 (through the reference's read-ahead window)
+        const uint32_t at = (uint32_t)(p0 + 1 - ref_start);
+        return R.wbuf ? *R.win((uint32_t)R.P->nslots + 1u, ref->off, ref->len, at, 1) : refb[at];
+    };
     auto md_run = [&](int64_t n) {                                        // n reference bases copied as they are: only an N counts as a mismatch
         if (!(decode_md || decode_nm)) return;
         int64_t i = 0;
@@ -368,7 +373,7 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
                     if (seq && pos - 1 < len) seq[pos - 1] = P->sm[16 + base];
                     if (decode_md || decode_nm) { if (md_dist >= 0 && decode_md) aux_uint((uint32_t)md_dist); md_dist = -1; nm--; }
                 } else {
-                    const uint8_t rc = ref_pos < ref_end ? refb[ref_pos + 1 - ref_start] : (uint8_t)'N';
+                    const uint8_t rc = ref_pos < ref_end ? ref_at(ref_pos) : (uint8_t)'N';
                     const int l1 = (rc == 'A' || rc == 'a') ? 0 : (rc == 'C' || rc == 'c') ? 1 : (rc == 'G' || rc == 'g') ? 2 : (rc == 'T' || rc == 't') ? 3 : 4;
                     if (seq && pos - 1 < len) seq[pos - 1] = P->sm[4 * l1 + base];
                     md_char(rc);
@@ -477,7 +482,7 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
     if (decode_md && md_dist >= 0) aux_uint((uint32_t)md_dist);
     if (cig_len) emit((uint32_t)cig_len, cig_op);
     O.cigar_off[rec] = cig0; O.ncigar[rec] = (int32_t)(ncig_total - cig0);
-    O.aend[rec] = ref_pos > O.apos[rec] ? ref_pos : O.apos[rec];
+    O.aend[rec] = ref_pos > apos ? ref_pos : apos;
     O.mqual[rec] = R.ival(S_MQ);
     if ((cf & CF_PRESERVE_QUAL) && !R.err) {                             // len quality bytes
         if (P->codec_of[S_QS] < 0) { R.err = ERR_MALFORMED; return; }
@@ -493,7 +498,7 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
         else if (nm <= 0xffffu) { aux_char('S'); aux_char((uint8_t)nm); aux_char((uint8_t)(nm >> 8)); }
         else { aux_char('I'); aux_char((uint8_t)nm); aux_char((uint8_t)(nm >> 8)); aux_char((uint8_t)(nm >> 16)); aux_char((uint8_t)(nm >> 24)); }
     }
-    if (O.aux && !R.err) O.aux_len[rec] += (int32_t)(naux - aux0);
+    if (O.aux && !R.err) O.aux_len[rec] = (int32_t)(aux_stored + (naux - aux0));
 }
 
 // cram_decode_aux (cram_decode.c:2008-2137): tag list of the record (TL -> dictionary line), then one value per tag.  The values are
@@ -589,8 +594,8 @@ HGR_FN int xref(const Cols &O, int32_t nrec) {
 // The record loop of cram_decode_slice (cram_decode.c:2553-2967).  Returns 0, ERR_MALFORMED or ERR_UNSUPPORTED.
 HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
     Reader R; R.P = P; R.S = S; R.bit = 0; R.work = 0; R.err = 0;
-    R.wbuf = S->wbuf; R.wpos = S->wpos;
-    if (R.wbuf) for (int32_t i = 0; i <= P->nslots; i++) R.wpos[i] = 0xffffff00u;          // windows empty
+    R.wbuf = S->wbuf; R.wpos = S->wpos; R.win_ref = nullptr;
+    if (R.wbuf) for (int32_t i = 0; i <= P->nslots + 1; i++) R.wpos[i] = 0xffffff00u;      // windows empty (blocks, CORE, reference)
     R.jobs = P->qs_seq_orient ? S->jobs : nullptr; R.njobs = 0; R.job_cap = S->job_cap;      // the quality reversal of QO = 0 files reads the record back: no deferral there
     for (int32_t i = 0; i < P->nslots; i++) S->cursor[i] = 0;
     uint32_t ncig = 0, nname = 0, naux = 0;
@@ -638,6 +643,7 @@ HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
             O.explicit_tlen[rec] = R.ival(S_TS);
         }
         int has_md = 0, has_nm = 0;
+        const uint32_t aux_rec0 = naux;
         decode_aux(R, O, rec, naux, has_md, has_nm);
         if (R.err) break;
         // room for the bases / qualities of this record (cram_decode.c:2890-2906), and the reference span it aligns to
@@ -654,10 +660,11 @@ HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
             O.seq_off[rec] = at; seq = O.seq + at; qual = O.qual + at;
         }
         for (int32_t i = 0; i < S->nrefs; i++) if (S->refs[i].ref_id == ref_id) { ref = &S->refs[i]; break; }
+        if (ref && apos < ref->start) ref = nullptr;                      // the span does not reach back to this record: as if no reference had been given
         if (seq && !ref) for (int32_t i = 0; i < len; i++) seq[i] = '=';
         if (!(bf & BAM_FUNMAP)) {
             if (apos <= 0) { R.err = ERR_MALFORMED; break; }
-            decode_features(R, O, rec, cf, ncig, seq, qual, ref, naux, has_md, has_nm);
+            decode_features(R, O, rec, cf, ncig, seq, qual, ref, naux, has_md, has_nm, len, ref_id, apos, naux - aux_rec0);
         } else {
             O.cigar_off[rec] = ncig; O.ncigar[rec] = 0; O.aend[rec] = apos; O.mqual[rec] = 0;
             if (len) {
@@ -673,7 +680,7 @@ HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
                 else for (int32_t i = 0; i < len && !R.err; i++) { const int32_t q = R.bval(S_QS); if (qual) qual[i] = (uint8_t)q; }
             } else if (qual) for (int32_t i = 0; i < len; i++) qual[i] = 255;
         }
-        if (qual && !R.err && !P->qs_seq_orient && (O.flags[rec] & BAM_FREVERSE))           // qualities stored in read orientation (cram_decode.c:2957-2965)
+        if (qual && !R.err && !P->qs_seq_orient && (bf & BAM_FREVERSE))           // qualities stored in read orientation (cram_decode.c:2957-2965)
             for (int32_t i = 0, j = len - 1; i < j; i++, j--) { const uint8_t t = qual[i]; qual[i] = qual[j]; qual[j] = t; }
     }
     O.totals[0] = ncig; O.totals[1] = nname; O.totals[2] = naux; O.totals[3] = R.njobs;

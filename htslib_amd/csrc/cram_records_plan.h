@@ -241,6 +241,7 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
     for (size_t i = 0; i < n; i++) {
         const SliceIn &s = in[i];
         SliceDev d; memset(&d, 0, sizeof d);
+        d.rec_off = B.nrec;                                               // a slice that fails early holds no records
         SliceHeader sh;
         if (!s.comp_hdr || !s.slice_hdr || parse_slice_header(s.slice_hdr, s.slice_hdr_len, major, sh)) { B.status[i] = -1; B.slices.push_back(d); continue; }
         const auto key = std::make_pair(s.comp_hdr, s.comp_hdr_len);
@@ -282,6 +283,9 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
             const RefIn &r = s.refs[k];
             B.refs.push_back(RefSpan{r.ref_id, (uint32_t)stage(r.bases, r.len), r.len, 0u, r.start, r.sq_len});
         }
+        // a header that claims more records than its blocks could possibly describe (16 per byte) is damage, not data: it must not turn
+        // into a minutes-long walk over constant codecs or into gigabytes of columns
+        if ((uint64_t)sh.nrec > 16ull * (ext_bytes + d.core_len) + 1024ull) { B.status[i] = -3; d.nrec = 0; B.slices.push_back(d); continue; }
         d.rec_off = B.nrec; B.nrec += (uint64_t)sh.nrec;
         // capacities: a read name is copied out of a block, a CIGAR op needs a feature; features that cost no bits at all (constant
         // codecs) are bounded by 4 ops per record on top of one op per byte of the slice

@@ -39,7 +39,7 @@ extern "C" int hgr_host_decode_records(size_t nslices, const hgr::SliceIn *in, i
         hgr::Slice S; S.data = data.data(); S.blk_off = B.tab.data() + d.tab_off; S.blk_len = S.blk_off + pd.nslots; S.cursor = B.tab.data() + d.tab_off + 2 * pd.nslots;
         S.core_off = d.core_off; S.core_len = d.core_len; S.nrec = d.nrec; S.ref_seq_id = d.ref_seq_id; S.ref_seq_start = d.ref_seq_start; S.nref = nref;
         S.cigar_cap = d.cig_cap; S.name_cap = d.name_cap; S.aux_cap = d.aux_cap; S.refs = B.refs.data() + d.ref_first; S.nrefs = (int32_t)d.nrefs; S.decode_md = d.decode_md; S.jobs = jobs.data() + d.job_off; S.job_cap = d.job_cap;
-        std::vector<uint32_t> wbuf32(32 * ((size_t)pd.nslots + 1)), wpos((size_t)pd.nslots + 1);      // the read-ahead windows the device keeps in LDS
+        std::vector<uint32_t> wbuf32(32 * ((size_t)pd.nslots + 2)), wpos((size_t)pd.nslots + 2);      // the read-ahead windows the device keeps in LDS
         S.wbuf = (uint8_t *)wbuf32.data(); S.wpos = wpos.data();
         uint32_t totals[4] = {0, 0, 0, 0};
         const uint64_t r0 = d.rec_off;
