@@ -116,7 +116,6 @@ struct Reader {
     // Read-ahead windows (device, wave mapping: in LDS): WIN bytes of every block -- slot s at wbuf + WIN * s, the CORE block after the
     // last slot -- so that the values of a series cost one global round trip per WIN bytes, not one per value.  wbuf == nullptr: none.
     HGR_LDS uint8_t *wbuf; HGR_LDS uint32_t *wpos;
-    const RefSpan *win_ref;               // the reference span the last window (index nslots + 1) holds
     enum { WIN = 128 };
 
     // bytes [c, c + need) of the block that starts at data + off (len bytes, staged on a 16-byte boundary with >= 16 readable bytes of
@@ -306,11 +305,9 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
     auto aux_char = [&](uint8_t c) { if (naux >= R.S->aux_cap) { if (!R.err) R.err = ERR_UNSUPPORTED; return; } O.aux[naux++] = c; };
     auto aux_uint = [&](uint32_t v) { uint32_t div = 1; while (v / div >= 10u) div *= 10u; for (; div; div /= 10u) aux_char((uint8_t)('0' + (v / div) % 10u)); };   // BLOCK_APPEND_UINT
     auto md_char = [&](uint8_t c) { if (decode_md) { aux_uint((uint32_t)md_dist); aux_char(c); md_dist = 0; } };      // add_md_char
-    if (R.wbuf && ref && R.win_ref != ref) { R.wpos[R.P->nslots + 1] = 0xffffff00u; R.win_ref = ref; }   // another reference: its window starts empty
-    auto ref_at = [&](int64_t p0) -> uint8_t {                            // base at 0-based position p0 (through the reference's read-ahead window)
-        const uint32_t at = (uint32_t)(p0 + 1 - ref_start);
-        return R.wbuf ? *R.win((uint32_t)R.P->nslots + 1u, ref->off, ref->len, at, 1) : refb[at];
-    };
+    // per-base look-ups go straight to the staged reference: a window in LDS was tried and LOST (151 ms against 131 ms for the bench
+    // batch) -- the look-ups of one stretch are independent loads, sixteen per round trip, while every window access is a dependent LDS read
+    auto ref_at = [&](int64_t p0) -> uint8_t { return refb[p0 + 1 - ref_start]; };                                      // base at 0-based position p0
     auto md_run = [&](int64_t n) {                                        // n reference bases copied as they are: only an N counts as a mismatch
         if (!(decode_md || decode_nm)) return;
         int64_t i = 0;
@@ -594,8 +591,8 @@ HGR_FN int xref(const Cols &O, int32_t nrec) {
 // The record loop of cram_decode_slice (cram_decode.c:2553-2967).  Returns 0, ERR_MALFORMED or ERR_UNSUPPORTED.
 HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
     Reader R; R.P = P; R.S = S; R.bit = 0; R.work = 0; R.err = 0;
-    R.wbuf = S->wbuf; R.wpos = S->wpos; R.win_ref = nullptr;
-    if (R.wbuf) for (int32_t i = 0; i <= P->nslots + 1; i++) R.wpos[i] = 0xffffff00u;      // windows empty (blocks, CORE, reference)
+    R.wbuf = S->wbuf; R.wpos = S->wpos;
+    if (R.wbuf) for (int32_t i = 0; i <= P->nslots; i++) R.wpos[i] = 0xffffff00u;          // windows empty (blocks, CORE)
     R.jobs = P->qs_seq_orient ? S->jobs : nullptr; R.njobs = 0; R.job_cap = S->job_cap;      // the quality reversal of QO = 0 files reads the record back: no deferral there
     for (int32_t i = 0; i < P->nslots; i++) S->cursor[i] = 0;
     uint32_t ncig = 0, nname = 0, naux = 0;
