@@ -374,3 +374,21 @@ def test_gpu_cram_to_bam_records(engine):
     small = np.zeros(64, np.uint8)
     rc = nat.lib.hg_cram_decode_bam_host(engine._h, n, C.cast(arr, _vp), 3, f["nref"], None, 0, bases, small.ctypes.data, len(small), rec_off.ctypes.data, None, C.byref(total), st.ctypes.data)
     assert rc == -3 and total.value > 64
+
+
+def test_crai_slice_lines_single_reference_and_unsorted(built):
+    """cram_index_slice: a single-reference slice is indexed from its header alone; a multi-reference slice whose records go backwards on
+    one reference is refused with -2 like the reference ("CRAM file is not sorted by chromosome / position")."""
+    from htslib_amd import _native as nat
+    from htslib_amd.synth_cram import put_itf8
+    buf = C.create_string_buffer(256)
+    hdr = put_itf8(3) + put_itf8(1000) + put_itf8(250) + put_itf8(7) + bytes([0]) + put_itf8(5) + put_itf8(0) + put_itf8(-1) + bytes(16)
+    n = nat.lib.hg_cram_crai_slice(C.cast(C.c_char_p(hdr), _vp), len(hdr), 3, None, None, None, 4096, 17, 999, buf, 256)
+    assert buf.raw[:n] == b"3\t1000\t250\t4096\t17\t999\n"
+    multi = put_itf8(-2) + put_itf8(0) + put_itf8(0) + put_itf8(4) + bytes([0]) + put_itf8(5) + put_itf8(0) + put_itf8(-1) + bytes(16)
+    rid = np.array([0, 0, 1, -1], np.int32); ap = np.array([10, 20, 5, 0], np.int64); ae = np.array([59, 40, 104, 0], np.int64)
+    call = lambda r, a, e, cap=256: nat.lib.hg_cram_crai_slice(C.cast(C.c_char_p(multi), _vp), len(multi), 3, r.ctypes.data, a.ctypes.data, e.ctypes.data, 1, 2, 3, buf, cap)
+    n = call(rid, ap, ae)
+    assert buf.raw[:n] == b"0\t10\t50\t1\t2\t3\n1\t5\t100\t1\t2\t3\n-1\t0\t1\t1\t2\t3\n"          # the span reaches the furthest end of the run, not the last one
+    assert call(rid, np.array([10, 9, 5, 0], np.int64), ae) == -2
+    assert call(rid, ap, ae, cap=20) < 0                                   # the text does not fit
