@@ -1,0 +1,183 @@
+// cram_file_host.hip -- a whole CRAM 2.x / 3.x file to an uncompressed BAM stream: the job of `samtools view -u -b in.cram` without the
+// BGZF layer, as a composition of the pieces of this library.  Host code only (no kernel of its own):
+//   1. the container / block walk of cram_read_container and cram_read_block (reference cram/cram_io.c:3590-3760, 1414-1500): file
+//      definition, file-header container (the SAM header text), data containers = compression header block + slices;
+//   2. every compressed block of the file through hg_cram_uncompress_blocks_crc_host (cram_uncompress_block incl. its CRC check) in ONE
+//      batch;
+//   3. every slice through hg_cram_decode_bam_host (cram_decode_slice + cram_to_bam on the device) in ONE batch;
+//   4. the BAM header of bam_hdr_write (sam.c): magic, the header text, the @SQ names and lengths.
+// The caller supplies the reference sequences the file was written against (or none: bases come out as '=' plus the stored edits, as
+// the reference does with no_ref files); embedded references are taken from the file.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "htsgpu.h"
+#include "hg_internal.h"
+#include "cram_records_plan.h"
+
+namespace {
+
+struct Blk { int32_t method, ctype, cid; uint32_t csz, usz; const uint8_t *data; uint32_t crc_part, crc; size_t out; };   // out: index into the decoded buffers
+struct Sl { size_t hdr; std::vector<size_t> body; int32_t ref_seq_id; int64_t start, span; int32_t embedded; size_t comp; };
+
+uint32_t crc32_small(const uint8_t *p, size_t n) {                      // CRC-32 of a block header (a few bytes): bitwise is enough
+    uint32_t c = 0xffffffffu;
+    for (size_t i = 0; i < n; i++) { c ^= p[i]; for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u))); }
+    return ~c;
+}
+
+}  // namespace
+
+extern "C" int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given, uint8_t *bam_out,
+                                        size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords) {
+    if (!ctx || !cram || !bam_out || !bam_bytes || (nrefs_given && !refs)) return HG_EINVAL;
+    if (cram_len < 26 || memcmp(cram, "CRAM", 4) != 0) return HG_EINVAL;
+    const int major = cram[4];
+    if (major != 2 && major != 3) return HG_BLOCK_EUNSUPPORTED;
+    // ---- 1. walk ----
+    std::vector<Blk> blocks;
+    std::vector<Sl> slices;
+    size_t file_hdr = (size_t)-1;
+    uint64_t bases = 0;
+    hgr::Cursor c{cram + 26, cram + cram_len};
+    while (c.p < c.end) {
+        if (c.end - c.p < 4) return HG_EINVAL;
+        const uint32_t clen = (uint32_t)c.p[0] | (uint32_t)c.p[1] << 8 | (uint32_t)c.p[2] << 16 | (uint32_t)c.p[3] << 24; c.p += 4;
+        (void)c.itf8(); (void)c.itf8(); (void)c.itf8();                  // reference id, start, span of the container
+        const int32_t nrec = c.itf8();
+        if (major >= 3) (void)c.ltf8(); else (void)c.itf8();             // record counter
+        bases += (uint64_t)c.ltf8();
+        const int32_t nblk = c.itf8(), nland = c.itf8();
+        for (int32_t i = 0; i < nland; i++) (void)c.itf8();
+        if (major >= 3) c.p += 4;                                        // CRC of the container header
+        if (c.bad || nblk < 0 || c.p > c.end || (size_t)(c.end - c.p) < clen) return HG_EINVAL;
+        const uint8_t *cend = c.p + clen;
+        hgr::Cursor b{c.p, cend};
+        size_t comp = (size_t)-1;
+        int32_t left_in_slice = 0;
+        for (int32_t k = 0; k < nblk && b.p < b.end; k++) {
+            const uint8_t *h0 = b.p;
+            Blk x; memset(&x, 0, sizeof x);
+            x.method = b.byte(); x.ctype = b.byte(); x.cid = b.itf8(); x.csz = (uint32_t)b.itf8(); x.usz = (uint32_t)b.itf8();
+            if (b.bad || (size_t)(b.end - b.p) < (size_t)x.csz + (major >= 3 ? 4u : 0u)) return HG_EINVAL;
+            x.crc_part = crc32_small(h0, (size_t)(b.p - h0));
+            x.data = b.p; b.p += x.csz;
+            if (major >= 3) { x.crc = (uint32_t)b.p[0] | (uint32_t)b.p[1] << 8 | (uint32_t)b.p[2] << 16 | (uint32_t)b.p[3] << 24; b.p += 4; }
+            blocks.push_back(x);
+            const size_t me = blocks.size() - 1;
+            if (x.ctype == 0 && file_hdr == (size_t)-1) file_hdr = me;                       // FILE_HEADER
+            else if (x.ctype == 1) comp = me;                                              // COMPRESSION_HEADER
+            else if (x.ctype == 2 || x.ctype == 3) { Sl s; s.hdr = me; s.comp = comp; s.ref_seq_id = -1; s.start = s.span = 0; s.embedded = -1; slices.push_back(s); left_in_slice = -1; }
+            else if ((x.ctype == 4 || x.ctype == 5) && !slices.empty() && left_in_slice != 0) slices.back().body.push_back(me);
+        }
+        (void)nrec;
+        c.p = cend;
+    }
+    if (file_hdr == (size_t)-1) return HG_EINVAL;
+    // ---- 2. every block through cram_uncompress_block in one batch ----
+    const size_t nb = blocks.size();
+    std::vector<std::vector<uint8_t>> dec(nb);
+    {
+        std::vector<int32_t> method(nb), status(nb); std::vector<const uint8_t *> in(nb); std::vector<uint32_t> il(nb), ol(nb), part(nb), crc(nb); std::vector<uint8_t *> out(nb);
+        for (size_t i = 0; i < nb; i++) {
+            dec[i].resize(blocks[i].usz ? blocks[i].usz : 1);
+            method[i] = blocks[i].method; in[i] = blocks[i].data; il[i] = blocks[i].csz; ol[i] = blocks[i].usz; out[i] = dec[i].data(); part[i] = blocks[i].crc_part; crc[i] = blocks[i].crc;
+        }
+        const int rc = major >= 3 ? hg_cram_uncompress_blocks_crc_host(ctx, nb, method.data(), in.data(), il.data(), part.data(), crc.data(), out.data(), ol.data(), status.data())
+                                  : hg_cram_uncompress_blocks_host(ctx, nb, method.data(), in.data(), il.data(), out.data(), ol.data(), status.data());
+        if (rc != HG_OK) return rc;                                      // a block that fails (CRC, malformed, bzip2 / lzma) fails the file, like cram_read_slice / cram_decode_slice
+    }
+    // ---- SAM header: text, @SQ, @RG ----
+    const std::vector<uint8_t> &fh = dec[file_hdr];
+    if (fh.size() < 4) return HG_EINVAL;
+    const uint32_t tl = (uint32_t)fh[0] | (uint32_t)fh[1] << 8 | (uint32_t)fh[2] << 16 | (uint32_t)fh[3] << 24;
+    if ((size_t)tl + 4 > fh.size()) return HG_EINVAL;
+    const std::string text((const char *)fh.data() + 4, tl);
+    std::vector<std::string> sq_name, rg_id; std::vector<int64_t> sq_len;
+    for (size_t at = 0; at < text.size();) {
+        size_t e = text.find('\n', at); if (e == std::string::npos) e = text.size();
+        const std::string line = text.substr(at, e - at); at = e + 1;
+        const bool sq = line.compare(0, 3, "@SQ") == 0, rg = line.compare(0, 3, "@RG") == 0;
+        if (!sq && !rg) continue;
+        std::string name; int64_t ln = 0;
+        for (size_t f = 3; f < line.size();) {
+            size_t t = line.find('\t', f + 1); if (t == std::string::npos) t = line.size();
+            const std::string fld = line.substr(f + 1, t - f - 1); f = t;
+            if (sq && fld.compare(0, 3, "SN:") == 0) name = fld.substr(3);
+            if (sq && fld.compare(0, 3, "LN:") == 0) ln = strtoll(fld.c_str() + 3, nullptr, 10);
+            if (rg && fld.compare(0, 3, "ID:") == 0) name = fld.substr(3);
+        }
+        if (sq) { sq_name.push_back(name); sq_len.push_back(ln); } else rg_id.push_back(name);
+    }
+    const int nref = (int)sq_name.size();
+    // ---- BAM header (bam_hdr_write) ----
+    size_t hb = 4 + 4 + text.size() + 4;
+    for (int i = 0; i < nref; i++) hb += 4 + sq_name[(size_t)i].size() + 1 + 4;
+    if (hb > bam_cap) { *bam_bytes = hb; return HG_ENOMEM; }
+    {
+        uint8_t *o = bam_out;
+        auto put32 = [&](uint32_t v) { o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); o[3] = (uint8_t)(v >> 24); o += 4; };
+        memcpy(o, "BAM\1", 4); o += 4;
+        put32((uint32_t)text.size()); memcpy(o, text.data(), text.size()); o += text.size();
+        put32((uint32_t)nref);
+        for (int i = 0; i < nref; i++) { const std::string &nm = sq_name[(size_t)i]; put32((uint32_t)nm.size() + 1); memcpy(o, nm.c_str(), nm.size() + 1); o += nm.size() + 1; put32((uint32_t)sq_len[(size_t)i]); }
+    }
+    // ---- 3. slices -> BAM records ----
+    const size_t ns = slices.size();
+    std::vector<hg_cram_slice_blocks> sb(ns);
+    std::vector<std::vector<int32_t>> ids(ns); std::vector<std::vector<const uint8_t *>> ptr(ns); std::vector<std::vector<uint32_t>> len(ns);
+    std::vector<std::vector<hg_cram_ref_span>> spans(ns);
+    for (size_t i = 0; i < ns; i++) {
+        Sl &s = slices[i];
+        if (s.comp == (size_t)-1) return HG_EINVAL;
+        hgr::SliceHeader sh;
+        const std::vector<uint8_t> &hd = dec[s.hdr];
+        if (hgr::parse_slice_header(hd.data(), blocks[s.hdr].usz, major, sh)) return HG_EINVAL;
+        {   // the embedded-reference block id sits behind the content-id list
+            hgr::Cursor q{hd.data(), hd.data() + blocks[s.hdr].usz};
+            (void)q.itf8(); (void)q.itf8(); (void)q.itf8(); (void)q.itf8(); if (major >= 3) (void)q.ltf8(); else (void)q.itf8(); (void)q.itf8();
+            const int32_t nids = q.itf8();
+            for (int32_t k = 0; k < nids && !q.bad; k++) (void)q.itf8();
+            s.embedded = q.bad ? -1 : q.itf8();
+        }
+        memset(&sb[i], 0, sizeof sb[i]);
+        sb[i].comp_hdr = dec[s.comp].data(); sb[i].comp_hdr_len = blocks[s.comp].usz;
+        sb[i].slice_hdr = hd.data(); sb[i].slice_hdr_len = blocks[s.hdr].usz;
+        size_t taken = 0;
+        for (size_t k : s.body) {
+            if ((int32_t)taken >= sh.nblocks) break;                     // blocks beyond the slice's count belong to nobody
+            taken++;
+            if (blocks[k].ctype == 5) { sb[i].core = dec[k].data(); sb[i].core_len = blocks[k].usz; continue; }
+            ids[i].push_back(blocks[k].cid); ptr[i].push_back(dec[k].data()); len[i].push_back(blocks[k].usz);
+            if (s.embedded >= 0 && blocks[k].cid == s.embedded && sh.ref_seq_id >= 0)
+                spans[i].push_back(hg_cram_ref_span{sh.ref_seq_id, sh.ref_seq_start, dec[k].data(), blocks[k].usz, sh.ref_seq_id < nref ? sq_len[(size_t)sh.ref_seq_id] : (int64_t)blocks[k].usz});
+        }
+        sb[i].nblocks = (uint32_t)ids[i].size(); sb[i].content_id = ids[i].data(); sb[i].data = ptr[i].data(); sb[i].len = len[i].data();
+        if (spans[i].empty()) {                                          // the caller's references: the slice's stretch, or all of them for a multi-reference slice
+            auto whole = [&](int r) { if (r >= 0 && r < nrefs_given && refs[r].bases) spans[i].push_back(hg_cram_ref_span{r, 1, refs[r].bases, (uint32_t)refs[r].len, r < nref ? sq_len[(size_t)r] : (int64_t)refs[r].len}); };
+            if (sh.ref_seq_id >= 0) {
+                const int r = sh.ref_seq_id;
+                if (r < nrefs_given && refs[r].bases && sh.ref_seq_start >= 1 && (uint64_t)sh.ref_seq_start <= refs[r].len) {
+                    const uint64_t avail = refs[r].len - (uint64_t)sh.ref_seq_start + 1;
+                    spans[i].push_back(hg_cram_ref_span{r, sh.ref_seq_start, refs[r].bases + sh.ref_seq_start - 1, (uint32_t)std::min<uint64_t>(avail, 0xffffffffull),
+                                                        r < nref ? sq_len[(size_t)r] : (int64_t)refs[r].len});
+                }
+            } else if (sh.ref_seq_id == -2) for (int r = 0; r < nrefs_given; r++) whole(r);
+        }
+        sb[i].nrefs = (uint32_t)spans[i].size(); sb[i].refs = spans[i].data(); sb[i].decode_md = -1;      // hts_open's default
+    }
+    std::vector<const char *> rgp; for (auto &r : rg_id) rgp.push_back(r.c_str());
+    std::vector<uint64_t> rec_off(ns + 1, 0); std::vector<int32_t> status(ns, 0);
+    uint64_t rec_bytes = 0;
+    int rc = HG_OK;
+    if (ns) {
+        rc = hg_cram_decode_bam_host(ctx, ns, sb.data(), major, nref, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), bases + 4096, bam_out + hb, bam_cap - hb, rec_off.data(), nullptr,
+                                     &rec_bytes, status.data());
+    }
+    *bam_bytes = hb + rec_bytes;
+    if (nrecords) *nrecords = rec_off[ns];
+    return rc;
+}

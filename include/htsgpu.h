@@ -430,6 +430,16 @@ int hg_cram_decode_bam_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blo
                             const char *const *rg_names, int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap,
                             uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes, int32_t *status);
 
+/* A whole CRAM 2.x / 3.x file -> the uncompressed BAM stream `samtools view -u -b` would hand to bgzf_write: the container / block walk
+ * of cram_read_container / cram_read_block on the host, every block through cram_uncompress_block (CRC check included) in one batch,
+ * every slice through hg_cram_decode_bam_host in one batch, and bam_hdr_write's header in front.  refs[i] = reference sequence i of the
+ * @SQ lines in upper case (bases == NULL or nrefs_given == 0: not available -- bases come out as '=' plus the stored edits); embedded
+ * reference blocks are used when a slice has one.  *bam_bytes = bytes written, or needed when the call returns HG_ENOMEM.  A block that
+ * fails to decode fails the file (HG_EBLOCK), as in the reference. */
+typedef struct hg_cram_ref_seq { const uint8_t *bases; uint64_t len; } hg_cram_ref_seq;
+int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given,
+                             uint8_t *bam_out, size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords);
+
 /* The .crai text of one slice (cram_index_slice / cram_index_build_multiref, cram/cram_index.c:632-728): "ref start span container_pos
  * landmark slice_bytes" -- one line from the slice header, or, for a multi-reference slice, one line per run of records on the same
  * reference from the ref_id / apos / aend columns of hg_cram_decode_records_host (the arrays of THIS slice).  Returns the number of

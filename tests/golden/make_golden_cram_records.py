@@ -175,7 +175,9 @@ def main():
         else:
             hd = gzip.open(twin, "rb").read(); hl = struct.unpack_from("<i", hd, 4)[0]
             rgs = [[x[3:] for x in ln.split("\t") if x.startswith("ID:")][0] for ln in hd[8:8 + hl].decode().split("\n") if ln.startswith("@RG")]
-        out.append({"rg": rgs, "crai": crai, "file": "test/" + os.path.relpath(path, REF), "twin": "test/" + os.path.relpath(twin, REF), "major": 3, "nref": len(refs), "slices": slices})
+        full = [[n, pack(bases[n].encode())] for n in refs] if base in FASTA and FASTA[base] != "ce.fa" else None      # whole small references (ce.fa is 1 MB: spans only)
+        if base not in FASTA: full = [[n, pack(TLEN_REF[n].encode())] for n in refs]
+        out.append({"cram": pack(b), "ref_names": refs, "full_refs": full, "rg": rgs, "crai": crai, "file": "test/" + os.path.relpath(path, REF), "twin": "test/" + os.path.relpath(twin, REF), "major": 3, "nref": len(refs), "slices": slices})
     json.dump(out, open(os.path.join(HERE, "cram_records.json"), "w"), separators=(",", ":"))
     print(len(out), "files,", sum(len(f["slices"]) for f in out), "slices,", sum(s["nrec"] for f in out for s in f["slices"]), "records,",
           os.path.getsize(os.path.join(HERE, "cram_records.json")), "bytes")

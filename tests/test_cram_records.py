@@ -392,3 +392,55 @@ def test_crai_slice_lines_single_reference_and_unsorted(built):
     assert buf.raw[:n] == b"0\t10\t50\t1\t2\t3\n1\t5\t100\t1\t2\t3\n-1\t0\t1\t1\t2\t3\n"          # the span reaches the furthest end of the run, not the last one
     assert call(rid, np.array([10, 9, 5, 0], np.int64), ae) == -2
     assert call(rid, ap, ae, cap=20) < 0                                   # the text does not fit
+
+
+@pytest.mark.gpu
+def test_gpu_whole_cram_file_to_bam(engine):
+    """hg_cram_file_to_bam_host: the reference's 34 CRAM files, byte for byte as they sit in its test directory, come back as an
+    uncompressed BAM stream -- header with the file's @SQ lines, then the records of the twin (container walk, block CRCs and
+    decompression, record decoding, cram_to_bam: all inside the one call)."""
+    import struct
+    from htslib_amd import _native as nat
+
+    class RefSeq(C.Structure):
+        _fields_ = [("bases", _vp), ("len", C.c_uint64)]
+
+    nrec = 0
+    for f in json.load(open(GOLD)):
+        cram = unpack(f["cram"])
+        spans = {}
+        for s in f["slices"]:
+            for t, a, b, ln in s["refs"]:
+                spans.setdefault(t, (ln, []))[1].append((a, unpack(b)))
+        seqs = []
+        for i, name in enumerate(f["ref_names"]):
+            if f["full_refs"]: seqs.append(bytearray(unpack(dict(f["full_refs"])[name])))
+            elif i in spans:                                                 # paste the stored stretches into an all-N sequence of the @SQ length
+                sq = bytearray(b"N" * spans[i][0])
+                for a, b in spans[i][1]: sq[a - 1:a - 1 + len(b)] = b
+                seqs.append(sq)
+            else: seqs.append(None)
+        keep = [C.create_string_buffer(bytes(q), len(q)) if q is not None else None for q in seqs]
+        arr = (RefSeq * max(len(seqs), 1))(*[RefSeq(C.addressof(k), len(q)) if k is not None else RefSeq(None, 0) for k, q in zip(keep, seqs)])
+        out = np.zeros(1 << 22, np.uint8); total = C.c_uint64(); n = C.c_uint64()
+        cb = C.create_string_buffer(cram, len(cram))
+        rc = nat.lib.hg_cram_file_to_bam_host(engine._h, C.cast(cb, _vp), len(cram), C.cast(arr, _vp), len(seqs), out.ctypes.data, len(out), C.byref(total), C.byref(n))
+        assert rc == 0, (f["file"], rc)
+        b = bytes(out[:total.value])
+        assert b[:4] == b"BAM\x01"
+        lt = struct.unpack_from("<i", b, 4)[0]; p = 8 + lt
+        nref = struct.unpack_from("<i", b, p)[0]; p += 4
+        names = []
+        for _ in range(nref):
+            ln = struct.unpack_from("<i", b, p)[0]; names.append(b[p + 4:p + 4 + ln - 1].decode()); p += 4 + ln + 4
+        assert names == f["ref_names"], f["file"]
+        recs = _parse_bam_records(b[p:])
+        expect = [e for s in f["slices"] for e in s["expect"]]
+        assert len(recs) == len(expect) == n.value, f["file"]
+        for (g, bn, raw), e in zip(recs, expect):
+            check_against_twin(f["file"], [g], [e]); nrec += 1
+    assert nrec == 230
+    # a damaged file: one payload byte of the last data block flipped -> the block's CRC fails the file
+    bad = bytearray(cram); bad[len(bad) // 2] ^= 0x10
+    cb = C.create_string_buffer(bytes(bad), len(bad))
+    assert nat.lib.hg_cram_file_to_bam_host(engine._h, C.cast(cb, _vp), len(bad), C.cast(arr, _vp), len(seqs), out.ctypes.data, len(out), C.byref(total), C.byref(n)) != 0
