@@ -57,7 +57,7 @@ extern "C" int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t
         const uint8_t *cend = c.p + clen;
         hgr::Cursor b{c.p, cend};
         size_t comp = (size_t)-1;
-        int32_t left_in_slice = 0;
+        bool in_slice = false;                                           // blocks before the container's first slice header belong to no slice
         for (int32_t k = 0; k < nblk && b.p < b.end; k++) {
             const uint8_t *h0 = b.p;
             Blk x; memset(&x, 0, sizeof x);
@@ -70,8 +70,8 @@ extern "C" int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t
             const size_t me = blocks.size() - 1;
             if (x.ctype == 0 && file_hdr == (size_t)-1) file_hdr = me;                       // FILE_HEADER
             else if (x.ctype == 1) comp = me;                                              // COMPRESSION_HEADER
-            else if (x.ctype == 2 || x.ctype == 3) { Sl s; s.hdr = me; s.comp = comp; s.ref_seq_id = -1; s.start = s.span = 0; s.embedded = -1; slices.push_back(s); left_in_slice = -1; }
-            else if ((x.ctype == 4 || x.ctype == 5) && !slices.empty() && left_in_slice != 0) slices.back().body.push_back(me);
+            else if (x.ctype == 2 || x.ctype == 3) { Sl s; s.hdr = me; s.comp = comp; s.ref_seq_id = -1; s.start = s.span = 0; s.embedded = -1; slices.push_back(s); in_slice = true; }
+            else if ((x.ctype == 4 || x.ctype == 5) && in_slice) slices.back().body.push_back(me);
         }
         (void)nrec;
         c.p = cend;
