@@ -444,3 +444,44 @@ def test_gpu_whole_cram_file_to_bam(engine):
     bad = bytearray(cram); bad[len(bad) // 2] ^= 0x10
     cb = C.create_string_buffer(bytes(bad), len(bad))
     assert nat.lib.hg_cram_file_to_bam_host(engine._h, C.cast(cb, _vp), len(bad), C.cast(arr, _vp), len(seqs), out.ctypes.data, len(out), C.byref(total), C.byref(n)) != 0
+
+
+def test_data_parallel_prototype_matches_the_chain_decoder(hostlib, tmp_path):
+    """tests/native/cram_fastpath_proto.cpp: the scan-and-map formulation planned for the device -- whole-block column decodes,
+    prefix sums for every "which item does this record / feature read" question, one independent walk per record -- gives exactly the chain
+    decoder's columns, CIGARs, names, bases and qualities on production-size EXTERNAL-only slices."""
+    from htslib_amd import synth_cram
+    so = str(tmp_path / "libproto.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas", "-o", so, os.path.join(ROOT, "tests", "native", "cram_fastpath_proto.cpp")], check=True)
+    Pr = C.CDLL(so)
+    Pr.hgr_proto_decode_slice.argtypes = [_vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp]
+    rng = np.random.default_rng(31)
+    slices = [synth_cram.make_slice(rng, 3000, 100), synth_cram.make_slice(rng, 500, 151, unmapped_every=3, detached_every=4), synth_cram.make_slice(rng, 1, 40, ref_len=500),
+              synth_cram.make_slice(rng, 257, 75, unmapped_every=0, detached_every=0)]
+    st, chain = decode(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, 3, 1)
+    assert (st == 0).all()
+    for s, want in zip(slices, chain):
+        keep = []
+        arr = _slice_array([s], keep)
+        R = s["nrec"]
+        i32 = {k: np.full(R, -99, np.int32) for k in ("flags", "cram_flags", "ref_id", "len", "rg", "mqual", "mate_ref_id", "ncigar", "name_len")}
+        i64 = {k: np.full(R, -99, np.int64) for k in ("apos", "aend", "mate_pos", "tlen")}
+        u64 = {k: np.zeros(R, np.uint64) for k in ("cigar_off", "name_off")}
+        cigar = np.zeros(R * 16 + 64, np.uint32); names = np.zeros(R * 16 + 64, np.uint8)
+        ncap = sum(len(e[9]) for e in s["expect"]) + 64
+        seq_off = np.zeros(R, np.uint64); seq = np.zeros(ncap, np.uint8); qual = np.zeros(ncap, np.uint8)
+        cols = Cols(*[a.ctypes.data for a in list(i32.values()) + list(i64.values()) + list(u64.values()) + [cigar, names]], seq_off.ctypes.data, seq.ctypes.data, qual.ctypes.data, None, None, None)
+        used = np.zeros(3, np.uint64)
+        rc = Pr.hgr_proto_decode_slice(C.cast(arr, _vp), 3, 1, len(cigar), len(names), ncap, C.byref(cols), used.ctypes.data)
+        assert rc == 0, rc
+        for r in range(R):
+            co, nc = int(u64["cigar_off"][r]), int(i32["ncigar"][r]); no, nl = int(u64["name_off"][r]), int(i32["name_len"][r]); so_, ln = int(seq_off[r]), int(i32["len"][r])
+            q = qual[so_:so_ + ln]
+            got = [bytes(names[no:no + nl]).decode(), int(i32["flags"][r]), int(i32["ref_id"][r]), int(i64["apos"][r]), int(i32["mqual"][r]),
+                   [[int(c >> 4), int(c & 15)] for c in cigar[co:co + nc]], int(i32["mate_ref_id"][r]), int(i64["mate_pos"][r]), int(i64["tlen"][r]),
+                   bytes(seq[so_:so_ + ln]).decode("latin1") if ln else "*", "*" if ln == 0 or (q == 255).all() else bytes((q + 33).astype(np.uint8)).decode("latin1")]
+            assert got == want[r][:11], (r, got, want[r][:11])
+    # a slice the scheme does not cover (CORE-coded series, shared blocks: the reference's fixtures) is handed back
+    fx = [x for _, _, _, x in load_slices()][0]
+    keep = []
+    assert Pr.hgr_proto_decode_slice(C.cast(_slice_array([fx], keep), _vp), 3, 1, 64, 64, 64, C.byref(cols), used.ctypes.data) == -3
