@@ -28,30 +28,40 @@ def _map(entries):
     return put_itf8(len(body)) + body
 
 
-def compression_header():
+TAG_LINES = [b"", b"NMcXZZ", b"NMc"]                               # the tag dictionary of slices made with tags=True
+NM_ID, XZ_ID = 60, 61
+
+
+def compression_header(tags=False):
     """-> (block bytes, {series: content id})"""
     ids = {s: 10 + k for k, s in enumerate(SERIES)}
-    pres = _map([b"RN\x01", b"AP\x01", b"RR\x01", b"SM" + bytes([0x1B] * 5), b"TD" + put_itf8(1) + b"\0"])
+    td = b"".join(t + b"\0" for t in TAG_LINES) if tags else b"\0"
+    pres = _map([b"RN\x01", b"AP\x01", b"RR\x01", b"SM" + bytes([0x1B] * 5), b"TD" + put_itf8(len(td)) + td])
     ext = lambda cid: put_itf8(1) + put_itf8(len(put_itf8(cid))) + put_itf8(cid)
     const = lambda v: put_itf8(3) + (lambda p: put_itf8(len(p)) + p)(put_itf8(1) + put_itf8(v) + put_itf8(1) + put_itf8(0))
     stop = lambda c, cid: put_itf8(5) + (lambda p: put_itf8(len(p)) + p)(bytes([c]) + put_itf8(cid))
     enc = []
     for s in SERIES:
         if s == "RG": e = const(-1)
-        elif s == "TL": e = const(0)
+        elif s == "TL": e = ext(ids[s]) if tags else const(0)
         elif s == "RN": e = stop(0, ids[s])
         elif s in ("IN", "SC"): e = stop(ord("\t"), ids[s])
         else: e = ext(ids[s])
         enc.append(s.encode() + e)
-    return pres + _map(enc) + _map([]), ids
+    tagmap = []
+    if tags:                                                         # NM:c = BYTE_ARRAY_LEN(constant length 1, EXTERNAL bytes); XZ:Z = BYTE_ARRAY_STOP('\t'), value stored with its NUL
+        bal = put_itf8(4) + (lambda p: put_itf8(len(p)) + p)(const(1) + ext(NM_ID))
+        tagmap = [put_itf8((ord("N") << 16) | (ord("M") << 8) | ord("c")) + bal, put_itf8((ord("X") << 16) | (ord("Z") << 8) | ord("Z")) + stop(ord("\t"), XZ_ID)]
+    return pres + _map(enc) + _map(tagmap), ids
 
 
-def make_slice(rng, nrec, readlen=100, ref_len=None, unmapped_every=37, detached_every=11):
+def make_slice(rng, nrec, readlen=100, ref_len=None, unmapped_every=37, detached_every=11, tags=False):
     """-> a slice dict in the layout Engine.cram_decode_bam takes (and tests/test_cram_records.load_slices() yields) plus "truth": per record (flag base bits, pos, len, cigar, seq, qual)"""
     ref_len = ref_len or (nrec * 8 + 10 * readlen)
     ref = bytes(BASES[i] for i in rng.integers(0, 4, ref_len))
-    comp, ids = compression_header()
+    comp, ids = compression_header(tags)
     col = {s: bytearray() for s in SERIES}
+    nm_col, xz_col = bytearray(), bytearray()
     truth, pos_prev, start = [], 1, 1
     positions = np.sort(rng.integers(1, ref_len - 3 * readlen, nrec))
     start = int(positions[0]); pos_prev = start
@@ -71,11 +81,20 @@ def make_slice(rng, nrec, readlen=100, ref_len=None, unmapped_every=37, detached
         if detached:
             col["MF"] += put_itf8(0); col["NS"] += put_itf8(-1); col["NP"] += put_itf8(0); col["TS"] += put_itf8(0)
         elif paired_down: col["NF"] += put_itf8(0)
+        aux = b""
+        if tags:                                                     # the record's tag line and values (cram_decode_aux reads them right after the mate fields)
+            tl = int(rng.integers(0, len(TAG_LINES)))
+            col["TL"] += put_itf8(tl)
+            if tl:
+                v = int(rng.integers(0, 128)); nm_col.append(v); aux += b"NMc" + bytes([v])
+            if tl == 1:
+                z = bytes(rng.integers(65, 91, int(rng.integers(0, 40)), dtype=np.uint8)) + b"\0"
+                xz_col += z + b"\t"; aux += b"XZZ" + z
         qual = rng.integers(2, 41, readlen).astype(np.uint8).tobytes()
         if unmapped:
             seq = bytes(BASES[i] for i in rng.integers(0, 4, readlen))
             col["BA"] += seq; col["QS"] += qual
-            truth.append({"flag": flag, "pos": pos, "cigar": [], "seq": seq, "qual": qual, "down": False, "name": name})
+            truth.append({"flag": flag, "pos": pos, "cigar": [], "seq": seq, "qual": qual, "down": False, "name": name, "aux": aux})
             continue
         # features: a leading soft clip, then substitutions / one insertion / one deletion at increasing read positions
         feats, cigar, seq, rp, sp = [], [], bytearray(), pos, 1                # rp: reference position, sp: read position (1-based)
@@ -112,9 +131,10 @@ def make_slice(rng, nrec, readlen=100, ref_len=None, unmapped_every=37, detached
             elif code == ord("X"): col["BS"].append(val)
             else: col["DL"] += put_itf8(val)
         col["MQ"] += put_itf8(int(rng.integers(0, 61))); col["QS"] += qual
-        truth.append({"flag": flag, "pos": pos, "cigar": [c[:] for c in cigar], "seq": bytes(seq), "qual": qual, "down": bool(paired_down), "name": name})
+        truth.append({"flag": flag, "pos": pos, "cigar": [c[:] for c in cigar], "seq": bytes(seq), "qual": qual, "down": bool(paired_down), "name": name, "aux": aux})
     sh = put_itf8(0) + put_itf8(start) + put_itf8(ref_len - start) + put_itf8(nrec) + _ltf8(0) + put_itf8(len(SERIES) + 1)
     blocks = [(ids[s], bytes(col[s])) for s in SERIES if len(col[s])]
+    if tags: blocks += [(NM_ID, bytes(nm_col)), (XZ_ID, bytes(xz_col))]
     sh += put_itf8(len(blocks)) + b"".join(put_itf8(cid) for cid, _ in blocks) + put_itf8(-1) + bytes(16)
     return {"comp_hdr": comp, "slice_hdr": sh, "core": b"", "blocks": blocks, "nrec": nrec, "refs": [(0, 1, ref, ref_len)], "truth": truth,
             "expect": [[t["name"].decode(), 0, 0, 0, 0, [], 0, 0, 0, t["seq"].decode()] for t in truth]}

@@ -5,8 +5,9 @@
 // column, against the pinned chain decoder (cram_records_core.h) on synthetic production-size slices.
 //
 // Eligible slices: every series a record reads is EXTERNAL in a block no other series reads, a zero-bit HUFFMAN constant, or
-// BYTE_ARRAY_STOP over such a block; read names present in every record (RN = 1); no tags (TL constant, empty line).  Anything else
-// returns -3 and stays with the chain decoder.
+// BYTE_ARRAY_STOP over such a block; read names present in every record (RN = 1); tag values BYTE_ARRAY_LEN (constant or EXTERNAL
+// length, EXTERNAL bytes) or BYTE_ARRAY_STOP over blocks of their own.  Anything else returns -3 and stays with the chain decoder.
+// MD / NM regeneration is not part of the prototype (compare with decode_md = 0).
 #include <stdint.h>
 #include <string.h>
 #include <vector>
@@ -31,15 +32,16 @@ struct out_cols {            // = record_cols of cram_records_host.cpp
 
 }  // namespace
 
-extern "C" int hgr_proto_decode_slice(const SliceIn *in, int major, int nref, size_t cigar_cap, size_t name_cap, size_t seq_cap, const out_cols *out, uint64_t *used /* cigar, names, seq */) {
+extern "C" int hgr_proto_decode_slice(const SliceIn *in, int major, int nref, size_t cigar_cap, size_t name_cap, size_t seq_cap, size_t aux_cap, const out_cols *out,
+                                      uint64_t *used /* cigar, names, seq, aux */) {
     PlanHost H; SliceHeader sh;
     if (plan_from_compression_header(H, in->comp_hdr, in->comp_hdr_len) || parse_slice_header(in->slice_hdr, in->slice_hdr_len, major, sh)) return -1;
     const Plan &P = H.plan;
-    if (!P.rn_included || sh.ref_seq_id == -2 || P.nTL != 1 || H.tl_off[1] != 0) return -3;
+    if (!P.rn_included || sh.ref_seq_id == -2) return -3;
     // ---- eligibility + STEP 1: whole-block column decodes (hg_cram_itf8_decode_dev / hg_cram_byte_array_stop_dev on the device) ----
     auto block = [&](int32_t slot, const uint8_t *&p, uint32_t &n) { p = nullptr; n = 0; for (uint32_t k = 0; k < in->nblocks; k++) if (in->content_id[k] == H.slot_id[(size_t)slot]) { p = in->data[k]; n = in->len[k]; } };
     std::vector<int> slot_users(H.slot_id.size(), 0);
-    static const int ints[] = {S_BF, S_CF, S_RL, S_AP, S_RG, S_MF, S_NS, S_NP, S_TS, S_NF, S_TL, S_FN, S_FP, S_DL, S_HC, S_PD, S_RS, S_MQ};
+    static const int ints[] = {S_BF, S_CF, S_RL, S_AP, S_RG, S_MF, S_NS, S_NP, S_TS, S_NF, S_TL, S_FN, S_FP, S_DL, S_HC, S_PD, S_RS, S_MQ};     // TL: which tag line a record has
     static const int bytes_[] = {S_FC, S_BS, S_BA, S_QS};
     static const int arrays[] = {S_RN, S_IN, S_SC};
     Col col[S_N];
@@ -70,6 +72,7 @@ extern "C" int hgr_proto_decode_slice(const SliceIn *in, int major, int nref, si
         for (uint32_t i = 0; i < col[s].nbytes; i++) if (col[s].bytes[i] == (uint8_t)C.b) col[s].item.push_back(i + 1);   // MAP + compaction
     }
     for (int u : slot_users) if (u > 1) return -3;                       // a shared block interleaves its series record by record: chain decoder
+    used[3] = 0;
     auto I = [&](int s, size_t i) -> int32_t { return col[s].konst ? col[s].k : col[s].v.at(i); };
     const size_t n = (size_t)sh.nrec;
     // ---- STEP 2: per record, from BF / CF alone ----
@@ -180,6 +183,71 @@ extern "C" int hgr_proto_decode_slice(const SliceIn *in, int major, int nref, si
         if (a + (uint64_t)(b - a) > name_cap) return -5;
         memcpy(out->names + a, col[S_RN].bytes + a, b - a);              // names keep their block offsets: no scan needed
         out->name_off[r] = a; out->name_len[r] = (int32_t)(b - a); noff[r] = a; names_used = b;
+    }
+    // ---- STEP 5b: tags.  Per tag (a codec of the tag encoding map): which records carry it (their TL line lists it) -> scan -> item index;
+    //      where item k of the tag's block starts: k * L (constant length), a scan over its length column, or the stop-byte split ----
+    {
+        struct Tag { int32_t ci; std::vector<uint64_t> at; const uint8_t *bytes; };      // at: n_items + 1 offsets into bytes; STOP items end one byte before the next start
+        std::vector<Tag> tags; std::vector<int> stopped;
+        std::vector<int32_t> tag_of((size_t)H.tl_codec.size(), -1);
+        for (size_t t = 0; t < H.tl_codec.size(); t++) {
+            const int32_t ci = H.tl_codec[t];
+            if (ci < 0) return -1;
+            size_t k = 0; while (k < tags.size() && tags[k].ci != ci) k++;
+            if (k == tags.size()) {
+                const Codec &C = H.codecs[(size_t)ci];
+                Tag T; T.ci = ci; T.bytes = nullptr; uint32_t nbytes = 0;
+                if (C.kind == E_BYTE_ARRAY_STOP) {
+                    if (++slot_users[(size_t)C.a] > 1) return -3;
+                    block(C.a, T.bytes, nbytes);
+                    T.at.push_back(0);
+                    for (uint32_t i = 0; i < nbytes; i++) if (T.bytes[i] == (uint8_t)C.b) T.at.push_back((uint64_t)i + 1);
+                    stopped.push_back(1);
+                } else if (C.kind == E_BYTE_ARRAY_LEN) {
+                    const Codec &L = H.codecs[(size_t)C.a], &V = H.codecs[(size_t)C.b];
+                    if (V.kind != E_EXTERNAL || ++slot_users[(size_t)V.a] > 1) return -3;
+                    block(V.a, T.bytes, nbytes);
+                    T.at.push_back(0);
+                    if (L.kind == E_HUFFMAN && L.b == 1 && H.huff[(size_t)L.a].len == 0) {
+                        const uint64_t len = (uint64_t)H.huff[(size_t)L.a].symbol;
+                        if (len == 0) return -3;
+                        for (uint64_t a = len; a <= nbytes; a += len) T.at.push_back(a);
+                    } else if (L.kind == E_EXTERNAL) {
+                        if (++slot_users[(size_t)L.a] > 1) return -3;
+                        const uint8_t *lp; uint32_t ln; block(L.a, lp, ln);
+                        Cursor c{lp, lp + ln}; uint64_t a = 0;
+                        while (c.p < c.end) { a += (uint64_t)c.itf8(); if (c.bad) return -1; T.at.push_back(a); }      // SCAN over the length column
+                    } else return -3;
+                    stopped.push_back(0);
+                } else return -3;
+                tags.push_back(T);
+            }
+            tag_of[t] = (int32_t)k;
+        }
+        std::vector<std::vector<uint64_t>> item(tags.size());               // item[k][r] = index of record r's value in tag k's block
+        std::vector<uint64_t> asz(n, 0);
+        std::vector<int32_t> line(n);
+        for (size_t r = 0; r < n; r++) { line[r] = I(S_TL, r); if (line[r] < 0 || line[r] >= P.nTL) return -1; }       // MAP
+        for (size_t k = 0; k < tags.size(); k++) {
+            std::vector<uint64_t> has(n, 0);
+            for (size_t r = 0; r < n; r++) for (int32_t t = H.tl_off[(size_t)line[r]]; t < H.tl_off[(size_t)line[r] + 1]; t++) if (tag_of[(size_t)t] == (int32_t)k) has[r] = 1;   // MAP
+            item[k] = exscan(has);                                                                                                                                      // SCAN
+        }
+        auto vlen = [&](size_t k, uint64_t it) -> uint64_t { return tags[k].at.at(it + 1) - tags[k].at.at(it) - (stopped[k] ? 1u : 0u); };
+        for (size_t r = 0; r < n; r++) for (int32_t t = H.tl_off[(size_t)line[r]]; t < H.tl_off[(size_t)line[r] + 1]; t++) asz[r] += 3 + vlen((size_t)tag_of[(size_t)t], item[(size_t)tag_of[(size_t)t]][r]);   // MAP
+        const auto a_off = exscan(asz);                                                                                                                                  // SCAN
+        if (a_off[n] > aux_cap) return -5;
+        for (size_t r = 0; r < n && out->aux; r++) {                                                                                                                      // MAP
+            uint8_t *o = out->aux + a_off[r];
+            for (int32_t t = H.tl_off[(size_t)line[r]]; t < H.tl_off[(size_t)line[r] + 1]; t++) {
+                const size_t k = (size_t)tag_of[(size_t)t]; const uint64_t it = item[k][r], ln = vlen(k, it);
+                const int32_t tag = H.tl_tag[(size_t)t];
+                o[0] = (uint8_t)(tag >> 16); o[1] = (uint8_t)(tag >> 8); o[2] = (uint8_t)tag;
+                memcpy(o + 3, tags[k].bytes + tags[k].at[it], (size_t)ln); o += 3 + ln;
+            }
+            out->aux_off[r] = a_off[r]; out->aux_len[r] = (int32_t)asz[r];
+        }
+        used[3] = a_off[n];
     }
     // ---- STEP 6: mates (the chain decoder's own function: O(records) of cheap work per slice) ----
     uint32_t totals[4] = {0, 0, 0, 0};

@@ -16,6 +16,7 @@ from tests.golden import make_golden_cram_records as G
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden", "cram_records.json")
 _vp = C.c_void_p
+DECODE_MD = [-1]                            # fd->decode_md of the slices built below (hts_open's default; tests that compare stored tags only set 0)
 
 
 class SliceIn(C.Structure):                 # = hg_cram_slice_blocks
@@ -62,7 +63,7 @@ def decode(call_bound, call_decode, slices, major, nref, with_seq=True):
         ra = (RefIn * max(len(rb), 1))(*[RefIn(t, a, C.addressof(buf), len(b), ln) for (t, a, b, ln), buf in zip(s.get("refs", []), rb)])
         keep.append((ch, sh, co, bl, ids, lens, ptrs, rb, ra))
         arr[i] = SliceIn(C.addressof(ch), len(s["comp_hdr"]), C.addressof(sh), len(s["slice_hdr"]), C.addressof(co), len(s["core"]), len(bl), ids.ctypes.data,
-                         C.addressof(ptrs), lens.ctypes.data, len(rb) if with_seq else 0, C.addressof(ra), -1)
+                         C.addressof(ptrs), lens.ctypes.data, len(rb) if with_seq else 0, C.addressof(ra), DECODE_MD[0])
     nrec, ccap, ncap, acap = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
     assert call_bound(n, arr, major, C.byref(nrec), C.byref(ccap), C.byref(ncap), C.byref(acap)) == 0
     R = max(nrec.value, 1)
@@ -266,6 +267,7 @@ def _check_truth(slices, got):
         for r, t in zip(g, s["truth"]):
             qual = "*" if not len(t["qual"]) else bytes(q + 33 for q in t["qual"]).decode("latin1")
             assert (r[0], r[1] & ~0x28, r[3], r[5], r[9], r[10]) == (t["name"].decode(), t["flag"], t["pos"], t["cigar"], t["seq"].decode(), qual), (r, t)
+            if DECODE_MD[0] == 0: assert r[11] == [G.short_tag(x) for x in G.aux_to_text(t["aux"])], (r[11], t["aux"])     # stored tags only
 
 
 def test_synthetic_slices_of_production_size_on_the_cpu_compile(hostlib):
@@ -278,6 +280,14 @@ def test_synthetic_slices_of_production_size_on_the_cpu_compile(hostlib):
     st, got = decode(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, 3, 1)
     assert (st == 0).all(), st
     _check_truth(slices, got)
+    tagged = [cram_synth.make_slice(rng, 900, 100, tags=True), cram_synth.make_slice(rng, 40, 151, unmapped_every=3, tags=True)]
+    DECODE_MD[0] = 0                                                  # compare the STORED tags: no MD / NM regeneration
+    try:
+        st, got = decode(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, tagged, 3, 1)
+        assert (st == 0).all(), st
+        _check_truth(tagged, got)
+    finally:
+        DECODE_MD[0] = -1
 
 
 @pytest.mark.gpu
@@ -311,7 +321,7 @@ def _slice_array(slices, keep):
         ra = (RefIn * max(len(rb), 1))(*[RefIn(t, a, C.addressof(buf), len(b), ln) for (t, a, b, ln), buf in zip(s.get("refs", []), rb)])
         keep.append((ch, sh, co, bl, ids, lens, ptrs, rb, ra))
         arr[i] = SliceIn(C.addressof(ch), len(s["comp_hdr"]), C.addressof(sh), len(s["slice_hdr"]), C.addressof(co), len(s["core"]), len(bl), ids.ctypes.data,
-                         C.addressof(ptrs), lens.ctypes.data, len(rb), C.addressof(ra), -1)
+                         C.addressof(ptrs), lens.ctypes.data, len(rb), C.addressof(ra), DECODE_MD[0])
     return arr
 
 
@@ -454,11 +464,16 @@ def test_data_parallel_prototype_matches_the_chain_decoder(hostlib, tmp_path):
     so = str(tmp_path / "libproto.so")
     subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas", "-o", so, os.path.join(ROOT, "tests", "native", "cram_fastpath_proto.cpp")], check=True)
     Pr = C.CDLL(so)
-    Pr.hgr_proto_decode_slice.argtypes = [_vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp]
+    Pr.hgr_proto_decode_slice.argtypes = [_vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp]
     rng = np.random.default_rng(31)
     slices = [synth_cram.make_slice(rng, 3000, 100), synth_cram.make_slice(rng, 500, 151, unmapped_every=3, detached_every=4), synth_cram.make_slice(rng, 1, 40, ref_len=500),
-              synth_cram.make_slice(rng, 257, 75, unmapped_every=0, detached_every=0)]
-    st, chain = decode(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, 3, 1)
+              synth_cram.make_slice(rng, 257, 75, unmapped_every=0, detached_every=0), synth_cram.make_slice(rng, 1200, 100, tags=True),
+              synth_cram.make_slice(rng, 33, 60, unmapped_every=2, tags=True)]
+    DECODE_MD[0] = 0                                                  # the prototype does not regenerate MD / NM: compare the stored tags
+    try:
+        st, chain = decode(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, 3, 1)
+    finally:
+        DECODE_MD[0] = -1
     assert (st == 0).all()
     for s, want in zip(slices, chain):
         keep = []
@@ -470,9 +485,11 @@ def test_data_parallel_prototype_matches_the_chain_decoder(hostlib, tmp_path):
         cigar = np.zeros(R * 16 + 64, np.uint32); names = np.zeros(R * 16 + 64, np.uint8)
         ncap = sum(len(e[9]) for e in s["expect"]) + 64
         seq_off = np.zeros(R, np.uint64); seq = np.zeros(ncap, np.uint8); qual = np.zeros(ncap, np.uint8)
-        cols = Cols(*[a.ctypes.data for a in list(i32.values()) + list(i64.values()) + list(u64.values()) + [cigar, names]], seq_off.ctypes.data, seq.ctypes.data, qual.ctypes.data, None, None, None)
-        used = np.zeros(3, np.uint64)
-        rc = Pr.hgr_proto_decode_slice(C.cast(arr, _vp), 3, 1, len(cigar), len(names), ncap, C.byref(cols), used.ctypes.data)
+        aux_off = np.zeros(R, np.uint64); aux_len = np.zeros(R, np.int32); aux = np.zeros(R * 64 + 64, np.uint8)
+        cols = Cols(*[a.ctypes.data for a in list(i32.values()) + list(i64.values()) + list(u64.values()) + [cigar, names]], seq_off.ctypes.data, seq.ctypes.data, qual.ctypes.data,
+                    aux_off.ctypes.data, aux_len.ctypes.data, aux.ctypes.data)
+        used = np.zeros(4, np.uint64)
+        rc = Pr.hgr_proto_decode_slice(C.cast(arr, _vp), 3, 1, len(cigar), len(names), ncap, len(aux), C.byref(cols), used.ctypes.data)
         assert rc == 0, rc
         for r in range(R):
             co, nc = int(u64["cigar_off"][r]), int(i32["ncigar"][r]); no, nl = int(u64["name_off"][r]), int(i32["name_len"][r]); so_, ln = int(seq_off[r]), int(i32["len"][r])
@@ -480,8 +497,9 @@ def test_data_parallel_prototype_matches_the_chain_decoder(hostlib, tmp_path):
             got = [bytes(names[no:no + nl]).decode(), int(i32["flags"][r]), int(i32["ref_id"][r]), int(i64["apos"][r]), int(i32["mqual"][r]),
                    [[int(c >> 4), int(c & 15)] for c in cigar[co:co + nc]], int(i32["mate_ref_id"][r]), int(i64["mate_pos"][r]), int(i64["tlen"][r]),
                    bytes(seq[so_:so_ + ln]).decode("latin1") if ln else "*", "*" if ln == 0 or (q == 255).all() else bytes((q + 33).astype(np.uint8)).decode("latin1")]
-            assert got == want[r][:11], (r, got, want[r][:11])
+            got.append([G.short_tag(t) for t in G.aux_to_text(bytes(aux[int(aux_off[r]):int(aux_off[r]) + int(aux_len[r])]))])
+            assert got == want[r][:12], (r, got, want[r][:12])
     # a slice the scheme does not cover (CORE-coded series, shared blocks: the reference's fixtures) is handed back
     fx = [x for _, _, _, x in load_slices()][0]
     keep = []
-    assert Pr.hgr_proto_decode_slice(C.cast(_slice_array([fx], keep), _vp), 3, 1, 64, 64, 64, C.byref(cols), used.ctypes.data) == -3
+    assert Pr.hgr_proto_decode_slice(C.cast(_slice_array([fx], keep), _vp), 3, 1, 64, 64, 64, 64, C.byref(cols), used.ctypes.data) == -3
