@@ -15,7 +15,7 @@ all: $(LIB) $(FRONT) oracle
 # (hfile_min.cpp = bundled local-file hFILE provider; a libhts build links hfile.c instead, see oracle/Makefile)
 FRONTSRC := $(CSRC)/bgzf_front.cpp $(CSRC)/cram_block_front.cpp $(CSRC)/hfile_min.cpp
 $(FRONT): $(FRONTSRC) include/hts_bgzf_gpu.h include/hts_cram_gpu.h include/hts_hfile_abi.h include/htsgpu.h $(LIB)
-	g++ -O2 -std=c++17 -fPIC -shared -Wall -Iinclude $(FRONTSRC) -o $@ -Lhtslib_amd -lhtsgpu -lpthread -Wl,-rpath,'$$ORIGIN'
+	g++ -O2 -std=c++17 -fPIC -shared -Wall -Iinclude $(FRONTSRC) -o $@ -Lhtslib_amd -lhtsgpu -lpthread -ldl -Wl,-rpath,'$$ORIGIN'
 
 # one object per source (make -j builds them in parallel; a kernel edit recompiles one file)
 OBJDIR  := build/obj

@@ -8,6 +8,7 @@
 // for everybody and hands the results back.  A lone caller pays the linger (tens of microseconds) and gets its block
 // alone -- correct, just not fast; the array forms (a whole slice per call) are the intended hook
 // (cram_decode.c:624-627 loops over a slice's blocks; cram_encode.c:803-988 compresses them in one function).
+#include <dlfcn.h>
 #include <errno.h>
 #include <pthread.h>
 #include <stdarg.h>
@@ -111,6 +112,47 @@ int varint_get(hFILE *fp, int major, int32_t *out, uint8_t *hdr, size_t *hl) {
     return 0;
 }
 
+// ================================================================================ bzip2 / lzma blocks
+// CRAM methods 2 and 3 are general-purpose CPU codecs the reference itself only reaches through libbz2 / liblzma
+// (cram_io.c:1626-1664, HAVE_LIBBZ2 / HAVE_LIBLZMA); there is no data-parallel form of either worth a kernel.  The front-end does what
+// the reference does: hand the block to the system's library -- looked up at run time, so that the library has no link-time dependency --
+// and fail with the reference's message when it is absent.  Nothing of the GPU path runs through here.
+namespace hostlib {
+typedef int (*bz2_fn)(char *, unsigned int *, char *, unsigned int, int, int);
+typedef int (*lzma_fn)(uint64_t *, uint32_t, const void *, const uint8_t *, size_t *, size_t, uint8_t *, size_t *, size_t);
+bz2_fn bz2 = nullptr; lzma_fn lzma = nullptr;
+std::once_flag once;
+void load() {
+    for (const char *n : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"}) if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) { bz2 = (bz2_fn)dlsym(h, "BZ2_bzBuffToBuffDecompress"); if (bz2) break; }
+    for (const char *n : {"liblzma.so.5", "liblzma.so"}) if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) { lzma = (lzma_fn)dlsym(h, "lzma_stream_buffer_decode"); if (lzma) break; }
+}
+// 0 / -1, the block left untouched on failure
+int inflate(cram_block *x) {
+    std::call_once(once, load);
+    const bool is_bz2 = x->method == BZIP2;
+    if (is_bz2 ? !bz2 : !lzma) {
+        logerr("cram_uncompress_block", "%s compression is not compiled into this version. Please rebuild and try again", is_bz2 ? "Bzip2" : "Lzma");
+        return -1;
+    }
+    uint8_t *out = (uint8_t *)malloc(x->uncomp_size ? (size_t)x->uncomp_size : 1);
+    if (!out) return -1;
+    size_t got = 0;
+    bool ok;
+    if (is_bz2) {
+        unsigned int usize = (unsigned int)x->uncomp_size;
+        ok = bz2((char *)out, &usize, (char *)x->data, (unsigned int)x->comp_size, 0, 0) == 0;     // BZ_OK
+        got = usize;
+    } else {
+        uint64_t memlimit = UINT64_MAX; size_t in_pos = 0;
+        ok = lzma(&memlimit, 0, nullptr, x->data, &in_pos, (size_t)x->comp_size, out, &got, (size_t)x->uncomp_size) == 0 && in_pos == (size_t)x->comp_size;   // LZMA_OK, whole input used
+    }
+    if (!ok || got != (size_t)x->uncomp_size) { free(out); return -1; }   // the reference's size check (cram_io.c:1639-1642, 1655-1658)
+    free(x->data);
+    x->data = out; x->alloc = got; x->method = RAW;
+    return 0;
+}
+}  // namespace hostlib
+
 // ================================================================================ batch workers
 // Decode a set of blocks in one engine round.  rc[i] = 0 / -1.
 void uncompress_batch(cram_block **b, int n, int *rc) {
@@ -139,6 +181,7 @@ void uncompress_batch(cram_block **b, int n, int *rc) {
         if (x->uncomp_size == 0) { x->method = RAW; continue; }            // blank block (cram_io.c:1594-1598)
         if (x->method == RAW) continue;
         if (x->uncomp_size < 0 || x->comp_size < 0 || (int)x->method < 0 || (int)x->method > TOK3) { rc[i] = -1; continue; }
+        if (x->method == BZIP2 || x->method == LZMA) { rc[i] = hostlib::inflate(x); continue; }    // the system's library, as in the reference
         todo.push_back(i);
     }
     if (todo.empty()) return;

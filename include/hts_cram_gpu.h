@@ -88,7 +88,8 @@ void cram_free_block(cram_block *b);
 cram_metrics *cram_new_metrics(void);
 
 /* Exactly the reference's function: CRC check (once), method dispatch, b->data replaced, method = RAW; 0 / -1.
- * bzip2 and lzma blocks fail with -1 and an error message, like a libhts built without those libraries. */
+ * bzip2 and lzma blocks (methods 2, 3) go to the system's libbz2 / liblzma, looked up with dlopen at first use -- what the reference does
+ * with HAVE_LIBBZ2 / HAVE_LIBLZMA (cram_io.c:1626-1664); when the library is absent they fail with -1 and the reference's message. */
 int cram_uncompress_block(cram_block *b);
 /* All blocks of a slice / container at once; returns 0 or -1 if any block failed (each block is left either fully
  * decoded or untouched; blk_rc, if given, receives the per-block 0 / -1). */
