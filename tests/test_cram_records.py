@@ -586,3 +586,13 @@ def test_encode_prototype_round_trips_through_the_pinned_decoder(hostlib, tmp_pa
         assert done >= 200 + 1560 and len(skipped) <= 6, (done, skipped)
     finally:
         DECODE_MD[0] = -1
+
+
+def test_columns_only_mode_without_bases_qualities_and_tags(hostlib):
+    """The caller may ask for the record columns alone (seq / qual / aux pointers NULL, no reference spans): same fields, nothing else touched."""
+    slices = [s for fname, major, nref, s in load_slices() if fname == "test/range.cram"]
+    st, full = decode(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, 3, 7)
+    st2, cols = decode(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, 3, 7, with_seq=False)
+    assert (st == 0).all() and (st2 == 0).all()
+    for a, b in zip(full, cols):
+        assert [r[:9] for r in a] == [r[:9] for r in b] and all(len(r) == 9 for r in b)
