@@ -113,6 +113,8 @@ struct Reader {
     uint64_t work;                        // features walked so far: a damaged count with zero-bit codecs must not spin for minutes
     int err;
     CopyJob *jobs; uint32_t njobs, job_cap;   // jobs == nullptr: copy at once
+    uint32_t rec_job0;                    // first deferred job of the record being decoded
+    const uint8_t *pend_lo[2], *pend_hi[2];   // what the record's deferred jobs cover in seq[] ([0]) and qual[] ([1]): a later direct access there runs them first
     // Read-ahead windows (device, wave mapping: in LDS): WIN bytes of every block -- slot s at wbuf + WIN * s, the CORE block after the
     // last slot -- so that the values of a series cost one global round trip per WIN bytes, not one per value.  wbuf == nullptr: none.
     HGR_LDS uint8_t *wbuf; HGR_LDS uint32_t *wpos;
@@ -138,10 +140,27 @@ struct Reader {
         return wbuf + (size_t)WIN * w + (c - st);
     }
 
-    HGR_FN void bulk(uint8_t *dst, const uint8_t *src, uint32_t n) {
-        if (jobs && n >= 32u && njobs < job_cap) { jobs[njobs].dst = dst; jobs[njobs].src = src; jobs[njobs].n = n; jobs[njobs].pad = 0; njobs++; }
-        else copy_bytes(dst, src, n);
+    // which: 0 = into seq[], 1 = into qual[], 2 = elsewhere (aux values: nothing writes there again)
+    HGR_FN void bulk(uint8_t *dst, const uint8_t *src, uint32_t n, int which = 2) {
+        if (jobs && n >= 32u && njobs < job_cap) {
+            jobs[njobs].dst = dst; jobs[njobs].src = src; jobs[njobs].n = n; jobs[njobs].pad = 0; njobs++;
+            if (which < 2) { if (!pend_lo[which] || dst < pend_lo[which]) pend_lo[which] = dst; if (!pend_hi[which] || dst + n > pend_hi[which]) pend_hi[which] = dst + n; }
+        } else copy_bytes(dst, src, n);
     }
+    HGR_FN void begin_record() { rec_job0 = njobs; pend_lo[0] = pend_lo[1] = pend_hi[0] = pend_hi[1] = nullptr; }
+    // The reference applies features in order (cram_decode.c:1260-1700).  A direct access to bytes a deferred copy of THIS record will
+    // write later would see (or be clobbered by) the wrong order: carry the record's pending copies out first.
+    HGR_FN void note_access(int which, const uint8_t *p, uint32_t n) {
+        if (!jobs || njobs == rec_job0 || !pend_lo[which] || p >= pend_hi[which] || p + n <= pend_lo[which]) return;
+        for (uint32_t j = rec_job0; j < njobs; j++) copy_bytes(jobs[j].dst, jobs[j].src, jobs[j].n);
+        njobs = rec_job0; pend_lo[0] = pend_lo[1] = pend_hi[0] = pend_hi[1] = nullptr;
+    }
+    // what decode_features / decode_body ask of a reader (the column reader of cram_records_fast.h answers the same questions)
+    HGR_FN bool has(int s) const { return P->codec_of[s] >= 0; }
+    HGR_FN uint32_t cigar_cap() const { return S->cigar_cap; }
+    HGR_FN uint32_t aux_cap() const { return S->aux_cap; }
+    HGR_FN int32_t decode_md() const { return S->decode_md; }
+    HGR_FN const uint8_t *data() const { return S->data; }
 
     // ---- CORE bit stream (get_bit_MSB / get_bits_MSB, cram_codecs.c:73-200) ----
     HGR_FN bool need_bits(uint64_t n) { if (bit + n > (uint64_t)S->core_len * 8u) { if (!err) err = ERR_MALFORMED; return false; } return true; }
@@ -173,12 +192,12 @@ struct Reader {
         S->cursor[s] = c + 1u + (uint32_t)extra;
         return (int32_t)v;
     }
-    HGR_FN void ext_bytes(int32_t s, uint8_t *out, uint32_t n) {      // cram_external_decode_char
+    HGR_FN void ext_bytes(int32_t s, uint8_t *out, uint32_t n, int which = 2) {      // cram_external_decode_char
         if (!slot_ok(s)) return;
         const uint32_t c = S->cursor[s];
         if (n > S->blk_len[s] || c > S->blk_len[s] - n) { if (!err) err = ERR_MALFORMED; return; }
         if (out && n == 1u) out[0] = wbuf ? *win((uint32_t)s, S->blk_off[s], S->blk_len[s], c, 1) : S->data[S->blk_off[s] + c];     // a byte series (FC, BS, BA, QS of a feature)
-        else if (out) bulk(out, S->data + S->blk_off[s] + c, n);
+        else if (out) bulk(out, S->data + S->blk_off[s] + c, n, which);
         S->cursor[s] = c + n;
     }
 
@@ -228,7 +247,7 @@ struct Reader {
     HGR_FN int32_t bval(int s) { return value(P->codec_of[s], true); }
 
     // ---- one item of a byte-array series: the bytes go to out (may be null), the length is returned ----
-    HGR_FN int32_t array(int32_t ci, uint8_t *out, uint32_t cap) {
+    HGR_FN int32_t array(int32_t ci, uint8_t *out, uint32_t cap, int which = 2) {
         if (ci < 0) { if (!err) err = ERR_MALFORMED; return 0; }
         const Codec C = P->codecs[ci];
         if (C.kind == E_BYTE_ARRAY_STOP) {                                // cram_byte_array_stop_decode_char
@@ -269,40 +288,63 @@ struct Reader {
             if (out && (uint32_t)len > cap) { err = ERR_UNSUPPORTED; return 0; }
             if (C.b < 0) { err = ERR_MALFORMED; return 0; }
             const Codec V = P->codecs[C.b];
-            if (V.kind == E_EXTERNAL) ext_bytes(V.a, out, (uint32_t)len);
+            if (V.kind == E_EXTERNAL) ext_bytes(V.a, out, (uint32_t)len, which);
             else for (int32_t i = 0; i < len && !err; i++) { const int32_t b = value(C.b, true); if (out) out[i] = (uint8_t)b; }
             return len;
         }
         if (!err) err = ERR_UNSUPPORTED;                                  // array series through a scalar codec: not written by any encoder we know
         return 0;
     }
+    HGR_FN int32_t array_s(int s, uint8_t *out, uint32_t cap, int which) { return array(P->codec_of[s], out, cap, which); }
+    // n bytes of a byte series in one go: the qualities of a record, the bases of an unmapped read (cram_decode.c:2917-2953)
+    HGR_FN void bytes_bulk(int s, uint8_t *out, uint32_t n, int which) {
+        if (P->codec_of[s] < 0) { if (!err) err = ERR_MALFORMED; return; }
+        const Codec C = P->codecs[P->codec_of[s]];
+        if (C.kind == E_EXTERNAL) ext_bytes(C.a, out, n, which);
+        else for (uint32_t i = 0; i < n && !err; i++) { const int32_t b = bval(s); if (out) out[i] = (uint8_t)b; }
+    }
 };
 
-// cram_decode_seq (cram_decode.c:1096-1900) without MD / NM generation: features -> CIGAR, alignment end, and -- when the caller asked
-// for them -- the bases (reference span + edits) and the qualities; MQ.
-HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint32_t &ncig_total, uint8_t *seq, uint8_t *qual, const RefSpan *ref,
+// cram_decode_seq (cram_decode.c:1096-1900): features -> CIGAR, alignment end, and -- when the caller asked for them -- the bases
+// (reference span + edits) and the qualities; MQ; MD:Z / NM regenerated like the reference's decode_md.
+// RD: the reader that hands out the values of the series -- Reader above (one chain per slice) or the column reader of
+// cram_records_fast.h (one lane per record, start positions from prefix sums).  DRY: count only -- the CIGAR ops and the generated
+// aux bytes of the record are counted (ncig_total / naux advance), nothing is stored and no capacity is checked; the data-parallel
+// path sizes its outputs with such a pass.
+template <class RD, bool DRY>
+HGR_FN void decode_features(RD &R, const Cols &O, int rec, int32_t cf, uint32_t &ncig_total, uint8_t *seq, uint8_t *qual, const RefSpan *ref,
                             uint32_t &naux, int has_md, int has_nm, int32_t len, int32_t ref_id, int64_t apos, uint32_t aux_stored) {
     const Plan *P = R.P;
     int64_t ref_pos = apos - 1;                                           // 0-based position of the next reference base (the record's fields come in as
                                                                           // arguments: reading a column back waits for every store in flight)
     int32_t prev_pos = 0, seq_pos = 1, cig_len = 0, cig_op = C_MATCH;
     const uint32_t cig0 = ncig_total;
-    const uint8_t *refb = ref ? R.S->data + ref->off : nullptr;           // refb[p - ref->start] = base at 1-based position p
+    const uint8_t *refb = ref ? R.data() + ref->off : nullptr;            // refb[p - ref->start] = base at 1-based position p
     const int64_t ref_start = ref ? ref->start : 0, ref_end = ref ? ref->start + (int64_t)ref->len - 1 : 0, sq_len = ref ? ref->sq_len : 0;
     const bool have_ref = ref && ref_id >= 0;
-    auto emit = [&](uint32_t l, int op) { if (ncig_total >= R.S->cigar_cap) { if (!R.err) R.err = ERR_UNSUPPORTED; return; } O.cigar[ncig_total++] = (l << 4) | (uint32_t)op; };
+    auto emit = [&](uint32_t l, int op) {
+        if (!DRY) { if (ncig_total >= R.cigar_cap()) { if (!R.err) R.err = ERR_UNSUPPORTED; return; } O.cigar[ncig_total] = (l << 4) | (uint32_t)op; }
+        ncig_total++;
+    };
     auto flush_unless = [&](int op) { if (cig_len && cig_op != op) { emit((uint32_t)cig_len, cig_op); cig_len = 0; } };
-    auto fill = [&](int32_t at, uint8_t c, int64_t n) { if (seq) for (int64_t i = 0; i < n; i++) seq[at + i] = c; };
-    auto copy_ref = [&](int32_t at, int64_t n) { if (seq && n > 0) R.bulk(seq + at, refb + (ref_pos + 1 - ref_start), (uint32_t)n); };
-    auto qual_touch = [&]() { if (qual && !(cf & CF_PRESERVE_QUAL) && len > 0 && qual[0] == 255) for (int32_t i = 0; i < len; i++) qual[i] = 30; };   // "same as htsjdk"
+    auto fill = [&](int32_t at, uint8_t c, int64_t n) { if (seq && n > 0) { R.note_access(0, seq + at, (uint32_t)n); for (int64_t i = 0; i < n; i++) seq[at + i] = c; } };
+    auto copy_ref = [&](int32_t at, int64_t n) { if (seq && n > 0) R.bulk(seq + at, refb + (ref_pos + 1 - ref_start), (uint32_t)n, 0); };
+    auto qual_touch = [&]() {                                             // "same as htsjdk"
+        if (qual && !(cf & CF_PRESERVE_QUAL) && len > 0) { R.note_access(1, qual, (uint32_t)len); if (qual[0] == 255) for (int32_t i = 0; i < len; i++) qual[i] = 30; }
+    };
+    auto put_seq = [&](uint8_t *p, uint8_t c) { R.note_access(0, p, 1); *p = c; };
+    auto put_qual = [&](uint8_t *p, uint8_t c) { R.note_access(1, p, 1); *p = c; };
     if (qual && !(cf & CF_PRESERVE_QUAL)) for (int32_t i = 0; i < len; i++) qual[i] = 255;
     // MD:Z / NM regeneration (decode_md, cram_decode.c:1111-1137): needs the reference and somewhere to put the tags
-    const bool do_md = R.S->decode_md != 0 && O.aux != nullptr;
+    const bool do_md = R.decode_md() != 0 && O.aux != nullptr;
     bool decode_md = do_md && ref && ref_id >= 0 && !has_md, decode_nm = do_md && ref && ref_id >= 0 && !has_nm;
     if (cf & CF_NO_SEQ) decode_md = decode_nm = false;
     uint32_t nm = 0; int32_t md_dist = 0;
     const uint32_t aux0 = naux;
-    auto aux_char = [&](uint8_t c) { if (naux >= R.S->aux_cap) { if (!R.err) R.err = ERR_UNSUPPORTED; return; } O.aux[naux++] = c; };
+    auto aux_char = [&](uint8_t c) {
+        if (!DRY) { if (naux >= R.aux_cap()) { if (!R.err) R.err = ERR_UNSUPPORTED; return; } O.aux[naux] = c; }
+        naux++;
+    };
     auto aux_uint = [&](uint32_t v) { uint32_t div = 1; while (v / div >= 10u) div *= 10u; for (; div; div /= 10u) aux_char((uint8_t)('0' + (v / div) % 10u)); };   // BLOCK_APPEND_UINT
     auto md_char = [&](uint8_t c) { if (decode_md) { aux_uint((uint32_t)md_dist); aux_char(c); md_dist = 0; } };      // add_md_char
     // per-base look-ups go straight to the staged reference: a window in LDS was tried and LOST (151 ms against 131 ms for the bench
@@ -325,7 +367,7 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
     const int32_t fn = R.ival(S_FN);                                      // a series the walk needs and the map lacks is an error, as in the reference
     {
         for (int32_t f = 0; f < fn && !R.err; f++) {
-            if (++R.work > 16ull * R.S->cigar_cap) { R.err = ERR_UNSUPPORTED; break; }
+            if (++R.work > 16ull * R.cigar_cap()) { R.err = ERR_UNSUPPORTED; break; }
             const int32_t op = R.bval(S_FC);
             int32_t pos = R.ival(S_FP) + prev_pos;
             if (R.err) break;
@@ -359,7 +401,7 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
             case 'S': {
                 if (cig_len) { emit((uint32_t)cig_len, cig_op); cig_len = 0; }
                 int32_t n = 1;                                            // no SC codec: one unknown base (cram_decode.c:1317-1329)
-                if (P->codec_of[S_SC] >= 0) n = R.array(P->codec_of[S_SC], sp, room); else if (sp) sp[0] = 'N';
+                if (R.has(S_SC)) { if (sp) R.note_access(0, sp, room); n = R.array_s(S_SC, sp, room, 0); } else if (sp) put_seq(sp, 'N');
                 emit((uint32_t)n, C_SOFT_CLIP); cig_op = C_SOFT_CLIP; seq_pos += n;
                 break;
             }
@@ -367,12 +409,12 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
                 flush_unless(C_MATCH);
                 const int32_t base = R.bval(S_BS) & 3;
                 if (ref_id < 0 || ref_pos >= sq_len || !ref) {
-                    if (seq && pos - 1 < len) seq[pos - 1] = P->sm[16 + base];
+                    if (seq && pos - 1 < len) put_seq(seq + (pos - 1), P->sm[16 + base]);
                     if (decode_md || decode_nm) { if (md_dist >= 0 && decode_md) aux_uint((uint32_t)md_dist); md_dist = -1; nm--; }
                 } else {
                     const uint8_t rc = ref_pos < ref_end ? ref_at(ref_pos) : (uint8_t)'N';
                     const int l1 = (rc == 'A' || rc == 'a') ? 0 : (rc == 'C' || rc == 'c') ? 1 : (rc == 'G' || rc == 'g') ? 2 : (rc == 'T' || rc == 't') ? 3 : 4;
-                    if (seq && pos - 1 < len) seq[pos - 1] = P->sm[4 * l1 + base];
+                    if (seq && pos - 1 < len) put_seq(seq + (pos - 1), P->sm[4 * l1 + base]);
                     md_char(rc);
                 }
                 nm++;
@@ -404,13 +446,14 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
             }
             case 'I': {
                 flush_unless(C_INS);
-                { const int32_t n = R.array(P->codec_of[S_IN], sp, room); cig_op = C_INS; cig_len += n; seq_pos += n; nm += (uint32_t)n; }
+                { if (sp) R.note_access(0, sp, room); const int32_t n = R.array_s(S_IN, sp, room, 0); cig_op = C_INS; cig_len += n; seq_pos += n; nm += (uint32_t)n; }
                 break;
             }
-            case 'i': { flush_unless(C_INS); const int32_t b = R.bval(S_BA); if (sp) sp[0] = (uint8_t)b; cig_op = C_INS; cig_len++; seq_pos++; nm++; break; }
+            case 'i': { flush_unless(C_INS); const int32_t b = R.bval(S_BA); if (sp) put_seq(sp, (uint8_t)b); cig_op = C_INS; cig_len++; seq_pos++; nm++; break; }
             case 'b': {
                 flush_unless(C_MATCH);
-                const int32_t n = R.array(P->codec_of[S_BB], sp, room);
+                if (sp) R.note_access(0, sp, room);
+                const int32_t n = R.array_s(S_BB, sp, room, 0);
                 if (decode_md || decode_nm) {                             // every stored base counts as a mismatch (cram_decode.c:1515-1541)
                     if (md_dist >= 0 && decode_md) aux_uint((uint32_t)md_dist);
                     int32_t x = 0;
@@ -425,21 +468,21 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
                 cig_op = C_MATCH; cig_len += n; seq_pos += n; ref_pos += n;
                 break;
             }
-            case 'q': flush_unless(C_MATCH); qual_touch(); (void)R.array(P->codec_of[S_QQ], qp, room); cig_op = C_MATCH; break;
+            case 'q': flush_unless(C_MATCH); qual_touch(); if (qp) R.note_access(1, qp, room); (void)R.array_s(S_QQ, qp, room, 1); cig_op = C_MATCH; break;
             case 'B': {
                 flush_unless(C_MATCH);
-                const int32_t b = R.bval(S_BA); if (sp) sp[0] = (uint8_t)b;
+                const int32_t b = R.bval(S_BA); if (sp) put_seq(sp, (uint8_t)b);
                 if (decode_md || decode_nm) {                             // cram_decode.c:1593-1610
                     if (md_dist >= 0 && decode_md) aux_uint((uint32_t)md_dist);
                     if (ref_pos >= sq_len || !ref) md_dist = -1;
                     else { if (decode_md) { if (ref_pos >= ref_end) { R.err = ERR_MALFORMED; break; } aux_char(ref_at(ref_pos)); } nm++; md_dist = 0; }
                 }
                 qual_touch();
-                const int32_t q = R.bval(S_QS); if (qp) qp[0] = (uint8_t)q;
+                const int32_t q = R.bval(S_QS); if (qp) put_qual(qp, (uint8_t)q);
                 cig_op = C_MATCH; cig_len++; seq_pos++; ref_pos++;
                 break;
             }
-            case 'Q': { qual_touch(); const int32_t q = R.bval(S_QS); if (qp) qp[0] = (uint8_t)q; break; }
+            case 'Q': { qual_touch(); const int32_t q = R.bval(S_QS); if (qp) put_qual(qp, (uint8_t)q); break; }
             case 'H': {
                 flush_unless(C_HARD_CLIP);
                 { const int32_t v = R.ival(S_HC); if (v < 0) { if (!R.err) R.err = ERR_MALFORMED; break; } cig_op = C_HARD_CLIP; cig_len += v; }
@@ -478,16 +521,14 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
     }
     if (decode_md && md_dist >= 0) aux_uint((uint32_t)md_dist);
     if (cig_len) emit((uint32_t)cig_len, cig_op);
-    O.cigar_off[rec] = cig0; O.ncigar[rec] = (int32_t)(ncig_total - cig0);
-    O.aend[rec] = ref_pos > apos ? ref_pos : apos;
-    O.mqual[rec] = R.ival(S_MQ);
-    if ((cf & CF_PRESERVE_QUAL) && !R.err) {                             // len quality bytes
-        if (P->codec_of[S_QS] < 0) { R.err = ERR_MALFORMED; return; }
-        const Codec C = P->codecs[P->codec_of[S_QS]];
-        if (C.kind == E_EXTERNAL) R.ext_bytes(C.a, qual, (uint32_t)len);
-        else for (int32_t i = 0; i < len && !R.err; i++) { const int32_t q = R.bval(S_QS); if (qual) qual[i] = (uint8_t)q; }
+    const int32_t mq = R.ival(S_MQ);
+    if (!DRY) {
+        O.cigar_off[rec] = cig0; O.ncigar[rec] = (int32_t)(ncig_total - cig0);
+        O.aend[rec] = ref_pos > apos ? ref_pos : apos;
+        O.mqual[rec] = mq;
     }
-    if (cf & CF_NO_SEQ) O.len[rec] = 0;
+    if ((cf & CF_PRESERVE_QUAL) && !R.err) R.bytes_bulk(S_QS, qual, (uint32_t)len, 1);      // len quality bytes
+    if (!DRY && (cf & CF_NO_SEQ)) O.len[rec] = 0;
     if (decode_md) aux_char(0);                                           // MD:Z: is a NUL-terminated string
     if (decode_nm) {                                                      // NM in the narrowest unsigned type (cram_decode.c:1884-1908)
         aux_char('N'); aux_char('M');
@@ -495,7 +536,29 @@ HGR_FN void decode_features(Reader &R, const Cols &O, int rec, int32_t cf, uint3
         else if (nm <= 0xffffu) { aux_char('S'); aux_char((uint8_t)nm); aux_char((uint8_t)(nm >> 8)); }
         else { aux_char('I'); aux_char((uint8_t)nm); aux_char((uint8_t)(nm >> 8)); aux_char((uint8_t)(nm >> 16)); aux_char((uint8_t)(nm >> 24)); }
     }
-    if (O.aux && !R.err) O.aux_len[rec] = (int32_t)(aux_stored + (naux - aux0));
+    if (!DRY && O.aux && !R.err) O.aux_len[rec] = (int32_t)(aux_stored + (naux - aux0));
+}
+
+// What follows the fixed fields and the tags of a record in cram_decode_slice's loop (cram_decode.c:2890-2967): bases and qualities of a
+// mapped record through the feature walk, of an unmapped one straight from BA / QS, and the quality reversal of QO = 0 files.
+template <class RD, bool DRY>
+HGR_FN void decode_body(RD &R, const Cols &O, int rec, int32_t bf, int32_t cf, int32_t len, int32_t ref_id, int64_t apos, uint8_t *seq, uint8_t *qual,
+                        const RefSpan *ref, uint32_t &ncig, uint32_t &naux, int has_md, int has_nm, uint32_t aux_stored) {
+    if (seq && !ref) for (int32_t i = 0; i < len; i++) seq[i] = '=';
+    if (!(bf & BAM_FUNMAP)) {
+        if (apos <= 0) { R.err = ERR_MALFORMED; return; }
+        decode_features<RD, DRY>(R, O, rec, cf, ncig, seq, qual, ref, naux, has_md, has_nm, len, ref_id, apos, aux_stored);
+    } else {
+        if (!DRY) { O.cigar_off[rec] = ncig; O.ncigar[rec] = 0; O.aend[rec] = apos; O.mqual[rec] = 0; }
+        if (len) R.bytes_bulk(S_BA, seq, (uint32_t)len, 0);
+        if (R.err) return;
+        if (cf & CF_PRESERVE_QUAL) R.bytes_bulk(S_QS, qual, (uint32_t)len, 1);
+        else if (qual) for (int32_t i = 0; i < len; i++) qual[i] = 255;
+    }
+    if (qual && !R.err && !R.P->qs_seq_orient && (bf & BAM_FREVERSE)) {  // qualities stored in read orientation (cram_decode.c:2957-2965)
+        R.note_access(1, qual, (uint32_t)len);
+        for (int32_t i = 0, j = len - 1; i < j; i++, j--) { const uint8_t t = qual[i]; qual[i] = qual[j]; qual[j] = t; }
+    }
 }
 
 // cram_decode_aux (cram_decode.c:2008-2137): tag list of the record (TL -> dictionary line), then one value per tag.  The values are
@@ -593,11 +656,12 @@ HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
     Reader R; R.P = P; R.S = S; R.bit = 0; R.work = 0; R.err = 0;
     R.wbuf = S->wbuf; R.wpos = S->wpos;
     if (R.wbuf) for (int32_t i = 0; i <= P->nslots; i++) R.wpos[i] = 0xffffff00u;          // windows empty (blocks, CORE)
-    R.jobs = P->qs_seq_orient ? S->jobs : nullptr; R.njobs = 0; R.job_cap = S->job_cap;      // the quality reversal of QO = 0 files reads the record back: no deferral there
+    R.jobs = P->qs_seq_orient ? S->jobs : nullptr; R.njobs = 0; R.job_cap = S->job_cap; R.begin_record();      // the quality reversal of QO = 0 files reads the record back: no deferral there
     for (int32_t i = 0; i < P->nslots; i++) S->cursor[i] = 0;
     uint32_t ncig = 0, nname = 0, naux = 0;
     int64_t last_apos = S->ref_seq_start;
     for (int32_t rec = 0; rec < S->nrec && !R.err; rec++) {
+        R.begin_record();
         const int32_t bf = R.ival(S_BF);
         if (!R.err && (bf < 0 || bf >= 0x1000)) R.err = ERR_MALFORMED;
         O.flags[rec] = bf;
@@ -658,27 +722,7 @@ HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
         }
         for (int32_t i = 0; i < S->nrefs; i++) if (S->refs[i].ref_id == ref_id) { ref = &S->refs[i]; break; }
         if (ref && apos < ref->start) ref = nullptr;                      // the span does not reach back to this record: as if no reference had been given
-        if (seq && !ref) for (int32_t i = 0; i < len; i++) seq[i] = '=';
-        if (!(bf & BAM_FUNMAP)) {
-            if (apos <= 0) { R.err = ERR_MALFORMED; break; }
-            decode_features(R, O, rec, cf, ncig, seq, qual, ref, naux, has_md, has_nm, len, ref_id, apos, naux - aux_rec0);
-        } else {
-            O.cigar_off[rec] = ncig; O.ncigar[rec] = 0; O.aend[rec] = apos; O.mqual[rec] = 0;
-            if (len) {
-                if (P->codec_of[S_BA] < 0) { R.err = ERR_MALFORMED; break; }
-                const Codec C = P->codecs[P->codec_of[S_BA]];
-                if (C.kind == E_EXTERNAL) R.ext_bytes(C.a, seq, (uint32_t)len);
-                else for (int32_t i = 0; i < len && !R.err; i++) { const int32_t b = R.bval(S_BA); if (seq) seq[i] = (uint8_t)b; }
-            }
-            if (cf & CF_PRESERVE_QUAL) {
-                if (P->codec_of[S_QS] < 0) { R.err = ERR_MALFORMED; break; }
-                const Codec C = P->codecs[P->codec_of[S_QS]];
-                if (C.kind == E_EXTERNAL) R.ext_bytes(C.a, qual, (uint32_t)len);
-                else for (int32_t i = 0; i < len && !R.err; i++) { const int32_t q = R.bval(S_QS); if (qual) qual[i] = (uint8_t)q; }
-            } else if (qual) for (int32_t i = 0; i < len; i++) qual[i] = 255;
-        }
-        if (qual && !R.err && !P->qs_seq_orient && (bf & BAM_FREVERSE))           // qualities stored in read orientation (cram_decode.c:2957-2965)
-            for (int32_t i = 0, j = len - 1; i < j; i++, j--) { const uint8_t t = qual[i]; qual[i] = qual[j]; qual[j] = t; }
+        decode_body<Reader, false>(R, O, rec, bf, cf, len, ref_id, apos, seq, qual, ref, ncig, naux, has_md, has_nm, naux - aux_rec0);
     }
     O.totals[0] = ncig; O.totals[1] = nname; O.totals[2] = naux; O.totals[3] = R.njobs;
     if (R.err) return R.err;

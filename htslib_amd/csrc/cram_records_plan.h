@@ -224,6 +224,7 @@ struct Batch {
     std::vector<const uint8_t *> src_ptr; std::vector<uint32_t> src_len;
     uint64_t data_bytes = 0, nrec = 0, cig_total = 0, name_total = 0, aux_total = 0, job_total = 0;
     std::vector<int32_t> status;          // per slice: 0 = goes to the decoder, else the status already known
+    std::vector<PlanHost> hosts;          // the parsed compression headers, parallel to plans (cram_records_fast_plan.h reads them)
 };
 
 // One input slice as the caller hands it over (mirrors hg_cram_slice_blocks / hg_cram_ref_span)
@@ -235,7 +236,7 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
     B = Batch();
     if (major != 2 && major != 3) return -3;
     std::map<std::pair<const uint8_t *, uint32_t>, int32_t> seen;        // containers share a compression header: parse it once
-    std::vector<PlanHost> hosts;
+    std::vector<PlanHost> &hosts = B.hosts;
     B.status.assign(n, 0);
     auto stage = [&](const uint8_t *p, uint32_t len) { const uint64_t off = B.data_bytes; B.src_off.push_back(off); B.src_ptr.push_back(p); B.src_len.push_back(len); B.data_bytes += ((uint64_t)len + 15u) & ~15ull; return off; };
     for (size_t i = 0; i < n; i++) {

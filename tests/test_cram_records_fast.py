@@ -1,0 +1,147 @@
+"""The data-parallel CRAM record decoder (htslib_amd/csrc/cram_records_fast.h; reference cram/cram_decode.c:2553-2985, :2140-2307): per-record
+passes + prefix sums instead of one serial chain per slice.  The per-record passes are ONE source for host and device; here the CPU compile
+(tests/native/cram_records_host.cpp, plain loops in the kernels' order) is checked against
+
+  * the SAM / BAM twins of the reference's 34 CRAM fixtures (slices the path takes; the rest must fall through to the chain decoder),
+  * the pinned chain decoder, column for column, on production-shaped synthetic slices (tags, MD / NM regeneration, unmapped and
+    detached records, multi-slice batches),
+  * the chain decoder's verdict on damaged slices (the path may only ever say "not mine").
+
+The -m gpu tests run the same comparisons through the kernels (tests/test_cram_records.py holds the shared plumbing)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import test_cram_records as T
+
+_vp = C.c_void_p
+
+
+@pytest.fixture(scope="module")
+def hostlib(tmp_path_factory):
+    import subprocess
+    so = str(tmp_path_factory.mktemp("cramfast") / "libcram_records_host.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas", "-o", so, os.path.join(T.ROOT, "tests", "native", "cram_records_host.cpp")], check=True)
+    L = C.CDLL(so)
+    L.hgr_host_records_bound.argtypes = [C.c_size_t, _vp, C.c_int, _vp, _vp, _vp, _vp]
+    L.hgr_host_decode_records.argtypes = [C.c_size_t, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp]
+    L.hgr_host_decode_records_fast.argtypes = L.hgr_host_decode_records.argtypes + [_vp]
+    return L
+
+
+def fast_call(L):
+    """hgr_host_decode_records_fast with decode()'s calling convention; .path = which slices the data-parallel path decoded"""
+    def call(n, *a):
+        path = np.full(max(n, 1), -1, np.int32)
+        rc = L.hgr_host_decode_records_fast(n, *a, path.ctypes.data)
+        call.path = path[:n].copy()
+        return rc
+    return call
+
+
+def test_fixture_slices_the_path_takes_match_the_sam_twins(hostlib):
+    files = {}
+    for fname, major, nref, s in T.load_slices():
+        files.setdefault((fname, major, nref), []).append(s)
+    fc = fast_call(hostlib)
+    nrec = took = 0
+    for (fname, major, nref), slices in files.items():
+        st, got = T.decode(hostlib.hgr_host_records_bound, fc, slices, major, nref)
+        assert (st == 0).all(), (fname, st)
+        took += int(fc.path.sum())
+        for s, g in zip(slices, got):
+            T.check_against_twin(fname, g, s["expect"]); nrec += len(g)
+    assert nrec == 230
+    # the fixtures are CRAM 3.0 by old htslib / htsjdk writers: most put BF, CF, ... into the CORE block.  Whatever the count, every slice
+    # decoded to its twin above; the synthetic tests below are the ones that must run on the path.
+    print("fixture slices decoded by the data-parallel path:", took)
+
+
+def _raw(call_bound, call_decode, slices, major, nref, with_seq=True):
+    st, got = T.decode(call_bound, call_decode, slices, major, nref, with_seq)
+    return st, got, T.decode.last_aend
+
+
+@pytest.mark.parametrize("decode_md", [-1, 0])
+def test_synthetic_slices_equal_the_chain_decoder(hostlib, decode_md):
+    from htslib_amd import synth_cram
+    rng = np.random.default_rng(101)
+    slices = [synth_cram.make_slice(rng, 3000, 100), synth_cram.make_slice(rng, 500, 151, unmapped_every=3, detached_every=4), synth_cram.make_slice(rng, 1, 40, ref_len=500),
+              synth_cram.make_slice(rng, 257, 75, unmapped_every=0, detached_every=0), synth_cram.make_slice(rng, 1200, 100, tags=True),
+              synth_cram.make_slice(rng, 33, 60, unmapped_every=2, tags=True), synth_cram.make_slice(rng, 2, 50, ref_len=900), synth_cram.make_slice(rng, 255, 90),
+              synth_cram.make_slice(rng, 256, 90), synth_cram.make_slice(rng, 513, 64, tags=True)]
+    fc = fast_call(hostlib)
+    T.DECODE_MD[0] = decode_md
+    try:
+        st, chain, aend = _raw(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, 3, 1)
+        st2, fast, aend2 = _raw(hostlib.hgr_host_records_bound, fc, slices, 3, 1)
+        st3, cols, _ = _raw(hostlib.hgr_host_records_bound, fc, slices, 3, 1, with_seq=False)
+    finally:
+        T.DECODE_MD[0] = -1
+    assert (st == 0).all() and (st2 == 0).all() and (st3 == 0).all()
+    assert fc.path.all(), fc.path                                       # every one of them went through the data-parallel passes
+    assert fast == chain and aend == aend2
+    assert [[r[:9] for r in s] for s in cols] == [[r[:9] for r in s] for s in chain]
+    T._check_truth(slices, fast) if decode_md == 0 else None
+
+
+def test_mixed_batch_fixture_and_synthetic_slices(hostlib):
+    """one batch holding slices of both kinds: the CORE-coded ones keep the chain decoder, the others take the passes; placement of bases is
+    deterministic (fast slices first, in slice order)"""
+    from htslib_amd import synth_cram
+    rng = np.random.default_rng(5)
+    fx = [s for f, major, nref, s in T.load_slices() if f == "test/range.cram"]
+    syn = [synth_cram.make_slice(rng, 300, 80), synth_cram.make_slice(rng, 90, 80, tags=True)]
+    slices = [syn[0]] + fx[:1] + [syn[1]] + fx[1:]
+    fc = fast_call(hostlib)
+    st, chain, _ = _raw(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, 3, 7)
+    st2, fast, _ = _raw(hostlib.hgr_host_records_bound, fc, slices, 3, 7)
+    assert (st == 0).all() and (st2 == 0).all()
+    assert fast == chain
+    assert fc.path[0] == 1 and fc.path[2] == 1
+
+
+def test_damaged_slices_get_the_chain_decoders_verdict(hostlib):
+    """mutated EXTERNAL-only slices: the data-parallel path either decodes exactly what the chain decoder decodes or steps aside"""
+    from htslib_amd import synth_cram
+    rng = np.random.default_rng(404)
+    base = [synth_cram.make_slice(rng, 60, 70, tags=True), synth_cram.make_slice(rng, 45, 50, unmapped_every=4), synth_cram.make_slice(rng, 30, 64, detached_every=2, tags=True)]
+    fc = fast_call(hostlib)
+
+    def mutate(b):
+        b = bytearray(b)
+        if not b: return bytes(b)
+        k = int(rng.integers(0, 4))
+        if k == 0:
+            for _ in range(int(rng.integers(1, 4))): b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 1: b = b[:int(rng.integers(0, len(b)))]
+        elif k == 2: b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        else:
+            i = int(rng.integers(0, len(b))); b[i:i] = bytes(rng.integers(0, 256, int(rng.integers(1, 5)), dtype=np.uint8))
+        return bytes(b)
+
+    same = took = failed = 0
+    for it in range(500):
+        s = dict(base[int(rng.integers(0, len(base)))])
+        what = int(rng.integers(0, 6))
+        if what == 0: s["comp_hdr"] = mutate(s["comp_hdr"])
+        elif what == 1: s["slice_hdr"] = mutate(s["slice_hdr"][:3]) + s["slice_hdr"][3:] if it % 2 else mutate(s["slice_hdr"])
+        elif what <= 4:
+            j = int(rng.integers(0, len(s["blocks"]))); bl = list(s["blocks"]); bl[j] = (bl[j][0], mutate(bl[j][1])); s["blocks"] = bl
+        else: s["refs"] = [(t, a, b[:len(b) // 2], ln) for t, a, b, ln in s.get("refs", [])]
+        res = []
+        for call in (hostlib.hgr_host_decode_records, fc):
+            try:
+                st, got, aend = _raw(hostlib.hgr_host_records_bound, call, [s], 3, 1)
+                res.append((int(st[0]), got if st[0] == 0 else None, aend if st[0] == 0 else None))
+            except AssertionError:
+                res.append(("refused",))
+            except (ValueError, IndexError, UnicodeDecodeError, T.struct_error):      # tag bytes that are not BAM aux: "decoded", but the text helper cannot render them
+                res.append(("unrenderable",))
+        assert res[0] == res[1], (it, what, res[0][0], res[1][0])
+        same += 1
+        if res[1][0] == 0: took += int(fc.path[0])
+        else: failed += 1
+    assert took > 50 and failed > 50, (took, failed)
