@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <vector>
 #include "htsgpu.h"
 #include "hg_internal.h"
@@ -29,10 +31,54 @@ uint32_t crc32_small(const uint8_t *p, size_t n) {                      // CRC-3
     return ~c;
 }
 
+// MD5 (RFC 1321) of a reference span: cram_decode_slice compares it with the slice header's (cram_decode.c:2480-2540).  Written from the RFC.
+void md5_of(const uint8_t *p, uint64_t n, uint8_t out[16]) {
+    static const uint32_t K[64] = {
+        0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
+        0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
+        0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70, 0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
+        0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+    static const int S[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
+                              4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
+    uint32_t h[4] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
+    auto block = [&](const uint8_t *b) {
+        uint32_t w[16];
+        for (int i = 0; i < 16; i++) w[i] = (uint32_t)b[4 * i] | (uint32_t)b[4 * i + 1] << 8 | (uint32_t)b[4 * i + 2] << 16 | (uint32_t)b[4 * i + 3] << 24;
+        uint32_t a = h[0], bb = h[1], c = h[2], d = h[3];
+        for (int i = 0; i < 64; i++) {
+            uint32_t f; int g;
+            if (i < 16) { f = (bb & c) | (~bb & d); g = i; }
+            else if (i < 32) { f = (d & bb) | (~d & c); g = (5 * i + 1) & 15; }
+            else if (i < 48) { f = bb ^ c ^ d; g = (3 * i + 5) & 15; }
+            else { f = c ^ (bb | ~d); g = (7 * i) & 15; }
+            const uint32_t t = a + f + K[i] + w[g];
+            a = d; d = c; c = bb; bb += (t << S[i]) | (t >> (32 - S[i]));
+        }
+        h[0] += a; h[1] += bb; h[2] += c; h[3] += d;
+    };
+    uint64_t i = 0;
+    for (; i + 64 <= n; i += 64) block(p + i);
+    uint8_t tail[128]; const size_t r = (size_t)(n - i);
+    memset(tail, 0, sizeof tail);
+    if (r) memcpy(tail, p + i, r);
+    tail[r] = 0x80;
+    const size_t tl = r < 56 ? 64 : 128;
+    const uint64_t bits = n * 8;
+    for (int k = 0; k < 8; k++) tail[tl - 8 + k] = (uint8_t)(bits >> (8 * k));
+    block(tail); if (tl == 128) block(tail + 64);
+    for (int k = 0; k < 16; k++) out[k] = (uint8_t)(h[k >> 2] >> (8 * (k & 3)));
+}
+
 }  // namespace
 
+extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given, uint8_t *bam_out,
+                                         size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags);
 extern "C" int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given, uint8_t *bam_out,
                                         size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords) {
+    return hg_cram_file_to_bam_host2(ctx, cram, cram_len, refs, nrefs_given, bam_out, bam_cap, bam_bytes, nrecords, 0);
+}
+extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given, uint8_t *bam_out,
+                                         size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags) {
     if (!ctx || !cram || !bam_out || !bam_bytes || (nrefs_given && !refs)) return HG_EINVAL;
     if (cram_len < 26 || memcmp(cram, "CRAM", 4) != 0) return HG_EINVAL;
     const int major = cram[4];
@@ -127,6 +173,8 @@ extern "C" int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t
     }
     // ---- 3. slices -> BAM records ----
     const size_t ns = slices.size();
+    std::vector<size_t> md5_jobs;
+    std::vector<hgr::SliceHeader> shs(ns);
     std::vector<hg_cram_slice_blocks> sb(ns);
     std::vector<std::vector<int32_t>> ids(ns); std::vector<std::vector<const uint8_t *>> ptr(ns); std::vector<std::vector<uint32_t>> len(ns);
     std::vector<std::vector<hg_cram_ref_span>> spans(ns);
@@ -136,13 +184,9 @@ extern "C" int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t
         hgr::SliceHeader sh;
         const std::vector<uint8_t> &hd = dec[s.hdr];
         if (hgr::parse_slice_header(hd.data(), blocks[s.hdr].usz, major, sh)) return HG_EINVAL;
-        {   // the embedded-reference block id sits behind the content-id list
-            hgr::Cursor q{hd.data(), hd.data() + blocks[s.hdr].usz};
-            (void)q.itf8(); (void)q.itf8(); (void)q.itf8(); (void)q.itf8(); if (major >= 3) (void)q.ltf8(); else (void)q.itf8(); (void)q.itf8();
-            const int32_t nids = q.itf8();
-            for (int32_t k = 0; k < nids && !q.bad; k++) (void)q.itf8();
-            s.embedded = q.bad ? -1 : q.itf8();
-        }
+        shs[i] = sh;
+        s.embedded = sh.ref_base_id;
+        s.ref_seq_id = sh.ref_seq_id; s.start = sh.ref_seq_start; s.span = sh.ref_seq_span;
         memset(&sb[i], 0, sizeof sb[i]);
         sb[i].comp_hdr = dec[s.comp].data(); sb[i].comp_hdr_len = blocks[s.comp].usz;
         sb[i].slice_hdr = hd.data(); sb[i].slice_hdr_len = blocks[s.hdr].usz;
@@ -156,26 +200,72 @@ extern "C" int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t
                 spans[i].push_back(hg_cram_ref_span{sh.ref_seq_id, sh.ref_seq_start, dec[k].data(), blocks[k].usz, sh.ref_seq_id < nref ? sq_len[(size_t)sh.ref_seq_id] : (int64_t)blocks[k].usz});
         }
         sb[i].nblocks = (uint32_t)ids[i].size(); sb[i].content_id = ids[i].data(); sb[i].data = ptr[i].data(); sb[i].len = len[i].data();
-        if (spans[i].empty()) {                                          // the caller's references: the slice's stretch, or all of them for a multi-reference slice
-            auto whole = [&](int r) { if (r >= 0 && r < nrefs_given && refs[r].bases) spans[i].push_back(hg_cram_ref_span{r, 1, refs[r].bases, (uint32_t)refs[r].len, r < nref ? sq_len[(size_t)r] : (int64_t)refs[r].len}); };
+        // RR = 0 in the container's preservation map: written without a reference -- none is attached (cram_decode.c:2436-2442)
+        hgr::PlanHost ph;
+        const bool no_ref = hgr::plan_from_compression_header(ph, dec[s.comp].data(), blocks[s.comp].usz) == 0 && ph.no_ref;
+        if (spans[i].empty() && !no_ref) {                               // the caller's references: the slice's stretch (s->ref_start .. ref_end of the reference), or whole sequences for a multi-reference slice (each staged once per batch)
+            auto whole = [&](int r) { if (r >= 0 && r < nrefs_given && refs[r].bases) spans[i].push_back(hg_cram_ref_span{r, 1, refs[r].bases, (uint32_t)std::min<uint64_t>(refs[r].len, 0xfffffff0ull), r < nref ? sq_len[(size_t)r] : (int64_t)refs[r].len}); };
             if (sh.ref_seq_id >= 0) {
                 const int r = sh.ref_seq_id;
                 if (r < nrefs_given && refs[r].bases && sh.ref_seq_start >= 1 && (uint64_t)sh.ref_seq_start <= refs[r].len) {
                     const uint64_t avail = refs[r].len - (uint64_t)sh.ref_seq_start + 1;
-                    spans[i].push_back(hg_cram_ref_span{r, sh.ref_seq_start, refs[r].bases + sh.ref_seq_start - 1, (uint32_t)std::min<uint64_t>(avail, 0xffffffffull),
+                    const uint64_t want = sh.ref_seq_span > 0 ? (uint64_t)sh.ref_seq_span : avail;      // cram_get_ref(fd, id, start, start + span - 1)
+                    spans[i].push_back(hg_cram_ref_span{r, sh.ref_seq_start, refs[r].bases + sh.ref_seq_start - 1, (uint32_t)std::min<uint64_t>(std::min(avail, want), 0xfffffff0ull),
                                                         r < nref ? sq_len[(size_t)r] : (int64_t)refs[r].len});
                 }
             } else if (sh.ref_seq_id == -2) for (int r = 0; r < nrefs_given; r++) whole(r);
         }
+        // "MD5 checksum reference mismatch" (cram_decode.c:2480-2540): the slice header's digest against the span about to be used
+        static const uint8_t zero16[16] = {0};
+        if (major >= 2 && sh.ref_seq_id >= 0 && !(flags & HG_CRAM_IGNORE_MD5) && sh.has_md5 && memcmp(sh.md5, zero16, 16) != 0 && !no_ref) {
+            if (spans[i].empty()) return HG_EBLOCK;                      // no reference and no embedded block: "Unable to fetch reference"
+            md5_jobs.push_back(i);
+        }
         sb[i].nrefs = (uint32_t)spans[i].size(); sb[i].refs = spans[i].data(); sb[i].decode_md = -1;      // hts_open's default
+    }
+    if (!md5_jobs.empty()) {                                             // host threads: the digests are independent (the reference computes them in its slice workers)
+        std::atomic<size_t> next{0}; std::atomic<int> bad{0};
+        auto work = [&]() {
+            for (size_t j; (j = next.fetch_add(1)) < md5_jobs.size();) {
+                const size_t i = md5_jobs[j];
+                const hg_cram_ref_span &sp = spans[i][0];
+                const hgr::SliceHeader &sh = shs[i];
+                uint64_t start = sh.ref_seq_start >= sp.start ? (uint64_t)(sh.ref_seq_start - sp.start) : 0u, len = (uint64_t)sh.ref_seq_span;
+                const bool embedded = slices[i].embedded >= 0 && sp.bases != (refs && sh.ref_seq_id < nrefs_given && refs[sh.ref_seq_id].bases ? refs[sh.ref_seq_id].bases + sh.ref_seq_start - 1 : nullptr);
+                if (embedded) { start = 0; len = sp.len; }               // an embedded reference block is digested whole
+                if (start > sp.len) start = sp.len;
+                if (start + len > sp.len) len = sp.len - start;
+                uint8_t dg[16]; md5_of(sp.bases + start, len, dg);
+                if (memcmp(dg, sh.md5, 16) != 0) bad = 1;
+            }
+        };
+        const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<size_t>(md5_jobs.size(), 16));
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        if (bad) return HG_EBLOCK;                                       // the reference: error "MD5 checksum reference mismatch", cram_decode_slice returns -1
     }
     std::vector<const char *> rgp; for (auto &r : rg_id) rgp.push_back(r.c_str());
     std::vector<uint64_t> rec_off(ns + 1, 0); std::vector<int32_t> status(ns, 0);
     uint64_t rec_bytes = 0;
     int rc = HG_OK;
-    if (ns) {
-        rc = hg_cram_decode_bam_host(ctx, ns, sb.data(), major, nref, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), bases + 4096, bam_out + hb, bam_cap - hb, rec_off.data(), nullptr,
-                                     &rec_bytes, status.data());
+    // the blocks of one device batch are addressed with 32 bits (cram_records_plan.h): a large file goes through in several batches
+    for (size_t i0 = 0; i0 < ns && rc == HG_OK;) {
+        uint64_t bytes = 0; size_t i1 = i0;
+        while (i1 < ns) {
+            uint64_t b = (uint64_t)sb[i1].core_len + 64;
+            for (uint32_t k = 0; k < sb[i1].nblocks; k++) b += ((uint64_t)sb[i1].len[k] + 15) & ~15ull;
+            if (i1 > i0 && bytes + b > 0xc0000000ull) break;
+            bytes += b; i1++;
+        }
+        std::vector<uint64_t> ro(i1 - i0 + 1, 0);
+        uint64_t got = 0;
+        rc = hg_cram_decode_bam_host(ctx, i1 - i0, sb.data() + i0, major, nref, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), bases + 4096, bam_out + hb + rec_bytes,
+                                     bam_cap - hb - rec_bytes, ro.data(), nullptr, &got, status.data() + i0);
+        rec_bytes += got;
+        for (size_t k = 0; k <= i1 - i0; k++) rec_off[i0 + k] = rec_off[i0] + ro[k];
+        i0 = i1;
     }
     *bam_bytes = hb + rec_bytes;
     if (nrecords) *nrecords = rec_off[ns];

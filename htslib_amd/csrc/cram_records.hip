@@ -29,24 +29,10 @@
 #include "hg_device.h"
 #include "hg_internal.h"
 #include "cram_records_plan.h"
+#include "cram_records_fast_plan.h"
+#include "cram_records_dev.h"
 
 namespace hgr {
-
-struct DevTables {
-    const PlanDev *plans; const Codec *codecs; const HuffCode *huff; const int32_t *tl_off, *tl_codec, *tl_tag;
-    const SliceDev *slices; uint32_t *tab; const uint8_t *data; const RefSpan *refs;
-};
-struct DevCols {
-    int32_t *flags, *cram_flags, *ref_id, *len, *rg, *mqual, *mate_ref_id, *ncigar, *name_len;
-    int64_t *apos, *aend, *mate_pos, *tlen;
-    uint64_t *cigar_off, *name_off;
-    uint32_t *cigar; uint8_t *names;
-    uint64_t *seq_off; uint8_t *seq, *qual; unsigned long long *seq_pool; uint64_t seq_cap;   // seq == nullptr: bases / qualities not wanted
-    uint64_t *aux_off; int32_t *aux_len; uint8_t *aux;                                      // aux == nullptr: not wanted
-    int32_t *mate_flags, *mate_line; int64_t *explicit_tlen; uint32_t *coff, *noff, *aoff;   // scratch columns
-    uint32_t *totals;                                                                        // per slice: CIGAR words, name bytes, aux bytes written, copy jobs noted
-    CopyJob *jobs;                                                                           // deferred bulk copies of all slices (SliceDev::job_off); nullptr = none
-};
 
 // Runs the record loop of slice k (one thread).
 __device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, const SliceDev &d, int32_t nref, uint32_t k, bool defer, uint32_t *tab, const Codec *codecs, HGR_LDS uint8_t *wbuf, HGR_LDS uint32_t *wpos) {
@@ -102,7 +88,7 @@ __global__ __launch_bounds__(64)
 void cram_records_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref, const int32_t *pre_status, int32_t *status) {
     const int lane = threadIdx.x & 63;
     for (uint32_t k = blockIdx.x; k < nslices; k += gridDim.x) {
-        if (pre_status[k] != 0) { if (lane == 0) status[k] = pre_status[k]; continue; }
+        if (pre_status[k] != 0) continue;                                   // failed while the batch was planned, or not this launch's (STATUS_SKIP): status[] holds the verdict
         const SliceDev d = T.slices[k];
         // block offsets / lengths / cursors of the slice: every value read starts with a look at them, so they live in LDS (a global
         // table cost one extra dependent round trip per value)
@@ -130,7 +116,7 @@ void cram_records_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref,
 __global__ __launch_bounds__(64)
 void cram_records_lane_kernel(DevTables T, DevCols D, uint32_t nslices, int32_t nref, const int32_t *pre_status, int32_t *status) {
     for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < nslices; k += gridDim.x * 64u) {
-        if (pre_status[k] != 0) { status[k] = pre_status[k]; continue; }
+        if (pre_status[k] != 0) continue;
         const SliceDev d = T.slices[k];
         status[k] = decode_one(T, D, d, nref, k, false, T.tab + d.tab_off, T.codecs + T.plans[d.plan].codec_base, nullptr, nullptr);                   // every lane is a chain of its own here: nothing to hand the copies to
     }
@@ -163,19 +149,59 @@ void cram_bam_size_kernel(DevTables T, DevCols D, const uint32_t *rg_off, int32_
         hg::wave_sync();
     }
 }
-// exclusive prefix sum of n values in place, n + 1 outputs (one workgroup: each thread owns a contiguous piece)
-__global__ __launch_bounds__(1024)
-void scan_u64_kernel(uint64_t *v, uint64_t n) {
-    __shared__ uint64_t part[1024];
-    const uint64_t t = threadIdx.x, per = (n + 1023) / 1024, a = t * per < n ? t * per : n, b = a + per < n ? a + per : n;
+// exclusive prefix sum of n values in place, n + 1 outputs, over the whole device: tiles of SCAN_TILE values are summed (one workgroup each),
+// the tile sums are scanned by one workgroup, and a third launch scans inside the tiles from their bases.  (Round 2 used ONE workgroup for
+// everything: 1.9 ms for 1 M records, a quarter of cram_to_bam's time.)
+constexpr uint32_t SCAN_TILE = 4096, SCAN_TPB = 256;
+__device__ __forceinline__ uint64_t wg_excl_scan_u64(uint64_t x, uint64_t *lds, uint64_t &total) {     // 256 threads
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long inc = x;
+    for (int sft = 1; sft < 64; sft <<= 1) { const unsigned long long y = __shfl_up(inc, sft, 64); if (lane >= sft) inc += y; }
+    if (lane == 63) lds[wv] = inc;
+    __syncthreads();
+    uint64_t before = 0, all = 0;
+    for (int w = 0; w < 4; w++) { const uint64_t t = lds[w]; if (w < wv) before += t; all += t; }
+    __syncthreads();
+    total = all;
+    return before + inc - x;
+}
+__global__ __launch_bounds__(SCAN_TPB)
+void scan_tile_sums_kernel(const uint64_t *v, uint64_t n, uint64_t *tile_sum) {
+    __shared__ uint64_t lds[4];
+    const uint64_t t0 = (uint64_t)blockIdx.x * SCAN_TILE;
     uint64_t sum = 0;
-    for (uint64_t i = a; i < b; i++) sum += v[i];
-    part[t] = sum;
-    __syncthreads();
-    if (t == 0) { uint64_t run = 0; for (int i = 0; i < 1024; i++) { const uint64_t x = part[i]; part[i] = run; run += x; } v[n] = run; }
-    __syncthreads();
-    uint64_t run = part[t];
-    for (uint64_t i = a; i < b; i++) { const uint64_t x = v[i]; v[i] = run; run += x; }
+    for (uint32_t i = threadIdx.x; i < SCAN_TILE; i += SCAN_TPB) if (t0 + i < n) sum += v[t0 + i];
+    uint64_t total;
+    (void)wg_excl_scan_u64(sum, lds, total);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(SCAN_TPB)
+void scan_tile_bases_kernel(uint64_t *tile_sum, uint64_t ntiles, uint64_t *grand_total) {           // one workgroup
+    __shared__ uint64_t lds[4];
+    uint64_t carry = 0;
+    for (uint64_t i0 = 0; i0 < ntiles; i0 += SCAN_TPB) {
+        const uint64_t i = i0 + threadIdx.x;
+        const uint64_t x = i < ntiles ? tile_sum[i] : 0;
+        uint64_t total;
+        const uint64_t ex = wg_excl_scan_u64(x, lds, total);
+        if (i < ntiles) tile_sum[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *grand_total = carry;
+}
+__global__ __launch_bounds__(SCAN_TPB)
+void scan_tiles_kernel(uint64_t *v, uint64_t n, const uint64_t *tile_base) {
+    __shared__ uint64_t lds[4];
+    const uint64_t t0 = (uint64_t)blockIdx.x * SCAN_TILE;
+    constexpr uint32_t PER = SCAN_TILE / SCAN_TPB;                         // consecutive values per thread
+    uint64_t x[PER], sum = 0;
+    const uint64_t a = t0 + (uint64_t)threadIdx.x * PER;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) { x[j] = a + j < n ? v[a + j] : 0; sum += x[j]; }
+    uint64_t total;
+    uint64_t run = tile_base[blockIdx.x] + wg_excl_scan_u64(sum, lds, total);
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) { if (a + j < n) v[a + j] = run; run += x[j]; }
 }
 __device__ __forceinline__ uint32_t nt16(uint32_t c) {                    // seq_nt16_table (hts.c)
     switch (c & ~0x20u) {
@@ -193,49 +219,63 @@ __device__ __forceinline__ uint32_t reg2bin(int64_t beg, int64_t end) {  // bam_
     if (beg >> 26 == end >> 26) return (uint32_t)(((1 << 3) - 1) / 7 + (beg >> 26));
     return 0;
 }
-__global__ __launch_bounds__(64)
-void cram_bam_write_kernel(DevTables T, DevCols D, Dense P, const unsigned char *rg_names, const uint32_t *rg_off, int32_t nrg, uint32_t nslices,
-                           const int32_t *status, const uint64_t *off, uint8_t *out) {
+// One WAVEFRONT per record: the 36 fixed bytes by nine lanes, then name, CIGAR, packed bases, qualities, tags a byte (or word) per lane --
+// consecutive lanes write consecutive bytes, so a record costs a dozen coalesced stores.  (Round 2 had one LANE per record writing ~350
+// bytes one after the other: 64 cache lines per store instruction, 7.5 ms per million records.)  Records of failed slices have size 0.
+__global__ __launch_bounds__(256)
+void cram_bam_write_kernel(DevCols D, Dense P, const unsigned char *rg_names, const uint32_t *rg_off, int32_t nrg, uint64_t nrec, const uint64_t *off, uint8_t *out) {
     const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t k = blockIdx.x; k < nslices; k += gridDim.x) {
-        if (status[k] != 0) continue;
-        const SliceDev d = T.slices[k];
-        for (uint32_t q = lane; q < (uint32_t)d.nrec; q += 64) {
-            const uint64_t r = d.rec_off + q;
-            uint8_t *o = out + off[r];
-            const uint32_t bytes = (uint32_t)(off[r + 1] - off[r]);
-            const uint32_t nl = D.name_len[r] > 0 ? (uint32_t)D.name_len[r] : 0u, len = (uint32_t)D.len[r], nc = (uint32_t)D.ncigar[r], flag = (uint32_t)D.flags[r];
-            const uint32_t *cig = P.cigar + D.cigar_off[r];
-            int64_t rlen = 0;
-            if (!(flag & BAM_FUNMAP)) for (uint32_t i = 0; i < nc; i++) { const uint32_t op = cig[i] & 15u; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += cig[i] >> 4; }
-            if (rlen == 0) rlen = 1;
-            const int64_t pos = D.apos[r] - 1, mpos = D.mate_pos[r] - 1;
-            auto put32 = [&](uint32_t at, uint32_t v) { o[at] = (uint8_t)v; o[at + 1] = (uint8_t)(v >> 8); o[at + 2] = (uint8_t)(v >> 16); o[at + 3] = (uint8_t)(v >> 24); };
-            put32(0, bytes - 4u);
-            put32(4, (uint32_t)D.ref_id[r]); put32(8, (uint32_t)pos);
-            put32(12, reg2bin(pos, pos + rlen) << 16 | ((uint32_t)D.mqual[r] & 0xffu) << 8 | ((nl ? nl : 1u) + 1u));
-            put32(16, flag << 16 | (nc & 0xffffu)); put32(20, len);
-            put32(24, (uint32_t)D.mate_ref_id[r]); put32(28, (uint32_t)mpos); put32(32, (uint32_t)D.tlen[r]);
-            uint32_t at = 36;
-            if (nl) { const uint8_t *nm = P.names + D.name_off[r]; for (uint32_t i = 0; i < nl; i++) o[at + i] = nm[i]; at += nl; } else o[at++] = '*';
-            o[at++] = 0;
-            for (uint32_t i = 0; i < nc; i++) { put32(at, cig[i]); at += 4; }
-            const uint8_t *sq = D.seq + D.seq_off[r], *ql = D.qual + D.seq_off[r];
-            for (uint32_t i = 0; i + 1 < len; i += 2) o[at + (i >> 1)] = (uint8_t)(nt16(sq[i]) << 4 | nt16(sq[i + 1]));
-            if (len & 1u) o[at + (len >> 1)] = (uint8_t)(nt16(sq[len - 1]) << 4);
-            at += (len + 1u) / 2u;
-            for (uint32_t i = 0; i < len; i++) o[at + i] = ql[i];
-            at += len;
-            const uint32_t na = (uint32_t)D.aux_len[r];
-            const uint8_t *ax = P.aux + D.aux_off[r];
-            for (uint32_t i = 0; i < na; i++) o[at + i] = ax[i];
-            at += na;
-            const int32_t rg = D.rg[r];
-            if (rg >= 0 && rg < nrg) {                                       // RG:Z: from the read-group series (cram_decode.c:3180-3189)
-                o[at++] = 'R'; o[at++] = 'G'; o[at++] = 'Z';
-                for (uint32_t i = rg_off[rg]; i < rg_off[rg + 1]; i++) o[at++] = rg_names[i];
-                o[at++] = 0;
+    const uint64_t nw = (uint64_t)gridDim.x * 4u;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); r < nrec; r += nw) {
+        const uint64_t o0 = off[r];
+        const uint32_t bytes = (uint32_t)(off[r + 1] - o0);
+        if (!bytes) continue;
+        uint8_t *o = out + o0;
+        const uint32_t nl = D.name_len[r] > 0 ? (uint32_t)D.name_len[r] : 0u, len = (uint32_t)D.len[r], nc = (uint32_t)D.ncigar[r], flag = (uint32_t)D.flags[r];
+        const uint32_t *cig = P.cigar + D.cigar_off[r];
+        long long rl = 0;                                                  // reference length of the alignment (bam_cigar2rlen) -> bin
+        if (!(flag & BAM_FUNMAP)) for (uint32_t i = lane; i < nc; i += 64) { const uint32_t op = cig[i] & 15u; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += cig[i] >> 4; }
+        for (int sft = 1; sft < 64; sft <<= 1) rl += __shfl_xor(rl, sft, 64);
+        if (rl == 0) rl = 1;
+        const int64_t pos = D.apos[r] - 1, mpos = D.mate_pos[r] - 1;
+        if (lane < 9) {
+            uint32_t w;
+            switch (lane) {
+            case 0: w = bytes - 4u; break;
+            case 1: w = (uint32_t)D.ref_id[r]; break;
+            case 2: w = (uint32_t)pos; break;
+            case 3: w = reg2bin(pos, pos + rl) << 16 | ((uint32_t)D.mqual[r] & 0xffu) << 8 | ((nl ? nl : 1u) + 1u); break;
+            case 4: w = flag << 16 | (nc & 0xffffu); break;
+            case 5: w = len; break;
+            case 6: w = (uint32_t)D.mate_ref_id[r]; break;
+            case 7: w = (uint32_t)mpos; break;
+            default: w = (uint32_t)D.tlen[r]; break;
             }
+            uint8_t *q = o + 4u * lane;
+            q[0] = (uint8_t)w; q[1] = (uint8_t)(w >> 8); q[2] = (uint8_t)(w >> 16); q[3] = (uint8_t)(w >> 24);
+        }
+        uint32_t at = 36;
+        if (nl) { const uint8_t *nm = P.names + D.name_off[r]; for (uint32_t i = lane; i < nl; i += 64) o[at + i] = nm[i]; at += nl; }
+        else { if (lane == 0) o[at] = '*'; at++; }
+        if (lane == 0) o[at] = 0;
+        at++;
+        for (uint32_t i = lane; i < nc; i += 64) { const uint32_t w = cig[i]; uint8_t *q = o + at + 4u * i; q[0] = (uint8_t)w; q[1] = (uint8_t)(w >> 8); q[2] = (uint8_t)(w >> 16); q[3] = (uint8_t)(w >> 24); }
+        at += 4u * nc;
+        const uint8_t *sq = D.seq + D.seq_off[r], *ql = D.qual + D.seq_off[r];
+        for (uint32_t i = lane; i < (len + 1u) / 2u; i += 64) o[at + i] = (uint8_t)(nt16(sq[2u * i]) << 4 | (2u * i + 1u < len ? nt16(sq[2u * i + 1u]) : 0u));
+        at += (len + 1u) / 2u;
+        for (uint32_t i = lane; i < len; i += 64) o[at + i] = ql[i];
+        at += len;
+        const uint32_t na = (uint32_t)D.aux_len[r];
+        const uint8_t *ax = P.aux + D.aux_off[r];
+        for (uint32_t i = lane; i < na; i += 64) o[at + i] = ax[i];
+        at += na;
+        const int32_t rg = D.rg[r];
+        if (rg >= 0 && rg < nrg) {                                           // RG:Z: from the read-group series (cram_decode.c:3180-3189)
+            const uint32_t a = rg_off[rg], n = rg_off[rg + 1] - a;
+            if (lane < 3) o[at + lane] = lane == 0 ? 'R' : lane == 1 ? 'G' : 'Z';
+            for (uint32_t i = lane; i < n; i += 64) o[at + 3u + i] = rg_names[a + i];
+            if (lane == 0) o[at + 3u + n] = 0;
         }
     }
 }
@@ -262,174 +302,368 @@ struct PhaseTimer {
         if (!on) return;
         (void)hipStreamSynchronize(s);
         const auto t = std::chrono::steady_clock::now();
-        char b[96]; snprintf(b, sizeof b, " %s %.1f ms", what, std::chrono::duration<double, std::milli>(t - t0).count()); log += b; t0 = t;
+        char b[96]; snprintf(b, sizeof b, " %s %.2f ms", what, std::chrono::duration<double, std::milli>(t - t0).count()); log += b; t0 = t;
     }
     ~PhaseTimer() { if (on) fprintf(stderr, "cram records phases:%s\n", log.c_str()); }
 };
 struct BamSink { const char *const *rg_names; int nrg; uint8_t *out; size_t cap; uint64_t *rec_bam_off; uint64_t *total; };
-}
-static int records_impl(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, size_t rec_cap, size_t cigar_cap,
-                        size_t name_cap, size_t seq_cap, size_t aux_cap, const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status, uint64_t *used,
-                        const BamSink *bam) {
-    if (!ctx || (nslices && (!slices || !out || !rec_off || !status))) return HG_EINVAL;
-    if (nslices == 0) { if (rec_off) rec_off[0] = 0; return HG_OK; }
-    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
-    hgr::Batch B;
+
+// Device memory of a batch: slots of the context's scratch (host entry points: grown on demand, kept between calls) or allocations of
+// its own (a staged batch that outlives the call: hg_cram_batch)
+enum { M_DATA, M_OUT, M_TAB, M_PACK, M_BSZ, M_BAM, M_JOBS, M_FAST, M_POOL, M_FSCR, M_TMPSEQ, M_N };
+struct RecMem {
+    hg_ctx *ctx = nullptr; bool own = false; void *p[M_N] = {}; size_t cap[M_N] = {};
+    int need(int slot, size_t bytes) {
+        static const int ctx_slot[M_N] = {0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11};
+        if (!own) { const int rc = hg::ensure_scratch(ctx, ctx_slot[slot], bytes); if (rc) return rc; p[slot] = ctx->d_scratch[ctx_slot[slot]]; return HG_OK; }
+        if (cap[slot] >= bytes) return HG_OK;
+        if (p[slot]) (void)hipFree(p[slot]);
+        p[slot] = nullptr; cap[slot] = 0;
+        if (hipMalloc(&p[slot], bytes + 256) != hipSuccess) return HG_ENOMEM;
+        cap[slot] = bytes;
+        return HG_OK;
+    }
+    void release() { if (own) for (int i = 0; i < M_N; i++) if (p[i]) { (void)hipFree(p[i]); p[i] = nullptr; cap[i] = 0; } }
+};
+}  // namespace
+
+// A batch of slices staged on the device (blocks, reference spans, header tables) and everything one decoding run leaves behind.
+struct hg_cram_batch {
+    hgr::Batch B; hgr::FastBatch F;
+    RecMem M;
+    size_t nslices = 0; int major = 3, nref = 0; bool want_seq = false, want_aux = false; size_t seq_cap = 0;
+    // carved images
+    size_t o32[12], o64[5], ou64[3], ou32[3], ocig, onam, ost, oaux, otot, obase, oso, oseq, oqual, opool, opre;
+    size_t t_off[10];
+    hgr::DevTables T; hgr::DevCols D; hgr::FastDev FD;
+    int32_t *d_status = nullptr, *d_pre0 = nullptr, *d_pre1 = nullptr;
+    uint32_t *d_list = nullptr;                         // device copy of a slice list (chain placement)
+    // results of the last run (host)
+    std::vector<int32_t> status; std::vector<uint32_t> tot; std::vector<uint64_t> base;
+    uint64_t used_c = 0, used_n = 0, used_a = 0, pool_used = 0, bam_bytes = 0;
+    hgr::Dense PK{};
+    uint64_t *d_bam_off = nullptr; uint8_t *d_bam = nullptr;
+    size_t n_chain0 = 0;                                // slices the passes do not take
+    std::vector<uint8_t> retried;                       // slices the passes gave up (last run)
+    // column descriptors of the passes (device)
+    const hg_stream_desc *d_itf8 = nullptr, *d_stop = nullptr; const uint32_t *d_sum_src = nullptr, *d_col_slice = nullptr; int32_t *d_col_status = nullptr;
+};
+
+static int rec_stage(hg_ctx *ctx, hg_cram_batch &R, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, bool want_seq, bool want_aux, size_t seq_cap) {
+    hgr::Batch &B = R.B;
     int rc = hgr::batch_build(B, (const hgr::SliceIn *)slices, nslices, major_version);
     if (rc) return rc == -3 ? HG_BLOCK_EUNSUPPORTED : HG_EINVAL;
-    const bool want_aux = bam || (out->aux && out->aux_off && out->aux_len);
-    if (B.nrec > rec_cap) return HG_EINVAL;
-    for (size_t i = 0; i < nslices; i++) rec_off[i] = B.slices[i].rec_off;
-    rec_off[nslices] = B.nrec;
-    // device image of the tables: one buffer, carved
-    struct Part { const void *src; size_t bytes; size_t off; };
-    std::vector<Part> parts = {{B.plans.data(), B.plans.size() * sizeof(hgr::PlanDev), 0}, {B.codecs.data(), B.codecs.size() * sizeof(hgr::Codec), 0},
-                               {B.huff.data(), B.huff.size() * sizeof(hgr::HuffCode), 0}, {B.tl_off.data(), B.tl_off.size() * 4, 0},
-                               {B.tl_codec.data(), B.tl_codec.size() * 4, 0}, {B.slices.data(), B.slices.size() * sizeof(hgr::SliceDev), 0},
-                               {B.tab.data(), B.tab.size() * 4, 0}, {B.status.data(), B.status.size() * 4, 0},
-                               {B.refs.data(), B.refs.size() * sizeof(hgr::RefSpan), 0}, {B.tl_tag.data(), B.tl_tag.size() * 4, 0}};
+    const char *fp = getenv("HG_CRAM_RECORDS_PATH");                   // "chain": every slice through the chain decoder (the checker of the data-parallel passes)
+    hgr::fast_build(B, R.F, !(fp && fp[0] == 'c'));
+    hgr::FastBatch &F = R.F;
+    R.nslices = nslices; R.major = major_version; R.nref = nref; R.want_seq = want_seq; R.want_aux = want_aux; R.seq_cap = seq_cap;
+    R.n_chain0 = 0;
+    for (size_t i = 0; i < nslices; i++) if (B.status[i] == 0 && !F.is_fast[i]) R.n_chain0++;
+    hipStream_t s = ctx->stream;
+    // ---- header tables: one buffer, carved
+    struct Part { const void *src; size_t bytes; };
+    const Part parts[10] = {{B.plans.data(), B.plans.size() * sizeof(hgr::PlanDev)}, {B.codecs.data(), B.codecs.size() * sizeof(hgr::Codec)},
+                            {B.huff.data(), B.huff.size() * sizeof(hgr::HuffCode)}, {B.tl_off.data(), B.tl_off.size() * 4},
+                            {B.tl_codec.data(), B.tl_codec.size() * 4}, {B.slices.data(), B.slices.size() * sizeof(hgr::SliceDev)},
+                            {B.tab.data(), B.tab.size() * 4}, {B.status.data(), B.status.size() * 4},
+                            {B.refs.data(), B.refs.size() * sizeof(hgr::RefSpan)}, {B.tl_tag.data(), B.tl_tag.size() * 4}};
     size_t tbytes = 0;
-    for (auto &p : parts) { p.off = tbytes; tbytes += (p.bytes + 63) & ~(size_t)63; }
-    const size_t R = B.nrec ? B.nrec : 1;
-    // output image: 9 + 2 int32, 4 + 1 int64, 2 uint64, 2 uint32 scratch columns, cigar, names, status
+    for (int i = 0; i < 10; i++) { R.t_off[i] = tbytes; tbytes += (parts[i].bytes + 63) & ~(size_t)63; }
+    // ---- output image
+    const size_t N = B.nrec ? B.nrec : 1;
     size_t obytes = 0;
     auto carve = [&](size_t bytes) { const size_t o = obytes; obytes += (bytes + 63) & ~(size_t)63; return o; };
-    size_t o32[12], o64[5], ou64[3], ou32[3];
-    for (auto &o : o32) o = carve(R * 4);
-    for (auto &o : o64) o = carve(R * 8);
-    for (auto &o : ou64) o = carve(R * 8);
-    for (auto &o : ou32) o = carve(R * 4);
-    const size_t ocig = carve((B.cig_total ? B.cig_total : 1) * 4), onam = carve(B.name_total ? B.name_total : 1), ost = carve(nslices * 4);
-    const bool want_seq = bam || (out->seq && out->qual && out->seq_off);
-    const size_t oaux = carve(want_aux ? B.aux_total + 1 : 1);
-    const size_t otot = carve(nslices * 16), obase = carve(nslices * 24);
-    const size_t oso = carve(R * 8), oseq = carve(want_seq ? seq_cap + 1 : 1), oqual = carve(want_seq ? seq_cap + 1 : 1), opool = carve(8);
-    if ((rc = hg::ensure_scratch(ctx, 0, B.data_bytes + 64)) || (rc = hg::ensure_scratch(ctx, 1, obytes + 64)) || (rc = hg::ensure_scratch(ctx, 2, tbytes + 64))) return rc;
-    hipStream_t s = ctx->stream;
-    PhaseTimer PT(s);
-    PT.mark("plan");
-    uint8_t *d_data = (uint8_t *)ctx->d_scratch[0], *d_out = (uint8_t *)ctx->d_scratch[1], *d_tab = (uint8_t *)ctx->d_scratch[2];
+    for (auto &o : R.o32) o = carve(N * 4);
+    for (auto &o : R.o64) o = carve(N * 8);
+    for (auto &o : R.ou64) o = carve(N * 8);
+    for (auto &o : R.ou32) o = carve(N * 4);
+    R.ocig = carve((B.cig_total ? B.cig_total : 1) * 4); R.onam = carve(B.name_total ? B.name_total : 1); R.ost = carve(nslices * 4);
+    R.oaux = carve(want_aux ? B.aux_total + 1 : 1);
+    R.otot = carve(nslices * 16); R.obase = carve(nslices * 24);
+    R.oso = carve(N * 8); R.oseq = carve(want_seq ? seq_cap + 1 : 1); R.oqual = carve(want_seq ? seq_cap + 1 : 1); R.opool = carve(64);
+    R.opre = carve(nslices * 8 + nslices * 4);                           // two pre-status vectors, a slice list
+    RecMem &M = R.M;
+    if ((rc = M.need(M_DATA, B.data_bytes + 64)) || (rc = M.need(M_OUT, obytes + 64)) || (rc = M.need(M_TAB, tbytes + 64))) return rc;
+    uint8_t *d_data = (uint8_t *)M.p[M_DATA], *d_out = (uint8_t *)M.p[M_OUT], *d_tab = (uint8_t *)M.p[M_TAB];
     bool ok = hg::stage_upload(ctx, B.src_ptr.data(), B.src_len.data(), B.src_off.data(), nullptr, B.src_ptr.size(), B.data_bytes, d_data, s) == HG_OK;
-    for (auto &p : parts) if (ok && p.bytes) ok = hipMemcpyAsync(d_tab + p.off, p.src, p.bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+    for (int i = 0; i < 10; i++) if (ok && parts[i].bytes) ok = hipMemcpyAsync(d_tab + R.t_off[i], parts[i].src, parts[i].bytes, hipMemcpyHostToDevice, s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
-    hgr::DevTables T{(const hgr::PlanDev *)(d_tab + parts[0].off), (const hgr::Codec *)(d_tab + parts[1].off), (const hgr::HuffCode *)(d_tab + parts[2].off),
-                     (const int32_t *)(d_tab + parts[3].off), (const int32_t *)(d_tab + parts[4].off), (const int32_t *)(d_tab + parts[9].off),
-                     (const hgr::SliceDev *)(d_tab + parts[5].off),
-                     (uint32_t *)(d_tab + parts[6].off), d_data, (const hgr::RefSpan *)(d_tab + parts[8].off)};
-    hgr::DevCols D;
+    R.T = hgr::DevTables{(const hgr::PlanDev *)(d_tab + R.t_off[0]), (const hgr::Codec *)(d_tab + R.t_off[1]), (const hgr::HuffCode *)(d_tab + R.t_off[2]),
+                         (const int32_t *)(d_tab + R.t_off[3]), (const int32_t *)(d_tab + R.t_off[4]), (const int32_t *)(d_tab + R.t_off[9]),
+                         (const hgr::SliceDev *)(d_tab + R.t_off[5]), (uint32_t *)(d_tab + R.t_off[6]), d_data, (const hgr::RefSpan *)(d_tab + R.t_off[8])};
+    hgr::DevCols &D = R.D;
     int32_t **p32[11] = {&D.flags, &D.cram_flags, &D.ref_id, &D.len, &D.rg, &D.mqual, &D.mate_ref_id, &D.ncigar, &D.name_len, &D.mate_flags, &D.mate_line};
-    for (int i = 0; i < 11; i++) *p32[i] = (int32_t *)(d_out + o32[i]);
+    for (int i = 0; i < 11; i++) *p32[i] = (int32_t *)(d_out + R.o32[i]);
     int64_t **p64[5] = {&D.apos, &D.aend, &D.mate_pos, &D.tlen, &D.explicit_tlen};
-    for (int i = 0; i < 5; i++) *p64[i] = (int64_t *)(d_out + o64[i]);
-    D.cigar_off = (uint64_t *)(d_out + ou64[0]); D.name_off = (uint64_t *)(d_out + ou64[1]);
-    D.coff = (uint32_t *)(d_out + ou32[0]); D.noff = (uint32_t *)(d_out + ou32[1]); D.aoff = (uint32_t *)(d_out + ou32[2]);
-    D.aux_off = (uint64_t *)(d_out + ou64[2]); D.aux_len = (int32_t *)(d_out + o32[11]); D.aux = want_aux ? d_out + oaux : nullptr;
-    D.cigar = (uint32_t *)(d_out + ocig); D.names = d_out + onam;
-    D.seq_off = (uint64_t *)(d_out + oso); D.seq = want_seq ? d_out + oseq : nullptr; D.qual = want_seq ? d_out + oqual : nullptr;
-    D.seq_pool = (unsigned long long *)(d_out + opool); D.seq_cap = seq_cap;
-    if (hipMemsetAsync(d_out + opool, 0, 8, s) != hipSuccess) return HG_ELAUNCH;
-    D.totals = (uint32_t *)(d_out + otot);
+    for (int i = 0; i < 5; i++) *p64[i] = (int64_t *)(d_out + R.o64[i]);
+    D.cigar_off = (uint64_t *)(d_out + R.ou64[0]); D.name_off = (uint64_t *)(d_out + R.ou64[1]);
+    D.coff = (uint32_t *)(d_out + R.ou32[0]); D.noff = (uint32_t *)(d_out + R.ou32[1]); D.aoff = (uint32_t *)(d_out + R.ou32[2]);
+    D.aux_off = (uint64_t *)(d_out + R.ou64[2]); D.aux_len = (int32_t *)(d_out + R.o32[11]); D.aux = want_aux ? d_out + R.oaux : nullptr;
+    D.cigar = (uint32_t *)(d_out + R.ocig); D.names = d_out + R.onam;
+    D.seq_off = (uint64_t *)(d_out + R.oso); D.seq = want_seq ? d_out + R.oseq : nullptr; D.qual = want_seq ? d_out + R.oqual : nullptr;
+    D.seq_pool = (unsigned long long *)(d_out + R.opool); D.seq_cap = seq_cap;
+    D.totals = (uint32_t *)(d_out + R.otot);
     D.jobs = nullptr;
-    int32_t *d_status = (int32_t *)(d_out + ost);
-    PT.mark("upload");
-    // one wavefront per slice until the chip is full of them several times over, then one slice per lane
-    bool lane_mode = nslices >= 1024;                                  // measured at 8192 slices: 19.9 ms per call against 32.6 ms (profiles/r02_cram_records_probe.txt)
-    if (const char *m = getenv("HG_CRAM_RECORDS_MODE")) lane_mode = m[0] == 'l';
-    if (!lane_mode && (want_seq || want_aux)) {                           // room for the copies the chain hands over
-        if ((rc = hg::ensure_scratch(ctx, 7, (B.job_total + 1) * sizeof(hgr::CopyJob)))) return rc;
-        D.jobs = (hgr::CopyJob *)ctx->d_scratch[7];
+    R.d_status = (int32_t *)(d_out + R.ost);
+    R.d_pre0 = (int32_t *)(d_out + R.opre); R.d_pre1 = R.d_pre0 + nslices; R.d_list = (uint32_t *)(R.d_pre1 + nslices);
+    {   // the chain decoder's first launch leaves the passes' slices alone
+        std::vector<int32_t> pre(B.status);
+        for (size_t i = 0; i < nslices; i++) if (F.is_fast[i]) pre[i] = hgr::STATUS_SKIP;
+        // (a pageable source is copied by the runtime before the call returns)
+        if (nslices && hipMemcpyAsync(R.d_pre0, pre.data(), nslices * 4, hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
     }
-    if (lane_mode) {
-        const unsigned grid = (unsigned)std::min<size_t>((nslices + 63) / 64, (size_t)ctx->cus * 16);
-        hipLaunchKernelGGL(hgr::cram_records_lane_kernel, dim3(grid), dim3(64), 0, s, T, D, (uint32_t)nslices, (int32_t)nref, (const int32_t *)(d_tab + parts[7].off), d_status);
-    } else {
-        const unsigned grid = (unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 16);
-        hipLaunchKernelGGL(hgr::cram_records_kernel, dim3(grid), dim3(64), 0, s, T, D, (uint32_t)nslices, (int32_t)nref, (const int32_t *)(d_tab + parts[7].off), d_status);
+    // ---- tables, columns and scratch of the data-parallel passes
+    memset(&R.FD, 0, sizeof R.FD);
+    if (!F.fast_list.empty()) {
+        const size_t ncols = F.ncols(), ni = F.itf8.size(), ns = F.stop.size(), nsum = F.sums.size(), nch = F.chunk_slice.size(), nf = F.fast_list.size();
+        std::vector<hg_stream_desc> di(ni), ds(ns);
+        std::vector<uint64_t> col_off(ncols + 1); std::vector<uint32_t> col_slice(ncols + 1), sum_src(nsum + 1);
+        for (size_t c = 0; c < ni; c++) { memset(&di[c], 0, sizeof di[c]); di[c].in_off = F.itf8[c].in_off; di[c].in_len = F.itf8[c].in_len; di[c].out_off = F.itf8[c].pool_off; di[c].out_len = F.itf8[c].cap; col_off[c] = F.itf8[c].pool_off; col_slice[c] = F.itf8[c].slice; }
+        for (size_t c = 0; c < ns; c++) { memset(&ds[c], 0, sizeof ds[c]); ds[c].in_off = F.stop[c].in_off; ds[c].in_len = F.stop[c].in_len; ds[c].out_off = F.stop[c].pool_off; ds[c].out_len = F.stop[c].cap; ds[c].reserved = F.stop[c].stop; col_off[ni + c] = F.stop[c].pool_off; col_slice[ni + c] = F.stop[c].slice; }
+        for (size_t c = 0; c < nsum; c++) { col_off[ni + ns + c] = F.sums[c].pool_off; col_slice[ni + ns + c] = F.sums[c].slice; sum_src[c] = F.sums[c].src; }
+        struct FPart { const void *src; size_t bytes; size_t off; };
+        FPart fpart[12] = {{F.ser.data(), F.ser.size() * sizeof(hgr::FSer), 0}, {F.tl_tagidx.data(), F.tl_tagidx.size() * 4, 0}, {F.ser_off.data(), nslices * 4, 0}, {F.ntag.data(), nslices * 4, 0},
+                           {col_off.data(), ncols * 8, 0}, {col_slice.data(), ncols * 4, 0}, {sum_src.data(), nsum * 4, 0}, {di.data(), ni * sizeof(hg_stream_desc), 0},
+                           {ds.data(), ns * sizeof(hg_stream_desc), 0}, {F.chunk_slice.data(), nch * 4, 0}, {F.chunk_r0.data(), nch * 4, 0}, {F.fast_list.data(), nf * 4, 0}};
+        size_t fb = 0;
+        for (auto &q : fpart) { q.off = fb; fb += (q.bytes + 63) & ~(size_t)63; }
+        const size_t o_coln = fb; fb += (ncols * 4 + 63) & ~(size_t)63;
+        const size_t o_colst = fb; fb += (ncols * 4 + 63) & ~(size_t)63;
+        const size_t o_fail = fb; fb += (nslices * 4 + 63) & ~(size_t)63;
+        const size_t o_uncl = fb; fb += (nslices * 4 + 63) & ~(size_t)63;
+        const size_t o_tot = fb; fb += (nslices * hgr::TOT_N * 8 + 63) & ~(size_t)63;
+        const size_t o_sbase = fb; fb += (nslices * 8 + 63) & ~(size_t)63;
+        const size_t o_sused = fb; fb += 64;
+        // scratch columns: 8 x u32, 1 x i64, tags, classes, bits, pred
+        const size_t NN = (N + 15) & ~(size_t)15;
+        const size_t ntagc = F.ntag_max ? F.ntag_max : 1;
+        const size_t zbytes = NN * 4 * (9 + ntagc + hgr::NCLS) + NN * 8 + NN + 256;
+        if ((rc = M.need(M_FAST, fb + 64)) || (rc = M.need(M_POOL, F.pool_words * 4 + 256)) || (rc = M.need(M_FSCR, zbytes))) return rc;
+        uint8_t *d_f = (uint8_t *)M.p[M_FAST], *d_z = (uint8_t *)M.p[M_FSCR];
+        for (auto &q : fpart) if (q.bytes && hipMemcpyAsync(d_f + q.off, q.src, q.bytes, hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
+        if (hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;    // the vectors above go out of scope
+        hgr::FastDev &FD = R.FD;
+        FD.ser = (const hgr::FSer *)(d_f + fpart[0].off); FD.tl_tagidx = (const int32_t *)(d_f + fpart[1].off); FD.ser_off = (const uint32_t *)(d_f + fpart[2].off);
+        FD.ntag = (const uint32_t *)(d_f + fpart[3].off); FD.pool = (const uint32_t *)M.p[M_POOL]; FD.col_off = (const uint64_t *)(d_f + fpart[4].off);
+        FD.col_n = (const uint32_t *)(d_f + o_coln);
+        FD.chunk_slice = (const uint32_t *)(d_f + fpart[9].off); FD.chunk_r0 = (const uint32_t *)(d_f + fpart[10].off); FD.nchunks = (uint32_t)nch;
+        FD.fast_list = (const uint32_t *)(d_f + fpart[11].off); FD.nfast = (uint32_t)nf;
+        FD.fail = (int32_t *)(d_f + o_fail); FD.unclean = (int32_t *)(d_f + o_uncl); FD.tot = (uint64_t *)(d_f + o_tot);
+        FD.seq_base = (uint64_t *)(d_f + o_sbase); FD.seq_used = (uint64_t *)(d_f + o_sused);
+        FD.nref = nref; FD.want_aux = want_aux ? 1 : 0;
+        hgr::FScr &Z = FD.Z;
+        uint32_t *z32 = (uint32_t *)d_z;
+        Z.c_det = z32; Z.c_down = z32 + NN; Z.c_ts = z32 + 2 * NN; Z.c_map = z32 + 3 * NN; Z.seq_at = z32 + 4 * NN; Z.fn = z32 + 5 * NN; Z.work = z32 + 6 * NN; Z.aux_stored = z32 + 7 * NN;
+        Z.pred = (int32_t *)(z32 + 8 * NN); Z.tag = z32 + 9 * NN; Z.cls = Z.tag + ntagc * NN;
+        Z.ap = (int64_t *)(Z.cls + (size_t)hgr::NCLS * NN); Z.bits = (uint8_t *)(Z.ap + NN); Z.N = NN;
+        R.d_itf8 = (const hg_stream_desc *)(d_f + fpart[7].off); R.d_stop = (const hg_stream_desc *)(d_f + fpart[8].off); R.d_sum_src = (const uint32_t *)(d_f + fpart[6].off);
+        R.d_col_status = (int32_t *)(d_f + o_colst); R.d_col_slice = (const uint32_t *)(d_f + fpart[5].off);
+    } else if (R.n_chain0 && want_seq) {
+        // chain-only batch: the placement pass still needs a few per-slice words and one scratch column
+        const size_t NN = (N + 15) & ~(size_t)15;
+        size_t fb = 0;
+        const size_t o_tot = fb; fb += (nslices * hgr::TOT_N * 8 + 63) & ~(size_t)63;
+        const size_t o_sbase = fb; fb += (nslices * 8 + 63) & ~(size_t)63;
+        const size_t o_sused = fb; fb += 64;
+        if ((rc = M.need(M_FAST, fb + 64)) || (rc = M.need(M_FSCR, NN * 4 + 256))) return rc;
+        uint8_t *d_f = (uint8_t *)M.p[M_FAST];
+        R.FD.tot = (uint64_t *)(d_f + o_tot); R.FD.seq_base = (uint64_t *)(d_f + o_sbase); R.FD.seq_used = (uint64_t *)(d_f + o_sused);
+        R.FD.Z.seq_at = (uint32_t *)M.p[M_FSCR]; R.FD.Z.N = NN;
     }
-    if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
-    PT.mark("record loop");
-    // pack: totals back, prefix sums on the host, second kernel
-    std::vector<uint32_t> tot(nslices * 4);
-    ok = hipMemcpyAsync(status, d_status, nslices * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
-         hipMemcpyAsync(tot.data(), d_out + otot, nslices * 16, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    if (hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+    return HG_OK;
+}
+
+// One decoding run over a staged batch: the columns, the packed CIGAR / name / aux arrays and -- with a sink -- the BAM stream, all left on
+// the device.  Host work between the launches: one look at the per-slice verdicts and totals (a few bytes per slice).
+static int rec_run(hg_ctx *ctx, hg_cram_batch &R, const BamSink *bam, size_t cigar_cap, size_t name_cap, size_t aux_cap) {
+    hgr::Batch &B = R.B; hgr::FastBatch &F = R.F;
+    const size_t nslices = R.nslices;
+    hipStream_t s = ctx->stream;
+    RecMem &M = R.M;
+    uint8_t *d_out = (uint8_t *)M.p[M_OUT];
+    hgr::DevTables &T = R.T; hgr::DevCols D = R.D; hgr::FastDev &FD = R.FD;
+    const bool want_seq = R.want_seq, want_aux = R.want_aux;
+    int rc;
+    PhaseTimer PT(s);
+    R.status.assign(nslices, 0); R.tot.assign(nslices * 4, 0u);
+    bool ok = hipMemsetAsync(d_out + R.opool, 0, 64, s) == hipSuccess && hipMemcpyAsync(R.d_status, R.d_pre0, nslices * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+              hipMemsetAsync(d_out + R.otot, 0, nslices * 16, s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
-    std::vector<uint64_t> base(nslices * 3);
+    // ---- the chain decoder: slices the data-parallel passes do not take.  Their bases go to a pool of their own (placed afterwards)
+    hgr::DevCols Dc = D;
+    auto chain_launch = [&](size_t count, const int32_t *d_pre) -> int {
+        if (want_seq && !M.p[M_TMPSEQ]) { if ((rc = M.need(M_TMPSEQ, 2 * (R.seq_cap + 64)))) return rc; }
+        if (want_seq) { Dc.seq = (uint8_t *)M.p[M_TMPSEQ]; Dc.qual = Dc.seq + R.seq_cap + 64; }
+        bool lane_mode = count >= 1024;                                  // measured at 8192 slices: 19.9 ms per call against 32.6 ms (profiles/r02_cram_records_probe.txt)
+        if (const char *m = getenv("HG_CRAM_RECORDS_MODE")) lane_mode = m[0] == 'l';
+        Dc.jobs = nullptr;
+        if (!lane_mode && (want_seq || want_aux)) {                       // room for the copies the chain hands over
+            if ((rc = M.need(M_JOBS, (B.job_total + 1) * sizeof(hgr::CopyJob)))) return rc;
+            Dc.jobs = (hgr::CopyJob *)M.p[M_JOBS];
+        }
+        if (lane_mode) {
+            const unsigned grid = (unsigned)std::min<size_t>((nslices + 63) / 64, (size_t)ctx->cus * 16);
+            hipLaunchKernelGGL(hgr::cram_records_lane_kernel, dim3(grid), dim3(64), 0, s, T, Dc, (uint32_t)nslices, (int32_t)R.nref, d_pre, R.d_status);
+        } else {
+            const unsigned grid = (unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 16);
+            hipLaunchKernelGGL(hgr::cram_records_kernel, dim3(grid), dim3(64), 0, s, T, Dc, (uint32_t)nslices, (int32_t)R.nref, d_pre, R.d_status);
+        }
+        return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+    };
+    if (R.n_chain0 && (rc = chain_launch(R.n_chain0, R.d_pre0))) return rc;
+    PT.mark("chain");
+    // ---- the data-parallel passes
+    if (FD.nfast) {
+        const size_t ncols = F.ncols();
+        ok = hipMemsetAsync(FD.fail, 0, nslices * 4, s) == hipSuccess && hipMemsetAsync(FD.unclean, 0, nslices * 4, s) == hipSuccess &&
+             hipMemsetAsync(FD.tot, 0, nslices * hgr::TOT_N * 8, s) == hipSuccess && hipMemsetAsync(FD.Z.pred, 0, FD.Z.N * 4, s) == hipSuccess &&
+             hipMemsetAsync((void *)FD.col_n, 0, ncols * 4, s) == hipSuccess;
+        if (!ok) return HG_ELAUNCH;
+        if ((rc = hgr::launch_fast_columns(ctx, T.data, R.d_itf8, F.itf8.size(), R.d_stop, F.stop.size(), R.d_sum_src, F.sums.size(), (uint32_t *)M.p[M_POOL], FD.col_off,
+                                           (uint32_t *)FD.col_n, R.d_col_status, R.d_col_slice, FD.fail, s))) return rc;
+        PT.mark("columns");
+        if ((rc = hgr::launch_fast_passes(ctx, T, D, FD, (uint32_t)nslices, R.d_status, s))) return rc;
+        PT.mark("passes");
+    } else if (want_seq && FD.seq_used && hipMemsetAsync(FD.seq_used, 0, 8, s) != hipSuccess) return HG_ELAUNCH;
+    // ---- verdicts so far.  Slices the passes gave up go through the chain decoder; so do slices of the chain decoder that found its pool of
+    //      bases used up -- by neighbours that have been moved to their final place by then, or by a damaged neighbour's read lengths
+    std::vector<int32_t> &status = R.status; std::vector<uint32_t> &tot = R.tot;
+    auto verdicts = [&]() {
+        return hipMemcpyAsync(status.data(), R.d_status, nslices * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+               hipMemcpyAsync(tot.data(), d_out + R.otot, nslices * 16, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    };
+    if (!verdicts()) return HG_ELAUNCH;
+    R.retried.assign(nslices, 0);
+    std::vector<uint32_t> round;                                         // slices the chain decoder took in the round just run
+    for (size_t i = 0; i < nslices; i++) if (B.status[i] == 0 && !F.is_fast[i]) round.push_back((uint32_t)i);
+    for (int rounds = 0;; rounds++) {
+        // the round's good slices: bases from the pool to slice order behind everything placed so far (deterministic: prefix sums)
+        std::vector<uint32_t> good, again;
+        for (uint32_t i : round) { if (status[i] == 0) good.push_back(i); else if (status[i] == hgr::ERR_POOL) again.push_back(i); }
+        if (want_seq && !good.empty()) {
+            if (hipMemcpyAsync(R.d_list, good.data(), good.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+            hgr::FastDev Fc = FD; Fc.fast_list = R.d_list; Fc.nfast = (uint32_t)good.size();
+            if ((rc = hgr::launch_chain_placement(ctx, T, D, Fc, R.d_status, Dc.seq, Dc.qual, s))) return rc;
+        }
+        if (rounds == 0) for (size_t i = 0; i < nslices; i++) if (status[i] == hgr::STATUS_RETRY) { again.push_back((uint32_t)i); R.retried[i] = 1; }
+        const bool progress = rounds == 0 || again.size() < round.size();
+        if (again.empty() || !progress) { for (uint32_t i : again) status[i] = hgr::ERR_UNSUPPORTED; break; }     // alone in the pool and still no room: the batch's seq_cap is too small for it
+        std::vector<int32_t> pre(nslices, hgr::STATUS_SKIP);
+        for (uint32_t i : again) pre[i] = 0;
+        if (hipMemcpyAsync(R.d_pre1, pre.data(), nslices * 4, hipMemcpyHostToDevice, s) != hipSuccess || hipMemsetAsync(d_out + R.opool, 0, 8, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+        if ((rc = chain_launch(again.size(), R.d_pre1))) return rc;
+        if (!verdicts()) return HG_ELAUNCH;
+        round.swap(again);
+        PT.mark("chain (again)");
+    }
+    if (hipMemcpyAsync(R.d_status, status.data(), nslices * 4, hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;      // final verdicts (pool retries resolved) for the kernels below
+    R.pool_used = 0;
+    if (want_seq && FD.seq_used) {
+        unsigned long long u = 0;
+        if (hipMemcpyAsync(&u, FD.seq_used, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+        R.pool_used = u;
+    }
+    PT.mark("placement");
+    // ---- pack: prefix sums of the per-slice totals on the host (a few words per slice), second kernel
+    std::vector<uint64_t> &base = R.base;
+    base.assign(nslices * 3 + 1, 0);
     uint64_t used_c = 0, used_n = 0, used_a = 0;
     for (size_t i = 0; i < nslices; i++) {
         base[3 * i] = used_c; base[3 * i + 1] = used_n; base[3 * i + 2] = used_a;
         if (status[i] == 0) { used_c += tot[4 * i]; used_n += tot[4 * i + 1]; used_a += want_aux ? tot[4 * i + 2] : 0u; }
     }
-    if (used) { used[0] = used_c; used[1] = used_n; used[2] = used_a; used[3] = 0; }
+    R.used_c = used_c; R.used_n = used_n; R.used_a = used_a;
     if (used_c > cigar_cap || used_n > name_cap || used_a > aux_cap) return HG_ENOMEM;      // the caller's arrays are too small: `used` says what is needed
+    if (want_seq && R.pool_used > R.seq_cap) return HG_ENOMEM;
     const size_t pc = (used_c * 4 + 63) & ~(size_t)63, pn = (used_n + 63) & ~(size_t)63, pa = (used_a + 63) & ~(size_t)63;
-    if ((rc = hg::ensure_scratch(ctx, 3, pc + pn + pa + 64))) return rc;
-    uint8_t *d_pack = (uint8_t *)ctx->d_scratch[3];
-    hgr::Dense PK{(uint32_t *)d_pack, d_pack + pc, d_pack + pc + pn, (const uint64_t *)(d_out + obase)};
-    if (hipMemcpyAsync(d_out + obase, base.data(), nslices * 24, hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
-    hipLaunchKernelGGL(hgr::cram_records_pack_kernel, dim3((unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 32)), dim3(64), 0, s, T, D, PK, (uint32_t)nslices, d_status);
+    if ((rc = M.need(M_PACK, pc + pn + pa + 64))) return rc;
+    uint8_t *d_pack = (uint8_t *)M.p[M_PACK];
+    R.PK = hgr::Dense{(uint32_t *)d_pack, d_pack + pc, d_pack + pc + pn, (const uint64_t *)(d_out + R.obase)};
+    if (hipMemcpyAsync(d_out + R.obase, base.data(), nslices * 24, hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
+    hipLaunchKernelGGL(hgr::cram_records_pack_kernel, dim3((unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 32)), dim3(64), 0, s, T, D, R.PK, (uint32_t)nslices, R.d_status);
     if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
     PT.mark("pack");
-    // results back: every column in one copy
-    void *dst32[9] = {out->flags, out->cram_flags, out->ref_id, out->len, out->rg, out->mqual, out->mate_ref_id, out->ncigar, out->name_len};
-    for (int i = 0; i < 9 && ok; i++) if (dst32[i] && B.nrec) ok = hipMemcpyAsync(dst32[i], d_out + o32[i], B.nrec * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
-    void *dst64[4] = {out->apos, out->aend, out->mate_pos, out->tlen};
-    for (int i = 0; i < 4 && ok; i++) if (dst64[i] && B.nrec) ok = hipMemcpyAsync(dst64[i], d_out + o64[i], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
-    if (ok && out->cigar_off && B.nrec) ok = hipMemcpyAsync(out->cigar_off, d_out + ou64[0], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
-    if (ok && out->name_off && B.nrec) ok = hipMemcpyAsync(out->name_off, d_out + ou64[1], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
-    if (ok && out->cigar && used_c) ok = hipMemcpyAsync(out->cigar, PK.cigar, used_c * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
-    if (ok && out->names && used_n) ok = hipMemcpyAsync(out->names, PK.names, used_n, hipMemcpyDeviceToHost, s) == hipSuccess;
-    if (ok && want_aux && out->aux && B.nrec) ok = hipMemcpyAsync(out->aux_off, d_out + ou64[2], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                                       hipMemcpyAsync(out->aux_len, d_out + o32[11], B.nrec * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                                       (!used_a || hipMemcpyAsync(out->aux, PK.aux, used_a, hipMemcpyDeviceToHost, s) == hipSuccess);
-    unsigned long long pool_used = 0;
-    if (ok && want_seq) ok = hipMemcpyAsync(&pool_used, d_out + opool, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-    if (ok && want_seq && B.nrec && used) used[3] = pool_used;
-    if (ok && want_seq && pool_used > seq_cap) return HG_ENOMEM;
-    if (ok && want_seq && out->seq && B.nrec) {
-        if (pool_used > seq_cap) pool_used = seq_cap;
-        ok = hipMemcpyAsync(out->seq_off, d_out + oso, B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
-             (!pool_used || (hipMemcpyAsync(out->seq, d_out + oseq, pool_used, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                             hipMemcpyAsync(out->qual, d_out + oqual, pool_used, hipMemcpyDeviceToHost, s) == hipSuccess));
-    }
-    PT.mark("columns back");
-    if (ok && bam) {                                                     // cram_to_bam on the device: sizes, prefix sum, bytes
+    R.bam_bytes = 0;
+    if (bam) {                                                           // cram_to_bam on the device: sizes, prefix sum, bytes
         std::vector<uint32_t> rgo((size_t)bam->nrg + 1, 0u); std::vector<unsigned char> rgn;
         for (int i = 0; i < bam->nrg; i++) { const size_t l = strlen(bam->rg_names[i]); rgn.insert(rgn.end(), bam->rg_names[i], bam->rg_names[i] + l); rgo[(size_t)i + 1] = (uint32_t)rgn.size(); }
-        const size_t szb = (R + 1) * 8, rgb = (rgo.size() * 4 + 63) & ~(size_t)63;
-        if ((rc = hg::ensure_scratch(ctx, 4, szb + rgb + rgn.size() + 128))) return rc;
-        uint8_t *d_b = (uint8_t *)ctx->d_scratch[4];
-        uint64_t *d_sz = (uint64_t *)d_b; uint32_t *d_rgo = (uint32_t *)(d_b + ((szb + 63) & ~(size_t)63)); unsigned char *d_rgn = (unsigned char *)d_rgo + rgb;
+        const size_t NR = B.nrec ? B.nrec : 1, ntiles = (NR + hgr::SCAN_TILE - 1) / hgr::SCAN_TILE;
+        const size_t szb = ((NR + 1) * 8 + 63) & ~(size_t)63, tlb = ((ntiles + 1) * 8 + 63) & ~(size_t)63, rgb = (rgo.size() * 4 + 63) & ~(size_t)63;
+        if ((rc = M.need(M_BSZ, szb + tlb + rgb + rgn.size() + 128))) return rc;
+        uint8_t *d_b = (uint8_t *)M.p[M_BSZ];
+        uint64_t *d_sz = (uint64_t *)d_b, *d_tile = (uint64_t *)(d_b + szb); uint32_t *d_rgo = (uint32_t *)(d_b + szb + tlb); unsigned char *d_rgn = (unsigned char *)d_rgo + rgb;
         ok = hipMemcpyAsync(d_rgo, rgo.data(), rgo.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
              (rgn.empty() || hipMemcpyAsync(d_rgn, rgn.data(), rgn.size(), hipMemcpyHostToDevice, s) == hipSuccess);
+        if (!ok) return HG_ELAUNCH;
         const unsigned grid = (unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 32);
-        if (ok) {
-            hipLaunchKernelGGL(hgr::cram_bam_size_kernel, dim3(grid), dim3(64), 0, s, T, D, d_rgo, (int32_t)bam->nrg, (uint32_t)nslices, d_status, d_sz);
-            hipLaunchKernelGGL(hgr::scan_u64_kernel, dim3(1), dim3(1024), 0, s, d_sz, (uint64_t)B.nrec);
-        }
+        hipLaunchKernelGGL(hgr::cram_bam_size_kernel, dim3(grid), dim3(64), 0, s, T, D, d_rgo, (int32_t)bam->nrg, (uint32_t)nslices, R.d_status, d_sz);
+        hipLaunchKernelGGL(hgr::scan_tile_sums_kernel, dim3((unsigned)ntiles), dim3(hgr::SCAN_TPB), 0, s, d_sz, (uint64_t)B.nrec, d_tile);
+        hipLaunchKernelGGL(hgr::scan_tile_bases_kernel, dim3(1), dim3(hgr::SCAN_TPB), 0, s, d_tile, (uint64_t)ntiles, d_sz + B.nrec);
+        hipLaunchKernelGGL(hgr::scan_tiles_kernel, dim3((unsigned)ntiles), dim3(hgr::SCAN_TPB), 0, s, d_sz, (uint64_t)B.nrec, d_tile);
         uint64_t total = 0;
-        ok = ok && hipMemcpyAsync(&total, d_sz + B.nrec, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&total, d_sz + B.nrec, 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipMemcpyAsync(status.data(), R.d_status, nslices * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
         if (!ok) return HG_ELAUNCH;
         PT.mark("bam sizes + scan");
+        R.bam_bytes = total; R.d_bam_off = d_sz;
         if (bam->total) *bam->total = total;
         if (total > bam->cap) return HG_ENOMEM;
-        if ((rc = hg::ensure_scratch(ctx, 5, total + 64))) return rc;
-        uint8_t *d_bam = (uint8_t *)ctx->d_scratch[5];
-        hipLaunchKernelGGL(hgr::cram_bam_write_kernel, dim3(grid), dim3(64), 0, s, T, D, PK, d_rgn, d_rgo, (int32_t)bam->nrg, (uint32_t)nslices, d_status, d_sz, d_bam);
-        ok = hipGetLastError() == hipSuccess && (!total || hipMemcpyAsync(bam->out, d_bam, total, hipMemcpyDeviceToHost, s) == hipSuccess) &&
-             (!bam->rec_bam_off || hipMemcpyAsync(bam->rec_bam_off, d_sz, (B.nrec + 1) * 8, hipMemcpyDeviceToHost, s) == hipSuccess) &&
-             hipMemcpyAsync(status, d_status, nslices * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
+        if ((rc = M.need(M_BAM, total + 64))) return rc;
+        R.d_bam = (uint8_t *)M.p[M_BAM];
+        const unsigned wgrid = (unsigned)std::min<size_t>((B.nrec + 3) / 4 + 1, (size_t)ctx->cus * 16);
+        hipLaunchKernelGGL(hgr::cram_bam_write_kernel, dim3(wgrid), dim3(256), 0, s, D, R.PK, d_rgn, d_rgo, (int32_t)bam->nrg, (uint64_t)B.nrec, d_sz, R.d_bam);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+        PT.mark("bam write");
     }
-    ok = ok && hipStreamSynchronize(s) == hipSuccess;
-    PT.mark("bam write + back");
-    if (!ok) return HG_ELAUNCH;
-    for (size_t i = 0; i < nslices; i++) if (status[i] != 0) return HG_EBLOCK;
     return HG_OK;
+}
+// the decoded columns of the last run -> the caller's arrays
+static int rec_fetch(hg_ctx *ctx, hg_cram_batch &R, const hg_cram_record_cols *out) {
+    hipStream_t s = ctx->stream;
+    const hgr::Batch &B = R.B;
+    const uint8_t *d_out = (const uint8_t *)R.M.p[M_OUT];
+    bool ok = true;
+    void *dst32[9] = {out->flags, out->cram_flags, out->ref_id, out->len, out->rg, out->mqual, out->mate_ref_id, out->ncigar, out->name_len};
+    for (int i = 0; i < 9 && ok; i++) if (dst32[i] && B.nrec) ok = hipMemcpyAsync(dst32[i], d_out + R.o32[i], B.nrec * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
+    void *dst64[4] = {out->apos, out->aend, out->mate_pos, out->tlen};
+    for (int i = 0; i < 4 && ok; i++) if (dst64[i] && B.nrec) ok = hipMemcpyAsync(dst64[i], d_out + R.o64[i], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (ok && out->cigar_off && B.nrec) ok = hipMemcpyAsync(out->cigar_off, d_out + R.ou64[0], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (ok && out->name_off && B.nrec) ok = hipMemcpyAsync(out->name_off, d_out + R.ou64[1], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (ok && out->cigar && R.used_c) ok = hipMemcpyAsync(out->cigar, R.PK.cigar, R.used_c * 4, hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (ok && out->names && R.used_n) ok = hipMemcpyAsync(out->names, R.PK.names, R.used_n, hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (ok && R.want_aux && out->aux && B.nrec) ok = hipMemcpyAsync(out->aux_off, d_out + R.ou64[2], B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                                                 hipMemcpyAsync(out->aux_len, d_out + R.o32[11], B.nrec * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                                                 (!R.used_a || hipMemcpyAsync(out->aux, R.PK.aux, R.used_a, hipMemcpyDeviceToHost, s) == hipSuccess);
+    if (ok && R.want_seq && out->seq && B.nrec) {
+        const uint64_t n = R.pool_used < R.seq_cap ? R.pool_used : R.seq_cap;
+        ok = hipMemcpyAsync(out->seq_off, d_out + R.oso, B.nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             (!n || (hipMemcpyAsync(out->seq, d_out + R.oseq, n, hipMemcpyDeviceToHost, s) == hipSuccess && hipMemcpyAsync(out->qual, d_out + R.oqual, n, hipMemcpyDeviceToHost, s) == hipSuccess));
+    }
+    return ok && hipStreamSynchronize(s) == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
 
 extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, size_t rec_cap,
                                            size_t cigar_cap, size_t name_cap, size_t seq_cap, size_t aux_cap, const hg_cram_record_cols *out, uint64_t *rec_off, int32_t *status,
                                            uint64_t *used) {
-    return records_impl(ctx, nslices, slices, major_version, nref, rec_cap, cigar_cap, name_cap, seq_cap, aux_cap, out, rec_off, status, used, nullptr);
+    if (!ctx || (nslices && (!slices || !out || !rec_off || !status))) return HG_EINVAL;
+    if (nslices == 0) { if (rec_off) rec_off[0] = 0; return HG_OK; }
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
+    hg_cram_batch R; R.M.ctx = ctx;
+    const bool want_aux = out->aux && out->aux_off && out->aux_len, want_seq = out->seq && out->qual && out->seq_off;
+    int rc = rec_stage(ctx, R, nslices, slices, major_version, nref, want_seq, want_aux, seq_cap);
+    if (rc) return rc;
+    if (R.B.nrec > rec_cap) return HG_EINVAL;
+    for (size_t i = 0; i < nslices; i++) rec_off[i] = R.B.slices[i].rec_off;
+    rec_off[nslices] = R.B.nrec;
+    rc = rec_run(ctx, R, nullptr, cigar_cap, name_cap, aux_cap);
+    if (used) { used[0] = R.used_c; used[1] = R.used_n; used[2] = R.used_a; used[3] = R.pool_used; }
+    for (size_t i = 0; i < nslices && i < R.status.size(); i++) status[i] = R.status[i];
+    if (rc) return rc;
+    if ((rc = rec_fetch(ctx, R, out))) return rc;
+    for (size_t i = 0; i < nslices; i++) if (status[i] != 0) return HG_EBLOCK;
+    return HG_OK;
 }
 
 // CRAM slices -> uncompressed BAM records (cram_decode_slice + cram_to_bam, cram_decode.c:2346-3192), everything on the device; only the
@@ -438,12 +672,64 @@ extern "C" int hg_cram_decode_bam_host(hg_ctx *ctx, size_t nslices, const hg_cra
                                        int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap, uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes,
                                        int32_t *status) {
     if (!ctx || (nslices && (!slices || !bam_out || !rec_off || !status)) || (nrg && !rg_names)) return HG_EINVAL;
-    hg_cram_record_cols none; memset(&none, 0, sizeof none);
-    uint64_t nrec = 0, c0 = 0, c1 = 0, c2 = 0;
-    int rc = hg_cram_records_bound(nslices, slices, major_version, &nrec, &c0, &c1, &c2);
+    if (nslices == 0) { if (rec_off) rec_off[0] = 0; if (bam_bytes) *bam_bytes = 0; return HG_OK; }
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
+    hg_cram_batch R; R.M.ctx = ctx;
+    int rc = rec_stage(ctx, R, nslices, slices, major_version, nref, true, true, (size_t)total_bases);
     if (rc) return rc;
+    for (size_t i = 0; i < nslices; i++) rec_off[i] = R.B.slices[i].rec_off;
+    rec_off[nslices] = R.B.nrec;
     const BamSink sink{rg_names, nrg, bam_out, bam_cap, rec_bam_off, bam_bytes};
-    return records_impl(ctx, nslices, slices, major_version, nref, (size_t)nrec, (size_t)-1, (size_t)-1, (size_t)total_bases, (size_t)-1, &none, rec_off, status, nullptr, &sink);
+    rc = rec_run(ctx, R, &sink, (size_t)-1, (size_t)-1, (size_t)-1);
+    for (size_t i = 0; i < nslices && i < R.status.size(); i++) status[i] = R.status[i];
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    const bool ok = (!R.bam_bytes || hipMemcpyAsync(bam_out, R.d_bam, R.bam_bytes, hipMemcpyDeviceToHost, s) == hipSuccess) &&
+                    (!rec_bam_off || hipMemcpyAsync(rec_bam_off, R.d_bam_off, (R.B.nrec + 1) * 8, hipMemcpyDeviceToHost, s) == hipSuccess) && hipStreamSynchronize(s) == hipSuccess;
+    if (!ok) return HG_ELAUNCH;
+    for (size_t i = 0; i < nslices; i++) if (status[i] != 0) return HG_EBLOCK;
+    return HG_OK;
+}
+
+// ---- device-resident form: stage once, decode as often as wanted, the BAM stream stays in HBM (the next consumer is hg_bgzf_deflate_dev) ----
+extern "C" int hg_cram_batch_stage(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, uint64_t total_bases, hg_cram_batch **out) {
+    if (!ctx || !out || !nslices || !slices) return HG_EINVAL;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
+    hg_cram_batch *R = new (std::nothrow) hg_cram_batch;
+    if (!R) return HG_ENOMEM;
+    R->M.ctx = ctx; R->M.own = true;
+    const int rc = rec_stage(ctx, *R, nslices, slices, major_version, nref, true, true, (size_t)total_bases);
+    if (rc) { R->M.release(); delete R; return rc; }
+    *out = R;
+    return HG_OK;
+}
+extern "C" int hg_cram_batch_decode_bam_dev(hg_ctx *ctx, hg_cram_batch *batch, const char *const *rg_names, int nrg, void **d_bam, uint64_t *bam_bytes, uint64_t *nrec,
+                                            uint64_t *fast_slices, int32_t *status) {
+    if (!ctx || !batch || (nrg && !rg_names)) return HG_EINVAL;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
+    uint64_t total = 0;
+    const BamSink sink{rg_names, nrg, nullptr, (size_t)-1, nullptr, &total};
+    const int rc = rec_run(ctx, *batch, &sink, (size_t)-1, (size_t)-1, (size_t)-1);
+    if (status) for (size_t i = 0; i < batch->nslices && i < batch->status.size(); i++) status[i] = batch->status[i];
+    if (rc) return rc;
+    if (d_bam) *d_bam = batch->d_bam;
+    if (bam_bytes) *bam_bytes = total;
+    if (nrec) *nrec = batch->B.nrec;
+    if (fast_slices) { uint64_t n = 0; for (size_t i = 0; i < batch->nslices; i++) n += batch->F.is_fast[i] && !batch->retried[i]; *fast_slices = n; }
+    for (size_t i = 0; i < batch->nslices; i++) if (batch->status[i] != 0) return HG_EBLOCK;
+    return HG_OK;
+}
+extern "C" int hg_cram_batch_read_bam(hg_ctx *ctx, hg_cram_batch *batch, uint8_t *dst, size_t cap) {
+    if (!ctx || !batch || (!dst && batch->bam_bytes)) return HG_EINVAL;
+    if (batch->bam_bytes > cap) return HG_ENOMEM;
+    hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
+    if (batch->bam_bytes && (hipMemcpyAsync(dst, batch->d_bam, batch->bam_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) return HG_ELAUNCH;
+    return HG_OK;
+}
+extern "C" void hg_cram_batch_free(hg_ctx *ctx, hg_cram_batch *batch) {
+    if (!batch) return;
+    if (ctx) { hg::CtxGuard guard_(ctx); (void)hipStreamSynchronize(ctx->stream); batch->M.release(); }
+    delete batch;
 }
 
 // The .crai lines of one slice (cram_index_slice / cram_index_build_multiref, reference cram/cram_index.c:632-728): a single-reference

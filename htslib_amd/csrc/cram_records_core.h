@@ -58,7 +58,8 @@ struct Plan {
 struct CopyJob { uint8_t *dst; const uint8_t *src; uint32_t n, pad; };
 
 // A stretch of reference bases the caller supplies for a slice (upper case ASCII; an embedded-reference block is one of these)
-struct RefSpan { int32_t ref_id; uint32_t off, len, pad; int64_t start, sq_len; };   // off into Slice::data; start = 1-based position of the first base; sq_len = @SQ LN
+struct RefSpan { int32_t ref_id; uint32_t off, len, off_hi; int64_t start, sq_len; };   // off_hi:off into Slice::data (reference spans may lie beyond 4 GiB: a genome staged once per batch); start = 1-based position of the first base; sq_len = @SQ LN
+HGR_FN uint64_t ref_off(const RefSpan *r) { return (uint64_t)r->off_hi << 32 | r->off; }
 // One slice: its blocks by slot (offset / length into `data`; length 0xffffffff = block absent), the CORE block, scratch cursors
 struct Slice {
     const uint8_t *data;
@@ -86,7 +87,8 @@ struct Cols {
     // bases and qualities (seq == nullptr: not wanted): len bytes each per record at seq_off[rec], handed out from one pool
     uint8_t *seq, *qual; uint64_t *seq_off; unsigned long long *seq_pool; uint64_t seq_cap;
 };
-enum { ERR_MALFORMED = -1, ERR_UNSUPPORTED = -3 };
+enum { ERR_MALFORMED = -1, ERR_UNSUPPORTED = -3,
+       ERR_POOL = -7 };      // device launcher only: no room left in the shared pool of bases -- the slice is decoded again once the others have been moved out
 enum { BAM_FPAIRED = 1, BAM_FUNMAP = 4, BAM_FMUNMAP = 8, BAM_FREVERSE = 16, BAM_FMREVERSE = 32, BAM_FREAD1 = 64 };
 enum { CF_PRESERVE_QUAL = 1, CF_DETACHED = 2, CF_MATE_DOWNSTREAM = 4, CF_NO_SEQ = 8, CF_EXPLICIT_TLEN = 16 };
 enum { CRAM_M_REVERSE = 1, CRAM_M_UNMAP = 2 };
@@ -319,7 +321,7 @@ HGR_FN void decode_features(RD &R, const Cols &O, int rec, int32_t cf, uint32_t 
                                                                           // arguments: reading a column back waits for every store in flight)
     int32_t prev_pos = 0, seq_pos = 1, cig_len = 0, cig_op = C_MATCH;
     const uint32_t cig0 = ncig_total;
-    const uint8_t *refb = ref ? R.data() + ref->off : nullptr;            // refb[p - ref->start] = base at 1-based position p
+    const uint8_t *refb = ref ? R.data() + ref_off(ref) : nullptr;            // refb[p - ref->start] = base at 1-based position p
     const int64_t ref_start = ref ? ref->start : 0, ref_end = ref ? ref->start + (int64_t)ref->len - 1 : 0, sq_len = ref ? ref->sq_len : 0;
     const bool have_ref = ref && ref_id >= 0;
     auto emit = [&](uint32_t l, int op) {
@@ -712,12 +714,21 @@ HGR_FN int decode_slice(const Plan *P, const Slice *S, const Cols &O) {
         const RefSpan *ref = nullptr;
         if (O.seq) {
             uint64_t at;
+            // room for len bases and qualities from the pool the slices of a launch share.  A request that does not fit takes NOTHING (a slice with
+            // a damaged read length must not starve its neighbours); the launcher runs such a slice again when the pool has been emptied.
 #if defined(__HIP_DEVICE_COMPILE__)
-            at = atomicAdd(O.seq_pool, (unsigned long long)len);
+            {
+                unsigned long long seen = *(volatile unsigned long long *)O.seq_pool, want;
+                bool fits;
+                do { want = seen; fits = want + (unsigned long long)len <= O.seq_cap; if (!fits) break; seen = atomicCAS(O.seq_pool, want, want + (unsigned long long)len); } while (seen != want);
+                if (!fits) { R.err = ERR_POOL; break; }
+                at = want;
+            }
 #else
-            at = *O.seq_pool; *O.seq_pool += (unsigned long long)len;
-#endif
+            at = *O.seq_pool;
             if (at + (uint64_t)len > O.seq_cap) { R.err = ERR_UNSUPPORTED; break; }
+            *O.seq_pool += (unsigned long long)len;
+#endif
             O.seq_off[rec] = at; seq = O.seq + at; qual = O.qual + at;
         }
         for (int32_t i = 0; i < S->nrefs; i++) if (S->refs[i].ref_id == ref_id) { ref = &S->refs[i]; break; }

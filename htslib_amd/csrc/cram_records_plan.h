@@ -21,6 +21,7 @@ struct PlanHost {
     std::map<int32_t, int32_t> slot_of;          // content id -> slot
     std::vector<int32_t> slot_id;                // slot -> content id
     int unsupported = 0;                         // a codec this build does not decode is present (reported when a slice uses the plan)
+    int no_ref = 0;                              // preservation map RR = 0: the slices were written without a reference (cram_decode.c:250-262)
     void finish() { plan.sm = sm.data(); plan.tl_off = tl_off.data(); plan.tl_codec = tl_codec.data(); plan.tl_tag = tl_tag.data(); plan.codecs = codecs.data(); plan.huff = huff.data(); plan.nslots = (int32_t)slot_id.size(); }
 };
 
@@ -129,6 +130,7 @@ inline int plan_from_compression_header(PlanHost &H, const uint8_t *b, size_t n)
             if (k0 == 'R' && k1 == 'N') H.plan.rn_included = c.byte();
             else if (k0 == 'A' && k1 == 'P') H.plan.ap_delta = c.byte();
             else if (k0 == 'Q' && k1 == 'O') H.plan.qs_seq_orient = c.byte();
+            else if (k0 == 'R' && k1 == 'R') H.no_ref = !c.byte();
             else if (k0 == 'S' && k1 == 'M') {                          // cram_decode.c:290-318: code -> base, per reference base
                 if (c.end - c.p < 5) return -1;
                 static const char *others[5] = {"CGTN", "AGTN", "ACTN", "ACGN", "ACGT"};
@@ -188,7 +190,8 @@ inline int plan_from_compression_header(PlanHost &H, const uint8_t *b, size_t n)
     return 0;
 }
 
-struct SliceHeader { int32_t ref_seq_id = -1; int64_t ref_seq_start = 0, ref_seq_span = 0; int32_t nrec = 0, nblocks = 0; int64_t record_counter = 0; };
+struct SliceHeader { int32_t ref_seq_id = -1; int64_t ref_seq_start = 0, ref_seq_span = 0; int32_t nrec = 0, nblocks = 0; int64_t record_counter = 0;
+                     int32_t ref_base_id = -1; uint8_t md5[16] = {0}; bool has_md5 = false; };
 // The slice header block (content type 2 = mapped / multi-reference, 3 = unmapped in CRAM 1; v2+ always writes type 2).  0 or -1.
 inline int parse_slice_header(const uint8_t *b, size_t n, int major, SliceHeader &h) {
     Cursor c{b, b + n};
@@ -197,7 +200,13 @@ inline int parse_slice_header(const uint8_t *b, size_t n, int major, SliceHeader
     h.nrec = c.itf8();
     h.record_counter = major >= 3 ? c.ltf8() : c.itf8();
     h.nblocks = c.itf8();
-    return c.bad || h.nrec < 0 ? -1 : 0;
+    if (c.bad || h.nrec < 0) return -1;
+    // the rest is optional for the record decoder: content ids, the embedded-reference block id, the MD5 of the reference span (v2+)
+    const int32_t nids = c.itf8();
+    for (int32_t k = 0; k < nids && !c.bad; k++) (void)c.itf8();
+    if (!c.bad) { const int32_t e = c.itf8(); if (!c.bad) h.ref_base_id = e; }
+    if (!c.bad && major >= 2 && c.end - c.p >= 16) { memcpy(h.md5, c.p, 16); h.has_md5 = true; }
+    return 0;
 }
 
 
@@ -239,6 +248,9 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
     std::vector<PlanHost> &hosts = B.hosts;
     B.status.assign(n, 0);
     auto stage = [&](const uint8_t *p, uint32_t len) { const uint64_t off = B.data_bytes; B.src_off.push_back(off); B.src_ptr.push_back(p); B.src_len.push_back(len); B.data_bytes += ((uint64_t)len + 15u) & ~15ull; return off; };
+    // reference spans go behind all blocks (64-bit offsets), each distinct buffer once: the slices of a chromosome share its bases
+    struct PendingRef { size_t ref_index; const uint8_t *p; uint32_t len; };
+    std::vector<PendingRef> pending;
     for (size_t i = 0; i < n; i++) {
         const SliceIn &s = in[i];
         SliceDev d; memset(&d, 0, sizeof d);
@@ -282,7 +294,8 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
         d.ref_first = (uint32_t)B.refs.size(); d.nrefs = s.refs ? s.nrefs : 0; d.decode_md = s.decode_md;
         for (uint32_t k = 0; k < d.nrefs; k++) {
             const RefIn &r = s.refs[k];
-            B.refs.push_back(RefSpan{r.ref_id, (uint32_t)stage(r.bases, r.len), r.len, 0u, r.start, r.sq_len});
+            pending.push_back(PendingRef{B.refs.size(), r.bases, r.len});
+            B.refs.push_back(RefSpan{r.ref_id, 0u, r.len, 0u, r.start, r.sq_len});
         }
         // a header that claims more records than its blocks could possibly describe (16 per byte) is damage, not data: it must not turn
         // into a minutes-long walk over constant codecs or into gigabytes of columns
@@ -301,7 +314,17 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
         d.job_off = B.job_total; B.job_total += d.job_cap;
         B.slices.push_back(d);
     }
-    if (B.data_bytes > 0xfffffff0ull) return -4;                       // 32-bit offsets into the data image
+    if (B.data_bytes > 0xfffffff0ull) return -4;                       // 32-bit offsets of the blocks in the data image: the caller splits the batch
+    {
+        std::map<std::pair<const uint8_t *, uint32_t>, uint64_t> placed;
+        for (const PendingRef &q : pending) {
+            const auto key = std::make_pair(q.p, q.len);
+            auto it = placed.find(key);
+            uint64_t off;
+            if (it == placed.end()) { off = stage(q.p, q.len); placed[key] = off; } else off = it->second;
+            B.refs[q.ref_index].off = (uint32_t)off; B.refs[q.ref_index].off_hi = (uint32_t)(off >> 32);
+        }
+    }
     return 0;
 }
 

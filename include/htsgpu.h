@@ -379,7 +379,8 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
  *      CIGAR (BAM encoding, cram_decode_seq's feature walk), the read name, mate_ref_id, mate_pos, tlen, and -- given the reference
  *      spans -- the bases and qualities (cram_decode_seq's reconstruction), the aux tags as stored (cram_decode_aux) and, with
  *      decode_md, regenerated MD:Z / NM.  Pinned on the reference's 34 CRAM fixtures against their SAM / BAM twins
- *      (tests/test_cram_records.py).  One wavefront per slice (cram_records.hip). ---- */
+ *      (tests/test_cram_records.py).  Data-parallel passes where the compression header allows, else one wavefront per slice
+ *      (cram_records_fast.hip, cram_records.hip).  Bases / qualities are placed by prefix sums: slice order, record order. ---- */
 typedef struct hg_cram_slice_blocks {
     const uint8_t *comp_hdr; uint32_t comp_hdr_len;     /* compression header block of the slice's container (slices of one container may share the pointer) */
     const uint8_t *slice_hdr; uint32_t slice_hdr_len;   /* slice header block */
@@ -430,6 +431,22 @@ int hg_cram_decode_bam_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blo
                             const char *const *rg_names, int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap,
                             uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes, int32_t *status);
 
+/* Device-resident form of the same path: stage a batch of slices in HBM once (headers parsed, blocks and reference spans uploaded),
+ * then decode it -- cram_decode_slice + cram_to_bam -- with the BAM stream left on the device, where hg_bgzf_deflate_dev or the BAM
+ * kernels take it.  A run costs kernel launches and two small read-backs (per-slice verdicts and totals, the BAM size).
+ * How a slice is decoded (cram_records_fast.h): slices whose compression header gives every series a block of its own (what htslib
+ * writes for sorted data) go through data-parallel passes -- column decodes, per-record passes, prefix sums, one lane per record for
+ * the feature walk; slices with CORE-coded or shared series, and slices the passes find irregular, go through the serial chain
+ * decoder (one wavefront per slice), whose verdict is the one reported.  Both produce the same bytes (tests/test_cram_records_fast.py).
+ * *d_bam stays valid until the next run or hg_cram_batch_free; *fast_slices = slices decoded by the passes. */
+typedef struct hg_cram_batch hg_cram_batch;
+int hg_cram_batch_stage(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref,
+                        uint64_t total_bases, hg_cram_batch **out);
+int hg_cram_batch_decode_bam_dev(hg_ctx *ctx, hg_cram_batch *batch, const char *const *rg_names, int nrg, void **d_bam,
+                                 uint64_t *bam_bytes, uint64_t *nrec, uint64_t *fast_slices, int32_t *status);
+int hg_cram_batch_read_bam(hg_ctx *ctx, hg_cram_batch *batch, uint8_t *dst, size_t cap);   /* the last run's stream -> host */
+void hg_cram_batch_free(hg_ctx *ctx, hg_cram_batch *batch);
+
 /* A whole CRAM 2.x / 3.x file -> the uncompressed BAM stream `samtools view -u -b` would hand to bgzf_write: the container / block walk
  * of cram_read_container / cram_read_block on the host, every block through cram_uncompress_block (CRC check included) in one batch,
  * every slice through hg_cram_decode_bam_host in one batch, and bam_hdr_write's header in front.  refs[i] = reference sequence i of the
@@ -439,6 +456,12 @@ int hg_cram_decode_bam_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blo
 typedef struct hg_cram_ref_seq { const uint8_t *bases; uint64_t len; } hg_cram_ref_seq;
 int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given,
                              uint8_t *bam_out, size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords);
+/* The same with options.  By default the MD5 of the reference span in every slice header is checked against the bases about to be used,
+ * as cram_decode_slice does (cram/cram_decode.c:2480-2540; a mismatch fails the file with HG_EBLOCK -- the reference's "MD5 checksum
+ * reference mismatch"); HG_CRAM_IGNORE_MD5 = the reference's ignore_md5 option.  Containers written without a reference (RR = 0) get none. */
+#define HG_CRAM_IGNORE_MD5 1
+int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given,
+                              uint8_t *bam_out, size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags);
 
 /* The .crai text of one slice (cram_index_slice / cram_index_build_multiref, cram/cram_index.c:632-728): "ref start span container_pos
  * landmark slice_bytes" -- one line from the slice header, or, for a multi-reference slice, one line per run of records on the same

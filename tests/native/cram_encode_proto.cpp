@@ -143,7 +143,7 @@ extern "C" long hgr_proto_reencode_slice(const SliceIn *in, int major, int nref,
                     const uint8_t b = sq[sp - 1];
                     const bool in_ref = ref && rp >= ref->start && rp < ref->start + (int64_t)ref->len && rp <= ref->sq_len;
                     if (in_ref) {
-                        const uint8_t rb = S.data[ref->off + (rp - ref->start)];
+                        const uint8_t rb = S.data[ref_off(ref) + (rp - ref->start)];
                         if (b == rb) continue;
                         const int l1 = rb == 'A' ? 0 : rb == 'C' ? 1 : rb == 'G' ? 2 : rb == 'T' ? 3 : 4;
                         const char *hit = (const char *)memchr(SM[l1], b, 4);

@@ -416,7 +416,7 @@ def test_gpu_whole_cram_file_to_bam(engine):
     class RefSeq(C.Structure):
         _fields_ = [("bases", _vp), ("len", C.c_uint64)]
 
-    nrec = 0
+    nrec = md5_refused = 0
     for f in json.load(open(GOLD)):
         cram = unpack(f["cram"])
         spans = {}
@@ -450,7 +450,20 @@ def test_gpu_whole_cram_file_to_bam(engine):
         assert len(recs) == len(expect) == n.value, f["file"]
         for (g, bn, raw), e in zip(recs, expect):
             check_against_twin(f["file"], [g], [e]); nrec += 1
+        # the wrong reference: one base changed inside every stored stretch -> "MD5 checksum reference mismatch" (cram_decode.c:2480-2540) for
+        # files whose slice headers carry a digest; the reference's ignore_md5 option decodes them all the same
+        wrong = [bytearray(q) if q is not None else None for q in seqs]
+        for i in spans:
+            for a, bb in spans[i][1]:
+                if i < len(wrong) and wrong[i] is not None and len(bb): wrong[i][a - 1 + len(bb) // 2] ^= 0x06      # A<->G, C<->E ...: never the same base
+        keepw = [C.create_string_buffer(bytes(q), len(q)) if q is not None else None for q in wrong]
+        arrw = (RefSeq * max(len(wrong), 1))(*[RefSeq(C.addressof(k), len(q)) if k is not None else RefSeq(None, 0) for k, q in zip(keepw, wrong)])
+        rcw = nat.lib.hg_cram_file_to_bam_host(engine._h, C.cast(cb, _vp), len(cram), C.cast(arrw, _vp), len(wrong), out.ctypes.data, len(out), C.byref(total), C.byref(n))
+        rci = nat.lib.hg_cram_file_to_bam_host2(engine._h, C.cast(cb, _vp), len(cram), C.cast(arrw, _vp), len(wrong), out.ctypes.data, len(out), C.byref(total), C.byref(n), 1)
+        assert rci == 0, (f["file"], rci)
+        md5_refused += int(rcw != 0)
     assert nrec == 230
+    assert md5_refused >= 3, md5_refused
     # a damaged file: one payload byte of the last data block flipped -> the block's CRC fails the file
     bad = bytearray(cram); bad[len(bad) // 2] ^= 0x10
     cb = C.create_string_buffer(bytes(bad), len(bad))

@@ -145,3 +145,111 @@ def test_damaged_slices_get_the_chain_decoders_verdict(hostlib):
         if res[1][0] == 0: took += int(fc.path[0])
         else: failed += 1
     assert took > 50 and failed > 50, (took, failed)
+
+
+# ---------------------------------------------------------------- on the MI355X: the kernels of cram_records_fast.hip ----
+def _synthetic(rng):
+    from htslib_amd import synth_cram
+    return [synth_cram.make_slice(rng, 3000, 100), synth_cram.make_slice(rng, 500, 151, unmapped_every=3, detached_every=4), synth_cram.make_slice(rng, 1, 40, ref_len=500),
+            synth_cram.make_slice(rng, 257, 75, unmapped_every=0, detached_every=0), synth_cram.make_slice(rng, 1200, 100, tags=True),
+            synth_cram.make_slice(rng, 33, 60, unmapped_every=2, tags=True), synth_cram.make_slice(rng, 2, 50, ref_len=900), synth_cram.make_slice(rng, 255, 90),
+            synth_cram.make_slice(rng, 256, 90), synth_cram.make_slice(rng, 513, 64, tags=True), synth_cram.make_slice(rng, 1025, 70), synth_cram.make_slice(rng, 4097, 36, tags=True)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("decode_md", [-1, 0])
+def test_gpu_passes_equal_the_chain_decoder_on_synthetic_slices(engine, hostlib, decode_md):
+    """the default device path (data-parallel passes) == the chain decoder compiled for the CPU == the chain kernel (HG_CRAM_RECORDS_PATH=chain)"""
+    bound, dec = T._gpu_calls(engine)
+    slices = _synthetic(np.random.default_rng(202))
+    T.DECODE_MD[0] = decode_md
+    try:
+        st_c, chain, aend_c = _raw(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, 3, 1)
+        st_g, gpu, aend_g = _raw(bound, dec, slices, 3, 1)
+        st_n, cols, _ = _raw(bound, dec, slices, 3, 1, with_seq=False)
+        os.environ["HG_CRAM_RECORDS_PATH"] = "chain"
+        try:
+            st_k, kern, aend_k = _raw(bound, dec, slices, 3, 1)
+        finally:
+            del os.environ["HG_CRAM_RECORDS_PATH"]
+    finally:
+        T.DECODE_MD[0] = -1
+    assert (st_c == 0).all() and (st_g == 0).all() and (st_n == 0).all() and (st_k == 0).all()
+    assert gpu == chain and aend_g == aend_c
+    assert kern == chain and aend_k == aend_c
+    assert [[r[:9] for r in s] for s in cols] == [[r[:9] for r in s] for s in chain]
+
+
+@pytest.mark.gpu
+def test_gpu_staged_batch_gives_the_same_bam_stream_and_uses_the_passes(engine):
+    """hg_cram_batch_stage + hg_cram_batch_decode_bam_dev (BAM left in HBM) == hg_cram_decode_bam_host; every synthetic slice goes through the
+    passes; the stream is identical from run to run (bases are placed by prefix sums) and identical to the chain kernel's"""
+    from htslib_amd import _native as nat
+    slices = _synthetic(np.random.default_rng(303))
+    keep = []
+    arr = nat.cram_slice_array(slices, keep)
+    n = len(slices)
+    bases = sum(len(t["seq"]) for s in slices for t in s["truth"]) + 4096
+    bam, rec_off, st = engine.cram_decode_bam(arr, n, 3, 1, [], bases, bases * 3 + 400 * int(sum(s["nrec"] for s in slices)))
+    assert (st == 0).all()
+    h = engine.cram_batch_stage(arr, n, 3, 1, bases)
+    try:
+        runs = []
+        for _ in range(3):
+            d, nb, nr, nf, st2 = engine.cram_batch_decode_bam(h, n)
+            assert (st2 == 0).all() and nr == sum(s["nrec"] for s in slices) and nf == n
+            runs.append(bytes(engine.cram_batch_read_bam(h, nb)))
+        assert runs[0] == runs[1] == runs[2] == bytes(bam)
+    finally:
+        engine.cram_batch_free(h)
+    os.environ["HG_CRAM_RECORDS_PATH"] = "chain"
+    try:
+        bam_k, _, st_k = engine.cram_decode_bam(arr, n, 3, 1, [], bases, bases * 3 + 400 * int(sum(s["nrec"] for s in slices)))
+    finally:
+        del os.environ["HG_CRAM_RECORDS_PATH"]
+    assert (st_k == 0).all() and bytes(bam_k) == bytes(bam)
+    recs = T._parse_bam_records(bytes(bam))
+    assert len(recs) == sum(s["nrec"] for s in slices)
+
+
+@pytest.mark.gpu
+def test_gpu_mixed_and_damaged_batches_get_the_chain_decoders_verdict(engine, hostlib):
+    """fixture slices (CORE-coded: chain kernel) and synthetic ones (passes) in one call; then 150 damaged synthetic slices in one call: per-slice
+    status and records equal the chain decoder compiled for the CPU"""
+    from htslib_amd import synth_cram
+    bound, dec = T._gpu_calls(engine)
+    rng = np.random.default_rng(5)
+    fx = [s for f, major, nref, s in T.load_slices() if f == "test/range.cram"]
+    syn = [synth_cram.make_slice(rng, 300, 80), synth_cram.make_slice(rng, 90, 80, tags=True)]
+    slices = [syn[0]] + fx[:1] + [syn[1]] + fx[1:]
+    st, chain, _ = _raw(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, slices, 3, 7)
+    st2, gpu, _ = _raw(bound, dec, slices, 3, 7)
+    assert (st == 0).all() and (st2 == 0).all() and gpu == chain
+    base = [synth_cram.make_slice(rng, 60, 70, tags=True), synth_cram.make_slice(rng, 45, 50, unmapped_every=4), synth_cram.make_slice(rng, 30, 64, detached_every=2, tags=True)]
+
+    def mutate(b):
+        b = bytearray(b)
+        if not b: return bytes(b)
+        k = int(rng.integers(0, 4))
+        if k == 0:
+            for _ in range(int(rng.integers(1, 4))): b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 1: b = b[:int(rng.integers(0, len(b)))]
+        elif k == 2: b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        else:
+            i = int(rng.integers(0, len(b))); b[i:i] = bytes(rng.integers(0, 256, int(rng.integers(1, 5)), dtype=np.uint8))
+        return bytes(b)
+
+    bad = []
+    while len(bad) < 150:
+        s = dict(base[int(rng.integers(0, len(base)))])
+        j = int(rng.integers(0, len(s["blocks"]))); bl = list(s["blocks"]); bl[j] = (bl[j][0], mutate(bl[j][1])); s["blocks"] = bl
+        try:                                                             # keep what the CPU compile can render: the comparison below needs text on both sides
+            stc, gc, _ = _raw(hostlib.hgr_host_records_bound, hostlib.hgr_host_decode_records, [s], 3, 1)
+        except (AssertionError, ValueError, IndexError, UnicodeDecodeError, T.struct_error):
+            continue
+        bad.append((s, int(stc[0]), gc[0]))
+    st_g, got_g, _ = _raw(bound, dec, [b[0] for b in bad], 3, 1)
+    assert [int(x) for x in st_g] == [b[1] for b in bad]
+    assert sum(1 for b in bad if b[1] == 0) > 20 and sum(1 for b in bad if b[1] != 0) > 20
+    for k, b in enumerate(bad):
+        if b[1] == 0: assert got_g[k] == b[2], k
