@@ -77,9 +77,10 @@ lib.hg_arith_encode_host.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp]
 lib.hg_fqz_decode_host.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]
 lib.hg_cram_decode_bam_host.argtypes = [_vp, C.c_size_t, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_uint64, _vp, C.c_size_t, _vp, _vp, _vp, _vp]
 lib.hg_cram_file_to_bam_host.argtypes = [_vp, _vp, C.c_size_t, _vp, C.c_int, _vp, C.c_size_t, _vp, _vp]
-lib.hg_cram_file_to_bam_host2.argtypes = [_vp, _vp, C.c_size_t, _vp, C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_int]
+lib.hg_cram_file_to_bam_host2.argtypes = [_vp, _vp, C.c_size_t, _vp, C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_int, C.c_char_p]
+lib.hg_cram_decode_bam_host2.argtypes = [_vp, C.c_size_t, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_uint64, _vp, C.c_size_t, _vp, _vp, _vp, _vp, C.c_char_p]
 lib.hg_cram_batch_stage.argtypes = [_vp, C.c_size_t, _vp, C.c_int, C.c_int, C.c_uint64, _vp]
-lib.hg_cram_batch_decode_bam_dev.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
+lib.hg_cram_batch_decode_bam_dev.argtypes = [_vp, _vp, _vp, C.c_int, C.c_char_p, _vp, _vp, _vp, _vp, _vp]
 lib.hg_cram_batch_read_bam.argtypes = [_vp, _vp, _vp, C.c_size_t]
 lib.hg_cram_batch_free.argtypes = [_vp, _vp]
 lib.hg_cram_batch_free.restype = None
@@ -177,7 +178,7 @@ EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info
            "hg_gzip_inflate_dev", "hg_cram_uncompress_blocks_host", "hg_ransnx16_decode_host", "hg_ransnx16_decode_dev",
            "hg_ransnx16_compress_bound", "hg_ransnx16_encode_host", "hg_rans4x8_compress_bound",
            "hg_rans4x8_encode_host", "hg_gzip_compress_bound", "hg_gzip_deflate_host", "hg_cram_compress_bound",
-           "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host", "hg_cram_records_bound", "hg_cram_crai_slice", "hg_cram_file_to_bam_host", "hg_cram_decode_bam_host", "hg_cram_decode_records_host", "hg_cram_batch_stage", "hg_cram_batch_decode_bam_dev", "hg_cram_batch_read_bam", "hg_cram_batch_free", "hg_cram_file_to_bam_host2", "hg_fqz_decode_host", "hg_fqz_compress_bound", "hg_fqz_encode_host", "hg_tok3_decode_host", "hg_tok3_compress_bound", "hg_tok3_encode_host", "hg_cram_metrics_new", "hg_cram_metrics_free",
+           "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host", "hg_cram_records_bound", "hg_cram_crai_slice", "hg_cram_file_to_bam_host", "hg_cram_decode_bam_host", "hg_cram_decode_records_host", "hg_cram_batch_stage", "hg_cram_batch_decode_bam_dev", "hg_cram_batch_read_bam", "hg_cram_batch_free", "hg_cram_file_to_bam_host2", "hg_cram_decode_bam_host2", "hg_fqz_decode_host", "hg_fqz_compress_bound", "hg_fqz_encode_host", "hg_tok3_decode_host", "hg_tok3_compress_bound", "hg_tok3_encode_host", "hg_cram_metrics_new", "hg_cram_metrics_free",
            "hg_cram_compress_blocks_metrics_host", "hg_cram_compress_blocks_metrics_fqz_host", "hg_bam_header_host", "hg_bam_frame_dev", "hg_bam_bases_dev", "hg_bam_core_dev", "hg_bam_quals_dev", "hg_bai_build_dev", "hg_idx_build_dev", "hg_csi_levels", "hg_cram_uncompress_blocks_crc_host",
            "hg_pipe_create", "hg_pipe_destroy", "hg_pipe_input", "hg_pipe_inflate", "hg_pipe_deflate", "hg_pipe_wait",
            "hg_gzip_stream_inflate_host", "hg_crc32_host", "hg_crc32_batch_host",
@@ -432,14 +433,14 @@ class Engine:
         check(lib.hg_fqz_encode_host(self._h, ip, il.ctypes.data, slp, st.ctypes.data, n, op, ol.ctypes.data), "hg_fqz_encode_host")
         return [outs[i].raw[:int(ol[i])] for i in range(n)]
 
-    def cram_decode_bam(self, slice_array, nslices, major, nref, rg_names, total_bases, cap):
+    def cram_decode_bam(self, slice_array, nslices, major, nref, rg_names, total_bases, cap, name_prefix=None):
         """hg_cram_decode_bam_host on a cram_slice_array: -> (uncompressed BAM bytes as ndarray view, record offsets per slice, status)"""
         import numpy as np
         out = np.empty(cap, np.uint8); rec_off = np.zeros(nslices + 1, np.uint64); st = np.full(nslices, 9, np.int32); total = C.c_uint64()
         rg = [r.encode() if isinstance(r, str) else r for r in rg_names]
         rgp = (C.c_char_p * max(len(rg), 1))(*rg) if rg else None
-        rc = lib.hg_cram_decode_bam_host(self._h, nslices, C.cast(slice_array, _vp), major, nref, C.cast(rgp, _vp) if rg else None, len(rg), total_bases,
-                                         out.ctypes.data, cap, rec_off.ctypes.data, None, C.byref(total), st.ctypes.data)
+        rc = lib.hg_cram_decode_bam_host2(self._h, nslices, C.cast(slice_array, _vp), major, nref, C.cast(rgp, _vp) if rg else None, len(rg), total_bases,
+                                          out.ctypes.data, cap, rec_off.ctypes.data, None, C.byref(total), st.ctypes.data, name_prefix)
         if rc not in (0, -6):
             check(rc, "hg_cram_decode_bam_host")
         return out[:total.value], rec_off, st
@@ -450,13 +451,13 @@ class Engine:
         check(lib.hg_cram_batch_stage(self._h, nslices, C.cast(slice_array, _vp), major, nref, total_bases, C.byref(h)), "hg_cram_batch_stage")
         return h
 
-    def cram_batch_decode_bam(self, batch, nslices, rg_names=()):
+    def cram_batch_decode_bam(self, batch, nslices, rg_names=(), name_prefix=None):
         """hg_cram_batch_decode_bam_dev: one decoding run, BAM stream left on the device -> (device pointer, bytes, records, slices decoded by the passes, status)"""
         import numpy as np
         rg = [r.encode() if isinstance(r, str) else r for r in rg_names]
         rgp = (C.c_char_p * max(len(rg), 1))(*rg) if rg else None
         d = _vp(); nb, nr, nf = C.c_uint64(), C.c_uint64(), C.c_uint64(); st = np.full(nslices, 9, np.int32)
-        rc = lib.hg_cram_batch_decode_bam_dev(self._h, batch, C.cast(rgp, _vp) if rg else None, len(rg), C.byref(d), C.byref(nb), C.byref(nr), C.byref(nf), st.ctypes.data)
+        rc = lib.hg_cram_batch_decode_bam_dev(self._h, batch, C.cast(rgp, _vp) if rg else None, len(rg), name_prefix, C.byref(d), C.byref(nb), C.byref(nr), C.byref(nf), st.ctypes.data)
         if rc not in (0, -6):
             check(rc, "hg_cram_batch_decode_bam_dev")
         return d.value, nb.value, nr.value, nf.value, st

@@ -72,13 +72,13 @@ void md5_of(const uint8_t *p, uint64_t n, uint8_t out[16]) {
 }  // namespace
 
 extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given, uint8_t *bam_out,
-                                         size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags);
+                                         size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags, const char *name_prefix);
 extern "C" int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given, uint8_t *bam_out,
                                         size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords) {
-    return hg_cram_file_to_bam_host2(ctx, cram, cram_len, refs, nrefs_given, bam_out, bam_cap, bam_bytes, nrecords, 0);
+    return hg_cram_file_to_bam_host2(ctx, cram, cram_len, refs, nrefs_given, bam_out, bam_cap, bam_bytes, nrecords, 0, nullptr);
 }
 extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given, uint8_t *bam_out,
-                                         size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags) {
+                                         size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags, const char *name_prefix) {
     if (!ctx || !cram || !bam_out || !bam_bytes || (nrefs_given && !refs)) return HG_EINVAL;
     if (cram_len < 26 || memcmp(cram, "CRAM", 4) != 0) return HG_EINVAL;
     const int major = cram[4];
@@ -261,8 +261,8 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
         }
         std::vector<uint64_t> ro(i1 - i0 + 1, 0);
         uint64_t got = 0;
-        rc = hg_cram_decode_bam_host(ctx, i1 - i0, sb.data() + i0, major, nref, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), bases + 4096, bam_out + hb + rec_bytes,
-                                     bam_cap - hb - rec_bytes, ro.data(), nullptr, &got, status.data() + i0);
+        rc = hg_cram_decode_bam_host2(ctx, i1 - i0, sb.data() + i0, major, nref, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), bases + 4096, bam_out + hb + rec_bytes,
+                                      bam_cap - hb - rec_bytes, ro.data(), nullptr, &got, status.data() + i0, name_prefix);
         rec_bytes += got;
         for (size_t k = 0; k <= i1 - i0; k++) rec_off[i0 + k] = rec_off[i0] + ro[k];
         i0 = i1;

@@ -61,18 +61,18 @@ __device__ __forceinline__ int decode_one(const DevTables &T, const DevCols &D, 
 // each slice's part starts, from a host prefix sum over the totals) and turn the slice-relative offsets of the records into offsets
 // of the packed arrays.  One wavefront per slice.
 struct Dense { uint32_t *cigar; uint8_t *names, *aux; const uint64_t *base; };      // base: 3 per slice
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(1024)
 void cram_records_pack_kernel(DevTables T, DevCols D, Dense P, uint32_t nslices, const int32_t *status) {
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
     for (uint32_t k = blockIdx.x; k < nslices; k += gridDim.x) {
         if (status[k] != 0) continue;
         const SliceDev d = T.slices[k];
         const uint64_t bc = P.base[3 * (size_t)k], bn = P.base[3 * (size_t)k + 1], ba = P.base[3 * (size_t)k + 2];
         const uint32_t nc = D.totals[4 * (size_t)k], nn = D.totals[4 * (size_t)k + 1], na = D.totals[4 * (size_t)k + 2];
-        for (uint32_t i = lane; i < nc; i += 64) P.cigar[bc + i] = D.cigar[d.cig_off + i];
-        for (uint32_t i = lane; i < nn; i += 64) P.names[bn + i] = D.names[d.name_off + i];
-        if (D.aux) for (uint32_t i = lane; i < na; i += 64) P.aux[ba + i] = D.aux[d.aux_off + i];
-        for (uint32_t r = lane; r < (uint32_t)d.nrec; r += 64) {
+        for (uint32_t i = tid; i < nc; i += nt) P.cigar[bc + i] = D.cigar[d.cig_off + i];
+        for (uint32_t i = tid; i < nn; i += nt) P.names[bn + i] = D.names[d.name_off + i];
+        if (D.aux) for (uint32_t i = tid; i < na; i += nt) P.aux[ba + i] = D.aux[d.aux_off + i];
+        for (uint32_t r = tid; r < (uint32_t)d.nrec; r += nt) {
             D.cigar_off[d.rec_off + r] = bc + D.coff[d.rec_off + r];
             D.name_off[d.rec_off + r] = bn + D.noff[d.rec_off + r];
             if (D.aux) D.aux_off[d.rec_off + r] = ba + D.aoff[d.rec_off + r];
@@ -128,25 +128,66 @@ struct BamIn {
     const DevCols *D; const unsigned char *rg_names; const uint32_t *rg_off;   // read-group names back to back, rg_off[nrg + 1]
     int32_t nrg;
 };
-__device__ __forceinline__ uint32_t bam_record_bytes(const DevCols &D, uint64_t r, const uint32_t *rg_off, int32_t nrg) {
-    const uint32_t nl = D.name_len[r] > 0 ? (uint32_t)D.name_len[r] : 1u, len = (uint32_t)D.len[r];
-    const int32_t rg = D.rg[r];
-    const uint32_t rgb = rg >= 0 && rg < nrg ? rg_off[rg + 1] - rg_off[rg] + 4u : 0u;
-    return 4u + 32u + nl + 1u + 4u * (uint32_t)D.ncigar[r] + (len + 1u) / 2u + len + (uint32_t)D.aux_len[r] + rgb;
-}
-__global__ __launch_bounds__(64)
-void cram_bam_size_kernel(DevTables T, DevCols D, const uint32_t *rg_off, int32_t nrg, uint32_t nslices, int32_t *status, uint64_t *sizes) {
-    const uint32_t lane = threadIdx.x & 63u;
+// Names of records stored without one (cram_to_bam, cram_decode.c:3113-3143): the mate's name when it has one, else "<prefix>:<number>" with the
+// number of the record in the file (of the earlier record of the pair, so that mates agree).  code >= 0: that number; code <= -2: copy the
+// name of record -(code + 2) of the batch.  Without a prefix the record is called "*".
+__device__ __forceinline__ uint32_t dec_digits(uint64_t v) { uint32_t n = 1; while (v >= 10u) { v /= 10u; n++; } return n; }
+// What the writer needs to know about a record, gathered ONCE by the sizing pass (one lane per record: every column read is coalesced) into 32
+// words -- the writer, one wavefront per record, then pays one round trip for the descriptor and one for the bytes instead of a chain of a
+// dozen dependent column reads.
+enum { BD_W0 = 0 /* 9 words of block_size + core */, BD_NL = 9, BD_NC, BD_LEN, BD_NA, BD_RG, BD_NKIND /* 0 stored name, 1 "<prefix>:<number>", 2 "*" */, BD_NAME_LO = 16, BD_NAME_HI,
+       BD_NUM_LO, BD_NUM_HI, BD_CIG_LO, BD_CIG_HI, BD_SEQ_LO, BD_SEQ_HI, BD_AUX_LO, BD_AUX_HI, BD_WORDS = 32 };
+__device__ __forceinline__ uint32_t reg2bin_(int64_t beg, int64_t end);
+__global__ __launch_bounds__(1024)
+void cram_bam_size_kernel(DevTables T, DevCols D, Dense P, const uint32_t *rg_off, int32_t nrg, uint32_t plen, uint32_t nslices, int32_t *status, uint64_t *sizes, uint32_t *desc) {
+    __shared__ int bad_any;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
     for (uint32_t k = blockIdx.x; k < nslices; k += gridDim.x) {
         const SliceDev d = T.slices[k];
         bool ok = status[k] == 0;
+        if (tid == 0) bad_any = 0;
+        __syncthreads();
         if (ok) {                                                          // what a BAM record cannot hold (bam_set1 / bam_write1 refuse or re-route these)
-            bool bad = false;
-            for (uint32_t r = lane; r < (uint32_t)d.nrec; r += 64) bad |= D.name_len[d.rec_off + r] > 254 || D.ncigar[d.rec_off + r] > 65535 || D.len[d.rec_off + r] < 0;
-            if (__ballot(bad)) { ok = false; if (lane == 0) status[k] = ERR_UNSUPPORTED; }
+            int bad = 0;
+            for (uint32_t r = tid; r < (uint32_t)d.nrec; r += nt) {
+                const uint64_t g = d.rec_off + r;
+                const int32_t rg = D.rg[g];
+                if (rg < -1 || rg >= nrg) bad |= 2;                                            // cram_to_bam returns -1 (cram_decode.c:3146-3147)
+                // the name: stored, the mate's, "<prefix>:<number>" or "*" (cram_decode.c:3113-3143)
+                uint32_t nkind = 0, nl = D.name_len[g] > 0 ? (uint32_t)D.name_len[g] : 0u; uint64_t nsrc = g, num = 0;
+                if (!nl) {
+                    const int32_t m = D.mate_line[g];
+                    if (!plen) { nkind = 2; nl = 1; }
+                    else if (m >= 0 && m < d.nrec && D.name_len[d.rec_off + (uint32_t)m] > 0) { nsrc = d.rec_off + (uint32_t)m; nl = (uint32_t)D.name_len[nsrc]; }
+                    else { nkind = 1; num = (uint64_t)(d.record_counter + (m >= 0 && m < (int32_t)r ? m : (int32_t)r) + 1); nl = plen + 1u + dec_digits(num); }
+                }
+                const int32_t len = D.len[g], nc = D.ncigar[g];
+                if (nl > 254 || nc > 65535 || len < 0) bad |= 1;
+                const uint32_t na = (uint32_t)D.aux_len[g], flag = (uint32_t)D.flags[g];
+                const uint32_t rgb = rg >= 0 && rg < nrg ? rg_off[rg + 1] - rg_off[rg] + 4u : 0u;
+                const uint32_t bytes = 4u + 32u + nl + 1u + 4u * (uint32_t)nc + ((uint32_t)len + 1u) / 2u + (uint32_t)len + na + rgb;
+                sizes[g] = bytes;
+                const uint64_t cig_off = D.cigar_off[g];
+                long long rl = 0;                                                              // reference length of the alignment (bam_cigar2rlen) -> bin
+                if (!(flag & BAM_FUNMAP)) for (int32_t i = 0; i < nc && i < 65536; i++) { const uint32_t c = P.cigar[cig_off + (uint32_t)i], op = c & 15u; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += c >> 4; }
+                if (rl == 0) rl = 1;
+                const int64_t pos = D.apos[g] - 1, mpos = D.mate_pos[g] - 1;
+                uint32_t *w = desc + g * BD_WORDS;
+                w[0] = bytes - 4u; w[1] = (uint32_t)D.ref_id[g]; w[2] = (uint32_t)pos;
+                w[3] = reg2bin_(pos, pos + rl) << 16 | ((uint32_t)D.mqual[g] & 0xffu) << 8 | (nl + 1u);
+                w[4] = flag << 16 | ((uint32_t)nc & 0xffffu); w[5] = (uint32_t)len; w[6] = (uint32_t)D.mate_ref_id[g]; w[7] = (uint32_t)mpos; w[8] = (uint32_t)D.tlen[g];
+                w[BD_NL] = nl; w[BD_NC] = (uint32_t)nc; w[BD_LEN] = (uint32_t)len; w[BD_NA] = na; w[BD_RG] = (uint32_t)rg; w[BD_NKIND] = nkind; w[15] = 0;
+                const uint64_t name_off = D.name_off[nsrc], seq_off = D.seq_off[g], aux_off = D.aux_off[g];
+                w[BD_NAME_LO] = (uint32_t)name_off; w[BD_NAME_HI] = (uint32_t)(name_off >> 32); w[BD_NUM_LO] = (uint32_t)num; w[BD_NUM_HI] = (uint32_t)(num >> 32);
+                w[BD_CIG_LO] = (uint32_t)cig_off; w[BD_CIG_HI] = (uint32_t)(cig_off >> 32); w[BD_SEQ_LO] = (uint32_t)seq_off; w[BD_SEQ_HI] = (uint32_t)(seq_off >> 32);
+                w[BD_AUX_LO] = (uint32_t)aux_off; w[BD_AUX_HI] = (uint32_t)(aux_off >> 32);
+            }
+            if (bad) atomicOr(&bad_any, bad);
         }
-        for (uint32_t r = lane; r < (uint32_t)d.nrec; r += 64) sizes[d.rec_off + r] = ok ? bam_record_bytes(D, d.rec_off + r, rg_off, nrg) : 0u;
-        hg::wave_sync();
+        __syncthreads();
+        if (ok && bad_any) { ok = false; if (tid == 0) status[k] = (bad_any & 2) ? ERR_MALFORMED : ERR_UNSUPPORTED; }
+        if (!ok) for (uint32_t r = tid; r < (uint32_t)d.nrec; r += nt) sizes[d.rec_off + r] = 0u;
+        __syncthreads();
     }
 }
 // exclusive prefix sum of n values in place, n + 1 outputs, over the whole device: tiles of SCAN_TILE values are summed (one workgroup each),
@@ -203,12 +244,20 @@ void scan_tiles_kernel(uint64_t *v, uint64_t n, const uint64_t *tile_base) {
 #pragma unroll
     for (uint32_t j = 0; j < PER; j++) { if (a + j < n) v[a + j] = run; run += x[j]; }
 }
-__device__ __forceinline__ uint32_t nt16(uint32_t c) {                    // seq_nt16_table (hts.c)
+__device__ __forceinline__ uint32_t nt16_switch(uint32_t c) {             // seq_nt16_table (hts.c)
     switch (c & ~0x20u) {
     case 'A': return 1; case 'C': return 2; case 'M': return 3; case 'G': return 4; case 'R': return 5; case 'S': return 6; case 'V': return 7; case 'T': return 8;
     case 'W': return 9; case 'Y': return 10; case 'H': return 11; case 'K': return 12; case 'D': return 13; case 'B': return 14;
     default: return c == '=' ? 0u : 15u;
     }
+}
+// the same table for the letters A..Z (either case) as 4-bit entries of two 64-bit words: no branches per base
+__device__ __forceinline__ uint32_t nt16(uint32_t c) {
+    if (c == '=') return 0u;
+    const uint32_t u = (c & ~0x20u) - 'A';                                 // 0..25 for letters
+    // A=1 B=14 C=2 D=13 E=15 F=15 G=4 H=11 I=15 J=15 K=12 L=15 M=3 N=15 O=15 P=15 | Q=15 R=5 S=6 T=8 U=15 V=7 W=9 X=15 Y=10 Z=15
+    const unsigned long long lo = 0xfff3fcffb4ffd2e1ull, hi = 0xfaf97f865full;
+    return u < 16u ? (uint32_t)(lo >> (4u * u)) & 15u : u < 26u ? (uint32_t)(hi >> (4u * (u - 16u))) & 15u : 15u;
 }
 __device__ __forceinline__ uint32_t reg2bin(int64_t beg, int64_t end) {  // bam_reg2bin (sam.h)
     --end;
@@ -219,59 +268,47 @@ __device__ __forceinline__ uint32_t reg2bin(int64_t beg, int64_t end) {  // bam_
     if (beg >> 26 == end >> 26) return (uint32_t)(((1 << 3) - 1) / 7 + (beg >> 26));
     return 0;
 }
-// One WAVEFRONT per record: the 36 fixed bytes by nine lanes, then name, CIGAR, packed bases, qualities, tags a byte (or word) per lane --
-// consecutive lanes write consecutive bytes, so a record costs a dozen coalesced stores.  (Round 2 had one LANE per record writing ~350
-// bytes one after the other: 64 cache lines per store instruction, 7.5 ms per million records.)  Records of failed slices have size 0.
+__device__ __forceinline__ uint32_t reg2bin_(int64_t beg, int64_t end) { return reg2bin(beg, end); }
+// One WAVEFRONT per record: one coalesced load of the record's descriptor (its words go to scalar registers), then name, CIGAR, packed
+// bases, qualities and tags a byte per lane -- consecutive lanes write consecutive bytes.  Records of failed slices have size 0.
+// (Round 2: one LANE per record writing ~350 bytes one after the other, 7.5 ms per million records.)
 __global__ __launch_bounds__(256)
-void cram_bam_write_kernel(DevCols D, Dense P, const unsigned char *rg_names, const uint32_t *rg_off, int32_t nrg, uint64_t nrec, const uint64_t *off, uint8_t *out) {
+void cram_bam_write_kernel(DevCols D, Dense P, const unsigned char *rg_names, const uint32_t *rg_off, const unsigned char *prefix, uint32_t plen, uint64_t nrec,
+                           const uint64_t *off, const uint32_t *desc, uint8_t *out) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t nw = (uint64_t)gridDim.x * 4u;
     for (uint64_t r = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); r < nrec; r += nw) {
         const uint64_t o0 = off[r];
-        const uint32_t bytes = (uint32_t)(off[r + 1] - o0);
-        if (!bytes) continue;
+        if (off[r + 1] == o0) continue;
+        const uint32_t dw = desc[r * BD_WORDS + (lane & 31u)];
+        auto W = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)dw, i); };
+        auto W64 = [&](int i) -> uint64_t { return (uint64_t)W(i) | (uint64_t)W(i + 1) << 32; };
         uint8_t *o = out + o0;
-        const uint32_t nl = D.name_len[r] > 0 ? (uint32_t)D.name_len[r] : 0u, len = (uint32_t)D.len[r], nc = (uint32_t)D.ncigar[r], flag = (uint32_t)D.flags[r];
-        const uint32_t *cig = P.cigar + D.cigar_off[r];
-        long long rl = 0;                                                  // reference length of the alignment (bam_cigar2rlen) -> bin
-        if (!(flag & BAM_FUNMAP)) for (uint32_t i = lane; i < nc; i += 64) { const uint32_t op = cig[i] & 15u; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += cig[i] >> 4; }
-        for (int sft = 1; sft < 64; sft <<= 1) rl += __shfl_xor(rl, sft, 64);
-        if (rl == 0) rl = 1;
-        const int64_t pos = D.apos[r] - 1, mpos = D.mate_pos[r] - 1;
-        if (lane < 9) {
-            uint32_t w;
-            switch (lane) {
-            case 0: w = bytes - 4u; break;
-            case 1: w = (uint32_t)D.ref_id[r]; break;
-            case 2: w = (uint32_t)pos; break;
-            case 3: w = reg2bin(pos, pos + rl) << 16 | ((uint32_t)D.mqual[r] & 0xffu) << 8 | ((nl ? nl : 1u) + 1u); break;
-            case 4: w = flag << 16 | (nc & 0xffffu); break;
-            case 5: w = len; break;
-            case 6: w = (uint32_t)D.mate_ref_id[r]; break;
-            case 7: w = (uint32_t)mpos; break;
-            default: w = (uint32_t)D.tlen[r]; break;
-            }
-            uint8_t *q = o + 4u * lane;
-            q[0] = (uint8_t)w; q[1] = (uint8_t)(w >> 8); q[2] = (uint8_t)(w >> 16); q[3] = (uint8_t)(w >> 24);
-        }
+        const uint32_t nl = W(BD_NL), nc = W(BD_NC), len = W(BD_LEN), na = W(BD_NA), nkind = W(BD_NKIND);
+        const int32_t rg = (int32_t)W(BD_RG);
+        if (lane < 9) { uint8_t *q = o + 4u * lane; q[0] = (uint8_t)dw; q[1] = (uint8_t)(dw >> 8); q[2] = (uint8_t)(dw >> 16); q[3] = (uint8_t)(dw >> 24); }      // block_size + the 32-byte core: lane i holds word i
         uint32_t at = 36;
-        if (nl) { const uint8_t *nm = P.names + D.name_off[r]; for (uint32_t i = lane; i < nl; i += 64) o[at + i] = nm[i]; at += nl; }
-        else { if (lane == 0) o[at] = '*'; at++; }
-        if (lane == 0) o[at] = 0;
-        at++;
+        if (nkind == 0) { const uint8_t *nm = P.names + W64(BD_NAME_LO); for (uint32_t i = lane; i < nl; i += 64) o[at + i] = nm[i]; }
+        else if (nkind == 1) {                                               // "<prefix>:<number>"
+            for (uint32_t i = lane; i < plen; i += 64) o[at + i] = prefix[i];
+            if (lane == 0) { o[at + plen] = ':'; uint64_t v = W64(BD_NUM_LO); for (uint32_t i = nl; i > plen + 1u; i--) { o[at + i - 1u] = (uint8_t)('0' + v % 10u); v /= 10u; } }
+        }
+        else if (lane == 0) o[at] = '*';
+        if (lane == 0) o[at + nl] = 0;
+        at += nl + 1u;
+        const uint32_t *cig = P.cigar + W64(BD_CIG_LO);
         for (uint32_t i = lane; i < nc; i += 64) { const uint32_t w = cig[i]; uint8_t *q = o + at + 4u * i; q[0] = (uint8_t)w; q[1] = (uint8_t)(w >> 8); q[2] = (uint8_t)(w >> 16); q[3] = (uint8_t)(w >> 24); }
         at += 4u * nc;
-        const uint8_t *sq = D.seq + D.seq_off[r], *ql = D.qual + D.seq_off[r];
+        const uint64_t so = W64(BD_SEQ_LO);
+        const uint8_t *sq = D.seq + so, *ql = D.qual + so;
         for (uint32_t i = lane; i < (len + 1u) / 2u; i += 64) o[at + i] = (uint8_t)(nt16(sq[2u * i]) << 4 | (2u * i + 1u < len ? nt16(sq[2u * i + 1u]) : 0u));
         at += (len + 1u) / 2u;
         for (uint32_t i = lane; i < len; i += 64) o[at + i] = ql[i];
         at += len;
-        const uint32_t na = (uint32_t)D.aux_len[r];
-        const uint8_t *ax = P.aux + D.aux_off[r];
+        const uint8_t *ax = P.aux + W64(BD_AUX_LO);
         for (uint32_t i = lane; i < na; i += 64) o[at + i] = ax[i];
         at += na;
-        const int32_t rg = D.rg[r];
-        if (rg >= 0 && rg < nrg) {                                           // RG:Z: from the read-group series (cram_decode.c:3180-3189)
+        if (rg >= 0) {                                                       // RG:Z: from the read-group series (cram_decode.c:3180-3189); the sizing pass checked the range
             const uint32_t a = rg_off[rg], n = rg_off[rg + 1] - a;
             if (lane < 3) o[at + lane] = lane == 0 ? 'R' : lane == 1 ? 'G' : 'Z';
             for (uint32_t i = lane; i < n; i += 64) o[at + 3u + i] = rg_names[a + i];
@@ -306,7 +343,7 @@ struct PhaseTimer {
     }
     ~PhaseTimer() { if (on) fprintf(stderr, "cram records phases:%s\n", log.c_str()); }
 };
-struct BamSink { const char *const *rg_names; int nrg; uint8_t *out; size_t cap; uint64_t *rec_bam_off; uint64_t *total; };
+struct BamSink { const char *const *rg_names; int nrg; uint8_t *out; size_t cap; uint64_t *rec_bam_off; uint64_t *total; const char *prefix; };
 
 // Device memory of a batch: slots of the context's scratch (host entry points: grown on demand, kept between calls) or allocations of
 // its own (a staged batch that outlives the call: hg_cram_batch)
@@ -582,23 +619,28 @@ static int rec_run(hg_ctx *ctx, hg_cram_batch &R, const BamSink *bam, size_t cig
     uint8_t *d_pack = (uint8_t *)M.p[M_PACK];
     R.PK = hgr::Dense{(uint32_t *)d_pack, d_pack + pc, d_pack + pc + pn, (const uint64_t *)(d_out + R.obase)};
     if (hipMemcpyAsync(d_out + R.obase, base.data(), nslices * 24, hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
-    hipLaunchKernelGGL(hgr::cram_records_pack_kernel, dim3((unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 32)), dim3(64), 0, s, T, D, R.PK, (uint32_t)nslices, R.d_status);
+    hipLaunchKernelGGL(hgr::cram_records_pack_kernel, dim3((unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 8)), dim3(1024), 0, s, T, D, R.PK, (uint32_t)nslices, R.d_status);
     if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
     PT.mark("pack");
     R.bam_bytes = 0;
     if (bam) {                                                           // cram_to_bam on the device: sizes, prefix sum, bytes
         std::vector<uint32_t> rgo((size_t)bam->nrg + 1, 0u); std::vector<unsigned char> rgn;
         for (int i = 0; i < bam->nrg; i++) { const size_t l = strlen(bam->rg_names[i]); rgn.insert(rgn.end(), bam->rg_names[i], bam->rg_names[i] + l); rgo[(size_t)i + 1] = (uint32_t)rgn.size(); }
+        const uint32_t plen = bam->prefix ? (uint32_t)std::min<size_t>(strlen(bam->prefix), 200) : 0u;      // the read-group names are followed by the name prefix
+        const size_t rg_bytes = rgn.size();
+        if (plen) rgn.insert(rgn.end(), bam->prefix, bam->prefix + plen);
         const size_t NR = B.nrec ? B.nrec : 1, ntiles = (NR + hgr::SCAN_TILE - 1) / hgr::SCAN_TILE;
         const size_t szb = ((NR + 1) * 8 + 63) & ~(size_t)63, tlb = ((ntiles + 1) * 8 + 63) & ~(size_t)63, rgb = (rgo.size() * 4 + 63) & ~(size_t)63;
-        if ((rc = M.need(M_BSZ, szb + tlb + rgb + rgn.size() + 128))) return rc;
+        const size_t dsb = NR * hgr::BD_WORDS * 4;
+        if ((rc = M.need(M_BSZ, szb + tlb + rgb + ((rgn.size() + 63) & ~(size_t)63) + dsb + 256))) return rc;
         uint8_t *d_b = (uint8_t *)M.p[M_BSZ];
+        uint32_t *d_desc = (uint32_t *)(d_b + szb + tlb + rgb + ((rgn.size() + 63) & ~(size_t)63) + 64);
         uint64_t *d_sz = (uint64_t *)d_b, *d_tile = (uint64_t *)(d_b + szb); uint32_t *d_rgo = (uint32_t *)(d_b + szb + tlb); unsigned char *d_rgn = (unsigned char *)d_rgo + rgb;
         ok = hipMemcpyAsync(d_rgo, rgo.data(), rgo.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
              (rgn.empty() || hipMemcpyAsync(d_rgn, rgn.data(), rgn.size(), hipMemcpyHostToDevice, s) == hipSuccess);
         if (!ok) return HG_ELAUNCH;
-        const unsigned grid = (unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 32);
-        hipLaunchKernelGGL(hgr::cram_bam_size_kernel, dim3(grid), dim3(64), 0, s, T, D, d_rgo, (int32_t)bam->nrg, (uint32_t)nslices, R.d_status, d_sz);
+        const unsigned grid = (unsigned)std::min<size_t>(nslices, (size_t)ctx->cus * 8);
+        hipLaunchKernelGGL(hgr::cram_bam_size_kernel, dim3(grid), dim3(1024), 0, s, T, D, R.PK, d_rgo, (int32_t)bam->nrg, plen, (uint32_t)nslices, R.d_status, d_sz, d_desc);
         hipLaunchKernelGGL(hgr::scan_tile_sums_kernel, dim3((unsigned)ntiles), dim3(hgr::SCAN_TPB), 0, s, d_sz, (uint64_t)B.nrec, d_tile);
         hipLaunchKernelGGL(hgr::scan_tile_bases_kernel, dim3(1), dim3(hgr::SCAN_TPB), 0, s, d_tile, (uint64_t)ntiles, d_sz + B.nrec);
         hipLaunchKernelGGL(hgr::scan_tiles_kernel, dim3((unsigned)ntiles), dim3(hgr::SCAN_TPB), 0, s, d_sz, (uint64_t)B.nrec, d_tile);
@@ -612,8 +654,8 @@ static int rec_run(hg_ctx *ctx, hg_cram_batch &R, const BamSink *bam, size_t cig
         if (total > bam->cap) return HG_ENOMEM;
         if ((rc = M.need(M_BAM, total + 64))) return rc;
         R.d_bam = (uint8_t *)M.p[M_BAM];
-        const unsigned wgrid = (unsigned)std::min<size_t>((B.nrec + 3) / 4 + 1, (size_t)ctx->cus * 16);
-        hipLaunchKernelGGL(hgr::cram_bam_write_kernel, dim3(wgrid), dim3(256), 0, s, D, R.PK, d_rgn, d_rgo, (int32_t)bam->nrg, (uint64_t)B.nrec, d_sz, R.d_bam);
+        const unsigned wgrid = (unsigned)std::min<size_t>((B.nrec + 3) / 4 + 1, (size_t)ctx->cus * 64);
+        hipLaunchKernelGGL(hgr::cram_bam_write_kernel, dim3(wgrid), dim3(256), 0, s, D, R.PK, d_rgn, d_rgo, d_rgn + rg_bytes, plen, (uint64_t)B.nrec, d_sz, d_desc, R.d_bam);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
         PT.mark("bam write");
     }
@@ -668,9 +710,17 @@ extern "C" int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg
 
 // CRAM slices -> uncompressed BAM records (cram_decode_slice + cram_to_bam, cram_decode.c:2346-3192), everything on the device; only the
 // BAM bytes come back.  rg_names: the @RG IDs in header order (the RG series indexes them).  Records of failed slices are left out.
+extern "C" int hg_cram_decode_bam_host2(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, const char *const *rg_names,
+                                        int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap, uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes,
+                                        int32_t *status, const char *name_prefix);
 extern "C" int hg_cram_decode_bam_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, const char *const *rg_names,
                                        int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap, uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes,
                                        int32_t *status) {
+    return hg_cram_decode_bam_host2(ctx, nslices, slices, major_version, nref, rg_names, nrg, total_bases, bam_out, bam_cap, rec_off, rec_bam_off, bam_bytes, status, nullptr);
+}
+extern "C" int hg_cram_decode_bam_host2(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, const char *const *rg_names,
+                                        int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap, uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes,
+                                        int32_t *status, const char *name_prefix) {
     if (!ctx || (nslices && (!slices || !bam_out || !rec_off || !status)) || (nrg && !rg_names)) return HG_EINVAL;
     if (nslices == 0) { if (rec_off) rec_off[0] = 0; if (bam_bytes) *bam_bytes = 0; return HG_OK; }
     hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
@@ -679,7 +729,7 @@ extern "C" int hg_cram_decode_bam_host(hg_ctx *ctx, size_t nslices, const hg_cra
     if (rc) return rc;
     for (size_t i = 0; i < nslices; i++) rec_off[i] = R.B.slices[i].rec_off;
     rec_off[nslices] = R.B.nrec;
-    const BamSink sink{rg_names, nrg, bam_out, bam_cap, rec_bam_off, bam_bytes};
+    const BamSink sink{rg_names, nrg, bam_out, bam_cap, rec_bam_off, bam_bytes, name_prefix};
     rc = rec_run(ctx, R, &sink, (size_t)-1, (size_t)-1, (size_t)-1);
     for (size_t i = 0; i < nslices && i < R.status.size(); i++) status[i] = R.status[i];
     if (rc) return rc;
@@ -703,12 +753,12 @@ extern "C" int hg_cram_batch_stage(hg_ctx *ctx, size_t nslices, const hg_cram_sl
     *out = R;
     return HG_OK;
 }
-extern "C" int hg_cram_batch_decode_bam_dev(hg_ctx *ctx, hg_cram_batch *batch, const char *const *rg_names, int nrg, void **d_bam, uint64_t *bam_bytes, uint64_t *nrec,
-                                            uint64_t *fast_slices, int32_t *status) {
+extern "C" int hg_cram_batch_decode_bam_dev(hg_ctx *ctx, hg_cram_batch *batch, const char *const *rg_names, int nrg, const char *name_prefix, void **d_bam, uint64_t *bam_bytes,
+                                            uint64_t *nrec, uint64_t *fast_slices, int32_t *status) {
     if (!ctx || !batch || (nrg && !rg_names)) return HG_EINVAL;
     hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     uint64_t total = 0;
-    const BamSink sink{rg_names, nrg, nullptr, (size_t)-1, nullptr, &total};
+    const BamSink sink{rg_names, nrg, nullptr, (size_t)-1, nullptr, &total, name_prefix};
     const int rc = rec_run(ctx, *batch, &sink, (size_t)-1, (size_t)-1, (size_t)-1);
     if (status) for (size_t i = 0; i < batch->nslices && i < batch->status.size(); i++) status[i] = batch->status[i];
     if (rc) return rc;

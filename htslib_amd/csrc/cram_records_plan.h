@@ -222,6 +222,7 @@ struct SliceDev {
     uint32_t ref_first, nrefs;            // reference spans of the slice in Batch::refs
     int32_t decode_md, pad2;
     uint64_t job_off; uint32_t job_cap, pad3;   // deferred bulk copies (Batch::job_total entries in all)
+    int64_t record_counter;               // slice header: number of the slice's first record in the file (names of name-less records, cram_decode.c:3113-3143)
 };
 struct Batch {
     std::vector<PlanDev> plans;
@@ -277,7 +278,7 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
         } else pi = it->second;
         if (pi < 0) { B.status[i] = -1; B.slices.push_back(d); continue; }
         const PlanHost &H = hosts[(size_t)pi];
-        d.plan = (uint32_t)pi; d.nrec = sh.nrec; d.ref_seq_id = sh.ref_seq_id; d.ref_seq_start = sh.ref_seq_start;
+        d.plan = (uint32_t)pi; d.nrec = sh.nrec; d.ref_seq_id = sh.ref_seq_id; d.ref_seq_start = sh.ref_seq_start; d.record_counter = sh.record_counter;
         d.tab_off = (uint32_t)B.tab.size();
         const size_t ns = H.slot_id.size();
         B.tab.resize(B.tab.size() + 3 * ns, 0u);

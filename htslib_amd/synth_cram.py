@@ -32,11 +32,11 @@ TAG_LINES = [b"", b"NMcXZZ", b"NMc"]                               # the tag dic
 NM_ID, XZ_ID = 60, 61
 
 
-def compression_header(tags=False):
+def compression_header(tags=False, names=True):
     """-> (block bytes, {series: content id})"""
     ids = {s: 10 + k for k, s in enumerate(SERIES)}
     td = b"".join(t + b"\0" for t in TAG_LINES) if tags else b"\0"
-    pres = _map([b"RN\x01", b"AP\x01", b"RR\x01", b"SM" + bytes([0x1B] * 5), b"TD" + put_itf8(len(td)) + td])
+    pres = _map([b"RN\x01" if names else b"RN\x00", b"AP\x01", b"RR\x01", b"SM" + bytes([0x1B] * 5), b"TD" + put_itf8(len(td)) + td])
     ext = lambda cid: put_itf8(1) + put_itf8(len(put_itf8(cid))) + put_itf8(cid)
     const = lambda v: put_itf8(3) + (lambda p: put_itf8(len(p)) + p)(put_itf8(1) + put_itf8(v) + put_itf8(1) + put_itf8(0))
     stop = lambda c, cid: put_itf8(5) + (lambda p: put_itf8(len(p)) + p)(bytes([c]) + put_itf8(cid))
@@ -55,11 +55,11 @@ def compression_header(tags=False):
     return pres + _map(enc) + _map(tagmap), ids
 
 
-def make_slice(rng, nrec, readlen=100, ref_len=None, unmapped_every=37, detached_every=11, tags=False):
+def make_slice(rng, nrec, readlen=100, ref_len=None, unmapped_every=37, detached_every=11, tags=False, names=True, record_counter=0):
     """-> a slice dict in the layout Engine.cram_decode_bam takes (and tests/test_cram_records.load_slices() yields) plus "truth": per record (flag base bits, pos, len, cigar, seq, qual)"""
     ref_len = ref_len or (nrec * 8 + 10 * readlen)
     ref = bytes(BASES[i] for i in rng.integers(0, 4, ref_len))
-    comp, ids = compression_header(tags)
+    comp, ids = compression_header(tags, names)
     col = {s: bytearray() for s in SERIES}
     nm_col, xz_col = bytearray(), bytearray()
     truth, pos_prev, start = [], 1, 1
@@ -77,7 +77,8 @@ def make_slice(rng, nrec, readlen=100, ref_len=None, unmapped_every=37, detached
         cf = 1 | (2 if detached else 0) | (4 if paired_down else 0)
         col["BF"] += put_itf8(flag); col["CF"] += put_itf8(cf); col["RL"] += put_itf8(readlen)
         col["AP"] += put_itf8(pos - pos_prev); pos_prev = pos
-        name = ("r%07d" % r).encode(); col["RN"] += name + b"\0"
+        name = ("r%07d" % r).encode()
+        if names or (detached_every and r % detached_every == 0): col["RN"] += name + b"\0"      # RN = 0: only detached records store their name (cram_decode.c:2745-2757)
         if detached:
             col["MF"] += put_itf8(0); col["NS"] += put_itf8(-1); col["NP"] += put_itf8(0); col["TS"] += put_itf8(0)
         elif paired_down: col["NF"] += put_itf8(0)
@@ -132,7 +133,7 @@ def make_slice(rng, nrec, readlen=100, ref_len=None, unmapped_every=37, detached
             else: col["DL"] += put_itf8(val)
         col["MQ"] += put_itf8(int(rng.integers(0, 61))); col["QS"] += qual
         truth.append({"flag": flag, "pos": pos, "cigar": [c[:] for c in cigar], "seq": bytes(seq), "qual": qual, "down": bool(paired_down), "name": name, "aux": aux})
-    sh = put_itf8(0) + put_itf8(start) + put_itf8(ref_len - start) + put_itf8(nrec) + _ltf8(0) + put_itf8(len(SERIES) + 1)
+    sh = put_itf8(0) + put_itf8(start) + put_itf8(ref_len - start) + put_itf8(nrec) + _ltf8(record_counter) + put_itf8(len(SERIES) + 1)
     blocks = [(ids[s], bytes(col[s])) for s in SERIES if len(col[s])]
     if tags: blocks += [(NM_ID, bytes(nm_col)), (XZ_ID, bytes(xz_col))]
     sh += put_itf8(len(blocks)) + b"".join(put_itf8(cid) for cid, _ in blocks) + put_itf8(-1) + bytes(16)

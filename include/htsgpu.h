@@ -425,8 +425,10 @@ int hg_cram_decode_records_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice
  * from the read-group series.  Only the BAM bytes cross PCIe; they are what bgzf_write / hg_bgzf_deflate take.  rg_names = the @RG IDs
  * in header order; total_bases >= the bases of the slices (sum of the containers' `bases` fields).  rec_off as above; rec_bam_off
  * (optional, records + 1 entries) = where each record starts in bam_out; *bam_bytes = bytes written, or needed when the call returns
- * HG_ENOMEM.  Records of failed slices are left out.  Not done: names for files written without read names
- * (such records get "*"), CIGARs of more than 65535 operations. */
+ * HG_ENOMEM.  Records of failed slices are left out; a read-group index outside the header's @RG lines fails its slice with -1 like
+ * cram_to_bam.  Records stored without a name get "*"; hg_cram_decode_bam_host2 with a name_prefix (the reference uses the file's base
+ * name, cram/cram_io.c:5346) gives them the reference's names instead: the mate's name when it has one, else "<prefix>:<number of the
+ * record in the file>" (cram_decode.c:3113-3143).  Not done: CIGARs of more than 65535 operations. */
 int hg_cram_decode_bam_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref,
                             const char *const *rg_names, int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap,
                             uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes, int32_t *status);
@@ -442,8 +444,8 @@ int hg_cram_decode_bam_host(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blo
 typedef struct hg_cram_batch hg_cram_batch;
 int hg_cram_batch_stage(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref,
                         uint64_t total_bases, hg_cram_batch **out);
-int hg_cram_batch_decode_bam_dev(hg_ctx *ctx, hg_cram_batch *batch, const char *const *rg_names, int nrg, void **d_bam,
-                                 uint64_t *bam_bytes, uint64_t *nrec, uint64_t *fast_slices, int32_t *status);
+int hg_cram_batch_decode_bam_dev(hg_ctx *ctx, hg_cram_batch *batch, const char *const *rg_names, int nrg, const char *name_prefix,
+                                 void **d_bam, uint64_t *bam_bytes, uint64_t *nrec, uint64_t *fast_slices, int32_t *status);
 int hg_cram_batch_read_bam(hg_ctx *ctx, hg_cram_batch *batch, uint8_t *dst, size_t cap);   /* the last run's stream -> host */
 void hg_cram_batch_free(hg_ctx *ctx, hg_cram_batch *batch);
 
@@ -453,6 +455,9 @@ void hg_cram_batch_free(hg_ctx *ctx, hg_cram_batch *batch);
  * @SQ lines in upper case (bases == NULL or nrefs_given == 0: not available -- bases come out as '=' plus the stored edits); embedded
  * reference blocks are used when a slice has one.  *bam_bytes = bytes written, or needed when the call returns HG_ENOMEM.  A block that
  * fails to decode fails the file (HG_EBLOCK), as in the reference. */
+int hg_cram_decode_bam_host2(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref,
+                             const char *const *rg_names, int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap,
+                             uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes, int32_t *status, const char *name_prefix);
 typedef struct hg_cram_ref_seq { const uint8_t *bases; uint64_t len; } hg_cram_ref_seq;
 int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given,
                              uint8_t *bam_out, size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords);
@@ -461,7 +466,7 @@ int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, 
  * reference mismatch"); HG_CRAM_IGNORE_MD5 = the reference's ignore_md5 option.  Containers written without a reference (RR = 0) get none. */
 #define HG_CRAM_IGNORE_MD5 1
 int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given,
-                              uint8_t *bam_out, size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags);
+                              uint8_t *bam_out, size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags, const char *name_prefix);
 
 /* The .crai text of one slice (cram_index_slice / cram_index_build_multiref, cram/cram_index.c:632-728): "ref start span container_pos
  * landmark slice_bytes" -- one line from the slice header, or, for a multi-reference slice, one line per run of records on the same

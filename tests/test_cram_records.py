@@ -459,7 +459,7 @@ def test_gpu_whole_cram_file_to_bam(engine):
         keepw = [C.create_string_buffer(bytes(q), len(q)) if q is not None else None for q in wrong]
         arrw = (RefSeq * max(len(wrong), 1))(*[RefSeq(C.addressof(k), len(q)) if k is not None else RefSeq(None, 0) for k, q in zip(keepw, wrong)])
         rcw = nat.lib.hg_cram_file_to_bam_host(engine._h, C.cast(cb, _vp), len(cram), C.cast(arrw, _vp), len(wrong), out.ctypes.data, len(out), C.byref(total), C.byref(n))
-        rci = nat.lib.hg_cram_file_to_bam_host2(engine._h, C.cast(cb, _vp), len(cram), C.cast(arrw, _vp), len(wrong), out.ctypes.data, len(out), C.byref(total), C.byref(n), 1)
+        rci = nat.lib.hg_cram_file_to_bam_host2(engine._h, C.cast(cb, _vp), len(cram), C.cast(arrw, _vp), len(wrong), out.ctypes.data, len(out), C.byref(total), C.byref(n), 1, None)
         assert rci == 0, (f["file"], rci)
         md5_refused += int(rcw != 0)
     assert nrec == 230
