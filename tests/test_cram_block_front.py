@@ -85,3 +85,33 @@ def test_c_driver_reports_corrupt_blocks_like_the_reference(driver, engine, tmp_
     for i, b in enumerate(bl):
         rc, n = struct.unpack_from("<ii", raw, pos); pos += 8 + n
         assert rc == (-1 if i % 5 == 0 else 0) and n == (0 if i % 5 == 0 else b["usize"])
+
+
+@pytest.fixture(scope="module")
+def slice_driver(built, tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("cramsl") / "cram_slice_c")
+    lib = os.path.join(ROOT, "htslib_amd")
+    subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(NAT, "cram_slice_c.c"),
+                    "-o", exe, "-L", lib, "-lhts_bgzf", "-lhtsgpu", "-lpthread", "-Wl,-rpath," + lib], check=True)
+    return exe
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level,major,use_fqz,use_arith", [(5, 3, 0, 0), (7, 3, 1, 1), (1, 3, 0, 0), (5, 2, 0, 0)])
+def test_c_driver_compress_slice_in_one_batch(slice_driver, engine, level, major, use_fqz, use_arith):
+    """hg_cram_compress_slice_fqz = cram_compress_slice (cram/cram_encode.c:803-988) for one slice: every block decodes back to its bytes with
+    cram_uncompress_block, every chosen method belongs to the set hg_cram_slice_plan offers that series (or methodF of the final sweep), the
+    metrics objects carry over five slices (trial phase, then the learnt method); with use_fqz the quality block may come out as method 7"""
+    r = subprocess.run([slice_driver, str(level), str(major), str(use_fqz), str(use_arith), "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-800:]
+    assert "undecodable 0" in r.stdout and "methods_offered_ok" in r.stdout
+    rows = [l.split() for l in r.stdout.splitlines() if l.startswith("slice")]
+    assert len(rows) == 5 * 8
+    methods = {(int(x[3]), int(x[5])) for x in rows}                     # (ds, on-disk method)
+    qs = {m for ds, m in methods if ds == 12}
+    assert all(int(x[9]) <= int(x[7]) for x in rows)                      # nothing grows (RAW is kept when nothing beats it)
+    if major >= 3:
+        assert 8 in {m for ds, m in methods if ds == 11}                  # read names: the tokeniser
+        assert qs <= ({5, 7} if use_fqz else {5}) | ({6} if use_arith else set()) | {1, 4}
+    else:
+        assert not ({5, 6, 7, 8} & {m for _, m in methods})               # CRAM 2.x: gzip / rANS 4x8 only
