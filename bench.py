@@ -47,7 +47,7 @@ def _prep_chunk(args):
     """Worker: synthesise chunk `idx` and deflate it the way stock htslib (zlib, level 6) does."""
     seed, idx, nbytes, level, cache_dir = args
     from htslib_amd import synth
-    key = f"{GEN_VERSION}_{seed:x}_{idx}_{nbytes}_{level}"
+    key = f"{GEN_VERSION}{'' if synth.QUAL_VARIANT == 'A' else synth.QUAL_VARIANT}_{seed:x}_{idx}_{nbytes}_{level}"
     path = os.path.join(cache_dir, key + ".bgzf") if cache_dir else None
     if path and os.path.exists(path):
         with open(path, "rb") as f:
@@ -304,6 +304,40 @@ def stage(run: Run) -> Staged:
     return S
 
 
+def inflate_variant_b(run: Run, steps: int, gib: float = 2.0):
+    """SURVEY 8d variant B beside the headline: the same BAM generator with HiSeq-like 41-level qualities (ratio ~3.3 instead of ~5.5; many more
+    literals per byte).  GB/s flatters easy data, symbols/s is the unit to compare."""
+    import torch
+    from htslib_amd import synth, _native as nat
+    synth.QUAL_VARIANT = "B"
+    try:
+        cache = None if run.args.no_cache else os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "htsgpu_bench_cache")
+        comp = prepare(0x5EED0B01, int(gib * (1 << 30)), run.args.level, run.workers, cache)
+        plain0, _, _ = synth.bam_stream(min(CHUNK, int(gib * (1 << 30))), 0x5EED0B01, 0, True)
+    finally:
+        synth.QUAL_VARIANT = "A"
+    eng = nat.Engine(run.local)
+    desc, total_u = nat.bgzf_scan(comp)
+    d_comp = torch.zeros(len(comp) + 512, dtype=torch.uint8, device=run.dev)
+    d_comp[:len(comp)].copy_(torch.frombuffer(bytearray(comp), dtype=torch.uint8))
+    d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(run.dev)
+    d_out = torch.empty(int(total_u) + 256, dtype=torch.uint8, device=run.dev)
+    d_status = torch.full((len(desc),), 77, dtype=torch.int32, device=run.dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.bgzf_inflate_dev(d_comp.data_ptr(), len(comp), d_desc.data_ptr(), len(desc), d_out.data_ptr(), int(total_u), d_status.data_ptr(), stream)
+
+    elapsed, k_ms = run.timed(step, steps, 1)
+    ok = int((d_status != 0).sum()) == 0 and d_out[:len(plain0)].cpu().numpy().tobytes() == plain0
+    spb, litfrac = symbols_per_byte(comp, desc)
+    gbs = total_u * steps / elapsed / 1e9
+    return {"metric": "BGZF inflate, variant B (41-level qualities), uncompressed GB/s", "value": round(gbs, 3), "unit": "GB/s", "steps": steps, "ms_per_step": round(elapsed * 1e3 / steps, 3),
+            "ratio": round(total_u / len(comp), 3), "plain_bytes": int(total_u), "symbols_per_plain_byte": None if spb is None else round(spb, 4),
+            "literal_fraction_of_symbols": None if litfrac is None else round(litfrac, 3), "Gsymbols_per_s": None if spb is None else round(gbs * spb, 2),
+            "roofline_frac": round((total_u + len(comp)) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "kernel_ms": round(k_ms, 3), "verified": bool(ok)}
+
+
 def op_inflate(run: Run, S: Staged, steps: int, warmup: int):
     import torch
     from htslib_amd import synth
@@ -400,6 +434,81 @@ def _rans_cpu_worker(task):
     return done, time.perf_counter() - t                       # the worker times its own loop (pool start-up excluded)
 
 
+def _cram_cpu_worker(task):
+    """cpu_baseline worker for the CRAM block codecs: the oracle's scalar C restatements (NOT reference code) on a share of blocks.  mode "dec": each
+    (method, stream, plaintext) is decoded; "enc": each plaintext is encoded with the codec family that won on the GPU (one call = the tuner's steady state)."""
+    import ctypes as C, zlib
+    blocks, mode, seconds = task
+    orc = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    sz = C.c_size_t
+    for f in ("orc_ransnx16_uncompress", "orc_rans4x8_uncompress", "orc_tok3_decode"):
+        getattr(orc, f).argtypes = [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(sz)]
+    orc.orc_arith_uncompress.argtypes = [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(sz), C.c_long]
+    for f in ("orc_ransnx16_compress", "orc_arith_compress", "orc_tok3_encode"):
+        getattr(orc, f).restype = sz; getattr(orc, f).argtypes = [C.c_char_p, sz, C.c_char_p, C.c_int]
+    orc.orc_rans4x8_compress.restype = sz; orc.orc_rans4x8_compress.argtypes = [C.c_char_p, sz, C.c_char_p, C.c_int]
+    cap = max(len(b[2]) for b in blocks) * 2 + (1 << 20)
+    buf = C.create_string_buffer(cap); got = sz(0)
+    done = 0
+    t = time.perf_counter()
+    while time.perf_counter() - t < seconds:
+        for meth, comp, plain in blocks:
+            if mode == "dec":
+                if meth == 0: pass
+                elif meth == 1: zlib.decompress(comp, 31)
+                elif meth == 4: orc.orc_rans4x8_uncompress(comp, len(comp), buf, cap, C.byref(got))
+                elif meth == 5: orc.orc_ransnx16_uncompress(comp, len(comp), buf, cap, C.byref(got))
+                elif meth == 6: orc.orc_arith_uncompress(comp, len(comp), buf, cap, C.byref(got), -1)
+                elif meth == 8: orc.orc_tok3_decode(comp, len(comp), buf, cap, C.byref(got))
+            else:
+                if meth == 1: zlib.compress(plain, 5)
+                elif meth == 4: orc.orc_rans4x8_compress(plain, len(plain), buf, comp[0] & 1)
+                elif meth == 5: orc.orc_ransnx16_compress(plain, len(plain), buf, comp[0])
+                elif meth == 6: orc.orc_arith_compress(plain, len(plain), buf, comp[0])
+                elif meth == 8: orc.orc_tok3_encode(plain, len(plain), buf, comp[8] if len(comp) > 8 else 0)
+            done += len(plain)
+    return done, time.perf_counter() - t
+
+
+def cpu_baseline_cram(sample, nproc, mode, seconds=8.0):
+    with mp.get_context("fork").Pool(nproc) as pool:
+        parts = pool.map(_cram_cpu_worker, [(sample, mode, seconds)] * nproc)
+    return {"value": round(sum(d / t for d, t in parts) / 1e9, 3), "unit": "GB/s", "cores": nproc, "kind": "port",
+            "sample": "NOT reference code (htscodecs is absent): the oracle's scalar C codecs (oracle/*_oracle.c; zlib for method 1) %s the blocks of four of the same slices "
+                      "in a loop for %.0f s on %d processes" % ("decoding" if mode == "dec" else "encoding (each block with the codec and flags that won on the GPU)", seconds, nproc)}
+
+
+def _rans_variants(eng, qs_list, steps):
+    """SURVEY 8d's matrix for the Nx16 codec: 4-way and 32-way x order 0 / 1 x +-PACK x +-RLE, each on the same quality series (4 symbols, runs: both
+    transforms apply), encoded by the gfx950 encoder and decoded through hg_ransnx16_decode_host -- the HOST entry point, so these figures
+    include the PCIe transfers and the header planning on the host (the headline above is device-resident).  Every output is compared."""
+    import ctypes as C
+    from htslib_amd import _native as nat
+    out = {}
+    n = len(qs_list)
+    total = sum(len(q) for q in qs_list)
+    for x32 in (0, 4):
+        for order in (0, 1):
+            for xf, tag in ((0, ""), (0x80, "+PACK"), (0x40, "+RLE"), (0xC0, "+PACK+RLE")):
+                fl = x32 | order | xf
+                streams = eng.ransnx16_encode_host(qs_list, [fl] * n)
+                ins = [(C.c_char * len(s_)).from_buffer_copy(s_) for s_ in streams]
+                outs = [C.create_string_buffer(len(q)) for q in qs_list]
+                ip = (C.c_void_p * n)(*[C.addressof(x) for x in ins]); opp = (C.c_void_p * n)(*[C.addressof(x) for x in outs])
+                il = np.array([len(s_) for s_ in streams], np.uint32); ol = np.array([len(q) for q in qs_list], np.uint32); st = np.zeros(n, np.int32)
+                ts = []
+                for _ in range(steps + 1):
+                    t = time.perf_counter()
+                    rc = nat.lib.hg_ransnx16_decode_host(eng._h, ip, il.ctypes.data, n, opp, ol.ctypes.data, st.ctypes.data)
+                    ts.append(time.perf_counter() - t)
+                good = rc == 0 and not st.any() and all(outs[i].raw == qs_list[i] for i in range(n))
+                out["%s o%d%s" % ("32-way" if x32 else "4-way", order, tag)] = {
+                    "GBps_host_api": round(total / sorted(ts[1:])[len(ts[1:]) // 2] / 1e9, 3), "ratio": round(float(il.sum()) / total, 4), "flags_written": [hex(s_[0]) for s_ in streams[:1]][0],
+                    "verified": bool(good)}
+    return {"note": "host entry point incl. PCIe + host planning, %d quality series of 1.5 MB each, median of %d; decode of streams written by the gfx950 encoder (format parity with htscodecs UNPINNED)" % (n, steps),
+            "results": out}
+
+
 def op_rans(run: Run, steps: int, warmup: int, slices: int):
     """BASELINE configs[3]: CRAM 3.1 rANS Nx16 decode (order-1 32-way QS + order-0 32-way BA) of `slices` x 10 000 reads per
     GPU.  The streams are produced by the gfx950 ENCODER (htscodecs is absent: format parity UNPINNED); the timed region is
@@ -449,9 +558,14 @@ def op_rans(run: Run, steps: int, warmup: int, slices: int):
 
     elapsed, k_ms = run.timed(step, steps, warmup)
     ok = int((d_status != 0).sum()) == 0
-    host_out = d_out.cpu().numpy()
-    for i in (0, 1, n - 2, n - 1):
-        ok = ok and host_out[int(desc["out_off"][i]):int(desc["out_off"][i]) + int(out_len[i])].tobytes() == plains[i]
+    # EVERY stream is compared, on the device (rANS has no checksum: status 0 alone proves little): the plaintexts laid out like the output image
+    expect = bytearray(int(d_out.numel()))
+    for d, p_ in zip(desc, plains):
+        expect[int(d["out_off"]):int(d["out_off"]) + len(p_)] = p_
+    d_expect = torch.frombuffer(expect, dtype=torch.uint8).to(run.dev)
+    ok = ok and bool(torch.equal(d_out, d_expect))
+    del d_expect
+    variants = _rans_variants(eng, [qs for qs, _ in series[:24]], max(3, min(steps, 5))) if run.rank == 0 and run.world == 1 and not getattr(run.args, "no_variants", False) else None
     elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(total_u), float(total_c), ok, run.world, run.dev)
     if run.rank != 0:
         return None, ok
@@ -463,7 +577,8 @@ def op_rans(run: Run, steps: int, warmup: int, slices: int):
            "config": {"workload": f"rANS Nx16 decode of {slices} CRAM slices x 10 000 x 150 bp per GPU: QS (order-1, 32-way) "
                                   "+ BA (order-0, 32-way) data series; streams written by the gfx950 encoder; format parity "
                                   "with htscodecs UNPINNED", "streams_per_gpu": n, "plain_bytes_per_gpu": total_u,
-                      "compressed_bytes_per_gpu": total_c, "verified": bool(ok), "prep_seconds": round(t_prep, 1)},
+                      "compressed_bytes_per_gpu": total_c, "verified": bool(ok), "verified_streams": n, "prep_seconds": round(t_prep, 1),
+                      "variants": variants},
            "roofline": {"bound": "hbm", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                         "traffic": hbm_traffic_file("hbm_traffic_rans.json", ["traffic_bytes_per_plain_byte"], total_u),
@@ -492,7 +607,7 @@ def op_cram(run: Run, steps: int, slices: int):
     import bench_cram_slices
     if run.dist is not None:
         run.dist.barrier()
-    r = bench_cram_slices.main(slices, device=run.local, reps=max(2, steps), quiet=True)
+    r = bench_cram_slices.main(slices, device=run.local, reps=max(5, steps), quiet=True)
     from htslib_amd.bgzf import reduce_timing
     enc_s, sum_u, sum_c, ok = reduce_timing(r["encode_s"], float(r["plain_bytes"]), float(r["comp_bytes"]), True, run.world, run.dev)
     dec_s, _, _, _ = reduce_timing(r["decode_s"], float(r["plain_bytes"]), float(r["comp_bytes"]), True, run.world, run.dev)
@@ -502,10 +617,10 @@ def op_cram(run: Run, steps: int, slices: int):
     alg_enc = 2.0 * r["plain_bytes"] + r["comp_bytes"]
     alg_dec = float(r["plain_bytes"] + r["comp_bytes"])
     return {"metric": "CRAM 3.1 slice encode throughput through the block-method auto-tuner, plain GB/s (host entry points, PCIe included)",
-            "value": round(sum_u / enc_s / 1e9, 3), "unit": "GB/s", "n_gpus": run.world, "steps": max(2, steps), "warmup": 1,
+            "value": round(sum_u / enc_s / 1e9, 3), "unit": "GB/s", "n_gpus": run.world, "steps": max(5, steps), "warmup": 1,
             "ms_per_step": round(enc_s * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%d slices x 10 000 reads per GPU, series QS BA RN AP BF TS MQ NP; best steady call" % slices,
+            "config": {"workload": "%d slices x 10 000 reads per GPU, series QS BA RN AP BF TS MQ NP; median of the steady calls" % slices,
                        "blocks_per_gpu": r["blocks"], "plain_bytes_per_gpu": r["plain_bytes"], "ratio": round(r["comp_bytes"] / r["plain_bytes"], 4),
                        "decode_GBps": round(sum_u / dec_s / 1e9, 3), "on_disk_methods": r["methods"], "verified": True,
                        "format_parity": "rANS Nx16 / range coder / tok3 UNPINNED against htscodecs"},
@@ -514,7 +629,8 @@ def op_cram(run: Run, steps: int, slices: int):
                          "kernel": "whole call (several kernels + PCIe): hge::ransnx16_encode_kernel dominates (profiles/)",
                          "kernel_ms": round(r["encode_s"] * 1e3, 2), "algorithmic_bytes_per_launch": int(alg_enc),
                          "decode_achieved": round(alg_dec / r["decode_s"] / 1e9, 3)},
-            "cpu_baseline": None}, ok
+            "cpu_baseline": None if run.world != 1 or run.args.no_cpu_baseline else cpu_baseline_cram(r["sample"], max(1, min(run.ncores - 2, 64)), "enc"),
+            "cpu_baseline_decode": None if run.world != 1 or run.args.no_cpu_baseline else cpu_baseline_cram(r["sample"], max(1, min(run.ncores - 2, 64)), "dec")}, ok
 
 def bench_bam(args, eng, comp, desc, total_u, d_comp, d_desc, d_plain, d_status, dev, rank, world, seed):
     """frame every record of the inflated BAM (bam_read1's framing + checks) and decode all bases
@@ -941,16 +1057,44 @@ def op_fqz(run: Run, steps: int, streams: int = 512):
     datas = [quals[i % 4] for i in range(streams)]
     args = (datas, [lens[i % 4] for i in range(streams)], [None] * streams, [i % 4 for i in range(streams)])
     te, td, enc = [], [], None
-    for _ in range(max(2, steps)):
+    steps = max(5, steps)
+    for _ in range(steps + 1):
         t = time.perf_counter(); enc = eng.fqz_encode_host(*args); te.append(time.perf_counter() - t)
         blocks = [(7, e, len(d)) for e, d in zip(enc, datas)]
         t = time.perf_counter(); outs, st = eng.cram_uncompress_blocks(blocks); td.append(time.perf_counter() - t)
-    assert (st == 0).all() and outs[0] == datas[0] and outs[-1] == datas[-1]
-    nb = sum(map(len, datas))
-    return {"metric": "fqzcomp (CRAM method 7) decode, plain GB/s through the host entry points (PCIe included)", "value": round(nb / min(td) / 1e9, 3), "unit": "GB/s",
-            "n_gpus": 1, "steps": max(2, steps), "warmup": 0, "ms_per_step": round(min(td) * 1e3, 2), "higher_is_better": True, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%d quality blocks of %d x %d bp; one adaptive chain per block" % (streams, nrec, rl), "encode_GBps": round(nb / min(te) / 1e9, 3),
-                       "ratio": round(sum(map(len, enc)) / nb, 4), "format_parity": "UNPINNED against htscodecs (oracle/fqzcomp_oracle.c)"}}
+    assert (st == 0).all() and all(o == d for o, d in zip(outs, datas))
+    nb = sum(map(len, datas)); nc = sum(map(len, enc))
+    med = lambda v: sorted(v[1:])[len(v[1:]) // 2]
+    out = {"metric": "fqzcomp (CRAM method 7) decode, plain GB/s through the host entry points (PCIe included)", "value": round(nb / med(td) / 1e9, 3), "unit": "GB/s",
+           "n_gpus": 1, "steps": steps, "warmup": 1, "ms_per_step": round(med(td) * 1e3, 2), "higher_is_better": True, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "%d quality blocks of %d x %d bp; one adaptive chain per block; medians" % (streams, nrec, rl), "encode_GBps": round(nb / med(te) / 1e9, 3),
+                      "ratio": round(nc / nb, 4), "verified_blocks": len(datas), "format_parity": "UNPINNED against htscodecs (oracle/fqzcomp_oracle.c)"},
+           "roofline": {"bound": "hbm", "achieved": round((nb + nc) / med(td) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((nb + nc) / med(td) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                        "kernel": "whole decode call (hgq::fqz_decode_kernel dominates: profiles/r02_fqz_kernel_stats.csv); the path is one dependent chain per block, not bandwidth",
+                        "algorithmic_bytes": int(nb + nc)}}
+    if not run.args.no_cpu_baseline:
+        nproc = max(1, min(run.ncores - 2, 64))
+        with mp.get_context("fork").Pool(nproc) as pool:
+            parts = pool.map(_fqz_cpu_worker, [([(enc[i], datas[i], nrec) for i in range(4)], 8.0)] * nproc)
+        out["cpu_baseline"] = {"value": round(sum(d / t for d, t in parts) / 1e9, 3), "unit": "GB/s", "cores": nproc, "kind": "port",
+                               "sample": "NOT reference code (htscodecs is absent): oracle/fqzcomp_oracle.c decoding four of the same blocks in a loop for 8 s on %d processes" % nproc}
+    return out
+
+
+def _fqz_cpu_worker(task):
+    import ctypes as C
+    blocks, seconds = task
+    orc = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    sz = C.c_size_t
+    orc.orc_fqz_decode.argtypes = [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(sz), C.c_void_p, sz, C.POINTER(sz)]
+    cap = max(len(b[1]) for b in blocks) + 4096
+    buf = C.create_string_buffer(cap); got = sz(0); lens = (C.c_uint32 * (max(b[2] for b in blocks) + 16))()
+    done = 0
+    t = time.perf_counter()
+    while time.perf_counter() - t < seconds:
+        for comp, plain, nrec in blocks:
+            nr = sz(0); orc.orc_fqz_decode(comp, len(comp), buf, cap, C.byref(got), lens, len(lens), C.byref(nr)); done += len(plain)
+    return done, time.perf_counter() - t
 
 
 
@@ -969,7 +1113,7 @@ def main():
     ap.add_argument("--slices", type=int, default=0, help="CRAM slices of 10 000 reads (rans: default 1000 = 10 M reads; cram: default 256)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="strong: ONE data set split over the ranks by shard_blocks (inflate only)")
-    ap.add_argument("--extra-steps", type=int, default=3, help="timed steps of the `extra` ops in --op all")
+    ap.add_argument("--extra-steps", type=int, default=5, help="timed steps of the `extra` ops in --op all")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -1007,6 +1151,11 @@ def main():
                 del S
                 import torch
                 torch.cuda.empty_cache()
+                if run.world == 1:
+                    try:
+                        extra["bgzf_inflate_variant_B"] = inflate_variant_b(run, es)
+                    except Exception as e:
+                        extra["bgzf_inflate_variant_B"] = {"error": repr(e)}
                 d, ok2 = op_rans(run, es, 1, args.slices or 1000); ok = ok and ok2
                 if d: extra["cram_rans_nx16_decode"] = d
                 d, ok2 = op_cram(run, es, 256 if not args.slices else args.slices); ok = ok and ok2

@@ -302,6 +302,7 @@ void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
                 HG_TRACE(1, 50 + st);
                 if (st == ST_OK && made != ulen) st = ST_SIZE;
                 if (st == ST_OK && tr[1] != ulen) st = ST_SIZE;
+#ifndef HG_AB_NO_CRC_PASS        /* measurement variant only (scripts/pmc_ab_crc.sh): how much of the FETCH_SIZE counter is the CRC pass re-reading the output */
                 if (st == ST_OK) {
                     HG_TRACE(11, 1);
                     HG_T0(tcrc);
@@ -310,6 +311,7 @@ void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
                     HG_TRACE(11, 2);
                     if (uni(crc) != tr[0]) st = ST_CRC;
                 }
+#endif
             }
         }
         HG_TRACE(1, 90 + st);
