@@ -525,6 +525,61 @@ int hg_cram_compress_slice_fqz(const hg_cram_slice_opts *o, const hg_cram_opts *
     return 0;
 }
 
+// ---- the reference's entry points by name, over the real cram_fd / cram_slice of htslib 1.23 (fields read through the offsets of
+//      hts_cram_gpu.h, which the layout test asserts against cram/cram_structs.h) ----
+}  // extern "C" (helpers below have C++ linkage)
+namespace {
+template <class T> T field(const void *p, size_t off) { T v; memcpy(&v, (const char *)p + off, sizeof v); return v; }
+hg_cram_opts opts_of(cram_fd *fd) {
+    hg_cram_opts o; memset(&o, 0, sizeof o);
+    o.level = field<int>(fd, HG_CRAM_FD_LEVEL); o.version = field<int>(fd, HG_CRAM_FD_VERSION);
+    o.use_bz2 = field<int>(fd, HG_CRAM_FD_USE_BZ2); o.use_lzma = field<int>(fd, HG_CRAM_FD_USE_LZMA);
+    o.metrics_lock = (char *)fd + HG_CRAM_FD_METRICS_LOCK;
+    return o;
+}
+}  // namespace
+extern "C" {
+size_t hg_cram_fd_layout(size_t *o) {
+    const size_t v[] = {HG_CRAM_FD_FP, HG_CRAM_FD_VERSION, HG_CRAM_FD_LEVEL, HG_CRAM_FD_IGNORE_MD5, HG_CRAM_FD_USE_BZ2, HG_CRAM_FD_USE_LZMA, HG_CRAM_FD_METRICS_LOCK, HG_CRAM_SLICE_HDR,
+                        HG_CRAM_SLICE_BLOCK, HG_CRAM_SLICE_CRECS, HG_CRAM_SLICE_HDR_NUM_RECORDS, HG_CRAM_RECORD_SIZE, HG_CRAM_RECORD_FLAGS, HG_CRAM_RECORD_QUAL, HG_CRAM_DS_QS};
+    for (size_t i = 0; i < sizeof v / sizeof v[0]; i++) o[i] = v[i];
+    return sizeof v / sizeof v[0];
+}
+int cram_compress_block2(cram_fd *fd, cram_slice *s, cram_block *b, cram_metrics *metrics, int method, int level) {
+    if (!fd || !b) return -1;
+    const hg_cram_opts o = opts_of(fd);
+    // the slice only matters for the FQZ methods: per-record quality lengths and flags, gathered as cram_io.c:1808-1820 does
+    std::vector<uint32_t> len, flags;
+    hg_fqz_slice fq; const hg_fqz_slice *fqp = nullptr;
+    const unsigned fqz_bits = 1u << FQZ | 1u << FQZ_b | 1u << FQZ_c | 1u << FQZ_d;
+    if (s && method != -1 && ((unsigned)method & fqz_bits)) {
+        const char *hdr = field<const char *>(s, HG_CRAM_SLICE_HDR);
+        const char *crecs = field<const char *>(s, HG_CRAM_SLICE_CRECS);
+        cram_block *const *blocks = field<cram_block *const *>(s, HG_CRAM_SLICE_BLOCK);
+        const int32_t n = hdr ? field<int32_t>(hdr, HG_CRAM_SLICE_HDR_NUM_RECORDS) : 0;
+        if (hdr && crecs && blocks && blocks[HG_CRAM_DS_QS] && n > 0) {
+            len.resize((size_t)n); flags.resize((size_t)n);
+            for (int32_t i = 0; i < n; i++) {
+                const char *r = crecs + (size_t)i * HG_CRAM_RECORD_SIZE;
+                flags[(size_t)i] = (uint32_t)field<int32_t>(r, HG_CRAM_RECORD_FLAGS);
+                const int32_t q = field<int32_t>(r, HG_CRAM_RECORD_QUAL);
+                len[(size_t)i] = (uint32_t)(i + 1 < n ? field<int32_t>(r + HG_CRAM_RECORD_SIZE, HG_CRAM_RECORD_QUAL) - q : blocks[HG_CRAM_DS_QS]->uncomp_size - q);
+            }
+            fq.num_records = (uint32_t)n; fq.len = len.data(); fq.flags = flags.data(); fqp = &fq;
+        }
+    }
+    return hg_cram_compress_block_fqz(&o, fqp, b, metrics, method, level);
+}
+int cram_compress_block(cram_fd *fd, cram_block *b, cram_metrics *metrics, int method, int level) { return cram_compress_block2(fd, nullptr, b, metrics, method, level); }
+cram_block *cram_read_block(cram_fd *fd) {
+    if (!fd) return nullptr;
+    return hg_cram_read_block(field<hFILE *>(fd, HG_CRAM_FD_FP), field<int>(fd, HG_CRAM_FD_VERSION) >> 8, field<int>(fd, HG_CRAM_FD_IGNORE_MD5));
+}
+int cram_write_block(cram_fd *fd, cram_block *b) {
+    if (!fd || !b) return -1;
+    return hg_cram_write_block(field<hFILE *>(fd, HG_CRAM_FD_FP), field<int>(fd, HG_CRAM_FD_VERSION) >> 8, b);
+}
+
 uint32_t cram_block_size(cram_block *b) {
     uint8_t tmp[32];
     size_t n = 2;

@@ -166,6 +166,24 @@ int hg_cram_compress_slice_fqz(const hg_cram_slice_opts *o, const hg_cram_opts *
  * CRC-32 (v3+).  read: b->crc_part = CRC of the header bytes, crc32_checked = ignore_crc. */
 cram_block *hg_cram_read_block(struct hFILE *fp, int major_version, int ignore_crc);
 int hg_cram_write_block(struct hFILE *fp, int major_version, cram_block *b);
+
+/* ---- The reference's own entry points, by name (cram/cram_io.c:2316-2325, 1414, 1511; htslib.map:149) -- for callers that hold a real
+ * `cram_fd *` / `cram_slice *` of htslib 1.23 (LP64).  Those structs are large and private; the functions below read exactly these
+ * fields through the byte offsets listed here (tests/native/cram_layout_*.c assert every one of them against the reference's
+ * cram/cram_structs.h with offsetof):
+ *   cram_fd:    fp (hFILE *), version, level, ignore_md5, use_bz2, use_lzma, metrics_lock
+ *   cram_slice: hdr -> num_records, block[DS_QS], crecs[i].flags / .qual   (only for the FQZ methods, as cram_io.c:1808-1820)
+ * A libhts built from another release must regenerate the offsets (the layout test prints them) or use the hg_* forms above. */
+typedef struct cram_fd cram_fd;
+typedef struct cram_slice cram_slice;
+enum { HG_CRAM_FD_FP = 0, HG_CRAM_FD_VERSION = 12, HG_CRAM_FD_LEVEL = 136, HG_CRAM_FD_IGNORE_MD5 = 556, HG_CRAM_FD_USE_BZ2 = 560, HG_CRAM_FD_USE_LZMA = 568,
+       HG_CRAM_FD_METRICS_LOCK = 35016, HG_CRAM_SLICE_HDR = 0, HG_CRAM_SLICE_BLOCK = 16, HG_CRAM_SLICE_CRECS = 48, HG_CRAM_SLICE_HDR_NUM_RECORDS = 24,
+       HG_CRAM_RECORD_SIZE = 144, HG_CRAM_RECORD_FLAGS = 12, HG_CRAM_RECORD_QUAL = 104, HG_CRAM_DS_QS = 12 };
+int cram_compress_block(cram_fd *fd, cram_block *b, cram_metrics *metrics, int method, int level);
+int cram_compress_block2(cram_fd *fd, cram_slice *s, cram_block *b, cram_metrics *metrics, int method, int level);
+cram_block *cram_read_block(cram_fd *fd);
+int cram_write_block(cram_fd *fd, cram_block *b);
+size_t hg_cram_fd_layout(size_t *offsets);            /* the offsets above in that order (for the layout test) */
 uint32_t cram_block_size(cram_block *b);                                   /* cram_io.c:1490-1505 */
 
 /* ---- CRAM 4.0 E_XPACK / E_XRLE transforms: the htscodecs functions cram_codecs.c calls (cram/cram_codecs.c:1399, 1520,

@@ -16,5 +16,8 @@ size_t our_layout(size_t *o) {
     o[n++] = RAW; o[n++] = GZIP; o[n++] = RANS; o[n++] = RANSPR; o[n++] = ARITH; o[n++] = FQZ; o[n++] = TOK3; o[n++] = GZIP_RLE; o[n++] = GZIP_1; o[n++] = FQZ_d;
     o[n++] = RANS1; o[n++] = RANS_PR1; o[n++] = RANS_PR193; o[n++] = TOKA; o[n++] = ARITH_PR1; o[n++] = ARITH_PR193;
     o[n++] = EXTERNAL; o[n++] = CORE; o[n++] = CRAM_MAX_METHOD;
+    o[n++] = HG_CRAM_FD_FP; o[n++] = HG_CRAM_FD_VERSION; o[n++] = HG_CRAM_FD_LEVEL; o[n++] = HG_CRAM_FD_IGNORE_MD5; o[n++] = HG_CRAM_FD_USE_BZ2; o[n++] = HG_CRAM_FD_USE_LZMA;
+    o[n++] = HG_CRAM_FD_METRICS_LOCK; o[n++] = HG_CRAM_SLICE_HDR; o[n++] = HG_CRAM_SLICE_BLOCK; o[n++] = HG_CRAM_SLICE_CRECS; o[n++] = HG_CRAM_SLICE_HDR_NUM_RECORDS;
+    o[n++] = HG_CRAM_RECORD_SIZE; o[n++] = HG_CRAM_RECORD_FLAGS; o[n++] = HG_CRAM_RECORD_QUAL; o[n++] = HG_CRAM_DS_QS;
     return n;
 }

@@ -16,5 +16,10 @@ size_t ref_layout(size_t *o) {
     o[n++] = RAW; o[n++] = GZIP; o[n++] = RANS; o[n++] = RANSPR; o[n++] = ARITH; o[n++] = FQZ; o[n++] = TOK3; o[n++] = GZIP_RLE; o[n++] = GZIP_1; o[n++] = FQZ_d;
     o[n++] = RANS1; o[n++] = RANS_PR1; o[n++] = RANS_PR193; o[n++] = TOKA; o[n++] = ARITH_PR1; o[n++] = ARITH_PR193;
     o[n++] = EXTERNAL; o[n++] = CORE; o[n++] = CRAM_MAX_METHOD;
+    /* cram_fd / cram_slice / cram_record fields the reference-named exports read (hts_cram_gpu.h: HG_CRAM_FD_* ...) */
+    o[n++] = offsetof(cram_fd, fp); o[n++] = offsetof(cram_fd, version); o[n++] = offsetof(cram_fd, level); o[n++] = offsetof(cram_fd, ignore_md5);
+    o[n++] = offsetof(cram_fd, use_bz2); o[n++] = offsetof(cram_fd, use_lzma); o[n++] = offsetof(cram_fd, metrics_lock);
+    o[n++] = offsetof(cram_slice, hdr); o[n++] = offsetof(cram_slice, block); o[n++] = offsetof(cram_slice, crecs); o[n++] = offsetof(cram_block_slice_hdr, num_records);
+    o[n++] = sizeof(cram_record); o[n++] = offsetof(cram_record, flags); o[n++] = offsetof(cram_record, qual); o[n++] = DS_QS;
     return n;
 }

@@ -91,6 +91,7 @@ int main(int argc, char **argv) {
             const int method = b->method, csz = b->comp_size;
             if (!set_allows(chk[k].set, method)) { offered_ok = 0; fprintf(stderr, "ds %d: method %d not in set %x\n", chk[k].ds, method, chk[k].set); }
             printf("slice %d ds %d method %d size %d -> %d\n", sl, chk[k].ds, method, chk[k].n, csz);
+            b->crc32_checked = 1;                                            /* not read from a file: no stored CRC to check (cram_io.c:1585-1592) */
             if (cram_uncompress_block(b) != 0 || b->uncomp_size != chk[k].n || memcmp(b->data, chk[k].copy, chk[k].n) != 0) { bad++; fprintf(stderr, "ds %d: does not decode back\n", chk[k].ds); }
             free(chk[k].copy); cram_free_block(b);
         }

@@ -115,3 +115,17 @@ def test_c_driver_compress_slice_in_one_batch(slice_driver, engine, level, major
         assert qs <= ({5, 7} if use_fqz else {5}) | ({6} if use_arith else set()) | {1, 4}
     else:
         assert not ({5, 6, 7, 8} & {m for _, m in methods})               # CRAM 2.x: gzip / rANS 4x8 only
+
+
+@pytest.mark.gpu
+def test_reference_named_entry_points_on_a_real_cram_fd(engine, tmp_path):
+    """cram_compress_block / cram_compress_block2 / cram_write_block / cram_read_block / cram_uncompress_block by their reference names on the
+    reference's REAL struct cram_fd and cram_slice: tests/native/cram_fd_driver.c is compiled against /root/reference's headers (oracle/Makefile,
+    where the reference is present) and linked to our library; the offsets it relies on are asserted by test_struct_layout_equals_reference_headers."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "cram_fd_driver")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/cram_fd_driver not built (needs the reference headers at build time)")
+    r = subprocess.run([exe, str(tmp_path / "blocks.cram")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "cram_fd entry points ok" in r.stdout, r.stderr[-1500:] + r.stdout[-500:]
+    meth = [int(x) for x in r.stdout.split()[1:4]]
+    assert meth[1] in (5, 7) and meth[2] == 8, meth                      # qualities: rANS Nx16 or fqzcomp; names: the tokeniser
