@@ -1132,13 +1132,34 @@ int bgzf_compress(void *dst, size_t *dlen, const void *src, size_t slen, int lev
     return 0;
 }
 
+// Short buffers (the 10-30 byte block headers cram_read_block / cram_write_block checksum, cram_io.c:1431-1470, 1547-1552) are not worth a
+// device round trip, and a process without a usable GPU must still get a CORRECT checksum rather than die: a byte-wise table CRC on the
+// host for buffers below HOST_CRC_MAX and whenever the engine is unavailable; everything else on the device (hg_crc32_host).
+static uint32_t crc32_table_host(uint32_t crc, const uint8_t *p, size_t n) {
+    static uint32_t T[8][256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u))); T[0][i] = c; }
+        for (uint32_t i = 0; i < 256; i++) for (int k = 1; k < 8; k++) T[k][i] = (T[k - 1][i] >> 8) ^ T[0][T[k - 1][i] & 0xff];
+    });
+    uint32_t c = ~crc;
+    for (; n >= 8; n -= 8, p += 8) {
+        const uint32_t a = c ^ ((uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24);
+        c = T[7][a & 0xff] ^ T[6][(a >> 8) & 0xff] ^ T[5][(a >> 16) & 0xff] ^ T[4][a >> 24] ^ T[3][p[4]] ^ T[2][p[5]] ^ T[1][p[6]] ^ T[0][p[7]];
+    }
+    for (; n; n--, p++) c = T[0][(c ^ *p) & 0xff] ^ (c >> 8);
+    return ~c;
+}
 uint32_t hts_crc32(uint32_t crc, const void *buf, size_t len) {
     if (len == 0) return crc;
+    constexpr size_t HOST_CRC_MAX = 4096;
+    if (len < HOST_CRC_MAX) return crc32_table_host(crc, (const uint8_t *)buf, len);
     hg_ctx *ctx = shared_ctx();
     uint32_t c = 0;
     if (!ctx || hg_crc32_host(ctx, buf, len, &c) != HG_OK) {
-        logmsg(LOG_ERROR, "hts_crc32", "no usable GPU engine");
-        abort();                                                             // no silent wrong checksum, no CPU fallback
+        static std::once_flag warned;
+        std::call_once(warned, [] { logmsg(LOG_WARNING, "hts_crc32", "no usable GPU engine: checksums are computed on the host"); });
+        return crc32_table_host(crc, (const uint8_t *)buf, len);
     }
     return crc_concat(crc, c, len);
 }

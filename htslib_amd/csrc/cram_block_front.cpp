@@ -225,7 +225,7 @@ void compress_batch(CompJob *jobs, int n) {
         j.rc = 0;
         cram_block *x = j.b;
         if (!x || x->method != RAW) continue;                                  // already compressed (cram_io.c:1945-1952)
-        if (j.method == -1) j.method = 1 << GZIP;                             // bz2 / lzma are never offered
+        if (j.method == -1) j.method = 1 << GZIP | (j.opts && j.opts->use_bz2 ? 1 << BZIP2 : 0) | (j.opts && j.opts->use_lzma ? 1 << LZMA : 0);   // cram_io.c:1954-1960
         if (j.level == -1) j.level = j.opts ? j.opts->level : 5;
         if (j.method == RAW || j.level == 0 || x->uncomp_size == 0) { x->method = RAW; x->comp_size = x->uncomp_size; continue; }
         todo.push_back(i);

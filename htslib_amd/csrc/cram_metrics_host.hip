@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
+#include <dlfcn.h>
+#include <mutex>
 #include <vector>
 #include "htsgpu.h"
 #include "hg_internal.h"
@@ -42,6 +44,24 @@ struct Job { size_t blk; int m; };
 // reference's cram_compress_block3 driven by the same script.
 uint32_t (*g_size_script)(int method, size_t blk, uint32_t in_len) = nullptr;
 
+struct HostLibs {
+    int (*bz2)(char *, unsigned int *, char *, unsigned int, int, int, int) = nullptr;                                                      // BZ2_bzBuffToBuffCompress
+    int (*lzma_enc)(uint32_t, int, const void *, const uint8_t *, size_t, uint8_t *, size_t *, size_t) = nullptr;                           // lzma_easy_buffer_encode
+    size_t (*lzma_bound)(size_t) = nullptr;                                                                                                // lzma_stream_buffer_bound
+};
+const HostLibs &host_libs() {
+    static HostLibs H;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *n : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"}) if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) { H.bz2 = (decltype(H.bz2))dlsym(h, "BZ2_bzBuffToBuffCompress"); if (H.bz2) break; }
+        for (const char *n : {"liblzma.so.5", "liblzma.so"}) if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
+            H.lzma_enc = (decltype(H.lzma_enc))dlsym(h, "lzma_easy_buffer_encode"); H.lzma_bound = (decltype(H.lzma_bound))dlsym(h, "lzma_stream_buffer_bound");
+            if (H.lzma_enc && H.lzma_bound) break;
+        }
+    });
+    return H;
+}
+
 // Runs every (block, method) job.  Jobs are grouped by CODEC FAMILY, not by method id: the entry points take a
 // parameter per stream (order / flag byte / back-end), so e.g. all seven RANS_PR* trials of all blocks are ONE batched
 // GPU call.  res[j] = malloc'd payload (or null when the method is not available / failed), rlen[j] = its size.
@@ -54,6 +74,23 @@ int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t
             if (sz) { res[j] = (uint8_t *)calloc(sz, 1); rlen[j] = sz; }
         }
         return HG_OK;
+    }
+    // bzip2 / lzma (cram_io.c:1781-1832): the system's libraries, looked up at first use like the read side does (cram_block_front.cpp) -- the
+    // reference calls the very same functions when built with HAVE_LIBBZ2 / HAVE_LIBLZMA; absent libraries = the method fails, as there.
+    for (size_t j = 0; j < jobs.size(); j++) {
+        const int m = jobs[j].m;
+        if (m != HG_M_BZIP2 && m != HG_M_LZMA) continue;
+        const HostLibs &H = host_libs();
+        const size_t b = jobs[j].blk;
+        if (m == HG_M_BZIP2 && H.bz2) {
+            unsigned int cap = (unsigned int)(in_len[b] * 1.01 + 600);
+            char *p = (char *)malloc(cap);
+            if (p && H.bz2(p, &cap, (char *)in[b], in_len[b], level > 0 ? level : 5, 0, 30) == 0) { res[j] = (uint8_t *)p; rlen[j] = cap; } else free(p);
+        } else if (m == HG_M_LZMA && H.lzma_enc && H.lzma_bound) {
+            const size_t cap = H.lzma_bound(in_len[b]);
+            uint8_t *p = (uint8_t *)malloc(cap ? cap : 1); size_t pos = 0;
+            if (p && H.lzma_enc((uint32_t)(level > 0 ? level : 5), 1 /* LZMA_CHECK_CRC32 */, nullptr, in[b], in_len[b], p, &pos, cap) == 0) { res[j] = p; rlen[j] = (uint32_t)pos; } else free(p);
+        }
     }
     enum Fam { F_GZ = 0, F_GZ1, F_R4, F_NX, F_AR, F_TK, F_FQ, F_N };
     auto family = [](int m) -> int {
@@ -207,10 +244,12 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
             taken.push_back(i);
             if (!trial) { jobs.push_back({i, M->method}); b.j1 = jobs.size(); continue; }
             b.trial = true;
-            // like an htslib built without bz2 / lzma (fd->use_bz2 = 0): methods the engine does not have leave the set; fqzcomp
+            // bzip2 / lzma stay in the set when the system has the libraries (else like an htslib built without them: they leave it); fqzcomp
             // needs the slice's record lengths (cram_compress_by_method gets them from its cram_slice, cram_io.c:1808-1820)
             const uint32_t fqz_bits = (1u << HG_M_FQZ) | (1u << HG_M_FQZ_b) | (1u << HG_M_FQZ_c) | (1u << HG_M_FQZ_d);
-            const uint32_t have = ~((1u << HG_M_BZIP2) | (1u << HG_M_LZMA) | (fqz && fqz[i] ? 0u : fqz_bits) | (1u << 9) | (1u << 10));
+            uint32_t nolib = (1u << HG_M_BZIP2) | (1u << HG_M_LZMA);      // (the scripted test runs against a reference build without the libraries)
+            if (!g_size_script) { const HostLibs &HL = host_libs(); nolib = (HL.bz2 ? 0u : 1u << HG_M_BZIP2) | (HL.lzma_enc && HL.lzma_bound ? 0u : 1u << HG_M_LZMA); }
+            const uint32_t have = ~(nolib | (fqz && fqz[i] ? 0u : fqz_bits) | (1u << 9) | (1u << 10));
             uint32_t method = b.method & have;
             if (M->revised_method) method = M->revised_method & have; else M->revised_method = method;
             if (M->next_trial <= 0) {

@@ -99,7 +99,7 @@ int cram_uncompress_blocks(cram_block **b, int n, int *blk_rc);
 typedef struct hg_cram_opts {
     int level;            /* fd->level                                                              */
     int version;          /* fd->version (major << 8 | minor)                                       */
-    int use_bz2, use_lzma;/* accepted; those codecs are not offered (as in a build without the libs) */
+    int use_bz2, use_lzma;/* fd->use_bz2 / use_lzma: offered through the system's libbz2 / liblzma when present     */
     void *metrics_lock;   /* &fd->metrics_lock (pthread_mutex_t *) or NULL                          */
 } hg_cram_opts;
 

@@ -39,9 +39,9 @@ int main(int argc, char **argv) {
     if (argc != 6) return fail("usage");
     hg_cram_slice_opts so; memset(&so, 0, sizeof so);
     so.level = atoi(argv[1]); so.version = atoi(argv[2]) << 8 | (atoi(argv[2]) >= 3 ? 1 : 0); so.use_rans = 1; so.use_tok = atoi(argv[2]) >= 3;
-    so.use_fqz = atoi(argv[3]); so.use_arith = atoi(argv[4]);
+    so.use_fqz = atoi(argv[3]) & 1; so.use_arith = atoi(argv[4]); so.use_bz2 = so.use_lzma = (atoi(argv[3]) >> 1) & 1;     /* use_fqz argument: bit 1 = also bzip2 + lzma */
     const int nslices = atoi(argv[5]);
-    hg_cram_opts op; memset(&op, 0, sizeof op); op.level = so.level; op.version = so.version;
+    hg_cram_opts op; memset(&op, 0, sizeof op); op.level = so.level; op.version = so.version; op.use_bz2 = so.use_bz2; op.use_lzma = so.use_lzma;
     cram_metrics *metrics[HG_DS_END]; memset(metrics, 0, sizeof metrics);
     for (int i = 1; i < HG_DS_END; i++) metrics[i] = cram_new_metrics();
     cram_metrics *auxm[2] = {cram_new_metrics(), cram_new_metrics()};

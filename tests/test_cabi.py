@@ -83,3 +83,15 @@ def test_headers_are_plain_c99_and_link_from_c(built, tmp_path):
                     "-L", os.path.join(root, "htslib_amd"), "-lhtsgpu", "-lhts_bgzf", "-Wl,-rpath," + os.path.join(root, "htslib_amd")], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "htsgpu" in out.stdout, out.stderr
+
+
+def test_hts_crc32_is_correct_with_or_without_a_gpu(built):
+    """hts_crc32 (bgzf.c:557-559) of libhts_bgzf.so: short buffers (block headers) never leave the host, and a process without a usable engine
+    gets a correct checksum instead of an abort."""
+    import ctypes as C, random, zlib
+    L = C.CDLL(os.path.join(ROOT, "htslib_amd", "libhts_bgzf.so"))
+    L.hts_crc32.restype = C.c_uint32; L.hts_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]
+    rnd = random.Random(5)
+    for n in (0, 1, 7, 8, 9, 26, 4095, 4096, 70000):
+        b = bytes(rnd.randrange(256) for _ in range(n))
+        assert L.hts_crc32(zlib.crc32(b[:n // 3]), b[n // 3:], n - n // 3) == zlib.crc32(b), n

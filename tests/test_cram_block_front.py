@@ -97,7 +97,7 @@ def slice_driver(built, tmp_path_factory):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("level,major,use_fqz,use_arith", [(5, 3, 0, 0), (7, 3, 1, 1), (1, 3, 0, 0), (5, 2, 0, 0)])
+@pytest.mark.parametrize("level,major,use_fqz,use_arith", [(5, 3, 0, 0), (7, 3, 1, 1), (1, 3, 0, 0), (5, 2, 0, 0), (5, 2, 2, 0)])
 def test_c_driver_compress_slice_in_one_batch(slice_driver, engine, level, major, use_fqz, use_arith):
     """hg_cram_compress_slice_fqz = cram_compress_slice (cram/cram_encode.c:803-988) for one slice: every block decodes back to its bytes with
     cram_uncompress_block, every chosen method belongs to the set hg_cram_slice_plan offers that series (or methodF of the final sweep), the
@@ -112,9 +112,17 @@ def test_c_driver_compress_slice_in_one_batch(slice_driver, engine, level, major
     assert all(int(x[9]) <= int(x[7]) for x in rows)                      # nothing grows (RAW is kept when nothing beats it)
     if major >= 3:
         assert 8 in {m for ds, m in methods if ds == 11}                  # read names: the tokeniser
-        assert qs <= ({5, 7} if use_fqz else {5}) | ({6} if use_arith else set()) | {1, 4}
+        assert qs <= ({5, 7} if use_fqz & 1 else {5}) | ({6} if use_arith else set()) | {1, 4}
     else:
-        assert not ({5, 6, 7, 8} & {m for _, m in methods})               # CRAM 2.x: gzip / rANS 4x8 only
+        assert not ({5, 6, 7, 8} & {m for _, m in methods})               # CRAM 2.x: gzip / rANS 4x8 only (+ bzip2 / lzma when asked for and installed)
+        if use_fqz & 2:
+            import ctypes
+            have = []
+            for name, mid in (("libbz2.so.1.0", 2), ("liblzma.so.5", 3)):
+                try: ctypes.CDLL(name); have.append(mid)
+                except OSError: pass
+            print("bzip2 / lzma available:", have, "chosen somewhere:", sorted({m for _, m in methods} & {2, 3}))
+            assert {m for _, m in methods} & {2, 3} <= set(have)
 
 
 @pytest.mark.gpu
