@@ -15,6 +15,7 @@
 // the test harness (tests/native/cram_records_host.cpp) compiles the same source for the CPU to check it against the reference's
 // SAM twins without a GPU.  It is NOT a CPU fallback of the product: libhtsgpu exports only the device path.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -50,6 +50,7 @@ int launch_fast_columns(hg_ctx *ctx, const uint8_t *d_data, const hg_stream_desc
                         const uint32_t *d_col_slice, int32_t *d_fail, hipStream_t s);
 // Fc: a FastDev whose fast_list names the slices the CHAIN decoder decoded (their bases sit in seq_tmp / qual_tmp at seq_off[])
 int launch_chain_placement(hg_ctx *ctx, const DevTables &T, const DevCols &D, const FastDev &Fc, const int32_t *d_status, const uint8_t *seq_tmp, const uint8_t *qual_tmp, hipStream_t s);
+int launch_seg_scan(hg_ctx *ctx, const SliceDev *d_slices, const uint32_t *d_list, uint32_t nlist, uint32_t *cols, int ncols, uint64_t N, uint64_t *d_tot, hipStream_t s);
 int launch_fast_passes(hg_ctx *ctx, const DevTables &T, const DevCols &D, const FastDev &F, uint32_t nslices, int32_t *d_status, hipStream_t s);
 
 }  // namespace hgr

@@ -107,6 +107,7 @@ struct ScanArgs {
     uint32_t *cols[8]; int32_t tot[8]; int ncols;      // plain columns; tot[i] >= 0: the column's total goes to F.tot[slice][tot[i]]
     uint32_t *fam; int fam_n;                          // a family of columns fam + j * N: fam_n of them, or (fam_n < 0) as many as the slice has tags
     int do_ap;                                         // AP deltas -> positions (inclusive, from the slice's start), for slices whose header says delta
+    uint64_t *tot_all; int tot_stride;                 // optional: the total of EVERY column, tot_all[list position * tot_stride + column]
 };
 __device__ __forceinline__ unsigned long long block_exscan(unsigned long long x, unsigned long long *lds, unsigned long long &total) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -142,6 +143,7 @@ void fast_scan_kernel(DevTables T, FastDev F, ScanArgs A) {
             }
             if (carry > 0xffffffffull) over = true;
             if (ci < A.ncols && A.tot[ci] >= 0 && threadIdx.x == 0) F.tot[(size_t)k * TOT_N + A.tot[ci]] = carry;
+            if (A.tot_all && threadIdx.x == 0) A.tot_all[(size_t)q * A.tot_stride + ci] = carry > 0xffffffffull ? ~0ull : carry;
         }
         if (A.do_ap && T.plans[d.plan].ap_delta) {
             long long carry = d.ref_seq_start;
@@ -155,7 +157,7 @@ void fast_scan_kernel(DevTables T, FastDev F, ScanArgs A) {
                 carry += (long long)tot;
             }
         }
-        if (over && threadIdx.x == 0) F.tot[(size_t)k * TOT_N + TOT_OVER] = 1;
+        if (over && threadIdx.x == 0 && F.tot) F.tot[(size_t)k * TOT_N + TOT_OVER] = 1;
     }
 }
 
@@ -215,16 +217,16 @@ int launch_fast_passes(hg_ctx *ctx, const DevTables &T, const DevCols &D, const 
     const FScr &Z = F.Z;
     ScanArgs A;
     hipLaunchKernelGGL(fast_pass_kernel<PH_M1>, grid, blk, 0, s, T, D, F);
-    A = ScanArgs{{Z.c_det, Z.c_down, Z.c_ts, Z.c_map, Z.seq_at}, {-1, -1, -1, -1, TOT_SEQ}, 5, nullptr, 0, 1};
+    A = ScanArgs{{Z.c_det, Z.c_down, Z.c_ts, Z.c_map, Z.seq_at}, {-1, -1, -1, -1, TOT_SEQ}, 5, nullptr, 0, 1, nullptr, 0};
     hipLaunchKernelGGL(fast_scan_kernel, sgrid, sblk, 0, s, T, F, A);
     hipLaunchKernelGGL(fast_pass_kernel<PH_M2>, grid, blk, 0, s, T, D, F);
-    A = ScanArgs{{Z.fn, D.noff, Z.work}, {-1, TOT_NAME, TOT_WORK}, 3, Z.tag, -1, 0};
+    A = ScanArgs{{Z.fn, D.noff, Z.work}, {-1, TOT_NAME, TOT_WORK}, 3, Z.tag, -1, 0, nullptr, 0};
     hipLaunchKernelGGL(fast_scan_kernel, sgrid, sblk, 0, s, T, F, A);
     hipLaunchKernelGGL(fast_pass_kernel<PH_M3>, grid, blk, 0, s, T, D, F);
-    A = ScanArgs{{}, {}, 0, Z.cls, NCLS, 0};
+    A = ScanArgs{{}, {}, 0, Z.cls, NCLS, 0, nullptr, 0};
     hipLaunchKernelGGL(fast_scan_kernel, sgrid, sblk, 0, s, T, F, A);
     hipLaunchKernelGGL(fast_pass_kernel<PH_M4>, grid, blk, 0, s, T, D, F);
-    A = ScanArgs{{D.coff, D.aoff}, {TOT_CIG, TOT_AUX}, 2, nullptr, 0, 0};
+    A = ScanArgs{{D.coff, D.aoff}, {TOT_CIG, TOT_AUX}, 2, nullptr, 0, 0, nullptr, 0};
     hipLaunchKernelGGL(fast_scan_kernel, sgrid, sblk, 0, s, T, F, A);
     hipLaunchKernelGGL(fast_finish_kernel, dim3((F.nfast + 255) / 256), dim3(256), 0, s, T, D, F);
     hipLaunchKernelGGL(fast_seqbase_kernel, dim3(1), dim3(SCAN_NT), 0, s, F, 0);
@@ -268,10 +270,21 @@ int launch_chain_placement(hg_ctx *ctx, const DevTables &T, const DevCols &D, co
     if (!Fc.nfast) return HG_OK;
     const dim3 grid((unsigned)std::min<size_t>(Fc.nfast, (size_t)ctx->cus * 8));
     hipLaunchKernelGGL(chain_len_kernel, grid, dim3(256), 0, s, T, D, Fc, d_status);
-    ScanArgs A{{Fc.Z.seq_at}, {TOT_SEQ}, 1, nullptr, 0, 0};
+    ScanArgs A{{Fc.Z.seq_at}, {TOT_SEQ}, 1, nullptr, 0, 0, nullptr, 0};
     hipLaunchKernelGGL(fast_scan_kernel, dim3((unsigned)std::min<size_t>(Fc.nfast, (size_t)ctx->cus * 4)), dim3(SCAN_NT), 0, s, T, Fc, A);
     hipLaunchKernelGGL(fast_seqbase_kernel, dim3(1), dim3(SCAN_NT), 0, s, Fc, 1);
     hipLaunchKernelGGL(chain_reorder_kernel, grid, dim3(256), 0, s, T, D, Fc, d_status, seq_tmp, qual_tmp);
+    return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+
+// exclusive prefix sums, per slice, of `ncols` columns cols + j * N (records of slice k = d_slices[list[k]].rec_off .. + nrec); the totals of
+// every column of every listed slice go to d_tot[k * ncols + j] (~0 = does not fit 32 bits).  Used by the encoder (cram_encode.hip).
+int launch_seg_scan(hg_ctx *ctx, const SliceDev *d_slices, const uint32_t *d_list, uint32_t nlist, uint32_t *cols, int ncols, uint64_t N, uint64_t *d_tot, hipStream_t s) {
+    if (!nlist || !ncols) return HG_OK;
+    DevTables T{}; T.slices = d_slices;
+    FastDev F{}; F.fast_list = d_list; F.nfast = nlist; F.Z.N = N;
+    ScanArgs A{{}, {}, 0, cols, ncols, 0, d_tot, ncols};
+    hipLaunchKernelGGL(fast_scan_kernel, dim3((unsigned)std::min<size_t>(nlist, (size_t)ctx->cus * 4)), dim3(SCAN_NT), 0, s, T, F, A);
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
 

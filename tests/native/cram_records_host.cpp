@@ -211,3 +211,101 @@ extern "C" int hgr_host_decode_records_fast(size_t nslices, const hgr::SliceIn *
     rec_off[nslices] = B.nrec;
     return 0;
 }
+
+// ---- the ENCODER (cram_encode_core.h / cram_encode_plan.h) run from plain loops, in the order of the kernels of cram_encode.hip: tag survey,
+//      counting walk, prefix sums per slice, writing walk, headers.  Output: per slice a blob  u32 comp_len, comp, u32 slice_hdr_len, slice_hdr,
+//      u32 nblocks, then per block i32 content id, u32 len, bytes  (the layout of tests/native/cram_encode_proto.cpp); slice_off[i] .. [i + 1]. ----
+#include "../../htslib_amd/csrc/cram_encode_plan.h"
+
+struct ref_seq_in { const uint8_t *bases; uint64_t len; };
+extern "C" long hgr_host_encode_slices(const uint8_t *bam, size_t bam_len, size_t nrec_in, uint32_t per_slice, const ref_seq_in *refs, int nrefs, const char *const *rg_names, int nrg,
+                                       int64_t record_counter0, uint8_t *out, size_t cap, uint64_t *slice_off, size_t max_slices, int32_t *status) {
+    using namespace hgr;
+    std::vector<uint64_t> rec_off;                                       // frame the records (bam_read1: block_size + bytes)
+    for (uint64_t at = 0; at + 4 <= bam_len && rec_off.size() < nrec_in;) { rec_off.push_back(at); at += 4ull + ld32(bam + at); if (at > bam_len) return -1; }
+    if (rec_off.size() != nrec_in) return -1;
+    rec_off.push_back(rec_off.empty() ? 0 : rec_off.back() + 4ull + ld32(bam + rec_off.back()));
+    const size_t n = nrec_in, ns = per_slice ? (n + per_slice - 1) / per_slice : 0;
+    if (ns > max_slices) return -5;
+    std::vector<uint8_t> data; std::vector<EncRef> er((size_t)nrefs);
+    for (int i = 0; i < nrefs; i++) { er[(size_t)i].off = data.size(); er[(size_t)i].len = refs[i].bases ? (int64_t)refs[i].len : 0; if (refs[i].bases) data.insert(data.end(), refs[i].bases, refs[i].bases + refs[i].len); }
+    std::vector<uint8_t> rgn; std::vector<uint32_t> rgo((size_t)nrg + 1, 0);
+    for (int i = 0; i < nrg; i++) { rgn.insert(rgn.end(), rg_names[i], rg_names[i] + strlen(rg_names[i])); rgo[(size_t)i + 1] = (uint32_t)rgn.size(); }
+    std::vector<EncSlice> S(ns);
+    std::vector<uint32_t> keytab(ns * ENC_KEY_SLOTS, ENC_EMPTY), lfirst(ns * ENC_LINE_SLOTS, 0xffffffffu); std::vector<uint64_t> lhash(ns * ENC_LINE_SLOTS, 0);
+    std::vector<int32_t> fail(ns + 1, 0);
+    auto ctx_of = [&](size_t k) {
+        EncCtx C{}; C.bam = bam; C.rec_off = rec_off.data(); C.data = data.data(); C.refs = er.data(); C.nref = nrefs; C.rg_names = rgn.data(); C.rg_off = rgo.data(); C.nrg = nrg;
+        C.r0 = S[k].r0; C.nrec = S[k].nrec; C.keys = S[k].keys.data(); C.nkeys = (uint32_t)S[k].keys.size(); C.line_hash = S[k].lhash.data(); C.nlines = (uint32_t)S[k].lhash.size(); C.fail = &fail[k];
+        return C;
+    };
+    const EncSurvey V{keytab.data(), lhash.data(), lfirst.data()};
+    for (size_t k = 0; k < ns; k++) {                                    // survey + slice statistics
+        S[k].r0 = k * per_slice; S[k].nrec = (uint32_t)std::min<size_t>(per_slice, n - S[k].r0);
+        const EncCtx C = ctx_of(k);
+        int32_t lo = INT32_MAX, hi = INT32_MIN; int64_t p0 = INT64_MAX, p1 = INT64_MIN;
+        for (uint32_t r = 0; r < S[k].nrec; r++) {
+            enc_survey_record(C, r, V, (uint32_t)k);
+            BamRec B;
+            if (!bam_parse(bam, rec_off[S[k].r0 + r], rec_off[S[k].r0 + r + 1], B)) continue;
+            int64_t rl = 0;
+            if (!(B.flag & BAM_FUNMAP)) for (uint32_t c = 0; c < B.n_cigar; c++) { const uint32_t cw = ld32(B.cigar + 4 * c), op = cw & 15u; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += cw >> 4; }
+            const int64_t ap = (int64_t)B.pos + 1, ae = rl ? ap + rl - 1 : ap;
+            lo = std::min(lo, B.ref_id); hi = std::max(hi, B.ref_id); p0 = std::min(p0, ap); p1 = std::max(p1, ae);
+        }
+        S[k].min_ref = lo; S[k].max_ref = hi; S[k].min_pos = p0; S[k].max_end = p1; S[k].fail = fail[k];
+        enc_survey_finish(keytab.data() + k * ENC_KEY_SLOTS, lhash.data() + k * ENC_LINE_SLOTS, lfirst.data() + k * ENC_LINE_SLOTS, S[k]);
+        fail[k] = S[k].fail;
+    }
+    size_t ncmax = W_N; for (auto &s : S) ncmax = std::max<size_t>(ncmax, (size_t)s.ncols());
+    const size_t N = n + 1;
+    std::vector<uint32_t> col(ncmax * N, 0u);
+    std::vector<std::vector<uint64_t>> tot(ns), base(ns);
+    auto prev_of = [&](size_t k, uint32_t r) -> int64_t { if (r == 0) return S[k].start(); BamRec B; bam_parse(bam, rec_off[S[k].r0 + r - 1], rec_off[S[k].r0 + r], B); return (int64_t)B.pos + 1; };
+    uint64_t out_bytes = 0;
+    for (size_t k = 0; k < ns; k++) {                                    // counting walk + prefix sums
+        if (fail[k]) continue;
+        const EncCtx C = ctx_of(k);
+        const int nc = S[k].ncols();
+        for (uint32_t r = 0; r < S[k].nrec; r++) {
+            Sink<false> K{}; K.col = col.data(); K.N = N; K.g = S[k].r0 + r;
+            if (!enc_record<false>(C, r, prev_of(k, r), S[k].multi(), K)) break;
+            for (int s = 0; s < W_N; s++) col[(size_t)s * N + K.g] = K.n[s];
+        }
+        if (fail[k]) continue;
+        tot[k].assign((size_t)nc, 0); base[k].assign((size_t)nc, 0);
+        for (int c = 0; c < nc; c++) {
+            uint64_t run = 0;
+            for (uint32_t r = 0; r < S[k].nrec; r++) { uint32_t &x = col[(size_t)c * N + S[k].r0 + r]; const uint32_t v = x; x = (uint32_t)run; run += v; }
+            if (run > 0xffffffffull) fail[k] = -3;
+            tot[k][(size_t)c] = run; base[k][(size_t)c] = out_bytes; out_bytes += (run + 15u) & ~15ull;
+        }
+    }
+    std::vector<uint8_t> blk(out_bytes + 64);
+    for (size_t k = 0; k < ns; k++) {                                    // writing walk
+        if (fail[k]) continue;
+        const EncCtx C = ctx_of(k);
+        for (uint32_t r = 0; r < S[k].nrec; r++) {
+            Sink<true> K{}; K.col = col.data(); K.N = N; K.g = S[k].r0 + r; K.out = blk.data(); K.base = base[k].data();
+            for (int s = 0; s < W_N; s++) K.p[s] = blk.data() + base[k][(size_t)s] + col[(size_t)s * N + K.g];
+            if (!enc_record<true>(C, r, prev_of(k, r), S[k].multi(), K)) break;
+        }
+    }
+    uint64_t at = 0;
+    for (size_t k = 0; k < ns; k++) {                                    // headers + blob
+        slice_off[k] = at; status[k] = fail[k];
+        if (fail[k]) continue;
+        std::vector<uint8_t> comp, sh; std::vector<std::pair<int32_t, uint32_t>> blocks;
+        enc_headers(S[k], bam, rec_off.data(), tot[k].data(), record_counter0 + (int64_t)S[k].r0, comp, sh, blocks);
+        uint64_t need = 12 + comp.size() + sh.size();
+        for (auto &b : blocks) need += 8 + tot[k][b.second];
+        if (at + need > cap) return -5;
+        auto put32 = [&](uint32_t v) { for (int i = 0; i < 4; i++) out[at++] = (uint8_t)(v >> (8 * i)); };
+        put32((uint32_t)comp.size()); memcpy(out + at, comp.data(), comp.size()); at += comp.size();
+        put32((uint32_t)sh.size()); memcpy(out + at, sh.data(), sh.size()); at += sh.size();
+        put32((uint32_t)blocks.size());
+        for (auto &b : blocks) { put32((uint32_t)b.first); put32((uint32_t)tot[k][b.second]); memcpy(out + at, blk.data() + base[k][b.second], tot[k][b.second]); at += tot[k][b.second]; }
+    }
+    slice_off[ns] = at;
+    return (long)ns;
+}

@@ -100,6 +100,8 @@ def decode(call_bound, call_decode, slices, major, nref, with_seq=True):
                              [G.short_tag(t) for t in G.aux_to_text(bytes(aux[int(aux_off[r]):int(aux_off[r]) + int(aux_len[r])]))]]
         out.append(recs)
     decode.last_aend = [[int(i64["aend"][r]) for r in range(int(rec_off[i]), int(rec_off[i + 1]))] for i in range(n)]    # for the index test
+    decode.last_aux = [[bytes(aux[int(aux_off[r]):int(aux_off[r]) + int(aux_len[r])]) for r in range(int(rec_off[i]), int(rec_off[i + 1]))] if with_seq and status[i] == 0 else [] for i in range(n)]
+    decode.last_rg = [[int(i32["rg"][r]) for r in range(int(rec_off[i]), int(rec_off[i + 1]))] for i in range(n)]
     return status, out
 
 
