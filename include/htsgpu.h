@@ -449,6 +449,21 @@ int hg_cram_batch_decode_bam_dev(hg_ctx *ctx, hg_cram_batch *batch, const char *
 int hg_cram_batch_read_bam(hg_ctx *ctx, hg_cram_batch *batch, uint8_t *dst, size_t cap);   /* the last run's stream -> host */
 void hg_cram_batch_free(hg_ctx *ctx, hg_cram_batch *batch);
 
+typedef struct hg_cram_ref_seq { const uint8_t *bases; uint64_t len; } hg_cram_ref_seq;
+/* ---- The write side of the record layer: BAM records -> CRAM slices, i.e. cram_encode_slice fed by process_one_read
+ * (cram/cram_encode.c:572-793, 1096-1209, 3382-3700) -- per-record walks (CIGAR against the reference -> features, fixed fields, tags) and
+ * prefix sums on the device (cram_encode.hip / cram_encode_core.h).  bam = nrec records in bam_write1's layout, back to back (no header);
+ * refs[i] = reference sequence i in upper case (bases NULL = not available: every base is then stored); rg_names = the @RG ids (an RG:Z tag
+ * becomes the RG series).  Slices of records_per_slice records; a slice spanning several references is a multi-reference slice.  Per slice
+ * i, out + slice_off[i] holds: u32 length + the compression header block, u32 length + the slice header block, u32 nblocks, then per block
+ * i32 content id, u32 length, bytes -- uncompressed EXTERNAL blocks, ready for cram_compress_slice / hg_cram_compress_blocks_metrics_host
+ * and decodable by hg_cram_decode_records_host (all of it by the data-parallel passes).  Writer's choices: cram_encode_core.h's header.
+ * status[i] = 0, -1 (malformed BAM record) or HG_BLOCK_EUNSUPPORTED (a record with a CIGAR but no bases; more than 64 distinct tags or 256
+ * distinct tag lists in the slice; an RG:Z naming no @RG line).  Returns HG_OK / HG_EBLOCK / HG_ENOMEM (*out_bytes = bytes needed). */
+int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, size_t nrec, uint32_t records_per_slice,
+                               const hg_cram_ref_seq *refs, int nrefs, const char *const *rg_names, int nrg, int64_t record_counter0,
+                               uint8_t *out, size_t out_cap, uint64_t *slice_off, size_t max_slices, int32_t *status, uint64_t *out_bytes);
+
 /* A whole CRAM 2.x / 3.x file -> the uncompressed BAM stream `samtools view -u -b` would hand to bgzf_write: the container / block walk
  * of cram_read_container / cram_read_block on the host, every block through cram_uncompress_block (CRC check included) in one batch,
  * every slice through hg_cram_decode_bam_host in one batch, and bam_hdr_write's header in front.  refs[i] = reference sequence i of the
@@ -458,7 +473,6 @@ void hg_cram_batch_free(hg_ctx *ctx, hg_cram_batch *batch);
 int hg_cram_decode_bam_host2(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref,
                              const char *const *rg_names, int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap,
                              uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes, int32_t *status, const char *name_prefix);
-typedef struct hg_cram_ref_seq { const uint8_t *bases; uint64_t len; } hg_cram_ref_seq;
 int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given,
                              uint8_t *bam_out, size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords);
 /* The same with options.  By default the MD5 of the reference span in every slice header is checked against the bases about to be used,

@@ -149,3 +149,90 @@ def test_fixture_records_survive_encode_and_decode(hostlib):
             assert x[:11] == y[:11] and x[11] == [t for t in y[11] if not t.startswith("RG:Z:")] and g2 == want_rg, (fname, x, y, g0, g2)
         done += len(got[0])
     assert done >= 200 and refused <= 7, (done, refused)
+
+
+# ---------------------------------------------------------------- on the MI355X: cram_encode.hip ----
+def encode_gpu(engine, bam, nrec, per_slice, refs, rg_names=(), counter=0):
+    from htslib_amd import _native as nat
+    keep = [C.create_string_buffer(r, len(r)) if r is not None else None for r in refs]
+    arr = (RefSeq * max(len(refs), 1))(*[RefSeq(C.addressof(k), len(r)) if k is not None else RefSeq(None, 0) for k, r in zip(keep, refs)])
+    rg = [r.encode() if isinstance(r, str) else r for r in rg_names]; rgp = (C.c_char_p * max(len(rg), 1))(*rg)
+    ns = (nrec + per_slice - 1) // per_slice
+    out = np.zeros(len(bam) * 2 + 65536 * ns + 4096, np.uint8); off = np.zeros(ns + 2, np.uint64); st = np.full(ns + 1, 9, np.int32); total = C.c_uint64()
+    b = C.create_string_buffer(bam, len(bam))
+    rc = nat.lib.hg_cram_encode_slices_host(engine._h, C.cast(b, _vp), len(bam), nrec, per_slice, C.cast(arr, _vp), len(refs), C.cast(rgp, _vp) if rg else None, len(rg), counter,
+                                            out.ctypes.data, len(out), off.ctypes.data, ns + 1, st.ctypes.data, C.byref(total))
+    assert rc in (0, -6), rc
+    return st[:ns], [bytes(out[int(off[i]):int(off[i + 1])]) for i in range(ns)]
+
+
+@pytest.mark.gpu
+def test_gpu_encoder_equals_the_cpu_compile_and_round_trips_to_the_same_bam(engine, hostlib):
+    """synthetic slices -> BAM (device: cram_decode_slice + cram_to_bam) -> CRAM slices (device encoder) -> BAM again: byte-identical streams, for whole
+    slices and for a different slicing; the encoder's blobs equal the CPU compile's byte for byte"""
+    from htslib_amd import _native as nat, synth_cram
+    rng = np.random.default_rng(43)
+    slices = [synth_cram.make_slice(rng, 3000, 100, tags=True), synth_cram.make_slice(rng, 700, 151, unmapped_every=3), synth_cram.make_slice(rng, 1, 50, ref_len=900),
+              synth_cram.make_slice(rng, 513, 64, detached_every=2, tags=True)]
+    for s in slices:
+        keep = []
+        arr = nat.cram_slice_array([s], keep)
+        bases = s["nrec"] * 160 + 4096
+        bam, rec_off, st = engine.cram_decode_bam(arr, 1, 3, 1, [], bases, bases * 4 + 600 * s["nrec"])
+        assert st[0] == 0
+        bam = bytes(bam)
+        ref = s["refs"][0][2]
+        for per in (s["nrec"], 257):
+            st_g, blobs = encode_gpu(engine, bam, s["nrec"], per, [ref])
+            st_c, blobs_c = encode_host(hostlib, bam, s["nrec"], per, [ref])
+            assert (st_g == 0).all() and (st_c == 0).all()
+            assert blobs == blobs_c                                     # the same source on both sides: same bytes
+            again = [parse_blob(b, min(per, s["nrec"] - i * per), s["refs"], []) for i, b in enumerate(blobs)]
+            keep2 = []
+            arr2 = nat.cram_slice_array(again, keep2)
+            h = engine.cram_batch_stage(arr2, len(again), 3, 1, bases)
+            try:
+                d, nb, nr, nf, st2 = engine.cram_batch_decode_bam(h, len(again))
+                assert (st2 == 0).all() and nf == len(again) and nr == s["nrec"]
+                bam2 = bytes(engine.cram_batch_read_bam(h, nb))
+            finally:
+                engine.cram_batch_free(h)
+            assert bam2 == bam
+
+
+@pytest.mark.gpu
+def test_gpu_encoder_on_the_reference_fixtures(engine):
+    """the reference's CRAM fixtures: file -> BAM (device) -> CRAM slices (device encoder, one slice per file) -> BAM: the same records (RG:Z included: it
+    travels as the RG series).  Files with a CIGAR-without-bases record or the 511-tag stress file are refused with -3."""
+    import json
+    from htslib_amd import _native as nat
+    done = refused = 0
+    for f in json.load(open(T.GOLD)):
+        slices = [s for fname, major, nref, s in T.load_slices() if fname == f["file"]]
+        rg = [r if isinstance(r, str) else r[0] for r in (f.get("rg") or [])]
+        keep = []
+        arr = nat.cram_slice_array(slices, keep)
+        nrec = sum(s["nrec"] for s in slices)
+        bases = sum(len(e[9]) for s in slices for e in s["expect"]) + 4096
+        bam, rec_off, st = engine.cram_decode_bam(arr, len(slices), f["major"], f["nref"], rg, bases, 1 << 22)
+        assert (st == 0).all(), f["file"]
+        bam = bytes(bam)
+        refs = [None] * max(f["nref"], 1)
+        for s in slices:
+            for t, a, b, ln in s["refs"]:
+                if refs[t] is None: refs[t] = bytearray(b"N" * ln)
+                refs[t][a - 1:a - 1 + len(b)] = b
+        refs = [bytes(r) if r is not None else None for r in refs]
+        st_g, blobs = encode_gpu(engine, bam, nrec, max(nrec, 1), refs, rg)
+        if st_g[0] == -3: refused += 1; continue
+        assert st_g[0] == 0, (f["file"], st_g)
+        allrefs = [x for s in slices for x in s["refs"]]
+        s2 = parse_blob(blobs[0], nrec, [(t, 1, r, len(r)) for t, r in enumerate(refs) if r is not None], [])
+        keep2 = []
+        arr2 = nat.cram_slice_array([s2], keep2)
+        bam2, _, st2 = engine.cram_decode_bam(arr2, 1, 3, f["nref"], rg, bases, 1 << 22)
+        assert st2[0] == 0, f["file"]
+        one, two = T._parse_bam_records(bam), T._parse_bam_records(bytes(bam2))
+        assert [r[0] for r in one] == [r[0] for r in two], (f["file"], [(x[0], y[0]) for x, y in zip(one, two) if x[0] != y[0]][:1])
+        done += len(one)
+    assert done >= 200 and refused <= 6, (done, refused)
