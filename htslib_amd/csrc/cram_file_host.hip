@@ -12,7 +12,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
 #include <string>
+#include <tuple>
 #include <thread>
 #include <atomic>
 #include <vector>
@@ -270,4 +272,176 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
     *bam_bytes = hb + rec_bytes;
     if (nrecords) *nrecords = rec_off[ns];
     return rc;
+}
+
+// ---- the other direction: an uncompressed BAM stream (header + records, what hg_cram_file_to_bam_host returns / bam_hdr_write + bam_write1 produce) ->
+//      a CRAM 3.0 file.  Host composition of library pieces, like the reader above:
+//        1. bam_hdr_read's walk of the header (sam.c): text, reference names / lengths; @RG ids from the text;
+//        2. hg_cram_encode_slices_host: records -> the series blocks and headers of slices of `records_per_slice` reads (device);
+//        3. every block through the method auto-tuner (hg_cram_compress_blocks_metrics_host, one cram_metrics per content id as cram_encode.c keeps
+//           one per data series) with the CRAM 3.0 method set GZIP | RANS0 | RANS1 -- rANS 4x8 is the codec of this library that is PINNED against
+//           the reference's fixtures, so the files need nothing unpinned to be read;
+//        4. framing (cram_write_file_def, cram_write_SAM_hdr, cram_write_container, cram_write_block, cram/cram_io.c:1511-1560, 3890-4060, 4380-4500):
+//           file definition, header container, one container per slice (compression header block RAW, slice header block RAW, the series blocks),
+//           the EOF container; block and container CRC-32s on the device.
+namespace {
+void put_itf8(std::vector<uint8_t> &o, int32_t sv) {
+    const uint32_t v = (uint32_t)sv;
+    if (v < 0x80) o.push_back((uint8_t)v);
+    else if (v < 0x4000) { o.push_back((uint8_t)(0x80 | (v >> 8))); o.push_back((uint8_t)v); }
+    else if (v < 0x200000) { o.push_back((uint8_t)(0xc0 | (v >> 16))); o.push_back((uint8_t)(v >> 8)); o.push_back((uint8_t)v); }
+    else if (v < 0x10000000) { o.push_back((uint8_t)(0xe0 | (v >> 24))); o.push_back((uint8_t)(v >> 16)); o.push_back((uint8_t)(v >> 8)); o.push_back((uint8_t)v); }
+    else { o.push_back((uint8_t)(0xf0 | (v >> 28))); o.push_back((uint8_t)(v >> 20)); o.push_back((uint8_t)(v >> 12)); o.push_back((uint8_t)(v >> 4)); o.push_back((uint8_t)(v & 0x0f)); }
+}
+void put_ltf8(std::vector<uint8_t> &o, uint64_t v) {                     // ltf8_put (cram_io.c:475-560), values below 2^56
+    int extra = 0;
+    while (extra < 7 && v >= (1ull << (7 * (extra + 1)))) extra++;
+    if (extra == 0) { o.push_back((uint8_t)v); return; }
+    o.push_back((uint8_t)((0xff00u >> extra) & 0xffu) | (uint8_t)(v >> (8 * extra)));
+    for (int i = extra - 1; i >= 0; i--) o.push_back((uint8_t)(v >> (8 * i)));
+}
+void put32le(std::vector<uint8_t> &o, uint32_t v) { for (int i = 0; i < 4; i++) o.push_back((uint8_t)(v >> (8 * i))); }
+}  // namespace
+
+extern "C" int hg_bam_to_cram_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, const hg_cram_ref_seq *refs, int nrefs_given, uint32_t records_per_slice, int level,
+                                   uint8_t *cram_out, size_t cram_cap, uint64_t *cram_bytes, uint64_t *nrecords) {
+    if (!ctx || !bam || !cram_out || !cram_bytes || (nrefs_given && !refs)) return HG_EINVAL;
+    if (!records_per_slice) records_per_slice = 10000;                   // the reference's default (cram/cram_structs.h:87-89)
+    if (level <= 0) level = 5;
+    // ---- 1. BAM header
+    if (bam_len < 12 || memcmp(bam, "BAM\1", 4) != 0) return HG_EINVAL;
+    auto rd32 = [&](size_t at) { return (uint32_t)bam[at] | (uint32_t)bam[at + 1] << 8 | (uint32_t)bam[at + 2] << 16 | (uint32_t)bam[at + 3] << 24; };
+    const uint32_t l_text = rd32(4);
+    if ((size_t)l_text + 12 > bam_len) return HG_EINVAL;
+    const std::string text((const char *)bam + 8, l_text);
+    size_t p = 8 + (size_t)l_text;
+    const uint32_t n_ref = rd32(p); p += 4;
+    for (uint32_t i = 0; i < n_ref; i++) { if (p + 4 > bam_len) return HG_EINVAL; const uint32_t ln = rd32(p); p += 4 + (size_t)ln + 4; if (p > bam_len) return HG_EINVAL; }
+    std::vector<std::string> rg_id;
+    for (size_t at = 0; at < text.size();) {
+        size_t e = text.find('\n', at); if (e == std::string::npos) e = text.size();
+        const std::string line = text.substr(at, e - at); at = e + 1;
+        if (line.compare(0, 3, "@RG") != 0) continue;
+        for (size_t f = 3; f < line.size();) { size_t t = line.find('\t', f + 1); if (t == std::string::npos) t = line.size(); const std::string fld = line.substr(f + 1, t - f - 1); f = t; if (fld.compare(0, 3, "ID:") == 0) rg_id.push_back(fld.substr(3)); }
+    }
+    // ---- 2. records -> slices
+    size_t nrec = 0;
+    for (size_t q = p; q + 4 <= bam_len;) { q += 4 + (size_t)rd32(q); if (q > bam_len) return HG_EINVAL; nrec++; }
+    if (nrecords) *nrecords = nrec;
+    const size_t ns = (nrec + records_per_slice - 1) / records_per_slice;
+    std::vector<uint8_t> blob((bam_len - p) * 2 + 65536 * (ns + 1) + 4096);
+    std::vector<uint64_t> soff(ns + 2, 0); std::vector<int32_t> sst(ns + 1, 0);
+    std::vector<const char *> rgp; for (auto &r : rg_id) rgp.push_back(r.c_str());
+    int rc = HG_OK;
+    if (nrec) {
+        uint64_t need = 0;
+        rc = hg_cram_encode_slices_host(ctx, bam + p, bam_len - p, nrec, records_per_slice, refs, nrefs_given, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), 0, blob.data(), blob.size(),
+                                        soff.data(), ns + 1, sst.data(), &need);
+        if (rc != HG_OK) return rc;                                     // a slice the encoder does not cover fails the file
+    }
+    // ---- 3. every series block through the auto-tuner
+    struct Blk { int32_t cid; const uint8_t *p; uint32_t n; size_t slice; };
+    struct SliceParts { const uint8_t *comp; uint32_t comp_len; const uint8_t *sh; uint32_t sh_len; size_t b0, b1; hgr::SliceHeader hdr; uint64_t bases; };
+    std::vector<Blk> blks; std::vector<SliceParts> parts(ns);
+    for (size_t k = 0; k < ns; k++) {
+        const uint8_t *b = blob.data() + soff[k];
+        auto r32 = [&](const uint8_t *q) { return (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24; };
+        SliceParts &P = parts[k];
+        P.comp_len = r32(b); P.comp = b + 4; b += 4 + P.comp_len;
+        P.sh_len = r32(b); P.sh = b + 4; b += 4 + P.sh_len;
+        const uint32_t nb = r32(b); b += 4;
+        P.b0 = blks.size();
+        for (uint32_t i = 0; i < nb; i++) { const int32_t cid = (int32_t)r32(b); const uint32_t n = r32(b + 4); blks.push_back(Blk{cid, b + 8, n, k}); b += 8 + n; }
+        P.b1 = blks.size();
+        if (hgr::parse_slice_header(P.sh, P.sh_len, 3, P.hdr)) return HG_EINVAL;
+        P.bases = 0;
+    }
+    {   // bases per slice (container header): the read lengths of its records
+        size_t q = p;
+        for (size_t r = 0; r < nrec; r++) { parts[r / records_per_slice].bases += rd32(q + 4 + 16); q += 4 + (size_t)rd32(q); }
+    }
+    const size_t nb = blks.size();
+    std::vector<std::vector<uint8_t>> cdata(nb); std::vector<uint32_t> clen(nb, 0); std::vector<int32_t> cmeth(nb, 0);
+    if (nb) {
+        std::map<int32_t, hg_cram_metrics *> met;
+        std::vector<hg_cram_metrics *> mp(nb); std::vector<uint32_t> sets(nb, (1u << 1) | (1u << 4) | (1u << 16));      // GZIP, RANS0, RANS1 (internal method ids)
+        std::vector<const uint8_t *> in(nb); std::vector<uint32_t> il(nb); std::vector<uint8_t *> out(nb);
+        for (size_t i = 0; i < nb; i++) {
+            auto it = met.find(blks[i].cid);
+            if (it == met.end()) it = met.emplace(blks[i].cid, hg_cram_metrics_new()).first;
+            mp[i] = it->second; in[i] = blks[i].p; il[i] = blks[i].n;
+            cdata[i].resize(hg_cram_compress_bound(blks[i].n)); out[i] = cdata[i].data();
+        }
+        // slice by slice, so that the metrics see the blocks of a series in file order (trial phase first, then the learnt method)
+        for (size_t k = 0; k < ns && rc == HG_OK; k++) {
+            const size_t a = parts[k].b0, n = parts[k].b1 - a;
+            if (n) rc = hg_cram_compress_blocks_metrics_host(ctx, n, mp.data() + a, sets.data() + a, level, 3, in.data() + a, il.data() + a, out.data() + a, clen.data() + a, cmeth.data() + a);
+        }
+        for (auto &m : met) hg_cram_metrics_free(m.second);
+        if (rc != HG_OK) return rc;
+    }
+    // ---- 4. framing
+    std::vector<uint8_t> o;
+    o.reserve(bam_len / 2 + 65536);
+    std::vector<uint64_t> crc_from, crc_at;                              // byte ranges [from, at) whose CRC-32 goes to o[at .. at + 4)
+    auto block = [&](int method, int ctype, int32_t cid, const uint8_t *data, uint32_t csz, uint32_t usz) {
+        const uint64_t from = o.size();
+        o.push_back((uint8_t)method); o.push_back((uint8_t)ctype); put_itf8(o, cid); put_itf8(o, (int32_t)csz); put_itf8(o, (int32_t)usz);
+        o.insert(o.end(), data, data + csz);
+        crc_from.push_back(from); crc_at.push_back(o.size()); put32le(o, 0);
+    };
+    auto container = [&](int32_t ref, int64_t start, int64_t span, int32_t nrecs, uint64_t counter, uint64_t bases, int32_t nblocks, const std::vector<int32_t> &landmarks, const std::vector<uint8_t> &body) {
+        const uint64_t from = o.size();
+        put32le(o, (uint32_t)body.size());
+        put_itf8(o, ref); put_itf8(o, (int32_t)start); put_itf8(o, (int32_t)span); put_itf8(o, nrecs); put_ltf8(o, counter); put_ltf8(o, bases); put_itf8(o, nblocks);
+        put_itf8(o, (int32_t)landmarks.size()); for (int32_t l : landmarks) put_itf8(o, l);
+        crc_from.push_back(from); crc_at.push_back(o.size()); put32le(o, 0);
+        const uint64_t shift = o.size();
+        o.insert(o.end(), body.begin(), body.end());
+        return shift;
+    };
+    // file definition: "CRAM", 3.0, 20-byte file id
+    o.insert(o.end(), {'C', 'R', 'A', 'M', 3, 0}); { const char id[20] = "htslib_amd"; o.insert(o.end(), id, id + 20); }
+    // blocks of a container are built in a scratch vector first (the container header needs their total size); CRC slots are re-based afterwards
+    auto build = [&](auto &&fill) {
+        std::vector<uint8_t> saved; saved.swap(o);
+        std::vector<uint64_t> f0, a0; f0.swap(crc_from); a0.swap(crc_at);
+        fill();
+        std::vector<uint8_t> body; body.swap(o); o.swap(saved);
+        std::vector<uint64_t> f1, a1; f1.swap(crc_from); a1.swap(crc_at); crc_from.swap(f0); crc_at.swap(a0);
+        return std::make_tuple(std::move(body), std::move(f1), std::move(a1));
+    };
+    {   // header container: one FILE_HEADER block = int32 text length + text (cram_write_SAM_hdr)
+        auto [body, f1, a1] = build([&] { std::vector<uint8_t> h; put32le(h, (uint32_t)text.size()); h.insert(h.end(), text.begin(), text.end()); block(0, 0, 0, h.data(), (uint32_t)h.size(), (uint32_t)h.size()); });
+        const uint64_t shift = container(0, 0, 0, 0, 0, 0, 1, {0}, body);
+        for (size_t i = 0; i < f1.size(); i++) { crc_from.push_back(f1[i] + shift); crc_at.push_back(a1[i] + shift); }
+    }
+    for (size_t k = 0; k < ns; k++) {
+        const SliceParts &P = parts[k];
+        int32_t landmark = 0;
+        auto [body, f1, a1] = build([&] {
+            block(0, 1, 0, P.comp, P.comp_len, P.comp_len);                // compression header
+            landmark = (int32_t)o.size();
+            block(0, 2, 0, P.sh, P.sh_len, P.sh_len);                      // slice header (MAPPED_SLICE)
+            { const uint8_t none = 0; block(0, 5, 0, &none, 0, 0); }       // the CORE block: empty (every series is EXTERNAL)
+            for (size_t i = P.b0; i < P.b1; i++) block(cmeth[i], 4, blks[i].cid, cmeth[i] == 0 ? blks[i].p : cdata[i].data(), cmeth[i] == 0 ? blks[i].n : clen[i], blks[i].n);
+        });
+        const uint64_t shift = container(P.hdr.ref_seq_id, P.hdr.ref_seq_start, P.hdr.ref_seq_span, P.hdr.nrec, (uint64_t)k * records_per_slice, P.bases, (int32_t)(3 + (P.b1 - P.b0)), {landmark}, body);
+        for (size_t i = 0; i < f1.size(); i++) { crc_from.push_back(f1[i] + shift); crc_at.push_back(a1[i] + shift); }
+    }
+    {   // checksums, one batched device call (block CRCs cover header + payload, container CRCs the container header, cram_io.c:1547-1552, 3990-4010)
+        const size_t nc = crc_from.size();
+        std::vector<const uint8_t *> bp(nc); std::vector<uint32_t> bl(nc), crc(nc);
+        for (size_t i = 0; i < nc; i++) { bp[i] = o.data() + crc_from[i]; bl[i] = (uint32_t)(crc_at[i] - crc_from[i]); }
+        if (nc && (rc = hg_crc32_batch_host(ctx, bp.data(), bl.data(), nc, crc.data())) != HG_OK) return rc;
+        for (size_t i = 0; i < nc; i++) for (int b = 0; b < 4; b++) o[crc_at[i] + (size_t)b] = (uint8_t)(crc[i] >> (8 * b));
+    }
+    // the slice header's block count includes the CORE block: the encoder counted blocks + 1 already
+    static const uint8_t eof3[38] = {0x0f, 0x00, 0x00, 0x00, 0xff, 0xff, 0xff, 0xff, 0x0f, 0xe0, 0x45, 0x4f, 0x46, 0x00, 0x00, 0x00, 0x00, 0x01, 0x00, 0x05, 0xbd, 0xd9, 0x4f, 0x00, 0x01, 0x00, 0x06, 0x06,
+                                     0x01, 0x00, 0x01, 0x00, 0x01, 0x00, 0xee, 0x63, 0x01, 0x4b};      // cram_write_eof_block, CRAM 3 (cram_io.c:4320-4370)
+    o.insert(o.end(), eof3, eof3 + 38);
+    *cram_bytes = o.size();
+    if (o.size() > cram_cap) return HG_ENOMEM;
+    memcpy(cram_out, o.data(), o.size());
+    return HG_OK;
 }

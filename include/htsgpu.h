@@ -482,6 +482,15 @@ int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, 
 int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given,
                               uint8_t *bam_out, size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags, const char *name_prefix);
 
+/* The other direction: an uncompressed BAM stream (header + records, as bam_hdr_write / bam_write1 lay it out and as
+ * hg_cram_file_to_bam_host returns it) -> a CRAM 3.0 file: hg_cram_encode_slices_host for the records, every series block through the
+ * method auto-tuner with the CRAM 3.0 set GZIP | rANS 4x8 (the codec of this library that is pinned against the reference's fixtures),
+ * then cram_write_file_def / cram_write_SAM_hdr / cram_write_container / cram_write_block's framing with one slice per container and the
+ * EOF container.  records_per_slice 0 = 10 000, level <= 0 = 5.  Read back by hg_cram_file_to_bam_host (tests/test_cram_encode.py); the
+ * container / block layout follows the reference's writer, but no stock htslib was available to read these files here. */
+int hg_bam_to_cram_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, const hg_cram_ref_seq *refs, int nrefs_given,
+                        uint32_t records_per_slice, int level, uint8_t *cram_out, size_t cram_cap, uint64_t *cram_bytes, uint64_t *nrecords);
+
 /* The .crai text of one slice (cram_index_slice / cram_index_build_multiref, cram/cram_index.c:632-728): "ref start span container_pos
  * landmark slice_bytes" -- one line from the slice header, or, for a multi-reference slice, one line per run of records on the same
  * reference from the ref_id / apos / aend columns of hg_cram_decode_records_host (the arrays of THIS slice).  Returns the number of

@@ -236,3 +236,77 @@ def test_gpu_encoder_on_the_reference_fixtures(engine):
         assert [r[0] for r in one] == [r[0] for r in two], (f["file"], [(x[0], y[0]) for x, y in zip(one, two) if x[0] != y[0]][:1])
         done += len(one)
     assert done >= 200 and refused <= 6, (done, refused)
+
+
+def _file_to_bam(engine, cram, seqs, flags=0):
+    from htslib_amd import _native as nat
+    keep = [C.create_string_buffer(bytes(q), len(q)) if q is not None else None for q in seqs]
+    arr = (RefSeq * max(len(seqs), 1))(*[RefSeq(C.addressof(k), len(q)) if k is not None else RefSeq(None, 0) for k, q in zip(keep, seqs)])
+    out = np.zeros(max(1 << 22, len(cram) * 40), np.uint8); total = C.c_uint64(); n = C.c_uint64()
+    cb = C.create_string_buffer(cram, len(cram))
+    rc = nat.lib.hg_cram_file_to_bam_host2(engine._h, C.cast(cb, _vp), len(cram), C.cast(arr, _vp), len(seqs), out.ctypes.data, len(out), C.byref(total), C.byref(n), flags, None)
+    return rc, bytes(out[:total.value]), n.value
+
+
+def _bam_to_cram(engine, bam, seqs, per_slice=0):
+    from htslib_amd import _native as nat
+    keep = [C.create_string_buffer(bytes(q), len(q)) if q is not None else None for q in seqs]
+    arr = (RefSeq * max(len(seqs), 1))(*[RefSeq(C.addressof(k), len(q)) if k is not None else RefSeq(None, 0) for k, q in zip(keep, seqs)])
+    out = np.zeros(len(bam) * 2 + (1 << 20), np.uint8); total = C.c_uint64(); n = C.c_uint64()
+    b = C.create_string_buffer(bam, len(bam))
+    rc = nat.lib.hg_bam_to_cram_host(engine._h, C.cast(b, _vp), len(bam), C.cast(arr, _vp), len(seqs), per_slice, 5, out.ctypes.data, len(out), C.byref(total), C.byref(n))
+    return rc, bytes(out[:total.value]), n.value
+
+
+@pytest.mark.gpu
+def test_gpu_bam_to_cram_file_and_back(engine):
+    """whole files: the reference's CRAM fixtures -> BAM stream (hg_cram_file_to_bam_host) -> CRAM 3.0 file (hg_bam_to_cram_host: encoder, block auto-tuner
+    with gzip / rANS 4x8, container framing, EOF container) -> BAM stream again: identical bytes, header included.  Then a 150 bp synthetic BAM of 20 000
+    records in slices of 3 000 without a reference (every base stored)."""
+    import json
+    from htslib_amd import synth
+    ok = refused = 0
+    for f in json.load(open(T.GOLD)):
+        cram = T.unpack(f["cram"])
+        spans = {}
+        for s in f["slices"]:
+            for t, a, b, ln in s["refs"]:
+                spans.setdefault(t, (ln, []))[1].append((a, T.unpack(b)))
+        seqs = []
+        for i, name in enumerate(f["ref_names"]):
+            if f["full_refs"]: seqs.append(bytearray(T.unpack(dict(f["full_refs"])[name])))
+            elif i in spans:
+                sq = bytearray(b"N" * spans[i][0])
+                for a, b in spans[i][1]: sq[a - 1:a - 1 + len(b)] = b
+                seqs.append(sq)
+            else: seqs.append(None)
+        rc, bam, n = _file_to_bam(engine, cram, seqs)
+        assert rc == 0, f["file"]
+        rc2, cram2, n2 = _bam_to_cram(engine, bam, seqs)
+        if rc2 == -6: refused += 1; continue                            # a slice the encoder does not cover (CF_NO_SEQ, 511 distinct tags)
+        assert rc2 == 0 and n2 == n and cram2[:6] == b"CRAM\\x03\\x00" and cram2[-38:-34] == b"\\x0f\\x00\\x00\\x00", (f["file"], rc2)
+        rc3, bam3, n3 = _file_to_bam(engine, cram2, seqs)
+        assert rc3 == 0 and n3 == n, (f["file"], rc3)
+        assert bam3 == bam, f["file"]
+        ok += 1
+    assert ok >= 28 and refused <= 6, (ok, refused)
+    plain, _, _ = synth.bam_stream(6 << 20, 0x5EED0001, 0, True)
+    # cut at a record boundary: walk the records of the stream
+    import struct
+    lt = struct.unpack_from("<i", plain, 4)[0]; p = 8 + lt; nref = struct.unpack_from("<i", plain, p)[0]; p += 4
+    for _ in range(nref): p += 4 + struct.unpack_from("<i", plain, p)[0] + 4
+    q, nrec = p, 0
+    while q + 4 <= len(plain) and nrec < 20000:
+        nxt = q + 4 + struct.unpack_from("<i", plain, q)[0]
+        if nxt > len(plain): break
+        q = nxt; nrec += 1
+    bam = plain[:q]
+    rc, cram, n = _bam_to_cram(engine, bam, [None] * nref, 3000)
+    assert rc == 0 and n == nrec, rc
+    rc, back, n2 = _file_to_bam(engine, cram, [None] * nref)
+    assert rc == 0 and n2 == nrec
+    one, two = T._parse_bam_records(bam[p:]), T._parse_bam_records(back[p:])
+    assert back[:p] == bam[:p] and len(one) == len(two) == nrec
+    for x, y in zip(one, two):
+        assert x[0][:11] == y[0][:11] and sorted(x[0][11]) == sorted(y[0][11]), (x[0], y[0])   # RG:Z moves to the end of the tag list
+    print("synthetic BAM %d bytes -> CRAM %d bytes (%.2fx)" % (len(bam), len(cram), len(bam) / len(cram)))
