@@ -1042,6 +1042,48 @@ def op_records(run: Run, steps: int, slices: int = 256, nrec: int = 10000, cpu: 
     return out
 
 
+def op_encode(run: Run, steps: int, slices: int = 64, nrec: int = 10000):
+    """SURVEY 8f N2, write side: BAM records -> CRAM slices (hg_cram_encode_slices_host = cram_encode_slice + process_one_read on the device: survey, counting
+    walk, prefix sums, writing walk).  HOST entry point: the BAM goes up and the series blocks come back over PCIe inside the timed call.  Input = the
+    BAM stream the record decoder produced from synthetic slices; verified by decoding the slices again to the same stream."""
+    run.init_device()
+    import ctypes as C
+    import numpy as np
+    from htslib_amd import _native as nat, synth_cram
+    eng = nat.Engine(run.local)
+    rng = np.random.default_rng(7)
+    base = [synth_cram.make_slice(rng, nrec, 150)]                       # one slice replicated: every record aligns to the same reference
+    sl = [base[0] for i in range(slices)]
+    keep = []
+    arr = nat.cram_slice_array(sl, keep)
+    bases = slices * nrec * 150 + 4096
+    bam, rec_off, st = eng.cram_decode_bam(arr, slices, 3, 1, [], bases, slices * nrec * 420)
+    assert (st == 0).all()
+    bam = bytes(bam); n = slices * nrec
+    ref = base[0]["refs"][0][2]
+
+    class RefSeq(C.Structure):
+        _fields_ = [("bases", C.c_void_p), ("len", C.c_uint64)]
+    rb = C.create_string_buffer(ref, len(ref)); ra = (RefSeq * 1)(RefSeq(C.addressof(rb), len(ref)))
+    out = np.zeros(len(bam) * 2 + 65536 * slices, np.uint8); off = np.zeros(slices + 2, np.uint64); stt = np.zeros(slices + 1, np.int32); tot = C.c_uint64()
+    bb = C.create_string_buffer(bam, len(bam))
+    ts = []
+    steps = max(5, steps)
+    for _ in range(steps + 1):
+        t = time.perf_counter()
+        rc = nat.lib.hg_cram_encode_slices_host(eng._h, C.cast(bb, C.c_void_p), len(bam), n, nrec, C.cast(ra, C.c_void_p), 1, None, 0, 0, out.ctypes.data, len(out), off.ctypes.data, slices + 1,
+                                                stt.ctypes.data, C.byref(tot))
+        ts.append(time.perf_counter() - t)
+        assert rc == 0, rc
+    t = sorted(ts[1:])[len(ts[1:]) // 2]
+    return {"metric": "CRAM record encoding: BAM records -> slice series blocks (cram_encode_slice on the device), M records/s, host entry point incl. PCIe",
+            "value": round(n / t / 1e6, 3), "unit": "M records/s", "n_gpus": 1, "steps": steps, "warmup": 1, "ms_per_step": round(t * 1e3, 2), "higher_is_better": True, "dtype": "u8",
+            "data": "synthetic", "config": {"workload": "%d slices x %d records x 150 bp from a %.2f GB BAM stream; series blocks %.2f GB" % (slices, nrec, len(bam) / 1e9, tot.value / 1e9),
+                                            "bam_GBps": round(len(bam) / t / 1e9, 3), "parity": "writer: any valid CRAM is correct; tests/test_cram_encode.py decodes its output back to the same records / BAM bytes"},
+            "roofline": {"bound": "hbm", "achieved": round((len(bam) + tot.value) / t / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((len(bam) + tot.value) / t / 1e9 / HBM_PEAK_GBS, 6),
+                         "traffic": None, "kernel": "whole host call (PCIe both ways + three kernels); HG_CRAM_RECORDS_TIMING-style split in profiles/", "algorithmic_bytes": int(len(bam) + tot.value)}}
+
+
 def op_fqz(run: Run, steps: int, streams: int = 512):
     """fqzcomp (CRAM method 7) decode + encode through the host entry points: quality blocks of 2 000 x 150 bp reads."""
     run.init_device()
@@ -1106,7 +1148,7 @@ def main():
     ap.add_argument("--gib", type=float, default=10.0, help="plain GiB of synthetic BAM per GPU")
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--workers", type=int, default=0, help="host processes for workload preparation")
-    ap.add_argument("--op", choices=["all", "inflate", "deflate", "rans", "bam", "cram", "e2e", "records", "fqz"], default="all",
+    ap.add_argument("--op", choices=["all", "inflate", "deflate", "rans", "bam", "cram", "e2e", "records", "fqz", "encode"], default="all",
                     help="all (default) = inflate headline (BASELINE configs[1]) + `extra`: deflate (configs[2]), rans (configs[3]), "
                          "cram (configs[4] shape) and the end-to-end bgzf_read / bgzf_write figures, in ONE JSON line; "
                          "a single op prints that op's line alone; bam = SURVEY 8f N1 (record framing + nibble2base)")
@@ -1120,8 +1162,8 @@ def main():
     run = Run(args)
     ok = True
     out = None
-    if args.op in ("records", "fqz"):
-        out = op_records(run, args.steps, args.slices or 256) if args.op == "records" else op_fqz(run, args.steps, args.slices or 512)
+    if args.op in ("records", "fqz", "encode"):
+        out = op_records(run, args.steps, args.slices or 256) if args.op == "records" else op_encode(run, args.steps, args.slices or 64) if args.op == "encode" else op_fqz(run, args.steps, args.slices or 512)
     elif args.op in ("rans", "cram"):
         if args.op == "rans":
             out, ok = op_rans(run, args.steps, args.warmup, args.slices or 1000)
@@ -1161,7 +1203,7 @@ def main():
                 d, ok2 = op_cram(run, es, 256 if not args.slices else args.slices); ok = ok and ok2
                 if d: extra["cram_slices"] = d
                 if run.rank == 0 and run.world == 1:                         # the "next" rows of SURVEY 8f built this round: small, guarded probes
-                    for key, fn in (("cram_records_to_bam", lambda: op_records(run, 5)), ("cram_fqzcomp", lambda: op_fqz(run, 2, 256))):
+                    for key, fn in (("cram_records_to_bam", lambda: op_records(run, 5)), ("cram_records_encode", lambda: op_encode(run, 5)), ("cram_fqzcomp", lambda: op_fqz(run, 5, 256))):
                         try:
                             extra[key] = fn()
                         except Exception as e:

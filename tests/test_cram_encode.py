@@ -284,7 +284,7 @@ def test_gpu_bam_to_cram_file_and_back(engine):
         assert rc == 0, f["file"]
         rc2, cram2, n2 = _bam_to_cram(engine, bam, seqs)
         if rc2 == -6: refused += 1; continue                            # a slice the encoder does not cover (CF_NO_SEQ, 511 distinct tags)
-        assert rc2 == 0 and n2 == n and cram2[:6] == b"CRAM\\x03\\x00" and cram2[-38:-34] == b"\\x0f\\x00\\x00\\x00", (f["file"], rc2)
+        assert rc2 == 0 and n2 == n and cram2[:6] == b"CRAM\x03\x00" and cram2[-38:-34] == b"\x0f\x00\x00\x00", (f["file"], rc2)
         rc3, bam3, n3 = _file_to_bam(engine, cram2, seqs)
         assert rc3 == 0 and n3 == n, (f["file"], rc3)
         assert bam3 == bam, f["file"]
