@@ -10,7 +10,10 @@
 // The per-record walks are cram_encode_core.h, one source for host and device (CPU compile: tests/native/cram_records_host.cpp).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <string>
 #include <vector>
 #include "htsgpu.h"
@@ -18,6 +21,21 @@
 #include "hg_internal.h"
 #include "cram_records_dev.h"
 #include "cram_encode_plan.h"
+
+namespace {
+// HG_CRAM_RECORDS_TIMING=1: phase times of a call on stderr (stream-synchronising, for probes only)
+struct EncTimer {
+    bool on; hipStream_t s; std::chrono::steady_clock::time_point t0; std::string log;
+    EncTimer(hipStream_t st) : on(getenv("HG_CRAM_RECORDS_TIMING") != nullptr), s(st), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto t = std::chrono::steady_clock::now();
+        char b[96]; snprintf(b, sizeof b, " %s %.2f ms", what, std::chrono::duration<double, std::milli>(t - t0).count()); log += b; t0 = t;
+    }
+    ~EncTimer() { if (on) fprintf(stderr, "cram encode phases:%s\n", log.c_str()); }
+};
+}  // namespace
 
 namespace hgr {
 
@@ -95,12 +113,9 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
     if (out_bytes) *out_bytes = 0;
     if (!nrec) { slice_off[0] = 0; return HG_OK; }
     hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
-    // ---- frame the records (block_size fields), lay out references and read-group names
-    std::vector<uint64_t> rec_off;
-    rec_off.reserve(nrec + 1);
-    uint64_t at = 0;
-    for (size_t i = 0; i < nrec; i++) { if (at + 4 > bam_len) return HG_EINVAL; rec_off.push_back(at); at += 4ull + ld32(bam + at); if (at > bam_len) return HG_EINVAL; }
-    rec_off.push_back(at);
+    // ---- lay out references and read-group names (the records are framed on the device: a host walk of the block_size fields is one cache miss
+    //      per record, 50 ms for 640 k records -- more than everything else in this call)
+    std::vector<uint64_t> rec_off(nrec + 1);
     std::vector<EncRef> er((size_t)nrefs + 1); uint64_t dbytes = 0;
     for (int i = 0; i < nrefs; i++) { er[(size_t)i].off = dbytes; er[(size_t)i].len = refs[i].bases ? (int64_t)refs[i].len : 0; if (refs[i].bases) dbytes += (refs[i].len + 15) & ~15ull; }
     std::vector<uint8_t> rgn; std::vector<uint32_t> rgo((size_t)nrg + 1, 0);
@@ -115,12 +130,23 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
     const size_t N = (nrec + 16) & ~(size_t)15, nch = chunk_slice.size();
     hipStream_t s = ctx->stream;
     int rc;
+    EncTimer PT(s);
+    PT.mark("frame");
     // ---- device image 1: BAM, offsets, references, small tables
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_bam = 0, o_off = al(bam_len + 64), o_data = o_off + al((nrec + 1) * 8), o_end1 = o_data + al(dbytes + 64);
     if ((rc = hg::ensure_scratch(ctx, 0, o_end1))) return rc;
     uint8_t *d1 = (uint8_t *)ctx->d_scratch[0];
-    bool ok = hipMemcpyAsync(d1 + o_bam, bam, bam_len, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(d1 + o_off, rec_off.data(), (nrec + 1) * 8, hipMemcpyHostToDevice, s) == hipSuccess;
+    bool ok = hipMemcpyAsync(d1 + o_bam, bam, bam_len, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (ok) {                                                            // bam_read1's framing, exact (hg_bam_frame_dev verifies its per-chunk guesses link by link)
+        uint64_t bad = 0, end = bam_len;
+        const long got = hg_bam_frame_dev(ctx, d1 + o_bam, bam_len, 0, 0x7fffffff, (uint64_t *)(d1 + o_off), nrec, &bad, s);
+        if (got < 0) return got == HG_BAM_ETRUNC || got == HG_BAM_EINVALID ? HG_EINVAL : (int)got;
+        if ((size_t)got != nrec) return HG_EINVAL;
+        ok = hipMemcpyAsync(d1 + o_off + nrec * 8, &end, 8, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(rec_off.data(), d1 + o_off, nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipStreamSynchronize(s) == hipSuccess;
+        rec_off[nrec] = bam_len;
+    }
     for (int i = 0; i < nrefs && ok; i++) if (refs[i].bases && refs[i].len) ok = hipMemcpyAsync(d1 + o_data + er[(size_t)i].off, refs[i].bases, refs[i].len, hipMemcpyHostToDevice, s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
     size_t tb = 0;
@@ -143,6 +169,7 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
     E.slices = (const SliceDev *)(dt + t_sl); E.chunk_slice = (const uint32_t *)(dt + t_cs); E.chunk_r0 = (const uint32_t *)(dt + t_cr); E.nchunks = (uint32_t)nch;
     E.V = EncSurvey{(uint32_t *)(dt + t_keys), (uint64_t *)(dt + t_lh), (uint32_t *)(dt + t_lf)}; E.fail = (int32_t *)(dt + t_fail); E.stat = (SliceStat *)(dt + t_stat);
     E.N = N;
+    PT.mark("upload");
     // ---- survey
     hipLaunchKernelGGL(enc_survey_kernel, dim3((unsigned)nch), dim3(ENC_CHUNK), 0, s, E);
     std::vector<uint32_t> keytab(ns * ENC_KEY_SLOTS), lfirst(ns * ENC_LINE_SLOTS); std::vector<uint64_t> lhash(ns * ENC_LINE_SLOTS); std::vector<int32_t> fail(ns);
@@ -151,6 +178,7 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
          hipMemcpyAsync(fail.data(), dt + t_fail, ns * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipMemcpyAsync(stat.data(), dt + t_stat, ns * sizeof(SliceStat), hipMemcpyDeviceToHost, s) == hipSuccess &&
          hipStreamSynchronize(s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
+    PT.mark("survey");
     std::vector<uint32_t> k2, ko(ns + 1, 0), lo(ns + 1, 0); std::vector<uint64_t> l2; std::vector<int64_t> start(ns); std::vector<uint8_t> multi(ns);
     size_t ncmax = W_N;
     for (size_t k = 0; k < ns; k++) {
@@ -182,6 +210,7 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
     ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(tot.data(), d_tot, tot.size() * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
          hipMemcpyAsync(fail.data(), dt + t_fail, ns * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
+    PT.mark("count + sums");
     uint64_t blk_bytes = 0;
     for (size_t k = 0; k < ns; k++) {
         if (fail[k]) continue;
@@ -196,17 +225,18 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
     if (!ok) return HG_ELAUNCH;
     // ---- writing walk, blocks back
     hipLaunchKernelGGL(enc_walk_kernel<true>, dim3((unsigned)nch), dim3(ENC_CHUNK), 0, s, E);
-    std::vector<uint8_t> blk(blk_bytes + 64);
-    ok = hipGetLastError() == hipSuccess && (!blk_bytes || hipMemcpyAsync(blk.data(), E.out, blk_bytes, hipMemcpyDeviceToHost, s) == hipSuccess) &&
-         hipMemcpyAsync(fail.data(), dt + t_fail, ns * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(fail.data(), dt + t_fail, ns * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
-    // ---- headers + blobs
+    PT.mark("write");
+    // ---- headers + blobs: the blocks go from the device straight to their places in the caller's buffer (one pinned transfer, hg_stage.hip)
     uint64_t o = 0; bool any_bad = false, too_small = false;
+    std::vector<uint64_t> src_off; std::vector<uint32_t> src_len; std::vector<uint8_t *> dst;
     for (size_t k = 0; k < ns; k++) {
         slice_off[k] = o; status[k] = fail[k];
         if (fail[k]) { any_bad = true; continue; }
         std::vector<uint8_t> comp, sh; std::vector<std::pair<int32_t, uint32_t>> blocks;
-        enc_headers(S[k], bam, rec_off.data(), tot.data() + k * ncmax, record_counter0 + (int64_t)S[k].r0, comp, sh, blocks);
+        EncCtx H{}; H.bam = bam; H.rec_off = rec_off.data(); H.rg_names = rgn.data(); H.rg_off = rgo.data(); H.nrg = nrg;
+        enc_headers(S[k], H, tot.data() + k * ncmax, record_counter0 + (int64_t)S[k].r0, comp, sh, blocks);
         uint64_t need = 12 + comp.size() + sh.size();
         for (auto &b : blocks) need += 8 + tot[k * ncmax + b.second];
         if (o + need > out_cap) { too_small = true; o += need; continue; }
@@ -214,9 +244,16 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
         put32((uint32_t)comp.size()); memcpy(out + o, comp.data(), comp.size()); o += comp.size();
         put32((uint32_t)sh.size()); memcpy(out + o, sh.data(), sh.size()); o += sh.size();
         put32((uint32_t)blocks.size());
-        for (auto &b : blocks) { const uint64_t n = tot[k * ncmax + b.second]; put32((uint32_t)b.first); put32((uint32_t)n); memcpy(out + o, blk.data() + base[k * ncmax + b.second], n); o += n; }
+        for (auto &b : blocks) {
+            const uint64_t n = tot[k * ncmax + b.second];
+            put32((uint32_t)b.first); put32((uint32_t)n);
+            src_off.push_back(base[k * ncmax + b.second]); src_len.push_back((uint32_t)n); dst.push_back(out + o);
+            o += n;
+        }
     }
+    if (!src_off.empty() && (rc = hg::stage_download(ctx, E.out, src_off.data(), src_len.data(), dst.data(), src_off.size(), s)) != HG_OK) return rc;
     slice_off[ns] = o;
     if (out_bytes) *out_bytes = o;
+    PT.mark("headers + blocks back");
     return too_small ? HG_ENOMEM : any_bad ? HG_EBLOCK : HG_OK;
 }

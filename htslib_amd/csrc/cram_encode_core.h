@@ -91,6 +91,19 @@ struct EncCtx {
     int32_t *fail;                                                  // per slice: -1 malformed BAM record, -3 not covered
 };
 
+// an RG:Z tag naming one of the header's read groups becomes the RG series (cram_encode.c:2683-2700); -1: any other tag (an RG:Z value the header
+// does not list stays an ordinary tag, so nothing is lost)
+HGR_FN int32_t rg_index(const EncCtx &C, const uint8_t *a, uint32_t vs) {
+    if (!is_rg(a)) return -1;
+    for (int32_t k = 0; k < C.nrg; k++) {
+        const uint32_t ln = C.rg_off[k + 1] - C.rg_off[k];
+        bool same = ln + 1u == vs;
+        for (uint32_t i = 0; same && i < ln; i++) same = C.rg_names[C.rg_off[k] + i] == a[3 + i];
+        if (same) return k;
+    }
+    return -1;
+}
+
 // where a walk puts its values: counts (first walk) or bytes (second walk)
 template <bool WRITE> struct Sink {
     uint32_t n[W_N];                                                // counting: bytes so far
@@ -144,15 +157,9 @@ HGR_FN bool enc_record(const EncCtx &C, uint32_t r, int64_t prev_apos, bool mult
         if (B.end - a < 3) { *C.fail = -1; return false; }
         const uint32_t vs = aux_size(a[2], a + 3, B.end);
         if (!vs) { *C.fail = -1; return false; }
-        if (is_rg(a)) {
-            for (int32_t k = 0; k < C.nrg; k++) {
-                const uint32_t ln = C.rg_off[k + 1] - C.rg_off[k];
-                bool same = ln + 1u == vs;
-                for (uint32_t i = 0; same && i < ln; i++) same = C.rg_names[C.rg_off[k] + i] == a[3 + i];
-                if (same) { rg = k; break; }
-            }
-            if (rg < 0) { *C.fail = -3; return false; }                                          // a read group the header does not list (the reference adds it to the header)
-        } else {
+        const int32_t this_rg = rg_index(C, a, vs);
+        if (this_rg >= 0) rg = this_rg;
+        else {
             const uint32_t key = tag_key(a);
             lh = fnv_step(lh, key);
             const int32_t k = enc_find_key(C.keys, C.nkeys, key);
@@ -242,7 +249,7 @@ HGR_FN void enc_survey_record(const EncCtx &C, uint32_t r, const EncSurvey &V, u
         if (B.end - a < 3) { *C.fail = -1; return; }
         const uint32_t vs = aux_size(a[2], a + 3, B.end);
         if (!vs) { *C.fail = -1; return; }
-        if (!is_rg(a)) {
+        if (rg_index(C, a, vs) < 0) {
             const uint32_t key = tag_key(a);
             lh = fnv_step(lh, key);
             uint32_t *T = V.keys + (size_t)slice * ENC_KEY_SLOTS;
@@ -274,11 +281,4 @@ HGR_FN void enc_survey_record(const EncCtx &C, uint32_t r, const EncSurvey &V, u
     }
     *C.fail = -3;
 }
-// the same hash of a record's tag list as enc_record computes (RG:Z left out)
-HGR_FN uint64_t enc_list_hash(const BamRec &B) {
-    uint64_t lh = FNV0;
-    for (const uint8_t *a = B.aux; a + 3 <= B.end;) { const uint32_t vs = aux_size(a[2], a + 3, B.end); if (!vs) break; if (!is_rg(a)) lh = fnv_step(lh, tag_key(a)); a += 3u + vs; }
-    return lh ? lh : 1;
-}
-
 }  // namespace hgr

@@ -51,8 +51,9 @@ inline int32_t enc_tag_cid(uint32_t key, bool len_block) { return (int32_t)(key 
 
 // Headers of one slice.  tot[c] = bytes of column c (W_N series, then value / length column per key).  blocks: (content id, column) of every
 // non-empty block, in the order they are listed in the slice header.
-inline void enc_headers(const EncSlice &S, const uint8_t *bam, const uint64_t *rec_off, const uint64_t *tot, int64_t record_counter, std::vector<uint8_t> &comp,
+inline void enc_headers(const EncSlice &S, const EncCtx &C, const uint64_t *tot, int64_t record_counter, std::vector<uint8_t> &comp,
                         std::vector<uint8_t> &sh, std::vector<std::pair<int32_t, uint32_t>> &blocks) {
+    const uint8_t *bam = C.bam; const uint64_t *rec_off = C.rec_off;     // (host copies: only the first record of every tag list is looked at)
     using namespace enc;
     static const char *NAME[W_N] = {"BF", "CF", "RI", "RL", "AP", "RG", "RN", "MF", "NS", "NP", "TS", "TL", "FN", "FC", "FP", "DL", "BA", "BS", "IN", "SC", "HC", "PD", "RS", "MQ", "QS"};
     comp.clear(); sh.clear(); blocks.clear();
@@ -62,11 +63,11 @@ inline void enc_headers(const EncSlice &S, const uint8_t *bam, const uint64_t *r
         for (auto &k : kv) body.insert(body.end(), k, k + 3);
         body.push_back('S'); body.push_back('M'); for (int i = 0; i < 5; i++) body.push_back(0x1B);
         std::vector<uint8_t> td;
-        for (size_t l = 0; l < S.lfirst.size(); l++) {                      // the line = the tag keys of its first record, in that record's order (RG:Z left out)
+        for (size_t l = 0; l < S.lfirst.size(); l++) {                      // the line = the tag keys of its first record, in that record's order (an RG:Z that became the RG series left out)
             BamRec B;
             const uint64_t g = S.r0 + S.lfirst[l];
             if (bam_parse(bam, rec_off[g], rec_off[g + 1], B))
-                for (const uint8_t *a = B.aux; a + 3 <= B.end;) { const uint32_t vs = aux_size(a[2], a + 3, B.end); if (!vs) break; if (!is_rg(a)) td.insert(td.end(), a, a + 3); a += 3u + vs; }
+                for (const uint8_t *a = B.aux; a + 3 <= B.end;) { const uint32_t vs = aux_size(a[2], a + 3, B.end); if (!vs) break; if (rg_index(C, a, vs) < 0) td.insert(td.end(), a, a + 3); a += 3u + vs; }
             td.push_back(0);
         }
         if (S.lfirst.empty()) td.push_back(0);

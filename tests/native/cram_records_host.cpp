@@ -296,7 +296,7 @@ extern "C" long hgr_host_encode_slices(const uint8_t *bam, size_t bam_len, size_
         slice_off[k] = at; status[k] = fail[k];
         if (fail[k]) continue;
         std::vector<uint8_t> comp, sh; std::vector<std::pair<int32_t, uint32_t>> blocks;
-        enc_headers(S[k], bam, rec_off.data(), tot[k].data(), record_counter0 + (int64_t)S[k].r0, comp, sh, blocks);
+        enc_headers(S[k], ctx_of(k), tot[k].data(), record_counter0 + (int64_t)S[k].r0, comp, sh, blocks);
         uint64_t need = 12 + comp.size() + sh.size();
         for (auto &b : blocks) need += 8 + tot[k][b.second];
         if (at + need > cap) return -5;
