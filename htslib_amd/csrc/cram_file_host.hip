@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <tuple>
@@ -337,6 +338,11 @@ extern "C" int hg_bam_to_cram_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_l
         uint64_t need = 0;
         rc = hg_cram_encode_slices_host(ctx, bam + p, bam_len - p, nrec, records_per_slice, refs, nrefs_given, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), 0, blob.data(), blob.size(),
                                         soff.data(), ns + 1, sst.data(), &need);
+        if (rc == HG_ENOMEM && need > blob.size()) {                    // reads far from their reference (or no reference at all) store every base: several bytes per base
+            blob.resize(need + 64);
+            rc = hg_cram_encode_slices_host(ctx, bam + p, bam_len - p, nrec, records_per_slice, refs, nrefs_given, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), 0, blob.data(), blob.size(),
+                                            soff.data(), ns + 1, sst.data(), &need);
+        }
         if (rc != HG_OK) return rc;                                     // a slice the encoder does not cover fails the file
     }
     // ---- 3. every series block through the auto-tuner
@@ -444,4 +450,128 @@ extern "C" int hg_bam_to_cram_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_l
     if (o.size() > cram_cap) return HG_ENOMEM;
     memcpy(cram_out, o.data(), o.size());
     return HG_OK;
+}
+
+// ---- cram_index_build (reference cram/cram_index.c:779-870 over cram_index_container / cram_index_slice / cram_index_build_multiref :632-760): the .crai
+//      text of a whole CRAM file -- one line per slice ("ref start span container_offset slice_offset slice_bytes"), or one per run of records on the
+//      same reference for a multi-reference slice.  The container / block walk is host code (a few bytes per block); only multi-reference slices are
+//      decoded: their blocks through cram_uncompress_block and their records through the record decoder (ref_id / apos / aend columns) in one batch
+//      each.  The reference writes the text through bgzf_open(fn, "wg") (gzip); this returns the text, the caller compresses it (hg_gzip_deflate_host).
+extern "C" long hg_cram_index_build_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, char *out, size_t cap) {
+    if (!ctx || !cram || !out) return HG_EINVAL;
+    if (cram_len < 26 || memcmp(cram, "CRAM", 4) != 0) return HG_EINVAL;
+    const int major = cram[4];
+    if (major != 2 && major != 3) return HG_BLOCK_EUNSUPPORTED;
+    struct SliceAt { int64_t cpos; int32_t landmark, bytes; size_t hdr; std::vector<size_t> body; size_t comp; };
+    std::vector<Blk> blocks; std::vector<SliceAt> slices;
+    hgr::Cursor c{cram + 26, cram + cram_len};
+    bool first = true;
+    while (c.p < c.end) {
+        const int64_t cpos = c.p - cram;
+        if (c.end - c.p < 4) return HG_EINVAL;
+        const uint32_t clen = (uint32_t)c.p[0] | (uint32_t)c.p[1] << 8 | (uint32_t)c.p[2] << 16 | (uint32_t)c.p[3] << 24; c.p += 4;
+        (void)c.itf8(); (void)c.itf8(); (void)c.itf8(); (void)c.itf8();
+        if (major >= 3) (void)c.ltf8(); else (void)c.itf8();
+        (void)c.ltf8();
+        const int32_t nblk = c.itf8(), nland = c.itf8();
+        for (int32_t i = 0; i < nland; i++) (void)c.itf8();
+        if (major >= 3) c.p += 4;
+        if (c.bad || nblk < 0 || c.p > c.end || (size_t)(c.end - c.p) < clen) return HG_EINVAL;
+        const uint8_t *region = c.p, *cend = c.p + clen;
+        hgr::Cursor b{c.p, cend};
+        size_t comp = (size_t)-1; bool in_slice = false;
+        for (int32_t k = 0; k < nblk && b.p < b.end && !first; k++) {      // (the first container holds the SAM header)
+            const uint8_t *h0 = b.p;
+            Blk x; memset(&x, 0, sizeof x);
+            x.method = b.byte(); x.ctype = b.byte(); x.cid = b.itf8(); x.csz = (uint32_t)b.itf8(); x.usz = (uint32_t)b.itf8();
+            if (b.bad || (size_t)(b.end - b.p) < (size_t)x.csz + (major >= 3 ? 4u : 0u)) return HG_EINVAL;
+            x.crc_part = crc32_small(h0, (size_t)(b.p - h0));
+            x.data = b.p; b.p += x.csz;
+            if (major >= 3) { x.crc = (uint32_t)b.p[0] | (uint32_t)b.p[1] << 8 | (uint32_t)b.p[2] << 16 | (uint32_t)b.p[3] << 24; b.p += 4; }
+            blocks.push_back(x);
+            const size_t me = blocks.size() - 1;
+            const int32_t nbytes = (int32_t)(b.p - h0);
+            if (x.ctype == 1) comp = me;
+            else if (x.ctype == 2 || x.ctype == 3) { slices.push_back(SliceAt{cpos, (int32_t)(h0 - region), nbytes, me, {}, comp}); in_slice = true; }
+            else if ((x.ctype == 4 || x.ctype == 5) && in_slice) { slices.back().body.push_back(me); slices.back().bytes += nbytes; }
+        }
+        first = false;
+        c.p = cend;
+    }
+    // slice headers are small RAW / gzip blocks: decode them (and, for multi-reference slices, everything they need) in one batch
+    std::vector<size_t> want;
+    for (auto &s : slices) { want.push_back(s.hdr); }
+    std::vector<std::vector<uint8_t>> dec(blocks.size());
+    auto decode_blocks = [&](const std::vector<size_t> &idx) -> int {
+        const size_t n = idx.size();
+        if (!n) return HG_OK;
+        std::vector<int32_t> method(n), status(n); std::vector<const uint8_t *> in(n); std::vector<uint32_t> il(n), ol(n), part(n), crc(n); std::vector<uint8_t *> o(n);
+        for (size_t i = 0; i < n; i++) {
+            const Blk &x = blocks[idx[i]];
+            dec[idx[i]].resize(x.usz ? x.usz : 1);
+            method[i] = x.method; in[i] = x.data; il[i] = x.csz; ol[i] = x.usz; o[i] = dec[idx[i]].data(); part[i] = x.crc_part; crc[i] = x.crc;
+        }
+        return major >= 3 ? hg_cram_uncompress_blocks_crc_host(ctx, n, method.data(), in.data(), il.data(), part.data(), crc.data(), o.data(), ol.data(), status.data())
+                          : hg_cram_uncompress_blocks_host(ctx, n, method.data(), in.data(), il.data(), o.data(), ol.data(), status.data());
+    };
+    int rc = decode_blocks(want);
+    if (rc != HG_OK) return rc;
+    std::vector<hgr::SliceHeader> sh(slices.size());
+    std::vector<size_t> multi;
+    want.clear();
+    for (size_t i = 0; i < slices.size(); i++) {
+        if (hgr::parse_slice_header(dec[slices[i].hdr].data(), blocks[slices[i].hdr].usz, major, sh[i])) return HG_EINVAL;
+        if (sh[i].ref_seq_id == -2) {
+            multi.push_back(i);
+            if (slices[i].comp == (size_t)-1) return HG_EINVAL;
+            want.push_back(slices[i].comp);
+            for (size_t k : slices[i].body) want.push_back(k);
+        }
+    }
+    std::sort(want.begin(), want.end()); want.erase(std::unique(want.begin(), want.end()), want.end());
+    if ((rc = decode_blocks(want)) != HG_OK) return rc;
+    // records of the multi-reference slices: ref_id / apos / aend
+    std::vector<int32_t> ref_id; std::vector<int64_t> apos, aend; std::vector<uint64_t> rec_off(multi.size() + 1, 0);
+    if (!multi.empty()) {
+        const size_t nm = multi.size();
+        std::vector<hg_cram_slice_blocks> sb(nm);
+        std::vector<std::vector<int32_t>> ids(nm); std::vector<std::vector<const uint8_t *>> ptr(nm); std::vector<std::vector<uint32_t>> len(nm);
+        for (size_t j = 0; j < nm; j++) {
+            const SliceAt &s = slices[multi[j]];
+            memset(&sb[j], 0, sizeof sb[j]);
+            sb[j].comp_hdr = dec[s.comp].data(); sb[j].comp_hdr_len = blocks[s.comp].usz; sb[j].slice_hdr = dec[s.hdr].data(); sb[j].slice_hdr_len = blocks[s.hdr].usz;
+            size_t taken = 0;
+            for (size_t k : s.body) {
+                if ((int32_t)taken >= sh[multi[j]].nblocks) break;
+                taken++;
+                if (blocks[k].ctype == 5) { sb[j].core = dec[k].data(); sb[j].core_len = blocks[k].usz; continue; }
+                ids[j].push_back(blocks[k].cid); ptr[j].push_back(dec[k].data()); len[j].push_back(blocks[k].usz);
+            }
+            sb[j].nblocks = (uint32_t)ids[j].size(); sb[j].content_id = ids[j].data(); sb[j].data = ptr[j].data(); sb[j].len = len[j].data(); sb[j].decode_md = 0;
+        }
+        uint64_t nrec = 0, cc = 0, nc = 0, ac = 0;
+        if ((rc = hg_cram_records_bound(nm, sb.data(), major, &nrec, &cc, &nc, &ac)) != HG_OK) return rc;
+        ref_id.resize(nrec + 1); apos.resize(nrec + 1); aend.resize(nrec + 1);
+        hg_cram_record_cols cols; memset(&cols, 0, sizeof cols);
+        cols.ref_id = ref_id.data(); cols.apos = apos.data(); cols.aend = aend.data();
+        std::vector<int32_t> st(nm);
+        rc = hg_cram_decode_records_host(ctx, nm, sb.data(), major, 0x7fffffff, (size_t)nrec + 1, (size_t)-1, (size_t)-1, 0, 0, &cols, rec_off.data(), st.data(), nullptr);
+        if (rc != HG_OK) return rc;
+    }
+    // the lines, in file order; "CRAM file is not sorted by chromosome / position" like the reference (per container there, per slice here)
+    size_t n = 0, mj = 0;
+    int64_t last_ref = -9, last_start = -9;
+    for (size_t i = 0; i < slices.size(); i++) {
+        const SliceAt &s = slices[i];
+        if (sh[i].ref_seq_id == last_ref && sh[i].ref_seq_start < last_start) return -2;
+        last_ref = sh[i].ref_seq_id; last_start = sh[i].ref_seq_start;
+        const bool is_multi = sh[i].ref_seq_id == -2;
+        const uint64_t r0 = is_multi ? rec_off[mj] : 0;
+        const long got = hg_cram_crai_slice(dec[s.hdr].data(), blocks[s.hdr].usz, major, is_multi ? ref_id.data() + r0 : nullptr, is_multi ? apos.data() + r0 : nullptr,
+                                            is_multi ? aend.data() + r0 : nullptr, s.cpos, s.landmark, s.bytes, out + n, cap - n);
+        if (is_multi) mj++;
+        if (got < 0) return got;
+        n += (size_t)got;
+    }
+    return (long)n;
 }

@@ -482,6 +482,12 @@ int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, 
 int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given,
                               uint8_t *bam_out, size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags, const char *name_prefix);
 
+/* cram_index_build (cram/cram_index.c:779-870): the .crai text of a whole CRAM 2.x / 3.x file, one line per slice -- or per run of records on one
+ * reference for multi-reference slices, which are the only slices decoded (blocks + the ref_id / apos / aend columns, one batch each).
+ * Returns the number of bytes written, -2 for a file that is not sorted (the reference's error), or a negative HG_E* code.  The reference
+ * gzips the text (bgzf "wg"); compress with hg_gzip_deflate_host when a .crai file is wanted. */
+long hg_cram_index_build_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, char *out, size_t cap);
+
 /* The other direction: an uncompressed BAM stream (header + records, as bam_hdr_write / bam_write1 lay it out and as
  * hg_cram_file_to_bam_host returns it) -> a CRAM 3.0 file: hg_cram_encode_slices_host for the records, every series block through the
  * method auto-tuner with the CRAM 3.0 set GZIP | rANS 4x8 (the codec of this library that is pinned against the reference's fixtures),

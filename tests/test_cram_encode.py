@@ -63,7 +63,7 @@ def encode_host(L, bam, nrec, per_slice, refs, rg_names=(), counter=0):
     arr = (RefSeq * max(len(refs), 1))(*[RefSeq(C.addressof(k), len(r)) if k is not None else RefSeq(None, 0) for k, r in zip(keep, refs)])
     rg = [r.encode() for r in rg_names]; rgp = (C.c_char_p * max(len(rg), 1))(*rg)
     ns = (nrec + per_slice - 1) // per_slice
-    out = np.zeros(len(bam) * 2 + 65536 * ns + 4096, np.uint8); off = np.zeros(ns + 2, np.uint64); st = np.full(ns + 1, 9, np.int32)
+    out = np.zeros(len(bam) * 6 + 65536 * ns + 4096, np.uint8); off = np.zeros(ns + 2, np.uint64); st = np.full(ns + 1, 9, np.int32)
     L.hgr_host_encode_slices.restype = C.c_long
     L.hgr_host_encode_slices.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_uint32, _vp, C.c_int, _vp, C.c_int, C.c_int64, _vp, C.c_size_t, _vp, C.c_size_t, _vp]
     n = L.hgr_host_encode_slices(bam, len(bam), nrec, per_slice, C.cast(arr, _vp), len(refs), C.cast(rgp, _vp), len(rg), counter, out.ctypes.data, len(out), off.ctypes.data, ns + 1, st.ctypes.data)
@@ -158,7 +158,7 @@ def encode_gpu(engine, bam, nrec, per_slice, refs, rg_names=(), counter=0):
     arr = (RefSeq * max(len(refs), 1))(*[RefSeq(C.addressof(k), len(r)) if k is not None else RefSeq(None, 0) for k, r in zip(keep, refs)])
     rg = [r.encode() if isinstance(r, str) else r for r in rg_names]; rgp = (C.c_char_p * max(len(rg), 1))(*rg)
     ns = (nrec + per_slice - 1) // per_slice
-    out = np.zeros(len(bam) * 2 + 65536 * ns + 4096, np.uint8); off = np.zeros(ns + 2, np.uint64); st = np.full(ns + 1, 9, np.int32); total = C.c_uint64()
+    out = np.zeros(len(bam) * 6 + 65536 * ns + 4096, np.uint8); off = np.zeros(ns + 2, np.uint64); st = np.full(ns + 1, 9, np.int32); total = C.c_uint64()
     b = C.create_string_buffer(bam, len(bam))
     rc = nat.lib.hg_cram_encode_slices_host(engine._h, C.cast(b, _vp), len(bam), nrec, per_slice, C.cast(arr, _vp), len(refs), C.cast(rgp, _vp) if rg else None, len(rg), counter,
                                             out.ctypes.data, len(out), off.ctypes.data, ns + 1, st.ctypes.data, C.byref(total))
