@@ -58,7 +58,7 @@ struct bgzidx_t {                      // behind fp->idx; opaque to callers (bgz
 
 namespace {
 
-constexpr int NPIPES = 3;
+constexpr int NPIPES_MIN = 3, NPIPES_MAX = 16;     // pipes per handle: 3 on one device, 2 per device on several (HTS_GPU_DEVICES)
 constexpr size_t WINDOW_MIN = 256u << 10;      // compressed bytes of the first batch after open / seek
 constexpr size_t WINDOW_MAX = 32u << 20;
 constexpr uint64_t PLAIN_MAX = 768ull << 20;   // plain bytes per batch (highly compressible input)
@@ -94,6 +94,24 @@ bool bgzf_header_ok(const uint8_t *h) {   // check_header, bgzf.c:896-903
 }
 
 int device_choice() { const char *d = getenv("HTS_GPU_DEVICE"); return d ? atoi(d) : 0; }
+// HTS_GPU_DEVICES = "0-7" / "0,2,5" / "4": the devices a handle spreads its batches over (north_star: "independent blocks are sharded across the GPUs of
+// one node with a trivial static split").  Each batch (window of whole blocks) is one job on one device's pipe; the pipes rotate, so consecutive windows go
+// to consecutive devices and come back in submission order -- no collective, no cross-device traffic.  Unset: the one device of HTS_GPU_DEVICE.
+std::vector<int> device_list() {
+    std::vector<int> v;
+    const char *d = getenv("HTS_GPU_DEVICES");
+    if (d) {
+        for (const char *p = d; *p;) {
+            if (*p < '0' || *p > '9') { p++; continue; }
+            char *q; const long a = strtol(p, &q, 10); long b = a;
+            if (*q == '-') { b = strtol(q + 1, &q, 10); }
+            for (long x = a; x <= b && v.size() < 64; x++) v.push_back((int)x);
+            p = q;
+        }
+    }
+    if (v.empty()) v.push_back(device_choice());
+    return v;
+}
 
 // process-wide context for the stateless entry points (bgzf_compress, hts_crc32); its host calls lock it
 hg_ctx *shared_ctx() {
@@ -130,7 +148,9 @@ enum Kind { K_READ, K_WRITE, K_GZREAD, K_GZWRITE };
 struct Engine {
     BGZF *fp = nullptr;
     Kind kind = K_READ;
-    hg_ctx *gpu = nullptr;
+    hg_ctx *gpu = nullptr;                 // first device (stateless helpers: gzip streams, CRCs)
+    std::vector<hg_ctx *> devs;            // every device of the handle; pipe i lives on devs[i % devs.size()]
+    int NPIPES = NPIPES_MIN;
     void *own_block = nullptr;     // the malloc'd 128 KiB block (fp->uncompressed_block is re-pointed by readers)
     std::thread th;
     bool started = false;
@@ -138,13 +158,13 @@ struct Engine {
     std::condition_variable cv;
     bool stop = false;
     // ---------------- reader
-    ReadBatch rb[NPIPES];
+    ReadBatch rb[NPIPES_MAX];
     uint64_t fill_seq = 0, done_seq = 0;   // batches filled by the I/O thread / released by the consumer
-    bool cur_loaded = false;               // rb[done_seq % NPIPES] has been waited for and is being consumed
+    bool cur_loaded = false;               // rb[done_seq % e->NPIPES] has been waited for and is being consumed
     bool input_done = false;               // the I/O thread met EOF or a fatal input error
     bool pause_req = false, paused = false;
     size_t window = WINDOW_MIN;
-    size_t ahead = NPIPES;                 // batches the I/O thread may run ahead: 1 after a seek until the consumer shows
+    size_t ahead = NPIPES_MIN;             // batches the I/O thread may run ahead: 1 after a seek until the consumer shows
                                            // that it is scanning (a random-access caller reads a few bytes and seeks again)
     std::vector<uint8_t> carry;            // bytes of a block cut by the window end
     int64_t read_off = 0;                  // file offset of carry[0] / of the next byte to hread
@@ -153,9 +173,9 @@ struct Engine {
     int64_t next_addr = 0;                 // file offset of the block after the current one
     bool eof_seen = false;
     // ---------------- writer
-    WriteBatch wb[NPIPES];
+    WriteBatch wb[NPIPES_MAX];
     uint64_t w_fill = 0, w_done = 0;       // batches submitted / written out
-    bool w_open = false;                   // wb[w_fill % NPIPES] is being filled
+    bool w_open = false;                   // wb[w_fill % e->NPIPES] is being filled
     size_t w_target = WBLOCKS_MIN;
     int64_t block_address = 0;             // compressed bytes written so far (owned by the output thread)
     int w_err = 0;                         // BGZF_ERR_* raised by the output thread
@@ -241,7 +261,7 @@ void reader_main(Engine *e) {
             e->paused = false;
             continue;
         }
-        ReadBatch &b = e->rb[e->fill_seq % NPIPES];
+        ReadBatch &b = e->rb[e->fill_seq % e->NPIPES];
         lk.unlock();
         const bool finished = fill_batch(e, b);
         lk.lock();
@@ -253,7 +273,7 @@ void reader_main(Engine *e) {
 
 bool start_reader(Engine *e) {
     if (e->started) return true;
-    for (auto &b : e->rb) if (!b.pipe && hg_pipe_create(e->gpu, &b.pipe) != HG_OK) return false;
+    for (int i = 0; i < e->NPIPES; i++) if (!e->rb[i].pipe && hg_pipe_create(e->devs[(size_t)i % e->devs.size()], &e->rb[i].pipe) != HG_OK) return false;
     e->read_off = hg_htell(e->fp->fp);
     e->started = true;
     e->th = std::thread(reader_main, e);
@@ -273,7 +293,7 @@ int restart_reader_at(Engine *e, int64_t addr) {
     std::unique_lock<std::mutex> lk(e->m);
     pause_reader(e, lk);
     for (uint64_t s = e->done_seq + (e->cur_loaded ? 1 : 0); s < e->fill_seq; s++) {
-        ReadBatch &b = e->rb[s % NPIPES];
+        ReadBatch &b = e->rb[s % e->NPIPES];
         if (b.submitted) { (void)hg_pipe_wait(b.pipe, nullptr, nullptr, nullptr, nullptr, nullptr); b.submitted = false; }
     }
     e->fill_seq = e->done_seq = 0; e->cur_loaded = false;
@@ -296,9 +316,9 @@ int restart_reader_at(Engine *e, int64_t addr) {
 
 // The consumer has moved past the first blocks after a seek: it is scanning, let the I/O thread run ahead again.
 inline void widen_readahead(Engine *e) {
-    if (e->ahead >= NPIPES) return;
+    if (e->ahead >= e->NPIPES) return;
     std::lock_guard<std::mutex> lk(e->m);
-    e->ahead = NPIPES; e->cv.notify_all();
+    e->ahead = e->NPIPES; e->cv.notify_all();
 }
 
 // Make the next batch current.  Returns 1 = batch loaded, 0 = end of input, -1 = error (errcode set).
@@ -306,10 +326,10 @@ int next_batch(Engine *e) {
     BGZF *fp = e->fp;
     if (!start_reader(e)) { fp->errcode |= BGZF_ERR_IO; return -1; }
     std::unique_lock<std::mutex> lk(e->m);
-    if (e->cur_loaded) { e->cur_loaded = false; e->done_seq++; e->ahead = NPIPES; e->cv.notify_all(); }
+    if (e->cur_loaded) { e->cur_loaded = false; e->done_seq++; e->ahead = e->NPIPES; e->cv.notify_all(); }
     e->cv.wait(lk, [&] { return e->done_seq < e->fill_seq || e->input_done; });
     if (e->done_seq == e->fill_seq) return 0;
-    ReadBatch &b = e->rb[e->done_seq % NPIPES];
+    ReadBatch &b = e->rb[e->done_seq % e->NPIPES];
     lk.unlock();
     b.plain = nullptr; b.status = nullptr; b.good = 0;
     if (b.submitted) {
@@ -325,7 +345,7 @@ int next_batch(Engine *e) {
     return 1;
 }
 
-inline ReadBatch &cur_batch(Engine *e) { return e->rb[e->done_seq % NPIPES]; }
+inline ReadBatch &cur_batch(Engine *e) { return e->rb[e->done_seq % e->NPIPES]; }
 
 // Bookkeeping for a block the consumer steps onto or over (bgzf.c:1066-1076).
 inline void note_block(BGZF *fp, const ReadBatch &b, size_t i) {
@@ -368,7 +388,7 @@ int engine_read_block(BGZF *fp) {
                 return -1;
             }
             std::unique_lock<std::mutex> lk(e->m);
-            e->cur_loaded = false; e->done_seq++; e->ahead = NPIPES; e->cv.notify_all();
+            e->cur_loaded = false; e->done_seq++; e->ahead = e->NPIPES; e->cv.notify_all();
             continue;
         }
         const hg_bgzf_desc &d = b.desc[e->blk];
@@ -588,7 +608,7 @@ void writer_main(Engine *e) {
     for (;;) {
         e->cv.wait(lk, [&] { return e->stop || e->w_done < e->w_fill; });
         if (e->w_done >= e->w_fill) { if (e->stop) break; continue; }
-        WriteBatch &b = e->wb[e->w_done % NPIPES];
+        WriteBatch &b = e->wb[e->w_done % e->NPIPES];
         lk.unlock();
         const uint8_t *out = nullptr; size_t out_len = 0; const uint64_t *off = nullptr; const uint32_t *crc = nullptr;
         int err = 0;
@@ -621,7 +641,7 @@ void writer_main(Engine *e) {
 
 bool start_writer(Engine *e) {
     if (e->started) return true;
-    for (auto &b : e->wb) if (!b.pipe && hg_pipe_create(e->gpu, &b.pipe) != HG_OK) return false;
+    for (int i = 0; i < e->NPIPES; i++) if (!e->wb[i].pipe && hg_pipe_create(e->devs[(size_t)i % e->devs.size()], &e->wb[i].pipe) != HG_OK) return false;
     e->started = true;
     e->th = std::thread(writer_main, e);
     return true;
@@ -631,7 +651,7 @@ bool start_writer(Engine *e) {
 int submit_write_batch(Engine *e) {
     BGZF *fp = e->fp;
     if (!e->w_open) return 0;
-    WriteBatch &b = e->wb[e->w_fill % NPIPES];
+    WriteBatch &b = e->wb[e->w_fill % e->NPIPES];
     e->w_open = false;
     if (b.cuts.size() <= 1) return 0;
     int level = fp->compress_level < 0 ? 6 : fp->compress_level;
@@ -652,10 +672,10 @@ int queue_block(BGZF *fp) {
     if (!start_writer(e)) { fp->errcode |= BGZF_ERR_IO; return -1; }
     if (!e->w_open) {
         std::unique_lock<std::mutex> lk(e->m);
-        e->cv.wait(lk, [&] { return e->w_fill - e->w_done < NPIPES; });
+        e->cv.wait(lk, [&] { return e->w_fill - e->w_done < e->NPIPES; });
         if (e->w_err) { fp->errcode |= e->w_err; return -1; }
         lk.unlock();
-        WriteBatch &b = e->wb[e->w_fill % NPIPES];
+        WriteBatch &b = e->wb[e->w_fill % e->NPIPES];
         b.target = fp->mt ? e->w_target : 1;                               // exact mode: one block per job
         if (fp->mt && e->w_target < WBLOCKS_MAX) e->w_target *= 2;
         b.cap = b.target * (size_t)BGZF_BLOCK_SIZE;
@@ -664,7 +684,7 @@ int queue_block(BGZF *fp) {
         b.len = 0; b.cuts.assign(1, 0);
         e->w_open = true;
     }
-    WriteBatch &b = e->wb[e->w_fill % NPIPES];
+    WriteBatch &b = e->wb[e->w_fill % e->NPIPES];
     memcpy(b.in + b.len, fp->uncompressed_block, (size_t)fp->block_offset);
     b.len += (size_t)fp->block_offset;
     b.cuts.push_back(b.len);
@@ -705,7 +725,8 @@ void stop_engine(Engine *e) {
     }
     for (auto &b : e->rb) if (b.pipe) { if (b.submitted) (void)hg_pipe_wait(b.pipe, nullptr, nullptr, nullptr, nullptr, nullptr); hg_pipe_destroy(b.pipe); b.pipe = nullptr; }
     for (auto &b : e->wb) if (b.pipe) { hg_pipe_destroy(b.pipe); b.pipe = nullptr; }
-    if (e->gpu) { hg_destroy(e->gpu); e->gpu = nullptr; }
+    for (hg_ctx *c : e->devs) hg_destroy(c);
+    e->devs.clear(); e->gpu = nullptr;
 }
 
 void free_handle(BGZF *fp) {
@@ -725,7 +746,14 @@ int mode_level(const char *mode) {            // first digit = level, 'u' = no c
 Engine *new_engine(BGZF *fp, Kind kind) {
     Engine *e = new Engine();
     e->fp = fp; e->kind = kind;
-    if (hg_init(device_choice(), &e->gpu) != HG_OK) { delete e; errno = ENODEV; return nullptr; }
+    for (int d : device_list()) {
+        hg_ctx *c = nullptr;
+        if (hg_init(d, &c) != HG_OK) { for (hg_ctx *x : e->devs) hg_destroy(x); delete e; errno = ENODEV; return nullptr; }
+        e->devs.push_back(c);
+    }
+    e->gpu = e->devs[0];
+    e->NPIPES = e->devs.size() == 1 ? NPIPES_MIN : (int)std::min<size_t>(2 * e->devs.size(), (size_t)NPIPES_MAX);
+    e->ahead = (size_t)e->NPIPES;
     e->own_block = fp->uncompressed_block;
     fp->cache = reinterpret_cast<bgzf_cache_t *>(e);
     if (kind == K_READ || kind == K_GZREAD) fp->mt = reinterpret_cast<struct bgzf_mtaux_t *>(e);

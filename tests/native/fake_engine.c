@@ -10,20 +10,31 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 #include <zlib.h>
 #include "htsgpu.h"
 
-struct hg_ctx { int dummy; };
+/* "devices": the double has as many as HTS_GPU_DEVICES names; FAKE_ENGINE_REPORT=1 prints how many batches each one got when the process ends
+ * (tests/test_front_host_logic.py: a handle spreads its windows over all devices and still delivers them in order) */
+struct hg_ctx { int device; };
+static long g_jobs[64];
+static void report(void) { if (getenv("FAKE_ENGINE_REPORT")) { fprintf(stderr, "fake_engine jobs per device:"); for (int i = 0; i < 64; i++) if (g_jobs[i]) fprintf(stderr, " %d=%ld", i, g_jobs[i]); fprintf(stderr, "\n"); } }
 struct hg_pipe {
+    int device;
     uint8_t *in; size_t in_cap;
     uint8_t *out; size_t out_cap, out_len;
     int32_t *status; uint64_t *off; uint32_t *crc;
     size_t n; int kind;
 };
 
-int hg_init(int device, hg_ctx **ctx) { (void)device; *ctx = calloc(1, sizeof(hg_ctx)); return *ctx ? HG_OK : HG_ENOMEM; }
+int hg_init(int device, hg_ctx **ctx) {
+    static int once; if (!once) { once = 1; atexit(report); }
+    if (device < 0 || device >= 64) return HG_ENODEV;
+    *ctx = calloc(1, sizeof(hg_ctx)); if (*ctx) (*ctx)->device = device;
+    return *ctx ? HG_OK : HG_ENOMEM;
+}
 void hg_destroy(hg_ctx *ctx) { free(ctx); }
-int hg_pipe_create(hg_ctx *ctx, hg_pipe **p) { (void)ctx; *p = calloc(1, sizeof(hg_pipe)); return *p ? HG_OK : HG_ENOMEM; }
+int hg_pipe_create(hg_ctx *ctx, hg_pipe **p) { *p = calloc(1, sizeof(hg_pipe)); if (*p) (*p)->device = ctx->device; return *p ? HG_OK : HG_ENOMEM; }
 void hg_pipe_destroy(hg_pipe *p) { if (!p) return; free(p->in); free(p->out); free(p->status); free(p->off); free(p->crc); free(p); }
 
 void *hg_pipe_input(hg_pipe *p, size_t bytes) {
@@ -39,6 +50,7 @@ static int grow_out(hg_pipe *p, size_t need) {
 int hg_pipe_inflate(hg_pipe *p, size_t comp_len, const hg_bgzf_desc *desc, size_t n) {
     uint64_t plain = 0;
     (void)comp_len;
+    __sync_fetch_and_add(&g_jobs[p->device], 1);
     for (size_t i = 0; i < n; i++) plain += desc[i].ulen;
     if (grow_out(p, plain + 64)) return HG_ENOMEM;
     free(p->status); p->status = calloc(n ? n : 1, sizeof(int32_t));
@@ -61,6 +73,7 @@ int hg_pipe_inflate(hg_pipe *p, size_t comp_len, const hg_bgzf_desc *desc, size_
 
 int hg_pipe_deflate(hg_pipe *p, size_t len, const uint64_t *cuts, size_t n, int level, int raw) {
     (void)len;
+    __sync_fetch_and_add(&g_jobs[p->device], 1);
     if (grow_out(p, n * 65536 + 64)) return HG_ENOMEM;
     free(p->off); free(p->crc);
     p->off = calloc(n + 1, 8); p->crc = calloc(n ? n : 1, 4);

@@ -56,3 +56,29 @@ def test_large_reads_go_through_the_copy_helpers(progs, tmp_path):
     out = subprocess.run([exe, str(gz)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     assert out.stdout == data
+
+
+def test_a_handle_spreads_its_batches_over_several_devices(progs, tmp_path):
+    """HTS_GPU_DEVICES=0-3: one context per device, two pipes each, windows rotate over the devices and come back in submission order (static
+    split, no collective).  The reference's bgzip on the front-end + the test double with four "devices": the compressed file is byte-identical to the
+    one-device run, decompression gives the input back, and every device took batches in both directions."""
+    import numpy as np
+    data = (np.random.default_rng(9).integers(0, 40, 40_000_000, dtype=np.uint8) + 48).tobytes()
+    plain = tmp_path / "in.txt"; plain.write_bytes(data)
+    outs = {}
+    for devs in ("0", "0-3"):
+        env = dict(os.environ, HTS_GPU_DEVICES=devs, FAKE_ENGINE_REPORT="1", TSAN_OPTIONS="halt_on_error=1")
+        gz = tmp_path / f"out_{len(devs)}.gz"
+        with open(gz, "wb") as f:
+            r = subprocess.run([progs[1], "-@4", "-c", str(plain)], stdout=f, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        rep_c = [l for l in r.stderr.decode().splitlines() if "jobs per device" in l][-1]
+        r = subprocess.run([progs[1], "-@4", "-d", "-c", str(gz)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0 and r.stdout == data, r.stderr.decode()[-1500:]
+        rep_d = [l for l in r.stderr.decode().splitlines() if "jobs per device" in l][-1]
+        outs[devs] = (gz.read_bytes(), rep_c, rep_d)
+    assert outs["0"][0] == outs["0-3"][0]                                 # same bytes whichever devices did the work
+    for rep in outs["0-3"][1:]:
+        used = {int(x.split("=")[0]): int(x.split("=")[1]) for x in rep.split(":")[1].split()}
+        assert set(used) == {0, 1, 2, 3} and min(used.values()) >= 1, rep
+    assert set(int(x.split("=")[0]) for x in outs["0"][1].split(":")[1].split()) == {0}
