@@ -195,7 +195,13 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                 for (uint32_t p = lo + (uint32_t)lane; p < pos; p += 64) S.u.ring[p & (RING - 1u)] = out[p];
             }
             wave_sync();
+#if defined(HG_LOOP_VEC)            /* A/B builds only (scripts/mk_variant.sh): the compiled loops the assembly one replaced */
 #include "inflate_loop_vec.inc"
+#elif defined(HG_LOOP_MIX)
+#include "inflate_loop_mix.inc"
+#else
+#include "inflate_loop_asm.inc"
+#endif
             if (br_byte_pos(br) > in_end) return ST_INFLATE;
         }
         if (bfinal) break;

@@ -42,7 +42,7 @@ struct BuildScratch {               // only live while the Huffman tables of a d
     uint32_t pad[3];
     uint8_t lens[352];
 };
-struct WaveLds {
+struct alignas(1024) WaveLds {         // 1 KiB boundary: the ring (at +5 KiB) is addressed as (pos & 1023) | base
     uint32_t lit[LIT_TAB];
     uint32_t dist[DIST_TAB];
     union {                         // the output ring shares its LDS with the table-build scratch;
