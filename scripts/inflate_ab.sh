@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; cd $R
 G=$1; shift
 python scripts/prep_bgzf.py $G /dev/shm/k.bgzf >/dev/null
 LIBS=""; for l in "$@"; do LIBS="$LIBS $R/$l"; done
-timeout 300 tests/native/kbench /dev/shm/k.bgzf 5 $LIBS 2>&1 | grep -v "in-kernel wave time"
+timeout 300 tests/native/kbench /dev/shm/k.bgzf 5 $LIBS 2>&1 
 export TMPDIR=/tmp
 for l in "$@"; do
   n=$(basename $l .so); O=$R/gpurun_out/ab_pmc_$n; rm -rf $O; mkdir -p $O

@@ -44,6 +44,8 @@ int main(int argc, char **argv) {
             double tot = (double)pr[0];
             printf("   in-kernel wave time (s_memtime ticks, 100 MHz): blocks %llu  per-block total %.0f  header+tables %.1f%%  symbols %.1f%%  resolve %.1f%%  crc %.1f%%\n",
                    pr[5], tot / pr[5], 100 * pr[1] / tot, 100 * pr[2] / tot, 100 * pr[3] / tot, 100 * pr[4] / tot);
+            printf("   fast path left per block: not-root entry %.1f (literal via 2nd level %.1f)  pending match %.1f (overlapping %.1f, long %.1f)  2nd-level distance %.1f\n",
+                   (double)pr[8] / pr[5], (double)pr[11] / pr[5], (double)pr[9] / pr[5], (double)pr[12] / pr[5], (double)pr[13] / pr[5], (double)pr[10] / pr[5]);
         }
         auto p_prof2 = (int (*)(unsigned long long *, int))dlsym(h, "hg_debug_get_profile2");
         if (p_prof2 && getenv("HG_INFLATE_V2")) {
