@@ -9,20 +9,20 @@
 //     a per-launch ticket counter, so the 168 k blocks of a 10 GiB BAM load-balance over 256 CUs without a tail;
 //   * the compressed stream is read with coalesced 256-byte wave loads: the wave keeps a 64-dword window of the input in ONE
 //     VGPR (+ the next window prefetched in a second one) and the bit reader pulls dwords out of it with v_readlane;
-//   * the symbol loop keeps bit buffer, bit count and output position VECTOR-UNIFORM (the same value in every lane of a VGPR):
-//     a CU has one scalar ALU for its four SIMDs, and the first version of this kernel, with the decode state in SGPRs, was
-//     bound by it (inflate_loop_vec.inc);
 //   * decode tables live in LDS (9-bit litlen root + zlib-style second level, 8-bit distance root: 5.1 KiB per wave) and are
 //     built by all 64 lanes (LDS-atomic histogram, ballot-ranked canonical codes); root-table literals carry a sign bit so
 //     that the hot path is one compare;
-//   * literals are parked one per lane and written with one scattered byte store per 64; the last 1 KiB of output is mirrored
-//     in an LDS ring, so near matches are LDS -> LDS plus a fire-and-forget global store, far matches read global memory (a
-//     wave sees its own earlier stores in program order);
+//   * the symbol loop of a deflate block is hand-scheduled assembly (inflate_loop_asm.inc): every lane computes the same
+//     decode state, so what bounds the loop is instruction issue -- one vector and one scalar instruction per SIMD per
+//     quad-cycle -- and the work is split evenly between the two sides by hand (17.9 VALU + 17.5 SALU per symbol against the
+//     compiler's 39 + 15; profiles/r03_inflate_instruction_mix.txt);
+//   * output goes into a 1 KiB LDS ring per wave and nowhere else: a literal is one ds_write of the table entry, a match is
+//     ring -> ring (or global -> ring for a look-back beyond the ring: the wave's own flushed output, whose load is not waited
+//     for until the next copy needs the ring); every 256 finished bytes leave the ring as one coalesced dword store per lane;
 //   * the CRC-32 is fused: after the last deflate block the wave re-reads its output (L2-resident), 64 lanes x slice-by-4, and
 //     folds the partials with a 6-step butterfly;
-//   * 80 VGPRs, 6 KiB of LDS per wave -> 24 wavefronts per CU; at that occupancy the kernel is VALU-issue bound (~40 vector
-//     instructions per symbol).  gzip members of any length (CRAM GZIP blocks, plain .gz files) use the same decoder in a
-//     resumable form (mode 1, gzip_stream_kernel).
+//   * 80 VGPRs, 6 KiB of LDS per wave -> 24 wavefronts per CU.  gzip members of any length (CRAM GZIP blocks, plain .gz files)
+//     use the same decoder in a resumable form (mode 1, gzip_stream_kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -195,7 +195,7 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                 for (uint32_t p = lo + (uint32_t)lane; p < pos; p += 64) S.u.ring[p & (RING - 1u)] = out[p];
             }
             wave_sync();
-#if defined(HG_LOOP_VEC)            /* A/B builds only (scripts/mk_variant.sh): the compiled loops the assembly one replaced */
+#if defined(HG_LOOP_VEC)            /* A/B builds only (scripts/mk_variant.sh ... -DHG_LOOP_VEC -Iexperiments): the compiled loops the assembly replaced */
 #include "inflate_loop_vec.inc"
 #elif defined(HG_LOOP_MIX)
 #include "inflate_loop_mix.inc"
@@ -442,7 +442,6 @@ int launch_bgzf_inflate(hg_ctx *ctx, const void *d_comp, size_t comp_len, const 
                         size_t nblocks, void *d_out, size_t out_cap, int32_t *d_status, hipStream_t s, int mode) {
     if (nblocks == 0) return HG_OK;
     if (nblocks > 0xffffffffull) return HG_EINVAL;
-    if (mode == 0 && ctx->inflate_v2) return launch_bgzf_inflate_v2(ctx, d_comp, comp_len, d_desc, nblocks, d_out, out_cap, d_status, s);
     unsigned int *ticket = next_ticket(ctx);
     if (hipMemsetAsync(ticket, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
     size_t waves = (size_t)ctx->waves_per_launch;

@@ -16,9 +16,6 @@ struct hg_ctx {
     std::atomic<unsigned int> *launch_seq;   // launches issued so far (any thread, any stream)
     std::mutex *tok_mu;       // orders deflate launches (shared token lists, see launch_bgzf_deflate)
     hipEvent_t ev_deflate; int ev_deflate_used;
-    void *d_tok2; size_t d_tok2_cap;           // token buffer of the two-kernel inflate (bgzf_inflate2.hip), ordered like d_tok
-    hipEvent_t ev_inflate2; int ev_inflate2_used;
-    int inflate_v2;                            // 1: BGZF blocks go through parse_kernel + resolve_kernel (HG_INFLATE_V2=0 selects the one-kernel path)
     std::recursive_mutex *mu;           // serialises the host-buffer entry points of this context (they share scratch + staging)
     // scratch for the host-buffer convenience entry points (grown on demand)
     void *d_scratch[HG_SCRATCH_SLOTS];
@@ -49,8 +46,6 @@ struct CtxGuard {
 };
 int launch_bgzf_inflate(hg_ctx *ctx, const void *d_comp, size_t comp_len, const hg_bgzf_desc *d_desc,
                         size_t nblocks, void *d_out, size_t out_cap, int32_t *d_status, hipStream_t s, int mode = 0);
-int launch_bgzf_inflate_v2(hg_ctx *ctx, const void *d_comp, size_t comp_len, const hg_bgzf_desc *d_desc, size_t nblocks, void *d_out,
-                           size_t out_cap, int32_t *d_status, hipStream_t s);
 int launch_bgzf_deflate(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_desc, size_t nblocks, int level,
                         void *d_slots, uint32_t *d_clen, hipStream_t s, int mode = 0, uint32_t *d_crc = nullptr);
 int launch_bgzf_pack(hg_ctx *ctx, const void *d_slots, const hg_bgzf_desc *d_desc, const uint32_t *d_clen,

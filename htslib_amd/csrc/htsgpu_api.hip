@@ -58,19 +58,17 @@ int hg_init(int device, hg_ctx **out) {
     if (!ctx) return HG_ENOMEM;
     ctx->device = device;
     ctx->cus = prop.multiProcessorCount;
-    // inflate: 30 KiB LDS per 4-wave workgroup -> 5 workgroups (20 waves) per CU
+    // inflate: 24 KiB LDS per 4-wave workgroup -> 6 workgroups (24 waves) per CU
     ctx->waves_per_launch = ctx->cus * 24;
     if (hipMalloc((void **)&ctx->d_ticket, HG_TICKETS * sizeof(unsigned int)) != hipSuccess) { free(ctx); return HG_ENOMEM; }
     ctx->launch_seq = new std::atomic<unsigned int>(0);
     ctx->mu = new std::recursive_mutex();
     ctx->tok_mu = new std::mutex();
-    { const char *v2 = getenv("HG_INFLATE_V2"); ctx->inflate_v2 = v2 ? atoi(v2) : 0; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_deflate, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_inflate2, hipEventDisableTiming) != hipSuccess) { (void)hipFree(ctx->d_ticket); delete ctx->launch_seq; delete ctx->mu; delete ctx->tok_mu; free(ctx); return HG_ENODEV; }
+        hipEventCreateWithFlags(&ctx->ev_deflate, hipEventDisableTiming) != hipSuccess) { (void)hipFree(ctx->d_ticket); delete ctx->launch_seq; delete ctx->mu; delete ctx->tok_mu; free(ctx); return HG_ENODEV; }
     *out = ctx;
     return HG_OK;
 }
@@ -91,8 +89,6 @@ void hg_destroy(hg_ctx *ctx) {
     delete ctx->mu;
     delete ctx->tok_mu;
     if (ctx->ev_deflate) (void)hipEventDestroy(ctx->ev_deflate);
-    if (ctx->ev_inflate2) (void)hipEventDestroy(ctx->ev_inflate2);
-    if (ctx->d_tok2) (void)hipFree(ctx->d_tok2);
     free(ctx);
 }
 

@@ -1,5 +1,5 @@
-// inflate_common.h -- decode tables, the table builder and the wave-window bit reader shared by the BGZF inflate kernels
-// (bgzf_inflate.hip: one block per wavefront; bgzf_inflate2.hip: the two-kernel parse / resolve pipeline).
+// inflate_common.h -- decode tables, the table builder and the wave-window bit reader of the BGZF inflate kernel (bgzf_inflate.hip:
+// one block per wavefront; also used by the shelved two-kernel pipeline under experiments/).
 // Everything lives in namespace hg; the includer may define HG_TRACE / HG_T0 / HG_TACC / HG_CNT before including.
 #pragma once
 #include <hip/hip_runtime.h>

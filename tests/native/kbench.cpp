@@ -44,18 +44,6 @@ int main(int argc, char **argv) {
             double tot = (double)pr[0];
             printf("   in-kernel wave time (s_memtime ticks, 100 MHz): blocks %llu  per-block total %.0f  header+tables %.1f%%  symbols %.1f%%  resolve %.1f%%  crc %.1f%%\n",
                    pr[5], tot / pr[5], 100 * pr[1] / tot, 100 * pr[2] / tot, 100 * pr[3] / tot, 100 * pr[4] / tot);
-            printf("   fast path left per block: not-root entry %.1f (literal via 2nd level %.1f)  pending match %.1f (overlapping %.1f, long %.1f)  2nd-level distance %.1f\n",
-                   (double)pr[8] / pr[5], (double)pr[11] / pr[5], (double)pr[9] / pr[5], (double)pr[12] / pr[5], (double)pr[13] / pr[5], (double)pr[10] / pr[5]);
-        }
-        auto p_prof2 = (int (*)(unsigned long long *, int))dlsym(h, "hg_debug_get_profile2");
-        if (p_prof2 && getenv("HG_INFLATE_V2")) {
-            unsigned long long pr[16]; p_prof2(pr, 1);
-            p_inf(ctx, dc, len, (hg_bgzf_desc *)dd, n, dout, total, dst, s); CK(hipStreamSynchronize(s)); p_prof2(pr, 1);
-            printf("   v2 parse  (ticks of 10 ns per block, workgroup time): total %.0f  header+tables %.0f  passes %.0f  prefix+emit %.0f   passes/round %.1f  rounds/block %.2f\n",
-                   (double)pr[0] / pr[4], (double)pr[1] / pr[4], (double)pr[2] / pr[4], (double)pr[3] / pr[4], (double)pr[5] / (pr[6] ? pr[6] : 1), (double)pr[6] / pr[4]);
-            printf("   v2 parse: wave-passes with a dirty lane per block %.1f, lane parses per block %.1f\n", (double)pr[7] / pr[4], (double)pr[13] / pr[4]);
-            printf("   v2 resolve (ticks per block, wave time): total %.0f  tokens %.0f  tail flush %.0f  crc %.0f\n",
-                   (double)pr[8] / pr[12], (double)pr[9] / pr[12], (double)pr[10] / pr[12], (double)pr[11] / pr[12]);
         }
         fflush(stdout);
         // ---- deflate the plain image that the inflate above produced --------------------------
