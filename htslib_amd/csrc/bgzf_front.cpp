@@ -31,7 +31,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -58,10 +60,13 @@ struct bgzidx_t {                      // behind fp->idx; opaque to callers (bgz
 
 namespace {
 
-constexpr int NPIPES_MIN = 3, NPIPES_MAX = 16;     // pipes per handle: 3 on one device, 2 per device on several (HTS_GPU_DEVICES)
+constexpr int NPIPES_MIN = 4, NPIPES_MAX = 16;     // pipes per handle: 4 on one device (one being consumed, three in flight: a job is ~2 ms of kernel
+                                                   // latency + 0.8 ms of D2H for a 0.7 ms slot), 2 per device on several (HTS_GPU_DEVICES; HTS_GPU_PIPES overrides)
 constexpr size_t WINDOW_MIN = 256u << 10;      // compressed bytes of the first batch after open / seek
-constexpr size_t WINDOW_MAX = 32u << 20;
-constexpr uint64_t PLAIN_MAX = 768ull << 20;   // plain bytes per batch (highly compressible input)
+constexpr size_t WINDOW_MAX = 8u << 20;        // 8 MiB of BGZF is 25-45 MiB of plain BAM per batch: the pinned buffers of a handle (3 pipes) stay
+                                               // under ~200 MiB -- pinning costs ~0.3 ms per MiB at open and as much again at close (32 MiB
+                                               // windows: 270 ms before the first GiB arrived, 170 ms to close; steady state is the same)
+constexpr uint64_t PLAIN_MAX = 256ull << 20;   // plain bytes per batch (highly compressible input)
 constexpr size_t WBLOCKS_MIN = 16, WBLOCKS_MAX = 512;
 const uint8_t kEof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0,
                           0, 0, 0, 0, 0, 0, 0, 0};
@@ -128,6 +133,7 @@ struct ReadBatch {
     size_t comp_len = 0;           // bytes covered by desc
     int fail = 0;                  // BGZF_ERR_* met while reading / framing BEHIND the last good block
     bool submitted = false;
+    bool reserved = false;         // the pipe's buffers have been sized for full windows (fill_batch)
     // after hg_pipe_wait:
     const uint8_t *plain = nullptr;
     const int32_t *status = nullptr;
@@ -145,8 +151,14 @@ struct WriteBatch {
 
 enum Kind { K_READ, K_WRITE, K_GZREAD, K_GZWRITE };
 
+// HTS_GPU_STATS=1: where a reader's wall time went, printed to stderr when the handle closes (seconds, per thread)
+struct ReadStats { double io_read = 0, io_frame = 0, io_submit = 0, io_idle = 0, c_wait = 0, c_copy = 0; uint64_t batches = 0, copies = 0; };
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline bool stats_on() { static const bool on = getenv("HTS_GPU_STATS") != nullptr; return on; }
+
 struct Engine {
     BGZF *fp = nullptr;
+    ReadStats st;
     Kind kind = K_READ;
     hg_ctx *gpu = nullptr;                 // first device (stateless helpers: gzip streams, CRCs)
     std::vector<hg_ctx *> devs;            // every device of the handle; pipe i lives on devs[i % devs.size()]
@@ -164,10 +176,12 @@ struct Engine {
     bool input_done = false;               // the I/O thread met EOF or a fatal input error
     bool pause_req = false, paused = false;
     size_t window = WINDOW_MIN;
+    double ratio_seen = 0;                 // best plain / compressed ratio of a batch so far (sizes the pinned output buffers)
     size_t ahead = NPIPES_MIN;             // batches the I/O thread may run ahead: 1 after a seek until the consumer shows
                                            // that it is scanning (a random-access caller reads a few bytes and seeks again)
     std::vector<uint8_t> carry;            // bytes of a block cut by the window end
     int64_t read_off = 0;                  // file offset of carry[0] / of the next byte to hread
+    int pfd = -1;                          // regular local file: a private descriptor for positional reads of the windows by several threads
     size_t blk = 0;                        // current block inside the current batch
     bool blk_pending = false;              // a seek positioned us BEFORE rb.desc[blk]
     int64_t next_addr = 0;                 // file offset of the block after the current one
@@ -198,6 +212,80 @@ struct Engine {
 // every compressed reader, and for a writer once bgzf_mt() / bgzf_thread_pool() has been called -- see queue_block().
 inline Engine *E(BGZF *fp) { return reinterpret_cast<Engine *>(fp->cache); }
 
+// ---- window reads.  One thread's read(2) out of the page cache moves 4-6 GB/s, i.e. ~25 GB/s of plain BAM -- less than the pipeline
+// behind it takes -- so when the input is a regular local file (bgzf_open on a path, bgzf_dopen on a regular file's descriptor) a window
+// is fetched with positional reads by a few threads at once (process-wide helpers, created on first use; HTS_GPU_READ_THREADS = readers
+// per window, default 4, 1 = the calling thread alone).  Anything else (pipes, hFILE plugins) keeps the single hread of the reference.
+class ReadPool {
+    struct Job { int fd; uint8_t *d; size_t n; off_t off; ssize_t *res; };
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, done_cv;
+    std::vector<Job> q;
+    size_t pending = 0;
+    bool stop = false;
+    static ssize_t pread_all(int fd, uint8_t *d, size_t n, off_t off) {
+        size_t got = 0;
+        while (got < n) {
+            ssize_t r;
+            do r = pread(fd, d + got, n - got, off + (off_t)got); while (r < 0 && errno == EINTR);
+            if (r < 0) return got ? (ssize_t)got : -1;
+            if (r == 0) break;
+            got += (size_t)r;
+        }
+        return (ssize_t)got;
+    }
+    void worker() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || !q.empty(); });
+            if (stop && q.empty()) return;
+            const Job j = q.back(); q.pop_back();
+            lk.unlock();
+            *j.res = pread_all(j.fd, j.d, j.n, j.off);
+            lk.lock();
+            if (--pending == 0) done_cv.notify_all();
+        }
+    }
+public:
+    explicit ReadPool(int helpers) { for (int i = 0; i < helpers; i++) th.emplace_back([this] { worker(); }); }
+    ~ReadPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); for (auto &t : th) t.join(); }
+    std::mutex big;                                    // one window at a time per pool
+    // bytes read into d (contiguous from `off`), < n only at end of file; -1 = I/O error before any byte
+    ssize_t read(int fd, uint8_t *d, size_t n, off_t off) {
+        constexpr size_t SLICE_MIN = 1u << 20;
+        const size_t parts = th.size() + 1;
+        if (n < 2 * SLICE_MIN || parts == 1) return pread_all(fd, d, n, off);
+        std::lock_guard<std::mutex> one(big);
+        const size_t each = (((n + parts - 1) / parts) + SLICE_MIN - 1) & ~(SLICE_MIN - 1);
+        ssize_t res[17]; size_t len[17]; size_t k = 0;
+        for (size_t o = 0; o < n; o += each, k++) { len[k] = n - o < each ? n - o : each; res[k] = 0; }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for (size_t i = 1; i < k; i++) { q.push_back(Job{fd, d + i * each, len[i], off + (off_t)(i * each), &res[i]}); pending++; }
+        }
+        cv.notify_all();
+        res[0] = pread_all(fd, d, len[0], off);
+        { std::unique_lock<std::mutex> lk(m); done_cv.wait(lk, [&] { return pending == 0; }); }
+        size_t total = 0;
+        for (size_t i = 0; i < k; i++) {
+            if (res[i] < 0) return total ? (ssize_t)total : -1;
+            total += (size_t)res[i];
+            if ((size_t)res[i] < len[i]) break;          // end of file inside this slice: what follows it is not contiguous
+        }
+        return (ssize_t)total;
+    }
+};
+ReadPool *read_pool() {
+    static ReadPool *pool = [] {
+        const char *v = getenv("HTS_GPU_READ_THREADS");
+        int n = v ? atoi(v) : 4;
+        if (n < 1) n = 1;
+        return new ReadPool((n > 16 ? 16 : n) - 1);      // lives until exit (helpers are parked on a condition variable)
+    }();
+    return pool;
+}
+
 // ================================================================================ reader: I/O thread
 // Fill one batch: read a window, frame whole blocks, submit the inflate job.  Returns true when no further batch
 // can follow (end of input or a fatal input error); the caller publishes that together with the batch.
@@ -207,18 +295,31 @@ bool fill_batch(Engine *e, ReadBatch &b) {
     b.desc.clear(); b.fail = 0; b.submitted = false; b.comp_len = 0; b.good = 0;
     b.file_off = e->read_off;
     const size_t want = e->window;
+    // Past the first window after an open / seek the reader is scanning and the windows grow to WINDOW_MAX: size this pipe's buffers for
+    // that once (input exactly, output from the best ratio seen so far) rather than re-pinning them at every step of the growth.
+    if (want > WINDOW_MIN && !b.reserved) {
+        const double r = e->ratio_seen > 1.0 ? e->ratio_seen * 1.15 : 4.0;
+        const uint64_t out_est = (uint64_t)((double)WINDOW_MAX * r);
+        (void)hg_pipe_reserve(b.pipe, WINDOW_MAX + 2 * BGZF_MAX_BLOCK_SIZE, (size_t)(out_est < PLAIN_MAX ? out_est : PLAIN_MAX));
+        b.reserved = true;
+    }
     uint8_t *buf = (uint8_t *)hg_pipe_input(b.pipe, e->carry.size() + want + BGZF_MAX_BLOCK_SIZE);
     if (!buf) { b.fail = BGZF_ERR_IO; return true; }
     size_t have = e->carry.size();
     if (have) memcpy(buf, e->carry.data(), have);
     e->carry.clear();
     bool at_eof = false;
+    const double t_r0 = stats_on() ? now_s() : 0;
     {
-        ssize_t n = hg_hread(fp->fp, buf + have, want);
+        // regular local file: positional reads by several threads; the hFILE is left where the window ends, for whoever uses it next
+        ssize_t n = e->pfd >= 0 ? read_pool()->read(e->pfd, buf + have, want, (off_t)(e->read_off + (int64_t)have))
+                                : hg_hread(fp->fp, buf + have, want);
+        if (n >= 0 && e->pfd >= 0 && hseek(fp->fp, (off_t)(e->read_off + (int64_t)have + n), SEEK_SET) < 0) n = -1;
         if (n < 0) { b.fail = BGZF_ERR_IO; return true; }
         if ((size_t)n < want) at_eof = true;
         have += (size_t)n;
     }
+    const double t_r1 = stats_on() ? now_s() : 0;
     size_t pos = 0; uint64_t plain = 0;
     bool capped = false;
     while (have - pos >= 18) {
@@ -240,12 +341,15 @@ bool fill_batch(Engine *e, ReadBatch &b) {
     if (b.fail || (at_eof && !capped)) finished = true;
     else if (pos < have) e->carry.assign(buf + pos, buf + have);
     b.comp_len = pos;
+    if (pos >= (64u << 10) && (double)plain / (double)pos > e->ratio_seen) e->ratio_seen = (double)plain / (double)pos;
     e->read_off += (int64_t)pos;
+    const double t_r2 = stats_on() ? now_s() : 0;
     if (!b.desc.empty()) {
         if (hg_pipe_inflate(b.pipe, pos, b.desc.data(), b.desc.size()) != HG_OK) {
             b.desc.clear(); b.fail = BGZF_ERR_ZLIB; finished = true;
         } else b.submitted = true;
     }
+    if (stats_on()) { const double t = now_s(); e->st.io_read += t_r1 - t_r0; e->st.io_frame += t_r2 - t_r1; e->st.io_submit += t - t_r2; e->st.batches++; }
     if (e->window < WINDOW_MAX) e->window = e->window * 4 > WINDOW_MAX ? WINDOW_MAX : e->window * 4;
     return finished;
 }
@@ -334,7 +438,9 @@ int next_batch(Engine *e) {
     b.plain = nullptr; b.status = nullptr; b.good = 0;
     if (b.submitted) {
         size_t plen = 0;
+        const double t_w0 = stats_on() ? now_s() : 0;
         const int rc = hg_pipe_wait(b.pipe, &b.plain, &plen, &b.status, nullptr, nullptr);
+        if (stats_on()) e->st.c_wait += now_s() - t_w0;
         b.submitted = false;
         if (rc != HG_OK && rc != HG_EBLOCK) { b.desc.clear(); b.fail = BGZF_ERR_ZLIB; }
         while (b.good < b.desc.size() && b.status[b.good] == 0) b.good++;
@@ -718,6 +824,10 @@ int drain_writer(BGZF *fp) {
 
 // ================================================================================ handle lifetime
 void stop_engine(Engine *e) {
+    if (stats_on() && e->kind == K_READ && e->st.batches)
+        fprintf(stderr, "[htsgpu stats] reader: %llu batches; I/O thread: read %.3f s, frame %.3f s, submit %.3f s; consumer: wait for batch %.3f s, "
+                "large copies %.3f s (%llu)\n", (unsigned long long)e->st.batches, e->st.io_read, e->st.io_frame, e->st.io_submit, e->st.c_wait,
+                e->st.c_copy, (unsigned long long)e->st.copies);
     if (e->started) {
         { std::lock_guard<std::mutex> g(e->m); e->stop = true; e->pause_req = false; e->cv.notify_all(); }
         e->th.join();
@@ -727,6 +837,7 @@ void stop_engine(Engine *e) {
     for (auto &b : e->wb) if (b.pipe) { hg_pipe_destroy(b.pipe); b.pipe = nullptr; }
     for (hg_ctx *c : e->devs) hg_destroy(c);
     e->devs.clear(); e->gpu = nullptr;
+    if (e->pfd >= 0) { close(e->pfd); e->pfd = -1; }
 }
 
 void free_handle(BGZF *fp) {
@@ -753,6 +864,7 @@ Engine *new_engine(BGZF *fp, Kind kind) {
     }
     e->gpu = e->devs[0];
     e->NPIPES = e->devs.size() == 1 ? NPIPES_MIN : (int)std::min<size_t>(2 * e->devs.size(), (size_t)NPIPES_MAX);
+    if (const char *np = getenv("HTS_GPU_PIPES")) { const int v = atoi(np); if (v >= 2 && v <= NPIPES_MAX) e->NPIPES = v; }
     e->ahead = (size_t)e->NPIPES;
     e->own_block = fp->uncompressed_block;
     fp->cache = reinterpret_cast<bgzf_cache_t *>(e);
@@ -818,12 +930,26 @@ BGZF *bgzf_hopen(hFILE *h, const char *mode) {
     return nullptr;
 }
 
+// A BGZF reader over a regular local file gets a descriptor of its own for positional window reads (ReadPool).
+static void adopt_pread_fd(BGZF *fp, int fd) {
+    Engine *e = fp ? E(fp) : nullptr;
+    struct stat st;
+    if (e && e->kind == K_READ && fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) e->pfd = fd;
+    else if (fd >= 0) close(fd);
+}
+
 BGZF *bgzf_open(const char *path, const char *mode) {
     if (!strchr(mode, 'r') && !strchr(mode, 'w') && !strchr(mode, 'a')) { errno = EINVAL; return nullptr; }
     hFILE *h = hopen(path, mode);
     if (!h) return nullptr;
     BGZF *fp = bgzf_hopen(h, mode);
     if (!fp) hclose_abruptly(h);
+    else if (fp->is_compressed && !fp->is_write && strcmp(path, "-") != 0 && !strstr(path, "://") && strncmp(path, "file:", 5) != 0 &&
+             strncmp(path, "data:", 5) != 0 && strncmp(path, "preload:", 8) != 0) {
+        const int keep = errno;
+        adopt_pread_fd(fp, open(path, O_RDONLY | O_CLOEXEC));
+        errno = keep;
+    }
     return fp;
 }
 
@@ -833,6 +959,7 @@ BGZF *bgzf_dopen(int fd, const char *mode) {
     if (!h) return nullptr;
     BGZF *fp = bgzf_hopen(h, mode);
     if (!fp) hclose_abruptly(h);
+    else if (fp->is_compressed && !fp->is_write) { const int keep = errno; adopt_pread_fd(fp, dup(fd)); errno = keep; }
     return fp;
 }
 
@@ -901,6 +1028,11 @@ ssize_t bgzf_read(BGZF *fp, void *data, size_t length) {
         }
         size_t n = span_avail(fp, e);
         if (n > want) n = want;
+        if (e && stats_on() && n >= COPY_SPLIT_MIN) {
+            const double t_c0 = now_s();
+            copy_out(dst, (const uint8_t *)fp->uncompressed_block + fp->block_offset, n);
+            e->st.c_copy += now_s() - t_c0; e->st.copies++;
+        } else
         copy_out(dst, (const uint8_t *)fp->uncompressed_block + fp->block_offset, n);
         span_advance(fp, e, n);
         dst += n; want -= n;

@@ -94,6 +94,15 @@ void *hg_pipe_input(hg_pipe *p, size_t bytes) {
     return p->h_in;
 }
 
+int hg_pipe_reserve(hg_pipe *p, size_t in_bytes, size_t out_bytes) {
+    if (!p || p->kind != 0) return HG_EINVAL;
+    if (hipSetDevice(p->ctx->device) != hipSuccess) return HG_ENODEV;
+    int rc;
+    if ((rc = grow_pinned(&p->h_in, &p->h_in_cap, in_bytes + 64)) || (rc = grow_pinned(&p->h_out, &p->h_out_cap, out_bytes + 64)) ||
+        (rc = grow_dev(&p->d_in, &p->d_in_cap, in_bytes + 256)) || (rc = grow_dev(&p->d_out, &p->d_out_cap, out_bytes + 256))) return rc;
+    return HG_OK;
+}
+
 int hg_pipe_inflate(hg_pipe *p, size_t comp_len, const hg_bgzf_desc *desc, size_t n) {
     if (!p || p->kind != 0 || (n && !desc) || comp_len + 64 > p->h_in_cap) return HG_EINVAL;
     if (n > 0xffffffffull) return HG_EINVAL;
@@ -112,13 +121,24 @@ int hg_pipe_inflate(hg_pipe *p, size_t comp_len, const hg_bgzf_desc *desc, size_
         (rc = grow_dev(&p->d_meta, &p->d_meta_cap, dsz + ssz))) { p->kind = 0; return rc; }
     memcpy(p->h_meta, desc, n * sizeof(hg_bgzf_desc));
     memset(p->h_in + comp_len, 0, 8);                                  // the kernel reads whole dwords
-    const size_t comp_pad = (comp_len + 3) & ~(size_t)3;
-    bool ok = hipMemcpyAsync(p->d_in, p->h_in, comp_pad, hipMemcpyHostToDevice, p->s) == hipSuccess &&
-              hipMemcpyAsync(p->d_meta, p->h_meta, n * sizeof(hg_bgzf_desc), hipMemcpyHostToDevice, p->s) == hipSuccess;
-    rc = ok ? hg::launch_bgzf_inflate(p->ctx, p->d_in, comp_len, (const hg_bgzf_desc *)p->d_meta, n, p->d_out, (size_t)plain,
-                                      (int32_t *)(p->d_meta + dsz), p->s) : HG_ELAUNCH;
+    // The kernel reads the compressed window and the block table straight out of the pinned host buffers and writes the block
+    // verdicts there (hipHostMalloc memory is mapped into the device's address space): a wavefront fetches its input in 256-byte
+    // windows, one ahead of the one being decoded, so the PCIe latency is off the decode chain -- and no host-to-device copy sits
+    // in the copy engine's queue behind the previous job's device-to-host copy (which waits for ITS kernel): measured on 8 MiB
+    // windows, the staged form ran D2H -> H2D -> kernel strictly one after the other across three pipes (17 GB/s of plain BAM).
+    // HTS_GPU_STAGE_INPUT=1 restores the staged form.
+    static const bool stage_in = getenv("HTS_GPU_STAGE_INPUT") != nullptr;
+    bool ok = true;
+    const uint8_t *k_in = p->h_in; const hg_bgzf_desc *k_desc = (const hg_bgzf_desc *)p->h_meta; int32_t *k_status = (int32_t *)(p->h_meta + dsz);
+    if (stage_in) {
+        const size_t comp_pad = (comp_len + 3) & ~(size_t)3;
+        ok = hipMemcpyAsync(p->d_in, p->h_in, comp_pad, hipMemcpyHostToDevice, p->s) == hipSuccess &&
+             hipMemcpyAsync(p->d_meta, p->h_meta, n * sizeof(hg_bgzf_desc), hipMemcpyHostToDevice, p->s) == hipSuccess;
+        k_in = p->d_in; k_desc = (const hg_bgzf_desc *)p->d_meta; k_status = (int32_t *)(p->d_meta + dsz);
+    }
+    rc = ok ? hg::launch_bgzf_inflate(p->ctx, k_in, comp_len, k_desc, n, p->d_out, (size_t)plain, k_status, p->s) : HG_ELAUNCH;
     if (rc == HG_OK) {
-        ok = hipMemcpyAsync(p->h_meta + dsz, p->d_meta + dsz, n * sizeof(int32_t), hipMemcpyDeviceToHost, p->s) == hipSuccess &&
+        ok = (!stage_in || hipMemcpyAsync(p->h_meta + dsz, p->d_meta + dsz, n * sizeof(int32_t), hipMemcpyDeviceToHost, p->s) == hipSuccess) &&
              (plain == 0 || hipMemcpyAsync(p->h_out, p->d_out, (size_t)plain, hipMemcpyDeviceToHost, p->s) == hipSuccess) &&
              hipEventRecord(p->ev, p->s) == hipSuccess;
         if (!ok) rc = HG_ELAUNCH;

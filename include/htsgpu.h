@@ -138,6 +138,10 @@ void hg_pipe_destroy(hg_pipe *pipe);
 /* Pinned staging buffer for the NEXT job's input, at least `bytes` long (contents are lost when it grows).
  * NULL while a job is in flight or on allocation failure. */
 void *hg_pipe_input(hg_pipe *pipe, size_t bytes);
+/* Size the pipe's buffers for jobs of up to in_bytes of input and out_bytes of output in one step (pinning host memory costs
+ * ~0.3 ms per MiB, so a reader that knows where its windows are heading asks once instead of growing job by job).  Only
+ * between jobs; contents of the buffers are lost. */
+int hg_pipe_reserve(hg_pipe *pipe, size_t in_bytes, size_t out_bytes);
 /* Inflate job: the first comp_len bytes of the input buffer are n whole BGZF blocks; desc[i].coff is relative to
  * the buffer, desc[i].uoff cumulative from 0.  Returns after queueing the work. */
 int hg_pipe_inflate(hg_pipe *pipe, size_t comp_len, const hg_bgzf_desc *desc, size_t n);

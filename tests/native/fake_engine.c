@@ -42,6 +42,12 @@ void *hg_pipe_input(hg_pipe *p, size_t bytes) {
     if (p->in_cap < bytes + 64) { free(p->in); p->in = malloc(bytes + 64); p->in_cap = p->in ? bytes + 64 : 0; }
     return p->in;
 }
+int hg_pipe_reserve(hg_pipe *p, size_t in_bytes, size_t out_bytes) {
+    if (p->kind) return HG_EINVAL;
+    if (!hg_pipe_input(p, in_bytes)) return HG_ENOMEM;
+    if (p->out_cap < out_bytes) { free(p->out); p->out = malloc(out_bytes); p->out_cap = p->out ? out_bytes : 0; }
+    return p->out ? HG_OK : HG_ENOMEM;
+}
 static int grow_out(hg_pipe *p, size_t need) {
     if (p->out_cap < need) { free(p->out); p->out = malloc(need); p->out_cap = p->out ? need : 0; }
     return p->out ? 0 : -1;
