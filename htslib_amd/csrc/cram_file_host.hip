@@ -264,8 +264,18 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
         }
         std::vector<uint64_t> ro(i1 - i0 + 1, 0);
         uint64_t got = 0;
-        rc = hg_cram_decode_bam_host2(ctx, i1 - i0, sb.data() + i0, major, nref, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), bases + 4096, bam_out + hb + rec_bytes,
-                                      bam_cap - hb - rec_bytes, ro.data(), nullptr, &got, status.data() + i0, name_prefix);
+        // Room for bases + qualities: the container headers' `bases` fields say how much, but they are a writer's claim, not a fact (a
+        // writer may leave 0 there): when a slice comes back "no room" the batch is decoded again with more, instead of failing the file.
+        uint64_t seq_cap = std::min<uint64_t>(bases, 1ull << 36) + 4096;
+        for (int attempt = 0;; attempt++) {
+            got = 0;
+            rc = hg_cram_decode_bam_host2(ctx, i1 - i0, sb.data() + i0, major, nref, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), seq_cap, bam_out + hb + rec_bytes,
+                                          bam_cap - hb - rec_bytes, ro.data(), nullptr, &got, status.data() + i0, name_prefix);
+            bool no_room = false;
+            for (size_t k = i0; k < i1; k++) if (status[k] == hgr::ERR_POOL) no_room = true;
+            if ((rc != HG_OK && rc != HG_EBLOCK) || !no_room || attempt == 2 || seq_cap >= (1ull << 36)) break;
+            seq_cap = seq_cap * 8 + (64ull << 20);
+        }
         rec_bytes += got;
         for (size_t k = 0; k <= i1 - i0; k++) rec_off[i0 + k] = rec_off[i0] + ro[k];
         i0 = i1;

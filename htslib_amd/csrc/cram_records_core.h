@@ -292,7 +292,13 @@ struct Reader {
             if (C.b < 0) { err = ERR_MALFORMED; return 0; }
             const Codec V = P->codecs[C.b];
             if (V.kind == E_EXTERNAL) ext_bytes(V.a, out, (uint32_t)len, which);
-            else for (int32_t i = 0; i < len && !err; i++) { const int32_t b = value(C.b, true); if (out) out[i] = (uint8_t)b; }
+            else {
+                // bytes out of a bit codec (no writer we know does this): a damaged length paired with a zero-bit codec must not spin -- one
+                // item is capped, and its bytes count against the same budget as the feature walk, whether or not anybody wants them
+                work += ((uint64_t)len >> 4) + 1u;
+                if ((uint32_t)len > (1u << 24) || work > 16ull * S->cigar_cap + (1ull << 16)) { err = ERR_UNSUPPORTED; return 0; }
+                for (int32_t i = 0; i < len && !err; i++) { const int32_t b = value(C.b, true); if (out) out[i] = (uint8_t)b; }
+            }
             return len;
         }
         if (!err) err = ERR_UNSUPPORTED;                                  // array series through a scalar codec: not written by any encoder we know
