@@ -179,3 +179,48 @@ def test_crc32_batch(engine, oracle):
     bufs = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in sizes]
     got = crc32_device(engine, bufs)
     assert [int(x) for x in got] == [zlib.crc32(b) for b in bufs] == [oracle.crc32(b) for b in bufs]
+
+
+def test_declared_size_lies_and_chunk_boundaries(engine, oracle):
+    """The decoder writes through a 1 KiB ring and flushes 256-byte chunks: output that stops short of / runs past the declared ISIZE
+    must give the reference's verdict (bgzf.c:775-804) and never touch a neighbour's bytes; lengths around every chunk boundary decode."""
+    rng = np.random.default_rng(11)
+    text = synth.fastq(200_000)
+    blocks, want = [], []
+    for n in [1, 2, 3, 4, 63, 64, 65, 255, 256, 257, 258, 259, 511, 512, 513, 767, 768, 769, 1023, 1024, 1025, 1279, 1280, 4095, 4096, 4097, 65279, 65280]:
+        for kind in range(3):
+            d = text[:n] if kind == 0 else bytes(n) if kind == 1 else rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+            blocks.append(refutil.raw_block(d, 6)); want.append(d)
+    comp = b"".join(blocks)
+    got, st = gpu_inflate(engine, comp)
+    assert (st == 0).all() and got == b"".join(want) == oracle.decompress(comp)[1]
+    # ISIZE says less / more than the stream makes; a good neighbour on either side must survive
+    data = text[:50_000]
+    payload = refutil.raw_block(data, 6)[18:-8]
+    zeros = refutil.raw_block(bytes(60_000), 6)[18:-8]                       # 258-byte overlapping copies, two chunks per copy
+    guard = refutil.raw_block(b"guard " * 2000)
+    cases = [guard,
+             refutil.wrap_payload(payload, data, isize=len(data) - 1), guard,
+             refutil.wrap_payload(payload, data, isize=len(data) - 300), guard,
+             refutil.wrap_payload(payload, data, isize=1000), guard,
+             refutil.wrap_payload(payload, data, isize=len(data) + 1), guard,
+             refutil.wrap_payload(payload, data, isize=65536), guard,
+             refutil.wrap_payload(zeros, bytes(60_000), isize=59_000), guard,
+             refutil.wrap_payload(zeros, bytes(60_000), isize=100), guard,
+             refutil.wrap_payload(zeros, bytes(60_000)), guard]
+    comp = b"".join(cases)
+    want_st = [oracle.uncompress_block(b)[0] for b in cases]
+    assert want_st[0::2] == [0] * len(cases[0::2]) and want_st[-2] == 0 and all(w != 0 for w in want_st[1:-2:2])
+    from htslib_amd.bgzf import DeviceStream
+    ds = DeviceStream(comp)
+    ds.inflate(engine)
+    got, st = ds.result()
+    assert list(st) == want_st
+    # every good block is intact wherever it sits (offsets follow the declared sizes)
+    off = 0
+    for b, w in zip(cases, want_st):
+        isize = struct.unpack("<I", b[-4:])[0]
+        if w == 0:
+            exp = b"guard " * 2000 if b is guard else bytes(60_000)
+            assert got[off:off + isize] == exp
+        off += isize
