@@ -272,9 +272,9 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
             rc = hg_cram_decode_bam_host2(ctx, i1 - i0, sb.data() + i0, major, nref, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), seq_cap, bam_out + hb + rec_bytes,
                                           bam_cap - hb - rec_bytes, ro.data(), nullptr, &got, status.data() + i0, name_prefix);
             bool no_room = false;
-            for (size_t k = i0; k < i1; k++) if (status[k] == hgr::ERR_POOL) no_room = true;
-            if ((rc != HG_OK && rc != HG_EBLOCK) || !no_room || attempt == 2 || seq_cap >= (1ull << 36)) break;
-            seq_cap = seq_cap * 8 + (64ull << 20);
+            for (size_t k = i0; k < i1; k++) if (status[k] == hgr::ERR_UNSUPPORTED) no_room = true;    // "does not fit" is one of its meanings
+            if ((rc != HG_OK && rc != HG_EBLOCK) || !no_room || attempt == 1 || seq_cap >= (1ull << 34)) break;   // once: a slice the decoder does not support says -3, too
+            seq_cap = seq_cap * 4 + (64ull << 20);
         }
         rec_bytes += got;
         for (size_t k = 0; k <= i1 - i0; k++) rec_off[i0 + k] = rec_off[i0] + ro[k];

@@ -585,7 +585,7 @@ static int rec_run(hg_ctx *ctx, hg_cram_batch &R, const BamSink *bam, size_t cig
         }
         if (rounds == 0) for (size_t i = 0; i < nslices; i++) if (status[i] == hgr::STATUS_RETRY) { again.push_back((uint32_t)i); R.retried[i] = 1; }
         const bool progress = rounds == 0 || again.size() < round.size();
-        if (again.empty() || !progress) { for (uint32_t i : again) status[i] = hgr::ERR_POOL; break; }     // alone in the pool and still no room: the batch's seq_cap is too small for it
+        if (again.empty() || !progress) { for (uint32_t i : again) status[i] = hgr::ERR_UNSUPPORTED; break; }     // alone in the pool and still no room: the batch's seq_cap is too small for it
         std::vector<int32_t> pre(nslices, hgr::STATUS_SKIP);
         for (uint32_t i : again) pre[i] = 0;
         if (hipMemcpyAsync(R.d_pre1, pre.data(), nslices * 4, hipMemcpyHostToDevice, s) != hipSuccess || hipMemsetAsync(d_out + R.opool, 0, 8, s) != hipSuccess ||

@@ -415,8 +415,8 @@ typedef struct hg_cram_record_cols {                    /* arrays of rec_cap ent
 int hg_cram_records_bound(size_t nslices, const hg_cram_slice_blocks *slices, int major_version, uint64_t *nrec, uint64_t *cigar_cap,
                           uint64_t *name_cap, uint64_t *aux_cap);
 /* nref = number of @SQ lines (bounds of RI / NS).  rec_off[i] .. rec_off[i+1] = the records of slice i (nslices + 1 entries).
- * status[i] = 0, -1 (malformed slice, as cram_decode_slice returning -1), HG_BLOCK_EUNSUPPORTED, or -7 when seq_cap has no room for the slice's
- * bases + qualities even with the other slices out of the way (call again with more; hg_cram_file_to_bam_host does).  cigar[] / names[] / aux[] come back
+ * status[i] = 0, -1 (malformed slice, as cram_decode_slice returning -1) or HG_BLOCK_EUNSUPPORTED -- which includes "seq_cap has no room for this slice's
+ * bases + qualities even with the other slices out of the way" (hg_cram_file_to_bam_host then decodes the batch once more with four times the room).  cigar[] / names[] / aux[] come back
  * PACKED (slice after slice, no gaps); the capacities may be any estimate: if one is too small the call returns HG_ENOMEM and used[]
  * (optional, 4 entries: CIGAR words, name bytes, aux bytes, sequence bytes) says what the batch needs -- hg_cram_records_bound's
  * figures always suffice.  Returns HG_OK / HG_EBLOCK / HG_ENOMEM. */
