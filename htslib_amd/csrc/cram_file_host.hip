@@ -74,6 +74,54 @@ void md5_of(const uint8_t *p, uint64_t n, uint8_t out[16]) {
 
 }  // namespace
 
+// ---- several GPUs ("independent blocks / slices are sharded across the GPUs of one node with a trivial static split").  HTS_GPU_DEVICES
+// ("0-7", "0,2,5") names the devices, as for the BGZF front-end.  A whole-file job keeps the caller's context as its first shard and opens one
+// sibling context per FURTHER entry of the list (process-wide, created on first use); blocks and slices are cut into that many contiguous
+// ranges of about equal bytes, every range runs its own batches on its own device from its own host thread, and the outputs are joined in
+// file order -- no collective, no cross-device traffic.  An entry may repeat a device ("0,0": two contexts on one GPU), which is how the
+// sharded path is tested on a one-GPU box.
+namespace {
+std::vector<hg_ctx *> job_contexts(hg_ctx *ctx) {
+    static std::mutex m;
+    static std::vector<int> devs;
+    static std::vector<hg_ctx *> peers;
+    static bool parsed = false;
+    std::lock_guard<std::mutex> lk(m);
+    if (!parsed) {
+        parsed = true;
+        if (const char *d = getenv("HTS_GPU_DEVICES")) {
+            for (const char *p = d; *p;) {
+                if (*p < '0' || *p > '9') { p++; continue; }
+                char *q; const long a = strtol(p, &q, 10); long b = a;
+                if (*q == '-') b = strtol(q + 1, &q, 10);
+                for (long x = a; x <= b && devs.size() < 64; x++) devs.push_back((int)x);
+                p = q;
+            }
+        }
+        peers.assign(devs.size(), nullptr);
+    }
+    std::vector<hg_ctx *> out{ctx};
+    for (size_t i = 1; i < devs.size(); i++) {
+        if (!peers[i] && hg_init(devs[i], &peers[i]) != HG_OK) peers[i] = nullptr;
+        if (peers[i]) out.push_back(peers[i]);
+    }
+    return out;
+}
+// [0, n) cut into `parts` contiguous ranges of about equal weight; cut[k] .. cut[k + 1] is range k
+template <class W> std::vector<size_t> cut_ranges(size_t n, size_t parts, W weight) {
+    std::vector<size_t> cut{0};
+    uint64_t total = 0; for (size_t i = 0; i < n; i++) total += weight(i);
+    uint64_t acc = 0; size_t i = 0;
+    for (size_t k = 1; k < parts; k++) {
+        const uint64_t want = total * k / parts;
+        while (i < n && acc < want) acc += weight(i++);
+        cut.push_back(i);
+    }
+    cut.push_back(n);
+    return cut;
+}
+}  // namespace
+
 extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given, uint8_t *bam_out,
                                          size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags, const char *name_prefix);
 extern "C" int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given, uint8_t *bam_out,
@@ -126,7 +174,8 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
         c.p = cend;
     }
     if (file_hdr == (size_t)-1) return HG_EINVAL;
-    // ---- 2. every block through cram_uncompress_block in one batch ----
+    // ---- 2. every block through cram_uncompress_block in one batch (one batch per device when HTS_GPU_DEVICES names several) ----
+    const std::vector<hg_ctx *> ctxs = job_contexts(ctx);
     const size_t nb = blocks.size();
     std::vector<std::vector<uint8_t>> dec(nb);
     {
@@ -135,9 +184,22 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
             dec[i].resize(blocks[i].usz ? blocks[i].usz : 1);
             method[i] = blocks[i].method; in[i] = blocks[i].data; il[i] = blocks[i].csz; ol[i] = blocks[i].usz; out[i] = dec[i].data(); part[i] = blocks[i].crc_part; crc[i] = blocks[i].crc;
         }
-        const int rc = major >= 3 ? hg_cram_uncompress_blocks_crc_host(ctx, nb, method.data(), in.data(), il.data(), part.data(), crc.data(), out.data(), ol.data(), status.data())
-                                  : hg_cram_uncompress_blocks_host(ctx, nb, method.data(), in.data(), il.data(), out.data(), ol.data(), status.data());
-        if (rc != HG_OK) return rc;                                      // a block that fails (CRC, malformed, bzip2 / lzma) fails the file, like cram_read_slice / cram_decode_slice
+        const std::vector<size_t> bcut = cut_ranges(nb, nb >= 64 ? ctxs.size() : 1, [&](size_t i) { return (uint64_t)blocks[i].csz + blocks[i].usz + 64; });
+        std::vector<int> brc(bcut.size() - 1, HG_OK);
+        auto unc = [&](size_t k) {
+            const size_t a = bcut[k], n_ = bcut[k + 1] - a;
+            hg_ctx *c = ctxs[k];
+            brc[k] = !n_ ? HG_OK : major >= 3
+                ? hg_cram_uncompress_blocks_crc_host(c, n_, method.data() + a, in.data() + a, il.data() + a, part.data() + a, crc.data() + a, out.data() + a, ol.data() + a, status.data() + a)
+                : hg_cram_uncompress_blocks_host(c, n_, method.data() + a, in.data() + a, il.data() + a, out.data() + a, ol.data() + a, status.data() + a);
+        };
+        {
+            std::vector<std::thread> th;
+            for (size_t k = 1; k + 1 < bcut.size(); k++) th.emplace_back(unc, k);
+            unc(0);
+            for (auto &t : th) t.join();
+        }
+        for (int rc : brc) if (rc != HG_OK) return rc;                                      // a block that fails (CRC, malformed, bzip2 / lzma) fails the file, like cram_read_slice / cram_decode_slice
     }
     // ---- SAM header: text, @SQ, @RG ----
     const std::vector<uint8_t> &fh = dec[file_hdr];
@@ -251,34 +313,82 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
     }
     std::vector<const char *> rgp; for (auto &r : rg_id) rgp.push_back(r.c_str());
     std::vector<uint64_t> rec_off(ns + 1, 0); std::vector<int32_t> status(ns, 0);
+    auto slice_bytes = [&](size_t i) { uint64_t b = (uint64_t)sb[i].core_len + 64; for (uint32_t k = 0; k < sb[i].nblocks; k++) b += ((uint64_t)sb[i].len[k] + 15) & ~15ull; return b; };
+    uint64_t all_bytes = 0; for (size_t i = 0; i < ns; i++) all_bytes += slice_bytes(i);
+    // slices s0 .. s1 on context c into dst (cap bytes): records back to back, ro[i - s0] = records before slice i
+    auto decode_range = [&](hg_ctx *c, size_t s0, size_t s1, uint8_t *dst, size_t cap, uint64_t &bytes_out, uint64_t *ro_out) -> int {
+        int rc = HG_OK;
+        uint64_t rec_bytes = 0; ro_out[0] = 0;
+        // the blocks of one device batch are addressed with 32 bits (cram_records_plan.h): a large range goes through in several batches
+        for (size_t i0 = s0; i0 < s1 && rc == HG_OK;) {
+            uint64_t bytes = 0; size_t i1 = i0;
+            while (i1 < s1) {
+                const uint64_t b = slice_bytes(i1);
+                if (i1 > i0 && bytes + b > 0xc0000000ull) break;
+                bytes += b; i1++;
+            }
+            std::vector<uint64_t> ro(i1 - i0 + 1, 0);
+            uint64_t got = 0;
+            // Room for bases + qualities: the container headers' `bases` fields say how much, but they are a writer's claim, not a fact (a
+            // writer may leave 0 there): when a slice comes back "no room" the batch is decoded again with more, instead of failing the file.
+            uint64_t seq_cap = std::min<uint64_t>(s1 - s0 == ns ? bases : (uint64_t)((double)bases * 1.25 * (double)bytes / (double)(all_bytes ? all_bytes : 1)), 1ull << 36) + 4096;
+            for (int attempt = 0;; attempt++) {
+                got = 0;
+                rc = hg_cram_decode_bam_host2(c, i1 - i0, sb.data() + i0, major, nref, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), seq_cap, dst + rec_bytes,
+                                              cap - rec_bytes, ro.data(), nullptr, &got, status.data() + i0, name_prefix);
+                bool no_room = false;
+                for (size_t k = i0; k < i1; k++) if (status[k] == hgr::ERR_UNSUPPORTED) no_room = true;    // "does not fit" is one of its meanings
+                if ((rc != HG_OK && rc != HG_EBLOCK) || !no_room || attempt == 1 || seq_cap >= (1ull << 34)) break;   // once: a slice the decoder does not support says -3, too
+                seq_cap = seq_cap * 4 + (64ull << 20);
+            }
+            rec_bytes += got;
+            for (size_t k = 0; k <= i1 - i0; k++) ro_out[i0 - s0 + k] = ro_out[i0 - s0] + ro[k];
+            i0 = i1;
+        }
+        bytes_out = rec_bytes;
+        return rc;
+    };
     uint64_t rec_bytes = 0;
     int rc = HG_OK;
-    // the blocks of one device batch are addressed with 32 bits (cram_records_plan.h): a large file goes through in several batches
-    for (size_t i0 = 0; i0 < ns && rc == HG_OK;) {
-        uint64_t bytes = 0; size_t i1 = i0;
-        while (i1 < ns) {
-            uint64_t b = (uint64_t)sb[i1].core_len + 64;
-            for (uint32_t k = 0; k < sb[i1].nblocks; k++) b += ((uint64_t)sb[i1].len[k] + 15) & ~15ull;
-            if (i1 > i0 && bytes + b > 0xc0000000ull) break;
-            bytes += b; i1++;
+    const std::vector<size_t> scut = cut_ranges(ns, ns >= 2 * ctxs.size() ? ctxs.size() : 1, slice_bytes);
+    if (scut.size() == 2) {
+        rc = decode_range(ctx, 0, ns, bam_out + hb, bam_cap - hb, rec_bytes, rec_off.data());
+    } else {
+        // every further range decodes into a buffer of its own (its place in the stream is only known when the ranges before it are done);
+        // the first one writes in place
+        const size_t nr = scut.size() - 1;
+        std::vector<std::vector<uint8_t>> tmp(nr); std::vector<uint64_t> got(nr, 0); std::vector<int> rrc(nr, HG_OK);
+        std::vector<std::vector<uint64_t>> ro(nr);
+        for (size_t k = 0; k < nr; k++) ro[k].assign(scut[k + 1] - scut[k] + 1, 0);
+        const uint64_t room = bam_cap - hb;
+        auto run = [&](size_t k) {
+            if (k == 0) { rrc[0] = decode_range(ctxs[0], scut[0], scut[1], bam_out + hb, (size_t)room, got[0], ro[0].data()); return; }
+            uint64_t w = 0; for (size_t i = scut[k]; i < scut[k + 1]; i++) w += slice_bytes(i);
+            const uint64_t cap = std::min<uint64_t>(room, (uint64_t)((double)room * 1.5 * (double)w / (double)(all_bytes ? all_bytes : 1)) + (4u << 20));
+            tmp[k].resize((size_t)cap);
+            rrc[k] = decode_range(ctxs[k], scut[k], scut[k + 1], tmp[k].data(), (size_t)cap, got[k], ro[k].data());
+        };
+        {
+            std::vector<std::thread> th;
+            for (size_t k = 1; k < nr; k++) th.emplace_back(run, k);
+            run(0);
+            for (auto &t : th) t.join();
         }
-        std::vector<uint64_t> ro(i1 - i0 + 1, 0);
-        uint64_t got = 0;
-        // Room for bases + qualities: the container headers' `bases` fields say how much, but they are a writer's claim, not a fact (a
-        // writer may leave 0 there): when a slice comes back "no room" the batch is decoded again with more, instead of failing the file.
-        uint64_t seq_cap = std::min<uint64_t>(bases, 1ull << 36) + 4096;
-        for (int attempt = 0;; attempt++) {
-            got = 0;
-            rc = hg_cram_decode_bam_host2(ctx, i1 - i0, sb.data() + i0, major, nref, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), seq_cap, bam_out + hb + rec_bytes,
-                                          bam_cap - hb - rec_bytes, ro.data(), nullptr, &got, status.data() + i0, name_prefix);
-            bool no_room = false;
-            for (size_t k = i0; k < i1; k++) if (status[k] == hgr::ERR_UNSUPPORTED) no_room = true;    // "does not fit" is one of its meanings
-            if ((rc != HG_OK && rc != HG_EBLOCK) || !no_room || attempt == 1 || seq_cap >= (1ull << 34)) break;   // once: a slice the decoder does not support says -3, too
-            seq_cap = seq_cap * 4 + (64ull << 20);
+        bool retry_serial = false;
+        for (size_t k = 0; k < nr; k++) if (rrc[k] == HG_ENOMEM) retry_serial = true;       // a range's private buffer was too small: the plain way
+        if (retry_serial) {
+            std::fill(status.begin(), status.end(), 0);
+            rc = decode_range(ctx, 0, ns, bam_out + hb, bam_cap - hb, rec_bytes, rec_off.data());
+        } else {
+            for (size_t k = 0; k < nr; k++) {
+                if (rrc[k] != HG_OK && (rc == HG_OK || rc == HG_EBLOCK)) rc = rrc[k];
+                if (rec_bytes + got[k] > room) { rc = HG_ENOMEM; break; }
+                if (k) memcpy(bam_out + hb + rec_bytes, tmp[k].data(), (size_t)got[k]);
+                for (size_t i = 0; i + 1 < ro[k].size() + 0; i++) rec_off[scut[k] + i] = rec_off[scut[k]] + ro[k][i];
+                rec_off[scut[k + 1]] = rec_off[scut[k]] + ro[k].back();
+                rec_bytes += got[k];
+            }
         }
-        rec_bytes += got;
-        for (size_t k = 0; k <= i1 - i0; k++) rec_off[i0 + k] = rec_off[i0] + ro[k];
-        i0 = i1;
     }
     *bam_bytes = hb + rec_bytes;
     if (nrecords) *nrecords = rec_off[ns];
@@ -379,22 +489,39 @@ extern "C" int hg_bam_to_cram_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_l
     const size_t nb = blks.size();
     std::vector<std::vector<uint8_t>> cdata(nb); std::vector<uint32_t> clen(nb, 0); std::vector<int32_t> cmeth(nb, 0);
     if (nb) {
-        std::map<int32_t, hg_cram_metrics *> met;
         std::vector<hg_cram_metrics *> mp(nb); std::vector<uint32_t> sets(nb, (1u << 1) | (1u << 4) | (1u << 16));      // GZIP, RANS0, RANS1 (internal method ids)
         std::vector<const uint8_t *> in(nb); std::vector<uint32_t> il(nb); std::vector<uint8_t *> out(nb);
-        for (size_t i = 0; i < nb; i++) {
-            auto it = met.find(blks[i].cid);
-            if (it == met.end()) it = met.emplace(blks[i].cid, hg_cram_metrics_new()).first;
-            mp[i] = it->second; in[i] = blks[i].p; il[i] = blks[i].n;
-            cdata[i].resize(hg_cram_compress_bound(blks[i].n)); out[i] = cdata[i].data();
+        // Several devices (HTS_GPU_DEVICES): the slices are cut into one contiguous range per device; a range has its OWN set of cram_metrics
+        // (one per content id, as cram_encode.c keeps one per data series) and learns its methods from its own blocks in file order, on its own
+        // context and host thread -- the file stays valid CRAM, only the method chosen for a block may differ from a one-device run.
+        const std::vector<hg_ctx *> ctxs = job_contexts(ctx);
+        const std::vector<size_t> scut = cut_ranges(ns, ns >= 2 * ctxs.size() ? ctxs.size() : 1, [&](size_t k) { uint64_t w = 64; for (size_t i = parts[k].b0; i < parts[k].b1; i++) w += blks[i].n; return w; });
+        const size_t nr = scut.size() - 1;
+        std::vector<std::map<int32_t, hg_cram_metrics *>> met(nr);
+        for (size_t r = 0; r < nr; r++)
+            for (size_t k = scut[r]; k < scut[r + 1]; k++)
+                for (size_t i = parts[k].b0; i < parts[k].b1; i++) {
+                    auto it = met[r].find(blks[i].cid);
+                    if (it == met[r].end()) it = met[r].emplace(blks[i].cid, hg_cram_metrics_new()).first;
+                    mp[i] = it->second; in[i] = blks[i].p; il[i] = blks[i].n;
+                    cdata[i].resize(hg_cram_compress_bound(blks[i].n)); out[i] = cdata[i].data();
+                }
+        std::vector<int> rrc(nr, HG_OK);
+        auto run = [&](size_t r) {
+            // slice by slice, so that the metrics see the blocks of a series in file order (trial phase first, then the learnt method)
+            for (size_t k = scut[r]; k < scut[r + 1] && rrc[r] == HG_OK; k++) {
+                const size_t a = parts[k].b0, n = parts[k].b1 - a;
+                if (n) rrc[r] = hg_cram_compress_blocks_metrics_host(ctxs[r], n, mp.data() + a, sets.data() + a, level, 3, in.data() + a, il.data() + a, out.data() + a, clen.data() + a, cmeth.data() + a);
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            for (size_t r = 1; r < nr; r++) th.emplace_back(run, r);
+            run(0);
+            for (auto &t : th) t.join();
         }
-        // slice by slice, so that the metrics see the blocks of a series in file order (trial phase first, then the learnt method)
-        for (size_t k = 0; k < ns && rc == HG_OK; k++) {
-            const size_t a = parts[k].b0, n = parts[k].b1 - a;
-            if (n) rc = hg_cram_compress_blocks_metrics_host(ctx, n, mp.data() + a, sets.data() + a, level, 3, in.data() + a, il.data() + a, out.data() + a, clen.data() + a, cmeth.data() + a);
-        }
-        for (auto &m : met) hg_cram_metrics_free(m.second);
-        if (rc != HG_OK) return rc;
+        for (auto &mm : met) for (auto &m : mm) hg_cram_metrics_free(m.second);
+        for (int r : rrc) if (r != HG_OK) return r;
     }
     // ---- 4. framing
     std::vector<uint8_t> o;

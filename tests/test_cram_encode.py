@@ -11,6 +11,7 @@ import struct
 import numpy as np
 import pytest
 
+from tests import refutil
 from tests import test_cram_records as T
 from tests.test_cram_records_fast import hostlib, fast_call  # noqa: F401  (fixture)
 
@@ -320,3 +321,54 @@ def test_gpu_bam_to_cram_file_and_back(engine):
     for x, y in zip(one, two):
         assert x[0][:11] == y[0][:11] and sorted(x[0][11]) == sorted(y[0][11]), (x[0], y[0])   # RG:Z moves to the end of the tag list
     print("synthetic BAM %d bytes -> CRAM %d bytes (%.2fx)" % (len(bam), len(cram), len(bam) / len(cram)))
+
+
+def _synthetic_bam(nrec_max=40000):
+    import struct
+    from htslib_amd import synth
+    plain, _, _ = synth.bam_stream(12 << 20, 0x5EED0001, 0, True)
+    lt = struct.unpack_from("<i", plain, 4)[0]; p = 8 + lt; nref = struct.unpack_from("<i", plain, p)[0]; p += 4
+    for _ in range(nref): p += 4 + struct.unpack_from("<i", plain, p)[0] + 4
+    q, nrec = p, 0
+    while q + 4 <= len(plain) and nrec < nrec_max:
+        nxt = q + 4 + struct.unpack_from("<i", plain, q)[0]
+        if nxt > len(plain): break
+        q = nxt; nrec += 1
+    return plain[:q], nref, nrec
+
+
+@pytest.mark.gpu
+def test_gpu_file_decode_sharded_over_several_contexts_is_byte_identical(engine, tmp_path):
+    """HTS_GPU_DEVICES names several devices: a whole-file decode cuts its blocks and slices into one contiguous range per entry, each range on its
+    own context / host thread, and joins the outputs in file order.  "0,0,0" = three contexts on the one GPU of the test box: the
+    sharded result must be the unsharded one, byte for byte.  (The variable is read once per process: the sharded run is a child process.)"""
+    import subprocess, sys, os
+    bam, nref, nrec = _synthetic_bam()
+    rc, cram, n = _bam_to_cram(engine, bam, [None] * nref, 2500)
+    assert rc == 0 and n == nrec and nrec >= 20000
+    rc, want, n1 = _file_to_bam(engine, cram, [None] * nref)
+    assert rc == 0 and n1 == nrec
+    (tmp_path / "in.cram").write_bytes(cram)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from htslib_amd import _native as nat\n"
+            "from tests.test_cram_encode import _file_to_bam\n"
+            "eng = nat.Engine(0)\n"
+            "rc, out, n = _file_to_bam(eng, open(%r, 'rb').read(), [None] * %d)\n"
+            "assert rc == 0, rc\n"
+            "open(%r, 'wb').write(out); print('sharded ok', n)\n") % (refutil.ROOT, str(tmp_path / "in.cram"), nref, str(tmp_path / "out.bam"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HTS_GPU_DEVICES="0,0,0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sharded ok %d" % nrec in r.stdout, r.stderr[-3000:]
+    assert (tmp_path / "out.bam").read_bytes() == want
+    # the writer, sharded the same way (one set of cram_metrics per range: a block's method may differ, the records may not)
+    (tmp_path / "in.bam").write_bytes(bam)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from htslib_amd import _native as nat\n"
+            "from tests.test_cram_encode import _bam_to_cram\n"
+            "eng = nat.Engine(0)\n"
+            "rc, out, n = _bam_to_cram(eng, open(%r, 'rb').read(), [None] * %d, 2500)\n"
+            "assert rc == 0, rc\n"
+            "open(%r, 'wb').write(out); print('sharded ok', n)\n") % (refutil.ROOT, str(tmp_path / "in.bam"), nref, str(tmp_path / "out.cram"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HTS_GPU_DEVICES="0,0,0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sharded ok %d" % nrec in r.stdout, r.stderr[-3000:]
+    rc, again, n2 = _file_to_bam(engine, (tmp_path / "out.cram").read_bytes(), [None] * nref)
+    assert rc == 0 and n2 == nrec and again == want
