@@ -2,7 +2,7 @@
 # Round-3 measurement on the GPU box: the default bench line (headline + extra), rocprofv3 kernel stats (CSV) of the single ops, HBM traffic PMC passes
 # (FETCH_SIZE / WRITE_SIZE, separate runs, kernel-trace only), the bgzip round trip.   usage: bash scripts/round3_measure.sh <outdir under gpurun_out>
 OUT=$(realpath -m "$1"); ROOT=$(pwd); mkdir -p "$OUT"
-python bench.py > "$OUT/bench_all.json" 2> "$OUT/bench_all.err"; echo "bench rc=$?"
+t0=$(date +%s); python bench.py > "$OUT/bench_all.json" 2> "$OUT/bench_all.err"; echo "bench rc=$? seconds=$(( $(date +%s) - t0 ))"
 cd /tmp; export TMPDIR=/tmp
 prof() { name=$1; shift; timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$name" -o $name -- python "$ROOT/bench.py" "$@" > "$OUT/stats_$name.log" 2>&1; echo "prof $name rc=$?"; }
 prof inflate --op inflate --no-cpu-baseline
