@@ -867,6 +867,18 @@ def op_e2e(run: Run, S: Staged):
         dt = time.perf_counter() - t
         L.bgzf_close(fp)
         out["read_GBps"] = round(tot / dt / 1e9, 3) if tot == S.total_u else None
+        if label == "gpu":
+            # the same loop on a second handle: the first one left its device context and pinned windows parked for it
+            fp = L.bgzf_open(path.encode(), b"r")
+            t = time.perf_counter(); tot = 0
+            while True:
+                n = L.bgzf_read(fp, buf, chunk)
+                if n <= 0:
+                    break
+                tot += n
+            dt = time.perf_counter() - t
+            L.bgzf_close(fp)
+            out["read_next_handle_GBps"] = round(tot / dt / 1e9, 3) if tot == S.total_u else None
         # ---- random access
         fp = L.bgzf_open(path.encode(), b"r")
         if threads:

@@ -151,6 +151,36 @@ struct WriteBatch {
 
 enum Kind { K_READ, K_WRITE, K_GZREAD, K_GZWRITE };
 
+// ---- contexts and pipes outlive their handle.  Opening the HIP side of a handle costs ~40 ms and pinning its windows ~0.3 ms per MiB (a streaming
+// reader: ~250 MiB); a program that opens one BGZF file after another (merge, cat, a region loop over many files) would pay that every time, and again
+// to unpin at close.  A closed handle therefore parks its device context with the pipes (and their buffers) it grew, and the next handle on that
+// device takes them over as they are.  At most two parked contexts per device (a reader and a writer); the rest is freed.  They live until exit.
+// HTS_GPU_KEEP=0 turns parking off.
+struct Parked { int dev; hg_ctx *ctx; std::vector<hg_pipe *> pipes; };
+class EnginePark {
+    std::mutex m;
+    std::vector<Parked> v;
+public:
+    bool take(int dev, hg_ctx *&ctx, std::vector<hg_pipe *> &pipes) {
+        std::lock_guard<std::mutex> lk(m);
+        for (size_t i = v.size(); i-- > 0;)
+            if (v[i].dev == dev) { ctx = v[i].ctx; pipes.swap(v[i].pipes); v.erase(v.begin() + (long)i); return true; }
+        return false;
+    }
+    void give(int dev, hg_ctx *ctx, std::vector<hg_pipe *> &pipes) {
+        static const bool keep = [] { const char *k = getenv("HTS_GPU_KEEP"); return !k || atoi(k) != 0; }();
+        {
+            std::lock_guard<std::mutex> lk(m);
+            size_t same = 0;
+            for (auto &p : v) same += p.dev == dev;
+            if (keep && same < 2) { v.push_back(Parked{dev, ctx, std::move(pipes)}); return; }
+        }
+        for (hg_pipe *p : pipes) hg_pipe_destroy(p);
+        hg_destroy(ctx);
+    }
+};
+EnginePark &engine_park() { static EnginePark *p = new EnginePark(); return *p; }
+
 // HTS_GPU_STATS=1: where a reader's wall time went, printed to stderr when the handle closes (seconds, per thread)
 struct ReadStats { double io_read = 0, io_frame = 0, io_submit = 0, io_idle = 0, c_wait = 0, c_copy = 0; uint64_t batches = 0, copies = 0; };
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -162,6 +192,8 @@ struct Engine {
     Kind kind = K_READ;
     hg_ctx *gpu = nullptr;                 // first device (stateless helpers: gzip streams, CRCs)
     std::vector<hg_ctx *> devs;            // every device of the handle; pipe i lives on devs[i % devs.size()]
+    std::vector<int> dev_ids;              // their ordinals
+    std::vector<std::vector<hg_pipe *>> spare;   // per device: pipes taken over from a closed handle, not yet in use
     int NPIPES = NPIPES_MIN;
     void *own_block = nullptr;     // the malloc'd 128 KiB block (fp->uncompressed_block is re-pointed by readers)
     std::thread th;
@@ -375,9 +407,16 @@ void reader_main(Engine *e) {
     }
 }
 
+// pipe number i of the handle: one left by a closed handle on that device, or a new one
+bool get_pipe(Engine *e, int i, hg_pipe **out) {
+    const size_t d = (size_t)i % e->devs.size();
+    if (!e->spare[d].empty()) { *out = e->spare[d].back(); e->spare[d].pop_back(); return true; }
+    return hg_pipe_create(e->devs[d], out) == HG_OK;
+}
+
 bool start_reader(Engine *e) {
     if (e->started) return true;
-    for (int i = 0; i < e->NPIPES; i++) if (!e->rb[i].pipe && hg_pipe_create(e->devs[(size_t)i % e->devs.size()], &e->rb[i].pipe) != HG_OK) return false;
+    for (int i = 0; i < e->NPIPES; i++) if (!e->rb[i].pipe && !get_pipe(e, i, &e->rb[i].pipe)) return false;
     e->read_off = hg_htell(e->fp->fp);
     e->started = true;
     e->th = std::thread(reader_main, e);
@@ -747,7 +786,7 @@ void writer_main(Engine *e) {
 
 bool start_writer(Engine *e) {
     if (e->started) return true;
-    for (int i = 0; i < e->NPIPES; i++) if (!e->wb[i].pipe && hg_pipe_create(e->devs[(size_t)i % e->devs.size()], &e->wb[i].pipe) != HG_OK) return false;
+    for (int i = 0; i < e->NPIPES; i++) if (!e->wb[i].pipe && !get_pipe(e, i, &e->wb[i].pipe)) return false;
     e->started = true;
     e->th = std::thread(writer_main, e);
     return true;
@@ -833,10 +872,16 @@ void stop_engine(Engine *e) {
         e->th.join();
         e->started = false;
     }
-    for (auto &b : e->rb) if (b.pipe) { if (b.submitted) (void)hg_pipe_wait(b.pipe, nullptr, nullptr, nullptr, nullptr, nullptr); hg_pipe_destroy(b.pipe); b.pipe = nullptr; }
-    for (auto &b : e->wb) if (b.pipe) { hg_pipe_destroy(b.pipe); b.pipe = nullptr; }
-    for (hg_ctx *c : e->devs) hg_destroy(c);
-    e->devs.clear(); e->gpu = nullptr;
+    // idle pipes go back to their device's list; context + pipes are parked for the next handle (EnginePark)
+    if (e->devs.empty()) { if (e->pfd >= 0) { close(e->pfd); e->pfd = -1; } return; }
+    for (int i = 0; i < NPIPES_MAX; i++) {
+        ReadBatch &b = e->rb[i];
+        if (b.pipe) { if (b.submitted) (void)hg_pipe_wait(b.pipe, nullptr, nullptr, nullptr, nullptr, nullptr); b.submitted = false; e->spare[(size_t)i % e->devs.size()].push_back(b.pipe); b.pipe = nullptr; }
+        WriteBatch &w = e->wb[i];
+        if (w.pipe) { e->spare[(size_t)i % e->devs.size()].push_back(w.pipe); w.pipe = nullptr; }
+    }
+    for (size_t i = 0; i < e->devs.size(); i++) engine_park().give(e->dev_ids[i], e->devs[i], e->spare[i]);
+    e->devs.clear(); e->dev_ids.clear(); e->spare.clear(); e->gpu = nullptr;
     if (e->pfd >= 0) { close(e->pfd); e->pfd = -1; }
 }
 
@@ -859,8 +904,12 @@ Engine *new_engine(BGZF *fp, Kind kind) {
     e->fp = fp; e->kind = kind;
     for (int d : device_list()) {
         hg_ctx *c = nullptr;
-        if (hg_init(d, &c) != HG_OK) { for (hg_ctx *x : e->devs) hg_destroy(x); delete e; errno = ENODEV; return nullptr; }
-        e->devs.push_back(c);
+        std::vector<hg_pipe *> pipes;
+        if (!engine_park().take(d, c, pipes) && hg_init(d, &c) != HG_OK) {
+            for (size_t i = 0; i < e->devs.size(); i++) engine_park().give(e->dev_ids[i], e->devs[i], e->spare[i]);
+            delete e; errno = ENODEV; return nullptr;
+        }
+        e->devs.push_back(c); e->dev_ids.push_back(d); e->spare.push_back(std::move(pipes));
     }
     e->gpu = e->devs[0];
     e->NPIPES = e->devs.size() == 1 ? NPIPES_MIN : (int)std::min<size_t>(2 * e->devs.size(), (size_t)NPIPES_MAX);
