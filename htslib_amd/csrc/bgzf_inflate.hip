@@ -14,7 +14,7 @@
 //     that the hot path is one compare;
 //   * the symbol loop of a deflate block is hand-scheduled assembly (inflate_loop_asm.inc): every lane computes the same
 //     decode state, so what bounds the loop is instruction issue -- one vector and one scalar instruction per SIMD per
-//     quad-cycle -- and the work is split evenly between the two sides by hand (17.9 VALU + 17.5 SALU per symbol against the
+//     quad-cycle -- and the work is split evenly between the two sides by hand (17.7 VALU + 15.0 SALU per symbol against the
 //     compiler's 39 + 15; profiles/r03_inflate_instruction_mix.txt);
 //   * output goes into a 1 KiB LDS ring per wave and nowhere else: a literal is one ds_write of the table entry, a match is
 //     ring -> ring (or global -> ring for a look-back beyond the ring: the wave's own flushed output, whose load is not waited
