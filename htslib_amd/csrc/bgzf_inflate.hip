@@ -120,8 +120,8 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                     S.u.b.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
                 if (lane < 32) S.u.b.lens[288 + lane] = 5;
                 wave_sync();
-                if (build_table<KIND_LITLEN, LIT_RB, LIT_TAB, 5>(S, S.lit, 0, 288, lane)) return ST_INFLATE;
-                if (build_table<KIND_DIST, DIST_RB, DIST_TAB, 1>(S, S.dist, 288, 32, lane)) return ST_INFLATE;
+                if (uni((uint32_t)build_table<KIND_LITLEN, LIT_RB, LIT_TAB, 5>(S, S.lit, 0, 288, lane))) return ST_INFLATE;
+                if (uni((uint32_t)build_table<KIND_DIST, DIST_RB, DIST_TAB, 1>(S, S.dist, 288, 32, lane))) return ST_INFLATE;
             } else {
                 // ---- dynamic codes (RFC 1951 3.2.7) ----
                 br_refill(br, lane);
@@ -146,7 +146,7 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                     if (lane == 0) S.u.b.lens[sym] = (uint8_t)v;
                 }
                 wave_sync();
-                if (build_table<KIND_PRE, PRE_RB, DIST_TAB, 1>(S, S.dist, 0, 19, lane)) return ST_INFLATE;
+                if (uni((uint32_t)build_table<KIND_PRE, PRE_RB, DIST_TAB, 1>(S, S.dist, 0, 19, lane))) return ST_INFLATE;
                 // the precode must be complete unless trivially small: zlib rejects incomplete
                 // code-length codes outright; build_table allows the 1-code case, which a
                 // conforming encoder never emits -- keep oracle behaviour (complete only).
@@ -184,8 +184,8 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                 wave_sync();
                 if (S.u.b.lens[32 + 256] == 0) return ST_INFLATE;          // no end-of-block code
                 // lengths sit at lens[32 .. 32+nlen+ndist): the precode table in S.dist is dead now
-                if (build_table<KIND_LITLEN, LIT_RB, LIT_TAB, 5>(S, S.lit, 32, (int)nlen, lane)) return ST_INFLATE;
-                if (build_table<KIND_DIST, DIST_RB, DIST_TAB, 1>(S, S.dist, 32 + (int)nlen, (int)ndist, lane)) return ST_INFLATE;
+                if (uni((uint32_t)build_table<KIND_LITLEN, LIT_RB, LIT_TAB, 5>(S, S.lit, 32, (int)nlen, lane))) return ST_INFLATE;
+                if (uni((uint32_t)build_table<KIND_DIST, DIST_RB, DIST_TAB, 1>(S, S.dist, 32 + (int)nlen, (int)ndist, lane))) return ST_INFLATE;
             }
             HG_TACC(1, tph);
             // the table-build scratch overlays the output ring: restore the ring from the wave's own
@@ -212,7 +212,7 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
 }
 
 #ifndef HG_INFLATE_MIN_WAVES
-#define HG_INFLATE_MIN_WAVES 6      // 80 VGPRs, 5.6 KiB LDS per wave -> 24 waves per CU
+#define HG_INFLATE_MIN_WAVES 7      // <= 72 VGPRs (63 used): 7 waves per SIMD, so that the 26 wavefronts the LDS allows are not cut to 24
 #endif
 __global__ __launch_bounds__(WAVES_PER_WG * 64, HG_INFLATE_MIN_WAVES)
 void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
@@ -444,7 +444,10 @@ int launch_bgzf_inflate(hg_ctx *ctx, const void *d_comp, size_t comp_len, const 
     if (nblocks > 0xffffffffull) return HG_EINVAL;
     unsigned int *ticket = next_ticket(ctx);
     if (hipMemsetAsync(ticket, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
-    size_t waves = (size_t)ctx->waves_per_launch;
+#ifndef HG_INFLATE_WAVES_PER_CU
+#define HG_INFLATE_WAVES_PER_CU 26     // what the LDS of a CU holds (160 KiB / 6 KiB)
+#endif
+    size_t waves = (size_t)ctx->cus * HG_INFLATE_WAVES_PER_CU;
     size_t wgs = (waves + WAVES_PER_WG - 1) / WAVES_PER_WG;
     size_t need = (nblocks + WAVES_PER_WG - 1) / WAVES_PER_WG;
     if (wgs > need) wgs = need;

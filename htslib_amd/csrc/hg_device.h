@@ -120,7 +120,10 @@ __device__ __forceinline__ uint32_t crc_word(uint32_t c, uint32_t w) {
 // partial states are concatenated with a 6-step butterfly:
 //     crc(A||B) = crc(A) * x^(8|B|) mod P  xor  crc(B)
 // Returns the finalised CRC in every lane.
-__device__ __forceinline__ uint32_t wave_crc32(const uint8_t *p, uint32_t n, int lane) {
+#ifndef HG_PHASE_FN
+#define HG_PHASE_FN __attribute__((noinline))      /* see inflate_common.h: build_table */
+#endif
+__device__ HG_PHASE_FN uint32_t wave_crc32(const uint8_t *p, uint32_t n, int lane) {
     if (n == 0) return 0;
     uint32_t per = (n + 63u) >> 6;
     int k = 2;

@@ -58,7 +58,7 @@ int hg_init(int device, hg_ctx **out) {
     if (!ctx) return HG_ENOMEM;
     ctx->device = device;
     ctx->cus = prop.multiProcessorCount;
-    // inflate: 24 KiB LDS per 4-wave workgroup -> 6 workgroups (24 waves) per CU
+    // inflate sizes its own launches (26 one-wave workgroups per CU: bgzf_inflate.hip); this is the figure other callers ask for
     ctx->waves_per_launch = ctx->cus * 24;
     if (hipMalloc((void **)&ctx->d_ticket, HG_TICKETS * sizeof(unsigned int)) != hipSuccess) { free(ctx); return HG_ENOMEM; }
     ctx->launch_seq = new std::atomic<unsigned int>(0);

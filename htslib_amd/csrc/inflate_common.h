@@ -20,7 +20,10 @@ constexpr int DIST_RB = 8;
 constexpr int LIT_TAB = HG_LIT_RB == 10 ? 1344 : 864;
 constexpr int DIST_TAB = 416;   // >= ENOUGH(30 symbols, root 8, max 15)  = 402
 constexpr int PRE_RB = 7;
-constexpr int WAVES_PER_WG = 4;
+#ifndef HG_WAVES_PER_WG
+#define HG_WAVES_PER_WG 1      // one wavefront per workgroup: LDS is handed out per workgroup, and 26 x 6 KiB fit a CU where 6 x 24 KiB leave a hole
+#endif
+constexpr int WAVES_PER_WG = HG_WAVES_PER_WG;
 #ifndef HG_RING
 #define HG_RING 1024
 #endif
@@ -77,7 +80,12 @@ __device__ __forceinline__ uint32_t make_entry(int kind, uint32_t sym, uint32_t 
 // Returns 0 ok, 1 invalid code set (over-subscribed / illegal incomplete).
 // All 64 lanes participate; result uniform.
 template <int KIND, int RB, int CAP, int NCHUNK>
-__device__ __forceinline__ int build_table(WaveLds &S, uint32_t *tab, int lens_off, int n, int lane) {
+// The table builder and the CRC pass are real calls: inlined into the kernel they set its register budget (105 VGPRs wanted, 80 granted with
+// spills to scratch); as functions the kernel needs 63 and spills nothing, and the calls cost nothing measurable (one per deflate block).
+#ifndef HG_PHASE_FN
+#define HG_PHASE_FN __attribute__((noinline))
+#endif
+__device__ HG_PHASE_FN int build_table(WaveLds &S, uint32_t *tab, int lens_off, int n, int lane) {
     // ---- zero root + count code lengths --------------------------------
     HG_TRACE(4, 100 + KIND);
     if (lane < 16) { S.u.b.cnt[lane] = 0; }
