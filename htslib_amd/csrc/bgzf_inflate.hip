@@ -120,8 +120,10 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                     S.u.b.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
                 if (lane < 32) S.u.b.lens[288 + lane] = 5;
                 wave_sync();
+                if (uni((uint32_t)build_table<KIND_DIST, DIST_RB, DIST_TAB, 1>(S, S.lit, 288, 32, lane))) return ST_INFLATE;
+                for (int i = lane; i < DIST_TAB; i += 64) S.dist[i] = (uint16_t)S.lit[i];      // built in the litlen area, kept as 16-bit entries
+                wave_sync();
                 if (uni((uint32_t)build_table<KIND_LITLEN, LIT_RB, LIT_TAB, 5>(S, S.lit, 0, 288, lane))) return ST_INFLATE;
-                if (uni((uint32_t)build_table<KIND_DIST, DIST_RB, DIST_TAB, 1>(S, S.dist, 288, 32, lane))) return ST_INFLATE;
             } else {
                 // ---- dynamic codes (RFC 1951 3.2.7) ----
                 br_refill(br, lane);
@@ -146,7 +148,7 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                     if (lane == 0) S.u.b.lens[sym] = (uint8_t)v;
                 }
                 wave_sync();
-                if (uni((uint32_t)build_table<KIND_PRE, PRE_RB, DIST_TAB, 1>(S, S.dist, 0, 19, lane))) return ST_INFLATE;
+                if (uni((uint32_t)build_table<KIND_PRE, PRE_RB, DIST_TAB, 1>(S, S.lit, 0, 19, lane))) return ST_INFLATE;
                 // the precode must be complete unless trivially small: zlib rejects incomplete
                 // code-length codes outright; build_table allows the 1-code case, which a
                 // conforming encoder never emits -- keep oracle behaviour (complete only).
@@ -162,7 +164,7 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                 uint32_t idx = 0, total = nlen + ndist, prev = 0;
                 while (idx < total) {
                     br_refill(br, lane);
-                    uint32_t e = lds_uniform(&S.dist[br_peek(br, PRE_RB)]);
+                    uint32_t e = lds_uniform(&S.lit[br_peek(br, PRE_RB)]);
                     if (!(e & F_LIT)) return ST_INFLATE;
                     br_drop(br, e & 15u);
                     uint32_t sym = e >> 16;
@@ -183,9 +185,11 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
                 }
                 wave_sync();
                 if (S.u.b.lens[32 + 256] == 0) return ST_INFLATE;          // no end-of-block code
-                // lengths sit at lens[32 .. 32+nlen+ndist): the precode table in S.dist is dead now
+                // lengths sit at lens[32 .. 32+nlen+ndist): the precode table (in the litlen area) is dead now
+                if (uni((uint32_t)build_table<KIND_DIST, DIST_RB, DIST_TAB, 1>(S, S.lit, 32 + (int)nlen, (int)ndist, lane))) return ST_INFLATE;
+                for (int i = lane; i < DIST_TAB; i += 64) S.dist[i] = (uint16_t)S.lit[i];      // built in the litlen area, kept as 16-bit entries
+                wave_sync();
                 if (uni((uint32_t)build_table<KIND_LITLEN, LIT_RB, LIT_TAB, 5>(S, S.lit, 32, (int)nlen, lane))) return ST_INFLATE;
-                if (uni((uint32_t)build_table<KIND_DIST, DIST_RB, DIST_TAB, 1>(S, S.dist, 32 + (int)nlen, (int)ndist, lane))) return ST_INFLATE;
             }
             HG_TACC(1, tph);
             // the table-build scratch overlays the output ring: restore the ring from the wave's own
@@ -212,7 +216,7 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
 }
 
 #ifndef HG_INFLATE_MIN_WAVES
-#define HG_INFLATE_MIN_WAVES 7      // <= 72 VGPRs (63 used): 7 waves per SIMD, so that the 26 wavefronts the LDS allows are not cut to 24
+#define HG_INFLATE_MIN_WAVES 8      // <= 64 VGPRs: 8 waves per SIMD, so that the 30 wavefronts the LDS allows are not cut to 28
 #endif
 __global__ __launch_bounds__(WAVES_PER_WG * 64, HG_INFLATE_MIN_WAVES)
 void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
@@ -445,7 +449,7 @@ int launch_bgzf_inflate(hg_ctx *ctx, const void *d_comp, size_t comp_len, const 
     unsigned int *ticket = next_ticket(ctx);
     if (hipMemsetAsync(ticket, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
 #ifndef HG_INFLATE_WAVES_PER_CU
-#define HG_INFLATE_WAVES_PER_CU 26     // what the LDS of a CU holds (160 KiB / 6 KiB)
+#define HG_INFLATE_WAVES_PER_CU 30     // what the LDS of a CU holds (160 KiB / 5 312 B)
 #endif
     size_t waves = (size_t)ctx->cus * HG_INFLATE_WAVES_PER_CU;
     size_t wgs = (waves + WAVES_PER_WG - 1) / WAVES_PER_WG;

@@ -45,14 +45,19 @@ struct BuildScratch {               // only live while the Huffman tables of a d
     uint32_t pad[3];
     uint8_t lens[352];
 };
-struct alignas(1024) WaveLds {         // 1 KiB boundary: the ring (at +5 KiB) is addressed as (pos & 1023) | base
-    uint32_t lit[LIT_TAB];
-    uint32_t dist[DIST_TAB];
+// One wavefront's LDS (= one workgroup's: WAVES_PER_WG is 1, so the struct sits at LDS address 0 and the ring on a 1 KiB boundary, which the
+// symbol loop's ring addressing (pos & 1023) | base needs).  5 312 bytes: 30 wavefronts per CU.
+struct WaveLds {
     union {                         // the output ring shares its LDS with the table-build scratch;
         BuildScratch b;             // it is re-filled from the wave's own output after each build
         uint8_t ring[RING > sizeof(BuildScratch) ? RING : sizeof(BuildScratch)];
     } u;
+    uint32_t lit[LIT_TAB];          // litlen table; also the workspace in which the precode table and the distance table are built
+    uint16_t dist[DIST_TAB];        // distance table, 16-bit entries: [3:0] code bits, 0x20 distance symbol in [12:8] (base and extra bits come
+                                    // from the symbol: a 30-entry table in one VGPR, read with v_readlane), 0x80 second level: [3:0] its index
+                                    // bits, [15:8] its first entry / 2
 };
+static_assert(WAVES_PER_WG == 1, "the ring must sit on a 1 KiB LDS boundary: one WaveLds per workgroup");
 
 enum { KIND_LITLEN = 0, KIND_DIST = 1, KIND_PRE = 2 };
 
@@ -70,10 +75,15 @@ __device__ __forceinline__ uint32_t make_entry(int kind, uint32_t sym, uint32_t 
         return (base << 16) | (extra << 8) | F_BASE | nb;
     }
     if (sym > 29) return 0;                                    // 30, 31: invalid
-    uint32_t extra, base;
-    if (sym < 4) { extra = 0; base = 1 + sym; }
-    else { extra = (sym - 2) >> 1; base = 1 + ((2 + (sym & 1)) << extra); }
-    return (base << 16) | (extra << 8) | F_BASE | nb;
+    return (sym << 8) | F_BASE | nb;                           // 16-bit form (WaveLds::dist); dist_base_extra() has the rest
+}
+
+// distance symbol -> base | extra bit count << 16 (RFC 1951 3.2.5)
+__device__ __forceinline__ uint32_t dist_base_extra(uint32_t sym) {
+    if (sym > 29) return 0;
+    const uint32_t extra = sym < 4 ? 0 : (sym - 2) >> 1;
+    const uint32_t base = sym < 4 ? 1 + sym : 1 + ((2 + (sym & 1)) << extra);
+    return base | (extra << 16);
 }
 
 // Build a root+subtable decode table from code lengths S.u.b.lens[lens_off ..+n).
@@ -168,7 +178,7 @@ __device__ HG_PHASE_FN int build_table(WaveLds &S, uint32_t *tab, int lens_off, 
             uint32_t sb = v - RB;
             uint32_t off = atomicAdd(&S.u.b.alloc, 1u << sb);
             if (off + (1u << sb) > (uint32_t)CAP) { bad = 1; tab[i] = 0; }
-            else tab[i] = (off << 16) | (sb << 8) | F_SUB | RB;
+            else tab[i] = KIND == KIND_DIST ? ((off >> 1) << 8) | F_SUB | sb : (off << 16) | (sb << 8) | F_SUB | RB;
         }
     }
     if (__ballot(bad)) return 1;
@@ -180,7 +190,7 @@ __device__ HG_PHASE_FN int build_table(WaveLds &S, uint32_t *tab, int lens_off, 
             uint32_t sym = (uint32_t)(c * 64 + lane);
             uint32_t rev = __brev(mycode) >> (32 - len);
             uint32_t root = tab[rev & ((1u << RB) - 1)];
-            uint32_t off = root >> 16, sb = (root >> 8) & 0xf;
+            const uint32_t off = KIND == KIND_DIST ? ((root >> 8) & 0xffu) << 1 : root >> 16, sb = KIND == KIND_DIST ? root & 0xfu : (root >> 8) & 0xfu;
             uint32_t e = make_entry(KIND, sym, len - RB, false);
             for (uint32_t idx = rev >> RB; idx < (1u << sb); idx += 1u << (len - RB)) tab[off + idx] = e;
         }
