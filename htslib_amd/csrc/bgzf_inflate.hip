@@ -216,7 +216,7 @@ __device__ __forceinline__ int inflate_stream(WaveLds &S, BitReader &br, uint32_
 }
 
 #ifndef HG_INFLATE_MIN_WAVES
-#define HG_INFLATE_MIN_WAVES 8      // <= 64 VGPRs: 8 waves per SIMD, so that the 30 wavefronts the LDS allows are not cut to 28
+#define HG_INFLATE_MIN_WAVES 8      // <= 64 VGPRs: 8 waves per SIMD, with the LDS at 4.5 KiB per wavefront
 #endif
 __global__ __launch_bounds__(WAVES_PER_WG * 64, HG_INFLATE_MIN_WAVES)
 void bgzf_inflate_kernel(const uint8_t *__restrict__ comp, uint64_t comp_len,
@@ -449,7 +449,7 @@ int launch_bgzf_inflate(hg_ctx *ctx, const void *d_comp, size_t comp_len, const 
     unsigned int *ticket = next_ticket(ctx);
     if (hipMemsetAsync(ticket, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
 #ifndef HG_INFLATE_WAVES_PER_CU
-#define HG_INFLATE_WAVES_PER_CU 30     // what the LDS of a CU holds (160 KiB / 5 312 B)
+#define HG_INFLATE_WAVES_PER_CU 32     // 4.5 KiB of LDS and 64 VGPRs per wavefront: the 8 wavefronts per SIMD the hardware has slots for
 #endif
     size_t waves = (size_t)ctx->cus * HG_INFLATE_WAVES_PER_CU;
     size_t wgs = (waves + WAVES_PER_WG - 1) / WAVES_PER_WG;

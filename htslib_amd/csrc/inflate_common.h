@@ -46,13 +46,15 @@ struct BuildScratch {               // only live while the Huffman tables of a d
     uint8_t lens[352];
 };
 // One wavefront's LDS (= one workgroup's: WAVES_PER_WG is 1, so the struct sits at LDS address 0 and the ring on a 1 KiB boundary, which the
-// symbol loop's ring addressing (pos & 1023) | base needs).  5 312 bytes: 30 wavefronts per CU.
+// symbol loop's ring addressing (pos & 1023) | base needs).  4 608 bytes: under the 5 KiB step that 32 wavefronts per CU need.
 struct WaveLds {
     union {                         // the output ring shares its LDS with the table-build scratch;
         BuildScratch b;             // it is re-filled from the wave's own output after each build
         uint8_t ring[RING > sizeof(BuildScratch) ? RING : sizeof(BuildScratch)];
     } u;
-    uint32_t lit[LIT_TAB];          // litlen table; also the workspace in which the precode table and the distance table are built
+    uint32_t lit[1 << LIT_RB];      // litlen root table (32-bit entries); also the workspace in which the precode table and the distance table are built
+    uint16_t litsub[LIT_TAB - (1 << LIT_RB)];   // litlen second level, 16-bit entries: [3:0] code bits, 0x10 literal in [15:8], 0x20 length symbol
+                                    // (0..28) in [12:8], 0x40 end of block; entry k of the table = litsub[k - 512]
     uint16_t dist[DIST_TAB];        // distance table, 16-bit entries: [3:0] code bits, 0x20 distance symbol in [12:8] (base and extra bits come
                                     // from the symbol: a 30-entry table in one VGPR, read with v_readlane), 0x80 second level: [3:0] its index
                                     // bits, [15:8] its first entry / 2
@@ -63,6 +65,11 @@ enum { KIND_LITLEN = 0, KIND_DIST = 1, KIND_PRE = 2 };
 
 __device__ __forceinline__ uint32_t make_entry(int kind, uint32_t sym, uint32_t nb, bool root) {
     if (kind == KIND_PRE) return (sym << 16) | F_LIT | nb;
+    if (kind == KIND_LITLEN && !root) {                        // second level: 16-bit form (WaveLds::litsub); len_base_extra() has the rest
+        if (sym < 256) return (sym << 8) | F_LIT | nb;
+        if (sym == 256) return F_EOB | nb;
+        return sym - 257 > 28 ? 0u : ((sym - 257) << 8) | F_BASE | nb;
+    }
     if (kind == KIND_LITLEN) {
         if (sym < 256) return (sym << 16) | F_LIT | nb | (root ? F_FAST : 0u);
         if (sym == 256) return F_EOB | nb;
@@ -78,12 +85,21 @@ __device__ __forceinline__ uint32_t make_entry(int kind, uint32_t sym, uint32_t 
     return (sym << 8) | F_BASE | nb;                           // 16-bit form (WaveLds::dist); dist_base_extra() has the rest
 }
 
-// distance symbol -> base | extra bit count << 16 (RFC 1951 3.2.5)
-__device__ __forceinline__ uint32_t dist_base_extra(uint32_t sym) {
-    if (sym > 29) return 0;
-    const uint32_t extra = sym < 4 ? 0 : (sym - 2) >> 1;
-    const uint32_t base = sym < 4 ? 1 + sym : 1 + ((2 + (sym & 1)) << extra);
-    return base | (extra << 16);
+// Lane k of ONE VGPR: what the 16-bit entries leave out (RFC 1951 3.2.5) -- distance symbol k: base in [14:0], extra bit count in [18:15];
+// length symbol 257 + k: base in [27:19], extra bit count in [30:28].  Read with v_readlane.
+__device__ __forceinline__ uint32_t sym_base_extra(uint32_t k) {
+    uint32_t v = 0;
+    if (k <= 29) {
+        const uint32_t extra = k < 4 ? 0 : (k - 2) >> 1;
+        const uint32_t base = k < 4 ? 1 + k : 1 + ((2 + (k & 1)) << extra);
+        v = base | (extra << 15);
+    }
+    if (k <= 28) {
+        const uint32_t extra = k < 8 || k == 28 ? 0 : (k - 4) >> 2;
+        const uint32_t base = k < 8 ? 3 + k : k == 28 ? 258 : 3 + ((4 + (k & 3)) << extra);
+        v |= (base << 19) | (extra << 28);
+    }
+    return v;
 }
 
 // Build a root+subtable decode table from code lengths S.u.b.lens[lens_off ..+n).
@@ -192,7 +208,8 @@ __device__ HG_PHASE_FN int build_table(WaveLds &S, uint32_t *tab, int lens_off, 
             uint32_t root = tab[rev & ((1u << RB) - 1)];
             const uint32_t off = KIND == KIND_DIST ? ((root >> 8) & 0xffu) << 1 : root >> 16, sb = KIND == KIND_DIST ? root & 0xfu : (root >> 8) & 0xfu;
             uint32_t e = make_entry(KIND, sym, len - RB, false);
-            for (uint32_t idx = rev >> RB; idx < (1u << sb); idx += 1u << (len - RB)) tab[off + idx] = e;
+            if (KIND == KIND_LITLEN) for (uint32_t idx = rev >> RB; idx < (1u << sb); idx += 1u << (len - RB)) S.litsub[off - (1u << RB) + idx] = (uint16_t)e;
+            else for (uint32_t idx = rev >> RB; idx < (1u << sb); idx += 1u << (len - RB)) tab[off + idx] = e;
         }
     }
     wave_sync();
