@@ -5,23 +5,24 @@
 // (RFC 1951) of one <=64 KiB block + CRC-32 check against the trailer.
 //
 // Mapping (designed for CDNA4, not translated from a CPU inflate):
-//   * one BGZF block per 64-lane wavefront, 4 wavefronts per workgroup; wavefronts are persistent and pull block indices from
+//   * one BGZF block per 64-lane wavefront, one wavefront per workgroup; wavefronts are persistent and pull block indices from
 //     a per-launch ticket counter, so the 168 k blocks of a 10 GiB BAM load-balance over 256 CUs without a tail;
 //   * the compressed stream is read with coalesced 256-byte wave loads: the wave keeps a 64-dword window of the input in ONE
 //     VGPR (+ the next window prefetched in a second one) and the bit reader pulls dwords out of it with v_readlane;
-//   * decode tables live in LDS (9-bit litlen root + zlib-style second level, 8-bit distance root: 5.1 KiB per wave) and are
+//   * decode tables live in LDS (9-bit litlen root + zlib-style second level, 8-bit distance root: 3.5 KiB per wave) and are
 //     built by all 64 lanes (LDS-atomic histogram, ballot-ranked canonical codes); root-table literals carry a sign bit so
 //     that the hot path is one compare;
 //   * the symbol loop of a deflate block is hand-scheduled assembly (inflate_loop_asm.inc): every lane computes the same
 //     decode state, so what bounds the loop is instruction issue -- one vector and one scalar instruction per SIMD per
-//     quad-cycle -- and the work is split evenly between the two sides by hand (17.7 VALU + 15.0 SALU per symbol against the
+//     quad-cycle -- and the work is split evenly between the two sides by hand (17.9 VALU + 15.9 SALU per symbol against the
 //     compiler's 39 + 15; profiles/r03_inflate_instruction_mix.txt);
 //   * output goes into a 1 KiB LDS ring per wave and nowhere else: a literal is one ds_write of the table entry, a match is
 //     ring -> ring (or global -> ring for a look-back beyond the ring: the wave's own flushed output, whose load is not waited
 //     for until the next copy needs the ring); every 256 finished bytes leave the ring as one coalesced dword store per lane;
 //   * the CRC-32 is fused: after the last deflate block the wave re-reads its output (L2-resident), 64 lanes x slice-by-4, and
 //     folds the partials with a 6-step butterfly;
-//   * 80 VGPRs, 6 KiB of LDS per wave -> 24 wavefronts per CU.  gzip members of any length (CRAM GZIP blocks, plain .gz files)
+//   * 64 VGPRs, 4.5 KiB of LDS per wave (16-bit distance / second-level entries; table builder and CRC pass as calls) -> 32
+//     wavefronts per CU.  gzip members of any length (CRAM GZIP blocks, plain .gz files)
 //     use the same decoder in a resumable form (mode 1, gzip_stream_kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
