@@ -35,6 +35,7 @@
 #include "hg_device.h"
 #include "hg_internal.h"
 #include "deflate_huff.h"
+#include "deflate_huff_wg.h"
 
 namespace hgd {
 
@@ -62,7 +63,13 @@ __device__ unsigned long long g_dprof[16];   // 0 total, 1 stage+crc, 2 match+pa
 constexpr int WG = 256;
 constexpr int HB = HG_DEF_HB;                 // hash buckets = 2^HB
 constexpr int MAX_WAYS = 12;                   // most recent positions kept per bucket (the level picks 4, 8 or 12 of them)
-constexpr uint32_t MAX_IN = 0xff00u;           // BGZF_BLOCK_SIZE (htslib/bgzf.h:50)
+#ifndef HG_DEF_MAX_IN
+#define HG_DEF_MAX_IN 0xff00u   // (experiments only: a smaller staged input = more workgroups per CU)
+#endif
+#ifndef HG_DEF_WGS_PER_CU
+#define HG_DEF_WGS_PER_CU 2
+#endif
+constexpr uint32_t MAX_IN = HG_DEF_MAX_IN;           // BGZF_BLOCK_SIZE (htslib/bgzf.h:50)
 #ifndef HG_LS_G0
 #define HG_LS_G0 32      // bytes over which the candidates of the first group are compared in lock step
 #endif
@@ -70,6 +77,12 @@ constexpr uint32_t MAX_IN = 0xff00u;           // BGZF_BLOCK_SIZE (htslib/bgzf.h
 #define HG_LS_G1 24      // ... of the second group (12 ways): 24 costs 0.02 % of size and gives 3.5 % of speed (r02 sweep)
 #endif
 constexpr uint32_t LOCKSTEP = (uint32_t)HG_LS_G0;
+#ifndef HG_DEF_ONEBAR
+#define HG_DEF_ONEBAR 1   // 0: two barriers per pointer-jumping round (rounds 1-2)
+#endif
+#ifndef HG_DEF_SERIAL_HUFF
+#define HG_DEF_SERIAL_HUFF 0   // 1: the single-lane Huffman phase of rounds 1-2 (deflate_huff.h) for A/B runs
+#endif
 constexpr uint32_t TOO_FAR = 4096u;            // a 3-byte match this far away costs more than 3 literals
 
 struct Huff {                                  // overlays the hash table once matching is done
@@ -78,8 +91,8 @@ struct Huff {                                  // overlays the hash table once m
     uint16_t order[320];
     uint16_t ll_code[288];
     uint16_t d_code[32];
-    uint8_t ll_len[288];
-    uint8_t d_len[32];
+    alignas(4) uint8_t ll_len[288];
+    alignas(4) uint8_t d_len[32];
     uint8_t cl_sym[320];
     uint8_t cl_ext[320];
     uint8_t hdr[328];
@@ -101,14 +114,19 @@ struct Lds {
     uint16_t mlen[WG + 2];
     uint16_t mdist[WG];
     uint16_t jump[WG];
+    uint16_t jump2[WG];
     uint8_t mark[WG];
     uint32_t wsum[8];
     uint32_t carry_next;
     uint32_t misc[7];
 };
 static_assert(sizeof(Huff) <= sizeof(uint16_t) * (1 << HB) * MAX_WAYS, "Huff scratch must fit in the hash table");
+static_assert(sizeof(hgdef::HuffWG) <= MAX_IN, "the collective Huffman phase works in the staged input's LDS once matching is done");
 static_assert(sizeof(Lds) <= 80 * 1024, "two workgroups per CU");
 
+// Unaligned reads of the staged input: aligned dword reads glued with v_alignbyte.  (Tried in round 3: gfx950 runs the LDS in unaligned-access
+// mode and the compiler emits ONE ds_read_b64 / b128 for a byte-aligned 8 / 16-byte read -- a third of the LDS instructions -- but a misaligned
+// wide read is slow in the LDS itself: level 6 went from 9.3 to 8.2 GB/s, level 1 from 22.2 to 20.6.)
 __device__ __forceinline__ uint32_t load4(const uint32_t *in32, uint32_t off) {
     uint32_t lo = in32[off >> 2], hi = in32[(off >> 2) + 1];
     return __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
@@ -117,6 +135,45 @@ __device__ __forceinline__ unsigned long long load8(const uint32_t *in32, uint32
     const uint32_t w0 = in32[off >> 2], w1 = in32[(off >> 2) + 1], w2 = in32[(off >> 2) + 2];
     const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, off & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, off & 3u);
     return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ void load16(const uint32_t *in32, uint32_t off, unsigned long long &a, unsigned long long &b) {
+    const uint32_t *q = in32 + (off >> 2);
+    const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4], sh = off & 3u;
+    const uint32_t r0 = __builtin_amdgcn_alignbyte(w1, w0, sh), r1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    const uint32_t r2 = __builtin_amdgcn_alignbyte(w3, w2, sh), r3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
+    a = ((unsigned long long)r1 << 32) | r0; b = ((unsigned long long)r3 << 32) | r2;
+}
+// NB / 4 dwords of the string at byte offset `off`
+template <int NB>
+__device__ __forceinline__ void load_string(const uint32_t *in32, uint32_t off, uint32_t (&out)[NB / 4]) {
+    const uint32_t *q = in32 + (off >> 2);
+    const uint32_t sh = off & 3u;
+    uint32_t w[NB / 4 + 1];
+#pragma unroll
+    for (int j = 0; j <= NB / 4; j++) w[j] = q[j];
+#pragma unroll
+    for (int j = 0; j < NB / 4; j++) out[j] = __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh);
+}
+// Length of the common prefix of the string at `c` and the NB bytes in own[], at most NB: straight-line code, no branches -- NB + 4 bytes read
+// as aligned dwords, every dword shifted into place and compared, the first difference picked with selects from the last dword down.
+// (The lock-step rounds of rounds 1-2 did this 8 or 16 bytes at a time inside a divergent loop; the compiler turned every candidate's
+// bookkeeping into exec-mask branches -- about 330 issue slots per round of nine candidates, a third of them scalar.  The kernel is bound by
+// instruction issue (PMC: 1600 VALU + 800 SALU + 200 LDS instructions per wavefront and chunk), so the instructions are what had to go.)
+template <int NB>
+__device__ __forceinline__ uint32_t common_prefix_fixed(const uint32_t *in32, uint32_t c, const uint32_t (&own)[8]) {
+    const uint32_t *q = in32 + (c >> 2);
+    const uint32_t sh = c & 3u;
+    uint32_t w[NB / 4 + 1];
+#pragma unroll
+    for (int j = 0; j <= NB / 4; j++) w[j] = q[j];
+    uint32_t first = 1u, idx = (uint32_t)NB;
+#pragma unroll
+    for (int j = NB / 4 - 1; j >= 0; j--) {
+        const uint32_t x = __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh) ^ own[j];
+        first = x ? x : first;
+        idx = x ? (uint32_t)(4 * j) : idx;
+    }
+    return idx + ((uint32_t)__builtin_ctz(first) >> 3);
 }
 __device__ __forceinline__ uint32_t hash4(uint32_t v) { return (v * 2654435761u) >> (32 - HB); }
 
@@ -293,10 +350,14 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 const uint32_t p = c0 + (uint32_t)tid;
                 uint32_t best = 0, bd = 0, h = 0;
                 const bool hashable = p + 4u <= n;
-                if (hashable) {
-                    const uint32_t maxl = n - p < 258u ? n - p : 258u;
-                    const uint32_t cur = load4(S.in32, p);
-                    h = hash4(cur);
+                {   // every lane walks through the search (the long-match phase is a wavefront's joint work); a position that cannot start a
+                    // match (the block's last three bytes, the tail of the last chunk) simply has no candidates
+                    const uint32_t maxl = !hashable ? 0u : n - p < 258u ? n - p : 258u;
+                    uint32_t own[8];
+                    load_string<32>(S.in32, hashable ? p : 0u, own);
+                    static_assert(LOCKSTEP <= 32 && HG_LS_G1 <= 32 && LOCKSTEP % 4 == 0 && HG_LS_G1 % 4 == 0, "own[] holds 32 bytes");
+                    const uint32_t cur = own[0];
+                    h = hashable ? hash4(cur) : 0u;
                     // Candidates are evaluated in groups of up to GW table entries (+ distance 1 with the first group: runs are
                     // never in this chunk's table) to bound the registers held per lane: one group for 4 or 8 ways, 8 + 4 for 12.  Inside a group all candidates
                     // advance in LOCKSTEP, 16 or 8 bytes per round, so that a round costs one LDS round trip for every candidate together.
@@ -315,59 +376,32 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
 #pragma unroll
                         for (int w = 0; w < GW; w++) {
                             const uint32_t c = (cw[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
-                            const bool ok = c != 0xffffu && p - c <= 32768u && g * GW + w < WAYS;     // 32 KiB window
+                            const bool ok = hashable && c != 0xffffu && p - c <= 32768u && g * GW + w < WAYS;     // 32 KiB window
                             cand[w] = ok ? c : 0u;
                             if (ok) alive |= 1u << w;
                         }
                         cand[GW] = p >= 1u ? p - 1u : 0u;
-                        if (g == 0 && p >= 1u) alive |= 1u << GW;
+                        if (g == 0 && p >= 1u && hashable) alive |= 1u << GW;
                         // no separate look at the first four bytes: on BAM data most bucket entries are real repeats and survive
                         // it, so it was one more dependent round for nothing
+                        // every candidate over the first LSB bytes, branch-free (common_prefix_fixed); a candidate that gets through them is "alive"
+                        const uint32_t lsb = (WAYS <= 8 || g == 0) ? LOCKSTEP : (uint32_t)HG_LS_G1;
+                        if (WAYS <= 8 || g == 0) {
 #pragma unroll
-                        for (int w = 0; w < G; w++) len[w] = 0;
-                        uint32_t off = 0;
-                        // sixteen bytes per step where the registers allow it (<= 8 ways), else eight: the steps are dependent LDS round
-                        // trips, so fewer and wider ones win (4 -> 8 bytes: +21 % at level 6; 16 bytes: +4 % more at levels 1-5, spills at 12 ways)
-                        if constexpr (WAYS <= 8) {
-                        while (alive != 0u && off < maxl && off < LOCKSTEP) {
-                            const unsigned long long own0 = load8(S.in32, p + off), own1 = load8(S.in32, p + off + 8u);
-                            unsigned long long nx0[G], nx1[G];
-#pragma unroll
-                            for (int w = 0; w < G; w++) {
-                                const uint32_t a = ((alive >> w) & 1u) ? cand[w] + off : 0u;
-                                nx0[w] = load8(S.in32, a); nx1[w] = load8(S.in32, a + 8u);
-                            }
-#pragma unroll
-                            for (int w = 0; w < G; w++) {
-                                if ((alive >> w) & 1u) {
-                                    const unsigned long long x0 = nx0[w] ^ own0, x1 = nx1[w] ^ own1;
-                                    if (x0) { len[w] = off + ((uint32_t)__builtin_ctzll(x0) >> 3); alive &= ~(1u << w); }
-                                    else if (x1) { len[w] = off + 8u + ((uint32_t)__builtin_ctzll(x1) >> 3); alive &= ~(1u << w); }
-                                    else len[w] = off + 16;
-                                }
-                            }
-                            off += 16;
-                        }
+                            for (int w = 0; w < G; w++) len[w] = common_prefix_fixed<(int)LOCKSTEP>(S.in32, cand[w], own);
                         } else {
-                        const uint32_t lsg = g == 0 ? LOCKSTEP : (uint32_t)HG_LS_G1;     // the second group holds the older positions
-                        while (alive != 0u && off < maxl && off < lsg) {
-                            const unsigned long long own = load8(S.in32, p + off);
-                            unsigned long long nxt[G];
 #pragma unroll
-                            for (int w = 0; w < G; w++) nxt[w] = load8(S.in32, ((alive >> w) & 1u) ? cand[w] + off : 0u);
+                            for (int w = 0; w < G; w++) len[w] = common_prefix_fixed<HG_LS_G1>(S.in32, cand[w], own);
+                        }
 #pragma unroll
-                            for (int w = 0; w < G; w++) {
-                                if ((alive >> w) & 1u) {
-                                    const unsigned long long x = nxt[w] ^ own;
-                                    if (x) { len[w] = off + ((uint32_t)__builtin_ctzll(x) >> 3); alive &= ~(1u << w); }
-                                    else len[w] = off + 8;
-                                }
-                            }
-                            off += 8;
+                        for (int w = 0; w < G; w++) {
+                            const bool ok = (alive >> w) & 1u;
+                            len[w] = ok ? len[w] : 0u;
+                            if (len[w] < lsb) alive &= ~(1u << w);
                         }
-                        }
-                        // long-match phase: only the nearest candidate that is still going is extended
-                        // (8 bytes per step); the others keep the LOCKSTEP bytes they have proven.
+                        const uint32_t off = lsb;
+                        // long-match phase: only the nearest candidate that is still going is extended; the others keep the LOCKSTEP
+                        // bytes they have proven.
                         if (alive != 0u && off < maxl) {
                             uint32_t bw = 0, bdist = 0xffffffffu;
 #pragma unroll
@@ -378,8 +412,9 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                             for (int w = 0; w < G; w++) c = bw == (uint32_t)w ? cand[w] : c;
                             uint32_t l = off;
                             while (l < maxl) {                             // 16 bytes per (dependent) round
-                                const unsigned long long x0 = load8(S.in32, c + l) ^ load8(S.in32, p + l);
-                                const unsigned long long x1 = load8(S.in32, c + l + 8) ^ load8(S.in32, p + l + 8);
+                                unsigned long long a0, a1, b0, b1;
+                                load16(S.in32, c + l, a0, a1); load16(S.in32, p + l, b0, b1);
+                                const unsigned long long x0 = a0 ^ b0, x1 = a1 ^ b1;
                                 if (x0) { l += (uint32_t)__builtin_ctzll(x0) >> 3; break; }
                                 if (x1) { l += 8u + ((uint32_t)__builtin_ctzll(x1) >> 3); break; }
                                 l += 16;
@@ -425,6 +460,28 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 if (nx > WG) nx = WG;
                 bool marked = false;
                 if (carry < WG) {
+#if HG_DEF_ONEBAR
+                    // one barrier per round: the doubled pointers alternate between two arrays (a round reads one and writes the other), the marks
+                    // only ever go from 0 to 1 and a round's marks are complete at its barrier
+                    S.jump[tid] = (uint16_t)nx;
+                    S.mark[tid] = (uint8_t)(((uint32_t)tid == carry) && live);
+                    __syncthreads();
+#pragma unroll 1
+                    for (int r = 0; r < 8; r += 2) {
+                        {
+                            const uint32_t j = S.jump[tid];
+                            if (S.mark[tid] && j < WG) S.mark[j] = 1;
+                            S.jump2[tid] = (uint16_t)(j < WG ? (uint32_t)S.jump[j] : (uint32_t)WG);
+                            __syncthreads();
+                        }
+                        {
+                            const uint32_t j = S.jump2[tid];
+                            if (S.mark[tid] && j < WG) S.mark[j] = 1;
+                            S.jump[tid] = (uint16_t)(j < WG ? (uint32_t)S.jump2[j] : (uint32_t)WG);
+                            __syncthreads();
+                        }
+                    }
+#else
                     S.jump[tid] = (uint16_t)nx;
                     S.mark[tid] = (uint8_t)(((uint32_t)tid == carry) && live);
                     __syncthreads();
@@ -437,6 +494,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                         S.jump[tid] = (uint16_t)nj;
                         __syncthreads();
                     }
+#endif
                     marked = S.mark[tid] != 0 && live;
                     if (marked && (uint32_t)tid + step >= WG) S.carry_next = (uint32_t)tid + step - WG;
                     if (tid == 0 && c0 + WG >= n) S.carry_next = 0;   // last chunk: value unused
@@ -476,7 +534,8 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
         // ---- choose the block type and build the codes -------------------------------------
         __syncthreads();
         HD_TACC(2, tp);
-        uint32_t hdr_bits = 0, dyn_bits = 0;
+        uint32_t hdr_bits = 0, dyn_bits = 0; (void)hdr_bits;
+#if HG_DEF_SERIAL_HUFF
         if (level != 0) {
             Huff &H = S.u.h;
             // (the hash table is dead now: its LDS is reused for the Huffman scratch)
@@ -524,6 +583,36 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
             __syncthreads();
             hdr_bits = S.misc[1]; dyn_bits = S.misc[2];
         }
+#else
+        if (level != 0) {
+            // the staged input and the hash table are dead now: the collective Huffman phase (deflate_huff_wg.h) works in the input's LDS,
+            // the codes and the bit-packing window in the table's
+            Huff &H = S.u.h;
+            hgdef::HuffWG &W = *reinterpret_cast<hgdef::HuffWG *>(S.in32);
+            if (tid == 0) S.lfreq[256] = 1;                                       // end of block
+            HD_T0(th);
+            hgdef::wg_code_lengths<WG, 15>(W, S.lfreq, 286, H.ll_len, S.dfreq, 30, H.d_len, tid);
+            HD_TACCH(6, th);
+            hgdef::wg_assign_codes<WG>(W, H.ll_len, 286, H.ll_code, H.d_len, 30, H.d_code, tid);
+            HD_TACCH(7, th);
+            hgdef::wg_dynamic_header<WG>(W, H.ll_len, H.d_len, !(mode == 1 && !last_chunk), tid);
+            HD_TACCH(8, th);
+            if (tid == 0) { S.misc[1] = W.hdr_bits; S.misc[2] = W.hdr_bits; }
+            __syncthreads();
+            {   // size of the dynamic block: one symbol per thread, summed with an LDS atomic
+                uint32_t part = 0;
+                for (int s = tid; s < 286; s += WG) {
+                    uint32_t xb = 0;
+                    if (s > 264 && s < 285) xb = (uint32_t)(s - 261) >> 2;
+                    part += S.lfreq[s] * (H.ll_len[s] + xb);
+                }
+                if (tid < 30) part += S.dfreq[tid] * (H.d_len[tid] + (tid < 4 ? 0u : (uint32_t)(tid - 2) >> 1));
+                if (part) atomicAdd(&S.misc[2], part);
+            }
+            __syncthreads();
+            hdr_bits = S.misc[1]; dyn_bits = S.misc[2];
+        }
+#endif
         HD_TACC(3, tp);
         const uint32_t dyn_bytes = (dyn_bits + 7u) >> 3;
         const bool stored = level == 0 || dyn_bytes >= n + 5u;
@@ -540,13 +629,14 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 o8[hoff] = (mode == 1 && !last_chunk) ? 0 : 1; o8[hoff + 1] = (uint8_t)n; o8[hoff + 2] = (uint8_t)(n >> 8);
                 o8[hoff + 3] = (uint8_t)~n; o8[hoff + 4] = (uint8_t)(~n >> 8);
             }
-            for (uint32_t i = tid; i < n; i += WG) o8[hoff + 5 + i] = in8[i];
+            for (uint32_t i = tid; i < n; i += WG) o8[hoff + 5 + i] = src[i];      // (the staged copy may hold the Huffman scratch by now)
             total_len = hoff + 5u + n + (mode == 1 ? 0u : 8u);
         } else {
             Huff &H = S.u.h;
             for (int i = tid; i < 520; i += WG) H.obuf[i] = 0;
             __syncthreads();
             uint32_t bitpos = hoff * 8u;
+#if HG_DEF_SERIAL_HUFF
             // the dynamic-block header, one byte per thread
             const uint32_t hbytes = (hdr_bits + 7u) >> 3;
             for (uint32_t i0 = 0; i0 < hbytes; i0 += WG) {
@@ -555,6 +645,18 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 if (i < hbytes) { v = H.hdr[i]; nb = (i == hbytes - 1 && (hdr_bits & 7u)) ? (hdr_bits & 7u) : 8u; }
                 pack_bits(S, o32, bitpos, v, nb, tid);
             }
+#else
+            {   // the dynamic-block header: (value, bit count) items of wg_dynamic_header, one per thread
+                const hgdef::HuffWG &W = *reinterpret_cast<const hgdef::HuffWG *>(S.in32);
+                const uint32_t nitems = W.nitems;
+                for (uint32_t i0 = 0; i0 < nitems; i0 += WG) {
+                    const uint32_t i = i0 + (uint32_t)tid;
+                    uint32_t nb = 0; uint64_t v = 0;
+                    if (i < nitems) { v = W.item_v[i]; nb = W.item_n[i]; }
+                    pack_bits(S, o32, bitpos, v, nb, tid);
+                }
+            }
+#endif
             // the tokens (+ end-of-block after the last one)
             for (uint32_t i0 = 0; i0 <= ntok; i0 += WG) {
                 const uint32_t i = i0 + (uint32_t)tid;
@@ -675,9 +777,9 @@ int launch_bgzf_deflate(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_
                         void *d_slots, uint32_t *d_clen, hipStream_t s, int mode, uint32_t *d_crc) {
     if (nblocks == 0) return HG_OK;
     if (nblocks > 0xffffffffull) return HG_EINVAL;
-    size_t wgs = (size_t)ctx->cus * 2;
+    size_t wgs = (size_t)ctx->cus * HG_DEF_WGS_PER_CU;
     if (wgs > nblocks) wgs = nblocks;
-    size_t need = (size_t)ctx->cus * 2 * 65536 * sizeof(uint32_t);
+    size_t need = (size_t)ctx->cus * HG_DEF_WGS_PER_CU * 65536 * sizeof(uint32_t);
     {
         std::lock_guard<std::mutex> order(*ctx->tok_mu);
         if (ctx->d_tok_cap < need) {                                   // allocated once (the size depends on the device only)

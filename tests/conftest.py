@@ -30,8 +30,8 @@ def oracle(built):
 
 @pytest.fixture(scope="session")
 def engine(built):
-    import torch
-    if not torch.cuda.is_available():
+    # (no torch import here: the first one on a fresh box pages in for a minute or two, and the engine is plain HIP)
+    if not os.path.exists("/dev/kfd"):
         pytest.skip("no GPU")
     from htslib_amd import _native as nat
     return nat.Engine(0)

@@ -117,3 +117,102 @@ def test_dynamic_header_and_codes_decode_with_zlib(hh, oracle, case):
     assert zlib.decompress(raw, -15) == data
     rc, got, used = oracle.inflate_raw(raw, len(data) + 16)
     assert rc == 0 and got == data
+
+
+# ---- the workgroup-collective version (htslib_amd/csrc/deflate_huff_wg.h): package-merge lengths, parallel header ----------------
+@pytest.fixture(scope="module")
+def hhw():
+    so = os.path.join(ROOT, "tests", "native", "libhuffwghost.so")
+    src = os.path.join(ROOT, "tests", "native", "huffwg_host.cpp")
+    hdrs = [os.path.join(ROOT, "htslib_amd", "csrc", h) for h in ("deflate_huff.h", "deflate_huff_wg.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in [src] + hdrs):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "htslib_amd", "csrc"), src, "-o", so, "-lpthread"], check=True)
+    L = C.CDLL(so)
+    L.hhw_encode_tokens.restype = C.c_long
+    L.hhw_encode_tokens.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int]
+    L.hhw_build_lengths.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    return L
+
+
+def limited_optimal_cost(freq, maxbits):
+    """Exact optimum of sum(freq * len) under len <= maxbits (Kraft equality): textbook package-merge; an item carries the summed
+    weight of the leaves inside it counted with multiplicity, i.e. what it adds to the cost when selected."""
+    w = sorted(f for f in freq if f)
+    n = len(w)
+    if n < 2:
+        return sum(freq)
+    prev = [(x, x) for x in w]
+    for _ in range(maxbits - 1):
+        pk = [(prev[2 * j][0] + prev[2 * j + 1][0], prev[2 * j][1] + prev[2 * j + 1][1]) for j in range(len(prev) // 2)]
+        prev = sorted([(x, x) for x in w] + pk, key=lambda t: t[0])
+    return sum(t[1] for t in prev[:2 * n - 2])
+
+
+def wg_lengths(hhw, freq, maxbits, nt=32):
+    f = np.asarray(freq, dtype=np.uint32)
+    out = np.zeros(len(f), dtype=np.uint8)
+    hhw.hhw_build_lengths(f.ctypes.data, len(f), maxbits, out.ctypes.data, nt)
+    return out
+
+
+def test_package_merge_list_sizes_reach_the_selection_point():
+    # the walk starts at item 2n - 2 of the last level's list: the list must be that long (15 levels for <= 286 leaves, 7 for <= 19)
+    for levels, nmax in ((15, 286), (7, 19)):
+        for n in range(2, nmax + 1):
+            m = n
+            for _ in range(levels - 1):
+                m = n + m // 2
+            assert m >= 2 * n - 2, (levels, n, m)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_wg_lengths_are_complete_limited_and_exactly_optimal(hhw, seed):
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.choice([19, 30, 286]))
+    kind = seed % 6
+    if kind == 0: freq = rng.integers(0, 1000, n)
+    elif kind == 1: freq = (rng.pareto(0.7, n) * 10).astype(np.int64)
+    elif kind == 2: freq = np.where(rng.random(n) < 0.1, rng.integers(1, 50, n), 0)
+    elif kind == 3: freq = np.array([int(1.6 ** i) for i in range(n)]) % (1 << 30)
+    elif kind == 4: freq = np.ones(n, dtype=np.int64) * int(rng.integers(1, 5))     # all ties
+    else: freq = np.where(np.arange(n) < int(rng.integers(0, 3)), 7, 0)              # 0, 1 or 2 used symbols
+    freq = np.minimum(np.asarray(freq, dtype=np.int64), 1 << 24)
+    maxbits = 7 if n == 19 else 15
+    ln = wg_lengths(hhw, freq, maxbits, nt=256 if seed % 8 == 0 else 32)
+    used = freq > 0
+    assert ln.max() <= maxbits
+    assert sum(2.0 ** -int(l) for l in ln if l) == 1.0
+    if used.sum() >= 2:
+        assert (ln[used] > 0).all() and (ln[~used] == 0).all()
+        assert int((freq * ln).sum()) == limited_optimal_cost(freq.tolist(), maxbits)
+
+
+@pytest.mark.parametrize("nt", [32, 256])
+@pytest.mark.parametrize("case", ["text", "binary", "one_symbol", "empty", "runs", "long_zero_runs", "repeats"])
+def test_wg_dynamic_header_and_codes_decode_with_zlib(hh, hhw, oracle, case, nt):
+    rng = np.random.default_rng(5)
+    data = {"text": b"GATTACA quality IIIIFFFF:::: " * 400, "binary": rng.integers(0, 256, 20000, dtype=np.uint8).tobytes(),
+            "one_symbol": b"A" * 5000, "empty": b"", "runs": bytes([7] * 3000 + [9] * 10 + list(range(256)) * 3),
+            "long_zero_runs": bytes([0, 255] * 2000 + [3] * 50),                 # symbols 1..254 unused: zero runs > 138 in the header
+            "repeats": bytes(rng.permutation(256).astype(np.uint8).tolist() * 40)}[case]   # equal frequencies: long runs of one length
+    tok = np.frombuffer(data, dtype=np.uint8).astype(np.uint32)
+    if case in ("text", "runs") and len(data) > 600:
+        toks, i = [], 0
+        while i < len(data):
+            per = 29 if case == "text" else 1
+            if i >= 300 and i + 40 < len(data) and data[i:i + 40] == data[i - per:i - per + 40] and rng.random() < 0.5:
+                ln = int(rng.integers(3, 41)); toks.append(0x80000000 | ((ln - 3) << 16) | (per - 1)); i += ln
+            else:
+                toks.append(data[i]); i += 1
+        tok = np.array(toks, dtype=np.uint32)
+    out = np.zeros(len(data) * 2 + 1024, dtype=np.uint8)
+    n = hhw.hhw_encode_tokens(tok.ctypes.data, len(tok), out.ctypes.data, len(out), nt)
+    assert n > 0
+    raw = out[:n].tobytes()
+    assert zlib.decompress(raw, -15) == data
+    rc, got, used = oracle.inflate_raw(raw, len(data) + 16)
+    assert rc == 0 and got == data
+    # never larger than the serial construction (package-merge is optimal, the token coding of the header is the same greedy scan)
+    out2 = np.zeros(len(out), dtype=np.uint8)
+    n2 = hh.hh_encode_tokens(tok.ctypes.data, len(tok), out2.ctypes.data, len(out2))
+    assert n <= n2
