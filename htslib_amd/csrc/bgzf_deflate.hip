@@ -36,6 +36,7 @@
 #include "hg_internal.h"
 #include "deflate_huff.h"
 #include "deflate_huff_wg.h"
+#include <type_traits>
 
 namespace hgd {
 
@@ -358,60 +359,50 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                     static_assert(LOCKSTEP <= 32 && HG_LS_G1 <= 32 && LOCKSTEP % 4 == 0 && HG_LS_G1 % 4 == 0, "own[] holds 32 bytes");
                     const uint32_t cur = own[0];
                     h = hashable ? hash4(cur) : 0u;
-                    // Candidates are evaluated in groups of up to GW table entries (+ distance 1 with the first group: runs are
-                    // never in this chunk's table) to bound the registers held per lane: one group for 4 or 8 ways, 8 + 4 for 12.  Inside a group all candidates
-                    // advance in LOCKSTEP, 16 or 8 bytes per round, so that a round costs one LDS round trip for every candidate together.
-                    constexpr int GW = WAYS < 8 ? WAYS : 8, G = GW + 1, NGROUPS = (WAYS + GW - 1) / GW;
+                    // Candidates are evaluated in groups of up to 8 table entries (+ distance 1 with the first group: runs are never in this
+                    // chunk's table) to bound the registers held per lane: one group for 4 or 8 ways, 8 + 4 for 12.  All of this is straight-line
+                    // code -- the kernel is bound by instruction issue, every exec-mask branch costs scalar instructions on top of both sides.
+                    // The best match so far is one key: length << 16 | (32768 - distance): a maximum picks the longer match and, among equals,
+                    // the nearer one.
                     const uint32_t *row32 = (const uint32_t *)&S.u.tab[h * MAX_WAYS];           // 24-byte rows, 8-byte aligned
-#pragma unroll 1
-                    for (int g = 0; g < NGROUPS; g++) {
-                        uint32_t cw[GW / 2];
+                    uint32_t bestkey = 0;
+                    auto group = [&](auto nc_, auto ls_, auto first_, auto d1_) {
+                        constexpr int NC = decltype(nc_)::value, LS = decltype(ls_)::value, FIRST = decltype(first_)::value;
+                        constexpr bool D1 = decltype(d1_)::value;
+                        constexpr int G = NC + (D1 ? 1 : 0);
+                        static_assert(NC % 4 == 0 && FIRST % 4 == 0, "the ways are read eight bytes at a time");
+                        uint32_t cw[NC / 2];
 #pragma unroll
-                        for (int k = 0; k < GW / 2; k += 2) {
-                            const bool in_row = g * GW + 2 * k < WAYS;
-                            const uint2 rw = in_row ? *(const uint2 *)(row32 + g * (GW / 2) + k) : uint2{0xffffffffu, 0xffffffffu};
+                        for (int k = 0; k < NC / 2; k += 2) {
+                            const uint2 rw = *(const uint2 *)(row32 + FIRST / 2 + k);
                             cw[k] = rw.x; cw[k + 1] = rw.y;
                         }
-                        uint32_t cand[G], len[G], alive = 0;
+                        uint32_t cand[G], dist[G];                                               // dist 0 = no candidate
 #pragma unroll
-                        for (int w = 0; w < GW; w++) {
+                        for (int w = 0; w < NC; w++) {
                             const uint32_t c = (cw[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
-                            const bool ok = hashable && c != 0xffffu && p - c <= 32768u && g * GW + w < WAYS;     // 32 KiB window
+                            const bool ok = hashable && c != 0xffffu && p - c <= 32768u;         // 32 KiB window
                             cand[w] = ok ? c : 0u;
-                            if (ok) alive |= 1u << w;
+                            dist[w] = ok ? p - c : 0u;
                         }
-                        cand[GW] = p >= 1u ? p - 1u : 0u;
-                        if (g == 0 && p >= 1u && hashable) alive |= 1u << GW;
-                        // no separate look at the first four bytes: on BAM data most bucket entries are real repeats and survive
-                        // it, so it was one more dependent round for nothing
-                        // every candidate over the first LSB bytes, branch-free (common_prefix_fixed); a candidate that gets through them is "alive"
-                        const uint32_t lsb = (WAYS <= 8 || g == 0) ? LOCKSTEP : (uint32_t)HG_LS_G1;
-                        if (WAYS <= 8 || g == 0) {
-#pragma unroll
-                            for (int w = 0; w < G; w++) len[w] = common_prefix_fixed<(int)LOCKSTEP>(S.in32, cand[w], own);
-                        } else {
-#pragma unroll
-                            for (int w = 0; w < G; w++) len[w] = common_prefix_fixed<HG_LS_G1>(S.in32, cand[w], own);
-                        }
+                        if constexpr (D1) { const bool ok = hashable && p >= 1u; cand[NC] = ok ? p - 1u : 0u; dist[NC] = ok ? 1u : 0u; }
+                        // every candidate over the first LS bytes (common_prefix_fixed); the nearest one that gets through them goes on alone
+                        uint32_t near = 0xffffffffu;
 #pragma unroll
                         for (int w = 0; w < G; w++) {
-                            const bool ok = (alive >> w) & 1u;
-                            len[w] = ok ? len[w] : 0u;
-                            if (len[w] < lsb) alive &= ~(1u << w);
+                            uint32_t l = common_prefix_fixed<LS>(S.in32, cand[w], own);
+                            l = dist[w] ? l : 0u;
+                            if (l >= (uint32_t)LS) near = dist[w] < near ? dist[w] : near;
+                            l = l < maxl ? l : maxl;
+                            const uint32_t key = (l << 16) | (32768u - dist[w]);
+                            bestkey = key > bestkey ? key : bestkey;
                         }
-                        const uint32_t off = lsb;
-                        // long-match phase: only the nearest candidate that is still going is extended; the others keep the LOCKSTEP
-                        // bytes they have proven.
-                        if (alive != 0u && off < maxl) {
-                            uint32_t bw = 0, bdist = 0xffffffffu;
-#pragma unroll
-                            for (int w = 0; w < G; w++)
-                                if (((alive >> w) & 1u) && p - cand[w] < bdist) { bdist = p - cand[w]; bw = (uint32_t)w; }
-                            uint32_t c = 0;
-#pragma unroll
-                            for (int w = 0; w < G; w++) c = bw == (uint32_t)w ? cand[w] : c;
-                            uint32_t l = off;
-                            while (l < maxl) {                             // 16 bytes per (dependent) round
+                        // long-match phase: only the nearest survivor is extended (16 bytes per dependent round); the others keep the LS bytes
+                        // they have proven
+                        if (near != 0xffffffffu && (uint32_t)LS < maxl) {
+                            const uint32_t c = p - near;
+                            uint32_t l = (uint32_t)LS;
+                            while (l < maxl) {
                                 unsigned long long a0, a1, b0, b1;
                                 load16(S.in32, c + l, a0, a1); load16(S.in32, p + l, b0, b1);
                                 const unsigned long long x0 = a0 ^ b0, x1 = a1 ^ b1;
@@ -419,16 +410,16 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                                 if (x1) { l += 8u + ((uint32_t)__builtin_ctzll(x1) >> 3); break; }
                                 l += 16;
                             }
-#pragma unroll
-                            for (int w = 0; w < G; w++) len[w] = bw == (uint32_t)w ? l : len[w];
+                            l = l < maxl ? l : maxl;
+                            const uint32_t key = (l << 16) | (32768u - near);
+                            bestkey = key > bestkey ? key : bestkey;
                         }
-#pragma unroll
-                        for (int w = 0; w < G; w++) {
-                            const uint32_t l = len[w] < maxl ? len[w] : maxl;
-                            const uint32_t d = p - cand[w];
-                            if (l >= 3u && (l > best || (l == best && d < bd))) { best = l; bd = d; }
-                        }
-                    }
+                    };
+                    constexpr int GW = WAYS < 8 ? WAYS : 8;
+                    group(std::integral_constant<int, GW>{}, std::integral_constant<int, (int)LOCKSTEP>{}, std::integral_constant<int, 0>{}, std::true_type{});
+                    if constexpr (WAYS > 8)
+                        group(std::integral_constant<int, WAYS - 8>{}, std::integral_constant<int, HG_LS_G1>{}, std::integral_constant<int, 8>{}, std::false_type{});
+                    best = bestkey >> 16; bd = 32768u - (bestkey & 0xffffu);
                     if (best < 3u || (best == 3u && bd > TOO_FAR) || (LAZY >= 2 && best == 4u && bd > 2048u)) best = 0;
                 }
                 S.mlen[tid] = (uint16_t)best;
