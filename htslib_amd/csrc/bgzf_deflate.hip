@@ -67,8 +67,11 @@ constexpr int MAX_WAYS = 12;                   // most recent positions kept per
 #ifndef HG_DEF_MAX_IN
 #define HG_DEF_MAX_IN 0xff00u   // (experiments only: a smaller staged input = more workgroups per CU)
 #endif
+#ifndef HG_DEF_KERNEL_ATTR
+#define HG_DEF_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))   // 168 VGPRs: three wavefronts per SIMD (the LDS allows three workgroups per CU)
+#endif
 #ifndef HG_DEF_WGS_PER_CU
-#define HG_DEF_WGS_PER_CU 2
+#define HG_DEF_WGS_PER_CU 3
 #endif
 constexpr uint32_t MAX_IN = HG_DEF_MAX_IN;           // BGZF_BLOCK_SIZE (htslib/bgzf.h:50)
 #ifndef HG_LS_G0
@@ -103,8 +106,16 @@ struct Huff {                                  // overlays the hash table once m
     uint32_t nxtA[16], nxtB[16];
 };
 
+// The staged input is a RING of the last 36 KiB (DEFLATE looks back 32 KiB): position x of the block lives at byte x mod RING, the ring's first
+// MIRROR bytes are kept twice (again behind its end) so that a read that starts near the end runs straight on.  With the whole 64 KiB block
+// staged the kernel held 80 KiB of LDS and two workgroups per CU; with the ring it holds 53 KiB: three per CU, +33 % (measured on a build that
+// simply staged half blocks).  A block of up to 36 KiB never wraps; behind that the ring is topped up 2 KiB at a time while the chunks advance.
+constexpr uint32_t RING = 36864u, MIRROR = 64u, REFILL = 2048u, AHEAD = 544u;   // AHEAD: a chunk reads up to 256 + 258 + 19 bytes past its start
+static_assert(RING % 16 == 0 && REFILL == WG * 8 && RING >= 32768u + WG + AHEAD + REFILL, "ring geometry");
+__device__ __forceinline__ uint32_t ro(uint32_t pos) { const uint32_t w = pos - RING; return w < pos ? w : pos; }   // pos mod RING for pos < 2 * RING
+
 struct Lds {
-    uint32_t in32[(MAX_IN + 48) / 4];          // + zero padding: the wide compares read up to 19 bytes past the last position
+    uint32_t in32[(RING + MIRROR) / 4];
     union {
         uint16_t tab[(1 << HB) * MAX_WAYS];
         Huff h;
@@ -122,8 +133,8 @@ struct Lds {
     uint32_t misc[7];
 };
 static_assert(sizeof(Huff) <= sizeof(uint16_t) * (1 << HB) * MAX_WAYS, "Huff scratch must fit in the hash table");
-static_assert(sizeof(hgdef::HuffWG) <= MAX_IN, "the collective Huffman phase works in the staged input's LDS once matching is done");
-static_assert(sizeof(Lds) <= 80 * 1024, "two workgroups per CU");
+static_assert(sizeof(hgdef::HuffWG) <= RING, "the collective Huffman phase works in the staged input's LDS once matching is done");
+static_assert(sizeof(Lds) <= 53 * 1024, "three workgroups per CU");
 
 // Unaligned reads of the staged input: aligned dword reads glued with v_alignbyte.  (Tried in round 3: gfx950 runs the LDS in unaligned-access
 // mode and the compiler emits ONE ds_read_b64 / b128 for a byte-aligned 8 / 16-byte read -- a third of the LDS instructions -- but a misaligned
@@ -189,10 +200,11 @@ __device__ __forceinline__ uint32_t match_len(const uint32_t *in32, uint32_t a, 
     return l < maxl ? l : maxl;
 }
 
-// CRC-32 of the LDS-resident block, all 256 threads; result valid in thread 0.
-__device__ uint32_t wg_crc32(Lds &S, uint32_t n, int tid) {
+// CRC-32 register after the n bytes at the start of the ring (no wrap: n <= RING), all 256 threads; valid in thread 0.  `first`: the bytes are the
+// start of the message (register preset to all ones); the final inversion is the caller's.
+__device__ uint32_t wg_crc32_raw(Lds &S, uint32_t n, int tid, bool first) {
     using namespace hg;
-    if (n == 0) return 0;
+    if (n == 0) return first ? 0xffffffffu : 0u;
     uint32_t per = (n + 255u) >> 8;
     int k = 2;
     while ((1u << k) < per) k++;
@@ -202,7 +214,7 @@ __device__ uint32_t wg_crc32(Lds &S, uint32_t n, int tid) {
     if (beg < 0) beg = 0;
     if (end < 0) end = 0;
     uint32_t len = (uint32_t)(end - beg), q = (uint32_t)beg;
-    uint32_t c = (beg == 0 && end > 0) ? 0xffffffffu : 0u;
+    uint32_t c = (beg == 0 && end > 0 && first) ? 0xffffffffu : 0u;
     const uint8_t *in8 = (const uint8_t *)S.in32;
     uint32_t head = len & 3u;
     for (uint32_t i = 0; i < head; i++) c = crc_byte(c, in8[q + i]);
@@ -226,7 +238,6 @@ __device__ uint32_t wg_crc32(Lds &S, uint32_t n, int tid) {
         r = crc_mulmod(r, X) ^ S.wsum[5];
         r = crc_mulmod(r, X) ^ S.wsum[6];
         r = crc_mulmod(r, X) ^ S.wsum[7];
-        r ^= 0xffffffffu;
     }
     __syncthreads();
     return r;
@@ -277,7 +288,7 @@ __device__ __forceinline__ void pack_bits(Lds &S, uint32_t *out32, uint32_t &bit
 //   4-5: 8 candidates, one-step lazy parse
 //   6-9: 12 candidates, two-step lazy parse, 4-byte matches farther than 2 KiB dropped (they cost more than literals)
 template <int WAYS, int LAZY>
-__global__ __launch_bounds__(WG)
+__global__ __launch_bounds__(WG) HG_DEF_KERNEL_ATTR
 void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *__restrict__ desc, uint32_t nblocks,
                          uint8_t *slots, uint32_t *clen_out, uint32_t *tokbuf, unsigned int *ticket, int level,
                          int mode, uint32_t *crc_out) {
@@ -320,18 +331,42 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
         unsigned long long dacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
         HD_T0(tp); HD_T0(tb);
-        // ---- stage the block in LDS (coalesced 16-byte loads) ----------------------------
-        for (uint32_t i = (uint32_t)tid * 16u; i < n + 32u; i += WG * 16u) {
-            uint4 w = {0, 0, 0, 0};
-            if (i + 16u <= n) __builtin_memcpy(&w, src + i, 16);
-            else if (i < n) {
-                uint8_t t[16];
-                for (int k = 0; k < 16; k++) t[k] = i + k < n ? src[i + k] : 0;
-                __builtin_memcpy(&w, t, 16);
+        // ---- stage the block's first RING bytes (coalesced 16-byte loads) and take the CRC from LDS ----------------
+        // bytes [from, to) of the block into the ring, zeros behind the block's end; from and to are multiples of 16
+        auto stage = [&](uint32_t from, uint32_t to) {
+            for (uint32_t i = from + (uint32_t)tid * 16u; i < to; i += WG * 16u) {
+                uint4 w = {0, 0, 0, 0};
+                if (i + 16u <= n) __builtin_memcpy(&w, src + i, 16);
+                else if (i < n) {
+                    uint8_t t[16];
+                    for (int k = 0; k < 16; k++) t[k] = i + k < n ? src[i + k] : 0;
+                    __builtin_memcpy(&w, t, 16);
+                }
+                const uint32_t r = ro(i) >> 2;
+                S.in32[r] = w.x; S.in32[r + 1] = w.y; S.in32[r + 2] = w.z; S.in32[r + 3] = w.w;
+                if (r < MIRROR / 4) { S.in32[RING / 4 + r] = w.x; S.in32[RING / 4 + r + 1] = w.y; S.in32[RING / 4 + r + 2] = w.z; S.in32[RING / 4 + r + 3] = w.w; }
             }
-            if (i / 4 + 3 < sizeof(S.in32) / 4) {
-                S.in32[i / 4] = w.x; S.in32[i / 4 + 1] = w.y; S.in32[i / 4 + 2] = w.z; S.in32[i / 4 + 3] = w.w;
+        };
+        const uint32_t pad_end = (n + 48u + 15u) & ~15u;                  // the reads behind the last position find zeros
+        uint32_t hi = pad_end < RING ? pad_end : RING;                    // bytes of the block staged so far
+        uint32_t crc;
+        if (n <= RING) {
+            stage(0, hi);
+            __syncthreads();
+            crc = ~wg_crc32_raw(S, n, tid, true);                         // valid in thread 0
+        } else {
+            // a block longer than the ring: CRC of its tail first (staged at the ring's start), then of its head, which stays for the matching
+            stage(RING, pad_end);
+            __syncthreads();
+            const uint32_t tail = wg_crc32_raw(S, n - RING, tid, false);
+            stage(0, RING);
+            __syncthreads();
+            uint32_t head = wg_crc32_raw(S, RING, tid, true);
+            if (tid == 0) {                                                // head * x^(8 * tail bytes) + tail
+                const uint32_t lt = n - RING;
+                for (int j = 0; (lt >> j) != 0u; j++) if ((lt >> j) & 1u) head = hg::crc_mulmod(head, hg::g_crc.xpow[j]);
             }
+            crc = ~(head ^ tail);
         }
         for (int i = tid; i < (1 << HB) * MAX_WAYS / 2; i += WG) ((uint32_t *)S.u.tab)[i] = 0xffffffffu;
         for (int i = tid; i < (1 << HB) / 4; i += WG) S.cnt32[i] = 0;
@@ -339,7 +374,6 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
         if (tid < 32) S.dfreq[tid] = 0;
         if (tid == 0) { S.mlen[WG] = 0; S.mlen[WG + 1] = 0; }
         __syncthreads();
-        const uint32_t crc = wg_crc32(S, n, tid);          // valid in thread 0
 
         HD_TACC(1, tp);
         uint32_t ntok = 0;
@@ -349,13 +383,26 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
             for (uint32_t c0 = 0; c0 < n; c0 += WG) {
                 HD_T0(tq);
                 const uint32_t p = c0 + (uint32_t)tid;
+                // top up the ring for the NEXT chunk: 8 bytes per thread, requested now, stored behind this chunk's search (the bytes they
+                // replace lie more than 32 KiB before the next chunk)
+                const bool refill = hi < pad_end && hi < c0 + WG + AHEAD;
+                uint2 rf = {0, 0};
+                if (refill) {
+                    const uint32_t q = hi + (uint32_t)tid * 8u;
+                    if (q + 8u <= n) __builtin_memcpy(&rf, src + q, 8);
+                    else if (q < n) {
+                        uint8_t t[8];
+                        for (int k = 0; k < 8; k++) t[k] = q + k < n ? src[q + k] : 0;
+                        __builtin_memcpy(&rf, t, 8);
+                    }
+                }
                 uint32_t best = 0, bd = 0, h = 0;
                 const bool hashable = p + 4u <= n;
                 {   // every lane walks through the search (the long-match phase is a wavefront's joint work); a position that cannot start a
                     // match (the block's last three bytes, the tail of the last chunk) simply has no candidates
                     const uint32_t maxl = !hashable ? 0u : n - p < 258u ? n - p : 258u;
                     uint32_t own[8];
-                    load_string<32>(S.in32, hashable ? p : 0u, own);
+                    load_string<32>(S.in32, hashable ? ro(p) : 0u, own);
                     static_assert(LOCKSTEP <= 32 && HG_LS_G1 <= 32 && LOCKSTEP % 4 == 0 && HG_LS_G1 % 4 == 0, "own[] holds 32 bytes");
                     const uint32_t cur = own[0];
                     h = hashable ? hash4(cur) : 0u;
@@ -390,7 +437,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                         uint32_t near = 0xffffffffu;
 #pragma unroll
                         for (int w = 0; w < G; w++) {
-                            uint32_t l = common_prefix_fixed<LS>(S.in32, cand[w], own);
+                            uint32_t l = common_prefix_fixed<LS>(S.in32, ro(cand[w]), own);
                             l = dist[w] ? l : 0u;
                             if (l >= (uint32_t)LS) near = dist[w] < near ? dist[w] : near;
                             l = l < maxl ? l : maxl;
@@ -404,7 +451,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                             uint32_t l = (uint32_t)LS;
                             while (l < maxl) {
                                 unsigned long long a0, a1, b0, b1;
-                                load16(S.in32, c + l, a0, a1); load16(S.in32, p + l, b0, b1);
+                                load16(S.in32, ro(c + l), a0, a1); load16(S.in32, ro(p + l), b0, b1);
                                 const unsigned long long x0 = a0 ^ b0, x1 = a1 ^ b1;
                                 if (x0) { l += (uint32_t)__builtin_ctzll(x0) >> 3; break; }
                                 if (x1) { l += 8u + ((uint32_t)__builtin_ctzll(x1) >> 3); break; }
@@ -438,6 +485,12 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                     }
                 };
                 if (wave == 0) publish();
+                if (refill) {                                              // (every wave is past its search: the barrier above)
+                    const uint32_t r = ro(hi + (uint32_t)tid * 8u) >> 2;
+                    S.in32[r] = rf.x; S.in32[r + 1] = rf.y;
+                    if (r < MIRROR / 4) { S.in32[RING / 4 + r] = rf.x; S.in32[RING / 4 + r + 1] = rf.y; }
+                    hi += REFILL;
+                }
                 __syncthreads();
                 if (wave == 1) publish();
                 // ---- lazy parse by pointer jumping -----------------------------------------
@@ -509,7 +562,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                         hgdef::len_symbol(best, s, xb, xv); atomicAdd(&S.lfreq[257 + s], 1u);
                         hgdef::dist_symbol(bd, s, xb, xv); atomicAdd(&S.dfreq[s], 1u);
                     } else {
-                        const uint32_t byte = in8[p];
+                        const uint32_t byte = in8[ro(p)];
                         tok[idx] = byte;
                         atomicAdd(&S.lfreq[byte], 1u);
                     }
