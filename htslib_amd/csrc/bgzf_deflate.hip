@@ -9,26 +9,22 @@
 // per cent of zlib level 6 in size.
 //
 // Mapping (CDNA4 first, not a port of a CPU deflate):
-//   * one BGZF block per 256-thread workgroup, the whole 64 KiB input staged ONCE in LDS with
-//     coalesced 16-byte loads; every later access (hashing, match extension, literals, CRC) is an
-//     LDS access.  77 KiB of LDS per workgroup -> 2 workgroups (8 waves) per CU, persistent
-//     workgroups pull block tickets from a global counter;
-//   * match finding is position-parallel: the block is walked in chunks of 256 positions, one
-//     position per lane; a lane hashes its 4 bytes, reads the WAYS (4 / 8 / 12 by level) most recent
-//     earlier positions with that hash from a set-associative table in LDS and compares all of
-//     them with its own bytes in LOCK STEP, 16 or 8 bytes per round (the rounds are dependent LDS
-//     round trips: few and wide), then the nearest survivor alone; then the chunk's positions are
-//     inserted (LDS atomics pick the way).  Candidates are always from earlier chunks; distance 1
-//     is probed directly;
-//   * the lazy parse (take a match unless the next position has a longer one) is a chain over
-//     positions; it is resolved per chunk with 8 rounds of pointer jumping in LDS, then the
-//     chosen tokens are compacted in order with ballots and appended to a per-workgroup token
+//   * one BGZF block per 256-thread workgroup; the input is staged in LDS as a RING of the last 36 KiB (32 KiB window + look-ahead, topped
+//     up 2 KiB at a time while the chunks advance), every later access (hashing, match extension, literals, CRC) is an LDS access.  53 KiB of
+//     LDS and <= 168 VGPRs per workgroup -> 3 workgroups (12 waves) per CU, persistent workgroups pull block tickets from a global counter;
+//   * match finding is position-parallel: the block is walked in chunks of 256 positions, one position per lane; a lane hashes its 4 bytes,
+//     reads the WAYS (4 / 8 / 12 by level) most recent earlier positions with that hash from a set-associative table in LDS and compares
+//     each with its own bytes over 32 (24) bytes in straight-line code (aligned dword reads, v_alignbyte, xor, v_ffbl, one unsigned minimum:
+//     the kernel is bound by instruction ISSUE, so the instruction count per candidate is what matters), then the nearest survivor alone,
+//     16 bytes per round; then the chunk's positions are inserted (LDS atomics pick the way).  Candidates are always from earlier chunks;
+//     distance 1 is probed directly;
+//   * the lazy parse (take a match unless the next position has a longer one) is a chain over positions; it is resolved per chunk with 8
+//     rounds of pointer jumping in LDS, then the chosen tokens are compacted in order with ballots and appended to a per-workgroup token
 //     list in HBM while LDS atomics build the litlen/distance histograms;
-//   * Huffman construction (<= 316 symbols) is the serial tail, run by one lane on LDS arrays
-//     (deflate_huff.h, unit-tested on the host);
-//   * bit packing is a prefix scan of code lengths over 256 tokens per step; lanes OR their
-//     <= 48 bits into an LDS staging window with ds_or and the finished dwords leave with
-//     coalesced stores.
+//   * the Huffman phase (<= 286 + 30 + 19 symbols) is a workgroup-collective routine (deflate_huff_wg.h): package-merge code lengths, one
+//     binary search per item and level; canonical codes; the header's run-length coding per run start -- unit-tested on the host;
+//   * bit packing is a prefix scan of code lengths over 256 tokens per step; lanes OR their <= 48 bits into an LDS staging window with
+//     ds_or and the finished dwords leave with coalesced stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "htsgpu.h"
@@ -64,16 +60,13 @@ __device__ unsigned long long g_dprof[16];   // 0 total, 1 stage+crc, 2 match+pa
 constexpr int WG = 256;
 constexpr int HB = HG_DEF_HB;                 // hash buckets = 2^HB
 constexpr int MAX_WAYS = 12;                   // most recent positions kept per bucket (the level picks 4, 8 or 12 of them)
-#ifndef HG_DEF_MAX_IN
-#define HG_DEF_MAX_IN 0xff00u   // (experiments only: a smaller staged input = more workgroups per CU)
-#endif
 #ifndef HG_DEF_KERNEL_ATTR
 #define HG_DEF_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))   // 168 VGPRs: three wavefronts per SIMD (the LDS allows three workgroups per CU)
 #endif
 #ifndef HG_DEF_WGS_PER_CU
 #define HG_DEF_WGS_PER_CU 3
 #endif
-constexpr uint32_t MAX_IN = HG_DEF_MAX_IN;           // BGZF_BLOCK_SIZE (htslib/bgzf.h:50)
+constexpr uint32_t MAX_IN = 0xff00u;           // BGZF_BLOCK_SIZE (htslib/bgzf.h:50)
 #ifndef HG_LS_G0
 #define HG_LS_G0 32      // bytes over which the candidates of the first group are compared in lock step
 #endif
@@ -81,29 +74,14 @@ constexpr uint32_t MAX_IN = HG_DEF_MAX_IN;           // BGZF_BLOCK_SIZE (htslib/
 #define HG_LS_G1 24      // ... of the second group (12 ways): 24 costs 0.02 % of size and gives 3.5 % of speed (r02 sweep)
 #endif
 constexpr uint32_t LOCKSTEP = (uint32_t)HG_LS_G0;
-#ifndef HG_DEF_ONEBAR
-#define HG_DEF_ONEBAR 1   // 0: two barriers per pointer-jumping round (rounds 1-2)
-#endif
-#ifndef HG_DEF_SERIAL_HUFF
-#define HG_DEF_SERIAL_HUFF 0   // 1: the single-lane Huffman phase of rounds 1-2 (deflate_huff.h) for A/B runs
-#endif
 constexpr uint32_t TOO_FAR = 4096u;            // a 3-byte match this far away costs more than 3 literals
 
 struct Huff {                                  // overlays the hash table once matching is done
     uint32_t obuf[520];                        // bit-packing staging window (dwords)
-    uint32_t work[320];
-    uint16_t order[320];
     uint16_t ll_code[288];
     uint16_t d_code[32];
     alignas(4) uint8_t ll_len[288];
     alignas(4) uint8_t d_len[32];
-    uint8_t cl_sym[320];
-    uint8_t cl_ext[320];
-    uint8_t hdr[328];
-    uint32_t work2[32];
-    uint16_t order2[32];
-    uint32_t cntA[34], cntB[34];
-    uint32_t nxtA[16], nxtB[16];
 };
 
 // The staged input is a RING of the last 36 KiB (DEFLATE looks back 32 KiB): position x of the block lives at byte x mod RING, the ring's first
@@ -178,14 +156,19 @@ __device__ __forceinline__ uint32_t common_prefix_fixed(const uint32_t *in32, ui
     uint32_t w[NB / 4 + 1];
 #pragma unroll
     for (int j = 0; j <= NB / 4; j++) w[j] = q[j];
-    uint32_t first = 1u, idx = (uint32_t)NB;
+    // position of the first differing bit: v_ffbl_b32 answers -1 for "no bit set", OR-ing the dword's bit offset into that leaves it -1, so a
+    // plain unsigned minimum over the dwords finds the first difference (4.5 instructions per dword, no condition registers)
+    uint32_t m = 0xffffffffu;
 #pragma unroll
-    for (int j = NB / 4 - 1; j >= 0; j--) {
+    for (int j = 0; j < NB / 4; j++) {
         const uint32_t x = __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh) ^ own[j];
-        first = x ? x : first;
-        idx = x ? (uint32_t)(4 * j) : idx;
+        uint32_t f;
+        asm("v_ffbl_b32 %0, %1" : "=v"(f) : "v"(x));
+        f |= (uint32_t)(32 * j);
+        m = f < m ? f : m;
     }
-    return idx + ((uint32_t)__builtin_ctz(first) >> 3);
+    m >>= 3;
+    return m < (uint32_t)NB ? m : (uint32_t)NB;
 }
 __device__ __forceinline__ uint32_t hash4(uint32_t v) { return (v * 2654435761u) >> (32 - HB); }
 
@@ -504,7 +487,6 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 if (nx > WG) nx = WG;
                 bool marked = false;
                 if (carry < WG) {
-#if HG_DEF_ONEBAR
                     // one barrier per round: the doubled pointers alternate between two arrays (a round reads one and writes the other), the marks
                     // only ever go from 0 to 1 and a round's marks are complete at its barrier
                     S.jump[tid] = (uint16_t)nx;
@@ -525,20 +507,6 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                             __syncthreads();
                         }
                     }
-#else
-                    S.jump[tid] = (uint16_t)nx;
-                    S.mark[tid] = (uint8_t)(((uint32_t)tid == carry) && live);
-                    __syncthreads();
-#pragma unroll 1
-                    for (int r = 0; r < 8; r++) {
-                        const uint32_t j = S.jump[tid];
-                        if (S.mark[tid] && j < WG) S.mark[j] = 1;
-                        const uint32_t nj = j < WG ? (uint32_t)S.jump[j] : (uint32_t)WG;
-                        __syncthreads();
-                        S.jump[tid] = (uint16_t)nj;
-                        __syncthreads();
-                    }
-#endif
                     marked = S.mark[tid] != 0 && live;
                     if (marked && (uint32_t)tid + step >= WG) S.carry_next = (uint32_t)tid + step - WG;
                     if (tid == 0 && c0 + WG >= n) S.carry_next = 0;   // last chunk: value unused
@@ -578,56 +546,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
         // ---- choose the block type and build the codes -------------------------------------
         __syncthreads();
         HD_TACC(2, tp);
-        uint32_t hdr_bits = 0, dyn_bits = 0; (void)hdr_bits;
-#if HG_DEF_SERIAL_HUFF
-        if (level != 0) {
-            Huff &H = S.u.h;
-            // (the hash table is dead now: its LDS is reused for the Huffman scratch)
-            for (int i = tid; i < 288; i += WG) H.ll_len[i] = 0;
-            if (tid < 32) H.d_len[tid] = 0;
-            if (tid == 0) { S.lfreq[256] = 1; S.misc[3] = 0; S.misc[4] = 0; }
-            __syncthreads();
-            // rank-sort the used symbols by frequency: one thread per symbol
-            for (int i = tid; i < 286; i += WG) {
-                const uint32_t f = S.lfreq[i];
-                if (f) { const int r = hgdef::rank_symbol(S.lfreq, 286, i); H.order[r] = (uint16_t)i; H.work[r] = f; atomicAdd(&S.misc[3], 1u); }
-            }
-            if (tid >= 64 && tid < 94) {
-                const int i = tid - 64;
-                const uint32_t f = S.dfreq[i];
-                if (f) { const int r = hgdef::rank_symbol(S.dfreq, 30, i); H.order2[r] = (uint16_t)i; H.work2[r] = f; atomicAdd(&S.misc[4], 1u); }
-            }
-            __syncthreads();
-            HD_T0(th);
-            HD_TACCH(6, th);
-            // serial tails of the two trees on two different waves
-            if (tid == 0) { hgdef::finish_lengths((int)S.misc[3], 15, H.ll_len, H.order, H.work, H.cntA); hgdef::first_codes(H.ll_len, 286, H.cntA, H.nxtA); }
-            if (tid == 64) { hgdef::finish_lengths((int)S.misc[4], 15, H.d_len, H.order2, H.work2, H.cntB); hgdef::first_codes(H.d_len, 30, H.cntB, H.nxtB); }
-            __syncthreads();
-            HD_TACCH(7, th);
-            for (int i = tid; i < 286; i += WG) H.ll_code[i] = hgdef::code_of(H.ll_len, i, H.nxtA);
-            if (tid >= 64 && tid < 94) H.d_code[tid - 64] = hgdef::code_of(H.d_len, tid - 64, H.nxtB);
-            if (tid == 0) {
-                uint32_t hb = hgdef::write_dynamic_header(H.ll_len, H.d_len, H.hdr, H.cl_sym, H.cl_ext, H.work, H.order);
-                if (mode == 1 && !last_chunk) H.hdr[0] &= 0xfe;                 // BFINAL = 0
-                S.misc[1] = hb; S.misc[2] = hb;
-            }
-            __syncthreads();
-            HD_TACCH(8, th);
-            {   // size of the dynamic block: one symbol per thread, summed with an LDS atomic
-                uint32_t part = 0;
-                for (int s = tid; s < 286; s += WG) {
-                    uint32_t xb = 0;
-                    if (s > 264 && s < 285) xb = (uint32_t)(s - 261) >> 2;
-                    part += S.lfreq[s] * (H.ll_len[s] + xb);
-                }
-                if (tid < 30) part += S.dfreq[tid] * (H.d_len[tid] + (tid < 4 ? 0u : (uint32_t)(tid - 2) >> 1));
-                if (part) atomicAdd(&S.misc[2], part);
-            }
-            __syncthreads();
-            hdr_bits = S.misc[1]; dyn_bits = S.misc[2];
-        }
-#else
+        uint32_t dyn_bits = 0;
         if (level != 0) {
             // the staged input and the hash table are dead now: the collective Huffman phase (deflate_huff_wg.h) works in the input's LDS,
             // the codes and the bit-packing window in the table's
@@ -641,7 +560,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
             HD_TACCH(7, th);
             hgdef::wg_dynamic_header<WG>(W, H.ll_len, H.d_len, !(mode == 1 && !last_chunk), tid);
             HD_TACCH(8, th);
-            if (tid == 0) { S.misc[1] = W.hdr_bits; S.misc[2] = W.hdr_bits; }
+            if (tid == 0) S.misc[2] = W.hdr_bits;
             __syncthreads();
             {   // size of the dynamic block: one symbol per thread, summed with an LDS atomic
                 uint32_t part = 0;
@@ -654,9 +573,8 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 if (part) atomicAdd(&S.misc[2], part);
             }
             __syncthreads();
-            hdr_bits = S.misc[1]; dyn_bits = S.misc[2];
+            dyn_bits = S.misc[2];
         }
-#endif
         HD_TACC(3, tp);
         const uint32_t dyn_bytes = (dyn_bits + 7u) >> 3;
         const bool stored = level == 0 || dyn_bytes >= n + 5u;
@@ -680,16 +598,6 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
             for (int i = tid; i < 520; i += WG) H.obuf[i] = 0;
             __syncthreads();
             uint32_t bitpos = hoff * 8u;
-#if HG_DEF_SERIAL_HUFF
-            // the dynamic-block header, one byte per thread
-            const uint32_t hbytes = (hdr_bits + 7u) >> 3;
-            for (uint32_t i0 = 0; i0 < hbytes; i0 += WG) {
-                const uint32_t i = i0 + (uint32_t)tid;
-                uint32_t nb = 0; uint64_t v = 0;
-                if (i < hbytes) { v = H.hdr[i]; nb = (i == hbytes - 1 && (hdr_bits & 7u)) ? (hdr_bits & 7u) : 8u; }
-                pack_bits(S, o32, bitpos, v, nb, tid);
-            }
-#else
             {   // the dynamic-block header: (value, bit count) items of wg_dynamic_header, one per thread
                 const hgdef::HuffWG &W = *reinterpret_cast<const hgdef::HuffWG *>(S.in32);
                 const uint32_t nitems = W.nitems;
@@ -700,7 +608,6 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                     pack_bits(S, o32, bitpos, v, nb, tid);
                 }
             }
-#endif
             // the tokens (+ end-of-block after the last one)
             for (uint32_t i0 = 0; i0 <= ntok; i0 += WG) {
                 const uint32_t i = i0 + (uint32_t)tid;
