@@ -67,7 +67,7 @@ constexpr size_t WINDOW_MAX = 8u << 20;        // 8 MiB of BGZF is 25-45 MiB of 
                                                // under ~200 MiB -- pinning costs ~0.3 ms per MiB at open and as much again at close (32 MiB
                                                // windows: 270 ms before the first GiB arrived, 170 ms to close; steady state is the same)
 constexpr uint64_t PLAIN_MAX = 256ull << 20;   // plain bytes per batch (highly compressible input)
-constexpr size_t WBLOCKS_MIN = 16, WBLOCKS_MAX = 512;
+constexpr size_t WBLOCKS_MIN = 16, WBLOCKS_MAX = 512;    // (1536 blocks = two rounds of the deflate kernel's 768 resident workgroups measured no better: 15.5 against 16-17 GB/s)
 const uint8_t kEof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0,
                           0, 0, 0, 0, 0, 0, 0, 0};
 enum { LOG_ERROR = 1, LOG_WARNING = 3 };
@@ -810,25 +810,30 @@ int submit_write_batch(Engine *e) {
     return 0;
 }
 
+// Open the batch that the next blocks go to (waits for a free pipe).
+int open_write_batch(BGZF *fp, Engine *e) {
+    if (e->w_open) return 0;
+    std::unique_lock<std::mutex> lk(e->m);
+    e->cv.wait(lk, [&] { return e->w_fill - e->w_done < e->NPIPES; });
+    if (e->w_err) { fp->errcode |= e->w_err; return -1; }
+    lk.unlock();
+    WriteBatch &b = e->wb[e->w_fill % e->NPIPES];
+    b.target = fp->mt ? e->w_target : 1;                               // exact mode: one block per job
+    if (fp->mt && e->w_target < WBLOCKS_MAX) e->w_target = e->w_target * 2 < WBLOCKS_MAX ? e->w_target * 2 : WBLOCKS_MAX;
+    b.cap = b.target * (size_t)BGZF_BLOCK_SIZE;
+    b.in = (uint8_t *)hg_pipe_input(b.pipe, b.cap);
+    if (!b.in) { fp->errcode |= BGZF_ERR_IO; return -1; }
+    b.len = 0; b.cuts.assign(1, 0);
+    e->w_open = true;
+    return 0;
+}
+
 // Queue fp->uncompressed_block[0 .. block_offset) as one block (mt_queue, bgzf.c:1852-1895).
 int queue_block(BGZF *fp) {
     Engine *e = E(fp);
     if (fp->block_offset == 0) return 0;
     if (!start_writer(e)) { fp->errcode |= BGZF_ERR_IO; return -1; }
-    if (!e->w_open) {
-        std::unique_lock<std::mutex> lk(e->m);
-        e->cv.wait(lk, [&] { return e->w_fill - e->w_done < e->NPIPES; });
-        if (e->w_err) { fp->errcode |= e->w_err; return -1; }
-        lk.unlock();
-        WriteBatch &b = e->wb[e->w_fill % e->NPIPES];
-        b.target = fp->mt ? e->w_target : 1;                               // exact mode: one block per job
-        if (fp->mt && e->w_target < WBLOCKS_MAX) e->w_target *= 2;
-        b.cap = b.target * (size_t)BGZF_BLOCK_SIZE;
-        b.in = (uint8_t *)hg_pipe_input(b.pipe, b.cap);
-        if (!b.in) { fp->errcode |= BGZF_ERR_IO; return -1; }
-        b.len = 0; b.cuts.assign(1, 0);
-        e->w_open = true;
-    }
+    if (open_write_batch(fp, e) != 0) return -1;
     WriteBatch &b = e->wb[e->w_fill % e->NPIPES];
     memcpy(b.in + b.len, fp->uncompressed_block, (size_t)fp->block_offset);
     b.len += (size_t)fp->block_offset;
@@ -840,6 +845,32 @@ int queue_block(BGZF *fp) {
 }
 
 int drain_writer(BGZF *fp);
+
+// Whole blocks straight from the caller's buffer into the batches (after bgzf_mt(), at a block boundary): the same cuts as the block-by-block
+// path, without the stop in fp->uncompressed_block -- a bulk writer (bgzip, a sorter's output) was bounded by the caller's thread copying every
+// byte twice -- and with the copy helpers for spans of megabytes.  Returns the bytes taken (a multiple of the block size) or -1.
+ssize_t queue_whole_blocks(BGZF *fp, const uint8_t *in, size_t length) {
+    Engine *e = E(fp);
+    size_t blocks = length / BGZF_BLOCK_SIZE, taken = 0;
+    if (!blocks) return 0;
+    if (!start_writer(e)) { fp->errcode |= BGZF_ERR_IO; return -1; }
+    while (blocks) {
+        if (open_write_batch(fp, e) != 0) return -1;
+        WriteBatch &b = e->wb[e->w_fill % e->NPIPES];
+        size_t room = b.target - (b.cuts.size() - 1);
+        const size_t by_cap = (b.cap - b.len) / BGZF_BLOCK_SIZE;
+        if (room > by_cap) room = by_cap;
+        if (room > blocks) room = blocks;
+        if (room) {
+            copy_out(b.in + b.len, in + taken, room * (size_t)BGZF_BLOCK_SIZE);
+            for (size_t i = 0; i < room; i++) { b.len += BGZF_BLOCK_SIZE; b.cuts.push_back(b.len); }
+            e->block_number += room;
+            taken += room * (size_t)BGZF_BLOCK_SIZE; blocks -= room;
+        }
+        if (b.cuts.size() - 1 >= b.target || b.len + BGZF_BLOCK_SIZE > b.cap) { if (submit_write_batch(e) != 0) return -1; }
+    }
+    return (ssize_t)taken;
+}
 
 // A block has been cut (lazy_flush, bgzf.c:1927-1933).  Without bgzf_mt() the reference compresses it on the spot and
 // callers may rely on an exact bgzf_tell() between writes (test/test_bgzf.c test_tell_seek_getc; sam.c:942-943 amends
@@ -1263,6 +1294,12 @@ ssize_t bgzf_write(BGZF *fp, const void *data, size_t length) {
     const uint8_t *in = (const uint8_t *)data;
     size_t left = length;
     while (left) {
+        if (fp->mt && fp->block_offset == 0 && left >= (size_t)BGZF_BLOCK_SIZE && E(fp)) {
+            const ssize_t took = queue_whole_blocks(fp, in, left);
+            if (took < 0) return -1;
+            in += took; left -= (size_t)took;
+            if (!left) break;
+        }
         size_t n = (size_t)(BGZF_BLOCK_SIZE - fp->block_offset);
         if (n > left) n = left;
         memcpy((uint8_t *)fp->uncompressed_block + fp->block_offset, in, n);

@@ -58,6 +58,30 @@ def test_large_reads_go_through_the_copy_helpers(progs, tmp_path):
     assert out.stdout == data
 
 
+def test_bulk_writes_take_whole_blocks_from_the_callers_buffer(progs, tmp_path):
+    """bgzf_write after bgzf_mt() with calls from 3 bytes to 8 MiB: whole blocks skip fp->uncompressed_block (and spans of megabytes use the copy helpers;
+    race detector on in the `thread` build).  Same cuts as a writer that only ever sees 1000-byte calls: identical file and .gzi; the file decompresses."""
+    import numpy as np
+    suf = "_thread" if progs[0].endswith("_thread") else ""
+    exe = str(tmp_path / "bigwrite")
+    r = subprocess.run(["gcc", "-O1", "-g"] + (["-fsanitize=thread"] if suf else []) +
+                       ["-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "bigwrite.c"), "-o", exe,
+                        "-L", OUT, "-lhts_bgzf_fake" + suf, "-Wl,-rpath," + OUT, "-lpthread"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    data = (np.random.default_rng(4).integers(0, 64, 40_000_123, dtype=np.uint8) + 32).tobytes()
+    plain = tmp_path / "big.txt"; plain.write_bytes(data)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")
+    outs = []
+    for mode in ("0", "1"):
+        gz = tmp_path / f"w{mode}.gz"
+        r = subprocess.run([exe, str(plain), str(gz), mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0, (r.returncode, r.stderr.decode()[-2000:])
+        outs.append((gz.read_bytes(), (tmp_path / f"w{mode}.gz.gzi").read_bytes()))
+    assert outs[0] == outs[1]
+    r = subprocess.run([progs[1], "-@4", "-d", "-c", str(tmp_path / "w0.gz")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert r.returncode == 0 and r.stdout == data, r.stderr.decode()[-1500:]
+
+
 def test_a_handle_spreads_its_batches_over_several_devices(progs, tmp_path):
     """HTS_GPU_DEVICES=0-3: one context per device, two pipes each, windows rotate over the devices and come back in submission order (static
     split, no collective).  The reference's bgzip on the front-end + the test double with four "devices": the compressed file is byte-identical to the
