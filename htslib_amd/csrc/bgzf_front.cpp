@@ -67,7 +67,8 @@ constexpr size_t WINDOW_MAX = 8u << 20;        // 8 MiB of BGZF is 25-45 MiB of 
                                                // under ~200 MiB -- pinning costs ~0.3 ms per MiB at open and as much again at close (32 MiB
                                                // windows: 270 ms before the first GiB arrived, 170 ms to close; steady state is the same)
 constexpr uint64_t PLAIN_MAX = 256ull << 20;   // plain bytes per batch (highly compressible input)
-constexpr size_t WBLOCKS_MIN = 16, WBLOCKS_MAX = 512;    // (1536 blocks = two rounds of the deflate kernel's 768 resident workgroups measured no better: 15.5 against 16-17 GB/s)
+constexpr size_t WBLOCKS_MIN = 16, WBLOCKS_MAX = 768;    // = the deflate kernel's resident workgroups on a 256-CU device (3 per CU): a launch lasts as long as
+                                                         // its slowest block whatever their number (trace: 1.68 ms for 512 blocks, back to back, the chip a third empty)
 const uint8_t kEof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0,
                           0, 0, 0, 0, 0, 0, 0, 0};
 enum { LOG_ERROR = 1, LOG_WARNING = 3 };

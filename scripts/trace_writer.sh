@@ -14,6 +14,6 @@ for p in glob.glob(sys.argv[1] + '/**/*memory_copy_trace.csv', recursive=True):
         ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Direction'][12:], '-'))
 ev.sort()
 t0 = ev[0][0]
-for s, e, k, q in ev[-70:-10]:
-    if e - s > 20000: print(f"{(s - t0) / 1e6:10.3f} ms  +{(e - s) / 1e3:8.1f} us  {k:30s} q={q}")
+for s, e, k, q in ev[-90:-10]:
+    if e - s > 5000: print(f"{(s - t0) / 1e6:10.3f} ms  +{(e - s) / 1e3:8.1f} us  {k:30s} q={q}")
 PY
