@@ -724,13 +724,26 @@ extern "C" int hg_debug_get_deflate_profile(unsigned long long *out16, int reset
 
 namespace hg {
 
+size_t bgzf_deflate_tok_bytes(const hg_ctx *ctx) { return (size_t)ctx->cus * HG_DEF_WGS_PER_CU * 65536 * sizeof(uint32_t); }
+
 int launch_bgzf_deflate(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_desc, size_t nblocks, int level,
-                        void *d_slots, uint32_t *d_clen, hipStream_t s, int mode, uint32_t *d_crc) {
+                        void *d_slots, uint32_t *d_clen, hipStream_t s, int mode, uint32_t *d_crc, void *own_tok) {
     if (nblocks == 0) return HG_OK;
     if (nblocks > 0xffffffffull) return HG_EINVAL;
     size_t wgs = (size_t)ctx->cus * HG_DEF_WGS_PER_CU;
     if (wgs > nblocks) wgs = nblocks;
-    size_t need = (size_t)ctx->cus * HG_DEF_WGS_PER_CU * 65536 * sizeof(uint32_t);
+    const size_t need = bgzf_deflate_tok_bytes(ctx);
+    auto kern = level <= 3 ? hgd::bgzf_deflate_kernel<4, 0> : level <= 5 ? hgd::bgzf_deflate_kernel<8, 1> : hgd::bgzf_deflate_kernel<12, 2>;
+    if (own_tok) {
+        // the caller's own token lists (a pipe of the BGZF writer): nothing is shared with other launches, so launches of different pipes overlap
+        // and the next job's workgroups take the CUs the slowest blocks of this one leave idle
+        unsigned int *ticket;
+        { std::lock_guard<std::mutex> order(*ctx->tok_mu); ticket = next_ticket(ctx); }
+        if (hipMemsetAsync(ticket, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
+        hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(hgd::WG), 0, s, (const uint8_t *)d_plain,
+                           d_desc, (uint32_t)nblocks, (uint8_t *)d_slots, d_clen, (uint32_t *)own_tok, ticket, level, mode, d_crc);
+        return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+    }
     {
         std::lock_guard<std::mutex> order(*ctx->tok_mu);
         if (ctx->d_tok_cap < need) {                                   // allocated once (the size depends on the device only)
@@ -738,14 +751,13 @@ int launch_bgzf_deflate(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_
             ctx->d_tok_cap = need;
         }
     }
-    // The token lists (ctx->d_tok) are indexed by workgroup, so two deflate launches of one context must not overlap:
-    // each launch waits for the previous one's completion event, whatever streams the callers use.
+    // The context's token lists (ctx->d_tok) are indexed by workgroup, so two launches that use them must not overlap:
+    // each waits for the previous one's completion event, whatever streams the callers use.
     {
         std::lock_guard<std::mutex> order(*ctx->tok_mu);
         if (ctx->ev_deflate_used && hipStreamWaitEvent(s, ctx->ev_deflate, 0) != hipSuccess) return HG_ELAUNCH;
         unsigned int *ticket = next_ticket(ctx);
         if (hipMemsetAsync(ticket, 0, sizeof(unsigned int), s) != hipSuccess) return HG_ELAUNCH;
-        auto kern = level <= 3 ? hgd::bgzf_deflate_kernel<4, 0> : level <= 5 ? hgd::bgzf_deflate_kernel<8, 1> : hgd::bgzf_deflate_kernel<12, 2>;
         hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(hgd::WG), 0, s, (const uint8_t *)d_plain,
                            d_desc, (uint32_t)nblocks, (uint8_t *)d_slots, d_clen, (uint32_t *)ctx->d_tok,
                            ticket, level, mode, d_crc);

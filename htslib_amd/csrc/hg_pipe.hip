@@ -20,8 +20,8 @@ struct hg_pipe {
     hipEvent_t ev;
     uint8_t *h_in, *h_out, *h_meta;                     // pinned host
     size_t h_in_cap, h_out_cap, h_meta_cap;
-    uint8_t *d_in, *d_out, *d_meta, *d_slots;           // device
-    size_t d_in_cap, d_out_cap, d_meta_cap, d_slots_cap;
+    uint8_t *d_in, *d_out, *d_meta, *d_slots, *d_tok;   // device (d_tok: the deflate kernel's token lists, the pipe's own so that pipes overlap)
+    size_t d_in_cap, d_out_cap, d_meta_cap, d_slots_cap, d_tok_cap;
     int kind;                                            // 0 idle, 1 inflate, 2 deflate
     size_t n;                                            // blocks of the job in flight
     uint64_t out_len;
@@ -82,6 +82,7 @@ void hg_pipe_destroy(hg_pipe *p) {
     if (p->d_out) (void)hipFree(p->d_out);
     if (p->d_meta) (void)hipFree(p->d_meta);
     if (p->d_slots) (void)hipFree(p->d_slots);
+    if (p->d_tok) (void)hipFree(p->d_tok);
     (void)hipEventDestroy(p->ev);
     (void)hipStreamDestroy(p->s);
     free(p);
@@ -157,7 +158,7 @@ int hg_pipe_deflate(hg_pipe *p, size_t len, const uint64_t *cuts, size_t n, int 
     int rc;
     if ((rc = grow_pinned(&p->h_meta, &p->h_meta_cap, dsz + 2 * csz + osz)) || (rc = grow_dev(&p->d_meta, &p->d_meta_cap, dsz + 2 * csz + osz)) ||
         (rc = grow_dev(&p->d_in, &p->d_in_cap, len + 256)) || (rc = grow_dev(&p->d_slots, &p->d_slots_cap, slots + 256)) ||
-        (rc = grow_dev(&p->d_out, &p->d_out_cap, slots + 256))) return rc;
+        (rc = grow_dev(&p->d_out, &p->d_out_cap, slots + 256)) || (rc = grow_dev(&p->d_tok, &p->d_tok_cap, hg::bgzf_deflate_tok_bytes(p->ctx)))) return rc;
     hg_bgzf_desc *d = (hg_bgzf_desc *)p->h_meta;
     for (size_t i = 0; i < n; i++) {
         if (cuts[i + 1] < cuts[i] || cuts[i + 1] - cuts[i] > HG_BGZF_BLOCK_SIZE) return HG_EINVAL;
@@ -171,7 +172,7 @@ int hg_pipe_deflate(hg_pipe *p, size_t len, const uint64_t *cuts, size_t n, int 
               hipMemcpyAsync(p->d_meta, p->h_meta, n * sizeof(hg_bgzf_desc), hipMemcpyHostToDevice, p->s) == hipSuccess &&
               hipMemsetAsync(d_crc, 0, n * 4, p->s) == hipSuccess;
     rc = ok ? hg::launch_bgzf_deflate(p->ctx, p->d_in, (const hg_bgzf_desc *)p->d_meta, n, level, p->d_slots, d_clen, p->s,
-                                      raw ? 1 : 0, d_crc) : HG_ELAUNCH;
+                                      raw ? 1 : 0, d_crc, p->d_tok) : HG_ELAUNCH;
     if (rc == HG_OK)
         rc = hg::launch_bgzf_pack(p->ctx, p->d_slots, (const hg_bgzf_desc *)p->d_meta, d_clen, n, p->d_out, slots + 256, d_poff, d_poff + n,
                                   0, p->s);
