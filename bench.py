@@ -809,9 +809,10 @@ def op_deflate(run: Run, S: Staged, steps: int, warmup: int):
     alg = float(total_u + comp_len)
     out = {"metric": "BGZF deflate throughput, uncompressed GB/s (encode, HBM-resident)", "value": round(sum_u * steps / elapsed / 1e9, 3),
            "unit": "GB/s", "n_gpus": run.world, "steps": steps, "warmup": warmup,
-           "ms_per_step": round(elapsed * 1e3 / steps, 3), "higher_is_better": True, "scaling": "weak",
+           "ms_per_step": round(elapsed * 1e3 / steps, 3), "higher_is_better": True, "scaling": "strong" if S.shard is not None else "weak",
            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": f"BGZF deflate (level {args.level}) of a {args.gib:g} GiB synthetic BAM per GPU, "
+           "config": {"workload": (f"BGZF deflate (level {args.level}) of ONE {args.gib:g} GiB synthetic BAM, block ranges split over the ranks (shard_blocks), "
+                                   if S.shard is not None else f"BGZF deflate (level {args.level}) of a {args.gib:g} GiB synthetic BAM per GPU, ") +
                                   "blocks cut as bam_write1/bgzf_flush_try would", "blocks_per_gpu": nblocks,
                       "plain_bytes_per_gpu": int(total_u), "compressed_bytes_per_gpu": int(comp_len),
                       "ratio": round(total_u / comp_len, 3), "zlib6_ratio": round(total_u / S.comp_len, 3),
@@ -1173,7 +1174,7 @@ def main():
                          "a single op prints that op's line alone; bam = SURVEY 8f N1 (record framing + nibble2base)")
     ap.add_argument("--slices", type=int, default=0, help="CRAM slices of 10 000 reads (rans: default 1000 = 10 M reads; cram: default 256)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="strong: ONE data set split over the ranks by shard_blocks (inflate only)")
+                    help="strong: ONE data set split over the ranks by shard_blocks (--op inflate / deflate / all: the headline and the deflate extra)")
     ap.add_argument("--extra-steps", type=int, default=5, help="timed steps of the `extra` ops in --op all")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

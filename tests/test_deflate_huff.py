@@ -216,3 +216,27 @@ def test_wg_dynamic_header_and_codes_decode_with_zlib(hh, hhw, oracle, case, nt)
     out2 = np.zeros(len(out), dtype=np.uint8)
     n2 = hh.hh_encode_tokens(tok.ctypes.data, len(tok), out2.ctypes.data, len(out2))
     assert n <= n2
+
+
+def test_input_ring_schedule_of_the_deflate_kernel_never_overwrites_live_bytes():
+    """bgzf_deflate.hip stages the block as a ring of RING bytes: before chunk c0 the bytes up to c0 + AHEAD must be there, and the REFILL bytes a chunk requests
+    for the next one may only replace positions more than 32 KiB before that next chunk.  The constants are read from the kernel source; the schedule is the
+    kernel's (`refill = hi < pad_end && hi < c0 + WG + AHEAD`)."""
+    import re
+    src = open(os.path.join(ROOT, "htslib_amd", "csrc", "bgzf_deflate.hip")).read()
+    m = re.search(r"constexpr uint32_t RING = (\d+)u, MIRROR = (\d+)u, REFILL = (\d+)u, AHEAD = (\d+)u;", src)
+    assert m, "ring constants not found"
+    RING, MIRROR, REFILL, AHEAD = map(int, m.groups())
+    WG = 256
+    assert "const bool refill = hi < pad_end && hi < c0 + WG + AHEAD;" in src
+    assert RING % 16 == 0 and REFILL == WG * 8 and MIRROR >= 36 + 4          # a compare reads 36 bytes from a dword-aligned address
+    for n in list(range(1, 600, 37)) + list(range(RING - 80, RING + 80, 7)) + list(range(40000, 65281, 211)) + [65280]:
+        pad_end = (n + 48 + 15) & ~15
+        hi = min(pad_end, RING)
+        for c0 in range(0, n, WG):
+            last_read = min(n + 19, c0 + 255 + 258 + 19)                     # own string, fixed compare (p + 35), long-match rounds (p + l + 19, l < 258)
+            assert hi > last_read or hi >= pad_end, (n, c0, hi)
+            if hi < pad_end and hi < c0 + WG + AHEAD:
+                replaced_end = hi + REFILL - RING                            # positions [hi - RING, replaced_end) lose their bytes
+                assert replaced_end <= max(0, c0 + WG - 32768), (n, c0, hi)  # dead for the next chunk (and for this chunk's literal reads: < c0)
+                hi += REFILL
