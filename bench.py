@@ -1062,7 +1062,62 @@ def op_records(run: Run, steps: int, slices: int = 256, nrec: int = 10000, cpu: 
     return out
 
 
-def op_encode(run: Run, steps: int, slices: int = 64, nrec: int = 10000):
+def cpu_baseline_encode(bam_sample: bytes, nrec: int, per_slice: int, ref: bytes, procs: int, seconds: float = 8.0):
+    """The record ENCODER's own source (cram_encode_core.h / cram_encode_plan.h) compiled for the CPU -- tests/native/cram_records_host.cpp:
+    hgr_host_encode_slices, test infrastructure, "not reference code" (htslib's cram_encode_slice needs htscodecs and the whole cram_fd machinery) --
+    on `procs` processes, each encoding the same `nrec` BAM records in a loop for ~`seconds`."""
+    import tempfile
+    src = os.path.join(ROOT, "tests", "native", "cram_records_host.cpp")
+    tmp = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    so = os.path.join(tempfile.gettempdir(), f"libcram_records_host_enc_{os.getpid()}.so")
+    fb, fr = os.path.join(tmp, f"htsgpu_encbase_{os.getpid()}.bam"), os.path.join(tmp, f"htsgpu_encbase_{os.getpid()}.ref")
+    if subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, src]).returncode != 0:
+        return None
+    open(fb, "wb").write(bam_sample); open(fr, "wb").write(ref)
+    code = (
+        "import sys, time, ctypes as C, numpy as np\n"
+        "L = C.CDLL(%r)\n"
+        "vp = C.c_void_p\n"
+        "class RefSeq(C.Structure):\n"
+        "    _fields_ = [('bases', vp), ('len', C.c_uint64)]\n"
+        "bam = open(%r, 'rb').read(); ref = open(%r, 'rb').read()\n"
+        "nrec, per = %d, %d; ns = (nrec + per - 1) // per\n"
+        "rb = C.create_string_buffer(ref, len(ref)); ra = (RefSeq * 1)(RefSeq(C.addressof(rb), len(ref)))\n"
+        "rgp = (C.c_char_p * 1)()\n"
+        "out = np.zeros(len(bam) * 6 + 65536 * ns + 4096, np.uint8); off = np.zeros(ns + 2, np.uint64); st = np.full(ns + 1, 9, np.int32)\n"
+        "L.hgr_host_encode_slices.restype = C.c_long\n"
+        "L.hgr_host_encode_slices.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_uint32, vp, C.c_int, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp, C.c_size_t, vp]\n"
+        "def once():\n"
+        "    n = L.hgr_host_encode_slices(bam, len(bam), nrec, per, C.cast(ra, vp), 1, C.cast(rgp, vp), 0, 0, out.ctypes.data, len(out), off.ctypes.data, ns + 1, st.ctypes.data)\n"
+        "    assert n == ns and (st[:ns] == 0).all(), (n, st[:ns])\n"
+        "once()\n"
+        "print('ready', flush=True); sys.stdin.readline()\n"
+        "t0 = time.perf_counter(); done = 0\n"
+        "while time.perf_counter() - t0 < %f:\n"
+        "    once(); done += nrec\n"
+        "print(done, time.perf_counter() - t0, flush=True)\n" % (so, fb, fr, nrec, per_slice, seconds))
+    ps = [subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for _ in range(procs)]
+    try:
+        for q in ps:
+            if q.stdout.readline().strip() != "ready": return None
+        for q in ps: q.stdin.write("go\n"); q.stdin.flush()
+        tot = 0.0
+        for q in ps:
+            d, t = q.stdout.readline().split(); tot += int(d) / float(t)
+    except Exception:
+        return None
+    finally:
+        for q in ps: q.kill()
+        for f in (so, fb, fr):
+            try: os.unlink(f)
+            except OSError: pass
+    return {"value": round(tot / 1e6, 3), "unit": "M records/s", "cores": procs, "kind": "port",
+            "sample": "NOT reference code: this repository's record encoder (cram_encode_core.h / cram_encode_plan.h, the kernels' source) compiled for the CPU and run "
+                      "from plain loops, %d processes x the same %d BAM records (one slice) for %.0f s (cram_encode_slice of htslib is not buildable here: htscodecs absent)"
+                      % (procs, nrec, seconds)}
+
+
+def op_encode(run: Run, steps: int, slices: int = 64, nrec: int = 10000, cpu: bool = True):
     """SURVEY 8f N2, write side: BAM records -> CRAM slices (hg_cram_encode_slices_host = cram_encode_slice + process_one_read on the device: survey, counting
     walk, prefix sums, writing walk).  HOST entry point: the BAM goes up and the series blocks come back over PCIe inside the timed call.  Input = the
     BAM stream the record decoder produced from synthetic slices; verified by decoding the slices again to the same stream."""
@@ -1096,12 +1151,22 @@ def op_encode(run: Run, steps: int, slices: int = 64, nrec: int = 10000):
         ts.append(time.perf_counter() - t)
         assert rc == 0, rc
     t = sorted(ts[1:])[len(ts[1:]) // 2]
-    return {"metric": "CRAM record encoding: BAM records -> slice series blocks (cram_encode_slice on the device), M records/s, host entry point incl. PCIe",
+    res = {"metric": "CRAM record encoding: BAM records -> slice series blocks (cram_encode_slice on the device), M records/s, host entry point incl. PCIe",
             "value": round(n / t / 1e6, 3), "unit": "M records/s", "n_gpus": 1, "steps": steps, "warmup": 1, "ms_per_step": round(t * 1e3, 2), "higher_is_better": True, "dtype": "u8",
             "data": "synthetic", "config": {"workload": "%d slices x %d records x 150 bp from a %.2f GB BAM stream; series blocks %.2f GB" % (slices, nrec, len(bam) / 1e9, tot.value / 1e9),
                                             "bam_GBps": round(len(bam) / t / 1e9, 3), "parity": "writer: any valid CRAM is correct; tests/test_cram_encode.py decodes its output back to the same records / BAM bytes"},
             "roofline": {"bound": "hbm", "achieved": round((len(bam) + tot.value) / t / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((len(bam) + tot.value) / t / 1e9 / HBM_PEAK_GBS, 6),
                          "traffic": None, "kernel": "whole host call (PCIe both ways + three kernels); HG_CRAM_RECORDS_TIMING-style split in profiles/", "algorithmic_bytes": int(len(bam) + tot.value)}}
+    if cpu and run.world == 1 and not run.args.no_cpu_baseline:
+        try:                                                               # frame the first slice's records (bam_read1: block_size + bytes)
+            at = 0
+            for _ in range(nrec):
+                at += 4 + int.from_bytes(bam[at:at + 4], "little")
+            cb = cpu_baseline_encode(bam[:at], nrec, nrec, ref, min(64, run.ncores))
+            if cb: res["cpu_baseline"] = cb
+        except Exception as e:
+            res["cpu_baseline_error"] = repr(e)
+    return res
 
 
 def op_fqz(run: Run, steps: int, streams: int = 512):
