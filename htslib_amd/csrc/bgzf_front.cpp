@@ -184,12 +184,15 @@ EnginePark &engine_park() { static EnginePark *p = new EnginePark(); return *p; 
 
 // HTS_GPU_STATS=1: where a reader's wall time went, printed to stderr when the handle closes (seconds, per thread)
 struct ReadStats { double io_read = 0, io_frame = 0, io_submit = 0, io_idle = 0, c_wait = 0, c_copy = 0; uint64_t batches = 0, copies = 0; };
+// ... and a writer's: the caller's side (waiting for a free pipe, copying into the batch, submitting) and the output thread's (waiting for the device, hwrite)
+struct WriteStats { double c_pipe = 0, c_copy = 0, c_submit = 0, o_wait = 0, o_write = 0; uint64_t batches = 0, blocks = 0, out_bytes = 0; };
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline bool stats_on() { static const bool on = getenv("HTS_GPU_STATS") != nullptr; return on; }
 
 struct Engine {
     BGZF *fp = nullptr;
     ReadStats st;
+    WriteStats wst;
     Kind kind = K_READ;
     hg_ctx *gpu = nullptr;                 // first device (stateless helpers: gzip streams, CRCs)
     std::vector<hg_ctx *> devs;            // every device of the handle; pipe i lives on devs[i % devs.size()]
@@ -759,7 +762,9 @@ void writer_main(Engine *e) {
         const uint8_t *out = nullptr; size_t out_len = 0; const uint64_t *off = nullptr; const uint32_t *crc = nullptr;
         int err = 0;
         const size_t n = b.cuts.size() - 1;
+        const double t_o0 = stats_on() ? now_s() : 0;
         if (hg_pipe_wait(b.pipe, &out, &out_len, nullptr, &off, &crc) != HG_OK) err = BGZF_ERR_ZLIB;
+        const double t_o1 = stats_on() ? now_s() : 0;
         int64_t addr = e->block_address;
         if (!err) {
             if (e->kind == K_GZWRITE && !e->gz_header_done) {
@@ -778,6 +783,7 @@ void writer_main(Engine *e) {
             }
             if (!err && out_len && hg_hwrite(fp->fp, out, out_len) != (ssize_t)out_len) err = BGZF_ERR_IO;
         }
+        if (stats_on()) { e->wst.o_wait += t_o1 - t_o0; e->wst.o_write += now_s() - t_o1; e->wst.batches++; e->wst.blocks += n; e->wst.out_bytes += out_len; }
         lk.lock();
         if (err) e->w_err |= err; else e->block_address = addr + (int64_t)out_len;
         e->w_done++;
@@ -801,7 +807,10 @@ int submit_write_batch(Engine *e) {
     e->w_open = false;
     if (b.cuts.size() <= 1) return 0;
     int level = fp->compress_level < 0 ? 6 : fp->compress_level;
-    if (hg_pipe_deflate(b.pipe, b.len, b.cuts.data(), b.cuts.size() - 1, level, e->kind == K_GZWRITE) != HG_OK) {
+    const double t_s0 = stats_on() ? now_s() : 0;
+    const int src = hg_pipe_deflate(b.pipe, b.len, b.cuts.data(), b.cuts.size() - 1, level, e->kind == K_GZWRITE);
+    if (stats_on()) e->wst.c_submit += now_s() - t_s0;
+    if (src != HG_OK) {
         fp->errcode |= BGZF_ERR_ZLIB;
         return -1;
     }
@@ -814,8 +823,10 @@ int submit_write_batch(Engine *e) {
 // Open the batch that the next blocks go to (waits for a free pipe).
 int open_write_batch(BGZF *fp, Engine *e) {
     if (e->w_open) return 0;
+    const double t_p0 = stats_on() ? now_s() : 0;
     std::unique_lock<std::mutex> lk(e->m);
     e->cv.wait(lk, [&] { return e->w_fill - e->w_done < e->NPIPES; });
+    if (stats_on()) e->wst.c_pipe += now_s() - t_p0;
     if (e->w_err) { fp->errcode |= e->w_err; return -1; }
     lk.unlock();
     WriteBatch &b = e->wb[e->w_fill % e->NPIPES];
@@ -863,7 +874,9 @@ ssize_t queue_whole_blocks(BGZF *fp, const uint8_t *in, size_t length) {
         if (room > by_cap) room = by_cap;
         if (room > blocks) room = blocks;
         if (room) {
+            const double t_c0 = stats_on() ? now_s() : 0;
             copy_out(b.in + b.len, in + taken, room * (size_t)BGZF_BLOCK_SIZE);
+            if (stats_on()) e->wst.c_copy += now_s() - t_c0;
             for (size_t i = 0; i < room; i++) { b.len += BGZF_BLOCK_SIZE; b.cuts.push_back(b.len); }
             e->block_number += room;
             taken += room * (size_t)BGZF_BLOCK_SIZE; blocks -= room;
@@ -895,6 +908,11 @@ int drain_writer(BGZF *fp) {
 
 // ================================================================================ handle lifetime
 void stop_engine(Engine *e) {
+    if (stats_on() && e->kind != K_READ && e->wst.batches)
+        fprintf(stderr, "[htsgpu stats] writer: %llu jobs, %llu blocks, %.1f MB out; caller: wait for a pipe %.3f s, bulk copies %.3f s, submit %.3f s; output thread: "
+                "wait for the device %.3f s, index + hwrite %.3f s\n", (unsigned long long)e->wst.batches, (unsigned long long)e->wst.blocks, e->wst.out_bytes / 1e6,
+                e->wst.c_pipe, e->wst.c_copy, e->wst.c_submit, e->wst.o_wait, e->wst.o_write);
+    e->wst.batches = 0;                                                     // (printed once)
     if (stats_on() && e->kind == K_READ && e->st.batches)
         fprintf(stderr, "[htsgpu stats] reader: %llu batches; I/O thread: read %.3f s, frame %.3f s, submit %.3f s; consumer: wait for batch %.3f s, "
                 "large copies %.3f s (%llu)\n", (unsigned long long)e->st.batches, e->st.io_read, e->st.io_frame, e->st.io_submit, e->st.c_wait,
