@@ -125,3 +125,26 @@ def test_deflate_output_is_reproducible(engine):
     a = engine.gzip_deflate_host([plain[:300_000], plain[300_000:900_000]], level=6)
     b = engine.gzip_deflate_host([plain[300_000:900_000], plain[:2_000_000], plain[:300_000]], level=6)
     assert a[0] == b[2] and a[1] == b[0]
+
+
+def test_block_sizes_around_the_input_ring(engine, oracle):
+    """The kernel stages a block as a 36 KiB ring (bgzf_deflate.hip: RING = 36864, topped up 2 KiB at a time, the CRC of a longer block joined from
+    tail + head): block lengths just below / at / above the ring, around the first top-ups and up to the maximum, at the three level classes,
+    on data with matches near and far (so that look-backs cross the wrap)."""
+    rng = np.random.default_rng(11)
+    unit = synth.fastq(70_000)
+    noise = rng.integers(0, 256, 70_000, dtype=np.uint8).tobytes()
+    ring = 36864
+    sizes = [ring - 49, ring - 48, ring - 17, ring - 1, ring, ring + 1, ring + 15, ring + 16, ring + 17, ring + 63, ring + 64, ring + 65,
+             ring + 2047, ring + 2048, ring + 2049, ring + 4096 + 31, 40_000, 50_001, 65_279, 65_280]
+    for level in (1, 5, 6):
+        parts, cuts = [], [0]
+        for k, n in enumerate(sizes):
+            src = unit if k % 3 else bytes(a ^ (b & 3) for a, b in zip(unit[:n], noise[:n]))      # every third block: lightly perturbed (short matches)
+            parts.append(src[:n]); cuts.append(cuts[-1] + n)
+        data = b"".join(parts)
+        comp = engine.bgzf_deflate_host(data, level=level, cuts=np.array(cuts, dtype=np.uint64))
+        blocks = check_stream(comp, data, oracle)
+        assert [b[2] for b in blocks[:-1]] == sizes
+    comp0 = engine.bgzf_deflate_host(noise[:ring + 1] + noise[:ring + 2049], level=6, cuts=np.array([0, ring + 1, 2 * ring + 2050], dtype=np.uint64))
+    check_stream(comp0, noise[:ring + 1] + noise[:ring + 2049], oracle)                            # incompressible: stored blocks, CRC from the two-part pass
