@@ -92,7 +92,7 @@ void enc_walk_kernel(EncDev E) {
 #pragma unroll
         for (int s = 0; s < W_N; s++) S.n[s] = 0;
     }
-    if (!enc_record<WRITE>(C, r, prev, E.multi[k] != 0, S)) return;
+    if (!enc_record<WRITE>(C, r, prev, (int)E.multi[k], S)) return;
     if (!WRITE) {
 #pragma unroll
         for (int s = 0; s < W_N; s++) E.col[(uint64_t)s * E.N + g] = S.n[s];
@@ -188,7 +188,8 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
         if (fail[k]) { S[k].keys.clear(); S[k].lhash.clear(); S[k].lfirst.clear(); }
         k2.insert(k2.end(), S[k].keys.begin(), S[k].keys.end()); ko[k + 1] = (uint32_t)k2.size();
         l2.insert(l2.end(), S[k].lhash.begin(), S[k].lhash.end()); lo[k + 1] = (uint32_t)l2.size();
-        start[k] = S[k].start(); multi[k] = S[k].multi();
+        enc_ref_policy(S[k], refs, nrefs);
+        start[k] = S[k].start(); multi[k] = (uint8_t)S[k].walk_mode();
         ncmax = std::max<size_t>(ncmax, (size_t)S[k].ncols());
     }
     ok = (k2.empty() || hipMemcpyAsync(dt + t_k2, k2.data(), k2.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess) && hipMemcpyAsync(dt + t_ko, ko.data(), ko.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&

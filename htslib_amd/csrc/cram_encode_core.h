@@ -134,8 +134,11 @@ HGR_FN int32_t enc_find_key(const uint32_t *keys, uint32_t nkeys, uint32_t key) 
 
 // The walk of one record.  prev_apos: alignment position of the record before it (slice start for the first).  tag sinks are indexed by the
 // key's position in C.keys.  Returns false when the record cannot be encoded (C.fail says why).
+// mode: ENC_MODE_MULTI = multi-reference slice (RI stored per record); ENC_MODE_NOREF = the slice is written without any reference (RR = 0).
+constexpr int ENC_MODE_MULTI = 1, ENC_MODE_NOREF = 2;
 template <bool WRITE>
-HGR_FN bool enc_record(const EncCtx &C, uint32_t r, int64_t prev_apos, bool multi_ref, Sink<WRITE> &S) {
+HGR_FN bool enc_record(const EncCtx &C, uint32_t r, int64_t prev_apos, int mode, Sink<WRITE> &S) {
+    const bool multi_ref = (mode & ENC_MODE_MULTI) != 0;
     BamRec B;
     const uint64_t g = C.r0 + r;
     if (!bam_parse(C.bam, C.rec_off[g], C.rec_off[g + 1], B)) { *C.fail = -1; return false; }
@@ -189,7 +192,7 @@ HGR_FN bool enc_record(const EncCtx &C, uint32_t r, int64_t prev_apos, bool mult
         return true;
     }
     // features from CIGAR + bases + reference (process_one_read's feature generation, cram_encode.c:3480-3680)
-    const EncRef *ref = B.ref_id >= 0 && B.ref_id < C.nref && C.refs[B.ref_id].len > 0 ? &C.refs[B.ref_id] : nullptr;
+    const EncRef *ref = !(mode & ENC_MODE_NOREF) && B.ref_id >= 0 && B.ref_id < C.nref && C.refs[B.ref_id].len > 0 ? &C.refs[B.ref_id] : nullptr;
     int32_t sp = 1, prev = 0, nfeat = 0; int64_t rp = apos;
     auto feature = [&](uint8_t code) { S.byte(W_FC, code); S.itf8(W_FP, sp - prev); prev = sp; nfeat++; };
     for (uint32_t c = 0; c < B.n_cigar; c++) {

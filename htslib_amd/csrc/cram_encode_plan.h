@@ -8,6 +8,7 @@
 #include <utility>
 #include <vector>
 #include "cram_encode_core.h"
+#include "hg_md5.h"
 
 namespace hgr {
 
@@ -17,6 +18,11 @@ struct EncSlice {
     std::vector<uint64_t> lhash; std::vector<uint32_t> lfirst;      // tag lists in order of first appearance
     int32_t min_ref = 0, max_ref = 0; int64_t min_pos = 0, max_end = 0;
     int32_t fail = 0;
+    // Does the slice lean on reference sequences?  Decided after the survey (enc_ref_policy): yes when every reference its records sit on was handed
+    // over.  Otherwise NO base of the slice is compared with a reference (all stored as B features) and the container says RR = 0, so that a reader
+    // does not go looking for a sequence nobody had (htslib: "Unable to fetch reference").  md5: digest of the span of a single-reference slice.
+    bool use_ref = true; uint8_t md5[16] = {0};
+    int walk_mode() const { return (multi() ? ENC_MODE_MULTI : 0) | (use_ref ? 0 : ENC_MODE_NOREF); }
     bool multi() const { return min_ref != max_ref; }
     int32_t ref_id() const { return multi() ? -2 : min_ref; }
     int64_t start() const { return multi() || min_ref < 0 ? 0 : min_pos; }
@@ -34,6 +40,20 @@ inline void enc_survey_finish(const uint32_t *keytab, const uint64_t *lh, const 
     std::sort(lines.begin(), lines.end());
     for (auto &l : lines) { S.lfirst.push_back(l.first); S.lhash.push_back(l.second); }
     if (!S.fail && (S.keys.size() > (size_t)ENC_MAX_TAGS || S.lhash.size() > (size_t)ENC_MAX_LINES)) S.fail = -3;
+}
+
+// refs[i].bases / refs[i].len: the sequences the caller has (bases == nullptr: not available).  cram_encode_slice stores the MD5 of the span
+// [start, start + span) of a single-reference slice (clamped at the end of the sequence, like the reader's check cram_decode.c:2480-2540).
+template <class Ref>
+inline void enc_ref_policy(EncSlice &S, const Ref *refs, int nrefs) {
+    memset(S.md5, 0, 16);
+    S.use_ref = true;
+    for (int32_t t = std::max<int32_t>(S.min_ref, 0); t <= S.max_ref; t++)
+        if (t >= nrefs || !refs[t].bases || !refs[t].len) S.use_ref = false;
+    if (S.use_ref && !S.multi() && S.min_ref >= 0 && S.span() > 0) {
+        const int64_t len = (int64_t)refs[S.min_ref].len, a = S.start() - 1, b = std::min<int64_t>(a + S.span(), len);
+        if (a >= 0 && a < b) md5_of((const uint8_t *)refs[S.min_ref].bases + a, (uint64_t)(b - a), S.md5);
+    }
 }
 
 namespace enc {
@@ -59,7 +79,7 @@ inline void enc_headers(const EncSlice &S, const EncCtx &C, const uint64_t *tot,
     comp.clear(); sh.clear(); blocks.clear();
     {   // preservation map: RN, AP, RR, SM (the default matrix), TD
         std::vector<uint8_t> body; itf8(body, 5);
-        const uint8_t kv[][3] = {{'R', 'N', 1}, {'A', 'P', 1}, {'R', 'R', 1}};
+        const uint8_t kv[][3] = {{'R', 'N', 1}, {'A', 'P', 1}, {'R', 'R', (uint8_t)(S.use_ref ? 1 : 0)}};
         for (auto &k : kv) body.insert(body.end(), k, k + 3);
         body.push_back('S'); body.push_back('M'); for (int i = 0; i < 5; i++) body.push_back(0x1B);
         std::vector<uint8_t> td;
@@ -100,7 +120,7 @@ inline void enc_headers(const EncSlice &S, const EncCtx &C, const uint64_t *tot,
         if (tot[W_N + 2 * k]) blocks.emplace_back(enc_tag_cid(S.keys[k], false), (uint32_t)(W_N + 2 * k));
         if (tot[W_N + 2 * k + 1]) blocks.emplace_back(enc_tag_cid(S.keys[k], true), (uint32_t)(W_N + 2 * k + 1));
     }
-    // slice header (cram_encode_slice_header): reference, start, span, records, record counter, blocks, content ids, embedded reference, MD5 (none)
+    // slice header (cram_encode_slice_header): reference, start, span, records, record counter, blocks, content ids, embedded reference (none), MD5 of the reference span
     itf8(sh, S.ref_id()); itf8(sh, (int32_t)S.start()); itf8(sh, (int32_t)S.span()); itf8(sh, (int32_t)S.nrec);
     {   // LTF8 record counter
         const uint64_t v = (uint64_t)record_counter;
@@ -112,7 +132,7 @@ inline void enc_headers(const EncSlice &S, const EncCtx &C, const uint64_t *tot,
     }
     itf8(sh, (int32_t)blocks.size() + 1); itf8(sh, (int32_t)blocks.size());
     for (auto &b : blocks) itf8(sh, b.first);
-    itf8(sh, -1); sh.insert(sh.end(), 16, 0);
+    itf8(sh, -1); sh.insert(sh.end(), S.md5, S.md5 + 16);
 }
 
 }  // namespace hgr

@@ -256,6 +256,7 @@ extern "C" long hgr_host_encode_slices(const uint8_t *bam, size_t bam_len, size_
         S[k].min_ref = lo; S[k].max_ref = hi; S[k].min_pos = p0; S[k].max_end = p1; S[k].fail = fail[k];
         enc_survey_finish(keytab.data() + k * ENC_KEY_SLOTS, lhash.data() + k * ENC_LINE_SLOTS, lfirst.data() + k * ENC_LINE_SLOTS, S[k]);
         fail[k] = S[k].fail;
+        enc_ref_policy(S[k], refs, nrefs);
     }
     size_t ncmax = W_N; for (auto &s : S) ncmax = std::max<size_t>(ncmax, (size_t)s.ncols());
     const size_t N = n + 1;
@@ -269,7 +270,7 @@ extern "C" long hgr_host_encode_slices(const uint8_t *bam, size_t bam_len, size_
         const int nc = S[k].ncols();
         for (uint32_t r = 0; r < S[k].nrec; r++) {
             Sink<false> K{}; K.col = col.data(); K.N = N; K.g = S[k].r0 + r;
-            if (!enc_record<false>(C, r, prev_of(k, r), S[k].multi(), K)) break;
+            if (!enc_record<false>(C, r, prev_of(k, r), S[k].walk_mode(), K)) break;
             for (int s = 0; s < W_N; s++) col[(size_t)s * N + K.g] = K.n[s];
         }
         if (fail[k]) continue;
@@ -288,7 +289,7 @@ extern "C" long hgr_host_encode_slices(const uint8_t *bam, size_t bam_len, size_
         for (uint32_t r = 0; r < S[k].nrec; r++) {
             Sink<true> K{}; K.col = col.data(); K.N = N; K.g = S[k].r0 + r; K.out = blk.data(); K.base = base[k].data();
             for (int s = 0; s < W_N; s++) K.p[s] = blk.data() + base[k][(size_t)s] + col[(size_t)s * N + K.g];
-            if (!enc_record<true>(C, r, prev_of(k, r), S[k].multi(), K)) break;
+            if (!enc_record<true>(C, r, prev_of(k, r), S[k].walk_mode(), K)) break;
         }
     }
     uint64_t at = 0;
