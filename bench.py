@@ -955,6 +955,82 @@ def op_e2e(run: Run, S: Staged):
     return res
 
 
+REF_VIEW = os.path.join(ROOT, "oracle", "_ref", "ref_view")
+
+
+def have_ref_view() -> bool:
+    return os.path.exists(REF_VIEW) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_hts.so"))
+
+
+class RefCramWorkload:
+    """Inputs for timing the REFERENCE's record layer (oracle/_ref/ref_view = the reference's test/test_view.c on the reference's whole libhts, built by
+    oracle/Makefile with a stand-in for the absent htscodecs: a CRAM <= 3.0 tool).  From synthetic slices: a sorted BAM file with stored (level 0)
+    BGZF blocks, the FASTA, and the CRAM 3.0 file ref_view itself writes from them with level 0 (RAW blocks) -- so that a timed run is
+    cram_decode_slice + cram_to_bam (decode) or bam_read1 + cram_encode_slice + container framing (encode) and no block codec."""
+    def __init__(self, eng, slices, copies):
+        import tempfile
+        from htslib_amd import synth, synth_cram
+        base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+        self.dir = tempfile.mkdtemp(prefix="htsgpu_refcram_", dir=base)
+        bam, names, seqs, self.nrec = synth_cram.bam_from_slices(eng, slices, copies)
+        self.bam = os.path.join(self.dir, "in.bam"); self.fa = os.path.join(self.dir, "ref.fa"); self.cram = os.path.join(self.dir, "in_l0.cram")
+        open(self.bam, "wb").write(synth.bgzf_compress(bam, level=0))
+        fai = []
+        with open(self.fa, "wb") as f:
+            for nm, sq in zip(names, seqs):
+                f.write(b">" + nm.encode() + b"\n"); off = f.tell()
+                for i in range(0, len(sq), 60): f.write(sq[i:i + 60] + b"\n")
+                fai.append("%s\t%d\t%d\t60\t61\n" % (nm, len(sq), off))
+        open(self.fa + ".fai", "w").write("".join(fai))
+        r = subprocess.run([REF_VIEW, "-C", "-l", "0", "-o", "version=3.0", "-t", self.fa, "-p", self.cram, self.bam], capture_output=True)
+        if r.returncode != 0: raise RuntimeError("ref_view -C failed: " + r.stderr.decode("latin1")[-400:])
+
+    def decode_cmd(self, threads): return [REF_VIEW, "-@", str(threads), "-B", "-i", "reference=" + self.fa, self.cram]
+    def encode_cmd(self, threads): return [REF_VIEW, "-@", str(threads), "-C", "-l", "0", "-o", "version=3.0", "-t", self.fa, "-p", "/dev/null", self.bam]
+
+    def close(self):
+        import shutil
+        shutil.rmtree(self.dir, ignore_errors=True)
+
+
+def time_ref_view(cmd, procs: int, seconds: float, env=None):
+    """`procs` copies of the command side by side, each started again and again for ~`seconds` -> completed runs per second, all copies together"""
+    import threading
+    done = [0] * procs; bad = []
+    t_end = time.perf_counter() + seconds
+    def work(i):
+        while time.perf_counter() < t_end:
+            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
+            if r.returncode != 0: bad.append(r.stderr.decode("latin1")[-300:]); return
+            done[i] += 1
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(procs)]
+    for t in th: t.start()
+    for t in th: t.join()
+    el = time.perf_counter() - t0
+    if bad or not sum(done): return None, (bad[:1] or ["no run finished"])[0]
+    return sum(done) / el, None
+
+
+def cpu_baseline_reference_records(eng, slices, ncores: int, mode: str, seconds: float = 10.0):
+    """cpu_baseline kind "reference" for the record layer: the reference's own cram_decode_slice (cram/cram_decode.c:2346) + cram_to_bam, or bam_read1 +
+    cram_encode_slice (cram/cram_encode.c:1096-1209) + container framing, through its own thread pool: ncores/4 processes x 4 pool threads."""
+    if not have_ref_view(): return None
+    threads = 4; procs = max(1, min(64, ncores // threads))
+    w = RefCramWorkload(eng, slices, 4)
+    try:
+        cmd = w.decode_cmd(threads) if mode == "decode" else w.encode_cmd(threads)
+        rate, err = time_ref_view(cmd, procs, seconds)
+        if rate is None: return {"error": err}
+        return {"value": round(rate * w.nrec / 1e6, 3), "unit": "M records/s", "cores": procs * threads, "kind": "reference",
+                "sample": "reference htslib (oracle/_ref/ref_view = test/test_view.c on the reference's libhts; htscodecs stand-in, CRAM 3.0, level 0 so no block codec runs): "
+                          "%d processes x -@%d, each %s %d records (%d slices of 10 000 on %d references) again and again for %.0f s"
+                          % (procs, threads, "reading (cram_decode_slice + cram_to_bam, -B: no output)" if mode == "decode" else "writing BAM -> CRAM to /dev/null (bam_read1 + cram_encode_slice)",
+                             w.nrec, w.nrec // 10000, 4 * len(slices), seconds)}
+    finally:
+        w.close()
+
+
 def cpu_baseline_records(base_slices, procs: int, seconds: float = 12.0):
     """The record decoder's own source (cram_records_core.h, the serial chain) compiled for the CPU -- tests/native/cram_records_host.cpp, test
     infrastructure, "not reference code": htslib's cram_decode_slice cannot be built here (htscodecs absent) -- on `procs` processes, each
@@ -1058,7 +1134,12 @@ def op_records(run: Run, steps: int, slices: int = 256, nrec: int = 10000, cpu: 
                         "kernel": "the whole step (about thirty launches; profiles/ has the per-kernel split)", "algorithmic_bytes": int(alg),
                         "note": "algorithmic bytes = decoded blocks + reference spans read once + BAM bytes written once"}}
     if cpu:
-        out["cpu_baseline"] = cpu_baseline_records(base, min(os.cpu_count() or 1, 64))
+        ref = None
+        try: ref = cpu_baseline_reference_records(eng, base, os.cpu_count() or 1, "decode")
+        except Exception as e: out["cpu_baseline_error"] = repr(e)
+        port = cpu_baseline_records(base, min(os.cpu_count() or 1, 64))
+        if ref and "value" in ref: out["cpu_baseline"] = ref; out["cpu_baseline_port"] = port
+        else: out["cpu_baseline"] = port
     return out
 
 
@@ -1163,7 +1244,13 @@ def op_encode(run: Run, steps: int, slices: int = 64, nrec: int = 10000, cpu: bo
             for _ in range(nrec):
                 at += 4 + int.from_bytes(bam[at:at + 4], "little")
             cb = cpu_baseline_encode(bam[:at], nrec, nrec, ref, min(64, run.ncores))
-            if cb: res["cpu_baseline"] = cb
+            rb = None
+            try: rb = cpu_baseline_reference_records(eng, [synth_cram.make_slice(np.random.default_rng(70 + i), nrec, 150) for i in range(3)] + base, run.ncores, "encode")
+            except Exception as e: res["cpu_baseline_error"] = repr(e)
+            if rb and "value" in rb:
+                res["cpu_baseline"] = rb
+                if cb: res["cpu_baseline_port"] = cb
+            elif cb: res["cpu_baseline"] = cb
         except Exception as e:
             res["cpu_baseline_error"] = repr(e)
     return res

@@ -725,6 +725,11 @@ extern "C" int hg_debug_get_deflate_profile(unsigned long long *out16, int reset
 namespace hg {
 
 size_t bgzf_deflate_tok_bytes(const hg_ctx *ctx) { return (size_t)ctx->cus * HG_DEF_WGS_PER_CU * 65536 * sizeof(uint32_t); }
+// ... of a launch over nblocks blocks: the lists are indexed by workgroup and a launch has min(resident workgroups, blocks) of them
+size_t bgzf_deflate_tok_bytes_for(const hg_ctx *ctx, size_t nblocks) {
+    const size_t wgs = std::min<size_t>((size_t)ctx->cus * HG_DEF_WGS_PER_CU, nblocks ? nblocks : 1);
+    return wgs * 65536 * sizeof(uint32_t);
+}
 
 int launch_bgzf_deflate(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_desc, size_t nblocks, int level,
                         void *d_slots, uint32_t *d_clen, hipStream_t s, int mode, uint32_t *d_crc, void *own_tok) {

@@ -1054,11 +1054,17 @@ BGZF *bgzf_open(const char *path, const char *mode) {
 
 BGZF *bgzf_dopen(int fd, const char *mode) {
     if (!strchr(mode, 'r') && !strchr(mode, 'w') && !strchr(mode, 'a')) { errno = EINVAL; return nullptr; }
+    // hdopen's logical offsets start at 0 wherever the descriptor stands (hfile.c:640-680), and the stream begins THERE: positional window reads
+    // use file offsets, so they are only taken when the two agree (descriptor at the start of a regular file).  A descriptor that was read from,
+    // lseek()ed, or is a pipe keeps the hread path, which -- like the reference -- reads from the current position.
+    const int keep0 = errno;
+    const off_t base = lseek(fd, 0, SEEK_CUR);
+    errno = keep0;
     hFILE *h = hdopen(fd, mode);
     if (!h) return nullptr;
     BGZF *fp = bgzf_hopen(h, mode);
     if (!fp) hclose_abruptly(h);
-    else if (fp->is_compressed && !fp->is_write) { const int keep = errno; adopt_pread_fd(fp, dup(fd)); errno = keep; }
+    else if (fp->is_compressed && !fp->is_write && base == 0) { const int keep = errno; adopt_pread_fd(fp, dup(fd)); errno = keep; }
     return fp;
 }
 

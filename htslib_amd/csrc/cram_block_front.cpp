@@ -587,6 +587,40 @@ uint32_t cram_block_size(cram_block *b) {
     return (uint32_t)(n + 4 + (size_t)(b->method == RAW ? b->uncomp_size : b->comp_size));
 }
 
+// ---- the public accessors of struct cram_block (reference cram/cram_external.c:522-555; htslib.map:313-328,617): how tools outside libhts reach a block.
+// "offset" / "size" is the fill level b->byte; growth follows block_resize (cram/cram_io.h:225-238): at least +25 % + 1000 bytes at a time.
+int32_t cram_block_get_content_id(cram_block *b) { return b->content_type == CORE ? -1 : b->content_id; }
+int32_t cram_block_get_comp_size(cram_block *b) { return b->comp_size; }
+int32_t cram_block_get_uncomp_size(cram_block *b) { return b->uncomp_size; }
+int32_t cram_block_get_crc32(cram_block *b) { return (int32_t)b->crc32; }
+void *cram_block_get_data(cram_block *b) { return b->data; }
+int32_t cram_block_get_size(cram_block *b) { return (int32_t)b->byte; }
+enum cram_block_method cram_block_get_method(cram_block *b) { return (enum cram_block_method)b->orig_method; }
+enum cram_content_type cram_block_get_content_type(cram_block *b) { return b->content_type; }
+void cram_block_set_content_id(cram_block *b, int32_t id) { b->content_id = id; }
+void cram_block_set_comp_size(cram_block *b, int32_t size) { b->comp_size = size; }
+void cram_block_set_uncomp_size(cram_block *b, int32_t size) { b->uncomp_size = size; }
+void cram_block_set_crc32(cram_block *b, int32_t crc) { b->crc32 = (uint32_t)crc; }
+void cram_block_set_data(cram_block *b, void *data) { b->data = (unsigned char *)data; }
+void cram_block_set_size(cram_block *b, int32_t size) { b->byte = (size_t)size; }
+size_t cram_block_get_offset(cram_block *b) { return b->byte; }
+void cram_block_set_offset(cram_block *b, size_t offset) { b->byte = offset; }
+void cram_block_update_size(cram_block *b) { b->comp_size = b->uncomp_size = (int32_t)b->byte; }
+int cram_block_append(cram_block *b, const void *data, int size) {
+    if (size < 0) return -1;
+    const size_t need = b->byte + (size_t)size;
+    if (b->alloc <= need) {
+        size_t alloc = b->alloc + 800;
+        alloc += alloc >> 2;
+        if (alloc < need) alloc = need;
+        unsigned char *t = (unsigned char *)realloc(b->data, alloc ? alloc : 1);
+        if (!t) return -1;
+        b->data = t; b->alloc = alloc;
+    }
+    if (size) { memcpy(b->data + b->byte, data, (size_t)size); b->byte += (size_t)size; }
+    return 0;
+}
+
 cram_block *hg_cram_read_block(hFILE *fp, int major, int ignore_crc) {
     cram_block *b = (cram_block *)calloc(1, sizeof(cram_block));
     if (!b) return nullptr;

@@ -48,6 +48,7 @@ int launch_bgzf_inflate(hg_ctx *ctx, const void *d_comp, size_t comp_len, const 
                         size_t nblocks, void *d_out, size_t out_cap, int32_t *d_status, hipStream_t s, int mode = 0);
 int launch_bgzf_deflate(hg_ctx *ctx, const void *d_plain, const hg_bgzf_desc *d_desc, size_t nblocks, int level,
                         void *d_slots, uint32_t *d_clen, hipStream_t s, int mode = 0, uint32_t *d_crc = nullptr, void *own_tok = nullptr);
+size_t bgzf_deflate_tok_bytes_for(const hg_ctx *ctx, size_t nblocks);   // ... of a launch over nblocks blocks (a writer pipe sizes its lists by its job)
 size_t bgzf_deflate_tok_bytes(const hg_ctx *ctx);     // token lists of one launch (own_tok: a caller that brings its own may overlap its launches)
 int launch_bgzf_pack(hg_ctx *ctx, const void *d_slots, const hg_bgzf_desc *d_desc, const uint32_t *d_clen,
                      size_t nblocks, void *d_packed, size_t cap, uint64_t *d_poff, uint64_t *d_total, int add_eof,

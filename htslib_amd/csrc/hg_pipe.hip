@@ -158,7 +158,7 @@ int hg_pipe_deflate(hg_pipe *p, size_t len, const uint64_t *cuts, size_t n, int 
     int rc;
     if ((rc = grow_pinned(&p->h_meta, &p->h_meta_cap, dsz + 2 * csz + osz)) || (rc = grow_dev(&p->d_meta, &p->d_meta_cap, dsz + 2 * csz + osz)) ||
         (rc = grow_dev(&p->d_in, &p->d_in_cap, len + 256)) || (rc = grow_dev(&p->d_slots, &p->d_slots_cap, slots + 256)) ||
-        (rc = grow_dev(&p->d_out, &p->d_out_cap, slots + 256)) || (rc = grow_dev(&p->d_tok, &p->d_tok_cap, hg::bgzf_deflate_tok_bytes(p->ctx)))) return rc;
+        (rc = grow_dev(&p->d_out, &p->d_out_cap, slots + 256)) || (rc = grow_dev(&p->d_tok, &p->d_tok_cap, hg::bgzf_deflate_tok_bytes_for(p->ctx, n)))) return rc;
     hg_bgzf_desc *d = (hg_bgzf_desc *)p->h_meta;
     for (size_t i = 0; i < n; i++) {
         if (cuts[i + 1] < cuts[i] || cuts[i + 1] - cuts[i] > HG_BGZF_BLOCK_SIZE) return HG_EINVAL;

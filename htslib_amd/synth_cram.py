@@ -139,3 +139,39 @@ def make_slice(rng, nrec, readlen=100, ref_len=None, unmapped_every=37, detached
     sh += put_itf8(len(blocks)) + b"".join(put_itf8(cid) for cid, _ in blocks) + put_itf8(-1) + bytes(16)
     return {"comp_hdr": comp, "slice_hdr": sh, "core": b"", "blocks": blocks, "nrec": nrec, "refs": [(0, 1, ref, ref_len)], "truth": truth,
             "expect": [[t["name"].decode(), 0, 0, 0, 0, [], 0, 0, 0, t["seq"].decode()] for t in truth]}
+
+
+def bam_from_slices(engine, slices, copies=1):
+    """Slices of make_slice() -> ONE coordinate-sorted BAM stream with a header: the records come out of the pinned record decoder
+    (engine.cram_decode_bam), slice k's records are moved to a reference of their own ("chr<k+1>" = the slice's random reference), so that
+    any CRAM writer sees sorted single-reference runs.  copies > 1 repeats the whole set under further reference names.
+    -> (bam bytes incl. header, [names], [sequences], records)"""
+    import struct
+    from htslib_amd import _native as nat
+    n = len(slices); nrec = sum(s["nrec"] for s in slices)
+    keep = []
+    arr = nat.cram_slice_array(slices, keep)
+    readlen = max(len(t["seq"]) for t in slices[0]["truth"][:64])
+    recs, rec_off, st = engine.cram_decode_bam(arr, n, 3, 1, [], nrec * readlen + 4096, nrec * (readlen * 2 + 400))
+    assert (st == 0).all(), st
+    one = bytearray(recs.tobytes())
+    ends, at = [], 0
+    for s in slices:
+        for _ in range(s["nrec"]): at += 4 + struct.unpack_from("<i", one, at)[0]
+        ends.append(at)
+    assert at == len(one)
+    body = bytearray()
+    for c in range(copies):
+        b = bytearray(one); at = 0
+        for k, end in enumerate(ends):
+            while at < end:
+                struct.pack_into("<i", b, at + 4, c * n + k)
+                if struct.unpack_from("<i", b, at + 24)[0] >= 0: struct.pack_into("<i", b, at + 24, c * n + k)
+                at += 4 + struct.unpack_from("<i", b, at)[0]
+        body += b
+    names = ["chr%d" % (i + 1) for i in range(n * copies)]
+    seqs = [slices[i % n]["refs"][0][2] for i in range(n * copies)]
+    text = b"@HD\tVN:1.6\tSO:coordinate\n" + b"".join(b"@SQ\tSN:%s\tLN:%d\n" % (a.encode(), len(q)) for a, q in zip(names, seqs))
+    hdr = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(names))
+    for a, q in zip(names, seqs): hdr += struct.pack("<i", len(a) + 1) + a.encode() + b"\0" + struct.pack("<i", len(q))
+    return bytes(hdr) + bytes(body), names, seqs, nrec * copies

@@ -49,6 +49,12 @@ enum cram_block_method_int {
     ARITH_PR1, ARITH_PR64, ARITH_PR9, ARITH_PR128, ARITH_PR129, ARITH_PR192, ARITH_PR193
 };
 
+/* htslib/cram.h:84-101: the public (on-disk) method ids, what cram_block_get_method answers */
+enum cram_block_method {
+    CRAM_COMP_UNKNOWN = -1, CRAM_COMP_RAW = 0, CRAM_COMP_GZIP = 1, CRAM_COMP_BZIP2 = 2, CRAM_COMP_LZMA = 3, CRAM_COMP_RANS4x8 = 4,
+    CRAM_COMP_RANSNx16 = 5, CRAM_COMP_ARITH = 6, CRAM_COMP_FQZ = 7, CRAM_COMP_TOK3 = 8
+};
+
 /* htslib/cram.h:103-111 */
 enum cram_content_type {
     CT_ERROR = -1, FILE_HEADER = 0, COMPRESSION_HEADER = 1, MAPPED_SLICE = 2, UNMAPPED_SLICE = 3, EXTERNAL = 4, CORE = 5
@@ -185,6 +191,27 @@ cram_block *cram_read_block(cram_fd *fd);
 int cram_write_block(cram_fd *fd, cram_block *b);
 size_t hg_cram_fd_layout(size_t *offsets);            /* the offsets above in that order (for the layout test) */
 uint32_t cram_block_size(cram_block *b);                                   /* cram_io.c:1490-1505 */
+/* The public accessors of a block (cram/cram_external.c:522-555; htslib/cram.h:230-262; htslib.map:313-328,617).  cram_block_get_content_id
+ * answers -1 for the CORE block; get_method answers the method the block had when it was read (orig_method); "size" / "offset" is the fill
+ * level of a block under construction; cram_block_append grows it as block_resize does (cram/cram_io.h:225-238), 0 / -1. */
+int32_t cram_block_get_content_id(cram_block *b);
+int32_t cram_block_get_comp_size(cram_block *b);
+int32_t cram_block_get_uncomp_size(cram_block *b);
+int32_t cram_block_get_crc32(cram_block *b);
+void *cram_block_get_data(cram_block *b);
+int32_t cram_block_get_size(cram_block *b);
+enum cram_block_method cram_block_get_method(cram_block *b);
+enum cram_content_type cram_block_get_content_type(cram_block *b);
+void cram_block_set_content_id(cram_block *b, int32_t id);
+void cram_block_set_comp_size(cram_block *b, int32_t size);
+void cram_block_set_uncomp_size(cram_block *b, int32_t size);
+void cram_block_set_crc32(cram_block *b, int32_t crc);
+void cram_block_set_data(cram_block *b, void *data);
+void cram_block_set_size(cram_block *b, int32_t size);
+size_t cram_block_get_offset(cram_block *b);
+void cram_block_set_offset(cram_block *b, size_t offset);
+int cram_block_append(cram_block *b, const void *data, int size);
+void cram_block_update_size(cram_block *b);
 
 /* ---- CRAM 4.0 E_XPACK / E_XRLE transforms: the htscodecs functions cram_codecs.c calls (cram/cram_codecs.c:1399, 1520,
  *      2106, 2278), same names and signatures as htscodecs/pack.h and rle.h, computed by the engine (htsgpu.h:

@@ -210,3 +210,30 @@ def test_single_block_bgzf_compress_and_errors(L, tmp_path, oracle):  # bgzf.c:5
     L.bgzf_close(fp)
     assert L.bgzf_is_bgzf(p.encode()) == 1
     assert not L.bgzf_open(str(tmp_path / "missing").encode(), b"r")
+
+
+@pytest.mark.gpu
+def test_dopen_reads_from_where_the_descriptor_stands(L, tmp_path):     # hfile.c hdopen: logical offset 0 = the descriptor's position
+    """a descriptor that was positioned behind a foreign prefix (or behind the first of two concatenated BGZF streams) is read from THERE, as the
+    reference's hread path does -- not from file offset 0 by the positional window reads"""
+    rnd = np.random.default_rng(3)
+    one = bytes(rnd.integers(65, 70, 300_000, dtype=np.uint8)); two = bytes(rnd.integers(70, 75, 500_000, dtype=np.uint8))
+    p1, p2 = str(tmp_path / "one.gz"), str(tmp_path / "two.gz")
+    write_file(L, p1, one); write_file(L, p2, two)
+    prefix = b"#!not bgzf at all\n" * 1000
+    cat = str(tmp_path / "cat.bin")
+    open(cat, "wb").write(prefix + open(p1, "rb").read() + open(p2, "rb").read())
+    for start, want in ((len(prefix), one + two), (len(prefix) + os.path.getsize(p1), two), (0, None)):
+        fd = os.open(cat, os.O_RDONLY)
+        os.lseek(fd, start, os.SEEK_SET)
+        fp = L.bgzf_dopen(fd, b"r")
+        assert fp
+        if want is None:
+            assert fp.contents.is_compressed == 0                        # offset 0 holds the text prefix: read through as plain bytes
+            assert read_all(L, fp, 1 << 20)[:len(prefix)] == prefix
+        else:
+            assert read_all(L, fp) == want, start
+        assert L.bgzf_close(fp) == 0
+    fd = os.open(p2, os.O_RDONLY)                                        # the common case keeps the fast path: descriptor at the start of a regular file
+    fp = L.bgzf_dopen(fd, b"r")
+    assert read_all(L, fp) == two and L.bgzf_close(fp) == 0

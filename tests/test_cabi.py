@@ -95,3 +95,43 @@ def test_hts_crc32_is_correct_with_or_without_a_gpu(built):
     for n in (0, 1, 7, 8, 9, 26, 4095, 4096, 70000):
         b = bytes(rnd.randrange(256) for _ in range(n))
         assert L.hts_crc32(zlib.crc32(b[:n // 3]), b[n // 3:], n - n // 3) == zlib.crc32(b), n
+
+
+CRAM_BLOCK_SYMBOLS = """cram_block_append cram_block_get_comp_size cram_block_get_content_id cram_block_get_content_type cram_block_get_crc32 cram_block_get_data
+cram_block_get_offset cram_block_get_uncomp_size cram_block_set_comp_size cram_block_set_content_id cram_block_set_crc32 cram_block_set_data cram_block_set_offset
+cram_block_set_uncomp_size cram_block_size cram_block_update_size cram_block_get_method cram_new_block cram_free_block cram_uncompress_block cram_compress_block
+cram_compress_block2 cram_read_block cram_write_block""".split()          # htslib.map:149,164,313-328,617 + cram/cram_io.h
+
+
+def test_cram_block_accessors_of_the_front_library(built):
+    """cram/cram_external.c:522-555: the accessors external tools use on a cram_block -- exported under the reference's names, reference semantics
+    (content id of the CORE block is -1, offset = fill level, append grows, update_size copies the fill level into both sizes)."""
+    L = C.CDLL(os.path.join(ROOT, "htslib_amd", "libhts_bgzf.so"))
+    for s in CRAM_BLOCK_SYMBOLS: assert hasattr(L, s), s
+    vp = C.c_void_p
+    L.cram_new_block.restype = vp; L.cram_new_block.argtypes = [C.c_int, C.c_int]
+    L.cram_block_get_data.restype = vp; L.cram_block_get_offset.restype = C.c_size_t
+    for f in ("cram_block_append", "cram_block_update_size", "cram_block_get_content_id", "cram_block_get_comp_size", "cram_block_get_uncomp_size", "cram_block_get_data", "cram_block_get_offset",
+              "cram_block_get_method", "cram_block_get_content_type", "cram_block_get_crc32", "cram_free_block", "cram_block_size"):
+        getattr(L, f).argtypes = [vp] + ([C.c_char_p, C.c_int] if f == "cram_block_append" else [])
+    for f in ("cram_block_set_content_id", "cram_block_set_comp_size", "cram_block_set_uncomp_size", "cram_block_set_crc32"): getattr(L, f).argtypes = [vp, C.c_int32]
+    L.cram_block_set_offset.argtypes = [vp, C.c_size_t]
+    b = L.cram_new_block(4, 77)                                          # EXTERNAL
+    assert L.cram_block_get_content_id(b) == 77 and L.cram_block_get_content_type(b) == 4 and L.cram_block_get_method(b) == 0 and L.cram_block_get_offset(b) == 0
+    want = b""
+    for i in range(300):
+        piece = bytes([i & 255]) * (i * 7 % 1900)
+        assert L.cram_block_append(b, piece, len(piece)) == 0
+        want += piece
+    assert L.cram_block_get_offset(b) == len(want) and C.string_at(L.cram_block_get_data(b), len(want)) == want
+    assert L.cram_block_get_uncomp_size(b) == 0
+    L.cram_block_update_size(b)
+    assert L.cram_block_get_uncomp_size(b) == L.cram_block_get_comp_size(b) == len(want)
+    itf8 = lambda v: 1 if v < 0x80 else 2 if v < 0x4000 else 3 if v < 0x200000 else 4 if v < 0x10000000 else 5
+    assert L.cram_block_size(b) == 2 + itf8(77) + 2 * itf8(len(want)) + 4 + len(want)          # method, type, id, both sizes, CRC, payload (cram_io.c:1490-1505)
+    L.cram_block_set_content_id(b, 5); L.cram_block_set_crc32(b, 0x1234567); L.cram_block_set_offset(b, 10)
+    assert L.cram_block_get_content_id(b) == 5 and L.cram_block_get_crc32(b) == 0x1234567 and L.cram_block_get_offset(b) == 10
+    L.cram_free_block(b)
+    core = L.cram_new_block(5, 0)
+    assert L.cram_block_get_content_id(core) == -1
+    L.cram_free_block(core)

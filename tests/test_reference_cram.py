@@ -21,26 +21,12 @@ needs_ref_view = pytest.mark.skipif(not RC.have(), reason="oracle/_ref/ref_view 
 
 def _synthetic(engine, nslices, nrec, tags=True, seed=11, readlen=150):
     """slices of htslib_amd/synth_cram.py (reads aligned to a random reference of their own: clips, substitutions, insertions, deletions, unmapped and detached
-    records, tags) -> the pinned record decoder -> BAM records; slice k's records are moved to reference k -> (BAM stream with header, names, sequences)"""
-    from htslib_amd import _native as nat, synth_cram
+    records, tags) -> the pinned record decoder -> BAM records; slice k's records sit on reference k -> (BAM stream with header, names, sequences)"""
+    from htslib_amd import synth_cram
     rng = np.random.default_rng(seed)
     sl = [synth_cram.make_slice(rng, nrec, readlen, tags=tags) for _ in range(nslices)]
-    keep = []
-    arr = nat.cram_slice_array(sl, keep)
-    recs, rec_off, st = engine.cram_decode_bam(arr, nslices, 3, 1, [], nslices * nrec * readlen + 4096, nslices * nrec * (readlen * 2 + 400))
-    assert (st == 0).all()
-    b = bytearray(recs.tobytes()); at = 0
-    for k in range(nslices):
-        for _ in range(nrec):
-            ln = struct.unpack_from("<i", b, at)[0]
-            struct.pack_into("<i", b, at + 4, k)
-            if struct.unpack_from("<i", b, at + 24)[0] >= 0: struct.pack_into("<i", b, at + 24, k)
-            at += 4 + ln
-    assert at == len(b)
-    names = ["chr%d" % (k + 1) for k in range(nslices)]
-    seqs = [s["refs"][0][2] for s in sl]
-    text = b"@HD\tVN:1.6\tSO:coordinate\n" + b"".join(b"@SQ\tSN:%s\tLN:%d\n" % (n.encode(), len(q)) for n, q in zip(names, seqs))
-    return RC.bam_header(text, [(n, len(q)) for n, q in zip(names, seqs)]) + bytes(b), names, seqs
+    bam, names, seqs, _ = synth_cram.bam_from_slices(engine, sl)
+    return bam, names, seqs
 
 
 @needs_ref_view
