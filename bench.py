@@ -509,10 +509,10 @@ def _rans_variants(eng, qs_list, steps):
             "results": out}
 
 
-def op_rans(run: Run, steps: int, warmup: int, slices: int):
-    """BASELINE configs[3]: CRAM 3.1 rANS Nx16 decode (order-1 32-way QS + order-0 32-way BA) of `slices` x 10 000 reads per
-    GPU.  The streams are produced by the gfx950 ENCODER (htscodecs is absent: format parity UNPINNED); the timed region is
-    the decode launch, device resident."""
+def op_rans(run: Run, steps: int, warmup: int, slices: int, nway: int = 32):
+    """BASELINE configs[3]: CRAM 3.1 rANS Nx16 decode (order-1 QS + order-0 BA, 32-way -- or 4-way, north_star's "rANS 4x16", with nway = 4) of
+    `slices` x 10 000 reads per GPU.  The streams are produced by the gfx950 ENCODER (htscodecs is absent: format parity UNPINNED); the timed
+    region is the decode launch, device resident."""
     torch = run.init_device()
     from htslib_amd import _native as nat
     from htslib_amd.bgzf import reduce_timing
@@ -524,7 +524,10 @@ def op_rans(run: Run, steps: int, warmup: int, slices: int):
     eng = nat.Engine(run.local)
     plains, flags = [], []
     for qs, ba in series:
-        plains += [qs, ba]; flags += [5, 4]                      # QS: order-1 X32, BA: order-0 X32
+        plains += [qs, ba]; flags += [5, 4] if nway == 32 else [1, 0]   # QS: order 1, BA: order 0; X32 or 4-way
+    if os.environ.get("HG_BENCH_RANS_FLAGS"):                       # probe: both series with these flags, e.g. "0,0" = everything order 0
+        fq, fb = (int(x, 0) for x in os.environ["HG_BENCH_RANS_FLAGS"].split(","))
+        flags = [fq, fb] * (len(flags) // 2)
     streams = []
     for i in range(0, len(plains), 64):                           # encode on the GPU, in batches
         streams += eng.ransnx16_encode_host(plains[i:i + 64], flags[i:i + 64])
@@ -553,8 +556,12 @@ def op_rans(run: Run, steps: int, warmup: int, slices: int):
     torch.cuda.synchronize()
 
     def step():
-        nat.check(nat.lib.hg_ransnx16_decode_dev(eng._h, d_in.data_ptr(), d_desc.data_ptr(), None, 0, d_sel.data_ptr(), n,
-                                                 d_out.data_ptr(), d_status.data_ptr(), d_scratch.data_ptr(), stream), "rans decode")
+        if nway == 32:
+            nat.check(nat.lib.hg_ransnx16_decode_dev(eng._h, d_in.data_ptr(), d_desc.data_ptr(), None, 0, d_sel.data_ptr(), n,
+                                                     d_out.data_ptr(), d_status.data_ptr(), d_scratch.data_ptr(), stream), "rans decode")
+        else:
+            nat.check(nat.lib.hg_ransnx16_decode_dev(eng._h, d_in.data_ptr(), d_desc.data_ptr(), d_sel.data_ptr(), n, None, 0,
+                                                     d_out.data_ptr(), d_status.data_ptr(), d_scratch.data_ptr(), stream), "rans decode")
 
     elapsed, k_ms = run.timed(step, steps, warmup)
     ok = int((d_status != 0).sum()) == 0
@@ -565,7 +572,7 @@ def op_rans(run: Run, steps: int, warmup: int, slices: int):
     d_expect = torch.frombuffer(expect, dtype=torch.uint8).to(run.dev)
     ok = ok and bool(torch.equal(d_out, d_expect))
     del d_expect
-    variants = _rans_variants(eng, [qs for qs, _ in series[:24]], max(3, min(steps, 5))) if run.rank == 0 and run.world == 1 and not getattr(run.args, "no_variants", False) else None
+    variants = _rans_variants(eng, [qs for qs, _ in series[:24]], max(3, min(steps, 5))) if run.rank == 0 and run.world == 1 and nway == 32 and not getattr(run.args, "no_variants", False) else None
     elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(total_u), float(total_c), ok, run.world, run.dev)
     if run.rank != 0:
         return None, ok
@@ -574,15 +581,16 @@ def op_rans(run: Run, steps: int, warmup: int, slices: int):
            "value": round(sum_u * steps / elapsed / 1e9, 3), "unit": "GB/s", "n_gpus": run.world, "steps": steps,
            "warmup": warmup, "ms_per_step": round(elapsed * 1e3 / steps, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": {"workload": f"rANS Nx16 decode of {slices} CRAM slices x 10 000 x 150 bp per GPU: QS (order-1, 32-way) "
-                                  "+ BA (order-0, 32-way) data series; streams written by the gfx950 encoder; format parity "
+           "config": {"workload": f"rANS Nx16 decode of {slices} CRAM slices x 10 000 x 150 bp per GPU: QS (order-1, {nway}-way) "
+                                  f"+ BA (order-0, {nway}-way) data series; streams written by the gfx950 encoder; format parity "
                                   "with htscodecs UNPINNED", "streams_per_gpu": n, "plain_bytes_per_gpu": total_u,
                       "compressed_bytes_per_gpu": total_c, "verified": bool(ok), "verified_streams": n, "prep_seconds": round(t_prep, 1),
                       "variants": variants},
            "roofline": {"bound": "hbm", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                        "traffic": hbm_traffic_file("hbm_traffic_rans.json", ["traffic_bytes_per_plain_byte"], total_u),
-                        "kernel": "hgn::ransnx16_decode_kernel<32>", "kernel_ms": round(k_ms, 3),
+                        "traffic": hbm_traffic_file("hbm_traffic_rans.json" if nway == 32 else "hbm_traffic_rans4.json", ["traffic_bytes_per_plain_byte"], total_u),
+                        "kernel": "hgn::ransnx16_decode_kernel<32>" if nway == 32 else "hgn::rans4x16_big_decode_kernel", "kernel_ms": round(k_ms, 3),
+                        "MBps_per_stream": round(1.5 / (k_ms * 1e-3), 1),
                         "algorithmic_bytes_per_launch": int(alg)}}
     if run.world == 1 and not run.args.no_cpu_baseline:
         # N processes, one share of the streams each ("N threads, one slice each"); ~10-20 s of CPU work
@@ -1324,6 +1332,7 @@ def main():
                     help="all (default) = inflate headline (BASELINE configs[1]) + `extra`: deflate (configs[2]), rans (configs[3]), "
                          "cram (configs[4] shape) and the end-to-end bgzf_read / bgzf_write figures, in ONE JSON line; "
                          "a single op prints that op's line alone; bam = SURVEY 8f N1 (record framing + nibble2base)")
+    ap.add_argument("--nway", type=int, choices=[4, 32], default=32, help="--op rans: 32-way (default) or 4-way (rANS 4x16) streams")
     ap.add_argument("--slices", type=int, default=0, help="CRAM slices of 10 000 reads (rans: default 1000 = 10 M reads; cram: default 256)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="strong: ONE data set split over the ranks by shard_blocks (--op inflate / deflate / all: the headline and the deflate extra)")
@@ -1338,7 +1347,7 @@ def main():
         out = op_records(run, args.steps, args.slices or 256) if args.op == "records" else op_encode(run, args.steps, args.slices or 64) if args.op == "encode" else op_fqz(run, args.steps, args.slices or 512)
     elif args.op in ("rans", "cram"):
         if args.op == "rans":
-            out, ok = op_rans(run, args.steps, args.warmup, args.slices or 1000)
+            out, ok = op_rans(run, args.steps, args.warmup, args.slices or 1000, args.nway)
         else:
             out, ok = op_cram(run, args.steps, args.slices or 256)
     else:
@@ -1372,6 +1381,8 @@ def main():
                         extra["bgzf_inflate_variant_B"] = {"error": repr(e)}
                 d, ok2 = op_rans(run, es, 1, args.slices or 1000); ok = ok and ok2
                 if d: extra["cram_rans_nx16_decode"] = d
+                d, ok2 = op_rans(run, es, 1, args.slices or 1000, 4); ok = ok and ok2
+                if d: extra["cram_rans_4x16_decode"] = d
                 d, ok2 = op_cram(run, es, 256 if not args.slices else args.slices); ok = ok and ok2
                 if d: extra["cram_slices"] = d
                 if run.rank == 0 and run.world == 1:                         # the "next" rows of SURVEY 8f built this round: small, guarded probes

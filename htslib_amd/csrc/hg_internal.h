@@ -55,6 +55,8 @@ int launch_bgzf_pack(hg_ctx *ctx, const void *d_slots, const hg_bgzf_desc *d_des
                      hipStream_t s);
 int launch_rans4x8_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, size_t n, void *d_out,
                           int32_t *d_status, uint32_t *d_scratch, hipStream_t s);
+int launch_rans4x16_big_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_sel4, size_t n4, void *d_out, int32_t *d_status,
+                               uint32_t *d_scratch, hipStream_t s);
 int launch_ransnx16_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_sel4,
                            size_t n4, const uint32_t *d_sel32, size_t n32, void *d_out, int32_t *d_status,
                            uint32_t *d_scratch, hipStream_t s);

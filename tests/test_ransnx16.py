@@ -153,3 +153,36 @@ def test_gpu_encoder_transforms_match_oracle(engine, norc):
     assert not bad, bad[:12]
     outs, st = engine.cram_uncompress_blocks([(5, e, len(d)) for d, e in zip(datas, enc)])
     assert (st == 0).all() and outs == datas
+
+
+@pytest.mark.gpu
+def test_gpu_long_four_way_streams_take_the_chain_kernel(engine, norc):
+    """4-way streams of >= 16 KiB go to rans4x16_big.hip (one stream per wavefront, scalar renormalisation window, one-read order-0 table, the LDS forms of the
+    order-1 tables) -- lengths around the hand-over and every remainder mod 4, every table form: dense (qual4 / bases), bucket (qual41), lists that do not
+    fit the pool (bytes: 256 contexts of 256 symbols), a single-symbol alphabet, order 0 and 1, raw (size in the stream), NOSZ, and behind PACK / RLE /
+    STRIPE (pre-parsed descriptors); then damaged streams: the verdict is the oracle's."""
+    rng = np.random.default_rng(404)
+    blocks, want = [], []
+    for kind in ("qual4", "qual41", "bases", "bytes", "const"):
+        for n in (16383, 16384, 16385, 16386, 16387, 40_001, 262_146, 1_000_003):
+            d = synth_series(rng, kind, n)
+            for fl in (0, 1, 0x10, 0x11, 0x80, 0x81, 0x41, 0xC1, 0x09, 0x08):
+                if n > 300_000 and fl not in (0, 1, 0x81): continue
+                blocks.append((5, norc.encode(d, fl), len(d))); want.append(d)
+    outs, st = engine.cram_uncompress_blocks(blocks)
+    bad = [(i, hex(blocks[i][1][0]), blocks[i][2]) for i in range(len(blocks)) if st[i] != 0 or outs[i] != want[i]]
+    assert not bad, bad[:10]
+    small = synth_series(rng, "qual41", 30_000)
+    base = [norc.encode(small, fl) for fl in (0, 1)] + [norc.encode(synth_series(rng, "qual4", 30_000), 1), norc.encode(synth_series(rng, "bytes", 30_000), 1)]
+    dmg = []
+    for rep in range(600):
+        b = bytearray(base[rep & 3])
+        pos = int(rng.integers(1, len(b)))
+        b[pos] ^= 1 << int(rng.integers(0, 8))
+        dmg.append(bytes(b))
+    dmg += [base[0][:-5], base[1][:-1], base[1][:len(base[1]) // 2], base[2][:200]]
+    outs, st = engine.cram_uncompress_blocks([(5, b, 30_000) for b in dmg])
+    for b, o, s in zip(dmg, outs, st):
+        rc, w = norc.decode(b, 30_000)
+        if rc == 0 and len(w) == 30_000: assert s == 0 and o == w
+        else: assert s != 0
