@@ -42,6 +42,7 @@
 #include "hts_bgzf_gpu.h"
 #include "hts_hfile_abi.h"
 #include "htsgpu.h"
+#include "bgzf_host_codec.h"
 
 // libhts symbols used when present (inside a libhts build they always are)
 extern "C" {
@@ -139,7 +140,15 @@ struct ReadBatch {
     const uint8_t *plain = nullptr;
     const int32_t *status = nullptr;
     size_t good = 0;               // leading blocks with status 0
+    // a HOST batch (the first blocks after bgzf_open / bgzf_seek, bgzf_host_codec.h): not submitted to the device; a block is decoded on the consumer's
+    // thread when the consumer steps onto it (a region query that reads 100 bytes pays for one block, not for a device round trip)
+    bool host = false;
+    const uint8_t *hcomp = nullptr;    // the framed blocks (the pipe's pinned input buffer)
+    std::vector<uint8_t> hplain;       // their plain image, filled block by block
+    std::vector<int32_t> hstatus;      // HOST_PENDING until decoded, then 0 / -1 / -2
 };
+constexpr int32_t HOST_PENDING = 1;
+constexpr size_t HOST_FIRST_BLOCKS = 4;
 
 struct IdxPush { void *hidx; int tid; int64_t beg, end; uint32_t offset; int mapped; uint64_t block_number; };
 
@@ -325,10 +334,10 @@ ReadPool *read_pool() {
 // ================================================================================ reader: I/O thread
 // Fill one batch: read a window, frame whole blocks, submit the inflate job.  Returns true when no further batch
 // can follow (end of input or a fatal input error); the caller publishes that together with the batch.
-bool fill_batch(Engine *e, ReadBatch &b) {
+bool fill_batch(Engine *e, ReadBatch &b, size_t host_blocks = 0) {
     bool finished = false;
     BGZF *fp = e->fp;
-    b.desc.clear(); b.fail = 0; b.submitted = false; b.comp_len = 0; b.good = 0;
+    b.desc.clear(); b.fail = 0; b.submitted = false; b.comp_len = 0; b.good = 0; b.host = false;
     b.file_off = e->read_off;
     const size_t want = e->window;
     // Past the first window after an open / seek the reader is scanning and the windows grow to WINDOW_MAX: size this pipe's buffers for
@@ -367,7 +376,7 @@ bool fill_batch(Engine *e, ReadBatch &b) {
         const uint8_t *t = h + bs - 4;
         const uint32_t isize = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
         if (isize > BGZF_MAX_BLOCK_SIZE) { b.fail = BGZF_ERR_ZLIB; break; }
-        if (plain + isize > PLAIN_MAX && !b.desc.empty()) { capped = true; break; }
+        if ((plain + isize > PLAIN_MAX && !b.desc.empty()) || (host_blocks && b.desc.size() >= host_blocks)) { capped = true; break; }
         hg_bgzf_desc d; d.coff = pos; d.uoff = plain; d.clen = (uint32_t)bs; d.ulen = isize;
         b.desc.push_back(d);
         plain += isize; pos += bs;
@@ -380,6 +389,12 @@ bool fill_batch(Engine *e, ReadBatch &b) {
     if (pos >= (64u << 10) && (double)plain / (double)pos > e->ratio_seen) e->ratio_seen = (double)plain / (double)pos;
     e->read_off += (int64_t)pos;
     const double t_r2 = stats_on() ? now_s() : 0;
+    if (host_blocks) {                                                       // decoded later, block by block, on the consumer's thread
+        b.host = true; b.hcomp = buf;
+        b.hplain.resize((size_t)plain + 64); b.hstatus.assign(b.desc.size(), HOST_PENDING);
+        if (stats_on()) { const double t = now_s(); e->st.io_read += t_r1 - t_r0; e->st.io_frame += t - t_r1; e->st.batches++; }
+        return finished;
+    }
     if (!b.desc.empty()) {
         if (hg_pipe_inflate(b.pipe, pos, b.desc.data(), b.desc.size()) != HG_OK) {
             b.desc.clear(); b.fail = BGZF_ERR_ZLIB; finished = true;
@@ -422,6 +437,11 @@ bool start_reader(Engine *e) {
     if (e->started) return true;
     for (int i = 0; i < e->NPIPES; i++) if (!e->rb[i].pipe && !get_pipe(e, i, &e->rb[i].pipe)) return false;
     e->read_off = hg_htell(e->fp->fp);
+    // the first blocks of the file are framed here and decoded on the host as the consumer reaches them (first bytes without a device round trip);
+    // the I/O thread takes over behind them once the consumer shows that it is scanning (widen_readahead)
+    e->ahead = 1;
+    if (fill_batch(e, e->rb[0], HOST_FIRST_BLOCKS)) e->input_done = true;
+    e->fill_seq = 1;
     e->started = true;
     e->th = std::thread(reader_main, e);
     return true;
@@ -454,7 +474,7 @@ int restart_reader_at(Engine *e, int64_t addr) {
         // The first (small) window is read and submitted right here, on the caller's thread: no hand-over to the I/O
         // thread on the latency path of a random access.  Nothing is prefetched behind it until widen_readahead().
         e->ahead = 1;
-        if (fill_batch(e, e->rb[0])) e->input_done = true;
+        if (fill_batch(e, e->rb[0], HOST_FIRST_BLOCKS)) e->input_done = true;
         e->fill_seq = 1;
     }
     resume_reader(e);
@@ -488,6 +508,7 @@ int next_batch(Engine *e) {
         if (rc != HG_OK && rc != HG_EBLOCK) { b.desc.clear(); b.fail = BGZF_ERR_ZLIB; }
         while (b.good < b.desc.size() && b.status[b.good] == 0) b.good++;
     }
+    if (b.host) { b.plain = b.hplain.data(); b.status = b.hstatus.data(); b.good = 0; }
     lk.lock();
     e->cur_loaded = true;
     e->blk = 0; e->blk_pending = true;
@@ -542,6 +563,11 @@ int engine_read_block(BGZF *fp) {
         }
         const hg_bgzf_desc &d = b.desc[e->blk];
         const int64_t addr = b.file_off + (int64_t)d.coff;
+        if (b.host && b.hstatus[e->blk] == HOST_PENDING) {                  // bgzf_read_block's single-threaded branch: inflate_block on this thread (bgzf.c:1198-1205)
+            static thread_local hgh::Inflater I;
+            b.hstatus[e->blk] = hgh::bgzf_block_inflate(I, b.hcomp + d.coff, d.clen, b.hplain.data() + d.uoff, d.ulen);
+            while (b.good < b.desc.size() && b.hstatus[b.good] == 0) b.good++;
+        }
         if (b.status[e->blk] != 0) {
             fp->errcode |= b.status[e->blk] == HG_BLOCK_ECRC ? BGZF_ERR_CRC : BGZF_ERR_ZLIB;
             logmsg(LOG_ERROR, "bgzf_read_block", "BGZF decode returned error %d for block offset %lld", (int)b.status[e->blk], (long long)addr);
@@ -891,9 +917,41 @@ ssize_t queue_whole_blocks(BGZF *fp, const uint8_t *in, size_t length) {
 // the index with it), so the block goes through the engine alone and is waited for: correct, but one device round
 // trip per block.  After bgzf_mt() blocks are batched and fp->block_address is only valid after bgzf_flush(), exactly
 // as with the reference's threads (bgzf.c:1953-1967).
+int host_cut_block(BGZF *fp);
 int cut_block(BGZF *fp) {
+    if (!fp->mt && E(fp)->kind == K_WRITE) return host_cut_block(fp);
     if (queue_block(fp) != 0) return -1;
     return fp->mt ? 0 : drain_writer(fp);
+}
+
+// The reference's single-threaded writer (bgzf_flush -> deflate_block + hwrite, bgzf.c:1949-1994, 709-726): without bgzf_mt() a block is compressed
+// when it is cut, on the caller's thread, and bgzf_tell() is exact right away.  A device job for ONE block costs a launch + a PCIe round trip (~4 ms:
+// 16 MB/s); the host codec (bgzf_host_codec.h) does a block in ~0.6 ms.  The handle still owns a live engine: bgzf_mt() at any later point switches to
+// batched device jobs, and e->block_address / block_number stay those of the output thread's bookkeeping.
+int host_cut_block(BGZF *fp) {
+    Engine *e = E(fp);
+    if (fp->block_offset == 0) return 0;
+    if (e->started && drain_writer(fp) != 0) return -1;                  // (device jobs of an earlier bgzf_mt phase first: order on disk)
+    static thread_local hgh::Deflater D;
+    uint8_t *dst = (uint8_t *)fp->compressed_block;
+    size_t dlen = BGZF_MAX_BLOCK_SIZE;
+    const size_t ulen = (size_t)fp->block_offset;
+    if (hgh::bgzf_block_deflate(D, dst, &dlen, (const uint8_t *)fp->uncompressed_block, ulen, fp->compress_level < 0 ? 6 : fp->compress_level) != 0) {
+        fp->errcode |= BGZF_ERR_ZLIB;
+        return -1;
+    }
+    if (fp->idx_build_otf && fp->idx) {
+        const GziEntry last = fp->idx->offs.back();
+        fp->idx->offs.push_back(GziEntry{last.caddr + dlen, last.uaddr + ulen});
+    }
+    if (hg_hwrite(fp->fp, dst, dlen) != (ssize_t)dlen) { fp->errcode |= BGZF_ERR_IO; return -1; }
+    {
+        std::lock_guard<std::mutex> g(e->m);
+        e->block_address += (int64_t)dlen; e->block_number++; e->block_written++;
+        fp->block_address = e->block_address;
+    }
+    fp->block_offset = 0;
+    return 0;
 }
 
 int drain_writer(BGZF *fp) {
@@ -1366,7 +1424,8 @@ int bgzf_flush_try(BGZF *fp, ssize_t size) {
 int bgzf_flush(BGZF *fp) {
     if (!fp->is_write) return 0;
     if (!fp->is_compressed) return hflush(fp->fp);
-    if (queue_block(fp) != 0) return -1;
+    if (!fp->mt && E(fp)->kind == K_WRITE) { if (host_cut_block(fp) != 0) return -1; }
+    else if (queue_block(fp) != 0) return -1;
     return drain_writer(fp);
 }
 
@@ -1390,17 +1449,11 @@ int bgzf_compress(void *dst, size_t *dlen, const void *src, size_t slen, int lev
         memcpy(dst, kEof, 28); *dlen = 28;
         return 0;
     }
-    hg_ctx *ctx = shared_ctx();
-    if (!ctx || slen > BGZF_BLOCK_SIZE) return -1;
-    std::vector<uint8_t> tmp(BGZF_MAX_BLOCK_SIZE + 64);
-    size_t out_len = 0;
-    const uint64_t cuts[2] = {0, slen};
-    const int rc = hg_bgzf_deflate_host(ctx, (const uint8_t *)src, slen, cuts, 1, level < 0 || level > 9 ? 6 : level, 0,
-                                        tmp.data(), tmp.size(), &out_len);
-    if (rc != HG_OK || out_len > *dlen) return -1;
-    memcpy(dst, tmp.data(), out_len);
-    *dlen = out_len;
-    return 0;
+    // One block, synchronously: the host codec (SURVEY 8b keeps bgzf_compress() on the scalar path; a device job for one block is a 4 ms round trip).
+    // The engine must exist all the same -- this library has no life without a device.
+    if (!shared_ctx() || slen > BGZF_BLOCK_SIZE) return -1;
+    static thread_local hgh::Deflater D;
+    return hgh::bgzf_block_deflate(D, (uint8_t *)dst, dlen, (const uint8_t *)src, slen, level < 0 || level > 9 ? 6 : level);
 }
 
 // Short buffers (the 10-30 byte block headers cram_read_block / cram_write_block checksum, cram_io.c:1431-1470, 1547-1552) are not worth a

@@ -1,0 +1,342 @@
+// bgzf_host_codec.h -- the LATENCY path of the BGZF front-end: one block at a time on the calling thread, host code only.
+//
+// "keep the scalar CPU path for single blocks, gzip streams, bgzf_compress() and tiny inputs" -- the reference's single-threaded
+// reader / writer (bgzf.c:1004-1239 bgzf_read_block, :2029-2060 bgzf_block_write, :561-683 bgzf_compress).  A GPU batch costs a launch and a PCIe
+// round trip (~1.5 ms) however small it is, so a handle uses this file for
+//   * the first blocks after bgzf_open / bgzf_seek (region queries read a few hundred bytes and seek again),
+//   * every block of a writer that never called bgzf_mt() (the reference's synchronous writer: bgzf_tell() must be exact after each block),
+//   * bgzf_compress().
+// It is NOT a fallback: a handle only exists with a live GPU engine (no device -> bgzf_open fails as before), and everything that streams goes to
+// the device.  Own code, written from RFC 1951 / 1952: no zlib, no libdeflate, nothing from oracle/.  The verdicts are the device kernel's
+// (bgzf_inflate.hip) rule for rule -- same invalid-code-set tests, same ISIZE rule -- and tests/test_host_codec.py holds both against the real
+// reference (oracle/_ref) on the reference's fixtures and on damaged blocks.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+#include "deflate_huff.h"
+
+namespace hgh {
+
+// ---- CRC-32 (IEEE 802.3, the gzip polynomial), slicing-by-8 --------------------------------------------------------------------------
+struct CrcTab {
+    uint32_t t[8][256];
+    CrcTab() {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u))); t[0][i] = c; }
+        for (uint32_t i = 0; i < 256; i++) for (int s = 1; s < 8; s++) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xffu];
+    }
+};
+inline const CrcTab &crc_tab() { static const CrcTab T; return T; }
+inline uint32_t crc32(uint32_t crc, const uint8_t *p, size_t n) {
+    const CrcTab &T = crc_tab();
+    uint32_t c = ~crc;
+    while (n && ((uintptr_t)p & 7u)) { c = (c >> 8) ^ T.t[0][(c ^ *p++) & 0xffu]; n--; }
+    while (n >= 8) {
+        uint64_t w; memcpy(&w, p, 8);
+        const uint32_t lo = (uint32_t)w ^ c, hi = (uint32_t)(w >> 32);
+        c = T.t[7][lo & 0xffu] ^ T.t[6][(lo >> 8) & 0xffu] ^ T.t[5][(lo >> 16) & 0xffu] ^ T.t[4][lo >> 24] ^
+            T.t[3][hi & 0xffu] ^ T.t[2][(hi >> 8) & 0xffu] ^ T.t[1][(hi >> 16) & 0xffu] ^ T.t[0][hi >> 24];
+        p += 8; n -= 8;
+    }
+    while (n--) c = (c >> 8) ^ T.t[0][(c ^ *p++) & 0xffu];
+    return ~c;
+}
+
+// ---- inflate (RFC 1951) -----------------------------------------------------------------------------------------------------------------
+// decode table entry: bits [7:0] code bits to drop; [15:8] op -- OP_LIT, OP_EOB, OP_BAD, OP_BASE | extra-bit count (length / distance base in the
+// value), OP_SUB | index bits of a second-level table (its first entry in the value); [31:16] value
+enum : uint32_t { OP_LIT = 0x00, OP_BASE = 0x10, OP_EOB = 0x20, OP_SUB = 0x40, OP_BAD = 0x80 };
+constexpr int LROOT = 10, DROOT = 8, PROOT = 7;
+constexpr int LTAB = (1 << LROOT) + 4608, DTAB = (1 << DROOT) + 2048;     // <= 143 / 15 second-level tables of <= 32 / 128 entries
+
+struct Inflater {
+    uint32_t lit[LTAB], dist[DTAB];
+    std::vector<uint8_t> pad;                                            // the payload + zero padding: the bit reader never tests for the end per byte
+
+    static uint32_t entry(int kind, uint32_t sym, uint32_t nb) {       // kind 0 litlen, 1 distance, 2 precode
+        if (kind == 2) return (sym << 16) | (OP_LIT << 8) | nb;
+        if (kind == 0) {
+            if (sym < 256) return (sym << 16) | (OP_LIT << 8) | nb;
+            if (sym == 256) return (OP_EOB << 8) | nb;
+            const uint32_t s = sym - 257;
+            if (s > 28) return (OP_BAD << 8) | nb;                       // 286, 287
+            const uint32_t extra = s < 8 || s == 28 ? 0 : (s - 4) >> 2;
+            const uint32_t base = s < 8 ? 3 + s : s == 28 ? 258 : 3 + ((4 + (s & 3)) << extra);
+            return (base << 16) | ((OP_BASE | extra) << 8) | nb;
+        }
+        if (sym > 29) return (OP_BAD << 8) | nb;                         // 30, 31
+        const uint32_t extra = sym < 4 ? 0 : (sym - 2) >> 1;
+        const uint32_t base = sym < 4 ? 1 + sym : 1 + ((2 + (sym & 1)) << extra);
+        return (base << 16) | ((OP_BASE | extra) << 8) | nb;
+    }
+    static uint32_t rev(uint32_t code, int len) { uint32_t r = 0; for (int i = 0; i < len; i++) { r = (r << 1) | (code & 1u); code >>= 1; } return r; }
+
+    // lens[0..n) -> root table of `root` bits + second-level tables behind it.  false = over-subscribed, or incomplete and not "no code at all" /
+    // "a single one-bit code" (the kernel's build_table rule = zlib's inftrees.c verdict), or out of table room.
+    static bool build(int kind, const uint8_t *lens, int n, int root, uint32_t *tab, int cap) {
+        int cnt[16] = {0};
+        for (int i = 0; i < n; i++) cnt[lens[i]]++;
+        cnt[0] = 0;
+        int left = 1, total = 0, maxlen = 0;
+        uint32_t next[16], code = 0;
+        for (int l = 1; l <= 15; l++) {
+            next[l] = code; code = (code + (uint32_t)cnt[l]) << 1;
+            left = (left << 1) - cnt[l];
+            if (left < 0) return false;
+            total += cnt[l]; if (cnt[l]) maxlen = l;
+        }
+        if (left > 0 && !(total == 0 || (total == 1 && maxlen == 1))) return false;
+        const uint32_t rmask = (1u << root) - 1u;
+        for (uint32_t i = 0; i <= rmask; i++) tab[i] = (OP_BAD << 8) | 1u;            // slots no code reaches (incomplete sets): invalid
+        uint8_t sublen[1 << LROOT];
+        if (maxlen > root) memset(sublen, 0, (size_t)1 << root);
+        uint32_t codes[288];
+        for (int i = 0; i < n; i++) {
+            const int l = lens[i];
+            if (!l) continue;
+            const uint32_t r = rev(next[l]++, l);
+            codes[i] = r;
+            if (l <= root) { const uint32_t e = entry(kind, (uint32_t)i, (uint32_t)l); for (uint32_t k = r; k <= rmask; k += 1u << l) tab[k] = e; }
+            else if (l > sublen[r & rmask]) sublen[r & rmask] = (uint8_t)l;
+        }
+        if (maxlen <= root) return true;
+        uint32_t alloc = rmask + 1u;
+        for (uint32_t p = 0; p <= rmask; p++) {
+            if (!sublen[p]) continue;
+            const uint32_t sb = (uint32_t)sublen[p] - (uint32_t)root;
+            if (alloc + (1u << sb) > (uint32_t)cap) return false;
+            for (uint32_t k = 0; k < (1u << sb); k++) tab[alloc + k] = (OP_BAD << 8) | 1u;
+            tab[p] = (alloc << 16) | ((OP_SUB | sb) << 8) | (uint32_t)root;
+            alloc += 1u << sb;
+        }
+        for (int i = 0; i < n; i++) {
+            const int l = lens[i];
+            if (l <= root) continue;
+            const uint32_t r = codes[i], p = r & rmask, off = tab[p] >> 16, sb = (tab[p] >> 8) & 15u;
+            const uint32_t e = entry(kind, (uint32_t)i, (uint32_t)(l - root));
+            for (uint32_t k = r >> root; k < (1u << sb); k += 1u << (l - root)) tab[off + k] = e;
+        }
+        return true;
+    }
+
+    // Raw deflate stream in[0..n) -> out[0..cap).  0 = a complete stream decoded (*produced bytes), -1 = invalid / needs more input or room.
+    int run(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *produced) {
+        constexpr size_t PAD = 64;
+        pad.resize(n + PAD);
+        memcpy(pad.data(), in, n); memset(pad.data() + n, 0, PAD);
+        const uint8_t *ip = pad.data(), *const ilim = pad.data() + n + 8;   // a reader beyond this has consumed bytes that are not there
+        uint64_t bb = 0; uint32_t bc = 0;
+        uint8_t *op = out, *const oend = out + cap;
+        auto refill = [&]() { uint64_t w; memcpy(&w, ip, 8); bb |= w << bc; ip += (63u - bc) >> 3; bc |= 56u; };      // >= 56 valid bits afterwards
+        auto take = [&](uint32_t k) -> uint32_t { const uint32_t v = (uint32_t)bb & ((1u << k) - 1u); bb >>= k; bc -= k; return v; };
+        auto bytepos = [&]() -> size_t { return (size_t)(ip - pad.data()) - (bc >> 3); };
+        for (;;) {
+            if (ip > ilim) return -1;
+            refill();
+            if (bytepos() > n) return -1;
+            const uint32_t bfinal = take(1), btype = take(2);
+            if (btype == 0) {
+                take(bc & 7u);
+                refill();
+                const uint32_t len = take(16), nlen = take(16);
+                if ((len ^ 0xffffu) != nlen) return -1;
+                const size_t src = bytepos();
+                if (src + len > n || (size_t)(oend - op) < len) return -1;
+                memcpy(op, pad.data() + src, len); op += len;
+                ip = pad.data() + src + len; bb = 0; bc = 0;
+            } else if (btype == 3) return -1;
+            else {
+                uint8_t lens[320];
+                if (btype == 1) {
+                    for (int i = 0; i < 288; i++) lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+                    uint8_t dl[32]; memset(dl, 5, 32);
+                    if (!build(1, dl, 32, DROOT, dist, DTAB) || !build(0, lens, 288, LROOT, lit, LTAB)) return -1;
+                } else {
+                    const uint32_t nlen = take(5) + 257, ndist = take(5) + 1, ncode = take(4) + 4;
+                    if (nlen > 286 || ndist > 30) return -1;
+                    static const uint8_t perm[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                    uint8_t pl[19] = {0};
+                    for (uint32_t i = 0; i < ncode; i++) { if (bc < 3) refill(); pl[perm[i]] = (uint8_t)take(3); }
+                    uint32_t *pre = dist;                                                // the distance table's room, free until it is built
+                    if (!build(2, pl, 19, PROOT, pre, DTAB)) return -1;
+                    { int left = 1; int c[8] = {0}; for (int i = 0; i < 19; i++) c[pl[i]]++; for (int l = 1; l <= 7; l++) left = (left << 1) - c[l]; if (left != 0) return -1; }   // complete precode only
+                    uint32_t idx = 0, prev = 0;
+                    const uint32_t total = nlen + ndist;
+                    while (idx < total) {
+                        if (ip > ilim) return -1;
+                        refill();
+                        const uint32_t e = pre[bb & ((1u << PROOT) - 1u)];
+                        if (((e >> 8) & 0xffu) != OP_LIT) return -1;
+                        take(e & 0xffu);
+                        const uint32_t sym = e >> 16;
+                        if (sym < 16) { lens[idx++] = (uint8_t)sym; prev = sym; continue; }
+                        uint32_t rep, val = 0;
+                        if (sym == 16) { if (idx == 0) return -1; val = prev; rep = 3 + take(2); }
+                        else if (sym == 17) rep = 3 + take(3);
+                        else rep = 11 + take(7);
+                        if (idx + rep > total) return -1;
+                        memset(lens + idx, (int)val, rep); idx += rep; prev = val;
+                    }
+                    if (lens[256] == 0) return -1;                                       // no end-of-block code
+                    if (!build(1, lens + nlen, (int)ndist, DROOT, dist, DTAB) || !build(0, lens, (int)nlen, LROOT, lit, LTAB)) return -1;
+                }
+                // ---- the symbols of the block
+                for (;;) {
+                    if (ip > ilim) return -1;
+                    refill();
+                    uint32_t e = lit[bb & ((1u << LROOT) - 1u)];
+                    if ((e & 0xc000u) == (OP_SUB << 8)) { take(e & 0xffu); e = lit[(e >> 16) + ((uint32_t)bb & ((1u << ((e >> 8) & 15u)) - 1u))]; }
+                    uint32_t opc = (e >> 8) & 0xffu;
+                    take(e & 0xffu);
+                    if (opc == OP_LIT) {
+                        if (op >= oend) return -1;
+                        *op++ = (uint8_t)(e >> 16);
+                        // a second literal out of the same refill (>= 56 - 15 bits are left)
+                        e = lit[bb & ((1u << LROOT) - 1u)];
+                        if (((e >> 8) & 0xffu) != OP_LIT || op >= oend) continue;
+                        take(e & 0xffu); *op++ = (uint8_t)(e >> 16);
+                        continue;
+                    }
+                    if (opc == OP_EOB) break;
+                    if (!(opc & OP_BASE) || (opc & 0xc0u)) return -1;                    // invalid code
+                    const uint32_t len = (e >> 16) + take(opc & 15u);
+                    if (bc < 32) refill();
+                    uint32_t d = dist[bb & ((1u << DROOT) - 1u)];
+                    if ((d & 0xc000u) == (OP_SUB << 8)) { take(d & 0xffu); d = dist[(d >> 16) + ((uint32_t)bb & ((1u << ((d >> 8) & 15u)) - 1u))]; }
+                    const uint32_t dop = (d >> 8) & 0xffu;
+                    take(d & 0xffu);
+                    if (!(dop & OP_BASE) || (dop & 0xc0u)) return -1;
+                    const uint32_t dst = (d >> 16) + take(dop & 15u);
+                    if (dst > (size_t)(op - out) || (size_t)(oend - op) < len) return -1;
+                    const uint8_t *sp = op - dst;
+                    if (dst >= 8 && (size_t)(oend - op) >= len + 8u) {                  // 8 bytes at a time (may write up to 7 bytes past the match, inside the buffer)
+                        uint8_t *e8 = op + len;
+                        do { uint64_t w; memcpy(&w, sp, 8); memcpy(op, &w, 8); sp += 8; op += 8; } while (op < e8);
+                        op = e8;
+                    } else for (uint32_t k = 0; k < len; k++) *op++ = *sp++;
+                }
+                if (bytepos() > n) return -1;
+            }
+            if (bfinal) break;
+        }
+        *produced = (size_t)(op - out);
+        return 0;
+    }
+};
+
+// One BGZF block (18-byte header already checked, clen = BSIZE + 1) -> out[0..ulen) where ulen = its ISIZE field.  bgzf_uncompress's
+// verdicts (bgzf.c:730-804): 0, -1 = the deflate stream does not decode (to exactly ISIZE bytes: the kernel's rule), -2 = CRC-32 mismatch.
+inline int bgzf_block_inflate(Inflater &I, const uint8_t *block, size_t clen, uint8_t *out, uint32_t ulen) {
+    if (clen < 26) return -1;
+    const uint8_t *t = block + clen - 8;
+    const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    size_t made = 0;
+    if (I.run(block + 18, clen - 26, out, ulen, &made) != 0 || made != ulen) return -1;
+    return crc32(0, out, ulen) == want ? 0 : -2;
+}
+
+// ---- deflate (one block, one setting: greedy parse over hash chains, one dynamic-Huffman block) --------------------------------------------
+struct Deflater {
+    static constexpr int HBITS = 15;
+    uint16_t head[1 << HBITS], prev[65536];
+    uint32_t tok[65536 + 8];
+
+    // Raw deflate of src[0..n), n <= 65536, BFINAL set, into dst[0..cap).  Returns the bytes written, 0 = does not fit.  depth: hash-chain links followed
+    // per position (level 1-3: 4, 4-6: 16, 7-9: 48).
+    size_t run(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int depth) {
+        using namespace hgdef;
+        uint32_t lf[288] = {0}, df[32] = {0};
+        size_t nt = 0;
+        memset(head, 0, sizeof head);
+        auto hash = [&](size_t i) -> uint32_t { uint32_t v; memcpy(&v, src + i, 4); return (v * 2654435761u) >> (32 - HBITS); };
+        size_t i = 0;
+        while (i < n) {
+            uint32_t best = 0, bd = 0;
+            if (i + 4 <= n) {
+                const uint32_t h = hash(i);
+                uint32_t cand = head[h];                                               // position + 1, 0 = none
+                const size_t maxl = n - i < 258 ? n - i : 258;
+                for (int d = 0; cand && d < depth; d++) {
+                    const size_t c = cand - 1;
+                    if (i - c > 32768) break;                                           // older links are farther still
+                    if (src[c + best] == src[i + best] || best == 0) {
+                        size_t l = 0;
+                        while (l + 8 <= maxl) { uint64_t a, b; memcpy(&a, src + c + l, 8); memcpy(&b, src + i + l, 8); if (a != b) { l += (size_t)__builtin_ctzll(a ^ b) >> 3; goto done; } l += 8; }
+                        while (l < maxl && src[c + l] == src[i + l]) l++;
+                    done:
+                        if (l > maxl) l = maxl;
+                        if (l > best) { best = (uint32_t)l; bd = (uint32_t)(i - c); if (l == maxl) break; }
+                    }
+                    cand = prev[c];
+                }
+                prev[i] = head[h]; head[h] = (uint16_t)(i + 1);                       // (position 65535 + 1 wraps to 0 = "none": the last byte is never a match start that matters)
+                if (best < 4 || (best == 4 && bd > 4096)) best = 0;
+            }
+            if (best) {
+                uint32_t s, xb, xv;
+                len_symbol(best, s, xb, xv); lf[257 + s]++;
+                dist_symbol(bd, s, xb, xv); df[s]++;
+                tok[nt++] = 0x80000000u | ((best - 3u) << 16) | (bd - 1u);
+                for (size_t k = 1; k < best && i + k + 4 <= n; k++) { const uint32_t h = hash(i + k); prev[i + k] = head[h]; head[h] = (uint16_t)(i + k + 1); }
+                i += best;
+            } else { lf[src[i]]++; tok[nt++] = src[i]; i++; }
+        }
+        lf[256] = 1;
+        uint8_t ll[288], dl[32], cs[320], ce[320]; uint16_t lc[288], dc[32], order[320]; uint32_t work[320];
+        build_lengths(lf, 286, 15, ll, order, work); build_lengths(df, 30, 15, dl, order, work);
+        assign_codes(ll, 286, lc); assign_codes(dl, 30, dc);
+        // size before writing: header (<= 320 bytes) + the tokens
+        uint64_t bits = 0;
+        for (int s = 0; s < 286; s++) bits += (uint64_t)lf[s] * ll[s];
+        for (int s = 0; s < 30; s++) bits += (uint64_t)df[s] * dl[s];
+        for (int s = 265; s < 285; s++) bits += (uint64_t)lf[s] * (uint32_t)((s - 261) >> 2);
+        for (int s = 4; s < 30; s++) bits += (uint64_t)df[s] * (uint32_t)((s - 2) >> 1);
+        if (cap < 330 + 8 || (bits >> 3) + 330 + 8 > cap) return 0;
+        memset(dst, 0, 330);
+        const uint32_t hb = write_dynamic_header(ll, dl, dst, cs, ce, work, order);
+        uint64_t acc = 0; uint32_t have = hb & 7u; size_t at = hb >> 3;
+        if (have) acc = dst[at];
+        auto put = [&](uint32_t v, uint32_t k) { acc |= (uint64_t)v << have; have += k; };
+        auto flush = [&]() { while (have >= 8) { dst[at++] = (uint8_t)acc; acc >>= 8; have -= 8; } };
+        for (size_t k = 0; k < nt; k++) {
+            const uint32_t t = tok[k];
+            if (t & 0x80000000u) {
+                uint32_t s, xb, xv;
+                len_symbol(((t >> 16) & 0xffu) + 3u, s, xb, xv);
+                put(lc[257 + s], ll[257 + s]); put(xv, xb); flush();
+                dist_symbol((t & 0xffffu) + 1u, s, xb, xv);
+                put(dc[s], dl[s]); put(xv, xb); flush();
+            } else { put(lc[t & 0xffu], ll[t & 0xffu]); flush(); }
+        }
+        put(lc[256], ll[256]); flush();
+        if (have) dst[at++] = (uint8_t)acc;
+        return at;
+    }
+};
+
+// bgzf_compress (bgzf.c:561-683): one complete BGZF block from src[0..slen), slen <= 0xff00 for a block the reference would write (any slen <= 65536
+// works), into dst[0..*dlen).  level 0 = a stored block; a block that does not shrink is stored as well (:652-667); slen == 0 = the EOF block.
+// 0 / -1 (dst too small).
+inline int bgzf_block_deflate(Deflater &D, uint8_t *dst, size_t *dlen, const uint8_t *src, size_t slen, int level) {
+    static const uint8_t EOFB[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (slen == 0) { if (*dlen < 28) return -1; memcpy(dst, EOFB, 28); *dlen = 28; return 0; }
+    if (slen > 65536 || *dlen < 26) return -1;
+    size_t room = *dlen - 26 < 65536 - 26 ? *dlen - 26 : 65536 - 26, clen = 0;
+    if (level != 0) clen = D.run(src, slen, dst + 18, room, level < 0 || level > 9 ? 16 : level <= 3 ? 4 : level <= 6 ? 16 : 48);
+    if (clen == 0 || clen >= slen + 5) {                                                 // stored: 01 LEN NLEN bytes
+        if (slen + 5 > room || slen > 65535) return -1;
+        dst[18] = 1; dst[19] = (uint8_t)slen; dst[20] = (uint8_t)(slen >> 8); dst[21] = (uint8_t)~slen; dst[22] = (uint8_t)(~slen >> 8);
+        memcpy(dst + 23, src, slen); clen = slen + 5;
+    }
+    static const uint8_t HDR[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    memcpy(dst, HDR, 16);
+    const size_t bs = clen + 26;
+    dst[16] = (uint8_t)(bs - 1); dst[17] = (uint8_t)((bs - 1) >> 8);
+    const uint32_t crc = crc32(0, src, slen);
+    uint8_t *t = dst + 18 + clen;
+    for (int k = 0; k < 4; k++) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)((uint32_t)slen >> (8 * k)); }
+    *dlen = bs;
+    return 0;
+}
+
+}  // namespace hgh

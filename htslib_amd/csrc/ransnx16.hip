@@ -25,6 +25,7 @@
 #include "htsgpu.h"
 #include "hg_device.h"
 #include "hg_internal.h"
+#include <type_traits>
 #include "ransnx16_dev.h"
 
 namespace hgn {
@@ -164,55 +165,68 @@ void ransnx16_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
         uint32_t rctx = Fm.drank0;                                      // dense form: rank of the current context
         const uint32_t steps = per, rem = usz - per * N;
         const uint32_t max_steps = (live && !err) ? steps + (order ? rem : 0u) : 0u;
-        for (uint32_t it = 0; __any(it < max_steps); it++) {
-            const bool act = live && !err && it < max_steps;
-            const bool mine = act && (it < steps || (order && sub == N - 1));
-            uint32_t need = 0;
-            if (mine) {
-                const uint32_t m = R & mask;
-                uint32_t sym = 0, cum = 0, f = 1;
-                if (order == 0) {
-                    uint32_t lo = 0, hi = 256;
-                    if (lut) lo = lut[m];
-                    else while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (G.C[mid] <= m) lo = mid; else hi = mid; }
-                    sym = lo; cum = G.C[lo]; f = (uint32_t)G.C[lo + 1] - cum;
+        // The decode loop, once per table form: the form is the same for every lane of a 32-way launch's wavefront (one stream per wavefront), so the
+        // choice is made ONCE, outside the loop -- inside it, a per-step dispatch on a value the compiler cannot prove uniform became nested exec-mask branches.
+        auto run = [&](auto formc) {
+            O1Forms Gf = Fm; Gf.form = decltype(formc)::value;
+            for (uint32_t it = 0; __any(it < max_steps); it++) {
+                const bool act = live && !err && it < max_steps;
+                const bool mine = act && (it < steps || (order && sub == N - 1));
+                uint32_t need = 0;
+                if (mine) {
+                    const uint32_t m = R & mask;
+                    uint32_t sym = 0, cum = 0, f = 1;
+                    if (order == 0) {
+                        uint32_t lo = 0, hi = 256;
+                        if (lut) lo = lut[m];
+                        else while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (G.C[mid] <= m) lo = mid; else hi = mid; }
+                        sym = lo; cum = G.C[lo]; f = (uint32_t)G.C[lo + 1] - cum;
+                    } else {
+                        if (!lookup_o1(Gf, pool[N == 32 ? (tid >> 6) * GROUPS + grp : 0], tabs, ctx, rctx, m, shift, sym, cum, f)) err = 1;
+                    }
+                    if (!err) {
+                        o[pos] = (uint8_t)sym;
+                        pos += order == 0 ? (uint32_t)N : 1u;
+                        ctx = sym;
+                        R = f * (R >> shift) + m - cum;
+                        need = R < RANS_L ? 1u : 0u;
+                    }
+                }
+                // the lanes that renormalise take consecutive 16-bit words in lane order
+                const unsigned long long b = __ballot(need != 0) & gmask;
+                const uint32_t before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+                const uint32_t tot = (uint32_t)__popcll(b);
+                if constexpr (N == 32) {
+                    if (need) {
+                        const uint32_t k = wpos + before;
+                        if (k >= wavail) err = 1;
+                        else R = (R << 16) | (uint32_t)((const uint16_t *)ring)[k & 127u];
+                    }
+                    wpos += tot;
+                    if (act && wfill - wpos < 32u) {                      // whole group takes this branch together
+                        ring[((wfill >> 1) + (uint32_t)sub) & 63u] = pre;
+                        wfill += 64;
+                        pre = load_chunk(wfill >> 6);
+                    }
                 } else {
-                    if (!lookup_o1(Fm, pool[N == 32 ? (tid >> 6) * GROUPS + grp : 0], tabs, ctx, rctx, m, shift, sym, cum, f)) err = 1;
+                    if (need) {
+                        const uint8_t *w = cp + 2u * before;
+                        if (w + 2 > end) err = 1;
+                        else R = (R << 16) | (uint32_t)w[0] | ((uint32_t)w[1] << 8);
+                    }
+                    cp += 2u * tot;
                 }
-                if (!err) {
-                    o[pos] = (uint8_t)sym;
-                    pos += order == 0 ? (uint32_t)N : 1u;
-                    ctx = sym;
-                    R = f * (R >> shift) + m - cum;
-                    need = R < RANS_L ? 1u : 0u;
-                }
+                err = (__ballot(err == 1) & gmask) ? 1 : err;
             }
-            // the lanes that renormalise take consecutive 16-bit words in lane order
-            const unsigned long long b = __ballot(need != 0) & gmask;
-            const uint32_t before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-            const uint32_t tot = (uint32_t)__popcll(b);
-            if constexpr (N == 32) {
-                if (need) {
-                    const uint32_t k = wpos + before;
-                    if (k >= wavail) err = 1;
-                    else R = (R << 16) | (uint32_t)((const uint16_t *)ring)[k & 127u];
-                }
-                wpos += tot;
-                if (act && wfill - wpos < 32u) {                      // whole group takes this branch together
-                    ring[((wfill >> 1) + (uint32_t)sub) & 63u] = pre;
-                    wfill += 64;
-                    pre = load_chunk(wfill >> 6);
-                }
-            } else {
-                if (need) {
-                    const uint8_t *w = cp + 2u * before;
-                    if (w + 2 > end) err = 1;
-                    else R = (R << 16) | (uint32_t)w[0] | ((uint32_t)w[1] << 8);
-                }
-                cp += 2u * tot;
+        };
+        if constexpr (N == 32) {
+            switch (__builtin_amdgcn_readfirstlane((int)Fm.form)) {
+            case O1_DENSE: run(std::integral_constant<uint32_t, O1_DENSE>()); break;
+            case O1_BUCKET: run(std::integral_constant<uint32_t, O1_BUCKET>()); break;
+            case O1_LISTS_LDS: run(std::integral_constant<uint32_t, O1_LISTS_LDS>()); break;
+            default: run(std::integral_constant<uint32_t, O1_LISTS_GLOBAL>()); break;
             }
-            err = (__ballot(err == 1) & gmask) ? 1 : err;
-        }
+        } else run(std::integral_constant<uint32_t, O1_LISTS_GLOBAL>());       // sixteen 4-way streams per wavefront: no pool, lists in global scratch
         // order-0 tail: states 0..rem-1 give one more symbol each, without update
         if (live && !err && order == 0 && (uint32_t)sub < rem) {
             const uint32_t m = R & mask;

@@ -237,3 +237,48 @@ def test_dopen_reads_from_where_the_descriptor_stands(L, tmp_path):     # hfile.
     fd = os.open(p2, os.O_RDONLY)                                        # the common case keeps the fast path: descriptor at the start of a regular file
     fp = L.bgzf_dopen(fd, b"r")
     assert read_all(L, fp) == two and L.bgzf_close(fp) == 0
+
+
+@pytest.mark.gpu
+def test_latency_path_runs_on_the_host_codec(L, tmp_path):            # bgzf.c:1004-1239 (ST reader), :2029-2060 (ST writer); SURVEY 8b
+    """random access and unthreaded writing do not pay a device round trip per block: bgzf_seek + a 100-byte read decodes ONE block on the calling thread
+    (the reference: ~0.1 ms; a device job: ~1.5 ms), a writer that never calls bgzf_mt() compresses each block as it is cut (a device job per block: 16 MB/s)
+    and keeps bgzf_tell() exact; the bytes are the same as on the streaming path"""
+    import time
+    plain, _, _ = synth.bam_stream(48 << 20, 0x5EED0001, 0, True)
+    p = str(tmp_path / "w.bam")
+    fp = L.bgzf_open(p.encode(), b"w")                                  # no bgzf_mt(): the synchronous writer
+    t0 = time.perf_counter()
+    tells = []
+    for at in range(0, len(plain), 50_000):
+        piece = plain[at:at + 50_000]
+        assert L.bgzf_write(fp, piece, len(piece)) == len(piece)
+        tells.append(bgzf_capi.tell(fp))
+    assert L.bgzf_close(fp) == 0
+    dt = time.perf_counter() - t0
+    rate = len(plain) / dt / 1e6
+    assert tells == sorted(tells) and tells[-1] >> 16 > 0               # the block address moves while writing (exact bgzf_tell)
+    comp = open(p, "rb").read()
+    assert refutil.Oracle().decompress(comp)[1] == plain
+    assert rate >= 60, rate                                              # 16 MB/s when every block was a device job of its own; ~90 MB/s here
+    # random access: seek to block starts all over the file, read 100 bytes
+    blocks = refutil.split_blocks(comp)
+    uoffs = np.concatenate([[0], np.cumsum([b[2] for b in blocks])])
+    fp = L.bgzf_open(p.encode(), b"r")
+    buf = C.create_string_buffer(100)
+    rng = np.random.default_rng(1)
+    lat = []
+    for k in rng.integers(0, len(blocks) - 1, 300):
+        off = blocks[int(k)][0]
+        t = time.perf_counter()
+        assert L.bgzf_seek(fp, off << 16 | 17, 0) == 0 and L.bgzf_read(fp, buf, 100) == 100
+        lat.append(time.perf_counter() - t)
+        u = int(uoffs[int(k)]) + 17
+        assert buf.raw == plain[u:u + 100]
+    assert L.bgzf_close(fp) == 0
+    med = sorted(lat)[len(lat) // 2] * 1e3
+    print("non-mt writer %.0f MB/s, seek + 100 B read median %.3f ms" % (rate, med))
+    assert med <= 0.5, med                                               # 1.6 ms through a device job; the reference ~0.11 ms
+    # sequential reading across the host-decoded first blocks into device batches gives the same bytes
+    fp = L.bgzf_open(p.encode(), b"r")
+    assert bgzf_capi.read_all(L, fp, 1 << 20) == plain and L.bgzf_close(fp) == 0

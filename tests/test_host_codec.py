@@ -1,0 +1,153 @@
+"""The front-end's HOST block codec (htslib_amd/csrc/bgzf_host_codec.h: the latency path behind bgzf_seek + small reads, writers without bgzf_mt() and
+bgzf_compress(); reference bgzf.c:1004-1239, 2029-2060, 561-683) -- no GPU needed: the header is compiled into a small C harness.
+
+Inflate: bit-exact on the reference's 17 BGZF fixtures (expected bytes from the real reference), on real-reference streams of both flavours and several levels,
+on every block-length edge; on damaged blocks the verdict (0 / -1 / -2) is the oracle's = bgzf_uncompress's.  Deflate: every block decodes with python's zlib,
+the oracle and the real reference to the input; sizes are sane; BGZF framing fields are right."""
+import ctypes as C
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import refutil
+from htslib_amd import synth
+
+
+@pytest.fixture(scope="module")
+def hc(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("hc") / "libhostcodec.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(refutil.ROOT, "htslib_amd", "csrc"),
+                    os.path.join(refutil.ROOT, "tests", "native", "host_codec_c.cpp"), "-o", so], check=True)
+    L = C.CDLL(so)
+    L.hc_block_inflate.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_uint32]
+    L.hc_block_deflate.argtypes = [C.c_char_p, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.c_int]
+    L.hc_crc32.restype = C.c_uint32; L.hc_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]
+    return L
+
+
+def inflate_stream(L, comp):
+    """every block of a BGZF stream -> (bytes, [rc per block])"""
+    out, rcs = [], []
+    for off, clen, isize in refutil.split_blocks(comp):
+        buf = C.create_string_buffer(isize + 8)
+        rc = L.hc_block_inflate(comp[off:off + clen], clen, buf, isize)
+        rcs.append(rc); out.append(buf.raw[:isize] if rc == 0 else b"")
+    return b"".join(out), rcs
+
+
+def deflate_block(L, data, level):
+    dst = C.create_string_buffer(65536 + 64); n = C.c_size_t(65536)
+    rc = L.hc_block_deflate(dst, C.byref(n), data, len(data), level)
+    return rc, dst.raw[:n.value]
+
+
+def test_crc32(hc):
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 7, 8, 9, 63, 64, 65, 4095, 65280, 1 << 20):
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        for k in (0, 1, 3):
+            assert hc.hc_crc32(zlib.crc32(b[:k]), b[k:], len(b) - min(k, len(b))) == zlib.crc32(b), (n, k)
+
+
+def test_reference_fixtures_bit_exact(hc):
+    n = 0
+    for name, comp, plain in refutil.golden_cases():
+        got, rcs = inflate_stream(hc, comp)
+        assert all(r == 0 for r in rcs) and got == plain, name
+        n += 1
+    assert n >= 17
+
+
+@pytest.mark.skipif(not refutil.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("flavour", ["zlib", "libdeflate"])
+def test_streams_written_by_the_real_reference(hc, flavour):
+    plain, _, _ = synth.bam_stream(3 << 20, 0x5EED0001, 0, True)
+    fq = synth.fastq(1 << 20)
+    for data in (plain, fq, bytes(300_000), np.random.default_rng(2).integers(0, 256, 200_000, dtype=np.uint8).tobytes()):
+        for level in (0, 1, 6, 9):
+            comp = refutil.ref_bgzip(["-l", str(level)], data, flavour)
+            got, rcs = inflate_stream(hc, comp)
+            assert all(r == 0 for r in rcs) and got == data, (flavour, level)
+
+
+def test_block_lengths_and_kinds(hc, oracle):
+    rng = np.random.default_rng(11)
+    text = synth.fastq(200_000)
+    for n in [1, 2, 3, 4, 7, 8, 9, 63, 64, 65, 255, 256, 257, 258, 259, 1023, 1024, 1025, 4095, 4096, 4097, 32767, 32768, 32769, 65279, 65280]:
+        for kind in range(3):
+            d = text[:n] if kind == 0 else bytes(n) if kind == 1 else rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+            for level, strategy in ((6, 0), (1, 0), (9, 0), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (0, 0)):
+                b = refutil.raw_block(d, level, strategy)
+                buf = C.create_string_buffer(n + 8)
+                assert hc.hc_block_inflate(b, len(b), buf, n) == 0 and buf.raw[:n] == d, (n, kind, level, strategy)
+    assert hc.hc_block_inflate(synth.BGZF_EOF, 28, C.create_string_buffer(8), 0) == 0
+
+
+def test_verdicts_on_damaged_blocks_are_bgzf_uncompress_s(hc, oracle):
+    data = synth.fastq(120_000)[:60000]
+    good = refutil.raw_block(data)
+    payload = good[18:-8]
+    from tests.test_bgzf_inflate_gpu import fixed_block_with_far_match
+    cases = [good, good[:-8] + bytes([good[-8] ^ 0x40]) + good[-7:], refutil.wrap_payload(payload[:len(payload) // 2], data),
+             refutil.wrap_payload(b"\x07" + payload[1:], data), refutil.wrap_payload(b"\x01\x05\x00\x00\x00hello", b"hello"),
+             refutil.wrap_payload(fixed_block_with_far_match(), b"aaaa"),
+             refutil.wrap_payload(payload, data, isize=len(data) - 1), refutil.wrap_payload(payload, data + b"x", isize=len(data) + 1)]
+    want = [0, -2, -1, -1, -1, -1, -1, -1]                               # the last two: ISIZE lies (the engine's rule, host path included)
+    for b, w in zip(cases, want):
+        isize = struct.unpack("<I", b[-4:])[0]
+        assert hc.hc_block_inflate(b, len(b), C.create_string_buffer(isize + 8), isize) == w
+    for b, w in zip(cases[:6], want[:6]): assert oracle.uncompress_block(b)[0] == w
+    # one flipped bit in each of 1200 blocks: never a crash, always the oracle's verdict, and the bytes when it is 0
+    plain, bg = synth.bam_bgzf(1 << 20, seed=99)
+    blocks = refutil.split_blocks(bg)
+    rng = np.random.default_rng(12345)
+    seen = set()
+    for rep in range(1200):
+        off, clen, isize = blocks[rep % len(blocks)]
+        b = bytearray(bg[off:off + clen])
+        pos = int(rng.integers(18, clen - 4))
+        b[pos] ^= 1 << int(rng.integers(0, 8))
+        b = bytes(b)
+        rc, d = oracle.uncompress_block(b)
+        buf = C.create_string_buffer(isize + 8)
+        got = hc.hc_block_inflate(b, clen, buf, isize)
+        assert got == rc, (rep, pos)
+        if rc == 0: assert buf.raw[:isize] == d
+        seen.add(rc)
+    assert seen == {0, -1, -2} or seen == {-1, -2}
+
+
+def test_deflate_blocks_decode_everywhere(hc, oracle):
+    rng = np.random.default_rng(3)
+    plain, _, _ = synth.bam_stream(1 << 20, 0x5EED0001, 0, True)
+    fq = synth.fastq(300_000)
+    total_in = total_out = 0
+    stream = b""
+    for data in (plain, fq, bytes(200_000), rng.integers(0, 256, 100_000, dtype=np.uint8).tobytes(), b"a", b"ab" * 40000, bytes(range(256)) * 255):
+        for level in (0, 1, 5, 9, -1):
+            for at in range(0, len(data), 0xff00):
+                d = data[at:at + 0xff00]
+                rc, blk = deflate_block(hc, d, level)
+                assert rc == 0 and len(blk) <= 65536
+                bs = struct.unpack_from("<H", blk, 16)[0] + 1
+                assert bs == len(blk) and blk[:16] == synth.BGZF_EOF[:16]
+                assert struct.unpack("<II", blk[-8:]) == (zlib.crc32(d), len(d))
+                assert zlib.decompress(blk[18:-8], -15) == d
+                assert oracle.uncompress_block(blk) == (0, d)
+                buf = C.create_string_buffer(len(d) + 8)
+                assert hc.hc_block_inflate(blk, len(blk), buf, len(d)) == 0 and buf.raw[:len(d)] == d
+                if level == 5 and data is plain: total_in += len(d); total_out += len(blk); stream += blk
+                if level == 0: assert len(blk) == len(d) + 5 + 26
+    assert total_out < 0.30 * total_in, (total_in, total_out)                     # BAM at the default setting: zlib -6 makes ~0.18 of it, zlib -1 ~0.23
+    rc, eof = deflate_block(hc, b"", 6)
+    assert rc == 0 and eof == synth.BGZF_EOF
+    if refutil.have_ref():                                                         # the real reference reads a file made of these blocks
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".gz") as f:
+            f.write(stream + synth.BGZF_EOF); f.flush()
+            r = subprocess.run([os.path.join(refutil.REF_DIR, "ref_bgzip_ld"), "-d", "-c", f.name], capture_output=True)
+            assert r.returncode == 0 and r.stdout == plain[:len(r.stdout)] and len(r.stdout) == total_in
