@@ -230,13 +230,13 @@ def test_dopen_reads_from_where_the_descriptor_stands(L, tmp_path):     # hfile.
         assert fp
         if want is None:
             assert fp.contents.is_compressed == 0                        # offset 0 holds the text prefix: read through as plain bytes
-            assert read_all(L, fp, 1 << 20)[:len(prefix)] == prefix
+            assert bgzf_capi.read_all(L, fp, 1 << 20)[:len(prefix)] == prefix
         else:
-            assert read_all(L, fp) == want, start
+            assert bgzf_capi.read_all(L, fp) == want, start
         assert L.bgzf_close(fp) == 0
     fd = os.open(p2, os.O_RDONLY)                                        # the common case keeps the fast path: descriptor at the start of a regular file
     fp = L.bgzf_dopen(fd, b"r")
-    assert read_all(L, fp) == two and L.bgzf_close(fp) == 0
+    assert bgzf_capi.read_all(L, fp) == two and L.bgzf_close(fp) == 0
 
 
 @pytest.mark.gpu
