@@ -78,10 +78,19 @@ void arith_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
             Decoder D;
             D.start(cp + 1, d.in_len - 1, lane);
             uint32_t last = 0, keep = 0;
+            // every model goes through the lean step of arith_dev.h (the symbol is nearly always among a model's first 64 entries)
+            auto loops = [&](auto small_lit) {
+            (void)small_lit;
+            auto lit_sym = [&](uint32_t ctx) -> uint32_t {
+                return D.template symbol_lean<LM>(Q.M, Q.TT, Q.lit(ctx), Q.m, Q.lit_tot(ctx), lane);
+            };
+            auto run_sym = [&](uint32_t rctx) -> uint32_t {
+                return D.template symbol_lean<LM>(Q.M, Q.TT, Q.run(rctx), 4, Q.run_tot(rctx), lane);
+            };
             if (!rle) {
                 for (uint32_t i = 0; i < n; i++) {
                     const uint32_t ctx = order ? last : 0u;
-                    const uint32_t c = D.symbol(Q.M, Q.TT, Q.lit(ctx), Q.m, Q.lit_tot(ctx), lane);
+                    const uint32_t c = lit_sym(ctx);
                     if (D.err) break;
                     last = c;
                     if ((uint32_t)lane == (i & 63u)) keep = c;
@@ -91,12 +100,12 @@ void arith_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
             } else {
                 for (uint32_t i = 0; i < n;) {
                     const uint32_t ctx = order ? last : 0u;
-                    const uint32_t c = D.symbol(Q.M, Q.TT, Q.lit(ctx), Q.m, Q.lit_tot(ctx), lane);
+                    const uint32_t c = lit_sym(ctx);
                     if (D.err) break;
                     last = c;
                     unsigned long long r = 0; uint32_t rctx = c, part;
                     do {
-                        part = D.symbol(Q.M, Q.TT, Q.run(rctx), 4, Q.run_tot(rctx), lane);
+                        part = run_sym(rctx);
                         if (D.err) break;
                         rctx = rctx == c ? 256u : 257u;
                         r += part;
@@ -108,6 +117,8 @@ void arith_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
                     i += (uint32_t)r + 1u;
                 }
             }
+            };
+            if (LM && Q.m <= 64u) loops(std::true_type{}); else loops(std::false_type{});
             if (D.err || D.in.overrun) err = 1;
 #ifdef HG_ARITH_PROFILE
             if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -185,18 +196,26 @@ void arith_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
             Encoder E;
             E.start(o + 1);
             uint32_t last = 0;
+            auto loops = [&](auto small_lit) {
+            (void)small_lit;
+            auto lit_sym = [&](uint32_t ctx, uint32_t c) {
+                E.template symbol_lean<LM>(Q.M, Q.TT, Q.lit(ctx), Q.m, Q.lit_tot(ctx), c, lane);
+            };
+            auto run_sym = [&](uint32_t rctx, uint32_t part) {
+                E.template symbol_lean<LM>(Q.M, Q.TT, Q.run(rctx), 4, Q.run_tot(rctx), part, lane);
+            };
             if (!rle) {
                 uint32_t win = 0;
                 for (uint32_t i = 0; i < n; i++) {
                     if ((i & 63u) == 0) { const uint32_t p = i + (uint32_t)lane; win = p < n ? src[p] : 0u; }
                     const uint32_t c = rl(win, i & 63u), ctx = order ? last : 0u;
-                    E.symbol(Q.M, Q.TT, Q.lit(ctx), Q.m, Q.lit_tot(ctx), c, lane);
+                    lit_sym(ctx, c);
                     last = c;
                 }
             } else {
                 for (uint32_t i = 0; i < n;) {
                     const uint32_t c = src[i], ctx = order ? last : 0u;
-                    E.symbol(Q.M, Q.TT, Q.lit(ctx), Q.m, Q.lit_tot(ctx), c, lane);
+                    lit_sym(ctx, c);
                     last = c;
                     uint32_t r = 0;                                  // how many more copies of c follow
                     for (;;) {
@@ -209,12 +228,14 @@ void arith_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
                     uint32_t rctx = c, part;
                     do {
                         part = r < 3u ? r : 3u;
-                        E.symbol(Q.M, Q.TT, Q.run(rctx), 4, Q.run_tot(rctx), part, lane);
+                        run_sym(rctx, part);
                         rctx = rctx == c ? 256u : 257u;
                         r -= part;
                     } while (part == 3u);
                 }
             }
+            };
+            if (LM && Q.m <= 64u) loops(std::true_type{}); else loops(std::false_type{});
             total = 1u + E.finish(lane);
             };
             if (model_words(mx + 1u, order, rle) <= (uint32_t)POOLW) body(std::true_type{}); else body(std::false_type{});
@@ -249,3 +270,36 @@ int launch_arith_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
 }  // namespace hg
+
+// ---- self-check of the short divisions of arith_dev.h against the hardware's exact expansion, on the device (tests/test_arith.py): n random pairs per
+// lane in the ranges the coder produces plus the corners; returns the number of disagreements
+namespace hga {
+__global__ void udiv_check_kernel(unsigned long long seed, uint32_t rounds, unsigned long long *bad) {
+    unsigned long long x = seed + 0x9e3779b97f4a7c15ull * (blockIdx.x * blockDim.x + threadIdx.x + 1);
+    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    unsigned long long miss = 0;
+    for (uint32_t i = 0; i < rounds; i++) {
+        const unsigned long long r = next();
+        const uint32_t tot = 2u + (uint32_t)(r % 65518u);                       // a model's total: 2 .. 65519
+        uint32_t range = (uint32_t)(r >> 20) | (1u << 24);                       // >= 2^24 after renormalisation
+        if ((i & 15u) == 0) range = 0xffffffffu;
+        if ((i & 15u) == 1) range = 1u << 24;
+        if (udiv_small_divisor(range, tot) != range / tot) miss++;
+        const uint32_t rr = range / tot;
+        const uint32_t code = (uint32_t)(next() % ((unsigned long long)range + ((i & 7u) == 0 ? 1u : 0u)));   // < range (sometimes == range at the start)
+        if (udiv_small_quotient(code, rr) != code / rr) miss++;
+        const uint32_t code2 = (i & 3u) == 0 ? range - 1u : code;               // the largest quotients
+        if (udiv_small_quotient(code2, rr) != code2 / rr) miss++;
+    }
+    if (miss) atomicAdd(bad, miss);
+}
+}  // namespace hga
+extern "C" long hg_debug_udiv_check(hg_ctx *ctx, unsigned long long seed, uint32_t rounds) {
+    if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return -1;
+    unsigned long long *d = nullptr, h = 0;
+    if (hipMalloc(&d, 8) != hipSuccess || hipMemset(d, 0, 8) != hipSuccess) return -1;
+    hipLaunchKernelGGL(hga::udiv_check_kernel, dim3(1024), dim3(256), 0, ctx->stream, seed, rounds, d);
+    const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess && hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    return ok ? (long)h : -1;
+}

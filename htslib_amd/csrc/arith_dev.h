@@ -28,6 +28,24 @@ enum { F_ORDER = 1, F_RLE = 64 };
 
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 
+// The two divisions of a coder step (range / total, code / r) sit on every symbol's chain, and the compiler's 32-bit division is ~22 instructions.
+// Both have structure: (1) a quotient below 2^17 -- one single-precision estimate is within 1 of it, one correction either way;
+__device__ __forceinline__ uint32_t udiv_small_quotient(uint32_t a, uint32_t b) {
+    uint32_t q = (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)b));
+    const uint32_t rem = a - q * b;                                  // (mod 2^32) -b <= rem < 2b
+    if ((int32_t)rem < 0) q--; else if (rem >= b) q++;
+    return q;
+}
+// (2) a divisor below 2^16 (a model's total): an estimate scaled to stay BELOW the quotient, the remainder's own estimate on top, one correction.
+__device__ __forceinline__ uint32_t udiv_small_divisor(uint32_t a, uint32_t b) {
+    const float rb = __builtin_amdgcn_rcpf((float)b) * 0.9999995f;
+    const uint32_t q1 = (uint32_t)((float)a * rb);                  // <= a / b, short by a relative 2^-20 at most
+    const uint32_t r1 = a - q1 * b;                                  // < 2^12 * b < 2^28
+    uint32_t q = q1 + (uint32_t)((float)r1 * rb);
+    if (a - q * b >= b) q++;
+    return q;
+}
+
 // 64-byte window over the compressed stream: lane l holds byte pos0 + l
 struct ByteWindow {
     const uint8_t *base; uint32_t len, pos0, idx, win; bool overrun;
@@ -43,6 +61,8 @@ struct ByteWindow {
 // After the coder step: bump entry x of the model at B (n entries, total at T), halve when due, keep sorted.
 // f_x / f_prev are the frequencies of entries x and x-1 as read before the bump.
 // e_prev = entry x - 1 as the symbol search saw it (HAVE_PREV) -- it came in the same 64-entry read, so the update needs no load.
+// LDSM: the model is in LDS, which serves a wavefront's accesses in order -- the next symbol's read sees these writes without a fence.
+template <bool LDSM = false>
 __device__ __forceinline__ void model_update(uint32_t *M, uint32_t *TT, uint32_t B, uint32_t n, uint32_t T, uint32_t tot, uint32_t x,
                                              uint32_t e_x, bool have_prev, uint32_t e_prev, int lane) {
     uint32_t ex = e_x + (STEP << 8);
@@ -68,7 +88,7 @@ __device__ __forceinline__ void model_update(uint32_t *M, uint32_t *TT, uint32_t
         else if (lane == 0) M[B + x] = ex;
     } else if (lane == 0) M[B + x] = ex;
     if (lane == 0) TT[T] = tot;
-    wave_sync();
+    if (!LDSM) wave_sync();
 }
 
 struct Decoder {
@@ -83,7 +103,38 @@ struct Decoder {
         in.init(b, n, lane); err = 0; code = 0; range = 0xffffffffu;
         for (int i = 0; i < 5; i++) code = (code << 8) | in.next(lane);
     }
-    // decodes one symbol with the model at B (n entries, total at T)
+    // The LEAN step: models are kept sorted by frequency, so the symbol nearly always sits among the first 64 entries -- ONE 64-lane read of those, the two
+    // short divisions above, one scan + ballot, and an update in which the (one or two) lanes whose entry changes write their own word.  ~70 instructions
+    // per symbol against ~250 of the general routine below, which takes over when the symbol lies beyond entry 63 of a larger model (it starts again
+    // from the untouched coder state) and for the halving of a model.  LDSM: the model is in LDS (no fence needed between the update and the next read).
+    template <bool LDSM>
+    __device__ __forceinline__ uint32_t symbol_lean(uint32_t *M, uint32_t *TT, uint32_t B, uint32_t n, uint32_t T, int lane) {
+        const uint32_t e = (uint32_t)lane < n ? M[B + (uint32_t)lane] : 0u;
+        uint32_t tot = hg::uni(TT[T]);
+        const uint32_t r = udiv_small_divisor(range, tot), freq = udiv_small_quotient(code, r);
+        if (freq >= tot) { err = 1; return 0; }
+        const uint32_t incl = wave_incl_scan_dpp(e >> 8);            // lanes >= n carry the total: with n <= 64 the first lane above freq is inside the model
+        const unsigned long long hit = __ballot(incl > freq);
+        if (n > 64u && !hit) return symbol<LDSM>(M, TT, B, n, T, lane);
+        const uint32_t l = (uint32_t)__builtin_ctzll(hit);
+        const uint32_t ex = rl(e, l), f = ex >> 8;
+        code -= (rl(incl, l) - f) * r; range = r * f;
+        while (range < TOP) { code = (code << 8) | in.next(lane); range <<= 8; }
+        tot += STEP;
+        if (tot > MAX_FREQ) {                                          // halve every frequency (rare): the general routine
+            model_update<LDSM>(M, TT, B, n, T, tot - STEP, l, ex, false, 0u, lane);
+            return ex & 0xffu;
+        }
+        const uint32_t nex = ex + (STEP << 8), ep = l ? rl(e, l - 1u) : 0xffffffffu;
+        const bool swap = (nex >> 8) > (ep >> 8);                     // keep the list sorted by frequency: at most one step towards the front
+        if ((uint32_t)lane == l) M[B + l] = swap ? ep : nex;
+        if (swap && (uint32_t)lane + 1u == l) M[B + l - 1u] = nex;
+        if (lane == 0) TT[T] = tot;
+        if (!LDSM) wave_sync();
+        return ex & 0xffu;
+    }
+    // decodes one symbol with the model at B (n entries, total at T): the general routine (any n <= 256, the symbol anywhere in the list)
+    template <bool LDSM = false>
     __device__ uint32_t symbol(uint32_t *M, uint32_t *TT, uint32_t B, uint32_t n, uint32_t T, int lane) {
         HA_T(5);
         // all (<= 4) 64-entry pieces of the model are requested at once, together with the total: the search below then runs
@@ -93,7 +144,7 @@ struct Decoder {
         for (uint32_t c = 0; c < 4; c++) { const uint32_t i = c * 64u + (uint32_t)lane; ev[c] = (c * 64u < n && i < n) ? M[B + i] : 0u; }
         const uint32_t tot = TT[T];
         HA_T(0);
-        const uint32_t r = range / tot, freq = code / r;
+        const uint32_t r = udiv_small_divisor(range, tot), freq = udiv_small_quotient(code, r);
         if (freq >= tot) { err = 1; return 0; }
         HA_T(1);
         uint32_t acc0 = 0, x = 0, ex = 0, acc = 0, eprev = 0;
@@ -118,7 +169,7 @@ struct Decoder {
         code -= acc * r; range = r * f;
         while (range < TOP) { code = (code << 8) | in.next(lane); range <<= 8; }
         HA_T(3);
-        model_update(M, TT, B, n, T, tot, x, ex, have_prev, eprev, lane);
+        model_update<LDSM>(M, TT, B, n, T, tot, x, ex, have_prev, eprev, lane);
         HA_T(4);
         return ex & 0xffu;
     }
@@ -142,7 +193,7 @@ struct Encoder {
     }
     __device__ void encode(uint32_t cum, uint32_t freq, uint32_t tot, int lane) {
         const uint32_t old = low;
-        range /= tot;
+        range = udiv_small_divisor(range, tot);                        // tot <= MAX_FREQ < 2^16
         low += cum * range;
         range *= freq;
         if (low < old) carry = 1;
@@ -153,7 +204,36 @@ struct Encoder {
         if ((uint32_t)lane < oidx) out[opos + (uint32_t)lane] = (uint8_t)obuf;
         return opos + oidx;
     }
+    // the encoder's twin of Decoder::symbol_lean: the symbol is looked for among the first 64 entries; beyond them (larger models only) the general routine
+    template <bool LDSM>
+    __device__ __forceinline__ void symbol_lean(uint32_t *M, uint32_t *TT, uint32_t B, uint32_t n, uint32_t T, uint32_t sym, int lane) {
+        const bool mine = (uint32_t)lane < n;
+        const uint32_t e = mine ? M[B + (uint32_t)lane] : 0u;
+        uint32_t tot = hg::uni(TT[T]);
+        const unsigned long long hit = __ballot(mine && (e & 0xffu) == sym);
+        if (!hit) { symbol<LDSM>(M, TT, B, n, T, sym, lane); return; }    // (n > 64: the symbol lies further back)
+        const uint32_t incl = wave_incl_scan_dpp(e >> 8);
+        const uint32_t l = (uint32_t)__builtin_ctzll(hit);
+        const uint32_t ex = rl(e, l), f = ex >> 8;
+        {                                                                  // encode(cum, f, tot)
+            const uint32_t old = low;
+            range = udiv_small_divisor(range, tot);
+            low += (rl(incl, l) - f) * range;
+            range *= f;
+            if (low < old) carry = 1;
+            while (range < TOP) { range <<= 8; shift_low(lane); }
+        }
+        tot += STEP;
+        if (tot > MAX_FREQ) { model_update<LDSM>(M, TT, B, n, T, tot - STEP, l, ex, false, 0u, lane); return; }
+        const uint32_t nex = ex + (STEP << 8), ep = l ? rl(e, l - 1u) : 0xffffffffu;
+        const bool swap = (nex >> 8) > (ep >> 8);
+        if ((uint32_t)lane == l) M[B + l] = swap ? ep : nex;
+        if (swap && (uint32_t)lane + 1u == l) M[B + l - 1u] = nex;
+        if (lane == 0) TT[T] = tot;
+        if (!LDSM) wave_sync();
+    }
     // codes `sym` with the model at B (n entries, total at T)
+    template <bool LDSM = false>
     __device__ void symbol(uint32_t *M, uint32_t *TT, uint32_t B, uint32_t n, uint32_t T, uint32_t sym, int lane) {
         uint32_t ev[4];                                                    // the whole model at once (see the decoder)
 #pragma unroll
@@ -177,7 +257,7 @@ struct Encoder {
             acc0 = rl(incl, 63);
         }
         encode(acc, ex >> 8, tot, lane);
-        model_update(M, TT, B, n, T, tot, x, ex, have_prev, eprev, lane);
+        model_update<LDSM>(M, TT, B, n, T, tot, x, ex, have_prev, eprev, lane);
     }
 };
 

@@ -18,7 +18,8 @@
 //   * output bytes are gathered 64 per store; a record that is reversed or a duplicate of its predecessor is fixed up in
 //     place when it ends (reversal is an involution, so "copy the predecessor as decoded, reverse at the very end" of the
 //     oracle becomes "copy straight or mirrored, depending on whether the two reverse flags agree").
-// Streams with more than HGQ_MAX_PARAM parameter sets report HG_BLOCK_EUNSUPPORTED (the caller keeps its CPU codec).
+// Any number of parameter sets (the format allows 256; htscodecs writes one or two): the wavefront's LDS holds TWO at a time, the sets of a stream beyond
+// the first two wait in a global overflow image and replace the less recently used slot when a record selects them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -35,11 +36,11 @@ using hga::rl;
 
 enum { GF_MULTI = 1, GF_STAB = 2, GF_REV = 4, PF_DEDUP = 2, PF_LEN = 4, PF_SEL = 8, PF_QMAP = 16, PF_PTAB = 32, PF_DTAB = 64, PF_QTAB = 128 };
 constexpr uint32_t FQZ_VERS = 5, CTX_SIZE = 65536;
-constexpr int HGQ_MAX_PARAM = 2;
+constexpr int HGQ_MAX_PARAM = 2;                                  // parameter sets resident in LDS (slots); a stream may have up to 256
 
 // ---- the per-stream image the host builds (32-bit words) ------------------------------------------------------------
 // head: [0] gflags [1] nparam [2] max_sel [3] ns = max_sym + 1 [4] offset of the range-coder bytes in the stream [5] ulen
-//       [6] (encoder) number of records [7] reserved; then stab (256 bytes = 64 words); then per parameter set:
+//       [6] (encoder) number of records / (decoder) word offset of parameter set 2 in the overflow image [7] (encoder) have flags; then stab (256 bytes = 64 words); then per parameter set:
 //       8 words {context, pflags, qmask, qshift, qloc, sloc, ploc, dloc}, qmap (256 bytes), qtab / dtab (256 x u16 each), ptab (1024 x u16)
 constexpr uint32_t IMG_HEAD = 8, IMG_STAB = 64, IMG_PSCAL = 8, IMG_QMAP = 64, IMG_QTAB = 128, IMG_DTAB = 128, IMG_PTAB = 512;
 constexpr uint32_t IMG_PARAM = IMG_PSCAL + IMG_QMAP + IMG_QTAB + IMG_DTAB + IMG_PTAB;          // 840 words
@@ -76,8 +77,9 @@ static int read_array_h(const uint8_t *in, size_t in_size, uint16_t *array, int 
 }
 
 // 0 ok, -1 malformed, -3 more parameter sets than the kernel keeps in LDS
-static int build_image(const uint8_t *in, uint32_t n, uint32_t want_ulen, uint32_t *img) {
+static int build_image(const uint8_t *in, uint32_t n, uint32_t want_ulen, uint32_t *img, std::vector<uint32_t> &overflow) {
     memset(img, 0, IMG_WORDS * 4);
+    const size_t over0 = overflow.size();
     uint32_t ulen = 0, k = 0; uint8_t c;
     do { if (k >= n || k >= 5) return -1; c = in[k++]; ulen = (ulen << 7) | (c & 0x7fu); } while (c & 0x80u);
     if (ulen != want_ulen) return -1;
@@ -98,10 +100,10 @@ static int build_image(const uint8_t *in, uint32_t n, uint32_t want_ulen, uint32
     } else {
         for (uint32_t i = 0; i < 256; i++) stab[i] = (uint8_t)(i < nparam ? i : nparam - 1);
     }
-    if (nparam > (uint32_t)HGQ_MAX_PARAM) return -3;
+    if (nparam > (uint32_t)HGQ_MAX_PARAM) overflow.resize(over0 + (size_t)(nparam - HGQ_MAX_PARAM) * IMG_PARAM, 0u);
     uint32_t max_sym = 0;
     for (uint32_t s = 0; s < nparam; s++) {
-        uint32_t *P = img + IMG_HEAD + IMG_STAB + s * IMG_PARAM;
+        uint32_t *P = s < (uint32_t)HGQ_MAX_PARAM ? img + IMG_HEAD + IMG_STAB + s * IMG_PARAM : overflow.data() + over0 + (size_t)(s - HGQ_MAX_PARAM) * IMG_PARAM;
         if (p + 7 > n) return -1;
         const uint32_t pflags = in[p + 2], msym = in[p + 3];
         P[0] = in[p] | (uint32_t)in[p + 1] << 8; P[1] = pflags;
@@ -118,7 +120,8 @@ static int build_image(const uint8_t *in, uint32_t n, uint32_t want_ulen, uint32
         if (msym > max_sym) max_sym = msym;
     }
     if (p > n) return -1;
-    img[0] = gflags; img[1] = nparam; img[2] = max_sel; img[3] = max_sym + 1u; img[4] = (uint32_t)p; img[5] = ulen;
+    img[0] = gflags; img[1] = nparam; img[2] = max_sel; img[3] = max_sym + 1u; img[4] = (uint32_t)p; img[5] = ulen; img[6] = (uint32_t)over0;
+    if (overflow.size() > 0xffffffffull) return -1;
     return 0;
 }
 
@@ -244,6 +247,23 @@ __device__ __forceinline__ void load_param(ParamRegs &R, const uint32_t *img, ui
     R.context = P[0]; R.pflags = P[1]; R.qmask = P[2]; R.qshift = P[3]; R.qloc = P[4]; R.sloc = P[5]; R.ploc = P[6]; R.dloc = P[7];
     R.base = P;
 }
+// Parameter set x of the stream in one of the two LDS slots: c0 / c1 = the sets they hold, victim = the slot replaced next.  gimg = the stream's base
+// image in global memory (sets 0, 1), over = its further sets.  Wave-uniform throughout.
+__device__ __forceinline__ void select_param(ParamRegs &R, uint32_t *img, const uint32_t *gimg, const uint32_t *over, uint32_t x, uint32_t &c0, uint32_t &c1,
+                                             uint32_t &victim, int lane) {
+    uint32_t slot;
+    if (x == c0) slot = 0; else if (x == c1) slot = 1;
+    else {
+        slot = victim; victim ^= 1u;
+        const uint32_t *src = x < (uint32_t)HGQ_MAX_PARAM ? gimg + IMG_HEAD + IMG_STAB + x * IMG_PARAM : over + (size_t)(x - HGQ_MAX_PARAM) * IMG_PARAM;
+        uint32_t *dst = img + IMG_HEAD + IMG_STAB + slot * IMG_PARAM;
+        hg::wave_sync();
+        for (uint32_t i = (uint32_t)lane; i < IMG_PARAM; i += 64) dst[i] = src[i];
+        hg::wave_sync();
+        if (slot) c1 = x; else c0 = x;
+    }
+    load_param(R, img, slot);
+}
 struct State { uint32_t qctx, p, delta, prevq, s; };
 __device__ __forceinline__ uint32_t update_ctx(const ParamRegs &R, State &st, uint32_t q) {
     const uint16_t *qtab = (const uint16_t *)(R.base + IMG_PSCAL + IMG_QMAP), *dtab = qtab + 256, *ptab = dtab + 256;
@@ -264,7 +284,7 @@ __device__ __forceinline__ void lds_model_init(uint32_t *m, uint32_t n, int lane
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64)
 void fqz_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc, const uint32_t *__restrict__ images,
-                       uint32_t nstreams, uint8_t *out, int32_t *status, uint32_t *gscratch, unsigned long long slot_words) {
+                       const uint32_t *__restrict__ overflow, uint32_t nstreams, uint8_t *out, int32_t *status, uint32_t *gscratch, unsigned long long slot_words) {
     __shared__ uint32_t pool[WAVES][POOLW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t slot = blockIdx.x * WAVES + wv;
@@ -276,6 +296,8 @@ void fqz_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__r
         wave_sync();
         const uint32_t gflags = img[0], max_sel = img[2], ns = img[3], data_off = img[4], ulen = img[5];
         const uint8_t *stab = (const uint8_t *)(img + IMG_HEAD);
+        const uint32_t *gimg = images + (size_t)d.scratch_off * IMG_WORDS, *over = overflow + img[6];
+        uint32_t pc0 = 0, pc1 = 1, pvictim = 0;
         uint8_t *o = out + d.out_off;
         // models
         {
@@ -298,7 +320,7 @@ void fqz_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__r
         uint32_t i = 0, last = 0, last_len = 0, keep = 0, prev_rev = 0;
         bool first_len = true;
         int err = 0;
-        auto lsym = [&](uint32_t base, uint32_t n) { return D.symbol(mdl, mdl, base + 1u, n, base, lane); };
+        auto lsym = [&](uint32_t base, uint32_t n) { return D.template symbol_lean<true>(mdl, mdl, base + 1u, n, base, lane); };
         auto flush_tail = [&]() { if ((uint32_t)lane < (i & 63u)) o[(i & ~63u) + (uint32_t)lane] = (uint8_t)keep; wave_sync(); };
         auto reload_tail = [&]() { wave_sync(); if ((uint32_t)lane < (i & 63u)) keep = o[(i & ~63u) + (uint32_t)lane]; };
         uint32_t rec_start = 0, rec_len = 0, rec_rev = 0;
@@ -307,7 +329,7 @@ void fqz_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__r
                 uint32_t s = 0;
                 if (max_sel > 0) { s = lsym(M_SEL, max_sel + 1u); if (D.err) break; }
                 st.s = s;
-                load_param(R, img, stab[s]);
+                select_param(R, img, gimg, over, stab[s], pc0, pc1, pvictim, lane);
                 uint32_t len;
                 if (!(R.pflags & PF_LEN) || first_len) {
                     len = lsym(M_LEN, 256);
@@ -340,7 +362,7 @@ void fqz_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__r
                 last = R.context;
             }
             const size_t mb = (size_t)last * (ns + 1u);
-            const uint32_t Q = D.symbol(gq + mb, gq + mb, 1u, ns, 0u, lane);
+            const uint32_t Q = D.template symbol_lean<false>(gq + mb, gq + mb, 1u, ns, 0u, lane);
             if (D.err) break;
             const uint32_t q = ((const uint8_t *)(R.base + IMG_PSCAL))[Q];
             last = update_ctx(R, st, Q);
@@ -401,7 +423,7 @@ void fqz_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__r
         }
         hga::Encoder E;
         E.start(out + d.out_off);
-        auto lsym = [&](uint32_t base, uint32_t n, uint32_t sym) { E.symbol(mdl, mdl, base + 1u, n, base, sym, lane); };
+        auto lsym = [&](uint32_t base, uint32_t n, uint32_t sym) { E.template symbol_lean<true>(mdl, mdl, base + 1u, n, base, sym, lane); };
         ParamRegs R; load_param(R, img, 0);
         State st = {0, 0, 0, 0, 0};
         bool first_len = true;
@@ -438,7 +460,7 @@ void fqz_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__r
                 if ((j & 63u) == 0) { const uint32_t jj = j + (uint32_t)lane; win = jj < len ? src[rv ? at + len - 1u - jj : at + jj] : 0u; }
                 const uint32_t q = inv[rl(win, j & 63u)];
                 const size_t mb = (size_t)last * (ns + 1u);
-                E.symbol(gq + mb, gq + mb, 1u, ns, 0u, q, lane);
+                E.template symbol_lean<false>(gq + mb, gq + mb, 1u, ns, 0u, q, lane);
                 last = update_ctx(R, st, q);
             }
             at += len; prev_len = len; prev_rev = rv;
@@ -452,13 +474,13 @@ void fqz_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__r
 
 namespace hg {
 // images: one IMG_WORDS image per stream (desc[k].scratch_off = its index); d_scratch: gridDim * WAVES slots of slot_words words
-int launch_fqz_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_images, size_t n, void *d_out,
+int launch_fqz_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_images, const uint32_t *d_overflow, size_t n, void *d_out,
                       int32_t *d_status, uint32_t *d_scratch, size_t slots, size_t slot_words, hipStream_t s) {
     (void)ctx;
     if (!n) return HG_OK;
     constexpr int WAVES = 2;
     const size_t wgs = (slots + WAVES - 1) / WAVES;
-    hipLaunchKernelGGL((hgq::fqz_decode_kernel<WAVES>), dim3((unsigned)wgs), dim3(WAVES * 64), 0, s, (const uint8_t *)d_in, d_desc, d_images,
+    hipLaunchKernelGGL((hgq::fqz_decode_kernel<WAVES>), dim3((unsigned)wgs), dim3(WAVES * 64), 0, s, (const uint8_t *)d_in, d_desc, d_images, d_overflow,
                        (uint32_t)n, (uint8_t *)d_out, d_status, d_scratch, (unsigned long long)slot_words);
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
@@ -495,14 +517,16 @@ extern "C" int hg_fqz_decode_host(hg_ctx *ctx, const uint8_t *const *in, const u
     if (n == 0) return HG_OK;
     hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     std::vector<uint32_t> images; images.reserve(n * hgq::IMG_WORDS);
+    std::vector<uint32_t> overflow(1, 0u);                            // parameter sets beyond the two that fit LDS (img[6] = a stream's offset)
     std::vector<size_t> live;                                         // streams that reach the device, longest first
     uint32_t max_ns = 0;
     for (size_t i = 0; i < n; i++) {
         status[i] = 0;
         if (out_len[i] == 0) { continue; }
         uint32_t img[hgq::IMG_WORDS];
-        const int r = hgq::build_image(in[i], in_len[i], out_len[i], img);
-        if (r) { status[i] = r == -3 ? HG_BLOCK_EUNSUPPORTED : -1; continue; }
+        const size_t over0 = overflow.size();
+        const int r = hgq::build_image(in[i], in_len[i], out_len[i], img, overflow);
+        if (r) { overflow.resize(over0); status[i] = r == -3 ? HG_BLOCK_EUNSUPPORTED : -1; continue; }
         images.insert(images.end(), img, img + hgq::IMG_WORDS);
         live.push_back(i);
         max_ns = std::max(max_ns, img[3]);
@@ -528,12 +552,15 @@ extern "C" int hg_fqz_decode_host(hg_ctx *ctx, const uint8_t *const *in, const u
         if ((rc = hg::fqz_slots(ctx, m, slot_words, &slots))) return rc;
         if ((rc = hg::ensure_scratch(ctx, 0, ioff + 64)) || (rc = hg::ensure_scratch(ctx, 1, ooff + 64)) ||
             (rc = hg::ensure_scratch(ctx, 2, m * sizeof(hg_stream_desc))) || (rc = hg::ensure_scratch(ctx, 3, m * 4 + 64)) ||
-            (rc = hg::ensure_scratch(ctx, 4, images.size() * 4 + 64)) || (rc = hg::ensure_scratch(ctx, 6, slots * slot_words * 4 + 64))) return rc;
+            (rc = hg::ensure_scratch(ctx, 4, images.size() * 4 + 64)) || (rc = hg::ensure_scratch(ctx, 5, overflow.size() * 4 + 64)) ||
+            (rc = hg::ensure_scratch(ctx, 6, slots * slot_words * 4 + 64))) return rc;
         hipStream_t s = ctx->stream;
         bool ok = hg::stage_upload(ctx, sp.data(), sl.data(), so.data(), nullptr, m, ioff, (uint8_t *)ctx->d_scratch[0], s) == HG_OK;
         ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc.data(), m * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess &&
-             hipMemcpyAsync(ctx->d_scratch[4], images.data(), images.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess;
-        rc = ok ? hg::launch_fqz_decode(ctx, ctx->d_scratch[0], (const hg_stream_desc *)ctx->d_scratch[2], (const uint32_t *)ctx->d_scratch[4], m,
+             hipMemcpyAsync(ctx->d_scratch[4], images.data(), images.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+             hipMemcpyAsync(ctx->d_scratch[5], overflow.data(), overflow.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess;
+        rc = ok ? hg::launch_fqz_decode(ctx, ctx->d_scratch[0], (const hg_stream_desc *)ctx->d_scratch[2], (const uint32_t *)ctx->d_scratch[4],
+                                        (const uint32_t *)ctx->d_scratch[5], m,
                                         ctx->d_scratch[1], (int32_t *)ctx->d_scratch[3], (uint32_t *)ctx->d_scratch[6], slots, slot_words, s)
                 : HG_ELAUNCH;
         if (rc == HG_OK) {

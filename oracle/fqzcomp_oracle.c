@@ -287,7 +287,9 @@ static const int PRESET[4][10] = {
     {12, 6, 0, 0, 0, 0, 0, 12, 0, 0},
 };
 /* opts: bit 0 = use the READ2 flag of each record as the selector (two parameter sets), bit 1 = honour the reverse flags,
- * bit 2 = allow duplicate detection, bit 3 = force a selector table, bit 4 = never use a quality map.
+ * bit 2 = allow duplicate detection, bit 3 = force a selector table, bit 4 = never use a quality map; bits 5-7 = with bit 0: 2 + that many EXTRA
+ * parameter sets, record r using set (READ2 flag + 2 * (r mod ...)) -- no htscodecs strategy writes more than two, but the format allows 256 and a
+ * decoder must take them (the decoder tests need such streams); every extra set gets another preset and context seed so that they really differ.
  * rflags[i]: the record's BAM flags as in fqz_slice.flags (cram_io.c:1815): 16 = reverse strand, 128 = second read; NULL = none.
  * Returns the stream length or 0 on error. */
 #define FQZ_FREVERSE 16u
@@ -323,14 +325,15 @@ ORC_EXPORT size_t orc_fqz_encode(const uint8_t *in_, size_t n, const uint32_t *l
     }
     const int do_sel = (opts & 1) && rflags, do_dedup = (opts & 4) && dups * 10 >= nrec && nrec > 1;
     g->gflags = (do_sel ? GF_MULTI : 0) | (do_rev ? GF_REV : 0) | ((opts & 8) && do_sel ? GF_STAB : 0);
-    g->nparam = do_sel ? 2 : 1;
-    g->max_sel = do_sel ? 1 : 0;
+    const uint32_t extra = do_sel ? (uint32_t)(opts >> 5) & 7u : 0u;
+    g->nparam = do_sel ? 2 + extra : 1;
+    g->max_sel = do_sel ? g->nparam - 1 : 0;
     for (uint32_t i = 0; i < 256; i++) g->stab[i] = i < g->nparam ? i : g->nparam - 1;
-    const int *P = PRESET[strat];
     uint32_t inv[256] = {0};
     for (uint32_t k = 0; k < g->nparam; k++) {
+        const int *P = PRESET[(strat + (int)(k >> 1)) & 3];
         fqz_param *m = &g->p[k];
-        m->context = 0;
+        m->context = k < 2 ? 0 : k * 0x0101u;
         m->qbits = (uint32_t)P[0]; m->qshift = (uint32_t)P[1];
         m->qloc = (uint32_t)P[6]; m->sloc = (uint32_t)P[7]; m->ploc = (uint32_t)P[8]; m->dloc = (uint32_t)P[9];
         m->pflags = (do_dedup ? PF_DEDUP : 0) | (fixed ? PF_LEN : 0) | (do_sel ? PF_SEL : 0);
@@ -372,7 +375,8 @@ ORC_EXPORT size_t orc_fqz_encode(const uint8_t *in_, size_t n, const uint32_t *l
     size_t at = 0;
     for (size_t r = 0; r < nrec; r++) {
         const uint32_t len = lens[r];
-        const uint32_t s = do_sel ? (uint32_t)((rflags[r] & FQZ_FREAD2) != 0) : 0;
+        uint32_t s = do_sel ? (uint32_t)((rflags[r] & FQZ_FREAD2) != 0) + 2u * (uint32_t)(r % ((g->nparam + 1u) / 2u)) : 0;
+        if (s >= g->nparam) s = g->nparam - 1;
         if (g->max_sel > 0) model_encode(&M.sel, &rc, s);
         st.s = s;
         const fqz_param *pm = &g->p[g->stab[s]];

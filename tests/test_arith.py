@@ -111,3 +111,15 @@ def test_gpu_encoder_is_byte_identical_to_oracle(engine, aorc):
     assert not bad, bad[:12]
     outs, st = engine.cram_uncompress_blocks([(6, e, len(d)) for d, e in zip(datas, enc)])
     assert (st == 0).all() and outs == datas
+
+
+@pytest.mark.gpu
+def test_gpu_short_divisions_are_exact(engine):
+    """arith_dev.h replaces the two 32-bit divisions of a coder step (range / total, code / r) by single-precision estimates with one correction; checked here
+    against the exact division on the device over 1.5 G random operand pairs in the coder's ranges (+ the corners): any disagreement would change a stream"""
+    import ctypes as C
+    from htslib_amd import _native as nat
+    nat.lib.hg_debug_udiv_check.restype = C.c_long
+    nat.lib.hg_debug_udiv_check.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+    assert nat.lib.hg_debug_udiv_check(engine._h, 12345, 2000) == 0
+    assert nat.lib.hg_debug_udiv_check(engine._h, 987654321, 2000) == 0

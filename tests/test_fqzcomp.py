@@ -177,3 +177,36 @@ def test_auto_tuner_offers_fqzcomp_when_the_slice_is_known(engine, qorc):
     assert A.method in (7, 13, 14, 15) and Bm.method in (1, 5, 17)        # learnt: an fqzcomp preset / gzip or an Nx16 order
     assert not (Bm.revised_method & M(7, 13, 14, 15)) and (A.revised_method & M(7, 13, 14, 15))
     nat.lib.hg_cram_metrics_free(m1); nat.lib.hg_cram_metrics_free(m2)
+
+
+def test_oracle_roundtrip_with_more_than_two_parameter_sets(qorc):
+    """the format allows 256 parameter sets (htscodecs writes one or two): the oracle's encoder can be asked for 2 + k sets chosen per record"""
+    rng = np.random.default_rng(21)
+    for extra in (1, 2, 3, 6):
+        for fixed in (True, False):
+            q, lens, fl = reads(rng, 200, 90, fixed, 41, dup=0.1)
+            e = qorc.encode(q, lens, fl, 1, F.SEL | F.REV | F.DEDUP | (extra << 5))
+            assert e[1 + (1 if len(q) < 128 else 2 if len(q) < 16384 else 3)] == 5                 # version byte behind the uint7 size
+            rc, out, ln = qorc.decode(e, len(q), 200)
+            assert rc == 0 and out == q and (ln == lens).all(), extra
+
+
+@pytest.mark.gpu
+def test_gpu_decoder_takes_any_number_of_parameter_sets(engine, qorc):
+    """streams with more than two parameter sets were refused (and with no CPU codec the block was undecodable).  The wavefront keeps two sets in
+    LDS and swaps the others in from a global overflow image as records select them: 3, 4, 5 and 8 sets, with and without a selector table, fixed and
+    variable lengths, next to ordinary one- and two-set streams in the same batch"""
+    rng = np.random.default_rng(22)
+    blocks, want = [], []
+    for extra in (1, 2, 3, 6):
+        for opts in (F.SEL, F.SEL | F.REV | F.DEDUP, F.SEL | F.STAB | F.REV, F.SEL | F.NOQMAP):
+            for fixed in (True, False):
+                for nq in (4, 41):
+                    q, lens, fl = reads(rng, 300, 80, fixed, nq, dup=0.2 if opts & F.DEDUP else 0.0)
+                    blocks.append((7, qorc.encode(q, lens, fl, extra & 3, opts | (extra << 5)), len(q))); want.append(q)
+    q, lens, fl = reads(rng, 100, 100, True, 41)
+    blocks.append((7, qorc.encode(q, lens, fl, 0, 0), len(q))); want.append(q)
+    blocks.append((7, qorc.encode(q, lens, fl, 1, F.SEL), len(q))); want.append(q)
+    outs, st = engine.cram_uncompress_blocks(blocks)
+    assert (st == 0).all(), np.nonzero(st)[0][:10]
+    assert outs == want
