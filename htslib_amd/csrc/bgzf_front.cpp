@@ -1481,6 +1481,9 @@ uint32_t hts_crc32(uint32_t crc, const void *buf, size_t len) {
     hg_ctx *ctx = shared_ctx();
     uint32_t c = 0;
     if (!ctx || hg_crc32_host(ctx, buf, len, &c) != HG_OK) {
+        // HTS_GPU_STRICT=1: a deployment that must never compute on the host without noticing gets the hard stop back
+        static const bool strict = [] { const char *v = getenv("HTS_GPU_STRICT"); return v && atoi(v) != 0; }();
+        if (strict) { logmsg(LOG_ERROR, "hts_crc32", "no usable GPU engine and HTS_GPU_STRICT is set"); abort(); }
         static std::once_flag warned;
         std::call_once(warned, [] { logmsg(LOG_WARNING, "hts_crc32", "no usable GPU engine: checksums are computed on the host"); });
         return crc32_table_host(crc, (const uint8_t *)buf, len);

@@ -16,6 +16,9 @@
 #include <chrono>
 #include <string>
 #include <vector>
+#include <thread>
+#include <atomic>
+#include <memory>
 #include "htsgpu.h"
 #include "hg_device.h"
 #include "hg_internal.h"
@@ -188,10 +191,20 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
         if (fail[k]) { S[k].keys.clear(); S[k].lhash.clear(); S[k].lfirst.clear(); }
         k2.insert(k2.end(), S[k].keys.begin(), S[k].keys.end()); ko[k + 1] = (uint32_t)k2.size();
         l2.insert(l2.end(), S[k].lhash.begin(), S[k].lhash.end()); lo[k + 1] = (uint32_t)l2.size();
-        enc_ref_policy(S[k], refs, nrefs);
+        enc_ref_policy(S[k], refs, nrefs, false);
         start[k] = S[k].start(); multi[k] = (uint8_t)S[k].walk_mode();
         ncmax = std::max<size_t>(ncmax, (size_t)S[k].ncols());
     }
+    // the reference-span digests of the slice headers: host threads, beside the device's two walks (joined before the headers are written)
+    std::vector<std::thread> md5_threads;
+    {
+        std::shared_ptr<std::atomic<size_t>> next = std::make_shared<std::atomic<size_t>>(0);
+        const unsigned nt = (unsigned)std::min<size_t>(std::min<size_t>(ns, 8), std::max(1u, std::thread::hardware_concurrency()));
+        EncSlice *Sp = S.data();
+        for (unsigned t = 0; t < nt; t++)
+            md5_threads.emplace_back([next, Sp, ns, refs] { for (size_t k; (k = next->fetch_add(1)) < ns;) if (!Sp[k].fail) enc_ref_md5(Sp[k], refs); });
+    }
+    struct Joiner { std::vector<std::thread> &v; ~Joiner() { for (auto &t : v) if (t.joinable()) t.join(); } } md5_join{md5_threads};
     ok = (k2.empty() || hipMemcpyAsync(dt + t_k2, k2.data(), k2.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess) && hipMemcpyAsync(dt + t_ko, ko.data(), ko.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
          (l2.empty() || hipMemcpyAsync(dt + t_l2, l2.data(), l2.size() * 8, hipMemcpyHostToDevice, s) == hipSuccess) && hipMemcpyAsync(dt + t_lo, lo.data(), lo.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
          hipMemcpyAsync(dt + t_start, start.data(), ns * 8, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dt + t_multi, multi.data(), ns, hipMemcpyHostToDevice, s) == hipSuccess &&
@@ -229,6 +242,8 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
     ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(fail.data(), dt + t_fail, ns * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
     PT.mark("write");
+    for (auto &t : md5_threads) t.join();
+    md5_threads.clear();
     // ---- headers + blobs: the blocks go from the device straight to their places in the caller's buffer (one pinned transfer, hg_stage.hip)
     uint64_t o = 0; bool any_bad = false, too_small = false;
     std::vector<uint64_t> src_off; std::vector<uint32_t> src_len; std::vector<uint8_t *> dst;

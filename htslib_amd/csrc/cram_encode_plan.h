@@ -44,13 +44,22 @@ inline void enc_survey_finish(const uint32_t *keytab, const uint64_t *lh, const 
 
 // refs[i].bases / refs[i].len: the sequences the caller has (bases == nullptr: not available).  cram_encode_slice stores the MD5 of the span
 // [start, start + span) of a single-reference slice (clamped at the end of the sequence, like the reader's check cram_decode.c:2480-2540).
+// (the digest is a pass over the span on the host: enc_ref_md5 can run apart from the decision, beside the device's walks)
 template <class Ref>
-inline void enc_ref_policy(EncSlice &S, const Ref *refs, int nrefs) {
+inline void enc_ref_md5(EncSlice &S, const Ref *refs) {
+    memset(S.md5, 0, 16);
+    if (S.use_ref && !S.multi() && S.min_ref >= 0 && S.span() > 0) {
+        const int64_t len = (int64_t)refs[S.min_ref].len, a = S.start() - 1, b = std::min<int64_t>(a + S.span(), len);
+        if (a >= 0 && a < b) md5_of((const uint8_t *)refs[S.min_ref].bases + a, (uint64_t)(b - a), S.md5);
+    }
+}
+template <class Ref>
+inline void enc_ref_policy(EncSlice &S, const Ref *refs, int nrefs, bool with_md5 = true) {
     memset(S.md5, 0, 16);
     S.use_ref = true;
     for (int32_t t = std::max<int32_t>(S.min_ref, 0); t <= S.max_ref; t++)
         if (t >= nrefs || !refs[t].bases || !refs[t].len) S.use_ref = false;
-    if (S.use_ref && !S.multi() && S.min_ref >= 0 && S.span() > 0) {
+    if (with_md5 && S.use_ref && !S.multi() && S.min_ref >= 0 && S.span() > 0) {
         const int64_t len = (int64_t)refs[S.min_ref].len, a = S.start() - 1, b = std::min<int64_t>(a + S.span(), len);
         if (a >= 0 && a < b) md5_of((const uint8_t *)refs[S.min_ref].bases + a, (uint64_t)(b - a), S.md5);
     }

@@ -11,9 +11,10 @@
  * How it differs from bgzf.c, by design:
  *   - blocks are (de)compressed in BATCHES on the GPU (libhtsgpu.so, hg_pipe_*).  A reader always behaves like the
  *     reference's threaded mode: an I/O thread prefetches and inflates windows of blocks, `fp->mt` is non-NULL,
- *     bgzf_set_cache_size() is ignored as it is with threads (bgzf.c:2126-2130).
+ *     bgzf_set_cache_size() is ignored as it is with threads (bgzf.c:2126-2130).  The first blocks after bgzf_open / bgzf_seek are
+ *     inflated on the calling thread by the host codec (bgzf_host_codec.h): random access costs what it costs the reference.
  *   - a writer WITHOUT bgzf_mt() keeps bgzf_tell() exact between writes like the reference's single-threaded writer
- *     (each block goes to the device alone and is waited for: correct, slow).  bgzf_mt() / bgzf_thread_pool() create no
+ *     (each block is compressed where it is cut, on the caller's thread, by the host codec).  bgzf_mt() / bgzf_thread_pool() create no
  *     threads but switch the writer to the reference's threaded contract: blocks are batched, `fp->mt` becomes non-NULL,
  *     fp->block_address is valid after bgzf_flush() only and index offsets go through bgzf_idx_push
  *     (bgzf.c:189-290, 1953-1967; sam.c:942).
