@@ -1141,7 +1141,7 @@ def op_records(run: Run, steps: int, slices: int = 256, nrec: int = 10000, cpu: 
            "roofline": {"bound": "hbm", "achieved": round(alg / t / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
                         "kernel": "the whole step (about thirty launches; profiles/ has the per-kernel split)", "algorithmic_bytes": int(alg),
                         "note": "algorithmic bytes = decoded blocks + reference spans read once + BAM bytes written once"}}
-    if cpu:
+    if cpu and not run.args.no_cpu_baseline:
         ref = None
         try: ref = cpu_baseline_reference_records(eng, base, os.cpu_count() or 1, "decode")
         except Exception as e: out["cpu_baseline_error"] = repr(e)
@@ -1359,6 +1359,7 @@ def main():
     ap.add_argument("--extra-steps", type=int, default=5, help="timed steps of the `extra` ops in --op all")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="--op rans: skip the 16-variant host-API matrix (profiling runs)")
     args = ap.parse_args()
     run = Run(args)
     ok = True

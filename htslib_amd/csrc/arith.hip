@@ -51,7 +51,10 @@ __device__ void models_init(const Models &Q, bool rle, int lane) {
     wave_sync();
 }
 
-template <int POOLW, int WAVES>
+// MODE 0: every stream of the list; 1: only streams whose models fit the pool; 2: only streams whose models do NOT fit HG_ARITH_POOL_BIG (global
+// scratch; the pool then holds their totals only).  1 and 2 walk the same list ("big" streams): a stream with global models needs 3 KiB of LDS, not the
+// 64 KiB of the big pool -- which kept its workgroups from sharing a CU with the 68 KiB workgroups of the rANS kernels (they ran one after the other).
+template <int POOLW, int WAVES, int MODE = 0>
 __global__ __launch_bounds__(WAVES * 64)
 void arith_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc, const uint32_t *__restrict__ sel,
                          uint32_t nsel, uint8_t *out, int32_t *status, uint32_t *gscratch) {
@@ -127,8 +130,10 @@ void arith_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
 #endif
         };
         if (!err && n) {
-            const uint32_t m0 = cp[0] ? cp[0] : 256u;
-            if (model_words(m0, order, rle) <= (uint32_t)POOLW) body(std::true_type{}); else body(std::false_type{});
+            const uint32_t m0 = cp[0] ? cp[0] : 256u, words = model_words(m0, order, rle);
+            if (MODE == 1 && words > (uint32_t)POOLW) continue;      // (wave-uniform) the other kernel's stream
+            if (MODE == 2 && words <= (uint32_t)HG_ARITH_POOL_BIG) continue;
+            if (MODE != 2 && words <= (uint32_t)POOLW) body(std::true_type{}); else body(std::false_type{});
         }
         status[sidx] = err ? -1 : 0;                                 // every lane stores the same word
         wave_sync();
@@ -154,8 +159,15 @@ int launch_arith_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
     if (nbig) {
         size_t wgs = nbig;
         if (wgs > maxw) wgs = maxw;
-        hipLaunchKernelGGL((hga::arith_decode_kernel<HG_ARITH_POOL_BIG, 1>), dim3((unsigned)wgs), dim3(64), 0, s2, (const uint8_t *)d_in,
+        hipLaunchKernelGGL((hga::arith_decode_kernel<HG_ARITH_POOL_BIG, 1, 1>), dim3((unsigned)wgs), dim3(64), 0, s2, (const uint8_t *)d_in,
                            d_desc, d_sel_big, (uint32_t)nbig, (uint8_t *)d_out, d_status, d_scratch);
+        // the same list again for the streams with global models, four per workgroup and 3 KiB of LDS each, beside the others
+        hipStream_t s3 = fork_side3(ctx, s);
+        size_t wg4 = (nbig + 3) / 4;
+        if (wg4 > maxw) wg4 = maxw;
+        hipLaunchKernelGGL((hga::arith_decode_kernel<HG_ARITH_POOL_TOTALS, 4, 2>), dim3((unsigned)wg4), dim3(256), 0, s3, (const uint8_t *)d_in,
+                           d_desc, d_sel_big, (uint32_t)nbig, (uint8_t *)d_out, d_status, d_scratch);
+        join_side3(ctx, s);
         if (side) join_side(ctx, s);
     }
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
@@ -167,7 +179,7 @@ int launch_arith_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
 // ================================================================================================
 namespace hga {
 
-template <int POOLW, int WAVES>
+template <int POOLW, int WAVES, int MODE = 0>
 __global__ __launch_bounds__(WAVES * 64)
 void arith_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc, const uint8_t *__restrict__ flags_in,
                          const uint32_t *__restrict__ sel, uint32_t nsel, uint8_t *out, uint32_t *out_len, uint32_t *gscratch) {
@@ -238,7 +250,10 @@ void arith_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
             if (LM && Q.m <= 64u) loops(std::true_type{}); else loops(std::false_type{});
             total = 1u + E.finish(lane);
             };
-            if (model_words(mx + 1u, order, rle) <= (uint32_t)POOLW) body(std::true_type{}); else body(std::false_type{});
+            const uint32_t words = model_words(mx + 1u, order, rle);
+            if (MODE == 1 && words > (uint32_t)POOLW) continue;      // (wave-uniform) the other kernel's stream
+            if (MODE == 2 && words <= (uint32_t)HG_ARITH_POOL_BIG) continue;
+            if (MODE != 2 && words <= (uint32_t)POOLW) body(std::true_type{}); else body(std::false_type{});
         }
         out_len[sidx] = total;                                       // every lane stores the same word
         wave_sync();
@@ -263,8 +278,14 @@ int launch_arith_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
     if (nbig) {
         size_t wgs = nbig;
         if (wgs > maxw) wgs = maxw;
-        hipLaunchKernelGGL((hga::arith_encode_kernel<HG_ARITH_POOL_BIG, 1>), dim3((unsigned)wgs), dim3(64), 0, s2, (const uint8_t *)d_in,
+        hipLaunchKernelGGL((hga::arith_encode_kernel<HG_ARITH_POOL_BIG, 1, 1>), dim3((unsigned)wgs), dim3(64), 0, s2, (const uint8_t *)d_in,
                            d_desc, d_flags, d_sel_big, (uint32_t)nbig, (uint8_t *)d_out, d_out_len, d_scratch);
+        hipStream_t s3 = fork_side3(ctx, s);
+        size_t wg4 = (nbig + 3) / 4;
+        if (wg4 > maxw) wg4 = maxw;
+        hipLaunchKernelGGL((hga::arith_encode_kernel<HG_ARITH_POOL_TOTALS, 4, 2>), dim3((unsigned)wg4), dim3(256), 0, s3, (const uint8_t *)d_in,
+                           d_desc, d_flags, d_sel_big, (uint32_t)nbig, (uint8_t *)d_out, d_out_len, d_scratch);
+        join_side3(ctx, s);
         if (side) join_side(ctx, s);
     }
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;

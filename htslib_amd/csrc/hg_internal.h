@@ -27,6 +27,8 @@ struct hg_ctx {
     hipStream_t stream;       // the host entry points run on this non-blocking stream (one per context)
     hipStream_t stream2;      // side stream: the second of two independent kernel variants of one call (fork_side / join_side)
     hipEvent_t ev_fork, ev_join;
+    hipStream_t stream3;      // a second side stream (a third variant of one call: the range coder's global-model streams, the long 4-way rANS streams)
+    hipEvent_t ev_fork3, ev_join3;
     hg_ctx *sub[8];           // lazily created sibling contexts: independent codec families of one CRAM batch run concurrently
 };
 
@@ -56,7 +58,7 @@ int launch_bgzf_pack(hg_ctx *ctx, const void *d_slots, const hg_bgzf_desc *d_des
 int launch_rans4x8_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, size_t n, void *d_out,
                           int32_t *d_status, uint32_t *d_scratch, hipStream_t s);
 int launch_rans4x16_big_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_sel4, size_t n4, void *d_out, int32_t *d_status,
-                               uint32_t *d_scratch, hipStream_t s);
+                               uint32_t *d_scratch, hipStream_t s, bool leave_room);
 int launch_ransnx16_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_sel4,
                            size_t n4, const uint32_t *d_sel32, size_t n32, void *d_out, int32_t *d_status,
                            uint32_t *d_scratch, hipStream_t s);
@@ -95,6 +97,7 @@ int launch_ransnx16_xenc(hg_ctx *ctx, void *d_buf, const nx16_xenc *d_jobs, size
 // waves per CU) and a big-pool launch, larger models fall back to global scratch words.
 #define HG_ARITH_POOL_SMALL 3072     /* words: order-0 (+RLE), order-1 up to 54 symbols (41 with RLE) */
 #define HG_ARITH_POOL_BIG   16384    /* words: order-1 up to 127 symbols, or 120 with RLE */
+#define HG_ARITH_POOL_TOTALS 768     /* words: the totals of a stream whose models live in global scratch (256 literal + 258 run models) */
 uint32_t arith_model_words(uint32_t max_sym, uint32_t flags);
 int launch_arith_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_sel_small, size_t nsmall,
                         const uint32_t *d_sel_big, size_t nbig, void *d_out, int32_t *d_status, uint32_t *d_scratch, hipStream_t s);
@@ -131,6 +134,15 @@ inline hipStream_t fork_side(hg_ctx *ctx, hipStream_t s) {
 inline void join_side(hg_ctx *ctx, hipStream_t s) {
     (void)hipEventRecord(ctx->ev_join, ctx->stream2);
     (void)hipStreamWaitEvent(s, ctx->ev_join, 0);
+}
+inline hipStream_t fork_side3(hg_ctx *ctx, hipStream_t s) {
+    (void)hipEventRecord(ctx->ev_fork3, s);
+    (void)hipStreamWaitEvent(ctx->stream3, ctx->ev_fork3, 0);
+    return ctx->stream3;
+}
+inline void join_side3(hg_ctx *ctx, hipStream_t s) {
+    (void)hipEventRecord(ctx->ev_join3, ctx->stream3);
+    (void)hipStreamWaitEvent(s, ctx->ev_join3, 0);
 }
 // hg_stage.hip: many scattered host buffers <-> one device buffer, one PCIe transfer each way
 int stage_upload(hg_ctx *ctx, const uint8_t *const *src, const uint32_t *len, const uint64_t *dst_off, const int32_t *skip, size_t n,

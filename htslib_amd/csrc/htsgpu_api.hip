@@ -66,6 +66,9 @@ int hg_init(int device, hg_ctx **out) {
     ctx->tok_mu = new std::mutex();
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork3, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_deflate, hipEventDisableTiming) != hipSuccess) { (void)hipFree(ctx->d_ticket); delete ctx->launch_seq; delete ctx->mu; delete ctx->tok_mu; free(ctx); return HG_ENODEV; }
@@ -82,6 +85,9 @@ void hg_destroy(hg_ctx *ctx) {
     for (hg_ctx *c : ctx->sub) if (c) hg_destroy(c);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->stream3) { (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamDestroy(ctx->stream3); }
+    if (ctx->ev_fork3) (void)hipEventDestroy(ctx->ev_fork3);
+    if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);

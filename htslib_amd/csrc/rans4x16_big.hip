@@ -212,10 +212,11 @@ void rans4x16_big_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_
 
 namespace hg {
 int launch_rans4x16_big_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_sel4, size_t n4, void *d_out, int32_t *d_status,
-                               uint32_t *d_scratch, hipStream_t s) {
+                               uint32_t *d_scratch, hipStream_t s, bool leave_room) {
     if (!n4) return HG_OK;
     size_t wgs = (n4 + hgn::BW - 1) / hgn::BW;
-    const size_t maxw = (size_t)ctx->cus * 2;                          // two workgroups per CU are resident (LDS)
+    // two workgroups per CU are resident (72 KiB of LDS each); with a 32-way launch beside it (68 KiB workgroups) one per CU, or the two kernels take turns
+    const size_t maxw = (size_t)ctx->cus * (leave_room ? 1 : 2);
     if (wgs > maxw) wgs = maxw;
     hipLaunchKernelGGL(hgn::rans4x16_big_decode_kernel, dim3((unsigned)wgs), dim3(hgn::BW * 64), 0, s, (const uint8_t *)d_in, d_desc, d_sel4, (uint32_t)n4,
                        (uint8_t *)d_out, d_status, d_scratch);
