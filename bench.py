@@ -37,6 +37,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the library asks for 16 hardware queues when it is loaded (htsgpu_api.hip); torch initialises HIP first in this process, so the request is made here as well
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 CHUNK = 32 << 20          # plain bytes generated + deflated by one worker task
 GEN_VERSION = "v1"

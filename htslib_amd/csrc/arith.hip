@@ -82,9 +82,12 @@ void arith_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
             D.start(cp + 1, d.in_len - 1, lane);
             uint32_t last = 0, keep = 0;
             // every model goes through the lean step of arith_dev.h (the symbol is nearly always among a model's first 64 entries)
-            auto loops = [&](auto small_lit) {
-            (void)small_lit;
+            WideO0 W;
+            auto loops = [&](auto wide_c) {
+            constexpr bool WIDE = decltype(wide_c)::value;           // order 0, 65..256 symbols, model in LDS: arith_dev.h WideO0
+            if (WIDE) W.init(Q.M, nullptr, Q.m, false, lane);
             auto lit_sym = [&](uint32_t ctx) -> uint32_t {
+                if (WIDE) return wide_decode(D, W, lane);
                 return D.template symbol_lean<LM>(Q.M, Q.TT, Q.lit(ctx), Q.m, Q.lit_tot(ctx), lane);
             };
             auto run_sym = [&](uint32_t rctx) -> uint32_t {
@@ -121,7 +124,7 @@ void arith_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
                 }
             }
             };
-            if (LM && Q.m <= 64u) loops(std::true_type{}); else loops(std::false_type{});
+            if (LM && !order && Q.m > 64u) loops(std::true_type{}); else loops(std::false_type{});
             if (D.err || D.in.overrun) err = 1;
 #ifdef HG_ARITH_PROFILE
             if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -150,6 +153,7 @@ int launch_arith_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
     const size_t maxw = (size_t)ctx->cus * 8;
     const bool side = nsmall != 0 && nbig != 0;                  // both variants present: overlap them
     hipStream_t s2 = side ? fork_side(ctx, s) : s;
+    hipStream_t s3 = nbig ? fork_side3(ctx, s) : s;              // (forked BEFORE anything of this call is queued on s: the three kernels start together)
     if (nsmall) {
         size_t wgs = (nsmall + 3) / 4;
         if (wgs > maxw) wgs = maxw;
@@ -162,7 +166,6 @@ int launch_arith_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
         hipLaunchKernelGGL((hga::arith_decode_kernel<HG_ARITH_POOL_BIG, 1, 1>), dim3((unsigned)wgs), dim3(64), 0, s2, (const uint8_t *)d_in,
                            d_desc, d_sel_big, (uint32_t)nbig, (uint8_t *)d_out, d_status, d_scratch);
         // the same list again for the streams with global models, four per workgroup and 3 KiB of LDS each, beside the others
-        hipStream_t s3 = fork_side3(ctx, s);
         size_t wg4 = (nbig + 3) / 4;
         if (wg4 > maxw) wg4 = maxw;
         hipLaunchKernelGGL((hga::arith_decode_kernel<HG_ARITH_POOL_TOTALS, 4, 2>), dim3((unsigned)wg4), dim3(256), 0, s3, (const uint8_t *)d_in,
@@ -208,9 +211,12 @@ void arith_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
             Encoder E;
             E.start(o + 1);
             uint32_t last = 0;
-            auto loops = [&](auto small_lit) {
-            (void)small_lit;
+            WideO0 W;
+            auto loops = [&](auto wide_c) {
+            constexpr bool WIDE = decltype(wide_c)::value;
+            if (WIDE) W.init(Q.M, (uint8_t *)(pool[wv] + (POOLW - 64)), Q.m, true, lane);     // the symbol -> position map: the pool's last 256 bytes
             auto lit_sym = [&](uint32_t ctx, uint32_t c) {
+                if (WIDE) { wide_encode(E, W, c, lane); return; }
                 E.template symbol_lean<LM>(Q.M, Q.TT, Q.lit(ctx), Q.m, Q.lit_tot(ctx), c, lane);
             };
             auto run_sym = [&](uint32_t rctx, uint32_t part) {
@@ -247,7 +253,7 @@ void arith_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *_
                 }
             }
             };
-            if (LM && Q.m <= 64u) loops(std::true_type{}); else loops(std::false_type{});
+            if (LM && !order && Q.m > 64u && model_words(Q.m, order, rle) + 64u <= (uint32_t)POOLW) loops(std::true_type{}); else loops(std::false_type{});
             total = 1u + E.finish(lane);
             };
             const uint32_t words = model_words(mx + 1u, order, rle);
@@ -269,6 +275,7 @@ int launch_arith_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
     const size_t maxw = (size_t)ctx->cus * 8;
     const bool side = nsmall != 0 && nbig != 0;                  // both variants present: overlap them
     hipStream_t s2 = side ? fork_side(ctx, s) : s;
+    hipStream_t s3 = nbig ? fork_side3(ctx, s) : s;
     if (nsmall) {
         size_t wgs = (nsmall + 3) / 4;
         if (wgs > maxw) wgs = maxw;
@@ -280,7 +287,6 @@ int launch_arith_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
         if (wgs > maxw) wgs = maxw;
         hipLaunchKernelGGL((hga::arith_encode_kernel<HG_ARITH_POOL_BIG, 1, 1>), dim3((unsigned)wgs), dim3(64), 0, s2, (const uint8_t *)d_in,
                            d_desc, d_flags, d_sel_big, (uint32_t)nbig, (uint8_t *)d_out, d_out_len, d_scratch);
-        hipStream_t s3 = fork_side3(ctx, s);
         size_t wg4 = (nbig + 3) / 4;
         if (wg4 > maxw) wg4 = maxw;
         hipLaunchKernelGGL((hga::arith_encode_kernel<HG_ARITH_POOL_TOTALS, 4, 2>), dim3((unsigned)wg4), dim3(256), 0, s3, (const uint8_t *)d_in,

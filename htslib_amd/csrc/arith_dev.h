@@ -175,6 +175,51 @@ struct Decoder {
     }
 };
 
+
+// ---- order 0 with a WIDE alphabet (65..256 symbols): one model, met by every symbol of the stream ---------------------------------------------------
+// The lean step above looks at the first 64 entries only; data whose bytes are spread evenly (the byte planes of 32-bit integers) finds its symbol
+// there one time in four and falls back to the general routine -- four reads, up to four scans.  With a single model per stream the bookkeeping that
+// makes the step independent of WHERE the symbol sits fits in scalar registers: the totals of the four 64-entry pieces (sum[]) select the piece -- from
+// the cumulative frequency when decoding, from a symbol -> position byte map in LDS when encoding -- and ONE read + ONE scan of that piece do the rest.
+// The list itself is unchanged (sorted by frequency, one step towards the front per hit, halved when the total passes MAX_FREQ): same bytes as before.
+struct WideO0 {
+    uint32_t *M; uint8_t *pos; uint32_t n, tot, sum[4];
+    __device__ __forceinline__ void init(uint32_t *M_, uint8_t *pos_, uint32_t n_, bool want_pos, int lane) {
+        M = M_; pos = pos_; n = n_; tot = n_;
+        for (uint32_t p = 0; p < 4; p++) sum[p] = n_ > 64u * p ? (n_ - 64u * p < 64u ? n_ - 64u * p : 64u) : 0u;     // every frequency starts at 1
+        if (want_pos) for (uint32_t i = (uint32_t)lane; i < 256u; i += 64) pos_[i] = (uint8_t)i;                     // models_init: entry i holds symbol i
+        wave_sync();
+    }
+    __device__ __forceinline__ uint32_t base(uint32_t p) const { return p == 0 ? 0u : p == 1 ? sum[0] : p == 2 ? sum[0] + sum[1] : sum[0] + sum[1] + sum[2]; }
+    __device__ __forceinline__ uint32_t piece(uint32_t p, int lane) const { const uint32_t i = 64u * p + (uint32_t)lane; return i < n ? M[i] : 0u; }
+    // entry l of piece p (word ex, as read) has been coded: bump it, keep the list sorted, keep sum[] / pos[] / tot in step
+    template <bool POS>
+    __device__ __forceinline__ void bump(uint32_t p, uint32_t l, uint32_t ex, uint32_t e, int lane) {
+        uint32_t nex = ex + (STEP << 8);
+        tot += STEP; sum[p] += STEP;
+        if (tot > MAX_FREQ) {                                          // halve every frequency (rare)
+            if ((uint32_t)lane == l) M[64u * p + l] = nex;
+            uint32_t t = 0;
+            for (uint32_t q = 0; q < 4 && 64u * q < n; q++) {
+                const uint32_t i = 64u * q + (uint32_t)lane;
+                uint32_t f = 0;
+                if (i < n) { const uint32_t w = M[i]; f = w >> 8; f -= f >> 1; M[i] = (f << 8) | (w & 0xffu); }
+                sum[q] = rl(wave_incl_scan_dpp(f), 63); t += sum[q];
+            }
+            tot = t;
+            const uint32_t w = piece(p, lane);
+            nex = rl(w, l); e = w;
+        }
+        const uint32_t x = 64u * p + l;
+        if (x == 0) { if (lane == 0 && !(tot > MAX_FREQ)) M[0] = nex; return; }
+        const uint32_t ep = l ? rl(e, l - 1u) : hg::uni(M[x - 1u]);   // the neighbour towards the front (the last entry of the piece before, when l = 0)
+        if ((nex >> 8) > (ep >> 8)) {
+            if (lane == 0) { M[x] = ep; M[x - 1u] = nex; if (POS) { pos[nex & 0xffu] = (uint8_t)(x - 1u); pos[ep & 0xffu] = (uint8_t)x; } }
+            if (l == 0) { const uint32_t d = (nex >> 8) - (ep >> 8); sum[p] -= d; sum[p - 1u] += d; }     // the entries changed pieces
+        } else if (lane == 0) M[x] = nex;
+    }
+};
+
 struct Encoder {
     uint32_t low, range, carry, cache, ffnum;
     uint8_t *out; uint32_t opos, oidx, obuf;                         // 64 output bytes are gathered in one VGPR
@@ -260,5 +305,30 @@ struct Encoder {
         model_update<LDSM>(M, TT, B, n, T, tot, x, ex, have_prev, eprev, lane);
     }
 };
+
+
+// one symbol through a WideO0 model (see there)
+__device__ __forceinline__ uint32_t wide_decode(Decoder &D, WideO0 &W, int lane) {
+    const uint32_t r = udiv_small_divisor(D.range, W.tot), freq = udiv_small_quotient(D.code, r);
+    if (freq >= W.tot) { D.err = 1; return 0; }
+    const uint32_t a = W.sum[0], b = a + W.sum[1], c = b + W.sum[2];
+    const uint32_t p = (freq >= a ? 1u : 0u) + (freq >= b ? 1u : 0u) + (freq >= c ? 1u : 0u);
+    const uint32_t e = W.piece(p, lane);
+    const uint32_t incl = W.base(p) + wave_incl_scan_dpp(e >> 8);   // lanes past the model's end carry the total
+    const uint32_t l = (uint32_t)__builtin_ctzll(__ballot(incl > freq));
+    const uint32_t ex = rl(e, l), f = ex >> 8;
+    D.code -= (rl(incl, l) - f) * r; D.range = r * f;
+    while (D.range < TOP) { D.code = (D.code << 8) | D.in.next(lane); D.range <<= 8; }
+    W.bump<false>(p, l, ex, e, lane);
+    return ex & 0xffu;
+}
+__device__ __forceinline__ void wide_encode(Encoder &E, WideO0 &W, uint32_t sym, int lane) {
+    const uint32_t x = hg::uni((uint32_t)W.pos[sym]), p = x >> 6, l = x & 63u;
+    const uint32_t e = W.piece(p, lane);
+    const uint32_t incl = wave_incl_scan_dpp(e >> 8);
+    const uint32_t ex = rl(e, l), f = ex >> 8;
+    E.encode(W.base(p) + rl(incl, l) - f, f, W.tot, lane);
+    W.bump<true>(p, l, ex, e, lane);
+}
 
 }  // namespace hga

@@ -29,6 +29,13 @@ int ensure_scratch(hg_ctx *ctx, int slot, size_t bytes) {
 }  // namespace hg
 using hg::ensure_scratch;
 
+// The block layer runs the codec families of a batch on separate HIP streams (up to three per family context) so that their latency-bound kernels
+// overlap.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and a hardware queue runs its kernels in order: with ~15
+// streams on 4 queues the families took turns (kernel timeline: profiles/r04_cram_slices_256_timeline.txt; a decode call of 256 slices 62 -> 40 ms with
+// 16 queues).  Asked for when this library is loaded, unless the user set the variable; without effect (and without harm) when the process initialised
+// HIP earlier.
+__attribute__((constructor)) static void hg_more_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 extern "C" {
 
 const char *hg_version(void) { return HG_VERSION_STRING; }

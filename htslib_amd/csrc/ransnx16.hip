@@ -251,13 +251,13 @@ int launch_ransnx16_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *
     const size_t maxw = (size_t)ctx->cus * 8;
     const bool side = n4 != 0 && n32 != 0;                  // both variants present: overlap them
     hipStream_t s2 = side ? fork_side(ctx, s) : s;
+    hipStream_t s3 = n4 ? fork_side3(ctx, s) : s;               // (forked before anything of this call is queued on s)
     if (n4) {
         size_t wgs = (n4 + hgn::WAVES * 16 - 1) / (hgn::WAVES * 16);
         if (wgs > maxw) wgs = maxw;
         hipLaunchKernelGGL(hgn::ransnx16_decode_kernel<4>, dim3((unsigned)wgs), dim3(hgn::WAVES * 64), 0, s,
                            (const uint8_t *)d_in, d_desc, d_sel4, (uint32_t)n4, (uint8_t *)d_out, d_status, d_scratch);
         // the long 4-way streams of the same list, one per wavefront (the kernel above skipped them; this one skips the others)
-        hipStream_t s3 = fork_side3(ctx, s);
         const int rc = launch_rans4x16_big_decode(ctx, d_in, d_desc, d_sel4, n4, d_out, d_status, d_scratch, s3, n32 != 0);
         join_side3(ctx, s);
         if (rc != HG_OK) return rc;
