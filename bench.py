@@ -837,7 +837,8 @@ def op_deflate(run: Run, S: Staged, steps: int, warmup: int):
                       "size_vs_zlib6": round(comp_len / S.comp_len, 4), "verified": bool(ok),
                       "decodes_with_reference_htslib": ref_ok},
            "roofline": {"bound": "hbm", "achieved": round(alg / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                        "unit": "GB/s", "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "traffic": hbm_traffic_file("hbm_traffic_deflate.json", ["fetch_bytes_per_plain_byte", "write_bytes_per_plain_byte"], total_u),
                         "kernel": "hgd::bgzf_deflate_kernel", "kernel_ms": round(k_ms, 3),
                         "algorithmic_bytes_per_launch": int(alg)}}
     if run.world == 1 and not args.no_cpu_baseline:
@@ -1302,7 +1303,7 @@ def op_fqz(run: Run, steps: int, streams: int = 512):
            "config": {"workload": "%d quality blocks of %d x %d bp; one adaptive chain per block; medians" % (streams, nrec, rl), "encode_GBps": round(nb / med(te) / 1e9, 3),
                       "ratio": round(nc / nb, 4), "verified_blocks": len(datas), "format_parity": "UNPINNED against htscodecs (oracle/fqzcomp_oracle.c)"},
            "roofline": {"bound": "hbm", "achieved": round((nb + nc) / med(td) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((nb + nc) / med(td) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
-                        "kernel": "whole decode call (hgq::fqz_decode_kernel dominates: profiles/r02_fqz_kernel_stats.csv); the path is one dependent chain per block, not bandwidth",
+                        "kernel": "whole decode call (hgq::fqz_decode_kernel dominates: profiles/r04_fqz_kernel_stats.csv); the path is one dependent chain per block, not bandwidth",
                         "algorithmic_bytes": int(nb + nc)}}
     if not run.args.no_cpu_baseline:
         nproc = max(1, min(run.ncores - 2, 64))
