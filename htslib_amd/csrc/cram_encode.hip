@@ -155,7 +155,7 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
     size_t tb = 0;
     auto carve = [&](size_t b) { const size_t o = tb; tb += al(b); return o; };
     const size_t t_refs = carve(er.size() * sizeof(EncRef)), t_rgn = carve(rgn.size() + 1), t_rgo = carve(rgo.size() * 4), t_sl = carve(ns * sizeof(SliceDev)), t_cs = carve(nch * 4), t_cr = carve(nch * 4),
-                 t_list = carve(ns * 4), t_keys = carve(ns * ENC_KEY_SLOTS * 4), t_lh = carve(ns * ENC_LINE_SLOTS * 8), t_lf = carve(ns * ENC_LINE_SLOTS * 4), t_fail = carve(ns * 4), t_stat = carve(ns * sizeof(SliceStat)),
+                 t_list = carve(ns * 4), t_keys = carve(ns * ENC_KEY_SLOTS * 4), t_lh = carve(ns * ENC_LINE_SLOTS * 8), t_lf = carve(ns * ENC_LINE_SLOTS * 4), t_lc = carve(ns * ENC_LINE_SLOTS * 8), t_fail = carve(ns * 4), t_stat = carve(ns * sizeof(SliceStat)),
                  t_k2 = carve(ns * ENC_MAX_TAGS * 4 + 4), t_ko = carve((ns + 1) * 4), t_l2 = carve(ns * ENC_MAX_LINES * 8 + 8), t_lo = carve((ns + 1) * 4), t_start = carve(ns * 8), t_multi = carve(ns);
     if ((rc = hg::ensure_scratch(ctx, 2, tb + 64))) return rc;
     uint8_t *dt = (uint8_t *)ctx->d_scratch[2];
@@ -164,13 +164,13 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
          hipMemcpyAsync(dt + t_rgo, rgo.data(), rgo.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dt + t_sl, sl.data(), ns * sizeof(SliceDev), hipMemcpyHostToDevice, s) == hipSuccess &&
          hipMemcpyAsync(dt + t_cs, chunk_slice.data(), nch * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dt + t_cr, chunk_r0.data(), nch * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
          hipMemcpyAsync(dt + t_list, list.data(), ns * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemsetAsync(dt + t_keys, 0xff, ns * ENC_KEY_SLOTS * 4, s) == hipSuccess &&
-         hipMemsetAsync(dt + t_lh, 0, ns * ENC_LINE_SLOTS * 8, s) == hipSuccess && hipMemsetAsync(dt + t_lf, 0xff, ns * ENC_LINE_SLOTS * 4, s) == hipSuccess && hipMemsetAsync(dt + t_fail, 0, ns * 4, s) == hipSuccess &&
+         hipMemsetAsync(dt + t_lh, 0, ns * ENC_LINE_SLOTS * 8, s) == hipSuccess && hipMemsetAsync(dt + t_lc, 0, ns * ENC_LINE_SLOTS * 8, s) == hipSuccess && hipMemsetAsync(dt + t_lf, 0xff, ns * ENC_LINE_SLOTS * 4, s) == hipSuccess && hipMemsetAsync(dt + t_fail, 0, ns * 4, s) == hipSuccess &&
          hipMemcpyAsync(dt + t_stat, stat.data(), ns * sizeof(SliceStat), hipMemcpyHostToDevice, s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
     EncDev E; memset(&E, 0, sizeof E);
     E.bam = d1 + o_bam; E.rec_off = (const uint64_t *)(d1 + o_off); E.data = d1 + o_data; E.refs = (const EncRef *)(dt + t_refs); E.nref = nrefs; E.rg_names = dt + t_rgn; E.rg_off = (const uint32_t *)(dt + t_rgo); E.nrg = nrg;
     E.slices = (const SliceDev *)(dt + t_sl); E.chunk_slice = (const uint32_t *)(dt + t_cs); E.chunk_r0 = (const uint32_t *)(dt + t_cr); E.nchunks = (uint32_t)nch;
-    E.V = EncSurvey{(uint32_t *)(dt + t_keys), (uint64_t *)(dt + t_lh), (uint32_t *)(dt + t_lf)}; E.fail = (int32_t *)(dt + t_fail); E.stat = (SliceStat *)(dt + t_stat);
+    E.V = EncSurvey{(uint32_t *)(dt + t_keys), (uint64_t *)(dt + t_lh), (uint64_t *)(dt + t_lc), (uint32_t *)(dt + t_lf)}; E.fail = (int32_t *)(dt + t_fail); E.stat = (SliceStat *)(dt + t_stat);
     E.N = N;
     PT.mark("upload");
     // ---- survey

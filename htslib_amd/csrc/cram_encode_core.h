@@ -241,13 +241,16 @@ HGR_FN bool enc_record(const EncCtx &C, uint32_t r, int64_t prev_apos, int mode,
 struct EncSurvey {
     uint32_t *keys;            // [slice][ENC_KEY_SLOTS]: tag << 8 | type, ENC_EMPTY = free
     uint64_t *lhash;           // [slice][ENC_LINE_SLOTS]: list hashes, 0 = free
+    uint64_t *lcheck;          // [slice][ENC_LINE_SLOTS]: a SECOND, independent 64-bit hash of the list that owns the slot (0 = not yet written): two lists that
+                               // collide on lhash would share a dictionary line and decode with each other's tag names -- they would have to collide on
+                               // both (128 bits) to pass unnoticed; a mismatch fails the slice with -3
     uint32_t *lfirst;          // [slice][ENC_LINE_SLOTS]: lowest record of the slice with that list
 };
 HGR_FN void enc_survey_record(const EncCtx &C, uint32_t r, const EncSurvey &V, uint32_t slice) {
     BamRec B;
     const uint64_t g = C.r0 + r;
     if (!bam_parse(C.bam, C.rec_off[g], C.rec_off[g + 1], B)) { *C.fail = -1; return; }
-    uint64_t lh = FNV0;
+    uint64_t lh = FNV0, lc = 0x9e3779b97f4a7c15ull;
     for (const uint8_t *a = B.aux; a < B.end;) {
         if (B.end - a < 3) { *C.fail = -1; return; }
         const uint32_t vs = aux_size(a[2], a + 3, B.end);
@@ -255,6 +258,7 @@ HGR_FN void enc_survey_record(const EncCtx &C, uint32_t r, const EncSurvey &V, u
         if (rg_index(C, a, vs) < 0) {
             const uint32_t key = tag_key(a);
             lh = fnv_step(lh, key);
+            lc = (lc ^ key) * 0xff51afd7ed558ccdull; lc ^= lc >> 29;                              // (a multiply-xorshift chain: nothing in common with FNV-1a)
             uint32_t *T = V.keys + (size_t)slice * ENC_KEY_SLOTS;
             uint32_t h = (key * 2654435761u) >> 25;                                              // 7 bits
             bool placed = false;
@@ -273,13 +277,25 @@ HGR_FN void enc_survey_record(const EncCtx &C, uint32_t r, const EncSurvey &V, u
     uint64_t *H = V.lhash + (size_t)slice * ENC_LINE_SLOTS; uint32_t *F = V.lfirst + (size_t)slice * ENC_LINE_SLOTS;
     uint32_t h = (uint32_t)(lh >> 40) & (ENC_LINE_SLOTS - 1u);
     if (lh == 0) lh = 1;
+    if (lc == 0) lc = 1;
+    uint64_t *K = V.lcheck + (size_t)slice * ENC_LINE_SLOTS;
     for (int probe = 0; probe < ENC_LINE_SLOTS; probe++, h = (h + 1u) & (ENC_LINE_SLOTS - 1u)) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const unsigned long long old = atomicCAS((unsigned long long *)H + h, 0ull, (unsigned long long)lh);
-        if (old == 0ull || old == lh) { atomicMin(F + h, r); return; }
+        if (old == 0ull || old == lh) {
+            const unsigned long long oc = atomicCAS((unsigned long long *)K + h, 0ull, (unsigned long long)lc);
+            if (oc != 0ull && oc != lc) { *C.fail = -3; return; }                                   // two different tag lists, one hash
+            atomicMin(F + h, r);
+            return;
+        }
 #else
         if (H[h] == 0) H[h] = lh;
-        if (H[h] == lh) { if (r < F[h]) F[h] = r; return; }
+        if (H[h] == lh) {
+            if (K[h] == 0) K[h] = lc;
+            if (K[h] != lc) { *C.fail = -3; return; }
+            if (r < F[h]) F[h] = r;
+            return;
+        }
 #endif
     }
     *C.fail = -3;

@@ -232,14 +232,14 @@ extern "C" long hgr_host_encode_slices(const uint8_t *bam, size_t bam_len, size_
     std::vector<uint8_t> rgn; std::vector<uint32_t> rgo((size_t)nrg + 1, 0);
     for (int i = 0; i < nrg; i++) { rgn.insert(rgn.end(), rg_names[i], rg_names[i] + strlen(rg_names[i])); rgo[(size_t)i + 1] = (uint32_t)rgn.size(); }
     std::vector<EncSlice> S(ns);
-    std::vector<uint32_t> keytab(ns * ENC_KEY_SLOTS, ENC_EMPTY), lfirst(ns * ENC_LINE_SLOTS, 0xffffffffu); std::vector<uint64_t> lhash(ns * ENC_LINE_SLOTS, 0);
+    std::vector<uint32_t> keytab(ns * ENC_KEY_SLOTS, ENC_EMPTY), lfirst(ns * ENC_LINE_SLOTS, 0xffffffffu); std::vector<uint64_t> lhash(ns * ENC_LINE_SLOTS, 0), lcheck(ns * ENC_LINE_SLOTS, 0);
     std::vector<int32_t> fail(ns + 1, 0);
     auto ctx_of = [&](size_t k) {
         EncCtx C{}; C.bam = bam; C.rec_off = rec_off.data(); C.data = data.data(); C.refs = er.data(); C.nref = nrefs; C.rg_names = rgn.data(); C.rg_off = rgo.data(); C.nrg = nrg;
         C.r0 = S[k].r0; C.nrec = S[k].nrec; C.keys = S[k].keys.data(); C.nkeys = (uint32_t)S[k].keys.size(); C.line_hash = S[k].lhash.data(); C.nlines = (uint32_t)S[k].lhash.size(); C.fail = &fail[k];
         return C;
     };
-    const EncSurvey V{keytab.data(), lhash.data(), lfirst.data()};
+    const EncSurvey V{keytab.data(), lhash.data(), lcheck.data(), lfirst.data()};
     for (size_t k = 0; k < ns; k++) {                                    // survey + slice statistics
         S[k].r0 = k * per_slice; S[k].nrec = (uint32_t)std::min<size_t>(per_slice, n - S[k].r0);
         const EncCtx C = ctx_of(k);
