@@ -119,9 +119,10 @@ def test_stock_htslib_reads_our_rewrite_of_the_reference_fixtures(engine, tmp_pa
     assert done >= 28, done
 
 
-def _check_they_write_we_read(engine, tmp_path, src_bam, fa, names, seqs, opts, tag, threads=4):
-    p = RC.to_cram(src_bam, str(tmp_path / (tag + ".cram")), fa, opts=("version=3.0",) + tuple(opts), threads=threads)
-    ht, theirs = RC.sam_records(p, fa)
+def _check_they_write_we_read(engine, tmp_path, src_bam, fa, names, seqs, opts, tag, threads=4, version="3.0", env=None):
+    p = RC.to_cram(src_bam, str(tmp_path / (tag + ".cram")), fa, opts=("version=" + version,) + tuple(opts), threads=threads, env=env)
+    assert open(p, "rb").read(6) == b"CRAM" + bytes([int(version[0]), int(version[2])])
+    ht, theirs = RC.sam_records(p, fa, env=env)
     rc, ours, n = _file_to_bam(engine, open(p, "rb").read(), seqs)
     assert rc == 0 and n == len(theirs), (tag, rc, n, len(theirs))
     ho, got = RC.sam_records(RC.write_bam_file(str(tmp_path / (tag + ".ours.bam")), ours))
@@ -146,3 +147,66 @@ def test_we_read_the_cram_files_stock_htslib_writes(engine, tmp_path):
     _check_they_write_we_read(engine, tmp_path, src, fa, names, seqs, ("embed_ref=1",), "embed_ref")
     _check_they_write_we_read(engine, tmp_path, src, fa, names, seqs, ("level=1", "use_bzip2=0"), "level1")
     _check_they_write_we_read(engine, tmp_path, src, fa, names, seqs, ("level=9",), "level9")
+
+
+def _block_methods(cram: bytes):
+    """the on-disk method byte of every block of a CRAM 3.x file (container walk: cram_read_container / cram_read_block, cram_io.c:3590-3760, 1414-1483)"""
+    def itf8(b, p):
+        c = b[p]
+        if c < 0x80: return c, p + 1
+        if c < 0xc0: return ((c & 0x3f) << 8) | b[p + 1], p + 2
+        if c < 0xe0: return ((c & 0x1f) << 16) | (b[p + 1] << 8) | b[p + 2], p + 3
+        if c < 0xf0: return ((c & 0x0f) << 24) | (b[p + 1] << 16) | (b[p + 2] << 8) | b[p + 3], p + 4
+        return ((c & 0x0f) << 28) | (b[p + 1] << 20) | (b[p + 2] << 12) | (b[p + 3] << 4) | (b[p + 4] & 0x0f), p + 5
+    def ltf8(b, p):
+        c = b[p]; n = 0
+        while n < 8 and c & (0x80 >> n): n += 1
+        return 0, p + 1 + n
+    methods = {}
+    p = 26
+    while p < len(cram):
+        length = struct.unpack_from("<i", cram, p)[0]; q = p + 4
+        for _ in range(3): _, q = itf8(cram, q)                           # ref id, start, span
+        _, q = itf8(cram, q)                                             # records
+        _, q = ltf8(cram, q); _, q = ltf8(cram, q)                       # record counter, bases
+        nblk, q = itf8(cram, q); nland, q = itf8(cram, q)
+        for _ in range(nland): _, q = itf8(cram, q)
+        q += 4                                                           # header CRC
+        end = q + length
+        while q < end:
+            m = cram[q]; q += 2
+            _, q = itf8(cram, q); csz, q = itf8(cram, q); _, q = itf8(cram, q)
+            methods[m] = methods.get(m, 0) + 1
+            q += csz + 4
+        p = end
+    return methods
+
+
+@pytest.mark.gpu
+@needs_ref_view
+def test_we_read_cram31_files_of_the_reference_writer_with_the_unpinned_codecs(engine, tmp_path):
+    """CRAM 3.1 END TO END, as far as this box allows.  The reference's writer (cram_encode_slice, cram_compress_block3, the fqz_slice it builds, its tok3 levels and
+    flag maps: cram_io.c:1756-1904) runs with the htscodecs stand-in switched to oracle/'s restatements of methods 5-8 (ORC_STUB_CODECS31=1) -- the codec DIALECT
+    stays unpinned (htscodecs is absent), but everything around it is the reference's: which method and flags each series gets, block framing, what the
+    quality codec is told about the records.  Our whole-file decoder (device codecs for rANS Nx16 / range coder / fqzcomp / tok3 + the record passes) must
+    give exactly what the reference's own reader makes of the same file, for every profile the reference offers."""
+    bam, names, seqs = _synthetic(engine, 4, 10000, seed=9)
+    # qualities the way a sequencer writes them (a slow walk that decays along the read): with the generator's uniform noise no quality codec ever wins a trial
+    b = bytearray(bam); at = RC.header_len(bam); rng = np.random.default_rng(3)
+    while at < len(b):
+        ln = struct.unpack_from("<i", b, at)[0]
+        l_name, n_cig, l_seq = b[at + 12], struct.unpack_from("<H", b, at + 16)[0], struct.unpack_from("<i", b, at + 20)[0]
+        q0 = at + 36 + l_name + 4 * n_cig + (l_seq + 1) // 2
+        walk = np.cumsum(rng.integers(-1, 2, l_seq)) - np.arange(l_seq) * (12.0 / max(l_seq, 1))
+        b[q0:q0 + l_seq] = np.clip(38 + walk, 2, 40).astype(np.uint8).tobytes()
+        at += 4 + ln
+    bam = bytes(b)
+    fa = RC.write_fasta(str(tmp_path / "ref.fa"), names, seqs)
+    src = RC.write_bam_file(str(tmp_path / "in.bam"), bam)
+    E = {"ORC_STUB_CODECS31": "1"}
+    seen = {}
+    for tag, opts in (("normal", ()), ("fast", ("fast",)), ("small", ("small",)), ("archive", ("archive",)),
+                      ("arith_fqz_tok", ("use_arith=1", "use_fqz=1", "use_tok=1", "level=7")), ("s3000_multi", ("seqs_per_slice=3000", "multi_seq_per_slice=1", "use_arith=1"))):
+        _check_they_write_we_read(engine, tmp_path, src, fa, names, seqs, opts, "v31_" + tag, version="3.1", env=E)
+        for m, c in _block_methods(open(tmp_path / ("v31_" + tag + ".cram"), "rb").read()).items(): seen[m] = seen.get(m, 0) + c
+    assert seen.get(5, 0) > 20 and seen.get(8, 0) > 0 and seen.get(6, 0) > 0 and seen.get(7, 0) > 0, seen     # rANS Nx16, tok3, range coder, fqzcomp blocks were all there
