@@ -1001,6 +1001,7 @@ class RefCramWorkload:
         base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
         self.dir = tempfile.mkdtemp(prefix="htsgpu_refcram_", dir=base)
         bam, names, seqs, self.nrec = synth_cram.bam_from_slices(eng, slices, copies)
+        self.bam_bytes, self.names, self.seqs = bam, names, seqs
         self.bam = os.path.join(self.dir, "in.bam"); self.fa = os.path.join(self.dir, "ref.fa"); self.cram = os.path.join(self.dir, "in_l0.cram")
         open(self.bam, "wb").write(synth.bgzf_compress(bam, level=0))
         fai = []
@@ -1038,6 +1039,64 @@ def time_ref_view(cmd, procs: int, seconds: float, env=None):
     el = time.perf_counter() - t0
     if bad or not sum(done): return None, (bad[:1] or ["no run finished"])[0]
     return sum(done) / el, None
+
+
+def op_cram31(run: Run, steps: int, copies: int = 16, nrec: int = 10000):
+    """BASELINE configs[4] as a FILE: "full CRAM 3.1 encode (rANS + name tokeniser + range coder)" of sorted 150 bp reads -- hg_bam_to_cram_host2 with
+    HG_CRAM_WRITE_V31 | HG_CRAM_WRITE_ARITH: BAM header walk, record encoder on the device (cram_encode_slice), every series block through the auto-tuner with
+    the 3.1 method sets, container framing + CRCs.  HOST entry point: the BAM goes up and the file comes back inside the timed call.  Beside it: the
+    REFERENCE's own writer on the same BAM (ref_view -C -o version=3.1, its record layer + auto-tuner; the 3.1 codecs behind the htscodecs stand-in are
+    oracle/'s scalar restatements -- htscodecs is absent)."""
+    run.init_device()
+    import ctypes as C
+    from htslib_amd import _native as nat, synth_cram
+    eng = nat.Engine(run.local)
+    rng = np.random.default_rng(7)
+    base = [synth_cram.make_slice(rng, nrec, 150, tags=True) for _ in range(4)]
+    w = RefCramWorkload(eng, base, copies)
+    try:
+        bam = w.bam_bytes
+
+        class RefSeq(C.Structure):
+            _fields_ = [("bases", C.c_void_p), ("len", C.c_uint64)]
+        keep = [C.create_string_buffer(q, len(q)) for q in w.seqs]
+        arr = (RefSeq * len(keep))(*[RefSeq(C.addressof(k), len(q)) for k, q in zip(keep, w.seqs)])
+        out = np.zeros(len(bam) + (1 << 20), np.uint8); tot = C.c_uint64(); n = C.c_uint64()
+        bb = C.create_string_buffer(bam, len(bam))
+        flags = 3
+        ts = []
+        for _ in range(max(3, steps) + 1):
+            t = time.perf_counter()
+            rc = nat.lib.hg_bam_to_cram_host2(eng._h, C.cast(bb, C.c_void_p), len(bam), C.cast(arr, C.c_void_p), len(keep), nrec, 5, flags, out.ctypes.data, len(out), C.byref(tot), C.byref(n))
+            ts.append(time.perf_counter() - t)
+            assert rc == 0 and n.value == w.nrec, (rc, n.value)
+        t = sorted(ts[1:])[len(ts[1:]) // 2]
+        cram = bytes(out[:tot.value])
+        # verification outside the timed region: our own whole-file decoder gives the records back
+        back = np.zeros(len(bam) + (1 << 22), np.uint8); bt = C.c_uint64(); bn = C.c_uint64()
+        cb = C.create_string_buffer(cram, len(cram))
+        rc = nat.lib.hg_cram_file_to_bam_host2(eng._h, C.cast(cb, C.c_void_p), len(cram), C.cast(arr, C.c_void_p), len(keep), back.ctypes.data, len(back), C.byref(bt), C.byref(bn), 0, None)
+        verified = rc == 0 and bn.value == w.nrec
+        res = {"metric": "full CRAM 3.1 file encode: BAM -> CRAM 3.1 (record encoder + block auto-tuner with rANS Nx16 / range coder / tok3 + framing), M records/s, host entry point incl. PCIe",
+               "value": round(w.nrec / t / 1e6, 3), "unit": "M records/s", "n_gpus": 1, "steps": max(3, steps), "warmup": 1, "ms_per_step": round(t * 1e3, 2), "higher_is_better": True,
+               "dtype": "u8", "data": "synthetic", "verified": bool(verified),
+               "config": {"workload": "%d slices x %d records x 150 bp on %d references, tags; BAM %.2f GB -> CRAM 3.1 %.3f GB" % (w.nrec // nrec, nrec, len(keep), len(bam) / 1e9, len(cram) / 1e9),
+                          "bam_GBps": round(len(bam) / t / 1e9, 3), "cram_ratio": round(len(cram) / len(bam), 4),
+                          "parity": "tests/test_reference_cram.py: the reference's reader (htscodecs stand-in on oracle/'s codecs: dialect unpinned) reads these files back to the input records"},
+               "roofline": {"bound": "hbm", "achieved": round((2 * len(bam) + len(cram)) / t / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((2 * len(bam) + len(cram)) / t / 1e9 / HBM_PEAK_GBS, 6),
+                            "traffic": None, "kernel": "whole host call (PCIe both ways, record encoder, ~30 codec launches per auto-tuner round)", "algorithmic_bytes": int(2 * len(bam) + len(cram))}}
+        if run.world == 1 and not run.args.no_cpu_baseline and have_ref_view():
+            threads = 4; procs = max(1, min(64, run.ncores // threads))
+            env = dict(os.environ, ORC_STUB_CODECS31="1")
+            cmd = [REF_VIEW, "-@", str(threads), "-C", "-o", "version=3.1", "-o", "use_arith=1", "-t", w.fa, "-p", "/dev/null", w.bam]
+            rate, err = time_ref_view(cmd, procs, 12.0, env=env)
+            res["cpu_baseline"] = {"error": err} if rate is None else {
+                "value": round(rate * w.nrec / 1e6, 3), "unit": "M records/s", "cores": procs * threads, "kind": "reference",
+                "sample": "the reference's writer (ref_view -C -o version=3.1 -o use_arith=1: bam_read1, cram_encode_slice, cram_compress_block3, framing) with ORC_STUB_CODECS31=1 = "
+                          "oracle/'s scalar restatements behind the htscodecs stand-in (NOT htscodecs): %d processes x -@%d on the same %d-record BAM for 12 s" % (procs, threads, w.nrec)}
+        return res
+    finally:
+        w.close()
 
 
 def cpu_baseline_reference_records(eng, slices, ncores: int, mode: str, seconds: float = 10.0):
@@ -1368,7 +1427,7 @@ def main():
     ap.add_argument("--gib", type=float, default=10.0, help="plain GiB of synthetic BAM per GPU")
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--workers", type=int, default=0, help="host processes for workload preparation")
-    ap.add_argument("--op", choices=["all", "inflate", "deflate", "rans", "bam", "cram", "e2e", "records", "fqz", "encode"], default="all",
+    ap.add_argument("--op", choices=["all", "inflate", "deflate", "rans", "bam", "cram", "e2e", "records", "fqz", "encode", "cram31"], default="all",
                     help="all (default) = inflate headline (BASELINE configs[1]) + `extra`: deflate (configs[2]), rans (configs[3]), "
                          "cram (configs[4] shape) and the end-to-end bgzf_read / bgzf_write figures, in ONE JSON line; "
                          "a single op prints that op's line alone; bam = SURVEY 8f N1 (record framing + nibble2base)")
@@ -1384,7 +1443,9 @@ def main():
     run = Run(args)
     ok = True
     out = None
-    if args.op in ("records", "fqz", "encode"):
+    if args.op == "cram31":
+        out = op_cram31(run, args.steps, max(1, (args.slices or 64) // 4))
+    elif args.op in ("records", "fqz", "encode"):
         out = op_records(run, args.steps, args.slices or 256) if args.op == "records" else op_encode(run, args.steps, args.slices or 64) if args.op == "encode" else op_fqz(run, args.steps, args.slices or 512)
     elif args.op in ("rans", "cram"):
         if args.op == "rans":
@@ -1427,7 +1488,8 @@ def main():
                 d, ok2 = op_cram(run, es, 256 if not args.slices else args.slices); ok = ok and ok2
                 if d: extra["cram_slices"] = d
                 if run.rank == 0 and run.world == 1:                         # the "next" rows of SURVEY 8f built this round: small, guarded probes
-                    for key, fn in (("cram_records_to_bam", lambda: op_records(run, 5)), ("cram_records_encode", lambda: op_encode(run, 5)), ("cram_fqzcomp", lambda: op_fqz(run, 5, 256))):
+                    for key, fn in (("cram_records_to_bam", lambda: op_records(run, 5)), ("cram_records_encode", lambda: op_encode(run, 5)), ("cram31_file_encode", lambda: op_cram31(run, 3)),
+                                    ("cram_fqzcomp", lambda: op_fqz(run, 5, 256))):
                         try:
                             extra[key] = fn()
                         except Exception as e:

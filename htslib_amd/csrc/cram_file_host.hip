@@ -389,7 +389,17 @@ void put32le(std::vector<uint8_t> &o, uint32_t v) { for (int i = 0; i < 4; i++) 
 
 extern "C" int hg_bam_to_cram_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, const hg_cram_ref_seq *refs, int nrefs_given, uint32_t records_per_slice, int level,
                                    uint8_t *cram_out, size_t cram_cap, uint64_t *cram_bytes, uint64_t *nrecords) {
+    return hg_bam_to_cram_host2(ctx, bam, bam_len, refs, nrefs_given, records_per_slice, level, 0, cram_out, cram_cap, cram_bytes, nrecords);
+}
+
+// flags: HG_CRAM_WRITE_V31 = a CRAM 3.1 file -- the block auto-tuner is offered what cram_compress_slice offers a 3.1 writer with use_rans and use_tok
+// (htslib's "normal" profile): GZIP, GZIP_RLE, (level >= 5) GZIP_1, rANS Nx16 PR0 / PR1 (+ PR64 / PR9 / PR128 / PR193 above level 1, + PR129 / PR192 above
+// level 5), the read names TOK3 instead of rANS (cram_encode.c:818-826, 937-942); HG_CRAM_WRITE_ARITH adds the range coder's sets (use_arith, :833-845; names: TOKA).
+// Without V31: the CRAM 3.0 set GZIP | rANS 4x8.  fqzcomp is not offered (the writer would have to hand the quality block's per-record lengths over).
+extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, const hg_cram_ref_seq *refs, int nrefs_given, uint32_t records_per_slice, int level,
+                                    int flags, uint8_t *cram_out, size_t cram_cap, uint64_t *cram_bytes, uint64_t *nrecords) {
     if (!ctx || !bam || !cram_out || !cram_bytes || (nrefs_given && !refs)) return HG_EINVAL;
+    const bool v31 = (flags & HG_CRAM_WRITE_V31) != 0, arith = v31 && (flags & HG_CRAM_WRITE_ARITH) != 0;
     if (!records_per_slice) records_per_slice = 10000;                   // the reference's default (cram/cram_structs.h:87-89)
     if (level <= 0) level = 5;
     // ---- 1. BAM header
@@ -452,7 +462,22 @@ extern "C" int hg_bam_to_cram_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_l
     const size_t nb = blks.size();
     std::vector<std::vector<uint8_t>> cdata(nb); std::vector<uint32_t> clen(nb, 0); std::vector<int32_t> cmeth(nb, 0);
     if (nb) {
-        std::vector<hg_cram_metrics *> mp(nb); std::vector<uint32_t> sets(nb, (1u << 1) | (1u << 4) | (1u << 16));      // GZIP, RANS0, RANS1 (internal method ids)
+        // method sets per block (internal method ids of cram/cram_structs.h:215-266: GZIP 1, RANS0 4, RANS_PR0 5, ARITH_PR0 6, TOK3 8, GZIP_RLE 11, GZIP_1 12, RANS1 16,
+        // RANS_PR1 / 64 / 9 / 128 / 129 / 192 / 193 = 17..23, TOKA 24, ARITH_PR1 / 64 / 9 / 128 / 129 / 192 / 193 = 25..31)
+        uint32_t set_gen = (1u << 1) | (1u << 4) | (1u << 16), set_rn = set_gen;
+        if (v31) {
+            uint32_t ranspr = (1u << 5) | (1u << 17);
+            if (level > 1) ranspr |= (1u << 18) | (1u << 19) | (1u << 20) | (1u << 23);
+            if (level > 5) ranspr |= (1u << 21) | (1u << 22);
+            set_gen = (1u << 1) | (1u << 11) | ranspr;
+            if (arith) { set_gen |= (1u << 6) | (1u << 25); if (level > 1) set_gen |= (1u << 26) | (1u << 27) | (1u << 28) | (1u << 29) | (1u << 30) | (1u << 31); }
+            if (level >= 5) set_gen |= 1u << 12;
+            if (level == 1) set_gen = (set_gen & ~(1u << 1)) | (1u << 12);
+            set_rn = (set_gen & ~(ranspr | (1u << 11))) | (arith ? 1u << 24 : 1u << 8);
+        }
+        const int32_t cid_rn = 10 + 6;                                                                                   // the RN series (cram_encode_plan.h: content id 10 + series)
+        std::vector<hg_cram_metrics *> mp(nb); std::vector<uint32_t> sets(nb, set_gen);
+        for (size_t i = 0; i < nb; i++) if (blks[i].cid == cid_rn) sets[i] = set_rn;
         std::vector<const uint8_t *> in(nb); std::vector<uint32_t> il(nb); std::vector<uint8_t *> out(nb);
         // Several devices (HTS_GPU_DEVICES): the slices are cut into one contiguous range per device; a range has its OWN set of cram_metrics
         // (one per content id, as cram_encode.c keeps one per data series) and learns its methods from its own blocks in file order, on its own
@@ -507,7 +532,7 @@ extern "C" int hg_bam_to_cram_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_l
         return shift;
     };
     // file definition: "CRAM", 3.0, 20-byte file id
-    o.insert(o.end(), {'C', 'R', 'A', 'M', 3, 0}); { const char id[20] = "htslib_amd"; o.insert(o.end(), id, id + 20); }
+    o.insert(o.end(), {'C', 'R', 'A', 'M', 3, (uint8_t)(v31 ? 1 : 0)}); { const char id[20] = "htslib_amd"; o.insert(o.end(), id, id + 20); }
     // blocks of a container are built in a scratch vector first (the container header needs their total size); CRC slots are re-based afterwards
     auto build = [&](auto &&fill) {
         std::vector<uint8_t> saved; saved.swap(o);

@@ -501,6 +501,13 @@ long hg_cram_index_build_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len,
  * container / block layout follows the reference's writer, but no stock htslib was available to read these files here. */
 int hg_bam_to_cram_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, const hg_cram_ref_seq *refs, int nrefs_given,
                         uint32_t records_per_slice, int level, uint8_t *cram_out, size_t cram_cap, uint64_t *cram_bytes, uint64_t *nrecords);
+/* ... with flags: HG_CRAM_WRITE_V31 = a CRAM 3.1 file whose blocks go through the auto-tuner with the method sets cram_compress_slice gives a 3.1 writer with
+ * use_rans + use_tok (htslib's default profile: rANS Nx16 with PACK / RLE / STRIPE / order-1 variants by level, TOK3 for the read names, GZIP);
+ * HG_CRAM_WRITE_ARITH adds the range coder's sets (use_arith; names: TOKA).  Codec format parity with htscodecs is UNPINNED. */
+#define HG_CRAM_WRITE_V31   1
+#define HG_CRAM_WRITE_ARITH 2
+int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, const hg_cram_ref_seq *refs, int nrefs_given,
+                         uint32_t records_per_slice, int level, int flags, uint8_t *cram_out, size_t cram_cap, uint64_t *cram_bytes, uint64_t *nrecords);
 
 /* The .crai text of one slice (cram_index_slice / cram_index_build_multiref, cram/cram_index.c:632-728): "ref start span container_pos
  * landmark slice_bytes" -- one line from the slice header, or, for a multi-reference slice, one line per run of records on the same

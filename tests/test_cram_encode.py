@@ -249,13 +249,14 @@ def _file_to_bam(engine, cram, seqs, flags=0):
     return rc, bytes(out[:total.value]), n.value
 
 
-def _bam_to_cram(engine, bam, seqs, per_slice=0):
+def _bam_to_cram(engine, bam, seqs, per_slice=0, flags=0, level=5):
+    """flags: 1 = CRAM 3.1 (rANS Nx16 + tok3 sets), 3 = + the range coder's sets (hg_bam_to_cram_host2)"""
     from htslib_amd import _native as nat
     keep = [C.create_string_buffer(bytes(q), len(q)) if q is not None else None for q in seqs]
     arr = (RefSeq * max(len(seqs), 1))(*[RefSeq(C.addressof(k), len(q)) if k is not None else RefSeq(None, 0) for k, q in zip(keep, seqs)])
     out = np.zeros(len(bam) * 2 + (1 << 20), np.uint8); total = C.c_uint64(); n = C.c_uint64()
     b = C.create_string_buffer(bam, len(bam))
-    rc = nat.lib.hg_bam_to_cram_host(engine._h, C.cast(b, _vp), len(bam), C.cast(arr, _vp), len(seqs), per_slice, 5, out.ctypes.data, len(out), C.byref(total), C.byref(n))
+    rc = nat.lib.hg_bam_to_cram_host2(engine._h, C.cast(b, _vp), len(bam), C.cast(arr, _vp), len(seqs), per_slice, level, flags, out.ctypes.data, len(out), C.byref(total), C.byref(n))
     return rc, bytes(out[:total.value]), n.value
 
 

@@ -48,14 +48,15 @@ def test_ref_view_round_trips_through_its_own_cram30_writer(tmp_path):
     assert RC.sam_records(str(tmp_path / "v31.cram"))[1] == r1
 
 
-def _check_we_write_they_read(engine, tmp_path, bam, names, seqs, per_slice, tag, md_default=False):
-    rc, cram, n = _bam_to_cram(engine, bam, seqs, per_slice)
+def _check_we_write_they_read(engine, tmp_path, bam, names, seqs, per_slice, tag, md_default=False, flags=0, level=5, env=None):
+    rc, cram, n = _bam_to_cram(engine, bam, seqs, per_slice, flags, level)
     assert rc == 0, (tag, rc)
+    assert cram[:6] == b"CRAM\x03" + bytes([1 if flags & 1 else 0])
     p = str(tmp_path / (tag + ".cram")); open(p, "wb").write(cram)
     fa = RC.write_fasta(str(tmp_path / (tag + ".fa")), names, seqs) if any(s is not None for s in seqs) else None
     src = RC.write_bam_file(str(tmp_path / (tag + ".bam")), bam)
     hw, want = RC.sam_records(src)
-    hg, got = RC.sam_records(p, fa, extra=() if md_default else ("-i", "decode_md=0"))
+    hg, got = RC.sam_records(p, fa, extra=() if md_default else ("-i", "decode_md=0"), env=env)
     assert len(want) == n
     # the RG:Z tag of a record becomes the RG series and comes back at the end of the tag list (cram_decode.c:3178-3190): compare with RG moved there
     def norm(l):
@@ -65,7 +66,25 @@ def _check_we_write_they_read(engine, tmp_path, bam, names, seqs, per_slice, tag
     d = RC.first_difference([norm(l) for l in got], [norm(l) for l in want])
     assert d is None, (tag, d)
     assert [l for l in hg if l[:3] in (b"@SQ", b"@RG")] and len([l for l in hg if l.startswith(b"@SQ")]) == len(names)
-    return len(cram)
+    return cram
+
+
+@pytest.mark.gpu
+@needs_ref_view
+def test_the_reference_reader_reads_the_cram31_files_we_write(engine, tmp_path):
+    """BASELINE configs[4], "full CRAM 3.1 encode": hg_bam_to_cram_host2 with HG_CRAM_WRITE_V31 (+ HG_CRAM_WRITE_ARITH) -- record encoder on the device, every series
+    through the block auto-tuner with the method sets cram_compress_slice gives a 3.1 writer (rANS Nx16 variants, tok3 for the names, the range coder, gzip).  The
+    reference's READER (ref_view with the htscodecs stand-in on oracle/'s codecs: the codec dialect is unpinned, the container / block / record layers are the
+    reference's) must give back the records that went in; so must our own decoder; and the 3.1 methods must actually have been chosen."""
+    bam, names, seqs = _synthetic(engine, 4, 10000, seed=13)
+    E = {"ORC_STUB_CODECS31": "1"}
+    seen = {}
+    for tag, flags, level, per in (("v31", 1, 5, 10000), ("v31_arith", 3, 5, 10000), ("v31_l7_multi", 3, 7, 7000), ("v31_l1", 1, 1, 10000)):
+        cram = _check_we_write_they_read(engine, tmp_path, bam, names, seqs, per, tag, flags=flags, level=level, env=E)
+        for m, c in _block_methods(cram).items(): seen[m] = seen.get(m, 0) + c
+        rc, back, n = _file_to_bam(engine, cram, seqs)
+        assert rc == 0 and n == 40000, (tag, rc)
+    assert seen.get(5, 0) > 20 and seen.get(8, 0) >= 4 and seen.get(6, 0) > 0 and seen.get(4, 0) == 0, seen      # rANS Nx16, tok3, range coder; no 4x8 in a 3.1 file
 
 
 @pytest.mark.gpu
