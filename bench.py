@@ -1043,7 +1043,7 @@ def time_ref_view(cmd, procs: int, seconds: float, env=None):
 
 def op_cram31(run: Run, steps: int, copies: int = 16, nrec: int = 10000):
     """BASELINE configs[4] as a FILE: "full CRAM 3.1 encode (rANS + name tokeniser + range coder)" of sorted 150 bp reads -- hg_bam_to_cram_host2 with
-    HG_CRAM_WRITE_V31 | HG_CRAM_WRITE_ARITH: BAM header walk, record encoder on the device (cram_encode_slice), every series block through the auto-tuner with
+    HG_CRAM_WRITE_V31 (HG_BENCH_CRAM31_FLAGS=3 adds HG_CRAM_WRITE_ARITH): BAM header walk, record encoder on the device (cram_encode_slice), every series block through the auto-tuner with
     the 3.1 method sets, container framing + CRCs.  HOST entry point: the BAM goes up and the file comes back inside the timed call.  Beside it: the
     REFERENCE's own writer on the same BAM (ref_view -C -o version=3.1, its record layer + auto-tuner; the 3.1 codecs behind the htscodecs stand-in are
     oracle/'s scalar restatements -- htscodecs is absent)."""
@@ -1063,7 +1063,7 @@ def op_cram31(run: Run, steps: int, copies: int = 16, nrec: int = 10000):
         arr = (RefSeq * len(keep))(*[RefSeq(C.addressof(k), len(q)) for k, q in zip(keep, w.seqs)])
         out = np.zeros(len(bam) + (1 << 20), np.uint8); tot = C.c_uint64(); n = C.c_uint64()
         bb = C.create_string_buffer(bam, len(bam))
-        flags = 3
+        flags = int(os.environ.get("HG_BENCH_CRAM31_FLAGS", "1"))      # 1 = rANS Nx16 + tok3 (htslib's default 3.1 profile), 3 = + the range coder (TOKA for the names: ~5x the time)
         ts = []
         for _ in range(max(3, steps) + 1):
             t = time.perf_counter()
@@ -1077,7 +1077,7 @@ def op_cram31(run: Run, steps: int, copies: int = 16, nrec: int = 10000):
         cb = C.create_string_buffer(cram, len(cram))
         rc = nat.lib.hg_cram_file_to_bam_host2(eng._h, C.cast(cb, C.c_void_p), len(cram), C.cast(arr, C.c_void_p), len(keep), back.ctypes.data, len(back), C.byref(bt), C.byref(bn), 0, None)
         verified = rc == 0 and bn.value == w.nrec
-        res = {"metric": "full CRAM 3.1 file encode: BAM -> CRAM 3.1 (record encoder + block auto-tuner with rANS Nx16 / range coder / tok3 + framing), M records/s, host entry point incl. PCIe",
+        res = {"metric": "full CRAM 3.1 file encode: BAM -> CRAM 3.1 (record encoder + block auto-tuner with rANS Nx16 / tok3%s + framing), M records/s, host entry point incl. PCIe" % (" / range coder" if flags & 2 else ""),
                "value": round(w.nrec / t / 1e6, 3), "unit": "M records/s", "n_gpus": 1, "steps": max(3, steps), "warmup": 1, "ms_per_step": round(t * 1e3, 2), "higher_is_better": True,
                "dtype": "u8", "data": "synthetic", "verified": bool(verified),
                "config": {"workload": "%d slices x %d records x 150 bp on %d references, tags; BAM %.2f GB -> CRAM 3.1 %.3f GB" % (w.nrec // nrec, nrec, len(keep), len(bam) / 1e9, len(cram) / 1e9),
@@ -1088,11 +1088,11 @@ def op_cram31(run: Run, steps: int, copies: int = 16, nrec: int = 10000):
         if run.world == 1 and not run.args.no_cpu_baseline and have_ref_view():
             threads = 4; procs = max(1, min(64, run.ncores // threads))
             env = dict(os.environ, ORC_STUB_CODECS31="1")
-            cmd = [REF_VIEW, "-@", str(threads), "-C", "-o", "version=3.1", "-o", "use_arith=1", "-t", w.fa, "-p", "/dev/null", w.bam]
+            cmd = [REF_VIEW, "-@", str(threads), "-C", "-o", "version=3.1"] + (["-o", "use_arith=1"] if flags & 2 else []) + ["-t", w.fa, "-p", "/dev/null", w.bam]
             rate, err = time_ref_view(cmd, procs, 12.0, env=env)
             res["cpu_baseline"] = {"error": err} if rate is None else {
                 "value": round(rate * w.nrec / 1e6, 3), "unit": "M records/s", "cores": procs * threads, "kind": "reference",
-                "sample": "the reference's writer (ref_view -C -o version=3.1 -o use_arith=1: bam_read1, cram_encode_slice, cram_compress_block3, framing) with ORC_STUB_CODECS31=1 = "
+                "sample": "the reference's writer (ref_view -C -o version=3.1: bam_read1, cram_encode_slice, cram_compress_block3, framing) with ORC_STUB_CODECS31=1 = "
                           "oracle/'s scalar restatements behind the htscodecs stand-in (NOT htscodecs): %d processes x -@%d on the same %d-record BAM for 12 s" % (procs, threads, w.nrec)}
         return res
     finally:

@@ -496,11 +496,12 @@ extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_
                 }
         std::vector<int> rrc(nr, HG_OK);
         auto run = [&](size_t r) {
-            // slice by slice, so that the metrics see the blocks of a series in file order (trial phase first, then the learnt method)
-            for (size_t k = scut[r]; k < scut[r + 1] && rrc[r] == HG_OK; k++) {
-                const size_t a = parts[k].b0, n = parts[k].b1 - a;
-                if (n) rrc[r] = hg_cram_compress_blocks_metrics_host(ctxs[r], n, mp.data() + a, sets.data() + a, level, 3, in.data() + a, il.data() + a, out.data() + a, clen.data() + a, cmeth.data() + a);
-            }
+            // ALL blocks of the range in one call, in file order: the auto-tuner works through the blocks that share a metrics object in their order and
+            // splits the call into rounds where a trial phase ends (hg_cram_compress_blocks_metrics_host), so the decisions are those of a slice-by-slice
+            // walk -- which is what this was until round 4: one call per slice = ~30 latency-bound launches per slice, 12.7 s for 64 slices with the
+            // fourteen-method sets of a 3.1 writer.  A few rounds now, each one batch over every slice.
+            const size_t a = parts[scut[r]].b0, n = parts[scut[r + 1] - 1].b1 - a;
+            if (n) rrc[r] = hg_cram_compress_blocks_metrics_host(ctxs[r], n, mp.data() + a, sets.data() + a, level, 3, in.data() + a, il.data() + a, out.data() + a, clen.data() + a, cmeth.data() + a);
         };
         {
             std::vector<std::thread> th;
