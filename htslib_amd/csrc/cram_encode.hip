@@ -42,7 +42,7 @@ struct EncTimer {
 
 namespace hgr {
 
-struct SliceStat { int32_t min_ref, max_ref; long long min_pos, max_end; };
+struct SliceStat { int32_t min_ref, max_ref; long long min_pos, max_end; unsigned long long bases; };   // bases: sum of l_seq (the container header's base count)
 struct EncDev {
     const uint8_t *bam; const uint64_t *rec_off; const uint8_t *data; const EncRef *refs; int32_t nref; const uint8_t *rg_names; const uint32_t *rg_off; int32_t nrg;
     const SliceDev *slices; const uint32_t *chunk_slice, *chunk_r0; uint32_t nchunks;
@@ -74,6 +74,7 @@ void enc_survey_kernel(EncDev E) {
     const long long ap = (long long)B.pos + 1, ae = rl ? ap + rl - 1 : ap;
     SliceStat *st = E.stat + k;
     atomicMin(&st->min_ref, B.ref_id); atomicMax(&st->max_ref, B.ref_id); atomicMin(&st->min_pos, ap); atomicMax(&st->max_end, ae);
+    atomicAdd(&st->bases, (unsigned long long)B.l_seq);
 }
 template <bool WRITE>
 __global__ __launch_bounds__(ENC_CHUNK)
@@ -109,20 +110,55 @@ void enc_walk_kernel(EncDev E) {
 extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, size_t nrec, uint32_t records_per_slice, const hg_cram_ref_seq *refs, int nrefs,
                                           const char *const *rg_names, int nrg, int64_t record_counter0, uint8_t *out, size_t out_cap, uint64_t *slice_off, size_t max_slices,
                                           int32_t *status, uint64_t *out_bytes) {
+    if (!nrec) { if (!ctx || !records_per_slice) return HG_EINVAL; if (out_bytes) *out_bytes = 0; if (slice_off) slice_off[0] = 0; return HG_OK; }
+    size_t n = nrec;
+    return hg_cram_encode_slices_host2(ctx, bam, bam_len, &n, records_per_slice, refs, nrefs, rg_names, nrg, record_counter0, out, out_cap, slice_off, max_slices, status, out_bytes, nullptr);
+}
+
+// *nrec_io = 0 on entry: the records are counted here (bam_read1's framing runs on the device anyway); on return the number of records.  slice_bases (may be
+// NULL): per slice the sum of the records' l_seq -- what the container header of cram_write_container wants -- from the survey pass.
+extern "C" int hg_cram_encode_slices_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, size_t *nrec_io, uint32_t records_per_slice, const hg_cram_ref_seq *refs, int nrefs,
+                                           const char *const *rg_names, int nrg, int64_t record_counter0, uint8_t *out, size_t out_cap, uint64_t *slice_off, size_t max_slices,
+                                           int32_t *status, uint64_t *out_bytes, uint64_t *slice_bases) {
     using namespace hgr;
-    if (!ctx || (nrec && (!bam || !out || !slice_off || !status)) || !records_per_slice || (nrefs && !refs) || (nrg && !rg_names)) return HG_EINVAL;
-    const size_t ns = (nrec + records_per_slice - 1) / records_per_slice;
-    if (ns > max_slices) return HG_ENOMEM;
+    if (!ctx || !nrec_io || !bam || !out || !slice_off || !status || !records_per_slice || (nrefs && !refs) || (nrg && !rg_names)) return HG_EINVAL;
+    const size_t nrec_in = *nrec_io, nrec_bound = nrec_in ? nrec_in : bam_len / 36 + 1;       // (a record is at least 36 bytes: block_size + the fixed fields)
     if (out_bytes) *out_bytes = 0;
-    if (!nrec) { slice_off[0] = 0; return HG_OK; }
+    if (bam_len < 36) { if (nrec_in) return HG_EINVAL; *nrec_io = 0; slice_off[0] = 0; return bam_len ? HG_EINVAL : HG_OK; }
     hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
     // ---- lay out references and read-group names (the records are framed on the device: a host walk of the block_size fields is one cache miss
     //      per record, 50 ms for 640 k records -- more than everything else in this call)
-    std::vector<uint64_t> rec_off(nrec + 1);
     std::vector<EncRef> er((size_t)nrefs + 1); uint64_t dbytes = 0;
     for (int i = 0; i < nrefs; i++) { er[(size_t)i].off = dbytes; er[(size_t)i].len = refs[i].bases ? (int64_t)refs[i].len : 0; if (refs[i].bases) dbytes += (refs[i].len + 15) & ~15ull; }
     std::vector<uint8_t> rgn; std::vector<uint32_t> rgo((size_t)nrg + 1, 0);
     for (int i = 0; i < nrg; i++) { rgn.insert(rgn.end(), rg_names[i], rg_names[i] + strlen(rg_names[i])); rgo[(size_t)i + 1] = (uint32_t)rgn.size(); }
+    hipStream_t s = ctx->stream;
+    int rc;
+    EncTimer PT(s);
+    // ---- device image 1: BAM, offsets, references, small tables
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_bam = 0, o_off = al(bam_len + 64), o_data = o_off + al((nrec_bound + 1) * 8), o_end1 = o_data + al(dbytes + 64);
+    if ((rc = hg::ensure_scratch(ctx, 0, o_end1))) return rc;
+    uint8_t *d1 = (uint8_t *)ctx->d_scratch[0];
+    bool ok = hipMemcpyAsync(d1 + o_bam, bam, bam_len, hipMemcpyHostToDevice, s) == hipSuccess;
+    size_t nrec = 0;
+    std::vector<uint64_t> rec_off;
+    if (ok) {                                                            // bam_read1's framing, exact (hg_bam_frame_dev verifies its per-chunk guesses link by link)
+        uint64_t bad = 0, end = bam_len;
+        const long got = hg_bam_frame_dev(ctx, d1 + o_bam, bam_len, 0, 0x7fffffff, (uint64_t *)(d1 + o_off), nrec_bound, &bad, s);
+        if (got < 0) return got == HG_BAM_ETRUNC || got == HG_BAM_EINVALID ? HG_EINVAL : (int)got;
+        if ((nrec_in && (size_t)got != nrec_in) || (size_t)got > nrec_bound) return HG_EINVAL;
+        nrec = (size_t)got; *nrec_io = nrec;
+        if (!nrec) { slice_off[0] = 0; return HG_OK; }
+        rec_off.resize(nrec + 1);
+        ok = hipMemcpyAsync(d1 + o_off + nrec * 8, &end, 8, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(rec_off.data(), d1 + o_off, nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipStreamSynchronize(s) == hipSuccess;
+        rec_off[nrec] = bam_len;
+    }
+    if (!ok) return HG_ELAUNCH;
+    PT.mark("upload + frame");
+    const size_t ns = (nrec + records_per_slice - 1) / records_per_slice;
+    if (ns > max_slices) return HG_ENOMEM;
     std::vector<SliceDev> sl(ns); std::vector<uint32_t> chunk_slice, chunk_r0, list(ns);
     std::vector<EncSlice> S(ns);
     for (size_t k = 0; k < ns; k++) {
@@ -131,25 +167,6 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
         for (uint32_t r0 = 0; r0 < S[k].nrec; r0 += ENC_CHUNK) { chunk_slice.push_back((uint32_t)k); chunk_r0.push_back(r0); }
     }
     const size_t N = (nrec + 16) & ~(size_t)15, nch = chunk_slice.size();
-    hipStream_t s = ctx->stream;
-    int rc;
-    EncTimer PT(s);
-    PT.mark("frame");
-    // ---- device image 1: BAM, offsets, references, small tables
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t o_bam = 0, o_off = al(bam_len + 64), o_data = o_off + al((nrec + 1) * 8), o_end1 = o_data + al(dbytes + 64);
-    if ((rc = hg::ensure_scratch(ctx, 0, o_end1))) return rc;
-    uint8_t *d1 = (uint8_t *)ctx->d_scratch[0];
-    bool ok = hipMemcpyAsync(d1 + o_bam, bam, bam_len, hipMemcpyHostToDevice, s) == hipSuccess;
-    if (ok) {                                                            // bam_read1's framing, exact (hg_bam_frame_dev verifies its per-chunk guesses link by link)
-        uint64_t bad = 0, end = bam_len;
-        const long got = hg_bam_frame_dev(ctx, d1 + o_bam, bam_len, 0, 0x7fffffff, (uint64_t *)(d1 + o_off), nrec, &bad, s);
-        if (got < 0) return got == HG_BAM_ETRUNC || got == HG_BAM_EINVALID ? HG_EINVAL : (int)got;
-        if ((size_t)got != nrec) return HG_EINVAL;
-        ok = hipMemcpyAsync(d1 + o_off + nrec * 8, &end, 8, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(rec_off.data(), d1 + o_off, nrec * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
-             hipStreamSynchronize(s) == hipSuccess;
-        rec_off[nrec] = bam_len;
-    }
     for (int i = 0; i < nrefs && ok; i++) if (refs[i].bases && refs[i].len) ok = hipMemcpyAsync(d1 + o_data + er[(size_t)i].off, refs[i].bases, refs[i].len, hipMemcpyHostToDevice, s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
     size_t tb = 0;
@@ -159,7 +176,7 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
                  t_k2 = carve(ns * ENC_MAX_TAGS * 4 + 4), t_ko = carve((ns + 1) * 4), t_l2 = carve(ns * ENC_MAX_LINES * 8 + 8), t_lo = carve((ns + 1) * 4), t_start = carve(ns * 8), t_multi = carve(ns);
     if ((rc = hg::ensure_scratch(ctx, 2, tb + 64))) return rc;
     uint8_t *dt = (uint8_t *)ctx->d_scratch[2];
-    std::vector<SliceStat> stat(ns, SliceStat{INT32_MAX, INT32_MIN, INT64_MAX, INT64_MIN});
+    std::vector<SliceStat> stat(ns, SliceStat{INT32_MAX, INT32_MIN, INT64_MAX, INT64_MIN, 0});
     ok = hipMemcpyAsync(dt + t_refs, er.data(), er.size() * sizeof(EncRef), hipMemcpyHostToDevice, s) == hipSuccess && (rgn.empty() || hipMemcpyAsync(dt + t_rgn, rgn.data(), rgn.size(), hipMemcpyHostToDevice, s) == hipSuccess) &&
          hipMemcpyAsync(dt + t_rgo, rgo.data(), rgo.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dt + t_sl, sl.data(), ns * sizeof(SliceDev), hipMemcpyHostToDevice, s) == hipSuccess &&
          hipMemcpyAsync(dt + t_cs, chunk_slice.data(), nch * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dt + t_cr, chunk_r0.data(), nch * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
@@ -185,6 +202,7 @@ extern "C" int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_
     std::vector<uint32_t> k2, ko(ns + 1, 0), lo(ns + 1, 0); std::vector<uint64_t> l2; std::vector<int64_t> start(ns); std::vector<uint8_t> multi(ns);
     size_t ncmax = W_N;
     for (size_t k = 0; k < ns; k++) {
+        if (slice_bases) slice_bases[k] = stat[k].bases;
         S[k].fail = fail[k]; S[k].min_ref = stat[k].min_ref; S[k].max_ref = stat[k].max_ref; S[k].min_pos = stat[k].min_pos; S[k].max_end = stat[k].max_end;
         enc_survey_finish(keytab.data() + k * ENC_KEY_SLOTS, lhash.data() + k * ENC_LINE_SLOTS, lfirst.data() + k * ENC_LINE_SLOTS, S[k]);
         fail[k] = S[k].fail;

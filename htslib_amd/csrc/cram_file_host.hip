@@ -10,14 +10,18 @@
 // the reference does with no_ref files); embedded references are taken from the file.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <map>
+#include <memory>
+#include <new>
 #include <string>
 #include <tuple>
 #include <thread>
 #include <atomic>
+#include <chrono>
 #include <vector>
 #include "htsgpu.h"
 #include "hg_internal.h"
@@ -369,7 +373,7 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
 //           file definition, header container, one container per slice (compression header block RAW, slice header block RAW, the series blocks),
 //           the EOF container; block and container CRC-32s on the device.
 namespace {
-void put_itf8(std::vector<uint8_t> &o, int32_t sv) {
+template <class O> void put_itf8(O &o, int32_t sv) {
     const uint32_t v = (uint32_t)sv;
     if (v < 0x80) o.push_back((uint8_t)v);
     else if (v < 0x4000) { o.push_back((uint8_t)(0x80 | (v >> 8))); o.push_back((uint8_t)v); }
@@ -377,14 +381,14 @@ void put_itf8(std::vector<uint8_t> &o, int32_t sv) {
     else if (v < 0x10000000) { o.push_back((uint8_t)(0xe0 | (v >> 24))); o.push_back((uint8_t)(v >> 16)); o.push_back((uint8_t)(v >> 8)); o.push_back((uint8_t)v); }
     else { o.push_back((uint8_t)(0xf0 | (v >> 28))); o.push_back((uint8_t)(v >> 20)); o.push_back((uint8_t)(v >> 12)); o.push_back((uint8_t)(v >> 4)); o.push_back((uint8_t)(v & 0x0f)); }
 }
-void put_ltf8(std::vector<uint8_t> &o, uint64_t v) {                     // ltf8_put (cram_io.c:475-560), values below 2^56
+template <class O> void put_ltf8(O &o, uint64_t v) {                     // ltf8_put (cram_io.c:475-560), values below 2^56
     int extra = 0;
     while (extra < 7 && v >= (1ull << (7 * (extra + 1)))) extra++;
     if (extra == 0) { o.push_back((uint8_t)v); return; }
     o.push_back((uint8_t)((0xff00u >> extra) & 0xffu) | (uint8_t)(v >> (8 * extra)));
     for (int i = extra - 1; i >= 0; i--) o.push_back((uint8_t)(v >> (8 * i)));
 }
-void put32le(std::vector<uint8_t> &o, uint32_t v) { for (int i = 0; i < 4; i++) o.push_back((uint8_t)(v >> (8 * i))); }
+template <class O> void put32le(O &o, uint32_t v) { for (int i = 0; i < 4; i++) o.push_back((uint8_t)(v >> (8 * i))); }
 }  // namespace
 
 extern "C" int hg_bam_to_cram_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, const hg_cram_ref_seq *refs, int nrefs_given, uint32_t records_per_slice, int level,
@@ -402,6 +406,12 @@ extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_
     const bool v31 = (flags & HG_CRAM_WRITE_V31) != 0, arith = v31 && (flags & HG_CRAM_WRITE_ARITH) != 0;
     if (!records_per_slice) records_per_slice = 10000;                   // the reference's default (cram/cram_structs.h:87-89)
     if (level <= 0) level = 5;
+    // HTS_GPU_STATS=1: where the call's wall time went, on stderr (the stages below)
+    const bool stats = getenv("HTS_GPU_STATS") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev = now();
+    double t_stage[5] = {0, 0, 0, 0, 0};
+    auto lap = [&](int k) { const auto t = now(); t_stage[k] += std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; };
     // ---- 1. BAM header
     if (bam_len < 12 || memcmp(bam, "BAM\1", 4) != 0) return HG_EINVAL;
     auto rd32 = [&](size_t at) { return (uint32_t)bam[at] | (uint32_t)bam[at + 1] << 8 | (uint32_t)bam[at + 2] << 16 | (uint32_t)bam[at + 3] << 24; };
@@ -418,32 +428,41 @@ extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_
         if (line.compare(0, 3, "@RG") != 0) continue;
         for (size_t f = 3; f < line.size();) { size_t t = line.find('\t', f + 1); if (t == std::string::npos) t = line.size(); const std::string fld = line.substr(f + 1, t - f - 1); f = t; if (fld.compare(0, 3, "ID:") == 0) rg_id.push_back(fld.substr(3)); }
     }
-    // ---- 2. records -> slices
-    size_t nrec = 0;
-    for (size_t q = p; q + 4 <= bam_len;) { q += 4 + (size_t)rd32(q); if (q > bam_len) return HG_EINVAL; nrec++; }
-    if (nrecords) *nrecords = nrec;
-    const size_t ns = (nrec + records_per_slice - 1) / records_per_slice;
-    std::vector<uint8_t> blob((bam_len - p) * 2 + 65536 * (ns + 1) + 4096);
-    std::vector<uint64_t> soff(ns + 2, 0); std::vector<int32_t> sst(ns + 1, 0);
+    // ---- 2. records -> slices.  The records are counted (and their bases summed per slice, for the container headers) by the encoder's own device passes:
+    //      a host walk of the block_size fields is one cache miss per record -- two such walks were 60 % of this call for 640 k records.
+    const size_t ns_max = (bam_len - p) / 36 / records_per_slice + 2;
+    // (no zero-filled vector: filling this size costs more host time than the device needs for the records)
+    size_t blob_cap = (bam_len - p) * 2 + 65536 * ns_max + 4096;
+    hg::CtxGuard whole_call(ctx); if (whole_call.rc) return whole_call.rc;   // the buffers below are the context's (hg::host_slab) for as long as this call runs
+    uint8_t *blob = hg::host_slab(ctx, 0, blob_cap);
+    if (!blob) return HG_ENOMEM;
+    blob_cap = ctx->h_slab_cap[0];
+    std::vector<uint64_t> soff(ns_max + 1, 0), sbases(ns_max, 0); std::vector<int32_t> sst(ns_max, 0);
     std::vector<const char *> rgp; for (auto &r : rg_id) rgp.push_back(r.c_str());
     int rc = HG_OK;
-    if (nrec) {
+    size_t nrec = 0;
+    if (bam_len > p) {
         uint64_t need = 0;
-        rc = hg_cram_encode_slices_host(ctx, bam + p, bam_len - p, nrec, records_per_slice, refs, nrefs_given, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), 0, blob.data(), blob.size(),
-                                        soff.data(), ns + 1, sst.data(), &need);
-        if (rc == HG_ENOMEM && need > blob.size()) {                    // reads far from their reference (or no reference at all) store every base: several bytes per base
-            blob.resize(need + 64);
-            rc = hg_cram_encode_slices_host(ctx, bam + p, bam_len - p, nrec, records_per_slice, refs, nrefs_given, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), 0, blob.data(), blob.size(),
-                                            soff.data(), ns + 1, sst.data(), &need);
+        rc = hg_cram_encode_slices_host2(ctx, bam + p, bam_len - p, &nrec, records_per_slice, refs, nrefs_given, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), 0, blob, blob_cap,
+                                         soff.data(), ns_max, sst.data(), &need, sbases.data());
+        if (rc == HG_ENOMEM && need > blob_cap) {                       // reads far from their reference (or no reference at all) store every base: several bytes per base
+            blob = hg::host_slab(ctx, 0, need + 64);
+            if (!blob) return HG_ENOMEM;
+            blob_cap = ctx->h_slab_cap[0];
+            rc = hg_cram_encode_slices_host2(ctx, bam + p, bam_len - p, &nrec, records_per_slice, refs, nrefs_given, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), 0, blob, blob_cap,
+                                             soff.data(), ns_max, sst.data(), &need, sbases.data());
         }
         if (rc != HG_OK) return rc;                                     // a slice the encoder does not cover fails the file
     }
+    if (nrecords) *nrecords = nrec;
+    const size_t ns = (nrec + records_per_slice - 1) / records_per_slice;
+    lap(0);
     // ---- 3. every series block through the auto-tuner
     struct Blk { int32_t cid; const uint8_t *p; uint32_t n; size_t slice; };
     struct SliceParts { const uint8_t *comp; uint32_t comp_len; const uint8_t *sh; uint32_t sh_len; size_t b0, b1; hgr::SliceHeader hdr; uint64_t bases; };
     std::vector<Blk> blks; std::vector<SliceParts> parts(ns);
     for (size_t k = 0; k < ns; k++) {
-        const uint8_t *b = blob.data() + soff[k];
+        const uint8_t *b = blob + soff[k];
         auto r32 = [&](const uint8_t *q) { return (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24; };
         SliceParts &P = parts[k];
         P.comp_len = r32(b); P.comp = b + 4; b += 4 + P.comp_len;
@@ -453,14 +472,15 @@ extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_
         for (uint32_t i = 0; i < nb; i++) { const int32_t cid = (int32_t)r32(b); const uint32_t n = r32(b + 4); blks.push_back(Blk{cid, b + 8, n, k}); b += 8 + n; }
         P.b1 = blks.size();
         if (hgr::parse_slice_header(P.sh, P.sh_len, 3, P.hdr)) return HG_EINVAL;
-        P.bases = 0;
-    }
-    {   // bases per slice (container header): the read lengths of its records
-        size_t q = p;
-        for (size_t r = 0; r < nrec; r++) { parts[r / records_per_slice].bases += rd32(q + 4 + 16); q += 4 + (size_t)rd32(q); }
+        P.bases = sbases[k];
     }
     const size_t nb = blks.size();
-    std::vector<std::vector<uint8_t>> cdata(nb); std::vector<uint32_t> clen(nb, 0); std::vector<int32_t> cmeth(nb, 0);
+    // compressed payloads: one arena, a block's slot as long as the block (a block that does not shrink is stored RAW, so nothing longer comes back)
+    std::vector<uint64_t> coff(nb + 1, 0);
+    for (size_t i = 0; i < nb; i++) coff[i + 1] = coff[i] + ((blks[i].n + 15u) & ~(uint64_t)15);
+    uint8_t *cdata = hg::host_slab(ctx, 1, coff[nb] + 16);
+    if (!cdata) return HG_ENOMEM;
+    std::vector<uint32_t> clen(nb, 0); std::vector<int32_t> cmeth(nb, 0);
     if (nb) {
         // method sets per block (internal method ids of cram/cram_structs.h:215-266: GZIP 1, RANS0 4, RANS_PR0 5, ARITH_PR0 6, TOK3 8, GZIP_RLE 11, GZIP_1 12, RANS1 16,
         // RANS_PR1 / 64 / 9 / 128 / 129 / 192 / 193 = 17..23, TOKA 24, ARITH_PR1 / 64 / 9 / 128 / 129 / 192 / 193 = 25..31)
@@ -492,7 +512,7 @@ extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_
                     auto it = met[r].find(blks[i].cid);
                     if (it == met[r].end()) it = met[r].emplace(blks[i].cid, hg_cram_metrics_new()).first;
                     mp[i] = it->second; in[i] = blks[i].p; il[i] = blks[i].n;
-                    cdata[i].resize(hg_cram_compress_bound(blks[i].n)); out[i] = cdata[i].data();
+                    out[i] = cdata + coff[i];
                 }
         std::vector<int> rrc(nr, HG_OK);
         auto run = [&](size_t r) {
@@ -512,69 +532,67 @@ extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_
         for (auto &mm : met) for (auto &m : mm) hg_cram_metrics_free(m.second);
         for (int r : rrc) if (r != HG_OK) return r;
     }
-    // ---- 4. framing
-    std::vector<uint8_t> o;
-    o.reserve(bam_len / 2 + 65536);
+    lap(1);
+    // ---- 4. framing, straight into the caller's buffer.  Every size is known by now (a block is 2 + itf8(cid) + itf8(csz) + itf8(usz) + csz + 4 bytes), so a
+    //      container's header goes out before its blocks; past the end of the buffer the sink only counts (cram_bytes = what the file needs).
+    struct Sink {
+        uint8_t *p; size_t cap, n;
+        void push_back(uint8_t b) { if (n < cap) p[n] = b; n++; }
+        void bytes(const uint8_t *d, size_t k) { if (k && n + k <= cap) memcpy(p + n, d, k); n += k; }
+        size_t size() const { return n; }
+    } o{cram_out, cram_cap, 0};
+    auto itf8_len = [](int32_t sv) { const uint32_t v = (uint32_t)sv; return v < 0x80 ? 1u : v < 0x4000 ? 2u : v < 0x200000 ? 3u : v < 0x10000000 ? 4u : 5u; };
+    auto block_size = [&](int32_t cid, uint32_t csz, uint32_t usz) { return (uint64_t)2 + itf8_len(cid) + itf8_len((int32_t)csz) + itf8_len((int32_t)usz) + csz + 4; };
     std::vector<uint64_t> crc_from, crc_at;                              // byte ranges [from, at) whose CRC-32 goes to o[at .. at + 4)
+    crc_from.reserve(nb + 4 * ns + 8); crc_at.reserve(nb + 4 * ns + 8);
     auto block = [&](int method, int ctype, int32_t cid, const uint8_t *data, uint32_t csz, uint32_t usz) {
         const uint64_t from = o.size();
         o.push_back((uint8_t)method); o.push_back((uint8_t)ctype); put_itf8(o, cid); put_itf8(o, (int32_t)csz); put_itf8(o, (int32_t)usz);
-        o.insert(o.end(), data, data + csz);
+        o.bytes(data, csz);
         crc_from.push_back(from); crc_at.push_back(o.size()); put32le(o, 0);
     };
-    auto container = [&](int32_t ref, int64_t start, int64_t span, int32_t nrecs, uint64_t counter, uint64_t bases, int32_t nblocks, const std::vector<int32_t> &landmarks, const std::vector<uint8_t> &body) {
+    auto container = [&](uint64_t body_bytes, int32_t ref, int64_t start, int64_t span, int32_t nrecs, uint64_t counter, uint64_t bases, int32_t nblocks, int32_t landmark) {
         const uint64_t from = o.size();
-        put32le(o, (uint32_t)body.size());
+        put32le(o, (uint32_t)body_bytes);
         put_itf8(o, ref); put_itf8(o, (int32_t)start); put_itf8(o, (int32_t)span); put_itf8(o, nrecs); put_ltf8(o, counter); put_ltf8(o, bases); put_itf8(o, nblocks);
-        put_itf8(o, (int32_t)landmarks.size()); for (int32_t l : landmarks) put_itf8(o, l);
+        put_itf8(o, 1); put_itf8(o, landmark);
         crc_from.push_back(from); crc_at.push_back(o.size()); put32le(o, 0);
-        const uint64_t shift = o.size();
-        o.insert(o.end(), body.begin(), body.end());
-        return shift;
     };
-    // file definition: "CRAM", 3.0, 20-byte file id
-    o.insert(o.end(), {'C', 'R', 'A', 'M', 3, (uint8_t)(v31 ? 1 : 0)}); { const char id[20] = "htslib_amd"; o.insert(o.end(), id, id + 20); }
-    // blocks of a container are built in a scratch vector first (the container header needs their total size); CRC slots are re-based afterwards
-    auto build = [&](auto &&fill) {
-        std::vector<uint8_t> saved; saved.swap(o);
-        std::vector<uint64_t> f0, a0; f0.swap(crc_from); a0.swap(crc_at);
-        fill();
-        std::vector<uint8_t> body; body.swap(o); o.swap(saved);
-        std::vector<uint64_t> f1, a1; f1.swap(crc_from); a1.swap(crc_at); crc_from.swap(f0); crc_at.swap(a0);
-        return std::make_tuple(std::move(body), std::move(f1), std::move(a1));
-    };
+    // file definition: "CRAM", 3.0 / 3.1, 20-byte file id
+    { const uint8_t def[6] = {'C', 'R', 'A', 'M', 3, (uint8_t)(v31 ? 1 : 0)}; o.bytes(def, 6); const char id[20] = "htslib_amd"; o.bytes((const uint8_t *)id, 20); }
     {   // header container: one FILE_HEADER block = int32 text length + text (cram_write_SAM_hdr)
-        auto [body, f1, a1] = build([&] { std::vector<uint8_t> h; put32le(h, (uint32_t)text.size()); h.insert(h.end(), text.begin(), text.end()); block(0, 0, 0, h.data(), (uint32_t)h.size(), (uint32_t)h.size()); });
-        const uint64_t shift = container(0, 0, 0, 0, 0, 0, 1, {0}, body);
-        for (size_t i = 0; i < f1.size(); i++) { crc_from.push_back(f1[i] + shift); crc_at.push_back(a1[i] + shift); }
+        std::vector<uint8_t> h; put32le(h, (uint32_t)text.size()); h.insert(h.end(), text.begin(), text.end());
+        container(block_size(0, (uint32_t)h.size(), (uint32_t)h.size()), 0, 0, 0, 0, 0, 0, 1, 0);
+        block(0, 0, 0, h.data(), (uint32_t)h.size(), (uint32_t)h.size());
     }
     for (size_t k = 0; k < ns; k++) {
         const SliceParts &P = parts[k];
-        int32_t landmark = 0;
-        auto [body, f1, a1] = build([&] {
-            block(0, 1, 0, P.comp, P.comp_len, P.comp_len);                // compression header
-            landmark = (int32_t)o.size();
-            block(0, 2, 0, P.sh, P.sh_len, P.sh_len);                      // slice header (MAPPED_SLICE)
-            { const uint8_t none = 0; block(0, 5, 0, &none, 0, 0); }       // the CORE block: empty (every series is EXTERNAL)
-            for (size_t i = P.b0; i < P.b1; i++) block(cmeth[i], 4, blks[i].cid, cmeth[i] == 0 ? blks[i].p : cdata[i].data(), cmeth[i] == 0 ? blks[i].n : clen[i], blks[i].n);
-        });
-        const uint64_t shift = container(P.hdr.ref_seq_id, P.hdr.ref_seq_start, P.hdr.ref_seq_span, P.hdr.nrec, (uint64_t)k * records_per_slice, P.bases, (int32_t)(3 + (P.b1 - P.b0)), {landmark}, body);
-        for (size_t i = 0; i < f1.size(); i++) { crc_from.push_back(f1[i] + shift); crc_at.push_back(a1[i] + shift); }
+        const uint64_t comp_bytes = block_size(0, P.comp_len, P.comp_len);
+        uint64_t body = comp_bytes + block_size(0, P.sh_len, P.sh_len) + block_size(0, 0, 0);
+        for (size_t i = P.b0; i < P.b1; i++) body += block_size(blks[i].cid, cmeth[i] == 0 ? blks[i].n : clen[i], blks[i].n);
+        // (the slice header's block count includes the CORE block: the encoder counted blocks + 1 already)
+        container(body, P.hdr.ref_seq_id, P.hdr.ref_seq_start, P.hdr.ref_seq_span, P.hdr.nrec, (uint64_t)k * records_per_slice, P.bases, (int32_t)(3 + (P.b1 - P.b0)), (int32_t)comp_bytes);
+        block(0, 1, 0, P.comp, P.comp_len, P.comp_len);                    // compression header
+        block(0, 2, 0, P.sh, P.sh_len, P.sh_len);                          // slice header (MAPPED_SLICE); the landmark points here
+        { const uint8_t none = 0; block(0, 5, 0, &none, 0, 0); }           // the CORE block: empty (every series is EXTERNAL)
+        for (size_t i = P.b0; i < P.b1; i++) block(cmeth[i], 4, blks[i].cid, cmeth[i] == 0 ? blks[i].p : cdata + coff[i], cmeth[i] == 0 ? blks[i].n : clen[i], blks[i].n);
     }
+    static const uint8_t eof3[38] = {0x0f, 0x00, 0x00, 0x00, 0xff, 0xff, 0xff, 0xff, 0x0f, 0xe0, 0x45, 0x4f, 0x46, 0x00, 0x00, 0x00, 0x00, 0x01, 0x00, 0x05, 0xbd, 0xd9, 0x4f, 0x00, 0x01, 0x00, 0x06, 0x06,
+                                     0x01, 0x00, 0x01, 0x00, 0x01, 0x00, 0xee, 0x63, 0x01, 0x4b};      // cram_write_eof_block, CRAM 3 (cram_io.c:4320-4370)
+    o.bytes(eof3, 38);
+    *cram_bytes = o.size();
+    if (o.size() > cram_cap) return HG_ENOMEM;
+    lap(2);
     {   // checksums, one batched device call (block CRCs cover header + payload, container CRCs the container header, cram_io.c:1547-1552, 3990-4010)
         const size_t nc = crc_from.size();
         std::vector<const uint8_t *> bp(nc); std::vector<uint32_t> bl(nc), crc(nc);
-        for (size_t i = 0; i < nc; i++) { bp[i] = o.data() + crc_from[i]; bl[i] = (uint32_t)(crc_at[i] - crc_from[i]); }
+        for (size_t i = 0; i < nc; i++) { bp[i] = cram_out + crc_from[i]; bl[i] = (uint32_t)(crc_at[i] - crc_from[i]); }
         if (nc && (rc = hg_crc32_batch_host(ctx, bp.data(), bl.data(), nc, crc.data())) != HG_OK) return rc;
-        for (size_t i = 0; i < nc; i++) for (int b = 0; b < 4; b++) o[crc_at[i] + (size_t)b] = (uint8_t)(crc[i] >> (8 * b));
+        for (size_t i = 0; i < nc; i++) for (int b = 0; b < 4; b++) cram_out[crc_at[i] + (size_t)b] = (uint8_t)(crc[i] >> (8 * b));
     }
-    // the slice header's block count includes the CORE block: the encoder counted blocks + 1 already
-    static const uint8_t eof3[38] = {0x0f, 0x00, 0x00, 0x00, 0xff, 0xff, 0xff, 0xff, 0x0f, 0xe0, 0x45, 0x4f, 0x46, 0x00, 0x00, 0x00, 0x00, 0x01, 0x00, 0x05, 0xbd, 0xd9, 0x4f, 0x00, 0x01, 0x00, 0x06, 0x06,
-                                     0x01, 0x00, 0x01, 0x00, 0x01, 0x00, 0xee, 0x63, 0x01, 0x4b};      // cram_write_eof_block, CRAM 3 (cram_io.c:4320-4370)
-    o.insert(o.end(), eof3, eof3 + 38);
-    *cram_bytes = o.size();
-    if (o.size() > cram_cap) return HG_ENOMEM;
-    memcpy(cram_out, o.data(), o.size());
+    lap(3);
+    if (stats) fprintf(stderr, "[hts-gpu] bam_to_cram: %zu records, %zu slices, %zu blocks: header walk + record encoder %.1f ms, block auto-tuner %.1f ms, framing %.1f ms, CRC-32s + copy out %.1f ms\n",
+                       nrec, ns, nb, t_stage[0], t_stage[1], t_stage[2], t_stage[3]);
     return HG_OK;
 }
 

@@ -12,6 +12,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+#include <chrono>
 #include <thread>
 #include <dlfcn.h>
 #include <mutex>
@@ -64,14 +66,17 @@ const HostLibs &host_libs() {
 
 // Runs every (block, method) job.  Jobs are grouped by CODEC FAMILY, not by method id: the entry points take a
 // parameter per stream (order / flag byte / back-end), so e.g. all seven RANS_PR* trials of all blocks are ONE batched
-// GPU call.  res[j] = malloc'd payload (or null when the method is not available / failed), rlen[j] = its size.
+// GPU call.  res[j] = the payload (or null when the method is not available / failed), rlen[j] = its size.  The payloads of a
+// codec family live in one buffer of its sibling context (hg::host_slab: a malloc per job of the codecs' worst-case bounds was
+// thousands of mmap / munmap pairs per round, and fresh pages fault); those of the host libraries are malloc'd and listed in
+// `arenas`, which the caller frees when it has picked the winners.  Valid until the next run_jobs on this context.
 int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t *const *in, const uint32_t *in_len,
-             const hg_fqz_slice *const *fqz, std::vector<uint8_t *> &res, std::vector<uint32_t> &rlen) {
+             const hg_fqz_slice *const *fqz, std::vector<uint8_t *> &res, std::vector<uint32_t> &rlen, std::vector<uint8_t *> &arenas) {
     res.assign(jobs.size(), nullptr); rlen.assign(jobs.size(), 0);
     if (g_size_script) {
         for (size_t j = 0; j < jobs.size(); j++) {
             const uint32_t sz = g_size_script(jobs[j].m, jobs[j].blk, in_len[jobs[j].blk]);
-            if (sz) { res[j] = (uint8_t *)calloc(sz, 1); rlen[j] = sz; }
+            if (sz) { res[j] = (uint8_t *)calloc(sz, 1); rlen[j] = sz; arenas.push_back(res[j]); }
         }
         return HG_OK;
     }
@@ -85,11 +90,11 @@ int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t
         if (m == HG_M_BZIP2 && H.bz2) {
             unsigned int cap = (unsigned int)(in_len[b] * 1.01 + 600);
             char *p = (char *)malloc(cap);
-            if (p && H.bz2(p, &cap, (char *)in[b], in_len[b], level > 0 ? level : 5, 0, 30) == 0) { res[j] = (uint8_t *)p; rlen[j] = cap; } else free(p);
+            if (p && H.bz2(p, &cap, (char *)in[b], in_len[b], level > 0 ? level : 5, 0, 30) == 0) { res[j] = (uint8_t *)p; rlen[j] = cap; arenas.push_back(res[j]); } else free(p);
         } else if (m == HG_M_LZMA && H.lzma_enc && H.lzma_bound) {
             const size_t cap = H.lzma_bound(in_len[b]);
             uint8_t *p = (uint8_t *)malloc(cap ? cap : 1); size_t pos = 0;
-            if (p && H.lzma_enc((uint32_t)(level > 0 ? level : 5), 1 /* LZMA_CHECK_CRC32 */, nullptr, in[b], in_len[b], p, &pos, cap) == 0) { res[j] = p; rlen[j] = (uint32_t)pos; } else free(p);
+            if (p && H.lzma_enc((uint32_t)(level > 0 ? level : 5), 1 /* LZMA_CHECK_CRC32 */, nullptr, in[b], in_len[b], p, &pos, cap) == 0) { res[j] = p; rlen[j] = (uint32_t)pos; arenas.push_back(p); } else free(p);
         }
     }
     enum Fam { F_GZ = 0, F_GZ1, F_R4, F_NX, F_AR, F_TK, F_FQ, F_N };
@@ -106,6 +111,9 @@ int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t
     // The families are independent: each runs on its own thread, sibling context (own scratch, own HIP stream), so
     // their -- individually latency-bound -- kernels overlap on the GPU.
     int frc[F_N];
+    static const char *const fam_name[F_N] = {"gzip", "gzip-1", "rans4x8", "ransNx16", "arith", "tok3", "fqzcomp"};
+    const bool stats = getenv("HTS_GPU_STATS") != nullptr;
+    double fam_ms[F_N] = {0}; size_t fam_jobs[F_N] = {0}; uint64_t fam_bytes[F_N] = {0};
     std::vector<std::thread> th;
     for (int fam = 0; fam < F_N; fam++) {
         frc[fam] = HG_OK;
@@ -116,9 +124,11 @@ int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t
         hg_ctx *sub = ctx->sub[fam];
         th.emplace_back([&, fam, sub, idx]() {
             if (hipSetDevice(ctx->device) != hipSuccess) { frc[fam] = HG_ENODEV; return; }
+            const auto t0 = std::chrono::steady_clock::now();
             std::vector<const uint8_t *> sin; std::vector<uint8_t *> sout; std::vector<uint32_t> slen, solen(idx.size(), 0);
             std::vector<uint8_t> par(idx.size());
             std::vector<const hg_fqz_slice *> fsl; std::vector<int32_t> fstrat;
+            std::vector<size_t> caps(idx.size() + 1, 0);
             for (size_t k = 0; k < idx.size(); k++) {
                 const size_t b = jobs[idx[k]].blk; const int m = jobs[idx[k]].m;
                 sin.push_back(in[b]); slen.push_back(in_len[b]);
@@ -129,13 +139,16 @@ int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t
                 if (fam == F_FQ) {                                     // strat = 0..3 for FQZ, FQZ_b, FQZ_c, FQZ_d (cram_io.c:2065-2068)
                     fsl.push_back(fqz ? fqz[b] : nullptr); fstrat.push_back(m == HG_M_FQZ ? 0 : m - HG_M_FQZ_b + 1);
                 }
-                uint8_t *p = (uint8_t *)malloc(cap);
-                if (!p) { for (auto q : sout) free(q); frc[fam] = HG_ENOMEM; return; }
-                sout.push_back(p);
+                caps[k + 1] = caps[k] + ((cap + 63) & ~(size_t)63);
                 // RANS_ORDER_SIMD_AUTO (cram_io.c:1860): the 32-way layout for inputs big enough to fill it
                 par[k] = fam == F_R4 ? (uint8_t)(m == HG_M_RANS1) : fam == F_NX ? (uint8_t)(pr_flags(m) | (in_len[b] >= 65536u ? 4 : 0))
                        : fam == F_AR ? (uint8_t)pr_flags(m) : (uint8_t)(m == HG_M_TOKA);
             }
+            // the family's sibling context keeps the buffer between rounds and calls (untouched pages cost nothing: the bounds are worst cases; the
+            // caller of this round holds the parent's lock, so nobody else is in here)
+            uint8_t *arena = hg::host_slab(sub, 2, caps[idx.size()] + 64);
+            if (!arena) { frc[fam] = HG_ENOMEM; return; }
+            for (size_t k = 0; k < idx.size(); k++) sout.push_back(arena + caps[k]);
             int rc;
             // libdeflate has no Z_RLE strategy: GZIP_RLE is run as level 1, like GZIP_1 (cram_io.c:2057-2062)
             if (fam <= F_GZ1) rc = hg_gzip_deflate_host(sub, sin.data(), slen.data(), sin.size(), fam == F_GZ ? level : 1, sout.data(), solen.data());
@@ -144,13 +157,19 @@ int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t
             else if (fam == F_AR) rc = hg_arith_encode_host(sub, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
             else if (fam == F_FQ) rc = hg_fqz_encode_host(sub, sin.data(), slen.data(), fsl.data(), fstrat.data(), sin.size(), sout.data(), solen.data());
             else rc = hg_tok3_encode_host(sub, sin.data(), slen.data(), par.data(), sin.size(), sout.data(), solen.data());
-            if (rc != HG_OK) { for (auto q : sout) free(q); frc[fam] = rc; return; }
-            for (size_t k = 0; k < idx.size(); k++) {                  // distinct jobs: no two threads touch the same slot
-                if (solen[k]) { res[idx[k]] = sout[k]; rlen[idx[k]] = solen[k]; } else free(sout[k]);
-            }
+            if (rc != HG_OK) { frc[fam] = rc; return; }
+            for (size_t k = 0; k < idx.size(); k++)                    // distinct jobs: no two threads touch the same slot
+                if (solen[k]) { res[idx[k]] = sout[k]; rlen[idx[k]] = solen[k]; }
+            fam_ms[fam] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            fam_jobs[fam] = idx.size(); for (uint32_t l : slen) fam_bytes[fam] += l;
         });
     }
     for (auto &t : th) t.join();
+    if (stats) {
+        fprintf(stderr, "[hts-gpu] cram auto-tuner round: %zu jobs:", jobs.size());
+        for (int fam = 0; fam < F_N; fam++) if (fam_jobs[fam]) fprintf(stderr, " %s %zu jobs %.1f MB %.1f ms;", fam_name[fam], fam_jobs[fam], fam_bytes[fam] / 1e6, fam_ms[fam]);
+        fprintf(stderr, "\n");
+    }
     for (int fam = 0; fam < F_N; fam++) if (frc[fam] != HG_OK) return frc[fam];
     return HG_OK;
 }
@@ -181,6 +200,8 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
                                              int version_major, const uint8_t *const *in, const uint32_t *in_len, const hg_fqz_slice *const *fqz,
                                              uint8_t *const *out, uint32_t *out_len, int32_t *method_used) {
     if (!ctx || (n && (!method_set || !in || !in_len || !out || !out_len || !method_used))) return HG_EINVAL;
+    std::unique_lock<std::recursive_mutex> whole_call;                     // the sibling contexts' result buffers are this call's until it returns
+    if (!g_size_script) whole_call = std::unique_lock<std::recursive_mutex>(*ctx->mu);   // (the scripted CPU test has no context)
     struct Blk { bool trial, done, retry; uint32_t method, orig; size_t j0, j1; };
     std::vector<Blk> B(n);
     for (size_t i = 0; i < n; i++) {
@@ -272,9 +293,11 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
         }
         if (taken.empty()) break;
         // ---- compress -------------------------------------------------------------------------------------------
-        std::vector<uint8_t *> res; std::vector<uint32_t> rlen;
-        int rc = run_jobs(ctx, jobs, level, in, in_len, fqz, res, rlen);
-        if (rc != HG_OK) { for (auto p : res) free(p); return rc; }
+        std::vector<uint8_t *> res, arenas; std::vector<uint32_t> rlen;
+        const auto t_round = std::chrono::steady_clock::now();
+        int rc = run_jobs(ctx, jobs, level, in, in_len, fqz, res, rlen, arenas);
+        const auto t_jobs = std::chrono::steady_clock::now();
+        if (rc != HG_OK) { for (auto p : arenas) free(p); return rc; }
         // ---- select, then fold the statistics in block order (cram_io.c:2064-2244) ------------------------------
         for (size_t i : taken) {
             Blk &b = B[i];
@@ -330,7 +353,10 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
                 M->revised_method = method;
             }
         }
-        for (auto p : res) free(p);
+        for (auto p : arenas) free(p);
+        if (getenv("HTS_GPU_STATS") && !g_size_script)
+            fprintf(stderr, "[hts-gpu] cram auto-tuner round: codecs %.1f ms, picking winners + statistics %.1f ms\n", std::chrono::duration<double, std::milli>(t_jobs - t_round).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_jobs).count());
     }
     for (size_t i = 0; i < n; i++) if (method_used[i] == HG_CRAM_RAW && in_len[i]) memcpy(out[i], in[i], in_len[i]);
     return HG_OK;

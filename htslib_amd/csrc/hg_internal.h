@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <atomic>
 #include <mutex>
 #include "htsgpu.h"
@@ -30,6 +31,8 @@ struct hg_ctx {
     hipStream_t stream3;      // a second side stream (a third variant of one call: the range coder's global-model streams, the long 4-way rANS streams)
     hipEvent_t ev_fork3, ev_join3;
     hg_ctx *sub[8];           // lazily created sibling contexts: independent codec families of one CRAM batch run concurrently
+    void *h_slab[4];          // pageable host buffers the file-level entry points keep between calls (host_slab(): a writer comes back with the next
+    size_t h_slab_cap[4];     // chunk, and first-touch page faults on fresh hundreds-of-MB buffers cost more than the device work they hold)
 };
 
 // Persistent kernels pull block indices from a counter that must start at 0.  Launches of one context may overlap
@@ -37,6 +40,17 @@ struct hg_ctx {
 // zeroes it on its own stream; HG_TICKETS bounds the number of launches of one context that may be in flight at once.
 #define HG_TICKETS 256
 namespace hg {
+// slot 0: series blocks of the record encoder, 1: compressed payloads of a CRAM writer call, 2: a codec family's trial results (in its sibling
+// context).  Contents are NOT kept across a growth; the caller holds the context lock (CtxGuard) for as long as it uses the pointer.
+inline uint8_t *host_slab(hg_ctx *ctx, int slot, size_t bytes) {
+    if (ctx->h_slab_cap[slot] < bytes || !ctx->h_slab[slot]) {
+        free(ctx->h_slab[slot]);
+        const size_t cap = bytes + bytes / 4 + 4096;
+        ctx->h_slab[slot] = malloc(cap);
+        ctx->h_slab_cap[slot] = ctx->h_slab[slot] ? cap : 0;
+    }
+    return (uint8_t *)ctx->h_slab[slot];
+}
 inline unsigned int *next_ticket(hg_ctx *ctx) {
     return ctx->d_ticket + (ctx->launch_seq->fetch_add(1u, std::memory_order_relaxed) % HG_TICKETS);
 }

@@ -89,6 +89,7 @@ void hg_destroy(hg_ctx *ctx) {
     for (int i = 0; i < HG_SCRATCH_SLOTS; i++) if (ctx->d_scratch[i]) (void)hipFree(ctx->d_scratch[i]);
     if (ctx->d_tok) (void)hipFree(ctx->d_tok);
     hg::stage_free(ctx);
+    for (void *p : ctx->h_slab) free(p);
     for (hg_ctx *c : ctx->sub) if (c) hg_destroy(c);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }

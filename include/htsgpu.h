@@ -363,7 +363,8 @@ void hg_cram_metrics_free(hg_cram_metrics *m);
  * the culling of persistently bad methods follow the reference.  Blocks of one call that share a metrics object are
  * handled in their order with the reference's state sequence (the call runs in rounds, split where a trial phase
  * ends).  bzip2 / lzma bits (and the fqzcomp bits of a block without slice information) are dropped from the set, as in an
- * htslib built without those libraries.  method_used[i] = on-disk method id; out[i] must hold hg_cram_compress_bound(in_len[i]). */
+ * htslib built without those libraries.  method_used[i] = on-disk method id; out[i] must hold in_len[i] bytes: a block that no method
+ * shrinks is stored RAW (cram_io.c:2229-2244), so out_len[i] <= in_len[i] always. */
 int hg_cram_compress_blocks_metrics_host(hg_ctx *ctx, size_t n, hg_cram_metrics *const *metrics, const uint32_t *method_set,
                                          int level, int version_major, const uint8_t *const *in, const uint32_t *in_len,
                                          uint8_t *const *out, uint32_t *out_len, int32_t *method_used);
@@ -468,6 +469,14 @@ typedef struct hg_cram_ref_seq { const uint8_t *bases; uint64_t len; } hg_cram_r
 int hg_cram_encode_slices_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, size_t nrec, uint32_t records_per_slice,
                                const hg_cram_ref_seq *refs, int nrefs, const char *const *rg_names, int nrg, int64_t record_counter0,
                                uint8_t *out, size_t out_cap, uint64_t *slice_off, size_t max_slices, int32_t *status, uint64_t *out_bytes);
+/* The same for a caller that has not walked the records: *nrec_io = 0 on entry -> they are counted here (bam_read1's framing, sam.c:784-866, runs on the
+ * device in any case; a host walk costs one cache miss per record), on return the number of records; slice_off / status need room for
+ * bam_len / 36 / records_per_slice + 2 slices then.  slice_bases (may be NULL): per slice the sum of the records' l_seq -- the base count of the
+ * container header (cram_write_container, cram/cram_io.c:3890-4010). */
+int hg_cram_encode_slices_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, size_t *nrec_io, uint32_t records_per_slice,
+                                const hg_cram_ref_seq *refs, int nrefs, const char *const *rg_names, int nrg, int64_t record_counter0,
+                                uint8_t *out, size_t out_cap, uint64_t *slice_off, size_t max_slices, int32_t *status, uint64_t *out_bytes,
+                                uint64_t *slice_bases);
 
 /* A whole CRAM 2.x / 3.x file -> the uncompressed BAM stream `samtools view -u -b` would hand to bgzf_write: the container / block walk
  * of cram_read_container / cram_read_block on the host, every block through cram_uncompress_block (CRC check included) in one batch,
