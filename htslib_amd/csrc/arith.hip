@@ -307,7 +307,8 @@ __global__ void udiv_check_kernel(unsigned long long seed, uint32_t rounds, unsi
     unsigned long long miss = 0;
     for (uint32_t i = 0; i < rounds; i++) {
         const unsigned long long r = next();
-        const uint32_t tot = 2u + (uint32_t)(r % 65518u);                       // a model's total: 2 .. 65519
+        uint32_t tot = 2u + (uint32_t)(r % 65518u);                             // a model's total: 2 .. 65519
+        if ((i & 31u) == 2) tot = 1u + (uint32_t)(r % 3u);                       // ... and the totals of tiny alphabets at their first symbols (r up to 2^32 - 1)
         uint32_t range = (uint32_t)(r >> 20) | (1u << 24);                       // >= 2^24 after renormalisation
         if ((i & 15u) == 0) range = 0xffffffffu;
         if ((i & 15u) == 1) range = 1u << 24;

@@ -31,6 +31,9 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint
 // The two divisions of a coder step (range / total, code / r) sit on every symbol's chain, and the compiler's 32-bit division is ~22 instructions.
 // Both have structure: (1) a quotient below 2^17 -- one single-precision estimate is within 1 of it, one correction either way;
 __device__ __forceinline__ uint32_t udiv_small_quotient(uint32_t a, uint32_t b) {
+    // (the sign test below reads a remainder of up to 2b - 1 as an int32: b < 2^30.  Larger divisors only come from models whose total is 1 .. 3 -- the
+    // first symbols of an alphabet of one to three symbols -- and take the plain division; round 4: an all-zero block, alphabet {0}, failed to decode)
+    if (__builtin_expect(b >= (1u << 30), 0)) return a / b;
     uint32_t q = (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)b));
     const uint32_t rem = a - q * b;                                  // (mod 2^32) -b <= rem < 2b
     if ((int32_t)rem < 0) q--; else if (rem >= b) q++;

@@ -26,7 +26,7 @@ namespace {
 enum { F_ORDER = 1, F_X32 = 4, F_EXT = 4, F_STRIPE = 8, F_NOSZ = 16, F_CAT = 32, F_RLE = 64, F_PACK = 128 };
 constexpr uint32_t NONE = 0xffffffffu;
 enum Codec { NX16 = 0, ARITH = 1 };
-enum CoreClass { C_NX4 = 0, C_NX32 = 1, C_ARITH_SMALL = 2, C_ARITH_BIG = 3, C_CLASSES = 4 };
+enum CoreClass { C_NX4 = 0, C_NX32 = 1, C_ARITH_SMALL = 2, C_ARITH_BIG = 3, C_ARITH_2P = 4 /* encoder only: arith_enc2.hip */, C_CLASSES = 5 };
 
 struct Plan {
     std::vector<hg_stream_desc> core;      // out_off is into the work buffer, or (bit 63 set) the output buffer
@@ -496,6 +496,7 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
     uint64_t ooff = 0, soff = 0, woff = 0;
     bool too_big = false;
     std::vector<uint8_t> ccls;
+    static const bool two_phase = !(getenv("HG_ARITH_2P") && atoi(getenv("HG_ARITH_2P")) == 0);   // (HG_ARITH_2P=0: every stream through the one-pass kernels, for A/B runs)
     auto add_core = [&](uint64_t src_off, uint32_t len, uint32_t fl, Codec cc, uint32_t max_sym) {
         hg_stream_desc d;
         memset(&d, 0, sizeof d);
@@ -504,7 +505,13 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         d.in_off = src_off; d.in_len = len; d.out_off = ooff; d.out_len = (uint32_t)(cap > 0xffffffffull ? 0xffffffffu : cap);
         d.scratch_off = (uint32_t)soff; d.reserved = (uint32_t)(woff / 16);
         ooff += (cap + 15u) & ~15ull;
-        if (cc == ARITH) {
+        if (cc == ARITH && two_phase && len >= HG_ARITH_2P_MIN) {
+            // long streams: models and coder in two phases (arith_enc2.hip); 8 bytes per record slot in the work buffer -- one slot per byte, two with RLE --
+            // and 16 words of stream information
+            ccls.push_back(C_ARITH_2P);
+            soff += 16;
+            woff += ((uint64_t)len * ((fl & F_RLE) ? 16u : 8u) + 15u) & ~15ull;
+        } else if (cc == ARITH) {
             const uint32_t words = hg::arith_model_words(max_sym + 1u, fl);
             ccls.push_back(words <= HG_ARITH_POOL_SMALL ? C_ARITH_SMALL : C_ARITH_BIG);
             soff += words > HG_ARITH_POOL_BIG ? words + 16 : 16;
@@ -562,9 +569,31 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         if (cnt[C_NX4] + cnt[C_NX32])
             rc = hg::launch_ransnx16_encode(ctx, d_buf, (const hg_stream_desc *)ctx->d_scratch[2], d_fl, d_sel + first[C_NX4], cnt[C_NX4],
                                             d_sel + first[C_NX32], cnt[C_NX32], d_out, d_ol, ctx->d_scratch[5], (uint32_t *)ctx->d_scratch[6], s);
+        bool forked4 = false;
+        std::vector<uint32_t> tasks;                                      // (outlives the asynchronous upload: the call synchronises below)
+        if (cnt[C_ARITH_2P]) {
+            // tasks: one per (stream, model) -- 256 literal contexts for an order-1 stream, 1 for order 0, 258 run models with RLE; absent ones leave at once
+            // (device-side presence bits).
+            // Long streams first.
+            for (size_t q = 0; q < cnt[C_ARITH_2P] && q < (1u << 22); q++) {
+                const uint32_t k = sel[first[C_ARITH_2P] + q], nm = (cfl[k] & F_ORDER) ? 256u : 1u;
+                for (uint32_t m = 0; m < nm; m++) tasks.push_back(m | (uint32_t)q << 10);
+                if (cfl[k] & F_RLE) for (uint32_t m = 256; m < 514; m++) tasks.push_back(m | (uint32_t)q << 10);   // the run models of the 256 symbols, then models 256 and 257
+            }
+            if (cnt[C_ARITH_2P] >= (1u << 22)) return HG_EINVAL;
+            if ((rc = ensure_scratch(ctx, 13, tasks.size() * 4 + 64))) return rc;
+            const bool others = cnt[C_NX4] + cnt[C_NX32] + cnt[C_ARITH_SMALL] + cnt[C_ARITH_BIG] != 0;
+            hipStream_t s4 = others ? hg::fork_side4(ctx, s) : s;          // (forked before anything else of this call is queued on s)
+            forked4 = others;
+            if (hipMemcpyAsync(ctx->d_scratch[13], tasks.data(), tasks.size() * 4, hipMemcpyHostToDevice, s4) != hipSuccess) return HG_ELAUNCH;
+            rc = hg::launch_arith_encode2(ctx, d_buf, (const hg_stream_desc *)ctx->d_scratch[2], d_fl, d_sel + first[C_ARITH_2P], cnt[C_ARITH_2P], (const uint32_t *)ctx->d_scratch[13],
+                                          tasks.size(), d_out, d_ol, (uint32_t *)ctx->d_scratch[6], ctx->d_scratch[5], s4);
+            if (rc) return rc;
+        }
         if (rc == HG_OK && cnt[C_ARITH_SMALL] + cnt[C_ARITH_BIG])
             rc = hg::launch_arith_encode(ctx, d_buf, (const hg_stream_desc *)ctx->d_scratch[2], d_fl, d_sel + first[C_ARITH_SMALL], cnt[C_ARITH_SMALL],
                                          d_sel + first[C_ARITH_BIG], cnt[C_ARITH_BIG], d_out, d_ol, (uint32_t *)ctx->d_scratch[6], s);
+        if (forked4) hg::join_side4(ctx, s);
         if (rc) return rc;
         if (hipMemcpyAsync(ol.data(), d_ol, nc * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
     }

@@ -30,6 +30,8 @@ struct hg_ctx {
     hipEvent_t ev_fork, ev_join;
     hipStream_t stream3;      // a second side stream (a third variant of one call: the range coder's global-model streams, the long 4-way rANS streams)
     hipEvent_t ev_fork3, ev_join3;
+    hipStream_t stream4;      // a third side stream: the two-phase range-coder encoder (arith_enc2.hip) beside the one-pass kernels
+    hipEvent_t ev_fork4, ev_join4;
     hg_ctx *sub[8];           // lazily created sibling contexts: independent codec families of one CRAM batch run concurrently
     void *h_slab[4];          // pageable host buffers the file-level entry points keep between calls (host_slab(): a writer comes back with the next
     size_t h_slab_cap[4];     // chunk, and first-touch page faults on fresh hundreds-of-MB buffers cost more than the device work they hold)
@@ -118,6 +120,10 @@ int launch_arith_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
 int launch_arith_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags, const uint32_t *d_sel_small,
                         size_t nsmall, const uint32_t *d_sel_big, size_t nbig, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch,
                         hipStream_t s);
+// arith_enc2.hip: the two-phase encoder for long streams (d_sel2: indices into d_desc; d_tasks: model | position in d_sel2 << 10)
+#define HG_ARITH_2P_MIN 8192u
+int launch_arith_encode2(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags, const uint32_t *d_sel2, size_t n2, const uint32_t *d_tasks,
+                         size_t ntasks, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch, void *d_work, hipStream_t s);
 // tok3.hip: one name-reconstruction job per CRAM method-8 block
 struct tok3_job {
     uint64_t tb_base;      // where this block's decoded token streams start in the token buffer
@@ -157,6 +163,15 @@ inline hipStream_t fork_side3(hg_ctx *ctx, hipStream_t s) {
 inline void join_side3(hg_ctx *ctx, hipStream_t s) {
     (void)hipEventRecord(ctx->ev_join3, ctx->stream3);
     (void)hipStreamWaitEvent(s, ctx->ev_join3, 0);
+}
+inline hipStream_t fork_side4(hg_ctx *ctx, hipStream_t s) {
+    (void)hipEventRecord(ctx->ev_fork4, s);
+    (void)hipStreamWaitEvent(ctx->stream4, ctx->ev_fork4, 0);
+    return ctx->stream4;
+}
+inline void join_side4(hg_ctx *ctx, hipStream_t s) {
+    (void)hipEventRecord(ctx->ev_join4, ctx->stream4);
+    (void)hipStreamWaitEvent(s, ctx->ev_join4, 0);
 }
 // hg_stage.hip: many scattered host buffers <-> one device buffer, one PCIe transfer each way
 int stage_upload(hg_ctx *ctx, const uint8_t *const *src, const uint32_t *len, const uint64_t *dst_off, const int32_t *skip, size_t n,

@@ -74,6 +74,9 @@ int hg_init(int device, hg_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream4, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork4, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join4, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -94,6 +97,9 @@ void hg_destroy(hg_ctx *ctx) {
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->stream3) { (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamDestroy(ctx->stream3); }
+    if (ctx->stream4) { (void)hipStreamSynchronize(ctx->stream4); (void)hipStreamDestroy(ctx->stream4); }
+    if (ctx->ev_fork4) (void)hipEventDestroy(ctx->ev_fork4);
+    if (ctx->ev_join4) (void)hipEventDestroy(ctx->ev_join4);
     if (ctx->ev_fork3) (void)hipEventDestroy(ctx->ev_fork3);
     if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);

@@ -114,6 +114,51 @@ def test_gpu_encoder_is_byte_identical_to_oracle(engine, aorc):
 
 
 @pytest.mark.gpu
+def test_gpu_tiny_alphabets_starting_at_zero(engine, aorc):
+    """Alphabets {0}, {0,1}, {0,1,2}: the first symbols are coded with totals of 1 .. 3, where range / total reaches 2^30 .. 2^32 - 1 -- the short division
+    of the decoder (arith_dev.h udiv_small_quotient) mis-read such remainders until round 4 (an all-zero block did not decode)."""
+    rng = np.random.default_rng(3)
+    datas, flags = [], []
+    for m in (1, 2, 3):
+        for n in (1, 2, 5, 64, 1000, 70_000, 300_000):
+            for rep in range(6 if n <= 1000 else 1):
+                d = bytes(rng.integers(0, m, n, dtype=np.uint8)) if rep else bytes(n)
+                for fl in (0, 1, 64, 65, 9, 193):
+                    datas.append(d); flags.append(fl)
+    enc = engine.arith_encode_host(datas, flags)
+    bad = [(len(d), max(d) + 1, hex(fl)) for d, fl, e in zip(datas, flags, enc) if e != aorc.encode(d, fl)]
+    assert not bad, bad[:12]
+    outs, st = engine.cram_uncompress_blocks([(6, e, len(d)) for d, e in zip(datas, enc)])
+    bad = [(len(d), max(d) + 1, hex(fl), int(s)) for d, fl, o, s in zip(datas, flags, outs, st) if s != 0 or o != d]
+    assert not bad, bad[:12]
+
+
+@pytest.mark.gpu
+def test_gpu_two_phase_encoder_is_byte_identical_to_oracle(engine, aorc):
+    """Streams of HG_ARITH_2P_MIN (8192) bytes and more take the two-phase encoder (arith_enc2.hip: one wavefront per model, then one per stream): sizes
+    around its 64-position tiles, alphabets of 1 / 2 / 40 / 64 / 65 / 130 / 256 symbols (register models up to 64, the LDS form above), skew that halves
+    the models many times, order 0 and 1, with STRIPE / PACK / RLE around it."""
+    rng = np.random.default_rng(77)
+    datas, flags = [], []
+    for n in (8192, 8193, 8255, 8256, 8257, 20_000, 300_000):
+        for m in (1, 2, 40, 64, 65, 130, 256):
+            p = rng.dirichlet(np.full(m, 0.3)) if m > 1 else np.ones(1)
+            d = bytes(rng.choice(m, n, p=p).astype(np.uint8))
+            if m == 256: d = bytes([255]) + d[1:]
+            for fl in (0, 1) if n != 300_000 else (0, 1, 9, 8, 64, 65, 128, 129, 193):
+                datas.append(d); flags.append(fl)
+    top = bytes(rng.choice(np.array([7, 9, 200], dtype=np.uint8), 200_000, p=[0.98, 0.015, 0.005]))     # one context carries nearly everything
+    for fl in (0, 1, 65):
+        datas.append(top); flags.append(fl)
+    enc = engine.arith_encode_host(datas, flags)
+    bad = [(len(d), len(set(d)), hex(fl)) for d, fl, e in zip(datas, flags, enc) if e != aorc.encode(d, fl)]
+    assert not bad, bad[:12]
+    outs, st = engine.cram_uncompress_blocks([(6, e, len(d)) for d, e in zip(datas, enc)])
+    bad = [(len(d), len(set(d)), hex(fl), int(s)) for d, fl, o, s in zip(datas, flags, outs, st) if s != 0 or o != d]
+    assert not bad, bad[:12]
+
+
+@pytest.mark.gpu
 def test_gpu_short_divisions_are_exact(engine):
     """arith_dev.h replaces the two 32-bit divisions of a coder step (range / total, code / r) by single-precision estimates with one correction; checked here
     against the exact division on the device over 1.5 G random operand pairs in the coder's ranges (+ the corners): any disagreement would change a stream"""
