@@ -1407,9 +1407,10 @@ def compact(o, depth=0):
         for k, v in o.items():
             if k in ("variants", "on_disk_methods", "note", "parity", "timing", "format_parity", "sample_detail", "traffic_note", "sharding", "prep_seconds"): continue
             if depth >= 2 and k in ("higher_is_better", "scaling", "vs_baseline", "dtype", "data", "n_gpus", "warmup", "algorithmic_bytes_per_launch", "algorithmic_bytes",
-                                    "cpu_baseline_port", "in_bytes", "bam_bytes", "blocks_per_gpu", "plain_bytes_per_gpu", "compressed_bytes_per_gpu"): continue
+                                    "cpu_baseline_port", "in_bytes", "bam_bytes", "blocks_per_gpu", "plain_bytes_per_gpu", "compressed_bytes_per_gpu", "peak", "streams_per_gpu", "verified_streams",
+                                    "slices_decoded_by_the_data_parallel_passes", "verified_blocks"): continue
             if isinstance(v, str):
-                lim = (150 if k == "workload" else 110 if k in ("metric", "sample") else 70) if depth < 2 else (90 if k == "workload" else 60)
+                lim = (150 if k == "workload" else 110 if k in ("metric", "sample") else 70) if depth < 2 else (90 if k == "workload" else 48)
                 out[k] = v if len(v) <= lim else v[:lim - 1] + "~"
             elif isinstance(v, (dict, list)):
                 if depth < 4: out[k] = compact(v, depth + 1)

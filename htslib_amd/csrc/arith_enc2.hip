@@ -121,6 +121,29 @@ struct RecOut {
 // task word: model id (10 bits: 0..255 literal context, 256 + c run model of symbol c, 512 / 513 the run models 256 / 257) | index into sel << 10
 constexpr uint32_t TASK_MODEL_BITS = 10;
 
+// Every task walks its whole stream, 64 positions per step, and most steps find little to do: the loads of the next FOUR steps are in flight while one is
+// worked on (with one step of look-ahead the walk ran at memory latency -- ~1 us per 64 bytes, times a few hundred tasks per stream).
+// body(i0, cur, prev): lane l holds the byte at i0 + l and the one before it (0 before the stream; 0x100 / 0 past its end).
+template <class Body>
+__device__ __forceinline__ void scan_tiles(const uint8_t *src, uint32_t n, int lane, Body body) {
+    auto load = [&](uint32_t i0, uint32_t &cur, uint32_t &prev) {
+        const uint32_t p = i0 + (uint32_t)lane;
+        cur = p < n ? (uint32_t)src[p] : 0x100u; prev = (p && p < n) ? (uint32_t)src[p - 1u] : 0u;
+    };
+    uint32_t nc[4], np[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { nc[t] = 0x100u; np[t] = 0u; if (64u * (uint32_t)t < n) load(64u * (uint32_t)t, nc[t], np[t]); }
+    for (uint32_t g0 = 0; g0 < n; g0 += 256u) {
+        uint32_t c[4], q[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) { c[t] = nc[t]; q[t] = np[t]; }
+#pragma unroll
+        for (int t = 0; t < 4; t++) { const uint32_t i0 = g0 + 256u + 64u * (uint32_t)t; if (i0 < n) load(i0, nc[t], np[t]); }
+#pragma unroll
+        for (int t = 0; t < 4; t++) { const uint32_t i0 = g0 + 64u * (uint32_t)t; if (i0 < n) body(i0, c[t], q[t]); }
+    }
+}
+
 // The literal events of one context (order 1: the positions whose predecessor is `ctx`; order 0: every position).  With RLE only the first symbol of a run
 // is a literal, and its context is the symbol of the run before -- the byte before it.
 template <bool WIDE>
@@ -131,15 +154,7 @@ __device__ __forceinline__ void lit_task(const uint8_t *src, uint32_t n, uint32_
         W.init(wide_mem, (uint8_t *)(wide_mem + 256), m, true, lane);
     } else G.init(m, lane);
     RecOut O; O.start(R);
-    auto tile = [&](uint32_t i0, uint32_t &cur, uint32_t &prev) {
-        const uint32_t p = i0 + (uint32_t)lane;
-        cur = p < n ? src[p] : 0u; prev = (p && p < n) ? src[p - 1u] : 0u;
-    };
-    uint32_t cur, prev, ncur, nprev;
-    tile(0, ncur, nprev);
-    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-        cur = ncur; prev = nprev;
-        if (i0 + 64u < n) tile(i0 + 64u, ncur, nprev);                  // the next tile is on its way while this one is worked through
+    scan_tiles(src, n, lane, [&](uint32_t i0, uint32_t cur, uint32_t prev) {
         const uint32_t p = i0 + (uint32_t)lane;
         unsigned long long mask = __ballot(p < n && (!order || prev == ctx) && (!rle || p == 0 || cur != prev));
         while (mask) {
@@ -156,7 +171,7 @@ __device__ __forceinline__ void lit_task(const uint8_t *src, uint32_t n, uint32_
             } else G.step(sym, cum, f, t, lane);
             O.put(rle ? 2u * (i0 + b) : i0 + b, cum, f, t, lane);
         }
-    }
+    });
     O.finish(lane);
 }
 
@@ -172,17 +187,13 @@ __device__ __forceinline__ void run_first_task(const uint8_t *src, uint32_t n, u
         G.step(r < 3u ? r : 3u, cum, f, t, lane);
         O.put(2u * s + 1u, cum, f, t, lane);
     };
-    auto tile = [&](uint32_t i0) { const uint32_t p = i0 + (uint32_t)lane; return p < n ? (uint32_t)src[p] : 0x100u; };
     bool open = false; uint32_t s = 0, len = 0;
-    uint32_t ncur = tile(0);
-    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-        const uint32_t cur = ncur;
-        if (i0 + 64u < n) ncur = tile(i0 + 64u);
+    scan_tiles(src, n, lane, [&](uint32_t i0, uint32_t cur, uint32_t) {
         unsigned long long bits = __ballot(cur == c);                    // the runs of c are the runs of set bits (positions past the end never match)
         if (open) {
             const uint32_t ones = ~bits ? (uint32_t)__builtin_ctzll(~bits) : 64u;
             len += ones;
-            if (ones == 64u) continue;
+            if (ones == 64u) return;
             emit(s, len); open = false;
             bits &= ~((1ull << ones) - 1ull);
         }
@@ -194,7 +205,7 @@ __device__ __forceinline__ void run_first_task(const uint8_t *src, uint32_t n, u
             emit(i0 + b, ones);
             bits &= ~(((1ull << ones) - 1ull) << b);
         }
-    }
+    });
     if (open) emit(s, len);
     O.finish(lane);
 }
@@ -221,19 +232,11 @@ __device__ __forceinline__ void run_more_task(const uint8_t *src, uint32_t n, ui
             } while (part == 3u);
         }
     };
-    auto tile = [&](uint32_t i0, uint32_t &cur, uint32_t &prev) {
-        const uint32_t p = i0 + (uint32_t)lane;
-        cur = p < n ? src[p] : 0u; prev = (p && p < n) ? src[p - 1u] : 0u;
-    };
     bool have = false; uint32_t s_last = 0;
-    uint32_t cur, prev, ncur, nprev;
-    tile(0, ncur, nprev);
-    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-        cur = ncur; prev = nprev;
-        if (i0 + 64u < n) tile(i0 + 64u, ncur, nprev);
+    scan_tiles(src, n, lane, [&](uint32_t i0, uint32_t cur, uint32_t prev) {
         const uint32_t p = i0 + (uint32_t)lane;
         const unsigned long long valid = __ballot(p < n), st = __ballot(p < n && (p == 0 || cur != prev));
-        if (!st) continue;
+        if (!st) return;
         const unsigned long long nst = valid & ~st, longish = nst & (nst >> 1) & (nst >> 2);
         uint32_t a = (uint32_t)__builtin_ctzll(st);
         if (have) handle(s_last, i0 + a - s_last);
@@ -246,7 +249,7 @@ __device__ __forceinline__ void run_more_task(const uint8_t *src, uint32_t n, ui
             }
         }
         s_last = i0 + 63u - (uint32_t)__builtin_clzll(st); have = true;
-    }
+    });
     if (have) handle(s_last, n - s_last);
     O.finish(lane);
 }

@@ -496,7 +496,8 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
     uint64_t ooff = 0, soff = 0, woff = 0;
     bool too_big = false;
     std::vector<uint8_t> ccls;
-    static const bool two_phase = !(getenv("HG_ARITH_2P") && atoi(getenv("HG_ARITH_2P")) == 0);   // (HG_ARITH_2P=0: every stream through the one-pass kernels, for A/B runs)
+    const bool two_phase = !(getenv("HG_ARITH_2P") && atoi(getenv("HG_ARITH_2P")) == 0);          // (HG_ARITH_2P=0: every stream through the one-pass kernels, for A/B runs)
+    const uint32_t two_phase_min = getenv("HG_ARITH_2P_MIN") && atoi(getenv("HG_ARITH_2P_MIN")) > 0 ? (uint32_t)atoi(getenv("HG_ARITH_2P_MIN")) : HG_ARITH_2P_MIN;
     auto add_core = [&](uint64_t src_off, uint32_t len, uint32_t fl, Codec cc, uint32_t max_sym) {
         hg_stream_desc d;
         memset(&d, 0, sizeof d);
@@ -505,7 +506,7 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         d.in_off = src_off; d.in_len = len; d.out_off = ooff; d.out_len = (uint32_t)(cap > 0xffffffffull ? 0xffffffffu : cap);
         d.scratch_off = (uint32_t)soff; d.reserved = (uint32_t)(woff / 16);
         ooff += (cap + 15u) & ~15ull;
-        if (cc == ARITH && two_phase && len >= HG_ARITH_2P_MIN) {
+        if (cc == ARITH && two_phase && len >= two_phase_min) {
             // long streams: models and coder in two phases (arith_enc2.hip); 8 bytes per record slot in the work buffer -- one slot per byte, two with RLE --
             // and 16 words of stream information
             ccls.push_back(C_ARITH_2P);

@@ -121,7 +121,10 @@ int launch_arith_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
                         size_t nsmall, const uint32_t *d_sel_big, size_t nbig, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch,
                         hipStream_t s);
 // arith_enc2.hip: the two-phase encoder for long streams (d_sel2: indices into d_desc; d_tasks: model | position in d_sel2 << 10)
-#define HG_ARITH_2P_MIN 8192u
+// Above this size a stream's serial chain in the one-pass kernel is what a batch waits for (1.5 MB of qualities: ~0.8 s); below it the one-pass kernels win
+// on a batch of slices: every two-phase stream brings 256 .. 514 single-wavefront tasks, and a few hundred streams of 20 .. 40 KB flooded the dispatcher
+// (profiles/r04_arith_two_phase.txt).  HG_ARITH_2P_MIN overrides (tests run the two-phase path from 8 KiB).
+#define HG_ARITH_2P_MIN 262144u
 int launch_arith_encode2(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags, const uint32_t *d_sel2, size_t n2, const uint32_t *d_tasks,
                          size_t ntasks, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch, void *d_work, hipStream_t s);
 // tok3.hip: one name-reconstruction job per CRAM method-8 block

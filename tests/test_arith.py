@@ -134,9 +134,9 @@ def test_gpu_tiny_alphabets_starting_at_zero(engine, aorc):
 
 
 @pytest.mark.gpu
-def test_gpu_two_phase_encoder_is_byte_identical_to_oracle(engine, aorc):
-    """Streams of HG_ARITH_2P_MIN (8192) bytes and more take the two-phase encoder (arith_enc2.hip: one wavefront per model, then one per stream): sizes
-    around its 64-position tiles, alphabets of 1 / 2 / 40 / 64 / 65 / 130 / 256 symbols (register models up to 64, the LDS form above), skew that halves
+def test_gpu_two_phase_encoder_is_byte_identical_to_oracle(engine, aorc, monkeypatch):
+    """Long streams (HG_ARITH_2P_MIN: 256 KiB by default, 8 KiB for this test) take the two-phase encoder (arith_enc2.hip: one wavefront per model, then one per
+    stream): sizes around its 64-position tiles, alphabets of 1 / 2 / 40 / 64 / 65 / 130 / 256 symbols (register models up to 64, the LDS form above), skew that halves
     the models many times, order 0 and 1, with STRIPE / PACK / RLE around it."""
     rng = np.random.default_rng(77)
     datas, flags = [], []
@@ -150,7 +150,10 @@ def test_gpu_two_phase_encoder_is_byte_identical_to_oracle(engine, aorc):
     top = bytes(rng.choice(np.array([7, 9, 200], dtype=np.uint8), 200_000, p=[0.98, 0.015, 0.005]))     # one context carries nearly everything
     for fl in (0, 1, 65):
         datas.append(top); flags.append(fl)
+    monkeypatch.setenv("HG_ARITH_2P_MIN", "8192")                       # (read by the library at every call)
     enc = engine.arith_encode_host(datas, flags)
+    monkeypatch.delenv("HG_ARITH_2P_MIN")
+    assert enc == engine.arith_encode_host(datas, flags)                # the default threshold: same bytes
     bad = [(len(d), len(set(d)), hex(fl)) for d, fl, e in zip(datas, flags, enc) if e != aorc.encode(d, fl)]
     assert not bad, bad[:12]
     outs, st = engine.cram_uncompress_blocks([(6, e, len(d)) for d, e in zip(datas, enc)])
