@@ -12,6 +12,7 @@
 // reference (oracle/_ref) on the reference's fixtures and on damaged blocks.
 #pragma once
 #include <stdint.h>
+#include <algorithm>
 #include <string.h>
 #include <vector>
 #include "deflate_huff.h"
@@ -236,6 +237,22 @@ inline int bgzf_block_inflate(Inflater &I, const uint8_t *block, size_t clen, ui
 }
 
 // ---- deflate (one block, one setting: greedy parse over hash chains, one dynamic-Huffman block) --------------------------------------------
+// Host forms of deflate_huff.h's build_lengths / assign_codes: the same results (symbols ranked by (frequency, symbol), canonical codes), but a sort and
+// one pass instead of the per-symbol O(n) loops that suit one GPU thread per symbol -- on one host thread those were 180 us of a 660 us block.
+inline void build_lengths_host(const uint32_t *freq, int n, int maxbits, uint8_t *len, uint16_t *order, uint32_t *work) {
+    uint64_t key[288]; int used = 0;
+    for (int i = 0; i < n; i++) { len[i] = 0; if (freq[i]) key[used++] = (uint64_t)freq[i] << 16 | (uint32_t)i; }
+    std::sort(key, key + used);
+    for (int r = 0; r < used; r++) { order[r] = (uint16_t)(key[r] & 0xffffu); work[r] = (uint32_t)(key[r] >> 16); }
+    uint32_t cnt[33];
+    hgdef::finish_lengths(used, maxbits, len, order, work, cnt);
+}
+inline void assign_codes_host(const uint8_t *len, int n, uint16_t *code) {
+    uint32_t cnt[16], nxt[16];
+    hgdef::first_codes(len, n, cnt, nxt);
+    for (int i = 0; i < n; i++) { const uint32_t l = len[i]; code[i] = l ? (uint16_t)(hgdef::rev16(nxt[l]++) >> (16 - l)) : 0; }
+}
+
 struct Deflater {
     static constexpr int HBITS = 15;
     uint16_t head[1 << HBITS], prev[65536];
@@ -250,13 +267,15 @@ struct Deflater {
         memset(head, 0, sizeof head);
         auto hash = [&](size_t i) -> uint32_t { uint32_t v; memcpy(&v, src + i, 4); return (v * 2654435761u) >> (32 - HBITS); };
         size_t i = 0;
+        uint32_t misses = 0;                                                            // literals in a row: text that does not repeat (base qualities) is searched less densely
         while (i < n) {
             uint32_t best = 0, bd = 0;
-            if (i + 4 <= n) {
+            if (i + 4 <= n && (misses < 64u || (i & (misses < 256u ? 1u : 3u)) == 0)) {
                 const uint32_t h = hash(i);
                 uint32_t cand = head[h];                                               // position + 1, 0 = none
                 const size_t maxl = n - i < 258 ? n - i : 258;
-                for (int d = 0; cand && d < depth; d++) {
+                int left = depth;
+                for (; cand && left > 0; left--) {
                     const size_t c = cand - 1;
                     if (i - c > 32768) break;                                           // older links are farther still
                     if (src[c + best] == src[i + best] || best == 0) {
@@ -265,7 +284,7 @@ struct Deflater {
                         while (l < maxl && src[c + l] == src[i + l]) l++;
                     done:
                         if (l > maxl) l = maxl;
-                        if (l > best) { best = (uint32_t)l; bd = (uint32_t)(i - c); if (l == maxl) break; }
+                        if (l > best) { best = (uint32_t)l; bd = (uint32_t)(i - c); if (l == maxl) break; if (l >= 32 && left > depth / 4) left = depth / 4; }   // good enough: a short look further
                     }
                     cand = prev[c];
                 }
@@ -278,13 +297,13 @@ struct Deflater {
                 dist_symbol(bd, s, xb, xv); df[s]++;
                 tok[nt++] = 0x80000000u | ((best - 3u) << 16) | (bd - 1u);
                 for (size_t k = 1; k < best && i + k + 4 <= n; k++) { const uint32_t h = hash(i + k); prev[i + k] = head[h]; head[h] = (uint16_t)(i + k + 1); }
-                i += best;
-            } else { lf[src[i]]++; tok[nt++] = src[i]; i++; }
+                i += best; misses = 0;
+            } else { lf[src[i]]++; tok[nt++] = src[i]; i++; misses++; }
         }
         lf[256] = 1;
         uint8_t ll[288], dl[32], cs[320], ce[320]; uint16_t lc[288], dc[32], order[320]; uint32_t work[320];
-        build_lengths(lf, 286, 15, ll, order, work); build_lengths(df, 30, 15, dl, order, work);
-        assign_codes(ll, 286, lc); assign_codes(dl, 30, dc);
+        build_lengths_host(lf, 286, 15, ll, order, work); build_lengths_host(df, 30, 15, dl, order, work);
+        assign_codes_host(ll, 286, lc); assign_codes_host(dl, 30, dc);
         // size before writing: header (<= 320 bytes) + the tokens
         uint64_t bits = 0;
         for (int s = 0; s < 286; s++) bits += (uint64_t)lf[s] * ll[s];
@@ -297,7 +316,8 @@ struct Deflater {
         uint64_t acc = 0; uint32_t have = hb & 7u; size_t at = hb >> 3;
         if (have) acc = dst[at];
         auto put = [&](uint32_t v, uint32_t k) { acc |= (uint64_t)v << have; have += k; };
-        auto flush = [&]() { while (have >= 8) { dst[at++] = (uint8_t)acc; acc >>= 8; have -= 8; } };
+        // (eight bytes stored at a time, the whole ones kept: the size check above leaves 8 bytes of slack behind the last token; little-endian hosts)
+        auto flush = [&]() { memcpy(dst + at, &acc, 8); const uint32_t whole = have >> 3; at += whole; acc = whole == 8 ? 0 : acc >> (whole * 8); have &= 7u; };
         for (size_t k = 0; k < nt; k++) {
             const uint32_t t = tok[k];
             if (t & 0x80000000u) {
