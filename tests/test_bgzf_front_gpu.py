@@ -260,7 +260,7 @@ def test_latency_path_runs_on_the_host_codec(L, tmp_path):            # bgzf.c:1
     assert tells == sorted(tells) and tells[-1] >> 16 > 0               # the block address moves while writing (exact bgzf_tell)
     comp = open(p, "rb").read()
     assert refutil.Oracle().decompress(comp)[1] == plain
-    assert rate >= 60, rate                                              # 16 MB/s when every block was a device job of its own; ~90 MB/s here
+    assert rate >= 60, rate                                              # 16 MB/s when every block was a device job of its own; ~200 MB/s here
     # random access: seek to block starts all over the file, read 100 bytes
     blocks = refutil.split_blocks(comp)
     uoffs = np.concatenate([[0], np.cumsum([b[2] for b in blocks])])
