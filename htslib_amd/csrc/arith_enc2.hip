@@ -254,12 +254,16 @@ __device__ __forceinline__ void run_more_task(const uint8_t *src, uint32_t n, ui
     O.finish(lane);
 }
 
-__global__ __launch_bounds__(64)
+// Four tasks per workgroup, one per wavefront (they never meet: no barrier): a quarter of the workgroups to dispatch.
+__global__ __launch_bounds__(256)
 void model_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc, const uint8_t *__restrict__ flags_in, const uint32_t *__restrict__ sel,
-                  const uint32_t *__restrict__ tasks, const uint32_t *gscratch, uint8_t *work) {
-    __shared__ uint32_t wide_mem[256 + 64];                              // WideO0: 256 entries + the symbol -> position bytes
-    const int lane = threadIdx.x;
-    const uint32_t task = tasks[blockIdx.x], model = task & ((1u << TASK_MODEL_BITS) - 1u), k = sel[task >> TASK_MODEL_BITS];
+                  const uint32_t *__restrict__ tasks, uint32_t ntasks, const uint32_t *gscratch, uint8_t *work) {
+    __shared__ uint32_t wide_mem_all[4][256 + 64];                       // per wavefront, WideO0: 256 entries + the symbol -> position bytes
+    const int lane = threadIdx.x & 63;
+    const uint32_t tix = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tix >= ntasks) return;
+    uint32_t *wide_mem = wide_mem_all[threadIdx.x >> 6];
+    const uint32_t task = tasks[tix], model = task & ((1u << TASK_MODEL_BITS) - 1u), k = sel[task >> TASK_MODEL_BITS];
     const hg_stream_desc d = desc[k];
     const Info *I = (const Info *)(gscratch + d.scratch_off);
     const uint32_t flags = flags_in[k], order = flags & F_ORDER, rle = flags & F_RLE, m = I->m, n = d.in_len;
@@ -325,7 +329,8 @@ int launch_arith_encode2(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_
                          size_t ntasks, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch, void *d_work, hipStream_t s) {
     if (!n2) return HG_OK;
     hipLaunchKernelGGL(hga2::prepass_kernel, dim3((unsigned)n2), dim3(256), 0, s, (const uint8_t *)d_in, d_desc, d_flags, d_sel2, d_scratch, (uint8_t *)d_work);
-    hipLaunchKernelGGL(hga2::model_kernel, dim3((unsigned)ntasks), dim3(64), 0, s, (const uint8_t *)d_in, d_desc, d_flags, d_sel2, d_tasks, (const uint32_t *)d_scratch, (uint8_t *)d_work);
+    hipLaunchKernelGGL(hga2::model_kernel, dim3((unsigned)((ntasks + 3) / 4)), dim3(256), 0, s, (const uint8_t *)d_in, d_desc, d_flags, d_sel2, d_tasks, (uint32_t)ntasks, (const uint32_t *)d_scratch,
+                       (uint8_t *)d_work);
     hipLaunchKernelGGL(hga2::code_kernel, dim3((unsigned)n2), dim3(64), 0, s, d_desc, d_flags, d_sel2, (const uint32_t *)d_scratch, (const uint8_t *)d_work, (uint8_t *)d_out, d_out_len);
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
