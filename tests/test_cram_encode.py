@@ -168,6 +168,46 @@ def encode_gpu(engine, bam, nrec, per_slice, refs, rg_names=(), counter=0):
 
 
 @pytest.mark.gpu
+def test_gpu_encoder_counts_the_records_itself(engine):
+    """hg_cram_encode_slices_host2 with *nrec_io = 0: bam_read1's framing on the device counts the records, the survey pass sums l_seq per slice (the container
+    header's base count) -- the same blobs as the call that is told the count, the sums of a host walk; a stream that ends inside a record is refused"""
+    from htslib_amd import _native as nat, synth_cram
+    rng = np.random.default_rng(47)
+    s = synth_cram.make_slice(rng, 2500, 120, tags=True, unmapped_every=7)
+    keep = []
+    arr = nat.cram_slice_array([s], keep)
+    bases = s["nrec"] * 130 + 4096
+    bam, rec_off, st = engine.cram_decode_bam(arr, 1, 3, 1, [], bases, bases * 4 + 600 * s["nrec"])
+    assert st[0] == 0
+    bam = bytes(bam)
+    ref = s["refs"][0][2]
+    per = 600
+    st_g, blobs = encode_gpu(engine, bam, s["nrec"], per, [ref])
+    assert (st_g == 0).all()
+    kr = C.create_string_buffer(ref, len(ref)); ra = (RefSeq * 1)(RefSeq(C.addressof(kr), len(ref)))
+    ns_max = len(bam) // 36 // per + 2
+    out = np.zeros(len(bam) * 6 + 65536 * ns_max + 4096, np.uint8); off = np.zeros(ns_max + 1, np.uint64); stt = np.full(ns_max, 9, np.int32); total = C.c_uint64()
+    sb = np.zeros(ns_max, np.uint64); n = C.c_size_t(0)
+    b = C.create_string_buffer(bam, len(bam))
+    f = nat.lib.hg_cram_encode_slices_host2
+    f.argtypes = [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_uint32, _vp, C.c_int, _vp, C.c_int, C.c_int64, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.POINTER(C.c_uint64), _vp]
+    rc = f(engine._h, C.cast(b, _vp), len(bam), C.byref(n), per, C.cast(ra, _vp), 1, None, 0, 0, out.ctypes.data, len(out), off.ctypes.data, ns_max, stt.ctypes.data, C.byref(total), sb.ctypes.data)
+    ns = (s["nrec"] + per - 1) // per
+    assert rc == 0 and n.value == s["nrec"] and (stt[:ns] == 0).all()
+    assert [bytes(out[int(off[i]):int(off[i + 1])]) for i in range(ns)] == blobs
+    lseq, at = [], 0
+    while at < len(bam):
+        bs = int.from_bytes(bam[at:at + 4], "little"); lseq.append(int.from_bytes(bam[at + 20:at + 24], "little")); at += 4 + bs
+    assert [int(x) for x in sb[:ns]] == [sum(lseq[i * per:(i + 1) * per]) for i in range(ns)]
+    n = C.c_size_t(0)
+    rc = f(engine._h, C.cast(b, _vp), len(bam) - 7, C.byref(n), per, C.cast(ra, _vp), 1, None, 0, 0, out.ctypes.data, len(out), off.ctypes.data, ns_max, stt.ctypes.data, C.byref(total), sb.ctypes.data)
+    assert rc == -1                                                     # HG_EINVAL: the last record is cut short
+    n = C.c_size_t(s["nrec"] + 1)
+    rc = f(engine._h, C.cast(b, _vp), len(bam), C.byref(n), per, C.cast(ra, _vp), 1, None, 0, 0, out.ctypes.data, len(out), off.ctypes.data, ns_max, stt.ctypes.data, C.byref(total), sb.ctypes.data)
+    assert rc == -1                                                     # a count that is not the stream's
+
+
+@pytest.mark.gpu
 def test_gpu_encoder_equals_the_cpu_compile_and_round_trips_to_the_same_bam(engine, hostlib):
     """synthetic slices -> BAM (device: cram_decode_slice + cram_to_bam) -> CRAM slices (device encoder) -> BAM again: byte-identical streams, for whole
     slices and for a different slicing; the encoder's blobs equal the CPU compile's byte for byte"""
