@@ -121,26 +121,30 @@ struct RecOut {
 // task word: model id (10 bits: 0..255 literal context, 256 + c run model of symbol c, 512 / 513 the run models 256 / 257) | index into sel << 10
 constexpr uint32_t TASK_MODEL_BITS = 10;
 
-// Every task walks its whole stream, 64 positions per step, and most steps find little to do: the loads of the next FOUR steps are in flight while one is
-// worked on (with one step of look-ahead the walk ran at memory latency -- ~1 us per 64 bytes, times a few hundred tasks per stream).
-// body(i0, cur, prev): lane l holds the byte at i0 + l and the one before it (0 before the stream; 0x100 / 0 past its end).
-template <class Body>
-__device__ __forceinline__ void scan_tiles(const uint8_t *src, uint32_t n, int lane, Body body) {
+// Every task walks its whole stream, 64 positions per step, and most steps find little to do: the loads of the next FOUR steps are in flight while four
+// are worked on.  pre(i0, cur, prev) -> the step's event mask; body(i0, cur, mask) works through it.  The masks of all four steps are formed BEFORE the next
+// loads are issued (and the scheduler is kept from moving the loads up): the first use of a loaded register makes the compiler wait for every load in
+// flight -- vmcnt counts in order and nothing is known across the loop edge -- so loads issued ahead of that use were waited for at once and the walk
+// ran at memory latency.  cur / prev: lane l holds the byte at i0 + l and the one before it (0 before the stream; 0x100 / 0 past its end).
+template <class Pre, class Body>
+__device__ __forceinline__ void scan_tiles(const uint8_t *src, uint32_t n, int lane, Pre pre, Body body) {
     auto load = [&](uint32_t i0, uint32_t &cur, uint32_t &prev) {
         const uint32_t p = i0 + (uint32_t)lane;
         cur = p < n ? (uint32_t)src[p] : 0x100u; prev = (p && p < n) ? (uint32_t)src[p - 1u] : 0u;
     };
     uint32_t nc[4], np[4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) { nc[t] = 0x100u; np[t] = 0u; if (64u * (uint32_t)t < n) load(64u * (uint32_t)t, nc[t], np[t]); }
+    for (int t = 0; t < 4; t++) load(64u * (uint32_t)t, nc[t], np[t]);
     for (uint32_t g0 = 0; g0 < n; g0 += 256u) {
-        uint32_t c[4], q[4];
+        uint32_t c[4]; unsigned long long m[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) { c[t] = nc[t]; q[t] = np[t]; }
+        for (int t = 0; t < 4; t++) { c[t] = nc[t]; m[t] = pre(g0 + 64u * (uint32_t)t, nc[t], np[t]); }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 4; t++) { const uint32_t i0 = g0 + 256u + 64u * (uint32_t)t; if (i0 < n) load(i0, nc[t], np[t]); }
+        for (int t = 0; t < 4; t++) load(g0 + 256u + 64u * (uint32_t)t, nc[t], np[t]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 4; t++) { const uint32_t i0 = g0 + 64u * (uint32_t)t; if (i0 < n) body(i0, c[t], q[t]); }
+        for (int t = 0; t < 4; t++) { const uint32_t i0 = g0 + 64u * (uint32_t)t; if (i0 < n) body(i0, c[t], m[t]); }
     }
 }
 
@@ -154,9 +158,10 @@ __device__ __forceinline__ void lit_task(const uint8_t *src, uint32_t n, uint32_
         W.init(wide_mem, (uint8_t *)(wide_mem + 256), m, true, lane);
     } else G.init(m, lane);
     RecOut O; O.start(R);
-    scan_tiles(src, n, lane, [&](uint32_t i0, uint32_t cur, uint32_t prev) {
+    scan_tiles(src, n, lane, [&](uint32_t i0, uint32_t cur, uint32_t prev) -> unsigned long long {
         const uint32_t p = i0 + (uint32_t)lane;
-        unsigned long long mask = __ballot(p < n && (!order || prev == ctx) && (!rle || p == 0 || cur != prev));
+        return __ballot(p < n && (!order || prev == ctx) && (!rle || p == 0 || cur != prev));
+    }, [&](uint32_t i0, uint32_t cur, unsigned long long mask) {
         while (mask) {
             const uint32_t b = (uint32_t)__builtin_ctzll(mask); mask &= mask - 1ull;
             const uint32_t sym = rl(cur, b);
@@ -188,8 +193,9 @@ __device__ __forceinline__ void run_first_task(const uint8_t *src, uint32_t n, u
         O.put(2u * s + 1u, cum, f, t, lane);
     };
     bool open = false; uint32_t s = 0, len = 0;
-    scan_tiles(src, n, lane, [&](uint32_t i0, uint32_t cur, uint32_t) {
-        unsigned long long bits = __ballot(cur == c);                    // the runs of c are the runs of set bits (positions past the end never match)
+    scan_tiles(src, n, lane, [&](uint32_t, uint32_t cur, uint32_t) -> unsigned long long {
+        return __ballot(cur == c);                                        // the runs of c are the runs of set bits (positions past the end never match)
+    }, [&](uint32_t i0, uint32_t, unsigned long long bits) {
         if (open) {
             const uint32_t ones = ~bits ? (uint32_t)__builtin_ctzll(~bits) : 64u;
             len += ones;
@@ -233,9 +239,11 @@ __device__ __forceinline__ void run_more_task(const uint8_t *src, uint32_t n, ui
         }
     };
     bool have = false; uint32_t s_last = 0;
-    scan_tiles(src, n, lane, [&](uint32_t i0, uint32_t cur, uint32_t prev) {
+    scan_tiles(src, n, lane, [&](uint32_t i0, uint32_t cur, uint32_t prev) -> unsigned long long {
         const uint32_t p = i0 + (uint32_t)lane;
-        const unsigned long long valid = __ballot(p < n), st = __ballot(p < n && (p == 0 || cur != prev));
+        return __ballot(p < n && (p == 0 || cur != prev));                // the run starts
+    }, [&](uint32_t i0, uint32_t, unsigned long long st) {
+        const unsigned long long valid = n - i0 >= 64u ? ~0ull : (1ull << (n - i0)) - 1ull;
         if (!st) return;
         const unsigned long long nst = valid & ~st, longish = nst & (nst >> 1) & (nst >> 2);
         uint32_t a = (uint32_t)__builtin_ctzll(st);

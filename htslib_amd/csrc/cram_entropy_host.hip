@@ -497,7 +497,10 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
     bool too_big = false;
     std::vector<uint8_t> ccls;
     const bool two_phase = !(getenv("HG_ARITH_2P") && atoi(getenv("HG_ARITH_2P")) == 0);          // (HG_ARITH_2P=0: every stream through the one-pass kernels, for A/B runs)
-    const uint32_t two_phase_min = getenv("HG_ARITH_2P_MIN") && atoi(getenv("HG_ARITH_2P_MIN")) > 0 ? (uint32_t)atoi(getenv("HG_ARITH_2P_MIN")) : HG_ARITH_2P_MIN;
+    // The two-phase form trades a stream's LATENCY (its serial chain) for machine WORK (every model's task walks the whole stream): it pays when the call
+    // has few streams to fill the GPU with, or when a stream is so long that the batch waits for it (profiles/r04_arith_two_phase.txt).
+    const bool two_phase_forced = getenv("HG_ARITH_2P_MIN") && atoi(getenv("HG_ARITH_2P_MIN")) > 0;
+    const uint32_t two_phase_min = two_phase_forced ? (uint32_t)atoi(getenv("HG_ARITH_2P_MIN")) : leaves.size() <= HG_ARITH_2P_FEW ? HG_ARITH_2P_MIN_FEW : HG_ARITH_2P_MIN;
     auto add_core = [&](uint64_t src_off, uint32_t len, uint32_t fl, Codec cc, uint32_t max_sym) {
         hg_stream_desc d;
         memset(&d, 0, sizeof d);
@@ -506,7 +509,9 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         d.in_off = src_off; d.in_len = len; d.out_off = ooff; d.out_len = (uint32_t)(cap > 0xffffffffull ? 0xffffffffu : cap);
         d.scratch_off = (uint32_t)soff; d.reserved = (uint32_t)(woff / 16);
         ooff += (cap + 15u) & ~15ull;
-        if (cc == ARITH && two_phase && len >= two_phase_min) {
+        // (order 0 without RLE is ONE model: its two phases run one after the other, no gain -- 40 / 72 ms against 47 / 63 for 100 000 symbols; the
+        // override of the tests takes it through both forms all the same)
+        if (cc == ARITH && two_phase && len >= two_phase_min && (two_phase_forced || (fl & (F_ORDER | F_RLE)))) {
             // long streams: models and coder in two phases (arith_enc2.hip); 8 bytes per record slot in the work buffer -- one slot per byte, two with RLE --
             // and 16 words of stream information
             ccls.push_back(C_ARITH_2P);

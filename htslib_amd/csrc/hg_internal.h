@@ -125,6 +125,8 @@ int launch_arith_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
 // on a batch of slices: every two-phase stream brings 256 .. 514 single-wavefront tasks, and a few hundred streams of 20 .. 40 KB flooded the dispatcher
 // (profiles/r04_arith_two_phase.txt).  HG_ARITH_2P_MIN overrides (tests run the two-phase path from 8 KiB).
 #define HG_ARITH_2P_MIN 262144u
+#define HG_ARITH_2P_FEW 32u            // a call with at most this many streams ...
+#define HG_ARITH_2P_MIN_FEW 16384u     // ... is latency-bound: two phases from 16 KiB (one stream of 100 000 symbols, order 1: 24 ms against 54)
 int launch_arith_encode2(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags, const uint32_t *d_sel2, size_t n2, const uint32_t *d_tasks,
                          size_t ntasks, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch, void *d_work, hipStream_t s);
 // tok3.hip: one name-reconstruction job per CRAM method-8 block
