@@ -17,7 +17,7 @@ REF = "/root/reference"
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference sources to compile test_bgzf.c / bgzip.c")
 
 
-@pytest.fixture(scope="module", params=["", "thread"])
+@pytest.fixture(scope="module", params=["", "thread", "address,undefined"])
 def progs(request):
     san = request.param
     r = subprocess.run(["bash", os.path.join(ROOT, "tests", "native", "build_hostlogic.sh"), *([san] if san else [])],
@@ -41,9 +41,9 @@ def test_large_reads_go_through_the_copy_helpers(progs, tmp_path):
     """bgzf_read with an 8 MiB buffer: copies of 2 MiB and more are shared with helper threads (race detector on in the
     `thread` build); the bytes must be the file's."""
     import numpy as np
-    suf = "_thread" if progs[0].endswith("_thread") else ""
+    suf = "_thread" if progs[0].endswith("_thread") else "_address,undefined" if progs[0].endswith("_address,undefined") else ""
     exe = str(tmp_path / "bigread")
-    r = subprocess.run(["gcc", "-O1", "-g"] + (["-fsanitize=thread"] if suf else []) +
+    r = subprocess.run(["gcc", "-O1", "-g"] + (["-fsanitize=" + suf[1:]] if suf else []) +
                        ["-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "bigread.c"), "-o", exe,
                         "-L", OUT, "-lhts_bgzf_fake" + suf, "-Wl,-rpath," + OUT, "-lpthread"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
@@ -52,7 +52,7 @@ def test_large_reads_go_through_the_copy_helpers(progs, tmp_path):
     plain.write_bytes(data)
     with open(gz, "wb") as f:
         assert subprocess.run([progs[1], "-@4", "-c", str(plain)], stdout=f).returncode == 0
-    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
     out = subprocess.run([exe, str(gz)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     assert out.stdout == data

@@ -151,3 +151,21 @@ def test_deflate_blocks_decode_everywhere(hc, oracle):
             f.write(stream + synth.BGZF_EOF); f.flush()
             r = subprocess.run([os.path.join(refutil.REF_DIR, "ref_bgzip_ld"), "-d", "-c", f.name], capture_output=True)
             assert r.returncode == 0 and r.stdout == plain[:len(r.stdout)] and len(r.stdout) == total_in
+
+
+def test_host_codec_under_sanitizers_with_damaged_blocks(tmp_path):
+    """tests/native/host_codec_san.cpp: AddressSanitizer + UBSan over deflate -> inflate round trips at four levels and six kinds of damage per block: no
+    out-of-bounds access, no truncated block accepted, a flipped bit accepted only if the output is still right"""
+    exe = str(tmp_path / "hc_san")
+    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17", "-I", os.path.join(refutil.ROOT, "htslib_amd", "csrc"),
+                        "-I", os.path.join(refutil.ROOT, "include"), os.path.join(refutil.ROOT, "tests", "native", "host_codec_san.cpp"), "-o", exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    rng = np.random.default_rng(5)
+    bam, _, _ = synth.bam_stream(2 << 20, 0x5EED0003, 0, True)
+    files = {"bam.raw": bam, "rand.raw": rng.integers(0, 256, 600_000, dtype=np.uint8).tobytes(), "runs.raw": (b"A" * 70000 + b"ACGT" * 20000 + bytes(100000)) * 2,
+             "text.raw": open(os.path.join(refutil.ROOT, "DESIGN.md"), "rb").read()}
+    paths = []
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data); paths.append(str(tmp_path / name))
+    r = subprocess.run([exe] + paths, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"), timeout=900)
+    assert r.returncode == 0 and b"blocks round-tripped" in r.stdout, r.stdout.decode()[-3000:]
