@@ -138,7 +138,7 @@ def check_against_twin(fname, got, expect):
 @pytest.fixture(scope="module")
 def hostlib(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("cramrec") / "libcram_records_host.so")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", so, os.path.join(ROOT, "tests", "native", "cram_records_host.cpp")], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall"] + os.environ.get("HG_TEST_HOSTLIB_FLAGS", "").split() + ["-o", so, os.path.join(ROOT, "tests", "native", "cram_records_host.cpp")], check=True)
     L = C.CDLL(so)
     L.hgr_host_records_bound.argtypes = [C.c_size_t, _vp, C.c_int, _vp, _vp, _vp, _vp]
     L.hgr_host_decode_records.argtypes = [C.c_size_t, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp]

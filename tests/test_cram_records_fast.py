@@ -23,7 +23,7 @@ _vp = C.c_void_p
 def hostlib(tmp_path_factory):
     import subprocess
     so = str(tmp_path_factory.mktemp("cramfast") / "libcram_records_host.so")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas", "-o", so, os.path.join(T.ROOT, "tests", "native", "cram_records_host.cpp")], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas"] + os.environ.get("HG_TEST_HOSTLIB_FLAGS", "").split() + ["-o", so, os.path.join(T.ROOT, "tests", "native", "cram_records_host.cpp")], check=True)
     L = C.CDLL(so)
     L.hgr_host_records_bound.argtypes = [C.c_size_t, _vp, C.c_int, _vp, _vp, _vp, _vp]
     L.hgr_host_decode_records.argtypes = [C.c_size_t, _vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, _vp]
