@@ -511,7 +511,7 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         ooff += (cap + 15u) & ~15ull;
         // (order 0 without RLE is ONE model: its two phases run one after the other, no gain -- 40 / 72 ms against 47 / 63 for 100 000 symbols; the
         // override of the tests takes it through both forms all the same)
-        if (cc == ARITH && two_phase && len >= two_phase_min && (two_phase_forced || (fl & (F_ORDER | F_RLE)))) {
+        if (cc == ARITH && two_phase && len >= two_phase_min && len < (1u << 30) /* slot numbers are 32-bit: 2 n with RLE */ && (two_phase_forced || (fl & (F_ORDER | F_RLE)))) {
             // long streams: models and coder in two phases (arith_enc2.hip); 8 bytes per record slot in the work buffer -- one slot per byte, two with RLE --
             // and 16 words of stream information
             ccls.push_back(C_ARITH_2P);
