@@ -1,0 +1,103 @@
+"""The two-phase form of the range coder's encoder (htslib_amd/csrc/arith_enc2.hip), as a plain-Python model checked against the oracle on the CPU: the events of a
+stream are grouped by MODEL (literal context, run model), every model walks only its own events and leaves a (cum, freq, total) record in the event's slot --
+slot i for the literal at position i, slots 2i, 2i+1, ... for the run that starts at i when RLE is on -- and one pass over the slots in order does the coder
+arithmetic.  If the decomposition were not equivalent to the one-pass coder (a model whose state depends on another model's events, a slot rule that loses
+stream order) the bytes would differ from oracle/arith_oracle.c's.  The kernels themselves are compared with the oracle under -m gpu (tests/test_arith.py)."""
+import numpy as np
+import pytest
+
+from tests import refutil
+from tests.test_ransnx16 import runs_series
+
+STEP, MAX_FREQ, TOP = 16, (1 << 16) - 17, 1 << 24
+M32 = 0xffffffff
+
+
+class Model:                                            # arith_dev.h model_update / RegModel::step
+    def __init__(self, m):
+        self.e = [[1, s] for s in range(m)]; self.tot = m
+
+    def step(self, sym):
+        x = next(i for i, (f, s) in enumerate(self.e) if s == sym)
+        f = self.e[x][0]; cum = sum(q[0] for q in self.e[:x]); tot = self.tot
+        self.e[x][0] += STEP; self.tot += STEP
+        if self.tot > MAX_FREQ:
+            for q in self.e: q[0] -= q[0] >> 1
+            self.tot = sum(q[0] for q in self.e)
+        if x and self.e[x][0] > self.e[x - 1][0]: self.e[x], self.e[x - 1] = self.e[x - 1], self.e[x]
+        return cum, f, tot
+
+
+def phase_a(d, order, rle):
+    """-> m, slots: {slot: (cum, freq, total)}; every model sees only its own events, in stream order"""
+    n = len(d); m = max(d) + 1
+    events = {}                                         # model id -> [(slot, symbol)]
+    def ev(model, slot, sym): events.setdefault(model, []).append((slot, sym))
+    if not rle:
+        for i, c in enumerate(d): ev(("lit", d[i - 1] if order and i else 0), i, c)
+    else:
+        i = 0
+        while i < n:
+            c = d[i]; r = 0
+            while i + 1 + r < n and d[i + 1 + r] == c: r += 1
+            ev(("lit", d[i - 1] if order and i else 0), 2 * i, c)                 # the context of a run's literal: the symbol of the run before = the byte before
+            rctx, j, rem = c, 1, r
+            while True:
+                part = min(rem, 3)
+                ev(("run", rctx), 2 * i + j, part)
+                rctx = 256 if rctx == c else 257; j += 1; rem -= part
+                if part != 3: break
+            assert j <= 2 * (r + 1)                                              # a run's events fit the slots of its positions
+            i += r + 1
+    slots = {}
+    for (kind, _), evs in events.items():
+        M = Model(m if kind == "lit" else 4)
+        for slot, sym in evs:
+            assert slot not in slots
+            slots[slot] = M.step(sym)
+    return m, slots
+
+
+def phase_b(m, slots, nslots):                          # arith_dev.h Encoder over the records; empty slots are skipped
+    out = bytearray([m & 0xff])
+    low, rng, carry, cache, ffnum = 0, M32, 0, 0, 0
+    def shift_low():
+        nonlocal low, carry, cache, ffnum
+        if low < 0xff000000 or carry:
+            out.append((cache + carry) & 0xff)
+            while ffnum: out.append((carry - 1) & 0xff); ffnum -= 1
+            cache = low >> 24; carry = 0
+        else: ffnum += 1
+        low = (low << 8) & M32
+    for s in range(nslots):
+        if s not in slots: continue
+        cum, f, tot = slots[s]
+        q = rng // tot
+        old = low; low = (low + cum * q) & M32; rng = q * f
+        if low < old: carry = 1
+        while rng < TOP: rng = (rng << 8) & M32; shift_low()
+    for _ in range(5): shift_low()
+    return bytes(out)
+
+
+def u7(v):
+    b = [v & 0x7f]; v >>= 7
+    while v: b.append(0x80 | (v & 0x7f)); v >>= 7
+    return bytes(reversed(b))
+
+
+@pytest.fixture(scope="module")
+def aorc(built):
+    return refutil.ArithOracle()
+
+
+def test_two_phase_decomposition_equals_the_one_pass_coder(aorc):
+    rng = np.random.default_rng(21)
+    cases = [bytes(rng.integers(0, 6, 900, dtype=np.uint8)), bytes(rng.integers(0, 200, 1200, dtype=np.uint8)), runs_series(rng, 1500), bytes(7000),
+             bytes(rng.choice(np.array([3, 9, 250], dtype=np.uint8), 9000, p=[0.97, 0.02, 0.01])), bytes([5]), bytes([0, 0, 0, 0, 0, 0, 0, 1])]
+    for d in cases:
+        for fl in (0, 1, 64, 65):
+            order, rle = fl & 1, 1 if fl & 64 else 0
+            m, slots = phase_a(d, order, rle)
+            got = bytes([fl]) + u7(len(d)) + phase_b(m, slots, (2 if rle else 1) * len(d))
+            assert got == aorc.encode(d, fl), (len(d), fl)
