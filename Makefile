@@ -13,7 +13,7 @@ all: $(LIB) $(FRONT) oracle
 
 # htslib's BGZF front-end API (bgzf_open/read/write/...) over the engine: host C++ only
 # (hfile_min.cpp = bundled local-file hFILE provider; a libhts build links hfile.c instead, see oracle/Makefile)
-FRONTSRC := $(CSRC)/bgzf_front.cpp $(CSRC)/cram_block_front.cpp $(CSRC)/hfile_min.cpp
+FRONTSRC := $(CSRC)/bgzf_front.cpp $(CSRC)/cram_block_front.cpp $(CSRC)/htscodecs_front.cpp $(CSRC)/hfile_min.cpp
 $(FRONT): $(FRONTSRC) include/hts_bgzf_gpu.h include/hts_cram_gpu.h include/hts_hfile_abi.h include/htsgpu.h $(LIB)
 	g++ -O2 -std=c++17 -fPIC -shared -Wall -Iinclude $(FRONTSRC) -o $@ -Lhtslib_amd -lhtsgpu -lpthread -ldl -Wl,-rpath,'$$ORIGIN'
 

@@ -342,6 +342,9 @@ Coalescer<CompReq> g_comp{{}, {}, {}, false, run_comp};
 
 }  // namespace
 
+// the block layer's context, for the htscodecs-named entry points (htscodecs_front.cpp)
+namespace hgfront { hg_ctx *shared_engine() { return engine(); } }
+
 extern "C" {
 
 cram_block *cram_new_block(enum cram_content_type content_type, int content_id) {
@@ -546,7 +549,8 @@ size_t hg_cram_fd_layout(size_t *o) {
     return sizeof v / sizeof v[0];
 }
 int cram_compress_block2(cram_fd *fd, cram_slice *s, cram_block *b, cram_metrics *metrics, int method, int level) {
-    if (!fd || !b) return -1;
+    if (!b) return 0;                                    // cram_compress_slice passes the data series a slice does not have (cram_io.c:1917-1918)
+    if (!fd) return -1;
     const hg_cram_opts o = opts_of(fd);
     // the slice only matters for the FQZ methods: per-record quality lengths and flags, gathered as cram_io.c:1808-1820 does
     std::vector<uint32_t> len, flags;

@@ -41,6 +41,10 @@ int main(int argc, char **argv) {
     if (cram_compress_block(fd, b[0], m[0], 1 << GZIP | 1 << RANS_PR0 | 1 << RANS_PR1, -1) != 0) return fail("cram_compress_block");
     if (cram_compress_block2(fd, &s, b[1], m[1], 1 << GZIP | 1 << RANS_PR1 | 1 << FQZ | 1 << FQZ_b, -1) != 0) return fail("cram_compress_block2 (FQZ)");
     if (cram_compress_block2(fd, &s, b[2], m[2], 1 << GZIP | 1 << TOK3, -1) != 0) return fail("cram_compress_block2 (TOK3)");
+    /* a data series the slice does not have: cram_compress_slice passes NULL and expects "nothing to do" (cram_io.c:1917-1918) */
+    if (cram_compress_block2(fd, &s, NULL, m[0], 1 << GZIP, -1) != 0 || cram_compress_block(fd, NULL, NULL, -1, -1) != 0) return fail("NULL block must be a no-op returning 0");
+    /* an already compressed block is left alone (cram_io.c:1945-1952) */
+    { int cs = b[0]->comp_size, me = b[0]->method; if (cram_compress_block(fd, b[0], m[0], 1 << GZIP, -1) != 0 || b[0]->comp_size != cs || b[0]->method != me) return fail("compressed block touched"); }
     printf("methods %d %d %d sizes %d %d %d\n", b[0]->method, b[1]->method, b[2]->method, b[0]->comp_size, b[1]->comp_size, b[2]->comp_size);
     fd->fp = hopen(argv[1], "w");
     if (!fd->fp) return fail("hopen w");

@@ -1,0 +1,241 @@
+"""THE DROP-IN INSIDE libhts: the reference's own programs on oracle/_ref/libhts_gpu.so.
+
+libhts_gpu.so (oracle/Makefile, target libhts_gpu) = every object of the reference's libhts except bgzf.o, with cram_io.o's / cram_external.o's
+block functions weakened, plus OUR bgzf_front.cpp, cram_block_front.cpp and htscodecs_front.cpp on libhtsgpu.so.  No oracle, no htscodecs stand-in, no
+bgzf.c.  The reference's test/test_view.c (a small `samtools view`), test/test_index.c and test/test_bgzf.c are linked to it UNMODIFIED, so here
+
+  * sam.c's bam_read1 / bam_write1 and the on-the-fly index (sam.c:784-928,942-943 -> bgzf_idx_push, hts.c:2558-2640) run on our bgzf_read / bgzf_write,
+  * cram_decode_slice's block loop (cram/cram_decode.c:624-627) runs on our cram_uncompress_block,
+  * cram_encode_slice / cram_compress_slice (cram/cram_encode.c:803-988) run on our cram_compress_block2 + cram_metrics,
+  * cram_read_container / cram_flush_container run on our cram_read_block / cram_write_block,
+
+driven the way the reference's harness drives them: test/test.pl:708-830 (test_view: SAM -> BAM / CRAM 2.1 / 3.0 / 3.1 -> SAM over every test/*#*.sam, the
+pre-made htsjdk CRAMs) and test/test.pl:1067-1160 (test_index: indexes written on the fly and by test_index against the reference's golden .bai / .csi /
+.crai / .tbi).  The checker is STOCK htslib: oracle/_ref/ref_view (the same program on the reference's whole libhts) must print the same SAM text for every
+file either side writes, in every direction.  Fixtures: tests/golden/view_fixtures.tar.gz (the reference's test data, made by tests/golden/make_view_fixtures.sh)."""
+import gzip
+import hashlib
+import os
+import subprocess
+import tarfile
+
+import pytest
+
+from tests import dropin_cases, refutil
+
+REF = refutil.REF_DIR
+VIEW_GPU = os.path.join(REF, "ref_view_gpu")
+VIEW_REF = os.path.join(REF, "ref_view")
+INDEX_GPU = os.path.join(REF, "test_index_gpu")
+BGZF_GPU = os.path.join(REF, "test_bgzf_libhts_gpu")
+FIX = os.path.join(refutil.ROOT, "tests", "golden", "view_fixtures.tar.gz")
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not (os.path.exists(VIEW_GPU) and os.path.exists(VIEW_REF) and os.path.exists(os.path.join(REF, "libhts_gpu.so"))),
+                                 reason="oracle/_ref/libhts_gpu.so + ref_view_gpu + ref_view not built (make -C oracle ref needs /root/reference)")]
+
+# test/test.pl:712-736
+CRAM31 = {"auxf#values.sam", "c1#pad3.sam", "ce#5.sam", "ce#1000.sam", "ce#large_seq.sam", "ce#supp.sam", "xx#MD.sam", "xx#blank.sam", "xx#large_aux.sam",
+          "xx#pair.sam", "xx#tlen.sam"}
+CRAM_MS = {"ce#1000.sam", "ce#5.sam", "ce#5b.sam", "ce#unmap.sam", "ce#unmap1.sam", "ce#unmap2.sam", "xx#blank.sam", "xx#minimal.sam", "xx#tlen.sam",
+           "xx#tlen2.sam", "xx#triplet.sam"}
+
+
+@pytest.fixture(scope="module")
+def fx(tmp_path_factory):
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU")
+    d = str(tmp_path_factory.mktemp("viewfix"))
+    with tarfile.open(FIX) as t:
+        t.extractall(d)
+    # the MD5 reference cache test.pl builds with ce_fa_to_md5_cache (REF_PATH=<dir>/%2s/%2s/%s): every sequence of every .fa
+    m5 = os.path.join(d, "md5")
+    for fa in [f for f in os.listdir(d) if f.endswith(".fa")]:
+        for rec in open(os.path.join(d, fa)).read().split(">")[1:]:
+            seq = "".join(rec.split("\n")[1:]).upper().encode()
+            h = hashlib.md5(seq).hexdigest()
+            os.makedirs(os.path.join(m5, h[:2], h[2:4]), exist_ok=True)
+            open(os.path.join(m5, h[:2], h[2:4], h[4:]), "wb").write(seq)
+    return d
+
+
+def _env(d):
+    e = dict(os.environ, REF_PATH=os.path.join(d, "md5", "%2s", "%2s", "%s"), REF_CACHE="", HTS_GPU_STRICT="1")
+    e.pop("ORC_STUB_CODECS31", None)
+    return e
+
+
+def view(exe, args, d, out=None, ok=True, env=None):
+    """run test_view in the fixture directory; -> stdout bytes (or writes `out`)"""
+    p = subprocess.run([exe] + list(args), cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env or _env(d), timeout=600)
+    if ok:
+        assert p.returncode == 0, (exe, args, p.returncode, p.stderr.decode("latin1")[-1500:])
+    if out:
+        open(os.path.join(d, out), "wb").write(p.stdout)
+    return p.stdout
+
+
+def sams(d):
+    return sorted(f for f in os.listdir(d) if "#" in f and f.endswith(".sam"))
+
+
+def at(n):
+    return [f"-@{n}"] if n else []
+
+
+# ------------------------------------------------------------------------------------------------------------ test/test_bgzf.c inside libhts
+def test_reference_test_bgzf_on_libhts_gpu(tmp_path):
+    if not os.path.exists("/dev/kfd"): pytest.skip("no GPU")
+    dropin_cases.reference_test_bgzf(BGZF_GPU, str(tmp_path))
+
+
+# ------------------------------------------------------------------------------------------------------------ BAM: bam_write1 / bam_read1 on our bgzf
+@pytest.mark.parametrize("threads", [0, 4])
+def test_view_bam_both_directions_equal_stock_htslib(fx, threads):
+    """test.pl:750-762 (SAM -> BAM -> SAM, compressed and -l0) for every *#*.sam: what ref_view_gpu writes, stock ref_view reads, and the other way round --
+    SAM text identical to stock -> stock."""
+    t = at(threads)
+    files = sams(fx) if threads == 0 else sorted(CRAM31 | CRAM_MS)
+    for sam in files:
+        for lv in ([], ["-l0"]) if sam in ("ce#1000.sam", "xx#large_aux.sam", "ce#5b.sam") else (["-l0"],) if threads == 0 else ([],):
+            view(VIEW_REF, ["-S", "-b", *lv, sam], fx, "stock.bam")
+            want = view(VIEW_REF, ["stock.bam"], fx)
+            view(VIEW_GPU, [*t, "-S", "-b", *lv, sam], fx, "gpu.bam")
+            assert view(VIEW_REF, ["gpu.bam"], fx) == want, (sam, lv, "stock reads what we wrote")
+            assert view(VIEW_GPU, [*t, "stock.bam"], fx) == want, (sam, lv, "we read what stock wrote")
+            if threads: assert view(VIEW_GPU, [*t, "gpu.bam"], fx) == want, (sam, lv, "round trip")
+
+
+# ------------------------------------------------------------------------------------------------------------ CRAM <= 3.0: both directions against stock
+@pytest.mark.parametrize("threads", [0, 4])
+def test_view_cram30_both_directions_equal_stock_htslib(fx, threads):
+    """test.pl:764-790: SAM -> CRAM 2.1 / 3.0 (+ multi-slice containers) -> SAM.  ref_view_gpu -C = the reference's cram_encode_slice + OUR
+    cram_compress_block2 / cram_write_block; reading = the reference's cram_decode_slice + OUR cram_read_block / cram_uncompress_block."""
+    t = at(threads)
+    files = sams(fx) if threads == 0 else sorted(CRAM31 | CRAM_MS)
+    for sam in files:
+        ref = sam.split("#")[0] + ".fa"
+        combos = [["-o", "VERSION=3.0"]]
+        if threads == 0 or sam in ("ce#1000.sam", "ce#5b.sam"): combos.append(["-o", "VERSION=2.1"])
+        if sam in CRAM_MS: combos.append(["-o", "VERSION=3.0", "-o", "seqs_per_slice=7", "-o", "slices_per_container=5"])
+        for o in combos:
+            view(VIEW_REF, ["-t", ref, "-S", "-C", *o, sam], fx, "stock.cram")
+            want = view(VIEW_REF, ["-D", "stock.cram"], fx)
+            view(VIEW_GPU, [*t, "-t", ref, "-S", "-C", *o, sam], fx, "gpu.cram")
+            assert view(VIEW_REF, ["-D", "gpu.cram"], fx) == want, (sam, o, "stock reads what we wrote")
+            assert view(VIEW_GPU, [*t, "-D", "stock.cram"], fx) == want, (sam, o, "we read what stock wrote")
+            assert view(VIEW_GPU, [*t, "-D", "gpu.cram"], fx) == want, (sam, o, "round trip")
+
+
+def test_view_reads_the_htsjdk_crams(fx):
+    """test.pl:818-824: the pre-made Java CRAMs (rANS 4x8 order 0/1, the pinned vectors) through the reference's decoder on our block layer"""
+    for base, ref in (("auxf#values", "auxf.fa"), ("ce#5b", "ce.fa"), ("xx#large_aux", "xx.fa")):
+        want = view(VIEW_REF, ["-i", "reference=" + ref, base + "_java.cram"], fx)
+        assert len(want) > 100
+        for t in (0, 4):
+            assert view(VIEW_GPU, [*at(t), "-i", "reference=" + ref, base + "_java.cram"], fx) == want, (base, t)
+    want = view(VIEW_REF, ["range.cram"], fx)
+    assert view(VIEW_GPU, ["-@4", "range.cram"], fx) == want
+    assert view(VIEW_GPU, ["range.cram", "CHROMOSOME_II:2000-3000"], fx) == view(VIEW_REF, ["range.cram", "CHROMOSOME_II:2000-3000"], fx)
+
+
+# ------------------------------------------------------------------------------------------------------------ CRAM 3.1: every method family on the device
+@pytest.mark.parametrize("threads", [0, 4])
+def test_view_cram31_profiles_round_trip_and_cross_check(fx, threads):
+    """test.pl:792-803: SAM -> CRAM 3.1 {fast, normal, small, archive} -> SAM (-l7).  The writer is the reference's cram_compress_slice with its real method
+    sets (rANS Nx16, range coder, fqzcomp, tok3 ...) on OUR codecs; stock htslib has no 3.1 codec in this container (htscodecs is an absent submodule), so
+    the bar is the reference's own: a self round trip, equal to the 3.0 text -- plus the independent restatements under oracle/ (ORC_STUB_CODECS31=1)
+    reading the same files."""
+    t = at(threads)
+    e31 = dict(_env(fx), ORC_STUB_CODECS31="1")
+    for sam in sorted(CRAM31):
+        ref = sam.split("#")[0] + ".fa"
+        profiles = ["fast", "normal", "small", "archive"] if sam == "ce#1000.sam" else ["archive"]
+        view(VIEW_REF, ["-t", ref, "-S", "-l7", "-C", "-o", "VERSION=3.0", sam], fx, "stock30.cram")
+        want = view(VIEW_REF, ["-D", "stock30.cram"], fx)
+        for prof in profiles:
+            view(VIEW_GPU, [*t, "-t", ref, "-S", "-l7", "-C", "-o", "VERSION=3.1", "-o", prof, sam], fx, "gpu31.cram")
+            assert open(os.path.join(fx, "gpu31.cram"), "rb").read(6) == b"CRAM\x03\x01"
+            assert view(VIEW_GPU, [*t, "-D", "gpu31.cram"], fx) == want, (sam, prof, "round trip")
+            assert view(VIEW_REF, ["-D", "gpu31.cram"], fx, env=e31) == want, (sam, prof, "the CPU restatements read what the device wrote")
+            view(VIEW_REF, ["-t", ref, "-S", "-l7", "-C", "-o", "VERSION=3.1", "-o", prof, sam], fx, "orc31.cram", env=e31)
+            assert view(VIEW_GPU, [*t, "-D", "orc31.cram"], fx) == want, (sam, prof, "the device reads what the CPU restatements wrote")
+
+
+def test_cram31_files_use_the_31_methods(fx):
+    """the archive profile of ce#1000 must really contain method 5-8 blocks (not a gzip fall-back): count on-disk method ids through the reference's reader"""
+    view(VIEW_GPU, ["-@4", "-t", "ce.fa", "-S", "-l7", "-C", "-o", "VERSION=3.1", "-o", "archive", "ce#1000.sam"], fx, "m31.cram")
+    import sys
+    sys.path.insert(0, os.path.join(refutil.ROOT, "tests", "golden"))
+    import make_golden_rans as R                                 # (its walker of the CRAM container format; test infrastructure)
+    meth = {blk[0] for _, blks in R.containers(open(os.path.join(fx, "m31.cram"), "rb").read()) for blk in blks}
+    assert any(m in meth for m in (5, 6)) and 8 in meth, meth
+
+
+# ------------------------------------------------------------------------------------------------------------ test.pl test_index
+def _cmp(d, got, want, gz=False):
+    a, b = open(os.path.join(d, got), "rb").read(), open(os.path.join(d, want), "rb").read()
+    if gz: a, b = gzip.decompress(a), gzip.decompress(b)
+    assert a == b, (got, want, len(a), len(b))
+
+
+@pytest.mark.parametrize("threads", [0, 4])
+def test_index_on_the_fly_and_test_index_equal_golden(fx, threads):
+    """test.pl:1067-1160 with test_view / test_index on libhts_gpu.so; the golden indexes are the reference's own files."""
+    t = at(threads)
+    d = fx
+
+    def idx(args):
+        p = subprocess.run([INDEX_GPU] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=_env(d), timeout=600)
+        assert p.returncode == 0, (args, p.stderr.decode("latin1")[-1500:])
+
+    def rm(f):
+        if os.path.exists(os.path.join(d, f)): os.unlink(os.path.join(d, f))
+
+    os.makedirs(os.path.join(d, "t"), exist_ok=True)
+    # BAM
+    view(VIEW_GPU, [*t, "-l", "0", "-b", "-m", "14", "-x", "t/index.bam.csi", "index.sam"], d, "t/index.bam"); _cmp(d, "t/index.bam.csi", "index.bam.csi", gz=True)
+    rm("t/index.bam.csi"); idx(["-c", "t/index.bam"]); _cmp(d, "t/index.bam.csi", "index.bam.csi", gz=True)
+    view(VIEW_GPU, [*t, "-l", "0", "-b", "-m", "0", "-x", "t/index.bam.bai", "index.sam"], d, "t/index.bam"); _cmp(d, "t/index.bam.bai", "index.bam.bai")
+    rm("t/index.bam.bai"); idx(["-b", "t/index.bam"]); _cmp(d, "t/index.bam.bai", "index.bam.bai")
+    # SAM.gz (and DOS line endings)
+    for src in ("index.sam", "index_dos.sam"):
+        view(VIEW_GPU, [*t, "-l", "0", "-z", "-m", "14", "-x", "t/index.sam.gz.csi", src], d, "t/index.sam.gz"); _cmp(d, "t/index.sam.gz.csi", "index.sam.gz.csi", gz=True)
+        rm("t/index.sam.gz.csi"); idx(["-c", "t/index.sam.gz"]); _cmp(d, "t/index.sam.gz.csi", "index.sam.gz.csi", gz=True)
+        view(VIEW_GPU, [*t, "-l", "0", "-z", "-m", "0", "-x", "t/index.sam.gz.bai", src], d, "t/index.sam.gz"); _cmp(d, "t/index.sam.gz.bai", "index.sam.gz.bai")
+        rm("t/index.sam.gz.bai"); idx(["-b", "t/index.sam.gz"]); _cmp(d, "t/index.sam.gz.bai", "index.sam.gz.bai")
+    # CRAM
+    view(VIEW_GPU, [*t, "-l", "0", "-C", "-x", "t/index.cram.crai", "index.sam"], d, "t/index.cram"); _cmp(d, "t/index.cram.crai", "index.cram.crai", gz=True)
+    rm("t/index.cram.crai"); idx(["t/index.cram"]); _cmp(d, "t/index.cram.crai", "index.cram.crai", gz=True)
+    # CRAM container skipping
+    view(VIEW_GPU, [*t, "-C", "-p", "t/index3.cram", "-x", "t/index3.cram.crai", "-o", "seqs_per_slice=2", "index3.sam"], d)
+    view(VIEW_GPU, [*t, "-p", "t/index3_rgn.sam", "t/index3.cram", "CHROMOSOME_I:5000-5100"], d); _cmp(d, "t/index3_rgn.sam", "index3_exp.sam")
+    view(VIEW_GPU, [*t, "-M", "-p", "t/index3_rgnm.sam", "t/index3.cram", "CHROMOSOME_I:5000-5100"], d); _cmp(d, "t/index3_rgnm.sam", "index3_exp.sam")
+    # BCF / VCF
+    view(VIEW_GPU, [*t, "-l", "0", "-b", "-m", "14", "-x", "t/index.bcf.csi", "index.vcf"], d, "t/index.bcf"); _cmp(d, "t/index.bcf.csi", "index.bcf.csi", gz=True)
+    rm("t/index.bcf.csi"); idx(["-c", "t/index.bcf"]); _cmp(d, "t/index.bcf.csi", "index.bcf.csi", gz=True)
+    view(VIEW_GPU, [*t, "-l", "0", "-z", "-m", "14", "-x", "t/index.vcf.gz.csi", "index.vcf"], d, "t/index.vcf.gz"); _cmp(d, "t/index.vcf.gz.csi", "index.vcf.gz.csi", gz=True)
+    rm("t/index.vcf.gz.csi"); idx(["-c", "t/index.vcf.gz"]); _cmp(d, "t/index.vcf.gz.csi", "index.vcf.gz.csi", gz=True)
+    view(VIEW_GPU, [*t, "-l", "0", "-z", "-m", "0", "-x", "t/index.vcf.gz.tbi", "index.vcf"], d, "t/index.vcf.gz"); _cmp(d, "t/index.vcf.gz.tbi", "index.vcf.gz.tbi", gz=True)
+    rm("t/index.vcf.gz.tbi"); idx(["-t", "t/index.vcf.gz"]); _cmp(d, "t/index.vcf.gz.tbi", "index.vcf.gz.tbi", gz=True)
+    # index2: mapped/unmapped pairs, every query returns exactly two records
+    view(VIEW_GPU, ["-b", "-p", "t/index2.bam", "-x", "t/index2.bam.bai", "index2.sam"], d)
+    for tid in (1, 2):
+        for pos in (1, 2):
+            out = view(VIEW_GPU, ["t/index2.bam", f"{tid}:{pos}000000-{pos}000000"], d)
+            assert sum(1 for ln in out.splitlines() if ln and not ln.startswith(b"@")) == 2
+
+
+def test_compressed_bam_with_index_on_the_fly_equals_stock(fx):
+    """a COMPRESSED, threaded writer (deferred block addresses: bgzf_idx_push resolves the virtual offsets when the device batch returns, bgzf.c:189-290) --
+    the index must describe OUR file: region queries through it return what stock htslib returns from its own file + index."""
+    view(VIEW_REF, ["-b", "-p", "t/stock.bam", "-x", "t/stock.bam.bai", "-m", "0", "ce#1000.sam"], fx)
+    view(VIEW_GPU, ["-@4", "-b", "-p", "t/gpu.bam", "-x", "t/gpu.bam.bai", "-m", "0", "ce#1000.sam"], fx)
+    view(VIEW_GPU, ["-@4", "-b", "-p", "t/gpu2.bam", "-x", "t/gpu2.bam.csi", "-m", "14", "xx#large_aux.sam"], fx)
+    for rgn in ("CHROMOSOME_I:1-1000", "CHROMOSOME_I:900-1100", "CHROMOSOME_I:1", "CHROMOSOME_I:100000"):
+        want = view(VIEW_REF, ["t/stock.bam", rgn], fx)
+        assert view(VIEW_GPU, ["t/gpu.bam", rgn], fx) == want, rgn
+        assert view(VIEW_REF, ["t/gpu.bam", rgn], fx) == want, rgn          # stock htslib + our file + our index
+    want = view(VIEW_REF, ["-S", "-b", "xx#large_aux.sam"], fx, "t/stock2.bam")
+    assert view(VIEW_REF, ["t/gpu2.bam", "xx"], fx) == view(VIEW_GPU, ["t/gpu2.bam", "xx"], fx)
+    assert view(VIEW_REF, ["t/gpu2.bam"], fx) == view(VIEW_REF, ["t/stock2.bam"], fx)
