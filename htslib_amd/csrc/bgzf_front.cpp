@@ -576,7 +576,10 @@ int engine_read_block(BGZF *fp) {
         }
         e->next_addr = addr + d.clen;
         note_block(fp, b, e->blk);
-        if (d.ulen == 0) { fp->block_address = e->next_addr; continue; }  // empty blocks are skipped (bgzf.c:1054-1061)
+        // empty blocks are skipped (bgzf.c:1054-1061) WITHOUT moving fp->block_address: it stays where bgzf_read left it when the previous block ran
+        // out, the start of the empty block (bgzf.c:1064-1066 `if (!j->hit_eof)`, :1147-1155) -- so bgzf_tell() at the end of a file is the address of
+        // the EOF block, which is what index builders store as the last chunk's end (hts_idx_finish(idx, bgzf_tell(fp)), test/index.bcf.csi)
+        if (d.ulen == 0) continue;
         if (fp->block_length != 0) fp->block_offset = 0;                 // a seek's offset survives (bgzf.c:1064)
         fp->block_address = addr;
         fp->block_clength = (int)d.clen;

@@ -106,3 +106,27 @@ def test_a_handle_spreads_its_batches_over_several_devices(progs, tmp_path):
         used = {int(x.split("=")[0]): int(x.split("=")[1]) for x in rep.split(":")[1].split()}
         assert set(used) == {0, 1, 2, 3} and min(used.values()) >= 1, rep
     assert set(int(x.split("=")[0]) for x in outs["0"][1].split(":")[1].split()) == {0}
+
+
+# ---- the front-end inside the reference's whole libhts (build_hostlogic.sh: libhts_fake.so = reference objects minus bgzf.o + bgzf_front.cpp on the test
+# double): sam.c's bam_read1 / bam_write1, vcf.c's BCF reader / writer and the on-the-fly indexes over our bgzf_* host logic.  GPU twin: tests/test_libhts_gpu.py
+@pytest.fixture(scope="module")
+def libhts_fake(tmp_path_factory):
+    r = subprocess.run(["bash", os.path.join(ROOT, "tests", "native", "build_hostlogic.sh")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    v, i = os.path.join(OUT, "test_view_fake"), os.path.join(OUT, "test_index_fake")
+    if not (os.path.exists(v) and os.path.exists(i)): pytest.skip("oracle/_ref/hts_obj not built")
+    from tests import test_libhts_gpu as L
+    if not os.path.exists(L.VIEW_REF): pytest.skip("oracle/_ref/ref_view not built")
+    return L, v, i, L.unpack_fixtures(str(tmp_path_factory.mktemp("viewfix")))
+
+
+@pytest.mark.parametrize("threads", [0, 4])
+def test_reference_test_index_scenarios_on_the_front_end_inside_libhts(libhts_fake, threads):
+    L, v, i, d = libhts_fake
+    L.index_scenarios(d, threads, v, i)
+
+
+def test_reference_test_view_bam_scenarios_on_the_front_end_inside_libhts(libhts_fake):
+    L, v, i, d = libhts_fake
+    L.bam_both_directions(d, 4, v)
