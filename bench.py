@@ -976,10 +976,53 @@ def op_e2e(run: Run, S: Staged):
         if res["reference"] is not None:
             res["reference"].update(write_loop(R, nthr) or {})
             res["reference"]["threads"] = nthr
+    try:
+        res["libhts_view"] = libhts_view(run, path, S.total_u)
+    except Exception as e:                                                  # an auxiliary figure never takes the others down
+        res["libhts_view"] = {"error": repr(e)}
     os.unlink(path)
     res["note"] = ("bgzf_read / bgzf_write loops with 8 MiB buffers on a /dev/shm file; gpu = htslib_amd/libhts_bgzf.so (4 pipes; first_handle_ms = open + 4 KiB read + close of the first handle of the process, i.e. HIP runtime + context creation, timed apart; "
                    "bgzf_mt called so the writer batches), reference = oracle/_ref/libref_bgzf_ld.so with bgzf_mt(threads); "
                    "write loop over the first %.1f GiB; seek_read_us = mean of 1000 random bgzf_seek + 100-byte bgzf_read" % (got / 2**30))
+    return res
+
+
+def libhts_view(run: Run, bam_path: str, plain_bytes: int, nreads: int = 12_000_000):
+    """The drop-in INSIDE libhts, as samtools sees it: the reference's own test/test_view.c (a small `samtools view`) linked to
+    oracle/_ref/libhts_gpu.so (the reference's libhts objects minus bgzf.o, on our bgzf_front.cpp / cram_block_front.cpp) against the same program on
+    the reference's whole libhts (oracle/_ref/ref_view, libdeflate flavour, -@threads), both on the synthetic BAM in /dev/shm:
+      decode  = view -@T -B -N n in.bam           (bam_read1 loop over bgzf_read, nothing written -- `samtools view -c`)
+      bam2bam = view -@T -b -N n -p out.bam in.bam (bam_read1 -> bam_write1 -> bgzf_write at level 6 -- `samtools view -b`)
+    Wall clock of the whole process (for ours that includes loading the HIP runtime), first n records (about n x 309 plain bytes)."""
+    import subprocess
+    gpu, ref = os.path.join(ROOT, "oracle", "_ref", "ref_view_gpu"), REF_VIEW
+    if not (os.path.exists(gpu) and os.path.exists(ref)):
+        return None
+    out = bam_path + ".view.bam"
+    plain = min(plain_bytes, int(nreads * 308.6))
+    nthr = min(run.ncores, 64)
+
+    def one(exe, threads, mode):
+        cmd = [exe, "-@", str(threads), "-N", str(nreads)] + (["-B"] if mode == "decode" else ["-b", "-p", out]) + [bam_path]
+        t = time.perf_counter()
+        p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+        dt = time.perf_counter() - t
+        sz = os.path.getsize(out) if mode != "decode" and os.path.exists(out) else None
+        if sz is not None: os.unlink(out)
+        if p.returncode != 0:
+            return {"error": p.stderr.decode("latin1")[-300:]}
+        r = {"seconds": round(dt, 3), "plain_GBps": round(plain / dt / 1e9, 3), "M_records_per_s": round(nreads / dt / 1e6, 3), "threads": threads}
+        if sz is not None: r["out_bytes"] = sz
+        return r
+
+    res = {"records": nreads, "plain_GB": round(plain / 1e9, 3)}
+    for mode in ("decode", "bam2bam"):
+        res[mode] = {"libhts_gpu": one(gpu, 4, mode)}
+        if not run.args.no_cpu_baseline:
+            res[mode]["reference"] = one(ref, nthr, mode)
+    res["note"] = ("the reference's test/test_view.c, unmodified, on oracle/_ref/libhts_gpu.so (reference libhts objects minus bgzf.o + our front-end, -@4 = bgzf_mt "
+                   "-> device batches) vs on the reference's own libhts (libdeflate, -@%d); whole-process wall clock on a /dev/shm BAM; both are bounded by "
+                   "the ONE thread that runs bam_read1 / bam_write1 (sam.c:784-928), which is why N1 (record framing on the device) exists" % nthr)
     return res
 
 

@@ -143,9 +143,10 @@ def test_view_reads_the_htsjdk_crams(fx):
         assert len(want) > 100
         for t in (0, 4):
             assert view(VIEW_GPU, [*at(t), "-i", "reference=" + ref, base + "_java.cram"], fx) == want, (base, t)
-    want = view(VIEW_REF, ["range.cram"], fx)
-    assert view(VIEW_GPU, ["-@4", "range.cram"], fx) == want
-    assert view(VIEW_GPU, ["range.cram", "CHROMOSOME_II:2000-3000"], fx) == view(VIEW_REF, ["range.cram", "CHROMOSOME_II:2000-3000"], fx)
+    r = ["-i", "reference=ce.fa"]
+    want = view(VIEW_REF, [*r, "range.cram"], fx)
+    assert len(want) > 10000 and view(VIEW_GPU, ["-@4", *r, "range.cram"], fx) == want
+    assert view(VIEW_GPU, [*r, "range.cram", "CHROMOSOME_II:2000-3000"], fx) == view(VIEW_REF, [*r, "range.cram", "CHROMOSOME_II:2000-3000"], fx)
 
 
 # ------------------------------------------------------------------------------------------------------------ CRAM 3.1: every method family on the device
