@@ -496,11 +496,17 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
     uint64_t ooff = 0, soff = 0, woff = 0;
     bool too_big = false;
     std::vector<uint8_t> ccls;
-    const bool two_phase = !(getenv("HG_ARITH_2P") && atoi(getenv("HG_ARITH_2P")) == 0);          // (HG_ARITH_2P=0: every stream through the one-pass kernels, for A/B runs)
-    // The two-phase form trades a stream's LATENCY (its serial chain) for machine WORK (every model's task walks the whole stream): it pays when the call
-    // has few streams to fill the GPU with, or when a stream is so long that the batch waits for it (profiles/r04_arith_two_phase.txt).
+    // The range coder's encoder in two phases (arith_enc2.hip) wherever a stream has more than one model -- order 1 and / or RLE: the models' chains run side by
+    // side and the coder pass is scalar work.  Order 0 without RLE is ONE model (its phases would run one after the other).  HG_ARITH_2P=0: one pass for
+    // everything (A/B runs); HG_ARITH_2P_MIN=<bytes>: the threshold, and order 0 takes the two-phase path as well (tests).
+    const bool two_phase = !(getenv("HG_ARITH_2P") && atoi(getenv("HG_ARITH_2P")) == 0);
     const bool two_phase_forced = getenv("HG_ARITH_2P_MIN") && atoi(getenv("HG_ARITH_2P_MIN")) > 0;
-    const uint32_t two_phase_min = two_phase_forced ? (uint32_t)atoi(getenv("HG_ARITH_2P_MIN")) : leaves.size() <= HG_ARITH_2P_FEW ? HG_ARITH_2P_MIN_FEW : HG_ARITH_2P_MIN;
+    const uint32_t two_phase_min = two_phase_forced ? (uint32_t)atoi(getenv("HG_ARITH_2P_MIN")) : HG_ARITH_2P_MIN;
+    // Work memory of the two-phase form is 12 bytes per input byte (26 with RLE), per trial variant: a call gets a budget -- a quarter of the free device memory --
+    // and the streams beyond it take the one-pass kernels (they need none).
+    uint64_t budget_2p = 0;
+    if (two_phase && codec == ARITH) { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget_2p = fr / 4 + ctx->d_scratch_cap[5]; }   // (+ what the context's work buffer already holds)
+    size_t task_cap = 0;
     auto add_core = [&](uint64_t src_off, uint32_t len, uint32_t fl, Codec cc, uint32_t max_sym) {
         hg_stream_desc d;
         memset(&d, 0, sizeof d);
@@ -509,14 +515,13 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         d.in_off = src_off; d.in_len = len; d.out_off = ooff; d.out_len = (uint32_t)(cap > 0xffffffffull ? 0xffffffffu : cap);
         d.scratch_off = (uint32_t)soff; d.reserved = (uint32_t)(woff / 16);
         ooff += (cap + 15u) & ~15ull;
-        // (order 0 without RLE is ONE model: its two phases run one after the other, no gain -- 40 / 72 ms against 47 / 63 for 100 000 symbols; the
-        // override of the tests takes it through both forms all the same)
-        if (cc == ARITH && two_phase && len >= two_phase_min && len < (1u << 30) /* slot numbers are 32-bit: 2 n with RLE */ && (two_phase_forced || (fl & (F_ORDER | F_RLE)))) {
-            // long streams: models and coder in two phases (arith_enc2.hip); 8 bytes per record slot in the work buffer -- one slot per byte, two with RLE --
-            // and 16 words of stream information
+        const uint64_t need_2p = cc == ARITH ? hg::arith2p_layout(len, (fl & F_RLE) != 0).end : 0;
+        if (cc == ARITH && two_phase && len >= two_phase_min && len < HG_ARITH_2P_MAX && (two_phase_forced || (fl & (F_ORDER | F_RLE))) && need_2p <= budget_2p) {
             ccls.push_back(C_ARITH_2P);
-            soff += 16;
-            woff += ((uint64_t)len * ((fl & F_RLE) ? 16u : 8u) + 15u) & ~15ull;
+            budget_2p -= need_2p;
+            soff += HG_ARITH_2P_INFO_WORDS;
+            woff += need_2p;
+            task_cap += hg::arith2p_max_tasks(fl);
         } else if (cc == ARITH) {
             const uint32_t words = hg::arith_model_words(max_sym + 1u, fl);
             ccls.push_back(words <= HG_ARITH_POOL_SMALL ? C_ARITH_SMALL : C_ARITH_BIG);
@@ -576,30 +581,21 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
             rc = hg::launch_ransnx16_encode(ctx, d_buf, (const hg_stream_desc *)ctx->d_scratch[2], d_fl, d_sel + first[C_NX4], cnt[C_NX4],
                                             d_sel + first[C_NX32], cnt[C_NX32], d_out, d_ol, ctx->d_scratch[5], (uint32_t *)ctx->d_scratch[6], s);
         bool forked4 = false;
-        std::vector<uint32_t> tasks;                                      // (outlives the asynchronous upload: the call synchronises below)
-        if (cnt[C_ARITH_2P]) {
-            // tasks: one per (stream, model) -- 256 literal contexts for an order-1 stream, 1 for order 0, 258 run models with RLE; absent ones leave at once
-            // (device-side presence bits).
-            // Long streams first.
-            for (size_t q = 0; q < cnt[C_ARITH_2P] && q < (1u << 22); q++) {
-                const uint32_t k = sel[first[C_ARITH_2P] + q], nm = (cfl[k] & F_ORDER) ? 256u : 1u;
-                for (uint32_t m = 0; m < nm; m++) tasks.push_back(m | (uint32_t)q << 10);
-                if (cfl[k] & F_RLE) for (uint32_t m = 256; m < 514; m++) tasks.push_back(m | (uint32_t)q << 10);   // the run models of the 256 symbols, then models 256 and 257
+        if (rc == HG_OK && cnt[C_ARITH_2P]) {
+            // the device builds its own task list (sort kernel): 16 counter words + room for every model of every stream
+            rc = ensure_scratch(ctx, 13, 64 + task_cap * 8 + 64);
+            if (rc == HG_OK) {
+                const bool others = cnt[C_NX4] + cnt[C_NX32] + cnt[C_ARITH_SMALL] + cnt[C_ARITH_BIG] != 0;
+                hipStream_t s4 = others ? hg::fork_side4(ctx, s) : s;      // the one-pass kernels of this call run beside the two phases
+                forked4 = others;
+                rc = hg::launch_arith_encode2(ctx, d_buf, (const hg_stream_desc *)ctx->d_scratch[2], d_fl, d_sel + first[C_ARITH_2P], cnt[C_ARITH_2P], ctx->d_scratch[13], task_cap,
+                                              d_out, d_ol, (uint32_t *)ctx->d_scratch[6], ctx->d_scratch[5], s4);
             }
-            if (cnt[C_ARITH_2P] >= (1u << 22)) return HG_EINVAL;
-            if ((rc = ensure_scratch(ctx, 13, tasks.size() * 4 + 64))) return rc;
-            const bool others = cnt[C_NX4] + cnt[C_NX32] + cnt[C_ARITH_SMALL] + cnt[C_ARITH_BIG] != 0;
-            hipStream_t s4 = others ? hg::fork_side4(ctx, s) : s;          // (forked before anything else of this call is queued on s)
-            forked4 = others;
-            if (hipMemcpyAsync(ctx->d_scratch[13], tasks.data(), tasks.size() * 4, hipMemcpyHostToDevice, s4) != hipSuccess) return HG_ELAUNCH;
-            rc = hg::launch_arith_encode2(ctx, d_buf, (const hg_stream_desc *)ctx->d_scratch[2], d_fl, d_sel + first[C_ARITH_2P], cnt[C_ARITH_2P], (const uint32_t *)ctx->d_scratch[13],
-                                          tasks.size(), d_out, d_ol, (uint32_t *)ctx->d_scratch[6], ctx->d_scratch[5], s4);
-            if (rc) return rc;
         }
         if (rc == HG_OK && cnt[C_ARITH_SMALL] + cnt[C_ARITH_BIG])
             rc = hg::launch_arith_encode(ctx, d_buf, (const hg_stream_desc *)ctx->d_scratch[2], d_fl, d_sel + first[C_ARITH_SMALL], cnt[C_ARITH_SMALL],
                                          d_sel + first[C_ARITH_BIG], cnt[C_ARITH_BIG], d_out, d_ol, (uint32_t *)ctx->d_scratch[6], s);
-        if (forked4) hg::join_side4(ctx, s);
+        if (forked4) hg::join_side4(ctx, s);                                // (on every path after the fork)
         if (rc) return rc;
         if (hipMemcpyAsync(ol.data(), d_ol, nc * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
     }

@@ -120,15 +120,32 @@ int launch_arith_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
 int launch_arith_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags, const uint32_t *d_sel_small,
                         size_t nsmall, const uint32_t *d_sel_big, size_t nbig, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch,
                         hipStream_t s);
-// arith_enc2.hip: the two-phase encoder for long streams (d_sel2: indices into d_desc; d_tasks: model | position in d_sel2 << 10)
-// Above this size a stream's serial chain in the one-pass kernel is what a batch waits for (1.5 MB of qualities: ~0.8 s); below it the one-pass kernels win
-// on a batch of slices: every two-phase stream brings 256 .. 514 single-wavefront tasks, and a few hundred streams of 20 .. 40 KB flooded the dispatcher
-// (profiles/r04_arith_two_phase.txt).  HG_ARITH_2P_MIN overrides (tests run the two-phase path from 8 KiB).
-#define HG_ARITH_2P_MIN 262144u
-#define HG_ARITH_2P_FEW 32u            // a call with at most this many streams ...
-#define HG_ARITH_2P_MIN_FEW 16384u     // ... is latency-bound: two phases from 16 KiB (one stream of 100 000 symbols, order 1: 24 ms against 54)
-int launch_arith_encode2(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags, const uint32_t *d_sel2, size_t n2, const uint32_t *d_tasks,
-                         size_t ntasks, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch, void *d_work, hipStream_t s);
+// arith_enc2.hip: the two-phase encoder (d_sel2: indices into d_desc).  Round 5: the events of a stream are sorted by model first, so the work is proportional to
+// the events and the form pays from a few KiB on (round 4: every model's task walked its whole stream; two phases only from 256 KiB in big batches).
+// HG_ARITH_2P_MIN overrides the threshold, HG_ARITH_2P=0 sends every stream through the one-pass kernels (A/B runs).
+#define HG_ARITH_2P_MIN 4096u
+#define HG_ARITH_2P_MAX (1u << 29)     /* record numbers are stored << 2 in 32-bit list words: at most 2 n < 2^30 events */
+// per stream in the model scratch (hg_stream_desc::scratch_off): alphabet size, number of events, list sizes, list offsets per literal context / run symbol
+struct Arith2pInfo { uint32_t m, nevents, n_r2, n_r3, pad[4]; uint32_t offL[260], offR[260]; };
+#define HG_ARITH_2P_INFO_WORDS ((uint32_t)(sizeof(hg::Arith2pInfo) / 4))
+// per stream in the work buffer (hg_stream_desc::reserved * 16): the dense records (8 bytes per event: n events, at most 2 n with RLE), the literal events'
+// record numbers and symbols, and with RLE the first-part / second-part / further-part lists of the runs
+struct Arith2pLayout { uint64_t rec, lidx, lsym, r1, r2, r3, end; };
+__host__ __device__ inline Arith2pLayout arith2p_layout(uint32_t n, bool rle) {
+    Arith2pLayout L;
+    uint64_t o = 0;
+    auto take = [&](uint64_t bytes) { const uint64_t at = o; o += (bytes + 15u) & ~15ull; return at; };
+    L.rec = take((rle ? 2ull : 1ull) * n * 8u);
+    L.lidx = take(4ull * n);
+    L.lsym = take(n);
+    L.r1 = L.r2 = L.r3 = o;
+    if (rle) { L.r1 = take(4ull * n); L.r2 = take(4ull * (n / 4u + 2u)); L.r3 = take(8ull * (n / 7u + 2u)); }
+    L.end = o;
+    return L;
+}
+inline uint32_t arith2p_max_tasks(uint32_t flags) { return (flags & 64u) ? 514u : (flags & 1u) ? 256u : 1u; }
+int launch_arith_encode2(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags, const uint32_t *d_sel2, size_t n2, void *d_tasks,
+                         size_t task_cap, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch, void *d_work, hipStream_t s);
 // tok3.hip: one name-reconstruction job per CRAM method-8 block
 struct tok3_job {
     uint64_t tb_base;      // where this block's decoded token streams start in the token buffer

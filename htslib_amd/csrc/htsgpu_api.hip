@@ -34,7 +34,12 @@ using hg::ensure_scratch;
 // streams on 4 queues the families took turns (kernel timeline: profiles/r04_cram_slices_256_timeline.txt; a decode call of 256 slices 62 -> 40 ms with
 // 16 queues).  Asked for when this library is loaded, unless the user set the variable; without effect (and without harm) when the process initialised
 // HIP earlier.
-__attribute__((constructor)) static void hg_more_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// HTS_GPU_NO_ENV=1 leaves the process environment alone (a host application that manages HIP's settings itself, or that loads this library with dlopen()
+// while other threads run -- setenv is not thread-safe); the request can then be made by the deployment: GPU_MAX_HW_QUEUES=16.
+__attribute__((constructor)) static void hg_more_hw_queues() {
+    const char *no = getenv("HTS_GPU_NO_ENV");
+    if (!(no && *no == '1')) (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
+}
 
 extern "C" {
 

@@ -1,28 +1,32 @@
-"""Probe of the two-phase range-coder encoder and the decoder behind it: the cases of tests/test_arith.py's two-phase test, one report line per failure (GPU box)."""
-import sys, time
+"""Probe of the two-phase range-coder encoder: the cases of tests/test_arith.py's two-phase test against the oracle, one report line per failure, and the
+wall time of the call in its three forms (everything two-phase / default / one pass).  GPU box."""
+import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
 from htslib_amd import _native as nat
 from tests import refutil
+from tests.test_arith import two_phase_cases
 
 eng = nat.Engine(0)
 orc = refutil.ArithOracle()
-rng = np.random.default_rng(77)
-datas, flags = [], []
-for n in (8192, 8193, 8255, 8256, 8257, 20_000, 300_000):
-    for m in (1, 2, 40, 64, 65, 130, 256):
-        p = rng.dirichlet(np.full(m, 0.3)) if m > 1 else np.ones(1)
-        d = bytes(rng.choice(m, n, p=p).astype(np.uint8))
-        if m == 256: d = bytes([255]) + d[1:]
-        for fl in (0, 1) if n != 300_000 else (0, 1, 9, 8, 64, 65, 128, 129, 193):
-            datas.append(d); flags.append(fl)
-t = time.perf_counter()
-enc = eng.arith_encode_host(datas, flags)
-print("encode call %.1f ms" % ((time.perf_counter() - t) * 1e3))
-outs, st = eng.cram_uncompress_blocks([(6, e, len(d)) for d, e in zip(datas, enc)])
-for d, fl, e, o, s in zip(datas, flags, enc, outs, st):
+datas, flags = two_phase_cases()
+res = {}
+for label, env in (("all two-phase", {"HG_ARITH_2P_MIN": "1"}), ("default", {}), ("one pass", {"HG_ARITH_2P": "0"})):
+    for k in ("HG_ARITH_2P_MIN", "HG_ARITH_2P"): os.environ.pop(k, None)
+    os.environ.update(env)
+    eng.arith_encode_host(datas[:4], flags[:4])
+    t = time.perf_counter()
+    res[label] = eng.arith_encode_host(datas, flags)
+    print("%-14s encode call %.1f ms" % (label, (time.perf_counter() - t) * 1e3), flush=True)
+for k in ("HG_ARITH_2P_MIN", "HG_ARITH_2P"): os.environ.pop(k, None)
+nbad = 0
+for i, (d, fl) in enumerate(zip(datas, flags)):
     ref = orc.encode(d, fl)
-    rc, back = orc.decode(e, len(d), -1)
-    if e != ref or s != 0 or o != d:
-        print("n=%d m=%d flags=%d: encoder %s, gpu decoder status %d %s, oracle decodes it: %s" % (len(d), max(d) + 1, fl, "ok" if e == ref else "DIFFERENT", s, "ok" if o == d else "WRONG", rc == 0 and back == d))
-print("done", len(datas))
+    for label, enc in res.items():
+        if enc[i] != ref:
+            nbad += 1
+            if nbad <= 40: print("n=%d distinct=%d flags=%d %s: DIFFERENT (len %d vs %d, first diff at %d)" % (len(d), len(set(d)), fl, label, len(enc[i]), len(ref),
+                                 next((j for j in range(min(len(enc[i]), len(ref))) if enc[i][j] != ref[j]), -1)), flush=True)
+outs, st = eng.cram_uncompress_blocks([(6, e, len(d)) for d, e in zip(datas, res["all two-phase"])])
+nd = sum(1 for d, o, s in zip(datas, outs, st) if s != 0 or o != d)
+print("done: %d streams, %d encoder mismatches, %d decode failures" % (len(datas), nbad, nd))

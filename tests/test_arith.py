@@ -133,11 +133,10 @@ def test_gpu_tiny_alphabets_starting_at_zero(engine, aorc):
     assert not bad, bad[:12]
 
 
-@pytest.mark.gpu
-def test_gpu_two_phase_encoder_is_byte_identical_to_oracle(engine, aorc, monkeypatch):
-    """Long streams (HG_ARITH_2P_MIN: 256 KiB by default, 8 KiB for this test) take the two-phase encoder (arith_enc2.hip: one wavefront per model, then one per
-    stream): sizes around its 64-position tiles, alphabets of 1 / 2 / 40 / 64 / 65 / 130 / 256 symbols (register models up to 64, the LDS form above), skew that halves
-    the models many times, order 0 and 1, with STRIPE / PACK / RLE around it."""
+def two_phase_cases():
+    """streams for the two-phase encoder (arith_enc2.hip): sizes around its 64-position steps, alphabets of 1 / 2 / 40 / 64 / 65 / 130 / 256 symbols (register models up
+    to 64, the LDS form above), skew that halves the models many times, order 0 and 1 with STRIPE / PACK / RLE around it, and -- for the run lists of the RLE form --
+    runs of every length around the part boundaries (3, 6, 9), runs that span many steps, a stream that is one run"""
     rng = np.random.default_rng(77)
     datas, flags = [], []
     for n in (8192, 8193, 8255, 8256, 8257, 20_000, 300_000):
@@ -150,12 +149,35 @@ def test_gpu_two_phase_encoder_is_byte_identical_to_oracle(engine, aorc, monkeyp
     top = bytes(rng.choice(np.array([7, 9, 200], dtype=np.uint8), 200_000, p=[0.98, 0.015, 0.005]))     # one context carries nearly everything
     for fl in (0, 1, 65):
         datas.append(top); flags.append(fl)
-    monkeypatch.setenv("HG_ARITH_2P_MIN", "8192")                       # (read by the library at every call)
+    small = []
+    for m in (1, 2, 3, 40):
+        for n in (1, 2, 3, 5, 63, 64, 65, 127, 128, 129, 1000, 4097):
+            small.append(bytes(rng.integers(0, m, n, dtype=np.uint8)))
+    runs = [bytes(70_000), bytes([5]) * 64, bytes([5]) * 65 + bytes([6]),
+            b"".join(bytes([int(s)]) * int(l) for s, l in zip(rng.integers(0, 4, 4000), rng.geometric(0.08, 4000))),           # lengths 1 .. ~100
+            b"".join(bytes([i % 3]) * l for i, l in enumerate(list(range(1, 14)) * 40)),                                        # every length 1 .. 13
+            b"".join(bytes([i % 7]) * int(l) for i, l in enumerate(rng.integers(60, 700, 300))),                                # runs across several steps
+            b"".join(bytes([int(s)]) * int(l) for s, l in zip(rng.integers(0, 40, 30000), rng.geometric(0.5, 30000)))]          # many short runs, 40 symbols
+    for d in small + runs:
+        for fl in (0, 1, 64, 65, 193):
+            datas.append(d); flags.append(fl)
+    return datas, flags
+
+
+@pytest.mark.gpu
+def test_gpu_two_phase_encoder_is_byte_identical_to_oracle(engine, aorc, monkeypatch):
+    """The two-phase encoder (events sorted by model, one task per model or bundle of models, one scalar coder pass per stream) against the one-pass kernels and the
+    oracle.  By default it takes the order-1 / RLE streams from 4 KiB; HG_ARITH_2P_MIN=1 sends EVERY stream through it (order 0 and the tiny ones too), HG_ARITH_2P=0 none."""
+    datas, flags = two_phase_cases()
+    monkeypatch.setenv("HG_ARITH_2P_MIN", "1")                          # (read by the library at every call)
     enc = engine.arith_encode_host(datas, flags)
     monkeypatch.delenv("HG_ARITH_2P_MIN")
-    assert enc == engine.arith_encode_host(datas, flags)                # the default threshold: same bytes
     bad = [(len(d), len(set(d)), hex(fl)) for d, fl, e in zip(datas, flags, enc) if e != aorc.encode(d, fl)]
     assert not bad, bad[:12]
+    assert enc == engine.arith_encode_host(datas, flags)                # the default threshold: same bytes
+    monkeypatch.setenv("HG_ARITH_2P", "0")
+    assert enc == engine.arith_encode_host(datas, flags)                # one pass: same bytes
+    monkeypatch.delenv("HG_ARITH_2P")
     outs, st = engine.cram_uncompress_blocks([(6, e, len(d)) for d, e in zip(datas, enc)])
     bad = [(len(d), len(set(d)), hex(fl), int(s)) for d, fl, o, s in zip(datas, flags, outs, st) if s != 0 or o != d]
     assert not bad, bad[:12]
