@@ -14,13 +14,15 @@
 //            a stream are bundled.
 //   phase A  persistent wavefronts take tasks by ticket.  A task reads only ITS events (index + symbol lists), keeps the model in REGISTERS -- lane l
 //            holds entry l, the running prefix sums are maintained incrementally (one masked add per event, no scan) -- and writes one 8-byte record
-//            (cum | freq << 16, total) per event at the event's number.  Models of more than 64 symbols use arith_dev.h's WideO0 (LDS).
+//            (cum | freq << 16, total) per event at the event's number.  Alphabets of more than 64 symbols: 2 or 4 entries per lane.
 //   phase B  one wavefront per stream walks the dense records, 64 per load; floor((2^32 - 1) / total) is computed by the 64 lanes for 64 records at
 //            once, and the coder step itself -- range / total as a multiply-high + correction, low += cum * r with the carry in a 64-bit add,
 //            range = r * freq, renormalisation -- is unrolled over the tile with constant lane numbers, so that it compiles to SCALAR instructions
 //            (s_mul_hi_u32, s_add_u32 / s_addc_u32, s_cselect): ~25 per event against ~55 with the records picked through VGPRs and ~130 in one pass.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "htsgpu.h"
 #include "hg_device.h"
 #include "hg_internal.h"
@@ -203,103 +205,123 @@ void sort_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restric
 }
 
 // ---- a model of at most 64 symbols in registers: lane l holds entry l ((freq << 8) | symbol, sorted by frequency like every model of this coder) and the
-//      inclusive prefix sum of the frequencies up to it
+//      inclusive prefix sum of the frequencies up to it.  A step stays on the VECTOR side: the lane that holds the symbol writes the event's record itself
+//      (one predicated store), the lanes behind it add STEP to their prefix sums (v_mbcnt of the hit mask), and the "one step towards the front" swap is
+//      two DPP wave shifts -- no v_readlane / scalar round trip on the chain from one event to the next (round 4's form: ~0.3 us per event).
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }   // lane i <- lane i - 1 (lane 0: 0)
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }   // lane i <- lane i + 1 (lane 63: 0)
+// EPL entries per lane: lane l holds entries EPL l .. EPL l + EPL - 1 (1: alphabets up to 64 symbols, 2: up to 128, 4: up to 256), so that neighbours inside a
+// lane are register moves and only the lane boundary needs the wave shift.
+template <int EPL>
 struct RegModel {
-    uint32_t e, incl, tot, n;
+    uint32_t e[EPL], incl[EPL], tot, n;
     __device__ __forceinline__ void init(uint32_t m, int lane) {
         n = m; tot = m;
-        e = (uint32_t)lane < m ? (1u << 8) | (uint32_t)lane : 0u;
-        incl = (uint32_t)lane < m ? (uint32_t)lane + 1u : m;
+#pragma unroll
+        for (int k = 0; k < EPL; k++) {
+            const uint32_t i = (uint32_t)lane * EPL + (uint32_t)k;
+            e[k] = i < m ? (1u << 8) | i : 0u;
+            incl[k] = i < m ? i + 1u : m;
+        }
     }
-    // the triple of `sym` under the current state, then the update (arith_dev.h model_update: bump by STEP, halve all when the total passes MAX_FREQ, one
+    // codes `sym` (wave-uniform) into record `slot`, then the update (arith_dev.h model_update: bump by STEP, halve all when the total passes MAX_FREQ, one
     // step towards the front when the entry outgrew its neighbour)
-    __device__ __forceinline__ void step(uint32_t sym, uint32_t &cum, uint32_t &f, uint32_t &totb, int lane) {
-        const unsigned long long hit = __ballot((uint32_t)lane < n && (e & 0xffu) == sym);
-        const uint32_t l = (uint32_t)__builtin_ctzll(hit);
-        const uint32_t ex = rl(e, l);
-        f = ex >> 8; cum = rl(incl, l) - f; totb = tot;
-        uint32_t nex = ex + (STEP << 8);
+    __device__ __forceinline__ void step(uint32_t sym, uint2 *R, uint32_t slot, int lane) {
+        bool hit[EPL], any = false;
+        uint32_t x = 0;
+#pragma unroll
+        for (int k = 0; k < EPL; k++) {
+            hit[k] = (uint32_t)lane * EPL + (uint32_t)k < n && (e[k] & 0xffu) == sym;      // exactly one entry of one lane
+            const uint32_t f = e[k] >> 8;
+            x = hit[k] ? (incl[k] - f) | f << 16 : x;
+            any = any || hit[k];
+        }
+        if (any) R[slot] = make_uint2(x, tot);
+        const unsigned long long hm = __ballot(any);
+        uint32_t acc = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));   // 1 on the lanes after the hit
+        uint32_t eb[EPL], ib[EPL];
+#pragma unroll
+        for (int k = 0; k < EPL; k++) {
+            acc |= (uint32_t)hit[k];                                       // ... and on the hit entry and the entries after it in its lane
+            eb[k] = hit[k] ? e[k] + (STEP << 8) : e[k];
+            ib[k] = incl[k] + (acc ? STEP : 0u);
+        }
         tot += STEP;
         if (tot > MAX_FREQ) {                                            // halve every frequency (rare)
-            e = (uint32_t)lane == l ? nex : e;
-            uint32_t fr = e >> 8; fr -= fr >> 1;
-            e = (uint32_t)lane < n ? (fr << 8) | (e & 0xffu) : 0u;
-            incl = wave_incl_scan_dpp((uint32_t)lane < n ? fr : 0u);
-            tot = rl(incl, 63);
-            nex = rl(e, l);
-        } else incl += (uint32_t)lane >= l ? STEP : 0u;
-        if (l) {
-            const uint32_t ep = rl(e, l - 1u);
-            if ((nex >> 8) > (ep >> 8)) {
-                const uint32_t through = rl(incl, l);                      // the sum through entry l does not change with the swap
-                e = (uint32_t)lane == l ? ep : (uint32_t)lane + 1u == l ? nex : e;
-                incl = (uint32_t)lane + 1u == l ? through - (ep >> 8) : incl;
-                return;
+            uint32_t fr[EPL], sum = 0;
+#pragma unroll
+            for (int k = 0; k < EPL; k++) {
+                const bool in = (uint32_t)lane * EPL + (uint32_t)k < n;
+                fr[k] = eb[k] >> 8; fr[k] -= fr[k] >> 1;
+                fr[k] = in ? fr[k] : 0u;
+                eb[k] = in ? (fr[k] << 8) | (eb[k] & 0xffu) : 0u;
+                sum += fr[k];
             }
+            const uint32_t through = wave_incl_scan_dpp(sum);
+            uint32_t run = through - sum;
+#pragma unroll
+            for (int k = 0; k < EPL; k++) { run += fr[k]; ib[k] = run; }
+            tot = rl(through, 63);
         }
-        e = (uint32_t)lane == l ? nex : e;
+        uint32_t e_left[EPL], swv[EPL];
+        bool swap_here[EPL];
+        e_left[0] = wave_shr1(eb[EPL - 1]);
+#pragma unroll
+        for (int k = 1; k < EPL; k++) e_left[k] = eb[k - 1];
+#pragma unroll
+        for (int k = 0; k < EPL; k++) {
+            swap_here[k] = hit[k] && (lane > 0 || k > 0) && (eb[k] >> 8) > (e_left[k] >> 8);
+            swv[k] = swap_here[k] ? eb[k] : 0u;
+        }
+        // the entry before a swapping hit receives the bumped entry, and the sum through the pair (which the swap does not change) minus its own frequency
+        const uint32_t fr_next = wave_shl1(swv[0]), ir_next = wave_shl1(ib[0]);
+#pragma unroll
+        for (int k = 0; k < EPL; k++) {
+            const uint32_t from_right = k + 1 < EPL ? swv[k + 1 < EPL ? k + 1 : 0] : fr_next;
+            const uint32_t i_right = k + 1 < EPL ? ib[k + 1 < EPL ? k + 1 : 0] : ir_next;
+            const uint32_t fk = eb[k] >> 8;
+            e[k] = swap_here[k] ? e_left[k] : from_right ? from_right : eb[k];
+            incl[k] = from_right ? i_right - fk : ib[k];
+        }
     }
 };
 
-// records gathered 64 at a time, then one scattered store
-struct RecOut {
-    uint2 *R; uint32_t idx, lo, hi, cnt;
-    __device__ __forceinline__ void start(uint2 *r) { R = r; idx = lo = hi = 0; cnt = 0; }
-    __device__ __forceinline__ void put(uint32_t slot, uint32_t cum, uint32_t f, uint32_t tot, int lane) {
-        idx = hg::writelane(slot, cnt, idx); lo = hg::writelane(cum | f << 16, cnt, lo); hi = hg::writelane(tot, cnt, hi);
-        if (++cnt == 64u) { R[idx] = make_uint2(lo, hi); cnt = 0; }
-    }
-    __device__ __forceinline__ void finish(int lane) { if ((uint32_t)lane < cnt) R[idx] = make_uint2(lo, hi); cnt = 0; }
-};
+// the events of one model, 64 per load: idx = record numbers, sym = symbols (lane k = event k0 + k); full tiles run with constant lane numbers
+template <int EPL>
+__device__ __forceinline__ void model_tile(RegModel<EPL> &G, uint2 *R, uint32_t iv, uint32_t sv, uint32_t nn, int lane) {
+    if (nn == 64u) {
+#pragma unroll
+        for (int j = 0; j < 64; j++) G.step(rl(sv, (uint32_t)j), R, rl(iv, (uint32_t)j), lane);
+    } else for (uint32_t j = 0; j < nn; j++) G.step(rl(sv, j), R, rl(iv, j), lane);
+}
 
 // the literal events of one context: (record number, symbol) lists
-template <bool WIDE>
-__device__ __forceinline__ void lit_model(const uint32_t *__restrict__ lidx, const uint8_t *__restrict__ lsym, uint32_t cnt, uint32_t m, RecOut &O, uint32_t *wide_mem, int lane) {
-    RegModel G; WideO0 Wd;
-    if (WIDE) {
-        for (uint32_t i = (uint32_t)lane; i < m; i += 64) wide_mem[i] = (1u << 8) | i;      // models_init: every frequency 1, entry i holds symbol i
-        Wd.init(wide_mem, (uint8_t *)(wide_mem + 256), m, true, lane);
-    } else G.init(m, lane);
+template <int EPL>
+__device__ __forceinline__ void lit_model(const uint32_t *__restrict__ lidx, const uint8_t *__restrict__ lsym, uint32_t cnt, uint32_t m, uint2 *R, int lane) {
+    RegModel<EPL> G; G.init(m, lane);
     uint32_t ni = (uint32_t)lane < cnt ? lidx[lane] : 0u, ns = (uint32_t)lane < cnt ? (uint32_t)lsym[lane] : 0u;
     for (uint32_t k0 = 0; k0 < cnt; k0 += 64u) {
         const uint32_t iv = ni, sv = ns, nn = cnt - k0 < 64u ? cnt - k0 : 64u;
         { const uint32_t k = k0 + 64u + (uint32_t)lane; if (k < cnt) { ni = lidx[k]; ns = (uint32_t)lsym[k]; } }
-        for (uint32_t b = 0; b < nn; b++) {
-            const uint32_t sym = rl(sv, b);
-            uint32_t cum, f, t;
-            if (WIDE) {
-                const uint32_t x = hg::uni((uint32_t)Wd.pos[sym]), pc = x >> 6, l = x & 63u;
-                const uint32_t e = Wd.piece(pc, lane);
-                const uint32_t incl = wave_incl_scan_dpp(e >> 8);
-                const uint32_t ex = rl(e, l);
-                f = ex >> 8; cum = Wd.base(pc) + rl(incl, l) - f; t = Wd.tot;
-                Wd.bump<true>(pc, l, ex, e, lane);
-            } else G.step(sym, cum, f, t, lane);
-            O.put(rl(iv, b), cum, f, t, lane);
-        }
+        model_tile<EPL>(G, R, iv, sv, nn, lane);
     }
 }
 
 // RLE: a run of r + 1 copies of c is coded as the literal c, then r in parts of at most 3 -- the first part with the run model of c, the second with run
 // model 256, all further ones with run model 257; a part below 3 ends the list (arith.hip's encoder loop).  First / second parts: one list word per
 // event, record number << 2 | part.
-__device__ __forceinline__ void part_model(const uint32_t *__restrict__ lst, uint32_t cnt, RecOut &O, int lane) {
-    RegModel G; G.init(4, lane);
+__device__ __forceinline__ void part_model(const uint32_t *__restrict__ lst, uint32_t cnt, uint2 *R, int lane) {
+    RegModel<1> G; G.init(4, lane);
     uint32_t nw = (uint32_t)lane < cnt ? lst[lane] : 0u;
     for (uint32_t k0 = 0; k0 < cnt; k0 += 64u) {
         const uint32_t wv = nw, nn = cnt - k0 < 64u ? cnt - k0 : 64u;
         { const uint32_t k = k0 + 64u + (uint32_t)lane; if (k < cnt) nw = lst[k]; }
-        for (uint32_t b = 0; b < nn; b++) {
-            const uint32_t w = rl(wv, b);
-            uint32_t cum, f, t;
-            G.step(w & 3u, cum, f, t, lane);
-            O.put(w >> 2, cum, f, t, lane);
-        }
+        model_tile<1>(G, R, wv >> 2, wv & 3u, nn, lane);
     }
 }
 // third and further parts (run model 257) of the runs of 7 and more: (first record number, r - 6) per run
-__device__ __forceinline__ void more_model(const uint2 *__restrict__ lst, uint32_t cnt, RecOut &O, int lane) {
-    RegModel G; G.init(4, lane);
+__device__ __forceinline__ void more_model(const uint2 *__restrict__ lst, uint32_t cnt, uint2 *R, int lane) {
+    RegModel<1> G; G.init(4, lane);
     for (uint32_t k0 = 0; k0 < cnt; k0 += 64u) {
         const uint32_t k = k0 + (uint32_t)lane, nn = cnt - k0 < 64u ? cnt - k0 : 64u;
         const uint2 wv = k < cnt ? lst[k] : make_uint2(0u, 0u);
@@ -307,9 +329,7 @@ __device__ __forceinline__ void more_model(const uint2 *__restrict__ lst, uint32
             uint32_t at = rl(wv.x, b), rem = rl(wv.y, b), part;
             do {
                 part = rem < 3u ? rem : 3u;
-                uint32_t cum, f, t;
-                G.step(part, cum, f, t, lane);
-                O.put(at, cum, f, t, lane);
+                G.step(part, R, at, lane);
                 at++; rem -= part;
             } while (part == 3u);
         }
@@ -320,9 +340,7 @@ __device__ __forceinline__ void more_model(const uint2 *__restrict__ lst, uint32
 __global__ __launch_bounds__(256)
 void model_kernel(const hg_stream_desc *__restrict__ desc, const uint8_t *__restrict__ flags_in, const uint32_t *__restrict__ sel, const uint32_t *gscratch,
                   uint8_t *work, uint32_t *ctr, const uint2 *__restrict__ tasks, uint32_t task_cap) {
-    __shared__ uint32_t wide_mem_all[4][256 + 64];                       // per wavefront, WideO0: 256 entries + the symbol -> position bytes
     const int lane = threadIdx.x & 63;
-    uint32_t *wide_mem = wide_mem_all[threadIdx.x >> 6];
     const uint32_t nbig = ctr[0], nsmall = ctr[1];
     for (;;) {
         uint32_t t = 0;
@@ -336,28 +354,29 @@ void model_kernel(const hg_stream_desc *__restrict__ desc, const uint8_t *__rest
         const uint32_t rle = flags_in[k] & F_RLE, m = I->m, n = d.in_len;
         uint8_t *W = work + (uint64_t)d.reserved * 16u;
         const hg::Arith2pLayout L = arith2p_layout(n, rle != 0u);
-        RecOut O; O.start((uint2 *)(W + L.rec));
+        uint2 *R = (uint2 *)(W + L.rec);
         for (uint32_t mdl = first; mdl <= last; mdl++) {
             if (mdl < 256u) {
                 const uint32_t o0 = I->offL[mdl], cnt = I->offL[mdl + 1u] - o0;
                 if (!cnt || (bundle && cnt >= BIG_TASK)) continue;
-                if (m > 64u) lit_model<true>((const uint32_t *)(W + L.lidx) + o0, W + L.lsym + o0, cnt, m, O, wide_mem, lane);
-                else lit_model<false>((const uint32_t *)(W + L.lidx) + o0, W + L.lsym + o0, cnt, m, O, wide_mem, lane);
+                const uint32_t *li = (const uint32_t *)(W + L.lidx) + o0; const uint8_t *ls = W + L.lsym + o0;
+                if (m > 128u) lit_model<4>(li, ls, cnt, m, R, lane);
+                else if (m > 64u) lit_model<2>(li, ls, cnt, m, R, lane);
+                else lit_model<1>(li, ls, cnt, m, R, lane);
             } else if (mdl < 512u) {
                 const uint32_t o0 = I->offR[mdl - 256u], cnt = I->offR[mdl - 255u] - o0;
                 if (!cnt || (bundle && cnt >= BIG_TASK)) continue;
-                part_model((const uint32_t *)(W + L.r1) + o0, cnt, O, lane);
+                part_model((const uint32_t *)(W + L.r1) + o0, cnt, R, lane);
             } else if (mdl == M_R2) {
                 const uint32_t cnt = I->n_r2;
                 if (!cnt || (bundle && cnt >= BIG_TASK)) continue;
-                part_model((const uint32_t *)(W + L.r2), cnt, O, lane);
+                part_model((const uint32_t *)(W + L.r2), cnt, R, lane);
             } else {
                 const uint32_t cnt = I->n_r3;
                 if (!cnt || (bundle && cnt >= BIG_TASK)) continue;
-                more_model((const uint2 *)(W + L.r3), cnt, O, lane);
+                more_model((const uint2 *)(W + L.r3), cnt, R, lane);
             }
         }
-        O.finish(lane);
     }
 }
 
@@ -381,13 +400,13 @@ struct Coder {
     // one event: x = cum | freq << 16, t = the model's total, inv = floor((2^32 - 1) / t)
     __device__ __forceinline__ void step(uint32_t x, uint32_t t, uint32_t inv, int lane) {
         const uint32_t cum = x & 0xffffu, f = x >> 16;
-        uint32_t q = __umulhi(range, inv), r = range - q * t;          // short by 2 at most
-        if (r >= t) { q++; r -= t; }
-        if (r >= t) q++;
+        uint32_t q = __umulhi(range, inv);
+        const uint32_t r = range - q * t;                               // q is short by 2 at most: r < 3 t < 2^18
+        q += ((t - 1u - r) >> 31) + ((2u * t - 1u - r) >> 31);            // + (r >= t) + (r >= 2 t), as sign bits: stays on the scalar ALU
         const unsigned long long s = (unsigned long long)low + (unsigned long long)cum * q;    // cum * q < 2^32: cum < t, q = range / t
         low = (uint32_t)s; carry |= (uint32_t)(s >> 32);
         range = q * f;
-        while (range < TOP) { range <<= 8; shift_low(lane); }
+        while (__builtin_expect(range < TOP, 0)) { range <<= 8; shift_low(lane); }   // (the common case falls through: a taken branch per event is dear)
     }
     __device__ __forceinline__ uint32_t finish(int lane) {
         for (int i = 0; i < 5; i++) shift_low(lane);
@@ -439,12 +458,27 @@ int launch_arith_encode2(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_
     uint32_t *ctr = (uint32_t *)d_tasks;
     uint2 *tasks = (uint2 *)(ctr + 16);
     if (hipMemsetAsync(ctr, 0, 64, s) != hipSuccess) return HG_ELAUNCH;
+    // HG_ARITH_2P_TIMES=1: the three kernels' durations on stderr (synchronises; measurement runs only)
+    static const bool times = getenv("HG_ARITH_2P_TIMES") && atoi(getenv("HG_ARITH_2P_TIMES")) > 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    auto mark = [&](int i) { if (times) { if (!ev[i]) (void)hipEventCreate(&ev[i]); (void)hipEventRecord(ev[i], s); } };
+    mark(0);
     hipLaunchKernelGGL(hga2::sort_kernel, dim3((unsigned)n2), dim3(64), 0, s, (const uint8_t *)d_in, d_desc, d_flags, d_sel2, d_scratch, (uint8_t *)d_work, ctr, tasks, (uint32_t)task_cap);
+    mark(1);
     // persistent grid: enough wavefronts to fill the chip, never more than there can be tasks
     const size_t waves = task_cap < 256u * 32u ? task_cap : 256u * 32u;
     hipLaunchKernelGGL(hga2::model_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, d_desc, d_flags, d_sel2, (const uint32_t *)d_scratch, (uint8_t *)d_work, ctr,
                        (const uint2 *)tasks, (uint32_t)task_cap);
+    mark(2);
     hipLaunchKernelGGL(hga2::code_kernel, dim3((unsigned)n2), dim3(64), 0, s, d_desc, d_flags, d_sel2, (const uint32_t *)d_scratch, (const uint8_t *)d_work, (uint8_t *)d_out, d_out_len);
+    mark(3);
+    if (times && hipStreamSynchronize(s) == hipSuccess) {
+        float a = 0, b = 0, c = 0; uint32_t h[4] = {0, 0, 0, 0};
+        (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&c, ev[2], ev[3]);
+        (void)hipMemcpy(h, ctr, 16, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[arith 2p] %zu streams, %u + %u tasks: sort %.3f ms, models %.3f ms, coder %.3f ms\n", n2, h[0], h[1], a, b, c);
+        for (auto e : ev) if (e) (void)hipEventDestroy(e);
+    }
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
 }  // namespace hg

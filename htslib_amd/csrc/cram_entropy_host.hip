@@ -496,9 +496,9 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
     uint64_t ooff = 0, soff = 0, woff = 0;
     bool too_big = false;
     std::vector<uint8_t> ccls;
-    // The range coder's encoder in two phases (arith_enc2.hip) wherever a stream has more than one model -- order 1 and / or RLE: the models' chains run side by
-    // side and the coder pass is scalar work.  Order 0 without RLE is ONE model (its phases would run one after the other).  HG_ARITH_2P=0: one pass for
-    // everything (A/B runs); HG_ARITH_2P_MIN=<bytes>: the threshold, and order 0 takes the two-phase path as well (tests).
+    // The range coder's encoder runs in two phases (arith_enc2.hip) from HG_ARITH_2P_MIN bytes on: the models' chains side by side (order 1, RLE), and even for
+    // a single model (order 0) the register-model pass + the scalar coder pass are quicker than the tangled one-pass step (0.12 + 0.15 us per symbol against
+    // 0.5 .. 0.95; profiles/r05_arith_two_phase.txt).  HG_ARITH_2P=0: one pass for everything (A/B runs); HG_ARITH_2P_MIN=<bytes>: the threshold (tests: 1).
     const bool two_phase = !(getenv("HG_ARITH_2P") && atoi(getenv("HG_ARITH_2P")) == 0);
     const bool two_phase_forced = getenv("HG_ARITH_2P_MIN") && atoi(getenv("HG_ARITH_2P_MIN")) > 0;
     const uint32_t two_phase_min = two_phase_forced ? (uint32_t)atoi(getenv("HG_ARITH_2P_MIN")) : HG_ARITH_2P_MIN;
@@ -516,7 +516,7 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         d.scratch_off = (uint32_t)soff; d.reserved = (uint32_t)(woff / 16);
         ooff += (cap + 15u) & ~15ull;
         const uint64_t need_2p = cc == ARITH ? hg::arith2p_layout(len, (fl & F_RLE) != 0).end : 0;
-        if (cc == ARITH && two_phase && len >= two_phase_min && len < HG_ARITH_2P_MAX && (two_phase_forced || (fl & (F_ORDER | F_RLE))) && need_2p <= budget_2p) {
+        if (cc == ARITH && two_phase && len >= two_phase_min && len < HG_ARITH_2P_MAX && need_2p <= budget_2p) {
             ccls.push_back(C_ARITH_2P);
             budget_2p -= need_2p;
             soff += HG_ARITH_2P_INFO_WORDS;

@@ -123,7 +123,7 @@ int launch_arith_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_d
 // arith_enc2.hip: the two-phase encoder (d_sel2: indices into d_desc).  Round 5: the events of a stream are sorted by model first, so the work is proportional to
 // the events and the form pays from a few KiB on (round 4: every model's task walked its whole stream; two phases only from 256 KiB in big batches).
 // HG_ARITH_2P_MIN overrides the threshold, HG_ARITH_2P=0 sends every stream through the one-pass kernels (A/B runs).
-#define HG_ARITH_2P_MIN 4096u
+#define HG_ARITH_2P_MIN 1024u
 #define HG_ARITH_2P_MAX (1u << 29)     /* record numbers are stored << 2 in 32-bit list words: at most 2 n < 2^30 events */
 // per stream in the model scratch (hg_stream_desc::scratch_off): alphabet size, number of events, list sizes, list offsets per literal context / run symbol
 struct Arith2pInfo { uint32_t m, nevents, n_r2, n_r3, pad[4]; uint32_t offL[260], offR[260]; };
