@@ -45,6 +45,9 @@ struct Job { size_t blk; int m; };
 // size the script names (0 = the method fails), so that the auto-tuner's decisions can be compared, on the CPU, with the
 // reference's cram_compress_block3 driven by the same script.
 uint32_t (*g_size_script)(int method, size_t blk, uint32_t in_len) = nullptr;
+// counters of the auto-tuner since the process started (hg_debug_cram_tuner_counters): calls, rounds, trial blocks compressed ahead of time, ... of those
+// folded from the cache, trial blocks that took the normal path
+uint64_t g_tuner[5] = {0, 0, 0, 0, 0};
 
 struct HostLibs {
     int (*bz2)(char *, unsigned int *, char *, unsigned int, int, int, int) = nullptr;                                                      // BZ2_bzBuffToBuffCompress
@@ -179,6 +182,7 @@ int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t
 extern "C" {
 
 void hg_debug_set_cram_size_script(uint32_t (*fn)(int, size_t, uint32_t)) { g_size_script = fn; }
+void hg_debug_cram_tuner_counters(uint64_t *out) { for (int i = 0; i < 5; i++) out[i] = g_tuner[i]; }
 
 hg_cram_metrics *hg_cram_metrics_new(void) {                            // cram_new_metrics, cram_io.c:2327-2339
     hg_cram_metrics *m = (hg_cram_metrics *)calloc(1, sizeof *m);
@@ -209,14 +213,74 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
         out_len[i] = in_len[i]; method_used[i] = HG_CRAM_RAW;               // RAW until something smaller turns up (copied at the end)
         if (method_set[i] == HG_M_RAW || level == 0 || in_len[i] == 0) B[i].done = true;   // cram_io.c:1967-1972
     }
+    // ---- trial phases ahead of time.  A series' blocks after a trial phase need the method it learns, and the phase after that needs the span the
+    // resolution sets: the reference's state sequence serialises a long call into one round per trial phase (a call of 1 250 slices: ~17 rounds, each as
+    // long as its slowest codec chain, the GPU nearly idle).  But WHICH blocks the later phases trial is predictable -- the counters move with the blocks'
+    // sizes, and the span only depends on whether the best method stays the same -- and WHAT a trial block needs is every method of a set that only ever
+    // shrinks.  So the first round also compresses the predicted trial blocks of all later phases with the current set ("stable" prediction: every phase
+    // confirms the method of the one before).  Their results (all sizes, the smallest payload) are kept; when the state machine, run exactly as before,
+    // reaches such a block and finds everything it asks for, it folds the block at once and goes on -- through the resolution and into the blocks behind the
+    // phase, in the same round.  A wrong prediction costs the wasted trials and nothing else: blocks the cache cannot answer take the normal path.
+    struct Spec { uint32_t ran_mask = 0; uint32_t sz[MAXM]; int best_m = -1; uint8_t *best = nullptr; uint32_t best_len = 0; };
+    std::vector<Spec *> spec(n, nullptr);
+    struct SpecJobs { size_t blk, j0, j1; };
+    bool speculate = metrics && n > (size_t)NTRIALS && !(getenv("HG_CRAM_SPECULATE") && atoi(getenv("HG_CRAM_SPECULATE")) == 0);
+    struct SpecFree { std::vector<Spec *> &v; ~SpecFree() { for (Spec *p : v) if (p) { free(p->best); delete p; } } } spec_free{spec};
+    const uint32_t fqz_bits_all = (1u << HG_M_FQZ) | (1u << HG_M_FQZ_b) | (1u << HG_M_FQZ_c) | (1u << HG_M_FQZ_d);
+    uint32_t nolib_all = (1u << HG_M_BZIP2) | (1u << HG_M_LZMA);          // (the scripted test runs against a reference build without the libraries)
+    if (!g_size_script) { const HostLibs &HL = host_libs(); nolib_all = (HL.bz2 ? 0u : 1u << HG_M_BZIP2) | (HL.lzma_enc && HL.lzma_bound ? 0u : 1u << HG_M_LZMA); }
+    auto have_mask = [&](size_t i) { return ~(nolib_all | (fqz && fqz[i] ? 0u : fqz_bits_all) | (1u << 9) | (1u << 10)); };
+    // picks the winner of a trial block and folds its sizes into the series' statistics (cram_io.c:2064-2244); result(m, p, len) = method m's output
+    auto fold_trial = [&](size_t i, hg_cram_metrics *M, uint32_t method_set, auto &&result) {
+        uint32_t sz[MAXM];
+        for (int m = 0; m < MAXM; m++) sz[m] = UINT_MAX;                // arbitrarily worse than raw
+        uint32_t sz_best = in_len[i]; int method_best = 0; const uint8_t *pbest = nullptr;
+        for (int m = 0; m < MAXM; m++) {
+            if (!(method_set & (1u << m))) continue;
+            const uint8_t *p = nullptr; uint32_t len = 0;
+            if (!result(m, p, len)) continue;
+            sz[m] = len;
+            if (sz_best > len) { sz_best = len; method_best = m; pbest = p; }
+        }
+        if (pbest) { memcpy(out[i], pbest, sz_best); out_len[i] = sz_best; method_used[i] = methmap[method_best]; }
+        for (int m = 0; m < MAXM; m++) M->sz[m] = (int)((unsigned)M->sz[m] + sz[m] + 2000u);   // int arithmetic wraps as in the reference
+        if (--M->trial == 0) {
+            uint32_t method = method_set;
+            int best_method = HG_M_RAW, best_sz = INT_MAX;
+            const double div = level <= 1 ? 0.25 : level <= 3 ? 1 : level <= 6 ? 2 : level <= 7 ? 3 : 0;
+            if (div > 0) for (int m = 0; m < MAXM; m++) M->sz[m] = (int)(M->sz[m] * (1 + (meth_cost[m] - 1) / div));
+            M->sz[9] = M->sz[10] = INT_MAX;
+            for (int m = 0; m < MAXM; m++) {
+                if (!M->sz[m] || !(method & (1u << m))) continue;
+                if (best_sz > M->sz[m]) { best_sz = M->sz[m]; best_method = m; }
+            }
+            if (best_method != M->method) M->consistency = 0;
+            else { const double f = 1 + M->consistency / 4.0; M->next_trial = (int)(M->next_trial * (f < 2 ? f : 2)); M->consistency++; }
+            M->method = best_method;
+            // zlib strategy / fqzcomp preset / tokeniser back-end of the learnt method (cram_io.c:2193-2205): Z_FILTERED = 1, Z_RLE = 3
+            M->strat = best_method == HG_M_GZIP ? 1 : best_method == HG_M_GZIP_RLE ? 3 : best_method == HG_M_TOKA ? 1 : 0;
+            const double MAXDELTA = 0.20; const int MAXFAILS = 4, mul = 1 + (level >= 7);
+            for (int m = 0; m < MAXM; m++) {
+                if (best_method == m) { M->cnt[m] = 0; M->extra[m] = 0; }
+                else if (best_sz < M->sz[m]) {
+                    const double r = (double)M->sz[m] / best_sz - 1;
+                    if (++M->cnt[m] >= MAXFAILS * mul && (M->extra[m] += r) >= MAXDELTA * mul) method &= ~(1u << m);
+                    if ((m == HG_M_FQZ || (m >= 13 && m <= 15)) && M->sz[m] > best_sz) method &= ~(1u << m);
+                }
+            }
+            M->revised_method = method;
+        }
+    };
     // Blocks that share a metrics object are handled in their order, exactly as the reference's one-at-a-time loop
     // would: a ROUND takes, per metrics object, every block whose branch is already decided by the current state --
     // cached-method blocks, then the blocks of the next trial phase -- and stops there, because the blocks after a
     // trial phase need the method that phase is about to learn.  Usually two rounds per call.
+    g_tuner[0]++;
     for (;;) {
         std::vector<Job> jobs;
         std::vector<size_t> taken;
         std::vector<hg_cram_metrics *> seen; std::vector<int> pend; std::vector<char> blocked;
+        std::vector<size_t> last_blk;                                    // the series' last block this round's walk has dealt with
         for (size_t i = 0; i < n; i++) {
             Blk &b = B[i];
             if (b.done) continue;
@@ -225,8 +289,9 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
             if (!M) { jobs.push_back({i, HG_M_GZIP}); b.j1 = jobs.size(); taken.push_back(i); continue; }   // cram_io.c:2282-2299
             size_t k = 0;
             while (k < seen.size() && seen[k] != M) k++;
-            if (k == seen.size()) { seen.push_back(M); pend.push_back(0); blocked.push_back(0); }
+            if (k == seen.size()) { seen.push_back(M); pend.push_back(0); blocked.push_back(0); last_blk.push_back(i); }
             if (blocked[k]) continue;
+            last_blk[k] = i;
             const int sz = (int)in_len[i];
             auto size_check_and_avg = [&]() {
                 // sudden changes in size trigger a retrial (cram_io.c:1988-1997)
@@ -267,10 +332,7 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
             b.trial = true;
             // bzip2 / lzma stay in the set when the system has the libraries (else like an htslib built without them: they leave it); fqzcomp
             // needs the slice's record lengths (cram_compress_by_method gets them from its cram_slice, cram_io.c:1808-1820)
-            const uint32_t fqz_bits = (1u << HG_M_FQZ) | (1u << HG_M_FQZ_b) | (1u << HG_M_FQZ_c) | (1u << HG_M_FQZ_d);
-            uint32_t nolib = (1u << HG_M_BZIP2) | (1u << HG_M_LZMA);      // (the scripted test runs against a reference build without the libraries)
-            if (!g_size_script) { const HostLibs &HL = host_libs(); nolib = (HL.bz2 ? 0u : 1u << HG_M_BZIP2) | (HL.lzma_enc && HL.lzma_bound ? 0u : 1u << HG_M_LZMA); }
-            const uint32_t have = ~(nolib | (fqz && fqz[i] ? 0u : fqz_bits) | (1u << 9) | (1u << 10));
+            const uint32_t have = have_mask(i);
             uint32_t method = b.method & have;
             if (M->revised_method) method = M->revised_method & have; else M->revised_method = method;
             if (M->next_trial <= 0) {
@@ -287,11 +349,60 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
             }
             if ((method & (1u << HG_M_GZIP_RLE)) && (method & (1u << HG_M_GZIP_1))) method &= ~(1u << HG_M_GZIP_RLE);   // cram_io.c:2057-2062
             b.method = method;
+            if (spec[i] && pend[k] == 0 && (method & ~spec[i]->ran_mask) == 0) {
+                // every method of the set was run ahead of time: if the winner among THESE methods is the payload that was kept, the block is done now
+                const Spec &S = *spec[i];
+                uint32_t bsz = in_len[i]; int bm = -1;
+                for (int m = 0; m < MAXM; m++) if ((method & (1u << m)) && S.sz[m] && S.sz[m] < bsz) { bsz = S.sz[m]; bm = m; }
+                if (bm < 0 || bm == S.best_m) {
+                    fold_trial(i, M, method, [&](int m, const uint8_t *&p, uint32_t &len) { if (!S.sz[m]) return false; len = S.sz[m]; p = m == S.best_m ? S.best : nullptr; return true; });
+                    b.done = true; b.trial = false;
+                    taken.pop_back();
+                    g_tuner[3]++;
+                    continue;
+                }
+            }
+            g_tuner[4]++;
             for (int m = 0; m < MAXM; m++) if (method & (1u << m)) jobs.push_back({i, m});
             b.j1 = jobs.size();
             if (M->trial - ++pend[k] <= 0) blocked[k] = 1;              // this block ends the trial phase: later blocks wait a round
         }
+        // ---- the predicted trial blocks of the later phases join the first round
+        std::vector<SpecJobs> spec_jobs;
+        if (speculate && !taken.empty()) {
+            speculate = false;                                           // once per call
+            for (size_t k = 0; k < seen.size(); k++) {
+                hg_cram_metrics S = *seen[k];                            // a copy: the walk below changes nothing
+                // the trial blocks this round collected will have been folded; a finished phase resolves -- prediction: it confirms the method before it
+                auto resolve = [&]() {
+                    if (S.method == HG_M_RAW) { S.consistency = 0; S.method = HG_M_GZIP; }
+                    else { const double f = 1 + S.consistency / 4.0; S.next_trial = (int)(S.next_trial * (f < 2 ? f : 2)); S.consistency++; }
+                };
+                if (pend[k]) { S.trial -= pend[k]; if (S.trial <= 0) { S.trial = 0; resolve(); } }
+                for (size_t i = last_blk[k] + 1; i < n; i++) {
+                    if (metrics[i] != seen[k] || B[i].done) continue;
+                    const int sz = (int)in_len[i];
+                    if (S.input_avg_sz && (sz / 4 - 750 > S.input_avg_sz || sz < S.input_avg_sz / 4 - 750) && abs(sz - S.input_avg_sz) / 10 > S.input_avg_delta) S.next_trial = 0;
+                    const bool trial = S.trial > 0 || --S.next_trial <= 0;
+                    S.input_avg_delta = (int)(0.9 * (S.input_avg_delta + abs(sz - S.input_avg_sz)));
+                    S.input_avg_sz += (int)(sz * .2);
+                    S.input_avg_sz = (int)(S.input_avg_sz * 0.8);
+                    if (!trial) continue;
+                    if (S.next_trial <= 0) { S.next_trial = TRIAL_SPAN; S.trial = NTRIALS; }
+                    uint32_t method = (seen[k]->revised_method ? (uint32_t)seen[k]->revised_method : B[i].orig) & have_mask(i);
+                    if ((method & (1u << HG_M_GZIP_RLE)) && (method & (1u << HG_M_GZIP_1))) method &= ~(1u << HG_M_GZIP_RLE);
+                    if (method) {
+                        SpecJobs sj{i, jobs.size(), 0};
+                        for (int m = 0; m < MAXM; m++) if (method & (1u << m)) jobs.push_back({i, m});
+                        sj.j1 = jobs.size();
+                        spec_jobs.push_back(sj); g_tuner[2]++;
+                    }
+                    if (--S.trial == 0) resolve();
+                }
+            }
+        }
         if (taken.empty()) break;
+        g_tuner[1]++;
         // ---- compress -------------------------------------------------------------------------------------------
         std::vector<uint8_t *> res, arenas; std::vector<uint32_t> rlen;
         const auto t_round = std::chrono::steady_clock::now();
@@ -316,42 +427,23 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
                 }
                 continue;
             }
-            uint32_t sz[MAXM];
-            for (int m = 0; m < MAXM; m++) sz[m] = UINT_MAX;            // arbitrarily worse than raw
-            uint32_t sz_best = in_len[i]; int method_best = 0; size_t jbest = (size_t)-1;
-            for (size_t j = b.j0; j < b.j1; j++) {
+            fold_trial(i, M, b.method, [&](int m, const uint8_t *&p, uint32_t &len) {
+                for (size_t j = b.j0; j < b.j1; j++) if (jobs[j].m == m) { if (!res[j]) return false; p = res[j]; len = rlen[j]; return true; }
+                return false;
+            });
+        }
+        // ---- keep what was compressed ahead of time: every size, the smallest payload
+        for (const SpecJobs &sj : spec_jobs) {
+            Spec *S = new Spec; memset(S->sz, 0, sizeof S->sz);
+            uint32_t bsz = in_len[sj.blk]; size_t jb = (size_t)-1;
+            for (size_t j = sj.j0; j < sj.j1; j++) {
+                S->ran_mask |= 1u << jobs[j].m;
                 if (!res[j]) continue;
-                sz[jobs[j].m] = rlen[j];
-                if (sz_best > rlen[j]) { sz_best = rlen[j]; method_best = jobs[j].m; jbest = j; }
+                S->sz[jobs[j].m] = rlen[j];
+                if (rlen[j] < bsz) { bsz = rlen[j]; jb = j; }
             }
-            if (jbest != (size_t)-1) { memcpy(out[i], res[jbest], sz_best); out_len[i] = sz_best; method_used[i] = methmap[method_best]; }
-            for (int m = 0; m < MAXM; m++) M->sz[m] = (int)((unsigned)M->sz[m] + sz[m] + 2000u);   // int arithmetic wraps as in the reference
-            if (--M->trial == 0) {
-                uint32_t method = b.method;
-                int best_method = HG_M_RAW, best_sz = INT_MAX;
-                const double div = level <= 1 ? 0.25 : level <= 3 ? 1 : level <= 6 ? 2 : level <= 7 ? 3 : 0;
-                if (div > 0) for (int m = 0; m < MAXM; m++) M->sz[m] = (int)(M->sz[m] * (1 + (meth_cost[m] - 1) / div));
-                M->sz[9] = M->sz[10] = INT_MAX;
-                for (int m = 0; m < MAXM; m++) {
-                    if (!M->sz[m] || !(method & (1u << m))) continue;
-                    if (best_sz > M->sz[m]) { best_sz = M->sz[m]; best_method = m; }
-                }
-                if (best_method != M->method) M->consistency = 0;
-                else { const double f = 1 + M->consistency / 4.0; M->next_trial = (int)(M->next_trial * (f < 2 ? f : 2)); M->consistency++; }
-                M->method = best_method;
-                // zlib strategy / fqzcomp preset / tokeniser back-end of the learnt method (cram_io.c:2193-2205): Z_FILTERED = 1, Z_RLE = 3
-                M->strat = best_method == HG_M_GZIP ? 1 : best_method == HG_M_GZIP_RLE ? 3 : best_method == HG_M_TOKA ? 1 : 0;
-                const double MAXDELTA = 0.20; const int MAXFAILS = 4, mul = 1 + (level >= 7);
-                for (int m = 0; m < MAXM; m++) {
-                    if (best_method == m) { M->cnt[m] = 0; M->extra[m] = 0; }
-                    else if (best_sz < M->sz[m]) {
-                        const double r = (double)M->sz[m] / best_sz - 1;
-                        if (++M->cnt[m] >= MAXFAILS * mul && (M->extra[m] += r) >= MAXDELTA * mul) method &= ~(1u << m);
-                        if ((m == HG_M_FQZ || (m >= 13 && m <= 15)) && M->sz[m] > best_sz) method &= ~(1u << m);
-                    }
-                }
-                M->revised_method = method;
-            }
+            if (jb != (size_t)-1) { S->best = (uint8_t *)malloc(bsz); if (S->best) { memcpy(S->best, res[jb], bsz); S->best_m = jobs[jb].m; S->best_len = bsz; } else S->ran_mask = 0; }
+            spec[sj.blk] = S;
         }
         for (auto p : arenas) free(p);
         if (getenv("HTS_GPU_STATS") && !g_size_script)

@@ -60,6 +60,7 @@ def test_auto_tuner_equals_the_reference_function(built, tmp_path, level, versio
     CB = C.CFUNCTYPE(C.c_uint32, C.c_int, C.c_size_t, C.c_uint32)
     cb = CB(lambda method, blk, in_len: script(method, base[0] + blk, in_len))
     L.hg_debug_set_cram_size_script(cb)
+    ctr0 = (C.c_uint64 * 5)(); L.hg_debug_cram_tuner_counters(ctr0)
     try:
         mets = [L.hg_cram_metrics_new() for _ in range(4)]
         mets[3].contents.unpackable = 1
@@ -86,5 +87,12 @@ def test_auto_tuner_equals_the_reference_function(built, tmp_path, level, versio
             assert ours == [int(x) for x in ref[:9]], (q, ours, ref[:9])
             for k in range(32):
                 assert (mm.sz[k], mm.cnt[k]) == (int(ref[9 + 3 * k]), int(ref[10 + 3 * k])) and abs(mm.extra[k] - float(ref[11 + 3 * k])) < 1e-5, (q, k)
+        # trial phases ahead of time (cram_metrics_host.hip): in one 800-block call the later phases' trial blocks are compressed with the first round and folded from
+        # the cache when the state machine reaches them -- the call takes a few rounds instead of one per phase, with the reference's decisions (checked above)
+        ctr = (C.c_uint64 * 5)(); L.hg_debug_cram_tuner_counters(ctr)
+        calls, rounds, ahead, folded, normal = [int(ctr[i] - ctr0[i]) for i in range(5)]
+        print("auto-tuner: %d calls, %d rounds, %d trial blocks ahead of time (%d folded from the cache), %d trial blocks on the normal path" % (calls, rounds, ahead, folded, normal))
+        if batch == 800 and os.environ.get("HG_CRAM_SPECULATE") != "0":
+            assert folded > 0 and rounds <= 6, (rounds, ahead, folded, normal)
     finally:
         L.hg_debug_set_cram_size_script(None)
