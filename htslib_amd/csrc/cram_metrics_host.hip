@@ -370,7 +370,8 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
         // ---- the predicted trial blocks of the later phases join the first round
         std::vector<SpecJobs> spec_jobs;
         if (speculate && !taken.empty()) {
-            speculate = false;                                           // once per call
+            // (every round: a series whose prediction failed -- the best method changed, a size jump re-armed the trial -- is predicted again from its new state;
+            // blocks that already have their results are skipped)
             for (size_t k = 0; k < seen.size(); k++) {
                 hg_cram_metrics S = *seen[k];                            // a copy: the walk below changes nothing
                 // the trial blocks this round collected will have been folded; a finished phase resolves -- prediction: it confirms the method before it
@@ -391,7 +392,8 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
                     if (S.next_trial <= 0) { S.next_trial = TRIAL_SPAN; S.trial = NTRIALS; }
                     uint32_t method = (seen[k]->revised_method ? (uint32_t)seen[k]->revised_method : B[i].orig) & have_mask(i);
                     if ((method & (1u << HG_M_GZIP_RLE)) && (method & (1u << HG_M_GZIP_1))) method &= ~(1u << HG_M_GZIP_RLE);
-                    if (method) {
+                    if (method && !(spec[i] && (method & ~spec[i]->ran_mask) == 0)) {
+                        if (spec[i]) { free(spec[i]->best); delete spec[i]; spec[i] = nullptr; }
                         SpecJobs sj{i, jobs.size(), 0};
                         for (int m = 0; m < MAXM; m++) if (method & (1u << m)) jobs.push_back({i, m});
                         sj.j1 = jobs.size();

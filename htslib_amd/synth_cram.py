@@ -155,20 +155,29 @@ def bam_from_slices(engine, slices, copies=1):
     recs, rec_off, st = engine.cram_decode_bam(arr, n, 3, 1, [], nrec * readlen + 4096, nrec * (readlen * 2 + 400))
     assert (st == 0).all(), st
     one = bytearray(recs.tobytes())
-    ends, at = [], 0
-    for s in slices:
-        for _ in range(s["nrec"]): at += 4 + struct.unpack_from("<i", one, at)[0]
+    ends, at, starts, slice_of = [], 0, [], []
+    for k, s in enumerate(slices):
+        for _ in range(s["nrec"]):
+            starts.append(at); slice_of.append(k)
+            at += 4 + struct.unpack_from("<i", one, at)[0]
         ends.append(at)
     assert at == len(one)
-    body = bytearray()
+    # every copy: the same records under the copy's reference ids (refID at +4, the mate's at +24 where there is one) -- four byte planes written with numpy
+    import numpy as np
+    base = np.frombuffer(bytes(one), dtype=np.uint8)
+    st = np.asarray(starts, dtype=np.int64); sl = np.asarray(slice_of, dtype=np.int64)
+    mate = (base[st + 24].astype(np.int64) | base[st + 25].astype(np.int64) << 8 | base[st + 26].astype(np.int64) << 16 | base[st + 27].astype(np.int64) << 24)
+    has_mate = mate < (1 << 31)                                              # (a negative int32 = no mate reference)
+    body = np.empty(len(one) * copies, dtype=np.uint8)
     for c in range(copies):
-        b = bytearray(one); at = 0
-        for k, end in enumerate(ends):
-            while at < end:
-                struct.pack_into("<i", b, at + 4, c * n + k)
-                if struct.unpack_from("<i", b, at + 24)[0] >= 0: struct.pack_into("<i", b, at + 24, c * n + k)
-                at += 4 + struct.unpack_from("<i", b, at)[0]
-        body += b
+        b = body[c * len(one):(c + 1) * len(one)]
+        b[:] = base
+        rid = c * n + sl
+        for sh in range(4):
+            plane = ((rid >> (8 * sh)) & 0xff).astype(np.uint8)
+            b[st + 4 + sh] = plane
+            b[st[has_mate] + 24 + sh] = plane[has_mate]
+    body = body.tobytes()
     names = ["chr%d" % (i + 1) for i in range(n * copies)]
     seqs = [slices[i % n]["refs"][0][2] for i in range(n * copies)]
     text = b"@HD\tVN:1.6\tSO:coordinate\n" + b"".join(b"@SQ\tSN:%s\tLN:%d\n" % (a.encode(), len(q)) for a, q in zip(names, seqs))
