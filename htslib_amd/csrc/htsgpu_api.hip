@@ -6,6 +6,8 @@
 // CPU implementation of any codec here: if HIP or the device is unavailable
 // every entry point fails with HG_ENODEV.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <mutex>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -219,6 +221,36 @@ int hg_gzip_inflate_dev(hg_ctx *ctx, const void *d_comp, size_t comp_len, const 
     return hg::launch_bgzf_inflate(ctx, d_comp, comp_len, d_desc, n, d_out, out_cap, d_status, (hipStream_t)stream, 1);
 }
 
+// CRAM methods 2 and 3 (bzip2, lzma; cram_io.c:1626-1664) are general-purpose CPU codecs the reference itself only reaches through libbz2 / liblzma: a block of
+// either goes to the system's library, looked up at run time (no link-time dependency); absent library = HG_BLOCK_EUNSUPPORTED, the reference's "not compiled
+// into this version".  Nothing of the GPU path runs through here.
+namespace {
+struct HostInflaters {
+    int (*bz2)(char *, unsigned int *, char *, unsigned int, int, int) = nullptr;                                                    // BZ2_bzBuffToBuffDecompress
+    int (*lzma)(uint64_t *, uint32_t, const void *, const uint8_t *, size_t *, size_t, uint8_t *, size_t *, size_t) = nullptr;      // lzma_stream_buffer_decode
+};
+const HostInflaters &host_inflaters() {
+    static HostInflaters H;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *n : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"}) if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) { H.bz2 = (decltype(H.bz2))dlsym(h, "BZ2_bzBuffToBuffDecompress"); if (H.bz2) break; }
+        for (const char *n : {"liblzma.so.5", "liblzma.so"}) if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) { H.lzma = (decltype(H.lzma))dlsym(h, "lzma_stream_buffer_decode"); if (H.lzma) break; }
+    });
+    return H;
+}
+int32_t host_inflate(int32_t method, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len) {
+    const HostInflaters &H = host_inflaters();
+    if (method == HG_CRAM_BZIP2) {
+        if (!H.bz2) return HG_BLOCK_EUNSUPPORTED;
+        unsigned int got = out_len;
+        return H.bz2((char *)out, &got, (char *)in, in_len, 0, 0) == 0 && got == out_len ? 0 : -1;
+    }
+    if (!H.lzma) return HG_BLOCK_EUNSUPPORTED;
+    uint64_t memlimit = 1ull << 31; size_t ip = 0, op = 0;
+    return H.lzma(&memlimit, 0, nullptr, in, &ip, in_len, out, &op, out_len) == 0 && op == out_len ? 0 : -1;
+}
+}  // namespace
+
 int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method, const uint8_t *const *in,
                                    const uint32_t *in_len, uint8_t *const *out, const uint32_t *out_len,
                                    int32_t *status) {
@@ -236,6 +268,7 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
         else if (method[i] == HG_CRAM_ARITH) na++;
         else if (method[i] == HG_CRAM_TOK3) nt++;
         else if (method[i] == HG_CRAM_FQZ) nq++;
+        else if (method[i] == HG_CRAM_BZIP2 || method[i] == HG_CRAM_LZMA) status[i] = host_inflate(method[i], in[i], in_len[i], out[i], out_len[i]);
         else status[i] = HG_BLOCK_EUNSUPPORTED;
     }
     // Six independent codec families; each runs on its own thread / sibling context / HIP stream when more than one

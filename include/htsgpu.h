@@ -298,7 +298,8 @@ int hg_fqz_encode_host(hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in
 /* Uncompress n CRAM blocks in one batch: block i has on-disk method method[i], compressed payload
  * in[i] (in_len[i] = comp_size) and must produce exactly out_len[i] = uncomp_size bytes into out[i]
  * (cram_uncompress_block's size check, cram_io.c:1611-1614).  RAW blocks are copied, GZIP, RANS4x8,
- * RANSNx16, ARITH and TOK3 blocks go to the gfx950 kernels; status[i] = 0 / -1 / -2 (CRC) / -3 (unsupported method).
+ * RANSNx16, ARITH, FQZ and TOK3 blocks go to the gfx950 kernels, BZIP2 / LZMA blocks to the system libraries the reference itself delegates them to (looked up at run
+ * time; absent = -3); status[i] = 0 / -1 / -2 (CRC) / -3 (unsupported method).
  * Synchronous; returns 0, or HG_EBLOCK if any status is non-zero. */
 int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method, const uint8_t *const *in,
                                    const uint32_t *in_len, uint8_t *const *out, const uint32_t *out_len,
