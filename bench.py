@@ -1494,14 +1494,15 @@ def op_encode(run: Run, steps: int, slices: int = 64, nrec: int = 10000, cpu: bo
     return res
 
 
-def op_fqz(run: Run, steps: int, streams: int = 512):
-    """fqzcomp (CRAM method 7) decode + encode through the host entry points: quality blocks of 2 000 x 150 bp reads."""
+def op_fqz(run: Run, steps: int, streams: int = 512, nrec: int = 2000):
+    """fqzcomp (CRAM method 7) decode + encode through the host entry points: quality blocks of nrec x 150 bp reads (streams = 1 248, nrec = 10 000: the quality
+    blocks of BASELINE configs[4]'s 1 250 slices per GPU).  One adaptive chain per block: the throughput is the number of blocks in flight x the chain's rate."""
     run.init_device()
     import numpy as np
     from htslib_amd import _native as nat
     eng = nat.Engine(run.local)
     rng = np.random.default_rng(8)
-    nrec, rl = 2000, 150
+    rl = 150
     quals, lens = [], []
     for _ in range(4):
         q = np.clip(38 + np.cumsum(rng.integers(-2, 3, nrec * rl)) % 12 - np.tile(np.arange(rl) // 12, nrec), 2, 41).astype(np.uint8)
@@ -1509,7 +1510,7 @@ def op_fqz(run: Run, steps: int, streams: int = 512):
     datas = [quals[i % 4] for i in range(streams)]
     args = (datas, [lens[i % 4] for i in range(streams)], [None] * streams, [i % 4 for i in range(streams)])
     te, td, enc = [], [], None
-    steps = max(5, steps)
+    steps = max(3, steps)
     for _ in range(steps + 1):
         t = time.perf_counter(); enc = eng.fqz_encode_host(*args); te.append(time.perf_counter() - t)
         blocks = [(7, e, len(d)) for e, d in zip(enc, datas)]
@@ -1598,7 +1599,7 @@ def main():
     if args.op == "cram31":
         out = op_cram31(run, args.steps, max(1, (args.slices or 64) // 4))
     elif args.op in ("records", "fqz", "encode"):
-        out = op_records(run, args.steps, args.slices or 256) if args.op == "records" else op_encode(run, args.steps, args.slices or 64) if args.op == "encode" else op_fqz(run, args.steps, args.slices or 512)
+        out = op_records(run, args.steps, args.slices or 256) if args.op == "records" else op_encode(run, args.steps, args.slices or 64) if args.op == "encode" else op_fqz(run, args.steps, args.slices or 512, 10000 if (args.slices or 0) >= 1000 else 2000)
     elif args.op in ("rans", "cram"):
         if args.op == "rans":
             out, ok = op_rans(run, args.steps, args.warmup, args.slices or 1000, args.nway)
@@ -1649,7 +1650,7 @@ def main():
                 if d: extra["cram_slices"] = d
                 if run.rank == 0 and run.world == 1:                         # the "next" rows of SURVEY 8f built this round: small, guarded probes
                     for key, fn in (("cram_records_to_bam", lambda: op_records(run, 5)), ("cram_records_encode", lambda: op_encode(run, 5)), ("cram31_file_encode", lambda: op_cram31(run, 2, 312, flag_sets=[3, 1])),
-                                    ("cram_fqzcomp", lambda: op_fqz(run, 5, 256))):
+                                    ("cram_fqzcomp", lambda: op_fqz(run, 3, 1248, 10000))):
                         try:
                             extra[key] = fn()
                         except Exception as e:
