@@ -607,8 +607,8 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
     auto fetch = [&](uint8_t *dst, int which, uint64_t off, size_t len) {
         if (len && dst) { F[which].off.push_back(off); F[which].len.push_back((uint32_t)len); F[which].dst.push_back(dst); }
     };
-    // dst == nullptr: measure only (returns the length as a pointer difference from nullptr)
-    auto emit_leaf = [&](uint8_t *cp, const Leaf &L) -> uint8_t * {
+    // cp == nullptr: measure only.  Returns the leaf's length.
+    auto emit_leaf = [&](uint8_t *cp, const Leaf &L) -> size_t {
         const bool wr = cp != nullptr;
         uint8_t hdr[64], *hp = hdr;
         const uint32_t f = L.r.flags;
@@ -638,19 +638,19 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
             const uint32_t bl = ol[L.core] > skip ? ol[L.core] - skip : 0u;
             fetch(wr ? cp + pos : nullptr, 1, cd[L.core].out_off + skip, bl); pos += bl;
         }
-        return cp + pos;
+        return pos;
     };
     for (size_t i = 0; i < n; i++) {
         uint8_t *cp = out[i];
         const uint32_t l0 = first_leaf[i], nl = first_leaf[i + 1] - l0;
-        if (nl == 1) cp = emit_leaf(cp, leaves[l0]);
+        if (nl == 1) cp += emit_leaf(cp, leaves[l0]);
         else {
             const uint32_t f = top_flags[i];
             *cp++ = (uint8_t)f;
             if (!(f & F_NOSZ)) cp += put_u7(cp, in_len[i]);
             *cp++ = (uint8_t)nl;
-            for (uint32_t k = 0; k < nl; k++) cp += put_u7(cp, (uint32_t)(emit_leaf(nullptr, leaves[l0 + k]) - (uint8_t *)nullptr));
-            for (uint32_t k = 0; k < nl; k++) cp = emit_leaf(cp, leaves[l0 + k]);
+            for (uint32_t k = 0; k < nl; k++) cp += put_u7(cp, (uint32_t)emit_leaf(nullptr, leaves[l0 + k]));
+            for (uint32_t k = 0; k < nl; k++) cp += emit_leaf(cp, leaves[l0 + k]);
         }
         out_len[i] = (uint32_t)(cp - out[i]);
     }

@@ -224,6 +224,7 @@ int hg_gzip_inflate_dev(hg_ctx *ctx, const void *d_comp, size_t comp_len, const 
 // CRAM methods 2 and 3 (bzip2, lzma; cram_io.c:1626-1664) are general-purpose CPU codecs the reference itself only reaches through libbz2 / liblzma: a block of
 // either goes to the system's library, looked up at run time (no link-time dependency); absent library = HG_BLOCK_EUNSUPPORTED, the reference's "not compiled
 // into this version".  Nothing of the GPU path runs through here.
+extern "C++" {
 namespace {
 struct HostInflaters {
     int (*bz2)(char *, unsigned int *, char *, unsigned int, int, int) = nullptr;                                                    // BZ2_bzBuffToBuffDecompress
@@ -250,6 +251,7 @@ int32_t host_inflate(int32_t method, const uint8_t *in, uint32_t in_len, uint8_t
     return H.lzma(&memlimit, 0, nullptr, in, &ip, in_len, out, &op, out_len) == 0 && op == out_len ? 0 : -1;
 }
 }  // namespace
+}  // extern "C++"
 
 int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method, const uint8_t *const *in,
                                    const uint32_t *in_len, uint8_t *const *out, const uint32_t *out_len,

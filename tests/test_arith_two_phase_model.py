@@ -1,8 +1,9 @@
 """The two-phase form of the range coder's encoder (htslib_amd/csrc/arith_enc2.hip), as a plain-Python model checked against the oracle on the CPU: the events of a
-stream are grouped by MODEL (literal context, run model), every model walks only its own events and leaves a (cum, freq, total) record in the event's slot --
-slot i for the literal at position i, slots 2i, 2i+1, ... for the run that starts at i when RLE is on -- and one pass over the slots in order does the coder
-arithmetic.  If the decomposition were not equivalent to the one-pass coder (a model whose state depends on another model's events, a slot rule that loses
-stream order) the bytes would differ from oracle/arith_oracle.c's.  The kernels themselves are compared with the oracle under -m gpu (tests/test_arith.py)."""
+stream are grouped by MODEL (literal context, run model), every model walks only its own events and leaves a (cum, freq, total) record at the event's NUMBER in
+coding order -- dense since round 5: position i without RLE; with RLE the run of r + 1 symbols that starts after E events owns numbers E (its literal), E + 1 ...
+(its r // 3 + 1 run-length parts), the rule sort_kernel computes with a prefix sum over the runs -- and one pass over the records in order does the coder arithmetic.
+If the decomposition were not equivalent to the one-pass coder (a model whose state depends on another model's events, a numbering that loses stream order) the
+bytes would differ from oracle/arith_oracle.c's.  The kernels themselves are compared with the oracle under -m gpu (tests/test_arith.py)."""
 import numpy as np
 import pytest
 
@@ -36,19 +37,21 @@ def phase_a(d, order, rle):
     if not rle:
         for i, c in enumerate(d): ev(("lit", d[i - 1] if order and i else 0), i, c)
     else:
-        i = 0
+        i = 0; E = 0
         while i < n:
             c = d[i]; r = 0
             while i + 1 + r < n and d[i + 1 + r] == c: r += 1
-            ev(("lit", d[i - 1] if order and i else 0), 2 * i, c)                 # the context of a run's literal: the symbol of the run before = the byte before
+            ev(("lit", d[i - 1] if order and i else 0), E, c)                     # the context of a run's literal: the symbol of the run before = the byte before
             rctx, j, rem = c, 1, r
             while True:
                 part = min(rem, 3)
-                ev(("run", rctx), 2 * i + j, part)
+                ev(("run", rctx), E + j, part)
                 rctx = 256 if rctx == c else 257; j += 1; rem -= part
                 if part != 3: break
-            assert j <= 2 * (r + 1)                                              # a run's events fit the slots of its positions
+            assert j == 2 + r // 3                                                # the event count sort_kernel's prefix sum uses
+            E += j
             i += r + 1
+        assert E <= 2 * n                                                         # the record area of an RLE stream: 2 n slots
     slots = {}
     for (kind, _), evs in events.items():
         M = Model(m if kind == "lit" else 4)
@@ -58,7 +61,7 @@ def phase_a(d, order, rle):
     return m, slots
 
 
-def phase_b(m, slots, nslots):                          # arith_dev.h Encoder over the records; empty slots are skipped
+def phase_b(m, slots, nslots):                          # arith_enc2.hip Coder over the records
     out = bytearray([m & 0xff])
     low, rng, carry, cache, ffnum = 0, M32, 0, 0, 0
     def shift_low():
@@ -99,5 +102,6 @@ def test_two_phase_decomposition_equals_the_one_pass_coder(aorc):
         for fl in (0, 1, 64, 65):
             order, rle = fl & 1, 1 if fl & 64 else 0
             m, slots = phase_a(d, order, rle)
-            got = bytes([fl]) + u7(len(d)) + phase_b(m, slots, (2 if rle else 1) * len(d))
+            assert sorted(slots) == list(range(len(slots)))                       # dense
+            got = bytes([fl]) + u7(len(d)) + phase_b(m, slots, len(slots))
             assert got == aorc.encode(d, fl), (len(d), fl)
