@@ -29,6 +29,7 @@
 #include "hg_device.h"
 #include "hg_internal.h"
 #include "arith_dev.h"
+#include "range_enc2_dev.h"
 
 namespace hgq {
 using hg::wave_sync;
@@ -470,6 +471,199 @@ void fqz_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__r
     }
 }
 
+
+// ================================================================================ the ENCODER in two phases (round 5)
+// An encoder knows every quality and therefore every CONTEXT before it codes anything: the 65 536 adaptive models only interact through the coder's
+// registers.  So, as in arith_enc2.hip: (1) events_kernel -- one workgroup per block, one THREAD per record -- walks each record's context state machine (it
+// restarts with every record) and writes the block's events in coding order: (model, symbol) with model = the 16-bit quality context, or one of the seven
+// record-level models (selector, four length bytes, reverse, duplicate); record r's first event number is a prefix sum over the records.  (2) sort_kernel,
+// one wavefront per block: a stable LSD radix sort of the events by model (8 + 9 bits, the lanes of a step ranking themselves with one ballot per key bit).
+// (3) models_kernel: the sorted events cut every ENC2_CUT positions; wave t takes the models that START in its stretch, each in REGISTERS (range_enc2_dev.h
+// RegModel: no model ever travels to HBM and back -- the one-pass kernel waits ~1 us for its model at every quality), and leaves an 8-byte record per event
+// at the event's number.  (4) the scalar coder pass over the records (hga2::code_kernel).  Byte-identical to the one-pass encoder and the oracle.
+constexpr uint32_t K_SEL = 65536, K_LEN = 65537, K_REV = 65541, K_DUP = 65542;
+constexpr uint32_t ENC2_CUT = 1024;
+struct Enc2Stream {            // per block, device: where its arrays lie (byte offsets into the work buffer) and what the events kernel found
+    uint64_t key0, pay0, key1, pay1, rec, ebase;
+    uint32_t ecap, nrec_first;   // nrec_first: index of the block's first record in the call's record arrays
+};
+
+__global__ __launch_bounds__(256)
+void fqz_events_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc, const uint32_t *__restrict__ images, const uint32_t *__restrict__ rec_len,
+                       const uint32_t *__restrict__ rec_flags, const uint32_t *__restrict__ rec_off, const Enc2Stream *__restrict__ streams, uint8_t *work, uint32_t *info) {
+    __shared__ uint32_t img[IMG_WORDS];
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t carry_s;
+    const uint32_t k = blockIdx.x, tid = threadIdx.x;
+    const hg_stream_desc d = desc[k];
+    const Enc2Stream S = streams[k];
+    for (uint32_t i = tid; i < IMG_WORDS; i += 256) img[i] = images[(size_t)d.scratch_off * IMG_WORDS + i];
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    const uint32_t gflags = img[0], max_sel = img[2], nrec = img[6], have_flags = img[7];
+    const uint8_t *stab = (const uint8_t *)(img + IMG_HEAD);
+    const uint8_t *src = in + d.in_off;
+    const uint32_t *lens = rec_len + S.nrec_first, *flg = rec_flags + S.nrec_first, *offs = rec_off + S.nrec_first;
+    uint32_t *ebase = (uint32_t *)(work + S.ebase);
+    uint32_t *key0 = (uint32_t *)(work + S.key0), *pay0 = (uint32_t *)(work + S.pay0);
+    // what record r codes before its qualities, and whether it is a duplicate of its predecessor (both in coding orientation)
+    auto record = [&](uint32_t r, uint32_t &len, uint32_t &rv, uint32_t &s, uint32_t &pflags, bool &coded_len, bool &dup) {
+        len = lens[r];
+        const uint32_t fl = have_flags ? flg[r] : 0u;
+        rv = (gflags & GF_REV) && (fl & FQZ_FREVERSE) ? 1u : 0u; s = max_sel && (fl & FQZ_FREAD2) ? 1u : 0u;
+        pflags = img[IMG_HEAD + IMG_STAB + (uint32_t)stab[s] * IMG_PARAM + 1u];
+        coded_len = !(pflags & PF_LEN) || r == 0u;
+        dup = false;
+        if ((pflags & PF_DEDUP) && r && lens[r - 1u] == len) {
+            const uint32_t pfl = have_flags ? flg[r - 1u] : 0u, prv = (gflags & GF_REV) && (pfl & FQZ_FREVERSE) ? 1u : 0u, at = offs[r];
+            dup = true;
+            for (uint32_t j = 0; j < len; j++) if (src[at + j] != (rv == prv ? src[at - len + j] : src[at - 1u - j])) { dup = false; break; }
+        }
+    };
+    // ---- pass 1: events per record, exclusive prefix sums (chunks of 256 records)
+    for (uint32_t r0 = 0; r0 < nrec; r0 += 256) {
+        const uint32_t r = r0 + tid;
+        uint32_t nev = 0;
+        if (r < nrec) {
+            uint32_t len, rv, s, pflags; bool cl, dup;
+            record(r, len, rv, s, pflags, cl, dup);
+            nev = (max_sel ? 1u : 0u) + (cl ? 4u : 0u) + ((gflags & GF_REV) ? 1u : 0u) + ((pflags & PF_DEDUP) ? 1u : 0u) + (dup ? 0u : len);
+        }
+        part[tid] = nev;
+        __syncthreads();
+        for (uint32_t st = 1; st < 256; st <<= 1) {                 // Hillis-Steele over the chunk
+            const uint32_t v = tid >= st ? part[tid - st] : 0u;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        if (r < nrec) ebase[r] = carry_s + part[tid] - nev;
+        __syncthreads();
+        if (tid == 255) carry_s += part[255];
+        __syncthreads();
+    }
+    if (tid == 0) { info[2 * k] = 0; info[2 * k + 1] = carry_s; }    // Arith2pInfo { m, nevents }: what the coder pass reads
+    // ---- pass 2: the events
+    for (uint32_t r = tid; r < nrec; r += 256) {
+        uint32_t len, rv, s, pflags; bool cl, dup;
+        record(r, len, rv, s, pflags, cl, dup);
+        uint32_t e = ebase[r];
+        auto ev = [&](uint32_t key, uint32_t sym) { key0[e] = key; pay0[e] = e << 8 | sym; e++; };
+        if (max_sel) ev(K_SEL, s);
+        if (cl) { ev(K_LEN, len & 0xffu); ev(K_LEN + 1u, (len >> 8) & 0xffu); ev(K_LEN + 2u, (len >> 16) & 0xffu); ev(K_LEN + 3u, len >> 24); }
+        if (gflags & GF_REV) ev(K_REV, rv);
+        if (pflags & PF_DEDUP) { ev(K_DUP, dup ? 1u : 0u); if (dup) continue; }
+        ParamRegs R; load_param(R, img, stab[s]);
+        State st = {0, len, 0, 0, s};
+        const uint8_t *inv = (const uint8_t *)(R.base + IMG_PSCAL);
+        const uint32_t at = offs[r];
+        uint32_t last = R.context;
+        for (uint32_t j = 0; j < len; j++) {
+            const uint32_t q = inv[src[rv ? at + len - 1u - j : at + j]];
+            ev(last, q);
+            last = update_ctx(R, st, q);
+        }
+    }
+}
+
+// one LSD pass: events (key, pay) of [0, n) from `in` to `out`, stable, by BITS bits of the key at `shift`; cnt / cur: 1 << BITS LDS words each
+template <int BITS>
+__device__ __forceinline__ void radix_pass(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ pin, uint32_t *kout, uint32_t *pout, uint32_t n, uint32_t shift,
+                                           uint32_t *cnt, uint32_t *cur, int lane) {
+    constexpr uint32_t NB = 1u << BITS;
+    const unsigned long long lt = hga2::lanes_below(lane);
+    for (uint32_t i = (uint32_t)lane; i < NB; i += 64) cnt[i] = 0u;
+    wave_sync();
+    for (int place = 0; place < 2; place++) {
+        uint32_t nk = (uint32_t)lane < n ? kin[lane] : 0u, np = place && (uint32_t)lane < n ? pin[lane] : 0u;
+        for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+            const uint32_t key = nk, pay = np, p = i0 + (uint32_t)lane;
+            { const uint32_t q = p + 64u; if (q < n) { nk = kin[q]; if (place) np = pin[q]; } }
+            const bool in = p < n;
+            const uint32_t dgt = (key >> shift) & (NB - 1u);
+            const unsigned long long m = hga2::match_bits<BITS>(dgt, in);
+            const uint32_t rank = (uint32_t)__popcll(m & lt), c = (uint32_t)__popcll(m);
+            if (!place) { if (in && rank == 0u) cnt[dgt] += c; }
+            else {
+                const uint32_t base = in ? cur[dgt] : 0u;
+                if (in && rank == 0u) cur[dgt] = base + c;
+                if (in) { kout[base + rank] = key; pout[base + rank] = pay; }
+            }
+        }
+        wave_sync();
+        if (!place) {                                               // exclusive prefix sums of the counts: lane l takes NB / 64 consecutive entries
+            constexpr uint32_t PER = NB / 64u;
+            uint32_t a[PER], sum = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < PER; q++) { a[q] = cnt[PER * (uint32_t)lane + q]; sum += a[q]; }
+            uint32_t ex = hg::wave_incl_scan_dpp(sum) - sum;
+#pragma unroll
+            for (uint32_t q = 0; q < PER; q++) { cur[PER * (uint32_t)lane + q] = ex; ex += a[q]; }
+            wave_sync();
+        }
+    }
+}
+
+__global__ __launch_bounds__(64)
+void fqz_sort_kernel(const Enc2Stream *__restrict__ streams, uint8_t *work, const uint32_t *__restrict__ info) {
+    __shared__ uint32_t cnt[512], cur[512];
+    const int lane = threadIdx.x;
+    const uint32_t k = blockIdx.x, n = info[2 * k + 1];
+    const Enc2Stream S = streams[k];
+    uint32_t *key0 = (uint32_t *)(work + S.key0), *pay0 = (uint32_t *)(work + S.pay0), *key1 = (uint32_t *)(work + S.key1), *pay1 = (uint32_t *)(work + S.pay1);
+    radix_pass<8>(key0, pay0, key1, pay1, n, 0u, cnt, cur, lane);
+    radix_pass<9>(key1, pay1, key0, pay0, n, 8u, cnt, cur, lane);
+}
+
+// the events of the model that starts at sorted position i (key `key`, alphabet n_alpha): codes them, returns the position where the next model starts
+template <int EPL>
+__device__ __forceinline__ uint32_t enc2_model(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ pays, uint32_t i, uint32_t n, uint32_t key, uint32_t n_alpha, uint2 *R, int lane) {
+    hga2::RegModel<EPL> G; G.init(n_alpha, lane);
+    for (;;) {
+        const uint32_t p = i + (uint32_t)lane;
+        const uint32_t kv = p < n ? keys[p] : ~0u, pv = p < n ? pays[p] : 0u;
+        const unsigned long long other = __ballot(kv != key);
+        const uint32_t nn = other ? (uint32_t)__builtin_ctzll(other) : 64u;
+        for (uint32_t j = 0; j < nn; j++) { const uint32_t w = rl(pv, j); G.step(w & 0xffu, R, w >> 8, lane); }
+        i += nn;
+        if (nn < 64u) return i;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void fqz_models_kernel(const hg_stream_desc *__restrict__ desc, const uint32_t *__restrict__ images, const Enc2Stream *__restrict__ streams, uint8_t *work, const uint32_t *__restrict__ info) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.y, t = blockIdx.x * 4u + (threadIdx.x >> 6), n = info[2 * k + 1];
+    if ((unsigned long long)t * ENC2_CUT >= n) return;
+    const Enc2Stream S = streams[k];
+    const uint32_t *keys = (const uint32_t *)(work + S.key0), *pays = (const uint32_t *)(work + S.pay0);
+    uint2 *R = (uint2 *)(work + S.rec);
+    const uint32_t *img = images + (size_t)desc[k].scratch_off * IMG_WORDS;
+    const uint32_t max_sel = img[2], ns = img[3];
+    uint32_t i = t * ENC2_CUT;
+    const uint32_t stop = (t + 1u) * ENC2_CUT;                          // models starting at or behind this position belong to the next stretches
+    if (t) {
+        // the first model START in [i, ...): nothing when one model covers the stretch and beyond
+        const uint32_t last = stop < n ? stop - 1u : n - 1u;
+        if (keys[i - 1u] == keys[last]) return;
+        for (;;) {
+            const uint32_t p = i + (uint32_t)lane;
+            const uint32_t a = p < n ? keys[p] : ~0u, b = keys[p < n ? p - 1u : n - 1u];
+            const unsigned long long st = __ballot(p < n && a != b);
+            if (st) { i += (uint32_t)__builtin_ctzll(st); break; }
+            i += 64u;
+            if (i >= n) return;
+        }
+        if (i >= stop) return;
+    }
+    while (i < n && i < stop) {
+        const uint32_t key = hg::uni(keys[i]);
+        if (key < CTX_SIZE) i = ns > 128u ? enc2_model<4>(keys, pays, i, n, key, ns, R, lane) : ns > 64u ? enc2_model<2>(keys, pays, i, n, key, ns, R, lane) : enc2_model<1>(keys, pays, i, n, key, ns, R, lane);
+        else if (key >= K_LEN && key < K_LEN + 4u) i = enc2_model<4>(keys, pays, i, n, key, 256u, R, lane);
+        else i = enc2_model<1>(keys, pays, i, n, key, key == K_SEL ? max_sel + 1u : 2u, R, lane);
+    }
+}
+
 }  // namespace hgq
 
 namespace hg {
@@ -494,6 +688,20 @@ int launch_fqz_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_des
     hipLaunchKernelGGL((hgq::fqz_encode_kernel<WAVES>), dim3((unsigned)wgs), dim3(WAVES * 64), 0, s, (const uint8_t *)d_in, d_desc, d_images,
                        d_rec_len, d_rec_flags, (uint32_t)n, (uint8_t *)d_out, d_out_len, d_scratch, (unsigned long long)slot_words);
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
+}
+// the two-phase encoder: events -> sort -> models -> coder (arith_enc2.hip's code kernel over the records); d_info: 2 words per stream {0, events}
+int launch_fqz_encode2(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const hg_stream_desc *d_code_desc, const uint32_t *d_images, const uint32_t *d_rec_len,
+                       const uint32_t *d_rec_flags, const uint32_t *d_rec_off, const void *d_streams, size_t n, size_t max_ecap, void *d_work, uint32_t *d_info, void *d_out,
+                       uint32_t *d_out_len, hipStream_t s) {
+    (void)ctx;
+    if (!n) return HG_OK;
+    const hgq::Enc2Stream *st = (const hgq::Enc2Stream *)d_streams;
+    hipLaunchKernelGGL(hgq::fqz_events_kernel, dim3((unsigned)n), dim3(256), 0, s, (const uint8_t *)d_in, d_desc, d_images, d_rec_len, d_rec_flags, d_rec_off, st, (uint8_t *)d_work, d_info);
+    hipLaunchKernelGGL(hgq::fqz_sort_kernel, dim3((unsigned)n), dim3(64), 0, s, st, (uint8_t *)d_work, (const uint32_t *)d_info);
+    const unsigned stretches = (unsigned)((max_ecap + hgq::ENC2_CUT - 1) / hgq::ENC2_CUT);
+    hipLaunchKernelGGL(hgq::fqz_models_kernel, dim3((stretches + 3) / 4, (unsigned)n), dim3(256), 0, s, d_desc, d_images, st, (uint8_t *)d_work, (const uint32_t *)d_info);
+    if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
+    return launch_range_code(d_code_desc, n, d_info, d_work, d_out, d_out_len, s);
 }
 // resident wavefronts: every one owns 65536 models in scratch, so the count is bounded by memory as well as by the chip
 static int fqz_slots(hg_ctx *ctx, size_t m, size_t slot_words, size_t *slots) {
@@ -622,16 +830,76 @@ extern "C" int hg_fqz_encode_host(hg_ctx *ctx, const uint8_t *const *in, const u
         ooff += (hg_fqz_compress_bound(in_len[i], f->num_records) + 63u) & ~63ull;
         if (rlen.size() > 0xffffffffull) return HG_EINVAL;
     }
+    int rc;
+    hipStream_t s = ctx->stream;
+    // ---- two phases (events sorted by model, register models, scalar coder pass) when the work arrays fit: 24 bytes per event.  HG_FQZ_2P=0: the one-pass kernel
+    //      (A/B runs); it also takes over when the device memory does not do, and for blocks beyond 2^24 events (event numbers travel in 24 bits).
+    {
+        const bool want = !(getenv("HG_FQZ_2P") && atoi(getenv("HG_FQZ_2P")) == 0);
+        std::vector<hgq::Enc2Stream> st(m);
+        std::vector<hg_stream_desc> cdesc(m);
+        std::vector<uint32_t> roff(rlen.size());
+        uint64_t woff = 0; size_t max_ecap = 0; bool fits = want;
+        size_t rbase = 0;
+        for (size_t k = 0; k < m && fits; k++) {
+            const size_t i = live[ord[k]];
+            const uint32_t nrec = slice[i]->num_records;
+            const uint64_t ecap = (uint64_t)in_len[i] + 7ull * nrec;
+            if (ecap >= (1u << 24)) { fits = false; break; }
+            auto take = [&](uint64_t bytes) { const uint64_t at = woff; woff += (bytes + 15u) & ~15ull; return at; };
+            st[k].rec = take(ecap * 8); st[k].key0 = take(ecap * 4); st[k].pay0 = take(ecap * 4); st[k].key1 = take(ecap * 4); st[k].pay1 = take(ecap * 4);
+            st[k].ebase = take((uint64_t)nrec * 4);
+            st[k].ecap = (uint32_t)ecap; st[k].nrec_first = (uint32_t)rbase;
+            uint32_t at = 0;
+            for (uint32_t r = 0; r < nrec; r++) { roff[rbase + r] = at; at += rlen[rbase + r]; }
+            rbase += nrec;
+            max_ecap = std::max<size_t>(max_ecap, (size_t)ecap);
+            cdesc[k] = desc[k]; cdesc[k].scratch_off = (uint32_t)(2 * k); cdesc[k].reserved = (uint32_t)(st[k].rec / 16);
+            if (st[k].rec / 16 > 0xffffffffull) fits = false;
+        }
+        if (fits) {
+            size_t freeb = 0, totalb = 0;
+            if (hipMemGetInfo(&freeb, &totalb) != hipSuccess || woff + ioff + ooff > freeb / 2 + ctx->d_scratch_cap[5] + ctx->d_scratch_cap[0] + ctx->d_scratch_cap[1]) fits = false;
+        }
+        if (fits) {
+            const size_t recb = rlen.size() * 4;
+            if ((rc = hg::ensure_scratch(ctx, 0, ioff + 64)) || (rc = hg::ensure_scratch(ctx, 1, ooff + 64)) || (rc = hg::ensure_scratch(ctx, 2, 2 * m * sizeof(hg_stream_desc) + 64)) ||
+                (rc = hg::ensure_scratch(ctx, 3, m * 4 + 64)) || (rc = hg::ensure_scratch(ctx, 4, images.size() * 4 + 64)) || (rc = hg::ensure_scratch(ctx, 5, woff + 64)) ||
+                (rc = hg::ensure_scratch(ctx, 7, 3 * recb + 64)) || (rc = hg::ensure_scratch(ctx, 8, m * sizeof(hgq::Enc2Stream) + m * 8 + 64))) return rc;
+            uint32_t *d_rlen = (uint32_t *)ctx->d_scratch[7], *d_rflg = d_rlen + rlen.size(), *d_roff = d_rflg + rlen.size();
+            hg_stream_desc *d_desc = (hg_stream_desc *)ctx->d_scratch[2], *d_cdesc = d_desc + m;
+            uint8_t *d_st = (uint8_t *)ctx->d_scratch[8]; uint32_t *d_info = (uint32_t *)(d_st + ((m * sizeof(hgq::Enc2Stream) + 15) & ~(size_t)15));
+            bool ok = hg::stage_upload(ctx, sp.data(), sl.data(), so.data(), nullptr, m, ioff, (uint8_t *)ctx->d_scratch[0], s) == HG_OK;
+            ok = ok && hipMemcpyAsync(d_desc, desc.data(), m * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(d_cdesc, cdesc.data(), m * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(ctx->d_scratch[4], images.data(), images.size() * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(d_rlen, rlen.data(), recb, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(d_rflg, rflg.data(), recb, hipMemcpyHostToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(d_roff, roff.data(), recb, hipMemcpyHostToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(d_st, st.data(), m * sizeof(hgq::Enc2Stream), hipMemcpyHostToDevice, s) == hipSuccess;
+            rc = ok ? hg::launch_fqz_encode2(ctx, ctx->d_scratch[0], d_desc, d_cdesc, (const uint32_t *)ctx->d_scratch[4], d_rlen, d_rflg, d_roff, d_st, m, max_ecap, ctx->d_scratch[5], d_info,
+                                             ctx->d_scratch[1], (uint32_t *)ctx->d_scratch[3], s) : HG_ELAUNCH;
+            if (rc != HG_OK) return rc;
+            std::vector<uint32_t> ol(m);
+            ok = hipMemcpyAsync(ol.data(), ctx->d_scratch[3], m * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+            ok = ok && hg::stage_download(ctx, (const uint8_t *)ctx->d_scratch[1], oo.data(), ol.data(), dp.data(), m, s) == HG_OK;
+            if (!ok) return HG_ELAUNCH;
+            for (size_t k = 0; k < m; k++) {
+                const size_t i = live[ord[k]];
+                const std::vector<uint8_t> &h = hdrs[ord[k]];
+                memcpy(out[i], h.data(), h.size());
+                out_len[i] = (uint32_t)h.size() + ol[k];
+            }
+            return HG_OK;
+        }
+    }
     const size_t slot_words = (size_t)hgq::CTX_SIZE * (max_ns + 1u);
     size_t slots = 0;
-    int rc;
     if ((rc = hg::fqz_slots(ctx, m, slot_words, &slots))) return rc;
     const size_t recb = rlen.size() * 4;
     if ((rc = hg::ensure_scratch(ctx, 0, ioff + 64)) || (rc = hg::ensure_scratch(ctx, 1, ooff + 64)) ||
         (rc = hg::ensure_scratch(ctx, 2, m * sizeof(hg_stream_desc))) || (rc = hg::ensure_scratch(ctx, 3, m * 4 + 64)) ||
         (rc = hg::ensure_scratch(ctx, 4, images.size() * 4 + 64)) || (rc = hg::ensure_scratch(ctx, 5, 2 * recb + 64)) ||
         (rc = hg::ensure_scratch(ctx, 6, slots * slot_words * 4 + 64))) return rc;
-    hipStream_t s = ctx->stream;
     uint32_t *d_rlen = (uint32_t *)ctx->d_scratch[5], *d_rflg = d_rlen + rlen.size();
     bool ok = hg::stage_upload(ctx, sp.data(), sl.data(), so.data(), nullptr, m, ioff, (uint8_t *)ctx->d_scratch[0], s) == HG_OK;
     ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc.data(), m * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess &&

@@ -143,6 +143,7 @@ __host__ __device__ inline Arith2pLayout arith2p_layout(uint32_t n, bool rle) {
     L.end = o;
     return L;
 }
+int launch_range_code(const hg_stream_desc *d_desc, size_t n, const uint32_t *d_scratch, const void *d_work, void *d_out, uint32_t *d_out_len, hipStream_t s);
 inline uint32_t arith2p_max_tasks(uint32_t flags) { return (flags & 64u) ? 514u : (flags & 1u) ? 256u : 1u; }
 int launch_arith_encode2(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags, const uint32_t *d_sel2, size_t n2, void *d_tasks,
                          size_t task_cap, void *d_out, uint32_t *d_out_len, uint32_t *d_scratch, void *d_work, hipStream_t s);

@@ -123,9 +123,12 @@ def test_gpu_decoder_rejects_what_the_oracle_rejects(engine, qorc):
 
 
 @pytest.mark.gpu
-def test_gpu_encoder_matches_oracle_and_decodes(engine, qorc):
+@pytest.mark.parametrize("form", ["two-phase", "one-pass"])
+def test_gpu_encoder_matches_oracle_and_decodes(engine, qorc, monkeypatch, form):
     """The gfx950 encoder emits exactly the oracle's bytes for the parameter choice both make (selector for preset 1, reversal when
-    flags are given, duplicates when one record in ten repeats), and the gfx950 decoder takes them back."""
+    flags are given, duplicates when one record in ten repeats), and the gfx950 decoder takes them back -- in its default two-phase form (events sorted by
+    model, register models, scalar coder pass) and in the one-pass form (HG_FQZ_2P=0), which remains for blocks the work memory cannot take."""
+    if form == "one-pass": monkeypatch.setenv("HG_FQZ_2P", "0")
     rng = np.random.default_rng(10)
     datas, lens, flags, strats, want = [], [], [], [], []
     for strat in range(4):
@@ -137,7 +140,7 @@ def test_gpu_encoder_matches_oracle_and_decodes(engine, qorc):
                         datas.append(q); lens.append(ln); flags.append(fl if with_flags else None); strats.append(strat)
                         opts = F.DEDUP | (F.REV if with_flags else 0) | (F.SEL if with_flags and strat == 1 else 0)
                         want.append(qorc.encode(q, ln, fl if with_flags else None, strat, opts))
-    for n, ln_ in ((1, 1), (1, 64), (2, 65), (1, 3000), (700, 151)):
+    for n, ln_ in ((1, 1), (1, 64), (2, 65), (1, 3000), (700, 151), (5000, 150), (3, 70000)):
         q, ln, fl = reads(rng, n, ln_, False, 41, 0.2)
         datas.append(q); lens.append(ln); flags.append(fl); strats.append(n % 4)
         want.append(qorc.encode(q, ln, fl, n % 4, F.DEDUP | F.REV | (F.SEL if n % 4 == 1 else 0)))
