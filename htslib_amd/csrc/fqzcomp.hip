@@ -22,8 +22,12 @@
 // the first two wait in a global overflow image and replace the less recently used slot when a record selects them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <vector>
 #include "htsgpu.h"
 #include "hg_device.h"
@@ -696,12 +700,27 @@ int launch_fqz_encode2(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_de
     (void)ctx;
     if (!n) return HG_OK;
     const hgq::Enc2Stream *st = (const hgq::Enc2Stream *)d_streams;
+    static const bool times = getenv("HG_FQZ_TIMES") && atoi(getenv("HG_FQZ_TIMES")) > 0;   // the four kernels' durations on stderr (synchronises; measurement runs only)
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    auto mark = [&](int i) { if (times) { (void)hipEventCreate(&ev[i]); (void)hipEventRecord(ev[i], s); } };
+    mark(0);
     hipLaunchKernelGGL(hgq::fqz_events_kernel, dim3((unsigned)n), dim3(256), 0, s, (const uint8_t *)d_in, d_desc, d_images, d_rec_len, d_rec_flags, d_rec_off, st, (uint8_t *)d_work, d_info);
+    mark(1);
     hipLaunchKernelGGL(hgq::fqz_sort_kernel, dim3((unsigned)n), dim3(64), 0, s, st, (uint8_t *)d_work, (const uint32_t *)d_info);
+    mark(2);
     const unsigned stretches = (unsigned)((max_ecap + hgq::ENC2_CUT - 1) / hgq::ENC2_CUT);
     hipLaunchKernelGGL(hgq::fqz_models_kernel, dim3((stretches + 3) / 4, (unsigned)n), dim3(256), 0, s, d_desc, d_images, st, (uint8_t *)d_work, (const uint32_t *)d_info);
+    mark(3);
     if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
-    return launch_range_code(d_code_desc, n, d_info, d_work, d_out, d_out_len, s);
+    const int rc = launch_range_code(d_code_desc, n, d_info, d_work, d_out, d_out_len, s);
+    mark(4);
+    if (times && hipStreamSynchronize(s) == hipSuccess) {
+        float t[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&t[i], ev[i], ev[i + 1]);
+        fprintf(stderr, "[fqz 2p] %zu blocks: events %.2f ms, sort %.2f ms, models %.2f ms, coder %.2f ms\n", n, t[0], t[1], t[2], t[3]);
+        for (auto e : ev) if (e) (void)hipEventDestroy(e);
+    }
+    return rc;
 }
 // resident wavefronts: every one owns 65536 models in scratch, so the count is bounded by memory as well as by the chip
 static int fqz_slots(hg_ctx *ctx, size_t m, size_t slot_words, size_t *slots) {
@@ -794,23 +813,43 @@ extern "C" int hg_fqz_encode_host(hg_ctx *ctx, const uint8_t *const *in, const u
     if (!ctx || (n && (!in || !in_len || !slice || !strat || !out || !out_len))) return HG_EINVAL;
     if (n == 0) return HG_OK;
     hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
+    const bool stats = getenv("HTS_GPU_STATS") != nullptr;
+    const auto t_call = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     std::vector<uint32_t> images; images.reserve(n * hgq::IMG_WORDS);
     std::vector<std::vector<uint8_t>> hdrs;
     std::vector<size_t> live;
     uint32_t max_ns = 0;
-    for (size_t i = 0; i < n; i++) {
-        out_len[i] = 0;
-        if (in_len[i] == 0) continue;
-        uint32_t img[hgq::IMG_WORDS];
-        std::vector<uint8_t> hdr;
-        if (hgq::build_encode_image(in[i], in_len[i], slice[i], strat[i], img, hdr)) continue;
-        images.insert(images.end(), img, img + hgq::IMG_WORDS);
-        hdrs.push_back(std::move(hdr));
-        live.push_back(i);
-        max_ns = std::max(max_ns, img[3]);
+    {
+        // the parameter choice reads every quality once (census, duplicates): blocks are independent -> a few host threads
+        std::vector<std::vector<uint32_t>> img_of(n); std::vector<std::vector<uint8_t>> hdr_of(n); std::vector<char> good(n, 0);
+        auto work = [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) {
+                out_len[i] = 0;
+                if (in_len[i] == 0) continue;
+                img_of[i].resize(hgq::IMG_WORDS);
+                good[i] = hgq::build_encode_image(in[i], in_len[i], slice[i], strat[i], img_of[i].data(), hdr_of[i]) == 0;
+            }
+        };
+        uint64_t total = 0; for (size_t i = 0; i < n; i++) total += in_len[i];
+        const size_t nt = total < (8u << 20) || n < 2 ? 1 : std::min<size_t>({n, 16, std::max(1u, std::thread::hardware_concurrency())});
+        if (nt <= 1) work(0, n);
+        else {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+            for (auto &t : th) t.join();
+        }
+        for (size_t i = 0; i < n; i++) {
+            if (!good[i]) continue;
+            images.insert(images.end(), img_of[i].begin(), img_of[i].end());
+            hdrs.push_back(std::move(hdr_of[i]));
+            live.push_back(i);
+            max_ns = std::max(max_ns, img_of[i][3]);
+        }
     }
     const size_t m = live.size();
     if (!m) return HG_OK;
+    const double ms_images = ms_since(t_call);
     std::vector<size_t> ord(m);
     for (size_t k = 0; k < m; k++) ord[k] = k;
     std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return in_len[live[a]] > in_len[live[b]]; });
@@ -876,11 +915,15 @@ extern "C" int hg_fqz_encode_host(hg_ctx *ctx, const uint8_t *const *in, const u
                  hipMemcpyAsync(d_rlen, rlen.data(), recb, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(d_rflg, rflg.data(), recb, hipMemcpyHostToDevice, s) == hipSuccess &&
                  hipMemcpyAsync(d_roff, roff.data(), recb, hipMemcpyHostToDevice, s) == hipSuccess &&
                  hipMemcpyAsync(d_st, st.data(), m * sizeof(hgq::Enc2Stream), hipMemcpyHostToDevice, s) == hipSuccess;
+            const auto t_dev = std::chrono::steady_clock::now();
+            if (stats) (void)hipStreamSynchronize(s);
+            const double ms_up = ms_since(t_dev);
             rc = ok ? hg::launch_fqz_encode2(ctx, ctx->d_scratch[0], d_desc, d_cdesc, (const uint32_t *)ctx->d_scratch[4], d_rlen, d_rflg, d_roff, d_st, m, max_ecap, ctx->d_scratch[5], d_info,
                                              ctx->d_scratch[1], (uint32_t *)ctx->d_scratch[3], s) : HG_ELAUNCH;
             if (rc != HG_OK) return rc;
             std::vector<uint32_t> ol(m);
             ok = hipMemcpyAsync(ol.data(), ctx->d_scratch[3], m * 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+            const double ms_kern = ms_since(t_dev) - ms_up;
             ok = ok && hg::stage_download(ctx, (const uint8_t *)ctx->d_scratch[1], oo.data(), ol.data(), dp.data(), m, s) == HG_OK;
             if (!ok) return HG_ELAUNCH;
             for (size_t k = 0; k < m; k++) {
@@ -889,6 +932,8 @@ extern "C" int hg_fqz_encode_host(hg_ctx *ctx, const uint8_t *const *in, const u
                 memcpy(out[i], h.data(), h.size());
                 out_len[i] = (uint32_t)h.size() + ol[k];
             }
+            if (stats) fprintf(stderr, "[hts-gpu] fqz encode, two phases: %zu blocks, %.1f MB: parameter choice (host) %.1f ms, staging + upload %.1f ms, kernels %.1f ms, whole call %.1f ms\n", m,
+                               ioff / 1e6, ms_images, ms_up, ms_kern, ms_since(t_call));
             return HG_OK;
         }
     }
