@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include "hts_cram_gpu.h"
 #include "htsgpu.h"
 
 namespace hgfront { hg_ctx *shared_engine(); }

@@ -224,6 +224,30 @@ uint8_t *hts_rle_encode(uint8_t *data, uint64_t data_len, uint8_t *run, uint64_t
 uint8_t *hts_rle_decode(uint8_t *lit, uint64_t lit_len, uint8_t *run, uint64_t run_len, uint8_t *rle_syms, int rle_nsyms,
                         uint8_t *out, uint64_t *out_len);
 
+/* ---- htscodecs' codec entry points, under htscodecs' own names and signatures (htscodecs_front.cpp): what cram_io.c calls for methods 4-8
+ *      (cram/cram_io.c:1668 rans_uncompress, :1838 rans_compress, :1699 rans_uncompress_4x16, :1859 rans_compress_4x16, :1718 arith_uncompress_to,
+ *      :1879 arith_compress_to, :1737 tok3_decode_names, :1891 tok3_encode_names, :1686 fqz_decompress, :1821 fqz_compress; hts.c:149 htscodecs_version),
+ *      so that an htslib built --with-external-htscodecs can link libhts_bgzf.so in place of libhtscodecs.so.  Results are malloc'd, the caller frees them
+ *      (cram_io.c:1675 ...); NULL on failure or when no engine can be had.  `order` of the *_4x16 / arith functions = the RANS_ORDER_* flag byte of
+ *      cram/cram_external.c:616-637 (+ 0x8000 RANS_ORDER_SIMD_AUTO: the 32-way layout from 64 KiB); fqz_slice has htscodecs' layout
+ *      { int num_records; uint32_t *len; uint32_t *flags; } = hg_fqz_slice.  htscodecs is an un-vendored submodule: parity unpinned. ---- */
+const char *htscodecs_version(void);
+unsigned char *rans_compress(unsigned char *in, unsigned int in_size, unsigned int *out_size, int order);
+unsigned char *rans_uncompress(unsigned char *in, unsigned int in_size, unsigned int *out_size);
+unsigned int rans_compress_bound_4x16(unsigned int size, int order);
+unsigned char *rans_compress_to_4x16(unsigned char *in, unsigned int in_size, unsigned char *out, unsigned int *out_size, int order);
+unsigned char *rans_compress_4x16(unsigned char *in, unsigned int in_size, unsigned int *out_size, int order);
+unsigned char *rans_uncompress_4x16(unsigned char *in, unsigned int in_size, unsigned int *out_size);
+unsigned int arith_compress_bound(unsigned int size, int order);
+unsigned char *arith_compress_to(unsigned char *in, unsigned int in_size, unsigned char *out, unsigned int *out_size, int order);
+unsigned char *arith_compress(unsigned char *in, unsigned int in_size, unsigned int *out_size, int order);
+unsigned char *arith_uncompress_to(unsigned char *in, unsigned int in_size, unsigned char *out, unsigned int *out_size);
+unsigned char *arith_uncompress(unsigned char *in, unsigned int in_size, unsigned int *out_size);
+uint8_t *tok3_encode_names(char *blk, int len, int level, int use_arith, int *out_len, int *last_start_p);
+uint8_t *tok3_decode_names(uint8_t *in, uint32_t sz, uint32_t *out_len);
+char *fqz_compress(int vers, void *fqz_slice, char *in, size_t uncomp_size, size_t *comp_size, int strat, void *gparams);
+char *fqz_decompress(char *in, size_t comp_size, size_t *uncomp_size, int *lengths, int nlengths);
+
 /* htscodecs/varint.h (static inlines there too; cram_codecs.c:2103, 2276): big-endian 7 bits per byte, continuation in
  * bit 7.  endp may be NULL for put (no bound).  Return the number of bytes used, 0 when out of room / input. */
 #ifndef VARINT_H

@@ -135,3 +135,22 @@ def test_cram_block_accessors_of_the_front_library(built):
     core = L.cram_new_block(5, 0)
     assert L.cram_block_get_content_id(core) == -1
     L.cram_free_block(core)
+
+
+def test_front_library_exports_every_function_its_headers_declare(built):
+    """libhts_bgzf.so = the libhts-named boundary (bgzf_*, hts_crc32, cram_* block layer, the htscodecs names): every function prototype of
+    include/hts_bgzf_gpu.h and include/hts_cram_gpu.h must be an exported symbol (no compute call here: that needs the GPU)."""
+    import re
+    L = C.CDLL(os.path.join(ROOT, "htslib_amd", "libhts_bgzf.so"))
+    names = set()
+    for h in ("hts_bgzf_gpu.h", "hts_cram_gpu.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)                    # comments out
+        text = re.sub(r"static inline[^{;]*\{.*?\n\}", " ", text, flags=re.S)   # header inlines are not exports
+        for m in re.finditer(r"^[A-Za-z_][A-Za-z0-9_ \*]*?[ \*]([a-z][a-z0-9_]+)\s*\([^;{]*\)\s*;", text, flags=re.M):
+            names.add(m.group(1))
+    assert len(names) > 70, len(names)
+    for want in ("bgzf_read", "bgzf_idx_push", "cram_compress_block2", "rans_compress_4x16", "arith_uncompress_to", "tok3_encode_names", "fqz_decompress", "htscodecs_version", "hts_pack"):
+        assert want in names, want
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
