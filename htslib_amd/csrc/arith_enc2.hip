@@ -240,17 +240,62 @@ __device__ __forceinline__ void more_model(const uint2 *__restrict__ lst, uint32
     }
 }
 
-// ---- phase A: persistent wavefronts, tasks by ticket (big tasks first)
+// ---- phase B inside the persistent kernel: the coder of one stream FOLLOWS the models.  Records are zero until a model task writes them (total >= 1: the second
+//      word marks a record valid), so the coder takes a tile as soon as its 64 records are there and sleeps a few cycles otherwise: the passes overlap, a stream
+//      costs max(models, coder) instead of their sum.  Coder roles are tickets BEHIND the model tasks: when one is handed out every model task of the call has been
+//      taken by a resident wavefront, so whatever a coder waits for is being produced.  (A poll budget turns a logic error into a failed stream, not a hang.)
+__device__ __forceinline__ void coder_role(const hg_stream_desc &d, const Arith2pInfo *I, const uint8_t *work, uint8_t *out, uint32_t *out_len, uint32_t k, int lane) {
+    const uint32_t ne = I->nevents;
+    const unsigned long long *R = (const unsigned long long *)(work + (uint64_t)d.reserved * 16u);   // (records lie first in the stream's work area)
+    uint8_t *o = out + d.out_off;
+    o[0] = (uint8_t)I->m;                                                  // every lane, same byte (256 -> 0)
+    Coder E;
+    E.start(o + 1);
+    auto peek = [&](uint32_t s0) -> unsigned long long {                   // lane j: record s0 + j as it is now (beyond the end: a harmless valid one)
+        const uint32_t s = s0 + (uint32_t)lane;
+        return s < ne ? __hip_atomic_load(R + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1ull << 32;
+    };
+    bool failed = false;
+    auto settle = [&](uint32_t s0, unsigned long long v) -> unsigned long long {   // ... once all 64 are valid
+        uint32_t polls = 0;
+        while (__ballot((uint32_t)(v >> 32) == 0u)) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++polls > (1u << 21)) { failed = true; break; }        // ~1 s
+            v = peek(s0);
+        }
+        return v;
+    };
+    // three tiles in flight behind the one being coded: a device-scope load comes from memory, several microseconds away
+    unsigned long long cur = peek(0u), n1 = peek(64u), n2 = peek(128u);
+    cur = settle(0u, cur);
+    for (uint32_t s0 = 0; s0 < ne && !failed; s0 += 64) {
+        const unsigned long long n3 = peek(s0 + 192u);
+        code_tile(E, make_uint2((uint32_t)cur, (uint32_t)(cur >> 32)), ne - s0 >= 64u ? 64u : ne - s0, lane);
+        cur = settle(s0 + 64u, n1);
+        n1 = n2; n2 = n3;
+    }
+    const uint32_t total = 1u + E.finish(lane);
+    out_len[k] = failed ? 0u : total;                                      // every lane stores the same word (0: the host reports the stream as failed)
+}
+
+// ---- phase A (+ B): persistent wavefronts, tickets: the model tasks (big ones first), then one coder role per stream
 __global__ __launch_bounds__(256)
 void model_kernel(const hg_stream_desc *__restrict__ desc, const uint8_t *__restrict__ flags_in, const uint32_t *__restrict__ sel, const uint32_t *gscratch,
-                  uint8_t *work, uint32_t *ctr, const uint2 *__restrict__ tasks, uint32_t task_cap) {
+                  uint8_t *work, uint32_t *ctr, const uint2 *__restrict__ tasks, uint32_t task_cap, uint32_t ncoders, uint8_t *out, uint32_t *out_len) {
     const int lane = threadIdx.x & 63;
     const uint32_t nbig = ctr[0], nsmall = ctr[1];
     for (;;) {
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(&ctr[2], 1u);
         t = hg::uni(t);
-        if (t >= nbig + nsmall) break;
+        if (t >= nbig + nsmall) {
+            const uint32_t q = t - (nbig + nsmall);
+            if (q >= ncoders) break;
+            const uint32_t kc = sel[q];
+            const hg_stream_desc dc = desc[kc];
+            coder_role(dc, (const Arith2pInfo *)(gscratch + dc.scratch_off), work, out, out_len, kc, lane);
+            continue;
+        }
         const uint2 task = t < nbig ? tasks[t] : tasks[task_cap - 1u - (t - nbig)];
         const uint32_t k = sel[task.x], first = task.y & 1023u, last = (task.y >> 10) & 1023u, bundle = task.y >> 20;
         const hg_stream_desc d = desc[k];
@@ -326,18 +371,21 @@ int launch_arith_encode2(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_
     mark(0);
     hipLaunchKernelGGL(hga2::sort_kernel, dim3((unsigned)n2), dim3(64), 0, s, (const uint8_t *)d_in, d_desc, d_flags, d_sel2, d_scratch, (uint8_t *)d_work, ctr, tasks, (uint32_t)task_cap);
     mark(1);
-    // persistent grid: enough wavefronts to fill the chip, never more than there can be tasks
-    const size_t waves = task_cap < 256u * 32u ? task_cap : 256u * 32u;
+    // persistent grid: enough wavefronts to fill the chip, never more than there can be tasks + coder roles.  HG_ARITH_2P_OVERLAP=0: the coder as a kernel of
+    // its own behind the models (A/B runs)
+    static const bool overlap = !(getenv("HG_ARITH_2P_OVERLAP") && atoi(getenv("HG_ARITH_2P_OVERLAP")) == 0);
+    const size_t roles = task_cap + (overlap ? n2 : 0);
+    const size_t waves = roles < 256u * 32u ? roles : 256u * 32u;
     hipLaunchKernelGGL(hga2::model_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, d_desc, d_flags, d_sel2, (const uint32_t *)d_scratch, (uint8_t *)d_work, ctr,
-                       (const uint2 *)tasks, (uint32_t)task_cap);
+                       (const uint2 *)tasks, (uint32_t)task_cap, (uint32_t)(overlap ? n2 : 0), (uint8_t *)d_out, d_out_len);
     mark(2);
-    hipLaunchKernelGGL(hga2::code_kernel, dim3((unsigned)n2), dim3(64), 0, s, d_desc, d_sel2, (const uint32_t *)d_scratch, (const uint8_t *)d_work, (uint8_t *)d_out, d_out_len, 1u);
+    if (!overlap) hipLaunchKernelGGL(hga2::code_kernel, dim3((unsigned)n2), dim3(64), 0, s, d_desc, d_sel2, (const uint32_t *)d_scratch, (const uint8_t *)d_work, (uint8_t *)d_out, d_out_len, 1u);
     mark(3);
     if (times && hipStreamSynchronize(s) == hipSuccess) {
         float a = 0, b = 0, c = 0; uint32_t h[4] = {0, 0, 0, 0};
         (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]); (void)hipEventElapsedTime(&c, ev[2], ev[3]);
         (void)hipMemcpy(h, ctr, 16, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[arith 2p] %zu streams, %u + %u tasks: sort %.3f ms, models %.3f ms, coder %.3f ms\n", n2, h[0], h[1], a, b, c);
+        fprintf(stderr, "[arith 2p] %zu streams, %u + %u tasks: sort %.3f ms, models%s %.3f ms, coder %.3f ms\n", n2, h[0], h[1], a, overlap ? " + coder (overlapped)" : "", b, c);
         for (auto e : ev) if (e) (void)hipEventDestroy(e);
     }
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;

@@ -588,6 +588,9 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
                 const bool others = cnt[C_NX4] + cnt[C_NX32] + cnt[C_ARITH_SMALL] + cnt[C_ARITH_BIG] != 0;
                 hipStream_t s4 = others ? hg::fork_side4(ctx, s) : s;      // the one-pass kernels of this call run beside the two phases
                 forked4 = others;
+                // (the record areas start out zero: a record's second word, the model's total, doubles as its "written" mark for the coder that follows the models)
+                if (hipMemsetAsync(ctx->d_scratch[5], 0, woff, s4) != hipSuccess) rc = HG_ELAUNCH;
+                if (rc == HG_OK)
                 rc = hg::launch_arith_encode2(ctx, d_buf, (const hg_stream_desc *)ctx->d_scratch[2], d_fl, d_sel + first[C_ARITH_2P], cnt[C_ARITH_2P], ctx->d_scratch[13], task_cap,
                                               d_out, d_ol, (uint32_t *)ctx->d_scratch[6], ctx->d_scratch[5], s4);
             }
@@ -598,6 +601,8 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         if (forked4) hg::join_side4(ctx, s);                                // (on every path after the fork)
         if (rc) return rc;
         if (hipMemcpyAsync(ol.data(), d_ol, nc * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+        // a two-phase stream always has at least its alphabet byte: 0 = its coder gave up waiting for records (a logic error, reported loudly, never as bytes)
+        for (size_t k = 0; k < nc; k++) if (ccls[k] == C_ARITH_2P && ol[k] == 0) return HG_ELAUNCH;
     }
     // ---- stitch --------------------------------------------------------------------------------
     // Payload pieces live in two device buffers (0: d_buf -- raw RLE meta and CAT data, 1: d_out -- entropy-coder output).

@@ -58,7 +58,8 @@ struct RegModel {
             x = hit[k] ? (incl[k] - f) | f << 16 : x;
             any = any || hit[k];
         }
-        if (any) R[slot] = make_uint2(x, tot);
+        // (device-scope store: the coder that follows the models may run on another XCD, whose L2 does not see this one's dirty lines)
+        if (any) __hip_atomic_store((unsigned long long *)(R + slot), (unsigned long long)x | (unsigned long long)tot << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long hm = __ballot(any);
         uint32_t acc = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));   // 1 on the lanes after the hit
         uint32_t eb[EPL], ib[EPL];
