@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhtsgpu.so")
+LIB_PATH = os.environ.get("HTSGPU_LIB") or os.path.join(_HERE, "libhtsgpu.so")   # (HTSGPU_LIB: an instrumented build of the same library, for probes)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

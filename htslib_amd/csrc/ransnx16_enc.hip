@@ -21,6 +21,7 @@
 // The host sorts the streams of a launch by flags and length (lane groups of a wavefront run in lock step).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "htsgpu.h"
 #include "hg_device.h"
@@ -121,7 +122,11 @@ __device__ __forceinline__ void for_each_pair(const uint8_t *src, uint32_t n, in
     for (uint32_t i = i0 + (uint32_t)sub; i < n; i += N) fn((uint32_t)src[i], i ? (uint32_t)src[i - 1] : 0u);
 }
 
-template <int N>
+// TABLES_ONLY (4-way streams, round 5): the kernel stops after the frequency tables are built and serialised, and leaves what the coder needs in the stream's
+// scratch (the sizes of header and table, the flag byte as it goes out, the order-0 cumulative table; the order-1 tables are in scratch anyway):
+// rans4_scalar_encode_kernel below does the coding, one stream per wavefront on the scalar ALU.
+constexpr uint32_t O0_META = 0, O0_CUM = 16, O0_WORDS = 16 + 130 + 14;      // order-0 scratch: 3 meta words, 129 words of u16 pairs
+template <int N, bool TABLES_ONLY = false>
 __global__ __launch_bounds__(waves_of(N) * 64)
 void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc,
                             const uint8_t *__restrict__ flags_in, const uint32_t *__restrict__ sel, uint32_t nsel,
@@ -431,6 +436,19 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         HE_T(4);
+        if constexpr (TABLES_ONLY) {
+            if (have) {
+                // meta words: where the requested order put its scratch (order 1: the spare words behind the tables)
+                uint32_t *meta = sc + ((flags_in[sidx] & F_ORDER) ? O1_WORDS - 16u : O0_META);
+                if (core) {
+                    if (order == 0) for (uint32_t j = (uint32_t)sub; j < 129u; j += N) sc[O0_CUM + j] = (uint32_t)G.C[2u * j] | (uint32_t)G.C[2u * j + 1u] << 16;
+                    if (sub == 0) { meta[0] = hdr; meta[1] = tab; meta[2] = flags; }
+                } else if (sub == 0) meta[0] = 0xffffffffu;          // CAT / empty: the stream is complete already
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         // ---- encode backwards ------------------------------------------------------------------
         uint32_t R = RANS_L;
         uint32_t wpos = wcap;                                     // next free byte (from the end) in wb
@@ -590,10 +608,147 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
     }
 }
 
+
+// ================================================================================ the 4-way coder on the scalar ALU (round 5)
+// A 4-way stream is four interleaved rANS states: in the lane-group form above a step costs a ballot -> popcount -> LDS round trip for the word placement
+// (~1 us per step of four symbols), sixteen streams per wavefront in lock step.  Here ONE stream has the wavefront: the 64 lanes look up (start, freq,
+// reciprocal) for 64 symbols at a time, and the step itself -- renormalisation test, the 16-bit word, x = (x / f << 12) + x % f + start by multiply-high --
+// runs unrolled with constant lane numbers on the scalar ALU, the four states in four scalar registers (independent chains: their latencies overlap).
+// Words go out through one VGPR, 64 per store, towards lower addresses exactly as the lane-group form places them (highest state first within a step),
+// so the stream is byte-identical.  Tables, header and table bytes come from ransnx16_encode_kernel<4, true>.
+__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+struct ScalarOut {
+    uint16_t *w16; uint32_t wpos, cnt, buf;                              // wpos: byte position in the word buffer (words lie in [wpos, cap))
+    __device__ __forceinline__ void put(uint32_t w, int lane) {
+        buf = hg::writelane(w & 0xffffu, 63u - cnt, buf);
+        if (++cnt == 64u) { w16[(wpos >> 1) - 64u + (uint32_t)lane] = (uint16_t)buf; wpos -= 128u; cnt = 0; }
+    }
+    __device__ __forceinline__ void finish(int lane) {
+        if ((uint32_t)lane >= 64u - cnt) w16[(wpos >> 1) - 64u + (uint32_t)lane] = (uint16_t)buf;
+        wpos -= 2u * cnt; cnt = 0;
+    }
+};
+// one symbol into state x: A = start << 16 | freq, rc = reciprocal of freq (rcp_tab)
+__device__ __forceinline__ void scalar_step(uint32_t &x, uint32_t A, uint32_t rc, ScalarOut &O, int lane) {
+    const uint32_t f = A & 0xffffu, start = A >> 16;
+    if (x >= (f << 19)) { O.put(x, lane); x >>= 16; }                    // x_max = ((RANS_L >> 12) << 16) * f
+    const uint32_t q = f < 2u ? x : __umulhi(x, rc) >> (31u - (uint32_t)__builtin_clz(f - 1u));
+    x = (q << 12) + (x - q * f) + start;
+}
+
+__global__ __launch_bounds__(256)
+void rans4_scalar_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc, const uint8_t *__restrict__ flags_in, const uint32_t *__restrict__ sel,
+                                uint32_t nsel, uint8_t *out, uint32_t *out_len, uint8_t *wbuf, const uint32_t *__restrict__ scratch) {
+    __shared__ uint32_t rcp_tab[4097];
+    __shared__ uint16_t ctab[4][260];
+    for (uint32_t f = threadIdx.x; f <= 4096u; f += 256) {
+        uint32_t sh = 0;
+        while (f > (1u << sh)) sh++;
+        rcp_tab[f] = f < 2u ? 0u : (uint32_t)((((unsigned long long)1 << (sh + 31u)) + f - 1u) / f);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t k = blockIdx.x * 4u + (uint32_t)wv;
+    if (k >= nsel) return;
+    const uint32_t sidx = sel[k];
+    const hg_stream_desc d = desc[sidx];
+    const uint32_t *sc = scratch + d.scratch_off;
+    const uint32_t *meta = sc + ((flags_in[sidx] & F_ORDER) ? O1_WORDS - 16u : O0_META);
+    const uint32_t hdr = meta[0], tab = meta[1], flags = meta[2];
+    if (hdr == 0xffffffffu) return;
+    const uint8_t *src = in + d.in_off;
+    const uint32_t n = d.in_len, order = flags & F_ORDER, wcap = 2u * n + 256u;
+    uint8_t *o = out + d.out_off, *wb = wbuf + (uint64_t)d.reserved * 16ull;
+    ScalarOut O{(uint16_t *)wb, wcap, 0u, 0u};
+    uint32_t R0 = RANS_L, R1 = RANS_L, R2 = RANS_L, R3 = RANS_L;
+    auto var_step = [&](uint32_t s, uint32_t A, uint32_t rc) {           // a state chosen at run time (ragged ends only)
+        uint32_t x = s == 0u ? R0 : s == 1u ? R1 : s == 2u ? R2 : R3;
+        scalar_step(x, A, rc, O, lane);
+        R0 = s == 0u ? x : R0; R1 = s == 1u ? x : R1; R2 = s == 2u ? x : R2; R3 = s == 3u ? x : R3;
+    };
+    if (order == 0) {
+        uint16_t *C = ctab[wv];
+        for (uint32_t j = (uint32_t)lane; j < 129u; j += 64) { const uint32_t w = sc[O0_CUM + j]; C[2u * j] = (uint16_t)w; C[2u * j + 1u] = (uint16_t)(w >> 16); }
+        LDS_ORDER();
+        auto look = [&](uint32_t sym, bool valid, uint32_t &A, uint32_t &B) {
+            const uint32_t st = C[sym], f = (uint32_t)C[sym + 1u] - st;
+            A = valid ? st << 16 | f : 1u; B = rcp_tab[f & 0x1fffu];
+        };
+        // symbol i belongs to state i & 3; tiles of 64 positions from the top, the ragged top tile first
+        const uint32_t top = (n - 1u) & ~63u;
+        auto sym_at = [&](uint32_t b) { const uint32_t i = b + (uint32_t)lane; return i < n ? (uint32_t)src[i] : 0u; };
+        uint32_t sy = sym_at(top), sy_next = top ? sym_at(top - 64u) : 0u;
+        uint32_t A, B; look(sy, top + (uint32_t)lane < n, A, B);
+        for (uint32_t j = n - 1u - top + 1u; j-- > 0u;) var_step(j & 3u, rl(A, j), rl(B, j));
+        for (uint32_t b = top; b >= 64u;) {
+            b -= 64u;
+            look(sy_next, true, A, B);                                   // (this tile's table entries; the tile after it is already on its way)
+            sy_next = b ? sym_at(b - 64u) : 0u;
+#pragma unroll
+            for (int j = 63; j >= 0; j--) {
+                const uint32_t a = rl(A, (uint32_t)j), r = rl(B, (uint32_t)j);
+                if ((j & 3) == 0) scalar_step(R0, a, r, O, lane); else if ((j & 3) == 1) scalar_step(R1, a, r, O, lane);
+                else if ((j & 3) == 2) scalar_step(R2, a, r, O, lane); else scalar_step(R3, a, r, O, lane);
+            }
+        }
+    } else {
+        const uint16_t *C16 = (const uint16_t *)(sc + O1_C);
+        const uint32_t *F = sc + O1_F;
+        const uint32_t per = n / 4u;
+        auto look1 = [&](uint32_t sym, uint32_t ctx, bool valid, uint32_t &A, uint32_t &B) {
+            const uint32_t st = valid ? C16[ctx * 258u + sym] : 0u, f = valid ? F[ctx * 256u + sym] : 1u;
+            A = st << 16 | f; B = rcp_tab[f & 0x1fffu];
+        };
+        // the last state first eats the remainder [4 per, n): positions n - 1 ... 4 per, each in the context of the byte before it
+        for (uint32_t pos = n; pos-- > 4u * per;) {
+            uint32_t A, B; look1(src[pos], pos ? src[pos - 1u] : 0u, true, A, B);
+            var_step(3u, hg::uni(A), hg::uni(B));
+        }
+        // then step k = 0 .. per - 1: state s codes position (s + 1) per - 1 - k (context: the byte before; 0 for the first byte of its quarter), states 3, 2, 1, 0
+        auto gather = [&](uint32_t k0, uint32_t &sym, uint32_t &ctx, bool &valid) {
+            const uint32_t kk = k0 + ((uint32_t)lane >> 2), s = 3u - ((uint32_t)lane & 3u);
+            valid = kk < per;
+            const uint32_t pos = (s + 1u) * per - 1u - (valid ? kk : 0u);
+            sym = valid ? (uint32_t)src[pos] : 0u; ctx = valid && kk + 1u < per ? (uint32_t)src[pos - 1u] : 0u;
+        };
+        uint32_t sy, cx, sy_n = 0, cx_n = 0; bool va, va_n = false;
+        gather(0u, sy, cx, va);
+        for (uint32_t k0 = 0; k0 < per; k0 += 16u) {
+            uint32_t A, B; look1(sy, cx, va, A, B);
+            if (k0 + 16u < per) gather(k0 + 16u, sy_n, cx_n, va_n);
+            if (per - k0 >= 16u) {
+#pragma unroll
+                for (int j = 0; j < 64; j++) {
+                    const uint32_t a = rl(A, (uint32_t)j), r = rl(B, (uint32_t)j);
+                    if ((j & 3) == 0) scalar_step(R3, a, r, O, lane); else if ((j & 3) == 1) scalar_step(R2, a, r, O, lane);
+                    else if ((j & 3) == 2) scalar_step(R1, a, r, O, lane); else scalar_step(R0, a, r, O, lane);
+                }
+            } else {
+                const uint32_t nn = 4u * (per - k0);
+                for (uint32_t j = 0; j < nn; j++) var_step(3u - (j & 3u), rl(A, j), rl(B, j));
+            }
+            sy = sy_n; cx = cx_n; va = va_n;
+        }
+    }
+    O.finish(lane);
+    // the four states in front of the words (state z at + 4 z), then everything behind the tables
+    uint32_t wpos = O.wpos - 16u;
+    {
+        const uint32_t Rz = lane == 0 ? R0 : lane == 1 ? R1 : lane == 2 ? R2 : R3;
+        if (lane < 4) { uint8_t *w = wb + wpos + 4u * (uint32_t)lane; w[0] = (uint8_t)Rz; w[1] = (uint8_t)(Rz >> 8); w[2] = (uint8_t)(Rz >> 16); w[3] = (uint8_t)(Rz >> 24); }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    const uint32_t body = wcap - wpos;
+    uint8_t *dst = o + hdr + tab;
+    const uint8_t *from = wb + wpos;
+    for (uint32_t i = (uint32_t)lane; i < body; i += 64) dst[i] = from[i];
+    if (lane == 0) { o[0] = (uint8_t)flags; out_len[sidx] = hdr + tab + body; }
+}
+
 }  // namespace hge
 
 namespace hg {
-uint32_t ransnx16_enc_scratch_words(uint32_t flags) { return (flags & 1u) ? hge::O1_WORDS : 16u; }
+uint32_t ransnx16_enc_scratch_words(uint32_t flags) { return (flags & 1u) ? hge::O1_WORDS : hge::O0_WORDS; }
 
 int launch_ransnx16_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint8_t *d_flags,
                            const uint32_t *d_sel4, size_t n4, const uint32_t *d_sel32, size_t n32, void *d_out,
@@ -605,6 +760,15 @@ int launch_ransnx16_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *
         constexpr int W4 = hge::waves_of(4);
         size_t wgs = (n4 + W4 * 16 - 1) / (W4 * 16);
         if (wgs > maxw) wgs = maxw;
+        // tables by lane groups (sixteen streams per wavefront), then the coding on the scalar ALU, one stream per wavefront.  HG_NX4_SCALAR=0: the lane-group
+        // coder of rounds 1-4 (A/B runs)
+        static const bool scalar = !(getenv("HG_NX4_SCALAR") && atoi(getenv("HG_NX4_SCALAR")) == 0);
+        if (scalar) {
+            hipLaunchKernelGGL((hge::ransnx16_encode_kernel<4, true>), dim3((unsigned)wgs), dim3(W4 * 64), 0, s, (const uint8_t *)d_in, d_desc, d_flags, d_sel4, (uint32_t)n4,
+                               (uint8_t *)d_out, d_out_len, (uint8_t *)d_wbuf, d_scratch);
+            hipLaunchKernelGGL(hge::rans4_scalar_encode_kernel, dim3((unsigned)((n4 + 3) / 4)), dim3(256), 0, s, (const uint8_t *)d_in, d_desc, d_flags, d_sel4, (uint32_t)n4,
+                               (uint8_t *)d_out, d_out_len, (uint8_t *)d_wbuf, (const uint32_t *)d_scratch);
+        } else
         hipLaunchKernelGGL(hge::ransnx16_encode_kernel<4>, dim3((unsigned)wgs), dim3(W4 * 64), 0, s,
                            (const uint8_t *)d_in, d_desc, d_flags, d_sel4, (uint32_t)n4, (uint8_t *)d_out, d_out_len,
                            (uint8_t *)d_wbuf, d_scratch);
