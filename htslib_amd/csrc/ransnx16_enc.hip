@@ -126,7 +126,9 @@ __device__ __forceinline__ void for_each_pair(const uint8_t *src, uint32_t n, in
 // scratch (the sizes of header and table, the flag byte as it goes out, the order-0 cumulative table; the order-1 tables are in scratch anyway):
 // rans4_scalar_encode_kernel below does the coding, one stream per wavefront on the scalar ALU.
 constexpr uint32_t O0_META = 0, O0_CUM = 16, O0_WORDS = 16 + 130 + 14;      // order-0 scratch: 3 meta words, 129 words of u16 pairs
-template <int N, bool TABLES_ONLY = false>
+// NS: the number of rANS states when it differs from the width N of the lane group that builds the tables (4-way streams, tables only: one stream per wavefront,
+// 32 lanes on its histogram and rows instead of 4)
+template <int N, bool TABLES_ONLY = false, int NS = N>
 __global__ __launch_bounds__(waves_of(N) * 64)
 void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc,
                             const uint8_t *__restrict__ flags_in, const uint32_t *__restrict__ sel, uint32_t nsel,
@@ -179,7 +181,7 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
             sc = scratch + d.scratch_off;
             wcap = 2u * n + 256u;
             wb = wbuf + (uint64_t)d.reserved * 16ull;          // word buffer offset (16-byte units)
-            if ((flags & F_ORDER) && n < 2u * N) flags &= ~(uint32_t)F_ORDER;   // tiny inputs: order 0
+            if ((flags & F_ORDER) && n < 2u * NS) flags &= ~(uint32_t)F_ORDER;  // tiny inputs: order 0
         }
         const uint32_t order = flags & F_ORDER;
         // ---- header: flags, size ---------------------------------------------------------------
@@ -238,7 +240,7 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
             }
         } else if (core) {
             // ---- order 1.  Pass 0: which byte values occur (value 0 always: it is the start context) ---------------
-            const uint32_t per = n / N;
+            const uint32_t per = n / NS;
             for (int j = sub; j < 256; j += N) G.H[j] = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
             for_each_pair<N>(src, n, sub, [&](uint32_t c, uint32_t) { G.H[c] = 1; });
@@ -266,7 +268,7 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                 // histogram with LDS atomics on the nsym x nsym matrix, then written out in the 256 x 256 layout
                 uint32_t *Dc = D + ((uint32_t)sub & (copies - 1u)) * nsym * nsym;
                 for_each_pair<N>(src, n, sub, [&](uint32_t c, uint32_t l) { atomicAdd(&Dc[(uint32_t)G.C[l] * nsym + G.C[c]], 1u); });
-                if (sub >= 1) atomicAdd(&Dc[(uint32_t)G.C[0] * nsym + G.C[src[(uint32_t)sub * per]]], 1u);   // states start in ctx 0
+                if (sub >= 1 && sub < NS) atomicAdd(&Dc[(uint32_t)G.C[0] * nsym + G.C[src[(uint32_t)sub * per]]], 1u);   // states start in ctx 0
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
                 if (copies > 1u) {
                     for (uint32_t i = (uint32_t)sub; i < nsym * nsym; i += N) {
@@ -286,7 +288,7 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
                 for_each_pair<N>(src, n, sub, [&](uint32_t c, uint32_t l) {
                     atomicAdd(&sc[O1_F + l * 256u + c], 1u);
                 });
-                if (sub >= 1) atomicAdd(&sc[O1_F + src[(uint32_t)sub * per]], 1u);   // states start in ctx 0
+                if (sub >= 1 && sub < NS) atomicAdd(&sc[O1_F + src[(uint32_t)sub * per]], 1u);   // states start in ctx 0
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
             HE_T(1);
@@ -764,7 +766,10 @@ int launch_ransnx16_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *
         // coder of rounds 1-4 (A/B runs)
         static const bool scalar = !(getenv("HG_NX4_SCALAR") && atoi(getenv("HG_NX4_SCALAR")) == 0);
         if (scalar) {
-            hipLaunchKernelGGL((hge::ransnx16_encode_kernel<4, true>), dim3((unsigned)wgs), dim3(W4 * 64), 0, s, (const uint8_t *)d_in, d_desc, d_flags, d_sel4, (uint32_t)n4,
+            constexpr int WT = hge::waves_of(32);                              // tables: 32 lanes per stream, one stream per wavefront
+            size_t wgt = (n4 + WT - 1) / WT;
+            if (wgt > maxw * 4) wgt = maxw * 4;
+            hipLaunchKernelGGL((hge::ransnx16_encode_kernel<32, true, 4>), dim3((unsigned)wgt), dim3(WT * 64), 0, s, (const uint8_t *)d_in, d_desc, d_flags, d_sel4, (uint32_t)n4,
                                (uint8_t *)d_out, d_out_len, (uint8_t *)d_wbuf, d_scratch);
             hipLaunchKernelGGL(hge::rans4_scalar_encode_kernel, dim3((unsigned)((n4 + 3) / 4)), dim3(256), 0, s, (const uint8_t *)d_in, d_desc, d_flags, d_sel4, (uint32_t)n4,
                                (uint8_t *)d_out, d_out_len, (uint8_t *)d_wbuf, (const uint32_t *)d_scratch);

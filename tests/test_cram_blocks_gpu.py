@@ -62,9 +62,11 @@ def test_status_codes(engine):
     good = gzip.compress(d, 6)
     bad_crc = good[:-8] + bytes([good[-8] ^ 1]) + good[-7:]
     blocks = [(1, good, len(d)), (1, bad_crc, len(d)), (1, good, len(d) - 1), (1, good[:len(good) // 2], len(d)),
-              (7, b"\x00" * 20, 10), (2, b"BZh", 10), (0, d, len(d)), (0, d, len(d) + 1), (1, b"", 0)]
+              (7, b"\x00" * 20, 10), (2, b"BZh", 10), (0, d, len(d)), (0, d, len(d) + 1), (1, b"", 0), (9, b"x", 10)]
     outs, st = engine.cram_uncompress_blocks(blocks)
-    assert list(st) == [0, -2, -1, -1, -1, -3, 0, -1, 0]        # a malformed fqzcomp block is -1 (the codec is in the engine), bzip2 is not offered
+    # a malformed fqzcomp block is -1 (the codec is in the engine); bzip2 goes to the system's libbz2 like in the reference (round 5: -1 for a damaged stream, -3 only
+    # where the library is absent); a method id beyond the format's is -3
+    assert list(st[:5]) == [0, -2, -1, -1, -1] and st[5] in (-1, -3) and list(st[6:]) == [0, -1, 0, -3]
     assert outs[0] == d and outs[6] == d and outs[1] is None
 
 
