@@ -634,7 +634,8 @@ struct ScalarOut {
 __device__ __forceinline__ void scalar_step(uint32_t &x, uint32_t A, uint32_t rc, ScalarOut &O, int lane) {
     const uint32_t f = A & 0xffffu, start = A >> 16;
     if (x >= (f << 19)) { O.put(x, lane); x >>= 16; }                    // x_max = ((RANS_L >> 12) << 16) * f
-    const uint32_t q = f < 2u ? x : __umulhi(x, rc) >> (31u - (uint32_t)__builtin_clz(f - 1u));
+    const uint32_t qq = __umulhi(x, rc) >> (31u - (uint32_t)__builtin_clz((f - 1u) | 1u));   // (| 1: f = 1, 2 give the same shift; f = 1 takes x below)
+    const uint32_t q = f < 2u ? x : qq;
     x = (q << 12) + (x - q * f) + start;
 }
 
@@ -649,7 +650,9 @@ void rans4_scalar_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_
         rcp_tab[f] = f < 2u ? 0u : (uint32_t)((((unsigned long long)1 << (sh + 31u)) + f - 1u) / f);
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // (the wavefront's index is uniform, but only readfirstlane tells the compiler so: without it every value below -- the stream, its length, the four states --
+    // counts as divergent and the coding loop lands on the vector ALU behind exec-mask branches)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t k = blockIdx.x * 4u + (uint32_t)wv;
     if (k >= nsel) return;
     const uint32_t sidx = sel[k];
