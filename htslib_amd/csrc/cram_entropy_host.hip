@@ -485,7 +485,7 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         hg::nx16_xenc *d_j = (hg::nx16_xenc *)ctx->d_scratch[4];
         hg::nx16_xenc_res *d_r = (hg::nx16_xenc_res *)(d_j + xj.size());
         ok = hipMemcpyAsync(d_j, xj.data(), xj.size() * sizeof(hg::nx16_xenc), hipMemcpyHostToDevice, s) == hipSuccess;
-        if (ok && (rc = hg::launch_ransnx16_xenc(ctx, d_buf, d_j, xj.size(), d_r, s))) return rc;
+        if (ok && (rc = hg::launch_ransnx16_xenc(ctx, d_buf, d_j, xj.size(), d_r, s, xj.data()))) return rc;
         ok = ok && hipMemcpyAsync(xr.data(), d_r, xj.size() * sizeof(hg::nx16_xenc_res), hipMemcpyDeviceToHost, s) == hipSuccess &&
              hipStreamSynchronize(s) == hipSuccess;
     }

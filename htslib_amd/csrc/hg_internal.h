@@ -108,7 +108,7 @@ struct nx16_xenc_res {
     uint8_t map[16];
     uint64_t pad;
 };
-int launch_ransnx16_xenc(hg_ctx *ctx, void *d_buf, const nx16_xenc *d_jobs, size_t njobs, nx16_xenc_res *d_res, hipStream_t s);
+int launch_ransnx16_xenc(hg_ctx *ctx, void *d_buf, const nx16_xenc *d_jobs, size_t njobs, nx16_xenc_res *d_res, hipStream_t s, const nx16_xenc *h_jobs = nullptr);
 // arith.hip: model memory is an LDS pool per wavefront; streams are sorted into a small-pool launch (many
 // waves per CU) and a big-pool launch, larger models fall back to global scratch words.
 #define HG_ARITH_POOL_SMALL 3072     /* words: order-0 (+RLE), order-1 up to 54 symbols (41 with RLE) */
