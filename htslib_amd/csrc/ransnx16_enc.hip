@@ -147,13 +147,15 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
     __shared__ uint8_t ipool[N == 32 ? WAVES * GROUPS : 1][64];
     // x / f for the state update without an integer division (no such instruction: ~40 VALU ops on the loop-carried chain):
     // rcp[f] = ceil(2^(31 + ceil(log2 f)) / f), q = mulhi(x, rcp[f]) >> (ceil(log2 f) - 1), exact for x < 2^31, 2 <= f <= 4096
-    __shared__ uint32_t rcp_tab[4097];
-    for (uint32_t f = threadIdx.x; f <= 4096u; f += WAVES * 64) {
-        uint32_t sh = 0;
-        while (f > (1u << sh)) sh++;
-        rcp_tab[f] = f < 2u ? 0u : (uint32_t)((((unsigned long long)1 << (sh + 31u)) + f - 1u) / f);
+    __shared__ uint32_t rcp_tab[TABLES_ONLY ? 1 : 4097];
+    if constexpr (!TABLES_ONLY) {                                      // (the table-only launches never divide: 4 097 64-bit divisions per workgroup were most of their time
+        for (uint32_t f = threadIdx.x; f <= 4096u; f += WAVES * 64) {  //  on the thousands of tiny token streams of a name block)
+            uint32_t sh = 0;
+            while (f > (1u << sh)) sh++;
+            rcp_tab[f] = f < 2u ? 0u : (uint32_t)((((unsigned long long)1 << (sh + 31u)) + f - 1u) / f);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63, sub = lane & (N - 1);
     const bool idle = lane / N >= GROUPS;
     const int grp = idle ? 0 : lane / N;
@@ -619,6 +621,20 @@ void ransnx16_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc
 // Words go out through one VGPR, 64 per store, towards lower addresses exactly as the lane-group form places them (highest state first within a step),
 // so the stream is byte-identical.  Tables, header and table bytes come from ransnx16_encode_kernel<4, true>.
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+// rcp[f] = ceil(2^(31 + ceil(log2 f)) / f) for f = 0 .. 4096, built at compile time (the scalar coder copies it to LDS: a workgroup of four tiny streams used to spend
+// longer on 4 097 divisions than on its symbols)
+struct RcpTable { uint32_t v[4097]; };
+constexpr RcpTable make_rcp_table() {
+    RcpTable t{};
+    for (uint32_t f = 0; f <= 4096u; f++) {
+        uint32_t sh = 0;
+        while (f > (1u << sh)) sh++;
+        t.v[f] = f < 2u ? 0u : (uint32_t)((((unsigned long long)1 << (sh + 31u)) + f - 1u) / f);
+    }
+    return t;
+}
+__device__ const RcpTable g_rcp = make_rcp_table();
+
 struct ScalarOut {
     uint16_t *w16; uint32_t wpos, cnt, buf;                              // wpos: byte position in the word buffer (words lie in [wpos, cap))
     __device__ __forceinline__ void put(uint32_t w, int lane) {
@@ -644,11 +660,7 @@ void rans4_scalar_encode_kernel(const uint8_t *__restrict__ in, const hg_stream_
                                 uint32_t nsel, uint8_t *out, uint32_t *out_len, uint8_t *wbuf, const uint32_t *__restrict__ scratch) {
     __shared__ uint32_t rcp_tab[4097];
     __shared__ uint16_t ctab[4][260];
-    for (uint32_t f = threadIdx.x; f <= 4096u; f += 256) {
-        uint32_t sh = 0;
-        while (f > (1u << sh)) sh++;
-        rcp_tab[f] = f < 2u ? 0u : (uint32_t)((((unsigned long long)1 << (sh + 31u)) + f - 1u) / f);
-    }
+    for (uint32_t f = threadIdx.x; f <= 4096u; f += 256) rcp_tab[f] = g_rcp.v[f];
     __syncthreads();
     // (the wavefront's index is uniform, but only readfirstlane tells the compiler so: without it every value below -- the stream, its length, the four states --
     // counts as divergent and the coding loop lands on the vector ALU behind exec-mask branches)
