@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <thread>
 #include <vector>
 #include "htsgpu.h"
 #include "hg_internal.h"
@@ -726,15 +727,21 @@ extern "C" int hg_tok3_encode_host(hg_ctx *ctx, const uint8_t *const *in, const 
             if (hipMemcpyAsync(res.data(), d_res, nj * sizeof(hg::tok3_enc_res), hipMemcpyDeviceToHost, s) != hipSuccess ||
                 hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
             std::vector<std::vector<hg::tok3_enc_stream>> lists(nj);
-            for (size_t k = 0; k < nj; k++) {
-                if (res[k].total == 0xffffffffu || res[k].nstreams > HG_TOK3_MAX_STREAMS) return HG_ELAUNCH;   // cannot happen: 8 bytes/char is the worst case
-                lists[k].resize(res[k].nstreams);
-                if (res[k].nstreams && hipMemcpy(lists[k].data(), d_list + k * (size_t)HG_TOK3_MAX_STREAMS, res[k].nstreams * sizeof(hg::tok3_enc_stream),
-                                                 hipMemcpyDeviceToHost) != hipSuccess) return HG_ELAUNCH;
+            {
+                // the stream lists of all jobs in ONE transfer (a blocking copy per job was several ms per call of a slice batch)
+                std::vector<hg::tok3_enc_stream> all(nj * (size_t)HG_TOK3_MAX_STREAMS);
+                if (hipMemcpy(all.data(), d_list, all.size() * sizeof(hg::tok3_enc_stream), hipMemcpyDeviceToHost) != hipSuccess) return HG_ELAUNCH;
+                for (size_t k = 0; k < nj; k++) {
+                    if (res[k].total == 0xffffffffu || res[k].nstreams > HG_TOK3_MAX_STREAMS) return HG_ELAUNCH;   // cannot happen: 8 bytes/char is the worst case
+                    lists[k].assign(all.begin() + k * (size_t)HG_TOK3_MAX_STREAMS, all.begin() + k * (size_t)HG_TOK3_MAX_STREAMS + res[k].nstreams);
+                }
             }
             // ---- entropy trials: one item per (stream, setting) ----------------------------------------------
             static const uint8_t sets[8] = {0, 1, 64, 65, 128, 129, 8, 9};
-            for (int codec = 0; codec < 2; codec++) {
+            // The blocks of the rANS back-end (TOK3) and of the range coder's (TOKA) are independent: the second half runs on a thread and sibling context of
+            // its own (the token streams lie in this context's device buffer, which both read), so their kernels and their host planning overlap.
+            auto run_codec = [&](int codec, hg_ctx *cctx) -> int {
+                int rc;
                 std::vector<uint64_t> soff; std::vector<uint32_t> slen; std::vector<uint8_t> sfl;
                 std::vector<std::pair<uint32_t, uint32_t>> owner;          // (job, stream index)
                 for (size_t k = 0; k < nj; k++) {
@@ -747,14 +754,14 @@ extern "C" int hg_tok3_encode_host(hg_ctx *ctx, const uint8_t *const *in, const 
                     }
                 }
                 const size_t ni = soff.size();
-                if (!ni) continue;
+                if (!ni) return HG_OK;
                 std::vector<uint64_t> boff(ni + 1, 0);
                 for (size_t t = 0; t < ni; t++) boff[t + 1] = boff[t] + (codec ? hg_arith_compress_bound(slen[t]) : nx16_tight_bound(slen[t]));
                 uint8_t *arena = (uint8_t *)malloc(boff[ni] + 64);
                 if (!arena) return HG_ENOMEM;
                 std::vector<uint8_t *> optr(ni); std::vector<uint32_t> olen(ni, 0);
                 for (size_t t = 0; t < ni; t++) optr[t] = arena + boff[t];
-                rc = entropy_encode_host(codec ? ARITH : NX16, ctx, nullptr, slen.data(), sfl.data(), ni, optr.data(), olen.data(), d_sb, soff.data());
+                rc = entropy_encode_host(codec ? ARITH : NX16, cctx, nullptr, slen.data(), sfl.data(), ni, optr.data(), olen.data(), d_sb, soff.data());
                 if (rc) { free(arena); return rc; }
                 // keep the smallest setting of every stream (the first one on ties), in list order
                 size_t t = 0;
@@ -783,7 +790,18 @@ extern "C" int hg_tok3_encode_host(hg_ctx *ctx, const uint8_t *const *in, const 
                     out_len[i] = (uint32_t)(cp - out[i]);
                 }
                 free(arena);
-            }
+                return HG_OK;
+            };
+            bool have[2] = {false, false};
+            for (size_t k = 0; k < nj; k++) have[use_arith[job_blk[k]] ? 1 : 0] = true;
+            if (have[0] && have[1]) {
+                if (!ctx->sub[0] && hg_init(ctx->device, &ctx->sub[0]) != HG_OK) return HG_ENOMEM;
+                int rc1 = HG_OK;
+                std::thread side([&] { rc1 = hipSetDevice(ctx->device) == hipSuccess ? run_codec(1, ctx->sub[0]) : HG_ENODEV; });
+                const int rc0 = run_codec(0, ctx);
+                side.join();
+                if (rc0 || rc1) return rc0 ? rc0 : rc1;
+            } else if ((rc = run_codec(have[1] ? 1 : 0, ctx))) return rc;
         }
         i0 = i1;
     }
