@@ -17,6 +17,7 @@
 #include <string.h>
 #include <algorithm>
 #include <thread>
+#include <functional>
 #include <vector>
 #include "htsgpu.h"
 #include "hg_internal.h"
@@ -428,7 +429,11 @@ int put_u7(uint8_t *cp, uint32_t v) {
 // When d_src is given the inputs are device-resident (input i = d_src + d_src_off[i], copied device-to-device into
 // the encoder's own staging buffer) and `in` is not read.
 static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *in, const uint32_t *in_len, const uint8_t *flags, size_t n,
-                               uint8_t *const *out, uint32_t *out_len, const uint8_t *d_src = nullptr, const uint64_t *d_src_off = nullptr) {
+                               uint8_t *const *out, uint32_t *out_len, const uint8_t *d_src = nullptr, const uint64_t *d_src_off = nullptr,
+                               const std::function<void()> *place = nullptr) {
+    // `place`: every out_len[] is filled in FIRST (all lengths are known once the kernels are done), then (*place)() runs and may rewrite out[]
+    // (the caller owns that array); items whose out[i] is then null are not fetched at all.  A caller that keeps one of several trial encodings
+    // of a stream (tok3) pays the PCIe transfer, the host copies and the page faults of a bound-sized buffer only for the one it keeps.
     if (!ctx || (n && ((!in && !d_src) || !in_len || !flags || !out || !out_len))) return HG_EINVAL;
     if (n == 0) return HG_OK;
     hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
@@ -646,8 +651,23 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         }
         return pos;
     };
+    if (place) {
+        auto u7_len = [](uint32_t v) { size_t k = 1; while (v >>= 7) k++; return k; };
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t l0 = first_leaf[i], nl = first_leaf[i + 1] - l0;
+            size_t len = 0;
+            if (nl == 1) len = emit_leaf(nullptr, leaves[l0]);
+            else {
+                len = 2 + ((top_flags[i] & F_NOSZ) ? 0 : u7_len(in_len[i]));
+                for (uint32_t k = 0; k < nl; k++) { const size_t ll = emit_leaf(nullptr, leaves[l0 + k]); len += u7_len((uint32_t)ll) + ll; }
+            }
+            out_len[i] = (uint32_t)len;
+        }
+        (*place)();
+    }
     for (size_t i = 0; i < n; i++) {
         uint8_t *cp = out[i];
+        if (place && !cp) continue;
         const uint32_t l0 = first_leaf[i], nl = first_leaf[i + 1] - l0;
         if (nl == 1) cp += emit_leaf(cp, leaves[l0]);
         else {
@@ -755,24 +775,28 @@ extern "C" int hg_tok3_encode_host(hg_ctx *ctx, const uint8_t *const *in, const 
                 }
                 const size_t ni = soff.size();
                 if (!ni) return HG_OK;
-                std::vector<uint64_t> boff(ni + 1, 0);
-                for (size_t t = 0; t < ni; t++) boff[t + 1] = boff[t] + (codec ? hg_arith_compress_bound(slen[t]) : nx16_tight_bound(slen[t]));
-                uint8_t *arena = (uint8_t *)malloc(boff[ni] + 64);
-                if (!arena) return HG_ENOMEM;
-                std::vector<uint8_t *> optr(ni); std::vector<uint32_t> olen(ni, 0);
-                for (size_t t = 0; t < ni; t++) optr[t] = arena + boff[t];
-                rc = entropy_encode_host(codec ? ARITH : NX16, cctx, nullptr, slen.data(), sfl.data(), ni, optr.data(), olen.data(), d_sb, soff.data());
-                if (rc) { free(arena); return rc; }
-                // keep the smallest setting of every stream (the first one on ties), in list order
-                size_t t = 0;
+                // Only the smallest setting of every stream (the first one on ties) is fetched: the encoder reports all lengths, `keep` picks the winners and
+                // gives them room in one compact buffer (a bound-sized slot per trial was ~1 GiB of fresh pages per slice batch, touched once each).
+                uint8_t *arena = nullptr; bool nomem = false;
+                std::vector<uint8_t *> optr(ni, nullptr); std::vector<uint32_t> olen(ni, 0);
                 std::vector<std::vector<std::pair<const uint8_t *, uint32_t>>> best(nj);
                 for (size_t k = 0; k < nj; k++) best[k].assign(lists[k].size(), {nullptr, 0});
-                while (t < ni) {
-                    size_t e = t, b = t;
-                    while (e < ni && owner[e] == owner[t]) { if (olen[e] < olen[b]) b = e; e++; }
-                    best[owner[t].first][owner[t].second] = {optr[b], olen[b]};
-                    t = e;
-                }
+                const std::function<void()> keep = [&]() {
+                    std::vector<size_t> win;
+                    uint64_t tot = 0;
+                    for (size_t t = 0; t < ni;) {
+                        size_t e = t, b = t;
+                        while (e < ni && owner[e] == owner[t]) { if (olen[e] < olen[b]) b = e; e++; }
+                        win.push_back(b); tot += olen[b];
+                        t = e;
+                    }
+                    arena = (uint8_t *)malloc(tot + 64);
+                    if (!arena) { nomem = true; return; }
+                    uint64_t o = 0;
+                    for (size_t b : win) { optr[b] = arena + o; best[owner[b].first][owner[b].second] = {optr[b], olen[b]}; o += olen[b]; }
+                };
+                rc = entropy_encode_host(codec ? ARITH : NX16, cctx, nullptr, slen.data(), sfl.data(), ni, optr.data(), olen.data(), d_sb, soff.data(), &keep);
+                if (rc || nomem) { free(arena); return rc ? rc : HG_ENOMEM; }
                 for (size_t k = 0; k < nj; k++) {
                     if ((use_arith[job_blk[k]] ? 1 : 0) != codec) continue;
                     const size_t i = job_blk[k];
