@@ -52,3 +52,9 @@ tests/native/latprobe: tests/native/latprobe.cpp include/htsgpu.h
 	$(HIPCC) -O2 --offload-arch=$(ARCH) -Iinclude tests/native/latprobe.cpp -o $@ -ldl
 kbench: tests/native/kbench tests/native/latprobe
 .PHONY: kbench
+
+# the fqzcomp decoder with per-phase tick counters (HG_FQZ_PROFILE): HTSGPU_LIB=tests/native/libhtsgpu_fqzprof.so python bench.py --op fqz ...
+fqzprof: $(LIB)
+	$(HIPCC) $(HIPFLAGS) -DHG_FQZ_PROFILE -c $(CSRC)/fqzcomp.hip -o $(OBJDIR)/fqzcomp_prof.o
+	$(HIPCC) $(HIPFLAGS) -shared $(filter-out $(OBJDIR)/fqzcomp.o,$(HIPOBJ)) $(OBJDIR)/fqzcomp_prof.o -o tests/native/libhtsgpu_fqzprof.so
+.PHONY: fqzprof

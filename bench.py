@@ -1508,7 +1508,8 @@ def op_fqz(run: Run, steps: int, streams: int = 512, nrec: int = 2000):
         q = np.clip(38 + np.cumsum(rng.integers(-2, 3, nrec * rl)) % 12 - np.tile(np.arange(rl) // 12, nrec), 2, 41).astype(np.uint8)
         quals.append(q.tobytes()); lens.append(np.full(nrec, rl, np.uint32))
     datas = [quals[i % 4] for i in range(streams)]
-    args = (datas, [lens[i % 4] for i in range(streams)], [None] * streams, [i % 4 for i in range(streams)])
+    fixed = os.environ.get("HG_BENCH_FQZ_STRAT")                      # diagnosis: every block with one strategy (default: the four presets in turn)
+    args = (datas, [lens[i % 4] for i in range(streams)], [None] * streams, [int(fixed) if fixed else i % 4 for i in range(streams)])
     te, td, enc = [], [], None
     steps = max(3, steps)
     for _ in range(steps + 1):

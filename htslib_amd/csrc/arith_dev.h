@@ -53,7 +53,9 @@ __device__ __forceinline__ uint32_t udiv_small_divisor(uint32_t a, uint32_t b) {
 struct ByteWindow {
     const uint8_t *base; uint32_t len, pos0, idx, win; bool overrun;
     __device__ void init(const uint8_t *b, uint32_t n, int lane) { base = b; len = n; pos0 = 0; idx = 0; overrun = false; load(lane); }
-    __device__ void load(int lane) { const uint32_t p = pos0 + (uint32_t)lane; win = p < len ? base[p] : 0u; }
+    // (the wait belongs HERE, once per 64 bytes: left to the compiler, every later use of `win` inside the symbol loop gets a conservative s_waitcnt vmcnt(0)
+    //  -- "it may have been loaded on the way round" -- which also waits for the model stores of the symbol before: a store round trip per symbol)
+    __device__ void load(int lane) { const uint32_t p = pos0 + (uint32_t)lane; win = p < len ? base[p] : 0u; hg::wait_vm0(); }
     __device__ uint32_t next(int lane) {
         if (idx == 64) { pos0 += 64; idx = 0; load(lane); }
         if (pos0 + idx >= len) overrun = true;

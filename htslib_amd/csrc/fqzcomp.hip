@@ -38,6 +38,12 @@
 namespace hgq {
 using hg::wave_sync;
 using hga::rl;
+// -DHG_FQZ_PROFILE: where the decoder's time per quality goes (core-clock ticks per phase, printed by the wavefront of stream 0; `make fqzprof`)
+#ifdef HG_FQZ_PROFILE
+#define FQ_T(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); fq_acc[slot] += n_ - fq_last; fq_last = n_; } while (0)
+#else
+#define FQ_T(slot) do { } while (0)
+#endif
 
 enum { GF_MULTI = 1, GF_STAB = 2, GF_REV = 4, PF_DEDUP = 2, PF_LEN = 4, PF_SEL = 8, PF_QMAP = 16, PF_PTAB = 32, PF_DTAB = 64, PF_QTAB = 128 };
 constexpr uint32_t FQZ_VERS = 5, CTX_SIZE = 65536;
@@ -53,6 +59,7 @@ constexpr uint32_t IMG_WORDS = IMG_HEAD + IMG_STAB + HGQ_MAX_PARAM * IMG_PARAM; 
 // record-level models in LDS: [total, entries...] each
 constexpr uint32_t M_LEN = 0, M_REV = 4 * 257, M_DUP = M_REV + 3, M_SEL = M_DUP + 3, M_WORDS = M_SEL + 257;   // 1291 words
 constexpr uint32_t POOLW = ((M_WORDS + 3) & ~3u) + IMG_WORDS;
+constexpr int QPF = 4;                                           // decoder: models fetched ahead per quality (see fqz_decode_kernel)
 
 // ---- host: parameter block -> image ----------------------------------------------------------------------------------
 static int read_array_h(const uint8_t *in, size_t in_size, uint16_t *array, int size) {
@@ -249,7 +256,9 @@ static int build_encode_image(const uint8_t *in, uint32_t n, const hg_fqz_slice 
 struct ParamRegs { uint32_t context, pflags, qmask, qshift, qloc, sloc, ploc, dloc; const uint32_t *base; };
 __device__ __forceinline__ void load_param(ParamRegs &R, const uint32_t *img, uint32_t x) {
     const uint32_t *P = img + IMG_HEAD + IMG_STAB + x * IMG_PARAM;
-    R.context = P[0]; R.pflags = P[1]; R.qmask = P[2]; R.qshift = P[3]; R.qloc = P[4]; R.sloc = P[5]; R.ploc = P[6]; R.dloc = P[7];
+    // (wave-uniform by construction; saying so moves the flag tests and shifts they feed to the scalar unit)
+    R.context = hg::uni(P[0]); R.pflags = hg::uni(P[1]); R.qmask = hg::uni(P[2]); R.qshift = hg::uni(P[3]);
+    R.qloc = hg::uni(P[4]); R.sloc = hg::uni(P[5]); R.ploc = hg::uni(P[6]); R.dloc = hg::uni(P[7]);
     R.base = P;
 }
 // Parameter set x of the stream in one of the two LDS slots: c0 / c1 = the sets they hold, victim = the slot replaced next.  gimg = the stream's base
@@ -286,10 +295,193 @@ __device__ __forceinline__ void lds_model_init(uint32_t *m, uint32_t n, int lane
     for (uint32_t i = (uint32_t)lane; i <= n; i += 64) m[i] = i ? ((1u << 8) | (i - 1u)) : n;
 }
 
+// One stream, start to finish (the kernel has set up its image and models).  FAST: see fqz_decode_kernel -- a template parameter rather than a branch inside the
+// symbol loop: with both forms in one loop the compiler's wait insertion merges their pending loads (the general routine requests up to four 64-entry pieces
+// of a model and may leave some unread), and the fast form then carries an s_waitcnt vmcnt(0) per quality for registers it never loads.
+template <bool FAST>
+__device__ __forceinline__ int decode_stream(const uint8_t *__restrict__ in, const hg_stream_desc &d, uint32_t *img, uint32_t *mdl, uint32_t *gq, const uint32_t *gimg,
+                                             const uint32_t *over, uint8_t *o, uint32_t k, int lane) {
+    const uint32_t gflags = hg::uni(img[0]), max_sel = hg::uni(img[2]), ns = hg::uni(img[3]), data_off = hg::uni(img[4]), ulen = hg::uni(img[5]);
+    const uint8_t *stab = (const uint8_t *)(img + IMG_HEAD);
+    uint32_t pc0 = 0, pc1 = 1, pvictim = 0;
+    const uint32_t qw = ns + 1u;
+    uint32_t cur = 0;                                              // fast form: the model of context `last` (valid iff have_cur)
+    bool have_cur = false;
+    hga::Decoder D;
+    D.start(in + d.in_off + data_off, d.in_len - data_off, lane);
+    ParamRegs R; load_param(R, img, 0);
+    State st = {0, 0, 0, 0, 0};
+    uint32_t i = 0, last = 0, last_len = 0, keep = 0, prev_rev = 0;
+    bool first_len = true;
+    int err = 0;
+    auto lsym = [&](uint32_t base, uint32_t n) { return D.template symbol_lean<true>(mdl, mdl, base + 1u, n, base, lane); };
+    auto flush_tail = [&]() { if ((uint32_t)lane < (i & 63u)) o[(i & ~63u) + (uint32_t)lane] = (uint8_t)keep; wave_sync(); };
+    auto reload_tail = [&]() { wave_sync(); if ((uint32_t)lane < (i & 63u)) keep = o[(i & ~63u) + (uint32_t)lane]; hg::wait_vm0(); };
+    uint32_t rec_start = 0, rec_len = 0, rec_rev = 0;
+#ifdef HG_FQZ_PROFILE
+    unsigned long long fq_acc[6] = {0, 0, 0, 0, 0, 0}, fq_last = __builtin_amdgcn_s_memtime();
+#endif
+    while (i < ulen) {
+        FQ_T(4);
+        if (st.p == 0) {
+            uint32_t s = 0;
+            if (max_sel > 0) { s = lsym(M_SEL, max_sel + 1u); if (D.err) break; }
+            st.s = s;
+            select_param(R, img, gimg, over, stab[s], pc0, pc1, pvictim, lane);
+            uint32_t len;
+            if (!(R.pflags & PF_LEN) || first_len) {
+                len = lsym(M_LEN, 256);
+                len |= lsym(M_LEN + 257, 256) << 8;
+                len |= lsym(M_LEN + 2 * 257, 256) << 16;
+                len |= lsym(M_LEN + 3 * 257, 256) << 24;
+                if (D.err) break;
+                first_len = false; last_len = len;
+            } else len = last_len;
+            if (len == 0 || len > ulen - i) { err = 1; break; }
+            uint32_t rv = 0;
+            if (gflags & GF_REV) { rv = lsym(M_REV, 2); if (D.err) break; }
+            rec_start = i; rec_len = len; rec_rev = rv;
+            if (R.pflags & PF_DEDUP) {
+                const uint32_t dup = lsym(M_DUP, 2);
+                if (D.err) break;
+                if (dup) {
+                    if (i < len) { err = 1; break; }
+                    flush_tail();
+                    // the predecessor sits in o[i - len, i) in its FINAL orientation: mirrored iff the two reverse flags differ
+                    const bool mirror = rv != prev_rev;
+                    for (uint32_t b = (uint32_t)lane; b < len; b += 64) o[i + b] = mirror ? o[i - 1u - b] : o[i - len + b];
+                    i += len;
+                    prev_rev = rv;
+                    reload_tail();
+                    continue;
+                }
+            }
+            st.p = len; st.delta = 0; st.qctx = 0; st.prevq = 0;
+            last = R.context;
+            have_cur = false;
+        }
+        uint32_t Q;
+        FQ_T(0);
+        const size_t mb = (size_t)last * qw;
+        uint32_t q;
+        if (FAST) {
+            // (every read of a model is 64 lanes wide, whatever its length: the words past it -- the next model's -- are masked where it matters.  A
+            //  conditional read zeroes the other lanes first, and that write to a register with a fetch still outstanding costs a vmcnt(0) per quality)
+            if (!have_cur) { cur = gq[mb + (uint32_t)lane]; hg::wait_vm0(); }
+            FQ_T(1);
+            // the part of the next context that does not depend on this quality, then the whole of it per candidate (lane j: entry j is the one decoded)
+            const uint16_t *qtab = (const uint16_t *)(R.base + IMG_PSCAL + IMG_QMAP), *dtab = qtab + 256, *ptab = dtab + 256;
+            const uint32_t tp = hg::uni(ptab[st.p < 1023u ? st.p : 1023u]), td = hg::uni(dtab[st.delta < 255u ? st.delta : 255u]);
+            const uint32_t tqv = qtab[cur & 0xffu];
+            uint32_t cb = R.context;
+            if (R.pflags & PF_PTAB) cb += tp << R.ploc;
+            if (R.pflags & PF_DTAB) cb += td << R.dloc;
+            if (R.pflags & PF_SEL) cb += st.s << R.sloc;
+            const uint32_t qnv = (st.qctx << R.qshift) + tqv;
+            const uint32_t cv = (cb + ((qnv & R.qmask) << R.qloc)) & (CTX_SIZE - 1u);
+            uint32_t pf[QPF];
+#pragma unroll
+            for (int c = 0; c < QPF; c++) {
+                // (issued HERE, by hand: as plain loads the compiler sinks them towards their only use, after the coder step -- and it reuses the registers of
+                //  the three that are never read, which costs a wait each.  The one s_waitcnt that covers them is wait_vm0() below.)
+                const uint32_t *src = gq + (__umul24(rl(cv, (uint32_t)c), qw) + (uint32_t)lane);   // (a slot is 65 536 x <= 64 words: 32-bit index)
+                asm volatile("global_load_dword %0, %1, off" : "=v"(pf[c]) : "v"(src) : "memory");
+            }
+            // coder step on the register model
+            const uint32_t tot = rl(cur, ns);
+            const uint32_t e = (uint32_t)lane < ns ? cur : 0u;
+            const uint32_t r = hga::udiv_small_divisor(D.range, tot);
+            const uint32_t incl = hg::wave_incl_scan_dpp(e >> 8);       // lanes >= ns carry the total
+            const unsigned long long hit = __ballot(incl * r > D.code);   // incl > code / r  <=>  incl r > code;  incl r <= tot r <= range: no overflow
+            if (!hit) { D.err = 1; break; }                              // code / r >= tot: not a valid stream
+            const uint32_t l = (uint32_t)__builtin_ctzll(hit);
+            const uint32_t ex = rl(e, l), f = ex >> 8;
+            D.code -= (rl(incl, l) - f) * r; D.range = r * f;
+            while (D.range < hga::TOP) { D.code = (D.code << 8) | D.in.next(lane); D.range <<= 8; }
+            Q = ex & 0xffu;
+            bool changed = false;                                        // lanes whose word of the model is new
+            if (tot + hga::STEP > hga::MAX_FREQ) {                      // halve every frequency (rare): the general routine on the stored model
+                hga::model_update<false>(gq + mb, gq + mb, 0u, ns, ns, tot, l, ex, false, 0u, lane);
+                cur = gq[mb + (uint32_t)lane];
+                hg::wait_vm0();
+            } else {
+                const uint32_t nex = ex + (hga::STEP << 8), ep = l ? rl(e, l - 1u) : 0xffffffffu;
+                const bool swap = (nex >> 8) > (ep >> 8);                // sorted by frequency: at most one step towards the front
+                const bool w0 = (uint32_t)lane == l, w1 = swap && (uint32_t)lane + 1u == l, wt = (uint32_t)lane == ns;
+                if (w0) cur = swap ? ep : nex;
+                if (w1) cur = nex;
+                if (wt) cur = tot + hga::STEP;
+                changed = w0 || w1 || wt;
+            }
+            FQ_T(2);
+            q = ((const uint8_t *)(R.base + IMG_PSCAL))[Q];
+            st.qctx = (st.qctx << R.qshift) + rl(tqv, l);
+            if (R.pflags & PF_DTAB) { st.delta += st.prevq != Q; st.prevq = Q; }
+            st.p--;
+            const uint32_t next = rl(cv, l), upd = cur;
+            hg::wait_vm0();                                              // the one wait for memory of a quality: the models requested before the coder step
+            {                                                            // (same context again: `cur` is already its updated model)
+                const uint32_t p01 = (l & 1u) ? pf[1] : pf[0], p23 = (l & 1u) ? pf[3] : pf[2], psel = (l & 2u) ? p23 : p01;
+                const bool same = next == last;
+                cur = same ? cur : psel;
+                have_cur = same || l < (uint32_t)QPF;
+            }
+            // the store goes LAST: vmcnt counts loads and stores together, so any wait after a store waits for its round trip as well -- the next such wait
+            // is a whole coder step away
+            if (changed) gq[mb + (uint32_t)lane] = upd;
+            last = next;
+        } else {
+            FQ_T(1);
+            Q = D.template symbol_lean<false>(gq + mb, gq + mb, 0u, ns, ns, lane);
+            FQ_T(2);
+            if (D.err) break;
+            q = ((const uint8_t *)(R.base + IMG_PSCAL))[Q];
+            last = update_ctx(R, st, Q);
+        }
+#ifdef HG_FQZ_PROFILE
+        asm volatile("" :: "v"(last), "v"(q));                       // the phase ends when the next context is known
+#endif
+        FQ_T(3);
+        if ((uint32_t)lane == (i & 63u)) keep = q;
+        if ((i & 63u) == 63u) o[i - 63u + (uint32_t)lane] = (uint8_t)keep;       // 64 qualities per store
+        i++;
+        if (st.p == 0 && (gflags & GF_REV)) {                                // the record is complete
+            if (rec_rev) {
+                flush_tail();
+                for (uint32_t b = (uint32_t)lane; b < rec_len / 2u; b += 64) {
+                    const uint8_t x = o[rec_start + b], y = o[rec_start + rec_len - 1u - b];
+                    o[rec_start + b] = y; o[rec_start + rec_len - 1u - b] = x;
+                }
+                reload_tail();
+            }
+            prev_rev = rec_rev;
+        }
+    }
+    if (!err && !D.err && (ulen & 63u) && (uint32_t)lane < (ulen & 63u) && i == ulen) o[(ulen & ~63u) + (uint32_t)lane] = (uint8_t)keep;
+    if (D.err || D.in.overrun || st.p != 0 || i != ulen) err = 1;
+#ifdef HG_FQZ_PROFILE
+    FQ_T(4);
+    if (k < 4 && lane == 0)
+        printf("[fqz-profile] stream %u: %u qualities, ns %u, fast form %d; ticks per quality: record %.1f, model fetch %.1f, coder step %.1f, next context %.1f, rest %.1f\n", k, ulen,
+               ns, (int)FAST, (double)fq_acc[0] / ulen, (double)fq_acc[1] / ulen, (double)fq_acc[2] / ulen, (double)fq_acc[3] / ulen, (double)fq_acc[4] / ulen);
+#endif
+    return err;
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64)
 void fqz_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__restrict__ desc, const uint32_t *__restrict__ images,
-                       const uint32_t *__restrict__ overflow, uint32_t nstreams, uint8_t *out, int32_t *status, uint32_t *gscratch, unsigned long long slot_words) {
+                       const uint32_t *__restrict__ overflow, uint32_t nstreams, uint8_t *out, int32_t *status, uint32_t *gscratch, unsigned long long slot_words,
+                       int qc_on) {
+    // The quality models of a stream (65 536 contexts x (ns + 1) words, ~11 MB; entries first, the total LAST) live in global memory.  Per quality the chain was
+    // context -> model fetch (an L2 / MALL round trip, ~650 clocks) -> coder step (~950) -> next context (~90): r05_fqz_decode_phases.txt.  The fast form
+    // (alphabets up to 63 symbols, i.e. every real quality block) keeps the model of the current context in one VGPR (lane j = entry j, lane n = total), and:
+    //   * BEFORE the coder step it computes the next context for every symbol of the model at once (lane j: "if entry j is decoded") and requests the models of
+    //     the first QPF candidates -- the list is sorted by frequency, so these are the likely ones; the fetch then overlaps the coder step;
+    //   * the symbol search multiplies the cumulative frequencies by r and compares with the code (one multiply per lane) instead of dividing the code by r;
+    //   * the update happens in the register, and only the two or three words that changed are stored.
+    // An LDS cache of recently used models (tags + write-back) was tried first and dropped: hits were 14 .. 80 % depending on the parameter set, and the
+    // stream with the fewest hits -- which sets the time of a batch -- got slower (same profile file).
     __shared__ uint32_t pool[WAVES][POOLW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t slot = blockIdx.x * WAVES + wv;
@@ -299,10 +491,8 @@ void fqz_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__r
         const hg_stream_desc d = desc[k];
         for (uint32_t i = (uint32_t)lane; i < IMG_WORDS; i += 64) img[i] = images[(size_t)d.scratch_off * IMG_WORDS + i];
         wave_sync();
-        const uint32_t gflags = img[0], max_sel = img[2], ns = img[3], data_off = img[4], ulen = img[5];
-        const uint8_t *stab = (const uint8_t *)(img + IMG_HEAD);
+        const uint32_t max_sel = img[2], ns = img[3];
         const uint32_t *gimg = images + (size_t)d.scratch_off * IMG_WORDS, *over = overflow + img[6];
-        uint32_t pc0 = 0, pc1 = 1, pvictim = 0;
         uint8_t *o = out + d.out_off;
         // models
         {
@@ -310,7 +500,7 @@ void fqz_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__r
             uint32_t r = (uint32_t)lane % w;                           // word i of the slot is word (i mod w) of its model
             const uint32_t step = 64u % w;
             for (size_t i = (size_t)lane; i < (size_t)CTX_SIZE * w; i += 64) {
-                gq[i] = r ? ((1u << 8) | (r - 1u)) : ns;
+                gq[i] = r < ns ? ((1u << 8) | r) : ns;                  // (decoder layout: the total is the model's last word)
                 r += step; if (r >= w) r -= w;
             }
             for (int j = 0; j < 4; j++) lds_model_init(mdl + M_LEN + j * 257, 256, lane);
@@ -318,76 +508,8 @@ void fqz_decode_kernel(const uint8_t *__restrict__ in, const hg_stream_desc *__r
             lds_model_init(mdl + M_SEL, max_sel + 1u, lane);
             wave_sync();
         }
-        hga::Decoder D;
-        D.start(in + d.in_off + data_off, d.in_len - data_off, lane);
-        ParamRegs R; load_param(R, img, 0);
-        State st = {0, 0, 0, 0, 0};
-        uint32_t i = 0, last = 0, last_len = 0, keep = 0, prev_rev = 0;
-        bool first_len = true;
-        int err = 0;
-        auto lsym = [&](uint32_t base, uint32_t n) { return D.template symbol_lean<true>(mdl, mdl, base + 1u, n, base, lane); };
-        auto flush_tail = [&]() { if ((uint32_t)lane < (i & 63u)) o[(i & ~63u) + (uint32_t)lane] = (uint8_t)keep; wave_sync(); };
-        auto reload_tail = [&]() { wave_sync(); if ((uint32_t)lane < (i & 63u)) keep = o[(i & ~63u) + (uint32_t)lane]; };
-        uint32_t rec_start = 0, rec_len = 0, rec_rev = 0;
-        while (i < ulen) {
-            if (st.p == 0) {
-                uint32_t s = 0;
-                if (max_sel > 0) { s = lsym(M_SEL, max_sel + 1u); if (D.err) break; }
-                st.s = s;
-                select_param(R, img, gimg, over, stab[s], pc0, pc1, pvictim, lane);
-                uint32_t len;
-                if (!(R.pflags & PF_LEN) || first_len) {
-                    len = lsym(M_LEN, 256);
-                    len |= lsym(M_LEN + 257, 256) << 8;
-                    len |= lsym(M_LEN + 2 * 257, 256) << 16;
-                    len |= lsym(M_LEN + 3 * 257, 256) << 24;
-                    if (D.err) break;
-                    first_len = false; last_len = len;
-                } else len = last_len;
-                if (len == 0 || len > ulen - i) { err = 1; break; }
-                uint32_t rv = 0;
-                if (gflags & GF_REV) { rv = lsym(M_REV, 2); if (D.err) break; }
-                rec_start = i; rec_len = len; rec_rev = rv;
-                if (R.pflags & PF_DEDUP) {
-                    const uint32_t dup = lsym(M_DUP, 2);
-                    if (D.err) break;
-                    if (dup) {
-                        if (i < len) { err = 1; break; }
-                        flush_tail();
-                        // the predecessor sits in o[i - len, i) in its FINAL orientation: mirrored iff the two reverse flags differ
-                        const bool mirror = rv != prev_rev;
-                        for (uint32_t b = (uint32_t)lane; b < len; b += 64) o[i + b] = mirror ? o[i - 1u - b] : o[i - len + b];
-                        i += len;
-                        prev_rev = rv;
-                        reload_tail();
-                        continue;
-                    }
-                }
-                st.p = len; st.delta = 0; st.qctx = 0; st.prevq = 0;
-                last = R.context;
-            }
-            const size_t mb = (size_t)last * (ns + 1u);
-            const uint32_t Q = D.template symbol_lean<false>(gq + mb, gq + mb, 1u, ns, 0u, lane);
-            if (D.err) break;
-            const uint32_t q = ((const uint8_t *)(R.base + IMG_PSCAL))[Q];
-            last = update_ctx(R, st, Q);
-            if ((uint32_t)lane == (i & 63u)) keep = q;
-            if ((i & 63u) == 63u) o[i - 63u + (uint32_t)lane] = (uint8_t)keep;       // 64 qualities per store
-            i++;
-            if (st.p == 0 && (gflags & GF_REV)) {                                // the record is complete
-                if (rec_rev) {
-                    flush_tail();
-                    for (uint32_t b = (uint32_t)lane; b < rec_len / 2u; b += 64) {
-                        const uint8_t x = o[rec_start + b], y = o[rec_start + rec_len - 1u - b];
-                        o[rec_start + b] = y; o[rec_start + rec_len - 1u - b] = x;
-                    }
-                    reload_tail();
-                }
-                prev_rev = rec_rev;
-            }
-        }
-        if (!err && !D.err && (ulen & 63u) && (uint32_t)lane < (ulen & 63u) && i == ulen) o[(ulen & ~63u) + (uint32_t)lane] = (uint8_t)keep;
-        if (D.err || D.in.overrun || st.p != 0 || i != ulen) err = 1;
+        const bool fast = qc_on && ns + 1u <= 64u;
+        const int err = fast ? decode_stream<true>(in, d, img, mdl, gq, gimg, over, o, k, lane) : decode_stream<false>(in, d, img, mdl, gq, gimg, over, o, k, lane);
         status[k] = err ? -1 : 0;                                     // every lane stores the same word
         wave_sync();
     }
@@ -676,10 +798,11 @@ int launch_fqz_decode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_des
                       int32_t *d_status, uint32_t *d_scratch, size_t slots, size_t slot_words, hipStream_t s) {
     (void)ctx;
     if (!n) return HG_OK;
-    constexpr int WAVES = 2;
+    constexpr int WAVES = 1;
     const size_t wgs = (slots + WAVES - 1) / WAVES;
+    static const int qc_on = [] { const char *e = getenv("HG_FQZ_FAST"); return (e && *e == '0') ? 0 : 1; }();   // 0: the general step for every stream (A/B)
     hipLaunchKernelGGL((hgq::fqz_decode_kernel<WAVES>), dim3((unsigned)wgs), dim3(WAVES * 64), 0, s, (const uint8_t *)d_in, d_desc, d_images, d_overflow,
-                       (uint32_t)n, (uint8_t *)d_out, d_status, d_scratch, (unsigned long long)slot_words);
+                       (uint32_t)n, (uint8_t *)d_out, d_status, d_scratch, (unsigned long long)slot_words, qc_on);
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
 int launch_fqz_encode(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_desc, const uint32_t *d_images, const uint32_t *d_rec_len,
@@ -723,8 +846,8 @@ int launch_fqz_encode2(hg_ctx *ctx, const void *d_in, const hg_stream_desc *d_de
     return rc;
 }
 // resident wavefronts: every one owns 65536 models in scratch, so the count is bounded by memory as well as by the chip
-static int fqz_slots(hg_ctx *ctx, size_t m, size_t slot_words, size_t *slots) {
-    size_t n = std::min<size_t>(m, (size_t)ctx->cus * 8);
+static int fqz_slots(hg_ctx *ctx, size_t m, size_t slot_words, size_t *slots, int per_cu = 8) {
+    size_t n = std::min<size_t>(m, (size_t)ctx->cus * per_cu);
     size_t freeb = 0, totalb = 0;
     if (hipMemGetInfo(&freeb, &totalb) == hipSuccess) {
         const size_t fit = ((freeb + ctx->d_scratch_cap[6]) / 2) / (slot_words * 4);
@@ -780,7 +903,7 @@ extern "C" int hg_fqz_decode_host(hg_ctx *ctx, const uint8_t *const *in, const u
         if ((rc = hg::ensure_scratch(ctx, 0, ioff + 64)) || (rc = hg::ensure_scratch(ctx, 1, ooff + 64)) ||
             (rc = hg::ensure_scratch(ctx, 2, m * sizeof(hg_stream_desc))) || (rc = hg::ensure_scratch(ctx, 3, m * 4 + 64)) ||
             (rc = hg::ensure_scratch(ctx, 4, images.size() * 4 + 64)) || (rc = hg::ensure_scratch(ctx, 5, overflow.size() * 4 + 64)) ||
-            (rc = hg::ensure_scratch(ctx, 6, slots * slot_words * 4 + 64))) return rc;
+            (rc = hg::ensure_scratch(ctx, 6, slots * slot_words * 4 + 512))) return rc;   // (+: the kernel reads a model with all 64 lanes, whatever its length)
         hipStream_t s = ctx->stream;
         bool ok = hg::stage_upload(ctx, sp.data(), sl.data(), so.data(), nullptr, m, ioff, (uint8_t *)ctx->d_scratch[0], s) == HG_OK;
         ok = ok && hipMemcpyAsync(ctx->d_scratch[2], desc.data(), m * sizeof(hg_stream_desc), hipMemcpyHostToDevice, s) == hipSuccess &&

@@ -43,6 +43,10 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15), as an instruction the compiler's own wait insertion sees: placed right after a RARE load
+// whose register is read in a hot loop, it keeps the per-iteration uses free of conservative waits.
+__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // Inclusive prefix sum over the 64 lanes on the DPP data path (no LDS round trips): shifts by
 // 1/2/4/8 inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals.
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x) {
