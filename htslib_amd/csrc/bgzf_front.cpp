@@ -35,6 +35,7 @@
 #include <unistd.h>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -43,6 +44,10 @@
 #include "hts_hfile_abi.h"
 #include "htsgpu.h"
 #include "bgzf_host_codec.h"
+// The host codec's state is ~450 KiB (Deflater) / ~32 KiB (Inflater): as plain `thread_local` objects that much static TLS would be reserved in EVERY thread
+// of the host process, whether it ever touches a BGZF handle or not.  One heap object per thread that actually uses the codec instead.
+static hgh::Deflater &tls_deflater() { static thread_local std::unique_ptr<hgh::Deflater> p; if (!p) p.reset(new hgh::Deflater); return *p; }
+static hgh::Inflater &tls_inflater() { static thread_local std::unique_ptr<hgh::Inflater> p; if (!p) p.reset(new hgh::Inflater); return *p; }
 
 // libhts symbols used when present (inside a libhts build they always are)
 extern "C" {
@@ -564,7 +569,7 @@ int engine_read_block(BGZF *fp) {
         const hg_bgzf_desc &d = b.desc[e->blk];
         const int64_t addr = b.file_off + (int64_t)d.coff;
         if (b.host && b.hstatus[e->blk] == HOST_PENDING) {                  // bgzf_read_block's single-threaded branch: inflate_block on this thread (bgzf.c:1198-1205)
-            static thread_local hgh::Inflater I;
+            hgh::Inflater &I = tls_inflater();
             b.hstatus[e->blk] = hgh::bgzf_block_inflate(I, b.hcomp + d.coff, d.clen, b.hplain.data() + d.uoff, d.ulen);
             while (b.good < b.desc.size() && b.hstatus[b.good] == 0) b.good++;
         }
@@ -935,7 +940,7 @@ int host_cut_block(BGZF *fp) {
     Engine *e = E(fp);
     if (fp->block_offset == 0) return 0;
     if (e->started && drain_writer(fp) != 0) return -1;                  // (device jobs of an earlier bgzf_mt phase first: order on disk)
-    static thread_local hgh::Deflater D;
+    hgh::Deflater &D = tls_deflater();
     uint8_t *dst = (uint8_t *)fp->compressed_block;
     size_t dlen = BGZF_MAX_BLOCK_SIZE;
     const size_t ulen = (size_t)fp->block_offset;
@@ -1455,7 +1460,7 @@ int bgzf_compress(void *dst, size_t *dlen, const void *src, size_t slen, int lev
     // One block, synchronously: the host codec (SURVEY 8b keeps bgzf_compress() on the scalar path; a device job for one block is a 4 ms round trip).
     // The engine must exist all the same -- this library has no life without a device.
     if (!shared_ctx() || slen > BGZF_BLOCK_SIZE) return -1;
-    static thread_local hgh::Deflater D;
+    hgh::Deflater &D = tls_deflater();
     return hgh::bgzf_block_deflate(D, (uint8_t *)dst, dlen, (const uint8_t *)src, slen, level < 0 || level > 9 ? 6 : level);
 }
 

@@ -120,6 +120,19 @@ struct Inflater {
         return true;
     }
 
+    // the two tables of a fixed-Huffman block (RFC 1951 3.2.6)
+    struct Fixed { uint32_t lit[LTAB], dist[DTAB]; bool ok; };
+    static const Fixed &fixed() {
+        static const Fixed F = [] {
+            Fixed f; uint8_t lens[288], dl[32];
+            for (int i = 0; i < 288; i++) lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+            memset(dl, 5, 32);
+            f.ok = build(1, dl, 32, DROOT, f.dist, DTAB) && build(0, lens, 288, LROOT, f.lit, LTAB);
+            return f;
+        }();
+        return F;
+    }
+
     // Raw deflate stream in[0..n) -> out[0..cap).  0 = a complete stream decoded (*produced bytes), -1 = invalid / needs more input or room.
     int run(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *produced) {
         constexpr size_t PAD = 64;
@@ -149,9 +162,9 @@ struct Inflater {
             else {
                 uint8_t lens[320];
                 if (btype == 1) {
-                    for (int i = 0; i < 288; i++) lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
-                    uint8_t dl[32]; memset(dl, 5, 32);
-                    if (!build(1, dl, 32, DROOT, dist, DTAB) || !build(0, lens, 288, LROOT, lit, LTAB)) return -1;
+                    const Fixed &F = fixed();                                            // built once per process, copied per block (was: rebuilt per block)
+                    if (!F.ok) return -1;
+                    memcpy(lit, F.lit, sizeof lit); memcpy(dist, F.dist, sizeof dist);
                 } else {
                     const uint32_t nlen = take(5) + 257, ndist = take(5) + 1, ncode = take(4) + 4;
                     if (nlen > 286 || ndist > 30) return -1;
