@@ -209,10 +209,12 @@ int launch_tok3_names(hg_ctx *ctx, const void *d_tb, const tok3_job *d_jobs, siz
 // ================================================================================================
 namespace hgt {
 
+constexpr uint32_t NAME_LDS = 256;                                  // a name up to this long is tokenised out of LDS (longer ones out of global memory)
 struct EncLds {
     uint32_t base[NTYPES][MAX_TOK], cur[NTYPES][MAX_TOK];
-    uint32_t toff[2][MAX_TOK], tlen[2][MAX_TOK], tval[2][MAX_TOK];
+    uint32_t toff[2][MAX_TOK], tlen[2][MAX_TOK], tval[2][MAX_TOK];   // toff: offset of the token INSIDE its name
     uint8_t tcls[2][MAX_TOK];
+    uint8_t nm[2][NAME_LDS];                                          // the characters of the current and of the previous tokenised name
 };
 
 __device__ __forceinline__ int char_class(uint32_t c) {          // 0 digit, 1 letter, 2 anything else
@@ -228,6 +230,19 @@ __device__ uint32_t tok_sweep(const uint8_t *__restrict__ src, uint32_t n, uint3
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t pos = begin, ppos = 0, plen = 0, pn = 0, rb = 0, nn = 0, maxpos = 0;
     bool have_prev = false;
+    // The tokeniser reads a name many times, a byte per lane and step (digit runs, letter runs, the comparison with the previous name's token): out of global
+    // memory every such read is a round trip on some lane's chain, and in the WRITE sweep each of them also waits for the byte stores issued before it (vmcnt
+    // counts loads and stores together) -- 30 us per name.  A name is therefore copied into LDS once (S.nm[rb]; the previous tokenised name stays in S.nm[rb ^ 1])
+    // and everything below reads the copy: C(i) = character i of the current name, P(i) = of the previous tokenised one.
+    uint32_t cabs = 0, pabs = 0;                                      // where the two names start in src (the fallback for names longer than NAME_LDS)
+    bool clds = false, plds = false;
+    auto stage = [&](uint32_t p0, uint32_t len) {
+        cabs = p0; clds = len <= NAME_LDS;
+        if (clds) for (uint32_t k = (uint32_t)lane; k < len; k += 64) S.nm[rb][k] = src[p0 + k];
+        wave_sync();
+    };
+    auto C = [&](uint32_t i) -> uint32_t { return clds ? (uint32_t)S.nm[rb][i] : (uint32_t)src[cabs + i]; };
+    auto P = [&](uint32_t i) -> uint32_t { return plds ? (uint32_t)S.nm[rb ^ 1u][i] : (uint32_t)src[pabs + i]; };
     auto put8 = [&](uint32_t ty, uint32_t tp, uint32_t v) {
         const uint32_t c = S.cur[ty][tp];
         if (wr) B[S.base[ty][tp] + c] = (uint8_t)v;
@@ -238,13 +253,13 @@ __device__ uint32_t tok_sweep(const uint8_t *__restrict__ src, uint32_t n, uint3
         if (wr) put32(B + S.base[ty][tp] + c, v);
         S.cur[ty][tp] = c + 4u;
     };
-    // tokenises name [p0, p0+len): emit == false only records the tokens (for the predecessor of the range)
-    auto do_name = [&](uint32_t p0, uint32_t len, bool emit) {
+    // tokenises the staged name (len characters): emit == false only records the tokens (for the predecessor of the range)
+    auto do_name = [&](uint32_t len, bool emit) {
         uint32_t nb = 0, pc = 3, prun = 0;                          // boundaries so far, class / run position of the previous char
         for (uint32_t c0 = 0; c0 < len; c0 += 64) {
             const uint32_t i = c0 + (uint32_t)lane;
             const bool has = i < len;
-            const uint32_t ch = has ? src[p0 + i] : 0u;
+            const uint32_t ch = has ? C(i) : 0u;
             const int cls = has ? char_class(ch) : 3;
             const uint32_t pcl = (uint32_t)__shfl_up(cls, 1, 64);
             const bool chg = has && (cls == 2 || (uint32_t)cls != (lane == 0 ? pc : pcl));
@@ -261,21 +276,21 @@ __device__ uint32_t tok_sweep(const uint8_t *__restrict__ src, uint32_t n, uint3
                 if (t == (uint32_t)(MAX_TOK - 3)) { tc = T_STRING; tl = len - i; }
                 else if (cls == 0) {
                     uint32_t e = i;
-                    while (e < len && e - i < 9u && (src[p0 + e] - '0') < 10u) { val = val * 10u + (src[p0 + e] - '0'); e++; }
+                    while (e < len && e - i < 9u && (C(e) - '0') < 10u) { val = val * 10u + (C(e) - '0'); e++; }
                     tl = e - i;
                     tc = (ch == '0' && tl > 1u) ? T_DIGITS0 : T_DIGITS;
                 } else if (cls == 1) {
                     uint32_t e = i;
-                    while (e < len && char_class(src[p0 + e]) == 1) e++;
+                    while (e < len && char_class(C(e)) == 1) e++;
                     tl = e - i; tc = tl == 1u ? T_CHAR : T_STRING;
                 } else tc = T_CHAR;
-                const uint32_t off = p0 + i;
+                const uint32_t off = i;
                 S.toff[rb][t] = off; S.tlen[rb][t] = tl; S.tval[rb][t] = val; S.tcls[rb][t] = (uint8_t)tc;
                 if (emit) {
                     const bool haveP = have_prev && t < pn;
                     const uint32_t po = S.toff[rb ^ 1][t], pl = S.tlen[rb ^ 1][t], pv = S.tval[rb ^ 1][t], pcs = S.tcls[rb ^ 1][t];
                     bool same = haveP && pcs == tc && pl == tl;
-                    for (uint32_t k = 0; same && k < tl; k++) same = src[po + k] == src[off + k];
+                    for (uint32_t k = 0; same && k < tl; k++) same = P(po + k) == C(off + k);
                     if (same) put8(T_TYPE, tp, T_MATCH);
                     else if (haveP && tc == T_DIGITS && pcs == T_DIGITS && val >= pv && val - pv < 256u) { put8(T_TYPE, tp, T_DELTA); put8(T_DELTA, tp, val - pv); }
                     else if (haveP && tc == T_DIGITS0 && pcs == T_DIGITS0 && tl == pl && val >= pv && val - pv < 256u) { put8(T_TYPE, tp, T_DELTA0); put8(T_DELTA0, tp, val - pv); }
@@ -283,7 +298,7 @@ __device__ uint32_t tok_sweep(const uint8_t *__restrict__ src, uint32_t n, uint3
                         put8(T_TYPE, tp, tc);
                         if (tc == T_STRING) {
                             const uint32_t c = S.cur[T_STRING][tp];
-                            if (wr) { uint8_t *w = B + S.base[T_STRING][tp] + c; for (uint32_t k = 0; k < tl; k++) w[k] = src[off + k]; w[tl] = 0; }
+                            if (wr) { uint8_t *w = B + S.base[T_STRING][tp] + c; for (uint32_t k = 0; k < tl; k++) w[k] = (uint8_t)C(off + k); w[tl] = 0; }
                             S.cur[T_STRING][tp] = c + tl + 1u;
                         } else if (tc == T_CHAR) put8(T_CHAR, tp, ch);
                         else { put32s(tc, tp, val); if (tc == T_DIGITS0) put8(T_DZLEN, tp, tl); }
@@ -300,7 +315,7 @@ __device__ uint32_t tok_sweep(const uint8_t *__restrict__ src, uint32_t n, uint3
             if (lane == 0) put8(T_TYPE, nt + 1u, T_END);
             if (maxpos < nt + 2u) maxpos = nt + 2u;
         }
-        rb ^= 1u; pn = nt;
+        rb ^= 1u; pn = nt; pabs = cabs; plds = clds;                  // the name just tokenised is the "previous" one from here on
         wave_sync();
     };
     if (begin > 0 && begin < end) {                                   // predecessor: the name that ends at begin - 1
@@ -314,7 +329,8 @@ __device__ uint32_t tok_sweep(const uint8_t *__restrict__ src, uint32_t n, uint3
             q -= back;
         }
         ppos = q; plen = begin - 1u - q; have_prev = true;
-        do_name(ppos, plen, false);
+        stage(ppos, plen);
+        do_name(plen, false);
     }
     while (pos < end) {
         uint32_t len = 0;                                             // distance to the terminating NUL
@@ -324,12 +340,13 @@ __device__ uint32_t tok_sweep(const uint8_t *__restrict__ src, uint32_t n, uint3
             if (z) { len += (uint32_t)__builtin_ctzll(z); break; }
             len += 64;
         }
+        stage(pos, len);
         bool dup = false;
-        if (have_prev && len == plen) {
+        if (have_prev && len == plen) {                               // (a duplicate of a duplicate equals the last TOKENISED name too: that is the one P() reads)
             dup = true;
             for (uint32_t k = 0; k < len && dup; k += 64) {
                 const uint32_t q = k + (uint32_t)lane;
-                if (__any(q < len && src[pos + q] != src[ppos + q])) dup = false;
+                if (__any(q < len && C(q) != P(q))) dup = false;
             }
         }
         if (dup) {
@@ -338,7 +355,7 @@ __device__ uint32_t tok_sweep(const uint8_t *__restrict__ src, uint32_t n, uint3
             wave_sync();
         } else {
             if (lane == 0) { put8(T_TYPE, 0, T_DIFF); put32s(T_DIFF, 0, have_prev ? 1u : 0u); }
-            do_name(pos, len, true);
+            do_name(len, true);
         }
         ppos = pos; plen = len; have_prev = true; nn++;
         pos += len + 1u;
