@@ -325,7 +325,24 @@ struct Deflater {
         for (int s = 4; s < 30; s++) bits += (uint64_t)df[s] * (uint32_t)((s - 2) >> 1);
         if (cap < 330 + 8 || (bits >> 3) + 330 + 8 > cap) return 0;
         memset(dst, 0, 330);
-        const uint32_t hb = write_dynamic_header(ll, dl, dst, cs, ce, work, order);
+        uint32_t hb = write_dynamic_header(ll, dl, dst, cs, ce, work, order);
+        // A short block is mostly its code-length header: with the fixed codes of RFC 1951 3.2.6 (header = 3 bits) it is smaller.  Same tokens, other codes.
+        {
+            uint8_t fl[288], fd[32];
+            for (int s = 0; s < 288; s++) fl[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            memset(fd, 5, 32);
+            uint64_t fbits = 3;
+            for (int s = 0; s < 286; s++) fbits += (uint64_t)lf[s] * fl[s];
+            for (int s = 0; s < 30; s++) fbits += (uint64_t)df[s] * 5u;
+            for (int s = 265; s < 285; s++) fbits += (uint64_t)lf[s] * (uint32_t)((s - 261) >> 2);
+            for (int s = 4; s < 30; s++) fbits += (uint64_t)df[s] * (uint32_t)((s - 2) >> 1);
+            if (fbits < (uint64_t)hb + bits) {
+                uint16_t flc[288], fdc[32];
+                assign_codes_host(fl, 288, flc); assign_codes_host(fd, 32, fdc);
+                memcpy(ll, fl, 288); memcpy(lc, flc, sizeof flc); memcpy(dl, fd, 32); memcpy(dc, fdc, sizeof fdc);
+                memset(dst, 0, 330); dst[0] = 3; hb = 3;                                     // BFINAL = 1, BTYPE = 01
+            }
+        }
         uint64_t acc = 0; uint32_t have = hb & 7u; size_t at = hb >> 3;
         if (have) acc = dst[at];
         auto put = [&](uint32_t v, uint32_t k) { acc |= (uint64_t)v << have; have += k; };

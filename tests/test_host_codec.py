@@ -159,6 +159,26 @@ def test_deflate_blocks_decode_everywhere(hc, oracle):
             assert r.returncode == 0 and r.stdout == plain[:len(r.stdout)] and len(r.stdout) == total_in
 
 
+def test_short_blocks_take_the_fixed_codes(hc, oracle):
+    """A block of a few hundred bytes is mostly its dynamic-Huffman header: the host deflate writes it with the fixed codes (BTYPE 01) when that is smaller,
+    as zlib does -- it used to fall back to a stored block.  Any valid stream is accepted by the format; the bound here is zlib -6 plus a few bytes."""
+    rng = np.random.default_rng(11)
+    fixed = 0
+    for n in (1, 2, 3, 7, 20, 50, 120, 300, 700):
+        for kind in range(3):
+            d = (b"chr1\t%d\t.\tA\tG\n" % n * n)[:n] if kind == 0 else bytes(rng.integers(65, 70, n, dtype=np.uint8)) if kind == 1 else bytes(n)
+            rc, blk = deflate_block(hc, d, 6)
+            assert rc == 0
+            assert zlib.decompress(blk[18:-8], -15) == d and oracle.uncompress_block(blk) == (0, d)
+            buf = C.create_string_buffer(len(d) + 8)
+            assert hc.hc_block_inflate(blk, len(blk), buf, len(d)) == 0 and buf.raw[:len(d)] == d
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            z = len(co.compress(d) + co.flush())
+            assert len(blk) - 26 <= z + 4, (n, kind, len(blk) - 26, z)
+            fixed += (blk[18] & 7) == 3
+    assert fixed >= 10                                                              # BFINAL = 1, BTYPE = 01
+
+
 def test_host_codec_under_sanitizers_with_damaged_blocks(tmp_path):
     """tests/native/host_codec_san.cpp: AddressSanitizer + UBSan over deflate -> inflate round trips at four levels and six kinds of damage per block: no
     out-of-bounds access, no truncated block accepted, a flipped bit accepted only if the output is still right"""
