@@ -1524,7 +1524,7 @@ def op_fqz(run: Run, steps: int, streams: int = 512, nrec: int = 2000):
            "config": {"workload": "%d quality blocks of %d x %d bp; one adaptive chain per block; medians" % (streams, nrec, rl), "encode_GBps": round(nb / med(te) / 1e9, 3),
                       "ratio": round(nc / nb, 4), "verified_blocks": len(datas), "format_parity": "UNPINNED against htscodecs (oracle/fqzcomp_oracle.c)"},
            "roofline": {"bound": "hbm", "achieved": round((nb + nc) / med(td) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((nb + nc) / med(td) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
-                        "kernel": "whole decode call (hgq::fqz_decode_kernel: one dependent chain per block, one memory round trip per quality -- latency, not bandwidth; DESIGN.md 4.10)",
+                        "kernel": "whole decode call (hgq::fqz_decode_kernel: one dependent chain per block, ~110 dependent instructions per quality with the next models fetched ahead -- instruction latency, not bandwidth; DESIGN.md 4.10)",
                         "algorithmic_bytes": int(nb + nc)}}
     if not run.args.no_cpu_baseline:
         nproc = max(1, min(run.ncores - 2, 64))
