@@ -419,6 +419,8 @@ __device__ __forceinline__ int decode_stream(const uint8_t *__restrict__ in, con
             if (R.pflags & PF_DTAB) { st.delta += st.prevq != Q; st.prevq = Q; }
             st.p--;
             const uint32_t next = rl(cv, l), upd = cur;
+            // (pf[] have no use above this line; should a future compiler schedule the selects below above the wait, make the four registers "+v" operands of an
+            //  `asm volatile("s_waitcnt vmcnt(0)")` here -- same code today, checked in the -S output, which is the build the GPU tests ran)
             hg::wait_vm0();                                              // the one wait for memory of a quality: the models requested before the coder step
             {                                                            // (same context again: `cur` is already its updated model)
                 const uint32_t p01 = (l & 1u) ? pf[1] : pf[0], p23 = (l & 1u) ? pf[3] : pf[2], psel = (l & 2u) ? p23 : p01;
