@@ -9,18 +9,21 @@
 // per cent of zlib level 6 in size.
 //
 // Mapping (CDNA4 first, not a port of a CPU deflate):
-//   * one BGZF block per 256-thread workgroup; the input is staged in LDS as a RING of the last 36 KiB (32 KiB window + look-ahead, topped
-//     up 2 KiB at a time while the chunks advance), every later access (hashing, match extension, literals, CRC) is an LDS access.  53 KiB of
-//     LDS and <= 168 VGPRs per workgroup -> 3 workgroups (12 waves) per CU, persistent workgroups pull block tickets from a global counter;
+//   * one BGZF block per 256-thread workgroup; the input is staged in LDS as a RING of the last 22 KiB (window + look-ahead, topped up 2 KiB at a
+//     time while the chunks advance), every later access (hashing, match extension, literals, CRC) is an LDS access.  The window is 19 KiB, not
+//     DEFLATE's 32: the table below remembers the 12 most recent positions of 512 buckets -- about 6 000 positions -- so nothing older than that
+//     is ever proposed (scripts/lzsim3.c: the same size to the fourth digit down to an 8 KiB window on every test input).  38 KiB of LDS and
+//     <= 128 VGPRs per workgroup -> 4 workgroups (16 waves) per CU, persistent workgroups pull block tickets from a global counter;
 //   * match finding is position-parallel: the block is walked in chunks of 256 positions, one position per lane; a lane hashes its 4 bytes,
 //     reads the WAYS (4 / 8 / 12 by level) most recent earlier positions with that hash from a set-associative table in LDS and compares
-//     each with its own bytes over 32 (24) bytes in straight-line code (aligned dword reads, v_alignbyte, xor, v_ffbl, one unsigned minimum:
+//     each with its own bytes over 32 bytes in straight-line code (aligned dword reads, v_alignbyte, xor, v_ffbl, one unsigned minimum:
 //     the kernel is bound by instruction ISSUE, so the instruction count per candidate is what matters), then the nearest survivor alone,
-//     16 bytes per round; then the chunk's positions are inserted (LDS atomics pick the way).  Candidates are always from earlier chunks;
-//     distance 1 is probed directly;
-//   * the lazy parse (take a match unless the next position has a longer one) is a chain over positions; it is resolved per chunk with 8
-//     rounds of pointer jumping in LDS, then the chosen tokens are compacted in order with ballots and appended to a per-workgroup token
-//     list in HBM while LDS atomics build the litlen/distance histograms;
+//     16 bytes per round; then one wavefront inserts the chunk's positions (LDS atomics pick the way).  Candidates are always from earlier
+//     chunks; distance 1 is probed directly;
+//   * the lazy parse (take a match unless the next position has a longer one) is a chain over positions; every wavefront resolves it for its own
+//     64 positions and EVERY entry point at once -- six rounds of pointer doubling in registers (ds_bpermute) -- then the wavefronts' exits are
+//     chained through LDS (two barriers per chunk; rounds 1-5: pointer jumping across the workgroup, fourteen); the chosen tokens are appended
+//     in order to a per-workgroup token list in HBM while LDS atomics build the litlen/distance histograms;
 //   * the Huffman phase (<= 286 + 30 + 19 symbols) is a workgroup-collective routine (deflate_huff_wg.h): package-merge code lengths, one
 //     binary search per item and level; canonical codes; the header's run-length coding per run start -- unit-tested on the host;
 //   * bit packing is a prefix scan of code lengths over 256 tokens per step; lanes OR their <= 48 bits into an LDS staging window with
@@ -61,22 +64,15 @@ constexpr int WG = 256;
 constexpr int HB = HG_DEF_HB;                 // hash buckets = 2^HB
 constexpr int MAX_WAYS = 12;                   // most recent positions kept per bucket (the level picks 4, 8 or 12 of them)
 #ifndef HG_DEF_KERNEL_ATTR
-#define HG_DEF_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))   // 168 VGPRs: three wavefronts per SIMD (the LDS allows three workgroups per CU)
+#define HG_DEF_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: four wavefronts per SIMD (the LDS allows four workgroups per CU)
 #endif
 #ifndef HG_DEF_WGS_PER_CU
-#define HG_DEF_WGS_PER_CU 3
+#define HG_DEF_WGS_PER_CU 4
 #endif
 constexpr uint32_t MAX_IN = 0xff00u;           // BGZF_BLOCK_SIZE (htslib/bgzf.h:50)
-#ifndef HG_LS_G0
-#define HG_LS_G0 32      // bytes over which the candidates of the first group are compared in lock step
-#endif
-#ifndef HG_LS_G1
-#define HG_LS_G1 24      // ... of the second group (12 ways): 24 costs 0.02 % of size and gives 3.5 % of speed (r02 sweep)
-#endif
-constexpr uint32_t LOCKSTEP = (uint32_t)HG_LS_G0;
 constexpr uint32_t TOO_FAR = 4096u;            // a 3-byte match this far away costs more than 3 literals
 
-struct Huff {                                  // overlays the hash table once matching is done
+struct Huff {                                  // codes + bit-packing window of the emit phase
     uint32_t obuf[520];                        // bit-packing staging window (dwords)
     uint16_t ll_code[288];
     uint16_t d_code[32];
@@ -84,35 +80,46 @@ struct Huff {                                  // overlays the hash table once m
     alignas(4) uint8_t d_len[32];
 };
 
-// The staged input is a RING of the last 36 KiB (DEFLATE looks back 32 KiB): position x of the block lives at byte x mod RING, the ring's first
-// MIRROR bytes are kept twice (again behind its end) so that a read that starts near the end runs straight on.  With the whole 64 KiB block
-// staged the kernel held 80 KiB of LDS and two workgroups per CU; with the ring it holds 53 KiB: three per CU, +33 % (measured on a build that
-// simply staged half blocks).  A block of up to 36 KiB never wraps; behind that the ring is topped up 2 KiB at a time while the chunks advance.
-constexpr uint32_t RING = 36864u, MIRROR = 64u, REFILL = 2048u, AHEAD = 544u;   // AHEAD: a chunk reads up to 256 + 258 + 19 bytes past its start
-static_assert(RING % 16 == 0 && REFILL == WG * 8 && RING >= 32768u + WG + AHEAD + REFILL, "ring geometry");
-__device__ __forceinline__ uint32_t ro(uint32_t pos) { const uint32_t w = pos - RING; return w < pos ? w : pos; }   // pos mod RING for pos < 2 * RING
+// The staged input is a RING of the last 22 KiB: position x of the block lives at byte x mod RING, the ring's first MIRROR bytes are kept twice
+// (again behind its end) so that a read that starts near the end runs straight on.  A block of up to 22 KiB never wraps; behind that the ring is
+// topped up 2 KiB at a time while the chunks advance.  History: the whole 64 KiB block staged (rounds 1-2: 80 KiB of LDS, two workgroups per CU),
+// a 36 KiB ring for DEFLATE's full 32 KiB look-back (rounds 3-5: 53 KiB, three per CU, +33 %), and now a ring for the look-back the hash table can
+// actually offer (WINDOW): the table keeps 12 positions in each of 512 buckets, ~6 000 positions in all, so a candidate farther than ~10 KiB back
+// practically never survives in it -- scripts/lzsim3.c gives the same compressed size to the fourth digit for windows from 32 KiB down to 8 KiB on
+// the BAM, the 41-level-quality BAM and the FASTQ inputs.  38 KiB of LDS: four workgroups per CU.
+constexpr uint32_t RING = 22528u, MIRROR = 64u, REFILL = 2048u, AHEAD = 544u;   // AHEAD: a chunk reads up to 256 + 258 + 19 bytes past its start
+constexpr uint32_t WINDOW = RING - (WG + AHEAD + REFILL);                        // how far back a match may start: 19 680
+static_assert(RING % 32 == 0 && REFILL == WG * 8 && WINDOW >= 16384u && WINDOW <= 32768u && 3u * RING >= MAX_IN + 64u,
+              "ring geometry (a top-up is stored in 32-byte pieces that must not straddle the ring's end; a block is at most three ring fills)");
+__device__ __forceinline__ uint32_t ro(uint32_t pos) {                           // pos mod RING for pos < 3 * RING
+    uint32_t w = pos - RING; pos = w < pos ? w : pos;
+    w = pos - RING; return w < pos ? w : pos;
+}
 
 struct Lds {
-    uint32_t in32[(RING + MIRROR) / 4];
     union {
-        uint16_t tab[(1 << HB) * MAX_WAYS];
-        Huff h;
+        struct {                               // matching phase
+            uint32_t in32[(RING + MIRROR) / 4];
+            uint16_t tab[(1 << HB) * MAX_WAYS];
+        } m;
+        struct {                               // Huffman + emit phases (the staged input and the hash table are dead by then)
+            hgdef::HuffWG w;
+            Huff h;
+        } e;
     } u;
     uint32_t cnt32[(1 << HB) / 4];             // 8-bit insertion counters, 4 per dword
     uint32_t lfreq[288];
     uint32_t dfreq[32];
-    uint16_t mlen[WG + 2];
-    uint16_t mdist[WG];
-    uint16_t jump[WG];
-    uint16_t jump2[WG];
-    uint8_t mark[WG];
+    uint16_t mlen[WG + 2];                     // match length a position offers to the parse (0 = literal)
+    uint16_t hk[WG];                           // hash bucket of a position (for the wavefront that publishes the chunk)
+    uint16_t exitp[WG];                        // final parse: where the walk from a position leaves its wavefront's 64 | tokens on the way << 9
     uint32_t wsum[8];
-    uint32_t carry_next;
-    uint32_t misc[7];
+    uint32_t misc[8];
 };
-static_assert(sizeof(Huff) <= sizeof(uint16_t) * (1 << HB) * MAX_WAYS, "Huff scratch must fit in the hash table");
-static_assert(sizeof(hgdef::HuffWG) <= RING, "the collective Huffman phase works in the staged input's LDS once matching is done");
-static_assert(sizeof(Lds) <= 53 * 1024, "three workgroups per CU");
+// gfx950 hands out its 160 KiB of LDS in granules of 1280 bytes (128 per CU): four workgroups per CU get 32 granules each.  (Measured in round 6: a
+// 53 892-byte build -- 43 granules where three workgroups have 42 each -- ran two per CU, SQ_WAVE_CYCLES / SQ_BUSY_CYCLES 15.8 instead of 23.5, and
+// lost a quarter of its speed.)
+static_assert(sizeof(Lds) <= 32 * 1280, "four workgroups per CU");
 
 // Unaligned reads of the staged input: aligned dword reads glued with v_alignbyte.  (Tried in round 3: gfx950 runs the LDS in unaligned-access
 // mode and the compiler emits ONE ds_read_b64 / b128 for a byte-aligned 8 / 16-byte read -- a third of the LDS instructions -- but a misaligned
@@ -198,11 +205,11 @@ __device__ uint32_t wg_crc32_raw(Lds &S, uint32_t n, int tid, bool first) {
     if (end < 0) end = 0;
     uint32_t len = (uint32_t)(end - beg), q = (uint32_t)beg;
     uint32_t c = (beg == 0 && end > 0 && first) ? 0xffffffffu : 0u;
-    const uint8_t *in8 = (const uint8_t *)S.in32;
+    const uint8_t *in8 = (const uint8_t *)S.u.m.in32;
     uint32_t head = len & 3u;
     for (uint32_t i = 0; i < head; i++) c = crc_byte(c, in8[q + i]);
     q += head; len -= head;
-    for (uint32_t i = 0; i < len; i += 4) c = crc_word(c, load4(S.in32, q + i));
+    for (uint32_t i = 0; i < len; i += 4) c = crc_word(c, load4(S.u.m.in32, q + i));
     const int lane = tid & 63;
 #pragma unroll
     for (int s = 0; s < 6; s++) {
@@ -244,7 +251,7 @@ __device__ __forceinline__ void pack_bits(Lds &S, uint32_t *out32, uint32_t &bit
     for (int w = 0; w < 4; w++) { uint32_t t = S.wsum[w]; if (w < wave) base += t; total += t; }
     const uint32_t my = bitpos + base + x - nb;            // my first bit
     const uint32_t w0 = bitpos >> 5;                        // first dword of the staging window
-    uint32_t *ob = S.u.h.obuf;
+    uint32_t *ob = S.u.e.h.obuf;
     if (nb) {
         uint32_t wi = (my >> 5) - w0, sh = my & 31u;
         uint64_t lo = v << sh;
@@ -280,9 +287,9 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
     // the last of its stream (BFINAL); every other chunk ends with an empty stored block (the zlib
     // "sync flush" marker 00 00 FF FF) so that chunks are byte aligned; crc_out[b] = CRC-32 of the chunk.
     __shared__ Lds S;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (the wavefront's number in a scalar register)
     uint32_t *tok = tokbuf + (size_t)blockIdx.x * 65536u;
-    const uint8_t *in8 = (const uint8_t *)S.in32;
+    const uint8_t *in8 = (const uint8_t *)S.u.m.in32;
 
     for (;;) {
         __syncthreads();
@@ -291,7 +298,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
         const uint32_t b = S.misc[0];
         if (b >= nblocks) break;
         const hg_bgzf_desc dsc = desc[b];
-        const uint32_t n = dsc.ulen > MAX_IN ? MAX_IN : dsc.ulen;     // API guarantees ulen <= 0xff00
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dsc.ulen > MAX_IN ? MAX_IN : dsc.ulen));     // API guarantees ulen <= 0xff00 (in a scalar register: the parse walk loops on it)
         const uint8_t *src = plain + dsc.uoff;
         uint8_t *o8 = slots + dsc.coff;
         uint32_t *o32 = (uint32_t *)o8;
@@ -311,12 +318,13 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
             continue;
         }
 #ifdef HG_PROFILE
-        unsigned long long dacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long dacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
         HD_T0(tp); HD_T0(tb);
-        // ---- stage the block's first RING bytes (coalesced 16-byte loads) and take the CRC from LDS ----------------
-        // bytes [from, to) of the block into the ring, zeros behind the block's end; from and to are multiples of 16
-        auto stage = [&](uint32_t from, uint32_t to) {
+        // ---- stage the block through the ring, one ring fill at a time from the LAST piece to the first (coalesced 16-byte loads), taking each
+        //      piece's CRC from LDS; the first piece stays for the matching ----------------------------------------------------------------------
+        // bytes [from, to) of the block to ring offset (position - base), zeros behind the block's end; from, to and base are multiples of 16
+        auto stage = [&](uint32_t from, uint32_t to, uint32_t base) {
             for (uint32_t i = from + (uint32_t)tid * 16u; i < to; i += WG * 16u) {
                 uint4 w = {0, 0, 0, 0};
                 if (i + 16u <= n) __builtin_memcpy(&w, src + i, 16);
@@ -325,33 +333,32 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                     for (int k = 0; k < 16; k++) t[k] = i + k < n ? src[i + k] : 0;
                     __builtin_memcpy(&w, t, 16);
                 }
-                const uint32_t r = ro(i) >> 2;
-                S.in32[r] = w.x; S.in32[r + 1] = w.y; S.in32[r + 2] = w.z; S.in32[r + 3] = w.w;
-                if (r < MIRROR / 4) { S.in32[RING / 4 + r] = w.x; S.in32[RING / 4 + r + 1] = w.y; S.in32[RING / 4 + r + 2] = w.z; S.in32[RING / 4 + r + 3] = w.w; }
+                const uint32_t r = (i - base) >> 2;
+                uint32_t *d = S.u.m.in32 + r;
+                d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
+                if (r < MIRROR / 4) { d = S.u.m.in32 + RING / 4 + r; d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w; }
             }
         };
         const uint32_t pad_end = (n + 48u + 15u) & ~15u;                  // the reads behind the last position find zeros
         uint32_t hi = pad_end < RING ? pad_end : RING;                    // bytes of the block staged so far
-        uint32_t crc;
-        if (n <= RING) {
-            stage(0, hi);
+        uint32_t crc = 0;                                                  // (thread 0's is the one that counts)
+        for (uint32_t base = n > RING ? ((n - 1u) / RING) * RING : 0u;; base -= RING) {
+            // CRC of the whole = sum over the pieces of (piece's register) * x^(8 * bytes behind the piece); the all-ones preset goes into the first piece
+            const uint32_t len = n - base < RING ? n - base : RING;
+            const uint32_t upto = base == 0u ? hi : (base + len + 15u) & ~15u;
             __syncthreads();
-            crc = ~wg_crc32_raw(S, n, tid, true);                         // valid in thread 0
-        } else {
-            // a block longer than the ring: CRC of its tail first (staged at the ring's start), then of its head, which stays for the matching
-            stage(RING, pad_end);
+            stage(base, upto, base);
             __syncthreads();
-            const uint32_t tail = wg_crc32_raw(S, n - RING, tid, false);
-            stage(0, RING);
-            __syncthreads();
-            uint32_t head = wg_crc32_raw(S, RING, tid, true);
-            if (tid == 0) {                                                // head * x^(8 * tail bytes) + tail
-                const uint32_t lt = n - RING;
-                for (int j = 0; (lt >> j) != 0u; j++) if ((lt >> j) & 1u) head = hg::crc_mulmod(head, hg::g_crc.xpow[j]);
+            uint32_t part = wg_crc32_raw(S, len, tid, base == 0u);
+            if (tid == 0) {
+                const uint32_t behind = n - base - len;
+                for (int j = 0; (behind >> j) != 0u; j++) if ((behind >> j) & 1u) part = hg::crc_mulmod(part, hg::g_crc.xpow[j]);
+                crc ^= part;
             }
-            crc = ~(head ^ tail);
+            if (base == 0u) break;
         }
-        for (int i = tid; i < (1 << HB) * MAX_WAYS / 2; i += WG) ((uint32_t *)S.u.tab)[i] = 0xffffffffu;
+        crc = ~crc;
+        for (int i = tid; i < (1 << HB) * MAX_WAYS / 2; i += WG) ((uint32_t *)S.u.m.tab)[i] = 0xffffffffu;
         for (int i = tid; i < (1 << HB) / 4; i += WG) S.cnt32[i] = 0;
         for (int i = tid; i < 288; i += WG) S.lfreq[i] = 0;
         if (tid < 32) S.dfreq[tid] = 0;
@@ -361,169 +368,171 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
         HD_TACC(1, tp);
         uint32_t ntok = 0;
         if (level != 0) {
-            // ---- match finding + lazy parse, 256 positions per step -----------------------
+            // ---- match finding + parse, 256 positions per step; two barriers per step -----------------------------------------------------------
             uint32_t carry = 0;                            // chunk-relative position of the next token
-            for (uint32_t c0 = 0; c0 < n; c0 += WG) {
+            uint32_t chunk = 0;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint32_t *in32 = S.u.m.in32;
+            for (uint32_t c0 = 0; c0 < n; c0 += WG, chunk++) {
                 HD_T0(tq);
                 const uint32_t p = c0 + (uint32_t)tid;
-                // top up the ring for the NEXT chunk: 8 bytes per thread, requested now, stored behind this chunk's search (the bytes they
-                // replace lie more than 32 KiB before the next chunk)
+                const int w_pub = (int)(chunk & 3u), w_fill = (w_pub + 2) & 3;     // the wavefront that publishes this chunk / tops up the ring
+                // top up the ring for the NEXT chunk: 32 bytes per lane of one wavefront, requested now, stored behind this chunk's searches (the
+                // bytes they replace lie more than WINDOW before the next chunk)
                 const bool refill = hi < pad_end && hi < c0 + WG + AHEAD;
-                uint2 rf = {0, 0};
-                if (refill) {
-                    const uint32_t q = hi + (uint32_t)tid * 8u;
-                    if (q + 8u <= n) __builtin_memcpy(&rf, src + q, 8);
+                uint4 rf0 = {0, 0, 0, 0}, rf1 = {0, 0, 0, 0};
+                if (refill && wave == w_fill) {
+                    const uint32_t q = hi + (uint32_t)lane * 32u;
+                    if (q + 32u <= n) { __builtin_memcpy(&rf0, src + q, 16); __builtin_memcpy(&rf1, src + q + 16, 16); }
                     else if (q < n) {
-                        uint8_t t[8];
-                        for (int k = 0; k < 8; k++) t[k] = q + k < n ? src[q + k] : 0;
-                        __builtin_memcpy(&rf, t, 8);
-                    }
-                }
-                uint32_t best = 0, bd = 0, h = 0;
-                const bool hashable = p + 4u <= n;
-                {   // every lane walks through the search (the long-match phase is a wavefront's joint work); a position that cannot start a
-                    // match (the block's last three bytes, the tail of the last chunk) simply has no candidates
-                    const uint32_t maxl = !hashable ? 0u : n - p < 258u ? n - p : 258u;
-                    uint32_t own[8];
-                    load_string<32>(S.in32, hashable ? ro(p) : 0u, own);
-                    static_assert(LOCKSTEP <= 32 && HG_LS_G1 <= 32 && LOCKSTEP % 4 == 0 && HG_LS_G1 % 4 == 0, "own[] holds 32 bytes");
-                    const uint32_t cur = own[0];
-                    h = hashable ? hash4(cur) : 0u;
-                    // Candidates are evaluated in groups of up to 8 table entries (+ distance 1 with the first group: runs are never in this
-                    // chunk's table) to bound the registers held per lane: one group for 4 or 8 ways, 8 + 4 for 12.  All of this is straight-line
-                    // code -- the kernel is bound by instruction issue, every exec-mask branch costs scalar instructions on top of both sides.
-                    // The best match so far is one key: length << 16 | (32768 - distance): a maximum picks the longer match and, among equals,
-                    // the nearer one.
-                    const uint32_t *row32 = (const uint32_t *)&S.u.tab[h * MAX_WAYS];           // 24-byte rows, 8-byte aligned
-                    uint32_t bestkey = 0;
-                    auto group = [&](auto nc_, auto ls_, auto first_, auto d1_) {
-                        constexpr int NC = decltype(nc_)::value, LS = decltype(ls_)::value, FIRST = decltype(first_)::value;
-                        constexpr bool D1 = decltype(d1_)::value;
-                        constexpr int G = NC + (D1 ? 1 : 0);
-                        static_assert(NC % 4 == 0 && FIRST % 4 == 0, "the ways are read eight bytes at a time");
-                        uint32_t cw[NC / 2];
-#pragma unroll
-                        for (int k = 0; k < NC / 2; k += 2) {
-                            const uint2 rw = *(const uint2 *)(row32 + FIRST / 2 + k);
-                            cw[k] = rw.x; cw[k + 1] = rw.y;
-                        }
-                        uint32_t cand[G], dist[G];                                               // dist 0 = no candidate
-#pragma unroll
-                        for (int w = 0; w < NC; w++) {
-                            const uint32_t c = (cw[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
-                            const bool ok = hashable && c != 0xffffu && p - c <= 32768u;         // 32 KiB window
-                            cand[w] = ok ? c : 0u;
-                            dist[w] = ok ? p - c : 0u;
-                        }
-                        if constexpr (D1) { const bool ok = hashable && p >= 1u; cand[NC] = ok ? p - 1u : 0u; dist[NC] = ok ? 1u : 0u; }
-                        // every candidate over the first LS bytes (common_prefix_fixed); the nearest one that gets through them goes on alone
-                        uint32_t near = 0xffffffffu;
-#pragma unroll
-                        for (int w = 0; w < G; w++) {
-                            uint32_t l = common_prefix_fixed<LS>(S.in32, ro(cand[w]), own);
-                            l = dist[w] ? l : 0u;
-                            if (l >= (uint32_t)LS) near = dist[w] < near ? dist[w] : near;
-                            l = l < maxl ? l : maxl;
-                            const uint32_t key = (l << 16) | (32768u - dist[w]);
-                            bestkey = key > bestkey ? key : bestkey;
-                        }
-                        // long-match phase: only the nearest survivor is extended (16 bytes per dependent round); the others keep the LS bytes
-                        // they have proven
-                        if (near != 0xffffffffu && (uint32_t)LS < maxl) {
-                            const uint32_t c = p - near;
-                            uint32_t l = (uint32_t)LS;
-                            while (l < maxl) {
-                                unsigned long long a0, a1, b0, b1;
-                                load16(S.in32, ro(c + l), a0, a1); load16(S.in32, ro(p + l), b0, b1);
-                                const unsigned long long x0 = a0 ^ b0, x1 = a1 ^ b1;
-                                if (x0) { l += (uint32_t)__builtin_ctzll(x0) >> 3; break; }
-                                if (x1) { l += 8u + ((uint32_t)__builtin_ctzll(x1) >> 3); break; }
-                                l += 16;
-                            }
-                            l = l < maxl ? l : maxl;
-                            const uint32_t key = (l << 16) | (32768u - near);
-                            bestkey = key > bestkey ? key : bestkey;
-                        }
-                    };
-                    constexpr int GW = WAYS < 8 ? WAYS : 8;
-                    group(std::integral_constant<int, GW>{}, std::integral_constant<int, (int)LOCKSTEP>{}, std::integral_constant<int, 0>{}, std::true_type{});
-                    if constexpr (WAYS > 8)
-                        group(std::integral_constant<int, WAYS - 8>{}, std::integral_constant<int, HG_LS_G1>{}, std::integral_constant<int, 8>{}, std::false_type{});
-                    best = bestkey >> 16; bd = 32768u - (bestkey & 0xffffu);
-                    if (best < 3u || (best == 3u && bd > TOO_FAR) || (LAZY >= 2 && best == 4u && bd > 2048u)) best = 0;
-                }
-                S.mlen[tid] = (uint16_t)best;
-                S.mdist[tid] = (uint16_t)bd;
-                HD_TACCM(6, tq);
-                __syncthreads();
-                HD_TACCM(7, tq);
-                // Publish this chunk's positions.  The slot a position gets inside its bucket comes from an atomic
-                // counter, so the four waves insert one after the other (a wave's own LDS atomics resolve in lane
-                // order): the table -- and with it the compressed bytes -- is the same on every run.
-                auto publish = [&]() {
-                    if (hashable) {
-                        const uint32_t sh = (h & 3u) * 8u;
-                        const uint32_t old = atomicAdd(&S.cnt32[h >> 2], 1u << sh);
-                        S.u.tab[h * MAX_WAYS + ((old >> sh) & 0xffu) % (uint32_t)WAYS] = (uint16_t)p;
-                    }
-                };
-                if (wave == 0) publish();
-                if (refill) {                                              // (every wave is past its search: the barrier above)
-                    const uint32_t r = ro(hi + (uint32_t)tid * 8u) >> 2;
-                    S.in32[r] = rf.x; S.in32[r + 1] = rf.y;
-                    if (r < MIRROR / 4) { S.in32[RING / 4 + r] = rf.x; S.in32[RING / 4 + r + 1] = rf.y; }
-                    hi += REFILL;
-                }
-                __syncthreads();
-                if (wave == 1) publish();
-                // ---- lazy parse by pointer jumping -----------------------------------------
-                const bool live = p < n;
-                // lazy parse: a match yields to a longer one starting at the next position (and, two-step, to one longer by
-                // two or more at the position after that); mlen[WG], mlen[WG + 1] = 0: the chunk's last positions cannot look ahead
-                const bool take = best >= 3u && !(LAZY >= 1 && (uint32_t)S.mlen[tid + 1] > best) &&
-                                  !(LAZY >= 2 && (uint32_t)S.mlen[tid + 2] > best + 1u);
-                const uint32_t step = take ? best : 1u;
-                uint32_t nx = (uint32_t)tid + step;
-                if (nx > WG) nx = WG;
-                bool marked = false;
-                if (carry < WG) {
-                    // one barrier per round: the doubled pointers alternate between two arrays (a round reads one and writes the other), the marks
-                    // only ever go from 0 to 1 and a round's marks are complete at its barrier
-                    S.jump[tid] = (uint16_t)nx;
-                    S.mark[tid] = (uint8_t)(((uint32_t)tid == carry) && live);
-                    __syncthreads();
+                        uint8_t t[32];
 #pragma unroll 1
-                    for (int r = 0; r < 8; r += 2) {
-                        {
-                            const uint32_t j = S.jump[tid];
-                            if (S.mark[tid] && j < WG) S.mark[j] = 1;
-                            S.jump2[tid] = (uint16_t)(j < WG ? (uint32_t)S.jump[j] : (uint32_t)WG);
-                            __syncthreads();
-                        }
-                        {
-                            const uint32_t j = S.jump2[tid];
-                            if (S.mark[tid] && j < WG) S.mark[j] = 1;
-                            S.jump[tid] = (uint16_t)(j < WG ? (uint32_t)S.jump2[j] : (uint32_t)WG);
-                            __syncthreads();
+                        for (int k = 0; k < 32; k++) t[k] = q + k < n ? src[q + k] : 0;
+                        __builtin_memcpy(&rf0, t, 16); __builtin_memcpy(&rf1, t + 16, 16);
+                    }
+                }
+                // ---- the candidates ------------------------------------------------------------------------------------------------------------
+                // A position that cannot start a match (the block's last three bytes, the tail of the last chunk) has maxl = 0: every length clamps to 0.
+                const bool hashable = p + 4u <= n;
+                const uint32_t maxl = !hashable ? 0u : n - p < 258u ? n - p : 258u;
+                const uint32_t rp = hashable ? ro(p) : 0u;
+                uint32_t own[8];
+                load_string<32>(in32, rp, own);
+                const uint32_t h = hashable ? hash4(own[0]) : 0u;
+                // The best match so far is one key: length << 16 | (32768 - distance): a maximum picks the longer match and, among equals, the nearer
+                // one -- so a key of length 32 names the NEAREST candidate that got through all 32 bytes.  All of this is straight-line code: the
+                // kernel is bound by instruction issue, every exec-mask branch costs scalar instructions on top of both sides.
+                uint32_t key = 0;
+                {
+                    static_assert(WAYS % 4 == 0, "the ways are read eight bytes at a time");
+                    const uint32_t *row32 = (const uint32_t *)&S.u.m.tab[h * MAX_WAYS];         // 24-byte rows, 8-byte aligned
+#pragma unroll
+                    for (int k = 0; k < WAYS / 2; k += 2) {
+                        const uint2 rw = *(const uint2 *)(row32 + k);
+                        const uint32_t cw[2] = {rw.x, rw.y};
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            const uint32_t c = (cw[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+                            // an empty slot (0xffff) lies "ahead" of p: its distance wraps to a huge number and fails the window test like a stale entry
+                            const uint32_t d = p - c;
+                            const bool ok = d <= WINDOW;
+                            const uint32_t dd = ok ? d : 0u;                          // (a failed candidate compares the position with itself; its key is dropped)
+                            const uint32_t rc0 = rp - dd, rc1 = rc0 + RING;           // ring offset of the candidate: rp - d, + RING when that wrapped
+                            uint32_t l = common_prefix_fixed<32>(in32, rc0 < rc1 ? rc0 : rc1, own);
+                            l = l < maxl ? l : maxl;
+                            const uint32_t k1 = ok ? (l << 16) | (32768u - d) : 0u;
+                            key = k1 > key ? k1 : key;
                         }
                     }
-                    marked = S.mark[tid] != 0 && live;
-                    if (marked && (uint32_t)tid + step >= WG) S.carry_next = (uint32_t)tid + step - WG;
-                    if (tid == 0 && c0 + WG >= n) S.carry_next = 0;   // last chunk: value unused
-                } else if (tid == 0) {
-                    S.carry_next = carry - WG;
                 }
-                HD_TACCM(8, tq);
-                // ---- compact the chosen tokens, in order -----------------------------------
-                const unsigned long long bal = __ballot(marked);
-                if (lane == 0) S.wsum[wave] = (uint32_t)__popcll(bal);
-                __syncthreads();
-                if (wave == 2) publish();
-                uint32_t base = ntok, total = 0;
+                {   // distance 1 (runs are never in the table: candidates come from earlier chunks).  A match of length L at distance 1 means the L bytes
+                    // from p on all equal the byte before p: compare the position's own bytes with that byte, no second string to fetch
+                    const uint32_t splat = (uint32_t)in8[p >= 1u ? ro(p - 1u) : 0u] * 0x01010101u;
+                    uint32_t m = 0xffffffffu;
 #pragma unroll
-                for (int w = 0; w < 4; w++) { uint32_t t = S.wsum[w]; if (w < wave) base += t; total += t; }
-                if (marked) {
-                    const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t x = own[j] ^ splat;
+                        uint32_t f;
+                        asm("v_ffbl_b32 %0, %1" : "=v"(f) : "v"(x));
+                        f |= (uint32_t)(32 * j);
+                        m = f < m ? f : m;
+                    }
+                    m >>= 3;
+                    uint32_t l = m < 32u ? m : 32u;
+                    l = l < maxl ? l : maxl;
+                    const uint32_t k1 = p >= 1u ? (l << 16) | 32767u : 0u;
+                    key = k1 > key ? k1 : key;
+                }
+                HD_TACCM(6, tq);
+                // ---- the nearest candidate that got through all 32 bytes goes on alone, 16 bytes per dependent round; the others keep what they have proven
+                if ((key >> 16) == 32u && maxl > 32u) {
+                    const uint32_t c = p - (32768u - (key & 0xffffu));
+                    uint32_t l = 32u;
+                    while (l < maxl) {
+                        unsigned long long a0, a1, b0, b1;
+                        load16(in32, ro(c + l), a0, a1); load16(in32, ro(p + l), b0, b1);
+                        const unsigned long long x0 = a0 ^ b0, x1 = a1 ^ b1;
+                        if (x0) { l += (uint32_t)__builtin_ctzll(x0) >> 3; break; }
+                        if (x1) { l += 8u + ((uint32_t)__builtin_ctzll(x1) >> 3); break; }
+                        l += 16;
+                    }
+                    l = l < maxl ? l : maxl;
+                    key = (l << 16) | (key & 0xffffu);
+                }
+                uint32_t best = key >> 16;
+                const uint32_t bd = 32768u - (key & 0xffffu);
+                if (best < 3u || (best == 3u && bd > TOO_FAR) || (LAZY >= 2 && best == 4u && bd > 2048u)) best = 0;
+                S.mlen[tid] = (uint16_t)best;
+                S.hk[tid] = (uint16_t)h;
+                HD_TACCM(7, tq);
+                __syncthreads();
+                HD_TACCM(8, tq);
+                // lazy parse: a match yields to a longer one starting at the next position (and, two-step, to one longer by two or more at the position
+                // after that); mlen[WG], mlen[WG + 1] = 0: the chunk's last positions cannot look ahead
+                const bool take = (best >= 3u) & !(LAZY >= 1 && (uint32_t)S.mlen[tid + 1] > best) & !(LAZY >= 2 && (uint32_t)S.mlen[tid + 2] > best + 1u);
+                // ---- one wavefront publishes the chunk's positions, one stores the ring's top-up --------------------------------------------------------
+                if (wave == w_pub) {
+                    // The slot a position gets inside its bucket comes from an atomic counter; ONE wavefront inserts the four groups of 64 one after the
+                    // other (a wave's own LDS atomics resolve in lane order): the table -- and with it the compressed bytes -- is the same on every run.
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const uint32_t q = 64u * s + (uint32_t)lane, pq = c0 + q;
+                        if (pq + 4u <= n) {
+                            const uint32_t hh = (uint32_t)S.hk[q];
+                            const uint32_t sh = (hh & 3u) * 8u;
+                            const uint32_t old = atomicAdd(&S.cnt32[hh >> 2], 1u << sh);
+                            S.u.m.tab[hh * MAX_WAYS + ((old >> sh) & 0xffu) % (uint32_t)WAYS] = (uint16_t)pq;
+                        }
+                    }
+                } else if (wave == w_fill && refill) {
+                    const uint32_t r = ro(hi + (uint32_t)lane * 32u) >> 2;
+                    uint32_t *d = S.u.m.in32 + r;
+                    d[0] = rf0.x; d[1] = rf0.y; d[2] = rf0.z; d[3] = rf0.w; d[4] = rf1.x; d[5] = rf1.y; d[6] = rf1.z; d[7] = rf1.w;
+                    if (r < MIRROR / 4) {
+                        d = S.u.m.in32 + RING / 4 + r;
+                        d[0] = rf0.x; d[1] = rf0.y; d[2] = rf0.z; d[3] = rf0.w; d[4] = rf1.x; d[5] = rf1.y; d[6] = rf1.z; d[7] = rf1.w;
+                    }
+                }
+                if (refill) hi += REFILL;
+                // ---- the parse of this wavefront's 64 positions for every entry at once: step = the token length a walk standing at a position takes;
+                //      R = mask of the token starts on the walk from this lane, J = where that walk leaves the 64 (64 .. 321).  Round t doubles the
+                //      tokens covered: R |= R[J], J = J[J] ------------------------------------------------------------------------------------------------
+                unsigned long long R = p < n ? 1ull << lane : 0ull;
+                uint32_t J = (uint32_t)lane + (take ? best : 1u);
+#pragma unroll 1
+                for (int t = 0; t < 6; t++) {
+                    const bool in = J < 64u;
+                    if (__ballot(in) == 0ull) break;
+                    const int idx = (int)((J & 63u) << 2);
+                    const uint32_t rl = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)(uint32_t)R);
+                    const uint32_t rh = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)(uint32_t)(R >> 32));
+                    const uint32_t j2 = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)J);
+                    if (in) { R |= ((unsigned long long)rh << 32) | rl; J = j2; }
+                }
+                S.exitp[tid] = (uint16_t)(J | ((uint32_t)__popcll(R) << 9));           // exit position (<= 321) and number of tokens of the walk from here
+                HD_TACCM(9, tq);
+                __syncthreads();
+                HD_TACCM(10, tq);
+                // ---- chain the wavefronts' walks: entry of the next = exit of this one - 64 ---------------------------------------------------------------
+                uint32_t e = carry, cnt = ntok, my_e = 0, my_base = 0;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    if (s == wave) { my_e = e; my_base = cnt; }
+                    if (e < 64u) {
+                        const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)S.exitp[64u * s + e]);
+                        cnt += v >> 9; e = (v & 511u) - 64u;
+                    } else e -= 64u;
+                }
+                carry = e; ntok = cnt;
+                unsigned long long mine = 0;
+                if (my_e < 64u) {
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)R, (int)my_e);
+                    const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(R >> 32), (int)my_e);
+                    mine = ((unsigned long long)hi32 << 32) | lo;
+                }
+                // ---- emit the chosen tokens, in order -------------------------------------------------------------------------------------------
+                if ((mine >> lane) & 1ull) {
+                    const uint32_t idx = my_base + (uint32_t)__popcll(mine & below);
                     if (take) {
                         tok[idx] = 0x80000000u | ((best - 3u) << 16) | (bd - 1u);
                         uint32_t s, xb, xv;
@@ -535,12 +544,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                         atomicAdd(&S.lfreq[byte], 1u);
                     }
                 }
-                ntok += total;
-                carry = S.carry_next;
-                __syncthreads();
-                if (wave == 3) publish();
-                __syncthreads();
-                HD_TACCM(9, tq);
+                HD_TACCM(11, tq);
             }
         }
         // ---- choose the block type and build the codes -------------------------------------
@@ -548,10 +552,10 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
         HD_TACC(2, tp);
         uint32_t dyn_bits = 0;
         if (level != 0) {
-            // the staged input and the hash table are dead now: the collective Huffman phase (deflate_huff_wg.h) works in the input's LDS,
-            // the codes and the bit-packing window in the table's
-            Huff &H = S.u.h;
-            hgdef::HuffWG &W = *reinterpret_cast<hgdef::HuffWG *>(S.in32);
+            // the staged input and the hash table are dead now: the collective Huffman phase (deflate_huff_wg.h), the codes and the bit-packing window
+            // take their LDS (the union in Lds)
+            Huff &H = S.u.e.h;
+            hgdef::HuffWG &W = S.u.e.w;
             if (tid == 0) S.lfreq[256] = 1;                                       // end of block
             HD_T0(th);
             hgdef::wg_code_lengths<WG, 15>(W, S.lfreq, 286, H.ll_len, S.dfreq, 30, H.d_len, tid);
@@ -594,12 +598,12 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
             for (uint32_t i = tid; i < n; i += WG) o8[hoff + 5 + i] = src[i];      // (the staged copy may hold the Huffman scratch by now)
             total_len = hoff + 5u + n + (mode == 1 ? 0u : 8u);
         } else {
-            Huff &H = S.u.h;
+            Huff &H = S.u.e.h;
             for (int i = tid; i < 520; i += WG) H.obuf[i] = 0;
             __syncthreads();
             uint32_t bitpos = hoff * 8u;
             {   // the dynamic-block header: (value, bit count) items of wg_dynamic_header, one per thread
-                const hgdef::HuffWG &W = *reinterpret_cast<const hgdef::HuffWG *>(S.in32);
+                const hgdef::HuffWG &W = S.u.e.w;
                 const uint32_t nitems = W.nitems;
                 for (uint32_t i0 = 0; i0 < nitems; i0 += WG) {
                     const uint32_t i = i0 + (uint32_t)tid;
@@ -658,7 +662,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
         }
         HD_TACC(4, tp); HD_TACC(0, tb);
 #ifdef HG_PROFILE
-        if (tid == 0) { atomicAdd(&g_dprof[5], 1ull); for (int k = 0; k < 10; k++) if (k != 5) atomicAdd(&g_dprof[k], dacc[k]); }
+        if (tid == 0) { atomicAdd(&g_dprof[5], 1ull); for (int k = 0; k < 16; k++) if (k != 5) atomicAdd(&g_dprof[k], dacc[k]); }
 #endif
     }
 }

@@ -69,7 +69,8 @@ int main(int argc, char **argv) {
             if (p_dprof) { unsigned long long pr[16]; p_dprof(pr, 1); double tot = (double)pr[0];
                 printf("   deflate in-kernel time per block %.0f ticks: stage+crc %.1f%%  match+parse %.1f%%  huffman %.1f%%  emit %.1f%%\n",
                        tot / pr[5], 100 * pr[1] / tot, 100 * pr[2] / tot, 100 * pr[3] / tot, 100 * pr[4] / tot);
-                printf("      match detail: candidates %.1f%%  barrier-wait %.1f%%  insert+parse %.1f%%  compact+hist %.1f%%\n", 100 * pr[6] / tot, 100 * pr[7] / tot, 100 * pr[8] / tot, 100 * pr[9] / tot); }
+                printf("      match detail (wave 0's clock): tier1 %.1f%%  wait %.1f%%  walk1 %.1f%%  tier-2 list %.1f%%  pairs %.1f%%  extend %.1f%%  merge %.1f%%  walk2+publish %.1f%%  emit %.1f%%\n", 100 * pr[6] / tot, 100 * pr[7] / tot, 100 * pr[8] / tot, 100 * pr[9] / tot,
+                       100 * pr[10] / tot, 100 * pr[11] / tot, 100 * pr[12] / tot, 100 * pr[13] / tot, 100 * pr[14] / tot); }
             CK(hipFree(dslots)); CK(hipFree(ddd)); CK(hipFree(dclen));
         }
         fflush(stdout);

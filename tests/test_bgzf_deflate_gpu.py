@@ -128,13 +128,13 @@ def test_deflate_output_is_reproducible(engine):
 
 
 def test_block_sizes_around_the_input_ring(engine, oracle):
-    """The kernel stages a block as a 36 KiB ring (bgzf_deflate.hip: RING = 36864, topped up 2 KiB at a time, the CRC of a longer block joined from
+    """The kernel stages a block as a 34.8 KiB ring (bgzf_deflate.hip: RING = 35616, topped up 2 KiB at a time, the CRC of a longer block joined from
     tail + head): block lengths just below / at / above the ring, around the first top-ups and up to the maximum, at the three level classes,
     on data with matches near and far (so that look-backs cross the wrap)."""
     rng = np.random.default_rng(11)
     unit = synth.fastq(70_000)
     noise = rng.integers(0, 256, 70_000, dtype=np.uint8).tobytes()
-    ring = 36864
+    ring = 35616
     sizes = [ring - 49, ring - 48, ring - 17, ring - 1, ring, ring + 1, ring + 15, ring + 16, ring + 17, ring + 63, ring + 64, ring + 65,
              ring + 2047, ring + 2048, ring + 2049, ring + 4096 + 31, 40_000, 50_001, 65_279, 65_280]
     for level in (1, 5, 6):
