@@ -164,7 +164,9 @@ __device__ __forceinline__ uint32_t common_prefix_fixed(const uint32_t *in32, ui
 #pragma unroll
     for (int j = 0; j <= NB / 4; j++) w[j] = q[j];
     // position of the first differing bit: v_ffbl_b32 answers -1 for "no bit set", OR-ing the dword's bit offset into that leaves it -1, so a
-    // plain unsigned minimum over the dwords finds the first difference (4.5 instructions per dword, no condition registers)
+    // plain unsigned minimum over the dwords finds the first difference (4.5 instructions per dword, no condition registers).
+    // (Round 6 tried ONE asm statement for all 35 instructions -- the compiler pads every asm statement with an s_nop, four per candidate -- and lost
+    // 3 %: the statement needs all nine dwords before it starts, the per-dword form overlaps the LDS returns with the arithmetic.)
     uint32_t m = 0xffffffffu;
 #pragma unroll
     for (int j = 0; j < NB / 4; j++) {
@@ -474,15 +476,19 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 if (wave == w_pub) {
                     // The slot a position gets inside its bucket comes from an atomic counter; ONE wavefront inserts the four groups of 64 one after the
                     // other (a wave's own LDS atomics resolve in lane order): the table -- and with it the compressed bytes -- is the same on every run.
+                    // (the four groups' reads, atomics and stores are issued back to back -- LDS operations of one wavefront complete in order)
+                    uint32_t hh[4], old[4];
+#pragma unroll
+                    for (int s = 0; s < 4; s++) hh[s] = (uint32_t)S.hk[64u * s + (uint32_t)lane];
 #pragma unroll
                     for (int s = 0; s < 4; s++) {
-                        const uint32_t q = 64u * s + (uint32_t)lane, pq = c0 + q;
-                        if (pq + 4u <= n) {
-                            const uint32_t hh = (uint32_t)S.hk[q];
-                            const uint32_t sh = (hh & 3u) * 8u;
-                            const uint32_t old = atomicAdd(&S.cnt32[hh >> 2], 1u << sh);
-                            S.u.m.tab[hh * MAX_WAYS + ((old >> sh) & 0xffu) % (uint32_t)WAYS] = (uint16_t)pq;
-                        }
+                        const bool v = c0 + 64u * s + (uint32_t)lane + 4u <= n;
+                        old[s] = atomicAdd(&S.cnt32[hh[s] >> 2], v ? 1u << ((hh[s] & 3u) * 8u) : 0u);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const uint32_t pq = c0 + 64u * s + (uint32_t)lane;
+                        if (pq + 4u <= n) S.u.m.tab[hh[s] * MAX_WAYS + ((old[s] >> ((hh[s] & 3u) * 8u)) & 0xffu) % (uint32_t)WAYS] = (uint16_t)pq;
                     }
                 } else if (wave == w_fill && refill) {
                     const uint32_t r = ro(hi + (uint32_t)lane * 32u) >> 2;
@@ -514,12 +520,17 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 __syncthreads();
                 HD_TACCM(10, tq);
                 // ---- chain the wavefronts' walks: entry of the next = exit of this one - 64 ---------------------------------------------------------------
+                // (lane i fetches the four wavefronts' records of entry i in one go; the chain itself is then four v_readlane steps instead of four
+                // dependent LDS round trips)
+                uint32_t xs[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) xs[s] = (uint32_t)S.exitp[64u * s + (uint32_t)lane];
                 uint32_t e = carry, cnt = ntok, my_e = 0, my_base = 0;
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     if (s == wave) { my_e = e; my_base = cnt; }
                     if (e < 64u) {
-                        const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)S.exitp[64u * s + e]);
+                        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)xs[s], (int)e);
                         cnt += v >> 9; e = (v & 511u) - 64u;
                     } else e -= 64u;
                 }
