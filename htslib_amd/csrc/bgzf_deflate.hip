@@ -394,9 +394,10 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                     }
                 }
                 // ---- the candidates ------------------------------------------------------------------------------------------------------------
-                // A position that cannot start a match (the block's last three bytes, the tail of the last chunk) has maxl = 0: every length clamps to 0.
+                // A position that cannot start a match (the block's first byte, its last three, the tail of the last chunk) has maxl = 0: every length
+                // clamps to 0.
                 const bool hashable = p + 4u <= n;
-                const uint32_t maxl = !hashable ? 0u : n - p < 258u ? n - p : 258u;
+                const uint32_t maxl = !hashable || p == 0u ? 0u : n - p < 258u ? n - p : 258u;
                 const uint32_t rp = hashable ? ro(p) : 0u;
                 uint32_t own[8];
                 load_string<32>(in32, rp, own);
@@ -408,6 +409,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 {
                     static_assert(WAYS % 4 == 0, "the ways are read eight bytes at a time");
                     const uint32_t *row32 = (const uint32_t *)&S.u.m.tab[h * MAX_WAYS];         // 24-byte rows, 8-byte aligned
+                    const uint32_t dcap = p < WINDOW + 1u ? p : WINDOW + 1u;
 #pragma unroll
                     for (int k = 0; k < WAYS / 2; k += 2) {
                         const uint2 rw = *(const uint2 *)(row32 + k);
@@ -415,21 +417,22 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
 #pragma unroll
                         for (int w = 0; w < 4; w++) {
                             const uint32_t c = (cw[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
-                            // an empty slot (0xffff) lies "ahead" of p: its distance wraps to a huge number and fails the window test like a stale entry
+                            // No validity test: an empty slot (0xffff lies "ahead" of p: the distance wraps to a huge number) or an entry that has left
+                            // the window is CLAMPED to the farthest position the ring still holds (or the block's first byte) -- a real position, whatever
+                            // it matches is a real match.  One v_min instead of a compare and two selects (and the wait states between them).
                             const uint32_t d = p - c;
-                            const bool ok = d <= WINDOW;
-                            const uint32_t dd = ok ? d : 0u;                          // (a failed candidate compares the position with itself; its key is dropped)
+                            const uint32_t dd = d < dcap ? d : dcap;
                             const uint32_t rc0 = rp - dd, rc1 = rc0 + RING;           // ring offset of the candidate: rp - d, + RING when that wrapped
                             uint32_t l = common_prefix_fixed<32>(in32, rc0 < rc1 ? rc0 : rc1, own);
                             l = l < maxl ? l : maxl;
-                            const uint32_t k1 = ok ? (l << 16) | (32768u - d) : 0u;
+                            const uint32_t k1 = (l << 16) + (32768u - dd);
                             key = k1 > key ? k1 : key;
                         }
                     }
                 }
                 {   // distance 1 (runs are never in the table: candidates come from earlier chunks).  A match of length L at distance 1 means the L bytes
                     // from p on all equal the byte before p: compare the position's own bytes with that byte, no second string to fetch
-                    const uint32_t splat = (uint32_t)in8[p >= 1u ? ro(p - 1u) : 0u] * 0x01010101u;
+                    const uint32_t splat = (uint32_t)in8[p >= 1u ? ro(p - 1u) : 0u] * 0x01010101u;      // (p = 0: maxl = 0)
                     uint32_t m = 0xffffffffu;
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
@@ -442,17 +445,19 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                     m >>= 3;
                     uint32_t l = m < 32u ? m : 32u;
                     l = l < maxl ? l : maxl;
-                    const uint32_t k1 = p >= 1u ? (l << 16) | 32767u : 0u;
+                    const uint32_t k1 = (l << 16) | 32767u;
                     key = k1 > key ? k1 : key;
                 }
                 HD_TACCM(6, tq);
                 // ---- the nearest candidate that got through all 32 bytes goes on alone, 16 bytes per dependent round; the others keep what they have proven
                 if ((key >> 16) == 32u && maxl > 32u) {
-                    const uint32_t c = p - (32768u - (key & 0xffffu));
+                    const uint32_t dist = 32768u - (key & 0xffffu);
+                    const uint32_t rc0 = rp - dist, rc1 = rc0 + RING, rc = rc0 < rc1 ? rc0 : rc1;      // ring offsets of both strings; + l stays below 2 * RING
                     uint32_t l = 32u;
                     while (l < maxl) {
                         unsigned long long a0, a1, b0, b1;
-                        load16(in32, ro(c + l), a0, a1); load16(in32, ro(p + l), b0, b1);
+                        const uint32_t qa = rc + l, qb = rp + l;
+                        load16(in32, qa - RING < qa ? qa - RING : qa, a0, a1); load16(in32, qb - RING < qb ? qb - RING : qb, b0, b1);
                         const unsigned long long x0 = a0 ^ b0, x1 = a1 ^ b1;
                         if (x0) { l += (uint32_t)__builtin_ctzll(x0) >> 3; break; }
                         if (x1) { l += 8u + ((uint32_t)__builtin_ctzll(x1) >> 3); break; }
