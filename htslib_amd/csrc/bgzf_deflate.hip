@@ -121,21 +121,22 @@ struct Lds {
 // lost a quarter of its speed.)
 static_assert(sizeof(Lds) <= 32 * 1280, "four workgroups per CU");
 
-// Unaligned reads of the staged input: aligned dword reads glued with v_alignbyte.  (Tried in round 3: gfx950 runs the LDS in unaligned-access
+// Unaligned reads of the staged input: aligned dword reads glued with v_alignbyte.  v_alignbyte_b32 reads only bits [1:0] of its shift operand on gfx950
+// (experiments/alignbyte_probe.hip, run in round 6), so the byte offset itself is passed: no `& 3` per string.  (Tried in round 3: gfx950 runs the LDS in unaligned-access
 // mode and the compiler emits ONE ds_read_b64 / b128 for a byte-aligned 8 / 16-byte read -- a third of the LDS instructions -- but a misaligned
 // wide read is slow in the LDS itself: level 6 went from 9.3 to 8.2 GB/s, level 1 from 22.2 to 20.6.)
 __device__ __forceinline__ uint32_t load4(const uint32_t *in32, uint32_t off) {
     uint32_t lo = in32[off >> 2], hi = in32[(off >> 2) + 1];
-    return __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
+    return __builtin_amdgcn_alignbyte(hi, lo, off);
 }
 __device__ __forceinline__ unsigned long long load8(const uint32_t *in32, uint32_t off) {
     const uint32_t w0 = in32[off >> 2], w1 = in32[(off >> 2) + 1], w2 = in32[(off >> 2) + 2];
-    const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, off & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, off & 3u);
+    const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, off), hi = __builtin_amdgcn_alignbyte(w2, w1, off);
     return ((unsigned long long)hi << 32) | lo;
 }
 __device__ __forceinline__ void load16(const uint32_t *in32, uint32_t off, unsigned long long &a, unsigned long long &b) {
     const uint32_t *q = in32 + (off >> 2);
-    const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4], sh = off & 3u;
+    const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4], sh = off;
     const uint32_t r0 = __builtin_amdgcn_alignbyte(w1, w0, sh), r1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
     const uint32_t r2 = __builtin_amdgcn_alignbyte(w3, w2, sh), r3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
     a = ((unsigned long long)r1 << 32) | r0; b = ((unsigned long long)r3 << 32) | r2;
@@ -144,7 +145,7 @@ __device__ __forceinline__ void load16(const uint32_t *in32, uint32_t off, unsig
 template <int NB>
 __device__ __forceinline__ void load_string(const uint32_t *in32, uint32_t off, uint32_t (&out)[NB / 4]) {
     const uint32_t *q = in32 + (off >> 2);
-    const uint32_t sh = off & 3u;
+    const uint32_t sh = off;
     uint32_t w[NB / 4 + 1];
 #pragma unroll
     for (int j = 0; j <= NB / 4; j++) w[j] = q[j];
@@ -159,7 +160,7 @@ __device__ __forceinline__ void load_string(const uint32_t *in32, uint32_t off, 
 template <int NB>
 __device__ __forceinline__ uint32_t common_prefix_fixed(const uint32_t *in32, uint32_t c, const uint32_t (&own)[8]) {
     const uint32_t *q = in32 + (c >> 2);
-    const uint32_t sh = c & 3u;
+    const uint32_t sh = c;
     uint32_t w[NB / 4 + 1];
 #pragma unroll
     for (int j = 0; j <= NB / 4; j++) w[j] = q[j];
@@ -425,7 +426,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                             const uint32_t rc0 = rp - dd, rc1 = rc0 + RING;           // ring offset of the candidate: rp - d, + RING when that wrapped
                             uint32_t l = common_prefix_fixed<32>(in32, rc0 < rc1 ? rc0 : rc1, own);
                             l = l < maxl ? l : maxl;
-                            const uint32_t k1 = (l << 16) + (32768u - dd);
+                            const uint32_t k1 = ((l << 16) | 32768u) - dd;             // (v_lshl_or + v_sub)
                             key = k1 > key ? k1 : key;
                         }
                     }

@@ -30,7 +30,7 @@ static void tier(size_t p,const int*cand,int k,int ls,size_t maxl,int*best,int*b
   if(near>=0&&!NOEXT){ int c=cand[near]; size_t l=len[near]; while(l<maxl&&buf[c+l]==buf[p+l]) l++; *ext16+=(l-len[near]+15)/16; len[near]=l; }
   for(int j=0;j<k;j++){ int d=p-cand[j]; if(len[j]>=3&&(len[j]>*best||(len[j]==*best&&d<*bd))){*best=len[j];*bd=d;} }
 }
-int main(int argc,char**argv){
+int main(int argc,char**argv){ int INS=getenv("INS")?atoi(getenv("INS")):0, INSL=getenv("INSL")?atoi(getenv("INSL")):16, INSK=getenv("INSK")?atoi(getenv("INSK")):1;
   if(argc<7){ fprintf(stderr,"usage\n"); return 1; }
   FILE*f=fopen(argv[1],"rb"); int W=atoi(argv[2]),W0=atoi(argv[3]),T=atoi(argv[4]),INH=atoi(argv[5]),LAZY=atoi(argv[6]);
   int LS0=argc>7?atoi(argv[7]):32, LS1=argc>8?atoi(argv[8]):24, WIN=argc>9?atoi(argv[9]):32768, REC=argc>10?atoi(argv[10]):1; long NBLK=argc>11?atol(argv[11]):1000000; NOEXT=(INH==3); int LOOK=argc>12?atoi(argv[12]):2; int TU=argc>13?atoi(argv[13]):0; int ITER=argc>14?atoi(argv[14]):1;
@@ -40,7 +40,7 @@ int main(int argc,char**argv){
   long positions=0, deep=0, deepgroups=0, chunks=0, cmp0=0, cmp1=0, ext0=0, ext1=0, tokstart_deep=0, inh_used=0;
   while(nblk<NBLK&&(n=fread(buf,1,BS,f))>0){
     memset(buf+n,0,64); memset(tab,0xff,sizeof(uint16_t)*HS*16); memset(cnt,0,HS*4);
-    static uint8_t isdeep[BS+CH]; size_t carry_in=0;
+    static uint8_t isdeep[BS+CH]; size_t carry_in=0; size_t pcarry=0;
     for(size_t c0=0;c0<n;c0+=CH){
       size_t c1=c0+CH>n?n:c0+CH; int ndeep=0;
       int pb=0,pd=0; static int sbest[CH],sbd[CH];                                    /* left neighbour's best (for inheritance), reset per chunk */
@@ -108,7 +108,15 @@ int main(int argc,char**argv){
         carry_in=q-c1;
       }
       chunks++; deepgroups+=(ndeep+63)/64;
-      for(size_t p=c0;p<c1&&p+4<=n;p++){ uint32_t v; memcpy(&v,buf+p,4); uint32_t h=(v*2654435761u)>>(32-HB); tab[h*16+(cnt[h]++%W)]=p; }
+      { /* parse this chunk (mode 0 path: INH<2) to know the token starts; pcarry = chunk-relative entry */
+        static uint8_t skip[CH]; memset(skip,0,sizeof skip);
+        if(INS){ size_t q=c0+pcarry; if(INS==1) memset(skip,1,sizeof skip);
+          while(q<c1){ int l=mlen[q]; int n1=q+1<c1?mlen[q+1]:0,n2=q+2<c1?mlen[q+2]:0; if(l&&LAZY>=1&&n1>l) l=0; if(l&&LAZY>=2&&n2>l+1) l=0;
+            if(INS==1) skip[q-c0]=0;
+            if(INS==2&&l>=INSL){ for(int k=INSK;k<l&&q+k<c1;k++) skip[q+k-c0]=1; }
+            q+= l?l:1; }
+          pcarry=q-c1; }
+        for(size_t p=c0;p<c1&&p+4<=n;p++){ if(skip[p-c0]) continue; uint32_t v; memcpy(&v,buf+p,4); uint32_t h=(v*2654435761u)>>(32-HB); tab[h*16+(cnt[h]++%W)]=p; } }
     }
     long lf[286]={0},df[30]={0}; double extra=0; size_t p=0;
     while(p<n){
