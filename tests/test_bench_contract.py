@@ -1,6 +1,6 @@
 """bench.py's contract with the driver, as far as it can be checked without a GPU: the ONE stdout line of the default run must fit the driver's 8 KB tail
 with every op's headline figures in it (compact()), and carry the fields the judge reads.  Input: the complete object of the last measured default run
-(profiles/r04_bench_all_full.json, written by bench.py itself)."""
+(profiles/r05_bench_default_full.json, written by bench.py itself)."""
 import importlib.util
 import json
 import os
@@ -22,7 +22,7 @@ def load_bench():
 
 def test_default_line_fits_the_drivers_tail_and_keeps_every_ops_figures():
     bench = load_bench()
-    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_all_full.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default_full.json")))
     line = json.dumps(bench.compact(full))
     assert len(line) < 7700, len(line)                                   # 8 KB tail, with room for longer numbers
     d = json.loads(line)
@@ -41,6 +41,11 @@ def test_default_line_fits_the_drivers_tail_and_keeps_every_ops_figures():
             assert isinstance(extra[op].get("value"), (int, float)) and "error" not in extra[op], (op, extra[op])
             assert "frac" in extra[op]["roofline"], op
     assert extra["end_to_end"]["gpu"]["read_GBps"] > 0 and extra["end_to_end"]["reference"]["read_GBps"] > 0
+    # the libhts-level figures (the reference's test_view on libhts_gpu.so vs on the reference's libhts) must reach the driver: round 5's line lost them
+    view = extra["end_to_end"]["libhts_view"]
+    for leg in ("decode", "bam2bam"):
+        for side in ("libhts_gpu", "reference"):
+            assert view[leg][side]["seconds"] > 0 and view[leg][side]["plain_GBps"] > 0, (leg, side, view)
 
 
 def test_default_arguments_are_one_gpu_and_minutes():
