@@ -1135,11 +1135,14 @@ def libhts_view(run: Run, bam_path: str, plain_bytes: int, nreads: int = 12_000_
     return res
 
 
-def libhts_view_cram(run: Run, gpu: str, ref: str, ref_threads, copies: int = 16, nrec: int = 10000):
+def libhts_view_cram(run: Run, gpu: str, ref: str, ref_threads, copies: int = 64, nrec: int = 10000):
     """libhts-level CRAM figures (north_star: "samtools/bcftools see a drop-in libhts"): test_view on libhts_gpu.so vs on the reference's libhts,
       cram_decode = view -@T -B in.cram              (cram_decode_slice on the pool's threads, cram_uncompress_block per block)
       cram_encode = view -@T -C -o version=3.0 in.bam (bam_read1 + cram_encode_slice + cram_compress_block2, to /dev/null)
-    on the 64-slice (640 000 records) workload the record baselines use, at the writer's default level (gzip + rANS 4x8).  Whole-process wall clock, best of 2."""
+    on 256 slices (2 560 000 records) of the record baselines' workload, at the writer's default level (gzip + rANS 4x8).  Whole-process wall clock, best of 2.
+    libhts_gpu runs with -@16 and -@64: its pool threads mostly WAIT (a slice's blocks are decoded ahead of the call that asks for them / compressed behind the
+    call that names them, in device batches that take ~0.1-0.2 s whatever their size -- one 1.5 MB quality stream through the 4-way rANS coder is one chain), so the
+    number of slices in flight, not the cores, sets its rate."""
     import subprocess
     import numpy as np
     from htslib_amd import _native as nat, synth_cram
@@ -1167,7 +1170,7 @@ def libhts_view_cram(run: Run, gpu: str, ref: str, ref_threads, copies: int = 16
 
         out = {"cram_records": w.nrec, "cram_file_bytes": os.path.getsize(cram), "cram_bam_GB": round(plain / 1e9, 3)}
         for mode in ("cram_decode", "cram_encode"):
-            tries_g = [one(gpu, t, mode) for t in (4, 16)]
+            tries_g = [one(gpu, t, mode) for t in (16, 64)]
             good = [x for x in tries_g if "seconds" in x]
             out[mode] = {"libhts_gpu": min(good, key=lambda x: x["seconds"]) if good else tries_g[-1]}
             if not run.args.no_cpu_baseline:

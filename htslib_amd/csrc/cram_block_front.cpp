@@ -19,8 +19,11 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 #include "hts_cram_gpu.h"
 #include "hts_hfile_abi.h"
@@ -127,7 +130,7 @@ void load() {
     for (const char *n : {"liblzma.so.5", "liblzma.so"}) if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) { lzma = (lzma_fn)dlsym(h, "lzma_stream_buffer_decode"); if (lzma) break; }
 }
 // 0 / -1, the block left untouched on failure
-int inflate(cram_block *x) {
+int inflate(cram_block *x, bool keep_input) {
     std::call_once(once, load);
     const bool is_bz2 = x->method == BZIP2;
     if (is_bz2 ? !bz2 : !lzma) {
@@ -147,15 +150,16 @@ int inflate(cram_block *x) {
         ok = lzma(&memlimit, 0, nullptr, x->data, &in_pos, (size_t)x->comp_size, out, &got, (size_t)x->uncomp_size) == 0 && in_pos == (size_t)x->comp_size;   // LZMA_OK, whole input used
     }
     if (!ok || got != (size_t)x->uncomp_size) { free(out); return -1; }   // the reference's size check (cram_io.c:1639-1642, 1655-1658)
-    free(x->data);
+    if (!keep_input) free(x->data);
     x->data = out; x->alloc = got; x->method = RAW;
     return 0;
 }
 }  // namespace hostlib
 
 // ================================================================================ batch workers
-// Decode a set of blocks in one engine round.  rc[i] = 0 / -1.
-void uncompress_batch(cram_block **b, int n, int *rc) {
+// Decode a set of blocks in one engine round.  rc[i] = 0 / -1.  keep_input: the compressed bytes a block came with are NOT freed when its data
+// pointer is replaced (read-ahead works on shadow copies of the callers' blocks: the originals keep their payload until they are asked for).
+void uncompress_batch(cram_block **b, int n, int *rc, bool keep_input = false) {
     hg_ctx *ctx = engine();
     std::vector<int> todo;                                     // blocks that need the device
     for (int i = 0; i < n; i++) rc[i] = 0;
@@ -181,7 +185,7 @@ void uncompress_batch(cram_block **b, int n, int *rc) {
         if (x->uncomp_size == 0) { x->method = RAW; continue; }            // blank block (cram_io.c:1594-1598)
         if (x->method == RAW) continue;
         if (x->uncomp_size < 0 || x->comp_size < 0 || (int)x->method < 0 || (int)x->method > TOK3) { rc[i] = -1; continue; }
-        if (x->method == BZIP2 || x->method == LZMA) { rc[i] = hostlib::inflate(x); continue; }    // the system's library, as in the reference
+        if (x->method == BZIP2 || x->method == LZMA) { rc[i] = hostlib::inflate(x, keep_input); continue; }    // the system's library, as in the reference
         todo.push_back(i);
     }
     if (todo.empty()) return;
@@ -208,7 +212,7 @@ void uncompress_batch(cram_block **b, int n, int *rc) {
             continue;
         }
         if (x->method == RANSPR || x->method == ARITH || x->method == TOK3) x->orig_method = x->method;   // cram_io.c:1706,1725,1740
-        free(x->data);
+        if (!keep_input) free(x->data);
         x->data = out[k];
         x->alloc = ol[k];
         x->method = RAW;
@@ -260,9 +264,30 @@ void compress_batch(CompJob *jobs, int n) {
         }
         std::sort(locks.begin(), locks.end());
         locks.erase(std::unique(locks.begin(), locks.end()), locks.end());
+        // The callers' metrics locks are held while the metrics are READ (a private copy of every object the batch names) and while the results
+        // are WRITTEN BACK, not across the engine call in between: cram_compress_slice takes fd->metrics_lock at its top (cram_encode.c:877), so a
+        // lock held for the ~100 ms of a device batch kept every other pool thread from even recording its slice (round 6: one or two slices per
+        // batch at -@16).  The reference does the same around its codec calls (cram_io.c:1979-2056, 2101-2236).  One batch at a time works on the
+        // copies (batch_mu); `unpackable`, which cram_compress_slice sets from outside, survives a change made during the call.
+        static std::mutex batch_mu;
+        std::lock_guard<std::mutex> one_batch(batch_mu);
+        std::vector<hg_cram_metrics *> uniq;
+        for (size_t k = 0; k < m; k++) if (met[k] && std::find(uniq.begin(), uniq.end(), met[k]) == uniq.end()) uniq.push_back(met[k]);
+        std::vector<hg_cram_metrics> copy(uniq.size());
+        std::vector<int> unp0(uniq.size());
         for (auto l : locks) pthread_mutex_lock(l);
-        int r = oom ? HG_ENOMEM : ctx ? hg_cram_compress_blocks_metrics_fqz_host(ctx, m, met.data(), set.data(), level, version >> 8, in.data(), il.data(),
+        for (size_t u = 0; u < uniq.size(); u++) { copy[u] = *uniq[u]; unp0[u] = uniq[u]->unpackable; }
+        for (auto it = locks.rbegin(); it != locks.rend(); ++it) pthread_mutex_unlock(*it);
+        std::vector<hg_cram_metrics *> metc(m, nullptr);
+        for (size_t k = 0; k < m; k++) if (met[k]) metc[k] = &copy[(size_t)(std::find(uniq.begin(), uniq.end(), met[k]) - uniq.begin())];
+        int r = oom ? HG_ENOMEM : ctx ? hg_cram_compress_blocks_metrics_fqz_host(ctx, m, metc.data(), set.data(), level, version >> 8, in.data(), il.data(),
                                                                                  fq.data(), out.data(), ol.data(), used.data()) : HG_ENODEV;
+        for (auto l : locks) pthread_mutex_lock(l);
+        for (size_t u = 0; u < uniq.size(); u++) {
+            const int now = uniq[u]->unpackable;
+            *uniq[u] = copy[u];
+            if (now != unp0[u]) uniq[u]->unpackable = now;
+        }
         for (auto it = locks.rbegin(); it != locks.rend(); ++it) pthread_mutex_unlock(*it);
         for (size_t k = 0; k < m; k++) {
             CompJob &j = jobs[todo[g0 + k]];
@@ -296,20 +321,30 @@ struct Coalescer {
     bool leader = false;
     void (*run)(Req **, int);
 
+    // adaptive: a leader waits 1/8 of the previous batch's run time for company, between the fixed linger and 10 ms -- when a batch takes 100 ms (a slice's
+    // 1.5 MB quality stream through a 4-way rANS coder is one chain), the pool threads it releases come back within a few ms of each other, and the
+    // first of them used to leave alone with ONE slice while the other fourteen waited out its 100 ms (round 6: batches of 1, 14, 1, 14 ... slices)
+    bool adaptive = false;
+    int last_run_us = 0;
+
     void submit(Req *r) {
         std::unique_lock<std::mutex> lk(m);
         queue.push_back(r);
         while (!r->done) {
             if (!leader) {
                 leader = true;
+                const int wait_us = adaptive ? std::max(linger_us(), std::min(10000, last_run_us / 8)) : linger_us();
                 lk.unlock();
-                std::this_thread::sleep_for(std::chrono::microseconds(linger_us()));
+                std::this_thread::sleep_for(std::chrono::microseconds(wait_us));
                 lk.lock();
                 std::vector<Req *> batch;
                 batch.swap(queue);
                 lk.unlock();
+                const auto t0 = std::chrono::steady_clock::now();
                 run(batch.data(), (int)batch.size());
+                const int took = (int)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
                 lk.lock();
+                last_run_us = took;
                 for (Req *q : batch) q->done = true;
                 leader = false;
                 cv.notify_all();
@@ -340,6 +375,134 @@ void run_comp(CompReq **r, int n) {
 Coalescer<UncReq> g_unc{{}, {}, {}, false, run_unc};
 Coalescer<CompReq> g_comp{{}, {}, {}, false, run_comp};
 
+// ================================================================================ read-ahead decode of the blocks cram_read_block hands out
+// The reference decodes a slice's blocks one call at a time (cram_decode_slice's loop, cram/cram_decode.c:624-627), each call a device round trip
+// of a millisecond or more here: 25 blocks per slice in a row made `test_view file.cram` on libhts_gpu.so 37 times slower than stock htslib
+// (round 6's first libhts-level CRAM figure).  But the library SEES every block long before it is asked to decode it: cram_read_slice
+// (cram/cram_io.c) reads all blocks of a slice through cram_read_block -- ours -- on the reading thread, which runs ahead of the pool's decode jobs.
+// So a compressed block is queued for decoding the moment it is read; one thread drains the queue in batches (a whole slice, usually several, per
+// engine round) into SHADOW copies of the blocks; cram_uncompress_block then only waits for its block's shadow and takes the result over.  The caller's
+// block is not touched in between (it keeps its compressed payload: cram_write_block / cram_copy_slice style callers that never decode see what they
+// read), cram_free_block drops a result nobody asked for.  HTS_GPU_CRAM_READAHEAD=0 turns it off.
+struct Ahead { cram_block shadow; int rc; bool done; };
+struct AheadState {
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::unordered_map<cram_block *, Ahead *> map;     // caller's block -> its shadow (until asked for or freed)
+    std::vector<Ahead *> queue;
+    bool started = false;
+};
+AheadState &ahead() { static AheadState *a = new AheadState(); return *a; }      // lives until exit (its thread is detached)
+bool ahead_enabled() {
+    static const bool on = [] { const char *e = getenv("HTS_GPU_CRAM_READAHEAD"); return !(e && e[0] == '0'); }();
+    return on;
+}
+void ahead_main() {
+    AheadState &A = ahead();
+    for (;;) {
+        std::vector<Ahead *> batch;
+        {
+            std::unique_lock<std::mutex> lk(A.m);
+            A.cv_work.wait(lk, [&] { return !A.queue.empty(); });
+            lk.unlock();
+            std::this_thread::sleep_for(std::chrono::microseconds(150));      // the rest of the slice is microseconds behind its first block
+            lk.lock();
+            batch.swap(A.queue);
+        }
+        std::vector<cram_block *> b(batch.size()); std::vector<int> rc(batch.size());
+        for (size_t i = 0; i < batch.size(); i++) b[i] = &batch[i]->shadow;
+        static const bool stats = getenv("HTS_GPU_STATS") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        size_t cb = 0, ub = 0; int meth[16] = {0};
+        if (stats) for (cram_block *x : b) { cb += (size_t)x->comp_size; ub += (size_t)x->uncomp_size; meth[(int)x->method & 15]++; }
+        uncompress_batch(b.data(), (int)b.size(), rc.data(), true);
+        if (stats) fprintf(stderr, "[htsgpu stats] cram read-ahead batch: %zu blocks (gzip %d bz2 %d lzma %d rans4x8 %d nx16 %d arith %d fqz %d tok3 %d), %.2f -> %.2f MB, %.2f ms\n", b.size(),
+                           meth[1], meth[2], meth[3], meth[4], meth[5], meth[6], meth[7], meth[8], cb / 1e6, ub / 1e6,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        {
+            std::lock_guard<std::mutex> lk(A.m);
+            for (size_t i = 0; i < batch.size(); i++) { batch[i]->rc = rc[i]; batch[i]->done = true; }
+        }
+        A.cv_done.notify_all();
+    }
+}
+void ahead_submit(cram_block *b) {
+    if (!ahead_enabled() || !b || b->method == RAW || b->uncomp_size <= 0 || b->comp_size <= 0) return;
+    AheadState &A = ahead();
+    Ahead *a = new Ahead{*b, 0, false};
+    std::lock_guard<std::mutex> lk(A.m);
+    if (!A.started) { A.started = true; std::thread(ahead_main).detach(); }
+    A.map[b] = a;
+    A.queue.push_back(a);
+    A.cv_work.notify_one();
+}
+// the shadow of a block, finished, removed from the table (nullptr: the block was never queued)
+Ahead *ahead_take(cram_block *b) {
+    AheadState &A = ahead();
+    std::unique_lock<std::mutex> lk(A.m);
+    if (A.map.empty()) return nullptr;
+    auto it = A.map.find(b);
+    if (it == A.map.end()) return nullptr;
+    Ahead *a = it->second;
+    A.cv_done.wait(lk, [&] { return a->done; });
+    A.map.erase(it);
+    return a;
+}
+
+
+// ================================================================================ write-behind compression of a slice's blocks
+// The reference compresses a slice one cram_compress_block2 call at a time (cram_compress_slice, cram/cram_encode.c:803-988: ~25 calls in a row,
+// then a sweep over whatever is still RAW), each call a device round trip here: `test_view -C` on libhts_gpu.so ran 28 times slower than stock
+// htslib.  Nothing looks at a block between those calls and cram_encode_slice_header, which starts with cram_new_block -- ours.  So a call that
+// names its slice only RECORDS the job (block, metrics, method set, level; a second call for a block of the same slice is the final sweep's: it
+// applies if the block is still RAW afterwards); the recorded jobs run as ONE engine batch -- together with the slices other pool threads have
+// recorded meanwhile (Coalescer) -- when the thread next enters the block layer with anything else (cram_new_block, cram_free_block,
+// cram_write_block, cram_block_size, a block without a slice, another slice).  Metrics see the jobs in the reference's order.  A failed batch
+// leaves the blocks RAW (a valid file) and logs the error: the call that could have returned -1 has returned.  HTS_GPU_CRAM_WRITEBEHIND=0: off.
+struct ManyReq { CompJob *jobs; int n; bool done; };
+void run_many(ManyReq **r, int n) {
+    std::vector<CompJob> all;
+    for (int i = 0; i < n; i++) all.insert(all.end(), r[i]->jobs, r[i]->jobs + r[i]->n);
+    compress_batch(all.data(), (int)all.size());
+    size_t at = 0;
+    for (int i = 0; i < n; i++) for (int k = 0; k < r[i]->n; k++) r[i]->jobs[k].rc = all[at++].rc;
+}
+Coalescer<ManyReq> g_many{{}, {}, {}, false, run_many, true};
+void compress_many(CompJob *jobs, int n) {
+    if (n <= 0) return;
+    ManyReq r{jobs, n, false};
+    g_many.submit(&r);
+}
+struct FqzKeep { std::vector<uint32_t> len, flags; hg_fqz_slice fq; };
+struct Behind {
+    cram_slice *slice = nullptr;
+    std::vector<CompJob> first, sweep;                 // the calls of the slice in order / second calls (final sweep)
+    std::deque<hg_cram_opts> opts;                     // (jobs point at these)
+    std::deque<std::unique_ptr<FqzKeep>> fqz;
+    bool empty() const { return first.empty() && sweep.empty(); }
+};
+thread_local Behind tl_behind;
+bool behind_enabled() {
+    static const bool on = [] { const char *e = getenv("HTS_GPU_CRAM_WRITEBEHIND"); return !(e && e[0] == '0'); }();
+    return on;
+}
+void behind_flush() {
+    Behind &B = tl_behind;
+    if (B.empty()) return;
+    std::vector<CompJob> first; first.swap(B.first);
+    std::vector<CompJob> sweep; sweep.swap(B.sweep);
+    B.slice = nullptr;
+    compress_many(first.data(), (int)first.size());
+    bool bad = false;
+    for (auto &j : first) bad |= j.rc != 0;
+    std::vector<CompJob> rest;
+    for (auto &j : sweep) if (j.b && j.b->method == RAW) rest.push_back(j);
+    if (!bad) { compress_many(rest.data(), (int)rest.size()); for (auto &j : rest) bad |= j.rc != 0; }
+    if (bad) logerr("cram_compress_block", "a deferred block batch failed: the slice's remaining blocks are written uncompressed");
+    B.opts.clear(); B.fqz.clear();
+}
+inline void behind_sync() { if (!tl_behind.empty()) behind_flush(); }
+
 }  // namespace
 
 // the block layer's context, for the htscodecs-named entry points (htscodecs_front.cpp)
@@ -348,6 +511,7 @@ namespace hgfront { hg_ctx *shared_engine() { return engine(); } }
 extern "C" {
 
 cram_block *cram_new_block(enum cram_content_type content_type, int content_id) {
+    behind_sync();                                                    // (cram_encode_slice_header right after cram_compress_slice comes through here)
     cram_block *b = (cram_block *)calloc(1, sizeof(cram_block));
     if (!b) return nullptr;
     b->method = b->orig_method = RAW;
@@ -359,6 +523,11 @@ cram_block *cram_new_block(enum cram_content_type content_type, int content_id) 
 
 void cram_free_block(cram_block *b) {
     if (!b) return;
+    behind_sync();
+    if (Ahead *a = ahead_take(b)) {                                   // read ahead, never asked for
+        if (a->shadow.data != b->data) free(a->shadow.data);
+        delete a;
+    }
     free(b->data);
     free(b);
 }
@@ -367,6 +536,17 @@ cram_metrics *cram_new_metrics(void) { return reinterpret_cast<cram_metrics *>(h
 
 int cram_uncompress_block(cram_block *b) {
     if (!b) return -1;
+    behind_sync();
+    if (Ahead *a = ahead_take(b)) {                                   // decoded while it waited for this call: take the result over
+        const int rc = a->rc;
+        b->crc32_checked = a->shadow.crc32_checked;
+        if (rc == 0) {
+            if (a->shadow.data != b->data) { free(b->data); b->data = a->shadow.data; b->alloc = a->shadow.alloc; }
+            b->method = a->shadow.method; b->orig_method = a->shadow.orig_method;
+        } else if (a->shadow.data != b->data) free(a->shadow.data);
+        delete a;
+        return rc;
+    }
     // nothing for the device to do: answer at once (cram_io.c:1594-1603) -- no linger for RAW blocks
     if (b->crc32_checked && (b->uncomp_size == 0 || b->method == RAW)) { if (b->uncomp_size == 0) b->method = RAW; return 0; }
     UncReq r{b, -1, false};
@@ -376,8 +556,22 @@ int cram_uncompress_block(cram_block *b) {
 
 int cram_uncompress_blocks(cram_block **b, int n, int *blk_rc) {
     if (n <= 0) return 0;
-    std::vector<int> rc(n);
-    uncompress_batch(b, n, rc.data());
+    std::vector<int> rc(n, 0);
+    std::vector<cram_block *> rest; std::vector<int> at;
+    for (int i = 0; i < n; i++) {
+        if (b[i] && ahead().map.size()) {                               // (a block that was read ahead: its own call collects it)
+            AheadState &A = ahead();
+            bool queued;
+            { std::lock_guard<std::mutex> lk(A.m); queued = A.map.count(b[i]) != 0; }
+            if (queued) { rc[i] = cram_uncompress_block(b[i]); continue; }
+        }
+        rest.push_back(b[i]); at.push_back(i);
+    }
+    if (!rest.empty()) {
+        std::vector<int> r2(rest.size());
+        uncompress_batch(rest.data(), (int)rest.size(), r2.data());
+        for (size_t k = 0; k < rest.size(); k++) rc[at[k]] = r2[k];
+    }
     int any = 0;
     for (int i = 0; i < n; i++) { if (blk_rc) blk_rc[i] = rc[i]; if (rc[i]) any = -1; }
     return any;
@@ -551,10 +745,13 @@ size_t hg_cram_fd_layout(size_t *o) {
 int cram_compress_block2(cram_fd *fd, cram_slice *s, cram_block *b, cram_metrics *metrics, int method, int level) {
     if (!b) return 0;                                    // cram_compress_slice passes the data series a slice does not have (cram_io.c:1917-1918)
     if (!fd) return -1;
+    Behind &B = tl_behind;
+    const bool defer = s && behind_enabled();
+    if (!defer || (B.slice && B.slice != s)) behind_sync();
     const hg_cram_opts o = opts_of(fd);
     // the slice only matters for the FQZ methods: per-record quality lengths and flags, gathered as cram_io.c:1808-1820 does
-    std::vector<uint32_t> len, flags;
-    hg_fqz_slice fq; const hg_fqz_slice *fqp = nullptr;
+    std::unique_ptr<FqzKeep> keep;
+    const hg_fqz_slice *fqp = nullptr;
     const unsigned fqz_bits = 1u << FQZ | 1u << FQZ_b | 1u << FQZ_c | 1u << FQZ_d;
     if (s && method != -1 && ((unsigned)method & fqz_bits)) {
         const char *hdr = field<const char *>(s, HG_CRAM_SLICE_HDR);
@@ -562,29 +759,43 @@ int cram_compress_block2(cram_fd *fd, cram_slice *s, cram_block *b, cram_metrics
         cram_block *const *blocks = field<cram_block *const *>(s, HG_CRAM_SLICE_BLOCK);
         const int32_t n = hdr ? field<int32_t>(hdr, HG_CRAM_SLICE_HDR_NUM_RECORDS) : 0;
         if (hdr && crecs && blocks && blocks[HG_CRAM_DS_QS] && n > 0) {
-            len.resize((size_t)n); flags.resize((size_t)n);
+            keep.reset(new FqzKeep());
+            keep->len.resize((size_t)n); keep->flags.resize((size_t)n);
             for (int32_t i = 0; i < n; i++) {
                 const char *r = crecs + (size_t)i * HG_CRAM_RECORD_SIZE;
-                flags[(size_t)i] = (uint32_t)field<int32_t>(r, HG_CRAM_RECORD_FLAGS);
+                keep->flags[(size_t)i] = (uint32_t)field<int32_t>(r, HG_CRAM_RECORD_FLAGS);
                 const int32_t q = field<int32_t>(r, HG_CRAM_RECORD_QUAL);
-                len[(size_t)i] = (uint32_t)(i + 1 < n ? field<int32_t>(r + HG_CRAM_RECORD_SIZE, HG_CRAM_RECORD_QUAL) - q : blocks[HG_CRAM_DS_QS]->uncomp_size - q);
+                keep->len[(size_t)i] = (uint32_t)(i + 1 < n ? field<int32_t>(r + HG_CRAM_RECORD_SIZE, HG_CRAM_RECORD_QUAL) - q : blocks[HG_CRAM_DS_QS]->uncomp_size - q);
             }
-            fq.num_records = (uint32_t)n; fq.len = len.data(); fq.flags = flags.data(); fqp = &fq;
+            keep->fq.num_records = (uint32_t)n; keep->fq.len = keep->len.data(); keep->fq.flags = keep->flags.data(); fqp = &keep->fq;
         }
     }
-    return hg_cram_compress_block_fqz(&o, fqp, b, metrics, method, level);
+    if (!defer) return hg_cram_compress_block_fqz(&o, fqp, b, metrics, method, level);
+    if (b->method != RAW) return 0;                                           // cram_io.c:1945-1952
+    B.slice = s;
+    B.opts.push_back(o);
+    if (keep) B.fqz.push_back(std::move(keep));
+    CompJob j{&B.opts.back(), b, metrics, method, level, -1, fqp};
+    bool again = false;
+    for (const CompJob &x : B.first) if (x.b == b) { again = true; break; }
+    (again ? B.sweep : B.first).push_back(j);
+    return 0;
 }
 int cram_compress_block(cram_fd *fd, cram_block *b, cram_metrics *metrics, int method, int level) { return cram_compress_block2(fd, nullptr, b, metrics, method, level); }
 cram_block *cram_read_block(cram_fd *fd) {
     if (!fd) return nullptr;
-    return hg_cram_read_block(field<hFILE *>(fd, HG_CRAM_FD_FP), field<int>(fd, HG_CRAM_FD_VERSION) >> 8, field<int>(fd, HG_CRAM_FD_IGNORE_MD5));
+    cram_block *b = hg_cram_read_block(field<hFILE *>(fd, HG_CRAM_FD_FP), field<int>(fd, HG_CRAM_FD_VERSION) >> 8, field<int>(fd, HG_CRAM_FD_IGNORE_MD5));
+    ahead_submit(b);
+    return b;
 }
 int cram_write_block(cram_fd *fd, cram_block *b) {
+    behind_sync();
     if (!fd || !b) return -1;
     return hg_cram_write_block(field<hFILE *>(fd, HG_CRAM_FD_FP), field<int>(fd, HG_CRAM_FD_VERSION) >> 8, b);
 }
 
 uint32_t cram_block_size(cram_block *b) {
+    behind_sync();
     uint8_t tmp[32];
     size_t n = 2;
     n += (size_t)itf8_put(tmp, b->content_id) + (size_t)itf8_put(tmp, b->comp_size) + (size_t)itf8_put(tmp, b->uncomp_size);
