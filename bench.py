@@ -215,6 +215,11 @@ class Run:
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        # Rehearsal of the multi-rank path on a box with ONE GPU (tests/test_multigpu_gpu.py): every rank takes device 0 and the ranks meet over gloo --
+        # RCCL refuses two ranks on one device.  Everything else (rank environment, sharding, per-rank verification, MAX-over-ranks timing) is the real path.
+        self.share_device = os.environ.get("HTS_BENCH_SHARE_DEVICE") == "1"
+        if self.share_device:
+            self.local = 0
         if self.world > 1:
             args.gpus = self.world
         self.ncores = os.cpu_count() or 1
@@ -229,9 +234,15 @@ class Run:
         if self.world > 1 and self.dist is None:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", device_id=self.dev)
+            if self.share_device: dist.init_process_group("gloo")
+            else: dist.init_process_group("nccl", device_id=self.dev)
             self.dist = dist
         return torch
+
+    @property
+    def reduce_dev(self):
+        """where the tensors of a cross-rank reduction live: the rank's GPU (RCCL), the host in the one-device rehearsal (gloo)"""
+        return None if self.share_device else self.dev
 
     def barrier(self):
         import torch
@@ -460,7 +471,7 @@ def op_inflate(run: Run, S: Staged, steps: int, warmup: int):
         plain0, _, _ = synth.bam_stream(min(CHUNK, int(args.gib * (1 << 30))), S.seed, S.first_chunk, S.first_chunk == 0)
         chk = min(chk, len(plain0))
         ok = ok and S.d_out[:chk].cpu().numpy().tobytes() == plain0[:chk]
-    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(S.total_u), float(S.comp_len), ok, run.world, run.dev)
+    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(S.total_u), float(S.comp_len), ok, run.world, run.reduce_dev)
     if strong:
         ok = ok and int(sum_u) == S.whole_plain                        # the shards cover the file exactly once
     if run.rank != 0:
@@ -690,7 +701,7 @@ def op_rans(run: Run, steps: int, warmup: int, slices: int, nway: int = 32):
     ok = ok and bool(torch.equal(d_out, d_expect))
     del d_expect
     variants = _rans_variants(eng, [qs for qs, _ in series[:24]], max(3, min(steps, 5))) if run.rank == 0 and run.world == 1 and nway == 32 and not getattr(run.args, "no_variants", False) else None
-    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(total_u), float(total_c), ok, run.world, run.dev)
+    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(total_u), float(total_c), ok, run.world, run.reduce_dev)
     if run.rank != 0:
         return None, ok
     alg = float(total_u + total_c)
@@ -734,8 +745,8 @@ def op_cram(run: Run, steps: int, slices: int):
         run.dist.barrier()
     r = bench_cram_slices.main(slices, device=run.local, reps=max(5, steps), quiet=True)
     from htslib_amd.bgzf import reduce_timing
-    enc_s, sum_u, sum_c, ok = reduce_timing(r["encode_s"], float(r["plain_bytes"]), float(r["comp_bytes"]), True, run.world, run.dev)
-    dec_s, _, _, _ = reduce_timing(r["decode_s"], float(r["plain_bytes"]), float(r["comp_bytes"]), True, run.world, run.dev)
+    enc_s, sum_u, sum_c, ok = reduce_timing(r["encode_s"], float(r["plain_bytes"]), float(r["comp_bytes"]), True, run.world, run.reduce_dev)
+    dec_s, _, _, _ = reduce_timing(r["decode_s"], float(r["plain_bytes"]), float(r["comp_bytes"]), True, run.world, run.reduce_dev)
     if run.rank != 0:
         return None, ok
     # algorithmic bytes of a whole-slice encode through the tuner's steady state: read U, write C (+ one histogram pass: 2U + C)
@@ -928,7 +939,7 @@ def op_deflate(run: Run, S: Staged, steps: int, warmup: int):
         ref_ok = r.returncode == 0 and r.stdout == want
         ok = ok and ref_ok
     del d_packed
-    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(total_u), float(comp_len), ok, run.world, run.dev)
+    elapsed, sum_u, sum_c, ok = reduce_timing(elapsed, float(total_u), float(comp_len), ok, run.world, run.reduce_dev)
     if run.rank != 0:
         return None, ok
     alg = float(total_u + comp_len)

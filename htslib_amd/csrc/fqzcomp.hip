@@ -393,7 +393,7 @@ __device__ __forceinline__ int decode_stream(const uint8_t *__restrict__ in, con
             const uint32_t r = hga::udiv_small_divisor(D.range, tot);
             const uint32_t incl = hg::wave_incl_scan_dpp(e >> 8);       // lanes >= ns carry the total
             const unsigned long long hit = __ballot(incl * r > D.code);   // incl > code / r  <=>  incl r > code;  incl r <= tot r <= range: no overflow
-            if (!hit) { D.err = 1; break; }                              // code / r >= tot: not a valid stream
+            if (!hit) { hg::wait_vm0(); D.err = 1; break; }             // code / r >= tot: not a valid stream (the four hand-issued loads must have landed before their registers are anyone else's)
             const uint32_t l = (uint32_t)__builtin_ctzll(hit);
             const uint32_t ex = rl(e, l), f = ex >> 8;
             D.code -= (rl(incl, l) - f) * r; D.range = r * f;
@@ -419,9 +419,10 @@ __device__ __forceinline__ int decode_stream(const uint8_t *__restrict__ in, con
             if (R.pflags & PF_DTAB) { st.delta += st.prevq != Q; st.prevq = Q; }
             st.p--;
             const uint32_t next = rl(cv, l), upd = cur;
-            // (pf[] have no use above this line; should a future compiler schedule the selects below above the wait, make the four registers "+v" operands of an
-            //  `asm volatile("s_waitcnt vmcnt(0)")` here -- same code today, checked in the -S output, which is the build the GPU tests ran)
-            hg::wait_vm0();                                              // the one wait for memory of a quality: the models requested before the coder step
+            // the one wait for memory of a quality: the models requested before the coder step.  The four registers are operands of the wait, so that no
+            // compiler can schedule the selects below above it (the loads were issued by hand: its own waitcnt bookkeeping does not know them)
+            static_assert(QPF == 4, "the wait names the four prefetch registers");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]) : : "memory");
             {                                                            // (same context again: `cur` is already its updated model)
                 const uint32_t p01 = (l & 1u) ? pf[1] : pf[0], p23 = (l & 1u) ? pf[3] : pf[2], psel = (l & 2u) ? p23 : p01;
                 const bool same = next == last;

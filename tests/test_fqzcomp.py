@@ -116,6 +116,19 @@ def test_gpu_decoder_rejects_what_the_oracle_rejects(engine, qorc):
     for k in range(1, len(blocks)):
         assert st[k] == -1 and outs[k] is None, k
         assert blocks[k][2] != len(q) or qorc.decode(blocks[k][1], blocks[k][2])[0] != 0, k      # the oracle rejects the same streams
+    # damaged streams FIRST in a launch, valid ones behind them (a wavefront takes several streams in turn: an early exit from the fast path must leave
+    # nothing in flight that could land in the next stream's registers -- the decoder issues its model prefetches by hand)
+    flipped = []
+    for k in range(24):
+        b = bytearray(good); pos = int(rng.integers(8, len(good))); b[pos] ^= 1 << int(rng.integers(0, 8)); flipped.append(bytes(b))
+    many = [(7, b, len(q)) for b in flipped] * 3 + [(7, good, len(q))] * 200
+    outs, st = engine.cram_uncompress_blocks(many)
+    for k in range(len(flipped) * 3):
+        rc, dec = qorc.decode(many[k][1], many[k][2])[:2]
+        assert (st[k] == 0) == (rc == 0), k
+        if st[k] == 0: assert outs[k] == dec, k
+    for k in range(len(flipped) * 3, len(many)):
+        assert st[k] == 0 and outs[k] == q, k
     # mixed with the other methods of a CRAM 3.1 slice: the dispatcher runs the families side by side
     mixed = [(7, good, len(q)), (0, b"abc", 3), (7, good, len(q))]
     outs, st = engine.cram_uncompress_blocks(mixed)
