@@ -73,7 +73,7 @@ constexpr uint32_t MAX_IN = 0xff00u;           // BGZF_BLOCK_SIZE (htslib/bgzf.h
 constexpr uint32_t TOO_FAR = 4096u;            // a 3-byte match this far away costs more than 3 literals
 
 struct Huff {                                  // codes + bit-packing window of the emit phase
-    uint32_t obuf[520];                        // bit-packing staging window (dwords)
+    uint32_t obuf[2][520];                     // bit-packing staging windows (dwords): one being filled, one flushed and zeroed behind it
     uint16_t ll_code[288];
     uint16_t d_code[32];
     alignas(4) uint8_t ll_len[288];
@@ -237,8 +237,10 @@ __device__ uint32_t wg_crc32_raw(Lds &S, uint32_t n, int tid, bool first) {
 }
 
 // Bit packer: every thread contributes `nb` (<= 56) bits `v` (LSB first) in thread order.
-// *bitpos is the absolute bit offset in the output slot; complete dwords are flushed.
-__device__ __forceinline__ void pack_bits(Lds &S, uint32_t *out32, uint32_t &bitpos, uint64_t v, uint32_t nb, int tid) {
+// *bitpos is the absolute bit offset in the output slot; complete dwords are flushed.  Two staging windows alternate (`win`): a step ORs its bits into
+// one, flushes its complete dwords and zeroes them behind the flush, and moves the partial last dword to the head of the OTHER window with one atomic OR --
+// two barriers per 256 tokens (rounds 1-5: one window, five barriers: flush, carry, clear, restore).
+__device__ __forceinline__ void pack_bits(Lds &S, uint32_t *out32, uint32_t &bitpos, uint32_t &win, uint64_t v, uint32_t nb, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     // inclusive scan of nb inside the wave
     uint32_t x = nb;
@@ -254,7 +256,7 @@ __device__ __forceinline__ void pack_bits(Lds &S, uint32_t *out32, uint32_t &bit
     for (int w = 0; w < 4; w++) { uint32_t t = S.wsum[w]; if (w < wave) base += t; total += t; }
     const uint32_t my = bitpos + base + x - nb;            // my first bit
     const uint32_t w0 = bitpos >> 5;                        // first dword of the staging window
-    uint32_t *ob = S.u.e.h.obuf;
+    uint32_t *ob = S.u.e.h.obuf[win], *nx = S.u.e.h.obuf[win ^ 1u];
     if (nb) {
         uint32_t wi = (my >> 5) - w0, sh = my & 31u;
         uint64_t lo = v << sh;
@@ -265,14 +267,11 @@ __device__ __forceinline__ void pack_bits(Lds &S, uint32_t *out32, uint32_t &bit
     __syncthreads();
     const uint32_t endbit = bitpos + total;
     const uint32_t ndone = (endbit >> 5) - w0;              // complete dwords
-    for (uint32_t i = tid; i < ndone; i += WG) out32[w0 + i] = ob[i];
-    uint32_t carry = ob[ndone];
-    __syncthreads();
-    for (uint32_t i = tid; i <= ndone + 1 && i < 520; i += WG) ob[i] = 0;
-    __syncthreads();
-    if (tid == 0) ob[0] = carry;
+    for (uint32_t i = tid; i < ndone; i += WG) { out32[w0 + i] = ob[i]; ob[i] = 0; }
+    if (tid == 0) { const uint32_t carry = ob[ndone]; ob[ndone] = 0; if (carry) atomicOr(&nx[0], carry); }
+    // (the other window is all zero but for that carry: it was cleared behind its own flush, a step ago; the next step's first barrier orders the rest)
     bitpos = endbit;
-    __syncthreads();
+    win ^= 1u;
 }
 
 // Compression levels (bgzf.c:583-585 maps 1..9 onto libdeflate levels; zlib uses them directly): the level picks the
@@ -616,9 +615,9 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
             total_len = hoff + 5u + n + (mode == 1 ? 0u : 8u);
         } else {
             Huff &H = S.u.e.h;
-            for (int i = tid; i < 520; i += WG) H.obuf[i] = 0;
+            for (int i = tid; i < 2 * 520; i += WG) (&H.obuf[0][0])[i] = 0;
             __syncthreads();
-            uint32_t bitpos = hoff * 8u;
+            uint32_t bitpos = hoff * 8u, win = 0;
             {   // the dynamic-block header: (value, bit count) items of wg_dynamic_header, one per thread
                 const hgdef::HuffWG &W = S.u.e.w;
                 const uint32_t nitems = W.nitems;
@@ -626,7 +625,7 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                     const uint32_t i = i0 + (uint32_t)tid;
                     uint32_t nb = 0; uint64_t v = 0;
                     if (i < nitems) { v = W.item_v[i]; nb = W.item_n[i]; }
-                    pack_bits(S, o32, bitpos, v, nb, tid);
+                    pack_bits(S, o32, bitpos, win, v, nb, tid);
                 }
             }
             // the tokens (+ end-of-block after the last one)
@@ -649,23 +648,24 @@ void bgzf_deflate_kernel(const uint8_t *__restrict__ plain, const hg_bgzf_desc *
                 } else if (i == ntok) {
                     v = H.ll_code[256]; nb = H.ll_len[256];
                 }
-                pack_bits(S, o32, bitpos, v, nb, tid);
+                pack_bits(S, o32, bitpos, win, v, nb, tid);
             }
             // a chunk that is not the last of its stream continues with an empty stored block:
             // 000 (BFINAL=0, BTYPE=00), pad to a byte, LEN=0000 NLEN=FFFF
-            if (mode == 1 && !last_chunk) { uint32_t nb = tid == 0 ? 3u : 0u; pack_bits(S, o32, bitpos, 0, nb, tid); }
+            if (mode == 1 && !last_chunk) { uint32_t nb = tid == 0 ? 3u : 0u; pack_bits(S, o32, bitpos, win, 0, nb, tid); }
             // pad to a byte boundary, then CRC32 + ISIZE as 8 single bytes
             {
                 uint32_t nb = 0; uint64_t v = 0;
                 if (tid == 0) nb = (8u - (bitpos & 7u)) & 7u;
-                pack_bits(S, o32, bitpos, v, nb, tid);
+                pack_bits(S, o32, bitpos, win, v, nb, tid);
             }
             if (mode == 1 && !last_chunk) {
-                { uint32_t nb = tid < 4 ? 8u : 0u; uint64_t v = tid >= 2 ? 0xffu : 0u; pack_bits(S, o32, bitpos, v, nb, tid); }
+                { uint32_t nb = tid < 4 ? 8u : 0u; uint64_t v = tid >= 2 ? 0xffu : 0u; pack_bits(S, o32, bitpos, win, v, nb, tid); }
             }
             total_len = (bitpos >> 3) + (mode == 1 ? 0u : 8u);
             // flush the partial dword that is still in the staging window
-            if (tid == 0 && (bitpos & 31u)) o32[bitpos >> 5] = H.obuf[0];
+            __syncthreads();
+            if (tid == 0 && (bitpos & 31u)) o32[bitpos >> 5] = H.obuf[win][0];
             __syncthreads();
         }
         if (tid == 0) {

@@ -220,8 +220,9 @@ def test_wg_dynamic_header_and_codes_decode_with_zlib(hh, hhw, oracle, case, nt)
 
 def test_input_ring_schedule_of_the_deflate_kernel_never_overwrites_live_bytes():
     """bgzf_deflate.hip stages the block as a ring of RING bytes: before chunk c0 the bytes up to c0 + AHEAD must be there, and the REFILL bytes a chunk requests
-    for the next one may only replace positions more than 32 KiB before that next chunk.  The constants are read from the kernel source; the schedule is the
-    kernel's (`refill = hi < pad_end && hi < c0 + WG + AHEAD`)."""
+    for the next one may only replace positions the next chunk can no longer name: a candidate lies at most WINDOW + 1 before its position (round 6: the window is
+    what the ring leaves, 19 680 bytes, not DEFLATE's 32 KiB -- the hash table does not remember farther back).  The constants are read from the kernel source; the
+    schedule is the kernel's (`refill = hi < pad_end && hi < c0 + WG + AHEAD`)."""
     import re
     src = open(os.path.join(ROOT, "htslib_amd", "csrc", "bgzf_deflate.hip")).read()
     m = re.search(r"constexpr uint32_t RING = (\d+)u, MIRROR = (\d+)u, REFILL = (\d+)u, AHEAD = (\d+)u;", src)
@@ -229,7 +230,9 @@ def test_input_ring_schedule_of_the_deflate_kernel_never_overwrites_live_bytes()
     RING, MIRROR, REFILL, AHEAD = map(int, m.groups())
     WG = 256
     assert "const bool refill = hi < pad_end && hi < c0 + WG + AHEAD;" in src
-    assert RING % 16 == 0 and REFILL == WG * 8 and MIRROR >= 36 + 4          # a compare reads 36 bytes from a dword-aligned address
+    assert "constexpr uint32_t WINDOW = RING - (WG + AHEAD + REFILL);" in src and "const uint32_t dcap = p < WINDOW + 1u ? p : WINDOW + 1u;" in src
+    WINDOW = RING - (WG + AHEAD + REFILL)
+    assert RING % 32 == 0 and REFILL == WG * 8 and MIRROR >= 36 + 4 and 16384 <= WINDOW <= 32768 and 3 * RING >= 65280 + 64   # a compare reads 36 bytes from a dword-aligned address
     for n in list(range(1, 600, 37)) + list(range(RING - 80, RING + 80, 7)) + list(range(40000, 65281, 211)) + [65280]:
         pad_end = (n + 48 + 15) & ~15
         hi = min(pad_end, RING)
@@ -238,5 +241,5 @@ def test_input_ring_schedule_of_the_deflate_kernel_never_overwrites_live_bytes()
             assert hi > last_read or hi >= pad_end, (n, c0, hi)
             if hi < pad_end and hi < c0 + WG + AHEAD:
                 replaced_end = hi + REFILL - RING                            # positions [hi - RING, replaced_end) lose their bytes
-                assert replaced_end <= max(0, c0 + WG - 32768), (n, c0, hi)  # dead for the next chunk (and for this chunk's literal reads: < c0)
+                assert replaced_end <= max(0, c0 + WG - (WINDOW + 1)), (n, c0, hi)  # dead for the next chunk (and for this chunk's literal reads: < c0)
                 hi += REFILL
