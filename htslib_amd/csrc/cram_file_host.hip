@@ -89,6 +89,195 @@ template <class W> std::vector<size_t> cut_ranges(size_t n, size_t parts, W weig
 }
 }  // namespace
 
+int hg_cram_decode_bam_devsrc(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, const char *const *rg_names,
+                              int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap, uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes,
+                              int32_t *status, const char *name_prefix, const uint8_t *dev_lo, const uint8_t *dev_hi);     // cram_records.hip
+
+namespace {
+constexpr int NOT_FUSABLE = 0x7f01;       // internal: this run goes through the host-buffer composition instead
+struct Walk { std::vector<Blk> blocks; std::vector<Sl> slices; size_t file_hdr = (size_t)-1; uint64_t bases = 0; };
+
+// the blocks of one container body (cram_read_container's successor calls: cram_read_block for the compression header, cram_read_slice for each
+// slice, cram/cram_io.c:1414-1500, cram_decode.c:3386-3416): block headers parsed in place, slices = header block + the blocks that follow it
+int walk_body(Walk &W, const uint8_t *p, const uint8_t *cend, int32_t nblk, int major) {
+    std::vector<Blk> &blocks = W.blocks; std::vector<Sl> &slices = W.slices;
+    hgr::Cursor b{p, cend};
+    size_t comp = (size_t)-1;
+    bool in_slice = false;                                           // blocks before the container's first slice header belong to no slice
+    for (int32_t k = 0; k < nblk && b.p < b.end; k++) {
+        const uint8_t *h0 = b.p;
+        Blk x; memset(&x, 0, sizeof x);
+        x.method = b.byte(); x.ctype = b.byte(); x.cid = b.itf8(); x.csz = (uint32_t)b.itf8(); x.usz = (uint32_t)b.itf8();
+        if (b.bad || (size_t)(b.end - b.p) < (size_t)x.csz + (major >= 3 ? 4u : 0u)) return HG_EINVAL;
+        x.crc_part = crc32_small(h0, (size_t)(b.p - h0));
+        x.data = b.p; b.p += x.csz;
+        if (major >= 3) { x.crc = (uint32_t)b.p[0] | (uint32_t)b.p[1] << 8 | (uint32_t)b.p[2] << 16 | (uint32_t)b.p[3] << 24; b.p += 4; }
+        blocks.push_back(x);
+        const size_t me = blocks.size() - 1;
+        if (x.ctype == 0 && W.file_hdr == (size_t)-1) W.file_hdr = me;                     // FILE_HEADER
+        else if (x.ctype == 1) comp = me;                                              // COMPRESSION_HEADER
+        else if (x.ctype == 2 || x.ctype == 3) { Sl s; s.hdr = me; s.comp = comp; s.ref_seq_id = -1; s.start = s.span = 0; s.embedded = -1; slices.push_back(s); in_slice = true; }
+        else if ((x.ctype == 4 || x.ctype == 5) && in_slice) slices.back().body.push_back(me);
+    }
+    return 0;
+}
+
+// every block through cram_uncompress_block in one batch (one batch per device when HTS_GPU_DEVICES names several)
+int uncompress_walk(const std::vector<hg_ctx *> &ctxs, int major, const std::vector<Blk> &blocks, std::vector<std::vector<uint8_t>> &dec) {
+    const size_t nb = blocks.size();
+    dec.assign(nb, std::vector<uint8_t>());
+    std::vector<int32_t> method(nb), status(nb); std::vector<const uint8_t *> in(nb); std::vector<uint32_t> il(nb), ol(nb), part(nb), crc(nb); std::vector<uint8_t *> out(nb);
+    for (size_t i = 0; i < nb; i++) {
+        dec[i].resize(blocks[i].usz ? blocks[i].usz : 1);
+        method[i] = blocks[i].method; in[i] = blocks[i].data; il[i] = blocks[i].csz; ol[i] = blocks[i].usz; out[i] = dec[i].data(); part[i] = blocks[i].crc_part; crc[i] = blocks[i].crc;
+    }
+    const std::vector<size_t> bcut = cut_ranges(nb, nb >= 64 ? ctxs.size() : 1, [&](size_t i) { return (uint64_t)blocks[i].csz + blocks[i].usz + 64; });
+    std::vector<int> brc(bcut.size() - 1, HG_OK);
+    auto unc = [&](size_t k) {
+        const size_t a = bcut[k], n_ = bcut[k + 1] - a;
+        hg_ctx *c = ctxs[k];
+        brc[k] = !n_ ? HG_OK : major >= 3
+            ? hg_cram_uncompress_blocks_crc_host(c, n_, method.data() + a, in.data() + a, il.data() + a, part.data() + a, crc.data() + a, out.data() + a, ol.data() + a, status.data() + a)
+            : hg_cram_uncompress_blocks_host(c, n_, method.data() + a, in.data() + a, il.data() + a, out.data() + a, ol.data() + a, status.data() + a);
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t k = 1; k + 1 < bcut.size(); k++) th.emplace_back(unc, k);
+        unc(0);
+        for (auto &t : th) t.join();
+    }
+    for (int rc : brc) if (rc != HG_OK) return rc;                                      // a block that fails (CRC, malformed, bzip2 / lzma) fails the file, like cram_read_slice / cram_decode_slice
+    return HG_OK;
+}
+
+// crc(A || B) from crc(A), crc(B), |B| (GF(2) polynomial arithmetic; x^8 is 0x00800000 in the reflected form)
+uint32_t crc_mulmod(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) { if (a & (0x80000000u >> i)) p ^= b; b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1; }
+    return p;
+}
+uint32_t crc_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+    uint32_t xp = 0x00800000u, acc = 0x80000000u;
+    for (; len_b; len_b >>= 1) { if (len_b & 1) acc = crc_mulmod(acc, xp); xp = crc_mulmod(xp, xp); }
+    return crc_mulmod(acc, crc_a) ^ crc_b;
+}
+
+// The blocks of a run decoded WHERE THE RECORD DECODER WILL READ THEM: the container bodies go to the device as they lie in the caller's buffer (one transfer),
+// the payload CRCs, the gzip members (inflate kernel) and the rANS 4x8 streams are taken straight from that image into one decoded image beside it -- both in a
+// sibling context's scratch, the two codec families on two streams.  bptr[k] = where block k's plain bytes are: a device address for data blocks (RAW ones
+// point into the uploaded image itself), the host bytes for the header blocks the planner parses.  NOT_FUSABLE: a method of CRAM 3.1, bzip2 / lzma, a
+// compressed header block, bodies scattered over the address space -- the caller takes the host-buffer composition.  HG_EBLOCK: a block failed its CRC or its codec.
+int blocks_on_device(hg_ctx *ctx, int major, const Walk &W, std::vector<const uint8_t *> &bptr, const uint8_t *&dev_lo, const uint8_t *&dev_hi) {
+    const std::vector<Blk> &blocks = W.blocks;
+    const size_t nb = blocks.size();
+    if (!nb) return NOT_FUSABLE;
+    const uint8_t *lo = nullptr, *hi = nullptr;
+    uint64_t csum = 0;
+    size_t ng = 0, nr = 0;
+    for (const Blk &b : blocks) {
+        const bool header = b.ctype <= 3;
+        if (header ? b.method != HG_CRAM_RAW : (b.method != HG_CRAM_RAW && b.method != HG_CRAM_GZIP && b.method != HG_CRAM_RANS4x8)) return NOT_FUSABLE;
+        if (b.method == HG_CRAM_RAW && b.csz != b.usz) return HG_EBLOCK;
+        if (!lo || b.data < lo) lo = b.data;
+        if (!hi || b.data + b.csz > hi) hi = b.data + b.csz;
+        csum += b.csz;
+        if (b.usz && b.method == HG_CRAM_GZIP) ng++;
+        if (b.usz && b.method == HG_CRAM_RANS4x8) nr++;
+    }
+    const uint64_t span = (uint64_t)(hi - lo);
+    if (span > 0xe0000000ull || span > 2 * csum + (64u << 20)) return NOT_FUSABLE;
+    if (!ctx->sub[3] && hg_init(ctx->device, &ctx->sub[3]) != HG_OK) return HG_ENOMEM;
+    hg_ctx *A = ctx->sub[3];
+    hg::CtxGuard ga(A); if (ga.rc) return ga.rc;
+    // ---- layout: [ uploaded image | decoded image ]; descriptor and result tables in two further buffers
+    const uint64_t raw_bytes = (span + 255u) & ~255ull;
+    std::vector<uint64_t> out_off(nb, 0);
+    uint64_t dec_bytes = 0, scratch_words = 0;
+    for (size_t k = 0; k < nb; k++) if (blocks[k].usz && blocks[k].method != HG_CRAM_RAW) { out_off[k] = dec_bytes; dec_bytes += ((uint64_t)blocks[k].usz + 15u) & ~15ull; }
+    if (raw_bytes + dec_bytes > 0xfffffff0ull * 4) return NOT_FUSABLE;
+    std::vector<hg_bgzf_desc> gz(ng); std::vector<hg_stream_desc> rs(nr); std::vector<size_t> gz_of(ng), rs_of(nr);
+    std::vector<uint64_t> c_off(nb); std::vector<uint32_t> c_len(nb);
+    {
+        size_t g = 0, r = 0;
+        for (size_t k = 0; k < nb; k++) {
+            const Blk &b = blocks[k];
+            c_off[k] = (uint64_t)(b.data - lo); c_len[k] = b.csz;
+            if (!b.usz) continue;
+            if (b.method == HG_CRAM_GZIP) { gz[g] = hg_bgzf_desc{c_off[k], out_off[k], b.csz, b.usz}; gz_of[g++] = k; }
+            else if (b.method == HG_CRAM_RANS4x8) {
+                uint32_t usz = 0;
+                if (b.csz >= 9) usz = (uint32_t)b.data[5] | (uint32_t)b.data[6] << 8 | (uint32_t)b.data[7] << 16 | (uint32_t)b.data[8] << 24;
+                if (usz != b.usz) return HG_EBLOCK;                              // cram_uncompress_block: "uncompressed size mismatch" (cram_io.c:1671-1680)
+                memset(&rs[r], 0, sizeof rs[r]);
+                rs[r].in_off = c_off[k]; rs[r].in_len = b.csz; rs[r].out_off = out_off[k]; rs[r].out_len = usz; rs[r].scratch_off = (uint32_t)scratch_words;
+                scratch_words += HG_RANS4X8_SCRATCH_WORDS(b.csz);
+                if (scratch_words > 0xffffffffull) return NOT_FUSABLE;
+                rs_of[r++] = k;
+            }
+        }
+    }
+    // Longest streams first: a stream is one chain on one lane group and a launch lasts as long as its longest group, so the groups start with one long
+    // stream each (the quality blocks) and pick up the short ones behind them -- the kernels hand out streams in descriptor order.
+    {
+        std::vector<size_t> ord(nr);
+        for (size_t r = 0; r < nr; r++) ord[r] = r;
+        std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return rs[a].in_len > rs[b].in_len; });
+        std::vector<hg_stream_desc> rs2(nr); std::vector<size_t> of2(nr);
+        for (size_t r = 0; r < nr; r++) { rs2[r] = rs[ord[r]]; of2[r] = rs_of[ord[r]]; }
+        rs.swap(rs2); rs_of.swap(of2);
+        std::vector<size_t> og(ng);
+        for (size_t g = 0; g < ng; g++) og[g] = g;
+        std::stable_sort(og.begin(), og.end(), [&](size_t a, size_t b) { return gz[a].clen > gz[b].clen; });
+        std::vector<hg_bgzf_desc> gz2(ng); std::vector<size_t> gof2(ng);
+        for (size_t g = 0; g < ng; g++) { gz2[g] = gz[og[g]]; gof2[g] = gz_of[og[g]]; }
+        gz.swap(gz2); gz_of.swap(gof2);
+    }
+    auto up64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t o_gz = 0, o_rs = o_gz + up64(ng * sizeof(hg_bgzf_desc)), o_coff = o_rs + up64(nr * sizeof(hg_stream_desc)), o_clen = o_coff + up64(nb * 8), tab_bytes = o_clen + up64(nb * 4);
+    const size_t r_gz = 0, r_rs = r_gz + up64(ng * 4), r_crc = r_rs + up64(nr * 4), res_bytes = r_crc + up64(nb * 4);
+    int rc;
+    if ((rc = hg::ensure_scratch(A, 0, (size_t)(raw_bytes + dec_bytes) + 256)) || (rc = hg::ensure_scratch(A, 2, tab_bytes + 64)) || (rc = hg::ensure_scratch(A, 3, res_bytes + 64)) ||
+        (rc = hg::ensure_scratch(A, 6, (size_t)scratch_words * 4 + 64))) return rc;
+    uint8_t *d_img = (uint8_t *)A->d_scratch[0], *d_dec = d_img + raw_bytes, *d_tab = (uint8_t *)A->d_scratch[2], *d_res = (uint8_t *)A->d_scratch[3];
+    hipStream_t s = A->stream;
+    std::vector<uint8_t> tab(tab_bytes, 0);
+    if (ng) memcpy(tab.data() + o_gz, gz.data(), ng * sizeof(hg_bgzf_desc));
+    if (nr) memcpy(tab.data() + o_rs, rs.data(), nr * sizeof(hg_stream_desc));
+    memcpy(tab.data() + o_coff, c_off.data(), nb * 8); memcpy(tab.data() + o_clen, c_len.data(), nb * 4);
+    if (hipMemcpyAsync(d_img, lo, (size_t)span, hipMemcpyHostToDevice, s) != hipSuccess || hipMemcpyAsync(d_tab, tab.data(), tab_bytes, hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
+    // gzip members on the side stream, rANS + the CRCs on this one
+    if (ng) {
+        hipStream_t s2 = hg::fork_side(A, s);
+        rc = hg::launch_bgzf_inflate(A, d_img, (size_t)span, (const hg_bgzf_desc *)(d_tab + o_gz), ng, d_dec, (size_t)dec_bytes, (int32_t *)(d_res + r_gz), s2, 1);
+        hg::join_side(A, s);
+        if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    }
+    if (nr && (rc = hg::launch_rans4x8_decode(A, d_img, (const hg_stream_desc *)(d_tab + o_rs), nr, d_dec, (int32_t *)(d_res + r_rs), (uint32_t *)A->d_scratch[6], s))) { (void)hipStreamSynchronize(s); return rc; }
+    if (major >= 3 && (rc = hg::launch_crc32(A, d_img, (const uint64_t *)(d_tab + o_coff), (const uint32_t *)(d_tab + o_clen), nb, (uint32_t *)(d_res + r_crc), s))) { (void)hipStreamSynchronize(s); return rc; }
+    std::vector<uint8_t> res(res_bytes);
+    if (hipMemcpyAsync(res.data(), d_res, res_bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
+    const int32_t *st_gz = (const int32_t *)(res.data() + r_gz), *st_rs = (const int32_t *)(res.data() + r_rs); const uint32_t *crc = (const uint32_t *)(res.data() + r_crc);
+    for (size_t g = 0; g < ng; g++) if (st_gz[g] != 0) return HG_EBLOCK;
+    for (size_t r = 0; r < nr; r++) if (st_rs[r] != 0) return HG_EBLOCK;
+    if (major >= 3)
+        for (size_t k = 0; k < nb; k++) {
+            const Blk &b = blocks[k];
+            if ((b.csz ? crc_join(b.crc_part, crc[k], b.csz) : b.crc_part) != b.crc) return HG_EBLOCK;       // cram_uncompress_block's first step (cram_io.c:1585-1592)
+        }
+    bptr.assign(nb, nullptr);
+    for (size_t k = 0; k < nb; k++) {
+        const Blk &b = blocks[k];
+        bptr[k] = b.ctype <= 3 ? b.data : b.method == HG_CRAM_RAW ? d_img + c_off[k] : d_dec + out_off[k];
+    }
+    dev_lo = d_img; dev_hi = d_img + raw_bytes + dec_bytes + 256;
+    return HG_OK;
+}
+
+int slices_to_bam(hg_ctx *ctx, const std::vector<hg_ctx *> &ctxs, int major, Walk &W, const uint8_t *const *dec, const uint8_t *dev_lo, const uint8_t *dev_hi, int nref, const int64_t *sq_len,
+                  const char *const *rg_names, int nrg, const hg_cram_ref_seq *refs, int nrefs_given, hg_cram_get_ref_fn get_ref, void *get_ref_ud, int flags, int decode_md,
+                  const char *name_prefix, uint8_t *rec_out, size_t rec_cap, uint64_t *rec_bytes_out, uint64_t *nrecords);
+}  // namespace
+
 extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given, uint8_t *bam_out,
                                          size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags, const char *name_prefix);
 extern "C" int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given, uint8_t *bam_out,
@@ -102,72 +291,29 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
     const int major = cram[4];
     if (major != 2 && major != 3) return HG_BLOCK_EUNSUPPORTED;
     // ---- 1. walk ----
-    std::vector<Blk> blocks;
-    std::vector<Sl> slices;
-    size_t file_hdr = (size_t)-1;
-    uint64_t bases = 0;
+    Walk W;
     hgr::Cursor c{cram + 26, cram + cram_len};
     while (c.p < c.end) {
         if (c.end - c.p < 4) return HG_EINVAL;
         const uint32_t clen = (uint32_t)c.p[0] | (uint32_t)c.p[1] << 8 | (uint32_t)c.p[2] << 16 | (uint32_t)c.p[3] << 24; c.p += 4;
         (void)c.itf8(); (void)c.itf8(); (void)c.itf8();                  // reference id, start, span of the container
-        const int32_t nrec = c.itf8();
+        (void)c.itf8();                                                  // number of records
         if (major >= 3) (void)c.ltf8(); else (void)c.itf8();             // record counter
-        bases += (uint64_t)c.ltf8();
+        W.bases += (uint64_t)c.ltf8();
         const int32_t nblk = c.itf8(), nland = c.itf8();
         for (int32_t i = 0; i < nland; i++) (void)c.itf8();
         if (major >= 3) c.p += 4;                                        // CRC of the container header
         if (c.bad || nblk < 0 || c.p > c.end || (size_t)(c.end - c.p) < clen) return HG_EINVAL;
         const uint8_t *cend = c.p + clen;
-        hgr::Cursor b{c.p, cend};
-        size_t comp = (size_t)-1;
-        bool in_slice = false;                                           // blocks before the container's first slice header belong to no slice
-        for (int32_t k = 0; k < nblk && b.p < b.end; k++) {
-            const uint8_t *h0 = b.p;
-            Blk x; memset(&x, 0, sizeof x);
-            x.method = b.byte(); x.ctype = b.byte(); x.cid = b.itf8(); x.csz = (uint32_t)b.itf8(); x.usz = (uint32_t)b.itf8();
-            if (b.bad || (size_t)(b.end - b.p) < (size_t)x.csz + (major >= 3 ? 4u : 0u)) return HG_EINVAL;
-            x.crc_part = crc32_small(h0, (size_t)(b.p - h0));
-            x.data = b.p; b.p += x.csz;
-            if (major >= 3) { x.crc = (uint32_t)b.p[0] | (uint32_t)b.p[1] << 8 | (uint32_t)b.p[2] << 16 | (uint32_t)b.p[3] << 24; b.p += 4; }
-            blocks.push_back(x);
-            const size_t me = blocks.size() - 1;
-            if (x.ctype == 0 && file_hdr == (size_t)-1) file_hdr = me;                       // FILE_HEADER
-            else if (x.ctype == 1) comp = me;                                              // COMPRESSION_HEADER
-            else if (x.ctype == 2 || x.ctype == 3) { Sl s; s.hdr = me; s.comp = comp; s.ref_seq_id = -1; s.start = s.span = 0; s.embedded = -1; slices.push_back(s); in_slice = true; }
-            else if ((x.ctype == 4 || x.ctype == 5) && in_slice) slices.back().body.push_back(me);
-        }
-        (void)nrec;
+        if (const int wrc = walk_body(W, c.p, cend, nblk, major)) return wrc;
         c.p = cend;
     }
+    const size_t file_hdr = W.file_hdr;
     if (file_hdr == (size_t)-1) return HG_EINVAL;
     // ---- 2. every block through cram_uncompress_block in one batch (one batch per device when HTS_GPU_DEVICES names several) ----
     const std::vector<hg_ctx *> ctxs = job_contexts(ctx);
-    const size_t nb = blocks.size();
-    std::vector<std::vector<uint8_t>> dec(nb);
-    {
-        std::vector<int32_t> method(nb), status(nb); std::vector<const uint8_t *> in(nb); std::vector<uint32_t> il(nb), ol(nb), part(nb), crc(nb); std::vector<uint8_t *> out(nb);
-        for (size_t i = 0; i < nb; i++) {
-            dec[i].resize(blocks[i].usz ? blocks[i].usz : 1);
-            method[i] = blocks[i].method; in[i] = blocks[i].data; il[i] = blocks[i].csz; ol[i] = blocks[i].usz; out[i] = dec[i].data(); part[i] = blocks[i].crc_part; crc[i] = blocks[i].crc;
-        }
-        const std::vector<size_t> bcut = cut_ranges(nb, nb >= 64 ? ctxs.size() : 1, [&](size_t i) { return (uint64_t)blocks[i].csz + blocks[i].usz + 64; });
-        std::vector<int> brc(bcut.size() - 1, HG_OK);
-        auto unc = [&](size_t k) {
-            const size_t a = bcut[k], n_ = bcut[k + 1] - a;
-            hg_ctx *c = ctxs[k];
-            brc[k] = !n_ ? HG_OK : major >= 3
-                ? hg_cram_uncompress_blocks_crc_host(c, n_, method.data() + a, in.data() + a, il.data() + a, part.data() + a, crc.data() + a, out.data() + a, ol.data() + a, status.data() + a)
-                : hg_cram_uncompress_blocks_host(c, n_, method.data() + a, in.data() + a, il.data() + a, out.data() + a, ol.data() + a, status.data() + a);
-        };
-        {
-            std::vector<std::thread> th;
-            for (size_t k = 1; k + 1 < bcut.size(); k++) th.emplace_back(unc, k);
-            unc(0);
-            for (auto &t : th) t.join();
-        }
-        for (int rc : brc) if (rc != HG_OK) return rc;                                      // a block that fails (CRC, malformed, bzip2 / lzma) fails the file, like cram_read_slice / cram_decode_slice
-    }
+    std::vector<std::vector<uint8_t>> dec;
+    if (const int urc = uncompress_walk(ctxs, major, W.blocks, dec)) return urc;
     // ---- SAM header: text, @SQ, @RG ----
     const std::vector<uint8_t> &fh = dec[file_hdr];
     if (fh.size() < 4) return HG_EINVAL;
@@ -204,7 +350,83 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
         for (int i = 0; i < nref; i++) { const std::string &nm = sq_name[(size_t)i]; put32((uint32_t)nm.size() + 1); memcpy(o, nm.c_str(), nm.size() + 1); o += nm.size() + 1; put32((uint32_t)sq_len[(size_t)i]); }
     }
     // ---- 3. slices -> BAM records ----
+    std::vector<const char *> rgp; for (auto &r : rg_id) rgp.push_back(r.c_str());
+    uint64_t rec_bytes = 0;
+    std::vector<const uint8_t *> dptr(dec.size()); for (size_t i = 0; i < dec.size(); i++) dptr[i] = dec[i].data();
+    const int rc = slices_to_bam(ctx, ctxs, major, W, dptr.data(), nullptr, nullptr, nref, sq_len.data(), rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), refs, nrefs_given, nullptr, nullptr, flags, -1 /* hts_open's default */,
+                                 name_prefix, bam_out + hb, bam_cap - hb, &rec_bytes, nrecords);
+    *bam_bytes = hb + rec_bytes;
+    return rc;
+}
+
+// The same path for a reader that walks the file itself (cram_read_container on the caller's side: cram_reader_front.c under cram_get_bam_seq): the BODIES of a
+// run of data containers -> their BAM records, back to back, no BAM header.
+extern "C" int hg_cram_containers_to_bam_host(hg_ctx *ctx, int major, size_t ncontainers, const hg_cram_container *cont, int nref, const int64_t *sq_len,
+                                              const char *const *rg_names, int nrg, const hg_cram_ref_seq *refs, int nrefs_given, hg_cram_get_ref_fn get_ref, void *get_ref_ud,
+                                              int flags, int decode_md, const char *name_prefix, uint8_t *bam_out, size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords) {
+    if (!ctx || (ncontainers && !cont) || !bam_out || !bam_bytes || (nrefs_given && !refs) || (nref && !sq_len) || (nrg && !rg_names)) return HG_EINVAL;
+    if (major != 2 && major != 3) return HG_BLOCK_EUNSUPPORTED;
+    static const bool stats = getenv("HTS_GPU_STATS") != nullptr;
+    static const bool fuse = [] { const char *e = getenv("HTS_GPU_CRAM_FUSED"); return !(e && e[0] == '0'); }();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = std::chrono::steady_clock::now();
+    Walk W;
+    for (size_t i = 0; i < ncontainers; i++) {
+        if (!cont[i].body || cont[i].num_blocks < 0) return HG_EINVAL;
+        if (const int wrc = walk_body(W, cont[i].body, cont[i].body + cont[i].body_len, cont[i].num_blocks, major)) return wrc;
+        W.bases += cont[i].bases;
+    }
+    const std::vector<hg_ctx *> ctxs = job_contexts(ctx);
+    uint64_t cb = 0, ub = 0; for (const Blk &b : W.blocks) { cb += b.csz; ub += b.usz; }
+    const auto t1 = std::chrono::steady_clock::now();
+    uint64_t rec_bytes = 0;
+    // ---- the fused form: the blocks never come back to the host between the block codecs and the record decoder ----
+    if (fuse && ctxs.size() == 1) {
+        hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;               // the sibling context's buffers hold this run's blocks until the records are out
+        std::vector<const uint8_t *> bptr; const uint8_t *dev_lo = nullptr, *dev_hi = nullptr;
+        int rc = blocks_on_device(ctx, major, W, bptr, dev_lo, dev_hi);
+        const auto t2 = std::chrono::steady_clock::now();
+        if (rc == HG_OK) rc = slices_to_bam(ctx, ctxs, major, W, bptr.data(), dev_lo, dev_hi, nref, sq_len, rg_names, nrg, refs, nrefs_given, get_ref, get_ref_ud, flags, decode_md, name_prefix,
+                                            bam_out, bam_cap, &rec_bytes, nrecords);
+        if (rc != NOT_FUSABLE) {
+            *bam_bytes = rec_bytes;
+            if (stats) fprintf(stderr, "[htsgpu stats] cram run (fused): %zu containers, %zu slices, %zu blocks %.1f -> %.1f MB, %.1f MB of BAM; walk %.1f ms, blocks %.1f ms, slices -> BAM %.1f ms (rc %d)\n",
+                               ncontainers, W.slices.size(), W.blocks.size(), cb / 1e6, ub / 1e6, rec_bytes / 1e6, ms(t0, t1), ms(t1, t2), ms(t2, std::chrono::steady_clock::now()), rc);
+            return rc;
+        }
+        rec_bytes = 0;
+    }
+    std::vector<std::vector<uint8_t>> dec;
+    const auto t1b = std::chrono::steady_clock::now();
+    if (const int urc = uncompress_walk(ctxs, major, W.blocks, dec)) return urc;
+    const auto t2 = std::chrono::steady_clock::now();
+    std::vector<const uint8_t *> dptr(dec.size()); for (size_t i = 0; i < dec.size(); i++) dptr[i] = dec[i].data();
+    const int rc = slices_to_bam(ctx, ctxs, major, W, dptr.data(), nullptr, nullptr, nref, sq_len, rg_names, nrg, refs, nrefs_given, get_ref, get_ref_ud, flags, decode_md, name_prefix, bam_out, bam_cap,
+                                 &rec_bytes, nrecords);
+    *bam_bytes = rec_bytes;
+    if (stats) fprintf(stderr, "[htsgpu stats] cram run: %zu containers, %zu slices, %zu blocks %.1f -> %.1f MB, %.1f MB of BAM; walk %.1f ms, blocks %.1f ms, slices -> BAM %.1f ms (rc %d)\n",
+                       ncontainers, W.slices.size(), W.blocks.size(), cb / 1e6, ub / 1e6, rec_bytes / 1e6, ms(t0, t1), ms(t1b, t2), ms(t2, std::chrono::steady_clock::now()), rc);
+    return rc;
+}
+
+namespace {
+int slices_to_bam(hg_ctx *ctx, const std::vector<hg_ctx *> &ctxs, int major, Walk &W, const uint8_t *const *dec, const uint8_t *dev_lo, const uint8_t *dev_hi, int nref, const int64_t *sq_len,
+                  const char *const *rg_names, int nrg, const hg_cram_ref_seq *refs, int nrefs_given, hg_cram_get_ref_fn get_ref, void *get_ref_ud, int flags, int decode_md,
+                  const char *name_prefix, uint8_t *rec_out, size_t rec_cap, uint64_t *rec_bytes_out, uint64_t *nrecords) {
+    std::vector<Blk> &blocks = W.blocks; std::vector<Sl> &slices = W.slices;
+    const uint64_t bases = W.bases;
     const size_t ns = slices.size();
+    const auto t_prep = std::chrono::steady_clock::now();
+    // references on demand (get_ref): a slice that brings its own bases (embedded block, RR = 0) never asks; the others ask for the sequence their header
+    // names, multi-reference slices for the ids their RI series holds -- what cram_decode_slice does record by record (cram_decode.c:2436-2446, 2610-2650)
+    std::vector<hg_cram_ref_seq> lazy; std::vector<char> asked;
+    if (get_ref) { lazy.assign((size_t)std::max(nref, 0), hg_cram_ref_seq{nullptr, 0}); asked.assign(lazy.size(), 0); refs = lazy.data(); nrefs_given = (int)lazy.size(); }
+    auto need = [&](int r) {
+        if (!get_ref || r < 0 || r >= nrefs_given || asked[(size_t)r]) return;
+        asked[(size_t)r] = 1;
+        hg_cram_ref_seq q{nullptr, 0};
+        if (get_ref(get_ref_ud, r, &q) == 0 && q.bases) lazy[(size_t)r] = q;
+    };
     std::vector<size_t> md5_jobs;
     std::vector<hgr::SliceHeader> shs(ns);
     std::vector<hg_cram_slice_blocks> sb(ns);
@@ -214,36 +436,58 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
         Sl &s = slices[i];
         if (s.comp == (size_t)-1) return HG_EINVAL;
         hgr::SliceHeader sh;
-        const std::vector<uint8_t> &hd = dec[s.hdr];
-        if (hgr::parse_slice_header(hd.data(), blocks[s.hdr].usz, major, sh)) return HG_EINVAL;
+        const uint8_t *hd = dec[s.hdr];
+        if (hgr::parse_slice_header(hd, blocks[s.hdr].usz, major, sh)) return HG_EINVAL;
+        if (dev_lo && (sh.ref_base_id >= 0 || (sh.ref_seq_id == -2 && get_ref))) return NOT_FUSABLE;      // an embedded reference is digested, the RI series of a multi-reference slice read, on the host
         shs[i] = sh;
         s.embedded = sh.ref_base_id;
         s.ref_seq_id = sh.ref_seq_id; s.start = sh.ref_seq_start; s.span = sh.ref_seq_span;
         memset(&sb[i], 0, sizeof sb[i]);
-        sb[i].comp_hdr = dec[s.comp].data(); sb[i].comp_hdr_len = blocks[s.comp].usz;
-        sb[i].slice_hdr = hd.data(); sb[i].slice_hdr_len = blocks[s.hdr].usz;
+        sb[i].comp_hdr = dec[s.comp]; sb[i].comp_hdr_len = blocks[s.comp].usz;
+        sb[i].slice_hdr = hd; sb[i].slice_hdr_len = blocks[s.hdr].usz;
         size_t taken = 0;
         for (size_t k : s.body) {
             if ((int32_t)taken >= sh.nblocks) break;                     // blocks beyond the slice's count belong to nobody
             taken++;
-            if (blocks[k].ctype == 5) { sb[i].core = dec[k].data(); sb[i].core_len = blocks[k].usz; continue; }
-            ids[i].push_back(blocks[k].cid); ptr[i].push_back(dec[k].data()); len[i].push_back(blocks[k].usz);
+            if (blocks[k].ctype == 5) { sb[i].core = dec[k]; sb[i].core_len = blocks[k].usz; continue; }
+            ids[i].push_back(blocks[k].cid); ptr[i].push_back(dec[k]); len[i].push_back(blocks[k].usz);
             if (s.embedded >= 0 && blocks[k].cid == s.embedded && sh.ref_seq_id >= 0)
-                spans[i].push_back(hg_cram_ref_span{sh.ref_seq_id, sh.ref_seq_start, dec[k].data(), blocks[k].usz, sh.ref_seq_id < nref ? sq_len[(size_t)sh.ref_seq_id] : (int64_t)blocks[k].usz});
+                spans[i].push_back(hg_cram_ref_span{sh.ref_seq_id, sh.ref_seq_start, dec[k], blocks[k].usz, sh.ref_seq_id < nref ? sq_len[sh.ref_seq_id] : (int64_t)blocks[k].usz});
         }
         sb[i].nblocks = (uint32_t)ids[i].size(); sb[i].content_id = ids[i].data(); sb[i].data = ptr[i].data(); sb[i].len = len[i].data();
         // RR = 0 in the container's preservation map: written without a reference -- none is attached (cram_decode.c:2436-2442)
         hgr::PlanHost ph;
-        const bool no_ref = hgr::plan_from_compression_header(ph, dec[s.comp].data(), blocks[s.comp].usz) == 0 && ph.no_ref;
+        const bool no_ref = hgr::plan_from_compression_header(ph, dec[s.comp], blocks[s.comp].usz) == 0 && ph.no_ref;
         if (spans[i].empty() && !no_ref) {                               // the caller's references: the slice's stretch (s->ref_start .. ref_end of the reference), or whole sequences for a multi-reference slice (each staged once per batch)
-            auto whole = [&](int r) { if (r >= 0 && r < nrefs_given && refs[r].bases) spans[i].push_back(hg_cram_ref_span{r, 1, refs[r].bases, (uint32_t)std::min<uint64_t>(refs[r].len, 0xfffffff0ull), r < nref ? sq_len[(size_t)r] : (int64_t)refs[r].len}); };
+            if (get_ref) {
+                if (sh.ref_seq_id >= 0) need(sh.ref_seq_id);
+                else if (sh.ref_seq_id == -2) {
+                    // the reference ids of a multi-reference slice: its RI series, when that is an EXTERNAL block of ITF8 values (what every writer emits) or a
+                    // one-symbol Huffman code; anything else: every reference of the header
+                    bool known = false;
+                    const int ci = ph.plan.codec_of[hgr::S_RI];
+                    if (ci >= 0 && (size_t)ci < ph.codecs.size()) {
+                        const hgr::Codec &cd = ph.codecs[(size_t)ci];
+                        if (cd.kind == hgr::E_EXTERNAL && cd.a >= 0 && (size_t)cd.a < ph.slot_id.size()) {
+                            const int32_t cid = ph.slot_id[(size_t)cd.a];
+                            for (size_t k = 0; k < ids[i].size(); k++) if (ids[i][k] == cid) {
+                                hgr::Cursor rc{ptr[i][k], ptr[i][k] + len[i][k]};
+                                while (rc.p < rc.end && !rc.bad) need(rc.itf8());
+                                known = true; break;
+                            }
+                        } else if (cd.kind == hgr::E_HUFFMAN && cd.b == 1 && (size_t)cd.a < ph.huff.size()) { need(ph.huff[(size_t)cd.a].symbol); known = true; }
+                    }
+                    if (!known) for (int r = 0; r < nrefs_given; r++) need(r);
+                }
+            }
+            auto whole = [&](int r) { if (r >= 0 && r < nrefs_given && refs[r].bases) spans[i].push_back(hg_cram_ref_span{r, 1, refs[r].bases, (uint32_t)std::min<uint64_t>(refs[r].len, 0xfffffff0ull), r < nref ? sq_len[r] : (int64_t)refs[r].len}); };
             if (sh.ref_seq_id >= 0) {
                 const int r = sh.ref_seq_id;
                 if (r < nrefs_given && refs[r].bases && sh.ref_seq_start >= 1 && (uint64_t)sh.ref_seq_start <= refs[r].len) {
                     const uint64_t avail = refs[r].len - (uint64_t)sh.ref_seq_start + 1;
                     const uint64_t want = sh.ref_seq_span > 0 ? (uint64_t)sh.ref_seq_span : avail;      // cram_get_ref(fd, id, start, start + span - 1)
                     spans[i].push_back(hg_cram_ref_span{r, sh.ref_seq_start, refs[r].bases + sh.ref_seq_start - 1, (uint32_t)std::min<uint64_t>(std::min(avail, want), 0xfffffff0ull),
-                                                        r < nref ? sq_len[(size_t)r] : (int64_t)refs[r].len});
+                                                        r < nref ? sq_len[r] : (int64_t)refs[r].len});
                 }
             } else if (sh.ref_seq_id == -2) for (int r = 0; r < nrefs_given; r++) whole(r);
         }
@@ -253,7 +497,7 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
             if (spans[i].empty()) return HG_EBLOCK;                      // no reference and no embedded block: "Unable to fetch reference"
             md5_jobs.push_back(i);
         }
-        sb[i].nrefs = (uint32_t)spans[i].size(); sb[i].refs = spans[i].data(); sb[i].decode_md = -1;      // hts_open's default
+        sb[i].nrefs = (uint32_t)spans[i].size(); sb[i].refs = spans[i].data(); sb[i].decode_md = decode_md;
     }
     if (!md5_jobs.empty()) {                                             // host threads: the digests are independent (the reference computes them in its slice workers)
         std::atomic<size_t> next{0}; std::atomic<int> bad{0};
@@ -278,7 +522,8 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
         for (auto &t : th) t.join();
         if (bad) return HG_EBLOCK;                                       // the reference: error "MD5 checksum reference mismatch", cram_decode_slice returns -1
     }
-    std::vector<const char *> rgp; for (auto &r : rg_id) rgp.push_back(r.c_str());
+    static const bool timing = getenv("HG_CRAM_RECORDS_TIMING") != nullptr;
+    if (timing) fprintf(stderr, "cram run prep (slice headers, references, MD5 of %zu spans): %.1f ms\n", md5_jobs.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prep).count());
     std::vector<uint64_t> rec_off(ns + 1, 0); std::vector<int32_t> status(ns, 0);
     auto slice_bytes = [&](size_t i) { uint64_t b = (uint64_t)sb[i].core_len + 64; for (uint32_t k = 0; k < sb[i].nblocks; k++) b += ((uint64_t)sb[i].len[k] + 15) & ~15ull; return b; };
     uint64_t all_bytes = 0; for (size_t i = 0; i < ns; i++) all_bytes += slice_bytes(i);
@@ -301,8 +546,8 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
             uint64_t seq_cap = std::min<uint64_t>(s1 - s0 == ns ? bases : (uint64_t)((double)bases * 1.25 * (double)bytes / (double)(all_bytes ? all_bytes : 1)), 1ull << 36) + 4096;
             for (int attempt = 0;; attempt++) {
                 got = 0;
-                rc = hg_cram_decode_bam_host2(c, i1 - i0, sb.data() + i0, major, nref, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), seq_cap, dst + rec_bytes,
-                                              cap - rec_bytes, ro.data(), nullptr, &got, status.data() + i0, name_prefix);
+                rc = hg_cram_decode_bam_devsrc(c, i1 - i0, sb.data() + i0, major, nref, rg_names, nrg, seq_cap, dst + rec_bytes,
+                                               cap - rec_bytes, ro.data(), nullptr, &got, status.data() + i0, name_prefix, dev_lo, dev_hi);
                 bool no_room = false;
                 for (size_t k = i0; k < i1; k++) if (status[k] == hgr::ERR_UNSUPPORTED) no_room = true;    // "does not fit" is one of its meanings
                 if ((rc != HG_OK && rc != HG_EBLOCK) || !no_room || attempt == 1 || seq_cap >= (1ull << 34)) break;   // once: a slice the decoder does not support says -3, too
@@ -319,7 +564,7 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
     int rc = HG_OK;
     const std::vector<size_t> scut = cut_ranges(ns, ns >= 2 * ctxs.size() ? ctxs.size() : 1, slice_bytes);
     if (scut.size() == 2) {
-        rc = decode_range(ctx, 0, ns, bam_out + hb, bam_cap - hb, rec_bytes, rec_off.data());
+        rc = decode_range(ctx, 0, ns, rec_out, rec_cap, rec_bytes, rec_off.data());
     } else {
         // every further range decodes into a buffer of its own (its place in the stream is only known when the ranges before it are done);
         // the first one writes in place
@@ -327,9 +572,9 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
         std::vector<std::vector<uint8_t>> tmp(nr); std::vector<uint64_t> got(nr, 0); std::vector<int> rrc(nr, HG_OK);
         std::vector<std::vector<uint64_t>> ro(nr);
         for (size_t k = 0; k < nr; k++) ro[k].assign(scut[k + 1] - scut[k] + 1, 0);
-        const uint64_t room = bam_cap - hb;
+        const uint64_t room = rec_cap;
         auto run = [&](size_t k) {
-            if (k == 0) { rrc[0] = decode_range(ctxs[0], scut[0], scut[1], bam_out + hb, (size_t)room, got[0], ro[0].data()); return; }
+            if (k == 0) { rrc[0] = decode_range(ctxs[0], scut[0], scut[1], rec_out, (size_t)room, got[0], ro[0].data()); return; }
             uint64_t w = 0; for (size_t i = scut[k]; i < scut[k + 1]; i++) w += slice_bytes(i);
             const uint64_t cap = std::min<uint64_t>(room, (uint64_t)((double)room * 1.5 * (double)w / (double)(all_bytes ? all_bytes : 1)) + (4u << 20));
             tmp[k].resize((size_t)cap);
@@ -345,22 +590,23 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
         for (size_t k = 0; k < nr; k++) if (rrc[k] == HG_ENOMEM) retry_serial = true;       // a range's private buffer was too small: the plain way
         if (retry_serial) {
             std::fill(status.begin(), status.end(), 0);
-            rc = decode_range(ctx, 0, ns, bam_out + hb, bam_cap - hb, rec_bytes, rec_off.data());
+            rc = decode_range(ctx, 0, ns, rec_out, rec_cap, rec_bytes, rec_off.data());
         } else {
             for (size_t k = 0; k < nr; k++) {
                 if (rrc[k] != HG_OK && (rc == HG_OK || rc == HG_EBLOCK)) rc = rrc[k];
                 if (rec_bytes + got[k] > room) { rc = HG_ENOMEM; break; }
-                if (k) memcpy(bam_out + hb + rec_bytes, tmp[k].data(), (size_t)got[k]);
+                if (k) memcpy(rec_out + rec_bytes, tmp[k].data(), (size_t)got[k]);
                 for (size_t i = 0; i + 1 < ro[k].size() + 0; i++) rec_off[scut[k] + i] = rec_off[scut[k]] + ro[k][i];
                 rec_off[scut[k + 1]] = rec_off[scut[k]] + ro[k].back();
                 rec_bytes += got[k];
             }
         }
     }
-    *bam_bytes = hb + rec_bytes;
+    *rec_bytes_out = rec_bytes;
     if (nrecords) *nrecords = rec_off[ns];
     return rc;
 }
+}  // namespace
 
 // ---- the other direction: an uncompressed BAM stream (header + records, what hg_cram_file_to_bam_host returns / bam_hdr_write + bam_write1 produce) ->
 //      a CRAM 3.0 file.  Host composition of library pieces, like the reader above:

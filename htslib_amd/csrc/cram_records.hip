@@ -381,6 +381,8 @@ struct hg_cram_batch {
     hgr::Dense PK{};
     uint64_t *d_bam_off = nullptr; uint8_t *d_bam = nullptr;
     size_t n_chain0 = 0;                                // slices the passes do not take
+    const uint8_t *dev_lo = nullptr, *dev_hi = nullptr; // block pointers inside [dev_lo, dev_hi) are DEVICE addresses (blocks decoded in place by the fused run
+                                                        // decoder, cram_file_host.hip): rec_stage gathers them on the device instead of uploading them
     std::vector<uint8_t> retried;                       // slices the passes gave up (last run)
     // column descriptors of the passes (device)
     const hg_stream_desc *d_itf8 = nullptr, *d_stop = nullptr; const uint32_t *d_sum_src = nullptr, *d_col_slice = nullptr; int32_t *d_col_status = nullptr;
@@ -388,10 +390,13 @@ struct hg_cram_batch {
 
 static int rec_stage(hg_ctx *ctx, hg_cram_batch &R, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, bool want_seq, bool want_aux, size_t seq_cap) {
     hgr::Batch &B = R.B;
+    static const bool timing = getenv("HG_CRAM_RECORDS_TIMING") != nullptr;
+    const auto ts0 = std::chrono::steady_clock::now();
     int rc = hgr::batch_build(B, (const hgr::SliceIn *)slices, nslices, major_version);
     if (rc) return rc == -3 ? HG_BLOCK_EUNSUPPORTED : HG_EINVAL;
     const char *fp = getenv("HG_CRAM_RECORDS_PATH");                   // "chain": every slice through the chain decoder (the checker of the data-parallel passes)
     hgr::fast_build(B, R.F, !(fp && fp[0] == 'c'));
+    if (timing) fprintf(stderr, "cram records stage: host plan %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count());
     hgr::FastBatch &F = R.F;
     R.nslices = nslices; R.major = major_version; R.nref = nref; R.want_seq = want_seq; R.want_aux = want_aux; R.seq_cap = seq_cap;
     R.n_chain0 = 0;
@@ -422,7 +427,20 @@ static int rec_stage(hg_ctx *ctx, hg_cram_batch &R, size_t nslices, const hg_cra
     RecMem &M = R.M;
     if ((rc = M.need(M_DATA, B.data_bytes + 64)) || (rc = M.need(M_OUT, obytes + 64)) || (rc = M.need(M_TAB, tbytes + 64))) return rc;
     uint8_t *d_data = (uint8_t *)M.p[M_DATA], *d_out = (uint8_t *)M.p[M_OUT], *d_tab = (uint8_t *)M.p[M_TAB];
-    bool ok = hg::stage_upload(ctx, B.src_ptr.data(), B.src_len.data(), B.src_off.data(), nullptr, B.src_ptr.size(), B.data_bytes, d_data, s) == HG_OK;
+    if (timing) fprintf(stderr, "cram records stage: + device memory (data %.0f MB, columns %.0f MB) %.1f ms\n", B.data_bytes / 1e6, obytes / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count());
+    bool ok;
+    if (R.dev_lo) {
+        const size_t nsrc = B.src_ptr.size();
+        std::vector<int32_t> skip(nsrc, 0);
+        std::vector<uint64_t> g_src, g_dst; std::vector<uint32_t> g_len;
+        for (size_t k = 0; k < nsrc; k++)
+            if (B.src_ptr[k] >= R.dev_lo && B.src_ptr[k] < R.dev_hi) {
+                skip[k] = 1;
+                if (B.src_len[k]) { g_src.push_back((uint64_t)(B.src_ptr[k] - R.dev_lo)); g_dst.push_back(B.src_off[k]); g_len.push_back(B.src_len[k]); }
+            }
+        ok = hg::stage_upload(ctx, B.src_ptr.data(), B.src_len.data(), B.src_off.data(), skip.data(), nsrc, B.data_bytes, d_data, s) == HG_OK &&
+             hg::stage_gather_dev(ctx, R.dev_lo, g_src.data(), g_len.data(), d_data, g_dst.data(), g_src.size(), s) == HG_OK;
+    } else ok = hg::stage_upload(ctx, B.src_ptr.data(), B.src_len.data(), B.src_off.data(), nullptr, B.src_ptr.size(), B.data_bytes, d_data, s) == HG_OK;
     for (int i = 0; i < 10; i++) if (ok && parts[i].bytes) ok = hipMemcpyAsync(d_tab + R.t_off[i], parts[i].src, parts[i].bytes, hipMemcpyHostToDevice, s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
     R.T = hgr::DevTables{(const hgr::PlanDev *)(d_tab + R.t_off[0]), (const hgr::Codec *)(d_tab + R.t_off[1]), (const hgr::HuffCode *)(d_tab + R.t_off[2]),
@@ -718,15 +736,29 @@ extern "C" int hg_cram_decode_bam_host(hg_ctx *ctx, size_t nslices, const hg_cra
                                        int32_t *status) {
     return hg_cram_decode_bam_host2(ctx, nslices, slices, major_version, nref, rg_names, nrg, total_bases, bam_out, bam_cap, rec_off, rec_bam_off, bam_bytes, status, nullptr);
 }
+// ... with block pointers that may be device addresses (internal: the fused run decoder of cram_file_host.hip)
+int hg_cram_decode_bam_devsrc(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, const char *const *rg_names,
+                              int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap, uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes,
+                              int32_t *status, const char *name_prefix, const uint8_t *dev_lo, const uint8_t *dev_hi);
 extern "C" int hg_cram_decode_bam_host2(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, const char *const *rg_names,
                                         int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap, uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes,
                                         int32_t *status, const char *name_prefix) {
+    return hg_cram_decode_bam_devsrc(ctx, nslices, slices, major_version, nref, rg_names, nrg, total_bases, bam_out, bam_cap, rec_off, rec_bam_off, bam_bytes, status, name_prefix,
+                                     nullptr, nullptr);
+}
+int hg_cram_decode_bam_devsrc(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, const char *const *rg_names,
+                              int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap, uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes,
+                              int32_t *status, const char *name_prefix, const uint8_t *dev_lo, const uint8_t *dev_hi) {
     if (!ctx || (nslices && (!slices || !bam_out || !rec_off || !status)) || (nrg && !rg_names)) return HG_EINVAL;
     if (nslices == 0) { if (rec_off) rec_off[0] = 0; if (bam_bytes) *bam_bytes = 0; return HG_OK; }
     hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
-    hg_cram_batch R; R.M.ctx = ctx;
+    hg_cram_batch R; R.M.ctx = ctx; R.dev_lo = dev_lo; R.dev_hi = dev_hi;
+    static const bool timing = getenv("HG_CRAM_RECORDS_TIMING") != nullptr;
+    const auto tt0 = std::chrono::steady_clock::now();
     int rc = rec_stage(ctx, R, nslices, slices, major_version, nref, true, true, (size_t)total_bases);
     if (rc) return rc;
+    if (timing) (void)hipStreamSynchronize(ctx->stream);
+    const auto tt1 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < nslices; i++) rec_off[i] = R.B.slices[i].rec_off;
     rec_off[nslices] = R.B.nrec;
     const BamSink sink{rg_names, nrg, bam_out, bam_cap, rec_bam_off, bam_bytes, name_prefix};
@@ -734,9 +766,14 @@ extern "C" int hg_cram_decode_bam_host2(hg_ctx *ctx, size_t nslices, const hg_cr
     for (size_t i = 0; i < nslices && i < R.status.size(); i++) status[i] = R.status[i];
     if (rc) return rc;
     hipStream_t s = ctx->stream;
+    const auto tt2 = std::chrono::steady_clock::now();
     const bool ok = (!R.bam_bytes || hipMemcpyAsync(bam_out, R.d_bam, R.bam_bytes, hipMemcpyDeviceToHost, s) == hipSuccess) &&
                     (!rec_bam_off || hipMemcpyAsync(rec_bam_off, R.d_bam_off, (R.B.nrec + 1) * 8, hipMemcpyDeviceToHost, s) == hipSuccess) && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) return HG_ELAUNCH;
+    if (timing) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "cram records call: stage %.1f ms, run %.1f ms, BAM to the host %.1f ms (%.1f MB)\n", ms(tt0, tt1), ms(tt1, tt2), ms(tt2, std::chrono::steady_clock::now()), R.bam_bytes / 1e6);
+    }
     for (size_t i = 0; i < nslices; i++) if (status[i] != 0) return HG_EBLOCK;
     return HG_OK;
 }

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <map>
 #include <vector>
+#include <cstdio>
+#include <cstdlib>
 #include "cram_records_core.h"
 
 namespace hgr {
@@ -304,12 +306,59 @@ inline int batch_build(Batch &B, const SliceIn *in, size_t n, int major) {
         d.rec_off = B.nrec; B.nrec += (uint64_t)sh.nrec;
         // capacities: a read name is copied out of a block, a CIGAR op needs a feature; features that cost no bits at all (constant
         // codecs) are bounded by 4 ops per record on top of one op per byte of the slice
-        d.name_cap = (uint32_t)std::min<uint64_t>(ext_bytes + (uint64_t)d.core_len + 16u, 0xffffffffull);
-        d.cig_cap = (uint32_t)std::min<uint64_t>(4ull * (uint64_t)sh.nrec + ext_bytes + 8ull * d.core_len + 16u, 0xffffffffull);
+        // ... and, where the compression header says WHICH blocks feed an array (EXTERNAL / BYTE_ARRAY_* codecs over blocks of the slice: what every
+        // writer emits for names, feature codes and tag values), by those blocks alone: names are copied out of the RN codec's blocks, a feature costs
+        // one byte of the FC block (and makes at most two CIGAR operations: the match run before it and its own), a tag value costs at least one byte of
+        // its codec's blocks.  (16 x cig_cap is also the decoder's run-away budget -- features + tag values walked per slice -- so a sixteenth of the slice's
+        // bytes stays in it: every feature and every tag value costs at least one byte.)  The generic bounds (every block of the slice could be names) made the arrays of a 10 000-read slice 17 MB -- 16 GB for the
+        // 1 000-slice batches of the whole-slice reader.  -1 = the codec reads the CORE block or is a constant: the generic bound stays.
+        auto slot_len = [&](int32_t slot) -> int64_t {
+            if (slot < 0 || (size_t)slot >= ns) return -1;
+            const uint32_t l = B.tab[d.tab_off + ns + (size_t)slot];
+            return l == 0xffffffffu ? 0 : (int64_t)l;
+        };
+        auto codec_bytes = [&](int32_t ci) -> int64_t {
+            if (ci < 0 || (size_t)ci >= H.codecs.size()) return -1;
+            const Codec &C = H.codecs[(size_t)ci];
+            if (C.kind == E_EXTERNAL || C.kind == E_BYTE_ARRAY_STOP) return slot_len(C.a);
+            if (C.kind == E_BYTE_ARRAY_LEN && C.a >= 0 && C.b >= 0 && (size_t)C.a < H.codecs.size() && (size_t)C.b < H.codecs.size()) {
+                const Codec &V = H.codecs[(size_t)C.b];
+                return V.kind == E_EXTERNAL ? slot_len(V.a) : -1;
+            }
+            return -1;
+        };
+        const uint64_t generic_names = ext_bytes + (uint64_t)d.core_len + 16u, generic_cig = 4ull * (uint64_t)sh.nrec + ext_bytes + 8ull * d.core_len + 16u;
+        const int64_t rn_bytes = H.plan.codec_of[S_RN] < 0 ? 0 : codec_bytes(H.plan.codec_of[S_RN]);
+        const int64_t fc_bytes = H.plan.codec_of[S_FC] < 0 ? 0 : (H.codecs[(size_t)H.plan.codec_of[S_FC]].kind == E_EXTERNAL ? codec_bytes(H.plan.codec_of[S_FC]) : -1);
+        d.name_cap = (uint32_t)std::min<uint64_t>(rn_bytes >= 0 ? std::min<uint64_t>((uint64_t)rn_bytes + 16u, generic_names) : generic_names, 0xffffffffull);
+        d.cig_cap = (uint32_t)std::min<uint64_t>(fc_bytes >= 0 ? std::min<uint64_t>(2ull * (uint64_t)fc_bytes + 4ull * (uint64_t)sh.nrec + 16u + (ext_bytes + 8ull * d.core_len) / 16u, generic_cig) : generic_cig, 0xffffffffull);
         d.cig_off = B.cig_total; B.cig_total += d.cig_cap;
         d.name_off = B.name_total; B.name_total += d.name_cap;
         // aux: the values are copied out of blocks, 3 bytes of tag + type are added per value; values that cost no bits bounded as above
-        d.aux_cap = (uint32_t)std::min<uint64_t>(4ull * (ext_bytes + d.core_len) + 64ull * (uint64_t)sh.nrec + 64u, 0xffffffffull);
+        uint64_t tag_bytes = 0; bool tags_known = true;
+        {
+            std::vector<char> seen_slot(ns, 0);
+            auto add_slot = [&](int32_t slot) { if (slot < 0 || (size_t)slot >= ns) { tags_known = false; return; } if (!seen_slot[(size_t)slot]) { seen_slot[(size_t)slot] = 1; tag_bytes += (uint64_t)slot_len(slot); } };
+            for (size_t t = 0; t < H.tl_codec.size() && tags_known; t++) {
+                const int32_t ci = H.tl_codec[t];
+                if (ci < 0) continue;
+                if ((size_t)ci >= H.codecs.size()) { tags_known = false; break; }
+                const Codec &C = H.codecs[(size_t)ci];
+                if (C.kind == E_EXTERNAL || C.kind == E_BYTE_ARRAY_STOP) add_slot(C.a);
+                else if (C.kind == E_BYTE_ARRAY_LEN && C.a >= 0 && C.b >= 0 && (size_t)C.a < H.codecs.size() && (size_t)C.b < H.codecs.size()) {
+                    const Codec &L = H.codecs[(size_t)C.a], &V = H.codecs[(size_t)C.b];
+                    if (V.kind != E_EXTERNAL || (L.kind != E_EXTERNAL && !(L.kind == E_HUFFMAN && L.b == 1))) tags_known = false;
+                    else { add_slot(V.a); if (L.kind == E_EXTERNAL) add_slot(L.a); else if (H.huff[(size_t)L.a].symbol <= 0) tags_known = false; }   // a constant length of 0 costs no byte at all
+                } else tags_known = false;
+            }
+        }
+        const uint64_t generic_aux = 4ull * (ext_bytes + d.core_len) + 64ull * (uint64_t)sh.nrec + 64u;
+        // regenerated MD:Z / NM (decode_md with a reference): a mismatch costs a byte of the FC block and a few
+        // characters of MD; a long deletion (few bytes in, its whole length out) can exceed this -- the slice then fails "no room" and the caller's fall-back takes it
+        const uint64_t md_room = !(s.decode_md != 0 && s.refs && s.nrefs) ? 0ull
+                               : fc_bytes >= 0 ? 8ull * (uint64_t)fc_bytes + 32ull * (uint64_t)sh.nrec          // per feature: a run length and a base; per record: "MD:Z", the last run, NM
+                                               : 2ull * ext_bytes + 8ull * d.core_len;
+        d.aux_cap = (uint32_t)std::min<uint64_t>(tags_known ? std::min<uint64_t>(4ull * tag_bytes + 64ull * (uint64_t)sh.nrec + 64u + md_room, generic_aux) : generic_aux, 0xffffffffull);
         d.aux_off = B.aux_total; B.aux_total += d.aux_cap;
         d.job_cap = (uint32_t)std::min<uint64_t>(4ull * (uint64_t)sh.nrec + 64u, 0x7fffffffull);     // a few per record; when the room runs out the copy is made at once
         d.job_off = B.job_total; B.job_total += d.job_cap;

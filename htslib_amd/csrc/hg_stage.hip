@@ -127,19 +127,21 @@ int stage_upload(hg_ctx *ctx, const uint8_t *const *src, const uint32_t *len, co
     if (!n || !total) return HG_OK;
     // the previous user of this pinned buffer may still be in flight on the stream
     if (hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
-    if (int rc = hgs::ensure_pinned(ctx, 0, total)) return rc;
-    uint8_t *h = (uint8_t *)ctx->h_stage[0];
-    uint64_t hi = 0;
-    std::vector<hgs::CopyJob> jobs;
-    jobs.reserve(n);
+    uint64_t hi = 0, lo = ~0ull;                             // only the stretch that holds pieces is mirrored and travels (skipped pieces: blocks that are already on the device)
     for (size_t i = 0; i < n; i++) {
         if (!len[i] || (skip && skip[i])) continue;
-        jobs.push_back({h + dst_off[i], src[i], len[i]});
         if (dst_off[i] + len[i] > hi) hi = dst_off[i] + len[i];
+        if (dst_off[i] < lo) lo = dst_off[i];
     }
-    hgs::host_copies(jobs);
     if (!hi) return HG_OK;
-    return hipMemcpyAsync(d_base, h, hi, hipMemcpyHostToDevice, s) == hipSuccess ? HG_OK : HG_ELAUNCH;
+    if (hi > total) return HG_EINVAL;
+    if (int rc = hgs::ensure_pinned(ctx, 0, hi - lo)) return rc;
+    uint8_t *h = (uint8_t *)ctx->h_stage[0];
+    std::vector<hgs::CopyJob> jobs;
+    jobs.reserve(n);
+    for (size_t i = 0; i < n; i++) if (len[i] && !(skip && skip[i])) jobs.push_back({h + (dst_off[i] - lo), src[i], len[i]});
+    hgs::host_copies(jobs);
+    return hipMemcpyAsync(d_base + lo, h, hi - lo, hipMemcpyHostToDevice, s) == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
 
 // Device pieces d_base + src_off[i] (len[i] bytes) -> host buffers dst[i].  Synchronises the stream.

@@ -497,6 +497,22 @@ int hg_cram_file_to_bam_host(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, 
 int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_t cram_len, const hg_cram_ref_seq *refs, int nrefs_given,
                               uint8_t *bam_out, size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags, const char *name_prefix);
 
+/* The same for a reader that walks the file itself -- cram_get_bam_seq's whole-slice path (cram/cram_decode.c:3268-3627: cram_next_slice -> cram_decode_slice ->
+ * cram_to_bam; htslib_amd/csrc/cram_reader_front.c calls this under that name inside a libhts build): the BODIES of a run of data containers, as they
+ * lie in the file after each container header (compression header block, then per slice the slice header block and its blocks), become the
+ * BAM records of those containers back to back -- no BAM header in front.  num_blocks / bases = the container header's fields.  sq_len[nref] = the
+ * @SQ LN values; rg_names = the @RG IDs in header order; refs as above; decode_md = the cram_fd's decode_md (-1 = hts_open's default: MD / NM are
+ * made when the file does not store them).  flags: HG_CRAM_IGNORE_MD5.  *bam_bytes = bytes written, or needed when the call returns HG_ENOMEM.
+ * HG_EBLOCK: a block or slice failed as it would fail cram_read_slice / cram_decode_slice (the caller lets the reference's decoder report it). */
+typedef struct hg_cram_container { const uint8_t *body; uint32_t body_len; int32_t num_blocks; uint64_t bases; } hg_cram_container;
+/* References on demand: called (on the calling thread, once per id and call) only for the sequences a slice actually needs -- cram_get_ref's role
+ * (cram/cram_io.c:3409).  Returns 0 and fills *out (upper case bases, valid until the decode call returns), or non-zero: not available.
+ * With get_ref != NULL, refs / nrefs_given are ignored. */
+typedef int (*hg_cram_get_ref_fn)(void *user, int ref_id, hg_cram_ref_seq *out);
+int hg_cram_containers_to_bam_host(hg_ctx *ctx, int major_version, size_t ncontainers, const hg_cram_container *containers, int nref, const int64_t *sq_len,
+                                   const char *const *rg_names, int nrg, const hg_cram_ref_seq *refs, int nrefs_given, hg_cram_get_ref_fn get_ref, void *user,
+                                   int flags, int decode_md, const char *name_prefix, uint8_t *bam_out, size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords);
+
 /* cram_index_build (cram/cram_index.c:779-870): the .crai text of a whole CRAM 2.x / 3.x file, one line per slice -- or per run of records on one
  * reference for multi-reference slices, which are the only slices decoded (blocks + the ref_id / apos / aend columns, one batch each).
  * Returns the number of bytes written, -2 for a file that is not sorted (the reference's error), or a negative HG_E* code.  The reference
