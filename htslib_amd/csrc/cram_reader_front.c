@@ -72,7 +72,7 @@ typedef struct reader {
     int nref, nrg; int64_t *sq_len; char **rg_names;
     int *held; int nheld, held_cap;   /* reference ids pinned by cram_get_ref for the run being decoded */
     int end_seen, end_eof, end_err;   /* cram_read_container has already said "no more": the next run is that news, it is not asked twice */
-    int stats; double t_io, t_dec; uint64_t tot_rec, tot_bam;
+    int stats; double t_io, t_dec, t_start, t_first, t_end, t_wait; uint64_t tot_rec, tot_bam;
 } reader;
 
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -80,7 +80,16 @@ static reader *g_readers;
 static volatile unsigned g_gen = 1;                         /* bumped whenever a reader goes away: invalidates the per-thread cache below */
 static __thread cram_fd *tl_fd; static __thread reader *tl_rd; static __thread unsigned tl_gen;
 
+static double g_t0;
+static void stats_at_exit(void);
+__attribute__((constructor)) static void reader_loaded(void) {
+    struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); g_t0 = (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+    const char *e = getenv("HTS_GPU_STATS");
+    if (e && e[0] == '1') atexit(stats_at_exit);
+}
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+static void stats_at_exit(void) { fprintf(stderr, "[htsgpu stats] process: exit handlers reached %.3f s after libhts was loaded\n", now_s() - g_t0); }
 
 static reader *find_reader(cram_fd *fd) {
     if (tl_fd == fd && tl_gen == g_gen) return tl_rd;
@@ -238,8 +247,9 @@ static void stop_producer(reader *R) {
 static void free_reader(reader *R) {
     stop_producer(R);
     if (R->stats)
-        fprintf(stderr, "[htsgpu stats] cram reader: %u runs, %llu records, %.1f MB of BAM; producer: I/O %.3f s, device decode %.3f s\n", R->runs_made,
-                (unsigned long long)R->tot_rec, (double)R->tot_bam / 1e6, R->t_io, R->t_dec);
+        fprintf(stderr, "[htsgpu stats] cram reader: %u runs, %llu records, %.1f MB of BAM; producer: I/O %.3f s, device decode %.3f s; consumer: first record after %.3f s, "
+                "end of input after %.3f s, waited for runs %.3f s, closed after %.3f s (reader started %.3f s after libhts was loaded)\n", R->runs_made, (unsigned long long)R->tot_rec, (double)R->tot_bam / 1e6, R->t_io, R->t_dec,
+                R->t_first - R->t_start, R->t_end - R->t_start, R->t_wait, now_s() - R->t_start, R->t_start - g_t0);
     for (int i = 0; i < 2; i++) { free(R->r[i].raw); free(R->r[i].cont); free(R->r[i].bam); }
     for (int i = 0; i < R->nrg; i++) free(R->rg_names[i]);
     free(R->rg_names); free(R->sq_len); free(R->held);
@@ -275,7 +285,7 @@ static reader *start_reader(cram_fd *fd) {
     if (hseek(fd->fp, here, SEEK_SET) < 0) { hclearerr(fd->fp); return NULL; }           /* a pipe: no way back for the fall-back */
     reader *R = calloc(1, sizeof *R);
     if (!R) return NULL;
-    R->fd = fd; R->ctx = ctx;
+    R->fd = fd; R->ctx = ctx; R->t_start = now_s();
     sam_hdr_t *h = fd->header;
     R->nref = sam_hdr_nref(h);
     R->nrg = sam_hdr_count_lines(h, "RG");
@@ -341,20 +351,23 @@ int cram_get_bam_seq(cram_fd *fd, bam_seq_t **bam) {
         if (R->cur && R->pos < R->cur->bam_len) {
             if (!*bam && !(*bam = bam_init1())) return -1;
             const int n = hand_out(R, *bam);
-            if (n >= 0) return n;
+            if (n >= 0) { if (R->t_first == 0) R->t_first = now_s(); return n; }
             hts_log_error("The device decoder returned a malformed BAM record");
             fd->err = EIO; fd->eof = 0;
             return -1;
         }
         pthread_mutex_lock(&R->m);
         if (R->cur) { R->cur = NULL; R->head ^= 1; R->ready--; pthread_cond_broadcast(&R->cv); }   /* the finished run goes back to the producer */
+        const double tw = now_s();
         while (R->ready == 0) pthread_cond_wait(&R->cv, &R->m);
         run *u = &R->r[R->head];
         pthread_mutex_unlock(&R->m);
+        R->t_wait += now_s() - tw;
         if (u->kind == RUN_RECORDS) { R->cur = u; R->pos = 0; continue; }
         /* the producer has exited (a run that is not records is its last) */
         stop_producer(R);
         if (u->kind == RUN_END) {
+            if (R->t_end == 0) R->t_end = now_s();
             fd->eof = u->fd_eof; fd->err = u->fd_err;
             return -1;                                          /* stays RUN_END: asking again gives the same answer, as the reference's reader does */
         }

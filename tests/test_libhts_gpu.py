@@ -257,3 +257,61 @@ def test_compressed_bam_with_index_on_the_fly_equals_stock(fx):
     want = view(VIEW_REF, ["-S", "-b", "xx#large_aux.sam"], fx, "t/stock2.bam")
     assert view(VIEW_REF, ["t/gpu2.bam", "xx"], fx) == view(VIEW_GPU, ["t/gpu2.bam", "xx"], fx)
     assert view(VIEW_REF, ["t/gpu2.bam"], fx) == view(VIEW_REF, ["t/stock2.bam"], fx)
+
+
+# ------------------------------------------------------------------------------------------------------------ the whole-slice reader under cram_get_bam_seq
+def _reader_stats(stderr):
+    return [ln for ln in stderr.decode("latin1").splitlines() if "cram reader:" in ln or "cram run" in ln]
+
+
+def test_whole_slice_reader_is_the_path_that_runs_and_its_switch_is_honoured(fx):
+    """cram_get_bam_seq inside libhts_gpu.so = htslib_amd/csrc/cram_reader_front.c (reference cram/cram_decode.c:3615): a plain sequential read goes through runs of
+    containers on the device (fused: blocks decoded in HBM, the record decoder beside them); HTS_GPU_CRAM_SLICE=0 leaves the reference's cram_decode_slice on our
+    per-block entry points; a region query (fd->range set) is the reference's reader by design.  All three print the SAM text stock htslib prints."""
+    view(VIEW_REF, ["-t", "ce.fa", "-S", "-C", "-o", "VERSION=3.0", "-o", "seqs_per_slice=100", "ce#1000.sam"], fx, "rd.cram")
+    want = view(VIEW_REF, ["-D", "rd.cram"], fx)
+    e = dict(_env(fx), HTS_GPU_STATS="1")
+    p = subprocess.run([VIEW_GPU, "-D", "rd.cram"], cwd=fx, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=600)
+    assert p.returncode == 0 and p.stdout == want
+    st = _reader_stats(p.stderr)
+    assert any("cram run (fused): 10 containers, 10 slices" in ln and "(rc 0)" in ln for ln in st), st
+    assert any("cram reader:" in ln and "1000 records" in ln for ln in st), st
+    p = subprocess.run([VIEW_GPU, "-D", "rd.cram"], cwd=fx, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(e, HTS_GPU_CRAM_SLICE="0"), timeout=600)
+    assert p.returncode == 0 and p.stdout == want and not _reader_stats(p.stderr)
+    p = subprocess.run([VIEW_GPU, "-D", "rd.cram"], cwd=fx, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(e, HTS_GPU_CRAM_FUSED="0"), timeout=600)
+    assert p.returncode == 0 and p.stdout == want and any("cram run:" in ln for ln in _reader_stats(p.stderr))        # the host-buffer composition of the same run
+
+
+def test_whole_slice_reader_hands_the_hard_cases_to_the_right_path(fx):
+    """embedded references and reference-less files (the run decoder digests an embedded block on the host: not fused), multi-reference slices (references asked for
+    by the ids in the RI series), multi-slice containers, an unsorted file: each equal to stock, each through the reader (no silent fall-back: the stats line
+    must show every record coming out of it)."""
+    cases = [("ce#1000.sam", "ce.fa", ["-o", "embed_ref=1"]), ("ce#1000.sam", "ce.fa", ["-o", "no_ref=1"]), ("ce#5b.sam", "ce.fa", ["-o", "multi_seq_per_slice=1"]),
+             ("ce#unmap2.sam", "ce.fa", ["-o", "seqs_per_slice=7", "-o", "slices_per_container=5"]), ("xx#unsorted.sam", "xx.fa", [])]
+    e = dict(_env(fx), HTS_GPU_STATS="1")
+    for sam, ref, o in cases:
+        view(VIEW_REF, ["-t", ref, "-S", "-C", "-o", "VERSION=3.0", *o, sam], fx, "hard.cram")
+        want = view(VIEW_REF, ["-D", "hard.cram"], fx)
+        nrec = sum(1 for ln in want.splitlines() if ln and not ln.startswith(b"@"))
+        p = subprocess.run([VIEW_GPU, "-D", "hard.cram"], cwd=fx, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=600)
+        assert p.returncode == 0 and p.stdout == want, (sam, o, p.stderr.decode("latin1")[-800:])
+        assert any("cram reader:" in ln and f" {nrec} records" in ln for ln in _reader_stats(p.stderr)), (sam, o, _reader_stats(p.stderr))
+
+
+def test_whole_slice_reader_leaves_damaged_files_to_the_reference(fx):
+    """a truncated file, a flipped payload byte (block CRC), a wrong reference (slice MD5): the run that meets the damage is handed back WHOLE to the reference's
+    reader (seek to its first container), so the records before it, the error text's last line and the exit status are stock htslib's."""
+    view(VIEW_REF, ["-t", "ce.fa", "-S", "-C", "-o", "VERSION=3.0", "-o", "seqs_per_slice=100", "ce#1000.sam"], fx, "dmg.cram")
+    raw = open(os.path.join(fx, "dmg.cram"), "rb").read()
+    flip = bytearray(raw); flip[len(raw) * 2 // 3] ^= 0x40
+    open(os.path.join(fx, "dmg_trunc.cram"), "wb").write(raw[:len(raw) * 3 // 5])
+    open(os.path.join(fx, "dmg_flip.cram"), "wb").write(bytes(flip))
+    fa = open(os.path.join(fx, "ce.fa")).read().replace("GCCTAAGCC", "GCCTTAGCC")
+    open(os.path.join(fx, "ce_wrong.fa"), "w").write(fa)
+    subprocess.run([VIEW_REF, "-t", "ce_wrong.fa", "-S", "-b", "ce#5.sam"], cwd=fx, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=_env(fx))      # (writes ce_wrong.fa.fai)
+    for f, args in (("dmg_trunc.cram", []), ("dmg_flip.cram", []), ("dmg.cram", ["-i", "reference=ce_wrong.fa"])):
+        r = subprocess.run([VIEW_REF, *args, f], cwd=fx, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=_env(fx), timeout=600)
+        g = subprocess.run([VIEW_GPU, *args, f], cwd=fx, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=_env(fx), timeout=600)
+        assert r.returncode != 0, (f, "the damage must be one stock htslib notices")
+        assert g.returncode == r.returncode and g.stdout == r.stdout, (f, r.returncode, g.returncode, len(r.stdout), len(g.stdout), g.stderr.decode("latin1")[-600:])
+        assert g.stderr.decode("latin1").strip().splitlines()[-1:] == r.stderr.decode("latin1").strip().splitlines()[-1:], (f, r.stderr[-300:], g.stderr[-300:])
