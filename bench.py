@@ -1148,12 +1148,14 @@ def libhts_view(run: Run, bam_path: str, plain_bytes: int, nreads: int = 12_000_
 
 def libhts_view_cram(run: Run, gpu: str, ref: str, ref_threads, copies: int = 64, nrec: int = 10000):
     """libhts-level CRAM figures (north_star: "samtools/bcftools see a drop-in libhts"): test_view on libhts_gpu.so vs on the reference's libhts,
-      cram_decode = view -@T -B in.cram              (cram_decode_slice on the pool's threads, cram_uncompress_block per block)
-      cram_encode = view -@T -C -o version=3.0 in.bam (bam_read1 + cram_encode_slice + cram_compress_block2, to /dev/null)
+      cram_decode       = view -@T -B in.cram               (ours: cram_get_bam_seq = the whole-slice reader, htslib_amd/csrc/cram_reader_front.c: runs of containers
+                                                              decoded on the device, block codecs + cram_decode_slice + cram_to_bam; stock: cram_decode_slice on the pool)
+      cram_decode_blocks = the same with HTS_GPU_CRAM_SLICE=0 (the reference's cram_decode_slice on our per-block entry points: round 6's first form)
+      cram_encode       = view -@T -C -o version=3.0 in.bam  (bam_read1 + cram_encode_slice + cram_compress_block2, to /dev/null)
+      cram_decode_large / cram_to_bam_large = view -B / view -b on a file of 4 x the slices (10 240 000 records): what a run of 1 024 slices buys, and `samtools view -b in.cram`
     on 256 slices (2 560 000 records) of the record baselines' workload, at the writer's default level (gzip + rANS 4x8).  Whole-process wall clock, best of 2.
-    libhts_gpu runs with -@16 and -@64: its pool threads mostly WAIT (a slice's blocks are decoded ahead of the call that asks for them / compressed behind the
-    call that names them, in device batches that take ~0.1-0.2 s whatever their size -- one 1.5 MB quality stream through the 4-way rANS coder is one chain), so the
-    number of slices in flight, not the cores, sets its rate."""
+    A run of the reader takes 0.2-0.4 s whatever it holds (one 1.5 MB quality stream through the 4-way rANS decoder is one chain on one lane group, ~150 ms), a
+    process pays ~0.2-0.3 s of HIP start-up before it and ~0.15 s of teardown after: stock htslib is through 2.56 M records before our first record is out."""
     import subprocess
     import numpy as np
     from htslib_amd import _native as nat, synth_cram
@@ -1167,28 +1169,46 @@ def libhts_view_cram(run: Run, gpu: str, ref: str, ref_threads, copies: int = 64
         if r.returncode != 0: return {"cram_error": r.stderr.decode("latin1")[-300:]}
         plain = len(w.bam_bytes)
 
-        def one(exe, threads, mode):
-            cmd = ([exe, "-@", str(threads), "-B", "-i", "reference=" + w.fa, cram] if mode == "cram_decode" else
-                   [exe, "-@", str(threads), "-C", "-o", "version=3.0", "-t", w.fa, "-p", "/dev/null", w.bam])
+        def one(exe, threads, mode, W=None, cram_=None, plain_=None):
+            W = W or w; cram_ = cram_ or cram; plain_ = plain_ or plain
+            env = dict(os.environ, HTS_GPU_CRAM_SLICE="0") if mode == "cram_decode_blocks" else None
+            cmd = ([exe, "-@", str(threads), "-B", "-i", "reference=" + W.fa, cram_] if mode in ("cram_decode", "cram_decode_blocks") else
+                   [exe, "-@", str(threads), "-b", "-i", "reference=" + W.fa, "-p", os.path.join(W.dir, "out.bam"), cram_] if mode == "cram_to_bam" else
+                   [exe, "-@", str(threads), "-C", "-o", "version=3.0", "-t", W.fa, "-p", "/dev/null", W.bam])
             best = None
             for _ in range(2):
                 t = time.perf_counter()
-                p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+                p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600, env=env)
                 dt = time.perf_counter() - t
                 if p.returncode != 0: return {"error": p.stderr.decode("latin1")[-300:], "threads": threads}
                 best = dt if best is None else min(best, dt)
-            return {"seconds": round(best, 3), "bam_GBps": round(plain / best / 1e9, 3), "M_records_per_s": round(w.nrec / best / 1e6, 3), "threads": threads}
+            return {"seconds": round(best, 3), "bam_GBps": round(plain_ / best / 1e9, 3), "M_records_per_s": round(W.nrec / best / 1e6, 3), "threads": threads}
+
+        def both(mode, gpu_threads, **kw):
+            tries_g = [one(gpu, t, mode, **kw) for t in gpu_threads]
+            good = [x for x in tries_g if "seconds" in x]
+            e = {"libhts_gpu": min(good, key=lambda x: x["seconds"]) if good else tries_g[-1]}
+            if not run.args.no_cpu_baseline and mode != "cram_decode_blocks":
+                tries = [one(ref, t, mode, **kw) for t in ref_threads]
+                good = [x for x in tries if "seconds" in x]
+                e["reference"] = min(good, key=lambda x: x["seconds"]) if good else tries[-1]
+                e["reference_by_threads"] = {str(x.get("threads", "?")): x.get("seconds") for x in tries}
+            return e
 
         out = {"cram_records": w.nrec, "cram_file_bytes": os.path.getsize(cram), "cram_bam_GB": round(plain / 1e9, 3)}
-        for mode in ("cram_decode", "cram_encode"):
-            tries_g = [one(gpu, t, mode) for t in (16, 64)]
-            good = [x for x in tries_g if "seconds" in x]
-            out[mode] = {"libhts_gpu": min(good, key=lambda x: x["seconds"]) if good else tries_g[-1]}
-            if not run.args.no_cpu_baseline:
-                tries = [one(ref, t, mode) for t in ref_threads]
-                good = [x for x in tries if "seconds" in x]
-                out[mode]["reference"] = min(good, key=lambda x: x["seconds"]) if good else tries[-1]
-                out[mode]["reference_by_threads"] = {str(x.get("threads", "?")): x.get("seconds") for x in tries}
+        out["cram_decode"] = both("cram_decode", (4, 16))
+        out["cram_decode_blocks"] = both("cram_decode_blocks", (64,))
+        out["cram_encode"] = both("cram_encode", (16, 64))
+        w.close()
+        # the large file: four times the slices (one run of 256 + one of 768 slices in the reader)
+        w = RefCramWorkload(eng, base, 4 * copies)
+        big = os.path.join(w.dir, "in_l5.cram")
+        r = subprocess.run([ref, "-@", "32", "-C", "-o", "version=3.0", "-t", w.fa, "-p", big, w.bam], capture_output=True)
+        if r.returncode != 0: return dict(out, cram_large_error=r.stderr.decode("latin1")[-300:])
+        out["cram_large_records"] = w.nrec
+        kw = dict(W=w, cram_=big, plain_=len(w.bam_bytes))
+        out["cram_decode_large"] = both("cram_decode", (4,), **kw)
+        out["cram_to_bam_large"] = both("cram_to_bam", (4,), **kw)
         return out
     finally:
         w.close()
@@ -1636,7 +1656,7 @@ def compact(o, depth=0):
             if k == "libhts_view" and isinstance(v, dict):
                 # the libhts-level figures, flat: {leg: {gpu_s, gpu_threads, ref_s, ref_threads}}
                 flat = {}
-                for leg in ("decode", "bam2bam", "cram_decode", "cram_encode"):
+                for leg in ("decode", "bam2bam", "cram_decode", "cram_decode_blocks", "cram_encode", "cram_decode_large", "cram_to_bam_large"):
                     e = v.get(leg)
                     if not isinstance(e, dict): continue
                     g, r = e.get("libhts_gpu") or {}, e.get("reference") or {}
