@@ -342,7 +342,7 @@ extern "C" int hg_tok3_decode_host(hg_ctx *ctx, const uint8_t *const *in, const 
         }
         if (rc_ > 0xffffffffull || tab.size() > 0x7fffffffull) return HG_EINVAL;
         J.rec_cap = (uint32_t)rc_;
-        recs += rc_ + 64; names += 3ull * (nn + 1ull);
+        recs += rc_ + 64; names += 14ull * (nn + 2ull);             // tok3.hip: PAR_ARRAYS words per name for the position-major kernel (the serial one uses three)
         ooff += ((uint64_t)ulen + 15u) & ~15ull;
         jobs.push_back(J); job_top.push_back((uint32_t)i);
     }
@@ -350,7 +350,7 @@ extern "C" int hg_tok3_decode_host(hg_ctx *ctx, const uint8_t *const *in, const 
     const size_t nj = jobs.size();
     const uint64_t tbytes = (tboff + 63u) & ~63ull;
     int rc;
-    if ((rc = ensure_scratch(ctx, 0, ioff + 64)) || (rc = ensure_scratch(ctx, 8, ooff + 64)) || (rc = ensure_scratch(ctx, 9, recs * 12 + 64)) ||
+    if ((rc = ensure_scratch(ctx, 0, ioff + 64)) || (rc = ensure_scratch(ctx, 8, ooff + 64)) || (rc = ensure_scratch(ctx, 9, recs * 16 + 64)) ||
         (rc = ensure_scratch(ctx, 10, names * 4 + 64)) || (rc = ensure_scratch(ctx, 11, tab.size() * 4 + 64)) ||
         (rc = ensure_scratch(ctx, 12, nj * sizeof(hg::tok3_job) + nj * 4 + 64))) return rc;
     hipStream_t s = ctx->stream;

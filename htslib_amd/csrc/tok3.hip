@@ -16,6 +16,7 @@
 //   lane writes its own few bytes.  Names with more than 64 tokens take a second pass.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "htsgpu.h"
 #include "hg_device.h"
 #include "hg_internal.h"
@@ -37,14 +38,15 @@ __device__ __forceinline__ uint32_t ndigits(uint32_t v) {
 
 __global__ __launch_bounds__(64)
 void tok3_names_kernel(const uint8_t *__restrict__ tb, const hg::tok3_job *__restrict__ jobs, uint32_t njobs,
-                       const uint32_t *__restrict__ tab, uint8_t *out, uint32_t *rec, uint32_t *names, int32_t *status) {
+                       const uint32_t *__restrict__ tab, uint8_t *out, uint32_t *rec, uint32_t *names, int32_t *status, int only_redo) {
     __shared__ WaveLds S;
     const int lane = threadIdx.x;
     for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
+        if (only_redo && status[j] != 1) continue;                  // (after the position-major kernel: the jobs it handed back)
         const hg::tok3_job J = jobs[j];
         const uint8_t *B = tb + J.tb_base;
         uint8_t *o = out + J.out_off;
-        uint32_t *R = rec + J.rec_off * 3ull;                      // (off, len | numeric << 31, val) per token
+        uint32_t *R = rec + J.rec_off * 4ull;                      // (off, len | numeric << 31, val) per token; the job's region is sized for the position-major kernel's 4-word records
         uint32_t *noff = names + J.name_off, *first = noff + (J.nn + 1u), *ntok = first + (J.nn + 1u);
         int err = (J.nn && J.ntp < 1) ? 1 : 0;
         // stream table -> LDS; positions beyond ntp are empty
@@ -182,17 +184,313 @@ void tok3_names_kernel(const uint8_t *__restrict__ tb, const hg::tok3_job *__res
     }
 }
 
+
+// ================================================================================================
+// The same reconstruction, POSITION-MAJOR (round 6): one workgroup of 16 wavefronts per block, lanes over the NAMES.
+//
+// The serial form above walks the names in order because name n refers to name n - d; 10 000 names x ~3 us were the long pole of every CRAM 3.1 slice
+// decode (27-33 ms per 256 slices beside 15-19 ms of entropy decoding).  Nothing in the format needs that order:
+//   * which stream entry a name reads is a COUNT: at token position p the k-th name still alive reads TYPE[p][k], and the k-th name of type t reads the k-th
+//     entry of stream (p, t) -- exclusive prefix sums over the names (the k-th STRING starts behind the k-th NUL: a prefix count over the stream's bytes);
+//   * what DELTA / MATCH take from the earlier name is the same position's token of that name: per position a forest over the names with edges n -> n - d,
+//     and along a path the tokens compose -- (value, length) -> (value + D, length rule) with three length rules (MATCH keeps, DELTA takes the digit count,
+//     DELTA0 pads to the earlier length).  Pointer jumping collapses every path to its root (a literal token) in log2(depth) rounds; a counter field that
+//     ticks through the whole block is a path of 10 000 names and takes 14 rounds;
+//   * where a token lands is the name's start + the lengths of the tokens before it: a running per-name sum over the positions, and one prefix sum over the
+//     finished name lengths; DUP names copy their (resolved) source afterwards.
+// Per position: two prefix-sum sweeps, the token fetch, the jumping rounds, the record sweep -- every one a coalesced pass over per-name arrays that stay in L2.
+// One thing is NOT reproduced: 32-bit wrap-around INSIDE a DELTA0 path changes the digit counts the serial walk would see on the way; such a block (and one with
+// 2^28 names) reports status 1 and the serial kernel decodes it (launch_tok3_names runs it over the status-1 jobs).  Error verdicts are those of the serial walk.
+// ================================================================================================
+constexpr int PT = 1024, PW = PT / 64;
+enum { K_NONE = 0, K_STR = 1, K_CHR = 2, K_NUM = 3 };
+enum { M_ID = 0, M_NUM = 1, M_PAD = 2 };
+constexpr uint32_t NOPE = 0xffffffffu, ROOTP = 0x3fffffffu;
+constexpr uint32_t PAR_ARRAYS = 14;                                 // words per name (+2) a job needs behind name_off; launch_tok3_names' callers size by it
+
+struct ParLds { uint32_t wsum[PW][8]; uint32_t soff[16], slen[16]; };
+
+template <int K>
+__device__ __forceinline__ void block_scan(uint32_t (&v)[K], uint32_t (&tot)[K], ParLds &L, int lane, int wave) {
+    uint32_t incl[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) incl[k] = wave_incl_scan_dpp(v[k]);
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < K; k++) L.wsum[wave][k] = incl[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        uint32_t base = 0, t = 0;
+#pragma unroll
+        for (int w = 0; w < PW; w++) { const uint32_t x = L.wsum[w][k]; if (w < wave) base += x; t += x; }
+        tot[k] = t; v[k] = base + incl[k] - v[k];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t rd32u(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+__global__ __launch_bounds__(PT)
+void tok3_names_par_kernel(const uint8_t *__restrict__ tb, const hg::tok3_job *__restrict__ jobs, uint32_t njobs,
+                           const uint32_t *__restrict__ tab, uint8_t *out, uint32_t *rec, uint32_t *names, int32_t *status) {
+    __shared__ ParLds L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
+        const hg::tok3_job J = jobs[j];
+        const uint8_t *B = tb + J.tb_base;
+        uint8_t *o = out + J.out_off;
+        uint32_t *R = rec + J.rec_off * 4ull;                       // (name, offset inside the name, length | kind << 28, value / stream offset / character) per token
+        const uint32_t nn = J.nn;
+        const size_t N2 = (size_t)nn + 2u;
+        uint32_t *W = names + J.name_off;
+        uint32_t *noff = W, *mraw = W + N2, *eff = W + 2 * N2, *pm = W + 3 * N2, *state = W + 4 * N2, *acc = W + 5 * N2, *tval = W + 6 * N2, *tlk = W + 7 * N2,
+                 *tsrc = W + 8 * N2, *rank = W + 9 * N2, *strs = W + 10 * N2;
+        unsigned long long *link = (unsigned long long *)(W + 12 * N2);     // par | mode << 30 in the low word, D in the high one
+        // (verdicts are gathered in registers and agreed on at barriers -- __syncthreads_or -- so that every thread takes every exit together)
+        int myerr = (nn && J.ntp < 1) ? 1 : 0, myredo = nn >= (1u << 28) ? 1 : 0;
+        bool stop = myerr || myredo;
+        // ---- position 0: DUP / DIFF and the distance -------------------------------------------------------------
+        if (!stop && nn) {
+            const uint32_t t0off = tab[J.tab_off + T_TYPE * 2u], t0raw = tab[J.tab_off + T_TYPE * 2u + 1u];
+            const uint32_t doff[2] = {tab[J.tab_off + T_DUP * 2u], tab[J.tab_off + T_DIFF * 2u]}, dlen[2] = {tab[J.tab_off + T_DUP * 2u + 1u], tab[J.tab_off + T_DIFF * 2u + 1u]};
+            uint32_t carry[2] = {0, 0};
+            for (uint32_t base = 0; base < nn; base += PT) {
+                const uint32_t n = base + (uint32_t)tid;
+                const bool has = n < nn;
+                uint32_t ty0 = 255;
+                if (has && n < (t0raw & 0x7fffffffu)) ty0 = (t0raw >> 31) ? (n == 0 ? t0off : (uint32_t)T_MATCH) : B[t0off + n];
+                bool bad = has && ty0 != T_DUP && ty0 != T_DIFF;
+                uint32_t v[2] = {has && ty0 == T_DUP ? 1u : 0u, has && ty0 == T_DIFF ? 1u : 0u}, tot[2];
+                block_scan<2>(v, tot, L, lane, wave);
+                if (has && !bad) {
+                    const int w = ty0 == T_DUP ? 0 : 1;
+                    const unsigned long long dc = 4ull * ((unsigned long long)carry[w] + v[w]);
+                    if (dc + 4u > dlen[w]) bad = true;
+                    else {
+                        const uint32_t dist = rd32u(B + doff[w] + dc);
+                        if (dist > n || (w == 0 && dist == 0)) bad = true;
+                        else { mraw[n] = n - dist; state[n] = w == 0 ? 1u : 0u; acc[n] = 0; eff[n] = w == 0 ? n - dist : n; }
+                    }
+                }
+                carry[0] += tot[0]; carry[1] += tot[1];
+                if (bad) myerr = 1;
+            }
+            stop = __syncthreads_or(myerr) != 0;
+            // a DUP name stands for the name its chain of DUPs ends in
+            while (!stop) {
+                int changed = 0;
+                for (uint32_t n = (uint32_t)tid; n < nn; n += PT) {
+                    const uint32_t e = eff[n];
+                    if (e != n && (state[e] & 1u)) { eff[n] = eff[e]; changed = 1; }
+                }
+                if (!__syncthreads_or(changed)) break;
+            }
+            if (!stop) for (uint32_t n = (uint32_t)tid; n < nn; n += PT) pm[n] = mraw[n] == n ? NOPE : eff[mraw[n]];
+            __syncthreads();
+        }
+        // ---- token positions ----------------------------------------------------------------------------------
+        uint32_t posbase = 0;
+        for (uint32_t tp = 1; !stop && nn && tp < J.ntp && tp < MAX_TOK; tp++) {
+            if (tid < 16) { L.soff[tid] = tab[J.tab_off + (tp * 16u + (uint32_t)tid) * 2u]; L.slen[tid] = tab[J.tab_off + (tp * 16u + (uint32_t)tid) * 2u + 1u]; }
+            __syncthreads();
+            int myany = 0;
+            const uint32_t toff = L.soff[T_TYPE], tcount = L.slen[T_TYPE] & 0x7fffffffu; const bool implied = (L.slen[T_TYPE] >> 31) != 0;
+            // sweep A: who is alive, its TYPE byte, its entry number in the stream of that type
+            uint32_t calive = 0, ccur[6] = {0, 0, 0, 0, 0, 0};
+            for (uint32_t base = 0; base < nn; base += PT) {
+                const uint32_t n = base + (uint32_t)tid;
+                const bool has = n < nn;
+                const bool alive = has && !(state[n] & 3u);
+                uint32_t a[1] = {alive ? 1u : 0u}, at[1];
+                block_scan<1>(a, at, L, lane, wave);
+                const uint32_t r = calive + a[0];
+                uint32_t ty = 255;
+                if (alive && r < tcount) ty = implied ? (r == 0 ? toff : (uint32_t)T_MATCH) : B[toff + r];
+                if (alive && (ty > T_END || ty == T_TYPE || ty == T_DZLEN || ty == T_DUP || ty == T_DIFF)) myerr = 1;      // out of TYPE bytes before END, or not a token type
+                uint32_t v[6] = {alive && ty == T_STRING, alive && ty == T_CHAR, alive && ty == T_DIGITS, alive && ty == T_DIGITS0, alive && ty == T_DELTA, alive && ty == T_DELTA0}, tot[6];
+                block_scan<6>(v, tot, L, lane, wave);
+                if (has) {
+                    rank[n] = alive ? r : NOPE;
+                    if (alive) {
+                        tlk[n] = ty;
+                        tval[n] = ty == T_STRING ? ccur[0] + v[0] : ty == T_CHAR ? ccur[1] + v[1] : ty == T_DIGITS ? ccur[2] + v[2] : ty == T_DIGITS0 ? ccur[3] + v[3]
+                                : ty == T_DELTA ? ccur[4] + v[4] : ty == T_DELTA0 ? ccur[5] + v[5] : 0u;
+                    }
+                }
+                calive += at[0];
+#pragma unroll
+                for (int k = 0; k < 6; k++) ccur[k] += tot[k];
+            }
+            if (__syncthreads_or(myerr)) { stop = true; break; }
+            if (calive == 0) break;                                  // every name has had its END
+            // the k-th STRING of this position starts behind the k-th NUL of the stream
+            const uint32_t nstr = ccur[0];
+            if (nstr) {
+                const uint32_t so = L.soff[T_STRING], sl = L.slen[T_STRING];
+                uint32_t cn = 0;
+                if (tid == 0) strs[0] = 0;
+                for (uint32_t base = 0; base < sl && cn <= nstr; base += PT * 16u) {
+                    const uint32_t i0 = base + (uint32_t)tid * 16u;
+                    uint32_t mask = 0;
+                    for (uint32_t k = 0; k < 16u && i0 + k < sl; k++) if (B[so + i0 + k] == 0) mask |= 1u << k;
+                    uint32_t c[1] = {(uint32_t)__popc(mask)}, ct[1];
+                    block_scan<1>(c, ct, L, lane, wave);
+                    uint32_t ord = cn + c[0];
+                    while (mask) { const uint32_t k = (uint32_t)__ffs((int)mask) - 1u; mask &= mask - 1u; if (ord + 1u <= nstr) strs[ord + 1u] = i0 + k + 1u; ord++; }
+                    cn += ct[0];
+                }
+                if (cn < nstr) myerr = 1;                             // a STRING without its terminator
+                if (__syncthreads_or(myerr)) { stop = true; break; }
+            }
+            // sweep B: fetch the tokens; literal ones are final, DELTA / MATCH note their edge
+            for (uint32_t n = (uint32_t)tid; n < nn; n += PT) {
+                if (rank[n] == NOPE) continue;
+                const uint32_t ty = tlk[n], k = tval[n];
+                uint32_t len = 0, kind = K_NONE, val = 0, src = 0, par = ROOTP, mode = M_ID, D = 0;
+                bool bad = false;
+                if (ty == T_STRING) { const uint32_t a = strs[k], e = strs[k + 1u] - 1u; len = e - a; kind = K_STR; src = L.soff[T_STRING] + a; }
+                else if (ty == T_CHAR) { if (k >= L.slen[T_CHAR]) bad = true; else { src = B[L.soff[T_CHAR] + k]; len = 1; kind = K_CHR; } }
+                else if (ty == T_DIGITS || ty == T_DIGITS0) {
+                    if (4ull * k + 4u > L.slen[ty]) bad = true;
+                    else {
+                        val = rd32u(B + L.soff[ty] + 4ull * k); kind = K_NUM;
+                        uint32_t width = 0;
+                        if (ty == T_DIGITS0) { if (k >= L.slen[T_DZLEN]) bad = true; else width = B[L.soff[T_DZLEN] + k]; }
+                        if (width > 15u) width = 15u;
+                        const uint32_t nd = ndigits(val); len = nd > width ? nd : width;
+                    }
+                } else if (ty == T_DELTA || ty == T_DELTA0 || ty == T_MATCH) {
+                    const uint32_t p = pm[n];
+                    if (p == NOPE || rank[p] == NOPE) bad = true;    // no earlier name, or it has no token at this position
+                    else if (ty == T_MATCH) par = p;
+                    else if (k >= L.slen[ty]) bad = true;
+                    else { par = p; D = B[L.soff[ty] + k]; mode = ty == T_DELTA ? M_NUM : M_PAD; }
+                } else if (ty == T_END) state[n] |= 2u;
+                if (bad) { myerr = 1; continue; }
+                if (par != ROOTP) myany = 1;
+                else { tval[n] = val; tlk[n] = len | (kind << 28); tsrc[n] = src; }
+                link[n] = (unsigned long long)(par | (mode << 30)) | ((unsigned long long)D << 32);
+            }
+            if (__syncthreads_or(myerr)) { stop = true; break; }
+            const bool any = __syncthreads_or(myany) != 0;
+            // pointer jumping: every edge ends at a literal token, carrying the composition of the steps on its path
+            while (any) {
+                int changed = 0;
+                for (uint32_t base = 0; base < nn; base += 4u * PT) {          // four independent edges per thread in flight: the loads are a dependent pair each
+                    unsigned long long me[4], up[4]; uint32_t idx[4]; bool go[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        idx[u] = base + (uint32_t)u * PT + (uint32_t)tid;
+                        go[u] = idx[u] < nn && rank[idx[u]] != NOPE;
+                        me[u] = go[u] ? link[idx[u]] : (unsigned long long)ROOTP;
+                        go[u] = go[u] && ((uint32_t)me[u] & ROOTP) != ROOTP;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) up[u] = go[u] ? link[(uint32_t)me[u] & ROOTP] : (unsigned long long)ROOTP;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t gpar = (uint32_t)up[u] & ROOTP;
+                        if (!go[u] || gpar == ROOTP) continue;       // my parent is a literal: done
+                        const uint32_t m1 = ((uint32_t)me[u] >> 30) & 3u, m0 = ((uint32_t)up[u] >> 30) & 3u;       // m0 applies first
+                        const unsigned long long Ds = (me[u] >> 32) + (up[u] >> 32);
+                        if (Ds > 0xffffffffull) myredo = 1;
+                        const uint32_t mo = m1 == M_ID ? m0 : m1 == M_NUM ? (uint32_t)M_NUM : (m0 == M_NUM ? (uint32_t)M_NUM : (uint32_t)M_PAD);
+                        link[idx[u]] = (unsigned long long)(gpar | (mo << 30)) | ((Ds & 0xffffffffull) << 32);
+                        changed = 1;
+                    }
+                }
+                if (!__syncthreads_or(changed)) break;
+            }
+            // sweep C: resolve, record, advance the names
+            for (uint32_t n = (uint32_t)tid; n < nn; n += PT) {
+                const uint32_t r = rank[n];
+                if (r == NOPE) continue;
+                const unsigned long long me = link[n];
+                const uint32_t par = (uint32_t)me & ROOTP;
+                uint32_t val, lk, src;
+                if (par == ROOTP) { val = tval[n]; lk = tlk[n]; src = tsrc[n]; }
+                else {
+                    const uint32_t mode = ((uint32_t)me >> 30) & 3u;
+                    const uint32_t rv = tval[par], rl = tlk[par];
+                    const unsigned long long sum = (unsigned long long)rv + (me >> 32);
+                    if (sum > 0xffffffffull) myredo = 1;
+                    val = (uint32_t)sum;
+                    if (mode == M_ID) { lk = rl; src = tsrc[par]; }
+                    else {
+                        const uint32_t nd = ndigits(val);
+                        uint32_t width = mode == M_PAD ? (rl & 0x0fffffffu) : 0u;
+                        if (width > 15u) width = 15u;
+                        lk = (nd > width ? nd : width) | ((uint32_t)K_NUM << 28); src = 0;
+                    }
+                }
+                const uint32_t a = acc[n], len = lk & 0x0fffffffu;
+                uint32_t *q = R + ((size_t)posbase + r) * 4u;
+                q[0] = n; q[1] = a; q[2] = lk; q[3] = (lk >> 28) == K_NUM ? val : src;
+                if ((unsigned long long)a + len > J.ulen) myerr = 1; else acc[n] = a + len;
+            }
+            if (__syncthreads_or(myerr)) { stop = true; break; }
+            posbase += calive;
+        }
+        // ---- name lengths -> offsets; tokens -> bytes ------------------------------------------------------------
+        const bool redo = __syncthreads_or(myredo) != 0;
+        if (!stop && !redo && nn) {
+            unsigned long long total = 0;
+            for (uint32_t base = 0; base < nn; base += PT) {
+                const uint32_t n = base + (uint32_t)tid;
+                const bool has = n < nn;
+                uint32_t len = 0;
+                if (has) {
+                    const uint32_t st = state[n];
+                    if (!(st & 1u) && !(st & 2u)) myerr = 1;            // a name without its END
+                    len = acc[(st & 1u) ? eff[n] : n] + 1u;
+                }
+                uint32_t v[1] = {len}, t[1];
+                block_scan<1>(v, t, L, lane, wave);
+                if (has) noff[n] = (uint32_t)(total + v[0]);
+                total += t[0];
+            }
+            if (total != J.ulen) myerr = 1;
+            if (!__syncthreads_or(myerr)) {
+                for (uint32_t t = (uint32_t)tid; t < posbase; t += PT) {
+                    const uint32_t *q = R + (size_t)t * 4u;
+                    const uint32_t lk = q[2], len = lk & 0x0fffffffu, kind = lk >> 28, x = q[3];
+                    uint8_t *w = o + noff[q[0]] + q[1];
+                    if (kind == K_STR) { const uint8_t *p = B + x; for (uint32_t k = 0; k < len; k++) w[k] = p[k]; }
+                    else if (kind == K_CHR) w[0] = (uint8_t)x;
+                    else if (kind == K_NUM) { uint32_t v = x; for (uint32_t k = len; k-- > 0;) { w[k] = (uint8_t)('0' + v % 10u); v /= 10u; } }
+                }
+                for (uint32_t n = (uint32_t)tid; n < nn; n += PT) if (!(state[n] & 1u)) o[noff[n] + acc[n]] = 0;
+                __syncthreads();
+                for (uint32_t n = (uint32_t)tid; n < nn; n += PT)
+                    if (state[n] & 1u) { const uint32_t e = eff[n], len = acc[e] + 1u; const uint8_t *p = o + noff[e]; uint8_t *w = o + noff[n]; for (uint32_t k = 0; k < len; k++) w[k] = p[k]; }
+            }
+        } else if (!stop && !redo && !nn && J.ulen != 0) myerr = 1;
+        const int err = __syncthreads_or(myerr);
+        if (tid == 0) status[j] = err ? -1 : redo ? 1 : 0;
+        __syncthreads();
+    }
+}
+
 }  // namespace hgt
 
 namespace hg {
 int launch_tok3_names(hg_ctx *ctx, const void *d_tb, const tok3_job *d_jobs, size_t njobs, const uint32_t *d_tab, void *d_out,
                       uint32_t *d_rec, uint32_t *d_names, int32_t *d_status, hipStream_t s) {
     if (!njobs) return HG_OK;
+    static const bool par = [] { const char *e = getenv("HG_TOK3_PAR"); return !(e && e[0] == '0'); }();      // 0: the serial walk for every block (A/B)
     size_t wgs = njobs;
+    if (par) {
+        const size_t maxp = (size_t)ctx->cus * 4;
+        hipLaunchKernelGGL(hgt::tok3_names_par_kernel, dim3((unsigned)(wgs > maxp ? maxp : wgs)), dim3(hgt::PT), 0, s, (const uint8_t *)d_tb, d_jobs, (uint32_t)njobs,
+                           d_tab, (uint8_t *)d_out, d_rec, d_names, d_status);
+        if (hipGetLastError() != hipSuccess) return HG_ELAUNCH;
+    }
     const size_t maxw = (size_t)ctx->cus * 8;
     if (wgs > maxw) wgs = maxw;
     hipLaunchKernelGGL(hgt::tok3_names_kernel, dim3((unsigned)wgs), dim3(64), 0, s, (const uint8_t *)d_tb, d_jobs, (uint32_t)njobs,
-                       d_tab, (uint8_t *)d_out, d_rec, d_names, d_status);
+                       d_tab, (uint8_t *)d_out, d_rec, d_names, d_status, par ? 1 : 0);
     return hipGetLastError() == hipSuccess ? HG_OK : HG_ELAUNCH;
 }
 }  // namespace hg
