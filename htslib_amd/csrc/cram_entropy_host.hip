@@ -12,6 +12,7 @@
 // then runs the two kernels back to back on one HIP stream.  All payload work is on the GPU; there
 // is no CPU decode path.  Header rules follow oracle/ransnx16_oracle.c (PARITY UNPINNED).
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -250,15 +251,22 @@ static int entropy_decode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
     if ((rc = ensure_scratch(ctx, 0, ioff + 64))) return rc;
     hipStream_t s = ctx->stream;
     uint8_t *d_in = (uint8_t *)ctx->d_scratch[0];
+    static const bool stats = getenv("HTS_GPU_STATS") != nullptr;
+    auto ms = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    const auto t0 = std::chrono::steady_clock::now();
     rc = hg::stage_upload(ctx, in, in_len, ioffs.data(), st.data(), n, ioff, d_in, s);
+    const double m_up = ms(t0);
     if (rc == HG_OK) rc = launch_plan(ctx, P, ioff, obytes, s);
     if (rc == HG_OK) {
         bool ok = hipStreamSynchronize(s) == hipSuccess && collect_plan_status(ctx, P, st, s);
+        const double m_k = ms(t0);
         if (ok) {
             std::vector<uint32_t> dl(n);
             for (size_t i = 0; i < n; i++) dl[i] = st[i] == 0 ? out_len[i] : 0u;
             rc = hg::stage_download(ctx, (const uint8_t *)ctx->d_scratch[1], ooffs.data(), dl.data(), out, n, s);
         } else rc = HG_ELAUNCH;
+        if (stats) fprintf(stderr, "[htsgpu stats] entropy decode (%s, %zu streams, %.1f -> %.1f MB): staged in %.1f ms, kernels done at %.1f ms, out at %.1f ms\n",
+                           codec == NX16 ? "nx16" : "arith", n, ioff / 1e6, ooff / 1e6, m_up, m_k, ms(t0));
     }
     if (rc == HG_OK)
         for (size_t i = 0; i < n; i++) { if (status) status[i] = st[i]; if (st[i] != 0) rc = HG_EBLOCK; }

@@ -6,6 +6,7 @@
 // CPU implementation of any codec here: if HIP or the device is unavailable
 // every entry point fails with HG_ENODEV.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <dlfcn.h>
 #include <mutex>
 #include <stdint.h>
@@ -346,7 +347,15 @@ int hg_cram_uncompress_blocks_host(hg_ctx *ctx, size_t n, const int32_t *method,
     int nact = 0;
     for (auto &t : tasks) nact += t.cnt != 0;
     int trc[6] = {HG_OK, HG_OK, HG_OK, HG_OK, HG_OK, HG_OK};
-    auto run_one = [&](int kind, hg_ctx *c) { trc[kind] = (kind <= 2 || kind == 5) ? run_entropy(c, kind) : kind == 3 ? run_rans4x8(c) : run_gzip(c); };
+    static const bool stats = getenv("HTS_GPU_STATS") != nullptr;
+    auto run_one = [&](int kind, hg_ctx *c) {
+        const auto t0 = std::chrono::steady_clock::now();
+        trc[kind] = (kind <= 2 || kind == 5) ? run_entropy(c, kind) : kind == 3 ? run_rans4x8(c) : run_gzip(c);
+        if (stats) {
+            static const char *nm[6] = {"nx16", "arith", "tok3", "rans4x8", "gzip", "fqz"};
+            fprintf(stderr, "[htsgpu stats] uncompress family %s: %.1f ms\n", nm[kind], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+    };
     if (nact <= 1) { for (auto &t : tasks) if (t.cnt) run_one(t.kind, ctx); }
     else {
         std::vector<std::thread> th;
