@@ -1148,7 +1148,7 @@ def libhts_view(run: Run, bam_path: str, plain_bytes: int, nreads: int = 12_000_
 
 def libhts_view_cram(run: Run, gpu: str, ref: str, ref_threads, copies: int = 64, nrec: int = 10000):
     """libhts-level CRAM figures (north_star: "samtools/bcftools see a drop-in libhts"): test_view on libhts_gpu.so vs on the reference's libhts,
-      cram_decode       = view -@T -B in.cram               (ours: cram_get_bam_seq = the whole-slice reader, htslib_amd/csrc/cram_reader_front.c: runs of containers
+      cram_decode       = view -@T -B in.cram               (ours: cram_get_bam_seq = the whole-slice reader, htslib_amd/csrc/cram_record_front.c: runs of containers
                                                               decoded on the device, block codecs + cram_decode_slice + cram_to_bam; stock: cram_decode_slice on the pool)
       cram_decode_blocks = the same with HTS_GPU_CRAM_SLICE=0 (the reference's cram_decode_slice on our per-block entry points: round 6's first form)
       cram_encode       = view -@T -C -o version=3.0 in.bam  (bam_read1 + cram_encode_slice + cram_compress_block2, to /dev/null)

@@ -507,7 +507,7 @@ inline void behind_sync() { if (!tl_behind.empty()) behind_flush(); }
 
 // the block layer's context, for the htscodecs-named entry points (htscodecs_front.cpp)
 namespace hgfront { hg_ctx *shared_engine() { return engine(); } }
-// ... and for the whole-slice reader under cram_get_bam_seq (cram_reader_front.c, a C source)
+// ... and for the whole-slice reader under cram_get_bam_seq (cram_record_front.c, a C source)
 extern "C" hg_ctx *hg_front_shared_engine(void) { return engine(); }
 
 extern "C" {

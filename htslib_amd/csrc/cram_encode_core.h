@@ -8,7 +8,7 @@
 //
 // Choices the format leaves to the writer, made the simple way (all valid CRAM 3.0, all decoded by the data-parallel passes):
 //   * every series EXTERNAL in a block of its own (content id 10 + series), RN / IN / SC as BYTE_ARRAY_STOP (NUL / tab);
-//   * every record DETACHED (CF = 2 [+1 when it has qualities]): mate reference, position and template length are stored, no in-slice
+//   * every record DETACHED (CF = 2 [+1 when it has bases: the qualities are kept, 0xff ones too]): mate reference, position and template length are stored, no in-slice
 //     mate links (htslib links mates inside a slice to save a few bytes per pair; the decoder's output is the same);
 //   * AP as a delta from the previous record (first from the slice's start), also in multi-reference slices;
 //   * substitution matrix = the default one; a base the code cannot express, or one outside the reference, is a 'B' feature;
@@ -144,8 +144,10 @@ HGR_FN bool enc_record(const EncCtx &C, uint32_t r, int64_t prev_apos, int mode,
     if (!bam_parse(C.bam, C.rec_off[g], C.rec_off[g + 1], B)) { *C.fail = -1; return false; }
     const bool unmapped = (B.flag & BAM_FUNMAP) != 0;
     const int32_t L = (int32_t)B.l_seq;
-    bool has_qual = false;
-    for (int32_t i = 0; i < L; i++) has_qual |= B.qual[i] != 0xff;
+    // qualities are always kept, also the 0xff bytes of a record that has none -- the reference's choice (cram_encode.c:3763-3790 under CRAM_FLAG_PRESERVE_QUAL_SCORES,
+    // which process_one_read sets for every record): a record WITHOUT the flag whose walk meets a 'B' feature comes back with quality 30 everywhere
+    // (cram_decode.c:1611-1615, "same as htsjdk"), not with '*'
+    const bool has_qual = L > 0;
     if (L == 0 && !unmapped && B.n_cigar) { *C.fail = -3; return false; }                          // CF_NO_SEQ: not covered
     const int64_t apos = (int64_t)B.pos + 1;
     S.itf8(W_BF, (int32_t)B.flag);

@@ -359,7 +359,7 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
     return rc;
 }
 
-// The same path for a reader that walks the file itself (cram_read_container on the caller's side: cram_reader_front.c under cram_get_bam_seq): the BODIES of a
+// The same path for a reader that walks the file itself (cram_read_container on the caller's side: cram_record_front.c under cram_get_bam_seq): the BODIES of a
 // run of data containers -> their BAM records, back to back, no BAM header.
 extern "C" int hg_cram_containers_to_bam_host(hg_ctx *ctx, int major, size_t ncontainers, const hg_cram_container *cont, int nref, const int64_t *sq_len,
                                               const char *const *rg_names, int nrg, const hg_cram_ref_seq *refs, int nrefs_given, hg_cram_get_ref_fn get_ref, void *get_ref_ud,
@@ -646,8 +646,36 @@ extern "C" int hg_bam_to_cram_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_l
 // (htslib's "normal" profile): GZIP, GZIP_RLE, (level >= 5) GZIP_1, rANS Nx16 PR0 / PR1 (+ PR64 / PR9 / PR128 / PR193 above level 1, + PR129 / PR192 above
 // level 5), the read names TOK3 instead of rANS (cram_encode.c:818-826, 937-942); HG_CRAM_WRITE_ARITH adds the range coder's sets (use_arith, :833-845; names: TOKA).
 // Without V31: the CRAM 3.0 set GZIP | rANS 4x8.  fqzcomp is not offered (the writer would have to hand the quality block's per-record lengths over).
+// A writer that comes back with more records (the whole-slice writer under cram_put_bam_seq, cram_record_front.c) keeps what a cram_fd keeps between slices: one
+// cram_metrics per data series -- the method trials of the first slices are not repeated -- and the record counter of the container headers.
+struct hg_cram_writer {
+    std::vector<std::map<int32_t, hg_cram_metrics *>> met;              // per device range (one range on one device)
+    uint64_t counter = 0;
+    uint32_t records_per_slice = 10000; int level = 5, flags = 0;
+};
+static int bam_to_cram_impl(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, const hg_cram_ref_seq *refs, int nrefs_given, uint32_t records_per_slice, int level,
+                            int flags, uint8_t *cram_out, size_t cram_cap, uint64_t *cram_bytes, uint64_t *nrecords, hg_cram_writer *W, const char *const *rg_names, int nrg);
 extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, const hg_cram_ref_seq *refs, int nrefs_given, uint32_t records_per_slice, int level,
                                     int flags, uint8_t *cram_out, size_t cram_cap, uint64_t *cram_bytes, uint64_t *nrecords) {
+    return bam_to_cram_impl(ctx, bam, bam_len, refs, nrefs_given, records_per_slice, level, flags, cram_out, cram_cap, cram_bytes, nrecords, nullptr, nullptr, 0);
+}
+extern "C" hg_cram_writer *hg_cram_writer_new(uint32_t records_per_slice, int level, int flags) {
+    hg_cram_writer *W = new (std::nothrow) hg_cram_writer;
+    if (W) { W->records_per_slice = records_per_slice ? records_per_slice : 10000; W->level = level <= 0 ? 5 : level; W->flags = flags; }
+    return W;
+}
+extern "C" void hg_cram_writer_free(hg_cram_writer *W) {
+    if (!W) return;
+    for (auto &mm : W->met) for (auto &m : mm) hg_cram_metrics_free(m.second);
+    delete W;
+}
+extern "C" int hg_cram_writer_containers_host(hg_ctx *ctx, hg_cram_writer *W, const uint8_t *bam_records, size_t len, const hg_cram_ref_seq *refs, int nrefs_given,
+                                              const char *const *rg_names, int nrg, uint8_t *out, size_t cap, uint64_t *out_bytes, uint64_t *nrecords) {
+    if (!W || (nrg && !rg_names)) return HG_EINVAL;
+    return bam_to_cram_impl(ctx, bam_records, len, refs, nrefs_given, W->records_per_slice, W->level, W->flags, out, cap, out_bytes, nrecords, W, rg_names, nrg);
+}
+static int bam_to_cram_impl(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, const hg_cram_ref_seq *refs, int nrefs_given, uint32_t records_per_slice, int level,
+                            int flags, uint8_t *cram_out, size_t cram_cap, uint64_t *cram_bytes, uint64_t *nrecords, hg_cram_writer *W, const char *const *rg_names, int nrg) {
     if (!ctx || !bam || !cram_out || !cram_bytes || (nrefs_given && !refs)) return HG_EINVAL;
     const bool v31 = (flags & HG_CRAM_WRITE_V31) != 0, arith = v31 && (flags & HG_CRAM_WRITE_ARITH) != 0;
     if (!records_per_slice) records_per_slice = 10000;                   // the reference's default (cram/cram_structs.h:87-89)
@@ -658,17 +686,22 @@ extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_
     auto t_prev = now();
     double t_stage[5] = {0, 0, 0, 0, 0};
     auto lap = [&](int k) { const auto t = now(); t_stage[k] += std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; };
-    // ---- 1. BAM header
+    // ---- 1. BAM header (a writer object brings records only, and the @RG ids with them)
+    std::string text;
+    size_t p = 0;
+    std::vector<std::string> rg_id;
+    if (W) for (int i = 0; i < nrg; i++) rg_id.push_back(rg_names[i] ? rg_names[i] : "");
+    else {
     if (bam_len < 12 || memcmp(bam, "BAM\1", 4) != 0) return HG_EINVAL;
     auto rd32 = [&](size_t at) { return (uint32_t)bam[at] | (uint32_t)bam[at + 1] << 8 | (uint32_t)bam[at + 2] << 16 | (uint32_t)bam[at + 3] << 24; };
     const uint32_t l_text = rd32(4);
     if ((size_t)l_text + 12 > bam_len) return HG_EINVAL;
-    const std::string text((const char *)bam + 8, l_text);
-    size_t p = 8 + (size_t)l_text;
+    text.assign((const char *)bam + 8, l_text);
+    p = 8 + (size_t)l_text;
     const uint32_t n_ref = rd32(p); p += 4;
     for (uint32_t i = 0; i < n_ref; i++) { if (p + 4 > bam_len) return HG_EINVAL; const uint32_t ln = rd32(p); p += 4 + (size_t)ln + 4; if (p > bam_len) return HG_EINVAL; }
-    std::vector<std::string> rg_id;
-    for (size_t at = 0; at < text.size();) {
+    }
+    for (size_t at = 0; !W && at < text.size();) {
         size_t e = text.find('\n', at); if (e == std::string::npos) e = text.size();
         const std::string line = text.substr(at, e - at); at = e + 1;
         if (line.compare(0, 3, "@RG") != 0) continue;
@@ -687,15 +720,16 @@ extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_
     std::vector<const char *> rgp; for (auto &r : rg_id) rgp.push_back(r.c_str());
     int rc = HG_OK;
     size_t nrec = 0;
+    const uint64_t counter0 = W ? W->counter : 0;
     if (bam_len > p) {
         uint64_t need = 0;
-        rc = hg_cram_encode_slices_host2(ctx, bam + p, bam_len - p, &nrec, records_per_slice, refs, nrefs_given, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), 0, blob, blob_cap,
+        rc = hg_cram_encode_slices_host2(ctx, bam + p, bam_len - p, &nrec, records_per_slice, refs, nrefs_given, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), (int64_t)counter0, blob, blob_cap,
                                          soff.data(), ns_max, sst.data(), &need, sbases.data());
         if (rc == HG_ENOMEM && need > blob_cap) {                       // reads far from their reference (or no reference at all) store every base: several bytes per base
             blob = hg::host_slab(ctx, 0, need + 64);
             if (!blob) return HG_ENOMEM;
             blob_cap = ctx->h_slab_cap[0];
-            rc = hg_cram_encode_slices_host2(ctx, bam + p, bam_len - p, &nrec, records_per_slice, refs, nrefs_given, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), 0, blob, blob_cap,
+            rc = hg_cram_encode_slices_host2(ctx, bam + p, bam_len - p, &nrec, records_per_slice, refs, nrefs_given, rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), (int64_t)counter0, blob, blob_cap,
                                              soff.data(), ns_max, sst.data(), &need, sbases.data());
         }
         if (rc != HG_OK) return rc;                                     // a slice the encoder does not cover fails the file
@@ -751,7 +785,9 @@ extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_
         const std::vector<hg_ctx *> ctxs = job_contexts(ctx);
         const std::vector<size_t> scut = cut_ranges(ns, ns >= 2 * ctxs.size() ? ctxs.size() : 1, [&](size_t k) { uint64_t w = 64; for (size_t i = parts[k].b0; i < parts[k].b1; i++) w += blks[i].n; return w; });
         const size_t nr = scut.size() - 1;
-        std::vector<std::map<int32_t, hg_cram_metrics *>> met(nr);
+        std::vector<std::map<int32_t, hg_cram_metrics *>> own(W ? 0 : nr);
+        if (W && W->met.size() < nr) W->met.resize(nr);
+        std::vector<std::map<int32_t, hg_cram_metrics *>> &met = W ? W->met : own;
         for (size_t r = 0; r < nr; r++)
             for (size_t k = scut[r]; k < scut[r + 1]; k++)
                 for (size_t i = parts[k].b0; i < parts[k].b1; i++) {
@@ -775,7 +811,7 @@ extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_
             run(0);
             for (auto &t : th) t.join();
         }
-        for (auto &mm : met) for (auto &m : mm) hg_cram_metrics_free(m.second);
+        for (auto &mm : own) for (auto &m : mm) hg_cram_metrics_free(m.second);
         for (int r : rrc) if (r != HG_OK) return r;
     }
     lap(1);
@@ -805,8 +841,8 @@ extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_
         crc_from.push_back(from); crc_at.push_back(o.size()); put32le(o, 0);
     };
     // file definition: "CRAM", 3.0 / 3.1, 20-byte file id
-    { const uint8_t def[6] = {'C', 'R', 'A', 'M', 3, (uint8_t)(v31 ? 1 : 0)}; o.bytes(def, 6); const char id[20] = "htslib_amd"; o.bytes((const uint8_t *)id, 20); }
-    {   // header container: one FILE_HEADER block = int32 text length + text (cram_write_SAM_hdr)
+    if (!W) { const uint8_t def[6] = {'C', 'R', 'A', 'M', 3, (uint8_t)(v31 ? 1 : 0)}; o.bytes(def, 6); const char id[20] = "htslib_amd"; o.bytes((const uint8_t *)id, 20); }
+    if (!W) {   // header container: one FILE_HEADER block = int32 text length + text (cram_write_SAM_hdr)
         std::vector<uint8_t> h; put32le(h, (uint32_t)text.size()); h.insert(h.end(), text.begin(), text.end());
         container(block_size(0, (uint32_t)h.size(), (uint32_t)h.size()), 0, 0, 0, 0, 0, 0, 1, 0);
         block(0, 0, 0, h.data(), (uint32_t)h.size(), (uint32_t)h.size());
@@ -817,7 +853,7 @@ extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_
         uint64_t body = comp_bytes + block_size(0, P.sh_len, P.sh_len) + block_size(0, 0, 0);
         for (size_t i = P.b0; i < P.b1; i++) body += block_size(blks[i].cid, cmeth[i] == 0 ? blks[i].n : clen[i], blks[i].n);
         // (the slice header's block count includes the CORE block: the encoder counted blocks + 1 already)
-        container(body, P.hdr.ref_seq_id, P.hdr.ref_seq_start, P.hdr.ref_seq_span, P.hdr.nrec, (uint64_t)k * records_per_slice, P.bases, (int32_t)(3 + (P.b1 - P.b0)), (int32_t)comp_bytes);
+        container(body, P.hdr.ref_seq_id, P.hdr.ref_seq_start, P.hdr.ref_seq_span, P.hdr.nrec, counter0 + (uint64_t)k * records_per_slice, P.bases, (int32_t)(3 + (P.b1 - P.b0)), (int32_t)comp_bytes);
         block(0, 1, 0, P.comp, P.comp_len, P.comp_len);                    // compression header
         block(0, 2, 0, P.sh, P.sh_len, P.sh_len);                          // slice header (MAPPED_SLICE); the landmark points here
         { const uint8_t none = 0; block(0, 5, 0, &none, 0, 0); }           // the CORE block: empty (every series is EXTERNAL)
@@ -825,7 +861,7 @@ extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_
     }
     static const uint8_t eof3[38] = {0x0f, 0x00, 0x00, 0x00, 0xff, 0xff, 0xff, 0xff, 0x0f, 0xe0, 0x45, 0x4f, 0x46, 0x00, 0x00, 0x00, 0x00, 0x01, 0x00, 0x05, 0xbd, 0xd9, 0x4f, 0x00, 0x01, 0x00, 0x06, 0x06,
                                      0x01, 0x00, 0x01, 0x00, 0x01, 0x00, 0xee, 0x63, 0x01, 0x4b};      // cram_write_eof_block, CRAM 3 (cram_io.c:4320-4370)
-    o.bytes(eof3, 38);
+    if (!W) o.bytes(eof3, 38);
     *cram_bytes = o.size();
     if (o.size() > cram_cap) return HG_ENOMEM;
     lap(2);
@@ -839,6 +875,7 @@ extern "C" int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_
     lap(3);
     if (stats) fprintf(stderr, "[hts-gpu] bam_to_cram: %zu records, %zu slices, %zu blocks: header walk + record encoder %.1f ms, block auto-tuner %.1f ms, framing %.1f ms, CRC-32s + copy out %.1f ms\n",
                        nrec, ns, nb, t_stage[0], t_stage[1], t_stage[2], t_stage[3]);
+    if (W) W->counter += nrec;
     return HG_OK;
 }
 

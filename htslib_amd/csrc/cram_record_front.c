@@ -1,4 +1,4 @@
-/* cram_reader_front.c -- the whole-slice CRAM path UNDER sam_read1: cram_get_bam_seq (reference cram/cram_decode.c:3615-3627) served by the device.
+/* cram_record_front.c -- the whole-slice CRAM path UNDER sam_read1: cram_get_bam_seq (reference cram/cram_decode.c:3615-3627) served by the device.
  *
  * The reference decodes a CRAM record by record on the host: cram_get_bam_seq -> cram_get_seq -> cram_next_slice (cram_decode.c:3268-3538: container and
  * slice I/O, one cram_decode_slice job per slice on the thread pool) -> cram_to_bam per record.  Putting the GPU under the per-block entry points
@@ -92,6 +92,7 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 static void stats_at_exit(void) { fprintf(stderr, "[htsgpu stats] process: exit handlers reached %.3f s after libhts was loaded\n", now_s() - g_t0); }
 
 static reader *find_reader(cram_fd *fd) {
+    if (fd->mode == 'w') return NULL;
     if (tl_fd == fd && tl_gen == g_gen) return tl_rd;
     pthread_mutex_lock(&g_lock);
     reader *r = g_readers;
@@ -309,13 +310,12 @@ static reader *start_reader(cram_fd *fd) {
     return R;
 }
 
-/* one record of the run into the caller's bam1_t: the memory layout bam_read1 builds (sam.c:808-866; QNAME padded with NULs to a multiple of four) */
-static int hand_out(reader *R, bam1_t *b) {
-    run *u = R->cur;
-    const uint8_t *p = u->bam + R->pos;
-    if (u->bam_len - R->pos < 36) return -1;
+/* one record in bam_write1's layout into a bam1_t: the memory layout bam_read1 builds (sam.c:808-866; QNAME padded with NULs to a multiple of four).
+ * Returns l_data, or -1 for a malformed record; *used = bytes of the stream the record took. */
+static int record_to_bam1(const uint8_t *p, uint64_t avail, bam1_t *b, uint64_t *used) {
+    if (avail < 36) return -1;
     const uint32_t block_len = (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
-    if (block_len < 32 || (uint64_t)block_len + 4 > u->bam_len - R->pos) return -1;
+    if (block_len < 32 || (uint64_t)block_len + 4 > avail) return -1;
     const uint8_t *x = p + 4;
     bam1_core_t *c = &b->core;
     #define U32(q) ((uint32_t)(q)[0] | (uint32_t)(q)[1] << 8 | (uint32_t)(q)[2] << 16 | (uint32_t)(q)[3] << 24)
@@ -335,8 +335,14 @@ static int hand_out(reader *R, bam1_t *b) {
     c->l_qname = (uint16_t)(l_name + c->l_extranul);
     memcpy(b->data + c->l_qname, x + 32 + l_name, body - l_name);
     b->l_data = (int)l_data;
-    R->pos += (uint64_t)block_len + 4;
+    *used = (uint64_t)block_len + 4;
     return (int)l_data;
+}
+static int hand_out(reader *R, bam1_t *b) {
+    uint64_t used = 0;
+    const int n = record_to_bam1(R->cur->bam + R->pos, R->cur->bam_len - R->pos, b, &used);
+    if (n >= 0) R->pos += used;
+    return n;
 }
 
 /* ---- the reference's names ---------------------------------------------------------------------------------------------------------- */
@@ -392,8 +398,273 @@ int cram_seek(cram_fd *fd, off_t offset, int whence) {
     return hg_ref_cram_seek(fd, offset, whence);
 }
 
+/* =====================================================================================================================================================
+ * The write direction: cram_put_bam_seq (reference cram/cram_encode.c:4042-4200: records gathered into a container, cram_encode_container ->
+ * cram_encode_slice + cram_compress_slice per slice on the pool, cram_flush_container).  Here the records are gathered -- as bam_write1 would lay them out --
+ * into RUNS of a few hundred slices; a run goes to hg_cram_writer_containers_host (record encoder on the device, every series block of every slice through
+ * the method auto-tuner in a few batched rounds, container framing + CRCs) on a helper thread while the caller fills the next run, and the containers
+ * are written to the file in order.  File definition, SAM header container (cram_write_SAM_hdr at open) and EOF container (cram_close) stay the
+ * reference's.  A valid CRAM is not a unique byte string: these containers hold one slice each, every series in an EXTERNAL block of its own (what
+ * htslib writes for sorted data), methods chosen by the same trial scheme over the same method sets -- stock htslib reads them (tests/test_libhts_gpu.py).
+ *
+ * The reference's writer runs instead when the cram_fd asks for something this writer does not do -- CRAM 2.x / 4.x, several slices per container, embedded or
+ * no reference, lossy names, forced AP delta, bzip2 / lzma / fqzcomp method sets, multi_seq_per_slice forced on or off, bases_per_slice changed, an index
+ * written on the fly -- decided at the first record; and from the first run on that meets something it cannot encode (a missing reference, a CIGAR of more
+ * than 65 535 operations, a record the device encoder declines): that run and everything after it is REPLAYED through the reference's cram_put_bam_seq in order.
+ * ===================================================================================================================================================== */
+int hg_ref_cram_put_bam_seq(cram_fd *fd, bam_seq_t *b);
+int hg_ref_cram_flush(cram_fd *fd);
+
+typedef struct wrun { uint8_t *recs; size_t len, cap; uint64_t nrec, bases; int32_t *tids; int ntid, tid_cap; int hard; } wrun;   /* hard: holds a record only the reference can write */
+typedef struct writer {
+    struct writer *next;
+    cram_fd *fd; hg_ctx *ctx; hg_cram_writer *W;
+    volatile int pass;                             /* the reference's writer owns the cram_fd from here on */
+    volatile int failed;                           /* an I/O or replay error: reported by the next call */
+    wrun r[2]; int fill;                           /* the run being filled by the caller; the other one may be with the helper */
+    pthread_t th; int th_on; pthread_mutex_t m; pthread_cond_t cv; volatile int busy; int job, stop;   /* job: index of the run handed to the helper, -1 none */
+    int nrg; char **rg_names;
+    uint8_t *out; size_t out_cap;
+    uint64_t want, runs, tot_rec; double t_enc, t_wait; int stats;
+} writer;
+static writer *g_writers;
+
+static writer *find_writer(cram_fd *fd) {
+    if (tl_fd == fd && tl_gen == g_gen) return (writer *)tl_rd;
+    pthread_mutex_lock(&g_lock);
+    writer *w = g_writers;
+    while (w && w->fd != fd) w = w->next;
+    tl_fd = fd; tl_rd = (reader *)w; tl_gen = g_gen;        /* (a cram_fd is a reader or a writer, never both: the cache slot is shared) */
+    pthread_mutex_unlock(&g_lock);
+    return w;
+}
+
+/* the records of a run through the reference's own writer, in order (the fall-back) */
+static int replay_run(writer *Wt, wrun *u) {
+    bam1_t *b = bam_init1();
+    if (!b) return -1;
+    int rc = 0;
+    for (uint64_t pos = 0; pos < u->len && rc == 0;) {
+        uint64_t used = 0;
+        if (record_to_bam1(u->recs + pos, u->len - pos, b, &used) < 0) { rc = -1; break; }
+        pos += used;
+        if (hg_ref_cram_put_bam_seq(Wt->fd, b) < 0) rc = -1;
+    }
+    bam_destroy1(b);
+    u->len = 0; u->nrec = 0; u->bases = 0; u->ntid = 0; u->hard = 0;
+    return rc;
+}
+
+/* one run on the device -> containers -> the file.  Returns 0 done, 1 "the reference's writer has to take this run", -1 I/O error */
+static int encode_run(writer *Wt, wrun *u) {
+    cram_fd *fd = Wt->fd;
+    if (u->hard) return 1;
+    const double t0 = now_s();
+    const int nref = sam_hdr_nref(fd->header);
+    hg_cram_ref_seq *refs = calloc((size_t)(nref > 0 ? nref : 1), sizeof *refs);
+    if (!refs) return 1;
+    int held = 0, ok = 1;
+    for (int i = 0; i < u->ntid && ok; i++) {                               /* the reference sequences of this run, whole (cram_get_ref pins them: cram_io.c:3409) */
+        const int id = u->tids[i];
+        if (id < 0) continue;
+        if (id >= nref || !fd->refs || id >= fd->refs->nref) { ok = 0; break; }
+        char *seq = cram_get_ref(fd, id, 1, 0);
+        if (!seq) { ok = 0; break; }
+        held = i + 1;
+        pthread_mutex_lock(&fd->refs->lock);
+        refs[id].len = (uint64_t)fd->refs->ref_id[id]->length;
+        pthread_mutex_unlock(&fd->refs->lock);
+        refs[id].bases = (const uint8_t *)seq;
+    }
+    int rc = 1;
+    if (ok) {
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const size_t need = attempt == 0 ? u->len + u->len / 2 + ((size_t)4 << 20) : Wt->out_cap;
+            if (big_grow(&Wt->out, &Wt->out_cap, 0, need) < 0) break;
+            uint64_t bytes = 0, nrec = 0;
+            const int e = hg_cram_writer_containers_host(Wt->ctx, Wt->W, u->recs, u->len, refs, nref, (const char *const *)Wt->rg_names, Wt->nrg, Wt->out, Wt->out_cap, &bytes, &nrec);
+            if (e == HG_ENOMEM && attempt == 0 && bytes > Wt->out_cap) { if (big_grow(&Wt->out, &Wt->out_cap, 0, (size_t)bytes + ((size_t)1 << 20)) < 0) break; continue; }
+            if (e == HG_OK && nrec == u->nrec) rc = hwrite(fd->fp, Wt->out, (size_t)bytes) == (ssize_t)bytes ? 0 : -1;
+            break;
+        }
+    }
+    for (int i = 0; i < held; i++) if (u->tids[i] >= 0) cram_ref_decr(fd->refs, u->tids[i]);
+    free(refs);
+    if (rc == 0) {
+        fd->record_counter += (int64_t)u->nrec;                             /* (container numbering continues from here if the reference's writer ever takes over) */
+        Wt->tot_rec += u->nrec; Wt->runs++; Wt->t_enc += now_s() - t0;
+        u->len = 0; u->nrec = 0; u->bases = 0; u->ntid = 0; u->hard = 0;
+    }
+    return rc;
+}
+
+static void *writer_helper(void *arg) {
+    writer *Wt = (writer *)arg;
+    pthread_mutex_lock(&Wt->m);
+    for (;;) {
+        while (Wt->job < 0 && !Wt->stop) pthread_cond_wait(&Wt->cv, &Wt->m);
+        if (Wt->job < 0) break;
+        wrun *u = &Wt->r[Wt->job];
+        pthread_mutex_unlock(&Wt->m);
+        int rc = Wt->pass ? 1 : encode_run(Wt, u);
+        if (rc == 1) { Wt->pass = 1; rc = replay_run(Wt, u); }                 /* in order: nothing later has been written yet */
+        pthread_mutex_lock(&Wt->m);
+        if (rc < 0) Wt->failed = 1;
+        Wt->job = -1; Wt->busy = 0;
+        pthread_cond_broadcast(&Wt->cv);
+    }
+    pthread_mutex_unlock(&Wt->m);
+    return NULL;
+}
+
+static void writer_wait_idle(writer *Wt) {
+    const double t0 = now_s();
+    pthread_mutex_lock(&Wt->m);
+    while (Wt->busy) pthread_cond_wait(&Wt->cv, &Wt->m);
+    pthread_mutex_unlock(&Wt->m);
+    Wt->t_wait += now_s() - t0;
+}
+
+/* hand the filled run to the helper (waiting for the previous one first: runs are written in order) and start filling the other buffer */
+static int writer_submit(writer *Wt, int wait_done) {
+    wrun *u = &Wt->r[Wt->fill];
+    if (u->nrec) {
+        writer_wait_idle(Wt);
+        pthread_mutex_lock(&Wt->m);
+        Wt->job = Wt->fill; Wt->busy = 1;
+        pthread_cond_broadcast(&Wt->cv);
+        pthread_mutex_unlock(&Wt->m);
+        Wt->fill ^= 1;
+        Wt->want = (uint64_t)1024 * (uint64_t)(Wt->fd->seqs_per_slice > 0 ? Wt->fd->seqs_per_slice : 10000);
+    }
+    if (wait_done) writer_wait_idle(Wt);
+    return Wt->failed ? -1 : 0;
+}
+
+static int writer_eligible(cram_fd *fd) {
+    static int enabled = -1;
+    if (enabled < 0) { const char *e = getenv("HTS_GPU_CRAM_SLICE"); enabled = !(e && e[0] == '0'); }
+    if (!enabled || !fd || fd->mode != 'w' || !fd->fp || !fd->header || fd->ctr || fd->ctr_mt) return 0;
+    if (CRAM_MAJOR_VERS(fd->version) != 3 || CRAM_MINOR_VERS(fd->version) > 1 || fd->level < 1) return 0;       /* (level 0 = every block RAW: the reference's writer) */
+    if (fd->slices_per_container != 1 || fd->seqs_per_slice < 1 || fd->bases_per_slice != fd->seqs_per_slice * 500) return 0;
+    if (fd->embed_ref > 0 || fd->no_ref || fd->lossy_read_names || fd->ap_delta || fd->multi_seq_user != -1 || fd->idxfp) return 0;
+    if (fd->use_bz2 || fd->use_lzma || fd->use_fqz || !fd->use_rans) return 0;
+    if (CRAM_MINOR_VERS(fd->version) == 1 ? !fd->use_tok : fd->use_arith) return 0;
+    return 1;
+}
+
+static void free_writer(writer *Wt) {
+    if (Wt->th_on) {
+        pthread_mutex_lock(&Wt->m); Wt->stop = 1; pthread_cond_broadcast(&Wt->cv); pthread_mutex_unlock(&Wt->m);
+        pthread_join(Wt->th, NULL);
+    }
+    if (Wt->stats)
+        fprintf(stderr, "[htsgpu stats] cram writer: %llu runs, %llu records through the device%s; helper busy %.3f s, caller waited for it %.3f s\n", (unsigned long long)Wt->runs,
+                (unsigned long long)Wt->tot_rec, Wt->pass ? ", then the reference's writer" : "", Wt->t_enc, Wt->t_wait);
+    for (int i = 0; i < 2; i++) { free(Wt->r[i].recs); free(Wt->r[i].tids); }
+    for (int i = 0; i < Wt->nrg; i++) free(Wt->rg_names[i]);
+    free(Wt->rg_names); free(Wt->out);
+    hg_cram_writer_free(Wt->W);
+    pthread_mutex_destroy(&Wt->m); pthread_cond_destroy(&Wt->cv);
+    free(Wt);
+}
+
+static writer *start_writer(cram_fd *fd) {
+    hg_ctx *ctx = hg_front_shared_engine();
+    if (!ctx) return NULL;
+    writer *Wt = calloc(1, sizeof *Wt);
+    if (!Wt) return NULL;
+    Wt->fd = fd; Wt->ctx = ctx; Wt->job = -1;
+    const int v31 = CRAM_MINOR_VERS(fd->version) == 1;
+    Wt->W = hg_cram_writer_new((uint32_t)fd->seqs_per_slice, fd->level, v31 ? (HG_CRAM_WRITE_V31 | (fd->use_arith ? HG_CRAM_WRITE_ARITH : 0)) : 0);
+    Wt->nrg = sam_hdr_count_lines(fd->header, "RG");
+    if (Wt->nrg < 0) Wt->nrg = 0;
+    Wt->rg_names = calloc((size_t)Wt->nrg + 1, sizeof *Wt->rg_names);
+    int ok = Wt->W && Wt->rg_names;
+    for (int i = 0; ok && i < Wt->nrg; i++) {
+        const char *id = sam_hdr_line_name(fd->header, "RG", i);
+        if (!id || !(Wt->rg_names[i] = strdup(id))) ok = 0;
+    }
+    Wt->want = (uint64_t)256 * (uint64_t)fd->seqs_per_slice;                /* the first run; 1024 slices from then on (a run costs about the same whatever it holds) */
+    pthread_mutex_init(&Wt->m, NULL); pthread_cond_init(&Wt->cv, NULL);
+    { const char *e = getenv("HTS_GPU_STATS"); Wt->stats = e && e[0] == '1'; }
+    if (!ok || pthread_create(&Wt->th, NULL, writer_helper, Wt) != 0) { free_writer(Wt); return NULL; }
+    Wt->th_on = 1;
+    pthread_mutex_lock(&g_lock);
+    Wt->next = g_writers; g_writers = Wt; g_gen++;
+    pthread_mutex_unlock(&g_lock);
+    return Wt;
+}
+
+static writer *detach_writer(cram_fd *fd) {
+    pthread_mutex_lock(&g_lock);
+    writer **pp = &g_writers, *Wt = NULL;
+    while (*pp && (*pp)->fd != fd) pp = &(*pp)->next;
+    if (*pp) { Wt = *pp; *pp = Wt->next; g_gen++; }
+    pthread_mutex_unlock(&g_lock);
+    return Wt;
+}
+
+int cram_put_bam_seq(cram_fd *fd, bam_seq_t *b) {
+    writer *Wt = fd && fd->mode == 'w' ? find_writer(fd) : NULL;
+    if (!Wt) {
+        if (!writer_eligible(fd) || !(Wt = start_writer(fd))) return hg_ref_cram_put_bam_seq(fd, b);
+        tl_fd = fd; tl_rd = (reader *)Wt; tl_gen = g_gen;
+    }
+    if (Wt->failed) return -1;
+    if (Wt->pass) {
+        if (Wt->busy || Wt->r[Wt->fill].nrec) {                              /* records still with us go first */
+            if (writer_submit(Wt, 1) < 0) return -1;
+        }
+        return hg_ref_cram_put_bam_seq(fd, b);
+    }
+    /* the record as bam_write1 lays it out (sam.c:868-928): block_size, the 32 fixed bytes, QNAME without its padding, the rest */
+    wrun *u = &Wt->r[Wt->fill];
+    const bam1_core_t *c = &b->core;
+    const uint32_t l_name = (uint32_t)c->l_qname - c->l_extranul, body = (uint32_t)b->l_data - c->l_extranul, block_len = body + 32;
+    if (u->len + block_len + 4 > u->cap) {
+        size_t cap = u->cap ? u->cap : (size_t)64 << 20;
+        while (cap < u->len + block_len + 4) cap *= 2;
+        uint8_t *q = realloc(u->recs, cap);
+        if (!q) return -1;
+        u->recs = q; u->cap = cap;
+    }
+    if (c->n_cigar > 0xffff || c->pos > INT32_MAX || c->mpos > INT32_MAX || l_name > 255 || c->tid < -1) u->hard = 1;      /* bam_write1's special cases: the reference's business */
+    uint8_t *p = u->recs + u->len;
+    #define P32(q, v) do { const uint32_t v_ = (uint32_t)(v); (q)[0] = (uint8_t)v_; (q)[1] = (uint8_t)(v_ >> 8); (q)[2] = (uint8_t)(v_ >> 16); (q)[3] = (uint8_t)(v_ >> 24); } while (0)
+    P32(p, block_len); P32(p + 4, c->tid); P32(p + 8, c->pos);
+    P32(p + 12, (uint32_t)c->bin << 16 | (uint32_t)c->qual << 8 | (l_name & 0xff));
+    P32(p + 16, (uint32_t)c->flag << 16 | (c->n_cigar & 0xffff));
+    P32(p + 20, c->l_qseq); P32(p + 24, c->mtid); P32(p + 28, c->mpos); P32(p + 32, c->isize);
+    #undef P32
+    memcpy(p + 36, b->data, l_name);
+    memcpy(p + 36 + l_name, b->data + c->l_qname, body - l_name);
+    u->len += (size_t)block_len + 4; u->nrec++; u->bases += (uint64_t)(c->l_qseq > 0 ? c->l_qseq : 0);
+    if (u->ntid == 0 || u->tids[u->ntid - 1] != c->tid) {                    /* the references this run touches (sorted input: a handful; unsorted: deduplicated below) */
+        int seen = 0;
+        for (int i = 0; i < u->ntid && !seen; i++) seen = u->tids[i] == c->tid;
+        if (!seen) {
+            if (u->ntid == u->tid_cap) { const int cap = u->tid_cap ? 2 * u->tid_cap : 64; int32_t *t = realloc(u->tids, (size_t)cap * sizeof *t); if (!t) return -1; u->tids = t; u->tid_cap = cap; }
+            u->tids[u->ntid++] = c->tid;
+        }
+    }
+    if (u->bases > u->nrec * 500 + 1000000) u->hard = 1;                    /* long reads: the reference cuts its slices by bases (bases_per_slice), this writer by records */
+    if (u->nrec >= Wt->want || u->len >= ((size_t)3 << 29)) return writer_submit(Wt, 0);
+    return 0;
+}
+
+int cram_flush(cram_fd *fd) {
+    writer *Wt = fd && fd->mode == 'w' ? find_writer(fd) : NULL;
+    if (Wt && writer_submit(Wt, 1) < 0) return -1;
+    return hg_ref_cram_flush(fd);
+}
+
 int cram_close(cram_fd *fd) {
-    reader *R = fd ? detach_reader(fd) : NULL;
+    reader *R = fd && fd->mode != 'w' ? detach_reader(fd) : NULL;
     if (R) free_reader(R);
-    return hg_ref_cram_close(fd);
+    int bad = 0;
+    writer *Wt = fd && fd->mode == 'w' ? detach_writer(fd) : NULL;
+    if (Wt) { bad = writer_submit(Wt, 1) < 0; free_writer(Wt); }
+    const int rc = hg_ref_cram_close(fd);
+    return bad ? -1 : rc;
 }

@@ -206,7 +206,7 @@ constexpr int PT = 1024, PW = PT / 64;
 enum { K_NONE = 0, K_STR = 1, K_CHR = 2, K_NUM = 3 };
 enum { M_ID = 0, M_NUM = 1, M_PAD = 2 };
 constexpr uint32_t NOPE = 0xffffffffu, ROOTP = 0x3fffffffu;
-constexpr uint32_t PAR_ARRAYS = 14;                                 // words per name (+2) a job needs behind name_off; launch_tok3_names' callers size by it
+
 
 struct ParLds { uint32_t wsum[PW][8]; uint32_t soff[16], slen[16]; };
 

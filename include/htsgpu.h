@@ -498,7 +498,7 @@ int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_t cram_len,
                               uint8_t *bam_out, size_t bam_cap, uint64_t *bam_bytes, uint64_t *nrecords, int flags, const char *name_prefix);
 
 /* The same for a reader that walks the file itself -- cram_get_bam_seq's whole-slice path (cram/cram_decode.c:3268-3627: cram_next_slice -> cram_decode_slice ->
- * cram_to_bam; htslib_amd/csrc/cram_reader_front.c calls this under that name inside a libhts build): the BODIES of a run of data containers, as they
+ * cram_to_bam; htslib_amd/csrc/cram_record_front.c calls this under that name inside a libhts build): the BODIES of a run of data containers, as they
  * lie in the file after each container header (compression header block, then per slice the slice header block and its blocks), become the
  * BAM records of those containers back to back -- no BAM header in front.  num_blocks / bases = the container header's fields.  sq_len[nref] = the
  * @SQ LN values; rg_names = the @RG IDs in header order; refs as above; decode_md = the cram_fd's decode_md (-1 = hts_open's default: MD / NM are
@@ -534,6 +534,18 @@ int hg_bam_to_cram_host(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, const h
 #define HG_CRAM_WRITE_ARITH 2
 int hg_bam_to_cram_host2(hg_ctx *ctx, const uint8_t *bam, size_t bam_len, const hg_cram_ref_seq *refs, int nrefs_given,
                          uint32_t records_per_slice, int level, int flags, uint8_t *cram_out, size_t cram_cap, uint64_t *cram_bytes, uint64_t *nrecords);
+
+/* A writer that hands its records over in RUNS (the whole-slice writer under cram_put_bam_seq, htslib_amd/csrc/cram_record_front.c: cram/cram_encode.c:4042
+ * cram_put_bam_seq -> cram_encode_container -> cram_flush_container, a run of slices at a time): the object keeps what a cram_fd keeps between slices -- one
+ * cram_metrics per data series, so that the method trials of the first slices are not repeated, and the record counter of the container headers.
+ * hg_cram_writer_containers_host: bam_records = records in bam_write1's layout back to back (no BAM header); out receives the data containers of these records
+ * (one slice per container, as hg_bam_to_cram_host2 writes them), nothing else -- file definition, header container and EOF container are the caller's.
+ * flags / level / records_per_slice as hg_bam_to_cram_host2.  HG_ENOMEM: *out_bytes = bytes needed (nothing of the run was kept: call again). */
+typedef struct hg_cram_writer hg_cram_writer;
+hg_cram_writer *hg_cram_writer_new(uint32_t records_per_slice, int level, int flags);
+void hg_cram_writer_free(hg_cram_writer *w);
+int hg_cram_writer_containers_host(hg_ctx *ctx, hg_cram_writer *w, const uint8_t *bam_records, size_t len, const hg_cram_ref_seq *refs, int nrefs_given,
+                                   const char *const *rg_names, int nrg, uint8_t *out, size_t cap, uint64_t *out_bytes, uint64_t *nrecords);
 
 /* The .crai text of one slice (cram_index_slice / cram_index_build_multiref, cram/cram_index.c:632-728): "ref start span container_pos
  * landmark slice_bytes" -- one line from the slice header, or, for a multi-reference slice, one line per run of records on the same
