@@ -1151,8 +1151,10 @@ def libhts_view_cram(run: Run, gpu: str, ref: str, ref_threads, copies: int = 64
       cram_decode       = view -@T -B in.cram               (ours: cram_get_bam_seq = the whole-slice reader, htslib_amd/csrc/cram_record_front.c: runs of containers
                                                               decoded on the device, block codecs + cram_decode_slice + cram_to_bam; stock: cram_decode_slice on the pool)
       cram_decode_blocks = the same with HTS_GPU_CRAM_SLICE=0 (the reference's cram_decode_slice on our per-block entry points: round 6's first form)
-      cram_encode       = view -@T -C -o version=3.0 in.bam  (bam_read1 + cram_encode_slice + cram_compress_block2, to /dev/null)
-      cram_decode_large / cram_to_bam_large = view -B / view -b on a file of 4 x the slices (10 240 000 records): what a run of 1 024 slices buys, and `samtools view -b in.cram`
+      cram_encode       = view -@T -C -o version=3.0 in.bam  (ours: cram_put_bam_seq = the whole-slice writer, runs of records through the device record encoder + block
+                                                              auto-tuner; stock: bam_read1 + cram_encode_slice + cram_compress_block3 on the pool; to /dev/null)
+      cram_encode_blocks = the same with HTS_GPU_CRAM_SLICE=0 (the reference's cram_encode_slice on our cram_compress_block2)
+      cram_decode_large / cram_to_bam_large / cram_encode_large = view -B / view -b / view -C on a file of 4 x the slices (10 240 000 records): what a run of 1 024 slices buys, and `samtools view -b in.cram`
     on 256 slices (2 560 000 records) of the record baselines' workload, at the writer's default level (gzip + rANS 4x8).  Whole-process wall clock, best of 2.
     A run of the reader takes 0.2-0.4 s whatever it holds (one 1.5 MB quality stream through the 4-way rANS decoder is one chain on one lane group, ~150 ms), a
     process pays ~0.2-0.3 s of HIP start-up before it and ~0.15 s of teardown after: stock htslib is through 2.56 M records before our first record is out."""
@@ -1171,7 +1173,7 @@ def libhts_view_cram(run: Run, gpu: str, ref: str, ref_threads, copies: int = 64
 
         def one(exe, threads, mode, W=None, cram_=None, plain_=None):
             W = W or w; cram_ = cram_ or cram; plain_ = plain_ or plain
-            env = dict(os.environ, HTS_GPU_CRAM_SLICE="0") if mode == "cram_decode_blocks" else None
+            env = dict(os.environ, HTS_GPU_CRAM_SLICE="0") if mode in ("cram_decode_blocks", "cram_encode_blocks") else None
             cmd = ([exe, "-@", str(threads), "-B", "-i", "reference=" + W.fa, cram_] if mode in ("cram_decode", "cram_decode_blocks") else
                    [exe, "-@", str(threads), "-b", "-i", "reference=" + W.fa, "-p", os.path.join(W.dir, "out.bam"), cram_] if mode == "cram_to_bam" else
                    [exe, "-@", str(threads), "-C", "-o", "version=3.0", "-t", W.fa, "-p", "/dev/null", W.bam])
@@ -1188,7 +1190,7 @@ def libhts_view_cram(run: Run, gpu: str, ref: str, ref_threads, copies: int = 64
             tries_g = [one(gpu, t, mode, **kw) for t in gpu_threads]
             good = [x for x in tries_g if "seconds" in x]
             e = {"libhts_gpu": min(good, key=lambda x: x["seconds"]) if good else tries_g[-1]}
-            if not run.args.no_cpu_baseline and mode != "cram_decode_blocks":
+            if not run.args.no_cpu_baseline and not mode.endswith("_blocks"):
                 tries = [one(ref, t, mode, **kw) for t in ref_threads]
                 good = [x for x in tries if "seconds" in x]
                 e["reference"] = min(good, key=lambda x: x["seconds"]) if good else tries[-1]
@@ -1198,7 +1200,8 @@ def libhts_view_cram(run: Run, gpu: str, ref: str, ref_threads, copies: int = 64
         out = {"cram_records": w.nrec, "cram_file_bytes": os.path.getsize(cram), "cram_bam_GB": round(plain / 1e9, 3)}
         out["cram_decode"] = both("cram_decode", (4, 16))
         out["cram_decode_blocks"] = both("cram_decode_blocks", (64,))
-        out["cram_encode"] = both("cram_encode", (16, 64))
+        out["cram_encode"] = both("cram_encode", (4,))
+        out["cram_encode_blocks"] = both("cram_encode_blocks", (64,))
         w.close()
         # the large file: four times the slices (one run of 256 + one of 768 slices in the reader)
         w = RefCramWorkload(eng, base, 4 * copies)
@@ -1209,6 +1212,7 @@ def libhts_view_cram(run: Run, gpu: str, ref: str, ref_threads, copies: int = 64
         kw = dict(W=w, cram_=big, plain_=len(w.bam_bytes))
         out["cram_decode_large"] = both("cram_decode", (4,), **kw)
         out["cram_to_bam_large"] = both("cram_to_bam", (4,), **kw)
+        out["cram_encode_large"] = both("cram_encode", (4,), **kw)
         return out
     finally:
         w.close()
@@ -1656,7 +1660,7 @@ def compact(o, depth=0):
             if k == "libhts_view" and isinstance(v, dict):
                 # the libhts-level figures, flat: {leg: {gpu_s, gpu_threads, ref_s, ref_threads}}
                 flat = {}
-                for leg in ("decode", "bam2bam", "cram_decode", "cram_decode_blocks", "cram_encode", "cram_decode_large", "cram_to_bam_large"):
+                for leg in ("decode", "bam2bam", "cram_decode", "cram_decode_blocks", "cram_encode", "cram_encode_blocks", "cram_decode_large", "cram_to_bam_large", "cram_encode_large"):
                     e = v.get(leg)
                     if not isinstance(e, dict): continue
                     g, r = e.get("libhts_gpu") or {}, e.get("reference") or {}
