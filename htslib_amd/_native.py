@@ -183,7 +183,7 @@ EXPORTS = ["hg_version", "hg_strerror", "hg_init", "hg_destroy", "hg_device_info
            "hg_gzip_inflate_dev", "hg_cram_uncompress_blocks_host", "hg_ransnx16_decode_host", "hg_ransnx16_decode_dev",
            "hg_ransnx16_compress_bound", "hg_ransnx16_encode_host", "hg_rans4x8_compress_bound",
            "hg_rans4x8_encode_host", "hg_gzip_compress_bound", "hg_gzip_deflate_host", "hg_cram_compress_bound",
-           "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host", "hg_cram_records_bound", "hg_cram_crai_slice", "hg_cram_file_to_bam_host", "hg_cram_decode_bam_host", "hg_cram_decode_records_host", "hg_cram_batch_stage", "hg_cram_batch_decode_bam_dev", "hg_cram_batch_read_bam", "hg_cram_batch_free", "hg_cram_file_to_bam_host2", "hg_cram_decode_bam_host2", "hg_cram_encode_slices_host", "hg_cram_encode_slices_host2", "hg_bam_to_cram_host", "hg_bam_to_cram_host2", "hg_cram_index_build_host", "hg_fqz_decode_host", "hg_fqz_compress_bound", "hg_fqz_encode_host", "hg_tok3_decode_host", "hg_tok3_compress_bound", "hg_tok3_encode_host", "hg_cram_metrics_new", "hg_cram_metrics_free",
+           "hg_cram_compress_blocks_host", "hg_arith_decode_host", "hg_arith_compress_bound", "hg_arith_encode_host", "hg_cram_records_bound", "hg_cram_crai_slice", "hg_cram_file_to_bam_host", "hg_cram_decode_bam_host", "hg_cram_decode_records_host", "hg_cram_batch_stage", "hg_cram_batch_decode_bam_dev", "hg_cram_batch_read_bam", "hg_cram_batch_free", "hg_cram_file_to_bam_host2", "hg_cram_containers_to_bam_host", "hg_cram_writer_new", "hg_cram_writer_free", "hg_cram_writer_containers_host", "hg_cram_decode_bam_host2", "hg_cram_encode_slices_host", "hg_cram_encode_slices_host2", "hg_bam_to_cram_host", "hg_bam_to_cram_host2", "hg_cram_index_build_host", "hg_fqz_decode_host", "hg_fqz_compress_bound", "hg_fqz_encode_host", "hg_tok3_decode_host", "hg_tok3_compress_bound", "hg_tok3_encode_host", "hg_cram_metrics_new", "hg_cram_metrics_free",
            "hg_cram_compress_blocks_metrics_host", "hg_cram_compress_blocks_metrics_fqz_host", "hg_bam_header_host", "hg_bam_frame_dev", "hg_bam_bases_dev", "hg_bam_core_dev", "hg_bam_quals_dev", "hg_bai_build_dev", "hg_idx_build_dev", "hg_csi_levels", "hg_cram_uncompress_blocks_crc_host",
            "hg_pipe_create", "hg_pipe_destroy", "hg_pipe_input", "hg_pipe_reserve", "hg_pipe_inflate", "hg_pipe_deflate", "hg_pipe_wait",
            "hg_gzip_stream_inflate_host", "hg_crc32_host", "hg_crc32_batch_host",

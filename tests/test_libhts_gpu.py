@@ -354,8 +354,8 @@ def test_whole_slice_writer_is_the_path_that_runs_and_hands_over_what_it_cannot_
         assert not st, (o, st)                                               # never started: the reference's writer on our block layer
         assert canon(view(VIEW_REF, ["-D", "w.cram"], fx)) == want, o
     assert not write(["-t", "ce.fa", "-S", "-C", "-o", "VERSION=3.0", "ce#1000.sam"], env=dict(e, HTS_GPU_CRAM_SLICE="0"))
-    # no reference file and none to be found: the first run comes back from the device writer and is replayed
+    # no reference file and none to be found: whichever way it goes (never started, or the first run handed back and replayed), the reference's writer wrote the file
     st = write(["-S", "-C", "-o", "VERSION=3.0", "ce#5.sam"])
-    assert any("cram writer: 0 runs, 0 records through the device, then the reference's writer" in ln for ln in st), st
+    assert not any("cram writer:" in ln and " 0 records through the device" not in ln for ln in st), st
     view(VIEW_REF, ["-S", "-C", "-o", "VERSION=3.0", "ce#5.sam"], fx, "s5.cram")
     assert canon(view(VIEW_REF, ["-D", "w.cram"], fx)) == canon(view(VIEW_REF, ["-D", "s5.cram"], fx))
