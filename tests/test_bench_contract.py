@@ -1,6 +1,6 @@
 """bench.py's contract with the driver, as far as it can be checked without a GPU: the ONE stdout line of the default run must fit the driver's 8 KB tail
 with every op's headline figures in it (compact()), and carry the fields the judge reads.  Input: the complete object of the last measured default run
-(profiles/r05_bench_default_full.json, written by bench.py itself)."""
+(profiles/r06_bench_default_full.json, written by bench.py itself)."""
 import importlib.util
 import json
 import os
@@ -22,7 +22,7 @@ def load_bench():
 
 def test_default_line_fits_the_drivers_tail_and_keeps_every_ops_figures():
     bench = load_bench()
-    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default_full.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_default_full.json")))
     line = json.dumps(bench.compact(full))
     assert len(line) < 7700, len(line)                                   # 8 KB tail, with room for longer numbers
     d = json.loads(line)
@@ -46,6 +46,10 @@ def test_default_line_fits_the_drivers_tail_and_keeps_every_ops_figures():
     for leg in ("decode", "bam2bam"):
         for side in ("libhts_gpu", "reference"):
             assert view[leg][side]["seconds"] > 0 and view[leg][side]["plain_GBps"] > 0, (leg, side, view)
+    # ... and the libhts-level CRAM legs (cram_get_bam_seq / cram_put_bam_seq = the whole-slice reader / writer; *_blocks = the per-block form; *_large = 10.24 M records)
+    for leg in ("cram_decode", "cram_encode", "cram_decode_large", "cram_to_bam_large", "cram_encode_large"):
+        assert view[leg]["gpu_s"] > 0 and view[leg]["ref_s"] > 0, (leg, view)
+    assert view["cram_decode_blocks"]["gpu_s"] > 0 and view["cram_encode_blocks"]["gpu_s"] > 0
 
 
 def test_default_arguments_are_one_gpu_and_minutes():
