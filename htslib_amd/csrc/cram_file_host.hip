@@ -91,7 +91,7 @@ template <class W> std::vector<size_t> cut_ranges(size_t n, size_t parts, W weig
 
 int hg_cram_decode_bam_devsrc(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, const char *const *rg_names,
                               int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap, uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes,
-                              int32_t *status, const char *name_prefix, const uint8_t *dev_lo, const uint8_t *dev_hi);     // cram_records.hip
+                              int32_t *status, const char *name_prefix, const uint8_t *dev_lo, const uint8_t *dev_hi, void *wait_ev);     // cram_records.hip
 
 namespace {
 constexpr int NOT_FUSABLE = 0x7f01;       // internal: this run goes through the host-buffer composition instead
@@ -167,7 +167,28 @@ uint32_t crc_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
 // sibling context's scratch, the two codec families on two streams.  bptr[k] = where block k's plain bytes are: a device address for data blocks (RAW ones
 // point into the uploaded image itself), the host bytes for the header blocks the planner parses.  NOT_FUSABLE: a method of CRAM 3.1, bzip2 / lzma, a
 // compressed header block, bodies scattered over the address space -- the caller takes the host-buffer composition.  HG_EBLOCK: a block failed its CRC or its codec.
-int blocks_on_device(hg_ctx *ctx, int major, const Walk &W, std::vector<const uint8_t *> &bptr, const uint8_t *&dev_lo, const uint8_t *&dev_hi) {
+// (The call returns with the kernels and the read-back of their verdicts IN FLIGHT: the caller plans the record decoder, fetches and digests references and
+// allocates its device memory meanwhile -- on a first run that is as long as the 150 ms rANS kernel -- and orders its gather behind P.done; blocks_verify then
+// reads the verdicts.)
+struct BlocksPending {
+    hg_ctx *A = nullptr; hipEvent_t done = nullptr; int major = 3;
+    std::vector<uint8_t> res; size_t ng = 0, nr = 0, nb = 0, r_gz = 0, r_rs = 0, r_crc = 0;
+    ~BlocksPending() { if (done) { if (A) (void)hipStreamSynchronize(A->stream); (void)hipEventDestroy(done); } }
+};
+int blocks_verify(BlocksPending &P, const Walk &W) {
+    if (!P.A) return HG_EINVAL;
+    if (hipStreamSynchronize(P.A->stream) != hipSuccess) return HG_ELAUNCH;
+    const int32_t *st_gz = (const int32_t *)(P.res.data() + P.r_gz), *st_rs = (const int32_t *)(P.res.data() + P.r_rs); const uint32_t *crc = (const uint32_t *)(P.res.data() + P.r_crc);
+    for (size_t g = 0; g < P.ng; g++) if (st_gz[g] != 0) return HG_EBLOCK;
+    for (size_t r = 0; r < P.nr; r++) if (st_rs[r] != 0) return HG_EBLOCK;
+    if (P.major >= 3)
+        for (size_t k = 0; k < P.nb; k++) {
+            const Blk &b = W.blocks[k];
+            if ((b.csz ? crc_join(b.crc_part, crc[k], b.csz) : b.crc_part) != b.crc) return HG_EBLOCK;       // cram_uncompress_block's first step (cram_io.c:1585-1592)
+        }
+    return HG_OK;
+}
+int blocks_on_device(hg_ctx *ctx, int major, const Walk &W, std::vector<const uint8_t *> &bptr, const uint8_t *&dev_lo, const uint8_t *&dev_hi, BlocksPending &P) {
     const std::vector<Blk> &blocks = W.blocks;
     const size_t nb = blocks.size();
     if (!nb) return NOT_FUSABLE;
@@ -254,16 +275,10 @@ int blocks_on_device(hg_ctx *ctx, int major, const Walk &W, std::vector<const ui
     }
     if (nr && (rc = hg::launch_rans4x8_decode(A, d_img, (const hg_stream_desc *)(d_tab + o_rs), nr, d_dec, (int32_t *)(d_res + r_rs), (uint32_t *)A->d_scratch[6], s))) { (void)hipStreamSynchronize(s); return rc; }
     if (major >= 3 && (rc = hg::launch_crc32(A, d_img, (const uint64_t *)(d_tab + o_coff), (const uint32_t *)(d_tab + o_clen), nb, (uint32_t *)(d_res + r_crc), s))) { (void)hipStreamSynchronize(s); return rc; }
-    std::vector<uint8_t> res(res_bytes);
-    if (hipMemcpyAsync(res.data(), d_res, res_bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
-    const int32_t *st_gz = (const int32_t *)(res.data() + r_gz), *st_rs = (const int32_t *)(res.data() + r_rs); const uint32_t *crc = (const uint32_t *)(res.data() + r_crc);
-    for (size_t g = 0; g < ng; g++) if (st_gz[g] != 0) return HG_EBLOCK;
-    for (size_t r = 0; r < nr; r++) if (st_rs[r] != 0) return HG_EBLOCK;
-    if (major >= 3)
-        for (size_t k = 0; k < nb; k++) {
-            const Blk &b = blocks[k];
-            if ((b.csz ? crc_join(b.crc_part, crc[k], b.csz) : b.crc_part) != b.crc) return HG_EBLOCK;       // cram_uncompress_block's first step (cram_io.c:1585-1592)
-        }
+    P.A = A; P.major = major; P.ng = ng; P.nr = nr; P.nb = nb; P.r_gz = r_gz; P.r_rs = r_rs; P.r_crc = r_crc;
+    P.res.resize(res_bytes);
+    if (hipEventCreateWithFlags(&P.done, hipEventDisableTiming) != hipSuccess) { P.done = nullptr; (void)hipStreamSynchronize(s); return HG_ELAUNCH; }
+    if (hipMemcpyAsync(P.res.data(), d_res, res_bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(P.done, s) != hipSuccess) { (void)hipStreamSynchronize(s); return HG_ELAUNCH; }
     bptr.assign(nb, nullptr);
     for (size_t k = 0; k < nb; k++) {
         const Blk &b = blocks[k];
@@ -273,7 +288,7 @@ int blocks_on_device(hg_ctx *ctx, int major, const Walk &W, std::vector<const ui
     return HG_OK;
 }
 
-int slices_to_bam(hg_ctx *ctx, const std::vector<hg_ctx *> &ctxs, int major, Walk &W, const uint8_t *const *dec, const uint8_t *dev_lo, const uint8_t *dev_hi, int nref, const int64_t *sq_len,
+int slices_to_bam(hg_ctx *ctx, const std::vector<hg_ctx *> &ctxs, int major, Walk &W, const uint8_t *const *dec, const uint8_t *dev_lo, const uint8_t *dev_hi, void *wait_ev, int nref, const int64_t *sq_len,
                   const char *const *rg_names, int nrg, const hg_cram_ref_seq *refs, int nrefs_given, hg_cram_get_ref_fn get_ref, void *get_ref_ud, int flags, int decode_md,
                   const char *name_prefix, uint8_t *rec_out, size_t rec_cap, uint64_t *rec_bytes_out, uint64_t *nrecords);
 }  // namespace
@@ -353,7 +368,7 @@ extern "C" int hg_cram_file_to_bam_host2(hg_ctx *ctx, const uint8_t *cram, size_
     std::vector<const char *> rgp; for (auto &r : rg_id) rgp.push_back(r.c_str());
     uint64_t rec_bytes = 0;
     std::vector<const uint8_t *> dptr(dec.size()); for (size_t i = 0; i < dec.size(); i++) dptr[i] = dec[i].data();
-    const int rc = slices_to_bam(ctx, ctxs, major, W, dptr.data(), nullptr, nullptr, nref, sq_len.data(), rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), refs, nrefs_given, nullptr, nullptr, flags, -1 /* hts_open's default */,
+    const int rc = slices_to_bam(ctx, ctxs, major, W, dptr.data(), nullptr, nullptr, nullptr, nref, sq_len.data(), rgp.empty() ? nullptr : rgp.data(), (int)rgp.size(), refs, nrefs_given, nullptr, nullptr, flags, -1 /* hts_open's default */,
                                  name_prefix, bam_out + hb, bam_cap - hb, &rec_bytes, nrecords);
     *bam_bytes = hb + rec_bytes;
     return rc;
@@ -384,10 +399,15 @@ extern "C" int hg_cram_containers_to_bam_host(hg_ctx *ctx, int major, size_t nco
     if (fuse && ctxs.size() == 1) {
         hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;               // the sibling context's buffers hold this run's blocks until the records are out
         std::vector<const uint8_t *> bptr; const uint8_t *dev_lo = nullptr, *dev_hi = nullptr;
-        int rc = blocks_on_device(ctx, major, W, bptr, dev_lo, dev_hi);
+        BlocksPending pend;
+        int rc = blocks_on_device(ctx, major, W, bptr, dev_lo, dev_hi, pend);
         const auto t2 = std::chrono::steady_clock::now();
-        if (rc == HG_OK) rc = slices_to_bam(ctx, ctxs, major, W, bptr.data(), dev_lo, dev_hi, nref, sq_len, rg_names, nrg, refs, nrefs_given, get_ref, get_ref_ud, flags, decode_md, name_prefix,
-                                            bam_out, bam_cap, &rec_bytes, nrecords);
+        if (rc == HG_OK) {
+            rc = slices_to_bam(ctx, ctxs, major, W, bptr.data(), dev_lo, dev_hi, pend.done, nref, sq_len, rg_names, nrg, refs, nrefs_given, get_ref, get_ref_ud, flags, decode_md, name_prefix,
+                               bam_out, bam_cap, &rec_bytes, nrecords);
+            const int vrc = blocks_verify(pend, W);                       // the blocks' own verdicts (CRC, codec status): a run with a bad block is not delivered, whatever the records looked like
+            if (vrc != HG_OK && rc != NOT_FUSABLE) rc = vrc;
+        }
         if (rc != NOT_FUSABLE) {
             *bam_bytes = rec_bytes;
             if (stats) fprintf(stderr, "[htsgpu stats] cram run (fused): %zu containers, %zu slices, %zu blocks %.1f -> %.1f MB, %.1f MB of BAM; walk %.1f ms, blocks %.1f ms, slices -> BAM %.1f ms (rc %d)\n",
@@ -401,7 +421,7 @@ extern "C" int hg_cram_containers_to_bam_host(hg_ctx *ctx, int major, size_t nco
     if (const int urc = uncompress_walk(ctxs, major, W.blocks, dec)) return urc;
     const auto t2 = std::chrono::steady_clock::now();
     std::vector<const uint8_t *> dptr(dec.size()); for (size_t i = 0; i < dec.size(); i++) dptr[i] = dec[i].data();
-    const int rc = slices_to_bam(ctx, ctxs, major, W, dptr.data(), nullptr, nullptr, nref, sq_len, rg_names, nrg, refs, nrefs_given, get_ref, get_ref_ud, flags, decode_md, name_prefix, bam_out, bam_cap,
+    const int rc = slices_to_bam(ctx, ctxs, major, W, dptr.data(), nullptr, nullptr, nullptr, nref, sq_len, rg_names, nrg, refs, nrefs_given, get_ref, get_ref_ud, flags, decode_md, name_prefix, bam_out, bam_cap,
                                  &rec_bytes, nrecords);
     *bam_bytes = rec_bytes;
     if (stats) fprintf(stderr, "[htsgpu stats] cram run: %zu containers, %zu slices, %zu blocks %.1f -> %.1f MB, %.1f MB of BAM; walk %.1f ms, blocks %.1f ms, slices -> BAM %.1f ms (rc %d)\n",
@@ -410,7 +430,7 @@ extern "C" int hg_cram_containers_to_bam_host(hg_ctx *ctx, int major, size_t nco
 }
 
 namespace {
-int slices_to_bam(hg_ctx *ctx, const std::vector<hg_ctx *> &ctxs, int major, Walk &W, const uint8_t *const *dec, const uint8_t *dev_lo, const uint8_t *dev_hi, int nref, const int64_t *sq_len,
+int slices_to_bam(hg_ctx *ctx, const std::vector<hg_ctx *> &ctxs, int major, Walk &W, const uint8_t *const *dec, const uint8_t *dev_lo, const uint8_t *dev_hi, void *wait_ev, int nref, const int64_t *sq_len,
                   const char *const *rg_names, int nrg, const hg_cram_ref_seq *refs, int nrefs_given, hg_cram_get_ref_fn get_ref, void *get_ref_ud, int flags, int decode_md,
                   const char *name_prefix, uint8_t *rec_out, size_t rec_cap, uint64_t *rec_bytes_out, uint64_t *nrecords) {
     std::vector<Blk> &blocks = W.blocks; std::vector<Sl> &slices = W.slices;
@@ -547,7 +567,7 @@ int slices_to_bam(hg_ctx *ctx, const std::vector<hg_ctx *> &ctxs, int major, Wal
             for (int attempt = 0;; attempt++) {
                 got = 0;
                 rc = hg_cram_decode_bam_devsrc(c, i1 - i0, sb.data() + i0, major, nref, rg_names, nrg, seq_cap, dst + rec_bytes,
-                                               cap - rec_bytes, ro.data(), nullptr, &got, status.data() + i0, name_prefix, dev_lo, dev_hi);
+                                               cap - rec_bytes, ro.data(), nullptr, &got, status.data() + i0, name_prefix, dev_lo, dev_hi, wait_ev);
                 bool no_room = false;
                 for (size_t k = i0; k < i1; k++) if (status[k] == hgr::ERR_UNSUPPORTED) no_room = true;    // "does not fit" is one of its meanings
                 if ((rc != HG_OK && rc != HG_EBLOCK) || !no_room || attempt == 1 || seq_cap >= (1ull << 34)) break;   // once: a slice the decoder does not support says -3, too

@@ -381,6 +381,7 @@ struct hg_cram_batch {
     hgr::Dense PK{};
     uint64_t *d_bam_off = nullptr; uint8_t *d_bam = nullptr;
     size_t n_chain0 = 0;                                // slices the passes do not take
+    void *wait_ev = nullptr;                            // a hipEvent_t the device-resident blocks are complete behind (their decoders run on another stream)
     const uint8_t *dev_lo = nullptr, *dev_hi = nullptr; // block pointers inside [dev_lo, dev_hi) are DEVICE addresses (blocks decoded in place by the fused run
                                                         // decoder, cram_file_host.hip): rec_stage gathers them on the device instead of uploading them
     std::vector<uint8_t> retried;                       // slices the passes gave up (last run)
@@ -439,6 +440,7 @@ static int rec_stage(hg_ctx *ctx, hg_cram_batch &R, size_t nslices, const hg_cra
                 if (B.src_len[k]) { g_src.push_back((uint64_t)(B.src_ptr[k] - R.dev_lo)); g_dst.push_back(B.src_off[k]); g_len.push_back(B.src_len[k]); }
             }
         ok = hg::stage_upload(ctx, B.src_ptr.data(), B.src_len.data(), B.src_off.data(), skip.data(), nsrc, B.data_bytes, d_data, s) == HG_OK &&
+             (!R.wait_ev || hipStreamWaitEvent(s, (hipEvent_t)R.wait_ev, 0) == hipSuccess) &&
              hg::stage_gather_dev(ctx, R.dev_lo, g_src.data(), g_len.data(), d_data, g_dst.data(), g_src.size(), s) == HG_OK;
     } else ok = hg::stage_upload(ctx, B.src_ptr.data(), B.src_len.data(), B.src_off.data(), nullptr, B.src_ptr.size(), B.data_bytes, d_data, s) == HG_OK;
     for (int i = 0; i < 10; i++) if (ok && parts[i].bytes) ok = hipMemcpyAsync(d_tab + R.t_off[i], parts[i].src, parts[i].bytes, hipMemcpyHostToDevice, s) == hipSuccess;
@@ -739,20 +741,20 @@ extern "C" int hg_cram_decode_bam_host(hg_ctx *ctx, size_t nslices, const hg_cra
 // ... with block pointers that may be device addresses (internal: the fused run decoder of cram_file_host.hip)
 int hg_cram_decode_bam_devsrc(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, const char *const *rg_names,
                               int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap, uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes,
-                              int32_t *status, const char *name_prefix, const uint8_t *dev_lo, const uint8_t *dev_hi);
+                              int32_t *status, const char *name_prefix, const uint8_t *dev_lo, const uint8_t *dev_hi, void *wait_ev);
 extern "C" int hg_cram_decode_bam_host2(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, const char *const *rg_names,
                                         int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap, uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes,
                                         int32_t *status, const char *name_prefix) {
     return hg_cram_decode_bam_devsrc(ctx, nslices, slices, major_version, nref, rg_names, nrg, total_bases, bam_out, bam_cap, rec_off, rec_bam_off, bam_bytes, status, name_prefix,
-                                     nullptr, nullptr);
+                                     nullptr, nullptr, nullptr);
 }
 int hg_cram_decode_bam_devsrc(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, const char *const *rg_names,
                               int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap, uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes,
-                              int32_t *status, const char *name_prefix, const uint8_t *dev_lo, const uint8_t *dev_hi) {
+                              int32_t *status, const char *name_prefix, const uint8_t *dev_lo, const uint8_t *dev_hi, void *wait_ev) {
     if (!ctx || (nslices && (!slices || !bam_out || !rec_off || !status)) || (nrg && !rg_names)) return HG_EINVAL;
     if (nslices == 0) { if (rec_off) rec_off[0] = 0; if (bam_bytes) *bam_bytes = 0; return HG_OK; }
     hg::CtxGuard guard_(ctx); if (guard_.rc) return guard_.rc;
-    hg_cram_batch R; R.M.ctx = ctx; R.dev_lo = dev_lo; R.dev_hi = dev_hi;
+    hg_cram_batch R; R.M.ctx = ctx; R.dev_lo = dev_lo; R.dev_hi = dev_hi; R.wait_ev = wait_ev;
     static const bool timing = getenv("HG_CRAM_RECORDS_TIMING") != nullptr;
     const auto tt0 = std::chrono::steady_clock::now();
     int rc = rec_stage(ctx, R, nslices, slices, major_version, nref, true, true, (size_t)total_bases);

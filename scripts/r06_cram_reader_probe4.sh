@@ -9,7 +9,7 @@ from htslib_amd import _native as nat, synth_cram
 eng = nat.Engine(0)
 base = [synth_cram.make_slice(np.random.default_rng(7 + i), 10000, 150) for i in range(4)]
 gpu = os.path.join(bench.ROOT, "oracle", "_ref", "ref_view_gpu"); ref = bench.REF_VIEW
-for copies in (64,):
+for copies in (64, 256):
     w = bench.RefCramWorkload(eng, base, copies)
     cram = os.path.join(w.dir, "in_l5.cram")
     r = subprocess.run([ref, "-@", "32", "-C", "-o", "version=3.0", "-t", w.fa, "-p", cram, w.bam], capture_output=True)
