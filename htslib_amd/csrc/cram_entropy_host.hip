@@ -616,7 +616,11 @@ static int entropy_encode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
         if (rc) return rc;
         if (hipMemcpyAsync(ol.data(), d_ol, nc * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return HG_ELAUNCH;
         // a two-phase stream always has at least its alphabet byte: 0 = its coder gave up waiting for records (a logic error, reported loudly, never as bytes)
-        for (size_t k = 0; k < nc; k++) if (ccls[k] == C_ARITH_2P && ol[k] == 0) return HG_ELAUNCH;
+        for (size_t k = 0; k < nc; k++)
+            if (ccls[k] == C_ARITH_2P && ol[k] == 0) {
+                fprintf(stderr, "[hts-gpu] range coder: the coder pass of core stream %zu of %zu (two-phase encoder) ran out of its poll budget waiting for model records; the batch fails\n", k, nc);
+                return HG_ELAUNCH;
+            }
     }
     // ---- stitch --------------------------------------------------------------------------------
     // Payload pieces live in two device buffers (0: d_buf -- raw RLE meta and CAT data, 1: d_out -- entropy-coder output).

@@ -8,6 +8,7 @@
 // loop.  A call is split into rounds at the points where a trial phase finishes (the blocks after it need the method
 // it learns); everything decidable goes to the GPU together, across all data series -- usually two rounds per call.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <limits.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -47,7 +48,7 @@ struct Job { size_t blk; int m; };
 uint32_t (*g_size_script)(int method, size_t blk, uint32_t in_len) = nullptr;
 // counters of the auto-tuner since the process started (hg_debug_cram_tuner_counters): calls, rounds, trial blocks compressed ahead of time, ... of those
 // folded from the cache, trial blocks that took the normal path
-uint64_t g_tuner[5] = {0, 0, 0, 0, 0};
+std::atomic<uint64_t> g_tuner[5];                                // (calls on different contexts run concurrently: sharded writers, several devices)
 
 struct HostLibs {
     int (*bz2)(char *, unsigned int *, char *, unsigned int, int, int, int) = nullptr;                                                      // BZ2_bzBuffToBuffCompress
@@ -182,7 +183,7 @@ int run_jobs(hg_ctx *ctx, const std::vector<Job> &jobs, int level, const uint8_t
 extern "C" {
 
 void hg_debug_set_cram_size_script(uint32_t (*fn)(int, size_t, uint32_t)) { g_size_script = fn; }
-void hg_debug_cram_tuner_counters(uint64_t *out) { for (int i = 0; i < 5; i++) out[i] = g_tuner[i]; }
+void hg_debug_cram_tuner_counters(uint64_t *out) { for (int i = 0; i < 5; i++) out[i] = g_tuner[i].load(std::memory_order_relaxed); }
 
 hg_cram_metrics *hg_cram_metrics_new(void) {                            // cram_new_metrics, cram_io.c:2327-2339
     hg_cram_metrics *m = (hg_cram_metrics *)calloc(1, sizeof *m);
@@ -275,7 +276,7 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
     // would: a ROUND takes, per metrics object, every block whose branch is already decided by the current state --
     // cached-method blocks, then the blocks of the next trial phase -- and stops there, because the blocks after a
     // trial phase need the method that phase is about to learn.  Usually two rounds per call.
-    g_tuner[0]++;
+    g_tuner[0].fetch_add(1, std::memory_order_relaxed);
     for (;;) {
         std::vector<Job> jobs;
         std::vector<size_t> taken;
@@ -358,11 +359,11 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
                     fold_trial(i, M, method, [&](int m, const uint8_t *&p, uint32_t &len) { if (!S.sz[m]) return false; len = S.sz[m]; p = m == S.best_m ? S.best : nullptr; return true; });
                     b.done = true; b.trial = false;
                     taken.pop_back();
-                    g_tuner[3]++;
+                    g_tuner[3].fetch_add(1, std::memory_order_relaxed);
                     continue;
                 }
             }
-            g_tuner[4]++;
+            g_tuner[4].fetch_add(1, std::memory_order_relaxed);
             for (int m = 0; m < MAXM; m++) if (method & (1u << m)) jobs.push_back({i, m});
             b.j1 = jobs.size();
             if (M->trial - ++pend[k] <= 0) blocked[k] = 1;              // this block ends the trial phase: later blocks wait a round
@@ -397,14 +398,14 @@ int hg_cram_compress_blocks_metrics_fqz_host(hg_ctx *ctx, size_t n, hg_cram_metr
                         SpecJobs sj{i, jobs.size(), 0};
                         for (int m = 0; m < MAXM; m++) if (method & (1u << m)) jobs.push_back({i, m});
                         sj.j1 = jobs.size();
-                        spec_jobs.push_back(sj); g_tuner[2]++;
+                        spec_jobs.push_back(sj); g_tuner[2].fetch_add(1, std::memory_order_relaxed);
                     }
                     if (--S.trial == 0) resolve();
                 }
             }
         }
         if (taken.empty()) break;
-        g_tuner[1]++;
+        g_tuner[1].fetch_add(1, std::memory_order_relaxed);
         // ---- compress -------------------------------------------------------------------------------------------
         std::vector<uint8_t *> res, arenas; std::vector<uint32_t> rlen;
         const auto t_round = std::chrono::steady_clock::now();

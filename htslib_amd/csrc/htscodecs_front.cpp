@@ -142,7 +142,12 @@ unsigned char *arith_uncompress_to(unsigned char *in, unsigned int in_size, unsi
         return hg_arith_decode_host(c, i, il, 1, o, ol, st);
     };
     if (!out) return sized_decode(in, in_size, out_size, dec);
-    // caller's buffer: *out_size = its capacity
+    // caller's buffer: *out_size = its capacity.  The size the stream declares is checked against it BEFORE anything is allocated or launched (a few
+    // bytes of hostile input must not buy a 2 GiB allocation and a device launch)
+    {
+        uint32_t usz = 0;
+        if (!in || in_size < 2 || (in[0] & F_NOSZ) || !get_u7(in + 1, in + in_size, &usz) || usz > *out_size) return nullptr;
+    }
     unsigned int got = 0;
     uint8_t *tmp = sized_decode(in, in_size, &got, dec);
     if (!tmp) return nullptr;
