@@ -359,3 +359,19 @@ def test_whole_slice_writer_is_the_path_that_runs_and_hands_over_what_it_cannot_
     assert not any("cram writer:" in ln and " 0 records through the device" not in ln for ln in st), st
     view(VIEW_REF, ["-S", "-C", "-o", "VERSION=3.0", "ce#5.sam"], fx, "s5.cram")
     assert canon(view(VIEW_REF, ["-D", "w.cram"], fx)) == canon(view(VIEW_REF, ["-D", "s5.cram"], fx))
+
+
+def test_reader_and_writer_in_one_process_transcode_cram(fx):
+    """`test_view -C in.cram` / `-b in.cram`: the whole-slice reader feeds the whole-slice writer (or bam_write1 on our bgzf_write) in the same process, both on the block layer's
+    device context; stock htslib reads the result back to what it reads from the input."""
+    view(VIEW_REF, ["-t", "ce.fa", "-S", "-C", "-o", "VERSION=3.0", "-o", "seqs_per_slice=100", "ce#1000.sam"], fx, "in.cram")
+    want = canon(view(VIEW_REF, ["-D", "in.cram"], fx))
+    e = dict(_env(fx), HTS_GPU_STATS="1")
+    p = subprocess.run([VIEW_GPU, "-@4", "-D", "-t", "ce.fa", "-C", "-o", "VERSION=3.0", "in.cram"], cwd=fx, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=600)
+    assert p.returncode == 0, p.stderr.decode("latin1")[-800:]
+    st = p.stderr.decode("latin1")
+    assert "cram reader: " in st and "1000 records" in st and "cram writer: 1 runs, 1000 records through the device;" in st, st[-1500:]
+    open(os.path.join(fx, "tc.cram"), "wb").write(p.stdout)
+    assert canon(view(VIEW_REF, ["-D", "tc.cram"], fx)) == want
+    view(VIEW_GPU, ["-@4", "-D", "-b", "in.cram"], fx, "tc.bam")
+    assert canon(view(VIEW_REF, ["tc.bam"], fx)) == want
