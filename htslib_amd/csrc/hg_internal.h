@@ -169,30 +169,48 @@ int ensure_scratch(hg_ctx *ctx, int slot, size_t bytes);
 // Two kernel variants of one call (4-way / 32-way rANS, small / big range-coder pool) work on disjoint streams of the
 // batch and are each latency-bound: the second one goes to the context's side stream, ordered after everything already
 // queued on s, and s then waits for it.
+// The side streams are created when a call first forks onto them (round 6): a context that never runs two variants side by side keeps ONE stream.  Streams are
+// not free: creating four costs ~40 ms of a process's start-up (experiments/startup_probe.cpp), and every live stream holds a place on one of the device's
+// GPU_MAX_HW_QUEUES hardware queues -- a CRAM batch with six codec-family contexts of four streams each had more streams than queues, and which two families'
+// long kernels ended up behind each other on one queue depended on what the process had created before (bench.py: cram_slices decode 21.9 GB/s alone, 15-17 inside
+// the default run).  The caller holds the context lock.
+inline hipStream_t side_stream(hipStream_t &st, hipStream_t fallback) {
+    if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; return fallback; }
+    return st;
+}
 inline hipStream_t fork_side(hg_ctx *ctx, hipStream_t s) {
+    hipStream_t t = side_stream(ctx->stream2, s);
+    if (t == s) return s;                                                // (no side stream to be had: the variant runs in line)
     (void)hipEventRecord(ctx->ev_fork, s);
-    (void)hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
-    return ctx->stream2;
+    (void)hipStreamWaitEvent(t, ctx->ev_fork, 0);
+    return t;
 }
 inline void join_side(hg_ctx *ctx, hipStream_t s) {
+    if (!ctx->stream2) return;
     (void)hipEventRecord(ctx->ev_join, ctx->stream2);
     (void)hipStreamWaitEvent(s, ctx->ev_join, 0);
 }
 inline hipStream_t fork_side3(hg_ctx *ctx, hipStream_t s) {
+    hipStream_t t = side_stream(ctx->stream3, s);
+    if (t == s) return s;
     (void)hipEventRecord(ctx->ev_fork3, s);
-    (void)hipStreamWaitEvent(ctx->stream3, ctx->ev_fork3, 0);
-    return ctx->stream3;
+    (void)hipStreamWaitEvent(t, ctx->ev_fork3, 0);
+    return t;
 }
 inline void join_side3(hg_ctx *ctx, hipStream_t s) {
+    if (!ctx->stream3) return;
     (void)hipEventRecord(ctx->ev_join3, ctx->stream3);
     (void)hipStreamWaitEvent(s, ctx->ev_join3, 0);
 }
 inline hipStream_t fork_side4(hg_ctx *ctx, hipStream_t s) {
+    hipStream_t t = side_stream(ctx->stream4, s);
+    if (t == s) return s;
     (void)hipEventRecord(ctx->ev_fork4, s);
-    (void)hipStreamWaitEvent(ctx->stream4, ctx->ev_fork4, 0);
-    return ctx->stream4;
+    (void)hipStreamWaitEvent(t, ctx->ev_fork4, 0);
+    return t;
 }
 inline void join_side4(hg_ctx *ctx, hipStream_t s) {
+    if (!ctx->stream4) return;
     (void)hipEventRecord(ctx->ev_join4, ctx->stream4);
     (void)hipStreamWaitEvent(s, ctx->ev_join4, 0);
 }

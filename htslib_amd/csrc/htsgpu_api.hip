@@ -79,10 +79,8 @@ int hg_init(int device, hg_ctx **out) {
     ctx->launch_seq = new std::atomic<unsigned int>(0);
     ctx->mu = new std::recursive_mutex();
     ctx->tok_mu = new std::mutex();
+    // (stream2 .. stream4 are created by the first call that forks onto them: hg_internal.h)
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream4, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork4, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join4, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork3, hipEventDisableTiming) != hipSuccess ||
