@@ -1651,7 +1651,7 @@ def compact(o, depth=0):
     if isinstance(o, dict):
         out = {}
         for k, v in o.items():
-            if k in ("variants", "on_disk_methods", "note", "parity", "timing", "format_parity", "sample_detail", "traffic_note", "sharding", "prep_seconds"): continue
+            if k in ("variants", "on_disk_methods", "note", "parity", "timing", "format_parity", "sample_detail", "traffic_note", "sharding", "prep_seconds", "op_seconds"): continue
             if depth >= 2 and k in ("metric", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "n_gpus", "warmup", "algorithmic_bytes_per_launch", "algorithmic_bytes",
                                     "cpu_baseline_port", "in_bytes", "bam_bytes", "blocks_per_gpu", "plain_bytes_per_gpu", "compressed_bytes_per_gpu", "peak", "streams_per_gpu", "verified_streams",
                                     "slices_decoded_by_the_data_parallel_passes", "verified_blocks"): continue
@@ -1688,6 +1688,7 @@ def compact(o, depth=0):
 
 
 def main():
+    t_main = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -1733,14 +1734,21 @@ def main():
             out, ok = op_inflate(run, S, args.steps, args.warmup)
             if args.op == "all" and args.scaling == "weak":
                 extra = {}
+                op_s = {"bgzf_inflate": round(time.perf_counter() - t_main, 1)}       # wall seconds per op of this run (the full object only; CPU baselines included)
+                def lap(name, t0): op_s[name] = round(time.perf_counter() - t0, 1)
                 es = max(1, args.extra_steps)
+                t0 = time.perf_counter()
                 d, ok2 = op_deflate(run, S, es, 1); ok = ok and ok2
                 if d: extra["bgzf_deflate"] = d
+                lap("bgzf_deflate", t0)
                 if run.rank == 0 and run.world == 1:
+                    t0 = time.perf_counter()
                     try:
                         extra["end_to_end"] = op_e2e(run, S)
                     except Exception as e:                                  # never lose the headline to an auxiliary figure
                         extra["end_to_end"] = {"error": repr(e)}
+                    lap("end_to_end", t0)
+                t0 = time.perf_counter()
                 ld_comp, ld_desc = S.comp, S.desc
                 del S
                 import torch
@@ -1757,21 +1765,29 @@ def main():
                         extra["bgzf_inflate_variant_B"] = inflate_variant_b(run, es)
                     except Exception as e:
                         extra["bgzf_inflate_variant_B"] = {"error": repr(e)}
+                lap("inflate_variants", t0)
+                t0 = time.perf_counter()
                 d, ok2 = op_rans(run, es, 1, args.slices or 1000); ok = ok and ok2
                 if d: extra["cram_rans_nx16_decode"] = d
+                lap("cram_rans_nx16_decode", t0); t0 = time.perf_counter()
                 d, ok2 = op_rans(run, es, 1, args.slices or 1000, 4); ok = ok and ok2
                 if d: extra["cram_rans_4x16_decode"] = d
+                lap("cram_rans_4x16_decode", t0); t0 = time.perf_counter()
                 d, ok2 = op_cram(run, es, 256 if not args.slices else args.slices); ok = ok and ok2
                 if d: extra["cram_slices"] = d
+                lap("cram_slices", t0)
                 if run.rank == 0 and run.world == 1:                         # the "next" rows of SURVEY 8f built this round: small, guarded probes
                     for key, fn in (("cram_records_to_bam", lambda: op_records(run, 5)), ("cram_records_encode", lambda: op_encode(run, 5)), ("cram31_file_encode", lambda: op_cram31(run, 2, 312, flag_sets=[3, 1])),
                                     ("cram_fqzcomp", lambda: op_fqz(run, 3, 1248, 10000))):
+                        t0 = time.perf_counter()
                         try:
                             extra[key] = fn()
                         except Exception as e:
                             extra[key] = {"error": repr(e)}
+                        lap(key, t0)
                 if out is not None:
                     out["extra"] = extra
+                    out["op_seconds"] = op_s
     if run.rank == 0 and out is not None:
         full = json.dumps(out)
         try:
