@@ -172,13 +172,18 @@ uint32_t crc_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
 // reads the verdicts.)
 struct BlocksPending {
     hg_ctx *A = nullptr; hipEvent_t done = nullptr; int major = 3;
-    std::vector<uint8_t> res; size_t ng = 0, nr = 0, nb = 0, r_gz = 0, r_rs = 0, r_crc = 0;
-    ~BlocksPending() { if (done) { if (A) (void)hipStreamSynchronize(A->stream); (void)hipEventDestroy(done); } }
+    uint8_t *res = nullptr;                                              // PAGE-LOCKED: a read-back into pageable memory does not return before the kernels ahead of it have finished
+    size_t ng = 0, nr = 0, nb = 0, r_gz = 0, r_rs = 0, r_crc = 0;
+    ~BlocksPending() {
+        if (A && (done || res)) (void)hipStreamSynchronize(A->stream);
+        if (done) (void)hipEventDestroy(done);
+        if (res) (void)hipHostFree(res);
+    }
 };
 int blocks_verify(BlocksPending &P, const Walk &W) {
-    if (!P.A) return HG_EINVAL;
+    if (!P.A || !P.res) return HG_EINVAL;
     if (hipStreamSynchronize(P.A->stream) != hipSuccess) return HG_ELAUNCH;
-    const int32_t *st_gz = (const int32_t *)(P.res.data() + P.r_gz), *st_rs = (const int32_t *)(P.res.data() + P.r_rs); const uint32_t *crc = (const uint32_t *)(P.res.data() + P.r_crc);
+    const int32_t *st_gz = (const int32_t *)(P.res + P.r_gz), *st_rs = (const int32_t *)(P.res + P.r_rs); const uint32_t *crc = (const uint32_t *)(P.res + P.r_crc);
     for (size_t g = 0; g < P.ng; g++) if (st_gz[g] != 0) return HG_EBLOCK;
     for (size_t r = 0; r < P.nr; r++) if (st_rs[r] != 0) return HG_EBLOCK;
     if (P.major >= 3)
@@ -276,9 +281,9 @@ int blocks_on_device(hg_ctx *ctx, int major, const Walk &W, std::vector<const ui
     if (nr && (rc = hg::launch_rans4x8_decode(A, d_img, (const hg_stream_desc *)(d_tab + o_rs), nr, d_dec, (int32_t *)(d_res + r_rs), (uint32_t *)A->d_scratch[6], s))) { (void)hipStreamSynchronize(s); return rc; }
     if (major >= 3 && (rc = hg::launch_crc32(A, d_img, (const uint64_t *)(d_tab + o_coff), (const uint32_t *)(d_tab + o_clen), nb, (uint32_t *)(d_res + r_crc), s))) { (void)hipStreamSynchronize(s); return rc; }
     P.A = A; P.major = major; P.ng = ng; P.nr = nr; P.nb = nb; P.r_gz = r_gz; P.r_rs = r_rs; P.r_crc = r_crc;
-    P.res.resize(res_bytes);
+    if (hipHostMalloc((void **)&P.res, res_bytes + 64, hipHostMallocDefault) != hipSuccess) { P.res = nullptr; (void)hipStreamSynchronize(s); return HG_ENOMEM; }
     if (hipEventCreateWithFlags(&P.done, hipEventDisableTiming) != hipSuccess) { P.done = nullptr; (void)hipStreamSynchronize(s); return HG_ELAUNCH; }
-    if (hipMemcpyAsync(P.res.data(), d_res, res_bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(P.done, s) != hipSuccess) { (void)hipStreamSynchronize(s); return HG_ELAUNCH; }
+    if (hipMemcpyAsync(P.res, d_res, res_bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(P.done, s) != hipSuccess) { (void)hipStreamSynchronize(s); return HG_ELAUNCH; }
     bptr.assign(nb, nullptr);
     for (size_t k = 0; k < nb; k++) {
         const Blk &b = blocks[k];
