@@ -429,12 +429,13 @@ typedef struct writer {
 } writer;
 static writer *g_writers;
 
+static __thread cram_fd *tl_wfd; static __thread writer *tl_wr; static __thread unsigned tl_wgen;      /* the writers' per-thread cache (as tl_fd / tl_rd for readers) */
 static writer *find_writer(cram_fd *fd) {
-    if (tl_fd == fd && tl_gen == g_gen) return (writer *)tl_rd;
+    if (tl_wfd == fd && tl_wgen == g_gen) return tl_wr;
     pthread_mutex_lock(&g_lock);
     writer *w = g_writers;
     while (w && w->fd != fd) w = w->next;
-    tl_fd = fd; tl_rd = (reader *)w; tl_gen = g_gen;        /* (a cram_fd is a reader or a writer, never both: the cache slot is shared) */
+    tl_wfd = fd; tl_wr = w; tl_wgen = g_gen;
     pthread_mutex_unlock(&g_lock);
     return w;
 }
@@ -609,7 +610,7 @@ int cram_put_bam_seq(cram_fd *fd, bam_seq_t *b) {
     writer *Wt = fd && fd->mode == 'w' ? find_writer(fd) : NULL;
     if (!Wt) {
         if (!writer_eligible(fd) || !(Wt = start_writer(fd))) return hg_ref_cram_put_bam_seq(fd, b);
-        tl_fd = fd; tl_rd = (reader *)Wt; tl_gen = g_gen;
+        tl_wfd = fd; tl_wr = Wt; tl_wgen = g_gen;
     }
     if (Wt->failed) return -1;
     if (Wt->pass) {
