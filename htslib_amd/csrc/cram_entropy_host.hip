@@ -274,6 +274,43 @@ static int entropy_decode_host(Codec codec, hg_ctx *ctx, const uint8_t *const *i
 }
 
 // ================================================================================================
+// The same plans for streams that are ALREADY ON THE DEVICE (the fused run decoder of cram_file_host.hip, round 6): stream i lies at in_off[i] of the
+// context's input image (scratch slot 0, which the caller has filled -- the container bodies of a run as they lie in the file) and its plain bytes go to out_off[i]
+// of the output image (slot 1, [0, obytes); the plan's work area follows behind).  Host bytes are needed only for the few header bytes the planner reads.
+// launch: everything is queued on the context's stream, nothing is waited for; finish (after the caller's other work): statuses.  codec[i]: 0 Nx16, 1 range coder.
+// ================================================================================================
+struct hg_entropy_inplace { Plan P; std::vector<int32_t> st; };
+int hg_entropy_decode_inplace_launch(hg_ctx *ctx, size_t n, const uint8_t *codec, const uint8_t *const *in, const uint32_t *in_len, const uint64_t *in_off,
+                                     const uint32_t *out_len, const uint64_t *out_off, uint64_t in_bytes, uint64_t obytes, hg_entropy_inplace **handle) {
+    if (!ctx || !handle || (n && (!codec || !in || !in_len || !in_off || !out_len || !out_off))) return HG_EINVAL;
+    hg_entropy_inplace *H = new (std::nothrow) hg_entropy_inplace;
+    if (!H) return HG_ENOMEM;
+    H->st.assign(n, 0);
+    Plan &P = H->P;
+    for (size_t i = 0; i < n; i++) {
+        const size_t c0 = P.core.size(), x0 = P.xf.size();
+        const uint64_t w0 = P.work, s0 = P.scratch;
+        if (int r = plan_stream(P, codec[i] ? ARITH : NX16, (uint32_t)i, in_off[i], in[i], in[i], in[i] + in_len[i], out_len[i], out_off[i], 1, 0)) {
+            H->st[i] = r;
+            P.core.resize(c0); P.core_top.resize(c0); P.core_cls.resize(c0); P.xf.resize(x0); P.xf_top.resize(x0); P.work = w0; P.scratch = s0;
+        }
+    }
+    if (P.too_big) { delete H; return HG_EINVAL; }
+    const int rc = launch_plan(ctx, P, in_bytes, obytes, ctx->stream);
+    if (rc != HG_OK) { (void)hipStreamSynchronize(ctx->stream); delete H; return rc; }
+    *handle = H;
+    return HG_OK;
+}
+int hg_entropy_decode_inplace_finish(hg_ctx *ctx, hg_entropy_inplace *H, int32_t *status) {
+    if (!ctx || !H) return HG_EINVAL;
+    const bool ok = hipStreamSynchronize(ctx->stream) == hipSuccess && collect_plan_status(ctx, H->P, H->st, ctx->stream);
+    int rc = ok ? HG_OK : HG_ELAUNCH;
+    for (size_t i = 0; i < H->st.size(); i++) { if (status) status[i] = H->st[i]; if (H->st[i] != 0 && rc == HG_OK) rc = HG_EBLOCK; }
+    delete H;
+    return rc;
+}
+
+// ================================================================================================
 // tok3 (name tokeniser, CRAM block method 8) decode: hg_tok3_decode_host replaces tok3_decode_names (call site
 // cram/cram_io.c:1735-1749).  The container walk (a few bytes per token stream) is done here; every token stream
 // is a complete Nx16 / range-coder stream and joins ONE entropy plan for the whole batch; the names are then

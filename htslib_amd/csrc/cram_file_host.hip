@@ -92,6 +92,10 @@ template <class W> std::vector<size_t> cut_ranges(size_t n, size_t parts, W weig
 int hg_cram_decode_bam_devsrc(hg_ctx *ctx, size_t nslices, const hg_cram_slice_blocks *slices, int major_version, int nref, const char *const *rg_names,
                               int nrg, uint64_t total_bases, uint8_t *bam_out, size_t bam_cap, uint64_t *rec_off, uint64_t *rec_bam_off, uint64_t *bam_bytes,
                               int32_t *status, const char *name_prefix, const uint8_t *dev_lo, const uint8_t *dev_hi, void *wait_ev);     // cram_records.hip
+struct hg_entropy_inplace;                                                                                              // cram_entropy_host.hip
+int hg_entropy_decode_inplace_launch(hg_ctx *ctx, size_t n, const uint8_t *codec, const uint8_t *const *in, const uint32_t *in_len, const uint64_t *in_off,
+                                     const uint32_t *out_len, const uint64_t *out_off, uint64_t in_bytes, uint64_t obytes, hg_entropy_inplace **handle);
+int hg_entropy_decode_inplace_finish(hg_ctx *ctx, hg_entropy_inplace *H, int32_t *status);
 
 namespace {
 constexpr int NOT_FUSABLE = 0x7f01;       // internal: this run goes through the host-buffer composition instead
@@ -174,8 +178,11 @@ struct BlocksPending {
     hg_ctx *A = nullptr; hipEvent_t done = nullptr; int major = 3;
     uint8_t *res = nullptr;                                              // PAGE-LOCKED: a read-back into pageable memory does not return before the kernels ahead of it have finished
     size_t ng = 0, nr = 0, nb = 0, r_gz = 0, r_rs = 0, r_crc = 0;
+    hg_entropy_inplace *ent = nullptr; size_t nent = 0;                  // the rANS Nx16 / range-coder streams of the run (cram_entropy_host.hip)
+    std::vector<std::vector<uint8_t>> tok_out; int tok_rc = HG_OK;        // tok3 name blocks: decoded through the host entry point (small), handed to the record decoder as host blocks
     ~BlocksPending() {
-        if (A && (done || res)) (void)hipStreamSynchronize(A->stream);
+        if (A && (done || res || ent)) (void)hipStreamSynchronize(A->stream);
+        if (ent) (void)hg_entropy_decode_inplace_finish(A, ent, nullptr);
         if (done) (void)hipEventDestroy(done);
         if (res) (void)hipHostFree(res);
     }
@@ -183,6 +190,10 @@ struct BlocksPending {
 int blocks_verify(BlocksPending &P, const Walk &W) {
     if (!P.A || !P.res) return HG_EINVAL;
     if (hipStreamSynchronize(P.A->stream) != hipSuccess) return HG_ELAUNCH;
+    int rc = HG_OK;
+    if (P.ent) { rc = hg_entropy_decode_inplace_finish(P.A, P.ent, nullptr); P.ent = nullptr; }
+    if (rc != HG_OK) return rc;
+    if (P.tok_rc != HG_OK) return P.tok_rc;
     const int32_t *st_gz = (const int32_t *)(P.res + P.r_gz), *st_rs = (const int32_t *)(P.res + P.r_rs); const uint32_t *crc = (const uint32_t *)(P.res + P.r_crc);
     for (size_t g = 0; g < P.ng; g++) if (st_gz[g] != 0) return HG_EBLOCK;
     for (size_t r = 0; r < P.nr; r++) if (st_rs[r] != 0) return HG_EBLOCK;
@@ -199,37 +210,46 @@ int blocks_on_device(hg_ctx *ctx, int major, const Walk &W, std::vector<const ui
     if (!nb) return NOT_FUSABLE;
     const uint8_t *lo = nullptr, *hi = nullptr;
     uint64_t csum = 0;
-    size_t ng = 0, nr = 0;
+    size_t ng = 0, nr = 0, ne = 0, nt = 0, nraw = 0;
     for (const Blk &b : blocks) {
         const bool header = b.ctype <= 3;
-        if (header ? b.method != HG_CRAM_RAW : (b.method != HG_CRAM_RAW && b.method != HG_CRAM_GZIP && b.method != HG_CRAM_RANS4x8)) return NOT_FUSABLE;
+        if (header ? b.method != HG_CRAM_RAW : (b.method != HG_CRAM_RAW && b.method != HG_CRAM_GZIP && b.method != HG_CRAM_RANS4x8 && b.method != HG_CRAM_RANSNx16 &&
+                                                 b.method != HG_CRAM_ARITH && b.method != HG_CRAM_TOK3)) return NOT_FUSABLE;     // fqzcomp, bzip2, lzma, a compressed header block
         if (b.method == HG_CRAM_RAW && b.csz != b.usz) return HG_EBLOCK;
         if (!lo || b.data < lo) lo = b.data;
         if (!hi || b.data + b.csz > hi) hi = b.data + b.csz;
         csum += b.csz;
-        if (b.usz && b.method == HG_CRAM_GZIP) ng++;
-        if (b.usz && b.method == HG_CRAM_RANS4x8) nr++;
+        if (!b.usz || header) continue;
+        if (b.method == HG_CRAM_GZIP) ng++;
+        else if (b.method == HG_CRAM_RANS4x8) nr++;
+        else if (b.method == HG_CRAM_RANSNx16 || b.method == HG_CRAM_ARITH) ne++;
+        else if (b.method == HG_CRAM_TOK3) nt++;
+        else nraw++;
     }
     const uint64_t span = (uint64_t)(hi - lo);
     if (span > 0xe0000000ull || span > 2 * csum + (64u << 20)) return NOT_FUSABLE;
     if (!ctx->sub[3] && hg_init(ctx->device, &ctx->sub[3]) != HG_OK) return HG_ENOMEM;
     hg_ctx *A = ctx->sub[3];
     hg::CtxGuard ga(A); if (ga.rc) return ga.rc;
-    // ---- layout: [ uploaded image | decoded image ]; descriptor and result tables in two further buffers
+    // ---- layout: the uploaded image in scratch slot 0, the decoded image at the front of slot 1 (the entropy plans' work area behind it); tables and results further back
     const uint64_t raw_bytes = (span + 255u) & ~255ull;
     std::vector<uint64_t> out_off(nb, 0);
     uint64_t dec_bytes = 0, scratch_words = 0;
-    for (size_t k = 0; k < nb; k++) if (blocks[k].usz && blocks[k].method != HG_CRAM_RAW) { out_off[k] = dec_bytes; dec_bytes += ((uint64_t)blocks[k].usz + 15u) & ~15ull; }
-    if (raw_bytes + dec_bytes > 0xfffffff0ull * 4) return NOT_FUSABLE;
-    std::vector<hg_bgzf_desc> gz(ng); std::vector<hg_stream_desc> rs(nr); std::vector<size_t> gz_of(ng), rs_of(nr);
+    for (size_t k = 0; k < nb; k++) if (blocks[k].usz && blocks[k].ctype > 3 && blocks[k].method != HG_CRAM_TOK3) { out_off[k] = dec_bytes; dec_bytes += ((uint64_t)blocks[k].usz + 15u) & ~15ull; }
+    dec_bytes = (dec_bytes + 255u) & ~255ull;
+    if (raw_bytes > 0xfffffff0ull || dec_bytes > 0xfffffff0ull * 2) return NOT_FUSABLE;
+    std::vector<hg_bgzf_desc> gz(ng); std::vector<hg_stream_desc> rs(nr);
     std::vector<uint64_t> c_off(nb); std::vector<uint32_t> c_len(nb);
+    std::vector<uint8_t> e_codec(ne); std::vector<const uint8_t *> e_in(ne); std::vector<uint32_t> e_il(ne), e_ol(ne); std::vector<uint64_t> e_io(ne), e_oo(ne);
+    std::vector<uint64_t> w_src(nraw), w_dst(nraw); std::vector<uint32_t> w_len(nraw);
+    std::vector<size_t> tok_of; tok_of.reserve(nt);
     {
-        size_t g = 0, r = 0;
+        size_t g = 0, r = 0, e = 0, w = 0;
         for (size_t k = 0; k < nb; k++) {
             const Blk &b = blocks[k];
             c_off[k] = (uint64_t)(b.data - lo); c_len[k] = b.csz;
-            if (!b.usz) continue;
-            if (b.method == HG_CRAM_GZIP) { gz[g] = hg_bgzf_desc{c_off[k], out_off[k], b.csz, b.usz}; gz_of[g++] = k; }
+            if (!b.usz || b.ctype <= 3) continue;
+            if (b.method == HG_CRAM_GZIP) gz[g++] = hg_bgzf_desc{c_off[k], out_off[k], b.csz, b.usz};
             else if (b.method == HG_CRAM_RANS4x8) {
                 uint32_t usz = 0;
                 if (b.csz >= 9) usz = (uint32_t)b.data[5] | (uint32_t)b.data[6] << 8 | (uint32_t)b.data[7] << 16 | (uint32_t)b.data[8] << 24;
@@ -238,58 +258,70 @@ int blocks_on_device(hg_ctx *ctx, int major, const Walk &W, std::vector<const ui
                 rs[r].in_off = c_off[k]; rs[r].in_len = b.csz; rs[r].out_off = out_off[k]; rs[r].out_len = usz; rs[r].scratch_off = (uint32_t)scratch_words;
                 scratch_words += HG_RANS4X8_SCRATCH_WORDS(b.csz);
                 if (scratch_words > 0xffffffffull) return NOT_FUSABLE;
-                rs_of[r++] = k;
-            }
+                r++;
+            } else if (b.method == HG_CRAM_RANSNx16 || b.method == HG_CRAM_ARITH) {
+                e_codec[e] = b.method == HG_CRAM_ARITH; e_in[e] = b.data; e_il[e] = b.csz; e_ol[e] = b.usz; e_io[e] = c_off[k]; e_oo[e] = out_off[k]; e++;
+            } else if (b.method == HG_CRAM_TOK3) tok_of.push_back(k);
+            else { w_src[w] = c_off[k]; w_dst[w] = out_off[k]; w_len[w] = b.usz; w++; }
         }
     }
     // Longest streams first: a stream is one chain on one lane group and a launch lasts as long as its longest group, so the groups start with one long
     // stream each (the quality blocks) and pick up the short ones behind them -- the kernels hand out streams in descriptor order.
-    {
-        std::vector<size_t> ord(nr);
-        for (size_t r = 0; r < nr; r++) ord[r] = r;
-        std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return rs[a].in_len > rs[b].in_len; });
-        std::vector<hg_stream_desc> rs2(nr); std::vector<size_t> of2(nr);
-        for (size_t r = 0; r < nr; r++) { rs2[r] = rs[ord[r]]; of2[r] = rs_of[ord[r]]; }
-        rs.swap(rs2); rs_of.swap(of2);
-        std::vector<size_t> og(ng);
-        for (size_t g = 0; g < ng; g++) og[g] = g;
-        std::stable_sort(og.begin(), og.end(), [&](size_t a, size_t b) { return gz[a].clen > gz[b].clen; });
-        std::vector<hg_bgzf_desc> gz2(ng); std::vector<size_t> gof2(ng);
-        for (size_t g = 0; g < ng; g++) { gz2[g] = gz[og[g]]; gof2[g] = gz_of[og[g]]; }
-        gz.swap(gz2); gz_of.swap(gof2);
-    }
+    std::stable_sort(rs.begin(), rs.end(), [](const hg_stream_desc &a, const hg_stream_desc &b) { return a.in_len > b.in_len; });
+    std::stable_sort(gz.begin(), gz.end(), [](const hg_bgzf_desc &a, const hg_bgzf_desc &b) { return a.clen > b.clen; });
     auto up64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
     const size_t o_gz = 0, o_rs = o_gz + up64(ng * sizeof(hg_bgzf_desc)), o_coff = o_rs + up64(nr * sizeof(hg_stream_desc)), o_clen = o_coff + up64(nb * 8), tab_bytes = o_clen + up64(nb * 4);
     const size_t r_gz = 0, r_rs = r_gz + up64(ng * 4), r_crc = r_rs + up64(nr * 4), res_bytes = r_crc + up64(nb * 4);
     int rc;
-    if ((rc = hg::ensure_scratch(A, 0, (size_t)(raw_bytes + dec_bytes) + 256)) || (rc = hg::ensure_scratch(A, 2, tab_bytes + 64)) || (rc = hg::ensure_scratch(A, 3, res_bytes + 64)) ||
-        (rc = hg::ensure_scratch(A, 6, (size_t)scratch_words * 4 + 64))) return rc;
-    uint8_t *d_img = (uint8_t *)A->d_scratch[0], *d_dec = d_img + raw_bytes, *d_tab = (uint8_t *)A->d_scratch[2], *d_res = (uint8_t *)A->d_scratch[3];
+    if ((rc = hg::ensure_scratch(A, 0, (size_t)raw_bytes + 256)) || (rc = hg::ensure_scratch(A, 8, tab_bytes + 64)) || (rc = hg::ensure_scratch(A, 9, res_bytes + 64)) ||
+        (rc = hg::ensure_scratch(A, 10, (size_t)scratch_words * 4 + 64))) return rc;
+    uint8_t *d_img = (uint8_t *)A->d_scratch[0], *d_tab = (uint8_t *)A->d_scratch[8], *d_res = (uint8_t *)A->d_scratch[9];
     hipStream_t s = A->stream;
     std::vector<uint8_t> tab(tab_bytes, 0);
     if (ng) memcpy(tab.data() + o_gz, gz.data(), ng * sizeof(hg_bgzf_desc));
     if (nr) memcpy(tab.data() + o_rs, rs.data(), nr * sizeof(hg_stream_desc));
     memcpy(tab.data() + o_coff, c_off.data(), nb * 8); memcpy(tab.data() + o_clen, c_len.data(), nb * 4);
     if (hipMemcpyAsync(d_img, lo, (size_t)span, hipMemcpyHostToDevice, s) != hipSuccess || hipMemcpyAsync(d_tab, tab.data(), tab_bytes, hipMemcpyHostToDevice, s) != hipSuccess) return HG_ELAUNCH;
-    // gzip members on the side stream, rANS + the CRCs on this one
+    P.A = A; P.major = major; P.ng = ng; P.nr = nr; P.nb = nb; P.r_gz = r_gz; P.r_rs = r_rs; P.r_crc = r_crc;
+    // the CRAM 3.1 entropy coders first: their plan sizes slot 1 (decoded image + work area), the other decoders then write into the same image
+    if (ne) {
+        if ((rc = hg_entropy_decode_inplace_launch(A, ne, e_codec.data(), e_in.data(), e_il.data(), e_io.data(), e_ol.data(), e_oo.data(), raw_bytes, dec_bytes, &P.ent))) { (void)hipStreamSynchronize(s); return rc; }
+        P.nent = ne;
+    } else if ((rc = hg::ensure_scratch(A, 1, (size_t)dec_bytes + 256))) { (void)hipStreamSynchronize(s); return rc; }
+    uint8_t *d_dec = (uint8_t *)A->d_scratch[1];
+    // gzip members on the side stream, rANS 4x8 + the CRCs + the RAW blocks on this one
     if (ng) {
         hipStream_t s2 = hg::fork_side(A, s);
         rc = hg::launch_bgzf_inflate(A, d_img, (size_t)span, (const hg_bgzf_desc *)(d_tab + o_gz), ng, d_dec, (size_t)dec_bytes, (int32_t *)(d_res + r_gz), s2, 1);
         hg::join_side(A, s);
         if (rc) { (void)hipStreamSynchronize(s); return rc; }
     }
-    if (nr && (rc = hg::launch_rans4x8_decode(A, d_img, (const hg_stream_desc *)(d_tab + o_rs), nr, d_dec, (int32_t *)(d_res + r_rs), (uint32_t *)A->d_scratch[6], s))) { (void)hipStreamSynchronize(s); return rc; }
+    if (nr && (rc = hg::launch_rans4x8_decode(A, d_img, (const hg_stream_desc *)(d_tab + o_rs), nr, d_dec, (int32_t *)(d_res + r_rs), (uint32_t *)A->d_scratch[10], s))) { (void)hipStreamSynchronize(s); return rc; }
     if (major >= 3 && (rc = hg::launch_crc32(A, d_img, (const uint64_t *)(d_tab + o_coff), (const uint32_t *)(d_tab + o_clen), nb, (uint32_t *)(d_res + r_crc), s))) { (void)hipStreamSynchronize(s); return rc; }
-    P.A = A; P.major = major; P.ng = ng; P.nr = nr; P.nb = nb; P.r_gz = r_gz; P.r_rs = r_rs; P.r_crc = r_crc;
+    if (nraw && (rc = hg::stage_gather_dev(A, d_img, w_src.data(), w_len.data(), d_dec, w_dst.data(), nraw, s))) { (void)hipStreamSynchronize(s); return rc; }
     if (hipHostMalloc((void **)&P.res, res_bytes + 64, hipHostMallocDefault) != hipSuccess) { P.res = nullptr; (void)hipStreamSynchronize(s); return HG_ENOMEM; }
     if (hipEventCreateWithFlags(&P.done, hipEventDisableTiming) != hipSuccess) { P.done = nullptr; (void)hipStreamSynchronize(s); return HG_ELAUNCH; }
     if (hipMemcpyAsync(P.res, d_res, res_bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(P.done, s) != hipSuccess) { (void)hipStreamSynchronize(s); return HG_ELAUNCH; }
-    bptr.assign(nb, nullptr);
-    for (size_t k = 0; k < nb; k++) {
-        const Blk &b = blocks[k];
-        bptr[k] = b.ctype <= 3 ? b.data : b.method == HG_CRAM_RAW ? d_img + c_off[k] : d_dec + out_off[k];
+    // the name blocks of a CRAM 3.1 run (method 8), beside all of that on their own family context: they come back as host blocks (a few hundred KB per slice)
+    if (nt) {
+        if (!ctx->sub[2] && hg_init(ctx->device, &ctx->sub[2]) != HG_OK) return HG_ENOMEM;
+        P.tok_out.resize(nt);
+        std::vector<const uint8_t *> ti(nt); std::vector<uint32_t> til(nt), tol(nt); std::vector<uint8_t *> to(nt); std::vector<int32_t> tst(nt, 0);
+        for (size_t q = 0; q < nt; q++) { const Blk &b = blocks[tok_of[q]]; P.tok_out[q].resize(b.usz ? b.usz : 1); ti[q] = b.data; til[q] = b.csz; tol[q] = b.usz; to[q] = P.tok_out[q].data(); }
+        const int trc = hg_tok3_decode_host(ctx->sub[2], ti.data(), til.data(), nt, to.data(), tol.data(), tst.data());
+        P.tok_rc = trc == HG_OK ? HG_OK : (trc == HG_EBLOCK ? HG_EBLOCK : trc);
     }
-    dev_lo = d_img; dev_hi = d_img + raw_bytes + dec_bytes + 256;
+    bptr.assign(nb, nullptr);
+    {
+        size_t q = 0;
+        for (size_t k = 0; k < nb; k++) {
+            const Blk &b = blocks[k];
+            if (b.ctype <= 3) bptr[k] = b.data;
+            else if (b.usz && b.method == HG_CRAM_TOK3) bptr[k] = P.tok_out[q++].data();
+            else bptr[k] = d_dec + out_off[k];
+        }
+    }
+    dev_lo = d_dec; dev_hi = d_dec + dec_bytes + 256;
     return HG_OK;
 }
 
@@ -463,7 +495,7 @@ int slices_to_bam(hg_ctx *ctx, const std::vector<hg_ctx *> &ctxs, int major, Wal
         hgr::SliceHeader sh;
         const uint8_t *hd = dec[s.hdr];
         if (hgr::parse_slice_header(hd, blocks[s.hdr].usz, major, sh)) return HG_EINVAL;
-        if (dev_lo && (sh.ref_base_id >= 0 || (sh.ref_seq_id == -2 && get_ref))) return NOT_FUSABLE;      // an embedded reference is digested, the RI series of a multi-reference slice read, on the host
+        if (dev_lo && sh.ref_base_id >= 0) return NOT_FUSABLE;                // an embedded reference is digested on the host
         shs[i] = sh;
         s.embedded = sh.ref_base_id;
         s.ref_seq_id = sh.ref_seq_id; s.start = sh.ref_seq_start; s.span = sh.ref_seq_span;
@@ -496,7 +528,16 @@ int slices_to_bam(hg_ctx *ctx, const std::vector<hg_ctx *> &ctxs, int major, Wal
                         if (cd.kind == hgr::E_EXTERNAL && cd.a >= 0 && (size_t)cd.a < ph.slot_id.size()) {
                             const int32_t cid = ph.slot_id[(size_t)cd.a];
                             for (size_t k = 0; k < ids[i].size(); k++) if (ids[i][k] == cid) {
-                                hgr::Cursor rc{ptr[i][k], ptr[i][k] + len[i][k]};
+                                const uint8_t *ri = ptr[i][k];
+                                std::vector<uint8_t> fetched;
+                                if (dev_lo && ri >= dev_lo && ri < dev_hi) {
+                                    // the block is on the device (fused run): its few KB come over once its decoder has finished -- a multi-reference slice costs the run the overlap, not the fused path
+                                    fetched.resize(len[i][k] ? len[i][k] : 1);
+                                    if ((wait_ev && hipEventSynchronize((hipEvent_t)wait_ev) != hipSuccess) ||
+                                        (len[i][k] && hipMemcpy(fetched.data(), ri, len[i][k], hipMemcpyDeviceToHost) != hipSuccess)) return HG_ELAUNCH;
+                                    ri = fetched.data();
+                                }
+                                hgr::Cursor rc{ri, ri + len[i][k]};
                                 while (rc.p < rc.end && !rc.bad) need(rc.itf8());
                                 known = true; break;
                             }
