@@ -375,3 +375,20 @@ def test_reader_and_writer_in_one_process_transcode_cram(fx):
     assert canon(view(VIEW_REF, ["-D", "tc.cram"], fx)) == want
     view(VIEW_GPU, ["-@4", "-D", "-b", "in.cram"], fx, "tc.bam")
     assert canon(view(VIEW_REF, ["tc.bam"], fx)) == want
+
+
+def test_whole_slice_reader_takes_cram31_and_multi_reference_slices_through_the_fused_run_decoder(fx):
+    """CRAM 3.1 (the reference's default output version): rANS Nx16 / tok3 blocks are decoded inside the fused run decoder (hg_entropy_decode_inplace_*, tok3 beside it), and a
+    multi-reference slice (its RI block fetched from the device) no longer sends the run through the host-buffer composition.  Checker: the file read back through the
+    CPU restatements of the 3.1 codecs (ORC_STUB_CODECS31=1) and through the reference's decoder on our per-block layer (HTS_GPU_CRAM_SLICE=0)."""
+    e = dict(_env(fx), HTS_GPU_STATS="1")
+    e31 = dict(_env(fx), ORC_STUB_CODECS31="1")
+    for sam, ref, o in (("ce#1000.sam", "ce.fa", ["-o", "seqs_per_slice=100"]), ("ce#5b.sam", "ce.fa", ["-o", "multi_seq_per_slice=1"])):
+        view(VIEW_REF, ["-t", ref, "-S", "-C", "-o", "VERSION=3.1", *o, sam], fx, "v31.cram", env=e31)
+        want = view(VIEW_REF, ["-D", "v31.cram"], fx, env=e31)
+        assert open(os.path.join(fx, "v31.cram"), "rb").read(6) == b"CRAM\x03\x01"
+        p = subprocess.run([VIEW_GPU, "-D", "v31.cram"], cwd=fx, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=600)
+        assert p.returncode == 0 and p.stdout == want, (sam, p.stderr.decode("latin1")[-800:])
+        st = _reader_stats(p.stderr)
+        assert any("cram run (fused):" in ln and "(rc 0)" in ln for ln in st) and not any("cram run:" in ln for ln in st), (sam, st)
+        assert view(VIEW_GPU, ["-D", "v31.cram"], fx, env=dict(_env(fx), HTS_GPU_CRAM_SLICE="0")) == want
