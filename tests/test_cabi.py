@@ -154,3 +154,23 @@ def test_front_library_exports_every_function_its_headers_declare(built):
         assert want in names, want
     missing = [n for n in sorted(names) if not hasattr(L, n)]
     assert not missing, missing
+
+
+def test_libhts_gpu_record_layer_symbols():
+    """oracle/_ref/libhts_gpu.so (the drop-in linked into the reference's libhts): the record-level entry points are OURS (cram_record_front.c) and the reference's bodies
+    stay reachable under hg_ref_* for the fall-back -- the rename recipe of oracle/Makefile (objcopy --redefine-sym) and INTEGRATION.md A4.  No GPU needed: symbols only."""
+    import os
+    import subprocess
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libhts_gpu.so")
+    if not os.path.exists(so):
+        import pytest
+        pytest.skip("oracle/_ref/libhts_gpu.so not built (needs /root/reference)")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], stdout=subprocess.PIPE, check=True).stdout.decode()
+    defined = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    for name in ("cram_get_bam_seq", "cram_put_bam_seq", "cram_seek", "cram_flush", "cram_close"):
+        assert name in defined and "hg_ref_" + name in defined, name
+    # ... and they resolve into our object, next to the block layer's accessor it uses (not into the reference's cram_decode.o / cram_encode.o)
+    addr = {ln.split()[-1]: int(ln.split()[0], 16) for ln in out.splitlines() if len(ln.split()) == 3}
+    ours = sorted(addr[n] for n in ("cram_get_bam_seq", "cram_put_bam_seq", "cram_seek", "cram_flush", "cram_close"))
+    assert ours[-1] - ours[0] < 0x10000, [hex(a) for a in ours]              # one small translation unit
+    assert not (ours[0] <= addr["hg_ref_cram_get_bam_seq"] <= ours[-1])
