@@ -179,7 +179,7 @@ struct BlocksPending {
     uint8_t *res = nullptr;                                              // PAGE-LOCKED: a read-back into pageable memory does not return before the kernels ahead of it have finished
     size_t ng = 0, nr = 0, nb = 0, r_gz = 0, r_rs = 0, r_crc = 0;
     hg_entropy_inplace *ent = nullptr; size_t nent = 0;                  // the rANS Nx16 / range-coder streams of the run (cram_entropy_host.hip)
-    std::vector<std::vector<uint8_t>> tok_out; int tok_rc = HG_OK;        // tok3 name blocks: decoded through the host entry point (small), handed to the record decoder as host blocks
+    std::vector<std::vector<uint8_t>> tok_out; int tok_rc = HG_OK;        // tok3 / fqzcomp / bzip2 / lzma blocks: decoded through the host entry point, handed to the record decoder as host blocks
     ~BlocksPending() {
         if (A && (done || res || ent)) (void)hipStreamSynchronize(A->stream);
         if (ent) (void)hg_entropy_decode_inplace_finish(A, ent, nullptr);
@@ -213,8 +213,7 @@ int blocks_on_device(hg_ctx *ctx, int major, const Walk &W, std::vector<const ui
     size_t ng = 0, nr = 0, ne = 0, nt = 0, nraw = 0;
     for (const Blk &b : blocks) {
         const bool header = b.ctype <= 3;
-        if (header ? b.method != HG_CRAM_RAW : (b.method != HG_CRAM_RAW && b.method != HG_CRAM_GZIP && b.method != HG_CRAM_RANS4x8 && b.method != HG_CRAM_RANSNx16 &&
-                                                 b.method != HG_CRAM_ARITH && b.method != HG_CRAM_TOK3)) return NOT_FUSABLE;     // fqzcomp, bzip2, lzma, a compressed header block
+        if (header ? b.method != HG_CRAM_RAW : (b.method < 0 || b.method > HG_CRAM_TOK3)) return NOT_FUSABLE;                     // a compressed header block, an unknown method
         if (b.method == HG_CRAM_RAW && b.csz != b.usz) return HG_EBLOCK;
         if (!lo || b.data < lo) lo = b.data;
         if (!hi || b.data + b.csz > hi) hi = b.data + b.csz;
@@ -223,8 +222,8 @@ int blocks_on_device(hg_ctx *ctx, int major, const Walk &W, std::vector<const ui
         if (b.method == HG_CRAM_GZIP) ng++;
         else if (b.method == HG_CRAM_RANS4x8) nr++;
         else if (b.method == HG_CRAM_RANSNx16 || b.method == HG_CRAM_ARITH) ne++;
-        else if (b.method == HG_CRAM_TOK3) nt++;
-        else nraw++;
+        else if (b.method == HG_CRAM_RAW) nraw++;
+        else nt++;                                                       // tok3, fqzcomp, bzip2, lzma: through the host entry point (below)
     }
     const uint64_t span = (uint64_t)(hi - lo);
     if (span > 0xe0000000ull || span > 2 * csum + (64u << 20)) return NOT_FUSABLE;
@@ -235,7 +234,8 @@ int blocks_on_device(hg_ctx *ctx, int major, const Walk &W, std::vector<const ui
     const uint64_t raw_bytes = (span + 255u) & ~255ull;
     std::vector<uint64_t> out_off(nb, 0);
     uint64_t dec_bytes = 0, scratch_words = 0;
-    for (size_t k = 0; k < nb; k++) if (blocks[k].usz && blocks[k].ctype > 3 && blocks[k].method != HG_CRAM_TOK3) { out_off[k] = dec_bytes; dec_bytes += ((uint64_t)blocks[k].usz + 15u) & ~15ull; }
+    auto on_host = [](int32_t m) { return m == HG_CRAM_TOK3 || m == HG_CRAM_FQZ || m == HG_CRAM_BZIP2 || m == HG_CRAM_LZMA; };
+    for (size_t k = 0; k < nb; k++) if (blocks[k].usz && blocks[k].ctype > 3 && !on_host(blocks[k].method)) { out_off[k] = dec_bytes; dec_bytes += ((uint64_t)blocks[k].usz + 15u) & ~15ull; }
     dec_bytes = (dec_bytes + 255u) & ~255ull;
     if (raw_bytes > 0xfffffff0ull || dec_bytes > 0xfffffff0ull * 2) return NOT_FUSABLE;
     std::vector<hg_bgzf_desc> gz(ng); std::vector<hg_stream_desc> rs(nr);
@@ -261,7 +261,7 @@ int blocks_on_device(hg_ctx *ctx, int major, const Walk &W, std::vector<const ui
                 r++;
             } else if (b.method == HG_CRAM_RANSNx16 || b.method == HG_CRAM_ARITH) {
                 e_codec[e] = b.method == HG_CRAM_ARITH; e_in[e] = b.data; e_il[e] = b.csz; e_ol[e] = b.usz; e_io[e] = c_off[k]; e_oo[e] = out_off[k]; e++;
-            } else if (b.method == HG_CRAM_TOK3) tok_of.push_back(k);
+            } else if (on_host(b.method)) tok_of.push_back(k);
             else { w_src[w] = c_off[k]; w_dst[w] = out_off[k]; w_len[w] = b.usz; w++; }
         }
     }
@@ -302,14 +302,14 @@ int blocks_on_device(hg_ctx *ctx, int major, const Walk &W, std::vector<const ui
     if (hipHostMalloc((void **)&P.res, res_bytes + 64, hipHostMallocDefault) != hipSuccess) { P.res = nullptr; (void)hipStreamSynchronize(s); return HG_ENOMEM; }
     if (hipEventCreateWithFlags(&P.done, hipEventDisableTiming) != hipSuccess) { P.done = nullptr; (void)hipStreamSynchronize(s); return HG_ELAUNCH; }
     if (hipMemcpyAsync(P.res, d_res, res_bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(P.done, s) != hipSuccess) { (void)hipStreamSynchronize(s); return HG_ELAUNCH; }
-    // the name blocks of a CRAM 3.1 run (method 8), beside all of that on their own family context: they come back as host blocks (a few hundred KB per slice)
+    // The blocks whose decoders have no in-place form -- the name tokeniser's (method 8: ~60 token streams per block, a plan of its own), fqzcomp's, and the host
+    // libraries' bzip2 / lzma -- go through the ordinary host entry point, beside all of the above on their own family contexts, and reach the record decoder as host
+    // blocks: a few hundred KB of names per slice, or the qualities of an fqzcomp file (whose decoder, not the round trip, is what such a file waits for).
     if (nt) {
-        if (!ctx->sub[2] && hg_init(ctx->device, &ctx->sub[2]) != HG_OK) return HG_ENOMEM;
         P.tok_out.resize(nt);
-        std::vector<const uint8_t *> ti(nt); std::vector<uint32_t> til(nt), tol(nt); std::vector<uint8_t *> to(nt); std::vector<int32_t> tst(nt, 0);
-        for (size_t q = 0; q < nt; q++) { const Blk &b = blocks[tok_of[q]]; P.tok_out[q].resize(b.usz ? b.usz : 1); ti[q] = b.data; til[q] = b.csz; tol[q] = b.usz; to[q] = P.tok_out[q].data(); }
-        const int trc = hg_tok3_decode_host(ctx->sub[2], ti.data(), til.data(), nt, to.data(), tol.data(), tst.data());
-        P.tok_rc = trc == HG_OK ? HG_OK : (trc == HG_EBLOCK ? HG_EBLOCK : trc);
+        std::vector<int32_t> tm(nt); std::vector<const uint8_t *> ti(nt); std::vector<uint32_t> til(nt), tol(nt); std::vector<uint8_t *> to(nt); std::vector<int32_t> tst(nt, 0);
+        for (size_t q = 0; q < nt; q++) { const Blk &b = blocks[tok_of[q]]; P.tok_out[q].resize(b.usz ? b.usz : 1); tm[q] = b.method; ti[q] = b.data; til[q] = b.csz; tol[q] = b.usz; to[q] = P.tok_out[q].data(); }
+        P.tok_rc = hg_cram_uncompress_blocks_host(ctx, nt, tm.data(), ti.data(), til.data(), to.data(), tol.data(), tst.data());
     }
     bptr.assign(nb, nullptr);
     {
@@ -317,7 +317,7 @@ int blocks_on_device(hg_ctx *ctx, int major, const Walk &W, std::vector<const ui
         for (size_t k = 0; k < nb; k++) {
             const Blk &b = blocks[k];
             if (b.ctype <= 3) bptr[k] = b.data;
-            else if (b.usz && b.method == HG_CRAM_TOK3) bptr[k] = P.tok_out[q++].data();
+            else if (b.usz && on_host(b.method)) bptr[k] = P.tok_out[q++].data();
             else bptr[k] = d_dec + out_off[k];
         }
     }
