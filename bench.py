@@ -1154,6 +1154,7 @@ def libhts_view_cram(run: Run, gpu: str, ref: str, ref_threads, copies: int = 64
       cram_encode       = view -@T -C -o version=3.0 in.bam  (ours: cram_put_bam_seq = the whole-slice writer, runs of records through the device record encoder + block
                                                               auto-tuner; stock: bam_read1 + cram_encode_slice + cram_compress_block3 on the pool; to /dev/null)
       cram_encode_blocks = the same with HTS_GPU_CRAM_SLICE=0 (the reference's cram_encode_slice on our cram_compress_block2)
+      cram31_decode / cram31_encode = the same on CRAM 3.1, the reference's default version (stock on oracle/'s scalar 3.1 codecs: a floor)
       cram_decode_large / cram_to_bam_large / cram_encode_large = view -B / view -b / view -C on a file of 4 x the slices (10 240 000 records): what a run of 1 024 slices buys, and `samtools view -b in.cram`
     on 256 slices (2 560 000 records) of the record baselines' workload, at the writer's default level (gzip + rANS 4x8).  Whole-process wall clock, best of 2.
     A run of the reader takes 0.2-0.4 s whatever it holds (one 1.5 MB quality stream through the 4-way rANS decoder is one chain on one lane group, ~150 ms), a
@@ -1174,7 +1175,9 @@ def libhts_view_cram(run: Run, gpu: str, ref: str, ref_threads, copies: int = 64
         def one(exe, threads, mode, W=None, cram_=None, plain_=None, reps=2):
             W = W or w; cram_ = cram_ or cram; plain_ = plain_ or plain
             env = dict(os.environ, HTS_GPU_CRAM_SLICE="0") if mode in ("cram_decode_blocks", "cram_encode_blocks") else None
-            cmd = ([exe, "-@", str(threads), "-B", "-i", "reference=" + W.fa, cram_] if mode in ("cram_decode", "cram_decode_blocks") else
+            if mode.startswith("cram31") and exe == ref: env = dict(os.environ, ORC_STUB_CODECS31="1")     # the reference's 3.1 codecs here: oracle/'s scalar restatements (htscodecs absent)
+            cmd = ([exe, "-@", str(threads), "-B", "-i", "reference=" + W.fa, cram_] if mode in ("cram_decode", "cram_decode_blocks", "cram31_decode") else
+                   [exe, "-@", str(threads), "-C", "-t", W.fa, "-p", "/dev/null", W.bam] if mode == "cram31_encode" else
                    [exe, "-@", str(threads), "-b", "-i", "reference=" + W.fa, "-p", os.path.join(W.dir, "out.bam"), cram_] if mode == "cram_to_bam" else
                    [exe, "-@", str(threads), "-C", "-o", "version=3.0", "-t", W.fa, "-p", "/dev/null", W.bam])
             best = None
@@ -1202,6 +1205,14 @@ def libhts_view_cram(run: Run, gpu: str, ref: str, ref_threads, copies: int = 64
         out["cram_decode_blocks"] = both("cram_decode_blocks", (64,), reps=1)
         out["cram_encode"] = both("cram_encode", (4,))
         out["cram_encode_blocks"] = both("cram_encode_blocks", (64,), reps=1)
+        # CRAM 3.1, the reference's default output version (rANS Nx16 + tok3): our writer's file, read by both; written by both.  The stock side decodes / encodes with the
+        # scalar restatements under oracle/ (ORC_STUB_CODECS31=1) -- real htscodecs has SIMD rANS, so its figures are a floor, not the reference's speed
+        c31 = os.path.join(w.dir, "ours31.cram")
+        r = subprocess.run([gpu, "-@", "4", "-C", "-t", w.fa, "-p", c31, w.bam], capture_output=True)
+        if r.returncode == 0:
+            out["cram31_decode"] = both("cram31_decode", (4,), (64,), cram_=c31, reps=1)
+            out["cram31_encode"] = both("cram31_encode", (4,), (64,), reps=1)
+        else: out["cram31_error"] = r.stderr.decode("latin1")[-200:]
         w.close()
         # the large file: four times the slices (one run of 256 + one of 768 slices in the reader)
         w = RefCramWorkload(eng, base, 4 * copies)
@@ -1659,13 +1670,13 @@ def compact(o, depth=0):
             if k == "libhts_view" and isinstance(v, dict):
                 # the libhts-level figures, flat: {leg: {gpu_s, gpu_threads, ref_s, ref_threads}}
                 flat = {}
-                for leg in ("decode", "bam2bam", "cram_decode", "cram_decode_blocks", "cram_encode", "cram_encode_blocks", "cram_decode_large", "cram_to_bam_large", "cram_encode_large"):
+                for leg in ("decode", "bam2bam", "cram_decode", "cram_decode_blocks", "cram_encode", "cram_encode_blocks", "cram31_decode", "cram31_encode", "cram_decode_large", "cram_to_bam_large", "cram_encode_large"):
                     e = v.get(leg)
                     if not isinstance(e, dict): continue
                     g, r = e.get("libhts_gpu") or {}, e.get("reference") or {}
-                    if leg.startswith("cram_"):                          # seconds and threads only (the line has to fit the driver's tail)
+                    if leg.startswith("cram"):                           # seconds only (the line has to fit the driver's tail)
                         flat[leg] = {"gpu_s": g.get("seconds")}
-                        if r: flat[leg].update({"ref_s": r.get("seconds"), "ref_threads": r.get("threads")})
+                        if r: flat[leg]["ref_s"] = r.get("seconds")          # (the reference's best thread count is in the full object)
                         if "error" in g or "error" in r: flat[leg]["error"] = str(g.get("error", r.get("error")))[:60]
                         continue
                     else:

@@ -47,7 +47,7 @@ def test_default_line_fits_the_drivers_tail_and_keeps_every_ops_figures():
         for side in ("libhts_gpu", "reference"):
             assert view[leg][side]["seconds"] > 0 and view[leg][side]["plain_GBps"] > 0, (leg, side, view)
     # ... and the libhts-level CRAM legs (cram_get_bam_seq / cram_put_bam_seq = the whole-slice reader / writer; *_blocks = the per-block form; *_large = 10.24 M records)
-    for leg in ("cram_decode", "cram_encode", "cram_decode_large", "cram_to_bam_large", "cram_encode_large"):
+    for leg in ("cram_decode", "cram_encode", "cram31_decode", "cram31_encode", "cram_decode_large", "cram_to_bam_large", "cram_encode_large"):
         assert view[leg]["gpu_s"] > 0 and view[leg]["ref_s"] > 0, (leg, view)
     assert view["cram_decode_blocks"]["gpu_s"] > 0 and view["cram_encode_blocks"]["gpu_s"] > 0
 
