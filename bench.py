@@ -449,6 +449,20 @@ def inflate_libdeflate(run: Run, comp: bytes, desc, steps: int, level: int):
             "note": "same plain blocks as the headline, re-compressed with libdeflate level map 6 -> 7 exactly as bgzf.c:583-612 frames them"}
 
 
+def host_cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown.  The round-6 GPU box shows 256 host threads and
+    grants 16: every cpu_baseline of this file -- the reference's thread pools as much as the 254-process codec ports, whose workers start seconds apart (each is handed a
+    12-14 MB pickled sample) and therefore mostly measure an unshared core each -- has to be read with that in mind (profiles/r06_host_scaling_probe.txt)."""
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            return None if q == "max" else round(int(q) / int(p_), 2)
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p_, 2)
+    except Exception:
+        return None
+
+
 def op_inflate(run: Run, S: Staged, steps: int, warmup: int):
     import torch
     from htslib_amd import synth
@@ -494,7 +508,7 @@ def op_inflate(run: Run, S: Staged, steps: int, warmup: int):
                    "literal_fraction_of_symbols": None if litfrac is None else round(litfrac, 3),
                    "Gsymbols_per_s": None if spb is None else round(value * spb, 2),
                    "sharding": "independent blocks, static split, no collective", "verified": bool(ok),
-                   "prep_seconds": round(S.t_prep, 1)},
+                   "prep_seconds": round(S.t_prep, 1), "host_cpus": os.cpu_count(), "host_cpu_quota": host_cpu_quota()},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": hbm_traffic_file("hbm_traffic_inflate.json", ["fetch_bytes_per_plain_byte", "write_bytes_per_plain_byte"], S.total_u),
