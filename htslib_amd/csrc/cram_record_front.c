@@ -1,4 +1,4 @@
-/* cram_record_front.c -- the whole-slice CRAM path UNDER sam_read1: cram_get_bam_seq (reference cram/cram_decode.c:3615-3627) served by the device.
+/* cram_record_front.c -- the whole-slice CRAM path UNDER sam_read1 / sam_write1: cram_get_bam_seq (reference cram/cram_decode.c:3615-3627) served by the device.
  *
  * The reference decodes a CRAM record by record on the host: cram_get_bam_seq -> cram_get_seq -> cram_next_slice (cram_decode.c:3268-3538: container and
  * slice I/O, one cram_decode_slice job per slice on the thread pool) -> cram_to_bam per record.  Putting the GPU under the per-block entry points
@@ -10,8 +10,9 @@
  * cram_get_bam_seq -- copies one BAM record per call into the caller's bam1_t, the way bam_read1 lays a record out in memory (sam.c:784-866).
  *
  * This is an INTEGRATION source: it is compiled against htslib's private headers (cram/cram.h) inside a libhts build, as a maintainer would add it
- * (INTEGRATION.md A3); oracle/Makefile builds it into oracle/_ref/libhts_gpu.so, where the reference's cram_get_bam_seq / cram_seek / cram_close are
- * renamed hg_ref_* (objcopy --redefine-sym) and the functions below take their names.  libhtsgpu.so and libhts_bgzf.so do not contain it.
+ * (INTEGRATION.md A4); oracle/Makefile builds it into oracle/_ref/libhts_gpu.so, where the reference's cram_get_bam_seq / cram_put_bam_seq / cram_seek /
+ * cram_flush / cram_close are renamed hg_ref_* (objcopy --redefine-sym) and the functions below take their names.  libhtsgpu.so and libhts_bgzf.so do not contain it.
+ * (The write direction -- cram_put_bam_seq -- has its own banner further down.)
  *
  * When the reference's own path runs instead (always complete, never partial):
  *   - a region is set (fd->range.refid != -2: iterators, CRAM_OPT_RANGE), required_fields was narrowed, the file is CRAM 1.x / 4.x, the input cannot
